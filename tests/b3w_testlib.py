@@ -1,0 +1,104 @@
+"""Shared helpers for the tests: the oracle (oracle/libb3w_oracle.so, CPU restatement used as the
+checker), golden fixtures, and input normalisation.  Test infrastructure only."""
+import ctypes, gzip, hashlib, importlib, json, os, subprocess
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden")
+PKG_DIR = os.path.join(ROOT, "hot-proofs-blake3-circom_amd")
+LAYOUTS = os.path.join(PKG_DIR, "layouts")
+
+CIRCUITS = ["compression", "nova_bn254", "nova_vesta", "nova_bn254_o1"]
+CIRCUIT_ID = {c: i for i, c in enumerate(CIRCUITS)}
+NWIT = {"compression": 24093, "nova_bn254": 23291, "nova_vesta": 23291, "nova_bn254_o1": 24614}
+NIN = {"compression": 28, "nova_bn254": 32, "nova_vesta": 32, "nova_bn254_o1": 32}
+BN254_R = 21888242871839275222246405745257275088548364400416034343698204186575808495617
+VESTA_Q = 0x40000000000000000000000000000000224698fc0994a8dd8c46eb2100000001
+PRIME = {"compression": BN254_R, "nova_bn254": BN254_R, "nova_vesta": VESTA_Q, "nova_bn254_o1": BN254_R}
+
+
+def pkg():
+    return importlib.import_module("hot-proofs-blake3-circom_amd")
+
+
+def workloads():
+    return importlib.import_module("hot-proofs-blake3-circom_amd.workloads")
+
+
+_oracle = None
+
+
+def oracle():
+    """ctypes handle on the CPU restatement, built on demand with gcc."""
+    global _oracle
+    if _oracle is not None:
+        return _oracle
+    so = os.path.join(ROOT, "oracle", "libb3w_oracle.so")
+    src = os.path.join(ROOT, "oracle", "b3w_oracle.c")
+    if not os.path.exists(so) or os.path.getmtime(so) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "oracle")], stdout=subprocess.DEVNULL)
+    lib = ctypes.CDLL(so)
+    lib.b3wo_witness.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t]
+    lib.b3wo_witness_u32.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_char_p, ctypes.c_size_t]
+    lib.b3wo_witness_batch_u32.argtypes = [ctypes.c_int, ctypes.c_void_p, ctypes.c_int, ctypes.c_void_p]
+    lib.b3wo_wtns_header.argtypes = [ctypes.c_int, ctypes.c_void_p]
+    lib.b3wo_load_layout.argtypes = [ctypes.c_int, ctypes.c_char_p]
+    for c in CIRCUITS:
+        rc = lib.b3wo_load_layout(CIRCUIT_ID[c], os.path.join(LAYOUTS, c + ".layout").encode())
+        assert rc == 0, (c, rc)
+    _oracle = lib
+    return lib
+
+
+def keys_of(circuit):
+    w = workloads()
+    return w.COMPRESSION_KEYS if circuit == "compression" else w.NOVA_KEYS
+
+
+def normalize_input(circuit, inp):
+    """circom input object -> uint8 [nin*32] of field elements reduced mod p (witness_calculator.js:319-323)."""
+    vals = workloads().input_to_values(inp, keys_of(circuit))
+    p = PRIME[circuit]
+    return np.frombuffer(b"".join((v % p).to_bytes(32, "little") for v in vals), dtype=np.uint8).copy()
+
+
+def is_canonical_u32(circuit, inp):
+    vals = workloads().input_to_values(inp, keys_of(circuit))
+    return all(0 <= v < 2**32 for v in vals)
+
+
+def oracle_witness(circuit, fe_inputs):
+    """-> (rc, body uint8 [nwit*32], err)"""
+    lib = oracle()
+    body = np.zeros(NWIT[circuit] * 32, dtype=np.uint8)
+    err = ctypes.create_string_buffer(256)
+    fe_inputs = np.ascontiguousarray(fe_inputs, dtype=np.uint8)
+    rc = lib.b3wo_witness(CIRCUIT_ID[circuit], fe_inputs.ctypes.data, body.ctypes.data, err, 256)
+    return rc, body, err.value.decode()
+
+
+def oracle_batch_u32(circuit, recs):
+    lib = oracle()
+    recs = np.ascontiguousarray(recs, dtype=np.uint32)
+    n = recs.shape[0]
+    bodies = np.zeros((n, NWIT[circuit] * 32), dtype=np.uint8)
+    bad = lib.b3wo_witness_batch_u32(CIRCUIT_ID[circuit], recs.ctypes.data, n, bodies.ctypes.data)
+    return bad, bodies
+
+
+def oracle_header(circuit):
+    hdr = np.zeros(76, dtype=np.uint8)
+    oracle().b3wo_wtns_header(CIRCUIT_ID[circuit], hdr.ctypes.data)
+    return hdr.tobytes()
+
+
+def golden(circuit):
+    return json.load(open(os.path.join(GOLD, circuit + ".json")))
+
+
+def golden_image(name):
+    return gzip.open(os.path.join(GOLD, name), "rb").read()
+
+
+def sha256(b):
+    return hashlib.sha256(bytes(b)).hexdigest()

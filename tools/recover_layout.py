@@ -37,8 +37,14 @@ def run_oracle(wasm_rel, inputs, nproc=8):
     """Returns (bodies uint8 [n, nwit*32], errors dict) from the reference WASM."""
     tmp = tempfile.mkdtemp(prefix="b3w_oracle_")
     inp = os.path.join(tmp, "in.json")
+    def strs(x):
+        if isinstance(x, dict):
+            return {k: strs(v) for k, v in x.items()}
+        if isinstance(x, (list, tuple)):
+            return [strs(v) for v in x]
+        return str(x)
     with open(inp, "w") as f:
-        json.dump(inputs, f)
+        json.dump(strs(inputs), f)          # decimal strings: JSON numbers lose precision past 2^53
     n = len(inputs)
     per = (n + nproc - 1) // nproc
     procs = []
@@ -61,12 +67,49 @@ def run_oracle(wasm_rel, inputs, nproc=8):
 
 
 # ---------------------------------------------------------------- probe generators
-def compression_probe(rng):
-    return dict(h=[rng.getrandbits(32) for _ in range(8)], m=[rng.getrandbits(32) for _ in range(16)],
+def _wild_word(rng):
+    """a message word outside [0,2^32) that the circuits still accept (SURVEY 8(b) domain facts)"""
+    return rng.choice([-rng.randint(1, 2000), (1 << 32) + rng.getrandbits(32), rng.getrandbits(32)])
+
+
+def compression_probe(rng, wild=False):
+    m = [rng.getrandbits(32) for _ in range(16)]
+    if wild:
+        m = [_wild_word(rng) if rng.random() < 0.4 else x for x in m]
+    return dict(h=[rng.getrandbits(32) for _ in range(8)], m=m,
                 t=[rng.getrandbits(32), rng.getrandbits(32)], b=rng.getrandbits(32), d=rng.getrandbits(32))
 
 
-def nova_probe(rng, directed=None):
+def nova_probe(rng, directed=None, wild=False):
+    pr = _nova_probe(rng, directed)
+    if not wild:
+        return pr
+    big = lambda: rng.getrandbits(250)
+    parent = pr["depth"] < pr["leaf_depth"] - 1
+    if rng.random() < 0.5:
+        pr["n_blocks"] = big()
+    if rng.random() < 0.5:
+        pr["block_count"] = big() if rng.random() < 0.7 else pr["n_blocks"] - 1
+    if rng.random() < 0.3 and directed is None:
+        pr["total_depth"] = big()
+    if rng.random() < 0.3:
+        x = big()
+        delta = pr["leaf_depth"] - pr["depth"]
+        if directed is not None:
+            pr["total_depth"] = pr["total_depth"] - pr["depth"] + x
+        pr["depth"], pr["leaf_depth"] = x, x + delta
+    if parent:
+        pr["m"] = pr["m"][:8] + [big() for _ in range(8)]
+        pr["h"] = [_wild_word(rng) if rng.random() < 0.3 else v for v in pr["h"]]
+        pr["m"] = [_wild_word(rng) if (i < 8 and rng.random() < 0.3) else v for i, v in enumerate(pr["m"])]
+        if directed is None:
+            pr["chunk_idx_low"] = rng.getrandbits(64)
+    else:
+        pr["m"] = [_wild_word(rng) if rng.random() < 0.3 else v for v in pr["m"]]
+    return pr
+
+
+def _nova_probe(rng, directed=None):
     n_blocks = rng.randint(1, 16)
     bc_kind = rng.randint(0, 3)
     block_count = 0 if bc_kind == 0 else (n_blocks - 1 if bc_kind == 1 else rng.randint(0, 40))
@@ -88,16 +131,17 @@ def nova_probe(rng, directed=None):
 def make_probes(kind, k, seed):
     rng = random.Random(seed)
     if kind == "compression":
-        return [compression_probe(rng) for _ in range(k)]
-    probes = [nova_probe(rng) for _ in range(k)]
+        return [compression_probe(rng, wild=(j % 2 == 1)) for j in range(k)]
+    probes = [nova_probe(rng, wild=(j % 2 == 1)) for j in range(k)]
     for i in range(64):
         for bit in (0, 1):
-            for _ in range(2):
-                probes.append(nova_probe(rng, directed=(i, bit)))
+            for w in (False, True):
+                probes.append(nova_probe(rng, directed=(i, bit), wild=w))
     return probes
 
 
 def eval_atoms(kind, prime, inp):
+    inp = {k: ([x % prime for x in v] if isinstance(v, list) else v % prime) for k, v in inp.items()}
     if kind == "compression":
         atoms = [0] * M.N_COMP_ATOMS
         M.eval_compression(prime, inp["h"], inp["m"], inp["t"], inp["b"], inp["d"], atoms)
@@ -105,13 +149,6 @@ def eval_atoms(kind, prime, inp):
         atoms = [0] * M.N_NOVA_ATOMS
         M.eval_nova(prime, inp, atoms)
     return atoms
-
-
-def bodies_to_ints(bodies):
-    """uint8 [n, nwit*32] -> list over probes of list of python ints (slow path, only used for wide slots)."""
-    n = bodies.shape[0]
-    limbs = bodies.reshape(n, -1, 4).view(np.uint64) if False else None
-    return limbs
 
 
 def parse_layout(path):
@@ -150,7 +187,11 @@ def recover(circuit, k, holdout, seed=1234):
     probes = make_probes(kind, k, seed)
     print(f"[{circuit}] {len(probes)} probes -> oracle", flush=True)
     bodies, errors = run_oracle(cfg["wasm"], probes)
-    assert not errors, errors
+    if errors:
+        print(f"[{circuit}] dropping {len(errors)} probes the WASM rejected")
+        keep = [q for q in range(len(probes)) if q not in errors]
+        probes = [probes[q] for q in keep]
+        bodies = bodies[keep]
     assert bodies.shape[1] == nwit * 32
     K = len(probes)
     atoms = [eval_atoms(kind, prime, p) for p in probes]          # [K][natoms]
@@ -234,24 +275,31 @@ def validate(circuit, n, seed):
     layout = parse_layout(os.path.join(LAYOUT_DIR, f"{circuit}.layout"))
     rng = random.Random(seed)
     if kind == "compression":
-        probes = [compression_probe(rng) for _ in range(n)]
+        probes = [compression_probe(rng, wild=(j % 3 == 2)) for j in range(n)]
     else:
-        probes = [nova_probe(rng) for _ in range(n)]
+        probes = [nova_probe(rng, wild=(j % 3 == 2)) for j in range(n)]
         for i in range(64):
             for bit in (0, 1):
-                probes.append(nova_probe(rng, directed=(i, bit)))
+                probes.append(nova_probe(rng, directed=(i, bit), wild=(bit == 1)))
     print(f"[{circuit}] validating on {len(probes)} held-out inputs", flush=True)
     bodies, errors = run_oracle(cfg["wasm"], probes)
-    assert not errors, errors
     bad = 0
     for q, pr in enumerate(probes):
+        if q in errors:
+            try:
+                eval_atoms(kind, prime, pr)
+                print("  model accepted an input the WASM rejected:", json.dumps(pr, default=str), errors[q][:80])
+                bad += 1
+            except M.AssertFailed:
+                pass
+            continue
         pred = predict_body(layout, eval_atoms(kind, prime, pr))
         if pred != bodies[q].tobytes():
             bad += 1
             if bad < 4:
                 got = np.frombuffer(pred, dtype=np.uint8).reshape(-1, 32)
                 diff = np.nonzero((got != bodies[q].reshape(-1, 32)).any(axis=1))[0]
-                print("  mismatch probe", q, "slots", diff[:10], json.dumps(pr))
+                print("  mismatch probe", q, "slots", diff[:10], json.dumps(pr, default=str))
     print(f"[{circuit}] held-out mismatches: {bad} / {len(probes)}")
     if bad:
         raise SystemExit(2)

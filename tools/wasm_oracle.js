@@ -23,7 +23,8 @@ async function main() {
   const realLog = console.log;
   const logs = [];
   console.log = (...a) => { logs.push(a.join(" ")); };      // nova circuits log "D_FLAGS:  0"
-  const wc = await builder(fs.readFileSync(wasmPath));
+  const code = fs.readFileSync(wasmPath);
+  let wc = await builder(code);
   const bodyLen = wc.witnessSize * wc.n32 * 4;
   const fd = fs.openSync(outPath, "w");
   const errs = {};
@@ -37,6 +38,7 @@ async function main() {
     } catch (e) {
       errs[start + i] = String(e.message);
       fs.writeSync(fd, zero);
+      wc = await builder(code);   // fresh instance: the reference never clears its errStr (witness_calculator.js:16,41)
     }
     nlogs.push(logs.length);
   }
