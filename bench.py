@@ -1,0 +1,173 @@
+#!/usr/bin/env python3
+"""bench.py — BLAKE3-compression witnesses/s on MI355X (BASELINE.json metric, config 2).
+
+A step = one pass of the hot path over one batch: 4096 independent blake3_compression witnesses
+(BN254) per GPU, inputs already resident in HBM, witness bodies written to HBM (3.16 GB per
+step and GPU).  With N > 1 GPUs every rank runs its own 4096 instances (weak scaling; instance
+ids rank*4096 ...) and the ranks all-gather the per-witness public outputs over RCCL.
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0 (see the driver contract) with `roofline` (HBM-write bound
+kernel: algorithmic bytes / HIP-event kernel time) and `cpu_baseline` (the C oracle timed on
+one host core on a bounded sample of the same workload).
+"""
+import argparse, importlib, json, os, sys, time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (about 6.3 TB/s achievable)
+BYTES_PER_WITNESS = {"compression": 770976 + 112, "nova_bn254": 745312 + 128, "nova_vesta": 745312 + 128,
+                     "nova_bn254_o1": 787648 + 128}   # body written + record read
+
+
+def cpu_baseline(circuit, recs, budget_s):
+    """Time the oracle (oracle/libb3w_oracle.so, the CPU restatement = "port") on one core over a
+    bounded sample of the same records.  Checker code, used here only as the reported baseline."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import b3w_testlib as T
+    import numpy as np
+    sample = recs[:256]
+    T.oracle_batch_u32(circuit, sample)                       # warm-up: faults the output buffer in
+    done, t0 = 0, time.perf_counter()
+    while True:
+        bad, _ = T.oracle_batch_u32(circuit, sample)
+        assert bad == 0
+        done += sample.shape[0]
+        dt = time.perf_counter() - t0
+        if dt >= budget_s:
+            break
+    return {"value": done / dt, "unit": "witnesses/s", "cores": 1, "kind": "port",
+            "sample": f"{done} witnesses ({done // sample.shape[0]} passes over the first {sample.shape[0]} "
+                      f"records of the workload) in {dt:.1f} s, C oracle, 1 thread"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=4096, help="witnesses per GPU per step")
+    ap.add_argument("--circuit", default="compression")
+    ap.add_argument("--variant", type=int, default=None, help="kernel tuning variant (B3W_VARIANT)")
+    ap.add_argument("--pitch", type=int, default=0, help="body pitch in bytes (0 = contiguous bodies)")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of the cpu_baseline leg (0 = skip)")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device: the product has no CPU path")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    if args.variant is not None:
+        os.environ["B3W_VARIANT"] = str(args.variant)
+    m = importlib.import_module("hot-proofs-blake3-circom_amd")
+    W = m.workloads
+    circuit, n = args.circuit, args.batch
+    ctx = m.Context(circuit, local_rank)
+    recs = W.config2_compression(n, first=rank * n) if circuit == "compression" else W.config3_nova(n, first=rank * n)
+    pitch = args.pitch or ctx.body_bytes
+    d_recs = torch.from_numpy(recs.view(np.int32)).to(dev)
+    d_bodies = torch.empty(n * pitch, dtype=torch.uint8, device=dev)
+    npub = ctx.public_words
+    d_pub = torch.zeros((n, npub), dtype=torch.int32, device=dev)
+    d_status = torch.zeros((n,), dtype=torch.int32, device=dev)
+    d_gather = torch.empty((world * n, npub), dtype=torch.int32, device=dev) if world > 1 else None
+    stream = torch.cuda.current_stream()
+
+    def step():
+        ctx.run_device(d_recs.data_ptr(), n, d_bodies.data_ptr(), pitch, d_pub.data_ptr(), d_status.data_ptr(),
+                       stream.cuda_stream)
+        if world > 1:                       # the fold's exchange step: per-step public outputs (h_out ...)
+            dist.all_gather_into_tensor(d_gather, d_pub)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        ev[i][0].record(stream)
+        ctx.run_device(d_recs.data_ptr(), n, d_bodies.data_ptr(), pitch, d_pub.data_ptr(), d_status.data_ptr(),
+                       stream.cuda_stream)
+        ev[i][1].record(stream)
+        if world > 1:
+            dist.all_gather_into_tensor(d_gather, d_pub)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    kern_ms = sum(a.elapsed_time(b) for a, b in ev) / args.steps      # HIP events on the launch stream
+    assert int(d_status.abs().sum().item()) == 0, "a witness reported a non-zero status"
+
+    t = torch.tensor([elapsed, kern_ms], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed, kern_ms = t[0].item(), t[1].item()
+
+    if rank == 0:
+        total = world * n * args.steps
+        alg_bytes = BYTES_PER_WITNESS[circuit] * n                   # per launch
+        achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
+        traffic = None
+        tf = os.path.join(ROOT, "profiles", "traffic_latest.json")   # PMC pass (WRITE_SIZE/FETCH_SIZE), see profiles/README.md
+        if os.path.exists(tf):
+            try:
+                tj = json.load(open(tf))
+                if tj.get("circuit") == circuit and tj.get("batch") == n:
+                    traffic = tj.get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "BLAKE3-compression witnesses/sec",
+            "value": total / elapsed,
+            "unit": "witnesses/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "u32",
+            "data": "synthetic",
+            "config": {"workload": f"config2: batch {n} independent {circuit} witnesses per GPU, "
+                                   f"{'BN254' if 'vesta' not in circuit else 'Vesta'} field, LCG(6429+i) inputs, "
+                                   "device-resident inputs and outputs",
+                       "circuit": circuit, "batch_per_gpu": n, "witness_bytes": ctx.body_bytes, "pitch": pitch,
+                       "exchange": "all_gather of public outputs (RCCL)" if world > 1 else "none"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
+                         "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": alg_bytes},
+        }
+        if args.cpu_seconds > 0 and world == 1:
+            out["cpu_baseline"] = cpu_baseline(circuit, recs, args.cpu_seconds)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

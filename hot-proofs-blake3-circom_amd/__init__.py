@@ -1,0 +1,300 @@
+"""hot-proofs-blake3-circom_amd — MI355X-native batched witness generator for the BLAKE3 circom
+circuits of banyancomputer/hot-proofs-blake3-circom.
+
+This module is the Python binding over the C-ABI in include/b3wit.h (libb3wit.so, HIP kernels
+for gfx950).  It mirrors the reference's witness-calculator surface
+(blake3_nova_js/witness_calculator.js: builder -> WitnessCalculator.calculateWitness /
+calculateBinWitness / calculateWTNSBin, same argument meaning and error text) so the parity
+tests read like the reference's, and adds the batch API the device path is built for.  The
+Node.js drop-in (N-API addon + witness_calculator.js shim) lives in js/.
+
+There is no CPU fallback: if libb3wit.so is missing or no HIP device is present every compute
+entry point raises.
+"""
+import ctypes
+import os
+
+import numpy as np
+
+from . import workloads  # noqa: F401
+
+PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(PKG_DIR, "libb3wit.so")
+
+CIRCUITS = ("compression", "nova_bn254", "nova_vesta", "nova_bn254_o1")
+CIRCUIT_ID = {c: i for i, c in enumerate(CIRCUITS)}
+
+B3W_OK = 0
+B3W_E_ASSERT_FAILED = 4
+B3W_E_NO_DEVICE = 101
+B3W_E_DOMAIN = 103
+
+# the strings witness_calculator.js:21-37 attaches to the circom exception codes
+_CIRCOM_ERR = {1: "Signal not found.\n", 2: "Too many signals set.\n", 3: "Signal already set.\n",
+               4: "Assert Failed.\n", 5: "Not enough memory.\n", 6: "Input signal array access exceeds the size.\n"}
+
+
+class B3WError(RuntimeError):
+    def __init__(self, status, message):
+        super().__init__(message)
+        self.status = status
+
+
+_lib = None
+
+
+def lib():
+    """The C-ABI library.  Raises (never falls back) when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise B3WError(B3W_E_NO_DEVICE, f"{LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'`")
+    L = ctypes.CDLL(LIB_PATH)
+    vp, u32, i32, u64, sz = ctypes.c_void_p, ctypes.c_uint32, ctypes.c_int32, ctypes.c_uint64, ctypes.c_size_t
+    sig = {
+        "b3w_abi_version": (u32, []),
+        "b3w_identify_wasm": (i32, [vp, sz]),
+        "b3w_create": (i32, [i32, i32, ctypes.POINTER(vp)]),
+        "b3w_destroy": (None, [vp]),
+        "b3w_info": (i32, [vp, vp, vp, vp, vp, vp]),
+        "b3w_input_signal_size": (i32, [vp, u64]),
+        "b3w_calc_witness": (i32, [vp, vp, vp, vp, u32, vp]),
+        "b3w_write_wtns_header": (i32, [vp, vp]),
+        "b3w_last_error": (i32, [vp, ctypes.c_char_p, sz]),
+        "b3w_batch_run_device": (i32, [vp, vp, u32, vp, u64, vp, vp, vp]),
+        "b3w_public_words": (u32, [vp]),
+        "b3w_batch_alloc": (i32, [vp, u32, u64, ctypes.POINTER(vp)]),
+        "b3w_batch_free": (None, [vp]),
+        "b3w_batch_run": (i32, [vp, vp, u32, vp]),
+        "b3w_batch_outputs": (i32, [vp, vp, vp]),
+        "b3w_batch_fetch": (i32, [vp, u32, vp]),
+        "b3w_batch_device_ptr": (vp, [vp, ctypes.POINTER(u64)]),
+        "b3w_batch_time_device": (i32, [vp, vp, u32, vp, u64, vp, vp, vp, u32, ctypes.POINTER(ctypes.c_float)]),
+    }
+    for name, (res, args) in sig.items():
+        fn = getattr(L, name)
+        fn.restype, fn.argtypes = res, args
+    _lib = L
+    return L
+
+
+EXPORTED_SYMBOLS = ("b3w_abi_version", "b3w_identify_wasm", "b3w_create", "b3w_destroy", "b3w_info",
+                    "b3w_input_signal_size", "b3w_calc_witness", "b3w_write_wtns_header", "b3w_last_error",
+                    "b3w_batch_run_device", "b3w_public_words", "b3w_batch_alloc", "b3w_batch_free",
+                    "b3w_batch_run", "b3w_batch_outputs", "b3w_batch_fetch", "b3w_batch_device_ptr",
+                    "b3w_batch_time_device")
+
+
+def fnv_hash(name):
+    """witness_calculator.js:325-337 fnvHash (FNV-1a 64) as an int."""
+    h = 0xCBF29CE484222325
+    for ch in name:
+        h ^= ord(ch)
+        h = (h * 0x100000001B3) % (1 << 64)
+    return h
+
+
+def flat_array(a):
+    """witness_calculator.js:303-317 flatArray."""
+    out = []
+
+    def fill(x):
+        if isinstance(x, (list, tuple)):
+            for y in x:
+                fill(y)
+        else:
+            out.append(x)
+    fill(a)
+    return out
+
+
+def _to_int(v):
+    if isinstance(v, str):
+        return int(v, 0)          # BigInt("0x..") / BigInt("123") / BigInt("-5")
+    return int(v)
+
+
+class Context:
+    """Owns a b3w_ctx (one circuit on one device)."""
+
+    def __init__(self, circuit, device=0):
+        self.circuit = circuit if isinstance(circuit, str) else CIRCUITS[circuit]
+        self._lib = lib()
+        h = ctypes.c_void_p()
+        rc = self._lib.b3w_create(CIRCUIT_ID[self.circuit], int(device), ctypes.byref(h))
+        if rc != B3W_OK:
+            raise B3WError(rc, f"b3w_create({self.circuit}, device={device}) failed with status {rc}"
+                               + (" (no HIP device: this library has no CPU path)" if rc == B3W_E_NO_DEVICE else ""))
+        self.handle = h
+        n32, nwit, nin = ctypes.c_uint32(), ctypes.c_uint32(), ctypes.c_uint32()
+        prime = (ctypes.c_uint8 * 32)()
+        ver = (ctypes.c_uint32 * 3)()
+        self._lib.b3w_info(h, ctypes.byref(n32), prime, ctypes.byref(nwit), ctypes.byref(nin), ver)
+        self.n32, self.witness_size, self.input_size = n32.value, nwit.value, nin.value
+        self.prime = int.from_bytes(bytes(prime), "little")
+        self.version = tuple(ver)
+        self.public_words = self._lib.b3w_public_words(h)
+        self.body_bytes = self.witness_size * 32
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self._lib.b3w_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def last_error(self):
+        buf = ctypes.create_string_buffer(512)
+        self._lib.b3w_last_error(self.handle, buf, 512)
+        return buf.value.decode()
+
+    def wtns_header(self):
+        out = (ctypes.c_uint8 * 76)()
+        self._lib.b3w_write_wtns_header(self.handle, out)
+        return bytes(out)
+
+    def input_signal_size(self, name):
+        return self._lib.b3w_input_signal_size(self.handle, fnv_hash(name))
+
+    # -- batch on caller-owned device memory (torch tensors or raw pointers) -----------------
+    def run_device(self, d_records, n, d_bodies, pitch=0, d_public=0, d_status=0, stream=0):
+        rc = self._lib.b3w_batch_run_device(self.handle, d_records, n, d_bodies, pitch, d_public or None,
+                                            d_status or None, stream or None)
+        if rc != B3W_OK:
+            raise B3WError(rc, f"b3w_batch_run_device: status {rc}: {self.last_error()}")
+
+    def time_device(self, d_records, n, d_bodies, pitch, d_public, d_status, stream, iters):
+        ms = ctypes.c_float()
+        rc = self._lib.b3w_batch_time_device(self.handle, d_records, n, d_bodies, pitch, d_public or None,
+                                             d_status or None, stream or None, iters, ctypes.byref(ms))
+        if rc != B3W_OK:
+            raise B3WError(rc, f"b3w_batch_time_device: status {rc}: {self.last_error()}")
+        return ms.value
+
+
+class Batch:
+    """Library-owned device buffers for up to `capacity` witnesses (b3w_batch_*)."""
+
+    def __init__(self, ctx, capacity, pitch=0):
+        self.ctx = ctx
+        h = ctypes.c_void_p()
+        rc = lib().b3w_batch_alloc(ctx.handle, capacity, pitch, ctypes.byref(h))
+        if rc != B3W_OK:
+            raise B3WError(rc, f"b3w_batch_alloc: status {rc}: {ctx.last_error()}")
+        self.handle, self.capacity, self.n = h, capacity, 0
+
+    def run(self, records):
+        records = np.ascontiguousarray(records, dtype=np.uint32)
+        assert records.ndim == 2 and records.shape[1] == self.ctx.input_size
+        rc = lib().b3w_batch_run(self.handle, records.ctypes.data, records.shape[0], None)
+        if rc != B3W_OK:
+            raise B3WError(rc, f"b3w_batch_run: status {rc}: {self.ctx.last_error()}")
+        self.n = records.shape[0]
+
+    def outputs(self):
+        pub = np.zeros((self.n, self.ctx.public_words), dtype=np.uint32)
+        st = np.zeros(self.n, dtype=np.int32)
+        rc = lib().b3w_batch_outputs(self.handle, pub.ctypes.data, st.ctypes.data)
+        if rc != B3W_OK:
+            raise B3WError(rc, f"b3w_batch_outputs: status {rc}")
+        return pub, st
+
+    def fetch(self, index):
+        body = np.zeros(self.ctx.body_bytes, dtype=np.uint8)
+        rc = lib().b3w_batch_fetch(self.handle, index, body.ctypes.data)
+        if rc != B3W_OK:
+            raise B3WError(rc, f"b3w_batch_fetch: status {rc}")
+        return body
+
+    def device_ptr(self):
+        pitch = ctypes.c_uint64()
+        p = lib().b3w_batch_device_ptr(self.handle, ctypes.byref(pitch))
+        return p, pitch.value
+
+    def close(self):
+        if self.handle:
+            lib().b3w_batch_free(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class WitnessCalculator:
+    """Mirror of `class WitnessCalculator` (witness_calculator.js:108-274) over the C-ABI.
+
+    Same fields (version, n32, prime, witnessSize), same methods, same error text.  The
+    reference methods are `async` but resolve synchronously; these are plain calls."""
+
+    def __init__(self, ctx, sanity_check=True):
+        self.instance = ctx
+        self.version = ctx.version[0]
+        self.n32 = ctx.n32
+        self.prime = ctx.prime
+        self.witnessSize = ctx.witness_size
+        self.sanityCheck = sanity_check
+
+    def circom_version(self):
+        return self.version
+
+    def _do_calculate_witness(self, inp):
+        """_doCalculateWitness (witness_calculator.js:131-169): returns the body (uint8 array)."""
+        ctx = self.instance
+        hashes, counts, vals = [], [], []
+        for k in inp.keys():
+            farr = flat_array(inp[k])
+            size = ctx.input_signal_size(k)
+            if len(farr) < size:
+                raise B3WError(6, f"Not enough values for input signal {k}\n")
+            if len(farr) > size:
+                raise B3WError(2, f"Too many values for input signal {k}\n")
+            hashes.append(fnv_hash(k))
+            counts.append(len(farr))
+            vals += [(_to_int(v) % self.prime) for v in farr]          # normalize(), :319-323
+        if len(vals) < ctx.input_size:
+            raise B3WError(104, f"Not all inputs have been set. Only {len(vals)} out of {ctx.input_size}")
+        h = np.array(hashes, dtype=np.uint64)
+        c = np.array(counts, dtype=np.uint32)
+        v = np.frombuffer(b"".join(x.to_bytes(32, "little") for x in vals), dtype=np.uint8)
+        body = np.zeros(ctx.body_bytes, dtype=np.uint8)
+        rc = lib().b3w_calc_witness(ctx.handle, h.ctypes.data, c.ctypes.data, v.ctypes.data, len(hashes), body.ctypes.data)
+        if rc != B3W_OK:
+            if rc in _CIRCOM_ERR:
+                tail = ctx.last_error()
+                raise B3WError(rc, "Error: " + _CIRCOM_ERR[rc] + ("" if tail == _CIRCOM_ERR[rc] else tail))
+            raise B3WError(rc, ctx.last_error())
+        return body
+
+    def calculateWitness(self, inp, sanity_check=0):
+        body = self._do_calculate_witness(inp)
+        b = body.tobytes()
+        return [int.from_bytes(b[32 * i:32 * i + 32], "little") for i in range(self.witnessSize)]
+
+    def calculateBinWitness(self, inp, sanity_check=0):
+        return self._do_calculate_witness(inp)
+
+    def calculateWTNSBin(self, inp, sanity_check=0):
+        body = self._do_calculate_witness(inp)
+        return np.frombuffer(self.instance.wtns_header() + body.tobytes(), dtype=np.uint8)
+
+
+def builder(code, options=None, device=0):
+    """Mirror of `module.exports = async function builder(code, options)` (witness_calculator.js:1-106).
+    `code` = the circuit's .wasm bytes (identified by sha256), or a circuit name."""
+    if isinstance(code, str):
+        circuit = code
+    else:
+        buf = bytes(code)
+        cid = lib().b3w_identify_wasm(buf, len(buf))
+        if cid < 0:
+            raise B3WError(100, "unknown circuit binary: not one of the reference's committed WASMs")
+        circuit = CIRCUITS[cid]
+    return WitnessCalculator(Context(circuit, device), True if options is None else options)

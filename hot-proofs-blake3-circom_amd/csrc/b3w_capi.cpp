@@ -1,0 +1,460 @@
+// b3w_capi.cpp — C-ABI of libb3wit.so (include/b3wit.h): context, slot tables, launch plumbing.
+// Host code only; every witness is computed by the HIP kernels in b3w_kernels.hip.  There is no
+// CPU evaluation path in this library: without a HIP device b3w_create fails with B3W_E_NO_DEVICE.
+#include <hip/hip_runtime_api.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <string>
+#include <vector>
+
+#include "../../include/b3wit.h"
+#include "b3w_atoms.h"
+#include "b3w_kernels.h"
+
+struct b3w_layout_run { char kind; uint32_t slot, atom, bit0, len; };
+#include "b3w_layout_tables.inc"
+
+namespace {
+
+// ------------------------------------------------------------------ sha256 (FIPS 180-4), for b3w_identify_wasm
+struct Sha256 {
+  uint32_t h[8];
+  uint8_t buf[64];
+  uint64_t len = 0;
+  size_t fill = 0;
+  Sha256() {
+    static const uint32_t init[8] = {0x6a09e667, 0xbb67ae85, 0x3c6ef372, 0xa54ff53a, 0x510e527f, 0x9b05688c, 0x1f83d9ab, 0x5be0cd19};
+    memcpy(h, init, sizeof h);
+  }
+  static uint32_t ror(uint32_t x, int r) { return (x >> r) | (x << (32 - r)); }
+  void block(const uint8_t *p) {
+    static const uint32_t K[64] = {
+        0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5, 0xd807aa98, 0x12835b01,
+        0x243185be, 0x550c7dc3, 0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174, 0xe49b69c1, 0xefbe4786, 0x0fc19dc6, 0x240ca1cc,
+        0x2de92c6f, 0x4a7484aa, 0x5cb0a9dc, 0x76f988da, 0x983e5152, 0xa831c66d, 0xb00327c8, 0xbf597fc7, 0xc6e00bf3, 0xd5a79147,
+        0x06ca6351, 0x14292967, 0x27b70a85, 0x2e1b2138, 0x4d2c6dfc, 0x53380d13, 0x650a7354, 0x766a0abb, 0x81c2c92e, 0x92722c85,
+        0xa2bfe8a1, 0xa81a664b, 0xc24b8b70, 0xc76c51a3, 0xd192e819, 0xd6990624, 0xf40e3585, 0x106aa070, 0x19a4c116, 0x1e376c08,
+        0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f, 0x682e6ff3, 0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208,
+        0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2};
+    uint32_t w[64];
+    for (int i = 0; i < 16; i++) w[i] = (uint32_t)p[4 * i] << 24 | (uint32_t)p[4 * i + 1] << 16 | (uint32_t)p[4 * i + 2] << 8 | p[4 * i + 3];
+    for (int i = 16; i < 64; i++) {
+      uint32_t s0 = ror(w[i - 15], 7) ^ ror(w[i - 15], 18) ^ (w[i - 15] >> 3);
+      uint32_t s1 = ror(w[i - 2], 17) ^ ror(w[i - 2], 19) ^ (w[i - 2] >> 10);
+      w[i] = w[i - 16] + s0 + w[i - 7] + s1;
+    }
+    uint32_t a = h[0], b = h[1], c = h[2], d = h[3], e = h[4], f = h[5], g = h[6], hh = h[7];
+    for (int i = 0; i < 64; i++) {
+      uint32_t t1 = hh + (ror(e, 6) ^ ror(e, 11) ^ ror(e, 25)) + ((e & f) ^ (~e & g)) + K[i] + w[i];
+      uint32_t t2 = (ror(a, 2) ^ ror(a, 13) ^ ror(a, 22)) + ((a & b) ^ (a & c) ^ (b & c));
+      hh = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
+    }
+    h[0] += a; h[1] += b; h[2] += c; h[3] += d; h[4] += e; h[5] += f; h[6] += g; h[7] += hh;
+  }
+  void update(const uint8_t *p, size_t n) {
+    len += n;
+    while (n) {
+      size_t k = 64 - fill < n ? 64 - fill : n;
+      memcpy(buf + fill, p, k);
+      fill += k; p += k; n -= k;
+      if (fill == 64) { block(buf); fill = 0; }
+    }
+  }
+  void final(uint8_t out[32]) {
+    uint64_t bits = len * 8;
+    uint8_t pad = 0x80;
+    update(&pad, 1);
+    uint8_t z = 0;
+    while (fill != 56) update(&z, 1);
+    uint8_t lb[8];
+    for (int i = 0; i < 8; i++) lb[i] = (uint8_t)(bits >> (56 - 8 * i));
+    update(lb, 8);
+    for (int i = 0; i < 8; i++) { out[4 * i] = h[i] >> 24; out[4 * i + 1] = h[i] >> 16; out[4 * i + 2] = h[i] >> 8; out[4 * i + 3] = h[i]; }
+  }
+};
+
+// sha256 of the reference's committed circuit binaries
+const char *const WASM_SHA256[4] = {
+    "6faf23ddfd697bbb7e8e922577589c2c06486258968a5a14f96fb5a16091b142",   // blake3_compression.wasm
+    "020bd11f289864c54c7d02cd05723dcf8323e31fa5c77d8700c618232685978e",   // build/blake3_nova_js/blake3_nova.wasm
+    "b982f960ebbfcabe957fe13857ea47adfeee30e18fbe05474e9b982eab187f46",   // build/blake3_nova_pasta_js/blake3_nova_pasta.wasm
+    "8d6317b72eab34d34e12dfd7bd310dce40f4190768669772f992a9510c441fca"};  // build/blake3_nova/.../blake3_nova.wasm (== circomkit "pasta")
+
+const uint64_t P_BN254[4] = {0x43e1f593f0000001ull, 0x2833e84879b97091ull, 0xb85045b68181585dull, 0x30644e72e131a029ull};
+const uint64_t P_VESTA[4] = {0x8c46eb2100000001ull, 0x224698fc0994a8ddull, 0x0ull, 0x4000000000000000ull};
+
+struct InputSignal { const char *name; uint32_t count; uint32_t rec_off; uint64_t hash; };
+
+// FNV-1a 64 of the signal name (witness_calculator.js:325-337)
+uint64_t fnv1a64(const char *s) {
+  uint64_t h = 0xCBF29CE484222325ull;
+  for (; *s; ++s) { h ^= (uint8_t)*s; h *= 0x100000001B3ull; }
+  return h;
+}
+
+struct CircuitDesc {
+  int kind;
+  uint32_t nwit, nin, npub;
+  const uint64_t *prime;
+  const b3w_layout_run *runs;
+  uint32_t nruns;
+  uint32_t lds_words;
+};
+
+const CircuitDesc CIRCUITS[4] = {
+    {B3W_KIND_COMP, 24093, 28, 16, P_BN254, B3W_LAYOUT_0, B3W_LAYOUT_0_NRUNS, B3W_LDS_WORDS_COMP},
+    {B3W_KIND_NOVA_O2, 23291, 32, 15, P_BN254, B3W_LAYOUT_1, B3W_LAYOUT_1_NRUNS, B3W_LDS_WORDS_NOVA_O2},
+    {B3W_KIND_NOVA_O2, 23291, 32, 15, P_VESTA, B3W_LAYOUT_2, B3W_LAYOUT_2_NRUNS, B3W_LDS_WORDS_NOVA_O2},
+    {B3W_KIND_NOVA_O1, 24614, 32, 15, P_BN254, B3W_LAYOUT_3, B3W_LAYOUT_3_NRUNS, B3W_LDS_WORDS_NOVA_O1},
+};
+
+// where an atom lives in the LDS image (b3w_atoms.h); returns false if this kind does not stage it
+bool atom_lds(int kind, uint32_t atom, uint32_t *word, int *width /* 32, 64 or 256 */) {
+  if (atom < B3W_A_HG) { *word = atom; *width = 32; return true; }
+  if (atom < B3W_A_NV) {
+    const uint32_t k = (atom - B3W_A_HG) / 8, j = (atom - B3W_A_HG) % 8;
+    static const uint32_t off[8] = {0, 0, 2, 2, 4, 5, 6, 7};   // S1 A S3 C D2 DI B4 BI
+    *word = B3W_LDS_HG + 8 * k + off[j];
+    *width = (j == B3W_HG_S1 || j == B3W_HG_S3) ? 64 : 32;
+    return true;
+  }
+  if (kind == B3W_KIND_COMP) return false;
+  const uint32_t i = atom - B3W_A_NV;
+  if (i == NV_CHUNK_IDX) { *word = B3W_LDS_CHUNK_IDX; *width = 64; return true; }
+  if (i < NV_NARROW_COUNT) { *word = B3W_LDS_NV + i; *width = 32; return true; }
+  if (i >= NV_COUNT) return false;
+  uint32_t j = i - NV_NARROW_COUNT;                            // wide index in numbering order
+  if (kind == B3W_KIND_NOVA_O2) {
+    if (j < 3) { /* root/e0/e1 inv */ }
+    else if (i >= NV_EQ_INV && i < NV_EQ_INV + 64) j = 3 + (i - NV_EQ_INV);
+    else return false;
+  }
+  *word = B3W_LDS_WIDE + 8 * j;
+  *width = 256;
+  return true;
+}
+
+bool build_slot_table(const CircuitDesc &c, std::vector<uint32_t> &table, std::string &err) {
+  const uint32_t padded = ((c.nwit + 31) / 32 + 8) * 32;   // + 8 groups: expand() prefetches ahead
+  table.assign(padded, B3W_ENTRY(0, 31, B3W_MODE_BIT));        // padding: bit 31 of ONE = 0 (never stored anyway)
+  std::vector<uint8_t> seen(c.nwit, 0);
+  char msg[128];
+  for (uint32_t r = 0; r < c.nruns; r++) {
+    const b3w_layout_run &run = c.runs[r];
+    for (uint32_t j = 0; j < run.len; j++) {
+      const uint32_t slot = run.slot + j;
+      if (slot >= c.nwit || seen[slot]) { err = "layout: bad or duplicate slot"; return false; }
+      seen[slot] = 1;
+      uint32_t word; int width;
+      if (run.kind == 'W') {
+        if (!atom_lds(c.kind, run.atom + j, &word, &width)) {
+          snprintf(msg, sizeof msg, "layout: atom %u not staged for this circuit kind", run.atom + j);
+          err = msg; return false;
+        }
+        table[slot] = B3W_ENTRY(word, 0, width == 32 ? B3W_MODE_W32 : width == 64 ? B3W_MODE_W64 : B3W_MODE_W256);
+      } else {
+        const uint32_t bit = run.bit0 + j;
+        if (!atom_lds(c.kind, run.atom, &word, &width) || (int)bit >= width || width == 256) {
+          snprintf(msg, sizeof msg, "layout: bit %u of atom %u not expressible", bit, run.atom);
+          err = msg; return false;
+        }
+        table[slot] = B3W_ENTRY(word + bit / 32, bit % 32, B3W_MODE_BIT);
+      }
+    }
+  }
+  for (uint32_t s = 0; s < c.nwit; s++) if (!seen[s]) { err = "layout: uncovered slot"; return false; }
+  return true;
+}
+
+}  // namespace
+
+struct b3w_ctx {
+  int circuit = -1;
+  CircuitDesc desc{};
+  int device = -1;
+  int variant = 0;
+  std::vector<InputSignal> inputs;
+  uint32_t *d_table = nullptr;
+  void *d_aux = nullptr;
+  // single-witness scratch
+  uint32_t *d_rec1 = nullptr;
+  uint8_t *d_body1 = nullptr;
+  int32_t *d_status1 = nullptr;
+  std::string last_error;
+};
+
+struct b3w_batch {
+  b3w_ctx *ctx = nullptr;
+  uint32_t capacity = 0, n = 0;
+  uint64_t pitch = 0;
+  uint32_t *d_recs = nullptr;
+  uint8_t *d_bodies = nullptr;
+  uint32_t *d_pub = nullptr;
+  int32_t *d_status = nullptr;
+};
+
+namespace {
+int32_t hip_fail(b3w_ctx *ctx, hipError_t e, const char *what) {
+  if (ctx) ctx->last_error = std::string(what) + ": " + hipGetErrorString(e);
+  return B3W_E_HIP;
+}
+#define HIP_TRY(ctx, call)                                  \
+  do {                                                      \
+    hipError_t _e = (call);                                 \
+    if (_e != hipSuccess) return hip_fail(ctx, _e, #call);  \
+  } while (0)
+
+void set_inputs(b3w_ctx *ctx) {
+  struct Def { const char *name; uint32_t count; };
+  static const Def comp[] = {{"h", 8}, {"m", 16}, {"t", 2}, {"b", 1}, {"d", 1}};
+  static const Def nova[] = {{"n_blocks", 1}, {"block_count", 1}, {"h", 8}, {"chunk_idx_low", 1}, {"chunk_idx_high", 1},
+                             {"leaf_depth", 1}, {"total_depth", 1}, {"depth", 1}, {"m", 16}, {"b", 1}};
+  const Def *d = ctx->desc.kind == B3W_KIND_COMP ? comp : nova;
+  const int nd = ctx->desc.kind == B3W_KIND_COMP ? 5 : 10;
+  uint32_t off = 0;
+  for (int i = 0; i < nd; i++) {
+    ctx->inputs.push_back({d[i].name, d[i].count, off, fnv1a64(d[i].name)});
+    off += d[i].count;
+  }
+}
+}  // namespace
+
+extern "C" {
+
+uint32_t b3w_abi_version(void) { return (1u << 16) | 0u; }
+
+int32_t b3w_identify_wasm(const uint8_t *code, size_t len) {
+  if (!code) return B3W_CIRCUIT_UNKNOWN;
+  Sha256 s;
+  s.update(code, len);
+  uint8_t dg[32];
+  s.final(dg);
+  char hex[65];
+  for (int i = 0; i < 32; i++) snprintf(hex + 2 * i, 3, "%02x", dg[i]);
+  for (int c = 0; c < 4; c++) if (!strcmp(hex, WASM_SHA256[c])) return c;
+  return B3W_CIRCUIT_UNKNOWN;
+}
+
+int32_t b3w_create(int32_t circuit, int32_t device, b3w_ctx **out) {
+  if (!out || circuit < 0 || circuit > 3) return B3W_E_BAD_ARGUMENT;
+  *out = nullptr;
+  int ndev = 0;
+  if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0 || device < 0 || device >= ndev) return B3W_E_NO_DEVICE;
+  b3w_ctx *ctx = new b3w_ctx;
+  ctx->circuit = circuit;
+  ctx->desc = CIRCUITS[circuit];
+  ctx->device = device;
+  set_inputs(ctx);
+  std::vector<uint32_t> table;
+  if (!build_slot_table(ctx->desc, table, ctx->last_error)) { delete ctx; return B3W_E_BAD_ARGUMENT; }
+  if (hipSetDevice(device) != hipSuccess) { delete ctx; return B3W_E_NO_DEVICE; }
+  const CircuitDesc &d = ctx->desc;
+  hipError_t e = hipMalloc((void **)&ctx->d_table, table.size() * 4);
+  if (e == hipSuccess) e = hipMemcpy(ctx->d_table, table.data(), table.size() * 4, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_rec1, d.nin * 4);
+  if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_body1, (size_t)d.nwit * 32);
+  if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_status1, 4);
+  if (e != hipSuccess) { b3w_destroy(ctx); return B3W_E_HIP; }
+  const char *v = getenv("B3W_VARIANT");
+  if (v) ctx->variant = atoi(v);
+  *out = ctx;
+  return B3W_OK;
+}
+
+void b3w_destroy(b3w_ctx *ctx) {
+  if (!ctx) return;
+  if (ctx->d_table) (void)hipFree(ctx->d_table);
+  if (ctx->d_aux) (void)hipFree(ctx->d_aux);
+  if (ctx->d_rec1) (void)hipFree(ctx->d_rec1);
+  if (ctx->d_body1) (void)hipFree(ctx->d_body1);
+  if (ctx->d_status1) (void)hipFree(ctx->d_status1);
+  delete ctx;
+}
+
+int32_t b3w_info(const b3w_ctx *ctx, uint32_t *n32, uint8_t prime_le[32], uint32_t *witness_size,
+                 uint32_t *input_size, uint32_t version[3]) {
+  if (!ctx) return B3W_E_BAD_ARGUMENT;
+  if (n32) *n32 = 8;
+  if (prime_le) memcpy(prime_le, ctx->desc.prime, 32);
+  if (witness_size) *witness_size = ctx->desc.nwit;
+  if (input_size) *input_size = ctx->desc.nin;
+  if (version) { version[0] = 2; version[1] = 1; version[2] = 6; }   // circom 2.1.6 (WASM getVersion & co.)
+  return B3W_OK;
+}
+
+int32_t b3w_input_signal_size(const b3w_ctx *ctx, uint64_t h) {
+  if (!ctx) return 0;
+  for (const InputSignal &s : ctx->inputs) if (s.hash == h) return (int32_t)s.count;
+  return 0;
+}
+
+uint32_t b3w_public_words(const b3w_ctx *ctx) { return ctx ? ctx->desc.npub : 0; }
+
+int32_t b3w_last_error(const b3w_ctx *ctx, char *buf, size_t len) {
+  if (!ctx || !buf || !len) return B3W_E_BAD_ARGUMENT;
+  snprintf(buf, len, "%s", ctx->last_error.c_str());
+  return B3W_OK;
+}
+
+int32_t b3w_write_wtns_header(const b3w_ctx *ctx, uint8_t out[76]) {
+  if (!ctx || !out) return B3W_E_BAD_ARGUMENT;
+  uint32_t w[19];
+  memcpy(&w[0], "wtns", 4);
+  w[1] = 2; w[2] = 2;                      // version, number of sections
+  w[3] = 1; w[4] = 8 + 32; w[5] = 0;       // section 1 id, u64 length
+  w[6] = 32;                               // n8
+  memcpy(&w[7], ctx->desc.prime, 32);
+  w[15] = ctx->desc.nwit;
+  const uint64_t len = 32ull * ctx->desc.nwit;
+  w[16] = 2; w[17] = (uint32_t)len; w[18] = (uint32_t)(len >> 32);
+  memcpy(out, w, 76);
+  return B3W_OK;
+}
+
+int32_t b3w_batch_run_device(b3w_ctx *ctx, const uint32_t *d_records, uint32_t n, uint8_t *d_bodies, uint64_t pitch,
+                             uint32_t *d_public, int32_t *d_status, void *stream) {
+  if (!ctx || !d_records || !d_bodies) return B3W_E_BAD_ARGUMENT;
+  const uint64_t body = 32ull * ctx->desc.nwit;
+  if (pitch == 0) pitch = body;
+  if (pitch < body || (pitch & 31)) { ctx->last_error = "pitch must be >= witness_size*32 and a multiple of 32"; return B3W_E_BAD_ARGUMENT; }
+  int rc = b3w_launch_batch(ctx->desc.kind, ctx->variant, d_records, n, d_bodies, pitch, ctx->d_table, ctx->desc.nwit,
+                            d_public, d_status, ctx->d_aux, (hipStream_t)stream);
+  if (rc == 0) return B3W_OK;
+  if (rc < 0) { ctx->last_error = "no kernel for this circuit kind / variant"; return B3W_E_BAD_ARGUMENT; }
+  return hip_fail(ctx, (hipError_t)rc, "kernel launch");
+}
+
+int32_t b3w_batch_time_device(b3w_ctx *ctx, const uint32_t *d_records, uint32_t n, uint8_t *d_bodies, uint64_t pitch,
+                              uint32_t *d_public, int32_t *d_status, void *stream, uint32_t iters, float *avg_ms) {
+  if (!ctx || !avg_ms || !iters) return B3W_E_BAD_ARGUMENT;
+  hipEvent_t e0, e1;
+  HIP_TRY(ctx, hipEventCreate(&e0));
+  HIP_TRY(ctx, hipEventCreate(&e1));
+  HIP_TRY(ctx, hipEventRecord(e0, (hipStream_t)stream));
+  for (uint32_t i = 0; i < iters; i++) {
+    int32_t rc = b3w_batch_run_device(ctx, d_records, n, d_bodies, pitch, d_public, d_status, stream);
+    if (rc) return rc;
+  }
+  HIP_TRY(ctx, hipEventRecord(e1, (hipStream_t)stream));
+  HIP_TRY(ctx, hipEventSynchronize(e1));
+  float ms = 0;
+  HIP_TRY(ctx, hipEventElapsedTime(&ms, e0, e1));
+  *avg_ms = ms / iters;
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  return B3W_OK;
+}
+
+int32_t b3w_calc_witness(b3w_ctx *ctx, const uint64_t *name_hashes, const uint32_t *counts, const uint8_t *values_le32,
+                         uint32_t nkeys, uint8_t *out_body) {
+  if (!ctx || !name_hashes || !counts || !values_le32 || !out_body) return B3W_E_BAD_ARGUMENT;
+  const CircuitDesc &d = ctx->desc;
+  std::vector<uint32_t> rec(d.nin, 0);
+  std::vector<uint8_t> set(d.nin, 0);
+  uint32_t nset = 0;
+  const uint8_t *v = values_le32;
+  char msg[160];
+  for (uint32_t k = 0; k < nkeys; k++) {
+    const InputSignal *sig = nullptr;
+    for (const InputSignal &s : ctx->inputs) if (s.hash == name_hashes[k]) sig = &s;
+    const uint32_t size = sig ? sig->count : 0;
+    if (counts[k] < size) { ctx->last_error = std::string("Not enough values for input signal ") + (sig ? sig->name : "?") + "\n"; return B3W_E_ARRAY_ACCESS; }
+    if (counts[k] > size) { ctx->last_error = std::string("Too many values for input signal ") + (sig ? sig->name : "?") + "\n"; return B3W_E_TOO_MANY_SIGNALS; }
+    for (uint32_t i = 0; i < size; i++, v += 32) {
+      if (set[sig->rec_off + i]) { ctx->last_error = "Signal already set.\n"; return B3W_E_SIGNAL_ALREADY_SET; }
+      uint32_t lo;
+      memcpy(&lo, v, 4);
+      bool canonical = true;
+      for (int b = 4; b < 32; b++) canonical &= (v[b] == 0);
+      if (!canonical) {
+        snprintf(msg, sizeof msg, "input %s[%u] is outside [0,2^32): not in the device fast-path domain", sig->name, i);
+        ctx->last_error = msg;
+        return B3W_E_DOMAIN;
+      }
+      rec[sig->rec_off + i] = lo;
+      set[sig->rec_off + i] = 1;
+      nset++;
+    }
+  }
+  if (nset < d.nin) {
+    snprintf(msg, sizeof msg, "Not all inputs have been set. Only %u out of %u", nset, d.nin);
+    ctx->last_error = msg;
+    return B3W_E_NOT_ALL_INPUTS;
+  }
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, hipMemcpy(ctx->d_rec1, rec.data(), d.nin * 4, hipMemcpyHostToDevice));
+  int32_t rc = b3w_batch_run_device(ctx, ctx->d_rec1, 1, ctx->d_body1, 0, nullptr, ctx->d_status1, nullptr);
+  if (rc) return rc;
+  int32_t st = 0;
+  HIP_TRY(ctx, hipMemcpy(&st, ctx->d_status1, 4, hipMemcpyDeviceToHost));
+  if (st != 0) {
+    ctx->last_error = st == B3W_E_ASSERT_FAILED ? "Assert Failed.\n" : "input outside the device fast-path domain";
+    return st;
+  }
+  HIP_TRY(ctx, hipMemcpy(out_body, ctx->d_body1, (size_t)d.nwit * 32, hipMemcpyDeviceToHost));
+  return B3W_OK;
+}
+
+int32_t b3w_batch_alloc(b3w_ctx *ctx, uint32_t capacity, uint64_t pitch, b3w_batch **out) {
+  if (!ctx || !out || !capacity) return B3W_E_BAD_ARGUMENT;
+  *out = nullptr;
+  const uint64_t body = 32ull * ctx->desc.nwit;
+  if (pitch == 0) pitch = body;
+  if (pitch < body || (pitch & 31)) return B3W_E_BAD_ARGUMENT;
+  b3w_batch *b = new b3w_batch;
+  b->ctx = ctx; b->capacity = capacity; b->pitch = pitch;
+  hipError_t e = hipSetDevice(ctx->device);
+  if (e == hipSuccess) e = hipMalloc((void **)&b->d_recs, (size_t)capacity * ctx->desc.nin * 4);
+  if (e == hipSuccess) e = hipMalloc((void **)&b->d_bodies, (size_t)capacity * pitch);
+  if (e == hipSuccess) e = hipMalloc((void **)&b->d_pub, (size_t)capacity * ctx->desc.npub * 4);
+  if (e == hipSuccess) e = hipMalloc((void **)&b->d_status, (size_t)capacity * 4);
+  if (e != hipSuccess) { b3w_batch_free(b); return e == hipErrorOutOfMemory ? B3W_E_NOT_ENOUGH_MEMORY : hip_fail(ctx, e, "hipMalloc"); }
+  *out = b;
+  return B3W_OK;
+}
+
+void b3w_batch_free(b3w_batch *b) {
+  if (!b) return;
+  if (b->d_recs) (void)hipFree(b->d_recs);
+  if (b->d_bodies) (void)hipFree(b->d_bodies);
+  if (b->d_pub) (void)hipFree(b->d_pub);
+  if (b->d_status) (void)hipFree(b->d_status);
+  delete b;
+}
+
+int32_t b3w_batch_run(b3w_batch *b, const uint32_t *host_records, uint32_t n, void *stream) {
+  if (!b || !host_records || n > b->capacity) return B3W_E_BAD_ARGUMENT;
+  b3w_ctx *ctx = b->ctx;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, hipMemcpyAsync(b->d_recs, host_records, (size_t)n * ctx->desc.nin * 4, hipMemcpyHostToDevice, (hipStream_t)stream));
+  int32_t rc = b3w_batch_run_device(ctx, b->d_recs, n, b->d_bodies, b->pitch, b->d_pub, b->d_status, stream);
+  if (rc) return rc;
+  HIP_TRY(ctx, hipStreamSynchronize((hipStream_t)stream));
+  b->n = n;
+  return B3W_OK;
+}
+
+int32_t b3w_batch_outputs(b3w_batch *b, uint32_t *host_public, int32_t *host_status) {
+  if (!b || !host_public) return B3W_E_BAD_ARGUMENT;
+  b3w_ctx *ctx = b->ctx;
+  HIP_TRY(ctx, hipMemcpy(host_public, b->d_pub, (size_t)b->n * ctx->desc.npub * 4, hipMemcpyDeviceToHost));
+  if (host_status) HIP_TRY(ctx, hipMemcpy(host_status, b->d_status, (size_t)b->n * 4, hipMemcpyDeviceToHost));
+  return B3W_OK;
+}
+
+int32_t b3w_batch_fetch(b3w_batch *b, uint32_t index, uint8_t *out_body) {
+  if (!b || !out_body || index >= b->n) return B3W_E_BAD_ARGUMENT;
+  b3w_ctx *ctx = b->ctx;
+  HIP_TRY(ctx, hipMemcpy(out_body, b->d_bodies + (size_t)index * b->pitch, (size_t)ctx->desc.nwit * 32, hipMemcpyDeviceToHost));
+  return B3W_OK;
+}
+
+void *b3w_batch_device_ptr(b3w_batch *b, uint64_t *pitch) {
+  if (!b) return nullptr;
+  if (pitch) *pitch = b->pitch;
+  return b->d_bodies;
+}
+
+}  // extern "C"

@@ -1,0 +1,129 @@
+/*
+ * b3wit.h — C-ABI of the MI355X-native batched witness generator for the reference's BLAKE3
+ * circom circuits (libb3wit.so).  Plain C: pointers and sizes only, no HIP / torch types.
+ *
+ * Every entry point names the piece of the reference interface it stands in for
+ * (paths relative to the reference repo banyancomputer/hot-proofs-blake3-circom):
+ *   WC  = blake3_nova_js/witness_calculator.js  (the circom-emitted loader, the drop-in boundary)
+ *   WASM exports = the functions WC calls on the compiled circuit instance (same file, cited lines)
+ *
+ * Status codes: 0 ok; 1..6 are the circom runtime exception codes WC maps to text at
+ * WC:21-37 (1 Signal not found, 2 Too many signals set, 3 Signal already set, 4 Assert Failed,
+ * 5 Not enough memory, 6 Input signal array access exceeds the size); >= 100 are runtime errors
+ * of this library.  No function throws; a ctx / batch is not thread-safe, distinct ones are.
+ */
+#ifndef B3WIT_H
+#define B3WIT_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Circuits = the committed circom builds of the reference. */
+#define B3W_CIRCUIT_COMPRESSION_BN254 0 /* build/blake3_compression/blake3_compression_js/blake3_compression.wasm  N=24093 */
+#define B3W_CIRCUIT_NOVA_BN254        1 /* build/blake3_nova_js/blake3_nova.wasm (--prime bn128, O2)               N=23291 */
+#define B3W_CIRCUIT_NOVA_VESTA        2 /* build/blake3_nova_pasta_js/blake3_nova_pasta.wasm (--prime vesta, O2)   N=23291 */
+#define B3W_CIRCUIT_NOVA_BN254_O1     3 /* build/blake3_nova/blake3_nova_js/blake3_nova.wasm (circomkit build)      N=24614 */
+#define B3W_CIRCUIT_UNKNOWN         (-1)
+
+#define B3W_OK                     0
+#define B3W_E_SIGNAL_NOT_FOUND     1
+#define B3W_E_TOO_MANY_SIGNALS     2
+#define B3W_E_SIGNAL_ALREADY_SET   3
+#define B3W_E_ASSERT_FAILED        4
+#define B3W_E_NOT_ENOUGH_MEMORY    5
+#define B3W_E_ARRAY_ACCESS         6
+#define B3W_E_BAD_ARGUMENT       100
+#define B3W_E_NO_DEVICE          101 /* no HIP device / HIP runtime error: the product has no CPU path */
+#define B3W_E_HIP                102
+#define B3W_E_DOMAIN             103 /* input outside the device fast-path domain (see DESIGN.md "Input domain") */
+#define B3W_E_NOT_ALL_INPUTS     104 /* WC:166-168 "Not all inputs have been set" */
+
+typedef struct b3w_ctx b3w_ctx;
+typedef struct b3w_batch b3w_batch;
+
+/* Library / ABI version (major<<16 | minor). */
+uint32_t b3w_abi_version(void);
+
+/* Which committed circuit is this WASM?  Replaces WebAssembly.compile(code) at WC:7: the
+ * builder receives the .wasm bytes; the native path keys on their sha256. */
+int32_t b3w_identify_wasm(const uint8_t *code, size_t len);
+
+/* Replaces WebAssembly.instantiate + `new WitnessCalculator(instance, sanityCheck)` (WC:19,78,
+ * ctor WC:109-125).  device = HIP device ordinal (>= 0).  Fails with B3W_E_NO_DEVICE when the
+ * HIP runtime has no such device — there is no CPU fallback. */
+int32_t b3w_create(int32_t circuit, int32_t device, b3w_ctx **out);
+void b3w_destroy(b3w_ctx *ctx);
+
+/* WASM exports getFieldNumLen32 / getRawPrime / getWitnessSize / getInputSize /
+ * getVersion+getMinorVersion+getPatchVersion (read by the ctor WC:112-122 and WC:166). */
+int32_t b3w_info(const b3w_ctx *ctx, uint32_t *n32, uint8_t prime_le[32], uint32_t *witness_size,
+                 uint32_t *input_size, uint32_t version[3]);
+
+/* WASM export getInputSignalSize(hMSB,hLSB) (WC:141): number of values the input signal whose
+ * FNV-1a-64 name hash (WC:325-337) is `fnv1a64_of_name` takes; 0 when the circuit has no such input. */
+int32_t b3w_input_signal_size(const b3w_ctx *ctx, uint64_t fnv1a64_of_name);
+
+/* One witness = WASM exports init + setInputSignal x inputs + getWitness x N as driven by
+ * _doCalculateWitness (WC:131-169) and calculateBinWitness (WC:190-205).
+ *   name_hashes[k], counts[k] : FNV-1a-64 of the k-th input name and how many values it carries
+ *   values_le32               : sum(counts) field elements, 32-byte little-endian, already
+ *                               reduced into [0,p) (WC:319-323 normalize), in key order
+ *   out_body                  : witness_size*32 bytes, canonical little-endian elements
+ * Size errors mirror WC:142-150 (B3W_E_TOO_MANY_SIGNALS / B3W_E_ARRAY_ACCESS /
+ * B3W_E_NOT_ALL_INPUTS); a failed circuit assert returns B3W_E_ASSERT_FAILED. */
+int32_t b3w_calc_witness(b3w_ctx *ctx, const uint64_t *name_hashes, const uint32_t *counts,
+                         const uint8_t *values_le32, uint32_t nkeys, uint8_t *out_body);
+
+/* The 76-byte .wtns v2 preamble calculateWTNSBin builds at WC:215-262 ("wtns", version 2,
+ * 2 sections, section 1 {n8, prime, nWitness}, section 2 id + length). */
+int32_t b3w_write_wtns_header(const b3w_ctx *ctx, uint8_t out[76]);
+
+/* Text of the last error on this ctx (the trace WC appends after "Assert Failed.\n", WC:41,38). */
+int32_t b3w_last_error(const b3w_ctx *ctx, char *buf, size_t len);
+
+/* ---- batch fast path (no counterpart in the reference: it computes one witness per call) ----
+ * Inputs are packed u32 records, all words canonical (< 2^32):
+ *   compression (28 words): h[8] m[16] t[2] b d
+ *   nova        (32 words): n_blocks block_count h[8] chunk_idx_low chunk_idx_high leaf_depth
+ *                           total_depth depth m[16] b
+ * Witness bodies stay in HBM: n bodies of witness_size*32 bytes, body i at out + i*pitch.   */
+
+/* Kernel launch only; every pointer is a DEVICE pointer, `stream` is a hipStream_t (NULL = default
+ * stream).  No allocation, no synchronisation: safe inside stream capture.
+ *   d_records : n * input_size u32                     d_bodies : n * pitch bytes (pitch % 32 == 0,
+ *   d_public  : n * public_words u32 or NULL             pitch >= witness_size*32)
+ *   d_status  : n int32 or NULL (0 ok, 4 assert failed, 103 outside the fast-path domain) */
+int32_t b3w_batch_run_device(b3w_ctx *ctx, const uint32_t *d_records, uint32_t n, uint8_t *d_bodies,
+                             uint64_t pitch, uint32_t *d_public, int32_t *d_status, void *stream);
+
+/* Number of u32 public-output words per witness written to d_public: compression 16 (out[16]),
+ * nova 15 (w[1..15]: n_blocks_out block_count_out h_out[8] total_depth_out depth_out
+ * chunk_idx_low_out chunk_idx_high_out leaf_depth_out). */
+uint32_t b3w_public_words(const b3w_ctx *ctx);
+
+/* Convenience wrappers that own device buffers (hipMalloc) for up to `capacity` witnesses. */
+int32_t b3w_batch_alloc(b3w_ctx *ctx, uint32_t capacity, uint64_t pitch /* 0 = witness_size*32 */, b3w_batch **out);
+void b3w_batch_free(b3w_batch *batch);
+/* H2D of n records + kernel on `stream`, then stream sync. */
+int32_t b3w_batch_run(b3w_batch *batch, const uint32_t *host_records, uint32_t n, void *stream);
+/* D2H of the public outputs (n * public_words u32) and per-witness status (n int32, may be NULL). */
+int32_t b3w_batch_outputs(b3w_batch *batch, uint32_t *host_public, int32_t *host_status);
+/* D2H of one full body (witness_size*32 bytes). */
+int32_t b3w_batch_fetch(b3w_batch *batch, uint32_t index, uint8_t *out_body);
+/* Zero-copy handle for on-GPU consumers: device pointer of body 0, and the pitch. */
+void *b3w_batch_device_ptr(b3w_batch *batch, uint64_t *pitch);
+
+/* Timing helper for harnesses: records HIP events around `iters` back-to-back launches of the
+ * batch kernel on `stream` and returns the average kernel time in milliseconds (device pointers
+ * as in b3w_batch_run_device). */
+int32_t b3w_batch_time_device(b3w_ctx *ctx, const uint32_t *d_records, uint32_t n, uint8_t *d_bodies,
+                              uint64_t pitch, uint32_t *d_public, int32_t *d_status, void *stream,
+                              uint32_t iters, float *avg_ms);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* B3WIT_H */

@@ -135,7 +135,9 @@ static fe fe_inv(const field_t *F, fe a) {
 static int fe_bit(const fe *a, int i) { return (int)((a->l[i >> 6] >> (i & 63)) & 1); }
 /* value >> n == 0 ? */
 static int fe_fits(const fe *a, int n) {
-  for (int i = n; i < 256; i++) if (fe_bit(a, i)) return 0;
+  const int limb = n >> 6, sh = n & 63;
+  if (limb < 4 && sh && (a->l[limb] >> sh)) return 0;
+  for (int i = limb + (sh ? 1 : 0); i < 4; i++) if (a->l[i]) return 0;
   return 1;
 }
 static void field_init(field_t *F, const uint64_t p[4]) {

@@ -77,11 +77,20 @@ def oracle_witness(circuit, fe_inputs):
     return rc, body, err.value.decode()
 
 
+_buf_cache = {}
+
+
 def oracle_batch_u32(circuit, recs):
+    """-> (number of failed asserts, bodies uint8 [n, nwit*32]).  The returned array is a reused
+    scratch buffer (first-touch page faults are very slow in the build sandbox): copy what you keep."""
     lib = oracle()
     recs = np.ascontiguousarray(recs, dtype=np.uint32)
     n = recs.shape[0]
-    bodies = np.zeros((n, NWIT[circuit] * 32), dtype=np.uint8)
+    key = (n, NWIT[circuit])
+    if key not in _buf_cache:
+        _buf_cache.clear()
+        _buf_cache[key] = np.zeros((n, NWIT[circuit] * 32), dtype=np.uint8)
+    bodies = _buf_cache[key]
     bad = lib.b3wo_witness_batch_u32(CIRCUIT_ID[circuit], recs.ctypes.data, n, bodies.ctypes.data)
     return bad, bodies
 
