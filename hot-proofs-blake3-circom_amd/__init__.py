@@ -50,6 +50,12 @@ def lib():
         return _lib
     if not os.path.exists(LIB_PATH):
         raise B3WError(B3W_E_NO_DEVICE, f"{LIB_PATH} not built: run `python -c 'import __graft_entry__ as g; g.build()'`")
+    # PyTorch-ROCm wheels bundle their own libamdhip64.so.7 / libhsa-runtime64; a process must hold ONE
+    # HIP runtime, so when torch is installed let it load first and libb3wit.so binds to that copy by soname.
+    try:
+        import torch  # noqa: F401
+    except ImportError:
+        pass
     L = ctypes.CDLL(LIB_PATH)
     vp, u32, i32, u64, sz = ctypes.c_void_p, ctypes.c_uint32, ctypes.c_int32, ctypes.c_uint64, ctypes.c_size_t
     sig = {
