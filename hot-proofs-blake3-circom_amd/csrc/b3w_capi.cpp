@@ -136,6 +136,51 @@ bool atom_lds(int kind, uint32_t atom, uint32_t *word, int *width /* 32, 64 or 2
   return true;
 }
 
+// 1/k mod p for 1 <= k < 2^32 (same closed form as the device routine in b3w_kernels.hip): with
+// t = -p^-1 mod k, (p*t + 1)/k is exact and is the inverse.  Used to fill the device-side table of
+// small inverses the nova kernels look IsZero arguments up in.
+void inv_small_host(uint32_t k, const uint32_t P[8], uint32_t out[8]) {
+  uint64_t r = 0;
+  for (int i = 7; i >= 0; --i) r = ((r << 32) | P[i]) % k;
+  int64_t x0 = 0, x1 = 1;
+  uint64_t a = k, b = r;
+  while (b > 1) {
+    const uint64_t q = a / b, tt = a - q * b;
+    a = b; b = tt;
+    const int64_t tx = x0 - (int64_t)q * x1;
+    x0 = x1; x1 = tx;
+  }
+  int64_t x = x1 % (int64_t)k;
+  if (x < 0) x += k;
+  const uint64_t t = ((uint64_t)k - (uint64_t)x) % k;
+  uint32_t prod[9];
+  uint64_t carry = 1;
+  for (int i = 0; i < 8; ++i) {
+    const uint64_t cur = (uint64_t)P[i] * t + carry;
+    prod[i] = (uint32_t)cur;
+    carry = cur >> 32;
+  }
+  prod[8] = (uint32_t)carry;
+  uint64_t rem = 0;
+  for (int i = 8; i >= 0; --i) {
+    const uint64_t cur = (rem << 32) | prod[i];
+    const uint64_t qd = cur / k;
+    rem = cur - qd * k;
+    if (i < 8) out[i] = (uint32_t)qd;
+  }
+}
+
+constexpr uint32_t B3W_INV_TABLE_N = 2048;
+
+// d_aux image: [0,8) prime limbs, [8] TABLE_N, [16 + 8k, +8) k^-1 mod p
+std::vector<uint32_t> build_nova_aux(const uint64_t *prime) {
+  std::vector<uint32_t> aux(16 + 8 * B3W_INV_TABLE_N, 0);
+  memcpy(aux.data(), prime, 32);
+  aux[8] = B3W_INV_TABLE_N;
+  for (uint32_t k = 1; k < B3W_INV_TABLE_N; ++k) inv_small_host(k, aux.data(), aux.data() + 16 + 8 * k);
+  return aux;
+}
+
 bool build_slot_table(const CircuitDesc &c, std::vector<uint32_t> &table, std::string &err) {
   const uint32_t padded = ((c.nwit + 31) / 32 + 8) * 32;   // + 8 groups: expand() prefetches ahead
   table.assign(padded, B3W_ENTRY(0, 31, B3W_MODE_BIT));        // padding: bit 31 of ONE = 0 (never stored anyway)
@@ -253,6 +298,11 @@ int32_t b3w_create(int32_t circuit, int32_t device, b3w_ctx **out) {
   const CircuitDesc &d = ctx->desc;
   hipError_t e = hipMalloc((void **)&ctx->d_table, table.size() * 4);
   if (e == hipSuccess) e = hipMemcpy(ctx->d_table, table.data(), table.size() * 4, hipMemcpyHostToDevice);
+  if (e == hipSuccess && d.kind != B3W_KIND_COMP) {
+    const std::vector<uint32_t> aux = build_nova_aux(d.prime);
+    e = hipMalloc(&ctx->d_aux, aux.size() * 4);
+    if (e == hipSuccess) e = hipMemcpy(ctx->d_aux, aux.data(), aux.size() * 4, hipMemcpyHostToDevice);
+  }
   if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_rec1, d.nin * 4);
   if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_body1, (size_t)d.nwit * 32);
   if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_status1, 4);

@@ -154,7 +154,7 @@ __device__ __forceinline__ void emit_group(const uint32_t *lds, uint32_t e, uint
 template <int W, int WORDS, bool WIDE, bool NT>
 __device__ __forceinline__ void expand(const uint32_t *lds, const uint32_t *__restrict__ table, uint32_t nwit,
                                        uint8_t *__restrict__ out, uint64_t pitch, uint32_t wit0, uint32_t n,
-                                       const uint32_t *okmask /* per-w LDS flags or null */) {
+                                       const uint32_t *okmask /* per-w LDS flags or null */, bool all_ok) {
   constexpr int U = 4;
   const int lane = threadIdx.x;
   const uint32_t ngroups = (nwit + 31) >> 5, full = nwit >> 5;
@@ -164,7 +164,7 @@ __device__ __forceinline__ void expand(const uint32_t *lds, const uint32_t *__re
   for (int w = 0; w < W; ++w) woff[w] = (uint64_t)(wit0 + w) * pitch + (uint32_t)lane * 16u;
   const uint32_t *tp = table + (lane >> 1);            // entry of this lane's slot in group 0
   uint32_t g = 0;
-  if (nact == (uint32_t)W && !okmask) {
+  if (nact == (uint32_t)W && all_ok) {
     uint32_t cur[U], nxt[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) cur[u] = tp[u * 32];   // table is padded by U groups past ngroups
@@ -211,7 +211,264 @@ __global__ __launch_bounds__(64) void b3w_compression_kernel(const uint32_t *__r
     }
   }
   __syncthreads();
-  expand<W, WORDS, false, NT>(lds, table, nwit, out, pitch, wit0, n, nullptr);
+  expand<W, WORDS, false, NT>(lds, table, nwit, out, pitch, wit0, n, nullptr, true);
+}
+
+
+// ------------------------------------------------------------------ nova step circuit
+// Blake3Nova(0) (circuits/blake3_nova.circom:169-267) = control logic over small integers + one
+// Blake3Compression.  For canonical u32 inputs every signal is a bit or a word EXCEPT the IsZero
+// inverses (circomlib IsZero: inv <-- in!=0 ? 1/in : 0): 67 per step, all of small signed integers
+//   -depth, -block_count, n_blocks-1-block_count, total_depth-i-2-depth (i<64),
+// and, in the circomkit (O1) build, the negative differences themselves (p - |k|).
+
+// d_aux: words [0,8) prime (little-endian limbs), [8] TABLE_N, [16 + 8k, +8) = k^-1 mod p, k < TABLE_N
+#define B3W_AUX_TABLE 16
+
+struct U256 { uint32_t l[8]; };
+
+__device__ __forceinline__ U256 u256_sub(const U256 &a, const U256 &b) {
+  U256 r;
+  uint32_t br = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const uint64_t d = (uint64_t)a.l[i] - b.l[i] - br;
+    r.l[i] = (uint32_t)d;
+    br = (uint32_t)(d >> 63);
+  }
+  return r;
+}
+
+__device__ __forceinline__ U256 u256_small(uint64_t x) {
+  U256 r;
+  r.l[0] = (uint32_t)x; r.l[1] = (uint32_t)(x >> 32);
+#pragma unroll
+  for (int i = 2; i < 8; ++i) r.l[i] = 0;
+  return r;
+}
+
+// k mod p for a small signed integer
+__device__ __forceinline__ U256 u256_signed(int64_t k, const U256 &P) {
+  return k >= 0 ? u256_small((uint64_t)k) : u256_sub(P, u256_small((uint64_t)(-k)));
+}
+
+// 1/k mod p for 1 <= k < 2^32 without field arithmetic: with t = -p^-1 mod k, (p*t + 1)/k is an
+// exact quotient below p whose product with k is 1 mod p.
+__device__ __forceinline__ U256 inv_small_general(uint32_t k, const U256 &P) {
+  uint64_t r = 0;
+#pragma unroll
+  for (int i = 7; i >= 0; --i) r = ((r << 32) | P.l[i]) % k;      // r = p mod k
+  // x = r^-1 mod k (extended Euclid; gcd(r,k) = 1 because p is prime and k < p)
+  int64_t x0 = 0, x1 = 1;
+  uint64_t a = k, b = r;
+  while (b > 1) {
+    const uint64_t q = a / b, tt = a - q * b;
+    a = b; b = tt;
+    const int64_t tx = x0 - (int64_t)q * x1;
+    x0 = x1; x1 = tx;
+  }
+  int64_t x = x1 % (int64_t)k;
+  if (x < 0) x += k;
+  const uint64_t t = ((uint64_t)k - (uint64_t)x) % k;              // p*t == -1 (mod k)
+  uint32_t prod[9];
+  uint64_t carry = 1;                                               // the "+ 1"
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const uint64_t cur = (uint64_t)P.l[i] * t + carry;
+    prod[i] = (uint32_t)cur;
+    carry = cur >> 32;
+  }
+  prod[8] = (uint32_t)carry;
+  U256 out;
+  uint64_t rem = 0;
+#pragma unroll
+  for (int i = 8; i >= 0; --i) {
+    const uint64_t cur = (rem << 32) | prod[i];
+    const uint64_t qd = cur / k;
+    rem = cur - qd * k;
+    if (i < 8) out.l[i] = (uint32_t)qd;
+  }
+  return out;
+}
+
+// inv <-- k != 0 ? 1/k : 0 in the field, k a small signed integer.  false = |k| outside the supported range.
+__device__ __forceinline__ bool inv_signed(int64_t k, const U256 &P, const uint32_t *__restrict__ aux, U256 &out) {
+  const uint64_t mag = k < 0 ? (uint64_t)(-k) : (uint64_t)k;
+  if (mag == 0) { out = u256_small(0); return true; }
+  if (mag >> 32) { out = u256_small(0); return false; }
+  const uint32_t tn = aux[8];
+  U256 v;
+  if (mag < tn) {
+    const uint4 *tp = reinterpret_cast<const uint4 *>(aux + B3W_AUX_TABLE + 8 * mag);
+    const uint4 lo = tp[0], hi = tp[1];
+    v.l[0] = lo.x; v.l[1] = lo.y; v.l[2] = lo.z; v.l[3] = lo.w;
+    v.l[4] = hi.x; v.l[5] = hi.y; v.l[6] = hi.z; v.l[7] = hi.w;
+  } else {
+    v = inv_small_general((uint32_t)mag, P);
+  }
+  out = k < 0 ? u256_sub(P, v) : v;
+  return true;
+}
+
+__device__ __forceinline__ void lds_put256(uint32_t *L, const U256 &v) {
+  *reinterpret_cast<uint4 *>(L) = make_uint4(v.l[0], v.l[1], v.l[2], v.l[3]);
+  *reinterpret_cast<uint4 *>(L + 4) = make_uint4(v.l[4], v.l[5], v.l[6], v.l[7]);
+}
+
+template <int KIND, int W, bool NT>
+__global__ __launch_bounds__(64) void b3w_nova_kernel(const uint32_t *__restrict__ recs, uint32_t n,
+                                                      uint8_t *__restrict__ out, uint64_t pitch,
+                                                      const uint32_t *__restrict__ table, uint32_t nwit,
+                                                      uint32_t *__restrict__ pub, int32_t *__restrict__ status,
+                                                      const uint32_t *__restrict__ aux) {
+  constexpr bool O1 = KIND == B3W_KIND_NOVA_O1;
+  constexpr int WORDS = O1 ? B3W_LDS_WORDS_NOVA_O1 : B3W_LDS_WORDS_NOVA_O2;
+  __shared__ __attribute__((aligned(16))) uint32_t lds[W * WORDS + 4];
+  __shared__ uint32_t okf[W];      // 1 = witness computed, stream it out
+  __shared__ uint32_t domf[W];     // 1 = an IsZero argument fell outside the supported magnitude
+  const int lane = threadIdx.x;
+  const uint32_t wit0 = blockIdx.x * W;
+  for (int i = lane; i < W * 32; i += 64) {
+    const int w = i >> 5, j = i & 31;
+    if (wit0 + w < n) lds[w * WORDS + B3W_LDS_NV + j] = recs[(uint64_t)(wit0 + w) * 32 + j];
+  }
+  if (lane < W) { okf[lane] = 0; domf[lane] = 0; }
+  __syncthreads();
+
+  U256 P;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) P.l[i] = aux[i];
+
+  // ---- A: the 67 IsZero gadgets of each step, one per lane-job
+  for (int t = lane; t < 67 * W; t += 64) {
+    const int w = t / 67, j = t - w * 67;
+    if (wit0 + w >= n) continue;
+    uint32_t *L = lds + w * WORDS;
+    const uint32_t *in = L + B3W_LDS_NV;
+    const int64_t depth = in[NV_DEPTH];
+    int64_t k, in1 = 0;
+    uint32_t flag_atom, isz_wide = 0, in1_wide = 0;
+    if (j == 0) { k = -depth; flag_atom = NV_IS_ROOT; isz_wide = NV_ROOT_ISZ_IN; }                     // check_root (:19-23)
+    else if (j == 1) { k = -(int64_t)in[NV_BLOCK_COUNT]; flag_atom = NV_E0; isz_wide = NV_E0_ISZ_IN; }  // check_block_counts[0] (:136-141)
+    else if (j == 2) { in1 = (int64_t)in[NV_N_BLOCKS] - 1; k = in1 - (int64_t)in[NV_BLOCK_COUNT];       // check_block_counts[1] (:142-144)
+                       flag_atom = NV_E1; isz_wide = NV_E1_ISZ_IN; in1_wide = NV_E1_IN1; }
+    else { const int i = j - 3; in1 = (int64_t)in[NV_TOTAL_DEPTH] - i - 2; k = in1 - depth;              // eqs[i] (:65-72)
+           flag_atom = NV_EQ_OUT + i; isz_wide = NV_EQ_ISZ_IN + i; in1_wide = NV_EQ_IN1 + i; }
+    U256 inv;
+    if (!inv_signed(k, P, aux, inv)) domf[w] = 1;
+    L[B3W_LDS_NV + flag_atom] = (k == 0) ? 1u : 0u;
+    if (!O1) {
+      lds_put256(L + B3W_LDS_WIDE + 8 * j, inv);                 // O2 keeps only the inverses: wide index = job index
+    } else {
+      const uint32_t inv_wide = j < 3 ? (uint32_t)j : (uint32_t)(NV_EQ_INV - NV_NARROW_COUNT + (j - 3));
+      lds_put256(L + B3W_LDS_WIDE + 8 * inv_wide, inv);
+      lds_put256(L + B3W_LDS_WIDE + 8 * (isz_wide - NV_NARROW_COUNT), u256_signed(k, P));
+      if (in1_wide) lds_put256(L + B3W_LDS_WIDE + 8 * (in1_wide - NV_NARROW_COUNT), u256_signed(in1, P));
+    }
+  }
+  __syncthreads();
+
+  // ---- B: flags, message / chaining-value selection; 4 lanes per witness
+  const int w = lane >> 2, col = lane & 3;
+  const bool active = w < W && wit0 + w < n;
+  uint32_t *L = lds + (active ? w : 0) * WORDS;
+  if (active) {
+    uint32_t *nv = L + B3W_LDS_NV;
+    const uint32_t n_blocks = nv[NV_N_BLOCKS], block_count = nv[NV_BLOCK_COUNT], cil = nv[NV_CIL], cih = nv[NV_CIH];
+    const uint32_t leaf_depth = nv[NV_LEAF_DEPTH], total_depth = nv[NV_TOTAL_DEPTH], depth = nv[NV_DEPTH];
+    // Blake3NovaTreePath_CheckDepth (:13-45): LessThan(8) / GreaterEqThan(8) through Num2Bits(9)
+    const int64_t cp = (int64_t)depth + 257 - (int64_t)leaf_depth;       // check_parent.n2b.in
+    const int64_t ed = (int64_t)leaf_depth + 255 - (int64_t)depth;       // exceed_depth.lt.n2b.in
+    const bool assert_fail = cp < 0 || cp >= 512 || ed < 0 || ed >= 512 || ((ed >> 8) & 1) == 0;
+    const uint32_t parent = 1u - (uint32_t)((cp >> 8) & 1);
+    const uint32_t is_root = depth == 0 ? 1u : 0u;
+    const uint32_t e0 = block_count == 0 ? 1u : 0u;
+    const uint32_t e1 = ((int64_t)n_blocks - 1 == (int64_t)block_count) ? 1u : 0u;
+    const bool dom = domf[w] != 0 || depth == 0xFFFFFFFFu || (block_count == 0xFFFFFFFFu && !parent);
+    const int32_t st = assert_fail ? 4 : dom ? 103 : 0;
+    // Blake3GetFlag (:122-167)
+    const uint32_t last = e1 & (1u - parent), first = e0 & (1u - parent);
+    const uint32_t ur_tmp = parent | e1, ur_flag = ur_tmp & is_root;
+    const uint32_t dflag = first + 2u * last + 8u * ur_flag + 4u * parent;
+    // Blake3GetDownLeftPath (:47-84): eqs[i].out = [i == istar]; bit_at_depth is a running sum
+    const int64_t istar = (int64_t)total_depth - 2 - (int64_t)depth;
+    const uint64_t chunk_idx = (uint64_t)cil | ((uint64_t)cih << 32);
+    const bool has_star = istar >= 0 && istar < 64;
+    const uint32_t nb_star = has_star ? 1u - (uint32_t)((chunk_idx >> (istar & 63)) & 1) : 0u;
+    const uint32_t dl = parent ? nb_star : 1u;                            // (1-parent) + parent*bit_at_depth[63]
+    const uint32_t cdd = last | parent, decr = cdd & (1u - is_root);
+    if (col == 0) {
+      okf[w] = st == 0 ? 1u : 0u;
+      if (status) status[wit0 + w] = st;
+      nv[NV_BLOCK_COUNT_OUT] = block_count + (1u - parent);               // :251
+      nv[NV_DEPTH_OUT] = depth - decr;                                    // :262
+      nv[NV_IS_PARENT] = parent;
+      nv[NV_CP_IN1] = leaf_depth - 1u;
+      nv[NV_CP_N2B_IN] = (uint32_t)cp;
+      nv[NV_ED_IN1] = depth + 1u;
+      nv[NV_ED_N2B_IN] = (uint32_t)ed;
+      nv[NV_ED_OUT] = 0u;
+      nv[NV_NOT_ROOT] = 1u - is_root;
+      nv[NV_NOT_PARENT] = 1u - parent;
+      nv[NV_IS_LAST_BLOCK] = last;
+      nv[NV_FIRST] = first;
+      nv[NV_UR_TMP] = ur_tmp;
+      nv[NV_UR_FLAG] = ur_flag;
+      nv[NV_DL] = dl;
+      nv[NV_CDD_OUT] = cdd;
+      nv[NV_DECR_DEPTH] = decr;
+      L[B3W_LDS_CHUNK_IDX] = cil;
+      L[B3W_LDS_CHUNK_IDX + 1] = cih;
+      L[B3W_A_T] = parent ? 0u : cil;                                     // :244-245
+      L[B3W_A_T + 1] = parent ? 0u : cih;
+      L[B3W_A_B] = nv[NV_B];
+      L[B3W_A_D] = dflag;
+    }
+    // Blake3GetFinal_m (:86-120) and h_compression (:229-233): products of a word and a bit
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const int i = col + 4 * q;
+      const uint32_t hsel = nv[NV_H + (i & 7)], msel = nv[NV_M + (i & 7)], mi = nv[NV_M + i];
+      const uint32_t take_h = i < 8 ? dl : 1u - dl;                        // tmp_down = h * (dl | 1-dl)
+      const uint32_t td = take_h ? hsel : 0u;
+      const uint32_t mp = (take_h ? 0u : msel) + td;                       // m_is_parent
+      const uint32_t tp = parent ? mp : 0u;
+      nv[NV_TMP_DOWN + i] = td;
+      nv[NV_M_IS_PARENT + i] = mp;
+      nv[NV_TMP_IS_PAR + i] = tp;
+      L[B3W_A_M + i] = (parent ? 0u : mi) + tp;                            // out_m
+    }
+#pragma unroll
+    for (int q = 0; q < 2; ++q) {
+      const int i = col + 4 * q;
+      const uint32_t iv = i == 0 ? 0x6A09E667u : i == 1 ? 0xBB67AE85u : i == 2 ? 0x3C6EF372u : i == 3 ? 0xA54FF53Au
+                        : i == 4 ? 0x510E527Fu : i == 5 ? 0x9B05688Cu : i == 6 ? 0x1F83D9ABu : 0x5BE0CD19u;
+      const uint32_t tiv = parent ? iv : 0u;
+      nv[NV_TMPIV + i] = tiv;
+      L[B3W_A_H + i] = (parent ? 0u : nv[NV_H + i]) + tiv;                 // h_compression
+    }
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      const int i = col * 16 + q;
+      nv[NV_BIT_AT_DEPTH + i] = (has_star && (int64_t)i >= istar) ? nb_star : 0u;
+    }
+  }
+  __syncthreads();
+  if (active && okf[w]) trace_compression(L, col, nullptr);
+  __syncthreads();
+  bool all_ok = true;
+#pragma unroll
+  for (int x = 0; x < W; ++x) all_ok = all_ok && (okf[x] != 0);
+  if (active && okf[w] && pub) {
+    // w[1..15]: n_blocks_out block_count_out h_out[8] total_depth_out depth_out chunk_idx_low_out chunk_idx_high_out leaf_depth_out
+    uint32_t *pw = pub + (uint64_t)(wit0 + w) * 15;
+    const uint32_t *nv = L + B3W_LDS_NV;
+    if (col == 0) { pw[0] = nv[NV_N_BLOCKS]; pw[1] = nv[NV_BLOCK_COUNT_OUT]; pw[10] = nv[NV_TOTAL_DEPTH]; pw[11] = nv[NV_DEPTH_OUT]; }
+    if (col == 1) { pw[12] = nv[NV_CIL]; pw[13] = nv[NV_CIH]; pw[14] = nv[NV_LEAF_DEPTH]; }
+    pw[2 + col] = L[B3W_A_O + col];
+    pw[6 + col] = L[B3W_A_O + 4 + col];
+  }
+  expand<W, WORDS, true, NT>(lds, table, nwit, out, pitch, wit0, n, okf, all_ok);
 }
 
 }  // namespace
@@ -220,7 +477,6 @@ __global__ __launch_bounds__(64) void b3w_compression_kernel(const uint32_t *__r
 extern "C" int b3w_launch_batch(int kind, int variant, const uint32_t *d_recs, uint32_t n, uint8_t *d_out,
                                 uint64_t pitch, const uint32_t *d_table, uint32_t nwit, uint32_t *d_pub,
                                 int32_t *d_status, const void *d_aux, hipStream_t stream) {
-  (void)d_aux;
   if (n == 0) return 0;
   if (kind == B3W_KIND_COMP) {
 #define B3W_LAUNCH_COMP(WV, NTV)                                                                         \
@@ -238,6 +494,28 @@ extern "C" int b3w_launch_batch(int kind, int variant, const uint32_t *d_recs, u
       default: return -1;
     }
 #undef B3W_LAUNCH_COMP
+    return (int)hipGetLastError();
+  }
+  if (kind == B3W_KIND_NOVA_O2 || kind == B3W_KIND_NOVA_O1) {
+    if (!d_aux) return -3;
+#define B3W_LAUNCH_NOVA(KV, WV)                                                                           \
+  hipLaunchKernelGGL((b3w_nova_kernel<KV, WV, false>), dim3((n + WV - 1) / WV), dim3(64), 0, stream,     \
+                     d_recs, n, d_out, pitch, d_table, nwit, d_pub, d_status, (const uint32_t *)d_aux)
+    if (kind == B3W_KIND_NOVA_O2) {
+      switch (variant) {
+        case 0: B3W_LAUNCH_NOVA(B3W_KIND_NOVA_O2, 2); break;
+        case 1: B3W_LAUNCH_NOVA(B3W_KIND_NOVA_O2, 1); break;
+        case 2: B3W_LAUNCH_NOVA(B3W_KIND_NOVA_O2, 4); break;
+        default: return -1;
+      }
+    } else {
+      switch (variant) {
+        case 0: B3W_LAUNCH_NOVA(B3W_KIND_NOVA_O1, 2); break;
+        case 1: B3W_LAUNCH_NOVA(B3W_KIND_NOVA_O1, 1); break;
+        default: return -1;
+      }
+    }
+#undef B3W_LAUNCH_NOVA
     return (int)hipGetLastError();
   }
   return -2;
