@@ -201,6 +201,12 @@ bool build_slot_table(const CircuitDesc &c, std::vector<uint32_t> &table, std::s
         table[slot] = B3W_ENTRY(word, 0, width == 32 ? B3W_MODE_W32 : width == 64 ? B3W_MODE_W64 : B3W_MODE_W256);
       } else {
         const uint32_t bit = run.bit0 + j;
+        if (run.atom == B3W_A_NV + NV_CHUNK_IDX && bit == 64) {
+          // Num2Bits(65).out[64] of chunk_idx = chunk_idx_low + 2^32*chunk_idx_high: always 0 for the
+          // u32 inputs of the device path (kept as a slot only by the circomkit build)
+          table[slot] = B3W_ENTRY(B3W_A_ONE, 31, B3W_MODE_BIT);
+          continue;
+        }
         if (!atom_lds(c.kind, run.atom, &word, &width) || (int)bit >= width || width == 256) {
           snprintf(msg, sizeof msg, "layout: bit %u of atom %u not expressible", bit, run.atom);
           err = msg; return false;
