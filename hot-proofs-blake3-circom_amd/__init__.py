@@ -18,6 +18,13 @@ import numpy as np
 
 from . import workloads  # noqa: F401
 
+
+def __getattr__(name):
+    if name == "sharding":          # imports torch.distributed: load on demand
+        import importlib
+        return importlib.import_module(__name__ + ".sharding")
+    raise AttributeError(name)
+
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(PKG_DIR, "libb3wit.so")
 

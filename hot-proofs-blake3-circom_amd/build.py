@@ -58,8 +58,8 @@ def build_napi(force=False):
         print("node_api.h not found; skipping N-API addon", file=sys.stderr)
         return None
     if force or _newer(NAPI, [src, os.path.join(ROOT, "include", "b3wit.h")]):
-        _run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-I", inc, "-I", os.path.join(ROOT, "include"),
-              "-o", NAPI, src, "-ldl"])
+        _run(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-DNODE_GYP_MODULE_NAME=b3wit_napi", "-I", inc,
+              "-I", os.path.join(ROOT, "include"), "-o", NAPI, src, "-ldl"])
     return NAPI
 
 

@@ -1,0 +1,308 @@
+// b3wit_napi.cc — Node.js N-API addon over the C-ABI of libb3wit.so (include/b3wit.h).
+// Thin marshalling only: every function below forwards to one b3w_* entry point.  The JS shim
+// js/witness_calculator.js builds the reference's `builder -> WitnessCalculator` surface
+// (blake3_nova_js/witness_calculator.js) on top of it.
+//
+// Build (no node-gyp needed; headers ship in /usr/include/node):
+//   g++ -O2 -std=c++17 -fPIC -shared -I/usr/include/node -Iinclude -o b3wit_napi.node b3wit_napi.cc -ldl
+// libb3wit.so is dlopen'ed from the package directory (one level above this file) on first use.
+#include <dlfcn.h>
+#include <node_api.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "b3wit.h"
+
+namespace {
+
+struct Api {
+  void *so = nullptr;
+  decltype(&b3w_abi_version) abi_version;
+  decltype(&b3w_identify_wasm) identify_wasm;
+  decltype(&b3w_create) create;
+  decltype(&b3w_destroy) destroy;
+  decltype(&b3w_info) info;
+  decltype(&b3w_input_signal_size) input_signal_size;
+  decltype(&b3w_calc_witness) calc_witness;
+  decltype(&b3w_write_wtns_header) write_wtns_header;
+  decltype(&b3w_last_error) last_error;
+  decltype(&b3w_public_words) public_words;
+  decltype(&b3w_batch_alloc) batch_alloc;
+  decltype(&b3w_batch_free) batch_free;
+  decltype(&b3w_batch_run) batch_run;
+  decltype(&b3w_batch_outputs) batch_outputs;
+  decltype(&b3w_batch_fetch) batch_fetch;
+  std::string err;
+} api;
+
+bool load_api() {
+  if (api.so) return true;
+  Dl_info di;
+  std::string dir = ".";
+  if (dladdr((void *)&load_api, &di) && di.dli_fname) {
+    dir = di.dli_fname;
+    size_t p = dir.rfind('/');
+    dir = p == std::string::npos ? "." : dir.substr(0, p);
+  }
+  const char *env = getenv("B3WIT_LIB");
+  const std::string path = env ? env : dir + "/../libb3wit.so";
+  void *so = dlopen(path.c_str(), RTLD_NOW | RTLD_LOCAL);
+  if (!so) { api.err = std::string("cannot load ") + path + ": " + dlerror(); return false; }
+#define SYM(name)                                                                     \
+  api.name = (decltype(api.name))dlsym(so, "b3w_" #name);                             \
+  if (!api.name) { api.err = "libb3wit.so lacks b3w_" #name; dlclose(so); return false; }
+  SYM(abi_version) SYM(identify_wasm) SYM(create) SYM(destroy) SYM(info) SYM(input_signal_size) SYM(calc_witness)
+  SYM(write_wtns_header) SYM(last_error) SYM(public_words) SYM(batch_alloc) SYM(batch_free) SYM(batch_run)
+  SYM(batch_outputs) SYM(batch_fetch)
+#undef SYM
+  api.so = so;
+  return true;
+}
+
+struct Handle {
+  b3w_ctx *ctx = nullptr;
+  b3w_batch *batch = nullptr;
+  uint32_t batch_cap = 0;
+};
+
+#define NAPI_OK(call)                                                   \
+  do {                                                                  \
+    if ((call) != napi_ok) {                                            \
+      napi_throw_error(env, nullptr, "b3wit_napi: N-API call failed: " #call); \
+      return nullptr;                                                   \
+    }                                                                   \
+  } while (0)
+
+napi_value throw_status(napi_env env, Handle *h, int32_t rc, const char *what) {
+  char msg[640], tail[512] = "";
+  if (h && h->ctx) api.last_error(h->ctx, tail, sizeof tail);
+  snprintf(msg, sizeof msg, "%s", tail[0] ? tail : what);
+  napi_value err, code, m;
+  napi_create_string_utf8(env, msg, NAPI_AUTO_LENGTH, &m);
+  napi_create_error(env, nullptr, m, &err);
+  napi_create_int32(env, rc, &code);
+  napi_set_named_property(env, err, "status", code);
+  napi_throw(env, err);
+  return nullptr;
+}
+
+Handle *get_handle(napi_env env, napi_value v) {
+  void *p = nullptr;
+  if (napi_get_value_external(env, v, &p) != napi_ok || !p) { napi_throw_type_error(env, nullptr, "expected a b3wit handle"); return nullptr; }
+  return (Handle *)p;
+}
+
+void finalize_handle(napi_env, void *data, void *) {
+  Handle *h = (Handle *)data;
+  if (h->batch) api.batch_free(h->batch);
+  if (h->ctx) api.destroy(h->ctx);
+  delete h;
+}
+
+// identifyWasm(Buffer|TypedArray|ArrayBuffer) -> circuit id or -1
+napi_value IdentifyWasm(napi_env env, napi_callback_info info) {
+  size_t argc = 1; napi_value argv[1];
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+  if (!load_api()) { napi_throw_error(env, nullptr, api.err.c_str()); return nullptr; }
+  void *data = nullptr; size_t len = 0;
+  bool is = false;
+  napi_is_buffer(env, argv[0], &is);
+  if (is) NAPI_OK(napi_get_buffer_info(env, argv[0], &data, &len));
+  else {
+    napi_is_typedarray(env, argv[0], &is);
+    if (is) {
+      napi_typedarray_type t; napi_value ab; size_t off;
+      NAPI_OK(napi_get_typedarray_info(env, argv[0], &t, &len, &data, &ab, &off));
+    } else {
+      napi_is_arraybuffer(env, argv[0], &is);
+      if (!is) { napi_throw_type_error(env, nullptr, "identifyWasm: expected Buffer / Uint8Array / ArrayBuffer"); return nullptr; }
+      NAPI_OK(napi_get_arraybuffer_info(env, argv[0], &data, &len));
+    }
+  }
+  napi_value out;
+  NAPI_OK(napi_create_int32(env, api.identify_wasm((const uint8_t *)data, len), &out));
+  return out;
+}
+
+// create(circuitId, device) -> handle
+napi_value Create(napi_env env, napi_callback_info info) {
+  size_t argc = 2; napi_value argv[2];
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+  if (!load_api()) { napi_throw_error(env, nullptr, api.err.c_str()); return nullptr; }
+  int32_t circuit = -1, device = 0;
+  NAPI_OK(napi_get_value_int32(env, argv[0], &circuit));
+  if (argc > 1) napi_get_value_int32(env, argv[1], &device);
+  Handle *h = new Handle;
+  const int32_t rc = api.create(circuit, device, &h->ctx);
+  if (rc != B3W_OK) {
+    delete h;
+    return throw_status(env, nullptr, rc, rc == B3W_E_NO_DEVICE
+        ? "b3wit: no HIP device available (this addon has no CPU path)" : "b3wit: b3w_create failed");
+  }
+  napi_value out;
+  NAPI_OK(napi_create_external(env, h, finalize_handle, nullptr, &out));
+  return out;
+}
+
+// info(handle) -> { n32, prime (BigInt), witnessSize, inputSize, version:[maj,min,patch], publicWords }
+napi_value Info(napi_env env, napi_callback_info info) {
+  size_t argc = 1; napi_value argv[1];
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+  Handle *h = get_handle(env, argv[0]);
+  if (!h) return nullptr;
+  uint32_t n32, nwit, nin, ver[3];
+  uint64_t prime[4];
+  api.info(h->ctx, &n32, (uint8_t *)prime, &nwit, &nin, ver);
+  napi_value o, v;
+  NAPI_OK(napi_create_object(env, &o));
+  napi_create_uint32(env, n32, &v); napi_set_named_property(env, o, "n32", v);
+  napi_create_bigint_words(env, 0, 4, prime, &v); napi_set_named_property(env, o, "prime", v);
+  napi_create_uint32(env, nwit, &v); napi_set_named_property(env, o, "witnessSize", v);
+  napi_create_uint32(env, nin, &v); napi_set_named_property(env, o, "inputSize", v);
+  napi_create_uint32(env, api.public_words(h->ctx), &v); napi_set_named_property(env, o, "publicWords", v);
+  napi_value arr;
+  napi_create_array_with_length(env, 3, &arr);
+  for (int i = 0; i < 3; i++) { napi_create_uint32(env, ver[i], &v); napi_set_element(env, arr, i, v); }
+  napi_set_named_property(env, o, "version", arr);
+  return o;
+}
+
+// inputSignalSize(handle, hMSB, hLSB) — the (hMSB,hLSB) pair the reference passes to getInputSignalSize
+napi_value InputSignalSize(napi_env env, napi_callback_info info) {
+  size_t argc = 3; napi_value argv[3];
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+  Handle *h = get_handle(env, argv[0]);
+  if (!h) return nullptr;
+  uint32_t hi = 0, lo = 0;
+  NAPI_OK(napi_get_value_uint32(env, argv[1], &hi));
+  NAPI_OK(napi_get_value_uint32(env, argv[2], &lo));
+  napi_value out;
+  NAPI_OK(napi_create_int32(env, api.input_signal_size(h->ctx, ((uint64_t)hi << 32) | lo), &out));
+  return out;
+}
+
+// calcWitness(handle, hashes: Uint32Array [hMSB,hLSB]*, counts: Uint32Array, values: Uint8Array(32*sum)) -> Uint8Array body
+napi_value CalcWitness(napi_env env, napi_callback_info info) {
+  size_t argc = 4; napi_value argv[4];
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+  Handle *h = get_handle(env, argv[0]);
+  if (!h) return nullptr;
+  napi_typedarray_type t; napi_value ab; size_t off;
+  void *ph, *pc, *pv; size_t nh, nc, nv;
+  NAPI_OK(napi_get_typedarray_info(env, argv[1], &t, &nh, &ph, &ab, &off));
+  if (t != napi_uint32_array) { napi_throw_type_error(env, nullptr, "hashes: Uint32Array"); return nullptr; }
+  NAPI_OK(napi_get_typedarray_info(env, argv[2], &t, &nc, &pc, &ab, &off));
+  if (t != napi_uint32_array || nh != 2 * nc) { napi_throw_type_error(env, nullptr, "counts: Uint32Array, hashes twice as long"); return nullptr; }
+  NAPI_OK(napi_get_typedarray_info(env, argv[3], &t, &nv, &pv, &ab, &off));
+  if (t != napi_uint8_array) { napi_throw_type_error(env, nullptr, "values: Uint8Array"); return nullptr; }
+  std::vector<uint64_t> hashes(nc);
+  uint64_t total = 0;
+  for (size_t i = 0; i < nc; i++) {
+    hashes[i] = ((uint64_t)((uint32_t *)ph)[2 * i] << 32) | ((uint32_t *)ph)[2 * i + 1];
+    total += ((uint32_t *)pc)[i];
+  }
+  if (nv < 32 * total) { napi_throw_range_error(env, nullptr, "values shorter than 32*sum(counts)"); return nullptr; }
+  uint32_t nwit = 0;
+  api.info(h->ctx, nullptr, nullptr, &nwit, nullptr, nullptr);
+  void *body = nullptr; napi_value abuf, out;
+  NAPI_OK(napi_create_arraybuffer(env, (size_t)nwit * 32, &body, &abuf));
+  const int32_t rc = api.calc_witness(h->ctx, hashes.data(), (const uint32_t *)pc, (const uint8_t *)pv, (uint32_t)nc, (uint8_t *)body);
+  if (rc != B3W_OK) return throw_status(env, h, rc, "b3w_calc_witness failed");
+  NAPI_OK(napi_create_typedarray(env, napi_uint8_array, (size_t)nwit * 32, abuf, 0, &out));
+  return out;
+}
+
+napi_value WtnsHeader(napi_env env, napi_callback_info info) {
+  size_t argc = 1; napi_value argv[1];
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+  Handle *h = get_handle(env, argv[0]);
+  if (!h) return nullptr;
+  void *p = nullptr; napi_value abuf, out;
+  NAPI_OK(napi_create_arraybuffer(env, 76, &p, &abuf));
+  api.write_wtns_header(h->ctx, (uint8_t *)p);
+  NAPI_OK(napi_create_typedarray(env, napi_uint8_array, 76, abuf, 0, &out));
+  return out;
+}
+
+// batchRun(handle, records: Uint32Array(n*inputSize)) -> { n, publicOutputs: Uint32Array, status: Int32Array }
+napi_value BatchRun(napi_env env, napi_callback_info info) {
+  size_t argc = 2; napi_value argv[2];
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+  Handle *h = get_handle(env, argv[0]);
+  if (!h) return nullptr;
+  napi_typedarray_type t; napi_value ab; size_t off, len; void *p;
+  NAPI_OK(napi_get_typedarray_info(env, argv[1], &t, &len, &p, &ab, &off));
+  if (t != napi_uint32_array) { napi_throw_type_error(env, nullptr, "records: Uint32Array"); return nullptr; }
+  uint32_t nin = 0;
+  api.info(h->ctx, nullptr, nullptr, nullptr, &nin, nullptr);
+  if (len == 0 || len % nin) { napi_throw_range_error(env, nullptr, "records length must be a positive multiple of the input size"); return nullptr; }
+  const uint32_t n = (uint32_t)(len / nin);
+  if (!h->batch || h->batch_cap < n) {
+    if (h->batch) { api.batch_free(h->batch); h->batch = nullptr; }
+    const int32_t rc = api.batch_alloc(h->ctx, n, 0, &h->batch);
+    if (rc != B3W_OK) return throw_status(env, h, rc, "b3w_batch_alloc failed");
+    h->batch_cap = n;
+  }
+  int32_t rc = api.batch_run(h->batch, (const uint32_t *)p, n, nullptr);
+  if (rc != B3W_OK) return throw_status(env, h, rc, "b3w_batch_run failed");
+  const uint32_t npub = api.public_words(h->ctx);
+  void *pp, *ps; napi_value abp, abs_, o, v;
+  NAPI_OK(napi_create_arraybuffer(env, (size_t)n * npub * 4, &pp, &abp));
+  NAPI_OK(napi_create_arraybuffer(env, (size_t)n * 4, &ps, &abs_));
+  rc = api.batch_outputs(h->batch, (uint32_t *)pp, (int32_t *)ps);
+  if (rc != B3W_OK) return throw_status(env, h, rc, "b3w_batch_outputs failed");
+  NAPI_OK(napi_create_object(env, &o));
+  napi_create_uint32(env, n, &v); napi_set_named_property(env, o, "n", v);
+  napi_create_typedarray(env, napi_uint32_array, (size_t)n * npub, abp, 0, &v); napi_set_named_property(env, o, "publicOutputs", v);
+  napi_create_typedarray(env, napi_int32_array, n, abs_, 0, &v); napi_set_named_property(env, o, "status", v);
+  return o;
+}
+
+// batchFetch(handle, index) -> Uint8Array body of witness `index` of the last batchRun
+napi_value BatchFetch(napi_env env, napi_callback_info info) {
+  size_t argc = 2; napi_value argv[2];
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+  Handle *h = get_handle(env, argv[0]);
+  if (!h) return nullptr;
+  uint32_t idx = 0, nwit = 0;
+  NAPI_OK(napi_get_value_uint32(env, argv[1], &idx));
+  if (!h->batch) { napi_throw_error(env, nullptr, "batchFetch before batchRun"); return nullptr; }
+  api.info(h->ctx, nullptr, nullptr, &nwit, nullptr, nullptr);
+  void *body; napi_value abuf, out;
+  NAPI_OK(napi_create_arraybuffer(env, (size_t)nwit * 32, &body, &abuf));
+  const int32_t rc = api.batch_fetch(h->batch, idx, (uint8_t *)body);
+  if (rc != B3W_OK) return throw_status(env, h, rc, "b3w_batch_fetch failed");
+  NAPI_OK(napi_create_typedarray(env, napi_uint8_array, (size_t)nwit * 32, abuf, 0, &out));
+  return out;
+}
+
+napi_value AbiVersion(napi_env env, napi_callback_info) {
+  if (!load_api()) { napi_throw_error(env, nullptr, api.err.c_str()); return nullptr; }
+  napi_value out;
+  napi_create_uint32(env, api.abi_version(), &out);
+  return out;
+}
+
+napi_value Init(napi_env env, napi_value exports) {
+  const napi_property_descriptor props[] = {
+      {"abiVersion", nullptr, AbiVersion, nullptr, nullptr, nullptr, napi_default, nullptr},
+      {"identifyWasm", nullptr, IdentifyWasm, nullptr, nullptr, nullptr, napi_default, nullptr},
+      {"create", nullptr, Create, nullptr, nullptr, nullptr, napi_default, nullptr},
+      {"info", nullptr, Info, nullptr, nullptr, nullptr, napi_default, nullptr},
+      {"inputSignalSize", nullptr, InputSignalSize, nullptr, nullptr, nullptr, napi_default, nullptr},
+      {"calcWitness", nullptr, CalcWitness, nullptr, nullptr, nullptr, napi_default, nullptr},
+      {"wtnsHeader", nullptr, WtnsHeader, nullptr, nullptr, nullptr, napi_default, nullptr},
+      {"batchRun", nullptr, BatchRun, nullptr, nullptr, nullptr, napi_default, nullptr},
+      {"batchFetch", nullptr, BatchFetch, nullptr, nullptr, nullptr, napi_default, nullptr},
+  };
+  napi_define_properties(env, exports, sizeof props / sizeof props[0], props);
+  return exports;
+}
+
+}  // namespace
+
+NAPI_MODULE(NODE_GYP_MODULE_NAME, Init)

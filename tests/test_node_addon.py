@@ -1,0 +1,128 @@
+"""The Node.js side of the drop-in boundary: N-API addon + witness_calculator.js shim
+(hot-proofs-blake3-circom_amd/js).  CPU tests: the addon loads, identifies the reference's circuit
+binaries and refuses to compute without a device.  GPU tests: the reference's CLI flow
+(generate_witness.js -> calculateWTNSBin) reproduces the golden .wtns files byte for byte."""
+import json, os, shutil, subprocess
+import pytest
+import b3w_testlib as T
+
+JS = os.path.join(T.PKG_DIR, "js")
+NODE = shutil.which("node")
+needs_node = pytest.mark.skipif(NODE is None, reason="node not installed")
+REF = "/root/reference"
+
+
+def _node(script, *args, env=None):
+    e = dict(os.environ)
+    e.update(env or {})
+    return subprocess.run([NODE, "-e", script, *args], capture_output=True, text=True, cwd=T.ROOT, env=e, timeout=300)
+
+
+@needs_node
+def test_addon_loads_and_refuses_without_device():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    assert os.path.exists(os.path.join(JS, "b3wit_napi.node")), "run __graft_entry__.build()"
+    r = _node("""
+      const b = require('./hot-proofs-blake3-circom_amd/js/witness_calculator.js');
+      const nat = require('./hot-proofs-blake3-circom_amd/js/b3wit_napi.node');
+      console.log('abi', nat.abiVersion() >> 16);
+      b('compression').then(() => console.log('UNEXPECTED')).catch(e => console.log('rejected', e.status, e.message));
+      b(Buffer.from('not a circuit')).catch(e => console.log('junk', e.message));
+    """)
+    assert r.returncode == 0, r.stderr
+    assert "abi 1" in r.stdout and "rejected 101" in r.stdout and "no CPU path" in r.stdout
+    assert "junk b3wit: not one of the reference's committed BLAKE3 circuits" in r.stdout and "UNEXPECTED" not in r.stdout
+
+
+@needs_node
+def test_addon_identifies_reference_binaries_and_module_swap():
+    if not os.path.isdir(REF):
+        pytest.skip("reference checkout not present (GPU box)")
+    r = _node("""
+      const nat = require('./hot-proofs-blake3-circom_amd/js/b3wit_napi.node');
+      const fs = require('fs');
+      for (const f of process.argv.slice(1)) console.log(nat.identifyWasm(fs.readFileSync(f)));
+    """, *[os.path.join(REF, "build", p) for p in (
+        "blake3_compression/blake3_compression_js/blake3_compression.wasm", "blake3_nova_js/blake3_nova.wasm",
+        "blake3_nova_pasta_js/blake3_nova_pasta.wasm", "blake3_nova/blake3_nova_js/blake3_nova.wasm")])
+    assert r.stdout.split() == ["0", "1", "2", "3"], r.stderr
+    # the reference's own generate_witness.js, unchanged, resolves its require("./witness_calculator.js")
+    # to the shim under `node -r register.js` (here without a GPU it must fail loudly, not fall back to WASM)
+    import torch
+    if torch.cuda.is_available():
+        return
+    inp = os.path.join(T.ROOT, "gpurun_out", "_swap_in.json")
+    os.makedirs(os.path.dirname(inp), exist_ok=True)
+    json.dump(T.golden("compression")["cases"][0]["input"], open(inp, "w"))
+    gw = os.path.join(REF, "build/blake3_compression/blake3_compression_js/generate_witness.js")
+    r = subprocess.run([NODE, "-r", os.path.join(JS, "register.js"), gw,
+                        os.path.join(REF, "build/blake3_compression/blake3_compression_js/blake3_compression.wasm"),
+                        inp, inp + ".wtns"], capture_output=True, text=True, timeout=120)
+    assert "no HIP device" in (r.stderr + r.stdout)
+    assert not os.path.exists(inp + ".wtns")
+
+
+@needs_node
+@pytest.mark.gpu
+@pytest.mark.parametrize("circuit", ["compression", "nova_vesta", "nova_bn254"])
+def test_generate_witness_cli_reproduces_goldens(circuit, tmp_path):
+    g = T.golden(circuit)
+    names = [f for f in os.listdir(T.GOLD) if f.startswith(circuit + ".") and f.endswith(".wtns.gz")]
+    for f in names:
+        case = next(c for c in g["cases"] if c["name"] == f[len(circuit) + 1:-len(".wtns.gz")])
+        inp, out = tmp_path / "in.json", tmp_path / "out.wtns"
+        inp.write_text(json.dumps(case["input"]))
+        r = subprocess.run([NODE, os.path.join(JS, "generate_witness.js"), circuit, str(inp), str(out)],
+                           capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr
+        assert out.read_bytes() == T.golden_image(f)
+
+
+@needs_node
+@pytest.mark.gpu
+def test_js_surface_errors_and_batch(tmp_path):
+    g = T.golden("compression")
+    cases = [c for c in g["cases"] if "error" not in c and T.is_canonical_u32("compression", c["input"])][:8]
+    (tmp_path / "cases.json").write_text(json.dumps(cases))
+    r = _node("""
+      const builder = require('./hot-proofs-blake3-circom_amd/js/witness_calculator.js');
+      const crypto = require('crypto'), fs = require('fs');
+      (async () => {
+        const cases = JSON.parse(fs.readFileSync(process.argv[1]));
+        const wc = await builder('compression');
+        const out = {fields: [wc.version, wc.n32, wc.witnessSize, wc.prime.toString(), wc.circom_version()], sha: [], first16: null, errs: []};
+        for (const c of cases) out.sha.push(crypto.createHash('sha256').update(await wc.calculateWTNSBin(c.input, 0)).digest('hex'));
+        const w = await wc.calculateWitness(cases[0].input, 0);
+        out.first16 = w.slice(0, 16).map(x => x.toString()); out.len = w.length;
+        out.bin = crypto.createHash('sha256').update(await wc.calculateBinWitness(cases[0].input, 0)).digest('hex');
+        const base = cases[0].input;
+        const tryErr = async (inp) => { try { await wc.calculateWitness(inp); out.errs.push('NOERR'); } catch (e) { out.errs.push(e.message); } };
+        let i = Object.assign({}, base); delete i.b; await tryErr(i);
+        i = Object.assign({}, base, {m: base.m.slice(0, 15)}); await tryErr(i);
+        i = Object.assign({}, base, {m: base.m.concat([1])}); await tryErr(i);
+        i = Object.assign({}, base, {zz: 1}); await tryErr(i);
+        i = Object.assign({}, base, {m: ['-1'].concat(base.m.slice(1))}); await tryErr(i);
+        // batch extension on packed records
+        const recs = new Uint32Array(28 * cases.length);
+        cases.forEach((c, k) => { const v = [].concat(c.input.h, c.input.m, c.input.t, [c.input.b, c.input.d]); v.forEach((x, j) => recs[28 * k + j] = Number(x)); });
+        const b = await wc.calculateWitnessBatch(recs);
+        out.batch = {n: b.n, status: Array.from(b.status), pub0: Array.from(b.publicOutputs.slice(0, 16)).map(String),
+                     body3: crypto.createHash('sha256').update(b.fetch(3)).digest('hex')};
+        console.log(JSON.stringify(out));
+      })().catch(e => { console.error(e); process.exit(1); });
+    """, str(tmp_path / "cases.json"))
+    assert r.returncode == 0, r.stderr
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out["fields"] == [2, 8, 24093, str(T.BN254_R), 2]
+    assert out["sha"] == [c["wtns_sha256"] for c in cases]
+    assert out["len"] == 24093 and out["first16"] == cases[0]["first16"] and out["bin"] == cases[0]["body_sha256"]
+    assert out["errs"][0] == "Not all inputs have been set. Only 27 out of 28"
+    assert out["errs"][1] == "Not enough values for input signal m\n"
+    assert out["errs"][2] == "Too many values for input signal m\n"
+    assert out["errs"][3] == "Too many values for input signal zz\n"
+    assert "fast-path domain" in out["errs"][4]
+    assert out["batch"]["n"] == 8 and out["batch"]["status"] == [0] * 8
+    assert out["batch"]["pub0"] == [str(x) for x in cases[0]["first16"][1:]] + [out["batch"]["pub0"][15]]
+    assert out["batch"]["body3"] == cases[3]["body_sha256"]
