@@ -56,6 +56,7 @@ enum {
 //   [1184 + 8j, +8)   wide atom j (256-bit).  O2 builds keep only the 67 IsZero inverses:
 //                     j = 0..2 root/e0/e1 inv, 3..66 eq_inv[0..63];   O1 keeps all 199 in
 //                     numbering order.
+#define B3W_LDS_OKWORD 45   // unused pad word: 1 = witness valid (two-kernel path)
 #define B3W_LDS_HG 48
 #define B3W_LDS_NV 944
 #define B3W_LDS_CHUNK_IDX 1182

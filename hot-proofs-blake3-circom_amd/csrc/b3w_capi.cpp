@@ -229,6 +229,8 @@ struct b3w_ctx {
   std::vector<InputSignal> inputs;
   uint32_t *d_table = nullptr;
   void *d_aux = nullptr;
+  uint32_t *d_scratch = nullptr;      // TRACE images of the two-kernel path
+  uint32_t scratch_cap = 0;
   // single-witness scratch
   uint32_t *d_rec1 = nullptr;
   uint8_t *d_body1 = nullptr;
@@ -315,6 +317,11 @@ int32_t b3w_create(int32_t circuit, int32_t device, b3w_ctx **out) {
   if (e != hipSuccess) { b3w_destroy(ctx); return B3W_E_HIP; }
   const char *v = getenv("B3W_VARIANT");
   if (v) ctx->variant = atoi(v);
+  if (ctx->variant >= B3W_VARIANT_SWEEP) {
+    ctx->scratch_cap = B3W_SWEEP_CHUNK;
+    e = hipMalloc((void **)&ctx->d_scratch, (size_t)ctx->scratch_cap * d.lds_words * 4);
+    if (e != hipSuccess) { b3w_destroy(ctx); return B3W_E_HIP; }
+  }
   *out = ctx;
   return B3W_OK;
 }
@@ -323,6 +330,7 @@ void b3w_destroy(b3w_ctx *ctx) {
   if (!ctx) return;
   if (ctx->d_table) (void)hipFree(ctx->d_table);
   if (ctx->d_aux) (void)hipFree(ctx->d_aux);
+  if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
   if (ctx->d_rec1) (void)hipFree(ctx->d_rec1);
   if (ctx->d_body1) (void)hipFree(ctx->d_body1);
   if (ctx->d_status1) (void)hipFree(ctx->d_status1);
@@ -376,7 +384,7 @@ int32_t b3w_batch_run_device(b3w_ctx *ctx, const uint32_t *d_records, uint32_t n
   if (pitch == 0) pitch = body;
   if (pitch < body || (pitch & 31)) { ctx->last_error = "pitch must be >= witness_size*32 and a multiple of 32"; return B3W_E_BAD_ARGUMENT; }
   int rc = b3w_launch_batch(ctx->desc.kind, ctx->variant, d_records, n, d_bodies, pitch, ctx->d_table, ctx->desc.nwit,
-                            d_public, d_status, ctx->d_aux, (hipStream_t)stream);
+                            d_public, d_status, ctx->d_aux, ctx->d_scratch, ctx->scratch_cap, (hipStream_t)stream);
   if (rc == 0) return B3W_OK;
   if (rc < 0) { ctx->last_error = "no kernel for this circuit kind / variant"; return B3W_E_BAD_ARGUMENT; }
   return hip_fail(ctx, (hipError_t)rc, "kernel launch");

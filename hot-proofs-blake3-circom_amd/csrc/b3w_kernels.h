@@ -6,6 +6,12 @@
 // number of tuning variants of the compression kernel (witnesses per wave, store flavour)
 #define B3W_NUM_VARIANTS 8
 
+// variants >= B3W_VARIANT_SWEEP use the two-kernel path (TRACE -> HBM scratch -> linear SWEEP of the output)
+#define B3W_VARIANT_SWEEP 100
+#define B3W_SWEEP_GRID 256       // one 256-thread workgroup per CU, tile = 4 KiB: the runtime fill kernel's shape
+#define B3W_SWEEP_CHUNK 8192     // witnesses per TRACE+SWEEP pair (bounds the scratch)
+
 extern "C" int b3w_launch_batch(int kind, int variant, const uint32_t *d_recs, uint32_t n, uint8_t *d_out,
                                 uint64_t pitch, const uint32_t *d_table, uint32_t nwit, uint32_t *d_pub,
-                                int32_t *d_status, const void *d_aux, hipStream_t stream);
+                                int32_t *d_status, const void *d_aux, uint32_t *d_scratch, uint32_t scratch_cap,
+                                hipStream_t stream);

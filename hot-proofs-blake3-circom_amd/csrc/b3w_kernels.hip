@@ -23,6 +23,8 @@
 
 namespace {
 
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
 __device__ __forceinline__ uint32_t rotr32(uint32_t x, int r) { return __builtin_rotateright32(x, r); }
 
 // lane j of every quad reads lane P[j] of its quad (DPP quad_perm, no LDS traffic)
@@ -112,8 +114,6 @@ __device__ __forceinline__ void trace_compression(uint32_t *L, int col, uint32_t
   if (pub) { pub[col] = o0; pub[4 + col] = o1; pub[8 + col] = o2; pub[12 + col] = o3; }
 }
 
-typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
-
 template <bool NT>
 __device__ __forceinline__ void store16(uint8_t *p, uint4 v) {
   const u32x4 x = {v.x, v.y, v.z, v.w};
@@ -187,8 +187,151 @@ __device__ __forceinline__ void expand(const uint32_t *lds, const uint32_t *__re
   }
 }
 
+// ------------------------------------------------------------------ two-kernel ("sweep") path
+// The fused kernels above leave every wave streaming its own bodies: thousands of independent
+// write streams, which HBM serves at ~5.45 TB/s on MI355X (tools/ubench/store_ceiling.hip measures
+// the bare store pattern).  A linear sweep in which workgroup b of exactly 256 (one per CU) writes
+// the 4 KiB tiles b, b+256, b+512, ... of the output — the access shape of the runtime's own fill
+// kernel — reaches 6.5 TB/s.  The sweep path therefore splits the work: a TRACE kernel parks the
+// LDS images in an HBM scratch (3.7-11 KB per witness, ~1 % of the body), and b3w_sweep_kernel
+// walks the output in that order, staging the one or two images a tile needs through LDS.
+
+// TRACE kernel epilogue: copy this wave's images to the scratch, word 45 = 1 if the witness is valid.
+template <int W, int WORDS>
+__device__ __forceinline__ void dump_images(uint32_t *lds, uint32_t *__restrict__ scratch, uint32_t wit0, uint32_t n,
+                                            const uint32_t *okf) {
+  const int lane = threadIdx.x;
+  if (lane < W) lds[lane * WORDS + B3W_LDS_OKWORD] = okf ? okf[lane] : 1u;
+  __syncthreads();
+#pragma unroll 1
+  for (int w = 0; w < W; ++w) {
+    if (wit0 + w >= n) break;
+    const uint4 *src = reinterpret_cast<const uint4 *>(lds + w * WORDS);
+    uint4 *dst = reinterpret_cast<uint4 *>(scratch + (uint64_t)(wit0 + w) * WORDS);
+    for (int i = lane; i < WORDS / 4; i += 64) dst[i] = src[i];
+  }
+}
+
+template <int PIECES>
+struct SweepRegs { u32x4 a[PIECES], b[PIECES]; };   // one thread's 16-byte pieces of a tile's two images
+
+struct SweepPos {          // tile t of the sweep: first body it touches and the byte offset inside it
+  uint64_t t;
+  int64_t rem;             // (t*4096 - lead) - w_lo*pitch; negative only inside the lead-in of tile 0
+  uint32_t w_lo;
+};
+
+template <bool WIDE, int TW, int P>
+__global__ __launch_bounds__(256, 1) void b3w_sweep_kernel(const uint32_t *__restrict__ scratch, uint32_t n,
+                                                           uint8_t *__restrict__ out_base, uint32_t lead, uint64_t pitch,
+                                                           const uint32_t *__restrict__ table, uint32_t nwit) {
+  constexpr int PIECES = (TW / 4 + 255) / 256;           // 16-byte pieces per thread per image
+  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+  const uint32_t ntab = (nwit + 3) & ~3u;
+  uint32_t *tab = smem;                                  // the whole slot table
+  uint32_t *ring = smem + ntab;                          // [2 slots][2 images][TW]
+  const uint32_t tid = threadIdx.x, G = gridDim.x;
+  for (uint32_t i = tid; i < nwit; i += 256) tab[i] = table[i];
+  const uint64_t body = 32ull * nwit, total = (uint64_t)lead + (uint64_t)n * pitch;
+  const uint64_t ntiles = (total + 4095) >> 12;
+  const uint64_t stride = (uint64_t)G * 4096;
+  const uint32_t dq = (uint32_t)(stride / pitch);
+  const uint64_t dr = stride % pitch;
+  auto start = [&](uint64_t t) {
+    SweepPos p;
+    p.t = t;
+    const int64_t pos = (int64_t)(t * 4096) - (int64_t)lead;
+    if (pos < 0) { p.w_lo = 0; p.rem = pos; }
+    else { p.w_lo = (uint32_t)((uint64_t)pos / pitch); p.rem = (int64_t)((uint64_t)pos % pitch); }
+    return p;
+  };
+  auto advance = [&](SweepPos &p) {
+    p.t += G; p.w_lo += dq; p.rem += (int64_t)dr;
+    if (p.rem >= (int64_t)pitch) { p.rem -= (int64_t)pitch; p.w_lo++; }
+  };
+  // does tile p also touch body w_lo+1 ?
+  auto straddles = [&](const SweepPos &p) { return p.rem + 4095 >= (int64_t)pitch && p.w_lo + 1 < n; };
+  // Unconditional loads (clamped addresses) so the register sets stay in VGPRs: a tile past the end
+  // re-reads image 0, a non-straddling tile reads its one image twice (second read hits L1/L2).
+  auto issue = [&](const SweepPos &p, SweepRegs<PIECES> &r) {
+    const bool live = p.t < ntiles && p.w_lo < n;
+    const uint32_t w0 = live ? p.w_lo : 0u;
+    const uint32_t w1 = (live && straddles(p)) ? p.w_lo + 1 : w0;
+    const u32x4 *g0 = reinterpret_cast<const u32x4 *>(scratch + (uint64_t)w0 * TW);
+    const u32x4 *g1 = reinterpret_cast<const u32x4 *>(scratch + (uint64_t)w1 * TW);
+#pragma unroll
+    for (int q = 0; q < PIECES; ++q) {
+      const uint32_t i = q * 256 + tid, ic = i < TW / 4 ? i : TW / 4 - 1;
+      r.a[q] = g0[ic];
+      r.b[q] = g1[ic];
+    }
+  };
+  auto park = [&](const SweepRegs<PIECES> &r, int slot) {
+    u32x4 *l0 = reinterpret_cast<u32x4 *>(ring + (slot * 2 + 0) * TW);
+    u32x4 *l1 = reinterpret_cast<u32x4 *>(ring + (slot * 2 + 1) * TW);
+#pragma unroll
+    for (int q = 0; q < PIECES; ++q) {
+      const uint32_t i = q * 256 + tid;
+      if (i < TW / 4) { l0[i] = r.a[q]; l1[i] = r.b[q]; }
+    }
+  };
+  auto emit = [&](const SweepPos &p, int slot) {
+    if (p.t >= ntiles) return;
+    int64_t r = p.rem + (int64_t)(tid * 16);
+    uint32_t sel = 0, w = p.w_lo;
+    if (r >= (int64_t)pitch) { r -= (int64_t)pitch; sel = 1; w++; }
+    if (r < 0 || r >= (int64_t)body || w >= n) return;
+    const uint32_t par = ((uint32_t)r >> 4) & 1u;
+    const uint32_t e = tab[(uint32_t)r >> 5];
+    const uint32_t src = e & 0xFFFu, sh = (e >> 12) & 31u, mode = (e >> 17) & 3u;
+    const uint32_t off = (WIDE && mode == B3W_MODE_W256) ? src + 4u * par : src;
+    const bool live = (par == 0) || (WIDE && mode == B3W_MODE_W256);
+    const uint32_t m0 = live ? (mode == B3W_MODE_BIT ? 1u : 0xFFFFFFFFu) : 0u;
+    const uint32_t m1 = (live && mode >= B3W_MODE_W64) ? 0xFFFFFFFFu : 0u;
+    const uint32_t m23 = (WIDE && mode == B3W_MODE_W256) ? 0xFFFFFFFFu : 0u;
+    const uint32_t *L = ring + (slot * 2 + sel) * TW;
+    if (L[B3W_LDS_OKWORD] == 0) return;                  // rejected step: body left untouched
+    uint4 v;
+    v.x = (L[off] >> sh) & m0;
+    v.y = L[off + 1] & m1;
+    if (WIDE) { v.z = L[off + 2] & m23; v.w = L[off + 3] & m23; } else { v.z = 0; v.w = 0; }
+    store16<false>(out_base + p.t * 4096 + tid * 16, v);
+  };
+
+  static_assert(P == 4, "the pipeline below is written out for four register sets");
+  SweepPos cur = start(blockIdx.x), pre = cur;
+  SweepRegs<PIECES> r0, r1, r2, r3;
+  // prologue: loads for iterations 0..3 in flight, iteration 0 parked in ring slot 0
+  issue(pre, r0); advance(pre);
+  issue(pre, r1); advance(pre);
+  issue(pre, r2); advance(pre);
+  issue(pre, r3); advance(pre);
+  park(r0, 0);
+  __syncthreads();
+  // iteration k: ring slot k&1 holds its images, RNEXT holds iteration k+1's, RCUR (iteration k's,
+  // already parked) is refilled with iteration k+4
+#define B3W_SWEEP_STEP(RCUR, RNEXT, SLOT)   \
+  {                                         \
+    SweepPos nxt = cur;                     \
+    advance(nxt);                           \
+    issue(pre, RCUR);                       \
+    advance(pre);                           \
+    park(RNEXT, (SLOT) ^ 1);                \
+    emit(cur, SLOT);                        \
+    __syncthreads();                        \
+    cur = nxt;                              \
+  }
+  while (cur.t < ntiles) {
+    B3W_SWEEP_STEP(r0, r1, 0)
+    B3W_SWEEP_STEP(r1, r2, 1)
+    B3W_SWEEP_STEP(r2, r3, 0)
+    B3W_SWEEP_STEP(r3, r0, 1)
+  }
+#undef B3W_SWEEP_STEP
+}
+
 // ------------------------------------------------------------------ compression circuit
-template <int W, bool NT>
+template <int W, bool NT, bool SWEEP>
 __global__ __launch_bounds__(64) void b3w_compression_kernel(const uint32_t *__restrict__ recs, uint32_t n,
                                                              uint8_t *__restrict__ out, uint64_t pitch,
                                                              const uint32_t *__restrict__ table, uint32_t nwit,
@@ -211,7 +354,8 @@ __global__ __launch_bounds__(64) void b3w_compression_kernel(const uint32_t *__r
     }
   }
   __syncthreads();
-  expand<W, WORDS, false, NT>(lds, table, nwit, out, pitch, wit0, n, nullptr, true);
+  if (SWEEP) dump_images<W, WORDS>(lds, reinterpret_cast<uint32_t *>(out), wit0, n, nullptr);   // out = scratch
+  else expand<W, WORDS, false, NT>(lds, table, nwit, out, pitch, wit0, n, nullptr, true);
 }
 
 
@@ -315,7 +459,7 @@ __device__ __forceinline__ void lds_put256(uint32_t *L, const U256 &v) {
   *reinterpret_cast<uint4 *>(L + 4) = make_uint4(v.l[4], v.l[5], v.l[6], v.l[7]);
 }
 
-template <int KIND, int W, bool NT>
+template <int KIND, int W, bool NT, bool SWEEP>
 __global__ __launch_bounds__(64) void b3w_nova_kernel(const uint32_t *__restrict__ recs, uint32_t n,
                                                       uint8_t *__restrict__ out, uint64_t pitch,
                                                       const uint32_t *__restrict__ table, uint32_t nwit,
@@ -468,19 +612,73 @@ __global__ __launch_bounds__(64) void b3w_nova_kernel(const uint32_t *__restrict
     pw[2 + col] = L[B3W_A_O + col];
     pw[6 + col] = L[B3W_A_O + 4 + col];
   }
-  expand<W, WORDS, true, NT>(lds, table, nwit, out, pitch, wit0, n, okf, all_ok);
+  if (SWEEP) dump_images<W, WORDS>(lds, reinterpret_cast<uint32_t *>(out), wit0, n, okf);       // out = scratch
+  else expand<W, WORDS, true, NT>(lds, table, nwit, out, pitch, wit0, n, okf, all_ok);
 }
 
 }  // namespace
 
 // ------------------------------------------------------------------ launch
+namespace {
+template <bool WIDE, int TW>
+int launch_sweep(const uint32_t *d_scratch, uint32_t n, uint8_t *d_out, uint64_t pitch, const uint32_t *d_table,
+                 uint32_t nwit, hipStream_t stream) {
+  constexpr int P = 4;
+  const uintptr_t addr = reinterpret_cast<uintptr_t>(d_out);
+  const uint32_t lead = (uint32_t)(addr & 4095);
+  const size_t smem = (((size_t)nwit + 3) & ~(size_t)3) * 4 + (size_t)4 * TW * 4 + 16;   // +16: emit reads off+1..3
+  static bool attr_done = false;                       // per instantiation
+  if (!attr_done) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&b3w_sweep_kernel<WIDE, TW, P>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
+    if (e != hipSuccess) return (int)e;
+    attr_done = true;
+  }
+  hipLaunchKernelGGL((b3w_sweep_kernel<WIDE, TW, P>), dim3(B3W_SWEEP_GRID), dim3(256), smem, stream, d_scratch, n,
+                     d_out - lead, lead, pitch, d_table, nwit);
+  return (int)hipGetLastError();
+}
+}  // namespace
+
 extern "C" int b3w_launch_batch(int kind, int variant, const uint32_t *d_recs, uint32_t n, uint8_t *d_out,
                                 uint64_t pitch, const uint32_t *d_table, uint32_t nwit, uint32_t *d_pub,
-                                int32_t *d_status, const void *d_aux, hipStream_t stream) {
+                                int32_t *d_status, const void *d_aux, uint32_t *d_scratch, uint32_t scratch_cap,
+                                hipStream_t stream) {
   if (n == 0) return 0;
+  if (variant >= B3W_VARIANT_SWEEP) {
+    // TRACE kernel -> scratch, SWEEP kernel -> bodies, in chunks of scratch_cap witnesses
+    if (!d_scratch || !scratch_cap) return -4;
+    for (uint32_t c0 = 0; c0 < n; c0 += scratch_cap) {
+      const uint32_t cn = n - c0 < scratch_cap ? n - c0 : scratch_cap;
+      uint32_t *pub_c = d_pub ? d_pub + (uint64_t)c0 * (kind == B3W_KIND_COMP ? 16 : 15) : nullptr;
+      int32_t *st_c = d_status ? d_status + c0 : nullptr;
+      uint8_t *out_c = d_out + (uint64_t)c0 * pitch;
+      int rc;
+      if (kind == B3W_KIND_COMP) {
+        const uint32_t *rc_recs = d_recs + (uint64_t)c0 * 28;
+        hipLaunchKernelGGL((b3w_compression_kernel<16, false, true>), dim3((cn + 15) / 16), dim3(64), 0, stream, rc_recs,
+                           cn, reinterpret_cast<uint8_t *>(d_scratch), pitch, d_table, nwit, pub_c, st_c);
+        rc = launch_sweep<false, B3W_LDS_WORDS_COMP>(d_scratch, cn, out_c, pitch, d_table, nwit, stream);
+      } else if (kind == B3W_KIND_NOVA_O2) {
+        const uint32_t *rc_recs = d_recs + (uint64_t)c0 * 32;
+        hipLaunchKernelGGL((b3w_nova_kernel<B3W_KIND_NOVA_O2, 4, false, true>), dim3((cn + 3) / 4), dim3(64), 0, stream,
+                           rc_recs, cn, reinterpret_cast<uint8_t *>(d_scratch), pitch, d_table, nwit, pub_c, st_c,
+                           (const uint32_t *)d_aux);
+        rc = launch_sweep<true, B3W_LDS_WORDS_NOVA_O2>(d_scratch, cn, out_c, pitch, d_table, nwit, stream);
+      } else {
+        const uint32_t *rc_recs = d_recs + (uint64_t)c0 * 32;
+        hipLaunchKernelGGL((b3w_nova_kernel<B3W_KIND_NOVA_O1, 2, false, true>), dim3((cn + 1) / 2), dim3(64), 0, stream,
+                           rc_recs, cn, reinterpret_cast<uint8_t *>(d_scratch), pitch, d_table, nwit, pub_c, st_c,
+                           (const uint32_t *)d_aux);
+        rc = launch_sweep<true, B3W_LDS_WORDS_NOVA_O1>(d_scratch, cn, out_c, pitch, d_table, nwit, stream);
+      }
+      if (rc) return rc;
+    }
+    return (int)hipGetLastError();
+  }
   if (kind == B3W_KIND_COMP) {
 #define B3W_LAUNCH_COMP(WV, NTV)                                                                         \
-  hipLaunchKernelGGL((b3w_compression_kernel<WV, NTV>), dim3((n + WV - 1) / WV), dim3(64), 0, stream,   \
+  hipLaunchKernelGGL((b3w_compression_kernel<WV, NTV, false>), dim3((n + WV - 1) / WV), dim3(64), 0, stream,   \
                      d_recs, n, d_out, pitch, d_table, nwit, d_pub, d_status)
     switch (variant) {
       case 0: B3W_LAUNCH_COMP(4, false); break;
@@ -499,7 +697,7 @@ extern "C" int b3w_launch_batch(int kind, int variant, const uint32_t *d_recs, u
   if (kind == B3W_KIND_NOVA_O2 || kind == B3W_KIND_NOVA_O1) {
     if (!d_aux) return -3;
 #define B3W_LAUNCH_NOVA(KV, WV)                                                                           \
-  hipLaunchKernelGGL((b3w_nova_kernel<KV, WV, false>), dim3((n + WV - 1) / WV), dim3(64), 0, stream,     \
+  hipLaunchKernelGGL((b3w_nova_kernel<KV, WV, false, false>), dim3((n + WV - 1) / WV), dim3(64), 0, stream,     \
                      d_recs, n, d_out, pitch, d_table, nwit, d_pub, d_status, (const uint32_t *)d_aux)
     if (kind == B3W_KIND_NOVA_O2) {
       switch (variant) {
