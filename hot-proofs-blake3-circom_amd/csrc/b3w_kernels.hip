@@ -212,8 +212,10 @@ __device__ __forceinline__ void dump_images(uint32_t *lds, uint32_t *__restrict_
   }
 }
 
-template <int PIECES>
-struct SweepRegs { u32x4 a[PIECES], b[PIECES]; };   // one thread's 16-byte pieces of a tile's two images
+// One thread's share of a sweep STEP (K tiles, 1 MiB apart): 16-byte pieces of each tile's two
+// images and the tile's slot-table word.  Native vector types: HIP's uint4 struct defeats SROA here.
+template <int PIECES, int K>
+struct SweepRegs { u32x4 a[K][PIECES], b[K][PIECES]; uint32_t e[K]; };
 
 struct SweepPos {          // tile t of the sweep: first body it touches and the byte offset inside it
   uint64_t t;
@@ -221,17 +223,17 @@ struct SweepPos {          // tile t of the sweep: first body it touches and the
   uint32_t w_lo;
 };
 
-template <bool WIDE, int TW, int P>
+// Workgroup b of G (= 256, one per CU) owns the 4 KiB tiles b, b+G, b+2G, ... of the output, so the chip
+// writes one contiguous G*4 KiB window at a time.  A step handles K consecutive tiles of the workgroup:
+// their images (1-2 per tile) are fetched from the scratch three steps ahead into registers, parked in
+// an LDS ring one step ahead, and expanded exactly like the fused kernel's EXPAND phase.
+template <bool WIDE, int TW, int K>
 __global__ __launch_bounds__(256, 1) void b3w_sweep_kernel(const uint32_t *__restrict__ scratch, uint32_t n,
                                                            uint8_t *__restrict__ out_base, uint32_t lead, uint64_t pitch,
                                                            const uint32_t *__restrict__ table, uint32_t nwit) {
   constexpr int PIECES = (TW / 4 + 255) / 256;           // 16-byte pieces per thread per image
-  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-  const uint32_t ntab = (nwit + 3) & ~3u;
-  uint32_t *tab = smem;                                  // the whole slot table
-  uint32_t *ring = smem + ntab;                          // [2 slots][2 images][TW]
+  extern __shared__ __attribute__((aligned(16))) uint32_t ring[];   // [2 slots][K tiles][2 images][TW]
   const uint32_t tid = threadIdx.x, G = gridDim.x;
-  for (uint32_t i = tid; i < nwit; i += 256) tab[i] = table[i];
   const uint64_t body = 32ull * nwit, total = (uint64_t)lead + (uint64_t)n * pitch;
   const uint64_t ntiles = (total + 4095) >> 12;
   const uint64_t stride = (uint64_t)G * 4096;
@@ -249,83 +251,97 @@ __global__ __launch_bounds__(256, 1) void b3w_sweep_kernel(const uint32_t *__res
     p.t += G; p.w_lo += dq; p.rem += (int64_t)dr;
     if (p.rem >= (int64_t)pitch) { p.rem -= (int64_t)pitch; p.w_lo++; }
   };
-  // does tile p also touch body w_lo+1 ?
   auto straddles = [&](const SweepPos &p) { return p.rem + 4095 >= (int64_t)pitch && p.w_lo + 1 < n; };
-  // Unconditional loads (clamped addresses) so the register sets stay in VGPRs: a tile past the end
-  // re-reads image 0, a non-straddling tile reads its one image twice (second read hits L1/L2).
-  auto issue = [&](const SweepPos &p, SweepRegs<PIECES> &r) {
-    const bool live = p.t < ntiles && p.w_lo < n;
-    const uint32_t w0 = live ? p.w_lo : 0u;
-    const uint32_t w1 = (live && straddles(p)) ? p.w_lo + 1 : w0;
-    const u32x4 *g0 = reinterpret_cast<const u32x4 *>(scratch + (uint64_t)w0 * TW);
-    const u32x4 *g1 = reinterpret_cast<const u32x4 *>(scratch + (uint64_t)w1 * TW);
-#pragma unroll
-    for (int q = 0; q < PIECES; ++q) {
-      const uint32_t i = q * 256 + tid, ic = i < TW / 4 ? i : TW / 4 - 1;
-      r.a[q] = g0[ic];
-      r.b[q] = g1[ic];
-    }
-  };
-  auto park = [&](const SweepRegs<PIECES> &r, int slot) {
-    u32x4 *l0 = reinterpret_cast<u32x4 *>(ring + (slot * 2 + 0) * TW);
-    u32x4 *l1 = reinterpret_cast<u32x4 *>(ring + (slot * 2 + 1) * TW);
-#pragma unroll
-    for (int q = 0; q < PIECES; ++q) {
-      const uint32_t i = q * 256 + tid;
-      if (i < TW / 4) { l0[i] = r.a[q]; l1[i] = r.b[q]; }
-    }
-  };
-  auto emit = [&](const SweepPos &p, int slot) {
-    if (p.t >= ntiles) return;
+  // this thread's 16 bytes of tile p: which image (sel), byte offset in the body (r), inside a body at all?
+  auto locate = [&](const SweepPos &p, uint32_t &sel, uint32_t &r32) {
     int64_t r = p.rem + (int64_t)(tid * 16);
-    uint32_t sel = 0, w = p.w_lo;
+    uint32_t w = p.w_lo;
+    sel = 0;
     if (r >= (int64_t)pitch) { r -= (int64_t)pitch; sel = 1; w++; }
-    if (r < 0 || r >= (int64_t)body || w >= n) return;
-    const uint32_t par = ((uint32_t)r >> 4) & 1u;
-    const uint32_t e = tab[(uint32_t)r >> 5];
-    const uint32_t src = e & 0xFFFu, sh = (e >> 12) & 31u, mode = (e >> 17) & 3u;
-    const uint32_t off = (WIDE && mode == B3W_MODE_W256) ? src + 4u * par : src;
-    const bool live = (par == 0) || (WIDE && mode == B3W_MODE_W256);
-    const uint32_t m0 = live ? (mode == B3W_MODE_BIT ? 1u : 0xFFFFFFFFu) : 0u;
-    const uint32_t m1 = (live && mode >= B3W_MODE_W64) ? 0xFFFFFFFFu : 0u;
-    const uint32_t m23 = (WIDE && mode == B3W_MODE_W256) ? 0xFFFFFFFFu : 0u;
-    const uint32_t *L = ring + (slot * 2 + sel) * TW;
-    if (L[B3W_LDS_OKWORD] == 0) return;                  // rejected step: body left untouched
-    uint4 v;
-    v.x = (L[off] >> sh) & m0;
-    v.y = L[off + 1] & m1;
-    if (WIDE) { v.z = L[off + 2] & m23; v.w = L[off + 3] & m23; } else { v.z = 0; v.w = 0; }
-    store16<false>(out_base + p.t * 4096 + tid * 16, v);
+    r32 = (uint32_t)r;
+    return p.t < ntiles && r >= 0 && r < (int64_t)body && w < n;
+  };
+  // Unconditional loads (clamped addresses) so the register sets stay in VGPRs: a tile past the end
+  // re-reads image 0, a non-straddling tile reads its one image twice (the second read hits L1/L2).
+  auto issue = [&](SweepPos &p, SweepRegs<PIECES, K> &r) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const bool live = p.t < ntiles && p.w_lo < n;
+      const uint32_t w0 = live ? p.w_lo : 0u;
+      const uint32_t w1 = (live && straddles(p)) ? p.w_lo + 1 : w0;
+      const u32x4 *g0 = reinterpret_cast<const u32x4 *>(scratch + (uint64_t)w0 * TW);
+      const u32x4 *g1 = reinterpret_cast<const u32x4 *>(scratch + (uint64_t)w1 * TW);
+#pragma unroll
+      for (int q = 0; q < PIECES; ++q) {
+        const uint32_t i = q * 256 + tid, ic = i < TW / 4 ? i : TW / 4 - 1;
+        r.a[k][q] = g0[ic];
+        r.b[k][q] = g1[ic];
+      }
+      uint32_t sel, r32;
+      const bool in = locate(p, sel, r32);
+      r.e[k] = table[in ? (r32 >> 5) : 0u];
+      advance(p);
+    }
+  };
+  auto park = [&](const SweepRegs<PIECES, K> &r, int slot) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      u32x4 *l0 = reinterpret_cast<u32x4 *>(ring + ((slot * K + k) * 2 + 0) * TW);
+      u32x4 *l1 = reinterpret_cast<u32x4 *>(ring + ((slot * K + k) * 2 + 1) * TW);
+#pragma unroll
+      for (int q = 0; q < PIECES; ++q) {
+        const uint32_t i = q * 256 + tid;
+        if (i < TW / 4) { l0[i] = r.a[k][q]; l1[i] = r.b[k][q]; }
+      }
+    }
+  };
+  auto emit = [&](SweepPos &p, const SweepRegs<PIECES, K> &rg, int slot) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      uint32_t sel, r32;
+      const bool in = locate(p, sel, r32);
+      const uint32_t par = (r32 >> 4) & 1u;
+      const uint32_t e = rg.e[k];
+      const uint32_t src = e & 0xFFFu, sh = (e >> 12) & 31u, mode = (e >> 17) & 3u;
+      const uint32_t off = (WIDE && mode == B3W_MODE_W256) ? src + 4u * par : src;
+      const bool live = (par == 0) || (WIDE && mode == B3W_MODE_W256);
+      const uint32_t m0 = live ? (mode == B3W_MODE_BIT ? 1u : 0xFFFFFFFFu) : 0u;
+      const uint32_t m1 = (live && mode >= B3W_MODE_W64) ? 0xFFFFFFFFu : 0u;
+      const uint32_t m23 = (WIDE && mode == B3W_MODE_W256) ? 0xFFFFFFFFu : 0u;
+      const uint32_t *L = ring + ((slot * K + k) * 2 + sel) * TW;
+      uint4 v;
+      v.x = (L[off] >> sh) & m0;
+      v.y = L[off + 1] & m1;
+      if (WIDE) { v.z = L[off + 2] & m23; v.w = L[off + 3] & m23; } else { v.z = 0; v.w = 0; }
+      if (in && L[B3W_LDS_OKWORD] != 0)                    // rejected step: body left untouched
+        store16<false>(out_base + p.t * 4096 + tid * 16, v);
+      advance(p);
+    }
   };
 
-  static_assert(P == 4, "the pipeline below is written out for four register sets");
   SweepPos cur = start(blockIdx.x), pre = cur;
-  SweepRegs<PIECES> r0, r1, r2, r3;
-  // prologue: loads for iterations 0..3 in flight, iteration 0 parked in ring slot 0
-  issue(pre, r0); advance(pre);
-  issue(pre, r1); advance(pre);
-  issue(pre, r2); advance(pre);
-  issue(pre, r3); advance(pre);
+  SweepRegs<PIECES, K> r0, r1, r2;
+  issue(pre, r0);
+  issue(pre, r1);
+  issue(pre, r2);
   park(r0, 0);
   __syncthreads();
-  // iteration k: ring slot k&1 holds its images, RNEXT holds iteration k+1's, RCUR (iteration k's,
-  // already parked) is refilled with iteration k+4
-#define B3W_SWEEP_STEP(RCUR, RNEXT, SLOT)   \
+  // step s: ring slot s&1 holds its images; RPARK holds step s+1 (parked now); RFILL held step s
+  // (parked during step s-1; its table words are still needed by emit) and is refilled after emit.
+#define B3W_SWEEP_STEP(RFILL, RPARK, SLOT)  \
   {                                         \
-    SweepPos nxt = cur;                     \
-    advance(nxt);                           \
-    issue(pre, RCUR);                       \
-    advance(pre);                           \
-    park(RNEXT, (SLOT) ^ 1);                \
-    emit(cur, SLOT);                        \
+    park(RPARK, (SLOT) ^ 1);                \
+    emit(cur, RFILL, SLOT);                 \
+    issue(pre, RFILL);                      \
     __syncthreads();                        \
-    cur = nxt;                              \
   }
   while (cur.t < ntiles) {
     B3W_SWEEP_STEP(r0, r1, 0)
     B3W_SWEEP_STEP(r1, r2, 1)
-    B3W_SWEEP_STEP(r2, r3, 0)
-    B3W_SWEEP_STEP(r3, r0, 1)
+    B3W_SWEEP_STEP(r2, r0, 0)
+    B3W_SWEEP_STEP(r0, r1, 1)
+    B3W_SWEEP_STEP(r1, r2, 0)
+    B3W_SWEEP_STEP(r2, r0, 1)
   }
 #undef B3W_SWEEP_STEP
 }
@@ -620,21 +636,20 @@ __global__ __launch_bounds__(64) void b3w_nova_kernel(const uint32_t *__restrict
 
 // ------------------------------------------------------------------ launch
 namespace {
-template <bool WIDE, int TW>
+template <bool WIDE, int TW, int K>
 int launch_sweep(const uint32_t *d_scratch, uint32_t n, uint8_t *d_out, uint64_t pitch, const uint32_t *d_table,
                  uint32_t nwit, hipStream_t stream) {
-  constexpr int P = 4;
   const uintptr_t addr = reinterpret_cast<uintptr_t>(d_out);
   const uint32_t lead = (uint32_t)(addr & 4095);
-  const size_t smem = (((size_t)nwit + 3) & ~(size_t)3) * 4 + (size_t)4 * TW * 4 + 16;   // +16: emit reads off+1..3
-  static bool attr_done = false;                       // per instantiation
+  const size_t smem = (size_t)2 * K * 2 * TW * 4 + 16;      // +16: emit reads off+1..3
+  static bool attr_done = false;                           // per instantiation
   if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&b3w_sweep_kernel<WIDE, TW, P>),
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&b3w_sweep_kernel<WIDE, TW, K>),
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
     if (e != hipSuccess) return (int)e;
     attr_done = true;
   }
-  hipLaunchKernelGGL((b3w_sweep_kernel<WIDE, TW, P>), dim3(B3W_SWEEP_GRID), dim3(256), smem, stream, d_scratch, n,
+  hipLaunchKernelGGL((b3w_sweep_kernel<WIDE, TW, K>), dim3(B3W_SWEEP_GRID), dim3(256), smem, stream, d_scratch, n,
                      d_out - lead, lead, pitch, d_table, nwit);
   return (int)hipGetLastError();
 }
@@ -658,19 +673,19 @@ extern "C" int b3w_launch_batch(int kind, int variant, const uint32_t *d_recs, u
         const uint32_t *rc_recs = d_recs + (uint64_t)c0 * 28;
         hipLaunchKernelGGL((b3w_compression_kernel<16, false, true>), dim3((cn + 15) / 16), dim3(64), 0, stream, rc_recs,
                            cn, reinterpret_cast<uint8_t *>(d_scratch), pitch, d_table, nwit, pub_c, st_c);
-        rc = launch_sweep<false, B3W_LDS_WORDS_COMP>(d_scratch, cn, out_c, pitch, d_table, nwit, stream);
+        rc = launch_sweep<false, B3W_LDS_WORDS_COMP, 4>(d_scratch, cn, out_c, pitch, d_table, nwit, stream);
       } else if (kind == B3W_KIND_NOVA_O2) {
         const uint32_t *rc_recs = d_recs + (uint64_t)c0 * 32;
         hipLaunchKernelGGL((b3w_nova_kernel<B3W_KIND_NOVA_O2, 4, false, true>), dim3((cn + 3) / 4), dim3(64), 0, stream,
                            rc_recs, cn, reinterpret_cast<uint8_t *>(d_scratch), pitch, d_table, nwit, pub_c, st_c,
                            (const uint32_t *)d_aux);
-        rc = launch_sweep<true, B3W_LDS_WORDS_NOVA_O2>(d_scratch, cn, out_c, pitch, d_table, nwit, stream);
+        rc = launch_sweep<true, B3W_LDS_WORDS_NOVA_O2, 4>(d_scratch, cn, out_c, pitch, d_table, nwit, stream);
       } else {
         const uint32_t *rc_recs = d_recs + (uint64_t)c0 * 32;
         hipLaunchKernelGGL((b3w_nova_kernel<B3W_KIND_NOVA_O1, 2, false, true>), dim3((cn + 1) / 2), dim3(64), 0, stream,
                            rc_recs, cn, reinterpret_cast<uint8_t *>(d_scratch), pitch, d_table, nwit, pub_c, st_c,
                            (const uint32_t *)d_aux);
-        rc = launch_sweep<true, B3W_LDS_WORDS_NOVA_O1>(d_scratch, cn, out_c, pitch, d_table, nwit, stream);
+        rc = launch_sweep<true, B3W_LDS_WORDS_NOVA_O1, 2>(d_scratch, cn, out_c, pitch, d_table, nwit, stream);
       }
       if (rc) return rc;
     }
