@@ -230,7 +230,8 @@ struct SweepPos {          // tile t of the sweep: first body it touches and the
 template <bool WIDE, int TW, int K>
 __global__ __launch_bounds__(256, 1) void b3w_sweep_kernel(const uint32_t *__restrict__ scratch, uint32_t n,
                                                            uint8_t *__restrict__ out_base, uint32_t lead, uint64_t pitch,
-                                                           const uint32_t *__restrict__ table, uint32_t nwit) {
+                                                           const uint32_t *__restrict__ table, uint32_t nwit,
+                                                           uint8_t *__restrict__ trash) {
   constexpr int PIECES = (TW / 4 + 255) / 256;           // 16-byte pieces per thread per image
   extern __shared__ __attribute__((aligned(16))) uint32_t ring[];   // [2 slots][K tiles][2 images][TW]
   const uint32_t tid = threadIdx.x, G = gridDim.x;
@@ -313,8 +314,13 @@ __global__ __launch_bounds__(256, 1) void b3w_sweep_kernel(const uint32_t *__res
       v.x = (L[off] >> sh) & m0;
       v.y = L[off + 1] & m1;
       if (WIDE) { v.z = L[off + 2] & m23; v.w = L[off + 3] & m23; } else { v.z = 0; v.w = 0; }
-      if (in && L[B3W_LDS_OKWORD] != 0)                    // rejected step: body left untouched
-        store16<false>(out_base + p.t * 4096 + tid * 16, v);
+      // Every lane stores every time, so the number of memory operations per step is fixed and the
+      // compiler can wait for the prefetched loads with a counted vmcnt instead of draining the store
+      // queue.  Lanes with nothing to write (lead-in, pitch padding, past the end, rejected step) hit a
+      // per-workgroup dump tile instead.
+      uint8_t *dst = (in && L[B3W_LDS_OKWORD] != 0) ? out_base + p.t * 4096 + tid * 16
+                                                    : trash + (uint64_t)blockIdx.x * 4096 + tid * 16;
+      store16<false>(dst, v);
       advance(p);
     }
   };
@@ -638,7 +644,7 @@ __global__ __launch_bounds__(64) void b3w_nova_kernel(const uint32_t *__restrict
 namespace {
 template <bool WIDE, int TW, int K>
 int launch_sweep(const uint32_t *d_scratch, uint32_t n, uint8_t *d_out, uint64_t pitch, const uint32_t *d_table,
-                 uint32_t nwit, hipStream_t stream) {
+                 uint32_t nwit, uint8_t *d_trash, hipStream_t stream) {
   const uintptr_t addr = reinterpret_cast<uintptr_t>(d_out);
   const uint32_t lead = (uint32_t)(addr & 4095);
   const size_t smem = (size_t)2 * K * 2 * TW * 4 + 16;      // +16: emit reads off+1..3
@@ -650,7 +656,7 @@ int launch_sweep(const uint32_t *d_scratch, uint32_t n, uint8_t *d_out, uint64_t
     attr_done = true;
   }
   hipLaunchKernelGGL((b3w_sweep_kernel<WIDE, TW, K>), dim3(B3W_SWEEP_GRID), dim3(256), smem, stream, d_scratch, n,
-                     d_out - lead, lead, pitch, d_table, nwit);
+                     d_out - lead, lead, pitch, d_table, nwit, d_trash);
   return (int)hipGetLastError();
 }
 }  // namespace
@@ -672,20 +678,20 @@ extern "C" int b3w_launch_batch(int kind, int variant, const uint32_t *d_recs, u
       if (kind == B3W_KIND_COMP) {
         const uint32_t *rc_recs = d_recs + (uint64_t)c0 * 28;
         hipLaunchKernelGGL((b3w_compression_kernel<16, false, true>), dim3((cn + 15) / 16), dim3(64), 0, stream, rc_recs,
-                           cn, reinterpret_cast<uint8_t *>(d_scratch), pitch, d_table, nwit, pub_c, st_c);
-        rc = launch_sweep<false, B3W_LDS_WORDS_COMP, 4>(d_scratch, cn, out_c, pitch, d_table, nwit, stream);
+                           cn, reinterpret_cast<uint8_t *>(d_scratch + (size_t)B3W_SWEEP_GRID * 1024), pitch, d_table, nwit, pub_c, st_c);
+        rc = launch_sweep<false, B3W_LDS_WORDS_COMP, 4>(d_scratch + (size_t)B3W_SWEEP_GRID * 1024, cn, out_c, pitch, d_table, nwit, reinterpret_cast<uint8_t *>(d_scratch), stream);
       } else if (kind == B3W_KIND_NOVA_O2) {
         const uint32_t *rc_recs = d_recs + (uint64_t)c0 * 32;
         hipLaunchKernelGGL((b3w_nova_kernel<B3W_KIND_NOVA_O2, 4, false, true>), dim3((cn + 3) / 4), dim3(64), 0, stream,
-                           rc_recs, cn, reinterpret_cast<uint8_t *>(d_scratch), pitch, d_table, nwit, pub_c, st_c,
+                           rc_recs, cn, reinterpret_cast<uint8_t *>(d_scratch + (size_t)B3W_SWEEP_GRID * 1024), pitch, d_table, nwit, pub_c, st_c,
                            (const uint32_t *)d_aux);
-        rc = launch_sweep<true, B3W_LDS_WORDS_NOVA_O2, 4>(d_scratch, cn, out_c, pitch, d_table, nwit, stream);
+        rc = launch_sweep<true, B3W_LDS_WORDS_NOVA_O2, 4>(d_scratch + (size_t)B3W_SWEEP_GRID * 1024, cn, out_c, pitch, d_table, nwit, reinterpret_cast<uint8_t *>(d_scratch), stream);
       } else {
         const uint32_t *rc_recs = d_recs + (uint64_t)c0 * 32;
         hipLaunchKernelGGL((b3w_nova_kernel<B3W_KIND_NOVA_O1, 2, false, true>), dim3((cn + 1) / 2), dim3(64), 0, stream,
-                           rc_recs, cn, reinterpret_cast<uint8_t *>(d_scratch), pitch, d_table, nwit, pub_c, st_c,
+                           rc_recs, cn, reinterpret_cast<uint8_t *>(d_scratch + (size_t)B3W_SWEEP_GRID * 1024), pitch, d_table, nwit, pub_c, st_c,
                            (const uint32_t *)d_aux);
-        rc = launch_sweep<true, B3W_LDS_WORDS_NOVA_O1, 2>(d_scratch, cn, out_c, pitch, d_table, nwit, stream);
+        rc = launch_sweep<true, B3W_LDS_WORDS_NOVA_O1, 2>(d_scratch + (size_t)B3W_SWEEP_GRID * 1024, cn, out_c, pitch, d_table, nwit, reinterpret_cast<uint8_t *>(d_scratch), stream);
       }
       if (rc) return rc;
     }
