@@ -188,34 +188,36 @@ __device__ __forceinline__ void expand(const uint32_t *lds, const uint32_t *__re
 }
 
 // ------------------------------------------------------------------ two-kernel ("sweep") path
-// The fused kernels above leave every wave streaming its own bodies: thousands of independent
-// write streams, which HBM serves at ~5.45 TB/s on MI355X (tools/ubench/store_ceiling.hip measures
-// the bare store pattern).  A linear sweep in which workgroup b of exactly 256 (one per CU) writes
-// the 4 KiB tiles b, b+256, b+512, ... of the output — the access shape of the runtime's own fill
-// kernel — reaches 6.5 TB/s.  The sweep path therefore splits the work: a TRACE kernel parks the
-// LDS images in an HBM scratch (3.7-11 KB per witness, ~1 % of the body), and b3w_sweep_kernel
-// walks the output in that order, staging the one or two images a tile needs through LDS.
+// The fused kernels above leave every wave streaming its own bodies: thousands of independent write
+// streams whose instantaneous positions load the HBM channels unevenly.  Measured on MI355X
+// (tools/ubench/store_patterns.hip, addr_sensitivity.py): 5.3-6.7 TB/s depending on where the output
+// buffer happens to sit, while a linear sweep in which workgroup b of exactly 256 (one per CU) writes
+// the 4 KiB tiles b, b+256, b+512, ... — the shape of the runtime's own fill kernel — holds 6.5-7.0
+// TB/s on every buffer: at any instant the chip writes one contiguous 1 MiB window that covers all
+// channels evenly.  The sweep path splits the work to get that shape:
+//   TRACE kernel  = the trace phase of the fused kernels; the images go to an HBM scratch
+//                   (3.7-11 KB per witness, ~1 % of the body), stored word-major ("transposed":
+//                   word j of witness w at scr[j*C + w]) so that the words one window needs are
+//                   spread over all L2 channels instead of sitting in two hot 4 KB images.
+//   SWEEP kernel  = walks the output in fill order; every lane gathers the 1-4 image words of its
+//                   16 bytes from the scratch (L2 resident) through a register-only software
+//                   pipeline: slot-table words two steps ahead, image words one step ahead.
 
-// TRACE kernel epilogue: copy this wave's images to the scratch, word 45 = 1 if the witness is valid.
+// TRACE kernel epilogue: scatter this wave's W images into the word-major scratch; row
+// B3W_LDS_OKWORD holds 1 for a valid witness.  C = witnesses per scratch row.
 template <int W, int WORDS>
-__device__ __forceinline__ void dump_images(uint32_t *lds, uint32_t *__restrict__ scratch, uint32_t wit0, uint32_t n,
-                                            const uint32_t *okf) {
+__device__ __forceinline__ void dump_images(uint32_t *lds, uint32_t *__restrict__ scratch, uint32_t C, uint32_t wit0,
+                                            uint32_t n, const uint32_t *okf) {
   const int lane = threadIdx.x;
   if (lane < W) lds[lane * WORDS + B3W_LDS_OKWORD] = okf ? okf[lane] : 1u;
   __syncthreads();
-#pragma unroll 1
-  for (int w = 0; w < W; ++w) {
-    if (wit0 + w >= n) break;
-    const uint4 *src = reinterpret_cast<const uint4 *>(lds + w * WORDS);
-    uint4 *dst = reinterpret_cast<uint4 *>(scratch + (uint64_t)(wit0 + w) * WORDS);
-    for (int i = lane; i < WORDS / 4; i += 64) dst[i] = src[i];
+  constexpr int ROWS = 64 / W;                       // image words handled per wave instruction
+  const int w = lane % W, jr = lane / W;
+  if (wit0 + w < n) {
+#pragma unroll 4
+    for (int j = jr; j < WORDS; j += ROWS) scratch[(uint64_t)j * C + wit0 + w] = lds[w * WORDS + j];
   }
 }
-
-// One thread's share of a sweep STEP (K tiles, 1 MiB apart): 16-byte pieces of each tile's two
-// images and the tile's slot-table word.  Native vector types: HIP's uint4 struct defeats SROA here.
-template <int PIECES, int K>
-struct SweepRegs { u32x4 a[K][PIECES], b[K][PIECES]; uint32_t e[K]; };
 
 struct SweepPos {          // tile t of the sweep: first body it touches and the byte offset inside it
   uint64_t t;
@@ -223,17 +225,16 @@ struct SweepPos {          // tile t of the sweep: first body it touches and the
   uint32_t w_lo;
 };
 
-// Workgroup b of G (= 256, one per CU) owns the 4 KiB tiles b, b+G, b+2G, ... of the output, so the chip
-// writes one contiguous G*4 KiB window at a time.  A step handles K consecutive tiles of the workgroup:
-// their images (1-2 per tile) are fetched from the scratch three steps ahead into registers, parked in
-// an LDS ring one step ahead, and expanded exactly like the fused kernel's EXPAND phase.
-template <bool WIDE, int TW, int K>
-__global__ __launch_bounds__(256, 1) void b3w_sweep_kernel(const uint32_t *__restrict__ scratch, uint32_t n,
+// one thread's pipeline registers for a step of K tiles
+template <int K, int NW>
+struct SweepRegs { uint32_t e[K]; uint32_t a[K][NW]; uint32_t ok[K]; };
+
+template <bool WIDE, int K>
+__global__ __launch_bounds__(256, 1) void b3w_sweep_kernel(const uint32_t *__restrict__ scr, uint32_t C, uint32_t n,
                                                            uint8_t *__restrict__ out_base, uint32_t lead, uint64_t pitch,
                                                            const uint32_t *__restrict__ table, uint32_t nwit,
                                                            uint8_t *__restrict__ trash) {
-  constexpr int PIECES = (TW / 4 + 255) / 256;           // 16-byte pieces per thread per image
-  extern __shared__ __attribute__((aligned(16))) uint32_t ring[];   // [2 slots][K tiles][2 images][TW]
+  constexpr int NW = WIDE ? 4 : 2;                       // image words gathered per 16 bytes
   const uint32_t tid = threadIdx.x, G = gridDim.x;
   const uint64_t body = 32ull * nwit, total = (uint64_t)lead + (uint64_t)n * pitch;
   const uint64_t ntiles = (total + 4095) >> 12;
@@ -252,102 +253,88 @@ __global__ __launch_bounds__(256, 1) void b3w_sweep_kernel(const uint32_t *__res
     p.t += G; p.w_lo += dq; p.rem += (int64_t)dr;
     if (p.rem >= (int64_t)pitch) { p.rem -= (int64_t)pitch; p.w_lo++; }
   };
-  auto straddles = [&](const SweepPos &p) { return p.rem + 4095 >= (int64_t)pitch && p.w_lo + 1 < n; };
-  // this thread's 16 bytes of tile p: which image (sel), byte offset in the body (r), inside a body at all?
-  auto locate = [&](const SweepPos &p, uint32_t &sel, uint32_t &r32) {
+  // this thread's 16 bytes of tile p: which witness, byte offset in its body, and whether they exist
+  auto locate = [&](const SweepPos &p, uint32_t &w, uint32_t &r32) {
     int64_t r = p.rem + (int64_t)(tid * 16);
-    uint32_t w = p.w_lo;
-    sel = 0;
-    if (r >= (int64_t)pitch) { r -= (int64_t)pitch; sel = 1; w++; }
+    w = p.w_lo;
+    if (r >= (int64_t)pitch) { r -= (int64_t)pitch; w++; }
     r32 = (uint32_t)r;
     return p.t < ntiles && r >= 0 && r < (int64_t)body && w < n;
   };
-  // Unconditional loads (clamped addresses) so the register sets stay in VGPRs: a tile past the end
-  // re-reads image 0, a non-straddling tile reads its one image twice (the second read hits L1/L2).
-  auto issue = [&](SweepPos &p, SweepRegs<PIECES, K> &r) {
+  // stage 1: slot-table words (coalesced)          -- every load below is unconditional with a clamped
+  auto fetch_table = [&](SweepPos p, SweepRegs<K, NW> &rg) {   // address so the register sets stay in VGPRs
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-      const bool live = p.t < ntiles && p.w_lo < n;
-      const uint32_t w0 = live ? p.w_lo : 0u;
-      const uint32_t w1 = (live && straddles(p)) ? p.w_lo + 1 : w0;
-      const u32x4 *g0 = reinterpret_cast<const u32x4 *>(scratch + (uint64_t)w0 * TW);
-      const u32x4 *g1 = reinterpret_cast<const u32x4 *>(scratch + (uint64_t)w1 * TW);
-#pragma unroll
-      for (int q = 0; q < PIECES; ++q) {
-        const uint32_t i = q * 256 + tid, ic = i < TW / 4 ? i : TW / 4 - 1;
-        r.a[k][q] = g0[ic];
-        r.b[k][q] = g1[ic];
-      }
-      uint32_t sel, r32;
-      const bool in = locate(p, sel, r32);
-      r.e[k] = table[in ? (r32 >> 5) : 0u];
+      uint32_t w, r32;
+      const bool in = locate(p, w, r32);
+      rg.e[k] = table[in ? (r32 >> 5) : 0u];
       advance(p);
     }
   };
-  auto park = [&](const SweepRegs<PIECES, K> &r, int slot) {
+  // stage 2: image words from the word-major scratch (1-2 cache lines per wave and word)
+  auto fetch_words = [&](SweepPos p, SweepRegs<K, NW> &rg) {
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-      u32x4 *l0 = reinterpret_cast<u32x4 *>(ring + ((slot * K + k) * 2 + 0) * TW);
-      u32x4 *l1 = reinterpret_cast<u32x4 *>(ring + ((slot * K + k) * 2 + 1) * TW);
+      uint32_t w, r32;
+      const bool in = locate(p, w, r32);
+      const uint32_t e = rg.e[k];
+      const uint32_t src = e & 0xFFFu, mode = (e >> 17) & 3u;
+      const uint32_t off = (WIDE && mode == B3W_MODE_W256) ? src + 4u * ((r32 >> 4) & 1u) : src;
+      const uint32_t *col = scr + (in ? w : 0u);
 #pragma unroll
-      for (int q = 0; q < PIECES; ++q) {
-        const uint32_t i = q * 256 + tid;
-        if (i < TW / 4) { l0[i] = r.a[k][q]; l1[i] = r.b[k][q]; }
-      }
+      for (int x = 0; x < NW; ++x) rg.a[k][x] = col[(uint64_t)(off + x) * C];
+      rg.ok[k] = WIDE ? col[(uint64_t)B3W_LDS_OKWORD * C] : 1u;      // only the nova circuits reject steps
+      advance(p);
     }
   };
-  auto emit = [&](SweepPos &p, const SweepRegs<PIECES, K> &rg, int slot) {
+  // stage 3: shape the 16 bytes and store them.  Every lane stores every time (lanes with nothing to
+  // write hit a per-workgroup dump tile) so the memory-operation count per step is fixed and the
+  // compiler waits for the prefetched loads with counted vmcnt instead of draining the store queue.
+  auto emit = [&](SweepPos &p, const SweepRegs<K, NW> &rg) {
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-      uint32_t sel, r32;
-      const bool in = locate(p, sel, r32);
+      uint32_t w, r32;
+      const bool in = locate(p, w, r32);
       const uint32_t par = (r32 >> 4) & 1u;
       const uint32_t e = rg.e[k];
-      const uint32_t src = e & 0xFFFu, sh = (e >> 12) & 31u, mode = (e >> 17) & 3u;
-      const uint32_t off = (WIDE && mode == B3W_MODE_W256) ? src + 4u * par : src;
+      const uint32_t sh = (e >> 12) & 31u, mode = (e >> 17) & 3u;
       const bool live = (par == 0) || (WIDE && mode == B3W_MODE_W256);
       const uint32_t m0 = live ? (mode == B3W_MODE_BIT ? 1u : 0xFFFFFFFFu) : 0u;
       const uint32_t m1 = (live && mode >= B3W_MODE_W64) ? 0xFFFFFFFFu : 0u;
       const uint32_t m23 = (WIDE && mode == B3W_MODE_W256) ? 0xFFFFFFFFu : 0u;
-      const uint32_t *L = ring + ((slot * K + k) * 2 + sel) * TW;
       uint4 v;
-      v.x = (L[off] >> sh) & m0;
-      v.y = L[off + 1] & m1;
-      if (WIDE) { v.z = L[off + 2] & m23; v.w = L[off + 3] & m23; } else { v.z = 0; v.w = 0; }
-      // Every lane stores every time, so the number of memory operations per step is fixed and the
-      // compiler can wait for the prefetched loads with a counted vmcnt instead of draining the store
-      // queue.  Lanes with nothing to write (lead-in, pitch padding, past the end, rejected step) hit a
-      // per-workgroup dump tile instead.
-      uint8_t *dst = (in && L[B3W_LDS_OKWORD] != 0) ? out_base + p.t * 4096 + tid * 16
-                                                    : trash + (uint64_t)blockIdx.x * 4096 + tid * 16;
+      v.x = (rg.a[k][0] >> sh) & m0;
+      v.y = rg.a[k][1] & m1;
+      if (WIDE) { v.z = rg.a[k][2] & m23; v.w = rg.a[k][3] & m23; } else { v.z = 0; v.w = 0; }
+      uint8_t *dst = (in && rg.ok[k] != 0) ? out_base + p.t * 4096 + tid * 16       // rejected step: body untouched
+                                           : trash + (uint64_t)blockIdx.x * 4096 + tid * 16;
       store16<false>(dst, v);
       advance(p);
     }
   };
+  auto skip = [&](SweepPos &p) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) advance(p);
+  };
 
-  SweepPos cur = start(blockIdx.x), pre = cur;
-  SweepRegs<PIECES, K> r0, r1, r2;
-  issue(pre, r0);
-  issue(pre, r1);
-  issue(pre, r2);
-  park(r0, 0);
-  __syncthreads();
-  // step s: ring slot s&1 holds its images; RPARK holds step s+1 (parked now); RFILL held step s
-  // (parked during step s-1; its table words are still needed by emit) and is refilled after emit.
-#define B3W_SWEEP_STEP(RFILL, RPARK, SLOT)  \
-  {                                         \
-    park(RPARK, (SLOT) ^ 1);                \
-    emit(cur, RFILL, SLOT);                 \
-    issue(pre, RFILL);                      \
-    __syncthreads();                        \
+  SweepPos cur = start(blockIdx.x);      // step being emitted
+  SweepPos p1 = cur, p2 = cur;           // step whose words / table entries are being fetched
+  SweepRegs<K, NW> r0, r1, r2;
+  fetch_table(p2, r0); skip(p2);                       // step 0
+  fetch_table(p2, r1); skip(p2);                       // step 1
+  fetch_words(p1, r0); skip(p1);                       // step 0
+  // step s: REMIT holds step s complete; RWORDS holds step s+1's table words (fetch its image words now);
+  // RTABLE is free (fetch step s+2's table words)
+#define B3W_SWEEP_STEP(REMIT, RWORDS, RTABLE) \
+  {                                            \
+    fetch_table(p2, RTABLE); skip(p2);         \
+    fetch_words(p1, RWORDS); skip(p1);         \
+    emit(cur, REMIT);                          \
   }
   while (cur.t < ntiles) {
-    B3W_SWEEP_STEP(r0, r1, 0)
-    B3W_SWEEP_STEP(r1, r2, 1)
-    B3W_SWEEP_STEP(r2, r0, 0)
-    B3W_SWEEP_STEP(r0, r1, 1)
-    B3W_SWEEP_STEP(r1, r2, 0)
-    B3W_SWEEP_STEP(r2, r0, 1)
+    B3W_SWEEP_STEP(r0, r1, r2)
+    B3W_SWEEP_STEP(r1, r2, r0)
+    B3W_SWEEP_STEP(r2, r0, r1)
   }
 #undef B3W_SWEEP_STEP
 }
@@ -376,7 +363,7 @@ __global__ __launch_bounds__(64) void b3w_compression_kernel(const uint32_t *__r
     }
   }
   __syncthreads();
-  if (SWEEP) dump_images<W, WORDS>(lds, reinterpret_cast<uint32_t *>(out), wit0, n, nullptr);   // out = scratch
+  if (SWEEP) dump_images<W, WORDS>(lds, reinterpret_cast<uint32_t *>(out), (uint32_t)pitch, wit0, n, nullptr);   // out = scratch, pitch = its row length   // out = scratch
   else expand<W, WORDS, false, NT>(lds, table, nwit, out, pitch, wit0, n, nullptr, true);
 }
 
@@ -634,7 +621,7 @@ __global__ __launch_bounds__(64) void b3w_nova_kernel(const uint32_t *__restrict
     pw[2 + col] = L[B3W_A_O + col];
     pw[6 + col] = L[B3W_A_O + 4 + col];
   }
-  if (SWEEP) dump_images<W, WORDS>(lds, reinterpret_cast<uint32_t *>(out), wit0, n, okf);       // out = scratch
+  if (SWEEP) dump_images<W, WORDS>(lds, reinterpret_cast<uint32_t *>(out), (uint32_t)pitch, wit0, n, okf);       // out = scratch, pitch = its row length       // out = scratch
   else expand<W, WORDS, true, NT>(lds, table, nwit, out, pitch, wit0, n, okf, all_ok);
 }
 
@@ -642,20 +629,12 @@ __global__ __launch_bounds__(64) void b3w_nova_kernel(const uint32_t *__restrict
 
 // ------------------------------------------------------------------ launch
 namespace {
-template <bool WIDE, int TW, int K>
-int launch_sweep(const uint32_t *d_scratch, uint32_t n, uint8_t *d_out, uint64_t pitch, const uint32_t *d_table,
+template <bool WIDE, int K>
+int launch_sweep(const uint32_t *d_images, uint32_t C, uint32_t n, uint8_t *d_out, uint64_t pitch, const uint32_t *d_table,
                  uint32_t nwit, uint8_t *d_trash, hipStream_t stream) {
   const uintptr_t addr = reinterpret_cast<uintptr_t>(d_out);
   const uint32_t lead = (uint32_t)(addr & 4095);
-  const size_t smem = (size_t)2 * K * 2 * TW * 4 + 16;      // +16: emit reads off+1..3
-  static bool attr_done = false;                           // per instantiation
-  if (!attr_done) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&b3w_sweep_kernel<WIDE, TW, K>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);
-    if (e != hipSuccess) return (int)e;
-    attr_done = true;
-  }
-  hipLaunchKernelGGL((b3w_sweep_kernel<WIDE, TW, K>), dim3(B3W_SWEEP_GRID), dim3(256), smem, stream, d_scratch, n,
+  hipLaunchKernelGGL((b3w_sweep_kernel<WIDE, K>), dim3(B3W_SWEEP_GRID), dim3(256), 0, stream, d_images, C, n,
                      d_out - lead, lead, pitch, d_table, nwit, d_trash);
   return (int)hipGetLastError();
 }
@@ -669,6 +648,8 @@ extern "C" int b3w_launch_batch(int kind, int variant, const uint32_t *d_recs, u
   if (variant >= B3W_VARIANT_SWEEP) {
     // TRACE kernel -> scratch, SWEEP kernel -> bodies, in chunks of scratch_cap witnesses
     if (!d_scratch || !scratch_cap) return -4;
+    uint8_t *d_trash = reinterpret_cast<uint8_t *>(d_scratch);            // [dump tiles][word-major images]
+    uint32_t *d_images = d_scratch + (size_t)B3W_SWEEP_GRID * 1024;
     for (uint32_t c0 = 0; c0 < n; c0 += scratch_cap) {
       const uint32_t cn = n - c0 < scratch_cap ? n - c0 : scratch_cap;
       uint32_t *pub_c = d_pub ? d_pub + (uint64_t)c0 * (kind == B3W_KIND_COMP ? 16 : 15) : nullptr;
@@ -678,20 +659,20 @@ extern "C" int b3w_launch_batch(int kind, int variant, const uint32_t *d_recs, u
       if (kind == B3W_KIND_COMP) {
         const uint32_t *rc_recs = d_recs + (uint64_t)c0 * 28;
         hipLaunchKernelGGL((b3w_compression_kernel<16, false, true>), dim3((cn + 15) / 16), dim3(64), 0, stream, rc_recs,
-                           cn, reinterpret_cast<uint8_t *>(d_scratch + (size_t)B3W_SWEEP_GRID * 1024), pitch, d_table, nwit, pub_c, st_c);
-        rc = launch_sweep<false, B3W_LDS_WORDS_COMP, 4>(d_scratch + (size_t)B3W_SWEEP_GRID * 1024, cn, out_c, pitch, d_table, nwit, reinterpret_cast<uint8_t *>(d_scratch), stream);
+                           cn, reinterpret_cast<uint8_t *>(d_images), (uint64_t)scratch_cap, d_table, nwit, pub_c, st_c);
+        rc = launch_sweep<false, 8>(d_images, scratch_cap, cn, out_c, pitch, d_table, nwit, d_trash, stream);
       } else if (kind == B3W_KIND_NOVA_O2) {
         const uint32_t *rc_recs = d_recs + (uint64_t)c0 * 32;
         hipLaunchKernelGGL((b3w_nova_kernel<B3W_KIND_NOVA_O2, 4, false, true>), dim3((cn + 3) / 4), dim3(64), 0, stream,
-                           rc_recs, cn, reinterpret_cast<uint8_t *>(d_scratch + (size_t)B3W_SWEEP_GRID * 1024), pitch, d_table, nwit, pub_c, st_c,
+                           rc_recs, cn, reinterpret_cast<uint8_t *>(d_images), (uint64_t)scratch_cap, d_table, nwit, pub_c, st_c,
                            (const uint32_t *)d_aux);
-        rc = launch_sweep<true, B3W_LDS_WORDS_NOVA_O2, 4>(d_scratch + (size_t)B3W_SWEEP_GRID * 1024, cn, out_c, pitch, d_table, nwit, reinterpret_cast<uint8_t *>(d_scratch), stream);
+        rc = launch_sweep<true, 4>(d_images, scratch_cap, cn, out_c, pitch, d_table, nwit, d_trash, stream);
       } else {
         const uint32_t *rc_recs = d_recs + (uint64_t)c0 * 32;
         hipLaunchKernelGGL((b3w_nova_kernel<B3W_KIND_NOVA_O1, 2, false, true>), dim3((cn + 1) / 2), dim3(64), 0, stream,
-                           rc_recs, cn, reinterpret_cast<uint8_t *>(d_scratch + (size_t)B3W_SWEEP_GRID * 1024), pitch, d_table, nwit, pub_c, st_c,
+                           rc_recs, cn, reinterpret_cast<uint8_t *>(d_images), (uint64_t)scratch_cap, d_table, nwit, pub_c, st_c,
                            (const uint32_t *)d_aux);
-        rc = launch_sweep<true, B3W_LDS_WORDS_NOVA_O1, 2>(d_scratch + (size_t)B3W_SWEEP_GRID * 1024, cn, out_c, pitch, d_table, nwit, reinterpret_cast<uint8_t *>(d_scratch), stream);
+        rc = launch_sweep<true, 4>(d_images, scratch_cap, cn, out_c, pitch, d_table, nwit, d_trash, stream);
       }
       if (rc) return rc;
     }
