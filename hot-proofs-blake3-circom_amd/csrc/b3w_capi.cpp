@@ -319,8 +319,7 @@ int32_t b3w_create(int32_t circuit, int32_t device, b3w_ctx **out) {
   if (v) ctx->variant = atoi(v);
   if (ctx->variant >= B3W_VARIANT_SWEEP) {
     ctx->scratch_cap = B3W_SWEEP_CHUNK;
-    // [dump tiles of the sweep kernel: B3W_SWEEP_GRID x 4 KiB][images: scratch_cap x lds_words]
-    e = hipMalloc((void **)&ctx->d_scratch, (size_t)B3W_SWEEP_GRID * 4096 + (size_t)ctx->scratch_cap * d.lds_words * 4);
+    e = hipMalloc((void **)&ctx->d_scratch, (size_t)ctx->scratch_cap * d.lds_words * 4);   // word-major images
     if (e != hipSuccess) { b3w_destroy(ctx); return B3W_E_HIP; }
   }
   *out = ctx;

@@ -9,7 +9,8 @@
 // variants >= B3W_VARIANT_SWEEP use the two-kernel path (TRACE -> HBM scratch -> linear SWEEP of the output)
 #define B3W_VARIANT_SWEEP 100
 #define B3W_SWEEP_GRID 256       // one 256-thread workgroup per CU, tile = 4 KiB: the runtime fill kernel's shape
-#define B3W_SWEEP_CHUNK 8192     // witnesses per TRACE+SWEEP pair (bounds the scratch)
+#define B3W_SWEEP_LOGC 13
+#define B3W_SWEEP_CHUNK (1u << B3W_SWEEP_LOGC)   // witnesses per TRACE+SWEEP pair = row length of the scratch
 
 extern "C" int b3w_launch_batch(int kind, int variant, const uint32_t *d_recs, uint32_t n, uint8_t *d_out,
                                 uint64_t pitch, const uint32_t *d_table, uint32_t nwit, uint32_t *d_pub,

@@ -221,7 +221,7 @@ __device__ __forceinline__ void dump_images(uint32_t *lds, uint32_t *__restrict_
 
 struct SweepPos {          // tile t of the sweep: first body it touches and the byte offset inside it
   uint64_t t;
-  int64_t rem;             // (t*4096 - lead) - w_lo*pitch; negative only inside the lead-in of tile 0
+  int32_t rem;             // (t*4096 - lead) - w_lo*pitch; negative only inside the lead-in of tile 0
   uint32_t w_lo;
 };
 
@@ -229,40 +229,43 @@ struct SweepPos {          // tile t of the sweep: first body it touches and the
 template <int K, int NW>
 struct SweepRegs { uint32_t e[K]; uint32_t a[K][NW]; uint32_t ok[K]; };
 
-template <bool WIDE, int K>
-__global__ __launch_bounds__(256, 1) void b3w_sweep_kernel(const uint32_t *__restrict__ scr, uint32_t C, uint32_t n,
-                                                           uint8_t *__restrict__ out_base, uint32_t lead, uint64_t pitch,
-                                                           const uint32_t *__restrict__ table, uint32_t nwit,
-                                                           uint8_t *__restrict__ trash) {
+// LOGC: the scratch holds 2^LOGC witnesses per row.  pitch < 2^30 (checked by the launcher) keeps the
+// per-thread position arithmetic in 32 bits: one wave per SIMD has to issue everything, so the
+// instruction count per 16 bytes decides whether the kernel keeps up with HBM.
+template <bool WIDE, int K, int LOGC>
+__global__ __launch_bounds__(256, 1) void b3w_sweep_kernel(const uint32_t *__restrict__ scr, uint32_t n,
+                                                           uint8_t *__restrict__ out_base, uint32_t lead, uint32_t pitch,
+                                                           const uint32_t *__restrict__ table, uint32_t nwit) {
   constexpr int NW = WIDE ? 4 : 2;                       // image words gathered per 16 bytes
-  const uint32_t tid = threadIdx.x, G = gridDim.x;
-  const uint64_t body = 32ull * nwit, total = (uint64_t)lead + (uint64_t)n * pitch;
+  const uint32_t tid16 = threadIdx.x * 16u, G = gridDim.x;
+  const uint32_t body = 32u * nwit;
+  const uint64_t total = (uint64_t)lead + (uint64_t)n * pitch;
   const uint64_t ntiles = (total + 4095) >> 12;
   const uint64_t stride = (uint64_t)G * 4096;
-  const uint32_t dq = (uint32_t)(stride / pitch);
-  const uint64_t dr = stride % pitch;
+  const uint32_t dq = (uint32_t)(stride / pitch), dr = (uint32_t)(stride % pitch);
   auto start = [&](uint64_t t) {
     SweepPos p;
     p.t = t;
     const int64_t pos = (int64_t)(t * 4096) - (int64_t)lead;
-    if (pos < 0) { p.w_lo = 0; p.rem = pos; }
-    else { p.w_lo = (uint32_t)((uint64_t)pos / pitch); p.rem = (int64_t)((uint64_t)pos % pitch); }
+    if (pos < 0) { p.w_lo = 0; p.rem = (int32_t)pos; }
+    else { p.w_lo = (uint32_t)((uint64_t)pos / pitch); p.rem = (int32_t)((uint64_t)pos % pitch); }
     return p;
   };
   auto advance = [&](SweepPos &p) {
-    p.t += G; p.w_lo += dq; p.rem += (int64_t)dr;
-    if (p.rem >= (int64_t)pitch) { p.rem -= (int64_t)pitch; p.w_lo++; }
+    p.t += G; p.w_lo += dq; p.rem += (int32_t)dr;
+    if (p.rem >= (int32_t)pitch) { p.rem -= (int32_t)pitch; p.w_lo++; }
   };
   // this thread's 16 bytes of tile p: which witness, byte offset in its body, and whether they exist
   auto locate = [&](const SweepPos &p, uint32_t &w, uint32_t &r32) {
-    int64_t r = p.rem + (int64_t)(tid * 16);
+    int32_t r = p.rem + (int32_t)tid16;
     w = p.w_lo;
-    if (r >= (int64_t)pitch) { r -= (int64_t)pitch; w++; }
+    if (r >= (int32_t)pitch) { r -= (int32_t)pitch; w++; }
     r32 = (uint32_t)r;
-    return p.t < ntiles && r >= 0 && r < (int64_t)body && w < n;
+    return p.t < ntiles && r32 < body && w < n;          // r < 0 wraps above body
   };
-  // stage 1: slot-table words (coalesced)          -- every load below is unconditional with a clamped
-  auto fetch_table = [&](SweepPos p, SweepRegs<K, NW> &rg) {   // address so the register sets stay in VGPRs
+  // stage 1: slot-table words (coalesced).  Loads are unconditional with clamped addresses so the
+  // register sets stay in VGPRs.
+  auto fetch_table = [&](SweepPos p, SweepRegs<K, NW> &rg) {
 #pragma unroll
     for (int k = 0; k < K; ++k) {
       uint32_t w, r32;
@@ -279,17 +282,15 @@ __global__ __launch_bounds__(256, 1) void b3w_sweep_kernel(const uint32_t *__res
       const bool in = locate(p, w, r32);
       const uint32_t e = rg.e[k];
       const uint32_t src = e & 0xFFFu, mode = (e >> 17) & 3u;
-      const uint32_t off = (WIDE && mode == B3W_MODE_W256) ? src + 4u * ((r32 >> 4) & 1u) : src;
-      const uint32_t *col = scr + (in ? w : 0u);
+      const uint32_t off = (WIDE && mode == B3W_MODE_W256) ? src + ((r32 >> 2) & 4u) : src;
+      const uint32_t idx = (off << LOGC) + (in ? w : 0u);                   // 32-bit index: scratch < 2^32 words
 #pragma unroll
-      for (int x = 0; x < NW; ++x) rg.a[k][x] = col[(uint64_t)(off + x) * C];
-      rg.ok[k] = WIDE ? col[(uint64_t)B3W_LDS_OKWORD * C] : 1u;      // only the nova circuits reject steps
+      for (int x = 0; x < NW; ++x) rg.a[k][x] = scr[idx + ((uint32_t)x << LOGC)];
+      rg.ok[k] = WIDE ? scr[((uint32_t)B3W_LDS_OKWORD << LOGC) + (in ? w : 0u)] : 1u;   // only nova rejects steps
       advance(p);
     }
   };
-  // stage 3: shape the 16 bytes and store them.  Every lane stores every time (lanes with nothing to
-  // write hit a per-workgroup dump tile) so the memory-operation count per step is fixed and the
-  // compiler waits for the prefetched loads with counted vmcnt instead of draining the store queue.
+  // stage 3: shape the 16 bytes and store them
   auto emit = [&](SweepPos &p, const SweepRegs<K, NW> &rg) {
 #pragma unroll
     for (int k = 0; k < K; ++k) {
@@ -306,9 +307,8 @@ __global__ __launch_bounds__(256, 1) void b3w_sweep_kernel(const uint32_t *__res
       v.x = (rg.a[k][0] >> sh) & m0;
       v.y = rg.a[k][1] & m1;
       if (WIDE) { v.z = rg.a[k][2] & m23; v.w = rg.a[k][3] & m23; } else { v.z = 0; v.w = 0; }
-      uint8_t *dst = (in && rg.ok[k] != 0) ? out_base + p.t * 4096 + tid * 16       // rejected step: body untouched
-                                           : trash + (uint64_t)blockIdx.x * 4096 + tid * 16;
-      store16<false>(dst, v);
+      if (in && rg.ok[k] != 0)                                            // rejected step: body untouched
+        store16<false>(out_base + p.t * 4096 + tid16, v);
       advance(p);
     }
   };
@@ -630,12 +630,13 @@ __global__ __launch_bounds__(64) void b3w_nova_kernel(const uint32_t *__restrict
 // ------------------------------------------------------------------ launch
 namespace {
 template <bool WIDE, int K>
-int launch_sweep(const uint32_t *d_images, uint32_t C, uint32_t n, uint8_t *d_out, uint64_t pitch, const uint32_t *d_table,
-                 uint32_t nwit, uint8_t *d_trash, hipStream_t stream) {
+int launch_sweep(const uint32_t *d_images, uint32_t n, uint8_t *d_out, uint64_t pitch, const uint32_t *d_table,
+                 uint32_t nwit, hipStream_t stream) {
+  if (pitch >= (1ull << 30)) return -5;
   const uintptr_t addr = reinterpret_cast<uintptr_t>(d_out);
   const uint32_t lead = (uint32_t)(addr & 4095);
-  hipLaunchKernelGGL((b3w_sweep_kernel<WIDE, K>), dim3(B3W_SWEEP_GRID), dim3(256), 0, stream, d_images, C, n,
-                     d_out - lead, lead, pitch, d_table, nwit, d_trash);
+  hipLaunchKernelGGL((b3w_sweep_kernel<WIDE, K, B3W_SWEEP_LOGC>), dim3(B3W_SWEEP_GRID), dim3(256), 0, stream, d_images, n,
+                     d_out - lead, lead, (uint32_t)pitch, d_table, nwit);
   return (int)hipGetLastError();
 }
 }  // namespace
@@ -647,9 +648,8 @@ extern "C" int b3w_launch_batch(int kind, int variant, const uint32_t *d_recs, u
   if (n == 0) return 0;
   if (variant >= B3W_VARIANT_SWEEP) {
     // TRACE kernel -> scratch, SWEEP kernel -> bodies, in chunks of scratch_cap witnesses
-    if (!d_scratch || !scratch_cap) return -4;
-    uint8_t *d_trash = reinterpret_cast<uint8_t *>(d_scratch);            // [dump tiles][word-major images]
-    uint32_t *d_images = d_scratch + (size_t)B3W_SWEEP_GRID * 1024;
+    if (!d_scratch || scratch_cap != (1u << B3W_SWEEP_LOGC)) return -4;
+    uint32_t *d_images = d_scratch;                                        // word-major images
     for (uint32_t c0 = 0; c0 < n; c0 += scratch_cap) {
       const uint32_t cn = n - c0 < scratch_cap ? n - c0 : scratch_cap;
       uint32_t *pub_c = d_pub ? d_pub + (uint64_t)c0 * (kind == B3W_KIND_COMP ? 16 : 15) : nullptr;
@@ -660,19 +660,19 @@ extern "C" int b3w_launch_batch(int kind, int variant, const uint32_t *d_recs, u
         const uint32_t *rc_recs = d_recs + (uint64_t)c0 * 28;
         hipLaunchKernelGGL((b3w_compression_kernel<16, false, true>), dim3((cn + 15) / 16), dim3(64), 0, stream, rc_recs,
                            cn, reinterpret_cast<uint8_t *>(d_images), (uint64_t)scratch_cap, d_table, nwit, pub_c, st_c);
-        rc = launch_sweep<false, 8>(d_images, scratch_cap, cn, out_c, pitch, d_table, nwit, d_trash, stream);
+        rc = launch_sweep<false, 8>(d_images, cn, out_c, pitch, d_table, nwit, stream);
       } else if (kind == B3W_KIND_NOVA_O2) {
         const uint32_t *rc_recs = d_recs + (uint64_t)c0 * 32;
         hipLaunchKernelGGL((b3w_nova_kernel<B3W_KIND_NOVA_O2, 4, false, true>), dim3((cn + 3) / 4), dim3(64), 0, stream,
                            rc_recs, cn, reinterpret_cast<uint8_t *>(d_images), (uint64_t)scratch_cap, d_table, nwit, pub_c, st_c,
                            (const uint32_t *)d_aux);
-        rc = launch_sweep<true, 4>(d_images, scratch_cap, cn, out_c, pitch, d_table, nwit, d_trash, stream);
+        rc = launch_sweep<true, 4>(d_images, cn, out_c, pitch, d_table, nwit, stream);
       } else {
         const uint32_t *rc_recs = d_recs + (uint64_t)c0 * 32;
         hipLaunchKernelGGL((b3w_nova_kernel<B3W_KIND_NOVA_O1, 2, false, true>), dim3((cn + 1) / 2), dim3(64), 0, stream,
                            rc_recs, cn, reinterpret_cast<uint8_t *>(d_images), (uint64_t)scratch_cap, d_table, nwit, pub_c, st_c,
                            (const uint32_t *)d_aux);
-        rc = launch_sweep<true, 4>(d_images, scratch_cap, cn, out_c, pitch, d_table, nwit, d_trash, stream);
+        rc = launch_sweep<true, 4>(d_images, cn, out_c, pitch, d_table, nwit, stream);
       }
       if (rc) return rc;
     }
