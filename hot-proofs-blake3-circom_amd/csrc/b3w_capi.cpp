@@ -219,6 +219,40 @@ bool build_slot_table(const CircuitDesc &c, std::vector<uint32_t> &table, std::s
   return true;
 }
 
+// slot -> atom | bit<<16 (0xFFFF = whole element) for the exact (field-element) kernel
+bool build_exact_table(const CircuitDesc &c, std::vector<uint32_t> &table) {
+  table.assign(c.nwit, 0);
+  for (uint32_t r = 0; r < c.nruns; r++) {
+    const b3w_layout_run &run = c.runs[r];
+    for (uint32_t j = 0; j < run.len; j++) {
+      const uint32_t slot = run.slot + j;
+      if (slot >= c.nwit) return false;
+      if (run.kind == 'W') table[slot] = (run.atom + j) | (0xFFFFu << 16);
+      else table[slot] = run.atom | ((run.bit0 + j) << 16);
+    }
+  }
+  return true;
+}
+
+const char *assert_site_text(uint32_t site, char *buf, size_t len) {
+  const uint32_t code = site & 0xFF, r = (site >> 8) & 0xF, g = (site >> 12) & 0xF, hf = (site >> 16) & 1;
+  switch (code) {
+    case 1: snprintf(buf, len, "Error in template Bits34 line: 201 (rounds[%u].GS[%u].half%u.add1)\n", r, g, hf + 1); break;
+    case 2: snprintf(buf, len, "Error in template ToBits line: 153 (rounds[%u].GS[%u].half%u.rxor2.tb)\n", r, g, hf + 1); break;
+    case 3: snprintf(buf, len, "Error in template Bits33 line: 176 (rounds[%u].GS[%u].half%u.add3)\n", r, g, hf + 1); break;
+    case 4: snprintf(buf, len, "Error in template ToBits line: 153 (rounds[%u].GS[%u].half%u.rxor4.tb)\n", r, g, hf + 1); break;
+    case 5: snprintf(buf, len, "Error in template ToBits line: 153 (outXor[%u].tb_x)\n", g + 8 * hf); break;
+    case 6: snprintf(buf, len, "Error in template ToBits line: 153 (outXor[%u].tb_y)\n", g + 8 * hf); break;
+    case 10: snprintf(buf, len, "Error in template Num2Bits line: 38 (check_depth.check_parent.n2b)\n"); break;
+    case 11: snprintf(buf, len, "Error in template Num2Bits line: 38 (check_depth.exceed_depth.lt.n2b)\n"); break;
+    case 12: snprintf(buf, len, "Error in template Blake3NovaTreePath_CheckDepth line: 38\n"); break;
+    case 13: snprintf(buf, len, "Error in template Num2Bits line: 38 (final_m.down_left_path.n2b)\n"); break;
+    case 14: snprintf(buf, len, "Error in template Blake3GetDownLeftPath line: 77\n"); break;
+    default: snprintf(buf, len, "assert site %u\n", site);
+  }
+  return buf;
+}
+
 }  // namespace
 
 struct b3w_ctx {
@@ -230,6 +264,10 @@ struct b3w_ctx {
   uint32_t *d_table = nullptr;
   void *d_aux = nullptr;
   uint32_t *d_scratch = nullptr;      // TRACE images of the two-kernel path
+  uint32_t *d_exact_table = nullptr;  // exact (field-element) path: slot -> atom | bit<<16
+  uint32_t *d_prime = nullptr;
+  uint32_t *d_fe_inputs = nullptr;
+  uint32_t *d_status2 = nullptr;
   uint32_t scratch_cap = 0;
   // single-witness scratch
   uint32_t *d_rec1 = nullptr;
@@ -311,6 +349,16 @@ int32_t b3w_create(int32_t circuit, int32_t device, b3w_ctx **out) {
     e = hipMalloc(&ctx->d_aux, aux.size() * 4);
     if (e == hipSuccess) e = hipMemcpy(ctx->d_aux, aux.data(), aux.size() * 4, hipMemcpyHostToDevice);
   }
+  {
+    std::vector<uint32_t> xt;
+    if (!build_exact_table(d, xt)) { b3w_destroy(ctx); return B3W_E_BAD_ARGUMENT; }
+    if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_exact_table, xt.size() * 4);
+    if (e == hipSuccess) e = hipMemcpy(ctx->d_exact_table, xt.data(), xt.size() * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_prime, 32);
+    if (e == hipSuccess) e = hipMemcpy(ctx->d_prime, d.prime, 32, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_fe_inputs, 32 * 32);
+    if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_status2, 8);
+  }
   if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_rec1, d.nin * 4);
   if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_body1, (size_t)d.nwit * 32);
   if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_status1, 4);
@@ -331,6 +379,10 @@ void b3w_destroy(b3w_ctx *ctx) {
   if (ctx->d_table) (void)hipFree(ctx->d_table);
   if (ctx->d_aux) (void)hipFree(ctx->d_aux);
   if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
+  if (ctx->d_exact_table) (void)hipFree(ctx->d_exact_table);
+  if (ctx->d_prime) (void)hipFree(ctx->d_prime);
+  if (ctx->d_fe_inputs) (void)hipFree(ctx->d_fe_inputs);
+  if (ctx->d_status2) (void)hipFree(ctx->d_status2);
   if (ctx->d_rec1) (void)hipFree(ctx->d_rec1);
   if (ctx->d_body1) (void)hipFree(ctx->d_body1);
   if (ctx->d_status1) (void)hipFree(ctx->d_status1);
@@ -416,10 +468,12 @@ int32_t b3w_calc_witness(b3w_ctx *ctx, const uint64_t *name_hashes, const uint32
   if (!ctx || !name_hashes || !counts || !values_le32 || !out_body) return B3W_E_BAD_ARGUMENT;
   const CircuitDesc &d = ctx->desc;
   std::vector<uint32_t> rec(d.nin, 0);
+  std::vector<uint8_t> fe((size_t)d.nin * 32, 0);       // inputs as field elements, record order
   std::vector<uint8_t> set(d.nin, 0);
   uint32_t nset = 0;
+  bool canonical = true;
   const uint8_t *v = values_le32;
-  char msg[160];
+  char msg[200];
   for (uint32_t k = 0; k < nkeys; k++) {
     const InputSignal *sig = nullptr;
     for (const InputSignal &s : ctx->inputs) if (s.hash == name_hashes[k]) sig = &s;
@@ -427,18 +481,12 @@ int32_t b3w_calc_witness(b3w_ctx *ctx, const uint64_t *name_hashes, const uint32
     if (counts[k] < size) { ctx->last_error = std::string("Not enough values for input signal ") + (sig ? sig->name : "?") + "\n"; return B3W_E_ARRAY_ACCESS; }
     if (counts[k] > size) { ctx->last_error = std::string("Too many values for input signal ") + (sig ? sig->name : "?") + "\n"; return B3W_E_TOO_MANY_SIGNALS; }
     for (uint32_t i = 0; i < size; i++, v += 32) {
-      if (set[sig->rec_off + i]) { ctx->last_error = "Signal already set.\n"; return B3W_E_SIGNAL_ALREADY_SET; }
-      uint32_t lo;
-      memcpy(&lo, v, 4);
-      bool canonical = true;
+      const uint32_t idx = sig->rec_off + i;
+      if (set[idx]) { ctx->last_error = "Signal already set.\n"; return B3W_E_SIGNAL_ALREADY_SET; }
+      memcpy(&fe[(size_t)idx * 32], v, 32);
+      memcpy(&rec[idx], v, 4);
       for (int b = 4; b < 32; b++) canonical &= (v[b] == 0);
-      if (!canonical) {
-        snprintf(msg, sizeof msg, "input %s[%u] is outside [0,2^32): not in the device fast-path domain", sig->name, i);
-        ctx->last_error = msg;
-        return B3W_E_DOMAIN;
-      }
-      rec[sig->rec_off + i] = lo;
-      set[sig->rec_off + i] = 1;
+      set[idx] = 1;
       nset++;
     }
   }
@@ -448,14 +496,29 @@ int32_t b3w_calc_witness(b3w_ctx *ctx, const uint64_t *name_hashes, const uint32
     return B3W_E_NOT_ALL_INPUTS;
   }
   HIP_TRY(ctx, hipSetDevice(ctx->device));
-  HIP_TRY(ctx, hipMemcpy(ctx->d_rec1, rec.data(), d.nin * 4, hipMemcpyHostToDevice));
-  int32_t rc = b3w_batch_run_device(ctx, ctx->d_rec1, 1, ctx->d_body1, 0, nullptr, ctx->d_status1, nullptr);
-  if (rc) return rc;
-  int32_t st = 0;
-  HIP_TRY(ctx, hipMemcpy(&st, ctx->d_status1, 4, hipMemcpyDeviceToHost));
-  if (st != 0) {
-    ctx->last_error = st == B3W_E_ASSERT_FAILED ? "Assert Failed.\n" : "input outside the device fast-path domain";
-    return st;
+  if (canonical) {
+    // canonical u32 record: the batch kernel with n = 1
+    HIP_TRY(ctx, hipMemcpy(ctx->d_rec1, rec.data(), d.nin * 4, hipMemcpyHostToDevice));
+    int32_t rc = b3w_batch_run_device(ctx, ctx->d_rec1, 1, ctx->d_body1, 0, nullptr, ctx->d_status1, nullptr);
+    if (rc) return rc;
+    int32_t st = 0;
+    HIP_TRY(ctx, hipMemcpy(&st, ctx->d_status1, 4, hipMemcpyDeviceToHost));
+    if (st == 0) {
+      HIP_TRY(ctx, hipMemcpy(out_body, ctx->d_body1, (size_t)d.nwit * 32, hipMemcpyDeviceToHost));
+      return B3W_OK;
+    }
+    // rejected or outside the fast-path domain: the exact kernel decides and names the assert
+  }
+  // field-element inputs: the exact kernel (b3w_exact.hip), still on the device
+  HIP_TRY(ctx, hipMemcpy(ctx->d_fe_inputs, fe.data(), fe.size(), hipMemcpyHostToDevice));
+  int rc = b3w_launch_exact(d.kind != B3W_KIND_COMP, ctx->d_fe_inputs, ctx->d_prime, ctx->d_exact_table, d.nwit,
+                            ctx->d_body1, ctx->d_status2, nullptr);
+  if (rc) return hip_fail(ctx, (hipError_t)rc, "exact kernel launch");
+  uint32_t st2[2] = {0, 0};
+  HIP_TRY(ctx, hipMemcpy(st2, ctx->d_status2, 8, hipMemcpyDeviceToHost));
+  if (st2[0] != 0) {
+    ctx->last_error = std::string("Assert Failed.\n") + assert_site_text(st2[1], msg, sizeof msg);
+    return B3W_E_ASSERT_FAILED;
   }
   HIP_TRY(ctx, hipMemcpy(out_body, ctx->d_body1, (size_t)d.nwit * 32, hipMemcpyDeviceToHost));
   return B3W_OK;

@@ -16,3 +16,7 @@ extern "C" int b3w_launch_batch(int kind, int variant, const uint32_t *d_recs, u
                                 uint64_t pitch, const uint32_t *d_table, uint32_t nwit, uint32_t *d_pub,
                                 int32_t *d_status, const void *d_aux, uint32_t *d_scratch, uint32_t scratch_cap,
                                 hipStream_t stream);
+
+// b3w_exact.hip: one witness with arbitrary field-element inputs (full circom field semantics)
+extern "C" int b3w_launch_exact(int nova, const uint32_t *d_inputs, const uint32_t *d_prime, const uint32_t *d_table,
+                                uint32_t nwit, uint8_t *d_out, uint32_t *d_status, hipStream_t stream);

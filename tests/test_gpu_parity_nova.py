@@ -46,24 +46,20 @@ def test_nova_goldens_through_witness_calculator(m, circuit):
     g = T.golden(circuit)
     wc = m.builder(circuit)
     assert wc.witnessSize == T.NWIT[circuit] and wc.prime == T.PRIME[circuit]
-    nok = nassert = ndomain = 0
+    nok = nassert = nwild = 0
     for case in g["cases"]:
         canonical = T.is_canonical_u32(circuit, case["input"])
-        if not canonical:
-            with pytest.raises(m.B3WError) as e:
-                wc.calculateWTNSBin(case["input"], 0)
-            assert e.value.status == m.B3W_E_DOMAIN      # refused loudly, never computed elsewhere
-            ndomain += 1
-        elif "error" in case:
+        if "error" in case:
             with pytest.raises(m.B3WError, match="Assert Failed") as e:
                 wc.calculateWTNSBin(case["input"], 0)
             assert e.value.status == m.B3W_E_ASSERT_FAILED
             nassert += 1
         else:
-            img = wc.calculateWTNSBin(case["input"], 0)
+            img = wc.calculateWTNSBin(case["input"], 0)   # non-canonical inputs go through the exact device kernel
             assert T.sha256(img) == case["wtns_sha256"], case["name"]
             nok += 1
-    assert nok >= 70 and nassert >= 3 and ndomain >= 4
+            nwild += 0 if canonical else 1
+    assert nok >= 80 and nassert >= 6 and nwild >= 4
     for f in os.listdir(T.GOLD):
         if f.startswith(circuit + ".") and f.endswith(".wtns.gz"):
             case = next(c for c in g["cases"] if c["name"] == f[len(circuit) + 1:-len(".wtns.gz")])

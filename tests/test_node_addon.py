@@ -86,6 +86,7 @@ def test_js_surface_errors_and_batch(tmp_path):
     g = T.golden("compression")
     cases = [c for c in g["cases"] if "error" not in c and T.is_canonical_u32("compression", c["input"])][:8]
     (tmp_path / "cases.json").write_text(json.dumps(cases))
+    neg = next(c for c in g["cases"] if c["name"] == "m0_neg1")
     r = _node("""
       const builder = require('./hot-proofs-blake3-circom_amd/js/witness_calculator.js');
       const crypto = require('crypto'), fs = require('fs');
@@ -103,7 +104,9 @@ def test_js_surface_errors_and_batch(tmp_path):
         i = Object.assign({}, base, {m: base.m.slice(0, 15)}); await tryErr(i);
         i = Object.assign({}, base, {m: base.m.concat([1])}); await tryErr(i);
         i = Object.assign({}, base, {zz: 1}); await tryErr(i);
-        i = Object.assign({}, base, {m: ['-1'].concat(base.m.slice(1))}); await tryErr(i);
+        i = Object.assign({}, base, {h: ['4294967296'].concat(base.h.slice(1))}); await tryErr(i);
+        // a negative message word is accepted by the circuit (field-element path)
+        out.neg = crypto.createHash('sha256').update(await wc.calculateWTNSBin(JSON.parse(process.argv[2]), 0)).digest('hex');
         // batch extension on packed records
         const recs = new Uint32Array(28 * cases.length);
         cases.forEach((c, k) => { const v = [].concat(c.input.h, c.input.m, c.input.t, [c.input.b, c.input.d]); v.forEach((x, j) => recs[28 * k + j] = Number(x)); });
@@ -112,7 +115,7 @@ def test_js_surface_errors_and_batch(tmp_path):
                      body3: crypto.createHash('sha256').update(b.fetch(3)).digest('hex')};
         console.log(JSON.stringify(out));
       })().catch(e => { console.error(e); process.exit(1); });
-    """, str(tmp_path / "cases.json"))
+    """, str(tmp_path / "cases.json"), json.dumps(neg["input"]))
     assert r.returncode == 0, r.stderr
     out = json.loads(r.stdout.strip().splitlines()[-1])
     assert out["fields"] == [2, 8, 24093, str(T.BN254_R), 2]
@@ -122,7 +125,8 @@ def test_js_surface_errors_and_batch(tmp_path):
     assert out["errs"][1] == "Not enough values for input signal m\n"
     assert out["errs"][2] == "Too many values for input signal m\n"
     assert out["errs"][3] == "Too many values for input signal zz\n"
-    assert "fast-path domain" in out["errs"][4]
+    assert out["errs"][4].startswith("Error: Assert Failed.\n")
+    assert out["neg"] == neg["wtns_sha256"]
     assert out["batch"]["n"] == 8 and out["batch"]["status"] == [0] * 8
     assert out["batch"]["pub0"] == [str(x) for x in cases[0]["first16"][1:]] + [out["batch"]["pub0"][15]]
     assert out["batch"]["body3"] == cases[3]["body_sha256"]
