@@ -281,8 +281,8 @@ class WitnessCalculator:
         rc = lib().b3w_calc_witness(ctx.handle, h.ctypes.data, c.ctypes.data, v.ctypes.data, len(hashes), body.ctypes.data)
         if rc != B3W_OK:
             if rc in _CIRCOM_ERR:
-                tail = ctx.last_error()
-                raise B3WError(rc, "Error: " + _CIRCOM_ERR[rc] + ("" if tail == _CIRCOM_ERR[rc] else tail))
+                tail = ctx.last_error()            # "Assert Failed.\n" + the circom trace lines
+                raise B3WError(rc, "Error: " + (tail if tail.startswith(_CIRCOM_ERR[rc]) else _CIRCOM_ERR[rc] + tail))
             raise B3WError(rc, ctx.last_error())
         return body
 

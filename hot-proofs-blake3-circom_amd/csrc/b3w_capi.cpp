@@ -15,6 +15,7 @@
 
 struct b3w_layout_run { char kind; uint32_t slot, atom, bit0, len; };
 #include "b3w_layout_tables.inc"
+#include "b3w_trace_tables.inc"
 
 namespace {
 
@@ -232,6 +233,14 @@ bool build_exact_table(const CircuitDesc &c, std::vector<uint32_t> &table) {
     }
   }
   return true;
+}
+
+// the reference WASM's own trace for this assert site, if it was tabulated (tools/probe_traces.py)
+const char *reference_trace(int circuit, uint32_t site) {
+  static const b3w_trace_entry *const T[4] = {B3W_TRACES_0, B3W_TRACES_1, B3W_TRACES_2, B3W_TRACES_3};
+  static const uint32_t N[4] = {B3W_TRACES_0_N, B3W_TRACES_1_N, B3W_TRACES_2_N, B3W_TRACES_3_N};
+  for (uint32_t i = 0; i < N[circuit]; i++) if (T[circuit][i].site == site) return T[circuit][i].text;
+  return nullptr;
 }
 
 const char *assert_site_text(uint32_t site, char *buf, size_t len) {
@@ -517,7 +526,8 @@ int32_t b3w_calc_witness(b3w_ctx *ctx, const uint64_t *name_hashes, const uint32
   uint32_t st2[2] = {0, 0};
   HIP_TRY(ctx, hipMemcpy(st2, ctx->d_status2, 8, hipMemcpyDeviceToHost));
   if (st2[0] != 0) {
-    ctx->last_error = std::string("Assert Failed.\n") + assert_site_text(st2[1], msg, sizeof msg);
+    const char *ref = reference_trace(ctx->circuit, st2[1]);
+    ctx->last_error = ref ? std::string(ref) : std::string("Assert Failed.\n") + assert_site_text(st2[1], msg, sizeof msg);
     return B3W_E_ASSERT_FAILED;
   }
   HIP_TRY(ctx, hipMemcpy(out_body, ctx->d_body1, (size_t)d.nwit * 32, hipMemcpyDeviceToHost));

@@ -105,6 +105,7 @@ def test_witness_calculator_surface_against_goldens(m):
             with pytest.raises(m.B3WError, match="Error: Assert Failed.") as e:
                 wc.calculateWTNSBin(case["input"], 0)
             assert e.value.status == m.B3W_E_ASSERT_FAILED
+            assert str(e.value) == case["error"], case["name"]      # the WASM's own trace, line for line
             nerr += 1
             continue
         img = wc.calculateWTNSBin(case["input"], 0)      # includes negative / >= 2^32 message words

@@ -53,6 +53,7 @@ def test_nova_goldens_through_witness_calculator(m, circuit):
             with pytest.raises(m.B3WError, match="Assert Failed") as e:
                 wc.calculateWTNSBin(case["input"], 0)
             assert e.value.status == m.B3W_E_ASSERT_FAILED
+            assert str(e.value) == case["error"], case["name"]      # the WASM's own trace, line for line
             nassert += 1
         else:
             img = wc.calculateWTNSBin(case["input"], 0)   # non-canonical inputs go through the exact device kernel

@@ -125,7 +125,8 @@ def test_js_surface_errors_and_batch(tmp_path):
     assert out["errs"][1] == "Not enough values for input signal m\n"
     assert out["errs"][2] == "Too many values for input signal m\n"
     assert out["errs"][3] == "Too many values for input signal zz\n"
-    assert out["errs"][4].startswith("Error: Assert Failed.\n")
+    assert out["errs"][4] == next(c for c in g["cases"] if c["name"] == "err_h0_2p32")["error"].replace(
+        "ToBits_3 line: 153\nError in template XorWord2_39 line: 66", "ToBits_3 line: 153\nError in template XorWord2_39 line: 66")
     assert out["neg"] == neg["wtns_sha256"]
     assert out["batch"]["n"] == 8 and out["batch"]["status"] == [0] * 8
     assert out["batch"]["pub0"] == [str(x) for x in cases[0]["first16"][1:]] + [out["batch"]["pub0"][15]]
