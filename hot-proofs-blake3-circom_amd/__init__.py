@@ -84,6 +84,12 @@ def lib():
         "b3w_batch_fetch": (i32, [vp, u32, vp]),
         "b3w_batch_device_ptr": (vp, [vp, ctypes.POINTER(u64)]),
         "b3w_batch_time_device": (i32, [vp, vp, u32, vp, u64, vp, vp, vp, u32, ctypes.POINTER(ctypes.c_float)]),
+        "b3w_chain_num_chunks": (u64, [u64]),
+        "b3w_chain_num_leaf_steps": (u64, [u64]),
+        "b3w_chain_path_len": (u32, [u64, u64]),
+        "b3w_chain_plan_leaves_device": (i32, [vp, vp, u64, u64, u32, vp, vp, vp]),
+        "b3w_chain_tree_device": (i32, [vp, vp, u64, vp, vp]),
+        "b3w_chain_plan_parents_device": (i32, [vp, vp, u64, u64, u64, u32, vp, vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)
@@ -96,7 +102,8 @@ EXPORTED_SYMBOLS = ("b3w_abi_version", "b3w_identify_wasm", "b3w_create", "b3w_d
                     "b3w_input_signal_size", "b3w_calc_witness", "b3w_write_wtns_header", "b3w_last_error",
                     "b3w_batch_run_device", "b3w_public_words", "b3w_batch_alloc", "b3w_batch_free",
                     "b3w_batch_run", "b3w_batch_outputs", "b3w_batch_fetch", "b3w_batch_device_ptr",
-                    "b3w_batch_time_device")
+                    "b3w_batch_time_device", "b3w_chain_num_chunks", "b3w_chain_num_leaf_steps", "b3w_chain_path_len",
+                    "b3w_chain_plan_leaves_device", "b3w_chain_tree_device", "b3w_chain_plan_parents_device")
 
 
 def fnv_hash(name):
@@ -188,6 +195,60 @@ class Context:
         if rc != B3W_OK:
             raise B3WError(rc, f"b3w_batch_time_device: status {rc}: {self.last_error()}")
         return ms.value
+
+
+class ChainPlanner:
+    """Chained-mode step-input planner over torch device tensors (b3w_chain_*): the device counterpart
+    of rust_fold's format_input / update_for_step / hash_with_path for ALL chunks of a preimage."""
+
+    def __init__(self, ctx):
+        self.ctx = ctx
+
+    def _chk(self, rc, what):
+        if rc != B3W_OK:
+            raise B3WError(rc, f"{what}: status {rc}: {self.ctx.last_error()}")
+
+    def plan(self, d_preimage, with_parents=True, first_chunk=0, n_chunks_local=None, stream=0):
+        """d_preimage: uint8 CUDA tensor holding the WHOLE preimage.  Returns a dict with
+        records (int32 [n_steps, 32]: leaf steps of the local chunks, then their parent steps),
+        n_leaf_steps, chunk_cvs (all chunks), root (8 words), n_chunks, path_len."""
+        import torch
+        L = lib()
+        ln = d_preimage.numel()
+        dev = d_preimage.device
+        n = L.b3w_chain_num_chunks(ln)
+        nl = n - first_chunk if n_chunks_local is None else n_chunks_local
+        last_local = first_chunk + nl == n
+        last_blocks = (max(ln - (n - 1) * 1024, 1) + 63) // 64
+        n_leaf = nl * 16 - ((16 - last_blocks) if last_local else 0)
+        P = L.b3w_chain_path_len(0, n)
+        complete = (n & (n - 1)) == 0
+        n_par = nl * P if (with_parents and complete) else 0
+        recs = torch.zeros((nl * 16 + n_par, 32), dtype=torch.int32, device=dev)
+        levels = torch.zeros(((2 * n + 64) * 8,), dtype=torch.int32, device=dev)
+        root = torch.zeros(8, dtype=torch.int32, device=dev)
+        s = stream or None
+        # chunk CVs of ALL chunks are needed for the tree (a multi-GPU job all-gathers them instead)
+        allrecs = recs if (first_chunk == 0 and nl == n) else None
+        if allrecs is None:
+            tmp = torch.zeros((n * 16, 32), dtype=torch.int32, device=dev)
+            self._chk(L.b3w_chain_plan_leaves_device(self.ctx.handle, d_preimage.data_ptr(), ln, 0, n, tmp.data_ptr(),
+                                                     levels.data_ptr(), s), "plan_leaves")
+            recs[:nl * 16] = tmp[first_chunk * 16:(first_chunk + nl) * 16]
+        else:
+            self._chk(L.b3w_chain_plan_leaves_device(self.ctx.handle, d_preimage.data_ptr(), ln, 0, n, recs.data_ptr(),
+                                                     levels.data_ptr(), s), "plan_leaves")
+        self._chk(L.b3w_chain_tree_device(self.ctx.handle, levels.data_ptr(), n, root.data_ptr(), s), "tree")
+        if n_par:
+            self._chk(L.b3w_chain_plan_parents_device(self.ctx.handle, levels.data_ptr(), n, ln, first_chunk, nl,
+                                                      recs[nl * 16:].data_ptr(), s), "plan_parents")
+        # drop the unused record slots of a partial last chunk
+        if last_local and last_blocks < 16:
+            keep = torch.ones(recs.shape[0], dtype=torch.bool, device=dev)
+            keep[(nl - 1) * 16 + last_blocks: nl * 16] = False
+            recs = recs[keep].contiguous()
+        return dict(records=recs, n_leaf_steps=n_leaf, n_parent_steps=n_par, chunk_cvs=levels[:n * 8].view(n, 8),
+                    root=root, n_chunks=n, path_len=P, complete=complete, last_blocks=last_blocks)
 
 
 class Batch:

@@ -594,4 +594,68 @@ void *b3w_batch_device_ptr(b3w_batch *b, uint64_t *pitch) {
   return b->d_bodies;
 }
 
+// ---------------------------------------------------------------- chained mode planner
+uint64_t b3w_chain_num_chunks(uint64_t len) { return len ? (len + 1023) / 1024 : 1; }
+uint64_t b3w_chain_num_leaf_steps(uint64_t len) { return len ? (len + 63) / 64 : 1; }
+uint32_t b3w_chain_path_len(uint64_t chunk, uint64_t n_chunks) { return b3w_plan_path_len(chunk, n_chunks); }
+
+int32_t b3w_chain_plan_leaves_device(b3w_ctx *ctx, const uint8_t *d_preimage, uint64_t preimage_len, uint64_t first_chunk,
+                                     uint32_t n_chunks_local, uint32_t *d_records, uint32_t *d_chunk_cvs, void *stream) {
+  if (!ctx || !d_preimage || !d_records || !d_chunk_cvs) return B3W_E_BAD_ARGUMENT;
+  const uint64_t n = b3w_chain_num_chunks(preimage_len);
+  if (first_chunk + n_chunks_local > n) { ctx->last_error = "chunk range exceeds the preimage"; return B3W_E_BAD_ARGUMENT; }
+  int rc = b3w_launch_plan_leaves(d_preimage, preimage_len, first_chunk, n_chunks_local, n, d_records, d_chunk_cvs, (hipStream_t)stream);
+  return rc ? hip_fail(ctx, (hipError_t)rc, "plan leaves launch") : B3W_OK;
+}
+
+int32_t b3w_chain_tree_device(b3w_ctx *ctx, uint32_t *d_levels, uint64_t n_chunks, uint32_t *d_root, void *stream) {
+  if (!ctx || !d_levels || !d_root || !n_chunks) return B3W_E_BAD_ARGUMENT;
+  hipStream_t st = (hipStream_t)stream;
+  if (n_chunks == 1) {
+    HIP_TRY(ctx, hipMemcpyAsync(d_root, d_levels, 32, hipMemcpyDeviceToDevice, st));
+    return B3W_OK;
+  }
+  // level by level; an odd node out at the end of a level is a complete subtree that waits ("carry")
+  std::vector<const uint32_t *> carries;            // in order of increasing subtree size
+  uint32_t *level = d_levels;
+  uint64_t count = n_chunks;
+  while (count > 1) {
+    const uint64_t pairs = count / 2;
+    if (count & 1) carries.push_back(level + (count - 1) * 8);
+    uint32_t *next = level + count * 8;
+    const bool root = pairs == 1 && carries.empty() && count == 2;
+    int rc = b3w_launch_plan_merge(level, level + 8, 16, pairs, root ? 1u : 0u, root ? d_root : next, st);
+    if (rc) return hip_fail(ctx, (hipError_t)rc, "plan merge launch");
+    if (root) return B3W_OK;
+    level = next;
+    count = pairs;
+  }
+  // root = P(main, P(carry_k, ... P(carry_2, carry_1)))  — BLAKE3's right-leaning chain of complete subtrees
+  uint32_t *scratch = d_levels + 2 * n_chunks * 8;
+  const uint32_t *right = carries[0];
+  for (size_t i = 1; i < carries.size(); i++) {
+    int rc = b3w_launch_plan_merge(carries[i], right, 0, 1, 0u, scratch, st);
+    if (rc) return hip_fail(ctx, (hipError_t)rc, "plan merge launch");
+    right = scratch;
+    scratch += 8;
+  }
+  int rc = b3w_launch_plan_merge(level, right, 0, 1, 1u, d_root, st);
+  return rc ? hip_fail(ctx, (hipError_t)rc, "plan merge launch") : B3W_OK;
+}
+
+int32_t b3w_chain_plan_parents_device(b3w_ctx *ctx, const uint32_t *d_levels, uint64_t n_chunks, uint64_t preimage_len,
+                                      uint64_t first_chunk, uint32_t n_chunks_local, uint32_t *d_records, void *stream) {
+  if (!ctx || !d_levels || !d_records) return B3W_E_BAD_ARGUMENT;
+  if (n_chunks != b3w_chain_num_chunks(preimage_len) || (n_chunks & (n_chunks - 1)) || first_chunk + n_chunks_local > n_chunks) {
+    ctx->last_error = "parent steps need a complete tree: n_chunks must be a power of two and match the preimage";
+    return B3W_E_BAD_ARGUMENT;
+  }
+  uint32_t P = 0;
+  while ((1ull << P) < n_chunks) P++;
+  const uint64_t last_bytes = preimage_len - (n_chunks - 1) * 1024;
+  const uint32_t last_blocks = last_bytes ? (uint32_t)((last_bytes + 63) / 64) : 1;
+  int rc = b3w_launch_plan_parents(d_levels, n_chunks, P, first_chunk, n_chunks_local, last_blocks, d_records, (hipStream_t)stream);
+  return rc ? hip_fail(ctx, (hipError_t)rc, "plan parents launch") : B3W_OK;
+}
+
 }  // extern "C"

@@ -20,3 +20,12 @@ extern "C" int b3w_launch_batch(int kind, int variant, const uint32_t *d_recs, u
 // b3w_exact.hip: one witness with arbitrary field-element inputs (full circom field semantics)
 extern "C" int b3w_launch_exact(int nova, const uint32_t *d_inputs, const uint32_t *d_prime, const uint32_t *d_table,
                                 uint32_t nwit, uint8_t *d_out, uint32_t *d_status, hipStream_t stream);
+
+// b3w_plan.hip: chained-mode step-input planner
+extern "C" uint32_t b3w_plan_path_len(uint64_t chunk, uint64_t nchunks);
+extern "C" int b3w_launch_plan_leaves(const uint8_t *d_pre, uint64_t total_len, uint64_t first_chunk, uint32_t nlocal,
+                                      uint64_t nchunks, uint32_t *d_recs, uint32_t *d_chunk_cv, hipStream_t stream);
+extern "C" int b3w_launch_plan_merge(const uint32_t *d_left, const uint32_t *d_right, uint32_t stride_words, uint64_t npairs,
+                                     uint32_t root, uint32_t *d_parents, hipStream_t stream);
+extern "C" int b3w_launch_plan_parents(const uint32_t *d_levels, uint64_t nchunks, uint32_t P, uint64_t first_chunk,
+                                       uint32_t nlocal, uint32_t last_chunk_blocks, uint32_t *d_recs, hipStream_t stream);

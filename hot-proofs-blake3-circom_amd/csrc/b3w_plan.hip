@@ -1,0 +1,191 @@
+// b3w_plan.hip — step-input planner for chained ("nova fold") mode, on the device.
+//
+// The reference folds ONE chunk path per proof, sequentially: every step's inputs come from the
+// previous step's outputs (rust_fold/src/main.rs:166-179; Blake3BlockCompressCircuit::format_input /
+// update_for_step, rust_fold/src/blake3_circuit.rs:160-289; sibling CVs from bao in
+// rust_fold/src/blake3_hash.rs:17-93).  The chaining value is plain BLAKE3, so a native pre-pass
+// produces the input record of EVERY step up front and all step witnesses become independent
+// (SURVEY.md §3.3): that is what these kernels do, for all chunks of a preimage at once.
+//
+//   b3w_plan_leaf_kernel    one thread per 1 KiB chunk: walks its <= 16 blocks, emits one nova step
+//                           record per block (n_blocks, block_count, h = running CV, chunk index,
+//                           depths, message words, b) and the chunk's chaining value
+//   b3w_plan_merge_kernel   one tree level: parent CV = compress(IV, left || right, PARENT [| ROOT])
+//   b3w_plan_parent_kernel  complete trees: one thread per (chunk, height): the parent step record
+//                           (h = own subtree CV, m[0..7] = sibling CV, depth) — what format_input
+//                           builds from PathNode for the steps after the leaf blocks
+//
+// Record layout = the batch input format of the nova kernels (b3wit.h).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "b3w_kernels.h"
+
+namespace {
+
+__device__ __forceinline__ uint32_t rotr(uint32_t x, int r) { return (x >> r) | (x << (32 - r)); }
+
+#define B3_G(a, b, c, d, x, y)                                       \
+  v[a] = v[a] + v[b] + (x); v[d] = rotr(v[d] ^ v[a], 16);            \
+  v[c] = v[c] + v[d];       v[b] = rotr(v[b] ^ v[c], 12);            \
+  v[a] = v[a] + v[b] + (y); v[d] = rotr(v[d] ^ v[a], 8);             \
+  v[c] = v[c] + v[d];       v[b] = rotr(v[b] ^ v[c], 7);
+
+// plain BLAKE3 compression, first 8 output words (BLAKE3 spec 2.2; the circuit's Blake3Compression
+// computes the same function, circuits/blake3_compression.circom:171-228)
+__device__ void blake3_cv(const uint32_t h[8], const uint32_t m_in[16], uint32_t t0, uint32_t t1, uint32_t b, uint32_t d,
+                          uint32_t out[8]) {
+  uint32_t v[16], m[16];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) v[i] = h[i];
+  v[8] = 0x6A09E667u; v[9] = 0xBB67AE85u; v[10] = 0x3C6EF372u; v[11] = 0xA54FF53Au;
+  v[12] = t0; v[13] = t1; v[14] = b; v[15] = d;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) m[i] = m_in[i];
+#pragma unroll
+  for (int r = 0; r < 7; ++r) {
+    B3_G(0, 4, 8, 12, m[0], m[1]) B3_G(1, 5, 9, 13, m[2], m[3]) B3_G(2, 6, 10, 14, m[4], m[5]) B3_G(3, 7, 11, 15, m[6], m[7])
+    B3_G(0, 5, 10, 15, m[8], m[9]) B3_G(1, 6, 11, 12, m[10], m[11]) B3_G(2, 7, 8, 13, m[12], m[13]) B3_G(3, 4, 9, 14, m[14], m[15])
+    const uint32_t t[16] = {m[2], m[6], m[3], m[10], m[7], m[0], m[4], m[13], m[1], m[11], m[12], m[5], m[9], m[14], m[15], m[8]};
+#pragma unroll
+    for (int i = 0; i < 16; ++i) m[i] = t[i];
+  }
+#pragma unroll
+  for (int i = 0; i < 8; ++i) out[i] = v[i] ^ v[i + 8];
+}
+
+__device__ __forceinline__ void iv(uint32_t h[8]) {
+  h[0] = 0x6A09E667u; h[1] = 0xBB67AE85u; h[2] = 0x3C6EF372u; h[3] = 0xA54FF53Au;
+  h[4] = 0x510E527Fu; h[5] = 0x9B05688Cu; h[6] = 0x1F83D9ABu; h[7] = 0x5BE0CD19u;
+}
+
+// number of parent nodes above chunk c in BLAKE3's tree over n chunks (left subtree = largest power
+// of two strictly below n)
+__host__ __device__ inline uint32_t path_len(uint64_t c, uint64_t n) {
+  uint32_t p = 0;
+  while (n > 1) {
+    uint64_t k = 1;
+    while (k * 2 < n) k *= 2;
+    if (c < k) n = k; else { c -= k; n -= k; }
+    p++;
+  }
+  return p;
+}
+
+__global__ __launch_bounds__(64) void b3w_plan_leaf_kernel(const uint8_t *__restrict__ pre /* at chunk first_chunk */,
+                                                           uint64_t total_len, uint64_t first_chunk, uint32_t nlocal,
+                                                           uint64_t nchunks, uint32_t *__restrict__ recs,
+                                                           uint32_t *__restrict__ chunk_cv) {
+  const uint32_t i = blockIdx.x * 64 + threadIdx.x;
+  if (i >= nlocal) return;
+  const uint64_t c = first_chunk + i;
+  const uint64_t off = c * 1024;
+  const uint32_t bytes = (uint32_t)(total_len - off < 1024 ? total_len - off : 1024);
+  const uint32_t n_blocks = bytes ? (bytes + 63) / 64 : 1;
+  const uint32_t P = path_len(c, nchunks);
+  const uint8_t *src = pre + (uint64_t)i * 1024;
+  uint32_t *rec = recs + (uint64_t)i * 16 * 32;          // chunks before the last are full: 16 steps each
+  uint32_t h[8];
+  iv(h);
+  for (uint32_t j = 0; j < n_blocks; ++j) {
+    const uint32_t bb = bytes - j * 64 < 64 ? bytes - j * 64 : 64;
+    uint32_t m[16];
+    if (bb == 64 && ((uintptr_t)src & 3) == 0) {
+#pragma unroll
+      for (int k = 0; k < 16; ++k) m[k] = reinterpret_cast<const uint32_t *>(src + j * 64)[k];
+    } else {
+#pragma unroll
+      for (int k = 0; k < 16; ++k) {
+        uint32_t w = 0;
+        for (int q = 0; q < 4; ++q) { const uint32_t p = k * 4 + q; if (p < bb) w |= (uint32_t)src[j * 64 + p] << (8 * q); }
+        m[k] = w;
+      }
+    }
+    uint32_t *r = rec + j * 32;
+    r[0] = n_blocks; r[1] = j;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) r[2 + k] = h[k];
+    r[10] = (uint32_t)c; r[11] = (uint32_t)(c >> 32);
+    r[12] = P + 1; r[13] = P + 1; r[14] = P;              // leaf_depth, total_depth, depth (blake3_circuit.rs:83-110)
+#pragma unroll
+    for (int k = 0; k < 16; ++k) r[15 + k] = m[k];
+    r[31] = bb;
+    // flags as Blake3GetFlag assigns them (circuits/blake3_nova.circom:122-167)
+    const uint32_t last = j == n_blocks - 1;
+    const uint32_t d = (j == 0 ? 1u : 0u) | (last ? 2u : 0u) | ((last && P == 0) ? 8u : 0u);
+    uint32_t o[8];
+    blake3_cv(h, m, (uint32_t)c, (uint32_t)(c >> 32), bb, d, o);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) h[k] = o[k];
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) chunk_cv[(uint64_t)i * 8 + k] = h[k];
+}
+
+// parents[i] = compress(IV, child[2i] || child[2i+1], t = 0, b = 64, PARENT | (root ? ROOT : 0))
+__global__ __launch_bounds__(64) void b3w_plan_merge_kernel(const uint32_t *__restrict__ left, const uint32_t *__restrict__ right,
+                                                            uint32_t stride_words, uint64_t npairs, uint32_t root,
+                                                            uint32_t *__restrict__ parents) {
+  const uint64_t i = (uint64_t)blockIdx.x * 64 + threadIdx.x;
+  if (i >= npairs) return;
+  uint32_t h[8], m[16], o[8];
+  iv(h);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { m[k] = left[i * stride_words + k]; m[8 + k] = right[i * stride_words + k]; }
+  blake3_cv(h, m, 0, 0, 64, 4u | (root ? 8u : 0u), o);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) parents[i * 8 + k] = o[k];
+}
+
+// complete tree over nchunks = 2^P chunks; levels[] = concatenated level arrays (level 0 = chunk CVs at
+// word offset 0, level j at level_off[j]); one thread per (local chunk, height j < P)
+__global__ __launch_bounds__(64) void b3w_plan_parent_kernel(const uint32_t *__restrict__ levels, uint64_t nchunks, uint32_t P,
+                                                             uint64_t first_chunk, uint32_t nlocal, uint32_t last_chunk_blocks,
+                                                             uint32_t *__restrict__ recs) {
+  const uint64_t i = (uint64_t)blockIdx.x * 64 + threadIdx.x;
+  if (i >= (uint64_t)nlocal * P) return;
+  const uint32_t j = (uint32_t)(i % P);
+  const uint64_t c = first_chunk + i / P;
+  uint64_t off = 0, cnt = nchunks;                       // word offset of level j
+  for (uint32_t l = 0; l < j; ++l) { off += cnt * 8; cnt >>= 1; }
+  const uint64_t node = c >> j;
+  const uint32_t *own = levels + off + node * 8, *sib = levels + off + (node ^ 1) * 8;
+  const uint32_t n_blocks = (c == nchunks - 1) ? last_chunk_blocks : 16;
+  uint32_t *r = recs + i * 32;
+  r[0] = n_blocks; r[1] = n_blocks;                      // block_count stays at n_blocks on parent steps (:251)
+#pragma unroll
+  for (int k = 0; k < 8; ++k) r[2 + k] = own[k];
+  r[10] = (uint32_t)c; r[11] = (uint32_t)(c >> 32);
+  r[12] = P + 1; r[13] = P + 1; r[14] = P - 1 - j;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) { r[15 + k] = sib[k]; r[23 + k] = 0; }     // sibling CV, then zeros (blake3_circuit.rs:230-245)
+  r[31] = 64;
+}
+
+}  // namespace
+
+extern "C" uint32_t b3w_plan_path_len(uint64_t chunk, uint64_t nchunks) { return path_len(chunk, nchunks); }
+
+extern "C" int b3w_launch_plan_leaves(const uint8_t *d_pre, uint64_t total_len, uint64_t first_chunk, uint32_t nlocal,
+                                      uint64_t nchunks, uint32_t *d_recs, uint32_t *d_chunk_cv, hipStream_t stream) {
+  if (!nlocal) return 0;
+  hipLaunchKernelGGL(b3w_plan_leaf_kernel, dim3((nlocal + 63) / 64), dim3(64), 0, stream, d_pre, total_len, first_chunk, nlocal,
+                     nchunks, d_recs, d_chunk_cv);
+  return (int)hipGetLastError();
+}
+
+extern "C" int b3w_launch_plan_merge(const uint32_t *d_left, const uint32_t *d_right, uint32_t stride_words, uint64_t npairs,
+                                     uint32_t root, uint32_t *d_parents, hipStream_t stream) {
+  if (!npairs) return 0;
+  hipLaunchKernelGGL(b3w_plan_merge_kernel, dim3((uint32_t)((npairs + 63) / 64)), dim3(64), 0, stream, d_left, d_right,
+                     stride_words, npairs, root, d_parents);
+  return (int)hipGetLastError();
+}
+
+extern "C" int b3w_launch_plan_parents(const uint32_t *d_levels, uint64_t nchunks, uint32_t P, uint64_t first_chunk,
+                                       uint32_t nlocal, uint32_t last_chunk_blocks, uint32_t *d_recs, hipStream_t stream) {
+  const uint64_t total = (uint64_t)nlocal * P;
+  if (!total) return 0;
+  hipLaunchKernelGGL(b3w_plan_parent_kernel, dim3((uint32_t)((total + 63) / 64)), dim3(64), 0, stream, d_levels, nchunks, P,
+                     first_chunk, nlocal, last_chunk_blocks, d_recs);
+  return (int)hipGetLastError();
+}

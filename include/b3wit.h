@@ -123,6 +123,35 @@ int32_t b3w_batch_time_device(b3w_ctx *ctx, const uint32_t *d_records, uint32_t 
                               uint64_t pitch, uint32_t *d_public, int32_t *d_status, void *stream,
                               uint32_t iters, float *avg_ms);
 
+/* ---- chained ("nova fold") mode: step-input planner -----------------------------------------
+ * Device counterpart of the reference's per-step input construction: Blake3BlockCompressCircuit::
+ * {new, update_for_step, format_input} (rust_fold/src/blake3_circuit.rs:160-289), Blake3CompressPubIO::new
+ * (:83-110) and the sibling-CV extraction of hash_with_path (rust_fold/src/blake3_hash.rs:17-93).
+ * Because the chaining value is plain BLAKE3, the records of ALL steps of ALL chunks are produced
+ * by a native pre-pass and every step witness becomes independent (b3w_batch_run_device on the
+ * records).  Records use the nova batch input format.  All pointers are device pointers. */
+uint64_t b3w_chain_num_chunks(uint64_t preimage_len);       /* ceil(len / 1024), at least 1 */
+uint64_t b3w_chain_num_leaf_steps(uint64_t preimage_len);   /* total number of 64-byte blocks */
+uint32_t b3w_chain_path_len(uint64_t chunk, uint64_t n_chunks); /* parents above `chunk` in BLAKE3's tree */
+
+/* Leaf steps of chunks [first_chunk, first_chunk + n_chunks_local): 16 records per chunk (fewer for the
+ * last, partial chunk), record j of chunk c at d_records + ((c - first_chunk)*16 + j)*32 words; the chunk
+ * chaining values (8 words each) go to d_chunk_cvs.  d_preimage points at byte first_chunk*1024. */
+int32_t b3w_chain_plan_leaves_device(b3w_ctx *ctx, const uint8_t *d_preimage, uint64_t preimage_len, uint64_t first_chunk,
+                                     uint32_t n_chunks_local, uint32_t *d_records, uint32_t *d_chunk_cvs, void *stream);
+
+/* BLAKE3 tree over n_chunks chunk CVs.  d_levels: (2*n_chunks + 64) * 8 words; the caller fills level 0
+ * (words [0, 8*n_chunks)) with the chunk CVs, level j+1 follows level j.  d_root receives the root
+ * chaining value = the BLAKE3 hash words (for n_chunks == 1 the chunk CV already is the root). */
+int32_t b3w_chain_tree_device(b3w_ctx *ctx, uint32_t *d_levels, uint64_t n_chunks, uint32_t *d_root, void *stream);
+
+/* Parent steps of chunks [first_chunk, +n_chunks_local) of a COMPLETE tree (n_chunks a power of two —
+ * the shape the reference circuit's left/right selection from chunk_idx bits is valid for):
+ * log2(n_chunks) records per chunk, record j (height j, depth = log2(n)-1-j) of chunk c at
+ * d_records + ((c - first_chunk)*log2(n) + j)*32 words. */
+int32_t b3w_chain_plan_parents_device(b3w_ctx *ctx, const uint32_t *d_levels, uint64_t n_chunks, uint64_t preimage_len,
+                                      uint64_t first_chunk, uint32_t n_chunks_local, uint32_t *d_records, void *stream);
+
 #ifdef __cplusplus
 }
 #endif

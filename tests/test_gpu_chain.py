@@ -1,0 +1,111 @@
+"""Chained ("nova fold") mode: the device planner produces every step's input record from the preimage;
+the nova kernels turn them into witnesses.  Checked the way the reference's Rust tests check the fold
+(rust_fold/src/main.rs:414-539: "h_out after all steps == BLAKE3(input)") plus step-to-step chaining
+and oracle parity of sampled bodies."""
+import numpy as np
+import pytest
+import b3w_testlib as T
+import blake3_ref as B
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(m, data, circuit="nova_vesta"):
+    import torch
+    dev = torch.device("cuda:0")
+    ctx = m.Context(circuit, 0)
+    d_pre = torch.from_numpy(np.frombuffer(bytes(data), dtype=np.uint8).copy()).to(dev)
+    plan = m.ChainPlanner(ctx).plan(d_pre)
+    recs = plan["records"]
+    n = recs.shape[0]
+    d_bodies = torch.empty((n, ctx.body_bytes), dtype=torch.uint8, device=dev)
+    d_pub = torch.zeros((n, 15), dtype=torch.int32, device=dev)
+    d_st = torch.full((n,), -1, dtype=torch.int32, device=dev)
+    ctx.run_device(recs.data_ptr(), n, d_bodies.data_ptr(), 0, d_pub.data_ptr(), d_st.data_ptr(),
+                   torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    return ctx, plan, recs.cpu().numpy().view(np.uint32), d_pub.cpu().numpy().view(np.uint32), d_st.cpu().numpy(), d_bodies
+
+
+def _check_chain(data, plan, recs, pub, st):
+    assert (st == 0).all()
+    n_leaf, n_chunks, P = plan["n_leaf_steps"], plan["n_chunks"], plan["path_len"]
+    cvs = plan["chunk_cvs"].cpu().numpy().view(np.uint32)
+    root = plan["root"].cpu().numpy().view(np.uint32)
+    assert list(root) == B.hash_words(data), "tree root != BLAKE3(preimage)"
+    # leaf steps: step j of chunk c feeds step j+1 (z_{i+1} = public outputs of step i, blake3_circuit.rs:111-123)
+    s = 0
+    for c in range(n_chunks):
+        nb = recs[s, 0]
+        for j in range(nb):
+            r, o = recs[s + j], pub[s + j]
+            assert r[1] == j and r[10] == c and o[0] == nb and o[1] == j + 1
+            if j + 1 < nb:
+                assert np.array_equal(o[2:10], recs[s + j + 1][2:10]), (c, j)
+                assert o[11] == r[14]                     # depth unchanged inside the chunk
+            else:
+                assert np.array_equal(o[2:10], cvs[c]), c   # chunk chaining value
+                assert o[11] == (r[14] - 1 if r[14] > 0 else 0)
+        s += nb
+    assert s == n_leaf
+    if n_chunks == 1:
+        assert np.array_equal(pub[n_leaf - 1][2:10], root)
+    if plan["n_parent_steps"]:
+        for c in range(n_chunks):
+            base = n_leaf + c * P
+            for j in range(P):
+                r, o = recs[base + j], pub[base + j]
+                assert r[14] == P - 1 - j and r[31] == 64 and (r[23:31] == 0).all()
+                if j + 1 < P:
+                    assert np.array_equal(o[2:10], recs[base + j + 1][2:10]), (c, j)
+                else:
+                    assert np.array_equal(o[2:10], root), c   # the fold's final h_out == BLAKE3(input)
+                    assert o[11] == 0
+
+
+@pytest.mark.parametrize("data", [bytes(4), bytes([117]) * 17, bytes(68), bytes(1024), bytes(1028), bytes(1024 * 3 + 5),
+                                  bytes(range(256)) * 8, bytes(range(251)) * 33],
+                         ids=["zero4", "b117x17", "zero68", "zero1024", "zero1028", "zero3077", "2048", "8283"])
+def test_reference_rust_test_shapes(data):
+    """The inputs of rust_fold/src/main.rs:478-539 (+ two more): every chunk's path at once."""
+    m = T.pkg()
+    ctx, plan, recs, pub, st, d_bodies = _run(m, data)
+    _check_chain(data, plan, recs, pub, st)
+    # sampled bodies against the oracle
+    idx = sorted(set([0, recs.shape[0] // 2, recs.shape[0] - 1]))
+    _, want = T.oracle_batch_u32("nova_vesta", recs[idx])
+    for k, i in enumerate(idx):
+        assert np.array_equal(d_bodies[i].cpu().numpy(), want[k]), i
+    ctx.close()
+
+
+@pytest.mark.parametrize("nbytes", [3 * 1024, 5 * 1024 + 1, 6 * 1024, 7 * 1024 - 3, 100 * 1024 + 77, 1])
+def test_tree_root_for_any_chunk_count(nbytes):
+    """Incomplete trees: leaf steps + tree root only (the reference circuit's left/right selection
+    from chunk_idx bits is valid for complete trees; parent steps are planned only there)."""
+    m = T.pkg()
+    rng = np.random.default_rng(nbytes)
+    data = rng.integers(0, 256, nbytes, dtype=np.uint8).tobytes()
+    ctx, plan, recs, pub, st, _ = _run(m, data, "nova_bn254")
+    assert plan["n_parent_steps"] == (0 if not plan["complete"] else plan["n_chunks"] * plan["path_len"])
+    _check_chain(data, plan, recs, pub, st)
+    ctx.close()
+
+
+def test_config4_one_mib_preimage():
+    """BASELINE config 4: 1 MiB preimage = LE stream of LCG(1): 1 024 chunks x 16 blocks = 16 384 leaf steps
+    + 10 parent steps per chunk path, leaf_depth = total_depth = 11."""
+    m = T.pkg()
+    W = T.workloads()
+    lcg = W.LCG(1)
+    words = np.array([lcg.next() for _ in range(1 << 18)], dtype=np.uint32)
+    data = words.tobytes()
+    ctx, plan, recs, pub, st, d_bodies = _run(m, data)
+    assert plan["n_leaf_steps"] == 16384 and plan["n_parent_steps"] == 10240 and plan["path_len"] == 10
+    assert (recs[:16384, 12] == 11).all() and (recs[:16384, 13] == 11).all() and (recs[:16384, 14] == 10).all()
+    _check_chain(data, plan, recs, pub, st)
+    idx = np.array([0, 15, 16, 8191, 16383, 16384, 16393, 20000, 26623])
+    _, want = T.oracle_batch_u32("nova_vesta", recs[idx])
+    for k, i in enumerate(idx):
+        assert np.array_equal(d_bodies[int(i)].cpu().numpy(), want[k]), i
+    ctx.close()
