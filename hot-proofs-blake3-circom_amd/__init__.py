@@ -20,9 +20,9 @@ from . import workloads  # noqa: F401
 
 
 def __getattr__(name):
-    if name == "sharding":          # imports torch.distributed: load on demand
+    if name in ("sharding", "chain"):  # import torch.distributed: load on demand
         import importlib
-        return importlib.import_module(__name__ + ".sharding")
+        return importlib.import_module(__name__ + "." + name)
     raise AttributeError(name)
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))

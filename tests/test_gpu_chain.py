@@ -109,3 +109,32 @@ def test_config4_one_mib_preimage():
     for k, i in enumerate(idx):
         assert np.array_equal(d_bodies[int(i)].cpu().numpy(), want[k]), i
     ctx.close()
+
+
+def test_streamed_fold_8mib_ring_buffer():
+    """Streaming driver (chain.fold_witnesses): 8 MiB preimage = 131 072 leaf + 106 496 parent steps = 177 GB of
+    witness through a 2-deep ring of 16 384-step buffers, H2D of the preimage overlapped slice by slice.
+    Final h_out of every chunk path == BLAKE3(preimage); a consumer sees every batch."""
+    import torch
+    m = T.pkg()
+    rng = np.random.default_rng(2024)
+    data = rng.integers(0, 256, 8 << 20, dtype=np.uint8)
+    ctx = m.Context("nova_vesta", 0)
+    seen = []
+
+    def consumer(bodies, first_step, k):
+        # slot 0 of every body is the constant 1: a device-side reduction the consumer enqueues per batch
+        seen.append((first_step, k, (bodies[:, 0] == 1).sum()))
+    out = m.chain.fold_witnesses(ctx, torch.from_numpy(data).pin_memory(), batch_steps=16384, ring=2, slice_chunks=1024,
+                                 consumer=consumer)
+    torch.cuda.synchronize()
+    assert out["n_leaf_steps"] == 131072 and out["n_parent_steps"] == 8192 * 13 and out["path_len"] == 13
+    assert (out["status"] == 0).all().item()
+    assert sum(k for _, k, _ in seen) == 131072 + 8192 * 13 and all(int(c.item()) == k for _, k, c in seen)
+    want = B.hash_words(data.tobytes())
+    assert list(out["root"].cpu().numpy().view(np.uint32)) == want
+    pub = out["public"].cpu().numpy().view(np.uint32)
+    last_parent = pub[131072 + 12::13][:8192]          # step j = 12 (depth 0) of every chunk path
+    assert (last_parent[:, 2:10] == np.array(want, dtype=np.uint32)).all()
+    assert (last_parent[:, 11] == 0).all()
+    ctx.close()
