@@ -45,6 +45,56 @@ def cpu_baseline(circuit, recs, budget_s):
                       f"records of the workload) in {dt:.1f} s, C oracle, 1 thread"}
 
 
+def bench_chain(args, m, torch, dist, dev, world, rank, local_rank):
+    """Configs 4/5: a step = one pass over the whole preimage (plan + all leaf and parent step witnesses of this
+    rank's chunk range, bodies streamed through a ring of batch buffers).  Strong scaling: the preimage is fixed."""
+    import numpy as np
+    circuit = args.circuit if args.circuit != "compression" else "nova_vesta"
+    ctx = m.Context(circuit, local_rank)
+    nbytes = int(args.preimage_mib * (1 << 20))
+    lcg_words = (np.arange(nbytes // 4 + 1, dtype=np.uint64) * np.uint64(2654435761) + np.uint64(12345)) & np.uint64(0xFFFFFFFF)
+    host = torch.from_numpy(lcg_words.astype(np.uint32).view(np.uint8)[:nbytes].copy()).pin_memory()
+    run = lambda: m.chain.fold_witnesses(ctx, host, batch_steps=args.batch if args.batch != 4096 else 16384, ring=2)
+    for _ in range(max(1, args.warmup)):
+        out = run()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = run()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    assert int(out["status"].abs().sum().item()) == 0
+    local_steps = out["n_leaf_steps"] + out["n_parent_steps"]
+    t = torch.tensor([elapsed, float(local_steps)], dtype=torch.float64, device=dev)
+    if world > 1:
+        tm = t.clone(); dist.all_reduce(tm, op=dist.ReduceOp.MAX)
+        ts = t.clone(); dist.all_reduce(ts, op=dist.ReduceOp.SUM)
+        elapsed, total_steps = tm[0].item(), ts[1].item()
+    else:
+        total_steps = float(local_steps)
+    if rank == 0:
+        per = BYTES_PER_WITNESS[circuit]
+        print(json.dumps({
+            "metric": "BLAKE3-compression witnesses/sec", "value": total_steps * args.steps / elapsed, "unit": "witnesses/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+            "config": {"workload": f"chain: {args.preimage_mib} MiB preimage -> {int(total_steps)} nova steps ({circuit}), "
+                                   "planner + witness kernels, bodies through a 2-deep ring, H2D overlapped",
+                       "circuit": circuit, "n_chunks": out["n_chunks"], "path_len": out["path_len"]},
+            "roofline": {"bound": "hbm", "achieved": total_steps * args.steps * per / elapsed / 1e9 / world, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": total_steps * args.steps * per / elapsed / 1e9 / world / HBM_PEAK_GBS,
+                         "traffic": None, "note": "end-to-end per-GPU rate incl. planner, H2D and launch gaps"},
+        }), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -55,6 +105,10 @@ def main():
     ap.add_argument("--variant", type=int, default=None, help="kernel tuning variant (B3W_VARIANT)")
     ap.add_argument("--pitch", type=int, default=0, help="body pitch in bytes (0 = contiguous bodies)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of the cpu_baseline leg (0 = skip)")
+    ap.add_argument("--workload", default="batch", choices=["batch", "chain"],
+                    help="batch = BASELINE config 2/3 (default, the headline metric); chain = configs 4/5: "
+                         "preimage -> planner -> nova step witnesses, streamed through a ring of buffers")
+    ap.add_argument("--preimage-mib", type=float, default=1.0, help="chain workload: preimage size (1 = config 4, 1024 = config 5)")
     args = ap.parse_args()
 
     import numpy as np
@@ -81,6 +135,8 @@ def main():
         os.environ["B3W_VARIANT"] = str(args.variant)
     m = importlib.import_module("hot-proofs-blake3-circom_amd")
     W = m.workloads
+    if args.workload == "chain":
+        return bench_chain(args, m, torch, dist, dev, world, rank, local_rank)
     circuit, n = args.circuit, args.batch
     ctx = m.Context(circuit, local_rank)
     recs = W.config2_compression(n, first=rank * n) if circuit == "compression" else W.config3_nova(n, first=rank * n)

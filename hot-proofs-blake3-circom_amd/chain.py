@@ -105,8 +105,13 @@ def fold_witnesses(ctx, preimage, batch_steps=16384, ring=2, slice_chunks=1024, 
         mx = max(e - s for s, e in sizes)
         pad = torch.zeros((mx, 8), dtype=torch.int32, device=dev)
         pad[:nl] = cvs_local[:nl]
-        allcv = torch.empty((world * mx, 8), dtype=torch.int32, device=dev)
-        dist.all_gather_into_tensor(allcv, pad)
+        if dist.get_backend() == "gloo":              # CPU rehearsal of the exchange (tests): stage through the host
+            allcv_h = torch.empty((world * mx, 8), dtype=torch.int32)
+            dist.all_gather_into_tensor(allcv_h, pad.cpu())
+            allcv = allcv_h.to(dev)
+        else:                                         # RCCL over xGMI
+            allcv = torch.empty((world * mx, 8), dtype=torch.int32, device=dev)
+            dist.all_gather_into_tensor(allcv, pad)
         for r, (s, e) in enumerate(sizes):
             levels[s * 8: e * 8] = allcv[r * mx: r * mx + (e - s)].reshape(-1)
     else:

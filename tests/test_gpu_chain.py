@@ -138,3 +138,39 @@ def test_streamed_fold_8mib_ring_buffer():
     assert (last_parent[:, 2:10] == np.array(want, dtype=np.uint32)).all()
     assert (last_parent[:, 11] == 0).all()
     ctx.close()
+
+
+def _two_rank_worker(rank, world, port, nbytes, ret):
+    import os, torch, torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)      # both ranks share the one GPU of the test box
+    try:
+        m = T.pkg()
+        torch.cuda.set_device(0)
+        rng = np.random.default_rng(99)
+        data = rng.integers(0, 256, nbytes, dtype=np.uint8)
+        ctx = m.Context("nova_bn254", 0)
+        out = m.chain.fold_witnesses(ctx, data, batch_steps=4096)
+        torch.cuda.synchronize()
+        ret[rank] = dict(root=out["root"].cpu().numpy().view(np.uint32).tolist(), first_chunk=out["first_chunk"],
+                         n_local=out["n_chunks_local"], ok=bool((out["status"] == 0).all().item()),
+                         last=out["public"].cpu().numpy().view(np.uint32)[out["n_leaf_steps"] + out["path_len"] - 1::out["path_len"], 2:10].tolist())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_ranks_shard_chunks_and_exchange_cvs():
+    """N > 1: each rank folds its contiguous chunk range; the chunk CVs are all-gathered so both build the same
+    tree; every chunk path on either rank ends in BLAKE3(preimage)."""
+    import os
+    import torch.multiprocessing as mp
+    nbytes = 64 * 1024
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_two_rank_worker, args=(2, 29700 + os.getpid() % 200, nbytes, ret), nprocs=2, join=True)
+    data = np.random.default_rng(99).integers(0, 256, nbytes, dtype=np.uint8).tobytes()
+    want = B.hash_words(data)
+    assert ret[0]["root"] == want and ret[1]["root"] == want and ret[0]["ok"] and ret[1]["ok"]
+    assert (ret[0]["first_chunk"], ret[0]["n_local"], ret[1]["first_chunk"], ret[1]["n_local"]) == (0, 32, 32, 32)
+    for r in (0, 1):
+        assert len(ret[r]["last"]) == 32 and all(x == want for x in ret[r]["last"])
