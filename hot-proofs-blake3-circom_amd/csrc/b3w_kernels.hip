@@ -225,19 +225,20 @@ struct SweepPos {          // tile t of the sweep: first body it touches and the
   uint32_t w_lo;
 };
 
-// one thread's pipeline registers for a step of K tiles
+// one lane's pipeline registers for a step of K tiles (one 32-byte slot per lane and tile)
 template <int K, int NW>
 struct SweepRegs { uint32_t e[K]; uint32_t a[K][NW]; uint32_t ok[K]; };
 
-// LOGC: the scratch holds 2^LOGC witnesses per row.  pitch < 2^30 (checked by the launcher) keeps the
-// per-thread position arithmetic in 32 bits: one wave per SIMD has to issue everything, so the
-// instruction count per 16 bytes decides whether the kernel keeps up with HBM.
+// Shape (measured, tools/ubench/store_shapes2.hip): exactly 256 workgroups, 4 KiB tiles, tile t of workgroup
+// b = b + 256k.  128 lanes x one 32-byte slot each gives that tile with half the per-byte instruction
+// count of 256 lanes x 16 bytes; two waves per CU must issue everything, so the loop is kept lean:
+// 32-bit position arithmetic (pitch < 2^30, scratch rows of 2^LOGC witnesses), SGPR-based addressing.
 template <bool WIDE, int K, int LOGC>
-__global__ __launch_bounds__(256, 1) void b3w_sweep_kernel(const uint32_t *__restrict__ scr, uint32_t n,
+__global__ __launch_bounds__(128, 1) void b3w_sweep_kernel(const uint32_t *__restrict__ scr, uint32_t n,
                                                            uint8_t *__restrict__ out_base, uint32_t lead, uint32_t pitch,
                                                            const uint32_t *__restrict__ table, uint32_t nwit) {
-  constexpr int NW = WIDE ? 4 : 2;                       // image words gathered per 16 bytes
-  const uint32_t tid16 = threadIdx.x * 16u, G = gridDim.x;
+  constexpr int NW = WIDE ? 8 : 2;                       // image words a slot can need
+  const uint32_t tid32 = threadIdx.x * 32u, G = gridDim.x;
   const uint32_t body = 32u * nwit;
   const uint64_t total = (uint64_t)lead + (uint64_t)n * pitch;
   const uint64_t ntiles = (total + 4095) >> 12;
@@ -255,9 +256,9 @@ __global__ __launch_bounds__(256, 1) void b3w_sweep_kernel(const uint32_t *__res
     p.t += G; p.w_lo += dq; p.rem += (int32_t)dr;
     if (p.rem >= (int32_t)pitch) { p.rem -= (int32_t)pitch; p.w_lo++; }
   };
-  // this thread's 16 bytes of tile p: which witness, byte offset in its body, and whether they exist
+  // this lane's slot of tile p: which witness, byte offset in its body, and whether it exists
   auto locate = [&](const SweepPos &p, uint32_t &w, uint32_t &r32) {
-    int32_t r = p.rem + (int32_t)tid16;
+    int32_t r = p.rem + (int32_t)tid32;
     w = p.w_lo;
     if (r >= (int32_t)pitch) { r -= (int32_t)pitch; w++; }
     r32 = (uint32_t)r;
@@ -281,34 +282,51 @@ __global__ __launch_bounds__(256, 1) void b3w_sweep_kernel(const uint32_t *__res
       uint32_t w, r32;
       const bool in = locate(p, w, r32);
       const uint32_t e = rg.e[k];
-      const uint32_t src = e & 0xFFFu, mode = (e >> 17) & 3u;
-      const uint32_t off = (WIDE && mode == B3W_MODE_W256) ? src + ((r32 >> 2) & 4u) : src;
-      const uint32_t idx = (off << LOGC) + (in ? w : 0u);                   // 32-bit index: scratch < 2^32 words
+      const uint32_t idx = ((e & 0xFFFu) << LOGC) + (in ? w : 0u);          // 32-bit index: scratch < 2^32 words
+      rg.a[k][0] = scr[idx];
+      rg.a[k][1] = scr[idx + (1u << LOGC)];
+      if (WIDE) {
+        rg.ok[k] = scr[((uint32_t)B3W_LDS_OKWORD << LOGC) + (in ? w : 0u)];   // only the nova circuits reject steps
+        // 256-bit slots (IsZero inverses ...) are 0.3 % of a body: fetch their other six words only in waves that hold one
+        if (__builtin_amdgcn_ballot_w64(((e >> 17) & 3u) == B3W_MODE_W256)) {
 #pragma unroll
-      for (int x = 0; x < NW; ++x) rg.a[k][x] = scr[idx + ((uint32_t)x << LOGC)];
-      rg.ok[k] = WIDE ? scr[((uint32_t)B3W_LDS_OKWORD << LOGC) + (in ? w : 0u)] : 1u;   // only nova rejects steps
+          for (int x = 2; x < 8; ++x) rg.a[k][x] = scr[idx + ((uint32_t)x << LOGC)];
+        } else {
+#pragma unroll
+          for (int x = 2; x < 8; ++x) rg.a[k][x] = 0;
+        }
+      } else {
+        rg.ok[k] = 1u;
+      }
       advance(p);
     }
   };
-  // stage 3: shape the 16 bytes and store them
+  // stage 3: shape the 32 bytes and store them
   auto emit = [&](SweepPos &p, const SweepRegs<K, NW> &rg) {
 #pragma unroll
     for (int k = 0; k < K; ++k) {
       uint32_t w, r32;
       const bool in = locate(p, w, r32);
-      const uint32_t par = (r32 >> 4) & 1u;
       const uint32_t e = rg.e[k];
       const uint32_t sh = (e >> 12) & 31u, mode = (e >> 17) & 3u;
-      const bool live = (par == 0) || (WIDE && mode == B3W_MODE_W256);
-      const uint32_t m0 = live ? (mode == B3W_MODE_BIT ? 1u : 0xFFFFFFFFu) : 0u;
-      const uint32_t m1 = (live && mode >= B3W_MODE_W64) ? 0xFFFFFFFFu : 0u;
-      const uint32_t m23 = (WIDE && mode == B3W_MODE_W256) ? 0xFFFFFFFFu : 0u;
-      uint4 v;
-      v.x = (rg.a[k][0] >> sh) & m0;
-      v.y = rg.a[k][1] & m1;
-      if (WIDE) { v.z = rg.a[k][2] & m23; v.w = rg.a[k][3] & m23; } else { v.z = 0; v.w = 0; }
-      if (in && rg.ok[k] != 0)                                            // rejected step: body untouched
-        store16<false>(out_base + p.t * 4096 + tid16, v);
+      const uint32_t m0 = mode == B3W_MODE_BIT ? 1u : 0xFFFFFFFFu;
+      const uint32_t m1 = mode >= B3W_MODE_W64 ? 0xFFFFFFFFu : 0u;
+      const uint32_t m2 = (WIDE && mode == B3W_MODE_W256) ? 0xFFFFFFFFu : 0u;
+      uint4 lo, hi;
+      lo.x = (rg.a[k][0] >> sh) & m0;
+      lo.y = rg.a[k][1] & m1;
+      if (WIDE) {
+        lo.z = rg.a[k][2] & m2; lo.w = rg.a[k][3] & m2;
+        hi = make_uint4(rg.a[k][4] & m2, rg.a[k][5] & m2, rg.a[k][6] & m2, rg.a[k][7] & m2);
+      } else {
+        lo.z = 0; lo.w = 0;
+        hi = make_uint4(0, 0, 0, 0);
+      }
+      if (in && rg.ok[k] != 0) {                                           // rejected step: body untouched
+        uint8_t *dst = out_base + p.t * 4096 + tid32;
+        store16<false>(dst, lo);
+        store16<false>(dst + 16, hi);
+      }
       advance(p);
     }
   };
@@ -632,10 +650,10 @@ namespace {
 template <bool WIDE, int K>
 int launch_sweep(const uint32_t *d_images, uint32_t n, uint8_t *d_out, uint64_t pitch, const uint32_t *d_table,
                  uint32_t nwit, hipStream_t stream) {
-  if (pitch >= (1ull << 30)) return -5;
   const uintptr_t addr = reinterpret_cast<uintptr_t>(d_out);
+  if (pitch >= (1ull << 30) || (addr & 31)) return -5;        // one 32-byte slot per lane: bodies must be 32-byte aligned
   const uint32_t lead = (uint32_t)(addr & 4095);
-  hipLaunchKernelGGL((b3w_sweep_kernel<WIDE, K, B3W_SWEEP_LOGC>), dim3(B3W_SWEEP_GRID), dim3(256), 0, stream, d_images, n,
+  hipLaunchKernelGGL((b3w_sweep_kernel<WIDE, K, B3W_SWEEP_LOGC>), dim3(B3W_SWEEP_GRID), dim3(128), 0, stream, d_images, n,
                      d_out - lead, lead, (uint32_t)pitch, d_table, nwit);
   return (int)hipGetLastError();
 }
