@@ -220,10 +220,13 @@ __device__ __forceinline__ void dump_images(uint32_t *lds, uint32_t *__restrict_
 }
 
 struct SweepPos {          // tile t of the sweep: first body it touches and the byte offset inside it
-  uint64_t t;
+  uint32_t t;              // < 2^32 tiles (16 TB)
   int32_t rem;             // (t*4096 - lead) - w_lo*pitch; negative only inside the lead-in of tile 0
   uint32_t w_lo;
 };
+
+// wave-uniform by construction (derived from blockIdx and kernel arguments): pin to SGPRs
+__device__ __forceinline__ uint32_t uni(uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }
 
 // one lane's pipeline registers for a step of K tiles (one 32-byte slot per lane and tile)
 template <int K, int NW>
@@ -241,20 +244,23 @@ __global__ __launch_bounds__(128, 1) void b3w_sweep_kernel(const uint32_t *__res
   const uint32_t tid32 = threadIdx.x * 32u, G = gridDim.x;
   const uint32_t body = 32u * nwit;
   const uint64_t total = (uint64_t)lead + (uint64_t)n * pitch;
-  const uint64_t ntiles = (total + 4095) >> 12;
+  const uint32_t ntiles = (uint32_t)((total + 4095) >> 12);
   const uint64_t stride = (uint64_t)G * 4096;
   const uint32_t dq = (uint32_t)(stride / pitch), dr = (uint32_t)(stride % pitch);
-  auto start = [&](uint64_t t) {
+  auto start = [&](uint32_t t) {
     SweepPos p;
     p.t = t;
-    const int64_t pos = (int64_t)(t * 4096) - (int64_t)lead;
+    const int64_t pos = (int64_t)((uint64_t)t * 4096) - (int64_t)lead;
     if (pos < 0) { p.w_lo = 0; p.rem = (int32_t)pos; }
-    else { p.w_lo = (uint32_t)((uint64_t)pos / pitch); p.rem = (int32_t)((uint64_t)pos % pitch); }
+    else { p.w_lo = uni((uint32_t)((uint64_t)pos / pitch)); p.rem = (int32_t)uni((uint32_t)((uint64_t)pos % pitch)); }
     return p;
   };
   auto advance = [&](SweepPos &p) {
-    p.t += G; p.w_lo += dq; p.rem += (int32_t)dr;
-    if (p.rem >= (int32_t)pitch) { p.rem -= (int32_t)pitch; p.w_lo++; }
+    const int32_t r = p.rem + (int32_t)dr;
+    const bool c = r >= (int32_t)pitch;
+    p.t = uni(p.t + G);
+    p.w_lo = uni(p.w_lo + dq + (c ? 1u : 0u));
+    p.rem = (int32_t)uni((uint32_t)(c ? r - (int32_t)pitch : r));
   };
   // this lane's slot of tile p: which witness, byte offset in its body, and whether it exists
   auto locate = [&](const SweepPos &p, uint32_t &w, uint32_t &r32) {
@@ -323,7 +329,7 @@ __global__ __launch_bounds__(128, 1) void b3w_sweep_kernel(const uint32_t *__res
         hi = make_uint4(0, 0, 0, 0);
       }
       if (in && rg.ok[k] != 0) {                                           // rejected step: body untouched
-        uint8_t *dst = out_base + p.t * 4096 + tid32;
+        uint8_t *dst = out_base + (uint64_t)p.t * 4096 + tid32;
         store16<false>(dst, lo);
         store16<false>(dst + 16, hi);
       }
@@ -335,19 +341,100 @@ __global__ __launch_bounds__(128, 1) void b3w_sweep_kernel(const uint32_t *__res
     for (int k = 0; k < K; ++k) advance(p);
   };
 
-  SweepPos cur = start(blockIdx.x);      // step being emitted
+  // ---- interior fast path: a step whose K tiles each lie inside the data of ONE body (no straddle, no
+  // padding, no lead-in, not past the end): witness and first slot are wave-uniform, so table and store
+  // addresses are SGPR base + constant lane offset and the per-lane work shrinks to decode + shape.
+  auto step_is_fast = [&](SweepPos p) {
+    bool fast = true;
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      fast = fast && p.t < ntiles && p.rem >= 0 && (uint32_t)p.rem + 4096u <= body && p.w_lo < n;
+      advance(p);
+    }
+    return fast;
+  };
+  const uint32_t tid = threadIdx.x;
+  auto fetch_table_fast = [&](SweepPos p, SweepRegs<K, NW> &rg) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      rg.e[k] = (table + ((uint32_t)p.rem >> 5))[tid];
+      advance(p);
+    }
+  };
+  auto fetch_words_fast = [&](SweepPos p, SweepRegs<K, NW> &rg) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const uint32_t e = rg.e[k];
+      const uint32_t *col = scr + p.w_lo;                                   // uniform base
+      const uint32_t row = (e & 0xFFFu) << LOGC;
+      rg.a[k][0] = col[row];
+      rg.a[k][1] = col[row + (1u << LOGC)];
+      if (WIDE) {
+        rg.ok[k] = col[(uint32_t)B3W_LDS_OKWORD << LOGC];                   // same address in every lane
+        if (__builtin_amdgcn_ballot_w64(((e >> 17) & 3u) == B3W_MODE_W256)) {
+#pragma unroll
+          for (int x = 2; x < 8; ++x) rg.a[k][x] = col[row + ((uint32_t)x << LOGC)];
+        } else {
+#pragma unroll
+          for (int x = 2; x < 8; ++x) rg.a[k][x] = 0;
+        }
+      } else {
+        rg.ok[k] = 1u;
+      }
+      advance(p);
+    }
+  };
+  auto emit_fast = [&](SweepPos &p, const SweepRegs<K, NW> &rg) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      const uint32_t e = rg.e[k];
+      const uint32_t sh = (e >> 12) & 31u, mode = (e >> 17) & 3u;
+      const uint32_t m0 = mode == B3W_MODE_BIT ? 1u : 0xFFFFFFFFu;
+      const uint32_t m1 = mode >= B3W_MODE_W64 ? 0xFFFFFFFFu : 0u;
+      uint4 lo, hi;
+      lo.x = (rg.a[k][0] >> sh) & m0;
+      lo.y = rg.a[k][1] & m1;
+      if (WIDE) {
+        const uint32_t m2 = mode == B3W_MODE_W256 ? 0xFFFFFFFFu : 0u;
+        lo.z = rg.a[k][2] & m2; lo.w = rg.a[k][3] & m2;
+        hi = make_uint4(rg.a[k][4] & m2, rg.a[k][5] & m2, rg.a[k][6] & m2, rg.a[k][7] & m2);
+      } else {
+        lo.z = 0; lo.w = 0;
+        hi = make_uint4(0, 0, 0, 0);
+      }
+      uint8_t *dst = out_base + (uint64_t)p.t * 4096;                       // uniform base, lane offset tid*32
+      if (!WIDE || rg.ok[k] != 0) {
+        store16<false>(dst + tid32, lo);
+        store16<false>(dst + tid32 + 16, hi);
+      }
+      advance(p);
+    }
+  };
+
+  SweepPos cur = start(uni(blockIdx.x)); // step being emitted
   SweepPos p1 = cur, p2 = cur;           // step whose words / table entries are being fetched
   SweepRegs<K, NW> r0, r1, r2;
-  fetch_table(p2, r0); skip(p2);                       // step 0
-  fetch_table(p2, r1); skip(p2);                       // step 1
-  fetch_words(p1, r0); skip(p1);                       // step 0
+  auto do_table = [&](SweepRegs<K, NW> &rg) {
+    if (step_is_fast(p2)) fetch_table_fast(p2, rg); else fetch_table(p2, rg);
+    skip(p2);
+  };
+  auto do_words = [&](SweepRegs<K, NW> &rg) {
+    if (step_is_fast(p1)) fetch_words_fast(p1, rg); else fetch_words(p1, rg);
+    skip(p1);
+  };
+  auto do_emit = [&](const SweepRegs<K, NW> &rg) {
+    if (step_is_fast(cur)) emit_fast(cur, rg); else emit(cur, rg);
+  };
+  do_table(r0);                                        // step 0
+  do_table(r1);                                        // step 1
+  do_words(r0);                                        // step 0
   // step s: REMIT holds step s complete; RWORDS holds step s+1's table words (fetch its image words now);
   // RTABLE is free (fetch step s+2's table words)
 #define B3W_SWEEP_STEP(REMIT, RWORDS, RTABLE) \
   {                                            \
-    fetch_table(p2, RTABLE); skip(p2);         \
-    fetch_words(p1, RWORDS); skip(p1);         \
-    emit(cur, REMIT);                          \
+    do_table(RTABLE);                          \
+    do_words(RWORDS);                          \
+    do_emit(REMIT);                            \
   }
   while (cur.t < ntiles) {
     B3W_SWEEP_STEP(r0, r1, r2)
