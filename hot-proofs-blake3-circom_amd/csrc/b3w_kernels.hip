@@ -228,149 +228,92 @@ struct SweepPos {          // tile t of the sweep: first body it touches and the
 // wave-uniform by construction (derived from blockIdx and kernel arguments): pin to SGPRs
 __device__ __forceinline__ uint32_t uni(uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }
 
-// one lane's pipeline registers for a step of K tiles (one 32-byte slot per lane and tile)
+// one lane's pipeline registers for a step of K tiles (one 32-byte slot per lane and tile), plus the
+// step's wave-uniform tile positions, computed once (table stage) and carried to the later stages
 template <int K, int NW>
-struct SweepRegs { uint32_t e[K]; uint32_t a[K][NW]; uint32_t ok[K]; };
+struct SweepRegs {
+  uint32_t e[K]; uint32_t a[K][NW]; uint32_t ok[K];
+  uint32_t t[K], wlo[K]; int32_t rem[K];     // uniform
+  bool fast;                                  // uniform: every tile of the step is interior to one body
+};
 
 // Shape (measured, tools/ubench/store_shapes2.hip): exactly 256 workgroups, 4 KiB tiles, tile t of workgroup
 // b = b + 256k.  128 lanes x one 32-byte slot each gives that tile with half the per-byte instruction
 // count of 256 lanes x 16 bytes; two waves per CU must issue everything, so the loop is kept lean:
-// 32-bit position arithmetic (pitch < 2^30, scratch rows of 2^LOGC witnesses), SGPR-based addressing.
+// 32-bit position arithmetic (pitch < 2^30, scratch rows of 2^LOGC witnesses), SGPR-based addressing,
+// tile positions computed once per step, and an interior fast path without per-lane position logic.
 template <bool WIDE, int K, int LOGC>
 __global__ __launch_bounds__(128, 1) void b3w_sweep_kernel(const uint32_t *__restrict__ scr, uint32_t n,
                                                            uint8_t *__restrict__ out_base, uint32_t lead, uint32_t pitch,
                                                            const uint32_t *__restrict__ table, uint32_t nwit) {
   constexpr int NW = WIDE ? 8 : 2;                       // image words a slot can need
-  const uint32_t tid32 = threadIdx.x * 32u, G = gridDim.x;
+  const uint32_t tid = threadIdx.x, tid32 = tid * 32u, G = gridDim.x;
   const uint32_t body = 32u * nwit;
   const uint64_t total = (uint64_t)lead + (uint64_t)n * pitch;
   const uint32_t ntiles = (uint32_t)((total + 4095) >> 12);
   const uint64_t stride = (uint64_t)G * 4096;
   const uint32_t dq = (uint32_t)(stride / pitch), dr = (uint32_t)(stride % pitch);
-  auto start = [&](uint32_t t) {
-    SweepPos p;
-    p.t = t;
-    const int64_t pos = (int64_t)((uint64_t)t * 4096) - (int64_t)lead;
-    if (pos < 0) { p.w_lo = 0; p.rem = (int32_t)pos; }
-    else { p.w_lo = uni((uint32_t)((uint64_t)pos / pitch)); p.rem = (int32_t)uni((uint32_t)((uint64_t)pos % pitch)); }
-    return p;
-  };
-  auto advance = [&](SweepPos &p) {
-    const int32_t r = p.rem + (int32_t)dr;
-    const bool c = r >= (int32_t)pitch;
-    p.t = uni(p.t + G);
-    p.w_lo = uni(p.w_lo + dq + (c ? 1u : 0u));
-    p.rem = (int32_t)uni((uint32_t)(c ? r - (int32_t)pitch : r));
-  };
-  // this lane's slot of tile p: which witness, byte offset in its body, and whether it exists
-  auto locate = [&](const SweepPos &p, uint32_t &w, uint32_t &r32) {
-    int32_t r = p.rem + (int32_t)tid32;
-    w = p.w_lo;
+  // running position of the table stage (wave-uniform)
+  uint32_t pt = uni(blockIdx.x), pw;
+  int32_t prem;
+  {
+    const int64_t pos = (int64_t)((uint64_t)pt * 4096) - (int64_t)lead;
+    if (pos < 0) { pw = 0; prem = (int32_t)pos; }
+    else { pw = uni((uint32_t)((uint64_t)pos / pitch)); prem = (int32_t)uni((uint32_t)((uint64_t)pos % pitch)); }
+  }
+  // a lane's slot of a tile at (rem, w_lo): which witness, byte offset in its body, does it exist
+  auto locate = [&](uint32_t t, int32_t rem, uint32_t w_lo, uint32_t &w, uint32_t &r32) {
+    int32_t r = rem + (int32_t)tid32;
+    w = w_lo;
     if (r >= (int32_t)pitch) { r -= (int32_t)pitch; w++; }
     r32 = (uint32_t)r;
-    return p.t < ntiles && r32 < body && w < n;          // r < 0 wraps above body
+    return t < ntiles && r32 < body && w < n;            // r < 0 wraps above body
   };
-  // stage 1: slot-table words (coalesced).  Loads are unconditional with clamped addresses so the
-  // register sets stay in VGPRs.
-  auto fetch_table = [&](SweepPos p, SweepRegs<K, NW> &rg) {
-#pragma unroll
-    for (int k = 0; k < K; ++k) {
-      uint32_t w, r32;
-      const bool in = locate(p, w, r32);
-      rg.e[k] = table[in ? (r32 >> 5) : 0u];
-      advance(p);
-    }
-  };
-  // stage 2: image words from the word-major scratch (1-2 cache lines per wave and word)
-  auto fetch_words = [&](SweepPos p, SweepRegs<K, NW> &rg) {
-#pragma unroll
-    for (int k = 0; k < K; ++k) {
-      uint32_t w, r32;
-      const bool in = locate(p, w, r32);
-      const uint32_t e = rg.e[k];
-      const uint32_t idx = ((e & 0xFFFu) << LOGC) + (in ? w : 0u);          // 32-bit index: scratch < 2^32 words
-      rg.a[k][0] = scr[idx];
-      rg.a[k][1] = scr[idx + (1u << LOGC)];
-      if (WIDE) {
-        rg.ok[k] = scr[((uint32_t)B3W_LDS_OKWORD << LOGC) + (in ? w : 0u)];   // only the nova circuits reject steps
-        // 256-bit slots (IsZero inverses ...) are 0.3 % of a body: fetch their other six words only in waves that hold one
-        if (__builtin_amdgcn_ballot_w64(((e >> 17) & 3u) == B3W_MODE_W256)) {
-#pragma unroll
-          for (int x = 2; x < 8; ++x) rg.a[k][x] = scr[idx + ((uint32_t)x << LOGC)];
-        } else {
-#pragma unroll
-          for (int x = 2; x < 8; ++x) rg.a[k][x] = 0;
-        }
-      } else {
-        rg.ok[k] = 1u;
-      }
-      advance(p);
-    }
-  };
-  // stage 3: shape the 32 bytes and store them
-  auto emit = [&](SweepPos &p, const SweepRegs<K, NW> &rg) {
-#pragma unroll
-    for (int k = 0; k < K; ++k) {
-      uint32_t w, r32;
-      const bool in = locate(p, w, r32);
-      const uint32_t e = rg.e[k];
-      const uint32_t sh = (e >> 12) & 31u, mode = (e >> 17) & 3u;
-      const uint32_t m0 = mode == B3W_MODE_BIT ? 1u : 0xFFFFFFFFu;
-      const uint32_t m1 = mode >= B3W_MODE_W64 ? 0xFFFFFFFFu : 0u;
-      const uint32_t m2 = (WIDE && mode == B3W_MODE_W256) ? 0xFFFFFFFFu : 0u;
-      uint4 lo, hi;
-      lo.x = (rg.a[k][0] >> sh) & m0;
-      lo.y = rg.a[k][1] & m1;
-      if (WIDE) {
-        lo.z = rg.a[k][2] & m2; lo.w = rg.a[k][3] & m2;
-        hi = make_uint4(rg.a[k][4] & m2, rg.a[k][5] & m2, rg.a[k][6] & m2, rg.a[k][7] & m2);
-      } else {
-        lo.z = 0; lo.w = 0;
-        hi = make_uint4(0, 0, 0, 0);
-      }
-      if (in && rg.ok[k] != 0) {                                           // rejected step: body untouched
-        uint8_t *dst = out_base + (uint64_t)p.t * 4096 + tid32;
-        store16<false>(dst, lo);
-        store16<false>(dst + 16, hi);
-      }
-      advance(p);
-    }
-  };
-  auto skip = [&](SweepPos &p) {
-#pragma unroll
-    for (int k = 0; k < K; ++k) advance(p);
-  };
-
-  // ---- interior fast path: a step whose K tiles each lie inside the data of ONE body (no straddle, no
-  // padding, no lead-in, not past the end): witness and first slot are wave-uniform, so table and store
-  // addresses are SGPR base + constant lane offset and the per-lane work shrinks to decode + shape.
-  auto step_is_fast = [&](SweepPos p) {
+  // stage 1: positions of the step's K tiles + slot-table words (coalesced).  Loads are unconditional
+  // with clamped addresses so the register sets stay in VGPRs.
+  auto do_table = [&](SweepRegs<K, NW> &rg) {
     bool fast = true;
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-      fast = fast && p.t < ntiles && p.rem >= 0 && (uint32_t)p.rem + 4096u <= body && p.w_lo < n;
-      advance(p);
+      rg.t[k] = pt; rg.rem[k] = prem; rg.wlo[k] = pw;
+      fast = fast && pt < ntiles && prem >= 0 && (uint32_t)prem + 4096u <= body && pw < n;
+      const int32_t r = prem + (int32_t)dr;
+      const bool c = r >= (int32_t)pitch;
+      pt = uni(pt + G);
+      pw = uni(pw + dq + (c ? 1u : 0u));
+      prem = (int32_t)uni((uint32_t)(c ? r - (int32_t)pitch : r));
     }
-    return fast;
-  };
-  const uint32_t tid = threadIdx.x;
-  auto fetch_table_fast = [&](SweepPos p, SweepRegs<K, NW> &rg) {
+    rg.fast = fast;
+    if (fast) {
 #pragma unroll
-    for (int k = 0; k < K; ++k) {
-      rg.e[k] = (table + ((uint32_t)p.rem >> 5))[tid];
-      advance(p);
+      for (int k = 0; k < K; ++k) rg.e[k] = (table + ((uint32_t)rg.rem[k] >> 5))[tid];   // uniform base + lane
+    } else {
+#pragma unroll
+      for (int k = 0; k < K; ++k) {
+        uint32_t w, r32;
+        const bool in = locate(rg.t[k], rg.rem[k], rg.wlo[k], w, r32);
+        rg.e[k] = table[in ? (r32 >> 5) : 0u];
+      }
     }
   };
-  auto fetch_words_fast = [&](SweepPos p, SweepRegs<K, NW> &rg) {
+  // stage 2: image words from the word-major scratch (1-2 cache lines per wave and word)
+  auto do_words = [&](SweepRegs<K, NW> &rg) {
 #pragma unroll
     for (int k = 0; k < K; ++k) {
       const uint32_t e = rg.e[k];
-      const uint32_t *col = scr + p.w_lo;                                   // uniform base
       const uint32_t row = (e & 0xFFFu) << LOGC;
+      uint32_t w = rg.wlo[k];
+      if (!rg.fast) {
+        uint32_t r32;
+        const bool in = locate(rg.t[k], rg.rem[k], rg.wlo[k], w, r32);
+        w = in ? w : 0u;
+      }
+      const uint32_t *col = scr + w;                     // fast path: uniform base
       rg.a[k][0] = col[row];
       rg.a[k][1] = col[row + (1u << LOGC)];
       if (WIDE) {
-        rg.ok[k] = col[(uint32_t)B3W_LDS_OKWORD << LOGC];                   // same address in every lane
+        rg.ok[k] = col[(uint32_t)B3W_LDS_OKWORD << LOGC];   // only the nova circuits reject steps
+        // 256-bit slots (IsZero inverses ...) are 0.3 % of a body: fetch their other six words only in waves that hold one
         if (__builtin_amdgcn_ballot_w64(((e >> 17) & 3u) == B3W_MODE_W256)) {
 #pragma unroll
           for (int x = 2; x < 8; ++x) rg.a[k][x] = col[row + ((uint32_t)x << LOGC)];
@@ -381,10 +324,10 @@ __global__ __launch_bounds__(128, 1) void b3w_sweep_kernel(const uint32_t *__res
       } else {
         rg.ok[k] = 1u;
       }
-      advance(p);
     }
   };
-  auto emit_fast = [&](SweepPos &p, const SweepRegs<K, NW> &rg) {
+  // stage 3: shape the 32 bytes and store them
+  auto do_emit = [&](const SweepRegs<K, NW> &rg) {
 #pragma unroll
     for (int k = 0; k < K; ++k) {
       const uint32_t e = rg.e[k];
@@ -402,29 +345,17 @@ __global__ __launch_bounds__(128, 1) void b3w_sweep_kernel(const uint32_t *__res
         lo.z = 0; lo.w = 0;
         hi = make_uint4(0, 0, 0, 0);
       }
-      uint8_t *dst = out_base + (uint64_t)p.t * 4096;                       // uniform base, lane offset tid*32
-      if (!WIDE || rg.ok[k] != 0) {
+      bool in = true;
+      if (!rg.fast) { uint32_t w, r32; in = locate(rg.t[k], rg.rem[k], rg.wlo[k], w, r32); }
+      uint8_t *dst = out_base + (uint64_t)rg.t[k] * 4096;   // uniform base, lane offset tid*32
+      if (in && (!WIDE || rg.ok[k] != 0)) {                // rejected step: body untouched
         store16<false>(dst + tid32, lo);
         store16<false>(dst + tid32 + 16, hi);
       }
-      advance(p);
     }
   };
 
-  SweepPos cur = start(uni(blockIdx.x)); // step being emitted
-  SweepPos p1 = cur, p2 = cur;           // step whose words / table entries are being fetched
   SweepRegs<K, NW> r0, r1, r2;
-  auto do_table = [&](SweepRegs<K, NW> &rg) {
-    if (step_is_fast(p2)) fetch_table_fast(p2, rg); else fetch_table(p2, rg);
-    skip(p2);
-  };
-  auto do_words = [&](SweepRegs<K, NW> &rg) {
-    if (step_is_fast(p1)) fetch_words_fast(p1, rg); else fetch_words(p1, rg);
-    skip(p1);
-  };
-  auto do_emit = [&](const SweepRegs<K, NW> &rg) {
-    if (step_is_fast(cur)) emit_fast(cur, rg); else emit(cur, rg);
-  };
   do_table(r0);                                        // step 0
   do_table(r1);                                        // step 1
   do_words(r0);                                        // step 0
@@ -436,9 +367,12 @@ __global__ __launch_bounds__(128, 1) void b3w_sweep_kernel(const uint32_t *__res
     do_words(RWORDS);                          \
     do_emit(REMIT);                            \
   }
-  while (cur.t < ntiles) {
+  while (true) {
+    if (r0.t[0] >= ntiles) break;
     B3W_SWEEP_STEP(r0, r1, r2)
+    if (r1.t[0] >= ntiles) break;
     B3W_SWEEP_STEP(r1, r2, r0)
+    if (r2.t[0] >= ntiles) break;
     B3W_SWEEP_STEP(r2, r0, r1)
   }
 #undef B3W_SWEEP_STEP
