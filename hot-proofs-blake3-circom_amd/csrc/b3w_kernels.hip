@@ -242,19 +242,22 @@ struct SweepRegs {
 // count of 256 lanes x 16 bytes; two waves per CU must issue everything, so the loop is kept lean:
 // 32-bit position arithmetic (pitch < 2^30, scratch rows of 2^LOGC witnesses), SGPR-based addressing,
 // tile positions computed once per step, and an interior fast path without per-lane position logic.
-template <bool WIDE, int K, int LOGC>
-__global__ __launch_bounds__(128, 1) void b3w_sweep_kernel(const uint32_t *__restrict__ scr, uint32_t n,
+// PAIRS wave-pairs per workgroup: pair q takes the workgroup's tiles k = q, q+PAIRS, ... — a second
+// independent pipeline per CU to cover load latency (store_shapes3.hip: the fill rate survives PAIRS = 2).
+template <bool WIDE, int K, int LOGC, int PAIRS>
+__global__ __launch_bounds__(128 * PAIRS, 1) void b3w_sweep_kernel(const uint32_t *__restrict__ scr, uint32_t n,
                                                            uint8_t *__restrict__ out_base, uint32_t lead, uint32_t pitch,
                                                            const uint32_t *__restrict__ table, uint32_t nwit) {
   constexpr int NW = WIDE ? 8 : 2;                       // image words a slot can need
-  const uint32_t tid = threadIdx.x, tid32 = tid * 32u, G = gridDim.x;
+  const uint32_t tid = threadIdx.x % 128u, tid32 = tid * 32u, pair = uni(threadIdx.x / 128u);
+  const uint32_t G = gridDim.x * PAIRS;                   // tile stride of one wave-pair
   const uint32_t body = 32u * nwit;
   const uint64_t total = (uint64_t)lead + (uint64_t)n * pitch;
   const uint32_t ntiles = (uint32_t)((total + 4095) >> 12);
   const uint64_t stride = (uint64_t)G * 4096;
   const uint32_t dq = (uint32_t)(stride / pitch), dr = (uint32_t)(stride % pitch);
   // running position of the table stage (wave-uniform)
-  uint32_t pt = uni(blockIdx.x), pw;
+  uint32_t pt = uni(blockIdx.x + gridDim.x * pair), pw;
   int32_t prem;
   {
     const int64_t pos = (int64_t)((uint64_t)pt * 4096) - (int64_t)lead;
@@ -674,7 +677,7 @@ int launch_sweep(const uint32_t *d_images, uint32_t n, uint8_t *d_out, uint64_t 
   const uintptr_t addr = reinterpret_cast<uintptr_t>(d_out);
   if (pitch >= (1ull << 30) || (addr & 31)) return -5;        // one 32-byte slot per lane: bodies must be 32-byte aligned
   const uint32_t lead = (uint32_t)(addr & 4095);
-  hipLaunchKernelGGL((b3w_sweep_kernel<WIDE, K, B3W_SWEEP_LOGC>), dim3(B3W_SWEEP_GRID), dim3(128), 0, stream, d_images, n,
+  hipLaunchKernelGGL((b3w_sweep_kernel<WIDE, K, B3W_SWEEP_LOGC, 2>), dim3(B3W_SWEEP_GRID), dim3(256), 0, stream, d_images, n,
                      d_out - lead, lead, (uint32_t)pitch, d_table, nwit);
   return (int)hipGetLastError();
 }
