@@ -18,6 +18,7 @@
 // compression witness); there is no contraction, so no MFMA.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "b3w_atoms.h"
 #include "b3w_kernels.h"
 
@@ -244,20 +245,28 @@ struct SweepRegs {
 // tile positions computed once per step, and an interior fast path without per-lane position logic.
 // PAIRS wave-pairs per workgroup: pair q takes the workgroup's tiles k = q, q+PAIRS, ... — a second
 // independent pipeline per CU to cover load latency (store_shapes3.hip: the fill rate survives PAIRS = 2).
-template <bool WIDE, int K, int LOGC, int PAIRS>
+// SPLIT: pair q takes a contiguous share of the workgroup's tile sequence instead of every PAIRS-th tile.
+template <bool WIDE, int K, int LOGC, int PAIRS, bool SPLIT>
 __global__ __launch_bounds__(128 * PAIRS, 1) void b3w_sweep_kernel(const uint32_t *__restrict__ scr, uint32_t n,
                                                            uint8_t *__restrict__ out_base, uint32_t lead, uint32_t pitch,
                                                            const uint32_t *__restrict__ table, uint32_t nwit) {
   constexpr int NW = WIDE ? 8 : 2;                       // image words a slot can need
   const uint32_t tid = threadIdx.x % 128u, tid32 = tid * 32u, pair = uni(threadIdx.x / 128u);
-  const uint32_t G = gridDim.x * PAIRS;                   // tile stride of one wave-pair
+  const uint32_t G = SPLIT ? gridDim.x : gridDim.x * PAIRS;   // tile stride of one wave-pair
   const uint32_t body = 32u * nwit;
   const uint64_t total = (uint64_t)lead + (uint64_t)n * pitch;
-  const uint32_t ntiles = (uint32_t)((total + 4095) >> 12);
+  const uint32_t ntiles_all = (uint32_t)((total + 4095) >> 12);
+  // tiles of this workgroup: b, b+G0, ...; SPLIT: pair q owns sequence indices [q*share, (q+1)*share)
+  const uint32_t G0 = gridDim.x;
+  const uint32_t nseq = ntiles_all > blockIdx.x ? (ntiles_all - blockIdx.x + G0 - 1) / G0 : 0;
+  const uint32_t share = (nseq + PAIRS - 1) / PAIRS;
+  const uint32_t first_seq = SPLIT ? pair * share : pair;
+  const uint32_t end_seq = SPLIT ? (first_seq + share < nseq ? first_seq + share : nseq) : nseq;
+  const uint32_t ntiles = uni(end_seq > 0 ? blockIdx.x + (end_seq - 1) * G0 + 1 : 0);   // exclusive tile bound of this pair
   const uint64_t stride = (uint64_t)G * 4096;
   const uint32_t dq = (uint32_t)(stride / pitch), dr = (uint32_t)(stride % pitch);
   // running position of the table stage (wave-uniform)
-  uint32_t pt = uni(blockIdx.x + gridDim.x * pair), pw;
+  uint32_t pt = uni(blockIdx.x + G0 * first_seq), pw;
   int32_t prem;
   {
     const int64_t pos = (int64_t)((uint64_t)pt * 4096) - (int64_t)lead;
@@ -677,8 +686,18 @@ int launch_sweep(const uint32_t *d_images, uint32_t n, uint8_t *d_out, uint64_t 
   const uintptr_t addr = reinterpret_cast<uintptr_t>(d_out);
   if (pitch >= (1ull << 30) || (addr & 31)) return -5;        // one 32-byte slot per lane: bodies must be 32-byte aligned
   const uint32_t lead = (uint32_t)(addr & 4095);
-  hipLaunchKernelGGL((b3w_sweep_kernel<WIDE, K, B3W_SWEEP_LOGC, 2>), dim3(B3W_SWEEP_GRID), dim3(256), 0, stream, d_images, n,
-                     d_out - lead, lead, (uint32_t)pitch, d_table, nwit);
+  static const int shape = getenv("B3W_SWEEP_SHAPE") ? atoi(getenv("B3W_SWEEP_SHAPE")) : 0;
+#define B3W_SWEEP_LAUNCH(PAIRS, SPLIT)                                                                              \
+  hipLaunchKernelGGL((b3w_sweep_kernel<WIDE, K, B3W_SWEEP_LOGC, PAIRS, SPLIT>), dim3(B3W_SWEEP_GRID), dim3(128 * PAIRS), 0, \
+                     stream, d_images, n, d_out - lead, lead, (uint32_t)pitch, d_table, nwit)
+  switch (shape) {
+    case 1: B3W_SWEEP_LAUNCH(1, false); break;
+    case 2: B3W_SWEEP_LAUNCH(2, true); break;
+    case 3: B3W_SWEEP_LAUNCH(4, true); break;
+    case 4: B3W_SWEEP_LAUNCH(3, true); break;
+    default: B3W_SWEEP_LAUNCH(2, false); break;
+  }
+#undef B3W_SWEEP_LAUNCH
   return (int)hipGetLastError();
 }
 }  // namespace
