@@ -155,6 +155,11 @@ def main():
         if world > 1:                       # the fold's exchange step: per-step public outputs (h_out ...)
             sharding.gather_public(d_pub, world * n)
 
+    chosen = args.variant
+    if args.variant is None:
+        # untimed: pick the faster of the two bit-identical kernel paths for THIS output buffer (DESIGN.md "Roofline")
+        chosen, _ = ctx.autotune_device(d_recs.data_ptr(), n, d_bodies.data_ptr(), pitch, d_pub.data_ptr(), d_status.data_ptr(),
+                                        stream.cuda_stream)
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
@@ -213,6 +218,7 @@ def main():
                                    f"{'BN254' if 'vesta' not in circuit else 'Vesta'} field, LCG(6429+i) inputs, "
                                    "device-resident inputs and outputs",
                        "circuit": circuit, "batch_per_gpu": n, "witness_bytes": ctx.body_bytes, "pitch": pitch,
+                       "kernel_variant": "sweep (TRACE + SWEEP kernels)" if chosen >= 100 else f"fused ({chosen})",
                        "exchange": "all_gather of public outputs (RCCL)" if world > 1 else "none"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

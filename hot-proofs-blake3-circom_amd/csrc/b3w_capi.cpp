@@ -306,6 +306,15 @@ int32_t hip_fail(b3w_ctx *ctx, hipError_t e, const char *what) {
     if (_e != hipSuccess) return hip_fail(ctx, _e, #call);  \
   } while (0)
 
+// word-major image scratch of the two-kernel (sweep) path
+int32_t ensure_scratch(b3w_ctx *ctx) {
+  if (ctx->d_scratch) return B3W_OK;
+  ctx->scratch_cap = B3W_SWEEP_CHUNK;
+  hipError_t e = hipMalloc((void **)&ctx->d_scratch, (size_t)ctx->scratch_cap * ctx->desc.lds_words * 4);
+  if (e != hipSuccess) { ctx->scratch_cap = 0; return hip_fail(ctx, e, "hipMalloc(sweep scratch)"); }
+  return B3W_OK;
+}
+
 void set_inputs(b3w_ctx *ctx) {
   struct Def { const char *name; uint32_t count; };
   static const Def comp[] = {{"h", 8}, {"m", 16}, {"t", 2}, {"b", 1}, {"d", 1}};
@@ -374,11 +383,7 @@ int32_t b3w_create(int32_t circuit, int32_t device, b3w_ctx **out) {
   if (e != hipSuccess) { b3w_destroy(ctx); return B3W_E_HIP; }
   const char *v = getenv("B3W_VARIANT");
   if (v) ctx->variant = atoi(v);
-  if (ctx->variant >= B3W_VARIANT_SWEEP) {
-    ctx->scratch_cap = B3W_SWEEP_CHUNK;
-    e = hipMalloc((void **)&ctx->d_scratch, (size_t)ctx->scratch_cap * d.lds_words * 4);   // word-major images
-    if (e != hipSuccess) { b3w_destroy(ctx); return B3W_E_HIP; }
-  }
+  if (ctx->variant >= B3W_VARIANT_SWEEP && ensure_scratch(ctx) != B3W_OK) { b3w_destroy(ctx); return B3W_E_HIP; }
   *out = ctx;
   return B3W_OK;
 }
@@ -449,6 +454,37 @@ int32_t b3w_batch_run_device(b3w_ctx *ctx, const uint32_t *d_records, uint32_t n
   if (rc == 0) return B3W_OK;
   if (rc < 0) { ctx->last_error = "no kernel for this circuit kind / variant"; return B3W_E_BAD_ARGUMENT; }
   return hip_fail(ctx, (hipError_t)rc, "kernel launch");
+}
+
+// Pick the kernel variant for THIS output buffer: the fused kernels' store pattern is sensitive to where
+// the buffer sits (5.3-6.7 TB/s), the two-kernel sweep path is not (~5.5 TB/s).  All variants are
+// bit-identical, so this is purely a speed choice.  Times each candidate on the caller's buffers (which are
+// overwritten with the correct witnesses), keeps the fastest in the ctx.  Allocates the sweep scratch.
+int32_t b3w_batch_autotune_device(b3w_ctx *ctx, const uint32_t *d_records, uint32_t n, uint8_t *d_bodies, uint64_t pitch,
+                                  uint32_t *d_public, int32_t *d_status, void *stream, int32_t *chosen_variant,
+                                  float *chosen_ms) {
+  if (!ctx || !d_records || !d_bodies || !n) return B3W_E_BAD_ARGUMENT;
+  int32_t rc = ensure_scratch(ctx);
+  if (rc) return rc;
+  const int candidates[2] = {0, B3W_VARIANT_SWEEP};
+  int best = ctx->variant;
+  float best_ms = 1e30f;
+  const int saved = ctx->variant;
+  for (int c : candidates) {
+    ctx->variant = c;
+    float ms = 0;
+    for (int w = 0; w < 2; w++) {
+      rc = b3w_batch_run_device(ctx, d_records, n, d_bodies, pitch, d_public, d_status, stream);
+      if (rc) { ctx->variant = saved; return rc; }
+    }
+    rc = b3w_batch_time_device(ctx, d_records, n, d_bodies, pitch, d_public, d_status, stream, 5, &ms);
+    if (rc) { ctx->variant = saved; return rc; }
+    if (ms < best_ms) { best_ms = ms; best = c; }
+  }
+  ctx->variant = best;
+  if (chosen_variant) *chosen_variant = best;
+  if (chosen_ms) *chosen_ms = best_ms;
+  return B3W_OK;
 }
 
 int32_t b3w_batch_time_device(b3w_ctx *ctx, const uint32_t *d_records, uint32_t n, uint8_t *d_bodies, uint64_t pitch,

@@ -686,16 +686,16 @@ int launch_sweep(const uint32_t *d_images, uint32_t n, uint8_t *d_out, uint64_t 
   const uintptr_t addr = reinterpret_cast<uintptr_t>(d_out);
   if (pitch >= (1ull << 30) || (addr & 31)) return -5;        // one 32-byte slot per lane: bodies must be 32-byte aligned
   const uint32_t lead = (uint32_t)(addr & 4095);
-  static const int shape = getenv("B3W_SWEEP_SHAPE") ? atoi(getenv("B3W_SWEEP_SHAPE")) : 0;
+  static const int shape = getenv("B3W_SWEEP_SHAPE") ? atoi(getenv("B3W_SWEEP_SHAPE")) : 2;   // 2 = two wave-pairs, split
 #define B3W_SWEEP_LAUNCH(PAIRS, SPLIT)                                                                              \
   hipLaunchKernelGGL((b3w_sweep_kernel<WIDE, K, B3W_SWEEP_LOGC, PAIRS, SPLIT>), dim3(B3W_SWEEP_GRID), dim3(128 * PAIRS), 0, \
                      stream, d_images, n, d_out - lead, lead, (uint32_t)pitch, d_table, nwit)
   switch (shape) {
     case 1: B3W_SWEEP_LAUNCH(1, false); break;
-    case 2: B3W_SWEEP_LAUNCH(2, true); break;
     case 3: B3W_SWEEP_LAUNCH(4, true); break;
     case 4: B3W_SWEEP_LAUNCH(3, true); break;
-    default: B3W_SWEEP_LAUNCH(2, false); break;
+    case 0: B3W_SWEEP_LAUNCH(2, false); break;
+    default: B3W_SWEEP_LAUNCH(2, true); break;
   }
 #undef B3W_SWEEP_LAUNCH
   return (int)hipGetLastError();

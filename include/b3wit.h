@@ -123,6 +123,14 @@ int32_t b3w_batch_time_device(b3w_ctx *ctx, const uint32_t *d_records, uint32_t 
                               uint64_t pitch, uint32_t *d_public, int32_t *d_status, void *stream,
                               uint32_t iters, float *avg_ms);
 
+/* Choose the fastest bit-identical kernel variant for THIS output buffer (fused one-kernel path vs the
+ * two-kernel sweep path, DESIGN.md "Roofline"): runs and times each candidate on the caller's device
+ * buffers, which end up holding the correct witnesses, and keeps the winner in the ctx for later
+ * b3w_batch_run_device calls.  Allocates the sweep scratch on first use; not for stream capture. */
+int32_t b3w_batch_autotune_device(b3w_ctx *ctx, const uint32_t *d_records, uint32_t n, uint8_t *d_bodies,
+                                  uint64_t pitch, uint32_t *d_public, int32_t *d_status, void *stream,
+                                  int32_t *chosen_variant, float *chosen_ms);
+
 /* ---- chained ("nova fold") mode: step-input planner -----------------------------------------
  * Device counterpart of the reference's per-step input construction: Blake3BlockCompressCircuit::
  * {new, update_for_step, format_input} (rust_fold/src/blake3_circuit.rs:160-289), Blake3CompressPubIO::new

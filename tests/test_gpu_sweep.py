@@ -115,3 +115,22 @@ def test_sweep_several_scratch_chunks(m):
     got = d_bodies[torch.from_numpy(idx).to(dev)].cpu().numpy()
     assert np.array_equal(got, want)
     ctx.close()
+
+
+def test_autotune_picks_a_variant_and_stays_bit_exact(m):
+    import torch
+    n = 512
+    recs = T.workloads().config2_compression(n, first=77)
+    ctx = m.Context("compression", 0)
+    dev = torch.device("cuda:0")
+    d_recs = torch.from_numpy(recs.view(np.int32)).to(dev)
+    d_bodies = torch.empty((n, ctx.body_bytes), dtype=torch.uint8, device=dev)
+    d_st = torch.zeros(n, dtype=torch.int32, device=dev)
+    v, ms = ctx.autotune_device(d_recs.data_ptr(), n, d_bodies.data_ptr(), 0, 0, d_st.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    assert v in (0, 100) and ms > 0
+    d_bodies.fill_(7)
+    ctx.run_device(d_recs.data_ptr(), n, d_bodies.data_ptr(), 0, 0, d_st.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    _, want = T.oracle_batch_u32("compression", recs[:64])
+    assert np.array_equal(d_bodies[:64].cpu().numpy(), want)
+    ctx.close()
