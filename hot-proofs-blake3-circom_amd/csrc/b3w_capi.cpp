@@ -624,6 +624,64 @@ int32_t b3w_batch_fetch(b3w_batch *b, uint32_t index, uint8_t *out_body) {
   return B3W_OK;
 }
 
+int32_t b3w_batch_write_wtns(b3w_batch *b, uint32_t first, uint32_t count, const char *dir, const char *prefix,
+                             uint32_t *written) {
+  if (!b || !dir || !prefix || first + count > b->n) return B3W_E_BAD_ARGUMENT;
+  b3w_ctx *ctx = b->ctx;
+  const size_t body = (size_t)ctx->desc.nwit * 32;
+  const uint32_t CH = 64;                                  // witnesses per staging buffer (~48 MB)
+  uint8_t hdr[76];
+  b3w_write_wtns_header(ctx, hdr);
+  std::vector<int32_t> st(count);
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, hipMemcpy(st.data(), b->d_status + first, (size_t)count * 4, hipMemcpyDeviceToHost));
+  uint8_t *stage[2] = {nullptr, nullptr};
+  hipStream_t cs;
+  hipEvent_t ev[2];
+  HIP_TRY(ctx, hipStreamCreate(&cs));
+  for (int i = 0; i < 2; i++) {
+    HIP_TRY(ctx, hipHostMalloc((void **)&stage[i], CH * body, hipHostMallocDefault));
+    HIP_TRY(ctx, hipEventCreate(&ev[i]));
+  }
+  auto issue = [&](uint32_t chunk) -> hipError_t {
+    const uint32_t c0 = chunk * CH, cn = count - c0 < CH ? count - c0 : CH;
+    hipError_t e = hipMemcpy2DAsync(stage[chunk & 1], body, b->d_bodies + (size_t)(first + c0) * b->pitch, b->pitch, body, cn,
+                                    hipMemcpyDeviceToHost, cs);
+    if (e == hipSuccess) e = hipEventRecord(ev[chunk & 1], cs);
+    return e;
+  };
+  const uint32_t nchunks = (count + CH - 1) / CH;
+  uint32_t nwritten = 0;
+  int32_t rc = B3W_OK;
+  if (nchunks) { hipError_t e = issue(0); if (e != hipSuccess) rc = hip_fail(ctx, e, "D2H"); }
+  for (uint32_t k = 0; k < nchunks && rc == B3W_OK; k++) {
+    if (k + 1 < nchunks) { hipError_t e = issue(k + 1); if (e != hipSuccess) { rc = hip_fail(ctx, e, "D2H"); break; } }
+    hipError_t e = hipEventSynchronize(ev[k & 1]);
+    if (e != hipSuccess) { rc = hip_fail(ctx, e, "D2H wait"); break; }
+    const uint32_t c0 = k * CH, cn = count - c0 < CH ? count - c0 : CH;
+    for (uint32_t i = 0; i < cn; i++) {
+      if (st[c0 + i] != 0) continue;
+      char path[1024];
+      snprintf(path, sizeof path, "%s/%s%u.wtns", dir, prefix, first + c0 + i);
+      FILE *f = fopen(path, "wb");
+      if (!f || fwrite(hdr, 1, 76, f) != 76 || fwrite(stage[k & 1] + (size_t)i * body, 1, body, f) != body) {
+        if (f) fclose(f);
+        ctx->last_error = std::string("cannot write ") + path;
+        rc = B3W_E_BAD_ARGUMENT;
+        break;
+      }
+      fclose(f);
+      nwritten++;
+    }
+    // the staging buffer written from is reused by chunk k+2, issued in the next iteration: safe, we are done with it
+  }
+  (void)hipStreamSynchronize(cs);
+  for (int i = 0; i < 2; i++) { (void)hipHostFree(stage[i]); (void)hipEventDestroy(ev[i]); }
+  (void)hipStreamDestroy(cs);
+  if (written) *written = nwritten;
+  return rc;
+}
+
 void *b3w_batch_device_ptr(b3w_batch *b, uint64_t *pitch) {
   if (!b) return nullptr;
   if (pitch) *pitch = b->pitch;

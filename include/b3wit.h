@@ -123,6 +123,15 @@ int32_t b3w_batch_time_device(b3w_ctx *ctx, const uint32_t *d_records, uint32_t 
                               uint64_t pitch, uint32_t *d_public, int32_t *d_status, void *stream,
                               uint32_t iters, float *avg_ms);
 
+/* Streaming .wtns writer (the hand-off the reference does one file at a time: generate_witness.js:15-18,
+ * circomkit `witness` in test/witness_gen.test.ts:41): witnesses [first, first+count) of the last
+ * b3w_batch_run are copied to the host through two pinned staging buffers (D2H of chunk k+1 overlaps the
+ * file writes of chunk k) and written as <dir>/<prefix><index>.wtns, each byte-identical to
+ * calculateWTNSBin's image (76-byte header + body).  Witnesses whose status is not 0 are skipped.
+ * Returns the number of files written in *written.  PCIe-bound (about 70 k witnesses/s). */
+int32_t b3w_batch_write_wtns(b3w_batch *batch, uint32_t first, uint32_t count, const char *dir, const char *prefix,
+                             uint32_t *written);
+
 /* Choose the fastest bit-identical kernel variant for THIS output buffer (fused one-kernel path vs the
  * two-kernel sweep path, DESIGN.md "Roofline"): runs and times each candidate on the caller's device
  * buffers, which end up holding the correct witnesses, and keeps the winner in the ctx for later

@@ -177,3 +177,34 @@ def test_compression_full_config2_batch(m):
     torch.cuda.synchronize()
     assert d_bodies.view(torch.int64).sum().item() == ck
     ctx.close()
+
+
+def test_streaming_wtns_writer(m, tmp_path):
+    """b3w_batch_write_wtns: every file equals calculateWTNSBin's image (goldens + oracle), rejected steps skipped."""
+    import hashlib
+    g = T.golden("compression")
+    cases = [c for c in g["cases"] if "error" not in c and T.is_canonical_u32("compression", c["input"])][:40]
+    W = T.workloads()
+    recs = np.array([W.input_to_values(c["input"], W.COMPRESSION_KEYS) for c in cases], dtype=np.uint32)
+    recs = np.concatenate([recs, W.config2_compression(150, first=9000)])          # several staging chunks
+    ctx = _ctx(m, "compression")
+    b = m.Batch(ctx, recs.shape[0], 771072)                                        # padded pitch on the device, files stay packed
+    b.run(recs)
+    assert b.write_wtns(tmp_path, "w") == recs.shape[0]
+    for i, c in enumerate(cases):
+        assert hashlib.sha256((tmp_path / f"w{i}.wtns").read_bytes()).hexdigest() == c["wtns_sha256"], c["name"]
+    _, want = T.oracle_batch_u32("compression", recs[40:])
+    hdr = T.oracle_header("compression")
+    for i in (40, 41, 103, 104, 167, 189):
+        assert (tmp_path / f"w{i}.wtns").read_bytes() == hdr + want[i - 40].tobytes()
+    b.close(); ctx.close()
+    # nova: a rejected step produces no file
+    nrecs = W.config3_nova(9, first=5).copy()
+    nrecs[4, 14] = nrecs[4, 12]
+    ctx = _ctx(m, "nova_vesta")
+    b = m.Batch(ctx, 9)
+    b.run(nrecs)
+    assert b.write_wtns(tmp_path, "n") == 8 and not (tmp_path / "n4.wtns").exists()
+    _, want = T.oracle_batch_u32("nova_vesta", nrecs)
+    assert (tmp_path / "n8.wtns").read_bytes() == T.oracle_header("nova_vesta") + want[8].tobytes()
+    b.close(); ctx.close()
