@@ -36,6 +36,7 @@ struct Api {
   decltype(&b3w_batch_run) batch_run;
   decltype(&b3w_batch_outputs) batch_outputs;
   decltype(&b3w_batch_fetch) batch_fetch;
+  decltype(&b3w_batch_write_wtns) batch_write_wtns;
   std::string err;
 } api;
 
@@ -57,7 +58,7 @@ bool load_api() {
   if (!api.name) { api.err = "libb3wit.so lacks b3w_" #name; dlclose(so); return false; }
   SYM(abi_version) SYM(identify_wasm) SYM(create) SYM(destroy) SYM(info) SYM(input_signal_size) SYM(calc_witness)
   SYM(write_wtns_header) SYM(last_error) SYM(public_words) SYM(batch_alloc) SYM(batch_free) SYM(batch_run)
-  SYM(batch_outputs) SYM(batch_fetch)
+  SYM(batch_outputs) SYM(batch_fetch) SYM(batch_write_wtns)
 #undef SYM
   api.so = so;
   return true;
@@ -280,6 +281,28 @@ napi_value BatchFetch(napi_env env, napi_callback_info info) {
   return out;
 }
 
+// batchWriteWtns(handle, first, count, dir, prefix) -> number of .wtns files written (streamed D2H)
+napi_value BatchWriteWtns(napi_env env, napi_callback_info info) {
+  size_t argc = 5; napi_value argv[5];
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+  Handle *h = get_handle(env, argv[0]);
+  if (!h) return nullptr;
+  if (!h->batch) { napi_throw_error(env, nullptr, "batchWriteWtns before batchRun"); return nullptr; }
+  uint32_t first = 0, count = 0;
+  NAPI_OK(napi_get_value_uint32(env, argv[1], &first));
+  NAPI_OK(napi_get_value_uint32(env, argv[2], &count));
+  char dir[1024], prefix[256];
+  size_t n1 = 0, n2 = 0;
+  NAPI_OK(napi_get_value_string_utf8(env, argv[3], dir, sizeof dir, &n1));
+  NAPI_OK(napi_get_value_string_utf8(env, argv[4], prefix, sizeof prefix, &n2));
+  uint32_t written = 0;
+  const int32_t rc = api.batch_write_wtns(h->batch, first, count, dir, prefix, &written);
+  if (rc != B3W_OK) return throw_status(env, h, rc, "b3w_batch_write_wtns failed");
+  napi_value out;
+  NAPI_OK(napi_create_uint32(env, written, &out));
+  return out;
+}
+
 napi_value AbiVersion(napi_env env, napi_callback_info) {
   if (!load_api()) { napi_throw_error(env, nullptr, api.err.c_str()); return nullptr; }
   napi_value out;
@@ -298,6 +321,7 @@ napi_value Init(napi_env env, napi_value exports) {
       {"wtnsHeader", nullptr, WtnsHeader, nullptr, nullptr, nullptr, napi_default, nullptr},
       {"batchRun", nullptr, BatchRun, nullptr, nullptr, nullptr, napi_default, nullptr},
       {"batchFetch", nullptr, BatchFetch, nullptr, nullptr, nullptr, napi_default, nullptr},
+      {"batchWriteWtns", nullptr, BatchWriteWtns, nullptr, nullptr, nullptr, napi_default, nullptr},
   };
   napi_define_properties(env, exports, sizeof props / sizeof props[0], props);
   return exports;

@@ -145,11 +145,15 @@ class WitnessCalculator {
   }
 
   // ---- extension: packed u32 records (h m t b d | nova step record), many witnesses per call.
-  // Returns { n, publicOutputs: Uint32Array, status: Int32Array, fetch(i) -> Uint8Array body }.
+  // Returns { n, publicOutputs: Uint32Array, status: Int32Array, fetch(i) -> Uint8Array body,
+  //           writeWtns(dir, prefix) -> number of files }.
   async calculateWitnessBatch(records) {
     const nat = native();
     const r = nat.batchRun(this.instance, records);
     r.fetch = (i) => nat.batchFetch(this.instance, i);
+    // stream every witness of the batch to <dir>/<prefix><index>.wtns (same bytes as calculateWTNSBin)
+    r.writeWtns = (dir, prefix, first, count) =>
+      nat.batchWriteWtns(this.instance, first || 0, count === undefined ? r.n - (first || 0) : count, dir, prefix || "witness_");
     return r;
   }
 }

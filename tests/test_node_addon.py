@@ -112,10 +112,12 @@ def test_js_surface_errors_and_batch(tmp_path):
         cases.forEach((c, k) => { const v = [].concat(c.input.h, c.input.m, c.input.t, [c.input.b, c.input.d]); v.forEach((x, j) => recs[28 * k + j] = Number(x)); });
         const b = await wc.calculateWitnessBatch(recs);
         out.batch = {n: b.n, status: Array.from(b.status), pub0: Array.from(b.publicOutputs.slice(0, 16)).map(String),
-                     body3: crypto.createHash('sha256').update(b.fetch(3)).digest('hex')};
+                     body3: crypto.createHash('sha256').update(b.fetch(3)).digest('hex'),
+                     files: b.writeWtns(process.argv[3], 'js_'),
+                     file5: crypto.createHash('sha256').update(fs.readFileSync(process.argv[3] + '/js_5.wtns')).digest('hex')};
         console.log(JSON.stringify(out));
       })().catch(e => { console.error(e); process.exit(1); });
-    """, str(tmp_path / "cases.json"), json.dumps(neg["input"]))
+    """, str(tmp_path / "cases.json"), json.dumps(neg["input"]), str(tmp_path))
     assert r.returncode == 0, r.stderr
     out = json.loads(r.stdout.strip().splitlines()[-1])
     assert out["fields"] == [2, 8, 24093, str(T.BN254_R), 2]
@@ -131,3 +133,4 @@ def test_js_surface_errors_and_batch(tmp_path):
     assert out["batch"]["n"] == 8 and out["batch"]["status"] == [0] * 8
     assert out["batch"]["pub0"] == [str(x) for x in cases[0]["first16"][1:]] + [out["batch"]["pub0"][15]]
     assert out["batch"]["body3"] == cases[3]["body_sha256"]
+    assert out["batch"]["files"] == 8 and out["batch"]["file5"] == cases[5]["wtns_sha256"]
