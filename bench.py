@@ -126,10 +126,17 @@ def main():
             raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the product has no CPU path")
+    ndev = torch.cuda.device_count()
+    if local_rank >= ndev and os.environ.get("B3W_DIST_BACKEND", "nccl") != "nccl":
+        local_rank = local_rank % ndev                      # dry run: several ranks share one GPU
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        backend = os.environ.get("B3W_DIST_BACKEND", "nccl")      # "nccl" = RCCL over xGMI; "gloo" only for dry runs
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
 
     if args.variant is not None:
         os.environ["B3W_VARIANT"] = str(args.variant)

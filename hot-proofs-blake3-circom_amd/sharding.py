@@ -25,6 +25,9 @@ def gather_public(pub_local, n_total=None, group=None):
     if world == 1:
         return pub_local
     words = pub_local.shape[1]
+    if pub_local.is_cuda and dist.get_backend(group) == "gloo":
+        # CPU rehearsal of the exchange (tests / single-GPU dry runs): stage through the host
+        return gather_public(pub_local.cpu(), n_total, group).to(pub_local.device)
     if n_total is None:
         cnt = torch.tensor([pub_local.shape[0]], dtype=torch.int64, device=pub_local.device)
         dist.all_reduce(cnt, group=group)
