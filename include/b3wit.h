@@ -38,7 +38,8 @@ extern "C" {
 #define B3W_E_BAD_ARGUMENT       100
 #define B3W_E_NO_DEVICE          101 /* no HIP device / HIP runtime error: the product has no CPU path */
 #define B3W_E_HIP                102
-#define B3W_E_DOMAIN             103 /* input outside the device fast-path domain (see DESIGN.md "Input domain") */
+#define B3W_E_DOMAIN             103 /* batch status only: record outside the batch kernels' domain (DESIGN.md "Input domain");
+                                        b3w_calc_witness evaluates such inputs with the exact kernel instead */
 #define B3W_E_NOT_ALL_INPUTS     104 /* WC:166-168 "Not all inputs have been set" */
 
 typedef struct b3w_ctx b3w_ctx;
@@ -72,8 +73,11 @@ int32_t b3w_input_signal_size(const b3w_ctx *ctx, uint64_t fnv1a64_of_name);
  *   values_le32               : sum(counts) field elements, 32-byte little-endian, already
  *                               reduced into [0,p) (WC:319-323 normalize), in key order
  *   out_body                  : witness_size*32 bytes, canonical little-endian elements
+ * Any field elements are accepted: canonical records run through the batch kernel, everything else
+ * through the exact (256-bit field arithmetic) device kernel — both on the GPU.
  * Size errors mirror WC:142-150 (B3W_E_TOO_MANY_SIGNALS / B3W_E_ARRAY_ACCESS /
- * B3W_E_NOT_ALL_INPUTS); a failed circuit assert returns B3W_E_ASSERT_FAILED. */
+ * B3W_E_NOT_ALL_INPUTS); a failed circuit assert returns B3W_E_ASSERT_FAILED and b3w_last_error gives
+ * the reference WASM's own trace text ("Assert Failed.\nError in template Bits34_1 line: 201\n..."). */
 int32_t b3w_calc_witness(b3w_ctx *ctx, const uint64_t *name_hashes, const uint32_t *counts,
                          const uint8_t *values_le32, uint32_t nkeys, uint8_t *out_body);
 
