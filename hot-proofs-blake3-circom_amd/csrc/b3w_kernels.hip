@@ -230,7 +230,7 @@ struct SweepPos {          // tile t of the sweep: first body it touches and the
 __device__ __forceinline__ uint32_t uni(uint32_t x) { return (uint32_t)__builtin_amdgcn_readfirstlane((int)x); }
 
 // one lane's pipeline registers for a step of K tiles (one 32-byte slot per lane and tile), plus the
-// step's wave-uniform tile positions, computed once (table stage) and carried to the later stages
+// step's wave-uniform tile positions, computed once and carried from the fetch stage to the emit stage
 template <int K, int NW>
 struct SweepRegs {
   uint32_t e[K]; uint32_t a[K][NW]; uint32_t ok[K];
@@ -238,19 +238,20 @@ struct SweepRegs {
   bool fast;                                  // uniform: every tile of the step is interior to one body
 };
 
-// Shape (measured, tools/ubench/store_shapes2.hip): exactly 256 workgroups, 4 KiB tiles, tile t of workgroup
-// b = b + 256k.  128 lanes x one 32-byte slot each gives that tile with half the per-byte instruction
-// count of 256 lanes x 16 bytes; two waves per CU must issue everything, so the loop is kept lean:
-// 32-bit position arithmetic (pitch < 2^30, scratch rows of 2^LOGC witnesses), SGPR-based addressing,
-// tile positions computed once per step, and an interior fast path without per-lane position logic.
-// PAIRS wave-pairs per workgroup: pair q takes the workgroup's tiles k = q, q+PAIRS, ... — a second
-// independent pipeline per CU to cover load latency (store_shapes3.hip: the fill rate survives PAIRS = 2).
-// SPLIT: pair q takes a contiguous share of the workgroup's tile sequence instead of every PAIRS-th tile.
+// Shape (measured, tools/ubench/store_shapes2/3.hip): exactly 256 workgroups, 4 KiB tiles, tile t of
+// workgroup b = b + 256k; 128 lanes x one 32-byte slot each; PAIRS wave-pairs per workgroup, pair q owning a
+// contiguous share (SPLIT) or every PAIRS-th (interleaved) of the workgroup's tile sequence.  One wave per
+// SIMD has to issue everything, so the loop is kept lean: the whole slot table lives in LDS (one workgroup
+// per CU, so the 96 KB are free), 32-bit position arithmetic in SGPRs (pitch < 2^30, scratch rows of 2^LOGC
+// witnesses), image words fetched two steps ahead in a register-only pipeline, rare second/wide words
+// fetched only by waves that hold such a slot, and an interior-tile fast path without per-lane position logic.
 template <bool WIDE, int K, int LOGC, int PAIRS, bool SPLIT>
 __global__ __launch_bounds__(128 * PAIRS, 1) void b3w_sweep_kernel(const uint32_t *__restrict__ scr, uint32_t n,
-                                                           uint8_t *__restrict__ out_base, uint32_t lead, uint32_t pitch,
-                                                           const uint32_t *__restrict__ table, uint32_t nwit) {
+                                                                   uint8_t *__restrict__ out_base, uint32_t lead, uint32_t pitch,
+                                                                   const uint32_t *__restrict__ table, uint32_t nwit) {
   constexpr int NW = WIDE ? 8 : 2;                       // image words a slot can need
+  extern __shared__ __attribute__((aligned(16))) uint32_t tab[];   // the slot table, nwit words
+  for (uint32_t i = threadIdx.x; i < nwit; i += 128 * PAIRS) tab[i] = table[i];
   const uint32_t tid = threadIdx.x % 128u, tid32 = tid * 32u, pair = uni(threadIdx.x / 128u);
   const uint32_t G = SPLIT ? gridDim.x : gridDim.x * PAIRS;   // tile stride of one wave-pair
   const uint32_t body = 32u * nwit;
@@ -265,7 +266,7 @@ __global__ __launch_bounds__(128 * PAIRS, 1) void b3w_sweep_kernel(const uint32_
   const uint32_t ntiles = uni(end_seq > 0 ? blockIdx.x + (end_seq - 1) * G0 + 1 : 0);   // exclusive tile bound of this pair
   const uint64_t stride = (uint64_t)G * 4096;
   const uint32_t dq = (uint32_t)(stride / pitch), dr = (uint32_t)(stride % pitch);
-  // running position of the table stage (wave-uniform)
+  // running position of the fetch stage (wave-uniform)
   uint32_t pt = uni(blockIdx.x + G0 * first_seq), pw;
   int32_t prem;
   {
@@ -273,6 +274,7 @@ __global__ __launch_bounds__(128 * PAIRS, 1) void b3w_sweep_kernel(const uint32_
     if (pos < 0) { pw = 0; prem = (int32_t)pos; }
     else { pw = uni((uint32_t)((uint64_t)pos / pitch)); prem = (int32_t)uni((uint32_t)((uint64_t)pos % pitch)); }
   }
+  __syncthreads();                                       // table in LDS
   // a lane's slot of a tile at (rem, w_lo): which witness, byte offset in its body, does it exist
   auto locate = [&](uint32_t t, int32_t rem, uint32_t w_lo, uint32_t &w, uint32_t &r32) {
     int32_t r = rem + (int32_t)tid32;
@@ -281,9 +283,10 @@ __global__ __launch_bounds__(128 * PAIRS, 1) void b3w_sweep_kernel(const uint32_
     r32 = (uint32_t)r;
     return t < ntiles && r32 < body && w < n;            // r < 0 wraps above body
   };
-  // stage 1: positions of the step's K tiles + slot-table words (coalesced).  Loads are unconditional
-  // with clamped addresses so the register sets stay in VGPRs.
-  auto do_table = [&](SweepRegs<K, NW> &rg) {
+  // stage 1: positions of the step's K tiles, slot-table words (LDS) and image words from the word-major
+  // scratch (1-2 cache lines per wave and word).  Loads are unconditional with clamped addresses so the
+  // register sets stay in VGPRs.
+  auto do_fetch = [&](SweepRegs<K, NW> &rg) {
     bool fast = true;
 #pragma unroll
     for (int k = 0; k < K; ++k) {
@@ -296,49 +299,34 @@ __global__ __launch_bounds__(128 * PAIRS, 1) void b3w_sweep_kernel(const uint32_
       prem = (int32_t)uni((uint32_t)(c ? r - (int32_t)pitch : r));
     }
     rg.fast = fast;
-    if (fast) {
-#pragma unroll
-      for (int k = 0; k < K; ++k) rg.e[k] = (table + ((uint32_t)rg.rem[k] >> 5))[tid];   // uniform base + lane
-    } else {
-#pragma unroll
-      for (int k = 0; k < K; ++k) {
-        uint32_t w, r32;
-        const bool in = locate(rg.t[k], rg.rem[k], rg.wlo[k], w, r32);
-        rg.e[k] = table[in ? (r32 >> 5) : 0u];
-      }
-    }
-  };
-  // stage 2: image words from the word-major scratch (1-2 cache lines per wave and word)
-  auto do_words = [&](SweepRegs<K, NW> &rg) {
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-      const uint32_t e = rg.e[k];
-      const uint32_t row = (e & 0xFFFu) << LOGC;
-      uint32_t w = rg.wlo[k];
-      if (!rg.fast) {
+      uint32_t w = rg.wlo[k], e;
+      if (fast) {
+        e = (tab + ((uint32_t)rg.rem[k] >> 5))[tid];     // uniform base + lane
+      } else {
         uint32_t r32;
         const bool in = locate(rg.t[k], rg.rem[k], rg.wlo[k], w, r32);
         w = in ? w : 0u;
+        e = tab[in ? (r32 >> 5) : 0u];
       }
+      rg.e[k] = e;
+      const uint32_t row = (e & 0xFFFu) << LOGC, mode = (e >> 17) & 3u;
       const uint32_t *col = scr + w;                     // fast path: uniform base
       rg.a[k][0] = col[row];
-      rg.a[k][1] = col[row + (1u << LOGC)];
-      if (WIDE) {
-        rg.ok[k] = col[(uint32_t)B3W_LDS_OKWORD << LOGC];   // only the nova circuits reject steps
-        // 256-bit slots (IsZero inverses ...) are 0.3 % of a body: fetch their other six words only in waves that hold one
-        if (__builtin_amdgcn_ballot_w64(((e >> 17) & 3u) == B3W_MODE_W256)) {
+      // second word (add1.inp / add3.inp whole values, ~1 % of the slots) and the 256-bit slots (IsZero inverses,
+      // 0.3 %): fetched only by waves that hold such a slot
+      if (__builtin_amdgcn_ballot_w64(mode >= B3W_MODE_W64)) {
 #pragma unroll
-          for (int x = 2; x < 8; ++x) rg.a[k][x] = col[row + ((uint32_t)x << LOGC)];
-        } else {
-#pragma unroll
-          for (int x = 2; x < 8; ++x) rg.a[k][x] = 0;
-        }
+        for (int x = 1; x < NW; ++x) rg.a[k][x] = col[row + ((uint32_t)x << LOGC)];
       } else {
-        rg.ok[k] = 1u;
+#pragma unroll
+        for (int x = 1; x < NW; ++x) rg.a[k][x] = 0;
       }
+      rg.ok[k] = WIDE ? col[(uint32_t)B3W_LDS_OKWORD << LOGC] : 1u;   // only the nova circuits reject steps
     }
   };
-  // stage 3: shape the 32 bytes and store them
+  // stage 2: shape the 32 bytes and store them
   auto do_emit = [&](const SweepRegs<K, NW> &rg) {
 #pragma unroll
     for (int k = 0; k < K; ++k) {
@@ -368,26 +356,17 @@ __global__ __launch_bounds__(128 * PAIRS, 1) void b3w_sweep_kernel(const uint32_
   };
 
   SweepRegs<K, NW> r0, r1, r2;
-  do_table(r0);                                        // step 0
-  do_table(r1);                                        // step 1
-  do_words(r0);                                        // step 0
-  // step s: REMIT holds step s complete; RWORDS holds step s+1's table words (fetch its image words now);
-  // RTABLE is free (fetch step s+2's table words)
-#define B3W_SWEEP_STEP(REMIT, RWORDS, RTABLE) \
-  {                                            \
-    do_table(RTABLE);                          \
-    do_words(RWORDS);                          \
-    do_emit(REMIT);                            \
-  }
+  do_fetch(r0);                                        // step 0
+  do_fetch(r1);                                        // step 1
+  // step s: emit REMIT (fetched two steps ago) after starting the fetch of step s+2 into RFETCH
   while (true) {
     if (r0.t[0] >= ntiles) break;
-    B3W_SWEEP_STEP(r0, r1, r2)
+    do_fetch(r2); do_emit(r0);
     if (r1.t[0] >= ntiles) break;
-    B3W_SWEEP_STEP(r1, r2, r0)
+    do_fetch(r0); do_emit(r1);
     if (r2.t[0] >= ntiles) break;
-    B3W_SWEEP_STEP(r2, r0, r1)
+    do_fetch(r1); do_emit(r2);
   }
-#undef B3W_SWEEP_STEP
 }
 
 // ------------------------------------------------------------------ compression circuit
@@ -687,9 +666,19 @@ int launch_sweep(const uint32_t *d_images, uint32_t n, uint8_t *d_out, uint64_t 
   if (pitch >= (1ull << 30) || (addr & 31)) return -5;        // one 32-byte slot per lane: bodies must be 32-byte aligned
   const uint32_t lead = (uint32_t)(addr & 4095);
   static const int shape = getenv("B3W_SWEEP_SHAPE") ? atoi(getenv("B3W_SWEEP_SHAPE")) : 2;   // 2 = two wave-pairs, split
+  const size_t smem = (size_t)nwit * 4 + 16;                 // the slot table
 #define B3W_SWEEP_LAUNCH(PAIRS, SPLIT)                                                                              \
-  hipLaunchKernelGGL((b3w_sweep_kernel<WIDE, K, B3W_SWEEP_LOGC, PAIRS, SPLIT>), dim3(B3W_SWEEP_GRID), dim3(128 * PAIRS), 0, \
-                     stream, d_images, n, d_out - lead, lead, (uint32_t)pitch, d_table, nwit)
+  {                                                                                                                 \
+    static bool attr_done = false;                                                                                  \
+    if (!attr_done) {                                                                                               \
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&b3w_sweep_kernel<WIDE, K, B3W_SWEEP_LOGC, PAIRS, SPLIT>), \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);                    \
+      if (e != hipSuccess) return (int)e;                                                                           \
+      attr_done = true;                                                                                             \
+    }                                                                                                               \
+    hipLaunchKernelGGL((b3w_sweep_kernel<WIDE, K, B3W_SWEEP_LOGC, PAIRS, SPLIT>), dim3(B3W_SWEEP_GRID), dim3(128 * PAIRS), smem, \
+                       stream, d_images, n, d_out - lead, lead, (uint32_t)pitch, d_table, nwit);                    \
+  }
   switch (shape) {
     case 1: B3W_SWEEP_LAUNCH(1, false); break;
     case 3: B3W_SWEEP_LAUNCH(4, true); break;
