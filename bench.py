@@ -200,12 +200,13 @@ def main():
         alg_bytes = BYTES_PER_WITNESS[circuit] * n                   # per launch
         achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
         traffic = None
-        tf = os.path.join(ROOT, "profiles", "traffic_latest.json")   # PMC pass (WRITE_SIZE/FETCH_SIZE), see profiles/README.md
+        tf = os.path.join(ROOT, "profiles", "traffic_latest.json")   # PMC passes (WRITE_SIZE/FETCH_SIZE), see profiles/README.md
         if os.path.exists(tf):
             try:
-                tj = json.load(open(tf))
-                if tj.get("circuit") == circuit and tj.get("batch") == n:
-                    traffic = tj.get("hbm_bytes_per_launch")
+                path = "sweep" if chosen >= 100 else "fused"
+                for ent in json.load(open(tf)).get("entries", []):
+                    if ent.get("circuit") == circuit and ent.get("batch") == n and ent.get("path") == path:
+                        traffic = ent.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
         out = {
