@@ -51,7 +51,6 @@ def fold_witnesses(ctx, preimage, batch_steps=16384, ring=2, slice_chunks=1024, 
     has_last = c1 == n
     n_leaf = nl * 16 - ((16 - last_blocks) if has_last else 0)
     n_par = nl * P if (with_parents and complete) else 0
-    nsteps = n_leaf + n_par
     body = ctx.body_bytes
 
     pinned = host if host.is_pinned() else None

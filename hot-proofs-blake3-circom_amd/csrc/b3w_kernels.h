@@ -3,9 +3,6 @@
 #include <hip/hip_runtime_api.h>
 #include <stdint.h>
 
-// number of tuning variants of the compression kernel (witnesses per wave, store flavour)
-#define B3W_NUM_VARIANTS 8
-
 // variants >= B3W_VARIANT_SWEEP use the two-kernel path (TRACE -> HBM scratch -> linear SWEEP of the output)
 #define B3W_VARIANT_SWEEP 100
 #define B3W_SWEEP_GRID 256       // one 256-thread workgroup per CU, tile = 4 KiB: the runtime fill kernel's shape
