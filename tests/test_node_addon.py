@@ -74,7 +74,7 @@ def test_generate_witness_cli_reproduces_goldens(circuit, tmp_path):
         case = next(c for c in g["cases"] if c["name"] == f[len(circuit) + 1:-len(".wtns.gz")])
         inp, out = tmp_path / "in.json", tmp_path / "out.wtns"
         inp.write_text(json.dumps(case["input"]))
-        r = subprocess.run([NODE, os.path.join(JS, "generate_witness.js"), circuit, str(inp), str(out)],
+        r = subprocess.run([NODE, os.path.join(JS, "b3wit_cli.js"), circuit, str(inp), str(out)],
                            capture_output=True, text=True, timeout=300)
         assert r.returncode == 0, r.stderr
         assert out.read_bytes() == T.golden_image(f)
