@@ -61,7 +61,7 @@ def test_exact_kernel_matches_oracle_on_wild_inputs(circuit):
     m = T.pkg()
     wc = m.builder(circuit)
     nok = nrej = 0
-    for inp in _wild_inputs(circuit, 48, 77):
+    for inp in _wild_inputs(circuit, 160, 77):
         rc, want, _ = T.oracle_witness(circuit, T.normalize_input(circuit, inp))
         if rc == 0:
             got = wc.calculateBinWitness(inp, 0)
@@ -72,4 +72,4 @@ def test_exact_kernel_matches_oracle_on_wild_inputs(circuit):
                 wc.calculateBinWitness(inp, 0)
             assert e.value.status == m.B3W_E_ASSERT_FAILED
             nrej += 1
-    assert nok >= 20 and nrej >= 3, (nok, nrej)
+    assert nok >= 80 and nrej >= 10, (nok, nrej)
