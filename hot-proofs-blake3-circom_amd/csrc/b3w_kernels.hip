@@ -369,174 +369,6 @@ __global__ __launch_bounds__(128 * PAIRS, 1) void b3w_sweep_kernel(const uint32_
   }
 }
 
-// ---- producer/consumer form of the sweep: the fill shape in its purest form is ONE wave-pair per
-// workgroup issuing nothing but stores (store_shapes2.hip: 6.5 TB/s).  Here waves 0-1 are that pair: per tile
-// they read their lane's finished 8 (32 for nova) bytes from an LDS ring and store them.  HP helper pairs
-// (waves 2..) do everything else — positions, slot-table lookups (table in LDS), image-word gathers from the
-// scratch with a two-step register pipeline, shaping — and fill the ring one step (K tiles) ahead.  One
-// workgroup barrier per step; ring is double buffered.
-template <bool WIDE, int K, int LOGC, int HP>
-__global__ __launch_bounds__(128 + 128 * HP, 1) void b3w_sweep_pc_kernel(const uint32_t *__restrict__ scr, uint32_t n,
-                                                                       uint8_t *__restrict__ out_base, uint32_t lead,
-                                                                       uint32_t pitch, const uint32_t *__restrict__ table,
-                                                                       uint32_t nwit) {
-  static_assert(K % HP == 0, "helpers split a step evenly");
-  constexpr int KH = K / HP;                             // tiles per helper pair and step
-  constexpr int NW = WIDE ? 8 : 2;                       // words per slot in the ring / image words a slot can need
-  extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
-  const uint32_t ntab = (nwit + 3) & ~3u;
-  uint32_t *tab = smem;                                  // slot table
-  uint32_t *ring = smem + ntab;                          // [2][K][128][NW]
-  uint32_t *maskw = ring + 2 * K * 128 * NW;             // [2][K][2 waves][2 words]: lanes that store
-  for (uint32_t i = threadIdx.x; i < nwit; i += blockDim.x) tab[i] = table[i];
-  const uint32_t wid = uni(threadIdx.x / 64u);
-  const uint32_t body = 32u * nwit;
-  const uint64_t total = (uint64_t)lead + (uint64_t)n * pitch;
-  const uint32_t ntiles = (uint32_t)((total + 4095) >> 12);
-  const uint32_t G0 = gridDim.x;
-  const uint32_t nseq = ntiles > blockIdx.x ? (ntiles - blockIdx.x + G0 - 1) / G0 : 0;   // tiles of this workgroup
-  const uint32_t nsteps = (nseq + K - 1) / K;
-  __syncthreads();                                       // table in LDS
-
-  if (wid < 2) {
-    // ------------------------------------------------ store pair
-    const uint32_t lane128 = threadIdx.x;                // 0..127
-    const uint32_t half = wid;                           // which 64-lane half of the tile
-    const uint32_t lane = lane128 & 63u;
-    for (uint32_t s = 0; s <= nsteps; ++s) {
-      if (s >= 1) {
-        const uint32_t buf = (s - 1) & 1u;
-#pragma unroll
-        for (int k = 0; k < K; ++k) {
-          const uint32_t j = (s - 1) * K + k;
-          if (j < nseq) {
-            const uint32_t *mw = maskw + ((buf * K + k) * 2 + half) * 2;
-            const uint64_t mask = (uint64_t)uni(mw[0]) | ((uint64_t)uni(mw[1]) << 32);
-            const uint32_t *src = ring + ((buf * K + k) * 128 + lane128) * NW;
-            uint4 lo, hi;
-            if (WIDE) {
-              lo = *reinterpret_cast<const uint4 *>(src);
-              hi = *reinterpret_cast<const uint4 *>(src + 4);
-            } else {
-              const uint2 v = *reinterpret_cast<const uint2 *>(src);
-              lo = make_uint4(v.x, v.y, 0, 0);
-              hi = make_uint4(0, 0, 0, 0);
-            }
-            if ((mask >> lane) & 1ull) {
-              uint8_t *dst = out_base + (uint64_t)(blockIdx.x + G0 * j) * 4096 + lane128 * 32u;
-              store16<false>(dst, lo);
-              store16<false>(dst + 16, hi);
-            }
-          }
-        }
-      }
-      __syncthreads();
-    }
-  } else {
-    // ------------------------------------------------ helper pairs
-    const uint32_t hp = uni((wid - 2) / 2u), half = uni((wid - 2) & 1u);
-    const uint32_t tid = (threadIdx.x - 128u) % 128u, tid32 = tid * 32u;
-    const uint32_t G = G0 * HP;                           // tile stride of one helper pair
-    const uint64_t stride = (uint64_t)G * 4096;
-    const uint32_t dq = (uint32_t)(stride / pitch), dr = (uint32_t)(stride % pitch);
-    uint32_t pj = hp;                                     // sequence index of the next tile to fetch
-    uint32_t pt = uni(blockIdx.x + G0 * hp), pw;
-    int32_t prem;
-    {
-      const int64_t pos = (int64_t)((uint64_t)pt * 4096) - (int64_t)lead;
-      if (pos < 0) { pw = 0; prem = (int32_t)pos; }
-      else { pw = uni((uint32_t)((uint64_t)pos / pitch)); prem = (int32_t)uni((uint32_t)((uint64_t)pos % pitch)); }
-    }
-    auto locate = [&](uint32_t t, int32_t rem, uint32_t w_lo, uint32_t &w, uint32_t &r32) {
-      int32_t r = rem + (int32_t)tid32;
-      w = w_lo;
-      if (r >= (int32_t)pitch) { r -= (int32_t)pitch; w++; }
-      r32 = (uint32_t)r;
-      return t < ntiles && r32 < body && w < n;
-    };
-    struct HRegs { uint32_t e[KH]; uint32_t a[KH][NW]; uint32_t ok[KH]; uint32_t t[KH], wlo[KH], j[KH]; int32_t rem[KH]; bool fast; };
-    auto do_fetch = [&](HRegs &rg) {
-      bool fast = true;
-#pragma unroll
-      for (int k = 0; k < KH; ++k) {
-        rg.t[k] = pt; rg.rem[k] = prem; rg.wlo[k] = pw; rg.j[k] = pj;
-        fast = fast && pt < ntiles && prem >= 0 && (uint32_t)prem + 4096u <= body && pw < n;
-        const int32_t r = prem + (int32_t)dr;
-        const bool c = r >= (int32_t)pitch;
-        pt = uni(pt + G); pj = uni(pj + HP);
-        pw = uni(pw + dq + (c ? 1u : 0u));
-        prem = (int32_t)uni((uint32_t)(c ? r - (int32_t)pitch : r));
-      }
-      rg.fast = fast;
-#pragma unroll
-      for (int k = 0; k < KH; ++k) {
-        uint32_t w = rg.wlo[k], e;
-        if (fast) {
-          e = (tab + ((uint32_t)rg.rem[k] >> 5))[tid];
-        } else {
-          uint32_t r32;
-          const bool in = locate(rg.t[k], rg.rem[k], rg.wlo[k], w, r32);
-          w = in ? w : 0u;
-          e = tab[in ? (r32 >> 5) : 0u];
-        }
-        rg.e[k] = e;
-        const uint32_t row = (e & 0xFFFu) << LOGC, mode = (e >> 17) & 3u;
-        const uint32_t *col = scr + w;
-        rg.a[k][0] = col[row];
-        if (__builtin_amdgcn_ballot_w64(mode >= B3W_MODE_W64)) {
-#pragma unroll
-          for (int x = 1; x < NW; ++x) rg.a[k][x] = col[row + ((uint32_t)x << LOGC)];
-        } else {
-#pragma unroll
-          for (int x = 1; x < NW; ++x) rg.a[k][x] = 0;
-        }
-        rg.ok[k] = WIDE ? col[(uint32_t)B3W_LDS_OKWORD << LOGC] : 1u;
-      }
-    };
-    // shape the slot and park it in the ring for the store pair
-    auto do_park = [&](const HRegs &rg) {
-#pragma unroll
-      for (int k = 0; k < KH; ++k) {
-        if (rg.j[k] >= nseq) continue;                    // uniform
-        const uint32_t e = rg.e[k];
-        const uint32_t sh = (e >> 12) & 31u, mode = (e >> 17) & 3u;
-        const uint32_t m0 = mode == B3W_MODE_BIT ? 1u : 0xFFFFFFFFu;
-        const uint32_t m1 = mode >= B3W_MODE_W64 ? 0xFFFFFFFFu : 0u;
-        const uint32_t x0 = (rg.a[k][0] >> sh) & m0, x1 = rg.a[k][1] & m1;
-        bool in = true;
-        if (!rg.fast) { uint32_t w, r32; in = locate(rg.t[k], rg.rem[k], rg.wlo[k], w, r32); }
-        const uint32_t slot = rg.j[k] % K, buf = (rg.j[k] / K) & 1u;
-        uint32_t *dst = ring + ((buf * K + slot) * 128 + tid) * NW;
-        if (WIDE) {
-          const uint32_t m2 = mode == B3W_MODE_W256 ? 0xFFFFFFFFu : 0u;
-          *reinterpret_cast<uint4 *>(dst) = make_uint4(x0, x1, rg.a[k][2] & m2, rg.a[k][3] & m2);
-          *reinterpret_cast<uint4 *>(dst + 4) = make_uint4(rg.a[k][4] & m2, rg.a[k][5] & m2, rg.a[k][6] & m2, rg.a[k][7] & m2);
-        } else {
-          *reinterpret_cast<uint2 *>(dst) = make_uint2(x0, x1);
-        }
-        const uint64_t mask = __builtin_amdgcn_ballot_w64(in && rg.ok[k] != 0);
-        if ((threadIdx.x & 63u) == 0) {
-          uint32_t *mw = maskw + ((buf * K + slot) * 2 + half) * 2;
-          mw[0] = (uint32_t)mask; mw[1] = (uint32_t)(mask >> 32);
-        }
-      }
-    };
-    HRegs r0, r1, r2;
-    do_fetch(r0);                                        // step 0
-    do_fetch(r1);                                        // step 1
-    // step s: start the fetch of step s+2, park step s (fetched two steps ago), meet the store pair
-    uint32_t s = 0;
-    while (true) {
-      if (s > nsteps) break;
-      do_fetch(r2); if (s < nsteps) do_park(r0); __syncthreads(); ++s;
-      if (s > nsteps) break;
-      do_fetch(r0); if (s < nsteps) do_park(r1); __syncthreads(); ++s;
-      if (s > nsteps) break;
-      do_fetch(r1); if (s < nsteps) do_park(r2); __syncthreads(); ++s;
-    }
-  }
-}
-
 // ------------------------------------------------------------------ compression circuit
 template <int W, bool NT, bool SWEEP>
 __global__ __launch_bounds__(64) void b3w_compression_kernel(const uint32_t *__restrict__ recs, uint32_t n,
@@ -846,25 +678,6 @@ int launch_sweep(const uint32_t *d_images, uint32_t n, uint8_t *d_out, uint64_t 
     }                                                                                                               \
     hipLaunchKernelGGL((b3w_sweep_kernel<WIDE, K, B3W_SWEEP_LOGC, PAIRS, SPLIT>), dim3(B3W_SWEEP_GRID), dim3(128 * PAIRS), smem, \
                        stream, d_images, n, d_out - lead, lead, (uint32_t)pitch, d_table, nwit);                    \
-  }
-  if (shape >= 5) {
-    constexpr int NWR = WIDE ? 8 : 2;
-    const size_t smem_pc = (((size_t)nwit + 3) & ~(size_t)3) * 4 + (size_t)2 * K * 128 * NWR * 4 + (size_t)2 * K * 2 * 2 * 4 + 16;
-#define B3W_SWEEP_PC_LAUNCH(HPV)                                                                                   \
-  {                                                                                                                 \
-    static bool attr_done = false;                                                                                  \
-    if (!attr_done) {                                                                                               \
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&b3w_sweep_pc_kernel<WIDE, K, B3W_SWEEP_LOGC, HPV>), \
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem_pc);                 \
-      if (e != hipSuccess) return (int)e;                                                                           \
-      attr_done = true;                                                                                             \
-    }                                                                                                               \
-    hipLaunchKernelGGL((b3w_sweep_pc_kernel<WIDE, K, B3W_SWEEP_LOGC, HPV>), dim3(B3W_SWEEP_GRID), dim3(128 + 128 * HPV),  \
-                       smem_pc, stream, d_images, n, d_out - lead, lead, (uint32_t)pitch, d_table, nwit);           \
-  }
-    if (shape == 6) B3W_SWEEP_PC_LAUNCH(4) else B3W_SWEEP_PC_LAUNCH(2)
-#undef B3W_SWEEP_PC_LAUNCH
-    return (int)hipGetLastError();
   }
   switch (shape) {
     case 1: B3W_SWEEP_LAUNCH(1, false); break;
