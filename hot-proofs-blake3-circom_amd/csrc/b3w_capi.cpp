@@ -449,9 +449,11 @@ int32_t b3w_batch_run_device(b3w_ctx *ctx, const uint32_t *d_records, uint32_t n
   const uint64_t body = 32ull * ctx->desc.nwit;
   if (pitch == 0) pitch = body;
   if (pitch < body || (pitch & 31)) { ctx->last_error = "pitch must be >= witness_size*32 and a multiple of 32"; return B3W_E_BAD_ARGUMENT; }
+  if (reinterpret_cast<uintptr_t>(d_bodies) & 15) { ctx->last_error = "d_bodies must be 16-byte aligned"; return B3W_E_BAD_ARGUMENT; }
   int rc = b3w_launch_batch(ctx->desc.kind, ctx->variant, d_records, n, d_bodies, pitch, ctx->d_table, ctx->desc.nwit,
                             d_public, d_status, ctx->d_aux, ctx->d_scratch, ctx->scratch_cap, (hipStream_t)stream);
   if (rc == 0) return B3W_OK;
+  if (rc == -5) { ctx->last_error = "the sweep path needs 32-byte aligned bodies and pitch < 2^30"; return B3W_E_BAD_ARGUMENT; }
   if (rc < 0) { ctx->last_error = "no kernel for this circuit kind / variant"; return B3W_E_BAD_ARGUMENT; }
   return hip_fail(ctx, (hipError_t)rc, "kernel launch");
 }
@@ -473,14 +475,15 @@ int32_t b3w_batch_autotune_device(b3w_ctx *ctx, const uint32_t *d_records, uint3
   for (int c : candidates) {
     ctx->variant = c;
     float ms = 0;
-    for (int w = 0; w < 2; w++) {
+    rc = B3W_OK;
+    for (int w = 0; w < 2 && rc == B3W_OK; w++)
       rc = b3w_batch_run_device(ctx, d_records, n, d_bodies, pitch, d_public, d_status, stream);
-      if (rc) { ctx->variant = saved; return rc; }
-    }
-    rc = b3w_batch_time_device(ctx, d_records, n, d_bodies, pitch, d_public, d_status, stream, 5, &ms);
+    if (rc == B3W_OK) rc = b3w_batch_time_device(ctx, d_records, n, d_bodies, pitch, d_public, d_status, stream, 5, &ms);
+    if (rc == B3W_E_BAD_ARGUMENT) continue;          // this path cannot take these buffers (alignment): not a candidate
     if (rc) { ctx->variant = saved; return rc; }
     if (ms < best_ms) { best_ms = ms; best = c; }
   }
+  if (best_ms >= 1e30f) { ctx->variant = saved; return B3W_E_BAD_ARGUMENT; }
   ctx->variant = best;
   if (chosen_variant) *chosen_variant = best;
   if (chosen_ms) *chosen_ms = best_ms;
