@@ -26,7 +26,7 @@ def __getattr__(name):
     raise AttributeError(name)
 
 PKG_DIR = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(PKG_DIR, "libb3wit.so")
+LIB_PATH = os.environ.get("B3WIT_LIB") or os.path.join(PKG_DIR, "libb3wit.so")   # same override as the N-API addon
 
 CIRCUITS = ("compression", "nova_bn254", "nova_vesta", "nova_bn254_o1")
 CIRCUIT_ID = {c: i for i, c in enumerate(CIRCUITS)}

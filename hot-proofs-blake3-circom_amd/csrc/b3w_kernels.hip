@@ -243,7 +243,7 @@ struct SweepRegs {
 // contiguous share (SPLIT) or every PAIRS-th (interleaved) of the workgroup's tile sequence.  One wave per
 // SIMD has to issue everything, so the loop is kept lean: the whole slot table lives in LDS (one workgroup
 // per CU, so the 96 KB are free), 32-bit position arithmetic in SGPRs (pitch < 2^30, scratch rows of 2^LOGC
-// witnesses), image words fetched two steps ahead in a register-only pipeline, rare second/wide words
+// witnesses), a three-stage register pipeline (table words, image words one step later, emit one more step later), rare second/wide words
 // fetched only by waves that hold such a slot, and an interior-tile fast path without per-lane position logic.
 template <bool WIDE, int K, int LOGC, int PAIRS, bool SPLIT>
 __global__ __launch_bounds__(128 * PAIRS, 1) void b3w_sweep_kernel(const uint32_t *__restrict__ scr, uint32_t n,
@@ -283,10 +283,8 @@ __global__ __launch_bounds__(128 * PAIRS, 1) void b3w_sweep_kernel(const uint32_
     r32 = (uint32_t)r;
     return t < ntiles && r32 < body && w < n;            // r < 0 wraps above body
   };
-  // stage 1: positions of the step's K tiles, slot-table words (LDS) and image words from the word-major
-  // scratch (1-2 cache lines per wave and word).  Loads are unconditional with clamped addresses so the
-  // register sets stay in VGPRs.
-  auto do_fetch = [&](SweepRegs<K, NW> &rg) {
+  // stage 1: positions of the step's K tiles and their slot-table words (LDS)
+  auto do_table = [&](SweepRegs<K, NW> &rg) {
     bool fast = true;
 #pragma unroll
     for (int k = 0; k < K; ++k) {
@@ -301,16 +299,28 @@ __global__ __launch_bounds__(128 * PAIRS, 1) void b3w_sweep_kernel(const uint32_
     rg.fast = fast;
 #pragma unroll
     for (int k = 0; k < K; ++k) {
-      uint32_t w = rg.wlo[k], e;
       if (fast) {
-        e = (tab + ((uint32_t)rg.rem[k] >> 5))[tid];     // uniform base + lane
+        rg.e[k] = (tab + ((uint32_t)rg.rem[k] >> 5))[tid];     // uniform base + lane
       } else {
+        uint32_t w, r32;
+        const bool in = locate(rg.t[k], rg.rem[k], rg.wlo[k], w, r32);
+        rg.e[k] = tab[in ? (r32 >> 5) : 0u];
+      }
+    }
+  };
+  // stage 2 (one step later, so the LDS latency is off the gather's critical path): image words from the
+  // word-major scratch (1-2 cache lines per wave and word).  Loads are unconditional with clamped addresses
+  // so the register sets stay in VGPRs.
+  auto do_words = [&](SweepRegs<K, NW> &rg) {
+#pragma unroll
+    for (int k = 0; k < K; ++k) {
+      uint32_t w = rg.wlo[k];
+      if (!rg.fast) {
         uint32_t r32;
         const bool in = locate(rg.t[k], rg.rem[k], rg.wlo[k], w, r32);
         w = in ? w : 0u;
-        e = tab[in ? (r32 >> 5) : 0u];
       }
-      rg.e[k] = e;
+      const uint32_t e = rg.e[k];
       const uint32_t row = (e & 0xFFFu) << LOGC, mode = (e >> 17) & 3u;
       const uint32_t *col = scr + w;                     // fast path: uniform base
       rg.a[k][0] = col[row];
@@ -326,7 +336,7 @@ __global__ __launch_bounds__(128 * PAIRS, 1) void b3w_sweep_kernel(const uint32_
       rg.ok[k] = WIDE ? col[(uint32_t)B3W_LDS_OKWORD << LOGC] : 1u;   // only the nova circuits reject steps
     }
   };
-  // stage 2: shape the 32 bytes and store them
+  // stage 3: shape the 32 bytes and store them
   auto do_emit = [&](const SweepRegs<K, NW> &rg) {
 #pragma unroll
     for (int k = 0; k < K; ++k) {
@@ -356,16 +366,17 @@ __global__ __launch_bounds__(128 * PAIRS, 1) void b3w_sweep_kernel(const uint32_
   };
 
   SweepRegs<K, NW> r0, r1, r2;
-  do_fetch(r0);                                        // step 0
-  do_fetch(r1);                                        // step 1
-  // step s: emit REMIT (fetched two steps ago) after starting the fetch of step s+2 into RFETCH
+  do_table(r0);                                        // step 0
+  do_table(r1);                                        // step 1
+  do_words(r0);                                        // step 0
+  // step s: table words of step s+2, image words of step s+1, emit step s
   while (true) {
     if (r0.t[0] >= ntiles) break;
-    do_fetch(r2); do_emit(r0);
+    do_table(r2); do_words(r1); do_emit(r0);
     if (r1.t[0] >= ntiles) break;
-    do_fetch(r0); do_emit(r1);
+    do_table(r0); do_words(r2); do_emit(r1);
     if (r2.t[0] >= ntiles) break;
-    do_fetch(r1); do_emit(r2);
+    do_table(r1); do_words(r0); do_emit(r2);
   }
 }
 
