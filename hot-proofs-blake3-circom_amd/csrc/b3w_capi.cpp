@@ -243,6 +243,23 @@ const char *reference_trace(int circuit, uint32_t site) {
   return nullptr;
 }
 
+// VERIFY mode: record word j of a witness is read back from slot in_slots[j] of its body (the slot the
+// layout gives the whole input atom: compression atoms 1..28, nova atoms NV+0..31 in record order)
+bool build_input_slots(const CircuitDesc &c, std::vector<uint32_t> &slots) {
+  slots.assign(c.nin, 0xFFFFFFFFu);
+  const uint32_t first = c.kind == B3W_KIND_COMP ? B3W_A_H : B3W_A_NV;
+  for (uint32_t r = 0; r < c.nruns; r++) {
+    const b3w_layout_run &run = c.runs[r];
+    if (run.kind != 'W') continue;
+    for (uint32_t j = 0; j < run.len; j++) {
+      const uint32_t atom = run.atom + j;
+      if (atom >= first && atom < first + c.nin && slots[atom - first] == 0xFFFFFFFFu) slots[atom - first] = run.slot + j;
+    }
+  }
+  for (uint32_t v : slots) if (v == 0xFFFFFFFFu) return false;
+  return true;
+}
+
 const char *assert_site_text(uint32_t site, char *buf, size_t len) {
   const uint32_t code = site & 0xFF, r = (site >> 8) & 0xF, g = (site >> 12) & 0xF, hf = (site >> 16) & 1;
   switch (code) {
@@ -277,6 +294,7 @@ struct b3w_ctx {
   uint32_t *d_prime = nullptr;
   uint32_t *d_fe_inputs = nullptr;
   uint32_t *d_status2 = nullptr;
+  uint32_t *d_in_slots = nullptr;     // VERIFY: body slot of each record word
   uint32_t scratch_cap = 0;
   // single-witness scratch
   uint32_t *d_rec1 = nullptr;
@@ -376,6 +394,11 @@ int32_t b3w_create(int32_t circuit, int32_t device, b3w_ctx **out) {
     if (e == hipSuccess) e = hipMemcpy(ctx->d_prime, d.prime, 32, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_fe_inputs, 32 * 32);
     if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_status2, 8);
+    std::vector<uint32_t> ins;
+    if (build_input_slots(d, ins)) {
+      if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_in_slots, ins.size() * 4);
+      if (e == hipSuccess) e = hipMemcpy(ctx->d_in_slots, ins.data(), ins.size() * 4, hipMemcpyHostToDevice);
+    }
   }
   if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_rec1, d.nin * 4);
   if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_body1, (size_t)d.nwit * 32);
@@ -397,6 +420,7 @@ void b3w_destroy(b3w_ctx *ctx) {
   if (ctx->d_prime) (void)hipFree(ctx->d_prime);
   if (ctx->d_fe_inputs) (void)hipFree(ctx->d_fe_inputs);
   if (ctx->d_status2) (void)hipFree(ctx->d_status2);
+  if (ctx->d_in_slots) (void)hipFree(ctx->d_in_slots);
   if (ctx->d_rec1) (void)hipFree(ctx->d_rec1);
   if (ctx->d_body1) (void)hipFree(ctx->d_body1);
   if (ctx->d_status1) (void)hipFree(ctx->d_status1);
@@ -456,6 +480,21 @@ int32_t b3w_batch_run_device(b3w_ctx *ctx, const uint32_t *d_records, uint32_t n
   if (rc == -5) { ctx->last_error = "the sweep path needs 32-byte aligned bodies and pitch < 2^30"; return B3W_E_BAD_ARGUMENT; }
   if (rc < 0) { ctx->last_error = "no kernel for this circuit kind / variant"; return B3W_E_BAD_ARGUMENT; }
   return hip_fail(ctx, (hipError_t)rc, "kernel launch");
+}
+
+int32_t b3w_batch_verify_device(b3w_ctx *ctx, const uint8_t *d_bodies, uint32_t n, uint64_t pitch, uint32_t *d_mismatch,
+                                void *stream) {
+  if (!ctx || !d_bodies || !d_mismatch) return B3W_E_BAD_ARGUMENT;
+  if (!ctx->d_in_slots) { ctx->last_error = "this circuit's layout does not keep every input as a slot"; return B3W_E_BAD_ARGUMENT; }
+  const uint64_t body = 32ull * ctx->desc.nwit;
+  if (pitch == 0) pitch = body;
+  if (pitch < body || (pitch & 31) || (reinterpret_cast<uintptr_t>(d_bodies) & 15)) {
+    ctx->last_error = "pitch must be >= witness_size*32 and a multiple of 32, bodies 16-byte aligned";
+    return B3W_E_BAD_ARGUMENT;
+  }
+  int rc = b3w_launch_verify(ctx->desc.kind, ctx->d_in_slots, n, d_bodies, pitch, ctx->d_table, ctx->desc.nwit, d_mismatch,
+                             ctx->d_aux, (hipStream_t)stream);
+  return rc ? hip_fail(ctx, (hipError_t)rc, "verify launch") : B3W_OK;
 }
 
 // Pick the kernel variant for THIS output buffer: the fused kernels' store pattern is sensitive to where

@@ -26,3 +26,7 @@ extern "C" int b3w_launch_plan_merge(const uint32_t *d_left, const uint32_t *d_r
                                      uint32_t root, uint32_t *d_parents, hipStream_t stream);
 extern "C" int b3w_launch_plan_parents(const uint32_t *d_levels, uint64_t nchunks, uint32_t P, uint64_t first_chunk,
                                        uint32_t nlocal, uint32_t last_chunk_blocks, uint32_t *d_recs, hipStream_t stream);
+
+extern "C" int b3w_launch_verify(int kind, const uint32_t *d_in_slots, uint32_t n, const uint8_t *d_bodies, uint64_t pitch,
+                                 const uint32_t *d_table, uint32_t nwit, uint32_t *d_mismatch, const void *d_aux,
+                                 hipStream_t stream);

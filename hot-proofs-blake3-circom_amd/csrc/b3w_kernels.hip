@@ -188,6 +188,66 @@ __device__ __forceinline__ void expand(const uint32_t *lds, const uint32_t *__re
   }
 }
 
+// VERIFY (on-device consumer): instead of storing, read the body back and compare it with what its own
+// input slots determine.  The circuits are deterministic — the inputs fix every signal — so "body equals
+// the witness recomputed from the body's input slots" is the same statement as "every constraint holds".
+// Returns this lane's count of differing 16-byte units per witness in cnt[].
+template <int W, int WORDS, bool WIDE>
+__device__ __forceinline__ void expand_verify(const uint32_t *lds, const uint32_t *__restrict__ table, uint32_t nwit,
+                                              const uint8_t *__restrict__ bodies, uint64_t pitch, uint32_t wit0, uint32_t n,
+                                              uint32_t (&cnt)[W]) {
+  const int lane = threadIdx.x;
+  const uint32_t par = lane & 1;
+  const uint32_t ngroups = (nwit + 31) >> 5;
+  const uint32_t nact = n - wit0 < (uint32_t)W ? n - wit0 : (uint32_t)W;
+#pragma unroll
+  for (int w = 0; w < W; ++w) cnt[w] = 0;
+#pragma unroll 2
+  for (uint32_t g = 0; g < ngroups; ++g) {
+    const uint32_t slot = g * 32 + (lane >> 1);
+    const uint32_t e = table[slot];
+    const bool in = slot < nwit;
+    const uint32_t src = e & 0xFFFu, sh = (e >> 12) & 31u, mode = (e >> 17) & 3u;
+    const uint32_t off = (WIDE && mode == B3W_MODE_W256) ? src + 4u * par : src;
+    const bool live = (par == 0) || (WIDE && mode == B3W_MODE_W256);
+    const uint32_t m0 = live ? (mode == B3W_MODE_BIT ? 1u : 0xFFFFFFFFu) : 0u;
+    const uint32_t m1 = (live && mode >= B3W_MODE_W64) ? 0xFFFFFFFFu : 0u;
+    const uint32_t m23 = (WIDE && mode == B3W_MODE_W256) ? 0xFFFFFFFFu : 0u;
+#pragma unroll
+    for (int w = 0; w < W; ++w) {
+      if ((uint32_t)w < nact && in) {
+        const uint32_t *L = lds + w * WORDS + off;
+        const uint4 got = *reinterpret_cast<const uint4 *>(bodies + (uint64_t)(wit0 + w) * pitch + (uint64_t)g * 1024 + lane * 16);
+        const uint32_t x = (L[0] >> sh) & m0, y = L[1] & m1;
+        const uint32_t z = WIDE ? (L[2] & m23) : 0u, t = WIDE ? (L[3] & m23) : 0u;
+        cnt[w] += ((got.x ^ x) | (got.y ^ y) | (got.z ^ z) | (got.w ^ t)) ? 1u : 0u;
+      }
+    }
+  }
+}
+
+// records for VERIFY mode come from the body's own input slots (in_slots[j] = slot holding record word j);
+// a slot that is not a plain 32-bit value cannot be checked on this path: flagged in nc
+__device__ __forceinline__ uint32_t body_input_word(const uint8_t *body, uint32_t slot, uint32_t &nc) {
+  const uint4 *p = reinterpret_cast<const uint4 *>(body + (uint64_t)slot * 32);
+  const uint4 lo = p[0], hi = p[1];
+  if (lo.y | lo.z | lo.w | hi.x | hi.y | hi.z | hi.w) nc = 1;
+  return lo.x;
+}
+
+// wave reduction of the per-lane counters, one global word per witness
+template <int W>
+__device__ __forceinline__ void publish_counts(uint32_t (&cnt)[W], uint32_t *__restrict__ mismatch, uint32_t wit0, uint32_t n,
+                                               const uint32_t *flags /* per-w: nonzero = not verifiable / rejected */) {
+#pragma unroll
+  for (int w = 0; w < W; ++w) {
+    uint32_t c = cnt[w];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+    if (threadIdx.x == 0 && wit0 + w < n) mismatch[wit0 + w] = flags[w] ? 0xFFFFFFFFu : c;
+  }
+}
+
 // ------------------------------------------------------------------ two-kernel ("sweep") path
 // The fused kernels above leave every wave streaming its own bodies: thousands of independent write
 // streams whose instantaneous positions load the HBM channels unevenly.  Measured on MI355X
@@ -381,7 +441,9 @@ __global__ __launch_bounds__(128 * PAIRS, 1) void b3w_sweep_kernel(const uint32_
 }
 
 // ------------------------------------------------------------------ compression circuit
-template <int W, bool NT, bool SWEEP>
+// MODE 0: witnesses -> bodies (fused);  1: images -> scratch (TRACE kernel of the sweep path);
+//      2: VERIFY — recs = in_slots table, out = bodies to check, pub = per-witness mismatch counts
+template <int W, bool NT, int MODE>
 __global__ __launch_bounds__(64) void b3w_compression_kernel(const uint32_t *__restrict__ recs, uint32_t n,
                                                              uint8_t *__restrict__ out, uint64_t pitch,
                                                              const uint32_t *__restrict__ table, uint32_t nwit,
@@ -391,21 +453,38 @@ __global__ __launch_bounds__(64) void b3w_compression_kernel(const uint32_t *__r
   const int lane = threadIdx.x;
   const uint32_t wit0 = blockIdx.x * W;
   // stage the 28-word records of this wave's witnesses into atoms H M T B D (image words 1..28)
+  __shared__ uint32_t ncf[W];      // VERIFY: an input slot of the body is not a plain 32-bit value
+  if (lane < W) ncf[lane] = 0;
+  if (MODE == 2) __syncthreads();
   for (int i = lane; i < W * 28; i += 64) {
     const int w = i / 28, j = i - w * 28;
-    if (wit0 + w < n) lds[w * WORDS + B3W_A_H + j] = recs[(uint64_t)(wit0 + w) * 28 + j];
+    if (wit0 + w < n) {
+      uint32_t v;
+      if (MODE == 2) {
+        uint32_t nc = 0;
+        v = body_input_word(out + (uint64_t)(wit0 + w) * pitch, recs[j], nc);
+        if (nc) ncf[w] = 1;
+      } else {
+        v = recs[(uint64_t)(wit0 + w) * 28 + j];
+      }
+      lds[w * WORDS + B3W_A_H + j] = v;
+    }
   }
   __syncthreads();
   {
     const int w = lane >> 2, col = lane & 3;
     if (w < W && wit0 + w < n) {
-      trace_compression(lds + w * WORDS, col, pub ? pub + (uint64_t)(wit0 + w) * 16 : nullptr);
-      if (status && col == 0) status[wit0 + w] = 0;     // canonical u32 inputs cannot fail an assert
+      trace_compression(lds + w * WORDS, col, (MODE != 2 && pub) ? pub + (uint64_t)(wit0 + w) * 16 : nullptr);
+      if (MODE != 2 && status && col == 0) status[wit0 + w] = 0;     // canonical u32 inputs cannot fail an assert
     }
   }
   __syncthreads();
-  if (SWEEP) dump_images<W, WORDS>(lds, reinterpret_cast<uint32_t *>(out), (uint32_t)pitch, wit0, n, nullptr);   // out = scratch, pitch = its row length   // out = scratch
-  else expand<W, WORDS, false, NT>(lds, table, nwit, out, pitch, wit0, n, nullptr, true);
+  if (MODE == 1) dump_images<W, WORDS>(lds, reinterpret_cast<uint32_t *>(out), (uint32_t)pitch, wit0, n, nullptr);   // out = scratch, pitch = its row length
+  else if (MODE == 2) {
+    uint32_t cnt[W];
+    expand_verify<W, WORDS, false>(lds, table, nwit, out, pitch, wit0, n, cnt);
+    publish_counts<W>(cnt, pub, wit0, n, ncf);
+  } else expand<W, WORDS, false, NT>(lds, table, nwit, out, pitch, wit0, n, nullptr, true);
 }
 
 
@@ -509,7 +588,7 @@ __device__ __forceinline__ void lds_put256(uint32_t *L, const U256 &v) {
   *reinterpret_cast<uint4 *>(L + 4) = make_uint4(v.l[4], v.l[5], v.l[6], v.l[7]);
 }
 
-template <int KIND, int W, bool NT, bool SWEEP>
+template <int KIND, int W, bool NT, int MODE>
 __global__ __launch_bounds__(64) void b3w_nova_kernel(const uint32_t *__restrict__ recs, uint32_t n,
                                                       uint8_t *__restrict__ out, uint64_t pitch,
                                                       const uint32_t *__restrict__ table, uint32_t nwit,
@@ -522,11 +601,23 @@ __global__ __launch_bounds__(64) void b3w_nova_kernel(const uint32_t *__restrict
   __shared__ uint32_t domf[W];     // 1 = an IsZero argument fell outside the supported magnitude
   const int lane = threadIdx.x;
   const uint32_t wit0 = blockIdx.x * W;
+  __shared__ uint32_t ncf[W];      // VERIFY: an input slot of the body is not a plain 32-bit value
+  if (lane < W) { okf[lane] = 0; domf[lane] = 0; ncf[lane] = 0; }
+  if (MODE == 2) __syncthreads();
   for (int i = lane; i < W * 32; i += 64) {
     const int w = i >> 5, j = i & 31;
-    if (wit0 + w < n) lds[w * WORDS + B3W_LDS_NV + j] = recs[(uint64_t)(wit0 + w) * 32 + j];
+    if (wit0 + w < n) {
+      uint32_t v;
+      if (MODE == 2) {
+        uint32_t nc = 0;
+        v = body_input_word(out + (uint64_t)(wit0 + w) * pitch, recs[j], nc);
+        if (nc) ncf[w] = 1;
+      } else {
+        v = recs[(uint64_t)(wit0 + w) * 32 + j];
+      }
+      lds[w * WORDS + B3W_LDS_NV + j] = v;
+    }
   }
-  if (lane < W) { okf[lane] = 0; domf[lane] = 0; }
   __syncthreads();
 
   U256 P;
@@ -593,7 +684,7 @@ __global__ __launch_bounds__(64) void b3w_nova_kernel(const uint32_t *__restrict
     const uint32_t cdd = last | parent, decr = cdd & (1u - is_root);
     if (col == 0) {
       okf[w] = st == 0 ? 1u : 0u;
-      if (status) status[wit0 + w] = st;
+      if (MODE != 2 && status) status[wit0 + w] = st;
       nv[NV_BLOCK_COUNT_OUT] = block_count + (1u - parent);               // :251
       nv[NV_DEPTH_OUT] = depth - decr;                                    // :262
       nv[NV_IS_PARENT] = parent;
@@ -653,7 +744,7 @@ __global__ __launch_bounds__(64) void b3w_nova_kernel(const uint32_t *__restrict
   bool all_ok = true;
 #pragma unroll
   for (int x = 0; x < W; ++x) all_ok = all_ok && (okf[x] != 0);
-  if (active && okf[w] && pub) {
+  if (MODE != 2 && active && okf[w] && pub) {
     // w[1..15]: n_blocks_out block_count_out h_out[8] total_depth_out depth_out chunk_idx_low_out chunk_idx_high_out leaf_depth_out
     uint32_t *pw = pub + (uint64_t)(wit0 + w) * 15;
     const uint32_t *nv = L + B3W_LDS_NV;
@@ -662,8 +753,15 @@ __global__ __launch_bounds__(64) void b3w_nova_kernel(const uint32_t *__restrict
     pw[2 + col] = L[B3W_A_O + col];
     pw[6 + col] = L[B3W_A_O + 4 + col];
   }
-  if (SWEEP) dump_images<W, WORDS>(lds, reinterpret_cast<uint32_t *>(out), (uint32_t)pitch, wit0, n, okf);       // out = scratch, pitch = its row length       // out = scratch
-  else expand<W, WORDS, true, NT>(lds, table, nwit, out, pitch, wit0, n, okf, all_ok);
+  if (MODE == 1) dump_images<W, WORDS>(lds, reinterpret_cast<uint32_t *>(out), (uint32_t)pitch, wit0, n, okf);    // out = scratch, pitch = its row length
+  else if (MODE == 2) {
+    // a body whose inputs the circuit rejects, or that this path cannot read, verifies as "all wrong"
+    if (lane < W) ncf[lane] |= okf[lane] ? 0u : 1u;
+    __syncthreads();
+    uint32_t cnt[W];
+    expand_verify<W, WORDS, true>(lds, table, nwit, out, pitch, wit0, n, cnt);
+    publish_counts<W>(cnt, pub, wit0, n, ncf);
+  } else expand<W, WORDS, true, NT>(lds, table, nwit, out, pitch, wit0, n, okf, all_ok);
 }
 
 }  // namespace
@@ -702,6 +800,25 @@ int launch_sweep(const uint32_t *d_images, uint32_t n, uint8_t *d_out, uint64_t 
 }
 }  // namespace
 
+// VERIFY launch: d_in_slots[j] = slot of record word j; d_mismatch[i] = differing 16-byte units of body i
+// (0 = the body is the witness its own inputs determine; 0xFFFFFFFF = rejected inputs / not checkable here)
+extern "C" int b3w_launch_verify(int kind, const uint32_t *d_in_slots, uint32_t n, const uint8_t *d_bodies, uint64_t pitch,
+                                 const uint32_t *d_table, uint32_t nwit, uint32_t *d_mismatch, const void *d_aux,
+                                 hipStream_t stream) {
+  if (n == 0) return 0;
+  uint8_t *bodies = const_cast<uint8_t *>(d_bodies);
+  if (kind == B3W_KIND_COMP)
+    hipLaunchKernelGGL((b3w_compression_kernel<4, false, 2>), dim3((n + 3) / 4), dim3(64), 0, stream, d_in_slots, n, bodies, pitch,
+                       d_table, nwit, d_mismatch, (int32_t *)nullptr);
+  else if (kind == B3W_KIND_NOVA_O2)
+    hipLaunchKernelGGL((b3w_nova_kernel<B3W_KIND_NOVA_O2, 2, false, 2>), dim3((n + 1) / 2), dim3(64), 0, stream, d_in_slots, n,
+                       bodies, pitch, d_table, nwit, d_mismatch, (int32_t *)nullptr, (const uint32_t *)d_aux);
+  else
+    hipLaunchKernelGGL((b3w_nova_kernel<B3W_KIND_NOVA_O1, 2, false, 2>), dim3((n + 1) / 2), dim3(64), 0, stream, d_in_slots, n,
+                       bodies, pitch, d_table, nwit, d_mismatch, (int32_t *)nullptr, (const uint32_t *)d_aux);
+  return (int)hipGetLastError();
+}
+
 extern "C" int b3w_launch_batch(int kind, int variant, const uint32_t *d_recs, uint32_t n, uint8_t *d_out,
                                 uint64_t pitch, const uint32_t *d_table, uint32_t nwit, uint32_t *d_pub,
                                 int32_t *d_status, const void *d_aux, uint32_t *d_scratch, uint32_t scratch_cap,
@@ -719,18 +836,18 @@ extern "C" int b3w_launch_batch(int kind, int variant, const uint32_t *d_recs, u
       int rc;
       if (kind == B3W_KIND_COMP) {
         const uint32_t *rc_recs = d_recs + (uint64_t)c0 * 28;
-        hipLaunchKernelGGL((b3w_compression_kernel<16, false, true>), dim3((cn + 15) / 16), dim3(64), 0, stream, rc_recs,
+        hipLaunchKernelGGL((b3w_compression_kernel<16, false, 1>), dim3((cn + 15) / 16), dim3(64), 0, stream, rc_recs,
                            cn, reinterpret_cast<uint8_t *>(d_images), (uint64_t)scratch_cap, d_table, nwit, pub_c, st_c);
         rc = launch_sweep<false, 8>(d_images, cn, out_c, pitch, d_table, nwit, stream);
       } else if (kind == B3W_KIND_NOVA_O2) {
         const uint32_t *rc_recs = d_recs + (uint64_t)c0 * 32;
-        hipLaunchKernelGGL((b3w_nova_kernel<B3W_KIND_NOVA_O2, 4, false, true>), dim3((cn + 3) / 4), dim3(64), 0, stream,
+        hipLaunchKernelGGL((b3w_nova_kernel<B3W_KIND_NOVA_O2, 4, false, 1>), dim3((cn + 3) / 4), dim3(64), 0, stream,
                            rc_recs, cn, reinterpret_cast<uint8_t *>(d_images), (uint64_t)scratch_cap, d_table, nwit, pub_c, st_c,
                            (const uint32_t *)d_aux);
         rc = launch_sweep<true, 4>(d_images, cn, out_c, pitch, d_table, nwit, stream);
       } else {
         const uint32_t *rc_recs = d_recs + (uint64_t)c0 * 32;
-        hipLaunchKernelGGL((b3w_nova_kernel<B3W_KIND_NOVA_O1, 2, false, true>), dim3((cn + 1) / 2), dim3(64), 0, stream,
+        hipLaunchKernelGGL((b3w_nova_kernel<B3W_KIND_NOVA_O1, 2, false, 1>), dim3((cn + 1) / 2), dim3(64), 0, stream,
                            rc_recs, cn, reinterpret_cast<uint8_t *>(d_images), (uint64_t)scratch_cap, d_table, nwit, pub_c, st_c,
                            (const uint32_t *)d_aux);
         rc = launch_sweep<true, 4>(d_images, cn, out_c, pitch, d_table, nwit, stream);
@@ -741,7 +858,7 @@ extern "C" int b3w_launch_batch(int kind, int variant, const uint32_t *d_recs, u
   }
   if (kind == B3W_KIND_COMP) {
 #define B3W_LAUNCH_COMP(WV, NTV)                                                                         \
-  hipLaunchKernelGGL((b3w_compression_kernel<WV, NTV, false>), dim3((n + WV - 1) / WV), dim3(64), 0, stream,   \
+  hipLaunchKernelGGL((b3w_compression_kernel<WV, NTV, 0>), dim3((n + WV - 1) / WV), dim3(64), 0, stream,   \
                      d_recs, n, d_out, pitch, d_table, nwit, d_pub, d_status)
     switch (variant) {
       case 0: B3W_LAUNCH_COMP(4, false); break;
@@ -760,7 +877,7 @@ extern "C" int b3w_launch_batch(int kind, int variant, const uint32_t *d_recs, u
   if (kind == B3W_KIND_NOVA_O2 || kind == B3W_KIND_NOVA_O1) {
     if (!d_aux) return -3;
 #define B3W_LAUNCH_NOVA(KV, WV)                                                                           \
-  hipLaunchKernelGGL((b3w_nova_kernel<KV, WV, false, false>), dim3((n + WV - 1) / WV), dim3(64), 0, stream,     \
+  hipLaunchKernelGGL((b3w_nova_kernel<KV, WV, false, 0>), dim3((n + WV - 1) / WV), dim3(64), 0, stream,     \
                      d_recs, n, d_out, pitch, d_table, nwit, d_pub, d_status, (const uint32_t *)d_aux)
     if (kind == B3W_KIND_NOVA_O2) {
       switch (variant) {

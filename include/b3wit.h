@@ -127,6 +127,16 @@ int32_t b3w_batch_time_device(b3w_ctx *ctx, const uint32_t *d_records, uint32_t 
                               uint64_t pitch, uint32_t *d_public, int32_t *d_status, void *stream,
                               uint32_t iters, float *avg_ms);
 
+/* On-device consumer: check n witness bodies in HBM.  The circuits are deterministic (the inputs fix every
+ * signal), so a body satisfies all constraints iff it equals the witness recomputed from its own input
+ * slots; the kernel reads each body once (HBM-read bound) and compares every 16-byte unit.
+ * d_mismatch[i] = number of differing units of body i: 0 = valid witness; 0xFFFFFFFF = the body's inputs are
+ * rejected by the circuit or are not plain 32-bit values (outside this path's domain).  Stands where the
+ * reference's consumers check a witness against the R1CS (circom_tester expectPass, test/blake3_hash.test.ts:36;
+ * synthesize_with_vec's constraints, rust_fold/src/utils.rs:17-88). */
+int32_t b3w_batch_verify_device(b3w_ctx *ctx, const uint8_t *d_bodies, uint32_t n, uint64_t pitch, uint32_t *d_mismatch,
+                                void *stream);
+
 /* Streaming .wtns writer (the hand-off the reference does one file at a time: generate_witness.js:15-18,
  * circomkit `witness` in test/witness_gen.test.ts:41): witnesses [first, first+count) of the last
  * b3w_batch_run are copied to the host through two pinned staging buffers (D2H of chunk k+1 overlaps the
