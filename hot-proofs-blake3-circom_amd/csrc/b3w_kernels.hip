@@ -196,31 +196,45 @@ template <int W, int WORDS, bool WIDE>
 __device__ __forceinline__ void expand_verify(const uint32_t *lds, const uint32_t *__restrict__ table, uint32_t nwit,
                                               const uint8_t *__restrict__ bodies, uint64_t pitch, uint32_t wit0, uint32_t n,
                                               uint32_t (&cnt)[W]) {
+  constexpr int U = 4;                                   // groups per iteration: U*W 16-byte loads in flight per lane
   const int lane = threadIdx.x;
   const uint32_t par = lane & 1;
   const uint32_t ngroups = (nwit + 31) >> 5;
   const uint32_t nact = n - wit0 < (uint32_t)W ? n - wit0 : (uint32_t)W;
 #pragma unroll
   for (int w = 0; w < W; ++w) cnt[w] = 0;
-#pragma unroll 2
-  for (uint32_t g = 0; g < ngroups; ++g) {
-    const uint32_t slot = g * 32 + (lane >> 1);
-    const uint32_t e = table[slot];
-    const bool in = slot < nwit;
-    const uint32_t src = e & 0xFFFu, sh = (e >> 12) & 31u, mode = (e >> 17) & 3u;
-    const uint32_t off = (WIDE && mode == B3W_MODE_W256) ? src + 4u * par : src;
-    const bool live = (par == 0) || (WIDE && mode == B3W_MODE_W256);
-    const uint32_t m0 = live ? (mode == B3W_MODE_BIT ? 1u : 0xFFFFFFFFu) : 0u;
-    const uint32_t m1 = (live && mode >= B3W_MODE_W64) ? 0xFFFFFFFFu : 0u;
-    const uint32_t m23 = (WIDE && mode == B3W_MODE_W256) ? 0xFFFFFFFFu : 0u;
+  for (uint32_t g0 = 0; g0 < ngroups; g0 += U) {
+    uint32_t e[U];
+    u32x4 got[U][W];
 #pragma unroll
-    for (int w = 0; w < W; ++w) {
-      if ((uint32_t)w < nact && in) {
+    for (int u = 0; u < U; ++u) {
+      const uint32_t g = g0 + u < ngroups ? g0 + u : ngroups - 1;          // clamped: the tail re-reads the last group
+      e[u] = table[g * 32 + (lane >> 1)];
+#pragma unroll
+      for (int w = 0; w < W; ++w) {
+        const uint32_t ww = (uint32_t)w < nact ? w : 0;                     // clamped: inactive witnesses re-read body 0
+        const uint32_t slot = g * 32 + (lane >> 1);
+        const uint32_t sl = slot < nwit ? slot : nwit - 1;                  // clamped inside the body
+        got[u][w] = *reinterpret_cast<const u32x4 *>(bodies + (uint64_t)(wit0 + ww) * pitch + (uint64_t)sl * 32 + par * 16);
+      }
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+      const uint32_t slot = (g0 + u) * 32 + (lane >> 1);
+      const bool in = g0 + u < ngroups && slot < nwit;
+      const uint32_t src = e[u] & 0xFFFu, sh = (e[u] >> 12) & 31u, mode = (e[u] >> 17) & 3u;
+      const uint32_t off = (WIDE && mode == B3W_MODE_W256) ? src + 4u * par : src;
+      const bool live = (par == 0) || (WIDE && mode == B3W_MODE_W256);
+      const uint32_t m0 = live ? (mode == B3W_MODE_BIT ? 1u : 0xFFFFFFFFu) : 0u;
+      const uint32_t m1 = (live && mode >= B3W_MODE_W64) ? 0xFFFFFFFFu : 0u;
+      const uint32_t m23 = (WIDE && mode == B3W_MODE_W256) ? 0xFFFFFFFFu : 0u;
+#pragma unroll
+      for (int w = 0; w < W; ++w) {
         const uint32_t *L = lds + w * WORDS + off;
-        const uint4 got = *reinterpret_cast<const uint4 *>(bodies + (uint64_t)(wit0 + w) * pitch + (uint64_t)g * 1024 + lane * 16);
         const uint32_t x = (L[0] >> sh) & m0, y = L[1] & m1;
         const uint32_t z = WIDE ? (L[2] & m23) : 0u, t = WIDE ? (L[3] & m23) : 0u;
-        cnt[w] += ((got.x ^ x) | (got.y ^ y) | (got.z ^ z) | (got.w ^ t)) ? 1u : 0u;
+        const bool bad = ((got[u][w].x ^ x) | (got[u][w].y ^ y) | (got[u][w].z ^ z) | (got[u][w].w ^ t)) != 0;
+        cnt[w] += (in && (uint32_t)w < nact && bad) ? 1u : 0u;
       }
     }
   }
