@@ -208,6 +208,11 @@ def main():
     elapsed = time.perf_counter() - t0
     kern_ms = sum(a.elapsed_time(b) for a, b in ev) / args.steps      # HIP events on the launch stream
     assert int(d_status.abs().sum().item()) == 0, "a witness reported a non-zero status"
+    # untimed: every body of the last step is checked on the device (recompute-from-own-inputs)
+    d_mm = torch.full((n,), -1, dtype=torch.int32, device=dev)
+    ctx.verify_device(d_bodies.data_ptr(), n, pitch, d_mm.data_ptr(), stream.cuda_stream)
+    torch.cuda.synchronize()
+    assert int(d_mm.abs().sum().item()) == 0, "on-device verification found a body that is not a valid witness"
 
     t = torch.tensor([elapsed, kern_ms], dtype=torch.float64, device=dev)
     if world > 1:
@@ -246,6 +251,7 @@ def main():
                                    "device-resident inputs and outputs",
                        "circuit": circuit, "batch_per_gpu": n, "witness_bytes": ctx.body_bytes, "pitch": pitch,
                        "kernel_variant": "sweep (TRACE + SWEEP kernels)" if chosen >= 100 else f"fused ({chosen})",
+                       "verified_on_device": True,
                        "placement_candidates_ms": placement,
                        "exchange": "all_gather of public outputs (RCCL)" if world > 1 else "none"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
