@@ -85,6 +85,7 @@ def lib():
         "b3w_batch_device_ptr": (vp, [vp, ctypes.POINTER(u64)]),
         "b3w_batch_time_device": (i32, [vp, vp, u32, vp, u64, vp, vp, vp, u32, ctypes.POINTER(ctypes.c_float)]),
         "b3w_batch_verify_device": (i32, [vp, vp, u32, u64, vp, vp]),
+        "b3w_batch_verify": (i32, [vp, vp]),
         "b3w_batch_write_wtns": (i32, [vp, u32, u32, ctypes.c_char_p, ctypes.c_char_p, ctypes.POINTER(u32)]),
         "b3w_batch_autotune_device": (i32, [vp, vp, u32, vp, u64, vp, vp, vp, ctypes.POINTER(i32), ctypes.POINTER(ctypes.c_float)]),
         "b3w_chain_num_chunks": (u64, [u64]),
@@ -105,7 +106,7 @@ EXPORTED_SYMBOLS = ("b3w_abi_version", "b3w_identify_wasm", "b3w_create", "b3w_d
                     "b3w_input_signal_size", "b3w_calc_witness", "b3w_write_wtns_header", "b3w_last_error",
                     "b3w_batch_run_device", "b3w_public_words", "b3w_batch_alloc", "b3w_batch_free",
                     "b3w_batch_run", "b3w_batch_outputs", "b3w_batch_fetch", "b3w_batch_device_ptr",
-                    "b3w_batch_time_device", "b3w_batch_verify_device", "b3w_batch_write_wtns", "b3w_batch_autotune_device", "b3w_chain_num_chunks", "b3w_chain_num_leaf_steps", "b3w_chain_path_len",
+                    "b3w_batch_time_device", "b3w_batch_verify_device", "b3w_batch_verify", "b3w_batch_write_wtns", "b3w_batch_autotune_device", "b3w_chain_num_chunks", "b3w_chain_num_leaf_steps", "b3w_chain_path_len",
                     "b3w_chain_plan_leaves_device", "b3w_chain_tree_device", "b3w_chain_plan_parents_device")
 
 
@@ -302,6 +303,14 @@ class Batch:
         if rc != B3W_OK:
             raise B3WError(rc, f"b3w_batch_fetch: status {rc}")
         return body
+
+    def verify(self):
+        """On-device check of the last run's bodies; returns per-witness mismatch counts (0 = valid witness)."""
+        mm = np.zeros(self.n, dtype=np.uint32)
+        rc = lib().b3w_batch_verify(self.handle, mm.ctypes.data)
+        if rc != B3W_OK:
+            raise B3WError(rc, f"b3w_batch_verify: status {rc}: {self.ctx.last_error()}")
+        return mm
 
     def write_wtns(self, directory, prefix="witness_", first=0, count=None):
         """Stream witnesses [first, first+count) to <directory>/<prefix><index>.wtns; returns files written."""

@@ -666,6 +666,20 @@ int32_t b3w_batch_fetch(b3w_batch *b, uint32_t index, uint8_t *out_body) {
   return B3W_OK;
 }
 
+int32_t b3w_batch_verify(b3w_batch *b, uint32_t *host_mismatch) {
+  if (!b || !host_mismatch) return B3W_E_BAD_ARGUMENT;
+  b3w_ctx *ctx = b->ctx;
+  if (!b->n) return B3W_OK;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  uint32_t *d_mm = nullptr;
+  HIP_TRY(ctx, hipMalloc((void **)&d_mm, (size_t)b->n * 4));
+  int32_t rc = b3w_batch_verify_device(ctx, b->d_bodies, b->n, b->pitch, d_mm, nullptr);
+  hipError_t e = rc == B3W_OK ? hipMemcpy(host_mismatch, d_mm, (size_t)b->n * 4, hipMemcpyDeviceToHost) : hipSuccess;
+  (void)hipFree(d_mm);
+  if (rc) return rc;
+  return e == hipSuccess ? B3W_OK : hip_fail(ctx, e, "hipMemcpy(mismatch)");
+}
+
 int32_t b3w_batch_write_wtns(b3w_batch *b, uint32_t first, uint32_t count, const char *dir, const char *prefix,
                              uint32_t *written) {
   if (!b || !dir || !prefix || first + count > b->n) return B3W_E_BAD_ARGUMENT;

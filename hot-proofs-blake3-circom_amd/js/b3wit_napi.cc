@@ -37,6 +37,7 @@ struct Api {
   decltype(&b3w_batch_outputs) batch_outputs;
   decltype(&b3w_batch_fetch) batch_fetch;
   decltype(&b3w_batch_write_wtns) batch_write_wtns;
+  decltype(&b3w_batch_verify) batch_verify;
   std::string err;
 } api;
 
@@ -58,7 +59,7 @@ bool load_api() {
   if (!api.name) { api.err = "libb3wit.so lacks b3w_" #name; dlclose(so); return false; }
   SYM(abi_version) SYM(identify_wasm) SYM(create) SYM(destroy) SYM(info) SYM(input_signal_size) SYM(calc_witness)
   SYM(write_wtns_header) SYM(last_error) SYM(public_words) SYM(batch_alloc) SYM(batch_free) SYM(batch_run)
-  SYM(batch_outputs) SYM(batch_fetch) SYM(batch_write_wtns)
+  SYM(batch_outputs) SYM(batch_fetch) SYM(batch_write_wtns) SYM(batch_verify)
 #undef SYM
   api.so = so;
   return true;
@@ -303,6 +304,23 @@ napi_value BatchWriteWtns(napi_env env, napi_callback_info info) {
   return out;
 }
 
+// batchVerify(handle, n) -> Uint32Array of per-witness mismatch counts of the last batchRun (0 = valid witness)
+napi_value BatchVerify(napi_env env, napi_callback_info info) {
+  size_t argc = 2; napi_value argv[2];
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+  Handle *h = get_handle(env, argv[0]);
+  if (!h) return nullptr;
+  if (!h->batch) { napi_throw_error(env, nullptr, "batchVerify before batchRun"); return nullptr; }
+  uint32_t n = 0;
+  NAPI_OK(napi_get_value_uint32(env, argv[1], &n));
+  void *p; napi_value ab, out;
+  NAPI_OK(napi_create_arraybuffer(env, (size_t)n * 4, &p, &ab));
+  const int32_t rc = api.batch_verify(h->batch, (uint32_t *)p);
+  if (rc != B3W_OK) return throw_status(env, h, rc, "b3w_batch_verify failed");
+  NAPI_OK(napi_create_typedarray(env, napi_uint32_array, n, ab, 0, &out));
+  return out;
+}
+
 napi_value AbiVersion(napi_env env, napi_callback_info) {
   if (!load_api()) { napi_throw_error(env, nullptr, api.err.c_str()); return nullptr; }
   napi_value out;
@@ -322,6 +340,7 @@ napi_value Init(napi_env env, napi_value exports) {
       {"batchRun", nullptr, BatchRun, nullptr, nullptr, nullptr, napi_default, nullptr},
       {"batchFetch", nullptr, BatchFetch, nullptr, nullptr, nullptr, napi_default, nullptr},
       {"batchWriteWtns", nullptr, BatchWriteWtns, nullptr, nullptr, nullptr, napi_default, nullptr},
+      {"batchVerify", nullptr, BatchVerify, nullptr, nullptr, nullptr, napi_default, nullptr},
   };
   napi_define_properties(env, exports, sizeof props / sizeof props[0], props);
   return exports;

@@ -151,6 +151,8 @@ class WitnessCalculator {
     const nat = native();
     const r = nat.batchRun(this.instance, records);
     r.fetch = (i) => nat.batchFetch(this.instance, i);
+    // on-device check of every body of the batch: Uint32Array of mismatch counts (0 = valid witness)
+    r.verify = () => nat.batchVerify(this.instance, r.n);
     // stream every witness of the batch to <dir>/<prefix><index>.wtns (same bytes as calculateWTNSBin)
     r.writeWtns = (dir, prefix, first, count) =>
       nat.batchWriteWtns(this.instance, first || 0, count === undefined ? r.n - (first || 0) : count, dir, prefix || "witness_");

@@ -137,6 +137,9 @@ int32_t b3w_batch_time_device(b3w_ctx *ctx, const uint32_t *d_records, uint32_t 
 int32_t b3w_batch_verify_device(b3w_ctx *ctx, const uint8_t *d_bodies, uint32_t n, uint64_t pitch, uint32_t *d_mismatch,
                                 void *stream);
 
+/* Same check on the witnesses of the last b3w_batch_run; host_mismatch receives n counts. */
+int32_t b3w_batch_verify(b3w_batch *batch, uint32_t *host_mismatch);
+
 /* Streaming .wtns writer (the hand-off the reference does one file at a time: generate_witness.js:15-18,
  * circomkit `witness` in test/witness_gen.test.ts:41): witnesses [first, first+count) of the last
  * b3w_batch_run are copied to the host through two pinned staging buffers (D2H of chunk k+1 overlaps the

@@ -75,3 +75,12 @@ def test_verify_catches_a_tampered_inverse_and_rejected_inputs():
     mm = _verify(ctx, d_bodies, n, pitch)
     assert mm[2] >= 1 and mm[4] == 0xFFFFFFFF and all(mm[i] == 0 for i in (0, 1, 3, 5, 6, 7))
     ctx.close()
+
+
+def test_batch_wrapper_verify():
+    m = T.pkg()
+    ctx = m.Context("nova_bn254_o1", 0)
+    b = m.Batch(ctx, 10)
+    b.run(T.workloads().config3_nova(10, first=40))
+    assert (b.verify() == 0).all()
+    b.close(); ctx.close()

@@ -114,6 +114,7 @@ def test_js_surface_errors_and_batch(tmp_path):
         out.batch = {n: b.n, status: Array.from(b.status), pub0: Array.from(b.publicOutputs.slice(0, 16)).map(String),
                      body3: crypto.createHash('sha256').update(b.fetch(3)).digest('hex'),
                      files: b.writeWtns(process.argv[3], 'js_'),
+                     verify: Array.from(b.verify()),
                      file5: crypto.createHash('sha256').update(fs.readFileSync(process.argv[3] + '/js_5.wtns')).digest('hex')};
         console.log(JSON.stringify(out));
       })().catch(e => { console.error(e); process.exit(1); });
@@ -133,4 +134,5 @@ def test_js_surface_errors_and_batch(tmp_path):
     assert out["batch"]["n"] == 8 and out["batch"]["status"] == [0] * 8
     assert out["batch"]["pub0"] == [str(x) for x in cases[0]["first16"][1:]] + [out["batch"]["pub0"][15]]
     assert out["batch"]["body3"] == cases[3]["body_sha256"]
+    assert out["batch"]["verify"] == [0] * 8
     assert out["batch"]["files"] == 8 and out["batch"]["file5"] == cases[5]["wtns_sha256"]
