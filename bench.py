@@ -105,7 +105,8 @@ def main():
     ap.add_argument("--variant", type=int, default=None, help="kernel tuning variant (B3W_VARIANT)")
     ap.add_argument("--pitch", type=int, default=0, help="body pitch in bytes (0 = contiguous bodies)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of the cpu_baseline leg (0 = skip)")
-    ap.add_argument("--placements", type=int, default=4, help="candidate output buffers tried during the untimed set-up")
+    ap.add_argument("--placement", default="mixed", choices=["mixed", "plain"],
+                    help="body buffer placement: mixed = b3w_bodies_alloc's two-class buffer (default), plain = hipMalloc")
     ap.add_argument("--workload", default="batch", choices=["batch", "chain"],
                     help="batch = BASELINE config 2/3 (default, the headline metric); chain = configs 4/5: "
                          "preimage -> planner -> nova step witnesses, streamed through a ring of buffers")
@@ -162,30 +163,18 @@ def main():
         if world > 1:                       # the fold's exchange step: per-step public outputs (h_out ...)
             sharding.gather_public(d_pub, world * n)
 
-    # Untimed set-up.  The fused kernels' store pattern runs at 5.3-6.7 TB/s depending on where the output buffer
-    # happens to sit (DESIGN.md "Roofline"), so — as a deployment would at start-up — allocate a few candidate output
-    # buffers, pick the faster of the two bit-identical kernel paths on each, keep the best pair, free the rest.
-    chosen, placement = args.variant, []
-    ncand = args.placements if n * pitch <= (16 << 30) else 1
-    cands = []
-    for _ in range(max(1, ncand)):
-        buf = torch.empty(n * pitch, dtype=torch.uint8, device=dev)
-        if args.variant is None:
-            v, ms = ctx.autotune_device(d_recs.data_ptr(), n, buf.data_ptr(), pitch, d_pub.data_ptr(), d_status.data_ptr(),
-                                        stream.cuda_stream)
-        else:
-            v, ms = args.variant, ctx.time_device(d_recs.data_ptr(), n, buf.data_ptr(), pitch, d_pub.data_ptr(),
-                                                  d_status.data_ptr(), stream.cuda_stream, 5)
-        cands.append((ms, v, buf))
-        placement.append(round(ms, 4))
-    best_ms, chosen, d_bodies = min(cands, key=lambda c: c[0])
-    del cands, buf
-    torch.cuda.empty_cache()
+    # Untimed set-up.  The body buffer comes from the library's placement allocator (b3w_bodies_alloc: its 256 MiB
+    # pieces alternate between two classes of HBM, DESIGN.md "Placement"), then the faster of the two bit-identical
+    # kernel paths is picked on that buffer.
+    if args.placement == "plain":
+        os.environ["B3W_PLACEMENT"] = "plain"
+    bodies = ctx.alloc_bodies(n * pitch)
+    d_bodies = bodies                                      # .data_ptr() like a tensor
     if args.variant is None:
-        os.environ["B3W_VARIANT"] = str(chosen)
-        ctx.close()
-        ctx = m.Context(circuit, local_rank)            # a context pinned to the chosen path
-        del os.environ["B3W_VARIANT"]
+        chosen, best_ms = ctx.autotune_device(d_recs.data_ptr(), n, bodies.ptr, pitch, d_pub.data_ptr(), d_status.data_ptr(),
+                                              stream.cuda_stream)
+    else:                                                   # (autotune leaves the winner selected in ctx)
+        chosen = args.variant
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
@@ -252,7 +241,7 @@ def main():
                        "circuit": circuit, "batch_per_gpu": n, "witness_bytes": ctx.body_bytes, "pitch": pitch,
                        "kernel_variant": "sweep (TRACE + SWEEP kernels)" if chosen >= 100 else f"fused ({chosen})",
                        "verified_on_device": True,
-                       "placement_candidates_ms": placement,
+                       "placement": bodies.placement,
                        "exchange": "all_gather of public outputs (RCCL)" if world > 1 else "none"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,

@@ -88,6 +88,9 @@ def lib():
         "b3w_batch_verify": (i32, [vp, vp]),
         "b3w_batch_write_wtns": (i32, [vp, u32, u32, ctypes.c_char_p, ctypes.c_char_p, ctypes.POINTER(u32)]),
         "b3w_batch_autotune_device": (i32, [vp, vp, u32, vp, u64, vp, vp, vp, ctypes.POINTER(i32), ctypes.POINTER(ctypes.c_float)]),
+        "b3w_bodies_alloc": (i32, [vp, u64, ctypes.POINTER(vp), ctypes.POINTER(i32)]),
+        "b3w_bodies_free": (i32, [vp, vp]),
+        "b3w_batch_placement": (i32, [vp]),
         "b3w_chain_num_chunks": (u64, [u64]),
         "b3w_chain_num_leaf_steps": (u64, [u64]),
         "b3w_chain_path_len": (u32, [u64, u64]),
@@ -106,7 +109,7 @@ EXPORTED_SYMBOLS = ("b3w_abi_version", "b3w_identify_wasm", "b3w_create", "b3w_d
                     "b3w_input_signal_size", "b3w_calc_witness", "b3w_write_wtns_header", "b3w_last_error",
                     "b3w_batch_run_device", "b3w_public_words", "b3w_batch_alloc", "b3w_batch_free",
                     "b3w_batch_run", "b3w_batch_outputs", "b3w_batch_fetch", "b3w_batch_device_ptr",
-                    "b3w_batch_time_device", "b3w_batch_verify_device", "b3w_batch_verify", "b3w_batch_write_wtns", "b3w_batch_autotune_device", "b3w_chain_num_chunks", "b3w_chain_num_leaf_steps", "b3w_chain_path_len",
+                    "b3w_batch_time_device", "b3w_batch_verify_device", "b3w_batch_verify", "b3w_batch_write_wtns", "b3w_batch_autotune_device", "b3w_bodies_alloc", "b3w_bodies_free", "b3w_batch_placement", "b3w_chain_num_chunks", "b3w_chain_num_leaf_steps", "b3w_chain_path_len",
                     "b3w_chain_plan_leaves_device", "b3w_chain_tree_device", "b3w_chain_plan_parents_device")
 
 
@@ -207,6 +210,10 @@ class Context:
             raise B3WError(rc, f"b3w_batch_autotune_device: status {rc}: {self.last_error()}")
         return v.value, ms.value
 
+    def alloc_bodies(self, nbytes):
+        """Device buffer for bodies, placed over two classes of HBM when possible (b3w_bodies_alloc)."""
+        return BodyBuffer(self, nbytes)
+
     def time_device(self, d_records, n, d_bodies, pitch, d_public, d_status, stream, iters):
         ms = ctypes.c_float()
         rc = self._lib.b3w_batch_time_device(self.handle, d_records, n, d_bodies, pitch, d_public or None,
@@ -214,6 +221,34 @@ class Context:
         if rc != B3W_OK:
             raise B3WError(rc, f"b3w_batch_time_device: status {rc}: {self.last_error()}")
         return ms.value
+
+
+class BodyBuffer:
+    """A linear device buffer for witness bodies from b3w_bodies_alloc: `ptr` (int), `nbytes`, and
+    `placement` ("mixed" = its 256 MiB pieces alternate between two classes of HBM, "plain" otherwise)."""
+
+    def __init__(self, ctx, nbytes):
+        self.ctx, self.nbytes = ctx, int(nbytes)
+        p, pl = ctypes.c_void_p(), ctypes.c_int32()
+        rc = lib().b3w_bodies_alloc(ctx.handle, self.nbytes, ctypes.byref(p), ctypes.byref(pl))
+        if rc != B3W_OK:
+            raise B3WError(rc, f"b3w_bodies_alloc({nbytes}): status {rc}: {ctx.last_error()}")
+        self.ptr = p.value
+        self.placement = "mixed" if pl.value == 1 else "plain"
+
+    def data_ptr(self):
+        return self.ptr
+
+    def free(self):
+        if getattr(self, "ptr", None):
+            lib().b3w_bodies_free(self.ctx.handle, self.ptr)
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
 
 
 class ChainPlanner:
@@ -320,6 +355,10 @@ class Batch:
         if rc != B3W_OK:
             raise B3WError(rc, f"b3w_batch_write_wtns: status {rc}: {self.ctx.last_error()}")
         return wr.value
+
+    @property
+    def placement(self):
+        return "mixed" if lib().b3w_batch_placement(self.handle) == 1 else "plain"
 
     def device_ptr(self):
         pitch = ctypes.c_uint64()

@@ -307,6 +307,7 @@ struct b3w_batch {
   b3w_ctx *ctx = nullptr;
   uint32_t capacity = 0, n = 0;
   uint64_t pitch = 0;
+  int32_t placement = B3W_PLACEMENT_PLAIN;
   uint32_t *d_recs = nullptr;
   uint8_t *d_bodies = nullptr;
   uint32_t *d_pub = nullptr;
@@ -612,6 +613,37 @@ int32_t b3w_calc_witness(b3w_ctx *ctx, const uint64_t *name_hashes, const uint32
   return B3W_OK;
 }
 
+int32_t b3w_bodies_alloc(b3w_ctx *ctx, uint64_t bytes, void **d_ptr, int32_t *placement) {
+  if (!ctx || !d_ptr || !bytes) return B3W_E_BAD_ARGUMENT;
+  *d_ptr = nullptr;
+  if (placement) *placement = B3W_PLACEMENT_PLAIN;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const char *env = getenv("B3W_PLACEMENT");
+  const bool want_mixed = !(env && !strcmp(env, "plain")) && bytes >= (512ull << 20);
+  if (want_mixed) {
+    int mixed = 0;
+    const int rc = b3w_place_alloc(ctx->device, bytes, 1, d_ptr, &mixed, nullptr);
+    if (rc == 0) {
+      if (placement) *placement = mixed ? B3W_PLACEMENT_MIXED : B3W_PLACEMENT_PLAIN;
+      return B3W_OK;
+    }
+    // the virtual-memory path is an optimisation: fall through to a plain allocation
+  }
+  hipError_t e = hipMalloc(d_ptr, bytes);
+  if (e != hipSuccess) { *d_ptr = nullptr; return e == hipErrorOutOfMemory ? B3W_E_NOT_ENOUGH_MEMORY : hip_fail(ctx, e, "hipMalloc(bodies)"); }
+  return B3W_OK;
+}
+
+int32_t b3w_bodies_free(b3w_ctx *ctx, void *d_ptr) {
+  if (!d_ptr) return B3W_OK;
+  if (ctx) (void)hipSetDevice(ctx->device);
+  if (b3w_place_free(d_ptr) == 0) return B3W_OK;
+  hipError_t e = hipFree(d_ptr);
+  return e == hipSuccess ? B3W_OK : hip_fail(ctx, e, "hipFree(bodies)");
+}
+
+int32_t b3w_batch_placement(const b3w_batch *b) { return b ? b->placement : B3W_PLACEMENT_PLAIN; }
+
 int32_t b3w_batch_alloc(b3w_ctx *ctx, uint32_t capacity, uint64_t pitch, b3w_batch **out) {
   if (!ctx || !out || !capacity) return B3W_E_BAD_ARGUMENT;
   *out = nullptr;
@@ -622,7 +654,10 @@ int32_t b3w_batch_alloc(b3w_ctx *ctx, uint32_t capacity, uint64_t pitch, b3w_bat
   b->ctx = ctx; b->capacity = capacity; b->pitch = pitch;
   hipError_t e = hipSetDevice(ctx->device);
   if (e == hipSuccess) e = hipMalloc((void **)&b->d_recs, (size_t)capacity * ctx->desc.nin * 4);
-  if (e == hipSuccess) e = hipMalloc((void **)&b->d_bodies, (size_t)capacity * pitch);
+  if (e == hipSuccess) {
+    const int32_t rc = b3w_bodies_alloc(ctx, (uint64_t)capacity * pitch, (void **)&b->d_bodies, &b->placement);
+    if (rc != B3W_OK) { b3w_batch_free(b); return rc; }
+  }
   if (e == hipSuccess) e = hipMalloc((void **)&b->d_pub, (size_t)capacity * ctx->desc.npub * 4);
   if (e == hipSuccess) e = hipMalloc((void **)&b->d_status, (size_t)capacity * 4);
   if (e != hipSuccess) { b3w_batch_free(b); return e == hipErrorOutOfMemory ? B3W_E_NOT_ENOUGH_MEMORY : hip_fail(ctx, e, "hipMalloc"); }
@@ -633,7 +668,7 @@ int32_t b3w_batch_alloc(b3w_ctx *ctx, uint32_t capacity, uint64_t pitch, b3w_bat
 void b3w_batch_free(b3w_batch *b) {
   if (!b) return;
   if (b->d_recs) (void)hipFree(b->d_recs);
-  if (b->d_bodies) (void)hipFree(b->d_bodies);
+  if (b->d_bodies) (void)b3w_bodies_free(b->ctx, b->d_bodies);
   if (b->d_pub) (void)hipFree(b->d_pub);
   if (b->d_status) (void)hipFree(b->d_status);
   delete b;

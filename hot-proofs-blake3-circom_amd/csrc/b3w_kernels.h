@@ -30,3 +30,7 @@ extern "C" int b3w_launch_plan_parents(const uint32_t *d_levels, uint64_t nchunk
 extern "C" int b3w_launch_verify(int kind, const uint32_t *d_in_slots, uint32_t n, const uint8_t *d_bodies, uint64_t pitch,
                                  const uint32_t *d_table, uint32_t nwit, uint32_t *d_mismatch, const void *d_aux,
                                  hipStream_t stream);
+
+// b3w_placement.hip: body buffers assembled from two classes of HBM (HIP virtual-memory API)
+extern "C" int b3w_place_alloc(int device, uint64_t bytes, int want_mixed, void **out, int *mixed, float *rates);
+extern "C" int b3w_place_free(void *ptr);
