@@ -287,7 +287,8 @@ struct b3w_ctx {
   int device = -1;
   int variant = 0;
   std::vector<InputSignal> inputs;
-  uint32_t *d_table = nullptr;
+  uint32_t *d_table = nullptr;        // slot table; 32 pad entries in front of it (expand() indexes from slot - 3)
+  uint32_t *d_table_base = nullptr;
   void *d_aux = nullptr;
   uint32_t *d_scratch = nullptr;      // TRACE images of the two-kernel path
   uint32_t *d_exact_table = nullptr;  // exact (field-element) path: slot -> atom | bit<<16
@@ -379,7 +380,9 @@ int32_t b3w_create(int32_t circuit, int32_t device, b3w_ctx **out) {
   if (!build_slot_table(ctx->desc, table, ctx->last_error)) { delete ctx; return B3W_E_BAD_ARGUMENT; }
   if (hipSetDevice(device) != hipSuccess) { delete ctx; return B3W_E_NO_DEVICE; }
   const CircuitDesc &d = ctx->desc;
-  hipError_t e = hipMalloc((void **)&ctx->d_table, table.size() * 4);
+  hipError_t e = hipMalloc((void **)&ctx->d_table_base, (table.size() + 32) * 4);
+  if (e == hipSuccess) e = hipMemset(ctx->d_table_base, 0, 32 * 4);
+  if (e == hipSuccess) ctx->d_table = ctx->d_table_base + 32;
   if (e == hipSuccess) e = hipMemcpy(ctx->d_table, table.data(), table.size() * 4, hipMemcpyHostToDevice);
   if (e == hipSuccess && d.kind != B3W_KIND_COMP) {
     const std::vector<uint32_t> aux = build_nova_aux(d.prime);
@@ -414,7 +417,7 @@ int32_t b3w_create(int32_t circuit, int32_t device, b3w_ctx **out) {
 
 void b3w_destroy(b3w_ctx *ctx) {
   if (!ctx) return;
-  if (ctx->d_table) (void)hipFree(ctx->d_table);
+  if (ctx->d_table_base) (void)hipFree(ctx->d_table_base);
   if (ctx->d_aux) (void)hipFree(ctx->d_aux);
   if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
   if (ctx->d_exact_table) (void)hipFree(ctx->d_exact_table);
@@ -508,11 +511,14 @@ int32_t b3w_batch_autotune_device(b3w_ctx *ctx, const uint32_t *d_records, uint3
   if (!ctx || !d_records || !d_bodies || !n) return B3W_E_BAD_ARGUMENT;
   int32_t rc = ensure_scratch(ctx);
   if (rc) return rc;
-  const int candidates[2] = {0, B3W_VARIANT_SWEEP};
+  // fused with 4 (compression) / 2 (nova) bodies per wave, compression also with 8, and the two-kernel sweep
+  const int candidates[3] = {0, ctx->desc.kind == B3W_KIND_COMP ? 3 : 0, B3W_VARIANT_SWEEP};
   int best = ctx->variant;
   float best_ms = 1e30f;
   const int saved = ctx->variant;
-  for (int c : candidates) {
+  for (int ci = 0; ci < 3; ci++) {
+    const int c = candidates[ci];
+    if (ci == 1 && c == candidates[0]) continue;
     ctx->variant = c;
     float ms = 0;
     rc = B3W_OK;

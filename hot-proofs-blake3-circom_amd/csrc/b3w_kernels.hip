@@ -150,28 +150,65 @@ __device__ __forceinline__ void emit_group(const uint32_t *lds, uint32_t e, uint
   }
 }
 
+// Which witnesses a wave computes.  Bodies sit `pitch` bytes apart, so body i starts (i * pitch) mod 128 bytes into
+// a 128-byte line; a wave takes W bodies `stride` apart with stride = 128 / gcd(pitch mod 128, 128) (1, 2 or 4), all
+// starting at the SAME offset into a line, so that one shifted lane->slot mapping serves them all (expand below).
+struct WaveBodies {
+  uint32_t first, stride;
+  __device__ __forceinline__ uint32_t operator()(int w) const { return first + (uint32_t)w * stride; }
+};
+template <int W>
+__device__ __forceinline__ WaveBodies wave_bodies(uint32_t bid, uint32_t stride) {
+  return WaveBodies{(bid / stride) * (stride * W) + bid % stride, stride};
+}
+// number of active witnesses of the wave (they form a prefix: the index grows with w)
+template <int W>
+__device__ __forceinline__ uint32_t wave_active(const WaveBodies &wb, uint32_t n) {
+  uint32_t a = 0;
+#pragma unroll
+  for (int w = 0; w < W; ++w) a += wb(w) < n ? 1u : 0u;
+  return a;
+}
+
 // U = groups per software-pipeline stage: the slot-table words of the next U groups are loaded
 // before the U*W stores of the current ones are issued, so a wave waits on memory once per U KiB*W.
+//
+// Tiles are aligned to 128-byte lines in ABSOLUTE addresses: with j = (body start mod 128) / 32, tile k of a body
+// covers its slots [32k - j, 32k - j + 32), so every wave store is eight whole lines (an unshifted 1 KiB store from
+// a body that starts 32 bytes into a line touches nine, two of them partially: measured 6 % slower).  The table
+// has 4 pad entries in front for the (masked) lanes of tile 0 that lie before the body.
 template <int W, int WORDS, bool WIDE, bool NT>
 __device__ __forceinline__ void expand(const uint32_t *lds, const uint32_t *__restrict__ table, uint32_t nwit,
-                                       uint8_t *__restrict__ out, uint64_t pitch, uint32_t wit0, uint32_t n,
+                                       uint8_t *__restrict__ out, uint64_t pitch, const WaveBodies wb, uint32_t n,
                                        const uint32_t *okmask /* per-w LDS flags or null */, bool all_ok) {
   constexpr int U = 4;
   const int lane = threadIdx.x;
-  const uint32_t ngroups = (nwit + 31) >> 5, full = nwit >> 5;
-  const uint32_t nact = n - wit0 < (uint32_t)W ? n - wit0 : (uint32_t)W;
-  uint64_t woff[W];                                    // byte offset of this lane's 16 B in group g of witness w
+  const uint32_t nact = wave_active<W>(wb, n);
+  const uint64_t start = reinterpret_cast<uint64_t>(out) + (uint64_t)wb.first * pitch;
+  const uint32_t j = (start & 31) ? 0u : (uint32_t)(start >> 5) & 3u;     // 16-byte aligned buffers: unshifted
+  const uint32_t ntiles = (nwit + j + 31) >> 5;
+  const uint32_t kf0 = j ? 1u : 0u, kf1 = (nwit + j) >> 5;                // full tiles [kf0, kf1)
+  uint64_t woff[W];                                    // byte offset of this lane's 16 B in tile k of witness w
 #pragma unroll
-  for (int w = 0; w < W; ++w) woff[w] = (uint64_t)(wit0 + w) * pitch + (uint32_t)lane * 16u;
-  const uint32_t *tp = table + (lane >> 1);            // entry of this lane's slot in group 0
-  uint32_t g = 0;
+  for (int w = 0; w < W; ++w) woff[w] = (uint64_t)wb(w) * pitch + (uint32_t)lane * 16u - 32u * j;
+  const uint32_t *tp = table + (lane >> 1) - j;        // entry of this lane's slot in tile 0
+  uint32_t k = 0;
+  auto ragged = [&](uint32_t kend) {
+    for (; k < kend; ++k) {
+      const uint32_t slot = k * 32 + (lane >> 1) - j;   // wraps above nwit for the lanes before the body
+      emit_group<W, WORDS, WIDE, NT, false>(lds, tp[k * 32], out, woff, 0, slot < nwit, nact, okmask);
+#pragma unroll
+      for (int w = 0; w < W; ++w) woff[w] += 1024u;
+    }
+  };
   if (nact == (uint32_t)W && all_ok) {
+    ragged(kf0);
     uint32_t cur[U], nxt[U];
 #pragma unroll
-    for (int u = 0; u < U; ++u) cur[u] = tp[u * 32];   // table is padded by U groups past ngroups
-    for (; g + U <= full; g += U) {
+    for (int u = 0; u < U; ++u) cur[u] = tp[(k + u) * 32];   // table is padded by 2U groups past the last slot
+    for (; k + U <= kf1; k += U) {
 #pragma unroll
-      for (int u = 0; u < U; ++u) nxt[u] = tp[(g + U + u) * 32];
+      for (int u = 0; u < U; ++u) nxt[u] = tp[(k + U + u) * 32];
 #pragma unroll
       for (int u = 0; u < U; ++u) emit_group<W, WORDS, WIDE, NT, true>(lds, cur[u], out, woff, u * 1024u, true, nact, nullptr);
 #pragma unroll
@@ -179,13 +216,8 @@ __device__ __forceinline__ void expand(const uint32_t *lds, const uint32_t *__re
 #pragma unroll
       for (int u = 0; u < U; ++u) cur[u] = nxt[u];
     }
-  } 
-  for (; g < ngroups; ++g) {                            // ragged waves, and the last (partial) groups
-    const uint32_t slot = g * 32 + (lane >> 1);
-    emit_group<W, WORDS, WIDE, NT, false>(lds, tp[g * 32], out, woff, 0, slot < nwit, nact, okmask);
-#pragma unroll
-    for (int w = 0; w < W; ++w) woff[w] += 1024u;
   }
+  ragged(ntiles);                                        // ragged waves, and the last (partial) tiles
 }
 
 // VERIFY (on-device consumer): instead of storing, read the body back and compare it with what its own
@@ -461,25 +493,27 @@ template <int W, bool NT, int MODE>
 __global__ __launch_bounds__(64) void b3w_compression_kernel(const uint32_t *__restrict__ recs, uint32_t n,
                                                              uint8_t *__restrict__ out, uint64_t pitch,
                                                              const uint32_t *__restrict__ table, uint32_t nwit,
-                                                             uint32_t *__restrict__ pub, int32_t *__restrict__ status) {
+                                                             uint32_t *__restrict__ pub, int32_t *__restrict__ status,
+                                                             uint32_t stride /* WaveBodies; 1 for MODE 1 and 2 */) {
   constexpr int WORDS = B3W_LDS_WORDS_COMP;
   __shared__ __attribute__((aligned(16))) uint32_t lds[W * WORDS + 4];   // +4: expand reads src+1 unconditionally
   const int lane = threadIdx.x;
-  const uint32_t wit0 = blockIdx.x * W;
+  const WaveBodies wb = wave_bodies<W>(blockIdx.x, stride);
+  const uint32_t wit0 = wb.first;                      // MODE 1 and 2 run with stride 1
   // stage the 28-word records of this wave's witnesses into atoms H M T B D (image words 1..28)
   __shared__ uint32_t ncf[W];      // VERIFY: an input slot of the body is not a plain 32-bit value
   if (lane < W) ncf[lane] = 0;
   if (MODE == 2) __syncthreads();
   for (int i = lane; i < W * 28; i += 64) {
     const int w = i / 28, j = i - w * 28;
-    if (wit0 + w < n) {
+    if (wb(w) < n) {
       uint32_t v;
       if (MODE == 2) {
         uint32_t nc = 0;
-        v = body_input_word(out + (uint64_t)(wit0 + w) * pitch, recs[j], nc);
+        v = body_input_word(out + (uint64_t)wb(w) * pitch, recs[j], nc);
         if (nc) ncf[w] = 1;
       } else {
-        v = recs[(uint64_t)(wit0 + w) * 28 + j];
+        v = recs[(uint64_t)wb(w) * 28 + j];
       }
       lds[w * WORDS + B3W_A_H + j] = v;
     }
@@ -487,9 +521,9 @@ __global__ __launch_bounds__(64) void b3w_compression_kernel(const uint32_t *__r
   __syncthreads();
   {
     const int w = lane >> 2, col = lane & 3;
-    if (w < W && wit0 + w < n) {
-      trace_compression(lds + w * WORDS, col, (MODE != 2 && pub) ? pub + (uint64_t)(wit0 + w) * 16 : nullptr);
-      if (MODE != 2 && status && col == 0) status[wit0 + w] = 0;     // canonical u32 inputs cannot fail an assert
+    if (w < W && wb(w) < n) {
+      trace_compression(lds + w * WORDS, col, (MODE != 2 && pub) ? pub + (uint64_t)wb(w) * 16 : nullptr);
+      if (MODE != 2 && status && col == 0) status[wb(w)] = 0;     // canonical u32 inputs cannot fail an assert
     }
   }
   __syncthreads();
@@ -498,7 +532,7 @@ __global__ __launch_bounds__(64) void b3w_compression_kernel(const uint32_t *__r
     uint32_t cnt[W];
     expand_verify<W, WORDS, false>(lds, table, nwit, out, pitch, wit0, n, cnt);
     publish_counts<W>(cnt, pub, wit0, n, ncf);
-  } else expand<W, WORDS, false, NT>(lds, table, nwit, out, pitch, wit0, n, nullptr, true);
+  } else expand<W, WORDS, false, NT>(lds, table, nwit, out, pitch, wb, n, nullptr, true);
 }
 
 
@@ -607,27 +641,28 @@ __global__ __launch_bounds__(64) void b3w_nova_kernel(const uint32_t *__restrict
                                                       uint8_t *__restrict__ out, uint64_t pitch,
                                                       const uint32_t *__restrict__ table, uint32_t nwit,
                                                       uint32_t *__restrict__ pub, int32_t *__restrict__ status,
-                                                      const uint32_t *__restrict__ aux) {
+                                                      const uint32_t *__restrict__ aux, uint32_t stride) {
   constexpr bool O1 = KIND == B3W_KIND_NOVA_O1;
   constexpr int WORDS = O1 ? B3W_LDS_WORDS_NOVA_O1 : B3W_LDS_WORDS_NOVA_O2;
   __shared__ __attribute__((aligned(16))) uint32_t lds[W * WORDS + 4];
   __shared__ uint32_t okf[W];      // 1 = witness computed, stream it out
   __shared__ uint32_t domf[W];     // 1 = an IsZero argument fell outside the supported magnitude
   const int lane = threadIdx.x;
-  const uint32_t wit0 = blockIdx.x * W;
+  const WaveBodies wb = wave_bodies<W>(blockIdx.x, stride);
+  const uint32_t wit0 = wb.first;                      // MODE 1 and 2 run with stride 1
   __shared__ uint32_t ncf[W];      // VERIFY: an input slot of the body is not a plain 32-bit value
   if (lane < W) { okf[lane] = 0; domf[lane] = 0; ncf[lane] = 0; }
   if (MODE == 2) __syncthreads();
   for (int i = lane; i < W * 32; i += 64) {
     const int w = i >> 5, j = i & 31;
-    if (wit0 + w < n) {
+    if (wb(w) < n) {
       uint32_t v;
       if (MODE == 2) {
         uint32_t nc = 0;
-        v = body_input_word(out + (uint64_t)(wit0 + w) * pitch, recs[j], nc);
+        v = body_input_word(out + (uint64_t)wb(w) * pitch, recs[j], nc);
         if (nc) ncf[w] = 1;
       } else {
-        v = recs[(uint64_t)(wit0 + w) * 32 + j];
+        v = recs[(uint64_t)wb(w) * 32 + j];
       }
       lds[w * WORDS + B3W_LDS_NV + j] = v;
     }
@@ -641,7 +676,7 @@ __global__ __launch_bounds__(64) void b3w_nova_kernel(const uint32_t *__restrict
   // ---- A: the 67 IsZero gadgets of each step, one per lane-job
   for (int t = lane; t < 67 * W; t += 64) {
     const int w = t / 67, j = t - w * 67;
-    if (wit0 + w >= n) continue;
+    if (wb(w) >= n) continue;
     uint32_t *L = lds + w * WORDS;
     const uint32_t *in = L + B3W_LDS_NV;
     const int64_t depth = in[NV_DEPTH];
@@ -669,7 +704,7 @@ __global__ __launch_bounds__(64) void b3w_nova_kernel(const uint32_t *__restrict
 
   // ---- B: flags, message / chaining-value selection; 4 lanes per witness
   const int w = lane >> 2, col = lane & 3;
-  const bool active = w < W && wit0 + w < n;
+  const bool active = w < W && wb(w) < n;
   uint32_t *L = lds + (active ? w : 0) * WORDS;
   if (active) {
     uint32_t *nv = L + B3W_LDS_NV;
@@ -698,7 +733,7 @@ __global__ __launch_bounds__(64) void b3w_nova_kernel(const uint32_t *__restrict
     const uint32_t cdd = last | parent, decr = cdd & (1u - is_root);
     if (col == 0) {
       okf[w] = st == 0 ? 1u : 0u;
-      if (MODE != 2 && status) status[wit0 + w] = st;
+      if (MODE != 2 && status) status[wb(w)] = st;
       nv[NV_BLOCK_COUNT_OUT] = block_count + (1u - parent);               // :251
       nv[NV_DEPTH_OUT] = depth - decr;                                    // :262
       nv[NV_IS_PARENT] = parent;
@@ -760,7 +795,7 @@ __global__ __launch_bounds__(64) void b3w_nova_kernel(const uint32_t *__restrict
   for (int x = 0; x < W; ++x) all_ok = all_ok && (okf[x] != 0);
   if (MODE != 2 && active && okf[w] && pub) {
     // w[1..15]: n_blocks_out block_count_out h_out[8] total_depth_out depth_out chunk_idx_low_out chunk_idx_high_out leaf_depth_out
-    uint32_t *pw = pub + (uint64_t)(wit0 + w) * 15;
+    uint32_t *pw = pub + (uint64_t)wb(w) * 15;
     const uint32_t *nv = L + B3W_LDS_NV;
     if (col == 0) { pw[0] = nv[NV_N_BLOCKS]; pw[1] = nv[NV_BLOCK_COUNT_OUT]; pw[10] = nv[NV_TOTAL_DEPTH]; pw[11] = nv[NV_DEPTH_OUT]; }
     if (col == 1) { pw[12] = nv[NV_CIL]; pw[13] = nv[NV_CIH]; pw[14] = nv[NV_LEAF_DEPTH]; }
@@ -775,7 +810,7 @@ __global__ __launch_bounds__(64) void b3w_nova_kernel(const uint32_t *__restrict
     uint32_t cnt[W];
     expand_verify<W, WORDS, true>(lds, table, nwit, out, pitch, wit0, n, cnt);
     publish_counts<W>(cnt, pub, wit0, n, ncf);
-  } else expand<W, WORDS, true, NT>(lds, table, nwit, out, pitch, wit0, n, okf, all_ok);
+  } else expand<W, WORDS, true, NT>(lds, table, nwit, out, pitch, wb, n, okf, all_ok);
 }
 
 }  // namespace
@@ -823,13 +858,13 @@ extern "C" int b3w_launch_verify(int kind, const uint32_t *d_in_slots, uint32_t 
   uint8_t *bodies = const_cast<uint8_t *>(d_bodies);
   if (kind == B3W_KIND_COMP)
     hipLaunchKernelGGL((b3w_compression_kernel<4, false, 2>), dim3((n + 3) / 4), dim3(64), 0, stream, d_in_slots, n, bodies, pitch,
-                       d_table, nwit, d_mismatch, (int32_t *)nullptr);
+                       d_table, nwit, d_mismatch, (int32_t *)nullptr, 1u);
   else if (kind == B3W_KIND_NOVA_O2)
     hipLaunchKernelGGL((b3w_nova_kernel<B3W_KIND_NOVA_O2, 2, false, 2>), dim3((n + 1) / 2), dim3(64), 0, stream, d_in_slots, n,
-                       bodies, pitch, d_table, nwit, d_mismatch, (int32_t *)nullptr, (const uint32_t *)d_aux);
+                       bodies, pitch, d_table, nwit, d_mismatch, (int32_t *)nullptr, (const uint32_t *)d_aux, 1u);
   else
     hipLaunchKernelGGL((b3w_nova_kernel<B3W_KIND_NOVA_O1, 2, false, 2>), dim3((n + 1) / 2), dim3(64), 0, stream, d_in_slots, n,
-                       bodies, pitch, d_table, nwit, d_mismatch, (int32_t *)nullptr, (const uint32_t *)d_aux);
+                       bodies, pitch, d_table, nwit, d_mismatch, (int32_t *)nullptr, (const uint32_t *)d_aux, 1u);
   return (int)hipGetLastError();
 }
 
@@ -851,29 +886,32 @@ extern "C" int b3w_launch_batch(int kind, int variant, const uint32_t *d_recs, u
       if (kind == B3W_KIND_COMP) {
         const uint32_t *rc_recs = d_recs + (uint64_t)c0 * 28;
         hipLaunchKernelGGL((b3w_compression_kernel<16, false, 1>), dim3((cn + 15) / 16), dim3(64), 0, stream, rc_recs,
-                           cn, reinterpret_cast<uint8_t *>(d_images), (uint64_t)scratch_cap, d_table, nwit, pub_c, st_c);
+                           cn, reinterpret_cast<uint8_t *>(d_images), (uint64_t)scratch_cap, d_table, nwit, pub_c, st_c, 1u);
         rc = launch_sweep<false, 8>(d_images, cn, out_c, pitch, d_table, nwit, stream);
       } else if (kind == B3W_KIND_NOVA_O2) {
         const uint32_t *rc_recs = d_recs + (uint64_t)c0 * 32;
         hipLaunchKernelGGL((b3w_nova_kernel<B3W_KIND_NOVA_O2, 4, false, 1>), dim3((cn + 3) / 4), dim3(64), 0, stream,
                            rc_recs, cn, reinterpret_cast<uint8_t *>(d_images), (uint64_t)scratch_cap, d_table, nwit, pub_c, st_c,
-                           (const uint32_t *)d_aux);
+                           (const uint32_t *)d_aux, 1u);
         rc = launch_sweep<true, 4>(d_images, cn, out_c, pitch, d_table, nwit, stream);
       } else {
         const uint32_t *rc_recs = d_recs + (uint64_t)c0 * 32;
         hipLaunchKernelGGL((b3w_nova_kernel<B3W_KIND_NOVA_O1, 2, false, 1>), dim3((cn + 1) / 2), dim3(64), 0, stream,
                            rc_recs, cn, reinterpret_cast<uint8_t *>(d_images), (uint64_t)scratch_cap, d_table, nwit, pub_c, st_c,
-                           (const uint32_t *)d_aux);
+                           (const uint32_t *)d_aux, 1u);
         rc = launch_sweep<true, 4>(d_images, cn, out_c, pitch, d_table, nwit, stream);
       }
       if (rc) return rc;
     }
     return (int)hipGetLastError();
   }
+  // bodies that start at the same offset into a 128-byte line are `stride` apart (WaveBodies); a wave takes W of them
+  const uint32_t pm = (uint32_t)(pitch >> 5) & 3u, stride = (pitch & 31) ? 1u : pm == 0 ? 1u : pm == 2 ? 2u : 4u;
+#define B3W_GRID(WV) dim3((n + stride * WV - 1) / (stride * WV) * stride)
   if (kind == B3W_KIND_COMP) {
 #define B3W_LAUNCH_COMP(WV, NTV)                                                                         \
-  hipLaunchKernelGGL((b3w_compression_kernel<WV, NTV, 0>), dim3((n + WV - 1) / WV), dim3(64), 0, stream,   \
-                     d_recs, n, d_out, pitch, d_table, nwit, d_pub, d_status)
+  hipLaunchKernelGGL((b3w_compression_kernel<WV, NTV, 0>), B3W_GRID(WV), dim3(64), 0, stream,              \
+                     d_recs, n, d_out, pitch, d_table, nwit, d_pub, d_status, stride)
     switch (variant) {
       case 0: B3W_LAUNCH_COMP(4, false); break;
       case 1: B3W_LAUNCH_COMP(1, false); break;
@@ -891,8 +929,8 @@ extern "C" int b3w_launch_batch(int kind, int variant, const uint32_t *d_recs, u
   if (kind == B3W_KIND_NOVA_O2 || kind == B3W_KIND_NOVA_O1) {
     if (!d_aux) return -3;
 #define B3W_LAUNCH_NOVA(KV, WV)                                                                           \
-  hipLaunchKernelGGL((b3w_nova_kernel<KV, WV, false, 0>), dim3((n + WV - 1) / WV), dim3(64), 0, stream,     \
-                     d_recs, n, d_out, pitch, d_table, nwit, d_pub, d_status, (const uint32_t *)d_aux)
+  hipLaunchKernelGGL((b3w_nova_kernel<KV, WV, false, 0>), B3W_GRID(WV), dim3(64), 0, stream,                \
+                     d_recs, n, d_out, pitch, d_table, nwit, d_pub, d_status, (const uint32_t *)d_aux, stride)
     if (kind == B3W_KIND_NOVA_O2) {
       switch (variant) {
         case 0: B3W_LAUNCH_NOVA(B3W_KIND_NOVA_O2, 2); break;
