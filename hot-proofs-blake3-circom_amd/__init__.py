@@ -239,6 +239,15 @@ class BodyBuffer:
     def data_ptr(self):
         return self.ptr
 
+    @property
+    def __cuda_array_interface__(self):
+        return {"shape": (self.nbytes,), "typestr": "|u1", "data": (self.ptr, False), "version": 2, "strides": None}
+
+    def tensor(self):
+        """Zero-copy 1-D uint8 torch view of the buffer (valid until free())."""
+        import torch
+        return torch.as_tensor(self, device=torch.device("cuda", torch.cuda.current_device()))
+
     def free(self):
         if getattr(self, "ptr", None):
             lib().b3w_bodies_free(self.ctx.handle, self.ptr)

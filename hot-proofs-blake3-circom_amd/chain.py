@@ -59,7 +59,16 @@ def fold_witnesses(ctx, preimage, batch_steps=16384, ring=2, slice_chunks=1024, 
     cvs_local = torch.zeros((max(nl, 1), 8), dtype=torch.int32, device=dev)
     pub = torch.zeros((nl * 16 + n_par, 15), dtype=torch.int32, device=dev)
     status = torch.zeros((nl * 16 + n_par,), dtype=torch.int32, device=dev)
-    bodies = [torch.empty((batch_steps, body), dtype=torch.uint8, device=dev) for _ in range(ring)]
+    # the ring of batch buffers: placed over two classes of HBM (b3w_bodies_alloc), allocated once per context
+    cache = ctx.__dict__.setdefault("_ring_cache", {})
+    key = (batch_steps, ring, dev.index)
+    if key not in cache:
+        for bufs in cache.values():
+            for b in bufs:
+                b.free()
+        cache.clear()
+        cache[key] = [ctx.alloc_bodies(batch_steps * body) for _ in range(ring)]
+    bodies = [b.tensor()[: batch_steps * body].view(batch_steps, body) for b in cache[key]]
     compute = torch.cuda.current_stream(dev)
     copy = torch.cuda.Stream(dev)
     nbatch = 0

@@ -633,7 +633,7 @@ int32_t b3w_bodies_alloc(b3w_ctx *ctx, uint64_t bytes, void **d_ptr, int32_t *pl
       if (placement) *placement = mixed ? B3W_PLACEMENT_MIXED : B3W_PLACEMENT_PLAIN;
       return B3W_OK;
     }
-    // the virtual-memory path is an optimisation: fall through to a plain allocation
+    (void)hipGetLastError();   // the virtual-memory path is an optimisation: fall through to a plain allocation
   }
   hipError_t e = hipMalloc(d_ptr, bytes);
   if (e != hipSuccess) { *d_ptr = nullptr; return e == hipErrorOutOfMemory ? B3W_E_NOT_ENOUGH_MEMORY : hip_fail(ctx, e, "hipMalloc(bodies)"); }

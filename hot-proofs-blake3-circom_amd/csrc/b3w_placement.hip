@@ -86,9 +86,10 @@ extern "C" int b3w_place_alloc(int device, uint64_t bytes, int want_mixed, void 
   size_t fr = 0, tot = 0;
   if ((e = hipMemGetInfo(&fr, &tot)) != hipSuccess) return -(int)e;
   if (fr < (uint64_t)nh * HANDLE + GiB) return -(int)hipErrorOutOfMemory;
-  // search budget: leave 4 GiB free, never walk more than 160 GiB past the buffer itself
-  uint64_t budget = fr > 4 * GiB ? fr - 4 * GiB : 0;
-  budget = std::min<uint64_t>(budget, (uint64_t)nh * HANDLE + 160 * GiB);
+  // search budget: the buffer itself plus at most half of what is free beyond it (other processes may be doing the
+  // same on this device), never more than 160 GiB
+  const uint64_t own = (uint64_t)nh * HANDLE;
+  const uint64_t budget = own + std::min<uint64_t>((fr - own) / 2, 160 * GiB);
   const uint32_t maxh = want_mixed ? (uint32_t)(budget / HANDLE) : nh;
   if (maxh < nh) return -(int)hipErrorOutOfMemory;
 
@@ -105,11 +106,13 @@ extern "C" int b3w_place_alloc(int device, uint64_t bytes, int want_mixed, void 
   bool found = false;
   for (uint32_t i = 0; i < maxh; i++) {
     hipMemGenericAllocationHandle_t hh;
-    if (hipMemCreate(&hh, HANDLE, &prop, 0) != hipSuccess) break;
-    if (hipMemMap(V + (size_t)i * HANDLE, HANDLE, 0, hh, 0) != hipSuccess) { (void)hipMemRelease(hh); break; }
+    // a failure here only ends the search; the sticky HIP error must not leak into the caller's next launch check
+    if (hipMemCreate(&hh, HANDLE, &prop, 0) != hipSuccess) { (void)hipGetLastError(); break; }
+    if (hipMemMap(V + (size_t)i * HANDLE, HANDLE, 0, hh, 0) != hipSuccess) { (void)hipMemRelease(hh); (void)hipGetLastError(); break; }
     if (hipMemSetAccess(V + (size_t)i * HANDLE, HANDLE, &acc, 1) != hipSuccess) {
       (void)hipMemUnmap(V + (size_t)i * HANDLE, HANDLE);
       (void)hipMemRelease(hh);
+      (void)hipGetLastError();
       break;
     }
     h.push_back(hh);

@@ -86,3 +86,25 @@ def test_kernel_on_raw_placed_pointer_verifies():
     assert int(d_mm.abs().sum().item()) == 0
     buf.free()
     ctx.close()
+
+
+def test_body_buffer_as_torch_tensor():
+    """zero-copy torch view of a placed buffer (what chain.fold_witnesses hands to its consumer)"""
+    import torch
+    ctx = m.Context("compression", 0)
+    n = 1024
+    recs = m.workloads.config2_compression(n)
+    buf = ctx.alloc_bodies(n * ctx.body_bytes)
+    t = buf.tensor()
+    assert t.data_ptr() == buf.ptr and t.numel() == buf.nbytes and t.dtype == torch.uint8
+    d_recs = torch.from_numpy(recs.view(np.int32)).cuda()
+    ctx.run_device(d_recs.data_ptr(), n, buf.ptr, ctx.body_bytes, 0, 0, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    idx = [0, 347, 348, 349, n - 1]                        # 348 = first body across the 256 MiB seam
+    bad, want = T.oracle_batch_u32("compression", recs[idx])
+    view = t[: n * ctx.body_bytes].view(n, ctx.body_bytes)
+    for j, i in enumerate(idx):
+        assert np.array_equal(view[i].cpu().numpy(), want[j])
+    del t, view
+    buf.free()
+    ctx.close()
