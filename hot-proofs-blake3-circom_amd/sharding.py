@@ -43,3 +43,55 @@ def gather_public(pub_local, n_total=None, group=None):
     out = torch.empty((world * mx, words), dtype=pub_local.dtype, device=pub_local.device)
     dist.all_gather_into_tensor(out, pad, group=group)
     return torch.cat([out[r * mx:r * mx + (e - s)] for r, (s, e) in enumerate(sizes)], dim=0)
+
+
+class PublicExchange:
+    """Pipelined exchange of the per-step public outputs: the all-gather of step i runs on RCCL's stream while the
+    witness kernel of step i+1 runs on the compute stream.  `depth` public-output buffers alternate; a buffer is
+    handed out again only after the gather that reads it has finished (stream-level wait, the host never blocks).
+
+        ex = PublicExchange(n_local, words, device)
+        for step in ...:
+            pub = ex.next_buffer()            # int32 [n_local, words], to be written by the kernel of this step
+            launch_kernel(..., pub.data_ptr())
+            ex.post()                         # enqueue the all-gather of this step's outputs
+        allpub = ex.finish()                  # [world * n_local, words] of the last step, global step order
+
+    Shards must be equal (weak scaling: every rank runs n_local units)."""
+
+    def __init__(self, n_local, words, device, depth=2, group=None):
+        self.group = group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.active = dist.is_initialized() and (self.world > 1 or dist.get_backend(group) == "nccl")
+        self.staged = self.active and dist.get_backend(group) == "gloo"      # CPU rehearsal: through the host, synchronous
+        self.bufs = [torch.zeros((n_local, words), dtype=torch.int32, device=device) for _ in range(depth)]
+        self.outs = [torch.empty((self.world * n_local, words), dtype=torch.int32, device=device) for _ in range(depth)] \
+            if self.active else self.bufs
+        self.work = [None] * depth
+        self.i = 0
+        self.last = None
+
+    def next_buffer(self):
+        k = self.i % len(self.bufs)
+        if self.work[k] is not None:
+            self.work[k].wait()               # the current stream waits for that gather; no host sync
+            self.work[k] = None
+        return self.bufs[k]
+
+    def post(self):
+        k = self.i % len(self.bufs)
+        if self.staged:
+            host = torch.empty(self.outs[k].shape, dtype=torch.int32)
+            dist.all_gather_into_tensor(host, self.bufs[k].cpu(), group=self.group)
+            self.outs[k].copy_(host)
+        elif self.active:
+            self.work[k] = dist.all_gather_into_tensor(self.outs[k], self.bufs[k], group=self.group, async_op=True)
+        self.last = k
+        self.i += 1
+
+    def finish(self):
+        for k, w in enumerate(self.work):
+            if w is not None:
+                w.wait()
+                self.work[k] = None
+        return None if self.last is None else self.outs[self.last]

@@ -51,3 +51,39 @@ def test_shard_range_covers_everything():
             assert r[0][0] == 0 and r[-1][1] == n
             assert all(r[k][1] == r[k + 1][0] for k in range(world - 1))
             assert max(e - s for s, e in r) - min(e - s for s, e in r) <= 1
+
+
+def _exchange_worker(rank, world, port, ret):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        sh = T.pkg().sharding
+        n, words, steps = 5, 16, 7
+        ex = sh.PublicExchange(n, words, torch.device("cpu"), depth=2)
+        seen = []
+        for step in range(steps):
+            pub = ex.next_buffer()
+            pub.copy_(torch.arange(n * words, dtype=torch.int32).view(n, words) + 1000 * rank + 100000 * step)
+            ex.post()
+            seen.append(ex.outs[ex.last].clone())
+        last = ex.finish()
+        ret[rank] = (torch.stack(seen).numpy(), last.numpy().copy())
+    finally:
+        dist.destroy_process_group()
+
+
+def test_pipelined_public_exchange_two_ranks():
+    """sharding.PublicExchange (what bench.py runs between steps at N > 1): every step's gather holds both ranks'
+    outputs of THAT step in rank order, and finish() returns the last step's."""
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    port = 31500 + (os.getpid() % 2000)
+    mp.spawn(_exchange_worker, args=(2, port, ret), nprocs=2, join=True)
+    n, words, steps = 5, 16, 7
+    base = np.arange(n * words, dtype=np.int32).reshape(n, words)
+    for rank in (0, 1):
+        seen, last = ret[rank]
+        for step in range(steps):
+            want = np.concatenate([base + 1000 * r + 100000 * step for r in (0, 1)])
+            assert np.array_equal(seen[step], want), (rank, step)
+        assert np.array_equal(last, seen[steps - 1])
