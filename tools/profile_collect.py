@@ -16,8 +16,8 @@ WITNESS_KERNELS = ("b3w_compression_kernel", "b3w_nova_kernel", "b3w_sweep_kerne
 
 
 def find(sub, pattern):
-    hits = glob.glob(os.path.join(src, sub, "**", pattern), recursive=True)
-    return hits[0] if hits else None
+    hits = glob.glob(os.path.join(src, sub, "**", pattern), recursive=True)      # merged gpurun_out keeps older runs too
+    return max(hits, key=os.path.getmtime) if hits else None
 
 
 bench = json.loads(open(os.path.join(src, "bench.json")).read().strip().splitlines()[-1])
