@@ -57,9 +57,15 @@ class WitnessCalculator {
     this.publicWords = info.publicWords;
     this.sanityCheck = sanityCheck;
     this.circuit = circuitName;
-    // the nova circuits log "D_FLAGS:  0" once per witness (circuits/blake3_nova.circom:166);
-    // set options.logDFlags to reproduce that console line
-    this._logDFlags = !!(sanityCheck && sanityCheck.logDFlags) && circuitName !== "compression";
+    // The nova circuits log "D_FLAGS:  0" through console.log once per witness (circuits/blake3_nova.circom:166 via
+    // writeBufferMessage, witness_calculator.js:44-58) — also when a later assert rejects the input, but not when
+    // the first component (Blake3NovaTreePath_CheckDepth, blake3_nova.circom:201) already does.  Reproduced by
+    // default; options.logDFlags === false silences it.
+    this._logDFlags = circuitName !== "compression" && !(sanityCheck && sanityCheck.logDFlags === false);
+    // options.strictErrorParity reproduces the loader's never-cleared errStr (witness_calculator.js:16,41): every
+    // assert trace thrown on this calculator is prefixed by the traces of all earlier failures on it.
+    this._strictErr = !!(sanityCheck && sanityCheck.strictErrorParity);
+    this._errStr = "";
   }
 
   circom_version() {
@@ -111,8 +117,15 @@ class WitnessCalculator {
     try {
       body = nat.calcWitness(this.instance, Uint32Array.from(hashes), Uint32Array.from(counts), vals);
     } catch (err) {
-      if (err.status === 4) throw new Error("Error: " + (err.message.startsWith("Assert Failed.") ? err.message : "Assert Failed.\n" + err.message));
-      throw err;
+      if (err.status !== 4) throw err;
+      const head = "Assert Failed.\n";
+      const trace = err.message.startsWith(head) ? err.message.slice(head.length) : err.message;
+      if (this._logDFlags && !/^Error in template (Num2Bits_\d+ line: \d+\nError in template (LessThan|GreaterEqThan)_\d+ line: \d+\nError in template )?Blake3NovaTreePath_CheckDepth_/.test(trace)) {
+        console.log("D_FLAGS:  0");
+      }
+      const prior = this._strictErr ? this._errStr : "";
+      this._errStr += trace;
+      throw new Error("Error: " + head + prior + trace);
     }
     if (this._logDFlags) console.log("D_FLAGS:  0");
     return body;

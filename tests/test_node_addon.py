@@ -136,3 +136,43 @@ def test_js_surface_errors_and_batch(tmp_path):
     assert out["batch"]["body3"] == cases[3]["body_sha256"]
     assert out["batch"]["verify"] == [0] * 8
     assert out["batch"]["files"] == 8 and out["batch"]["file5"] == cases[5]["wtns_sha256"]
+
+
+@needs_node
+@pytest.mark.gpu
+def test_nova_sequence_on_one_calculator_logs_and_sticky_errors():
+    """tests/golden/nova_vesta.sequence.json: ten witnesses on ONE reference calculator (tools/gen_sequence_golden.js) —
+    console.log lines ("D_FLAGS:  0": on success and on asserts past the first component, not on CheckDepth asserts)
+    and, with options.strictErrorParity, the reference's accumulating error text, call for call."""
+    seq = json.load(open(os.path.join(T.GOLD, "nova_vesta.sequence.json")))
+    r = _node("""
+      const builder = require('./hot-proofs-blake3-circom_amd/js/witness_calculator.js');
+      const crypto = require('crypto'), fs = require('fs');
+      (async () => {
+        const seq = JSON.parse(fs.readFileSync(process.argv[1]));
+        const out = {};
+        for (const mode of ['strict', 'default', 'quiet']) {
+          const wc = await builder('nova_vesta', mode === 'strict' ? {strictErrorParity: true} : mode === 'quiet' ? {logDFlags: false} : undefined);
+          const real = console.log, res = [];
+          for (const s of seq.steps) {
+            const logs = []; console.log = (...a) => logs.push(a.join(' '));
+            let err = null, sha = null;
+            try { sha = crypto.createHash('sha256').update(await wc.calculateBinWitness(s.input, 0)).digest('hex'); } catch (e) { err = e.message; }
+            console.log = real;
+            res.push({logs, error: err, body_sha256: sha});
+          }
+          out[mode] = res;
+        }
+        console.log(JSON.stringify(out));
+      })().catch(e => { console.error(e); process.exit(1); });
+    """, os.path.join(T.GOLD, "nova_vesta.sequence.json"))
+    assert r.returncode == 0, r.stderr
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    own = {c["name"]: c.get("error") for c in T.golden("nova_vesta")["cases"]}
+    for k, s in enumerate(seq["steps"]):
+        strict, default, quiet = out["strict"][k], out["default"][k], out["quiet"][k]
+        assert strict["logs"] == s["logs"] and default["logs"] == s["logs"] and quiet["logs"] == [], (s["name"], strict["logs"])
+        assert strict["body_sha256"] == s["body_sha256"] == default["body_sha256"], s["name"]
+        assert strict["error"] == s["error"], (s["name"], strict["error"])
+        if s["error"] is not None and s["name"] in own:       # default mode: only this call's own trace
+            assert default["error"] == own[s["name"]], s["name"]
