@@ -90,6 +90,7 @@ def lib():
         "b3w_batch_autotune_device": (i32, [vp, vp, u32, vp, u64, vp, vp, vp, ctypes.POINTER(i32), ctypes.POINTER(ctypes.c_float)]),
         "b3w_bodies_alloc": (i32, [vp, u64, ctypes.POINTER(vp), ctypes.POINTER(i32)]),
         "b3w_bodies_free": (i32, [vp, vp]),
+        "b3w_bodies_trim": (None, []),
         "b3w_batch_placement": (i32, [vp]),
         "b3w_chain_num_chunks": (u64, [u64]),
         "b3w_chain_num_leaf_steps": (u64, [u64]),
@@ -97,6 +98,16 @@ def lib():
         "b3w_chain_plan_leaves_device": (i32, [vp, vp, u64, u64, u32, vp, vp, vp]),
         "b3w_chain_tree_device": (i32, [vp, vp, u64, vp, vp]),
         "b3w_chain_plan_parents_device": (i32, [vp, vp, u64, u64, u64, u32, vp, vp]),
+        "b3w_chain_create": (i32, [vp, u64, u64, u32, u32, u32, i32, ctypes.POINTER(vp)]),
+        "b3w_chain_destroy": (None, [vp]),
+        "b3w_chain_run_leaves": (i32, [vp, vp, vp, vp, vp]),
+        "b3w_chain_run_parents": (i32, [vp, vp, vp, vp, vp]),
+        "b3w_chain_info": (i32, [vp, ctypes.POINTER(u64), ctypes.POINTER(u64), ctypes.POINTER(u64), ctypes.POINTER(u32), ctypes.POINTER(i32)]),
+        "b3w_chain_records": (vp, [vp]),
+        "b3w_chain_public": (vp, [vp]),
+        "b3w_chain_status": (vp, [vp]),
+        "b3w_chain_local_cvs": (vp, [vp]),
+        "b3w_chain_root": (vp, [vp]),
     }
     for name, (res, args) in sig.items():
         fn = getattr(L, name)
@@ -109,8 +120,10 @@ EXPORTED_SYMBOLS = ("b3w_abi_version", "b3w_identify_wasm", "b3w_create", "b3w_d
                     "b3w_input_signal_size", "b3w_calc_witness", "b3w_write_wtns_header", "b3w_last_error",
                     "b3w_batch_run_device", "b3w_public_words", "b3w_batch_alloc", "b3w_batch_free",
                     "b3w_batch_run", "b3w_batch_outputs", "b3w_batch_fetch", "b3w_batch_device_ptr",
-                    "b3w_batch_time_device", "b3w_batch_verify_device", "b3w_batch_verify", "b3w_batch_write_wtns", "b3w_batch_autotune_device", "b3w_bodies_alloc", "b3w_bodies_free", "b3w_batch_placement", "b3w_chain_num_chunks", "b3w_chain_num_leaf_steps", "b3w_chain_path_len",
-                    "b3w_chain_plan_leaves_device", "b3w_chain_tree_device", "b3w_chain_plan_parents_device")
+                    "b3w_batch_time_device", "b3w_batch_verify_device", "b3w_batch_verify", "b3w_batch_write_wtns", "b3w_batch_autotune_device", "b3w_bodies_alloc", "b3w_bodies_free", "b3w_bodies_trim", "b3w_batch_placement", "b3w_chain_num_chunks", "b3w_chain_num_leaf_steps", "b3w_chain_path_len",
+                    "b3w_chain_plan_leaves_device", "b3w_chain_tree_device", "b3w_chain_plan_parents_device",
+                    "b3w_chain_create", "b3w_chain_destroy", "b3w_chain_run_leaves", "b3w_chain_run_parents", "b3w_chain_info",
+                    "b3w_chain_records", "b3w_chain_public", "b3w_chain_status", "b3w_chain_local_cvs", "b3w_chain_root")
 
 
 def fnv_hash(name):
@@ -166,6 +179,8 @@ class Context:
 
     def close(self):
         if getattr(self, "handle", None):
+            for h in self.__dict__.pop("_chain_cache", {}).values():     # chain.fold_witnesses' native objects
+                self._lib.b3w_chain_destroy(h)
             self._lib.b3w_destroy(self.handle)
             self.handle = None
 

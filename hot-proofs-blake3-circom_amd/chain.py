@@ -15,6 +15,8 @@ Pipeline per GPU (one process per GPU; ranks take contiguous chunk ranges, SURVE
                    the upper tree levels redundantly; the per-step public outputs stay per rank
                    unless the caller gathers them (sharding.gather_public)
 """
+import ctypes
+
 import numpy as np
 import torch
 import torch.distributed as dist
@@ -28,87 +30,73 @@ def _chk(ctx, rc, what):
         raise B3WError(rc, f"{what}: status {rc}: {ctx.last_error()}")
 
 
+class _DevArray:
+    """zero-copy torch view of library-owned device memory (lives as long as the b3w_chain object)"""
+
+    def __init__(self, ptr, shape, typestr):
+        self.__cuda_array_interface__ = {"shape": tuple(shape), "typestr": typestr, "data": (ptr, False), "version": 2,
+                                         "strides": None}
+
+
+def _view(ptr, shape, typestr, dev):
+    return torch.as_tensor(_DevArray(ptr, shape, typestr), device=dev)
+
+
+_CONSUMER = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint32,
+                             ctypes.c_void_p)
+
+
 def fold_witnesses(ctx, preimage, batch_steps=16384, ring=2, slice_chunks=1024, with_parents=True, consumer=None,
                    device=None):
     """preimage: 1-D uint8 numpy array / torch CPU tensor (the whole preimage; every rank passes the same).
     consumer(bodies_view [k, body_bytes] uint8 CUDA, first_local_step, k): called after each batch is enqueued;
     it must enqueue its work on the current stream (the view is overwritten `ring` batches later).
     Returns dict(public=[n_local_steps, 15] int32 CUDA, status=[n_local_steps] int32 CUDA, root=[8] int32,
-    n_leaf_steps, n_parent_steps, first_chunk, n_chunks_local, n_chunks)."""
+    n_leaf_steps, n_parent_steps, first_chunk, n_chunks_local, n_chunks).  The device arrays belong to a b3w_chain
+    object cached on `ctx` and are overwritten by the next fold of the same shape.
+
+    The pass itself is the library's native driver (b3w_chain_run_leaves / b3w_chain_run_parents, include/b3wit.h);
+    this function adds the one thing that needs the process group: the all-gather of the chunk chaining values."""
     L = lib()
     world = dist.get_world_size() if dist.is_initialized() else 1
     rank = dist.get_rank() if dist.is_initialized() else 0
     dev = device or torch.device("cuda", torch.cuda.current_device())
     host = torch.from_numpy(preimage) if isinstance(preimage, np.ndarray) else preimage
-    assert host.dtype == torch.uint8 and host.dim() == 1 and host.numel() > 0
+    assert host.dtype == torch.uint8 and host.dim() == 1 and host.numel() > 0 and host.is_contiguous()
     ln = host.numel()
     n = L.b3w_chain_num_chunks(ln)
     c0, c1 = shard_range(n, rank, world)
     nl = c1 - c0
-    P = L.b3w_chain_path_len(0, n)
-    complete = (n & (n - 1)) == 0
-    last_blocks = (max(ln - (n - 1) * 1024, 1) + 63) // 64
-    has_last = c1 == n
-    n_leaf = nl * 16 - ((16 - last_blocks) if has_last else 0)
-    n_par = nl * P if (with_parents and complete) else 0
     body = ctx.body_bytes
 
-    pinned = host if host.is_pinned() else None
-    d_pre = torch.empty(max(nl, 1) * 1024, dtype=torch.uint8, device=dev)
-    recs = torch.zeros((nl * 16 + n_par, 32), dtype=torch.int32, device=dev)
-    cvs_local = torch.zeros((max(nl, 1), 8), dtype=torch.int32, device=dev)
-    pub = torch.zeros((nl * 16 + n_par, 15), dtype=torch.int32, device=dev)
-    status = torch.zeros((nl * 16 + n_par,), dtype=torch.int32, device=dev)
-    # the ring of batch buffers: placed over two classes of HBM (b3w_bodies_alloc), allocated once per context
-    cache = ctx.__dict__.setdefault("_ring_cache", {})
-    key = (batch_steps, ring, dev.index)
+    cache = ctx.__dict__.setdefault("_chain_cache", {})
+    key = (ln, c0, nl, batch_steps, ring, bool(with_parents))
     if key not in cache:
-        for bufs in cache.values():
-            for b in bufs:
-                b.free()
+        for h in cache.values():
+            L.b3w_chain_destroy(h)
         cache.clear()
-        cache[key] = [ctx.alloc_bodies(batch_steps * body) for _ in range(ring)]
-    bodies = [b.tensor()[: batch_steps * body].view(batch_steps, body) for b in cache[key]]
+        h = ctypes.c_void_p()
+        _chk(ctx, L.b3w_chain_create(ctx.handle, ln, c0, nl, batch_steps, ring, 1 if with_parents else 0, ctypes.byref(h)),
+             "b3w_chain_create")
+        cache[key] = h
+    h = cache[key]
+    nleaf, npar, nch, P, pl = ctypes.c_uint64(), ctypes.c_uint64(), ctypes.c_uint64(), ctypes.c_uint32(), ctypes.c_int32()
+    L.b3w_chain_info(h, ctypes.byref(nleaf), ctypes.byref(npar), ctypes.byref(nch), ctypes.byref(P), ctypes.byref(pl))
+    n_leaf, n_par = nleaf.value, npar.value
     compute = torch.cuda.current_stream(dev)
-    copy = torch.cuda.Stream(dev)
-    nbatch = 0
+    nbatch = [0]
+    cb = _CONSUMER()
+    if consumer is not None:
+        def _cb(user, d_bodies, pitch, first_step, count, stream):
+            nbatch[0] += 1
+            consumer(_view(d_bodies, (count, body), "|u1", dev), first_step, count)
+        cb = _CONSUMER(_cb)
+    _chk(ctx, L.b3w_chain_run_leaves(h, host.data_ptr(), cb, None, compute.cuda_stream), "b3w_chain_run_leaves")
 
-    def run_steps(first_row, count, first_step):
-        """witness kernel over record rows [first_row, first_row+count), in ring-buffered batches"""
-        nonlocal nbatch
-        done = 0
-        while done < count:
-            k = min(batch_steps, count - done)
-            slot = nbatch % ring
-            r0 = first_row + done
-            ctx.run_device(recs[r0:].data_ptr(), k, bodies[slot].data_ptr(), 0, pub[r0:].data_ptr(), status[r0:].data_ptr(),
-                           compute.cuda_stream)
-            if consumer is not None:
-                consumer(bodies[slot][:k], first_step + done, k)
-            nbatch += 1
-            done += k
-
-    # ---- leaf steps, slice by slice, H2D overlapped with planning + witness kernels of earlier slices
-    lo = c0 * 1024
-    for s0 in range(0, nl, slice_chunks):
-        sc = min(slice_chunks, nl - s0)
-        b0, b1 = lo + s0 * 1024, min(lo + (s0 + sc) * 1024, ln)
-        ev = torch.cuda.Event()
-        with torch.cuda.stream(copy):
-            src = (pinned if pinned is not None else host)[b0:b1]
-            d_pre[s0 * 1024: s0 * 1024 + (b1 - b0)].copy_(src, non_blocking=pinned is not None)
-            ev.record(copy)
-        compute.wait_event(ev)
-        _chk(ctx, L.b3w_chain_plan_leaves_device(ctx.handle, d_pre[s0 * 1024:].data_ptr(), ln, c0 + s0, sc,
-                                                 recs[s0 * 16:].data_ptr(), cvs_local[s0:].data_ptr(), compute.cuda_stream),
-             "plan_leaves")
-        steps_here = sc * 16 - ((16 - last_blocks) if (has_last and s0 + sc == nl) else 0)
-        run_steps(s0 * 16, steps_here, s0 * 16)
-
-    # ---- exchange: chunk chaining values of all ranks -> level 0 of the tree (32 B per chunk)
-    levels = torch.zeros(((2 * n + 64) * 8,), dtype=torch.int32, device=dev)
-    root = torch.zeros(8, dtype=torch.int32, device=dev)
+    # ---- exchange: chunk chaining values of all ranks (32 B per chunk)
+    all_cvs = None
     if world > 1:
+        cvs_local = _view(L.b3w_chain_local_cvs(h), (max(nl, 1), 8), "<i4", dev)
         sizes = [shard_range(n, r, world) for r in range(world)]
         mx = max(e - s for s, e in sizes)
         pad = torch.zeros((mx, 8), dtype=torch.int32, device=dev)
@@ -120,22 +108,13 @@ def fold_witnesses(ctx, preimage, batch_steps=16384, ring=2, slice_chunks=1024, 
         else:                                         # RCCL over xGMI
             allcv = torch.empty((world * mx, 8), dtype=torch.int32, device=dev)
             dist.all_gather_into_tensor(allcv, pad)
-        for r, (s, e) in enumerate(sizes):
-            levels[s * 8: e * 8] = allcv[r * mx: r * mx + (e - s)].reshape(-1)
-    else:
-        levels[: n * 8] = cvs_local[:n].reshape(-1)
-    _chk(ctx, L.b3w_chain_tree_device(ctx.handle, levels.data_ptr(), n, root.data_ptr(), compute.cuda_stream), "tree")
+        all_cvs = torch.cat([allcv[r * mx: r * mx + (e - s)] for r, (s, e) in enumerate(sizes)], dim=0).contiguous()
+    _chk(ctx, L.b3w_chain_run_parents(h, all_cvs.data_ptr() if all_cvs is not None else None, cb, None, compute.cuda_stream),
+         "b3w_chain_run_parents")
 
-    # ---- parent steps of the local chunks (complete trees)
-    if n_par:
-        _chk(ctx, L.b3w_chain_plan_parents_device(ctx.handle, levels.data_ptr(), n, ln, c0, nl, recs[nl * 16:].data_ptr(),
-                                                  compute.cuda_stream), "plan_parents")
-        run_steps(nl * 16, n_par, n_leaf)
-
-    # rows of a partial last chunk that hold no step are dropped from the returned views
-    if has_last and last_blocks < 16:
-        keep = torch.ones(recs.shape[0], dtype=torch.bool, device=dev)
-        keep[(nl - 1) * 16 + last_blocks: nl * 16] = False
-        recs, pub, status = recs[keep], pub[keep], status[keep]
-    return dict(public=pub, status=status, records=recs, root=root, n_leaf_steps=n_leaf, n_parent_steps=n_par,
-                first_chunk=c0, n_chunks_local=nl, n_chunks=n, path_len=P, batches=nbatch)
+    rows = n_leaf + n_par
+    return dict(public=_view(L.b3w_chain_public(h), (rows, 15), "<i4", dev), status=_view(L.b3w_chain_status(h), (rows,), "<i4", dev),
+                records=_view(L.b3w_chain_records(h), (rows, 32), "<i4", dev), root=_view(L.b3w_chain_root(h), (8,), "<i4", dev),
+                n_leaf_steps=n_leaf, n_parent_steps=n_par, first_chunk=c0, n_chunks_local=nl, n_chunks=n, path_len=P.value,
+                batches=-(-n_leaf // batch_steps) + -(-n_par // batch_steps) if consumer is None else nbatch[0],
+                placement="mixed" if pl.value == 1 else "plain")

@@ -6,6 +6,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <algorithm>
 #include <string>
 #include <vector>
 
@@ -648,6 +649,8 @@ int32_t b3w_bodies_free(b3w_ctx *ctx, void *d_ptr) {
   return e == hipSuccess ? B3W_OK : hip_fail(ctx, e, "hipFree(bodies)");
 }
 
+void b3w_bodies_trim(void) { b3w_place_trim(); }
+
 int32_t b3w_batch_placement(const b3w_batch *b) { return b ? b->placement : B3W_PLACEMENT_PLAIN; }
 
 int32_t b3w_batch_alloc(b3w_ctx *ctx, uint32_t capacity, uint64_t pitch, b3w_batch **out) {
@@ -848,5 +851,165 @@ int32_t b3w_chain_plan_parents_device(b3w_ctx *ctx, const uint32_t *d_levels, ui
   int rc = b3w_launch_plan_parents(d_levels, n_chunks, P, first_chunk, n_chunks_local, last_blocks, d_records, (hipStream_t)stream);
   return rc ? hip_fail(ctx, (hipError_t)rc, "plan parents launch") : B3W_OK;
 }
+
+// ---------------------------------------------------------------- chained mode: native driver
+}  // extern "C"
+
+struct b3w_chain {
+  b3w_ctx *ctx = nullptr;
+  uint64_t len = 0, n_chunks = 0, first_chunk = 0, n_leaf = 0, n_par = 0, nbatch = 0;
+  uint32_t nl = 0, P = 0, last_blocks = 16, batch_steps = 0, ring = 0;
+  bool has_last = false, complete = false;
+  int32_t placement = B3W_PLACEMENT_PLAIN;
+  uint8_t *d_pre = nullptr;
+  uint32_t *d_recs = nullptr, *d_cvs = nullptr, *d_pub = nullptr, *d_levels = nullptr, *d_root = nullptr;
+  int32_t *d_status = nullptr;
+  std::vector<void *> bodies;
+  hipStream_t copy = nullptr;
+  hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+};
+
+namespace {
+constexpr uint32_t CHAIN_SLICE_CHUNKS = 1024;       // 1 MiB of preimage per H2D slice = 16 384 leaf steps
+
+int32_t chain_run_steps(b3w_chain *c, uint64_t first_row, uint64_t count, b3w_batch_consumer consumer, void *user, void *stream) {
+  const uint64_t body = 32ull * c->ctx->desc.nwit;
+  for (uint64_t done = 0; done < count;) {
+    const uint32_t k = (uint32_t)std::min<uint64_t>(c->batch_steps, count - done);
+    uint8_t *slot = static_cast<uint8_t *>(c->bodies[c->nbatch % c->ring]);
+    const uint64_t r0 = first_row + done;
+    int32_t rc = b3w_batch_run_device(c->ctx, c->d_recs + r0 * 32, k, slot, body, c->d_pub + r0 * 15, c->d_status + r0, stream);
+    if (rc) return rc;
+    if (consumer) consumer(user, slot, body, r0, k, stream);
+    c->nbatch++;
+    done += k;
+  }
+  return B3W_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int32_t b3w_chain_create(b3w_ctx *ctx, uint64_t preimage_len, uint64_t first_chunk, uint32_t n_chunks_local, uint32_t batch_steps,
+                         uint32_t ring, int32_t with_parents, b3w_chain **out) {
+  if (!ctx || !out || !batch_steps || !ring) return B3W_E_BAD_ARGUMENT;
+  *out = nullptr;
+  if (ctx->desc.kind == B3W_KIND_COMP) { ctx->last_error = "chained mode runs the nova step circuits"; return B3W_E_BAD_ARGUMENT; }
+  const uint64_t n = b3w_chain_num_chunks(preimage_len);
+  if (first_chunk + n_chunks_local > n) { ctx->last_error = "chunk range exceeds the preimage"; return B3W_E_BAD_ARGUMENT; }
+  b3w_chain *c = new b3w_chain;
+  c->ctx = ctx; c->len = preimage_len; c->n_chunks = n; c->first_chunk = first_chunk; c->nl = n_chunks_local;
+  c->batch_steps = batch_steps; c->ring = ring;
+  c->P = b3w_plan_path_len(0, n);
+  c->complete = (n & (n - 1)) == 0;
+  const uint64_t last_bytes = preimage_len > (n - 1) * 1024 ? preimage_len - (n - 1) * 1024 : 0;
+  c->last_blocks = last_bytes ? (uint32_t)((last_bytes + 63) / 64) : 1;
+  c->has_last = first_chunk + n_chunks_local == n;
+  c->n_leaf = (uint64_t)n_chunks_local * 16 - ((c->has_last && n_chunks_local) ? 16 - c->last_blocks : 0);
+  c->n_par = (with_parents && c->complete) ? (uint64_t)n_chunks_local * c->P : 0;
+  const uint64_t rows = (uint64_t)n_chunks_local * 16 + c->n_par + 1;
+  const uint64_t body = 32ull * ctx->desc.nwit;
+  hipError_t e = hipSetDevice(ctx->device);
+  if (e == hipSuccess) e = hipMalloc((void **)&c->d_pre, std::max<uint64_t>(n_chunks_local, 1) * 1024);
+  if (e == hipSuccess) e = hipMalloc((void **)&c->d_recs, rows * 32 * 4);
+  if (e == hipSuccess) e = hipMalloc((void **)&c->d_cvs, std::max<uint64_t>(n_chunks_local, 1) * 8 * 4);
+  if (e == hipSuccess) e = hipMalloc((void **)&c->d_pub, rows * 15 * 4);
+  if (e == hipSuccess) e = hipMalloc((void **)&c->d_status, rows * 4);
+  if (e == hipSuccess) e = hipMalloc((void **)&c->d_levels, (2 * n + 64) * 8 * 4);
+  if (e == hipSuccess) e = hipMalloc((void **)&c->d_root, 8 * 4);
+  if (e == hipSuccess) e = hipMemset(c->d_status, 0, rows * 4);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->copy, hipStreamNonBlocking);
+  for (int i = 0; i < 4 && e == hipSuccess; i++) e = hipEventCreateWithFlags(&c->ev[i], hipEventDisableTiming);
+  if (e != hipSuccess) { b3w_chain_destroy(c); return e == hipErrorOutOfMemory ? B3W_E_NOT_ENOUGH_MEMORY : hip_fail(ctx, e, "chain buffers"); }
+  c->placement = B3W_PLACEMENT_MIXED;
+  for (uint32_t i = 0; i < ring; i++) {
+    void *p = nullptr;
+    int32_t pl = B3W_PLACEMENT_PLAIN;
+    const int32_t rc = b3w_bodies_alloc(ctx, (uint64_t)batch_steps * body, &p, &pl);
+    if (rc) { b3w_chain_destroy(c); return rc; }
+    c->bodies.push_back(p);
+    if (pl != B3W_PLACEMENT_MIXED) c->placement = B3W_PLACEMENT_PLAIN;
+  }
+  *out = c;
+  return B3W_OK;
+}
+
+void b3w_chain_destroy(b3w_chain *c) {
+  if (!c) return;
+  (void)hipSetDevice(c->ctx->device);
+  (void)hipDeviceSynchronize();
+  for (void *p : c->bodies) (void)b3w_bodies_free(c->ctx, p);
+  if (c->d_pre) (void)hipFree(c->d_pre);
+  if (c->d_recs) (void)hipFree(c->d_recs);
+  if (c->d_cvs) (void)hipFree(c->d_cvs);
+  if (c->d_pub) (void)hipFree(c->d_pub);
+  if (c->d_status) (void)hipFree(c->d_status);
+  if (c->d_levels) (void)hipFree(c->d_levels);
+  if (c->d_root) (void)hipFree(c->d_root);
+  if (c->copy) (void)hipStreamDestroy(c->copy);
+  for (int i = 0; i < 4; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
+  delete c;
+}
+
+int32_t b3w_chain_run_leaves(b3w_chain *c, const uint8_t *host_preimage, b3w_batch_consumer consumer, void *user, void *stream) {
+  if (!c || !host_preimage) return B3W_E_BAD_ARGUMENT;
+  b3w_ctx *ctx = c->ctx;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = (hipStream_t)stream;
+  // the copy stream must not run ahead of work still reading d_pre from an earlier pass on `stream`
+  HIP_TRY(ctx, hipEventRecord(c->ev[3], st));
+  HIP_TRY(ctx, hipStreamWaitEvent(c->copy, c->ev[3], 0));
+  uint32_t slice = 0;
+  static const uint32_t SLICE = getenv("B3W_CHAIN_SLICE_CHUNKS") ? (uint32_t)atoi(getenv("B3W_CHAIN_SLICE_CHUNKS")) : CHAIN_SLICE_CHUNKS;
+  for (uint32_t s0 = 0; s0 < c->nl; s0 += SLICE, slice++) {
+    const uint32_t sc = std::min<uint32_t>(SLICE, c->nl - s0);
+    const uint64_t b0 = (c->first_chunk + s0) * 1024, b1 = std::min<uint64_t>(b0 + (uint64_t)sc * 1024, c->len);
+    hipEvent_t ev = c->ev[slice % 3];
+    if (b1 > b0) HIP_TRY(ctx, hipMemcpyAsync(c->d_pre + (uint64_t)s0 * 1024, host_preimage + b0, b1 - b0, hipMemcpyHostToDevice, c->copy));
+    HIP_TRY(ctx, hipEventRecord(ev, c->copy));
+    HIP_TRY(ctx, hipStreamWaitEvent(st, ev, 0));
+    int32_t rc = b3w_chain_plan_leaves_device(ctx, c->d_pre + (uint64_t)s0 * 1024, c->len, c->first_chunk + s0, sc,
+                                              c->d_recs + (uint64_t)s0 * 16 * 32, c->d_cvs + (uint64_t)s0 * 8, stream);
+    if (rc) return rc;
+    const uint64_t steps_here = (uint64_t)sc * 16 - ((c->has_last && s0 + sc == c->nl) ? 16 - c->last_blocks : 0);
+    rc = chain_run_steps(c, (uint64_t)s0 * 16, steps_here, consumer, user, stream);
+    if (rc) return rc;
+  }
+  return B3W_OK;
+}
+
+int32_t b3w_chain_run_parents(b3w_chain *c, const uint32_t *d_all_chunk_cvs, b3w_batch_consumer consumer, void *user, void *stream) {
+  if (!c) return B3W_E_BAD_ARGUMENT;
+  b3w_ctx *ctx = c->ctx;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = (hipStream_t)stream;
+  if (!d_all_chunk_cvs) {
+    if (c->nl != c->n_chunks) { ctx->last_error = "a chunk sub-range needs the chunk CVs of all ranks"; return B3W_E_BAD_ARGUMENT; }
+    d_all_chunk_cvs = c->d_cvs;
+  }
+  HIP_TRY(ctx, hipMemcpyAsync(c->d_levels, d_all_chunk_cvs, c->n_chunks * 32, hipMemcpyDeviceToDevice, st));
+  int32_t rc = b3w_chain_tree_device(ctx, c->d_levels, c->n_chunks, c->d_root, stream);
+  if (rc) return rc;
+  if (!c->n_par) return B3W_OK;
+  rc = b3w_chain_plan_parents_device(ctx, c->d_levels, c->n_chunks, c->len, c->first_chunk, c->nl, c->d_recs + c->n_leaf * 32, stream);
+  if (rc) return rc;
+  return chain_run_steps(c, c->n_leaf, c->n_par, consumer, user, stream);
+}
+
+int32_t b3w_chain_info(const b3w_chain *c, uint64_t *n_leaf_steps, uint64_t *n_parent_steps, uint64_t *n_chunks, uint32_t *path_len,
+                       int32_t *placement) {
+  if (!c) return B3W_E_BAD_ARGUMENT;
+  if (n_leaf_steps) *n_leaf_steps = c->n_leaf;
+  if (n_parent_steps) *n_parent_steps = c->n_par;
+  if (n_chunks) *n_chunks = c->n_chunks;
+  if (path_len) *path_len = c->P;
+  if (placement) *placement = c->placement;
+  return B3W_OK;
+}
+uint32_t *b3w_chain_records(b3w_chain *c) { return c ? c->d_recs : nullptr; }
+uint32_t *b3w_chain_public(b3w_chain *c) { return c ? c->d_pub : nullptr; }
+int32_t *b3w_chain_status(b3w_chain *c) { return c ? c->d_status : nullptr; }
+uint32_t *b3w_chain_local_cvs(b3w_chain *c) { return c ? c->d_cvs : nullptr; }
+uint32_t *b3w_chain_root(b3w_chain *c) { return c ? c->d_root : nullptr; }
 
 }  // extern "C"

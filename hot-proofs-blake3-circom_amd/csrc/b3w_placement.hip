@@ -1,22 +1,43 @@
 // b3w_placement.hip — where witness bodies live in HBM.
 //
-// Measured on MI355X (tools/ubench/placement_map*.hip, vmm_classes.hip, profiles/r01/placement/): the 288 GB of
-// HBM3E fall into three "classes" of physical memory (about 96 GB each, in physical segments of 8-64 GiB;
-// presumably the three ranks of the 12-high stacks).  A store pattern made of thousands of independent streams —
-// one witness body per stream, what the witness kernels emit — runs at about 5.4 TB/s while all streams land in
-// ONE class and at about 7.0 TB/s when they are split over two; a plain hipMalloc buffer almost always sits in one.
+// Measured on MI355X (tools/ubench/placement_map*.hip, vmm_classes.hip, pair_matrix.hip; logs under
+// profiles/r01/placement/): the 288 GB of HBM3E fall into three "classes" of physical memory (about 96 GB each, in
+// physical segments of 8-64 GiB; presumably the three ranks of the 12-high stacks).  A store pattern made of
+// thousands of independent streams — one witness body per stream, what the witness kernels emit — runs at about
+// 5.4 TB/s while all streams land in ONE class and at about 7.0 TB/s when they are split over two; a plain
+// hipMalloc buffer almost always sits in one.  "Slow together" is an equivalence relation on fresh memory
+// (pair_matrix.log: clean blocks).
 //
-// b3w_place_alloc therefore builds the body buffer with the HIP virtual-memory API: physical handles of
-// B3W_PLACE_HANDLE bytes are created one after the other (the driver hands out physical memory linearly), each is
-// classified by timing a short split-store probe against the first handle ("same class" = slow, "other class" =
-// fast), until both groups can cover half the buffer; the two groups are then mapped ALTERNATELY into one
-// contiguous virtual range and every other handle is released.  Bodies written in natural order then always
-// straddle both classes; nothing changes for the kernels or for consumers of the buffer (one linear device
-// range).  When no second class shows up (other hardware, memory nearly full) the buffer is simply the first
-// handles in creation order — correct, only slower — and the placement is reported as "plain".
+// Physical memory cannot be chosen through HIP, but it can be classified.  Per device this file keeps a small
+// POOL of 256 MiB physical handles (HIP virtual-memory API) with a label each:
+//   * two reference handles stay allocated and mapped for the life of the process: h0 = the first handle ever
+//     created, f0 = the first later handle that a timed split-store probe shows to be FAST together with h0;
+//   * every other handle is probed against both (0.3 ms each): slow with h0 / fast with f0 -> label A (h0's class),
+//     fast / slow -> B (f0's class), fast / fast -> C (the third class), slow / slow -> M ("mixed": the driver
+//     assembled the handle from fragments of two classes, which happens once memory has been freed and reused;
+//     such handles are not used and are given back at the end of the search).
+// b3w_place_alloc takes labelled handles from the pool (creating and labelling new ones while it lacks them — the
+// driver hands out fresh memory linearly, so a search walks 15-30 GiB on average until both sides are covered),
+// maps them ALTERNATELY (A or C, then B or C, ...) into one contiguous virtual range, checks every seam of that
+// order with the same probe and repairs slow seams from the spare handles.  Bodies written in natural order then
+// always straddle two classes; nothing changes for the kernels or for consumers of the buffer (one linear device
+// range).  Handles left over from a search and the handles of a freed buffer go back to the pool (at most 12 GiB per label), so a
+// second buffer continues on the same clean, already labelled memory instead of on recycled fragments.
+// When no second class shows up (other hardware, memory nearly full) the buffer is simply handles in creation order
+// — correct, only slower — and the placement is reported as "plain".
+//
+// VIRTUAL ADDRESSES ARE NEVER REUSED.  On this ROCm stack a virtual address that has been unmapped and is mapped to
+// another physical handle keeps serving the OLD pages (tools/ubench/vmm_remap.hip: writes through the new mapping
+// land in the previous handle, also after hipDeviceSynchronize and after hipMemAddressFree + a new reservation that
+// returns the same range).  So each device gets one 32 TiB reservation (instant, costs nothing) from which every
+// mapping takes the next free 256 MiB slots; nothing in it is ever mapped twice and it is never freed.  A handle is
+// mapped once for probing when it is created and stays there until it is released (a second, simultaneous mapping
+// in a buffer is fine).  A buffer of B bytes therefore uses up B bytes of address space for good: thousands of
+// 12 GB buffers per process; when the range is used up allocations fall back to plain hipMalloc.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <stdio.h>
 #include <math.h>
 #include <vector>
 #include <algorithm>
@@ -28,7 +49,7 @@ namespace {
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 
-// probe: stream i writes `bytes` consecutive bytes, even streams from lo, odd ones from hi, one wave per stream
+// probe: stream i writes PROBE_PITCH consecutive bytes, even streams from lo, odd ones from hi, one wave per stream
 __global__ __launch_bounds__(64) void b3w_store_probe_kernel(uint8_t *lo, uint8_t *hi, uint64_t pitch, uint32_t groups) {
   const uint32_t i = blockIdx.x, lane = threadIdx.x;
   const u32x4 v = {0, 0, 0, 0};
@@ -40,29 +61,155 @@ constexpr uint64_t MiB = 1ull << 20, GiB = 1ull << 30;
 constexpr uint64_t HANDLE = 256 * MiB;             // physical granule of a placed buffer
 constexpr uint32_t PROBE_STREAMS = 512;            // 256 per side
 constexpr uint64_t PROBE_PITCH = 768 * 1024;       // 256 streams x 768 KiB = 192 MiB <= HANDLE
-constexpr double CONTRAST = 1.12;                  // fast / slow ratio that counts as "another class"
+constexpr double CONTRAST = 1.18;                  // fast / slow ratio that counts as "another class" (measured: 1.25-1.3)
+constexpr uint64_t POOL_CAP_PER_LABEL = 12 * GiB;  // labelled handles kept for later buffers, per label (A, B, C)
+constexpr uint64_t ARENA = 32ull << 40;            // virtual address range per device, bump-allocated, never reused
+
+enum : uint8_t { LA = 0, LB = 1, LC = 2, LM = 3 };
+
+struct Cand { hipMemGenericAllocationHandle_t h; uint8_t label; uint32_t slot; };   // slot: its own probe mapping in the arena
 
 struct Placed {
   void *va = nullptr;
   size_t va_bytes = 0;
-  std::vector<hipMemGenericAllocationHandle_t> handles;   // in VA order
+  std::vector<Cand> pieces;                         // in VA order
+  int device = 0;
   int mixed = 0;
 };
 
-std::vector<Placed *> &registry() { static std::vector<Placed *> r; return r; }
-std::mutex &registry_mutex() { static std::mutex m; return m; }
+struct Pool {
+  int device = -1;
+  bool refs = false;                                // h0 and f0 exist, thr is calibrated
+  bool hopeless = false;                            // a full search found no second class: do not walk again
+  hipMemGenericAllocationHandle_t h0{}, f0{};
+  double thr = 0, lo = 0, hi = 0;
+  uint8_t *arena = nullptr;                         // ARENA bytes of VA
+  uint32_t next_slot = 0;                           // next never-used 256 MiB slot of it
+  uint32_t slot_h0 = 0, slot_f0 = 0;
+  std::vector<Cand> spare;                          // labelled, each still mapped in its probe slot
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  hipMemAllocationProp prop{};
+  hipMemAccessDesc acc{};
+};
 
-double probe_rate(uint8_t *a, uint8_t *b, hipEvent_t e0, hipEvent_t e1) {
+std::mutex &mtx() { static std::mutex m; return m; }
+std::vector<Pool *> &pools() { static std::vector<Pool *> p; return p; }
+std::vector<Placed *> &registry() { static std::vector<Placed *> r; return r; }
+
+Pool *pool_for(int device) {
+  for (Pool *p : pools()) if (p->device == device) return p;
+  Pool *p = new Pool;
+  p->device = device;
+  p->prop.type = hipMemAllocationTypePinned;
+  p->prop.location.type = hipMemLocationTypeDevice;
+  p->prop.location.id = device;
+  p->acc.location = p->prop.location;
+  p->acc.flags = hipMemAccessFlagsProtReadWrite;
+  void *va = nullptr;
+  if (hipMemAddressReserve(&va, ARENA, 2 * MiB, nullptr, 0) != hipSuccess) { (void)hipGetLastError(); delete p; return nullptr; }
+  p->arena = static_cast<uint8_t *>(va);
+  (void)hipEventCreate(&p->e0);
+  (void)hipEventCreate(&p->e1);
+  pools().push_back(p);
+  return p;
+}
+
+// a failure in here only ends a search; the sticky HIP error must not leak into the caller's next launch check
+bool create_handle(Pool *p, hipMemGenericAllocationHandle_t *h) {
+  if (hipMemCreate(h, HANDLE, &p->prop, 0) == hipSuccess) return true;
+  (void)hipGetLastError();
+  return false;
+}
+uint8_t *slot_addr(Pool *p, uint32_t slot) { return p->arena + (size_t)slot * HANDLE; }
+uint32_t slots_left(Pool *p) { return (uint32_t)(ARENA / HANDLE) - p->next_slot; }
+// map a handle at the next never-used slot; false when the arena is used up or the driver refuses
+bool map_new(Pool *p, Cand &c) {
+  if (!slots_left(p)) return false;
+  uint8_t *a = slot_addr(p, p->next_slot);
+  if (hipMemMap(a, HANDLE, 0, c.h, 0) != hipSuccess) { (void)hipGetLastError(); return false; }
+  c.slot = p->next_slot++;                           // used up whatever happens next
+  if (hipMemSetAccess(a, HANDLE, &p->acc, 1) != hipSuccess) { (void)hipMemUnmap(a, HANDLE); (void)hipGetLastError(); return false; }
+  return true;
+}
+void release(Pool *p, Cand &c) {
+  (void)hipMemUnmap(slot_addr(p, c.slot), HANDLE);
+  (void)hipMemRelease(c.h);
+}
+
+double probe_slots(Pool *p, uint32_t sa, uint32_t sb, int reps = 3) {
+  uint8_t *a = slot_addr(p, sa), *b = slot_addr(p, sb);
   const uint32_t groups = (uint32_t)(PROBE_PITCH / 1024);
   hipLaunchKernelGGL(b3w_store_probe_kernel, dim3(PROBE_STREAMS), dim3(64), 0, 0, a, b, PROBE_PITCH, groups);
-  (void)hipEventRecord(e0, 0);
-  for (int i = 0; i < 3; i++)
+  (void)hipEventRecord(p->e0, 0);
+  for (int i = 0; i < reps; i++)
     hipLaunchKernelGGL(b3w_store_probe_kernel, dim3(PROBE_STREAMS), dim3(64), 0, 0, a, b, PROBE_PITCH, groups);
-  (void)hipEventRecord(e1, 0);
-  if (hipEventSynchronize(e1) != hipSuccess) return 0;
+  (void)hipEventRecord(p->e1, 0);
+  if (hipEventSynchronize(p->e1) != hipSuccess) { (void)hipGetLastError(); return 0; }
   float ms = 0;
-  (void)hipEventElapsedTime(&ms, e0, e1);
-  return ms > 0 ? 3.0 * PROBE_STREAMS * PROBE_PITCH / 1e6 / ms : 0;       // GB/s
+  (void)hipEventElapsedTime(&ms, p->e0, p->e1);
+  return ms > 0 ? (double)reps * PROBE_STREAMS * PROBE_PITCH / 1e6 / ms : 0;       // GB/s
+}
+
+// label of the handle mapped in `slot` against the two references
+uint8_t label_slot(Pool *p, uint32_t slot) {
+  const bool slow0 = probe_slots(p, p->slot_h0, slot) < p->thr, slow1 = probe_slots(p, p->slot_f0, slot) < p->thr;
+  return slow0 && !slow1 ? LA : !slow0 && slow1 ? LB : !slow0 && !slow1 ? LC : LM;
+}
+
+// First use on a device: walk fresh handles until one is clearly fast with h0 and the next one agrees; fix the
+// references and the threshold.  Handles seen on the way are labelled and returned in `got`.  `budget` = handles
+// this search may still create.
+bool calibrate(Pool *p, uint32_t &budget, std::vector<Cand> &got) {
+  Cand r{};
+  if (!budget || !create_handle(p, &r.h)) return false;
+  budget--;
+  if (!map_new(p, r)) { (void)hipMemRelease(r.h); return false; }
+  for (int i = 0; i < 6; i++) (void)probe_slots(p, r.slot, r.slot, 4);             // clocks up before anything is timed
+  std::vector<Cand> seen;
+  std::vector<double> r0;
+  int cand = -1;
+  while (budget) {
+    Cand c{};
+    if (!create_handle(p, &c.h)) break;
+    budget--;
+    if (!map_new(p, c)) { (void)hipMemRelease(c.h); break; }
+    seen.push_back(c);
+    r0.push_back(probe_slots(p, r.slot, c.slot));
+    double lo = r0[0], hi = r0[0];
+    for (double x : r0) { lo = std::min(lo, x); hi = std::max(hi, x); }
+    if (lo > 0 && hi >= CONTRAST * lo) {
+      const double thr = sqrt(lo * hi);
+      // two consecutive fast handles: not a timing outlier
+      const size_t n = r0.size();
+      if (n >= 2 && r0[n - 1] >= thr && r0[n - 2] >= thr) { cand = (int)n - 2; p->lo = lo; p->hi = hi; p->thr = thr; break; }
+    }
+  }
+  if (cand < 0) {                                     // one class as far as the budget reaches
+    r.label = LM;
+    got.push_back(r);
+    for (Cand &c : seen) { c.label = LM; got.push_back(c); }
+    p->hopeless = true;
+    return false;
+  }
+  p->h0 = r.h; p->slot_h0 = r.slot;
+  p->f0 = seen[cand].h; p->slot_f0 = seen[cand].slot;
+  p->refs = true;
+  for (size_t i = 0; i < seen.size(); i++) {
+    if ((int)i == cand) continue;
+    seen[i].label = label_slot(p, seen[i].slot);
+    got.push_back(seen[i]);
+  }
+  return true;
+}
+
+void give_back(Pool *p, std::vector<Cand> &v) {           // to the pool while it has room for that label, else to the driver
+  uint32_t held[4] = {0, 0, 0, 0};
+  for (const Cand &c : p->spare) held[c.label]++;
+  for (Cand &c : v) {
+    if (p->refs && c.label != LM && (uint64_t)(held[c.label] + 1) * HANDLE <= POOL_CAP_PER_LABEL) { p->spare.push_back(c); held[c.label]++; }
+    else release(p, c);
+  }
+  v.clear();
 }
 
 }  // namespace
@@ -75,134 +222,144 @@ extern "C" int b3w_place_alloc(int device, uint64_t bytes, int want_mixed, void 
   if (mixed) *mixed = 0;
   hipError_t e = hipSetDevice(device);
   if (e != hipSuccess) return -(int)e;
-  hipMemAllocationProp prop = {};
-  prop.type = hipMemAllocationTypePinned;
-  prop.location.type = hipMemLocationTypeDevice;
-  prop.location.id = device;
-  hipMemAccessDesc acc = {};
-  acc.location = prop.location;
-  acc.flags = hipMemAccessFlagsProtReadWrite;
-  const uint32_t nh = (uint32_t)((bytes + HANDLE - 1) / HANDLE), need = (nh + 1) / 2;
+  std::lock_guard<std::mutex> guard(mtx());
+  Pool *p = pool_for(device);
+  if (!p) return -(int)hipErrorOutOfMemory;
+  const uint32_t nh = (uint32_t)((bytes + HANDLE - 1) / HANDLE), need1 = (nh + 1) / 2, need2 = nh - need1;
   size_t fr = 0, tot = 0;
   if ((e = hipMemGetInfo(&fr, &tot)) != hipSuccess) return -(int)e;
-  if (fr < (uint64_t)nh * HANDLE + GiB) return -(int)hipErrorOutOfMemory;
-  // search budget: the buffer itself plus at most half of what is free beyond it (other processes may be doing the
-  // same on this device), never more than 160 GiB
-  const uint64_t own = (uint64_t)nh * HANDLE;
-  const uint64_t budget = own + std::min<uint64_t>((fr - own) / 2, 160 * GiB);
-  const uint32_t maxh = want_mixed ? (uint32_t)(budget / HANDLE) : nh;
-  if (maxh < nh) return -(int)hipErrorOutOfMemory;
+  const uint64_t own = (uint64_t)nh * HANDLE, pooled = (uint64_t)p->spare.size() * HANDLE;
+  if (fr + pooled < own + GiB) return -(int)hipErrorOutOfMemory;
+  // search budget in NEW handles: the buffer itself plus at most half of what is free beyond it (other processes may
+  // be doing the same on this device), never more than 160 GiB — and never more than the address range still has
+  uint32_t budget = (uint32_t)((std::min<uint64_t>(own, fr) + std::min<uint64_t>((fr > own ? fr - own : 0) / 2, 160 * GiB)) / HANDLE);
+  if (slots_left(p) < 2 * nh + 8) return -(int)hipErrorOutOfMemory;          // address range used up: caller falls back
+  budget = std::min<uint32_t>(budget, slots_left(p) - nh - 4);
 
-  void *scr = nullptr;
-  if ((e = hipMemAddressReserve(&scr, (size_t)maxh * HANDLE, 2 * MiB, nullptr, 0)) != hipSuccess) return -(int)e;
-  uint8_t *V = static_cast<uint8_t *>(scr);
-  std::vector<hipMemGenericAllocationHandle_t> h;
-  std::vector<double> rate;                          // rate[i] = probe(handle 0, handle i)
-  hipEvent_t e0 = nullptr, e1 = nullptr;
-  (void)hipEventCreate(&e0);
-  (void)hipEventCreate(&e1);
-  std::vector<uint32_t> same, other;                 // handle indices by class relative to handle 0
-  double lo = 0, hi = 0;
+  std::vector<Cand> side1, side2, thirds, rejects, extra;      // A, B, C, M, and what exceeds the need
+  auto sort_in = [&](const Cand &c) {
+    if (c.label == LA) (side1.size() < need1 + 2 ? side1 : extra).push_back(c);
+    else if (c.label == LB) (side2.size() < need2 + 2 ? side2 : extra).push_back(c);
+    else if (c.label == LC) thirds.push_back(c);
+    else rejects.push_back(c);
+  };
+  auto covered = [&]() {
+    const size_t s1 = std::min<size_t>(side1.size(), need1), s2 = std::min<size_t>(side2.size(), need2);
+    return (need1 - s1) + (need2 - s2) <= thirds.size();
+  };
   bool found = false;
-  for (uint32_t i = 0; i < maxh; i++) {
-    hipMemGenericAllocationHandle_t hh;
-    // a failure here only ends the search; the sticky HIP error must not leak into the caller's next launch check
-    if (hipMemCreate(&hh, HANDLE, &prop, 0) != hipSuccess) { (void)hipGetLastError(); break; }
-    if (hipMemMap(V + (size_t)i * HANDLE, HANDLE, 0, hh, 0) != hipSuccess) { (void)hipMemRelease(hh); (void)hipGetLastError(); break; }
-    if (hipMemSetAccess(V + (size_t)i * HANDLE, HANDLE, &acc, 1) != hipSuccess) {
-      (void)hipMemUnmap(V + (size_t)i * HANDLE, HANDLE);
-      (void)hipMemRelease(hh);
-      (void)hipGetLastError();
-      break;
+  std::vector<Cand> got;
+  got.swap(p->spare);                                          // labelled earlier, still mapped in their probe slots
+  if (want_mixed && !p->hopeless) {
+    if (!p->refs) (void)calibrate(p, budget, got);
+    for (const Cand &c : got) sort_in(c);
+    got.clear();
+    while (p->refs && !covered() && budget) {
+      Cand c{};
+      if (!create_handle(p, &c.h)) break;
+      budget--;
+      if (!map_new(p, c)) { (void)hipMemRelease(c.h); break; }
+      c.label = label_slot(p, c.slot);
+      sort_in(c);
     }
-    h.push_back(hh);
-    if (!want_mixed) { rate.push_back(0); continue; }
-    rate.push_back(i ? probe_rate(V, V + (size_t)i * HANDLE, e0, e1) : 0);
-    if (i < 1) continue;
-    lo = hi = rate[1];
-    for (uint32_t k = 1; k <= i; k++) { lo = std::min(lo, rate[k]); hi = std::max(hi, rate[k]); }
-    if (lo <= 0 || hi < CONTRAST * lo) continue;     // one class so far
-    const double thr = sqrt(lo * hi);
-    same.assign(1, 0u);
-    other.clear();
-    for (uint32_t k = 1; k <= i; k++) (rate[k] < thr ? same : other).push_back(k);
-    if (same.size() >= need && other.size() >= nh - need) { found = true; break; }
+    found = p->refs && covered();
   }
-  (void)hipEventDestroy(e0);
-  (void)hipEventDestroy(e1);
-  int rc = 0;
-  Placed *p = nullptr;
-  std::vector<char> used(h.size(), 0);
-  if (h.size() < nh) rc = -(int)hipErrorOutOfMemory;
-  if (rc == 0) {
-    // VA order of the final buffer: alternate the most recently created handles of both groups (plain: creation order)
-    std::vector<uint32_t> order;
-    if (found) {
-      for (uint32_t s = 0; s < nh; s++) {
-        std::vector<uint32_t> &g = (s & 1) ? other : same;
-        order.push_back(g[g.size() - 1 - s / 2]);
-      }
-    } else {
-      for (uint32_t s = 0; s < nh; s++) order.push_back(s);
+  for (const Cand &c : got) sort_in(c);                        // (search skipped)
+  // the order of the pieces
+  std::vector<Cand> order;
+  uint32_t slow_seams = 0;
+  if (found) {
+    while (side1.size() > need1) { extra.push_back(side1.back()); side1.pop_back(); }
+    while (side2.size() > need2) { extra.push_back(side2.back()); side2.pop_back(); }
+    while (side1.size() < need1) { side1.push_back(thirds.back()); thirds.pop_back(); }
+    while (side2.size() < need2) { side2.push_back(thirds.back()); thirds.pop_back(); }
+    for (const Cand &c : thirds) extra.push_back(c);
+    thirds.clear();
+    for (uint32_t s = 0; s < nh; s++) order.push_back((s & 1) ? side2[s / 2] : side1[s / 2]);
+    // check every seam of that order directly; where two neighbours are slow together try other candidates
+    for (uint32_t s = 0; s + 1 < nh; s++) {
+      bool ok = probe_slots(p, order[s].slot, order[s + 1].slot) >= p->thr;
+      for (size_t t = 0; t < extra.size() && t < 6 && !ok; t++)
+        if (probe_slots(p, order[s].slot, extra[t].slot) >= p->thr) { std::swap(order[s + 1], extra[t]); ok = true; }
+      if (!ok) slow_seams++;
     }
-    for (size_t i = 0; i < h.size(); i++) (void)hipMemUnmap(V + i * HANDLE, HANDLE);
-    void *fin = nullptr;
-    e = hipMemAddressReserve(&fin, (size_t)nh * HANDLE, 2 * MiB, nullptr, 0);
-    if (e != hipSuccess) rc = -(int)e;
-    else {
-      p = new Placed;
-      p->va = fin;
-      p->va_bytes = (size_t)nh * HANDLE;
-      p->mixed = found ? 1 : 0;
-      for (uint32_t s = 0; s < nh && rc == 0; s++) {
-        e = hipMemMap(static_cast<uint8_t *>(fin) + (size_t)s * HANDLE, HANDLE, 0, h[order[s]], 0);
-        if (e != hipSuccess) { rc = -(int)e; break; }
-        p->handles.push_back(h[order[s]]);
-        used[order[s]] = 1;
-      }
-      if (rc == 0 && (e = hipMemSetAccess(fin, (size_t)nh * HANDLE, &acc, 1)) != hipSuccess) rc = -(int)e;
-      if (rc != 0) {
-        for (size_t s = 0; s < p->handles.size(); s++) (void)hipMemUnmap(static_cast<uint8_t *>(fin) + s * HANDLE, HANDLE);
-        (void)hipMemAddressFree(fin, (size_t)nh * HANDLE);
-        std::fill(used.begin(), used.end(), 0);
-        delete p;
-        p = nullptr;
-      }
-    }
+    if (slow_seams > nh / 8) found = false;              // not worth calling it mixed
   } else {
-    for (size_t i = 0; i < h.size(); i++) (void)hipMemUnmap(V + i * HANDLE, HANDLE);
+    // plain: whatever handles there are, then new ones
+    std::vector<Cand> all;
+    for (auto *v : {&side1, &side2, &thirds, &rejects, &extra}) { all.insert(all.end(), v->begin(), v->end()); v->clear(); }
+    for (const Cand &c : all) (order.size() < nh ? order : extra).push_back(c);
+    while (order.size() < nh) {
+      Cand c{};
+      c.label = LM;
+      if (!create_handle(p, &c.h)) break;
+      if (!map_new(p, c)) { (void)hipMemRelease(c.h); break; }
+      order.push_back(c);
+    }
   }
-  for (size_t i = 0; i < h.size(); i++) if (!used[i]) (void)hipMemRelease(h[i]);
-  (void)hipMemAddressFree(scr, (size_t)maxh * HANDLE);
+  if (getenv("B3W_PLACE_DEBUG")) {
+    fprintf(stderr, "b3w_place_alloc: %u pieces, found=%d, thr=%.0f (lo %.0f hi %.0f), slow seams left=%u, spare %zu, rejects %zu, slots used %u\n  ", nh,
+            (int)found, p->thr, p->lo, p->hi, slow_seams, extra.size(), rejects.size(), p->next_slot);
+    for (const Cand &c : order) fputc("ABCM"[c.label], stderr);
+    fputc('\n', stderr);
+  }
+  int rc = order.size() < nh ? -(int)hipErrorOutOfMemory : 0;
+  Placed *pl = nullptr;
+  if (rc == 0) {
+    // the buffer: the next nh never-used slots of the arena, second mapping of every piece
+    uint8_t *fin = slot_addr(p, p->next_slot);
+    uint32_t mapped = 0;
+    for (; mapped < nh; mapped++) {
+      e = hipMemMap(fin + (size_t)mapped * HANDLE, HANDLE, 0, order[mapped].h, 0);
+      if (e != hipSuccess) { rc = -(int)e; break; }
+    }
+    p->next_slot += nh;                                  // used up whatever happens next
+    if (rc == 0 && (e = hipMemSetAccess(fin, (size_t)nh * HANDLE, &p->acc, 1)) != hipSuccess) rc = -(int)e;
+    if (rc != 0) {
+      for (uint32_t s = 0; s < mapped; s++) (void)hipMemUnmap(fin + (size_t)s * HANDLE, HANDLE);
+      (void)hipGetLastError();
+    } else {
+      pl = new Placed;
+      pl->va = fin;
+      pl->va_bytes = (size_t)nh * HANDLE;
+      pl->pieces = order;
+      pl->device = device;
+      pl->mixed = found ? 1 : 0;
+    }
+  }
+  if (rc != 0) give_back(p, order);
+  give_back(p, extra);
+  for (Cand &c : rejects) release(p, c);
   if (rc != 0) return rc;
-  {
-    std::lock_guard<std::mutex> g(registry_mutex());
-    registry().push_back(p);
-  }
-  *out = p->va;
-  if (mixed) *mixed = p->mixed;
-  if (rates) { rates[0] = (float)lo; rates[1] = (float)hi; }
+  registry().push_back(pl);
+  *out = pl->va;
+  if (mixed) *mixed = pl->mixed;
+  if (rates) { rates[0] = (float)p->lo; rates[1] = (float)p->hi; }
   return 0;
 }
 
 // 0 = freed; 1 = not a pointer handed out by b3w_place_alloc
 extern "C" int b3w_place_free(void *ptr) {
-  Placed *p = nullptr;
-  {
-    std::lock_guard<std::mutex> g(registry_mutex());
-    std::vector<Placed *> &r = registry();
-    for (size_t i = 0; i < r.size() && !p; i++)
-      if (r[i]->va == ptr) { p = r[i]; r.erase(r.begin() + i); }
-  }
-  if (!p) return 1;
-  {
-    (void)hipDeviceSynchronize();
-    for (size_t s = 0; s < p->handles.size(); s++) {
-      (void)hipMemUnmap(static_cast<uint8_t *>(p->va) + s * HANDLE, HANDLE);
-      (void)hipMemRelease(p->handles[s]);
-    }
-    (void)hipMemAddressFree(p->va, p->va_bytes);
-    delete p;
-  }
+  std::lock_guard<std::mutex> guard(mtx());
+  Placed *pl = nullptr;
+  std::vector<Placed *> &r = registry();
+  for (size_t i = 0; i < r.size() && !pl; i++)
+    if (r[i]->va == ptr) { pl = r[i]; r.erase(r.begin() + i); }
+  if (!pl) return 1;
+  (void)hipSetDevice(pl->device);
+  (void)hipDeviceSynchronize();
+  for (size_t s = 0; s < pl->pieces.size(); s++) (void)hipMemUnmap(static_cast<uint8_t *>(pl->va) + s * HANDLE, HANDLE);   // the range is not used again
+  Pool *p = pool_for(pl->device);
+  if (p) give_back(p, pl->pieces);                       // labelled pieces: kept for the next buffer while there is room
+  delete pl;
   return 0;
+}
+
+// release the pooled handles of every device (the references stay)
+extern "C" void b3w_place_trim(void) {
+  std::lock_guard<std::mutex> guard(mtx());
+  for (Pool *p : pools()) {
+    for (Cand &c : p->spare) release(p, c);
+    p->spare.clear();
+  }
 }

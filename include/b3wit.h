@@ -125,7 +125,8 @@ void *b3w_batch_device_ptr(b3w_batch *batch, uint64_t *pitch);
  * pattern — one stream per body — runs about 25 % faster when the bodies being written at any moment are spread
  * over two classes than when they all sit in one, which is where a plain hipMalloc puts them.  b3w_bodies_alloc
  * returns a linear device buffer of at least `bytes` bytes whose 256 MiB pieces alternate between two classes
- * (found by timing short store probes while the buffer is assembled through the HIP virtual-memory API);
+ * (found by timing short store probes against two reference pieces while the buffer is assembled through the HIP
+ * virtual-memory API);
  * *placement reports what was achieved.  Use the pointer like any device pointer (kernels, hipMemcpy); release it
  * with b3w_bodies_free.  B3W_PLACEMENT=plain in the environment turns the search off.
  * b3w_batch_alloc places its body buffer this way. */
@@ -133,6 +134,9 @@ void *b3w_batch_device_ptr(b3w_batch *batch, uint64_t *pitch);
 #define B3W_PLACEMENT_MIXED 1 /* alternating classes */
 int32_t b3w_bodies_alloc(b3w_ctx *ctx, uint64_t bytes, void **d_ptr, int32_t *placement);
 int32_t b3w_bodies_free(b3w_ctx *ctx, void *d_ptr);
+/* The allocator keeps up to 3 x 12 GiB of classified-but-unused physical memory per device for the next buffer (and two
+ * 256 MiB reference pieces for good); b3w_bodies_trim returns that reserve to the driver. */
+void b3w_bodies_trim(void);
 /* Placement of a batch's own body buffer. */
 int32_t b3w_batch_placement(const b3w_batch *batch);
 
@@ -201,6 +205,38 @@ int32_t b3w_chain_tree_device(b3w_ctx *ctx, uint32_t *d_levels, uint64_t n_chunk
  * d_records + ((c - first_chunk)*log2(n) + j)*32 words. */
 int32_t b3w_chain_plan_parents_device(b3w_ctx *ctx, const uint32_t *d_levels, uint64_t n_chunks, uint64_t preimage_len,
                                       uint64_t first_chunk, uint32_t n_chunks_local, uint32_t *d_records, void *stream);
+
+/* ---- chained mode: the whole pass, natively ---------------------------------------------------
+ * What rust_fold/src/main.rs:41-203 does one step at a time for one chunk path, for ALL steps of the chunk range
+ * [first_chunk, first_chunk + n_chunks_local) of a preimage (one rank's share; a single GPU takes all chunks):
+ *   b3w_chain_run_leaves   pageable or pinned host slices of the preimage -> HBM on a copy stream, overlapped with
+ *                          the leaf planner and the nova witness kernels of earlier slices on `stream`
+ *   (multi-GPU: all-gather the chunk chaining values of b3w_chain_local_cvs across ranks — 32 B per chunk)
+ *   b3w_chain_run_parents  BLAKE3 tree over all chunk CVs, parent-step records of the local chunks (complete trees),
+ *                          their witnesses
+ * Witness bodies go through a ring of `ring` placed buffers (b3w_bodies_alloc) of `batch_steps` bodies each: a
+ * 1 GiB preimage is 28 TB of witness.  After each batch `consumer` (may be NULL) is called with the device pointer
+ * of the batch; it must enqueue its work on `stream` — the buffer is overwritten `ring` batches later.
+ * Step records, public outputs (15 words per step) and status live in device arrays owned by the object: leaf
+ * steps first (chunk order, block order), then the parent steps (chunk order, height order).  Nothing is
+ * synchronised: results are valid once `stream` has drained. */
+typedef struct b3w_chain b3w_chain;
+typedef void (*b3w_batch_consumer)(void *user, const uint8_t *d_bodies, uint64_t pitch, uint64_t first_step, uint32_t count,
+                                   void *stream);
+int32_t b3w_chain_create(b3w_ctx *ctx, uint64_t preimage_len, uint64_t first_chunk, uint32_t n_chunks_local,
+                         uint32_t batch_steps, uint32_t ring, int32_t with_parents, b3w_chain **out);
+void b3w_chain_destroy(b3w_chain *chain);
+int32_t b3w_chain_run_leaves(b3w_chain *chain, const uint8_t *host_preimage /* byte 0 of the WHOLE preimage */,
+                             b3w_batch_consumer consumer, void *user, void *stream);
+int32_t b3w_chain_run_parents(b3w_chain *chain, const uint32_t *d_all_chunk_cvs /* n_chunks*8 words; NULL = the local ones,
+                              single rank */, b3w_batch_consumer consumer, void *user, void *stream);
+int32_t b3w_chain_info(const b3w_chain *chain, uint64_t *n_leaf_steps, uint64_t *n_parent_steps, uint64_t *n_chunks,
+                       uint32_t *path_len, int32_t *placement);
+uint32_t *b3w_chain_records(b3w_chain *chain);     /* device: (n_leaf + n_parent) * 32 u32 */
+uint32_t *b3w_chain_public(b3w_chain *chain);      /* device: (n_leaf + n_parent) * 15 u32 */
+int32_t *b3w_chain_status(b3w_chain *chain);       /* device: (n_leaf + n_parent) int32 */
+uint32_t *b3w_chain_local_cvs(b3w_chain *chain);   /* device: n_chunks_local * 8 u32 */
+uint32_t *b3w_chain_root(b3w_chain *chain);        /* device: 8 u32 = BLAKE3(preimage) words, after run_parents */
 
 #ifdef __cplusplus
 }

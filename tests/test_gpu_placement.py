@@ -108,3 +108,25 @@ def test_body_buffer_as_torch_tensor():
     del t, view
     buf.free()
     ctx.close()
+
+
+def test_recycled_buffers_hold_what_the_kernel_wrote():
+    """Allocate / run / read back through hipMemcpy / free, five times over: the pieces of a freed buffer are reused
+    by the next one.  (On this ROCm stack a virtual address that is unmapped and mapped to another physical handle
+    keeps serving the old pages — tools/ubench/vmm_remap.hip — which is why b3w_placement.hip never maps an address
+    twice; an allocator that did would fail exactly here: the kernel's stores and the copy engine's reads would see
+    different memory.)"""
+    ctx = m.Context("compression", 0)
+    n = 1024
+    idx = [0, 347, 348, 349, n - 1]
+    for rnd in range(5):
+        recs = m.workloads.config2_compression(n, first=5000 * rnd)
+        b = m.Batch(ctx, n)
+        b.run(recs)
+        bad, want = T.oracle_batch_u32("compression", recs[idx])
+        assert bad == 0
+        for j, i in enumerate(idx):
+            assert np.array_equal(b.fetch(i), want[j]), (rnd, i)
+        assert (b.verify() == 0).all()
+        b.close()
+    ctx.close()
