@@ -86,7 +86,8 @@ def bench_chain(args, m, torch, dist, dev, world, rank, local_rank):
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
             "config": {"workload": f"chain: {args.preimage_mib} MiB preimage -> {int(total_steps)} nova steps ({circuit}), "
                                    "planner + witness kernels, bodies through a 2-deep ring, H2D overlapped",
-                       "circuit": circuit, "n_chunks": out["n_chunks"], "path_len": out["path_len"]},
+                       "circuit": circuit, "n_chunks": out["n_chunks"], "path_len": out["path_len"],
+                       "placement": out.get("placement")},
             "roofline": {"bound": "hbm", "achieved": total_steps * args.steps * per / elapsed / 1e9 / world, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": total_steps * args.steps * per / elapsed / 1e9 / world / HBM_PEAK_GBS,
                          "traffic": None, "note": "end-to-end per-GPU rate incl. planner, H2D and launch gaps"},
