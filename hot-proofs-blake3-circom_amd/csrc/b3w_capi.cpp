@@ -1006,6 +1006,17 @@ int32_t b3w_chain_info(const b3w_chain *c, uint64_t *n_leaf_steps, uint64_t *n_p
   if (placement) *placement = c->placement;
   return B3W_OK;
 }
+int32_t b3w_chain_outputs(b3w_chain *c, uint32_t *host_public, int32_t *host_status, uint32_t *host_root, void *stream) {
+  if (!c) return B3W_E_BAD_ARGUMENT;
+  b3w_ctx *ctx = c->ctx;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  HIP_TRY(ctx, hipStreamSynchronize((hipStream_t)stream));
+  const uint64_t rows = c->n_leaf + c->n_par;
+  if (host_public) HIP_TRY(ctx, hipMemcpy(host_public, c->d_pub, rows * 15 * 4, hipMemcpyDeviceToHost));
+  if (host_status) HIP_TRY(ctx, hipMemcpy(host_status, c->d_status, rows * 4, hipMemcpyDeviceToHost));
+  if (host_root) HIP_TRY(ctx, hipMemcpy(host_root, c->d_root, 32, hipMemcpyDeviceToHost));
+  return B3W_OK;
+}
 uint32_t *b3w_chain_records(b3w_chain *c) { return c ? c->d_recs : nullptr; }
 uint32_t *b3w_chain_public(b3w_chain *c) { return c ? c->d_pub : nullptr; }
 int32_t *b3w_chain_status(b3w_chain *c) { return c ? c->d_status : nullptr; }

@@ -38,6 +38,14 @@ struct Api {
   decltype(&b3w_batch_fetch) batch_fetch;
   decltype(&b3w_batch_write_wtns) batch_write_wtns;
   decltype(&b3w_batch_verify) batch_verify;
+  decltype(&b3w_batch_placement) batch_placement;
+  decltype(&b3w_bodies_trim) bodies_trim;
+  decltype(&b3w_chain_create) chain_create;
+  decltype(&b3w_chain_destroy) chain_destroy;
+  decltype(&b3w_chain_run_leaves) chain_run_leaves;
+  decltype(&b3w_chain_run_parents) chain_run_parents;
+  decltype(&b3w_chain_info) chain_info;
+  decltype(&b3w_chain_outputs) chain_outputs;
   std::string err;
 } api;
 
@@ -59,7 +67,8 @@ bool load_api() {
   if (!api.name) { api.err = "libb3wit.so lacks b3w_" #name; dlclose(so); return false; }
   SYM(abi_version) SYM(identify_wasm) SYM(create) SYM(destroy) SYM(info) SYM(input_signal_size) SYM(calc_witness)
   SYM(write_wtns_header) SYM(last_error) SYM(public_words) SYM(batch_alloc) SYM(batch_free) SYM(batch_run)
-  SYM(batch_outputs) SYM(batch_fetch) SYM(batch_write_wtns) SYM(batch_verify)
+  SYM(batch_outputs) SYM(batch_fetch) SYM(batch_write_wtns) SYM(batch_verify) SYM(batch_placement) SYM(bodies_trim)
+  SYM(chain_create) SYM(chain_destroy) SYM(chain_run_leaves) SYM(chain_run_parents) SYM(chain_info) SYM(chain_outputs)
 #undef SYM
   api.so = so;
   return true;
@@ -321,6 +330,72 @@ napi_value BatchVerify(napi_env env, napi_callback_info info) {
   return out;
 }
 
+// batchPlacement(handle) -> "mixed" | "plain": where the body buffer of the last batchRun lives (b3w_bodies_alloc)
+napi_value BatchPlacement(napi_env env, napi_callback_info info) {
+  size_t argc = 1; napi_value argv[1];
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+  Handle *h = get_handle(env, argv[0]);
+  if (!h) return nullptr;
+  napi_value out;
+  NAPI_OK(napi_create_string_utf8(env, h->batch && api.batch_placement(h->batch) == B3W_PLACEMENT_MIXED ? "mixed" : "plain", NAPI_AUTO_LENGTH, &out));
+  return out;
+}
+
+// chainFold(handle, preimage: Buffer|Uint8Array, batchSteps, ring, withParents)
+//   -> { nLeafSteps, nParentSteps, nChunks, pathLen, placement, publicOutputs: Uint32Array(steps*15), status: Int32Array, root: Uint32Array(8) }
+// The whole chained-mode pass of b3wit.h (b3w_chain_*) over one preimage on this handle's device.
+napi_value ChainFold(napi_env env, napi_callback_info info) {
+  size_t argc = 5; napi_value argv[5];
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+  Handle *h = get_handle(env, argv[0]);
+  if (!h) return nullptr;
+  void *data = nullptr; size_t len = 0;
+  bool is = false;
+  napi_is_buffer(env, argv[1], &is);
+  if (is) NAPI_OK(napi_get_buffer_info(env, argv[1], &data, &len));
+  else {
+    napi_typedarray_type t; napi_value ab; size_t off;
+    NAPI_OK(napi_get_typedarray_info(env, argv[1], &t, &len, &data, &ab, &off));
+    if (t != napi_uint8_array) { napi_throw_type_error(env, nullptr, "preimage: Buffer or Uint8Array"); return nullptr; }
+  }
+  if (!len) { napi_throw_range_error(env, nullptr, "preimage must not be empty"); return nullptr; }
+  uint32_t batch_steps = 16384, ring = 2;
+  bool with_parents = true;
+  if (argc > 2) napi_get_value_uint32(env, argv[2], &batch_steps);
+  if (argc > 3) napi_get_value_uint32(env, argv[3], &ring);
+  if (argc > 4) napi_get_value_bool(env, argv[4], &with_parents);
+  const uint64_t nchunks = (len + 1023) / 1024;
+  if (nchunks > 0xFFFFFFFFull) { napi_throw_range_error(env, nullptr, "preimage too large for one pass"); return nullptr; }
+  b3w_chain *c = nullptr;
+  int32_t rc = api.chain_create(h->ctx, len, 0, (uint32_t)nchunks, batch_steps, ring, with_parents ? 1 : 0, &c);
+  if (rc != B3W_OK) return throw_status(env, h, rc, "b3w_chain_create failed");
+  rc = api.chain_run_leaves(c, (const uint8_t *)data, nullptr, nullptr, nullptr);
+  if (rc == B3W_OK) rc = api.chain_run_parents(c, nullptr, nullptr, nullptr, nullptr);
+  uint64_t nleaf = 0, npar = 0, nch = 0; uint32_t plen = 0; int32_t placement = 0;
+  api.chain_info(c, &nleaf, &npar, &nch, &plen, &placement);
+  const uint64_t rows = nleaf + npar;
+  void *pp = nullptr, *ps = nullptr, *pr = nullptr; napi_value abp, abs_, abr, o, v;
+  if (rc == B3W_OK && (napi_create_arraybuffer(env, rows * 15 * 4, &pp, &abp) != napi_ok || napi_create_arraybuffer(env, rows * 4, &ps, &abs_) != napi_ok ||
+                       napi_create_arraybuffer(env, 32, &pr, &abr) != napi_ok)) {
+    api.chain_destroy(c);
+    napi_throw_error(env, nullptr, "b3wit_napi: cannot allocate the result arrays");
+    return nullptr;
+  }
+  if (rc == B3W_OK) rc = api.chain_outputs(c, (uint32_t *)pp, (int32_t *)ps, (uint32_t *)pr, nullptr);
+  api.chain_destroy(c);
+  if (rc != B3W_OK) return throw_status(env, h, rc, "chained pass failed");
+  NAPI_OK(napi_create_object(env, &o));
+  napi_create_double(env, (double)nleaf, &v); napi_set_named_property(env, o, "nLeafSteps", v);
+  napi_create_double(env, (double)npar, &v); napi_set_named_property(env, o, "nParentSteps", v);
+  napi_create_double(env, (double)nch, &v); napi_set_named_property(env, o, "nChunks", v);
+  napi_create_uint32(env, plen, &v); napi_set_named_property(env, o, "pathLen", v);
+  napi_create_string_utf8(env, placement == B3W_PLACEMENT_MIXED ? "mixed" : "plain", NAPI_AUTO_LENGTH, &v); napi_set_named_property(env, o, "placement", v);
+  napi_create_typedarray(env, napi_uint32_array, rows * 15, abp, 0, &v); napi_set_named_property(env, o, "publicOutputs", v);
+  napi_create_typedarray(env, napi_int32_array, rows, abs_, 0, &v); napi_set_named_property(env, o, "status", v);
+  napi_create_typedarray(env, napi_uint32_array, 8, abr, 0, &v); napi_set_named_property(env, o, "root", v);
+  return o;
+}
+
 napi_value AbiVersion(napi_env env, napi_callback_info) {
   if (!load_api()) { napi_throw_error(env, nullptr, api.err.c_str()); return nullptr; }
   napi_value out;
@@ -341,6 +416,8 @@ napi_value Init(napi_env env, napi_value exports) {
       {"batchFetch", nullptr, BatchFetch, nullptr, nullptr, nullptr, napi_default, nullptr},
       {"batchWriteWtns", nullptr, BatchWriteWtns, nullptr, nullptr, nullptr, napi_default, nullptr},
       {"batchVerify", nullptr, BatchVerify, nullptr, nullptr, nullptr, napi_default, nullptr},
+      {"batchPlacement", nullptr, BatchPlacement, nullptr, nullptr, nullptr, napi_default, nullptr},
+      {"chainFold", nullptr, ChainFold, nullptr, nullptr, nullptr, napi_default, nullptr},
   };
   napi_define_properties(env, exports, sizeof props / sizeof props[0], props);
   return exports;

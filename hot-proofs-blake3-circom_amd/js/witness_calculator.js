@@ -169,6 +169,20 @@ class WitnessCalculator {
     // stream every witness of the batch to <dir>/<prefix><index>.wtns (same bytes as calculateWTNSBin)
     r.writeWtns = (dir, prefix, first, count) =>
       nat.batchWriteWtns(this.instance, first || 0, count === undefined ? r.n - (first || 0) : count, dir, prefix || "witness_");
+    r.placement = nat.batchPlacement(this.instance);   // "mixed": the body buffer alternates two classes of HBM
+    return r;
+  }
+
+  // ---- extension (nova circuits): chained mode.  preimage -> the step witnesses of every chunk path, what
+  // rust_fold/src/main.rs:41-203 folds one step at a time.  Returns { nLeafSteps, nParentSteps, nChunks, pathLen,
+  // placement, publicOutputs: Uint32Array (15 words per step: n_blocks_out block_count_out h_out[8] ...),
+  // status: Int32Array, root: Uint32Array(8) = BLAKE3(preimage) as little-endian words, hash: hex string }.
+  async foldPreimage(preimage, opts) {
+    opts = opts || {};
+    const r = native().chainFold(this.instance, preimage, opts.batchSteps || 16384, opts.ring || 2, opts.withParents !== false);
+    const b = Buffer.alloc(32);
+    r.root.forEach((w, i) => b.writeUInt32LE(w, 4 * i));
+    r.hash = b.toString("hex");
     return r;
   }
 }

@@ -232,6 +232,9 @@ int32_t b3w_chain_run_parents(b3w_chain *chain, const uint32_t *d_all_chunk_cvs 
                               single rank */, b3w_batch_consumer consumer, void *user, void *stream);
 int32_t b3w_chain_info(const b3w_chain *chain, uint64_t *n_leaf_steps, uint64_t *n_parent_steps, uint64_t *n_chunks,
                        uint32_t *path_len, int32_t *placement);
+/* Waits for `stream`, then copies the results to the host: (n_leaf + n_parent) * 15 public-output words, as many
+ * status words, the 8 root words (after run_parents).  Any pointer may be NULL. */
+int32_t b3w_chain_outputs(b3w_chain *chain, uint32_t *host_public, int32_t *host_status, uint32_t *host_root, void *stream);
 uint32_t *b3w_chain_records(b3w_chain *chain);     /* device: (n_leaf + n_parent) * 32 u32 */
 uint32_t *b3w_chain_public(b3w_chain *chain);      /* device: (n_leaf + n_parent) * 15 u32 */
 int32_t *b3w_chain_status(b3w_chain *chain);       /* device: (n_leaf + n_parent) int32 */

@@ -176,3 +176,45 @@ def test_nova_sequence_on_one_calculator_logs_and_sticky_errors():
         assert strict["error"] == s["error"], (s["name"], strict["error"])
         if s["error"] is not None and s["name"] in own:       # default mode: only this call's own trace
             assert default["error"] == own[s["name"]], s["name"]
+
+
+@needs_node
+@pytest.mark.gpu
+def test_js_fold_preimage_matches_blake3_and_python_driver(tmp_path):
+    """wc.foldPreimage (N-API chainFold over the native b3w_chain_* driver): the root equals BLAKE3(preimage)
+    (independent pure-Python BLAKE3), every step verifies, and counts / public outputs equal the Python driver's."""
+    import numpy as np, torch, blake3_ref
+    m = T.pkg()
+    shapes = {"complete": 16 * 1024, "ragged": 5 * 1024 + 100, "tiny": 4}
+    for name, nbytes in shapes.items():
+        data = ((np.arange(nbytes, dtype=np.uint64) * 2654435761 + 7) % 251).astype(np.uint8)
+        (tmp_path / (name + ".bin")).write_bytes(data.tobytes())
+    r = _node("""
+      const builder = require('./hot-proofs-blake3-circom_amd/js/witness_calculator.js');
+      const fs = require('fs'), crypto = require('crypto');
+      (async () => {
+        const wc = await builder('nova_vesta', {logDFlags: false});
+        const out = {};
+        for (const name of ['complete', 'ragged', 'tiny']) {
+          const r = await wc.foldPreimage(fs.readFileSync(process.argv[1] + '/' + name + '.bin'), {batchSteps: 64});
+          out[name] = {nLeaf: r.nLeafSteps, nPar: r.nParentSteps, nChunks: r.nChunks, pathLen: r.pathLen, hash: r.hash, placement: r.placement,
+                       bad: Array.from(r.status).filter(x => x !== 0).length,
+                       pub: crypto.createHash('sha256').update(Buffer.from(r.publicOutputs.buffer, r.publicOutputs.byteOffset, r.publicOutputs.byteLength)).digest('hex')};
+        }
+        console.log(JSON.stringify(out));
+      })().catch(e => { console.error(e); process.exit(1); });
+    """, str(tmp_path))
+    assert r.returncode == 0, r.stderr
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    ctx = m.Context("nova_vesta", 0)
+    import hashlib
+    for name, nbytes in shapes.items():
+        data = np.frombuffer((tmp_path / (name + ".bin")).read_bytes(), dtype=np.uint8).copy()
+        assert out[name]["hash"] == blake3_ref.blake3(data.tobytes()).hex(), name
+        assert out[name]["bad"] == 0
+        py = m.chain.fold_witnesses(ctx, data, batch_steps=64)
+        torch.cuda.synchronize()
+        assert (out[name]["nLeaf"], out[name]["nPar"]) == (py["n_leaf_steps"], py["n_parent_steps"]), name
+        assert out[name]["pub"] == hashlib.sha256(py["public"].cpu().numpy().tobytes()).hexdigest(), name
+    assert out["complete"]["nPar"] == 16 * 4 and out["ragged"]["nPar"] == 0 and out["tiny"]["nLeaf"] == 1
+    ctx.close()
