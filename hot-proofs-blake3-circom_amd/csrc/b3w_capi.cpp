@@ -865,8 +865,9 @@ struct b3w_chain {
   uint32_t *d_recs = nullptr, *d_cvs = nullptr, *d_pub = nullptr, *d_levels = nullptr, *d_root = nullptr;
   int32_t *d_status = nullptr;
   std::vector<void *> bodies;
-  hipStream_t copy = nullptr;
+  hipStream_t copy = nullptr, side = nullptr;        // H2D slices; tree + parent planning beside the leaf witness kernels
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
+  hipEvent_t ev_cvs = nullptr, ev_par = nullptr;     // chunk CVs complete (main stream); parent records ready (side stream)
 };
 
 namespace {
@@ -919,6 +920,9 @@ int32_t b3w_chain_create(b3w_ctx *ctx, uint64_t preimage_len, uint64_t first_chu
   if (e == hipSuccess) e = hipMalloc((void **)&c->d_root, 8 * 4);
   if (e == hipSuccess) e = hipMemset(c->d_status, 0, rows * 4);
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->copy, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_cvs, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_par, hipEventDisableTiming);
   for (int i = 0; i < 4 && e == hipSuccess; i++) e = hipEventCreateWithFlags(&c->ev[i], hipEventDisableTiming);
   if (e != hipSuccess) { b3w_chain_destroy(c); return e == hipErrorOutOfMemory ? B3W_E_NOT_ENOUGH_MEMORY : hip_fail(ctx, e, "chain buffers"); }
   c->placement = B3W_PLACEMENT_MIXED;
@@ -947,6 +951,9 @@ void b3w_chain_destroy(b3w_chain *c) {
   if (c->d_levels) (void)hipFree(c->d_levels);
   if (c->d_root) (void)hipFree(c->d_root);
   if (c->copy) (void)hipStreamDestroy(c->copy);
+  if (c->side) (void)hipStreamDestroy(c->side);
+  if (c->ev_cvs) (void)hipEventDestroy(c->ev_cvs);
+  if (c->ev_par) (void)hipEventDestroy(c->ev_par);
   for (int i = 0; i < 4; i++) if (c->ev[i]) (void)hipEventDestroy(c->ev[i]);
   delete c;
 }
@@ -971,6 +978,7 @@ int32_t b3w_chain_run_leaves(b3w_chain *c, const uint8_t *host_preimage, b3w_bat
     int32_t rc = b3w_chain_plan_leaves_device(ctx, c->d_pre + (uint64_t)s0 * 1024, c->len, c->first_chunk + s0, sc,
                                               c->d_recs + (uint64_t)s0 * 16 * 32, c->d_cvs + (uint64_t)s0 * 8, stream);
     if (rc) return rc;
+    if (s0 + sc == c->nl) HIP_TRY(ctx, hipEventRecord(c->ev_cvs, st));     // every local chunk CV is on its way
     const uint64_t steps_here = (uint64_t)sc * 16 - ((c->has_last && s0 + sc == c->nl) ? 16 - c->last_blocks : 0);
     rc = chain_run_steps(c, (uint64_t)s0 * 16, steps_here, consumer, user, stream);
     if (rc) return rc;
@@ -983,16 +991,24 @@ int32_t b3w_chain_run_parents(b3w_chain *c, const uint32_t *d_all_chunk_cvs, b3w
   b3w_ctx *ctx = c->ctx;
   HIP_TRY(ctx, hipSetDevice(ctx->device));
   hipStream_t st = (hipStream_t)stream;
+  // The tree and the parent-step records only need the chunk CVs, not the leaf witnesses: they run on a side stream
+  // beside the leaf witness kernels still queued on `stream` (250 us of small dependent launches for a 1 MiB preimage).
   if (!d_all_chunk_cvs) {
     if (c->nl != c->n_chunks) { ctx->last_error = "a chunk sub-range needs the chunk CVs of all ranks"; return B3W_E_BAD_ARGUMENT; }
     d_all_chunk_cvs = c->d_cvs;
+    HIP_TRY(ctx, hipStreamWaitEvent(c->side, c->ev_cvs, 0));
+  } else {                                             // gathered by the caller on `stream`: order after that
+    HIP_TRY(ctx, hipEventRecord(c->ev_cvs, st));
+    HIP_TRY(ctx, hipStreamWaitEvent(c->side, c->ev_cvs, 0));
   }
-  HIP_TRY(ctx, hipMemcpyAsync(c->d_levels, d_all_chunk_cvs, c->n_chunks * 32, hipMemcpyDeviceToDevice, st));
-  int32_t rc = b3w_chain_tree_device(ctx, c->d_levels, c->n_chunks, c->d_root, stream);
+  HIP_TRY(ctx, hipMemcpyAsync(c->d_levels, d_all_chunk_cvs, c->n_chunks * 32, hipMemcpyDeviceToDevice, c->side));
+  int32_t rc = b3w_chain_tree_device(ctx, c->d_levels, c->n_chunks, c->d_root, c->side);
+  if (rc == B3W_OK && c->n_par)
+    rc = b3w_chain_plan_parents_device(ctx, c->d_levels, c->n_chunks, c->len, c->first_chunk, c->nl, c->d_recs + c->n_leaf * 32, c->side);
+  HIP_TRY(ctx, hipEventRecord(c->ev_par, c->side));
+  HIP_TRY(ctx, hipStreamWaitEvent(st, c->ev_par, 0));   // also when something failed: `stream` must not run ahead of the side stream
   if (rc) return rc;
   if (!c->n_par) return B3W_OK;
-  rc = b3w_chain_plan_parents_device(ctx, c->d_levels, c->n_chunks, c->len, c->first_chunk, c->nl, c->d_recs + c->n_leaf * 32, stream);
-  if (rc) return rc;
   return chain_run_steps(c, c->n_leaf, c->n_par, consumer, user, stream);
 }
 
