@@ -174,6 +174,12 @@ def main():
     if args.placement == "plain":
         os.environ["B3W_PLACEMENT"] = "plain"
     bodies = ctx.alloc_bodies(n * pitch)
+    for _ in range(2):                                      # a box still releasing another process's memory: try again
+        if bodies.placement == "mixed" or args.placement == "plain":
+            break
+        bodies.free()
+        time.sleep(1.0)
+        bodies = ctx.alloc_bodies(n * pitch)
     d_bodies = bodies                                      # .data_ptr() like a tensor
     if args.variant is None:
         chosen, best_ms = ctx.autotune_device(d_recs.data_ptr(), n, bodies.ptr, pitch, d_pub.data_ptr(), d_status.data_ptr(),

@@ -908,9 +908,10 @@ extern "C" int b3w_launch_batch(int kind, int variant, const uint32_t *d_recs, u
   // bodies that start at the same offset into a 128-byte line are `stride` apart (WaveBodies); a wave takes W of them
   const uint32_t pm = (uint32_t)(pitch >> 5) & 3u, stride = (pitch & 31) ? 1u : pm == 0 ? 1u : pm == 2 ? 2u : 4u;
 #define B3W_GRID(WV) dim3((n + stride * WV - 1) / (stride * WV) * stride)
+  static const uint32_t lds_pad = getenv("B3W_LDS_PAD") ? (uint32_t)atoi(getenv("B3W_LDS_PAD")) : 0;   // experiment: occupancy limiter
   if (kind == B3W_KIND_COMP) {
 #define B3W_LAUNCH_COMP(WV, NTV)                                                                         \
-  hipLaunchKernelGGL((b3w_compression_kernel<WV, NTV, 0>), B3W_GRID(WV), dim3(64), 0, stream,              \
+  hipLaunchKernelGGL((b3w_compression_kernel<WV, NTV, 0>), B3W_GRID(WV), dim3(64), lds_pad, stream,        \
                      d_recs, n, d_out, pitch, d_table, nwit, d_pub, d_status, stride)
     switch (variant) {
       case 0: B3W_LAUNCH_COMP(4, false); break;
@@ -921,6 +922,11 @@ extern "C" int b3w_launch_batch(int kind, int variant, const uint32_t *d_recs, u
       case 5: B3W_LAUNCH_COMP(2, true); break;
       case 6: B3W_LAUNCH_COMP(1, true); break;
       case 7: B3W_LAUNCH_COMP(16, false); break;
+      case 8:   // W = 8 with two workgroups per CU (24 KB of unused dynamic LDS): about 4096 body streams in flight chip-wide,
+                // the count a 4096-witness batch has by itself; large batches 6.86 -> 7.30 TB/s (tools/ubench/occupancy.py)
+        hipLaunchKernelGGL((b3w_compression_kernel<8, false, 0>), B3W_GRID(8), dim3(64), lds_pad ? lds_pad : 24576u, stream, d_recs, n, d_out,
+                           pitch, d_table, nwit, d_pub, d_status, stride);
+        break;
       default: return -1;
     }
 #undef B3W_LAUNCH_COMP
@@ -929,7 +935,7 @@ extern "C" int b3w_launch_batch(int kind, int variant, const uint32_t *d_recs, u
   if (kind == B3W_KIND_NOVA_O2 || kind == B3W_KIND_NOVA_O1) {
     if (!d_aux) return -3;
 #define B3W_LAUNCH_NOVA(KV, WV)                                                                           \
-  hipLaunchKernelGGL((b3w_nova_kernel<KV, WV, false, 0>), B3W_GRID(WV), dim3(64), 0, stream,                \
+  hipLaunchKernelGGL((b3w_nova_kernel<KV, WV, false, 0>), B3W_GRID(WV), dim3(64), lds_pad, stream,          \
                      d_recs, n, d_out, pitch, d_table, nwit, d_pub, d_status, (const uint32_t *)d_aux, stride)
     if (kind == B3W_KIND_NOVA_O2) {
       switch (variant) {

@@ -80,7 +80,7 @@ struct Placed {
 struct Pool {
   int device = -1;
   bool refs = false;                                // h0 and f0 exist, thr is calibrated
-  bool hopeless = false;                            // a full search found no second class: do not walk again
+  bool hopeless = false;                            // a walk of 64 GiB or more found no second class: do not walk again
   hipMemGenericAllocationHandle_t h0{}, f0{};
   double thr = 0, lo = 0, hi = 0;
   uint8_t *arena = nullptr;                         // ARENA bytes of VA
@@ -188,7 +188,7 @@ bool calibrate(Pool *p, uint32_t &budget, std::vector<Cand> &got) {
     r.label = LM;
     got.push_back(r);
     for (Cand &c : seen) { c.label = LM; got.push_back(c); }
-    p->hopeless = true;
+    p->hopeless = (uint64_t)seen.size() * HANDLE >= 64 * GiB;   // a short walk (little free memory right now) may be retried
     return false;
   }
   p->h0 = r.h; p->slot_h0 = r.slot;
