@@ -174,3 +174,28 @@ def test_two_ranks_shard_chunks_and_exchange_cvs():
     assert (ret[0]["first_chunk"], ret[0]["n_local"], ret[1]["first_chunk"], ret[1]["n_local"]) == (0, 32, 32, 32)
     for r in (0, 1):
         assert len(ret[r]["last"]) == 32 and all(x == want for x in ret[r]["last"])
+
+
+def test_native_chain_driver_argument_errors():
+    """b3w_chain_* refuses what it cannot do: compression contexts, chunk ranges past the preimage, a chunk sub-range
+    without the other ranks' chaining values, zero-sized rings."""
+    import ctypes
+    m = T.pkg()
+    L = m.lib()
+    h = ctypes.c_void_p()
+    comp = m.Context("compression", 0)
+    assert L.b3w_chain_create(comp.handle, 4096, 0, 4, 64, 2, 1, ctypes.byref(h)) == 100 and "nova" in comp.last_error()
+    comp.close()
+    ctx = m.Context("nova_vesta", 0)
+    assert L.b3w_chain_create(ctx.handle, 4096, 2, 3, 64, 2, 1, ctypes.byref(h)) == 100          # 4 chunks: [2, 5) is past the end
+    assert L.b3w_chain_create(ctx.handle, 4096, 0, 4, 0, 2, 1, ctypes.byref(h)) == 100
+    assert L.b3w_chain_create(ctx.handle, 4096, 0, 4, 64, 0, 1, ctypes.byref(h)) == 100
+    assert L.b3w_chain_create(ctx.handle, 4096, 1, 2, 64, 2, 1, ctypes.byref(h)) == 0            # a rank's share: chunks 1..2
+    data = (np.arange(4096) % 251).astype(np.uint8)
+    assert L.b3w_chain_run_leaves(h, data.ctypes.data, None, None, None) == 0
+    assert L.b3w_chain_run_parents(h, None, None, None, None) == 100 and "all ranks" in ctx.last_error()
+    L.b3w_chain_destroy(h)
+    p, pl = ctypes.c_void_p(), ctypes.c_int32()
+    assert L.b3w_bodies_alloc(ctx.handle, 0, ctypes.byref(p), ctypes.byref(pl)) == 100
+    assert L.b3w_bodies_free(ctx.handle, None) == 0
+    ctx.close()
