@@ -226,34 +226,37 @@ __device__ __forceinline__ void expand(const uint32_t *lds, const uint32_t *__re
 // Returns this lane's count of differing 16-byte units per witness in cnt[].
 template <int W, int WORDS, bool WIDE>
 __device__ __forceinline__ void expand_verify(const uint32_t *lds, const uint32_t *__restrict__ table, uint32_t nwit,
-                                              const uint8_t *__restrict__ bodies, uint64_t pitch, uint32_t wit0, uint32_t n,
+                                              const uint8_t *__restrict__ bodies, uint64_t pitch, const WaveBodies wb, uint32_t n,
                                               uint32_t (&cnt)[W]) {
-  constexpr int U = 4;                                   // groups per iteration: U*W 16-byte loads in flight per lane
+  constexpr int U = 4;                                   // tiles per iteration: U*W 16-byte loads in flight per lane
   const int lane = threadIdx.x;
   const uint32_t par = lane & 1;
-  const uint32_t ngroups = (nwit + 31) >> 5;
-  const uint32_t nact = n - wit0 < (uint32_t)W ? n - wit0 : (uint32_t)W;
+  const uint32_t nact = wave_active<W>(wb, n);
+  // line-aligned tiles exactly as in expand(): tile k = slots [32k - j, 32k - j + 32), j from the first body's start
+  const uint64_t start = reinterpret_cast<uint64_t>(bodies) + (uint64_t)wb.first * pitch;
+  const uint32_t j = (start & 31) ? 0u : (uint32_t)(start >> 5) & 3u;
+  const uint32_t ntiles = (nwit + j + 31) >> 5;
 #pragma unroll
   for (int w = 0; w < W; ++w) cnt[w] = 0;
-  for (uint32_t g0 = 0; g0 < ngroups; g0 += U) {
+  for (uint32_t k0 = 0; k0 < ntiles; k0 += U) {
     uint32_t e[U];
     u32x4 got[U][W];
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const uint32_t g = g0 + u < ngroups ? g0 + u : ngroups - 1;          // clamped: the tail re-reads the last group
-      e[u] = table[g * 32 + (lane >> 1)];
+      const uint32_t k = k0 + u < ntiles ? k0 + u : ntiles - 1;            // clamped: the tail re-reads the last tile
+      const int32_t slot = (int32_t)(k * 32 + (lane >> 1)) - (int32_t)j;
+      const uint32_t sl = slot < 0 ? 0u : (uint32_t)slot < nwit ? (uint32_t)slot : nwit - 1;   // clamped inside the body
+      e[u] = table[sl];
 #pragma unroll
       for (int w = 0; w < W; ++w) {
-        const uint32_t ww = (uint32_t)w < nact ? w : 0;                     // clamped: inactive witnesses re-read body 0
-        const uint32_t slot = g * 32 + (lane >> 1);
-        const uint32_t sl = slot < nwit ? slot : nwit - 1;                  // clamped inside the body
-        got[u][w] = *reinterpret_cast<const u32x4 *>(bodies + (uint64_t)(wit0 + ww) * pitch + (uint64_t)sl * 32 + par * 16);
+        const uint32_t body = wb((uint32_t)w < nact ? w : 0);              // clamped: inactive witnesses re-read body 0
+        got[u][w] = *reinterpret_cast<const u32x4 *>(bodies + (uint64_t)body * pitch + (uint64_t)sl * 32 + par * 16);
       }
     }
 #pragma unroll
     for (int u = 0; u < U; ++u) {
-      const uint32_t slot = (g0 + u) * 32 + (lane >> 1);
-      const bool in = g0 + u < ngroups && slot < nwit;
+      const int32_t slot = (int32_t)((k0 + u) * 32 + (lane >> 1)) - (int32_t)j;
+      const bool in = k0 + u < ntiles && slot >= 0 && (uint32_t)slot < nwit;
       const uint32_t src = e[u] & 0xFFFu, sh = (e[u] >> 12) & 31u, mode = (e[u] >> 17) & 3u;
       const uint32_t off = (WIDE && mode == B3W_MODE_W256) ? src + 4u * par : src;
       const bool live = (par == 0) || (WIDE && mode == B3W_MODE_W256);
@@ -283,14 +286,14 @@ __device__ __forceinline__ uint32_t body_input_word(const uint8_t *body, uint32_
 
 // wave reduction of the per-lane counters, one global word per witness
 template <int W>
-__device__ __forceinline__ void publish_counts(uint32_t (&cnt)[W], uint32_t *__restrict__ mismatch, uint32_t wit0, uint32_t n,
+__device__ __forceinline__ void publish_counts(uint32_t (&cnt)[W], uint32_t *__restrict__ mismatch, const WaveBodies wb, uint32_t n,
                                                const uint32_t *flags /* per-w: nonzero = not verifiable / rejected */) {
 #pragma unroll
   for (int w = 0; w < W; ++w) {
     uint32_t c = cnt[w];
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
-    if (threadIdx.x == 0 && wit0 + w < n) mismatch[wit0 + w] = flags[w] ? 0xFFFFFFFFu : c;
+    if (threadIdx.x == 0 && wb(w) < n) mismatch[wb(w)] = flags[w] ? 0xFFFFFFFFu : c;
   }
 }
 
@@ -494,12 +497,13 @@ __global__ __launch_bounds__(64) void b3w_compression_kernel(const uint32_t *__r
                                                              uint8_t *__restrict__ out, uint64_t pitch,
                                                              const uint32_t *__restrict__ table, uint32_t nwit,
                                                              uint32_t *__restrict__ pub, int32_t *__restrict__ status,
-                                                             uint32_t stride /* WaveBodies; 1 for MODE 1 and 2 */) {
+                                                             uint32_t stride /* WaveBodies; 1 for MODE 1 */) {
   constexpr int WORDS = B3W_LDS_WORDS_COMP;
   __shared__ __attribute__((aligned(16))) uint32_t lds[W * WORDS + 4];   // +4: expand reads src+1 unconditionally
   const int lane = threadIdx.x;
   const WaveBodies wb = wave_bodies<W>(blockIdx.x, stride);
-  const uint32_t wit0 = wb.first;                      // MODE 1 and 2 run with stride 1
+  if (wb.first >= n) return;                           // the grid is rounded up to whole stride groups: nothing for this wave
+  const uint32_t wit0 = wb.first;                      // MODE 1 runs with stride 1
   // stage the 28-word records of this wave's witnesses into atoms H M T B D (image words 1..28)
   __shared__ uint32_t ncf[W];      // VERIFY: an input slot of the body is not a plain 32-bit value
   if (lane < W) ncf[lane] = 0;
@@ -530,8 +534,8 @@ __global__ __launch_bounds__(64) void b3w_compression_kernel(const uint32_t *__r
   if (MODE == 1) dump_images<W, WORDS>(lds, reinterpret_cast<uint32_t *>(out), (uint32_t)pitch, wit0, n, nullptr);   // out = scratch, pitch = its row length
   else if (MODE == 2) {
     uint32_t cnt[W];
-    expand_verify<W, WORDS, false>(lds, table, nwit, out, pitch, wit0, n, cnt);
-    publish_counts<W>(cnt, pub, wit0, n, ncf);
+    expand_verify<W, WORDS, false>(lds, table, nwit, out, pitch, wb, n, cnt);
+    publish_counts<W>(cnt, pub, wb, n, ncf);
   } else expand<W, WORDS, false, NT>(lds, table, nwit, out, pitch, wb, n, nullptr, true);
 }
 
@@ -649,7 +653,8 @@ __global__ __launch_bounds__(64) void b3w_nova_kernel(const uint32_t *__restrict
   __shared__ uint32_t domf[W];     // 1 = an IsZero argument fell outside the supported magnitude
   const int lane = threadIdx.x;
   const WaveBodies wb = wave_bodies<W>(blockIdx.x, stride);
-  const uint32_t wit0 = wb.first;                      // MODE 1 and 2 run with stride 1
+  if (wb.first >= n) return;                           // the grid is rounded up to whole stride groups: nothing for this wave
+  const uint32_t wit0 = wb.first;                      // MODE 1 runs with stride 1
   __shared__ uint32_t ncf[W];      // VERIFY: an input slot of the body is not a plain 32-bit value
   if (lane < W) { okf[lane] = 0; domf[lane] = 0; ncf[lane] = 0; }
   if (MODE == 2) __syncthreads();
@@ -808,8 +813,8 @@ __global__ __launch_bounds__(64) void b3w_nova_kernel(const uint32_t *__restrict
     if (lane < W) ncf[lane] |= okf[lane] ? 0u : 1u;
     __syncthreads();
     uint32_t cnt[W];
-    expand_verify<W, WORDS, true>(lds, table, nwit, out, pitch, wit0, n, cnt);
-    publish_counts<W>(cnt, pub, wit0, n, ncf);
+    expand_verify<W, WORDS, true>(lds, table, nwit, out, pitch, wb, n, cnt);
+    publish_counts<W>(cnt, pub, wb, n, ncf);
   } else expand<W, WORDS, true, NT>(lds, table, nwit, out, pitch, wb, n, okf, all_ok);
 }
 
@@ -856,15 +861,18 @@ extern "C" int b3w_launch_verify(int kind, const uint32_t *d_in_slots, uint32_t 
                                  hipStream_t stream) {
   if (n == 0) return 0;
   uint8_t *bodies = const_cast<uint8_t *>(d_bodies);
+  const uint32_t pm = (uint32_t)(pitch >> 5) & 3u, stride = (pitch & 31) ? 1u : pm == 0 ? 1u : pm == 2 ? 2u : 4u;   // WaveBodies
+#define B3W_VGRID(WV) dim3((n + stride * WV - 1) / (stride * WV) * stride)
   if (kind == B3W_KIND_COMP)
-    hipLaunchKernelGGL((b3w_compression_kernel<4, false, 2>), dim3((n + 3) / 4), dim3(64), 0, stream, d_in_slots, n, bodies, pitch,
-                       d_table, nwit, d_mismatch, (int32_t *)nullptr, 1u);
+    hipLaunchKernelGGL((b3w_compression_kernel<4, false, 2>), B3W_VGRID(4), dim3(64), 0, stream, d_in_slots, n, bodies, pitch,
+                       d_table, nwit, d_mismatch, (int32_t *)nullptr, stride);
   else if (kind == B3W_KIND_NOVA_O2)
-    hipLaunchKernelGGL((b3w_nova_kernel<B3W_KIND_NOVA_O2, 2, false, 2>), dim3((n + 1) / 2), dim3(64), 0, stream, d_in_slots, n,
-                       bodies, pitch, d_table, nwit, d_mismatch, (int32_t *)nullptr, (const uint32_t *)d_aux, 1u);
+    hipLaunchKernelGGL((b3w_nova_kernel<B3W_KIND_NOVA_O2, 2, false, 2>), B3W_VGRID(2), dim3(64), 0, stream, d_in_slots, n,
+                       bodies, pitch, d_table, nwit, d_mismatch, (int32_t *)nullptr, (const uint32_t *)d_aux, stride);
   else
-    hipLaunchKernelGGL((b3w_nova_kernel<B3W_KIND_NOVA_O1, 2, false, 2>), dim3((n + 1) / 2), dim3(64), 0, stream, d_in_slots, n,
-                       bodies, pitch, d_table, nwit, d_mismatch, (int32_t *)nullptr, (const uint32_t *)d_aux, 1u);
+    hipLaunchKernelGGL((b3w_nova_kernel<B3W_KIND_NOVA_O1, 2, false, 2>), B3W_VGRID(2), dim3(64), 0, stream, d_in_slots, n,
+                       bodies, pitch, d_table, nwit, d_mismatch, (int32_t *)nullptr, (const uint32_t *)d_aux, stride);
+#undef B3W_VGRID
   return (int)hipGetLastError();
 }
 

@@ -50,4 +50,18 @@ def test_all_alignments_bodies_exact_and_gaps_untouched(circuit, variants):
                     assert np.array_equal(got, want[i]), (variant, pad, base_off, i, np.nonzero(got != want[i])[0][:8])
                     gap = host[lo + i * pitch + body: lo + (i + 1) * pitch] if i + 1 < n else host[lo + i * pitch + body:]
                     assert (gap == FILL).all(), (variant, pad, base_off, i, "bytes after the body were written")
+                if variant == variants[0]:
+                    # the on-device consumer reads with the same line-aligned tiles: clean bodies verify clean, and a
+                    # flipped bit in the first / last slot of a body (the masked lanes' neighbours) is caught
+                    d_mm = torch.full((n,), -1, dtype=torch.int32, device=dev)
+                    s = torch.cuda.current_stream().cuda_stream
+                    ctx.verify_device(buf.data_ptr() + lo, n, pitch, d_mm.data_ptr(), s)
+                    torch.cuda.synchronize()
+                    assert int(d_mm.abs().sum().item()) == 0, (pad, base_off)
+                    buf[lo + 5 * pitch] ^= 1                                  # slot 0 of body 5
+                    buf[lo + 9 * pitch + body - 32] ^= 1                      # last slot of body 9
+                    ctx.verify_device(buf.data_ptr() + lo, n, pitch, d_mm.data_ptr(), s)
+                    torch.cuda.synchronize()
+                    mm = d_mm.cpu().numpy()
+                    assert mm[5] == 1 and mm[9] == 1 and mm.sum() == 2, (pad, base_off, mm[:12])
         ctx.close()
