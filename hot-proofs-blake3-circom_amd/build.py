@@ -38,7 +38,7 @@ def build_lib(force=False, extra_flags=()):
         [os.path.join(ROOT, "include", "b3wit.h")]
     if force or _newer(LIB, deps):
         _run([hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared", "-x", "hip",
-              "-Wall", "-Wno-unused-function", *extra_flags, "-o", LIB, *srcs])
+              "-Wall", "-Wno-unused-function", *extra_flags, "-o", LIB, *srcs, "-ldl"])
     return LIB
 
 

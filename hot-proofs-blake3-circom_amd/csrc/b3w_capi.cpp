@@ -853,6 +853,97 @@ int32_t b3w_chain_plan_parents_device(b3w_ctx *ctx, const uint32_t *d_levels, ui
   return rc ? hip_fail(ctx, (hipError_t)rc, "plan parents launch") : B3W_OK;
 }
 
+// ---------------------------------------------------------------- multi-GPU exchange (RCCL, loaded at run time)
+}  // extern "C"
+
+#include <dlfcn.h>
+
+struct b3w_comm {
+  b3w_ctx *ctx = nullptr;
+  void *comm = nullptr;          // ncclComm_t
+  int32_t rank = 0, nranks = 1;
+};
+
+namespace {
+struct RcclId { char b[128]; };  // ncclUniqueId (rccl.h: NCCL_UNIQUE_ID_BYTES = 128, passed by value)
+struct Rccl {                    // the five entry points used, with rccl.h's signatures
+  void *so = nullptr;
+  int (*GetUniqueId)(void *id) = nullptr;
+  int (*CommInitRank)(void **comm, int nranks, RcclId id, int rank) = nullptr;
+  int (*AllGather)(const void *send, void *recv, size_t count, int dtype, void *comm, hipStream_t stream) = nullptr;
+  int (*CommDestroy)(void *comm) = nullptr;
+  const char *(*GetErrorString)(int) = nullptr;
+  std::string err;
+} rccl;
+
+bool load_rccl() {
+  if (rccl.so) return true;
+  void *so = nullptr;
+  for (const char *name : {"librccl.so", "librccl.so.1"}) if (!so) so = dlopen(name, RTLD_NOW | RTLD_NOLOAD);   // one already in the process
+  for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) if (!so) so = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+  if (!so) { rccl.err = std::string("cannot load librccl: ") + dlerror(); return false; }
+  rccl.GetUniqueId = (decltype(rccl.GetUniqueId))dlsym(so, "ncclGetUniqueId");
+  rccl.CommInitRank = (decltype(rccl.CommInitRank))dlsym(so, "ncclCommInitRank");
+  rccl.AllGather = (decltype(rccl.AllGather))dlsym(so, "ncclAllGather");
+  rccl.CommDestroy = (decltype(rccl.CommDestroy))dlsym(so, "ncclCommDestroy");
+  rccl.GetErrorString = (decltype(rccl.GetErrorString))dlsym(so, "ncclGetErrorString");
+  if (!rccl.GetUniqueId || !rccl.CommInitRank || !rccl.AllGather || !rccl.CommDestroy || !rccl.GetErrorString) { rccl.err = "librccl lacks an ncclAllGather entry point"; return false; }
+  rccl.so = so;
+  return true;
+}
+}  // namespace
+
+extern "C" {
+
+int32_t b3w_comm_unique_id(uint8_t id[B3W_COMM_ID_BYTES]) {
+  if (!id) return B3W_E_BAD_ARGUMENT;
+  if (!load_rccl()) return B3W_E_RCCL;
+  return rccl.GetUniqueId(id) == 0 ? B3W_OK : B3W_E_RCCL;
+}
+
+int32_t b3w_comm_create(b3w_ctx *ctx, const uint8_t id[B3W_COMM_ID_BYTES], int32_t rank, int32_t nranks, b3w_comm **out) {
+  if (!ctx || !id || !out || nranks < 1 || rank < 0 || rank >= nranks) return B3W_E_BAD_ARGUMENT;
+  *out = nullptr;
+  if (!load_rccl()) { ctx->last_error = rccl.err; return B3W_E_RCCL; }
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  RcclId uid;
+  memcpy(uid.b, id, 128);
+  void *comm = nullptr;
+  const int rc = rccl.CommInitRank(&comm, nranks, uid, rank);
+  if (rc != 0) { ctx->last_error = std::string("ncclCommInitRank: ") + rccl.GetErrorString(rc); return B3W_E_RCCL; }
+  b3w_comm *c = new b3w_comm;
+  c->ctx = ctx; c->comm = comm; c->rank = rank; c->nranks = nranks;
+  *out = c;
+  return B3W_OK;
+}
+
+void b3w_comm_destroy(b3w_comm *c) {
+  if (!c) return;
+  if (c->comm && rccl.CommDestroy) (void)rccl.CommDestroy(c->comm);
+  delete c;
+}
+
+int32_t b3w_comm_allgather(b3w_comm *c, const void *d_send, void *d_recv, uint64_t bytes_per_rank, void *stream) {
+  if (!c || !d_send || !d_recv || !bytes_per_rank) return B3W_E_BAD_ARGUMENT;
+  const int rc = rccl.AllGather(d_send, d_recv, (size_t)bytes_per_rank, /* ncclInt8 */ 0, c->comm, (hipStream_t)stream);
+  if (rc != 0) { c->ctx->last_error = std::string("ncclAllGather: ") + rccl.GetErrorString(rc); return B3W_E_RCCL; }
+  return B3W_OK;
+}
+
+int32_t b3w_batch_allgather_public(b3w_batch *b, b3w_comm *c, uint32_t *host_all) {
+  if (!b || !c || !host_all || !b->n) return B3W_E_BAD_ARGUMENT;
+  b3w_ctx *ctx = b->ctx;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const uint64_t per = (uint64_t)b->n * ctx->desc.npub * 4;
+  void *d_all = nullptr;
+  HIP_TRY(ctx, hipMalloc(&d_all, per * c->nranks));
+  int32_t rc = b3w_comm_allgather(c, b->d_pub, d_all, per, nullptr);
+  hipError_t e = rc == B3W_OK ? hipMemcpy(host_all, d_all, per * c->nranks, hipMemcpyDeviceToHost) : hipSuccess;
+  (void)hipFree(d_all);
+  if (rc) return rc;
+  return e == hipSuccess ? B3W_OK : hip_fail(ctx, e, "hipMemcpy(gathered public outputs)");
+}
+
 // ---------------------------------------------------------------- chained mode: native driver
 }  // extern "C"
 

@@ -46,6 +46,10 @@ struct Api {
   decltype(&b3w_chain_run_parents) chain_run_parents;
   decltype(&b3w_chain_info) chain_info;
   decltype(&b3w_chain_outputs) chain_outputs;
+  decltype(&b3w_comm_unique_id) comm_unique_id;
+  decltype(&b3w_comm_create) comm_create;
+  decltype(&b3w_comm_destroy) comm_destroy;
+  decltype(&b3w_batch_allgather_public) batch_allgather_public;
   std::string err;
 } api;
 
@@ -69,6 +73,7 @@ bool load_api() {
   SYM(write_wtns_header) SYM(last_error) SYM(public_words) SYM(batch_alloc) SYM(batch_free) SYM(batch_run)
   SYM(batch_outputs) SYM(batch_fetch) SYM(batch_write_wtns) SYM(batch_verify) SYM(batch_placement) SYM(bodies_trim)
   SYM(chain_create) SYM(chain_destroy) SYM(chain_run_leaves) SYM(chain_run_parents) SYM(chain_info) SYM(chain_outputs)
+  SYM(comm_unique_id) SYM(comm_create) SYM(comm_destroy) SYM(batch_allgather_public)
 #undef SYM
   api.so = so;
   return true;
@@ -77,7 +82,9 @@ bool load_api() {
 struct Handle {
   b3w_ctx *ctx = nullptr;
   b3w_batch *batch = nullptr;
-  uint32_t batch_cap = 0;
+  uint32_t batch_cap = 0, batch_n = 0;
+  b3w_comm *comm = nullptr;
+  int32_t nranks = 1;
 };
 
 #define NAPI_OK(call)                                                   \
@@ -109,6 +116,7 @@ Handle *get_handle(napi_env env, napi_value v) {
 
 void finalize_handle(napi_env, void *data, void *) {
   Handle *h = (Handle *)data;
+  if (h->comm) api.comm_destroy(h->comm);
   if (h->batch) api.batch_free(h->batch);
   if (h->ctx) api.destroy(h->ctx);
   delete h;
@@ -260,6 +268,7 @@ napi_value BatchRun(napi_env env, napi_callback_info info) {
   }
   int32_t rc = api.batch_run(h->batch, (const uint32_t *)p, n, nullptr);
   if (rc != B3W_OK) return throw_status(env, h, rc, "b3w_batch_run failed");
+  h->batch_n = n;
   const uint32_t npub = api.public_words(h->ctx);
   void *pp, *ps; napi_value abp, abs_, o, v;
   NAPI_OK(napi_create_arraybuffer(env, (size_t)n * npub * 4, &pp, &abp));
@@ -396,6 +405,54 @@ napi_value ChainFold(napi_env env, napi_callback_info info) {
   return o;
 }
 
+// commUniqueId() -> Uint8Array(128): rank 0 creates it and hands it to the other ranks (file, socket, env)
+napi_value CommUniqueId(napi_env env, napi_callback_info) {
+  if (!load_api()) { napi_throw_error(env, nullptr, api.err.c_str()); return nullptr; }
+  void *p; napi_value ab, out;
+  NAPI_OK(napi_create_arraybuffer(env, B3W_COMM_ID_BYTES, &p, &ab));
+  const int32_t rc = api.comm_unique_id((uint8_t *)p);
+  if (rc != B3W_OK) return throw_status(env, nullptr, rc, "b3wit: librccl not available");
+  NAPI_OK(napi_create_typedarray(env, napi_uint8_array, B3W_COMM_ID_BYTES, ab, 0, &out));
+  return out;
+}
+
+// commCreate(handle, id: Uint8Array(128), rank, nranks): this handle's device joins the RCCL communicator
+napi_value CommCreate(napi_env env, napi_callback_info info) {
+  size_t argc = 4; napi_value argv[4];
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+  Handle *h = get_handle(env, argv[0]);
+  if (!h) return nullptr;
+  napi_typedarray_type t; napi_value ab; size_t off, len; void *p;
+  NAPI_OK(napi_get_typedarray_info(env, argv[1], &t, &len, &p, &ab, &off));
+  if (t != napi_uint8_array || len != B3W_COMM_ID_BYTES) { napi_throw_type_error(env, nullptr, "id: Uint8Array(128) from commUniqueId()"); return nullptr; }
+  int32_t rank = 0, nranks = 1;
+  NAPI_OK(napi_get_value_int32(env, argv[2], &rank));
+  NAPI_OK(napi_get_value_int32(env, argv[3], &nranks));
+  if (h->comm) { api.comm_destroy(h->comm); h->comm = nullptr; }
+  const int32_t rc = api.comm_create(h->ctx, (const uint8_t *)p, rank, nranks, &h->comm);
+  if (rc != B3W_OK) return throw_status(env, h, rc, "b3w_comm_create failed");
+  h->nranks = nranks;
+  napi_value u;
+  napi_get_undefined(env, &u);
+  return u;
+}
+
+// batchAllgatherPublic(handle) -> Uint32Array(nranks * n * publicWords): the last batchRun's public outputs of every rank
+napi_value BatchAllgatherPublic(napi_env env, napi_callback_info info) {
+  size_t argc = 1; napi_value argv[1];
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+  Handle *h = get_handle(env, argv[0]);
+  if (!h) return nullptr;
+  if (!h->batch || !h->comm || !h->batch_n) { napi_throw_error(env, nullptr, "batchAllgatherPublic needs commCreate and a batchRun"); return nullptr; }
+  const size_t words = (size_t)h->nranks * h->batch_n * api.public_words(h->ctx);
+  void *p; napi_value ab, out;
+  NAPI_OK(napi_create_arraybuffer(env, words * 4, &p, &ab));
+  const int32_t rc = api.batch_allgather_public(h->batch, h->comm, (uint32_t *)p);
+  if (rc != B3W_OK) return throw_status(env, h, rc, "b3w_batch_allgather_public failed");
+  NAPI_OK(napi_create_typedarray(env, napi_uint32_array, words, ab, 0, &out));
+  return out;
+}
+
 napi_value AbiVersion(napi_env env, napi_callback_info) {
   if (!load_api()) { napi_throw_error(env, nullptr, api.err.c_str()); return nullptr; }
   napi_value out;
@@ -418,6 +475,9 @@ napi_value Init(napi_env env, napi_value exports) {
       {"batchVerify", nullptr, BatchVerify, nullptr, nullptr, nullptr, napi_default, nullptr},
       {"batchPlacement", nullptr, BatchPlacement, nullptr, nullptr, nullptr, napi_default, nullptr},
       {"chainFold", nullptr, ChainFold, nullptr, nullptr, nullptr, napi_default, nullptr},
+      {"commUniqueId", nullptr, CommUniqueId, nullptr, nullptr, nullptr, napi_default, nullptr},
+      {"commCreate", nullptr, CommCreate, nullptr, nullptr, nullptr, napi_default, nullptr},
+      {"batchAllgatherPublic", nullptr, BatchAllgatherPublic, nullptr, nullptr, nullptr, napi_default, nullptr},
   };
   napi_define_properties(env, exports, sizeof props / sizeof props[0], props);
   return exports;

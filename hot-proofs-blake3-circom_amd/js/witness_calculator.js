@@ -44,6 +44,10 @@ module.exports = async function builder(code, options) {
   return new WitnessCalculator(handle, options, CIRCUITS[circuit]);
 };
 module.exports.CIRCUITS = CIRCUITS;
+// Multi-GPU (one Node process per GPU, B3WIT_DEVICE = rank): rank 0 calls commUniqueId() and hands the 128 bytes to
+// the other ranks; every rank then calls wc.joinRanks(id, rank, nranks).  After that a batch's
+// allgatherPublic() returns the public outputs (h_out ...) of every rank's batch — RCCL over xGMI.
+module.exports.commUniqueId = () => native().commUniqueId();
 
 class WitnessCalculator {
   constructor(handle, sanityCheck, circuitName) {
@@ -169,8 +173,17 @@ class WitnessCalculator {
     // stream every witness of the batch to <dir>/<prefix><index>.wtns (same bytes as calculateWTNSBin)
     r.writeWtns = (dir, prefix, first, count) =>
       nat.batchWriteWtns(this.instance, first || 0, count === undefined ? r.n - (first || 0) : count, dir, prefix || "witness_");
+    // every rank's public outputs of this batch (needs wc.joinRanks first; all ranks run the same batch size)
+    r.allgatherPublic = () => nat.batchAllgatherPublic(this.instance);
     r.placement = nat.batchPlacement(this.instance);   // "mixed": the body buffer alternates two classes of HBM
     return r;
+  }
+
+  // ---- extension: this calculator's GPU joins an RCCL communicator (see commUniqueId above)
+  joinRanks(id, rank, nranks) {
+    native().commCreate(this.instance, id, rank, nranks);
+    this.rank = rank;
+    this.nranks = nranks;
   }
 
   // ---- extension (nova circuits): chained mode.  preimage -> the step witnesses of every chunk path, what

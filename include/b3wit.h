@@ -41,6 +41,7 @@ extern "C" {
 #define B3W_E_DOMAIN             103 /* batch status only: record outside the batch kernels' domain (DESIGN.md "Input domain");
                                         b3w_calc_witness evaluates such inputs with the exact kernel instead */
 #define B3W_E_NOT_ALL_INPUTS     104 /* WC:166-168 "Not all inputs have been set" */
+#define B3W_E_RCCL               105 /* librccl missing or a collective failed (b3w_last_error has the text) */
 
 typedef struct b3w_ctx b3w_ctx;
 typedef struct b3w_batch b3w_batch;
@@ -205,6 +206,25 @@ int32_t b3w_chain_tree_device(b3w_ctx *ctx, uint32_t *d_levels, uint64_t n_chunk
  * d_records + ((c - first_chunk)*log2(n) + j)*32 words. */
 int32_t b3w_chain_plan_parents_device(b3w_ctx *ctx, const uint32_t *d_levels, uint64_t n_chunks, uint64_t preimage_len,
                                       uint64_t first_chunk, uint32_t n_chunks_local, uint32_t *d_records, void *stream);
+
+/* ---- multi-GPU exchange: RCCL over xGMI, for hosts that do not bring their own collectives ------------
+ * One process per GPU.  Witness bodies never leave the GPU that produced them; what the fold needs
+ * from every rank are the per-step public outputs (h_out ...: 15 or 16 words per step) and, in chained mode, the
+ * chunk chaining values (8 words per chunk).  b3w_comm_allgather is ncclAllGather on the caller's stream.
+ * librccl is loaded at run time on first use (an RCCL already loaded into the process is reused).
+ *   rank 0:  b3w_comm_unique_id(id)  -> hand the 128 bytes to the other ranks (file, socket, environment)
+ *   all:     b3w_comm_create(ctx, id, rank, nranks, &comm)
+ *            b3w_comm_allgather(comm, d_local, d_all, bytes_per_rank, stream)     d_all = nranks * bytes_per_rank
+ * The Python harness uses torch.distributed ("nccl" = RCCL) for the same exchange instead. */
+typedef struct b3w_comm b3w_comm;
+#define B3W_COMM_ID_BYTES 128
+int32_t b3w_comm_unique_id(uint8_t id[B3W_COMM_ID_BYTES]);
+int32_t b3w_comm_create(b3w_ctx *ctx, const uint8_t id[B3W_COMM_ID_BYTES], int32_t rank, int32_t nranks, b3w_comm **out);
+void b3w_comm_destroy(b3w_comm *comm);
+int32_t b3w_comm_allgather(b3w_comm *comm, const void *d_send, void *d_recv, uint64_t bytes_per_rank, void *stream);
+/* The public outputs of the last b3w_batch_run of every rank (all ranks ran the same number n of witnesses):
+ * host_all receives nranks * n * public_words u32 in rank order.  Device-side gather + one D2H. */
+int32_t b3w_batch_allgather_public(b3w_batch *batch, b3w_comm *comm, uint32_t *host_all);
 
 /* ---- chained mode: the whole pass, natively ---------------------------------------------------
  * What rust_fold/src/main.rs:41-203 does one step at a time for one chunk path, for ALL steps of the chunk range

@@ -44,3 +44,34 @@ def test_public_exchange_over_rccl_single_rank():
         ctx.close()
     finally:
         dist.destroy_process_group()
+
+
+def test_native_rccl_allgather_single_rank():
+    """b3w_comm_* (the C-ABI's own RCCL exchange, for hosts without torch.distributed — Node, C, Rust): a one-rank
+    communicator on the test box's GPU gathers a batch's public outputs; librccl is loaded at run time."""
+    import ctypes
+    m = T.pkg()
+    L = m.lib()
+    ctx = m.Context("compression", 0)
+    uid = (ctypes.c_uint8 * 128)()
+    assert L.b3w_comm_unique_id(uid) == 0, ctx.last_error()
+    comm = ctypes.c_void_p()
+    assert L.b3w_comm_create(ctx.handle, uid, 0, 1, ctypes.byref(comm)) == 0, ctx.last_error()
+    n = 256
+    recs = m.workloads.config2_compression(n, first=31)
+    dev = torch.device("cuda", 0)
+    d_recs = torch.from_numpy(recs.view(np.int32)).to(dev)
+    d_pub = torch.zeros((n, 16), dtype=torch.int32, device=dev)
+    d_all = torch.full((n, 16), -1, dtype=torch.int32, device=dev)
+    d_bodies = torch.empty(n * ctx.body_bytes, dtype=torch.uint8, device=dev)
+    s = torch.cuda.current_stream().cuda_stream
+    ctx.run_device(d_recs.data_ptr(), n, d_bodies.data_ptr(), 0, d_pub.data_ptr(), 0, s)
+    assert L.b3w_comm_allgather(comm, d_pub.data_ptr(), d_all.data_ptr(), n * 16 * 4, s) == 0, ctx.last_error()
+    torch.cuda.synchronize()
+    assert torch.equal(d_all, d_pub)
+    _, bodies = T.oracle_batch_u32("compression", recs[:4])
+    want = bodies.reshape(4, -1, 32)[:, 1:17, :4].copy().view(np.uint32).reshape(4, 16)
+    assert np.array_equal(d_all[:4].cpu().numpy().view(np.uint32), want)
+    assert L.b3w_comm_create(ctx.handle, uid, 3, 2, ctypes.byref(ctypes.c_void_p())) == 100      # rank outside [0, nranks)
+    L.b3w_comm_destroy(comm)
+    ctx.close()

@@ -218,3 +218,29 @@ def test_js_fold_preimage_matches_blake3_and_python_driver(tmp_path):
         assert out[name]["pub"] == hashlib.sha256(py["public"].cpu().numpy().tobytes()).hexdigest(), name
     assert out["complete"]["nPar"] == 16 * 4 and out["ragged"]["nPar"] == 0 and out["tiny"]["nLeaf"] == 1
     ctx.close()
+
+
+@needs_node
+@pytest.mark.gpu
+def test_js_rccl_exchange_single_rank():
+    """commUniqueId / wc.joinRanks / batch.allgatherPublic over the C-ABI's RCCL exchange (one rank on the test box)."""
+    g = T.golden("compression")
+    cases = [c for c in g["cases"] if "error" not in c and T.is_canonical_u32("compression", c["input"])][:4]
+    r = _node("""
+      const builder = require('./hot-proofs-blake3-circom_amd/js/witness_calculator.js');
+      (async () => {
+        const cases = JSON.parse(process.argv[1]);
+        const wc = await builder('compression');
+        const id = builder.commUniqueId();
+        wc.joinRanks(id, 0, 1);
+        const recs = new Uint32Array(28 * cases.length);
+        cases.forEach((c, k) => { const v = [].concat(c.input.h, c.input.m, c.input.t, [c.input.b, c.input.d]); v.forEach((x, j) => recs[28 * k + j] = Number(x)); });
+        const b = await wc.calculateWitnessBatch(recs);
+        const all = b.allgatherPublic();
+        console.log(JSON.stringify({idLen: id.length, n: b.n, same: Array.from(all).join() === Array.from(b.publicOutputs).join(), first: Array.from(all.slice(0, 15)).map(String)}));
+      })().catch(e => { console.error(e); process.exit(1); });
+    """, json.dumps(cases))
+    assert r.returncode == 0, r.stderr
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out["idLen"] == 128 and out["n"] == 4 and out["same"] is True
+    assert out["first"] == [str(x) for x in cases[0]["first16"][1:]]
