@@ -107,6 +107,8 @@ def lib():
         "b3w_chain_destroy": (None, [vp]),
         "b3w_chain_run_leaves": (i32, [vp, vp, vp, vp, vp]),
         "b3w_chain_run_parents": (i32, [vp, vp, vp, vp, vp]),
+        "b3w_chain_shard": (None, [u64, i32, i32, ctypes.POINTER(u64), ctypes.POINTER(u32)]),
+        "b3w_chain_run_parents_sharded": (i32, [vp, vp, vp, vp, vp]),
         "b3w_chain_info": (i32, [vp, ctypes.POINTER(u64), ctypes.POINTER(u64), ctypes.POINTER(u64), ctypes.POINTER(u32), ctypes.POINTER(i32)]),
         "b3w_chain_outputs": (i32, [vp, vp, vp, vp, vp]),
         "b3w_chain_records": (vp, [vp]),
@@ -129,7 +131,7 @@ EXPORTED_SYMBOLS = ("b3w_abi_version", "b3w_identify_wasm", "b3w_create", "b3w_d
                     "b3w_batch_time_device", "b3w_batch_verify_device", "b3w_batch_verify", "b3w_batch_write_wtns", "b3w_batch_autotune_device", "b3w_bodies_alloc", "b3w_bodies_free", "b3w_bodies_trim", "b3w_batch_placement", "b3w_chain_num_chunks", "b3w_chain_num_leaf_steps", "b3w_chain_path_len",
                     "b3w_chain_plan_leaves_device", "b3w_chain_tree_device", "b3w_chain_plan_parents_device",
                     "b3w_comm_unique_id", "b3w_comm_create", "b3w_comm_destroy", "b3w_comm_allgather", "b3w_batch_allgather_public",
-                    "b3w_chain_create", "b3w_chain_destroy", "b3w_chain_run_leaves", "b3w_chain_run_parents", "b3w_chain_info",
+                    "b3w_chain_create", "b3w_chain_destroy", "b3w_chain_run_leaves", "b3w_chain_run_parents", "b3w_chain_shard", "b3w_chain_run_parents_sharded", "b3w_chain_info",
                     "b3w_chain_outputs", "b3w_chain_records", "b3w_chain_public", "b3w_chain_status", "b3w_chain_local_cvs", "b3w_chain_root")
 
 

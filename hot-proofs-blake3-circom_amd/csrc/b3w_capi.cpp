@@ -1104,6 +1104,41 @@ int32_t b3w_chain_run_parents(b3w_chain *c, const uint32_t *d_all_chunk_cvs, b3w
   return chain_run_steps(c, c->n_leaf, c->n_par, consumer, user, stream);
 }
 
+void b3w_chain_shard(uint64_t n_chunks, int32_t rank, int32_t nranks, uint64_t *first_chunk, uint32_t *n_chunks_local) {
+  if (nranks < 1) nranks = 1;
+  const uint64_t q = n_chunks / (uint64_t)nranks, r = n_chunks % (uint64_t)nranks, k = (uint64_t)(rank < 0 ? 0 : rank);
+  if (first_chunk) *first_chunk = k * q + (k < r ? k : r);
+  if (n_chunks_local) *n_chunks_local = (uint32_t)(q + (k < r ? 1 : 0));
+}
+
+int32_t b3w_chain_run_parents_sharded(b3w_chain *c, b3w_comm *comm, b3w_batch_consumer consumer, void *user, void *stream) {
+  if (!c || !comm) return B3W_E_BAD_ARGUMENT;
+  b3w_ctx *ctx = c->ctx;
+  uint64_t first = 0; uint32_t count = 0;
+  b3w_chain_shard(c->n_chunks, comm->rank, comm->nranks, &first, &count);
+  if (first != c->first_chunk || count != c->nl) { ctx->last_error = "the chain was not created with this rank's b3w_chain_shard range"; return B3W_E_BAD_ARGUMENT; }
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  hipStream_t st = (hipStream_t)stream;
+  const uint64_t mx = (c->n_chunks + comm->nranks - 1) / comm->nranks;       // largest shard
+  uint32_t *d_pad = nullptr, *d_gath = nullptr, *d_all = nullptr;
+  HIP_TRY(ctx, hipMalloc((void **)&d_pad, mx * 32));
+  HIP_TRY(ctx, hipMalloc((void **)&d_gath, mx * 32 * comm->nranks));
+  HIP_TRY(ctx, hipMalloc((void **)&d_all, c->n_chunks * 32));
+  hipError_t e = hipMemsetAsync(d_pad, 0, mx * 32, st);
+  if (e == hipSuccess && c->nl) e = hipMemcpyAsync(d_pad, c->d_cvs, (uint64_t)c->nl * 32, hipMemcpyDeviceToDevice, st);
+  int32_t rc = e == hipSuccess ? b3w_comm_allgather(comm, d_pad, d_gath, mx * 32, stream) : hip_fail(ctx, e, "chunk CV staging");
+  for (int32_t r = 0; r < comm->nranks && rc == B3W_OK; r++) {                 // drop the padding: global chunk order
+    uint64_t f = 0; uint32_t k = 0;
+    b3w_chain_shard(c->n_chunks, r, comm->nranks, &f, &k);
+    if (k && (e = hipMemcpyAsync(d_all + f * 8, d_gath + (uint64_t)r * mx * 8, (uint64_t)k * 32, hipMemcpyDeviceToDevice, st)) != hipSuccess)
+      rc = hip_fail(ctx, e, "chunk CV compaction");
+  }
+  if (rc == B3W_OK) rc = b3w_chain_run_parents(c, d_all, consumer, user, stream);
+  (void)hipStreamSynchronize(st);                       // the temporaries are read by work queued above
+  (void)hipFree(d_pad); (void)hipFree(d_gath); (void)hipFree(d_all);
+  return rc;
+}
+
 int32_t b3w_chain_info(const b3w_chain *c, uint64_t *n_leaf_steps, uint64_t *n_parent_steps, uint64_t *n_chunks, uint32_t *path_len,
                        int32_t *placement) {
   if (!c) return B3W_E_BAD_ARGUMENT;

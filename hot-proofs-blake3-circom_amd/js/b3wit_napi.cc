@@ -46,6 +46,8 @@ struct Api {
   decltype(&b3w_chain_run_parents) chain_run_parents;
   decltype(&b3w_chain_info) chain_info;
   decltype(&b3w_chain_outputs) chain_outputs;
+  decltype(&b3w_chain_shard) chain_shard;
+  decltype(&b3w_chain_run_parents_sharded) chain_run_parents_sharded;
   decltype(&b3w_comm_unique_id) comm_unique_id;
   decltype(&b3w_comm_create) comm_create;
   decltype(&b3w_comm_destroy) comm_destroy;
@@ -73,7 +75,7 @@ bool load_api() {
   SYM(write_wtns_header) SYM(last_error) SYM(public_words) SYM(batch_alloc) SYM(batch_free) SYM(batch_run)
   SYM(batch_outputs) SYM(batch_fetch) SYM(batch_write_wtns) SYM(batch_verify) SYM(batch_placement) SYM(bodies_trim)
   SYM(chain_create) SYM(chain_destroy) SYM(chain_run_leaves) SYM(chain_run_parents) SYM(chain_info) SYM(chain_outputs)
-  SYM(comm_unique_id) SYM(comm_create) SYM(comm_destroy) SYM(batch_allgather_public)
+  SYM(chain_shard) SYM(chain_run_parents_sharded) SYM(comm_unique_id) SYM(comm_create) SYM(comm_destroy) SYM(batch_allgather_public)
 #undef SYM
   api.so = so;
   return true;
@@ -84,7 +86,7 @@ struct Handle {
   b3w_batch *batch = nullptr;
   uint32_t batch_cap = 0, batch_n = 0;
   b3w_comm *comm = nullptr;
-  int32_t nranks = 1;
+  int32_t rank = 0, nranks = 1;
 };
 
 #define NAPI_OK(call)                                                   \
@@ -376,10 +378,13 @@ napi_value ChainFold(napi_env env, napi_callback_info info) {
   const uint64_t nchunks = (len + 1023) / 1024;
   if (nchunks > 0xFFFFFFFFull) { napi_throw_range_error(env, nullptr, "preimage too large for one pass"); return nullptr; }
   b3w_chain *c = nullptr;
-  int32_t rc = api.chain_create(h->ctx, len, 0, (uint32_t)nchunks, batch_steps, ring, with_parents ? 1 : 0, &c);
+  uint64_t first = 0; uint32_t count = (uint32_t)nchunks;
+  if (h->comm) api.chain_shard(nchunks, h->rank, h->nranks, &first, &count);     // after commCreate: this rank's share of the chunks
+  int32_t rc = api.chain_create(h->ctx, len, first, count, batch_steps, ring, with_parents ? 1 : 0, &c);
   if (rc != B3W_OK) return throw_status(env, h, rc, "b3w_chain_create failed");
   rc = api.chain_run_leaves(c, (const uint8_t *)data, nullptr, nullptr, nullptr);
-  if (rc == B3W_OK) rc = api.chain_run_parents(c, nullptr, nullptr, nullptr, nullptr);
+  if (rc == B3W_OK) rc = h->comm ? api.chain_run_parents_sharded(c, h->comm, nullptr, nullptr, nullptr)
+                                 : api.chain_run_parents(c, nullptr, nullptr, nullptr, nullptr);
   uint64_t nleaf = 0, npar = 0, nch = 0; uint32_t plen = 0; int32_t placement = 0;
   api.chain_info(c, &nleaf, &npar, &nch, &plen, &placement);
   const uint64_t rows = nleaf + npar;
@@ -397,6 +402,8 @@ napi_value ChainFold(napi_env env, napi_callback_info info) {
   napi_create_double(env, (double)nleaf, &v); napi_set_named_property(env, o, "nLeafSteps", v);
   napi_create_double(env, (double)npar, &v); napi_set_named_property(env, o, "nParentSteps", v);
   napi_create_double(env, (double)nch, &v); napi_set_named_property(env, o, "nChunks", v);
+  napi_create_double(env, (double)first, &v); napi_set_named_property(env, o, "firstChunk", v);
+  napi_create_uint32(env, count, &v); napi_set_named_property(env, o, "nChunksLocal", v);
   napi_create_uint32(env, plen, &v); napi_set_named_property(env, o, "pathLen", v);
   napi_create_string_utf8(env, placement == B3W_PLACEMENT_MIXED ? "mixed" : "plain", NAPI_AUTO_LENGTH, &v); napi_set_named_property(env, o, "placement", v);
   napi_create_typedarray(env, napi_uint32_array, rows * 15, abp, 0, &v); napi_set_named_property(env, o, "publicOutputs", v);
@@ -431,6 +438,7 @@ napi_value CommCreate(napi_env env, napi_callback_info info) {
   if (h->comm) { api.comm_destroy(h->comm); h->comm = nullptr; }
   const int32_t rc = api.comm_create(h->ctx, (const uint8_t *)p, rank, nranks, &h->comm);
   if (rc != B3W_OK) return throw_status(env, h, rc, "b3w_comm_create failed");
+  h->rank = rank;
   h->nranks = nranks;
   napi_value u;
   napi_get_undefined(env, &u);

@@ -190,6 +190,8 @@ class WitnessCalculator {
   // rust_fold/src/main.rs:41-203 folds one step at a time.  Returns { nLeafSteps, nParentSteps, nChunks, pathLen,
   // placement, publicOutputs: Uint32Array (15 words per step: n_blocks_out block_count_out h_out[8] ...),
   // status: Int32Array, root: Uint32Array(8) = BLAKE3(preimage) as little-endian words, hash: hex string }.
+  // After wc.joinRanks every rank passes the same preimage and gets the steps of ITS chunk range (firstChunk,
+  // nChunksLocal); the chunk chaining values are all-gathered over RCCL so that each rank knows the whole tree.
   async foldPreimage(preimage, opts) {
     opts = opts || {};
     const r = native().chainFold(this.instance, preimage, opts.batchSteps || 16384, opts.ring || 2, opts.withParents !== false);

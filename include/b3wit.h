@@ -250,6 +250,13 @@ int32_t b3w_chain_run_leaves(b3w_chain *chain, const uint8_t *host_preimage /* b
                              b3w_batch_consumer consumer, void *user, void *stream);
 int32_t b3w_chain_run_parents(b3w_chain *chain, const uint32_t *d_all_chunk_cvs /* n_chunks*8 words; NULL = the local ones,
                               single rank */, b3w_batch_consumer consumer, void *user, void *stream);
+/* Contiguous, balanced chunk ranges (the first n_chunks % nranks ranks take one extra chunk): what rank `rank` passes
+ * to b3w_chain_create as first_chunk / n_chunks_local. */
+void b3w_chain_shard(uint64_t n_chunks, int32_t rank, int32_t nranks, uint64_t *first_chunk, uint32_t *n_chunks_local);
+/* b3w_chain_run_parents for a sharded pass: all-gathers the chunk chaining values over `comm` (RCCL, 32 B per chunk,
+ * shards padded to the largest) and continues with the tree and this rank's parent steps.  The chain must have been
+ * created with this rank's b3w_chain_shard range. */
+int32_t b3w_chain_run_parents_sharded(b3w_chain *chain, b3w_comm *comm, b3w_batch_consumer consumer, void *user, void *stream);
 int32_t b3w_chain_info(const b3w_chain *chain, uint64_t *n_leaf_steps, uint64_t *n_parent_steps, uint64_t *n_chunks,
                        uint32_t *path_len, int32_t *placement);
 /* Waits for `stream`, then copies the results to the host: (n_leaf + n_parent) * 15 public-output words, as many

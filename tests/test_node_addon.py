@@ -237,10 +237,21 @@ def test_js_rccl_exchange_single_rank():
         cases.forEach((c, k) => { const v = [].concat(c.input.h, c.input.m, c.input.t, [c.input.b, c.input.d]); v.forEach((x, j) => recs[28 * k + j] = Number(x)); });
         const b = await wc.calculateWitnessBatch(recs);
         const all = b.allgatherPublic();
-        console.log(JSON.stringify({idLen: id.length, n: b.n, same: Array.from(all).join() === Array.from(b.publicOutputs).join(), first: Array.from(all.slice(0, 15)).map(String)}));
+        // sharded chained mode through the same communicator (one rank: its shard is everything)
+        const nv = await builder('nova_vesta', {logDFlags: false});
+        nv.joinRanks(builder.commUniqueId(), 0, 1);
+        const pre = Buffer.alloc(8 * 1024); for (let i = 0; i < pre.length; i++) pre[i] = (i * 7 + 3) % 251;
+        const f = await nv.foldPreimage(pre, {batchSteps: 64});
+        const solo = await (await builder('nova_vesta', {logDFlags: false})).foldPreimage(pre, {batchSteps: 64});
+        const fold = {hash: f.hash, same: f.hash === solo.hash && Array.from(f.publicOutputs).join() === Array.from(solo.publicOutputs).join(),
+                      first: f.firstChunk, local: f.nChunksLocal, par: f.nParentSteps, bad: Array.from(f.status).filter(x => x !== 0).length};
+        console.log(JSON.stringify({idLen: id.length, n: b.n, same: Array.from(all).join() === Array.from(b.publicOutputs).join(), first: Array.from(all.slice(0, 15)).map(String), fold}));
       })().catch(e => { console.error(e); process.exit(1); });
     """, json.dumps(cases))
     assert r.returncode == 0, r.stderr
     out = json.loads(r.stdout.strip().splitlines()[-1])
     assert out["idLen"] == 128 and out["n"] == 4 and out["same"] is True
     assert out["first"] == [str(x) for x in cases[0]["first16"][1:]]
+    import blake3_ref
+    pre = bytes((i * 7 + 3) % 251 for i in range(8 * 1024))
+    assert out["fold"] == {"hash": blake3_ref.blake3(pre).hex(), "same": True, "first": 0, "local": 8, "par": 24, "bad": 0}

@@ -87,3 +87,17 @@ def test_pipelined_public_exchange_two_ranks():
             want = np.concatenate([base + 1000 * r + 100000 * step for r in (0, 1)])
             assert np.array_equal(seen[step], want), (rank, step)
         assert np.array_equal(last, seen[steps - 1])
+
+
+def test_native_shard_ranges_equal_the_python_ones():
+    """b3w_chain_shard (C-ABI, used by the native sharded chained pass) and sharding.shard_range agree."""
+    import ctypes
+    m = T.pkg()
+    L = m.lib()
+    for n in (1, 7, 8, 9, 1024, 16394):
+        for world in (1, 2, 3, 8):
+            for r in range(world):
+                f, k = ctypes.c_uint64(), ctypes.c_uint32()
+                L.b3w_chain_shard(n, r, world, ctypes.byref(f), ctypes.byref(k))
+                s, e = m.sharding.shard_range(n, r, world)
+                assert (f.value, k.value) == (s, e - s), (n, world, r)
