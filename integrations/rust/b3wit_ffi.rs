@@ -65,3 +65,42 @@ impl Calculator {
 impl Drop for Calculator {
     fn drop(&mut self) { unsafe { b3w_destroy(self.ctx) } }
 }
+
+// ---- chained mode: what `main.rs:41-203` does one `prove_step` at a time, as one streamed pass ----------------
+// (same caveat: source only).  The fold driver would take `z_{i+1}` of every step from `public()` instead of
+// reading it back from each witness (blake3_circuit.rs:111-123), and hand each batch of bodies to its own
+// consumer (commitment, R1CS check) from the callback while the next batch is being written.
+#[link(name = "b3wit")]
+extern "C" {
+    fn b3w_chain_create(ctx: *mut c_void, preimage_len: u64, first_chunk: u64, n_chunks_local: u32, batch_steps: u32,
+                        ring: u32, with_parents: i32, out: *mut *mut c_void) -> i32;
+    fn b3w_chain_destroy(chain: *mut c_void);
+    fn b3w_chain_run_leaves(chain: *mut c_void, host_preimage: *const u8,
+                            consumer: Option<extern "C" fn(*mut c_void, *const u8, u64, u64, u32, *mut c_void)>,
+                            user: *mut c_void, stream: *mut c_void) -> i32;
+    fn b3w_chain_run_parents(chain: *mut c_void, d_all_chunk_cvs: *const u32,
+                             consumer: Option<extern "C" fn(*mut c_void, *const u8, u64, u64, u32, *mut c_void)>,
+                             user: *mut c_void, stream: *mut c_void) -> i32;
+    fn b3w_chain_info(chain: *const c_void, n_leaf: *mut u64, n_parent: *mut u64, n_chunks: *mut u64, path_len: *mut u32,
+                      placement: *mut i32) -> i32;
+    fn b3w_chain_outputs(chain: *mut c_void, host_public: *mut u32, host_status: *mut i32, host_root: *mut u32,
+                         stream: *mut c_void) -> i32;
+}
+
+/// All step witnesses of `preimage` on one GPU; returns (public outputs: 15 words per step, status per step, BLAKE3 root words).
+pub fn fold_preimage(calc: &mut Calculator, preimage: &[u8]) -> Result<(Vec<u32>, Vec<i32>, [u32; 8]), i32> {
+    let n_chunks = std::cmp::max(1, (preimage.len() as u64 + 1023) / 1024);
+    let mut chain = std::ptr::null_mut();
+    let rc = unsafe { b3w_chain_create(calc.ctx, preimage.len() as u64, 0, n_chunks as u32, 16384, 2, 1, &mut chain) };
+    if rc != 0 { return Err(rc); }
+    let null = std::ptr::null_mut();
+    let mut rc = unsafe { b3w_chain_run_leaves(chain, preimage.as_ptr(), None, null, null) };
+    if rc == 0 { rc = unsafe { b3w_chain_run_parents(chain, std::ptr::null(), None, null, null) }; }
+    let (mut nl, mut np, mut nc, mut pl, mut place) = (0u64, 0u64, 0u64, 0u32, 0i32);
+    unsafe { b3w_chain_info(chain, &mut nl, &mut np, &mut nc, &mut pl, &mut place) };
+    let rows = (nl + np) as usize;
+    let (mut public, mut status, mut root) = (vec![0u32; rows * 15], vec![0i32; rows], [0u32; 8]);
+    if rc == 0 { rc = unsafe { b3w_chain_outputs(chain, public.as_mut_ptr(), status.as_mut_ptr(), root.as_mut_ptr(), null) }; }
+    unsafe { b3w_chain_destroy(chain) };
+    if rc != 0 { Err(rc) } else { Ok((public, status, root)) }
+}
