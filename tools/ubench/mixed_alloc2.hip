@@ -17,6 +17,23 @@ __global__ __launch_bounds__(64) void k_probe(uint8_t *lo, uint8_t *hi, uint64_t
   uint8_t *base = ((i & 1) ? hi : lo) + (uint64_t)(i >> 1) * pitch + lane * 16;
   for (uint32_t g = 0; g < full; ++g) *reinterpret_cast<u32x4 *>(base + (uint64_t)g * 1024) = v;
 }
+// W bodies per wave (stride ST apart), U consecutive 1 KiB groups of one body back to back
+template <int W, int U>
+__global__ __launch_bounds__(64) void k_family(uint8_t *out, uint64_t pitch, uint32_t full, uint32_t n, uint32_t st) {
+  const uint32_t b = blockIdx.x, lane = threadIdx.x;
+  const uint32_t first = (b / st) * (st * W) + b % st;
+  u32x4 v = {lane & 1 ? 0u : 1u, 0, 0, 0};
+  uint8_t *base[W];
+#pragma unroll
+  for (int w = 0; w < W; ++w) base[w] = out + (uint64_t)(first + w * st) * pitch + lane * 16;
+  if (first + (W - 1) * st >= n) return;
+  uint32_t g = 0;
+  for (; g + U <= full; g += U)
+#pragma unroll
+    for (int w = 0; w < W; ++w)
+#pragma unroll
+      for (int u = 0; u < U; ++u) *reinterpret_cast<u32x4 *>(base[w] + (uint64_t)(g + u) * 1024) = v;
+}
 template <int W>
 __global__ __launch_bounds__(64) void k_fused(uint8_t *out, uint64_t pitch, uint32_t full, uint32_t n) {
   const uint32_t wit0 = blockIdx.x * W, lane = threadIdx.x;
@@ -127,6 +144,25 @@ int main(int argc, char **argv) {
   const uint32_t n = (uint32_t)(S / body) & ~3u;
   const double ms = timeit([&] { hipLaunchKernelGGL((k_fused<4>), dim3(n / 4), dim3(64), 0, 0, F, body, full, n); }, 6);
   printf("fused pattern, %u contiguous bodies in natural order on the mixed buffer: %.0f GB/s\n", n, n * (double)body / 1e6 / ms);
+  {
+    auto fam = [&](const char *name, auto launch) {
+      const double t = timeit(launch, 8);
+      printf("  %-44s %7.0f GB/s\n", name, n * (double)body / 1e6 / t);
+    };
+    const uint64_t ap = 771072;   // 128-byte aligned pitch
+    const uint32_t na = (uint32_t)(S / ap) & ~31u;
+    fam("W4 U1 contiguous pitch", [&] { hipLaunchKernelGGL((k_family<4, 1>), dim3(n / 4), dim3(64), 0, 0, F, body, full, n, 1u); });
+    fam("W4 U1 contiguous pitch, stride-4 bodies", [&] { hipLaunchKernelGGL((k_family<4, 1>), dim3(n / 4), dim3(64), 0, 0, F, body, full, n, 4u); });
+    fam("W4 U1 aligned pitch", [&] { hipLaunchKernelGGL((k_family<4, 1>), dim3(na / 4), dim3(64), 0, 0, F, ap, full, na, 1u); });
+    fam("W4 U2 aligned pitch", [&] { hipLaunchKernelGGL((k_family<4, 2>), dim3(na / 4), dim3(64), 0, 0, F, ap, full, na, 1u); });
+    fam("W4 U4 aligned pitch", [&] { hipLaunchKernelGGL((k_family<4, 4>), dim3(na / 4), dim3(64), 0, 0, F, ap, full, na, 1u); });
+    fam("W8 U1 aligned pitch", [&] { hipLaunchKernelGGL((k_family<8, 1>), dim3(na / 8), dim3(64), 0, 0, F, ap, full, na, 1u); });
+    fam("W8 U2 aligned pitch", [&] { hipLaunchKernelGGL((k_family<8, 2>), dim3(na / 8), dim3(64), 0, 0, F, ap, full, na, 1u); });
+    fam("W2 U1 aligned pitch", [&] { hipLaunchKernelGGL((k_family<2, 1>), dim3(na / 2), dim3(64), 0, 0, F, ap, full, na, 1u); });
+    fam("W2 U4 aligned pitch", [&] { hipLaunchKernelGGL((k_family<2, 4>), dim3(na / 2), dim3(64), 0, 0, F, ap, full, na, 1u); });
+    fam("W16 U1 aligned pitch", [&] { hipLaunchKernelGGL((k_family<16, 1>), dim3(na / 16), dim3(64), 0, 0, F, ap, full, na, 1u); });
+    fam("W1 U1 aligned pitch", [&] { hipLaunchKernelGGL((k_family<1, 1>), dim3(na), dim3(64), 0, 0, F, ap, full, na, 1u); });
+  }
   uint8_t *plain;
   CK(hipMalloc((void **)&plain, (size_t)n * body));
   const double mp = timeit([&] { hipLaunchKernelGGL((k_fused<4>), dim3(n / 4), dim3(64), 0, 0, plain, body, full, n); }, 6);
