@@ -33,7 +33,7 @@ def hipcc():
 
 
 def build_lib(force=False, extra_flags=()):
-    srcs = [os.path.join(CSRC, f) for f in ("b3w_kernels.hip", "b3w_exact.hip", "b3w_plan.hip", "b3w_placement.hip", "b3w_capi.cpp")]
+    srcs = [os.path.join(CSRC, f) for f in ("b3w_kernels.hip", "b3w_exact.hip", "b3w_plan.hip", "b3w_placement.hip", "b3w_commit.hip", "b3w_capi.cpp")]
     deps = srcs + [os.path.join(CSRC, f) for f in ("b3w_atoms.h", "b3w_kernels.h", "b3w_layout_tables.inc")] + \
         [os.path.join(ROOT, "include", "b3wit.h")]
     if force or _newer(LIB, deps):

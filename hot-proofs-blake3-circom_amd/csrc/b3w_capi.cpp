@@ -853,6 +853,131 @@ int32_t b3w_chain_plan_parents_device(b3w_ctx *ctx, const uint32_t *d_levels, ui
   return rc ? hip_fail(ctx, (hipError_t)rc, "plan parents launch") : B3W_OK;
 }
 
+// ---------------------------------------------------------------- commitments (on-device consumer #2)
+}  // extern "C"
+
+struct b3w_commit_key {
+  b3w_ctx *ctx = nullptr;
+  B3wCurve curve{};
+  uint32_t first_slot = 0, V = 0;
+  uint32_t *d_vslots = nullptr, *d_points = nullptr;
+};
+
+namespace {
+// 256-bit helpers for the curve constants (host, little-endian u32 limbs)
+bool u256_geq(const uint32_t a[8], const uint32_t b[8]) { for (int i = 7; i >= 0; --i) if (a[i] != b[i]) return a[i] > b[i]; return true; }
+void u256_sub_host(uint32_t a[8], const uint32_t b[8]) {
+  uint64_t br = 0;
+  for (int i = 0; i < 8; i++) { const uint64_t t = (uint64_t)a[i] - b[i] - br; a[i] = (uint32_t)t; br = (t >> 63) & 1; }
+}
+void u256_double_mod(uint32_t a[8], const uint32_t p[8]) {            // a = 2a mod p (a < p < 2^255)
+  uint32_t c = 0;
+  for (int i = 0; i < 8; i++) { const uint32_t n = (a[i] << 1) | c; c = a[i] >> 31; a[i] = n; }
+  if (c || u256_geq(a, p)) u256_sub_host(a, p);
+}
+B3wCurve make_curve(const uint64_t p64[4]) {
+  B3wCurve C{};
+  memcpy(C.p, p64, 32);
+  uint32_t x[8] = {1, 0, 0, 0, 0, 0, 0, 0};
+  for (int i = 0; i < 256; i++) u256_double_mod(x, C.p);
+  memcpy(C.one, x, 32);
+  for (int i = 0; i < 256; i++) u256_double_mod(x, C.p);
+  memcpy(C.r2, x, 32);
+  memcpy(C.pm2, C.p, 32);
+  const uint32_t two[8] = {2, 0, 0, 0, 0, 0, 0, 0};
+  u256_sub_host(C.pm2, two);
+  uint32_t inv = C.p[0];                                             // Newton: inv = p^-1 mod 2^32
+  for (int i = 0; i < 5; i++) inv *= 2u - C.p[0] * inv;
+  C.inv = 0u - inv;
+  return C;
+}
+const uint64_t Q_BN254[4] = {0x3c208c16d87cfd47ull, 0x97816a916871ca8dull, 0xb85045b68181585dull, 0x30644e72e131a029ull};
+const uint64_t P_VESTA_BASE[4] = {0x992d30ed00000001ull, 0x224698fc094cf91bull, 0x0ull, 0x4000000000000000ull};
+}  // namespace
+
+extern "C" {
+
+int32_t b3w_commit_key_create(b3w_ctx *ctx, int32_t curve, uint32_t first_slot, const uint8_t *host_generators, b3w_commit_key **out) {
+  if (!ctx || !out || !host_generators || (curve != B3W_CURVE_BN254_G1 && curve != B3W_CURVE_VESTA) || first_slot >= ctx->desc.nwit)
+    return B3W_E_BAD_ARGUMENT;
+  *out = nullptr;
+  std::vector<uint32_t> table;
+  if (!build_slot_table(ctx->desc, table, ctx->last_error)) return B3W_E_BAD_ARGUMENT;
+  const uint32_t nslots = ctx->desc.nwit - first_slot;
+  // virtual slots: one per bit a slot can hold (BIT 1, W32 32, W64 64, W256 256)
+  std::vector<uint32_t> nbits(nslots), first_v(nslots), vslots;
+  for (uint32_t i = 0; i < nslots; i++) {
+    const uint32_t mode = (table[first_slot + i] >> 17) & 3u;
+    nbits[i] = mode == B3W_MODE_BIT ? 1u : mode == B3W_MODE_W32 ? 32u : mode == B3W_MODE_W64 ? 64u : 256u;
+    first_v[i] = (uint32_t)vslots.size();
+    for (uint32_t k = 0; k < nbits[i]; k++) vslots.push_back((first_slot + i) | (k << 19) | ((nbits[i] == 1 ? 1u : 0u) << 27));
+  }
+  b3w_commit_key *key = new b3w_commit_key;
+  key->ctx = ctx;
+  key->curve = make_curve(curve == B3W_CURVE_BN254_G1 ? Q_BN254 : P_VESTA_BASE);
+  key->first_slot = first_slot;
+  key->V = (uint32_t)vslots.size();
+  uint32_t *d_gens = nullptr, *d_first = nullptr, *d_nbits = nullptr;
+  hipError_t e = hipSetDevice(ctx->device);
+  if (e == hipSuccess) e = hipMalloc((void **)&key->d_vslots, vslots.size() * 4);
+  if (e == hipSuccess) e = hipMalloc((void **)&key->d_points, (size_t)key->V * 64);
+  if (e == hipSuccess) e = hipMalloc((void **)&d_gens, (size_t)nslots * 64);
+  if (e == hipSuccess) e = hipMalloc((void **)&d_first, (size_t)nslots * 4);
+  if (e == hipSuccess) e = hipMalloc((void **)&d_nbits, (size_t)nslots * 4);
+  if (e == hipSuccess) e = hipMemcpy(key->d_vslots, vslots.data(), vslots.size() * 4, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(d_gens, host_generators, (size_t)nslots * 64, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(d_first, first_v.data(), (size_t)nslots * 4, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(d_nbits, nbits.data(), (size_t)nslots * 4, hipMemcpyHostToDevice);
+  int rc = e == hipSuccess ? b3w_launch_commit_setup(d_gens, d_first, d_nbits, nslots, key->d_points, &key->curve, nullptr) : 0;
+  if (e == hipSuccess && rc == 0) e = hipDeviceSynchronize();
+  if (d_gens) (void)hipFree(d_gens);
+  if (d_first) (void)hipFree(d_first);
+  if (d_nbits) (void)hipFree(d_nbits);
+  if (e != hipSuccess || rc != 0) {
+    b3w_commit_key_destroy(key);
+    return hip_fail(ctx, e != hipSuccess ? e : (hipError_t)rc, "commitment key set-up");
+  }
+  *out = key;
+  return B3W_OK;
+}
+
+void b3w_commit_key_destroy(b3w_commit_key *key) {
+  if (!key) return;
+  if (key->d_vslots) (void)hipFree(key->d_vslots);
+  if (key->d_points) (void)hipFree(key->d_points);
+  delete key;
+}
+
+int32_t b3w_batch_commit_device(b3w_ctx *ctx, const b3w_commit_key *key, const uint8_t *d_bodies, uint32_t n, uint64_t pitch,
+                                uint8_t *d_points, int32_t *d_status, void *stream) {
+  if (!ctx || !key || key->ctx != ctx || !d_bodies || !d_points) return B3W_E_BAD_ARGUMENT;
+  const uint64_t body = 32ull * ctx->desc.nwit;
+  if (pitch == 0) pitch = body;
+  if (pitch < body || (pitch & 3) || (reinterpret_cast<uintptr_t>(d_bodies) & 3) || (reinterpret_cast<uintptr_t>(d_points) & 15)) {
+    ctx->last_error = "pitch must be >= witness_size*32, bodies 4-byte and points 16-byte aligned";
+    return B3W_E_BAD_ARGUMENT;
+  }
+  const int rc = b3w_launch_commit(d_bodies, n, pitch, key->d_vslots, key->d_points, key->V, d_points, d_status, &key->curve, (hipStream_t)stream);
+  return rc ? hip_fail(ctx, (hipError_t)rc, "commit launch") : B3W_OK;
+}
+
+int32_t b3w_batch_commit(b3w_batch *b, const b3w_commit_key *key, uint8_t *host_points, int32_t *host_status) {
+  if (!b || !key || !host_points) return B3W_E_BAD_ARGUMENT;
+  b3w_ctx *ctx = b->ctx;
+  if (!b->n) return B3W_OK;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  uint8_t *d_pts = nullptr;
+  int32_t *d_st = nullptr;
+  HIP_TRY(ctx, hipMalloc((void **)&d_pts, (size_t)b->n * 64));
+  HIP_TRY(ctx, hipMalloc((void **)&d_st, (size_t)b->n * 4));
+  int32_t rc = b3w_batch_commit_device(ctx, key, b->d_bodies, b->n, b->pitch, d_pts, d_st, nullptr);
+  hipError_t e = rc == B3W_OK ? hipMemcpy(host_points, d_pts, (size_t)b->n * 64, hipMemcpyDeviceToHost) : hipSuccess;
+  if (rc == B3W_OK && e == hipSuccess && host_status) e = hipMemcpy(host_status, d_st, (size_t)b->n * 4, hipMemcpyDeviceToHost);
+  (void)hipFree(d_pts); (void)hipFree(d_st);
+  if (rc) return rc;
+  return e == hipSuccess ? B3W_OK : hip_fail(ctx, e, "hipMemcpy(commitments)");
+}
+
 // ---------------------------------------------------------------- multi-GPU exchange (RCCL, loaded at run time)
 }  // extern "C"
 

@@ -35,3 +35,16 @@ extern "C" int b3w_launch_verify(int kind, const uint32_t *d_in_slots, uint32_t 
 extern "C" int b3w_place_alloc(int device, uint64_t bytes, int want_mixed, void **out, int *mixed, float *rates);
 extern "C" int b3w_place_free(void *ptr);
 extern "C" void b3w_place_trim(void);
+
+// b3w_commit.hip: Pedersen commitments of witness bodies (on-device consumer).  Field of the curve's coordinates:
+struct B3wCurve {
+  uint32_t p[8];      // modulus, little-endian limbs
+  uint32_t r2[8];     // 2^512 mod p   (into Montgomery form)
+  uint32_t one[8];    // 2^256 mod p   (1 in Montgomery form)
+  uint32_t pm2[8];    // p - 2         (Fermat inversion exponent)
+  uint32_t inv;       // -p^-1 mod 2^32
+};
+extern "C" int b3w_launch_commit_setup(const uint32_t *d_gens, const uint32_t *d_first_v, const uint32_t *d_nbits, uint32_t nslots,
+                                       uint32_t *d_points, const B3wCurve *curve, hipStream_t stream);
+extern "C" int b3w_launch_commit(const uint8_t *d_bodies, uint32_t n, uint64_t pitch, const uint32_t *d_vslots, const uint32_t *d_points,
+                                 uint32_t V, uint8_t *d_out, int32_t *d_status, const B3wCurve *curve, hipStream_t stream);

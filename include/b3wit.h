@@ -158,6 +158,26 @@ int32_t b3w_batch_time_device(b3w_ctx *ctx, const uint32_t *d_records, uint32_t 
 int32_t b3w_batch_verify_device(b3w_ctx *ctx, const uint8_t *d_bodies, uint32_t n, uint64_t pitch, uint32_t *d_mismatch,
                                 void *stream);
 
+/* On-device consumer #2: Pedersen commitments C_i = sum_s w_i[s] * G[s - first_slot] over slots s >= first_slot of n
+ * witness bodies in HBM — what the folding prover does with a step witness right after `synthesize`
+ * (rust_fold/src/main.rs:166-179 -> arecibo's prove_step commits to W).  The group is the one
+ * whose scalar field is the circuit's field: BN254 G1 for the bn128 circuits, the Vesta curve for the --prime vesta
+ * build (short Weierstrass, a = 0).  The generators are the caller's (arecibo's commitment key): affine points,
+ * x then y, 32-byte little-endian each, standard (non-Montgomery) form, one per committed slot.
+ * b3w_commit_key_create precomputes 2^k * G for the slots that hold more than one bit, so committing a witness is
+ * "add the points of its set bits" (no doublings).  Output: n affine points (x, y as above; all zero = the point
+ * at infinity); d_status (may be NULL): 0 ok, 103 = a bit slot of that body does not hold 0 or 1 (not a body of the
+ * batch kernels: commitment not meaningful). */
+#define B3W_CURVE_BN254_G1 0 /* y^2 = x^3 + 3 over q = 0x30644e72e131a029b85045b68181585d97816a916871ca8d3c208c16d87cfd47 */
+#define B3W_CURVE_VESTA    1 /* y^2 = x^3 + 5 over 0x40000000000000000000000000000000224698fc094cf91b992d30ed00000001 */
+typedef struct b3w_commit_key b3w_commit_key;
+int32_t b3w_commit_key_create(b3w_ctx *ctx, int32_t curve, uint32_t first_slot, const uint8_t *host_generators, b3w_commit_key **out);
+void b3w_commit_key_destroy(b3w_commit_key *key);
+int32_t b3w_batch_commit_device(b3w_ctx *ctx, const b3w_commit_key *key, const uint8_t *d_bodies, uint32_t n, uint64_t pitch,
+                                uint8_t *d_points /* n * 64 bytes */, int32_t *d_status, void *stream);
+/* The same for the witnesses of the last b3w_batch_run; host_points receives n * 64 bytes, host_status n int32 (may be NULL). */
+int32_t b3w_batch_commit(b3w_batch *batch, const b3w_commit_key *key, uint8_t *host_points, int32_t *host_status);
+
 /* Same check on the witnesses of the last b3w_batch_run; host_mismatch receives n counts. */
 int32_t b3w_batch_verify(b3w_batch *batch, uint32_t *host_mismatch);
 
