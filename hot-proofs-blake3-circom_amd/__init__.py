@@ -289,6 +289,41 @@ class BodyBuffer:
             pass
 
 
+class CommitKey:
+    """Commitment key on the device (b3w_commit_key_create): `generators` = bytes, one affine point (x, y: 32-byte
+    little-endian each, standard form) per committed slot, i.e. witness_size - first_slot of them; curve "bn254_g1"
+    or "vesta"."""
+    CURVES = {"bn254_g1": 0, "vesta": 1}
+
+    def __init__(self, ctx, curve, generators, first_slot=0):
+        self.ctx = ctx
+        buf = bytes(generators)
+        if len(buf) != 64 * (ctx.witness_size - first_slot):
+            raise B3WError(100, "generators: 64 bytes per committed slot")
+        h = ctypes.c_void_p()
+        rc = lib().b3w_commit_key_create(ctx.handle, self.CURVES[curve], first_slot, buf, ctypes.byref(h))
+        if rc != B3W_OK:
+            raise B3WError(rc, f"b3w_commit_key_create: status {rc}: {ctx.last_error()}")
+        self.handle = h
+
+    def commit_device(self, d_bodies, n, pitch, d_points, d_status=0, stream=0):
+        """n bodies in HBM -> n affine points (64 bytes each) in HBM."""
+        rc = lib().b3w_batch_commit_device(self.ctx.handle, self.handle, d_bodies, n, pitch, d_points, d_status or None, stream or None)
+        if rc != B3W_OK:
+            raise B3WError(rc, f"b3w_batch_commit_device: status {rc}: {self.ctx.last_error()}")
+
+    def close(self):
+        if getattr(self, "handle", None):
+            lib().b3w_commit_key_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class ChainPlanner:
     """Chained-mode step-input planner over torch device tensors (b3w_chain_*): the device counterpart
     of rust_fold's format_input / update_for_step / hash_with_path for ALL chunks of a preimage."""
@@ -393,6 +428,15 @@ class Batch:
         if rc != B3W_OK:
             raise B3WError(rc, f"b3w_batch_write_wtns: status {rc}: {self.ctx.last_error()}")
         return wr.value
+
+    def commit(self, key):
+        """Pedersen commitments of the last run's witnesses: (points uint8 [n, 64], status int32 [n])."""
+        pts = np.zeros((self.n, 64), dtype=np.uint8)
+        st = np.zeros(self.n, dtype=np.int32)
+        rc = lib().b3w_batch_commit(self.handle, key.handle, pts.ctypes.data, st.ctypes.data)
+        if rc != B3W_OK:
+            raise B3WError(rc, f"b3w_batch_commit: status {rc}: {self.ctx.last_error()}")
+        return pts, st
 
     @property
     def placement(self):

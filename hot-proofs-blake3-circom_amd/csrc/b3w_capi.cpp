@@ -859,8 +859,10 @@ int32_t b3w_chain_plan_parents_device(b3w_ctx *ctx, const uint32_t *d_levels, ui
 struct b3w_commit_key {
   b3w_ctx *ctx = nullptr;
   B3wCurve curve{};
-  uint32_t first_slot = 0, V = 0;
-  uint32_t *d_vslots = nullptr, *d_points = nullptr;
+  uint32_t first_slot = 0, nwin = 0;
+  uint32_t *d_vslots = nullptr, *d_table = nullptr;   // 8 virtual slots per window; 255 subset sums per window
+  uint32_t *d_sums = nullptr;                         // Jacobian sums between the two kernels, grown on demand
+  uint32_t sums_cap = 0;
 };
 
 namespace {
@@ -912,15 +914,19 @@ int32_t b3w_commit_key_create(b3w_ctx *ctx, int32_t curve, uint32_t first_slot, 
     first_v[i] = (uint32_t)vslots.size();
     for (uint32_t k = 0; k < nbits[i]; k++) vslots.push_back((first_slot + i) | (k << 19) | ((nbits[i] == 1 ? 1u : 0u) << 27));
   }
+  // windows of eight virtual slots; the pad entries read bit 31 of slot 0 (the constant 1): always 0
+  const uint32_t V0 = (uint32_t)vslots.size();
+  while (vslots.size() % 8) vslots.push_back(0u | (31u << 19));
   b3w_commit_key *key = new b3w_commit_key;
   key->ctx = ctx;
   key->curve = make_curve(curve == B3W_CURVE_BN254_G1 ? Q_BN254 : P_VESTA_BASE);
   key->first_slot = first_slot;
-  key->V = (uint32_t)vslots.size();
-  uint32_t *d_gens = nullptr, *d_first = nullptr, *d_nbits = nullptr;
+  key->nwin = (uint32_t)(vslots.size() / 8);
+  uint32_t *d_gens = nullptr, *d_first = nullptr, *d_nbits = nullptr, *d_points = nullptr;
   hipError_t e = hipSetDevice(ctx->device);
   if (e == hipSuccess) e = hipMalloc((void **)&key->d_vslots, vslots.size() * 4);
-  if (e == hipSuccess) e = hipMalloc((void **)&key->d_points, (size_t)key->V * 64);
+  if (e == hipSuccess) e = hipMalloc((void **)&key->d_table, (size_t)key->nwin * 255 * 64);
+  if (e == hipSuccess) e = hipMalloc((void **)&d_points, vslots.size() * 64);
   if (e == hipSuccess) e = hipMalloc((void **)&d_gens, (size_t)nslots * 64);
   if (e == hipSuccess) e = hipMalloc((void **)&d_first, (size_t)nslots * 4);
   if (e == hipSuccess) e = hipMalloc((void **)&d_nbits, (size_t)nslots * 4);
@@ -928,11 +934,16 @@ int32_t b3w_commit_key_create(b3w_ctx *ctx, int32_t curve, uint32_t first_slot, 
   if (e == hipSuccess) e = hipMemcpy(d_gens, host_generators, (size_t)nslots * 64, hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMemcpy(d_first, first_v.data(), (size_t)nslots * 4, hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMemcpy(d_nbits, nbits.data(), (size_t)nslots * 4, hipMemcpyHostToDevice);
-  int rc = e == hipSuccess ? b3w_launch_commit_setup(d_gens, d_first, d_nbits, nslots, key->d_points, &key->curve, nullptr) : 0;
+  // pad points: copies of the first point (never selected, but the table kernel adds them)
+  int rc = e == hipSuccess ? b3w_launch_commit_setup(d_gens, d_first, d_nbits, nslots, d_points, &key->curve, nullptr) : 0;
+  for (uint32_t v = V0; v < vslots.size() && e == hipSuccess && rc == 0; v++)
+    e = hipMemcpyAsync(d_points + (size_t)v * 16, d_points, 64, hipMemcpyDeviceToDevice, nullptr);
+  if (e == hipSuccess && rc == 0) rc = b3w_launch_commit_windows(d_points, key->nwin, key->d_table, &key->curve, nullptr);
   if (e == hipSuccess && rc == 0) e = hipDeviceSynchronize();
   if (d_gens) (void)hipFree(d_gens);
   if (d_first) (void)hipFree(d_first);
   if (d_nbits) (void)hipFree(d_nbits);
+  if (d_points) (void)hipFree(d_points);
   if (e != hipSuccess || rc != 0) {
     b3w_commit_key_destroy(key);
     return hip_fail(ctx, e != hipSuccess ? e : (hipError_t)rc, "commitment key set-up");
@@ -944,7 +955,8 @@ int32_t b3w_commit_key_create(b3w_ctx *ctx, int32_t curve, uint32_t first_slot, 
 void b3w_commit_key_destroy(b3w_commit_key *key) {
   if (!key) return;
   if (key->d_vslots) (void)hipFree(key->d_vslots);
-  if (key->d_points) (void)hipFree(key->d_points);
+  if (key->d_table) (void)hipFree(key->d_table);
+  if (key->d_sums) (void)hipFree(key->d_sums);
   delete key;
 }
 
@@ -957,7 +969,16 @@ int32_t b3w_batch_commit_device(b3w_ctx *ctx, const b3w_commit_key *key, const u
     ctx->last_error = "pitch must be >= witness_size*32, bodies 4-byte and points 16-byte aligned";
     return B3W_E_BAD_ARGUMENT;
   }
-  const int rc = b3w_launch_commit(d_bodies, n, pitch, key->d_vslots, key->d_points, key->V, d_points, d_status, &key->curve, (hipStream_t)stream);
+  b3w_commit_key *k = const_cast<b3w_commit_key *>(key);                     // scratch only
+  if (k->sums_cap < n) {
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipStreamSynchronize((hipStream_t)stream));
+    if (k->d_sums) (void)hipFree(k->d_sums);
+    k->d_sums = nullptr; k->sums_cap = 0;
+    HIP_TRY(ctx, hipMalloc((void **)&k->d_sums, (size_t)n * 96));
+    k->sums_cap = n;
+  }
+  const int rc = b3w_launch_commit(d_bodies, n, pitch, key->d_vslots, key->d_table, key->nwin, k->d_sums, d_points, d_status, &key->curve, (hipStream_t)stream);
   return rc ? hip_fail(ctx, (hipError_t)rc, "commit launch") : B3W_OK;
 }
 

@@ -7,19 +7,22 @@
 // is comparable with the prover's own commitment; tests check it against an independent big-integer implementation.
 //
 // The witness is almost all bits: of 24 093 compression slots ~23 500 hold 0 or 1, the rest 32/34-bit words (nova:
-// plus 67 256-bit inverses).  So the multi-scalar multiplication is turned into "add the selected points":
-//   set-up   for every slot with more than one bit the points 2^k * G_slot are precomputed (b3w_commit_setup_kernel),
-//            giving one flat table of V "virtual slots" (slot, bit k, point) — V = 40 k compression, 58 k nova O2;
-//   commit   one 256-thread workgroup per witness; thread t owns virtual slots t, t + 256, ...; it skips ahead to
-//            its next SET bit (reading one body word per virtual slot) and then the whole wave does one mixed
-//            Jacobian + affine addition — no doublings, no zero work in lock step; an LDS tree adds the 256 partial
-//            sums, thread 0 normalises (Fermat inversion) and stores the affine point.
+// plus 67 256-bit inverses).  So the multi-scalar multiplication is turned into "add precomputed points":
+//   set-up   every slot is cut into its bits ("virtual slots": slot, bit k; V = 40 k compression, 58 k nova O2) with
+//            the point 2^k * G_slot each (b3w_commit_setup_kernel); eight consecutive virtual slots form a WINDOW whose
+//            255 non-empty subset sums are tabulated (b3w_commit_window_kernel: 5 k windows x 255 affine points = 82 MB);
+//   commit   one 256-thread workgroup per witness; thread t owns windows t, t + 256, ...; it gathers the eight bits of
+//            a window from the body, skips ahead to its next NON-ZERO window, and then the whole wave does one mixed
+//            Jacobian + affine addition with the tabulated point — no doublings, one addition per eight slots, no
+//            zero work in lock step; an LDS tree adds the 256 partial sums; a second kernel normalises them, one
+//            thread per witness (Fermat inversion), and stores the affine points.
 // Arithmetic: 256-bit Montgomery (CIOS, eight 32-bit limbs, modulus passed at run time), complete handling of the
 // exceptional cases (infinity, P + P, P - P) so that related generators cannot break it.
 // Domain: bodies of the batch kernels (every bit slot holds 0 or 1, words fit their slot's width); a bit slot holding
 // anything else flags the witness (status 103) instead of producing a wrong commitment.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include "b3w_kernels.h"
 
 namespace {
@@ -156,6 +159,7 @@ __device__ Jac jac_dbl(const Jac &P, const B3wCurve &C) {
 
 // P + (x2, y2, 1) (madd-2007-bl) with the exceptional cases
 __device__ Jac jac_madd(const Jac &P, const Fp &x2, const Fp &y2, const B3wCurve &C) {
+  if (fp_is_zero(x2) && fp_is_zero(y2)) return P;        // (0, 0) is not on these curves (b != 0): the table's infinity
   if (fp_is_zero(P.Z)) {
     Jac R; R.X = x2; R.Y = y2;
 #pragma unroll
@@ -239,12 +243,32 @@ __global__ __launch_bounds__(64) void b3w_commit_setup_kernel(const uint32_t *__
   }
 }
 
+// ---- set-up 2: table[win * 255 + m - 1] = sum of the window's virtual-slot points selected by the bits of m
+__global__ __launch_bounds__(64) void b3w_commit_window_kernel(const uint32_t *__restrict__ points, uint32_t nwin,
+                                                               uint32_t *__restrict__ table, B3wCurve C) {
+  const uint64_t i = (uint64_t)blockIdx.x * 64 + threadIdx.x;
+  if (i >= (uint64_t)nwin * 255) return;
+  const uint32_t win = (uint32_t)(i / 255), m = (uint32_t)(i % 255) + 1;
+  Jac acc = jac_infinity();
+#pragma unroll 1
+  for (int j = 0; j < 8; ++j) {
+    if (!((m >> j) & 1)) continue;
+    const uint32_t *pt = points + (uint64_t)(win * 8 + j) * 16;
+    acc = jac_madd(acc, load_fp(pt), load_fp(pt + 8), C);
+  }
+  Fp x, y;
+  jac_to_affine(acc, x, y, C);                            // infinity -> (0, 0)
+  store_fp(table + i * 16, x);
+  store_fp(table + i * 16 + 8, y);
+}
+
 // ---- commit: one workgroup per witness
-__global__ __launch_bounds__(256) void b3w_commit_kernel(const uint8_t *__restrict__ bodies, uint32_t n, uint64_t pitch,
-                                                         const uint32_t *__restrict__ vslots /* slot | bit << 24 ... see host */,
-                                                         const uint32_t *__restrict__ points, uint32_t V, uint8_t *__restrict__ out,
+template <int T>        // threads per witness
+__global__ __launch_bounds__(T) void b3w_commit_kernel(const uint8_t *__restrict__ bodies, uint32_t n, uint64_t pitch,
+                                                         const uint32_t *__restrict__ vslots /* 8 per window: slot | bit << 19 | single << 27 */,
+                                                         const uint32_t *__restrict__ table, uint32_t nwin, uint32_t *__restrict__ sums /* n x 24 words: X Y Z */,
                                                          int32_t *__restrict__ status, B3wCurve C) {
-  __shared__ __attribute__((aligned(16))) uint32_t red[256 * 24];
+  __shared__ __attribute__((aligned(16))) uint32_t red[T * 24];
   __shared__ uint32_t bad;
   const uint32_t w = blockIdx.x, t = threadIdx.x;
   if (w >= n) return;
@@ -252,28 +276,36 @@ __global__ __launch_bounds__(256) void b3w_commit_kernel(const uint8_t *__restri
   __syncthreads();
   const uint32_t *body = reinterpret_cast<const uint32_t *>(bodies + (uint64_t)w * pitch);
   Jac acc = jac_infinity();
-  uint32_t v = t;
+  uint32_t win = t;
   while (true) {
-    // skip ahead to this lane's next set bit
-    while (v < V) {
-      const uint32_t e = vslots[v], slot = e & 0x7FFFFu, bit = (e >> 19) & 0xFFu, single = e >> 27;
-      const uint32_t word = body[(uint64_t)slot * 8 + (bit >> 5)];
-      if (single && word > 1) bad = 1;                       // a bit slot must hold 0 or 1
-      if ((word >> (bit & 31)) & 1) break;
-      v += 256;
+    // skip ahead to this lane's next window with a set bit
+    uint32_t m = 0;
+    while (win < nwin) {
+      const uint4 e0 = reinterpret_cast<const uint4 *>(vslots + (uint64_t)win * 8)[0], e1 = reinterpret_cast<const uint4 *>(vslots + (uint64_t)win * 8)[1];
+      const uint32_t e[8] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w};
+      uint32_t word[8];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) word[j] = body[(uint64_t)(e[j] & 0x7FFFFu) * 8 + (((e[j] >> 19) & 0xFFu) >> 5)];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        if ((e[j] >> 27) && word[j] > 1) bad = 1;            // a bit slot must hold 0 or 1
+        m |= ((word[j] >> ((e[j] >> 19) & 31u)) & 1u) << j;
+      }
+      if (m) break;
+      win += T;
     }
-    const bool has = v < V;
+    const bool has = win < nwin;
     if (!__any(has)) break;
     if (has) {
-      const uint32_t *pt = points + (uint64_t)v * 16;
+      const uint32_t *pt = table + ((uint64_t)win * 255 + m - 1) * 16;
       acc = jac_madd(acc, load_fp(pt), load_fp(pt + 8), C);
-      v += 256;
+      win += T;
     }
   }
-  // LDS tree over the 256 partial sums
+  // LDS tree over the T partial sums
   store_fp(red + t * 24, acc.X); store_fp(red + t * 24 + 8, acc.Y); store_fp(red + t * 24 + 16, acc.Z);
   __syncthreads();
-  for (uint32_t st = 128; st >= 1; st >>= 1) {
+  for (uint32_t st = T / 2; st >= 1; st >>= 1) {
     if (t < st) {
       Jac a, b;
       a.X = load_fp(red + t * 24); a.Y = load_fp(red + t * 24 + 8); a.Z = load_fp(red + t * 24 + 16);
@@ -283,20 +315,26 @@ __global__ __launch_bounds__(256) void b3w_commit_kernel(const uint8_t *__restri
     }
     __syncthreads();
   }
-  if (t == 0) {
-    Jac R;
-    R.X = load_fp(red); R.Y = load_fp(red + 8); R.Z = load_fp(red + 16);
-    Fp x, y, one_std;
-    jac_to_affine(R, x, y, C);
+  if (t < 24) sums[(uint64_t)w * 24 + t] = red[t];            // the Jacobian sum; normalised by the next kernel
+  if (t == 0 && status) status[w] = bad ? 103 : 0;
+}
+
+// ---- normalise: one THREAD per witness (a Fermat inversion is 380 dependent multiplications: on thread 0 of the commit
+// workgroup it took longer than the workgroup's whole share of additions)
+__global__ __launch_bounds__(64) void b3w_commit_normalize_kernel(const uint32_t *__restrict__ sums, uint32_t n, uint8_t *__restrict__ out, B3wCurve C) {
+  const uint32_t w = blockIdx.x * 64 + threadIdx.x;
+  if (w >= n) return;
+  Jac R;
+  R.X = load_fp(sums + (uint64_t)w * 24); R.Y = load_fp(sums + (uint64_t)w * 24 + 8); R.Z = load_fp(sums + (uint64_t)w * 24 + 16);
+  Fp x, y, one_std;
+  jac_to_affine(R, x, y, C);
 #pragma unroll
-    for (int i = 0; i < 8; ++i) one_std.l[i] = i == 0 ? 1u : 0u;
-    x = fp_mul(x, one_std, C);                               // out of Montgomery form
-    y = fp_mul(y, one_std, C);
-    uint32_t *o = reinterpret_cast<uint32_t *>(out + (uint64_t)w * 64);
-    store_fp(o, x);
-    store_fp(o + 8, y);
-    if (status) status[w] = bad ? 103 : 0;
-  }
+  for (int i = 0; i < 8; ++i) one_std.l[i] = i == 0 ? 1u : 0u;
+  x = fp_mul(x, one_std, C);                                 // out of Montgomery form
+  y = fp_mul(y, one_std, C);
+  uint32_t *o = reinterpret_cast<uint32_t *>(out + (uint64_t)w * 64);
+  store_fp(o, x);
+  store_fp(o + 8, y);
 }
 
 }  // namespace
@@ -308,9 +346,24 @@ extern "C" int b3w_launch_commit_setup(const uint32_t *d_gens, const uint32_t *d
   return (int)hipGetLastError();
 }
 
-extern "C" int b3w_launch_commit(const uint8_t *d_bodies, uint32_t n, uint64_t pitch, const uint32_t *d_vslots, const uint32_t *d_points,
-                                 uint32_t V, uint8_t *d_out, int32_t *d_status, const B3wCurve *curve, hipStream_t stream) {
+extern "C" int b3w_launch_commit_windows(const uint32_t *d_points, uint32_t nwin, uint32_t *d_table, const B3wCurve *curve, hipStream_t stream) {
+  if (!nwin) return 0;
+  const uint64_t total = (uint64_t)nwin * 255;
+  hipLaunchKernelGGL(b3w_commit_window_kernel, dim3((uint32_t)((total + 63) / 64)), dim3(64), 0, stream, d_points, nwin, d_table, *curve);
+  return (int)hipGetLastError();
+}
+
+extern "C" int b3w_launch_commit(const uint8_t *d_bodies, uint32_t n, uint64_t pitch, const uint32_t *d_vslots, const uint32_t *d_table,
+                                 uint32_t nwin, uint32_t *d_sums /* n * 24 words scratch */, uint8_t *d_out, int32_t *d_status,
+                                 const B3wCurve *curve, hipStream_t stream) {
   if (!n) return 0;
-  hipLaunchKernelGGL(b3w_commit_kernel, dim3(n), dim3(256), 0, stream, d_bodies, n, pitch, d_vslots, d_points, V, d_out, d_status, *curve);
+  static const int tpw = getenv("B3W_COMMIT_THREADS") ? atoi(getenv("B3W_COMMIT_THREADS")) : 64;
+  if (tpw == 256)
+    hipLaunchKernelGGL(b3w_commit_kernel<256>, dim3(n), dim3(256), 0, stream, d_bodies, n, pitch, d_vslots, d_table, nwin, d_sums, d_status, *curve);
+  else if (tpw == 128)
+    hipLaunchKernelGGL(b3w_commit_kernel<128>, dim3(n), dim3(128), 0, stream, d_bodies, n, pitch, d_vslots, d_table, nwin, d_sums, d_status, *curve);
+  else
+    hipLaunchKernelGGL(b3w_commit_kernel<64>, dim3(n), dim3(64), 0, stream, d_bodies, n, pitch, d_vslots, d_table, nwin, d_sums, d_status, *curve);
+  hipLaunchKernelGGL(b3w_commit_normalize_kernel, dim3((n + 63) / 64), dim3(64), 0, stream, d_sums, n, d_out, *curve);
   return (int)hipGetLastError();
 }
