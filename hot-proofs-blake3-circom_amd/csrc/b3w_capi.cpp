@@ -860,7 +860,7 @@ struct b3w_commit_key {
   b3w_ctx *ctx = nullptr;
   B3wCurve curve{};
   uint32_t first_slot = 0, nwin = 0;
-  uint32_t *d_vslots = nullptr, *d_table = nullptr;   // 8 virtual slots per window; 255 subset sums per window
+  uint32_t *d_vslots = nullptr, *d_table = nullptr;   // B3W_COMMIT_WINDOW virtual slots per window; 2^W - 1 subset sums each
   uint32_t *d_sums = nullptr;                         // Jacobian sums between the two kernels, grown on demand
   uint32_t sums_cap = 0;
 };
@@ -914,18 +914,18 @@ int32_t b3w_commit_key_create(b3w_ctx *ctx, int32_t curve, uint32_t first_slot, 
     first_v[i] = (uint32_t)vslots.size();
     for (uint32_t k = 0; k < nbits[i]; k++) vslots.push_back((first_slot + i) | (k << 19) | ((nbits[i] == 1 ? 1u : 0u) << 27));
   }
-  // windows of eight virtual slots; the pad entries read bit 31 of slot 0 (the constant 1): always 0
+  // windows of B3W_COMMIT_WINDOW virtual slots; the pad entries read bit 31 of slot 0 (the constant 1): always 0
   const uint32_t V0 = (uint32_t)vslots.size();
-  while (vslots.size() % 8) vslots.push_back(0u | (31u << 19));
+  while (vslots.size() % B3W_COMMIT_WINDOW) vslots.push_back(0u | (31u << 19));
   b3w_commit_key *key = new b3w_commit_key;
   key->ctx = ctx;
   key->curve = make_curve(curve == B3W_CURVE_BN254_G1 ? Q_BN254 : P_VESTA_BASE);
   key->first_slot = first_slot;
-  key->nwin = (uint32_t)(vslots.size() / 8);
+  key->nwin = (uint32_t)(vslots.size() / B3W_COMMIT_WINDOW);
   uint32_t *d_gens = nullptr, *d_first = nullptr, *d_nbits = nullptr, *d_points = nullptr;
   hipError_t e = hipSetDevice(ctx->device);
   if (e == hipSuccess) e = hipMalloc((void **)&key->d_vslots, vslots.size() * 4);
-  if (e == hipSuccess) e = hipMalloc((void **)&key->d_table, (size_t)key->nwin * 255 * 64);
+  if (e == hipSuccess) e = hipMalloc((void **)&key->d_table, (size_t)key->nwin * B3W_COMMIT_ENTRIES * 64);
   if (e == hipSuccess) e = hipMalloc((void **)&d_points, vslots.size() * 64);
   if (e == hipSuccess) e = hipMalloc((void **)&d_gens, (size_t)nslots * 64);
   if (e == hipSuccess) e = hipMalloc((void **)&d_first, (size_t)nslots * 4);
@@ -980,6 +980,14 @@ int32_t b3w_batch_commit_device(b3w_ctx *ctx, const b3w_commit_key *key, const u
   }
   const int rc = b3w_launch_commit(d_bodies, n, pitch, key->d_vslots, key->d_table, key->nwin, k->d_sums, d_points, d_status, &key->curve, (hipStream_t)stream);
   return rc ? hip_fail(ctx, (hipError_t)rc, "commit launch") : B3W_OK;
+}
+
+void b3w_commit_consumer(void *user, const uint8_t *d_bodies, uint64_t pitch, uint64_t first_step, uint32_t count, void *stream) {
+  b3w_commit_sink *sink = static_cast<b3w_commit_sink *>(user);
+  if (!sink || !sink->ctx || !sink->key || !sink->d_points) return;
+  const int32_t rc = b3w_batch_commit_device(sink->ctx, sink->key, d_bodies, count, pitch, sink->d_points + first_step * 64,
+                                             sink->d_status ? sink->d_status + first_step : nullptr, stream);
+  if (rc && !sink->error) sink->error = rc;
 }
 
 int32_t b3w_batch_commit(b3w_batch *b, const b3w_commit_key *key, uint8_t *host_points, int32_t *host_status) {

@@ -9,11 +9,11 @@
 // The witness is almost all bits: of 24 093 compression slots ~23 500 hold 0 or 1, the rest 32/34-bit words (nova:
 // plus 67 256-bit inverses).  So the multi-scalar multiplication is turned into "add precomputed points":
 //   set-up   every slot is cut into its bits ("virtual slots": slot, bit k; V = 40 k compression, 58 k nova O2) with
-//            the point 2^k * G_slot each (b3w_commit_setup_kernel); eight consecutive virtual slots form a WINDOW whose
-//            255 non-empty subset sums are tabulated (b3w_commit_window_kernel: 5 k windows x 255 affine points = 82 MB);
-//   commit   one 256-thread workgroup per witness; thread t owns windows t, t + 256, ...; it gathers the eight bits of
+//            the point 2^k * G_slot each (b3w_commit_setup_kernel); W = 12 consecutive virtual slots form a WINDOW whose
+//            4 095 non-empty subset sums are tabulated (b3w_commit_window_kernel: 3.3 k windows x 4 095 affine points = 0.9 GB);
+//   commit   one 256-thread workgroup per witness; thread t owns windows t, t + 256, ...; it gathers the W bits of
 //            a window from the body, skips ahead to its next NON-ZERO window, and then the whole wave does one mixed
-//            Jacobian + affine addition with the tabulated point — no doublings, one addition per eight slots, no
+//            Jacobian + affine addition with the tabulated point — no doublings, one addition per W slots, no
 //            zero work in lock step; an LDS tree adds the 256 partial sums; a second kernel normalises them, one
 //            thread per witness (Fermat inversion), and stores the affine points.
 // Arithmetic: 256-bit Montgomery (CIOS, eight 32-bit limbs, modulus passed at run time), complete handling of the
@@ -243,17 +243,17 @@ __global__ __launch_bounds__(64) void b3w_commit_setup_kernel(const uint32_t *__
   }
 }
 
-// ---- set-up 2: table[win * 255 + m - 1] = sum of the window's virtual-slot points selected by the bits of m
+// ---- set-up 2: table[win * (2^W - 1) + m - 1] = sum of the window's virtual-slot points selected by the bits of m
 __global__ __launch_bounds__(64) void b3w_commit_window_kernel(const uint32_t *__restrict__ points, uint32_t nwin,
                                                                uint32_t *__restrict__ table, B3wCurve C) {
   const uint64_t i = (uint64_t)blockIdx.x * 64 + threadIdx.x;
-  if (i >= (uint64_t)nwin * 255) return;
-  const uint32_t win = (uint32_t)(i / 255), m = (uint32_t)(i % 255) + 1;
+  if (i >= (uint64_t)nwin * B3W_COMMIT_ENTRIES) return;
+  const uint32_t win = (uint32_t)(i / B3W_COMMIT_ENTRIES), m = (uint32_t)(i % B3W_COMMIT_ENTRIES) + 1;
   Jac acc = jac_infinity();
 #pragma unroll 1
-  for (int j = 0; j < 8; ++j) {
+  for (int j = 0; j < B3W_COMMIT_WINDOW; ++j) {
     if (!((m >> j) & 1)) continue;
-    const uint32_t *pt = points + (uint64_t)(win * 8 + j) * 16;
+    const uint32_t *pt = points + (uint64_t)(win * B3W_COMMIT_WINDOW + j) * 16;
     acc = jac_madd(acc, load_fp(pt), load_fp(pt + 8), C);
   }
   Fp x, y;
@@ -265,7 +265,7 @@ __global__ __launch_bounds__(64) void b3w_commit_window_kernel(const uint32_t *_
 // ---- commit: one workgroup per witness
 template <int T>        // threads per witness
 __global__ __launch_bounds__(T) void b3w_commit_kernel(const uint8_t *__restrict__ bodies, uint32_t n, uint64_t pitch,
-                                                         const uint32_t *__restrict__ vslots /* 8 per window: slot | bit << 19 | single << 27 */,
+                                                         const uint32_t *__restrict__ vslots /* B3W_COMMIT_WINDOW per window: slot | bit << 19 | single << 27 */,
                                                          const uint32_t *__restrict__ table, uint32_t nwin, uint32_t *__restrict__ sums /* n x 24 words: X Y Z */,
                                                          int32_t *__restrict__ status, B3wCurve C) {
   __shared__ __attribute__((aligned(16))) uint32_t red[T * 24];
@@ -281,13 +281,17 @@ __global__ __launch_bounds__(T) void b3w_commit_kernel(const uint8_t *__restrict
     // skip ahead to this lane's next window with a set bit
     uint32_t m = 0;
     while (win < nwin) {
-      const uint4 e0 = reinterpret_cast<const uint4 *>(vslots + (uint64_t)win * 8)[0], e1 = reinterpret_cast<const uint4 *>(vslots + (uint64_t)win * 8)[1];
-      const uint32_t e[8] = {e0.x, e0.y, e0.z, e0.w, e1.x, e1.y, e1.z, e1.w};
-      uint32_t word[8];
+      constexpr int WN = B3W_COMMIT_WINDOW;
+      uint32_t e[WN], word[WN];
 #pragma unroll
-      for (int j = 0; j < 8; ++j) word[j] = body[(uint64_t)(e[j] & 0x7FFFFu) * 8 + (((e[j] >> 19) & 0xFFu) >> 5)];
+      for (int j = 0; j < WN; j += 4) {
+        const uint4 q = *reinterpret_cast<const uint4 *>(vslots + (uint64_t)win * WN + j);
+        e[j] = q.x; e[j + 1] = q.y; e[j + 2] = q.z; e[j + 3] = q.w;
+      }
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
+      for (int j = 0; j < WN; ++j) word[j] = body[(uint64_t)(e[j] & 0x7FFFFu) * 8 + (((e[j] >> 19) & 0xFFu) >> 5)];
+#pragma unroll
+      for (int j = 0; j < WN; ++j) {
         if ((e[j] >> 27) && word[j] > 1) bad = 1;            // a bit slot must hold 0 or 1
         m |= ((word[j] >> ((e[j] >> 19) & 31u)) & 1u) << j;
       }
@@ -297,7 +301,7 @@ __global__ __launch_bounds__(T) void b3w_commit_kernel(const uint8_t *__restrict
     const bool has = win < nwin;
     if (!__any(has)) break;
     if (has) {
-      const uint32_t *pt = table + ((uint64_t)win * 255 + m - 1) * 16;
+      const uint32_t *pt = table + ((uint64_t)win * B3W_COMMIT_ENTRIES + m - 1) * 16;
       acc = jac_madd(acc, load_fp(pt), load_fp(pt + 8), C);
       win += T;
     }
@@ -348,7 +352,7 @@ extern "C" int b3w_launch_commit_setup(const uint32_t *d_gens, const uint32_t *d
 
 extern "C" int b3w_launch_commit_windows(const uint32_t *d_points, uint32_t nwin, uint32_t *d_table, const B3wCurve *curve, hipStream_t stream) {
   if (!nwin) return 0;
-  const uint64_t total = (uint64_t)nwin * 255;
+  const uint64_t total = (uint64_t)nwin * B3W_COMMIT_ENTRIES;
   hipLaunchKernelGGL(b3w_commit_window_kernel, dim3((uint32_t)((total + 63) / 64)), dim3(64), 0, stream, d_points, nwin, d_table, *curve);
   return (int)hipGetLastError();
 }

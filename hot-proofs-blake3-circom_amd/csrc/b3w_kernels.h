@@ -36,7 +36,12 @@ extern "C" int b3w_place_alloc(int device, uint64_t bytes, int want_mixed, void 
 extern "C" int b3w_place_free(void *ptr);
 extern "C" void b3w_place_trim(void);
 
-// b3w_commit.hip: Pedersen commitments of witness bodies (on-device consumer).  Field of the curve's coordinates:
+// b3w_commit.hip: Pedersen commitments of witness bodies (on-device consumer).
+#ifndef B3W_COMMIT_WINDOW
+#define B3W_COMMIT_WINDOW 12                        // virtual slots per window: 2^W - 1 tabulated subset sums each
+#endif
+#define B3W_COMMIT_ENTRIES ((1u << B3W_COMMIT_WINDOW) - 1u)
+// Field of the curve's coordinates:
 struct B3wCurve {
   uint32_t p[8];      // modulus, little-endian limbs
   uint32_t r2[8];     // 2^512 mod p   (into Montgomery form)

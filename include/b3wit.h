@@ -178,6 +178,19 @@ int32_t b3w_batch_commit_device(b3w_ctx *ctx, const b3w_commit_key *key, const u
 /* The same for the witnesses of the last b3w_batch_run; host_points receives n * 64 bytes, host_status n int32 (may be NULL). */
 int32_t b3w_batch_commit(b3w_batch *batch, const b3w_commit_key *key, uint8_t *host_points, int32_t *host_status);
 
+/* A ready-made consumer for the chained pass (b3w_chain_run_leaves / run_parents below): commits every batch of step
+ * witnesses while it sits in the ring, so that of a 28 TB pass only one 64-byte point per step is kept.
+ * `user` = a b3w_commit_sink whose d_points has room for every step of the pass (n_leaf + n_parent points, step order);
+ * d_status may be NULL. */
+typedef struct {
+  b3w_ctx *ctx;
+  const b3w_commit_key *key;
+  uint8_t *d_points;
+  int32_t *d_status;
+  int32_t error; /* first non-zero status of a commit launch, 0 = none */
+} b3w_commit_sink;
+void b3w_commit_consumer(void *user, const uint8_t *d_bodies, uint64_t pitch, uint64_t first_step, uint32_t count, void *stream);
+
 /* Same check on the witnesses of the last b3w_batch_run; host_mismatch receives n counts. */
 int32_t b3w_batch_verify(b3w_batch *batch, uint32_t *host_mismatch);
 

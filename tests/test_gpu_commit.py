@@ -126,3 +126,52 @@ def test_commit_flags_bodies_outside_its_domain_and_reports_rate():
     assert st[7] == 103 and (np.delete(st, 7) == 0).all()
     L.b3w_commit_key_destroy(key)
     ctx.close()
+
+
+def test_chained_pass_with_the_commit_consumer():
+    """preimage -> every step witness (native chained pass) -> one commitment per step, nothing but 64-byte points kept:
+    b3w_commit_consumer as the ring's consumer.  Checked for sampled steps against the plain-integer group law on the
+    oracle's witness of the same step record, and the pass still yields BLAKE3(preimage)."""
+    import torch, blake3_ref
+
+    class Sink(ctypes.Structure):
+        _fields_ = [("ctx", ctypes.c_void_p), ("key", ctypes.c_void_p), ("d_points", ctypes.c_void_p), ("d_status", ctypes.c_void_p),
+                    ("error", ctypes.c_int32)]
+    m = T.pkg()
+    L = m.lib()
+    circuit, curve = "nova_vesta", "vesta"
+    ctx = m.Context(circuit, 0)
+    data = ((np.arange(8 * 1024, dtype=np.uint64) * 40503 + 11) % 253).astype(np.uint8)        # 8 chunks: 128 leaf + 24 parent steps
+    gens = E.random_points(curve, T.NWIT[circuit], seed=b"chain")
+    key = _key(m, ctx, curve, 0, gens)
+    h = ctypes.c_void_p()
+    assert L.b3w_chain_create(ctx.handle, data.size, 0, 8, 48, 2, 1, ctypes.byref(h)) == 0      # batches of 48 steps: several ring turns
+    nl, npar = ctypes.c_uint64(), ctypes.c_uint64()
+    L.b3w_chain_info(h, ctypes.byref(nl), ctypes.byref(npar), None, None, None)
+    steps = nl.value + npar.value
+    assert (nl.value, npar.value) == (128, 24)
+    dev = torch.device("cuda:0")
+    d_pts = torch.zeros((steps, 64), dtype=torch.uint8, device=dev)
+    d_st = torch.full((steps,), -1, dtype=torch.int32, device=dev)
+    sink = Sink(ctx.handle, key, d_pts.data_ptr(), d_st.data_ptr(), 0)
+    consumer = ctypes.cast(L.b3w_commit_consumer, ctypes.c_void_p)
+    assert L.b3w_chain_run_leaves(h, data.ctypes.data, consumer, ctypes.byref(sink), None) == 0
+    assert L.b3w_chain_run_parents(h, None, consumer, ctypes.byref(sink), None) == 0
+    recs = np.zeros((steps, 32), dtype=np.uint32)
+    root = np.zeros(8, dtype=np.uint32)
+    assert L.b3w_chain_outputs(h, None, None, root.ctypes.data, None) == 0
+    torch.cuda.synchronize()
+    assert sink.error == 0 and int(d_st.abs().sum().item()) == 0
+    assert root.tobytes() == blake3_ref.blake3(data.tobytes())
+    import ctypes as C
+    hip_recs = m.chain._view(L.b3w_chain_records(h), (steps, 32), "<i4", dev).cpu().numpy().view(np.uint32)
+    idx = [0, 47, 48, 127, 128, 151]                       # batch borders, first parent step, last step
+    bad, bodies = T.oracle_batch_u32(circuit, hip_recs[idx])
+    assert bad == 0
+    vals = _slot_values(bodies.copy())
+    pts = d_pts.cpu().numpy()
+    for j, i in enumerate(idx):
+        assert E.point_from_bytes(pts[i].tobytes()) == E.commit(vals[j], gens, curve), i
+    L.b3w_chain_destroy(h)
+    L.b3w_commit_key_destroy(key)
+    ctx.close()
