@@ -46,6 +46,9 @@ struct Api {
   decltype(&b3w_chain_run_parents) chain_run_parents;
   decltype(&b3w_chain_info) chain_info;
   decltype(&b3w_chain_outputs) chain_outputs;
+  decltype(&b3w_commit_key_create) commit_key_create;
+  decltype(&b3w_commit_key_destroy) commit_key_destroy;
+  decltype(&b3w_batch_commit) batch_commit;
   decltype(&b3w_chain_shard) chain_shard;
   decltype(&b3w_chain_run_parents_sharded) chain_run_parents_sharded;
   decltype(&b3w_comm_unique_id) comm_unique_id;
@@ -75,7 +78,7 @@ bool load_api() {
   SYM(write_wtns_header) SYM(last_error) SYM(public_words) SYM(batch_alloc) SYM(batch_free) SYM(batch_run)
   SYM(batch_outputs) SYM(batch_fetch) SYM(batch_write_wtns) SYM(batch_verify) SYM(batch_placement) SYM(bodies_trim)
   SYM(chain_create) SYM(chain_destroy) SYM(chain_run_leaves) SYM(chain_run_parents) SYM(chain_info) SYM(chain_outputs)
-  SYM(chain_shard) SYM(chain_run_parents_sharded) SYM(comm_unique_id) SYM(comm_create) SYM(comm_destroy) SYM(batch_allgather_public)
+  SYM(commit_key_create) SYM(commit_key_destroy) SYM(batch_commit) SYM(chain_shard) SYM(chain_run_parents_sharded) SYM(comm_unique_id) SYM(comm_create) SYM(comm_destroy) SYM(batch_allgather_public)
 #undef SYM
   api.so = so;
   return true;
@@ -87,6 +90,7 @@ struct Handle {
   uint32_t batch_cap = 0, batch_n = 0;
   b3w_comm *comm = nullptr;
   int32_t rank = 0, nranks = 1;
+  b3w_commit_key *key = nullptr;
 };
 
 #define NAPI_OK(call)                                                   \
@@ -118,6 +122,7 @@ Handle *get_handle(napi_env env, napi_value v) {
 
 void finalize_handle(napi_env, void *data, void *) {
   Handle *h = (Handle *)data;
+  if (h->key) api.commit_key_destroy(h->key);
   if (h->comm) api.comm_destroy(h->comm);
   if (h->batch) api.batch_free(h->batch);
   if (h->ctx) api.destroy(h->ctx);
@@ -412,6 +417,49 @@ napi_value ChainFold(napi_env env, napi_callback_info info) {
   return o;
 }
 
+// commitKey(handle, curve: 0 = BN254 G1 | 1 = Vesta, firstSlot, generators: Uint8Array((witnessSize - firstSlot) * 64))
+// installs the commitment key of this handle (tables on the device)
+napi_value CommitKey(napi_env env, napi_callback_info info) {
+  size_t argc = 4; napi_value argv[4];
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+  Handle *h = get_handle(env, argv[0]);
+  if (!h) return nullptr;
+  int32_t curve = 0; uint32_t first = 0, nwit = 0;
+  NAPI_OK(napi_get_value_int32(env, argv[1], &curve));
+  NAPI_OK(napi_get_value_uint32(env, argv[2], &first));
+  napi_typedarray_type t; napi_value ab; size_t off, len; void *p;
+  NAPI_OK(napi_get_typedarray_info(env, argv[3], &t, &len, &p, &ab, &off));
+  api.info(h->ctx, nullptr, nullptr, &nwit, nullptr, nullptr);
+  if (t != napi_uint8_array || first >= nwit || len != (size_t)(nwit - first) * 64) {
+    napi_throw_type_error(env, nullptr, "generators: Uint8Array with 64 bytes (x, y little-endian) per committed slot");
+    return nullptr;
+  }
+  if (h->key) { api.commit_key_destroy(h->key); h->key = nullptr; }
+  const int32_t rc = api.commit_key_create(h->ctx, curve, first, (const uint8_t *)p, &h->key);
+  if (rc != B3W_OK) return throw_status(env, h, rc, "b3w_commit_key_create failed");
+  napi_value u;
+  napi_get_undefined(env, &u);
+  return u;
+}
+
+// batchCommit(handle) -> { points: Uint8Array(n * 64), status: Int32Array(n) }: Pedersen commitments of the last batchRun
+napi_value BatchCommit(napi_env env, napi_callback_info info) {
+  size_t argc = 1; napi_value argv[1];
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+  Handle *h = get_handle(env, argv[0]);
+  if (!h) return nullptr;
+  if (!h->batch || !h->key || !h->batch_n) { napi_throw_error(env, nullptr, "batchCommit needs commitKey and a batchRun"); return nullptr; }
+  void *pp, *ps; napi_value abp, abs_, o, v;
+  NAPI_OK(napi_create_arraybuffer(env, (size_t)h->batch_n * 64, &pp, &abp));
+  NAPI_OK(napi_create_arraybuffer(env, (size_t)h->batch_n * 4, &ps, &abs_));
+  const int32_t rc = api.batch_commit(h->batch, h->key, (uint8_t *)pp, (int32_t *)ps);
+  if (rc != B3W_OK) return throw_status(env, h, rc, "b3w_batch_commit failed");
+  NAPI_OK(napi_create_object(env, &o));
+  napi_create_typedarray(env, napi_uint8_array, (size_t)h->batch_n * 64, abp, 0, &v); napi_set_named_property(env, o, "points", v);
+  napi_create_typedarray(env, napi_int32_array, h->batch_n, abs_, 0, &v); napi_set_named_property(env, o, "status", v);
+  return o;
+}
+
 // commUniqueId() -> Uint8Array(128): rank 0 creates it and hands it to the other ranks (file, socket, env)
 napi_value CommUniqueId(napi_env env, napi_callback_info) {
   if (!load_api()) { napi_throw_error(env, nullptr, api.err.c_str()); return nullptr; }
@@ -483,6 +531,8 @@ napi_value Init(napi_env env, napi_value exports) {
       {"batchVerify", nullptr, BatchVerify, nullptr, nullptr, nullptr, napi_default, nullptr},
       {"batchPlacement", nullptr, BatchPlacement, nullptr, nullptr, nullptr, napi_default, nullptr},
       {"chainFold", nullptr, ChainFold, nullptr, nullptr, nullptr, napi_default, nullptr},
+      {"commitKey", nullptr, CommitKey, nullptr, nullptr, nullptr, napi_default, nullptr},
+      {"batchCommit", nullptr, BatchCommit, nullptr, nullptr, nullptr, napi_default, nullptr},
       {"commUniqueId", nullptr, CommUniqueId, nullptr, nullptr, nullptr, napi_default, nullptr},
       {"commCreate", nullptr, CommCreate, nullptr, nullptr, nullptr, napi_default, nullptr},
       {"batchAllgatherPublic", nullptr, BatchAllgatherPublic, nullptr, nullptr, nullptr, napi_default, nullptr},

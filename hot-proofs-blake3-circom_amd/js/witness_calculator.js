@@ -175,8 +175,18 @@ class WitnessCalculator {
       nat.batchWriteWtns(this.instance, first || 0, count === undefined ? r.n - (first || 0) : count, dir, prefix || "witness_");
     // every rank's public outputs of this batch (needs wc.joinRanks first; all ranks run the same batch size)
     r.allgatherPublic = () => nat.batchAllgatherPublic(this.instance);
+    // Pedersen commitments of the batch's witnesses on the device (after wc.setCommitKey): { points, status }
+    r.commit = () => nat.batchCommit(this.instance);
     r.placement = nat.batchPlacement(this.instance);   // "mixed": the body buffer alternates two classes of HBM
     return r;
+  }
+
+  // ---- extension: commitment key for batch.commit().  curve: "bn254_g1" | "vesta"; generators: Uint8Array with one
+  // affine point per committed slot (x then y, 32-byte little-endian each), slots firstSlot .. witnessSize - 1.
+  setCommitKey(curve, generators, firstSlot) {
+    const id = {bn254_g1: 0, vesta: 1}[curve];
+    if (id === undefined) throw new Error("curve: bn254_g1 or vesta");
+    native().commitKey(this.instance, id, firstSlot || 0, generators);
   }
 
   // ---- extension: this calculator's GPU joins an RCCL communicator (see commUniqueId above)

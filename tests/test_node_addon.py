@@ -255,3 +255,38 @@ def test_js_rccl_exchange_single_rank():
     import blake3_ref
     pre = bytes((i * 7 + 3) % 251 for i in range(8 * 1024))
     assert out["fold"] == {"hash": blake3_ref.blake3(pre).hex(), "same": True, "first": 0, "local": 8, "par": 24, "bad": 0}
+
+
+@needs_node
+@pytest.mark.gpu
+def test_js_batch_commit_matches_plain_integer_group_law(tmp_path):
+    """wc.setCommitKey / batch.commit() from Node against tests/ec_ref.py."""
+    import numpy as np, ec_ref as E
+    g = T.golden("compression")
+    cases = [c for c in g["cases"] if "error" not in c and T.is_canonical_u32("compression", c["input"])][:2]
+    gens = E.random_points("bn254_g1", T.NWIT["compression"] - 17, seed=b"js")
+    (tmp_path / "gens.bin").write_bytes(E.points_to_bytes(gens))
+    r = _node("""
+      const builder = require('./hot-proofs-blake3-circom_amd/js/witness_calculator.js');
+      const fs = require('fs');
+      (async () => {
+        const cases = JSON.parse(process.argv[1]);
+        const wc = await builder('compression');
+        wc.setCommitKey('bn254_g1', new Uint8Array(fs.readFileSync(process.argv[2])), 17);
+        const recs = new Uint32Array(28 * cases.length);
+        cases.forEach((c, k) => { const v = [].concat(c.input.h, c.input.m, c.input.t, [c.input.b, c.input.d]); v.forEach((x, j) => recs[28 * k + j] = Number(x)); });
+        const b = await wc.calculateWitnessBatch(recs);
+        const c = b.commit();
+        console.log(JSON.stringify({points: Buffer.from(c.points).toString('hex'), status: Array.from(c.status)}));
+      })().catch(e => { console.error(e); process.exit(1); });
+    """, json.dumps(cases), str(tmp_path / "gens.bin"))
+    assert r.returncode == 0, r.stderr
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out["status"] == [0, 0]
+    W = T.workloads()
+    recs = np.array([[int(x) for x in (c["input"]["h"] + c["input"]["m"] + c["input"]["t"] + [c["input"]["b"], c["input"]["d"]])] for c in cases], dtype=np.uint32)
+    _, bodies = T.oracle_batch_u32("compression", recs)
+    pts = bytes.fromhex(out["points"])
+    for i in range(2):
+        vals = [int.from_bytes(bodies[i, 32 * s: 32 * s + 32].tobytes(), "little") for s in range(17, T.NWIT["compression"])]
+        assert E.point_from_bytes(pts[64 * i: 64 * i + 64]) == E.commit(vals, gens, "bn254_g1"), i
