@@ -63,7 +63,7 @@ constexpr uint32_t PROBE_STREAMS = 512;            // 256 per side
 constexpr uint64_t PROBE_PITCH = 768 * 1024;       // 256 streams x 768 KiB = 192 MiB <= HANDLE
 constexpr double CONTRAST = 1.18;                  // fast / slow ratio that counts as "another class" (measured: 1.25-1.3)
 constexpr uint64_t POOL_CAP_PER_LABEL = 12 * GiB;  // labelled handles kept for later buffers, per label (A, B, C)
-constexpr uint64_t ARENA = 32ull << 40;            // virtual address range per device, bump-allocated, never reused
+constexpr uint64_t ARENA = 32ull << 40;            // virtual address range per device (less if refused), bump-allocated, never reused
 
 enum : uint8_t { LA = 0, LB = 1, LC = 2, LM = 3 };
 
@@ -83,7 +83,8 @@ struct Pool {
   bool hopeless = false;                            // a walk of 64 GiB or more found no second class: do not walk again
   hipMemGenericAllocationHandle_t h0{}, f0{};
   double thr = 0, lo = 0, hi = 0;
-  uint8_t *arena = nullptr;                         // ARENA bytes of VA
+  uint8_t *arena = nullptr;                         // arena_bytes of VA
+  uint64_t arena_bytes = 0;
   uint32_t next_slot = 0;                           // next never-used 256 MiB slot of it
   uint32_t slot_h0 = 0, slot_f0 = 0;
   std::vector<Cand> spare;                          // labelled, each still mapped in its probe slot
@@ -106,7 +107,11 @@ Pool *pool_for(int device) {
   p->acc.location = p->prop.location;
   p->acc.flags = hipMemAccessFlagsProtReadWrite;
   void *va = nullptr;
-  if (hipMemAddressReserve(&va, ARENA, 2 * MiB, nullptr, 0) != hipSuccess) { (void)hipGetLastError(); delete p; return nullptr; }
+  for (uint64_t sz = ARENA; sz >= (1ull << 40) && !va; sz >>= 1) {
+    if (hipMemAddressReserve(&va, sz, 2 * MiB, nullptr, 0) == hipSuccess) p->arena_bytes = sz;
+    else { (void)hipGetLastError(); va = nullptr; }
+  }
+  if (!va) { delete p; return nullptr; }
   p->arena = static_cast<uint8_t *>(va);
   (void)hipEventCreate(&p->e0);
   (void)hipEventCreate(&p->e1);
@@ -121,7 +126,7 @@ bool create_handle(Pool *p, hipMemGenericAllocationHandle_t *h) {
   return false;
 }
 uint8_t *slot_addr(Pool *p, uint32_t slot) { return p->arena + (size_t)slot * HANDLE; }
-uint32_t slots_left(Pool *p) { return (uint32_t)(ARENA / HANDLE) - p->next_slot; }
+uint32_t slots_left(Pool *p) { return (uint32_t)(p->arena_bytes / HANDLE) - p->next_slot; }
 // map a handle at the next never-used slot; false when the arena is used up or the driver refuses
 bool map_new(Pool *p, Cand &c) {
   if (!slots_left(p)) return false;
@@ -359,6 +364,7 @@ extern "C" int b3w_place_free(void *ptr) {
 extern "C" void b3w_place_trim(void) {
   std::lock_guard<std::mutex> guard(mtx());
   for (Pool *p : pools()) {
+    (void)hipSetDevice(p->device);
     for (Cand &c : p->spare) release(p, c);
     p->spare.clear();
   }
