@@ -276,12 +276,12 @@ __global__ __launch_bounds__(T) void b3w_commit_kernel(const uint8_t *__restrict
   __syncthreads();
   const uint32_t *body = reinterpret_cast<const uint32_t *>(bodies + (uint64_t)w * pitch);
   Jac acc = jac_infinity();
-  uint32_t win = t;
-  while (true) {
-    // skip ahead to this lane's next window with a set bit
-    uint32_t m = 0;
+  // skip ahead from window `from` to this lane's next window with a set bit; returns its index (>= nwin: none) and bits
+  auto next_window = [&](uint32_t from, uint32_t &m) {
+    constexpr int WN = B3W_COMMIT_WINDOW;
+    uint32_t win = from;
+    m = 0;
     while (win < nwin) {
-      constexpr int WN = B3W_COMMIT_WINDOW;
       uint32_t e[WN], word[WN];
 #pragma unroll
       for (int j = 0; j < WN; j += 4) {
@@ -298,13 +298,19 @@ __global__ __launch_bounds__(T) void b3w_commit_kernel(const uint8_t *__restrict
       if (m) break;
       win += T;
     }
+    return win;
+  };
+  uint32_t m = 0, win = next_window(t, m);
+  while (__any(win < nwin)) {
+    // the tabulated point of this window is requested first, the search for the NEXT window runs under its latency
     const bool has = win < nwin;
-    if (!__any(has)) break;
-    if (has) {
-      const uint32_t *pt = table + ((uint64_t)win * B3W_COMMIT_ENTRIES + m - 1) * 16;
-      acc = jac_madd(acc, load_fp(pt), load_fp(pt + 8), C);
-      win += T;
-    }
+    const uint32_t *pt = table + ((uint64_t)(has ? win : 0) * B3W_COMMIT_ENTRIES + (has ? m - 1 : 0)) * 16;
+    const Fp px = load_fp(pt), py = load_fp(pt + 8);
+    uint32_t m2 = 0;
+    const uint32_t win2 = has ? next_window(win + T, m2) : win;
+    if (has) acc = jac_madd(acc, px, py, C);
+    win = win2;
+    m = m2;
   }
   // LDS tree over the T partial sums
   store_fp(red + t * 24, acc.X); store_fp(red + t * 24 + 8, acc.Y); store_fp(red + t * 24 + 16, acc.Z);
