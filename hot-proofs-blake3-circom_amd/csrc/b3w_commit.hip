@@ -143,7 +143,7 @@ __device__ Fp fp_inv(const Fp &a, const B3wCurve &C) {
 __device__ __forceinline__ Jac jac_infinity() { Jac r; r.X = fp_zero(); r.Y = fp_zero(); r.Z = fp_zero(); return r; }
 
 // 2P, a = 0 (dbl-2009-l)
-__device__ Jac jac_dbl(const Jac &P, const B3wCurve &C) {
+__device__ __forceinline__ Jac jac_dbl(const Jac &P, const B3wCurve &C) {
   if (fp_is_zero(P.Z) || fp_is_zero(P.Y)) return jac_infinity();
   const Fp A = fp_sqr(P.X, C), B = fp_sqr(P.Y, C), Cc = fp_sqr(B, C);
   Fp D = fp_sub(fp_sub(fp_sqr(fp_add(P.X, B, C), C), A, C), Cc, C);
@@ -158,7 +158,7 @@ __device__ Jac jac_dbl(const Jac &P, const B3wCurve &C) {
 }
 
 // P + (x2, y2, 1) (madd-2007-bl) with the exceptional cases
-__device__ Jac jac_madd(const Jac &P, const Fp &x2, const Fp &y2, const B3wCurve &C) {
+__device__ __forceinline__ Jac jac_madd(const Jac &P, const Fp &x2, const Fp &y2, const B3wCurve &C) {
   if (fp_is_zero(x2) && fp_is_zero(y2)) return P;        // (0, 0) is not on these curves (b != 0): the table's infinity
   if (fp_is_zero(P.Z)) {
     Jac R; R.X = x2; R.Y = y2;
@@ -184,7 +184,7 @@ __device__ Jac jac_madd(const Jac &P, const Fp &x2, const Fp &y2, const B3wCurve
 }
 
 // P + Q (add-2007-bl) with the exceptional cases
-__device__ Jac jac_add(const Jac &P, const Jac &Q, const B3wCurve &C) {
+__device__ __forceinline__ Jac jac_add(const Jac &P, const Jac &Q, const B3wCurve &C) {
   if (fp_is_zero(P.Z)) return Q;
   if (fp_is_zero(Q.Z)) return P;
   const Fp Z1Z1 = fp_sqr(P.Z, C), Z2Z2 = fp_sqr(Q.Z, C);
@@ -276,41 +276,34 @@ __global__ __launch_bounds__(T) void b3w_commit_kernel(const uint8_t *__restrict
   __syncthreads();
   const uint32_t *body = reinterpret_cast<const uint32_t *>(bodies + (uint64_t)w * pitch);
   Jac acc = jac_infinity();
-  // skip ahead from window `from` to this lane's next window with a set bit; returns its index (>= nwin: none) and bits
-  auto next_window = [&](uint32_t from, uint32_t &m) {
-    constexpr int WN = B3W_COMMIT_WINDOW;
-    uint32_t win = from;
-    m = 0;
+  uint32_t win = t;
+  while (true) {
+    // skip ahead to this lane's next window with a set bit (four virtual slots at a time: short live ranges)
+    uint32_t m = 0;
     while (win < nwin) {
-      uint32_t e[WN], word[WN];
 #pragma unroll
-      for (int j = 0; j < WN; j += 4) {
-        const uint4 q = *reinterpret_cast<const uint4 *>(vslots + (uint64_t)win * WN + j);
-        e[j] = q.x; e[j + 1] = q.y; e[j + 2] = q.z; e[j + 3] = q.w;
-      }
+      for (int j = 0; j < B3W_COMMIT_WINDOW; j += 4) {
+        const uint4 q = *reinterpret_cast<const uint4 *>(vslots + (uint64_t)win * B3W_COMMIT_WINDOW + j);
+        const uint32_t e[4] = {q.x, q.y, q.z, q.w};
+        uint32_t word[4];
 #pragma unroll
-      for (int j = 0; j < WN; ++j) word[j] = body[(uint64_t)(e[j] & 0x7FFFFu) * 8 + (((e[j] >> 19) & 0xFFu) >> 5)];
+        for (int i = 0; i < 4; ++i) word[i] = body[(uint64_t)(e[i] & 0x7FFFFu) * 8 + (((e[i] >> 19) & 0xFFu) >> 5)];
 #pragma unroll
-      for (int j = 0; j < WN; ++j) {
-        if ((e[j] >> 27) && word[j] > 1) bad = 1;            // a bit slot must hold 0 or 1
-        m |= ((word[j] >> ((e[j] >> 19) & 31u)) & 1u) << j;
+        for (int i = 0; i < 4; ++i) {
+          if ((e[i] >> 27) && word[i] > 1) bad = 1;          // a bit slot must hold 0 or 1
+          m |= ((word[i] >> ((e[i] >> 19) & 31u)) & 1u) << (j + i);
+        }
       }
       if (m) break;
       win += T;
     }
-    return win;
-  };
-  uint32_t m = 0, win = next_window(t, m);
-  while (__any(win < nwin)) {
-    // the tabulated point of this window is requested first, the search for the NEXT window runs under its latency
     const bool has = win < nwin;
-    const uint32_t *pt = table + ((uint64_t)(has ? win : 0) * B3W_COMMIT_ENTRIES + (has ? m - 1 : 0)) * 16;
-    const Fp px = load_fp(pt), py = load_fp(pt + 8);
-    uint32_t m2 = 0;
-    const uint32_t win2 = has ? next_window(win + T, m2) : win;
-    if (has) acc = jac_madd(acc, px, py, C);
-    win = win2;
-    m = m2;
+    if (!__any(has)) break;
+    if (has) {
+      const uint32_t *pt = table + ((uint64_t)win * B3W_COMMIT_ENTRIES + m - 1) * 16;
+      acc = jac_madd(acc, load_fp(pt), load_fp(pt + 8), C);
+      win += T;
+    }
   }
   // LDS tree over the T partial sums
   store_fp(red + t * 24, acc.X); store_fp(red + t * 24 + 8, acc.Y); store_fp(red + t * 24 + 16, acc.Z);
