@@ -208,3 +208,37 @@ def test_streaming_wtns_writer(m, tmp_path):
     _, want = T.oracle_batch_u32("nova_vesta", nrecs)
     assert (tmp_path / "n8.wtns").read_bytes() == T.oracle_header("nova_vesta") + want[8].tobytes()
     b.close(); ctx.close()
+
+
+def test_batch_launch_inside_a_hip_graph(m):
+    """b3w_batch_run_device only launches (no allocation, no synchronisation): it can be captured into a hipGraph and
+    replayed; the replay on NEW records must produce those records' witnesses."""
+    import torch
+    n = 64
+    ctx = _ctx(m, "compression")
+    dev = torch.device("cuda:0")
+    recs_a = T.workloads().config2_compression(n, first=10)
+    recs_b = T.workloads().config2_compression(n, first=5000)
+    d_recs = torch.from_numpy(recs_a.view(np.int32)).to(dev)
+    d_bodies = torch.zeros((n, ctx.body_bytes), dtype=torch.uint8, device=dev)
+    d_pub = torch.zeros((n, 16), dtype=torch.int32, device=dev)
+    d_st = torch.full((n,), -1, dtype=torch.int32, device=dev)
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):                                       # warm-up outside the capture
+        ctx.run_device(d_recs.data_ptr(), n, d_bodies.data_ptr(), 0, d_pub.data_ptr(), d_st.data_ptr(), side.cuda_stream)
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side):
+        ctx.run_device(d_recs.data_ptr(), n, d_bodies.data_ptr(), 0, d_pub.data_ptr(), d_st.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    d_recs.copy_(torch.from_numpy(recs_b.view(np.int32)))                 # new inputs, same buffers
+    d_bodies.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    assert int(d_st.abs().sum().item()) == 0
+    _, want = T.oracle_batch_u32("compression", recs_b)
+    got = d_bodies.cpu().numpy()
+    for i in (0, 17, n - 1):
+        assert np.array_equal(got[i], want[i]), i
+    ctx.close()
