@@ -130,3 +130,22 @@ def test_recycled_buffers_hold_what_the_kernel_wrote():
         assert (b.verify() == 0).all()
         b.close()
     ctx.close()
+
+
+def test_wtns_writer_streams_across_a_seam_of_a_placed_buffer(tmp_path):
+    """b3w_batch_write_wtns (pinned double-buffered hipMemcpy2DAsync) out of a placed buffer, bodies 340..359 straddle the
+    first 256 MiB seam (body 348): files byte-identical to calculateWTNSBin's image."""
+    ctx = m.Context("compression", 0)
+    n = 1024
+    recs = m.workloads.config2_compression(n, first=77)
+    b = m.Batch(ctx, n)
+    b.run(recs)
+    wrote = b.write_wtns(tmp_path, "w_", first=340, count=20)
+    assert wrote == 20
+    idx = [340, 347, 348, 349, 359]
+    bad, want = T.oracle_batch_u32("compression", recs[idx])
+    hdr = ctx.wtns_header()
+    for j, i in enumerate(idx):
+        assert (tmp_path / f"w_{i}.wtns").read_bytes() == hdr + want[j].tobytes(), i
+    b.close()
+    ctx.close()
