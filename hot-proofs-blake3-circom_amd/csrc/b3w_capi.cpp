@@ -512,9 +512,9 @@ int32_t b3w_batch_autotune_device(b3w_ctx *ctx, const uint32_t *d_records, uint3
   if (!ctx || !d_records || !d_bodies || !n) return B3W_E_BAD_ARGUMENT;
   int32_t rc = ensure_scratch(ctx);
   if (rc) return rc;
-  // fused with 4 (compression) / 2 (nova) bodies per wave, compression also with 8 (for large batches: occupancy-limited,
-  // variant 8), and the two-kernel sweep
-  const int candidates[3] = {0, ctx->desc.kind == B3W_KIND_COMP ? (n > 6144 ? 8 : 3) : 0, B3W_VARIANT_SWEEP};
+  // fused with 4 (compression) / 2 (nova) bodies per wave, also with 8 (compression: for large batches occupancy-limited,
+  // variant 8; nova O2: variant 3), and the two-kernel sweep
+  const int candidates[3] = {0, ctx->desc.kind == B3W_KIND_COMP ? (n > 6144 ? 8 : 3) : ctx->desc.kind == B3W_KIND_NOVA_O2 ? 3 : 0, B3W_VARIANT_SWEEP};
   int best = ctx->variant;
   float best_ms = 1e30f;
   const int saved = ctx->variant;

@@ -950,6 +950,7 @@ extern "C" int b3w_launch_batch(int kind, int variant, const uint32_t *d_recs, u
         case 0: B3W_LAUNCH_NOVA(B3W_KIND_NOVA_O2, 2); break;
         case 1: B3W_LAUNCH_NOVA(B3W_KIND_NOVA_O2, 1); break;
         case 2: B3W_LAUNCH_NOVA(B3W_KIND_NOVA_O2, 4); break;
+        case 3: B3W_LAUNCH_NOVA(B3W_KIND_NOVA_O2, 8); break;
         default: return -1;
       }
     } else {

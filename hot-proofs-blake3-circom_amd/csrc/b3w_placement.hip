@@ -184,9 +184,15 @@ bool calibrate(Pool *p, uint32_t &budget, std::vector<Cand> &got) {
     for (double x : r0) { lo = std::min(lo, x); hi = std::max(hi, x); }
     if (lo > 0 && hi >= CONTRAST * lo) {
       const double thr = sqrt(lo * hi);
-      // two consecutive fast handles: not a timing outlier
+      // two consecutive handles that are fast with h0 (not a timing outlier) AND slow with each other: both lie in one
+      // other class.  A handle that straddles a class border is fast with h0 and still fairly fast with its pure
+      // neighbour; as the second reference it would label a whole class "third" and both sides of the buffer would be
+      // filled from it (seen on a box whose first border fell into the second handle).
       const size_t n = r0.size();
-      if (n >= 2 && r0[n - 1] >= thr && r0[n - 2] >= thr) { cand = (int)n - 2; p->lo = lo; p->hi = hi; p->thr = thr; break; }
+      if (n >= 2 && r0[n - 1] >= thr && r0[n - 2] >= thr && probe_slots(p, seen[n - 2].slot, seen[n - 1].slot) < thr) {
+        cand = (int)n - 1; p->lo = lo; p->hi = hi; p->thr = thr;
+        break;
+      }
     }
   }
   if (cand < 0) {                                     // one class as far as the budget reaches
@@ -288,7 +294,40 @@ extern "C" int b3w_place_alloc(int device, uint64_t bytes, int want_mixed, void 
         if (probe_slots(p, order[s].slot, extra[t].slot) >= p->thr) { std::swap(order[s + 1], extra[t]); ok = true; }
       if (!ok) slow_seams++;
     }
-    if (slow_seams > nh / 8) found = false;              // not worth calling it mixed
+    if (slow_seams > nh / 8) {
+      // the labels did not hold (impure references or recycled, fragmented handles): build the chain greedily from
+      // direct probes instead — next piece = any unused candidate that is fast with the previous piece
+      std::vector<Cand> cands = order;
+      cands.insert(cands.end(), extra.begin(), extra.end());
+      std::vector<char> used(cands.size(), 0);
+      std::vector<Cand> chain;
+      chain.push_back(cands[0]);
+      used[0] = 1;
+      uint32_t slow2 = 0;
+      size_t scan = 1;
+      while (chain.size() < nh) {
+        int pick = -1, fallback = -1, tries = 0;
+        for (size_t k = 0; k < cands.size() && tries < 12; k++) {
+          const size_t i = (scan + k) % cands.size();
+          if (used[i]) continue;
+          if (fallback < 0) fallback = (int)i;
+          tries++;
+          if (probe_slots(p, chain.back().slot, cands[i].slot) >= p->thr) { pick = (int)i; break; }
+        }
+        if (pick < 0) { pick = fallback; slow2++; }
+        if (pick < 0) break;
+        used[pick] = 1;
+        chain.push_back(cands[pick]);
+        scan = (size_t)pick + 1;
+      }
+      if (chain.size() == nh && slow2 < slow_seams) {
+        order = chain;
+        extra.clear();
+        for (size_t i = 0; i < cands.size(); i++) if (!used[i]) extra.push_back(cands[i]);
+        slow_seams = slow2;
+      }
+      if (slow_seams > nh / 8) found = false;            // not worth calling it mixed
+    }
   } else {
     // plain: whatever handles there are, then new ones
     std::vector<Cand> all;
