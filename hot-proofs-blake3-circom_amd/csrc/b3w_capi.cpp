@@ -411,6 +411,7 @@ int32_t b3w_create(int32_t circuit, int32_t device, b3w_ctx **out) {
   if (e != hipSuccess) { b3w_destroy(ctx); return B3W_E_HIP; }
   const char *v = getenv("B3W_VARIANT");
   if (v) ctx->variant = atoi(v);
+  else if (ctx->desc.kind == B3W_KIND_NOVA_O2) ctx->variant = 3;      // 8 bodies per wave: 1-4 % faster than 2 at every batch size
   if (ctx->variant >= B3W_VARIANT_SWEEP && ensure_scratch(ctx) != B3W_OK) { b3w_destroy(ctx); return B3W_E_HIP; }
   *out = ctx;
   return B3W_OK;

@@ -247,25 +247,29 @@ extern "C" int b3w_place_alloc(int device, uint64_t bytes, int want_mixed, void 
   if (slots_left(p) < 2 * nh + 8) return -(int)hipErrorOutOfMemory;          // address range used up: caller falls back
   budget = std::min<uint32_t>(budget, slots_left(p) - nh - 4);
 
-  std::vector<Cand> side1, side2, thirds, rejects, extra;      // A, B, C, M, and what exceeds the need
-  auto sort_in = [&](const Cand &c) {
-    if (c.label == LA) (side1.size() < need1 + 2 ? side1 : extra).push_back(c);
-    else if (c.label == LB) (side2.size() < need2 + 2 ? side2 : extra).push_back(c);
-    else if (c.label == LC) thirds.push_back(c);
-    else rejects.push_back(c);
+  // Candidates by label.  The buffer alternates two SIDES; a side may mix two classes (its pieces are never neighbours),
+  // but no class may appear on both sides: the sides are one class against the other two.
+  std::vector<Cand> cls[3], rejects, extra;
+  auto sort_in = [&](const Cand &c) { (c.label < 3 ? cls[c.label] : rejects).push_back(c); };
+  // which class stands alone (and on which side) so that both sides can be covered; -1 = not yet
+  auto split = [&](bool &alone_is_side1) {
+    const size_t total = cls[0].size() + cls[1].size() + cls[2].size();
+    for (int x = 0; x < 3; x++) {
+      const size_t own = cls[x].size(), rest = total - own;
+      if (own >= need1 && rest >= need2) { alone_is_side1 = true; return x; }
+      if (own >= need2 && rest >= need1) { alone_is_side1 = false; return x; }
+    }
+    return -1;
   };
-  auto covered = [&]() {
-    const size_t s1 = std::min<size_t>(side1.size(), need1), s2 = std::min<size_t>(side2.size(), need2);
-    return (need1 - s1) + (need2 - s2) <= thirds.size();
-  };
-  bool found = false;
+  bool found = false, alone1 = true;
+  int alone = -1;
   std::vector<Cand> got;
   got.swap(p->spare);                                          // labelled earlier, still mapped in their probe slots
   if (want_mixed && !p->hopeless) {
     if (!p->refs) (void)calibrate(p, budget, got);
     for (const Cand &c : got) sort_in(c);
     got.clear();
-    while (p->refs && !covered() && budget) {
+    while (p->refs && (alone = split(alone1)) < 0 && budget) {
       Cand c{};
       if (!create_handle(p, &c.h)) break;
       budget--;
@@ -273,19 +277,22 @@ extern "C" int b3w_place_alloc(int device, uint64_t bytes, int want_mixed, void 
       c.label = label_slot(p, c.slot);
       sort_in(c);
     }
-    found = p->refs && covered();
+    found = p->refs && (alone = split(alone1)) >= 0;
   }
   for (const Cand &c : got) sort_in(c);                        // (search skipped)
   // the order of the pieces
   std::vector<Cand> order;
   uint32_t slow_seams = 0;
   if (found) {
-    while (side1.size() > need1) { extra.push_back(side1.back()); side1.pop_back(); }
-    while (side2.size() > need2) { extra.push_back(side2.back()); side2.pop_back(); }
-    while (side1.size() < need1) { side1.push_back(thirds.back()); thirds.pop_back(); }
-    while (side2.size() < need2) { side2.push_back(thirds.back()); thirds.pop_back(); }
-    for (const Cand &c : thirds) extra.push_back(c);
-    thirds.clear();
+    std::vector<Cand> side1, side2;                            // most recently created first
+    std::vector<Cand> &sa = alone1 ? side1 : side2, &sr = alone1 ? side2 : side1;
+    const uint32_t na = alone1 ? need1 : need2, nr = alone1 ? need2 : need1;
+    for (size_t i = cls[alone].size(); i-- > 0;) (sa.size() < na ? sa : extra).push_back(cls[alone][i]);
+    for (int x = 0; x < 3; x++) {
+      if (x == alone) continue;
+      for (size_t i = cls[x].size(); i-- > 0;) (sr.size() < nr ? sr : extra).push_back(cls[x][i]);
+    }
+    for (auto &v : cls) v.clear();
     for (uint32_t s = 0; s < nh; s++) order.push_back((s & 1) ? side2[s / 2] : side1[s / 2]);
     // check every seam of that order directly; where two neighbours are slow together try other candidates
     for (uint32_t s = 0; s + 1 < nh; s++) {
@@ -331,7 +338,7 @@ extern "C" int b3w_place_alloc(int device, uint64_t bytes, int want_mixed, void 
   } else {
     // plain: whatever handles there are, then new ones
     std::vector<Cand> all;
-    for (auto *v : {&side1, &side2, &thirds, &rejects, &extra}) { all.insert(all.end(), v->begin(), v->end()); v->clear(); }
+    for (auto *v : {&cls[0], &cls[1], &cls[2], &rejects, &extra}) { all.insert(all.end(), v->begin(), v->end()); v->clear(); }
     for (const Cand &c : all) (order.size() < nh ? order : extra).push_back(c);
     while (order.size() < nh) {
       Cand c{};
