@@ -913,7 +913,10 @@ int32_t b3w_commit_key_create(b3w_ctx *ctx, int32_t curve, uint32_t first_slot, 
     const uint32_t mode = (table[first_slot + i] >> 17) & 3u;
     nbits[i] = mode == B3W_MODE_BIT ? 1u : mode == B3W_MODE_W32 ? 32u : mode == B3W_MODE_W64 ? 64u : 256u;
     first_v[i] = (uint32_t)vslots.size();
-    for (uint32_t k = 0; k < nbits[i]; k++) vslots.push_back((first_slot + i) | (k << 19) | ((nbits[i] == 1 ? 1u : 0u) << 27));
+    // bits 28..: on bit 0 of a 32- / 64-bit slot its width in words (the kernel checks that the rest of the element is 0)
+    for (uint32_t k = 0; k < nbits[i]; k++)
+      vslots.push_back((first_slot + i) | (k << 19) | ((nbits[i] == 1 ? 1u : 0u) << 27) |
+                       ((k == 0 && (nbits[i] == 32 || nbits[i] == 64) ? nbits[i] / 32 : 0u) << 28));
   }
   // windows of B3W_COMMIT_WINDOW virtual slots; the pad entries read bit 31 of slot 0 (the constant 1): always 0
   const uint32_t V0 = (uint32_t)vslots.size();

@@ -18,8 +18,9 @@
 //            thread per witness (Fermat inversion), and stores the affine points.
 // Arithmetic: 256-bit Montgomery (CIOS, eight 32-bit limbs, modulus passed at run time), complete handling of the
 // exceptional cases (infinity, P + P, P - P) so that related generators cannot break it.
-// Domain: bodies of the batch kernels (every bit slot holds 0 or 1, words fit their slot's width); a bit slot holding
-// anything else flags the witness (status 103) instead of producing a wrong commitment.
+// Domain: bodies of the batch kernels (every bit slot holds 0 or 1, words fit their slot's width); a slot holding
+// anything else (e.g. a body of the exact kernel with a 254-bit input) flags the witness (status 103) instead of
+// producing a wrong commitment.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
@@ -265,7 +266,7 @@ __global__ __launch_bounds__(64) void b3w_commit_window_kernel(const uint32_t *_
 // ---- commit: one workgroup per witness
 template <int T>        // threads per witness
 __global__ __launch_bounds__(T) void b3w_commit_kernel(const uint8_t *__restrict__ bodies, uint32_t n, uint64_t pitch,
-                                                         const uint32_t *__restrict__ vslots /* B3W_COMMIT_WINDOW per window: slot | bit << 19 | single << 27 */,
+                                                         const uint32_t *__restrict__ vslots /* B3W_COMMIT_WINDOW per window: slot | bit << 19 | single << 27 | width words << 28 */,
                                                          const uint32_t *__restrict__ table, uint32_t nwin, uint32_t *__restrict__ sums /* n x 24 words: X Y Z */,
                                                          int32_t *__restrict__ status, B3wCurve C) {
   __shared__ __attribute__((aligned(16))) uint32_t red[T * 24];
@@ -290,7 +291,14 @@ __global__ __launch_bounds__(T) void b3w_commit_kernel(const uint8_t *__restrict
         for (int i = 0; i < 4; ++i) word[i] = body[(uint64_t)(e[i] & 0x7FFFFu) * 8 + (((e[i] >> 19) & 0xFFu) >> 5)];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          if ((e[i] >> 27) && word[i] > 1) bad = 1;          // a bit slot must hold 0 or 1
+          if (((e[i] >> 27) & 1u) && word[i] > 1) bad = 1;   // a bit slot must hold 0 or 1
+          const uint32_t words = e[i] >> 28;                 // on the first virtual slot of a 32- or 64-bit slot: its width in words
+          if (words) {                                       // (rare: 1.4 % of the virtual slots) the rest of the element must be 0
+            const uint32_t *el = body + (uint64_t)(e[i] & 0x7FFFFu) * 8;
+            uint32_t rest = 0;
+            for (uint32_t k = words; k < 8; ++k) rest |= el[k];
+            if (rest) bad = 1;
+          }
           m |= ((word[i] >> ((e[i] >> 19) & 31u)) & 1u) << (j + i);
         }
       }

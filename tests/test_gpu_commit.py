@@ -122,8 +122,11 @@ def test_commit_flags_bodies_outside_its_domain_and_reports_rate():
     d_bodies[7, 32 * 200] = 2                                   # slot 200 is a bit slot (outXor bits): 2 is not a bit
     L.b3w_batch_commit_device(ctx.handle, key, d_bodies.data_ptr(), n, 0, d_pts.data_ptr(), d_st.data_ptr(), s)
     torch.cuda.synchronize()
+    d_bodies[9, 32 * 25 + 9] = 1                                # slot 25 = m[0], a 32-bit slot: a byte beyond its width
+    L.b3w_batch_commit_device(ctx.handle, key, d_bodies.data_ptr(), n, 0, d_pts.data_ptr(), d_st.data_ptr(), s)
+    torch.cuda.synchronize()
     st = d_st.cpu().numpy()
-    assert st[7] == 103 and (np.delete(st, 7) == 0).all()
+    assert st[7] == 103 and st[9] == 103 and (np.delete(st, [7, 9]) == 0).all()
     L.b3w_commit_key_destroy(key)
     ctx.close()
 
