@@ -290,3 +290,17 @@ def test_js_batch_commit_matches_plain_integer_group_law(tmp_path):
     for i in range(2):
         vals = [int.from_bytes(bodies[i, 32 * s: 32 * s + 32].tobytes(), "little") for s in range(17, T.NWIT["compression"])]
         assert E.point_from_bytes(pts[64 * i: 64 * i + 64]) == E.commit(vals, gens, "bn254_g1"), i
+
+
+@needs_node
+@pytest.mark.gpu
+def test_cli_fold_prints_the_blake3_hash(tmp_path):
+    import blake3_ref
+    pre = bytes((i * 13 + 5) % 256 for i in range(3 * 1024 + 77))
+    (tmp_path / "pre.bin").write_bytes(pre)
+    r = subprocess.run([NODE, os.path.join(JS, "b3wit_cli.js"), "--fold", "nova_bn254", str(tmp_path / "pre.bin"), str(tmp_path / "pub.json")],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr
+    assert "blake3 = " + blake3_ref.blake3(pre).hex() in r.stdout and "(0 rejected)" in r.stdout
+    pub = json.loads((tmp_path / "pub.json").read_text())
+    assert pub["nLeafSteps"] == 3 * 16 + 2 and len(pub["publicOutputs"]) == 15 * (pub["nLeafSteps"] + pub["nParentSteps"])
