@@ -287,6 +287,7 @@ struct b3w_ctx {
   CircuitDesc desc{};
   int device = -1;
   int variant = 0;
+  bool variant_auto = true;           // no B3W_VARIANT and no autotune yet: bodies per wave chosen by batch size
   std::vector<InputSignal> inputs;
   uint32_t *d_table = nullptr;        // slot table; 32 pad entries in front of it (expand() indexes from slot - 3)
   uint32_t *d_table_base = nullptr;
@@ -410,8 +411,7 @@ int32_t b3w_create(int32_t circuit, int32_t device, b3w_ctx **out) {
   if (e == hipSuccess) e = hipMalloc((void **)&ctx->d_status1, 4);
   if (e != hipSuccess) { b3w_destroy(ctx); return B3W_E_HIP; }
   const char *v = getenv("B3W_VARIANT");
-  if (v) ctx->variant = atoi(v);
-  else if (ctx->desc.kind == B3W_KIND_NOVA_O2) ctx->variant = 3;      // 8 bodies per wave: 1-4 % faster than 2 at every batch size
+  if (v) { ctx->variant = atoi(v); ctx->variant_auto = false; }
   if (ctx->variant >= B3W_VARIANT_SWEEP && ensure_scratch(ctx) != B3W_OK) { b3w_destroy(ctx); return B3W_E_HIP; }
   *out = ctx;
   return B3W_OK;
@@ -480,7 +480,15 @@ int32_t b3w_batch_run_device(b3w_ctx *ctx, const uint32_t *d_records, uint32_t n
   if (pitch == 0) pitch = body;
   if (pitch < body || (pitch & 31)) { ctx->last_error = "pitch must be >= witness_size*32 and a multiple of 32"; return B3W_E_BAD_ARGUMENT; }
   if (reinterpret_cast<uintptr_t>(d_bodies) & 15) { ctx->last_error = "d_bodies must be 16-byte aligned"; return B3W_E_BAD_ARGUMENT; }
-  int rc = b3w_launch_batch(ctx->desc.kind, ctx->variant, d_records, n, d_bodies, pitch, ctx->d_table, ctx->desc.nwit,
+  // default choice of bodies per wave (tools/ubench/small_batches.py, batch_sizes.py): small batches want as many
+  // waves as bodies (one body streams at 13 GB/s per wave), large ones few fat waves
+  int variant = ctx->variant;
+  if (ctx->variant_auto) {
+    if (ctx->desc.kind == B3W_KIND_COMP) variant = n <= 1024 ? 1 : 0;
+    else if (ctx->desc.kind == B3W_KIND_NOVA_O2) variant = n <= 1024 ? 1 : n <= 3072 ? 0 : 3;
+    else variant = n <= 1024 ? 1 : 0;
+  }
+  int rc = b3w_launch_batch(ctx->desc.kind, variant, d_records, n, d_bodies, pitch, ctx->d_table, ctx->desc.nwit,
                             d_public, d_status, ctx->d_aux, ctx->d_scratch, ctx->scratch_cap, (hipStream_t)stream);
   if (rc == 0) return B3W_OK;
   if (rc == -5) { ctx->last_error = "the sweep path needs 32-byte aligned bodies and pitch < 2^30"; return B3W_E_BAD_ARGUMENT; }
@@ -519,6 +527,8 @@ int32_t b3w_batch_autotune_device(b3w_ctx *ctx, const uint32_t *d_records, uint3
   int best = ctx->variant;
   float best_ms = 1e30f;
   const int saved = ctx->variant;
+  const bool saved_auto = ctx->variant_auto;
+  ctx->variant_auto = false;
   for (int ci = 0; ci < 3; ci++) {
     const int c = candidates[ci];
     if (ci == 1 && c == candidates[0]) continue;
@@ -529,10 +539,10 @@ int32_t b3w_batch_autotune_device(b3w_ctx *ctx, const uint32_t *d_records, uint3
       rc = b3w_batch_run_device(ctx, d_records, n, d_bodies, pitch, d_public, d_status, stream);
     if (rc == B3W_OK) rc = b3w_batch_time_device(ctx, d_records, n, d_bodies, pitch, d_public, d_status, stream, 5, &ms);
     if (rc == B3W_E_BAD_ARGUMENT) continue;          // this path cannot take these buffers (alignment): not a candidate
-    if (rc) { ctx->variant = saved; return rc; }
+    if (rc) { ctx->variant = saved; ctx->variant_auto = saved_auto; return rc; }
     if (ms < best_ms) { best_ms = ms; best = c; }
   }
-  if (best_ms >= 1e30f) { ctx->variant = saved; return B3W_E_BAD_ARGUMENT; }
+  if (best_ms >= 1e30f) { ctx->variant = saved; ctx->variant_auto = saved_auto; return B3W_E_BAD_ARGUMENT; }
   ctx->variant = best;
   if (chosen_variant) *chosen_variant = best;
   if (chosen_ms) *chosen_ms = best_ms;
