@@ -10,12 +10,16 @@
 //           circuits/blake3_common.circom:142-203; SingleRound :128-161; permutation :15-26.
 //   EXPAND  all 64 lanes stream the flat witness vector to HBM: a per-circuit slot table
 //           (slot -> LDS word, shift, mode; built from layouts/*.layout) says which bit or word
-//           of the image each 32-byte slot holds.  Lane pair (2j,2j+1) owns slot 32g+j of group g
-//           and each lane stores one 16-byte half, so every wave store instruction is one fully
-//           coalesced 1 KiB segment (global_store_dwordx4 x 64 lanes).
+//           of the image each 32-byte slot holds.  The body is written in 1 KiB tiles aligned to
+//           128-byte lines in absolute addresses; a lane pair owns one slot of a tile and each lane
+//           stores one 16-byte half, so every wave store instruction is eight whole lines
+//           (global_store_dwordx4 x 64 lanes).  A wave takes W bodies that start at the same offset
+//           into a line (WaveBodies), so one lane -> slot mapping serves them all.
+//   VERIFY  (MODE 2) the same walk reading the bodies back and comparing (on-device consumer).
 //
 // The work is integer/bit expansion bound by HBM writes (770 976 B written for 112 B read per
-// compression witness); there is no contraction, so no MFMA.
+// compression witness); there is no contraction, so no MFMA.  Where the bodies live in HBM matters
+// as much as the kernel: see b3w_placement.hip.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
