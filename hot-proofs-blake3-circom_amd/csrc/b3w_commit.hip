@@ -11,10 +11,10 @@
 //   set-up   every slot is cut into its bits ("virtual slots": slot, bit k; V = 40 k compression, 58 k nova O2) with
 //            the point 2^k * G_slot each (b3w_commit_setup_kernel); W = 12 consecutive virtual slots form a WINDOW whose
 //            4 095 non-empty subset sums are tabulated (b3w_commit_window_kernel: 3.3 k windows x 4 095 affine points = 0.9 GB);
-//   commit   one 256-thread workgroup per witness; thread t owns windows t, t + 256, ...; it gathers the W bits of
+//   commit   32 lanes per witness (two witnesses per wave); lane t owns windows t, t + 32, ...; it gathers the W bits of
 //            a window from the body, skips ahead to its next NON-ZERO window, and then the whole wave does one mixed
 //            Jacobian + affine addition with the tabulated point — no doublings, one addition per W slots, no
-//            zero work in lock step; an LDS tree adds the 256 partial sums; a second kernel normalises them, one
+//            zero work in lock step; an LDS tree adds the 32 partial sums; a second kernel normalises them, one
 //            thread per witness (Fermat inversion), and stores the affine points.
 // Arithmetic: 256-bit Montgomery (CIOS, eight 32-bit limbs, modulus passed at run time), complete handling of the
 // exceptional cases (infinity, P + P, P - P) so that related generators cannot break it.
@@ -264,20 +264,21 @@ __global__ __launch_bounds__(64) void b3w_commit_window_kernel(const uint32_t *_
 }
 
 // ---- commit: one workgroup per witness
-template <int T>        // threads per witness
-__global__ __launch_bounds__(T) void b3w_commit_kernel(const uint8_t *__restrict__ bodies, uint32_t n, uint64_t pitch,
+template <int T, int WPB>        // threads per witness, witnesses per workgroup (T * WPB threads)
+__global__ __launch_bounds__(T * WPB) void b3w_commit_kernel(const uint8_t *__restrict__ bodies, uint32_t n, uint64_t pitch,
                                                          const uint32_t *__restrict__ vslots /* B3W_COMMIT_WINDOW per window: slot | bit << 19 | single << 27 | width words << 28 */,
                                                          const uint32_t *__restrict__ table, uint32_t nwin, uint32_t *__restrict__ sums /* n x 24 words: X Y Z */,
                                                          int32_t *__restrict__ status, B3wCurve C) {
-  __shared__ __attribute__((aligned(16))) uint32_t red[T * 24];
-  __shared__ uint32_t bad;
-  const uint32_t w = blockIdx.x, t = threadIdx.x;
-  if (w >= n) return;
-  if (t == 0) bad = 0;
+  __shared__ __attribute__((aligned(16))) uint32_t red[T * WPB * 24];
+  __shared__ uint32_t bad[WPB];
+  const uint32_t sub = threadIdx.x / T, t = threadIdx.x % T;       // which witness of the workgroup, lane within it
+  const uint32_t w = blockIdx.x * WPB + sub;
+  const bool live = w < n;
+  if (t == 0) bad[sub] = 0;
   __syncthreads();
-  const uint32_t *body = reinterpret_cast<const uint32_t *>(bodies + (uint64_t)w * pitch);
+  const uint32_t *body = reinterpret_cast<const uint32_t *>(bodies + (uint64_t)(live ? w : 0) * pitch);
   Jac acc = jac_infinity();
-  uint32_t win = t;
+  uint32_t win = live ? t : nwin;
   while (true) {
     // skip ahead to this lane's next window with a set bit (four virtual slots at a time: short live ranges)
     uint32_t m = 0;
@@ -291,13 +292,13 @@ __global__ __launch_bounds__(T) void b3w_commit_kernel(const uint8_t *__restrict
         for (int i = 0; i < 4; ++i) word[i] = body[(uint64_t)(e[i] & 0x7FFFFu) * 8 + (((e[i] >> 19) & 0xFFu) >> 5)];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
-          if (((e[i] >> 27) & 1u) && word[i] > 1) bad = 1;   // a bit slot must hold 0 or 1
+          if (((e[i] >> 27) & 1u) && word[i] > 1) bad[sub] = 1;   // a bit slot must hold 0 or 1
           const uint32_t words = e[i] >> 28;                 // on the first virtual slot of a 32- or 64-bit slot: its width in words
           if (words) {                                       // (rare: 1.4 % of the virtual slots) the rest of the element must be 0
             const uint32_t *el = body + (uint64_t)(e[i] & 0x7FFFFu) * 8;
             uint32_t rest = 0;
             for (uint32_t k = words; k < 8; ++k) rest |= el[k];
-            if (rest) bad = 1;
+            if (rest) bad[sub] = 1;
           }
           m |= ((word[i] >> ((e[i] >> 19) & 31u)) & 1u) << (j + i);
         }
@@ -313,21 +314,23 @@ __global__ __launch_bounds__(T) void b3w_commit_kernel(const uint8_t *__restrict
       win += T;
     }
   }
-  // LDS tree over the T partial sums
-  store_fp(red + t * 24, acc.X); store_fp(red + t * 24 + 8, acc.Y); store_fp(red + t * 24 + 16, acc.Z);
+  // LDS tree over each witness's T partial sums
+  uint32_t *mine = red + (sub * T + t) * 24;
+  store_fp(mine, acc.X); store_fp(mine + 8, acc.Y); store_fp(mine + 16, acc.Z);
   __syncthreads();
   for (uint32_t st = T / 2; st >= 1; st >>= 1) {
     if (t < st) {
       Jac a, b;
-      a.X = load_fp(red + t * 24); a.Y = load_fp(red + t * 24 + 8); a.Z = load_fp(red + t * 24 + 16);
-      b.X = load_fp(red + (t + st) * 24); b.Y = load_fp(red + (t + st) * 24 + 8); b.Z = load_fp(red + (t + st) * 24 + 16);
+      const uint32_t *other = mine + st * 24;
+      a.X = load_fp(mine); a.Y = load_fp(mine + 8); a.Z = load_fp(mine + 16);
+      b.X = load_fp(other); b.Y = load_fp(other + 8); b.Z = load_fp(other + 16);
       a = jac_add(a, b, C);
-      store_fp(red + t * 24, a.X); store_fp(red + t * 24 + 8, a.Y); store_fp(red + t * 24 + 16, a.Z);
+      store_fp(mine, a.X); store_fp(mine + 8, a.Y); store_fp(mine + 16, a.Z);
     }
     __syncthreads();
   }
-  if (t < 24) sums[(uint64_t)w * 24 + t] = red[t];            // the Jacobian sum; normalised by the next kernel
-  if (t == 0 && status) status[w] = bad ? 103 : 0;
+  if (live && t < 24) sums[(uint64_t)w * 24 + t] = red[sub * T * 24 + t];   // the Jacobian sum; normalised by the next kernel
+  if (live && t == 0 && status) status[w] = bad[sub] ? 103 : 0;
 }
 
 // ---- normalise: one THREAD per witness (a Fermat inversion is 380 dependent multiplications: on thread 0 of the commit
@@ -368,13 +371,18 @@ extern "C" int b3w_launch_commit(const uint8_t *d_bodies, uint32_t n, uint64_t p
                                  uint32_t nwin, uint32_t *d_sums /* n * 24 words scratch */, uint8_t *d_out, int32_t *d_status,
                                  const B3wCurve *curve, hipStream_t stream) {
   if (!n) return 0;
-  static const int tpw = getenv("B3W_COMMIT_THREADS") ? atoi(getenv("B3W_COMMIT_THREADS")) : 64;
-  if (tpw == 256)
-    hipLaunchKernelGGL(b3w_commit_kernel<256>, dim3(n), dim3(256), 0, stream, d_bodies, n, pitch, d_vslots, d_table, nwin, d_sums, d_status, *curve);
-  else if (tpw == 128)
-    hipLaunchKernelGGL(b3w_commit_kernel<128>, dim3(n), dim3(128), 0, stream, d_bodies, n, pitch, d_vslots, d_table, nwin, d_sums, d_status, *curve);
-  else
-    hipLaunchKernelGGL(b3w_commit_kernel<64>, dim3(n), dim3(64), 0, stream, d_bodies, n, pitch, d_vslots, d_table, nwin, d_sums, d_status, *curve);
+  // threads per witness: 32 (two witnesses per wave) for the compression circuit, 64 for the longer nova witnesses (measured)
+  static const int env_tpw = getenv("B3W_COMMIT_THREADS") ? atoi(getenv("B3W_COMMIT_THREADS")) : 0;
+  const int tpw = env_tpw ? env_tpw : nwin > 4200 ? 64 : 32;
+#define B3W_COMMIT_LAUNCH(T, WPB)                                                                                         \
+  hipLaunchKernelGGL((b3w_commit_kernel<T, WPB>), dim3((n + WPB - 1) / WPB), dim3(T * WPB), 0, stream, d_bodies, n, pitch, d_vslots, d_table, \
+                     nwin, d_sums, d_status, *curve)
+  if (tpw == 256) B3W_COMMIT_LAUNCH(256, 1);
+  else if (tpw == 128) B3W_COMMIT_LAUNCH(128, 1);
+  else if (tpw == 64) B3W_COMMIT_LAUNCH(64, 1);
+  else if (tpw == 16) B3W_COMMIT_LAUNCH(16, 4);
+  else B3W_COMMIT_LAUNCH(32, 2);                       // two witnesses per wave
+#undef B3W_COMMIT_LAUNCH
   hipLaunchKernelGGL(b3w_commit_normalize_kernel, dim3((n + 63) / 64), dim3(64), 0, stream, d_sums, n, d_out, *curve);
   return (int)hipGetLastError();
 }
