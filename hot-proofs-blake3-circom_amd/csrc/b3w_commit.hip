@@ -8,9 +8,9 @@
 //
 // The witness is almost all bits: of 24 093 compression slots ~23 500 hold 0 or 1, the rest 32/34-bit words (nova:
 // plus 67 256-bit inverses).  So the multi-scalar multiplication is turned into "add precomputed points":
-//   set-up   every slot is cut into its bits ("virtual slots": slot, bit k; V = 40 k compression, 58 k nova O2) with
+//   set-up   every slot is cut into its bits ("virtual slots": slot, bit k; V = 53 k compression, 58 k nova O2) with
 //            the point 2^k * G_slot each (b3w_commit_setup_kernel); W = 12 consecutive virtual slots form a WINDOW whose
-//            4 095 non-empty subset sums are tabulated (b3w_commit_window_kernel: 3.3 k windows x 4 095 affine points = 0.9 GB);
+//            4 095 non-empty subset sums are tabulated (b3w_commit_window_kernel: 4.5 k windows x 4 095 affine points = 1.2 GB);
 //   commit   32 lanes per witness (two witnesses per wave); lane t owns windows t, t + 32, ...; it gathers the W bits of
 //            a window from the body, skips ahead to its next NON-ZERO window, and then the whole wave does one mixed
 //            Jacobian + affine addition with the tabulated point — no doublings, one addition per W slots, no
@@ -373,7 +373,7 @@ extern "C" int b3w_launch_commit(const uint8_t *d_bodies, uint32_t n, uint64_t p
   if (!n) return 0;
   // threads per witness: 32 (two witnesses per wave) for the compression circuit, 64 for the longer nova witnesses (measured)
   static const int env_tpw = getenv("B3W_COMMIT_THREADS") ? atoi(getenv("B3W_COMMIT_THREADS")) : 0;
-  const int tpw = env_tpw ? env_tpw : nwin > 4200 ? 64 : 32;
+  const int tpw = env_tpw ? env_tpw : nwin > 4600 ? 64 : 32;      // windows: 4 455 compression, 4 853 nova O2, 8 981 nova O1
 #define B3W_COMMIT_LAUNCH(T, WPB)                                                                                         \
   hipLaunchKernelGGL((b3w_commit_kernel<T, WPB>), dim3((n + WPB - 1) / WPB), dim3(T * WPB), 0, stream, d_bodies, n, pitch, d_vslots, d_table, \
                      nwin, d_sums, d_status, *curve)
