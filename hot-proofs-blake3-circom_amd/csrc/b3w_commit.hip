@@ -127,7 +127,60 @@ __device__ __forceinline__ Fp fp_mul(const Fp &a, const Fp &b, const B3wCurve &C
   for (int i = 0; i < 8; ++i) r.l[i] = t[i];
   return fp_reduce_once(r, t[8], C);
 }
-__device__ __forceinline__ Fp fp_sqr(const Fp &a, const B3wCurve &C) { return fp_mul(a, a, C); }
+// Montgomery square: the 28 cross products once, doubled, plus the 8 squares (36 limb products, not 64), then the
+// reduction of the 512-bit product.  1.17x the rate of fp_mul(a, a) on gfx950 (tools/ubench/fpmul_peak.hip).
+__device__ __forceinline__ Fp fp_sqr(const Fp &a, const B3wCurve &C) {
+  uint32_t t[16];
+#pragma unroll
+  for (int i = 0; i < 16; ++i) t[i] = 0;
+#pragma unroll
+  for (int i = 0; i < 7; ++i) {
+    uint64_t c = 0;
+#pragma unroll
+    for (int j = i + 1; j < 8; ++j) {
+      c += (uint64_t)a.l[i] * a.l[j] + t[i + j];
+      t[i + j] = (uint32_t)c;
+      c >>= 32;
+    }
+    t[i + 8] = (uint32_t)c;
+  }
+  uint32_t top = 0;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const uint32_t n = (t[i] << 1) | top;
+    top = t[i] >> 31;
+    t[i] = n;
+  }
+  uint64_t c = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    c += (uint64_t)a.l[i] * a.l[i] + t[2 * i];
+    t[2 * i] = (uint32_t)c;
+    c >>= 32;
+    c += t[2 * i + 1];
+    t[2 * i + 1] = (uint32_t)c;
+    c >>= 32;
+  }
+  uint32_t carry = 0;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const uint32_t m = t[i] * C.inv;
+    uint64_t d = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      d += (uint64_t)m * C.p[j] + t[i + j];
+      t[i + j] = (uint32_t)d;
+      d >>= 32;
+    }
+    d += (uint64_t)t[i + 8] + carry;
+    t[i + 8] = (uint32_t)d;
+    carry = (uint32_t)(d >> 32);
+  }
+  Fp r;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) r.l[i] = t[i + 8];
+  return fp_reduce_once(r, carry, C);
+}
 
 // a^(p-2): Fermat inversion (a != 0)
 __device__ Fp fp_inv(const Fp &a, const B3wCurve &C) {
