@@ -989,7 +989,7 @@ int32_t b3w_batch_commit_device(b3w_ctx *ctx, const b3w_commit_key *key, const u
     HIP_TRY(ctx, hipStreamSynchronize((hipStream_t)stream));
     if (k->d_sums) (void)hipFree(k->d_sums);
     k->d_sums = nullptr; k->sums_cap = 0;
-    HIP_TRY(ctx, hipMalloc((void **)&k->d_sums, (size_t)n * 96));
+    HIP_TRY(ctx, hipMalloc((void **)&k->d_sums, (size_t)n * B3W_COMMIT_SUM_WORDS * 4));
     k->sums_cap = n;
   }
   const int rc = b3w_launch_commit(d_bodies, n, pitch, key->d_vslots, key->d_table, key->nwin, k->d_sums, d_points, d_status, &key->curve, (hipStream_t)stream);

@@ -273,6 +273,244 @@ __device__ void jac_to_affine(const Jac &P, Fp &x, Fp &y, const B3wCurve &C) {
   y = fp_mul(P.Y, fp_mul(zi2, zi, C), C);
 }
 
+// =====================================================================================================================
+// The commit kernel's own arithmetic: the same field in NINE 29-BIT LIMBS, Montgomery radix 2^261.
+// Every column of a 9 x 9 limb product (plus the reduction's) fits one 64-bit accumulator, so a limb product is ONE
+// v_mad_u64_u32 whose addend is the accumulator itself: no carry moves (the 8 x 32-bit CIOS above spends three quarters
+// of its instructions on them).  172 G multiplications/s against 93 (tools/ubench/fpmul29_peak.hip).
+// Values are LAZY: a value is any representative below 2^261 (>= 64p); limbs may exceed 29 bits between operations.
+// Each routine states what it needs and what it gives:  "tidy" = limbs 0..7 below 2^29;  "< kp" = the value's bound.
+//   mul29 / sqr29   limb bounds la * lb < 1.52 * 2^60; a < Ap, b < Bp  ->  tidy, < (AB/64 + 1)p
+//   cn29            any limbs  ->  tidy, same value
+//   red29           any limbs, value < 2^261  ->  tidy, < 2p   (one-word Barrett quotient, never too large, at most 1 short)
+//   a + sp4 - b     b tidy < 2p  ->  value a + 4p - b, limbs < a's + 2^30   (sp4 = 4p with every limb lifted by 2^29)
+#define M29 0x1FFFFFFFu
+struct F9 { uint32_t l[9]; };
+struct J9 { F9 X, Y, Z; bool inf; };      // invariant between additions: X, Y tidy < 2p; Z < 4p with limbs < 2^30
+struct B3wCurve9 {
+  uint32_t p[9];        // modulus
+  uint32_t sp4[9];      // 4p, limb i lifted by 2^29 and lowered by the 1 it lent to limb i - 1
+  uint32_t one[9];      // 2^261 mod p
+  uint32_t inv;         // -p^-1 mod 2^29
+  uint32_t mu;          // floor(2^269 / p) (or 1 less)
+  uint32_t kp0[3];      // limb 0 of 3p, 4p, 5p: the filter in front of the exact "H = 0 mod p" test
+  uint32_t k251[8];     // 2^251 mod p, eight 32-bit limbs: fp_mul(v * 2^261, k251) = v * 2^256, back to the CIOS form
+};
+
+__device__ __forceinline__ F9 mul29(const F9 &a, const F9 &b, const B3wCurve9 &C) {
+  uint64_t acc = 0;
+  uint32_t m[9];
+  F9 r;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+#pragma unroll
+    for (int i = 0; i <= k; ++i) acc += (uint64_t)a.l[i] * b.l[k - i];
+#pragma unroll
+    for (int i = 0; i < k; ++i) acc += (uint64_t)m[i] * C.p[k - i];
+    m[k] = ((uint32_t)acc * C.inv) & M29;
+    acc += (uint64_t)m[k] * C.p[0];
+    acc >>= 29;
+  }
+#pragma unroll
+  for (int k = 9; k < 17; ++k) {
+#pragma unroll
+    for (int i = k - 8; i < 9; ++i) acc += (uint64_t)a.l[i] * b.l[k - i];
+#pragma unroll
+    for (int i = k - 8; i < 9; ++i) acc += (uint64_t)m[i] * C.p[k - i];
+    r.l[k - 9] = (uint32_t)acc & M29;
+    acc >>= 29;
+  }
+  r.l[8] = (uint32_t)acc;
+  return r;
+}
+__device__ __forceinline__ F9 sqr29(const F9 &a, const B3wCurve9 &C) {      // limbs < 2^30
+  uint64_t acc = 0;
+  uint32_t m[9], d[9];
+  F9 r;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) d[i] = a.l[i] << 1;
+#pragma unroll
+  for (int k = 0; k < 17; ++k) {
+#pragma unroll
+    for (int i = (k > 8 ? k - 8 : 0); 2 * i < k; ++i) acc += (uint64_t)d[i] * a.l[k - i];
+    if (!(k & 1)) acc += (uint64_t)a.l[k / 2] * a.l[k / 2];
+    if (k < 9) {
+#pragma unroll
+      for (int i = 0; i < k; ++i) acc += (uint64_t)m[i] * C.p[k - i];
+      m[k] = ((uint32_t)acc * C.inv) & M29;
+      acc += (uint64_t)m[k] * C.p[0];
+    } else {
+#pragma unroll
+      for (int i = k - 8; i < 9; ++i) acc += (uint64_t)m[i] * C.p[k - i];
+      r.l[k - 9] = (uint32_t)acc & M29;
+    }
+    acc >>= 29;
+  }
+  r.l[8] = (uint32_t)acc;
+  return r;
+}
+__device__ __forceinline__ F9 cn29(F9 a) {
+#pragma unroll
+  for (int i = 0; i < 8; ++i) { a.l[i + 1] += a.l[i] >> 29; a.l[i] &= M29; }
+  return a;
+}
+__device__ __forceinline__ F9 red29(const F9 &a, const B3wCurve9 &C) {
+  const uint32_t top = (a.l[8] + (a.l[7] >> 29)) >> 13;            // value / 2^245, rounded down (< 2^16)
+  const uint32_t q = (top * C.mu) >> 24;                           // floor(value / p) or 1 less
+  int64_t acc = 0;
+  F9 r;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) {
+    acc += (int64_t)(uint64_t)a.l[i];
+    acc -= (int64_t)((uint64_t)q * C.p[i]);
+    r.l[i] = i < 8 ? (uint32_t)acc & M29 : (uint32_t)acc;
+    acc >>= 29;
+  }
+  return r;
+}
+__device__ __forceinline__ F9 add29(const F9 &a, const F9 &b) {
+  F9 r;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) r.l[i] = a.l[i] + b.l[i];
+  return r;
+}
+__device__ __forceinline__ F9 sub29(const F9 &a, const F9 &b, const B3wCurve9 &C) {     // a + 4p - b   (b tidy < 2p)
+  F9 r;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) r.l[i] = a.l[i] + (C.sp4[i] - b.l[i]);
+  return r;
+}
+__device__ __forceinline__ F9 neg29(const F9 &b, const B3wCurve9 &C) {                  // 4p - b
+  F9 r;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) r.l[i] = C.sp4[i] - b.l[i];
+  return r;
+}
+__device__ __forceinline__ F9 shl29(const F9 &a, int s) {
+  F9 r;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) r.l[i] = a.l[i] << s;
+  return r;
+}
+// tidy a == k * p ?
+__device__ __forceinline__ bool is_kp29(const F9 &a, uint32_t k, const B3wCurve9 &C) {
+  uint32_t c = 0, o = 0;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) {
+    const uint32_t t = k * C.p[i] + c;
+    o |= (i < 8 ? t & M29 : t) ^ a.l[i];
+    c = t >> 29;
+  }
+  return o == 0;
+}
+// the safe forms (tidy < 2p in, tidy < 2p out) for the rare paths and the tree
+__device__ __forceinline__ F9 s_add(const F9 &a, const F9 &b, const B3wCurve9 &C) { return red29(add29(a, b), C); }
+__device__ __forceinline__ F9 s_sub(const F9 &a, const F9 &b, const B3wCurve9 &C) { return red29(sub29(a, b, C), C); }
+__device__ __forceinline__ F9 s_dbl(const F9 &a, const B3wCurve9 &C) { return red29(shl29(a, 1), C); }
+__device__ __forceinline__ bool s_is_zero(const F9 &a, const B3wCurve9 &C) { return is_kp29(a, 0, C) || is_kp29(a, 1, C); }
+__device__ __forceinline__ F9 one29(const B3wCurve9 &C) {
+  F9 r;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) r.l[i] = C.one[i];
+  return r;
+}
+
+__device__ __forceinline__ F9 to29(const Fp &a) {                   // eight 32-bit words -> nine 29-bit limbs
+  F9 r;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+    const int bit = 29 * k, w = bit >> 5, sh = bit & 31;
+    uint64_t v = a.l[w];
+    if (w + 1 < 8) v |= (uint64_t)a.l[w + 1] << 32;
+    r.l[k] = (uint32_t)(v >> sh) & M29;
+  }
+  return r;
+}
+__device__ __forceinline__ Fp from29(const F9 &a, uint32_t &hi) {     // tidy -> eight words + the bits above 2^256
+  uint32_t t[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+    const int bit = 29 * k, w = bit >> 5, sh = bit & 31;
+    const uint64_t v = (uint64_t)a.l[k] << sh;
+    t[w] |= (uint32_t)v;
+    if (w + 1 < 9) t[w + 1] |= (uint32_t)(v >> 32);
+  }
+  Fp r;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) r.l[i] = t[i];
+  hi = t[8];
+  return r;
+}
+
+__device__ __forceinline__ J9 j9_infinity() {
+  J9 r;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) r.X.l[i] = r.Y.l[i] = r.Z.l[i] = 0;
+  r.inf = true;
+  return r;
+}
+// P = 2P (dbl-2009-l, a = 0), safe forms
+__device__ __forceinline__ void j9_dbl(J9 &P, const B3wCurve9 &C) {
+  if (P.inf) return;
+  if (s_is_zero(P.Y, C)) { P.inf = true; return; }
+  const F9 A = sqr29(P.X, C), B = sqr29(P.Y, C), Cc = sqr29(B, C);
+  F9 D = s_sub(s_sub(sqr29(s_add(P.X, B, C), C), A, C), Cc, C);
+  D = s_dbl(D, C);
+  const F9 E = s_add(s_dbl(A, C), A, C), F = sqr29(E, C);
+  const F9 X3 = s_sub(F, s_dbl(D, C), C);
+  const F9 c8 = s_dbl(s_dbl(s_dbl(Cc, C), C), C);
+  const F9 Y3 = s_sub(mul29(E, s_sub(D, X3, C), C), c8, C);
+  P.Z = s_dbl(mul29(P.Y, red29(P.Z, C), C), C);
+  P.X = X3; P.Y = Y3;
+}
+// P += (x2, y2, 1): madd-2007-bl with lazy values; x2, y2 tidy < p; (0, 0) (the table's infinity) is filtered by the caller
+__device__ __forceinline__ void j9_madd(J9 &P, const F9 &x2, const F9 &y2, const B3wCurve9 &C) {
+  if (P.inf) {
+    P.X = x2; P.Y = y2; P.Z = one29(C); P.inf = false;
+    return;
+  }
+  const F9 Z1Z1 = sqr29(P.Z, C);                                   // < 2p
+  const F9 U2 = mul29(x2, Z1Z1, C), S2 = mul29(mul29(y2, P.Z, C), Z1Z1, C);
+  const F9 H = cn29(sub29(U2, P.X, C));                            // tidy, in (2p, 6p): = 0 mod p iff 3p, 4p or 5p
+  const F9 rh = cn29(sub29(S2, P.Y, C));                           // likewise
+  if (H.l[0] == C.kp0[0] || H.l[0] == C.kp0[1] || H.l[0] == C.kp0[2]) {
+    if (is_kp29(H, 3, C) || is_kp29(H, 4, C) || is_kp29(H, 5, C)) {
+      if (!(is_kp29(rh, 3, C) || is_kp29(rh, 4, C) || is_kp29(rh, 5, C))) { P.inf = true; return; }   // P + (-P)
+      P.X = x2; P.Y = y2; P.Z = one29(C);
+      j9_dbl(P, C);                                                                                  // P + P
+      return;
+    }
+  }
+  const F9 HH = sqr29(H, C);                                       // < 2p
+  const F9 I = shl29(HH, 2);                                       // < 8p, limbs < 2^31
+  const F9 J = mul29(H, I, C), V = mul29(P.X, I, C);               // < 2p
+  const F9 r = shl29(rh, 1);                                       // < 12p, limbs < 2^30
+  const F9 X3 = red29(add29(add29(sqr29(r, C), neg29(J, C)), shl29(neg29(V, C), 1)), C);      // r^2 - J - 2V  (< 16p before)
+  const F9 M1 = mul29(r, sub29(V, X3, C), C), M2 = mul29(P.Y, J, C);                  // < 3p, < 2p
+  P.X = X3;
+  P.Y = red29(add29(M1, shl29(neg29(M2, C), 1)), C);               // r(V - X3) - 2 Y1 J  (< 11p before)
+  P.Z = shl29(mul29(P.Z, H, C), 1);                                // 2 Z1 H: < 4p, limbs < 2^30
+}
+// P += Q (add-2007-bl), safe forms
+__device__ __forceinline__ void j9_add(J9 &P, const J9 &Q, const B3wCurve9 &C) {
+  if (Q.inf) return;
+  if (P.inf) { P.X = Q.X; P.Y = Q.Y; P.Z = Q.Z; P.inf = false; return; }
+  const F9 Z1 = red29(P.Z, C), Z2 = red29(Q.Z, C);
+  const F9 Z1Z1 = sqr29(Z1, C), Z2Z2 = sqr29(Z2, C);
+  const F9 U1 = mul29(P.X, Z2Z2, C), U2 = mul29(Q.X, Z1Z1, C);
+  const F9 S1 = mul29(mul29(P.Y, Z2, C), Z2Z2, C), S2 = mul29(mul29(Q.Y, Z1, C), Z1Z1, C);
+  const F9 H = s_sub(U2, U1, C), rr = s_sub(S2, S1, C);
+  if (s_is_zero(H, C)) {
+    if (s_is_zero(rr, C)) j9_dbl(P, C); else P.inf = true;
+    return;
+  }
+  const F9 I = sqr29(shl29(H, 1), C), J = mul29(H, I, C), r = s_dbl(rr, C), V = mul29(U1, I, C);
+  const F9 X3 = s_sub(s_sub(sqr29(r, C), J, C), s_dbl(V, C), C);
+  P.Y = s_sub(mul29(r, s_sub(V, X3, C), C), s_dbl(mul29(S1, J, C), C), C);
+  P.Z = mul29(s_sub(s_sub(sqr29(add29(Z1, Z2), C), Z1Z1, C), Z2Z2, C), H, C);
+  P.X = X3;
+}
+
 // ---- set-up: points[first_v[s] + k] = 2^k * G_s (Montgomery affine) for every committed slot s
 __global__ __launch_bounds__(64) void b3w_commit_setup_kernel(const uint32_t *__restrict__ gens /* nslots x 16 words, standard form */,
                                                               const uint32_t *__restrict__ first_v, const uint32_t *__restrict__ nbits,
@@ -312,6 +550,13 @@ __global__ __launch_bounds__(64) void b3w_commit_window_kernel(const uint32_t *_
   }
   Fp x, y;
   jac_to_affine(acc, x, y, C);                            // infinity -> (0, 0)
+  Fp c32;                                                 // 32 in Montgomery form: the commit kernel's radix is 2^261
+#pragma unroll
+  for (int k = 0; k < 8; ++k) c32.l[k] = C.one[k];
+#pragma unroll 1
+  for (int k = 0; k < 5; ++k) c32 = fp_dbl(c32, C);
+  x = fp_mul(x, c32, C);
+  y = fp_mul(y, c32, C);
   store_fp(table + i * 16, x);
   store_fp(table + i * 16 + 8, y);
 }
@@ -320,9 +565,10 @@ __global__ __launch_bounds__(64) void b3w_commit_window_kernel(const uint32_t *_
 template <int T, int WPB>        // threads per witness, witnesses per workgroup (T * WPB threads)
 __global__ __launch_bounds__(T * WPB) void b3w_commit_kernel(const uint8_t *__restrict__ bodies, uint32_t n, uint64_t pitch,
                                                          const uint32_t *__restrict__ vslots /* B3W_COMMIT_WINDOW per window: slot | bit << 19 | single << 27 | width words << 28 */,
-                                                         const uint32_t *__restrict__ table, uint32_t nwin, uint32_t *__restrict__ sums /* n x 24 words: X Y Z */,
-                                                         int32_t *__restrict__ status, B3wCurve C) {
-  __shared__ __attribute__((aligned(16))) uint32_t red[T * WPB * 24];
+                                                         const uint32_t *__restrict__ table /* radix 2^261 */, uint32_t nwin,
+                                                         uint32_t *__restrict__ sums /* n x B3W_COMMIT_SUM_WORDS: X Y Z in 29-bit limbs */,
+                                                         int32_t *__restrict__ status, B3wCurve9 C) {
+  __shared__ uint32_t red[T * WPB * 27];
   __shared__ uint32_t bad[WPB];
   const uint32_t sub = threadIdx.x / T, t = threadIdx.x % T;       // which witness of the workgroup, lane within it
   const uint32_t w = blockIdx.x * WPB + sub;
@@ -330,7 +576,7 @@ __global__ __launch_bounds__(T * WPB) void b3w_commit_kernel(const uint8_t *__re
   if (t == 0) bad[sub] = 0;
   __syncthreads();
   const uint32_t *body = reinterpret_cast<const uint32_t *>(bodies + (uint64_t)(live ? w : 0) * pitch);
-  Jac acc = jac_infinity();
+  J9 acc = j9_infinity();
   uint32_t win = live ? t : nwin;
   while (true) {
     // skip ahead to this lane's next window with a set bit (four virtual slots at a time: short live ranges)
@@ -363,36 +609,59 @@ __global__ __launch_bounds__(T * WPB) void b3w_commit_kernel(const uint8_t *__re
     if (!__any(has)) break;
     if (has) {
       const uint32_t *pt = table + ((uint64_t)win * B3W_COMMIT_ENTRIES + m - 1) * 16;
-      acc = jac_madd(acc, load_fp(pt), load_fp(pt + 8), C);
+      const Fp x2 = load_fp(pt), y2 = load_fp(pt + 8);
+      if (!(fp_is_zero(x2) && fp_is_zero(y2)))             // (0, 0) is not on these curves (b != 0): the table's infinity
+        j9_madd(acc, to29(x2), to29(y2), C);
       win += T;
     }
   }
-  // LDS tree over each witness's T partial sums
-  uint32_t *mine = red + (sub * T + t) * 24;
-  store_fp(mine, acc.X); store_fp(mine + 8, acc.Y); store_fp(mine + 16, acc.Z);
+  // LDS tree over each witness's T partial sums (infinity travels as Z = 0)
+  uint32_t *mine = red + (sub * T + t) * 27;
+  auto put = [&](const J9 &a) {
+#pragma unroll
+    for (int i = 0; i < 9; ++i) { mine[i] = a.X.l[i]; mine[9 + i] = a.Y.l[i]; mine[18 + i] = a.inf ? 0u : a.Z.l[i]; }
+  };
+  auto get = [&](const uint32_t *src) {
+    J9 a;
+    uint32_t z = 0;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) { a.X.l[i] = src[i]; a.Y.l[i] = src[9 + i]; a.Z.l[i] = src[18 + i]; z |= src[18 + i]; }
+    a.inf = z == 0;
+    return a;
+  };
+  put(acc);
   __syncthreads();
   for (uint32_t st = T / 2; st >= 1; st >>= 1) {
-    if (t < st) {
-      Jac a, b;
-      const uint32_t *other = mine + st * 24;
-      a.X = load_fp(mine); a.Y = load_fp(mine + 8); a.Z = load_fp(mine + 16);
-      b.X = load_fp(other); b.Y = load_fp(other + 8); b.Z = load_fp(other + 16);
-      a = jac_add(a, b, C);
-      store_fp(mine, a.X); store_fp(mine + 8, a.Y); store_fp(mine + 16, a.Z);
-    }
+    if (t < st) { J9 a = get(mine); j9_add(a, get(mine + st * 27), C); put(a); }
     __syncthreads();
   }
-  if (live && t < 24) sums[(uint64_t)w * 24 + t] = red[sub * T * 24 + t];   // the Jacobian sum; normalised by the next kernel
+  if (live && t < 27) sums[(uint64_t)w * B3W_COMMIT_SUM_WORDS + t] = red[sub * T * 27 + t];   // normalised by the next kernel
   if (live && t == 0 && status) status[w] = bad[sub] ? 103 : 0;
 }
 
 // ---- normalise: one THREAD per witness (a Fermat inversion is 380 dependent multiplications: on thread 0 of the commit
-// workgroup it took longer than the workgroup's whole share of additions)
-__global__ __launch_bounds__(64) void b3w_commit_normalize_kernel(const uint32_t *__restrict__ sums, uint32_t n, uint8_t *__restrict__ out, B3wCurve C) {
+// workgroup it took longer than the workgroup's whole share of additions).  Takes the sums back to the 8 x 32-bit form.
+__global__ __launch_bounds__(64) void b3w_commit_normalize_kernel(const uint32_t *__restrict__ sums, uint32_t n, uint8_t *__restrict__ out,
+                                                                  B3wCurve C, B3wCurve9 C9) {
   const uint32_t w = blockIdx.x * 64 + threadIdx.x;
   if (w >= n) return;
+  Fp k251;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) k251.l[i] = C9.k251[i];
+  Fp co[3];
+  uint32_t z = 0;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    F9 v;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) v.l[i] = sums[(uint64_t)w * B3W_COMMIT_SUM_WORDS + c * 9 + i];
+    if (c == 2) for (int i = 0; i < 9; ++i) z |= v.l[i];
+    uint32_t hi;
+    const Fp f = from29(red29(v, C9), hi);                     // < 2p
+    co[c] = fp_mul(fp_reduce_once(f, hi, C), k251, C);          // v * 2^261 -> v * 2^256
+  }
   Jac R;
-  R.X = load_fp(sums + (uint64_t)w * 24); R.Y = load_fp(sums + (uint64_t)w * 24 + 8); R.Z = load_fp(sums + (uint64_t)w * 24 + 16);
+  R.X = co[0]; R.Y = co[1]; R.Z = z ? co[2] : fp_zero();
   Fp x, y, one_std;
   jac_to_affine(R, x, y, C);
 #pragma unroll
@@ -402,6 +671,56 @@ __global__ __launch_bounds__(64) void b3w_commit_normalize_kernel(const uint32_t
   uint32_t *o = reinterpret_cast<uint32_t *>(out + (uint64_t)w * 64);
   store_fp(o, x);
   store_fp(o + 8, y);
+}
+
+// host: the 29-bit constants of a curve
+void u288_split29(const uint32_t w[9], uint32_t out[9]) {
+  for (int k = 0; k < 9; ++k) {
+    const int bit = 29 * k, i = bit >> 5, sh = bit & 31;
+    uint64_t v = w[i];
+    if (i + 1 < 9) v |= (uint64_t)w[i + 1] << 32;
+    out[k] = (uint32_t)(v >> sh) & (k < 8 ? M29 : 0xFFFFFFFFu);
+  }
+}
+bool u256_geq_h(const uint32_t a[8], const uint32_t b[8]) {
+  for (int i = 7; i >= 0; --i) if (a[i] != b[i]) return a[i] > b[i];
+  return true;
+}
+void u256_dbl_mod_h(uint32_t a[8], const uint32_t p[8]) {
+  uint32_t c = 0;
+  for (int i = 0; i < 8; ++i) { const uint32_t n = (a[i] << 1) | c; c = a[i] >> 31; a[i] = n; }
+  if (c || u256_geq_h(a, p)) { uint64_t br = 0; for (int i = 0; i < 8; ++i) { const uint64_t t = (uint64_t)a[i] - p[i] - br; a[i] = (uint32_t)t; br = (t >> 63) & 1; } }
+}
+void u256_half_mod_h(uint32_t a[8], const uint32_t p[8]) {
+  uint32_t top = 0;
+  if (a[0] & 1) { uint64_t c = 0; for (int i = 0; i < 8; ++i) { const uint64_t t = (uint64_t)a[i] + p[i] + c; a[i] = (uint32_t)t; c = t >> 32; } top = (uint32_t)c; }
+  for (int i = 0; i < 8; ++i) a[i] = (a[i] >> 1) | ((i < 7 ? a[i + 1] : top) << 31);
+}
+B3wCurve9 make_curve9(const B3wCurve &C) {
+  B3wCurve9 D{};
+  uint32_t w[9];
+  for (int i = 0; i < 8; ++i) w[i] = C.p[i];
+  w[8] = 0;
+  u288_split29(w, D.p);
+  uint32_t p4[9];                                              // 4p
+  for (int i = 0; i < 9; ++i) p4[i] = (i < 8 ? C.p[i] << 2 : 0u) | (i > 0 ? C.p[i - 1] >> 30 : 0u);
+  u288_split29(p4, D.sp4);
+  for (int i = 0; i < 8; ++i) D.sp4[i] += (1u << 29) - (i > 0 ? 1u : 0u);
+  D.sp4[8] -= 1u;
+  uint32_t x[8];
+  for (int i = 0; i < 8; ++i) x[i] = C.one[i];
+  for (int k = 0; k < 5; ++k) u256_dbl_mod_h(x, C.p);           // 2^261 mod p
+  for (int i = 0; i < 8; ++i) w[i] = x[i];
+  w[8] = 0;
+  u288_split29(w, D.one);
+  for (int i = 0; i < 8; ++i) x[i] = C.one[i];
+  for (int k = 0; k < 5; ++k) u256_half_mod_h(x, C.p);          // 2^251 mod p
+  for (int i = 0; i < 8; ++i) D.k251[i] = x[i];
+  D.inv = C.inv & M29;
+  const uint64_t phi = ((uint64_t)C.p[7] << 32) | C.p[6];      // p >> 192
+  D.mu = (uint32_t)((((unsigned __int128)1) << 77) / ((unsigned __int128)phi + 1));
+  for (uint32_t k = 3; k <= 5; ++k) D.kp0[k - 3] = (k * D.p[0]) & M29;
+  return D;
 }
 
 }  // namespace
@@ -421,21 +740,22 @@ extern "C" int b3w_launch_commit_windows(const uint32_t *d_points, uint32_t nwin
 }
 
 extern "C" int b3w_launch_commit(const uint8_t *d_bodies, uint32_t n, uint64_t pitch, const uint32_t *d_vslots, const uint32_t *d_table,
-                                 uint32_t nwin, uint32_t *d_sums /* n * 24 words scratch */, uint8_t *d_out, int32_t *d_status,
+                                 uint32_t nwin, uint32_t *d_sums /* n * B3W_COMMIT_SUM_WORDS scratch */, uint8_t *d_out, int32_t *d_status,
                                  const B3wCurve *curve, hipStream_t stream) {
   if (!n) return 0;
   // threads per witness: 32 (two witnesses per wave) for the compression circuit, 64 for the longer nova witnesses (measured)
+  const B3wCurve9 c9 = make_curve9(*curve);
   static const int env_tpw = getenv("B3W_COMMIT_THREADS") ? atoi(getenv("B3W_COMMIT_THREADS")) : 0;
   const int tpw = env_tpw ? env_tpw : nwin > 4600 ? 64 : 32;      // windows: 4 455 compression, 4 853 nova O2, 8 981 nova O1
 #define B3W_COMMIT_LAUNCH(T, WPB)                                                                                         \
   hipLaunchKernelGGL((b3w_commit_kernel<T, WPB>), dim3((n + WPB - 1) / WPB), dim3(T * WPB), 0, stream, d_bodies, n, pitch, d_vslots, d_table, \
-                     nwin, d_sums, d_status, *curve)
+                     nwin, d_sums, d_status, c9)
   if (tpw == 256) B3W_COMMIT_LAUNCH(256, 1);
   else if (tpw == 128) B3W_COMMIT_LAUNCH(128, 1);
   else if (tpw == 64) B3W_COMMIT_LAUNCH(64, 1);
   else if (tpw == 16) B3W_COMMIT_LAUNCH(16, 4);
   else B3W_COMMIT_LAUNCH(32, 2);                       // two witnesses per wave
 #undef B3W_COMMIT_LAUNCH
-  hipLaunchKernelGGL(b3w_commit_normalize_kernel, dim3((n + 63) / 64), dim3(64), 0, stream, d_sums, n, d_out, *curve);
+  hipLaunchKernelGGL(b3w_commit_normalize_kernel, dim3((n + 63) / 64), dim3(64), 0, stream, d_sums, n, d_out, *curve, c9);
   return (int)hipGetLastError();
 }

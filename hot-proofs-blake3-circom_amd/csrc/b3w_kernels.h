@@ -41,6 +41,7 @@ extern "C" void b3w_place_trim(void);
 #define B3W_COMMIT_WINDOW 12                        // virtual slots per window: 2^W - 1 tabulated subset sums each
 #endif
 #define B3W_COMMIT_ENTRIES ((1u << B3W_COMMIT_WINDOW) - 1u)
+#define B3W_COMMIT_SUM_WORDS 28        // per witness between the commit and the normalise kernel: X, Y, Z in nine 29-bit limbs each
 // Field of the curve's coordinates:
 struct B3wCurve {
   uint32_t p[8];      // modulus, little-endian limbs
