@@ -294,7 +294,6 @@ struct B3wCurve9 {
   uint32_t inv;         // -p^-1 mod 2^29
   uint32_t mu;          // floor(2^269 / p) (or 1 less)
   uint32_t kp0[3];      // limb 0 of 3p, 4p, 5p: the filter in front of the exact "H = 0 mod p" test
-  uint32_t k251[8];     // 2^251 mod p, eight 32-bit limbs: fp_mul(v * 2^261, k251) = v * 2^256, back to the CIOS form
 };
 
 __device__ __forceinline__ F9 mul29(const F9 &a, const F9 &b, const B3wCurve9 &C) {
@@ -640,34 +639,38 @@ __global__ __launch_bounds__(T * WPB) void b3w_commit_kernel(const uint8_t *__re
 }
 
 // ---- normalise: one THREAD per witness (a Fermat inversion is 380 dependent multiplications: on thread 0 of the commit
-// workgroup it took longer than the workgroup's whole share of additions).  Takes the sums back to the 8 x 32-bit form.
+// workgroup it took longer than the workgroup's whole share of additions); affine, standard form, 64 bytes per point
 __global__ __launch_bounds__(64) void b3w_commit_normalize_kernel(const uint32_t *__restrict__ sums, uint32_t n, uint8_t *__restrict__ out,
                                                                   B3wCurve C, B3wCurve9 C9) {
   const uint32_t w = blockIdx.x * 64 + threadIdx.x;
   if (w >= n) return;
-  Fp k251;
-#pragma unroll
-  for (int i = 0; i < 8; ++i) k251.l[i] = C9.k251[i];
-  Fp co[3];
+  F9 co[3];
   uint32_t z = 0;
 #pragma unroll
-  for (int c = 0; c < 3; ++c) {
-    F9 v;
+  for (int c = 0; c < 3; ++c)
 #pragma unroll
-    for (int i = 0; i < 9; ++i) v.l[i] = sums[(uint64_t)w * B3W_COMMIT_SUM_WORDS + c * 9 + i];
-    if (c == 2) for (int i = 0; i < 9; ++i) z |= v.l[i];
+    for (int i = 0; i < 9; ++i) co[c].l[i] = sums[(uint64_t)w * B3W_COMMIT_SUM_WORDS + c * 9 + i];
+#pragma unroll
+  for (int i = 0; i < 9; ++i) z |= co[2].l[i];
+  Fp x = fp_zero(), y = fp_zero();                           // infinity -> (0, 0)
+  if (z) {
+    const F9 Z = red29(co[2], C9);
+    F9 zi = one29(C9);                                       // Z^(p-2)
+#pragma unroll 1
+    for (int i = 255; i >= 0; --i) {
+      zi = sqr29(zi, C9);
+      if ((C.pm2[i >> 5] >> (i & 31)) & 1) zi = mul29(zi, Z, C9);
+    }
+    const F9 zi2 = sqr29(zi, C9);
+    F9 unit;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) unit.l[i] = i == 0 ? 1u : 0u;
+    const F9 xs = mul29(mul29(co[0], zi2, C9), unit, C9);    // out of Montgomery form: < 2p
+    const F9 ys = mul29(mul29(co[1], mul29(zi2, zi, C9), C9), unit, C9);
     uint32_t hi;
-    const Fp f = from29(red29(v, C9), hi);                     // < 2p
-    co[c] = fp_mul(fp_reduce_once(f, hi, C), k251, C);          // v * 2^261 -> v * 2^256
+    x = from29(xs, hi); x = fp_reduce_once(x, hi, C);
+    y = from29(ys, hi); y = fp_reduce_once(y, hi, C);
   }
-  Jac R;
-  R.X = co[0]; R.Y = co[1]; R.Z = z ? co[2] : fp_zero();
-  Fp x, y, one_std;
-  jac_to_affine(R, x, y, C);
-#pragma unroll
-  for (int i = 0; i < 8; ++i) one_std.l[i] = i == 0 ? 1u : 0u;
-  x = fp_mul(x, one_std, C);                                 // out of Montgomery form
-  y = fp_mul(y, one_std, C);
   uint32_t *o = reinterpret_cast<uint32_t *>(out + (uint64_t)w * 64);
   store_fp(o, x);
   store_fp(o + 8, y);
@@ -691,11 +694,6 @@ void u256_dbl_mod_h(uint32_t a[8], const uint32_t p[8]) {
   for (int i = 0; i < 8; ++i) { const uint32_t n = (a[i] << 1) | c; c = a[i] >> 31; a[i] = n; }
   if (c || u256_geq_h(a, p)) { uint64_t br = 0; for (int i = 0; i < 8; ++i) { const uint64_t t = (uint64_t)a[i] - p[i] - br; a[i] = (uint32_t)t; br = (t >> 63) & 1; } }
 }
-void u256_half_mod_h(uint32_t a[8], const uint32_t p[8]) {
-  uint32_t top = 0;
-  if (a[0] & 1) { uint64_t c = 0; for (int i = 0; i < 8; ++i) { const uint64_t t = (uint64_t)a[i] + p[i] + c; a[i] = (uint32_t)t; c = t >> 32; } top = (uint32_t)c; }
-  for (int i = 0; i < 8; ++i) a[i] = (a[i] >> 1) | ((i < 7 ? a[i + 1] : top) << 31);
-}
 B3wCurve9 make_curve9(const B3wCurve &C) {
   B3wCurve9 D{};
   uint32_t w[9];
@@ -713,9 +711,6 @@ B3wCurve9 make_curve9(const B3wCurve &C) {
   for (int i = 0; i < 8; ++i) w[i] = x[i];
   w[8] = 0;
   u288_split29(w, D.one);
-  for (int i = 0; i < 8; ++i) x[i] = C.one[i];
-  for (int k = 0; k < 5; ++k) u256_half_mod_h(x, C.p);          // 2^251 mod p
-  for (int i = 0; i < 8; ++i) D.k251[i] = x[i];
   D.inv = C.inv & M29;
   const uint64_t phi = ((uint64_t)C.p[7] << 32) | C.p[6];      // p >> 192
   D.mu = (uint32_t)((((unsigned __int128)1) << 77) / ((unsigned __int128)phi + 1));
