@@ -16,8 +16,10 @@
 //            Jacobian + affine addition with the tabulated point — no doublings, one addition per W slots, no
 //            zero work in lock step; an LDS tree adds the 32 partial sums; a second kernel normalises them, one
 //            thread per witness (Fermat inversion), and stores the affine points.
-// Arithmetic: 256-bit Montgomery (CIOS, eight 32-bit limbs, modulus passed at run time), complete handling of the
-// exceptional cases (infinity, P + P, P - P) so that related generators cannot break it.
+// Arithmetic: 256-bit Montgomery, modulus passed at run time.  The one-time set-up kernels use the textbook CIOS on
+// eight 32-bit limbs; the commit and normalise kernels use nine 29-bit limbs (radix 2^261, lazy reduction: see the
+// F9 section below), in which a limb product is a single v_mad_u64_u32.  Complete handling of the exceptional cases
+// (infinity, P + P, P - P) so that related generators cannot break it.
 // Domain: bodies of the batch kernels (every bit slot holds 0 or 1, words fit their slot's width); a slot holding
 // anything else (e.g. a body of the exact kernel with a 254-bit input) flags the witness (status 103) instead of
 // producing a wrong commitment.
