@@ -99,6 +99,8 @@ def lib():
         "b3w_chain_tree_device": (i32, [vp, vp, u64, vp, vp]),
         "b3w_chain_plan_parents_device": (i32, [vp, vp, u64, u64, u64, u32, vp, vp]),
         "b3w_commit_key_create": (i32, [vp, i32, u32, vp, ctypes.POINTER(vp)]),
+        "b3w_commit_key_create_ex": (i32, [vp, i32, u32, vp, u32, ctypes.POINTER(vp)]),
+        "b3w_commit_key_window": (u32, [vp]),
         "b3w_commit_key_destroy": (None, [vp]),
         "b3w_batch_commit_device": (i32, [vp, vp, vp, u32, u64, vp, vp, vp]),
         "b3w_batch_commit": (i32, [vp, vp, vp, vp]),
@@ -135,7 +137,7 @@ EXPORTED_SYMBOLS = ("b3w_abi_version", "b3w_identify_wasm", "b3w_create", "b3w_d
                     "b3w_batch_run", "b3w_batch_outputs", "b3w_batch_fetch", "b3w_batch_device_ptr",
                     "b3w_batch_time_device", "b3w_batch_verify_device", "b3w_batch_verify", "b3w_batch_write_wtns", "b3w_batch_autotune_device", "b3w_bodies_alloc", "b3w_bodies_free", "b3w_bodies_trim", "b3w_batch_placement", "b3w_chain_num_chunks", "b3w_chain_num_leaf_steps", "b3w_chain_path_len",
                     "b3w_chain_plan_leaves_device", "b3w_chain_tree_device", "b3w_chain_plan_parents_device",
-                    "b3w_commit_key_create", "b3w_commit_key_destroy", "b3w_batch_commit_device", "b3w_batch_commit", "b3w_commit_consumer",
+                    "b3w_commit_key_create", "b3w_commit_key_create_ex", "b3w_commit_key_window", "b3w_commit_key_destroy", "b3w_batch_commit_device", "b3w_batch_commit", "b3w_commit_consumer",
                     "b3w_comm_unique_id", "b3w_comm_create", "b3w_comm_destroy", "b3w_comm_allgather", "b3w_batch_allgather_public",
                     "b3w_chain_create", "b3w_chain_destroy", "b3w_chain_run_leaves", "b3w_chain_run_parents", "b3w_chain_shard", "b3w_chain_run_parents_sharded", "b3w_chain_info",
                     "b3w_chain_outputs", "b3w_chain_records", "b3w_chain_public", "b3w_chain_status", "b3w_chain_local_cvs", "b3w_chain_root")
@@ -293,19 +295,20 @@ class BodyBuffer:
 class CommitKey:
     """Commitment key on the device (b3w_commit_key_create): `generators` = bytes, one affine point (x, y: 32-byte
     little-endian each, standard form) per committed slot, i.e. witness_size - first_slot of them; curve "bn254_g1"
-    or "vesta"."""
+    or "vesta"; window = 12 | 16 bits per table window (0: automatic, see include/b3wit.h)."""
     CURVES = {"bn254_g1": 0, "vesta": 1}
 
-    def __init__(self, ctx, curve, generators, first_slot=0):
+    def __init__(self, ctx, curve, generators, first_slot=0, window=0):
         self.ctx = ctx
         buf = bytes(generators)
         if len(buf) != 64 * (ctx.witness_size - first_slot):
             raise B3WError(100, "generators: 64 bytes per committed slot")
         h = ctypes.c_void_p()
-        rc = lib().b3w_commit_key_create(ctx.handle, self.CURVES[curve], first_slot, buf, ctypes.byref(h))
+        rc = lib().b3w_commit_key_create_ex(ctx.handle, self.CURVES[curve], first_slot, buf, window, ctypes.byref(h))
         if rc != B3W_OK:
-            raise B3WError(rc, f"b3w_commit_key_create: status {rc}: {ctx.last_error()}")
+            raise B3WError(rc, f"b3w_commit_key_create_ex: status {rc}: {ctx.last_error()}")
         self.handle = h
+        self.window = lib().b3w_commit_key_window(h)
 
     def commit_device(self, d_bodies, n, pitch, d_points, d_status=0, stream=0):
         """n bodies in HBM -> n affine points (64 bytes each) in HBM."""

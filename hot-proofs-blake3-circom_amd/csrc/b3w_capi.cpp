@@ -870,8 +870,8 @@ int32_t b3w_chain_plan_parents_device(b3w_ctx *ctx, const uint32_t *d_levels, ui
 struct b3w_commit_key {
   b3w_ctx *ctx = nullptr;
   B3wCurve curve{};
-  uint32_t first_slot = 0, nwin = 0;
-  uint32_t *d_vslots = nullptr, *d_table = nullptr;   // B3W_COMMIT_WINDOW virtual slots per window; 2^W - 1 subset sums each
+  uint32_t first_slot = 0, nwin = 0, window = 0;
+  uint32_t *d_vslots = nullptr, *d_table = nullptr;   // `window` virtual slots per window; 2^window - 1 subset sums each
   uint32_t *d_sums = nullptr;                         // Jacobian sums between the two kernels, grown on demand
   uint32_t sums_cap = 0;
 };
@@ -911,8 +911,18 @@ const uint64_t P_VESTA_BASE[4] = {0x992d30ed00000001ull, 0x224698fc094cf91bull, 
 extern "C" {
 
 int32_t b3w_commit_key_create(b3w_ctx *ctx, int32_t curve, uint32_t first_slot, const uint8_t *host_generators, b3w_commit_key **out) {
-  if (!ctx || !out || !host_generators || (curve != B3W_CURVE_BN254_G1 && curve != B3W_CURVE_VESTA) || first_slot >= ctx->desc.nwit)
+  return b3w_commit_key_create_ex(ctx, curve, first_slot, host_generators, 0, out);
+}
+
+uint32_t b3w_commit_key_window(const b3w_commit_key *key) { return key ? key->window : 0; }
+
+int32_t b3w_commit_key_create_ex(b3w_ctx *ctx, int32_t curve, uint32_t first_slot, const uint8_t *host_generators, uint32_t window_bits,
+                                 b3w_commit_key **out) {
+  if (!ctx || !out || !host_generators || (curve != B3W_CURVE_BN254_G1 && curve != B3W_CURVE_VESTA) || first_slot >= ctx->desc.nwit ||
+      (window_bits != 0 && window_bits != B3W_COMMIT_WINDOW_SMALL && window_bits != B3W_COMMIT_WINDOW_LARGE)) {
+    if (ctx) ctx->last_error = "commit key: curve 0/1, first_slot < witness_size, window_bits 0 (auto), 12 or 16";
     return B3W_E_BAD_ARGUMENT;
+  }
   *out = nullptr;
   std::vector<uint32_t> table;
   if (!build_slot_table(ctx->desc, table, ctx->last_error)) return B3W_E_BAD_ARGUMENT;
@@ -928,18 +938,31 @@ int32_t b3w_commit_key_create(b3w_ctx *ctx, int32_t curve, uint32_t first_slot, 
       vslots.push_back((first_slot + i) | (k << 19) | ((nbits[i] == 1 ? 1u : 0u) << 27) |
                        ((k == 0 && (nbits[i] == 32 || nbits[i] == 64) ? nbits[i] / 32 : 0u) << 28));
   }
-  // windows of B3W_COMMIT_WINDOW virtual slots; the pad entries read bit 31 of slot 0 (the constant 1): always 0
+  // window width: the caller's, else B3W_COMMIT_WINDOW, else 16 when its table takes at most a quarter of the free HBM
+  hipError_t e = hipSetDevice(ctx->device);
+  uint32_t window = window_bits;
+  if (!window && getenv("B3W_COMMIT_WINDOW")) {
+    window = (uint32_t)atoi(getenv("B3W_COMMIT_WINDOW"));
+    if (window != B3W_COMMIT_WINDOW_SMALL && window != B3W_COMMIT_WINDOW_LARGE) window = 0;
+  }
+  if (!window) {
+    size_t free_b = 0, total_b = 0;
+    const uint64_t large = ((uint64_t)vslots.size() / B3W_COMMIT_WINDOW_LARGE + 1) * B3W_COMMIT_ENTRIES(B3W_COMMIT_WINDOW_LARGE) * 64;
+    window = e == hipSuccess && hipMemGetInfo(&free_b, &total_b) == hipSuccess && large <= free_b / 4 ? B3W_COMMIT_WINDOW_LARGE
+                                                                                                      : B3W_COMMIT_WINDOW_SMALL;
+  }
+  // windows of `window` virtual slots; the pad entries read bit 31 of slot 0 (the constant 1): always 0
   const uint32_t V0 = (uint32_t)vslots.size();
-  while (vslots.size() % B3W_COMMIT_WINDOW) vslots.push_back(0u | (31u << 19));
+  while (vslots.size() % window) vslots.push_back(0u | (31u << 19));
   b3w_commit_key *key = new b3w_commit_key;
   key->ctx = ctx;
   key->curve = make_curve(curve == B3W_CURVE_BN254_G1 ? Q_BN254 : P_VESTA_BASE);
   key->first_slot = first_slot;
-  key->nwin = (uint32_t)(vslots.size() / B3W_COMMIT_WINDOW);
+  key->window = window;
+  key->nwin = (uint32_t)(vslots.size() / window);
   uint32_t *d_gens = nullptr, *d_first = nullptr, *d_nbits = nullptr, *d_points = nullptr;
-  hipError_t e = hipSetDevice(ctx->device);
   if (e == hipSuccess) e = hipMalloc((void **)&key->d_vslots, vslots.size() * 4);
-  if (e == hipSuccess) e = hipMalloc((void **)&key->d_table, (size_t)key->nwin * B3W_COMMIT_ENTRIES * 64);
+  if (e == hipSuccess) e = hipMalloc((void **)&key->d_table, (size_t)key->nwin * B3W_COMMIT_ENTRIES(window) * 64);
   if (e == hipSuccess) e = hipMalloc((void **)&d_points, vslots.size() * 64);
   if (e == hipSuccess) e = hipMalloc((void **)&d_gens, (size_t)nslots * 64);
   if (e == hipSuccess) e = hipMalloc((void **)&d_first, (size_t)nslots * 4);
@@ -952,7 +975,7 @@ int32_t b3w_commit_key_create(b3w_ctx *ctx, int32_t curve, uint32_t first_slot, 
   int rc = e == hipSuccess ? b3w_launch_commit_setup(d_gens, d_first, d_nbits, nslots, d_points, &key->curve, nullptr) : 0;
   for (uint32_t v = V0; v < vslots.size() && e == hipSuccess && rc == 0; v++)
     e = hipMemcpyAsync(d_points + (size_t)v * 16, d_points, 64, hipMemcpyDeviceToDevice, nullptr);
-  if (e == hipSuccess && rc == 0) rc = b3w_launch_commit_windows(d_points, key->nwin, key->d_table, &key->curve, nullptr);
+  if (e == hipSuccess && rc == 0) rc = b3w_launch_commit_windows(d_points, key->nwin, key->window, key->d_table, &key->curve, nullptr);
   if (e == hipSuccess && rc == 0) e = hipDeviceSynchronize();
   if (d_gens) (void)hipFree(d_gens);
   if (d_first) (void)hipFree(d_first);
@@ -992,7 +1015,7 @@ int32_t b3w_batch_commit_device(b3w_ctx *ctx, const b3w_commit_key *key, const u
     HIP_TRY(ctx, hipMalloc((void **)&k->d_sums, (size_t)n * B3W_COMMIT_SUM_WORDS * 4));
     k->sums_cap = n;
   }
-  const int rc = b3w_launch_commit(d_bodies, n, pitch, key->d_vslots, key->d_table, key->nwin, k->d_sums, d_points, d_status, &key->curve, (hipStream_t)stream);
+  const int rc = b3w_launch_commit(d_bodies, n, pitch, key->d_vslots, key->d_table, key->nwin, key->window, k->d_sums, d_points, d_status, &key->curve, (hipStream_t)stream);
   return rc ? hip_fail(ctx, (hipError_t)rc, "commit launch") : B3W_OK;
 }
 

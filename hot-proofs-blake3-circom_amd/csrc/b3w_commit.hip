@@ -537,16 +537,17 @@ __global__ __launch_bounds__(64) void b3w_commit_setup_kernel(const uint32_t *__
 }
 
 // ---- set-up 2: table[win * (2^W - 1) + m - 1] = sum of the window's virtual-slot points selected by the bits of m
+template <int W>
 __global__ __launch_bounds__(64) void b3w_commit_window_kernel(const uint32_t *__restrict__ points, uint32_t nwin,
                                                                uint32_t *__restrict__ table, B3wCurve C) {
   const uint64_t i = (uint64_t)blockIdx.x * 64 + threadIdx.x;
-  if (i >= (uint64_t)nwin * B3W_COMMIT_ENTRIES) return;
-  const uint32_t win = (uint32_t)(i / B3W_COMMIT_ENTRIES), m = (uint32_t)(i % B3W_COMMIT_ENTRIES) + 1;
+  if (i >= (uint64_t)nwin * B3W_COMMIT_ENTRIES(W)) return;
+  const uint32_t win = (uint32_t)(i / B3W_COMMIT_ENTRIES(W)), m = (uint32_t)(i % B3W_COMMIT_ENTRIES(W)) + 1;
   Jac acc = jac_infinity();
 #pragma unroll 1
-  for (int j = 0; j < B3W_COMMIT_WINDOW; ++j) {
+  for (int j = 0; j < W; ++j) {
     if (!((m >> j) & 1)) continue;
-    const uint32_t *pt = points + (uint64_t)(win * B3W_COMMIT_WINDOW + j) * 16;
+    const uint32_t *pt = points + (uint64_t)(win * W + j) * 16;
     acc = jac_madd(acc, load_fp(pt), load_fp(pt + 8), C);
   }
   Fp x, y;
@@ -563,9 +564,9 @@ __global__ __launch_bounds__(64) void b3w_commit_window_kernel(const uint32_t *_
 }
 
 // ---- commit: one workgroup per witness
-template <int T, int WPB>        // threads per witness, witnesses per workgroup (T * WPB threads)
+template <int T, int WPB, int W>        // threads per witness, witnesses per workgroup (T * WPB threads), window width
 __global__ __launch_bounds__(T * WPB) void b3w_commit_kernel(const uint8_t *__restrict__ bodies, uint32_t n, uint64_t pitch,
-                                                         const uint32_t *__restrict__ vslots /* B3W_COMMIT_WINDOW per window: slot | bit << 19 | single << 27 | width words << 28 */,
+                                                         const uint32_t *__restrict__ vslots /* W per window: slot | bit << 19 | single << 27 | width words << 28 */,
                                                          const uint32_t *__restrict__ table /* radix 2^261 */, uint32_t nwin,
                                                          uint32_t *__restrict__ sums /* n x B3W_COMMIT_SUM_WORDS: X Y Z in 29-bit limbs */,
                                                          int32_t *__restrict__ status, B3wCurve9 C) {
@@ -584,8 +585,8 @@ __global__ __launch_bounds__(T * WPB) void b3w_commit_kernel(const uint8_t *__re
     uint32_t m = 0;
     while (win < nwin) {
 #pragma unroll
-      for (int j = 0; j < B3W_COMMIT_WINDOW; j += 4) {
-        const uint4 q = *reinterpret_cast<const uint4 *>(vslots + (uint64_t)win * B3W_COMMIT_WINDOW + j);
+      for (int j = 0; j < W; j += 4) {
+        const uint4 q = *reinterpret_cast<const uint4 *>(vslots + (uint64_t)win * W + j);
         const uint32_t e[4] = {q.x, q.y, q.z, q.w};
         uint32_t word[4];
 #pragma unroll
@@ -609,7 +610,7 @@ __global__ __launch_bounds__(T * WPB) void b3w_commit_kernel(const uint8_t *__re
     const bool has = win < nwin;
     if (!__any(has)) break;
     if (has) {
-      const uint32_t *pt = table + ((uint64_t)win * B3W_COMMIT_ENTRIES + m - 1) * 16;
+      const uint32_t *pt = table + ((uint64_t)win * B3W_COMMIT_ENTRIES(W) + m - 1) * 16;
       const Fp x2 = load_fp(pt), y2 = load_fp(pt + 8);
       if (!(fp_is_zero(x2) && fp_is_zero(y2)))             // (0, 0) is not on these curves (b != 0): the table's infinity
         j9_madd(acc, to29(x2), to29(y2), C);
@@ -729,29 +730,38 @@ extern "C" int b3w_launch_commit_setup(const uint32_t *d_gens, const uint32_t *d
   return (int)hipGetLastError();
 }
 
-extern "C" int b3w_launch_commit_windows(const uint32_t *d_points, uint32_t nwin, uint32_t *d_table, const B3wCurve *curve, hipStream_t stream) {
+extern "C" int b3w_launch_commit_windows(const uint32_t *d_points, uint32_t nwin, uint32_t window, uint32_t *d_table, const B3wCurve *curve, hipStream_t stream) {
   if (!nwin) return 0;
-  const uint64_t total = (uint64_t)nwin * B3W_COMMIT_ENTRIES;
-  hipLaunchKernelGGL(b3w_commit_window_kernel, dim3((uint32_t)((total + 63) / 64)), dim3(64), 0, stream, d_points, nwin, d_table, *curve);
+  if (window != B3W_COMMIT_WINDOW_SMALL && window != B3W_COMMIT_WINDOW_LARGE) return (int)hipErrorInvalidValue;
+  const uint64_t total = (uint64_t)nwin * B3W_COMMIT_ENTRIES(window);
+  const dim3 grid((uint32_t)((total + 63) / 64));
+  if (window == B3W_COMMIT_WINDOW_LARGE)
+    hipLaunchKernelGGL(b3w_commit_window_kernel<B3W_COMMIT_WINDOW_LARGE>, grid, dim3(64), 0, stream, d_points, nwin, d_table, *curve);
+  else
+    hipLaunchKernelGGL(b3w_commit_window_kernel<B3W_COMMIT_WINDOW_SMALL>, grid, dim3(64), 0, stream, d_points, nwin, d_table, *curve);
   return (int)hipGetLastError();
 }
 
 extern "C" int b3w_launch_commit(const uint8_t *d_bodies, uint32_t n, uint64_t pitch, const uint32_t *d_vslots, const uint32_t *d_table,
-                                 uint32_t nwin, uint32_t *d_sums /* n * B3W_COMMIT_SUM_WORDS scratch */, uint8_t *d_out, int32_t *d_status,
-                                 const B3wCurve *curve, hipStream_t stream) {
+                                 uint32_t nwin, uint32_t window, uint32_t *d_sums /* n * B3W_COMMIT_SUM_WORDS scratch */, uint8_t *d_out,
+                                 int32_t *d_status, const B3wCurve *curve, hipStream_t stream) {
   if (!n) return 0;
-  // threads per witness: 32 (two witnesses per wave) for the compression circuit, 64 for the longer nova witnesses (measured)
+  if (window != B3W_COMMIT_WINDOW_SMALL && window != B3W_COMMIT_WINDOW_LARGE) return (int)hipErrorInvalidValue;
   const B3wCurve9 c9 = make_curve9(*curve);
+  // lanes per witness: 32 (two witnesses per wave) for the compression circuit, 64 for the longer nova witnesses (measured
+  // at both window widths).  Virtual slots: 53 k compression, 58 k nova O2, 108 k nova O1.
   static const int env_tpw = getenv("B3W_COMMIT_THREADS") ? atoi(getenv("B3W_COMMIT_THREADS")) : 0;
-  const int tpw = env_tpw ? env_tpw : nwin > 4600 ? 64 : 32;      // windows: 4 455 compression, 4 853 nova O2, 8 981 nova O1
-#define B3W_COMMIT_LAUNCH(T, WPB)                                                                                         \
-  hipLaunchKernelGGL((b3w_commit_kernel<T, WPB>), dim3((n + WPB - 1) / WPB), dim3(T * WPB), 0, stream, d_bodies, n, pitch, d_vslots, d_table, \
-                     nwin, d_sums, d_status, c9)
-  if (tpw == 256) B3W_COMMIT_LAUNCH(256, 1);
-  else if (tpw == 128) B3W_COMMIT_LAUNCH(128, 1);
-  else if (tpw == 64) B3W_COMMIT_LAUNCH(64, 1);
-  else if (tpw == 16) B3W_COMMIT_LAUNCH(16, 4);
-  else B3W_COMMIT_LAUNCH(32, 2);                       // two witnesses per wave
+  const int tpw = env_tpw ? env_tpw : (uint64_t)nwin * window > 55200 ? 64 : 32;
+#define B3W_COMMIT_LAUNCH(T, WPB, W)                                                                                      \
+  hipLaunchKernelGGL((b3w_commit_kernel<T, WPB, W>), dim3((n + WPB - 1) / WPB), dim3(T * WPB), 0, stream, d_bodies, n, pitch, d_vslots, \
+                     d_table, nwin, d_sums, d_status, c9)
+  if (window == B3W_COMMIT_WINDOW_LARGE) {
+    if (tpw == 64) B3W_COMMIT_LAUNCH(64, 1, B3W_COMMIT_WINDOW_LARGE);
+    else B3W_COMMIT_LAUNCH(32, 2, B3W_COMMIT_WINDOW_LARGE);
+  } else {
+    if (tpw == 64) B3W_COMMIT_LAUNCH(64, 1, B3W_COMMIT_WINDOW_SMALL);
+    else B3W_COMMIT_LAUNCH(32, 2, B3W_COMMIT_WINDOW_SMALL);
+  }
 #undef B3W_COMMIT_LAUNCH
   hipLaunchKernelGGL(b3w_commit_normalize_kernel, dim3((n + 63) / 64), dim3(64), 0, stream, d_sums, n, d_out, *curve, c9);
   return (int)hipGetLastError();

@@ -37,10 +37,11 @@ extern "C" int b3w_place_free(void *ptr);
 extern "C" void b3w_place_trim(void);
 
 // b3w_commit.hip: Pedersen commitments of witness bodies (on-device consumer).
-#ifndef B3W_COMMIT_WINDOW
-#define B3W_COMMIT_WINDOW 12                        // virtual slots per window: 2^W - 1 tabulated subset sums each
-#endif
-#define B3W_COMMIT_ENTRIES ((1u << B3W_COMMIT_WINDOW) - 1u)
+// Window width W (virtual slots per window, 2^W - 1 tabulated subset sums each) is a property of the key:
+//   12: 1.2 GB table, 0.15 s set-up;   16: 14 GB table, 1.2 s set-up, a quarter fewer additions per witness (+15-18 %)
+#define B3W_COMMIT_WINDOW_SMALL 12
+#define B3W_COMMIT_WINDOW_LARGE 16
+#define B3W_COMMIT_ENTRIES(W) ((1u << (W)) - 1u)
 #define B3W_COMMIT_SUM_WORDS 28        // per witness between the commit and the normalise kernel: X, Y, Z in nine 29-bit limbs each
 // Field of the curve's coordinates:
 struct B3wCurve {
@@ -52,6 +53,6 @@ struct B3wCurve {
 };
 extern "C" int b3w_launch_commit_setup(const uint32_t *d_gens, const uint32_t *d_first_v, const uint32_t *d_nbits, uint32_t nslots,
                                        uint32_t *d_points, const B3wCurve *curve, hipStream_t stream);
-extern "C" int b3w_launch_commit_windows(const uint32_t *d_points, uint32_t nwin, uint32_t *d_table, const B3wCurve *curve, hipStream_t stream);
+extern "C" int b3w_launch_commit_windows(const uint32_t *d_points, uint32_t nwin, uint32_t window, uint32_t *d_table, const B3wCurve *curve, hipStream_t stream);
 extern "C" int b3w_launch_commit(const uint8_t *d_bodies, uint32_t n, uint64_t pitch, const uint32_t *d_vslots, const uint32_t *d_table,
-                                 uint32_t nwin, uint32_t *d_sums, uint8_t *d_out, int32_t *d_status, const B3wCurve *curve, hipStream_t stream);
+                                 uint32_t nwin, uint32_t window, uint32_t *d_sums, uint8_t *d_out, int32_t *d_status, const B3wCurve *curve, hipStream_t stream);

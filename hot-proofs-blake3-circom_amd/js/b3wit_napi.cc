@@ -46,7 +46,7 @@ struct Api {
   decltype(&b3w_chain_run_parents) chain_run_parents;
   decltype(&b3w_chain_info) chain_info;
   decltype(&b3w_chain_outputs) chain_outputs;
-  decltype(&b3w_commit_key_create) commit_key_create;
+  decltype(&b3w_commit_key_create_ex) commit_key_create_ex;
   decltype(&b3w_commit_key_destroy) commit_key_destroy;
   decltype(&b3w_batch_commit) batch_commit;
   decltype(&b3w_chain_shard) chain_shard;
@@ -78,7 +78,7 @@ bool load_api() {
   SYM(write_wtns_header) SYM(last_error) SYM(public_words) SYM(batch_alloc) SYM(batch_free) SYM(batch_run)
   SYM(batch_outputs) SYM(batch_fetch) SYM(batch_write_wtns) SYM(batch_verify) SYM(batch_placement) SYM(bodies_trim)
   SYM(chain_create) SYM(chain_destroy) SYM(chain_run_leaves) SYM(chain_run_parents) SYM(chain_info) SYM(chain_outputs)
-  SYM(commit_key_create) SYM(commit_key_destroy) SYM(batch_commit) SYM(chain_shard) SYM(chain_run_parents_sharded) SYM(comm_unique_id) SYM(comm_create) SYM(comm_destroy) SYM(batch_allgather_public)
+  SYM(commit_key_create_ex) SYM(commit_key_destroy) SYM(batch_commit) SYM(chain_shard) SYM(chain_run_parents_sharded) SYM(comm_unique_id) SYM(comm_create) SYM(comm_destroy) SYM(batch_allgather_public)
 #undef SYM
   api.so = so;
   return true;
@@ -417,10 +417,11 @@ napi_value ChainFold(napi_env env, napi_callback_info info) {
   return o;
 }
 
-// commitKey(handle, curve: 0 = BN254 G1 | 1 = Vesta, firstSlot, generators: Uint8Array((witnessSize - firstSlot) * 64))
+// commitKey(handle, curve: 0 = BN254 G1 | 1 = Vesta, firstSlot, generators: Uint8Array((witnessSize - firstSlot) * 64)
+//           [, windowBits: 0 (automatic) | 12 | 16])
 // installs the commitment key of this handle (tables on the device)
 napi_value CommitKey(napi_env env, napi_callback_info info) {
-  size_t argc = 4; napi_value argv[4];
+  size_t argc = 5; napi_value argv[5];
   NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
   Handle *h = get_handle(env, argv[0]);
   if (!h) return nullptr;
@@ -435,8 +436,14 @@ napi_value CommitKey(napi_env env, napi_callback_info info) {
     return nullptr;
   }
   if (h->key) { api.commit_key_destroy(h->key); h->key = nullptr; }
-  const int32_t rc = api.commit_key_create(h->ctx, curve, first, (const uint8_t *)p, &h->key);
-  if (rc != B3W_OK) return throw_status(env, h, rc, "b3w_commit_key_create failed");
+  uint32_t window = 0;
+  if (argc > 4) {
+    napi_valuetype vt;
+    NAPI_OK(napi_typeof(env, argv[4], &vt));
+    if (vt == napi_number) NAPI_OK(napi_get_value_uint32(env, argv[4], &window));
+  }
+  const int32_t rc = api.commit_key_create_ex(h->ctx, curve, first, (const uint8_t *)p, window, &h->key);
+  if (rc != B3W_OK) return throw_status(env, h, rc, "b3w_commit_key_create_ex failed");
   napi_value u;
   napi_get_undefined(env, &u);
   return u;

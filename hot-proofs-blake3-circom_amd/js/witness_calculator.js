@@ -182,11 +182,12 @@ class WitnessCalculator {
   }
 
   // ---- extension: commitment key for batch.commit().  curve: "bn254_g1" | "vesta"; generators: Uint8Array with one
-  // affine point per committed slot (x then y, 32-byte little-endian each), slots firstSlot .. witnessSize - 1.
-  setCommitKey(curve, generators, firstSlot) {
+  // affine point per committed slot (x then y, 32-byte little-endian each), slots firstSlot .. witnessSize - 1;
+  // windowBits: 12 | 16 (table size against speed, see include/b3wit.h), default automatic.
+  setCommitKey(curve, generators, firstSlot, windowBits) {
     const id = {bn254_g1: 0, vesta: 1}[curve];
     if (id === undefined) throw new Error("curve: bn254_g1 or vesta");
-    native().commitKey(this.instance, id, firstSlot || 0, generators);
+    native().commitKey(this.instance, id, firstSlot || 0, generators, windowBits || 0);
   }
 
   // ---- extension: this calculator's GPU joins an RCCL communicator (see commUniqueId above)

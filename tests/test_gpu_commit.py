@@ -20,11 +20,17 @@ def _slot_values(bodies):
     return [[int.from_bytes(b[i, s].tobytes(), "little") for s in range(b.shape[1])] for i in range(n)]
 
 
-def _key(m, ctx, curve, first_slot, gens):
+def _key(m, ctx, curve, first_slot, gens, window=0):
+    """window: 12 or 16 bits per table window; 0 = the library's choice (b3w_commit_key_create)"""
     key = ctypes.c_void_p()
     buf = E.points_to_bytes(gens)
-    rc = m.lib().b3w_commit_key_create(ctx.handle, E.CURVE_ID[curve], first_slot, buf, ctypes.byref(key))
+    if window:
+        rc = m.lib().b3w_commit_key_create_ex(ctx.handle, E.CURVE_ID[curve], first_slot, buf, window, ctypes.byref(key))
+    else:
+        rc = m.lib().b3w_commit_key_create(ctx.handle, E.CURVE_ID[curve], first_slot, buf, ctypes.byref(key))
     assert rc == 0, ctx.last_error()
+    assert m.lib().b3w_commit_key_window(key) == (window or m.lib().b3w_commit_key_window(key)) and \
+        m.lib().b3w_commit_key_window(key) in (12, 16)
     return key
 
 
@@ -36,9 +42,10 @@ def _commit(m, batch, key, n):
     return [E.point_from_bytes(pts[64 * i: 64 * i + 64].tobytes()) for i in range(n)], st
 
 
-@pytest.mark.parametrize("circuit,curve,first_slot,n", [("compression", "bn254_g1", 0, 4), ("compression", "bn254_g1", 17, 2),
-                                                        ("nova_vesta", "vesta", 16, 3), ("nova_bn254", "bn254_g1", 0, 2)])
-def test_commitments_match_plain_integer_group_law(circuit, curve, first_slot, n):
+@pytest.mark.parametrize("circuit,curve,first_slot,n,window", [
+    ("compression", "bn254_g1", 0, 4, 12), ("compression", "bn254_g1", 17, 2, 16), ("nova_vesta", "vesta", 16, 3, 12),
+    ("nova_vesta", "vesta", 0, 2, 16), ("nova_bn254", "bn254_g1", 0, 2, 0)])
+def test_commitments_match_plain_integer_group_law(circuit, curve, first_slot, n, window):
     m = T.pkg()
     W = T.workloads()
     recs = W.config2_compression(n, first=11) if circuit == "compression" else W.config3_nova(n, first=11)
@@ -51,7 +58,7 @@ def test_commitments_match_plain_integer_group_law(circuit, curve, first_slot, n
     ctx = m.Context(circuit, 0)
     b = m.Batch(ctx, n)
     b.run(recs)
-    key = _key(m, ctx, curve, first_slot, gens)
+    key = _key(m, ctx, curve, first_slot, gens, window)
     got, st = _commit(m, b, key, n)
     assert (st == 0).all()
     for i in range(n):
@@ -75,20 +82,23 @@ def test_related_generators_hit_the_exceptional_cases():
     ctx = m.Context(circuit, 0)
     b = m.Batch(ctx, n)
     b.run(recs)
-    # (a) one point everywhere: C = (sum of all slot values) * G
-    key = _key(m, ctx, curve, 0, [base[0]] * nwit)
-    got, st = _commit(m, b, key, n)
-    for i in range(n):
-        assert got[i] == E.mul(sum(vals[i]) % (1 << 300), base[0], p), i
-    m.lib().b3w_commit_key_destroy(key)
-    # (b) +G, -G, +G, -G ...: C = (sum of even slots - sum of odd slots) * G
-    key = _key(m, ctx, curve, 0, [base[1] if s % 2 == 0 else E.neg(base[1], p) for s in range(nwit)])
-    got, st = _commit(m, b, key, n)
-    for i in range(n):
-        k = sum(vals[i][0::2]) - sum(vals[i][1::2])
-        want = E.mul(abs(k), base[1] if k >= 0 else E.neg(base[1], p), p)
-        assert got[i] == want, i
-    m.lib().b3w_commit_key_destroy(key)
+    for window in (12, 16):
+        # (a) one point everywhere: C = (sum of all slot values) * G
+        key = _key(m, ctx, curve, 0, [base[0]] * nwit, window)
+        got, st = _commit(m, b, key, n)
+        for i in range(n):
+            assert got[i] == E.mul(sum(vals[i]) % (1 << 300), base[0], p), (window, i)
+        m.lib().b3w_commit_key_destroy(key)
+        # (b) +G, -G, +G, -G ...: C = (sum of even slots - sum of odd slots) * G
+        key = _key(m, ctx, curve, 0, [base[1] if s % 2 == 0 else E.neg(base[1], p) for s in range(nwit)], window)
+        got, st = _commit(m, b, key, n)
+        for i in range(n):
+            k = sum(vals[i][0::2]) - sum(vals[i][1::2])
+            want = E.mul(abs(k), base[1] if k >= 0 else E.neg(base[1], p), p)
+            assert got[i] == want, (window, i)
+        m.lib().b3w_commit_key_destroy(key)
+    bad = ctypes.c_void_p()
+    assert m.lib().b3w_commit_key_create_ex(ctx.handle, 0, 0, E.points_to_bytes([base[0]] * nwit), 13, ctypes.byref(bad)) == 100
     b.close(); ctx.close()
 
 

@@ -5,13 +5,14 @@ import ec_ref as E
 m = importlib.import_module("hot-proofs-blake3-circom_amd")
 L = m.lib()
 dev = torch.device("cuda:0"); s = torch.cuda.current_stream().cuda_stream
-for circuit, curve, n in (("compression", "bn254_g1", 4096), ("compression", "bn254_g1", 16384), ("nova_vesta", "vesta", 8192)):
+for circuit, curve, n, window in (("compression", "bn254_g1", 4096, 12), ("compression", "bn254_g1", 16384, 12), ("nova_vesta", "vesta", 8192, 12),
+                                  ("compression", "bn254_g1", 4096, 16), ("compression", "bn254_g1", 16384, 16), ("nova_vesta", "vesta", 8192, 16)):
     ctx = m.Context(circuit, 0)
     recs = m.workloads.config2_compression(n) if circuit == "compression" else m.workloads.config3_nova(n)
     gens = E.random_points(curve, ctx.witness_size, seed=b"rate")
     key = ctypes.c_void_p()
     t0 = time.perf_counter()
-    assert L.b3w_commit_key_create(ctx.handle, E.CURVE_ID[curve], 0, E.points_to_bytes(gens), ctypes.byref(key)) == 0
+    assert L.b3w_commit_key_create_ex(ctx.handle, E.CURVE_ID[curve], 0, E.points_to_bytes(gens), window, ctypes.byref(key)) == 0
     tk = time.perf_counter() - t0
     d_recs = torch.from_numpy(recs.view(np.int32)).to(dev)
     bodies = ctx.alloc_bodies(n * ctx.body_bytes)
@@ -25,5 +26,5 @@ for circuit, curve, n in (("compression", "bn254_g1", 4096), ("compression", "bn
     e1.record(); torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / 3
     assert int(d_st.abs().sum().item()) == 0
-    print(f"{circuit} on {curve}: key set-up {tk*1e3:.0f} ms; commit {n} bodies in {ms:.2f} ms = {n/ms:.1f} k witnesses/s", flush=True)
+    print(f"{circuit} on {curve}, {window}-bit windows: key set-up {tk*1e3:.0f} ms; commit {n} bodies in {ms:.2f} ms = {n/ms:.1f} k witnesses/s", flush=True)
     L.b3w_commit_key_destroy(key); bodies.free(); ctx.close()
