@@ -296,9 +296,21 @@ struct B3wCurve9 {
   uint32_t inv;         // -p^-1 mod 2^29
   uint32_t mu;          // floor(2^269 / p) (or 1 less)
   uint32_t kp0[3];      // limb 0 of 3p, 4p, 5p: the filter in front of the exact "H = 0 mod p" test
+  __device__ __forceinline__ uint32_t P(int i) const { return p[i]; }
+  __device__ __forceinline__ uint32_t INV() const { return inv; }
+};
+// The Vesta base field with its modulus as compile-time constants: p = 2^254 + (126 bits) has limb 0 = 1, limbs 5..7 = 0
+// and limb 8 = 2^22, so a third of the reduction's multiplications fold away (same layout, chosen by the launcher
+// when the key's modulus is this one).
+struct B3wCurve9Vesta : B3wCurve9 {
+  __host__ __device__ static constexpr uint32_t P(int i) {
+    return i == 0 ? 0x1u : i == 1 ? 0x9698768u : i == 2 ? 0x133e46e6u : i == 3 ? 0xd31f812u : i == 4 ? 0x224u : i == 8 ? 0x400000u : 0u;
+  }
+  __host__ __device__ static constexpr uint32_t INV() { return M29; }
 };
 
-__device__ __forceinline__ F9 mul29(const F9 &a, const F9 &b, const B3wCurve9 &C) {
+template <class CV>
+__device__ __forceinline__ F9 mul29(const F9 &a, const F9 &b, const CV &C) {
   uint64_t acc = 0;
   uint32_t m[9];
   F9 r;
@@ -307,9 +319,9 @@ __device__ __forceinline__ F9 mul29(const F9 &a, const F9 &b, const B3wCurve9 &C
 #pragma unroll
     for (int i = 0; i <= k; ++i) acc += (uint64_t)a.l[i] * b.l[k - i];
 #pragma unroll
-    for (int i = 0; i < k; ++i) acc += (uint64_t)m[i] * C.p[k - i];
-    m[k] = ((uint32_t)acc * C.inv) & M29;
-    acc += (uint64_t)m[k] * C.p[0];
+    for (int i = 0; i < k; ++i) acc += (uint64_t)m[i] * C.P(k - i);
+    m[k] = ((uint32_t)acc * C.INV()) & M29;
+    acc += (uint64_t)m[k] * C.P(0);
     acc >>= 29;
   }
 #pragma unroll
@@ -317,14 +329,15 @@ __device__ __forceinline__ F9 mul29(const F9 &a, const F9 &b, const B3wCurve9 &C
 #pragma unroll
     for (int i = k - 8; i < 9; ++i) acc += (uint64_t)a.l[i] * b.l[k - i];
 #pragma unroll
-    for (int i = k - 8; i < 9; ++i) acc += (uint64_t)m[i] * C.p[k - i];
+    for (int i = k - 8; i < 9; ++i) acc += (uint64_t)m[i] * C.P(k - i);
     r.l[k - 9] = (uint32_t)acc & M29;
     acc >>= 29;
   }
   r.l[8] = (uint32_t)acc;
   return r;
 }
-__device__ __forceinline__ F9 sqr29(const F9 &a, const B3wCurve9 &C) {      // limbs < 2^30
+template <class CV>
+__device__ __forceinline__ F9 sqr29(const F9 &a, const CV &C) {      // limbs < 2^30
   uint64_t acc = 0;
   uint32_t m[9], d[9];
   F9 r;
@@ -337,12 +350,12 @@ __device__ __forceinline__ F9 sqr29(const F9 &a, const B3wCurve9 &C) {      // l
     if (!(k & 1)) acc += (uint64_t)a.l[k / 2] * a.l[k / 2];
     if (k < 9) {
 #pragma unroll
-      for (int i = 0; i < k; ++i) acc += (uint64_t)m[i] * C.p[k - i];
-      m[k] = ((uint32_t)acc * C.inv) & M29;
-      acc += (uint64_t)m[k] * C.p[0];
+      for (int i = 0; i < k; ++i) acc += (uint64_t)m[i] * C.P(k - i);
+      m[k] = ((uint32_t)acc * C.INV()) & M29;
+      acc += (uint64_t)m[k] * C.P(0);
     } else {
 #pragma unroll
-      for (int i = k - 8; i < 9; ++i) acc += (uint64_t)m[i] * C.p[k - i];
+      for (int i = k - 8; i < 9; ++i) acc += (uint64_t)m[i] * C.P(k - i);
       r.l[k - 9] = (uint32_t)acc & M29;
     }
     acc >>= 29;
@@ -355,7 +368,8 @@ __device__ __forceinline__ F9 cn29(F9 a) {
   for (int i = 0; i < 8; ++i) { a.l[i + 1] += a.l[i] >> 29; a.l[i] &= M29; }
   return a;
 }
-__device__ __forceinline__ F9 red29(const F9 &a, const B3wCurve9 &C) {
+template <class CV>
+__device__ __forceinline__ F9 red29(const F9 &a, const CV &C) {
   const uint32_t top = (a.l[8] + (a.l[7] >> 29)) >> 13;            // value / 2^245, rounded down (< 2^16)
   const uint32_t q = (top * C.mu) >> 24;                           // floor(value / p) or 1 less
   int64_t acc = 0;
@@ -363,7 +377,7 @@ __device__ __forceinline__ F9 red29(const F9 &a, const B3wCurve9 &C) {
 #pragma unroll
   for (int i = 0; i < 9; ++i) {
     acc += (int64_t)(uint64_t)a.l[i];
-    acc -= (int64_t)((uint64_t)q * C.p[i]);
+    acc -= (int64_t)((uint64_t)q * C.P(i));
     r.l[i] = i < 8 ? (uint32_t)acc & M29 : (uint32_t)acc;
     acc >>= 29;
   }
@@ -375,13 +389,15 @@ __device__ __forceinline__ F9 add29(const F9 &a, const F9 &b) {
   for (int i = 0; i < 9; ++i) r.l[i] = a.l[i] + b.l[i];
   return r;
 }
-__device__ __forceinline__ F9 sub29(const F9 &a, const F9 &b, const B3wCurve9 &C) {     // a + 4p - b   (b tidy < 2p)
+template <class CV>
+__device__ __forceinline__ F9 sub29(const F9 &a, const F9 &b, const CV &C) {     // a + 4p - b   (b tidy < 2p)
   F9 r;
 #pragma unroll
   for (int i = 0; i < 9; ++i) r.l[i] = a.l[i] + (C.sp4[i] - b.l[i]);
   return r;
 }
-__device__ __forceinline__ F9 neg29(const F9 &b, const B3wCurve9 &C) {                  // 4p - b
+template <class CV>
+__device__ __forceinline__ F9 neg29(const F9 &b, const CV &C) {                  // 4p - b
   F9 r;
 #pragma unroll
   for (int i = 0; i < 9; ++i) r.l[i] = C.sp4[i] - b.l[i];
@@ -394,22 +410,28 @@ __device__ __forceinline__ F9 shl29(const F9 &a, int s) {
   return r;
 }
 // tidy a == k * p ?
-__device__ __forceinline__ bool is_kp29(const F9 &a, uint32_t k, const B3wCurve9 &C) {
+template <class CV>
+__device__ __forceinline__ bool is_kp29(const F9 &a, uint32_t k, const CV &C) {
   uint32_t c = 0, o = 0;
 #pragma unroll
   for (int i = 0; i < 9; ++i) {
-    const uint32_t t = k * C.p[i] + c;
+    const uint32_t t = k * C.P(i) + c;
     o |= (i < 8 ? t & M29 : t) ^ a.l[i];
     c = t >> 29;
   }
   return o == 0;
 }
 // the safe forms (tidy < 2p in, tidy < 2p out) for the rare paths and the tree
-__device__ __forceinline__ F9 s_add(const F9 &a, const F9 &b, const B3wCurve9 &C) { return red29(add29(a, b), C); }
-__device__ __forceinline__ F9 s_sub(const F9 &a, const F9 &b, const B3wCurve9 &C) { return red29(sub29(a, b, C), C); }
-__device__ __forceinline__ F9 s_dbl(const F9 &a, const B3wCurve9 &C) { return red29(shl29(a, 1), C); }
-__device__ __forceinline__ bool s_is_zero(const F9 &a, const B3wCurve9 &C) { return is_kp29(a, 0, C) || is_kp29(a, 1, C); }
-__device__ __forceinline__ F9 one29(const B3wCurve9 &C) {
+template <class CV>
+__device__ __forceinline__ F9 s_add(const F9 &a, const F9 &b, const CV &C) { return red29(add29(a, b), C); }
+template <class CV>
+__device__ __forceinline__ F9 s_sub(const F9 &a, const F9 &b, const CV &C) { return red29(sub29(a, b, C), C); }
+template <class CV>
+__device__ __forceinline__ F9 s_dbl(const F9 &a, const CV &C) { return red29(shl29(a, 1), C); }
+template <class CV>
+__device__ __forceinline__ bool s_is_zero(const F9 &a, const CV &C) { return is_kp29(a, 0, C) || is_kp29(a, 1, C); }
+template <class CV>
+__device__ __forceinline__ F9 one29(const CV &C) {
   F9 r;
 #pragma unroll
   for (int i = 0; i < 9; ++i) r.l[i] = C.one[i];
@@ -451,7 +473,8 @@ __device__ __forceinline__ J9 j9_infinity() {
   return r;
 }
 // P = 2P (dbl-2009-l, a = 0), safe forms
-__device__ __forceinline__ void j9_dbl(J9 &P, const B3wCurve9 &C) {
+template <class CV>
+__device__ __forceinline__ void j9_dbl(J9 &P, const CV &C) {
   if (P.inf) return;
   if (s_is_zero(P.Y, C)) { P.inf = true; return; }
   const F9 A = sqr29(P.X, C), B = sqr29(P.Y, C), Cc = sqr29(B, C);
@@ -465,7 +488,8 @@ __device__ __forceinline__ void j9_dbl(J9 &P, const B3wCurve9 &C) {
   P.X = X3; P.Y = Y3;
 }
 // P += (x2, y2, 1): madd-2007-bl with lazy values; x2, y2 tidy < p; (0, 0) (the table's infinity) is filtered by the caller
-__device__ __forceinline__ void j9_madd(J9 &P, const F9 &x2, const F9 &y2, const B3wCurve9 &C) {
+template <class CV>
+__device__ __forceinline__ void j9_madd(J9 &P, const F9 &x2, const F9 &y2, const CV &C) {
   if (P.inf) {
     P.X = x2; P.Y = y2; P.Z = one29(C); P.inf = false;
     return;
@@ -493,7 +517,8 @@ __device__ __forceinline__ void j9_madd(J9 &P, const F9 &x2, const F9 &y2, const
   P.Z = shl29(mul29(P.Z, H, C), 1);                                // 2 Z1 H: < 4p, limbs < 2^30
 }
 // P += Q (add-2007-bl), safe forms
-__device__ __forceinline__ void j9_add(J9 &P, const J9 &Q, const B3wCurve9 &C) {
+template <class CV>
+__device__ __forceinline__ void j9_add(J9 &P, const J9 &Q, const CV &C) {
   if (Q.inf) return;
   if (P.inf) { P.X = Q.X; P.Y = Q.Y; P.Z = Q.Z; P.inf = false; return; }
   const F9 Z1 = red29(P.Z, C), Z2 = red29(Q.Z, C);
@@ -564,12 +589,12 @@ __global__ __launch_bounds__(64) void b3w_commit_window_kernel(const uint32_t *_
 }
 
 // ---- commit: one workgroup per witness
-template <int T, int WPB, int W>        // threads per witness, witnesses per workgroup (T * WPB threads), window width
-__global__ __launch_bounds__(T * WPB) void b3w_commit_kernel(const uint8_t *__restrict__ bodies, uint32_t n, uint64_t pitch,
+template <int T, int WPB, int W, class CV>        // threads per witness, witnesses per workgroup (T * WPB threads), window width, field
+__global__ __launch_bounds__(T * WPB) __attribute__((amdgpu_waves_per_eu(3, 3))) void b3w_commit_kernel(const uint8_t *__restrict__ bodies, uint32_t n, uint64_t pitch,
                                                          const uint32_t *__restrict__ vslots /* W per window: slot | bit << 19 | single << 27 | width words << 28 */,
                                                          const uint32_t *__restrict__ table /* radix 2^261 */, uint32_t nwin,
                                                          uint32_t *__restrict__ sums /* n x B3W_COMMIT_SUM_WORDS: X Y Z in 29-bit limbs */,
-                                                         int32_t *__restrict__ status, B3wCurve9 C) {
+                                                         int32_t *__restrict__ status, CV C) {
   __shared__ uint32_t red[T * WPB * 27];
   __shared__ uint32_t bad[WPB];
   const uint32_t sub = threadIdx.x / T, t = threadIdx.x % T;       // which witness of the workgroup, lane within it
@@ -643,8 +668,9 @@ __global__ __launch_bounds__(T * WPB) void b3w_commit_kernel(const uint8_t *__re
 
 // ---- normalise: one THREAD per witness (a Fermat inversion is 380 dependent multiplications: on thread 0 of the commit
 // workgroup it took longer than the workgroup's whole share of additions); affine, standard form, 64 bytes per point
+template <class CV>
 __global__ __launch_bounds__(64) void b3w_commit_normalize_kernel(const uint32_t *__restrict__ sums, uint32_t n, uint8_t *__restrict__ out,
-                                                                  B3wCurve C, B3wCurve9 C9) {
+                                                                  B3wCurve C, CV C9) {
   const uint32_t w = blockIdx.x * 64 + threadIdx.x;
   if (w >= n) return;
   F9 co[3];
@@ -752,17 +778,25 @@ extern "C" int b3w_launch_commit(const uint8_t *d_bodies, uint32_t n, uint64_t p
   // at both window widths).  Virtual slots: 53 k compression, 58 k nova O2, 108 k nova O1.
   static const int env_tpw = getenv("B3W_COMMIT_THREADS") ? atoi(getenv("B3W_COMMIT_THREADS")) : 0;
   const int tpw = env_tpw ? env_tpw : (uint64_t)nwin * window > 55200 ? 64 : 32;
-#define B3W_COMMIT_LAUNCH(T, WPB, W)                                                                                      \
-  hipLaunchKernelGGL((b3w_commit_kernel<T, WPB, W>), dim3((n + WPB - 1) / WPB), dim3(T * WPB), 0, stream, d_bodies, n, pitch, d_vslots, \
-                     d_table, nwin, d_sums, d_status, c9)
+  bool vesta = true;                                           // the modulus with compile-time limbs?
+  for (int i = 0; i < 9; ++i) vesta = vesta && c9.p[i] == B3wCurve9Vesta::P(i);
+  vesta = vesta && c9.inv == B3wCurve9Vesta::INV() && tpw == 64;
+  B3wCurve9Vesta c9v;
+  static_cast<B3wCurve9 &>(c9v) = c9;
+#define B3W_COMMIT_LAUNCH(T, WPB, W, CV, cv)                                                                              \
+  hipLaunchKernelGGL((b3w_commit_kernel<T, WPB, W, CV>), dim3((n + WPB - 1) / WPB), dim3(T * WPB), 0, stream, d_bodies, n, pitch, \
+                     d_vslots, d_table, nwin, d_sums, d_status, cv)
   if (window == B3W_COMMIT_WINDOW_LARGE) {
-    if (tpw == 64) B3W_COMMIT_LAUNCH(64, 1, B3W_COMMIT_WINDOW_LARGE);
-    else B3W_COMMIT_LAUNCH(32, 2, B3W_COMMIT_WINDOW_LARGE);
+    if (vesta) B3W_COMMIT_LAUNCH(64, 1, B3W_COMMIT_WINDOW_LARGE, B3wCurve9Vesta, c9v);
+    else if (tpw == 64) B3W_COMMIT_LAUNCH(64, 1, B3W_COMMIT_WINDOW_LARGE, B3wCurve9, c9);
+    else B3W_COMMIT_LAUNCH(32, 2, B3W_COMMIT_WINDOW_LARGE, B3wCurve9, c9);
   } else {
-    if (tpw == 64) B3W_COMMIT_LAUNCH(64, 1, B3W_COMMIT_WINDOW_SMALL);
-    else B3W_COMMIT_LAUNCH(32, 2, B3W_COMMIT_WINDOW_SMALL);
+    if (vesta) B3W_COMMIT_LAUNCH(64, 1, B3W_COMMIT_WINDOW_SMALL, B3wCurve9Vesta, c9v);
+    else if (tpw == 64) B3W_COMMIT_LAUNCH(64, 1, B3W_COMMIT_WINDOW_SMALL, B3wCurve9, c9);
+    else B3W_COMMIT_LAUNCH(32, 2, B3W_COMMIT_WINDOW_SMALL, B3wCurve9, c9);
   }
 #undef B3W_COMMIT_LAUNCH
-  hipLaunchKernelGGL(b3w_commit_normalize_kernel, dim3((n + 63) / 64), dim3(64), 0, stream, d_sums, n, d_out, *curve, c9);
+  if (vesta) hipLaunchKernelGGL(b3w_commit_normalize_kernel<B3wCurve9Vesta>, dim3((n + 63) / 64), dim3(64), 0, stream, d_sums, n, d_out, *curve, c9v);
+  else hipLaunchKernelGGL(b3w_commit_normalize_kernel<B3wCurve9>, dim3((n + 63) / 64), dim3(64), 0, stream, d_sums, n, d_out, *curve, c9);
   return (int)hipGetLastError();
 }
