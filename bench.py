@@ -54,7 +54,20 @@ def bench_chain(args, m, torch, dist, dev, world, rank, local_rank):
     nbytes = int(args.preimage_mib * (1 << 20))
     lcg_words = (np.arange(nbytes // 4 + 1, dtype=np.uint64) * np.uint64(2654435761) + np.uint64(12345)) & np.uint64(0xFFFFFFFF)
     host = torch.from_numpy(lcg_words.astype(np.uint32).view(np.uint8)[:nbytes].copy()).pin_memory()
-    run = lambda: m.chain.fold_witnesses(ctx, host, batch_steps=args.batch if args.batch != 4096 else 16384, ring=2)
+    consumer, key = None, None
+    if args.consumer == "commit":                      # what the folding prover does with each step witness
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import ec_ref as E                             # plain-integer curve arithmetic: here only to make valid generators
+        curve = "vesta" if "vesta" in circuit else "bn254_g1"
+        key = m.CommitKey(ctx, curve, E.points_to_bytes(E.random_points(curve, ctx.witness_size, seed=b"bench")))
+        n_max = m.lib().b3w_chain_num_chunks(nbytes) * 64 + 64
+        d_pts = torch.zeros((n_max, 64), dtype=torch.uint8, device=dev)
+        d_st = torch.zeros(n_max, dtype=torch.int32, device=dev)
+
+        def consumer(view, first, k):
+            key.commit_device(view.data_ptr(), k, view.stride(0), d_pts.data_ptr() + 64 * first, d_st.data_ptr() + 4 * first,
+                              torch.cuda.current_stream().cuda_stream)
+    run = lambda: m.chain.fold_witnesses(ctx, host, batch_steps=args.batch if args.batch != 4096 else 16384, ring=2, consumer=consumer)
     for _ in range(max(3, args.warmup)):        # the first passes pay the allocator (24 GB ring, record buffers)
         out = run()
     torch.cuda.synchronize()
@@ -71,6 +84,8 @@ def bench_chain(args, m, torch, dist, dev, world, rank, local_rank):
     elapsed = time.perf_counter() - t0
     assert int(out["status"].abs().sum().item()) == 0
     local_steps = out["n_leaf_steps"] + out["n_parent_steps"]
+    if key is not None:
+        assert int(d_st[:local_steps].abs().sum().item()) == 0 and int(d_pts[:local_steps].max(dim=1).values.min().item()) > 0
     t = torch.tensor([elapsed, float(local_steps)], dtype=torch.float64, device=dev)
     if world > 1:
         tm = t.clone(); dist.all_reduce(tm, op=dist.ReduceOp.MAX)
@@ -87,7 +102,8 @@ def bench_chain(args, m, torch, dist, dev, world, rank, local_rank):
             "config": {"workload": f"chain: {args.preimage_mib} MiB preimage -> {int(total_steps)} nova steps ({circuit}), "
                                    "planner + witness kernels, bodies through a 2-deep ring, H2D overlapped",
                        "circuit": circuit, "n_chunks": out["n_chunks"], "path_len": out["path_len"],
-                       "placement": out.get("placement")},
+                       "placement": out.get("placement"),
+                       "consumer": "none" if key is None else f"Pedersen commitment of every step witness on the device ({key.window}-bit windows)"},
             "roofline": {"bound": "hbm", "achieved": total_steps * args.steps * per / elapsed / 1e9 / world, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": total_steps * args.steps * per / elapsed / 1e9 / world / HBM_PEAK_GBS,
                          "traffic": None, "note": "end-to-end per-GPU rate incl. planner, H2D and launch gaps"},
@@ -112,6 +128,9 @@ def main():
                     help="batch = BASELINE config 2/3 (default, the headline metric); chain = configs 4/5: "
                          "preimage -> planner -> nova step witnesses, streamed through a ring of buffers")
     ap.add_argument("--preimage-mib", type=float, default=1.0, help="chain workload: preimage size (1 = config 4, 1024 = config 5)")
+    ap.add_argument("--consumer", default="none", choices=["none", "commit"],
+                    help="chain workload: what reads each batch of step witnesses while it sits in the ring "
+                         "(commit = Pedersen commitments on the circuit's curve, synthetic generators)")
     args = ap.parse_args()
 
     import numpy as np
