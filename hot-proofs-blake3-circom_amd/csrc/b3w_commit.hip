@@ -16,8 +16,8 @@
 //            Jacobian + affine addition with the tabulated point — no doublings, one addition per W slots, no
 //            zero work in lock step; an LDS tree adds the 32 partial sums; a second kernel normalises them, one
 //            thread per witness (Fermat inversion), and stores the affine points.
-// Arithmetic: 256-bit Montgomery, modulus passed at run time.  The one-time set-up kernels use the textbook CIOS on
-// eight 32-bit limbs; the commit and normalise kernels use nine 29-bit limbs (radix 2^261, lazy reduction: see the
+// Arithmetic: 256-bit Montgomery, modulus passed at run time.  The per-slot doubling chains of the set-up use the textbook
+// CIOS on eight 32-bit limbs; the table, commit and normalise kernels use nine 29-bit limbs (radix 2^261, lazy reduction: see the
 // F9 section below), in which a limb product is a single v_mad_u64_u32.  Complete handling of the exceptional cases
 // (infinity, P + P, P - P) so that related generators cannot break it.
 // Domain: bodies of the batch kernels (every bit slot holds 0 or 1, words fit their slot's width); a slot holding
@@ -438,6 +438,18 @@ __device__ __forceinline__ F9 one29(const CV &C) {
   return r;
 }
 
+// a^(p-2) (Fermat), a tidy < 2p and != 0 mod p; pm2 = p - 2 in eight 32-bit words
+template <class CV>
+__device__ __forceinline__ F9 inv29(const F9 &a, const uint32_t *pm2, const CV &C) {
+  F9 r = one29(C);
+#pragma unroll 1
+  for (int i = 255; i >= 0; --i) {
+    r = sqr29(r, C);
+    if ((pm2[i >> 5] >> (i & 31)) & 1) r = mul29(r, a, C);
+  }
+  return r;
+}
+
 __device__ __forceinline__ F9 to29(const Fp &a) {                   // eight 32-bit words -> nine 29-bit limbs
   F9 r;
 #pragma unroll
@@ -537,7 +549,7 @@ __device__ __forceinline__ void j9_add(J9 &P, const J9 &Q, const CV &C) {
   P.X = X3;
 }
 
-// ---- set-up: points[first_v[s] + k] = 2^k * G_s (Montgomery affine) for every committed slot s
+// ---- set-up: points[first_v[s] + k] = 2^k * G_s (affine, Montgomery radix 2^261, eight 32-bit words) for every committed slot s
 __global__ __launch_bounds__(64) void b3w_commit_setup_kernel(const uint32_t *__restrict__ gens /* nslots x 16 words, standard form */,
                                                               const uint32_t *__restrict__ first_v, const uint32_t *__restrict__ nbits,
                                                               uint32_t nslots, uint32_t *__restrict__ points, B3wCurve C) {
@@ -551,41 +563,106 @@ __global__ __launch_bounds__(64) void b3w_commit_setup_kernel(const uint32_t *__
   P.Y = fp_mul(load_fp(gens + (uint64_t)s * 16 + 8), r2, C);
 #pragma unroll
   for (int i = 0; i < 8; ++i) P.Z.l[i] = C.one[i];
+  Fp c32;                                                 // 32 in Montgomery form: the other kernels' radix is 2^261
+#pragma unroll
+  for (int k = 0; k < 8; ++k) c32.l[k] = C.one[k];
+#pragma unroll 1
+  for (int k = 0; k < 5; ++k) c32 = fp_dbl(c32, C);
   const uint32_t nb = nbits[s], v0 = first_v[s];
   for (uint32_t k = 0; k < nb; ++k) {
     Fp x, y;
     if (k == 0) { x = P.X; y = P.Y; } else jac_to_affine(P, x, y, C);
-    store_fp(points + (uint64_t)(v0 + k) * 16, x);
-    store_fp(points + (uint64_t)(v0 + k) * 16 + 8, y);
+    store_fp(points + (uint64_t)(v0 + k) * 16, fp_mul(x, c32, C));
+    store_fp(points + (uint64_t)(v0 + k) * 16 + 8, fp_mul(y, c32, C));
     if (k + 1 < nb) P = jac_dbl(P, C);
   }
 }
 
 // ---- set-up 2: table[win * (2^W - 1) + m - 1] = sum of the window's virtual-slot points selected by the bits of m
+// (affine, radix 2^261, eight 32-bit words; infinity = (0, 0)).  A thread walks K = 4 consecutive entries in Gray-code
+// order — the first from scratch, each next one is the previous +/- one point — and the four share one inversion
+// (Montgomery's trick), so an entry costs ~3 additions and a quarter of an inversion instead of W/2 additions and a
+// whole one.  The thread's Jacobian results and prefix products wait in LDS ([entry][limb][thread]: conflict-free).
+#define B3W_WINDOW_K 4
 template <int W>
 __global__ __launch_bounds__(64) void b3w_commit_window_kernel(const uint32_t *__restrict__ points, uint32_t nwin,
-                                                               uint32_t *__restrict__ table, B3wCurve C) {
-  const uint64_t i = (uint64_t)blockIdx.x * 64 + threadIdx.x;
-  if (i >= (uint64_t)nwin * B3W_COMMIT_ENTRIES(W)) return;
-  const uint32_t win = (uint32_t)(i / B3W_COMMIT_ENTRIES(W)), m = (uint32_t)(i % B3W_COMMIT_ENTRIES(W)) + 1;
-  Jac acc = jac_infinity();
+                                                               uint32_t *__restrict__ table, B3wCurve C, B3wCurve9 C9) {
+  constexpr int K = B3W_WINDOW_K;
+  constexpr uint32_t CHUNKS = (1u << W) / K;                  // per window
+  __shared__ uint32_t lds[4 * K * 9 * 64];                    // X, Y, Z, prefix product of the Zs
+  const uint32_t tid = threadIdx.x;
+  const uint64_t gid = (uint64_t)blockIdx.x * 64 + tid;
+  if (gid >= (uint64_t)nwin * CHUNKS) return;                 // no barriers below: every thread uses its own LDS column
+  const uint32_t win = (uint32_t)(gid / CHUNKS), g0 = (uint32_t)(gid % CHUNKS) * K;
+  auto at = [&](int what, int e, int l) -> uint32_t & { return lds[((what * K + e) * 9 + l) * 64 + tid]; };
+  auto point = [&](uint32_t b, bool negate, F9 &x, F9 &y) {
+    const uint32_t *pt = points + (uint64_t)(win * W + b) * 16;
+    Fp py = load_fp(pt + 8);
+    if (negate) py = fp_sub(fp_zero(), py, C);
+    x = to29(load_fp(pt)); y = to29(py);
+  };
+  J9 acc = j9_infinity();
+  const uint32_t m0 = g0 ^ (g0 >> 1);
 #pragma unroll 1
-  for (int j = 0; j < W; ++j) {
-    if (!((m >> j) & 1)) continue;
-    const uint32_t *pt = points + (uint64_t)(win * W + j) * 16;
-    acc = jac_madd(acc, load_fp(pt), load_fp(pt + 8), C);
+  for (uint32_t b = 0; b < (uint32_t)W; ++b) {
+    if (!((m0 >> b) & 1)) continue;
+    F9 x, y;
+    point(b, false, x, y);
+    j9_madd(acc, x, y, C9);
   }
-  Fp x, y;
-  jac_to_affine(acc, x, y, C);                            // infinity -> (0, 0)
-  Fp c32;                                                 // 32 in Montgomery form: the commit kernel's radix is 2^261
-#pragma unroll
-  for (int k = 0; k < 8; ++k) c32.l[k] = C.one[k];
 #pragma unroll 1
-  for (int k = 0; k < 5; ++k) c32 = fp_dbl(c32, C);
-  x = fp_mul(x, c32, C);
-  y = fp_mul(y, c32, C);
-  store_fp(table + i * 16, x);
-  store_fp(table + i * 16 + 8, y);
+  for (int e = 0; e < K; ++e) {
+    if (e > 0) {                                              // Gray code: entry g differs from g - 1 in bit ctz(g)
+      const uint32_t g = g0 + e, m = g ^ (g >> 1), b = (uint32_t)__builtin_ctz(g);
+      F9 x, y;
+      point(b, !((m >> b) & 1), x, y);
+      j9_madd(acc, x, y, C9);
+    }
+    const F9 Z = acc.inf ? one29(C9) : red29(acc.Z, C9);
+#pragma unroll
+    for (int l = 0; l < 9; ++l) { at(0, e, l) = acc.X.l[l]; at(1, e, l) = acc.Y.l[l]; at(2, e, l) = acc.inf ? 0u : Z.l[l]; }
+    F9 c;                                                     // prefix product of the (finite) Zs
+    if (e == 0) c = Z;
+    else {
+#pragma unroll
+      for (int l = 0; l < 9; ++l) c.l[l] = at(3, e - 1, l);
+      c = mul29(c, Z, C9);
+    }
+#pragma unroll
+    for (int l = 0; l < 9; ++l) at(3, e, l) = c.l[l];
+  }
+  F9 inv;
+#pragma unroll
+  for (int l = 0; l < 9; ++l) inv.l[l] = at(3, K - 1, l);
+  inv = inv29(inv, C.pm2, C9);                                // 1 / (Z_0 ... Z_{K-1})
+#pragma unroll 1
+  for (int e = K - 1; e >= 0; --e) {
+    F9 X, Y, Z, zi = inv;
+    uint32_t z = 0;
+#pragma unroll
+    for (int l = 0; l < 9; ++l) { X.l[l] = at(0, e, l); Y.l[l] = at(1, e, l); Z.l[l] = at(2, e, l); z |= Z.l[l]; }
+    if (z) {                                                  // finite: it took part in the product
+      if (e > 0) {
+        F9 c;
+#pragma unroll
+        for (int l = 0; l < 9; ++l) c.l[l] = at(3, e - 1, l);
+        zi = mul29(inv, c, C9);                               // 1 / Z_e
+      }
+      inv = mul29(inv, Z, C9);
+    }
+    const uint32_t g = g0 + e, m = g ^ (g >> 1);
+    if (m == 0) continue;                                     // the empty subset has no entry
+    Fp x = fp_zero(), y = fp_zero();
+    if (z) {
+      const F9 zi2 = sqr29(zi, C9);
+      uint32_t hi;
+      x = from29(mul29(X, zi2, C9), hi); x = fp_reduce_once(x, hi, C);
+      y = from29(mul29(Y, mul29(zi2, zi, C9), C9), hi); y = fp_reduce_once(y, hi, C);
+    }
+    uint32_t *o = table + ((uint64_t)win * B3W_COMMIT_ENTRIES(W) + m - 1) * 16;
+    store_fp(o, x);
+    store_fp(o + 8, y);
+  }
 }
 
 // ---- commit: one workgroup per witness
@@ -684,12 +761,7 @@ __global__ __launch_bounds__(64) void b3w_commit_normalize_kernel(const uint32_t
   Fp x = fp_zero(), y = fp_zero();                           // infinity -> (0, 0)
   if (z) {
     const F9 Z = red29(co[2], C9);
-    F9 zi = one29(C9);                                       // Z^(p-2)
-#pragma unroll 1
-    for (int i = 255; i >= 0; --i) {
-      zi = sqr29(zi, C9);
-      if ((C.pm2[i >> 5] >> (i & 31)) & 1) zi = mul29(zi, Z, C9);
-    }
+    const F9 zi = inv29(Z, C.pm2, C9);
     const F9 zi2 = sqr29(zi, C9);
     F9 unit;
 #pragma unroll
@@ -759,12 +831,13 @@ extern "C" int b3w_launch_commit_setup(const uint32_t *d_gens, const uint32_t *d
 extern "C" int b3w_launch_commit_windows(const uint32_t *d_points, uint32_t nwin, uint32_t window, uint32_t *d_table, const B3wCurve *curve, hipStream_t stream) {
   if (!nwin) return 0;
   if (window != B3W_COMMIT_WINDOW_SMALL && window != B3W_COMMIT_WINDOW_LARGE) return (int)hipErrorInvalidValue;
-  const uint64_t total = (uint64_t)nwin * B3W_COMMIT_ENTRIES(window);
+  const uint64_t total = (uint64_t)nwin * ((1u << window) / B3W_WINDOW_K);      // threads: B3W_WINDOW_K entries each
   const dim3 grid((uint32_t)((total + 63) / 64));
+  const B3wCurve9 c9 = make_curve9(*curve);
   if (window == B3W_COMMIT_WINDOW_LARGE)
-    hipLaunchKernelGGL(b3w_commit_window_kernel<B3W_COMMIT_WINDOW_LARGE>, grid, dim3(64), 0, stream, d_points, nwin, d_table, *curve);
+    hipLaunchKernelGGL(b3w_commit_window_kernel<B3W_COMMIT_WINDOW_LARGE>, grid, dim3(64), 0, stream, d_points, nwin, d_table, *curve, c9);
   else
-    hipLaunchKernelGGL(b3w_commit_window_kernel<B3W_COMMIT_WINDOW_SMALL>, grid, dim3(64), 0, stream, d_points, nwin, d_table, *curve);
+    hipLaunchKernelGGL(b3w_commit_window_kernel<B3W_COMMIT_WINDOW_SMALL>, grid, dim3(64), 0, stream, d_points, nwin, d_table, *curve, c9);
   return (int)hipGetLastError();
 }
 
