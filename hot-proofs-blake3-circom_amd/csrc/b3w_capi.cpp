@@ -871,7 +871,9 @@ struct b3w_commit_key {
   b3w_ctx *ctx = nullptr;
   B3wCurve curve{};
   uint32_t first_slot = 0, nwin = 0, window = 0;
-  uint32_t *d_vslots = nullptr, *d_table = nullptr;   // `window` virtual slots per window; 2^window - 1 subset sums each
+  uint32_t nslots = 0;                                // committed slots: first_slot .. witness_size - 1
+  uint32_t *d_slotdesc = nullptr;                     // per committed slot: first virtual slot (= its bit in the packed witness) | width code << 24
+  uint32_t *d_table = nullptr;                        // per window of `window` virtual slots: 2^window - 1 subset sums
   uint32_t *d_sums = nullptr;                         // Jacobian sums between the two kernels, grown on demand
   uint32_t sums_cap = 0;
 };
@@ -928,15 +930,13 @@ int32_t b3w_commit_key_create_ex(b3w_ctx *ctx, int32_t curve, uint32_t first_slo
   if (!build_slot_table(ctx->desc, table, ctx->last_error)) return B3W_E_BAD_ARGUMENT;
   const uint32_t nslots = ctx->desc.nwit - first_slot;
   // virtual slots: one per bit a slot can hold (BIT 1, W32 32, W64 64, W256 256)
-  std::vector<uint32_t> nbits(nslots), first_v(nslots), vslots;
+  std::vector<uint32_t> nbits(nslots), first_v(nslots);
+  uint64_t nv = 0;                                     // virtual slots = bits of the packed witness
   for (uint32_t i = 0; i < nslots; i++) {
     const uint32_t mode = (table[first_slot + i] >> 17) & 3u;
     nbits[i] = mode == B3W_MODE_BIT ? 1u : mode == B3W_MODE_W32 ? 32u : mode == B3W_MODE_W64 ? 64u : 256u;
-    first_v[i] = (uint32_t)vslots.size();
-    // bits 28..: on bit 0 of a 32- / 64-bit slot its width in words (the kernel checks that the rest of the element is 0)
-    for (uint32_t k = 0; k < nbits[i]; k++)
-      vslots.push_back((first_slot + i) | (k << 19) | ((nbits[i] == 1 ? 1u : 0u) << 27) |
-                       ((k == 0 && (nbits[i] == 32 || nbits[i] == 64) ? nbits[i] / 32 : 0u) << 28));
+    first_v[i] = (uint32_t)nv;
+    nv += nbits[i];
   }
   // window width: the caller's, else B3W_COMMIT_WINDOW, else 16 when its table takes at most a quarter of the free HBM
   hipError_t e = hipSetDevice(ctx->device);
@@ -947,33 +947,36 @@ int32_t b3w_commit_key_create_ex(b3w_ctx *ctx, int32_t curve, uint32_t first_slo
   }
   if (!window) {
     size_t free_b = 0, total_b = 0;
-    const uint64_t large = ((uint64_t)vslots.size() / B3W_COMMIT_WINDOW_LARGE + 1) * B3W_COMMIT_ENTRIES(B3W_COMMIT_WINDOW_LARGE) * 64;
+    const uint64_t large = (nv / B3W_COMMIT_WINDOW_LARGE + 1) * B3W_COMMIT_ENTRIES(B3W_COMMIT_WINDOW_LARGE) * 64;
     window = e == hipSuccess && hipMemGetInfo(&free_b, &total_b) == hipSuccess && large <= free_b / 4 ? B3W_COMMIT_WINDOW_LARGE
                                                                                                       : B3W_COMMIT_WINDOW_SMALL;
   }
-  // windows of `window` virtual slots; the pad entries read bit 31 of slot 0 (the constant 1): always 0
-  const uint32_t V0 = (uint32_t)vslots.size();
-  while (vslots.size() % window) vslots.push_back(0u | (31u << 19));
+  // windows of `window` virtual slots; the pad bits of the last window are never set
+  const uint32_t V0 = (uint32_t)nv;
+  nv = (nv + window - 1) / window * window;
   b3w_commit_key *key = new b3w_commit_key;
   key->ctx = ctx;
   key->curve = make_curve(curve == B3W_CURVE_BN254_G1 ? Q_BN254 : P_VESTA_BASE);
   key->first_slot = first_slot;
   key->window = window;
-  key->nwin = (uint32_t)(vslots.size() / window);
+  key->nwin = (uint32_t)(nv / window);
+  key->nslots = nslots;
   uint32_t *d_gens = nullptr, *d_first = nullptr, *d_nbits = nullptr, *d_points = nullptr;
-  if (e == hipSuccess) e = hipMalloc((void **)&key->d_vslots, vslots.size() * 4);
+  std::vector<uint32_t> desc(nslots);
+  for (uint32_t i = 0; i < nslots; i++) desc[i] = first_v[i] | (nbits[i] == 1 ? 0u : nbits[i] == 32 ? 1u : nbits[i] == 64 ? 2u : 3u) << 24;
+  if (e == hipSuccess) e = hipMalloc((void **)&key->d_slotdesc, (size_t)nslots * 4);
+  if (e == hipSuccess) e = hipMemcpy(key->d_slotdesc, desc.data(), (size_t)nslots * 4, hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMalloc((void **)&key->d_table, (size_t)key->nwin * B3W_COMMIT_ENTRIES(window) * 64);
-  if (e == hipSuccess) e = hipMalloc((void **)&d_points, vslots.size() * 64);
+  if (e == hipSuccess) e = hipMalloc((void **)&d_points, (size_t)nv * 64);
   if (e == hipSuccess) e = hipMalloc((void **)&d_gens, (size_t)nslots * 64);
   if (e == hipSuccess) e = hipMalloc((void **)&d_first, (size_t)nslots * 4);
   if (e == hipSuccess) e = hipMalloc((void **)&d_nbits, (size_t)nslots * 4);
-  if (e == hipSuccess) e = hipMemcpy(key->d_vslots, vslots.data(), vslots.size() * 4, hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMemcpy(d_gens, host_generators, (size_t)nslots * 64, hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMemcpy(d_first, first_v.data(), (size_t)nslots * 4, hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMemcpy(d_nbits, nbits.data(), (size_t)nslots * 4, hipMemcpyHostToDevice);
   // pad points: copies of the first point (never selected, but the table kernel adds them)
   int rc = e == hipSuccess ? b3w_launch_commit_setup(d_gens, d_first, d_nbits, nslots, d_points, &key->curve, nullptr) : 0;
-  for (uint32_t v = V0; v < vslots.size() && e == hipSuccess && rc == 0; v++)
+  for (uint32_t v = V0; v < nv && e == hipSuccess && rc == 0; v++)
     e = hipMemcpyAsync(d_points + (size_t)v * 16, d_points, 64, hipMemcpyDeviceToDevice, nullptr);
   if (e == hipSuccess && rc == 0) rc = b3w_launch_commit_windows(d_points, key->nwin, key->window, key->d_table, &key->curve, nullptr);
   if (e == hipSuccess && rc == 0) e = hipDeviceSynchronize();
@@ -991,7 +994,7 @@ int32_t b3w_commit_key_create_ex(b3w_ctx *ctx, int32_t curve, uint32_t first_slo
 
 void b3w_commit_key_destroy(b3w_commit_key *key) {
   if (!key) return;
-  if (key->d_vslots) (void)hipFree(key->d_vslots);
+  if (key->d_slotdesc) (void)hipFree(key->d_slotdesc);
   if (key->d_table) (void)hipFree(key->d_table);
   if (key->d_sums) (void)hipFree(key->d_sums);
   delete key;
@@ -1015,7 +1018,8 @@ int32_t b3w_batch_commit_device(b3w_ctx *ctx, const b3w_commit_key *key, const u
     HIP_TRY(ctx, hipMalloc((void **)&k->d_sums, (size_t)n * B3W_COMMIT_SUM_WORDS * 4));
     k->sums_cap = n;
   }
-  const int rc = b3w_launch_commit(d_bodies, n, pitch, key->d_vslots, key->d_table, key->nwin, key->window, k->d_sums, d_points, d_status, &key->curve, (hipStream_t)stream);
+  const int rc = b3w_launch_commit(d_bodies, n, pitch, key->first_slot, key->nslots, key->d_slotdesc, key->d_table, key->nwin, key->window,
+                                   k->d_sums, d_points, d_status, &key->curve, (hipStream_t)stream);
   return rc ? hip_fail(ctx, (hipError_t)rc, "commit launch") : B3W_OK;
 }
 

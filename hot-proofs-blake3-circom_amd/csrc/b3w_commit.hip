@@ -10,12 +10,13 @@
 // plus 67 256-bit inverses).  So the multi-scalar multiplication is turned into "add precomputed points":
 //   set-up   every slot is cut into its bits ("virtual slots": slot, bit k; V = 53 k compression, 58 k nova O2) with
 //            the point 2^k * G_slot each (b3w_commit_setup_kernel); W = 12 consecutive virtual slots form a WINDOW whose
-//            4 095 non-empty subset sums are tabulated (b3w_commit_window_kernel: 4.5 k windows x 4 095 affine points = 1.2 GB);
-//   commit   32 lanes per witness (two witnesses per wave); lane t owns windows t, t + 32, ...; it gathers the W bits of
-//            a window from the body, skips ahead to its next NON-ZERO window, and then the whole wave does one mixed
-//            Jacobian + affine addition with the tabulated point — no doublings, one addition per W slots, no
-//            zero work in lock step; an LDS tree adds the 32 partial sums; a second kernel normalises them, one
-//            thread per witness (Fermat inversion), and stores the affine points.
+//            4 095 non-empty subset sums are tabulated (b3w_commit_window_kernel: 4.5 k windows x 4 095 affine points = 1.2 GB; or W = 16:
+//            3.3 k windows x 65 535 points = 14 GB);
+//   commit   32 or 64 lanes per witness: they stream the body once and pack its virtual-slot bits into LDS; lane t then owns
+//            windows t, t + T, ...: it skips ahead to its next NON-ZERO window and the wave does one mixed Jacobian +
+//            affine addition with the tabulated point — no doublings, one addition per W slots, no zero work in lock
+//            step; an LDS tree adds the partial sums; a second kernel normalises them, one thread per witness
+//            (Fermat inversion), and stores the affine points.
 // Arithmetic: 256-bit Montgomery, modulus passed at run time.  The per-slot doubling chains of the set-up use the textbook
 // CIOS on eight 32-bit limbs; the table, commit and normalise kernels use nine 29-bit limbs (radix 2^261, lazy reduction: see the
 // F9 section below), in which a limb product is a single v_mad_u64_u32.  Complete handling of the exceptional cases
@@ -665,46 +666,84 @@ __global__ __launch_bounds__(64) void b3w_commit_window_kernel(const uint32_t *_
   }
 }
 
-// ---- commit: one workgroup per witness
+// ---- commit: T lanes per witness.
+//   phase 1  the lanes stream the body once (coalesced, 32 bytes per lane and step) and assemble the witness's
+//            virtual-slot bits as one bit string in LDS (bit v = virtual slot v; 6.7 KB for the compression circuit);
+//            the domain check lives here, where every word of an element is at hand anyway.  This phase waits on HBM,
+//            the next one on the ALU: waves of different workgroups in different phases share a SIMD and overlap.
+//            (Gathering the bits window by window — 12-16 dependent scattered loads each — cost 43 % of the kernel;
+//            as a separate streaming kernel in front, 30 %.)
+//   phase 2  lane t adds the tabulated points of the witness's non-zero windows t, t + T, ...
+//   phase 3  LDS tree over the T partial sums (in the bit string's place).
 template <int T, int WPB, int W, class CV>        // threads per witness, witnesses per workgroup (T * WPB threads), window width, field
 __global__ __launch_bounds__(T * WPB) __attribute__((amdgpu_waves_per_eu(3, 3))) void b3w_commit_kernel(const uint8_t *__restrict__ bodies, uint32_t n, uint64_t pitch,
-                                                         const uint32_t *__restrict__ vslots /* W per window: slot | bit << 19 | single << 27 | width words << 28 */,
+                                                         uint32_t first_slot, uint32_t nslots,
+                                                         const uint32_t *__restrict__ slotdesc /* per committed slot: first virtual slot | width code << 24 */,
+                                                         uint32_t region_words /* LDS words per witness: max(bit string, 27 T) */,
                                                          const uint32_t *__restrict__ table /* radix 2^261 */, uint32_t nwin,
                                                          uint32_t *__restrict__ sums /* n x B3W_COMMIT_SUM_WORDS: X Y Z in 29-bit limbs */,
                                                          int32_t *__restrict__ status, CV C) {
-  __shared__ uint32_t red[T * WPB * 27];
+  extern __shared__ uint32_t lds[];
   __shared__ uint32_t bad[WPB];
   const uint32_t sub = threadIdx.x / T, t = threadIdx.x % T;       // which witness of the workgroup, lane within it
   const uint32_t w = blockIdx.x * WPB + sub;
   const bool live = w < n;
+  uint32_t *packed = lds + sub * region_words;
+  for (uint32_t i = t; i < region_words; i += T) packed[i] = 0;
   if (t == 0) bad[sub] = 0;
   __syncthreads();
-  const uint32_t *body = reinterpret_cast<const uint32_t *>(bodies + (uint64_t)(live ? w : 0) * pitch);
+  {
+    const uint4 *body = reinterpret_cast<const uint4 *>(bodies + (uint64_t)(live ? w : 0) * pitch) + (uint64_t)first_slot * 2;
+    auto put32 = [&](uint32_t v, uint32_t x) {
+      if (!x) return;
+      atomicOr(&packed[v >> 5], x << (v & 31));
+      if (v & 31) atomicOr(&packed[(v >> 5) + 1], x >> (32 - (v & 31)));
+    };
+    const uint64_t mine = T == 64 ? ~0ull : (threadIdx.x & 32) ? 0xFFFFFFFF00000000ull : 0x00000000FFFFFFFFull;   // my witness's lanes of the wave
+    bool wrong = false;
+    constexpr int U = 8;                                        // steps in flight: 8 x (32 + 4) bytes per lane
+#pragma unroll 1
+    for (uint32_t s0 = 0; s0 < nslots; s0 += T * U) {
+      uint4 a[U], b[U];
+      uint32_t d[U];
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const uint32_t sl = s0 + u * T + t;
+        a[u] = make_uint4(0, 0, 0, 0); b[u] = a[u]; d[u] = 0xFFFFFFFFu;          // code 255: not a slot
+        if (live && sl < nslots) { a[u] = body[(uint64_t)sl * 2]; b[u] = body[(uint64_t)sl * 2 + 1]; d[u] = slotdesc[sl]; }
+      }
+#pragma unroll
+      for (int u = 0; u < U; ++u) {
+        const uint32_t v0 = d[u] & 0xFFFFFFu, code = d[u] >> 24, hi = b[u].x | b[u].y | b[u].z | b[u].w;
+        const uint32_t vbase = __shfl(v0, 0, T);
+        const uint64_t run = __ballot(code == 0 && v0 == vbase + t), ones = __ballot(a[u].x & 1);
+        if ((run & mine) == mine) {                             // T consecutive bit slots: one ballot
+          wrong |= a[u].x > 1 || (a[u].y | a[u].z | a[u].w | hi);
+          if (t == 0) {
+            const uint64_t mk = T == 64 ? ones : (threadIdx.x & 32) ? ones >> 32 : ones & 0xFFFFFFFFull;
+            put32(vbase, (uint32_t)mk);
+            if (T == 64) put32(vbase + 32, (uint32_t)(mk >> 32));
+          }
+        } else if (code == 0) { wrong |= a[u].x > 1 || (a[u].y | a[u].z | a[u].w | hi); put32(v0, a[u].x & 1); }
+        else if (code == 1) { wrong |= (a[u].y | a[u].z | a[u].w | hi) != 0; put32(v0, a[u].x); }
+        else if (code == 2) { wrong |= (a[u].z | a[u].w | hi) != 0; put32(v0, a[u].x); put32(v0 + 32, a[u].y); }
+        else if (code == 3) { put32(v0, a[u].x); put32(v0 + 32, a[u].y); put32(v0 + 64, a[u].z); put32(v0 + 96, a[u].w);
+                              put32(v0 + 128, b[u].x); put32(v0 + 160, b[u].y); put32(v0 + 192, b[u].z); put32(v0 + 224, b[u].w); }
+      }
+    }
+    if (wrong) bad[sub] = 1;
+  }
+  __syncthreads();
   J9 acc = j9_infinity();
   uint32_t win = live ? t : nwin;
   while (true) {
-    // skip ahead to this lane's next window with a set bit (four virtual slots at a time: short live ranges)
+    // skip ahead to this lane's next window with a set bit
     uint32_t m = 0;
     while (win < nwin) {
-#pragma unroll
-      for (int j = 0; j < W; j += 4) {
-        const uint4 q = *reinterpret_cast<const uint4 *>(vslots + (uint64_t)win * W + j);
-        const uint32_t e[4] = {q.x, q.y, q.z, q.w};
-        uint32_t word[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) word[i] = body[(uint64_t)(e[i] & 0x7FFFFu) * 8 + (((e[i] >> 19) & 0xFFu) >> 5)];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-          if (((e[i] >> 27) & 1u) && word[i] > 1) bad[sub] = 1;   // a bit slot must hold 0 or 1
-          const uint32_t words = e[i] >> 28;                 // on the first virtual slot of a 32- or 64-bit slot: its width in words
-          if (words) {                                       // (rare: 1.4 % of the virtual slots) the rest of the element must be 0
-            const uint32_t *el = body + (uint64_t)(e[i] & 0x7FFFFu) * 8;
-            uint32_t rest = 0;
-            for (uint32_t k = words; k < 8; ++k) rest |= el[k];
-            if (rest) bad[sub] = 1;
-          }
-          m |= ((word[i] >> ((e[i] >> 19) & 31u)) & 1u) << (j + i);
-        }
+      if (W == 16) m = (packed[win >> 1] >> ((win & 1) * 16)) & 0xFFFFu;
+      else {
+        const uint32_t bit = win * W;
+        m = (uint32_t)(((((uint64_t)packed[(bit >> 5) + 1]) << 32 | packed[bit >> 5]) >> (bit & 31)) & ((1u << W) - 1u));
       }
       if (m) break;
       win += T;
@@ -719,8 +758,9 @@ __global__ __launch_bounds__(T * WPB) __attribute__((amdgpu_waves_per_eu(3, 3)))
       win += T;
     }
   }
+  __syncthreads();                                           // every lane is done with the bit string: the tree takes its place
   // LDS tree over each witness's T partial sums (infinity travels as Z = 0)
-  uint32_t *mine = red + (sub * T + t) * 27;
+  uint32_t *mine = packed + t * 27;
   auto put = [&](const J9 &a) {
 #pragma unroll
     for (int i = 0; i < 9; ++i) { mine[i] = a.X.l[i]; mine[9 + i] = a.Y.l[i]; mine[18 + i] = a.inf ? 0u : a.Z.l[i]; }
@@ -739,7 +779,7 @@ __global__ __launch_bounds__(T * WPB) __attribute__((amdgpu_waves_per_eu(3, 3)))
     if (t < st) { J9 a = get(mine); j9_add(a, get(mine + st * 27), C); put(a); }
     __syncthreads();
   }
-  if (live && t < 27) sums[(uint64_t)w * B3W_COMMIT_SUM_WORDS + t] = red[sub * T * 27 + t];   // normalised by the next kernel
+  if (live && t < 27) sums[(uint64_t)w * B3W_COMMIT_SUM_WORDS + t] = packed[t];   // normalised by the next kernel
   if (live && t == 0 && status) status[w] = bad[sub] ? 103 : 0;
 }
 
@@ -841,11 +881,14 @@ extern "C" int b3w_launch_commit_windows(const uint32_t *d_points, uint32_t nwin
   return (int)hipGetLastError();
 }
 
-extern "C" int b3w_launch_commit(const uint8_t *d_bodies, uint32_t n, uint64_t pitch, const uint32_t *d_vslots, const uint32_t *d_table,
-                                 uint32_t nwin, uint32_t window, uint32_t *d_sums /* n * B3W_COMMIT_SUM_WORDS scratch */, uint8_t *d_out,
-                                 int32_t *d_status, const B3wCurve *curve, hipStream_t stream) {
+extern "C" int b3w_launch_commit(const uint8_t *d_bodies, uint32_t n, uint64_t pitch, uint32_t first_slot, uint32_t nslots,
+                                 const uint32_t *d_slotdesc, const uint32_t *d_table, uint32_t nwin, uint32_t window,
+                                 uint32_t *d_sums /* n * B3W_COMMIT_SUM_WORDS scratch */, uint8_t *d_out, int32_t *d_status,
+                                 const B3wCurve *curve, hipStream_t stream) {
   if (!n) return 0;
   if (window != B3W_COMMIT_WINDOW_SMALL && window != B3W_COMMIT_WINDOW_LARGE) return (int)hipErrorInvalidValue;
+  const uint32_t bits_words = (nwin * window + 31) / 32 + 2;   // one packed witness in LDS (nova O1: 13.5 KB)
+  if (bits_words * 4 > 32 * 1024) return (int)hipErrorInvalidValue;
   const B3wCurve9 c9 = make_curve9(*curve);
   // lanes per witness: 32 (two witnesses per wave) for the compression circuit, 64 for the longer nova witnesses (measured
   // at both window widths).  Virtual slots: 53 k compression, 58 k nova O2, 108 k nova O1.
@@ -857,16 +900,19 @@ extern "C" int b3w_launch_commit(const uint8_t *d_bodies, uint32_t n, uint64_t p
   B3wCurve9Vesta c9v;
   static_cast<B3wCurve9 &>(c9v) = c9;
 #define B3W_COMMIT_LAUNCH(T, WPB, W, CV, cv)                                                                              \
-  hipLaunchKernelGGL((b3w_commit_kernel<T, WPB, W, CV>), dim3((n + WPB - 1) / WPB), dim3(T * WPB), 0, stream, d_bodies, n, pitch, \
-                     d_vslots, d_table, nwin, d_sums, d_status, cv)
+  {                                                                                                                       \
+    const uint32_t region = bits_words > 27u * T ? bits_words : 27u * T;                                                  \
+    hipLaunchKernelGGL((b3w_commit_kernel<T, WPB, W, CV>), dim3((n + WPB - 1) / WPB), dim3(T * WPB), region * WPB * 4, stream, d_bodies, n, \
+                       pitch, first_slot, nslots, d_slotdesc, region, d_table, nwin, d_sums, d_status, cv);               \
+  }
   if (window == B3W_COMMIT_WINDOW_LARGE) {
-    if (vesta) B3W_COMMIT_LAUNCH(64, 1, B3W_COMMIT_WINDOW_LARGE, B3wCurve9Vesta, c9v);
-    else if (tpw == 64) B3W_COMMIT_LAUNCH(64, 1, B3W_COMMIT_WINDOW_LARGE, B3wCurve9, c9);
-    else B3W_COMMIT_LAUNCH(32, 2, B3W_COMMIT_WINDOW_LARGE, B3wCurve9, c9);
+    if (vesta) B3W_COMMIT_LAUNCH(64, 1, B3W_COMMIT_WINDOW_LARGE, B3wCurve9Vesta, c9v)
+    else if (tpw == 64) B3W_COMMIT_LAUNCH(64, 1, B3W_COMMIT_WINDOW_LARGE, B3wCurve9, c9)
+    else B3W_COMMIT_LAUNCH(32, 2, B3W_COMMIT_WINDOW_LARGE, B3wCurve9, c9)
   } else {
-    if (vesta) B3W_COMMIT_LAUNCH(64, 1, B3W_COMMIT_WINDOW_SMALL, B3wCurve9Vesta, c9v);
-    else if (tpw == 64) B3W_COMMIT_LAUNCH(64, 1, B3W_COMMIT_WINDOW_SMALL, B3wCurve9, c9);
-    else B3W_COMMIT_LAUNCH(32, 2, B3W_COMMIT_WINDOW_SMALL, B3wCurve9, c9);
+    if (vesta) B3W_COMMIT_LAUNCH(64, 1, B3W_COMMIT_WINDOW_SMALL, B3wCurve9Vesta, c9v)
+    else if (tpw == 64) B3W_COMMIT_LAUNCH(64, 1, B3W_COMMIT_WINDOW_SMALL, B3wCurve9, c9)
+    else B3W_COMMIT_LAUNCH(32, 2, B3W_COMMIT_WINDOW_SMALL, B3wCurve9, c9)
   }
 #undef B3W_COMMIT_LAUNCH
   if (vesta) hipLaunchKernelGGL(b3w_commit_normalize_kernel<B3wCurve9Vesta>, dim3((n + 63) / 64), dim3(64), 0, stream, d_sums, n, d_out, *curve, c9v);

@@ -54,5 +54,7 @@ struct B3wCurve {
 extern "C" int b3w_launch_commit_setup(const uint32_t *d_gens, const uint32_t *d_first_v, const uint32_t *d_nbits, uint32_t nslots,
                                        uint32_t *d_points, const B3wCurve *curve, hipStream_t stream);
 extern "C" int b3w_launch_commit_windows(const uint32_t *d_points, uint32_t nwin, uint32_t window, uint32_t *d_table, const B3wCurve *curve, hipStream_t stream);
-extern "C" int b3w_launch_commit(const uint8_t *d_bodies, uint32_t n, uint64_t pitch, const uint32_t *d_vslots, const uint32_t *d_table,
-                                 uint32_t nwin, uint32_t window, uint32_t *d_sums, uint8_t *d_out, int32_t *d_status, const B3wCurve *curve, hipStream_t stream);
+extern "C" int b3w_launch_commit(const uint8_t *d_bodies, uint32_t n, uint64_t pitch, uint32_t first_slot, uint32_t nslots,
+                                 const uint32_t *d_slotdesc /* first virtual slot | width code (0 bit, 1 32, 2 64, 3 256) << 24 */,
+                                 const uint32_t *d_table, uint32_t nwin, uint32_t window, uint32_t *d_sums, uint8_t *d_out,
+                                 int32_t *d_status, const B3wCurve *curve, hipStream_t stream);
