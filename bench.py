@@ -54,8 +54,8 @@ def bench_chain(args, m, torch, dist, dev, world, rank, local_rank):
     nbytes = int(args.preimage_mib * (1 << 20))
     lcg_words = (np.arange(nbytes // 4 + 1, dtype=np.uint64) * np.uint64(2654435761) + np.uint64(12345)) & np.uint64(0xFFFFFFFF)
     host = torch.from_numpy(lcg_words.astype(np.uint32).view(np.uint8)[:nbytes].copy()).pin_memory()
-    consumer, key = None, None
-    if args.consumer == "commit":                      # what the folding prover does with each step witness
+    consumer, key, commit_only = None, None, None
+    if args.consumer != "none":                      # what the folding prover does with each step witness
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import ec_ref as E                             # plain-integer curve arithmetic: here only to make valid generators
         curve = "vesta" if "vesta" in circuit else "bn254_g1"
@@ -67,7 +67,10 @@ def bench_chain(args, m, torch, dist, dev, world, rank, local_rank):
         def consumer(view, first, k):
             key.commit_device(view.data_ptr(), k, view.stride(0), d_pts.data_ptr() + 64 * first, d_st.data_ptr() + 4 * first,
                               torch.cuda.current_stream().cuda_stream)
-    run = lambda: m.chain.fold_witnesses(ctx, host, batch_steps=args.batch if args.batch != 4096 else 16384, ring=2, consumer=consumer)
+        if args.consumer == "commit-only":
+            consumer, commit_only = None, (key, d_pts)
+    run = lambda: m.chain.fold_witnesses(ctx, host, batch_steps=args.batch if args.batch != 4096 else 16384, ring=2, consumer=consumer,
+                                         commit_only=commit_only)
     for _ in range(max(3, args.warmup)):        # the first passes pay the allocator (24 GB ring, record buffers)
         out = run()
     torch.cuda.synchronize()
@@ -94,7 +97,7 @@ def bench_chain(args, m, torch, dist, dev, world, rank, local_rank):
     else:
         total_steps = float(local_steps)
     if rank == 0:
-        per = BYTES_PER_WITNESS[circuit]
+        per = BYTES_PER_WITNESS[circuit] if commit_only is None else 128      # commit-only reads the 128-byte step records
         print(json.dumps({
             "metric": "BLAKE3-compression witnesses/sec", "value": total_steps * args.steps / elapsed, "unit": "witnesses/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
@@ -103,7 +106,8 @@ def bench_chain(args, m, torch, dist, dev, world, rank, local_rank):
                                    "planner + witness kernels, bodies through a 2-deep ring, H2D overlapped",
                        "circuit": circuit, "n_chunks": out["n_chunks"], "path_len": out["path_len"],
                        "placement": out.get("placement"),
-                       "consumer": "none" if key is None else f"Pedersen commitment of every step witness on the device ({key.window}-bit windows)"},
+                       "consumer": "none" if key is None else f"Pedersen commitment of every step witness on the device ({key.window}-bit windows)"
+                                   + (", from the step records: no bodies written" if commit_only is not None else "")},
             "roofline": {"bound": "hbm", "achieved": total_steps * args.steps * per / elapsed / 1e9 / world, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": total_steps * args.steps * per / elapsed / 1e9 / world / HBM_PEAK_GBS,
                          "traffic": None, "note": "end-to-end per-GPU rate incl. planner, H2D and launch gaps"},
@@ -128,9 +132,10 @@ def main():
                     help="batch = BASELINE config 2/3 (default, the headline metric); chain = configs 4/5: "
                          "preimage -> planner -> nova step witnesses, streamed through a ring of buffers")
     ap.add_argument("--preimage-mib", type=float, default=1.0, help="chain workload: preimage size (1 = config 4, 1024 = config 5)")
-    ap.add_argument("--consumer", default="none", choices=["none", "commit"],
+    ap.add_argument("--consumer", default="none", choices=["none", "commit", "commit-only"],
                     help="chain workload: what reads each batch of step witnesses while it sits in the ring "
-                         "(commit = Pedersen commitments on the circuit's curve, synthetic generators)")
+                         "(commit = Pedersen commitments on the circuit's curve, synthetic generators; commit-only = the same "
+                         "commitments straight from the step records, no bodies written)")
     args = ap.parse_args()
 
     import numpy as np

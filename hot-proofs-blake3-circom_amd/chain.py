@@ -47,10 +47,12 @@ _CONSUMER = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_ui
 
 
 def fold_witnesses(ctx, preimage, batch_steps=16384, ring=2, slice_chunks=1024, with_parents=True, consumer=None,
-                   device=None):
+                   device=None, commit_only=None):
     """preimage: 1-D uint8 numpy array / torch CPU tensor (the whole preimage; every rank passes the same).
     consumer(bodies_view [k, body_bytes] uint8 CUDA, first_local_step, k): called after each batch is enqueued;
     it must enqueue its work on the current stream (the view is overwritten `ring` batches later).
+    commit_only=(CommitKey, d_points): no bodies at all — one commitment per step, computed from the step records
+    (b3w_chain_commit_only), into the caller's [n_steps, 64] uint8 CUDA tensor.
     Returns dict(public=[n_local_steps, 15] int32 CUDA, status=[n_local_steps] int32 CUDA, root=[8] int32,
     n_leaf_steps, n_parent_steps, first_chunk, n_chunks_local, n_chunks).  The device arrays belong to a b3w_chain
     object cached on `ctx` and are overwritten by the next fold of the same shape.
@@ -83,6 +85,10 @@ def fold_witnesses(ctx, preimage, batch_steps=16384, ring=2, slice_chunks=1024, 
     nleaf, npar, nch, P, pl = ctypes.c_uint64(), ctypes.c_uint64(), ctypes.c_uint64(), ctypes.c_uint32(), ctypes.c_int32()
     L.b3w_chain_info(h, ctypes.byref(nleaf), ctypes.byref(npar), ctypes.byref(nch), ctypes.byref(P), ctypes.byref(pl))
     n_leaf, n_par = nleaf.value, npar.value
+    if commit_only is not None:
+        _chk(ctx, L.b3w_chain_commit_only(h, commit_only[0].handle, commit_only[1].data_ptr()), "b3w_chain_commit_only")
+    else:
+        _chk(ctx, L.b3w_chain_commit_only(h, None, None), "b3w_chain_commit_only")
     compute = torch.cuda.current_stream(dev)
     nbatch = [0]
     cb = _CONSUMER()

@@ -873,6 +873,8 @@ struct b3w_commit_key {
   uint32_t first_slot = 0, nwin = 0, window = 0;
   uint32_t nslots = 0;                                // committed slots: first_slot .. witness_size - 1
   uint32_t *d_slotdesc = nullptr;                     // per committed slot: first virtual slot (= its bit in the packed witness) | width code << 24
+  uint32_t *d_runs = nullptr; uint32_t nruns = 0;     // the same bit string as pieces of TRACE-image words (records mode)
+  uint32_t *d_images = nullptr; uint32_t images_cap = 0;   // records mode: TRACE images of one chunk, word-major, grown on demand
   uint32_t *d_table = nullptr;                        // per window of `window` virtual slots: 2^window - 1 subset sums
   uint32_t *d_sums = nullptr;                         // Jacobian sums between the two kernels, grown on demand
   uint32_t sums_cap = 0;
@@ -964,6 +966,31 @@ int32_t b3w_commit_key_create_ex(b3w_ctx *ctx, int32_t curve, uint32_t first_slo
   uint32_t *d_gens = nullptr, *d_first = nullptr, *d_nbits = nullptr, *d_points = nullptr;
   std::vector<uint32_t> desc(nslots);
   for (uint32_t i = 0; i < nslots; i++) desc[i] = first_v[i] | (nbits[i] == 1 ? 0u : nbits[i] == 32 ? 1u : nbits[i] == 64 ? 2u : 3u) << 24;
+  // records mode: slot s holds (image[src] >> sh) & mask (b3w_kernels.hip emit_group), so a run of bit slots reading
+  // consecutive bits of one image word is one contiguous piece of the bit string
+  std::vector<uint32_t> runs;
+  for (uint32_t i = 0; i < nslots; i++) {
+    const uint32_t ent = table[first_slot + i], src = ent & 0xFFFu, sh = (ent >> 12) & 31u, v0 = first_v[i];
+    if (nbits[i] == 1) {
+      if (!runs.empty()) {
+        const uint32_t a = runs[runs.size() - 2], b = runs[runs.size() - 1];
+        const uint32_t plen = (a >> 24) + 1, pv = a & 0xFFFFFFu, psrc = b & 0xFFFFu, psh = b >> 16;
+        if ((a >> 31) == 0 && psrc == src && psh + plen == sh && pv + plen == v0 && plen < 32 && i > 0 && nbits[i - 1] == 1) {
+          runs[runs.size() - 2] = pv | plen << 24;               // one bit longer
+          continue;
+        }
+      }
+      runs.push_back(v0 | 0u << 24); runs.push_back(src | sh << 16);
+    } else {
+      const uint32_t words = nbits[i] / 32;                     // 1, 2 or 8 image words; the shift applies to words 0 and 4
+      for (uint32_t k = 0; k < words; k++) {
+        runs.push_back((v0 + 32 * k) | 31u << 24); runs.push_back((src + k) | ((k == 0 || k == 4) ? sh : 0u) << 16);
+      }
+    }
+  }
+  key->nruns = (uint32_t)(runs.size() / 2);
+  if (e == hipSuccess) e = hipMalloc((void **)&key->d_runs, runs.size() * 4);
+  if (e == hipSuccess) e = hipMemcpy(key->d_runs, runs.data(), runs.size() * 4, hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMalloc((void **)&key->d_slotdesc, (size_t)nslots * 4);
   if (e == hipSuccess) e = hipMemcpy(key->d_slotdesc, desc.data(), (size_t)nslots * 4, hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipMalloc((void **)&key->d_table, (size_t)key->nwin * B3W_COMMIT_ENTRIES(window) * 64);
@@ -995,6 +1022,8 @@ int32_t b3w_commit_key_create_ex(b3w_ctx *ctx, int32_t curve, uint32_t first_slo
 void b3w_commit_key_destroy(b3w_commit_key *key) {
   if (!key) return;
   if (key->d_slotdesc) (void)hipFree(key->d_slotdesc);
+  if (key->d_runs) (void)hipFree(key->d_runs);
+  if (key->d_images) (void)hipFree(key->d_images);
   if (key->d_table) (void)hipFree(key->d_table);
   if (key->d_sums) (void)hipFree(key->d_sums);
   delete key;
@@ -1018,9 +1047,51 @@ int32_t b3w_batch_commit_device(b3w_ctx *ctx, const b3w_commit_key *key, const u
     HIP_TRY(ctx, hipMalloc((void **)&k->d_sums, (size_t)n * B3W_COMMIT_SUM_WORDS * 4));
     k->sums_cap = n;
   }
-  const int rc = b3w_launch_commit(d_bodies, n, pitch, key->first_slot, key->nslots, key->d_slotdesc, key->d_table, key->nwin, key->window,
-                                   k->d_sums, d_points, d_status, &key->curve, (hipStream_t)stream);
+  const int rc = b3w_launch_commit(d_bodies, n, pitch, key->first_slot, key->nslots, key->d_slotdesc, nullptr, 0, nullptr, 0, key->d_table,
+                                   key->nwin, key->window, k->d_sums, d_points, d_status, &key->curve, (hipStream_t)stream);
   return rc ? hip_fail(ctx, (hipError_t)rc, "commit launch") : B3W_OK;
+}
+
+int32_t b3w_commit_records_device(b3w_ctx *ctx, const b3w_commit_key *key, const uint32_t *d_records, uint32_t n, uint8_t *d_points,
+                                  uint32_t *d_public, int32_t *d_status, void *stream) {
+  if (!ctx || !key || key->ctx != ctx || !d_records || !d_points || !d_status) return B3W_E_BAD_ARGUMENT;
+  if (n == 0) return B3W_OK;
+  if ((reinterpret_cast<uintptr_t>(d_points) & 15) || (reinterpret_cast<uintptr_t>(d_records) & 3)) {
+    ctx->last_error = "records 4-byte and points 16-byte aligned";
+    return B3W_E_BAD_ARGUMENT;
+  }
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  b3w_commit_key *k = const_cast<b3w_commit_key *>(key);                     // scratch only
+  constexpr uint32_t CHUNK = 32768;                                          // witnesses per TRACE + commit pair (images: 3.7-11 KB each)
+  const uint32_t want = std::min(n, CHUNK);
+  if (k->images_cap < want || k->sums_cap < want) {
+    HIP_TRY(ctx, hipStreamSynchronize((hipStream_t)stream));
+    if (k->sums_cap < want) {
+      if (k->d_sums) (void)hipFree(k->d_sums);
+      k->d_sums = nullptr; k->sums_cap = 0;
+      HIP_TRY(ctx, hipMalloc((void **)&k->d_sums, (size_t)want * B3W_COMMIT_SUM_WORDS * 4));
+      k->sums_cap = want;
+    }
+    if (k->images_cap < want) {
+      if (k->d_images) (void)hipFree(k->d_images);
+      k->d_images = nullptr; k->images_cap = 0;
+      HIP_TRY(ctx, hipMalloc((void **)&k->d_images, (size_t)want * ctx->desc.lds_words * 4));
+      k->images_cap = want;
+    }
+  }
+  const uint32_t cap = k->images_cap;
+  const uint32_t rw = ctx->desc.nin, pw = ctx->desc.npub;
+  for (uint32_t c0 = 0; c0 < n; c0 += cap) {                                 // the TRACE images of one chunk at a time
+    const uint32_t cn = std::min(cap, n - c0);
+    int lrc = b3w_launch_trace(ctx->desc.kind, d_records + (uint64_t)c0 * rw, cn, k->d_images, cap, ctx->d_table, ctx->desc.nwit,
+                               d_public ? d_public + (uint64_t)c0 * pw : nullptr, d_status + c0, ctx->d_aux, (hipStream_t)stream);
+    if (lrc == 0)
+      lrc = b3w_launch_commit(nullptr, cn, 0, key->first_slot, key->nslots, key->d_slotdesc, k->d_images, cap, key->d_runs, key->nruns,
+                              key->d_table, key->nwin, key->window, k->d_sums, d_points + (uint64_t)c0 * 64, nullptr, &key->curve,
+                              (hipStream_t)stream);
+    if (lrc) return hip_fail(ctx, (hipError_t)lrc, "commit-from-records launch");
+  }
+  return B3W_OK;
 }
 
 void b3w_commit_consumer(void *user, const uint8_t *d_bodies, uint64_t pitch, uint64_t first_step, uint32_t count, void *stream) {
@@ -1155,6 +1226,8 @@ struct b3w_chain {
   hipStream_t copy = nullptr, side = nullptr;        // H2D slices; tree + parent planning beside the leaf witness kernels
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   hipEvent_t ev_cvs = nullptr, ev_par = nullptr;     // chunk CVs complete (main stream); parent records ready (side stream)
+  const b3w_commit_key *co_key = nullptr;            // commitments only: no bodies, one point per step into co_points
+  uint8_t *co_points = nullptr;
 };
 
 namespace {
@@ -1166,6 +1239,14 @@ int32_t chain_run_steps(b3w_chain *c, uint64_t first_row, uint64_t count, b3w_ba
     const uint32_t k = (uint32_t)std::min<uint64_t>(c->batch_steps, count - done);
     uint8_t *slot = static_cast<uint8_t *>(c->bodies[c->nbatch % c->ring]);
     const uint64_t r0 = first_row + done;
+    if (c->co_key) {
+      const int32_t rc = b3w_commit_records_device(c->ctx, c->co_key, c->d_recs + r0 * 32, k, c->co_points + r0 * 64, c->d_pub + r0 * 15,
+                                                   c->d_status + r0, stream);
+      if (rc) return rc;
+      c->nbatch++;
+      done += k;
+      continue;
+    }
     int32_t rc = b3w_batch_run_device(c->ctx, c->d_recs + r0 * 32, k, slot, body, c->d_pub + r0 * 15, c->d_status + r0, stream);
     if (rc) return rc;
     if (consumer) consumer(user, slot, body, r0, k, stream);
@@ -1177,6 +1258,13 @@ int32_t chain_run_steps(b3w_chain *c, uint64_t first_row, uint64_t count, b3w_ba
 }  // namespace
 
 extern "C" {
+
+int32_t b3w_chain_commit_only(b3w_chain *c, const b3w_commit_key *key, uint8_t *d_points) {
+  if (!c || (key && (!d_points || key->ctx != c->ctx))) return B3W_E_BAD_ARGUMENT;
+  c->co_key = key;
+  c->co_points = key ? d_points : nullptr;
+  return B3W_OK;
+}
 
 int32_t b3w_chain_create(b3w_ctx *ctx, uint64_t preimage_len, uint64_t first_chunk, uint32_t n_chunks_local, uint32_t batch_steps,
                          uint32_t ring, int32_t with_parents, b3w_chain **out) {

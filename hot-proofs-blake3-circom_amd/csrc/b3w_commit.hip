@@ -28,6 +28,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include "b3w_kernels.h"
+#include "b3w_atoms.h"
 
 namespace {
 
@@ -679,6 +680,8 @@ template <int T, int WPB, int W, class CV>        // threads per witness, witnes
 __global__ __launch_bounds__(T * WPB) __attribute__((amdgpu_waves_per_eu(3, 3))) void b3w_commit_kernel(const uint8_t *__restrict__ bodies, uint32_t n, uint64_t pitch,
                                                          uint32_t first_slot, uint32_t nslots,
                                                          const uint32_t *__restrict__ slotdesc /* per committed slot: first virtual slot | width code << 24 */,
+                                                         const uint32_t *__restrict__ images /* or null: TRACE images, word j of witness w at [j * img_row + w] */,
+                                                         uint32_t img_row, const uint2 *__restrict__ runs, uint32_t nruns,
                                                          uint32_t region_words /* LDS words per witness: max(bit string, 27 T) */,
                                                          const uint32_t *__restrict__ table /* radix 2^261 */, uint32_t nwin,
                                                          uint32_t *__restrict__ sums /* n x B3W_COMMIT_SUM_WORDS: X Y Z in 29-bit limbs */,
@@ -692,7 +695,22 @@ __global__ __launch_bounds__(T * WPB) __attribute__((amdgpu_waves_per_eu(3, 3)))
   for (uint32_t i = t; i < region_words; i += T) packed[i] = 0;
   if (t == 0) bad[sub] = 0;
   __syncthreads();
-  {
+  if (images) {
+    // records mode: the witness is an expansion of its TRACE image (3.7-11 KB) through the slot table, so its bits are
+    // pieces of image words: run r = `len` bits of image word `src` from bit `sh` on, at bit v0 of the bit string
+    const uint32_t *img = images + (live ? w : 0);
+    const bool ok = live && img[(uint64_t)B3W_LDS_OKWORD * img_row] != 0;              // a rejected step leaves the string empty
+    for (uint32_t r = t; r < nruns; r += T) {
+      const uint2 e = runs[r];
+      const uint32_t len = (e.x >> 24) + 1u, x = ok ? img[(uint64_t)(e.y & 0xFFFFu) * img_row] >> (e.y >> 16) : 0u;
+      const uint32_t piece = len == 32 ? x : x & ((1u << len) - 1u);
+      if (piece) {
+        const uint32_t v = e.x & 0xFFFFFFu;
+        atomicOr(&packed[v >> 5], piece << (v & 31));
+        if (v & 31) atomicOr(&packed[(v >> 5) + 1], piece >> (32 - (v & 31)));
+      }
+    }
+  } else {
     const uint4 *body = reinterpret_cast<const uint4 *>(bodies + (uint64_t)(live ? w : 0) * pitch) + (uint64_t)first_slot * 2;
     auto put32 = [&](uint32_t v, uint32_t x) {
       if (!x) return;
@@ -882,7 +900,8 @@ extern "C" int b3w_launch_commit_windows(const uint32_t *d_points, uint32_t nwin
 }
 
 extern "C" int b3w_launch_commit(const uint8_t *d_bodies, uint32_t n, uint64_t pitch, uint32_t first_slot, uint32_t nslots,
-                                 const uint32_t *d_slotdesc, const uint32_t *d_table, uint32_t nwin, uint32_t window,
+                                 const uint32_t *d_slotdesc, const uint32_t *d_images /* or null */, uint32_t img_row, const uint32_t *d_runs,
+                                 uint32_t nruns, const uint32_t *d_table, uint32_t nwin, uint32_t window,
                                  uint32_t *d_sums /* n * B3W_COMMIT_SUM_WORDS scratch */, uint8_t *d_out, int32_t *d_status,
                                  const B3wCurve *curve, hipStream_t stream) {
   if (!n) return 0;
@@ -903,7 +922,8 @@ extern "C" int b3w_launch_commit(const uint8_t *d_bodies, uint32_t n, uint64_t p
   {                                                                                                                       \
     const uint32_t region = bits_words > 27u * T ? bits_words : 27u * T;                                                  \
     hipLaunchKernelGGL((b3w_commit_kernel<T, WPB, W, CV>), dim3((n + WPB - 1) / WPB), dim3(T * WPB), region * WPB * 4, stream, d_bodies, n, \
-                       pitch, first_slot, nslots, d_slotdesc, region, d_table, nwin, d_sums, d_status, cv);               \
+                       pitch, first_slot, nslots, d_slotdesc, d_images, img_row, reinterpret_cast<const uint2 *>(d_runs), nruns, region, d_table, nwin, \
+                       d_sums, d_status, cv);                                                                             \
   }
   if (window == B3W_COMMIT_WINDOW_LARGE) {
     if (vesta) B3W_COMMIT_LAUNCH(64, 1, B3W_COMMIT_WINDOW_LARGE, B3wCurve9Vesta, c9v)

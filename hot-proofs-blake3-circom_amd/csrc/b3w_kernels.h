@@ -27,6 +27,8 @@ extern "C" int b3w_launch_plan_merge(const uint32_t *d_left, const uint32_t *d_r
 extern "C" int b3w_launch_plan_parents(const uint32_t *d_levels, uint64_t nchunks, uint32_t P, uint64_t first_chunk,
                                        uint32_t nlocal, uint32_t last_chunk_blocks, uint32_t *d_recs, hipStream_t stream);
 
+extern "C" int b3w_launch_trace(int kind, const uint32_t *d_recs, uint32_t cn, uint32_t *d_images, uint32_t row, const uint32_t *d_table,
+                                uint32_t nwit, uint32_t *d_pub, int32_t *d_status, const void *d_aux, hipStream_t stream);
 extern "C" int b3w_launch_verify(int kind, const uint32_t *d_in_slots, uint32_t n, const uint8_t *d_bodies, uint64_t pitch,
                                  const uint32_t *d_table, uint32_t nwit, uint32_t *d_mismatch, const void *d_aux,
                                  hipStream_t stream);
@@ -56,5 +58,7 @@ extern "C" int b3w_launch_commit_setup(const uint32_t *d_gens, const uint32_t *d
 extern "C" int b3w_launch_commit_windows(const uint32_t *d_points, uint32_t nwin, uint32_t window, uint32_t *d_table, const B3wCurve *curve, hipStream_t stream);
 extern "C" int b3w_launch_commit(const uint8_t *d_bodies, uint32_t n, uint64_t pitch, uint32_t first_slot, uint32_t nslots,
                                  const uint32_t *d_slotdesc /* first virtual slot | width code (0 bit, 1 32, 2 64, 3 256) << 24 */,
+                                 const uint32_t *d_images /* null: read the bodies; else TRACE images (b3w_launch_trace), bodies unused */,
+                                 uint32_t img_row, const uint32_t *d_runs /* pairs: v0 | (len - 1) << 24, image word | shift << 16 */, uint32_t nruns,
                                  const uint32_t *d_table, uint32_t nwin, uint32_t window, uint32_t *d_sums, uint8_t *d_out,
                                  int32_t *d_status, const B3wCurve *curve, hipStream_t stream);

@@ -880,6 +880,26 @@ extern "C" int b3w_launch_verify(int kind, const uint32_t *d_in_slots, uint32_t 
   return (int)hipGetLastError();
 }
 
+// TRACE kernel alone: the images of `cn` <= row witnesses go to d_images, word-major (word j of witness w at d_images[j * row + w];
+// row B3W_LDS_OKWORD = 1 for a valid witness), with the public outputs and the status words.  The first half of the
+// two-kernel path; also what the commitment consumer needs of a witness (b3w_commit.hip, records mode).
+extern "C" int b3w_launch_trace(int kind, const uint32_t *d_recs, uint32_t cn, uint32_t *d_images, uint32_t row, const uint32_t *d_table,
+                                uint32_t nwit, uint32_t *d_pub, int32_t *d_status, const void *d_aux, hipStream_t stream) {
+  if (cn == 0) return 0;
+  if (cn > row) return -4;
+  if (kind == B3W_KIND_COMP)
+    hipLaunchKernelGGL((b3w_compression_kernel<16, false, 1>), dim3((cn + 15) / 16), dim3(64), 0, stream, d_recs, cn,
+                       reinterpret_cast<uint8_t *>(d_images), (uint64_t)row, d_table, nwit, d_pub, d_status, 1u);
+  else if (kind == B3W_KIND_NOVA_O2)
+    hipLaunchKernelGGL((b3w_nova_kernel<B3W_KIND_NOVA_O2, 4, false, 1>), dim3((cn + 3) / 4), dim3(64), 0, stream, d_recs, cn,
+                       reinterpret_cast<uint8_t *>(d_images), (uint64_t)row, d_table, nwit, d_pub, d_status, (const uint32_t *)d_aux, 1u);
+  else if (kind == B3W_KIND_NOVA_O1)
+    hipLaunchKernelGGL((b3w_nova_kernel<B3W_KIND_NOVA_O1, 2, false, 1>), dim3((cn + 1) / 2), dim3(64), 0, stream, d_recs, cn,
+                       reinterpret_cast<uint8_t *>(d_images), (uint64_t)row, d_table, nwit, d_pub, d_status, (const uint32_t *)d_aux, 1u);
+  else return -2;
+  return (int)hipGetLastError();
+}
+
 extern "C" int b3w_launch_batch(int kind, int variant, const uint32_t *d_recs, uint32_t n, uint8_t *d_out,
                                 uint64_t pitch, const uint32_t *d_table, uint32_t nwit, uint32_t *d_pub,
                                 int32_t *d_status, const void *d_aux, uint32_t *d_scratch, uint32_t scratch_cap,
@@ -888,31 +908,18 @@ extern "C" int b3w_launch_batch(int kind, int variant, const uint32_t *d_recs, u
   if (variant >= B3W_VARIANT_SWEEP) {
     // TRACE kernel -> scratch, SWEEP kernel -> bodies, in chunks of scratch_cap witnesses
     if (!d_scratch || scratch_cap != (1u << B3W_SWEEP_LOGC)) return -4;
+    if (kind != B3W_KIND_COMP && !d_aux) return -3;
     uint32_t *d_images = d_scratch;                                        // word-major images
     for (uint32_t c0 = 0; c0 < n; c0 += scratch_cap) {
       const uint32_t cn = n - c0 < scratch_cap ? n - c0 : scratch_cap;
       uint32_t *pub_c = d_pub ? d_pub + (uint64_t)c0 * (kind == B3W_KIND_COMP ? 16 : 15) : nullptr;
       int32_t *st_c = d_status ? d_status + c0 : nullptr;
       uint8_t *out_c = d_out + (uint64_t)c0 * pitch;
-      int rc;
-      if (kind == B3W_KIND_COMP) {
-        const uint32_t *rc_recs = d_recs + (uint64_t)c0 * 28;
-        hipLaunchKernelGGL((b3w_compression_kernel<16, false, 1>), dim3((cn + 15) / 16), dim3(64), 0, stream, rc_recs,
-                           cn, reinterpret_cast<uint8_t *>(d_images), (uint64_t)scratch_cap, d_table, nwit, pub_c, st_c, 1u);
-        rc = launch_sweep<false, 8>(d_images, cn, out_c, pitch, d_table, nwit, stream);
-      } else if (kind == B3W_KIND_NOVA_O2) {
-        const uint32_t *rc_recs = d_recs + (uint64_t)c0 * 32;
-        hipLaunchKernelGGL((b3w_nova_kernel<B3W_KIND_NOVA_O2, 4, false, 1>), dim3((cn + 3) / 4), dim3(64), 0, stream,
-                           rc_recs, cn, reinterpret_cast<uint8_t *>(d_images), (uint64_t)scratch_cap, d_table, nwit, pub_c, st_c,
-                           (const uint32_t *)d_aux, 1u);
-        rc = launch_sweep<true, 4>(d_images, cn, out_c, pitch, d_table, nwit, stream);
-      } else {
-        const uint32_t *rc_recs = d_recs + (uint64_t)c0 * 32;
-        hipLaunchKernelGGL((b3w_nova_kernel<B3W_KIND_NOVA_O1, 2, false, 1>), dim3((cn + 1) / 2), dim3(64), 0, stream,
-                           rc_recs, cn, reinterpret_cast<uint8_t *>(d_images), (uint64_t)scratch_cap, d_table, nwit, pub_c, st_c,
-                           (const uint32_t *)d_aux, 1u);
-        rc = launch_sweep<true, 4>(d_images, cn, out_c, pitch, d_table, nwit, stream);
-      }
+      int rc = b3w_launch_trace(kind, d_recs + (uint64_t)c0 * (kind == B3W_KIND_COMP ? 28 : 32), cn, d_images, scratch_cap, d_table, nwit, pub_c,
+                                st_c, d_aux, stream);
+      if (rc) return rc;
+      if (kind == B3W_KIND_COMP) rc = launch_sweep<false, 8>(d_images, cn, out_c, pitch, d_table, nwit, stream);
+      else rc = launch_sweep<true, 4>(d_images, cn, out_c, pitch, d_table, nwit, stream);
       if (rc) return rc;
     }
     return (int)hipGetLastError();

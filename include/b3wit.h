@@ -185,6 +185,14 @@ int32_t b3w_batch_commit_device(b3w_ctx *ctx, const b3w_commit_key *key, const u
 /* The same for the witnesses of the last b3w_batch_run; host_points receives n * 64 bytes, host_status n int32 (may be NULL). */
 int32_t b3w_batch_commit(b3w_batch *batch, const b3w_commit_key *key, uint8_t *host_points, int32_t *host_status);
 
+/* Commitments straight from the input records, without the witness bodies: a witness is an expansion of a 3.7-11 KB
+ * trace image through the slot table, so its bits — all the commitment needs — are pieces of image words.  Equal to
+ * b3w_batch_run_device followed by b3w_batch_commit_device, at the speed of the point additions alone (the 771 KB body
+ * is neither written nor read).  d_public (may be NULL) and d_status (required) receive what b3w_batch_run_device
+ * writes; a record whose status is not 0 gets the point at infinity (all zero). */
+int32_t b3w_commit_records_device(b3w_ctx *ctx, const b3w_commit_key *key, const uint32_t *d_records, uint32_t n, uint8_t *d_points,
+                                  uint32_t *d_public, int32_t *d_status, void *stream);
+
 /* A ready-made consumer for the chained pass (b3w_chain_run_leaves / run_parents below): commits every batch of step
  * witnesses while it sits in the ring, so that of a 28 TB pass only one 64-byte point per step is kept.
  * `user` = a b3w_commit_sink whose d_points has room for every step of the pass (n_leaf + n_parent points, step order);
@@ -286,6 +294,10 @@ typedef void (*b3w_batch_consumer)(void *user, const uint8_t *d_bodies, uint64_t
 int32_t b3w_chain_create(b3w_ctx *ctx, uint64_t preimage_len, uint64_t first_chunk, uint32_t n_chunks_local,
                          uint32_t batch_steps, uint32_t ring, int32_t with_parents, b3w_chain **out);
 void b3w_chain_destroy(b3w_chain *chain);
+/* Commitments only: from now on the pass computes one commitment per step straight from the step records
+ * (b3w_commit_records_device) into d_points (n_leaf + n_parent points of 64 bytes, step order) and writes no witness
+ * bodies; the consumer arguments of the run calls are ignored.  key = NULL switches back to bodies. */
+int32_t b3w_chain_commit_only(b3w_chain *chain, const b3w_commit_key *key, uint8_t *d_points);
 int32_t b3w_chain_run_leaves(b3w_chain *chain, const uint8_t *host_preimage /* byte 0 of the WHOLE preimage */,
                              b3w_batch_consumer consumer, void *user, void *stream);
 int32_t b3w_chain_run_parents(b3w_chain *chain, const uint32_t *d_all_chunk_cvs /* n_chunks*8 words; NULL = the local ones,

@@ -188,3 +188,73 @@ def test_chained_pass_with_the_commit_consumer():
     L.b3w_chain_destroy(h)
     L.b3w_commit_key_destroy(key)
     ctx.close()
+
+
+@pytest.mark.parametrize("circuit,curve,window", [("compression", "bn254_g1", 16), ("nova_vesta", "vesta", 12), ("nova_bn254", "bn254_g1", 16),
+                                                  ("nova_bn254_o1", "bn254_g1", 12)])
+def test_commitments_from_records_equal_commitments_of_the_bodies(circuit, curve, window):
+    """b3w_commit_records_device (bits taken from the TRACE images, no bodies) against b3w_batch_commit_device on the
+    bodies of the same records — including rejected nova steps — and against the plain-integer group law."""
+    import torch
+    m = T.pkg()
+    W = T.workloads()
+    n = 300                                                   # ragged against every tile of the kernels
+    recs = W.config2_compression(n, first=5) if circuit == "compression" else W.config3_nova(n, first=5)
+    if circuit != "compression":
+        recs = recs.copy()
+        recs[7, 14] = recs[7, 12]                             # depth = leaf_depth: CheckDepth rejects the step
+    ctx = m.Context(circuit, 0)
+    first_slot = 3
+    gens = E.random_points(curve, ctx.witness_size - first_slot, seed=b"records" + circuit.encode())
+    key = m.CommitKey(ctx, curve, E.points_to_bytes(gens), first_slot, window)
+    dev = torch.device("cuda:0")
+    s = torch.cuda.current_stream().cuda_stream
+    d_recs = torch.from_numpy(recs.view(np.int32)).to(dev)
+    d_bodies = torch.zeros((n, ctx.body_bytes), dtype=torch.uint8, device=dev)
+    d_pub = torch.zeros((n, ctx.public_words), dtype=torch.int32, device=dev)
+    d_st = torch.zeros(n, dtype=torch.int32, device=dev)
+    ctx.run_device(d_recs.data_ptr(), n, d_bodies.data_ptr(), 0, d_pub.data_ptr(), d_st.data_ptr(), s)
+    want = torch.zeros((n, 64), dtype=torch.uint8, device=dev)
+    cst = torch.zeros(n, dtype=torch.int32, device=dev)
+    key.commit_device(d_bodies.data_ptr(), n, 0, want.data_ptr(), cst.data_ptr(), s)
+    got = torch.full((n, 64), 7, dtype=torch.uint8, device=dev)
+    pub2 = torch.zeros_like(d_pub)
+    st2 = torch.full((n,), -1, dtype=torch.int32, device=dev)
+    key.commit_records_device(d_recs.data_ptr(), n, got.data_ptr(), st2.data_ptr(), pub2.data_ptr(), s)
+    torch.cuda.synchronize()
+    st = d_st.cpu().numpy()
+    assert torch.equal(st2, d_st) and (circuit == "compression" or st[7] != 0) and int((st != 0).sum()) == (0 if circuit == "compression" else 1)
+    ok = torch.from_numpy(st == 0).to(dev)
+    assert torch.equal(pub2[ok], d_pub[ok])
+    assert torch.equal(got[ok], want[ok])
+    assert int(got[~ok].abs().sum().item()) == 0               # rejected: the point at infinity
+    bad, bodies = T.oracle_batch_u32(circuit, recs[[0, n - 1]])
+    vals = _slot_values(bodies.copy())
+    pts = got.cpu().numpy()
+    for j, i in enumerate([0, n - 1]):
+        assert E.point_from_bytes(pts[i].tobytes()) == E.commit(vals[j][first_slot:], gens, curve), i
+    key.close(); ctx.close()
+
+
+def test_chained_pass_commit_only_matches_the_commit_consumer():
+    """b3w_chain_commit_only: the same points as committing every batch of bodies in the ring, and still BLAKE3(preimage)."""
+    import torch, blake3_ref
+    m = T.pkg()
+    circuit, curve = "nova_vesta", "vesta"
+    ctx = m.Context(circuit, 0)
+    data = ((np.arange(8 * 1024, dtype=np.uint64) * 40503 + 11) % 253).astype(np.uint8)        # 8 chunks: 128 leaf + 24 parent steps
+    key = m.CommitKey(ctx, curve, E.points_to_bytes(E.random_points(curve, T.NWIT[circuit], seed=b"chain")))
+    dev = torch.device("cuda:0")
+    a = torch.zeros((152, 64), dtype=torch.uint8, device=dev)
+    b = torch.zeros((152, 64), dtype=torch.uint8, device=dev)
+
+    def consumer(view, first, k):
+        key.commit_device(view.data_ptr(), k, view.stride(0), a.data_ptr() + 64 * first, 0, torch.cuda.current_stream().cuda_stream)
+    out = m.chain.fold_witnesses(ctx, data, batch_steps=48, ring=2, consumer=consumer)
+    torch.cuda.synchronize()
+    root = out["root"].cpu().numpy().view(np.uint32).tobytes()
+    out2 = m.chain.fold_witnesses(ctx, data, batch_steps=48, ring=2, commit_only=(key, b))
+    torch.cuda.synchronize()
+    assert out2["root"].cpu().numpy().view(np.uint32).tobytes() == root == blake3_ref.blake3(data.tobytes())
+    assert int(out2["status"].abs().sum().item()) == 0 and torch.equal(a, b) and int(b.max(dim=1).values.min().item()) > 0
+    key.close(); ctx.close()
