@@ -103,6 +103,7 @@ def lib():
         "b3w_commit_key_window": (u32, [vp]),
         "b3w_commit_key_destroy": (None, [vp]),
         "b3w_commit_records_device": (i32, [vp, vp, vp, u32, vp, vp, vp, vp]),
+        "b3w_commit_records": (i32, [vp, vp, vp, u32, vp, vp, vp]),
         "b3w_chain_commit_only": (i32, [vp, vp, vp]),
         "b3w_batch_commit_device": (i32, [vp, vp, vp, u32, u64, vp, vp, vp]),
         "b3w_batch_commit": (i32, [vp, vp, vp, vp]),
@@ -139,7 +140,7 @@ EXPORTED_SYMBOLS = ("b3w_abi_version", "b3w_identify_wasm", "b3w_create", "b3w_d
                     "b3w_batch_run", "b3w_batch_outputs", "b3w_batch_fetch", "b3w_batch_device_ptr",
                     "b3w_batch_time_device", "b3w_batch_verify_device", "b3w_batch_verify", "b3w_batch_write_wtns", "b3w_batch_autotune_device", "b3w_bodies_alloc", "b3w_bodies_free", "b3w_bodies_trim", "b3w_batch_placement", "b3w_chain_num_chunks", "b3w_chain_num_leaf_steps", "b3w_chain_path_len",
                     "b3w_chain_plan_leaves_device", "b3w_chain_tree_device", "b3w_chain_plan_parents_device",
-                    "b3w_commit_key_create", "b3w_commit_key_create_ex", "b3w_commit_key_window", "b3w_commit_key_destroy", "b3w_commit_records_device", "b3w_chain_commit_only", "b3w_batch_commit_device", "b3w_batch_commit", "b3w_commit_consumer",
+                    "b3w_commit_key_create", "b3w_commit_key_create_ex", "b3w_commit_key_window", "b3w_commit_key_destroy", "b3w_commit_records_device", "b3w_commit_records", "b3w_chain_commit_only", "b3w_batch_commit_device", "b3w_batch_commit", "b3w_commit_consumer",
                     "b3w_comm_unique_id", "b3w_comm_create", "b3w_comm_destroy", "b3w_comm_allgather", "b3w_batch_allgather_public",
                     "b3w_chain_create", "b3w_chain_destroy", "b3w_chain_run_leaves", "b3w_chain_run_parents", "b3w_chain_shard", "b3w_chain_run_parents_sharded", "b3w_chain_info",
                     "b3w_chain_outputs", "b3w_chain_records", "b3w_chain_public", "b3w_chain_status", "b3w_chain_local_cvs", "b3w_chain_root")
@@ -323,6 +324,18 @@ class CommitKey:
         rc = lib().b3w_commit_records_device(self.ctx.handle, self.handle, d_records, n, d_points, d_public or None, d_status, stream or None)
         if rc != B3W_OK:
             raise B3WError(rc, f"b3w_commit_records_device: status {rc}: {self.ctx.last_error()}")
+
+    def commit_records(self, records):
+        """records: uint32 [n, 28 | 32] numpy array -> (points uint8 [n, 64], public uint32 [n, 16 | 15], status int32 [n])."""
+        recs = np.ascontiguousarray(records, dtype=np.uint32)
+        n = recs.shape[0]
+        pts = np.zeros((n, 64), dtype=np.uint8)
+        pub = np.zeros((n, self.ctx.public_words), dtype=np.uint32)
+        st = np.zeros(n, dtype=np.int32)
+        rc = lib().b3w_commit_records(self.ctx.handle, self.handle, recs.ctypes.data, n, pts.ctypes.data, pub.ctypes.data, st.ctypes.data)
+        if rc != B3W_OK:
+            raise B3WError(rc, f"b3w_commit_records: status {rc}: {self.ctx.last_error()}")
+        return pts, pub, st
 
     def close(self):
         if getattr(self, "handle", None):

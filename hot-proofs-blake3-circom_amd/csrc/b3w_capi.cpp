@@ -1094,6 +1094,28 @@ int32_t b3w_commit_records_device(b3w_ctx *ctx, const b3w_commit_key *key, const
   return B3W_OK;
 }
 
+int32_t b3w_commit_records(b3w_ctx *ctx, const b3w_commit_key *key, const uint32_t *host_records, uint32_t n, uint8_t *host_points,
+                           uint32_t *host_public, int32_t *host_status) {
+  if (!ctx || !key || key->ctx != ctx || !host_records || !host_points) return B3W_E_BAD_ARGUMENT;
+  if (n == 0) return B3W_OK;
+  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  const size_t rb = (size_t)n * ctx->desc.nin * 4, pb = (size_t)n * ctx->desc.npub * 4;
+  uint8_t *d = nullptr;                                   // records | points | public outputs | status
+  const size_t o_pts = (rb + 255) & ~(size_t)255, o_pub = o_pts + (size_t)n * 64, o_st = o_pub + ((pb + 255) & ~(size_t)255);
+  HIP_TRY(ctx, hipMalloc((void **)&d, o_st + (size_t)n * 4));
+  hipError_t e = hipMemset(d + o_pub, 0, o_st - o_pub);   // a rejected record's public outputs are not written: zeros
+  if (e == hipSuccess) e = hipMemcpy(d, host_records, rb, hipMemcpyHostToDevice);
+  int32_t rc = B3W_OK;
+  if (e == hipSuccess) rc = b3w_commit_records_device(ctx, key, reinterpret_cast<uint32_t *>(d), n, d + o_pts, reinterpret_cast<uint32_t *>(d + o_pub),
+                                                      reinterpret_cast<int32_t *>(d + o_st), nullptr);
+  if (e == hipSuccess && rc == B3W_OK) e = hipMemcpy(host_points, d + o_pts, (size_t)n * 64, hipMemcpyDeviceToHost);
+  if (e == hipSuccess && rc == B3W_OK && host_public) e = hipMemcpy(host_public, d + o_pub, pb, hipMemcpyDeviceToHost);
+  if (e == hipSuccess && rc == B3W_OK && host_status) e = hipMemcpy(host_status, d + o_st, (size_t)n * 4, hipMemcpyDeviceToHost);
+  (void)hipFree(d);
+  if (rc) return rc;
+  return e == hipSuccess ? B3W_OK : hip_fail(ctx, e, "hipMemcpy(commit from records)");
+}
+
 void b3w_commit_consumer(void *user, const uint8_t *d_bodies, uint64_t pitch, uint64_t first_step, uint32_t count, void *stream) {
   b3w_commit_sink *sink = static_cast<b3w_commit_sink *>(user);
   if (!sink || !sink->ctx || !sink->key || !sink->d_points) return;

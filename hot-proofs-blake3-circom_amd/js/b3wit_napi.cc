@@ -48,6 +48,7 @@ struct Api {
   decltype(&b3w_chain_outputs) chain_outputs;
   decltype(&b3w_commit_key_create_ex) commit_key_create_ex;
   decltype(&b3w_commit_key_destroy) commit_key_destroy;
+  decltype(&b3w_commit_records) commit_records;
   decltype(&b3w_batch_commit) batch_commit;
   decltype(&b3w_chain_shard) chain_shard;
   decltype(&b3w_chain_run_parents_sharded) chain_run_parents_sharded;
@@ -78,7 +79,7 @@ bool load_api() {
   SYM(write_wtns_header) SYM(last_error) SYM(public_words) SYM(batch_alloc) SYM(batch_free) SYM(batch_run)
   SYM(batch_outputs) SYM(batch_fetch) SYM(batch_write_wtns) SYM(batch_verify) SYM(batch_placement) SYM(bodies_trim)
   SYM(chain_create) SYM(chain_destroy) SYM(chain_run_leaves) SYM(chain_run_parents) SYM(chain_info) SYM(chain_outputs)
-  SYM(commit_key_create_ex) SYM(commit_key_destroy) SYM(batch_commit) SYM(chain_shard) SYM(chain_run_parents_sharded) SYM(comm_unique_id) SYM(comm_create) SYM(comm_destroy) SYM(batch_allgather_public)
+  SYM(commit_key_create_ex) SYM(commit_key_destroy) SYM(commit_records) SYM(batch_commit) SYM(chain_shard) SYM(chain_run_parents_sharded) SYM(comm_unique_id) SYM(comm_create) SYM(comm_destroy) SYM(batch_allgather_public)
 #undef SYM
   api.so = so;
   return true;
@@ -467,6 +468,33 @@ napi_value BatchCommit(napi_env env, napi_callback_info info) {
   return o;
 }
 
+// commitRecords(handle, records: Uint32Array(n * inputSize)) -> { points: Uint8Array(n * 64), publicOutputs: Uint32Array(n * 16 | 15),
+// status: Int32Array(n) }: the commitments of the witnesses of these records, without the witnesses (b3w_commit_records)
+napi_value CommitRecords(napi_env env, napi_callback_info info) {
+  size_t argc = 2; napi_value argv[2];
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+  Handle *h = get_handle(env, argv[0]);
+  if (!h) return nullptr;
+  if (!h->key) { napi_throw_error(env, nullptr, "commitRecords needs commitKey"); return nullptr; }
+  uint32_t nin = 0;
+  api.info(h->ctx, nullptr, nullptr, nullptr, &nin, nullptr);
+  napi_typedarray_type t; napi_value ab; size_t off, len; void *p;
+  NAPI_OK(napi_get_typedarray_info(env, argv[1], &t, &len, &p, &ab, &off));
+  if (t != napi_uint32_array || nin == 0 || len == 0 || len % nin) { napi_throw_type_error(env, nullptr, "records: Uint32Array of whole input records"); return nullptr; }
+  const uint32_t n = (uint32_t)(len / nin), npub = api.public_words(h->ctx);
+  void *pp, *pq, *ps; napi_value abp, abq, abs_, o, v;
+  NAPI_OK(napi_create_arraybuffer(env, (size_t)n * 64, &pp, &abp));
+  NAPI_OK(napi_create_arraybuffer(env, (size_t)n * npub * 4, &pq, &abq));
+  NAPI_OK(napi_create_arraybuffer(env, (size_t)n * 4, &ps, &abs_));
+  const int32_t rc = api.commit_records(h->ctx, h->key, (const uint32_t *)p, n, (uint8_t *)pp, (uint32_t *)pq, (int32_t *)ps);
+  if (rc != B3W_OK) return throw_status(env, h, rc, "b3w_commit_records failed");
+  NAPI_OK(napi_create_object(env, &o));
+  napi_create_typedarray(env, napi_uint8_array, (size_t)n * 64, abp, 0, &v); napi_set_named_property(env, o, "points", v);
+  napi_create_typedarray(env, napi_uint32_array, (size_t)n * npub, abq, 0, &v); napi_set_named_property(env, o, "publicOutputs", v);
+  napi_create_typedarray(env, napi_int32_array, n, abs_, 0, &v); napi_set_named_property(env, o, "status", v);
+  return o;
+}
+
 // commUniqueId() -> Uint8Array(128): rank 0 creates it and hands it to the other ranks (file, socket, env)
 napi_value CommUniqueId(napi_env env, napi_callback_info) {
   if (!load_api()) { napi_throw_error(env, nullptr, api.err.c_str()); return nullptr; }
@@ -540,6 +568,7 @@ napi_value Init(napi_env env, napi_value exports) {
       {"chainFold", nullptr, ChainFold, nullptr, nullptr, nullptr, napi_default, nullptr},
       {"commitKey", nullptr, CommitKey, nullptr, nullptr, nullptr, napi_default, nullptr},
       {"batchCommit", nullptr, BatchCommit, nullptr, nullptr, nullptr, napi_default, nullptr},
+      {"commitRecords", nullptr, CommitRecords, nullptr, nullptr, nullptr, napi_default, nullptr},
       {"commUniqueId", nullptr, CommUniqueId, nullptr, nullptr, nullptr, napi_default, nullptr},
       {"commCreate", nullptr, CommCreate, nullptr, nullptr, nullptr, napi_default, nullptr},
       {"batchAllgatherPublic", nullptr, BatchAllgatherPublic, nullptr, nullptr, nullptr, napi_default, nullptr},

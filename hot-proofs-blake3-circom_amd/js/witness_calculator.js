@@ -190,6 +190,12 @@ class WitnessCalculator {
     native().commitKey(this.instance, id, firstSlot || 0, generators, windowBits || 0);
   }
 
+  // ---- extension: commitments of the witnesses of `records` (Uint32Array of whole input records, as for
+  // calculateWitnessBatch) without producing the witnesses: { points, publicOutputs, status }
+  commitRecords(records) {
+    return native().commitRecords(this.instance, records);
+  }
+
   // ---- extension: this calculator's GPU joins an RCCL communicator (see commUniqueId above)
   joinRanks(id, rank, nranks) {
     native().commCreate(this.instance, id, rank, nranks);

@@ -193,6 +193,10 @@ int32_t b3w_batch_commit(b3w_batch *batch, const b3w_commit_key *key, uint8_t *h
 int32_t b3w_commit_records_device(b3w_ctx *ctx, const b3w_commit_key *key, const uint32_t *d_records, uint32_t n, uint8_t *d_points,
                                   uint32_t *d_public, int32_t *d_status, void *stream);
 
+/* The same from and to host buffers (n records of 28 / 32 words; n * 64 bytes of points; public outputs and status may be NULL). */
+int32_t b3w_commit_records(b3w_ctx *ctx, const b3w_commit_key *key, const uint32_t *host_records, uint32_t n, uint8_t *host_points,
+                           uint32_t *host_public, int32_t *host_status);
+
 /* A ready-made consumer for the chained pass (b3w_chain_run_leaves / run_parents below): commits every batch of step
  * witnesses while it sits in the ring, so that of a 28 TB pass only one 64-byte point per step is kept.
  * `user` = a b3w_commit_sink whose d_points has room for every step of the pass (n_leaf + n_parent points, step order);

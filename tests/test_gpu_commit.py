@@ -228,6 +228,8 @@ def test_commitments_from_records_equal_commitments_of_the_bodies(circuit, curve
     assert torch.equal(pub2[ok], d_pub[ok])
     assert torch.equal(got[ok], want[ok])
     assert int(got[~ok].abs().sum().item()) == 0               # rejected: the point at infinity
+    hpts, hpub, hst = key.commit_records(recs)                # the host-buffer form
+    assert np.array_equal(hpts, got.cpu().numpy()) and np.array_equal(hst, st) and np.array_equal(hpub.view(np.int32), pub2.cpu().numpy())
     bad, bodies = T.oracle_batch_u32(circuit, recs[[0, n - 1]])
     vals = _slot_values(bodies.copy())
     pts = got.cpu().numpy()

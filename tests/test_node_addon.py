@@ -277,12 +277,16 @@ def test_js_batch_commit_matches_plain_integer_group_law(tmp_path):
         cases.forEach((c, k) => { const v = [].concat(c.input.h, c.input.m, c.input.t, [c.input.b, c.input.d]); v.forEach((x, j) => recs[28 * k + j] = Number(x)); });
         const b = await wc.calculateWitnessBatch(recs);
         const c = b.commit();
-        console.log(JSON.stringify({points: Buffer.from(c.points).toString('hex'), status: Array.from(c.status)}));
+        const r = wc.commitRecords(recs);                       // the same points without the witnesses
+        console.log(JSON.stringify({points: Buffer.from(c.points).toString('hex'), status: Array.from(c.status),
+                                    rpoints: Buffer.from(r.points).toString('hex'), rstatus: Array.from(r.status),
+                                    rpub: Array.from(r.publicOutputs), pub: Array.from(b.publicOutputs)}));
       })().catch(e => { console.error(e); process.exit(1); });
     """, json.dumps(cases), str(tmp_path / "gens.bin"))
     assert r.returncode == 0, r.stderr
     out = json.loads(r.stdout.strip().splitlines()[-1])
     assert out["status"] == [0, 0]
+    assert out["rpoints"] == out["points"] and out["rstatus"] == [0, 0] and out["rpub"] == out["pub"] and len(out["pub"]) == 32
     W = T.workloads()
     recs = np.array([[int(x) for x in (c["input"]["h"] + c["input"]["m"] + c["input"]["t"] + [c["input"]["b"], c["input"]["d"]])] for c in cases], dtype=np.uint32)
     _, bodies = T.oracle_batch_u32("compression", recs)
