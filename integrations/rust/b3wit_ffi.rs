@@ -104,3 +104,33 @@ pub fn fold_preimage(calc: &mut Calculator, preimage: &[u8]) -> Result<(Vec<u32>
     unsafe { b3w_chain_destroy(chain) };
     if rc != 0 { Err(rc) } else { Ok((public, status, root)) }
 }
+
+// ---- the witness commitment arecibo computes right after `synthesize` (rust_fold/src/main.rs:166-179 -> prove_step commits
+// to W): Pedersen commitments on the device with the prover's own generators (same caveat: source only).  `commit_steps`
+// returns one affine point (x, y: 32-byte little-endian each; all zero = infinity) per input record WITHOUT producing the
+// witnesses — the bits the commitment needs are taken from the trace image each witness is expanded from.
+#[link(name = "b3wit")]
+extern "C" {
+    fn b3w_commit_key_create_ex(ctx: *mut c_void, curve: i32, first_slot: u32, host_generators: *const u8, window_bits: u32,
+                                out: *mut *mut c_void) -> i32;
+    fn b3w_commit_key_destroy(key: *mut c_void);
+    fn b3w_commit_records(ctx: *mut c_void, key: *const c_void, host_records: *const u32, n: u32, host_points: *mut u8,
+                          host_public: *mut u32, host_status: *mut i32) -> i32;
+}
+
+pub const CURVE_BN254_G1: i32 = 0;
+pub const CURVE_VESTA: i32 = 1;
+
+/// `generators`: 64 bytes per committed slot (slots `first_slot..witness_size`), affine, standard form.
+/// `records`: whole input records (32 words per nova step).  Returns (points: 64 bytes each, status per record).
+pub fn commit_steps(calc: &mut Calculator, curve: i32, first_slot: u32, generators: &[u8], records: &[u32], words_per_record: usize)
+    -> Result<(Vec<u8>, Vec<i32>), i32> {
+    let n = records.len() / words_per_record;
+    let mut key = std::ptr::null_mut();
+    let rc = unsafe { b3w_commit_key_create_ex(calc.ctx, curve, first_slot, generators.as_ptr(), 0, &mut key) };
+    if rc != 0 { return Err(rc); }
+    let (mut points, mut status) = (vec![0u8; n * 64], vec![0i32; n]);
+    let rc = unsafe { b3w_commit_records(calc.ctx, key, records.as_ptr(), n as u32, points.as_mut_ptr(), std::ptr::null_mut(), status.as_mut_ptr()) };
+    unsafe { b3w_commit_key_destroy(key) };
+    if rc != 0 { Err(rc) } else { Ok((points, status)) }
+}
