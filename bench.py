@@ -198,11 +198,13 @@ def main():
     if args.placement == "plain":
         os.environ["B3W_PLACEMENT"] = "plain"
     bodies = ctx.alloc_bodies(n * pitch)
-    for _ in range(2):                                      # a box still releasing another process's memory: try again
+    for attempt in range(4):                                # a box still releasing another process's memory: try again
         if bodies.placement == "mixed" or args.placement == "plain":
             break
         bodies.free()
-        time.sleep(1.0)
+        m.lib().b3w_bodies_trim()                           # hand the pooled pieces back: the next search starts afresh
+        time.sleep(1.0 + attempt)
+        os.environ["B3W_PLACE_DEBUG"] = "1"                 # say on stderr what the search found
         bodies = ctx.alloc_bodies(n * pitch)
     d_bodies = bodies                                      # .data_ptr() like a tensor
     if args.variant is None:

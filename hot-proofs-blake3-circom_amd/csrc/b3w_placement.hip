@@ -188,10 +188,17 @@ bool calibrate(Pool *p, uint32_t &budget, std::vector<Cand> &got) {
       // other class.  A handle that straddles a class border is fast with h0 and still fairly fast with its pure
       // neighbour; as the second reference it would label a whole class "third" and both sides of the buffer would be
       // filled from it (seen on a box whose first border fell into the second handle).
+      // (On memory recycled from earlier processes the classes do not come in long runs: the partner may lie a few
+      // handles back, so the newest handle is tried against the last few that were fast with h0, nearest first.)
       const size_t n = r0.size();
-      if (n >= 2 && r0[n - 1] >= thr && r0[n - 2] >= thr && probe_slots(p, seen[n - 2].slot, seen[n - 1].slot) < thr) {
-        cand = (int)n - 1; p->lo = lo; p->hi = hi; p->thr = thr;
-        break;
+      if (n >= 2 && r0[n - 1] >= thr) {
+        int tried = 0;
+        for (size_t j = n - 1; j-- > 0 && tried < 4 && cand < 0;) {
+          if (r0[j] < thr) continue;
+          tried++;
+          if (probe_slots(p, seen[j].slot, seen[n - 1].slot) < thr) cand = (int)n - 1;
+        }
+        if (cand >= 0) { p->lo = lo; p->hi = hi; p->thr = thr; break; }
       }
     }
   }
