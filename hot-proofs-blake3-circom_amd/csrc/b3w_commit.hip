@@ -909,10 +909,10 @@ extern "C" int b3w_launch_commit(const uint8_t *d_bodies, uint32_t n, uint64_t p
   const uint32_t bits_words = (nwin * window + 31) / 32 + 2;   // one packed witness in LDS (nova O1: 13.5 KB)
   if (bits_words * 4 > 32 * 1024) return (int)hipErrorInvalidValue;
   const B3wCurve9 c9 = make_curve9(*curve);
-  // lanes per witness: 32 (two witnesses per wave) for the compression circuit, 64 for the longer nova witnesses (measured
-  // at both window widths).  Virtual slots: 53 k compression, 58 k nova O2, 108 k nova O1.
+  // lanes per witness: 32 (two witnesses per wave) for small batches of the compression circuit, 64 for large ones and for
+  // the longer nova witnesses (measured at both window widths).  Virtual slots: 53 k compression, 58 k nova O2, 108 k nova O1.
   static const int env_tpw = getenv("B3W_COMMIT_THREADS") ? atoi(getenv("B3W_COMMIT_THREADS")) : 0;
-  const int tpw = env_tpw ? env_tpw : (uint64_t)nwin * window > 55200 ? 64 : 32;
+  const int tpw = env_tpw ? env_tpw : ((uint64_t)nwin * window > 55200 || n >= 8192) ? 64 : 32;
   bool vesta = true;                                           // the modulus with compile-time limbs?
   for (int i = 0; i < 9; ++i) vesta = vesta && c9.p[i] == B3wCurve9Vesta::P(i);
   vesta = vesta && c9.inv == B3wCurve9Vesta::INV() && tpw == 64;
