@@ -1249,7 +1249,7 @@ struct b3w_chain {
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   hipEvent_t ev_cvs = nullptr, ev_par = nullptr;     // chunk CVs complete (main stream); parent records ready (side stream)
   const b3w_commit_key *co_key = nullptr;            // commitments only: no bodies, one point per step into co_points
-  uint8_t *co_points = nullptr;
+  uint8_t *co_points = nullptr, *co_own = nullptr;   // (co_own: the chain's own buffer when the caller passed none)
 };
 
 namespace {
@@ -1282,9 +1282,24 @@ int32_t chain_run_steps(b3w_chain *c, uint64_t first_row, uint64_t count, b3w_ba
 extern "C" {
 
 int32_t b3w_chain_commit_only(b3w_chain *c, const b3w_commit_key *key, uint8_t *d_points) {
-  if (!c || (key && (!d_points || key->ctx != c->ctx))) return B3W_E_BAD_ARGUMENT;
+  if (!c || (key && key->ctx != c->ctx)) return B3W_E_BAD_ARGUMENT;
+  if (key && !d_points) {                              // the chain's own buffer: fetch it with b3w_chain_commitments
+    if (!c->co_own) {
+      HIP_TRY(c->ctx, hipSetDevice(c->ctx->device));
+      HIP_TRY(c->ctx, hipMalloc((void **)&c->co_own, (size_t)(c->n_leaf + c->n_par + 1) * 64));
+    }
+    d_points = c->co_own;
+  }
   c->co_key = key;
   c->co_points = key ? d_points : nullptr;
+  return B3W_OK;
+}
+
+int32_t b3w_chain_commitments(b3w_chain *c, uint8_t *host_points, void *stream) {
+  if (!c || !host_points || !c->co_points) return B3W_E_BAD_ARGUMENT;
+  HIP_TRY(c->ctx, hipSetDevice(c->ctx->device));
+  HIP_TRY(c->ctx, hipStreamSynchronize((hipStream_t)stream));
+  HIP_TRY(c->ctx, hipMemcpy(host_points, c->co_points, (size_t)(c->n_leaf + c->n_par) * 64, hipMemcpyDeviceToHost));
   return B3W_OK;
 }
 
@@ -1347,6 +1362,7 @@ void b3w_chain_destroy(b3w_chain *c) {
   if (c->d_status) (void)hipFree(c->d_status);
   if (c->d_levels) (void)hipFree(c->d_levels);
   if (c->d_root) (void)hipFree(c->d_root);
+  if (c->co_own) (void)hipFree(c->co_own);
   if (c->copy) (void)hipStreamDestroy(c->copy);
   if (c->side) (void)hipStreamDestroy(c->side);
   if (c->ev_cvs) (void)hipEventDestroy(c->ev_cvs);

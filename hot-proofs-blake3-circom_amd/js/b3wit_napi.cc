@@ -49,6 +49,8 @@ struct Api {
   decltype(&b3w_commit_key_create_ex) commit_key_create_ex;
   decltype(&b3w_commit_key_destroy) commit_key_destroy;
   decltype(&b3w_commit_records) commit_records;
+  decltype(&b3w_chain_commit_only) chain_commit_only;
+  decltype(&b3w_chain_commitments) chain_commitments;
   decltype(&b3w_batch_commit) batch_commit;
   decltype(&b3w_chain_shard) chain_shard;
   decltype(&b3w_chain_run_parents_sharded) chain_run_parents_sharded;
@@ -79,7 +81,7 @@ bool load_api() {
   SYM(write_wtns_header) SYM(last_error) SYM(public_words) SYM(batch_alloc) SYM(batch_free) SYM(batch_run)
   SYM(batch_outputs) SYM(batch_fetch) SYM(batch_write_wtns) SYM(batch_verify) SYM(batch_placement) SYM(bodies_trim)
   SYM(chain_create) SYM(chain_destroy) SYM(chain_run_leaves) SYM(chain_run_parents) SYM(chain_info) SYM(chain_outputs)
-  SYM(commit_key_create_ex) SYM(commit_key_destroy) SYM(commit_records) SYM(batch_commit) SYM(chain_shard) SYM(chain_run_parents_sharded) SYM(comm_unique_id) SYM(comm_create) SYM(comm_destroy) SYM(batch_allgather_public)
+  SYM(commit_key_create_ex) SYM(commit_key_destroy) SYM(commit_records) SYM(chain_commit_only) SYM(chain_commitments) SYM(batch_commit) SYM(chain_shard) SYM(chain_run_parents_sharded) SYM(comm_unique_id) SYM(comm_create) SYM(comm_destroy) SYM(batch_allgather_public)
 #undef SYM
   api.so = so;
   return true;
@@ -362,7 +364,7 @@ napi_value BatchPlacement(napi_env env, napi_callback_info info) {
 //   -> { nLeafSteps, nParentSteps, nChunks, pathLen, placement, publicOutputs: Uint32Array(steps*15), status: Int32Array, root: Uint32Array(8) }
 // The whole chained-mode pass of b3wit.h (b3w_chain_*) over one preimage on this handle's device.
 napi_value ChainFold(napi_env env, napi_callback_info info) {
-  size_t argc = 5; napi_value argv[5];
+  size_t argc = 6; napi_value argv[6];
   NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
   Handle *h = get_handle(env, argv[0]);
   if (!h) return nullptr;
@@ -381,6 +383,9 @@ napi_value ChainFold(napi_env env, napi_callback_info info) {
   if (argc > 2) napi_get_value_uint32(env, argv[2], &batch_steps);
   if (argc > 3) napi_get_value_uint32(env, argv[3], &ring);
   if (argc > 4) napi_get_value_bool(env, argv[4], &with_parents);
+  bool commit_only = false;                              // one commitment per step instead of the witness bodies (needs commitKey)
+  if (argc > 5) napi_get_value_bool(env, argv[5], &commit_only);
+  if (commit_only && !h->key) { napi_throw_error(env, nullptr, "commitOnly needs setCommitKey first"); return nullptr; }
   const uint64_t nchunks = (len + 1023) / 1024;
   if (nchunks > 0xFFFFFFFFull) { napi_throw_range_error(env, nullptr, "preimage too large for one pass"); return nullptr; }
   b3w_chain *c = nullptr;
@@ -388,7 +393,8 @@ napi_value ChainFold(napi_env env, napi_callback_info info) {
   if (h->comm) api.chain_shard(nchunks, h->rank, h->nranks, &first, &count);     // after commCreate: this rank's share of the chunks
   int32_t rc = api.chain_create(h->ctx, len, first, count, batch_steps, ring, with_parents ? 1 : 0, &c);
   if (rc != B3W_OK) return throw_status(env, h, rc, "b3w_chain_create failed");
-  rc = api.chain_run_leaves(c, (const uint8_t *)data, nullptr, nullptr, nullptr);
+  if (commit_only) rc = api.chain_commit_only(c, h->key, nullptr);
+  if (rc == B3W_OK) rc = api.chain_run_leaves(c, (const uint8_t *)data, nullptr, nullptr, nullptr);
   if (rc == B3W_OK) rc = h->comm ? api.chain_run_parents_sharded(c, h->comm, nullptr, nullptr, nullptr)
                                  : api.chain_run_parents(c, nullptr, nullptr, nullptr, nullptr);
   uint64_t nleaf = 0, npar = 0, nch = 0; uint32_t plen = 0; int32_t placement = 0;
@@ -402,6 +408,11 @@ napi_value ChainFold(napi_env env, napi_callback_info info) {
     return nullptr;
   }
   if (rc == B3W_OK) rc = api.chain_outputs(c, (uint32_t *)pp, (int32_t *)ps, (uint32_t *)pr, nullptr);
+  void *pc = nullptr; napi_value abc;
+  if (rc == B3W_OK && commit_only) {
+    if (napi_create_arraybuffer(env, rows * 64, &pc, &abc) != napi_ok) { api.chain_destroy(c); napi_throw_error(env, nullptr, "b3wit_napi: cannot allocate the points"); return nullptr; }
+    rc = api.chain_commitments(c, (uint8_t *)pc, nullptr);
+  }
   api.chain_destroy(c);
   if (rc != B3W_OK) return throw_status(env, h, rc, "chained pass failed");
   NAPI_OK(napi_create_object(env, &o));
@@ -415,6 +426,7 @@ napi_value ChainFold(napi_env env, napi_callback_info info) {
   napi_create_typedarray(env, napi_uint32_array, rows * 15, abp, 0, &v); napi_set_named_property(env, o, "publicOutputs", v);
   napi_create_typedarray(env, napi_int32_array, rows, abs_, 0, &v); napi_set_named_property(env, o, "status", v);
   napi_create_typedarray(env, napi_uint32_array, 8, abr, 0, &v); napi_set_named_property(env, o, "root", v);
+  if (commit_only) { napi_create_typedarray(env, napi_uint8_array, rows * 64, abc, 0, &v); napi_set_named_property(env, o, "commitments", v); }
   return o;
 }
 

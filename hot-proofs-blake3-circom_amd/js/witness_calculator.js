@@ -211,7 +211,9 @@ class WitnessCalculator {
   // nChunksLocal); the chunk chaining values are all-gathered over RCCL so that each rank knows the whole tree.
   async foldPreimage(preimage, opts) {
     opts = opts || {};
-    const r = native().chainFold(this.instance, preimage, opts.batchSteps || 16384, opts.ring || 2, opts.withParents !== false);
+    // opts.commitOnly (after setCommitKey): r.commitments = one 64-byte point per step, no witness bodies written
+    const r = native().chainFold(this.instance, preimage, opts.batchSteps || 16384, opts.ring || 2, opts.withParents !== false,
+                                 !!opts.commitOnly);
     const b = Buffer.alloc(32);
     r.root.forEach((w, i) => b.writeUInt32LE(w, 4 * i));
     r.hash = b.toString("hex");

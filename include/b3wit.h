@@ -302,6 +302,8 @@ void b3w_chain_destroy(b3w_chain *chain);
  * (b3w_commit_records_device) into d_points (n_leaf + n_parent points of 64 bytes, step order) and writes no witness
  * bodies; the consumer arguments of the run calls are ignored.  key = NULL switches back to bodies. */
 int32_t b3w_chain_commit_only(b3w_chain *chain, const b3w_commit_key *key, uint8_t *d_points);
+/* d_points = NULL above: the chain keeps the points itself; this copies them (n_leaf + n_parent times 64 bytes) to the host. */
+int32_t b3w_chain_commitments(b3w_chain *chain, uint8_t *host_points, void *stream);
 int32_t b3w_chain_run_leaves(b3w_chain *chain, const uint8_t *host_preimage /* byte 0 of the WHOLE preimage */,
                              b3w_batch_consumer consumer, void *user, void *stream);
 int32_t b3w_chain_run_parents(b3w_chain *chain, const uint32_t *d_all_chunk_cvs /* n_chunks*8 words; NULL = the local ones,

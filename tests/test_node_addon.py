@@ -189,6 +189,9 @@ def test_js_fold_preimage_matches_blake3_and_python_driver(tmp_path):
     for name, nbytes in shapes.items():
         data = ((np.arange(nbytes, dtype=np.uint64) * 2654435761 + 7) % 251).astype(np.uint8)
         (tmp_path / (name + ".bin")).write_bytes(data.tobytes())
+    import ec_ref as E
+    gens_bytes = E.points_to_bytes(E.random_points("vesta", T.NWIT["nova_vesta"], seed=b"jsfold"))
+    (tmp_path / "gens.bin").write_bytes(gens_bytes)
     r = _node("""
       const builder = require('./hot-proofs-blake3-circom_amd/js/witness_calculator.js');
       const fs = require('fs'), crypto = require('crypto');
@@ -201,6 +204,11 @@ def test_js_fold_preimage_matches_blake3_and_python_driver(tmp_path):
                        bad: Array.from(r.status).filter(x => x !== 0).length,
                        pub: crypto.createHash('sha256').update(Buffer.from(r.publicOutputs.buffer, r.publicOutputs.byteOffset, r.publicOutputs.byteLength)).digest('hex')};
         }
+        // commitments only (setCommitKey, then foldPreimage with commitOnly): one point per step, same root
+        wc.setCommitKey('vesta', new Uint8Array(fs.readFileSync(process.argv[1] + '/gens.bin')), 0, 12);
+        const c = await wc.foldPreimage(fs.readFileSync(process.argv[1] + '/complete.bin'), {batchSteps: 64, commitOnly: true});
+        out.commitOnly = {hash: c.hash, n: c.commitments.length / 64, bad: Array.from(c.status).filter(x => x !== 0).length,
+                          points: crypto.createHash('sha256').update(Buffer.from(c.commitments.buffer, c.commitments.byteOffset, c.commitments.byteLength)).digest('hex')};
         console.log(JSON.stringify(out));
       })().catch(e => { console.error(e); process.exit(1); });
     """, str(tmp_path))
@@ -208,6 +216,15 @@ def test_js_fold_preimage_matches_blake3_and_python_driver(tmp_path):
     out = json.loads(r.stdout.strip().splitlines()[-1])
     ctx = m.Context("nova_vesta", 0)
     import hashlib
+    key = m.CommitKey(ctx, "vesta", gens_bytes, 0, 12)
+    data = np.frombuffer((tmp_path / "complete.bin").read_bytes(), dtype=np.uint8).copy()
+    pts = torch.zeros((16 * 16 + 16 * 4, 64), dtype=torch.uint8, device="cuda:0")
+    py = m.chain.fold_witnesses(ctx, data, batch_steps=64, commit_only=(key, pts))
+    torch.cuda.synchronize()
+    co = out.pop("commitOnly")
+    assert co["hash"] == out["complete"]["hash"] and co["n"] == pts.shape[0] and co["bad"] == 0
+    assert co["points"] == hashlib.sha256(pts.cpu().numpy().tobytes()).hexdigest() and int(pts.max(dim=1).values.min().item()) > 0
+    key.close()
     for name, nbytes in shapes.items():
         data = np.frombuffer((tmp_path / (name + ".bin")).read_bytes(), dtype=np.uint8).copy()
         assert out[name]["hash"] == blake3_ref.blake3(data.tobytes()).hex(), name
