@@ -1034,8 +1034,8 @@ int32_t b3w_batch_commit_device(b3w_ctx *ctx, const b3w_commit_key *key, const u
   if (!ctx || !key || key->ctx != ctx || !d_bodies || !d_points) return B3W_E_BAD_ARGUMENT;
   const uint64_t body = 32ull * ctx->desc.nwit;
   if (pitch == 0) pitch = body;
-  if (pitch < body || (pitch & 3) || (reinterpret_cast<uintptr_t>(d_bodies) & 3) || (reinterpret_cast<uintptr_t>(d_points) & 15)) {
-    ctx->last_error = "pitch must be >= witness_size*32, bodies 4-byte and points 16-byte aligned";
+  if (pitch < body || (pitch & 15) || (reinterpret_cast<uintptr_t>(d_bodies) & 15) || (reinterpret_cast<uintptr_t>(d_points) & 15)) {
+    ctx->last_error = "pitch must be >= witness_size*32 and a multiple of 16, bodies and points 16-byte aligned";
     return B3W_E_BAD_ARGUMENT;
   }
   b3w_commit_key *k = const_cast<b3w_commit_key *>(key);                     // scratch only

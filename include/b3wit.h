@@ -180,6 +180,7 @@ int32_t b3w_commit_key_create_ex(b3w_ctx *ctx, int32_t curve, uint32_t first_slo
                                  b3w_commit_key **out);
 uint32_t b3w_commit_key_window(const b3w_commit_key *key);     /* 12 or 16 */
 void b3w_commit_key_destroy(b3w_commit_key *key);
+/* d_bodies and d_points 16-byte aligned, pitch a multiple of 16 (0 = witness_size * 32). */
 int32_t b3w_batch_commit_device(b3w_ctx *ctx, const b3w_commit_key *key, const uint8_t *d_bodies, uint32_t n, uint64_t pitch,
                                 uint8_t *d_points /* n * 64 bytes */, int32_t *d_status, void *stream);
 /* The same for the witnesses of the last b3w_batch_run; host_points receives n * 64 bytes, host_status n int32 (may be NULL). */

@@ -260,3 +260,36 @@ def test_chained_pass_commit_only_matches_the_commit_consumer():
     assert out2["root"].cpu().numpy().view(np.uint32).tobytes() == root == blake3_ref.blake3(data.tobytes())
     assert int(out2["status"].abs().sum().item()) == 0 and torch.equal(a, b) and int(b.max(dim=1).values.min().item()) > 0
     key.close(); ctx.close()
+
+
+def test_commitments_from_records_across_a_chunk_border_and_argument_checks():
+    """Records mode works in chunks of 32 768 witnesses: points on both sides of the border equal the commitments of
+    the bodies of the same records; misaligned bodies are refused."""
+    import torch
+    m = T.pkg()
+    n = 32768 + 900
+    ctx = m.Context("compression", 0)
+    recs = T.workloads().config2_compression(n, first=1)
+    key = m.CommitKey(ctx, "bn254_g1", E.points_to_bytes(E.random_points("bn254_g1", ctx.witness_size, seed=b"border")), 0, 12)
+    dev = torch.device("cuda:0")
+    s = torch.cuda.current_stream().cuda_stream
+    d_recs = torch.from_numpy(recs.view(np.int32)).to(dev)
+    got = torch.zeros((n, 64), dtype=torch.uint8, device=dev)
+    st = torch.full((n,), -1, dtype=torch.int32, device=dev)
+    pub = torch.zeros((n, 16), dtype=torch.int32, device=dev)
+    key.commit_records_device(d_recs.data_ptr(), n, got.data_ptr(), st.data_ptr(), pub.data_ptr(), s)
+    sel = torch.tensor([0, 1, 32766, 32767, 32768, 32769, n - 2, n - 1], device=dev)
+    k = sel.numel()
+    d_sub = d_recs[sel].contiguous()
+    d_bodies = torch.zeros((k, ctx.body_bytes), dtype=torch.uint8, device=dev)
+    pub2 = torch.zeros((k, 16), dtype=torch.int32, device=dev)
+    st2 = torch.zeros(k, dtype=torch.int32, device=dev)
+    ctx.run_device(d_sub.data_ptr(), k, d_bodies.data_ptr(), 0, pub2.data_ptr(), st2.data_ptr(), s)
+    want = torch.zeros((k, 64), dtype=torch.uint8, device=dev)
+    key.commit_device(d_bodies.data_ptr(), k, 0, want.data_ptr(), 0, s)
+    torch.cuda.synchronize()
+    assert int(st.abs().sum().item()) == 0 and torch.equal(got[sel], want) and torch.equal(pub[sel], pub2)
+    assert int(got.max(dim=1).values.min().item()) > 0                       # every point written
+    with pytest.raises(m.B3WError):
+        key.commit_device(d_bodies.data_ptr() + 4, k - 1, 0, want.data_ptr(), 0, s)
+    key.close(); ctx.close()
