@@ -70,6 +70,36 @@ __device__ __forceinline__ F9 mul29(const F9 &a, const F9 &b, const Curve9 &C) {
   r.l[8] = (uint32_t)acc;
   return r;
 }
+// the same with the multiply-adds pinned (inline asm): no reassociation into partial sums by the compiler
+__device__ __forceinline__ void madacc(uint64_t &acc, uint32_t a, uint32_t b) {
+  asm("v_mad_u64_u32 %0, vcc, %1, %2, %0" : "+v"(acc) : "v"(a), "v"(b) : "vcc");
+}
+__device__ __forceinline__ F9 mul29asm(const F9 &a, const F9 &b, const Curve9 &C) {
+  uint64_t acc = 0;
+  uint32_t m[9];
+  F9 r;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+#pragma unroll
+    for (int i = 0; i <= k; ++i) madacc(acc, a.l[i], b.l[k - i]);
+#pragma unroll
+    for (int i = 0; i < k; ++i) madacc(acc, m[i], C.p[k - i]);
+    m[k] = ((uint32_t)acc * C.inv) & M29;
+    madacc(acc, m[k], C.p[0]);
+    acc >>= 29;
+  }
+#pragma unroll
+  for (int k = 9; k < 17; ++k) {
+#pragma unroll
+    for (int i = k - 8; i < 9; ++i) madacc(acc, a.l[i], b.l[k - i]);
+#pragma unroll
+    for (int i = k - 8; i < 9; ++i) madacc(acc, m[i], C.p[k - i]);
+    r.l[k - 9] = (uint32_t)acc & M29;
+    acc >>= 29;
+  }
+  r.l[8] = (uint32_t)acc;
+  return r;
+}
 __device__ __forceinline__ F9 sqr29(const F9 &a, const Curve9 &C) {
   uint64_t acc = 0;
   uint32_t m[9], d[9];
@@ -139,6 +169,17 @@ __global__ __launch_bounds__(256) void k32(uint32_t *out, uint32_t iters, B3wCur
   for (int c = 0; c < CHAINS; ++c) for (int i = 0; i < 8; ++i) x ^= a[c].l[i];
   out[blockIdx.x * 256 + threadIdx.x] = x;
 }
+template <int CHAINS>
+__global__ __launch_bounds__(256) void k29asm(uint32_t *out, uint32_t iters, Curve9 C) {
+  F9 a[CHAINS];
+  for (int c = 0; c < CHAINS; ++c) for (int i = 0; i < 9; ++i) a[c].l[i] = (threadIdx.x * 977u + i * 131u + c * 7u + blockIdx.x) & M29;
+  for (uint32_t it = 0; it < iters; ++it)
+#pragma unroll
+    for (int c = 0; c < CHAINS; ++c) a[c] = mul29asm(a[c], a[(c + 1) % CHAINS], C);
+  uint32_t x = 0;
+  for (int c = 0; c < CHAINS; ++c) for (int i = 0; i < 9; ++i) x ^= a[c].l[i];
+  out[blockIdx.x * 256 + threadIdx.x] = x;
+}
 template <int CHAINS, bool SQ>
 __global__ __launch_bounds__(256) void k29(uint32_t *out, uint32_t iters, Curve9 C) {
   F9 a[CHAINS];
@@ -192,6 +233,14 @@ int main() {
   run("8 x 32-bit CIOS, 2 chains", [&] { hipLaunchKernelGGL(k32<2>, dim3(grid), dim3(256), 0, 0, out, iters, C); }, (double)grid * 256 * iters * 2);
   run("9 x 29-bit mul, 1 chain", [&] { hipLaunchKernelGGL((k29<1, false>), dim3(grid), dim3(256), 0, 0, out, iters, C9); }, (double)grid * 256 * iters);
   run("9 x 29-bit mul, 2 chains", [&] { hipLaunchKernelGGL((k29<2, false>), dim3(grid), dim3(256), 0, 0, out, iters, C9); }, (double)grid * 256 * iters * 2);
+  run("9 x 29-bit mul, pinned mads, 2 chains", [&] { hipLaunchKernelGGL((k29asm<2>), dim3(grid), dim3(256), 0, 0, out, iters, C9); }, (double)grid * 256 * iters * 2);
+  {
+    uint32_t h1[256], h2[256];
+    hipLaunchKernelGGL((k29<2, false>), dim3(1), dim3(256), 0, 0, out, 50u, C9); hipMemcpy(h1, out, 1024, hipMemcpyDeviceToHost);
+    hipLaunchKernelGGL((k29asm<2>), dim3(1), dim3(256), 0, 0, out, 50u, C9); hipMemcpy(h2, out, 1024, hipMemcpyDeviceToHost);
+    int same = 1; for (int i = 0; i < 256; i++) same &= h1[i] == h2[i];
+    printf("pinned == compiler-scheduled over 50 iterations: %s\n", same ? "yes" : "NO");
+  }
   run("9 x 29-bit sqr, 2 chains", [&] { hipLaunchKernelGGL((k29<2, true>), dim3(grid), dim3(256), 0, 0, out, iters, C9); }, (double)grid * 256 * iters * 2);
   hipLaunchKernelGGL(kcheck, dim3(1), dim3(256), 0, 0, out, C, C9);
   uint32_t h[256]; hipMemcpy(h, out, 1024, hipMemcpyDeviceToHost);
