@@ -290,7 +290,8 @@ __device__ void jac_to_affine(const Jac &P, Fp &x, Fp &y, const B3wCurve &C) {
 //   a + sp4 - b     b tidy < 2p  ->  value a + 4p - b, limbs < a's + 2^30   (sp4 = 4p with every limb lifted by 2^29)
 #define M29 0x1FFFFFFFu
 struct F9 { uint32_t l[9]; };
-struct J9 { F9 X, Y, Z; bool inf; };      // invariant between additions: X, Y tidy < 2p; Z < 4p with limbs < 2^30
+struct J9 { F9 X, Y, ZZ, ZZZ; bool inf; };  // the point (X / ZZ, Y / ZZZ), ZZ^3 = ZZZ^2 ("XYZZ" coordinates: a mixed addition is
+                                             // 8M + 2S, one squaring less than Jacobian); between additions all four are tidy < 2p
 struct B3wCurve9 {
   uint32_t p[9];        // modulus
   uint32_t sp4[9];      // 4p, limb i lifted by 2^29 and lowered by the 1 it lent to limb i - 1
@@ -482,72 +483,68 @@ __device__ __forceinline__ Fp from29(const F9 &a, uint32_t &hi) {     // tidy ->
 __device__ __forceinline__ J9 j9_infinity() {
   J9 r;
 #pragma unroll
-  for (int i = 0; i < 9; ++i) r.X.l[i] = r.Y.l[i] = r.Z.l[i] = 0;
+  for (int i = 0; i < 9; ++i) r.X.l[i] = r.Y.l[i] = r.ZZ.l[i] = r.ZZZ.l[i] = 0;
   r.inf = true;
   return r;
 }
-// P = 2P (dbl-2009-l, a = 0), safe forms
+// P = 2P (dbl-2008-s-1, a = 0), safe forms
 template <class CV>
 __device__ __forceinline__ void j9_dbl(J9 &P, const CV &C) {
   if (P.inf) return;
   if (s_is_zero(P.Y, C)) { P.inf = true; return; }
-  const F9 A = sqr29(P.X, C), B = sqr29(P.Y, C), Cc = sqr29(B, C);
-  F9 D = s_sub(s_sub(sqr29(s_add(P.X, B, C), C), A, C), Cc, C);
-  D = s_dbl(D, C);
-  const F9 E = s_add(s_dbl(A, C), A, C), F = sqr29(E, C);
-  const F9 X3 = s_sub(F, s_dbl(D, C), C);
-  const F9 c8 = s_dbl(s_dbl(s_dbl(Cc, C), C), C);
-  const F9 Y3 = s_sub(mul29(E, s_sub(D, X3, C), C), c8, C);
-  P.Z = s_dbl(mul29(P.Y, red29(P.Z, C), C), C);
+  const F9 U = s_dbl(P.Y, C), V = sqr29(U, C), W = mul29(U, V, C), S = mul29(P.X, V, C);
+  const F9 XX = sqr29(P.X, C), M = s_add(s_dbl(XX, C), XX, C);
+  const F9 X3 = s_sub(sqr29(M, C), s_dbl(S, C), C);
+  const F9 Y3 = s_sub(mul29(M, s_sub(S, X3, C), C), mul29(W, P.Y, C), C);
+  P.ZZ = mul29(V, P.ZZ, C);
+  P.ZZZ = mul29(W, P.ZZZ, C);
   P.X = X3; P.Y = Y3;
 }
-// P += (x2, y2, 1): madd-2007-bl with lazy values; x2, y2 tidy < p; (0, 0) (the table's infinity) is filtered by the caller
+// P += (x2, y2): madd-2008-s with lazy values; x2, y2 tidy < p; (0, 0) (the table's infinity) is filtered by the caller.
+// Bounds: inputs X1, Y1, ZZ1, ZZZ1 tidy < 2p  ->  outputs the same.
 template <class CV>
 __device__ __forceinline__ void j9_madd(J9 &P, const F9 &x2, const F9 &y2, const CV &C) {
   if (P.inf) {
-    P.X = x2; P.Y = y2; P.Z = one29(C); P.inf = false;
+    P.X = x2; P.Y = y2; P.ZZ = one29(C); P.ZZZ = one29(C); P.inf = false;
     return;
   }
-  const F9 Z1Z1 = sqr29(P.Z, C);                                   // < 2p
-  const F9 U2 = mul29(x2, Z1Z1, C), S2 = mul29(mul29(y2, P.Z, C), Z1Z1, C);
-  const F9 H = cn29(sub29(U2, P.X, C));                            // tidy, in (2p, 6p): = 0 mod p iff 3p, 4p or 5p
-  const F9 rh = cn29(sub29(S2, P.Y, C));                           // likewise
-  if (H.l[0] == C.kp0[0] || H.l[0] == C.kp0[1] || H.l[0] == C.kp0[2]) {
-    if (is_kp29(H, 3, C) || is_kp29(H, 4, C) || is_kp29(H, 5, C)) {
-      if (!(is_kp29(rh, 3, C) || is_kp29(rh, 4, C) || is_kp29(rh, 5, C))) { P.inf = true; return; }   // P + (-P)
-      P.X = x2; P.Y = y2; P.Z = one29(C);
+  const F9 U2 = mul29(x2, P.ZZ, C), S2 = mul29(y2, P.ZZZ, C);      // < 2p
+  const F9 Pd = cn29(sub29(U2, P.X, C));                           // tidy, in (2p, 6p): = 0 mod p iff 3p, 4p or 5p
+  const F9 R = cn29(sub29(S2, P.Y, C));                            // likewise
+  if (Pd.l[0] == C.kp0[0] || Pd.l[0] == C.kp0[1] || Pd.l[0] == C.kp0[2]) {
+    if (is_kp29(Pd, 3, C) || is_kp29(Pd, 4, C) || is_kp29(Pd, 5, C)) {
+      if (!(is_kp29(R, 3, C) || is_kp29(R, 4, C) || is_kp29(R, 5, C))) { P.inf = true; return; }     // P + (-P)
+      P.X = x2; P.Y = y2; P.ZZ = one29(C); P.ZZZ = one29(C);
       j9_dbl(P, C);                                                                                  // P + P
       return;
     }
   }
-  const F9 HH = sqr29(H, C);                                       // < 2p
-  const F9 I = shl29(HH, 2);                                       // < 8p, limbs < 2^31
-  const F9 J = mul29(H, I, C), V = mul29(P.X, I, C);               // < 2p
-  const F9 r = shl29(rh, 1);                                       // < 12p, limbs < 2^30
-  const F9 X3 = red29(add29(add29(sqr29(r, C), neg29(J, C)), shl29(neg29(V, C), 1)), C);      // r^2 - J - 2V  (< 16p before)
-  const F9 M1 = mul29(r, sub29(V, X3, C), C), M2 = mul29(P.Y, J, C);                  // < 3p, < 2p
+  const F9 PP = sqr29(Pd, C);                                      // < 2p   (36 / 64 + 1)
+  const F9 PPP = mul29(Pd, PP, C), Q = mul29(P.X, PP, C);          // < 2p
+  const F9 X3 = red29(add29(add29(sqr29(R, C), neg29(PPP, C)), shl29(neg29(Q, C), 1)), C);    // R^2 - PPP - 2Q  (< 14p before)
+  const F9 T1 = mul29(R, sub29(Q, X3, C), C), T2 = mul29(P.Y, PPP, C);                 // < 2p each
   P.X = X3;
-  P.Y = red29(add29(M1, shl29(neg29(M2, C), 1)), C);               // r(V - X3) - 2 Y1 J  (< 11p before)
-  P.Z = shl29(mul29(P.Z, H, C), 1);                                // 2 Z1 H: < 4p, limbs < 2^30
+  P.Y = red29(add29(T1, neg29(T2, C)), C);                         // R (Q - X3) - Y1 PPP  (< 6p before)
+  P.ZZ = mul29(P.ZZ, PP, C);
+  P.ZZZ = mul29(P.ZZZ, PPP, C);
 }
-// P += Q (add-2007-bl), safe forms
+// P += Q (add-2008-s), safe forms
 template <class CV>
 __device__ __forceinline__ void j9_add(J9 &P, const J9 &Q, const CV &C) {
   if (Q.inf) return;
-  if (P.inf) { P.X = Q.X; P.Y = Q.Y; P.Z = Q.Z; P.inf = false; return; }
-  const F9 Z1 = red29(P.Z, C), Z2 = red29(Q.Z, C);
-  const F9 Z1Z1 = sqr29(Z1, C), Z2Z2 = sqr29(Z2, C);
-  const F9 U1 = mul29(P.X, Z2Z2, C), U2 = mul29(Q.X, Z1Z1, C);
-  const F9 S1 = mul29(mul29(P.Y, Z2, C), Z2Z2, C), S2 = mul29(mul29(Q.Y, Z1, C), Z1Z1, C);
-  const F9 H = s_sub(U2, U1, C), rr = s_sub(S2, S1, C);
-  if (s_is_zero(H, C)) {
-    if (s_is_zero(rr, C)) j9_dbl(P, C); else P.inf = true;
+  if (P.inf) { P.X = Q.X; P.Y = Q.Y; P.ZZ = Q.ZZ; P.ZZZ = Q.ZZZ; P.inf = false; return; }
+  const F9 U1 = mul29(P.X, Q.ZZ, C), U2 = mul29(Q.X, P.ZZ, C);
+  const F9 S1 = mul29(P.Y, Q.ZZZ, C), S2 = mul29(Q.Y, P.ZZZ, C);
+  const F9 Pd = s_sub(U2, U1, C), R = s_sub(S2, S1, C);
+  if (s_is_zero(Pd, C)) {
+    if (s_is_zero(R, C)) j9_dbl(P, C); else P.inf = true;
     return;
   }
-  const F9 I = sqr29(shl29(H, 1), C), J = mul29(H, I, C), r = s_dbl(rr, C), V = mul29(U1, I, C);
-  const F9 X3 = s_sub(s_sub(sqr29(r, C), J, C), s_dbl(V, C), C);
-  P.Y = s_sub(mul29(r, s_sub(V, X3, C), C), s_dbl(mul29(S1, J, C), C), C);
-  P.Z = mul29(s_sub(s_sub(sqr29(add29(Z1, Z2), C), Z1Z1, C), Z2Z2, C), H, C);
+  const F9 PP = sqr29(Pd, C), PPP = mul29(Pd, PP, C), Qq = mul29(U1, PP, C);
+  const F9 X3 = s_sub(s_sub(sqr29(R, C), PPP, C), s_dbl(Qq, C), C);
+  P.Y = s_sub(mul29(R, s_sub(Qq, X3, C), C), mul29(S1, PPP, C), C);
+  P.ZZ = mul29(mul29(P.ZZ, Q.ZZ, C), PP, C);
+  P.ZZZ = mul29(mul29(P.ZZZ, Q.ZZZ, C), PPP, C);
   P.X = X3;
 }
 
@@ -591,7 +588,7 @@ __global__ __launch_bounds__(64) void b3w_commit_window_kernel(const uint32_t *_
                                                                uint32_t *__restrict__ table, B3wCurve C, B3wCurve9 C9) {
   constexpr int K = B3W_WINDOW_K;
   constexpr uint32_t CHUNKS = (1u << W) / K;                  // per window
-  __shared__ uint32_t lds[4 * K * 9 * 64];                    // X, Y, Z, prefix product of the Zs
+  __shared__ uint32_t lds[5 * K * 9 * 64];                    // X, Y, ZZ, ZZZ, prefix product of the ZZ * ZZZ
   const uint32_t tid = threadIdx.x;
   const uint64_t gid = (uint64_t)blockIdx.x * 64 + tid;
   if (gid >= (uint64_t)nwin * CHUNKS) return;                 // no barriers below: every thread uses its own LDS column
@@ -620,46 +617,48 @@ __global__ __launch_bounds__(64) void b3w_commit_window_kernel(const uint32_t *_
       point(b, !((m >> b) & 1), x, y);
       j9_madd(acc, x, y, C9);
     }
-    const F9 Z = acc.inf ? one29(C9) : red29(acc.Z, C9);
+    const F9 A = acc.inf ? one29(C9) : mul29(acc.ZZ, acc.ZZZ, C9);      // what has to be inverted: 1/ZZ = ZZZ / A, 1/ZZZ = ZZ / A
 #pragma unroll
-    for (int l = 0; l < 9; ++l) { at(0, e, l) = acc.X.l[l]; at(1, e, l) = acc.Y.l[l]; at(2, e, l) = acc.inf ? 0u : Z.l[l]; }
-    F9 c;                                                     // prefix product of the (finite) Zs
-    if (e == 0) c = Z;
+    for (int l = 0; l < 9; ++l) {
+      at(0, e, l) = acc.X.l[l]; at(1, e, l) = acc.Y.l[l];
+      at(2, e, l) = acc.inf ? 0u : acc.ZZ.l[l]; at(3, e, l) = acc.inf ? 0u : acc.ZZZ.l[l];
+    }
+    F9 c;                                                     // prefix product of the (finite) As
+    if (e == 0) c = A;
     else {
 #pragma unroll
-      for (int l = 0; l < 9; ++l) c.l[l] = at(3, e - 1, l);
-      c = mul29(c, Z, C9);
+      for (int l = 0; l < 9; ++l) c.l[l] = at(4, e - 1, l);
+      c = mul29(c, A, C9);
     }
 #pragma unroll
-    for (int l = 0; l < 9; ++l) at(3, e, l) = c.l[l];
+    for (int l = 0; l < 9; ++l) at(4, e, l) = c.l[l];
   }
   F9 inv;
 #pragma unroll
-  for (int l = 0; l < 9; ++l) inv.l[l] = at(3, K - 1, l);
-  inv = inv29(inv, C.pm2, C9);                                // 1 / (Z_0 ... Z_{K-1})
+  for (int l = 0; l < 9; ++l) inv.l[l] = at(4, K - 1, l);
+  inv = inv29(inv, C.pm2, C9);                                // 1 / (A_0 ... A_{K-1})
 #pragma unroll 1
   for (int e = K - 1; e >= 0; --e) {
-    F9 X, Y, Z, zi = inv;
+    F9 X, Y, ZZ, ZZZ, ia = inv;
     uint32_t z = 0;
 #pragma unroll
-    for (int l = 0; l < 9; ++l) { X.l[l] = at(0, e, l); Y.l[l] = at(1, e, l); Z.l[l] = at(2, e, l); z |= Z.l[l]; }
+    for (int l = 0; l < 9; ++l) { X.l[l] = at(0, e, l); Y.l[l] = at(1, e, l); ZZ.l[l] = at(2, e, l); ZZZ.l[l] = at(3, e, l); z |= ZZ.l[l]; }
     if (z) {                                                  // finite: it took part in the product
       if (e > 0) {
         F9 c;
 #pragma unroll
-        for (int l = 0; l < 9; ++l) c.l[l] = at(3, e - 1, l);
-        zi = mul29(inv, c, C9);                               // 1 / Z_e
+        for (int l = 0; l < 9; ++l) c.l[l] = at(4, e - 1, l);
+        ia = mul29(inv, c, C9);                               // 1 / A_e
       }
-      inv = mul29(inv, Z, C9);
+      inv = mul29(inv, mul29(ZZ, ZZZ, C9), C9);
     }
     const uint32_t g = g0 + e, m = g ^ (g >> 1);
     if (m == 0) continue;                                     // the empty subset has no entry
     Fp x = fp_zero(), y = fp_zero();
     if (z) {
-      const F9 zi2 = sqr29(zi, C9);
       uint32_t hi;
-      x = from29(mul29(X, zi2, C9), hi); x = fp_reduce_once(x, hi, C);
-      y = from29(mul29(Y, mul29(zi2, zi, C9), C9), hi); y = fp_reduce_once(y, hi, C);
+      x = from29(mul29(X, mul29(ia, ZZZ, C9), C9), hi); x = fp_reduce_once(x, hi, C);
+      y = from29(mul29(Y, mul29(ia, ZZ, C9), C9), hi); y = fp_reduce_once(y, hi, C);
     }
     uint32_t *o = table + ((uint64_t)win * B3W_COMMIT_ENTRIES(W) + m - 1) * 16;
     store_fp(o, x);
@@ -682,9 +681,9 @@ __global__ __launch_bounds__(T * WPB) __attribute__((amdgpu_waves_per_eu(3, 3)))
                                                          const uint32_t *__restrict__ slotdesc /* per committed slot: first virtual slot | width code << 24 */,
                                                          const uint32_t *__restrict__ images /* or null: TRACE images, word j of witness w at [j * img_row + w] */,
                                                          uint32_t img_row, const uint2 *__restrict__ runs, uint32_t nruns,
-                                                         uint32_t region_words /* LDS words per witness: max(bit string, 27 T) */,
+                                                         uint32_t region_words /* LDS words per witness: max(bit string, 36 T) */,
                                                          const uint32_t *__restrict__ table /* radix 2^261 */, uint32_t nwin,
-                                                         uint32_t *__restrict__ sums /* n x B3W_COMMIT_SUM_WORDS: X Y Z in 29-bit limbs */,
+                                                         uint32_t *__restrict__ sums /* n x B3W_COMMIT_SUM_WORDS: X Y ZZ ZZZ in 29-bit limbs */,
                                                          int32_t *__restrict__ status, CV C) {
   extern __shared__ uint32_t lds[];
   __shared__ uint32_t bad[WPB];
@@ -778,26 +777,26 @@ __global__ __launch_bounds__(T * WPB) __attribute__((amdgpu_waves_per_eu(3, 3)))
   }
   __syncthreads();                                           // every lane is done with the bit string: the tree takes its place
   // LDS tree over each witness's T partial sums (infinity travels as Z = 0)
-  uint32_t *mine = packed + t * 27;
+  uint32_t *mine = packed + t * 36;
   auto put = [&](const J9 &a) {
 #pragma unroll
-    for (int i = 0; i < 9; ++i) { mine[i] = a.X.l[i]; mine[9 + i] = a.Y.l[i]; mine[18 + i] = a.inf ? 0u : a.Z.l[i]; }
+    for (int i = 0; i < 9; ++i) { mine[i] = a.X.l[i]; mine[9 + i] = a.Y.l[i]; mine[18 + i] = a.inf ? 0u : a.ZZ.l[i]; mine[27 + i] = a.inf ? 0u : a.ZZZ.l[i]; }
   };
   auto get = [&](const uint32_t *src) {
     J9 a;
     uint32_t z = 0;
 #pragma unroll
-    for (int i = 0; i < 9; ++i) { a.X.l[i] = src[i]; a.Y.l[i] = src[9 + i]; a.Z.l[i] = src[18 + i]; z |= src[18 + i]; }
+    for (int i = 0; i < 9; ++i) { a.X.l[i] = src[i]; a.Y.l[i] = src[9 + i]; a.ZZ.l[i] = src[18 + i]; a.ZZZ.l[i] = src[27 + i]; z |= src[18 + i]; }
     a.inf = z == 0;
     return a;
   };
   put(acc);
   __syncthreads();
   for (uint32_t st = T / 2; st >= 1; st >>= 1) {
-    if (t < st) { J9 a = get(mine); j9_add(a, get(mine + st * 27), C); put(a); }
+    if (t < st) { J9 a = get(mine); j9_add(a, get(mine + st * 36), C); put(a); }
     __syncthreads();
   }
-  if (live && t < 27) sums[(uint64_t)w * B3W_COMMIT_SUM_WORDS + t] = packed[t];   // normalised by the next kernel
+  if (live) for (uint32_t i = t; i < 36; i += T) sums[(uint64_t)w * B3W_COMMIT_SUM_WORDS + i] = packed[i];   // normalised by the next kernel
   if (live && t == 0 && status) status[w] = bad[sub] ? 103 : 0;
 }
 
@@ -808,24 +807,22 @@ __global__ __launch_bounds__(64) void b3w_commit_normalize_kernel(const uint32_t
                                                                   B3wCurve C, CV C9) {
   const uint32_t w = blockIdx.x * 64 + threadIdx.x;
   if (w >= n) return;
-  F9 co[3];
+  F9 co[4];                                                  // X, Y, ZZ, ZZZ (tidy < 2p)
   uint32_t z = 0;
 #pragma unroll
-  for (int c = 0; c < 3; ++c)
+  for (int c = 0; c < 4; ++c)
 #pragma unroll
     for (int i = 0; i < 9; ++i) co[c].l[i] = sums[(uint64_t)w * B3W_COMMIT_SUM_WORDS + c * 9 + i];
 #pragma unroll
   for (int i = 0; i < 9; ++i) z |= co[2].l[i];
   Fp x = fp_zero(), y = fp_zero();                           // infinity -> (0, 0)
   if (z) {
-    const F9 Z = red29(co[2], C9);
-    const F9 zi = inv29(Z, C.pm2, C9);
-    const F9 zi2 = sqr29(zi, C9);
+    const F9 ia = inv29(mul29(co[2], co[3], C9), C.pm2, C9);  // 1 / (ZZ * ZZZ): 1/ZZ = ZZZ * ia, 1/ZZZ = ZZ * ia
     F9 unit;
 #pragma unroll
     for (int i = 0; i < 9; ++i) unit.l[i] = i == 0 ? 1u : 0u;
-    const F9 xs = mul29(mul29(co[0], zi2, C9), unit, C9);    // out of Montgomery form: < 2p
-    const F9 ys = mul29(mul29(co[1], mul29(zi2, zi, C9), C9), unit, C9);
+    const F9 xs = mul29(mul29(co[0], mul29(ia, co[3], C9), C9), unit, C9);    // out of Montgomery form: < 2p
+    const F9 ys = mul29(mul29(co[1], mul29(ia, co[2], C9), C9), unit, C9);
     uint32_t hi;
     x = from29(xs, hi); x = fp_reduce_once(x, hi, C);
     y = from29(ys, hi); y = fp_reduce_once(y, hi, C);
@@ -920,7 +917,7 @@ extern "C" int b3w_launch_commit(const uint8_t *d_bodies, uint32_t n, uint64_t p
   static_cast<B3wCurve9 &>(c9v) = c9;
 #define B3W_COMMIT_LAUNCH(T, WPB, W, CV, cv)                                                                              \
   {                                                                                                                       \
-    const uint32_t region = bits_words > 27u * T ? bits_words : 27u * T;                                                  \
+    const uint32_t region = bits_words > 36u * T ? bits_words : 36u * T;                                                  \
     hipLaunchKernelGGL((b3w_commit_kernel<T, WPB, W, CV>), dim3((n + WPB - 1) / WPB), dim3(T * WPB), region * WPB * 4, stream, d_bodies, n, \
                        pitch, first_slot, nslots, d_slotdesc, d_images, img_row, reinterpret_cast<const uint2 *>(d_runs), nruns, region, d_table, nwin, \
                        d_sums, d_status, cv);                                                                             \

@@ -44,7 +44,7 @@ extern "C" void b3w_place_trim(void);
 #define B3W_COMMIT_WINDOW_SMALL 12
 #define B3W_COMMIT_WINDOW_LARGE 16
 #define B3W_COMMIT_ENTRIES(W) ((1u << (W)) - 1u)
-#define B3W_COMMIT_SUM_WORDS 28        // per witness between the commit and the normalise kernel: X, Y, Z in nine 29-bit limbs each
+#define B3W_COMMIT_SUM_WORDS 36        // per witness between the commit and the normalise kernel: X, Y, ZZ, ZZZ in nine 29-bit limbs each
 // Field of the curve's coordinates:
 struct B3wCurve {
   uint32_t p[8];      // modulus, little-endian limbs
