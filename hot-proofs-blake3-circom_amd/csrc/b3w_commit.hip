@@ -13,8 +13,8 @@
 //            4 095 non-empty subset sums are tabulated (b3w_commit_window_kernel: 4.5 k windows x 4 095 affine points = 1.2 GB; or W = 16:
 //            3.3 k windows x 65 535 points = 14 GB);
 //   commit   32 or 64 lanes per witness: they stream the body once and pack its virtual-slot bits into LDS; lane t then owns
-//            windows t, t + T, ...: it skips ahead to its next NON-ZERO window and the wave does one mixed Jacobian +
-//            affine addition with the tabulated point — no doublings, one addition per W slots, no zero work in lock
+//            windows t, t + T, ...: it skips ahead to its next NON-ZERO window and the wave does one mixed (XYZZ +
+//            affine) addition with the tabulated point — no doublings, one addition per W slots, no zero work in lock
 //            step; an LDS tree adds the partial sums; a second kernel normalises them, one thread per witness
 //            (Fermat inversion), and stores the affine points.
 // Arithmetic: 256-bit Montgomery, modulus passed at run time.  The per-slot doubling chains of the set-up use the textbook
@@ -581,7 +581,7 @@ __global__ __launch_bounds__(64) void b3w_commit_setup_kernel(const uint32_t *__
 // (affine, radix 2^261, eight 32-bit words; infinity = (0, 0)).  A thread walks K = 4 consecutive entries in Gray-code
 // order — the first from scratch, each next one is the previous +/- one point — and the four share one inversion
 // (Montgomery's trick), so an entry costs ~3 additions and a quarter of an inversion instead of W/2 additions and a
-// whole one.  The thread's Jacobian results and prefix products wait in LDS ([entry][limb][thread]: conflict-free).
+// whole one.  The thread's projective results and prefix products wait in LDS ([entry][limb][thread]: conflict-free).
 #define B3W_WINDOW_K 4
 template <int W>
 __global__ __launch_bounds__(64) void b3w_commit_window_kernel(const uint32_t *__restrict__ points, uint32_t nwin,
