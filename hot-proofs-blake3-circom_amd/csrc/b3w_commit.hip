@@ -339,6 +339,35 @@ __device__ __forceinline__ F9 mul29(const F9 &a, const F9 &b, const CV &C) {
   r.l[8] = (uint32_t)acc;
   return r;
 }
+// (a b + c d) / 2^261: two products, ONE reduction.  Column bound: 9 (la lb + lc ld) + 9 * 2^58 < 2^64, i.e.
+// la lb + lc ld < 1.52 * 2^60 (e.g. 2^29 x 1.5 * 2^30 and 2^30 x 2^29); a < Ap ... d < Dp  ->  tidy, < ((AB + CD)/64 + 1)p
+template <class CV>
+__device__ __forceinline__ F9 muladd29(const F9 &a, const F9 &b, const F9 &c, const F9 &d, const CV &C) {
+  uint64_t acc = 0;
+  uint32_t m[9];
+  F9 r;
+#pragma unroll
+  for (int k = 0; k < 9; ++k) {
+#pragma unroll
+    for (int i = 0; i <= k; ++i) { acc += (uint64_t)a.l[i] * b.l[k - i]; acc += (uint64_t)c.l[i] * d.l[k - i]; }
+#pragma unroll
+    for (int i = 0; i < k; ++i) acc += (uint64_t)m[i] * C.P(k - i);
+    m[k] = ((uint32_t)acc * C.INV()) & M29;
+    acc += (uint64_t)m[k] * C.P(0);
+    acc >>= 29;
+  }
+#pragma unroll
+  for (int k = 9; k < 17; ++k) {
+#pragma unroll
+    for (int i = k - 8; i < 9; ++i) { acc += (uint64_t)a.l[i] * b.l[k - i]; acc += (uint64_t)c.l[i] * d.l[k - i]; }
+#pragma unroll
+    for (int i = k - 8; i < 9; ++i) acc += (uint64_t)m[i] * C.P(k - i);
+    r.l[k - 9] = (uint32_t)acc & M29;
+    acc >>= 29;
+  }
+  r.l[8] = (uint32_t)acc;
+  return r;
+}
 template <class CV>
 __device__ __forceinline__ F9 sqr29(const F9 &a, const CV &C) {      // limbs < 2^30
   uint64_t acc = 0;
@@ -522,9 +551,8 @@ __device__ __forceinline__ void j9_madd(J9 &P, const F9 &x2, const F9 &y2, const
   const F9 PP = sqr29(Pd, C);                                      // < 2p   (36 / 64 + 1)
   const F9 PPP = mul29(Pd, PP, C), Q = mul29(P.X, PP, C);          // < 2p
   const F9 X3 = red29(add29(add29(sqr29(R, C), neg29(PPP, C)), shl29(neg29(Q, C), 1)), C);    // R^2 - PPP - 2Q  (< 14p before)
-  const F9 T1 = mul29(R, sub29(Q, X3, C), C), T2 = mul29(P.Y, PPP, C);                 // < 2p each
+  P.Y = muladd29(R, sub29(Q, X3, C), neg29(P.Y, C), PPP, C);       // R (Q - X3) + (4p - Y1) PPP: (6 * 5.1 + 4 * 1.2)/64 + 1 < 2p
   P.X = X3;
-  P.Y = red29(add29(T1, neg29(T2, C)), C);                         // R (Q - X3) - Y1 PPP  (< 6p before)
   P.ZZ = mul29(P.ZZ, PP, C);
   P.ZZZ = mul29(P.ZZZ, PPP, C);
 }
