@@ -804,11 +804,12 @@ __global__ __launch_bounds__(T * WPB) __attribute__((amdgpu_waves_per_eu(3, 3)))
     }
   }
   __syncthreads();                                           // every lane is done with the bit string: the tree takes its place
-  // LDS tree over each witness's T partial sums (infinity travels as Z = 0)
-  uint32_t *mine = packed + t * 36;
-  auto put = [&](const J9 &a) {
+  // LDS tree over each witness's T partial sums (infinity travels as ZZ = 0).  The additions of all WPB witnesses of a
+  // level are dealt to the first threads of the workgroup, so whole waves drop out instead of running half empty
+  // (one witness per wave spent 6 nearly empty wave-wide additions here: 10 % of the kernel).
+  auto put = [&](uint32_t *dst, const J9 &a) {
 #pragma unroll
-    for (int i = 0; i < 9; ++i) { mine[i] = a.X.l[i]; mine[9 + i] = a.Y.l[i]; mine[18 + i] = a.inf ? 0u : a.ZZ.l[i]; mine[27 + i] = a.inf ? 0u : a.ZZZ.l[i]; }
+    for (int i = 0; i < 9; ++i) { dst[i] = a.X.l[i]; dst[9 + i] = a.Y.l[i]; dst[18 + i] = a.inf ? 0u : a.ZZ.l[i]; dst[27 + i] = a.inf ? 0u : a.ZZZ.l[i]; }
   };
   auto get = [&](const uint32_t *src) {
     J9 a;
@@ -818,10 +819,15 @@ __global__ __launch_bounds__(T * WPB) __attribute__((amdgpu_waves_per_eu(3, 3)))
     a.inf = z == 0;
     return a;
   };
-  put(acc);
+  put(packed + t * 36, acc);
   __syncthreads();
   for (uint32_t st = T / 2; st >= 1; st >>= 1) {
-    if (t < st) { J9 a = get(mine); j9_add(a, get(mine + st * 36), C); put(a); }
+    if (threadIdx.x < WPB * st) {
+      uint32_t *m = lds + (threadIdx.x / st) * region_words + (threadIdx.x % st) * 36;
+      J9 a = get(m);
+      j9_add(a, get(m + st * 36), C);
+      put(m, a);
+    }
     __syncthreads();
   }
   if (live) for (uint32_t i = t; i < 36; i += T) sums[(uint64_t)w * B3W_COMMIT_SUM_WORDS + i] = packed[i];   // normalised by the next kernel
@@ -951,12 +957,12 @@ extern "C" int b3w_launch_commit(const uint8_t *d_bodies, uint32_t n, uint64_t p
                        d_sums, d_status, cv);                                                                             \
   }
   if (window == B3W_COMMIT_WINDOW_LARGE) {
-    if (vesta) B3W_COMMIT_LAUNCH(64, 1, B3W_COMMIT_WINDOW_LARGE, B3wCurve9Vesta, c9v)
-    else if (tpw == 64) B3W_COMMIT_LAUNCH(64, 1, B3W_COMMIT_WINDOW_LARGE, B3wCurve9, c9)
+    if (vesta) B3W_COMMIT_LAUNCH(64, 4, B3W_COMMIT_WINDOW_LARGE, B3wCurve9Vesta, c9v)
+    else if (tpw == 64) B3W_COMMIT_LAUNCH(64, 4, B3W_COMMIT_WINDOW_LARGE, B3wCurve9, c9)
     else B3W_COMMIT_LAUNCH(32, 2, B3W_COMMIT_WINDOW_LARGE, B3wCurve9, c9)
   } else {
-    if (vesta) B3W_COMMIT_LAUNCH(64, 1, B3W_COMMIT_WINDOW_SMALL, B3wCurve9Vesta, c9v)
-    else if (tpw == 64) B3W_COMMIT_LAUNCH(64, 1, B3W_COMMIT_WINDOW_SMALL, B3wCurve9, c9)
+    if (vesta) B3W_COMMIT_LAUNCH(64, 4, B3W_COMMIT_WINDOW_SMALL, B3wCurve9Vesta, c9v)
+    else if (tpw == 64) B3W_COMMIT_LAUNCH(64, 4, B3W_COMMIT_WINDOW_SMALL, B3wCurve9, c9)
     else B3W_COMMIT_LAUNCH(32, 2, B3W_COMMIT_WINDOW_SMALL, B3wCurve9, c9)
   }
 #undef B3W_COMMIT_LAUNCH
