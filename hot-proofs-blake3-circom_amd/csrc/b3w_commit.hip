@@ -952,6 +952,7 @@ extern "C" int b3w_launch_commit(const uint8_t *d_bodies, uint32_t n, uint64_t p
 #define B3W_COMMIT_LAUNCH(T, WPB, W, CV, cv)                                                                              \
   {                                                                                                                       \
     const uint32_t region = bits_words > 36u * T ? bits_words : 36u * T;                                                  \
+    if ((size_t)region * WPB * 4 > 64 * 1024) return (int)hipErrorInvalidValue;   /* LDS of one workgroup (nova O1: 54 KB) */ \
     hipLaunchKernelGGL((b3w_commit_kernel<T, WPB, W, CV>), dim3((n + WPB - 1) / WPB), dim3(T * WPB), region * WPB * 4, stream, d_bodies, n, \
                        pitch, first_slot, nslots, d_slotdesc, d_images, img_row, reinterpret_cast<const uint2 *>(d_runs), nruns, region, d_table, nwin, \
                        d_sums, d_status, cv);                                                                             \
