@@ -576,12 +576,16 @@ __device__ __forceinline__ void j9_add(J9 &P, const J9 &Q, const CV &C) {
   P.X = X3;
 }
 
-// ---- set-up: points[first_v[s] + k] = 2^k * G_s (affine, Montgomery radix 2^261, eight 32-bit words) for every committed slot s
+// ---- set-up: points[first_v[s] + k] = 2^k * G_s (affine, Montgomery radix 2^261, eight 32-bit words) for every committed slot s.
+// One workgroup per slot, thread t takes bits t, t + 64, ...: t doublings to get there (a single thread walking all 256
+// bits of a field-element slot, with an inversion per bit, was the whole key set-up time of the 12-bit tables).
 __global__ __launch_bounds__(64) void b3w_commit_setup_kernel(const uint32_t *__restrict__ gens /* nslots x 16 words, standard form */,
                                                               const uint32_t *__restrict__ first_v, const uint32_t *__restrict__ nbits,
                                                               uint32_t nslots, uint32_t *__restrict__ points, B3wCurve C) {
-  const uint32_t s = blockIdx.x * 64 + threadIdx.x;
+  const uint32_t s = blockIdx.x, t = threadIdx.x;
   if (s >= nslots) return;
+  const uint32_t nb = nbits[s], v0 = first_v[s];
+  if (t >= nb) return;
   Fp r2;
 #pragma unroll
   for (int i = 0; i < 8; ++i) r2.l[i] = C.r2[i];
@@ -595,13 +599,17 @@ __global__ __launch_bounds__(64) void b3w_commit_setup_kernel(const uint32_t *__
   for (int k = 0; k < 8; ++k) c32.l[k] = C.one[k];
 #pragma unroll 1
   for (int k = 0; k < 5; ++k) c32 = fp_dbl(c32, C);
-  const uint32_t nb = nbits[s], v0 = first_v[s];
-  for (uint32_t k = 0; k < nb; ++k) {
+#pragma unroll 1
+  for (uint32_t i = 0; i < t; ++i) P = jac_dbl(P, C);
+#pragma unroll 1
+  for (uint32_t k = t; k < nb; k += 64) {
     Fp x, y;
     if (k == 0) { x = P.X; y = P.Y; } else jac_to_affine(P, x, y, C);
     store_fp(points + (uint64_t)(v0 + k) * 16, fp_mul(x, c32, C));
     store_fp(points + (uint64_t)(v0 + k) * 16 + 8, fp_mul(y, c32, C));
-    if (k + 1 < nb) P = jac_dbl(P, C);
+    if (k + 64 < nb)
+#pragma unroll 1
+      for (int i = 0; i < 64; ++i) P = jac_dbl(P, C);
   }
 }
 
@@ -913,7 +921,7 @@ B3wCurve9 make_curve9(const B3wCurve &C) {
 extern "C" int b3w_launch_commit_setup(const uint32_t *d_gens, const uint32_t *d_first_v, const uint32_t *d_nbits, uint32_t nslots,
                                        uint32_t *d_points, const B3wCurve *curve, hipStream_t stream) {
   if (!nslots) return 0;
-  hipLaunchKernelGGL(b3w_commit_setup_kernel, dim3((nslots + 63) / 64), dim3(64), 0, stream, d_gens, d_first_v, d_nbits, nslots, d_points, *curve);
+  hipLaunchKernelGGL(b3w_commit_setup_kernel, dim3(nslots), dim3(64), 0, stream, d_gens, d_first_v, d_nbits, nslots, d_points, *curve);
   return (int)hipGetLastError();
 }
 

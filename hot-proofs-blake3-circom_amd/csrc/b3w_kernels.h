@@ -40,7 +40,7 @@ extern "C" void b3w_place_trim(void);
 
 // b3w_commit.hip: Pedersen commitments of witness bodies (on-device consumer).
 // Window width W (virtual slots per window, 2^W - 1 tabulated subset sums each) is a property of the key:
-//   12: 1.2 GB table, 0.1 s set-up;   16: 14 GB table, 0.3 s set-up, a quarter fewer additions per witness (+15-18 %)
+//   12: 1.2 GB table, 0.03 s set-up;   16: 14 GB table, 0.3 s set-up, a quarter fewer additions per witness (+15-18 %)
 #define B3W_COMMIT_WINDOW_SMALL 12
 #define B3W_COMMIT_WINDOW_LARGE 16
 #define B3W_COMMIT_ENTRIES(W) ((1u << (W)) - 1u)

@@ -173,7 +173,7 @@ int32_t b3w_batch_verify_device(b3w_ctx *ctx, const uint8_t *d_bodies, uint32_t 
 typedef struct b3w_commit_key b3w_commit_key;
 int32_t b3w_commit_key_create(b3w_ctx *ctx, int32_t curve, uint32_t first_slot, const uint8_t *host_generators, b3w_commit_key **out);
 /* The same with the table's window width chosen by the caller: every `window_bits` consecutive bits of the witness share one
- * table of 2^window_bits - 1 precomputed subset sums.  12: 1.2-1.3 GB of HBM, 0.1 s set-up;  16: 14-15 GB, 0.3 s, a
+ * table of 2^window_bits - 1 precomputed subset sums.  12: 1.2-1.3 GB of HBM, 0.03 s set-up;  16: 14-15 GB, 0.3 s, a
  * quarter fewer point additions per witness (+15-18 % throughput).  0 = automatic (b3w_commit_key_create): the
  * environment's B3W_COMMIT_WINDOW, else 16 when that table takes at most a quarter of the free device memory. */
 int32_t b3w_commit_key_create_ex(b3w_ctx *ctx, int32_t curve, uint32_t first_slot, const uint8_t *host_generators, uint32_t window_bits,
