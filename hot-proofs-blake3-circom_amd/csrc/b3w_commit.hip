@@ -12,10 +12,11 @@
 //            the point 2^k * G_slot each (b3w_commit_setup_kernel); W = 12 consecutive virtual slots form a WINDOW whose
 //            4 095 non-empty subset sums are tabulated (b3w_commit_window_kernel: 4.5 k windows x 4 095 affine points = 1.2 GB; or W = 16:
 //            3.3 k windows x 65 535 points = 14 GB);
-//   commit   32 or 64 lanes per witness: they stream the body once and pack its virtual-slot bits into LDS; lane t then owns
+//   commit   32 or 64 lanes per witness: they stream the body once and pack its virtual-slot bits into LDS (records mode:
+//            the same bits from the witness's 3.7-11 KB TRACE image — no body at all); lane t then owns
 //            windows t, t + T, ...: it skips ahead to its next NON-ZERO window and the wave does one mixed (XYZZ +
 //            affine) addition with the tabulated point — no doublings, one addition per W slots, no zero work in lock
-//            step; an LDS tree adds the partial sums; a second kernel normalises them, one thread per witness
+//            step; an LDS tree shared by the workgroup's witnesses adds the partial sums; a second kernel normalises them, one thread per witness
 //            (Fermat inversion), and stores the affine points.
 // Arithmetic: 256-bit Montgomery, modulus passed at run time.  The per-slot doubling chains of the set-up use the textbook
 // CIOS on eight 32-bit limbs; the table, commit and normalise kernels use nine 29-bit limbs (radix 2^261, lazy reduction: see the
