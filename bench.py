@@ -1,19 +1,21 @@
 #!/usr/bin/env python3
-"""bench.py — BLAKE3-compression witnesses/s on MI355X (BASELINE.json metric, config 2).
+"""bench.py — BLAKE3-compression witnesses/s on MI355X (BASELINE.json metric; N=1 workload = config 2).
 
-A step = one pass of the hot path over one batch: 4096 independent blake3_compression witnesses
-(BN254) per GPU, inputs already resident in HBM, witness bodies written to HBM (3.16 GB per
-step and GPU).  With N > 1 GPUs every rank runs its own 4096 instances (weak scaling; instance
-ids rank*4096 ...) and the ranks all-gather the per-witness public outputs over RCCL.
+A launch = one pass of the hot path over one batch: 4096 independent blake3_compression witnesses (BN254) per GPU,
+inputs already resident in HBM, witness bodies written to HBM (3.16 GB per launch and GPU).  A launch lasts 0.44 ms,
+so a timed STEP is `--inner` back-to-back launches over the same batch (default: as many as make the K timed steps
+last >= 1 s; `config.launches_per_step` says how many) — sustained clocks, not a 9 ms burst.  With N > 1 GPUs every
+rank runs its own 4096 instances (weak scaling; instance ids rank*4096 ...) and the ranks all-gather the per-witness
+public outputs over RCCL after every launch, pipelined with the next launch.
 
-  python bench.py [--gpus N] [--steps K] [--warmup W]
-  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+  python bench.py [--gpus N] [--steps K] [--warmup W]          N > 1: spawns one fresh child process per GPU itself
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...      (the launcher form works too)
 
-Prints ONE JSON line on rank 0 (see the driver contract) with `roofline` (HBM-write bound
-kernel: algorithmic bytes / HIP-event kernel time) and `cpu_baseline` (the C oracle timed on
-one host core on a bounded sample of the same workload).
+Prints ONE JSON line on rank 0 (see the driver contract) with `roofline` (HBM-write bound kernel: algorithmic
+bytes / HIP-event kernel time) and, at N = 1, `cpu_baseline` (the C oracle timed on all host cores on a bounded
+sample of the same workload, with the reference WASM's rate quoted beside it).
 """
-import argparse, importlib, json, os, sys, time
+import argparse, importlib, json, math, os, sys, time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -22,44 +24,114 @@ if ROOT not in sys.path:
 HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (about 6.3 TB/s achievable)
 BYTES_PER_WITNESS = {"compression": 770976 + 112, "nova_bn254": 745312 + 128, "nova_vesta": 745312 + 128,
                      "nova_bn254_o1": 787648 + 128}   # body written + record read
+FIELD = {"compression": "BN254", "nova_bn254": "BN254", "nova_vesta": "Vesta", "nova_bn254_o1": "BN254"}
+# BASELINE.md section 2 (survey session, build container, reference WASM under its own witness_calculator.js)
+REFERENCE_WASM = {"compression": 5.0, "nova_vesta": 4.7, "nova_bn254": 5.3}
+
+
+def self_launch(n, argv):
+    """`python bench.py --gpus N` without a launcher: N fresh child processes, one rank per GPU, started BEFORE this
+    process has touched HIP (it never does: the parent only waits).  Rank 0's child prints the JSON line; the parent
+    exits with the first non-zero child status, after ending the other children (they would wait in a collective)."""
+    import socket, subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        env.setdefault("OMP_NUM_THREADS", "1")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *argv], env=env))
+    rc = 0
+    live = list(procs)
+    while live:
+        time.sleep(0.1)
+        for p in list(live):
+            st = p.poll()
+            if st is None:
+                continue
+            live.remove(p)
+            if st != 0 and rc == 0:
+                rc = st if st > 0 else 128 - st
+                for q in live:                      # exactly the children started above
+                    q.terminate()
+    return rc
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
 
 
 def cpu_baseline(circuit, recs, budget_s):
-    """Time the oracle (oracle/libb3w_oracle.so, the CPU restatement = "port") on one core over a
-    bounded sample of the same records.  Checker code, used here only as the reported baseline."""
+    """Time the oracle (oracle/libb3w_oracle.so, the CPU restatement = "port") on ALL host cores this process may
+    use, over a bounded sample of the same records.  Checker code, used here only as the reported baseline; the
+    reference WASM cannot travel to the GPU box, so its build-container rate is quoted."""
+    import ctypes, threading
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import b3w_testlib as T
     import numpy as np
-    sample = recs[:256]
-    T.oracle_batch_u32(circuit, sample)                       # warm-up: faults the output buffer in
-    done, t0 = 0, time.perf_counter()
-    while True:
-        bad, _ = T.oracle_batch_u32(circuit, sample)
-        assert bad == 0
-        done += sample.shape[0]
-        dt = time.perf_counter() - t0
-        if dt >= budget_s:
-            break
-    return {"value": done / dt, "unit": "witnesses/s", "cores": 1, "kind": "port",
-            "sample": f"{done} witnesses ({done // sample.shape[0]} passes over the first {sample.shape[0]} "
-                      f"records of the workload) in {dt:.1f} s, C oracle, 1 thread"}
+    lib = T.oracle()                                          # ctypes releases the GIL inside the C call
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    sample = np.ascontiguousarray(recs[:128], dtype=np.uint32)
+    k, cid = sample.shape[0], T.CIRCUIT_ID[circuit]
+    bufs = [np.zeros((k, T.NWIT[circuit] * 32), dtype=np.uint8) for _ in range(cores)]
+    for b in bufs[:1]:
+        assert lib.b3wo_witness_batch_u32(cid, sample.ctypes.data, k, b.ctypes.data) == 0      # warm-up
+    done = [0] * cores
+    t_end = [0.0] * cores
+    t0 = time.perf_counter()
+
+    def work(i):
+        while time.perf_counter() - t0 < budget_s:
+            assert lib.b3wo_witness_batch_u32(cid, sample.ctypes.data, k, bufs[i].ctypes.data) == 0
+            done[i] += k
+        t_end[i] = time.perf_counter()
+    th = [threading.Thread(target=work, args=(i,)) for i in range(cores)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    dt = max(t_end) - t0
+    total = sum(done)
+    out = {"value": total / dt, "unit": "witnesses/s", "cores": cores, "kind": "port", "cpu": cpu_model(),
+           "per_core": total / dt / cores,
+           "sample": f"{total} witnesses ({cores} threads, each looping over the first {k} records of the workload) in "
+                     f"{dt:.1f} s, C oracle (oracle/b3w_oracle.c)"}
+    if circuit in REFERENCE_WASM:
+        out["reference_wasm"] = {"value": REFERENCE_WASM[circuit], "unit": "witnesses/s/core", "measured_here": False,
+                                 "where": "build container (Xeon 2.1 GHz, node 12), BASELINE.md section 2: the reference's "
+                                          "committed WASM under its own witness_calculator.js; it cannot travel to the GPU box"}
+    return out
+
+
+def gather_strings(dist, world, s):
+    if world == 1:
+        return [s]
+    out = [None] * world
+    dist.all_gather_object(out, s)
+    return out
 
 
 def bench_chain(args, m, torch, dist, dev, world, rank, local_rank):
     """Configs 4/5: a step = one pass over the whole preimage (plan + all leaf and parent step witnesses of this
-    rank's chunk range, bodies streamed through a ring of batch buffers).  Strong scaling: the preimage is fixed."""
-    import numpy as np
+    rank's chunk range, bodies streamed through a ring of batch buffers).  Strong scaling: the preimage is fixed.
+    Preimage = little-endian byte stream of LCG(1)."""
     circuit = args.circuit if args.circuit != "compression" else "nova_vesta"
     ctx = m.Context(circuit, local_rank)
     nbytes = int(args.preimage_mib * (1 << 20))
-    lcg_words = (np.arange(nbytes // 4 + 1, dtype=np.uint64) * np.uint64(2654435761) + np.uint64(12345)) & np.uint64(0xFFFFFFFF)
-    host = torch.from_numpy(lcg_words.astype(np.uint32).view(np.uint8)[:nbytes].copy()).pin_memory()
+    host = torch.from_numpy(m.workloads.lcg_preimage(nbytes, seed=1).copy()).pin_memory()
     consumer, key, commit_only = None, None, None
     if args.consumer != "none":                      # SURVEY.md 8(f) row 2: what the folding prover does with each step witness
-        sys.path.insert(0, os.path.join(ROOT, "tests"))
-        import ec_ref as E                             # plain-integer curve arithmetic: here only to make valid generators
+        K = importlib.import_module("hot-proofs-blake3-circom_amd.synthetic_key")
         curve = "vesta" if "vesta" in circuit else "bn254_g1"
-        key = m.CommitKey(ctx, curve, E.points_to_bytes(E.random_points(curve, ctx.witness_size, seed=b"bench")))
+        key = m.CommitKey(ctx, curve, K.generators(curve, ctx.witness_size, seed=b"bench"))
         n_max = m.lib().b3w_chain_num_chunks(nbytes) * 64 + 64
         d_pts = torch.zeros((n_max, 64), dtype=torch.uint8, device=dev)
         d_st = torch.zeros(n_max, dtype=torch.int32, device=dev)
@@ -96,16 +168,20 @@ def bench_chain(args, m, torch, dist, dev, world, rank, local_rank):
         elapsed, total_steps = tm[0].item(), ts[1].item()
     else:
         total_steps = float(local_steps)
+    placements = gather_strings(dist, world, out.get("placement"))
     if rank == 0:
         per = BYTES_PER_WITNESS[circuit] if commit_only is None else 128      # commit-only reads the 128-byte step records
         print(json.dumps({
             "metric": "BLAKE3-compression witnesses/sec", "value": total_steps * args.steps / elapsed, "unit": "witnesses/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
-            "config": {"workload": f"chain: {args.preimage_mib} MiB preimage -> {int(total_steps)} nova steps ({circuit}), "
+            "config": {"workload": f"config{5 if args.preimage_mib >= 1024 else 4}-style chain: {args.preimage_mib:g} MiB preimage "
+                                   f"(LE stream of LCG(1)) -> {int(total_steps)} nova steps ({circuit}), "
                                    "planner + witness kernels, bodies through a 2-deep ring, H2D overlapped",
                        "circuit": circuit, "n_chunks": out["n_chunks"], "path_len": out["path_len"],
-                       "placement": out.get("placement"),
+                       "placement": placements[0], "placement_per_rank": placements,
+                       "exchange": f"all_gather of chunk chaining values over {dist.get_world_size()} ranks "
+                                   f"({dist.get_backend()})" if world > 1 else "none",
                        "consumer": "none" if key is None else f"Pedersen commitment of every step witness on the device ({key.window}-bit windows)"
                                    + (", from the step records: no bodies written" if commit_only is not None else "")},
             "roofline": {"bound": "hbm", "achieved": total_steps * args.steps * per / elapsed / 1e9 / world, "peak": HBM_PEAK_GBS,
@@ -121,7 +197,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=4096, help="witnesses per GPU per step")
+    ap.add_argument("--inner", type=int, default=0,
+                    help="batch workload: launches per timed step (0 = as many as make the timed region last >= 1 s)")
+    ap.add_argument("--batch", type=int, default=4096, help="witnesses per GPU per launch")
     ap.add_argument("--circuit", default="compression")
     ap.add_argument("--variant", type=int, default=None, help="kernel tuning variant (B3W_VARIANT)")
     ap.add_argument("--pitch", type=int, default=0, help="body pitch in bytes (0 = contiguous bodies)")
@@ -138,6 +216,9 @@ def main():
                          "commitments straight from the step records, no bodies written)")
     args = ap.parse_args()
 
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args.gpus, sys.argv[1:]))      # nothing above has loaded torch or HIP
+
     import numpy as np
     import torch
     import torch.distributed as dist
@@ -148,18 +229,20 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N")
+    if args.gpus != world and rank == 0:
+        print(f"bench.py: --gpus {args.gpus} but the launcher started {world} ranks; using {world}", file=sys.stderr)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device: the product has no CPU path")
     ndev = torch.cuda.device_count()
-    if local_rank >= ndev and os.environ.get("B3W_DIST_BACKEND", "nccl") != "nccl":
+    backend = os.environ.get("B3W_DIST_BACKEND", "nccl")      # "nccl" = RCCL over xGMI; "gloo" only for dry runs
+    if local_rank >= ndev:
+        if backend == "nccl":
+            raise SystemExit(f"bench.py: rank {rank} has no GPU of its own ({ndev} visible, one rank per GPU); "
+                             "B3W_DIST_BACKEND=gloo rehearses several ranks on one GPU")
         local_rank = local_rank % ndev                      # dry run: several ranks share one GPU
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
-        backend = os.environ.get("B3W_DIST_BACKEND", "nccl")      # "nccl" = RCCL over xGMI; "gloo" only for dry runs
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
@@ -183,18 +266,18 @@ def main():
     stream = torch.cuda.current_stream()
 
     # the fold's exchange step (N > 1): all-gather of the per-step public outputs (h_out ...), pipelined — the gather
-    # of step i overlaps the kernel of step i+1 on RCCL's own stream (sharding.PublicExchange)
+    # of launch i overlaps the kernel of launch i+1 on RCCL's own stream (sharding.PublicExchange)
     ex = sharding.PublicExchange(n, npub, dev)
 
-    def step():
+    def launch():
         pub = ex.next_buffer()
         ctx.run_device(d_recs.data_ptr(), n, d_bodies.data_ptr(), pitch, pub.data_ptr(), d_status.data_ptr(),
                        stream.cuda_stream)
         ex.post()
 
     # Untimed set-up.  The body buffer comes from the library's placement allocator (b3w_bodies_alloc: its 256 MiB
-    # pieces alternate between two classes of HBM, DESIGN.md "Placement"), then the faster of the two bit-identical
-    # kernel paths is picked on that buffer.
+    # pieces alternate between two classes of HBM, DESIGN.md "Placement"), then the faster of the bit-identical
+    # kernel variants is picked on that buffer.
     if args.placement == "plain":
         os.environ["B3W_PLACEMENT"] = "plain"
     bodies = ctx.alloc_bodies(n * pitch)
@@ -212,32 +295,46 @@ def main():
                                               stream.cuda_stream)
     else:                                                   # (autotune leaves the winner selected in ctx)
         chosen = args.variant
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for _ in range(2):
+        launch()
+    ev0.record(stream)
+    for _ in range(4):
+        launch()
+    ev1.record(stream)
+    ex.finish()
+    torch.cuda.synchronize()
+    est = torch.tensor([ev0.elapsed_time(ev1) / 4], dtype=torch.float64, device=dev)
+    if world > 1:
+        dist.all_reduce(est, op=dist.ReduceOp.MAX)          # every rank must settle on the same launch count
+    inner = args.inner if args.inner > 0 else max(1, min(4096, math.ceil(1000.0 / (args.steps * max(est.item(), 1e-3)))))
     for _ in range(args.warmup):
-        step()
+        for _ in range(inner):
+            launch()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
-    # HIP events on the launch stream around the K launches: average launch duration = region / K (event records
-    # between the launches would cost 7 us per step: tools/ubench/launch_gap.py)
-    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    # HIP events on the launch stream around the K * inner launches: average launch duration = region / launches
+    # (event records between the launches would cost 7 us each: tools/ubench/launch_gap.py)
     t0 = time.perf_counter()
     ev0.record(stream)
     for i in range(args.steps):
-        pub = ex.next_buffer()
-        ctx.run_device(d_recs.data_ptr(), n, d_bodies.data_ptr(), pitch, pub.data_ptr(), d_status.data_ptr(),
-                       stream.cuda_stream)
-        ex.post()
+        for _ in range(inner):
+            launch()
     ev1.record(stream)
-    allpub = ex.finish()                                    # every step's exchange is inside the timed region
+    allpub = ex.finish()                                    # every launch's exchange is inside the timed region
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    kern_ms = ev0.elapsed_time(ev1) / args.steps                      # HIP events on the launch stream
+    launches = args.steps * inner
+    kern_ms = ev0.elapsed_time(ev1) / launches                        # HIP events on the launch stream
     assert int(d_status.abs().sum().item()) == 0, "a witness reported a non-zero status"
-    # untimed: every body of the last step is checked on the device (recompute-from-own-inputs)
+    if world > 1:                                           # the gathered buffer of the last launch: every rank's outputs
+        assert allpub.shape == (world * n, npub) and int((allpub[:, :npub].abs().sum(dim=1) == 0).sum().item()) == 0
+    # untimed: every body of the last launch is checked on the device
     d_mm = torch.full((n,), -1, dtype=torch.int32, device=dev)
     ctx.verify_device(d_bodies.data_ptr(), n, pitch, d_mm.data_ptr(), stream.cuda_stream)
     torch.cuda.synchronize()
@@ -247,21 +344,26 @@ def main():
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     elapsed, kern_ms = t[0].item(), t[1].item()
+    placements = gather_strings(dist, world, bodies.placement)
 
     if rank == 0:
-        total = world * n * args.steps
+        total = world * n * launches
         alg_bytes = BYTES_PER_WITNESS[circuit] * n                   # per launch
         achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
-        traffic = None
+        traffic, traffic_source = None, None
         tf = os.path.join(ROOT, "profiles", "traffic_latest.json")   # PMC passes (WRITE_SIZE/FETCH_SIZE), see profiles/README.md
         if os.path.exists(tf):
             try:
                 path = "sweep" if chosen >= 100 else "fused"
-                for ent in json.load(open(tf)).get("entries", []):
+                doc = json.load(open(tf))
+                for ent in doc.get("entries", []):
                     if ent.get("circuit") == circuit and ent.get("batch") == n and ent.get("path") == path:
                         traffic = ent.get("hbm_bytes_per_launch")
+                        traffic_source = (f"NOT measured by this run: profiles/r{int(doc.get('round', 0)):02d}/{ent.get('tag', circuit)}"
+                                          "_pmc_{WRITE,FETCH}_SIZE.csv (separate rocprofv3 --pmc passes of this command)")
             except Exception:
                 traffic = None
+        cfgname = "config2" if circuit == "compression" else "config3"
         out = {
             "metric": "BLAKE3-compression witnesses/sec",
             "value": total / elapsed,
@@ -275,17 +377,19 @@ def main():
             "vs_baseline": None,
             "dtype": "u32",
             "data": "synthetic",
-            "config": {"workload": f"config2: batch {n} independent {circuit} witnesses per GPU, "
-                                   f"{'BN254' if 'vesta' not in circuit else 'Vesta'} field, LCG(6429+i) inputs, "
-                                   "device-resident inputs and outputs",
-                       "circuit": circuit, "batch_per_gpu": n, "witness_bytes": ctx.body_bytes, "pitch": pitch,
+            "config": {"workload": f"{cfgname}: batch {n} independent {circuit} witnesses per GPU and launch, "
+                                   f"{FIELD[circuit]} field, LCG(6429+i) inputs, device-resident inputs and outputs; "
+                                   f"one step = {inner} launches over the batch",
+                       "circuit": circuit, "batch_per_gpu": n, "launches_per_step": inner, "witnesses_per_step": world * n * inner,
+                       "timed_region_s": elapsed, "witness_bytes": ctx.body_bytes, "pitch": pitch,
                        "kernel_variant": "sweep (TRACE + SWEEP kernels)" if chosen >= 100 else f"fused ({chosen})",
                        "verified_on_device": True,
-                       "placement": bodies.placement,
-                       "exchange": "all_gather of public outputs (RCCL), pipelined with the next step's kernel" if world > 1 else "none"},
+                       "placement": placements[0], "placement_per_rank": placements,
+                       "exchange": f"all_gather of public outputs over {dist.get_world_size()} ranks ({dist.get_backend()}), "
+                                   "pipelined with the next launch's kernel" if world > 1 else "none"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic,
-                         "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": alg_bytes},
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
+                         "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": alg_bytes, "launches_timed": launches},
         }
         if args.cpu_seconds > 0 and world == 1:
             out["cpu_baseline"] = cpu_baseline(circuit, recs, args.cpu_seconds)

@@ -34,7 +34,7 @@ def hipcc():
 
 def build_lib(force=False, extra_flags=()):
     srcs = [os.path.join(CSRC, f) for f in ("b3w_kernels.hip", "b3w_exact.hip", "b3w_plan.hip", "b3w_placement.hip", "b3w_commit.hip", "b3w_capi.cpp")]
-    deps = srcs + [os.path.join(CSRC, f) for f in ("b3w_atoms.h", "b3w_kernels.h", "b3w_layout_tables.inc")] + \
+    deps = srcs + [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".h", ".inc"))] + \
         [os.path.join(ROOT, "include", "b3wit.h")]
     if force or _newer(LIB, deps):
         _run([hipcc(), f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-shared", "-x", "hip",

@@ -7,6 +7,7 @@
 #include <stdlib.h>
 #include <string.h>
 #include <algorithm>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -328,6 +329,28 @@ int32_t hip_fail(b3w_ctx *ctx, hipError_t e, const char *what) {
     if (_e != hipSuccess) return hip_fail(ctx, _e, #call);  \
   } while (0)
 
+// Every entry point that touches the device runs with ctx->device current and puts the caller's device back on the
+// way out: a process may hold contexts on several GPUs (or torch may have another device selected), and a launch on
+// the null stream goes to whatever device is current.
+struct DeviceGuard {
+  int prev = -1;
+  bool switched = false;
+  hipError_t err = hipSuccess;
+  explicit DeviceGuard(int dev) {
+    err = hipGetDevice(&prev);
+    if (err == hipSuccess && prev != dev) {
+      err = hipSetDevice(dev);
+      switched = err == hipSuccess;
+    }
+  }
+  ~DeviceGuard() { if (switched) (void)hipSetDevice(prev); }
+  DeviceGuard(const DeviceGuard &) = delete;
+  DeviceGuard &operator=(const DeviceGuard &) = delete;
+};
+#define ON_DEVICE(ctx)                         \
+  DeviceGuard _dev_guard((ctx)->device);       \
+  if (_dev_guard.err != hipSuccess) return hip_fail(ctx, _dev_guard.err, "hipSetDevice")
+
 // word-major image scratch of the two-kernel (sweep) path
 int32_t ensure_scratch(b3w_ctx *ctx) {
   if (ctx->d_scratch) return B3W_OK;
@@ -380,7 +403,8 @@ int32_t b3w_create(int32_t circuit, int32_t device, b3w_ctx **out) {
   set_inputs(ctx);
   std::vector<uint32_t> table;
   if (!build_slot_table(ctx->desc, table, ctx->last_error)) { delete ctx; return B3W_E_BAD_ARGUMENT; }
-  if (hipSetDevice(device) != hipSuccess) { delete ctx; return B3W_E_NO_DEVICE; }
+  DeviceGuard guard(device);              // the caller's current device (torch's, say) is put back on return
+  if (guard.err != hipSuccess) { delete ctx; return B3W_E_NO_DEVICE; }
   const CircuitDesc &d = ctx->desc;
   hipError_t e = hipMalloc((void **)&ctx->d_table_base, (table.size() + 32) * 4);
   if (e == hipSuccess) e = hipMemset(ctx->d_table_base, 0, 32 * 4);
@@ -419,6 +443,7 @@ int32_t b3w_create(int32_t circuit, int32_t device, b3w_ctx **out) {
 
 void b3w_destroy(b3w_ctx *ctx) {
   if (!ctx) return;
+  DeviceGuard guard(ctx->device);
   if (ctx->d_table_base) (void)hipFree(ctx->d_table_base);
   if (ctx->d_aux) (void)hipFree(ctx->d_aux);
   if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
@@ -480,6 +505,7 @@ int32_t b3w_batch_run_device(b3w_ctx *ctx, const uint32_t *d_records, uint32_t n
   if (pitch == 0) pitch = body;
   if (pitch < body || (pitch & 31)) { ctx->last_error = "pitch must be >= witness_size*32 and a multiple of 32"; return B3W_E_BAD_ARGUMENT; }
   if (reinterpret_cast<uintptr_t>(d_bodies) & 15) { ctx->last_error = "d_bodies must be 16-byte aligned"; return B3W_E_BAD_ARGUMENT; }
+  ON_DEVICE(ctx);
   // default choice of bodies per wave (tools/ubench/small_batches.py, batch_sizes.py): small batches want as many
   // waves as bodies (one body streams at 13 GB/s per wave), large ones few fat waves
   int variant = ctx->variant;
@@ -506,6 +532,7 @@ int32_t b3w_batch_verify_device(b3w_ctx *ctx, const uint8_t *d_bodies, uint32_t 
     ctx->last_error = "pitch must be >= witness_size*32 and a multiple of 32, bodies 16-byte aligned";
     return B3W_E_BAD_ARGUMENT;
   }
+  ON_DEVICE(ctx);
   int rc = b3w_launch_verify(ctx->desc.kind, ctx->d_in_slots, n, d_bodies, pitch, ctx->d_table, ctx->desc.nwit, d_mismatch,
                              ctx->d_aux, (hipStream_t)stream);
   return rc ? hip_fail(ctx, (hipError_t)rc, "verify launch") : B3W_OK;
@@ -519,6 +546,7 @@ int32_t b3w_batch_autotune_device(b3w_ctx *ctx, const uint32_t *d_records, uint3
                                   uint32_t *d_public, int32_t *d_status, void *stream, int32_t *chosen_variant,
                                   float *chosen_ms) {
   if (!ctx || !d_records || !d_bodies || !n) return B3W_E_BAD_ARGUMENT;
+  ON_DEVICE(ctx);
   int32_t rc = ensure_scratch(ctx);
   if (rc) return rc;
   // fused with 4 (compression) / 2 (nova) bodies per wave, also with 8 (compression: for large batches occupancy-limited,
@@ -552,21 +580,23 @@ int32_t b3w_batch_autotune_device(b3w_ctx *ctx, const uint32_t *d_records, uint3
 int32_t b3w_batch_time_device(b3w_ctx *ctx, const uint32_t *d_records, uint32_t n, uint8_t *d_bodies, uint64_t pitch,
                               uint32_t *d_public, int32_t *d_status, void *stream, uint32_t iters, float *avg_ms) {
   if (!ctx || !avg_ms || !iters) return B3W_E_BAD_ARGUMENT;
-  hipEvent_t e0, e1;
-  HIP_TRY(ctx, hipEventCreate(&e0));
-  HIP_TRY(ctx, hipEventCreate(&e1));
-  HIP_TRY(ctx, hipEventRecord(e0, (hipStream_t)stream));
-  for (uint32_t i = 0; i < iters; i++) {
-    int32_t rc = b3w_batch_run_device(ctx, d_records, n, d_bodies, pitch, d_public, d_status, stream);
-    if (rc) return rc;
-  }
-  HIP_TRY(ctx, hipEventRecord(e1, (hipStream_t)stream));
-  HIP_TRY(ctx, hipEventSynchronize(e1));
+  ON_DEVICE(ctx);
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  hipError_t e = hipEventCreate(&e0);
+  if (e == hipSuccess) e = hipEventCreate(&e1);
+  if (e == hipSuccess) e = hipEventRecord(e0, (hipStream_t)stream);
+  int32_t rc = B3W_OK;
+  for (uint32_t i = 0; i < iters && e == hipSuccess && rc == B3W_OK; i++)
+    rc = b3w_batch_run_device(ctx, d_records, n, d_bodies, pitch, d_public, d_status, stream);
   float ms = 0;
-  HIP_TRY(ctx, hipEventElapsedTime(&ms, e0, e1));
+  if (e == hipSuccess && rc == B3W_OK) e = hipEventRecord(e1, (hipStream_t)stream);
+  if (e == hipSuccess && rc == B3W_OK) e = hipEventSynchronize(e1);
+  if (e == hipSuccess && rc == B3W_OK) e = hipEventElapsedTime(&ms, e0, e1);
+  if (e0) (void)hipEventDestroy(e0);
+  if (e1) (void)hipEventDestroy(e1);
+  if (rc) return rc;
+  if (e != hipSuccess) return hip_fail(ctx, e, "timing events");
   *avg_ms = ms / iters;
-  (void)hipEventDestroy(e0);
-  (void)hipEventDestroy(e1);
   return B3W_OK;
 }
 
@@ -602,7 +632,7 @@ int32_t b3w_calc_witness(b3w_ctx *ctx, const uint64_t *name_hashes, const uint32
     ctx->last_error = msg;
     return B3W_E_NOT_ALL_INPUTS;
   }
-  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  ON_DEVICE(ctx);
   if (canonical) {
     // canonical u32 record: the batch kernel with n = 1
     HIP_TRY(ctx, hipMemcpy(ctx->d_rec1, rec.data(), d.nin * 4, hipMemcpyHostToDevice));
@@ -636,7 +666,7 @@ int32_t b3w_bodies_alloc(b3w_ctx *ctx, uint64_t bytes, void **d_ptr, int32_t *pl
   if (!ctx || !d_ptr || !bytes) return B3W_E_BAD_ARGUMENT;
   *d_ptr = nullptr;
   if (placement) *placement = B3W_PLACEMENT_PLAIN;
-  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  ON_DEVICE(ctx);
   const char *env = getenv("B3W_PLACEMENT");
   const bool want_mixed = !(env && !strcmp(env, "plain")) && bytes >= (512ull << 20);
   if (want_mixed) {
@@ -655,7 +685,9 @@ int32_t b3w_bodies_alloc(b3w_ctx *ctx, uint64_t bytes, void **d_ptr, int32_t *pl
 
 int32_t b3w_bodies_free(b3w_ctx *ctx, void *d_ptr) {
   if (!d_ptr) return B3W_OK;
-  if (ctx) (void)hipSetDevice(ctx->device);
+  int cur = 0;
+  (void)hipGetDevice(&cur);
+  DeviceGuard guard(ctx ? ctx->device : cur);
   if (b3w_place_free(d_ptr) == 0) return B3W_OK;
   hipError_t e = hipFree(d_ptr);
   return e == hipSuccess ? B3W_OK : hip_fail(ctx, e, "hipFree(bodies)");
@@ -673,7 +705,8 @@ int32_t b3w_batch_alloc(b3w_ctx *ctx, uint32_t capacity, uint64_t pitch, b3w_bat
   if (pitch < body || (pitch & 31)) return B3W_E_BAD_ARGUMENT;
   b3w_batch *b = new b3w_batch;
   b->ctx = ctx; b->capacity = capacity; b->pitch = pitch;
-  hipError_t e = hipSetDevice(ctx->device);
+  DeviceGuard guard(ctx->device);
+  hipError_t e = guard.err;
   if (e == hipSuccess) e = hipMalloc((void **)&b->d_recs, (size_t)capacity * ctx->desc.nin * 4);
   if (e == hipSuccess) {
     const int32_t rc = b3w_bodies_alloc(ctx, (uint64_t)capacity * pitch, (void **)&b->d_bodies, &b->placement);
@@ -688,6 +721,7 @@ int32_t b3w_batch_alloc(b3w_ctx *ctx, uint32_t capacity, uint64_t pitch, b3w_bat
 
 void b3w_batch_free(b3w_batch *b) {
   if (!b) return;
+  DeviceGuard guard(b->ctx->device);
   if (b->d_recs) (void)hipFree(b->d_recs);
   if (b->d_bodies) (void)b3w_bodies_free(b->ctx, b->d_bodies);
   if (b->d_pub) (void)hipFree(b->d_pub);
@@ -698,7 +732,7 @@ void b3w_batch_free(b3w_batch *b) {
 int32_t b3w_batch_run(b3w_batch *b, const uint32_t *host_records, uint32_t n, void *stream) {
   if (!b || !host_records || n > b->capacity) return B3W_E_BAD_ARGUMENT;
   b3w_ctx *ctx = b->ctx;
-  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  ON_DEVICE(ctx);
   HIP_TRY(ctx, hipMemcpyAsync(b->d_recs, host_records, (size_t)n * ctx->desc.nin * 4, hipMemcpyHostToDevice, (hipStream_t)stream));
   int32_t rc = b3w_batch_run_device(ctx, b->d_recs, n, b->d_bodies, b->pitch, b->d_pub, b->d_status, stream);
   if (rc) return rc;
@@ -710,6 +744,7 @@ int32_t b3w_batch_run(b3w_batch *b, const uint32_t *host_records, uint32_t n, vo
 int32_t b3w_batch_outputs(b3w_batch *b, uint32_t *host_public, int32_t *host_status) {
   if (!b || !host_public) return B3W_E_BAD_ARGUMENT;
   b3w_ctx *ctx = b->ctx;
+  ON_DEVICE(ctx);
   HIP_TRY(ctx, hipMemcpy(host_public, b->d_pub, (size_t)b->n * ctx->desc.npub * 4, hipMemcpyDeviceToHost));
   if (host_status) HIP_TRY(ctx, hipMemcpy(host_status, b->d_status, (size_t)b->n * 4, hipMemcpyDeviceToHost));
   return B3W_OK;
@@ -718,6 +753,7 @@ int32_t b3w_batch_outputs(b3w_batch *b, uint32_t *host_public, int32_t *host_sta
 int32_t b3w_batch_fetch(b3w_batch *b, uint32_t index, uint8_t *out_body) {
   if (!b || !out_body || index >= b->n) return B3W_E_BAD_ARGUMENT;
   b3w_ctx *ctx = b->ctx;
+  ON_DEVICE(ctx);
   HIP_TRY(ctx, hipMemcpy(out_body, b->d_bodies + (size_t)index * b->pitch, (size_t)ctx->desc.nwit * 32, hipMemcpyDeviceToHost));
   return B3W_OK;
 }
@@ -726,7 +762,7 @@ int32_t b3w_batch_verify(b3w_batch *b, uint32_t *host_mismatch) {
   if (!b || !host_mismatch) return B3W_E_BAD_ARGUMENT;
   b3w_ctx *ctx = b->ctx;
   if (!b->n) return B3W_OK;
-  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  ON_DEVICE(ctx);
   uint32_t *d_mm = nullptr;
   HIP_TRY(ctx, hipMalloc((void **)&d_mm, (size_t)b->n * 4));
   int32_t rc = b3w_batch_verify_device(ctx, b->d_bodies, b->n, b->pitch, d_mm, nullptr);
@@ -738,22 +774,35 @@ int32_t b3w_batch_verify(b3w_batch *b, uint32_t *host_mismatch) {
 
 int32_t b3w_batch_write_wtns(b3w_batch *b, uint32_t first, uint32_t count, const char *dir, const char *prefix,
                              uint32_t *written) {
-  if (!b || !dir || !prefix || first + count > b->n) return B3W_E_BAD_ARGUMENT;
+  if (!b || !dir || !prefix || first > b->n || count > b->n - first) return B3W_E_BAD_ARGUMENT;   // (first + count wraps in u32)
+  if (written) *written = 0;
+  if (!count) return B3W_OK;
   b3w_ctx *ctx = b->ctx;
   const size_t body = (size_t)ctx->desc.nwit * 32;
   const uint32_t CH = 64;                                  // witnesses per staging buffer (~48 MB)
   uint8_t hdr[76];
   b3w_write_wtns_header(ctx, hdr);
   std::vector<int32_t> st(count);
-  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  ON_DEVICE(ctx);
   HIP_TRY(ctx, hipMemcpy(st.data(), b->d_status + first, (size_t)count * 4, hipMemcpyDeviceToHost));
   uint8_t *stage[2] = {nullptr, nullptr};
-  hipStream_t cs;
-  hipEvent_t ev[2];
-  HIP_TRY(ctx, hipStreamCreate(&cs));
-  for (int i = 0; i < 2; i++) {
-    HIP_TRY(ctx, hipHostMalloc((void **)&stage[i], CH * body, hipHostMallocDefault));
-    HIP_TRY(ctx, hipEventCreate(&ev[i]));
+  hipStream_t cs = nullptr;
+  hipEvent_t ev[2] = {nullptr, nullptr};
+  auto release = [&]() {
+    if (cs) (void)hipStreamSynchronize(cs);
+    for (int i = 0; i < 2; i++) {
+      if (stage[i]) (void)hipHostFree(stage[i]);
+      if (ev[i]) (void)hipEventDestroy(ev[i]);
+    }
+    if (cs) (void)hipStreamDestroy(cs);
+  };
+  {
+    hipError_t e = hipStreamCreate(&cs);
+    for (int i = 0; i < 2 && e == hipSuccess; i++) {
+      e = hipHostMalloc((void **)&stage[i], CH * body, hipHostMallocDefault);
+      if (e == hipSuccess) e = hipEventCreate(&ev[i]);
+    }
+    if (e != hipSuccess) { release(); return hip_fail(ctx, e, "staging buffers of the .wtns writer"); }
   }
   auto issue = [&](uint32_t chunk) -> hipError_t {
     const uint32_t c0 = chunk * CH, cn = count - c0 < CH ? count - c0 : CH;
@@ -787,9 +836,7 @@ int32_t b3w_batch_write_wtns(b3w_batch *b, uint32_t first, uint32_t count, const
     }
     // the staging buffer written from is reused by chunk k+2, issued in the next iteration: safe, we are done with it
   }
-  (void)hipStreamSynchronize(cs);
-  for (int i = 0; i < 2; i++) { (void)hipHostFree(stage[i]); (void)hipEventDestroy(ev[i]); }
-  (void)hipStreamDestroy(cs);
+  release();
   if (written) *written = nwritten;
   return rc;
 }
@@ -810,12 +857,14 @@ int32_t b3w_chain_plan_leaves_device(b3w_ctx *ctx, const uint8_t *d_preimage, ui
   if (!ctx || !d_preimage || !d_records || !d_chunk_cvs) return B3W_E_BAD_ARGUMENT;
   const uint64_t n = b3w_chain_num_chunks(preimage_len);
   if (first_chunk + n_chunks_local > n) { ctx->last_error = "chunk range exceeds the preimage"; return B3W_E_BAD_ARGUMENT; }
+  ON_DEVICE(ctx);
   int rc = b3w_launch_plan_leaves(d_preimage, preimage_len, first_chunk, n_chunks_local, n, d_records, d_chunk_cvs, (hipStream_t)stream);
   return rc ? hip_fail(ctx, (hipError_t)rc, "plan leaves launch") : B3W_OK;
 }
 
 int32_t b3w_chain_tree_device(b3w_ctx *ctx, uint32_t *d_levels, uint64_t n_chunks, uint32_t *d_root, void *stream) {
   if (!ctx || !d_levels || !d_root || !n_chunks) return B3W_E_BAD_ARGUMENT;
+  ON_DEVICE(ctx);
   hipStream_t st = (hipStream_t)stream;
   if (n_chunks == 1) {
     HIP_TRY(ctx, hipMemcpyAsync(d_root, d_levels, 32, hipMemcpyDeviceToDevice, st));
@@ -856,6 +905,7 @@ int32_t b3w_chain_plan_parents_device(b3w_ctx *ctx, const uint32_t *d_levels, ui
     ctx->last_error = "parent steps need a complete tree: n_chunks must be a power of two and match the preimage";
     return B3W_E_BAD_ARGUMENT;
   }
+  ON_DEVICE(ctx);
   uint32_t P = 0;
   while ((1ull << P) < n_chunks) P++;
   const uint64_t last_bytes = preimage_len - (n_chunks - 1) * 1024;
@@ -941,7 +991,8 @@ int32_t b3w_commit_key_create_ex(b3w_ctx *ctx, int32_t curve, uint32_t first_slo
     nv += nbits[i];
   }
   // window width: the caller's, else B3W_COMMIT_WINDOW, else 16 when its table takes at most a quarter of the free HBM
-  hipError_t e = hipSetDevice(ctx->device);
+  DeviceGuard guard(ctx->device);
+  hipError_t e = guard.err;
   uint32_t window = window_bits;
   if (!window && getenv("B3W_COMMIT_WINDOW")) {
     window = (uint32_t)atoi(getenv("B3W_COMMIT_WINDOW"));
@@ -1021,6 +1072,7 @@ int32_t b3w_commit_key_create_ex(b3w_ctx *ctx, int32_t curve, uint32_t first_slo
 
 void b3w_commit_key_destroy(b3w_commit_key *key) {
   if (!key) return;
+  DeviceGuard guard(key->ctx->device);
   if (key->d_slotdesc) (void)hipFree(key->d_slotdesc);
   if (key->d_runs) (void)hipFree(key->d_runs);
   if (key->d_images) (void)hipFree(key->d_images);
@@ -1039,8 +1091,8 @@ int32_t b3w_batch_commit_device(b3w_ctx *ctx, const b3w_commit_key *key, const u
     return B3W_E_BAD_ARGUMENT;
   }
   b3w_commit_key *k = const_cast<b3w_commit_key *>(key);                     // scratch only
+  ON_DEVICE(ctx);
   if (k->sums_cap < n) {
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipStreamSynchronize((hipStream_t)stream));
     if (k->d_sums) (void)hipFree(k->d_sums);
     k->d_sums = nullptr; k->sums_cap = 0;
@@ -1060,7 +1112,7 @@ int32_t b3w_commit_records_device(b3w_ctx *ctx, const b3w_commit_key *key, const
     ctx->last_error = "records 4-byte and points 16-byte aligned";
     return B3W_E_BAD_ARGUMENT;
   }
-  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  ON_DEVICE(ctx);
   b3w_commit_key *k = const_cast<b3w_commit_key *>(key);                     // scratch only
   constexpr uint32_t CHUNK = 32768;                                          // witnesses per TRACE + commit pair (images: 3.7-11 KB each)
   const uint32_t want = std::min(n, CHUNK);
@@ -1098,7 +1150,7 @@ int32_t b3w_commit_records(b3w_ctx *ctx, const b3w_commit_key *key, const uint32
                            uint32_t *host_public, int32_t *host_status) {
   if (!ctx || !key || key->ctx != ctx || !host_records || !host_points) return B3W_E_BAD_ARGUMENT;
   if (n == 0) return B3W_OK;
-  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  ON_DEVICE(ctx);
   const size_t rb = (size_t)n * ctx->desc.nin * 4, pb = (size_t)n * ctx->desc.npub * 4;
   uint8_t *d = nullptr;                                   // records | points | public outputs | status
   const size_t o_pts = (rb + 255) & ~(size_t)255, o_pub = o_pts + (size_t)n * 64, o_st = o_pub + ((pb + 255) & ~(size_t)255);
@@ -1128,7 +1180,7 @@ int32_t b3w_batch_commit(b3w_batch *b, const b3w_commit_key *key, uint8_t *host_
   if (!b || !key || !host_points) return B3W_E_BAD_ARGUMENT;
   b3w_ctx *ctx = b->ctx;
   if (!b->n) return B3W_OK;
-  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  ON_DEVICE(ctx);
   uint8_t *d_pts = nullptr;
   int32_t *d_st = nullptr;
   HIP_TRY(ctx, hipMalloc((void **)&d_pts, (size_t)b->n * 64));
@@ -1164,20 +1216,23 @@ struct Rccl {                    // the five entry points used, with rccl.h's si
   std::string err;
 } rccl;
 
-bool load_rccl() {
-  if (rccl.so) return true;
+void load_rccl_once() {
   void *so = nullptr;
   for (const char *name : {"librccl.so", "librccl.so.1"}) if (!so) so = dlopen(name, RTLD_NOW | RTLD_NOLOAD);   // one already in the process
   for (const char *name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) if (!so) so = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
-  if (!so) { rccl.err = std::string("cannot load librccl: ") + dlerror(); return false; }
+  if (!so) { rccl.err = std::string("cannot load librccl: ") + dlerror(); return; }
   rccl.GetUniqueId = (decltype(rccl.GetUniqueId))dlsym(so, "ncclGetUniqueId");
   rccl.CommInitRank = (decltype(rccl.CommInitRank))dlsym(so, "ncclCommInitRank");
   rccl.AllGather = (decltype(rccl.AllGather))dlsym(so, "ncclAllGather");
   rccl.CommDestroy = (decltype(rccl.CommDestroy))dlsym(so, "ncclCommDestroy");
   rccl.GetErrorString = (decltype(rccl.GetErrorString))dlsym(so, "ncclGetErrorString");
-  if (!rccl.GetUniqueId || !rccl.CommInitRank || !rccl.AllGather || !rccl.CommDestroy || !rccl.GetErrorString) { rccl.err = "librccl lacks an ncclAllGather entry point"; return false; }
+  if (!rccl.GetUniqueId || !rccl.CommInitRank || !rccl.AllGather || !rccl.CommDestroy || !rccl.GetErrorString) { rccl.err = "librccl lacks an ncclAllGather entry point"; return; }
   rccl.so = so;
-  return true;
+}
+std::once_flag rccl_once;
+bool load_rccl() {                 // thread-safe: distinct contexts may create communicators from different threads
+  std::call_once(rccl_once, load_rccl_once);
+  return rccl.so != nullptr;
 }
 }  // namespace
 
@@ -1193,7 +1248,7 @@ int32_t b3w_comm_create(b3w_ctx *ctx, const uint8_t id[B3W_COMM_ID_BYTES], int32
   if (!ctx || !id || !out || nranks < 1 || rank < 0 || rank >= nranks) return B3W_E_BAD_ARGUMENT;
   *out = nullptr;
   if (!load_rccl()) { ctx->last_error = rccl.err; return B3W_E_RCCL; }
-  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  ON_DEVICE(ctx);
   RcclId uid;
   memcpy(uid.b, id, 128);
   void *comm = nullptr;
@@ -1207,12 +1262,14 @@ int32_t b3w_comm_create(b3w_ctx *ctx, const uint8_t id[B3W_COMM_ID_BYTES], int32
 
 void b3w_comm_destroy(b3w_comm *c) {
   if (!c) return;
+  DeviceGuard guard(c->ctx->device);
   if (c->comm && rccl.CommDestroy) (void)rccl.CommDestroy(c->comm);
   delete c;
 }
 
 int32_t b3w_comm_allgather(b3w_comm *c, const void *d_send, void *d_recv, uint64_t bytes_per_rank, void *stream) {
   if (!c || !d_send || !d_recv || !bytes_per_rank) return B3W_E_BAD_ARGUMENT;
+  ON_DEVICE(c->ctx);
   const int rc = rccl.AllGather(d_send, d_recv, (size_t)bytes_per_rank, /* ncclInt8 */ 0, c->comm, (hipStream_t)stream);
   if (rc != 0) { c->ctx->last_error = std::string("ncclAllGather: ") + rccl.GetErrorString(rc); return B3W_E_RCCL; }
   return B3W_OK;
@@ -1221,7 +1278,7 @@ int32_t b3w_comm_allgather(b3w_comm *c, const void *d_send, void *d_recv, uint64
 int32_t b3w_batch_allgather_public(b3w_batch *b, b3w_comm *c, uint32_t *host_all) {
   if (!b || !c || !host_all || !b->n) return B3W_E_BAD_ARGUMENT;
   b3w_ctx *ctx = b->ctx;
-  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  ON_DEVICE(ctx);
   const uint64_t per = (uint64_t)b->n * ctx->desc.npub * 4;
   void *d_all = nullptr;
   HIP_TRY(ctx, hipMalloc(&d_all, per * c->nranks));
@@ -1285,7 +1342,7 @@ int32_t b3w_chain_commit_only(b3w_chain *c, const b3w_commit_key *key, uint8_t *
   if (!c || (key && key->ctx != c->ctx)) return B3W_E_BAD_ARGUMENT;
   if (key && !d_points) {                              // the chain's own buffer: fetch it with b3w_chain_commitments
     if (!c->co_own) {
-      HIP_TRY(c->ctx, hipSetDevice(c->ctx->device));
+      ON_DEVICE(c->ctx);
       HIP_TRY(c->ctx, hipMalloc((void **)&c->co_own, (size_t)(c->n_leaf + c->n_par + 1) * 64));
     }
     d_points = c->co_own;
@@ -1297,7 +1354,7 @@ int32_t b3w_chain_commit_only(b3w_chain *c, const b3w_commit_key *key, uint8_t *
 
 int32_t b3w_chain_commitments(b3w_chain *c, uint8_t *host_points, void *stream) {
   if (!c || !host_points || !c->co_points) return B3W_E_BAD_ARGUMENT;
-  HIP_TRY(c->ctx, hipSetDevice(c->ctx->device));
+  ON_DEVICE(c->ctx);
   HIP_TRY(c->ctx, hipStreamSynchronize((hipStream_t)stream));
   HIP_TRY(c->ctx, hipMemcpy(host_points, c->co_points, (size_t)(c->n_leaf + c->n_par) * 64, hipMemcpyDeviceToHost));
   return B3W_OK;
@@ -1322,7 +1379,8 @@ int32_t b3w_chain_create(b3w_ctx *ctx, uint64_t preimage_len, uint64_t first_chu
   c->n_par = (with_parents && c->complete) ? (uint64_t)n_chunks_local * c->P : 0;
   const uint64_t rows = (uint64_t)n_chunks_local * 16 + c->n_par + 1;
   const uint64_t body = 32ull * ctx->desc.nwit;
-  hipError_t e = hipSetDevice(ctx->device);
+  DeviceGuard guard(ctx->device);
+  hipError_t e = guard.err;
   if (e == hipSuccess) e = hipMalloc((void **)&c->d_pre, std::max<uint64_t>(n_chunks_local, 1) * 1024);
   if (e == hipSuccess) e = hipMalloc((void **)&c->d_recs, rows * 32 * 4);
   if (e == hipSuccess) e = hipMalloc((void **)&c->d_cvs, std::max<uint64_t>(n_chunks_local, 1) * 8 * 4);
@@ -1352,7 +1410,7 @@ int32_t b3w_chain_create(b3w_ctx *ctx, uint64_t preimage_len, uint64_t first_chu
 
 void b3w_chain_destroy(b3w_chain *c) {
   if (!c) return;
-  (void)hipSetDevice(c->ctx->device);
+  DeviceGuard guard(c->ctx->device);
   (void)hipDeviceSynchronize();
   for (void *p : c->bodies) (void)b3w_bodies_free(c->ctx, p);
   if (c->d_pre) (void)hipFree(c->d_pre);
@@ -1374,7 +1432,7 @@ void b3w_chain_destroy(b3w_chain *c) {
 int32_t b3w_chain_run_leaves(b3w_chain *c, const uint8_t *host_preimage, b3w_batch_consumer consumer, void *user, void *stream) {
   if (!c || !host_preimage) return B3W_E_BAD_ARGUMENT;
   b3w_ctx *ctx = c->ctx;
-  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  ON_DEVICE(ctx);
   hipStream_t st = (hipStream_t)stream;
   // the copy stream must not run ahead of work still reading d_pre from an earlier pass on `stream`
   HIP_TRY(ctx, hipEventRecord(c->ev[3], st));
@@ -1402,7 +1460,7 @@ int32_t b3w_chain_run_leaves(b3w_chain *c, const uint8_t *host_preimage, b3w_bat
 int32_t b3w_chain_run_parents(b3w_chain *c, const uint32_t *d_all_chunk_cvs, b3w_batch_consumer consumer, void *user, void *stream) {
   if (!c) return B3W_E_BAD_ARGUMENT;
   b3w_ctx *ctx = c->ctx;
-  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  ON_DEVICE(ctx);
   hipStream_t st = (hipStream_t)stream;
   // The tree and the parent-step records only need the chunk CVs, not the leaf witnesses: they run on a side stream
   // beside the leaf witness kernels still queued on `stream` (250 us of small dependent launches for a 1 MiB preimage).
@@ -1438,14 +1496,19 @@ int32_t b3w_chain_run_parents_sharded(b3w_chain *c, b3w_comm *comm, b3w_batch_co
   uint64_t first = 0; uint32_t count = 0;
   b3w_chain_shard(c->n_chunks, comm->rank, comm->nranks, &first, &count);
   if (first != c->first_chunk || count != c->nl) { ctx->last_error = "the chain was not created with this rank's b3w_chain_shard range"; return B3W_E_BAD_ARGUMENT; }
-  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  ON_DEVICE(ctx);
   hipStream_t st = (hipStream_t)stream;
   const uint64_t mx = (c->n_chunks + comm->nranks - 1) / comm->nranks;       // largest shard
   uint32_t *d_pad = nullptr, *d_gath = nullptr, *d_all = nullptr;
-  HIP_TRY(ctx, hipMalloc((void **)&d_pad, mx * 32));
-  HIP_TRY(ctx, hipMalloc((void **)&d_gath, mx * 32 * comm->nranks));
-  HIP_TRY(ctx, hipMalloc((void **)&d_all, c->n_chunks * 32));
-  hipError_t e = hipMemsetAsync(d_pad, 0, mx * 32, st);
+  hipError_t e = hipMalloc((void **)&d_pad, mx * 32);
+  if (e == hipSuccess) e = hipMalloc((void **)&d_gath, mx * 32 * comm->nranks);
+  if (e == hipSuccess) e = hipMalloc((void **)&d_all, c->n_chunks * 32);
+  if (e != hipSuccess) {
+    if (d_pad) (void)hipFree(d_pad);
+    if (d_gath) (void)hipFree(d_gath);
+    return e == hipErrorOutOfMemory ? B3W_E_NOT_ENOUGH_MEMORY : hip_fail(ctx, e, "chunk CV exchange buffers");
+  }
+  e = hipMemsetAsync(d_pad, 0, mx * 32, st);
   if (e == hipSuccess && c->nl) e = hipMemcpyAsync(d_pad, c->d_cvs, (uint64_t)c->nl * 32, hipMemcpyDeviceToDevice, st);
   int32_t rc = e == hipSuccess ? b3w_comm_allgather(comm, d_pad, d_gath, mx * 32, stream) : hip_fail(ctx, e, "chunk CV staging");
   for (int32_t r = 0; r < comm->nranks && rc == B3W_OK; r++) {                 // drop the padding: global chunk order
@@ -1473,7 +1536,7 @@ int32_t b3w_chain_info(const b3w_chain *c, uint64_t *n_leaf_steps, uint64_t *n_p
 int32_t b3w_chain_outputs(b3w_chain *c, uint32_t *host_public, int32_t *host_status, uint32_t *host_root, void *stream) {
   if (!c) return B3W_E_BAD_ARGUMENT;
   b3w_ctx *ctx = c->ctx;
-  HIP_TRY(ctx, hipSetDevice(ctx->device));
+  ON_DEVICE(ctx);
   HIP_TRY(ctx, hipStreamSynchronize((hipStream_t)stream));
   const uint64_t rows = c->n_leaf + c->n_par;
   if (host_public) HIP_TRY(ctx, hipMemcpy(host_public, c->d_pub, rows * 15 * 4, hipMemcpyDeviceToHost));

@@ -23,6 +23,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <atomic>
 #include "b3w_atoms.h"
 #include "b3w_kernels.h"
 
@@ -834,14 +835,20 @@ int launch_sweep(const uint32_t *d_images, uint32_t n, uint8_t *d_out, uint64_t 
   const uint32_t lead = (uint32_t)(addr & 4095);
   static const int shape = getenv("B3W_SWEEP_SHAPE") ? atoi(getenv("B3W_SWEEP_SHAPE")) : 2;   // 2 = two wave-pairs, split
   const size_t smem = (size_t)nwit * 4 + 16;                 // the slot table
+  constexpr size_t B3W_SWEEP_MAX_SMEM = 24614 * 4 + 16;       // the largest circuit's table (nova O1)
+  if (smem > B3W_SWEEP_MAX_SMEM) return -5;
 #define B3W_SWEEP_LAUNCH(PAIRS, SPLIT)                                                                              \
   {                                                                                                                 \
-    static bool attr_done = false;                                                                                  \
-    if (!attr_done) {                                                                                               \
+    /* the attribute is per device: one bit per device ordinal (setting it twice in a race is harmless) */         \
+    static std::atomic<uint64_t> attr_done{0};                                                                      \
+    int dev = 0;                                                                                                    \
+    (void)hipGetDevice(&dev);                                                                                       \
+    const uint64_t bit = 1ull << (dev & 63);                                                                        \
+    if (!(attr_done.load(std::memory_order_acquire) & bit)) {                                                       \
       hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&b3w_sweep_kernel<WIDE, K, B3W_SWEEP_LOGC, PAIRS, SPLIT>), \
-                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem);                    \
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)B3W_SWEEP_MAX_SMEM);     \
       if (e != hipSuccess) return (int)e;                                                                           \
-      attr_done = true;                                                                                             \
+      attr_done.fetch_or(bit, std::memory_order_release);                                                           \
     }                                                                                                               \
     hipLaunchKernelGGL((b3w_sweep_kernel<WIDE, K, B3W_SWEEP_LOGC, PAIRS, SPLIT>), dim3(B3W_SWEEP_GRID), dim3(128 * PAIRS), smem, \
                        stream, d_images, n, d_out - lead, lead, (uint32_t)pitch, d_table, nwit);                    \

@@ -91,6 +91,7 @@ struct Handle {
   b3w_ctx *ctx = nullptr;
   b3w_batch *batch = nullptr;
   uint32_t batch_cap = 0, batch_n = 0;
+  uint32_t generation = 0;          // bumped by every batchRun: the handle owns ONE batch, a later run replaces it
   b3w_comm *comm = nullptr;
   int32_t rank = 0, nranks = 1;
   b3w_commit_key *key = nullptr;
@@ -103,6 +104,18 @@ struct Handle {
       return nullptr;                                                   \
     }                                                                   \
   } while (0)
+
+// Methods of a batchRun result pass the generation they were created with: acting on the batch of a LATER run with
+// the sizes of an earlier one would read or write past buffers, so stale results are refused.
+bool fresh_result(napi_env env, Handle *h, size_t argc, napi_value *argv, size_t idx) {
+  if (argc <= idx) return true;
+  napi_valuetype t;
+  if (napi_typeof(env, argv[idx], &t) != napi_ok || t != napi_number) return true;
+  uint32_t g = 0;
+  if (napi_get_value_uint32(env, argv[idx], &g) == napi_ok && g == h->generation) return true;
+  napi_throw_error(env, nullptr, "stale batch result: a later calculateWitnessBatch on this calculator replaced it");
+  return false;
+}
 
 napi_value throw_status(napi_env env, Handle *h, int32_t rc, const char *what) {
   char msg[640], tail[512] = "";
@@ -279,6 +292,7 @@ napi_value BatchRun(napi_env env, napi_callback_info info) {
   int32_t rc = api.batch_run(h->batch, (const uint32_t *)p, n, nullptr);
   if (rc != B3W_OK) return throw_status(env, h, rc, "b3w_batch_run failed");
   h->batch_n = n;
+  h->generation++;
   const uint32_t npub = api.public_words(h->ctx);
   void *pp, *ps; napi_value abp, abs_, o, v;
   NAPI_OK(napi_create_arraybuffer(env, (size_t)n * npub * 4, &pp, &abp));
@@ -287,17 +301,18 @@ napi_value BatchRun(napi_env env, napi_callback_info info) {
   if (rc != B3W_OK) return throw_status(env, h, rc, "b3w_batch_outputs failed");
   NAPI_OK(napi_create_object(env, &o));
   napi_create_uint32(env, n, &v); napi_set_named_property(env, o, "n", v);
+  napi_create_uint32(env, h->generation, &v); napi_set_named_property(env, o, "generation", v);
   napi_create_typedarray(env, napi_uint32_array, (size_t)n * npub, abp, 0, &v); napi_set_named_property(env, o, "publicOutputs", v);
   napi_create_typedarray(env, napi_int32_array, n, abs_, 0, &v); napi_set_named_property(env, o, "status", v);
   return o;
 }
 
-// batchFetch(handle, index) -> Uint8Array body of witness `index` of the last batchRun
+// batchFetch(handle, index[, generation]) -> Uint8Array body of witness `index` of the last batchRun
 napi_value BatchFetch(napi_env env, napi_callback_info info) {
-  size_t argc = 2; napi_value argv[2];
+  size_t argc = 3; napi_value argv[3];
   NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
   Handle *h = get_handle(env, argv[0]);
-  if (!h) return nullptr;
+  if (!h || !fresh_result(env, h, argc, argv, 2)) return nullptr;
   uint32_t idx = 0, nwit = 0;
   NAPI_OK(napi_get_value_uint32(env, argv[1], &idx));
   if (!h->batch) { napi_throw_error(env, nullptr, "batchFetch before batchRun"); return nullptr; }
@@ -310,12 +325,12 @@ napi_value BatchFetch(napi_env env, napi_callback_info info) {
   return out;
 }
 
-// batchWriteWtns(handle, first, count, dir, prefix) -> number of .wtns files written (streamed D2H)
+// batchWriteWtns(handle, first, count, dir, prefix[, generation]) -> number of .wtns files written (streamed D2H)
 napi_value BatchWriteWtns(napi_env env, napi_callback_info info) {
-  size_t argc = 5; napi_value argv[5];
+  size_t argc = 6; napi_value argv[6];
   NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
   Handle *h = get_handle(env, argv[0]);
-  if (!h) return nullptr;
+  if (!h || !fresh_result(env, h, argc, argv, 5)) return nullptr;
   if (!h->batch) { napi_throw_error(env, nullptr, "batchWriteWtns before batchRun"); return nullptr; }
   uint32_t first = 0, count = 0;
   NAPI_OK(napi_get_value_uint32(env, argv[1], &first));
@@ -332,15 +347,15 @@ napi_value BatchWriteWtns(napi_env env, napi_callback_info info) {
   return out;
 }
 
-// batchVerify(handle, n) -> Uint32Array of per-witness mismatch counts of the last batchRun (0 = valid witness)
+// batchVerify(handle[, generation]) -> Uint32Array of per-witness mismatch counts of the last batchRun (0 = valid witness).
+// The result is sized from the handle's own batch, never from a caller-supplied count: b3w_batch_verify writes n * 4 bytes.
 napi_value BatchVerify(napi_env env, napi_callback_info info) {
   size_t argc = 2; napi_value argv[2];
   NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
   Handle *h = get_handle(env, argv[0]);
-  if (!h) return nullptr;
-  if (!h->batch) { napi_throw_error(env, nullptr, "batchVerify before batchRun"); return nullptr; }
-  uint32_t n = 0;
-  NAPI_OK(napi_get_value_uint32(env, argv[1], &n));
+  if (!h || !fresh_result(env, h, argc, argv, 1)) return nullptr;
+  if (!h->batch || !h->batch_n) { napi_throw_error(env, nullptr, "batchVerify before batchRun"); return nullptr; }
+  const uint32_t n = h->batch_n;
   void *p; napi_value ab, out;
   NAPI_OK(napi_create_arraybuffer(env, (size_t)n * 4, &p, &ab));
   const int32_t rc = api.batch_verify(h->batch, (uint32_t *)p);
@@ -462,12 +477,12 @@ napi_value CommitKey(napi_env env, napi_callback_info info) {
   return u;
 }
 
-// batchCommit(handle) -> { points: Uint8Array(n * 64), status: Int32Array(n) }: Pedersen commitments of the last batchRun
+// batchCommit(handle[, generation]) -> { points: Uint8Array(n * 64), status: Int32Array(n) }: Pedersen commitments of the last batchRun
 napi_value BatchCommit(napi_env env, napi_callback_info info) {
-  size_t argc = 1; napi_value argv[1];
+  size_t argc = 2; napi_value argv[2];
   NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
   Handle *h = get_handle(env, argv[0]);
-  if (!h) return nullptr;
+  if (!h || !fresh_result(env, h, argc, argv, 1)) return nullptr;
   if (!h->batch || !h->key || !h->batch_n) { napi_throw_error(env, nullptr, "batchCommit needs commitKey and a batchRun"); return nullptr; }
   void *pp, *ps; napi_value abp, abs_, o, v;
   NAPI_OK(napi_create_arraybuffer(env, (size_t)h->batch_n * 64, &pp, &abp));
@@ -540,12 +555,12 @@ napi_value CommCreate(napi_env env, napi_callback_info info) {
   return u;
 }
 
-// batchAllgatherPublic(handle) -> Uint32Array(nranks * n * publicWords): the last batchRun's public outputs of every rank
+// batchAllgatherPublic(handle[, generation]) -> Uint32Array(nranks * n * publicWords): the last batchRun's public outputs of every rank
 napi_value BatchAllgatherPublic(napi_env env, napi_callback_info info) {
-  size_t argc = 1; napi_value argv[1];
+  size_t argc = 2; napi_value argv[2];
   NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
   Handle *h = get_handle(env, argv[0]);
-  if (!h) return nullptr;
+  if (!h || !fresh_result(env, h, argc, argv, 1)) return nullptr;
   if (!h->batch || !h->comm || !h->batch_n) { napi_throw_error(env, nullptr, "batchAllgatherPublic needs commCreate and a batchRun"); return nullptr; }
   const size_t words = (size_t)h->nranks * h->batch_n * api.public_words(h->ctx);
   void *p; napi_value ab, out;

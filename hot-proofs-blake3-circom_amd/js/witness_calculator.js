@@ -167,16 +167,20 @@ class WitnessCalculator {
   async calculateWitnessBatch(records) {
     const nat = native();
     const r = nat.batchRun(this.instance, records);
-    r.fetch = (i) => nat.batchFetch(this.instance, i);
+    // The calculator owns ONE device batch: the next calculateWitnessBatch replaces it.  r.generation ties these
+    // methods to the run that made r; on a replaced batch they throw ("stale batch result") instead of touching
+    // the newer one with this one's sizes.
+    const g = r.generation;
+    r.fetch = (i) => nat.batchFetch(this.instance, i, g);
     // on-device check of every body of the batch: Uint32Array of mismatch counts (0 = valid witness)
-    r.verify = () => nat.batchVerify(this.instance, r.n);
+    r.verify = () => nat.batchVerify(this.instance, g);
     // stream every witness of the batch to <dir>/<prefix><index>.wtns (same bytes as calculateWTNSBin)
     r.writeWtns = (dir, prefix, first, count) =>
-      nat.batchWriteWtns(this.instance, first || 0, count === undefined ? r.n - (first || 0) : count, dir, prefix || "witness_");
+      nat.batchWriteWtns(this.instance, first || 0, count === undefined ? r.n - (first || 0) : count, dir, prefix || "witness_", g);
     // every rank's public outputs of this batch (needs wc.joinRanks first; all ranks run the same batch size)
-    r.allgatherPublic = () => nat.batchAllgatherPublic(this.instance);
+    r.allgatherPublic = () => nat.batchAllgatherPublic(this.instance, g);
     // Pedersen commitments of the batch's witnesses on the device (after wc.setCommitKey): { points, status }
-    r.commit = () => nat.batchCommit(this.instance);
+    r.commit = () => nat.batchCommit(this.instance, g);
     r.placement = nat.batchPlacement(this.instance);   // "mixed": the body buffer alternates two classes of HBM
     return r;
   }

@@ -39,6 +39,26 @@ def _lcg_columns(seeds, ndraws):
     return out
 
 
+def lcg_stream(seed, nwords):
+    """The first nwords draws of LCG(seed) as a uint32 array (config 4/5 preimage = their little-endian bytes,
+    SURVEY.md 8(d) item 4).  Jump-ahead doubling: x[k+L] = a^L x[k] + c (a^L - 1)/(a - 1) mod 2^32, so the array
+    doubles in ~log2(n) vector steps instead of n scalar draws."""
+    out = np.empty(max(int(nwords), 1), dtype=np.uint32)
+    out[0] = (1664525 * int(seed) + 1013904223) % 4294967296
+    a, c, have = 1664525, 1013904223, 1                 # x -> a*x + c advances `have` draws
+    while have < nwords:
+        k = min(have, nwords - have)
+        out[have:have + k] = out[:k] * np.uint32(a) + np.uint32(c)          # uint32 arithmetic wraps mod 2^32
+        a, c = (a * a) % 4294967296, (a * c + c) % 4294967296
+        have += k
+    return out[:nwords]
+
+
+def lcg_preimage(nbytes, seed=1):
+    """nbytes of the little-endian byte stream of LCG(seed) (uint8 array)."""
+    return lcg_stream(seed, (int(nbytes) + 3) // 4).view(np.uint8)[:int(nbytes)]
+
+
 def gen_random_chunk(lcg, b=64, d=0, t0=0, t1=0, h=None):
     """test/utils.ts:34-56 genRandomChunk -> compression record (28 u32)."""
     assert b % 4 == 0 and b <= 64

@@ -12,10 +12,13 @@ import b3w_testlib as T
 pytestmark = pytest.mark.gpu
 
 
-def _bench(*args):
-    r = subprocess.run([sys.executable, os.path.join(T.ROOT, "bench.py"), *args], capture_output=True, text=True, timeout=600, cwd=T.ROOT)
+def _bench(*args, env=None):
+    r = subprocess.run([sys.executable, os.path.join(T.ROOT, "bench.py"), *args], capture_output=True, text=True, timeout=600, cwd=T.ROOT,
+                       env=dict(os.environ, **(env or {})))
     assert r.returncode == 0, r.stderr[-2000:]
-    return json.loads(r.stdout.strip().splitlines()[-1])
+    lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout                    # ONE JSON line, from rank 0
+    return json.loads(lines[0])
 
 
 def test_default_line_has_the_contract_fields():
@@ -28,6 +31,34 @@ def test_default_line_has_the_contract_fields():
     assert abs(d["roofline"]["frac"] - d["roofline"]["achieved"] / d["roofline"]["peak"]) < 1e-9
     assert set(("value", "unit", "cores", "kind", "sample")) <= set(d["cpu_baseline"]) and d["cpu_baseline"]["kind"] == "port"
     assert "workload" in d["config"] and d["config"]["verified_on_device"] is True
+    assert d["cpu_baseline"]["cores"] >= 1 and d["cpu_baseline"]["reference_wasm"]["measured_here"] is False
+    # value, ms_per_step and the launch count hang together
+    c = d["config"]
+    assert c["witnesses_per_step"] == 512 * c["launches_per_step"]
+    assert abs(d["value"] - c["witnesses_per_step"] / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
+    assert d["roofline"]["launches_timed"] == 3 * c["launches_per_step"] and d["roofline"]["kernel_ms"] * c["launches_per_step"] <= d["ms_per_step"] * 1.001
+
+
+def test_nova_line_is_labelled_config3():
+    d = _bench("--circuit", "nova_vesta", "--batch", "512", "--steps", "2", "--warmup", "1", "--inner", "2", "--cpu-seconds", "0")
+    assert d["config"]["workload"].startswith("config3") and "Vesta" in d["config"]["workload"] and d["config"]["launches_per_step"] == 2
+
+
+def test_gpus_2_launches_itself():
+    """`python bench.py --gpus 2` (the driver's command shape, no launcher): the script spawns one child per rank before
+    touching the GPU.  On the one-GPU test box the two ranks share the card and rehearse the exchange over gloo."""
+    d = _bench("--gpus", "2", "--batch", "256", "--steps", "2", "--warmup", "1", "--inner", "3", env={"B3W_DIST_BACKEND": "gloo"})
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+    assert "2 ranks" in d["config"]["exchange"] and len(d["config"]["placement_per_rank"]) == 2
+    assert d["config"]["witnesses_per_step"] == 2 * 256 * 3 and "cpu_baseline" not in d
+
+
+def test_gpus_2_chain_launches_itself():
+    d = _bench("--gpus", "2", "--workload", "chain", "--preimage-mib", "0.25", "--steps", "1", "--warmup", "1", env={"B3W_DIST_BACKEND": "gloo"})
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["n_chunks"] == 256
+    assert "2 ranks" in d["config"]["exchange"] and len(d["config"]["placement_per_rank"]) == 2
+    # 256 chunks x 16 leaf steps + 8 parent steps per chunk path, summed over both ranks
+    assert "-> 6144 nova steps" in d["config"]["workload"]
 
 
 @pytest.mark.parametrize("consumer", ["none", "commit", "commit-only"])

@@ -116,6 +116,14 @@ def test_js_surface_errors_and_batch(tmp_path):
                      files: b.writeWtns(process.argv[3], 'js_'),
                      verify: Array.from(b.verify()),
                      file5: crypto.createHash('sha256').update(fs.readFileSync(process.argv[3] + '/js_5.wtns')).digest('hex')};
+        // the calculator owns one device batch: a later run replaces it, and the older result must refuse to act on it
+        const b2 = await wc.calculateWitnessBatch(recs.slice(0, 56));
+        out.stale = [];
+        for (const f of [() => b.verify(), () => b.fetch(0), () => b.writeWtns(process.argv[3], 'stale_'), () => b.commit()])
+          try { f(); out.stale.push('NOERR'); } catch (e) { out.stale.push(e.message); }
+        out.v2 = Array.from(b2.verify());
+        try { b2.writeWtns(process.argv[3], 'wrap_', 0xFFFFFFFF, 2); out.wrap = 'NOERR'; } catch (e) { out.wrap = 'refused'; }
+        out.none = b2.writeWtns(process.argv[3], 'none_', 2, 0);
         console.log(JSON.stringify(out));
       })().catch(e => { console.error(e); process.exit(1); });
     """, str(tmp_path / "cases.json"), json.dumps(neg["input"]), str(tmp_path))
@@ -136,6 +144,9 @@ def test_js_surface_errors_and_batch(tmp_path):
     assert out["batch"]["body3"] == cases[3]["body_sha256"]
     assert out["batch"]["verify"] == [0] * 8
     assert out["batch"]["files"] == 8 and out["batch"]["file5"] == cases[5]["wtns_sha256"]
+    assert out["stale"] == ["stale batch result: a later calculateWitnessBatch on this calculator replaced it"] * 4
+    assert out["v2"] == [0, 0] and out["wrap"] == "refused" and out["none"] == 0
+    assert not [f for f in os.listdir(tmp_path) if f.startswith(("stale_", "wrap_", "none_"))]
 
 
 @needs_node
