@@ -86,6 +86,12 @@ def lib():
         "b3w_batch_time_device": (i32, [vp, vp, u32, vp, u64, vp, vp, vp, u32, ctypes.POINTER(ctypes.c_float)]),
         "b3w_batch_verify_device": (i32, [vp, vp, u32, u64, vp, vp]),
         "b3w_batch_verify": (i32, [vp, vp]),
+        "b3w_r1cs_create": (i32, [vp, vp, sz, ctypes.POINTER(vp)]),
+        "b3w_r1cs_info": (i32, [vp, ctypes.POINTER(u32), ctypes.POINTER(u32), ctypes.POINTER(u64), ctypes.POINTER(u32),
+                                ctypes.POINTER(u32), ctypes.POINTER(u32)]),
+        "b3w_r1cs_destroy": (None, [vp]),
+        "b3w_r1cs_check_device": (i32, [vp, vp, vp, u32, u64, vp, vp, vp]),
+        "b3w_batch_r1cs_check": (i32, [vp, vp, vp, vp]),
         "b3w_batch_write_wtns": (i32, [vp, u32, u32, ctypes.c_char_p, ctypes.c_char_p, ctypes.POINTER(u32)]),
         "b3w_batch_autotune_device": (i32, [vp, vp, u32, vp, u64, vp, vp, vp, ctypes.POINTER(i32), ctypes.POINTER(ctypes.c_float)]),
         "b3w_bodies_alloc": (i32, [vp, u64, ctypes.POINTER(vp), ctypes.POINTER(i32)]),
@@ -139,7 +145,8 @@ EXPORTED_SYMBOLS = ("b3w_abi_version", "b3w_identify_wasm", "b3w_create", "b3w_d
                     "b3w_input_signal_size", "b3w_calc_witness", "b3w_write_wtns_header", "b3w_last_error",
                     "b3w_batch_run_device", "b3w_public_words", "b3w_batch_alloc", "b3w_batch_free",
                     "b3w_batch_run", "b3w_batch_outputs", "b3w_batch_fetch", "b3w_batch_device_ptr",
-                    "b3w_batch_time_device", "b3w_batch_verify_device", "b3w_batch_verify", "b3w_batch_write_wtns", "b3w_batch_autotune_device", "b3w_bodies_alloc", "b3w_bodies_free", "b3w_bodies_trim", "b3w_batch_placement", "b3w_chain_num_chunks", "b3w_chain_num_leaf_steps", "b3w_chain_path_len",
+                    "b3w_batch_time_device", "b3w_batch_verify_device", "b3w_batch_verify",
+                    "b3w_r1cs_create", "b3w_r1cs_info", "b3w_r1cs_destroy", "b3w_r1cs_check_device", "b3w_batch_r1cs_check", "b3w_batch_write_wtns", "b3w_batch_autotune_device", "b3w_bodies_alloc", "b3w_bodies_free", "b3w_bodies_trim", "b3w_batch_placement", "b3w_chain_num_chunks", "b3w_chain_num_leaf_steps", "b3w_chain_path_len",
                     "b3w_chain_plan_leaves_device", "b3w_chain_tree_device", "b3w_chain_plan_parents_device",
                     "b3w_commit_key_create", "b3w_commit_key_create_ex", "b3w_commit_key_window", "b3w_commit_key_destroy", "b3w_commit_records_device", "b3w_commit_records", "b3w_chain_commit_only", "b3w_chain_commitments", "b3w_batch_commit_device", "b3w_batch_commit", "b3w_commit_consumer",
                     "b3w_comm_unique_id", "b3w_comm_create", "b3w_comm_destroy", "b3w_comm_allgather", "b3w_batch_allgather_public",
@@ -296,6 +303,58 @@ class BodyBuffer:
             pass
 
 
+R1CS_DIR = os.path.join(PKG_DIR, "constraints")
+BUILTIN_R1CS = {"compression": "blake3_compression.r1cs.gz"}     # derived from the circuit text by tools/gen_r1cs.py
+
+
+class R1cs:
+    """A rank-1 constraint system on the device (b3w_r1cs_create) for on-device satisfaction checks of witness bodies
+    — the counterpart of circom_tester's expectPass (test/blake3_hash.test.ts:36) / synthesize_with_vec's constraints
+    (rust_fold/src/utils.rs:17-88).  `image`: bytes of an iden3 .r1cs file, or a path to one (.r1cs or .r1cs.gz);
+    None = the system this package derives for the circuit (blake3_compression only: the reference ships no .r1cs)."""
+
+    def __init__(self, ctx, image=None):
+        self.ctx = ctx
+        if image is None:
+            if ctx.circuit not in BUILTIN_R1CS:
+                raise B3WError(100, f"no derived constraint system for {ctx.circuit}: pass the circuit's .r1cs")
+            image = os.path.join(R1CS_DIR, BUILTIN_R1CS[ctx.circuit])
+        if isinstance(image, (str, os.PathLike)):
+            raw = open(image, "rb").read()
+            if raw[:2] == b"\x1f\x8b":
+                import gzip
+                raw = gzip.decompress(raw)
+            image = raw
+        buf = bytes(image)
+        h = ctypes.c_void_p()
+        rc = lib().b3w_r1cs_create(ctx.handle, buf, len(buf), ctypes.byref(h))
+        if rc != B3W_OK:
+            raise B3WError(rc, f"b3w_r1cs_create: status {rc}: {ctx.last_error()}")
+        self.handle = h
+        m, nw, nt, po, pi, pr = (ctypes.c_uint32(), ctypes.c_uint32(), ctypes.c_uint64(), ctypes.c_uint32(), ctypes.c_uint32(),
+                                 ctypes.c_uint32())
+        lib().b3w_r1cs_info(h, ctypes.byref(m), ctypes.byref(nw), ctypes.byref(nt), ctypes.byref(po), ctypes.byref(pi), ctypes.byref(pr))
+        self.n_constraints, self.n_wires, self.n_terms = m.value, nw.value, nt.value
+        self.n_pub_out, self.n_pub_in, self.n_prv_in = po.value, pi.value, pr.value
+
+    def check_device(self, d_bodies, n, pitch, d_violations, d_first=0, stream=0):
+        """n bodies in HBM -> d_violations[i] = violated constraints of body i (0 = valid), d_first[i] = lowest one."""
+        rc = lib().b3w_r1cs_check_device(self.ctx.handle, self.handle, d_bodies, n, pitch, d_violations, d_first or None, stream or None)
+        if rc != B3W_OK:
+            raise B3WError(rc, f"b3w_r1cs_check_device: status {rc}: {self.ctx.last_error()}")
+
+    def close(self):
+        if getattr(self, "handle", None):
+            lib().b3w_r1cs_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 class CommitKey:
     """Commitment key on the device (b3w_commit_key_create): `generators` = bytes, one affine point (x, y: 32-byte
     little-endian each, standard form) per committed slot, i.e. witness_size - first_slot of them; curve "bn254_g1"
@@ -445,6 +504,15 @@ class Batch:
         if rc != B3W_OK:
             raise B3WError(rc, f"b3w_batch_verify: status {rc}: {self.ctx.last_error()}")
         return mm
+
+    def r1cs_check(self, r1cs):
+        """Constraint check of the last run's bodies: (violations uint32 [n], first violated constraint uint32 [n])."""
+        viol = np.zeros(self.n, dtype=np.uint32)
+        first = np.zeros(self.n, dtype=np.uint32)
+        rc = lib().b3w_batch_r1cs_check(self.handle, r1cs.handle, viol.ctypes.data, first.ctypes.data)
+        if rc != B3W_OK:
+            raise B3WError(rc, f"b3w_batch_r1cs_check: status {rc}: {self.ctx.last_error()}")
+        return viol, first
 
     def write_wtns(self, directory, prefix="witness_", first=0, count=None):
         """Stream witnesses [first, first+count) to <directory>/<prefix><index>.wtns; returns files written."""

@@ -7,6 +7,8 @@
 #include <stdlib.h>
 #include <string.h>
 #include <algorithm>
+#include <array>
+#include <map>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -912,6 +914,220 @@ int32_t b3w_chain_plan_parents_device(b3w_ctx *ctx, const uint32_t *d_levels, ui
   const uint32_t last_blocks = last_bytes ? (uint32_t)((last_bytes + 63) / 64) : 1;
   int rc = b3w_launch_plan_parents(d_levels, n_chunks, P, first_chunk, n_chunks_local, last_blocks, d_records, (hipStream_t)stream);
   return rc ? hip_fail(ctx, (hipError_t)rc, "plan parents launch") : B3W_OK;
+}
+
+// ---------------------------------------------------------------- rank-1 constraint check (on-device consumer #1)
+}  // extern "C"
+
+struct b3w_r1cs {
+  b3w_ctx *ctx = nullptr;
+  uint32_t m = 0, nwires = 0, npubout = 0, npubin = 0, nprvin = 0;
+  uint64_t nterms = 0;
+  B3wField field{};
+  uint32_t *d_rows = nullptr, *d_row_id = nullptr, *d_wires = nullptr, *d_coefR = nullptr;
+  uint16_t *d_cids = nullptr;
+};
+
+namespace {
+// little-endian reader over the file image; `ok` goes false on the first read past the end
+struct ByteReader {
+  const uint8_t *p; size_t len, pos = 0; bool ok = true;
+  ByteReader(const uint8_t *p_, size_t n) : p(p_), len(n) {}
+  bool need(size_t n) { if (!ok || len - pos < n) ok = false; return ok; }
+  uint32_t u32() { if (!need(4)) return 0; uint32_t v; memcpy(&v, p + pos, 4); pos += 4; return v; }
+  uint64_t u64() { if (!need(8)) return 0; uint64_t v; memcpy(&v, p + pos, 8); pos += 8; return v; }
+  const uint8_t *bytes(size_t n) { if (!need(n)) return nullptr; const uint8_t *q = p + pos; pos += n; return q; }
+};
+
+void u256_add_mod(uint32_t a[8], const uint32_t b[8], const uint32_t p[8]) {
+  uint64_t c = 0;
+  for (int i = 0; i < 8; i++) { const uint64_t t = (uint64_t)a[i] + b[i] + c; a[i] = (uint32_t)t; c = t >> 32; }
+  bool ge = c != 0;
+  if (!ge) { ge = true; for (int i = 7; i >= 0; --i) if (a[i] != p[i]) { ge = a[i] > p[i]; break; } }
+  if (ge) { uint64_t br = 0; for (int i = 0; i < 8; i++) { const uint64_t t = (uint64_t)a[i] - p[i] - br; a[i] = (uint32_t)t; br = (t >> 63) & 1; } }
+}
+// x * 2^256 mod p by 256 modular doublings (host, set-up only)
+void to_montgomery_host(uint32_t x[8], const uint32_t p[8]) {
+  for (int i = 0; i < 256; i++) { uint32_t y[8]; memcpy(y, x, 32); u256_add_mod(x, y, p); }
+}
+}  // namespace
+
+extern "C" {
+
+int32_t b3w_r1cs_create(b3w_ctx *ctx, const uint8_t *img, size_t len, b3w_r1cs **out) {
+  if (!ctx || !img || !out) return B3W_E_BAD_ARGUMENT;
+  *out = nullptr;
+  auto bad = [&](const char *why) { ctx->last_error = std::string("r1cs: ") + why; return B3W_E_BAD_ARGUMENT; };
+  // iden3 r1cs binary format v1: "r1cs" | u32 version | u32 nSections | { u32 type | u64 size | body }*
+  ByteReader rd(img, len);
+  const uint8_t *magic = rd.bytes(4);
+  if (!magic || memcmp(magic, "r1cs", 4)) return bad("not an r1cs file");
+  if (rd.u32() != 1) return bad("unsupported format version");
+  const uint32_t nsec = rd.u32();
+  size_t hdr_at = 0, cons_at = 0, cons_len = 0;
+  for (uint32_t s = 0; s < nsec && rd.ok; s++) {
+    const uint32_t type = rd.u32();
+    const uint64_t size = rd.u64();
+    if (!rd.ok || size > len - rd.pos) return bad("truncated section");
+    if (type == 1) hdr_at = rd.pos;
+    if (type == 2) { cons_at = rd.pos; cons_len = (size_t)size; }
+    if (type == 4 || type == 5) return bad("custom gates are not supported");
+    rd.pos += (size_t)size;
+  }
+  if (!hdr_at || !cons_at) return bad("header or constraint section missing");
+  ByteReader h(img + hdr_at, len - hdr_at);
+  if (h.u32() != 32) return bad("field size must be 32 bytes");
+  const uint8_t *prime = h.bytes(32);
+  if (!prime || memcmp(prime, ctx->desc.prime, 32)) return bad("the file's prime is not this circuit's field");
+  const uint32_t nwires = h.u32(), npubout = h.u32(), npubin = h.u32(), nprvin = h.u32();
+  (void)h.u64();                                          // nLabels
+  const uint32_t m = h.u32();
+  if (!h.ok) return bad("truncated header");
+  if (nwires != ctx->desc.nwit) return bad("nWires differs from this circuit's witness size");
+  // constraints: A, B, C as (u32 wire, 32-byte LE coefficient) lists; distinct coefficients are tabulated
+  uint32_t P[8];
+  memcpy(P, ctx->desc.prime, 32);
+  uint32_t pm1[8];
+  memcpy(pm1, P, 32);
+  pm1[0] -= 1;                                            // p is odd: no borrow
+  std::vector<std::array<uint32_t, 8>> coefs(2);          // ids 0 (+1) and 1 (-1) are handled without a multiplication
+  coefs[0] = {1, 0, 0, 0, 0, 0, 0, 0};
+  memcpy(coefs[1].data(), pm1, 32);
+  std::map<std::array<uint32_t, 8>, uint32_t> coef_id;
+  coef_id[coefs[0]] = 0;
+  coef_id[coefs[1]] = 1;
+  struct Row { uint32_t off, na, nb, nc, id; };
+  std::vector<Row> rows;
+  rows.reserve(m);
+  std::vector<uint32_t> wires;
+  std::vector<uint16_t> cids;
+  ByteReader c(img + cons_at, cons_len);
+  for (uint32_t k = 0; k < m; k++) {
+    Row r{(uint32_t)wires.size(), 0, 0, 0, k};
+    uint32_t *cnt[3] = {&r.na, &r.nb, &r.nc};
+    for (int part = 0; part < 3; part++) {
+      const uint32_t n = c.u32();
+      if (!c.ok || (uint64_t)n * 36 > cons_len - c.pos) return bad("truncated constraint section");
+      for (uint32_t t = 0; t < n; t++) {
+        const uint32_t w = c.u32();
+        std::array<uint32_t, 8> cf;
+        memcpy(cf.data(), c.bytes(32), 32);
+        if (w >= nwires) return bad("wire index out of range");
+        bool ge = true;
+        for (int i = 7; i >= 0; --i) if (cf[i] != P[i]) { ge = cf[i] > P[i]; break; }
+        if (ge) return bad("coefficient not reduced mod p");
+        bool zero = true;
+        for (int i = 0; i < 8; i++) zero &= cf[i] == 0;
+        if (zero) continue;
+        auto it = coef_id.find(cf);
+        uint32_t id;
+        if (it == coef_id.end()) {
+          id = (uint32_t)coefs.size();
+          if (id > 0xFFFF) return bad("more than 65 536 distinct coefficients");
+          coef_id[cf] = id;
+          coefs.push_back(cf);
+        } else id = it->second;
+        wires.push_back(w);
+        cids.push_back((uint16_t)id);
+        (*cnt[part])++;
+      }
+    }
+    if (wires.size() > 0xFFFFFFF0ull) return bad("too many terms");
+    rows.push_back(r);
+  }
+  // rows of one shape side by side: the lanes of a wave then run the same trip counts
+  std::stable_sort(rows.begin(), rows.end(), [](const Row &a, const Row &b) {
+    if (a.nc != b.nc) return a.nc > b.nc;
+    if (a.na != b.na) return a.na > b.na;
+    return a.nb > b.nb;
+  });
+  std::vector<uint32_t> rowdesc(4 * (size_t)m), row_id(m);
+  for (uint32_t k = 0; k < m; k++) {
+    rowdesc[4 * k] = rows[k].off; rowdesc[4 * k + 1] = rows[k].na; rowdesc[4 * k + 2] = rows[k].nb; rowdesc[4 * k + 3] = rows[k].nc;
+    row_id[k] = rows[k].id;
+  }
+  std::vector<uint32_t> coefR(8 * coefs.size());
+  for (size_t i = 0; i < coefs.size(); i++) {
+    memcpy(&coefR[8 * i], coefs[i].data(), 32);
+    to_montgomery_host(&coefR[8 * i], P);
+  }
+  b3w_r1cs *r = new b3w_r1cs;
+  r->ctx = ctx; r->m = m; r->nwires = nwires; r->npubout = npubout; r->npubin = npubin; r->nprvin = nprvin; r->nterms = wires.size();
+  memcpy(r->field.p, P, 32);
+  uint32_t r2[8] = {1, 0, 0, 0, 0, 0, 0, 0};
+  to_montgomery_host(r2, P);
+  to_montgomery_host(r2, P);                              // 2^512 mod p
+  memcpy(r->field.r2, r2, 32);
+  uint32_t inv = P[0];                                    // Newton: p^-1 mod 2^32
+  for (int i = 0; i < 5; i++) inv *= 2u - P[0] * inv;
+  r->field.inv = 0u - inv;
+  DeviceGuard guard(ctx->device);
+  hipError_t e = guard.err;
+  auto up = [&](void **d, const void *src, size_t bytes) {
+    if (e == hipSuccess) e = hipMalloc(d, bytes ? bytes : 4);
+    if (e == hipSuccess && bytes) e = hipMemcpy(*d, src, bytes, hipMemcpyHostToDevice);
+  };
+  up((void **)&r->d_rows, rowdesc.data(), rowdesc.size() * 4);
+  up((void **)&r->d_row_id, row_id.data(), row_id.size() * 4);
+  up((void **)&r->d_wires, wires.data(), wires.size() * 4);
+  up((void **)&r->d_cids, cids.data(), cids.size() * 2);
+  up((void **)&r->d_coefR, coefR.data(), coefR.size() * 4);
+  if (e != hipSuccess) { b3w_r1cs_destroy(r); return e == hipErrorOutOfMemory ? B3W_E_NOT_ENOUGH_MEMORY : hip_fail(ctx, e, "r1cs upload"); }
+  *out = r;
+  return B3W_OK;
+}
+
+int32_t b3w_r1cs_info(const b3w_r1cs *r, uint32_t *n_constraints, uint32_t *n_wires, uint64_t *n_terms, uint32_t *n_pub_out,
+                      uint32_t *n_pub_in, uint32_t *n_prv_in) {
+  if (!r) return B3W_E_BAD_ARGUMENT;
+  if (n_constraints) *n_constraints = r->m;
+  if (n_wires) *n_wires = r->nwires;
+  if (n_terms) *n_terms = r->nterms;
+  if (n_pub_out) *n_pub_out = r->npubout;
+  if (n_pub_in) *n_pub_in = r->npubin;
+  if (n_prv_in) *n_prv_in = r->nprvin;
+  return B3W_OK;
+}
+
+void b3w_r1cs_destroy(b3w_r1cs *r) {
+  if (!r) return;
+  DeviceGuard guard(r->ctx->device);
+  if (r->d_rows) (void)hipFree(r->d_rows);
+  if (r->d_row_id) (void)hipFree(r->d_row_id);
+  if (r->d_wires) (void)hipFree(r->d_wires);
+  if (r->d_cids) (void)hipFree(r->d_cids);
+  if (r->d_coefR) (void)hipFree(r->d_coefR);
+  delete r;
+}
+
+int32_t b3w_r1cs_check_device(b3w_ctx *ctx, const b3w_r1cs *r, const uint8_t *d_bodies, uint32_t n, uint64_t pitch,
+                              uint32_t *d_violations, uint32_t *d_first, void *stream) {
+  if (!ctx || !r || r->ctx != ctx || !d_bodies || !d_violations) return B3W_E_BAD_ARGUMENT;
+  const uint64_t body = 32ull * ctx->desc.nwit;
+  if (pitch == 0) pitch = body;
+  if (pitch < body || (pitch & 15) || (reinterpret_cast<uintptr_t>(d_bodies) & 15)) {
+    ctx->last_error = "pitch must be >= witness_size*32 and a multiple of 16, bodies 16-byte aligned";
+    return B3W_E_BAD_ARGUMENT;
+  }
+  ON_DEVICE(ctx);
+  const int rc = b3w_launch_r1cs(d_bodies, n, pitch, r->m, r->d_rows, r->d_row_id, r->d_wires, r->d_cids, r->d_coefR, &r->field,
+                                 d_violations, d_first, (hipStream_t)stream);
+  return rc ? hip_fail(ctx, (hipError_t)rc, "r1cs check launch") : B3W_OK;
+}
+
+int32_t b3w_batch_r1cs_check(b3w_batch *b, const b3w_r1cs *r, uint32_t *host_violations, uint32_t *host_first) {
+  if (!b || !r || !host_violations) return B3W_E_BAD_ARGUMENT;
+  b3w_ctx *ctx = b->ctx;
+  if (!b->n) return B3W_OK;
+  ON_DEVICE(ctx);
+  uint32_t *d = nullptr;
+  HIP_TRY(ctx, hipMalloc((void **)&d, (size_t)b->n * 8));
+  int32_t rc = b3w_r1cs_check_device(ctx, r, b->d_bodies, b->n, b->pitch, d, d + b->n, nullptr);
+  hipError_t e = rc == B3W_OK ? hipMemcpy(host_violations, d, (size_t)b->n * 4, hipMemcpyDeviceToHost) : hipSuccess;
+  if (rc == B3W_OK && e == hipSuccess && host_first) e = hipMemcpy(host_first, d + b->n, (size_t)b->n * 4, hipMemcpyDeviceToHost);
+  (void)hipFree(d);
+  if (rc) return rc;
+  return e == hipSuccess ? B3W_OK : hip_fail(ctx, e, "hipMemcpy(r1cs check)");
 }
 
 // ---------------------------------------------------------------- commitments (on-device consumer #2)

@@ -62,3 +62,15 @@ extern "C" int b3w_launch_commit(const uint8_t *d_bodies, uint32_t n, uint64_t p
                                  uint32_t img_row, const uint32_t *d_runs /* pairs: v0 | (len - 1) << 24, image word | shift << 16 */, uint32_t nruns,
                                  const uint32_t *d_table, uint32_t nwin, uint32_t window, uint32_t *d_sums, uint8_t *d_out,
                                  int32_t *d_status, const B3wCurve *curve, hipStream_t stream);
+
+// b3w_r1cs.hip: rank-1 constraint check of witness bodies (on-device consumer #1: A z * B z - C z = 0 for every row)
+struct B3wField {
+  uint32_t p[8];      // modulus of the circuit's field, little-endian limbs
+  uint32_t r2[8];     // 2^512 mod p
+  uint32_t inv;       // -p^-1 mod 2^32
+};
+// rows: m x {first term, terms in A, in B, in C} (terms of a row are stored A then B then C); row_id: the row's index in the
+// .r1cs file (rows are sorted by shape); term k = wires[k], cids[k] (0: coefficient +1, 1: -1, else coefR[8 * cid ..] = coef * 2^256 mod p)
+extern "C" int b3w_launch_r1cs(const uint8_t *d_bodies, uint32_t n, uint64_t pitch, uint32_t m, const uint32_t *d_rows,
+                               const uint32_t *d_row_id, const uint32_t *d_wires, const uint16_t *d_cids, const uint32_t *d_coefR,
+                               const B3wField *field, uint32_t *d_violations, uint32_t *d_first, hipStream_t stream);

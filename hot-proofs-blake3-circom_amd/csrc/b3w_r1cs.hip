@@ -1,0 +1,223 @@
+// b3w_r1cs.hip — on-device rank-1 constraint check of witness bodies: for every constraint (A, B, C) of an R1CS and every
+// body z in HBM, is <A,z> * <B,z> - <C,z> = 0 in the circuit's field?
+//
+// This is what the reference's consumers do with a witness before anything else: circom_tester's expectPass /
+// checkConstraints (test/blake3_hash.test.ts:36) and the Nova driver's synthesize_with_vec, which enforces
+// every R1CS row over the witness variables (rust_fold/src/utils.rs:17-88).  The constraint system is DATA (an iden3
+// .r1cs image parsed in b3w_capi.cpp: for blake3_compression the one tools/gen_r1cs.py derives from the circuit text
+// and checks against the build's .sym and the committed witness); nothing in here knows BLAKE3, the slot tables or the
+// TRACE code of the witness kernels, so a wrong witness kernel or a wrong slot table cannot hide behind it.
+//
+// Arithmetic: full 256-bit field elements, eight 32-bit limbs, Montgomery multiplication (CIOS) with the modulus passed
+// at run time (BN254 scalar field or the Vesta base field).  A term coef * z[wire] is montmul(coef * R, z) = coef * z;
+// coefficients +1 / -1 (93 % of the terms of the compression system) are an addition / subtraction.
+//
+// Mapping: thread = (constraint, body).  blockIdx.y = body, 256 consecutive rows per workgroup; rows are sorted by
+// shape (terms in A, B, C) on the host so that the 64 lanes of a wave run the same trip counts.  The constraint stream
+// (117 760 terms, 0.9 MB for blake3_compression) is shared by all bodies and stays in L2; each term gathers one 32-byte
+// element of the body — neighbouring rows read neighbouring slots (the bit runs), so most wave loads are whole lines.
+// Bound: L2/TA gather rate and integer ALU, not HBM: a body is read ~4.9x (once per term), 0.2 % of peak flops are needed.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "b3w_kernels.h"
+
+namespace {
+
+struct Fe { uint32_t l[8]; };
+
+__device__ __forceinline__ bool fe_geq(const Fe &a, const uint32_t p[8]) {
+#pragma unroll
+  for (int i = 7; i >= 0; --i) {
+    if (a.l[i] != p[i]) return a.l[i] > p[i];
+  }
+  return true;
+}
+
+__device__ __forceinline__ void fe_sub_p(Fe &a, const uint32_t p[8]) {
+  uint64_t br = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    const uint64_t t = (uint64_t)a.l[i] - p[i] - br;
+    a.l[i] = (uint32_t)t;
+    br = (t >> 63) & 1;
+  }
+}
+
+// a = a + b mod p (a, b < p)
+__device__ __forceinline__ void fe_add(Fe &a, const Fe &b, const uint32_t p[8]) {
+  uint64_t c = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    const uint64_t t = (uint64_t)a.l[i] + b.l[i] + c;
+    a.l[i] = (uint32_t)t;
+    c = t >> 32;
+  }
+  if (c || fe_geq(a, p)) fe_sub_p(a, p);
+}
+
+// a = a - b mod p (a, b < p)
+__device__ __forceinline__ void fe_sub(Fe &a, const Fe &b, const uint32_t p[8]) {
+  uint64_t br = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    const uint64_t t = (uint64_t)a.l[i] - b.l[i] - br;
+    a.l[i] = (uint32_t)t;
+    br = (t >> 63) & 1;
+  }
+  if (br) {
+    uint64_t c = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      const uint64_t t = (uint64_t)a.l[i] + p[i] + c;
+      a.l[i] = (uint32_t)t;
+      c = t >> 32;
+    }
+  }
+}
+
+__device__ __forceinline__ bool fe_is_zero(const Fe &a) {
+  uint32_t o = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) o |= a.l[i];
+  return o == 0;
+}
+
+// a * b / 2^256 mod p (a, b < p): coarsely integrated operand scanning
+__device__ __forceinline__ Fe mont_mul(const Fe &a, const Fe &b, const B3wField &F) {
+  uint32_t t[10];
+#pragma unroll
+  for (int i = 0; i < 10; i++) t[i] = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    uint64_t c = 0;
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+      const uint64_t s = (uint64_t)a.l[j] * b.l[i] + t[j] + c;
+      t[j] = (uint32_t)s;
+      c = s >> 32;
+    }
+    uint64_t s = (uint64_t)t[8] + c;
+    t[8] = (uint32_t)s;
+    t[9] = (uint32_t)(s >> 32);
+    const uint32_t m = t[0] * F.inv;
+    c = ((uint64_t)m * F.p[0] + t[0]) >> 32;
+#pragma unroll
+    for (int j = 1; j < 8; j++) {
+      s = (uint64_t)m * F.p[j] + t[j] + c;
+      t[j - 1] = (uint32_t)s;
+      c = s >> 32;
+    }
+    s = (uint64_t)t[8] + c;
+    t[7] = (uint32_t)s;
+    t[8] = t[9] + (uint32_t)(s >> 32);
+  }
+  Fe r;
+#pragma unroll
+  for (int i = 0; i < 8; i++) r.l[i] = t[i];
+  if (t[8] || fe_geq(r, F.p)) fe_sub_p(r, F.p);
+  return r;
+}
+
+// one element of a body; *wild is set when it is not a canonical representative (>= p)
+__device__ __forceinline__ Fe load_z(const uint8_t *body, uint32_t wire, const B3wField &F, bool *wild) {
+  const uint4 *q = reinterpret_cast<const uint4 *>(body + (size_t)wire * 32);
+  const uint4 lo = q[0], hi = q[1];
+  Fe z;
+  z.l[0] = lo.x; z.l[1] = lo.y; z.l[2] = lo.z; z.l[3] = lo.w;
+  z.l[4] = hi.x; z.l[5] = hi.y; z.l[6] = hi.z; z.l[7] = hi.w;
+  if (fe_geq(z, F.p)) {
+    *wild = true;
+    do fe_sub_p(z, F.p); while (fe_geq(z, F.p));         // keep the arithmetic below in range all the same
+  }
+  return z;
+}
+
+// <row, z>: `n` terms starting at `off`; term = wire | coefficient id (0: +1, 1: -1, else index into coefR)
+__device__ __forceinline__ Fe dot(const uint8_t *body, const uint32_t *wires, const uint16_t *cids, const uint32_t *coefR,
+                                  uint32_t off, uint32_t n, const B3wField &F, bool *wild) {
+  Fe acc;
+#pragma unroll
+  for (int i = 0; i < 8; i++) acc.l[i] = 0;
+  for (uint32_t k = 0; k < n; k++) {
+    const uint32_t w = wires[off + k];
+    const uint32_t cid = cids[off + k];
+    const Fe z = load_z(body, w, F, wild);
+    if (cid == 0) fe_add(acc, z, F.p);
+    else if (cid == 1) fe_sub(acc, z, F.p);
+    else {
+      Fe cf;
+      const uint4 *q = reinterpret_cast<const uint4 *>(coefR + (size_t)cid * 8);
+      const uint4 lo = q[0], hi = q[1];
+      cf.l[0] = lo.x; cf.l[1] = lo.y; cf.l[2] = lo.z; cf.l[3] = lo.w;
+      cf.l[4] = hi.x; cf.l[5] = hi.y; cf.l[6] = hi.z; cf.l[7] = hi.w;
+      const Fe t = mont_mul(cf, z, F);                   // (coef * R) * z / R
+      fe_add(acc, t, F.p);
+    }
+  }
+  return acc;
+}
+
+__global__ __launch_bounds__(256) void b3w_r1cs_kernel(const uint8_t *__restrict__ bodies, uint64_t pitch, uint32_t m,
+                                                       const uint4 *__restrict__ rows /* off, nA, nB, nC */,
+                                                       const uint32_t *__restrict__ row_id, const uint32_t *__restrict__ wires,
+                                                       const uint16_t *__restrict__ cids, const uint32_t *__restrict__ coefR,
+                                                       B3wField F, uint32_t *__restrict__ violations, uint32_t *__restrict__ first) {
+  const uint32_t r = blockIdx.x * 256 + threadIdx.x;
+  const uint32_t b = blockIdx.y;
+  const uint8_t *body = bodies + (uint64_t)b * pitch;
+  bool bad = false;
+  uint32_t id = 0xFFFFFFFFu;
+  if (r < m) {
+    const uint4 d = rows[r];
+    bool wild = false;
+    const Fe cz = dot(body, wires, cids, coefR, d.x + d.y + d.z, d.w, F, &wild);
+    if (d.y == 0 || d.z == 0) {
+      bad = !fe_is_zero(cz);                             // 0 * B - C = 0  (a linear constraint)
+      if (d.y) (void)dot(body, wires, cids, coefR, d.x, d.y, F, &wild);              // still read for the canonical-form check
+      if (d.z) (void)dot(body, wires, cids, coefR, d.x + d.y, d.z, F, &wild);
+    } else {
+      const Fe az = dot(body, wires, cids, coefR, d.x, d.y, F, &wild);
+      const Fe bz = dot(body, wires, cids, coefR, d.x + d.y, d.z, F, &wild);
+      Fe r2;
+#pragma unroll
+      for (int i = 0; i < 8; i++) r2.l[i] = F.r2[i];
+      const Fe ab = mont_mul(mont_mul(az, r2, F), bz, F);                            // (az * R) * bz / R = az * bz
+      Fe diff = ab;
+      fe_sub(diff, cz, F.p);
+      bad = !fe_is_zero(diff);
+    }
+    bad = bad || wild;                                   // an element >= p is no witness value, whatever it is congruent to
+    id = row_id[r];
+  }
+  const uint64_t mask = __ballot(bad);
+  if (mask) {
+    uint32_t mine = bad ? id : 0xFFFFFFFFu;
+#pragma unroll
+    for (int s = 32; s > 0; s >>= 1) mine = min(mine, (uint32_t)__shfl_xor((int)mine, s));
+    if ((threadIdx.x & 63) == 0) {
+      atomicAdd(&violations[b], (uint32_t)__popcll(mask));
+      if (first) atomicMin(&first[b], mine);
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" int b3w_launch_r1cs(const uint8_t *d_bodies, uint32_t n, uint64_t pitch, uint32_t m, const uint32_t *d_rows,
+                               const uint32_t *d_row_id, const uint32_t *d_wires, const uint16_t *d_cids, const uint32_t *d_coefR,
+                               const B3wField *field, uint32_t *d_violations, uint32_t *d_first, hipStream_t stream) {
+  if (!n || !m) return 0;
+  hipError_t e = hipMemsetAsync(d_violations, 0, (size_t)n * 4, stream);
+  if (e == hipSuccess && d_first) e = hipMemsetAsync(d_first, 0xFF, (size_t)n * 4, stream);
+  if (e != hipSuccess) return (int)e;
+  // grid.y is limited to 65 535: bodies in slabs
+  for (uint32_t b0 = 0; b0 < n; b0 += 65535) {
+    const uint32_t nb = n - b0 < 65535 ? n - b0 : 65535;
+    hipLaunchKernelGGL(b3w_r1cs_kernel, dim3((m + 255) / 256, nb), dim3(256), 0, stream, d_bodies + (uint64_t)b0 * pitch, pitch, m,
+                       reinterpret_cast<const uint4 *>(d_rows), d_row_id, d_wires, d_cids, d_coefR, *field, d_violations + b0,
+                       d_first ? d_first + b0 : nullptr);
+    e = hipGetLastError();
+    if (e != hipSuccess) return (int)e;
+  }
+  return 0;
+}

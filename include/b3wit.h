@@ -148,7 +148,32 @@ int32_t b3w_batch_time_device(b3w_ctx *ctx, const uint32_t *d_records, uint32_t 
                               uint64_t pitch, uint32_t *d_public, int32_t *d_status, void *stream,
                               uint32_t iters, float *avg_ms);
 
-/* On-device consumer: check n witness bodies in HBM.  The circuits are deterministic (the inputs fix every
+/* On-device consumer #1: the rank-1 constraint check  <A_k, z> * <B_k, z> - <C_k, z> = 0  for every constraint k of an
+ * R1CS and every witness body z in HBM — what the reference's consumers do with a witness first: circom_tester's
+ * expectPass / checkConstraints (test/blake3_hash.test.ts:36) and synthesize_with_vec, which enforces every R1CS row over
+ * the witness variables (rust_fold/src/utils.rs:17-88, rows read from the circuit's .r1cs by circom-scotia).
+ * The constraint system is the caller's: `r1cs_image` is a complete iden3 .r1cs file image (format version 1: header,
+ * constraints, wire map) over the ctx's field with nWires = witness_size — the circuit's own .r1cs where the maintainer
+ * has it (the reference checkout does not: .MISSING_LARGE_BLOBS), or the one this repository derives for blake3_compression
+ * from the circuit text (tools/gen_r1cs.py -> hot-proofs-blake3-circom_amd/constraints/blake3_compression.r1cs.gz, gunzip first).
+ * The check is independent of the witness kernels: full field arithmetic on the 32-byte elements as they lie in the
+ * body, no knowledge of the circuit beyond the file.
+ *   d_violations[i] = number of constraints body i violates (0 = a valid witness); an element >= p counts as a violation
+ *                     of every constraint that reads it;   d_first[i] (may be NULL) = lowest violated constraint index
+ *                     (file order), 0xFFFFFFFF if none. */
+typedef struct b3w_r1cs b3w_r1cs;
+int32_t b3w_r1cs_create(b3w_ctx *ctx, const uint8_t *r1cs_image, size_t len, b3w_r1cs **out);
+int32_t b3w_r1cs_info(const b3w_r1cs *r1cs, uint32_t *n_constraints, uint32_t *n_wires, uint64_t *n_terms,
+                      uint32_t *n_pub_out, uint32_t *n_pub_in, uint32_t *n_prv_in);
+void b3w_r1cs_destroy(b3w_r1cs *r1cs);
+/* d_bodies 16-byte aligned, pitch a multiple of 16 (0 = witness_size * 32). */
+int32_t b3w_r1cs_check_device(b3w_ctx *ctx, const b3w_r1cs *r1cs, const uint8_t *d_bodies, uint32_t n, uint64_t pitch,
+                              uint32_t *d_violations, uint32_t *d_first, void *stream);
+/* The same on the witnesses of the last b3w_batch_run; host arrays of n entries (host_first may be NULL). */
+int32_t b3w_batch_r1cs_check(b3w_batch *batch, const b3w_r1cs *r1cs, uint32_t *host_violations, uint32_t *host_first);
+
+/* A cheaper tamper check of n witness bodies in HBM (NOT independent evidence: it shares the witness kernels' trace code
+ * and slot table).  The circuits are deterministic (the inputs fix every
  * signal), so a body satisfies all constraints iff it equals the witness recomputed from its own input
  * slots; the kernel reads each body once (HBM-read bound) and compares every 16-byte unit.
  * d_mismatch[i] = number of differing units of body i: 0 = valid witness; 0xFFFFFFFF = the body's inputs are

@@ -1,0 +1,157 @@
+"""The on-device rank-1 constraint check (b3w_r1cs_check_device, csrc/b3w_r1cs.hip) — the GPU counterpart of
+circom_tester's expectPass / expectFail in the reference's tests (test/blake3_hash.test.ts:36,44).  The constraint
+system is the one tools/gen_r1cs.py derives from the circuit text (pinned on the CPU by tests/test_r1cs_cpu.py against
+the reference's own witness); the kernel's verdicts are compared with a plain-integer evaluation (tests/r1cs_ref.py).
+None of this runs the witness kernels' TRACE code on the bodies under test."""
+import ctypes
+import random
+
+import numpy as np
+import pytest
+
+import b3w_testlib as T
+import r1cs_ref as R
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def env():
+    import torch
+    m = T.pkg()
+    ctx = m.Context("compression", 0)
+    return dict(m=m, ctx=ctx, r1cs=m.R1cs(ctx), sys=R.parse(R.read_image()), torch=torch, dev=torch.device("cuda:0"))
+
+
+def _check(env, bodies):
+    """bodies: uint8 [n, body_bytes] CUDA tensor -> (violations, first) as numpy"""
+    torch = env["torch"]
+    n = bodies.shape[0]
+    viol = torch.full((n,), 77, dtype=torch.int32, device=env["dev"])
+    first = torch.zeros((n,), dtype=torch.int32, device=env["dev"])
+    env["r1cs"].check_device(bodies.data_ptr(), n, bodies.stride(0), viol.data_ptr(), first.data_ptr(),
+                             torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    return viol.cpu().numpy().view(np.uint32), first.cpu().numpy().view(np.uint32)
+
+
+def test_the_loaded_system_is_the_files(env):
+    r = env["r1cs"]
+    assert (r.n_constraints, r.n_wires, r.n_terms) == (24544, 24093, 117760)
+    assert (r.n_pub_out, r.n_pub_in, r.n_prv_in) == (16, 0, 28)
+
+
+def test_reference_witness_passes(env):
+    """build/blake3_compression/testInp/witness.wtns as committed by the reference: 0 violations."""
+    torch = env["torch"]
+    body = np.frombuffer(T.golden_image("reference_testInp_witness.wtns.gz")[76:], dtype=np.uint8).copy()
+    viol, first = _check(env, torch.from_numpy(body).to(env["dev"]).view(1, -1))
+    assert viol[0] == 0 and first[0] == 0xFFFFFFFF
+
+
+def test_kernel_witnesses_pass_and_1000_single_slot_corruptions_fail(env):
+    """A clean config-2 batch satisfies every constraint; then one slot of each of 1 000 bodies is changed (bit flips,
+    off-by-ones, random elements, a word in a bit slot): every one is caught, and count and first violated constraint
+    equal the plain-integer evaluation."""
+    torch, m, ctx, sys_ = env["torch"], env["m"], env["ctx"], env["sys"]
+    n = 1000
+    recs = m.workloads.config2_compression(n, first=50000)
+    d_recs = torch.from_numpy(recs.view(np.int32)).to(env["dev"])
+    bodies = torch.empty((n, ctx.body_bytes), dtype=torch.uint8, device=env["dev"])
+    st = torch.zeros(n, dtype=torch.int32, device=env["dev"])
+    ctx.run_device(d_recs.data_ptr(), n, bodies.data_ptr(), 0, 0, st.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert int(st.abs().sum().item()) == 0
+    viol, first = _check(env, bodies)
+    assert (viol == 0).all() and (first == 0xFFFFFFFF).all()
+
+    rng = random.Random(2024)
+    p = sys_["prime"]
+    by_wire = R.rows_of_wire(sys_)
+    host = bodies.cpu().numpy()
+    slots = rng.sample(range(24093), 900) + [0, 1, 16, 17, 44, 45, 24092] + [rng.randrange(24093) for _ in range(93)]
+    changed = []
+    for i, s in enumerate(slots):
+        old = int.from_bytes(host[i, 32 * s:32 * s + 32].tobytes(), "little")
+        new = rng.choice([old ^ 1, (old + 1) % p, (old - 1) % p, rng.randrange(p), old ^ (1 << rng.randrange(34)), 2 if old < 2 else 0])
+        if new == old:
+            new = (old + 5) % p
+        host[i, 32 * s:32 * s + 32] = np.frombuffer(new.to_bytes(32, "little"), dtype=np.uint8)
+        changed.append((s, new))
+    viol, first = _check(env, torch.from_numpy(host).to(env["dev"]))
+    assert (viol > 0).all(), np.nonzero(viol == 0)[0][:10]
+    for i in range(0, n, 9):                          # every 9th body against the integer evaluation of the rows that read the slot
+        s, new = changed[i]
+        z = R.body_to_ints(host[i])
+        want = R.violated(sys_, z, by_wire[s])
+        assert viol[i] == len(want) and first[i] == min(want), (i, s)
+
+
+def test_accepted_non_canonical_inputs_pass_and_elements_past_p_fail(env):
+    """The circuit has no range check on m: the WASM accepts m[0] = -1, 2^32, 2^33; those witnesses (exact
+    kernel) satisfy the constraints too.  An element >= p is not a witness value even when congruent to the right one."""
+    torch, m = env["torch"], env["m"]
+    g = T.golden("compression")
+    wild = [c for c in g["cases"] if "error" not in c and not T.is_canonical_u32("compression", c["input"])][:6]
+    assert wild
+    wc = m.WitnessCalculator(env["ctx"])
+    bodies = np.stack([wc.calculateBinWitness(c["input"], 0) for c in wild])
+    viol, _ = _check(env, torch.from_numpy(bodies).to(env["dev"]))
+    assert (viol == 0).all(), [c["name"] for c, v in zip(wild, viol) if v]
+    p = env["sys"]["prime"]
+    z = R.body_to_ints(bodies[0])
+    s = 20000
+    bodies[0, 32 * s:32 * s + 32] = np.frombuffer((z[s] + p).to_bytes(32, "little"), dtype=np.uint8)
+    viol, first = _check(env, torch.from_numpy(bodies).to(env["dev"]))
+    want = R.violated(env["sys"], R.body_to_ints(bodies[0]))
+    assert viol[0] == len(want) > 0 and first[0] == min(want) and (viol[1:] == 0).all()
+
+
+def test_padded_pitch_and_batch_entry_point(env):
+    torch, m, ctx = env["torch"], env["m"], env["ctx"]
+    recs = m.workloads.config2_compression(5, first=123)
+    b = m.Batch(ctx, 8, pitch=ctx.body_bytes + 96)
+    b.run(recs)
+    viol, first = b.r1cs_check(env["r1cs"])
+    assert (viol == 0).all() and (first == 0xFFFFFFFF).all() and len(viol) == 5
+    b.close()
+
+
+def test_bad_images_are_refused(env):
+    m, ctx = env["m"], env["ctx"]
+    img = R.read_image()
+    for bad, why in ((img[:1000], "truncated"), (b"r1cx" + img[4:], "not an r1cs"), (img[:4] + b"\x02" + img[5:], "version")):
+        with pytest.raises(m.B3WError) as e:
+            m.R1cs(ctx, bad)
+        assert why in str(e.value), str(e.value)
+    nova = m.Context("nova_vesta", 0)
+    with pytest.raises(m.B3WError) as e:
+        m.R1cs(nova, img)
+    assert "prime" in str(e.value)
+    with pytest.raises(m.B3WError):
+        m.R1cs(nova)                                   # no derived system for the nova circuits
+    nova.close()
+    nb = m.Context("nova_bn254", 0)
+    with pytest.raises(m.B3WError) as e:
+        m.R1cs(nb, img)
+    assert "nWires" in str(e.value)
+    nb.close()
+
+
+def test_full_config2_batch_passes(env):
+    """All 4 096 witnesses of BASELINE config 2 satisfy all 24 544 constraints (100 M constraint evaluations)."""
+    torch, m, ctx = env["torch"], env["m"], env["ctx"]
+    n = 4096
+    recs = m.workloads.config2_compression(n)
+    d_recs = torch.from_numpy(recs.view(np.int32)).to(env["dev"])
+    bodies = torch.empty((n, ctx.body_bytes), dtype=torch.uint8, device=env["dev"])
+    ctx.run_device(d_recs.data_ptr(), n, bodies.data_ptr(), 0, 0, 0, torch.cuda.current_stream().cuda_stream)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    viol = torch.zeros(n, dtype=torch.int32, device=env["dev"])
+    env["r1cs"].check_device(bodies.data_ptr(), n, 0, viol.data_ptr(), 0, torch.cuda.current_stream().cuda_stream)
+    e0.record()
+    env["r1cs"].check_device(bodies.data_ptr(), n, 0, viol.data_ptr(), 0, torch.cuda.current_stream().cuda_stream)
+    e1.record()
+    torch.cuda.synchronize()
+    assert int(viol.abs().sum().item()) == 0
+    print(f"r1cs check: {n} bodies x 24544 constraints in {e0.elapsed_time(e1):.2f} ms")

@@ -1,0 +1,72 @@
+"""The constraint system the on-device check uses (hot-proofs-blake3-circom_amd/constraints/blake3_compression.r1cs.gz,
+derived from the circuit text by tools/gen_r1cs.py) against the reference's own data, on the CPU in plain integers:
+the reference's committed witness satisfies it, so do the oracle's witnesses (incl. the non-canonical inputs the circuit
+accepts), and any single changed slot violates it.  What the reference's tests do with circom_tester
+(test/blake3_hash.test.ts:36 expectPass / :44 expectFail)."""
+import os
+import random
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+import b3w_testlib as T
+import r1cs_ref as R
+
+
+@pytest.fixture(scope="module")
+def system():
+    return R.parse(R.read_image())
+
+
+def test_header_is_the_compression_circuit(system):
+    assert system["prime"] == T.BN254_R and system["n_wires"] == 24093
+    assert (system["n_pub_out"], system["n_pub_in"], system["n_prv_in"]) == (16, 0, 28)
+    cons = system["constraints"]
+    assert len(cons) == 24544
+    kinds = [("linear" if not a else "bool" if not c else "quadratic") for a, b, c in cons]
+    # per half-G: 34 + 33 + 2 * 32 booleanity, 2 * 32 xor products, 10 linear; per output xor: 64, 32, 3
+    assert (kinds.count("bool"), kinds.count("quadratic"), kinds.count("linear")) == (112 * 131 + 16 * 64, 112 * 64 + 16 * 32, 112 * 10 + 16 * 3)
+    used = set()
+    for a, b, c in cons:
+        used |= a.keys() | b.keys() | c.keys()
+    assert used == set(range(24093)), "every witness slot is read by some constraint"
+    assert system["wire2label"][0] == 0 and system["wire2label"][1] == 1 and len(set(system["wire2label"])) == 24093
+
+
+def test_reference_witness_satisfies_every_constraint(system):
+    img = T.golden_image("reference_testInp_witness.wtns.gz")       # build/blake3_compression/testInp/witness.wtns
+    z = R.body_to_ints(img[76:])
+    assert len(z) == 24093 and R.violated(system, z) == []
+
+
+def test_oracle_witnesses_satisfy_it_and_single_slot_changes_do_not(system):
+    g = T.golden("compression")
+    ok = [c for c in g["cases"] if "error" not in c]
+    picks = ok[:3] + [c for c in ok if not T.is_canonical_u32("compression", c["input"])][:3]
+    by_wire = R.rows_of_wire(system)
+    rng = random.Random(7)
+    for case in picks:
+        rc, body, _ = T.oracle_witness("compression", T.normalize_input("compression", case["input"]))
+        assert rc == 0
+        z = R.body_to_ints(body)
+        assert R.violated(system, z) == [], case["name"]
+        for _ in range(60):
+            s = rng.randrange(24093)
+            old = z[s]
+            z[s] = rng.choice([old ^ 1, (old + 1) % system["prime"], rng.randrange(system["prime"]), 0 if old else 2])
+            if z[s] != old:
+                assert R.violated(system, z, by_wire[s]), (case["name"], s)
+            z[s] = old
+
+
+def test_generator_reproduces_the_committed_file(tmp_path):
+    if not os.path.isdir("/root/reference"):
+        pytest.skip("reference checkout not present (GPU box): the generator reads its .sym and witness")
+    out = tmp_path / "x.r1cs.gz"
+    r = subprocess.run([sys.executable, os.path.join(T.ROOT, "tools", "gen_r1cs.py"), "--out", str(out)], capture_output=True, text=True,
+                       timeout=300)
+    assert r.returncode == 0, r.stderr[-1500:]
+    assert "69380 signals = the .sym's" in r.stdout and "reference witness satisfies all" in r.stdout
+    assert out.read_bytes() == open(R.BUILTIN, "rb").read()
