@@ -101,6 +101,9 @@ def lib():
         "b3w_chain_num_chunks": (u64, [u64]),
         "b3w_chain_num_leaf_steps": (u64, [u64]),
         "b3w_chain_path_len": (u32, [u64, u64]),
+        "b3w_chain_num_parent_steps": (u64, [u64, u64, u64]),
+        "b3w_chain_parent_row": (u64, [u64, u64]),
+        "b3w_chain_path_provable": (i32, [u64, u64]),
         "b3w_chain_plan_leaves_device": (i32, [vp, vp, u64, u64, u32, vp, vp, vp]),
         "b3w_chain_tree_device": (i32, [vp, vp, u64, vp, vp]),
         "b3w_chain_plan_parents_device": (i32, [vp, vp, u64, u64, u64, u32, vp, vp]),
@@ -147,6 +150,7 @@ EXPORTED_SYMBOLS = ("b3w_abi_version", "b3w_identify_wasm", "b3w_create", "b3w_d
                     "b3w_batch_run", "b3w_batch_outputs", "b3w_batch_fetch", "b3w_batch_device_ptr",
                     "b3w_batch_time_device", "b3w_batch_verify_device", "b3w_batch_verify",
                     "b3w_r1cs_create", "b3w_r1cs_info", "b3w_r1cs_destroy", "b3w_r1cs_check_device", "b3w_batch_r1cs_check", "b3w_batch_write_wtns", "b3w_batch_autotune_device", "b3w_bodies_alloc", "b3w_bodies_free", "b3w_bodies_trim", "b3w_batch_placement", "b3w_chain_num_chunks", "b3w_chain_num_leaf_steps", "b3w_chain_path_len",
+                    "b3w_chain_num_parent_steps", "b3w_chain_parent_row", "b3w_chain_path_provable",
                     "b3w_chain_plan_leaves_device", "b3w_chain_tree_device", "b3w_chain_plan_parents_device",
                     "b3w_commit_key_create", "b3w_commit_key_create_ex", "b3w_commit_key_window", "b3w_commit_key_destroy", "b3w_commit_records_device", "b3w_commit_records", "b3w_chain_commit_only", "b3w_chain_commitments", "b3w_batch_commit_device", "b3w_batch_commit", "b3w_commit_consumer",
                     "b3w_comm_unique_id", "b3w_comm_create", "b3w_comm_destroy", "b3w_comm_allgather", "b3w_batch_allgather_public",
@@ -420,10 +424,19 @@ class ChainPlanner:
         if rc != B3W_OK:
             raise B3WError(rc, f"{what}: status {rc}: {self.ctx.last_error()}")
 
+    def parent_rows(self, n_chunks, first_chunk=0, n_chunks_local=None):
+        """Where each local chunk's parent steps sit among the parent records: (row of its first parent step, path length,
+        provable) per chunk — b3w_chain_parent_row / path_len / path_provable.  Complete trees: (c * P, P, True)."""
+        L = lib()
+        nl = n_chunks - first_chunk if n_chunks_local is None else n_chunks_local
+        r0 = L.b3w_chain_parent_row(first_chunk, n_chunks)
+        return [(L.b3w_chain_parent_row(c, n_chunks) - r0, L.b3w_chain_path_len(c, n_chunks), bool(L.b3w_chain_path_provable(c, n_chunks)))
+                for c in range(first_chunk, first_chunk + nl)]
+
     def plan(self, d_preimage, with_parents=True, first_chunk=0, n_chunks_local=None, stream=0):
         """d_preimage: uint8 CUDA tensor holding the WHOLE preimage.  Returns a dict with
-        records (int32 [n_steps, 32]: leaf steps of the local chunks, then their parent steps),
-        n_leaf_steps, chunk_cvs (all chunks), root (8 words), n_chunks, path_len."""
+        records (int32 [n_steps, 32]: leaf steps of the local chunks, then their parent steps — see parent_rows),
+        n_leaf_steps, chunk_cvs (all chunks), root (8 words), n_chunks, path_len (the longest path)."""
         import torch
         L = lib()
         ln = d_preimage.numel()
@@ -433,9 +446,9 @@ class ChainPlanner:
         last_local = first_chunk + nl == n
         last_blocks = (max(ln - (n - 1) * 1024, 1) + 63) // 64
         n_leaf = nl * 16 - ((16 - last_blocks) if last_local else 0)
-        P = L.b3w_chain_path_len(0, n)
+        P = L.b3w_chain_path_len(0, n)                     # the longest path (chunk 0's); every path in a complete tree
         complete = (n & (n - 1)) == 0
-        n_par = nl * P if (with_parents and complete) else 0
+        n_par = L.b3w_chain_num_parent_steps(ln, first_chunk, nl) if with_parents else 0
         recs = torch.zeros((nl * 16 + n_par, 32), dtype=torch.int32, device=dev)
         levels = torch.zeros(((2 * n + 64) * 8,), dtype=torch.int32, device=dev)
         root = torch.zeros(8, dtype=torch.int32, device=dev)

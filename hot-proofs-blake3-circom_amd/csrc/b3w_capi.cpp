@@ -853,6 +853,13 @@ void *b3w_batch_device_ptr(b3w_batch *b, uint64_t *pitch) {
 uint64_t b3w_chain_num_chunks(uint64_t len) { return len ? (len + 1023) / 1024 : 1; }
 uint64_t b3w_chain_num_leaf_steps(uint64_t len) { return len ? (len + 63) / 64 : 1; }
 uint32_t b3w_chain_path_len(uint64_t chunk, uint64_t n_chunks) { return b3w_plan_path_len(chunk, n_chunks); }
+uint64_t b3w_chain_num_parent_steps(uint64_t len, uint64_t first_chunk, uint64_t n_chunks_local) {
+  const uint64_t n = b3w_chain_num_chunks(len);
+  if (first_chunk > n || n_chunks_local > n - first_chunk) return 0;
+  return b3w_plan_parent_row(first_chunk + n_chunks_local, n) - b3w_plan_parent_row(first_chunk, n);
+}
+uint64_t b3w_chain_parent_row(uint64_t chunk, uint64_t n_chunks) { return b3w_plan_parent_row(chunk, n_chunks); }
+int32_t b3w_chain_path_provable(uint64_t chunk, uint64_t n_chunks) { return chunk < n_chunks ? b3w_plan_path_provable(chunk, n_chunks) : 0; }
 
 int32_t b3w_chain_plan_leaves_device(b3w_ctx *ctx, const uint8_t *d_preimage, uint64_t preimage_len, uint64_t first_chunk,
                                      uint32_t n_chunks_local, uint32_t *d_records, uint32_t *d_chunk_cvs, void *stream) {
@@ -903,16 +910,14 @@ int32_t b3w_chain_tree_device(b3w_ctx *ctx, uint32_t *d_levels, uint64_t n_chunk
 int32_t b3w_chain_plan_parents_device(b3w_ctx *ctx, const uint32_t *d_levels, uint64_t n_chunks, uint64_t preimage_len,
                                       uint64_t first_chunk, uint32_t n_chunks_local, uint32_t *d_records, void *stream) {
   if (!ctx || !d_levels || !d_records) return B3W_E_BAD_ARGUMENT;
-  if (n_chunks != b3w_chain_num_chunks(preimage_len) || (n_chunks & (n_chunks - 1)) || first_chunk + n_chunks_local > n_chunks) {
-    ctx->last_error = "parent steps need a complete tree: n_chunks must be a power of two and match the preimage";
+  if (n_chunks != b3w_chain_num_chunks(preimage_len) || first_chunk + n_chunks_local > n_chunks) {
+    ctx->last_error = "n_chunks must match the preimage and the chunk range lie inside it";
     return B3W_E_BAD_ARGUMENT;
   }
   ON_DEVICE(ctx);
-  uint32_t P = 0;
-  while ((1ull << P) < n_chunks) P++;
-  const uint64_t last_bytes = preimage_len - (n_chunks - 1) * 1024;
+  const uint64_t last_bytes = preimage_len > (n_chunks - 1) * 1024 ? preimage_len - (n_chunks - 1) * 1024 : 0;
   const uint32_t last_blocks = last_bytes ? (uint32_t)((last_bytes + 63) / 64) : 1;
-  int rc = b3w_launch_plan_parents(d_levels, n_chunks, P, first_chunk, n_chunks_local, last_blocks, d_records, (hipStream_t)stream);
+  int rc = b3w_launch_plan_parents(d_levels, n_chunks, first_chunk, n_chunks_local, last_blocks, d_records, (hipStream_t)stream);
   return rc ? hip_fail(ctx, (hipError_t)rc, "plan parents launch") : B3W_OK;
 }
 
@@ -1592,7 +1597,7 @@ int32_t b3w_chain_create(b3w_ctx *ctx, uint64_t preimage_len, uint64_t first_chu
   c->last_blocks = last_bytes ? (uint32_t)((last_bytes + 63) / 64) : 1;
   c->has_last = first_chunk + n_chunks_local == n;
   c->n_leaf = (uint64_t)n_chunks_local * 16 - ((c->has_last && n_chunks_local) ? 16 - c->last_blocks : 0);
-  c->n_par = (with_parents && c->complete) ? (uint64_t)n_chunks_local * c->P : 0;
+  c->n_par = with_parents ? b3w_chain_num_parent_steps(preimage_len, first_chunk, n_chunks_local) : 0;
   const uint64_t rows = (uint64_t)n_chunks_local * 16 + c->n_par + 1;
   const uint64_t body = 32ull * ctx->desc.nwit;
   DeviceGuard guard(ctx->device);

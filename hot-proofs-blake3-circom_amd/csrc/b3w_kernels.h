@@ -24,8 +24,10 @@ extern "C" int b3w_launch_plan_leaves(const uint8_t *d_pre, uint64_t total_len, 
                                       uint64_t nchunks, uint32_t *d_recs, uint32_t *d_chunk_cv, hipStream_t stream);
 extern "C" int b3w_launch_plan_merge(const uint32_t *d_left, const uint32_t *d_right, uint32_t stride_words, uint64_t npairs,
                                      uint32_t root, uint32_t *d_parents, hipStream_t stream);
-extern "C" int b3w_launch_plan_parents(const uint32_t *d_levels, uint64_t nchunks, uint32_t P, uint64_t first_chunk,
-                                       uint32_t nlocal, uint32_t last_chunk_blocks, uint32_t *d_recs, hipStream_t stream);
+extern "C" int b3w_launch_plan_parents(const uint32_t *d_levels, uint64_t nchunks, uint64_t first_chunk, uint32_t nlocal,
+                                       uint32_t last_chunk_blocks, uint32_t *d_recs, hipStream_t stream);
+extern "C" uint64_t b3w_plan_parent_row(uint64_t chunk, uint64_t nchunks);     // chunk == nchunks: all parent steps
+extern "C" int b3w_plan_path_provable(uint64_t chunk, uint64_t nchunks);
 
 extern "C" int b3w_launch_trace(int kind, const uint32_t *d_recs, uint32_t cn, uint32_t *d_images, uint32_t row, const uint32_t *d_table,
                                 uint32_t nwit, uint32_t *d_pub, int32_t *d_status, const void *d_aux, hipStream_t stream);

@@ -11,9 +11,9 @@
 //                           record per block (n_blocks, block_count, h = running CV, chunk index,
 //                           depths, message words, b) and the chunk's chaining value
 //   b3w_plan_merge_kernel   one tree level: parent CV = compress(IV, left || right, PARENT [| ROOT])
-//   b3w_plan_parent_kernel  complete trees: one thread per (chunk, height): the parent step record
-//                           (h = own subtree CV, m[0..7] = sibling CV, depth) — what format_input
-//                           builds from PathNode for the steps after the leaf blocks
+//   b3w_plan_paths_kernel   one thread per chunk: the parent steps of its path, bottom up, for ANY chunk count, planned
+//                           the way the reference's driver plans them (h = the chain's running value, m[0..7] = the
+//                           PathNode's sibling, depth; rust_fold/src/blake3_hash.rs:58-84, blake3_circuit.rs:230-245)
 //
 // Record layout = the batch input format of the nova kernels (b3wit.h).
 #include <hip/hip_runtime.h>
@@ -136,29 +136,136 @@ __global__ __launch_bounds__(64) void b3w_plan_merge_kernel(const uint32_t *__re
   for (int k = 0; k < 8; ++k) parents[i * 8 + k] = o[k];
 }
 
-// complete tree over nchunks = 2^P chunks; levels[] = concatenated level arrays (level 0 = chunk CVs at
-// word offset 0, level j at level_off[j]); one thread per (local chunk, height j < P)
-__global__ __launch_bounds__(64) void b3w_plan_parent_kernel(const uint32_t *__restrict__ levels, uint64_t nchunks, uint32_t P,
-                                                             uint64_t first_chunk, uint32_t nlocal, uint32_t last_chunk_blocks,
-                                                             uint32_t *__restrict__ recs) {
+// ---- parent steps of every chunk path, any chunk count ----------------------------------------------------------
+// BLAKE3's tree over n chunks (left subtree = the largest power of two below the count) is a right spine of complete
+// subtrees: seg[0] (the largest, chunks 0 ..), seg[1], ... seg[last]; suffix[i] = the node over seg[i] .. seg[last]
+// (suffix[0] = the root, suffix[last] = seg[last], suffix[i] = parent(seg[i], suffix[i+1])).  The level arrays of
+// b3w_chain_tree_device hold every complete subtree (level t, node index), its scratch chain the suffix nodes.
+//
+// The step circuit takes left/right at height g from bit g of chunk_idx (Blake3GetDownLeftPath,
+// circuits/blake3_nova.circom:47-84), and the reference's driver picks the PathNode's sibling by the same bit
+// (blake3_hash.rs:63-78: bit clear -> the node's RIGHT child CV, bit set -> its LEFT child CV).  That is the leaf's true
+// sibling exactly when the leaf's real path spells the low bits of its index — always in a complete tree; in an
+// incomplete one only for some leaves (those of seg[0], and of later segments whose position happens to agree).  For
+// the others the reference hands the circuit the node's other child, i.e. the path child's own CV, and the fold ends in a
+// value that is not BLAKE3(input) (tests/golden/incomplete_trees.nova_vesta.json: the reference WASM driven that way).
+// This kernel reproduces the reference's records for every leaf — running value computed the way the circuit does —
+// and b3w_plan_path_provable says which paths end in the root.
+struct B3wSpine {
+  uint32_t nseg;                 // segments on the spine (1 = complete tree)
+  uint32_t level[64];            // seg i = complete subtree of 2^level[i] chunks
+  uint32_t plen[64];             // path length of its chunks
+  uint64_t lo[64];               // first chunk
+  uint64_t seg_off[64];          // word offset of the segment's CV in the levels buffer
+  uint64_t suf_off[64];          // word offset of suffix[i]'s CV (i >= 1)
+  uint64_t row_base[64];         // parent-step row of chunk lo[i]'s first parent step (rows of chunk 0 start at 0)
+};
+
+__host__ inline uint64_t level_off_words(uint64_t n, uint32_t t) {
+  uint64_t off = 0;
+  for (uint32_t l = 0; l < t; ++l) off += (n >> l) * 8;
+  return off;
+}
+
+__host__ inline B3wSpine spine_of(uint64_t n) {
+  B3wSpine sp{};
+  // pairwise levels: an odd node out at level l is a complete subtree of 2^l chunks that waits (a "carry")
+  uint32_t carry_level[64];
+  uint64_t carry_node[64];
+  uint32_t nc = 0, l = 0;
+  uint64_t count = n;
+  while (count > 1) {
+    if (count & 1) { carry_level[nc] = l; carry_node[nc] = count - 1; nc++; }
+    count >>= 1;
+    l++;
+  }
+  sp.nseg = nc + 1;
+  sp.level[0] = l; sp.lo[0] = 0; sp.seg_off[0] = level_off_words(n, l);
+  for (uint32_t i = 0; i < nc; ++i) {                     // root-down order = decreasing size = reverse carry order
+    const uint32_t k = nc - 1 - i;
+    sp.level[1 + i] = carry_level[k];
+    sp.lo[1 + i] = carry_node[k] << carry_level[k];
+    sp.seg_off[1 + i] = level_off_words(n, carry_level[k]) + carry_node[k] * 8;
+  }
+  const uint32_t last = nc;
+  const uint64_t scratch = 2 * n * 8;                     // b3w_chain_tree_device: suffix[last - i] = scratch[i - 1], i = 1 .. last - 1
+  for (uint32_t i = 1; i < last; ++i) sp.suf_off[i] = scratch + (uint64_t)(last - i - 1) * 8;
+  sp.suf_off[last] = sp.seg_off[last];
+  uint64_t row = 0;
+  for (uint32_t i = 0; i <= last; ++i) {
+    sp.plen[i] = sp.level[i] + (last == 0 ? 0 : (i == last ? last : i + 1));
+    sp.row_base[i] = row;
+    row += (uint64_t)sp.plen[i] << sp.level[i];
+  }
+  return sp;
+}
+
+__host__ __device__ inline uint32_t seg_of(const B3wSpine &sp, uint64_t c) {
+  uint32_t s = 0;
+  while (s + 1 < sp.nseg && c >= sp.lo[s + 1]) s++;
+  return s;
+}
+
+__global__ __launch_bounds__(64) void b3w_plan_paths_kernel(const uint32_t *__restrict__ levels, uint64_t nchunks, B3wSpine sp,
+                                                            uint64_t first_chunk, uint32_t nlocal, uint32_t last_chunk_blocks,
+                                                            uint64_t row0, uint32_t *__restrict__ recs) {
   const uint64_t i = (uint64_t)blockIdx.x * 64 + threadIdx.x;
-  if (i >= (uint64_t)nlocal * P) return;
-  const uint32_t j = (uint32_t)(i % P);
-  const uint64_t c = first_chunk + i / P;
-  uint64_t off = 0, cnt = nchunks;                       // word offset of level j
-  for (uint32_t l = 0; l < j; ++l) { off += cnt * 8; cnt >>= 1; }
-  const uint64_t node = c >> j;
-  const uint32_t *own = levels + off + node * 8, *sib = levels + off + (node ^ 1) * 8;
+  if (i >= nlocal) return;
+  const uint64_t c = first_chunk + i;
+  const uint32_t s = seg_of(sp, c), last = sp.nseg - 1, t = sp.level[s], plen = sp.plen[s];
   const uint32_t n_blocks = (c == nchunks - 1) ? last_chunk_blocks : 16;
-  uint32_t *r = recs + i * 32;
-  r[0] = n_blocks; r[1] = n_blocks;                      // block_count stays at n_blocks on parent steps (:251)
+  uint32_t *r = recs + (sp.row_base[s] + (c - sp.lo[s]) * plen - row0) * 32;
+  uint32_t h[8];
 #pragma unroll
-  for (int k = 0; k < 8; ++k) r[2 + k] = own[k];
-  r[10] = (uint32_t)c; r[11] = (uint32_t)(c >> 32);
-  r[12] = P + 1; r[13] = P + 1; r[14] = P - 1 - j;
+  for (int k = 0; k < 8; ++k) h[k] = levels[c * 8 + k];
+  uint64_t off = 0, cnt = nchunks;                        // word offset of level g
+  for (uint32_t g = 0; g < plen; ++g, r += 32) {
+    const uint32_t *own, *sib;
+    bool true_left;
+    if (g < t) {                                          // inside the complete subtree
+      const uint64_t node = c >> g;
+      own = levels + off + node * 8;
+      sib = levels + off + (node ^ 1) * 8;
+      true_left = (node & 1) == 0;
+      off += cnt * 8;
+      cnt >>= 1;
+    } else {                                              // on the spine
+      const uint32_t k = g - t;
+      if (s == last) {                                    // suffix[last - k] is the right child of suffix[last - k - 1]
+        own = levels + sp.suf_off[last - k];
+        sib = levels + sp.seg_off[last - k - 1];
+        true_left = false;
+      } else if (k == 0) {                                // seg[s] is the left child of suffix[s]
+        own = levels + sp.seg_off[s];
+        sib = levels + sp.suf_off[s + 1];
+        true_left = true;
+      } else {                                            // suffix[s - k + 1] is the right child of suffix[s - k]
+        own = levels + sp.suf_off[s - k + 1];
+        sib = levels + sp.seg_off[s - k];
+        true_left = false;
+      }
+    }
+    const bool bit_left = ((c >> g) & 1) == 0;
+    const uint32_t *m8 = bit_left == true_left ? sib : own;      // blake3_hash.rs:63-78 (the PathNode's "other" child by the bit)
+    const uint32_t depth = plen - 1 - g;
+    r[0] = n_blocks; r[1] = n_blocks;                     // block_count stays at n_blocks on parent steps (blake3_nova.circom:251)
 #pragma unroll
-  for (int k = 0; k < 8; ++k) { r[15 + k] = sib[k]; r[23 + k] = 0; }     // sibling CV, then zeros (blake3_circuit.rs:230-245)
-  r[31] = 64;
+    for (int k = 0; k < 8; ++k) r[2 + k] = h[k];
+    r[10] = (uint32_t)c; r[11] = (uint32_t)(c >> 32);
+    r[12] = plen + 1; r[13] = plen + 1; r[14] = depth;
+    uint32_t m[16];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { const uint32_t w = m8[k]; r[15 + k] = w; r[23 + k] = 0; m[bit_left ? 8 + k : k] = w; }   // sibling CV, then zeros (blake3_circuit.rs:230-245)
+    r[31] = 64;
+    // the next step's h = this step's h_out: compress(IV, h || sibling or sibling || h, PARENT [| ROOT at depth 0])
+#pragma unroll
+    for (int k = 0; k < 8; ++k) m[bit_left ? k : 8 + k] = h[k];
+    uint32_t ivv[8], o[8];
+    iv(ivv);
+    blake3_cv(ivv, m, 0, 0, 64, 4u | (depth == 0 ? 8u : 0u), o);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) h[k] = o[k];
+  }
 }
 
 }  // namespace
@@ -181,11 +288,39 @@ extern "C" int b3w_launch_plan_merge(const uint32_t *d_left, const uint32_t *d_r
   return (int)hipGetLastError();
 }
 
-extern "C" int b3w_launch_plan_parents(const uint32_t *d_levels, uint64_t nchunks, uint32_t P, uint64_t first_chunk,
-                                       uint32_t nlocal, uint32_t last_chunk_blocks, uint32_t *d_recs, hipStream_t stream) {
-  const uint64_t total = (uint64_t)nlocal * P;
-  if (!total) return 0;
-  hipLaunchKernelGGL(b3w_plan_parent_kernel, dim3((uint32_t)((total + 63) / 64)), dim3(64), 0, stream, d_levels, nchunks, P,
-                     first_chunk, nlocal, last_chunk_blocks, d_recs);
+extern "C" int b3w_launch_plan_parents(const uint32_t *d_levels, uint64_t nchunks, uint64_t first_chunk, uint32_t nlocal,
+                                       uint32_t last_chunk_blocks, uint32_t *d_recs, hipStream_t stream) {
+  if (!nlocal || nchunks < 2) return 0;
+  const B3wSpine sp = spine_of(nchunks);
+  const uint32_t s0 = seg_of(sp, first_chunk);
+  const uint64_t row0 = sp.row_base[s0] + (first_chunk - sp.lo[s0]) * sp.plen[s0];
+  hipLaunchKernelGGL(b3w_plan_paths_kernel, dim3((nlocal + 63) / 64), dim3(64), 0, stream, d_levels, nchunks, sp, first_chunk, nlocal,
+                     last_chunk_blocks, row0, d_recs);
   return (int)hipGetLastError();
+}
+
+// parent-step row (counted from chunk 0's first parent step) of `chunk`'s first parent step; chunk == nchunks: the total
+extern "C" uint64_t b3w_plan_parent_row(uint64_t chunk, uint64_t nchunks) {
+  if (nchunks < 2) return 0;
+  const B3wSpine sp = spine_of(nchunks);
+  if (chunk >= nchunks) return sp.row_base[sp.nseg - 1] + ((uint64_t)sp.plen[sp.nseg - 1] << sp.level[sp.nseg - 1]);
+  const uint32_t s = seg_of(sp, chunk);
+  return sp.row_base[s] + (chunk - sp.lo[s]) * sp.plen[s];
+}
+
+// does the chunk's real path through the tree spell the low bits of its index (then, and only then, the reference's
+// fold of that path ends in BLAKE3(input))?
+extern "C" int b3w_plan_path_provable(uint64_t chunk, uint64_t nchunks) {
+  uint32_t dirs[64], p = 0;                                // true directions, root first: 1 = left
+  uint64_t c = chunk, n = nchunks;
+  while (n > 1) {
+    uint64_t k = 1;
+    while (k * 2 < n) k *= 2;
+    if (c < k) { n = k; dirs[p++] = 1; } else { c -= k; n -= k; dirs[p++] = 0; }
+  }
+  for (uint32_t i = 0; i < p; ++i) {
+    const uint32_t g = p - 1 - i;                          // height of the node the direction is taken at
+    if ((((chunk >> g) & 1) == 0) != (dirs[i] == 1)) return 0;
+  }
+  return 1;
 }

@@ -12,8 +12,11 @@
 // (generate_witness.js:9-10, snarkjs wtns calculate, circomkit).  It is only hashed: the four
 // committed circuits are recognised by sha256 and computed by the MI355X kernels behind the
 // N-API addon (b3wit_napi.node -> libb3wit.so).  A circuit name ("compression", "nova_bn254",
-// "nova_vesta", "nova_bn254_o1") is accepted in place of the bytes.  Anything else is refused:
-// there is no WebAssembly or CPU path in here.
+// "nova_vesta", "nova_bn254_o1") is accepted in place of the bytes.  Bytes of any OTHER circom witness generator
+// run through a generic WebAssembly loader written for this shim (wasm_fallback.js: the same calculator surface over the
+// module's own exports), so swapping the reference loader for this file loses nothing for circuits outside this build's
+// scope; options.wasmFallback === false refuses them instead.  The four BLAKE3 circuits never take that road (no CPU path
+// for them) unless options.forceWasm asks for it (parity tests of the loader itself).
 //
 // Extensions the reference does not have: wc.calculateWitnessBatch(records) on packed u32 records.
 "use strict";
@@ -28,6 +31,7 @@ function native() {
 
 module.exports = async function builder(code, options) {
   options = options || {};
+  if (options.forceWasm && typeof code !== "string") return require("./wasm_fallback.js")(code, options);
   const nat = native();
   let circuit;
   if (typeof code === "string") {
@@ -36,7 +40,9 @@ module.exports = async function builder(code, options) {
     circuit = nat.identifyWasm(code);
   }
   if (circuit < 0) {
-    throw new Error("b3wit: not one of the reference's committed BLAKE3 circuits; this calculator has no generic WebAssembly path");
+    if (typeof code !== "string" && options.wasmFallback !== false) return require("./wasm_fallback.js")(code, options);
+    throw new Error("b3wit: not one of the reference's committed BLAKE3 circuits" +
+                    (typeof code === "string" ? "" : " (and options.wasmFallback is false)"));
   }
   const device = options.device === undefined ? parseInt(process.env.B3WIT_DEVICE || "0") : options.device;
   const handle = nat.create(circuit, device);

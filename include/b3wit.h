@@ -278,10 +278,21 @@ int32_t b3w_chain_plan_leaves_device(b3w_ctx *ctx, const uint8_t *d_preimage, ui
  * chaining value = the BLAKE3 hash words (for n_chunks == 1 the chunk CV already is the root). */
 int32_t b3w_chain_tree_device(b3w_ctx *ctx, uint32_t *d_levels, uint64_t n_chunks, uint32_t *d_root, void *stream);
 
-/* Parent steps of chunks [first_chunk, +n_chunks_local) of a COMPLETE tree (n_chunks a power of two —
- * the shape the reference circuit's left/right selection from chunk_idx bits is valid for):
- * log2(n_chunks) records per chunk, record j (height j, depth = log2(n)-1-j) of chunk c at
- * d_records + ((c - first_chunk)*log2(n) + j)*32 words. */
+/* Parent steps of the paths of chunks [first_chunk, +n_chunks_local), for ANY chunk count, planned the way the
+ * reference's driver plans them (hash_with_path, rust_fold/src/blake3_hash.rs:58-84: the PathNode at height g carries the
+ * node's right child CV when bit g of the chunk index is clear, else its left child CV; format_input, blake3_circuit.rs:
+ * 230-245: that CV as m[0..7], zeros above, b = 64; h and depth come from the previous step).  Chunk c gets
+ * b3w_chain_path_len(c, n) records, bottom up (record g: height g, depth = path_len - 1 - g), starting at row
+ * b3w_chain_parent_row(c, n) - b3w_chain_parent_row(first_chunk, n) of d_records; in a complete tree that is row
+ * (c - first_chunk) * log2(n).  The step circuit takes left/right from the same index bits (Blake3GetDownLeftPath,
+ * circuits/blake3_nova.circom:47-84), which is the leaf's real position only when b3w_chain_path_provable(c, n) = 1
+ * (every leaf of a complete tree; in an incomplete tree the leaves of the leading power-of-two subtree and those later ones
+ * whose position happens to agree): exactly those paths end in h_out = BLAKE3(preimage).  For the other leaves the records are
+ * still the reference's, and so is the (wrong) final value — tests/golden/incomplete_trees.nova_vesta.json holds the
+ * reference WASM's transcript.  d_levels must have been through b3w_chain_tree_device. */
+uint64_t b3w_chain_num_parent_steps(uint64_t preimage_len, uint64_t first_chunk, uint64_t n_chunks_local);
+uint64_t b3w_chain_parent_row(uint64_t chunk, uint64_t n_chunks);       /* chunk == n_chunks: the total */
+int32_t b3w_chain_path_provable(uint64_t chunk, uint64_t n_chunks);
 int32_t b3w_chain_plan_parents_device(b3w_ctx *ctx, const uint32_t *d_levels, uint64_t n_chunks, uint64_t preimage_len,
                                       uint64_t first_chunk, uint32_t n_chunks_local, uint32_t *d_records, void *stream);
 

@@ -51,15 +51,19 @@ def _check_chain(data, plan, recs, pub, st):
     if n_chunks == 1:
         assert np.array_equal(pub[n_leaf - 1][2:10], root)
     if plan["n_parent_steps"]:
-        for c in range(n_chunks):
-            base = n_leaf + c * P
-            for j in range(P):
+        rows = T.pkg().ChainPlanner(None).parent_rows(n_chunks)
+        assert sum(pl for _, pl, _ in rows) == plan["n_parent_steps"]
+        for c, (row, pl, provable) in enumerate(rows):
+            base = n_leaf + row
+            for j in range(pl):
                 r, o = recs[base + j], pub[base + j]
-                assert r[14] == P - 1 - j and r[31] == 64 and (r[23:31] == 0).all()
-                if j + 1 < P:
+                assert r[10] == c and r[12] == pl + 1 and r[13] == pl + 1
+                assert r[14] == pl - 1 - j and r[31] == 64 and (r[23:31] == 0).all()
+                if j + 1 < pl:
                     assert np.array_equal(o[2:10], recs[base + j + 1][2:10]), (c, j)
                 else:
-                    assert np.array_equal(o[2:10], root), c   # the fold's final h_out == BLAKE3(input)
+                    # the fold's final h_out == BLAKE3(input) exactly for the paths the circuit's index-bit rule gets right
+                    assert np.array_equal(o[2:10], root) == provable, (c, provable)
                     assert o[11] == 0
 
 
@@ -79,17 +83,66 @@ def test_reference_rust_test_shapes(data):
     ctx.close()
 
 
-@pytest.mark.parametrize("nbytes", [3 * 1024, 5 * 1024 + 1, 6 * 1024, 7 * 1024 - 3, 100 * 1024 + 77, 1])
-def test_tree_root_for_any_chunk_count(nbytes):
-    """Incomplete trees: leaf steps + tree root only (the reference circuit's left/right selection
-    from chunk_idx bits is valid for complete trees; parent steps are planned only there)."""
+@pytest.mark.parametrize("nbytes", [3 * 1024, 5 * 1024 + 1, 6 * 1024, 7 * 1024 - 3, 11 * 1024, 100 * 1024 + 77, 1, 37 * 1024 + 64])
+def test_paths_for_any_chunk_count(nbytes):
+    """Incomplete trees: every chunk gets the parent steps of ITS path (lengths differ per chunk), planned by the reference
+    driver's rule; the tree root is BLAKE3(input); the paths whose position agrees with their index bits end in it, the
+    others do not (as with the reference: tests/golden/incomplete_trees.nova_vesta.json)."""
     m = T.pkg()
     rng = np.random.default_rng(nbytes)
     data = rng.integers(0, 256, nbytes, dtype=np.uint8).tobytes()
     ctx, plan, recs, pub, st, _ = _run(m, data, "nova_bn254")
-    assert plan["n_parent_steps"] == (0 if not plan["complete"] else plan["n_chunks"] * plan["path_len"])
+    n = plan["n_chunks"]
+    rows = m.ChainPlanner(ctx).parent_rows(n)
+    assert plan["n_parent_steps"] == sum(pl for _, pl, _ in rows) and [pl for _, pl, _ in rows] == [_path_len(c, n) for c in range(n)]
+    assert all(ok for _, _, ok in rows[:1 << (n.bit_length() - 1)])          # the leading power-of-two subtree is always provable
+    if n & (n - 1):
+        assert not rows[-1][2]                                                # the last chunk of an incomplete tree never is
     _check_chain(data, plan, recs, pub, st)
     ctx.close()
+
+
+def _path_len(c, n):
+    p = 0
+    while n > 1:
+        k = 1
+        while k * 2 < n:
+            k *= 2
+        if c < k:
+            n = k
+        else:
+            c, n = c - k, n - k
+        p += 1
+    return p
+
+
+def test_incomplete_trees_match_the_reference_wasm_transcript():
+    """The reference WASM folded along every path of 2 ... 100-chunk trees by the reference driver's rules
+    (tools/probe_incomplete_trees.js, build container): the planner's parent records equal the transcript's inputs word for
+    word, the kernels' public outputs equal the WASM's, and `provable` is exactly "ended in BLAKE3(input)"."""
+    import gzip, json, os
+    m = T.pkg()
+    W = T.workloads()
+    doc = json.load(gzip.open(os.path.join(T.GOLD, "incomplete_trees.nova_vesta.json.gz"), "rt"))
+    for tree in doc["trees"]:
+        n = tree["n_chunks"]
+        data = W.lcg_preimage(n * 1024, seed=1).tobytes()
+        ctx, plan, recs, pub, st, _ = _run(m, data, "nova_vesta")
+        assert (st == 0).all() and list(plan["root"].cpu().numpy().view(np.uint32)) == tree["root"]
+        rows = m.ChainPlanner(ctx).parent_rows(n)
+        n_leaf = plan["n_leaf_steps"]
+        for leaf in tree["leaves"]:
+            c = leaf["leaf"]
+            row, pl, provable = rows[c]
+            assert pl == leaf["path_len"] and provable == leaf["ends_in_root"] == leaf["bits_agree"], (n, c)
+            steps = leaf["steps"]                         # the last leaf block, then the parent steps
+            assert len(steps) == 1 + pl
+            idx = [c * 16 + 15] + [n_leaf + row + j for j in range(pl)]
+            for k, (i, stp) in enumerate(zip(idx, steps)):
+                assert list(recs[i]) == stp["record"], (n, c, k)
+                assert list(pub[i]) == stp["public"], (n, c, k)
+            assert list(pub[idx[-1]][2:10]) == leaf["final_h"]
+        ctx.close()
 
 
 def test_config4_one_mib_preimage():
@@ -137,6 +190,72 @@ def test_streamed_fold_8mib_ring_buffer():
     last_parent = pub[131072 + 12::13][:8192]          # step j = 12 (depth 0) of every chunk path
     assert (last_parent[:, 2:10] == np.array(want, dtype=np.uint32)).all()
     assert (last_parent[:, 11] == 0).all()
+    ctx.close()
+
+
+def test_config5_one_gib_preimage_full_size():
+    """BASELINE config 5 at its full size: the 1 GiB little-endian stream of LCG(1) -> 1 048 576 chunks -> 16 777 216 leaf +
+    20 971 520 parent steps = 28 TB of step witnesses through the two-deep ring, H2D overlapped slice by slice.
+    Checked against an independent numpy BLAKE3 over the whole preimage: every chunk's leaf chain ends in its chaining
+    value, every parent step carries the right sibling, every one of the 1 048 576 paths ends in BLAKE3(preimage), all
+    statuses are 0; and 96 bodies copied out of the ring while it was being overwritten (both slots, first to last
+    generation) equal the oracle's witnesses of their step records byte for byte."""
+    import torch
+    m = T.pkg()
+    W = T.workloads()
+    dev = torch.device("cuda:0")
+    data = W.lcg_preimage(1 << 30, seed=1)
+    n_chunks, P, batch = 1 << 20, 20, 16384
+    n_leaf, n_par = 16 * n_chunks, P * n_chunks
+    n_batches = n_leaf // batch + n_par // batch
+    picks = set(np.linspace(0, n_batches - 1, 96).astype(np.int64).tolist())
+    assert {b & 1 for b in picks} == {0, 1}                    # both ring slots
+    ctx = m.Context("nova_vesta", 0)
+    grabbed, seen = [], [0]
+
+    def consumer(view, first_step, k):
+        b = seen[0]
+        seen[0] += 1
+        if b in picks:
+            j = (b * 7919) % k
+            grabbed.append((first_step + j, view[j].clone()))      # enqueued on the pass's stream, before the slot is reused
+    out = m.chain.fold_witnesses(ctx, torch.from_numpy(data).pin_memory(), batch_steps=batch, ring=2, consumer=consumer)
+    torch.cuda.synchronize()
+    assert (out["n_leaf_steps"], out["n_parent_steps"], out["path_len"], out["n_chunks"]) == (n_leaf, n_par, P, n_chunks)
+    assert seen[0] == n_batches and len(grabbed) == 96
+    assert int(out["status"].abs().sum().item()) == 0
+
+    cvs = B.chunk_cvs_np(data)
+    levels = B.tree_levels_np(cvs)
+    root = levels[-1][0]
+    assert list(out["root"].cpu().numpy().view(np.uint32)) == list(root)
+    as_dev = lambda a: torch.from_numpy(a.view(np.int32)).to(dev)
+    pub, recs = out["public"], out["records"]
+    # leaf chains: block 15 of every chunk outputs the chunk's chaining value; its depth drops from 20 to 19
+    last_leaf = pub[15:n_leaf:16]
+    assert torch.equal(last_leaf[:, 2:10], as_dev(cvs)) and bool((last_leaf[:, 11] == P - 1).all().item())
+    assert bool((recs[:n_leaf, 10].view(n_chunks, 16) == torch.arange(n_chunks, device=dev, dtype=torch.int32)[:, None]).all().item())
+    # parent steps: step j of chunk c starts from the subtree value at height j and carries the sibling at that height
+    par_recs = recs[n_leaf:].view(n_chunks, P, 32)
+    c_idx = torch.arange(n_chunks, device=dev, dtype=torch.int64)
+    for j in range(P):
+        lv = as_dev(levels[j])
+        node = c_idx >> j
+        assert torch.equal(par_recs[:, j, 2:10], lv[node]), j
+        assert torch.equal(par_recs[:, j, 15:23], lv[node ^ 1]), j
+        assert bool((par_recs[:, j, 14] == P - 1 - j).all().item())
+    # every path ends in BLAKE3(preimage)
+    final = pub[n_leaf + P - 1::P]
+    assert final.shape[0] == n_chunks and bool((final[:, 2:10] == as_dev(root.reshape(1, 8))).all().item())
+    assert bool((final[:, 11] == 0).all().item())
+    # bodies that went through the ring
+    steps = [s for s, _ in grabbed]
+    want_recs = recs[torch.tensor(steps, device=dev)].cpu().numpy().view(np.uint32)
+    bad, want = T.oracle_batch_u32("nova_vesta", want_recs)
+    assert bad == 0
+    for k, (s, body) in enumerate(grabbed):
+        assert np.array_equal(body.cpu().numpy(), want[k]), s
+    assert min(steps) < batch and max(steps) >= n_leaf + n_par - batch and any(s < n_leaf for s in steps) and any(s >= n_leaf for s in steps)
     ctx.close()
 
 

@@ -28,12 +28,74 @@ def test_addon_loads_and_refuses_without_device():
       const b = require('./hot-proofs-blake3-circom_amd/js/witness_calculator.js');
       const nat = require('./hot-proofs-blake3-circom_amd/js/b3wit_napi.node');
       console.log('abi', nat.abiVersion() >> 16);
-      b('compression').then(() => console.log('UNEXPECTED')).catch(e => console.log('rejected', e.status, e.message));
-      b(Buffer.from('not a circuit')).catch(e => console.log('junk', e.message));
+      (async () => {
+        await b('compression').then(() => console.log('UNEXPECTED')).catch(e => console.log('rejected', e.status, e.message));
+        await b(Buffer.from('not a circuit'), {wasmFallback: false}).catch(e => console.log('junk', e.message));
+        const say = console.log; console.log = () => {};          // the loader prints the CompileError, like the reference's
+        const msg = await b(Buffer.from('not a circuit')).then(() => 'UNEXPECTED', e => e.message);
+        console.log = say;
+        console.log('fallback', msg);
+      })();
     """)
     assert r.returncode == 0, r.stderr
     assert "abi 1" in r.stdout and "rejected 101" in r.stdout and "no CPU path" in r.stdout
     assert "junk b3wit: not one of the reference's committed BLAKE3 circuits" in r.stdout and "UNEXPECTED" not in r.stdout
+    assert "fallback CompileError" in r.stdout            # unknown bytes go to the generic WebAssembly loader
+
+
+@needs_node
+def test_generic_wasm_fallback_reproduces_the_reference_loader():
+    """Unknown circom WASM runs through js/wasm_fallback.js.  Here the reference's own circuit binaries are forced down
+    that road (options.forceWasm) and compared with the goldens the reference loader produced: .wtns images, error text,
+    and — on ONE calculator, in sequence — the console lines and the never-cleared error trace
+    (tests/golden/nova_vesta.sequence.json)."""
+    if not os.path.isdir(REF):
+        pytest.skip("reference checkout not present (GPU box): the circuit binaries live there")
+    g = T.golden("compression")
+    ok = [c for c in g["cases"] if "error" not in c][:2] + [c for c in g["cases"] if c["name"] in ("m0_neg1",)]
+    bad = [c for c in g["cases"] if "error" in c][:2]
+    seq = json.load(open(os.path.join(T.GOLD, "nova_vesta.sequence.json")))["steps"]
+    r = _node("""
+      const builder = require('./hot-proofs-blake3-circom_amd/js/witness_calculator.js');
+      const crypto = require('crypto'), fs = require('fs');
+      const sha = (b) => crypto.createHash('sha256').update(b).digest('hex');
+      (async () => {
+        const [ok, bad, seq] = JSON.parse(process.argv[1]);
+        const out = {ok: [], bad: [], seq: []};
+        const code = fs.readFileSync(process.argv[2]);
+        let wc = await builder(code, {forceWasm: true});
+        out.fields = [wc.version, wc.n32, wc.witnessSize, wc.prime.toString(), wc.circom_version(), wc.constructor.name];
+        for (const c of ok) out.ok.push(sha(await wc.calculateWTNSBin(c.input, 0)));
+        out.bin = sha(await wc.calculateBinWitness(ok[0].input, 0));
+        out.w = (await wc.calculateWitness(ok[0].input, 0)).slice(0, 16).map(String);
+        for (const c of bad) { wc = await builder(code, {forceWasm: true}); try { await wc.calculateWitness(c.input, 0); out.bad.push('NOERR'); } catch (e) { out.bad.push(e.message); } }
+        const i = Object.assign({}, ok[0].input); delete i.b;
+        try { await wc.calculateWitness(i, 0); } catch (e) { out.missing = e.message; }
+        try { await wc.calculateWitness(Object.assign({zz: 1}, ok[0].input), 0); } catch (e) { out.unknown = e.message; }
+        // one calculator, a sequence of good and rejected nova steps: console lines and error text per call
+        const nova = await builder(fs.readFileSync(process.argv[3]), {forceWasm: true});
+        const real = console.log;
+        for (const s of seq) {
+          const logs = [];
+          console.log = (...a) => logs.push(a.join(' '));
+          let err = null, h = null;
+          try { h = sha(await nova.calculateBinWitness(s.input, 0)); } catch (e) { err = e.message; }
+          console.log = real;
+          out.seq.push({logs, error: err, body_sha256: h});
+        }
+        console.log(JSON.stringify(out));
+      })().catch(e => { console.error(e); process.exit(1); });
+    """, json.dumps([ok, bad, [{"input": s["input"]} for s in seq]]),
+        os.path.join(REF, "build/blake3_compression/blake3_compression_js/blake3_compression.wasm"),
+        os.path.join(REF, "build/blake3_nova_pasta_js/blake3_nova_pasta.wasm"))
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = json.loads(r.stdout.strip().splitlines()[-1])
+    assert out["fields"] == [2, 8, 24093, str(T.BN254_R), 2, "GenericWitnessCalculator"]
+    assert out["ok"] == [c["wtns_sha256"] for c in ok] and out["bin"] == ok[0]["body_sha256"] and out["w"] == ok[0]["first16"]
+    assert out["bad"] == [c["error"] for c in bad]
+    assert out["missing"] == "Not all inputs have been set. Only 27 out of 28" and out["unknown"] == "Too many values for input signal zz\n"
+    for got, want in zip(out["seq"], seq):
+        assert got["logs"] == want["logs"] and got["error"] == want["error"] and got["body_sha256"] == want["body_sha256"], want["name"]
 
 
 @needs_node
