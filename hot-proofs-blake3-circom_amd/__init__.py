@@ -97,6 +97,8 @@ def lib():
         "b3w_bodies_alloc": (i32, [vp, u64, ctypes.POINTER(vp), ctypes.POINTER(i32)]),
         "b3w_bodies_free": (i32, [vp, vp]),
         "b3w_bodies_trim": (None, []),
+        "b3w_bodies_configure": (None, [ctypes.c_int64, ctypes.c_int64]),
+        "b3w_bodies_stats": (i32, [vp, vp]),
         "b3w_batch_placement": (i32, [vp]),
         "b3w_chain_num_chunks": (u64, [u64]),
         "b3w_chain_num_leaf_steps": (u64, [u64]),
@@ -149,7 +151,7 @@ EXPORTED_SYMBOLS = ("b3w_abi_version", "b3w_identify_wasm", "b3w_create", "b3w_d
                     "b3w_batch_run_device", "b3w_public_words", "b3w_batch_alloc", "b3w_batch_free",
                     "b3w_batch_run", "b3w_batch_outputs", "b3w_batch_fetch", "b3w_batch_device_ptr",
                     "b3w_batch_time_device", "b3w_batch_verify_device", "b3w_batch_verify",
-                    "b3w_r1cs_create", "b3w_r1cs_info", "b3w_r1cs_destroy", "b3w_r1cs_check_device", "b3w_batch_r1cs_check", "b3w_batch_write_wtns", "b3w_batch_autotune_device", "b3w_bodies_alloc", "b3w_bodies_free", "b3w_bodies_trim", "b3w_batch_placement", "b3w_chain_num_chunks", "b3w_chain_num_leaf_steps", "b3w_chain_path_len",
+                    "b3w_r1cs_create", "b3w_r1cs_info", "b3w_r1cs_destroy", "b3w_r1cs_check_device", "b3w_batch_r1cs_check", "b3w_batch_write_wtns", "b3w_batch_autotune_device", "b3w_bodies_alloc", "b3w_bodies_free", "b3w_bodies_trim", "b3w_bodies_configure", "b3w_bodies_stats", "b3w_batch_placement", "b3w_chain_num_chunks", "b3w_chain_num_leaf_steps", "b3w_chain_path_len",
                     "b3w_chain_num_parent_steps", "b3w_chain_parent_row", "b3w_chain_path_provable",
                     "b3w_chain_plan_leaves_device", "b3w_chain_tree_device", "b3w_chain_plan_parents_device",
                     "b3w_commit_key_create", "b3w_commit_key_create_ex", "b3w_commit_key_window", "b3w_commit_key_destroy", "b3w_commit_records_device", "b3w_commit_records", "b3w_chain_commit_only", "b3w_chain_commitments", "b3w_batch_commit_device", "b3w_batch_commit", "b3w_commit_consumer",
@@ -260,6 +262,12 @@ class Context:
     def alloc_bodies(self, nbytes):
         """Device buffer for bodies, placed over two classes of HBM when possible (b3w_bodies_alloc)."""
         return BodyBuffer(self, nbytes)
+
+    def bodies_stats(self):
+        """Placement allocator of this context's device (b3w_bodies_stats): arena / used-up address space, pooled and live bytes."""
+        out = (ctypes.c_uint64 * 6)()
+        self._lib.b3w_bodies_stats(self.handle, out)
+        return dict(arena_bytes=out[0], arena_used=out[1], pooled_bytes=out[2], live_bytes=out[3], live_buffers=out[4], handles_created=out[5])
 
     def time_device(self, d_records, n, d_bodies, pitch, d_public, d_status, stream, iters):
         ms = ctypes.c_float()

@@ -306,6 +306,9 @@ struct b3w_ctx {
   uint32_t *d_rec1 = nullptr;
   uint8_t *d_body1 = nullptr;
   int32_t *d_status1 = nullptr;
+  float plain_ms_per_gb = 0;          // the witness kernel on a plain hipMalloc buffer, measured once (b3w_bodies_alloc's sanity check)
+  struct Spare { void *ptr; uint64_t bytes; int32_t placement; };
+  std::vector<Spare> ring_spares;     // ring buffers of destroyed chains, reused by the next b3w_chain_create of the same size
   std::string last_error;
 };
 
@@ -446,6 +449,8 @@ int32_t b3w_create(int32_t circuit, int32_t device, b3w_ctx **out) {
 void b3w_destroy(b3w_ctx *ctx) {
   if (!ctx) return;
   DeviceGuard guard(ctx->device);
+  for (const b3w_ctx::Spare &sp : ctx->ring_spares) (void)b3w_bodies_free(ctx, sp.ptr);
+  ctx->ring_spares.clear();
   if (ctx->d_table_base) (void)hipFree(ctx->d_table_base);
   if (ctx->d_aux) (void)hipFree(ctx->d_aux);
   if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
@@ -664,6 +669,54 @@ int32_t b3w_calc_witness(b3w_ctx *ctx, const uint64_t *name_hashes, const uint32
   return B3W_OK;
 }
 
+}  // extern "C"
+
+namespace {
+// ms per GB of bodies of ONE real witness launch filling `d_buf` (valid synthetic records, all alike: the store pattern
+// is what matters); 0 when it could not be measured.  Used to check that a buffer labelled "mixed" really is faster.
+float time_witness_fill(b3w_ctx *ctx, uint8_t *d_buf, uint64_t bytes) {
+  const CircuitDesc &d = ctx->desc;
+  const uint64_t body = 32ull * d.nwit;
+  const uint32_t n = (uint32_t)std::min<uint64_t>(bytes / body, 16384);
+  if (n < 256) return 0;
+  std::vector<uint32_t> recs((size_t)n * d.nin, 0);
+  for (uint32_t i = 0; i < n; i++) {
+    uint32_t *r = &recs[(size_t)i * d.nin];
+    for (uint32_t k = 0; k < d.nin; k++) r[k] = 0x9E3779B9u * (i * d.nin + k + 1);
+    if (d.kind == B3W_KIND_COMP) { r[26] = 64; r[27] = 3; }
+    else { r[0] = 16; r[1] = 3; r[11] = 0; r[12] = 11; r[13] = 11; r[14] = 10; r[31] = 64; }   // a leaf step at depth 10 of 11
+  }
+  uint32_t *d_recs = nullptr;
+  int32_t *d_st = nullptr;
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  float ms = 0;
+  hipError_t e = hipMalloc((void **)&d_recs, recs.size() * 4);
+  if (e == hipSuccess) e = hipMalloc((void **)&d_st, (size_t)n * 4);
+  if (e == hipSuccess) e = hipMemcpy(d_recs, recs.data(), recs.size() * 4, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipEventCreate(&e0);
+  if (e == hipSuccess) e = hipEventCreate(&e1);
+  int32_t rc = B3W_OK;
+  for (int it = 0; it < 4 && e == hipSuccess && rc == B3W_OK; it++) {
+    if (it == 1) e = hipEventRecord(e0, nullptr);
+    if (e == hipSuccess) rc = b3w_batch_run_device(ctx, d_recs, n, d_buf, body, nullptr, d_st, nullptr);
+  }
+  if (e == hipSuccess && rc == B3W_OK) e = hipEventRecord(e1, nullptr);
+  if (e == hipSuccess && rc == B3W_OK) e = hipEventSynchronize(e1);
+  if (e == hipSuccess && rc == B3W_OK) e = hipEventElapsedTime(&ms, e0, e1);
+  int32_t st0 = -1;
+  if (e == hipSuccess && rc == B3W_OK) e = hipMemcpy(&st0, d_st, 4, hipMemcpyDeviceToHost);
+  if (e0) (void)hipEventDestroy(e0);
+  if (e1) (void)hipEventDestroy(e1);
+  if (d_recs) (void)hipFree(d_recs);
+  if (d_st) (void)hipFree(d_st);
+  if (e != hipSuccess) (void)hipGetLastError();
+  if (e != hipSuccess || rc != B3W_OK || st0 != 0 || ms <= 0) return 0;
+  return ms / 3.0f / (float)((double)n * body / 1e9);
+}
+}  // namespace
+
+extern "C" {
+
 int32_t b3w_bodies_alloc(b3w_ctx *ctx, uint64_t bytes, void **d_ptr, int32_t *placement) {
   if (!ctx || !d_ptr || !bytes) return B3W_E_BAD_ARGUMENT;
   *d_ptr = nullptr;
@@ -675,6 +728,32 @@ int32_t b3w_bodies_alloc(b3w_ctx *ctx, uint64_t bytes, void **d_ptr, int32_t *pl
     int mixed = 0;
     const int rc = b3w_place_alloc(ctx->device, bytes, 1, d_ptr, &mixed, nullptr);
     if (rc == 0) {
+      // "mixed" is a claim about speed: check it with the real witness kernel against a plain hipMalloc buffer
+      // (measured once per context) and take the label back when the gain is below 10 % — the buffer stays usable.
+      static const bool check = !(getenv("B3W_PLACE_CHECK") && !strcmp(getenv("B3W_PLACE_CHECK"), "0"));
+      if (mixed && check) {
+        if (ctx->plain_ms_per_gb == 0) {
+          void *plain = nullptr;
+          const uint64_t pb = std::min<uint64_t>(bytes, 4ull << 30);
+          if (hipMalloc(&plain, pb) == hipSuccess) {
+            ctx->plain_ms_per_gb = time_witness_fill(ctx, static_cast<uint8_t *>(plain), pb);
+            (void)hipFree(plain);
+          } else (void)hipGetLastError();
+          if (ctx->plain_ms_per_gb == 0) ctx->plain_ms_per_gb = -1;          // could not measure: do not try again
+        }
+        if (ctx->plain_ms_per_gb > 0) {
+          const float placed = time_witness_fill(ctx, static_cast<uint8_t *>(*d_ptr), std::min<uint64_t>(bytes, 4ull << 30));
+          if (placed > 0 && placed > ctx->plain_ms_per_gb / 1.10f) {
+            mixed = 0;
+            if (getenv("B3W_PLACE_DEBUG"))
+              fprintf(stderr, "b3w_bodies_alloc: placed buffer %.4f ms/GB against plain %.4f ms/GB: below +10 %%, reported as plain\n", placed,
+                      ctx->plain_ms_per_gb);
+          } else if (getenv("B3W_PLACE_DEBUG")) {
+            fprintf(stderr, "b3w_bodies_alloc: placed buffer %.4f ms/GB, plain %.4f ms/GB (%+.0f %%)\n", placed, ctx->plain_ms_per_gb,
+                    placed > 0 ? (ctx->plain_ms_per_gb / placed - 1.0) * 100.0 : 0.0);
+          }
+        }
+      }
       if (placement) *placement = mixed ? B3W_PLACEMENT_MIXED : B3W_PLACEMENT_PLAIN;
       return B3W_OK;
     }
@@ -696,6 +775,14 @@ int32_t b3w_bodies_free(b3w_ctx *ctx, void *d_ptr) {
 }
 
 void b3w_bodies_trim(void) { b3w_place_trim(); }
+
+void b3w_bodies_configure(int64_t search_gib, int64_t pool_gib) { b3w_place_configure(search_gib, pool_gib); }
+
+int32_t b3w_bodies_stats(const b3w_ctx *ctx, uint64_t out[6]) {
+  if (!ctx || !out) return B3W_E_BAD_ARGUMENT;
+  b3w_place_stats(ctx->device, out);
+  return B3W_OK;
+}
 
 int32_t b3w_batch_placement(const b3w_batch *b) { return b ? b->placement : B3W_PLACEMENT_PLAIN; }
 
@@ -1051,10 +1138,11 @@ int32_t b3w_r1cs_create(b3w_ctx *ctx, const uint8_t *img, size_t len, b3w_r1cs *
     rowdesc[4 * k] = rows[k].off; rowdesc[4 * k + 1] = rows[k].na; rowdesc[4 * k + 2] = rows[k].nb; rowdesc[4 * k + 3] = rows[k].nc;
     row_id[k] = rows[k].id;
   }
-  std::vector<uint32_t> coefR(8 * coefs.size());
+  std::vector<uint32_t> coefR(16 * coefs.size());           // per coefficient: plain, then Montgomery form
   for (size_t i = 0; i < coefs.size(); i++) {
-    memcpy(&coefR[8 * i], coefs[i].data(), 32);
-    to_montgomery_host(&coefR[8 * i], P);
+    memcpy(&coefR[16 * i], coefs[i].data(), 32);
+    memcpy(&coefR[16 * i + 8], coefs[i].data(), 32);
+    to_montgomery_host(&coefR[16 * i + 8], P);
   }
   b3w_r1cs *r = new b3w_r1cs;
   r->ctx = ctx; r->m = m; r->nwires = nwires; r->npubout = npubout; r->npubin = npubin; r->nprvin = nprvin; r->nterms = wires.size();
@@ -1533,6 +1621,33 @@ struct b3w_chain {
 namespace {
 constexpr uint32_t CHAIN_SLICE_CHUNKS = 1024;       // 1 MiB of preimage per H2D slice = 16 384 leaf steps
 
+// roctx ranges around the stages of the chained pass (H2D slice, leaf planning, witness batches, consumer, tree + parent
+// planning): `rocprofv3 --marker-trace --kernel-trace --memory-copy-trace` then shows which kernels and copies belong to
+// which stage and how they overlap (profiles/r02/chain_*).  The marker library is looked up at run time, and only under a profiler (or
+// B3W_ROCTX=1); otherwise a range costs one branch.
+struct Roctx {
+  int (*push)(const char *) = nullptr;
+  int (*pop)() = nullptr;
+  Roctx() {
+    // only under a profiler (rocprofv3 exports ROCP_TOOL_LIBRARIES) or when asked for: B3W_ROCTX=1
+    const char *want = getenv("B3W_ROCTX");
+    if (want ? strcmp(want, "1") != 0 : getenv("ROCP_TOOL_LIBRARIES") == nullptr) return;
+    void *so = nullptr;
+    for (const char *name : {"librocprofiler-sdk-roctx.so.1", "librocprofiler-sdk-roctx.so", "libroctx64.so.4", "libroctx64.so"})
+      if (!so) so = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+    if (!so) return;
+    push = (int (*)(const char *))dlsym(so, "roctxRangePushA");
+    pop = (int (*)())dlsym(so, "roctxRangePop");
+    if (!push || !pop) { push = nullptr; pop = nullptr; }
+  }
+};
+Roctx &roctx() { static Roctx r; return r; }
+struct Range {
+  bool on;
+  explicit Range(const char *name) : on(roctx().push != nullptr) { if (on) roctx().push(name); }
+  ~Range() { if (on) roctx().pop(); }
+};
+
 int32_t chain_run_steps(b3w_chain *c, uint64_t first_row, uint64_t count, b3w_batch_consumer consumer, void *user, void *stream) {
   const uint64_t body = 32ull * c->ctx->desc.nwit;
   for (uint64_t done = 0; done < count;) {
@@ -1540,6 +1655,7 @@ int32_t chain_run_steps(b3w_chain *c, uint64_t first_row, uint64_t count, b3w_ba
     uint8_t *slot = static_cast<uint8_t *>(c->bodies[c->nbatch % c->ring]);
     const uint64_t r0 = first_row + done;
     if (c->co_key) {
+      Range r("b3w:commit from records");
       const int32_t rc = b3w_commit_records_device(c->ctx, c->co_key, c->d_recs + r0 * 32, k, c->co_points + r0 * 64, c->d_pub + r0 * 15,
                                                    c->d_status + r0, stream);
       if (rc) return rc;
@@ -1547,9 +1663,10 @@ int32_t chain_run_steps(b3w_chain *c, uint64_t first_row, uint64_t count, b3w_ba
       done += k;
       continue;
     }
-    int32_t rc = b3w_batch_run_device(c->ctx, c->d_recs + r0 * 32, k, slot, body, c->d_pub + r0 * 15, c->d_status + r0, stream);
+    int32_t rc;
+    { Range r("b3w:witness batch"); rc = b3w_batch_run_device(c->ctx, c->d_recs + r0 * 32, k, slot, body, c->d_pub + r0 * 15, c->d_status + r0, stream); }
     if (rc) return rc;
-    if (consumer) consumer(user, slot, body, r0, k, stream);
+    if (consumer) { Range r("b3w:consumer"); consumer(user, slot, body, r0, k, stream); }
     c->nbatch++;
     done += k;
   }
@@ -1620,7 +1737,13 @@ int32_t b3w_chain_create(b3w_ctx *ctx, uint64_t preimage_len, uint64_t first_chu
   for (uint32_t i = 0; i < ring; i++) {
     void *p = nullptr;
     int32_t pl = B3W_PLACEMENT_PLAIN;
-    const int32_t rc = b3w_bodies_alloc(ctx, (uint64_t)batch_steps * body, &p, &pl);
+    const uint64_t want = (uint64_t)batch_steps * body;
+    for (size_t k = 0; k < ctx->ring_spares.size() && !p; k++)         // a ring buffer of an earlier chain of this context
+      if (ctx->ring_spares[k].bytes == want) {
+        p = ctx->ring_spares[k].ptr; pl = ctx->ring_spares[k].placement;
+        ctx->ring_spares.erase(ctx->ring_spares.begin() + k);
+      }
+    const int32_t rc = p ? B3W_OK : b3w_bodies_alloc(ctx, want, &p, &pl);
     if (rc) { b3w_chain_destroy(c); return rc; }
     c->bodies.push_back(p);
     if (pl != B3W_PLACEMENT_MIXED) c->placement = B3W_PLACEMENT_PLAIN;
@@ -1633,7 +1756,13 @@ void b3w_chain_destroy(b3w_chain *c) {
   if (!c) return;
   DeviceGuard guard(c->ctx->device);
   (void)hipDeviceSynchronize();
-  for (void *p : c->bodies) (void)b3w_bodies_free(c->ctx, p);
+  // ring buffers go back to the context (placed buffers use up address space for good: DESIGN.md "Placement"); at most
+  // four are kept, the rest is freed
+  const uint64_t ring_bytes = (uint64_t)c->batch_steps * 32ull * c->ctx->desc.nwit;
+  for (void *p : c->bodies) {
+    if (c->ctx->ring_spares.size() < 4) c->ctx->ring_spares.push_back({p, ring_bytes, c->placement});
+    else (void)b3w_bodies_free(c->ctx, p);
+  }
   if (c->d_pre) (void)hipFree(c->d_pre);
   if (c->d_recs) (void)hipFree(c->d_recs);
   if (c->d_cvs) (void)hipFree(c->d_cvs);
@@ -1664,11 +1793,18 @@ int32_t b3w_chain_run_leaves(b3w_chain *c, const uint8_t *host_preimage, b3w_bat
     const uint32_t sc = std::min<uint32_t>(SLICE, c->nl - s0);
     const uint64_t b0 = (c->first_chunk + s0) * 1024, b1 = std::min<uint64_t>(b0 + (uint64_t)sc * 1024, c->len);
     hipEvent_t ev = c->ev[slice % 3];
-    if (b1 > b0) HIP_TRY(ctx, hipMemcpyAsync(c->d_pre + (uint64_t)s0 * 1024, host_preimage + b0, b1 - b0, hipMemcpyHostToDevice, c->copy));
-    HIP_TRY(ctx, hipEventRecord(ev, c->copy));
-    HIP_TRY(ctx, hipStreamWaitEvent(st, ev, 0));
-    int32_t rc = b3w_chain_plan_leaves_device(ctx, c->d_pre + (uint64_t)s0 * 1024, c->len, c->first_chunk + s0, sc,
-                                              c->d_recs + (uint64_t)s0 * 16 * 32, c->d_cvs + (uint64_t)s0 * 8, stream);
+    {
+      Range r("b3w:h2d preimage slice");
+      if (b1 > b0) HIP_TRY(ctx, hipMemcpyAsync(c->d_pre + (uint64_t)s0 * 1024, host_preimage + b0, b1 - b0, hipMemcpyHostToDevice, c->copy));
+      HIP_TRY(ctx, hipEventRecord(ev, c->copy));
+      HIP_TRY(ctx, hipStreamWaitEvent(st, ev, 0));
+    }
+    int32_t rc;
+    {
+      Range r("b3w:plan leaf steps");
+      rc = b3w_chain_plan_leaves_device(ctx, c->d_pre + (uint64_t)s0 * 1024, c->len, c->first_chunk + s0, sc,
+                                        c->d_recs + (uint64_t)s0 * 16 * 32, c->d_cvs + (uint64_t)s0 * 8, stream);
+    }
     if (rc) return rc;
     if (s0 + sc == c->nl) HIP_TRY(ctx, hipEventRecord(c->ev_cvs, st));     // every local chunk CV is on its way
     const uint64_t steps_here = (uint64_t)sc * 16 - ((c->has_last && s0 + sc == c->nl) ? 16 - c->last_blocks : 0);
@@ -1693,10 +1829,14 @@ int32_t b3w_chain_run_parents(b3w_chain *c, const uint32_t *d_all_chunk_cvs, b3w
     HIP_TRY(ctx, hipEventRecord(c->ev_cvs, st));
     HIP_TRY(ctx, hipStreamWaitEvent(c->side, c->ev_cvs, 0));
   }
-  HIP_TRY(ctx, hipMemcpyAsync(c->d_levels, d_all_chunk_cvs, c->n_chunks * 32, hipMemcpyDeviceToDevice, c->side));
-  int32_t rc = b3w_chain_tree_device(ctx, c->d_levels, c->n_chunks, c->d_root, c->side);
-  if (rc == B3W_OK && c->n_par)
-    rc = b3w_chain_plan_parents_device(ctx, c->d_levels, c->n_chunks, c->len, c->first_chunk, c->nl, c->d_recs + c->n_leaf * 32, c->side);
+  int32_t rc;
+  {
+    Range r("b3w:tree + plan parent steps");
+    HIP_TRY(ctx, hipMemcpyAsync(c->d_levels, d_all_chunk_cvs, c->n_chunks * 32, hipMemcpyDeviceToDevice, c->side));
+    rc = b3w_chain_tree_device(ctx, c->d_levels, c->n_chunks, c->d_root, c->side);
+    if (rc == B3W_OK && c->n_par)
+      rc = b3w_chain_plan_parents_device(ctx, c->d_levels, c->n_chunks, c->len, c->first_chunk, c->nl, c->d_recs + c->n_leaf * 32, c->side);
+  }
   HIP_TRY(ctx, hipEventRecord(c->ev_par, c->side));
   HIP_TRY(ctx, hipStreamWaitEvent(st, c->ev_par, 0));   // also when something failed: `stream` must not run ahead of the side stream
   if (rc) return rc;

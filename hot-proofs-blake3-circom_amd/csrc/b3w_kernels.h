@@ -39,6 +39,8 @@ extern "C" int b3w_launch_verify(int kind, const uint32_t *d_in_slots, uint32_t 
 extern "C" int b3w_place_alloc(int device, uint64_t bytes, int want_mixed, void **out, int *mixed, float *rates);
 extern "C" int b3w_place_free(void *ptr);
 extern "C" void b3w_place_trim(void);
+extern "C" void b3w_place_configure(int64_t search_gib, int64_t pool_gib);      // < 0: leave as is
+extern "C" void b3w_place_stats(int device, uint64_t out[6]);
 
 // b3w_commit.hip: Pedersen commitments of witness bodies (on-device consumer).
 // Window width W (virtual slots per window, 2^W - 1 tabulated subset sums each) is a property of the key:
@@ -72,7 +74,8 @@ struct B3wField {
   uint32_t inv;       // -p^-1 mod 2^32
 };
 // rows: m x {first term, terms in A, in B, in C} (terms of a row are stored A then B then C); row_id: the row's index in the
-// .r1cs file (rows are sorted by shape); term k = wires[k], cids[k] (0: coefficient +1, 1: -1, else coefR[8 * cid ..] = coef * 2^256 mod p)
+// .r1cs file (rows are sorted by shape); term k = wires[k], cids[k] (0: coefficient +1, 1: -1, else d_coefR[16 * cid ..] =
+// the coefficient (8 words), then coefficient * 2^256 mod p (8 words))
 extern "C" int b3w_launch_r1cs(const uint8_t *d_bodies, uint32_t n, uint64_t pitch, uint32_t m, const uint32_t *d_rows,
                                const uint32_t *d_row_id, const uint32_t *d_wires, const uint16_t *d_cids, const uint32_t *d_coefR,
                                const B3wField *field, uint32_t *d_violations, uint32_t *d_first, hipStream_t stream);

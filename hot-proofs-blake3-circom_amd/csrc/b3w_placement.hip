@@ -62,7 +62,8 @@ constexpr uint64_t HANDLE = 256 * MiB;             // physical granule of a plac
 constexpr uint32_t PROBE_STREAMS = 512;            // 256 per side
 constexpr uint64_t PROBE_PITCH = 768 * 1024;       // 256 streams x 768 KiB = 192 MiB <= HANDLE
 constexpr double CONTRAST = 1.18;                  // fast / slow ratio that counts as "another class" (measured: 1.25-1.3)
-constexpr uint64_t POOL_CAP_PER_LABEL = 12 * GiB;  // labelled handles kept for later buffers, per label (A, B, C)
+constexpr uint64_t POOL_CAP_DEFAULT = 4 * GiB;     // labelled handles kept for later buffers, per label (A, B, C): 12 GiB in all
+constexpr uint64_t SEARCH_CAP_MAX = 160 * GiB;     // new handles a search may walk beyond the buffer itself, at the very most
 constexpr uint64_t ARENA = 32ull << 40;            // virtual address range per device (less if refused), bump-allocated, never reused
 
 enum : uint8_t { LA = 0, LB = 1, LC = 2, LM = 3 };
@@ -89,9 +90,28 @@ struct Pool {
   uint32_t slot_h0 = 0, slot_f0 = 0;
   std::vector<Cand> spare;                          // labelled, each still mapped in its probe slot
   hipEvent_t e0 = nullptr, e1 = nullptr;
+  hipStream_t stream = nullptr;                     // the probes' own stream: other work of the process does not sit between the events
+  uint64_t handles_created = 0;
   hipMemAllocationProp prop{};
   hipMemAccessDesc acc{};
 };
+
+// Knobs (b3w_place_configure / B3W_PLACE_SEARCH_GIB, B3W_PLACE_POOL_GIB): how much memory a search may touch
+// transiently and how much labelled memory stays pooled — co-resident allocators (torch, RCCL) cannot see either.
+struct Knobs {
+  int64_t search_gib = -1;     // < 0: 16 x the buffer, at least 24 GiB, at most 160 GiB
+  int64_t pool_gib = -1;       // < 0: POOL_CAP_DEFAULT per label
+  Knobs() {
+    if (const char *e = getenv("B3W_PLACE_SEARCH_GIB")) search_gib = atoll(e);
+    if (const char *e = getenv("B3W_PLACE_POOL_GIB")) pool_gib = atoll(e);
+  }
+};
+Knobs &knobs() { static Knobs k; return k; }
+uint64_t pool_cap_per_label() { return knobs().pool_gib < 0 ? POOL_CAP_DEFAULT : (uint64_t)knobs().pool_gib * GiB / 3; }
+uint64_t search_cap(uint64_t own) {
+  if (knobs().search_gib >= 0) return std::min<uint64_t>((uint64_t)knobs().search_gib * GiB, SEARCH_CAP_MAX);
+  return std::min<uint64_t>(std::max<uint64_t>(16 * own, 24 * GiB), SEARCH_CAP_MAX);
+}
 
 std::mutex &mtx() { static std::mutex m; return m; }
 std::vector<Pool *> &pools() { static std::vector<Pool *> p; return p; }
@@ -115,13 +135,14 @@ Pool *pool_for(int device) {
   p->arena = static_cast<uint8_t *>(va);
   (void)hipEventCreate(&p->e0);
   (void)hipEventCreate(&p->e1);
+  if (hipStreamCreateWithFlags(&p->stream, hipStreamNonBlocking) != hipSuccess) { (void)hipGetLastError(); p->stream = nullptr; }
   pools().push_back(p);
   return p;
 }
 
 // a failure in here only ends a search; the sticky HIP error must not leak into the caller's next launch check
 bool create_handle(Pool *p, hipMemGenericAllocationHandle_t *h) {
-  if (hipMemCreate(h, HANDLE, &p->prop, 0) == hipSuccess) return true;
+  if (hipMemCreate(h, HANDLE, &p->prop, 0) == hipSuccess) { p->handles_created++; return true; }
   (void)hipGetLastError();
   return false;
 }
@@ -144,11 +165,11 @@ void release(Pool *p, Cand &c) {
 double probe_slots(Pool *p, uint32_t sa, uint32_t sb, int reps = 3) {
   uint8_t *a = slot_addr(p, sa), *b = slot_addr(p, sb);
   const uint32_t groups = (uint32_t)(PROBE_PITCH / 1024);
-  hipLaunchKernelGGL(b3w_store_probe_kernel, dim3(PROBE_STREAMS), dim3(64), 0, 0, a, b, PROBE_PITCH, groups);
-  (void)hipEventRecord(p->e0, 0);
+  hipLaunchKernelGGL(b3w_store_probe_kernel, dim3(PROBE_STREAMS), dim3(64), 0, p->stream, a, b, PROBE_PITCH, groups);
+  (void)hipEventRecord(p->e0, p->stream);
   for (int i = 0; i < reps; i++)
-    hipLaunchKernelGGL(b3w_store_probe_kernel, dim3(PROBE_STREAMS), dim3(64), 0, 0, a, b, PROBE_PITCH, groups);
-  (void)hipEventRecord(p->e1, 0);
+    hipLaunchKernelGGL(b3w_store_probe_kernel, dim3(PROBE_STREAMS), dim3(64), 0, p->stream, a, b, PROBE_PITCH, groups);
+  (void)hipEventRecord(p->e1, p->stream);
   if (hipEventSynchronize(p->e1) != hipSuccess) { (void)hipGetLastError(); return 0; }
   float ms = 0;
   (void)hipEventElapsedTime(&ms, p->e0, p->e1);
@@ -224,7 +245,7 @@ void give_back(Pool *p, std::vector<Cand> &v) {           // to the pool while i
   uint32_t held[4] = {0, 0, 0, 0};
   for (const Cand &c : p->spare) held[c.label]++;
   for (Cand &c : v) {
-    if (p->refs && c.label != LM && (uint64_t)(held[c.label] + 1) * HANDLE <= POOL_CAP_PER_LABEL) { p->spare.push_back(c); held[c.label]++; }
+    if (p->refs && c.label != LM && (uint64_t)(held[c.label] + 1) * HANDLE <= pool_cap_per_label()) { p->spare.push_back(c); held[c.label]++; }
     else release(p, c);
   }
   v.clear();
@@ -249,8 +270,9 @@ extern "C" int b3w_place_alloc(int device, uint64_t bytes, int want_mixed, void 
   const uint64_t own = (uint64_t)nh * HANDLE, pooled = (uint64_t)p->spare.size() * HANDLE;
   if (fr + pooled < own + GiB) return -(int)hipErrorOutOfMemory;
   // search budget in NEW handles: the buffer itself plus at most half of what is free beyond it (other processes may
-  // be doing the same on this device), never more than 160 GiB — and never more than the address range still has
-  uint32_t budget = (uint32_t)((std::min<uint64_t>(own, fr) + std::min<uint64_t>((fr > own ? fr - own : 0) / 2, 160 * GiB)) / HANDLE);
+  // be doing the same on this device), bounded by the search knob — and never more than the address range still has
+  uint32_t budget = (uint32_t)((std::min<uint64_t>(own, fr) + std::min<uint64_t>((fr > own ? fr - own : 0) / 2, search_cap(own))) / HANDLE);
+  if (want_mixed) (void)hipDeviceSynchronize();               // the probes time stores: nothing else should be running
   if (slots_left(p) < 2 * nh + 8) return -(int)hipErrorOutOfMemory;          // address range used up: caller falls back
   budget = std::min<uint32_t>(budget, slots_left(p) - nh - 4);
 
@@ -411,6 +433,27 @@ extern "C" int b3w_place_free(void *ptr) {
   if (p) give_back(p, pl->pieces);                       // labelled pieces: kept for the next buffer while there is room
   delete pl;
   return 0;
+}
+
+extern "C" void b3w_place_configure(int64_t search_gib, int64_t pool_gib) {
+  std::lock_guard<std::mutex> guard(mtx());
+  if (search_gib >= 0) knobs().search_gib = search_gib;
+  if (pool_gib >= 0) knobs().pool_gib = pool_gib;
+}
+
+// out: arena bytes, arena bytes used up (never reused), pooled bytes, bytes of live placed buffers, live placed buffers,
+// physical handles created so far
+extern "C" void b3w_place_stats(int device, uint64_t out[6]) {
+  std::lock_guard<std::mutex> guard(mtx());
+  for (int i = 0; i < 6; i++) out[i] = 0;
+  for (Pool *p : pools()) {
+    if (p->device != device) continue;
+    out[0] = p->arena_bytes;
+    out[1] = (uint64_t)p->next_slot * HANDLE;
+    out[2] = (uint64_t)p->spare.size() * HANDLE;
+    out[5] = p->handles_created;
+  }
+  for (Placed *pl : registry()) if (pl->device == device) { out[3] += pl->va_bytes; out[4]++; }
 }
 
 // release the pooled handles of every device (the references stay)

@@ -12,11 +12,16 @@
 // at run time (BN254 scalar field or the Vesta base field).  A term coef * z[wire] is montmul(coef * R, z) = coef * z;
 // coefficients +1 / -1 (93 % of the terms of the compression system) are an addition / subtraction.
 //
-// Mapping: thread = (constraint, body).  blockIdx.y = body, 256 consecutive rows per workgroup; rows are sorted by
-// shape (terms in A, B, C) on the host so that the 64 lanes of a wave run the same trip counts.  The constraint stream
-// (117 760 terms, 0.9 MB for blake3_compression) is shared by all bodies and stays in L2; each term gathers one 32-byte
-// element of the body — neighbouring rows read neighbouring slots (the bit runs), so most wave loads are whole lines.
-// Bound: L2/TA gather rate and integer ALU, not HBM: a body is read ~4.9x (once per term), 0.2 % of peak flops are needed.
+// Mapping: thread = (constraint, body), 256 consecutive rows per workgroup; rows are sorted by shape (terms in A, B, C)
+// on the host so that the 64 lanes of a wave run the same trip counts.  The workgroups of ONE body all land on one XCD
+// (the hardware deals consecutive workgroup ids round-robin over the 8 XCDs: id -> body = 8 * (id / (8 * RB)) + id % 8,
+// row block = (id / 8) % RB), so a body is fetched from HBM into one L2 once and its ~4.9 reads per element (once per
+// term) are L2 hits.  The constraint stream (117 760 terms, 0.9 MB for blake3_compression) is shared by all bodies and
+// stays in L2; neighbouring rows read neighbouring slots (the bit runs), so most wave loads are whole lines.
+// Values decide how much arithmetic a term costs, never what it computes: an element that is 0 contributes nothing, an
+// element that is 1 contributes the coefficient itself, a product with a factor 0 or 1 needs no multiplication — the
+// general Montgomery path is taken for everything else (any field element is handled exactly).  A valid witness of these
+// circuits is 98 % bits, so the check of a valid batch is gather-bound (L2/TA), not ALU-bound.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "b3w_kernels.h"
@@ -132,8 +137,26 @@ __device__ __forceinline__ Fe load_z(const uint8_t *body, uint32_t wire, const B
   return z;
 }
 
-// <row, z>: `n` terms starting at `off`; term = wire | coefficient id (0: +1, 1: -1, else index into coefR)
-__device__ __forceinline__ Fe dot(const uint8_t *body, const uint32_t *wires, const uint16_t *cids, const uint32_t *coefR,
+__device__ __forceinline__ Fe load_fe(const uint32_t *p) {
+  const uint4 *q = reinterpret_cast<const uint4 *>(p);
+  const uint4 lo = q[0], hi = q[1];
+  Fe r;
+  r.l[0] = lo.x; r.l[1] = lo.y; r.l[2] = lo.z; r.l[3] = lo.w;
+  r.l[4] = hi.x; r.l[5] = hi.y; r.l[6] = hi.z; r.l[7] = hi.w;
+  return r;
+}
+
+// 0, 1 or 2 = "something else"
+__device__ __forceinline__ int small01(const Fe &a) {
+  uint32_t hi = 0;
+#pragma unroll
+  for (int i = 1; i < 8; i++) hi |= a.l[i];
+  return (hi | (a.l[0] >> 1)) ? 2 : (int)a.l[0];
+}
+
+// <row, z>: `n` terms starting at `off`; term = wire | coefficient id (0: +1, 1: -1, else index into the tables:
+// coefs[16 * cid ..] = the coefficient, then the coefficient * 2^256 mod p)
+__device__ __forceinline__ Fe dot(const uint8_t *body, const uint32_t *wires, const uint16_t *cids, const uint32_t *coefs,
                                   uint32_t off, uint32_t n, const B3wField &F, bool *wild) {
   Fe acc;
 #pragma unroll
@@ -142,14 +165,15 @@ __device__ __forceinline__ Fe dot(const uint8_t *body, const uint32_t *wires, co
     const uint32_t w = wires[off + k];
     const uint32_t cid = cids[off + k];
     const Fe z = load_z(body, w, F, wild);
+    const int zs = small01(z);
+    if (zs == 0) continue;                               // coef * 0
     if (cid == 0) fe_add(acc, z, F.p);
     else if (cid == 1) fe_sub(acc, z, F.p);
-    else {
-      Fe cf;
-      const uint4 *q = reinterpret_cast<const uint4 *>(coefR + (size_t)cid * 8);
-      const uint4 lo = q[0], hi = q[1];
-      cf.l[0] = lo.x; cf.l[1] = lo.y; cf.l[2] = lo.z; cf.l[3] = lo.w;
-      cf.l[4] = hi.x; cf.l[5] = hi.y; cf.l[6] = hi.z; cf.l[7] = hi.w;
+    else if (zs == 1) {                                  // coef * 1
+      const Fe cf = load_fe(coefs + (size_t)cid * 16);
+      fe_add(acc, cf, F.p);
+    } else {
+      const Fe cf = load_fe(coefs + (size_t)cid * 16 + 8);
       const Fe t = mont_mul(cf, z, F);                   // (coef * R) * z / R
       fe_add(acc, t, F.p);
     }
@@ -157,13 +181,16 @@ __device__ __forceinline__ Fe dot(const uint8_t *body, const uint32_t *wires, co
   return acc;
 }
 
-__global__ __launch_bounds__(256) void b3w_r1cs_kernel(const uint8_t *__restrict__ bodies, uint64_t pitch, uint32_t m,
-                                                       const uint4 *__restrict__ rows /* off, nA, nB, nC */,
+__global__ __launch_bounds__(256) void b3w_r1cs_kernel(const uint8_t *__restrict__ bodies, uint64_t pitch, uint32_t n, uint32_t m,
+                                                       uint32_t row_blocks, const uint4 *__restrict__ rows /* off, nA, nB, nC */,
                                                        const uint32_t *__restrict__ row_id, const uint32_t *__restrict__ wires,
                                                        const uint16_t *__restrict__ cids, const uint32_t *__restrict__ coefR,
                                                        B3wField F, uint32_t *__restrict__ violations, uint32_t *__restrict__ first) {
-  const uint32_t r = blockIdx.x * 256 + threadIdx.x;
-  const uint32_t b = blockIdx.y;
+  // all row blocks of a body on one XCD (see the header): groups of 8 bodies x row_blocks workgroups
+  const uint32_t per_group = 8u * row_blocks;
+  const uint32_t b = (blockIdx.x / per_group) * 8u + (blockIdx.x & 7u);
+  const uint32_t r = ((blockIdx.x % per_group) >> 3) * 256u + threadIdx.x;
+  if (b >= n) return;                                    // whole workgroup: the last group of a ragged batch
   const uint8_t *body = bodies + (uint64_t)b * pitch;
   bool bad = false;
   uint32_t id = 0xFFFFFFFFu;
@@ -178,10 +205,19 @@ __global__ __launch_bounds__(256) void b3w_r1cs_kernel(const uint8_t *__restrict
     } else {
       const Fe az = dot(body, wires, cids, coefR, d.x, d.y, F, &wild);
       const Fe bz = dot(body, wires, cids, coefR, d.x + d.y, d.z, F, &wild);
-      Fe r2;
+      const int as = small01(az), bs = small01(bz);
+      Fe ab;
+      if (as == 0 || bs == 0) {                                                      // 0 * x
 #pragma unroll
-      for (int i = 0; i < 8; i++) r2.l[i] = F.r2[i];
-      const Fe ab = mont_mul(mont_mul(az, r2, F), bz, F);                            // (az * R) * bz / R = az * bz
+        for (int i = 0; i < 8; i++) ab.l[i] = 0;
+      } else if (as == 1) ab = bz;                                                   // 1 * x
+      else if (bs == 1) ab = az;
+      else {
+        Fe r2;
+#pragma unroll
+        for (int i = 0; i < 8; i++) r2.l[i] = F.r2[i];
+        ab = mont_mul(mont_mul(az, r2, F), bz, F);                                   // (az * R) * bz / R = az * bz
+      }
       Fe diff = ab;
       fe_sub(diff, cz, F.p);
       bad = !fe_is_zero(diff);
@@ -210,11 +246,14 @@ extern "C" int b3w_launch_r1cs(const uint8_t *d_bodies, uint32_t n, uint64_t pit
   hipError_t e = hipMemsetAsync(d_violations, 0, (size_t)n * 4, stream);
   if (e == hipSuccess && d_first) e = hipMemsetAsync(d_first, 0xFF, (size_t)n * 4, stream);
   if (e != hipSuccess) return (int)e;
-  // grid.y is limited to 65 535: bodies in slabs
-  for (uint32_t b0 = 0; b0 < n; b0 += 65535) {
-    const uint32_t nb = n - b0 < 65535 ? n - b0 : 65535;
-    hipLaunchKernelGGL(b3w_r1cs_kernel, dim3((m + 255) / 256, nb), dim3(256), 0, stream, d_bodies + (uint64_t)b0 * pitch, pitch, m,
-                       reinterpret_cast<const uint4 *>(d_rows), d_row_id, d_wires, d_cids, d_coefR, *field, d_violations + b0,
+  const uint32_t row_blocks = (m + 255) / 256;
+  // one-dimensional grid, bodies in slabs that keep the workgroup count below 2^31
+  const uint32_t slab = (0x7FFFFFFFu / row_blocks) & ~7u;
+  for (uint32_t b0 = 0; b0 < n; b0 += slab) {
+    const uint32_t nb = n - b0 < slab ? n - b0 : slab;
+    const uint32_t groups = (nb + 7) / 8;
+    hipLaunchKernelGGL(b3w_r1cs_kernel, dim3(groups * 8 * row_blocks), dim3(256), 0, stream, d_bodies + (uint64_t)b0 * pitch, pitch, nb, m,
+                       row_blocks, reinterpret_cast<const uint4 *>(d_rows), d_row_id, d_wires, d_cids, d_coefR, *field, d_violations + b0,
                        d_first ? d_first + b0 : nullptr);
     e = hipGetLastError();
     if (e != hipSuccess) return (int)e;

@@ -128,7 +128,10 @@ void *b3w_batch_device_ptr(b3w_batch *batch, uint64_t *pitch);
  * returns a linear device buffer of at least `bytes` bytes whose 256 MiB pieces alternate between two classes
  * (found by timing short store probes against two reference pieces while the buffer is assembled through the HIP
  * virtual-memory API);
- * *placement reports what was achieved.  Use the pointer like any device pointer (kernels, hipMemcpy); release it
+ * *placement reports what was achieved — and "mixed" is only reported when ONE REAL witness launch of this context's
+ * circuit into the buffer is at least 10 % faster than into a plain hipMalloc buffer (measured once per context; a buffer
+ * that fails the check stays usable and is reported as plain; B3W_PLACE_CHECK=0 skips the check).  Use the pointer like
+ * any device pointer (kernels, hipMemcpy); release it
  * with b3w_bodies_free.  B3W_PLACEMENT=plain in the environment turns the search off.
  * b3w_batch_alloc places its body buffer this way. */
 #define B3W_PLACEMENT_PLAIN 0 /* one class (no search, search failed, or a buffer below 512 MiB) */
@@ -138,6 +141,15 @@ int32_t b3w_bodies_free(b3w_ctx *ctx, void *d_ptr);
 /* The allocator keeps up to 3 x 12 GiB of classified-but-unused physical memory per device for the next buffer (and two
  * 256 MiB reference pieces for good); b3w_bodies_trim returns that reserve to the driver. */
 void b3w_bodies_trim(void);
+/* Bounds of the placement allocator, in GiB (negative = leave as is): `search_gib` = new physical memory one search may
+ * touch transiently beyond the buffer itself (default 16 x the buffer, at least 24, at most 160 — released again at the end
+ * of the search); `pool_gib` = labelled memory kept pooled for later buffers, all three labels together (default 12).
+ * Also B3W_PLACE_SEARCH_GIB / B3W_PLACE_POOL_GIB in the environment.  Other allocators in the process (torch, RCCL) cannot
+ * see pooled memory: b3w_bodies_trim hands it back. */
+void b3w_bodies_configure(int64_t search_gib, int64_t pool_gib);
+/* out[0] address-space arena of the ctx's device in bytes, out[1] of it used up (never reused), out[2] pooled bytes,
+ * out[3] bytes of live placed buffers, out[4] their number, out[5] physical 256 MiB handles created so far. */
+int32_t b3w_bodies_stats(const b3w_ctx *ctx, uint64_t out[6]);
 /* Placement of a batch's own body buffer. */
 int32_t b3w_batch_placement(const b3w_batch *batch);
 
@@ -321,8 +333,8 @@ int32_t b3w_batch_allgather_public(b3w_batch *batch, b3w_comm *comm, uint32_t *h
  *   b3w_chain_run_leaves   pageable or pinned host slices of the preimage -> HBM on a copy stream, overlapped with
  *                          the leaf planner and the nova witness kernels of earlier slices on `stream`
  *   (multi-GPU: all-gather the chunk chaining values of b3w_chain_local_cvs across ranks — 32 B per chunk)
- *   b3w_chain_run_parents  BLAKE3 tree over all chunk CVs, parent-step records of the local chunks (complete trees),
- *                          their witnesses
+ *   b3w_chain_run_parents  BLAKE3 tree over all chunk CVs, parent-step records of the local chunks' paths (any chunk
+ *                          count: b3w_chain_plan_parents_device), their witnesses
  * Witness bodies go through a ring of `ring` placed buffers (b3w_bodies_alloc) of `batch_steps` bodies each: a
  * 1 GiB preimage is 28 TB of witness.  After each batch `consumer` (may be NULL) is called with the device pointer
  * of the batch; it must enqueue its work on `stream` — the buffer is overwritten `ring` batches later.

@@ -149,3 +149,104 @@ def test_wtns_writer_streams_across_a_seam_of_a_placed_buffer(tmp_path):
         assert (tmp_path / f"w_{i}.wtns").read_bytes() == hdr + want[j].tobytes(), i
     b.close()
     ctx.close()
+
+
+def _fill_rate(ctx, ptr, n, d_recs, d_st, torch):
+    """GB/s of the witness kernel writing n bodies at ptr (2 warm-ups, 6 timed launches)"""
+    s = torch.cuda.current_stream().cuda_stream
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for _ in range(2):
+        ctx.run_device(d_recs.data_ptr(), n, ptr, 0, 0, d_st.data_ptr(), s)
+    e0.record()
+    for _ in range(6):
+        ctx.run_device(d_recs.data_ptr(), n, ptr, 0, 0, d_st.data_ptr(), s)
+    e1.record()
+    torch.cuda.synchronize()
+    return 6 * n * ctx.body_bytes / 1e6 / e0.elapsed_time(e1)
+
+
+def test_mixed_is_a_measured_claim():
+    """A buffer reported "mixed" has been timed with the real witness kernel against plain memory inside b3w_bodies_alloc
+    (demoted below +10 %); re-measured here from outside: every mixed buffer beats a plain hipMalloc buffer by > 10 %."""
+    import torch
+    ctx = m.Context("compression", 0)
+    n = 4096
+    d_recs = torch.from_numpy(m.workloads.config2_compression(n).view(np.int32)).cuda()
+    d_st = torch.zeros(n, dtype=torch.int32, device="cuda")
+    plain = torch.empty(n * ctx.body_bytes, dtype=torch.uint8, device="cuda")
+    r_plain = _fill_rate(ctx, plain.data_ptr(), n, d_recs, d_st, torch)
+    buf = ctx.alloc_bodies(n * ctx.body_bytes)
+    r_buf = _fill_rate(ctx, buf.ptr, n, d_recs, d_st, torch)
+    print(f"plain {r_plain:.0f} GB/s, b3w_bodies_alloc ({buf.placement}) {r_buf:.0f} GB/s")
+    if buf.placement == "mixed":
+        assert r_buf > 1.08 * r_plain                      # the allocator's own threshold is 1.10; timing noise allowed for
+    st = ctx.bodies_stats()
+    assert st["live_buffers"] >= 1 and st["live_bytes"] >= n * ctx.body_bytes and st["arena_used"] <= st["arena_bytes"]
+    buf.free()
+    del plain
+    ctx.close()
+
+
+def test_soak_200_buffers_keep_their_rate_and_the_pool_stays_bounded():
+    """200 allocate / fill / free cycles of a 3.2 GB body buffer: the 200th buffer is as fast as the first (within 3 %),
+    every one holds what the kernel wrote, the pool never exceeds its cap, and the address space used up is what
+    DESIGN.md says (one buffer's size per cycle, never reused) — far from the 32 TiB arena."""
+    import torch
+    ctx = m.Context("compression", 0)
+    n = 4096
+    recs = m.workloads.config2_compression(n)
+    d_recs = torch.from_numpy(recs.view(np.int32)).cuda()
+    d_st = torch.zeros(n, dtype=torch.int32, device="cuda")
+    d_mm = torch.zeros(n, dtype=torch.int32, device="cuda")
+    rates, labels = [], []
+    used0 = ctx.bodies_stats()["arena_used"]
+    for k in range(200):
+        buf = ctx.alloc_bodies(n * ctx.body_bytes)
+        labels.append(buf.placement)
+        if k in (0, 1, 2, 197, 198, 199):
+            rates.append(_fill_rate(ctx, buf.ptr, n, d_recs, d_st, torch))
+        else:
+            ctx.run_device(d_recs.data_ptr(), n, buf.ptr, 0, 0, d_st.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        if k % 20 == 0 or k == 199:
+            ctx.verify_device(buf.ptr, n, 0, d_mm.data_ptr(), torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            assert int(d_mm.abs().sum().item()) == 0 and int(d_st.abs().sum().item()) == 0, k
+        st = ctx.bodies_stats()
+        assert st["pooled_bytes"] <= 13 << 30 and st["live_buffers"] == 1
+        buf.free()
+    st = ctx.bodies_stats()
+    print(f"rates GB/s first {rates[:3]} last {rates[3:]}; labels {sorted(set(labels))}; arena used {(st['arena_used'] - used0) / 2**30:.0f} GiB "
+          f"of {st['arena_bytes'] / 2**40:.0f} TiB; handles created {st['handles_created']}")
+    assert len(set(labels)) == 1, "the placement changed along the way"
+    first, last = max(rates[:3]), max(rates[3:])
+    assert abs(last - first) <= 0.03 * first, (first, last)
+    assert st["arena_used"] - used0 <= 200 * (13 * HANDLE) + (64 << 30) and st["live_buffers"] == 0
+    ctx.close()
+
+
+def test_chain_rings_are_reused_across_chain_objects():
+    """b3w_chain_create after b3w_chain_destroy on one context takes the destroyed chain's ring buffers: no new address
+    space, same pointers."""
+    import ctypes
+    ctx = m.Context("nova_vesta", 0)
+    L = m.lib()
+    data = (np.arange(64 * 1024) % 251).astype(np.uint8)
+
+    def chain(nbytes):
+        h = ctypes.c_void_p()
+        assert L.b3w_chain_create(ctx.handle, nbytes, 0, L.b3w_chain_num_chunks(nbytes), 1024, 2, 1, ctypes.byref(h)) == 0
+        return h
+    h = chain(64 * 1024)
+    assert L.b3w_chain_run_leaves(h, data.ctypes.data, None, None, None) == 0 and L.b3w_chain_run_parents(h, None, None, None, None) == 0
+    used = ctx.bodies_stats()["arena_used"]
+    L.b3w_chain_destroy(h)
+    for nbytes in (32 * 1024, 64 * 1024, 5 * 1024):       # other preimages, same ring geometry
+        h = chain(nbytes)
+        assert L.b3w_chain_run_leaves(h, data.ctypes.data, None, None, None) == 0 and L.b3w_chain_run_parents(h, None, None, None, None) == 0
+        root = np.zeros(8, dtype=np.uint32)
+        assert L.b3w_chain_outputs(h, None, None, root.ctypes.data, None) == 0
+        import blake3_ref as B
+        assert list(root) == B.hash_words(data[:nbytes].tobytes())
+        L.b3w_chain_destroy(h)
+        assert ctx.bodies_stats()["arena_used"] == used
+    ctx.close()
