@@ -191,12 +191,12 @@ class WitnessCalculator {
     return r;
   }
 
-  // ---- extension: commitment key for batch.commit().  curve: "bn254_g1" | "vesta"; generators: Uint8Array with one
+  // ---- extension: commitment key for batch.commit().  curve: "bn254_g1" | "pallas" (the group over the --prime vesta circuit's scalar field); generators: Uint8Array with one
   // affine point per committed slot (x then y, 32-byte little-endian each), slots firstSlot .. witnessSize - 1;
   // windowBits: 12 | 16 (table size against speed, see include/b3wit.h), default automatic.
   setCommitKey(curve, generators, firstSlot, windowBits) {
-    const id = {bn254_g1: 0, vesta: 1}[curve];
-    if (id === undefined) throw new Error("curve: bn254_g1 or vesta");
+    const id = {bn254_g1: 0, pallas: 1, vesta: 1}[curve];      // "vesta": older name of the Pallas curve id (after the circuit's prime)
+    if (id === undefined) throw new Error("curve: bn254_g1 or pallas");
     native().commitKey(this.instance, id, firstSlot || 0, generators, windowBits || 0);
   }
 

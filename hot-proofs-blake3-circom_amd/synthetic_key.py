@@ -10,8 +10,9 @@ import hashlib
 # y^2 = x^3 + b over the base field p
 CURVES = {
     "bn254_g1": (21888242871839275222246405745257275088696311157297823662689037894645226208583, 3),
-    "vesta": (0x40000000000000000000000000000000224698fc094cf91b992d30ed00000001, 5),
+    "vesta": (0x40000000000000000000000000000000224698fc094cf91b992d30ed00000001, 5),     # the Pallas curve (scalar field = circom's "vesta" prime)
 }
+CURVES["pallas"] = CURVES["vesta"]
 
 
 def _sqrt(a, p):

@@ -198,7 +198,7 @@ int32_t b3w_batch_verify_device(b3w_ctx *ctx, const uint8_t *d_bodies, uint32_t 
 /* On-device consumer #2: Pedersen commitments C_i = sum_s w_i[s] * G[s - first_slot] over slots s >= first_slot of n
  * witness bodies in HBM — what the folding prover does with a step witness right after `synthesize`
  * (rust_fold/src/main.rs:166-179 -> arecibo's prove_step commits to W).  The group is the one
- * whose scalar field is the circuit's field: BN254 G1 for the bn128 circuits, the Vesta curve for the --prime vesta
+ * whose scalar field is the circuit's field: BN254 G1 for the bn128 circuits, the Pallas curve for the --prime vesta
  * build (short Weierstrass, a = 0).  The generators are the caller's (arecibo's commitment key): affine points,
  * x then y, 32-byte little-endian each, standard (non-Montgomery) form, one per committed slot.
  * b3w_commit_key_create precomputes 2^k * G for the slots that hold more than one bit, so committing a witness is
@@ -206,7 +206,10 @@ int32_t b3w_batch_verify_device(b3w_ctx *ctx, const uint8_t *d_bodies, uint32_t 
  * at infinity); d_status (may be NULL): 0 ok, 103 = a bit slot of that body does not hold 0 or 1 (not a body of the
  * batch kernels: commitment not meaningful). */
 #define B3W_CURVE_BN254_G1 0 /* y^2 = x^3 + 3 over q = 0x30644e72e131a029b85045b68181585d97816a916871ca8d3c208c16d87cfd47 */
-#define B3W_CURVE_VESTA    1 /* y^2 = x^3 + 5 over 0x40000000000000000000000000000000224698fc094cf91b992d30ed00000001 */
+#define B3W_CURVE_PALLAS   1 /* y^2 = x^3 + 5 over 0x40000000000000000000000000000000224698fc094cf91b992d30ed00000001: the Pallas curve
+                               * (pasta_curves; generator (-1, 2)), whose SCALAR field is the prime circom calls "vesta" — the group
+                               * arecibo's PallasEngine commits in for the --prime vesta build (rust_fold/src/main.rs:366) */
+#define B3W_CURVE_VESTA    B3W_CURVE_PALLAS /* older name of the same id, after the circuit's prime; kept for source compatibility */
 typedef struct b3w_commit_key b3w_commit_key;
 int32_t b3w_commit_key_create(b3w_ctx *ctx, int32_t curve, uint32_t first_slot, const uint8_t *host_generators, b3w_commit_key **out);
 /* The same with the table's window width chosen by the caller: every `window_bits` consecutive bits of the witness share one

@@ -6,10 +6,12 @@ import hashlib
 CURVES = {
     # BN254 / alt_bn128 G1: y^2 = x^3 + 3 over q
     "bn254_g1": (21888242871839275222246405745257275088696311157297823662689037894645226208583, 3),
-    # Vesta: y^2 = x^3 + 5 over the Pallas scalar field (its own scalar field is the circuits' "vesta" prime)
+    # Pallas (pasta_curves): y^2 = x^3 + 5 over p below; its scalar field is the prime circom calls "vesta", which is why the
+    # key is "vesta" here and in the library's older name B3W_CURVE_VESTA (tests/test_ec_ref_public_vectors.py pins it)
     "vesta": (0x40000000000000000000000000000000224698fc094cf91b992d30ed00000001, 5),
 }
-CURVE_ID = {"bn254_g1": 0, "vesta": 1}
+CURVES["pallas"] = CURVES["vesta"]
+CURVE_ID = {"bn254_g1": 0, "vesta": 1, "pallas": 1}
 
 
 def sqrt_mod(a, p):

@@ -293,3 +293,58 @@ def test_commitments_from_records_across_a_chunk_border_and_argument_checks():
     with pytest.raises(m.B3WError):
         key.commit_device(d_bodies.data_ptr() + 4, k - 1, 0, want.data_ptr(), 0, s)
     key.close(); ctx.close()
+
+
+def test_device_reproduces_published_known_answers():
+    """The commit kernel against PUBLISHED constants, not just against tests/ec_ref.py: hand-made bodies whose only
+    non-zero slots are w[0] = 1 and the 32-bit output slots w[1], w[2] (b3w_batch_commit_device does not care whether
+    a body is a valid witness, only that bit slots hold bits).
+      BN254 G1 (EIP-196): generators (G, G): 1*G + 2*G = 3G as printed in EIP-196 / py_ecc;
+                          generators (-, Q, 2^32 Q): lo*Q + hi*2^32 Q = k*Q with go-ethereum's bn256ScalarMul vector
+                          "chfast1" (k = 0x11138ce750fa15c2 -> S); generators (P1, P2): go-ethereum's bn256Add vector "chfast1";
+      Pallas (pasta_curves): generator (-1, 2): 1*G + 5*G = 6G, and (q - 1) G = -G pins 6G through ec_ref's order test."""
+    import torch
+    m = T.pkg()
+    H = lambda s: int(s, 16)
+    dev = torch.device("cuda:0")
+
+    def commit_body(circuit, curve, slot_vals, gens3):
+        ctx = m.Context(circuit, 0)
+        nwit = ctx.witness_size
+        body = np.zeros(nwit * 32, dtype=np.uint8)
+        for s, v in slot_vals.items():
+            body[32 * s:32 * s + 32] = np.frombuffer(int(v).to_bytes(32, "little"), dtype=np.uint8)
+        filler = E.random_points(curve, 1, seed=b"kat")[0]
+        gens = list(gens3) + [filler] * (nwit - len(gens3))
+        key = m.CommitKey(ctx, curve, E.points_to_bytes(gens), window=12)
+        d_body = torch.from_numpy(body).to(dev)
+        d_pts = torch.zeros(64, dtype=torch.uint8, device=dev)
+        d_st = torch.full((1,), -1, dtype=torch.int32, device=dev)
+        key.commit_device(d_body.data_ptr(), 1, 0, d_pts.data_ptr(), d_st.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        torch.cuda.synchronize()
+        assert int(d_st.item()) == 0
+        out = E.point_from_bytes(d_pts.cpu().numpy().tobytes())
+        key.close(); ctx.close()
+        return out
+
+    q_bn, _ = E.CURVES["bn254_g1"]
+    G = (1, 2)
+    G3 = (3353031288059533942658390886683067124040920775575537747144343083137631628272,
+          19321533766552368860946552437480515441416830039777911637913418824951667761761)
+    assert commit_body("compression", "bn254_g1", {0: 1, 1: 2}, [G, G]) == G3
+    # bn256ScalarMul "chfast1": k * Q = S, with k split over two 32-bit slots; then bn256Add "chfast1": P1 + P2 = R
+    Q = (H("2bd3e6d0f3b142924f5ca7b49ce5b9d54c4703d7ae5648e61d02268b1a0a9fb7"), H("21611ce0a6af85915e2f1d70300909ce2e49dfad4a4619c8390cae66cefdb204"))
+    k = H("11138ce750fa15c2")
+    S = (H("070a8d6a982153cae4be29d434e8faef8a47b274a053f5a4ee2a6c9c13c31e5c"), H("031b8ce914eba3a9ffb989f9cdd5b0f01943074bf4f0f315690ec3cec6981afc"))
+    Q32 = E.mul(1 << 32, Q, q_bn)
+    O = commit_body("compression", "bn254_g1", {0: 0, 1: k & 0xFFFFFFFF, 2: k >> 32}, [G, Q, Q32])
+    assert O == S
+    P1 = (H("18b18acfb4c2c30276db5411368e7185b311dd124691610c5d3b74034e093dc9"), H("063c909c4720840cb5134cb9f59fa749755796819658d32efc0d288198f37266"))
+    P2 = (H("07c2b7f58a84bd6145f00c9c2bc0bb1a187f20ff2c92963a88019e7c6a014eed"), H("06614e20c147e940f2d70da3f74c9a17df361706a4485c742bd6788478fa17d7"))
+    R = (H("2243525c5efd4b9c3d3c45ac0ca3fe4dd85e830a4ce6b65fa1eeaee202839703"), H("301d1d33be6da8e509df21cc35964723180eed7532537db9ae5e7d48f195c915"))
+    assert commit_body("compression", "bn254_g1", {0: 1, 1: 1}, [P1, P2]) == R
+    # Pallas: generator (-1, 2)
+    p_pa, _ = E.CURVES["pallas"]
+    Gp = (p_pa - 1, 2)
+    assert commit_body("nova_vesta", "pallas", {0: 1, 1: 5}, [Gp, Gp]) == E.mul(6, Gp, p_pa)
+    assert commit_body("nova_vesta", "pallas", {0: 1}, [E.neg(Gp, p_pa)]) == E.mul(T.VESTA_Q - 1, Gp, p_pa)
