@@ -513,11 +513,12 @@ int32_t b3w_batch_run_device(b3w_ctx *ctx, const uint32_t *d_records, uint32_t n
   if (pitch < body || (pitch & 31)) { ctx->last_error = "pitch must be >= witness_size*32 and a multiple of 32"; return B3W_E_BAD_ARGUMENT; }
   if (reinterpret_cast<uintptr_t>(d_bodies) & 15) { ctx->last_error = "d_bodies must be 16-byte aligned"; return B3W_E_BAD_ARGUMENT; }
   ON_DEVICE(ctx);
-  // default choice of bodies per wave (tools/ubench/small_batches.py, batch_sizes.py): small batches want as many
-  // waves as bodies (one body streams at 13 GB/s per wave), large ones few fat waves
+  // default choice of bodies per wave (profiles/r02/batch_curve.json, tools/ubench/batch_curve.py: every setting at every
+  // batch size 64 ... 65 536): small batches want as many waves as bodies (one body streams at 13 GB/s per wave), large
+  // ones few fat waves; above 6 144 compression witnesses the occupancy-limited 8-body variant wins by 4-5 %
   int variant = ctx->variant;
   if (ctx->variant_auto) {
-    if (ctx->desc.kind == B3W_KIND_COMP) variant = n <= 1024 ? 1 : 0;
+    if (ctx->desc.kind == B3W_KIND_COMP) variant = n <= 1024 ? 1 : n <= 6144 ? 0 : 8;
     else if (ctx->desc.kind == B3W_KIND_NOVA_O2) variant = n <= 1024 ? 1 : n <= 3072 ? 0 : 3;
     else variant = n <= 1024 ? 1 : 0;
   }
@@ -733,12 +734,15 @@ int32_t b3w_bodies_alloc(b3w_ctx *ctx, uint64_t bytes, void **d_ptr, int32_t *pl
       static const bool check = !(getenv("B3W_PLACE_CHECK") && !strcmp(getenv("B3W_PLACE_CHECK"), "0"));
       if (mixed && check) {
         if (ctx->plain_ms_per_gb == 0) {
-          void *plain = nullptr;
+          // the slowest of three distinct hipMalloc buffers: one plain buffer in eight or so straddles a class border
+          // by luck and is as fast as a placed one — that must not become the yardstick
+          void *plain[3] = {nullptr, nullptr, nullptr};
           const uint64_t pb = std::min<uint64_t>(bytes, 4ull << 30);
-          if (hipMalloc(&plain, pb) == hipSuccess) {
-            ctx->plain_ms_per_gb = time_witness_fill(ctx, static_cast<uint8_t *>(plain), pb);
-            (void)hipFree(plain);
-          } else (void)hipGetLastError();
+          for (int i = 0; i < 3; i++) {
+            if (hipMalloc(&plain[i], pb) != hipSuccess) { (void)hipGetLastError(); plain[i] = nullptr; break; }
+            ctx->plain_ms_per_gb = std::max(ctx->plain_ms_per_gb, time_witness_fill(ctx, static_cast<uint8_t *>(plain[i]), pb));
+          }
+          for (int i = 0; i < 3; i++) if (plain[i]) (void)hipFree(plain[i]);
           if (ctx->plain_ms_per_gb == 0) ctx->plain_ms_per_gb = -1;          // could not measure: do not try again
         }
         if (ctx->plain_ms_per_gb > 0) {

@@ -58,6 +58,10 @@ struct Api {
   decltype(&b3w_comm_create) comm_create;
   decltype(&b3w_comm_destroy) comm_destroy;
   decltype(&b3w_batch_allgather_public) batch_allgather_public;
+  decltype(&b3w_r1cs_create) r1cs_create;
+  decltype(&b3w_r1cs_info) r1cs_info;
+  decltype(&b3w_r1cs_destroy) r1cs_destroy;
+  decltype(&b3w_batch_r1cs_check) batch_r1cs_check;
   std::string err;
 } api;
 
@@ -82,6 +86,7 @@ bool load_api() {
   SYM(batch_outputs) SYM(batch_fetch) SYM(batch_write_wtns) SYM(batch_verify) SYM(batch_placement) SYM(bodies_trim)
   SYM(chain_create) SYM(chain_destroy) SYM(chain_run_leaves) SYM(chain_run_parents) SYM(chain_info) SYM(chain_outputs)
   SYM(commit_key_create_ex) SYM(commit_key_destroy) SYM(commit_records) SYM(chain_commit_only) SYM(chain_commitments) SYM(batch_commit) SYM(chain_shard) SYM(chain_run_parents_sharded) SYM(comm_unique_id) SYM(comm_create) SYM(comm_destroy) SYM(batch_allgather_public)
+  SYM(r1cs_create) SYM(r1cs_info) SYM(r1cs_destroy) SYM(batch_r1cs_check)
 #undef SYM
   api.so = so;
   return true;
@@ -95,6 +100,7 @@ struct Handle {
   b3w_comm *comm = nullptr;
   int32_t rank = 0, nranks = 1;
   b3w_commit_key *key = nullptr;
+  b3w_r1cs *r1cs = nullptr;
 };
 
 #define NAPI_OK(call)                                                   \
@@ -139,6 +145,7 @@ Handle *get_handle(napi_env env, napi_value v) {
 void finalize_handle(napi_env, void *data, void *) {
   Handle *h = (Handle *)data;
   if (h->key) api.commit_key_destroy(h->key);
+  if (h->r1cs) api.r1cs_destroy(h->r1cs);
   if (h->comm) api.comm_destroy(h->comm);
   if (h->batch) api.batch_free(h->batch);
   if (h->ctx) api.destroy(h->ctx);
@@ -495,6 +502,48 @@ napi_value BatchCommit(napi_env env, napi_callback_info info) {
   return o;
 }
 
+// r1csLoad(handle, image: Uint8Array of an iden3 .r1cs file) -> { nConstraints, nWires, nTerms }: the constraint system
+// batchR1csCheck evaluates (b3w_r1cs_create)
+napi_value R1csLoad(napi_env env, napi_callback_info info) {
+  size_t argc = 2; napi_value argv[2];
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+  Handle *h = get_handle(env, argv[0]);
+  if (!h) return nullptr;
+  napi_typedarray_type t; napi_value ab; size_t off, len; void *p;
+  NAPI_OK(napi_get_typedarray_info(env, argv[1], &t, &len, &p, &ab, &off));
+  if (t != napi_uint8_array) { napi_throw_type_error(env, nullptr, "image: Uint8Array / Buffer with the bytes of a .r1cs file"); return nullptr; }
+  if (h->r1cs) { api.r1cs_destroy(h->r1cs); h->r1cs = nullptr; }
+  const int32_t rc = api.r1cs_create(h->ctx, (const uint8_t *)p, len, &h->r1cs);
+  if (rc != B3W_OK) return throw_status(env, h, rc, "b3w_r1cs_create failed");
+  uint32_t m = 0, nw = 0; uint64_t nt = 0;
+  api.r1cs_info(h->r1cs, &m, &nw, &nt, nullptr, nullptr, nullptr);
+  napi_value o, v;
+  NAPI_OK(napi_create_object(env, &o));
+  napi_create_uint32(env, m, &v); napi_set_named_property(env, o, "nConstraints", v);
+  napi_create_uint32(env, nw, &v); napi_set_named_property(env, o, "nWires", v);
+  napi_create_double(env, (double)nt, &v); napi_set_named_property(env, o, "nTerms", v);
+  return o;
+}
+
+// batchR1csCheck(handle[, generation]) -> { violations: Uint32Array(n), first: Uint32Array(n) }: A z * B z - C z = 0 for every
+// constraint and every witness of the last batchRun, on the device (0 violations = a valid witness; first = 0xFFFFFFFF then)
+napi_value BatchR1csCheck(napi_env env, napi_callback_info info) {
+  size_t argc = 2; napi_value argv[2];
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+  Handle *h = get_handle(env, argv[0]);
+  if (!h || !fresh_result(env, h, argc, argv, 1)) return nullptr;
+  if (!h->batch || !h->r1cs || !h->batch_n) { napi_throw_error(env, nullptr, "batchR1csCheck needs r1csLoad and a batchRun"); return nullptr; }
+  void *pv, *pf; napi_value abv, abf, o, v;
+  NAPI_OK(napi_create_arraybuffer(env, (size_t)h->batch_n * 4, &pv, &abv));
+  NAPI_OK(napi_create_arraybuffer(env, (size_t)h->batch_n * 4, &pf, &abf));
+  const int32_t rc = api.batch_r1cs_check(h->batch, h->r1cs, (uint32_t *)pv, (uint32_t *)pf);
+  if (rc != B3W_OK) return throw_status(env, h, rc, "b3w_batch_r1cs_check failed");
+  NAPI_OK(napi_create_object(env, &o));
+  napi_create_typedarray(env, napi_uint32_array, h->batch_n, abv, 0, &v); napi_set_named_property(env, o, "violations", v);
+  napi_create_typedarray(env, napi_uint32_array, h->batch_n, abf, 0, &v); napi_set_named_property(env, o, "first", v);
+  return o;
+}
+
 // commitRecords(handle, records: Uint32Array(n * inputSize)) -> { points: Uint8Array(n * 64), publicOutputs: Uint32Array(n * 16 | 15),
 // status: Int32Array(n) }: the commitments of the witnesses of these records, without the witnesses (b3w_commit_records)
 napi_value CommitRecords(napi_env env, napi_callback_info info) {
@@ -595,6 +644,8 @@ napi_value Init(napi_env env, napi_value exports) {
       {"chainFold", nullptr, ChainFold, nullptr, nullptr, nullptr, napi_default, nullptr},
       {"commitKey", nullptr, CommitKey, nullptr, nullptr, nullptr, napi_default, nullptr},
       {"batchCommit", nullptr, BatchCommit, nullptr, nullptr, nullptr, napi_default, nullptr},
+      {"r1csLoad", nullptr, R1csLoad, nullptr, nullptr, nullptr, napi_default, nullptr},
+      {"batchR1csCheck", nullptr, BatchR1csCheck, nullptr, nullptr, nullptr, napi_default, nullptr},
       {"commitRecords", nullptr, CommitRecords, nullptr, nullptr, nullptr, napi_default, nullptr},
       {"commUniqueId", nullptr, CommUniqueId, nullptr, nullptr, nullptr, napi_default, nullptr},
       {"commCreate", nullptr, CommCreate, nullptr, nullptr, nullptr, napi_default, nullptr},

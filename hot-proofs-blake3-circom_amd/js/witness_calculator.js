@@ -187,8 +187,22 @@ class WitnessCalculator {
     r.allgatherPublic = () => nat.batchAllgatherPublic(this.instance, g);
     // Pedersen commitments of the batch's witnesses on the device (after wc.setCommitKey): { points, status }
     r.commit = () => nat.batchCommit(this.instance, g);
+    // rank-1 constraint check of every witness of the batch on the device (after wc.loadR1cs): { violations, first }
+    r.checkConstraints = () => nat.batchR1csCheck(this.instance, g);
     r.placement = nat.batchPlacement(this.instance);   // "mixed": the body buffer alternates two classes of HBM
     return r;
+  }
+
+  // ---- extension: the constraint system batch.checkConstraints() evaluates (what circom_tester's expectPass does with a
+  // witness, test/blake3_hash.test.ts:36).  image: the bytes of an iden3 .r1cs file (.gz accepted) over this circuit's field
+  // and witness size; omitted: the system this package derives from the circuit text (blake3_compression only).
+  loadR1cs(image) {
+    if (image === undefined) {
+      if (this.circuit !== "compression") throw new Error("no derived constraint system for " + this.circuit + ": pass the circuit's .r1cs");
+      image = require("fs").readFileSync(path.join(__dirname, "..", "constraints", "blake3_compression.r1cs.gz"));
+    }
+    if (image[0] === 0x1f && image[1] === 0x8b) image = require("zlib").gunzipSync(image);
+    return native().r1csLoad(this.instance, new Uint8Array(image.buffer, image.byteOffset, image.length));
   }
 
   // ---- extension: commitment key for batch.commit().  curve: "bn254_g1" | "pallas" (the group over the --prime vesta circuit's scalar field); generators: Uint8Array with one

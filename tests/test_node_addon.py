@@ -178,6 +178,10 @@ def test_js_surface_errors_and_batch(tmp_path):
                      files: b.writeWtns(process.argv[3], 'js_'),
                      verify: Array.from(b.verify()),
                      file5: crypto.createHash('sha256').update(fs.readFileSync(process.argv[3] + '/js_5.wtns')).digest('hex')};
+        // constraint check of the batch on the device (the derived blake3_compression system), clean and with a tampered input
+        out.r1cs = wc.loadR1cs();
+        const cc = b.checkConstraints();
+        out.cc = [Array.from(cc.violations), Array.from(cc.first)];
         // the calculator owns one device batch: a later run replaces it, and the older result must refuse to act on it
         const b2 = await wc.calculateWitnessBatch(recs.slice(0, 56));
         out.stale = [];
@@ -206,6 +210,8 @@ def test_js_surface_errors_and_batch(tmp_path):
     assert out["batch"]["body3"] == cases[3]["body_sha256"]
     assert out["batch"]["verify"] == [0] * 8
     assert out["batch"]["files"] == 8 and out["batch"]["file5"] == cases[5]["wtns_sha256"]
+    assert out["r1cs"] == {"nConstraints": 24544, "nWires": 24093, "nTerms": 117760}
+    assert out["cc"] == [[0] * 8, [0xFFFFFFFF] * 8]
     assert out["stale"] == ["stale batch result: a later calculateWitnessBatch on this calculator replaced it"] * 4
     assert out["v2"] == [0, 0] and out["wrap"] == "refused" and out["none"] == 0
     assert not [f for f in os.listdir(tmp_path) if f.startswith(("stale_", "wrap_", "none_"))]

@@ -63,12 +63,18 @@ def under_kernels(s, e):
     return tot
 
 
-h2d = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), int(r.get("Bytes", r.get("Size", 0)) or 0)) for r in ctrace
-       if "HOST_TO_DEVICE" in r.get("Direction", "").upper() or "H2D" in r.get("Direction", "").upper()]
-big = [x for x in h2d if x[2] >= 1 << 20]                     # the preimage slices (1 MiB each)
+import re
+h2d = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), int(r["Stream_Id"])) for r in ctrace if "HOST_TO_DEVICE" in r.get("Direction", "")]
+# the preimage slices (1 MiB each) are the copies on the chain's own copy stream: the stream with by far the most H2D copies
+per_stream = {}
+for x in h2d:
+    per_stream[x[2]] = per_stream.get(x[2], 0) + 1
+copy_stream = max(per_stream, key=per_stream.get) if per_stream else None
+big = [x for x in h2d if x[2] == copy_stream]
 by_kernel = {}
 for s, e, name in kiv:
-    key = name.split("(")[0]
+    mt = re.search(r"(b3w_\w+|__amd_rocclr_\w+|at::native::\w+)", name)
+    key = mt.group(1) if mt else name[:40]
     by_kernel[key] = by_kernel.get(key, 0) + (e - s)
 total_k = sum(by_kernel.values())
 doc = {
@@ -81,7 +87,7 @@ doc = {
     "h2d_slice_copies": len(big),
     "h2d_slice_ms": sum(e - s for s, e, _ in big) / 1e6,
     "h2d_slice_ms_under_a_running_kernel": sum(under_kernels(s, e) for s, e, _ in big) / 1e6,
-    "h2d_slice_bytes": sum(b for _, _, b in big),
+    "h2d_slice_bytes": "1 MiB per slice (b3w_chain_run_leaves: CHAIN_SLICE_CHUNKS = 1024 chunks)",
     "marker_ranges": {r.get("Name", r.get("Function", "?")): {"calls": int(r.get("Calls", 0)), "total_ms": float(r.get("TotalDurationNs", 0)) / 1e6}
                       for r in mstats if "b3w:" in r.get("Name", r.get("Function", ""))},
 }
