@@ -316,14 +316,17 @@ class BodyBuffer:
 
 
 R1CS_DIR = os.path.join(PKG_DIR, "constraints")
-BUILTIN_R1CS = {"compression": "blake3_compression.r1cs.gz"}     # derived from the circuit text by tools/gen_r1cs.py
+# derived from the circuit text by tools/gen_r1cs.py (the builds whose simplification — aliases and constants only — can be
+# restated exactly; the O2 nova builds went through circom's linear elimination and have no derived system)
+BUILTIN_R1CS = {"compression": "blake3_compression.r1cs.gz", "nova_bn254_o1": "blake3_nova_bn254_o1.r1cs.gz"}
 
 
 class R1cs:
     """A rank-1 constraint system on the device (b3w_r1cs_create) for on-device satisfaction checks of witness bodies
     — the counterpart of circom_tester's expectPass (test/blake3_hash.test.ts:36) / synthesize_with_vec's constraints
     (rust_fold/src/utils.rs:17-88).  `image`: bytes of an iden3 .r1cs file, or a path to one (.r1cs or .r1cs.gz);
-    None = the system this package derives for the circuit (blake3_compression only: the reference ships no .r1cs)."""
+    None = the system this package derives for the circuit (blake3_compression and the circomkit nova build; the reference
+    ships no .r1cs)."""
 
     def __init__(self, ctx, image=None):
         self.ctx = ctx

@@ -697,8 +697,8 @@ float time_witness_fill(b3w_ctx *ctx, uint8_t *d_buf, uint64_t bytes) {
   if (e == hipSuccess) e = hipEventCreate(&e0);
   if (e == hipSuccess) e = hipEventCreate(&e1);
   int32_t rc = B3W_OK;
-  for (int it = 0; it < 4 && e == hipSuccess && rc == B3W_OK; it++) {
-    if (it == 1) e = hipEventRecord(e0, nullptr);
+  for (int it = 0; it < 8 && e == hipSuccess && rc == B3W_OK; it++) {
+    if (it == 2) e = hipEventRecord(e0, nullptr);
     if (e == hipSuccess) rc = b3w_batch_run_device(ctx, d_recs, n, d_buf, body, nullptr, d_st, nullptr);
   }
   if (e == hipSuccess && rc == B3W_OK) e = hipEventRecord(e1, nullptr);
@@ -712,7 +712,7 @@ float time_witness_fill(b3w_ctx *ctx, uint8_t *d_buf, uint64_t bytes) {
   if (d_st) (void)hipFree(d_st);
   if (e != hipSuccess) (void)hipGetLastError();
   if (e != hipSuccess || rc != B3W_OK || st0 != 0 || ms <= 0) return 0;
-  return ms / 3.0f / (float)((double)n * body / 1e9);
+  return ms / 6.0f / (float)((double)n * body / 1e9);
 }
 }  // namespace
 
@@ -735,18 +735,22 @@ int32_t b3w_bodies_alloc(b3w_ctx *ctx, uint64_t bytes, void **d_ptr, int32_t *pl
       if (mixed && check) {
         if (ctx->plain_ms_per_gb == 0) {
           // the slowest of three distinct hipMalloc buffers: one plain buffer in eight or so straddles a class border
-          // by luck and is as fast as a placed one — that must not become the yardstick
-          void *plain[3] = {nullptr, nullptr, nullptr};
-          const uint64_t pb = std::min<uint64_t>(bytes, 4ull << 30);
+          // by luck and is as fast as a placed one (profiles/r02: a `--placement plain` bench run at 0.87) — that must
+          // not become the yardstick.  Two of them are alive at a time, so that the next one lies elsewhere: 16 GiB at most.
+          void *prev = nullptr;
+          const uint64_t pb = std::min<uint64_t>(bytes, 8ull << 30);
           for (int i = 0; i < 3; i++) {
-            if (hipMalloc(&plain[i], pb) != hipSuccess) { (void)hipGetLastError(); plain[i] = nullptr; break; }
-            ctx->plain_ms_per_gb = std::max(ctx->plain_ms_per_gb, time_witness_fill(ctx, static_cast<uint8_t *>(plain[i]), pb));
+            void *cur = nullptr;
+            if (hipMalloc(&cur, pb) != hipSuccess) { (void)hipGetLastError(); break; }
+            if (prev) (void)hipFree(prev);
+            prev = cur;
+            ctx->plain_ms_per_gb = std::max(ctx->plain_ms_per_gb, time_witness_fill(ctx, static_cast<uint8_t *>(cur), pb));
           }
-          for (int i = 0; i < 3; i++) if (plain[i]) (void)hipFree(plain[i]);
+          if (prev) (void)hipFree(prev);
           if (ctx->plain_ms_per_gb == 0) ctx->plain_ms_per_gb = -1;          // could not measure: do not try again
         }
         if (ctx->plain_ms_per_gb > 0) {
-          const float placed = time_witness_fill(ctx, static_cast<uint8_t *>(*d_ptr), std::min<uint64_t>(bytes, 4ull << 30));
+          const float placed = time_witness_fill(ctx, static_cast<uint8_t *>(*d_ptr), std::min<uint64_t>(bytes, 8ull << 30));
           if (placed > 0 && placed > ctx->plain_ms_per_gb / 1.10f) {
             mixed = 0;
             if (getenv("B3W_PLACE_DEBUG"))

@@ -7,6 +7,7 @@ import struct
 import b3w_testlib as T
 
 BUILTIN = os.path.join(T.PKG_DIR, "constraints", "blake3_compression.r1cs.gz")
+BUILTIN_NOVA_O1 = os.path.join(T.PKG_DIR, "constraints", "blake3_nova_bn254_o1.r1cs.gz")
 
 
 def read_image(path=BUILTIN):

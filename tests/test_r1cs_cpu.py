@@ -68,5 +68,59 @@ def test_generator_reproduces_the_committed_file(tmp_path):
     r = subprocess.run([sys.executable, os.path.join(T.ROOT, "tools", "gen_r1cs.py"), "--out", str(out)], capture_output=True, text=True,
                        timeout=300)
     assert r.returncode == 0, r.stderr[-1500:]
-    assert "69380 signals = the .sym's" in r.stdout and "reference witness satisfies all" in r.stdout
+    assert "69380 signals = the .sym's, ids and slots by the numbering rule = the .sym's" in r.stdout and "reference witness satisfies all" in r.stdout
     assert out.read_bytes() == open(R.BUILTIN, "rb").read()
+
+
+# ---- the circomkit build of blake3_nova (BN254, 24 614 wires): no .sym in the checkout, wires by circom's numbering rule
+@pytest.fixture(scope="module")
+def nova_system():
+    return R.parse(R.read_image(R.BUILTIN_NOVA_O1))
+
+
+def test_nova_o1_header_and_reference_wasm_witnesses(nova_system):
+    s = nova_system
+    assert s["prime"] == T.BN254_R and s["n_wires"] == 24614 == T.NWIT["nova_bn254_o1"]
+    assert (s["n_pub_out"], s["n_pub_in"], s["n_prv_in"]) == (15, 12, 20) and len(s["constraints"]) == 25067
+    used = set()
+    for a, b, c in s["constraints"]:
+        used |= a.keys() | b.keys() | c.keys()
+    assert used == set(range(24614))
+    # two complete witnesses of the reference WASM are held as fixtures (a leaf step and a parent step)
+    for name in ("nova_bn254_o1.config3_0.wtns.gz", "nova_bn254_o1.config3_3.wtns.gz"):
+        z = R.body_to_ints(T.golden_image(name)[76:])
+        assert len(z) == 24614 and R.violated(s, z) == [], name
+
+
+def test_nova_o1_oracle_witnesses_satisfy_it_and_single_slot_changes_do_not(nova_system):
+    g = T.golden("nova_bn254_o1")
+    ok = [c for c in g["cases"] if "error" not in c]
+    picks = ok[:2] + [c for c in ok if c["name"].startswith("directed")][:3] + [c for c in ok if not T.is_canonical_u32("nova_bn254_o1", c["input"])][:2]
+    assert len(picks) >= 5
+    by_wire = R.rows_of_wire(nova_system)
+    rng = random.Random(11)
+    p = nova_system["prime"]
+    for case in picks:
+        rc, body, _ = T.oracle_witness("nova_bn254_o1", T.normalize_input("nova_bn254_o1", case["input"]))
+        assert rc == 0
+        assert T.sha256(body) == case["body_sha256"]                 # the oracle's body is the reference WASM's
+        z = R.body_to_ints(body)
+        assert R.violated(nova_system, z) == [], case["name"]
+        for _ in range(60):
+            s = rng.randrange(24614)
+            old = z[s]
+            z[s] = rng.choice([old ^ 1, (old + 1) % p, rng.randrange(p), 0 if old else 2])
+            if z[s] != old:
+                assert R.violated(nova_system, z, by_wire[s]), (case["name"], s)
+            z[s] = old
+
+
+def test_nova_generator_reproduces_the_committed_file(tmp_path):
+    if not os.path.isdir("/root/reference"):
+        pytest.skip("reference checkout not present (GPU box): the generator runs the reference WASM")
+    out = tmp_path / "n.r1cs.gz"
+    r = subprocess.run([sys.executable, os.path.join(T.ROOT, "tools", "gen_r1cs.py"), "--circuit", "nova_o1", "--out", str(out)], capture_output=True,
+                       text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-1500:]
+    assert "24614 wires = the WASM's witness size" in r.stdout and "reference-WASM witnesses (accepted goldens) satisfy all" in r.stdout
+    assert out.read_bytes() == open(R.BUILTIN_NOVA_O1, "rb").read()

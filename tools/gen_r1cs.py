@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""tools/gen_r1cs.py — derive the rank-1 constraint system of `blake3_compression` (BN254, the circomkit / O1 build)
-from the circuit text and write it as a standard iden3 `.r1cs` file over the witness slots of the committed WASM.
+"""tools/gen_r1cs.py [--circuit compression | nova_o1] — derive the rank-1 constraint system of `blake3_compression`
+(BN254, the circomkit / O1 build) or of the circomkit build of `blake3_nova` (BN254, 24 614 wires) from the circuit text and
+write it as a standard iden3 `.r1cs` file over the witness slots of the committed WASM.
 
 The reference checkout has no `.r1cs` (`.MISSING_LARGE_BLOBS`), but every constraint of the circuit is written out in
   /root/reference/circuits/blake3_common.circom:15-26,42-80,142-203     (Blake3Permute, XOR2, XorWord2, ToBits, Bits33, Bits34)
@@ -20,14 +21,30 @@ and checks the result against the reference before writing anything:
 Nothing here reads this repository's slot tables, kernels or oracle: the constraint system is an INDEPENDENT statement of
 what a valid witness is (the on-device check `b3w_r1cs_check_device` evaluates Az * Bz - Cz with it).
 
+`blake3_nova` has no .sym in the checkout (`.MISSING_LARGE_BLOBS`), so its wires come from circom's numbering RULE instead,
+which this script implements and first proves on blake3_compression, where the .sym exists: inside a template instance the
+outputs, then the inputs, then the intermediate signals get consecutive ids in declaration order, then its sub-components
+follow in alphabetical order (arrays by index), recursively; an alias class keeps its lowest id; witness slots are handed
+out in increasing id order over the classes that are not constants (`rule ids == .sym ids` and `rule slots == .sym slots`
+for all 69 380 signals).  The nova templates are elaborated as the committed WASMs were compiled — WITHOUT the two
+Num2Bits(8) range checks of circuits/blake3_nova.circom:25-29 (they are in no committed WASM) — with
+circomlib 2.0.5's IsZero / IsEqual / Num2Bits / LessThan / GreaterEqThan / NOT / AND / OR (yarn.lock:1243; not vendored:
+restated from the published library).  Checks for nova: exactly 24 614 wires (the WASM's getWitnessSize), and every witness
+the reference WASM produces for the accepted golden inputs (tests/golden/nova_bn254_o1.json, non-canonical ones included;
+run here through tools/wasm_oracle.js) satisfies every constraint.
+
 Build container only (it reads /root/reference).  Output (committed): hot-proofs-blake3-circom_amd/constraints/
-blake3_compression.r1cs.gz — iden3 r1cs v1: header, constraints (A, B, C as (wire, coefficient) lists; A*B - C = 0),
-wire-to-label map (labels = .sym signal ids).
+blake3_compression.r1cs.gz, blake3_nova_bn254_o1.r1cs.gz — iden3 r1cs v1: header, constraints (A, B, C as (wire,
+coefficient) lists; A*B - C = 0), wire-to-label map (labels = circom signal ids).
 """
 import gzip
+import json
 import os
+import re
 import struct
+import subprocess
 import sys
+import tempfile
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF = os.environ.get("B3W_REFERENCE", "/root/reference")
@@ -40,15 +57,26 @@ P = 2188824287183927522224640574525727508854836440041603434369820418657580849561
 # ------------------------------------------------------------------ a very small circom: signals, linear combinations
 class Circuit:
     def __init__(self):
-        self.names = []            # signal id -> hierarchical name (circom numbers them differently; names are the key)
-        self.parent = []           # union-find over signals related by `a <== b`
-        self.const = {}            # class root -> constant value (signal <== constant)
+        self.names = []            # signal -> hierarchical name
+        self.kinds = []            # 0 output, 1 input, 2 intermediate (of its template instance)
+        self.parent = []           # union-find over signals the build's simplification merges
+        self.const = {}            # class root -> constant value
         self.cons = []             # (A, B, C) with A*B - C = 0; each an LC = {signal or None (the constant 1): coefficient}
 
-    def signal(self, name):
+    def signal(self, name, kind):
         self.names.append(name)
+        self.kinds.append(kind)
         self.parent.append(len(self.parent))
         return len(self.names) - 1
+
+    def out(self, name):
+        return self.signal(name, 0)
+
+    def inp(self, name):
+        return self.signal(name, 1)
+
+    def mid(self, name):
+        return self.signal(name, 2)
 
     def find(self, s):
         while self.parent[s] != s:
@@ -57,25 +85,18 @@ class Circuit:
         return s
 
     def alias(self, a, b):
-        """a <== b with b a single signal: no constraint survives, the two are one wire"""
+        """a <== b with b a single signal: the constraint a - b = 0, which the build's simplification turns into "one wire"
+        (see simplify) — recorded as a constraint like any other so that the classification sees it"""
+        self.linear(sub(S(a), S(b)))
+
+    def union(self, a, b):
         ra, rb = self.find(a), self.find(b)
-        if ra == rb:
-            return
-        assert not (ra in self.const and rb in self.const)
-        if ra in self.const:
-            ra, rb = rb, ra
-        self.parent[ra] = rb       # constants stay roots
+        if ra != rb:
+            self.parent[ra] = rb
 
     def assign(self, sig, lc):
         """sig <== lc for a linear right-hand side"""
-        lc = {k: v % P for k, v in lc.items() if v % P}
-        keys = list(lc)
-        if keys == [None] or not keys:
-            self.const[self.find(sig)] = lc.get(None, 0)
-        elif len(keys) == 1 and lc[keys[0]] == 1:
-            self.alias(sig, keys[0])
-        else:
-            self.linear(sub(lc, {sig: 1}))
+        self.linear(sub(lc, {sig: 1}))
 
     def linear(self, lc):
         """lc === 0"""
@@ -84,6 +105,86 @@ class Circuit:
     def quadratic(self, a, b, c):
         """a * b === c"""
         self.cons.append((dict(a), dict(b), dict(c)))
+
+    def resolve(self, lc):
+        """lc over class representatives, constants folded into the None term"""
+        out = {}
+        for k, v in lc.items():
+            if k is not None:
+                r = self.find(k)
+                k, v = (None, v * self.const[r]) if r in self.const else (r, v)
+            out[k] = (out.get(k, 0) + v) % P
+        return {k: v for k, v in out.items() if v}
+
+    def simplify(self, public=()):
+        """The two simplifications of the circomkit (O1) build.  The constraints AS WRITTEN are classified once: `signal =
+        signal` (two signals, coefficients k and -k, no constant) merges the two into one wire; `signal = constant` (one
+        signal) makes it a constant; both constraints disappear.  Everything else stays — linear constraints included,
+        also those that shrink to one or two signals only after the substitutions (exceed_depth.lt.n2b.out[8] = 1 stays a
+        wire with its constraint).  `public` = the main component's outputs and public inputs: they always keep their own
+        wire, so an equality between two of them stays a constraint (n_blocks_out = n_blocks)."""
+        public = set(public)
+        eqs, consts, keep = [], [], []
+        for a, b, cc in self.cons:
+            if a or b:
+                keep.append((a, b, cc))
+                continue
+            lc = {k: v % P for k, v in cc.items() if v % P}
+            sigs = [k for k in lc if k is not None]
+            if len(sigs) == 2 and None not in lc and (lc[sigs[0]] + lc[sigs[1]]) % P == 0:
+                eqs.append((sigs[0], sigs[1], (a, b, cc)))
+            elif len(sigs) == 1:
+                consts.append((sigs[0], (-lc.get(None, 0)) * pow(lc[sigs[0]], -1, P) % P))
+            else:
+                keep.append((a, b, cc))
+        has_public = {}
+        for s in public:
+            has_public[s] = True
+        for x, y, con in eqs:
+            rx, ry = self.find(x), self.find(y)
+            if rx == ry:
+                continue
+            if has_public.get(rx) and has_public.get(ry):
+                keep.append(con)                              # two public wires: the equality stays a constraint
+                continue
+            self.union(x, y)
+            if has_public.get(rx) or has_public.get(ry):
+                has_public[self.find(x)] = True
+        for s0, val in consts:
+            r = self.find(s0)
+            assert not has_public.get(r), "a public signal assigned a constant: not handled"
+            assert self.const.get(r, val) == val
+            self.const[r] = val
+        self.cons = keep
+
+    # ---- circom's signal numbering
+    def number(self):
+        """{signal: id}: per template instance outputs, inputs, intermediates in declaration order, then the
+        sub-components in alphabetical order (component arrays by index), recursively; id 0 is the constant one."""
+        tree = {}
+        for s, name in enumerate(self.names):
+            comp, _ = name.rsplit(".", 1)
+            node = tree
+            for part in comp.split("."):
+                node = node.setdefault(("c", part), {})
+            node.setdefault(("s",), []).append(s)
+        ids, nxt = {}, [1]
+
+        def order_key(part):
+            mt = re.match(r"^(\w+?)((?:\[\d+\])*)$", part)
+            return (mt.group(1), [int(x) for x in re.findall(r"\[(\d+)\]", mt.group(2))])
+
+        def walk(node):
+            own = node.get(("s",), [])
+            for kind in (0, 1, 2):
+                for s in own:                                 # creation order = declaration order within a kind
+                    if self.kinds[s] == kind:
+                        ids[s] = nxt[0]
+                        nxt[0] += 1
+            for key in sorted((k for k in node if k[0] == "c"), key=lambda k: order_key(k[1])):
+                walk(node[key])
+        walk(tree)
+        return ids
 
 
 def add(*lcs):
@@ -115,10 +216,11 @@ def K(v):
 
 
 # ------------------------------------------------------------------ templates (blake3_common.circom)
+# Signals are created in the source's declaration order: the numbering rule depends on it.
 def ToBits(c, pfx, n=32):
     """blake3_common.circom:142-154"""
-    inp = c.signal(f"{pfx}.inp")
-    out = [c.signal(f"{pfx}.out[{i}]") for i in range(n)]
+    inp = c.inp(f"{pfx}.inp")
+    out = [c.out(f"{pfx}.out[{i}]") for i in range(n)]
     total = {}
     for i in range(n):
         c.quadratic(S(out[i]), sub(K(1), S(out[i])), {})          # out[i] * (1 - out[i]) === 0      (:150)
@@ -129,10 +231,10 @@ def ToBits(c, pfx, n=32):
 
 def BitsN(c, pfx, carries):
     """Bits33 (carries = 1, blake3_common.circom:160-178) and Bits34 (carries = 2, :183-203)"""
-    inp = c.signal(f"{pfx}.inp")
-    out_bits = [c.signal(f"{pfx}.out_bits[{i}]") for i in range(32)]
-    out_word = c.signal(f"{pfx}.out_word")
-    cs = [c.signal(f"{pfx}.{nm}") for nm in ("u", "v")[:carries]]
+    inp = c.inp(f"{pfx}.inp")
+    out_bits = [c.out(f"{pfx}.out_bits[{i}]") for i in range(32)]
+    out_word = c.out(f"{pfx}.out_word")
+    cs = [c.mid(f"{pfx}.{nm}") for nm in ("u", "v")[:carries]]
     total = {}
     for i in range(32):
         c.quadratic(S(out_bits[i]), sub(K(1), S(out_bits[i])), {})
@@ -149,7 +251,7 @@ def BitsN(c, pfx, carries):
 
 def XOR2(c, pfx):
     """blake3_common.circom:42-50"""
-    x, y, out = c.signal(f"{pfx}.x"), c.signal(f"{pfx}.y"), c.signal(f"{pfx}.out")
+    x, y, out = c.inp(f"{pfx}.x"), c.inp(f"{pfx}.y"), c.out(f"{pfx}.out")
     # out <== x + y - 2*x*y   ->   (2x) * y = x + y - out
     c.quadratic(scale(S(x), 2), S(y), sub(add(S(x), S(y)), S(out)))
     return dict(x=x, y=y, out=out)
@@ -157,9 +259,9 @@ def XOR2(c, pfx):
 
 def XorWord2(c, pfx, n=32):
     """blake3_common.circom:55-80"""
-    x, y = c.signal(f"{pfx}.x"), c.signal(f"{pfx}.y")
-    out_bits = [c.signal(f"{pfx}.out_bits[{i}]") for i in range(n)]
-    out_word = c.signal(f"{pfx}.out_word")
+    x, y = c.inp(f"{pfx}.x"), c.inp(f"{pfx}.y")
+    out_bits = [c.mid(f"{pfx}.out_bits[{i}]") for i in range(n)]
+    out_word = c.out(f"{pfx}.out_word")
     tb_x, tb_y = ToBits(c, f"{pfx}.tb_x", n), ToBits(c, f"{pfx}.tb_y", n)
     c.alias(tb_x["inp"], x)
     c.alias(tb_y["inp"], y)
@@ -177,30 +279,32 @@ def XorWord2(c, pfx, n=32):
 def Blake3Permute(c, pfx):
     """blake3_common.circom:15-26"""
     sigma = [2, 6, 3, 10, 7, 0, 4, 13, 1, 11, 12, 5, 9, 14, 15, 8]
-    inp = [c.signal(f"{pfx}.inp[{j}]") for j in range(16)]
-    out = [c.signal(f"{pfx}.out[{j}]") for j in range(16)]
+    inp = [c.inp(f"{pfx}.inp[{j}]") for j in range(16)]
+    out = [c.out(f"{pfx}.out[{j}]") for j in range(16)]
     for j in range(16):
         c.alias(out[j], inp[sigma[j]])
     return dict(inp=inp, out=out)
 
 
 # ------------------------------------------------------------------ templates (blake3_compression.circom)
+IV_WORDS = [0x6A09E667, 0xBB67AE85, 0x3C6EF372, 0xA54FF53A, 0x510E527F, 0x9B05688C, 0x1F83D9AB, 0x5BE0CD19]
+
+
 def IV(c, pfx):
     """:17-24"""
-    iv = [0x6A09E667, 0xBB67AE85, 0x3C6EF372, 0xA54FF53A, 0x510E527F, 0x9B05688C, 0x1F83D9AB, 0x5BE0CD19]
-    out = [c.signal(f"{pfx}.out[{j}]") for j in range(8)]
+    out = [c.out(f"{pfx}.out[{j}]") for j in range(8)]
     for j in range(8):
-        c.assign(out[j], K(iv[j]))
+        c.assign(out[j], K(IV_WORDS[j]))
     return dict(out=out)
 
 
 def RotXorBits(c, pfx, R):
     """:29-47"""
-    inp1 = [c.signal(f"{pfx}.inp1_bits[{i}]") for i in range(32)]
-    inp2 = [c.signal(f"{pfx}.inp2_bits[{i}]") for i in range(32)]
-    out_bits = [c.signal(f"{pfx}.out_bits[{i}]") for i in range(32)]
-    out_word = c.signal(f"{pfx}.out_word")
-    aux = [c.signal(f"{pfx}.aux[{i}]") for i in range(32)]
+    inp1 = [c.inp(f"{pfx}.inp1_bits[{i}]") for i in range(32)]
+    inp2 = [c.inp(f"{pfx}.inp2_bits[{i}]") for i in range(32)]
+    out_bits = [c.out(f"{pfx}.out_bits[{i}]") for i in range(32)]
+    out_word = c.out(f"{pfx}.out_word")
+    aux = [c.mid(f"{pfx}.aux[{i}]") for i in range(32)]
     for i in range(32):
         # aux[i] <== inp1[i] + inp2[i] - 2 * inp1[i] * inp2[i]
         c.quadratic(scale(S(inp1[i]), 2), S(inp2[i]), sub(add(S(inp1[i]), S(inp2[i])), S(aux[i])))
@@ -214,10 +318,10 @@ def RotXorBits(c, pfx, R):
 
 def RotXorWordBits(c, pfx, R):
     """:53-67"""
-    inp1_word = c.signal(f"{pfx}.inp1_word")
-    inp2_bits = [c.signal(f"{pfx}.inp2_bits[{i}]") for i in range(32)]
-    out_bits = [c.signal(f"{pfx}.out_bits[{i}]") for i in range(32)]
-    out_word = c.signal(f"{pfx}.out_word")
+    inp1_word = c.inp(f"{pfx}.inp1_word")
+    inp2_bits = [c.inp(f"{pfx}.inp2_bits[{i}]") for i in range(32)]
+    out_bits = [c.out(f"{pfx}.out_bits[{i}]") for i in range(32)]
+    out_word = c.out(f"{pfx}.out_word")
     tb = ToBits(c, f"{pfx}.tb", 32)
     rx = RotXorBits(c, f"{pfx}.rx", R)
     c.alias(tb["inp"], inp1_word)
@@ -231,9 +335,9 @@ def RotXorWordBits(c, pfx, R):
 
 def HalfFunG(c, pfx, a, b, cc, d, R1, R2):
     """:72-100"""
-    v = [c.signal(f"{pfx}.v[{i}]") for i in range(16)]
-    xy = c.signal(f"{pfx}.xy")
-    out = [c.signal(f"{pfx}.out[{i}]") for i in range(16)]
+    v = [c.inp(f"{pfx}.v[{i}]") for i in range(16)]
+    xy = c.inp(f"{pfx}.xy")
+    out = [c.out(f"{pfx}.out[{i}]") for i in range(16)]
     for i in range(16):
         if i not in (a, b, cc, d):
             c.alias(out[i], v[i])
@@ -258,9 +362,9 @@ def HalfFunG(c, pfx, a, b, cc, d, R1, R2):
 
 def MixFunG(c, pfx, a, b, cc, d):
     """:106-123"""
-    inp = [c.signal(f"{pfx}.inp[{i}]") for i in range(16)]
-    out = [c.signal(f"{pfx}.out[{i}]") for i in range(16)]
-    x, y = c.signal(f"{pfx}.x"), c.signal(f"{pfx}.y")
+    inp = [c.inp(f"{pfx}.inp[{i}]") for i in range(16)]
+    out = [c.out(f"{pfx}.out[{i}]") for i in range(16)]
+    x, y = c.inp(f"{pfx}.x"), c.inp(f"{pfx}.y")
     h1 = HalfFunG(c, f"{pfx}.half1", a, b, cc, d, 16, 12)
     h2 = HalfFunG(c, f"{pfx}.half2", a, b, cc, d, 8, 7)
     for i in range(16):
@@ -276,10 +380,10 @@ def MixFunG(c, pfx, a, b, cc, d):
 
 def SingleRound(c, pfx):
     """:128-161"""
-    inp = [c.signal(f"{pfx}.inp[{i}]") for i in range(16)]
-    msg = [c.signal(f"{pfx}.msg[{i}]") for i in range(16)]
-    out = [c.signal(f"{pfx}.out[{i}]") for i in range(16)]
-    vs = [[c.signal(f"{pfx}.vs[{k}][{i}]") for i in range(16)] for k in range(9)]
+    inp = [c.inp(f"{pfx}.inp[{i}]") for i in range(16)]
+    msg = [c.inp(f"{pfx}.msg[{i}]") for i in range(16)]
+    out = [c.out(f"{pfx}.out[{i}]") for i in range(16)]
+    vs = [[c.mid(f"{pfx}.vs[{k}][{i}]") for i in range(16)] for k in range(9)]
     for i in range(16):
         c.alias(vs[0][i], inp[i])
     idx = [(0, 4, 8, 12), (1, 5, 9, 13), (2, 6, 10, 14), (3, 7, 11, 15), (0, 5, 10, 15), (1, 6, 11, 12), (2, 7, 8, 13), (3, 4, 9, 14)]
@@ -300,12 +404,12 @@ def SingleRound(c, pfx):
 
 def Blake3Compression(c, pfx="main"):
     """:171-228"""
-    h = [c.signal(f"{pfx}.h[{i}]") for i in range(8)]
-    m = [c.signal(f"{pfx}.m[{i}]") for i in range(16)]
-    t = [c.signal(f"{pfx}.t[{i}]") for i in range(2)]
-    b, d = c.signal(f"{pfx}.b"), c.signal(f"{pfx}.d")
-    out = [c.signal(f"{pfx}.out[{i}]") for i in range(16)]
-    init = [c.signal(f"{pfx}.init[{i}]") for i in range(16)]
+    h = [c.inp(f"{pfx}.h[{i}]") for i in range(8)]
+    m = [c.inp(f"{pfx}.m[{i}]") for i in range(16)]
+    t = [c.inp(f"{pfx}.t[{i}]") for i in range(2)]
+    b, d = c.inp(f"{pfx}.b"), c.inp(f"{pfx}.d")
+    out = [c.out(f"{pfx}.out[{i}]") for i in range(16)]
+    init = [c.mid(f"{pfx}.init[{i}]") for i in range(16)]
     iv = IV(c, f"{pfx}.iv")
     for i in range(8):
         c.alias(init[i], h[i])
@@ -336,7 +440,240 @@ def Blake3Compression(c, pfx="main"):
     return dict(h=h, m=m, t=t, b=b, d=d, out=out)
 
 
-# ------------------------------------------------------------------ against the reference's symbol table and witness
+# ------------------------------------------------------------------ circomlib 2.0.5 (comparators, gates, bitify)
+def Num2Bits(c, pfx, n):
+    """bitify.circom Num2Bits(n): out[i] <-- (in >> i) & 1; out[i] * (out[i] - 1) === 0; sum 2^i out[i] === in"""
+    inp = c.inp(f"{pfx}.in")
+    out = [c.out(f"{pfx}.out[{i}]") for i in range(n)]
+    lc1 = {}
+    for i in range(n):
+        c.quadratic(S(out[i]), sub(S(out[i]), K(1)), {})
+        lc1 = add(lc1, scale(S(out[i]), 1 << i))
+    c.linear(sub(lc1, S(inp)))
+    return {"in": inp, "out": out}
+
+
+def IsZero(c, pfx):
+    """comparators.circom IsZero: inv <-- in != 0 ? 1/in : 0; out <== -in*inv + 1; in*out === 0"""
+    inp, out, inv = c.inp(f"{pfx}.in"), c.out(f"{pfx}.out"), c.mid(f"{pfx}.inv")
+    c.quadratic(neg(S(inp)), S(inv), sub(S(out), K(1)))           # (-in) * inv = out - 1
+    c.quadratic(S(inp), S(out), {})
+    return {"in": inp, "out": out}
+
+
+def IsEqual(c, pfx):
+    """comparators.circom IsEqual: isz.in <== in[1] - in[0]; out <== isz.out"""
+    inp = [c.inp(f"{pfx}.in[{i}]") for i in range(2)]
+    out = c.out(f"{pfx}.out")
+    isz = IsZero(c, f"{pfx}.isz")
+    c.assign(isz["in"], sub(S(inp[1]), S(inp[0])))
+    c.alias(out, isz["out"])
+    return {"in": inp, "out": out}
+
+
+def LessThan(c, pfx, n):
+    """comparators.circom LessThan(n): n2b = Num2Bits(n+1); n2b.in <== in[0] + (1<<n) - in[1]; out <== 1 - n2b.out[n]"""
+    inp = [c.inp(f"{pfx}.in[{i}]") for i in range(2)]
+    out = c.out(f"{pfx}.out")
+    n2b = Num2Bits(c, f"{pfx}.n2b", n + 1)
+    c.assign(n2b["in"], sub(add(S(inp[0]), K(1 << n)), S(inp[1])))
+    c.assign(out, sub(K(1), S(n2b["out"][n])))
+    return {"in": inp, "out": out}
+
+
+def GreaterEqThan(c, pfx, n):
+    """comparators.circom GreaterEqThan(n): lt = LessThan(n); lt.in[0] <== in[1]; lt.in[1] <== in[0] + 1; out <== lt.out"""
+    inp = [c.inp(f"{pfx}.in[{i}]") for i in range(2)]
+    out = c.out(f"{pfx}.out")
+    lt = LessThan(c, f"{pfx}.lt", n)
+    c.alias(lt["in"][0], inp[1])
+    c.assign(lt["in"][1], add(S(inp[0]), K(1)))
+    c.alias(out, lt["out"])
+    return {"in": inp, "out": out}
+
+
+def NOT(c, pfx):
+    """gates.circom NOT: out <== 1 + in - 2*in"""
+    inp, out = c.inp(f"{pfx}.in"), c.out(f"{pfx}.out")
+    c.assign(out, sub(K(1), S(inp)))
+    return {"in": inp, "out": out}
+
+
+def AND(c, pfx):
+    """gates.circom AND: out <== a*b"""
+    a, b, out = c.inp(f"{pfx}.a"), c.inp(f"{pfx}.b"), c.out(f"{pfx}.out")
+    c.quadratic(S(a), S(b), S(out))
+    return dict(a=a, b=b, out=out)
+
+
+def OR(c, pfx):
+    """gates.circom OR: out <== a + b - a*b"""
+    a, b, out = c.inp(f"{pfx}.a"), c.inp(f"{pfx}.b"), c.out(f"{pfx}.out")
+    c.quadratic(S(a), S(b), sub(add(S(a), S(b)), S(out)))
+    return dict(a=a, b=b, out=out)
+
+
+# ------------------------------------------------------------------ templates (blake3_nova.circom), as the WASMs were compiled
+def CheckDepth(c, pfx):
+    """Blake3NovaTreePath_CheckDepth :13-45 WITHOUT the Num2Bits(8) checks of :25-29 (absent from every committed WASM)"""
+    depth, leaf_depth = c.inp(f"{pfx}.depth"), c.inp(f"{pfx}.leaf_depth")
+    is_root, is_parent = c.out(f"{pfx}.is_root"), c.out(f"{pfx}.is_parent")
+    check_root = IsEqual(c, f"{pfx}.check_root")
+    c.alias(check_root["in"][0], depth)
+    c.assign(check_root["in"][1], K(0))
+    c.alias(is_root, check_root["out"])
+    check_parent = LessThan(c, f"{pfx}.check_parent", 8)
+    c.alias(check_parent["in"][0], depth)
+    c.assign(check_parent["in"][1], sub(S(leaf_depth), K(1)))
+    c.alias(is_parent, check_parent["out"])
+    exceed = GreaterEqThan(c, f"{pfx}.exceed_depth", 8)
+    c.alias(exceed["in"][0], depth)
+    c.alias(exceed["in"][1], leaf_depth)
+    c.linear(S(exceed["out"]))                                    # exceed_depth.out === 0
+    return dict(depth=depth, leaf_depth=leaf_depth, is_root=is_root, is_parent=is_parent)
+
+
+def GetDownLeftPath(c, pfx):
+    """Blake3GetDownLeftPath :47-84"""
+    depth, leaf_idx = c.inp(f"{pfx}.depth"), c.inp(f"{pfx}.leaf_idx")
+    is_parent, total_depth = c.inp(f"{pfx}.is_parent"), c.inp(f"{pfx}.total_depth")
+    out = c.out(f"{pfx}.out")
+    n2b = Num2Bits(c, f"{pfx}.n2b", 65)
+    c.alias(n2b["in"], leaf_idx)
+    bit_at_depth = [c.mid(f"{pfx}.bit_at_depth[{i}]") for i in range(65)]
+    for i in range(64):
+        eq = IsEqual(c, f"{pfx}.eqs[{i}]")
+        c.alias(eq["in"][0], depth)
+        c.assign(eq["in"][1], sub(S(total_depth), K(i + 2)))
+        # bit_at_depth[i] <== bit_at_depth[i-1] + (1 - n2b.out[i]) * eqs[i].out
+        prev = S(bit_at_depth[i - 1]) if i else {}
+        c.quadratic(sub(K(1), S(n2b["out"][i])), S(eq["out"]), sub(S(bit_at_depth[i]), prev))
+    # out <== 1 * (1 - is_parent) + 1 * is_parent * bit_at_depth[63]
+    c.quadratic(S(is_parent), S(bit_at_depth[63]), sub(add(S(out), S(is_parent)), K(1)))
+    c.quadratic(S(out), sub(K(1), S(out)), {})
+    return dict(depth=depth, leaf_idx=leaf_idx, is_parent=is_parent, total_depth=total_depth, out=out)
+
+
+def GetFinal_m(c, pfx):
+    """Blake3GetFinal_m :86-120"""
+    h = [c.inp(f"{pfx}.h[{i}]") for i in range(8)]
+    m = [c.inp(f"{pfx}.m[{i}]") for i in range(16)]
+    is_parent, depth = c.inp(f"{pfx}.is_parent"), c.inp(f"{pfx}.depth")
+    total_depth, chunk_idx = c.inp(f"{pfx}.total_depth"), c.inp(f"{pfx}.chunk_idx")
+    out_m = [c.out(f"{pfx}.out_m[{i}]") for i in range(16)]
+    dlp = GetDownLeftPath(c, f"{pfx}.down_left_path")
+    c.alias(dlp["depth"], depth)
+    c.alias(dlp["leaf_idx"], chunk_idx)
+    c.alias(dlp["is_parent"], is_parent)
+    c.alias(dlp["total_depth"], total_depth)
+    m_is_parent = [c.mid(f"{pfx}.m_is_parent[{i}]") for i in range(16)]
+    tmp_down = [c.mid(f"{pfx}.tmp_down[{i}]") for i in range(16)]
+    tmp_is_par = [c.mid(f"{pfx}.tmp_is_par[{i}]") for i in range(16)]
+    dl, ndl = S(dlp["out"]), sub(K(1), S(dlp["out"]))
+    for i in range(16):
+        if i < 8:
+            c.quadratic(S(h[i]), dl, S(tmp_down[i]))
+            c.quadratic(S(m[i]), ndl, sub(S(m_is_parent[i]), S(tmp_down[i])))
+        else:
+            c.quadratic(S(h[i - 8]), ndl, S(tmp_down[i]))
+            c.quadratic(S(m[i - 8]), dl, sub(S(m_is_parent[i]), S(tmp_down[i])))
+        c.quadratic(S(m_is_parent[i]), S(is_parent), S(tmp_is_par[i]))
+        c.quadratic(S(m[i]), sub(K(1), S(is_parent)), sub(S(out_m[i]), S(tmp_is_par[i])))
+    return dict(h=h, m=m, is_parent=is_parent, depth=depth, total_depth=total_depth, chunk_idx=chunk_idx, out_m=out_m)
+
+
+def GetFlag(c, pfx, D_FLAGS):
+    """Blake3GetFlag :122-167"""
+    is_parent, is_root = c.inp(f"{pfx}.is_parent"), c.inp(f"{pfx}.is_root")
+    block_count, n_blocks = c.inp(f"{pfx}.block_count"), c.inp(f"{pfx}.n_blocks")
+    out, is_last_block = c.out(f"{pfx}.out"), c.out(f"{pfx}.is_last_block")
+    use_root_flag = c.mid(f"{pfx}.use_root_flag")
+    not_root, not_parent = NOT(c, f"{pfx}.not_root"), NOT(c, f"{pfx}.not_parent")
+    c.alias(not_root["in"], is_root)
+    c.alias(not_parent["in"], is_parent)
+    cbc = [IsEqual(c, f"{pfx}.check_block_counts[{i}]") for i in range(2)]
+    c.alias(cbc[0]["in"][0], block_count)
+    c.assign(cbc[0]["in"][1], K(0))
+    c.alias(cbc[1]["in"][0], block_count)
+    c.assign(cbc[1]["in"][1], sub(S(n_blocks), K(1)))
+    c.quadratic(S(cbc[1]["out"]), S(not_parent["out"]), S(is_last_block))
+    first, last = AND(c, f"{pfx}.first_block_flag_set"), AND(c, f"{pfx}.last_block_flag_set")
+    c.alias(first["a"], cbc[0]["out"]); c.alias(first["b"], not_parent["out"])
+    c.alias(last["a"], cbc[1]["out"]); c.alias(last["b"], not_parent["out"])
+    urt = OR(c, f"{pfx}.use_root_flag_tmp")
+    c.alias(urt["a"], is_parent); c.alias(urt["b"], cbc[1]["out"])
+    c.quadratic(S(urt["out"]), S(is_root), S(use_root_flag))
+    c.assign(out, add(K(D_FLAGS), S(first["out"]), scale(S(last["out"]), 2), scale(S(use_root_flag), 8), scale(S(is_parent), 4)))
+    return dict(is_parent=is_parent, is_root=is_root, block_count=block_count, n_blocks=n_blocks, out=out, is_last_block=is_last_block)
+
+
+def Blake3Nova(c, pfx="main", D_FLAGS=0):
+    """Blake3Nova(0) :169-267"""
+    n_blocks, block_count = c.inp(f"{pfx}.n_blocks"), c.inp(f"{pfx}.block_count")
+    h = [c.inp(f"{pfx}.h[{i}]") for i in range(8)]
+    cil, cih = c.inp(f"{pfx}.chunk_idx_low"), c.inp(f"{pfx}.chunk_idx_high")
+    leaf_depth, total_depth, depth = c.inp(f"{pfx}.leaf_depth"), c.inp(f"{pfx}.total_depth"), c.inp(f"{pfx}.depth")
+    m = [c.inp(f"{pfx}.m[{i}]") for i in range(16)]
+    b = c.inp(f"{pfx}.b")
+    n_blocks_out, block_count_out = c.out(f"{pfx}.n_blocks_out"), c.out(f"{pfx}.block_count_out")
+    h_out = [c.out(f"{pfx}.h_out[{i}]") for i in range(8)]
+    total_depth_out, depth_out = c.out(f"{pfx}.total_depth_out"), c.out(f"{pfx}.depth_out")
+    cil_out, cih_out = c.out(f"{pfx}.chunk_idx_low_out"), c.out(f"{pfx}.chunk_idx_high_out")
+    leaf_depth_out = c.out(f"{pfx}.leaf_depth_out")
+    tmpIV = [c.mid(f"{pfx}.tmpIV[{i}]") for i in range(8)]
+    h_compression = [c.mid(f"{pfx}.h_compression[{i}]") for i in range(8)]
+    decr_depth = c.mid(f"{pfx}.decr_depth")
+    cd = CheckDepth(c, f"{pfx}.check_depth")
+    c.alias(cd["depth"], depth)
+    c.alias(cd["leaf_depth"], leaf_depth)
+    fl = GetFlag(c, f"{pfx}.comp_d", D_FLAGS)
+    c.alias(fl["is_parent"], cd["is_parent"])
+    c.alias(fl["is_root"], cd["is_root"])
+    c.alias(fl["block_count"], block_count)
+    c.alias(fl["n_blocks"], n_blocks)
+    iv = IV(c, f"{pfx}.iv")
+    fm = GetFinal_m(c, f"{pfx}.final_m")
+    for i in range(8):
+        c.alias(fm["h"][i], h[i])
+    for i in range(16):
+        c.alias(fm["m"][i], m[i])
+    c.alias(fm["is_parent"], cd["is_parent"])
+    c.alias(fm["depth"], depth)
+    c.alias(fm["total_depth"], total_depth)
+    c.assign(fm["chunk_idx"], add(S(cil), scale(S(cih), 1 << 32)))
+    npar = sub(K(1), S(cd["is_parent"]))
+    for i in range(8):
+        c.quadratic(S(iv["out"][i]), S(cd["is_parent"]), S(tmpIV[i]))
+        c.quadratic(S(h[i]), npar, sub(S(h_compression[i]), S(tmpIV[i])))
+    comp = Blake3Compression(c, f"{pfx}.blake3Compression")
+    for i in range(16):
+        c.alias(comp["m"][i], fm["out_m"][i])
+    for i in range(8):
+        c.alias(comp["h"][i], h_compression[i])
+    c.alias(comp["d"], fl["out"])
+    c.alias(comp["b"], b)
+    c.quadratic(S(cih), npar, S(comp["t"][1]))
+    c.quadratic(S(cil), npar, S(comp["t"][0]))
+    for i in range(8):
+        c.alias(h_out[i], comp["out"][i])
+    c.assign(block_count_out, add(S(block_count), npar))
+    c.alias(n_blocks_out, n_blocks)
+    cdd = OR(c, f"{pfx}.check_decr_depth")
+    c.alias(cdd["a"], fl["is_last_block"])
+    c.alias(cdd["b"], cd["is_parent"])
+    c.quadratic(S(cdd["out"]), sub(K(1), S(cd["is_root"])), S(decr_depth))
+    c.quadratic(S(decr_depth), sub(K(1), S(decr_depth)), {})
+    c.assign(depth_out, sub(S(depth), S(decr_depth)))
+    c.alias(total_depth_out, total_depth)
+    c.alias(cil_out, cil)
+    c.alias(cih_out, cih)
+    c.alias(leaf_depth_out, leaf_depth)
+    # circuits/main/blake3_nova.circom:6: component main {public [h, block_count, n_blocks, chunk_idx_low, chunk_idx_high]}
+    outs = [n_blocks_out, block_count_out] + h_out + [total_depth_out, depth_out, cil_out, cih_out, leaf_depth_out]
+    return dict(public=outs + [n_blocks, block_count] + h + [cil, cih])
+
+
+# ------------------------------------------------------------------ against the reference's symbol table and witnesses
 def read_sym(path):
     """id,witnessIdx,componentId,name  ->  {name: (id, witnessIdx)}"""
     tab = {}
@@ -353,41 +690,45 @@ def read_wtns(path):
     return [int.from_bytes(raw[76 + 32 * i: 108 + 32 * i], "little") for i in range(n)]
 
 
-def lower(c, sym):
-    """Substitute every signal by its wire (the slot of its alias class) or its constant; check the classes against
-    the .sym.  Returns (constraints over wires, nWires, wire2label)."""
-    assert set(c.names) == set(sym), (len(c.names), len(sym), sorted(set(sym) - set(c.names))[:5], sorted(set(c.names) - set(sym))[:5])
+def lower(c, sym=None, public=()):
+    """Number the signals by circom's rule, hand out the witness slots (increasing id over the non-constant classes) and
+    rewrite every constraint over wires.  With the build's .sym: ids, slots and names must all be the compiler's.
+    Returns (constraints over wires, nWires, wire2label, nLabels)."""
     assert len(set(c.names)) == len(c.names)
+    ids = c.number()
+    c.simplify(public)
     classes = {}
     for s in range(len(c.names)):
         classes.setdefault(c.find(s), []).append(s)
-    wire_of, label_of = {}, {0: 0}
-    for root, members in classes.items():
-        kept = [(sym[c.names[s]][0], sym[c.names[s]][1]) for s in members]
-        slots = [w for _, w in kept if w >= 0]
-        if root in c.const:
-            assert not slots, ("a constant signal kept a witness slot", c.names[root])
-            continue
-        lowest = min(kept)
-        assert len(slots) == 1 and lowest[1] == slots[0], ("alias class disagrees with the .sym", [c.names[s] for s in members][:4], kept[:4])
-        wire_of[root] = slots[0]
-        assert slots[0] not in label_of
-        label_of[slots[0]] = lowest[0]
-    nwires = 1 + len(wire_of)
-    assert sorted(label_of) == list(range(nwires)), "witness slots are not 0 .. nWires-1"
+    # a signal that no constraint mentions and that is not part of the main component's interface has no wire
+    # (Blake3GetDownLeftPath declares bit_at_depth[65] and eqs[65] but uses 64 of each: blake3_nova.circom:60-71)
+    used = {c.find(k) for a, b, cc in c.cons for lc in (a, b, cc) for k in lc if k is not None} | {c.find(s) for s in public}
+    used |= {c.find(s) for s, name in enumerate(c.names) if name.count(".") == 1}
+    live = sorted((min(ids[s] for s in members), root) for root, members in classes.items() if root not in c.const and root in used)
+    wire_of = {root: 1 + k for k, (_, root) in enumerate(live)}
+    wire2label = [0] + [i for i, _ in live]
+    nwires = 1 + len(live)
+    if sym is not None:
+        assert set(c.names) == set(sym), (len(c.names), len(sym), sorted(set(sym) - set(c.names))[:5], sorted(set(c.names) - set(sym))[:5])
+        wrong = [c.names[s] for s in range(len(c.names)) if ids[s] != sym[c.names[s]][0]]
+        assert not wrong, ("the numbering rule disagrees with the .sym", wrong[:5])
+        for root, members in classes.items():
+            kept = [sym[c.names[s]][1] for s in members if sym[c.names[s]][1] >= 0]
+            if root in c.const:
+                assert not kept, ("a constant signal kept a witness slot", c.names[root])
+            else:
+                lowest = min(members, key=lambda s: ids[s])
+                assert kept == [wire_of[root]] and sym[c.names[lowest]][1] == wire_of[root], \
+                    ("alias class disagrees with the .sym", [c.names[s] for s in members][:4], kept, wire_of[root])
 
     def low(lc):
         out = {}
-        for k, v in lc.items():
-            if k is None:
-                w, f = 0, v
-            else:
-                r = c.find(k)
-                w, f = (0, v * c.const[r]) if r in c.const else (wire_of[r], v)
-            out[w] = (out.get(w, 0) + f) % P
+        for k, v in c.resolve(lc).items():
+            w = 0 if k is None else wire_of[k]
+            out[w] = (out.get(w, 0) + v) % P
         return {w: f for w, f in sorted(out.items()) if f}
     cons = [(low(a), low(b), low(cc)) for a, b, cc in c.cons]
-    return cons, nwires, [label_of[w] for w in range(nwires)]
+    return cons, nwires, wire2label, len(c.names) + 1
 
 
 def violated(cons, z):
@@ -415,23 +756,55 @@ def write_r1cs(path, cons, nwires, wire2label, n_pub_out, n_pub_in, n_prv_in, n_
     return len(blob)
 
 
-def main():
-    out = sys.argv[sys.argv.index("--out") + 1] if "--out" in sys.argv else OUT
-    sym = read_sym(SYM)
-    c = Circuit()
-    Blake3Compression(c)
-    cons, nwires, w2l = lower(c, sym)
-    z = read_wtns(WTNS)
-    assert len(z) == nwires == 24093, (len(z), nwires)
-    bad = violated(cons, z)
-    assert not bad, f"the reference's own witness violates {len(bad)} derived constraints, first {bad[:5]}"
+def summary(cons):
     kinds = {"bool": 0, "quadratic": 0, "linear": 0}
     for a, b, cc in cons:
-        kinds["linear" if not a else "bool" if not cc else "quadratic"] += 1
-    nnz = sum(len(a) + len(b) + len(cc) for a, b, cc in cons)
-    size = write_r1cs(out, cons, nwires, w2l, 16, 0, 28, max(i for i, _ in sym.values()) + 1)
-    print(f"{len(c.names)} signals = the .sym's; {nwires} wires; {len(cons)} constraints {kinds}; {nnz} non-zeros; "
-          f"reference witness satisfies all; wrote {out} ({size} bytes before gzip)")
+        kinds["linear" if not a or not b else "bool" if not cc else "quadratic"] += 1
+    return kinds, sum(len(a) + len(b) + len(cc) for a, b, cc in cons)
+
+
+def wasm_witnesses(wasm, inputs):
+    """witnesses of the reference WASM under its own loader (tools/wasm_oracle.js), as lists of ints"""
+    with tempfile.TemporaryDirectory() as td:
+        json.dump(inputs, open(os.path.join(td, "in.json"), "w"))
+        subprocess.check_call(["node", os.path.join(ROOT, "tools", "wasm_oracle.js"), wasm, os.path.join(td, "in.json"), os.path.join(td, "out.bin")])
+        meta = json.load(open(os.path.join(td, "out.bin.err.json")))
+        assert not meta["errors"], meta["errors"]
+        raw = open(os.path.join(td, "out.bin"), "rb").read()
+    n = meta["witnessSize"]
+    return [[int.from_bytes(raw[(k * n + i) * 32:(k * n + i + 1) * 32], "little") for i in range(n)] for k in range(len(inputs))]
+
+
+def main():
+    which = sys.argv[sys.argv.index("--circuit") + 1] if "--circuit" in sys.argv else "compression"
+    c = Circuit()
+    if which == "compression":
+        out = sys.argv[sys.argv.index("--out") + 1] if "--out" in sys.argv else OUT
+        Blake3Compression(c)
+        cons, nwires, w2l, nlabels = lower(c, read_sym(SYM))
+        z = read_wtns(WTNS)
+        assert len(z) == nwires == 24093, (len(z), nwires)
+        bad = violated(cons, z)
+        assert not bad, f"the reference's own witness violates {len(bad)} derived constraints, first {bad[:5]}"
+        kinds, nnz = summary(cons)
+        size = write_r1cs(out, cons, nwires, w2l, 16, 0, 28, nlabels)
+        print(f"{len(c.names)} signals = the .sym's, ids and slots by the numbering rule = the .sym's; {nwires} wires; {len(cons)} constraints "
+              f"{kinds}; {nnz} non-zeros; reference witness satisfies all; wrote {out} ({size} bytes before gzip)")
+    else:
+        out = sys.argv[sys.argv.index("--out") + 1] if "--out" in sys.argv else OUT.replace("blake3_compression", "blake3_nova_bn254_o1")
+        nova = Blake3Nova(c)
+        cons, nwires, w2l, nlabels = lower(c, public=nova["public"])
+        assert nwires == 24614, nwires
+        gold = json.load(open(os.path.join(ROOT, "tests", "golden", "nova_bn254_o1.json")))
+        cases = [g for g in gold["cases"] if "error" not in g]
+        zs = wasm_witnesses(os.path.join(REF, "build/blake3_nova/blake3_nova_js/blake3_nova.wasm"), [g["input"] for g in cases])
+        for g, z in zip(cases, zs):
+            bad = violated(cons, z)
+            assert not bad, f"the reference WASM's witness of golden {g['name']} violates {len(bad)} derived constraints, first {bad[:5]}"
+        kinds, nnz = summary(cons)
+        size = write_r1cs(out, cons, nwires, w2l, 15, 12, 20, nlabels)
+        print(f"{len(c.names)} signals; {nwires} wires = the WASM's witness size; {len(cons)} constraints {kinds}; {nnz} non-zeros; "
+              f"{len(cases)} reference-WASM witnesses (accepted goldens) satisfy all; wrote {out} ({size} bytes before gzip)")
 
 
 if __name__ == "__main__":
