@@ -1026,6 +1026,10 @@ struct b3w_r1cs {
   B3wField field{};
   uint32_t *d_rows = nullptr, *d_row_id = nullptr, *d_wires = nullptr, *d_coefR = nullptr;
   uint16_t *d_cids = nullptr;
+  // tile formulation (b3w_r1cs.hip): used when every tile of B3W_R1CS_TILE wires needs at most that many outside wires
+  bool tiled = false;
+  uint32_t ntiles = 0, max_ext = 0;
+  uint32_t *d_tiles = nullptr, *d_ext = nullptr, *d_trows = nullptr, *d_trow_id = nullptr, *d_terms = nullptr;
 };
 
 namespace {
@@ -1146,6 +1150,50 @@ int32_t b3w_r1cs_create(b3w_ctx *ctx, const uint8_t *img, size_t len, b3w_r1cs *
     rowdesc[4 * k] = rows[k].off; rowdesc[4 * k + 1] = rows[k].na; rowdesc[4 * k + 2] = rows[k].nb; rowdesc[4 * k + 3] = rows[k].nc;
     row_id[k] = rows[k].id;
   }
+  // ---- tile formulation: a row belongs to the tile most of its wires lie in (the constant wire 0 does not vote); the
+  // wires it mentions outside that tile are the tile's "outside wires", staged into LDS behind the tile
+  const uint32_t T = B3W_R1CS_TILE, ntiles = (nwires + T - 1) / T;
+  std::vector<std::vector<uint32_t>> tile_rows(ntiles);
+  std::vector<std::map<uint32_t, uint32_t>> tile_ext(ntiles);     // outside wire -> its number in the tile
+  {
+    std::vector<uint32_t> votes(ntiles);
+    for (uint32_t k = 0; k < m; k++) {                            // rows[] is shape-sorted: tile_rows keeps that order
+      const Row &r = rows[k];
+      const uint32_t nt = r.na + r.nb + r.nc;
+      std::fill(votes.begin(), votes.end(), 0u);
+      uint32_t best = 0;
+      for (uint32_t t = 0; t < nt; t++) { const uint32_t w = wires[r.off + t]; if (w) votes[w / T]++; }
+      for (uint32_t t = 1; t < ntiles; t++) if (votes[t] > votes[best]) best = t;
+      tile_rows[best].push_back(k);
+      for (uint32_t t = 0; t < nt; t++) {
+        const uint32_t w = wires[r.off + t];
+        if (w / T != best && !tile_ext[best].count(w)) { const uint32_t id = (uint32_t)tile_ext[best].size(); tile_ext[best][w] = id; }
+      }
+    }
+  }
+  uint32_t max_ext = 0;
+  for (uint32_t t = 0; t < ntiles; t++) max_ext = std::max<uint32_t>(max_ext, (uint32_t)tile_ext[t].size());
+  const bool tiled = max_ext <= T && coefs.size() <= 0xFFFF;
+  std::vector<uint32_t> tdesc(4 * (size_t)ntiles), text, trows, trow_id, tterms;
+  if (tiled) {
+    for (uint32_t t = 0; t < ntiles; t++) {
+      tdesc[4 * t] = (uint32_t)(trows.size() / 4); tdesc[4 * t + 1] = (uint32_t)tile_rows[t].size();
+      tdesc[4 * t + 2] = (uint32_t)text.size(); tdesc[4 * t + 3] = (uint32_t)tile_ext[t].size();
+      std::vector<uint32_t> ext(tile_ext[t].size());
+      for (const auto &kv : tile_ext[t]) ext[kv.second] = kv.first;
+      text.insert(text.end(), ext.begin(), ext.end());
+      for (uint32_t k : tile_rows[t]) {
+        const Row &r = rows[k];
+        trows.push_back((uint32_t)tterms.size()); trows.push_back(r.na); trows.push_back(r.nb); trows.push_back(r.nc);
+        trow_id.push_back(r.id);
+        for (uint32_t q = 0; q < r.na + r.nb + r.nc; q++) {
+          const uint32_t w = wires[r.off + q];
+          const uint32_t idx = w / T == t ? w - t * T : T + tile_ext[t][w];
+          tterms.push_back(idx | (uint32_t)cids[r.off + q] << 16);
+        }
+      }
+    }
+  }
   std::vector<uint32_t> coefR(16 * coefs.size());           // per coefficient: plain, then Montgomery form
   for (size_t i = 0; i < coefs.size(); i++) {
     memcpy(&coefR[16 * i], coefs[i].data(), 32);
@@ -1173,6 +1221,14 @@ int32_t b3w_r1cs_create(b3w_ctx *ctx, const uint8_t *img, size_t len, b3w_r1cs *
   up((void **)&r->d_wires, wires.data(), wires.size() * 4);
   up((void **)&r->d_cids, cids.data(), cids.size() * 2);
   up((void **)&r->d_coefR, coefR.data(), coefR.size() * 4);
+  r->tiled = tiled; r->ntiles = ntiles; r->max_ext = max_ext;
+  if (tiled) {
+    up((void **)&r->d_tiles, tdesc.data(), tdesc.size() * 4);
+    up((void **)&r->d_ext, text.data(), text.size() * 4);
+    up((void **)&r->d_trows, trows.data(), trows.size() * 4);
+    up((void **)&r->d_trow_id, trow_id.data(), trow_id.size() * 4);
+    up((void **)&r->d_terms, tterms.data(), tterms.size() * 4);
+  }
   if (e != hipSuccess) { b3w_r1cs_destroy(r); return e == hipErrorOutOfMemory ? B3W_E_NOT_ENOUGH_MEMORY : hip_fail(ctx, e, "r1cs upload"); }
   *out = r;
   return B3W_OK;
@@ -1198,6 +1254,7 @@ void b3w_r1cs_destroy(b3w_r1cs *r) {
   if (r->d_wires) (void)hipFree(r->d_wires);
   if (r->d_cids) (void)hipFree(r->d_cids);
   if (r->d_coefR) (void)hipFree(r->d_coefR);
+  for (uint32_t *q : {r->d_tiles, r->d_ext, r->d_trows, r->d_trow_id, r->d_terms}) if (q) (void)hipFree(q);
   delete r;
 }
 
@@ -1211,8 +1268,12 @@ int32_t b3w_r1cs_check_device(b3w_ctx *ctx, const b3w_r1cs *r, const uint8_t *d_
     return B3W_E_BAD_ARGUMENT;
   }
   ON_DEVICE(ctx);
-  const int rc = b3w_launch_r1cs(d_bodies, n, pitch, r->m, r->d_rows, r->d_row_id, r->d_wires, r->d_cids, r->d_coefR, &r->field,
-                                 d_violations, d_first, (hipStream_t)stream);
+  static const bool gather_only = getenv("B3W_R1CS_GATHER") && !strcmp(getenv("B3W_R1CS_GATHER"), "1");      // the other kernel, for comparison
+  const int rc = r->tiled && !gather_only
+                     ? b3w_launch_r1cs_tiled(d_bodies, n, pitch, r->nwires, r->ntiles, r->max_ext, r->d_tiles, r->d_ext, r->d_trows,
+                                             r->d_trow_id, r->d_terms, r->d_coefR, &r->field, d_violations, d_first, (hipStream_t)stream)
+                     : b3w_launch_r1cs(d_bodies, n, pitch, r->m, r->d_rows, r->d_row_id, r->d_wires, r->d_cids, r->d_coefR, &r->field,
+                                       d_violations, d_first, (hipStream_t)stream);
   return rc ? hip_fail(ctx, (hipError_t)rc, "r1cs check launch") : B3W_OK;
 }
 

@@ -79,3 +79,11 @@ struct B3wField {
 extern "C" int b3w_launch_r1cs(const uint8_t *d_bodies, uint32_t n, uint64_t pitch, uint32_t m, const uint32_t *d_rows,
                                const uint32_t *d_row_id, const uint32_t *d_wires, const uint16_t *d_cids, const uint32_t *d_coefR,
                                const B3wField *field, uint32_t *d_violations, uint32_t *d_first, hipStream_t stream);
+// the tile formulation (preferred): tile t = wires [t * B3W_R1CS_TILE, +B3W_R1CS_TILE); tiles: ntiles x {first row, rows, first
+// outside wire, outside wires}; rows: {first term, terms in A, B, C}; term = LDS index (< TILE: wire - tile start; >= TILE: outside
+// wire number) | coefficient id << 16
+#define B3W_R1CS_TILE 1024u
+extern "C" int b3w_launch_r1cs_tiled(const uint8_t *d_bodies, uint32_t n, uint64_t pitch, uint32_t nwires, uint32_t ntiles, uint32_t max_ext,
+                                     const uint32_t *d_tiles, const uint32_t *d_ext, const uint32_t *d_rows, const uint32_t *d_row_id,
+                                     const uint32_t *d_terms, const uint32_t *d_coefs, const B3wField *field, uint32_t *d_violations,
+                                     uint32_t *d_first, hipStream_t stream);

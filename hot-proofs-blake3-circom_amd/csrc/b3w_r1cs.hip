@@ -12,7 +12,14 @@
 // at run time (BN254 scalar field or the Vesta base field).  A term coef * z[wire] is montmul(coef * R, z) = coef * z;
 // coefficients +1 / -1 (93 % of the terms of the compression system) are an addition / subtraction.
 //
-// Mapping: thread = (constraint, body), 256 consecutive rows per workgroup; rows are sorted by shape (terms in A, B, C)
+// TWO KERNELS, same arithmetic.  The TILE kernel (the one that runs whenever the system allows it) exploits that circom
+// constraints are local: a workgroup takes (body, tile of 1 024 consecutive wires), streams the tile from HBM into LDS
+// once — coalesced 32 KB — plus the few wires outside the tile its rows mention (<= 137 per tile for both derived systems,
+// listed per tile by the host), and evaluates the rows that belong to the tile entirely out of LDS.  A body is read from
+// HBM once (+6 % for the shared outside wires, L2 hits): the kernel is HBM-read bound like the tamper check.  A system
+// whose rows are not local enough (more than 1 024 outside wires for some tile) takes the GATHER kernel below.
+//
+// Gather kernel — mapping: thread = (constraint, body), 256 consecutive rows per workgroup; rows are sorted by shape (terms in A, B, C)
 // on the host so that the 64 lanes of a wave run the same trip counts.  The workgroups of ONE body all land on one XCD
 // (the hardware deals consecutive workgroup ids round-robin over the 8 XCDs: id -> body = 8 * (id / (8 * RB)) + id % 8,
 // row block = (id / 8) % RB), so a body is fetched from HBM into one L2 once and its ~4.9 reads per element (once per
@@ -237,7 +244,137 @@ __global__ __launch_bounds__(256) void b3w_r1cs_kernel(const uint8_t *__restrict
   }
 }
 
+// ---- tile kernel ----------------------------------------------------------------------------------------------------
+// LDS image of a workgroup: element i < n_local = wire tile * TILE + i, element TILE + j = outside wire ext[j]; 32 bytes each,
+// reduced mod p at load time; bit 255 (never set in a reduced element of these fields: p < 2^255) marks an element that was
+// NOT canonical in the body.
+__device__ __forceinline__ Fe lds_z(const uint4 *lds, uint32_t idx, bool *wild) {
+  const uint4 lo = lds[2 * idx], hi = lds[2 * idx + 1];
+  Fe z;
+  z.l[0] = lo.x; z.l[1] = lo.y; z.l[2] = lo.z; z.l[3] = lo.w;
+  z.l[4] = hi.x; z.l[5] = hi.y; z.l[6] = hi.z; z.l[7] = hi.w & 0x7FFFFFFFu;
+  *wild = *wild || (hi.w >> 31);
+  return z;
+}
+
+__device__ __forceinline__ Fe dot_lds(const uint4 *lds, const uint32_t *terms /* lds index | cid << 16 */, const uint32_t *coefs,
+                                      uint32_t off, uint32_t n, const B3wField &F, bool *wild) {
+  Fe acc;
+#pragma unroll
+  for (int i = 0; i < 8; i++) acc.l[i] = 0;
+  for (uint32_t k = 0; k < n; k++) {
+    const uint32_t t = terms[off + k];
+    const uint32_t cid = t >> 16;
+    const Fe z = lds_z(lds, t & 0xFFFFu, wild);
+    const int zs = small01(z);
+    if (zs == 0) continue;
+    if (cid == 0) fe_add(acc, z, F.p);
+    else if (cid == 1) fe_sub(acc, z, F.p);
+    else if (zs == 1) {
+      const Fe cf = load_fe(coefs + (size_t)cid * 16);
+      fe_add(acc, cf, F.p);
+    } else {
+      const Fe cf = load_fe(coefs + (size_t)cid * 16 + 8);
+      const Fe tt = mont_mul(cf, z, F);
+      fe_add(acc, tt, F.p);
+    }
+  }
+  return acc;
+}
+
+__device__ __forceinline__ void stage(uint4 *lds, uint32_t idx, const uint8_t *body, uint32_t wire, const B3wField &F) {
+  bool wild = false;
+  Fe z = load_z(body, wire, F, &wild);
+  lds[2 * idx] = make_uint4(z.l[0], z.l[1], z.l[2], z.l[3]);
+  lds[2 * idx + 1] = make_uint4(z.l[4], z.l[5], z.l[6], z.l[7] | (wild ? 0x80000000u : 0u));
+}
+
+__global__ __launch_bounds__(256) void b3w_r1cs_tile_kernel(const uint8_t *__restrict__ bodies, uint64_t pitch, uint32_t n, uint32_t nwires,
+                                                            uint32_t ntiles, const uint4 *__restrict__ tiles /* row_off, n_rows, ext_off, n_ext */,
+                                                            const uint32_t *__restrict__ ext_wires, const uint4 *__restrict__ rows,
+                                                            const uint32_t *__restrict__ row_id, const uint32_t *__restrict__ terms,
+                                                            const uint32_t *__restrict__ coefs, B3wField F,
+                                                            uint32_t *__restrict__ violations, uint32_t *__restrict__ first) {
+  extern __shared__ uint4 lds[];
+  // all tiles of a body on one XCD: its outside wires are then L2 hits of a neighbouring workgroup's tile
+  const uint32_t per_group = 8u * ntiles;
+  const uint32_t b = (blockIdx.x / per_group) * 8u + (blockIdx.x & 7u);
+  const uint32_t tile = (blockIdx.x % per_group) >> 3;
+  if (b >= n) return;
+  const uint8_t *body = bodies + (uint64_t)b * pitch;
+  const uint4 td = tiles[tile];
+  const uint32_t t0 = tile * B3W_R1CS_TILE;
+  const uint32_t n_local = nwires - t0 < B3W_R1CS_TILE ? nwires - t0 : B3W_R1CS_TILE;
+  for (uint32_t i = threadIdx.x; i < n_local; i += 256) stage(lds, i, body, t0 + i, F);
+  for (uint32_t j = threadIdx.x; j < td.w; j += 256) stage(lds, B3W_R1CS_TILE + j, body, ext_wires[td.z + j], F);
+  __syncthreads();
+  uint32_t nbad = 0, low = 0xFFFFFFFFu;
+  for (uint32_t r = td.x + threadIdx.x; r < td.x + td.y; r += 256) {
+    const uint4 d = rows[r];
+    bool wild = false, bad;
+    const Fe cz = dot_lds(lds, terms, coefs, d.x + d.y + d.z, d.w, F, &wild);
+    if (d.y == 0 || d.z == 0) {
+      bad = !fe_is_zero(cz);
+      if (d.y) (void)dot_lds(lds, terms, coefs, d.x, d.y, F, &wild);
+      if (d.z) (void)dot_lds(lds, terms, coefs, d.x + d.y, d.z, F, &wild);
+    } else {
+      const Fe az = dot_lds(lds, terms, coefs, d.x, d.y, F, &wild);
+      const Fe bz = dot_lds(lds, terms, coefs, d.x + d.y, d.z, F, &wild);
+      const int as = small01(az), bs = small01(bz);
+      Fe ab;
+      if (as == 0 || bs == 0) {
+#pragma unroll
+        for (int i = 0; i < 8; i++) ab.l[i] = 0;
+      } else if (as == 1) ab = bz;
+      else if (bs == 1) ab = az;
+      else {
+        Fe r2;
+#pragma unroll
+        for (int i = 0; i < 8; i++) r2.l[i] = F.r2[i];
+        ab = mont_mul(mont_mul(az, r2, F), bz, F);
+      }
+      Fe diff = ab;
+      fe_sub(diff, cz, F.p);
+      bad = !fe_is_zero(diff);
+    }
+    if (bad || wild) { nbad++; low = min(low, row_id[r]); }
+  }
+  // one atomic per wave
+#pragma unroll
+  for (int sh = 32; sh > 0; sh >>= 1) {
+    nbad += (uint32_t)__shfl_xor((int)nbad, sh);
+    low = min(low, (uint32_t)__shfl_xor((int)low, sh));
+  }
+  if ((threadIdx.x & 63) == 0 && nbad) {
+    atomicAdd(&violations[b], nbad);
+    if (first) atomicMin(&first[b], low);
+  }
+}
+
 }  // namespace
+
+extern "C" int b3w_launch_r1cs_tiled(const uint8_t *d_bodies, uint32_t n, uint64_t pitch, uint32_t nwires, uint32_t ntiles, uint32_t max_ext,
+                                     const uint32_t *d_tiles, const uint32_t *d_ext, const uint32_t *d_rows, const uint32_t *d_row_id,
+                                     const uint32_t *d_terms, const uint32_t *d_coefs, const B3wField *field, uint32_t *d_violations,
+                                     uint32_t *d_first, hipStream_t stream) {
+  if (!n || !ntiles) return 0;
+  if (max_ext > B3W_R1CS_TILE) return -5;
+  hipError_t e = hipMemsetAsync(d_violations, 0, (size_t)n * 4, stream);
+  if (e == hipSuccess && d_first) e = hipMemsetAsync(d_first, 0xFF, (size_t)n * 4, stream);
+  if (e != hipSuccess) return (int)e;
+  const size_t smem = (size_t)(B3W_R1CS_TILE + max_ext) * 32;
+  const uint32_t slab = (0x7FFFFFFFu / ntiles) & ~7u;
+  for (uint32_t b0 = 0; b0 < n; b0 += slab) {
+    const uint32_t nb = n - b0 < slab ? n - b0 : slab;
+    const uint32_t groups = (nb + 7) / 8;
+    hipLaunchKernelGGL(b3w_r1cs_tile_kernel, dim3(groups * 8 * ntiles), dim3(256), smem, stream, d_bodies + (uint64_t)b0 * pitch, pitch, nb,
+                       nwires, ntiles, reinterpret_cast<const uint4 *>(d_tiles), d_ext, reinterpret_cast<const uint4 *>(d_rows), d_row_id,
+                       d_terms, d_coefs, *field, d_violations + b0, d_first ? d_first + b0 : nullptr);
+    e = hipGetLastError();
+    if (e != hipSuccess) return (int)e;
+  }
+  return 0;
+}
 
 extern "C" int b3w_launch_r1cs(const uint8_t *d_bodies, uint32_t n, uint64_t pitch, uint32_t m, const uint32_t *d_rows,
                                const uint32_t *d_row_id, const uint32_t *d_wires, const uint16_t *d_cids, const uint32_t *d_coefR,

@@ -211,3 +211,46 @@ def test_nova_o1_build_on_the_device():
     with pytest.raises(m.B3WError):
         m.R1cs(m.Context("nova_bn254", 0))                 # the O2 builds have no derived system
     r1cs.close(); ctx.close()
+
+
+def test_gather_kernel_gives_the_same_verdicts(tmp_path):
+    """csrc/b3w_r1cs.hip has two kernels with the same arithmetic: the LDS-tile one (taken whenever the system is local
+    enough) and the gather one (any system).  A child process with B3W_R1CS_GATHER=1 runs the gather kernel over the same
+    clean and corrupted bodies; counts and first violated rows must be identical."""
+    import json, os, subprocess, sys
+    script = r'''
+import importlib, json, os, sys, random
+import numpy as np, torch
+sys.path.insert(0, os.getcwd())
+m = importlib.import_module("hot-proofs-blake3-circom_amd")
+out = {}
+for circuit in ("compression", "nova_bn254_o1"):
+    ctx = m.Context(circuit, 0)
+    r1cs = m.R1cs(ctx)
+    n = 300
+    recs = m.workloads.config2_compression(n, first=9) if circuit == "compression" else m.workloads.config3_nova(n, first=9)
+    d_recs = torch.from_numpy(recs.view(np.int32)).cuda()
+    bodies = torch.empty((n, ctx.body_bytes), dtype=torch.uint8, device="cuda")
+    ctx.run_device(d_recs.data_ptr(), n, bodies.data_ptr(), 0, 0, 0, torch.cuda.current_stream().cuda_stream)
+    host = bodies.cpu().numpy()
+    rng = random.Random(1)
+    for i in range(0, n, 2):                      # every other body: one slot changed
+        s = rng.randrange(ctx.witness_size)
+        host[i, 32 * s:32 * s + 32] = np.frombuffer(rng.randrange(1 << 255).to_bytes(32, "little"), dtype=np.uint8)
+    d = torch.from_numpy(host).cuda()
+    viol = torch.zeros(n, dtype=torch.int32, device="cuda"); first = torch.zeros(n, dtype=torch.int32, device="cuda")
+    r1cs.check_device(d.data_ptr(), n, 0, viol.data_ptr(), first.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    out[circuit] = [viol.cpu().numpy().view(np.uint32).tolist(), first.cpu().numpy().view(np.uint32).tolist()]
+print(json.dumps(out))
+'''
+    res = {}
+    for mode in ("0", "1"):
+        r = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, cwd=T.ROOT, timeout=600,
+                           env=dict(os.environ, B3W_R1CS_GATHER=mode))
+        assert r.returncode == 0, r.stderr[-1500:]
+        res[mode] = json.loads(r.stdout.strip().splitlines()[-1])
+    assert res["0"] == res["1"]
+    for circuit in res["0"]:
+        viol = res["0"][circuit][0]
+        assert all(v == 0 for v in viol[1::2]) and all(v > 0 for v in viol[0::2]), circuit
