@@ -1030,6 +1030,7 @@ struct b3w_r1cs {
   bool tiled = false;
   uint32_t ntiles = 0, max_ext = 0;
   uint32_t *d_tiles = nullptr, *d_ext = nullptr, *d_trows = nullptr, *d_trow_id = nullptr, *d_terms = nullptr;
+  long long *d_coef_small = nullptr;
 };
 
 namespace {
@@ -1155,6 +1156,7 @@ int32_t b3w_r1cs_create(b3w_ctx *ctx, const uint8_t *img, size_t len, b3w_r1cs *
   const uint32_t T = B3W_R1CS_TILE, ntiles = (nwires + T - 1) / T;
   std::vector<std::vector<uint32_t>> tile_rows(ntiles);
   std::vector<std::map<uint32_t, uint32_t>> tile_ext(ntiles);     // outside wire -> its number in the tile
+  for (uint32_t t = 1; t < ntiles; t++) tile_ext[t][0] = 0;       // the constant wire is outside wire 0 of every tile but the first
   {
     std::vector<uint32_t> votes(ntiles);
     for (uint32_t k = 0; k < m; k++) {                            // rows[] is shape-sorted: tile_rows keeps that order
@@ -1173,7 +1175,26 @@ int32_t b3w_r1cs_create(b3w_ctx *ctx, const uint8_t *img, size_t len, b3w_r1cs *
   }
   uint32_t max_ext = 0;
   for (uint32_t t = 0; t < ntiles; t++) max_ext = std::max<uint32_t>(max_ext, (uint32_t)tile_ext[t].size());
-  const bool tiled = max_ext <= T && coefs.size() <= 0xFFFF;
+  uint32_t longest = 0;
+  for (const Row &r : rows) longest = std::max(longest, r.na + r.nb + r.nc);
+  // (the tile kernel sums small terms as 128-bit integers: rows stay below 2^20 terms)
+  const bool tiled = max_ext <= T && coefs.size() <= 0xFFFF && longest < (1u << 20);
+  // coefficients as small signed integers (c or c - p), for the tile kernel's integer path
+  std::vector<long long> coef_small(coefs.size(), B3W_R1CS_NOT_SMALL);
+  for (size_t i = 0; i < coefs.size(); i++) {
+    const std::array<uint32_t, 8> &cf = coefs[i];
+    uint32_t hi = 0;
+    for (int q = 2; q < 8; q++) hi |= cf[q];
+    const uint64_t lo64 = (uint64_t)cf[0] | (uint64_t)cf[1] << 32;
+    if (!hi && lo64 < (1ull << 40)) { coef_small[i] = (long long)lo64; continue; }
+    uint32_t neg[8];                                                               // p - c
+    uint64_t br = 0;
+    for (int q = 0; q < 8; q++) { const uint64_t d = (uint64_t)P[q] - cf[q] - br; neg[q] = (uint32_t)d; br = (d >> 63) & 1; }
+    hi = 0;
+    for (int q = 2; q < 8; q++) hi |= neg[q];
+    const uint64_t n64 = (uint64_t)neg[0] | (uint64_t)neg[1] << 32;
+    if (!hi && n64 < (1ull << 40)) coef_small[i] = -(long long)n64;
+  }
   std::vector<uint32_t> tdesc(4 * (size_t)ntiles), text, trows, trow_id, tterms;
   if (tiled) {
     for (uint32_t t = 0; t < ntiles; t++) {
@@ -1184,7 +1205,15 @@ int32_t b3w_r1cs_create(b3w_ctx *ctx, const uint8_t *img, size_t len, b3w_r1cs *
       text.insert(text.end(), ext.begin(), ext.end());
       for (uint32_t k : tile_rows[t]) {
         const Row &r = rows[k];
-        trows.push_back((uint32_t)tterms.size()); trows.push_back(r.na); trows.push_back(r.nb); trows.push_back(r.nc);
+        // booleanity:  A = {w: 1},  B = {wire 0: 1, w: -1} or {w: 1, wire 0: -1},  C = {}
+        bool boolean = r.na == 1 && r.nb == 2 && r.nc == 0 && cids[r.off] == 0 && wires[r.off] != 0;
+        if (boolean) {
+          const uint32_t w = wires[r.off], w1 = wires[r.off + 1], w2 = wires[r.off + 2];
+          const uint16_t c1 = cids[r.off + 1], c2 = cids[r.off + 2];
+          boolean = (w1 == 0 && w2 == w && ((c1 == 0 && c2 == 1) || (c1 == 1 && c2 == 0))) ||
+                    (w2 == 0 && w1 == w && ((c2 == 0 && c1 == 1) || (c2 == 1 && c1 == 0)));
+        }
+        trows.push_back((uint32_t)tterms.size()); trows.push_back(r.na | (boolean ? 0x80000000u : 0u)); trows.push_back(r.nb); trows.push_back(r.nc);
         trow_id.push_back(r.id);
         for (uint32_t q = 0; q < r.na + r.nb + r.nc; q++) {
           const uint32_t w = wires[r.off + q];
@@ -1228,6 +1257,7 @@ int32_t b3w_r1cs_create(b3w_ctx *ctx, const uint8_t *img, size_t len, b3w_r1cs *
     up((void **)&r->d_trows, trows.data(), trows.size() * 4);
     up((void **)&r->d_trow_id, trow_id.data(), trow_id.size() * 4);
     up((void **)&r->d_terms, tterms.data(), tterms.size() * 4);
+    up((void **)&r->d_coef_small, coef_small.data(), coef_small.size() * 8);
   }
   if (e != hipSuccess) { b3w_r1cs_destroy(r); return e == hipErrorOutOfMemory ? B3W_E_NOT_ENOUGH_MEMORY : hip_fail(ctx, e, "r1cs upload"); }
   *out = r;
@@ -1255,6 +1285,7 @@ void b3w_r1cs_destroy(b3w_r1cs *r) {
   if (r->d_cids) (void)hipFree(r->d_cids);
   if (r->d_coefR) (void)hipFree(r->d_coefR);
   for (uint32_t *q : {r->d_tiles, r->d_ext, r->d_trows, r->d_trow_id, r->d_terms}) if (q) (void)hipFree(q);
+  if (r->d_coef_small) (void)hipFree(r->d_coef_small);
   delete r;
 }
 
@@ -1271,7 +1302,7 @@ int32_t b3w_r1cs_check_device(b3w_ctx *ctx, const b3w_r1cs *r, const uint8_t *d_
   static const bool gather_only = getenv("B3W_R1CS_GATHER") && !strcmp(getenv("B3W_R1CS_GATHER"), "1");      // the other kernel, for comparison
   const int rc = r->tiled && !gather_only
                      ? b3w_launch_r1cs_tiled(d_bodies, n, pitch, r->nwires, r->ntiles, r->max_ext, r->d_tiles, r->d_ext, r->d_trows,
-                                             r->d_trow_id, r->d_terms, r->d_coefR, &r->field, d_violations, d_first, (hipStream_t)stream)
+                                             r->d_trow_id, r->d_terms, r->d_coefR, r->d_coef_small, &r->field, d_violations, d_first, (hipStream_t)stream)
                      : b3w_launch_r1cs(d_bodies, n, pitch, r->m, r->d_rows, r->d_row_id, r->d_wires, r->d_cids, r->d_coefR, &r->field,
                                        d_violations, d_first, (hipStream_t)stream);
   return rc ? hip_fail(ctx, (hipError_t)rc, "r1cs check launch") : B3W_OK;

@@ -82,8 +82,11 @@ extern "C" int b3w_launch_r1cs(const uint8_t *d_bodies, uint32_t n, uint64_t pit
 // the tile formulation (preferred): tile t = wires [t * B3W_R1CS_TILE, +B3W_R1CS_TILE); tiles: ntiles x {first row, rows, first
 // outside wire, outside wires}; rows: {first term, terms in A, B, C}; term = LDS index (< TILE: wire - tile start; >= TILE: outside
 // wire number) | coefficient id << 16
+// rows: bit 31 of the A count marks a booleanity row (A = {w: 1}, B = {1, -w} or {w, -1}, C = {}), its first term names w;
+// coef_small[cid] = the coefficient as a signed integer when |c| < 2^40 (c or c - p), else B3W_R1CS_NOT_SMALL
 #define B3W_R1CS_TILE 1024u
+#define B3W_R1CS_NOT_SMALL ((long long)0x8000000000000000ull)
 extern "C" int b3w_launch_r1cs_tiled(const uint8_t *d_bodies, uint32_t n, uint64_t pitch, uint32_t nwires, uint32_t ntiles, uint32_t max_ext,
                                      const uint32_t *d_tiles, const uint32_t *d_ext, const uint32_t *d_rows, const uint32_t *d_row_id,
-                                     const uint32_t *d_terms, const uint32_t *d_coefs, const B3wField *field, uint32_t *d_violations,
-                                     uint32_t *d_first, hipStream_t stream);
+                                     const uint32_t *d_terms, const uint32_t *d_coefs, const long long *d_coef_small, const B3wField *field,
+                                     uint32_t *d_violations, uint32_t *d_first, hipStream_t stream);

@@ -257,29 +257,61 @@ __device__ __forceinline__ Fe lds_z(const uint4 *lds, uint32_t idx, bool *wild) 
   return z;
 }
 
-__device__ __forceinline__ Fe dot_lds(const uint4 *lds, const uint32_t *terms /* lds index | cid << 16 */, const uint32_t *coefs,
-                                      uint32_t off, uint32_t n, const B3wField &F, bool *wild) {
-  Fe acc;
+// <row, z> out of LDS, in two parts: `s` collects every term whose coefficient is a small signed integer (|c| < 2^40:
+// +-1, +-2^i, the IV words ... — all but none of the coefficients of these circuits) and whose element is below 2^64, as an
+// exact 128-bit integer (a row has < 2^20 terms: no overflow); `big` (mod p) collects the rest — the general Montgomery
+// path, any field element.  A valid witness of these circuits never leaves the integer part.
+struct Dot {
+  __int128 s;
+  Fe big;
+  bool has_big;
+};
+
+__device__ __forceinline__ Dot dot_lds(const uint4 *lds, const uint32_t *terms /* lds index | cid << 16 */, const uint32_t *coefs,
+                                       const long long *coef_small, uint32_t off, uint32_t n, const B3wField &F, bool *wild) {
+  Dot d;
+  d.s = 0;
+  d.has_big = false;
 #pragma unroll
-  for (int i = 0; i < 8; i++) acc.l[i] = 0;
+  for (int i = 0; i < 8; i++) d.big.l[i] = 0;
   for (uint32_t k = 0; k < n; k++) {
     const uint32_t t = terms[off + k];
     const uint32_t cid = t >> 16;
-    const Fe z = lds_z(lds, t & 0xFFFFu, wild);
-    const int zs = small01(z);
-    if (zs == 0) continue;
-    if (cid == 0) fe_add(acc, z, F.p);
-    else if (cid == 1) fe_sub(acc, z, F.p);
-    else if (zs == 1) {
-      const Fe cf = load_fe(coefs + (size_t)cid * 16);
-      fe_add(acc, cf, F.p);
+    const uint32_t idx = t & 0xFFFFu;
+    const uint4 lo = lds[2 * idx], hi = lds[2 * idx + 1];
+    *wild = *wild || (hi.w >> 31);
+    const long long c = coef_small[cid];
+    const uint32_t wide = lo.z | lo.w | hi.x | hi.y | hi.z | (hi.w & 0x7FFFFFFFu);
+    if (wide == 0 && c != B3W_R1CS_NOT_SMALL) {
+      const unsigned long long z64 = (unsigned long long)lo.x | (unsigned long long)lo.y << 32;
+      d.s += (__int128)c * (__int128)z64;
     } else {
-      const Fe cf = load_fe(coefs + (size_t)cid * 16 + 8);
-      const Fe tt = mont_mul(cf, z, F);
-      fe_add(acc, tt, F.p);
+      Fe z;
+      z.l[0] = lo.x; z.l[1] = lo.y; z.l[2] = lo.z; z.l[3] = lo.w;
+      z.l[4] = hi.x; z.l[5] = hi.y; z.l[6] = hi.z; z.l[7] = hi.w & 0x7FFFFFFFu;
+      d.has_big = true;
+      if (cid == 0) fe_add(d.big, z, F.p);
+      else if (cid == 1) fe_sub(d.big, z, F.p);
+      else {
+        const Fe cf = load_fe(coefs + (size_t)cid * 16 + 8);
+        const Fe tt = mont_mul(cf, z, F);
+        fe_add(d.big, tt, F.p);
+      }
     }
   }
-  return acc;
+  return d;
+}
+
+// the whole dot product as a field element: big + s mod p (|s| < 2^127 < p)
+__device__ __forceinline__ Fe dot_value(const Dot &d, const B3wField &F) {
+  const bool negative = d.s < 0;
+  const unsigned __int128 mag = negative ? (unsigned __int128)(-d.s) : (unsigned __int128)d.s;
+  Fe m;
+  m.l[0] = (uint32_t)mag; m.l[1] = (uint32_t)(mag >> 32); m.l[2] = (uint32_t)(mag >> 64); m.l[3] = (uint32_t)(mag >> 96);
+  m.l[4] = m.l[5] = m.l[6] = m.l[7] = 0;
+  Fe r = d.big;
+  if (negative) fe_sub(r, m, F.p); else fe_add(r, m, F.p);
+  return r;
 }
 
 __device__ __forceinline__ void stage(uint4 *lds, uint32_t idx, const uint8_t *body, uint32_t wire, const B3wField &F) {
@@ -293,7 +325,7 @@ __global__ __launch_bounds__(256) void b3w_r1cs_tile_kernel(const uint8_t *__res
                                                             uint32_t ntiles, const uint4 *__restrict__ tiles /* row_off, n_rows, ext_off, n_ext */,
                                                             const uint32_t *__restrict__ ext_wires, const uint4 *__restrict__ rows,
                                                             const uint32_t *__restrict__ row_id, const uint32_t *__restrict__ terms,
-                                                            const uint32_t *__restrict__ coefs, B3wField F,
+                                                            const uint32_t *__restrict__ coefs, const long long *__restrict__ coef_small, B3wField F,
                                                             uint32_t *__restrict__ violations, uint32_t *__restrict__ first) {
   extern __shared__ uint4 lds[];
   // all tiles of a body on one XCD: its outside wires are then L2 hits of a neighbouring workgroup's tile
@@ -309,33 +341,36 @@ __global__ __launch_bounds__(256) void b3w_r1cs_tile_kernel(const uint8_t *__res
   for (uint32_t j = threadIdx.x; j < td.w; j += 256) stage(lds, B3W_R1CS_TILE + j, body, ext_wires[td.z + j], F);
   __syncthreads();
   uint32_t nbad = 0, low = 0xFFFFFFFFu;
+  // is the constant wire 1?  (wire 0 is element 0 of tile 0 and outside wire 0 of every other tile that mentions it)
+  const uint4 one_lo = lds[tile == 0 ? 0 : 2 * B3W_R1CS_TILE], one_hi = lds[(tile == 0 ? 0 : 2 * B3W_R1CS_TILE) + 1];
+  const bool w0_is_one = one_lo.x == 1 && (one_lo.y | one_lo.z | one_lo.w | one_hi.x | one_hi.y | one_hi.z | one_hi.w) == 0;
+  const __int128 lim = (__int128)1 << 63;
   for (uint32_t r = td.x + threadIdx.x; r < td.x + td.y; r += 256) {
     const uint4 d = rows[r];
     bool wild = false, bad;
-    const Fe cz = dot_lds(lds, terms, coefs, d.x + d.y + d.z, d.w, F, &wild);
-    if (d.y == 0 || d.z == 0) {
-      bad = !fe_is_zero(cz);
-      if (d.y) (void)dot_lds(lds, terms, coefs, d.x, d.y, F, &wild);
-      if (d.z) (void)dot_lds(lds, terms, coefs, d.x + d.y, d.z, F, &wild);
+    if ((d.y >> 31) && w0_is_one) {
+      // a booleanity row  z * (1 - z) = 0  (or z * (z - 1) = 0), recognised by the host: in a field that says z is 0 or 1
+      const uint32_t idx = terms[d.x] & 0xFFFFu;
+      const uint4 lo = lds[2 * idx], hi = lds[2 * idx + 1];
+      wild = hi.w >> 31;
+      bad = ((lo.x >> 1) | lo.y | lo.z | lo.w | hi.x | hi.y | hi.z | (hi.w & 0x7FFFFFFFu)) != 0;
     } else {
-      const Fe az = dot_lds(lds, terms, coefs, d.x, d.y, F, &wild);
-      const Fe bz = dot_lds(lds, terms, coefs, d.x + d.y, d.z, F, &wild);
-      const int as = small01(az), bs = small01(bz);
-      Fe ab;
-      if (as == 0 || bs == 0) {
-#pragma unroll
-        for (int i = 0; i < 8; i++) ab.l[i] = 0;
-      } else if (as == 1) ab = bz;
-      else if (bs == 1) ab = az;
-      else {
+      const uint32_t na = d.y & 0x7FFFFFFFu;
+      const Dot C = dot_lds(lds, terms, coefs, coef_small, d.x + na + d.z, d.w, F, &wild);
+      const Dot A = dot_lds(lds, terms, coefs, coef_small, d.x, na, F, &wild);
+      const Dot B = dot_lds(lds, terms, coefs, coef_small, d.x + na, d.z, F, &wild);
+      if (!A.has_big && !B.has_big && !C.has_big && A.s < lim && A.s > -lim && B.s < lim && B.s > -lim) {
+        // integers all the way: |A * B - C| < 2^127 < p, so "= 0 mod p" is "= 0"  (an empty A or B is 0: linear rows too)
+        bad = A.s * B.s != C.s;
+      } else {
+        const Fe az = dot_value(A, F), bz = dot_value(B, F), cz = dot_value(C, F);
         Fe r2;
 #pragma unroll
         for (int i = 0; i < 8; i++) r2.l[i] = F.r2[i];
-        ab = mont_mul(mont_mul(az, r2, F), bz, F);
+        Fe diff = mont_mul(mont_mul(az, r2, F), bz, F);                              // (az * R) * bz / R = az * bz
+        fe_sub(diff, cz, F.p);
+        bad = !fe_is_zero(diff);
       }
-      Fe diff = ab;
-      fe_sub(diff, cz, F.p);
-      bad = !fe_is_zero(diff);
     }
     if (bad || wild) { nbad++; low = min(low, row_id[r]); }
   }
@@ -355,8 +390,8 @@ __global__ __launch_bounds__(256) void b3w_r1cs_tile_kernel(const uint8_t *__res
 
 extern "C" int b3w_launch_r1cs_tiled(const uint8_t *d_bodies, uint32_t n, uint64_t pitch, uint32_t nwires, uint32_t ntiles, uint32_t max_ext,
                                      const uint32_t *d_tiles, const uint32_t *d_ext, const uint32_t *d_rows, const uint32_t *d_row_id,
-                                     const uint32_t *d_terms, const uint32_t *d_coefs, const B3wField *field, uint32_t *d_violations,
-                                     uint32_t *d_first, hipStream_t stream) {
+                                     const uint32_t *d_terms, const uint32_t *d_coefs, const long long *d_coef_small, const B3wField *field,
+                                     uint32_t *d_violations, uint32_t *d_first, hipStream_t stream) {
   if (!n || !ntiles) return 0;
   if (max_ext > B3W_R1CS_TILE) return -5;
   hipError_t e = hipMemsetAsync(d_violations, 0, (size_t)n * 4, stream);
@@ -369,7 +404,7 @@ extern "C" int b3w_launch_r1cs_tiled(const uint8_t *d_bodies, uint32_t n, uint64
     const uint32_t groups = (nb + 7) / 8;
     hipLaunchKernelGGL(b3w_r1cs_tile_kernel, dim3(groups * 8 * ntiles), dim3(256), smem, stream, d_bodies + (uint64_t)b0 * pitch, pitch, nb,
                        nwires, ntiles, reinterpret_cast<const uint4 *>(d_tiles), d_ext, reinterpret_cast<const uint4 *>(d_rows), d_row_id,
-                       d_terms, d_coefs, *field, d_violations + b0, d_first ? d_first + b0 : nullptr);
+                       d_terms, d_coefs, d_coef_small, *field, d_violations + b0, d_first ? d_first + b0 : nullptr);
     e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
   }
