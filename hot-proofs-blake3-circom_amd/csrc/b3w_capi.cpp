@@ -1028,8 +1028,8 @@ struct b3w_r1cs {
   uint16_t *d_cids = nullptr;
   // tile formulation (b3w_r1cs.hip): used when every tile of B3W_R1CS_TILE wires needs at most that many outside wires
   bool tiled = false;
-  uint32_t ntiles = 0, max_ext = 0;
-  uint32_t *d_tiles = nullptr, *d_ext = nullptr, *d_trows = nullptr, *d_trow_id = nullptr, *d_terms = nullptr;
+  uint32_t ntiles = 0, max_ext = 0, max_tile_terms = 0;
+  uint32_t *d_tiles = nullptr, *d_ext = nullptr, *d_trows = nullptr, *d_trow_id = nullptr, *d_terms = nullptr, *d_tile_terms = nullptr;
   long long *d_coef_small = nullptr;
 };
 
@@ -1195,9 +1195,11 @@ int32_t b3w_r1cs_create(b3w_ctx *ctx, const uint8_t *img, size_t len, b3w_r1cs *
     const uint64_t n64 = (uint64_t)neg[0] | (uint64_t)neg[1] << 32;
     if (!hi && n64 < (1ull << 40)) coef_small[i] = -(long long)n64;
   }
-  std::vector<uint32_t> tdesc(4 * (size_t)ntiles), text, trows, trow_id, tterms;
+  std::vector<uint32_t> tdesc(4 * (size_t)ntiles), ttdesc(2 * (size_t)ntiles), text, trows, trow_id, tterms;
+  uint32_t max_tile_terms = 0;
   if (tiled) {
     for (uint32_t t = 0; t < ntiles; t++) {
+      ttdesc[2 * t] = (uint32_t)tterms.size();
       tdesc[4 * t] = (uint32_t)(trows.size() / 4); tdesc[4 * t + 1] = (uint32_t)tile_rows[t].size();
       tdesc[4 * t + 2] = (uint32_t)text.size(); tdesc[4 * t + 3] = (uint32_t)tile_ext[t].size();
       std::vector<uint32_t> ext(tile_ext[t].size());
@@ -1221,6 +1223,8 @@ int32_t b3w_r1cs_create(b3w_ctx *ctx, const uint8_t *img, size_t len, b3w_r1cs *
           tterms.push_back(idx | (uint32_t)cids[r.off + q] << 16);
         }
       }
+      ttdesc[2 * t + 1] = (uint32_t)tterms.size() - ttdesc[2 * t];
+      max_tile_terms = std::max(max_tile_terms, ttdesc[2 * t + 1]);
     }
   }
   std::vector<uint32_t> coefR(16 * coefs.size());           // per coefficient: plain, then Montgomery form
@@ -1251,8 +1255,10 @@ int32_t b3w_r1cs_create(b3w_ctx *ctx, const uint8_t *img, size_t len, b3w_r1cs *
   up((void **)&r->d_cids, cids.data(), cids.size() * 2);
   up((void **)&r->d_coefR, coefR.data(), coefR.size() * 4);
   r->tiled = tiled; r->ntiles = ntiles; r->max_ext = max_ext;
+  r->max_tile_terms = max_tile_terms;
   if (tiled) {
     up((void **)&r->d_tiles, tdesc.data(), tdesc.size() * 4);
+    up((void **)&r->d_tile_terms, ttdesc.data(), ttdesc.size() * 4);
     up((void **)&r->d_ext, text.data(), text.size() * 4);
     up((void **)&r->d_trows, trows.data(), trows.size() * 4);
     up((void **)&r->d_trow_id, trow_id.data(), trow_id.size() * 4);
@@ -1284,7 +1290,7 @@ void b3w_r1cs_destroy(b3w_r1cs *r) {
   if (r->d_wires) (void)hipFree(r->d_wires);
   if (r->d_cids) (void)hipFree(r->d_cids);
   if (r->d_coefR) (void)hipFree(r->d_coefR);
-  for (uint32_t *q : {r->d_tiles, r->d_ext, r->d_trows, r->d_trow_id, r->d_terms}) if (q) (void)hipFree(q);
+  for (uint32_t *q : {r->d_tiles, r->d_ext, r->d_trows, r->d_trow_id, r->d_terms, r->d_tile_terms}) if (q) (void)hipFree(q);
   if (r->d_coef_small) (void)hipFree(r->d_coef_small);
   delete r;
 }
@@ -1301,7 +1307,7 @@ int32_t b3w_r1cs_check_device(b3w_ctx *ctx, const b3w_r1cs *r, const uint8_t *d_
   ON_DEVICE(ctx);
   static const bool gather_only = getenv("B3W_R1CS_GATHER") && !strcmp(getenv("B3W_R1CS_GATHER"), "1");      // the other kernel, for comparison
   const int rc = r->tiled && !gather_only
-                     ? b3w_launch_r1cs_tiled(d_bodies, n, pitch, r->nwires, r->ntiles, r->max_ext, r->d_tiles, r->d_ext, r->d_trows,
+                     ? b3w_launch_r1cs_tiled(d_bodies, n, pitch, r->nwires, r->ntiles, r->max_ext, r->max_tile_terms, r->d_tiles, r->d_tile_terms, r->d_ext, r->d_trows,
                                              r->d_trow_id, r->d_terms, r->d_coefR, r->d_coef_small, &r->field, d_violations, d_first, (hipStream_t)stream)
                      : b3w_launch_r1cs(d_bodies, n, pitch, r->m, r->d_rows, r->d_row_id, r->d_wires, r->d_cids, r->d_coefR, &r->field,
                                        d_violations, d_first, (hipStream_t)stream);

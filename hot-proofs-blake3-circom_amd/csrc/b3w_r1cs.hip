@@ -322,7 +322,9 @@ __device__ __forceinline__ void stage(uint4 *lds, uint32_t idx, const uint8_t *b
 }
 
 __global__ __launch_bounds__(256) void b3w_r1cs_tile_kernel(const uint8_t *__restrict__ bodies, uint64_t pitch, uint32_t n, uint32_t nwires,
-                                                            uint32_t ntiles, const uint4 *__restrict__ tiles /* row_off, n_rows, ext_off, n_ext */,
+                                                            uint32_t ntiles, uint32_t max_ext, uint32_t lds_terms /* room for a tile's terms, 0: none */,
+                                                            const uint4 *__restrict__ tiles /* row_off, n_rows, ext_off, n_ext */,
+                                                            const uint2 *__restrict__ tile_terms /* term_off, n_terms */,
                                                             const uint32_t *__restrict__ ext_wires, const uint4 *__restrict__ rows,
                                                             const uint32_t *__restrict__ row_id, const uint32_t *__restrict__ terms,
                                                             const uint32_t *__restrict__ coefs, const long long *__restrict__ coef_small, B3wField F,
@@ -339,6 +341,15 @@ __global__ __launch_bounds__(256) void b3w_r1cs_tile_kernel(const uint8_t *__res
   const uint32_t n_local = nwires - t0 < B3W_R1CS_TILE ? nwires - t0 : B3W_R1CS_TILE;
   for (uint32_t i = threadIdx.x; i < n_local; i += 256) stage(lds, i, body, t0 + i, F);
   for (uint32_t j = threadIdx.x; j < td.w; j += 256) stage(lds, B3W_R1CS_TILE + j, body, ext_wires[td.z + j], F);
+  // the tile's term list (5 100 words for these systems) behind the elements: read once, coalesced, instead of one
+  // dependent global load per term on every lane's critical path
+  const uint2 tt = tile_terms[tile];                                               // first term of the tile, how many
+  uint32_t *lterms = reinterpret_cast<uint32_t *>(lds + 2 * (size_t)(B3W_R1CS_TILE + max_ext));
+  const uint32_t term0 = tt.x;
+  const bool staged = lds_terms != 0 && tt.y <= lds_terms;
+  if (staged)
+    for (uint32_t k = threadIdx.x; k < tt.y; k += 256) lterms[k] = terms[term0 + k];
+  const uint32_t *tsrc = staged ? lterms - term0 : terms;                         // indexable by global term offsets either way
   __syncthreads();
   uint32_t nbad = 0, low = 0xFFFFFFFFu;
   // is the constant wire 1?  (wire 0 is element 0 of tile 0 and outside wire 0 of every other tile that mentions it)
@@ -350,15 +361,15 @@ __global__ __launch_bounds__(256) void b3w_r1cs_tile_kernel(const uint8_t *__res
     bool wild = false, bad;
     if ((d.y >> 31) && w0_is_one) {
       // a booleanity row  z * (1 - z) = 0  (or z * (z - 1) = 0), recognised by the host: in a field that says z is 0 or 1
-      const uint32_t idx = terms[d.x] & 0xFFFFu;
+      const uint32_t idx = tsrc[d.x] & 0xFFFFu;
       const uint4 lo = lds[2 * idx], hi = lds[2 * idx + 1];
       wild = hi.w >> 31;
       bad = ((lo.x >> 1) | lo.y | lo.z | lo.w | hi.x | hi.y | hi.z | (hi.w & 0x7FFFFFFFu)) != 0;
     } else {
       const uint32_t na = d.y & 0x7FFFFFFFu;
-      const Dot C = dot_lds(lds, terms, coefs, coef_small, d.x + na + d.z, d.w, F, &wild);
-      const Dot A = dot_lds(lds, terms, coefs, coef_small, d.x, na, F, &wild);
-      const Dot B = dot_lds(lds, terms, coefs, coef_small, d.x + na, d.z, F, &wild);
+      const Dot C = dot_lds(lds, tsrc, coefs, coef_small, d.x + na + d.z, d.w, F, &wild);
+      const Dot A = dot_lds(lds, tsrc, coefs, coef_small, d.x, na, F, &wild);
+      const Dot B = dot_lds(lds, tsrc, coefs, coef_small, d.x + na, d.z, F, &wild);
       if (!A.has_big && !B.has_big && !C.has_big && A.s < lim && A.s > -lim && B.s < lim && B.s > -lim) {
         // integers all the way: |A * B - C| < 2^127 < p, so "= 0 mod p" is "= 0"  (an empty A or B is 0: linear rows too)
         bad = A.s * B.s != C.s;
@@ -389,7 +400,7 @@ __global__ __launch_bounds__(256) void b3w_r1cs_tile_kernel(const uint8_t *__res
 }  // namespace
 
 extern "C" int b3w_launch_r1cs_tiled(const uint8_t *d_bodies, uint32_t n, uint64_t pitch, uint32_t nwires, uint32_t ntiles, uint32_t max_ext,
-                                     const uint32_t *d_tiles, const uint32_t *d_ext, const uint32_t *d_rows, const uint32_t *d_row_id,
+                                     uint32_t max_tile_terms, const uint32_t *d_tiles, const uint32_t *d_tile_terms, const uint32_t *d_ext, const uint32_t *d_rows, const uint32_t *d_row_id,
                                      const uint32_t *d_terms, const uint32_t *d_coefs, const long long *d_coef_small, const B3wField *field,
                                      uint32_t *d_violations, uint32_t *d_first, hipStream_t stream) {
   if (!n || !ntiles) return 0;
@@ -397,13 +408,15 @@ extern "C" int b3w_launch_r1cs_tiled(const uint8_t *d_bodies, uint32_t n, uint64
   hipError_t e = hipMemsetAsync(d_violations, 0, (size_t)n * 4, stream);
   if (e == hipSuccess && d_first) e = hipMemsetAsync(d_first, 0xFF, (size_t)n * 4, stream);
   if (e != hipSuccess) return (int)e;
-  const size_t smem = (size_t)(B3W_R1CS_TILE + max_ext) * 32;
+  size_t smem = (size_t)(B3W_R1CS_TILE + max_ext) * 32;
+  uint32_t lds_terms = 0;                                  // the tile's terms ride along when they fit into 64 KB
+  if (smem + (size_t)max_tile_terms * 4 <= 65536) { lds_terms = max_tile_terms; smem += (size_t)max_tile_terms * 4; }
   const uint32_t slab = (0x7FFFFFFFu / ntiles) & ~7u;
   for (uint32_t b0 = 0; b0 < n; b0 += slab) {
     const uint32_t nb = n - b0 < slab ? n - b0 : slab;
     const uint32_t groups = (nb + 7) / 8;
     hipLaunchKernelGGL(b3w_r1cs_tile_kernel, dim3(groups * 8 * ntiles), dim3(256), smem, stream, d_bodies + (uint64_t)b0 * pitch, pitch, nb,
-                       nwires, ntiles, reinterpret_cast<const uint4 *>(d_tiles), d_ext, reinterpret_cast<const uint4 *>(d_rows), d_row_id,
+                       nwires, ntiles, max_ext, lds_terms, reinterpret_cast<const uint4 *>(d_tiles), reinterpret_cast<const uint2 *>(d_tile_terms), d_ext, reinterpret_cast<const uint4 *>(d_rows), d_row_id,
                        d_terms, d_coefs, d_coef_small, *field, d_violations + b0, d_first ? d_first + b0 : nullptr);
     e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
