@@ -267,6 +267,8 @@ struct Dot {
   bool has_big;
 };
 
+// (terms: term k of the row is terms[off + k]; the caller has already rebased `off` for a term list staged in LDS —
+// no pointer is ever formed outside its array)
 __device__ __forceinline__ Dot dot_lds(const uint4 *lds, const uint32_t *terms /* lds index | cid << 16 */, const uint32_t *coefs,
                                        const long long *coef_small, uint32_t off, uint32_t n, const B3wField &F, bool *wild) {
   Dot d;
@@ -321,8 +323,9 @@ __device__ __forceinline__ void stage(uint4 *lds, uint32_t idx, const uint8_t *b
   lds[2 * idx + 1] = make_uint4(z.l[4], z.l[5], z.l[6], z.l[7] | (wild ? 0x80000000u : 0u));
 }
 
+template <bool STAGED>
 __global__ __launch_bounds__(256) void b3w_r1cs_tile_kernel(const uint8_t *__restrict__ bodies, uint64_t pitch, uint32_t n, uint32_t nwires,
-                                                            uint32_t ntiles, uint32_t max_ext, uint32_t lds_terms /* room for a tile's terms, 0: none */,
+                                                            uint32_t ntiles, uint32_t max_ext,
                                                             const uint4 *__restrict__ tiles /* row_off, n_rows, ext_off, n_ext */,
                                                             const uint2 *__restrict__ tile_terms /* term_off, n_terms */,
                                                             const uint32_t *__restrict__ ext_wires, const uint4 *__restrict__ rows,
@@ -343,13 +346,14 @@ __global__ __launch_bounds__(256) void b3w_r1cs_tile_kernel(const uint8_t *__res
   for (uint32_t j = threadIdx.x; j < td.w; j += 256) stage(lds, B3W_R1CS_TILE + j, body, ext_wires[td.z + j], F);
   // the tile's term list (5 100 words for these systems) behind the elements: read once, coalesced, instead of one
   // dependent global load per term on every lane's critical path
+  // STAGED: the tile's term list (5 100 words for these systems) sits behind the elements — read once, coalesced, instead
+  // of one dependent global load per term on every lane's critical path
   const uint2 tt = tile_terms[tile];                                               // first term of the tile, how many
   uint32_t *lterms = reinterpret_cast<uint32_t *>(lds + 2 * (size_t)(B3W_R1CS_TILE + max_ext));
-  const uint32_t term0 = tt.x;
-  const bool staged = lds_terms != 0 && tt.y <= lds_terms;
-  if (staged)
-    for (uint32_t k = threadIdx.x; k < tt.y; k += 256) lterms[k] = terms[term0 + k];
-  const uint32_t *tsrc = staged ? lterms - term0 : terms;                         // indexable by global term offsets either way
+  if (STAGED)
+    for (uint32_t k = threadIdx.x; k < tt.y; k += 256) lterms[k] = terms[tt.x + k];
+  const uint32_t *tsrc = STAGED ? lterms : terms;
+  const uint32_t tbase = STAGED ? tt.x : 0u;                                      // row offsets are global term numbers
   __syncthreads();
   uint32_t nbad = 0, low = 0xFFFFFFFFu;
   // is the constant wire 1?  (wire 0 is element 0 of tile 0 and outside wire 0 of every other tile that mentions it)
@@ -361,15 +365,16 @@ __global__ __launch_bounds__(256) void b3w_r1cs_tile_kernel(const uint8_t *__res
     bool wild = false, bad;
     if ((d.y >> 31) && w0_is_one) {
       // a booleanity row  z * (1 - z) = 0  (or z * (z - 1) = 0), recognised by the host: in a field that says z is 0 or 1
-      const uint32_t idx = tsrc[d.x] & 0xFFFFu;
+      const uint32_t idx = tsrc[d.x - tbase] & 0xFFFFu;
       const uint4 lo = lds[2 * idx], hi = lds[2 * idx + 1];
       wild = hi.w >> 31;
       bad = ((lo.x >> 1) | lo.y | lo.z | lo.w | hi.x | hi.y | hi.z | (hi.w & 0x7FFFFFFFu)) != 0;
     } else {
       const uint32_t na = d.y & 0x7FFFFFFFu;
-      const Dot C = dot_lds(lds, tsrc, coefs, coef_small, d.x + na + d.z, d.w, F, &wild);
-      const Dot A = dot_lds(lds, tsrc, coefs, coef_small, d.x, na, F, &wild);
-      const Dot B = dot_lds(lds, tsrc, coefs, coef_small, d.x + na, d.z, F, &wild);
+      const uint32_t t0r = d.x - tbase;
+      const Dot C = dot_lds(lds, tsrc, coefs, coef_small, t0r + na + d.z, d.w, F, &wild);
+      const Dot A = dot_lds(lds, tsrc, coefs, coef_small, t0r, na, F, &wild);
+      const Dot B = dot_lds(lds, tsrc, coefs, coef_small, t0r + na, d.z, F, &wild);
       if (!A.has_big && !B.has_big && !C.has_big && A.s < lim && A.s > -lim && B.s < lim && B.s > -lim) {
         // integers all the way: |A * B - C| < 2^127 < p, so "= 0 mod p" is "= 0"  (an empty A or B is 0: linear rows too)
         bad = A.s * B.s != C.s;
@@ -415,9 +420,13 @@ extern "C" int b3w_launch_r1cs_tiled(const uint8_t *d_bodies, uint32_t n, uint64
   for (uint32_t b0 = 0; b0 < n; b0 += slab) {
     const uint32_t nb = n - b0 < slab ? n - b0 : slab;
     const uint32_t groups = (nb + 7) / 8;
-    hipLaunchKernelGGL(b3w_r1cs_tile_kernel, dim3(groups * 8 * ntiles), dim3(256), smem, stream, d_bodies + (uint64_t)b0 * pitch, pitch, nb,
-                       nwires, ntiles, max_ext, lds_terms, reinterpret_cast<const uint4 *>(d_tiles), reinterpret_cast<const uint2 *>(d_tile_terms), d_ext, reinterpret_cast<const uint4 *>(d_rows), d_row_id,
-                       d_terms, d_coefs, d_coef_small, *field, d_violations + b0, d_first ? d_first + b0 : nullptr);
+#define B3W_R1CS_TILE_LAUNCH(STAGED)                                                                                                   \
+    hipLaunchKernelGGL(b3w_r1cs_tile_kernel<STAGED>, dim3(groups * 8 * ntiles), dim3(256), smem, stream, d_bodies + (uint64_t)b0 * pitch, \
+                       pitch, nb, nwires, ntiles, max_ext, reinterpret_cast<const uint4 *>(d_tiles),                                       \
+                       reinterpret_cast<const uint2 *>(d_tile_terms), d_ext, reinterpret_cast<const uint4 *>(d_rows), d_row_id, d_terms,   \
+                       d_coefs, d_coef_small, *field, d_violations + b0, d_first ? d_first + b0 : nullptr)
+    if (lds_terms) B3W_R1CS_TILE_LAUNCH(true); else B3W_R1CS_TILE_LAUNCH(false);
+#undef B3W_R1CS_TILE_LAUNCH
     e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
   }
