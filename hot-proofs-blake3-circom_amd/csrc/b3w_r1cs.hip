@@ -414,8 +414,11 @@ extern "C" int b3w_launch_r1cs_tiled(const uint8_t *d_bodies, uint32_t n, uint64
   if (e == hipSuccess && d_first) e = hipMemsetAsync(d_first, 0xFF, (size_t)n * 4, stream);
   if (e != hipSuccess) return (int)e;
   size_t smem = (size_t)(B3W_R1CS_TILE + max_ext) * 32;
-  uint32_t lds_terms = 0;                                  // the tile's terms ride along when they fit into 64 KB
-  if (smem + (size_t)max_tile_terms * 4 <= 65536) { lds_terms = max_tile_terms; smem += (size_t)max_tile_terms * 4; }
+  // the tile's term list rides along in LDS only while four workgroups still fit a CU (160 KB): measured on blake3_compression,
+  // staging the terms at the price of two workgroups per CU is 4.2 ms per 4 096 bodies against 2.5 ms with the terms read from
+  // global memory (L1/L2 hits) — occupancy hides the term loads better than LDS shortens them
+  uint32_t lds_terms = 0;
+  if (smem + (size_t)max_tile_terms * 4 <= 40 * 1024) { lds_terms = max_tile_terms; smem += (size_t)max_tile_terms * 4; }
   const uint32_t slab = (0x7FFFFFFFu / ntiles) & ~7u;
   for (uint32_t b0 = 0; b0 < n; b0 += slab) {
     const uint32_t nb = n - b0 < slab ? n - b0 : slab;
