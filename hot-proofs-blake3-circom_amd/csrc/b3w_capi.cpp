@@ -1028,7 +1028,7 @@ struct b3w_r1cs {
   uint16_t *d_cids = nullptr;
   // tile formulation (b3w_r1cs.hip): used when every tile of B3W_R1CS_TILE wires needs at most that many outside wires
   bool tiled = false;
-  uint32_t ntiles = 0, max_ext = 0, max_tile_terms = 0;
+  uint32_t ntiles = 0, max_ext = 0, max_tile_terms = 0, ncoef = 0;
   uint32_t *d_tiles = nullptr, *d_ext = nullptr, *d_trows = nullptr, *d_trow_id = nullptr, *d_terms = nullptr, *d_tile_terms = nullptr;
   long long *d_coef_small = nullptr;
 };
@@ -1256,6 +1256,7 @@ int32_t b3w_r1cs_create(b3w_ctx *ctx, const uint8_t *img, size_t len, b3w_r1cs *
   up((void **)&r->d_coefR, coefR.data(), coefR.size() * 4);
   r->tiled = tiled; r->ntiles = ntiles; r->max_ext = max_ext;
   r->max_tile_terms = max_tile_terms;
+  r->ncoef = (uint32_t)coefs.size();
   if (tiled) {
     up((void **)&r->d_tiles, tdesc.data(), tdesc.size() * 4);
     up((void **)&r->d_tile_terms, ttdesc.data(), ttdesc.size() * 4);
@@ -1308,7 +1309,7 @@ int32_t b3w_r1cs_check_device(b3w_ctx *ctx, const b3w_r1cs *r, const uint8_t *d_
   static const bool gather_only = getenv("B3W_R1CS_GATHER") && !strcmp(getenv("B3W_R1CS_GATHER"), "1");      // the other kernel, for comparison
   const int rc = r->tiled && !gather_only
                      ? b3w_launch_r1cs_tiled(d_bodies, n, pitch, r->nwires, r->ntiles, r->max_ext, r->max_tile_terms, r->d_tiles, r->d_tile_terms, r->d_ext, r->d_trows,
-                                             r->d_trow_id, r->d_terms, r->d_coefR, r->d_coef_small, &r->field, d_violations, d_first, (hipStream_t)stream)
+                                             r->d_trow_id, r->d_terms, r->d_coefR, r->d_coef_small, r->ncoef, &r->field, d_violations, d_first, (hipStream_t)stream)
                      : b3w_launch_r1cs(d_bodies, n, pitch, r->m, r->d_rows, r->d_row_id, r->d_wires, r->d_cids, r->d_coefR, &r->field,
                                        d_violations, d_first, (hipStream_t)stream);
   return rc ? hip_fail(ctx, (hipError_t)rc, "r1cs check launch") : B3W_OK;

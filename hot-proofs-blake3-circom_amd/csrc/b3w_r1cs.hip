@@ -323,9 +323,9 @@ __device__ __forceinline__ void stage(uint4 *lds, uint32_t idx, const uint8_t *b
   lds[2 * idx + 1] = make_uint4(z.l[4], z.l[5], z.l[6], z.l[7] | (wild ? 0x80000000u : 0u));
 }
 
-template <bool STAGED>
+template <bool STAGED, bool COEF_LDS>
 __global__ __launch_bounds__(256) void b3w_r1cs_tile_kernel(const uint8_t *__restrict__ bodies, uint64_t pitch, uint32_t n, uint32_t nwires,
-                                                            uint32_t ntiles, uint32_t max_ext,
+                                                            uint32_t ntiles, uint32_t max_ext, uint32_t max_tile_terms, uint32_t ncoef,
                                                             const uint4 *__restrict__ tiles /* row_off, n_rows, ext_off, n_ext */,
                                                             const uint2 *__restrict__ tile_terms /* term_off, n_terms */,
                                                             const uint32_t *__restrict__ ext_wires, const uint4 *__restrict__ rows,
@@ -354,6 +354,11 @@ __global__ __launch_bounds__(256) void b3w_r1cs_tile_kernel(const uint8_t *__res
     for (uint32_t k = threadIdx.x; k < tt.y; k += 256) lterms[k] = terms[tt.x + k];
   const uint32_t *tsrc = STAGED ? lterms : terms;
   const uint32_t tbase = STAGED ? tt.x : 0u;                                      // row offsets are global term numbers
+  // COEF_LDS: the table of small coefficients (80 entries for these systems) too — it is looked up once per term
+  long long *lcoef = reinterpret_cast<long long *>(lterms + (STAGED ? max_tile_terms : 0u) + ((STAGED ? max_tile_terms : 0u) & 1u));
+  if (COEF_LDS)
+    for (uint32_t k = threadIdx.x; k < ncoef; k += 256) lcoef[k] = coef_small[k];
+  const long long *csrc = COEF_LDS ? lcoef : coef_small;
   __syncthreads();
   uint32_t nbad = 0, low = 0xFFFFFFFFu;
   // is the constant wire 1?  (wire 0 is element 0 of tile 0 and outside wire 0 of every other tile that mentions it)
@@ -372,9 +377,9 @@ __global__ __launch_bounds__(256) void b3w_r1cs_tile_kernel(const uint8_t *__res
     } else {
       const uint32_t na = d.y & 0x7FFFFFFFu;
       const uint32_t t0r = d.x - tbase;
-      const Dot C = dot_lds(lds, tsrc, coefs, coef_small, t0r + na + d.z, d.w, F, &wild);
-      const Dot A = dot_lds(lds, tsrc, coefs, coef_small, t0r, na, F, &wild);
-      const Dot B = dot_lds(lds, tsrc, coefs, coef_small, t0r + na, d.z, F, &wild);
+      const Dot C = dot_lds(lds, tsrc, coefs, csrc, t0r + na + d.z, d.w, F, &wild);
+      const Dot A = dot_lds(lds, tsrc, coefs, csrc, t0r, na, F, &wild);
+      const Dot B = dot_lds(lds, tsrc, coefs, csrc, t0r + na, d.z, F, &wild);
       if (!A.has_big && !B.has_big && !C.has_big && A.s < lim && A.s > -lim && B.s < lim && B.s > -lim) {
         // integers all the way: |A * B - C| < 2^127 < p, so "= 0 mod p" is "= 0"  (an empty A or B is 0: linear rows too)
         bad = A.s * B.s != C.s;
@@ -406,8 +411,8 @@ __global__ __launch_bounds__(256) void b3w_r1cs_tile_kernel(const uint8_t *__res
 
 extern "C" int b3w_launch_r1cs_tiled(const uint8_t *d_bodies, uint32_t n, uint64_t pitch, uint32_t nwires, uint32_t ntiles, uint32_t max_ext,
                                      uint32_t max_tile_terms, const uint32_t *d_tiles, const uint32_t *d_tile_terms, const uint32_t *d_ext, const uint32_t *d_rows, const uint32_t *d_row_id,
-                                     const uint32_t *d_terms, const uint32_t *d_coefs, const long long *d_coef_small, const B3wField *field,
-                                     uint32_t *d_violations, uint32_t *d_first, hipStream_t stream) {
+                                     const uint32_t *d_terms, const uint32_t *d_coefs, const long long *d_coef_small, uint32_t ncoef,
+                                     const B3wField *field, uint32_t *d_violations, uint32_t *d_first, hipStream_t stream) {
   if (!n || !ntiles) return 0;
   if (max_ext > B3W_R1CS_TILE) return -5;
   hipError_t e = hipMemsetAsync(d_violations, 0, (size_t)n * 4, stream);
@@ -418,17 +423,23 @@ extern "C" int b3w_launch_r1cs_tiled(const uint8_t *d_bodies, uint32_t n, uint64
   // staging the terms at the price of two workgroups per CU is 4.2 ms per 4 096 bodies against 2.5 ms with the terms read from
   // global memory (L1/L2 hits) — occupancy hides the term loads better than LDS shortens them
   uint32_t lds_terms = 0;
-  if (smem + (size_t)max_tile_terms * 4 <= 40 * 1024) { lds_terms = max_tile_terms; smem += (size_t)max_tile_terms * 4; }
+  if (smem + (size_t)max_tile_terms * 4 <= 40 * 1024) { lds_terms = max_tile_terms; smem += (size_t)max_tile_terms * 4 + 4; }
+  const bool coef_lds = ncoef <= 512;                      // 4 KB at most
+  if (coef_lds) smem = ((smem + 7) & ~(size_t)7) + (size_t)ncoef * 8;
   const uint32_t slab = (0x7FFFFFFFu / ntiles) & ~7u;
   for (uint32_t b0 = 0; b0 < n; b0 += slab) {
     const uint32_t nb = n - b0 < slab ? n - b0 : slab;
     const uint32_t groups = (nb + 7) / 8;
-#define B3W_R1CS_TILE_LAUNCH(STAGED)                                                                                                   \
-    hipLaunchKernelGGL(b3w_r1cs_tile_kernel<STAGED>, dim3(groups * 8 * ntiles), dim3(256), smem, stream, d_bodies + (uint64_t)b0 * pitch, \
-                       pitch, nb, nwires, ntiles, max_ext, reinterpret_cast<const uint4 *>(d_tiles),                                       \
-                       reinterpret_cast<const uint2 *>(d_tile_terms), d_ext, reinterpret_cast<const uint4 *>(d_rows), d_row_id, d_terms,   \
-                       d_coefs, d_coef_small, *field, d_violations + b0, d_first ? d_first + b0 : nullptr)
-    if (lds_terms) B3W_R1CS_TILE_LAUNCH(true); else B3W_R1CS_TILE_LAUNCH(false);
+#define B3W_R1CS_TILE_LAUNCH(STAGED, CL)                                                                                               \
+    hipLaunchKernelGGL((b3w_r1cs_tile_kernel<STAGED, CL>), dim3(groups * 8 * ntiles), dim3(256), smem, stream,                             \
+                       d_bodies + (uint64_t)b0 * pitch, pitch, nb, nwires, ntiles, max_ext, lds_terms, ncoef,                              \
+                       reinterpret_cast<const uint4 *>(d_tiles), reinterpret_cast<const uint2 *>(d_tile_terms), d_ext,                    \
+                       reinterpret_cast<const uint4 *>(d_rows), d_row_id, d_terms, d_coefs, d_coef_small, *field, d_violations + b0,       \
+                       d_first ? d_first + b0 : nullptr)
+    if (lds_terms && coef_lds) B3W_R1CS_TILE_LAUNCH(true, true);
+    else if (lds_terms) B3W_R1CS_TILE_LAUNCH(true, false);
+    else if (coef_lds) B3W_R1CS_TILE_LAUNCH(false, true);
+    else B3W_R1CS_TILE_LAUNCH(false, false);
 #undef B3W_R1CS_TILE_LAUNCH
     e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
