@@ -260,6 +260,9 @@ def main():
         os.environ["B3W_VARIANT"] = str(args.variant)
     m = importlib.import_module("hot-proofs-blake3-circom_amd")
     W = m.workloads
+    # the bench owns its GPU: let the placement search walk as far as it may (the library's default is bounded to 16 x the
+    # buffer so that co-resident allocators are not starved; the first class border of a fresh device can lie 64 GiB in)
+    m.lib().b3w_bodies_configure(160, -1)
     if args.workload == "chain":
         return bench_chain(args, m, torch, dist, dev, world, rank, local_rank)
     circuit, n = args.circuit, args.batch
