@@ -1195,18 +1195,12 @@ int32_t b3w_r1cs_create(b3w_ctx *ctx, const uint8_t *img, size_t len, b3w_r1cs *
     const uint64_t n64 = (uint64_t)neg[0] | (uint64_t)neg[1] << 32;
     if (!hi && n64 < (1ull << 40)) coef_small[i] = -(long long)n64;
   }
-  std::vector<uint32_t> tdesc(4 * (size_t)ntiles), ttdesc(4 * (size_t)ntiles), text, trows, trow_id, tterms;
-  constexpr uint32_t LONG_ROW = 16;                               // terms from which a row is evaluated by 8 lanes together
+  std::vector<uint32_t> tdesc(4 * (size_t)ntiles), ttdesc(2 * (size_t)ntiles), text, trows, trow_id, tterms;
   uint32_t max_tile_terms = 0;
   if (tiled) {
     for (uint32_t t = 0; t < ntiles; t++) {
-      ttdesc[4 * t] = (uint32_t)tterms.size();
-      // short rows first, then the long ones (each group in shape order)
-      std::stable_partition(tile_rows[t].begin(), tile_rows[t].end(), [&](uint32_t k) { return rows[k].na + rows[k].nb + rows[k].nc < LONG_ROW; });
-      uint32_t n_short = 0;
-      for (uint32_t k : tile_rows[t]) if (rows[k].na + rows[k].nb + rows[k].nc < LONG_ROW) n_short++;
-      tdesc[4 * t] = (uint32_t)(trows.size() / 4); tdesc[4 * t + 1] = n_short;
-      ttdesc[4 * t + 2] = tdesc[4 * t] + n_short; ttdesc[4 * t + 3] = (uint32_t)tile_rows[t].size() - n_short;
+      ttdesc[2 * t] = (uint32_t)tterms.size();
+      tdesc[4 * t] = (uint32_t)(trows.size() / 4); tdesc[4 * t + 1] = (uint32_t)tile_rows[t].size();
       tdesc[4 * t + 2] = (uint32_t)text.size(); tdesc[4 * t + 3] = (uint32_t)tile_ext[t].size();
       std::vector<uint32_t> ext(tile_ext[t].size());
       for (const auto &kv : tile_ext[t]) ext[kv.second] = kv.first;
@@ -1229,8 +1223,8 @@ int32_t b3w_r1cs_create(b3w_ctx *ctx, const uint8_t *img, size_t len, b3w_r1cs *
           tterms.push_back(idx | (uint32_t)cids[r.off + q] << 16);
         }
       }
-      ttdesc[4 * t + 1] = (uint32_t)tterms.size() - ttdesc[4 * t];
-      max_tile_terms = std::max(max_tile_terms, ttdesc[4 * t + 1]);
+      ttdesc[2 * t + 1] = (uint32_t)tterms.size() - ttdesc[2 * t];
+      max_tile_terms = std::max(max_tile_terms, ttdesc[2 * t + 1]);
     }
   }
   std::vector<uint32_t> coefR(16 * coefs.size());           // per coefficient: plain, then Montgomery form

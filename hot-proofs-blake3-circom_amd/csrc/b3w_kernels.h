@@ -87,6 +87,6 @@ extern "C" int b3w_launch_r1cs(const uint8_t *d_bodies, uint32_t n, uint64_t pit
 #define B3W_R1CS_TILE 1024u
 #define B3W_R1CS_NOT_SMALL ((long long)0x8000000000000000ull)
 extern "C" int b3w_launch_r1cs_tiled(const uint8_t *d_bodies, uint32_t n, uint64_t pitch, uint32_t nwires, uint32_t ntiles, uint32_t max_ext,
-                                     uint32_t max_tile_terms, const uint32_t *d_tiles, const uint32_t *d_tile_terms /* ntiles x {first term, terms, first long row, long rows}; tiles[].rows counts the short ones */, const uint32_t *d_ext, const uint32_t *d_rows, const uint32_t *d_row_id,
+                                     uint32_t max_tile_terms, const uint32_t *d_tiles, const uint32_t *d_tile_terms /* ntiles x {first term, terms} */, const uint32_t *d_ext, const uint32_t *d_rows, const uint32_t *d_row_id,
                                      const uint32_t *d_terms, const uint32_t *d_coefs, const long long *d_coef_small, uint32_t ncoef,
                                      const B3wField *field, uint32_t *d_violations, uint32_t *d_first, hipStream_t stream);

@@ -270,14 +270,13 @@ struct Dot {
 // (terms: term k of the row is terms[off + k]; the caller has already rebased `off` for a term list staged in LDS —
 // no pointer is ever formed outside its array)
 __device__ __forceinline__ Dot dot_lds(const uint4 *lds, const uint32_t *terms /* lds index | cid << 16 */, const uint32_t *coefs,
-                                       const long long *coef_small, uint32_t off, uint32_t n, const B3wField &F, bool *wild,
-                                       uint32_t first = 0, uint32_t step = 1 /* a lane's share of a row evaluated by several lanes */) {
+                                       const long long *coef_small, uint32_t off, uint32_t n, const B3wField &F, bool *wild) {
   Dot d;
   d.s = 0;
   d.has_big = false;
 #pragma unroll
   for (int i = 0; i < 8; i++) d.big.l[i] = 0;
-  for (uint32_t k = first; k < n; k += step) {
+  for (uint32_t k = 0; k < n; k++) {
     const uint32_t t = terms[off + k];
     const uint32_t cid = t >> 16;
     const uint32_t idx = t & 0xFFFFu;
@@ -305,18 +304,6 @@ __device__ __forceinline__ Dot dot_lds(const uint4 *lds, const uint32_t *terms /
   return d;
 }
 
-// sum of a 128-bit integer over the 8 consecutive lanes of a row group
-__device__ __forceinline__ __int128 group_sum8(__int128 v) {
-#pragma unroll
-  for (int m = 1; m < 8; m <<= 1) {
-    const unsigned __int128 u = (unsigned __int128)v;
-    const uint32_t w0 = (uint32_t)__shfl_xor((int)(uint32_t)u, m), w1 = (uint32_t)__shfl_xor((int)(uint32_t)(u >> 32), m);
-    const uint32_t w2 = (uint32_t)__shfl_xor((int)(uint32_t)(u >> 64), m), w3 = (uint32_t)__shfl_xor((int)(uint32_t)(u >> 96), m);
-    v += (__int128)((unsigned __int128)w0 | (unsigned __int128)w1 << 32 | (unsigned __int128)w2 << 64 | (unsigned __int128)w3 << 96);
-  }
-  return v;
-}
-
 // the whole dot product as a field element: big + s mod p (|s| < 2^127 < p)
 __device__ __forceinline__ Fe dot_value(const Dot &d, const B3wField &F) {
   const bool negative = d.s < 0;
@@ -340,7 +327,7 @@ template <bool STAGED, bool COEF_LDS>
 __global__ __launch_bounds__(256) void b3w_r1cs_tile_kernel(const uint8_t *__restrict__ bodies, uint64_t pitch, uint32_t n, uint32_t nwires,
                                                             uint32_t ntiles, uint32_t max_ext, uint32_t max_tile_terms, uint32_t ncoef,
                                                             const uint4 *__restrict__ tiles /* row_off, n_rows, ext_off, n_ext */,
-                                                            const uint4 *__restrict__ tile_terms /* term_off, n_terms, first long row, long rows */,
+                                                            const uint2 *__restrict__ tile_terms /* term_off, n_terms */,
                                                             const uint32_t *__restrict__ ext_wires, const uint4 *__restrict__ rows,
                                                             const uint32_t *__restrict__ row_id, const uint32_t *__restrict__ terms,
                                                             const uint32_t *__restrict__ coefs, const long long *__restrict__ coef_small, B3wField F,
@@ -361,7 +348,7 @@ __global__ __launch_bounds__(256) void b3w_r1cs_tile_kernel(const uint8_t *__res
   // dependent global load per term on every lane's critical path
   // STAGED: the tile's term list (5 100 words for these systems) sits behind the elements — read once, coalesced, instead
   // of one dependent global load per term on every lane's critical path
-  const uint4 tt = tile_terms[tile];                                               // first term of the tile, how many; its long rows
+  const uint2 tt = tile_terms[tile];                                               // first term of the tile, how many
   uint32_t *lterms = reinterpret_cast<uint32_t *>(lds + 2 * (size_t)(B3W_R1CS_TILE + max_ext));
   if (STAGED)
     for (uint32_t k = threadIdx.x; k < tt.y; k += 256) lterms[k] = terms[tt.x + k];
@@ -378,18 +365,6 @@ __global__ __launch_bounds__(256) void b3w_r1cs_tile_kernel(const uint8_t *__res
   const uint4 one_lo = lds[tile == 0 ? 0 : 2 * B3W_R1CS_TILE], one_hi = lds[(tile == 0 ? 0 : 2 * B3W_R1CS_TILE) + 1];
   const bool w0_is_one = one_lo.x == 1 && (one_lo.y | one_lo.z | one_lo.w | one_hi.x | one_hi.y | one_hi.z | one_hi.w) == 0;
   const __int128 lim = (__int128)1 << 63;
-  auto decide = [&](const Dot &A, const Dot &B, const Dot &C) -> bool {
-    if (!A.has_big && !B.has_big && !C.has_big && A.s < lim && A.s > -lim && B.s < lim && B.s > -lim)
-      return A.s * B.s != C.s;       // integers all the way: |A * B - C| < 2^127 < p, so "= 0 mod p" is "= 0" (an empty A or B is 0)
-    const Fe az = dot_value(A, F), bz = dot_value(B, F), cz = dot_value(C, F);
-    Fe r2;
-#pragma unroll
-    for (int i = 0; i < 8; i++) r2.l[i] = F.r2[i];
-    Fe diff = mont_mul(mont_mul(az, r2, F), bz, F);                                  // (az * R) * bz / R = az * bz
-    fe_sub(diff, cz, F.p);
-    return !fe_is_zero(diff);
-  };
-  // ---- short rows: one lane each
   for (uint32_t r = td.x + threadIdx.x; r < td.x + td.y; r += 256) {
     const uint4 d = rows[r];
     bool wild = false, bad;
@@ -405,41 +380,20 @@ __global__ __launch_bounds__(256) void b3w_r1cs_tile_kernel(const uint8_t *__res
       const Dot C = dot_lds(lds, tsrc, coefs, csrc, t0r + na + d.z, d.w, F, &wild);
       const Dot A = dot_lds(lds, tsrc, coefs, csrc, t0r, na, F, &wild);
       const Dot B = dot_lds(lds, tsrc, coefs, csrc, t0r + na, d.z, F, &wild);
-      bad = decide(A, B, C);
+      if (!A.has_big && !B.has_big && !C.has_big && A.s < lim && A.s > -lim && B.s < lim && B.s > -lim) {
+        // integers all the way: |A * B - C| < 2^127 < p, so "= 0 mod p" is "= 0"  (an empty A or B is 0: linear rows too)
+        bad = A.s * B.s != C.s;
+      } else {
+        const Fe az = dot_value(A, F), bz = dot_value(B, F), cz = dot_value(C, F);
+        Fe r2;
+#pragma unroll
+        for (int i = 0; i < 8; i++) r2.l[i] = F.r2[i];
+        Fe diff = mont_mul(mont_mul(az, r2, F), bz, F);                              // (az * R) * bz / R = az * bz
+        fe_sub(diff, cz, F.p);
+        bad = !fe_is_zero(diff);
+      }
     }
     if (bad || wild) { nbad++; low = min(low, row_id[r]); }
-  }
-  // ---- long rows (16 terms or more: the 32-bit recompositions): 8 lanes each, a lane takes every 8th term; the partial
-  // sums meet through three shuffle steps.  One lane working through 34 terms alone was half of the kernel's time.
-  const uint32_t grp = threadIdx.x >> 3, gl = threadIdx.x & 7u;
-  for (uint32_t base = 0; base < tt.w; base += 32) {                                // (uniform trip count: every lane shuffles)
-    const uint32_t li = base + grp;
-    const bool have = li < tt.w;
-    const uint32_t r = tt.z + (have ? li : 0u);
-    const uint4 d = have ? rows[r] : make_uint4(0, 0, 0, 0);
-    const uint32_t na = d.y & 0x7FFFFFFFu, t0r = d.x - (have ? tbase : 0u);
-    bool wild = false;
-    Dot C = dot_lds(lds, tsrc, coefs, csrc, t0r + na + d.z, d.w, F, &wild, gl, 8);
-    Dot A = dot_lds(lds, tsrc, coefs, csrc, t0r, na, F, &wild, gl, 8);
-    Dot B = dot_lds(lds, tsrc, coefs, csrc, t0r + na, d.z, F, &wild, gl, 8);
-    A.s = group_sum8(A.s); B.s = group_sum8(B.s); C.s = group_sum8(C.s);
-    int flags = (wild ? 1 : 0) | (A.has_big || B.has_big || C.has_big ? 2 : 0);
-#pragma unroll
-    for (int m = 1; m < 8; m <<= 1) flags |= __shfl_xor(flags, m);
-    if (have && gl == 0) {
-      bool bad;
-      if (flags & 2) {                                                              // a wide element or coefficient: this lane alone, exactly
-        bool w2 = false;
-        const Dot C1 = dot_lds(lds, tsrc, coefs, csrc, t0r + na + d.z, d.w, F, &w2);
-        const Dot A1 = dot_lds(lds, tsrc, coefs, csrc, t0r, na, F, &w2);
-        const Dot B1 = dot_lds(lds, tsrc, coefs, csrc, t0r + na, d.z, F, &w2);
-        bad = decide(A1, B1, C1);
-      } else {
-        A.has_big = B.has_big = C.has_big = false;
-        bad = decide(A, B, C);
-      }
-      if (bad || (flags & 1)) { nbad++; low = min(low, row_id[r]); }
-    }
   }
   // one atomic per wave
 #pragma unroll
@@ -479,7 +433,7 @@ extern "C" int b3w_launch_r1cs_tiled(const uint8_t *d_bodies, uint32_t n, uint64
 #define B3W_R1CS_TILE_LAUNCH(STAGED, CL)                                                                                               \
     hipLaunchKernelGGL((b3w_r1cs_tile_kernel<STAGED, CL>), dim3(groups * 8 * ntiles), dim3(256), smem, stream,                             \
                        d_bodies + (uint64_t)b0 * pitch, pitch, nb, nwires, ntiles, max_ext, lds_terms, ncoef,                              \
-                       reinterpret_cast<const uint4 *>(d_tiles), reinterpret_cast<const uint4 *>(d_tile_terms), d_ext,                    \
+                       reinterpret_cast<const uint4 *>(d_tiles), reinterpret_cast<const uint2 *>(d_tile_terms), d_ext,                    \
                        reinterpret_cast<const uint4 *>(d_rows), d_row_id, d_terms, d_coefs, d_coef_small, *field, d_violations + b0,       \
                        d_first ? d_first + b0 : nullptr)
     if (lds_terms && coef_lds) B3W_R1CS_TILE_LAUNCH(true, true);
