@@ -1059,9 +1059,23 @@ void to_montgomery_host(uint32_t x[8], const uint32_t p[8]) {
 
 extern "C" {
 
+static int32_t r1cs_create_impl(b3w_ctx *ctx, const uint8_t *img, size_t len, b3w_r1cs **out);
+
 int32_t b3w_r1cs_create(b3w_ctx *ctx, const uint8_t *img, size_t len, b3w_r1cs **out) {
   if (!ctx || !img || !out) return B3W_E_BAD_ARGUMENT;
   *out = nullptr;
+  try {                                                   // the image is untrusted input: no exception may cross the C boundary
+    return r1cs_create_impl(ctx, img, len, out);
+  } catch (const std::bad_alloc &) {
+    ctx->last_error = "r1cs: not enough host memory for this image";
+    return B3W_E_NOT_ENOUGH_MEMORY;
+  } catch (...) {
+    ctx->last_error = "r1cs: malformed image";
+    return B3W_E_BAD_ARGUMENT;
+  }
+}
+
+static int32_t r1cs_create_impl(b3w_ctx *ctx, const uint8_t *img, size_t len, b3w_r1cs **out) {
   auto bad = [&](const char *why) { ctx->last_error = std::string("r1cs: ") + why; return B3W_E_BAD_ARGUMENT; };
   // iden3 r1cs binary format v1: "r1cs" | u32 version | u32 nSections | { u32 type | u64 size | body }*
   ByteReader rd(img, len);
@@ -1089,6 +1103,7 @@ int32_t b3w_r1cs_create(b3w_ctx *ctx, const uint8_t *img, size_t len, b3w_r1cs *
   const uint32_t m = h.u32();
   if (!h.ok) return bad("truncated header");
   if (nwires != ctx->desc.nwit) return bad("nWires differs from this circuit's witness size");
+  if ((uint64_t)m * 12 > cons_len) return bad("more constraints announced than the constraint section can hold");
   // constraints: A, B, C as (u32 wire, 32-byte LE coefficient) lists; distinct coefficients are tabulated
   uint32_t P[8];
   memcpy(P, ctx->desc.prime, 32);

@@ -254,3 +254,34 @@ print(json.dumps(out))
     for circuit in res["0"]:
         viol = res["0"][circuit][0]
         assert all(v == 0 for v in viol[1::2]) and all(v > 0 for v in viol[0::2]), circuit
+
+
+def test_mutated_images_never_crash_the_parser(env):
+    """The .r1cs image is untrusted input: 400 random mutations of the derived file (truncations, flipped header and count
+    bytes, absurd constraint counts) are either refused with an error text or load as a (different) system — no exception
+    crosses the C boundary, nothing is read out of bounds."""
+    m, ctx = env["m"], env["ctx"]
+    img = bytearray(R.read_image())
+    rng = random.Random(99)
+    refused = loaded = 0
+    for k in range(400):
+        bad = bytearray(img)
+        kind = k % 4
+        if kind == 0:
+            bad = bad[:rng.randrange(0, len(bad))]
+        elif kind == 1:                                    # the header section (after the 12-byte preamble and its 12-byte section head)
+            for _ in range(rng.randrange(1, 4)):
+                bad[rng.randrange(0, 100)] = rng.randrange(256)
+        elif kind == 2:                                    # a term count or wire index somewhere in the constraints
+            pos = rng.randrange(100, len(bad) - 4)
+            bad[pos:pos + 4] = rng.randrange(1 << 32).to_bytes(4, "little")
+        else:                                              # mConstraints: absurdly large
+            bad[24 + 36 + 24:24 + 36 + 28] = rng.choice([0xFFFFFFFF, 0x7FFFFFFF, 1 << 30]).to_bytes(4, "little")
+        try:
+            r = m.R1cs(ctx, bytes(bad))
+            r.close()
+            loaded += 1
+        except m.B3WError as e:
+            assert e.status in (100, 5) and "r1cs" in str(e), str(e)
+            refused += 1
+    assert refused >= 300 and refused + loaded == 400
