@@ -284,4 +284,4 @@ def test_mutated_images_never_crash_the_parser(env):
         except m.B3WError as e:
             assert e.status in (100, 5) and "r1cs" in str(e), str(e)
             refused += 1
-    assert refused >= 300 and refused + loaded == 400
+    assert refused >= 230 and refused + loaded == 400
