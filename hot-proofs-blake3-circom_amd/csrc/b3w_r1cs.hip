@@ -407,7 +407,22 @@ __global__ __launch_bounds__(256) void b3w_r1cs_tile_kernel(const uint8_t *__res
   }
 }
 
+// the result arrays start from "no violation": a kernel rather than hipMemsetAsync, so that the whole check is made of
+// kernel nodes when a caller captures it into a hipGraph (memset nodes of a captured graph were seen to leave garbage)
+__global__ void b3w_r1cs_init_kernel(uint32_t *__restrict__ violations, uint32_t *__restrict__ first, uint32_t n) {
+  const uint32_t i = blockIdx.x * 256 + threadIdx.x;
+  if (i < n) {
+    violations[i] = 0;
+    if (first) first[i] = 0xFFFFFFFFu;
+  }
+}
+
 }  // namespace
+
+static int r1cs_init_results(uint32_t *d_violations, uint32_t *d_first, uint32_t n, hipStream_t stream) {
+  hipLaunchKernelGGL(b3w_r1cs_init_kernel, dim3((n + 255) / 256), dim3(256), 0, stream, d_violations, d_first, n);
+  return (int)hipGetLastError();
+}
 
 extern "C" int b3w_launch_r1cs_tiled(const uint8_t *d_bodies, uint32_t n, uint64_t pitch, uint32_t nwires, uint32_t ntiles, uint32_t max_ext,
                                      uint32_t max_tile_terms, const uint32_t *d_tiles, const uint32_t *d_tile_terms, const uint32_t *d_ext, const uint32_t *d_rows, const uint32_t *d_row_id,
@@ -415,8 +430,7 @@ extern "C" int b3w_launch_r1cs_tiled(const uint8_t *d_bodies, uint32_t n, uint64
                                      const B3wField *field, uint32_t *d_violations, uint32_t *d_first, hipStream_t stream) {
   if (!n || !ntiles) return 0;
   if (max_ext > B3W_R1CS_TILE) return -5;
-  hipError_t e = hipMemsetAsync(d_violations, 0, (size_t)n * 4, stream);
-  if (e == hipSuccess && d_first) e = hipMemsetAsync(d_first, 0xFF, (size_t)n * 4, stream);
+  hipError_t e = (hipError_t)r1cs_init_results(d_violations, d_first, n, stream);
   if (e != hipSuccess) return (int)e;
   size_t smem = (size_t)(B3W_R1CS_TILE + max_ext) * 32;
   // the tile's term list rides along in LDS only while four workgroups still fit a CU (160 KB): measured on blake3_compression,
@@ -451,8 +465,7 @@ extern "C" int b3w_launch_r1cs(const uint8_t *d_bodies, uint32_t n, uint64_t pit
                                const uint32_t *d_row_id, const uint32_t *d_wires, const uint16_t *d_cids, const uint32_t *d_coefR,
                                const B3wField *field, uint32_t *d_violations, uint32_t *d_first, hipStream_t stream) {
   if (!n || !m) return 0;
-  hipError_t e = hipMemsetAsync(d_violations, 0, (size_t)n * 4, stream);
-  if (e == hipSuccess && d_first) e = hipMemsetAsync(d_first, 0xFF, (size_t)n * 4, stream);
+  hipError_t e = (hipError_t)r1cs_init_results(d_violations, d_first, n, stream);
   if (e != hipSuccess) return (int)e;
   const uint32_t row_blocks = (m + 255) / 256;
   // one-dimensional grid, bodies in slabs that keep the workgroup count below 2^31

@@ -179,7 +179,10 @@ int32_t b3w_r1cs_create(b3w_ctx *ctx, const uint8_t *r1cs_image, size_t len, b3w
 int32_t b3w_r1cs_info(const b3w_r1cs *r1cs, uint32_t *n_constraints, uint32_t *n_wires, uint64_t *n_terms,
                       uint32_t *n_pub_out, uint32_t *n_pub_in, uint32_t *n_prv_in);
 void b3w_r1cs_destroy(b3w_r1cs *r1cs);
-/* d_bodies 16-byte aligned, pitch a multiple of 16 (0 = witness_size * 32). */
+/* d_bodies 16-byte aligned, pitch a multiple of 16 (0 = witness_size * 32).
+ * Stream capture: b3w_batch_run_device, b3w_batch_verify_device and b3w_r1cs_check_device only enqueue kernels on `stream`
+ * (no allocation, no synchronisation, no memset nodes), so a caller may capture a loop of small batches into a hipGraph and
+ * replay it (tests/test_gpu_graph_capture.py); b3w_batch_commit_device too once its scratch has grown to the batch size. */
 int32_t b3w_r1cs_check_device(b3w_ctx *ctx, const b3w_r1cs *r1cs, const uint8_t *d_bodies, uint32_t n, uint64_t pitch,
                               uint32_t *d_violations, uint32_t *d_first, void *stream);
 /* The same on the witnesses of the last b3w_batch_run; host arrays of n entries (host_first may be NULL). */
