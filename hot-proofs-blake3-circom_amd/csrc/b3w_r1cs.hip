@@ -10,7 +10,8 @@
 //
 // Arithmetic: full 256-bit field elements, eight 32-bit limbs, Montgomery multiplication (CIOS) with the modulus passed
 // at run time (BN254 scalar field or the Vesta base field).  A term coef * z[wire] is montmul(coef * R, z) = coef * z;
-// coefficients +1 / -1 (93 % of the terms of the compression system) are an addition / subtraction.
+// coefficients +1 / -1 (93 % of the terms of the compression system) are an addition / subtraction.  The tile kernel adds
+// an exact integer fast path in front of that (small coefficients times small elements summed in 128 bits, see dot_lds).
 //
 // TWO KERNELS, same arithmetic.  The TILE kernel (the one that runs whenever the system allows it) exploits that circom
 // constraints are local: a workgroup takes (body, tile of 1 024 consecutive wires), streams the tile from HBM into LDS
@@ -248,17 +249,9 @@ __global__ __launch_bounds__(256) void b3w_r1cs_kernel(const uint8_t *__restrict
 // LDS image of a workgroup: element i < n_local = wire tile * TILE + i, element TILE + j = outside wire ext[j]; 32 bytes each,
 // reduced mod p at load time; bit 255 (never set in a reduced element of these fields: p < 2^255) marks an element that was
 // NOT canonical in the body.
-__device__ __forceinline__ Fe lds_z(const uint4 *lds, uint32_t idx, bool *wild) {
-  const uint4 lo = lds[2 * idx], hi = lds[2 * idx + 1];
-  Fe z;
-  z.l[0] = lo.x; z.l[1] = lo.y; z.l[2] = lo.z; z.l[3] = lo.w;
-  z.l[4] = hi.x; z.l[5] = hi.y; z.l[6] = hi.z; z.l[7] = hi.w & 0x7FFFFFFFu;
-  *wild = *wild || (hi.w >> 31);
-  return z;
-}
 
 // <row, z> out of LDS, in two parts: `s` collects every term whose coefficient is a small signed integer (|c| < 2^40:
-// +-1, +-2^i, the IV words ... — all but none of the coefficients of these circuits) and whose element is below 2^64, as an
+// +-1, +-2^i, the IV words ... — every coefficient of these circuits) and whose element is below 2^64, as an
 // exact 128-bit integer (a row has < 2^20 terms: no overflow); `big` (mod p) collects the rest — the general Montgomery
 // path, any field element.  A valid witness of these circuits never leaves the integer part.
 struct Dot {
