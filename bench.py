@@ -167,6 +167,25 @@ def bench_chain(args, m, torch, dist, dev, world, rank, local_rank):
     elapsed = time.perf_counter() - t0
     assert int(out["status"].abs().sum().item()) == 0
     local_steps = out["n_leaf_steps"] + out["n_parent_steps"]
+    # untimed: one more pass over the first MiB (at most) of the preimage whose consumer checks EVERY step witness against the
+    # step circuit's rank-1 constraints while it sits in the ring
+    verification = "none"
+    if circuit in m.BUILTIN_R1CS and commit_only is None:
+        r1cs = m.R1cs(ctx)
+        vsteps = [0]
+        d_viol = torch.zeros(16384, dtype=torch.int32, device=dev)
+        d_sum = torch.zeros(1, dtype=torch.int64, device=dev)
+
+        def check(view, first, k):
+            r1cs.check_device(view.data_ptr(), k, view.stride(0), d_viol.data_ptr(), 0, torch.cuda.current_stream().cuda_stream)
+            d_sum.add_(d_viol[:k].to(torch.int64).sum())
+            vsteps[0] += k
+        m.chain.fold_witnesses(ctx, host[:min(nbytes, 1 << 20)].clone().pin_memory() if nbytes > (1 << 20) else host, batch_steps=16384, ring=2,
+                               consumer=check)
+        torch.cuda.synchronize()
+        assert int(d_sum.item()) == 0, "a step witness violates the step circuit's rank-1 constraints"
+        verification = f"r1cs: 0 of {r1cs.n_constraints} constraints violated by any of {vsteps[0]} step witnesses of the first MiB (rank 0's share)"
+        r1cs.close()
     if key is not None:
         assert int(d_st[:local_steps].abs().sum().item()) == 0 and int(d_pts[:local_steps].max(dim=1).values.min().item()) > 0
     t = torch.tensor([elapsed, float(local_steps)], dtype=torch.float64, device=dev)
@@ -187,7 +206,7 @@ def bench_chain(args, m, torch, dist, dev, world, rank, local_rank):
                                    f"(LE stream of LCG(1)) -> {int(total_steps)} nova steps ({circuit}), "
                                    "planner + witness kernels, bodies through a 2-deep ring, H2D overlapped",
                        "circuit": circuit, "n_chunks": out["n_chunks"], "path_len": out["path_len"],
-                       "placement": placements[0], "placement_per_rank": placements,
+                       "placement": placements[0], "placement_per_rank": placements, "verification": verification,
                        "exchange": f"all_gather of chunk chaining values over {dist.get_world_size()} ranks "
                                    f"({dist.get_backend()})" if world > 1 else "none",
                        "consumer": "none" if key is None else f"Pedersen commitment of every step witness on the device ({key.window}-bit windows)"

@@ -316,17 +316,18 @@ class BodyBuffer:
 
 
 R1CS_DIR = os.path.join(PKG_DIR, "constraints")
-# derived from the circuit text by tools/gen_r1cs.py (the builds whose simplification — aliases and constants only — can be
-# restated exactly; the O2 nova builds went through circom's linear elimination and have no derived system)
-BUILTIN_R1CS = {"compression": "blake3_compression.r1cs.gz", "nova_bn254_o1": "blake3_nova_bn254_o1.r1cs.gz"}
+# derived from the circuit text by tools/gen_r1cs.py: the two builds whose simplification (aliases and constants only) is
+# restated exactly, and the two O2 builds, whose wires are found by aligning the reference's O2 witnesses with its O1
+# witnesses on the same inputs and whose system is the O1 system with the missing wires eliminated
+BUILTIN_R1CS = {"compression": "blake3_compression.r1cs.gz", "nova_bn254_o1": "blake3_nova_bn254_o1.r1cs.gz",
+                "nova_bn254": "blake3_nova_bn254.r1cs.gz", "nova_vesta": "blake3_nova_vesta.r1cs.gz"}
 
 
 class R1cs:
     """A rank-1 constraint system on the device (b3w_r1cs_create) for on-device satisfaction checks of witness bodies
     — the counterpart of circom_tester's expectPass (test/blake3_hash.test.ts:36) / synthesize_with_vec's constraints
     (rust_fold/src/utils.rs:17-88).  `image`: bytes of an iden3 .r1cs file, or a path to one (.r1cs or .r1cs.gz);
-    None = the system this package derives for the circuit (blake3_compression and the circomkit nova build; the reference
-    ships no .r1cs)."""
+    None = the system this package derives for the circuit (all four committed builds; the reference ships no .r1cs)."""
 
     def __init__(self, ctx, image=None):
         self.ctx = ctx

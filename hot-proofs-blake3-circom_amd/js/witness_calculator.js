@@ -195,10 +195,11 @@ class WitnessCalculator {
 
   // ---- extension: the constraint system batch.checkConstraints() evaluates (what circom_tester's expectPass does with a
   // witness, test/blake3_hash.test.ts:36).  image: the bytes of an iden3 .r1cs file (.gz accepted) over this circuit's field
-  // and witness size; omitted: the system this package derives from the circuit text (blake3_compression, the circomkit nova build).
+  // and witness size; omitted: the system this package derives for the circuit (all four committed builds).
   loadR1cs(image) {
     if (image === undefined) {
-      const builtin = {compression: "blake3_compression.r1cs.gz", nova_bn254_o1: "blake3_nova_bn254_o1.r1cs.gz"}[this.circuit];
+      const builtin = {compression: "blake3_compression.r1cs.gz", nova_bn254_o1: "blake3_nova_bn254_o1.r1cs.gz",
+                       nova_bn254: "blake3_nova_bn254.r1cs.gz", nova_vesta: "blake3_nova_vesta.r1cs.gz"}[this.circuit];
       if (!builtin) throw new Error("no derived constraint system for " + this.circuit + ": pass the circuit's .r1cs");
       image = require("fs").readFileSync(path.join(__dirname, "..", "constraints", builtin));
     }

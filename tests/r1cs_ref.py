@@ -8,6 +8,8 @@ import b3w_testlib as T
 
 BUILTIN = os.path.join(T.PKG_DIR, "constraints", "blake3_compression.r1cs.gz")
 BUILTIN_NOVA_O1 = os.path.join(T.PKG_DIR, "constraints", "blake3_nova_bn254_o1.r1cs.gz")
+BUILTIN_NOVA_O2 = {"nova_bn254": os.path.join(T.PKG_DIR, "constraints", "blake3_nova_bn254.r1cs.gz"),
+                   "nova_vesta": os.path.join(T.PKG_DIR, "constraints", "blake3_nova_vesta.r1cs.gz")}
 
 
 def read_image(path=BUILTIN):

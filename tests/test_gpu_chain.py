@@ -255,6 +255,14 @@ def test_config5_one_gib_preimage_full_size():
     assert bad == 0
     for k, (s, body) in enumerate(grabbed):
         assert np.array_equal(body.cpu().numpy(), want[k]), s
+    # ... and satisfy every constraint of the nova step circuit (derived system of the Vesta O2 build, on the device)
+    r1cs = m.R1cs(ctx)
+    stack = torch.stack([b for _, b in grabbed])
+    viol = torch.full((len(grabbed),), -1, dtype=torch.int32, device=dev)
+    r1cs.check_device(stack.data_ptr(), len(grabbed), stack.stride(0), viol.data_ptr(), 0, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert int(viol.abs().sum().item()) == 0
+    r1cs.close()
     assert min(steps) < batch and max(steps) >= n_leaf + n_par - batch and any(s < n_leaf for s in steps) and any(s >= n_leaf for s in steps)
     ctx.close()
 

@@ -124,3 +124,48 @@ def test_nova_generator_reproduces_the_committed_file(tmp_path):
     assert r.returncode == 0, r.stderr[-1500:]
     assert "24614 wires = the WASM's witness size" in r.stdout and "reference-WASM witnesses (accepted goldens) satisfy all" in r.stdout
     assert out.read_bytes() == open(R.BUILTIN_NOVA_O1, "rb").read()
+
+
+# ---- the two O2 builds (BN254 and Vesta, 23 291 wires): wires by aligning the reference's O2 witnesses with its O1 witnesses,
+# system = the O1 system with the missing wires eliminated through its linear constraints (tools/gen_r1cs.py --circuit nova_o2)
+@pytest.mark.parametrize("circuit", ["nova_bn254", "nova_vesta"])
+def test_nova_o2_systems_against_reference_witnesses_and_corruptions(circuit):
+    s = R.parse(R.read_image(R.BUILTIN_NOVA_O2[circuit]))
+    assert s["prime"] == T.PRIME[circuit] and s["n_wires"] == 23291 == T.NWIT[circuit] and len(s["constraints"]) == 25067 - (24614 - 23291)
+    assert (s["n_pub_out"], s["n_pub_in"], s["n_prv_in"]) == (15, 12, 20)
+    used = set()
+    for a, b, c in s["constraints"]:
+        used |= a.keys() | b.keys() | c.keys()
+    assert used == set(range(23291)), "every witness slot is read by some constraint"
+    # complete witnesses of the reference WASM held as fixtures (a leaf step and a parent step)
+    for name in (f"{circuit}.config3_0.wtns.gz", f"{circuit}.config3_3.wtns.gz"):
+        z = R.body_to_ints(T.golden_image(name)[76:])
+        assert len(z) == 23291 and R.violated(s, z) == [], name
+    g = T.golden(circuit)
+    ok = [c for c in g["cases"] if "error" not in c]
+    picks = ok[:2] + [c for c in ok if c["name"].startswith("directed")][:3] + [c for c in ok if not T.is_canonical_u32(circuit, c["input"])][:2]
+    by_wire = R.rows_of_wire(s)
+    rng = random.Random(13)
+    p = s["prime"]
+    for case in picks:
+        rc, body, _ = T.oracle_witness(circuit, T.normalize_input(circuit, case["input"]))
+        assert rc == 0 and T.sha256(body) == case["body_sha256"]      # the oracle's body is the reference WASM's
+        z = R.body_to_ints(body)
+        assert R.violated(s, z) == [], case["name"]
+        for _ in range(60):
+            w = rng.randrange(23291)
+            old = z[w]
+            z[w] = rng.choice([old ^ 1, (old + 1) % p, rng.randrange(p), 0 if old else 2])
+            if z[w] != old:
+                assert R.violated(s, z, by_wire[w]), (case["name"], w)
+            z[w] = old
+
+
+def test_nova_o2_generator_reproduces_the_committed_files(tmp_path):
+    if not os.path.isdir("/root/reference") or os.environ.get("B3W_SLOW_TESTS") != "1":
+        pytest.skip("runs three reference WASMs over 580 probe inputs (7 minutes): B3W_SLOW_TESTS=1 in the build container")
+    r = subprocess.run([sys.executable, os.path.join(T.ROOT, "tools", "gen_r1cs.py"), "--circuit", "nova_o2", "--outdir", str(tmp_path)],
+                       capture_output=True, text=True, timeout=1800)
+    assert r.returncode == 0, r.stderr[-1500:]
+    for circuit, path in R.BUILTIN_NOVA_O2.items():
+        assert (tmp_path / os.path.basename(path)).read_bytes() == open(path, "rb").read(), circuit

@@ -763,16 +763,156 @@ def summary(cons):
     return kinds, sum(len(a) + len(b) + len(cc) for a, b, cc in cons)
 
 
-def wasm_witnesses(wasm, inputs):
-    """witnesses of the reference WASM under its own loader (tools/wasm_oracle.js), as lists of ints"""
+def wasm_witnesses(wasm, inputs, allow_rejects=False):
+    """witnesses of the reference WASM under its own loader (tools/wasm_oracle.js), as lists of ints (None for an input the
+    circuit rejects, when allowed)"""
+    def strs(x):
+        return [strs(y) for y in x] if isinstance(x, list) else str(x)
     with tempfile.TemporaryDirectory() as td:
-        json.dump(inputs, open(os.path.join(td, "in.json"), "w"))
+        json.dump([{k: strs(v) for k, v in inp.items()} for inp in inputs], open(os.path.join(td, "in.json"), "w"))
         subprocess.check_call(["node", os.path.join(ROOT, "tools", "wasm_oracle.js"), wasm, os.path.join(td, "in.json"), os.path.join(td, "out.bin")])
         meta = json.load(open(os.path.join(td, "out.bin.err.json")))
-        assert not meta["errors"], meta["errors"]
+        assert allow_rejects or not meta["errors"], meta["errors"]
         raw = open(os.path.join(td, "out.bin"), "rb").read()
     n = meta["witnessSize"]
-    return [[int.from_bytes(raw[(k * n + i) * 32:(k * n + i + 1) * 32], "little") for i in range(n)] for k in range(len(inputs))]
+    rejected = {int(k) for k in meta["errors"]}
+    return [None if k in rejected else [int.from_bytes(raw[(k * n + i) * 32:(k * n + i + 1) * 32], "little") for i in range(n)]
+            for k in range(len(inputs))]
+
+
+# ------------------------------------------------------------------ the O2 builds of blake3_nova (BN254 and Vesta, 23 291 wires)
+# circom's full simplification (the default, --O2) goes on after the O1 step: it eliminates one signal per linear constraint
+# by substitution.  WHICH signal goes is decided inside the compiler and cannot be restated from the circuit text — but the
+# reference holds both builds of the same circuit, and a kept signal keeps its value and its place in the id order.  So the
+# wires of the O2 build are found by running BOTH committed WASMs on the same probe inputs: every O2 slot carries the value
+# column of an O1 wire, in increasing wire order (an order-preserving alignment exists and is taken greedily; where several
+# O1 wires carry the same column on every probe they are equal by the constraints themselves — bit decompositions of one
+# word — or the probes below tell them apart).  The O1 wires that found no O2 slot are then eliminated from the O1 system
+# through its own linear constraints (sparse Gaussian elimination over the field), which leaves the O2 build's constraint
+# system up to row operations.  Nothing of this repository's kernels, slot tables or oracle enters.
+def nova_probes(seed=20260105):
+    """valid nova steps that exercise every signal: random leaf / parent steps with full-range words, 64-bit chunk indices
+    and large depths; for every i in [0, 64) a step with depth = total_depth - i - 2 (eqs[i] fires) for both values of bit i
+    of the chunk index, as a leaf and as a parent; first / last / middle blocks; roots; message words outside [0, 2^32)
+    where the circuit accepts them."""
+    import random
+    rng = random.Random(seed)
+
+    def step(directed=None, parent=None, wide=False):
+        n_blocks = rng.randint(1, 16)
+        kind = rng.randint(0, 3)
+        block_count = 0 if kind == 0 else n_blocks - 1 if kind == 1 else rng.randint(0, 40)
+        depth = rng.choice([0, 0, 1, 2, 3, rng.randint(0, 60), rng.randint(0, 250)])
+        par = rng.random() < 0.5 if parent is None else parent
+        leaf_depth = depth + 1 if not par else depth + 2 + rng.choice([0, 0, 1, 5, rng.randint(0, 3)])
+        total_depth = rng.choice([leaf_depth, depth + 2 + rng.randint(0, 63), rng.randint(0, 90), 1000])
+        ci = rng.getrandbits(64)
+        if directed is not None:
+            i, bit = directed
+            total_depth = depth + i + 2
+            ci = ci & ~(1 << i) | bit << i
+        word = (lambda: rng.choice([rng.getrandbits(32), -rng.randint(1, 2000), (1 << 32) + rng.getrandbits(32)])) if wide else (lambda: rng.getrandbits(32))
+        return dict(n_blocks=n_blocks, block_count=block_count, h=[rng.getrandbits(32) for _ in range(8)], chunk_idx_low=ci & 0xFFFFFFFF,
+                    chunk_idx_high=ci >> 32, leaf_depth=leaf_depth, total_depth=total_depth, depth=depth, m=[word() for _ in range(16)],
+                    b=rng.getrandbits(32))
+    probes = [step(wide=(k % 3 == 2)) for k in range(240)]
+    for i in range(64):
+        for bit in (0, 1):
+            for par in (False, True):
+                probes.append(step(directed=(i, bit), parent=par))
+    return probes
+
+
+def align(z_o1, z_o2):
+    """O2 slot -> O1 wire: equal value columns over all probes, increasing wire order"""
+    import bisect
+    import collections
+    K = len(z_o1)
+    by_col = collections.defaultdict(list)
+    for w in range(len(z_o1[0])):
+        by_col[tuple(z_o1[k][w] for k in range(K))].append(w)
+    amap, prev = [], -1
+    for s in range(len(z_o2[0])):
+        cands = by_col.get(tuple(z_o2[k][s] for k in range(K)), [])
+        i = bisect.bisect_right(cands, prev)
+        assert i < len(cands), f"O2 slot {s} has no O1 wire with its values after wire {prev}"
+        prev = cands[i]
+        amap.append(prev)
+    return amap
+
+
+def eliminate(cons, nwires, kept):
+    """The constraint system over the kept wires only: every other wire is solved from a linear constraint and
+    substituted everywhere (the constraint used up disappears).  Returns constraints over the ORIGINAL wire numbers."""
+    gone = set(range(nwires)) - set(kept)
+    sub_of = {}                                       # eliminated wire -> LC over wires still present
+
+    def apply(lc):
+        for _ in range(256):                           # (substitutions may mention wires that were solved later)
+            if not any(w in sub_of for w in lc):
+                return lc
+            out = {}
+            for w, f in lc.items():
+                for w2, f2 in (sub_of[w].items() if w in sub_of else ((w, 1),)):
+                    out[w2] = (out.get(w2, 0) + f * f2) % P
+            lc = {w: f for w, f in out.items() if f}
+        raise AssertionError("cyclic substitution")
+
+    def linear_form(a, b, c):
+        """the constraint as one LC = 0 if it is linear (A or B empty or a constant), else None"""
+        if not a or not b:
+            return neg(c)
+        for x, y in ((a, b), (b, a)):
+            if set(x) == {0}:
+                return sub(scale(y, x[0]), c)
+        return None
+    rows = []
+    rest = []
+    for a, b, c in cons:
+        lf = linear_form(a, b, c)
+        (rows if lf is not None and any(w in gone for w in lf) else rest).append(lf if lf is not None and any(w in gone for w in lf) else (a, b, c))
+    pending, kept_linear = list(rows), []
+
+    def solve(lc, e):
+        inv = pow(lc[e], -1, P)
+        sub_of[e] = {w: (-f * inv) % P for w, f in lc.items() if w != e}
+    while pending:
+        changed, nxt = False, []
+        for lc in pending:
+            lc = apply(lc)
+            unsolved = [w for w in lc if w in gone and w not in sub_of]
+            if not unsolved:
+                if lc:
+                    kept_linear.append(lc)             # a linear constraint among kept wires: stays
+            elif len(unsolved) == 1:                   # the system is nearly triangular: most rows end up here
+                solve(lc, unsolved[0])
+                changed = True
+            else:
+                nxt.append(lc)
+        pending = nxt
+        if pending and not changed:                    # a genuine pivot: one wire of the first open row goes
+            lc = apply(pending.pop(0))
+            solve(lc, next(w for w in lc if w in gone and w not in sub_of))
+    for _ in range(64):                                # close the substitutions (pivot rows mention wires solved later)
+        open_ = [e for e, lc in sub_of.items() if any(w in gone for w in lc)]
+        if not open_:
+            break
+        for e in open_:
+            sub_of[e] = apply(sub_of[e])
+    assert not any(w in gone for lc in sub_of.values() for w in lc)
+    assert not (gone - set(sub_of)), f"{len(gone - set(sub_of))} eliminated wires have no linear constraint to go through"
+    pending = kept_linear
+    out = []
+    for lc in pending:
+        lc = apply(lc)
+        if lc:
+            out.append(({}, {}, neg(lc)))
+    for item in rest:
+        a, b, c = item
+        out.append((apply(a), apply(b), apply(c)))
+    for a, b, c in out:
+        assert not (set(a) | set(b) | set(c)) & gone
+    return out
 
 
 def main():
@@ -790,6 +930,8 @@ def main():
         size = write_r1cs(out, cons, nwires, w2l, 16, 0, 28, nlabels)
         print(f"{len(c.names)} signals = the .sym's, ids and slots by the numbering rule = the .sym's; {nwires} wires; {len(cons)} constraints "
               f"{kinds}; {nnz} non-zeros; reference witness satisfies all; wrote {out} ({size} bytes before gzip)")
+    elif which == "nova_o2":
+        return main_nova_o2()
     else:
         out = sys.argv[sys.argv.index("--out") + 1] if "--out" in sys.argv else OUT.replace("blake3_compression", "blake3_nova_bn254_o1")
         nova = Blake3Nova(c)
@@ -805,6 +947,51 @@ def main():
         size = write_r1cs(out, cons, nwires, w2l, 15, 12, 20, nlabels)
         print(f"{len(c.names)} signals; {nwires} wires = the WASM's witness size; {len(cons)} constraints {kinds}; {nnz} non-zeros; "
               f"{len(cases)} reference-WASM witnesses (accepted goldens) satisfy all; wrote {out} ({size} bytes before gzip)")
+
+
+VESTA_Q = 0x40000000000000000000000000000000224698fc0994a8dd8c46eb2100000001      # circom's "vesta" prime
+
+
+def main_nova_o2():
+    """blake3_nova_bn254.r1cs.gz and blake3_nova_vesta.r1cs.gz (the two O2 builds, 23 291 wires)"""
+    global P
+    outdir = sys.argv[sys.argv.index("--outdir") + 1] if "--outdir" in sys.argv else os.path.dirname(OUT)
+    wasm = {"o1": "build/blake3_nova/blake3_nova_js/blake3_nova.wasm", "bn254": "build/blake3_nova_js/blake3_nova.wasm",
+            "vesta": "build/blake3_nova_pasta_js/blake3_nova_pasta.wasm"}
+    probes = nova_probes()
+    gold = json.load(open(os.path.join(ROOT, "tests", "golden", "nova_bn254.json")))
+    probes += [g["input"] for g in gold["cases"] if "error" not in g]
+    z = {k: wasm_witnesses(os.path.join(REF, v), probes, allow_rejects=True) for k, v in wasm.items()}
+    ok = [k for k in range(len(probes)) if all(z[b][k] is not None for b in z)]
+    assert len(ok) >= 400, len(ok)
+    # the O1 system (BN254) and the alignment of the O2 slots to its wires
+    c = Circuit()
+    nova = Blake3Nova(c)
+    cons1, nw1, w2l1, nlabels = lower(c, public=nova["public"])
+    assert nw1 == 24614
+    for k in ok:
+        assert not violated(cons1, z["o1"][k])
+    amap = align([z["o1"][k] for k in ok], [z["bn254"][k] for k in ok])
+    assert amap[:46] == list(range(46)) and len(amap) == 23291, amap[:50]
+    slot_of = {w: s_ for s_, w in enumerate(amap)}
+    for name, prime in (("bn254", P), ("vesta", VESTA_Q)):
+        P = prime
+        c = Circuit()
+        nova = Blake3Nova(c)
+        cons_o1, nw, w2l, _ = lower(c, public=nova["public"])          # the same circuit over this build's field
+        assert nw == nw1 and w2l == w2l1
+        cons = eliminate(cons_o1, nw, amap)
+        remap = lambda lc: {slot_of[w]: f for w, f in sorted(lc.items(), key=lambda kv: slot_of[kv[0]])}
+        cons = [(remap(a), remap(b), remap(cc)) for a, b, cc in cons]
+        bad = [(k, violated(cons, z[name][k])[:3]) for k in ok if violated(cons, z[name][k])]
+        assert not bad, f"{name}: reference-WASM witnesses violate the derived system: {bad[:3]}"
+        kinds, nnz = summary(cons)
+        out = os.path.join(outdir, f"blake3_nova_{name}.r1cs.gz")
+        size = write_r1cs(out, cons, len(amap), [w2l1[w] for w in amap], 15, 12, 20, nlabels)
+        print(f"nova {name} (O2): {len(amap)} wires aligned to the circomkit build's {nw1}; {nw1 - len(amap)} wires eliminated through linear "
+              f"constraints; {len(cons)} constraints {kinds}; {nnz} non-zeros; {len(ok)} reference-WASM witnesses satisfy all; wrote {out} "
+              f"({size} bytes before gzip)")
+    P = 21888242871839275222246405745257275088548364400416034343698204186575808495617
 
 
 if __name__ == "__main__":
