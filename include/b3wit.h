@@ -166,9 +166,10 @@ int32_t b3w_batch_time_device(b3w_ctx *ctx, const uint32_t *d_records, uint32_t 
  * the witness variables (rust_fold/src/utils.rs:17-88, rows read from the circuit's .r1cs by circom-scotia).
  * The constraint system is the caller's: `r1cs_image` is a complete iden3 .r1cs file image (format version 1: header,
  * constraints, wire map) over the ctx's field with nWires = witness_size — the circuit's own .r1cs where the maintainer
- * has it (the reference checkout does not: .MISSING_LARGE_BLOBS), or one this repository derives from the circuit text
- * (tools/gen_r1cs.py -> hot-proofs-blake3-circom_amd/constraints/blake3_compression.r1cs.gz and, for the circomkit nova
- * build B3W_CIRCUIT_NOVA_BN254_O1, blake3_nova_bn254_o1.r1cs.gz; gunzip first).
+ * has it (the reference checkout does not: .MISSING_LARGE_BLOBS), or one this repository derives (tools/gen_r1cs.py ->
+ * hot-proofs-blake3-circom_amd/constraints/: blake3_compression.r1cs.gz and blake3_nova_bn254_o1.r1cs.gz from the circuit
+ * text with circom's signal numbering rule; blake3_nova_bn254.r1cs.gz and blake3_nova_vesta.r1cs.gz — the O2 builds — by
+ * aligning the reference's O2 witnesses with its O1 witnesses and eliminating the missing wires; gunzip first).
  * The check is independent of the witness kernels: full field arithmetic on the 32-byte elements as they lie in the
  * body, no knowledge of the circuit beyond the file.
  *   d_violations[i] = number of constraints body i violates (0 = a valid witness); an element >= p counts as a violation
