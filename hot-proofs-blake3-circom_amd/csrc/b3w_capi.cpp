@@ -1201,14 +1201,14 @@ static int32_t r1cs_create_impl(b3w_ctx *ctx, const uint8_t *img, size_t len, b3
     uint32_t hi = 0;
     for (int q = 2; q < 8; q++) hi |= cf[q];
     const uint64_t lo64 = (uint64_t)cf[0] | (uint64_t)cf[1] << 32;
-    if (!hi && lo64 < (1ull << 40)) { coef_small[i] = (long long)lo64; continue; }
+    if (!hi && lo64 < (1ull << 62)) { coef_small[i] = (long long)lo64; continue; }
     uint32_t neg[8];                                                               // p - c
     uint64_t br = 0;
     for (int q = 0; q < 8; q++) { const uint64_t d = (uint64_t)P[q] - cf[q] - br; neg[q] = (uint32_t)d; br = (d >> 63) & 1; }
     hi = 0;
     for (int q = 2; q < 8; q++) hi |= neg[q];
     const uint64_t n64 = (uint64_t)neg[0] | (uint64_t)neg[1] << 32;
-    if (!hi && n64 < (1ull << 40)) coef_small[i] = -(long long)n64;
+    if (!hi && n64 < (1ull << 62)) coef_small[i] = -(long long)n64;
   }
   std::vector<uint32_t> tdesc(4 * (size_t)ntiles), ttdesc(2 * (size_t)ntiles), text, trows, trow_id, tterms;
   uint32_t max_tile_terms = 0;

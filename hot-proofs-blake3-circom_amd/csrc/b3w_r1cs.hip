@@ -250,9 +250,10 @@ __global__ __launch_bounds__(256) void b3w_r1cs_kernel(const uint8_t *__restrict
 // reduced mod p at load time; bit 255 (never set in a reduced element of these fields: p < 2^255) marks an element that was
 // NOT canonical in the body.
 
-// <row, z> out of LDS, in two parts: `s` collects every term whose coefficient is a small signed integer (|c| < 2^40:
-// +-1, +-2^i, the IV words ... — every coefficient of these circuits) and whose element is below 2^64, as an
-// exact 128-bit integer (a row has < 2^20 terms: no overflow); `big` (mod p) collects the rest — the general Montgomery
+// <row, z> out of LDS, in two parts: `s` collects every term whose coefficient is a small signed integer (|c| < 2^40 with an
+// element below 2^64, or |c| < 2^62 with an element below 2^32: +-1, +-2^i, the IV words, the 2^(i+j) of the row-scaled O2
+// systems — all but a handful of the coefficients of these circuits), as an exact 128-bit integer (a row has < 2^20 terms:
+// no overflow); `big` (mod p) collects the rest — the general Montgomery
 // path, any field element.  A valid witness of these circuits never leaves the integer part.
 struct Dot {
   __int128 s;
@@ -277,7 +278,9 @@ __device__ __forceinline__ Dot dot_lds(const uint4 *lds, const uint32_t *terms /
     *wild = *wild || (hi.w >> 31);
     const long long c = coef_small[cid];
     const uint32_t wide = lo.z | lo.w | hi.x | hi.y | hi.z | (hi.w & 0x7FFFFFFFu);
-    if (wide == 0 && c != B3W_R1CS_NOT_SMALL) {
+    const long long cmag = c < 0 ? -c : c;
+    // |c| < 2^40 with z < 2^64, or |c| < 2^62 with z < 2^32: the product stays below 2^104 and 2^20 of them below 2^127
+    if (wide == 0 && c != B3W_R1CS_NOT_SMALL && (cmag < (1ll << 40) || lo.y == 0)) {
       const unsigned long long z64 = (unsigned long long)lo.x | (unsigned long long)lo.y << 32;
       d.s += (__int128)c * (__int128)z64;
     } else {

@@ -790,6 +790,36 @@ def wasm_witnesses(wasm, inputs, allow_rejects=False):
 # word — or the probes below tell them apart).  The O1 wires that found no O2 slot are then eliminated from the O1 system
 # through its own linear constraints (sparse Gaussian elimination over the field), which leaves the O2 build's constraint
 # system up to row operations.  Nothing of this repository's kernels, slot tables or oracle enters.
+def dyadic(cons):
+    """Row scaling that keeps the coefficients small integers.  Eliminating a BIT b_i = (W - sum_{j != i} 2^j b_j) / 2^i puts
+    2^-i into every row that mentions it — a full-width field element per term.  A * B = C holds iff (2^s A) * (2^t B) =
+    2^(s+t) C: each side is multiplied by the smallest power of two that makes all its coefficients integers below 2^62 in
+    magnitude (c or c - p), when there is one."""
+    lim = 1 << 62
+
+    def shift_for(lc, least=0):
+        for t in range(least, 130):
+            if all((f << t) % P < lim or P - (f << t) % P < lim for f in lc.values()):
+                return t
+        return None
+    out = []
+    for a, b, c in cons:
+        ta, tb = shift_for(a), shift_for(b)
+        if ta is None or tb is None:
+            out.append((a, b, c))
+            continue
+        tc = shift_for(c, ta + tb)
+        if tc is None:
+            out.append((a, b, c))
+            continue
+        ta += tc - (ta + tb)                              # C needed more: put the difference on A
+        if max(ta, tb, tc) == 0:
+            out.append((a, b, c))
+        else:
+            out.append(({w: (f << ta) % P for w, f in a.items()}, {w: (f << tb) % P for w, f in b.items()}, {w: (f << tc) % P for w, f in c.items()}))
+    return out
+
+
 def nova_probes(seed=20260105):
     """valid nova steps that exercise every signal: random leaf / parent steps with full-range words, 64-bit chunk indices
     and large depths; for every i in [0, 64) a step with depth = total_depth - i - 2 (eqs[i] fires) for both values of bit i
@@ -980,7 +1010,7 @@ def main_nova_o2():
         nova = Blake3Nova(c)
         cons_o1, nw, w2l, _ = lower(c, public=nova["public"])          # the same circuit over this build's field
         assert nw == nw1 and w2l == w2l1
-        cons = eliminate(cons_o1, nw, amap)
+        cons = dyadic(eliminate(cons_o1, nw, amap))
         remap = lambda lc: {slot_of[w]: f for w, f in sorted(lc.items(), key=lambda kv: slot_of[kv[0]])}
         cons = [(remap(a), remap(b), remap(cc)) for a, b, cc in cons]
         bad = [(k, violated(cons, z[name][k])[:3]) for k in ok if violated(cons, z[name][k])]
