@@ -278,9 +278,10 @@ __device__ __forceinline__ Dot dot_lds(const uint4 *lds, const uint32_t *terms /
     *wild = *wild || (hi.w >> 31);
     const long long c = coef_small[cid];
     const uint32_t wide = lo.z | lo.w | hi.x | hi.y | hi.z | (hi.w & 0x7FFFFFFFu);
-    const long long cmag = c < 0 ? -c : c;
-    // |c| < 2^40 with z < 2^64, or |c| < 2^62 with z < 2^32: the product stays below 2^104 and 2^20 of them below 2^127
-    if (wide == 0 && c != B3W_R1CS_NOT_SMALL && (cmag < (1ll << 40) || lo.y == 0)) {
+    // |c| < 2^62 with z < 2^32, or |c| < 2^40 with z < 2^64: the product stays below 2^104 and 2^20 of them below 2^127
+    bool narrow = wide == 0 && c != B3W_R1CS_NOT_SMALL;
+    if (narrow && lo.y != 0) narrow = (c < 0 ? -c : c) < (1ll << 40);               // (rare: elements of 33 bits and more)
+    if (narrow) {
       const unsigned long long z64 = (unsigned long long)lo.x | (unsigned long long)lo.y << 32;
       d.s += (__int128)c * (__int128)z64;
     } else {
