@@ -1345,6 +1345,14 @@ int32_t b3w_batch_r1cs_check(b3w_batch *b, const b3w_r1cs *r, uint32_t *host_vio
   return e == hipSuccess ? B3W_OK : hip_fail(ctx, e, "hipMemcpy(r1cs check)");
 }
 
+void b3w_r1cs_consumer(void *user, const uint8_t *d_bodies, uint64_t pitch, uint64_t first_step, uint32_t count, void *stream) {
+  b3w_r1cs_sink *sink = static_cast<b3w_r1cs_sink *>(user);
+  if (!sink || !sink->ctx || !sink->r1cs || !sink->d_violations) return;
+  const int32_t rc = b3w_r1cs_check_device(sink->ctx, sink->r1cs, d_bodies, count, pitch, sink->d_violations + first_step, nullptr, stream);
+  if (rc && !sink->error) sink->error = rc;
+  if (sink->next) sink->next(sink->next_user, d_bodies, pitch, first_step, count, stream);
+}
+
 // ---------------------------------------------------------------- commitments (on-device consumer #2)
 }  // extern "C"
 

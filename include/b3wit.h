@@ -188,6 +188,20 @@ int32_t b3w_r1cs_check_device(b3w_ctx *ctx, const b3w_r1cs *r1cs, const uint8_t 
                               uint32_t *d_violations, uint32_t *d_first, void *stream);
 /* The same on the witnesses of the last b3w_batch_run; host arrays of n entries (host_first may be NULL). */
 int32_t b3w_batch_r1cs_check(b3w_batch *batch, const b3w_r1cs *r1cs, uint32_t *host_violations, uint32_t *host_first);
+/* A ready-made consumer for the chained pass (b3w_chain_run_leaves / run_parents): checks every batch of step witnesses
+ * against the step circuit's constraints while it sits in the ring — synthesize_with_vec's job (rust_fold/src/utils.rs:17-88)
+ * for every step of the fold.  `user` = a b3w_r1cs_sink; d_violations has room for every step of the pass (step order).
+ * `next` / `next_user` (may be NULL) name a second consumer that runs on the same batch afterwards, e.g. b3w_commit_consumer
+ * with its b3w_commit_sink: witness -> constraint check -> commitment, nothing but counts and points kept. */
+typedef struct {
+  b3w_ctx *ctx;
+  const b3w_r1cs *r1cs;
+  uint32_t *d_violations;
+  void (*next)(void *user, const uint8_t *d_bodies, uint64_t pitch, uint64_t first_step, uint32_t count, void *stream);
+  void *next_user;
+  int32_t error; /* first non-zero status of a check launch, 0 = none */
+} b3w_r1cs_sink;
+void b3w_r1cs_consumer(void *user, const uint8_t *d_bodies, uint64_t pitch, uint64_t first_step, uint32_t count, void *stream);
 
 /* A cheaper tamper check of n witness bodies in HBM (NOT independent evidence: it shares the witness kernels' trace code
  * and slot table).  The circuits are deterministic (the inputs fix every

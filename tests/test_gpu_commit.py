@@ -190,6 +190,62 @@ def test_chained_pass_with_the_commit_consumer():
     ctx.close()
 
 
+def test_chained_pass_check_then_commit():
+    """witness -> constraint check -> commitment for every step of a preimage, natively: b3w_r1cs_consumer (the derived
+    system of the Vesta O2 build) chained to b3w_commit_consumer as the ring's consumer.  Every step satisfies the step
+    circuit, the points equal those of the commit consumer alone, the fold ends in BLAKE3(preimage)."""
+    import torch, blake3_ref
+    CONSUMER = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_uint64, ctypes.c_uint32, ctypes.c_void_p)
+
+    class CommitSink(ctypes.Structure):
+        _fields_ = [("ctx", ctypes.c_void_p), ("key", ctypes.c_void_p), ("d_points", ctypes.c_void_p), ("d_status", ctypes.c_void_p),
+                    ("error", ctypes.c_int32)]
+
+    class R1csSink(ctypes.Structure):
+        _fields_ = [("ctx", ctypes.c_void_p), ("r1cs", ctypes.c_void_p), ("d_violations", ctypes.c_void_p), ("next", ctypes.c_void_p),
+                    ("next_user", ctypes.c_void_p), ("error", ctypes.c_int32)]
+    m = T.pkg()
+    L = m.lib()
+    circuit, curve = "nova_vesta", "pallas"
+    ctx = m.Context(circuit, 0)
+    r1cs = m.R1cs(ctx)
+    data = ((np.arange(5 * 1024 + 300, dtype=np.uint64) * 9973 + 5) % 251).astype(np.uint8)   # 6 chunks, incomplete tree: 85 leaf + 16 parent steps
+    key = m.CommitKey(ctx, curve, E.points_to_bytes(E.random_points(curve, T.NWIT[circuit], seed=b"cc")), window=12)
+    dev = torch.device("cuda:0")
+
+    def run(with_check):
+        h = ctypes.c_void_p()
+        assert L.b3w_chain_create(ctx.handle, data.size, 0, 6, 32, 2, 1, ctypes.byref(h)) == 0
+        nl, npar = ctypes.c_uint64(), ctypes.c_uint64()
+        L.b3w_chain_info(h, ctypes.byref(nl), ctypes.byref(npar), None, None, None)
+        steps = nl.value + npar.value
+        d_pts = torch.zeros((steps, 64), dtype=torch.uint8, device=dev)
+        d_st = torch.full((steps,), -1, dtype=torch.int32, device=dev)
+        d_viol = torch.full((steps,), -1, dtype=torch.int32, device=dev)
+        csink = CommitSink(ctx.handle, key.handle, d_pts.data_ptr(), d_st.data_ptr(), 0)
+        commit_fn = ctypes.cast(L.b3w_commit_consumer, ctypes.c_void_p)
+        if with_check:
+            rsink = R1csSink(ctx.handle, r1cs.handle, d_viol.data_ptr(), commit_fn, ctypes.cast(ctypes.byref(csink), ctypes.c_void_p), 0)
+            fn, user = ctypes.cast(L.b3w_r1cs_consumer, ctypes.c_void_p), ctypes.byref(rsink)
+        else:
+            rsink, fn, user = None, commit_fn, ctypes.byref(csink)
+        assert L.b3w_chain_run_leaves(h, data.ctypes.data, fn, user, None) == 0
+        assert L.b3w_chain_run_parents(h, None, fn, user, None) == 0
+        root = np.zeros(8, dtype=np.uint32)
+        assert L.b3w_chain_outputs(h, None, None, root.ctypes.data, None) == 0
+        torch.cuda.synchronize()
+        assert csink.error == 0 and (rsink is None or rsink.error == 0)
+        out = (steps, nl.value, npar.value, root.tobytes(), d_pts.cpu().numpy().copy(), d_st.cpu().numpy().copy(), d_viol.cpu().numpy().copy())
+        L.b3w_chain_destroy(h)
+        return out
+    steps, nl, npar, root, pts, st, viol = run(True)
+    assert (nl, npar) == (5 * 16 + 5, 4 * 3 + 2 * 2) and root == blake3_ref.blake3(data.tobytes())
+    assert (viol == 0).all() and (st == 0).all()                    # every step witness satisfies all 23 744 constraints
+    _, _, _, root2, pts2, st2, viol2 = run(False)
+    assert root2 == root and np.array_equal(pts, pts2) and (viol2 == -1).all()
+    key.close(); r1cs.close(); ctx.close()
+
+
 @pytest.mark.parametrize("circuit,curve,window", [("compression", "bn254_g1", 16), ("nova_vesta", "vesta", 12), ("nova_bn254", "bn254_g1", 16),
                                                   ("nova_bn254_o1", "bn254_g1", 12)])
 def test_commitments_from_records_equal_commitments_of_the_bodies(circuit, curve, window):
