@@ -1746,6 +1746,8 @@ struct b3w_chain {
   hipEvent_t ev_cvs = nullptr, ev_par = nullptr;     // chunk CVs complete (main stream); parent records ready (side stream)
   const b3w_commit_key *co_key = nullptr;            // commitments only: no bodies, one point per step into co_points
   uint8_t *co_points = nullptr, *co_own = nullptr;   // (co_own: the chain's own buffer when the caller passed none)
+  const b3w_r1cs *r1cs = nullptr;                    // constraint check of every batch while it sits in the ring
+  uint32_t *d_viol = nullptr;                        // ... violated constraints per step
 };
 
 namespace {
@@ -1796,6 +1798,11 @@ int32_t chain_run_steps(b3w_chain *c, uint64_t first_row, uint64_t count, b3w_ba
     int32_t rc;
     { Range r("b3w:witness batch"); rc = b3w_batch_run_device(c->ctx, c->d_recs + r0 * 32, k, slot, body, c->d_pub + r0 * 15, c->d_status + r0, stream); }
     if (rc) return rc;
+    if (c->r1cs) {
+      Range r("b3w:constraint check");
+      rc = b3w_r1cs_check_device(c->ctx, c->r1cs, slot, k, body, c->d_viol + r0, nullptr, stream);
+      if (rc) return rc;
+    }
     if (consumer) { Range r("b3w:consumer"); consumer(user, slot, body, r0, k, stream); }
     c->nbatch++;
     done += k;
@@ -1817,6 +1824,24 @@ int32_t b3w_chain_commit_only(b3w_chain *c, const b3w_commit_key *key, uint8_t *
   }
   c->co_key = key;
   c->co_points = key ? d_points : nullptr;
+  return B3W_OK;
+}
+
+int32_t b3w_chain_check_constraints(b3w_chain *c, const b3w_r1cs *r1cs) {
+  if (!c || (r1cs && r1cs->ctx != c->ctx)) return B3W_E_BAD_ARGUMENT;
+  if (r1cs && !c->d_viol) {
+    ON_DEVICE(c->ctx);
+    HIP_TRY(c->ctx, hipMalloc((void **)&c->d_viol, (size_t)(c->n_leaf + c->n_par + 1) * 4));
+  }
+  c->r1cs = r1cs;
+  return B3W_OK;
+}
+
+int32_t b3w_chain_violations(b3w_chain *c, uint32_t *host_violations, void *stream) {
+  if (!c || !host_violations || !c->r1cs || !c->d_viol) return B3W_E_BAD_ARGUMENT;
+  ON_DEVICE(c->ctx);
+  HIP_TRY(c->ctx, hipStreamSynchronize((hipStream_t)stream));
+  HIP_TRY(c->ctx, hipMemcpy(host_violations, c->d_viol, (size_t)(c->n_leaf + c->n_par) * 4, hipMemcpyDeviceToHost));
   return B3W_OK;
 }
 
@@ -1901,6 +1926,7 @@ void b3w_chain_destroy(b3w_chain *c) {
   if (c->d_levels) (void)hipFree(c->d_levels);
   if (c->d_root) (void)hipFree(c->d_root);
   if (c->co_own) (void)hipFree(c->co_own);
+  if (c->d_viol) (void)hipFree(c->d_viol);
   if (c->copy) (void)hipStreamDestroy(c->copy);
   if (c->side) (void)hipStreamDestroy(c->side);
   if (c->ev_cvs) (void)hipEventDestroy(c->ev_cvs);

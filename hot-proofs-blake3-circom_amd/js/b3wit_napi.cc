@@ -62,6 +62,8 @@ struct Api {
   decltype(&b3w_r1cs_info) r1cs_info;
   decltype(&b3w_r1cs_destroy) r1cs_destroy;
   decltype(&b3w_batch_r1cs_check) batch_r1cs_check;
+  decltype(&b3w_chain_check_constraints) chain_check_constraints;
+  decltype(&b3w_chain_violations) chain_violations;
   std::string err;
 } api;
 
@@ -86,7 +88,7 @@ bool load_api() {
   SYM(batch_outputs) SYM(batch_fetch) SYM(batch_write_wtns) SYM(batch_verify) SYM(batch_placement) SYM(bodies_trim)
   SYM(chain_create) SYM(chain_destroy) SYM(chain_run_leaves) SYM(chain_run_parents) SYM(chain_info) SYM(chain_outputs)
   SYM(commit_key_create_ex) SYM(commit_key_destroy) SYM(commit_records) SYM(chain_commit_only) SYM(chain_commitments) SYM(batch_commit) SYM(chain_shard) SYM(chain_run_parents_sharded) SYM(comm_unique_id) SYM(comm_create) SYM(comm_destroy) SYM(batch_allgather_public)
-  SYM(r1cs_create) SYM(r1cs_info) SYM(r1cs_destroy) SYM(batch_r1cs_check)
+  SYM(r1cs_create) SYM(r1cs_info) SYM(r1cs_destroy) SYM(batch_r1cs_check) SYM(chain_check_constraints) SYM(chain_violations)
 #undef SYM
   api.so = so;
   return true;
@@ -386,7 +388,7 @@ napi_value BatchPlacement(napi_env env, napi_callback_info info) {
 //   -> { nLeafSteps, nParentSteps, nChunks, pathLen, placement, publicOutputs: Uint32Array(steps*15), status: Int32Array, root: Uint32Array(8) }
 // The whole chained-mode pass of b3wit.h (b3w_chain_*) over one preimage on this handle's device.
 napi_value ChainFold(napi_env env, napi_callback_info info) {
-  size_t argc = 6; napi_value argv[6];
+  size_t argc = 7; napi_value argv[7];
   NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
   Handle *h = get_handle(env, argv[0]);
   if (!h) return nullptr;
@@ -408,6 +410,9 @@ napi_value ChainFold(napi_env env, napi_callback_info info) {
   bool commit_only = false;                              // one commitment per step instead of the witness bodies (needs commitKey)
   if (argc > 5) napi_get_value_bool(env, argv[5], &commit_only);
   if (commit_only && !h->key) { napi_throw_error(env, nullptr, "commitOnly needs setCommitKey first"); return nullptr; }
+  bool check = false;                                    // constraint check of every step witness in the ring (needs loadR1cs)
+  if (argc > 6) napi_get_value_bool(env, argv[6], &check);
+  if (check && (!h->r1cs || commit_only)) { napi_throw_error(env, nullptr, "checkConstraints needs loadR1cs first and witness bodies (no commitOnly)"); return nullptr; }
   const uint64_t nchunks = (len + 1023) / 1024;
   if (nchunks > 0xFFFFFFFFull) { napi_throw_range_error(env, nullptr, "preimage too large for one pass"); return nullptr; }
   b3w_chain *c = nullptr;
@@ -416,6 +421,7 @@ napi_value ChainFold(napi_env env, napi_callback_info info) {
   int32_t rc = api.chain_create(h->ctx, len, first, count, batch_steps, ring, with_parents ? 1 : 0, &c);
   if (rc != B3W_OK) return throw_status(env, h, rc, "b3w_chain_create failed");
   if (commit_only) rc = api.chain_commit_only(c, h->key, nullptr);
+  if (rc == B3W_OK && check) rc = api.chain_check_constraints(c, h->r1cs);
   if (rc == B3W_OK) rc = api.chain_run_leaves(c, (const uint8_t *)data, nullptr, nullptr, nullptr);
   if (rc == B3W_OK) rc = h->comm ? api.chain_run_parents_sharded(c, h->comm, nullptr, nullptr, nullptr)
                                  : api.chain_run_parents(c, nullptr, nullptr, nullptr, nullptr);
@@ -435,6 +441,11 @@ napi_value ChainFold(napi_env env, napi_callback_info info) {
     if (napi_create_arraybuffer(env, rows * 64, &pc, &abc) != napi_ok) { api.chain_destroy(c); napi_throw_error(env, nullptr, "b3wit_napi: cannot allocate the points"); return nullptr; }
     rc = api.chain_commitments(c, (uint8_t *)pc, nullptr);
   }
+  void *pv = nullptr; napi_value abv;
+  if (rc == B3W_OK && check) {
+    if (napi_create_arraybuffer(env, rows * 4, &pv, &abv) != napi_ok) { api.chain_destroy(c); napi_throw_error(env, nullptr, "b3wit_napi: cannot allocate the violation counts"); return nullptr; }
+    rc = api.chain_violations(c, (uint32_t *)pv, nullptr);
+  }
   api.chain_destroy(c);
   if (rc != B3W_OK) return throw_status(env, h, rc, "chained pass failed");
   NAPI_OK(napi_create_object(env, &o));
@@ -449,6 +460,7 @@ napi_value ChainFold(napi_env env, napi_callback_info info) {
   napi_create_typedarray(env, napi_int32_array, rows, abs_, 0, &v); napi_set_named_property(env, o, "status", v);
   napi_create_typedarray(env, napi_uint32_array, 8, abr, 0, &v); napi_set_named_property(env, o, "root", v);
   if (commit_only) { napi_create_typedarray(env, napi_uint8_array, rows * 64, abc, 0, &v); napi_set_named_property(env, o, "commitments", v); }
+  if (check) { napi_create_typedarray(env, napi_uint32_array, rows, abv, 0, &v); napi_set_named_property(env, o, "violations", v); }
   return o;
 }
 

@@ -238,8 +238,10 @@ class WitnessCalculator {
   async foldPreimage(preimage, opts) {
     opts = opts || {};
     // opts.commitOnly (after setCommitKey): r.commitments = one 64-byte point per step, no witness bodies written
+    // opts.checkConstraints (after loadR1cs): r.violations = per step, the constraints of the step circuit its witness violates
+    // (0 everywhere = every step of the fold is a valid witness), checked on the device while the bodies sit in the ring
     const r = native().chainFold(this.instance, preimage, opts.batchSteps || 16384, opts.ring || 2, opts.withParents !== false,
-                                 !!opts.commitOnly);
+                                 !!opts.commitOnly, !!opts.checkConstraints);
     const b = Buffer.alloc(32);
     r.root.forEach((w, i) => b.writeUInt32LE(w, 4 * i));
     r.hash = b.toString("hex");

@@ -375,6 +375,12 @@ void b3w_chain_destroy(b3w_chain *chain);
 int32_t b3w_chain_commit_only(b3w_chain *chain, const b3w_commit_key *key, uint8_t *d_points);
 /* d_points = NULL above: the chain keeps the points itself; this copies them (n_leaf + n_parent times 64 bytes) to the host. */
 int32_t b3w_chain_commitments(b3w_chain *chain, uint8_t *host_points, void *stream);
+/* Constraint check inside the chained pass: after this call (r1cs = a system of the chain's context; NULL turns it off) every
+ * batch of step witnesses is checked against the step circuit while it sits in the ring, before the consumer sees it;
+ * b3w_chain_violations copies the per-step counts (n_leaf + n_parent entries, step order; 0 = the step satisfies every
+ * constraint) to the host once `stream` has drained. */
+int32_t b3w_chain_check_constraints(b3w_chain *chain, const b3w_r1cs *r1cs);
+int32_t b3w_chain_violations(b3w_chain *chain, uint32_t *host_violations, void *stream);
 int32_t b3w_chain_run_leaves(b3w_chain *chain, const uint8_t *host_preimage /* byte 0 of the WHOLE preimage */,
                              b3w_batch_consumer consumer, void *user, void *stream);
 int32_t b3w_chain_run_parents(b3w_chain *chain, const uint32_t *d_all_chunk_cvs /* n_chunks*8 words; NULL = the local ones,

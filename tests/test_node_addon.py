@@ -283,6 +283,10 @@ def test_js_fold_preimage_matches_blake3_and_python_driver(tmp_path):
                        bad: Array.from(r.status).filter(x => x !== 0).length,
                        pub: crypto.createHash('sha256').update(Buffer.from(r.publicOutputs.buffer, r.publicOutputs.byteOffset, r.publicOutputs.byteLength)).digest('hex')};
         }
+        // every step witness checked against the step circuit (derived system of this build) while it sits in the ring
+        wc.loadR1cs();
+        const cc = await wc.foldPreimage(fs.readFileSync(process.argv[1] + '/ragged.bin'), {batchSteps: 64, checkConstraints: true});
+        out.checked = {n: cc.violations.length, bad: Array.from(cc.violations).filter(x => x !== 0).length, hash: cc.hash};
         // commitments only (setCommitKey, then foldPreimage with commitOnly): one point per step, same root
         wc.setCommitKey('vesta', new Uint8Array(fs.readFileSync(process.argv[1] + '/gens.bin')), 0, 12);
         const c = await wc.foldPreimage(fs.readFileSync(process.argv[1] + '/complete.bin'), {batchSteps: 64, commitOnly: true});
@@ -300,6 +304,8 @@ def test_js_fold_preimage_matches_blake3_and_python_driver(tmp_path):
     pts = torch.zeros((16 * 16 + 16 * 4, 64), dtype=torch.uint8, device="cuda:0")
     py = m.chain.fold_witnesses(ctx, data, batch_steps=64, commit_only=(key, pts))
     torch.cuda.synchronize()
+    chk = out.pop("checked")
+    assert chk == {"n": out["ragged"]["nLeaf"] + out["ragged"]["nPar"], "bad": 0, "hash": out["ragged"]["hash"]}
     co = out.pop("commitOnly")
     assert co["hash"] == out["complete"]["hash"] and co["n"] == pts.shape[0] and co["bad"] == 0
     assert co["points"] == hashlib.sha256(pts.cpu().numpy().tobytes()).hexdigest() and int(pts.max(dim=1).values.min().item()) > 0
