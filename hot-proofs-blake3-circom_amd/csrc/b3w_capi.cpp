@@ -1230,7 +1230,10 @@ static int32_t r1cs_create_impl(b3w_ctx *ctx, const uint8_t *img, size_t len, b3
           boolean = (w1 == 0 && w2 == w && ((c1 == 0 && c2 == 1) || (c1 == 1 && c2 == 0))) ||
                     (w2 == 0 && w1 == w && ((c2 == 0 && c1 == 1) || (c2 == 1 && c1 == 0)));
         }
-        trows.push_back((uint32_t)tterms.size()); trows.push_back(r.na | (boolean ? 0x80000000u : 0u)); trows.push_back(r.nb); trows.push_back(r.nc);
+        uint32_t bool_idx = 0;                                 // a booleanity row names its element by LDS index
+        if (boolean) { const uint32_t w_a = wires[r.off]; bool_idx = w_a / T == t ? w_a - t * T : T + tile_ext[t].at(w_a); }
+        trows.push_back((uint32_t)tterms.size()); trows.push_back(r.na | (boolean ? 0x80000000u : 0u)); trows.push_back(r.nb);
+        trows.push_back(boolean ? bool_idx : r.nc);
         trow_id.push_back(r.id);
         for (uint32_t q = 0; q < r.na + r.nb + r.nc; q++) {
           const uint32_t w = wires[r.off + q];

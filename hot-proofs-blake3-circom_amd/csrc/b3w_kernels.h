@@ -82,7 +82,8 @@ extern "C" int b3w_launch_r1cs(const uint8_t *d_bodies, uint32_t n, uint64_t pit
 // the tile formulation (preferred): tile t = wires [t * B3W_R1CS_TILE, +B3W_R1CS_TILE); tiles: ntiles x {first row, rows, first
 // outside wire, outside wires}; rows: {first term, terms in A, B, C}; term = LDS index (< TILE: wire - tile start; >= TILE: outside
 // wire number) | coefficient id << 16
-// rows: bit 31 of the A count marks a booleanity row (A = {w: 1}, B = {1, -w} or {w, -1}, C = {}), its first term names w;
+// rows: bit 31 of the A count marks a booleanity row (A = {w: 1}, B = {1, -w} or {w, -1}, C = {}): its C count field holds w's
+// LDS index instead (there are no C terms);
 // coef_small[cid] = the coefficient as a signed integer when |c| < 2^62 (c or c - p), else B3W_R1CS_NOT_SMALL
 #define B3W_R1CS_TILE 1024u
 #define B3W_R1CS_NOT_SMALL ((long long)0x8000000000000000ull)

@@ -339,6 +339,15 @@ __global__ __launch_bounds__(256) void b3w_r1cs_tile_kernel(const uint8_t *__res
   const uint4 td = tiles[tile];
   const uint32_t t0 = tile * B3W_R1CS_TILE;
   const uint32_t n_local = nwires - t0 < B3W_R1CS_TILE ? nwires - t0 : B3W_R1CS_TILE;
+  // this lane's first row descriptors, fetched now so that their latency lies under the staging of the tile (profiles/r02:
+  // the kernel's waves are parked on memory 63 % of their cycles; a tile of these systems has 4-5 rows per lane)
+  constexpr uint32_t PRE = 6;
+  uint4 pre[PRE];
+#pragma unroll
+  for (uint32_t q = 0; q < PRE; q++) {
+    const uint32_t r = td.x + threadIdx.x + 256 * q;
+    pre[q] = r < td.x + td.y ? rows[r] : make_uint4(0, 0, 0, 0);
+  }
   for (uint32_t i = threadIdx.x; i < n_local; i += 256) stage(lds, i, body, t0 + i, F);
   for (uint32_t j = threadIdx.x; j < td.w; j += 256) stage(lds, B3W_R1CS_TILE + j, body, ext_wires[td.z + j], F);
   // the tile's term list (5 100 words for these systems) behind the elements: read once, coalesced, instead of one
@@ -362,19 +371,31 @@ __global__ __launch_bounds__(256) void b3w_r1cs_tile_kernel(const uint8_t *__res
   const uint4 one_lo = lds[tile == 0 ? 0 : 2 * B3W_R1CS_TILE], one_hi = lds[(tile == 0 ? 0 : 2 * B3W_R1CS_TILE) + 1];
   const bool w0_is_one = one_lo.x == 1 && (one_lo.y | one_lo.z | one_lo.w | one_hi.x | one_hi.y | one_hi.z | one_hi.w) == 0;
   const __int128 lim = (__int128)1 << 63;
-  for (uint32_t r = td.x + threadIdx.x; r < td.x + td.y; r += 256) {
-    const uint4 d = rows[r];
+  uint32_t it = 0;
+  for (uint32_t r = td.x + threadIdx.x; r < td.x + td.y; r += 256, it++) {
+    uint4 d;
+    switch (it) {                                        // (constant indices keep `pre` in registers)
+      case 0: d = pre[0]; break;
+      case 1: d = pre[1]; break;
+      case 2: d = pre[2]; break;
+      case 3: d = pre[3]; break;
+      case 4: d = pre[4]; break;
+      case 5: d = pre[5]; break;
+      default: d = rows[r];
+    }
     bool wild = false, bad;
     if ((d.y >> 31) && w0_is_one) {
-      // a booleanity row  z * (1 - z) = 0  (or z * (z - 1) = 0), recognised by the host: in a field that says z is 0 or 1
-      const uint32_t idx = tsrc[d.x - tbase] & 0xFFFFu;
+      // a booleanity row  z * (1 - z) = 0  (or z * (z - 1) = 0), recognised by the host: in a field that says z is 0 or 1.
+      // Its descriptor carries the element's LDS index (d.w; the row has no C terms): no term is fetched at all.
+      const uint32_t idx = d.w;
       const uint4 lo = lds[2 * idx], hi = lds[2 * idx + 1];
       wild = hi.w >> 31;
       bad = ((lo.x >> 1) | lo.y | lo.z | lo.w | hi.x | hi.y | hi.z | (hi.w & 0x7FFFFFFFu)) != 0;
     } else {
       const uint32_t na = d.y & 0x7FFFFFFFu;
       const uint32_t t0r = d.x - tbase;
-      const Dot C = dot_lds(lds, tsrc, coefs, csrc, t0r + na + d.z, d.w, F, &wild);
+      const uint32_t nc = (d.y >> 31) ? 0u : d.w;        // (a booleanity row taking the general road: wire 0 is not 1)
+      const Dot C = dot_lds(lds, tsrc, coefs, csrc, t0r + na + d.z, nc, F, &wild);
       const Dot A = dot_lds(lds, tsrc, coefs, csrc, t0r, na, F, &wild);
       const Dot B = dot_lds(lds, tsrc, coefs, csrc, t0r + na, d.z, F, &wild);
       if (!A.has_big && !B.has_big && !C.has_big && A.s < lim && A.s > -lim && B.s < lim && B.s > -lim) {
