@@ -1031,6 +1031,13 @@ struct b3w_r1cs {
   uint32_t ntiles = 0, max_ext = 0, max_tile_terms = 0, ncoef = 0;
   uint32_t *d_tiles = nullptr, *d_ext = nullptr, *d_trows = nullptr, *d_trow_id = nullptr, *d_terms = nullptr, *d_tile_terms = nullptr;
   long long *d_coef_small = nullptr;
+  // the lean kernel pair: the system as the kernels take it, and the deferred-row scratch — one per stream a check was
+  // enqueued on, allocated at the first check on that stream and kept (a fixed size: checks go in slabs of B3W_R1CS_SLAB)
+  uint32_t max_tile_rows = 0;
+  uint32_t *d_trow_k = nullptr;
+  B3wR1csSystem sys{};
+  mutable std::mutex scratch_mu;
+  mutable std::map<void *, unsigned long long *> scratch;
 };
 
 namespace {
@@ -1210,10 +1217,11 @@ static int32_t r1cs_create_impl(b3w_ctx *ctx, const uint8_t *img, size_t len, b3
     const uint64_t n64 = (uint64_t)neg[0] | (uint64_t)neg[1] << 32;
     if (!hi && n64 < (1ull << 62)) coef_small[i] = -(long long)n64;
   }
-  std::vector<uint32_t> tdesc(4 * (size_t)ntiles), ttdesc(2 * (size_t)ntiles), text, trows, trow_id, tterms;
-  uint32_t max_tile_terms = 0;
+  std::vector<uint32_t> tdesc(4 * (size_t)ntiles), ttdesc(2 * (size_t)ntiles), text, trows, trow_id, trow_k, tterms;
+  uint32_t max_tile_terms = 0, max_tile_rows = 0;
   if (tiled) {
     for (uint32_t t = 0; t < ntiles; t++) {
+      while (tterms.size() & 3) tterms.push_back(0);      // a tile's list starts on 16 bytes (the lean kernel stages it in uint4s)
       ttdesc[2 * t] = (uint32_t)tterms.size();
       tdesc[4 * t] = (uint32_t)(trows.size() / 4); tdesc[4 * t + 1] = (uint32_t)tile_rows[t].size();
       tdesc[4 * t + 2] = (uint32_t)text.size(); tdesc[4 * t + 3] = (uint32_t)tile_ext[t].size();
@@ -1235,6 +1243,7 @@ static int32_t r1cs_create_impl(b3w_ctx *ctx, const uint8_t *img, size_t len, b3
         trows.push_back((uint32_t)tterms.size()); trows.push_back(r.na | (boolean ? 0x80000000u : 0u)); trows.push_back(r.nb);
         trows.push_back(boolean ? bool_idx : r.nc);
         trow_id.push_back(r.id);
+        trow_k.push_back(k);
         for (uint32_t q = 0; q < r.na + r.nb + r.nc; q++) {
           const uint32_t w = wires[r.off + q];
           const uint32_t idx = w / T == t ? w - t * T : T + tile_ext[t][w];
@@ -1243,7 +1252,10 @@ static int32_t r1cs_create_impl(b3w_ctx *ctx, const uint8_t *img, size_t len, b3
       }
       ttdesc[2 * t + 1] = (uint32_t)tterms.size() - ttdesc[2 * t];
       max_tile_terms = std::max(max_tile_terms, ttdesc[2 * t + 1]);
+      max_tile_rows = std::max<uint32_t>(max_tile_rows, (uint32_t)tile_rows[t].size());
     }
+    tterms.push_back(0);                                  // the lean kernel fetches one term word ahead,
+    while (tterms.size() & 3) tterms.push_back(0);        // and stages whole uint4s
   }
   std::vector<uint32_t> coefR(16 * coefs.size());           // per coefficient: plain, then Montgomery form
   for (size_t i = 0; i < coefs.size(); i++) {
@@ -1283,6 +1295,10 @@ static int32_t r1cs_create_impl(b3w_ctx *ctx, const uint8_t *img, size_t len, b3
     up((void **)&r->d_trow_id, trow_id.data(), trow_id.size() * 4);
     up((void **)&r->d_terms, tterms.data(), tterms.size() * 4);
     up((void **)&r->d_coef_small, coef_small.data(), coef_small.size() * 8);
+    up((void **)&r->d_trow_k, trow_k.data(), trow_k.size() * 4);
+    r->max_tile_rows = max_tile_rows;
+    r->sys = B3wR1csSystem{nwires, ntiles, max_ext, max_tile_terms, max_tile_rows, r->ncoef, r->d_tiles, r->d_tile_terms, r->d_ext, r->d_trows,
+                           r->d_trow_id, r->d_trow_k, r->d_terms, r->d_coefR, r->d_coef_small, r->d_rows, r->d_wires, r->d_cids};
   }
   if (e != hipSuccess) { b3w_r1cs_destroy(r); return e == hipErrorOutOfMemory ? B3W_E_NOT_ENOUGH_MEMORY : hip_fail(ctx, e, "r1cs upload"); }
   *out = r;
@@ -1311,6 +1327,8 @@ void b3w_r1cs_destroy(b3w_r1cs *r) {
   if (r->d_coefR) (void)hipFree(r->d_coefR);
   for (uint32_t *q : {r->d_tiles, r->d_ext, r->d_trows, r->d_trow_id, r->d_terms, r->d_tile_terms}) if (q) (void)hipFree(q);
   if (r->d_coef_small) (void)hipFree(r->d_coef_small);
+  if (r->d_trow_k) (void)hipFree(r->d_trow_k);
+  for (auto &kv : r->scratch) if (kv.second) (void)hipFree(kv.second);
   delete r;
 }
 
@@ -1324,8 +1342,23 @@ int32_t b3w_r1cs_check_device(b3w_ctx *ctx, const b3w_r1cs *r, const uint8_t *d_
     return B3W_E_BAD_ARGUMENT;
   }
   ON_DEVICE(ctx);
-  static const bool gather_only = getenv("B3W_R1CS_GATHER") && !strcmp(getenv("B3W_R1CS_GATHER"), "1");      // the other kernel, for comparison
-  const int rc = r->tiled && !gather_only
+  // B3W_R1CS_GATHER=1: the gather kernel, =2: the 32-byte tile kernel — the other formulations, for comparison
+  static const int other = getenv("B3W_R1CS_GATHER") ? atoi(getenv("B3W_R1CS_GATHER")) : 0;
+  if (r->tiled && other == 0) {
+    unsigned long long *scratch = nullptr;
+    {
+      std::lock_guard<std::mutex> lock(r->scratch_mu);
+      auto it = r->scratch.find(stream);
+      if (it == r->scratch.end()) {
+        // (the first check on a stream allocates: do one before capturing that stream into a graph)
+        HIP_TRY(ctx, hipMalloc((void **)&scratch, b3w_r1cs_scratch_bytes(&r->sys)));
+        r->scratch[stream] = scratch;
+      } else scratch = it->second;
+    }
+    const int lrc = b3w_launch_r1cs_lean(d_bodies, n, pitch, &r->sys, &r->field, scratch, d_violations, d_first, (hipStream_t)stream);
+    return lrc ? hip_fail(ctx, (hipError_t)lrc, "r1cs check launch") : B3W_OK;
+  }
+  const int rc = r->tiled && other != 1
                      ? b3w_launch_r1cs_tiled(d_bodies, n, pitch, r->nwires, r->ntiles, r->max_ext, r->max_tile_terms, r->d_tiles, r->d_tile_terms, r->d_ext, r->d_trows,
                                              r->d_trow_id, r->d_terms, r->d_coefR, r->d_coef_small, r->ncoef, &r->field, d_violations, d_first, (hipStream_t)stream)
                      : b3w_launch_r1cs(d_bodies, n, pitch, r->m, r->d_rows, r->d_row_id, r->d_wires, r->d_cids, r->d_coefR, &r->field,

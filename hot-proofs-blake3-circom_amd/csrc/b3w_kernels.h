@@ -91,3 +91,18 @@ extern "C" int b3w_launch_r1cs_tiled(const uint8_t *d_bodies, uint32_t n, uint64
                                      uint32_t max_tile_terms, const uint32_t *d_tiles, const uint32_t *d_tile_terms /* ntiles x {first term, terms} */, const uint32_t *d_ext, const uint32_t *d_rows, const uint32_t *d_row_id,
                                      const uint32_t *d_terms, const uint32_t *d_coefs, const long long *d_coef_small, uint32_t ncoef,
                                      const B3wField *field, uint32_t *d_violations, uint32_t *d_first, hipStream_t stream);
+// the LEAN pair (default): the same tiles with 8-byte elements in LDS and integer arithmetic only; the rows a workgroup cannot
+// decide that way (an element of 2^63 or more, a coefficient that is no small integer, |<A,z>| or |<B,z>| of 2^63 or more) are
+// marked in `scratch` and evaluated by a second launch with the gather kernel's field arithmetic.  Same verdicts as the other
+// two kernels.  row_k[r] = the gather formulation's row number of tile row r.
+struct B3wR1csSystem {
+  uint32_t nwires, ntiles, max_ext, max_tile_terms, max_tile_rows, ncoef;
+  const uint32_t *tiles, *tile_terms, *ext, *rows, *row_id, *row_k, *terms, *coefs;
+  const long long *coef_small;
+  const uint32_t *g_rows, *g_wires;
+  const uint16_t *g_cids;
+};
+#define B3W_R1CS_SLAB 8192u                                  // bodies per launch pair: bounds the scratch
+extern "C" size_t b3w_r1cs_scratch_bytes(const B3wR1csSystem *sys);
+extern "C" int b3w_launch_r1cs_lean(const uint8_t *d_bodies, uint32_t n, uint64_t pitch, const B3wR1csSystem *sys, const B3wField *field,
+                                    unsigned long long *d_scratch, uint32_t *d_violations, uint32_t *d_first, hipStream_t stream);

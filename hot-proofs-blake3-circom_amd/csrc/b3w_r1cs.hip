@@ -189,6 +189,38 @@ __device__ __forceinline__ Fe dot(const uint8_t *body, const uint32_t *wires, co
   return acc;
 }
 
+// one row of the gather formulation over one body: violated?  (d = first term, terms in A, B, C)
+__device__ __forceinline__ bool gather_row(const uint8_t *body, const uint4 d, const uint32_t *wires, const uint16_t *cids,
+                                           const uint32_t *coefR, const B3wField &F) {
+  bool wild = false, bad;
+  const Fe cz = dot(body, wires, cids, coefR, d.x + d.y + d.z, d.w, F, &wild);
+  if (d.y == 0 || d.z == 0) {
+    bad = !fe_is_zero(cz);                               // 0 * B - C = 0  (a linear constraint)
+    if (d.y) (void)dot(body, wires, cids, coefR, d.x, d.y, F, &wild);                // still read for the canonical-form check
+    if (d.z) (void)dot(body, wires, cids, coefR, d.x + d.y, d.z, F, &wild);
+  } else {
+    const Fe az = dot(body, wires, cids, coefR, d.x, d.y, F, &wild);
+    const Fe bz = dot(body, wires, cids, coefR, d.x + d.y, d.z, F, &wild);
+    const int as = small01(az), bs = small01(bz);
+    Fe ab;
+    if (as == 0 || bs == 0) {                                                        // 0 * x
+#pragma unroll
+      for (int i = 0; i < 8; i++) ab.l[i] = 0;
+    } else if (as == 1) ab = bz;                                                     // 1 * x
+    else if (bs == 1) ab = az;
+    else {
+      Fe r2;
+#pragma unroll
+      for (int i = 0; i < 8; i++) r2.l[i] = F.r2[i];
+      ab = mont_mul(mont_mul(az, r2, F), bz, F);                                     // (az * R) * bz / R = az * bz
+    }
+    Fe diff = ab;
+    fe_sub(diff, cz, F.p);
+    bad = !fe_is_zero(diff);
+  }
+  return bad || wild;                                    // an element >= p is no witness value, whatever it is congruent to
+}
+
 __global__ __launch_bounds__(256) void b3w_r1cs_kernel(const uint8_t *__restrict__ bodies, uint64_t pitch, uint32_t n, uint32_t m,
                                                        uint32_t row_blocks, const uint4 *__restrict__ rows /* off, nA, nB, nC */,
                                                        const uint32_t *__restrict__ row_id, const uint32_t *__restrict__ wires,
@@ -203,34 +235,7 @@ __global__ __launch_bounds__(256) void b3w_r1cs_kernel(const uint8_t *__restrict
   bool bad = false;
   uint32_t id = 0xFFFFFFFFu;
   if (r < m) {
-    const uint4 d = rows[r];
-    bool wild = false;
-    const Fe cz = dot(body, wires, cids, coefR, d.x + d.y + d.z, d.w, F, &wild);
-    if (d.y == 0 || d.z == 0) {
-      bad = !fe_is_zero(cz);                             // 0 * B - C = 0  (a linear constraint)
-      if (d.y) (void)dot(body, wires, cids, coefR, d.x, d.y, F, &wild);              // still read for the canonical-form check
-      if (d.z) (void)dot(body, wires, cids, coefR, d.x + d.y, d.z, F, &wild);
-    } else {
-      const Fe az = dot(body, wires, cids, coefR, d.x, d.y, F, &wild);
-      const Fe bz = dot(body, wires, cids, coefR, d.x + d.y, d.z, F, &wild);
-      const int as = small01(az), bs = small01(bz);
-      Fe ab;
-      if (as == 0 || bs == 0) {                                                      // 0 * x
-#pragma unroll
-        for (int i = 0; i < 8; i++) ab.l[i] = 0;
-      } else if (as == 1) ab = bz;                                                   // 1 * x
-      else if (bs == 1) ab = az;
-      else {
-        Fe r2;
-#pragma unroll
-        for (int i = 0; i < 8; i++) r2.l[i] = F.r2[i];
-        ab = mont_mul(mont_mul(az, r2, F), bz, F);                                   // (az * R) * bz / R = az * bz
-      }
-      Fe diff = ab;
-      fe_sub(diff, cz, F.p);
-      bad = !fe_is_zero(diff);
-    }
-    bad = bad || wild;                                   // an element >= p is no witness value, whatever it is congruent to
+    bad = gather_row(body, rows[r], wires, cids, coefR, F);
     id = row_id[r];
   }
   const uint64_t mask = __ballot(bad);
@@ -425,6 +430,237 @@ __global__ __launch_bounds__(256) void b3w_r1cs_tile_kernel(const uint8_t *__res
   }
 }
 
+// ---- lean pair ------------------------------------------------------------------------------------------------------
+// The tile kernel above carries the whole field arithmetic in every lane (150 VGPRs: three waves per SIMD) and 32-byte
+// elements (40 KB of LDS per workgroup), and its waves sit on one dependent L2 load per term (profiles/r02: parked 63 % of
+// their cycles).  A valid witness of these circuits needs none of that: its elements are bits, 32-bit words and a few
+// sums, the coefficients +-1, +-2^i and the IV words.  The LEAN kernel keeps only that case: elements as 8 bytes in LDS
+// (bit 63 = "not below 2^63"), the tile's term list and the coefficient table in LDS beside them (30 KB in all for
+// blake3_compression: five workgroups per CU, no global load inside the row loop), rows summed as 128-bit integers.  A row
+// it cannot decide that way is DEFERRED: one bit per row in `scratch`, evaluated afterwards by b3w_r1cs_deferred_kernel
+// with gather_row() — the rows of the 66 field inverses of a nova step, and whatever a corrupted body contains.
+//
+// scratch: per (body, tile) a block of 1 + 4 * ceil(max_tile_rows / 256) 64-bit words: [0] = any row deferred,
+// [1 + 4 * it + wave] = the deferred lanes of that wave in iteration `it` (row = first + 256 * it + thread).  Every word the
+// second kernel reads is written by the first: no initialisation.
+
+__device__ __forceinline__ unsigned long long lean_pack(const uint4 lo, const uint4 hi) {
+  const uint32_t wide = lo.z | lo.w | hi.x | hi.y | hi.z | hi.w | (lo.y & 0x80000000u);
+  return wide ? 0x8000000000000000ull : (unsigned long long)lo.x | (unsigned long long)lo.y << 32;
+}
+
+// <row part, z> as an exact integer; *defer when a term is outside the integer case (then the sum is not used).
+// The wave takes one of two roads per term: all its elements are bits (98 % of a valid witness) — the coefficient is added
+// or not, no multiplication — or the general 64 x 64 -> 128 product.  The next term word is fetched one step ahead (the word
+// behind a row's last term is the next row's first or the pad behind the list: always inside the array).
+__device__ __forceinline__ __int128 lean_dot(const unsigned long long *el, const uint32_t *terms, const long long *coef, uint32_t off,
+                                             uint32_t n, bool *defer) {
+  __int128 s = 0;
+  if (n == 0) return s;
+  uint32_t t = terms[off];
+  for (uint32_t k = 0; k < n; k++) {
+    const uint32_t tn = terms[off + k + 1];
+    const unsigned long long z = el[t & 0xFFFFu];
+    const long long c = coef[t >> 16];
+    t = tn;
+    if (c == B3W_R1CS_NOT_SMALL) *defer = true;            // (the sentinel's product below is never used)
+    if (__builtin_amdgcn_ballot_w64(z > 1ull) == 0) {
+      s += (__int128)(z ? c : 0ll);
+    } else {
+      const unsigned long long mag = c < 0 ? 0ull - (unsigned long long)c : (unsigned long long)c;
+      // |c| < 2^62 with z < 2^32, or |c| < 2^40 with z < 2^63: the product stays below 2^103 and 2^20 of them below 2^127
+      if ((z >> 63) || ((z >> 32) && mag >= (1ull << 40))) *defer = true;
+      s += (__int128)c * (__int128)(long long)z;
+    }
+  }
+  return s;
+}
+
+template <bool STAGED, bool COEF_LDS>
+__global__ __launch_bounds__(256) void b3w_r1cs_lean_kernel(const uint8_t *__restrict__ bodies, uint64_t pitch, uint32_t n, B3wR1csSystem S,
+                                                            unsigned long long *__restrict__ scratch, uint32_t block_words,
+                                                            uint32_t *__restrict__ violations, uint32_t *__restrict__ first) {
+  extern __shared__ unsigned long long el[];
+  const uint32_t per_group = 8u * S.ntiles;
+  const uint32_t b = (blockIdx.x / per_group) * 8u + (blockIdx.x & 7u);
+  const uint32_t tile = (blockIdx.x % per_group) >> 3;
+  if (b >= n) return;
+  const uint8_t *body = bodies + (uint64_t)b * pitch;
+  const uint4 td = reinterpret_cast<const uint4 *>(S.tiles)[tile];
+  const uint4 *rows = reinterpret_cast<const uint4 *>(S.rows);
+  const uint32_t t0 = tile * B3W_R1CS_TILE;
+  const uint32_t n_local = S.nwires - t0 < B3W_R1CS_TILE ? S.nwires - t0 : B3W_R1CS_TILE;
+  constexpr uint32_t PRE = 4;                              // row descriptors fetched under the staging (4 rows per lane in these systems)
+  uint4 pre[PRE];
+#pragma unroll
+  for (uint32_t q = 0; q < PRE; q++) {
+    const uint32_t r = td.x + threadIdx.x + 256 * q;
+    pre[q] = r < td.x + td.y ? rows[r] : make_uint4(0, 0, 0, 0);
+  }
+  // Staging.  Every load is issued before the first LDS write waits for one (a loop of load - pack - write makes each lane's
+  // loads serial round trips to HBM: 25 of them for a tile of blake3_compression).  LDS: elements [TILE + ext_cap] |
+  // term words | coefficients.
+  const uint2 tt = reinterpret_cast<const uint2 *>(S.tile_terms)[tile];            // first term of the tile (a multiple of 4), how many
+  const uint32_t ext_cap = (S.max_ext + 2u) & ~1u;                                // one dump slot; keeps the term words 16-byte aligned
+  uint4 *lterms4 = reinterpret_cast<uint4 *>(el + B3W_R1CS_TILE + ext_cap);
+  uint32_t *lterms = reinterpret_cast<uint32_t *>(lterms4);
+  const uint32_t lterm_words = STAGED ? (S.max_tile_terms + 4u) & ~3u : 0u;       // (room for the read-ahead word)
+  long long *lcoef = reinterpret_cast<long long *>(lterms + lterm_words + (STAGED ? 4u : 0u));       // (+ the dump uint4)
+  // (lanes with nothing to stage load element 0 / word 0 and write a dump slot: no branch for the compiler to sink a load into)
+  const uint32_t el_dump = B3W_R1CS_TILE + ext_cap - 1u;                           // (behind the last outside wire)
+  const uint32_t ew = S.ext[td.z + (threadIdx.x < td.w ? threadIdx.x : 0u)];       // this lane's outside wire (every tile has one)
+  uint4 lo[4], hi[4];
+#pragma unroll
+  for (uint32_t u = 0; u < 4; u++) {                                               // TILE = 4 x 256 elements
+    const uint32_t i = threadIdx.x + 256 * u;
+    const uint4 *q = reinterpret_cast<const uint4 *>(body + (size_t)(t0 + (i < n_local ? i : 0u)) * 32);
+    lo[u] = q[0]; hi[u] = q[1];
+  }
+  const uint4 *terms4 = reinterpret_cast<const uint4 *>(S.terms + tt.x);
+  const uint32_t nt4 = (tt.y + 4u) >> 2;                                           // the tile's term words + the read-ahead word, in fours
+  const uint32_t t_dump = lterm_words >> 2;                                        // one uint4 behind the list
+  // (named registers, not an array: the array went to scratch memory)
+  const uint32_t k40 = threadIdx.x, k41 = threadIdx.x + 256, k42 = threadIdx.x + 512, k43 = threadIdx.x + 768;
+  uint4 tv0 = make_uint4(0, 0, 0, 0), tv1 = tv0, tv2 = tv0, tv3 = tv0;
+  if (STAGED) {
+    tv0 = terms4[k40 < nt4 ? k40 : 0u];
+    tv1 = terms4[k41 < nt4 ? k41 : 0u];
+    tv2 = terms4[k42 < nt4 ? k42 : 0u];
+    tv3 = terms4[k43 < nt4 ? k43 : 0u];
+  }
+  long long cv[2] = {0, 0};
+  if (COEF_LDS) {
+#pragma unroll
+    for (uint32_t u = 0; u < 2; u++) {                                             // ncoef <= 512
+      const uint32_t k = threadIdx.x + 256 * u;
+      cv[u] = S.coef_small[k < S.ncoef ? k : 0u];
+    }
+  }
+  __builtin_amdgcn_sched_barrier(0);                                               // (the dependent load goes last)
+  const uint4 *eq = reinterpret_cast<const uint4 *>(body + (size_t)ew * 32);
+  const uint4 elo = eq[0], ehi = eq[1];
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (uint32_t u = 0; u < 4; u++) {
+    const uint32_t i = threadIdx.x + 256 * u;
+    el[i < n_local ? i : el_dump] = lean_pack(lo[u], hi[u]);
+  }
+  if (STAGED) {
+    lterms4[k40 < nt4 ? k40 : t_dump] = tv0;
+    lterms4[k41 < nt4 ? k41 : t_dump] = tv1;
+    lterms4[k42 < nt4 ? k42 : t_dump] = tv2;
+    lterms4[k43 < nt4 ? k43 : t_dump] = tv3;
+  }
+  if (COEF_LDS) {
+#pragma unroll
+    for (uint32_t u = 0; u < 2; u++) {
+      const uint32_t k = threadIdx.x + 256 * u;
+      if (k < S.ncoef) lcoef[k] = cv[u];
+    }
+  }
+  el[B3W_R1CS_TILE + (threadIdx.x < td.w ? threadIdx.x : ext_cap - 1u)] = lean_pack(elo, ehi);
+  if (STAGED) {
+    for (uint32_t base = 1024; base < nt4; base += 1024) {                         // lists beyond 4 096 words: four loads in flight again
+      const uint32_t a0 = base + k40, a1 = base + k41, a2 = base + k42, a3 = base + k43;
+      const uint4 w0 = terms4[a0 < nt4 ? a0 : 0u], w1 = terms4[a1 < nt4 ? a1 : 0u], w2 = terms4[a2 < nt4 ? a2 : 0u],
+                  w3 = terms4[a3 < nt4 ? a3 : 0u];
+      lterms4[a0 < nt4 ? a0 : t_dump] = w0;
+      lterms4[a1 < nt4 ? a1 : t_dump] = w1;
+      lterms4[a2 < nt4 ? a2 : t_dump] = w2;
+      lterms4[a3 < nt4 ? a3 : t_dump] = w3;
+    }
+  }
+  for (uint32_t j = threadIdx.x + 256; j < td.w; j += 256) {                       // (more than 256 outside wires)
+    const uint4 *q = reinterpret_cast<const uint4 *>(body + (size_t)S.ext[td.z + j] * 32);
+    el[B3W_R1CS_TILE + j] = lean_pack(q[0], q[1]);
+  }
+  const uint32_t *tsrc = STAGED ? lterms : S.terms;
+  const uint32_t tbase = STAGED ? tt.x : 0u;                                      // row offsets are global term numbers
+  const long long *csrc = COEF_LDS ? lcoef : S.coef_small;
+  __syncthreads();
+  const bool w0_is_one = el[tile == 0 ? 0 : B3W_R1CS_TILE] == 1ull;                // (outside wire 0 of every other tile)
+  unsigned long long *block = scratch + ((size_t)b * S.ntiles + tile) * block_words;
+  const uint32_t iters = (td.y + 255u) >> 8;
+  const __int128 lim = (__int128)1 << 63;
+  uint32_t nbad = 0, low = 0xFFFFFFFFu;
+  bool any = false;
+  // one iteration: row td.x + 256 * it + thread, its descriptor already in `d` (the first PRE calls are straight-line code so
+  // that `pre` stays in registers)
+  auto iteration = [&](const uint32_t it, const uint4 d) {
+    const uint32_t r = td.x + threadIdx.x + 256 * it;
+    bool defer = false, bad = false;
+    if (r < td.x + td.y) {
+      if ((d.y >> 31) && w0_is_one) {
+        bad = el[d.w] > 1ull;                              // booleanity (see the tile kernel); an element of 2^63 or more is no bit
+      } else {
+        const uint32_t na = d.y & 0x7FFFFFFFu;
+        const uint32_t t0r = d.x - tbase;
+        const uint32_t nc = (d.y >> 31) ? 0u : d.w;
+        const __int128 C = lean_dot(el, tsrc, csrc, t0r + na + d.z, nc, &defer);
+        const __int128 A = lean_dot(el, tsrc, csrc, t0r, na, &defer);
+        const __int128 B = lean_dot(el, tsrc, csrc, t0r + na, d.z, &defer);
+        if (!(A < lim && A > -lim && B < lim && B > -lim)) defer = true;
+        bad = !defer && A * B != C;                        // |A * B - C| < 2^127 < p: "= 0 mod p" is "= 0"
+      }
+      if (bad) { nbad++; low = min(low, S.row_id[r]); }
+    }
+    const unsigned long long mask = __ballot(defer);
+    if ((threadIdx.x & 63) == 0) block[1 + 4 * it + (threadIdx.x >> 6)] = mask;
+    any = any || defer;
+  };
+  if (iters > 0) iteration(0, pre[0]);
+  if (iters > 1) iteration(1, pre[1]);
+  if (iters > 2) iteration(2, pre[2]);
+  if (iters > 3) iteration(3, pre[3]);
+  for (uint32_t it = PRE; it < iters; it++) {
+    const uint32_t r = td.x + threadIdx.x + 256 * it;
+    iteration(it, r < td.x + td.y ? rows[r] : make_uint4(0, 0, 0, 0));
+  }
+  const int wg_any = __syncthreads_or(any ? 1 : 0);
+  if (threadIdx.x == 0) block[0] = wg_any ? 1ull : 0ull;
+#pragma unroll
+  for (int sh = 32; sh > 0; sh >>= 1) {
+    nbad += (uint32_t)__shfl_xor((int)nbad, sh);
+    low = min(low, (uint32_t)__shfl_xor((int)low, sh));
+  }
+  if ((threadIdx.x & 63) == 0 && nbad) {
+    atomicAdd(&violations[b], nbad);
+    if (first) atomicMin(&first[b], low);
+  }
+}
+
+// the rows the lean kernel left: (body, tile) workgroups again, almost all of which leave at once
+__global__ __launch_bounds__(256) void b3w_r1cs_deferred_kernel(const uint8_t *__restrict__ bodies, uint64_t pitch, uint32_t n, B3wR1csSystem S,
+                                                                const unsigned long long *__restrict__ scratch, uint32_t block_words, B3wField F,
+                                                                uint32_t *__restrict__ violations, uint32_t *__restrict__ first) {
+  const uint32_t per_group = 8u * S.ntiles;
+  const uint32_t b = (blockIdx.x / per_group) * 8u + (blockIdx.x & 7u);
+  const uint32_t tile = (blockIdx.x % per_group) >> 3;
+  if (b >= n) return;
+  const unsigned long long *block = scratch + ((size_t)b * S.ntiles + tile) * block_words;
+  if (block[0] == 0) return;
+  const uint8_t *body = bodies + (uint64_t)b * pitch;
+  const uint4 td = reinterpret_cast<const uint4 *>(S.tiles)[tile];
+  const uint32_t iters = (td.y + 255u) >> 8;
+  uint32_t nbad = 0, low = 0xFFFFFFFFu;
+  for (uint32_t it = 0; it < iters; it++) {
+    const unsigned long long mask = block[1 + 4 * it + (threadIdx.x >> 6)];
+    if (!((mask >> (threadIdx.x & 63)) & 1ull)) continue;
+    const uint32_t r = td.x + threadIdx.x + 256 * it;                              // (< td.x + td.y: only such lanes set a bit)
+    const uint4 d = reinterpret_cast<const uint4 *>(S.g_rows)[S.row_k[r]];
+    if (gather_row(body, d, S.g_wires, S.g_cids, S.coefs, F)) { nbad++; low = min(low, S.row_id[r]); }
+  }
+#pragma unroll
+  for (int sh = 32; sh > 0; sh >>= 1) {
+    nbad += (uint32_t)__shfl_xor((int)nbad, sh);
+    low = min(low, (uint32_t)__shfl_xor((int)low, sh));
+  }
+  if ((threadIdx.x & 63) == 0 && nbad) {
+    atomicAdd(&violations[b], nbad);
+    if (first) atomicMin(&first[b], low);
+  }
+}
+
 // the result arrays start from "no violation": a kernel rather than hipMemsetAsync, so that the whole check is made of
 // kernel nodes when a caller captures it into a hipGraph (memset nodes of a captured graph were seen to leave garbage)
 __global__ void b3w_r1cs_init_kernel(uint32_t *__restrict__ violations, uint32_t *__restrict__ first, uint32_t n) {
@@ -494,6 +730,49 @@ extern "C" int b3w_launch_r1cs(const uint8_t *d_bodies, uint32_t n, uint64_t pit
     hipLaunchKernelGGL(b3w_r1cs_kernel, dim3(groups * 8 * row_blocks), dim3(256), 0, stream, d_bodies + (uint64_t)b0 * pitch, pitch, nb, m,
                        row_blocks, reinterpret_cast<const uint4 *>(d_rows), d_row_id, d_wires, d_cids, d_coefR, *field, d_violations + b0,
                        d_first ? d_first + b0 : nullptr);
+    e = hipGetLastError();
+    if (e != hipSuccess) return (int)e;
+  }
+  return 0;
+}
+
+static inline uint32_t lean_block_words(const B3wR1csSystem *sys) { return 1u + 4u * ((sys->max_tile_rows + 255u) >> 8); }
+
+extern "C" size_t b3w_r1cs_scratch_bytes(const B3wR1csSystem *sys) {
+  return (size_t)B3W_R1CS_SLAB * sys->ntiles * lean_block_words(sys) * 8;
+}
+
+extern "C" int b3w_launch_r1cs_lean(const uint8_t *d_bodies, uint32_t n, uint64_t pitch, const B3wR1csSystem *sys, const B3wField *field,
+                                    unsigned long long *d_scratch, uint32_t *d_violations, uint32_t *d_first, hipStream_t stream) {
+  if (!n || !sys->ntiles) return 0;
+  if (sys->max_ext > B3W_R1CS_TILE || !d_scratch) return -5;
+  hipError_t e = (hipError_t)r1cs_init_results(d_violations, d_first, n, stream);
+  if (e != hipSuccess) return (int)e;
+  size_t smem = (size_t)(B3W_R1CS_TILE + ((sys->max_ext + 2u) & ~1u)) * 8;                            // (+ the dump element)
+  // the term list rides along while three workgroups still fit a CU
+  const size_t term_bytes = (size_t)((sys->max_tile_terms + 4u) & ~3u) * 4 + 16;                    // (+ the dump slot)
+  const bool coef_lds = sys->ncoef <= 512;                 // 4 KB at most
+  const bool staged = smem + term_bytes + (coef_lds ? (size_t)sys->ncoef * 8 : 0) <= 52 * 1024;
+  if (staged) smem += term_bytes;
+  if (coef_lds) smem += (size_t)sys->ncoef * 8;
+  const uint32_t bw = lean_block_words(sys);
+  uint32_t slab = (0x7FFFFFFFu / sys->ntiles) & ~7u;
+  if (slab > B3W_R1CS_SLAB) slab = B3W_R1CS_SLAB;
+  for (uint32_t b0 = 0; b0 < n; b0 += slab) {
+    const uint32_t nb = n - b0 < slab ? n - b0 : slab;
+    const dim3 grid(((nb + 7) / 8) * 8 * sys->ntiles);
+#define B3W_R1CS_LEAN_LAUNCH(STAGED, CL)                                                                                               \
+    hipLaunchKernelGGL((b3w_r1cs_lean_kernel<STAGED, CL>), grid, dim3(256), smem, stream, d_bodies + (uint64_t)b0 * pitch, pitch, nb, *sys,   \
+                       d_scratch, bw, d_violations + b0, d_first ? d_first + b0 : nullptr)
+    if (staged && coef_lds) B3W_R1CS_LEAN_LAUNCH(true, true);
+    else if (staged) B3W_R1CS_LEAN_LAUNCH(true, false);
+    else if (coef_lds) B3W_R1CS_LEAN_LAUNCH(false, true);
+    else B3W_R1CS_LEAN_LAUNCH(false, false);
+#undef B3W_R1CS_LEAN_LAUNCH
+    e = hipGetLastError();
+    if (e != hipSuccess) return (int)e;
+    hipLaunchKernelGGL(b3w_r1cs_deferred_kernel, grid, dim3(256), 0, stream, d_bodies + (uint64_t)b0 * pitch, pitch, nb, *sys, d_scratch, bw,
+                       *field, d_violations + b0, d_first ? d_first + b0 : nullptr);
     e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
   }

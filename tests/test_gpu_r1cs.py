@@ -266,9 +266,10 @@ def test_nova_o2_builds_on_the_device(circuit):
 
 
 def test_gather_kernel_gives_the_same_verdicts(tmp_path):
-    """csrc/b3w_r1cs.hip has two kernels with the same arithmetic: the LDS-tile one (taken whenever the system is local
-    enough) and the gather one (any system).  A child process with B3W_R1CS_GATHER=1 runs the gather kernel over the same
-    clean and corrupted bodies; counts and first violated rows must be identical."""
+    """csrc/b3w_r1cs.hip has three formulations with the same verdicts: the lean pair (8-byte elements and integer sums in
+    LDS, deferred rows by field arithmetic; taken whenever the system is local enough), the gather kernel (any system;
+    B3W_R1CS_GATHER=1) and the 32-byte tile kernel (B3W_R1CS_GATHER=2).  Child processes run each over the same clean and
+    corrupted bodies; counts and first violated rows must be identical."""
     import json, os, subprocess, sys
     script = r'''
 import importlib, json, os, sys, random
@@ -276,7 +277,7 @@ import numpy as np, torch
 sys.path.insert(0, os.getcwd())
 m = importlib.import_module("hot-proofs-blake3-circom_amd")
 out = {}
-for circuit in ("compression", "nova_bn254_o1"):
+for circuit in ("compression", "nova_bn254_o1", "nova_vesta"):
     ctx = m.Context(circuit, 0)
     r1cs = m.R1cs(ctx)
     n = 300
@@ -297,12 +298,12 @@ for circuit in ("compression", "nova_bn254_o1"):
 print(json.dumps(out))
 '''
     res = {}
-    for mode in ("0", "1"):
+    for mode in ("0", "1", "2"):
         r = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, cwd=T.ROOT, timeout=600,
                            env=dict(os.environ, B3W_R1CS_GATHER=mode))
         assert r.returncode == 0, r.stderr[-1500:]
         res[mode] = json.loads(r.stdout.strip().splitlines()[-1])
-    assert res["0"] == res["1"]
+    assert res["0"] == res["1"] == res["2"]
     for circuit in res["0"]:
         viol = res["0"][circuit][0]
         assert all(v == 0 for v in viol[1::2]) and all(v > 0 for v in viol[0::2]), circuit
