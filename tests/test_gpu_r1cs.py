@@ -338,3 +338,41 @@ def test_mutated_images_never_crash_the_parser(env):
             assert e.status in (100, 5) and "r1cs" in str(e), str(e)
             refused += 1
     assert refused >= 230 and refused + loaded == 400
+
+
+def test_slabs_and_streams(env):
+    """The lean kernel pair checks in slabs of 8 192 bodies through one deferred-row scratch per stream: a batch that spans
+    two slabs with corrupted bodies on both sides of the border is judged body by body like the same bodies checked alone,
+    and two streams checking different batches with one R1cs object at the same time do not disturb each other."""
+    torch, m, ctx = env["torch"], env["m"], env["ctx"]
+    dev = env["dev"]
+    n = 8192 + 300
+    recs = m.workloads.config2_compression(n, first=123)
+    d_recs = torch.from_numpy(recs.view(np.int32)).to(dev)
+    bodies = torch.empty((n, ctx.body_bytes), dtype=torch.uint8, device=dev)
+    ctx.run_device(d_recs.data_ptr(), n, bodies.data_ptr(), 0, 0, 0, torch.cuda.current_stream().cuda_stream)
+    rng = random.Random(5)
+    hit = sorted(rng.sample(range(8000, n), 60) + [0, 8191, 8192, n - 1])
+    elems = bodies.view(n, ctx.witness_size, 32)
+    for i in hit:                                            # a random element (almost surely >= 2^63: a deferred row) or a 2
+        s = rng.randrange(1, ctx.witness_size)
+        val = rng.randrange(1 << 250) if i % 2 else 2
+        elems[i, s] = torch.from_numpy(np.frombuffer(val.to_bytes(32, "little"), dtype=np.uint8).copy()).to(dev)
+    viol, first = _check(env, bodies)
+    got = set(np.nonzero(viol)[0].tolist())
+    assert got == set(hit), (sorted(got - set(hit))[:10], sorted(set(hit) - got)[:10])
+    alone_v, alone_f = _check(env, bodies[hit].contiguous())
+    assert np.array_equal(viol[hit], alone_v) and np.array_equal(first[hit], alone_f)
+    # two streams, one R1cs object
+    r1cs = env["r1cs"]
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    a, b = bodies[:3000], bodies[8000:8400].contiguous()
+    va = torch.full((a.shape[0],), 7, dtype=torch.int32, device=dev)
+    vb = torch.full((b.shape[0],), 7, dtype=torch.int32, device=dev)
+    torch.cuda.synchronize()
+    for _ in range(4):
+        r1cs.check_device(a.data_ptr(), a.shape[0], 0, va.data_ptr(), 0, sa.cuda_stream)
+        r1cs.check_device(b.data_ptr(), b.shape[0], 0, vb.data_ptr(), 0, sb.cuda_stream)
+    torch.cuda.synchronize()
+    assert np.array_equal(va.cpu().numpy().view(np.uint32), viol[:3000])
+    assert np.array_equal(vb.cpu().numpy().view(np.uint32), viol[8000:8400])
