@@ -1,4 +1,5 @@
-//! Source-only FFI stub (no Rust toolchain in the build image; not compiled or tested here).
+//! Source-only FFI stub (no Rust toolchain in the build image: not compiled here; its extern declarations are held
+//! against include/b3wit.h by tests/test_rust_ffi_decls_cpu.py).
 //! Drop-in for `circom_scotia::calculate_witness(&cfg, input, true)` at
 //! rust_fold/src/blake3_circuit.rs:305 of banyancomputer/hot-proofs-blake3-circom, over the C-ABI of
 //! libb3wit.so (include/b3wit.h).  The stale `override_h_to_IV` input (blake3_circuit.rs:260-265,285) must

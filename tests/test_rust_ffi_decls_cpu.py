@@ -1,0 +1,107 @@
+"""integrations/rust/b3wit_ffi.rs cannot be compiled here (no Rust toolchain), but its `extern "C"` declarations can be held
+against include/b3wit.h: every function the stub binds exists in the header with the same number of parameters, the same
+integer widths, pointer-ness and constness, and the same return type.  (the stub replaces
+circom_scotia::calculate_witness at rust_fold/src/blake3_circuit.rs:305.)"""
+import os
+import re
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _split_args(s):
+    out, depth, cur = [], 0, ""
+    for ch in s:
+        if ch in "(<[":
+            depth += 1
+        elif ch in ")>]":
+            depth -= 1
+        if ch == "," and depth == 0:
+            out.append(cur.strip()); cur = ""
+        else:
+            cur += ch
+    if cur.strip():
+        out.append(cur.strip())
+    return out
+
+
+def _c_decls():
+    text = open(os.path.join(ROOT, "include", "b3wit.h")).read()
+    text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
+    text = re.sub(r"//[^\n]*", " ", text)
+    decls = {}
+    for m in re.finditer(r"([A-Za-z_][A-Za-z0-9_ \*]*?)\b(b3w_[a-z0-9_]+)\s*\(([^;{]*)\)\s*;", text):
+        ret, name, args = m.group(1).strip(), m.group(2), m.group(3)
+        if "typedef" in ret:
+            continue
+        decls[name] = (ret, [] if args.strip() in ("", "void") else _split_args(args))
+    return decls
+
+
+INT = {"int32_t": "i32", "uint32_t": "u32", "uint64_t": "u64", "int64_t": "i64", "size_t": "usize", "int": "i32",
+       "uint8_t": "u8", "char": "c_char", "uint16_t": "u16"}
+
+
+def _c_fnptr_typedefs():
+    """typedef void (*name)(args); -> {name: [arg shapes]}"""
+    text = open(os.path.join(ROOT, "include", "b3wit.h")).read()
+    text = re.sub(r"/\*.*?\*/", " ", text, flags=re.S)
+    return {m.group(1): [_c_shape(a) for a in _split_args(m.group(2))]
+            for m in re.finditer(r"typedef\s+void\s*\(\s*\*\s*(b3w_[a-z0-9_]+)\s*\)\s*\(([^;]*)\)\s*;", text)}
+
+
+def _c_shape(decl):
+    """C parameter or return type -> canonical shape string, e.g. '*const u8', '*mut *mut opaque', 'u32', 'fnptr'."""
+    d = decl.strip()
+    if "(*" in d or re.match(r"b3w_[a-z0-9_]*consumer\b", d):
+        return "fnptr"
+    d = re.sub(r"\[[^\]]*\]", "*", d)                        # uint8_t out[76] -> pointer
+    stars = d.count("*")
+    const = bool(re.search(r"\bconst\b", d))
+    base = re.sub(r"\bconst\b|\bstruct\b|\*", " ", d).split()
+    base = base[0] if base else "void"
+    if stars == 0:
+        return INT.get(base, base)
+    kind = INT.get(base, "opaque")                          # struct handles, void, hipStream_t-as-void* are opaque
+    return ("*mut " * (stars - 1)) + ("*const " if const else "*mut ") + kind
+
+
+def _rs_shape(t):
+    t = t.strip()
+    if t.startswith("Option<extern"):
+        return "fnptr"
+    t = t.replace("c_void", "opaque")
+    return t
+
+
+def test_every_bound_function_matches_the_header():
+    src = open(os.path.join(ROOT, "integrations", "rust", "b3wit_ffi.rs")).read()
+    c = _c_decls()
+    bound = re.findall(r"\bfn\s+(b3w_[a-z0-9_]+)\s*\((.*?)\)\s*(?:->\s*([A-Za-z0-9_]+))?\s*;", src, flags=re.S)
+    assert len(bound) >= 14
+    for name, args, ret in bound:
+        assert name in c, f"{name} is not declared in include/b3wit.h"
+        c_ret, c_args = c[name]
+        assert _c_shape(c_ret) == (ret or "void"), (name, c_ret, ret)
+        rs_args = [a.split(":", 1)[1] for a in _split_args(" ".join(args.split()))]
+        assert len(rs_args) == len(c_args), (name, rs_args, c_args)
+        for k, (ra, ca) in enumerate(zip(rs_args, c_args)):
+            want, got = _c_shape(ca), _rs_shape(ra)
+            if want == "fnptr":                                       # the callback's own parameters too
+                cb = _c_fnptr_typedefs()[ca.split()[0]]
+                inner = re.search(r"fn\((.*)\)", ra).group(1)
+                rs_cb = [_rs_shape(a) for a in _split_args(inner)]
+                assert [x.count("*") for x in cb] == [x.count("*") for x in rs_cb] and \
+                       [x.split()[-1] for x in cb] == [x.split()[-1] for x in rs_cb], (name, cb, rs_cb)
+            if want.endswith("opaque") and got.endswith("opaque"):       # handles: constness of an opaque handle is advisory
+                assert want.count("*") == got.count("*"), (name, k, ca, ra)
+            else:
+                assert want == got, (name, k, ca, ra)
+
+
+def test_constants_match_the_header():
+    src = open(os.path.join(ROOT, "integrations", "rust", "b3wit_ffi.rs")).read()
+    hdr = open(os.path.join(ROOT, "include", "b3wit.h")).read()
+    ids = dict(re.findall(r"#define\s+(B3W_CIRCUIT_[A-Z0-9_]+)\s+(\d+)", hdr))
+    for rs_name, c_name in (("CIRCUIT_NOVA_BN254", "B3W_CIRCUIT_NOVA_BN254"), ("CIRCUIT_NOVA_VESTA", "B3W_CIRCUIT_NOVA_VESTA")):
+        m = re.search(rf"pub const {rs_name}: i32 = (\d+);", src)
+        assert m and c_name in ids and m.group(1) == ids[c_name], (rs_name, ids.get(c_name))
