@@ -513,14 +513,18 @@ int32_t b3w_batch_run_device(b3w_ctx *ctx, const uint32_t *d_records, uint32_t n
   if (pitch < body || (pitch & 31)) { ctx->last_error = "pitch must be >= witness_size*32 and a multiple of 32"; return B3W_E_BAD_ARGUMENT; }
   if (reinterpret_cast<uintptr_t>(d_bodies) & 15) { ctx->last_error = "d_bodies must be 16-byte aligned"; return B3W_E_BAD_ARGUMENT; }
   ON_DEVICE(ctx);
-  // default choice of bodies per wave (profiles/r02/batch_curve.json, tools/ubench/batch_curve.py: every setting at every
-  // batch size 64 ... 65 536): small batches want as many waves as bodies (one body streams at 13 GB/s per wave), large
-  // ones few fat waves; above 6 144 compression witnesses the occupancy-limited 8-body variant wins by 4-5 %
+  // default launch shape (profiles/r02/batch_curve.json, sliced_scan_*.log; tools/ubench/batch_curve.py, sliced_scan.py: every
+  // setting at every batch size 1 ... 65 536).  One body streams at 13 GB/s per wave, so up to 2 560 witnesses a body is SLICED
+  // over 64 ... 4 waves (about 4 096 store streams in flight whatever the batch: one witness 56 -> 5 us, 512 witnesses 4.4 -> 7.7
+  // M/s); large batches want few fat waves, and above 6 144 compression witnesses the occupancy-limited 8-body variant wins
+  // by 4-5 %
   int variant = ctx->variant;
   if (ctx->variant_auto) {
-    if (ctx->desc.kind == B3W_KIND_COMP) variant = n <= 1024 ? 1 : n <= 6144 ? 0 : 8;
-    else if (ctx->desc.kind == B3W_KIND_NOVA_O2) variant = n <= 1024 ? 1 : n <= 3072 ? 0 : 3;
-    else variant = n <= 1024 ? 1 : 0;
+    const bool comp = ctx->desc.kind == B3W_KIND_COMP;
+    if (n <= 2560) variant = B3W_VARIANT_SLICED + (n <= (comp ? 32u : 8u) ? 64 : n <= 96 ? 32 : n <= 192 ? 16 : n <= 768 ? 8 : 4);
+    else if (comp) variant = n <= 6144 ? 0 : 8;
+    else if (ctx->desc.kind == B3W_KIND_NOVA_O2) variant = n <= 3072 ? 0 : 3;
+    else variant = 0;
   }
   int rc = b3w_launch_batch(ctx->desc.kind, variant, d_records, n, d_bodies, pitch, ctx->d_table, ctx->desc.nwit,
                             d_public, d_status, ctx->d_aux, ctx->d_scratch, ctx->scratch_cap, (hipStream_t)stream);

@@ -5,6 +5,8 @@
 
 // variants >= B3W_VARIANT_SWEEP use the two-kernel path (TRACE -> HBM scratch -> linear SWEEP of the output)
 #define B3W_VARIANT_SWEEP 100
+// variants B3W_VARIANT_SLICED + s (s = 2 .. 64): one body per wave and s waves per body, each storing 1/s of its tiles (small batches)
+#define B3W_VARIANT_SLICED 20
 #define B3W_SWEEP_GRID 256       // one 256-thread workgroup per CU, tile = 4 KiB: the runtime fill kernel's shape
 #define B3W_SWEEP_LOGC 13
 #define B3W_SWEEP_CHUNK (1u << B3W_SWEEP_LOGC)   // witnesses per TRACE+SWEEP pair = row length of the scratch

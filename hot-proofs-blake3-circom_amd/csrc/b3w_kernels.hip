@@ -185,7 +185,8 @@ __device__ __forceinline__ uint32_t wave_active(const WaveBodies &wb, uint32_t n
 template <int W, int WORDS, bool WIDE, bool NT>
 __device__ __forceinline__ void expand(const uint32_t *lds, const uint32_t *__restrict__ table, uint32_t nwit,
                                        uint8_t *__restrict__ out, uint64_t pitch, const WaveBodies wb, uint32_t n,
-                                       const uint32_t *okmask /* per-w LDS flags or null */, bool all_ok) {
+                                       const uint32_t *okmask /* per-w LDS flags or null */, bool all_ok,
+                                       uint32_t slice = 0, uint32_t slices = 1 /* this wave stores tiles [slice, slice + 1) * per */) {
   constexpr int U = 4;
   const int lane = threadIdx.x;
   const uint32_t nact = wave_active<W>(wb, n);
@@ -197,7 +198,15 @@ __device__ __forceinline__ void expand(const uint32_t *lds, const uint32_t *__re
 #pragma unroll
   for (int w = 0; w < W; ++w) woff[w] = (uint64_t)wb(w) * pitch + (uint32_t)lane * 16u - 32u * j;
   const uint32_t *tp = table + (lane >> 1) - j;        // entry of this lane's slot in tile 0
-  uint32_t k = 0;
+  uint32_t k = 0, kend_all = ntiles;
+  if (slices > 1) {                                    // SLICED launch: a body's tiles are shared out to `slices` waves, in fours
+    const uint32_t per = ((ntiles + slices - 1) / slices + (U - 1)) & ~(uint32_t)(U - 1);
+    k = slice * per < ntiles ? slice * per : ntiles;
+    kend_all = k + per < ntiles ? k + per : ntiles;
+#pragma unroll
+    for (int w = 0; w < W; ++w) woff[w] += (uint64_t)k * 1024u;
+  }
+  const uint32_t kf1s = kf1 < kend_all ? kf1 : kend_all;
   auto ragged = [&](uint32_t kend) {
     for (; k < kend; ++k) {
       const uint32_t slot = k * 32 + (lane >> 1) - j;   // wraps above nwit for the lanes before the body
@@ -207,11 +216,11 @@ __device__ __forceinline__ void expand(const uint32_t *lds, const uint32_t *__re
     }
   };
   if (nact == (uint32_t)W && all_ok) {
-    ragged(kf0);
+    ragged(kf0 < kend_all ? kf0 : kend_all);
     uint32_t cur[U], nxt[U];
 #pragma unroll
     for (int u = 0; u < U; ++u) cur[u] = tp[(k + u) * 32];   // table is padded by 2U groups past the last slot
-    for (; k + U <= kf1; k += U) {
+    for (; k + U <= kf1s; k += U) {
 #pragma unroll
       for (int u = 0; u < U; ++u) nxt[u] = tp[(k + U + u) * 32];
 #pragma unroll
@@ -222,7 +231,7 @@ __device__ __forceinline__ void expand(const uint32_t *lds, const uint32_t *__re
       for (int u = 0; u < U; ++u) cur[u] = nxt[u];
     }
   }
-  ragged(ntiles);                                        // ragged waves, and the last (partial) tiles
+  ragged(kend_all);                                      // ragged waves, and the last (partial) tiles
 }
 
 // VERIFY (on-device consumer): instead of storing, read the body back and compare it with what its own
@@ -497,16 +506,21 @@ __global__ __launch_bounds__(128 * PAIRS, 1) void b3w_sweep_kernel(const uint32_
 // ------------------------------------------------------------------ compression circuit
 // MODE 0: witnesses -> bodies (fused);  1: images -> scratch (TRACE kernel of the sweep path);
 //      2: VERIFY — recs = in_slots table, out = bodies to check, pub = per-witness mismatch counts
-template <int W, bool NT, int MODE>
+// SL (MODE 0 only): SLICED launch for small batches — `slices` consecutive workgroups take the same W bodies, each recomputes
+// their (cheap) traces and stores 1/slices of the tiles.  A lone body streams at 13 GB/s per wave, so a batch of a few hundred
+// bodies is latency-bound with one wave per body; sliced, it has slices x as many store streams in flight.
+template <int W, bool NT, int MODE, bool SL = false>
 __global__ __launch_bounds__(64) void b3w_compression_kernel(const uint32_t *__restrict__ recs, uint32_t n,
                                                              uint8_t *__restrict__ out, uint64_t pitch,
                                                              const uint32_t *__restrict__ table, uint32_t nwit,
                                                              uint32_t *__restrict__ pub, int32_t *__restrict__ status,
-                                                             uint32_t stride /* WaveBodies; 1 for MODE 1 */) {
+                                                             uint32_t stride /* WaveBodies; 1 for MODE 1 */, uint32_t slices = 1) {
   constexpr int WORDS = B3W_LDS_WORDS_COMP;
   __shared__ __attribute__((aligned(16))) uint32_t lds[W * WORDS + 4];   // +4: expand reads src+1 unconditionally
   const int lane = threadIdx.x;
-  const WaveBodies wb = wave_bodies<W>(blockIdx.x, stride);
+  const uint32_t slice = SL ? blockIdx.x % slices : 0u;
+  if (SL && slice != 0) { pub = nullptr; status = nullptr; }             // slice 0 reports for the body
+  const WaveBodies wb = wave_bodies<W>(SL ? blockIdx.x / slices : blockIdx.x, stride);
   if (wb.first >= n) return;                           // the grid is rounded up to whole stride groups: nothing for this wave
   const uint32_t wit0 = wb.first;                      // MODE 1 runs with stride 1
   // stage the 28-word records of this wave's witnesses into atoms H M T B D (image words 1..28)
@@ -541,7 +555,8 @@ __global__ __launch_bounds__(64) void b3w_compression_kernel(const uint32_t *__r
     uint32_t cnt[W];
     expand_verify<W, WORDS, false>(lds, table, nwit, out, pitch, wb, n, cnt);
     publish_counts<W>(cnt, pub, wb, n, ncf);
-  } else expand<W, WORDS, false, NT>(lds, table, nwit, out, pitch, wb, n, nullptr, true);
+  } else if (SL) expand<W, WORDS, false, NT>(lds, table, nwit, out, pitch, wb, n, nullptr, true, slice, slices);
+  else expand<W, WORDS, false, NT>(lds, table, nwit, out, pitch, wb, n, nullptr, true);
 }
 
 
@@ -645,19 +660,21 @@ __device__ __forceinline__ void lds_put256(uint32_t *L, const U256 &v) {
   *reinterpret_cast<uint4 *>(L + 4) = make_uint4(v.l[4], v.l[5], v.l[6], v.l[7]);
 }
 
-template <int KIND, int W, bool NT, int MODE>
+template <int KIND, int W, bool NT, int MODE, bool SL = false>
 __global__ __launch_bounds__(64) void b3w_nova_kernel(const uint32_t *__restrict__ recs, uint32_t n,
                                                       uint8_t *__restrict__ out, uint64_t pitch,
                                                       const uint32_t *__restrict__ table, uint32_t nwit,
                                                       uint32_t *__restrict__ pub, int32_t *__restrict__ status,
-                                                      const uint32_t *__restrict__ aux, uint32_t stride) {
+                                                      const uint32_t *__restrict__ aux, uint32_t stride, uint32_t slices = 1) {
   constexpr bool O1 = KIND == B3W_KIND_NOVA_O1;
   constexpr int WORDS = O1 ? B3W_LDS_WORDS_NOVA_O1 : B3W_LDS_WORDS_NOVA_O2;
   __shared__ __attribute__((aligned(16))) uint32_t lds[W * WORDS + 4];
   __shared__ uint32_t okf[W];      // 1 = witness computed, stream it out
   __shared__ uint32_t domf[W];     // 1 = an IsZero argument fell outside the supported magnitude
   const int lane = threadIdx.x;
-  const WaveBodies wb = wave_bodies<W>(blockIdx.x, stride);
+  const uint32_t slice = SL ? blockIdx.x % slices : 0u;                  // SLICED launch: see b3w_compression_kernel
+  if (SL && slice != 0) { pub = nullptr; status = nullptr; }
+  const WaveBodies wb = wave_bodies<W>(SL ? blockIdx.x / slices : blockIdx.x, stride);
   if (wb.first >= n) return;                           // the grid is rounded up to whole stride groups: nothing for this wave
   const uint32_t wit0 = wb.first;                      // MODE 1 runs with stride 1
   __shared__ uint32_t ncf[W];      // VERIFY: an input slot of the body is not a plain 32-bit value
@@ -820,7 +837,8 @@ __global__ __launch_bounds__(64) void b3w_nova_kernel(const uint32_t *__restrict
     uint32_t cnt[W];
     expand_verify<W, WORDS, true>(lds, table, nwit, out, pitch, wb, n, cnt);
     publish_counts<W>(cnt, pub, wb, n, ncf);
-  } else expand<W, WORDS, true, NT>(lds, table, nwit, out, pitch, wb, n, okf, all_ok);
+  } else if (SL) expand<W, WORDS, true, NT>(lds, table, nwit, out, pitch, wb, n, okf, all_ok, slice, slices);
+  else expand<W, WORDS, true, NT>(lds, table, nwit, out, pitch, wb, n, okf, all_ok);
 }
 
 }  // namespace
@@ -939,6 +957,13 @@ extern "C" int b3w_launch_batch(int kind, int variant, const uint32_t *d_recs, u
 #define B3W_LAUNCH_COMP(WV, NTV)                                                                         \
   hipLaunchKernelGGL((b3w_compression_kernel<WV, NTV, 0>), B3W_GRID(WV), dim3(64), lds_pad, stream,        \
                      d_recs, n, d_out, pitch, d_table, nwit, d_pub, d_status, stride)
+    if (variant >= B3W_VARIANT_SLICED && variant < B3W_VARIANT_SWEEP) {     // one body per wave, its tiles shared out to `slices` waves
+      const uint32_t slices = (uint32_t)(variant - B3W_VARIANT_SLICED);
+      if (slices < 2 || slices > 64) return -1;
+      hipLaunchKernelGGL((b3w_compression_kernel<1, false, 0, true>), dim3(B3W_GRID(1).x * slices), dim3(64), 0, stream, d_recs, n, d_out,
+                         pitch, d_table, nwit, d_pub, d_status, stride, slices);
+      return (int)hipGetLastError();
+    }
     switch (variant) {
       case 0: B3W_LAUNCH_COMP(4, false); break;
       case 1: B3W_LAUNCH_COMP(1, false); break;
@@ -963,6 +988,17 @@ extern "C" int b3w_launch_batch(int kind, int variant, const uint32_t *d_recs, u
 #define B3W_LAUNCH_NOVA(KV, WV)                                                                           \
   hipLaunchKernelGGL((b3w_nova_kernel<KV, WV, false, 0>), B3W_GRID(WV), dim3(64), lds_pad, stream,          \
                      d_recs, n, d_out, pitch, d_table, nwit, d_pub, d_status, (const uint32_t *)d_aux, stride)
+    if (variant >= B3W_VARIANT_SLICED && variant < B3W_VARIANT_SWEEP) {
+      const uint32_t slices = (uint32_t)(variant - B3W_VARIANT_SLICED);
+      if (slices < 2 || slices > 64) return -1;
+      if (kind == B3W_KIND_NOVA_O2)
+        hipLaunchKernelGGL((b3w_nova_kernel<B3W_KIND_NOVA_O2, 1, false, 0, true>), dim3(B3W_GRID(1).x * slices), dim3(64), 0, stream, d_recs, n,
+                           d_out, pitch, d_table, nwit, d_pub, d_status, (const uint32_t *)d_aux, stride, slices);
+      else
+        hipLaunchKernelGGL((b3w_nova_kernel<B3W_KIND_NOVA_O1, 1, false, 0, true>), dim3(B3W_GRID(1).x * slices), dim3(64), 0, stream, d_recs, n,
+                           d_out, pitch, d_table, nwit, d_pub, d_status, (const uint32_t *)d_aux, stride, slices);
+      return (int)hipGetLastError();
+    }
     if (kind == B3W_KIND_NOVA_O2) {
       switch (variant) {
         case 0: B3W_LAUNCH_NOVA(B3W_KIND_NOVA_O2, 2); break;

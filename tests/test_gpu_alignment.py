@@ -12,7 +12,7 @@ pytestmark = pytest.mark.gpu
 FILL = 0xA5
 
 
-@pytest.mark.parametrize("circuit,variants", [("compression", (0, 1, 2, 3, 7, 8)), ("nova_vesta", (0, 1, 2, 3)), ("nova_bn254_o1", (0, 1))])
+@pytest.mark.parametrize("circuit,variants", [("compression", (0, 1, 2, 3, 7, 8, 22, 28, 84)), ("nova_vesta", (0, 1, 2, 3, 24, 52)), ("nova_bn254_o1", (0, 1, 23, 36))])
 def test_all_alignments_bodies_exact_and_gaps_untouched(circuit, variants):
     import os
     m = T.pkg()

@@ -1,5 +1,6 @@
-"""batch_curve.py — witnesses/s against batch size, 64 ... 65 536, for both circuit families and every bodies-per-wave
-setting, next to what the library's default policy (b3w_batch_run_device without autotune: b3w_capi.cpp) picks.
+"""batch_curve.py — witnesses/s against batch size, 1 ... 65 536, for both circuit families and every launch shape (bodies
+per wave; SLICED = waves per body, B3W_VARIANT 20 + s), next to what the library's default policy (b3w_batch_run_device
+without autotune: b3w_capi.cpp) picks.
 Writes profiles/r02/batch_curve.json (run on the GPU box: `python tools/ubench/batch_curve.py`).  The bodies-per-wave
 setting is B3W_VARIANT: compression 1 -> 1, 2 -> 2, 0 -> 4, 3 -> 8, 8 -> 8 + occupancy limit; nova O2 1 -> 1, 0 -> 2, 3 -> 8."""
 import importlib, json, os, sys
@@ -9,8 +10,9 @@ m = importlib.import_module("hot-proofs-blake3-circom_amd")
 dev = torch.device("cuda:0")
 s = torch.cuda.current_stream().cuda_stream
 OUT = os.path.join(os.getcwd(), "profiles", "r02", "batch_curve.json")
-VARIANTS = {"compression": {1: "W=1", 2: "W=2", 0: "W=4", 3: "W=8", 8: "W=8 occ"}, "nova_vesta": {1: "W=1", 0: "W=2", 3: "W=8"}}
-SIZES = [64, 128, 256, 512, 1024, 2048, 3072, 4096, 8192, 16384, 32768, 65536]
+SLICED = {20 + k: f"sliced {k}" for k in (4, 8, 16, 32, 64)}
+VARIANTS = {"compression": {1: "W=1", 2: "W=2", 0: "W=4", 3: "W=8", 8: "W=8 occ", **SLICED}, "nova_vesta": {1: "W=1", 0: "W=2", 3: "W=8", **SLICED}}
+SIZES = [1, 8, 64, 128, 256, 512, 1024, 2048, 3072, 4096, 8192, 16384, 32768, 65536]
 doc = {"unit": "witnesses/s (kernel only, HIP events over 10-40 launches, best of 3, placed body buffer)", "circuits": {}}
 for circuit, variants in VARIANTS.items():
     nmax = SIZES[-1]
@@ -32,6 +34,8 @@ for circuit, variants in VARIANTS.items():
             ms = min(ctx.time_device(d_recs.data_ptr(), n, buf.ptr, 0, d_pub.data_ptr(), d_st.data_ptr(), s, iters) for _ in range(3))
             return n / ms * 1e3
         for v, name in variants.items():
+            if v >= 20 and n > 4096:                          # sliced launches are for small batches
+                continue
             os.environ["B3W_VARIANT"] = str(v)
             ctx = m.Context(circuit, 0)
             row["rates"][name] = rate(ctx)
