@@ -629,10 +629,14 @@ __global__ __launch_bounds__(256) void b3w_r1cs_lean_kernel(const uint8_t *__res
   }
 }
 
-// the rows the lean kernel left: (body, tile) workgroups again, almost all of which leave at once
-__global__ __launch_bounds__(256) void b3w_r1cs_deferred_kernel(const uint8_t *__restrict__ bodies, uint64_t pitch, uint32_t n, B3wR1csSystem S,
-                                                                const unsigned long long *__restrict__ scratch, uint32_t block_words, B3wField F,
-                                                                uint32_t *__restrict__ violations, uint32_t *__restrict__ first) {
+// the rows the lean kernel left: one WAVE per (body, tile), almost all of which leave on their first load.  A wave, not the
+// lean kernel's four: a row of a flagged tile is a chain of dependent loads (term, element, coefficient), and 116 VGPRs allow
+// sixteen single-wave workgroups per CU where four-wave ones fit four: 354 -> 217 us per 4 096 nova bodies (66 field inverses a
+// step, in two or three tiles).  Compacting the marked rows of a tile into one list first was measured and changed nothing: the
+// time is the rows' own load chains.
+__global__ __launch_bounds__(64) void b3w_r1cs_deferred_kernel(const uint8_t *__restrict__ bodies, uint64_t pitch, uint32_t n, B3wR1csSystem S,
+                                                               const unsigned long long *__restrict__ scratch, uint32_t block_words, B3wField F,
+                                                               uint32_t *__restrict__ violations, uint32_t *__restrict__ first) {
   const uint32_t per_group = 8u * S.ntiles;
   const uint32_t b = (blockIdx.x / per_group) * 8u + (blockIdx.x & 7u);
   const uint32_t tile = (blockIdx.x % per_group) >> 3;
@@ -641,12 +645,12 @@ __global__ __launch_bounds__(256) void b3w_r1cs_deferred_kernel(const uint8_t *_
   if (block[0] == 0) return;
   const uint8_t *body = bodies + (uint64_t)b * pitch;
   const uint4 td = reinterpret_cast<const uint4 *>(S.tiles)[tile];
-  const uint32_t iters = (td.y + 255u) >> 8;
+  const uint32_t words = 4u * ((td.y + 255u) >> 8);      // word 4 * it + wave of the lean kernel = rows first + 64 * word + lane
   uint32_t nbad = 0, low = 0xFFFFFFFFu;
-  for (uint32_t it = 0; it < iters; it++) {
-    const unsigned long long mask = block[1 + 4 * it + (threadIdx.x >> 6)];
-    if (!((mask >> (threadIdx.x & 63)) & 1ull)) continue;
-    const uint32_t r = td.x + threadIdx.x + 256 * it;                              // (< td.x + td.y: only such lanes set a bit)
+  for (uint32_t wi = 0; wi < words; wi++) {
+    const unsigned long long mask = block[1 + wi];
+    if (!((mask >> threadIdx.x) & 1ull)) continue;
+    const uint32_t r = td.x + 64u * wi + threadIdx.x;    // (< td.x + td.y: only such lanes set a bit)
     const uint4 d = reinterpret_cast<const uint4 *>(S.g_rows)[S.row_k[r]];
     if (gather_row(body, d, S.g_wires, S.g_cids, S.coefs, F)) { nbad++; low = min(low, S.row_id[r]); }
   }
@@ -655,7 +659,7 @@ __global__ __launch_bounds__(256) void b3w_r1cs_deferred_kernel(const uint8_t *_
     nbad += (uint32_t)__shfl_xor((int)nbad, sh);
     low = min(low, (uint32_t)__shfl_xor((int)low, sh));
   }
-  if ((threadIdx.x & 63) == 0 && nbad) {
+  if (threadIdx.x == 0 && nbad) {
     atomicAdd(&violations[b], nbad);
     if (first) atomicMin(&first[b], low);
   }
@@ -771,7 +775,7 @@ extern "C" int b3w_launch_r1cs_lean(const uint8_t *d_bodies, uint32_t n, uint64_
 #undef B3W_R1CS_LEAN_LAUNCH
     e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(b3w_r1cs_deferred_kernel, grid, dim3(256), 0, stream, d_bodies + (uint64_t)b0 * pitch, pitch, nb, *sys, d_scratch, bw,
+    hipLaunchKernelGGL(b3w_r1cs_deferred_kernel, grid, dim3(64), 0, stream, d_bodies + (uint64_t)b0 * pitch, pitch, nb, *sys, d_scratch, bw,
                        *field, d_violations + b0, d_first ? d_first + b0 : nullptr);
     e = hipGetLastError();
     if (e != hipSuccess) return (int)e;

@@ -4,7 +4,7 @@ profiles/rNN/<tag>_{kernel_stats.csv, pmc_WRITE_SIZE.csv, pmc_FETCH_SIZE.csv, be
 profiles/rNN/traffic.json + profiles/traffic_latest.json.  Counter rules: /opt/skills/guides/MI355X_MICROARCH.md
 (HBM): values are KiB; on gfx950 FETCH_SIZE reports half of a wide coalesced read stream (double it);
 WRITE_SIZE is exact for 16-byte-per-lane stores."""
-import csv, glob, json, os, sys
+import csv, glob, json, os, re, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag = sys.argv[1]
@@ -13,6 +13,8 @@ src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
 dst = os.path.join(ROOT, "profiles", rnd)
 os.makedirs(dst, exist_ok=True)
 WITNESS_KERNELS = ("b3w_compression_kernel", "b3w_nova_kernel", "b3w_sweep_kernel")
+# the MODE template argument of the witness kernels: <W, NT, MODE, SL> / <KIND, W, NT, MODE, SL> (0 fused, 1 TRACE, 2 VERIFY)
+MODE = re.compile(r"(?:true|false), (\d), (?:true|false)>\(")
 
 
 def find(sub, pattern):
@@ -41,12 +43,12 @@ for name in ("WRITE_SIZE", "FETCH_SIZE"):
     fused = {}
     for r in allrows:
         kn = r["Kernel_Name"]
-        if ("b3w_compression_kernel" in kn or "b3w_nova_kernel" in kn) and ", 0>(" in kn:
+        if ("b3w_compression_kernel" in kn or "b3w_nova_kernel" in kn) and MODE.search(kn) and MODE.search(kn).group(1) == "0":
             fused[kn] = fused.get(kn, 0) + 1
     chosen = max(fused, key=fused.get) if fused else None
     def timed(kn):
         if sweep:
-            return "b3w_sweep_kernel" in kn or ", 1>(" in kn
+            return "b3w_sweep_kernel" in kn or bool(MODE.search(kn) and MODE.search(kn).group(1) == "1")
         return kn == chosen
     keep = [r for r in allrows if timed(r["Kernel_Name"])]
     with open(os.path.join(dst, f"{tag}_pmc_{name}.csv"), "w") as g:
