@@ -236,9 +236,11 @@ napi_value InputSignalSize(napi_env env, napi_callback_info info) {
   return out;
 }
 
-// calcWitness(handle, hashes: Uint32Array [hMSB,hLSB]*, counts: Uint32Array, values: Uint8Array(32*sum)) -> Uint8Array body
+// calcWitness(handle, hashes: Uint32Array [hMSB,hLSB]*, counts: Uint32Array, values: Uint8Array(32*sum)[, asWtns: boolean])
+//   -> Uint8Array body, or the whole .wtns image (76-byte preamble + body, witness_calculator.js:208-272) when asWtns is true:
+//   the body then lands behind the preamble straight from the device, no second 771 KB copy in JS
 napi_value CalcWitness(napi_env env, napi_callback_info info) {
-  size_t argc = 4; napi_value argv[4];
+  size_t argc = 5; napi_value argv[5];
   NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
   Handle *h = get_handle(env, argv[0]);
   if (!h) return nullptr;
@@ -259,11 +261,19 @@ napi_value CalcWitness(napi_env env, napi_callback_info info) {
   if (nv < 32 * total) { napi_throw_range_error(env, nullptr, "values shorter than 32*sum(counts)"); return nullptr; }
   uint32_t nwit = 0;
   api.info(h->ctx, nullptr, nullptr, &nwit, nullptr, nullptr);
-  void *body = nullptr; napi_value abuf, out;
-  NAPI_OK(napi_create_arraybuffer(env, (size_t)nwit * 32, &body, &abuf));
-  const int32_t rc = api.calc_witness(h->ctx, hashes.data(), (const uint32_t *)pc, (const uint8_t *)pv, (uint32_t)nc, (uint8_t *)body);
+  bool as_wtns = false;
+  if (argc >= 5) {
+    napi_valuetype vt;
+    NAPI_OK(napi_typeof(env, argv[4], &vt));
+    if (vt == napi_boolean) NAPI_OK(napi_get_value_bool(env, argv[4], &as_wtns));
+  }
+  const size_t head = as_wtns ? 76 : 0;
+  void *buf = nullptr; napi_value abuf, out;
+  NAPI_OK(napi_create_arraybuffer(env, head + (size_t)nwit * 32, &buf, &abuf));
+  const int32_t rc = api.calc_witness(h->ctx, hashes.data(), (const uint32_t *)pc, (const uint8_t *)pv, (uint32_t)nc, (uint8_t *)buf + head);
   if (rc != B3W_OK) return throw_status(env, h, rc, "b3w_calc_witness failed");
-  NAPI_OK(napi_create_typedarray(env, napi_uint8_array, (size_t)nwit * 32, abuf, 0, &out));
+  if (as_wtns) api.write_wtns_header(h->ctx, (uint8_t *)buf);
+  NAPI_OK(napi_create_typedarray(env, napi_uint8_array, head + (size_t)nwit * 32, abuf, 0, &out));
   return out;
 }
 
