@@ -89,6 +89,7 @@ def lib():
         "b3w_r1cs_create": (i32, [vp, vp, sz, ctypes.POINTER(vp)]),
         "b3w_r1cs_info": (i32, [vp, ctypes.POINTER(u32), ctypes.POINTER(u32), ctypes.POINTER(u64), ctypes.POINTER(u32),
                                 ctypes.POINTER(u32), ctypes.POINTER(u32)]),
+        "b3w_r1cs_is_tiled": (i32, [vp]),
         "b3w_r1cs_destroy": (None, [vp]),
         "b3w_r1cs_check_device": (i32, [vp, vp, vp, u32, u64, vp, vp, vp]),
         "b3w_batch_r1cs_check": (i32, [vp, vp, vp, vp]),
@@ -154,7 +155,7 @@ EXPORTED_SYMBOLS = ("b3w_abi_version", "b3w_identify_wasm", "b3w_create", "b3w_d
                     "b3w_batch_run_device", "b3w_public_words", "b3w_batch_alloc", "b3w_batch_free",
                     "b3w_batch_run", "b3w_batch_outputs", "b3w_batch_fetch", "b3w_batch_device_ptr",
                     "b3w_batch_time_device", "b3w_batch_verify_device", "b3w_batch_verify",
-                    "b3w_r1cs_create", "b3w_r1cs_info", "b3w_r1cs_destroy", "b3w_r1cs_check_device", "b3w_batch_r1cs_check", "b3w_r1cs_consumer", "b3w_batch_write_wtns", "b3w_batch_autotune_device", "b3w_bodies_alloc", "b3w_bodies_free", "b3w_bodies_trim", "b3w_bodies_configure", "b3w_bodies_stats", "b3w_batch_placement", "b3w_chain_num_chunks", "b3w_chain_num_leaf_steps", "b3w_chain_path_len",
+                    "b3w_r1cs_create", "b3w_r1cs_info", "b3w_r1cs_is_tiled", "b3w_r1cs_destroy", "b3w_r1cs_check_device", "b3w_batch_r1cs_check", "b3w_r1cs_consumer", "b3w_batch_write_wtns", "b3w_batch_autotune_device", "b3w_bodies_alloc", "b3w_bodies_free", "b3w_bodies_trim", "b3w_bodies_configure", "b3w_bodies_stats", "b3w_batch_placement", "b3w_chain_num_chunks", "b3w_chain_num_leaf_steps", "b3w_chain_path_len",
                     "b3w_chain_num_parent_steps", "b3w_chain_parent_row", "b3w_chain_path_provable",
                     "b3w_chain_plan_leaves_device", "b3w_chain_tree_device", "b3w_chain_plan_parents_device",
                     "b3w_commit_key_create", "b3w_commit_key_create_ex", "b3w_commit_key_window", "b3w_commit_key_destroy", "b3w_commit_records_device", "b3w_commit_records", "b3w_chain_commit_only", "b3w_chain_commitments", "b3w_chain_check_constraints", "b3w_chain_violations", "b3w_batch_commit_device", "b3w_batch_commit", "b3w_commit_consumer",
@@ -355,6 +356,7 @@ class R1cs:
         lib().b3w_r1cs_info(h, ctypes.byref(m), ctypes.byref(nw), ctypes.byref(nt), ctypes.byref(po), ctypes.byref(pi), ctypes.byref(pr))
         self.n_constraints, self.n_wires, self.n_terms = m.value, nw.value, nt.value
         self.n_pub_out, self.n_pub_in, self.n_prv_in = po.value, pi.value, pr.value
+        self.tiled = bool(lib().b3w_r1cs_is_tiled(h))      # False: rows not local enough, the gather kernel serves this system
 
     def check_device(self, d_bodies, n, pitch, d_violations, d_first=0, stream=0):
         """n bodies in HBM -> d_violations[i] = violated constraints of body i (0 = valid), d_first[i] = lowest one."""

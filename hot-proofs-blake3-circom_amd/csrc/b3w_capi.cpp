@@ -1321,6 +1321,8 @@ int32_t b3w_r1cs_info(const b3w_r1cs *r, uint32_t *n_constraints, uint32_t *n_wi
   return B3W_OK;
 }
 
+int32_t b3w_r1cs_is_tiled(const b3w_r1cs *r) { return r && r->tiled ? 1 : 0; }
+
 void b3w_r1cs_destroy(b3w_r1cs *r) {
   if (!r) return;
   DeviceGuard guard(r->ctx->device);

@@ -104,7 +104,7 @@ struct B3wR1csSystem {
   const uint32_t *g_rows, *g_wires;
   const uint16_t *g_cids;
 };
-#define B3W_R1CS_SLAB 8192u                                  // bodies per launch pair: bounds the scratch
+#define B3W_R1CS_SLAB 8192u                                  // bodies per launch pair at most: bounds the scratch (64 MB at most)
 extern "C" size_t b3w_r1cs_scratch_bytes(const B3wR1csSystem *sys);
 extern "C" int b3w_launch_r1cs_lean(const uint8_t *d_bodies, uint32_t n, uint64_t pitch, const B3wR1csSystem *sys, const B3wField *field,
                                     unsigned long long *d_scratch, uint32_t *d_violations, uint32_t *d_first, hipStream_t stream);

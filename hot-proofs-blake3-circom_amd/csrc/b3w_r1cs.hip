@@ -742,8 +742,20 @@ extern "C" int b3w_launch_r1cs(const uint8_t *d_bodies, uint32_t n, uint64_t pit
 
 static inline uint32_t lean_block_words(const B3wR1csSystem *sys) { return 1u + 4u * ((sys->max_tile_rows + 255u) >> 8); }
 
+// bodies per launch pair: B3W_R1CS_SLAB, fewer for a system whose scratch blocks are large (many rows per tile) so that the scratch
+// stays below 64 MB, and never so many that the grid leaves 31 bits
+static inline uint32_t lean_slab(const B3wR1csSystem *sys) {
+  const uint64_t per_body = (uint64_t)sys->ntiles * lean_block_words(sys) * 8;
+  uint64_t slab = (64ull << 20) / per_body;
+  if (slab > B3W_R1CS_SLAB) slab = B3W_R1CS_SLAB;
+  const uint64_t grid_cap = 0x7FFFFFFFu / sys->ntiles;
+  if (slab > grid_cap) slab = grid_cap;
+  slab &= ~7ull;
+  return slab < 8 ? 8u : (uint32_t)slab;
+}
+
 extern "C" size_t b3w_r1cs_scratch_bytes(const B3wR1csSystem *sys) {
-  return (size_t)B3W_R1CS_SLAB * sys->ntiles * lean_block_words(sys) * 8;
+  return (size_t)lean_slab(sys) * sys->ntiles * lean_block_words(sys) * 8;
 }
 
 extern "C" int b3w_launch_r1cs_lean(const uint8_t *d_bodies, uint32_t n, uint64_t pitch, const B3wR1csSystem *sys, const B3wField *field,
@@ -760,8 +772,7 @@ extern "C" int b3w_launch_r1cs_lean(const uint8_t *d_bodies, uint32_t n, uint64_
   if (staged) smem += term_bytes;
   if (coef_lds) smem += (size_t)sys->ncoef * 8;
   const uint32_t bw = lean_block_words(sys);
-  uint32_t slab = (0x7FFFFFFFu / sys->ntiles) & ~7u;
-  if (slab > B3W_R1CS_SLAB) slab = B3W_R1CS_SLAB;
+  const uint32_t slab = lean_slab(sys);
   for (uint32_t b0 = 0; b0 < n; b0 += slab) {
     const uint32_t nb = n - b0 < slab ? n - b0 : slab;
     const dim3 grid(((nb + 7) / 8) * 8 * sys->ntiles);

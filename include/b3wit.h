@@ -179,6 +179,9 @@ typedef struct b3w_r1cs b3w_r1cs;
 int32_t b3w_r1cs_create(b3w_ctx *ctx, const uint8_t *r1cs_image, size_t len, b3w_r1cs **out);
 int32_t b3w_r1cs_info(const b3w_r1cs *r1cs, uint32_t *n_constraints, uint32_t *n_wires, uint64_t *n_terms,
                       uint32_t *n_pub_out, uint32_t *n_pub_in, uint32_t *n_prv_in);
+/* Which formulation the checks of this system take: 1 = the tile kernels (rows local enough: at most 1 024 wires outside
+ * any tile of 1 024 consecutive wires — every circom circuit seen so far), 0 = the gather kernel (any system). */
+int32_t b3w_r1cs_is_tiled(const b3w_r1cs *r1cs);
 void b3w_r1cs_destroy(b3w_r1cs *r1cs);
 /* d_bodies 16-byte aligned, pitch a multiple of 16 (0 = witness_size * 32).
  * Stream capture: b3w_batch_run_device, b3w_batch_verify_device and b3w_r1cs_check_device only enqueue kernels on `stream`

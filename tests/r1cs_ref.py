@@ -76,3 +76,20 @@ def rows_of_wire(sys_):
         for w in a.keys() | b.keys() | c.keys():
             idx.setdefault(w, []).append(k)
     return idx
+
+
+def write_image(prime, nwires, constraints, npubout=0, npubin=0, nprvin=0):
+    """iden3 .r1cs v1 image of `constraints` = [(A, B, C)] with A, B, C = {wire: coefficient} (test systems)."""
+    import struct
+    hdr = struct.pack("<I", 32) + prime.to_bytes(32, "little") + struct.pack("<IIIIQI", nwires, npubout, npubin, nprvin, nwires, len(constraints))
+    body = bytearray()
+    for parts in constraints:
+        for lc in parts:
+            body += struct.pack("<I", len(lc))
+            for w, c in sorted(lc.items()):
+                body += struct.pack("<I", w) + (c % prime).to_bytes(32, "little")
+    wmap = b"".join(struct.pack("<Q", i) for i in range(nwires))
+    out = bytearray(b"r1cs" + struct.pack("<II", 1, 3))
+    for typ, sec in ((1, hdr), (2, bytes(body)), (3, wmap)):
+        out += struct.pack("<IQ", typ, len(sec)) + sec
+    return bytes(out)
