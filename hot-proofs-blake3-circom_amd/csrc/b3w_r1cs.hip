@@ -450,27 +450,47 @@ __device__ __forceinline__ unsigned long long lean_pack(const uint4 lo, const ui
 }
 
 // <row part, z> as an exact integer; *defer when a term is outside the integer case (then the sum is not used).
-// The wave takes one of two roads per term: all its elements are bits (98 % of a valid witness) — the coefficient is added
-// or not, no multiplication — or the general 64 x 64 -> 128 product.  The next term word is fetched one step ahead (the word
-// behind a row's last term is the next row's first or the pad behind the list: always inside the array).
-__device__ __forceinline__ __int128 lean_dot(const unsigned long long *el, const uint32_t *terms, const long long *coef, uint32_t off,
-                                             uint32_t n, bool *defer) {
+// A part is `n` words of the lean term stream.  A word idx | cid << 16 is a term; per term the wave takes one of two roads: all
+// its elements are bits (98 % of a valid witness) — the coefficient is added or not, no multiplication — or the general
+// 64 x 64 -> 128 product.  A word idx0 | 0xFFFF << 16 opens a BIT RUN (two words; the second: n | k << 8 | negative << 16): the
+// sum of 2^(k+i) * z[idx0 + i] over i < n <= 64, which is the run's bits — cut out of the tile's bit-packed elements, `packed`
+// = for every 64 elements a word of "is 1" bits, then a word of "is neither 0 nor 1" bits — shifted by k; a run with an element
+// that is no bit defers the row.  (A recomposition row "word = sum 2^i bit_i" is 32 terms on one lane without this.)  Term
+// words are fetched ahead; the words behind a row's last are the next row's or the pad: always inside the array.
+__device__ __forceinline__ __int128 lean_dot(const unsigned long long *el, const unsigned long long *packed, const uint32_t *terms,
+                                             const long long *coef, uint32_t off, uint32_t n, bool *defer) {
   __int128 s = 0;
   if (n == 0) return s;
   uint32_t t = terms[off];
-  for (uint32_t k = 0; k < n; k++) {
-    const uint32_t tn = terms[off + k + 1];
-    const unsigned long long z = el[t & 0xFFFFu];
-    const long long c = coef[t >> 16];
-    t = tn;
-    if (c == B3W_R1CS_NOT_SMALL) *defer = true;            // (the sentinel's product below is never used)
-    if (__builtin_amdgcn_ballot_w64(z > 1ull) == 0) {
-      s += (__int128)(z ? c : 0ll);
+  uint32_t k = 0;
+  while (k < n) {
+    const uint32_t t1 = terms[off + k + 1];
+    if ((t >> 16) == 0xFFFFu) {
+      const uint32_t idx0 = t & 0xFFFFu, len = t1 & 0xFFu, sh = (t1 >> 8) & 0xFFu;
+      const uint32_t g = idx0 >> 6, r = idx0 & 63u;
+      const unsigned long long one_lo = packed[2 * g], bad_lo = packed[2 * g + 1], one_hi = packed[2 * g + 2], bad_hi = packed[2 * g + 3];
+      const unsigned long long mask = len == 64u ? ~0ull : (1ull << len) - 1ull;
+      const unsigned long long ones = ((one_lo >> r) | (r ? one_hi << (64u - r) : 0ull)) & mask;
+      const unsigned long long bads = ((bad_lo >> r) | (r ? bad_hi << (64u - r) : 0ull)) & mask;
+      if (bads) *defer = true;
+      const __int128 v = (__int128)((unsigned __int128)ones << sh);                // < 2^(len + sh) <= 2^62 * 2: the coefficients are below 2^62
+      s += (t1 >> 16) & 1u ? -v : v;
+      k += 2;
+      t = terms[off + k];
     } else {
-      const unsigned long long mag = c < 0 ? 0ull - (unsigned long long)c : (unsigned long long)c;
-      // |c| < 2^62 with z < 2^32, or |c| < 2^40 with z < 2^63: the product stays below 2^103 and 2^20 of them below 2^127
-      if ((z >> 63) || ((z >> 32) && mag >= (1ull << 40))) *defer = true;
-      s += (__int128)c * (__int128)(long long)z;
+      const unsigned long long z = el[t & 0xFFFFu];
+      const long long c = coef[t >> 16];
+      if (c == B3W_R1CS_NOT_SMALL) *defer = true;          // (the sentinel's product below is never used)
+      if (__builtin_amdgcn_ballot_w64(z > 1ull) == 0) {
+        s += (__int128)(z ? c : 0ll);
+      } else {
+        const unsigned long long mag = c < 0 ? 0ull - (unsigned long long)c : (unsigned long long)c;
+        // |c| < 2^62 with z < 2^32, or |c| < 2^40 with z < 2^63: the product stays below 2^103 and 2^20 of them below 2^127
+        if ((z >> 63) || ((z >> 32) && mag >= (1ull << 40))) *defer = true;
+        s += (__int128)c * (__int128)(long long)z;
+      }
+      k += 1;
+      t = t1;
     }
   }
   return s;
@@ -502,9 +522,12 @@ __global__ __launch_bounds__(256) void b3w_r1cs_lean_kernel(const uint8_t *__res
   // term words | coefficients.
   const uint2 tt = reinterpret_cast<const uint2 *>(S.tile_terms)[tile];            // first term of the tile (a multiple of 4), how many
   const uint32_t ext_cap = (S.max_ext + 2u) & ~1u;                                // one dump slot; keeps the term words 16-byte aligned
-  uint4 *lterms4 = reinterpret_cast<uint4 *>(el + B3W_R1CS_TILE + ext_cap);
+  // packed: for every 64 elements {bits "is 1", bits "is neither 0 nor 1"}; one spare pair behind (a run reads its group and the next)
+  unsigned long long *packed = el + B3W_R1CS_TILE + ext_cap;
+  const uint32_t groups = ((B3W_R1CS_TILE + ext_cap + 63u) >> 6) + 1u;
+  uint4 *lterms4 = reinterpret_cast<uint4 *>(packed + 2 * groups);
   uint32_t *lterms = reinterpret_cast<uint32_t *>(lterms4);
-  const uint32_t lterm_words = STAGED ? (S.max_tile_terms + 4u) & ~3u : 0u;       // (room for the read-ahead word)
+  const uint32_t lterm_words = STAGED ? (S.max_tile_terms + 5u) & ~3u : 0u;       // (room for the two read-ahead words)
   long long *lcoef = reinterpret_cast<long long *>(lterms + lterm_words + (STAGED ? 4u : 0u));       // (+ the dump uint4)
   // (lanes with nothing to stage load element 0 / word 0 and write a dump slot: no branch for the compiler to sink a load into)
   const uint32_t el_dump = B3W_R1CS_TILE + ext_cap - 1u;                           // (behind the last outside wire)
@@ -517,7 +540,7 @@ __global__ __launch_bounds__(256) void b3w_r1cs_lean_kernel(const uint8_t *__res
     lo[u] = q[0]; hi[u] = q[1];
   }
   const uint4 *terms4 = reinterpret_cast<const uint4 *>(S.terms + tt.x);
-  const uint32_t nt4 = (tt.y + 4u) >> 2;                                           // the tile's term words + the read-ahead word, in fours
+  const uint32_t nt4 = (tt.y + 5u) >> 2;                                           // the tile's term words + the two read-ahead words, in fours
   const uint32_t t_dump = lterm_words >> 2;                                        // one uint4 behind the list
   // (named registers, not an array: the array went to scratch memory)
   const uint32_t k40 = threadIdx.x, k41 = threadIdx.x + 256, k42 = threadIdx.x + 512, k43 = threadIdx.x + 768;
@@ -543,7 +566,10 @@ __global__ __launch_bounds__(256) void b3w_r1cs_lean_kernel(const uint8_t *__res
 #pragma unroll
   for (uint32_t u = 0; u < 4; u++) {
     const uint32_t i = threadIdx.x + 256 * u;
-    el[i < n_local ? i : el_dump] = lean_pack(lo[u], hi[u]);
+    const unsigned long long z = i < n_local ? lean_pack(lo[u], hi[u]) : 0ull;
+    el[i < n_local ? i : el_dump] = z;
+    const unsigned long long ones = __ballot(z == 1ull), bads = __ballot(z > 1ull);       // the wave holds elements 64 g ... 64 g + 63
+    if ((threadIdx.x & 63) == 0) { packed[2 * (i >> 6)] = ones; packed[2 * (i >> 6) + 1] = bads; }
   }
   if (STAGED) {
     lterms4[k40 < nt4 ? k40 : t_dump] = tv0;
@@ -558,7 +584,13 @@ __global__ __launch_bounds__(256) void b3w_r1cs_lean_kernel(const uint8_t *__res
       if (k < S.ncoef) lcoef[k] = cv[u];
     }
   }
-  el[B3W_R1CS_TILE + (threadIdx.x < td.w ? threadIdx.x : ext_cap - 1u)] = lean_pack(elo, ehi);
+  {
+    const unsigned long long z = threadIdx.x < td.w ? lean_pack(elo, ehi) : 0ull;
+    el[B3W_R1CS_TILE + (threadIdx.x < td.w ? threadIdx.x : ext_cap - 1u)] = z;
+    const unsigned long long ones = __ballot(z == 1ull), bads = __ballot(z > 1ull);
+    const uint32_t g = (B3W_R1CS_TILE + threadIdx.x) >> 6;                         // (TILE is a multiple of 64)
+    if ((threadIdx.x & 63) == 0 && g < groups) { packed[2 * g] = ones; packed[2 * g + 1] = bads; }
+  }
   if (STAGED) {
     for (uint32_t base = 1024; base < nt4; base += 1024) {                         // lists beyond 4 096 words: four loads in flight again
       const uint32_t a0 = base + k40, a1 = base + k41, a2 = base + k42, a3 = base + k43;
@@ -570,9 +602,17 @@ __global__ __launch_bounds__(256) void b3w_r1cs_lean_kernel(const uint8_t *__res
       lterms4[a3 < nt4 ? a3 : t_dump] = w3;
     }
   }
-  for (uint32_t j = threadIdx.x + 256; j < td.w; j += 256) {                       // (more than 256 outside wires)
-    const uint4 *q = reinterpret_cast<const uint4 *>(body + (size_t)S.ext[td.z + j] * 32);
-    el[B3W_R1CS_TILE + j] = lean_pack(q[0], q[1]);
+  for (uint32_t j0 = 256; j0 < td.w; j0 += 256) {                                  // (more than 256 outside wires; whole waves, for the ballots)
+    const uint32_t j = j0 + threadIdx.x;
+    unsigned long long z = 0ull;
+    if (j < td.w) {
+      const uint4 *q = reinterpret_cast<const uint4 *>(body + (size_t)S.ext[td.z + j] * 32);
+      z = lean_pack(q[0], q[1]);
+      el[B3W_R1CS_TILE + j] = z;
+    }
+    const unsigned long long ones = __ballot(z == 1ull), bads = __ballot(z > 1ull);
+    const uint32_t g = (B3W_R1CS_TILE + j) >> 6;
+    if ((threadIdx.x & 63) == 0 && g < groups) { packed[2 * g] = ones; packed[2 * g + 1] = bads; }
   }
   const uint32_t *tsrc = STAGED ? lterms : S.terms;
   const uint32_t tbase = STAGED ? tt.x : 0u;                                      // row offsets are global term numbers
@@ -596,9 +636,9 @@ __global__ __launch_bounds__(256) void b3w_r1cs_lean_kernel(const uint8_t *__res
         const uint32_t na = d.y & 0x7FFFFFFFu;
         const uint32_t t0r = d.x - tbase;
         const uint32_t nc = (d.y >> 31) ? 0u : d.w;
-        const __int128 C = lean_dot(el, tsrc, csrc, t0r + na + d.z, nc, &defer);
-        const __int128 A = lean_dot(el, tsrc, csrc, t0r, na, &defer);
-        const __int128 B = lean_dot(el, tsrc, csrc, t0r + na, d.z, &defer);
+        const __int128 C = lean_dot(el, packed, tsrc, csrc, t0r + na + d.z, nc, &defer);
+        const __int128 A = lean_dot(el, packed, tsrc, csrc, t0r, na, &defer);
+        const __int128 B = lean_dot(el, packed, tsrc, csrc, t0r + na, d.z, &defer);
         if (!(A < lim && A > -lim && B < lim && B > -lim)) defer = true;
         bad = !defer && A * B != C;                        // |A * B - C| < 2^127 < p: "= 0 mod p" is "= 0"
       }
@@ -764,9 +804,10 @@ extern "C" int b3w_launch_r1cs_lean(const uint8_t *d_bodies, uint32_t n, uint64_
   if (sys->max_ext > B3W_R1CS_TILE || !d_scratch) return -5;
   hipError_t e = (hipError_t)r1cs_init_results(d_violations, d_first, n, stream);
   if (e != hipSuccess) return (int)e;
-  size_t smem = (size_t)(B3W_R1CS_TILE + ((sys->max_ext + 2u) & ~1u)) * 8;                            // (+ the dump element)
+  const uint32_t ext_cap = (sys->max_ext + 2u) & ~1u;                                                  // (+ the dump element)
+  size_t smem = (size_t)(B3W_R1CS_TILE + ext_cap) * 8 + (size_t)(((B3W_R1CS_TILE + ext_cap + 63u) >> 6) + 1u) * 16;   // elements, packed bits
   // the term list rides along while three workgroups still fit a CU
-  const size_t term_bytes = (size_t)((sys->max_tile_terms + 4u) & ~3u) * 4 + 16;                    // (+ the dump slot)
+  const size_t term_bytes = (size_t)((sys->max_tile_terms + 5u) & ~3u) * 4 + 16;                    // (+ the dump slot)
   const bool coef_lds = sys->ncoef <= 512;                 // 4 KB at most
   const bool staged = smem + term_bytes + (coef_lds ? (size_t)sys->ncoef * 8 : 0) <= 52 * 1024;
   if (staged) smem += term_bytes;

@@ -403,6 +403,20 @@ def test_random_systems_against_plain_integers(shape, tmp_path):
         if k % 500 == 0:
             sizes[2] = 300
         cons.append((lc(sizes[0], centre), lc(sizes[1], centre), lc(sizes[2], centre)))
+    # bit runs (the lean kernel folds 4 ... 64 terms  +-2^(k+i) * z[s+i]  over consecutive wires into one step): rows
+    # run * 1 = w_x over wires that hold bits in every body, every length, shift, sign, across 64-element groups and the tile border
+    runs = []
+    if shape == "local":
+        for j in range(60):
+            ln = rng.choice([4, 5, 31, 32, 33, 63, 64, 64])
+            s0 = rng.choice([5000, 5056 - ln // 2, 5120 - 1, 6144 - ln // 2, 5200 + j])       # (6144 = a tile border)
+            k0 = rng.randrange(0, 62 - ln) if ln < 62 else 0
+            sgn = rng.choice([1, -1])
+            a = {s0 + i: (sgn * (1 << (k0 + i))) % p for i in range(ln)}
+            if j % 3 == 0:
+                a[7000 + j] = 5                               # a run inside a longer part
+            runs.append((len(cons), a, 8000 + j))
+            cons.append((a, {0: 1}, {8000 + j: 1}))
     img = R.write_image(p, nw, cons, 16, 0, 28)
     path = tmp_path / "random.r1cs"
     path.write_bytes(img)
@@ -416,6 +430,11 @@ def test_random_systems_against_plain_integers(shape, tmp_path):
             v = (1 if w == 0 and i % 5 else rng.randrange(2) if kind < 0.6 else rng.randrange(1 << 32) if kind < 0.8 else
                  rng.randrange(1 << 40) if kind < 0.85 else rng.randrange(p) if kind < 0.995 else p + rng.randrange(1 << 200))
             z.append(v)
+        if shape == "local":
+            for w in range(4990, 6300):
+                z[w] = rng.randrange(2) if i != 3 else rng.randrange(3)          # (body 3: some of the run's elements are no bits)
+            for row, a, wx in runs:
+                z[wx] = (sum(cf * z[w] for w, cf in a.items()) * z[0] + (i & 1 if row % 2 else 0)) % p
         zs.append(z)
         bodies[i] = np.frombuffer(b"".join(v.to_bytes(32, "little") for v in z), dtype=np.uint8).reshape(nw, 32)
     np.save(tmp_path / "bodies.npy", bodies)
