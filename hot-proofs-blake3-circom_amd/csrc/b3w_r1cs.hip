@@ -165,11 +165,11 @@ __device__ __forceinline__ int small01(const Fe &a) {
 // <row, z>: `n` terms starting at `off`; term = wire | coefficient id (0: +1, 1: -1, else index into the tables:
 // coefs[16 * cid ..] = the coefficient, then the coefficient * 2^256 mod p)
 __device__ __forceinline__ Fe dot(const uint8_t *body, const uint32_t *wires, const uint16_t *cids, const uint32_t *coefs,
-                                  uint32_t off, uint32_t n, const B3wField &F, bool *wild) {
+                                  uint32_t off, uint32_t n, const B3wField &F, bool *wild, uint32_t start = 0, uint32_t step = 1) {
   Fe acc;
 #pragma unroll
   for (int i = 0; i < 8; i++) acc.l[i] = 0;
-  for (uint32_t k = 0; k < n; k++) {
+  for (uint32_t k = start; k < n; k += step) {               // (start, step: a lane's share when a wave splits a long row)
     const uint32_t w = wires[off + k];
     const uint32_t cid = cids[off + k];
     const Fe z = load_z(body, w, F, wild);
@@ -189,36 +189,57 @@ __device__ __forceinline__ Fe dot(const uint8_t *body, const uint32_t *wires, co
   return acc;
 }
 
+// A z * B z = C z for the three sums of a row?  (linear: the row has no A or no B terms: 0 * B - C = 0)
+__device__ __forceinline__ bool row_violated(const Fe &az, const Fe &bz, const Fe &cz, bool linear, const B3wField &F) {
+  if (linear) return !fe_is_zero(cz);
+  const int as = small01(az), bs = small01(bz);
+  Fe ab;
+  if (as == 0 || bs == 0) {                                                          // 0 * x
+#pragma unroll
+    for (int i = 0; i < 8; i++) ab.l[i] = 0;
+  } else if (as == 1) ab = bz;                                                       // 1 * x
+  else if (bs == 1) ab = az;
+  else {
+    Fe r2;
+#pragma unroll
+    for (int i = 0; i < 8; i++) r2.l[i] = F.r2[i];
+    ab = mont_mul(mont_mul(az, r2, F), bz, F);                                       // (az * R) * bz / R = az * bz
+  }
+  Fe diff = ab;
+  fe_sub(diff, cz, F.p);
+  return !fe_is_zero(diff);
+}
+
 // one row of the gather formulation over one body: violated?  (d = first term, terms in A, B, C)
 __device__ __forceinline__ bool gather_row(const uint8_t *body, const uint4 d, const uint32_t *wires, const uint16_t *cids,
                                            const uint32_t *coefR, const B3wField &F) {
-  bool wild = false, bad;
+  bool wild = false;
   const Fe cz = dot(body, wires, cids, coefR, d.x + d.y + d.z, d.w, F, &wild);
-  if (d.y == 0 || d.z == 0) {
-    bad = !fe_is_zero(cz);                               // 0 * B - C = 0  (a linear constraint)
-    if (d.y) (void)dot(body, wires, cids, coefR, d.x, d.y, F, &wild);                // still read for the canonical-form check
-    if (d.z) (void)dot(body, wires, cids, coefR, d.x + d.y, d.z, F, &wild);
-  } else {
-    const Fe az = dot(body, wires, cids, coefR, d.x, d.y, F, &wild);
-    const Fe bz = dot(body, wires, cids, coefR, d.x + d.y, d.z, F, &wild);
-    const int as = small01(az), bs = small01(bz);
-    Fe ab;
-    if (as == 0 || bs == 0) {                                                        // 0 * x
+  // (a linear row's other part is still read, for the canonical-form check)
+  const Fe az = dot(body, wires, cids, coefR, d.x, d.y, F, &wild);
+  const Fe bz = dot(body, wires, cids, coefR, d.x + d.y, d.z, F, &wild);
+  return row_violated(az, bz, cz, d.y == 0 || d.z == 0, F) || wild;                  // an element >= p is no witness value, whatever it is congruent to
+}
+
+// the same with the row's terms dealt to the 64 lanes of the wave (all lanes call it with the same d; all get the verdict)
+__device__ __forceinline__ Fe wave_sum(Fe v, const uint32_t p[8]) {
 #pragma unroll
-      for (int i = 0; i < 8; i++) ab.l[i] = 0;
-    } else if (as == 1) ab = bz;                                                     // 1 * x
-    else if (bs == 1) ab = az;
-    else {
-      Fe r2;
+  for (int sh = 32; sh > 0; sh >>= 1) {
+    Fe o;
 #pragma unroll
-      for (int i = 0; i < 8; i++) r2.l[i] = F.r2[i];
-      ab = mont_mul(mont_mul(az, r2, F), bz, F);                                     // (az * R) * bz / R = az * bz
-    }
-    Fe diff = ab;
-    fe_sub(diff, cz, F.p);
-    bad = !fe_is_zero(diff);
+    for (int i = 0; i < 8; i++) o.l[i] = (uint32_t)__shfl_xor((int)v.l[i], sh);
+    fe_add(v, o, p);
   }
-  return bad || wild;                                    // an element >= p is no witness value, whatever it is congruent to
+  return v;
+}
+__device__ __forceinline__ bool gather_row_wave(const uint8_t *body, const uint4 d, const uint32_t *wires, const uint16_t *cids,
+                                                const uint32_t *coefR, const B3wField &F) {
+  bool wild = false;
+  const uint32_t lane = threadIdx.x & 63u;
+  const Fe cz = wave_sum(dot(body, wires, cids, coefR, d.x + d.y + d.z, d.w, F, &wild, lane, 64), F.p);
+  const Fe az = wave_sum(dot(body, wires, cids, coefR, d.x, d.y, F, &wild, lane, 64), F.p);
+  const Fe bz = wave_sum(dot(body, wires, cids, coefR, d.x + d.y, d.z, F, &wild, lane, 64), F.p);
+  return row_violated(az, bz, cz, d.y == 0 || d.z == 0, F) || __ballot(wild) != 0;
 }
 
 __global__ __launch_bounds__(256) void b3w_r1cs_kernel(const uint8_t *__restrict__ bodies, uint64_t pitch, uint32_t n, uint32_t m,
@@ -670,10 +691,10 @@ __global__ __launch_bounds__(256) void b3w_r1cs_lean_kernel(const uint8_t *__res
 }
 
 // the rows the lean kernel left: one WAVE per (body, tile), almost all of which leave on their first load.  A wave, not the
-// lean kernel's four: a row of a flagged tile is a chain of dependent loads (term, element, coefficient), and 116 VGPRs allow
-// sixteen single-wave workgroups per CU where four-wave ones fit four: 354 -> 217 us per 4 096 nova bodies (66 field inverses a
-// step, in two or three tiles).  Compacting the marked rows of a tile into one list first was measured and changed nothing: the
-// time is the rows' own load chains.
+// lean kernel's four: a row of a flagged tile is a chain of dependent loads (term, element, coefficient), and sixteen single-wave
+// workgroups fit a CU where four-wave ones fit four (354 -> 217 us per 4 096 nova bodies).  A lane takes a row; a LONG row (each
+// derived nova system has one of 66 ... 133 terms whose coefficients, 2^70 and more, are no small integers: always deferred, and
+// 200 us of dependent loads on one lane) is dealt to all 64 lanes instead.
 __global__ __launch_bounds__(64) void b3w_r1cs_deferred_kernel(const uint8_t *__restrict__ bodies, uint64_t pitch, uint32_t n, B3wR1csSystem S,
                                                                const unsigned long long *__restrict__ scratch, uint32_t block_words, B3wField F,
                                                                uint32_t *__restrict__ violations, uint32_t *__restrict__ first) {
@@ -689,10 +710,22 @@ __global__ __launch_bounds__(64) void b3w_r1cs_deferred_kernel(const uint8_t *__
   uint32_t nbad = 0, low = 0xFFFFFFFFu;
   for (uint32_t wi = 0; wi < words; wi++) {
     const unsigned long long mask = block[1 + wi];
-    if (!((mask >> threadIdx.x) & 1ull)) continue;
-    const uint32_t r = td.x + 64u * wi + threadIdx.x;    // (< td.x + td.y: only such lanes set a bit)
-    const uint4 d = reinterpret_cast<const uint4 *>(S.g_rows)[S.row_k[r]];
-    if (gather_row(body, d, S.g_wires, S.g_cids, S.coefs, F)) { nbad++; low = min(low, S.row_id[r]); }
+    if (mask == 0) continue;                             // (wave-uniform)
+    const bool mine = (mask >> threadIdx.x) & 1ull;
+    const uint32_t r = td.x + 64u * wi + threadIdx.x;    // (< td.x + td.y for a marked lane: only such lanes set a bit)
+    uint4 d = make_uint4(0, 0, 0, 0);
+    if (mine) d = reinterpret_cast<const uint4 *>(S.g_rows)[S.row_k[r]];
+    const bool is_long = mine && d.y + d.z + d.w > 24u;
+    if (mine && !is_long && gather_row(body, d, S.g_wires, S.g_cids, S.coefs, F)) { nbad++; low = min(low, S.row_id[r]); }
+    unsigned long long longs = __ballot(is_long);
+    while (longs) {                                      // (wave-uniform)
+      const int L = __ffsll((long long)longs) - 1;
+      longs &= longs - 1ull;
+      const uint4 dl = make_uint4((uint32_t)__shfl((int)d.x, L), (uint32_t)__shfl((int)d.y, L), (uint32_t)__shfl((int)d.z, L),
+                                  (uint32_t)__shfl((int)d.w, L));
+      const bool bad = gather_row_wave(body, dl, S.g_wires, S.g_cids, S.coefs, F);
+      if ((int)threadIdx.x == L && bad) { nbad++; low = min(low, S.row_id[r]); }
+    }
   }
 #pragma unroll
   for (int sh = 32; sh > 0; sh >>= 1) {
