@@ -135,16 +135,27 @@ def bench_chain(args, m, torch, dist, dev, world, rank, local_rank):
     ctx = m.Context(circuit, local_rank)
     nbytes = int(args.preimage_mib * (1 << 20))
     host = torch.from_numpy(m.workloads.lcg_preimage(nbytes, seed=1).copy()).pin_memory()
-    consumer, key, commit_only = None, None, None
-    if args.consumer != "none":                      # what the folding prover does with each step witness
+    consumer, key, commit_only, r1cs_t, d_viol_t = None, None, None, None, None
+    n_max = m.lib().b3w_chain_num_chunks(nbytes) * 64 + 64
+    if "check" in args.consumer:                     # SURVEY.md 8(f) row 2, first half: Az * Bz = Cz for every step witness, timed
+        if circuit not in m.BUILTIN_R1CS:
+            raise SystemExit(f"bench.py: no constraint system for {circuit}")
+        r1cs_t = m.R1cs(ctx)
+        d_viol_t = torch.zeros(n_max, dtype=torch.int32, device=dev)
+
+        def consumer(view, first, k):
+            r1cs_t.check_device(view.data_ptr(), k, view.stride(0), d_viol_t.data_ptr() + 4 * first, 0, torch.cuda.current_stream().cuda_stream)
+    if "commit" in args.consumer:                    # second half: what the folding prover does with each step witness
         K = importlib.import_module("hot-proofs-blake3-circom_amd.synthetic_key")
         curve = "vesta" if "vesta" in circuit else "bn254_g1"
         key = m.CommitKey(ctx, curve, K.generators(curve, ctx.witness_size, seed=b"bench"))
-        n_max = m.lib().b3w_chain_num_chunks(nbytes) * 64 + 64
         d_pts = torch.zeros((n_max, 64), dtype=torch.uint8, device=dev)
         d_st = torch.zeros(n_max, dtype=torch.int32, device=dev)
+        check_first = consumer
 
         def consumer(view, first, k):
+            if check_first is not None:
+                check_first(view, first, k)
             key.commit_device(view.data_ptr(), k, view.stride(0), d_pts.data_ptr() + 64 * first, d_st.data_ptr() + 4 * first,
                               torch.cuda.current_stream().cuda_stream)
         if args.consumer == "commit-only":
@@ -170,7 +181,7 @@ def bench_chain(args, m, torch, dist, dev, world, rank, local_rank):
     # untimed: one more pass over the first MiB (at most) of the preimage whose consumer checks EVERY step witness against the
     # step circuit's rank-1 constraints while it sits in the ring
     verification = "none"
-    if circuit in m.BUILTIN_R1CS and commit_only is None:
+    if circuit in m.BUILTIN_R1CS and commit_only is None and r1cs_t is None:
         r1cs = m.R1cs(ctx)
         vsteps = [0]
         d_viol = torch.zeros(16384, dtype=torch.int32, device=dev)
@@ -188,6 +199,9 @@ def bench_chain(args, m, torch, dist, dev, world, rank, local_rank):
         r1cs.close()
     if key is not None:
         assert int(d_st[:local_steps].abs().sum().item()) == 0 and int(d_pts[:local_steps].max(dim=1).values.min().item()) > 0
+    if r1cs_t is not None:
+        assert int(d_viol_t[:local_steps].abs().sum().item()) == 0, "a step witness violates the step circuit's rank-1 constraints"
+        verification = f"r1cs, inside the timed pass: 0 of {r1cs_t.n_constraints} constraints violated by any of {local_steps} step witnesses (rank 0's share)"
     t = torch.tensor([elapsed, float(local_steps)], dtype=torch.float64, device=dev)
     if world > 1:
         tm = t.clone(); dist.all_reduce(tm, op=dist.ReduceOp.MAX)
@@ -209,8 +223,10 @@ def bench_chain(args, m, torch, dist, dev, world, rank, local_rank):
                        "placement": placements[0], "placement_per_rank": placements, "verification": verification,
                        "exchange": f"all_gather of chunk chaining values over {dist.get_world_size()} ranks "
                                    f"({dist.get_backend()})" if world > 1 else "none",
-                       "consumer": "none" if key is None else f"Pedersen commitment of every step witness on the device ({key.window}-bit windows)"
-                                   + (", from the step records: no bodies written" if commit_only is not None else "")},
+                       "consumer": " then ".join(
+                           ([f"rank-1 constraint check of every step witness on the device ({r1cs_t.n_constraints} constraints)"] if r1cs_t is not None else []) +
+                           ([f"Pedersen commitment of every step witness on the device ({key.window}-bit windows)"
+                             + (", from the step records: no bodies written" if commit_only is not None else "")] if key is not None else [])) or "none"},
             "roofline": {"bound": "hbm", "achieved": total_steps * args.steps * per / elapsed / 1e9 / world, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": total_steps * args.steps * per / elapsed / 1e9 / world / HBM_PEAK_GBS,
                          "traffic": None, "note": "end-to-end per-GPU rate incl. planner, H2D and launch gaps"},
@@ -237,10 +253,11 @@ def main():
                     help="batch = BASELINE config 2/3 (default, the headline metric); chain = configs 4/5: "
                          "preimage -> planner -> nova step witnesses, streamed through a ring of buffers")
     ap.add_argument("--preimage-mib", type=float, default=1.0, help="chain workload: preimage size (1 = config 4, 1024 = config 5)")
-    ap.add_argument("--consumer", default="none", choices=["none", "commit", "commit-only"],
+    ap.add_argument("--consumer", default="none", choices=["none", "commit", "commit-only", "check", "check+commit"],
                     help="chain workload: what reads each batch of step witnesses while it sits in the ring "
                          "(commit = Pedersen commitments on the circuit's curve, synthetic generators; commit-only = the same "
-                         "commitments straight from the step records, no bodies written)")
+                         "commitments straight from the step records, no bodies written; check = the step circuit's rank-1 "
+                         "constraints over every step witness; check+commit = both, in that order)")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:

@@ -61,8 +61,11 @@ def test_gpus_2_chain_launches_itself():
     assert "-> 6144 nova steps" in d["config"]["workload"]
 
 
-@pytest.mark.parametrize("consumer", ["none", "commit", "commit-only"])
+@pytest.mark.parametrize("consumer", ["none", "commit", "commit-only", "check", "check+commit"])
 def test_chain_workload_with_each_consumer(consumer):
     d = _bench("--workload", "chain", "--preimage-mib", "0.25", "--steps", "1", "--warmup", "1", "--consumer", consumer)
     assert d["scaling"] == "strong" and d["value"] > 0 and d["config"]["n_chunks"] == 256 and d["config"]["path_len"] == 8
     assert ("no bodies" in d["config"]["consumer"]) == (consumer == "commit-only")
+    assert ("constraint check" in d["config"]["consumer"]) == ("check" in consumer)
+    if "check" in consumer:
+        assert "inside the timed pass: 0 of 23744 constraints violated by any of 6144 step witnesses" in d["config"]["verification"]
