@@ -10,15 +10,20 @@
 //
 // Arithmetic: full 256-bit field elements, eight 32-bit limbs, Montgomery multiplication (CIOS) with the modulus passed
 // at run time (BN254 scalar field or the Vesta base field).  A term coef * z[wire] is montmul(coef * R, z) = coef * z;
-// coefficients +1 / -1 (93 % of the terms of the compression system) are an addition / subtraction.  The tile kernel adds
-// an exact integer fast path in front of that (small coefficients times small elements summed in 128 bits, see dot_lds).
+// coefficients +1 / -1 (93 % of the terms of the compression system) are an addition / subtraction.  The tile formulations put
+// an exact integer fast path in front of that (small coefficients times small elements summed in 128 bits).
 //
-// TWO KERNELS, same arithmetic.  The TILE kernel (the one that runs whenever the system allows it) exploits that circom
-// constraints are local: a workgroup takes (body, tile of 1 024 consecutive wires), streams the tile from HBM into LDS
-// once — coalesced 32 KB — plus the few wires outside the tile its rows mention (<= 137 per tile for both derived systems,
-// listed per tile by the host), and evaluates the rows that belong to the tile entirely out of LDS.  A body is read from
-// HBM once (+6 % for the shared outside wires, L2 hits): the kernel is HBM-read bound like the tamper check.  A system
-// whose rows are not local enough (more than 1 024 outside wires for some tile) takes the GATHER kernel below.
+// THREE FORMULATIONS, same verdicts (tests/test_gpu_r1cs.py runs all three over clean, corrupted and random inputs):
+//  * the LEAN pair (default whenever the system allows tiles): circom constraints are local, so a workgroup takes (body, tile
+//    of 1 024 consecutive wires), streams the tile from HBM once plus the few wires outside the tile its rows mention (<= 137
+//    per tile for the derived systems, listed per tile by the host: +6 % reads, L2 hits), keeps 8 bytes per element in LDS
+//    together with bit-packed copies, the tile's term list and the small coefficients, and decides the rows as exact integers;
+//    recomposition rows "word = sum 2^i bit_i" are folded into BIT RUNS.  What the integer case does not cover is marked and
+//    evaluated by a second launch (b3w_r1cs_deferred_kernel) with the field arithmetic.  A body is read from HBM once.
+//  * the 32-byte TILE kernel (B3W_R1CS_GATHER=2): the same tiles with whole elements in LDS and field arithmetic in every lane —
+//    the first tile kernel, kept as the reference formulation.
+//  * the GATHER kernel (B3W_R1CS_GATHER=1, and any system whose rows are not local enough: more than 1 024 outside wires for
+//    some tile).
 //
 // Gather kernel — mapping: thread = (constraint, body), 256 consecutive rows per workgroup; rows are sorted by shape (terms in A, B, C)
 // on the host so that the 64 lanes of a wave run the same trip counts.  The workgroups of ONE body all land on one XCD
