@@ -290,7 +290,8 @@ struct b3w_ctx {
   CircuitDesc desc{};
   int device = -1;
   int variant = 0;
-  bool variant_auto = true;           // no B3W_VARIANT and no autotune yet: bodies per wave chosen by batch size
+  bool variant_auto = true;           // no B3W_VARIANT and no autotune yet: launch shape chosen by batch size
+  bool variant_tuned = false;         // `variant` comes from b3w_batch_autotune_device: it holds for large batches only
   std::vector<InputSignal> inputs;
   uint32_t *d_table = nullptr;        // slot table; 32 pad entries in front of it (expand() indexes from slot - 3)
   uint32_t *d_table_base = nullptr;
@@ -519,7 +520,8 @@ int32_t b3w_batch_run_device(b3w_ctx *ctx, const uint32_t *d_records, uint32_t n
   // M/s); large batches want few fat waves, and above 6 144 compression witnesses the occupancy-limited 8-body variant wins
   // by 4-5 %
   int variant = ctx->variant;
-  if (ctx->variant_auto) {
+  // (a variant picked by the autotuner on a large batch does not apply to small ones: those are sliced unless B3W_VARIANT says otherwise)
+  if (ctx->variant_auto || (ctx->variant_tuned && n <= 2560)) {
     const bool comp = ctx->desc.kind == B3W_KIND_COMP;
     if (n <= 2560) variant = B3W_VARIANT_SLICED + (n <= (comp ? 32u : 8u) ? 64 : n <= 96 ? 32 : n <= 192 ? 16 : n <= 768 ? 8 : 4);
     else if (comp) variant = n <= 6144 ? 0 : 8;
@@ -559,7 +561,21 @@ int32_t b3w_batch_autotune_device(b3w_ctx *ctx, const uint32_t *d_records, uint3
                                   float *chosen_ms) {
   if (!ctx || !d_records || !d_bodies || !n) return B3W_E_BAD_ARGUMENT;
   ON_DEVICE(ctx);
-  int32_t rc = ensure_scratch(ctx);
+  int32_t rc;
+  if (n <= 2560 && (ctx->variant_auto || ctx->variant_tuned)) {
+    // small batches: the sliced launch the default policy picks is the only candidate (profiles/r02/batch_curve.json: within 2 %
+    // of the best shape at every size); time it and say which it is
+    float ms = 0;
+    rc = B3W_OK;
+    for (int w = 0; w < 2 && rc == B3W_OK; w++) rc = b3w_batch_run_device(ctx, d_records, n, d_bodies, pitch, d_public, d_status, stream);
+    if (rc == B3W_OK) rc = b3w_batch_time_device(ctx, d_records, n, d_bodies, pitch, d_public, d_status, stream, 5, &ms);
+    if (rc) return rc;
+    const bool comp = ctx->desc.kind == B3W_KIND_COMP;
+    if (chosen_variant) *chosen_variant = B3W_VARIANT_SLICED + (n <= (comp ? 32u : 8u) ? 64 : n <= 96 ? 32 : n <= 192 ? 16 : n <= 768 ? 8 : 4);
+    if (chosen_ms) *chosen_ms = ms;
+    return B3W_OK;
+  }
+  rc = ensure_scratch(ctx);
   if (rc) return rc;
   // fused with 4 (compression) / 2 (nova) bodies per wave, also with 8 (compression: for large batches occupancy-limited,
   // variant 8; nova O2: variant 3), and the two-kernel sweep
@@ -584,6 +600,7 @@ int32_t b3w_batch_autotune_device(b3w_ctx *ctx, const uint32_t *d_records, uint3
   }
   if (best_ms >= 1e30f) { ctx->variant = saved; ctx->variant_auto = saved_auto; return B3W_E_BAD_ARGUMENT; }
   ctx->variant = best;
+  ctx->variant_tuned = true;
   if (chosen_variant) *chosen_variant = best;
   if (chosen_ms) *chosen_ms = best_ms;
   return B3W_OK;

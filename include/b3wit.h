@@ -290,7 +290,10 @@ int32_t b3w_batch_write_wtns(b3w_batch *batch, uint32_t first, uint32_t count, c
 /* Choose the fastest bit-identical kernel variant for THIS output buffer (fused one-kernel path vs the
  * two-kernel sweep path, DESIGN.md "Roofline"): runs and times each candidate on the caller's device
  * buffers, which end up holding the correct witnesses, and keeps the winner in the ctx for later
- * b3w_batch_run_device calls.  Allocates the sweep scratch on first use; not for stream capture. */
+ * b3w_batch_run_device calls of more than 2 560 witnesses.  Batches up to 2 560 witnesses are always launched SLICED —
+ * several waves per body, DESIGN.md "Batch size" — unless B3W_VARIANT says otherwise; for such an n the call only times that
+ * shape and reports it (*chosen_variant = 20 + waves per body).  Allocates the sweep scratch on first use; not for stream
+ * capture. */
 int32_t b3w_batch_autotune_device(b3w_ctx *ctx, const uint32_t *d_records, uint32_t n, uint8_t *d_bodies,
                                   uint64_t pitch, uint32_t *d_public, int32_t *d_status, void *stream,
                                   int32_t *chosen_variant, float *chosen_ms);

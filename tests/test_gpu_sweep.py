@@ -118,19 +118,30 @@ def test_sweep_several_scratch_chunks(m):
 
 
 def test_autotune_picks_a_variant_and_stays_bit_exact(m):
+    """Large batches: the autotuner times the bit-identical candidates on the caller's buffers and keeps the fastest.  Small
+    batches (up to 2 560 witnesses) are launched sliced whatever a tuning run on a large batch chose: the tuner then reports the
+    sliced shape of the default policy (20 + waves per body)."""
     import torch
-    n = 512
+    dev = torch.device("cuda:0")
+    s = torch.cuda.current_stream().cuda_stream
+    n = 4096
     recs = T.workloads().config2_compression(n, first=77)
     ctx = m.Context("compression", 0)
-    dev = torch.device("cuda:0")
     d_recs = torch.from_numpy(recs.view(np.int32)).to(dev)
     d_bodies = torch.empty((n, ctx.body_bytes), dtype=torch.uint8, device=dev)
     d_st = torch.zeros(n, dtype=torch.int32, device=dev)
-    v, ms = ctx.autotune_device(d_recs.data_ptr(), n, d_bodies.data_ptr(), 0, 0, d_st.data_ptr(), torch.cuda.current_stream().cuda_stream)
-    assert v in (0, 100) and ms > 0
-    d_bodies.fill_(7)
-    ctx.run_device(d_recs.data_ptr(), n, d_bodies.data_ptr(), 0, 0, d_st.data_ptr(), torch.cuda.current_stream().cuda_stream)
-    torch.cuda.synchronize()
+    v, ms = ctx.autotune_device(d_recs.data_ptr(), n, d_bodies.data_ptr(), 0, 0, d_st.data_ptr(), s)
+    assert v in (0, 3, 100) and ms > 0
     _, want = T.oracle_batch_u32("compression", recs[:64])
-    assert np.array_equal(d_bodies[:64].cpu().numpy(), want)
+    for k in (n, 512, 5):                                    # the tuned variant, then small batches on the same context
+        d_bodies.fill_(7)
+        ctx.run_device(d_recs.data_ptr(), k, d_bodies.data_ptr(), 0, 0, d_st.data_ptr(), s)
+        torch.cuda.synchronize()
+        assert np.array_equal(d_bodies[:min(k, 64)].cpu().numpy(), want[:min(k, 64)]), k
+        if k < n:
+            assert int((d_bodies[k:k + 2] != 7).sum().item()) == 0, "a small batch wrote past its bodies"
+    v512, ms512 = ctx.autotune_device(d_recs.data_ptr(), 512, d_bodies.data_ptr(), 0, 0, d_st.data_ptr(), s)
+    assert v512 == 20 + 8 and 0 < ms512 < 0.15                 # (one body per wave took 0.14 ms for 512 witnesses, sliced 0.07)
+    v1, _ = ctx.autotune_device(d_recs.data_ptr(), 1, d_bodies.data_ptr(), 0, 0, d_st.data_ptr(), s)
+    assert v1 == 20 + 64
     ctx.close()
