@@ -16,6 +16,7 @@
 #include "../../include/b3wit.h"
 #include "b3w_atoms.h"
 #include "b3w_kernels.h"
+#include "b3w_r1cs_host.h"
 
 struct b3w_layout_run { char kind; uint32_t slot, atom, bit0, len; };
 #include "b3w_layout_tables.inc"
@@ -1061,29 +1062,6 @@ struct b3w_r1cs {
   mutable std::map<void *, unsigned long long *> scratch;
 };
 
-namespace {
-// little-endian reader over the file image; `ok` goes false on the first read past the end
-struct ByteReader {
-  const uint8_t *p; size_t len, pos = 0; bool ok = true;
-  ByteReader(const uint8_t *p_, size_t n) : p(p_), len(n) {}
-  bool need(size_t n) { if (!ok || len - pos < n) ok = false; return ok; }
-  uint32_t u32() { if (!need(4)) return 0; uint32_t v; memcpy(&v, p + pos, 4); pos += 4; return v; }
-  uint64_t u64() { if (!need(8)) return 0; uint64_t v; memcpy(&v, p + pos, 8); pos += 8; return v; }
-  const uint8_t *bytes(size_t n) { if (!need(n)) return nullptr; const uint8_t *q = p + pos; pos += n; return q; }
-};
-
-void u256_add_mod(uint32_t a[8], const uint32_t b[8], const uint32_t p[8]) {
-  uint64_t c = 0;
-  for (int i = 0; i < 8; i++) { const uint64_t t = (uint64_t)a[i] + b[i] + c; a[i] = (uint32_t)t; c = t >> 32; }
-  bool ge = c != 0;
-  if (!ge) { ge = true; for (int i = 7; i >= 0; --i) if (a[i] != p[i]) { ge = a[i] > p[i]; break; } }
-  if (ge) { uint64_t br = 0; for (int i = 0; i < 8; i++) { const uint64_t t = (uint64_t)a[i] - p[i] - br; a[i] = (uint32_t)t; br = (t >> 63) & 1; } }
-}
-// x * 2^256 mod p by 256 modular doublings (host, set-up only)
-void to_montgomery_host(uint32_t x[8], const uint32_t p[8]) {
-  for (int i = 0; i < 256; i++) { uint32_t y[8]; memcpy(y, x, 32); u256_add_mod(x, y, p); }
-}
-}  // namespace
 
 extern "C" {
 
@@ -1104,278 +1082,39 @@ int32_t b3w_r1cs_create(b3w_ctx *ctx, const uint8_t *img, size_t len, b3w_r1cs *
 }
 
 static int32_t r1cs_create_impl(b3w_ctx *ctx, const uint8_t *img, size_t len, b3w_r1cs **out) {
-  auto bad = [&](const char *why) { ctx->last_error = std::string("r1cs: ") + why; return B3W_E_BAD_ARGUMENT; };
-  // iden3 r1cs binary format v1: "r1cs" | u32 version | u32 nSections | { u32 type | u64 size | body }*
-  ByteReader rd(img, len);
-  const uint8_t *magic = rd.bytes(4);
-  if (!magic || memcmp(magic, "r1cs", 4)) return bad("not an r1cs file");
-  if (rd.u32() != 1) return bad("unsupported format version");
-  const uint32_t nsec = rd.u32();
-  size_t hdr_at = 0, cons_at = 0, cons_len = 0;
-  for (uint32_t s = 0; s < nsec && rd.ok; s++) {
-    const uint32_t type = rd.u32();
-    const uint64_t size = rd.u64();
-    if (!rd.ok || size > len - rd.pos) return bad("truncated section");
-    if (type == 1) hdr_at = rd.pos;
-    if (type == 2) { cons_at = rd.pos; cons_len = (size_t)size; }
-    if (type == 4 || type == 5) return bad("custom gates are not supported");
-    rd.pos += (size_t)size;
-  }
-  if (!hdr_at || !cons_at) return bad("header or constraint section missing");
-  ByteReader h(img + hdr_at, len - hdr_at);
-  if (h.u32() != 32) return bad("field size must be 32 bytes");
-  const uint8_t *prime = h.bytes(32);
-  if (!prime || memcmp(prime, ctx->desc.prime, 32)) return bad("the file's prime is not this circuit's field");
-  const uint32_t nwires = h.u32(), npubout = h.u32(), npubin = h.u32(), nprvin = h.u32();
-  (void)h.u64();                                          // nLabels
-  const uint32_t m = h.u32();
-  if (!h.ok) return bad("truncated header");
-  if (nwires != ctx->desc.nwit) return bad("nWires differs from this circuit's witness size");
-  if ((uint64_t)m * 12 > cons_len) return bad("more constraints announced than the constraint section can hold");
-  // constraints: A, B, C as (u32 wire, 32-byte LE coefficient) lists; distinct coefficients are tabulated
-  uint32_t P[8];
-  memcpy(P, ctx->desc.prime, 32);
-  uint32_t pm1[8];
-  memcpy(pm1, P, 32);
-  pm1[0] -= 1;                                            // p is odd: no borrow
-  std::vector<std::array<uint32_t, 8>> coefs(2);          // ids 0 (+1) and 1 (-1) are handled without a multiplication
-  coefs[0] = {1, 0, 0, 0, 0, 0, 0, 0};
-  memcpy(coefs[1].data(), pm1, 32);
-  std::map<std::array<uint32_t, 8>, uint32_t> coef_id;
-  coef_id[coefs[0]] = 0;
-  coef_id[coefs[1]] = 1;
-  struct Row { uint32_t off, na, nb, nc, id; };
-  std::vector<Row> rows;
-  rows.reserve(m);
-  std::vector<uint32_t> wires;
-  std::vector<uint16_t> cids;
-  ByteReader c(img + cons_at, cons_len);
-  for (uint32_t k = 0; k < m; k++) {
-    Row r{(uint32_t)wires.size(), 0, 0, 0, k};
-    uint32_t *cnt[3] = {&r.na, &r.nb, &r.nc};
-    for (int part = 0; part < 3; part++) {
-      const uint32_t n = c.u32();
-      if (!c.ok || (uint64_t)n * 36 > cons_len - c.pos) return bad("truncated constraint section");
-      for (uint32_t t = 0; t < n; t++) {
-        const uint32_t w = c.u32();
-        std::array<uint32_t, 8> cf;
-        memcpy(cf.data(), c.bytes(32), 32);
-        if (w >= nwires) return bad("wire index out of range");
-        bool ge = true;
-        for (int i = 7; i >= 0; --i) if (cf[i] != P[i]) { ge = cf[i] > P[i]; break; }
-        if (ge) return bad("coefficient not reduced mod p");
-        bool zero = true;
-        for (int i = 0; i < 8; i++) zero &= cf[i] == 0;
-        if (zero) continue;
-        auto it = coef_id.find(cf);
-        uint32_t id;
-        if (it == coef_id.end()) {
-          id = (uint32_t)coefs.size();
-          if (id > 0xFFFF) return bad("more than 65 536 distinct coefficients");
-          coef_id[cf] = id;
-          coefs.push_back(cf);
-        } else id = it->second;
-        wires.push_back(w);
-        cids.push_back((uint16_t)id);
-        (*cnt[part])++;
-      }
-    }
-    if (wires.size() > 0xFFFFFFF0ull) return bad("too many terms");
-    rows.push_back(r);
-  }
-  // rows of one shape side by side: the lanes of a wave then run the same trip counts
-  std::stable_sort(rows.begin(), rows.end(), [](const Row &a, const Row &b) {
-    if (a.nc != b.nc) return a.nc > b.nc;
-    if (a.na != b.na) return a.na > b.na;
-    return a.nb > b.nb;
-  });
-  std::vector<uint32_t> rowdesc(4 * (size_t)m), row_id(m);
-  for (uint32_t k = 0; k < m; k++) {
-    rowdesc[4 * k] = rows[k].off; rowdesc[4 * k + 1] = rows[k].na; rowdesc[4 * k + 2] = rows[k].nb; rowdesc[4 * k + 3] = rows[k].nc;
-    row_id[k] = rows[k].id;
-  }
-  // ---- tile formulation: a row belongs to the tile most of its wires lie in (the constant wire 0 does not vote); the
-  // wires it mentions outside that tile are the tile's "outside wires", staged into LDS behind the tile
-  const uint32_t T = B3W_R1CS_TILE, ntiles = (nwires + T - 1) / T;
-  std::vector<std::vector<uint32_t>> tile_rows(ntiles);
-  std::vector<std::map<uint32_t, uint32_t>> tile_ext(ntiles);     // outside wire -> its number in the tile
-  for (uint32_t t = 1; t < ntiles; t++) tile_ext[t][0] = 0;       // the constant wire is outside wire 0 of every tile but the first
-  {
-    std::vector<uint32_t> votes(ntiles);
-    for (uint32_t k = 0; k < m; k++) {                            // rows[] is shape-sorted: tile_rows keeps that order
-      const Row &r = rows[k];
-      const uint32_t nt = r.na + r.nb + r.nc;
-      std::fill(votes.begin(), votes.end(), 0u);
-      uint32_t best = 0;
-      for (uint32_t t = 0; t < nt; t++) { const uint32_t w = wires[r.off + t]; if (w) votes[w / T]++; }
-      for (uint32_t t = 1; t < ntiles; t++) if (votes[t] > votes[best]) best = t;
-      tile_rows[best].push_back(k);
-      for (uint32_t t = 0; t < nt; t++) {
-        const uint32_t w = wires[r.off + t];
-        if (w / T != best && !tile_ext[best].count(w)) { const uint32_t id = (uint32_t)tile_ext[best].size(); tile_ext[best][w] = id; }
-      }
-    }
-  }
-  uint32_t max_ext = 0;
-  for (uint32_t t = 0; t < ntiles; t++) max_ext = std::max<uint32_t>(max_ext, (uint32_t)tile_ext[t].size());
-  uint32_t longest = 0;
-  for (const Row &r : rows) longest = std::max(longest, r.na + r.nb + r.nc);
-  // (the tile kernel sums small terms as 128-bit integers: rows stay below 2^20 terms)
-  const bool tiled = max_ext <= T && coefs.size() <= 0xFFFF && longest < (1u << 20);
-  // coefficients as small signed integers (c or c - p), for the tile kernel's integer path
-  std::vector<long long> coef_small(coefs.size(), B3W_R1CS_NOT_SMALL);
-  for (size_t i = 0; i < coefs.size(); i++) {
-    const std::array<uint32_t, 8> &cf = coefs[i];
-    uint32_t hi = 0;
-    for (int q = 2; q < 8; q++) hi |= cf[q];
-    const uint64_t lo64 = (uint64_t)cf[0] | (uint64_t)cf[1] << 32;
-    if (!hi && lo64 < (1ull << 62)) { coef_small[i] = (long long)lo64; continue; }
-    uint32_t neg[8];                                                               // p - c
-    uint64_t br = 0;
-    for (int q = 0; q < 8; q++) { const uint64_t d = (uint64_t)P[q] - cf[q] - br; neg[q] = (uint32_t)d; br = (d >> 63) & 1; }
-    hi = 0;
-    for (int q = 2; q < 8; q++) hi |= neg[q];
-    const uint64_t n64 = (uint64_t)neg[0] | (uint64_t)neg[1] << 32;
-    if (!hi && n64 < (1ull << 62)) coef_small[i] = -(long long)n64;
-  }
-  std::vector<uint32_t> tdesc(4 * (size_t)ntiles), ttdesc(2 * (size_t)ntiles), text, trows, trow_id, trow_k, tterms;
-  uint32_t max_tile_terms = 0, max_tile_rows = 0;
-  // the lean kernel's own term stream: the same rows, each part sorted by LDS index, with BIT RUNS folded — four or more terms
-  // over consecutive elements whose coefficients are +-2^k, +-2^(k+1), ... (the recomposition rows "word = sum 2^i bit_i" of a
-  // circom circuit, 26 % of the terms of blake3_compression and 43 % of the O2 nova systems) become two words:
-  // idx0 | 0xFFFF << 16, then n | k << 8 | negative << 16.  The kernel evaluates a run from the tile's bit-packed elements.
-  std::vector<uint32_t> ltdesc(2 * (size_t)ntiles), lrows, lterms;
-  uint32_t max_lean_terms = 0;
-  auto pow2 = [&](uint16_t cid, bool &neg, uint32_t &k) {
-    const long long c = coef_small[cid];
-    if (c == B3W_R1CS_NOT_SMALL || c == 0) return false;
-    const unsigned long long mag = c < 0 ? 0ull - (unsigned long long)c : (unsigned long long)c;
-    if (mag & (mag - 1)) return false;
-    neg = c < 0;
-    k = (uint32_t)__builtin_ctzll(mag);
-    return true;
-  };
-  auto emit_part = [&](std::vector<std::pair<uint32_t, uint16_t>> &part) -> uint32_t {       // returns the words emitted
-    std::stable_sort(part.begin(), part.end(), [](const std::pair<uint32_t, uint16_t> &a, const std::pair<uint32_t, uint16_t> &b) { return a.first < b.first; });
-    const size_t before = lterms.size();
-    for (size_t i = 0; i < part.size();) {
-      bool neg = false; uint32_t k0 = 0;
-      size_t j = i + 1;
-      if (pow2(part[i].second, neg, k0)) {
-        while (j < part.size() && j - i < 64 && part[j].first == part[j - 1].first + 1) {
-          bool ng = false; uint32_t kk = 0;
-          if (!pow2(part[j].second, ng, kk) || ng != neg || kk != k0 + (uint32_t)(j - i)) break;
-          j++;
-        }
-      }
-      if (j - i >= 4) {
-        lterms.push_back(part[i].first | 0xFFFF0000u);
-        lterms.push_back((uint32_t)(j - i) | k0 << 8 | (neg ? 1u << 16 : 0u));
-        i = j;
-      } else {
-        lterms.push_back(part[i].first | (uint32_t)part[i].second << 16);
-        i++;
-      }
-    }
-    return (uint32_t)(lterms.size() - before);
-  };
-  if (tiled) {
-    for (uint32_t t = 0; t < ntiles; t++) {
-      while (lterms.size() & 3) lterms.push_back(0);      // a tile's list starts on 16 bytes (the lean kernel stages it in uint4s)
-      ltdesc[2 * t] = (uint32_t)lterms.size();
-      ttdesc[2 * t] = (uint32_t)tterms.size();
-      tdesc[4 * t] = (uint32_t)(trows.size() / 4); tdesc[4 * t + 1] = (uint32_t)tile_rows[t].size();
-      tdesc[4 * t + 2] = (uint32_t)text.size(); tdesc[4 * t + 3] = (uint32_t)tile_ext[t].size();
-      std::vector<uint32_t> ext(tile_ext[t].size());
-      for (const auto &kv : tile_ext[t]) ext[kv.second] = kv.first;
-      text.insert(text.end(), ext.begin(), ext.end());
-      for (uint32_t k : tile_rows[t]) {
-        const Row &r = rows[k];
-        // booleanity:  A = {w: 1},  B = {wire 0: 1, w: -1} or {w: 1, wire 0: -1},  C = {}
-        bool boolean = r.na == 1 && r.nb == 2 && r.nc == 0 && cids[r.off] == 0 && wires[r.off] != 0;
-        if (boolean) {
-          const uint32_t w = wires[r.off], w1 = wires[r.off + 1], w2 = wires[r.off + 2];
-          const uint16_t c1 = cids[r.off + 1], c2 = cids[r.off + 2];
-          boolean = (w1 == 0 && w2 == w && ((c1 == 0 && c2 == 1) || (c1 == 1 && c2 == 0))) ||
-                    (w2 == 0 && w1 == w && ((c2 == 0 && c1 == 1) || (c2 == 1 && c1 == 0)));
-        }
-        uint32_t bool_idx = 0;                                 // a booleanity row names its element by LDS index
-        if (boolean) { const uint32_t w_a = wires[r.off]; bool_idx = w_a / T == t ? w_a - t * T : T + tile_ext[t].at(w_a); }
-        trows.push_back((uint32_t)tterms.size()); trows.push_back(r.na | (boolean ? 0x80000000u : 0u)); trows.push_back(r.nb);
-        trows.push_back(boolean ? bool_idx : r.nc);
-        trow_id.push_back(r.id);
-        trow_k.push_back(k);
-        const uint32_t lean_off = (uint32_t)lterms.size();
-        uint32_t lean_n[3] = {0, 0, 0};
-        const uint32_t part_len[3] = {r.na, r.nb, r.nc};
-        uint32_t q = 0;
-        for (int part = 0; part < 3; part++) {
-          std::vector<std::pair<uint32_t, uint16_t>> terms_of_part;
-          for (uint32_t x = 0; x < part_len[part]; x++, q++) {
-            const uint32_t w = wires[r.off + q];
-            const uint32_t idx = w / T == t ? w - t * T : T + tile_ext[t][w];
-            tterms.push_back(idx | (uint32_t)cids[r.off + q] << 16);
-            terms_of_part.emplace_back(idx, cids[r.off + q]);
-          }
-          lean_n[part] = emit_part(terms_of_part);
-        }
-        lrows.push_back(lean_off); lrows.push_back(lean_n[0] | (boolean ? 0x80000000u : 0u)); lrows.push_back(lean_n[1]);
-        lrows.push_back(boolean ? bool_idx : lean_n[2]);
-      }
-      ttdesc[2 * t + 1] = (uint32_t)tterms.size() - ttdesc[2 * t];
-      max_tile_terms = std::max(max_tile_terms, ttdesc[2 * t + 1]);
-      ltdesc[2 * t + 1] = (uint32_t)lterms.size() - ltdesc[2 * t];
-      max_lean_terms = std::max(max_lean_terms, ltdesc[2 * t + 1]);
-      max_tile_rows = std::max<uint32_t>(max_tile_rows, (uint32_t)tile_rows[t].size());
-    }
-    tterms.push_back(0);
-    lterms.push_back(0); lterms.push_back(0);             // the lean kernel fetches up to two term words ahead,
-    while (lterms.size() & 3) lterms.push_back(0);        // and stages whole uint4s
-  }
-  std::vector<uint32_t> coefR(16 * coefs.size());           // per coefficient: plain, then Montgomery form
-  for (size_t i = 0; i < coefs.size(); i++) {
-    memcpy(&coefR[16 * i], coefs[i].data(), 32);
-    memcpy(&coefR[16 * i + 8], coefs[i].data(), 32);
-    to_montgomery_host(&coefR[16 * i + 8], P);
-  }
+  B3wR1csHost H;                                          // (parsing and tiling: b3w_r1cs_host.cpp, no device involved)
+  if (!b3w_r1cs_host_build(img, len, reinterpret_cast<const uint8_t *>(ctx->desc.prime), ctx->desc.nwit, &H)) { ctx->last_error = H.error; return B3W_E_BAD_ARGUMENT; }
   b3w_r1cs *r = new b3w_r1cs;
-  r->ctx = ctx; r->m = m; r->nwires = nwires; r->npubout = npubout; r->npubin = npubin; r->nprvin = nprvin; r->nterms = wires.size();
-  memcpy(r->field.p, P, 32);
-  uint32_t r2[8] = {1, 0, 0, 0, 0, 0, 0, 0};
-  to_montgomery_host(r2, P);
-  to_montgomery_host(r2, P);                              // 2^512 mod p
-  memcpy(r->field.r2, r2, 32);
-  uint32_t inv = P[0];                                    // Newton: p^-1 mod 2^32
-  for (int i = 0; i < 5; i++) inv *= 2u - P[0] * inv;
-  r->field.inv = 0u - inv;
+  r->ctx = ctx; r->m = H.m; r->nwires = H.nwires; r->npubout = H.npubout; r->npubin = H.npubin; r->nprvin = H.nprvin; r->nterms = H.nterms;
+  r->field = H.field;
   DeviceGuard guard(ctx->device);
   hipError_t e = guard.err;
   auto up = [&](void **d, const void *src, size_t bytes) {
     if (e == hipSuccess) e = hipMalloc(d, bytes ? bytes : 4);
     if (e == hipSuccess && bytes) e = hipMemcpy(*d, src, bytes, hipMemcpyHostToDevice);
   };
-  up((void **)&r->d_rows, rowdesc.data(), rowdesc.size() * 4);
-  up((void **)&r->d_row_id, row_id.data(), row_id.size() * 4);
-  up((void **)&r->d_wires, wires.data(), wires.size() * 4);
-  up((void **)&r->d_cids, cids.data(), cids.size() * 2);
-  up((void **)&r->d_coefR, coefR.data(), coefR.size() * 4);
-  r->tiled = tiled; r->ntiles = ntiles; r->max_ext = max_ext;
-  r->max_tile_terms = max_tile_terms;
-  r->ncoef = (uint32_t)coefs.size();
-  if (tiled) {
-    up((void **)&r->d_tiles, tdesc.data(), tdesc.size() * 4);
-    up((void **)&r->d_tile_terms, ttdesc.data(), ttdesc.size() * 4);
-    up((void **)&r->d_ext, text.data(), text.size() * 4);
-    up((void **)&r->d_trows, trows.data(), trows.size() * 4);
-    up((void **)&r->d_trow_id, trow_id.data(), trow_id.size() * 4);
-    up((void **)&r->d_terms, tterms.data(), tterms.size() * 4);
-    up((void **)&r->d_coef_small, coef_small.data(), coef_small.size() * 8);
-    up((void **)&r->d_trow_k, trow_k.data(), trow_k.size() * 4);
-    up((void **)&r->d_lrows, lrows.data(), lrows.size() * 4);
-    up((void **)&r->d_lterms, lterms.data(), lterms.size() * 4);
-    up((void **)&r->d_ltile_terms, ltdesc.data(), ltdesc.size() * 4);
-    r->max_tile_rows = max_tile_rows;
-    r->sys = B3wR1csSystem{nwires, ntiles, max_ext, max_lean_terms, max_tile_rows, r->ncoef, r->d_tiles, r->d_ltile_terms, r->d_ext, r->d_lrows,
+  up((void **)&r->d_rows, H.rowdesc.data(), H.rowdesc.size() * 4);
+  up((void **)&r->d_row_id, H.row_id.data(), H.row_id.size() * 4);
+  up((void **)&r->d_wires, H.wires.data(), H.wires.size() * 4);
+  up((void **)&r->d_cids, H.cids.data(), H.cids.size() * 2);
+  up((void **)&r->d_coefR, H.coefR.data(), H.coefR.size() * 4);
+  r->tiled = H.tiled; r->ntiles = H.ntiles; r->max_ext = H.max_ext;
+  r->max_tile_terms = H.max_tile_terms;
+  r->ncoef = H.ncoef;
+  if (H.tiled) {
+    up((void **)&r->d_tiles, H.tdesc.data(), H.tdesc.size() * 4);
+    up((void **)&r->d_tile_terms, H.ttdesc.data(), H.ttdesc.size() * 4);
+    up((void **)&r->d_ext, H.text.data(), H.text.size() * 4);
+    up((void **)&r->d_trows, H.trows.data(), H.trows.size() * 4);
+    up((void **)&r->d_trow_id, H.trow_id.data(), H.trow_id.size() * 4);
+    up((void **)&r->d_terms, H.tterms.data(), H.tterms.size() * 4);
+    up((void **)&r->d_coef_small, H.coef_small.data(), H.coef_small.size() * 8);
+    up((void **)&r->d_trow_k, H.trow_k.data(), H.trow_k.size() * 4);
+    up((void **)&r->d_lrows, H.lrows.data(), H.lrows.size() * 4);
+    up((void **)&r->d_lterms, H.lterms.data(), H.lterms.size() * 4);
+    up((void **)&r->d_ltile_terms, H.ltdesc.data(), H.ltdesc.size() * 4);
+    r->max_tile_rows = H.max_tile_rows;
+    r->sys = B3wR1csSystem{H.nwires, H.ntiles, H.max_ext, H.max_lean_terms, H.max_tile_rows, r->ncoef, r->d_tiles, r->d_ltile_terms, r->d_ext, r->d_lrows,
                            r->d_trow_id, r->d_trow_k, r->d_lterms, r->d_coefR, r->d_coef_small, r->d_rows, r->d_wires, r->d_cids};
   }
   if (e != hipSuccess) { b3w_r1cs_destroy(r); return e == hipErrorOutOfMemory ? B3W_E_NOT_ENOUGH_MEMORY : hip_fail(ctx, e, "r1cs upload"); }

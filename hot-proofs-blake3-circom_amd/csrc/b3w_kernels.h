@@ -70,11 +70,7 @@ extern "C" int b3w_launch_commit(const uint8_t *d_bodies, uint32_t n, uint64_t p
                                  int32_t *d_status, const B3wCurve *curve, hipStream_t stream);
 
 // b3w_r1cs.hip: rank-1 constraint check of witness bodies (on-device consumer #1: A z * B z - C z = 0 for every row)
-struct B3wField {
-  uint32_t p[8];      // modulus of the circuit's field, little-endian limbs
-  uint32_t r2[8];     // 2^512 mod p
-  uint32_t inv;       // -p^-1 mod 2^32
-};
+#include "b3w_r1cs_defs.h"          // B3wField, B3W_R1CS_TILE, B3W_R1CS_NOT_SMALL (shared with the HIP-free host code)
 // rows: m x {first term, terms in A, in B, in C} (terms of a row are stored A then B then C); row_id: the row's index in the
 // .r1cs file (rows are sorted by shape); term k = wires[k], cids[k] (0: coefficient +1, 1: -1, else d_coefR[16 * cid ..] =
 // the coefficient (8 words), then coefficient * 2^256 mod p (8 words))
@@ -87,8 +83,6 @@ extern "C" int b3w_launch_r1cs(const uint8_t *d_bodies, uint32_t n, uint64_t pit
 // rows: bit 31 of the A count marks a booleanity row (A = {w: 1}, B = {1, -w} or {w, -1}, C = {}): its C count field holds w's
 // LDS index instead (there are no C terms);
 // coef_small[cid] = the coefficient as a signed integer when |c| < 2^62 (c or c - p), else B3W_R1CS_NOT_SMALL
-#define B3W_R1CS_TILE 1024u
-#define B3W_R1CS_NOT_SMALL ((long long)0x8000000000000000ull)
 extern "C" int b3w_launch_r1cs_tiled(const uint8_t *d_bodies, uint32_t n, uint64_t pitch, uint32_t nwires, uint32_t ntiles, uint32_t max_ext,
                                      uint32_t max_tile_terms, const uint32_t *d_tiles, const uint32_t *d_tile_terms /* ntiles x {first term, terms} */, const uint32_t *d_ext, const uint32_t *d_rows, const uint32_t *d_row_id,
                                      const uint32_t *d_terms, const uint32_t *d_coefs, const long long *d_coef_small, uint32_t ncoef,

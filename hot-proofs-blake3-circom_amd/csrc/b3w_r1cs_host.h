@@ -1,0 +1,29 @@
+// b3w_r1cs_host.h — what b3w_r1cs_host_build makes of an iden3 .r1cs image (see b3w_r1cs_host.cpp); layouts as documented at
+// the launch declarations in b3w_kernels.h.  No HIP in here.
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "b3w_r1cs_defs.h"
+
+struct B3wR1csHost {
+  std::string error;                                       // why the image was refused
+  uint32_t m = 0, nwires = 0, npubout = 0, npubin = 0, nprvin = 0;
+  uint64_t nterms = 0;
+  B3wField field{};
+  // gather formulation
+  std::vector<uint32_t> rowdesc, row_id, wires, coefR;
+  std::vector<uint16_t> cids;
+  // tile formulations (tiled: every tile of B3W_R1CS_TILE wires needs at most that many outside wires)
+  bool tiled = false;
+  uint32_t ntiles = 0, max_ext = 0, max_tile_terms = 0, max_tile_rows = 0, max_lean_terms = 0, ncoef = 0;
+  std::vector<long long> coef_small;
+  std::vector<uint32_t> tdesc, ttdesc, text, trows, trow_id, trow_k, tterms;      // 32-byte tile kernel
+  std::vector<uint32_t> ltdesc, lrows, lterms;                                    // lean kernel: its own rows and term stream (bit runs folded)
+};
+
+// false: refused, H->error says why.  May throw std::bad_alloc / std::length_error on absurd sizes (the caller catches).
+bool b3w_r1cs_host_build(const uint8_t *img, size_t len, const uint8_t prime_le[32], uint32_t nwit, B3wR1csHost *H);

@@ -1,0 +1,171 @@
+// r1cs_host_harness.cpp — test harness of hot-proofs-blake3-circom_amd/csrc/b3w_r1cs_host.cpp, compiled by
+// tests/test_r1cs_host_asan_cpu.py with AddressSanitizer + UBSan (no GPU, no HIP):
+//   harness <image> <nwit> <mutations> <seed>
+// 1. the pristine image must load; every index the kernels would follow is checked to lie inside its array, and the lean term
+//    stream (parts sorted, bit runs folded) must say the same as the gather formulation: for pseudo-random small z, every part
+//    of every row sums to the same value (mod 2^64, coefficients taken by their low 64 bits) in both.
+// 2. `mutations` mutated copies (truncations, flipped bytes, patched counts and wire numbers) are either refused with a text
+//    or load as a different system that passes the same index checks.  The sanitizers watch the whole time.
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <new>
+#include <stdexcept>
+#include <vector>
+
+#include "b3w_r1cs_host.h"
+
+#define CHECK(c)                                                                 \
+  do {                                                                           \
+    if (!(c)) { fprintf(stderr, "invariant failed at line %d: %s\n", __LINE__, #c); return false; } \
+  } while (0)
+
+static uint64_t rng_state;
+static uint64_t rnd() { rng_state ^= rng_state << 13; rng_state ^= rng_state >> 7; rng_state ^= rng_state << 17; return rng_state; }
+
+static bool indices_ok(const B3wR1csHost &H) {
+  const uint32_t T = B3W_R1CS_TILE;
+  CHECK(H.rowdesc.size() == 4 * (size_t)H.m && H.row_id.size() == H.m && H.cids.size() == H.wires.size());
+  CHECK(H.coefR.size() == 16 * (size_t)H.ncoef);
+  for (uint32_t k = 0; k < H.m; k++) {
+    const uint64_t end = (uint64_t)H.rowdesc[4 * k] + H.rowdesc[4 * k + 1] + H.rowdesc[4 * k + 2] + H.rowdesc[4 * k + 3];
+    CHECK(end <= H.wires.size() && H.row_id[k] < H.m);
+  }
+  for (size_t i = 0; i < H.wires.size(); i++) CHECK(H.wires[i] < H.nwires && H.cids[i] < H.ncoef);
+  if (!H.tiled) return true;
+  CHECK(H.ntiles == (H.nwires + T - 1) / T && H.tdesc.size() == 4 * (size_t)H.ntiles && H.ttdesc.size() == 2 * (size_t)H.ntiles);
+  CHECK(H.ltdesc.size() == 2 * (size_t)H.ntiles && H.coef_small.size() == H.ncoef && H.max_ext <= T);
+  CHECK(H.trows.size() == H.lrows.size() && H.trow_id.size() * 4 == H.trows.size() && H.trow_k.size() == H.trow_id.size());
+  CHECK(H.lterms.size() % 4 == 0);
+  for (uint32_t t = 0; t < H.ntiles; t++) {
+    const uint32_t row0 = H.tdesc[4 * t], nrows = H.tdesc[4 * t + 1], ext0 = H.tdesc[4 * t + 2], next = H.tdesc[4 * t + 3];
+    CHECK((uint64_t)row0 + nrows <= H.trow_id.size() && (uint64_t)ext0 + next <= H.text.size() && next <= H.max_ext && nrows <= H.max_tile_rows);
+    for (uint32_t j = 0; j < next; j++) CHECK(H.text[ext0 + j] < H.nwires);
+    const uint32_t lt0 = H.ltdesc[2 * t], ltn = H.ltdesc[2 * t + 1], tt0 = H.ttdesc[2 * t], ttn = H.ttdesc[2 * t + 1];
+    CHECK(lt0 % 4 == 0 && (uint64_t)lt0 + ltn + 2 <= H.lterms.size() && ltn <= H.max_lean_terms);       // (two read-ahead words behind)
+    CHECK((uint64_t)tt0 + ttn + 1 <= H.tterms.size() && ttn <= H.max_tile_terms);
+    for (uint32_t r = row0; r < row0 + nrows; r++) {
+      CHECK(H.trow_k[r] < H.m && H.trow_id[r] < H.m);
+      for (int lean = 0; lean < 2; lean++) {
+        const std::vector<uint32_t> &rows = lean ? H.lrows : H.trows;
+        const std::vector<uint32_t> &terms = lean ? H.lterms : H.tterms;
+        const uint32_t base = lean ? lt0 : tt0, cnt = lean ? ltn : ttn;
+        const uint32_t off = rows[4 * r], ya = rows[4 * r + 1], nb = rows[4 * r + 2], w3 = rows[4 * r + 3];
+        const bool boolean = ya >> 31;
+        const uint32_t na = ya & 0x7FFFFFFFu, nc = boolean ? 0u : w3;
+        if (boolean) CHECK(w3 < T + next);
+        CHECK(off >= base && (uint64_t)off + na + nb + (boolean && !lean ? 0u : nc) <= (uint64_t)base + cnt);
+        const uint32_t total = na + nb + nc;
+        for (uint32_t q = 0; q < total; q++) {
+          const uint32_t w = terms[off + q];
+          if (lean && (w >> 16) == 0xFFFFu) {
+            CHECK(q + 1 < total);
+            const uint32_t w1 = terms[off + q + 1], n = w1 & 0xFFu, sh = (w1 >> 8) & 0xFFu;
+            CHECK(n >= 4 && n <= 64 && sh + n <= 62 && (w & 0xFFFFu) + n <= T + next);
+            // a run lies inside one part
+            const uint32_t part_end = q < na ? na : q < na + nb ? na + nb : total;
+            CHECK(q + 1 < part_end);
+            q++;
+          } else {
+            CHECK((w & 0xFFFFu) < T + next && (w >> 16) < H.ncoef);
+          }
+        }
+      }
+    }
+  }
+  return true;
+}
+
+// the lean stream against the gather arrays
+static bool same_sums(const B3wR1csHost &H, const uint8_t prime_le[32]) {
+  if (!H.tiled) return true;
+  const uint32_t T = B3W_R1CS_TILE;
+  uint64_t p_lo;
+  memcpy(&p_lo, prime_le, 8);
+  std::vector<uint64_t> z(H.nwires);
+  for (auto &v : z) { const uint64_t x = rnd(); v = (x & 3) ? (x >> 2) & 1 : (x >> 8) & 0xFFFFFFFFu; }
+  auto coef_lo = [&](uint32_t cid) { uint64_t c; memcpy(&c, &H.coefR[16 * (size_t)cid], 8); return c; };
+  for (uint32_t t = 0; t < H.ntiles; t++) {
+    const uint32_t row0 = H.tdesc[4 * t], nrows = H.tdesc[4 * t + 1], ext0 = H.tdesc[4 * t + 2];
+    auto wire_of = [&](uint32_t idx) { return idx < T ? t * T + idx : H.text[ext0 + idx - T]; };
+    for (uint32_t r = row0; r < row0 + nrows; r++) {
+      const uint32_t k = H.trow_k[r];
+      const uint32_t g_off = H.rowdesc[4 * k], g_n[3] = {H.rowdesc[4 * k + 1], H.rowdesc[4 * k + 2], H.rowdesc[4 * k + 3]};
+      const uint32_t off = H.lrows[4 * r], ya = H.lrows[4 * r + 1];
+      const bool boolean = ya >> 31;
+      const uint32_t l_n[3] = {ya & 0x7FFFFFFFu, H.lrows[4 * r + 2], boolean ? 0u : H.lrows[4 * r + 3]};
+      if (boolean) CHECK(g_n[0] == 1 && g_n[1] == 2 && g_n[2] == 0 && wire_of(H.lrows[4 * r + 3]) == H.wires[g_off]);
+      uint32_t gq = g_off, lq = off;
+      for (int part = 0; part < 3; part++) {
+        uint64_t want = 0, got = 0;
+        for (uint32_t x = 0; x < g_n[part]; x++, gq++) want += coef_lo(H.cids[gq]) * z[H.wires[gq]];
+        for (uint32_t x = 0; x < l_n[part]; x++, lq++) {
+          const uint32_t w = H.lterms[lq];
+          if ((w >> 16) == 0xFFFFu) {
+            const uint32_t w1 = H.lterms[lq + 1], n = w1 & 0xFFu, sh = (w1 >> 8) & 0xFFu;
+            const bool neg = (w1 >> 16) & 1u;
+            for (uint32_t i = 0; i < n; i++) {
+              const uint64_t c = neg ? p_lo - (1ull << (sh + i)) : 1ull << (sh + i);
+              got += c * z[wire_of((w & 0xFFFFu) + i)];
+            }
+            x++; lq++;
+          } else {
+            got += coef_lo(w >> 16) * z[wire_of(w & 0xFFFFu)];
+          }
+        }
+        CHECK(want == got);
+      }
+    }
+  }
+  return true;
+}
+
+int main(int argc, char **argv) {
+  if (argc < 5) { fprintf(stderr, "usage: harness <image> <nwit> <mutations> <seed>\n"); return 2; }
+  FILE *f = fopen(argv[1], "rb");
+  if (!f) { perror(argv[1]); return 2; }
+  std::vector<uint8_t> img;
+  uint8_t buf[65536];
+  size_t n;
+  while ((n = fread(buf, 1, sizeof buf, f)) > 0) img.insert(img.end(), buf, buf + n);
+  fclose(f);
+  const uint32_t nwit = (uint32_t)strtoul(argv[2], nullptr, 10);
+  const int mutations = atoi(argv[3]);
+  rng_state = strtoull(argv[4], nullptr, 10) * 0x9E3779B97F4A7C15ull + 1;
+  if (img.size() < 64) { fprintf(stderr, "image too short\n"); return 2; }
+  uint8_t prime[32];
+  memcpy(prime, &img[12 + 12 + 4], 32);                    // "r1cs" ver nsec | type size(8) | fieldSize | prime   (header section first)
+  {
+    B3wR1csHost H;
+    if (!b3w_r1cs_host_build(img.data(), img.size(), prime, nwit, &H)) { fprintf(stderr, "pristine image refused: %s\n", H.error.c_str()); return 1; }
+    if (!indices_ok(H) || !same_sums(H, prime)) return 1;
+    uint64_t runs = 0;
+    for (size_t i = 0; i + 1 < H.lterms.size(); i++) runs += (H.lterms[i] >> 16) == 0xFFFFu;
+    printf("pristine: %u constraints, %llu terms, tiled %d, %u tiles, max_ext %u, lean words %zu (%llu runs)\n", H.m,
+           (unsigned long long)H.nterms, (int)H.tiled, H.ntiles, H.max_ext, H.lterms.size(), (unsigned long long)runs);
+  }
+  int refused = 0, loaded = 0;
+  for (int k = 0; k < mutations; k++) {
+    std::vector<uint8_t> bad(img);
+    switch (k % 5) {
+      case 0: bad.resize(rnd() % bad.size()); break;
+      case 1: for (int i = 0, e = 1 + (int)(rnd() % 3); i < e; i++) bad[rnd() % 100] = (uint8_t)rnd(); break;           // header bytes
+      case 2: { const size_t pos = 100 + rnd() % (bad.size() - 104); const uint32_t v = (uint32_t)rnd(); memcpy(&bad[pos], &v, 4); break; }
+      case 3: { const uint32_t v = (rnd() & 1) ? 0xFFFFFFFFu : (uint32_t)(rnd() % 100000); memcpy(&bad[24 + 36 + 24], &v, 4); break; }     // mConstraints
+      default: for (int i = 0; i < 8; i++) bad[100 + rnd() % (bad.size() - 100)] ^= (uint8_t)(1u << (rnd() & 7)); break;  // bit flips in the constraints
+    }
+    try {
+      B3wR1csHost H;
+      if (b3w_r1cs_host_build(bad.data(), bad.size(), prime, nwit, &H)) {
+        if (!indices_ok(H)) { fprintf(stderr, "mutation %d loaded with bad indices\n", k); return 1; }
+        loaded++;
+      } else {
+        if (H.error.empty()) { fprintf(stderr, "mutation %d refused without a text\n", k); return 1; }
+        refused++;
+      }
+    } catch (const std::bad_alloc &) { refused++; } catch (const std::length_error &) { refused++; }
+  }
+  printf("mutations: %d refused, %d loaded\n", refused, loaded);
+  return 0;
+}
