@@ -37,6 +37,7 @@ def test_distinct_contexts_on_concurrent_host_threads():
             d_st = torch.zeros(n, dtype=torch.int32, device=dev)
             viol = torch.zeros(n, dtype=torch.int32, device=dev)
             mm = torch.zeros(n, dtype=torch.int32, device=dev)
+            torch.cuda.synchronize()                                 # (the tensors above were made on torch's default stream)
             barrier.wait()
             for rnd in range(6):
                 buf = ctx.alloc_bodies(n * ctx.body_bytes)          # the placement allocator is shared by all contexts
@@ -46,7 +47,8 @@ def test_distinct_contexts_on_concurrent_host_threads():
                 r1cs.check_device(buf.ptr, n, 0, viol.data_ptr(), 0, stream.cuda_stream)
                 ctx.verify_device(buf.ptr, n, 0, mm.data_ptr(), stream.cuda_stream)
                 stream.synchronize()
-                got = torch.full((24, ctx.body_bytes), 9, dtype=torch.uint8, device=dev)     # the same kernels into torch memory, to look at
+                with torch.cuda.stream(stream):                      # (torch's fill on the same stream as the kernels: no race of the test's own)
+                    got = torch.full((24, ctx.body_bytes), 9, dtype=torch.uint8, device=dev)     # the same kernels into torch memory, to look at
                 ctx.run_device(d_recs.data_ptr(), 24, got.data_ptr(), 0, 0, d_st.data_ptr(), stream.cuda_stream)
                 stream.synchronize()
                 assert np.array_equal(got.cpu().numpy().reshape(24, -1), want), (circuit, rnd, "bodies")
