@@ -141,7 +141,7 @@ def test_autotune_picks_a_variant_and_stays_bit_exact(m):
         if k < n:
             assert int((d_bodies[k:k + 2] != 7).sum().item()) == 0, "a small batch wrote past its bodies"
     v512, ms512 = ctx.autotune_device(d_recs.data_ptr(), 512, d_bodies.data_ptr(), 0, 0, d_st.data_ptr(), s)
-    assert v512 == 20 + 8 and 0 < ms512 < 0.15                 # (one body per wave took 0.14 ms for 512 witnesses, sliced 0.07)
+    assert v512 == 20 + 8 and 0 < ms512 < 0.5                  # (sliced: 0.07 ms for 512 witnesses; one body per wave took 0.14)
     v1, _ = ctx.autotune_device(d_recs.data_ptr(), 1, d_bodies.data_ptr(), 0, 0, d_st.data_ptr(), s)
     assert v1 == 20 + 64
     ctx.close()
