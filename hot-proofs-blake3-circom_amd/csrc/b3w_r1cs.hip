@@ -536,7 +536,7 @@ __global__ __launch_bounds__(256) void b3w_r1cs_lean_kernel(const uint8_t *__res
   const uint4 *rows = reinterpret_cast<const uint4 *>(S.rows);
   const uint32_t t0 = tile * B3W_R1CS_TILE;
   const uint32_t n_local = S.nwires - t0 < B3W_R1CS_TILE ? S.nwires - t0 : B3W_R1CS_TILE;
-  constexpr uint32_t PRE = 4;                              // row descriptors fetched under the staging (4 rows per lane in these systems)
+  constexpr uint32_t PRE = 5;                              // row descriptors fetched under the staging (a tile of these systems has 1 030 ... 1 055 rows: five rounds of 256)
   uint4 pre[PRE];
 #pragma unroll
   for (uint32_t q = 0; q < PRE; q++) {
@@ -678,6 +678,7 @@ __global__ __launch_bounds__(256) void b3w_r1cs_lean_kernel(const uint8_t *__res
   if (iters > 1) iteration(1, pre[1]);
   if (iters > 2) iteration(2, pre[2]);
   if (iters > 3) iteration(3, pre[3]);
+  if (iters > 4) iteration(4, pre[4]);
   for (uint32_t it = PRE; it < iters; it++) {
     const uint32_t r = td.x + threadIdx.x + 256 * it;
     iteration(it, r < td.x + td.y ? rows[r] : make_uint4(0, 0, 0, 0));
