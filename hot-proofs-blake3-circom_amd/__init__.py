@@ -113,6 +113,8 @@ def lib():
         "b3w_chain_plan_parents_device": (i32, [vp, vp, u64, u64, u64, u32, vp, vp]),
         "b3w_commit_key_create": (i32, [vp, i32, u32, vp, ctypes.POINTER(vp)]),
         "b3w_commit_key_create_ex": (i32, [vp, i32, u32, vp, u32, ctypes.POINTER(vp)]),
+        "b3w_commit_key_create_folded": (i32, [vp, i32, u32, vp, vp, u32, ctypes.POINTER(vp)]),
+        "b3w_slot_widths": (i32, [vp, vp]),
         "b3w_commit_key_window": (u32, [vp]),
         "b3w_commit_key_destroy": (None, [vp]),
         "b3w_commit_records_device": (i32, [vp, vp, vp, u32, vp, vp, vp, vp]),
@@ -158,7 +160,7 @@ EXPORTED_SYMBOLS = ("b3w_abi_version", "b3w_identify_wasm", "b3w_create", "b3w_d
                     "b3w_r1cs_create", "b3w_r1cs_info", "b3w_r1cs_is_tiled", "b3w_r1cs_destroy", "b3w_r1cs_check_device", "b3w_batch_r1cs_check", "b3w_r1cs_consumer", "b3w_batch_write_wtns", "b3w_batch_autotune_device", "b3w_bodies_alloc", "b3w_bodies_free", "b3w_bodies_trim", "b3w_bodies_configure", "b3w_bodies_stats", "b3w_batch_placement", "b3w_chain_num_chunks", "b3w_chain_num_leaf_steps", "b3w_chain_path_len",
                     "b3w_chain_num_parent_steps", "b3w_chain_parent_row", "b3w_chain_path_provable",
                     "b3w_chain_plan_leaves_device", "b3w_chain_tree_device", "b3w_chain_plan_parents_device",
-                    "b3w_commit_key_create", "b3w_commit_key_create_ex", "b3w_commit_key_window", "b3w_commit_key_destroy", "b3w_commit_records_device", "b3w_commit_records", "b3w_chain_commit_only", "b3w_chain_commitments", "b3w_chain_check_constraints", "b3w_chain_violations", "b3w_batch_commit_device", "b3w_batch_commit", "b3w_commit_consumer",
+                    "b3w_commit_key_create", "b3w_commit_key_create_ex", "b3w_commit_key_create_folded", "b3w_slot_widths", "b3w_commit_key_window", "b3w_commit_key_destroy", "b3w_commit_records_device", "b3w_commit_records", "b3w_chain_commit_only", "b3w_chain_commitments", "b3w_chain_check_constraints", "b3w_chain_violations", "b3w_batch_commit_device", "b3w_batch_commit", "b3w_commit_consumer",
                     "b3w_comm_unique_id", "b3w_comm_create", "b3w_comm_destroy", "b3w_comm_allgather", "b3w_batch_allgather_public",
                     "b3w_chain_create", "b3w_chain_destroy", "b3w_chain_run_leaves", "b3w_chain_run_parents", "b3w_chain_shard", "b3w_chain_run_parents_sharded", "b3w_chain_info",
                     "b3w_chain_outputs", "b3w_chain_records", "b3w_chain_public", "b3w_chain_status", "b3w_chain_local_cvs", "b3w_chain_root")
@@ -263,6 +265,14 @@ class Context:
             raise B3WError(rc, f"b3w_batch_autotune_device: status {rc}: {self.last_error()}")
         return v.value, ms.value
 
+    def slot_widths(self):
+        """Bits each witness slot can hold (1, 32, 64 or 256), as the commitment kernel cuts it into virtual slots."""
+        out = np.zeros(self.witness_size, dtype=np.uint16)
+        rc = lib().b3w_slot_widths(self.handle, out.ctypes.data)
+        if rc != B3W_OK:
+            raise B3WError(rc, f"b3w_slot_widths: status {rc}: {self.last_error()}")
+        return out
+
     def alloc_bodies(self, nbytes):
         """Device buffer for bodies, placed over two classes of HBM when possible (b3w_bodies_alloc)."""
         return BodyBuffer(self, nbytes)
@@ -327,6 +337,18 @@ BUILTIN_R1CS = {"compression": "blake3_compression.r1cs.gz", "nova_bn254_o1": "b
                 "nova_bn254": "blake3_nova_bn254.r1cs.gz", "nova_vesta": "blake3_nova_vesta.r1cs.gz"}
 
 
+def read_r1cs_image(image):
+    """bytes of an .r1cs image from bytes, a path (.r1cs or .r1cs.gz) or the name of a built-in file under constraints/."""
+    if isinstance(image, (str, os.PathLike)):
+        path = image if os.path.exists(image) else os.path.join(R1CS_DIR, image)
+        raw = open(path, "rb").read()
+        if raw[:2] == b"\x1f\x8b":
+            import gzip
+            raw = gzip.decompress(raw)
+        return raw
+    return bytes(image)
+
+
 class R1cs:
     """A rank-1 constraint system on the device (b3w_r1cs_create) for on-device satisfaction checks of witness bodies
     — the counterpart of circom_tester's expectPass (test/blake3_hash.test.ts:36) / synthesize_with_vec's constraints
@@ -382,15 +404,26 @@ class CommitKey:
     or "pallas" (the group whose scalar field is the --prime vesta circuit's field; "vesta" is accepted as its older name); window = 12 | 16 bits per table window (0: automatic, see include/b3wit.h)."""
     CURVES = {"bn254_g1": 0, "pallas": 1, "vesta": 1}     # "vesta" = older name of the Pallas curve id (after the circuit's prime)
 
-    def __init__(self, ctx, curve, generators, first_slot=0, window=0):
+    def __init__(self, ctx, curve, generators, first_slot=0, window=0, fold=None):
+        """fold: an .r1cs image (bytes / path), or True for the circuit's built-in one — the slots that the circuit's linear
+        constraints express through others (every 32-bit word through its bits) are folded into those slots' generators
+        (fold.py) and not committed by themselves: the same point for every witness, half the point additions."""
         self.ctx = ctx
         buf = bytes(generators)
-        if len(buf) != 64 * (ctx.witness_size - first_slot):
+        nslots = ctx.witness_size - first_slot
+        if len(buf) != 64 * nslots:
             raise B3WError(100, "generators: 64 bytes per committed slot")
+        self.folded_slots, mask = 0, None
+        if fold is not None and fold is not False:
+            from . import fold as _fold
+            image = read_r1cs_image(BUILTIN_R1CS[ctx.circuit]) if fold is True else read_r1cs_image(fold)
+            buf, mask, self.fold_stats = _fold.fold_generators(image, ctx.slot_widths(), first_slot, buf, curve)
+            self.folded_slots = int(sum(mask))
         h = ctypes.c_void_p()
-        rc = lib().b3w_commit_key_create_ex(ctx.handle, self.CURVES[curve], first_slot, buf, window, ctypes.byref(h))
+        rc = lib().b3w_commit_key_create_folded(ctx.handle, self.CURVES[curve], first_slot, buf, bytes(mask) if mask is not None else None, window,
+                                                ctypes.byref(h))
         if rc != B3W_OK:
-            raise B3WError(rc, f"b3w_commit_key_create_ex: status {rc}: {ctx.last_error()}")
+            raise B3WError(rc, f"b3w_commit_key_create_folded: status {rc}: {ctx.last_error()}")
         self.handle = h
         self.window = lib().b3w_commit_key_window(h)
 

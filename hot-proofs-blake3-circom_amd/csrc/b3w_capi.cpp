@@ -1266,6 +1266,22 @@ uint32_t b3w_commit_key_window(const b3w_commit_key *key) { return key ? key->wi
 
 int32_t b3w_commit_key_create_ex(b3w_ctx *ctx, int32_t curve, uint32_t first_slot, const uint8_t *host_generators, uint32_t window_bits,
                                  b3w_commit_key **out) {
+  return b3w_commit_key_create_folded(ctx, curve, first_slot, host_generators, nullptr, window_bits, out);
+}
+
+int32_t b3w_slot_widths(b3w_ctx *ctx, uint16_t *out_bits) {
+  if (!ctx || !out_bits) return B3W_E_BAD_ARGUMENT;
+  std::vector<uint32_t> table;
+  if (!build_slot_table(ctx->desc, table, ctx->last_error)) return B3W_E_BAD_ARGUMENT;
+  for (uint32_t i = 0; i < ctx->desc.nwit; i++) {
+    const uint32_t mode = (table[i] >> 17) & 3u;
+    out_bits[i] = mode == B3W_MODE_BIT ? 1 : mode == B3W_MODE_W32 ? 32 : mode == B3W_MODE_W64 ? 64 : 256;
+  }
+  return B3W_OK;
+}
+
+int32_t b3w_commit_key_create_folded(b3w_ctx *ctx, int32_t curve, uint32_t first_slot, const uint8_t *host_generators,
+                                     const uint8_t *folded /* per committed slot, or null */, uint32_t window_bits, b3w_commit_key **out) {
   if (!ctx || !out || !host_generators || (curve != B3W_CURVE_BN254_G1 && curve != B3W_CURVE_VESTA) || first_slot >= ctx->desc.nwit ||
       (window_bits != 0 && window_bits != B3W_COMMIT_WINDOW_SMALL && window_bits != B3W_COMMIT_WINDOW_LARGE)) {
     if (ctx) ctx->last_error = "commit key: curve 0/1, first_slot < witness_size, window_bits 0 (auto), 12 or 16";
@@ -1281,6 +1297,7 @@ int32_t b3w_commit_key_create_ex(b3w_ctx *ctx, int32_t curve, uint32_t first_slo
   for (uint32_t i = 0; i < nslots; i++) {
     const uint32_t mode = (table[first_slot + i] >> 17) & 3u;
     nbits[i] = mode == B3W_MODE_BIT ? 1u : mode == B3W_MODE_W32 ? 32u : mode == B3W_MODE_W64 ? 64u : 256u;
+    if (folded && folded[i]) nbits[i] = 0;            // folded into other slots' generators by the caller: no virtual slots, no points
     first_v[i] = (uint32_t)nv;
     nv += nbits[i];
   }
@@ -1310,12 +1327,14 @@ int32_t b3w_commit_key_create_ex(b3w_ctx *ctx, int32_t curve, uint32_t first_slo
   key->nslots = nslots;
   uint32_t *d_gens = nullptr, *d_first = nullptr, *d_nbits = nullptr, *d_points = nullptr;
   std::vector<uint32_t> desc(nslots);
-  for (uint32_t i = 0; i < nslots; i++) desc[i] = first_v[i] | (nbits[i] == 1 ? 0u : nbits[i] == 32 ? 1u : nbits[i] == 64 ? 2u : 3u) << 24;
+  for (uint32_t i = 0; i < nslots; i++)
+    desc[i] = first_v[i] | (nbits[i] == 0 ? 4u : nbits[i] == 1 ? 0u : nbits[i] == 32 ? 1u : nbits[i] == 64 ? 2u : 3u) << 24;   // 4: folded, skipped
   // records mode: slot s holds (image[src] >> sh) & mask (b3w_kernels.hip emit_group), so a run of bit slots reading
   // consecutive bits of one image word is one contiguous piece of the bit string
   std::vector<uint32_t> runs;
   for (uint32_t i = 0; i < nslots; i++) {
     const uint32_t ent = table[first_slot + i], src = ent & 0xFFFu, sh = (ent >> 12) & 31u, v0 = first_v[i];
+    if (nbits[i] == 0) continue;
     if (nbits[i] == 1) {
       if (!runs.empty()) {
         const uint32_t a = runs[runs.size() - 2], b = runs[runs.size() - 1];

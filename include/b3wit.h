@@ -242,6 +242,19 @@ int32_t b3w_commit_key_create(b3w_ctx *ctx, int32_t curve, uint32_t first_slot, 
  * environment's B3W_COMMIT_WINDOW, else 16 when that table takes at most a quarter of the free device memory. */
 int32_t b3w_commit_key_create_ex(b3w_ctx *ctx, int32_t curve, uint32_t first_slot, const uint8_t *host_generators, uint32_t window_bits,
                                  b3w_commit_key **out);
+/* FOLDED keys.  A witness satisfies its circuit's LINEAR constraints, so a slot that is a linear combination of others — every
+ * 32-bit word of these circuits is the sum of its bit slots — need not be committed by itself: with w_k = sum_j a_kj w_j,
+ * w_k G_k = sum_j w_j (a_kj G_k), i.e. the caller adds a_kj G_k to the generator of slot j once and marks slot k as folded
+ * (folded[k - first_slot] != 0: no table windows, the slot's bytes are not even read for their value).  The commitment of every
+ * body that satisfies those relations is the same point; half of the point additions are gone (46 289 -> 23 377 virtual slots
+ * for blake3_compression).  A body that violates them (not a witness) gets the commitment of the witness its remaining slots
+ * determine: run the constraint check where that matters.  The Python binding derives the relations from an .r1cs image and folds
+ * the generators (fold.py: CommitKey(..., fold=image)).  b3w_slot_widths: bits a slot can hold (1, 32, 64, 256) as the
+ * commitment kernel cuts it into virtual slots. */
+int32_t b3w_commit_key_create_folded(b3w_ctx *ctx, int32_t curve, uint32_t first_slot, const uint8_t *host_generators,
+                                     const uint8_t *folded /* witness_size - first_slot flags, or NULL */, uint32_t window_bits,
+                                     b3w_commit_key **out);
+int32_t b3w_slot_widths(b3w_ctx *ctx, uint16_t *out_bits /* witness_size */);
 uint32_t b3w_commit_key_window(const b3w_commit_key *key);     /* 12 or 16 */
 void b3w_commit_key_destroy(b3w_commit_key *key);
 /* d_bodies and d_points 16-byte aligned, pitch a multiple of 16 (0 = witness_size * 32). */

@@ -404,3 +404,56 @@ def test_device_reproduces_published_known_answers():
     Gp = (p_pa - 1, 2)
     assert commit_body("nova_vesta", "pallas", {0: 1, 1: 5}, [Gp, Gp]) == E.mul(6, Gp, p_pa)
     assert commit_body("nova_vesta", "pallas", {0: 1}, [E.neg(Gp, p_pa)]) == E.mul(T.VESTA_Q - 1, Gp, p_pa)
+
+
+@pytest.mark.parametrize("circuit,curve,first_slot,window", [("compression", "bn254_g1", 0, 16), ("compression", "bn254_g1", 45, 12),
+                                                             ("nova_vesta", "vesta", 0, 16), ("nova_bn254_o1", "bn254_g1", 3, 12)])
+def test_folded_keys_commit_to_the_same_points(circuit, curve, first_slot, window):
+    """include/b3wit.h "FOLDED keys": the slots that the circuit's linear constraints express through others (every 32-bit
+    word through its bits; fold.py derives that from the .r1cs image alone) are folded into those slots' generators and drop
+    out of the table.  The commitment of every witness must be the same point as under the unfolded key — from the bodies and
+    straight from the records, rejected nova steps included — with about half the virtual slots for the O1-style builds
+    (blake3_compression, the circomkit nova build); the O2 builds have no linear constraints left to fold."""
+    import torch
+    m = T.pkg()
+    W = T.workloads()
+    n = 200
+    recs = W.config2_compression(n, first=31) if circuit == "compression" else W.config3_nova(n, first=31)
+    if circuit != "compression":
+        recs = recs.copy()
+        recs[5, 14] = recs[5, 12]                             # a rejected step
+    ctx = m.Context(circuit, 0)
+    gens = E.points_to_bytes(E.random_points(curve, ctx.witness_size - first_slot, seed=b"fold" + circuit.encode()))
+    plain = m.CommitKey(ctx, curve, gens, first_slot, window)
+    folded = m.CommitKey(ctx, curve, gens, first_slot, window, fold=True)
+    st = folded.fold_stats
+    if circuit == "nova_vesta":
+        # circom's O2 pass has already used up the linear constraints (each took one BIT of a word away): nothing left to fold
+        assert folded.folded_slots < 20, st
+    else:
+        # (the circomkit nova build keeps 190 full field elements, 256 virtual slots each: 107 697 -> 76 849)
+        assert folded.folded_slots >= 400 and st["virtual_slots_folded"] < (0.62 if circuit == "compression" else 0.75) * st["virtual_slots"], st
+    dev = torch.device("cuda:0")
+    s = torch.cuda.current_stream().cuda_stream
+    d_recs = torch.from_numpy(recs.view(np.int32)).to(dev)
+    d_bodies = torch.zeros((n, ctx.body_bytes), dtype=torch.uint8, device=dev)
+    d_st = torch.zeros(n, dtype=torch.int32, device=dev)
+    ctx.run_device(d_recs.data_ptr(), n, d_bodies.data_ptr(), 0, 0, d_st.data_ptr(), s)
+    out = {}
+    for name, key in (("plain", plain), ("folded", folded)):
+        a = torch.full((n, 64), 7, dtype=torch.uint8, device=dev)
+        b = torch.full((n, 64), 7, dtype=torch.uint8, device=dev)
+        sa = torch.full((n,), -1, dtype=torch.int32, device=dev)
+        sb = torch.full((n,), -1, dtype=torch.int32, device=dev)
+        key.commit_device(d_bodies.data_ptr(), n, 0, a.data_ptr(), sa.data_ptr(), s)
+        key.commit_records_device(d_recs.data_ptr(), n, b.data_ptr(), sb.data_ptr(), 0, s)
+        torch.cuda.synchronize()
+        out[name] = (a.cpu().numpy(), b.cpu().numpy(), sa.cpu().numpy(), sb.cpu().numpy())
+    ok = d_st.cpu().numpy() == 0
+    assert int((~ok).sum()) == (0 if circuit == "compression" else 1)
+    assert np.array_equal(out["plain"][0][ok], out["folded"][0][ok]), "bodies: folded key gives other points"
+    assert np.array_equal(out["plain"][1], out["folded"][1]), "records: folded key gives other points"
+    assert np.array_equal(out["plain"][0][ok], out["plain"][1][ok])
+    assert (out["folded"][2][ok] == 0).all() and np.array_equal(out["folded"][3], out["plain"][3])
+    assert int(out["folded"][1][~ok].astype(np.int64).sum()) == 0               # rejected: the point at infinity
+    plain.close(); folded.close(); ctx.close()
