@@ -148,7 +148,9 @@ def bench_chain(args, m, torch, dist, dev, world, rank, local_rank):
     if "commit" in args.consumer:                    # second half: what the folding prover does with each step witness
         K = importlib.import_module("hot-proofs-blake3-circom_amd.synthetic_key")
         curve = "vesta" if "vesta" in circuit else "bn254_g1"
-        key = m.CommitKey(ctx, curve, K.generators(curve, ctx.witness_size, seed=b"bench"))
+        # (folded key: slots the circuit's linear constraints express through others drop out of the tables — the circomkit /
+        # compression builds lose half their virtual slots, the O2 builds have no linear constraints left: DESIGN.md 8d)
+        key = m.CommitKey(ctx, curve, K.generators(curve, ctx.witness_size, seed=b"bench"), fold=True if circuit in m.BUILTIN_R1CS else None)
         d_pts = torch.zeros((n_max, 64), dtype=torch.uint8, device=dev)
         d_st = torch.zeros(n_max, dtype=torch.int32, device=dev)
         check_first = consumer
@@ -225,7 +227,7 @@ def bench_chain(args, m, torch, dist, dev, world, rank, local_rank):
                                    f"({dist.get_backend()})" if world > 1 else "none",
                        "consumer": " then ".join(
                            ([f"rank-1 constraint check of every step witness on the device ({r1cs_t.n_constraints} constraints)"] if r1cs_t is not None else []) +
-                           ([f"Pedersen commitment of every step witness on the device ({key.window}-bit windows)"
+                           ([f"Pedersen commitment of every step witness on the device ({key.window}-bit windows, {key.folded_slots} slots folded)"
                              + (", from the step records: no bodies written" if commit_only is not None else "")] if key is not None else [])) or "none"},
             "roofline": {"bound": "hbm", "achieved": total_steps * args.steps * per / elapsed / 1e9 / world, "peak": HBM_PEAK_GBS,
                          "unit": "GB/s", "frac": total_steps * args.steps * per / elapsed / 1e9 / world / HBM_PEAK_GBS,
