@@ -1297,7 +1297,11 @@ int32_t b3w_commit_key_create_folded(b3w_ctx *ctx, int32_t curve, uint32_t first
   for (uint32_t i = 0; i < nslots; i++) {
     const uint32_t mode = (table[first_slot + i] >> 17) & 3u;
     nbits[i] = mode == B3W_MODE_BIT ? 1u : mode == B3W_MODE_W32 ? 32u : mode == B3W_MODE_W64 ? 64u : 256u;
-    if (folded && folded[i]) nbits[i] = 0;            // folded into other slots' generators by the caller: no virtual slots, no points
+    if (folded && folded[i] == 1) nbits[i] = 0;       // folded into other slots' generators by the caller: no virtual slots, no points
+    else if (folded && (folded[i] & 0x80)) {          // only bit (folded[i] & 31) of this 32-bit word is committed, with the generator given
+      if (mode != B3W_MODE_W32 || (folded[i] & 0x60)) { ctx->last_error = "commit key: a single-bit fold needs a 32-bit slot and a bit below 32"; return B3W_E_BAD_ARGUMENT; }
+      nbits[i] = 1;
+    } else if (folded && folded[i]) { ctx->last_error = "commit key: folded[] holds 0, 1 or 0x80 | bit"; return B3W_E_BAD_ARGUMENT; }
     first_v[i] = (uint32_t)nv;
     nv += nbits[i];
   }
@@ -1327,14 +1331,19 @@ int32_t b3w_commit_key_create_folded(b3w_ctx *ctx, int32_t curve, uint32_t first
   key->nslots = nslots;
   uint32_t *d_gens = nullptr, *d_first = nullptr, *d_nbits = nullptr, *d_points = nullptr;
   std::vector<uint32_t> desc(nslots);
-  for (uint32_t i = 0; i < nslots; i++)
-    desc[i] = first_v[i] | (nbits[i] == 0 ? 4u : nbits[i] == 1 ? 0u : nbits[i] == 32 ? 1u : nbits[i] == 64 ? 2u : 3u) << 24;   // 4: folded, skipped
+  auto one_bit_of_word = [&](uint32_t i) { return folded && (folded[i] & 0x80) != 0; };
+  for (uint32_t i = 0; i < nslots; i++)                  // code 4: folded, skipped; 8 + b: bit b of a 32-bit word
+    desc[i] = first_v[i] | (one_bit_of_word(i) ? 8u + (folded[i] & 31u) : nbits[i] == 0 ? 4u : nbits[i] == 1 ? 0u : nbits[i] == 32 ? 1u : nbits[i] == 64 ? 2u : 3u) << 24;
   // records mode: slot s holds (image[src] >> sh) & mask (b3w_kernels.hip emit_group), so a run of bit slots reading
   // consecutive bits of one image word is one contiguous piece of the bit string
   std::vector<uint32_t> runs;
   for (uint32_t i = 0; i < nslots; i++) {
     const uint32_t ent = table[first_slot + i], src = ent & 0xFFFu, sh = (ent >> 12) & 31u, v0 = first_v[i];
     if (nbits[i] == 0) continue;
+    if (one_bit_of_word(i)) {                               // one bit of the word's image word
+      runs.push_back(v0 | 0u << 24); runs.push_back(src | (sh + (folded[i] & 31u)) << 16);
+      continue;
+    }
     if (nbits[i] == 1) {
       if (!runs.empty()) {
         const uint32_t a = runs[runs.size() - 2], b = runs[runs.size() - 1];

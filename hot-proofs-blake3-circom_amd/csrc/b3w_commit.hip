@@ -783,6 +783,8 @@ __global__ __launch_bounds__(T * WPB) __attribute__((amdgpu_waves_per_eu(3, 3)))
         else if (code == 2) { wrong |= (a[u].z | a[u].w | hi) != 0; put32(v0, a[u].x); put32(v0 + 32, a[u].y); }
         else if (code == 3) { put32(v0, a[u].x); put32(v0 + 32, a[u].y); put32(v0 + 64, a[u].z); put32(v0 + 96, a[u].w);
                               put32(v0 + 128, b[u].x); put32(v0 + 160, b[u].y); put32(v0 + 192, b[u].z); put32(v0 + 224, b[u].w); }
+        else if (code >= 8 && code < 40) { wrong |= (a[u].y | a[u].z | a[u].w | hi) != 0; put32(v0, (a[u].x >> (code - 8)) & 1u); }   // folded key: one bit of a word
+        // (code 4: a slot folded into others' generators — nothing to add)
       }
     }
     if (wrong) bad[sub] = 1;

@@ -65,6 +65,53 @@ def linear_relations(prime, cons):
     return out
 
 
+def bit_of_word_relations(prime, n_wires, cons, widths):
+    """What circom's O2 pass leaves of a word's decomposition  W = sum 2^j b_j  after it has used the linear constraint to take bit
+    i out of the witness: the booleanity of that bit,  N (N - 2^i) = 0  with  N = W - sum_{j != i} 2^j b_j  (up to scaling, the
+    constant on either side).  Then  W = sum_{j != i} 2^j b_j + 2^i beta  with beta = bit i of W's value.  Returned as linear rows
+    over the wires plus one VIRTUAL wire n_wires + W per word (its beta), and {W: i}.  Only the clean case is taken: one 32-bit
+    word, 31 distinct bit slots with coefficients 2^j, roots 0 and 2^i, all 32 positions covered."""
+    p = prime
+    rows, bit_of = [], {}
+    for a, b, c in cons:
+        if c:
+            continue
+        wa, wb = set(a) - {0}, set(b) - {0}
+        if wa != wb or len(wa) != 32:
+            continue
+        words = [w for w in wa if widths[w] != 1]
+        if len(words) != 1 or widths[words[0]] != 32 or words[0] in bit_of:
+            continue
+        W = words[0]
+        ia, ib = pow(a[W], -1, p), pow(b[W], -1, p)
+        na = {w: cf * ia % p for w, cf in a.items()}
+        nb = {w: cf * ib % p for w, cf in b.items()}
+        if any(na[w] != nb[w] for w in wa):
+            continue
+        roots = sorted([(-na.get(0, 0)) % p, (-nb.get(0, 0)) % p])      # N = W + sum c_j b_j is one of these
+        d = roots[1]
+        if roots[0] != 0 or d == 0 or d & (d - 1) or d.bit_length() > 32:
+            continue
+        i = d.bit_length() - 1
+        J = {}
+        for w in wa:
+            if w == W:
+                continue
+            cj = (-na[w]) % p                                            # W = sum cj b_j + N
+            if cj == 0 or cj & (cj - 1) or cj.bit_length() > 32 or (cj.bit_length() - 1) in J:
+                J = None
+                break
+            J[cj.bit_length() - 1] = w
+        if J is None or i in J or set(J) | {i} != set(range(32)):
+            continue
+        row = {W: 1, n_wires + W: (-d) % p}
+        for j, w in J.items():
+            row[w] = (-(1 << j)) % p
+        rows.append(row)
+        bit_of[W] = i
+    return rows, bit_of
+
+
 def eliminate(prime, n_wires, rows, widths, first_slot):
     """-> {k: {j: a_kj}}: slot k (wider than one bit) as a combination of kept slots, all of them committed (>= first_slot)."""
     p = prime
@@ -88,7 +135,7 @@ def eliminate(prime, n_wires, rows, widths, first_slot):
 
     for row in rows:
         row = substitute(dict(row))
-        cands = [w for w, cf in row.items() if w >= first_slot and widths[w] > 1 and cf in (1, p - 1)]
+        cands = [w for w, cf in row.items() if first_slot <= w < n_wires and widths[w] > 1 and cf in (1, p - 1)]
         if not cands:
             continue
         k = max(cands, key=lambda w: (widths[w], w))
@@ -106,7 +153,7 @@ def eliminate(prime, n_wires, rows, widths, first_slot):
                     else:
                         e2.pop(w2, None)
     # only what stays inside the committed range, over slots that are kept
-    return {k: e for k, e in expr.items() if all(w >= first_slot and w not in expr for w in e)}
+    return {k: e for k, e in expr.items() if all(w >= first_slot and w not in expr for w in e)}   # (virtual wires: >= n_wires)
 
 
 class _Curve:
@@ -151,7 +198,12 @@ def fold_generators(image, widths, first_slot, generators, curve):
     if n_wires != len(widths):
         raise ValueError("the constraint system is not this circuit's")
     widths = [int(w) for w in widths]
-    expr = eliminate(prime, n_wires, linear_relations(prime, cons), widths, first_slot)
+    bow_rows, bit_of = bit_of_word_relations(prime, n_wires, cons, widths)
+    expr = eliminate(prime, n_wires, linear_relations(prime, cons) + bow_rows, widths, first_slot)
+    # a word whose relation was not used for ITS elimination keeps its slot as it is (its virtual wire then stands for nothing)
+    bit_of = {W: i for W, i in bit_of.items() if W in expr and (n_wires + W) in expr[W]}
+    if any(w >= n_wires and (w - n_wires) not in bit_of for e in expr.values() for w in e):
+        raise ValueError("a virtual bit is used outside its word's elimination")
     q, b = CURVES[curve]
     E = _Curve(q, b)
     nslots = n_wires - first_slot
@@ -161,6 +213,13 @@ def fold_generators(image, widths, first_slot, generators, curve):
         y = int.from_bytes(generators[64 * i + 32:64 * i + 64], "little")
         G.append(None if x == 0 and y == 0 else (x, y))
     out = list(G)
+    virt = {}                                               # generators of the virtual bits: they start at infinity
+
+    def acc(j, T):
+        if j >= n_wires:
+            virt[j - n_wires] = E.add(virt.get(j - n_wires), T)
+        else:
+            out[j - first_slot] = E.add(out[j - first_slot], T)
     half = prime >> 1
     for k, e in expr.items():
         Gk = G[k - first_slot]
@@ -178,19 +237,22 @@ def fold_generators(image, widths, first_slot, generators, curve):
                 T = pow2[i]
             else:
                 T = E.mul(mag, Gk)
-            out[j - first_slot] = E.add(out[j - first_slot], E.neg(T) if neg else T)
+            acc(j, E.neg(T) if neg else T)
     mask = bytearray(nslots)
     buf = bytearray(generators)
     for k in expr:
         mask[k - first_slot] = 1
+    for W, i in bit_of.items():                             # the word's slot now stands for bit i of its value
+        mask[W - first_slot] = 0x80 | i
+        out[W - first_slot] = virt[W]
     for i, P in enumerate(out):
         if P is None:
-            if not mask[i]:
+            if mask[i] != 1:
                 raise ValueError("a folded generator is the point at infinity")     # (cannot happen with independent generators)
             continue
         buf[64 * i:64 * i + 32] = P[0].to_bytes(32, "little")
         buf[64 * i + 32:64 * i + 64] = P[1].to_bytes(32, "little")
     v0 = sum(widths[first_slot:])
-    v1 = sum(w for i, w in enumerate(widths[first_slot:]) if not mask[i])
-    return bytes(buf), mask, {"folded_slots": len(expr), "virtual_slots": v0, "virtual_slots_folded": v1,
+    v1 = sum((1 if mask[i] & 0x80 else w) for i, w in enumerate(widths[first_slot:]) if mask[i] != 1)
+    return bytes(buf), mask, {"folded_slots": len(expr), "single_bit_words": len(bit_of), "virtual_slots": v0, "virtual_slots_folded": v1,
                               "terms": sum(len(e) for e in expr.values())}

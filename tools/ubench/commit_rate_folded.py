@@ -5,10 +5,11 @@ sys.path.insert(0, os.getcwd()); sys.path.insert(0, os.path.join(os.getcwd(), "t
 import ec_ref as E
 m = importlib.import_module("hot-proofs-blake3-circom_amd")
 dev = torch.device("cuda:0"); s = torch.cuda.current_stream().cuda_stream
-for circuit, curve, n, window in (("compression", "bn254_g1", 16384, 16), ("compression", "bn254_g1", 4096, 12), ("nova_bn254_o1", "bn254_g1", 8192, 16)):
+for circuit, curve, n, window in (("compression", "bn254_g1", 16384, 16), ("compression", "bn254_g1", 4096, 12), ("nova_bn254_o1", "bn254_g1", 8192, 16), ("nova_vesta", "pallas", 8192, 16),
+                                  ("nova_vesta", "pallas", 8192, 12)):
     ctx = m.Context(circuit, 0)
     recs = m.workloads.config2_compression(n) if circuit == "compression" else m.workloads.config3_nova(n)
-    gens = E.points_to_bytes(E.random_points(curve, ctx.witness_size, seed=b"rate"))
+    gens = E.points_to_bytes(E.random_points("vesta" if curve == "pallas" else curve, ctx.witness_size, seed=b"rate"))
     d_recs = torch.from_numpy(recs.view(np.int32)).to(dev)
     bodies = ctx.alloc_bodies(n * ctx.body_bytes)
     ctx.run_device(d_recs.data_ptr(), n, bodies.ptr, 0, 0, 0, s)
