@@ -418,7 +418,7 @@ class CommitKey:
             from . import fold as _fold
             image = read_r1cs_image(BUILTIN_R1CS[ctx.circuit]) if fold is True else read_r1cs_image(fold)
             buf, mask, self.fold_stats = _fold.fold_generators(image, ctx.slot_widths(), first_slot, buf, curve)
-            self.folded_slots = int(sum(mask))
+            self.folded_slots = sum(1 for v in mask if v)          # folded away, or cut down to one bit
         h = ctypes.c_void_p()
         rc = lib().b3w_commit_key_create_folded(ctx.handle, self.CURVES[curve], first_slot, buf, bytes(mask) if mask is not None else None, window,
                                                 ctypes.byref(h))

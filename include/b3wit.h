@@ -247,7 +247,9 @@ int32_t b3w_commit_key_create_ex(b3w_ctx *ctx, int32_t curve, uint32_t first_slo
  * w_k G_k = sum_j w_j (a_kj G_k), i.e. the caller adds a_kj G_k to the generator of slot j once and marks slot k as folded
  * (folded[k - first_slot] != 0: no table windows, the slot's bytes are not even read for their value).  The commitment of every
  * body that satisfies those relations is the same point; half of the point additions are gone (46 289 -> 23 377 virtual slots
- * for blake3_compression).  A body that violates them (not a witness) gets the commitment of the witness its remaining slots
+ * for blake3_compression).  folded[k] = 0x80 | i keeps ONE virtual slot of a 32-bit word: bit i of its value, with the generator
+ * given for it (the O2 builds: a word is 31 bit slots + 2^i * the bit circom's O2 pass took out of the witness).
+ * A body that violates the relations (not a witness) gets the commitment of the witness its remaining slots
  * determine: run the constraint check where that matters.  The Python binding derives the relations from an .r1cs image and folds
  * the generators (fold.py: CommitKey(..., fold=image)).  b3w_slot_widths: bits a slot can hold (1, 32, 64, 256) as the
  * commitment kernel cuts it into virtual slots. */
