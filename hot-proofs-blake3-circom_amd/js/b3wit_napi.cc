@@ -47,6 +47,7 @@ struct Api {
   decltype(&b3w_chain_info) chain_info;
   decltype(&b3w_chain_outputs) chain_outputs;
   decltype(&b3w_commit_key_create_ex) commit_key_create_ex;
+  decltype(&b3w_commit_key_create_folded) commit_key_create_folded;
   decltype(&b3w_commit_key_destroy) commit_key_destroy;
   decltype(&b3w_commit_records) commit_records;
   decltype(&b3w_chain_commit_only) chain_commit_only;
@@ -87,7 +88,7 @@ bool load_api() {
   SYM(write_wtns_header) SYM(last_error) SYM(public_words) SYM(batch_alloc) SYM(batch_free) SYM(batch_run)
   SYM(batch_outputs) SYM(batch_fetch) SYM(batch_write_wtns) SYM(batch_verify) SYM(batch_placement) SYM(bodies_trim)
   SYM(chain_create) SYM(chain_destroy) SYM(chain_run_leaves) SYM(chain_run_parents) SYM(chain_info) SYM(chain_outputs)
-  SYM(commit_key_create_ex) SYM(commit_key_destroy) SYM(commit_records) SYM(chain_commit_only) SYM(chain_commitments) SYM(batch_commit) SYM(chain_shard) SYM(chain_run_parents_sharded) SYM(comm_unique_id) SYM(comm_create) SYM(comm_destroy) SYM(batch_allgather_public)
+  SYM(commit_key_create_ex) SYM(commit_key_create_folded) SYM(commit_key_destroy) SYM(commit_records) SYM(chain_commit_only) SYM(chain_commitments) SYM(batch_commit) SYM(chain_shard) SYM(chain_run_parents_sharded) SYM(comm_unique_id) SYM(comm_create) SYM(comm_destroy) SYM(batch_allgather_public)
   SYM(r1cs_create) SYM(r1cs_info) SYM(r1cs_destroy) SYM(batch_r1cs_check) SYM(chain_check_constraints) SYM(chain_violations)
 #undef SYM
   api.so = so;
@@ -475,10 +476,12 @@ napi_value ChainFold(napi_env env, napi_callback_info info) {
 }
 
 // commitKey(handle, curve: 0 = BN254 G1 | 1 = Vesta, firstSlot, generators: Uint8Array((witnessSize - firstSlot) * 64)
-//           [, windowBits: 0 (automatic) | 12 | 16])
-// installs the commitment key of this handle (tables on the device)
+//           [, windowBits: 0 (automatic) | 12 | 16[, folded: Uint8Array(witnessSize - firstSlot)]])
+// installs the commitment key of this handle (tables on the device).  folded: include/b3wit.h "FOLDED keys" — the generators are
+// then the folded ones and folded[k] says what became of slot k (0 kept, 1 folded away, 0x80 | i only bit i of the word);
+// tools/fold_key.py writes both files for a circuit and a key.
 napi_value CommitKey(napi_env env, napi_callback_info info) {
-  size_t argc = 5; napi_value argv[5];
+  size_t argc = 6; napi_value argv[6];
   NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
   Handle *h = get_handle(env, argv[0]);
   if (!h) return nullptr;
@@ -499,8 +502,19 @@ napi_value CommitKey(napi_env env, napi_callback_info info) {
     NAPI_OK(napi_typeof(env, argv[4], &vt));
     if (vt == napi_number) NAPI_OK(napi_get_value_uint32(env, argv[4], &window));
   }
-  const int32_t rc = api.commit_key_create_ex(h->ctx, curve, first, (const uint8_t *)p, window, &h->key);
-  if (rc != B3W_OK) return throw_status(env, h, rc, "b3w_commit_key_create_ex failed");
+  const uint8_t *folded = nullptr;
+  if (argc > 5) {
+    napi_valuetype vt;
+    NAPI_OK(napi_typeof(env, argv[5], &vt));
+    if (vt == napi_object) {
+      napi_typedarray_type ft; napi_value fab; size_t foff, flen; void *fp;
+      NAPI_OK(napi_get_typedarray_info(env, argv[5], &ft, &flen, &fp, &fab, &foff));
+      if (ft != napi_uint8_array || flen != (size_t)(nwit - first)) { napi_throw_type_error(env, nullptr, "folded: Uint8Array with one byte per committed slot"); return nullptr; }
+      folded = (const uint8_t *)fp;
+    }
+  }
+  const int32_t rc = api.commit_key_create_folded(h->ctx, curve, first, (const uint8_t *)p, folded, window, &h->key);
+  if (rc != B3W_OK) return throw_status(env, h, rc, "b3w_commit_key_create_folded failed");
   napi_value u;
   napi_get_undefined(env, &u);
   return u;

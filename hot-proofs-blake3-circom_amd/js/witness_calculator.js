@@ -213,10 +213,13 @@ class WitnessCalculator {
   // ---- extension: commitment key for batch.commit().  curve: "bn254_g1" | "pallas" (the group over the --prime vesta circuit's scalar field); generators: Uint8Array with one
   // affine point per committed slot (x then y, 32-byte little-endian each), slots firstSlot .. witnessSize - 1;
   // windowBits: 12 | 16 (table size against speed, see include/b3wit.h), default automatic.
-  setCommitKey(curve, generators, firstSlot, windowBits) {
+  // folded (optional Uint8Array, one byte per committed slot): `generators` are FOLDED ones (include/b3wit.h "FOLDED keys": slots
+  // the circuit's constraints express through others are folded into those slots' generators — same points, fewer additions);
+  // tools/fold_key.py derives both arrays from a circuit and a key.
+  setCommitKey(curve, generators, firstSlot, windowBits, folded) {
     const id = {bn254_g1: 0, pallas: 1, vesta: 1}[curve];      // "vesta": older name of the Pallas curve id (after the circuit's prime)
     if (id === undefined) throw new Error("curve: bn254_g1 or pallas");
-    native().commitKey(this.instance, id, firstSlot || 0, generators, windowBits || 0);
+    native().commitKey(this.instance, id, firstSlot || 0, generators, windowBits || 0, folded || null);
   }
 
   // ---- extension: commitments of the witnesses of `records` (Uint32Array of whole input records, as for

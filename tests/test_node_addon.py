@@ -369,6 +369,10 @@ def test_js_batch_commit_matches_plain_integer_group_law(tmp_path):
     cases = [c for c in g["cases"] if "error" not in c and T.is_canonical_u32("compression", c["input"])][:2]
     gens = E.random_points("bn254_g1", T.NWIT["compression"] - 17, seed=b"js")
     (tmp_path / "gens.bin").write_bytes(E.points_to_bytes(gens))
+    import subprocess, sys
+    fk = subprocess.run([sys.executable, os.path.join(T.ROOT, "tools", "fold_key.py"), "compression", "bn254_g1", str(tmp_path / "gens.bin"),
+                         str(tmp_path / "folded"), "--first-slot", "17"], capture_output=True, text=True, cwd=T.ROOT, timeout=600)
+    assert fk.returncode == 0 and "'folded_slots': 7" in fk.stdout, (fk.stdout[-500:], fk.stderr[-1500:])
     r = _node("""
       const builder = require('./hot-proofs-blake3-circom_amd/js/witness_calculator.js');
       const fs = require('fs');
@@ -381,14 +385,21 @@ def test_js_batch_commit_matches_plain_integer_group_law(tmp_path):
         const b = await wc.calculateWitnessBatch(recs);
         const c = b.commit();
         const r = wc.commitRecords(recs);                       // the same points without the witnesses
+        // a FOLDED key (tools/fold_key.py wrote the folded generators and the mask): same points again
+        wc.setCommitKey('bn254_g1', new Uint8Array(fs.readFileSync(process.argv[3] + '.gens')), 17, 0, new Uint8Array(fs.readFileSync(process.argv[3] + '.mask')));
+        const b2 = await wc.calculateWitnessBatch(recs);
+        const f = b2.commit();
+        const fr = wc.commitRecords(recs);
         console.log(JSON.stringify({points: Buffer.from(c.points).toString('hex'), status: Array.from(c.status),
                                     rpoints: Buffer.from(r.points).toString('hex'), rstatus: Array.from(r.status),
+                                    fpoints: Buffer.from(f.points).toString('hex'), frpoints: Buffer.from(fr.points).toString('hex'),
                                     rpub: Array.from(r.publicOutputs), pub: Array.from(b.publicOutputs)}));
       })().catch(e => { console.error(e); process.exit(1); });
-    """, json.dumps(cases), str(tmp_path / "gens.bin"))
+    """, json.dumps(cases), str(tmp_path / "gens.bin"), str(tmp_path / "folded"))
     assert r.returncode == 0, r.stderr
     out = json.loads(r.stdout.strip().splitlines()[-1])
     assert out["status"] == [0, 0]
+    assert out["fpoints"] == out["points"] and out["frpoints"] == out["points"], "the folded key gives other points"
     assert out["rpoints"] == out["points"] and out["rstatus"] == [0, 0] and out["rpub"] == out["pub"] and len(out["pub"]) == 32
     W = T.workloads()
     recs = np.array([[int(x) for x in (c["input"]["h"] + c["input"]["m"] + c["input"]["t"] + [c["input"]["b"], c["input"]["d"]])] for c in cases], dtype=np.uint32)
