@@ -16,5 +16,6 @@ def test_gpus_n_spawns_n_ranks_and_propagates_failure():
                        capture_output=True, text=True, timeout=300, cwd=T.ROOT,
                        env={k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")})
     assert r.returncode != 0
-    assert r.stderr.count("needs a HIP device") == 3, r.stderr[-1500:]
+    # (the launcher ends the other ranks as soon as one has failed: one to three of them get to say why)
+    assert 1 <= r.stderr.count("needs a HIP device") <= 3, r.stderr[-1500:]
     assert r.stdout.strip() == ""
