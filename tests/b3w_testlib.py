@@ -111,3 +111,11 @@ def golden_image(name):
 
 def sha256(b):
     return hashlib.sha256(bytes(b)).hexdigest()
+
+
+def free_port():
+    """a TCP port nobody listens on right now (for 127.0.0.1 rendezvous in multi-process tests)"""
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as so:
+        so.bind(("127.0.0.1", 0))
+        return so.getsockname()[1]

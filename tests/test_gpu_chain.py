@@ -294,7 +294,7 @@ def test_two_ranks_shard_chunks_and_exchange_cvs():
     nbytes = 64 * 1024
     mgr = mp.Manager()
     ret = mgr.dict()
-    mp.spawn(_two_rank_worker, args=(2, 29700 + os.getpid() % 200, nbytes, ret), nprocs=2, join=True)
+    mp.spawn(_two_rank_worker, args=(2, T.free_port(), nbytes, ret), nprocs=2, join=True)
     data = np.random.default_rng(99).integers(0, 256, nbytes, dtype=np.uint8).tobytes()
     want = B.hash_words(data)
     assert ret[0]["root"] == want and ret[1]["root"] == want and ret[0]["ok"] and ret[1]["ok"]

@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 
 def test_public_exchange_over_rccl_single_rank():
     m = T.pkg()
-    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(32500 + os.getpid() % 2000), RANK="0", WORLD_SIZE="1")
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(T.free_port()), RANK="0", WORLD_SIZE="1")
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     dev = torch.device("cuda", 0)
     torch.cuda.set_device(0)

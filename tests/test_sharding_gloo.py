@@ -33,7 +33,7 @@ def test_two_rank_shard_and_gather(circuit, n_total):
     importlib.import_module("hot-proofs-blake3-circom_amd.sharding")
     mgr = mp.Manager()
     ret = mgr.dict()
-    port = 29500 + (os.getpid() % 2000)
+    port = T.free_port()
     mp.spawn(_worker, args=(2, port, n_total, circuit, ret), nprocs=2, join=True)
     W = T.workloads()
     recs = W.config3_nova(n_total) if circuit != "compression" else W.config2_compression(n_total)
@@ -77,7 +77,7 @@ def test_pipelined_public_exchange_two_ranks():
     outputs of THAT step in rank order, and finish() returns the last step's."""
     mgr = mp.Manager()
     ret = mgr.dict()
-    port = 31500 + (os.getpid() % 2000)
+    port = T.free_port()
     mp.spawn(_exchange_worker, args=(2, port, ret), nprocs=2, join=True)
     n, words, steps = 5, 16, 7
     base = np.arange(n * words, dtype=np.int32).reshape(n, words)
