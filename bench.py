@@ -29,34 +29,95 @@ FIELD = {"compression": "BN254", "nova_bn254": "BN254", "nova_vesta": "Vesta", "
 REFERENCE_WASM = {"compression": 5.0, "nova_vesta": 4.7, "nova_bn254": 5.3}
 
 
-def self_launch(n, argv):
+def self_launch(n, argv, launch_timeout):
     """`python bench.py --gpus N` without a launcher: N fresh child processes, one rank per GPU, started BEFORE this
     process has touched HIP (it never does: the parent only waits).  Rank 0's child prints the JSON line; the parent
-    exits with the first non-zero child status, after ending the other children (they would wait in a collective)."""
-    import socket, subprocess
+    exits with the first non-zero child status, after ending the other children (they would wait in a collective).
+    Watchdog: every rank reports "torch imported" and "rendezvous passed" through files in a scratch directory; when a rank
+    has not passed rendezvous `launch_timeout` seconds after the first one finished importing torch (a rank stuck in
+    ncclCommInitRank, a peer that never came up), all children are ended and the exit status is 124.  The children run in
+    their own sessions: the parent forwards SIGTERM / SIGINT to them and leaves no rank behind, whatever ends it."""
+    import shutil, signal, socket, subprocess, tempfile
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
+    stage = tempfile.mkdtemp(prefix="b3w_bench_")
     procs = []
-    for r in range(n):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
-                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
-        env.setdefault("OMP_NUM_THREADS", "1")
-        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *argv], env=env))
+
+    def end_all(sig):
+        for q in procs:
+            if q.poll() is None:
+                try:
+                    os.killpg(q.pid, sig)                   # exactly the sessions started below (start_new_session)
+                except (ProcessLookupError, PermissionError):
+                    pass
+
+    def on_signal(signum, frame):
+        end_all(signal.SIGTERM)
+        raise SystemExit(128 + signum)
+    old = {sg: signal.signal(sg, on_signal) for sg in (signal.SIGTERM, signal.SIGINT)}
     rc = 0
-    live = list(procs)
-    while live:
-        time.sleep(0.1)
-        for p in list(live):
-            st = p.poll()
-            if st is None:
-                continue
-            live.remove(p)
-            if st != 0 and rc == 0:
-                rc = st if st > 0 else 128 - st
-                for q in live:                      # exactly the children started above
-                    q.terminate()
-    return rc
+    try:
+        for r in range(n):
+            env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                       MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), B3W_BENCH_STAGE_DIR=stage)
+            env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # this pool's host driver only does dmabuf IPC (DESIGN.md 8e)
+            env.setdefault("OMP_NUM_THREADS", "1")
+            procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *argv], env=env, start_new_session=True))
+        live = list(procs)
+        t_start, t_first_import, t_fail = time.monotonic(), None, None
+        while live:
+            time.sleep(0.1)
+            if rc != 0:
+                t_fail = t_fail or time.monotonic()
+                if time.monotonic() - t_fail > 5.0:          # ranks that do not react to SIGTERM: the `finally` below kills them
+                    break
+            for p in list(live):
+                st = p.poll()
+                if st is None:
+                    continue
+                live.remove(p)
+                if st != 0 and rc == 0:
+                    rc = st if st > 0 else 128 - st
+                    end_all(signal.SIGTERM)
+            if rc == 0 and live and launch_timeout > 0:
+                names = os.listdir(stage)
+                if t_first_import is None and any(x.startswith("imported.") for x in names):
+                    t_first_import = time.monotonic()
+                ready = sum(1 for x in names if x.startswith("ready."))
+                now = time.monotonic()
+                late = (t_first_import is not None and now - t_first_import > launch_timeout) or now - t_start > launch_timeout + 300
+                if ready < n and late:
+                    missing = sorted(set(range(n)) - {int(x.split(".")[1]) for x in names if x.startswith("ready.")})
+                    print(f"bench.py: ranks {missing} have not passed rendezvous after {launch_timeout:g} s "
+                          f"(--launch-timeout); ending all {n} ranks", file=sys.stderr, flush=True)
+                    rc = 124
+                    end_all(signal.SIGTERM)
+        return rc
+    finally:
+        t_kill = time.monotonic() + 5.0                      # a rank that ignores SIGTERM (stuck in a driver call) is killed
+        while any(q.poll() is None for q in procs) and time.monotonic() < t_kill:
+            end_all(signal.SIGTERM)
+            time.sleep(0.2)
+        end_all(signal.SIGKILL)
+        for q in procs:
+            try:
+                q.wait(timeout=5)
+            except Exception:
+                pass
+        for sg, h in old.items():
+            signal.signal(sg, h)
+        shutil.rmtree(stage, ignore_errors=True)
+
+
+def stage_mark(name, rank):
+    """tell the launching parent (self_launch) how far this rank has come"""
+    d = os.environ.get("B3W_BENCH_STAGE_DIR")
+    if d:
+        try:
+            open(os.path.join(d, f"{name}.{rank}"), "w").close()
+        except OSError:
+            pass
 
 
 def cpu_model():
@@ -110,8 +171,8 @@ def cpu_baseline(circuit, recs, budget_s):
     total = sum(done)
     out = {"value": total / dt, "unit": "witnesses/s", "cores": cores, "kind": "port", "cpu": cpu_model(),
            "per_core": total / dt / cores, "cpu_quota": quota,
-           "sample": f"{total} witnesses ({cores} threads, each looping over the first {k} records of the workload) in "
-                     f"{dt:.1f} s, C oracle (oracle/b3w_oracle.c)"}
+           "sample": f"{total} witnesses in {dt:.1f} s: {cores} threads, each a cache-resident {k}-record loop (the first {k} records "
+                     f"of the workload, rewriting one 12 MB block of bodies in place), C oracle (oracle/b3w_oracle.c)"}
     if circuit in REFERENCE_WASM:
         out["reference_wasm"] = {"value": REFERENCE_WASM[circuit], "unit": "witnesses/s/core", "measured_here": False,
                                  "where": "build container (Xeon 2.1 GHz, node 12), BASELINE.md section 2: the reference's "
@@ -162,8 +223,9 @@ def bench_chain(args, m, torch, dist, dev, world, rank, local_rank):
                               torch.cuda.current_stream().cuda_stream)
         if args.consumer == "commit-only":
             consumer, commit_only = None, (key, d_pts)
+    # the fold's exchange (N > 1) is part of every pass: chunk chaining values, then every step's h_out (BASELINE config 4)
     run = lambda: m.chain.fold_witnesses(ctx, host, batch_steps=args.batch if args.batch != 4096 else 16384, ring=2, consumer=consumer,
-                                         commit_only=commit_only)
+                                         commit_only=commit_only, gather_hout=args.exchange != "none")
     for _ in range(max(3, args.warmup)):        # the first passes pay the allocator (24 GB ring, record buffers)
         out = run()
     torch.cuda.synchronize()
@@ -174,12 +236,25 @@ def bench_chain(args, m, torch, dist, dev, world, rank, local_rank):
     for _ in range(args.steps):
         out = run()
     torch.cuda.synchronize()
+    local_elapsed = time.perf_counter() - t0                # this rank's own passes, before it waits for the others
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     assert int(out["status"].abs().sum().item()) == 0
     local_steps = out["n_leaf_steps"] + out["n_parent_steps"]
+    n_leaf_all = m.lib().b3w_chain_num_leaf_steps(nbytes)
+    if args.exchange != "none" or world == 1:
+        # the gathered h_out, on every rank: the last leaf step of chunk c carries chunk c's chaining value — checked for this
+        # rank's own chunks against the planner's CVs, and the array has every rank's rows
+        h_all = out["h_out_all"]
+        assert h_all.shape == (n_leaf_all, 8)
+        c0, ncl = out["first_chunk"], out["n_chunks_local"]
+        full = ncl - (1 if (c0 + ncl == out["n_chunks"] and nbytes % 1024) else 0)
+        if full > 0:
+            assert torch.equal(h_all[c0 * 16 + 15:(c0 + full) * 16:16], out["chunk_cvs_local"][:full]), "gathered h_out of step 16c+15 is not chunk c's chaining value"
+        if world > 1:
+            assert int((h_all.abs().sum(dim=1) == 0).sum().item()) == 0, "rows of another rank are missing from the gathered h_out"
     # untimed: one more pass over the first MiB (at most) of the preimage whose consumer checks EVERY step witness against the
     # step circuit's rank-1 constraints while it sits in the ring
     verification = "none"
@@ -212,6 +287,7 @@ def bench_chain(args, m, torch, dist, dev, world, rank, local_rank):
     else:
         total_steps = float(local_steps)
     placements = gather_strings(dist, world, out.get("placement"))
+    pass_ms = [float(x) for x in gather_strings(dist, world, repr(local_elapsed / args.steps * 1e3))]
     if rank == 0:
         per = BYTES_PER_WITNESS[circuit] if commit_only is None else 128      # commit-only reads the 128-byte step records
         print(json.dumps({
@@ -223,8 +299,13 @@ def bench_chain(args, m, torch, dist, dev, world, rank, local_rank):
                                    "planner + witness kernels, bodies through a 2-deep ring, H2D overlapped",
                        "circuit": circuit, "n_chunks": out["n_chunks"], "path_len": out["path_len"],
                        "placement": placements[0], "placement_per_rank": placements, "verification": verification,
-                       "exchange": f"all_gather of chunk chaining values over {dist.get_world_size()} ranks "
-                                   f"({dist.get_backend()})" if world > 1 else "none",
+                       "exchange": "none" if world == 1 else
+                                   (f"all_gather of {n_leaf_all} x 8 u32 h_out (+ {int(total_steps) - n_leaf_all} x 8 of the parent steps) + "
+                                    if args.exchange != "none" else "--exchange none: ") +
+                                   f"all_gather of {out['n_chunks']} x 8 u32 chunk chaining values over {dist.get_world_size()} ranks "
+                                   f"({dist.get_backend()}), inside every timed pass",
+                       "exchange_mode": ("every" if args.exchange != "none" else "none") if world > 1 else "none",
+                       "pass_ms_per_rank": pass_ms,
                        "consumer": " then ".join(
                            ([f"rank-1 constraint check of every step witness on the device ({r1cs_t.n_constraints} constraints)"] if r1cs_t is not None else []) +
                            ([f"Pedersen commitment of every step witness on the device ({key.window}-bit windows, {key.folded_slots} slots folded)"
@@ -243,7 +324,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--inner", type=int, default=0,
-                    help="batch workload: launches per timed step (0 = as many as make the timed region last >= 1 s)")
+                    help="batch workload: launches per timed step (0 = as many as make the timed region last >= 5 s)")
     ap.add_argument("--batch", type=int, default=4096, help="witnesses per GPU per launch")
     ap.add_argument("--circuit", default="compression")
     ap.add_argument("--variant", type=int, default=None, help="kernel tuning variant (B3W_VARIANT)")
@@ -260,20 +341,41 @@ def main():
                          "(commit = Pedersen commitments on the circuit's curve, synthetic generators; commit-only = the same "
                          "commitments straight from the step records, no bodies written; check = the step circuit's rank-1 "
                          "constraints over every step witness; check+commit = both, in that order)")
+    ap.add_argument("--exchange", default="every", choices=["every", "last", "none"],
+                    help="N > 1: the fold's exchange inside the timed region.  batch workload: all-gather of the public outputs "
+                         "after EVERY launch (default; pipelined with the next launch), after the LAST launch only, or not at all — "
+                         "the three together split a scaling number into kernel and RCCL contention.  chain workload: every / last "
+                         "= gather every step's h_out inside each pass, none = chunk chaining values only")
+    ap.add_argument("--launch-timeout", type=float, default=120.0,
+                    help="N > 1: seconds every rank has to pass rendezvous (process group + first barrier), counted from the moment "
+                         "the first rank has imported torch; also the process group's own timeout.  0 = no watchdog")
+    ap.add_argument("--timed-ms", type=float, default=5000.0,
+                    help="batch workload with --inner 0: how long the K timed steps should last together (the driver's busy "
+                         "sampler needs seconds, not a 9 ms burst)")
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
-        sys.exit(self_launch(args.gpus, sys.argv[1:]))      # nothing above has loaded torch or HIP
+        sys.exit(self_launch(args.gpus, sys.argv[1:], args.launch_timeout))      # nothing above has loaded torch or HIP
 
+    rank = int(os.environ.get("RANK", "0"))
+    hang = os.environ.get("B3W_BENCH_TEST_HANG_RANK")       # tests only: this rank never reaches the rendezvous
+    if hang is not None and str(rank) in hang.split(",") and os.environ.get("B3W_BENCH_TEST_HANG_AT", "start") == "start":
+        time.sleep(3600)
+
+    import datetime
     import numpy as np
     import torch
     import torch.distributed as dist
+    stage_mark("imported", rank)
+    if hang is not None and str(rank) in hang.split(",") and os.environ.get("B3W_BENCH_TEST_HANG_AT") == "imported":
+        time.sleep(3600)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        # this pool's host driver only supports dmabuf IPC: with the legacy mode RCCL's (and torch's) cross-process buffer
+        # sharing fails in hipIpcGetMemHandle.  Left alone when the environment already sets it.
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     if args.gpus != world and rank == 0:
         print(f"bench.py: --gpus {args.gpus} but the launcher started {world} ranks; using {world}", file=sys.stderr)
@@ -288,11 +390,23 @@ def main():
         local_rank = local_rank % ndev                      # dry run: several ranks share one GPU
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    devices = [f"cuda:{local_rank}"]
     if world > 1:
+        if hang is not None and str(rank) in hang.split(",") and os.environ.get("B3W_BENCH_TEST_HANG_AT") == "rendezvous":   # tests only: hung with the GPU initialised
+            time.sleep(3600)
+        pg_timeout = datetime.timedelta(seconds=args.launch_timeout if args.launch_timeout > 0 else 1800)
         if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=pg_timeout)
         else:
-            dist.init_process_group(backend, rank=rank, world_size=world)
+            dist.init_process_group(backend, rank=rank, world_size=world, timeout=pg_timeout)
+        # one rank per GPU: every rank's card must be a different one (uuid where torch reports it, else the PCI address)
+        pr = torch.cuda.get_device_properties(dev)
+        ident = f"{getattr(pr, 'uuid', '')}@pci{getattr(pr, 'pci_domain_id', 0):04x}:{getattr(pr, 'pci_bus_id', 0):02x}:{getattr(pr, 'pci_device_id', 0):02x}"
+        devices = gather_strings(dist, world, f"cuda:{local_rank}={ident}")
+        if backend == "nccl" and len(set(d.split("=", 1)[1] for d in devices)) != world:
+            raise SystemExit(f"bench.py: ranks share a GPU under RCCL: {devices}")
+        dist.barrier()
+    stage_mark("ready", rank)
 
     if args.variant is not None:
         os.environ["B3W_VARIANT"] = str(args.variant)
@@ -318,11 +432,12 @@ def main():
     # of launch i overlaps the kernel of launch i+1 on RCCL's own stream (sharding.PublicExchange)
     ex = sharding.PublicExchange(n, npub, dev)
 
-    def launch():
+    def launch(post=None):
         pub = ex.next_buffer()
         ctx.run_device(d_recs.data_ptr(), n, d_bodies.data_ptr(), pitch, pub.data_ptr(), d_status.data_ptr(),
                        stream.cuda_stream)
-        ex.post()
+        if post if post is not None else args.exchange == "every":
+            ex.post()
 
     # Untimed set-up.  The body buffer comes from the library's placement allocator (b3w_bodies_alloc: its 256 MiB
     # pieces alternate between two classes of HBM, DESIGN.md "Placement"), then the faster of the bit-identical
@@ -342,6 +457,7 @@ def main():
         if bodies.placement == "mixed" or os.environ.get("B3W_PLACEMENT") == "plain":
             break
         bodies.free()
+        ctx.trim()                                          # (ring buffers a context keeps from destroyed chains: none here, but say so)
         m.lib().b3w_bodies_trim()                           # hand the pooled pieces back: the next search starts afresh
         time.sleep(1.0 + attempt)
         os.environ["B3W_PLACE_DEBUG"] = "1"                 # say on stderr what the search found
@@ -354,7 +470,7 @@ def main():
         chosen = args.variant
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     for _ in range(2):
-        launch()
+        launch(post=args.exchange != "none")                # (the communicator's first collective — connection set-up — stays untimed)
     ev0.record(stream)
     for _ in range(4):
         launch()
@@ -364,7 +480,7 @@ def main():
     est = torch.tensor([ev0.elapsed_time(ev1) / 4], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(est, op=dist.ReduceOp.MAX)          # every rank must settle on the same launch count
-    inner = args.inner if args.inner > 0 else max(1, min(4096, math.ceil(1000.0 / (args.steps * max(est.item(), 1e-3)))))
+    inner = args.inner if args.inner > 0 else max(1, min(8192, math.ceil(args.timed_ms / (args.steps * max(est.item(), 1e-3)))))
     for _ in range(args.warmup):
         for _ in range(inner):
             launch()
@@ -377,10 +493,10 @@ def main():
     t0 = time.perf_counter()
     ev0.record(stream)
     for i in range(args.steps):
-        for _ in range(inner):
-            launch()
+        for j in range(inner):
+            launch(post=True if args.exchange == "last" and i == args.steps - 1 and j == inner - 1 else None)
     ev1.record(stream)
-    allpub = ex.finish()                                    # every launch's exchange is inside the timed region
+    allpub = ex.finish()                                    # every exchange posted above is inside the timed region
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -389,8 +505,9 @@ def main():
     launches = args.steps * inner
     kern_ms = ev0.elapsed_time(ev1) / launches                        # HIP events on the launch stream
     assert int(d_status.abs().sum().item()) == 0, "a witness reported a non-zero status"
-    if world > 1:                                           # the gathered buffer of the last launch: every rank's outputs
+    if world > 1 and args.exchange != "none":               # the gathered buffer of the last launch: every rank's outputs
         assert allpub.shape == (world * n, npub) and int((allpub[:, :npub].abs().sum(dim=1) == 0).sum().item()) == 0
+        assert torch.equal(allpub[rank * n:(rank + 1) * n], ex.bufs[ex.last]), "this rank's share of the gathered outputs differs from what it sent"
     # untimed: every body of the last launch is checked on the device: the rank-1 constraint check
     # Az*Bz = Cz with the constraint system derived from the circuit text where there is one (blake3_compression), and the
     # recompute-and-compare tamper check
@@ -411,6 +528,7 @@ def main():
     t = torch.tensor([elapsed, kern_ms], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    kern_per_rank = [float(x) for x in gather_strings(dist, world, repr(kern_ms))]     # every rank's own HIP-event average
     elapsed, kern_ms = t[0].item(), t[1].item()
     placements = gather_strings(dist, world, bodies.placement)
 
@@ -453,11 +571,18 @@ def main():
                        "kernel_variant": "sweep (TRACE + SWEEP kernels)" if chosen >= 100 else f"fused ({chosen})",
                        "verified_on_device": True, "verification": verified,
                        "placement": placements[0], "placement_per_rank": placements,
-                       "exchange": f"all_gather of public outputs over {dist.get_world_size()} ranks ({dist.get_backend()}), "
-                                   "pipelined with the next launch's kernel" if world > 1 else "none"},
+                       "exchange": "none" if world == 1 else
+                                   f"--exchange {args.exchange}: " + {
+                                       "every": f"all_gather of the {n} x {npub} u32 public outputs over {dist.get_world_size()} ranks "
+                                                f"({dist.get_backend()}) after every launch, pipelined with the next launch's kernel",
+                                       "last": f"all_gather of the {n} x {npub} u32 public outputs over {dist.get_world_size()} ranks "
+                                               f"({dist.get_backend()}) after the last timed launch only",
+                                       "none": f"no collective inside the timed region ({dist.get_world_size()} ranks, {dist.get_backend()}): kernels only"}[args.exchange],
+                       "exchange_mode": args.exchange if world > 1 else "none", "devices_per_rank": devices},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
-                         "kernel_ms": kern_ms, "algorithmic_bytes_per_launch": alg_bytes, "launches_timed": launches},
+                         "kernel_ms": kern_ms, "kernel_ms_per_rank": kern_per_rank, "kernel_ms_min": min(kern_per_rank),
+                         "kernel_ms_max": max(kern_per_rank), "algorithmic_bytes_per_launch": alg_bytes, "launches_timed": launches},
         }
         if args.cpu_seconds > 0 and world == 1:
             out["cpu_baseline"] = cpu_baseline(circuit, recs, args.cpu_seconds)

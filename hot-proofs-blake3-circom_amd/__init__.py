@@ -99,6 +99,7 @@ def lib():
         "b3w_bodies_alloc": (i32, [vp, u64, ctypes.POINTER(vp), ctypes.POINTER(i32)]),
         "b3w_bodies_free": (i32, [vp, vp]),
         "b3w_bodies_trim": (None, []),
+        "b3w_ctx_trim": (i32, [vp]),
         "b3w_bodies_configure": (None, [ctypes.c_int64, ctypes.c_int64]),
         "b3w_bodies_stats": (i32, [vp, vp]),
         "b3w_batch_placement": (i32, [vp]),
@@ -137,6 +138,7 @@ def lib():
         "b3w_chain_run_parents": (i32, [vp, vp, vp, vp, vp]),
         "b3w_chain_shard": (None, [u64, i32, i32, ctypes.POINTER(u64), ctypes.POINTER(u32)]),
         "b3w_chain_run_parents_sharded": (i32, [vp, vp, vp, vp, vp]),
+        "b3w_chain_allgather_hout": (i32, [vp, vp, vp, vp, vp]),
         "b3w_chain_info": (i32, [vp, ctypes.POINTER(u64), ctypes.POINTER(u64), ctypes.POINTER(u64), ctypes.POINTER(u32), ctypes.POINTER(i32)]),
         "b3w_chain_outputs": (i32, [vp, vp, vp, vp, vp]),
         "b3w_chain_records": (vp, [vp]),
@@ -157,12 +159,12 @@ EXPORTED_SYMBOLS = ("b3w_abi_version", "b3w_identify_wasm", "b3w_create", "b3w_d
                     "b3w_batch_run_device", "b3w_public_words", "b3w_batch_alloc", "b3w_batch_free",
                     "b3w_batch_run", "b3w_batch_outputs", "b3w_batch_fetch", "b3w_batch_device_ptr",
                     "b3w_batch_time_device", "b3w_batch_verify_device", "b3w_batch_verify",
-                    "b3w_r1cs_create", "b3w_r1cs_info", "b3w_r1cs_is_tiled", "b3w_r1cs_destroy", "b3w_r1cs_check_device", "b3w_batch_r1cs_check", "b3w_r1cs_consumer", "b3w_batch_write_wtns", "b3w_batch_autotune_device", "b3w_bodies_alloc", "b3w_bodies_free", "b3w_bodies_trim", "b3w_bodies_configure", "b3w_bodies_stats", "b3w_batch_placement", "b3w_chain_num_chunks", "b3w_chain_num_leaf_steps", "b3w_chain_path_len",
+                    "b3w_r1cs_create", "b3w_r1cs_info", "b3w_r1cs_is_tiled", "b3w_r1cs_destroy", "b3w_r1cs_check_device", "b3w_batch_r1cs_check", "b3w_r1cs_consumer", "b3w_batch_write_wtns", "b3w_batch_autotune_device", "b3w_bodies_alloc", "b3w_bodies_free", "b3w_bodies_trim", "b3w_ctx_trim", "b3w_bodies_configure", "b3w_bodies_stats", "b3w_batch_placement", "b3w_chain_num_chunks", "b3w_chain_num_leaf_steps", "b3w_chain_path_len",
                     "b3w_chain_num_parent_steps", "b3w_chain_parent_row", "b3w_chain_path_provable",
                     "b3w_chain_plan_leaves_device", "b3w_chain_tree_device", "b3w_chain_plan_parents_device",
                     "b3w_commit_key_create", "b3w_commit_key_create_ex", "b3w_commit_key_create_folded", "b3w_slot_widths", "b3w_commit_key_window", "b3w_commit_key_destroy", "b3w_commit_records_device", "b3w_commit_records", "b3w_chain_commit_only", "b3w_chain_commitments", "b3w_chain_check_constraints", "b3w_chain_violations", "b3w_batch_commit_device", "b3w_batch_commit", "b3w_commit_consumer",
                     "b3w_comm_unique_id", "b3w_comm_create", "b3w_comm_destroy", "b3w_comm_allgather", "b3w_batch_allgather_public",
-                    "b3w_chain_create", "b3w_chain_destroy", "b3w_chain_run_leaves", "b3w_chain_run_parents", "b3w_chain_shard", "b3w_chain_run_parents_sharded", "b3w_chain_info",
+                    "b3w_chain_create", "b3w_chain_destroy", "b3w_chain_run_leaves", "b3w_chain_run_parents", "b3w_chain_shard", "b3w_chain_run_parents_sharded", "b3w_chain_allgather_hout", "b3w_chain_info",
                     "b3w_chain_outputs", "b3w_chain_records", "b3w_chain_public", "b3w_chain_status", "b3w_chain_local_cvs", "b3w_chain_root")
 
 
@@ -277,6 +279,13 @@ class Context:
         """Device buffer for bodies, placed over two classes of HBM when possible (b3w_bodies_alloc)."""
         return BodyBuffer(self, nbytes)
 
+    def trim(self):
+        """Release what this context holds beyond its tables: chain.fold_witnesses' cached chain objects and the ring buffers
+        kept from destroyed chains (b3w_ctx_trim).  Follow with lib().b3w_bodies_trim() to hand the memory to the driver."""
+        for h in self.__dict__.pop("_chain_cache", {}).values():
+            self._lib.b3w_chain_destroy(h)
+        self._lib.b3w_ctx_trim(self.handle)
+
     def bodies_stats(self):
         """Placement allocator of this context's device (b3w_bodies_stats): arena / used-up address space, pooled and live bytes."""
         out = (ctypes.c_uint64 * 6)()
@@ -327,6 +336,38 @@ class BodyBuffer:
             self.free()
         except Exception:
             pass
+
+
+class Comm:
+    """A native RCCL communicator of the C-ABI (b3w_comm_*: one process per GPU, librccl loaded at run time) — for hosts
+    without torch.distributed, and for chain.fold_witnesses(comm=...).  Rank 0 makes the id (Comm.unique_id()) and hands its
+    128 bytes to the other ranks."""
+
+    @staticmethod
+    def unique_id():
+        uid = (ctypes.c_uint8 * 128)()
+        rc = lib().b3w_comm_unique_id(uid)
+        if rc != B3W_OK:
+            raise B3WError(rc, f"b3w_comm_unique_id: status {rc}")
+        return bytes(uid)
+
+    def __init__(self, ctx, uid, rank, nranks):
+        self.ctx, self.rank, self.nranks = ctx, int(rank), int(nranks)
+        h = ctypes.c_void_p()
+        rc = lib().b3w_comm_create(ctx.handle, (ctypes.c_uint8 * 128).from_buffer_copy(uid), self.rank, self.nranks, ctypes.byref(h))
+        if rc != B3W_OK:
+            raise B3WError(rc, f"b3w_comm_create: status {rc}: {ctx.last_error()}")
+        self.handle = h
+
+    def allgather(self, d_send, d_recv, bytes_per_rank, stream=0):
+        rc = lib().b3w_comm_allgather(self.handle, d_send, d_recv, bytes_per_rank, stream or None)
+        if rc != B3W_OK:
+            raise B3WError(rc, f"b3w_comm_allgather: status {rc}: {self.ctx.last_error()}")
+
+    def close(self):
+        if getattr(self, "handle", None):
+            lib().b3w_comm_destroy(self.handle)
+            self.handle = None
 
 
 R1CS_DIR = os.path.join(PKG_DIR, "constraints")

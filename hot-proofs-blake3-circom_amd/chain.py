@@ -11,9 +11,13 @@ Pipeline per GPU (one process per GPU; ranks take contiguous chunk ranges, SURVE
   compute stream : plan leaf steps of the slice -> nova witness kernel over batches of steps, bodies
                    written into a RING of batch buffers (a 1 GiB preimage is 27 TB of witness: bodies
                    are handed to a consumer per batch and then overwritten)
-  exchange       : all-gather of chunk chaining values (32 B per chunk) so that every rank can build
-                   the upper tree levels redundantly; the per-step public outputs stay per rank
-                   unless the caller gathers them (sharding.gather_public)
+  exchange       : (1) all-gather of chunk chaining values (32 B per chunk) so that every rank can build
+                   the upper tree levels redundantly; (2) all-gather of every step's h_out (8 u32 per
+                   step: 16 384 x 8 for the 1 MiB preimage of BASELINE config 4) — the running chaining
+                   value the fold consumes as z_{i+1} (Blake3CompressPubIO::to_vec,
+                   rust_fold/src/blake3_circuit.rs:111-123; fed back at rust_fold/src/main.rs:166-179) —
+                   into global step order on every rank.  RCCL over xGMI through torch.distributed
+                   ("nccl"), or natively through a b3w_comm (b3w_chain_allgather_hout, include/b3wit.h)
 """
 import ctypes
 
@@ -22,7 +26,7 @@ import torch
 import torch.distributed as dist
 
 from . import B3W_OK, B3WError, lib
-from .sharding import shard_range
+from .sharding import gather_rows, shard_range
 
 
 def _chk(ctx, rc, what):
@@ -46,22 +50,60 @@ _CONSUMER = ctypes.CFUNCTYPE(None, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_ui
                              ctypes.c_void_p)
 
 
+def step_shards(preimage_len, world, with_parents=True):
+    """Per rank: (first chunk, chunks, leaf steps, first parent row, parent steps) of the contiguous chunk shards — the geometry
+    of the h_out exchange (rank order = global step order)."""
+    L = lib()
+    n = L.b3w_chain_num_chunks(preimage_len)
+    last_bytes = preimage_len - (n - 1) * 1024 if preimage_len > (n - 1) * 1024 else 0
+    last_blocks = -(-last_bytes // 64) if last_bytes else 1
+    out = []
+    for r in range(world):
+        f, e = shard_range(n, r, world)
+        k = e - f
+        leaf = k * 16 - ((16 - last_blocks) if (k and e == n) else 0)
+        p0 = L.b3w_chain_parent_row(f, n) if with_parents else 0
+        p1 = L.b3w_chain_parent_row(e, n) if with_parents else 0
+        out.append((f, k, leaf, p0, p1 - p0))
+    return out
+
+
+def gather_h_out(public_local, n_leaf_local, preimage_len, with_parents=True, group=None):
+    """The fold's exchange: all-gather of h_out (public words 2..9) of every step of a sharded pass.  public_local: this rank's
+    [n_leaf_local + n_parent_local, 15] public outputs (leaf steps first).  Returns (leaf [n_leaf_total, 8], parents
+    [n_parent_total, 8]) in global step order — (chunk, block) and (chunk, height) — on every rank."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    h = public_local[:, 2:10]
+    if world == 1:
+        return h[:n_leaf_local], h[n_leaf_local:]
+    sh = step_shards(preimage_len, world, with_parents)
+    leaf = gather_rows(h[:n_leaf_local].contiguous(), [x[2] for x in sh], group)
+    par = gather_rows(h[n_leaf_local:].contiguous(), [x[4] for x in sh], group)
+    return leaf, par
+
+
 def fold_witnesses(ctx, preimage, batch_steps=16384, ring=2, slice_chunks=1024, with_parents=True, consumer=None,
-                   device=None, commit_only=None):
+                   device=None, commit_only=None, gather_hout=True, comm=None):
     """preimage: 1-D uint8 numpy array / torch CPU tensor (the whole preimage; every rank passes the same).
     consumer(bodies_view [k, body_bytes] uint8 CUDA, first_local_step, k): called after each batch is enqueued;
     it must enqueue its work on the current stream (the view is overwritten `ring` batches later).
     commit_only=(CommitKey, d_points): no bodies at all — one commitment per step, computed from the step records
     (b3w_chain_commit_only), into the caller's [n_steps, 64] uint8 CUDA tensor.
+    gather_hout: all-gather every step's h_out across the ranks inside the pass (the fold's exchange, module docstring);
+    comm: a native b3w_comm handle (b3w_comm_create) — the two exchanges then go through the library's own RCCL calls
+    (b3w_chain_run_parents_sharded, b3w_chain_allgather_hout) instead of torch.distributed.
     Returns dict(public=[n_local_steps, 15] int32 CUDA, status=[n_local_steps] int32 CUDA, root=[8] int32,
-    n_leaf_steps, n_parent_steps, first_chunk, n_chunks_local, n_chunks).  The device arrays belong to a b3w_chain
-    object cached on `ctx` and are overwritten by the next fold of the same shape.
+    h_out_all=[n_leaf_steps of ALL ranks, 8] int32, h_out_parents_all=[n_parent_steps of all ranks, 8] (global step order;
+    None with gather_hout=False on several ranks), n_leaf_steps, n_parent_steps, first_chunk, n_chunks_local, n_chunks).
+    The device arrays belong to a b3w_chain object cached on `ctx` and are overwritten by the next fold of the same shape.
 
     The pass itself is the library's native driver (b3w_chain_run_leaves / b3w_chain_run_parents, include/b3wit.h);
-    this function adds the one thing that needs the process group: the all-gather of the chunk chaining values."""
+    this function adds what needs the process group: the all-gathers of the chunk chaining values and of h_out."""
     L = lib()
     world = dist.get_world_size() if dist.is_initialized() else 1
     rank = dist.get_rank() if dist.is_initialized() else 0
+    if comm is not None:
+        world, rank = comm.nranks, comm.rank
     dev = device or torch.device("cuda", torch.cuda.current_device())
     host = torch.from_numpy(preimage) if isinstance(preimage, np.ndarray) else preimage
     assert host.dtype == torch.uint8 and host.dim() == 1 and host.numel() > 0 and host.is_contiguous()
@@ -99,27 +141,33 @@ def fold_witnesses(ctx, preimage, batch_steps=16384, ring=2, slice_chunks=1024, 
         cb = _CONSUMER(_cb)
     _chk(ctx, L.b3w_chain_run_leaves(h, host.data_ptr(), cb, None, compute.cuda_stream), "b3w_chain_run_leaves")
 
-    # ---- exchange: chunk chaining values of all ranks (32 B per chunk)
-    all_cvs = None
-    if world > 1:
-        cvs_local = _view(L.b3w_chain_local_cvs(h), (max(nl, 1), 8), "<i4", dev)
-        sizes = [shard_range(n, r, world) for r in range(world)]
-        mx = max(e - s for s, e in sizes)
-        pad = torch.zeros((mx, 8), dtype=torch.int32, device=dev)
-        pad[:nl] = cvs_local[:nl]
-        if dist.get_backend() == "gloo":              # CPU rehearsal of the exchange (tests): stage through the host
-            allcv_h = torch.empty((world * mx, 8), dtype=torch.int32)
-            dist.all_gather_into_tensor(allcv_h, pad.cpu())
-            allcv = allcv_h.to(dev)
-        else:                                         # RCCL over xGMI
-            allcv = torch.empty((world * mx, 8), dtype=torch.int32, device=dev)
-            dist.all_gather_into_tensor(allcv, pad)
-        all_cvs = torch.cat([allcv[r * mx: r * mx + (e - s)] for r, (s, e) in enumerate(sizes)], dim=0).contiguous()
-    _chk(ctx, L.b3w_chain_run_parents(h, all_cvs.data_ptr() if all_cvs is not None else None, cb, None, compute.cuda_stream),
-         "b3w_chain_run_parents")
-
     rows = n_leaf + n_par
-    return dict(public=_view(L.b3w_chain_public(h), (rows, 15), "<i4", dev), status=_view(L.b3w_chain_status(h), (rows,), "<i4", dev),
+    public = _view(L.b3w_chain_public(h), (rows, 15), "<i4", dev)
+    h_leaf, h_par = None, None
+    if comm is not None:
+        # ---- both exchanges natively (RCCL through the C-ABI)
+        _chk(ctx, L.b3w_chain_run_parents_sharded(h, comm.handle, cb, None, compute.cuda_stream), "b3w_chain_run_parents_sharded")
+        if gather_hout:
+            sh = step_shards(ln, world, with_parents)
+            h_leaf = torch.empty((sum(x[2] for x in sh), 8), dtype=torch.int32, device=dev)
+            h_par = torch.empty((sum(x[4] for x in sh), 8), dtype=torch.int32, device=dev)
+            with torch.cuda.stream(compute):
+                _chk(ctx, L.b3w_chain_allgather_hout(h, comm.handle, h_leaf.data_ptr(), h_par.data_ptr() if h_par.numel() else None,
+                                                     compute.cuda_stream), "b3w_chain_allgather_hout")
+    else:
+        # ---- exchange 1: chunk chaining values of all ranks (32 B per chunk)
+        all_cvs = None
+        if world > 1:
+            cvs_local = _view(L.b3w_chain_local_cvs(h), (max(nl, 1), 8), "<i4", dev)
+            all_cvs = gather_rows(cvs_local[:nl], [e - s for s, e in (shard_range(n, r, world) for r in range(world))]).contiguous()
+        _chk(ctx, L.b3w_chain_run_parents(h, all_cvs.data_ptr() if all_cvs is not None else None, cb, None, compute.cuda_stream),
+             "b3w_chain_run_parents")
+        # ---- exchange 2: h_out of every step (8 u32 per step), global step order on every rank
+        if gather_hout or world == 1:
+            h_leaf, h_par = gather_h_out(public, n_leaf, ln, with_parents)
+
+    return dict(public=public, h_out_all=h_leaf, h_out_parents_all=h_par, chunk_cvs_local=_view(L.b3w_chain_local_cvs(h), (max(nl, 1), 8), "<i4", dev)[:nl],
+                status=_view(L.b3w_chain_status(h), (rows,), "<i4", dev),
                 records=_view(L.b3w_chain_records(h), (rows, 32), "<i4", dev), root=_view(L.b3w_chain_root(h), (8,), "<i4", dev),
                 n_leaf_steps=n_leaf, n_parent_steps=n_par, first_chunk=c0, n_chunks_local=nl, n_chunks=n, path_len=P.value,
                 batches=-(-n_leaf // batch_steps) + -(-n_par // batch_steps) if consumer is None else nbatch[0],

@@ -310,7 +310,8 @@ struct b3w_ctx {
   int32_t *d_status1 = nullptr;
   float plain_ms_per_gb = 0;          // the witness kernel on a plain hipMalloc buffer, measured once (b3w_bodies_alloc's sanity check)
   struct Spare { void *ptr; uint64_t bytes; int32_t placement; };
-  std::vector<Spare> ring_spares;     // ring buffers of destroyed chains, reused by the next b3w_chain_create of the same size
+  std::vector<Spare> ring_spares;     // ring buffers of destroyed chains, reused by the next b3w_chain_create of the same size;
+                                      // one size at a time, at most RING_SPARE_CAP bytes, released by b3w_ctx_trim (b3wit.h)
   std::string last_error;
 };
 
@@ -451,8 +452,7 @@ int32_t b3w_create(int32_t circuit, int32_t device, b3w_ctx **out) {
 void b3w_destroy(b3w_ctx *ctx) {
   if (!ctx) return;
   DeviceGuard guard(ctx->device);
-  for (const b3w_ctx::Spare &sp : ctx->ring_spares) (void)b3w_bodies_free(ctx, sp.ptr);
-  ctx->ring_spares.clear();
+  (void)b3w_ctx_trim(ctx);
   if (ctx->d_table_base) (void)hipFree(ctx->d_table_base);
   if (ctx->d_aux) (void)hipFree(ctx->d_aux);
   if (ctx->d_scratch) (void)hipFree(ctx->d_scratch);
@@ -805,6 +805,14 @@ int32_t b3w_bodies_free(b3w_ctx *ctx, void *d_ptr) {
 }
 
 void b3w_bodies_trim(void) { b3w_place_trim(); }
+
+int32_t b3w_ctx_trim(b3w_ctx *ctx) {
+  if (!ctx) return B3W_E_BAD_ARGUMENT;
+  DeviceGuard guard(ctx->device);
+  for (const b3w_ctx::Spare &sp : ctx->ring_spares) (void)b3w_bodies_free(ctx, sp.ptr);
+  ctx->ring_spares.clear();
+  return B3W_OK;
+}
 
 void b3w_bodies_configure(int64_t search_gib, int64_t pool_gib) { b3w_place_configure(search_gib, pool_gib); }
 
@@ -1618,7 +1626,7 @@ struct b3w_chain {
   b3w_ctx *ctx = nullptr;
   uint64_t len = 0, n_chunks = 0, first_chunk = 0, n_leaf = 0, n_par = 0, nbatch = 0;
   uint32_t nl = 0, P = 0, last_blocks = 16, batch_steps = 0, ring = 0;
-  bool has_last = false, complete = false;
+  bool has_last = false, complete = false, with_parents = false;
   int32_t placement = B3W_PLACEMENT_PLAIN;
   uint8_t *d_pre = nullptr;
   uint32_t *d_recs = nullptr, *d_cvs = nullptr, *d_pub = nullptr, *d_levels = nullptr, *d_root = nullptr;
@@ -1631,10 +1639,20 @@ struct b3w_chain {
   uint8_t *co_points = nullptr, *co_own = nullptr;   // (co_own: the chain's own buffer when the caller passed none)
   const b3w_r1cs *r1cs = nullptr;                    // constraint check of every batch while it sits in the ring
   uint32_t *d_viol = nullptr;                        // ... violated constraints per step
+  // sharded passes: exchange buffers, allocated on the first exchange for that communicator's rank count and kept
+  // (no allocation, no host synchronisation inside a pass that has run once)
+  struct Exchange {
+    int32_t nranks = 0;
+    uint64_t mx_chunks = 0, mx_leaf = 0, mx_par = 0;  // largest shard: chunks, leaf steps, parent steps
+    uint32_t *d_cv_pad = nullptr, *d_cv_gath = nullptr, *d_cv_all = nullptr;
+    uint32_t *d_h_send = nullptr, *d_h_recv = nullptr;
+    uint64_t *d_tab = nullptr;                        // per rank {leaf dst row, leaf rows, parent dst row, parent rows}
+  } x;
 };
 
 namespace {
 constexpr uint32_t CHAIN_SLICE_CHUNKS = 1024;       // 1 MiB of preimage per H2D slice = 16 384 leaf steps
+constexpr uint64_t RING_SPARE_CAP = 26ull << 30;    // ring buffers a context keeps between chains: two 16 384-step nova buffers
 
 // roctx ranges around the stages of the chained pass (H2D slice, leaf planning, witness batches, consumer, tree + parent
 // planning): `rocprofv3 --marker-trace --kernel-trace --memory-copy-trace` then shows which kernels and copies belong to
@@ -1752,6 +1770,7 @@ int32_t b3w_chain_create(b3w_ctx *ctx, uint64_t preimage_len, uint64_t first_chu
   c->last_blocks = last_bytes ? (uint32_t)((last_bytes + 63) / 64) : 1;
   c->has_last = first_chunk + n_chunks_local == n;
   c->n_leaf = (uint64_t)n_chunks_local * 16 - ((c->has_last && n_chunks_local) ? 16 - c->last_blocks : 0);
+  c->with_parents = with_parents != 0;
   c->n_par = with_parents ? b3w_chain_num_parent_steps(preimage_len, first_chunk, n_chunks_local) : 0;
   const uint64_t rows = (uint64_t)n_chunks_local * 16 + c->n_par + 1;
   const uint64_t body = 32ull * ctx->desc.nwit;
@@ -1772,6 +1791,7 @@ int32_t b3w_chain_create(b3w_ctx *ctx, uint64_t preimage_len, uint64_t first_chu
   for (int i = 0; i < 4 && e == hipSuccess; i++) e = hipEventCreateWithFlags(&c->ev[i], hipEventDisableTiming);
   if (e != hipSuccess) { b3w_chain_destroy(c); return e == hipErrorOutOfMemory ? B3W_E_NOT_ENOUGH_MEMORY : hip_fail(ctx, e, "chain buffers"); }
   c->placement = B3W_PLACEMENT_MIXED;
+  if (!ctx->ring_spares.empty() && ctx->ring_spares[0].bytes != (uint64_t)batch_steps * body) (void)b3w_ctx_trim(ctx);   // spares of another geometry: evicted
   for (uint32_t i = 0; i < ring; i++) {
     void *p = nullptr;
     int32_t pl = B3W_PLACEMENT_PLAIN;
@@ -1794,13 +1814,21 @@ void b3w_chain_destroy(b3w_chain *c) {
   if (!c) return;
   DeviceGuard guard(c->ctx->device);
   (void)hipDeviceSynchronize();
-  // ring buffers go back to the context (placed buffers use up address space for good: DESIGN.md "Placement"); at most
-  // four are kept, the rest is freed
+  // ring buffers go back to the context (placed buffers use up address space for good: DESIGN.md "Placement") for the next
+  // chain of the same ring geometry.  Spares of another size are released first (one size at a time) and the spares never
+  // hold more than RING_SPARE_CAP bytes; b3w_ctx_trim releases them.
   const uint64_t ring_bytes = (uint64_t)c->batch_steps * 32ull * c->ctx->desc.nwit;
-  for (void *p : c->bodies) {
-    if (c->ctx->ring_spares.size() < 4) c->ctx->ring_spares.push_back({p, ring_bytes, c->placement});
-    else (void)b3w_bodies_free(c->ctx, p);
+  {
+    std::vector<b3w_ctx::Spare> &sp = c->ctx->ring_spares;
+    if (!sp.empty() && sp[0].bytes != ring_bytes) (void)b3w_ctx_trim(c->ctx);
+    uint64_t held = (uint64_t)sp.size() * ring_bytes;
+    for (void *p : c->bodies) {
+      if (held + ring_bytes <= RING_SPARE_CAP) { sp.push_back({p, ring_bytes, c->placement}); held += ring_bytes; }
+      else (void)b3w_bodies_free(c->ctx, p);
+    }
   }
+  for (void *q : {(void *)c->x.d_cv_pad, (void *)c->x.d_cv_gath, (void *)c->x.d_cv_all, (void *)c->x.d_h_send, (void *)c->x.d_h_recv, (void *)c->x.d_tab})
+    if (q) (void)hipFree(q);
   if (c->d_pre) (void)hipFree(c->d_pre);
   if (c->d_recs) (void)hipFree(c->d_recs);
   if (c->d_cvs) (void)hipFree(c->d_cvs);
@@ -1890,37 +1918,91 @@ void b3w_chain_shard(uint64_t n_chunks, int32_t rank, int32_t nranks, uint64_t *
   if (n_chunks_local) *n_chunks_local = (uint32_t)(q + (k < r ? 1 : 0));
 }
 
+namespace {
+// exchange buffers of a sharded pass, sized for `nranks` (allocated once per chain; a communicator of another size re-allocates)
+int32_t chain_exchange(b3w_chain *c, int32_t nranks) {
+  b3w_chain::Exchange &x = c->x;
+  if (x.nranks == nranks) return B3W_OK;
+  b3w_ctx *ctx = c->ctx;
+  for (void *q : {(void *)x.d_cv_pad, (void *)x.d_cv_gath, (void *)x.d_cv_all, (void *)x.d_h_send, (void *)x.d_h_recv, (void *)x.d_tab})
+    if (q) (void)hipFree(q);
+  x = b3w_chain::Exchange();
+  std::vector<uint64_t> tab(4 * (size_t)nranks);
+  uint64_t mxc = 0, mxl = 0, mxp = 0;
+  const uint64_t last_short = 16 - c->last_blocks;          // steps the last chunk of the preimage lacks
+  for (int32_t r = 0; r < nranks; r++) {
+    uint64_t f = 0; uint32_t k = 0;
+    b3w_chain_shard(c->n_chunks, r, nranks, &f, &k);
+    const uint64_t leaf = (uint64_t)k * 16 - ((k && f + k == c->n_chunks) ? last_short : 0);
+    const uint64_t p0 = c->with_parents ? b3w_plan_parent_row(f, c->n_chunks) : 0, p1 = c->with_parents ? b3w_plan_parent_row(f + k, c->n_chunks) : 0;
+    tab[4 * r] = f * 16; tab[4 * r + 1] = leaf; tab[4 * r + 2] = p0; tab[4 * r + 3] = p1 - p0;
+    mxc = std::max<uint64_t>(mxc, k); mxl = std::max(mxl, leaf); mxp = std::max(mxp, p1 - p0);
+  }
+  x.mx_chunks = std::max<uint64_t>(mxc, 1); x.mx_leaf = std::max<uint64_t>(mxl, 1); x.mx_par = mxp;
+  const uint64_t hwords = (x.mx_leaf + x.mx_par) * 8;
+  hipError_t e = hipMalloc((void **)&x.d_cv_pad, x.mx_chunks * 32);
+  if (e == hipSuccess) e = hipMalloc((void **)&x.d_cv_gath, x.mx_chunks * 32 * nranks);
+  if (e == hipSuccess) e = hipMalloc((void **)&x.d_cv_all, c->n_chunks * 32);
+  if (e == hipSuccess) e = hipMalloc((void **)&x.d_h_send, hwords * 4);
+  if (e == hipSuccess) e = hipMalloc((void **)&x.d_h_recv, hwords * 4 * nranks);
+  if (e == hipSuccess) e = hipMalloc((void **)&x.d_tab, tab.size() * 8);
+  if (e == hipSuccess) e = hipMemset(x.d_cv_pad, 0, x.mx_chunks * 32);           // the padding goes over the wire: zeros, once
+  if (e == hipSuccess) e = hipMemset(x.d_h_send, 0, hwords * 4);
+  if (e == hipSuccess) e = hipMemcpy(x.d_tab, tab.data(), tab.size() * 8, hipMemcpyHostToDevice);
+  if (e != hipSuccess) return e == hipErrorOutOfMemory ? B3W_E_NOT_ENOUGH_MEMORY : hip_fail(ctx, e, "exchange buffers of the sharded pass");
+  x.nranks = nranks;
+  return B3W_OK;
+}
+
+int32_t chain_check_shard(b3w_chain *c, const b3w_comm *comm) {
+  uint64_t first = 0; uint32_t count = 0;
+  b3w_chain_shard(c->n_chunks, comm->rank, comm->nranks, &first, &count);
+  if (first != c->first_chunk || count != c->nl) { c->ctx->last_error = "the chain was not created with this rank's b3w_chain_shard range"; return B3W_E_BAD_ARGUMENT; }
+  return B3W_OK;
+}
+}  // namespace
+
 int32_t b3w_chain_run_parents_sharded(b3w_chain *c, b3w_comm *comm, b3w_batch_consumer consumer, void *user, void *stream) {
   if (!c || !comm) return B3W_E_BAD_ARGUMENT;
   b3w_ctx *ctx = c->ctx;
-  uint64_t first = 0; uint32_t count = 0;
-  b3w_chain_shard(c->n_chunks, comm->rank, comm->nranks, &first, &count);
-  if (first != c->first_chunk || count != c->nl) { ctx->last_error = "the chain was not created with this rank's b3w_chain_shard range"; return B3W_E_BAD_ARGUMENT; }
+  int32_t rc = chain_check_shard(c, comm);
+  if (rc) return rc;
   ON_DEVICE(ctx);
+  if ((rc = chain_exchange(c, comm->nranks)) != B3W_OK) return rc;
   hipStream_t st = (hipStream_t)stream;
-  const uint64_t mx = (c->n_chunks + comm->nranks - 1) / comm->nranks;       // largest shard
-  uint32_t *d_pad = nullptr, *d_gath = nullptr, *d_all = nullptr;
-  hipError_t e = hipMalloc((void **)&d_pad, mx * 32);
-  if (e == hipSuccess) e = hipMalloc((void **)&d_gath, mx * 32 * comm->nranks);
-  if (e == hipSuccess) e = hipMalloc((void **)&d_all, c->n_chunks * 32);
-  if (e != hipSuccess) {
-    if (d_pad) (void)hipFree(d_pad);
-    if (d_gath) (void)hipFree(d_gath);
-    return e == hipErrorOutOfMemory ? B3W_E_NOT_ENOUGH_MEMORY : hip_fail(ctx, e, "chunk CV exchange buffers");
-  }
-  e = hipMemsetAsync(d_pad, 0, mx * 32, st);
-  if (e == hipSuccess && c->nl) e = hipMemcpyAsync(d_pad, c->d_cvs, (uint64_t)c->nl * 32, hipMemcpyDeviceToDevice, st);
-  int32_t rc = e == hipSuccess ? b3w_comm_allgather(comm, d_pad, d_gath, mx * 32, stream) : hip_fail(ctx, e, "chunk CV staging");
+  b3w_chain::Exchange &x = c->x;
+  hipError_t e = hipSuccess;
+  if (c->nl) e = hipMemcpyAsync(x.d_cv_pad, c->d_cvs, (uint64_t)c->nl * 32, hipMemcpyDeviceToDevice, st);
+  rc = e == hipSuccess ? b3w_comm_allgather(comm, x.d_cv_pad, x.d_cv_gath, x.mx_chunks * 32, stream) : hip_fail(ctx, e, "chunk CV staging");
   for (int32_t r = 0; r < comm->nranks && rc == B3W_OK; r++) {                 // drop the padding: global chunk order
     uint64_t f = 0; uint32_t k = 0;
     b3w_chain_shard(c->n_chunks, r, comm->nranks, &f, &k);
-    if (k && (e = hipMemcpyAsync(d_all + f * 8, d_gath + (uint64_t)r * mx * 8, (uint64_t)k * 32, hipMemcpyDeviceToDevice, st)) != hipSuccess)
+    if (k && (e = hipMemcpyAsync(x.d_cv_all + f * 8, x.d_cv_gath + (uint64_t)r * x.mx_chunks * 8, (uint64_t)k * 32, hipMemcpyDeviceToDevice, st)) != hipSuccess)
       rc = hip_fail(ctx, e, "chunk CV compaction");
   }
-  if (rc == B3W_OK) rc = b3w_chain_run_parents(c, d_all, consumer, user, stream);
-  (void)hipStreamSynchronize(st);                       // the temporaries are read by work queued above
-  (void)hipFree(d_pad); (void)hipFree(d_gath); (void)hipFree(d_all);
-  return rc;
+  if (rc) return rc;
+  return b3w_chain_run_parents(c, x.d_cv_all, consumer, user, stream);
+}
+
+int32_t b3w_chain_allgather_hout(b3w_chain *c, b3w_comm *comm, uint32_t *d_leaf_hout, uint32_t *d_parent_hout, void *stream) {
+  if (!c || !comm || (!d_leaf_hout && !d_parent_hout)) return B3W_E_BAD_ARGUMENT;
+  b3w_ctx *ctx = c->ctx;
+  int32_t rc = chain_check_shard(c, comm);
+  if (rc) return rc;
+  ON_DEVICE(ctx);
+  if ((rc = chain_exchange(c, comm->nranks)) != B3W_OK) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  b3w_chain::Exchange &x = c->x;
+  // wire format per rank: [leaf h_out, mx_leaf rows | parent h_out, mx_par rows], 8 words a row
+  int e = b3w_launch_pack_hout(c->d_pub, 0, c->n_leaf, x.d_h_send, st);
+  if (e == 0) e = b3w_launch_pack_hout(c->d_pub, c->n_leaf, c->n_par, x.d_h_send + x.mx_leaf * 8, st);
+  if (e) return hip_fail(ctx, (hipError_t)e, "h_out packing");
+  const uint64_t block_words = (x.mx_leaf + x.mx_par) * 8;
+  if ((rc = b3w_comm_allgather(comm, x.d_h_send, x.d_h_recv, block_words * 4, stream)) != B3W_OK) return rc;
+  e = b3w_launch_unpack_hout(x.d_h_recv, block_words, x.mx_leaf * 8, x.d_tab, (uint32_t)comm->nranks, x.mx_leaf + x.mx_par, d_leaf_hout,
+                             x.mx_par ? d_parent_hout : nullptr, st);
+  if (e) return hip_fail(ctx, (hipError_t)e, "h_out unpacking");
+  return B3W_OK;
 }
 
 int32_t b3w_chain_info(const b3w_chain *c, uint64_t *n_leaf_steps, uint64_t *n_parent_steps, uint64_t *n_chunks, uint32_t *path_len,

@@ -30,6 +30,10 @@ extern "C" int b3w_launch_plan_parents(const uint32_t *d_levels, uint64_t nchunk
                                        uint32_t last_chunk_blocks, uint32_t *d_recs, hipStream_t stream);
 extern "C" uint64_t b3w_plan_parent_row(uint64_t chunk, uint64_t nchunks);     // chunk == nchunks: all parent steps
 extern "C" int b3w_plan_path_provable(uint64_t chunk, uint64_t nchunks);
+// the fold's exchange (h_out = public words 2 .. 9 of a step): strided rows -> wire format, gathered rank blocks -> global step order
+extern "C" int b3w_launch_pack_hout(const uint32_t *d_pub, uint64_t row0, uint64_t count, uint32_t *d_dst, hipStream_t stream);
+extern "C" int b3w_launch_unpack_hout(const uint32_t *d_gathered, uint64_t block_words, uint64_t par_off, const uint64_t *d_tab, uint32_t nranks,
+                                      uint64_t max_rows, uint32_t *d_leaf_all, uint32_t *d_par_all, hipStream_t stream);
 
 extern "C" int b3w_launch_trace(int kind, const uint32_t *d_recs, uint32_t cn, uint32_t *d_images, uint32_t row, const uint32_t *d_table,
                                 uint32_t nwit, uint32_t *d_pub, int32_t *d_status, const void *d_aux, hipStream_t stream);

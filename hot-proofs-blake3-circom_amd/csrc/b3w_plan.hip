@@ -270,6 +270,46 @@ __global__ __launch_bounds__(64) void b3w_plan_paths_kernel(const uint32_t *__re
 
 }  // namespace
 
+// ---- the fold's exchange: h_out of every step (public words 2 .. 9 of the 15 per step) -----------------------------------
+namespace {
+// pack: rows [row0, row0 + count) of the public-output array -> count x 8 contiguous words (what goes over the wire)
+__global__ __launch_bounds__(256) void b3w_plan_pack_hout_kernel(const uint32_t *__restrict__ pub, uint64_t row0, uint64_t count,
+                                                                 uint32_t *__restrict__ dst) {
+  const uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x;          // one word per thread: coalesced stores
+  if (i >= count * 8) return;
+  dst[i] = pub[(row0 + (i >> 3)) * 15 + 2 + (i & 7)];
+}
+
+// unpack: the gathered per-rank blocks (each `block_words` long: leaf part at 0, parent part at `par_off` words, both padded to
+// the largest shard) -> two dense arrays in global step order.  tab[r] = {leaf dst row, leaf rows, parent dst row, parent rows}.
+__global__ __launch_bounds__(256) void b3w_plan_unpack_hout_kernel(const uint32_t *__restrict__ gathered, uint64_t block_words, uint64_t par_off,
+                                                                   const uint64_t *__restrict__ tab, uint32_t *__restrict__ leaf_all,
+                                                                   uint32_t *__restrict__ par_all) {
+  const uint32_t r = blockIdx.y;
+  const uint64_t l0 = tab[4 * r], ln = tab[4 * r + 1], p0 = tab[4 * r + 2], pn = tab[4 * r + 3];
+  const uint32_t *src = gathered + (uint64_t)r * block_words;
+  for (uint64_t i = (uint64_t)blockIdx.x * 256 + threadIdx.x; i < (ln + pn) * 8; i += (uint64_t)gridDim.x * 256) {
+    if (i < ln * 8) { if (leaf_all) leaf_all[l0 * 8 + i] = src[i]; }
+    else if (par_all) par_all[p0 * 8 + (i - ln * 8)] = src[par_off + (i - ln * 8)];
+  }
+}
+}  // namespace
+
+extern "C" int b3w_launch_pack_hout(const uint32_t *d_pub, uint64_t row0, uint64_t count, uint32_t *d_dst, hipStream_t stream) {
+  if (!count) return 0;
+  hipLaunchKernelGGL(b3w_plan_pack_hout_kernel, dim3((uint32_t)((count * 8 + 255) / 256)), dim3(256), 0, stream, d_pub, row0, count, d_dst);
+  return (int)hipGetLastError();
+}
+
+extern "C" int b3w_launch_unpack_hout(const uint32_t *d_gathered, uint64_t block_words, uint64_t par_off, const uint64_t *d_tab, uint32_t nranks,
+                                      uint64_t max_rows, uint32_t *d_leaf_all, uint32_t *d_par_all, hipStream_t stream) {
+  if (!nranks || !max_rows) return 0;
+  const uint64_t want = (max_rows * 8 + 255) / 256;
+  hipLaunchKernelGGL(b3w_plan_unpack_hout_kernel, dim3((uint32_t)(want < 4096 ? want : 4096), nranks), dim3(256), 0, stream, d_gathered,
+                     block_words, par_off, d_tab, d_leaf_all, d_par_all);
+  return (int)hipGetLastError();
+}
+
 extern "C" uint32_t b3w_plan_path_len(uint64_t chunk, uint64_t nchunks) { return path_len(chunk, nchunks); }
 
 extern "C" int b3w_launch_plan_leaves(const uint8_t *d_pre, uint64_t total_len, uint64_t first_chunk, uint32_t nlocal,

@@ -17,32 +17,42 @@ def shard_range(n_total, rank, world):
     return start, start + q + (1 if rank < r else 0)
 
 
+def gather_rows(local, counts, group=None):
+    """All-gather of ragged row blocks: rank r contributes counts[r] rows (`local`: [counts[rank], words] on this rank, device or
+    CPU).  Returns [sum(counts), words] in rank order on every rank.  Shards are padded to the largest for the collective
+    (ncclAllGather takes equal counts) and trimmed afterwards."""
+    world = dist.get_world_size(group) if dist.is_initialized() else 1
+    if world == 1:
+        return local
+    assert len(counts) == world and local.shape[0] == counts[dist.get_rank(group)]
+    if local.is_cuda and dist.get_backend(group) == "gloo":
+        # CPU rehearsal of the exchange (tests / single-GPU dry runs): stage through the host
+        return gather_rows(local.cpu(), counts, group).to(local.device)
+    words, mx = local.shape[1], max(max(counts), 1)
+    if all(c == mx for c in counts):
+        out = torch.empty((world * mx, words), dtype=local.dtype, device=local.device)
+        dist.all_gather_into_tensor(out, local.contiguous(), group=group)
+        return out
+    pad = torch.zeros((mx, words), dtype=local.dtype, device=local.device)
+    pad[:local.shape[0]] = local
+    out = torch.empty((world * mx, words), dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(out, pad, group=group)
+    return torch.cat([out[r * mx:r * mx + c] for r, c in enumerate(counts)], dim=0)
+
+
 def gather_public(pub_local, n_total=None, group=None):
     """All-gather per-step public outputs.  pub_local: [n_local, words] int32 tensor (device or CPU).
-    Returns [n_total, words] in global step order on every rank.  Ragged shards are padded to the
-    largest shard for the collective and trimmed afterwards."""
+    Returns [n_total, words] in global step order on every rank (shards = shard_range(n_total, r, world))."""
     world = dist.get_world_size(group) if dist.is_initialized() else 1
     if world == 1:
         return pub_local
-    words = pub_local.shape[1]
-    if pub_local.is_cuda and dist.get_backend(group) == "gloo":
-        # CPU rehearsal of the exchange (tests / single-GPU dry runs): stage through the host
-        return gather_public(pub_local.cpu(), n_total, group).to(pub_local.device)
     if n_total is None:
         cnt = torch.tensor([pub_local.shape[0]], dtype=torch.int64, device=pub_local.device)
+        if pub_local.is_cuda and dist.get_backend(group) == "gloo":
+            cnt = cnt.cpu()
         dist.all_reduce(cnt, group=group)
         n_total = int(cnt.item())
-    sizes = [shard_range(n_total, r, world) for r in range(world)]
-    mx = max(e - s for s, e in sizes)
-    if all(e - s == mx for s, e in sizes):
-        out = torch.empty((world * mx, words), dtype=pub_local.dtype, device=pub_local.device)
-        dist.all_gather_into_tensor(out, pub_local.contiguous(), group=group)
-        return out
-    pad = torch.zeros((mx, words), dtype=pub_local.dtype, device=pub_local.device)
-    pad[:pub_local.shape[0]] = pub_local
-    out = torch.empty((world * mx, words), dtype=pub_local.dtype, device=pub_local.device)
-    dist.all_gather_into_tensor(out, pad, group=group)
-    return torch.cat([out[r * mx:r * mx + (e - s)] for r, (s, e) in enumerate(sizes)], dim=0)
+    return gather_rows(pub_local, [e - s for s, e in (shard_range(n_total, r, world) for r in range(world))], group)
 
 
 class PublicExchange:

@@ -141,6 +141,12 @@ int32_t b3w_bodies_free(b3w_ctx *ctx, void *d_ptr);
 /* The allocator keeps up to 3 x 12 GiB of classified-but-unused physical memory per device for the next buffer (and two
  * 256 MiB reference pieces for good); b3w_bodies_trim returns that reserve to the driver. */
 void b3w_bodies_trim(void);
+/* Memory a CONTEXT keeps: when a b3w_chain is destroyed its ring buffers (batch_steps bodies each — 12 GB for 16 384 nova steps)
+ * stay with the context for the next chain of the same ring geometry, because placed buffers use up address space for good.
+ * Bounds: spares of one ring size at a time (a chain of another geometry releases them first) and at most 26 GiB in all.
+ * Neither torch nor RCCL can see that memory; b3w_ctx_trim(ctx) releases it (to the placement pool — follow with
+ * b3w_bodies_trim to hand it to the driver), b3w_destroy does the same. */
+int32_t b3w_ctx_trim(b3w_ctx *ctx);
 /* Bounds of the placement allocator, in GiB (negative = leave as is): `search_gib` = new physical memory one search may
  * touch transiently beyond the buffer itself (default 16 x the buffer, at least 24, at most 160 — released again at the end
  * of the search); `pool_gib` = labelled memory kept pooled for later buffers, all three labels together (default 12).
@@ -415,6 +421,17 @@ void b3w_chain_shard(uint64_t n_chunks, int32_t rank, int32_t nranks, uint64_t *
  * shards padded to the largest) and continues with the tree and this rank's parent steps.  The chain must have been
  * created with this rank's b3w_chain_shard range. */
 int32_t b3w_chain_run_parents_sharded(b3w_chain *chain, b3w_comm *comm, b3w_batch_consumer consumer, void *user, void *stream);
+/* The fold's exchange in chained mode (BASELINE config 4: "RCCL gather of h_out"): the folding driver consumes z_{i+1} = the
+ * public outputs of step i (Blake3CompressPubIO::to_vec, rust_fold/src/blake3_circuit.rs:111-123, fed back at
+ * rust_fold/src/main.rs:166-179), of which h_out — public words 2..9 — is the running chaining value.  One ncclAllGather over
+ * `comm` of this rank's h_out rows (packed to 8 words a row, shards padded to the largest) and a scatter into
+ *   d_leaf_hout   : b3w_chain_num_leaf_steps(len) * 8 u32, GLOBAL step order (chunk, block): row 16 c + blocks(c) - 1 is chunk
+ *                   c's chaining value
+ *   d_parent_hout : b3w_chain_parent_row(n_chunks, n_chunks) * 8 u32, (chunk, height) order: the last row of a provable chunk
+ *                   path is BLAKE3(preimage)
+ * on every rank (either pointer may be NULL).  Enqueued on `stream` behind the pass; exchange buffers are allocated on the
+ * first sharded call of a chain and kept, so a pass that has run once neither allocates nor synchronises. */
+int32_t b3w_chain_allgather_hout(b3w_chain *chain, b3w_comm *comm, uint32_t *d_leaf_hout, uint32_t *d_parent_hout, void *stream);
 int32_t b3w_chain_info(const b3w_chain *chain, uint64_t *n_leaf_steps, uint64_t *n_parent_steps, uint64_t *n_chunks,
                        uint32_t *path_len, int32_t *placement);
 /* Waits for `stream`, then copies the results to the host: (n_leaf + n_parent) * 15 public-output words, as many

@@ -53,12 +53,45 @@ def test_gpus_2_launches_itself():
     assert d["config"]["witnesses_per_step"] == 2 * 256 * 3 and "cpu_baseline" not in d
 
 
+@pytest.mark.parametrize("mode", ["every", "last", "none"])
+def test_gpus_2_exchange_modes(mode):
+    """--exchange splits an N > 1 number into kernel and collective: all three modes run, verify themselves, and say what they did;
+    every rank's own kernel time is in the line."""
+    d = _bench("--gpus", "2", "--batch", "256", "--steps", "2", "--warmup", "1", "--inner", "3", "--exchange", mode, env={"B3W_DIST_BACKEND": "gloo"})
+    c, r = d["config"], d["roofline"]
+    assert d["n_gpus"] == 2 and c["exchange_mode"] == mode and c["exchange"].startswith(f"--exchange {mode}")
+    assert len(r["kernel_ms_per_rank"]) == 2 and r["kernel_ms_min"] <= r["kernel_ms_max"] == r["kernel_ms"]
+    assert len(c["devices_per_rank"]) == 2 and all(x.startswith("cuda:") for x in c["devices_per_rank"])
+
+
+def test_a_rank_hung_before_the_rendezvous_fails_the_run_quickly():
+    """one rank never reaches init_process_group (GPU initialised, then stuck): the launcher's watchdog ends the run with status
+    124 well inside the driver's time limit instead of waiting for it"""
+    import time
+    t0 = time.monotonic()
+    r = subprocess.run([sys.executable, os.path.join(T.ROOT, "bench.py"), "--gpus", "2", "--batch", "256", "--steps", "1", "--warmup", "0",
+                        "--launch-timeout", "20"], capture_output=True, text=True, timeout=400, cwd=T.ROOT,
+                       env=dict(os.environ, B3W_DIST_BACKEND="gloo", B3W_BENCH_TEST_HANG_RANK="1", B3W_BENCH_TEST_HANG_AT="rendezvous"))
+    assert r.returncode == 124, (r.returncode, r.stderr[-1500:])
+    assert "ranks [0, 1] have not passed rendezvous" in r.stderr or "ranks [1] have not passed rendezvous" in r.stderr
+    assert r.stdout.strip() == "" and time.monotonic() - t0 < 150
+
+
 def test_gpus_2_chain_launches_itself():
     d = _bench("--gpus", "2", "--workload", "chain", "--preimage-mib", "0.25", "--steps", "1", "--warmup", "1", env={"B3W_DIST_BACKEND": "gloo"})
     assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["n_chunks"] == 256
     assert "2 ranks" in d["config"]["exchange"] and len(d["config"]["placement_per_rank"]) == 2
     # 256 chunks x 16 leaf steps + 8 parent steps per chunk path, summed over both ranks
     assert "-> 6144 nova steps" in d["config"]["workload"]
+    # BASELINE config 4's exchange, inside the timed pass: every step's h_out and the chunk chaining values
+    assert d["config"]["exchange"].startswith("all_gather of 4096 x 8 u32 h_out (+ 2048 x 8 of the parent steps) + all_gather of 256 x 8 u32 chunk chaining values")
+    assert len(d["config"]["pass_ms_per_rank"]) == 2
+
+
+def test_gpus_2_chain_without_the_h_out_gather():
+    d = _bench("--gpus", "2", "--workload", "chain", "--preimage-mib", "0.25", "--steps", "1", "--warmup", "1", "--exchange", "none",
+               env={"B3W_DIST_BACKEND": "gloo"})
+    assert d["config"]["exchange"].startswith("--exchange none: all_gather of 256 x 8 u32 chunk chaining values") and d["config"]["exchange_mode"] == "none"
 
 
 @pytest.mark.parametrize("consumer", ["none", "commit", "commit-only", "check", "check+commit"])

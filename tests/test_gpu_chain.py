@@ -303,6 +303,126 @@ def test_two_ranks_shard_chunks_and_exchange_cvs():
         assert len(ret[r]["last"]) == 32 and all(x == want for x in ret[r]["last"])
 
 
+def _hout_worker(rank, world, port, nbytes, ret):
+    import os, torch, torch.distributed as dist
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)      # both ranks share the one GPU of the test box
+    try:
+        m = T.pkg()
+        torch.cuda.set_device(0)
+        data = m.workloads.lcg_preimage(nbytes, seed=1)
+        ctx = m.Context("nova_vesta", 0)
+        out = m.chain.fold_witnesses(ctx, data, batch_steps=4096)
+        torch.cuda.synchronize()
+        ret[rank] = dict(leaf=out["h_out_all"].cpu().numpy().view(np.uint32).copy(),
+                         par=out["h_out_parents_all"].cpu().numpy().view(np.uint32).copy(),
+                         root=out["root"].cpu().numpy().view(np.uint32).tolist(), n_leaf_local=out["n_leaf_steps"],
+                         ok=bool((out["status"] == 0).all().item()))
+        ctx.close()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("nbytes", [1 << 20, 5 * 1024 + 100], ids=["config4_1mib", "6chunks_partial_last"])
+def test_two_ranks_gather_h_out_of_every_step(nbytes):
+    """BASELINE config 4 as it is worded: the 1 MiB LCG(1) preimage -> 16 384 chained leaf steps sharded over the ranks, and the
+    per-step h_out (16 384 x 8 u32) all-gathered inside the pass: on BOTH ranks the gathered h_out of step 16 c + 15 is chunk c's
+    chaining value for every chunk, and every provable chunk path's last parent step carries BLAKE3(preimage)
+    (z_{i+1} = outputs of step i: rust_fold/src/blake3_circuit.rs:111-123)."""
+    import torch.multiprocessing as mp
+    m = T.pkg()
+    mgr = mp.Manager()
+    ret = mgr.dict()
+    mp.spawn(_hout_worker, args=(2, T.free_port(), nbytes, ret), nprocs=2, join=True)
+    data = m.workloads.lcg_preimage(nbytes, seed=1)
+    n = (nbytes + 1023) // 1024
+    L = m.lib()
+    want_root = B.hash_words(data.tobytes())
+    full = n - (1 if nbytes % 1024 else 0)
+    cvs = B.chunk_cvs_np(data[:full * 1024]) if full >= 2 else None
+    n_leaf, n_par = L.b3w_chain_num_leaf_steps(nbytes), L.b3w_chain_parent_row(n, n)
+    assert ret[0]["n_leaf_local"] + ret[1]["n_leaf_local"] == n_leaf and ret[0]["n_leaf_local"] > 0 and ret[1]["n_leaf_local"] > 0
+    for r in (0, 1):
+        assert ret[r]["ok"] and ret[r]["root"] == want_root
+        leaf, par = ret[r]["leaf"], ret[r]["par"]
+        assert leaf.shape == (n_leaf, 8) and par.shape == (n_par, 8)
+        assert np.array_equal(leaf[15:full * 16:16], cvs), "gathered h_out of step 16c+15 != chunk CV c"
+        if full < n:                                                      # the partial last chunk: its last block's h_out
+            assert list(leaf[-1]) == B.chunk_cv(data[full * 1024:].tobytes(), full, False)
+        for c in range(n):
+            row = L.b3w_chain_parent_row(c, n)
+            plen = L.b3w_chain_path_len(c, n)
+            assert (list(par[row + plen - 1]) == want_root) == bool(L.b3w_chain_path_provable(c, n)), c
+    assert np.array_equal(ret[0]["leaf"], ret[1]["leaf"]) and np.array_equal(ret[0]["par"], ret[1]["par"])
+    # ... and equal to what ONE rank computes for the whole preimage
+    ctx = m.Context("nova_vesta", 0)
+    one = m.chain.fold_witnesses(ctx, data, batch_steps=4096)
+    import torch
+    torch.cuda.synchronize()
+    assert one["h_out_all"].shape == (n_leaf, 8)
+    assert np.array_equal(one["h_out_all"].cpu().numpy().view(np.uint32), ret[0]["leaf"])
+    assert np.array_equal(one["h_out_parents_all"].cpu().numpy().view(np.uint32), ret[1]["par"])
+    ctx.close()
+
+
+def test_native_h_out_exchange_over_rccl_single_rank():
+    """b3w_chain_run_parents_sharded + b3w_chain_allgather_hout (the C-ABI's own RCCL calls) with the one-rank communicator a
+    one-GPU box can form: both exchanges run through ncclAllGather, the result is the pass's own h_out in step order; twice,
+    so that the second pass runs on the exchange buffers the first one allocated."""
+    import torch
+    m = T.pkg()
+    ctx = m.Context("nova_vesta", 0)
+    comm = m.Comm(ctx, m.Comm.unique_id(), 0, 1)
+    data = m.workloads.lcg_preimage(37 * 1024 + 333, seed=1)
+    for _ in range(2):
+        out = m.chain.fold_witnesses(ctx, data, batch_steps=256, comm=comm)
+        torch.cuda.synchronize()
+        pub = out["public"].cpu().numpy().view(np.uint32)
+        assert bool((out["status"] == 0).all().item())
+        assert out["root"].cpu().numpy().view(np.uint32).tolist() == B.hash_words(data.tobytes())
+        nl = out["n_leaf_steps"]
+        assert out["h_out_all"].shape == (nl, 8) and out["h_out_parents_all"].shape == (out["n_parent_steps"], 8)
+        assert np.array_equal(out["h_out_all"].cpu().numpy().view(np.uint32), pub[:nl, 2:10])
+        assert np.array_equal(out["h_out_parents_all"].cpu().numpy().view(np.uint32), pub[nl:, 2:10])
+    # a chain that is not this rank's shard is refused
+    import ctypes
+    L = m.lib()
+    h = ctypes.c_void_p()
+    assert L.b3w_chain_create(ctx.handle, 8192, 1, 2, 64, 2, 1, ctypes.byref(h)) == 0
+    d = torch.zeros(8 * 128, dtype=torch.int32, device="cuda")
+    assert L.b3w_chain_allgather_hout(h, comm.handle, d.data_ptr(), None, None) == 100 and "b3w_chain_shard" in ctx.last_error()
+    assert L.b3w_chain_allgather_hout(h, comm.handle, None, None, None) == 100
+    L.b3w_chain_destroy(h)
+    comm.close()
+    ctx.close()
+
+
+def test_ring_spares_are_bounded_and_trimmed():
+    """a context keeps the ring buffers of a destroyed chain for the next chain of the same geometry — one size at a
+    time, and b3w_ctx_trim releases them."""
+    import ctypes
+    m = T.pkg()
+    L = m.lib()
+    ctx = m.Context("nova_vesta", 0)
+    live = lambda: ctx.bodies_stats()["live_buffers"]
+    base = live()
+    h = ctypes.c_void_p()
+    assert L.b3w_chain_create(ctx.handle, 1 << 16, 0, 64, 1024, 2, 1, ctypes.byref(h)) == 0        # 2 x 1 024 bodies = 2 x 763 MB (placed)
+    assert live() == base + 2
+    L.b3w_chain_destroy(h)
+    assert live() == base + 2                                   # kept as spares
+    assert L.b3w_chain_create(ctx.handle, 1 << 16, 0, 64, 1024, 2, 1, ctypes.byref(h)) == 0        # same geometry: reused
+    assert live() == base + 2
+    L.b3w_chain_destroy(h)
+    assert L.b3w_chain_create(ctx.handle, 1 << 16, 0, 64, 768, 2, 1, ctypes.byref(h)) == 0         # another geometry: the old spares go first
+    assert live() == base + 2
+    L.b3w_chain_destroy(h)
+    assert live() == base + 2
+    assert L.b3w_ctx_trim(ctx.handle) == 0 and live() == base
+    assert L.b3w_ctx_trim(None) == 100
+    ctx.close()
+
+
 def test_native_chain_driver_argument_errors():
     """b3w_chain_* refuses what it cannot do: compression contexts, chunk ranges past the preimage, a chunk sub-range
     without the other ranks' chaining values, zero-sized rings."""
