@@ -394,7 +394,9 @@ def main():
     if world > 1:
         if hang is not None and str(rank) in hang.split(",") and os.environ.get("B3W_BENCH_TEST_HANG_AT") == "rendezvous":   # tests only: hung with the GPU initialised
             time.sleep(3600)
-        pg_timeout = datetime.timedelta(seconds=args.launch_timeout if args.launch_timeout > 0 else 1800)
+        # (the process group's own limit is the backstop under a foreign launcher; 30 s later than the watchdog so that it is the
+        # watchdog that reports which ranks were missing)
+        pg_timeout = datetime.timedelta(seconds=args.launch_timeout + 30 if args.launch_timeout > 0 else 1800)
         if backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=pg_timeout)
         else:

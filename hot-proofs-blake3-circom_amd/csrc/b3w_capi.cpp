@@ -1049,6 +1049,8 @@ int32_t b3w_chain_plan_parents_device(b3w_ctx *ctx, const uint32_t *d_levels, ui
 // ---------------------------------------------------------------- rank-1 constraint check (on-device consumer #1)
 }  // extern "C"
 
+constexpr size_t R1CS_SCRATCH_STREAMS = 8;           // deferred-row scratches (27 MB each) one constraint system keeps, one per stream
+
 struct b3w_r1cs {
   b3w_ctx *ctx = nullptr;
   uint32_t m = 0, nwires = 0, npubout = 0, npubin = 0, nprvin = 0;
@@ -1065,9 +1067,15 @@ struct b3w_r1cs {
   // enqueued on, allocated at the first check on that stream and kept (a fixed size: checks go in slabs of B3W_R1CS_SLAB)
   uint32_t max_tile_rows = 0;
   uint32_t *d_trow_k = nullptr, *d_lrows = nullptr, *d_lterms = nullptr, *d_ltile_terms = nullptr;   // (its own rows and term stream: bit runs folded)
+  uint32_t *d_srows = nullptr, *d_sgdesc = nullptr, *d_sgwords = nullptr, *d_sgmeta = nullptr;       // the stream kernel's program
+  unsigned long long *d_coef_zlim = nullptr;
   B3wR1csSystem sys{};
+  // ... at most R1CS_SCRATCH_STREAMS of them: the least recently used one goes when another stream comes (after the event that
+  // follows its last check; a scratch a stream capture has seen stays, its graph may be replayed any time)
+  struct Scratch { void *stream; unsigned long long *buf; hipEvent_t done; uint64_t tick; bool pinned; };
   mutable std::mutex scratch_mu;
-  mutable std::map<void *, unsigned long long *> scratch;
+  mutable std::vector<Scratch> scratch;
+  mutable uint64_t scratch_tick = 0;
 };
 
 
@@ -1122,8 +1130,14 @@ static int32_t r1cs_create_impl(b3w_ctx *ctx, const uint8_t *img, size_t len, b3
     up((void **)&r->d_lterms, H.lterms.data(), H.lterms.size() * 4);
     up((void **)&r->d_ltile_terms, H.ltdesc.data(), H.ltdesc.size() * 4);
     r->max_tile_rows = H.max_tile_rows;
+    up((void **)&r->d_srows, H.srows.data(), H.srows.size() * 4);
+    up((void **)&r->d_sgdesc, H.sgdesc.data(), H.sgdesc.size() * 4);
+    up((void **)&r->d_sgwords, H.sgwords.data(), H.sgwords.size() * 4);
+    up((void **)&r->d_sgmeta, H.sgmeta.data(), H.sgmeta.size() * 4);
+    up((void **)&r->d_coef_zlim, H.coef_zlim.data(), H.coef_zlim.size() * 8);
     r->sys = B3wR1csSystem{H.nwires, H.ntiles, H.max_ext, H.max_lean_terms, H.max_tile_rows, r->ncoef, r->d_tiles, r->d_ltile_terms, r->d_ext, r->d_lrows,
-                           r->d_trow_id, r->d_trow_k, r->d_lterms, r->d_coefR, r->d_coef_small, r->d_rows, r->d_wires, r->d_cids};
+                           r->d_trow_id, r->d_trow_k, r->d_lterms, r->d_coefR, r->d_coef_small, r->d_rows, r->d_wires, r->d_cids,
+                           H.max_g_words, H.max_g_rows, r->d_srows, r->d_sgdesc, r->d_sgwords, r->d_sgmeta, r->d_coef_zlim};
   }
   if (e != hipSuccess) { b3w_r1cs_destroy(r); return e == hipErrorOutOfMemory ? B3W_E_NOT_ENOUGH_MEMORY : hip_fail(ctx, e, "r1cs upload"); }
   *out = r;
@@ -1154,8 +1168,12 @@ void b3w_r1cs_destroy(b3w_r1cs *r) {
   if (r->d_coefR) (void)hipFree(r->d_coefR);
   for (uint32_t *q : {r->d_tiles, r->d_ext, r->d_trows, r->d_trow_id, r->d_terms, r->d_tile_terms}) if (q) (void)hipFree(q);
   if (r->d_coef_small) (void)hipFree(r->d_coef_small);
-  for (uint32_t *q : {r->d_trow_k, r->d_lrows, r->d_lterms, r->d_ltile_terms}) if (q) (void)hipFree(q);
-  for (auto &kv : r->scratch) if (kv.second) (void)hipFree(kv.second);
+  for (uint32_t *q : {r->d_trow_k, r->d_lrows, r->d_lterms, r->d_ltile_terms, r->d_srows, r->d_sgdesc, r->d_sgwords, r->d_sgmeta}) if (q) (void)hipFree(q);
+  if (r->d_coef_zlim) (void)hipFree(r->d_coef_zlim);
+  for (auto &sc : r->scratch) {
+    if (sc.done) { (void)hipEventSynchronize(sc.done); (void)hipEventDestroy(sc.done); }
+    if (sc.buf) (void)hipFree(sc.buf);
+  }
   delete r;
 }
 
@@ -1169,20 +1187,47 @@ int32_t b3w_r1cs_check_device(b3w_ctx *ctx, const b3w_r1cs *r, const uint8_t *d_
     return B3W_E_BAD_ARGUMENT;
   }
   ON_DEVICE(ctx);
-  // B3W_R1CS_GATHER=1: the gather kernel, =2: the 32-byte tile kernel — the other formulations, for comparison
+  // B3W_R1CS_GATHER=1: the gather kernel, =2: the 32-byte tile kernel, =3: the lean pair — the other formulations, for comparison
   static const int other = getenv("B3W_R1CS_GATHER") ? atoi(getenv("B3W_R1CS_GATHER")) : 0;
-  if (r->tiled && other == 0) {
+  if (r->tiled && (other == 0 || other == 3)) {
     unsigned long long *scratch = nullptr;
+    hipEvent_t done = nullptr;
     {
       std::lock_guard<std::mutex> lock(r->scratch_mu);
-      auto it = r->scratch.find(stream);
-      if (it == r->scratch.end()) {
-        // (the first check on a stream allocates: do one before capturing that stream into a graph)
-        HIP_TRY(ctx, hipMalloc((void **)&scratch, b3w_r1cs_scratch_bytes(&r->sys)));
-        r->scratch[stream] = scratch;
-      } else scratch = it->second;
+      hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+      if (stream) (void)hipStreamIsCapturing((hipStream_t)stream, &cap);          // (the null stream cannot be captured)
+      (void)hipGetLastError();
+      const bool capturing = cap != hipStreamCaptureStatusNone;
+      b3w_r1cs::Scratch *hit = nullptr;
+      for (auto &sc : r->scratch) if (sc.stream == stream) hit = &sc;
+      if (!hit) {
+        // the first check on a stream allocates that stream's deferred-row scratch — not something a capture may contain
+        if (capturing) { ctx->last_error = "the first constraint check on a stream allocates its scratch: run one check on this stream before capturing it"; return B3W_E_BAD_ARGUMENT; }
+        if (r->scratch.size() >= R1CS_SCRATCH_STREAMS) {                           // a caller cycling through streams: the least recently used goes
+          size_t lru = r->scratch.size();
+          for (size_t k = 0; k < r->scratch.size(); k++)
+            if (!r->scratch[k].pinned && (lru == r->scratch.size() || r->scratch[k].tick < r->scratch[lru].tick)) lru = k;
+          if (lru == r->scratch.size()) { ctx->last_error = "every scratch of this constraint system belongs to a captured stream"; return B3W_E_NOT_ENOUGH_MEMORY; }
+          (void)hipEventSynchronize(r->scratch[lru].done);                         // its last check has finished (its stream may be gone by now)
+          (void)hipEventDestroy(r->scratch[lru].done);
+          (void)hipFree(r->scratch[lru].buf);
+          r->scratch.erase(r->scratch.begin() + lru);
+        }
+        b3w_r1cs::Scratch sc{stream, nullptr, nullptr, 0, false};
+        HIP_TRY(ctx, hipMalloc((void **)&sc.buf, b3w_r1cs_scratch_bytes(&r->sys)));
+        hipError_t ee = hipEventCreateWithFlags(&sc.done, hipEventDisableTiming);
+        if (ee != hipSuccess) { (void)hipFree(sc.buf); return hip_fail(ctx, ee, "hipEventCreate(r1cs scratch)"); }
+        r->scratch.push_back(sc);
+        hit = &r->scratch.back();
+      }
+      hit->tick = ++r->scratch_tick;
+      if (capturing) hit->pinned = true;
+      scratch = hit->buf;
+      done = capturing ? nullptr : hit->done;                                      // (a captured check stays made of kernel nodes only)
     }
-    const int lrc = b3w_launch_r1cs_lean(d_bodies, n, pitch, &r->sys, &r->field, scratch, d_violations, d_first, (hipStream_t)stream);
+    int lrc = other == 3 ? -6 : b3w_launch_r1cs_stream(d_bodies, n, pitch, &r->sys, &r->field, scratch, d_violations, d_first, (hipStream_t)stream);
+    if (lrc == -6) lrc = b3w_launch_r1cs_lean(d_bodies, n, pitch, &r->sys, &r->field, scratch, d_violations, d_first, (hipStream_t)stream);
+    if (done) (void)hipEventRecord(done, (hipStream_t)stream);
     return lrc ? hip_fail(ctx, (hipError_t)lrc, "r1cs check launch") : B3W_OK;
   }
   const int rc = r->tiled && other != 1

@@ -101,8 +101,18 @@ struct B3wR1csSystem {
   const long long *coef_small;
   const uint32_t *g_rows, *g_wires;
   const uint16_t *g_cids;
+  // the stream kernel's program (b3w_r1cs_host.h): row descriptors by class, per tile {first general word, words, rows, -}, the
+  // general rows' words and meta words, per coefficient the bound an element must stay below
+  uint32_t max_g_words, max_g_rows;
+  const uint32_t *srows, *sgdesc, *sgwords, *sgmeta;
+  const unsigned long long *coef_zlim;
 };
 #define B3W_R1CS_SLAB 8192u                                  // bodies per launch pair at most: bounds the scratch (64 MB at most)
 extern "C" size_t b3w_r1cs_scratch_bytes(const B3wR1csSystem *sys);
 extern "C" int b3w_launch_r1cs_lean(const uint8_t *d_bodies, uint32_t n, uint64_t pitch, const B3wR1csSystem *sys, const B3wField *field,
                                     unsigned long long *d_scratch, uint32_t *d_violations, uint32_t *d_first, hipStream_t stream);
+// the STREAM kernel (default where the system fits): the lean kernel's arithmetic in one persistent 1 024-thread workgroup per CU
+// fed by LDS-DMA through a ring of raw tile images (b3w_r1cs.hip); same scratch, same deferred kernel, same verdicts.
+// Returns -6 when the system does not fit (more than 2 048 rows or 480 outside wires per tile, or no room in LDS).
+extern "C" int b3w_launch_r1cs_stream(const uint8_t *d_bodies, uint32_t n, uint64_t pitch, const B3wR1csSystem *sys, const B3wField *field,
+                                      unsigned long long *d_scratch, uint32_t *d_violations, uint32_t *d_first, hipStream_t stream);

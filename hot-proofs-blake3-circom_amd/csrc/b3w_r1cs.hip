@@ -37,6 +37,8 @@
 // circuits is 98 % bits, so the check of a valid batch is gather-bound (L2/TA), not ALU-bound.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
+#include <mutex>
 #include "b3w_kernels.h"
 
 namespace {
@@ -470,6 +472,8 @@ __global__ __launch_bounds__(256) void b3w_r1cs_tile_kernel(const uint8_t *__res
 // [1 + 4 * it + wave] = the deferred lanes of that wave in iteration `it` (row = first + 256 * it + thread).  Every word the
 // second kernel reads is written by the first: no initialisation.
 
+#define B3W_LEAN_ALWAYS_DEFER 0x40000000u                  // bit 30 of a lean row's A count: a coefficient of the row is no small integer — no
+                                                           // integer evaluation can decide it, it goes to the deferred kernel unread
 __device__ __forceinline__ unsigned long long lean_pack(const uint4 lo, const uint4 hi) {
   const uint32_t wide = lo.z | lo.w | hi.x | hi.y | hi.z | hi.w | (lo.y & 0x80000000u);
   return wide ? 0x8000000000000000ull : (unsigned long long)lo.x | (unsigned long long)lo.y << 32;
@@ -658,8 +662,10 @@ __global__ __launch_bounds__(256) void b3w_r1cs_lean_kernel(const uint8_t *__res
     if (r < td.x + td.y) {
       if ((d.y >> 31) && w0_is_one) {
         bad = el[d.w] > 1ull;                              // booleanity (see the tile kernel); an element of 2^63 or more is no bit
+      } else if (!(d.y >> 31) && (d.y & B3W_LEAN_ALWAYS_DEFER)) {
+        defer = true;
       } else {
-        const uint32_t na = d.y & 0x7FFFFFFFu;
+        const uint32_t na = d.y & 0x3FFFFFFFu;
         const uint32_t t0r = d.x - tbase;
         const uint32_t nc = (d.y >> 31) ? 0u : d.w;
         const __int128 C = lean_dot(el, packed, tsrc, csrc, t0r + na + d.z, nc, &defer);
@@ -696,6 +702,254 @@ __global__ __launch_bounds__(256) void b3w_r1cs_lean_kernel(const uint8_t *__res
   }
 }
 
+// ---- the STREAM kernel (default): the lean kernel's arithmetic inside a persistent workgroup whose loads never stop --------
+// The lean kernel is (body, tile) workgroups that load, pack, evaluate and leave: its HBM loads are in flight only part of a
+// workgroup's life, and with five workgroups per CU the sum of load time and evaluate time — not their maximum — is what a tile
+// costs (profiles/r02: 2.06 us per tile and CU = 1.37 us of loads at the achievable HBM rate + 0.7 us of evaluation; waves
+// parked 53-58 % of their cycles).  Here ONE 1 024-thread workgroup per CU walks a contiguous range of the tile-major unit
+// list (tile, body) and the next tiles' bytes travel HBM -> LDS by LDS-DMA (global_load_lds_dwordx4: no VGPRs, nothing for the
+// compiler to wait on) into a ring of NBUF raw 32-byte tile images while the current tile is packed and its rows evaluated:
+//     wait (counted vmcnt: the NBUF - 1 younger tiles stay in flight) | barrier | pack raw -> 8-byte elements + bit words |
+//     barrier | issue the DMA of tile i + NBUF into the buffer just freed | rows of tile i
+// Word list, coefficients, row descriptors and the DMA geometry are per TILE, so they are fetched once per tile switch (one or
+// two per workgroup) instead of once per (body, tile): the steady-state loop has no global load at all — only the DMAs, the
+// deferred-row mask stores and (rarely) the violation atomics.  The outside wires of a tile are gathered by the same DMAs
+// (per-lane source addresses).  Raw image of a 1 KiB DMA block = 32 elements: their 32 low halves, then their 32 high halves
+// (the swizzle is on the SOURCE address, the block still covers whole 128-byte lines), so the pack phase's ds_read_b128 are
+// conflict-free.  Same scratch format, same deferred kernel, same verdicts as the lean pair.
+// ROWS.  With one workgroup per CU nothing else runs while its rows are evaluated, so the lean kernel's "one row per lane walks its
+// words" (three dependent LDS round trips per term on the few waves that hold general rows: 2 us per tile) is replaced by the host's
+// STREAM PROGRAM (b3w_r1cs_host.cpp): booleanity rows as before; TRUTH-TABLE rows — a row over at most five wires that hold bits is
+// a function of five bits, tabulated by the host with exact field arithmetic and looked up from the elements' bits (every XOR gate
+// of these circuits: 87 % of the other rows); GENERAL rows one WORD per lane — every lane multiplies its coefficient and element
+// and adds the product into its row's sums in LDS (ds_add_u64), all sixteen waves sharing the tile's word list — then the row's
+// owner lane compares A * B with C.  A product that would not stay below 2^55, an element that is no bit in a truth-table row or
+// a coefficient that is no small integer defers the row to the deferred kernel's field arithmetic.
+__device__ __forceinline__ void glds16(uint32_t lds_dst /* wave-uniform byte address */, const void *gsrc /* per lane */) {
+  uint32_t keep;
+  const uint32_t dst = __builtin_amdgcn_readfirstlane(lds_dst);                    // (an SGPR operand needs a provably uniform value)
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
+}
+// wait until at most `outstanding` of this wave's vector-memory operations are in flight (DMAs retire in issue order; the mask
+// stores between them are not counted on, so the wait is exact or early-safe whichever way stores and loads are ordered)
+__device__ __forceinline__ void vm_wait(uint32_t outstanding) {
+  switch (outstanding) {                                   // (wave-uniform; s_waitcnt takes an immediate)
+    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
+    case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
+    case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
+    case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
+    case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+  }
+}
+// workgroup barrier that leaves vector-memory operations (the DMAs) in flight: LDS traffic retired, then s_barrier
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+
+#define B3W_R1CS_STREAM_THREADS 1024u
+
+template <int NBUF>
+__global__ __launch_bounds__(1024) void b3w_r1cs_stream_kernel(const uint8_t *__restrict__ bodies, uint64_t pitch, uint32_t n, B3wR1csSystem S,
+                                                               unsigned long long *__restrict__ scratch, uint32_t block_words,
+                                                               uint32_t *__restrict__ violations, uint32_t *__restrict__ first, uint32_t dbg) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
+  const uint32_t ext_cap = (S.max_ext + 32u) & ~31u;                               // outside wires, in whole DMA blocks of 32 (+ at least one spare element)
+  const uint32_t raw_stride = (B3W_R1CS_TILE + ext_cap) * 32u;                     // one raw image: tile blocks, then outside-wire blocks
+  unsigned long long *el = reinterpret_cast<unsigned long long *>(smem + (size_t)NBUF * raw_stride);
+  unsigned long long *packed = el + B3W_R1CS_TILE + ext_cap;
+  const uint32_t groups = ((B3W_R1CS_TILE + ext_cap + 63u) >> 6) + 1u;            // (one spare pair: a run reads its group and the next)
+  // general rows of the tile: per-row sums {A, B, C} and flags, the word list with its meta words; per coefficient {c, zlim}
+  unsigned long long *gsum = packed + 2 * groups;
+  uint32_t *gflag = reinterpret_cast<uint32_t *>(gsum + 3u * S.max_g_rows);
+  uint32_t *gwords = gflag + ((S.max_g_rows + 1u) & ~1u);
+  uint32_t *gmeta = gwords + ((S.max_g_words + 4u) & ~3u);
+  ulonglong2 *coef2 = reinterpret_cast<ulonglong2 *>(gmeta + ((S.max_g_words + 4u) & ~3u));
+  for (uint32_t k = tid; k < S.ncoef; k += B3W_R1CS_STREAM_THREADS) coef2[k] = make_ulonglong2((unsigned long long)S.coef_small[k], S.coef_zlim[k]);
+  if (tid < 2) packed[2 * (groups - 1) + tid] = 0ull;                              // the spare pair
+  const uint32_t lds0 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)smem);
+
+  const uint64_t U = (uint64_t)S.ntiles * n;                                       // units, tile-major: u = tile * n + body
+  uint64_t u = U * blockIdx.x / gridDim.x;
+  const uint64_t u_end = U * (blockIdx.x + 1ull) / gridDim.x;
+  while (u < u_end) {
+    const uint32_t tile = (uint32_t)(u / n), b_lo = (uint32_t)(u - (uint64_t)tile * n);
+    const uint32_t m = (uint32_t)((u_end - u) < (uint64_t)(n - b_lo) ? (u_end - u) : (uint64_t)(n - b_lo));      // bodies of this tile
+    // ---- per tile: descriptors, the term list, the DMA geometry.  (No DMA is in flight here: the pipeline below drains.)
+    lds_barrier();                                                                 // the previous tile's rows are done with the word list
+    const uint4 td = reinterpret_cast<const uint4 *>(S.tiles)[tile];               // {first row, rows, first outside wire, outside wires}
+    const uint4 gd = reinterpret_cast<const uint4 *>(S.sgdesc)[tile];              // {first general word, general words, general rows, -}
+    const uint32_t t0 = tile * B3W_R1CS_TILE;
+    const uint32_t n_local = S.nwires - t0 < B3W_R1CS_TILE ? S.nwires - t0 : B3W_R1CS_TILE;
+    const uint32_t r0 = td.x + tid, r1 = td.x + tid + B3W_R1CS_STREAM_THREADS;
+    const uint4 *srows = reinterpret_cast<const uint4 *>(S.srows);
+    const uint4 pre0 = r0 < td.x + td.y ? srows[r0] : make_uint4(0, 0, 0, 0);
+    const uint4 pre1 = r1 < td.x + td.y ? srows[r1] : make_uint4(0, 0, 0, 0);
+    const uint32_t rid0 = r0 < td.x + td.y ? S.row_id[r0] : 0u, rid1 = r1 < td.x + td.y ? S.row_id[r1] : 0u;
+    for (uint32_t k = tid; k < gd.y + 1u; k += B3W_R1CS_STREAM_THREADS) {           // (+ 1: a lane reads the word behind its own)
+      gwords[k] = S.sgwords[gd.x + k];
+      gmeta[k] = S.sgmeta[gd.x + k];
+    }
+    // DMA blocks of this wave: tile blocks `wave` and `wave + 16` (a block = 32 elements = 1 KiB), outside-wire block `wave`.
+    // Lane l of a block fetches the low (l < 32) or high half of element 32 * block + (l & 31).
+    const uint32_t half = lane >> 5, ein = lane & 31u;
+    const uint32_t nblk = (n_local + 31u) >> 5, nxblk = (td.w + 31u) >> 5;
+    const bool has0 = wave < nblk, has1 = wave + 16u < nblk, hasx = wave < nxblk;
+    const uint32_t e0 = wave * 32u + ein, e1 = (wave + 16u) * 32u + ein, ex = wave * 32u + ein;
+    const uint64_t off0 = (uint64_t)(t0 + (e0 < n_local ? e0 : n_local - 1u)) * 32u + half * 16u;
+    const uint64_t off1 = (uint64_t)(t0 + (e1 < n_local ? e1 : n_local - 1u)) * 32u + half * 16u;
+    const uint64_t offx = (uint64_t)(hasx ? S.ext[td.z + (ex < td.w ? ex : td.w - 1u)] : 0u) * 32u + half * 16u;
+    const uint32_t per_tile = (has0 ? 1u : 0u) + (has1 ? 1u : 0u) + (hasx ? 1u : 0u);          // this wave's DMAs per tile (wave-uniform)
+    auto issue = [&](const uint32_t body_index, const uint32_t buf) {
+      const uint8_t *body = bodies + (uint64_t)body_index * pitch;
+      const uint32_t dst = lds0 + buf * raw_stride;
+      if (dbg & 12u) return;
+      if (has0) glds16(dst + wave * 1024u, body + off0);
+      if (has1) glds16(dst + (wave + 16u) * 1024u, body + off1);
+      if (hasx) glds16(dst + B3W_R1CS_TILE * 32u + wave * 1024u, body + offx);
+    };
+    // every global load above has landed before the first DMA is issued: inside the pipeline the compiler must find nothing of
+    // its own to wait for (a wait it placed at a first use in the loop would drain the DMAs on every iteration)
+    asm volatile("" :: "v"(pre0.x), "v"(pre0.y), "v"(pre0.z), "v"(pre0.w), "v"(pre1.x), "v"(pre1.y), "v"(pre1.z), "v"(pre1.w), "v"(rid0), "v"(rid1),
+                 "v"(off0), "v"(off1), "v"(offx));
+    lds_barrier();                                                                 // the word list (and, the first time, the coefficients) in place
+    if (dbg & 8u) {                                        // experiment: ONE body's tile staged, its rows evaluated m times
+      const uint8_t *body = bodies + (uint64_t)b_lo * pitch;
+      if (has0) glds16(lds0 + wave * 1024u, body + off0);
+      if (has1) glds16(lds0 + (wave + 16u) * 1024u, body + off1);
+      if (hasx) glds16(lds0 + B3W_R1CS_TILE * 32u + wave * 1024u, body + offx);
+    }
+    for (uint32_t k = 0; k < (uint32_t)NBUF && k < m; k++) issue(b_lo + k, k);
+    for (uint32_t i = 0; i < m; i++) {
+      const uint32_t b = b_lo + i, buf = i % (uint32_t)NBUF;
+      const uint32_t ahead = m - 1u - i < (uint32_t)NBUF - 1u ? m - 1u - i : (uint32_t)NBUF - 1u;      // younger tiles in flight
+      vm_wait(per_tile * ahead);                                                   // this wave's pieces of tile i have landed
+      lds_barrier();                                                               // ... and everyone's; the rows of tile i - 1 are done with el
+      // ---- pack: 32-byte elements -> 8 bytes (bit 63 = "not below 2^63") + two bit words per 64 elements
+      const unsigned char *raw = smem + (size_t)((dbg & 8u) ? 0u : buf) * raw_stride;
+      if (!(dbg & 2u) && !((dbg & 8u) && i > 0)) {
+        const uint4 lo = *reinterpret_cast<const uint4 *>(raw + (tid >> 5) * 1024u + (tid & 31u) * 16u);
+        const uint4 hi = *reinterpret_cast<const uint4 *>(raw + (tid >> 5) * 1024u + 512u + (tid & 31u) * 16u);
+        const unsigned long long z = tid < n_local ? lean_pack(lo, hi) : 0ull;
+        el[tid] = z;
+        const unsigned long long ones = __ballot(z == 1ull), bads = __ballot(z > 1ull);       // the wave holds elements 64 w ... 64 w + 63
+        if (lane == 0) { packed[2 * wave] = ones; packed[2 * wave + 1] = bads; }
+      }
+      if (!(dbg & 2u) && !((dbg & 8u) && i > 0) && wave * 64u < ext_cap) {                                   // (whole waves, for the ballots)
+        const uint32_t j = tid;                                                    // outside wire j of the tile
+        unsigned long long z = 0ull;
+        if (j < td.w) {
+          const uint4 lo = *reinterpret_cast<const uint4 *>(raw + B3W_R1CS_TILE * 32u + (j >> 5) * 1024u + (j & 31u) * 16u);
+          const uint4 hi = *reinterpret_cast<const uint4 *>(raw + B3W_R1CS_TILE * 32u + (j >> 5) * 1024u + 512u + (j & 31u) * 16u);
+          z = lean_pack(lo, hi);
+        }
+        if (j < ext_cap) el[B3W_R1CS_TILE + j] = z;
+        const unsigned long long ones = __ballot(z == 1ull), bads = __ballot(z > 1ull);
+        const uint32_t g = (B3W_R1CS_TILE >> 6) + wave;
+        if (lane == 0 && g < groups - 1u) { packed[2 * g] = ones; packed[2 * g + 1] = bads; }
+      }
+      for (uint32_t k = tid; k < 3u * gd.z; k += B3W_R1CS_STREAM_THREADS) gsum[k] = 0ull;       // (the previous unit's owner lanes read theirs before barrier one)
+      for (uint32_t k = tid; k < gd.z; k += B3W_R1CS_STREAM_THREADS) gflag[k] = 0u;
+      lds_barrier();                                                               // raw image read out (lgkmcnt retired), el / packed in place
+      if (i + (uint32_t)NBUF < m) issue(b + (uint32_t)NBUF, buf);                  // the freed buffer takes tile i + NBUF
+      if (dbg & 1u) continue;
+      // ---- general rows, one WORD per lane: chunk c of 64 words goes to wave c mod 16; a lane adds coefficient * element (or the
+      // value of a bit run) into its row's part sum.  |product| < 2^55 by the coefficient's element bound, a row has at most 256
+      // words: the 64-bit sums are exact.
+      if (!(dbg & 32u))
+        for (uint32_t c0 = wave * 64u; c0 < gd.y; c0 += B3W_R1CS_STREAM_THREADS) {
+          const uint32_t iw = c0 + lane;
+          const bool act = iw < gd.y;
+          const uint32_t w = gwords[act ? iw : 0u], w1 = gwords[act ? iw + 1u : 0u], mt = gmeta[act ? iw : 0u];
+          const bool second = (mt >> 2) & 1u;                // the second word of a run: nothing of its own
+          const bool is_run = act && !second && (w >> 16) == 0xFFFFu;
+          const bool is_term = act && !second && !is_run;
+          const unsigned long long z = el[is_term ? w & 0xFFFFu : 0u];
+          const ulonglong2 cz = coef2[is_term ? w >> 16 : 0u];
+          bool ok = z < cz.y;                                // (a coefficient that is no small integer has bound 0; bit 63 = "not below 2^63")
+          unsigned long long v = cz.x * z;                   // two's complement: the low 64 bits of c * z are the product when it fits
+          if (__ballot(is_run) != 0ull) {
+            if (is_run) {
+              const uint32_t idx0 = w & 0xFFFFu, len = w1 & 0xFFu, sh = (w1 >> 8) & 0xFFu;
+              const uint32_t g = idx0 >> 6, r = idx0 & 63u;
+              const unsigned long long one_lo = packed[2 * g], bad_lo = packed[2 * g + 1], one_hi = packed[2 * g + 2], bad_hi = packed[2 * g + 3];
+              const unsigned long long mask = len == 64u ? ~0ull : (1ull << len) - 1ull;
+              const unsigned long long ones = ((one_lo >> r) | (r ? one_hi << (64u - r) : 0ull)) & mask;
+              const unsigned long long bads = ((bad_lo >> r) | (r ? bad_hi << (64u - r) : 0ull)) & mask;
+              ok = bads == 0ull && sh + len <= 55u;          // (an element of the run that is no bit; a run that could pass 2^55)
+              const unsigned long long val = ones << (sh & 63u);
+              v = (w1 >> 16) & 1u ? 0ull - val : val;
+            }
+          }
+          if (is_term || is_run) {
+            const uint32_t g = mt >> 8;
+            if (ok) atomicAdd(&gsum[3u * g + (mt & 3u)], v);
+            else atomicOr(&gflag[g], 1u);
+          }
+        }
+      // ---- one row per lane: booleanity and truth-table rows are decided here, general rows once their sums are complete
+      const bool w0_is_one = el[tile == 0 ? 0 : B3W_R1CS_TILE] == 1ull;            // (outside wire 0 of every other tile)
+      const uint32_t passes = td.y > B3W_R1CS_STREAM_THREADS && !(dbg & 16u) ? 2u : 1u;
+      uint32_t verdict = 0;                                  // bit `it`: deferred, bit 2 + `it`: violated (the passes' verdicts, in a register)
+      for (uint32_t it = 0; it < passes; it++) {
+        const uint4 d = it ? pre1 : pre0;
+        const bool in = td.x + tid + B3W_R1CS_STREAM_THREADS * it < td.x + td.y;
+        bool defer = false, bad = false;
+        if (in && (d.y >> 31)) {                             // booleanity  z * (1 - z) = 0: is the element 0 or 1
+          if (w0_is_one) bad = el[d.w] > 1ull;               // (an element of 2^63 or more is no bit)
+          else defer = true;                                 // (wire 0 is not 1: nothing here means what it should — field arithmetic)
+        } else if (in && (d.y & 0x40000000u)) {
+          defer = true;                                      // a coefficient that is no small integer, or a very long row
+        }
+        if (__ballot(in && (d.y >> 29) == 1u) != 0ull) {     // truth-table rows (whole waves of them: the rows are sorted by shape)
+          if (in && (d.y >> 29) == 1u) {
+            const uint32_t k = (d.y >> 16) & 7u;
+            const unsigned long long z0 = el[d.x & 0xFFFFu], z1 = el[d.x >> 16], z2 = el[d.z & 0xFFFFu], z3 = el[d.z >> 16], z4 = el[d.y & 0xFFFFu];
+            const unsigned long long nonbit = (z0 | (k > 1 ? z1 : 0ull) | (k > 2 ? z2 : 0ull) | (k > 3 ? z3 : 0ull) | (k > 4 ? z4 : 0ull)) >> 1;
+            const uint32_t a = ((uint32_t)z0 & 1u) | ((uint32_t)z1 & 1u) << 1 | ((uint32_t)z2 & 1u) << 2 | ((uint32_t)z3 & 1u) << 3 | ((uint32_t)z4 & 1u) << 4;
+            // (unused positions name element 0 and the host's table does not depend on their bits)
+            defer = nonbit != 0ull;
+            bad = !defer && !((d.w >> (a & ((1u << k) - 1u))) & 1u);
+          }
+        }
+        verdict |= (defer ? 1u : 0u) << it | (bad ? 4u : 0u) << it;
+      }
+      lds_barrier();                                                               // every word's contribution is in its row's sums
+      unsigned long long *block = scratch + ((size_t)b * S.ntiles + tile) * block_words;
+      uint32_t nbad = 0, low = 0xFFFFFFFFu;
+      for (uint32_t it = 0; it < passes; it++) {
+        const uint4 d = it ? pre1 : pre0;
+        const bool in = td.x + tid + B3W_R1CS_STREAM_THREADS * it < td.x + td.y;
+        bool defer = (verdict >> it) & 1u, bad = (verdict >> (2u + it)) & 1u;
+        const bool general = in && (d.y >> 28) == 1u;
+        if (__ballot(general) != 0ull) {
+          if (general) {
+            const long long A = (long long)gsum[3u * d.x], B = (long long)gsum[3u * d.x + 1u], C = (long long)gsum[3u * d.x + 2u];
+            defer = gflag[d.x] != 0u || (dbg & 32u) != 0u;
+            bad = !defer && (__int128)A * (__int128)B != (__int128)C;      // |A * B - C| < 2^127 < p: "= 0 mod p" is "= 0"
+          }
+        }
+        if (bad) { nbad++; low = min(low, it ? rid1 : rid0); }
+        const unsigned long long mask = __ballot(defer);
+        if (lane == 0 && B3W_R1CS_STREAM_THREADS * it + wave * 64u < td.y) block[1 + 16u * it + wave] = mask;
+      }
+      if (__ballot(nbad != 0) != 0ull) {                   // (rare: a body that violates something)
+#pragma unroll
+        for (int sh = 32; sh > 0; sh >>= 1) {
+          nbad += (uint32_t)__shfl_xor((int)nbad, sh);
+          low = min(low, (uint32_t)__shfl_xor((int)low, sh));
+        }
+        if (lane == 0) {
+          atomicAdd(&violations[b], nbad);
+          if (first) atomicMin(&first[b], low);
+        }
+      }
+    }
+    u += m;
+  }
+}
+
 // the rows the lean kernel left: one WAVE per (body, tile), almost all of which leave on their first load.  A wave, not the
 // lean kernel's four: a row of a flagged tile is a chain of dependent loads (term, element, coefficient), and sixteen single-wave
 // workgroups fit a CU where four-wave ones fit four (354 -> 217 us per 4 096 nova bodies).  A lane takes a row; a LONG row (each
@@ -709,13 +963,15 @@ __global__ __launch_bounds__(64) void b3w_r1cs_deferred_kernel(const uint8_t *__
   const uint32_t tile = (blockIdx.x % per_group) >> 3;
   if (b >= n) return;
   const unsigned long long *block = scratch + ((size_t)b * S.ntiles + tile) * block_words;
-  if (block[0] == 0) return;
-  const uint8_t *body = bodies + (uint64_t)b * pitch;
   const uint4 td = reinterpret_cast<const uint4 *>(S.tiles)[tile];
-  const uint32_t words = 4u * ((td.y + 255u) >> 8);      // word 4 * it + wave of the lean kernel = rows first + 64 * word + lane
+  const uint32_t words = (td.y + 63u) >> 6;              // word w of the first kernel = rows first + 64 * w + lane (at most 64 words: 4 096 rows)
+  // one load decides: lane w fetches mask word w; a (body, tile) none of whose rows was deferred leaves here
+  const unsigned long long mine_w = threadIdx.x < words ? block[1 + threadIdx.x] : 0ull;
+  if (__ballot(mine_w != 0ull) == 0ull) return;
+  const uint8_t *body = bodies + (uint64_t)b * pitch;
   uint32_t nbad = 0, low = 0xFFFFFFFFu;
   for (uint32_t wi = 0; wi < words; wi++) {
-    const unsigned long long mask = block[1 + wi];
+    const unsigned long long mask = __shfl(mine_w, (int)wi);
     if (mask == 0) continue;                             // (wave-uniform)
     const bool mine = (mask >> threadIdx.x) & 1ull;
     const uint32_t r = td.x + 64u * wi + threadIdx.x;    // (< td.x + td.y for a marked lane: only such lanes set a bit)
@@ -777,6 +1033,24 @@ extern "C" int b3w_launch_r1cs_tiled(const uint8_t *d_bodies, uint32_t n, uint64
   if (smem + (size_t)max_tile_terms * 4 <= 40 * 1024) { lds_terms = max_tile_terms; smem += (size_t)max_tile_terms * 4 + 4; }
   const bool coef_lds = ncoef <= 512;                      // 4 KB at most
   if (coef_lds) smem = ((smem + 7) & ~(size_t)7) + (size_t)ncoef * 8;
+  if (smem > 64 * 1024) {
+    // a system with many outside wires per tile (max_ext near 1 024: 64 KB of elements alone) needs more than the default
+    // dynamic-LDS limit: raise it for the instantiation this launch takes, once per device
+    static std::mutex mu;
+    static unsigned done[64][4];
+    int dev = 0;
+    if ((e = hipGetDevice(&dev)) != hipSuccess) return (int)e;
+    const int inst = (lds_terms ? 2 : 0) + (coef_lds ? 1 : 0);
+    std::lock_guard<std::mutex> lock(mu);
+    if (!done[dev & 63][inst]) {
+      const void *fn = inst == 3   ? reinterpret_cast<const void *>(&b3w_r1cs_tile_kernel<true, true>)
+                       : inst == 2 ? reinterpret_cast<const void *>(&b3w_r1cs_tile_kernel<true, false>)
+                       : inst == 1 ? reinterpret_cast<const void *>(&b3w_r1cs_tile_kernel<false, true>)
+                                   : reinterpret_cast<const void *>(&b3w_r1cs_tile_kernel<false, false>);
+      if ((e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return (int)e;
+      done[dev & 63][inst] = 1;
+    }
+  }
   const uint32_t slab = (0x7FFFFFFFu / ntiles) & ~7u;
   for (uint32_t b0 = 0; b0 < n; b0 += slab) {
     const uint32_t nb = n - b0 < slab ? n - b0 : slab;
@@ -873,3 +1147,79 @@ extern "C" int b3w_launch_r1cs_lean(const uint8_t *d_bodies, uint32_t n, uint64_
   }
   return 0;
 }
+
+// LDS of the stream kernel for a system: NBUF raw images + elements + bit words + term list + coefficients
+static inline size_t stream_smem(const B3wR1csSystem *sys, int nbuf) {
+  const uint32_t ext_cap = (sys->max_ext + 32u) & ~31u;
+  const uint32_t groups = ((B3W_R1CS_TILE + ext_cap + 63u) >> 6) + 1u;
+  return (size_t)nbuf * (B3W_R1CS_TILE + ext_cap) * 32u + (size_t)(B3W_R1CS_TILE + ext_cap) * 8u + (size_t)groups * 16u +
+         (size_t)sys->max_g_rows * 24u + (size_t)((sys->max_g_rows + 1u) & ~1u) * 4u + 2u * (size_t)((sys->max_g_words + 4u) & ~3u) * 4u +
+         (size_t)sys->ncoef * 16u;
+}
+
+// 0 = launched; -6 = this system does not fit the stream kernel (the caller takes the lean pair)
+extern "C" int b3w_launch_r1cs_stream(const uint8_t *d_bodies, uint32_t n, uint64_t pitch, const B3wR1csSystem *sys, const B3wField *field,
+                                      unsigned long long *d_scratch, uint32_t *d_violations, uint32_t *d_first, hipStream_t stream) {
+  if (!n || !sys->ntiles) return 0;
+  if (!d_scratch) return -5;
+  static const int env_nbuf = getenv("B3W_R1CS_NBUF") ? atoi(getenv("B3W_R1CS_NBUF")) : 0;
+  static const int env_grid = getenv("B3W_R1CS_GRID") ? atoi(getenv("B3W_R1CS_GRID")) : 0;
+  static const uint32_t env_dbg = getenv("B3W_R1CS_DBG") ? (uint32_t)atoi(getenv("B3W_R1CS_DBG")) : 0u;     // experiments: 1 no rows, 2 no pack, 4 no DMA, 8 one body staged once per tile and re-evaluated, 16 no second row pass, 32 booleanity rows only
+  if (sys->max_tile_rows > 2u * B3W_R1CS_STREAM_THREADS || sys->max_ext > 480u) return -6;
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return (int)e;
+  struct PerDevice { int cus = 0, lds = 0; bool attr[4] = {false, false, false, false}; };
+  static PerDevice per[64];
+  static std::mutex mu;
+  int nbuf = 0;
+  size_t smem = 0;
+  int cus = 0;
+  {
+    std::lock_guard<std::mutex> lock(mu);
+    PerDevice &pd = per[dev & 63];
+    if (!pd.cus) {
+      if ((e = hipDeviceGetAttribute(&pd.cus, hipDeviceAttributeMultiprocessorCount, dev)) != hipSuccess) return (int)e;
+      if ((e = hipDeviceGetAttribute(&pd.lds, hipDeviceAttributeMaxSharedMemoryPerBlock, dev)) != hipSuccess) return (int)e;
+      if (pd.lds < 160 * 1024) pd.lds = 64 * 1024;         // (gfx950: 160 KB per workgroup; anything else: be modest)
+    }
+    for (int nb : {3, 2}) {
+      if (env_nbuf && nb != env_nbuf) continue;
+      if (stream_smem(sys, nb) <= (size_t)pd.lds) { nbuf = nb; break; }
+    }
+    if (!nbuf) return -6;
+    smem = stream_smem(sys, nbuf);
+    if (!pd.attr[nbuf]) {
+      const void *fn = nbuf == 3 ? reinterpret_cast<const void *>(&b3w_r1cs_stream_kernel<3>) : reinterpret_cast<const void *>(&b3w_r1cs_stream_kernel<2>);
+      if ((e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, pd.lds)) != hipSuccess) return (int)e;
+      pd.attr[nbuf] = true;
+    }
+    cus = pd.cus;
+  }
+  e = (hipError_t)r1cs_init_results(d_violations, d_first, n, stream);
+  if (e != hipSuccess) return (int)e;
+  const uint32_t bw = lean_block_words(sys);
+  const uint32_t slab = lean_slab(sys);
+  for (uint32_t b0 = 0; b0 < n; b0 += slab) {
+    const uint32_t nb = n - b0 < slab ? n - b0 : slab;
+    const uint64_t units = (uint64_t)nb * sys->ntiles;
+    uint32_t grid = env_grid > 0 ? (uint32_t)env_grid : (uint32_t)cus;       // one persistent workgroup per CU
+    if (grid > units) grid = (uint32_t)units;
+    if (nbuf == 3)
+      hipLaunchKernelGGL((b3w_r1cs_stream_kernel<3>), dim3(grid), dim3(B3W_R1CS_STREAM_THREADS), smem, stream, d_bodies + (uint64_t)b0 * pitch, pitch, nb,
+                         *sys, d_scratch, bw, d_violations + b0, d_first ? d_first + b0 : nullptr, env_dbg);
+    else
+      hipLaunchKernelGGL((b3w_r1cs_stream_kernel<2>), dim3(grid), dim3(B3W_R1CS_STREAM_THREADS), smem, stream, d_bodies + (uint64_t)b0 * pitch, pitch, nb,
+                         *sys, d_scratch, bw, d_violations + b0, d_first ? d_first + b0 : nullptr, env_dbg);
+    e = hipGetLastError();
+    if (e != hipSuccess) return (int)e;
+    if (env_dbg) continue;                                 // (an experiment that skips phases leaves no valid masks behind)
+    const dim3 dgrid(((nb + 7) / 8) * 8 * sys->ntiles);
+    hipLaunchKernelGGL(b3w_r1cs_deferred_kernel, dgrid, dim3(64), 0, stream, d_bodies + (uint64_t)b0 * pitch, pitch, nb, *sys, d_scratch, bw,
+                       *field, d_violations + b0, d_first ? d_first + b0 : nullptr);
+    e = hipGetLastError();
+    if (e != hipSuccess) return (int)e;
+  }
+  return 0;
+}
+

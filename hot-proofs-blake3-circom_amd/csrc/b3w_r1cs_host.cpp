@@ -26,6 +26,26 @@ void u256_add_mod(uint32_t a[8], const uint32_t b[8], const uint32_t p[8]) {
   if (!ge) { ge = true; for (int i = 7; i >= 0; --i) if (a[i] != p[i]) { ge = a[i] > p[i]; break; } }
   if (ge) { uint64_t br = 0; for (int i = 0; i < 8; i++) { const uint64_t t = (uint64_t)a[i] - p[i] - br; a[i] = (uint32_t)t; br = (t >> 63) & 1; } }
 }
+// a * b / 2^256 mod p (CIOS; a, b < p; inv = -p^-1 mod 2^32) — exact field products for the truth tables of the stream program
+void mont_mul_host(uint32_t out[8], const uint32_t a[8], const uint32_t b[8], const uint32_t p[8], uint32_t inv) {
+  uint32_t t[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
+  for (int i = 0; i < 8; i++) {
+    uint64_t c = 0;
+    for (int j = 0; j < 8; j++) { const uint64_t s = (uint64_t)a[j] * b[i] + t[j] + c; t[j] = (uint32_t)s; c = s >> 32; }
+    uint64_t s = (uint64_t)t[8] + c;
+    t[8] = (uint32_t)s; t[9] = (uint32_t)(s >> 32);
+    const uint32_t m = t[0] * inv;
+    c = ((uint64_t)m * p[0] + t[0]) >> 32;
+    for (int j = 1; j < 8; j++) { const uint64_t s2 = (uint64_t)m * p[j] + t[j] + c; t[j - 1] = (uint32_t)s2; c = s2 >> 32; }
+    s = (uint64_t)t[8] + c;
+    t[7] = (uint32_t)s;
+    t[8] = t[9] + (uint32_t)(s >> 32);
+  }
+  bool ge = t[8] != 0;
+  if (!ge) { ge = true; for (int i = 7; i >= 0; --i) if (t[i] != p[i]) { ge = t[i] > p[i]; break; } }
+  if (ge) { uint64_t br = 0; for (int i = 0; i < 8; i++) { const uint64_t d = (uint64_t)t[i] - p[i] - br; t[i] = (uint32_t)d; br = (d >> 63) & 1; } }
+  memcpy(out, t, 32);
+}
 // x * 2^256 mod p by 256 modular doublings (host, set-up only)
 void to_montgomery_host(uint32_t x[8], const uint32_t p[8]) {
   for (int i = 0; i < 256; i++) { uint32_t y[8]; memcpy(y, x, 32); u256_add_mod(x, y, p); }
@@ -175,6 +195,9 @@ bool b3w_r1cs_host_build(const uint8_t *img, size_t len, const uint8_t prime_le[
   // idx0 | 0xFFFF << 16, then n | k << 8 | negative << 16.  The kernel evaluates a run from the tile's bit-packed elements.
   std::vector<uint32_t> ltdesc(2 * (size_t)ntiles), lrows, lterms;
   uint32_t max_lean_terms = 0;
+  std::vector<uint8_t> in_run(nwires, 0);                  // wires that stand in a bit run: bits of a recomposed word
+  std::vector<uint32_t> cur_ext;                           // outside wires of the tile emit_part is working on
+  uint32_t cur_tile = 0;
   auto pow2 = [&](uint16_t cid, bool &neg, uint32_t &k) {
     const long long c = coef_small[cid];
     if (c == B3W_R1CS_NOT_SMALL || c == 0) return false;
@@ -198,6 +221,10 @@ bool b3w_r1cs_host_build(const uint8_t *img, size_t len, const uint8_t prime_le[
         }
       }
       if (j - i >= 4) {
+        for (size_t q = i; q < j; q++) {
+          const uint32_t idx = part[q].first;
+          in_run[idx < T ? cur_tile * T + idx : cur_ext[idx - T]] = 1;
+        }
         lterms.push_back(part[i].first | 0xFFFF0000u);
         lterms.push_back((uint32_t)(j - i) | k0 << 8 | (neg ? 1u << 16 : 0u));
         i = j;
@@ -218,6 +245,7 @@ bool b3w_r1cs_host_build(const uint8_t *img, size_t len, const uint8_t prime_le[
       std::vector<uint32_t> ext(tile_ext[t].size());
       for (const auto &kv : tile_ext[t]) ext[kv.second] = kv.first;
       text.insert(text.end(), ext.begin(), ext.end());
+      cur_ext = ext; cur_tile = t;
       for (uint32_t k : tile_rows[t]) {
         const Row &r = rows[k];
         // booleanity:  A = {w: 1},  B = {wire 0: 1, w: -1} or {w: 1, wire 0: -1},  C = {}
@@ -248,7 +276,11 @@ bool b3w_r1cs_host_build(const uint8_t *img, size_t len, const uint8_t prime_le[
           }
           lean_n[part] = emit_part(terms_of_part);
         }
-        lrows.push_back(lean_off); lrows.push_back(lean_n[0] | (boolean ? 0x80000000u : 0u)); lrows.push_back(lean_n[1]);
+        // a row with a coefficient that is no small integer cannot be decided by the integer kernels: flagged (bit 30), so that they
+        // hand it to the deferred kernel without walking its terms (the O2 nova systems have one such row of 66 ... 133 terms)
+        bool not_small = false;
+        for (uint32_t x = 0; x < r.na + r.nb + r.nc; x++) not_small = not_small || coef_small[cids[r.off + x]] == B3W_R1CS_NOT_SMALL;
+        lrows.push_back(lean_off); lrows.push_back(lean_n[0] | (boolean ? 0x80000000u : not_small ? 0x40000000u : 0u)); lrows.push_back(lean_n[1]);
         lrows.push_back(boolean ? bool_idx : lean_n[2]);
       }
       ttdesc[2 * t + 1] = (uint32_t)tterms.size() - ttdesc[2 * t];
@@ -260,6 +292,115 @@ bool b3w_r1cs_host_build(const uint8_t *img, size_t len, const uint8_t prime_le[
     tterms.push_back(0);
     lterms.push_back(0); lterms.push_back(0);             // the lean kernel fetches up to two term words ahead,
     while (lterms.size() & 3) lterms.push_back(0);        // and stages whole uint4s
+  }
+  // ---- the STREAM program (b3w_r1cs_stream_kernel): the same tiles and the same row order, every row in one of four classes
+  //   B  booleanity                 (descriptor only, as in the lean rows)
+  //   T  TRUTH TABLE: a row over at most five distinct wires each of which is expected to hold a bit (a booleanity row of its own,
+  //      a place in a bit run, or the constant wire): whether it holds is a function of at most five bits, tabulated HERE with exact field arithmetic — any
+  //      coefficients — and looked up by the kernel from the elements' bits (87 % of the non-booleanity rows of blake3_compression:
+  //      the XOR gates (2a)(b) = a + b - out).  An element that turns out to be no bit defers the row to the field arithmetic.
+  //   D  always deferred            (a coefficient that is no small integer, or more than 256 words)
+  //   G  general: its lean words go to a flat list evaluated one WORD per lane (contributions added into per-row sums in LDS),
+  //      instead of one row per lane walking its words
+  std::vector<uint32_t> srows, sgdesc(4 * (size_t)ntiles), sgwords, sgmeta;
+  std::vector<unsigned long long> coef_zlim(coefs.size(), 0ull);      // an element times coefficient c stays below 2^55 while it is below zlim
+  uint32_t max_g_words = 0, max_g_rows = 0;
+  if (tiled) {
+    for (size_t i = 0; i < coefs.size(); i++) {
+      const long long c = coef_small[i];
+      if (c == B3W_R1CS_NOT_SMALL) continue;
+      const unsigned long long mag = c < 0 ? 0ull - (unsigned long long)c : (unsigned long long)c;
+      coef_zlim[i] = mag <= 1 ? 1ull << 55 : (1ull << 55) / mag;
+    }
+    uint32_t inv = P[0];                                   // Newton: p^-1 mod 2^32
+    for (int i = 0; i < 5; i++) inv *= 2u - P[0] * inv;
+    inv = 0u - inv;
+    const uint32_t one[8] = {1, 0, 0, 0, 0, 0, 0, 0};
+    auto boolean_wire = [&](const Row &r, uint32_t *w_out) {    // A = {w: 1},  B = {wire 0: 1, w: -1} or {w: 1, wire 0: -1},  C = {}
+      if (!(r.na == 1 && r.nb == 2 && r.nc == 0 && cids[r.off] == 0 && wires[r.off] != 0)) return false;
+      const uint32_t w = wires[r.off], w1 = wires[r.off + 1], w2 = wires[r.off + 2];
+      const uint16_t c1 = cids[r.off + 1], c2 = cids[r.off + 2];
+      const bool ok = (w1 == 0 && w2 == w && ((c1 == 0 && c2 == 1) || (c1 == 1 && c2 == 0))) ||
+                      (w2 == 0 && w1 == w && ((c2 == 0 && c1 == 1) || (c2 == 1 && c1 == 0)));
+      if (ok) *w_out = w;
+      return ok;
+    };
+    // wires expected to hold bits: a booleanity row of their own, or a place in a bit run (circom's XOR gate constrains its
+    // output only through the gate itself; the outputs are then recomposed into words).  A wrong guess costs time, not
+    // correctness: an element that is no bit defers its truth-table rows to the field arithmetic.
+    std::vector<uint8_t> is_bit(in_run);
+    is_bit[0] = 1;                                         // the constant wire: 1 in every witness (the kernels check it)
+    for (const Row &r : rows) { uint32_t w = 0; if (boolean_wire(r, &w)) is_bit[w] = 1; }
+    std::map<std::vector<uint32_t>, uint32_t> table_of;    // (wires' positions, coefficient ids, part lengths) -> truth table
+    for (uint32_t t = 0; t < ntiles; t++) {
+      const uint32_t gw0 = (uint32_t)sgwords.size();
+      uint32_t ng = 0;
+      auto lds_index = [&](uint32_t w) { return w / T == t ? w - t * T : T + tile_ext[t].at(w); };
+      for (uint32_t k : tile_rows[t]) {
+        const Row &r = rows[k];
+        const uint32_t nt = r.na + r.nb + r.nc;
+        uint32_t bw = 0;
+        if (boolean_wire(r, &bw)) { srows.insert(srows.end(), {0u, 0x80000000u | 1u, 2u, lds_index(bw)}); continue; }
+        bool not_small = false;
+        for (uint32_t x = 0; x < nt; x++) not_small = not_small || coef_small[cids[r.off + x]] == B3W_R1CS_NOT_SMALL;
+        // T: at most five distinct wires, all of them bits by their own constraints
+        std::vector<uint32_t> W;
+        bool all_bits = true;
+        for (uint32_t x = 0; x < nt && all_bits && W.size() <= 5; x++) {
+          const uint32_t w = wires[r.off + x];
+          all_bits = is_bit[w] != 0;
+          if (std::find(W.begin(), W.end(), w) == W.end()) W.push_back(w);
+        }
+        if (all_bits && W.size() <= 5 && nt <= 64) {
+          std::vector<uint32_t> key = {r.na, r.nb, r.nc};
+          for (uint32_t x = 0; x < nt; x++) {
+            key.push_back((uint32_t)(std::find(W.begin(), W.end(), wires[r.off + x]) - W.begin()));
+            key.push_back(cids[r.off + x]);
+          }
+          auto it = table_of.find(key);
+          if (it == table_of.end()) {
+            uint32_t table = 0;
+            for (uint32_t a = 0; a < (1u << W.size()); a++) {
+              uint32_t sum[3][8];
+              memset(sum, 0, sizeof sum);
+              uint32_t q = 0;
+              const uint32_t plen[3] = {r.na, r.nb, r.nc};
+              for (int part = 0; part < 3; part++)
+                for (uint32_t x = 0; x < plen[part]; x++, q++)
+                  if ((a >> key[3 + 2 * q]) & 1u) u256_add_mod(sum[part], coefs[cids[r.off + q]].data(), P);
+              uint32_t ab[8], cr[8];
+              mont_mul_host(ab, sum[0], sum[1], P, inv);    // A * B / R
+              mont_mul_host(cr, sum[2], one, P, inv);       // C / R
+              if (!memcmp(ab, cr, 32)) table |= 1u << a;
+            }
+            it = table_of.emplace(key, table).first;
+          }
+          uint32_t idx[5] = {0, 0, 0, 0, 0};
+          for (size_t j = 0; j < W.size(); j++) idx[j] = lds_index(W[j]);
+          srows.insert(srows.end(), {idx[0] | idx[1] << 16, 0x20000000u | (uint32_t)W.size() << 16 | idx[4], idx[2] | idx[3] << 16, it->second});
+          continue;
+        }
+        // the row's lean words (what emit_part made of it: the lean rows are in the same order)
+        const size_t lr = srows.size();                     // (= 4 * this row's number in lrows)
+        const uint32_t off = lrows[lr], n3[3] = {lrows[lr + 1] & 0x3FFFFFFFu, lrows[lr + 2], lrows[lr + 3]};
+        const uint32_t nw = n3[0] + n3[1] + n3[2];
+        if (not_small || nw > 256 || ng >= 0xFFFFFFu) { srows.insert(srows.end(), {0u, 0x40000000u, 0u, 0u}); continue; }
+        uint32_t q = off;
+        for (uint32_t part = 0; part < 3; part++)
+          for (uint32_t x = 0; x < n3[part]; x++, q++) {
+            const uint32_t w = lterms[q];
+            sgwords.push_back(w);
+            sgmeta.push_back(part | ng << 8);
+            if ((w >> 16) == 0xFFFFu) { sgwords.push_back(lterms[++q]); sgmeta.push_back(part | 4u | ng << 8); x++; }      // the run's second word
+          }
+        srows.insert(srows.end(), {ng, 0x10000000u, 0u, 0u});
+        ng++;
+      }
+      sgdesc[4 * t] = gw0; sgdesc[4 * t + 1] = (uint32_t)sgwords.size() - gw0; sgdesc[4 * t + 2] = ng; sgdesc[4 * t + 3] = 0;
+      max_g_words = std::max(max_g_words, sgdesc[4 * t + 1]);
+      max_g_rows = std::max(max_g_rows, ng);
+    }
+    sgwords.push_back(0); sgmeta.push_back(4u);            // (a lane reads the word behind its own)
   }
   std::vector<uint32_t> coefR(16 * coefs.size());           // per coefficient: plain, then Montgomery form
   for (size_t i = 0; i < coefs.size(); i++) {
@@ -283,5 +424,7 @@ bool b3w_r1cs_host_build(const uint8_t *img, size_t len, const uint8_t prime_le[
   H->tdesc = std::move(tdesc); H->ttdesc = std::move(ttdesc); H->text = std::move(text); H->trows = std::move(trows);
   H->trow_id = std::move(trow_id); H->trow_k = std::move(trow_k); H->tterms = std::move(tterms);
   H->ltdesc = std::move(ltdesc); H->lrows = std::move(lrows); H->lterms = std::move(lterms);
+  H->srows = std::move(srows); H->sgdesc = std::move(sgdesc); H->sgwords = std::move(sgwords); H->sgmeta = std::move(sgmeta);
+  H->coef_zlim = std::move(coef_zlim); H->max_g_words = max_g_words; H->max_g_rows = max_g_rows;
   return true;
 }

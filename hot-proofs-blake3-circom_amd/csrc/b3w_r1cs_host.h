@@ -23,6 +23,12 @@ struct B3wR1csHost {
   std::vector<long long> coef_small;
   std::vector<uint32_t> tdesc, ttdesc, text, trows, trow_id, trow_k, tterms;      // 32-byte tile kernel
   std::vector<uint32_t> ltdesc, lrows, lterms;                                    // lean kernel: its own rows and term stream (bit runs folded)
+  // stream kernel: one descriptor per tile row (same order as lrows; classes booleanity / truth table / always deferred / general),
+  // per tile {first general word, general words, general rows, 0}, the general rows' lean words and per word part | run-second-word
+  // << 2 | general row << 8; per coefficient the bound an element must stay below for its product to stay below 2^55
+  std::vector<uint32_t> srows, sgdesc, sgwords, sgmeta;
+  std::vector<unsigned long long> coef_zlim;
+  uint32_t max_g_words = 0, max_g_rows = 0;
 };
 
 // false: refused, H->error says why.  May throw std::bad_alloc / std::length_error on absurd sizes (the caller catches).

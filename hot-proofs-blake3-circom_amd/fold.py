@@ -17,6 +17,11 @@ import struct
 
 from .synthetic_key import CURVES
 
+# order of each curve's group = the field the circuit must be over for its linear relations to carry over to the points
+GROUP_ORDER = {"bn254_g1": 21888242871839275222246405745257275088548364400416034343698204186575808495617,
+               "pallas": 0x40000000000000000000000000000000224698fc0994a8dd8c46eb2100000001}
+GROUP_ORDER["vesta"] = GROUP_ORDER["pallas"]              # (older name of the same curve id, after the circuit's prime)
+
 
 def parse_r1cs(img):
     """-> (prime, n_wires, [(A, B, C)]) with A, B, C = {wire: coefficient}"""
@@ -42,9 +47,10 @@ def parse_r1cs(img):
             lc = {}
             for _ in range(n):
                 w = struct.unpack_from("<I", img, c)[0]
-                lc[w] = int.from_bytes(img[c + 4:c + 4 + fs], "little")
+                # a wire repeated inside one list ADDS its terms (the device parser, b3w_r1cs_host.cpp, keeps both)
+                lc[w] = (lc.get(w, 0) + int.from_bytes(img[c + 4:c + 4 + fs], "little")) % prime
                 c += 4 + fs
-            parts.append(lc)
+            parts.append({w: cf for w, cf in lc.items() if cf})
         cons.append(tuple(parts))
     return prime, nw, cons
 
@@ -197,6 +203,8 @@ def fold_generators(image, widths, first_slot, generators, curve):
     prime, n_wires, cons = parse_r1cs(image)
     if n_wires != len(widths):
         raise ValueError("the constraint system is not this circuit's")
+    if prime != GROUP_ORDER[curve]:
+        raise ValueError(f"the constraint system's prime is not the order of {curve}: its linear relations do not carry over to the points")
     widths = [int(w) for w in widths]
     bow_rows, bit_of = bit_of_word_relations(prime, n_wires, cons, widths)
     expr = eliminate(prime, n_wires, linear_relations(prime, cons) + bow_rows, widths, first_slot)

@@ -194,7 +194,10 @@ void b3w_r1cs_destroy(b3w_r1cs *r1cs);
  * (no allocation, no synchronisation, no memset nodes), so a caller may capture a loop of small batches into a hipGraph and
  * replay it (tests/test_gpu_graph_capture.py); b3w_batch_commit_device too once its scratch has grown to the batch size, and
  * b3w_r1cs_check_device after its first call on that stream (which allocates the stream's deferred-row scratch, a fixed
- * 27 MB for these systems, kept until b3w_r1cs_destroy): check once before capturing.  One check at a time per stream. */
+ * 27 MB for these systems): check once before capturing — a first check on a stream that is being captured is refused
+ * (B3W_E_BAD_ARGUMENT, b3w_last_error says why) instead of allocating inside the capture.  A system keeps the scratch of at most
+ * eight streams: when a ninth comes, the least recently used one is released once its last check has finished (streams seen
+ * under capture keep theirs until b3w_r1cs_destroy).  One check at a time per stream. */
 int32_t b3w_r1cs_check_device(b3w_ctx *ctx, const b3w_r1cs *r1cs, const uint8_t *d_bodies, uint32_t n, uint64_t pitch,
                               uint32_t *d_violations, uint32_t *d_first, void *stream);
 /* The same on the witnesses of the last b3w_batch_run; host arrays of n entries (host_first may be NULL). */

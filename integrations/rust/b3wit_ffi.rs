@@ -67,71 +67,28 @@ impl Drop for Calculator {
     fn drop(&mut self) { unsafe { b3w_destroy(self.ctx) } }
 }
 
-// ---- chained mode: what `main.rs:41-203` does one `prove_step` at a time, as one streamed pass ----------------
-// (same caveat: source only).  The fold driver would take `z_{i+1}` of every step from `public()` instead of
-// reading it back from each witness (blake3_circuit.rs:111-123), and hand each batch of bodies to its own
-// consumer (commitment, R1CS check) from the callback while the next batch is being written.
+// ---- declarations only (no wrappers: nothing here can be compiled or run in the build image, so the untested surface stays
+// at the one call the reference makes).  The chained pass a fold driver would stream (main.rs:41-203 as one pass) and the
+// witness commitment (main.rs:166-179 -> prove_step commits to W); parameter names, order and types are held against
+// include/b3wit.h by tests/test_rust_ffi_decls_cpu.py.
 #[link(name = "b3wit")]
 extern "C" {
-    fn b3w_chain_create(ctx: *mut c_void, preimage_len: u64, first_chunk: u64, n_chunks_local: u32, batch_steps: u32,
-                        ring: u32, with_parents: i32, out: *mut *mut c_void) -> i32;
-    fn b3w_chain_destroy(chain: *mut c_void);
-    fn b3w_chain_run_leaves(chain: *mut c_void, host_preimage: *const u8,
-                            consumer: Option<extern "C" fn(*mut c_void, *const u8, u64, u64, u32, *mut c_void)>,
-                            user: *mut c_void, stream: *mut c_void) -> i32;
-    fn b3w_chain_run_parents(chain: *mut c_void, d_all_chunk_cvs: *const u32,
-                             consumer: Option<extern "C" fn(*mut c_void, *const u8, u64, u64, u32, *mut c_void)>,
-                             user: *mut c_void, stream: *mut c_void) -> i32;
-    fn b3w_chain_info(chain: *const c_void, n_leaf: *mut u64, n_parent: *mut u64, n_chunks: *mut u64, path_len: *mut u32,
-                      placement: *mut i32) -> i32;
-    fn b3w_chain_outputs(chain: *mut c_void, host_public: *mut u32, host_status: *mut i32, host_root: *mut u32,
-                         stream: *mut c_void) -> i32;
-}
-
-/// All step witnesses of `preimage` on one GPU; returns (public outputs: 15 words per step, status per step, BLAKE3 root words).
-pub fn fold_preimage(calc: &mut Calculator, preimage: &[u8]) -> Result<(Vec<u32>, Vec<i32>, [u32; 8]), i32> {
-    let n_chunks = std::cmp::max(1, (preimage.len() as u64 + 1023) / 1024);
-    let mut chain = std::ptr::null_mut();
-    let rc = unsafe { b3w_chain_create(calc.ctx, preimage.len() as u64, 0, n_chunks as u32, 16384, 2, 1, &mut chain) };
-    if rc != 0 { return Err(rc); }
-    let null = std::ptr::null_mut();
-    let mut rc = unsafe { b3w_chain_run_leaves(chain, preimage.as_ptr(), None, null, null) };
-    if rc == 0 { rc = unsafe { b3w_chain_run_parents(chain, std::ptr::null(), None, null, null) }; }
-    let (mut nl, mut np, mut nc, mut pl, mut place) = (0u64, 0u64, 0u64, 0u32, 0i32);
-    unsafe { b3w_chain_info(chain, &mut nl, &mut np, &mut nc, &mut pl, &mut place) };
-    let rows = (nl + np) as usize;
-    let (mut public, mut status, mut root) = (vec![0u32; rows * 15], vec![0i32; rows], [0u32; 8]);
-    if rc == 0 { rc = unsafe { b3w_chain_outputs(chain, public.as_mut_ptr(), status.as_mut_ptr(), root.as_mut_ptr(), null) }; }
-    unsafe { b3w_chain_destroy(chain) };
-    if rc != 0 { Err(rc) } else { Ok((public, status, root)) }
-}
-
-// ---- the witness commitment arecibo computes right after `synthesize` (rust_fold/src/main.rs:166-179 -> prove_step commits
-// to W): Pedersen commitments on the device with the prover's own generators (same caveat: source only).  `commit_steps`
-// returns one affine point (x, y: 32-byte little-endian each; all zero = infinity) per input record WITHOUT producing the
-// witnesses — the bits the commitment needs are taken from the trace image each witness is expanded from.
-#[link(name = "b3wit")]
-extern "C" {
-    fn b3w_commit_key_create_ex(ctx: *mut c_void, curve: i32, first_slot: u32, host_generators: *const u8, window_bits: u32,
-                                out: *mut *mut c_void) -> i32;
-    fn b3w_commit_key_destroy(key: *mut c_void);
-    fn b3w_commit_records(ctx: *mut c_void, key: *const c_void, host_records: *const u32, n: u32, host_points: *mut u8,
-                          host_public: *mut u32, host_status: *mut i32) -> i32;
-}
-
-pub const CURVE_BN254_G1: i32 = 0;
-pub const CURVE_VESTA: i32 = 1;
-
-/// `generators`: 64 bytes per committed slot (slots `first_slot..witness_size`), affine, standard form.
-/// `records`: whole input records (32 words per nova step).  Returns (points: 64 bytes each, status per record).
-pub fn commit_steps(calc: &mut Calculator, curve: i32, first_slot: u32, generators: &[u8], records: &[u32], words_per_record: usize)
-    -> Result<(Vec<u8>, Vec<i32>), i32> {
-    let n = records.len() / words_per_record;
-    let mut key = std::ptr::null_mut();
-    let rc = unsafe { b3w_commit_key_create_ex(calc.ctx, curve, first_slot, generators.as_ptr(), 0, &mut key) };
-    if rc != 0 { return Err(rc); }
-    let (mut points, mut status) = (vec![0u8; n * 64], vec![0i32; n]);
-    let rc = unsafe { b3w_commit_records(calc.ctx, key, records.as_ptr(), n as u32, points.as_mut_ptr(), std::ptr::null_mut(), status.as_mut_ptr()) };
-    unsafe { b3w_commit_key_destroy(key) };
-    if rc != 0 { Err(rc) } else { Ok((points, status)) }
+    pub fn b3w_chain_create(ctx: *mut c_void, preimage_len: u64, first_chunk: u64, n_chunks_local: u32, batch_steps: u32,
+                            ring: u32, with_parents: i32, out: *mut *mut c_void) -> i32;
+    pub fn b3w_chain_destroy(chain: *mut c_void);
+    pub fn b3w_chain_run_leaves(chain: *mut c_void, host_preimage: *const u8,
+                                consumer: Option<extern "C" fn(*mut c_void, *const u8, u64, u64, u32, *mut c_void)>,
+                                user: *mut c_void, stream: *mut c_void) -> i32;
+    pub fn b3w_chain_run_parents(chain: *mut c_void, d_all_chunk_cvs: *const u32,
+                                 consumer: Option<extern "C" fn(*mut c_void, *const u8, u64, u64, u32, *mut c_void)>,
+                                 user: *mut c_void, stream: *mut c_void) -> i32;
+    pub fn b3w_chain_info(chain: *const c_void, n_leaf_steps: *mut u64, n_parent_steps: *mut u64, n_chunks: *mut u64, path_len: *mut u32,
+                          placement: *mut i32) -> i32;
+    pub fn b3w_chain_outputs(chain: *mut c_void, host_public: *mut u32, host_status: *mut i32, host_root: *mut u32,
+                             stream: *mut c_void) -> i32;
+    pub fn b3w_commit_key_create_ex(ctx: *mut c_void, curve: i32, first_slot: u32, host_generators: *const u8, window_bits: u32,
+                                    out: *mut *mut c_void) -> i32;
+    pub fn b3w_commit_key_destroy(key: *mut c_void);
+    pub fn b3w_commit_records(ctx: *mut c_void, key: *const c_void, host_records: *const u32, n: u32, host_points: *mut u8,
+                              host_public: *mut u32, host_status: *mut i32) -> i32;
 }

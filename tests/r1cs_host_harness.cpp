@@ -53,7 +53,8 @@ static bool indices_ok(const B3wR1csHost &H) {
         const uint32_t base = lean ? lt0 : tt0, cnt = lean ? ltn : ttn;
         const uint32_t off = rows[4 * r], ya = rows[4 * r + 1], nb = rows[4 * r + 2], w3 = rows[4 * r + 3];
         const bool boolean = ya >> 31;
-        const uint32_t na = ya & 0x7FFFFFFFu, nc = boolean ? 0u : w3;
+        const uint32_t na = ya & (lean ? 0x3FFFFFFFu : 0x7FFFFFFFu), nc = boolean ? 0u : w3;      // (lean rows: bit 30 = "always deferred")
+        if (lean && (ya & 0x40000000u)) CHECK(!boolean);
         if (boolean) CHECK(w3 < T + next);
         CHECK(off >= base && (uint64_t)off + na + nb + (boolean && !lean ? 0u : nc) <= (uint64_t)base + cnt);
         const uint32_t total = na + nb + nc;
@@ -72,6 +73,40 @@ static bool indices_ok(const B3wR1csHost &H) {
           }
         }
       }
+    }
+  }
+  // the stream kernel's program: every index it follows inside its array
+  CHECK(H.srows.size() == H.lrows.size() && H.sgdesc.size() == 4 * (size_t)H.ntiles && H.sgwords.size() == H.sgmeta.size());
+  CHECK(H.coef_zlim.size() == H.ncoef);
+  for (uint32_t t = 0; t < H.ntiles; t++) {
+    const uint32_t row0 = H.tdesc[4 * t], nrows = H.tdesc[4 * t + 1], next = H.tdesc[4 * t + 3];
+    const uint32_t gw0 = H.sgdesc[4 * t], gwn = H.sgdesc[4 * t + 1], ng = H.sgdesc[4 * t + 2];
+    CHECK((uint64_t)gw0 + gwn + 1 <= H.sgwords.size() && gwn <= H.max_g_words && ng <= H.max_g_rows);      // (a lane reads the word behind its own)
+    uint32_t seen_g = 0;
+    for (uint32_t r = row0; r < row0 + nrows; r++) {
+      const uint32_t x = H.srows[4 * r], y = H.srows[4 * r + 1], z = H.srows[4 * r + 2], w = H.srows[4 * r + 3];
+      if (y >> 31) { CHECK(w < T + next && (H.lrows[4 * r + 1] >> 31) && H.lrows[4 * r + 3] == w); continue; }
+      CHECK(!(H.lrows[4 * r + 1] >> 31));
+      if ((y >> 29) == 1u) {
+        const uint32_t k = (y >> 16) & 7u;
+        CHECK(k >= 1 && k <= 5);
+        const uint32_t idx[5] = {x & 0xFFFFu, x >> 16, z & 0xFFFFu, z >> 16, y & 0xFFFFu};
+        for (uint32_t j = 0; j < 5; j++) CHECK(j < k ? idx[j] < T + next : idx[j] == 0);
+      } else if ((y >> 28) == 1u) {
+        CHECK(x == seen_g && x < ng);
+        seen_g++;
+      } else CHECK(y == 0x40000000u);
+    }
+    CHECK(seen_g == ng);
+    for (uint32_t i = 0; i < gwn; i++) {
+      const uint32_t w = H.sgwords[gw0 + i], mt = H.sgmeta[gw0 + i];
+      CHECK((mt & 3u) < 3u && (mt >> 8) < ng);
+      if (mt & 4u) { CHECK(i > 0 && (H.sgwords[gw0 + i - 1] >> 16) == 0xFFFFu && !(H.sgmeta[gw0 + i - 1] & 4u)); continue; }
+      if ((w >> 16) == 0xFFFFu) {
+        CHECK(i + 1 < gwn && (H.sgmeta[gw0 + i + 1] & 4u) && (H.sgmeta[gw0 + i + 1] >> 8) == (mt >> 8));
+        const uint32_t w1 = H.sgwords[gw0 + i + 1], n = w1 & 0xFFu;
+        CHECK(n >= 4 && n <= 64 && (w & 0xFFFFu) + n <= T + next);
+      } else CHECK((w & 0xFFFFu) < T + next && (w >> 16) < H.ncoef);
     }
   }
   return true;
@@ -94,7 +129,12 @@ static bool same_sums(const B3wR1csHost &H, const uint8_t prime_le[32]) {
       const uint32_t g_off = H.rowdesc[4 * k], g_n[3] = {H.rowdesc[4 * k + 1], H.rowdesc[4 * k + 2], H.rowdesc[4 * k + 3]};
       const uint32_t off = H.lrows[4 * r], ya = H.lrows[4 * r + 1];
       const bool boolean = ya >> 31;
-      const uint32_t l_n[3] = {ya & 0x7FFFFFFFu, H.lrows[4 * r + 2], boolean ? 0u : H.lrows[4 * r + 3]};
+      const uint32_t l_n[3] = {ya & 0x3FFFFFFFu, H.lrows[4 * r + 2], boolean ? 0u : H.lrows[4 * r + 3]};
+      if (!boolean) {                                        // the "always deferred" flag = the row has a coefficient that is no small integer
+        bool not_small = false;
+        for (uint32_t x = 0; x < g_n[0] + g_n[1] + g_n[2]; x++) not_small = not_small || H.coef_small[H.cids[g_off + x]] == B3W_R1CS_NOT_SMALL;
+        CHECK(not_small == ((ya & 0x40000000u) != 0));
+      }
       if (boolean) CHECK(g_n[0] == 1 && g_n[1] == 2 && g_n[2] == 0 && wire_of(H.lrows[4 * r + 3]) == H.wires[g_off]);
       uint32_t gq = g_off, lq = off;
       for (int part = 0; part < 3; part++) {
@@ -115,6 +155,29 @@ static bool same_sums(const B3wR1csHost &H, const uint8_t prime_le[32]) {
           }
         }
         CHECK(want == got);
+      }
+    }
+    // the stream program's general rows: the words of row g, part by part, against the gather arrays
+    const uint32_t gw0 = H.sgdesc[4 * t], gwn = H.sgdesc[4 * t + 1], ng = H.sgdesc[4 * t + 2];
+    std::vector<uint64_t> sums(3 * (size_t)ng, 0);
+    for (uint32_t i = 0; i < gwn; i++) {
+      const uint32_t w = H.sgwords[gw0 + i], mt = H.sgmeta[gw0 + i];
+      if (mt & 4u) continue;
+      uint64_t v = 0;
+      if ((w >> 16) == 0xFFFFu) {
+        const uint32_t w1 = H.sgwords[gw0 + i + 1], n = w1 & 0xFFu, sh = (w1 >> 8) & 0xFFu;
+        for (uint32_t q = 0; q < n; q++) v += ((w1 >> 16) & 1u ? p_lo - (1ull << (sh + q)) : 1ull << (sh + q)) * z[wire_of((w & 0xFFFFu) + q)];
+      } else v = coef_lo(w >> 16) * z[wire_of(w & 0xFFFFu)];
+      sums[3 * (size_t)(mt >> 8) + (mt & 3u)] += v;
+    }
+    for (uint32_t r = row0; r < row0 + nrows; r++) {
+      if ((H.srows[4 * r + 1] >> 28) != 1u) continue;
+      const uint32_t g = H.srows[4 * r], k = H.trow_k[r];
+      uint32_t gq = H.rowdesc[4 * k];
+      for (int part = 0; part < 3; part++) {
+        uint64_t want = 0;
+        for (uint32_t x = 0; x < H.rowdesc[4 * k + 1 + part]; x++, gq++) want += coef_lo(H.cids[gq]) * z[H.wires[gq]];
+        CHECK(want == sums[3 * (size_t)g + part]);
       }
     }
   }

@@ -79,14 +79,15 @@ def rows_of_wire(sys_):
 
 
 def write_image(prime, nwires, constraints, npubout=0, npubin=0, nprvin=0):
-    """iden3 .r1cs v1 image of `constraints` = [(A, B, C)] with A, B, C = {wire: coefficient} (test systems)."""
+    """iden3 .r1cs v1 image of `constraints` = [(A, B, C)] with A, B, C = {wire: coefficient}, or a list of (wire, coefficient)
+    pairs where a test wants a wire repeated inside one list (test systems)."""
     import struct
     hdr = struct.pack("<I", 32) + prime.to_bytes(32, "little") + struct.pack("<IIIIQI", nwires, npubout, npubin, nprvin, nwires, len(constraints))
     body = bytearray()
     for parts in constraints:
         for lc in parts:
             body += struct.pack("<I", len(lc))
-            for w, c in sorted(lc.items()):
+            for w, c in (sorted(lc.items()) if isinstance(lc, dict) else lc):
                 body += struct.pack("<I", w) + (c % prime).to_bytes(32, "little")
     wmap = b"".join(struct.pack("<Q", i) for i in range(nwires))
     out = bytearray(b"r1cs" + struct.pack("<II", 1, 3))

@@ -54,3 +54,61 @@ def test_witness_and_checks_replay_from_a_graph():
         for q, (i, j) in enumerate(idx):
             assert np.array_equal(bodies[i, j].cpu().numpy(), want[q]), (round_, i, j)
     r1cs.close(); ctx.close()
+
+
+def test_first_check_on_a_capturing_stream_is_refused_not_allocated():
+    """the first constraint check on a stream allocates that stream's deferred-row scratch; inside a capture that would
+    break the capture — the call says so instead (and the capture goes on with what is allowed)."""
+    import torch
+    m = T.pkg()
+    dev = torch.device("cuda:0")
+    ctx = m.Context("compression", 0)
+    r1cs = m.R1cs(ctx)
+    n = 64
+    recs = torch.from_numpy(T.workloads().config2_compression(n).view(np.int32)).to(dev)
+    bodies = torch.zeros((n, ctx.body_bytes), dtype=torch.uint8, device=dev)
+    viol = torch.full((n,), -1, dtype=torch.int32, device=dev)
+    side = torch.cuda.Stream()
+    with torch.cuda.stream(side):
+        ctx.run_device(recs.data_ptr(), n, bodies.data_ptr(), 0, 0, 0, side.cuda_stream)          # (the witness kernel may be captured cold)
+    side.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side):
+        s = torch.cuda.current_stream().cuda_stream
+        ctx.run_device(recs.data_ptr(), n, bodies.data_ptr(), 0, 0, 0, s)
+        with pytest.raises(m.B3WError) as e:
+            r1cs.check_device(bodies.data_ptr(), n, 0, viol.data_ptr(), 0, s)
+        assert e.value.status == 100 and "before capturing" in str(e.value)
+    g.replay()
+    torch.cuda.synchronize()
+    r1cs.check_device(bodies.data_ptr(), n, 0, viol.data_ptr(), 0, 0)
+    torch.cuda.synchronize()
+    assert int(viol.abs().sum().item()) == 0
+    r1cs.close(); ctx.close()
+
+
+def test_scratch_of_short_lived_streams_is_bounded():
+    """a caller that cycles through streams: a constraint system keeps the deferred-row scratch of at most eight of them"""
+    import torch
+    m = T.pkg()
+    dev = torch.device("cuda:0")
+    ctx = m.Context("compression", 0)
+    r1cs = m.R1cs(ctx)
+    n = 64
+    recs = torch.from_numpy(T.workloads().config2_compression(n).view(np.int32)).to(dev)
+    bodies = torch.zeros((n, ctx.body_bytes), dtype=torch.uint8, device=dev)
+    ctx.run_device(recs.data_ptr(), n, bodies.data_ptr(), 0, 0, 0, 0)
+    torch.cuda.synchronize()
+    viol = torch.full((n,), -1, dtype=torch.int32, device=dev)
+    free = []
+    for k in range(24):
+        st = torch.cuda.Stream()
+        with torch.cuda.stream(st):
+            r1cs.check_device(bodies.data_ptr(), n, 0, viol.data_ptr(), 0, st.cuda_stream)
+        st.synchronize()
+        assert int(viol.abs().sum().item()) == 0
+        del st
+        free.append(torch.cuda.mem_get_info()[0])
+    # after the eighth stream the footprint stops growing (24 unbounded scratches would be 650 MB)
+    assert free[8] - free[-1] < (64 << 20), [f >> 20 for f in free]
+    r1cs.close(); ctx.close()

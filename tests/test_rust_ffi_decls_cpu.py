@@ -1,6 +1,7 @@
 """integrations/rust/b3wit_ffi.rs cannot be compiled here (no Rust toolchain), but its `extern "C"` declarations can be held
-against include/b3wit.h: every function the stub binds exists in the header with the same number of parameters, the same
-integer widths, pointer-ness and constness, and the same return type.  (the stub replaces
+against include/b3wit.h: every function the stub binds exists in the header with the same parameters IN THE SAME ORDER — same
+names (a swap of two u64 parameters would otherwise go unseen), the same integer widths, pointer-ness and constness — and the
+same return type.  (the stub replaces
 circom_scotia::calculate_witness at rust_fold/src/blake3_circuit.rs:305.)"""
 import os
 import re
@@ -77,13 +78,17 @@ def test_every_bound_function_matches_the_header():
     src = open(os.path.join(ROOT, "integrations", "rust", "b3wit_ffi.rs")).read()
     c = _c_decls()
     bound = re.findall(r"\bfn\s+(b3w_[a-z0-9_]+)\s*\((.*?)\)\s*(?:->\s*([A-Za-z0-9_]+))?\s*;", src, flags=re.S)
-    assert len(bound) >= 14
+    assert len(bound) >= 14 and {"b3w_calc_witness", "b3w_create", "b3w_chain_run_leaves"} <= {b[0] for b in bound}
     for name, args, ret in bound:
         assert name in c, f"{name} is not declared in include/b3wit.h"
         c_ret, c_args = c[name]
         assert _c_shape(c_ret) == (ret or "void"), (name, c_ret, ret)
-        rs_args = [a.split(":", 1)[1] for a in _split_args(" ".join(args.split()))]
+        rs_named = [a.split(":", 1) for a in _split_args(" ".join(args.split()))]
+        rs_args = [a[1] for a in rs_named]
         assert len(rs_args) == len(c_args), (name, rs_args, c_args)
+        # parameter names, position by position (C: the last identifier of the declarator)
+        c_names = [re.findall(r"[A-Za-z_][A-Za-z0-9_]*", re.sub(r"\[[^\]]*\]", "", ca))[-1] for ca in c_args]
+        assert [a[0].strip() for a in rs_named] == c_names, (name, [a[0].strip() for a in rs_named], c_names)
         for k, (ra, ca) in enumerate(zip(rs_args, c_args)):
             want, got = _c_shape(ca), _rs_shape(ra)
             if want == "fnptr":                                       # the callback's own parameters too
@@ -96,6 +101,13 @@ def test_every_bound_function_matches_the_header():
                 assert want.count("*") == got.count("*"), (name, k, ca, ra)
             else:
                 assert want == got, (name, k, ca, ra)
+
+
+def test_the_stub_stays_small():
+    """what cannot be compiled here stays declarations + the one safe wrapper the reference's call site needs"""
+    src = open(os.path.join(ROOT, "integrations", "rust", "b3wit_ffi.rs")).read()
+    assert len(re.findall(r"\bpub fn (?!b3w_)", src)) <= 3, "wrappers beyond Calculator::{new, calculate_witness} and fnv1a64"
+    assert len(src.splitlines()) <= 110
 
 
 def test_constants_match_the_header():

@@ -39,7 +39,7 @@ if mode == "rings":
         out["buffers"].append({"ring": i, "label": b.placement, "GBps": round(rate(b.ptr))})
     plain = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
     out["plain_torch_empty_GBps"] = round(rate(plain.data_ptr()))
-    out["stats"] = [int(x) for x in ctx.bodies_stats()]
+    out["stats"] = {k: int(v) for k, v in ctx.bodies_stats().items()}
     print(json.dumps(out), flush=True)
 else:
     rates, alive = [], []
