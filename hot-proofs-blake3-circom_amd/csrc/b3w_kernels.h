@@ -103,9 +103,9 @@ struct B3wR1csSystem {
   const uint16_t *g_cids;
   // the stream kernel's program (b3w_r1cs_host.h): row descriptors by class, per tile {first general word, words, rows, -}, the
   // general rows' words and meta words, per coefficient the bound an element must stay below
-  uint32_t max_g_words, max_g_rows;
+  uint32_t max_g_words, max_g_rows, smask_groups;
   const uint32_t *srows, *sgdesc, *sgwords, *sgmeta;
-  const unsigned long long *coef_zlim;
+  const unsigned long long *smask;                 // per tile x smask_groups: elements the tile's rows take for bits
 };
 #define B3W_R1CS_SLAB 8192u                                  // bodies per launch pair at most: bounds the scratch (64 MB at most)
 extern "C" size_t b3w_r1cs_scratch_bytes(const B3wR1csSystem *sys);

@@ -37,6 +37,7 @@
 // circuits is 98 % bits, so the check of a valid batch is gather-bound (L2/TA), not ALU-bound.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <mutex>
 #include "b3w_kernels.h"
@@ -711,6 +712,10 @@ __global__ __launch_bounds__(256) void b3w_r1cs_lean_kernel(const uint8_t *__res
 // compiler to wait on) into a ring of NBUF raw 32-byte tile images while the current tile is packed and its rows evaluated:
 //     wait (counted vmcnt: the NBUF - 1 younger tiles stay in flight) | barrier | pack raw -> 8-byte elements + bit words |
 //     barrier | issue the DMA of tile i + NBUF into the buffer just freed | rows of tile i
+// Measured (profiles/r03/r1cs_stream_*): ONE buffer and two 8-wave workgroups per CU beat deeper rings in one 16-wave workgroup
+// (0.77 against 0.98 ms per 4 096 compression bodies) — with a single buffer the next tile still travels while this one's rows
+// are evaluated, and two workgroups whose phases drift apart fill each other's barrier waits; the tile loads are non-temporal
+// (read once: -4 % compression, -12 % nova, whose outside-wire gathers then keep their L2 lines).
 // Word list, coefficients, row descriptors and the DMA geometry are per TILE, so they are fetched once per tile switch (one or
 // two per workgroup) instead of once per (body, tile): the steady-state loop has no global load at all — only the DMAs, the
 // deferred-row mask stores and (rarely) the violation atomics.  The outside wires of a tile are gathered by the same DMAs
@@ -741,34 +746,84 @@ __device__ __forceinline__ void vm_wait(uint32_t outstanding) {
     case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
     case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
     case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
-    default: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+    case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
+    case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
+    case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
+    case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
+    case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
+    case 11: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
+    default: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;      // (six DMAs per tile and wave at most, two tiles ahead)
   }
 }
 // workgroup barrier that leaves vector-memory operations (the DMAs) in flight: LDS traffic retired, then s_barrier
 __device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-#define B3W_R1CS_STREAM_THREADS 1024u
+// LDS-DMA with a scalar base: 16 bytes per lane from base + off (off < 4 GiB) into the wave's 1 KiB block at `lds_dst`
+__device__ __forceinline__ void glds16s(uint32_t lds_dst /* wave-uniform byte address */, const uint8_t *base /* wave-uniform */, uint32_t off /* per lane */,
+                                        bool nt = false /* wave-uniform: non-temporal (bytes read once) */) {
+  uint32_t keep;
+  const uint32_t dst = __builtin_amdgcn_readfirstlane(lds_dst);
+  if (nt)
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3 nt\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(off), "s"(dst), "s"(base) : "memory");
+  else
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "v"(off), "s"(dst), "s"(base) : "memory");
+}
 
-template <int NBUF>
-__global__ __launch_bounds__(1024) void b3w_r1cs_stream_kernel(const uint8_t *__restrict__ bodies, uint64_t pitch, uint32_t n, B3wR1csSystem S,
-                                                               unsigned long long *__restrict__ scratch, uint32_t block_words,
-                                                               uint32_t *__restrict__ violations, uint32_t *__restrict__ first, uint32_t dbg) {
+// Everything a wave does here costs every other wave of its SIMD four cycles per instruction, and the waves of one workgroup move in
+// lockstep from barrier to barrier (profiles/r03 stamps: sixteen waves at 340 instructions per unit were 5 400 cycles), so
+//   * the steady state is written for instruction count: wave-uniform values live in SGPRs (the wave number comes through
+//     readfirstlane), whole classes of rows are decided by masks instead of row by row, a wave runs only the code of the row classes
+//     it owns;
+//   * the workgroup size is a template parameter: WAVES = 8 (512 threads, two elements and up to four rows per lane) lets two or
+//     three workgroups share a CU (LDS permitting) — their phases drift apart, so one workgroup's barrier waits and LDS round trips are
+//     the other's issue slots, and each keeps its own DMAs in flight.
+// Row classes (host: b3w_r1cs_host.cpp, "the STREAM program"):
+//   * booleanity rows (64 % of all rows) and the bit-ness of every truth-table operand: the host's per-tile masks of "elements taken
+//     for bits" ANDed with the pack phase's "neither 0 nor 1" ballots — one scalar AND per 64 elements.  Only if that (or wire 0 not
+//     being 1) finds something does the tile take the row-by-row road (`anomaly`).
+//   * truth-table rows: the operands' low bits index the host's table.
+//   * general rows: one word per lane into the rows' sums (LDS atomics), verdict by the row's owner lane after a barrier.
+//   * always-deferred rows: their mask bits are the same for every body of the tile.
+template <int NBUF, int WAVES>
+__global__ __launch_bounds__(64 * WAVES, 4) void b3w_r1cs_stream_kernel(   // (second argument: waves per SIMD the register budget must allow — two 8-wave workgroups or one of 16)
+    const uint8_t *__restrict__ bodies, uint64_t pitch, uint32_t n, B3wR1csSystem S,
+                                                                     unsigned long long *__restrict__ scratch, uint32_t block_words,
+                                                                     uint32_t *__restrict__ violations, uint32_t *__restrict__ first, uint32_t dbg,
+                                                                     unsigned long long *__restrict__ stamps) {
+  constexpr uint32_t THREADS = 64u * WAVES;
+  constexpr int EG = 16 / WAVES;                           // groups of 64 tile elements a wave packs (1 or 2)
+  constexpr int RP = 32 / WAVES;                           // row passes at most (a tile has at most 2 048 rows)
+  constexpr int MB = 32 / WAVES;                           // tile DMA blocks (32 elements, 1 KiB) a wave issues
+  constexpr int XB = 16 / WAVES;                           // outside-wire DMA blocks a wave issues (at most 512 outside wires)
   extern __shared__ __align__(16) unsigned char smem[];
-  const uint32_t tid = threadIdx.x, wave = tid >> 6, lane = tid & 63u;
+  const uint32_t tid = threadIdx.x, lane = tid & 63u;
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);                  // (an SGPR: what depends on it alone is scalar code)
+  // diagnostic build only (B3W_R1CS_STAMPS=1): cycles per phase, summed over the units of workgroup 0, per wave
+  unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_prev = 0;
+  const bool stamping = stamps != nullptr && blockIdx.x == 0;
+#define B3W_STAMP(k) do { if (stamping) { const unsigned long long t_now = __builtin_amdgcn_s_memtime(); ph[k] += t_now - t_prev; t_prev = t_now; } } while (0)
   const uint32_t ext_cap = (S.max_ext + 32u) & ~31u;                               // outside wires, in whole DMA blocks of 32 (+ at least one spare element)
   const uint32_t raw_stride = (B3W_R1CS_TILE + ext_cap) * 32u;                     // one raw image: tile blocks, then outside-wire blocks
   unsigned long long *el = reinterpret_cast<unsigned long long *>(smem + (size_t)NBUF * raw_stride);
+  const uint32_t *el32 = reinterpret_cast<const uint32_t *>(el);
   unsigned long long *packed = el + B3W_R1CS_TILE + ext_cap;
   const uint32_t groups = ((B3W_R1CS_TILE + ext_cap + 63u) >> 6) + 1u;            // (one spare pair: a run reads its group and the next)
-  // general rows of the tile: per-row sums {A, B, C} and flags, the word list with its meta words; per coefficient {c, zlim}
+  // general rows of the tile: per-row sums {A, B, C} x {low, high} and flags, the word list with its meta words; the coefficients
   unsigned long long *gsum = packed + 2 * groups;
-  uint32_t *gflag = reinterpret_cast<uint32_t *>(gsum + 3u * S.max_g_rows);
+  uint32_t *gflag = reinterpret_cast<uint32_t *>(gsum + 6u * S.max_g_rows);
   uint32_t *gwords = gflag + ((S.max_g_rows + 1u) & ~1u);
   uint32_t *gmeta = gwords + ((S.max_g_words + 4u) & ~3u);
-  ulonglong2 *coef2 = reinterpret_cast<ulonglong2 *>(gmeta + ((S.max_g_words + 4u) & ~3u));
-  for (uint32_t k = tid; k < S.ncoef; k += B3W_R1CS_STREAM_THREADS) coef2[k] = make_ulonglong2((unsigned long long)S.coef_small[k], S.coef_zlim[k]);
+  long long *lcoef = reinterpret_cast<long long *>(gmeta + ((S.max_g_words + 4u) & ~3u));
+  uint32_t *lanom = reinterpret_cast<uint32_t *>(lcoef + S.ncoef);                 // != 0: something the masks cannot vouch for in this (body, tile)
+  const __int128 lim = (__int128)1 << 63;
+  for (uint32_t k = tid; k < S.ncoef; k += THREADS) lcoef[k] = S.coef_small[k];
   if (tid < 2) packed[2 * (groups - 1) + tid] = 0ull;                              // the spare pair
   const uint32_t lds0 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)smem);
+  const uint32_t nxg = (ext_cap + 63u) >> 6;                                       // groups of outside wires (at most 8: the LAST waves pack them)
+  const uint32_t xg = (uint32_t)WAVES - 1u - wave;                                 // ... this wave's, if it has one
+  const bool packs_ext = xg < nxg;
 
   const uint64_t U = (uint64_t)S.ntiles * n;                                       // units, tile-major: u = tile * n + body
   uint64_t u = U * blockIdx.x / gridDim.x;
@@ -776,89 +831,134 @@ __global__ __launch_bounds__(1024) void b3w_r1cs_stream_kernel(const uint8_t *__
   while (u < u_end) {
     const uint32_t tile = (uint32_t)(u / n), b_lo = (uint32_t)(u - (uint64_t)tile * n);
     const uint32_t m = (uint32_t)((u_end - u) < (uint64_t)(n - b_lo) ? (u_end - u) : (uint64_t)(n - b_lo));      // bodies of this tile
-    // ---- per tile: descriptors, the term list, the DMA geometry.  (No DMA is in flight here: the pipeline below drains.)
+    // ---- per tile: descriptors, the word list, the masks, the DMA geometry.  (No DMA is in flight here: the pipeline below drains.)
     lds_barrier();                                                                 // the previous tile's rows are done with the word list
     const uint4 td = reinterpret_cast<const uint4 *>(S.tiles)[tile];               // {first row, rows, first outside wire, outside wires}
     const uint4 gd = reinterpret_cast<const uint4 *>(S.sgdesc)[tile];              // {first general word, general words, general rows, -}
     const uint32_t t0 = tile * B3W_R1CS_TILE;
     const uint32_t n_local = S.nwires - t0 < B3W_R1CS_TILE ? S.nwires - t0 : B3W_R1CS_TILE;
-    const uint32_t r0 = td.x + tid, r1 = td.x + tid + B3W_R1CS_STREAM_THREADS;
     const uint4 *srows = reinterpret_cast<const uint4 *>(S.srows);
-    const uint4 pre0 = r0 < td.x + td.y ? srows[r0] : make_uint4(0, 0, 0, 0);
-    const uint4 pre1 = r1 < td.x + td.y ? srows[r1] : make_uint4(0, 0, 0, 0);
-    const uint32_t rid0 = r0 < td.x + td.y ? S.row_id[r0] : 0u, rid1 = r1 < td.x + td.y ? S.row_id[r1] : 0u;
-    for (uint32_t k = tid; k < gd.y + 1u; k += B3W_R1CS_STREAM_THREADS) {           // (+ 1: a lane reads the word behind its own)
+    // this lane's rows (pass p: row p * THREADS + tid) and what the wave owns in each pass (wave-uniform: SGPRs)
+    uint4 pre[RP];
+    uint32_t rid[RP];
+    bool has_rows[RP], has_tt[RP], has_gen[RP];
+    unsigned long long dmask[RP];                            // always-deferred rows: the same mask bits for every body
+#pragma unroll
+    for (int p = 0; p < RP; p++) {
+      const uint32_t r = (uint32_t)p * THREADS + tid;
+      pre[p] = r < td.y ? srows[td.x + r] : make_uint4(0, 0, 0, 0);
+      rid[p] = r < td.y ? S.row_id[td.x + r] : 0u;
+      has_rows[p] = (uint32_t)p * THREADS + wave * 64u < td.y && !(p > 0 && (dbg & 16u));
+      has_tt[p] = __ballot((pre[p].y >> 29) == 1u) != 0ull;
+      has_gen[p] = __ballot((pre[p].y >> 28) == 1u) != 0ull;
+      dmask[p] = __ballot((pre[p].y >> 30) == 1u);
+    }
+    unsigned long long mbit[EG];                             // elements of this wave's groups the tile's rows take for bits
+#pragma unroll
+    for (int q = 0; q < EG; q++) mbit[q] = S.smask[(size_t)tile * S.smask_groups + wave + (uint32_t)q * WAVES];
+    const unsigned long long xbit = packs_ext ? S.smask[(size_t)tile * S.smask_groups + 16u + xg] : 0ull;
+    for (uint32_t k = tid; k < gd.y + 1u; k += THREADS) {    // (+ 1: a lane reads the word behind its own)
       gwords[k] = S.sgwords[gd.x + k];
       gmeta[k] = S.sgmeta[gd.x + k];
     }
-    // DMA blocks of this wave: tile blocks `wave` and `wave + 16` (a block = 32 elements = 1 KiB), outside-wire block `wave`.
+    if (tid == 0) *lanom = 0u;
+    // DMA blocks of this wave: tile blocks wave + q * WAVES (a block = 32 elements = 1 KiB), outside-wire blocks likewise.
     // Lane l of a block fetches the low (l < 32) or high half of element 32 * block + (l & 31).
     const uint32_t half = lane >> 5, ein = lane & 31u;
     const uint32_t nblk = (n_local + 31u) >> 5, nxblk = (td.w + 31u) >> 5;
-    const bool has0 = wave < nblk, has1 = wave + 16u < nblk, hasx = wave < nxblk;
-    const uint32_t e0 = wave * 32u + ein, e1 = (wave + 16u) * 32u + ein, ex = wave * 32u + ein;
-    const uint64_t off0 = (uint64_t)(t0 + (e0 < n_local ? e0 : n_local - 1u)) * 32u + half * 16u;
-    const uint64_t off1 = (uint64_t)(t0 + (e1 < n_local ? e1 : n_local - 1u)) * 32u + half * 16u;
-    const uint64_t offx = (uint64_t)(hasx ? S.ext[td.z + (ex < td.w ? ex : td.w - 1u)] : 0u) * 32u + half * 16u;
-    const uint32_t per_tile = (has0 ? 1u : 0u) + (has1 ? 1u : 0u) + (hasx ? 1u : 0u);          // this wave's DMAs per tile (wave-uniform)
+    uint32_t off[MB], offx[XB];
+    uint32_t per_tile = 0;                                   // this wave's DMAs per tile
+#pragma unroll
+    for (int q = 0; q < MB; q++) {
+      const uint32_t e = (wave + (uint32_t)q * WAVES) * 32u + ein;
+      off[q] = (t0 + (e < n_local ? e : n_local - 1u)) * 32u + half * 16u;
+      per_tile += wave + (uint32_t)q * WAVES < nblk ? 1u : 0u;
+    }
+#pragma unroll
+    for (int q = 0; q < XB; q++) {
+      const uint32_t blk = wave + (uint32_t)q * WAVES, e = blk * 32u + ein;
+      offx[q] = (blk < nxblk ? S.ext[td.z + (e < td.w ? e : td.w - 1u)] : 0u) * 32u + half * 16u;
+      per_tile += blk < nxblk ? 1u : 0u;
+    }
     auto issue = [&](const uint32_t body_index, const uint32_t buf) {
-      const uint8_t *body = bodies + (uint64_t)body_index * pitch;
+      const uint8_t *body = bodies + (uint64_t)body_index * pitch;                 // (scalar arithmetic)
       const uint32_t dst = lds0 + buf * raw_stride;
-      if (dbg & 12u) return;
-      if (has0) glds16(dst + wave * 1024u, body + off0);
-      if (has1) glds16(dst + (wave + 16u) * 1024u, body + off1);
-      if (hasx) glds16(dst + B3W_R1CS_TILE * 32u + wave * 1024u, body + offx);
+      if ((dbg & 4u) || ((dbg & 8u) && body_index != b_lo)) return;       // (8: only the first body of the tile is ever staged)
+#pragma unroll
+      for (int q = 0; q < MB; q++)
+        if (wave + (uint32_t)q * WAVES < nblk) glds16s(dst + (wave + (uint32_t)q * WAVES) * 1024u, body, off[q], !(dbg & 64u));      // tile bytes are read once: non-temporal
+#pragma unroll
+      for (int q = 0; q < XB; q++)
+        if (wave + (uint32_t)q * WAVES < nxblk) glds16s(dst + B3W_R1CS_TILE * 32u + (wave + (uint32_t)q * WAVES) * 1024u, body, offx[q], (dbg & 128u) != 0u);
     };
     // every global load above has landed before the first DMA is issued: inside the pipeline the compiler must find nothing of
     // its own to wait for (a wait it placed at a first use in the loop would drain the DMAs on every iteration)
-    asm volatile("" :: "v"(pre0.x), "v"(pre0.y), "v"(pre0.z), "v"(pre0.w), "v"(pre1.x), "v"(pre1.y), "v"(pre1.z), "v"(pre1.w), "v"(rid0), "v"(rid1),
-                 "v"(off0), "v"(off1), "v"(offx));
+#pragma unroll
+    for (int p = 0; p < RP; p++) asm volatile("" :: "v"(pre[p].x), "v"(pre[p].y), "v"(pre[p].z), "v"(pre[p].w), "v"(rid[p]));
+#pragma unroll
+    for (int q = 0; q < MB; q++) asm volatile("" :: "v"(off[q]));
+#pragma unroll
+    for (int q = 0; q < XB; q++) asm volatile("" :: "v"(offx[q]));
+#pragma unroll
+    for (int q = 0; q < EG; q++) asm volatile("" :: "s"((uint32_t)mbit[q]), "s"((uint32_t)(mbit[q] >> 32)));
+    asm volatile("" :: "s"((uint32_t)xbit), "s"((uint32_t)(xbit >> 32)));
     lds_barrier();                                                                 // the word list (and, the first time, the coefficients) in place
-    if (dbg & 8u) {                                        // experiment: ONE body's tile staged, its rows evaluated m times
-      const uint8_t *body = bodies + (uint64_t)b_lo * pitch;
-      if (has0) glds16(lds0 + wave * 1024u, body + off0);
-      if (has1) glds16(lds0 + (wave + 16u) * 1024u, body + off1);
-      if (hasx) glds16(lds0 + B3W_R1CS_TILE * 32u + wave * 1024u, body + offx);
-    }
     for (uint32_t k = 0; k < (uint32_t)NBUF && k < m; k++) issue(b_lo + k, k);
     for (uint32_t i = 0; i < m; i++) {
       const uint32_t b = b_lo + i, buf = i % (uint32_t)NBUF;
       const uint32_t ahead = m - 1u - i < (uint32_t)NBUF - 1u ? m - 1u - i : (uint32_t)NBUF - 1u;      // younger tiles in flight
+      if (stamping) t_prev = __builtin_amdgcn_s_memtime();
       vm_wait(per_tile * ahead);                                                   // this wave's pieces of tile i have landed
+      B3W_STAMP(0);
       lds_barrier();                                                               // ... and everyone's; the rows of tile i - 1 are done with el
-      // ---- pack: 32-byte elements -> 8 bytes (bit 63 = "not below 2^63") + two bit words per 64 elements
-      const unsigned char *raw = smem + (size_t)((dbg & 8u) ? 0u : buf) * raw_stride;
-      if (!(dbg & 2u) && !((dbg & 8u) && i > 0)) {
-        const uint4 lo = *reinterpret_cast<const uint4 *>(raw + (tid >> 5) * 1024u + (tid & 31u) * 16u);
-        const uint4 hi = *reinterpret_cast<const uint4 *>(raw + (tid >> 5) * 1024u + 512u + (tid & 31u) * 16u);
-        const unsigned long long z = tid < n_local ? lean_pack(lo, hi) : 0ull;
-        el[tid] = z;
-        const unsigned long long ones = __ballot(z == 1ull), bads = __ballot(z > 1ull);       // the wave holds elements 64 w ... 64 w + 63
-        if (lane == 0) { packed[2 * wave] = ones; packed[2 * wave + 1] = bads; }
-      }
-      if (!(dbg & 2u) && !((dbg & 8u) && i > 0) && wave * 64u < ext_cap) {                                   // (whole waves, for the ballots)
-        const uint32_t j = tid;                                                    // outside wire j of the tile
-        unsigned long long z = 0ull;
-        if (j < td.w) {
-          const uint4 lo = *reinterpret_cast<const uint4 *>(raw + B3W_R1CS_TILE * 32u + (j >> 5) * 1024u + (j & 31u) * 16u);
-          const uint4 hi = *reinterpret_cast<const uint4 *>(raw + B3W_R1CS_TILE * 32u + (j >> 5) * 1024u + 512u + (j & 31u) * 16u);
-          z = lean_pack(lo, hi);
+      B3W_STAMP(1);
+      // ---- pack: 32-byte elements -> 8 bytes (bit 63 = "not below 2^63") + two bit words per 64 elements; anything the masks
+      // take for a bit and that is none raises the anomaly flag, and so does wire 0 not being 1
+      const unsigned char *raw = smem + (size_t)buf * raw_stride;
+      const bool do_pack = !(dbg & 2u) && !((dbg & 8u) && i > 0);                  // (8: ... and packed once; its rows are evaluated m times)
+      if (do_pack) {
+        bool flag = false;
+#pragma unroll
+        for (int q = 0; q < EG; q++) {
+          const uint32_t g = wave + (uint32_t)q * WAVES, e = g * 64u + lane;       // the wave holds elements 64 g ... 64 g + 63
+          const uint4 lo = *reinterpret_cast<const uint4 *>(raw + (e >> 5) * 1024u + (e & 31u) * 16u);
+          const uint4 hi = *reinterpret_cast<const uint4 *>(raw + (e >> 5) * 1024u + 512u + (e & 31u) * 16u);
+          const unsigned long long z = e < n_local ? lean_pack(lo, hi) : 0ull;
+          el[e] = z;
+          const unsigned long long ones = __ballot(z == 1ull), bads = __ballot(z > 1ull);
+          if (lane == 0) { packed[2 * g] = ones; packed[2 * g + 1] = bads; }
+          flag = flag || (bads & mbit[q]) != 0ull || (tile == 0 && g == 0 && !(ones & 1ull));        // (wire 0 is element 0 of tile 0)
         }
-        if (j < ext_cap) el[B3W_R1CS_TILE + j] = z;
-        const unsigned long long ones = __ballot(z == 1ull), bads = __ballot(z > 1ull);
-        const uint32_t g = (B3W_R1CS_TILE >> 6) + wave;
-        if (lane == 0 && g < groups - 1u) { packed[2 * g] = ones; packed[2 * g + 1] = bads; }
+        if (packs_ext) {                                                           // (whole waves, for the ballots)
+          const uint32_t j = xg * 64u + lane;                                      // outside wire j of the tile
+          unsigned long long z = 0ull;
+          if (j < td.w) {
+            const uint4 lo = *reinterpret_cast<const uint4 *>(raw + B3W_R1CS_TILE * 32u + (j >> 5) * 1024u + (j & 31u) * 16u);
+            const uint4 hi = *reinterpret_cast<const uint4 *>(raw + B3W_R1CS_TILE * 32u + (j >> 5) * 1024u + 512u + (j & 31u) * 16u);
+            z = lean_pack(lo, hi);
+          }
+          if (j < ext_cap) el[B3W_R1CS_TILE + j] = z;
+          const unsigned long long ones = __ballot(z == 1ull), bads = __ballot(z > 1ull);
+          if (lane == 0) { packed[2 * (16u + xg)] = ones; packed[2 * (16u + xg) + 1] = bads; }
+          flag = flag || (bads & xbit) != 0ull || (tile != 0 && xg == 0 && !(ones & 1ull));          // (outside wire 0 of every other tile)
+        }
+        if (flag && lane == 0) *lanom = 1u;
       }
-      for (uint32_t k = tid; k < 3u * gd.z; k += B3W_R1CS_STREAM_THREADS) gsum[k] = 0ull;       // (the previous unit's owner lanes read theirs before barrier one)
-      for (uint32_t k = tid; k < gd.z; k += B3W_R1CS_STREAM_THREADS) gflag[k] = 0u;
+      B3W_STAMP(2);
+      for (uint32_t k = tid; k < 6u * gd.z; k += THREADS) gsum[k] = 0ull;          // (the previous unit's owner lanes read theirs before barrier one)
+      for (uint32_t k = tid; k < gd.z; k += THREADS) gflag[k] = 0u;
       lds_barrier();                                                               // raw image read out (lgkmcnt retired), el / packed in place
       if (i + (uint32_t)NBUF < m) issue(b + (uint32_t)NBUF, buf);                  // the freed buffer takes tile i + NBUF
+      B3W_STAMP(3);
       if (dbg & 1u) continue;
-      // ---- general rows, one WORD per lane: chunk c of 64 words goes to wave c mod 16; a lane adds coefficient * element (or the
-      // value of a bit run) into its row's part sum.  |product| < 2^55 by the coefficient's element bound, a row has at most 256
-      // words: the 64-bit sums are exact.
+      const bool anomaly = __builtin_amdgcn_readfirstlane(*lanom) != 0u;
+      // ---- general rows, one WORD per lane: chunk c of 64 words goes to wave c mod WAVES; a lane adds coefficient * element (or
+      // the value of a bit run) into its row's part sum.  A part sum is two 64-bit counters {low, high} worth low + high * 2^52: a
+      // contribution below 2^54 goes to `low` whole, a larger one (the dyadic row scaling of the O2 systems makes 2^30 * word) is cut
+      // at bit 52 — products stay below 2^103 (the lean kernel's bound) and a row has at most 256 words, so no counter overflows
+      // and the sum is exact.
       if (!(dbg & 32u))
-        for (uint32_t c0 = wave * 64u; c0 < gd.y; c0 += B3W_R1CS_STREAM_THREADS) {
+        for (uint32_t c0 = wave * 64u; c0 < gd.y; c0 += THREADS) {
           const uint32_t iw = c0 + lane;
           const bool act = iw < gd.y;
           const uint32_t w = gwords[act ? iw : 0u], w1 = gwords[act ? iw + 1u : 0u], mt = gmeta[act ? iw : 0u];
@@ -866,9 +966,11 @@ __global__ __launch_bounds__(1024) void b3w_r1cs_stream_kernel(const uint8_t *__
           const bool is_run = act && !second && (w >> 16) == 0xFFFFu;
           const bool is_term = act && !second && !is_run;
           const unsigned long long z = el[is_term ? w & 0xFFFFu : 0u];
-          const ulonglong2 cz = coef2[is_term ? w >> 16 : 0u];
-          bool ok = z < cz.y;                                // (a coefficient that is no small integer has bound 0; bit 63 = "not below 2^63")
-          unsigned long long v = cz.x * z;                   // two's complement: the low 64 bits of c * z are the product when it fits
+          const long long c = lcoef[is_term ? w >> 16 : 0u];
+          const unsigned long long mag = c < 0 ? 0ull - (unsigned long long)c : (unsigned long long)c;
+          unsigned long long lo = mag * z, hi = __umul64hi(mag, z);
+          bool neg = c < 0;
+          bool ok = c != B3W_R1CS_NOT_SMALL && !(z >> 63) && hi < (1ull << 39);      // (bit 63 of an element = "not below 2^63")
           if (__ballot(is_run) != 0ull) {
             if (is_run) {
               const uint32_t idx0 = w & 0xFFFFu, len = w1 & 0xFFu, sh = (w1 >> 8) & 0xFFu;
@@ -877,62 +979,84 @@ __global__ __launch_bounds__(1024) void b3w_r1cs_stream_kernel(const uint8_t *__
               const unsigned long long mask = len == 64u ? ~0ull : (1ull << len) - 1ull;
               const unsigned long long ones = ((one_lo >> r) | (r ? one_hi << (64u - r) : 0ull)) & mask;
               const unsigned long long bads = ((bad_lo >> r) | (r ? bad_hi << (64u - r) : 0ull)) & mask;
-              ok = bads == 0ull && sh + len <= 55u;          // (an element of the run that is no bit; a run that could pass 2^55)
-              const unsigned long long val = ones << (sh & 63u);
-              v = (w1 >> 16) & 1u ? 0ull - val : val;
+              ok = bads == 0ull;                             // (an element of the run that is no bit)
+              lo = ones << (sh & 63u); hi = 0ull;            // (below 2^62: the host checks sh + len)
+              neg = (w1 >> 16) & 1u;
             }
           }
           if (is_term || is_run) {
             const uint32_t g = mt >> 8;
-            if (ok) atomicAdd(&gsum[3u * g + (mt & 3u)], v);
-            else atomicOr(&gflag[g], 1u);
+            unsigned long long *sum = gsum + 6u * g + 2u * (mt & 3u);
+            if (!ok) atomicOr(&gflag[g], 1u);
+            else if (hi == 0ull && lo < (1ull << 54)) atomicAdd(sum, neg ? 0ull - lo : lo);
+            else {                                           // cut at bit 52: value = low + high * 2^52, low in [0, 2^52)
+              __int128 v = (__int128)(((unsigned __int128)hi << 64) | lo);
+              if (neg) v = -v;
+              atomicAdd(sum, (unsigned long long)v & ((1ull << 52) - 1ull));
+              atomicAdd(sum + 1, (unsigned long long)(long long)(v >> 52));
+            }
           }
         }
-      // ---- one row per lane: booleanity and truth-table rows are decided here, general rows once their sums are complete
-      const bool w0_is_one = el[tile == 0 ? 0 : B3W_R1CS_TILE] == 1ull;            // (outside wire 0 of every other tile)
-      const uint32_t passes = td.y > B3W_R1CS_STREAM_THREADS && !(dbg & 16u) ? 2u : 1u;
-      uint32_t verdict = 0;                                  // bit `it`: deferred, bit 2 + `it`: violated (the passes' verdicts, in a register)
-      for (uint32_t it = 0; it < passes; it++) {
-        const uint4 d = it ? pre1 : pre0;
-        const bool in = td.x + tid + B3W_R1CS_STREAM_THREADS * it < td.x + td.y;
-        bool defer = false, bad = false;
-        if (in && (d.y >> 31)) {                             // booleanity  z * (1 - z) = 0: is the element 0 or 1
-          if (w0_is_one) bad = el[d.w] > 1ull;               // (an element of 2^63 or more is no bit)
-          else defer = true;                                 // (wire 0 is not 1: nothing here means what it should — field arithmetic)
-        } else if (in && (d.y & 0x40000000u)) {
-          defer = true;                                      // a coefficient that is no small integer, or a very long row
+      B3W_STAMP(4);
+      // ---- this wave's own rows.  Usual road: the masks have vouched for every bit, so booleanity rows hold, and a truth-table row
+      // is its table indexed by the operands' low bits.  Anomaly road: row by row, with the bit-ness of every operand looked at.
+      uint32_t verdict = 0;                                  // bit p: row of pass p deferred, bit 8 + p: violated
+      auto table_row = [&](const uint4 d) {
+        const uint32_t k = (d.y >> 16) & 7u;
+        const uint32_t a = (el32[2u * (d.x & 0xFFFFu)] & 1u) | (el32[2u * (d.x >> 16)] & 1u) << 1 | (el32[2u * (d.z & 0xFFFFu)] & 1u) << 2 |
+                           (el32[2u * (d.z >> 16)] & 1u) << 3 | (el32[2u * (d.y & 0xFFFFu)] & 1u) << 4;      // (unused positions name element 0: masked)
+        return (d.y >> 29) == 1u && !((d.w >> (a & ((1u << k) - 1u))) & 1u);
+      };
+      auto careful_row = [&](const uint4 d, bool *defer, bool *bad) {
+        const bool w0_is_one = el[tile == 0 ? 0 : B3W_R1CS_TILE] == 1ull;
+        if (d.y >> 31) {                                     // booleanity  z * (1 - z) = 0: is the element 0 or 1
+          if (w0_is_one) *bad = el[d.w] > 1ull;              // (an element of 2^63 or more is no bit)
+          else *defer = true;                                // (wire 0 is not 1: nothing here means what it should — field arithmetic)
         }
-        if (__ballot(in && (d.y >> 29) == 1u) != 0ull) {     // truth-table rows (whole waves of them: the rows are sorted by shape)
-          if (in && (d.y >> 29) == 1u) {
-            const uint32_t k = (d.y >> 16) & 7u;
-            const unsigned long long z0 = el[d.x & 0xFFFFu], z1 = el[d.x >> 16], z2 = el[d.z & 0xFFFFu], z3 = el[d.z >> 16], z4 = el[d.y & 0xFFFFu];
-            const unsigned long long nonbit = (z0 | (k > 1 ? z1 : 0ull) | (k > 2 ? z2 : 0ull) | (k > 3 ? z3 : 0ull) | (k > 4 ? z4 : 0ull)) >> 1;
-            const uint32_t a = ((uint32_t)z0 & 1u) | ((uint32_t)z1 & 1u) << 1 | ((uint32_t)z2 & 1u) << 2 | ((uint32_t)z3 & 1u) << 3 | ((uint32_t)z4 & 1u) << 4;
-            // (unused positions name element 0 and the host's table does not depend on their bits)
-            defer = nonbit != 0ull;
-            bad = !defer && !((d.w >> (a & ((1u << k) - 1u))) & 1u);
-          }
+        if ((d.y >> 29) == 1u) {
+          const uint32_t k = (d.y >> 16) & 7u;
+          const unsigned long long z0 = el[d.x & 0xFFFFu], z1 = el[d.x >> 16], z2 = el[d.z & 0xFFFFu], z3 = el[d.z >> 16], z4 = el[d.y & 0xFFFFu];
+          const unsigned long long nonbit = (z0 | (k > 1 ? z1 : 0ull) | (k > 2 ? z2 : 0ull) | (k > 3 ? z3 : 0ull) | (k > 4 ? z4 : 0ull)) >> 1;
+          const uint32_t a = ((uint32_t)z0 & 1u) | ((uint32_t)z1 & 1u) << 1 | ((uint32_t)z2 & 1u) << 2 | ((uint32_t)z3 & 1u) << 3 | ((uint32_t)z4 & 1u) << 4;
+          *defer = nonbit != 0ull || !w0_is_one;
+          *bad = !*defer && !((d.w >> (a & ((1u << k) - 1u))) & 1u);
         }
-        verdict |= (defer ? 1u : 0u) << it | (bad ? 4u : 0u) << it;
+      };
+#pragma unroll
+      for (int p = 0; p < RP; p++) {
+        if (!has_rows[p]) continue;
+        if (!anomaly) {
+          if (has_tt[p] && table_row(pre[p])) verdict |= 0x100u << p;
+        } else {
+          bool defer = false, bad = false;
+          careful_row(pre[p], &defer, &bad);                 // (a lane without a row holds an all-zero descriptor: no class)
+          verdict |= (defer ? 1u : 0u) << p | (bad ? 0x100u : 0u) << p;
+        }
       }
+      B3W_STAMP(5);
       lds_barrier();                                                               // every word's contribution is in its row's sums
+      B3W_STAMP(6);
+      if (tid == 0) *lanom = 0u;                                                   // (everyone has read it; the next unit's pack comes after a barrier)
       unsigned long long *block = scratch + ((size_t)b * S.ntiles + tile) * block_words;
       uint32_t nbad = 0, low = 0xFFFFFFFFu;
-      for (uint32_t it = 0; it < passes; it++) {
-        const uint4 d = it ? pre1 : pre0;
-        const bool in = td.x + tid + B3W_R1CS_STREAM_THREADS * it < td.x + td.y;
-        bool defer = (verdict >> it) & 1u, bad = (verdict >> (2u + it)) & 1u;
-        const bool general = in && (d.y >> 28) == 1u;
-        if (__ballot(general) != 0ull) {
-          if (general) {
-            const long long A = (long long)gsum[3u * d.x], B = (long long)gsum[3u * d.x + 1u], C = (long long)gsum[3u * d.x + 2u];
-            defer = gflag[d.x] != 0u || (dbg & 32u) != 0u;
-            bad = !defer && (__int128)A * (__int128)B != (__int128)C;      // |A * B - C| < 2^127 < p: "= 0 mod p" is "= 0"
+#pragma unroll
+      for (int p = 0; p < RP; p++) {
+        if (!has_rows[p]) continue;
+        const uint4 d = pre[p];
+        bool defer = (verdict >> p) & 1u, bad = (verdict >> (8 + p)) & 1u;
+        if (has_gen[p]) {
+          if ((d.y >> 28) == 1u) {
+            const unsigned long long *sum = gsum + 6u * d.x;
+            const __int128 A = (__int128)(long long)sum[0] + ((__int128)(long long)sum[1] << 52);
+            const __int128 B = (__int128)(long long)sum[2] + ((__int128)(long long)sum[3] << 52);
+            const __int128 C = (__int128)(long long)sum[4] + ((__int128)(long long)sum[5] << 52);
+            defer = gflag[d.x] != 0u || (dbg & 32u) != 0u || !(A < lim && A > -lim && B < lim && B > -lim);
+            bad = !defer && A * B != C;                      // |A * B - C| < 2^127 < p: "= 0 mod p" is "= 0"
           }
         }
-        if (bad) { nbad++; low = min(low, it ? rid1 : rid0); }
-        const unsigned long long mask = __ballot(defer);
-        if (lane == 0 && B3W_R1CS_STREAM_THREADS * it + wave * 64u < td.y) block[1 + 16u * it + wave] = mask;
+        if (bad) { nbad++; low = min(low, rid[p]); }
+        const unsigned long long mask = (has_gen[p] || anomaly ? __ballot(defer) : 0ull) | dmask[p];
+        if (lane == 0) block[1 + (uint32_t)p * WAVES + wave] = mask;               // (word (row - first) / 64)
       }
       if (__ballot(nbad != 0) != 0ull) {                   // (rare: a body that violates something)
 #pragma unroll
@@ -945,9 +1069,13 @@ __global__ __launch_bounds__(1024) void b3w_r1cs_stream_kernel(const uint8_t *__
           if (first) atomicMin(&first[b], low);
         }
       }
+      B3W_STAMP(7);
     }
     u += m;
   }
+  if (stamping && lane == 0)
+    for (int k = 0; k < 8; k++) stamps[wave * 8 + k] = ph[k];
+#undef B3W_STAMP
 }
 
 // the rows the lean kernel left: one WAVE per (body, tile), almost all of which leave on their first load.  A wave, not the
@@ -1153,8 +1281,8 @@ static inline size_t stream_smem(const B3wR1csSystem *sys, int nbuf) {
   const uint32_t ext_cap = (sys->max_ext + 32u) & ~31u;
   const uint32_t groups = ((B3W_R1CS_TILE + ext_cap + 63u) >> 6) + 1u;
   return (size_t)nbuf * (B3W_R1CS_TILE + ext_cap) * 32u + (size_t)(B3W_R1CS_TILE + ext_cap) * 8u + (size_t)groups * 16u +
-         (size_t)sys->max_g_rows * 24u + (size_t)((sys->max_g_rows + 1u) & ~1u) * 4u + 2u * (size_t)((sys->max_g_words + 4u) & ~3u) * 4u +
-         (size_t)sys->ncoef * 16u;
+         (size_t)sys->max_g_rows * 48u + (size_t)((sys->max_g_rows + 1u) & ~1u) * 4u + 2u * (size_t)((sys->max_g_words + 4u) & ~3u) * 4u +
+         (size_t)sys->ncoef * 8u + 16u;
 }
 
 // 0 = launched; -6 = this system does not fit the stream kernel (the caller takes the lean pair)
@@ -1163,18 +1291,23 @@ extern "C" int b3w_launch_r1cs_stream(const uint8_t *d_bodies, uint32_t n, uint6
   if (!n || !sys->ntiles) return 0;
   if (!d_scratch) return -5;
   static const int env_nbuf = getenv("B3W_R1CS_NBUF") ? atoi(getenv("B3W_R1CS_NBUF")) : 0;
+  static const int env_waves = getenv("B3W_R1CS_WAVES") ? atoi(getenv("B3W_R1CS_WAVES")) : 0;
+  static const int env_wgs = getenv("B3W_R1CS_WGS") ? atoi(getenv("B3W_R1CS_WGS")) : 0;         // workgroups per CU
   static const int env_grid = getenv("B3W_R1CS_GRID") ? atoi(getenv("B3W_R1CS_GRID")) : 0;
-  static const uint32_t env_dbg = getenv("B3W_R1CS_DBG") ? (uint32_t)atoi(getenv("B3W_R1CS_DBG")) : 0u;     // experiments: 1 no rows, 2 no pack, 4 no DMA, 8 one body staged once per tile and re-evaluated, 16 no second row pass, 32 booleanity rows only
-  if (sys->max_tile_rows > 2u * B3W_R1CS_STREAM_THREADS || sys->max_ext > 480u) return -6;
+  static const uint32_t env_dbg = getenv("B3W_R1CS_DBG") ? (uint32_t)atoi(getenv("B3W_R1CS_DBG")) : 0u;     // experiments: 1 no rows, 2 no pack, 4 no DMA, 8 one body per tile staged and evaluated over and over, 16 first row pass only, 32 no general words, 64 tile loads without nt, 128 outside-wire loads nt
+  if (sys->max_tile_rows > 2048u || sys->max_ext > 480u) return -6;
   int dev = 0;
   hipError_t e = hipGetDevice(&dev);
   if (e != hipSuccess) return (int)e;
-  struct PerDevice { int cus = 0, lds = 0; bool attr[4] = {false, false, false, false}; };
+  // the shapes: {raw buffers, waves per workgroup}; the default is the first that fits
+  struct Shape { int nbuf, waves; const void *fn; };
+  static const Shape shapes[] = {
+      {1, 8, reinterpret_cast<const void *>(&b3w_r1cs_stream_kernel<1, 8>)},   {2, 8, reinterpret_cast<const void *>(&b3w_r1cs_stream_kernel<2, 8>)},
+      {2, 16, reinterpret_cast<const void *>(&b3w_r1cs_stream_kernel<2, 16>)}, {3, 16, reinterpret_cast<const void *>(&b3w_r1cs_stream_kernel<3, 16>)}};
+  struct PerDevice { int cus = 0, lds = 0; bool attr[8] = {false, false, false, false, false, false, false, false}; };
   static PerDevice per[64];
   static std::mutex mu;
-  int nbuf = 0;
-  size_t smem = 0;
-  int cus = 0;
+  int pick = -1, cus = 0, lds = 0;
   {
     std::lock_guard<std::mutex> lock(mu);
     PerDevice &pd = per[dev & 63];
@@ -1183,36 +1316,57 @@ extern "C" int b3w_launch_r1cs_stream(const uint8_t *d_bodies, uint32_t n, uint6
       if ((e = hipDeviceGetAttribute(&pd.lds, hipDeviceAttributeMaxSharedMemoryPerBlock, dev)) != hipSuccess) return (int)e;
       if (pd.lds < 160 * 1024) pd.lds = 64 * 1024;         // (gfx950: 160 KB per workgroup; anything else: be modest)
     }
-    for (int nb : {3, 2}) {
-      if (env_nbuf && nb != env_nbuf) continue;
-      if (stream_smem(sys, nb) <= (size_t)pd.lds) { nbuf = nb; break; }
+    for (int k = 0; k < (int)(sizeof shapes / sizeof shapes[0]) && pick < 0; k++) {
+      if ((env_nbuf && shapes[k].nbuf != env_nbuf) || (env_waves && shapes[k].waves != env_waves)) continue;
+      if (stream_smem(sys, shapes[k].nbuf) <= (size_t)pd.lds) pick = k;
     }
-    if (!nbuf) return -6;
-    smem = stream_smem(sys, nbuf);
-    if (!pd.attr[nbuf]) {
-      const void *fn = nbuf == 3 ? reinterpret_cast<const void *>(&b3w_r1cs_stream_kernel<3>) : reinterpret_cast<const void *>(&b3w_r1cs_stream_kernel<2>);
-      if ((e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, pd.lds)) != hipSuccess) return (int)e;
-      pd.attr[nbuf] = true;
+    if (pick < 0) return -6;
+    if (!pd.attr[pick]) {
+      if ((e = hipFuncSetAttribute(shapes[pick].fn, hipFuncAttributeMaxDynamicSharedMemorySize, pd.lds)) != hipSuccess) return (int)e;
+      pd.attr[pick] = true;
     }
-    cus = pd.cus;
+    cus = pd.cus; lds = pd.lds;
   }
+  const size_t smem = stream_smem(sys, shapes[pick].nbuf);
+  // workgroups per CU: what the LDS holds, and sixteen waves (the kernels are built for four waves per SIMD: 128 VGPRs)
+  int wgs = (int)((size_t)lds / smem);
+  if (wgs > 16 / shapes[pick].waves) wgs = 16 / shapes[pick].waves;
+  if (env_wgs > 0) wgs = env_wgs;
+  if (wgs < 1) wgs = 1;
   e = (hipError_t)r1cs_init_results(d_violations, d_first, n, stream);
   if (e != hipSuccess) return (int)e;
+  // diagnostics (B3W_R1CS_STAMPS=1): per-phase cycle sums of workgroup 0, printed after every launch (synchronises: not for timing runs)
+  static const bool want_stamps = getenv("B3W_R1CS_STAMPS") && atoi(getenv("B3W_R1CS_STAMPS"));
+  static unsigned long long *d_stamps = nullptr;
+  if (want_stamps && !d_stamps && hipMalloc((void **)&d_stamps, 16 * 8 * 8) != hipSuccess) d_stamps = nullptr;
   const uint32_t bw = lean_block_words(sys);
   const uint32_t slab = lean_slab(sys);
   for (uint32_t b0 = 0; b0 < n; b0 += slab) {
     const uint32_t nb = n - b0 < slab ? n - b0 : slab;
     const uint64_t units = (uint64_t)nb * sys->ntiles;
-    uint32_t grid = env_grid > 0 ? (uint32_t)env_grid : (uint32_t)cus;       // one persistent workgroup per CU
+    uint32_t grid = env_grid > 0 ? (uint32_t)env_grid : (uint32_t)(cus * wgs);     // persistent workgroups
     if (grid > units) grid = (uint32_t)units;
-    if (nbuf == 3)
-      hipLaunchKernelGGL((b3w_r1cs_stream_kernel<3>), dim3(grid), dim3(B3W_R1CS_STREAM_THREADS), smem, stream, d_bodies + (uint64_t)b0 * pitch, pitch, nb,
-                         *sys, d_scratch, bw, d_violations + b0, d_first ? d_first + b0 : nullptr, env_dbg);
-    else
-      hipLaunchKernelGGL((b3w_r1cs_stream_kernel<2>), dim3(grid), dim3(B3W_R1CS_STREAM_THREADS), smem, stream, d_bodies + (uint64_t)b0 * pitch, pitch, nb,
-                         *sys, d_scratch, bw, d_violations + b0, d_first ? d_first + b0 : nullptr, env_dbg);
-    e = hipGetLastError();
+    void *args[] = {(void *)&d_bodies, (void *)&pitch, (void *)&nb, (void *)sys, (void *)&d_scratch, (void *)&bw, (void *)&d_violations, (void *)&d_first,
+                    (void *)&env_dbg, (void *)&d_stamps};
+    const uint8_t *bodies0 = d_bodies + (uint64_t)b0 * pitch;
+    uint32_t *viol0 = d_violations + b0, *first0 = d_first ? d_first + b0 : nullptr;
+    args[0] = (void *)&bodies0; args[6] = (void *)&viol0; args[7] = (void *)&first0;
+    e = hipLaunchKernel(shapes[pick].fn, dim3(grid), dim3(64u * (uint32_t)shapes[pick].waves), args, smem, stream);
     if (e != hipSuccess) return (int)e;
+    if (d_stamps) {
+      unsigned long long h[128];
+      if (hipStreamSynchronize(stream) == hipSuccess && hipMemcpy(h, d_stamps, sizeof h, hipMemcpyDeviceToHost) == hipSuccess) {
+        const double un = (double)(units / grid);
+        static const char *name[8] = {"dma-wait", "barrierA", "pack", "barrierB+issue", "words", "own-rows", "barrierC", "finish"};
+        fprintf(stderr, "b3w_r1cs_stream stamps (cycles per unit, workgroup 0 of %u, %d waves, %d buffers, %g units):\n", grid, shapes[pick].waves,
+                shapes[pick].nbuf, un);
+        for (int k = 0; k < 8; k++) {
+          fprintf(stderr, "  %-15s", name[k]);
+          for (int w = 0; w < shapes[pick].waves; w++) fprintf(stderr, " %5.0f", (double)h[w * 8 + k] / un);
+          fprintf(stderr, "\n");
+        }
+      }
+    }
     if (env_dbg) continue;                                 // (an experiment that skips phases leaves no valid masks behind)
     const dim3 dgrid(((nb + 7) / 8) * 8 * sys->ntiles);
     hipLaunchKernelGGL(b3w_r1cs_deferred_kernel, dgrid, dim3(64), 0, stream, d_bodies + (uint64_t)b0 * pitch, pitch, nb, *sys, d_scratch, bw,
@@ -1222,4 +1376,3 @@ extern "C" int b3w_launch_r1cs_stream(const uint8_t *d_bodies, uint32_t n, uint6
   }
   return 0;
 }
-

@@ -305,6 +305,10 @@ bool b3w_r1cs_host_build(const uint8_t *img, size_t len, const uint8_t prime_le[
   std::vector<uint32_t> srows, sgdesc(4 * (size_t)ntiles), sgwords, sgmeta;
   std::vector<unsigned long long> coef_zlim(coefs.size(), 0ull);      // an element times coefficient c stays below 2^55 while it is below zlim
   uint32_t max_g_words = 0, max_g_rows = 0;
+  // per tile and group of 64 LDS elements: the elements a booleanity or truth-table row of the tile takes for bits.  While none of
+  // them is anything else (and wire 0 is 1) the kernel decides those rows without looking at them one by one.
+  const uint32_t smask_groups = (T + ((max_ext + 32u) & ~31u) + 63u) >> 6;
+  std::vector<unsigned long long> smask((size_t)ntiles * smask_groups, 0ull);
   if (tiled) {
     for (size_t i = 0; i < coefs.size(); i++) {
       const long long c = coef_small[i];
@@ -340,7 +344,8 @@ bool b3w_r1cs_host_build(const uint8_t *img, size_t len, const uint8_t prime_le[
         const Row &r = rows[k];
         const uint32_t nt = r.na + r.nb + r.nc;
         uint32_t bw = 0;
-        if (boolean_wire(r, &bw)) { srows.insert(srows.end(), {0u, 0x80000000u | 1u, 2u, lds_index(bw)}); continue; }
+        auto must_be_bit = [&](uint32_t idx) { smask[(size_t)t * smask_groups + (idx >> 6)] |= 1ull << (idx & 63u); };
+        if (boolean_wire(r, &bw)) { must_be_bit(lds_index(bw)); srows.insert(srows.end(), {0u, 0x80000000u | 1u, 2u, lds_index(bw)}); continue; }
         bool not_small = false;
         for (uint32_t x = 0; x < nt; x++) not_small = not_small || coef_small[cids[r.off + x]] == B3W_R1CS_NOT_SMALL;
         // T: at most five distinct wires, all of them bits by their own constraints
@@ -376,7 +381,7 @@ bool b3w_r1cs_host_build(const uint8_t *img, size_t len, const uint8_t prime_le[
             it = table_of.emplace(key, table).first;
           }
           uint32_t idx[5] = {0, 0, 0, 0, 0};
-          for (size_t j = 0; j < W.size(); j++) idx[j] = lds_index(W[j]);
+          for (size_t j = 0; j < W.size(); j++) { idx[j] = lds_index(W[j]); must_be_bit(idx[j]); }
           srows.insert(srows.end(), {idx[0] | idx[1] << 16, 0x20000000u | (uint32_t)W.size() << 16 | idx[4], idx[2] | idx[3] << 16, it->second});
           continue;
         }
@@ -426,5 +431,6 @@ bool b3w_r1cs_host_build(const uint8_t *img, size_t len, const uint8_t prime_le[
   H->ltdesc = std::move(ltdesc); H->lrows = std::move(lrows); H->lterms = std::move(lterms);
   H->srows = std::move(srows); H->sgdesc = std::move(sgdesc); H->sgwords = std::move(sgwords); H->sgmeta = std::move(sgmeta);
   H->coef_zlim = std::move(coef_zlim); H->max_g_words = max_g_words; H->max_g_rows = max_g_rows;
+  H->smask = std::move(smask); H->smask_groups = smask_groups;
   return true;
 }

@@ -29,6 +29,8 @@ struct B3wR1csHost {
   std::vector<uint32_t> srows, sgdesc, sgwords, sgmeta;
   std::vector<unsigned long long> coef_zlim;
   uint32_t max_g_words = 0, max_g_rows = 0;
+  std::vector<unsigned long long> smask;          // per tile x smask_groups: LDS elements the tile's booleanity / truth-table rows take for bits
+  uint32_t smask_groups = 0;
 };
 
 // false: refused, H->error says why.  May throw std::bad_alloc / std::length_error on absurd sizes (the caller catches).

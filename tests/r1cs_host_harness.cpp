@@ -78,6 +78,7 @@ static bool indices_ok(const B3wR1csHost &H) {
   // the stream kernel's program: every index it follows inside its array
   CHECK(H.srows.size() == H.lrows.size() && H.sgdesc.size() == 4 * (size_t)H.ntiles && H.sgwords.size() == H.sgmeta.size());
   CHECK(H.coef_zlim.size() == H.ncoef);
+  CHECK(H.smask_groups == (T + ((H.max_ext + 32u) & ~31u) + 63u) / 64u && H.smask.size() == (size_t)H.ntiles * H.smask_groups);
   for (uint32_t t = 0; t < H.ntiles; t++) {
     const uint32_t row0 = H.tdesc[4 * t], nrows = H.tdesc[4 * t + 1], next = H.tdesc[4 * t + 3];
     const uint32_t gw0 = H.sgdesc[4 * t], gwn = H.sgdesc[4 * t + 1], ng = H.sgdesc[4 * t + 2];
@@ -85,13 +86,14 @@ static bool indices_ok(const B3wR1csHost &H) {
     uint32_t seen_g = 0;
     for (uint32_t r = row0; r < row0 + nrows; r++) {
       const uint32_t x = H.srows[4 * r], y = H.srows[4 * r + 1], z = H.srows[4 * r + 2], w = H.srows[4 * r + 3];
-      if (y >> 31) { CHECK(w < T + next && (H.lrows[4 * r + 1] >> 31) && H.lrows[4 * r + 3] == w); continue; }
+      auto masked = [&](uint32_t idx) { return (H.smask[(size_t)t * H.smask_groups + (idx >> 6)] >> (idx & 63u)) & 1ull; };
+      if (y >> 31) { CHECK(w < T + next && (H.lrows[4 * r + 1] >> 31) && H.lrows[4 * r + 3] == w && masked(w)); continue; }
       CHECK(!(H.lrows[4 * r + 1] >> 31));
       if ((y >> 29) == 1u) {
         const uint32_t k = (y >> 16) & 7u;
         CHECK(k >= 1 && k <= 5);
         const uint32_t idx[5] = {x & 0xFFFFu, x >> 16, z & 0xFFFFu, z >> 16, y & 0xFFFFu};
-        for (uint32_t j = 0; j < 5; j++) CHECK(j < k ? idx[j] < T + next : idx[j] == 0);
+        for (uint32_t j = 0; j < 5; j++) CHECK(j < k ? idx[j] < T + next && masked(idx[j]) : idx[j] == 0);
       } else if ((y >> 28) == 1u) {
         CHECK(x == seen_g && x < ng);
         seen_g++;

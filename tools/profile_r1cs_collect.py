@@ -1,12 +1,12 @@
 #!/usr/bin/env python3
 """tools/profile_r1cs_collect.py [round] — distil gpurun_out/prof_r1cs/ (tools/profile_r1cs.sh) into
 profiles/rNN/r1cs_check_<circuit>_{kernel_stats.csv, pmc_FETCH_SIZE.csv} and profiles/rNN/r1cs_check.json: per check, the
-lean and the deferred kernel's average durations, the HBM bytes fetched (FETCH_SIZE in KiB, doubled: on gfx950 the counter
+stream (or lean) and the deferred kernel's average durations, the HBM bytes fetched (FETCH_SIZE in KiB, doubled: on gfx950 the counter
 reports half of a wide coalesced read stream — /opt/skills/guides/MI355X_MICROARCH.md, HBM section) against the body bytes."""
 import csv, glob, json, os, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-rnd = sys.argv[1] if len(sys.argv) > 1 else "r02"
+rnd = sys.argv[1] if len(sys.argv) > 1 else "r03"
 src = os.path.join(ROOT, "gpurun_out", "prof_r1cs")
 dst = os.path.join(ROOT, "profiles", rnd)
 os.makedirs(dst, exist_ok=True)
@@ -25,7 +25,8 @@ for c in ("compression", "nova_vesta"):
     with open(os.path.join(dst, f"r1cs_check_{c}_kernel_stats.csv"), "w") as f:
         w = csv.DictWriter(f, fieldnames=rows[0].keys(), quoting=csv.QUOTE_NONNUMERIC)
         w.writeheader(); w.writerows(rows)
-    avg = {("lean" if "lean" in r["Name"] else "deferred" if "deferred" in r["Name"] else "init"): float(r["AverageNs"]) for r in rows}
+    kind = lambda name: "stream" if "stream" in name else "lean" if "lean" in name else "deferred" if "deferred" in name else "init"
+    avg = {kind(r["Name"]): float(r["AverageNs"]) for r in rows}
     pm = [r for r in csv.DictReader(open(find(f"fetch_{c}", "*counter_collection.csv")))
           if r["Counter_Name"] == "FETCH_SIZE" and "b3w_r1cs" in r["Kernel_Name"]]
     with open(os.path.join(dst, f"r1cs_check_{c}_pmc_FETCH_SIZE.csv"), "w") as f:
@@ -33,7 +34,7 @@ for c in ("compression", "nova_vesta"):
         w.writeheader(); w.writerows(pm)
     per = {}
     for r in pm:
-        k = "lean" if "lean" in r["Kernel_Name"] else "deferred" if "deferred" in r["Kernel_Name"] else "init"
+        k = kind(r["Kernel_Name"])
         per.setdefault(k, []).append(float(r["Counter_Value"]))
     fetched = {k: 2.0 * 1024.0 * sum(v) / len(v) for k, v in per.items()}
     body_bytes = N * BODY[c]

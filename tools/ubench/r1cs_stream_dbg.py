@@ -1,5 +1,5 @@
 """r1cs_stream_dbg.py [circuit] [n] — where the stream formulation of the constraint check spends its time: the same check with
-phases switched off (B3W_R1CS_DBG: 1 no rows, 2 no pack, 4 no DMA), ring depths and grid sizes, each in a child process (the
+phases switched off (B3W_R1CS_DBG: 1 no rows, 2 no pack, 4 no DMA, 16 no second row pass, 32 no general words), ring depths and grid sizes, each in a child process (the
 switches are read once per process).  Times only; verdicts are meaningless with a phase missing."""
 import importlib, os, subprocess, sys
 if len(sys.argv) > 1 and sys.argv[1] == "--child":
@@ -27,12 +27,13 @@ if len(sys.argv) > 1 and sys.argv[1] == "--child":
     sys.exit(0)
 circuit = sys.argv[1] if len(sys.argv) > 1 else "compression"
 n = sys.argv[2] if len(sys.argv) > 2 else "4096"
-for label, env in (("lean pair (GATHER=3)", {"B3W_R1CS_GATHER": "3"}), ("stream, 3 buffers", {}), ("stream, 2 buffers", {"B3W_R1CS_NBUF": "2"}),
-                   ("  no rows", {"B3W_R1CS_DBG": "1"}), ("  no rows, no pack (DMA + barriers)", {"B3W_R1CS_DBG": "3"}),
-                   ("  no DMA (pack + rows)", {"B3W_R1CS_DBG": "4"}), ("  no DMA, no pack (rows)", {"B3W_R1CS_DBG": "6"}),
-                   ("  nothing (loop + barriers)", {"B3W_R1CS_DBG": "7"}),
-                   ("  rows on valid data, staged once (8)", {"B3W_R1CS_DBG": "8"}), ("  ... without the second row pass (24)", {"B3W_R1CS_DBG": "24"}),
-                   ("  ... booleanity rows only (40)", {"B3W_R1CS_DBG": "40"}), ("  ... booleanity only, no second pass (56)", {"B3W_R1CS_DBG": "56"}),
-                   ("  all but the second row pass (16)", {"B3W_R1CS_DBG": "16"}), ("  all but the general rows (32)", {"B3W_R1CS_DBG": "32"})):
+E = lambda **kw: {"B3W_R1CS_" + k.upper(): str(v) for k, v in kw.items()}
+for label, env in (("lean pair (GATHER=3)", {"B3W_R1CS_GATHER": "3"}), ("stream, default shape", {}),
+                   ("stream 8 waves, 1 buffer, 2 WG/CU", E(waves=8, nbuf=1, wgs=2)), ("... tile loads without nt (64)", E(waves=8, nbuf=1, wgs=2, dbg=64)),
+                   ("... outside-wire loads nt too (128)", E(waves=8, nbuf=1, wgs=2, dbg=128)),
+                   ("stream 8 waves, 1 buffer, 1 WG/CU", E(waves=8, nbuf=1, wgs=1)), ("stream 8 waves, 2 buffers, 1 WG/CU", E(waves=8, nbuf=2, wgs=1)),
+                   ("stream 16 waves, 2 buffers", E(waves=16, nbuf=2)), ("stream 16 waves, 3 buffers", E(waves=16, nbuf=3)),
+                   ("default: no rows (1)", E(dbg=1)), ("default: DMA + barriers (3)", E(dbg=3)),
+                   ("default: rows on valid data, no DMA (8)", E(dbg=8)), ("default: loop + barriers (7)", E(dbg=7))):
     r = subprocess.run([sys.executable, __file__, "--child", circuit, n], capture_output=True, text=True, env=dict(os.environ, **env), timeout=300)
     print(f"{label:40s} {r.stdout.strip() if r.returncode == 0 else 'FAILED ' + r.stderr[-300:]}", flush=True)
