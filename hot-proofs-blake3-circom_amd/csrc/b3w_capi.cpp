@@ -1068,7 +1068,7 @@ struct b3w_r1cs {
   uint32_t max_tile_rows = 0;
   uint32_t *d_trow_k = nullptr, *d_lrows = nullptr, *d_lterms = nullptr, *d_ltile_terms = nullptr;   // (its own rows and term stream: bit runs folded)
   uint32_t *d_srows = nullptr, *d_sgdesc = nullptr, *d_sgwords = nullptr, *d_sgmeta = nullptr;       // the stream kernel's program
-  unsigned long long *d_smask = nullptr;
+  unsigned long long *d_smask = nullptr, *d_scost = nullptr;
   B3wR1csSystem sys{};
   // ... at most R1CS_SCRATCH_STREAMS of them: the least recently used one goes when another stream comes (after the event that
   // follows its last check; a scratch a stream capture has seen stays, its graph may be replayed any time)
@@ -1135,9 +1135,10 @@ static int32_t r1cs_create_impl(b3w_ctx *ctx, const uint8_t *img, size_t len, b3
     up((void **)&r->d_sgwords, H.sgwords.data(), H.sgwords.size() * 4);
     up((void **)&r->d_sgmeta, H.sgmeta.data(), H.sgmeta.size() * 4);
     up((void **)&r->d_smask, H.smask.data(), H.smask.size() * 8);
+    up((void **)&r->d_scost, H.scost.data(), H.scost.size() * 8);
     r->sys = B3wR1csSystem{H.nwires, H.ntiles, H.max_ext, H.max_lean_terms, H.max_tile_rows, r->ncoef, r->d_tiles, r->d_ltile_terms, r->d_ext, r->d_lrows,
                            r->d_trow_id, r->d_trow_k, r->d_lterms, r->d_coefR, r->d_coef_small, r->d_rows, r->d_wires, r->d_cids,
-                           H.max_g_words, H.max_g_rows, H.smask_groups, r->d_srows, r->d_sgdesc, r->d_sgwords, r->d_sgmeta, r->d_smask};
+                           H.max_g_words, H.max_g_rows, H.smask_groups, r->d_srows, r->d_sgdesc, r->d_sgwords, r->d_sgmeta, r->d_smask, r->d_scost};
   }
   if (e != hipSuccess) { b3w_r1cs_destroy(r); return e == hipErrorOutOfMemory ? B3W_E_NOT_ENOUGH_MEMORY : hip_fail(ctx, e, "r1cs upload"); }
   *out = r;
@@ -1170,6 +1171,7 @@ void b3w_r1cs_destroy(b3w_r1cs *r) {
   if (r->d_coef_small) (void)hipFree(r->d_coef_small);
   for (uint32_t *q : {r->d_trow_k, r->d_lrows, r->d_lterms, r->d_ltile_terms, r->d_srows, r->d_sgdesc, r->d_sgwords, r->d_sgmeta}) if (q) (void)hipFree(q);
   if (r->d_smask) (void)hipFree(r->d_smask);
+  if (r->d_scost) (void)hipFree(r->d_scost);
   for (auto &sc : r->scratch) {
     if (sc.done) { (void)hipEventSynchronize(sc.done); (void)hipEventDestroy(sc.done); }
     if (sc.buf) (void)hipFree(sc.buf);

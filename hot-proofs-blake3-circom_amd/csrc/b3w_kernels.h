@@ -106,6 +106,7 @@ struct B3wR1csSystem {
   uint32_t max_g_words, max_g_rows, smask_groups;
   const uint32_t *srows, *sgdesc, *sgwords, *sgmeta;
   const unsigned long long *smask;                 // per tile x smask_groups: elements the tile's rows take for bits
+  const unsigned long long *scost;                 // ntiles + 1 prefix sums of the tiles' relative unit costs
 };
 #define B3W_R1CS_SLAB 8192u                                  // bodies per launch pair at most: bounds the scratch (64 MB at most)
 extern "C" size_t b3w_r1cs_scratch_bytes(const B3wR1csSystem *sys);

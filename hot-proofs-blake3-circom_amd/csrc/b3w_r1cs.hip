@@ -825,9 +825,20 @@ __global__ __launch_bounds__(64 * WAVES, 4) void b3w_r1cs_stream_kernel(   // (s
   const uint32_t xg = (uint32_t)WAVES - 1u - wave;                                 // ... this wave's, if it has one
   const bool packs_ext = xg < nxg;
 
-  const uint64_t U = (uint64_t)S.ntiles * n;                                       // units, tile-major: u = tile * n + body
-  uint64_t u = U * blockIdx.x / gridDim.x;
-  const uint64_t u_end = U * (blockIdx.x + 1ull) / gridDim.x;
+  // units, tile-major: u = tile * n + body; a workgroup takes a contiguous range of equal COST (S.scost: a tile with many general
+  // words costs more than one of booleanity rows): position x of n * (total cost) lies in the tile t with n * scost[t] <= x, at body
+  // (x - n * scost[t]) / (cost of t)
+  auto unit_at = [&](const uint32_t k) -> uint64_t {       // first unit of workgroup k (k = gridDim.x: one past the last unit)
+    if (k >= gridDim.x) return (uint64_t)S.ntiles * n;
+    const uint64_t total = S.scost[S.ntiles] * n;
+    const uint64_t x = total / gridDim.x * k + total % gridDim.x * k / gridDim.x;
+    uint32_t t = 0;
+    while (t + 1u < S.ntiles && S.scost[t + 1u] * n <= x) t++;
+    const uint64_t body = (x - S.scost[t] * n) / (S.scost[t + 1u] - S.scost[t]);
+    return (uint64_t)t * n + (body < n ? body : n - 1u);
+  };
+  uint64_t u = unit_at(blockIdx.x);
+  const uint64_t u_end = unit_at(blockIdx.x + 1u);
   while (u < u_end) {
     const uint32_t tile = (uint32_t)(u / n), b_lo = (uint32_t)(u - (uint64_t)tile * n);
     const uint32_t m = (uint32_t)((u_end - u) < (uint64_t)(n - b_lo) ? (u_end - u) : (uint64_t)(n - b_lo));      // bodies of this tile

@@ -407,6 +407,17 @@ bool b3w_r1cs_host_build(const uint8_t *img, size_t len, const uint8_t prime_le[
     }
     sgwords.push_back(0); sgmeta.push_back(4u);            // (a lane reads the word behind its own)
   }
+  // what a (body, tile) unit costs the stream kernel, relative: a fixed part (barriers, descriptors), the tile's bytes, its
+  // general words (a tile of blake3_compression with 170 words: 3.9 us; + 2 ns per word) — the kernel deals units
+  // to its persistent workgroups by cost, not by count: tile 23 of the circomkit nova build has 1 246 general words, seven times
+  // the others', and a workgroup that drew only such units would finish half again as late as the rest
+  std::vector<unsigned long long> scost(ntiles + 1, 0ull);
+  if (tiled)
+    for (uint32_t t = 0; t < ntiles; t++) {
+      const uint32_t n_local = std::min<uint32_t>(T, nwires - t * T);
+      // (calibrated on the three tilings, profiles/r03/r1cs_cost_calibration.log: fixed 1 500, bytes 400 per full tile, 1 per word)
+      scost[t + 1] = scost[t] + 1500u + (400u * n_local) / T + sgdesc[4 * t + 1];
+    }
   std::vector<uint32_t> coefR(16 * coefs.size());           // per coefficient: plain, then Montgomery form
   for (size_t i = 0; i < coefs.size(); i++) {
     memcpy(&coefR[16 * i], coefs[i].data(), 32);
@@ -431,6 +442,6 @@ bool b3w_r1cs_host_build(const uint8_t *img, size_t len, const uint8_t prime_le[
   H->ltdesc = std::move(ltdesc); H->lrows = std::move(lrows); H->lterms = std::move(lterms);
   H->srows = std::move(srows); H->sgdesc = std::move(sgdesc); H->sgwords = std::move(sgwords); H->sgmeta = std::move(sgmeta);
   H->coef_zlim = std::move(coef_zlim); H->max_g_words = max_g_words; H->max_g_rows = max_g_rows;
-  H->smask = std::move(smask); H->smask_groups = smask_groups;
+  H->smask = std::move(smask); H->smask_groups = smask_groups; H->scost = std::move(scost);
   return true;
 }

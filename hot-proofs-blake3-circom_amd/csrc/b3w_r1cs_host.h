@@ -31,6 +31,7 @@ struct B3wR1csHost {
   uint32_t max_g_words = 0, max_g_rows = 0;
   std::vector<unsigned long long> smask;          // per tile x smask_groups: LDS elements the tile's booleanity / truth-table rows take for bits
   uint32_t smask_groups = 0;
+  std::vector<unsigned long long> scost;          // ntiles + 1 prefix sums of the tiles' relative unit costs (stream kernel's work split)
 };
 
 // false: refused, H->error says why.  May throw std::bad_alloc / std::length_error on absurd sizes (the caller catches).
