@@ -451,9 +451,17 @@ def main():
             return ctx.alloc_bodies(n * pitch)
         except m.B3WError as e:                             # a search that ran the device out of memory: plain buffer, and say so
             print(f"bench.py: {e}; falling back to a plain buffer", file=sys.stderr)
-            m.lib().b3w_bodies_trim()
             os.environ["B3W_PLACEMENT"] = "plain"
-            return ctx.alloc_bodies(n * pitch)
+            for attempt in range(6):                        # (a box still releasing the previous process's memory: wait for it)
+                ctx.trim()
+                m.lib().b3w_bodies_trim()
+                try:
+                    return ctx.alloc_bodies(n * pitch)
+                except m.B3WError as e2:
+                    if attempt == 5:
+                        raise
+                    print(f"bench.py: {e2}; trying again in {2 + attempt} s", file=sys.stderr)
+                    time.sleep(2 + attempt)
     bodies = alloc()
     for attempt in range(4):                                # a box still releasing another process's memory: try again
         if bodies.placement == "mixed" or os.environ.get("B3W_PLACEMENT") == "plain":

@@ -139,6 +139,7 @@ def lib():
         "b3w_chain_shard": (None, [u64, i32, i32, ctypes.POINTER(u64), ctypes.POINTER(u32)]),
         "b3w_chain_run_parents_sharded": (i32, [vp, vp, vp, vp, vp]),
         "b3w_chain_allgather_hout": (i32, [vp, vp, vp, vp, vp]),
+        "b3w_chain_allgather_hout_host": (i32, [vp, vp, vp, vp, vp]),
         "b3w_chain_info": (i32, [vp, ctypes.POINTER(u64), ctypes.POINTER(u64), ctypes.POINTER(u64), ctypes.POINTER(u32), ctypes.POINTER(i32)]),
         "b3w_chain_outputs": (i32, [vp, vp, vp, vp, vp]),
         "b3w_chain_records": (vp, [vp]),
@@ -164,7 +165,7 @@ EXPORTED_SYMBOLS = ("b3w_abi_version", "b3w_identify_wasm", "b3w_create", "b3w_d
                     "b3w_chain_plan_leaves_device", "b3w_chain_tree_device", "b3w_chain_plan_parents_device",
                     "b3w_commit_key_create", "b3w_commit_key_create_ex", "b3w_commit_key_create_folded", "b3w_slot_widths", "b3w_commit_key_window", "b3w_commit_key_destroy", "b3w_commit_records_device", "b3w_commit_records", "b3w_chain_commit_only", "b3w_chain_commitments", "b3w_chain_check_constraints", "b3w_chain_violations", "b3w_batch_commit_device", "b3w_batch_commit", "b3w_commit_consumer",
                     "b3w_comm_unique_id", "b3w_comm_create", "b3w_comm_destroy", "b3w_comm_allgather", "b3w_batch_allgather_public",
-                    "b3w_chain_create", "b3w_chain_destroy", "b3w_chain_run_leaves", "b3w_chain_run_parents", "b3w_chain_shard", "b3w_chain_run_parents_sharded", "b3w_chain_allgather_hout", "b3w_chain_info",
+                    "b3w_chain_create", "b3w_chain_destroy", "b3w_chain_run_leaves", "b3w_chain_run_parents", "b3w_chain_shard", "b3w_chain_run_parents_sharded", "b3w_chain_allgather_hout", "b3w_chain_allgather_hout_host", "b3w_chain_info",
                     "b3w_chain_outputs", "b3w_chain_records", "b3w_chain_public", "b3w_chain_status", "b3w_chain_local_cvs", "b3w_chain_root")
 
 

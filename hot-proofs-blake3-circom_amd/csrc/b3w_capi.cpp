@@ -2052,6 +2052,22 @@ int32_t b3w_chain_allgather_hout(b3w_chain *c, b3w_comm *comm, uint32_t *d_leaf_
   return B3W_OK;
 }
 
+int32_t b3w_chain_allgather_hout_host(b3w_chain *c, b3w_comm *comm, uint32_t *host_leaf_hout, uint32_t *host_parent_hout, void *stream) {
+  if (!c || !comm || (!host_leaf_hout && !host_parent_hout)) return B3W_E_BAD_ARGUMENT;
+  b3w_ctx *ctx = c->ctx;
+  ON_DEVICE(ctx);
+  const uint64_t n_leaf = b3w_chain_num_leaf_steps(c->len), n_par = c->with_parents ? b3w_plan_parent_row(c->n_chunks, c->n_chunks) : 0;
+  uint32_t *d = nullptr;
+  HIP_TRY(ctx, hipMalloc((void **)&d, (size_t)(n_leaf + n_par + 1) * 32));
+  int32_t rc = b3w_chain_allgather_hout(c, comm, d, n_par ? d + n_leaf * 8 : nullptr, stream);
+  hipError_t e = rc == B3W_OK ? hipStreamSynchronize((hipStream_t)stream) : hipSuccess;
+  if (rc == B3W_OK && e == hipSuccess && host_leaf_hout) e = hipMemcpy(host_leaf_hout, d, (size_t)n_leaf * 32, hipMemcpyDeviceToHost);
+  if (rc == B3W_OK && e == hipSuccess && host_parent_hout && n_par) e = hipMemcpy(host_parent_hout, d + n_leaf * 8, (size_t)n_par * 32, hipMemcpyDeviceToHost);
+  (void)hipFree(d);
+  if (rc) return rc;
+  return e == hipSuccess ? B3W_OK : hip_fail(ctx, e, "h_out exchange (host)");
+}
+
 int32_t b3w_chain_info(const b3w_chain *c, uint64_t *n_leaf_steps, uint64_t *n_parent_steps, uint64_t *n_chunks, uint32_t *path_len,
                        int32_t *placement) {
   if (!c) return B3W_E_BAD_ARGUMENT;

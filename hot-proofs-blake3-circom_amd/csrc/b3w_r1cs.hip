@@ -568,7 +568,7 @@ __global__ __launch_bounds__(256) void b3w_r1cs_lean_kernel(const uint8_t *__res
   for (uint32_t u = 0; u < 4; u++) {                                               // TILE = 4 x 256 elements
     const uint32_t i = threadIdx.x + 256 * u;
     const uint4 *q = reinterpret_cast<const uint4 *>(body + (size_t)(t0 + (i < n_local ? i : 0u)) * 32);
-    lo[u] = q[0]; hi[u] = q[1];
+    lo[u] = q[0]; hi[u] = q[1];                            // (default cache policy: the outside wires of the body's other tiles hit these lines in L2 — nt loads were 5-10 % slower here)
   }
   const uint4 *terms4 = reinterpret_cast<const uint4 *>(S.terms + tt.x);
   const uint32_t nt4 = (tt.y + 5u) >> 2;                                           // the tile's term words + the two read-ahead words, in fours

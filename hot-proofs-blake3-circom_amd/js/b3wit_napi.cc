@@ -55,6 +55,9 @@ struct Api {
   decltype(&b3w_batch_commit) batch_commit;
   decltype(&b3w_chain_shard) chain_shard;
   decltype(&b3w_chain_run_parents_sharded) chain_run_parents_sharded;
+  decltype(&b3w_chain_allgather_hout_host) chain_allgather_hout_host;
+  decltype(&b3w_chain_num_leaf_steps) chain_num_leaf_steps;
+  decltype(&b3w_chain_parent_row) chain_parent_row;
   decltype(&b3w_comm_unique_id) comm_unique_id;
   decltype(&b3w_comm_create) comm_create;
   decltype(&b3w_comm_destroy) comm_destroy;
@@ -88,7 +91,7 @@ bool load_api() {
   SYM(write_wtns_header) SYM(last_error) SYM(public_words) SYM(batch_alloc) SYM(batch_free) SYM(batch_run)
   SYM(batch_outputs) SYM(batch_fetch) SYM(batch_write_wtns) SYM(batch_verify) SYM(batch_placement) SYM(bodies_trim)
   SYM(chain_create) SYM(chain_destroy) SYM(chain_run_leaves) SYM(chain_run_parents) SYM(chain_info) SYM(chain_outputs)
-  SYM(commit_key_create_ex) SYM(commit_key_create_folded) SYM(commit_key_destroy) SYM(commit_records) SYM(chain_commit_only) SYM(chain_commitments) SYM(batch_commit) SYM(chain_shard) SYM(chain_run_parents_sharded) SYM(comm_unique_id) SYM(comm_create) SYM(comm_destroy) SYM(batch_allgather_public)
+  SYM(commit_key_create_ex) SYM(commit_key_create_folded) SYM(commit_key_destroy) SYM(commit_records) SYM(chain_commit_only) SYM(chain_commitments) SYM(batch_commit) SYM(chain_shard) SYM(chain_run_parents_sharded) SYM(chain_allgather_hout_host) SYM(chain_num_leaf_steps) SYM(chain_parent_row) SYM(comm_unique_id) SYM(comm_create) SYM(comm_destroy) SYM(batch_allgather_public)
   SYM(r1cs_create) SYM(r1cs_info) SYM(r1cs_destroy) SYM(batch_r1cs_check) SYM(chain_check_constraints) SYM(chain_violations)
 #undef SYM
   api.so = so;
@@ -396,7 +399,8 @@ napi_value BatchPlacement(napi_env env, napi_callback_info info) {
 }
 
 // chainFold(handle, preimage: Buffer|Uint8Array, batchSteps, ring, withParents)
-//   -> { nLeafSteps, nParentSteps, nChunks, pathLen, placement, publicOutputs: Uint32Array(steps*15), status: Int32Array, root: Uint32Array(8) }
+//   -> { nLeafSteps, nParentSteps, nChunks, pathLen, placement, publicOutputs: Uint32Array(steps*15), status: Int32Array, root: Uint32Array(8)
+//        [, hOutAll: Uint32Array(all ranks' leaf steps * 8), hOutParentsAll: Uint32Array(all ranks' parent steps * 8) after commCreate] }
 // The whole chained-mode pass of b3wit.h (b3w_chain_*) over one preimage on this handle's device.
 napi_value ChainFold(napi_env env, napi_callback_info info) {
   size_t argc = 7; napi_value argv[7];
@@ -457,9 +461,22 @@ napi_value ChainFold(napi_env env, napi_callback_info info) {
     if (napi_create_arraybuffer(env, rows * 4, &pv, &abv) != napi_ok) { api.chain_destroy(c); napi_throw_error(env, nullptr, "b3wit_napi: cannot allocate the violation counts"); return nullptr; }
     rc = api.chain_violations(c, (uint32_t *)pv, nullptr);
   }
+  // after joinRanks: the fold's exchange — every step's h_out of EVERY rank, global step order (b3w_chain_allgather_hout)
+  void *phl = nullptr, *php = nullptr; napi_value abhl, abhp;
+  const uint64_t hl_rows = api.chain_num_leaf_steps(len), hp_rows = with_parents ? api.chain_parent_row(nchunks, nchunks) : 0;
+  if (rc == B3W_OK && h->comm) {
+    if (napi_create_arraybuffer(env, hl_rows * 32, &phl, &abhl) != napi_ok || napi_create_arraybuffer(env, hp_rows * 32, &php, &abhp) != napi_ok) {
+      api.chain_destroy(c); napi_throw_error(env, nullptr, "b3wit_napi: cannot allocate the gathered h_out"); return nullptr;
+    }
+    rc = api.chain_allgather_hout_host(c, h->comm, (uint32_t *)phl, hp_rows ? (uint32_t *)php : nullptr, nullptr);
+  }
   api.chain_destroy(c);
   if (rc != B3W_OK) return throw_status(env, h, rc, "chained pass failed");
   NAPI_OK(napi_create_object(env, &o));
+  if (h->comm) {
+    napi_create_typedarray(env, napi_uint32_array, hl_rows * 8, abhl, 0, &v); napi_set_named_property(env, o, "hOutAll", v);
+    napi_create_typedarray(env, napi_uint32_array, hp_rows * 8, abhp, 0, &v); napi_set_named_property(env, o, "hOutParentsAll", v);
+  }
   napi_create_double(env, (double)nleaf, &v); napi_set_named_property(env, o, "nLeafSteps", v);
   napi_create_double(env, (double)npar, &v); napi_set_named_property(env, o, "nParentSteps", v);
   napi_create_double(env, (double)nch, &v); napi_set_named_property(env, o, "nChunks", v);

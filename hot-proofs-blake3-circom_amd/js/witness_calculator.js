@@ -240,7 +240,9 @@ class WitnessCalculator {
   // placement, publicOutputs: Uint32Array (15 words per step: n_blocks_out block_count_out h_out[8] ...),
   // status: Int32Array, root: Uint32Array(8) = BLAKE3(preimage) as little-endian words, hash: hex string }.
   // After wc.joinRanks every rank passes the same preimage and gets the steps of ITS chunk range (firstChunk,
-  // nChunksLocal); the chunk chaining values are all-gathered over RCCL so that each rank knows the whole tree.
+  // nChunksLocal); the chunk chaining values are all-gathered over RCCL so that each rank knows the whole tree, and so is every
+  // step's h_out (the running chaining value the fold consumes, rust_fold/src/blake3_circuit.rs:111-123): r.hOutAll (8 words per
+  // leaf step of ALL ranks, global step order: row 16 c + 15 is chunk c's chaining value), r.hOutParentsAll.
   async foldPreimage(preimage, opts) {
     opts = opts || {};
     // opts.commitOnly (after setCommitKey): r.commitments = one 64-byte point per step, no witness bodies written

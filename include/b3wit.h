@@ -435,6 +435,8 @@ int32_t b3w_chain_run_parents_sharded(b3w_chain *chain, b3w_comm *comm, b3w_batc
  * on every rank (either pointer may be NULL).  Enqueued on `stream` behind the pass; exchange buffers are allocated on the
  * first sharded call of a chain and kept, so a pass that has run once neither allocates nor synchronises. */
 int32_t b3w_chain_allgather_hout(b3w_chain *chain, b3w_comm *comm, uint32_t *d_leaf_hout, uint32_t *d_parent_hout, void *stream);
+/* The same into host arrays (for bindings that hold no device memory: Node).  Waits for `stream`. */
+int32_t b3w_chain_allgather_hout_host(b3w_chain *chain, b3w_comm *comm, uint32_t *host_leaf_hout, uint32_t *host_parent_hout, void *stream);
 int32_t b3w_chain_info(const b3w_chain *chain, uint64_t *n_leaf_steps, uint64_t *n_parent_steps, uint64_t *n_chunks,
                        uint32_t *path_len, int32_t *placement);
 /* Waits for `stream`, then copies the results to the host: (n_leaf + n_parent) * 15 public-output words, as many

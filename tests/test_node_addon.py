@@ -346,8 +346,13 @@ def test_js_rccl_exchange_single_rank():
         const pre = Buffer.alloc(8 * 1024); for (let i = 0; i < pre.length; i++) pre[i] = (i * 7 + 3) % 251;
         const f = await nv.foldPreimage(pre, {batchSteps: 64});
         const solo = await (await builder('nova_vesta', {logDFlags: false})).foldPreimage(pre, {batchSteps: 64});
+        // the gathered h_out (8 words per step, global step order) = words 2..9 of this rank's own public outputs when it is alone
+        const nl = f.nLeafSteps, np_ = f.nParentSteps;
+        let hout = f.hOutAll.length === 8 * nl && f.hOutParentsAll.length === 8 * np_ && solo.hOutAll === undefined;
+        for (let s = 0; s < nl + np_ && hout; s++)
+          for (let j = 0; j < 8; j++) hout = hout && (s < nl ? f.hOutAll[8 * s + j] : f.hOutParentsAll[8 * (s - nl) + j]) === f.publicOutputs[15 * s + 2 + j];
         const fold = {hash: f.hash, same: f.hash === solo.hash && Array.from(f.publicOutputs).join() === Array.from(solo.publicOutputs).join(),
-                      first: f.firstChunk, local: f.nChunksLocal, par: f.nParentSteps, bad: Array.from(f.status).filter(x => x !== 0).length};
+                      first: f.firstChunk, local: f.nChunksLocal, par: f.nParentSteps, bad: Array.from(f.status).filter(x => x !== 0).length, hout};
         console.log(JSON.stringify({idLen: id.length, n: b.n, same: Array.from(all).join() === Array.from(b.publicOutputs).join(), first: Array.from(all.slice(0, 15)).map(String), fold}));
       })().catch(e => { console.error(e); process.exit(1); });
     """, json.dumps(cases))
@@ -357,7 +362,7 @@ def test_js_rccl_exchange_single_rank():
     assert out["first"] == [str(x) for x in cases[0]["first16"][1:]]
     import blake3_ref
     pre = bytes((i * 7 + 3) % 251 for i in range(8 * 1024))
-    assert out["fold"] == {"hash": blake3_ref.blake3(pre).hex(), "same": True, "first": 0, "local": 8, "par": 24, "bad": 0}
+    assert out["fold"] == {"hash": blake3_ref.blake3(pre).hex(), "same": True, "first": 0, "local": 8, "par": 24, "bad": 0, "hout": True}
 
 
 @needs_node
