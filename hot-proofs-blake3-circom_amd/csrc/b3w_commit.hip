@@ -614,6 +614,47 @@ __global__ __launch_bounds__(64) void b3w_commit_setup_kernel(const uint32_t *__
   }
 }
 
+// ---- set-up 1b (O2 nova circuits): invtab[(j * 2 + neg) * nk + mag - 1] = (+-1 / mag mod r) * G of the slot that holds the inverse of
+// IsZero gadget j, for mag = 1 ... nk (affine, radix 2^261, eight 32-bit words; (0, 0) where that slot is not committed).  A step has 67
+// such slots — 256 virtual bit slots, i.e. sixteen 16-bit windows each, 39 % of what a folded O2 key commits — but their values
+// are 1 / k for a SMALL signed k the step's inputs determine (k = -depth, -block_count, n_blocks - 1 - block_count,
+// total_depth - i - 2 - depth: circuits/blake3_nova.circom:19-23,65-72,136-144), the same 2 048-entry table of inverses the
+// witness kernels use: records mode adds ONE tabulated point per gadget instead of sixteen.
+// One thread per entry: 255 doublings and the additions of the scalar's bits (set-up only: 8 ms for 67 x 2 047 entries).
+__global__ __launch_bounds__(64) void b3w_commit_invtab_kernel(const uint32_t *__restrict__ gens /* nslots x 16 words, standard form */,
+                                                               const uint32_t *__restrict__ inv_slot /* 67: committed slot index or ~0 */,
+                                                               const uint32_t *__restrict__ inverses /* 8 words per magnitude, standard form; entry 0 unused */,
+                                                               uint32_t njobs, uint32_t nk, uint32_t *__restrict__ invtab, B3wCurve C) {
+  const uint64_t gid = (uint64_t)blockIdx.x * 64 + threadIdx.x;
+  if (gid >= (uint64_t)njobs * nk) return;
+  const uint32_t j = (uint32_t)(gid / nk), mag = (uint32_t)(gid % nk) + 1u;
+  uint32_t *o = invtab + ((uint64_t)j * 2 * nk + mag - 1u) * 16, *on = o + (uint64_t)nk * 16;        // 1 / mag, -1 / mag
+  const uint32_t s = inv_slot[j];
+  if (s == 0xFFFFFFFFu) { store_fp(o, fp_zero()); store_fp(o + 8, fp_zero()); store_fp(on, fp_zero()); store_fp(on + 8, fp_zero()); return; }
+  Fp r2;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) r2.l[i] = C.r2[i];
+  const Fp gx = fp_mul(load_fp(gens + (uint64_t)s * 16), r2, C), gy = fp_mul(load_fp(gens + (uint64_t)s * 16 + 8), r2, C);
+  const uint32_t *sc = inverses + 8ull * mag;
+  Jac R = jac_infinity();
+#pragma unroll 1
+  for (int b = 255; b >= 0; --b) {
+    R = jac_dbl(R, C);
+    if ((sc[b >> 5] >> (b & 31)) & 1u) R = jac_madd(R, gx, gy, C);
+  }
+  Fp x, y, c32;
+  jac_to_affine(R, x, y, C);
+#pragma unroll
+  for (int k = 0; k < 8; ++k) c32.l[k] = C.one[k];
+#pragma unroll 1
+  for (int k = 0; k < 5; ++k) c32 = fp_dbl(c32, C);         // 32 in Montgomery form: the commit kernel's radix is 2^261
+  const Fp xo = fp_mul(x, c32, C);
+  store_fp(o, xo);
+  store_fp(o + 8, fp_mul(y, c32, C));
+  store_fp(on, xo);
+  store_fp(on + 8, fp_mul(fp_sub(fp_zero(), y, C), c32, C));
+}
+
 // ---- set-up 2: table[win * (2^W - 1) + m - 1] = sum of the window's virtual-slot points selected by the bits of m
 // (affine, radix 2^261, eight 32-bit words; infinity = (0, 0)).  A thread walks K = 4 consecutive entries in Gray-code
 // order — the first from scratch, each next one is the previous +/- one point — and the four share one inversion
@@ -721,15 +762,35 @@ __global__ __launch_bounds__(T * WPB) __attribute__((amdgpu_waves_per_eu(3, 3)))
                                                          uint32_t region_words /* LDS words per witness: max(bit string, 36 T) */,
                                                          const uint32_t *__restrict__ table /* radix 2^261 */, uint32_t nwin,
                                                          uint32_t *__restrict__ sums /* n x B3W_COMMIT_SUM_WORDS: X Y ZZ ZZZ in 29-bit limbs */,
-                                                         int32_t *__restrict__ status, CV C) {
+                                                         int32_t *__restrict__ status,
+                                                         const uint32_t *__restrict__ invtab /* or null: records mode of the O2 nova circuits, b3w_commit_invtab_kernel */,
+                                                         uint32_t inv_nk, CV C) {
   extern __shared__ uint32_t lds[];
   __shared__ uint32_t bad[WPB];
+  // invtab: per IsZero gadget of the step 0 = nothing to add (k = 0: the inverse is 0; or a rejected step), +-mag = the tabulated
+  // point of 1 / k (both signs are in the table), INV_WINDOWS = k beyond the table: the slot's bits go through the windows like any other slot's
+  constexpr int32_t INV_WINDOWS = (int32_t)0x80000000;
+  __shared__ int32_t kinv[WPB][B3W_NOVA_ISZERO];
   const uint32_t sub = threadIdx.x / T, t = threadIdx.x % T;       // which witness of the workgroup, lane within it
   const uint32_t w = blockIdx.x * WPB + sub;
   const bool live = w < n;
   uint32_t *packed = lds + sub * region_words;
   for (uint32_t i = t; i < region_words; i += T) packed[i] = 0;
   if (t == 0) bad[sub] = 0;
+  if (images && invtab) {
+    const uint32_t *img = images + (live ? w : 0);
+    const bool ok = live && img[(uint64_t)B3W_LDS_OKWORD * img_row] != 0;
+    for (uint32_t j = t; j < B3W_NOVA_ISZERO; j += T) {        // the gadgets' arguments, as the TRACE phase of the witness kernel derives them
+      const int64_t depth = img[(uint64_t)(B3W_LDS_NV + NV_DEPTH) * img_row];
+      int64_t k;
+      if (j == 0) k = -depth;
+      else if (j == 1) k = -(int64_t)img[(uint64_t)(B3W_LDS_NV + NV_BLOCK_COUNT) * img_row];
+      else if (j == 2) k = (int64_t)img[(uint64_t)(B3W_LDS_NV + NV_N_BLOCKS) * img_row] - 1 - (int64_t)img[(uint64_t)(B3W_LDS_NV + NV_BLOCK_COUNT) * img_row];
+      else k = (int64_t)img[(uint64_t)(B3W_LDS_NV + NV_TOTAL_DEPTH) * img_row] - (int64_t)(j - 3) - 2 - depth;
+      const uint64_t mag = k < 0 ? (uint64_t)(-k) : (uint64_t)k;
+      kinv[sub][j] = !ok || mag == 0 ? 0 : mag > inv_nk ? INV_WINDOWS : k < 0 ? -(int32_t)mag : (int32_t)mag;
+    }
+  }
   __syncthreads();
   if (images) {
     // records mode: the witness is an expansion of its TRACE image (3.7-11 KB) through the slot table, so its bits are
@@ -738,6 +799,10 @@ __global__ __launch_bounds__(T * WPB) __attribute__((amdgpu_waves_per_eu(3, 3)))
     const bool ok = live && img[(uint64_t)B3W_LDS_OKWORD * img_row] != 0;              // a rejected step leaves the string empty
     for (uint32_t r = t; r < nruns; r += T) {
       const uint2 e = runs[r];
+      if (invtab) {                                          // an inverse whose point is tabulated stays out of the bit string
+        const uint32_t src = e.y & 0xFFFFu;
+        if (src >= B3W_LDS_WIDE && src < B3W_LDS_WIDE + 8u * B3W_NOVA_ISZERO && kinv[sub][(src - B3W_LDS_WIDE) >> 3] != INV_WINDOWS) continue;
+      }
       const uint32_t len = (e.x >> 24) + 1u, x = ok ? img[(uint64_t)(e.y & 0xFFFFu) * img_row] >> (e.y >> 16) : 0u;
       const uint32_t piece = len == 32 ? x : x & ((1u << len) - 1u);
       if (piece) {
@@ -814,6 +879,15 @@ __global__ __launch_bounds__(T * WPB) __attribute__((amdgpu_waves_per_eu(3, 3)))
       win += T;
     }
   }
+  if (images && invtab && live)
+    for (uint32_t j = t; j < B3W_NOVA_ISZERO; j += T) {        // one tabulated point per IsZero gadget (y negated for a negative argument)
+      const int32_t kc = kinv[sub][j];
+      if (kc == 0 || kc == INV_WINDOWS) continue;
+      const uint32_t *pt = invtab + (((uint64_t)j * 2 + (kc < 0 ? 1u : 0u)) * inv_nk + (uint32_t)(kc < 0 ? -kc : kc) - 1u) * 16;
+      const Fp x2 = load_fp(pt), y2 = load_fp(pt + 8);
+      if (fp_is_zero(x2) && fp_is_zero(y2)) continue;          // (the gadget's slot is not committed)
+      j9_madd(acc, to29(x2), to29(y2), C);
+    }
   __syncthreads();                                           // every lane is done with the bit string: the tree takes its place
   // LDS tree over each witness's T partial sums (infinity travels as ZZ = 0).  The additions of all WPB witnesses of a
   // level are dealt to the first threads of the workgroup, so whole waves drop out instead of running half empty
@@ -945,7 +1019,7 @@ extern "C" int b3w_launch_commit(const uint8_t *d_bodies, uint32_t n, uint64_t p
                                  const uint32_t *d_slotdesc, const uint32_t *d_images /* or null */, uint32_t img_row, const uint32_t *d_runs,
                                  uint32_t nruns, const uint32_t *d_table, uint32_t nwin, uint32_t window,
                                  uint32_t *d_sums /* n * B3W_COMMIT_SUM_WORDS scratch */, uint8_t *d_out, int32_t *d_status,
-                                 const B3wCurve *curve, hipStream_t stream) {
+                                 const uint32_t *d_invtab, uint32_t inv_nk, const B3wCurve *curve, hipStream_t stream) {
   if (!n) return 0;
   if (window != B3W_COMMIT_WINDOW_SMALL && window != B3W_COMMIT_WINDOW_LARGE) return (int)hipErrorInvalidValue;
   const uint32_t bits_words = (nwin * window + 31) / 32 + 2;   // one packed witness in LDS (nova O1: 13.5 KB)
@@ -966,7 +1040,7 @@ extern "C" int b3w_launch_commit(const uint8_t *d_bodies, uint32_t n, uint64_t p
     if ((size_t)region * WPB * 4 > 64 * 1024) return (int)hipErrorInvalidValue;   /* LDS of one workgroup (nova O1: 54 KB) */ \
     hipLaunchKernelGGL((b3w_commit_kernel<T, WPB, W, CV>), dim3((n + WPB - 1) / WPB), dim3(T * WPB), region * WPB * 4, stream, d_bodies, n, \
                        pitch, first_slot, nslots, d_slotdesc, d_images, img_row, reinterpret_cast<const uint2 *>(d_runs), nruns, region, d_table, nwin, \
-                       d_sums, d_status, cv);                                                                             \
+                       d_sums, d_status, d_images ? d_invtab : nullptr, inv_nk, cv);                                      \
   }
   if (window == B3W_COMMIT_WINDOW_LARGE) {
     if (vesta) B3W_COMMIT_LAUNCH(64, 4, B3W_COMMIT_WINDOW_LARGE, B3wCurve9Vesta, c9v)
@@ -980,5 +1054,14 @@ extern "C" int b3w_launch_commit(const uint8_t *d_bodies, uint32_t n, uint64_t p
 #undef B3W_COMMIT_LAUNCH
   if (vesta) hipLaunchKernelGGL(b3w_commit_normalize_kernel<B3wCurve9Vesta>, dim3((n + 63) / 64), dim3(64), 0, stream, d_sums, n, d_out, *curve, c9v);
   else hipLaunchKernelGGL(b3w_commit_normalize_kernel<B3wCurve9>, dim3((n + 63) / 64), dim3(64), 0, stream, d_sums, n, d_out, *curve, c9);
+  return (int)hipGetLastError();
+}
+
+extern "C" int b3w_launch_commit_invtab(const uint32_t *d_gens, const uint32_t *d_inv_slot, const uint32_t *d_inverses, uint32_t njobs, uint32_t nk,
+                                        uint32_t *d_invtab, const B3wCurve *curve, hipStream_t stream) {
+  if (!njobs || !nk) return 0;
+  const uint64_t total = (uint64_t)njobs * nk;
+  hipLaunchKernelGGL(b3w_commit_invtab_kernel, dim3((uint32_t)((total + 63) / 64)), dim3(64), 0, stream, d_gens, d_inv_slot, d_inverses, njobs, nk, d_invtab,
+                     *curve);
   return (int)hipGetLastError();
 }

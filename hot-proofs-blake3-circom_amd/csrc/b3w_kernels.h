@@ -71,7 +71,13 @@ extern "C" int b3w_launch_commit(const uint8_t *d_bodies, uint32_t n, uint64_t p
                                  const uint32_t *d_images /* null: read the bodies; else TRACE images (b3w_launch_trace), bodies unused */,
                                  uint32_t img_row, const uint32_t *d_runs /* pairs: v0 | (len - 1) << 24, image word | shift << 16 */, uint32_t nruns,
                                  const uint32_t *d_table, uint32_t nwin, uint32_t window, uint32_t *d_sums, uint8_t *d_out,
-                                 int32_t *d_status, const B3wCurve *curve, hipStream_t stream);
+                                 int32_t *d_status, const uint32_t *d_invtab /* or null: records mode of the O2 nova circuits */, uint32_t inv_nk,
+                                 const B3wCurve *curve, hipStream_t stream);
+// O2 nova circuits, records mode: invtab[j * nk + mag - 1] = (1 / mag) * G of the slot holding IsZero gadget j's inverse
+// (d_inverses: 8 words per magnitude, standard form — the witness kernels' table; d_inv_slot[j] = committed slot index or ~0)
+#define B3W_NOVA_ISZERO 67
+extern "C" int b3w_launch_commit_invtab(const uint32_t *d_gens, const uint32_t *d_inv_slot, const uint32_t *d_inverses, uint32_t njobs, uint32_t nk,
+                                        uint32_t *d_invtab, const B3wCurve *curve, hipStream_t stream);
 
 // b3w_r1cs.hip: rank-1 constraint check of witness bodies (on-device consumer #1: A z * B z - C z = 0 for every row)
 #include "b3w_r1cs_defs.h"          // B3wField, B3W_R1CS_TILE, B3W_R1CS_NOT_SMALL (shared with the HIP-free host code)

@@ -278,7 +278,11 @@ int32_t b3w_batch_commit(b3w_batch *batch, const b3w_commit_key *key, uint8_t *h
  * trace image through the slot table, so its bits — all the commitment needs — are pieces of image words.  Equal to
  * b3w_batch_run_device followed by b3w_batch_commit_device, at the speed of the point additions alone (the 771 KB body
  * is neither written nor read).  d_public (may be NULL) and d_status (required) receive what b3w_batch_run_device
- * writes; a record whose status is not 0 gets the point at infinity (all zero). */
+ * writes; a record whose status is not 0 gets the point at infinity (all zero).
+ * O2 nova circuits: the 67 IsZero inverses of a step (256 virtual bit slots each, 39 % of a folded key) are 1/k of small signed
+ * k the record determines, so the key also holds, per gadget, the points (+-1/k) G for |k| <= 2 047 (18 MB, 10 ms of set-up)
+ * and this path adds ONE point per gadget instead of sixteen windows; a larger |k| goes through the windows as before.
+ * Same points either way (tests/test_gpu_commit.py); B3W_COMMIT_INVTAB=0 builds keys without the tables. */
 int32_t b3w_commit_records_device(b3w_ctx *ctx, const b3w_commit_key *key, const uint32_t *d_records, uint32_t n, uint8_t *d_points,
                                   uint32_t *d_public, int32_t *d_status, void *stream);
 

@@ -259,6 +259,12 @@ def test_commitments_from_records_equal_commitments_of_the_bodies(circuit, curve
     if circuit != "compression":
         recs = recs.copy()
         recs[7, 14] = recs[7, 12]                             # depth = leaf_depth: CheckDepth rejects the step
+        # IsZero arguments beyond the 2 047-entry table of tabulated inverse points (r03: the O2 builds add ONE point per gadget in
+        # records mode): total_depth 40 000 puts k = total_depth - i - 2 - depth past it for every eqs[i] — those slots must then go
+        # through the bit windows like any other; n_blocks - 1 - block_count likewise
+        recs[11, 13] = 40000
+        recs[12, 13] = 2049 + recs[12, 14] + 2                 # k = 2 049, 2 048, 2 047, ...: both sides of the table's edge
+        recs[13, 0] = 5000; recs[13, 1] = 3                   # n_blocks - 1 - block_count = 4 996
     ctx = m.Context(circuit, 0)
     first_slot = 3
     gens = E.random_points(curve, ctx.witness_size - first_slot, seed=b"records" + circuit.encode())
@@ -286,10 +292,12 @@ def test_commitments_from_records_equal_commitments_of_the_bodies(circuit, curve
     assert int(got[~ok].abs().sum().item()) == 0               # rejected: the point at infinity
     hpts, hpub, hst = key.commit_records(recs)                # the host-buffer form
     assert np.array_equal(hpts, got.cpu().numpy()) and np.array_equal(hst, st) and np.array_equal(hpub.view(np.int32), pub2.cpu().numpy())
-    bad, bodies = T.oracle_batch_u32(circuit, recs[[0, n - 1]])
+    probe = [0, n - 1] if circuit == "compression" else [0, 11, 12, n - 1]
+    bad, bodies = T.oracle_batch_u32(circuit, recs[probe])
+    assert bad == 0
     vals = _slot_values(bodies.copy())
     pts = got.cpu().numpy()
-    for j, i in enumerate([0, n - 1]):
+    for j, i in enumerate(probe):
         assert E.point_from_bytes(pts[i].tobytes()) == E.commit(vals[j][first_slot:], gens, curve), i
     key.close(); ctx.close()
 
