@@ -816,7 +816,7 @@ __global__ __launch_bounds__(64 * WAVES, 4) void b3w_r1cs_stream_kernel(   // (s
   uint32_t *gwords = gflag + ((S.max_g_rows + 1u) & ~1u);
   uint32_t *gmeta = gwords + ((S.max_g_words + 4u) & ~3u);
   long long *lcoef = reinterpret_cast<long long *>(gmeta + ((S.max_g_words + 4u) & ~3u));
-  uint32_t *lanom = reinterpret_cast<uint32_t *>(lcoef + S.ncoef);                 // != 0: something the masks cannot vouch for in this (body, tile)
+  uint32_t *lanom = reinterpret_cast<uint32_t *>(lcoef + S.ncoef);                 // [unit parity] != 0: something the masks cannot vouch for in this (body, tile)
   const __int128 lim = (__int128)1 << 63;
   for (uint32_t k = tid; k < S.ncoef; k += THREADS) lcoef[k] = S.coef_small[k];
   if (tid < 2) packed[2 * (groups - 1) + tid] = 0ull;                              // the spare pair
@@ -851,14 +851,12 @@ __global__ __launch_bounds__(64 * WAVES, 4) void b3w_r1cs_stream_kernel(   // (s
     const uint4 *srows = reinterpret_cast<const uint4 *>(S.srows);
     // this lane's rows (pass p: row p * THREADS + tid) and what the wave owns in each pass (wave-uniform: SGPRs)
     uint4 pre[RP];
-    uint32_t rid[RP];
     bool has_rows[RP], has_tt[RP], has_gen[RP];
     unsigned long long dmask[RP];                            // always-deferred rows: the same mask bits for every body
 #pragma unroll
     for (int p = 0; p < RP; p++) {
       const uint32_t r = (uint32_t)p * THREADS + tid;
       pre[p] = r < td.y ? srows[td.x + r] : make_uint4(0, 0, 0, 0);
-      rid[p] = r < td.y ? S.row_id[td.x + r] : 0u;
       has_rows[p] = (uint32_t)p * THREADS + wave * 64u < td.y && !(p > 0 && (dbg & 16u));
       has_tt[p] = __ballot((pre[p].y >> 29) == 1u) != 0ull;
       has_gen[p] = __ballot((pre[p].y >> 28) == 1u) != 0ull;
@@ -872,7 +870,9 @@ __global__ __launch_bounds__(64 * WAVES, 4) void b3w_r1cs_stream_kernel(   // (s
       gwords[k] = S.sgwords[gd.x + k];
       gmeta[k] = S.sgmeta[gd.x + k];
     }
-    if (tid == 0) *lanom = 0u;
+    if (tid < 2) lanom[tid] = 0u;
+    for (uint32_t k = tid; k < 6u * gd.z; k += THREADS) gsum[k] = 0ull;            // (afterwards every general row's owner lane zeroes its own sums)
+    for (uint32_t k = tid; k < gd.z; k += THREADS) gflag[k] = 0u;
     // DMA blocks of this wave: tile blocks wave + q * WAVES (a block = 32 elements = 1 KiB), outside-wire blocks likewise.
     // Lane l of a block fetches the low (l < 32) or high half of element 32 * block + (l & 31).
     const uint32_t half = lane >> 5, ein = lane & 31u;
@@ -905,7 +905,7 @@ __global__ __launch_bounds__(64 * WAVES, 4) void b3w_r1cs_stream_kernel(   // (s
     // every global load above has landed before the first DMA is issued: inside the pipeline the compiler must find nothing of
     // its own to wait for (a wait it placed at a first use in the loop would drain the DMAs on every iteration)
 #pragma unroll
-    for (int p = 0; p < RP; p++) asm volatile("" :: "v"(pre[p].x), "v"(pre[p].y), "v"(pre[p].z), "v"(pre[p].w), "v"(rid[p]));
+    for (int p = 0; p < RP; p++) asm volatile("" :: "v"(pre[p].x), "v"(pre[p].y), "v"(pre[p].z), "v"(pre[p].w));
 #pragma unroll
     for (int q = 0; q < MB; q++) asm volatile("" :: "v"(off[q]));
 #pragma unroll
@@ -914,15 +914,64 @@ __global__ __launch_bounds__(64 * WAVES, 4) void b3w_r1cs_stream_kernel(   // (s
     for (int q = 0; q < EG; q++) asm volatile("" :: "s"((uint32_t)mbit[q]), "s"((uint32_t)(mbit[q] >> 32)));
     asm volatile("" :: "s"((uint32_t)xbit), "s"((uint32_t)(xbit >> 32)));
     lds_barrier();                                                                 // the word list (and, the first time, the coefficients) in place
+    // ---- the verdicts of a unit: general rows from their finished sums (the owner lane zeroes them for the next unit), the mask
+    // words of the deferred rows, the violation counts.  Runs one barrier AFTER the unit's words were added — behind barrier one
+    // of the NEXT unit, beside that unit's pack phase — so a unit costs two barriers, not three.
+    auto verdicts = [&](const uint32_t b, const uint32_t verdict, const bool anomaly) {
+      unsigned long long *block = scratch + ((size_t)b * S.ntiles + tile) * block_words;
+      uint32_t nbad = 0, low = 0xFFFFFFFFu, badmask = 0;
+#pragma unroll
+      for (int p = 0; p < RP; p++) {
+        if (!has_rows[p]) continue;
+        const uint4 d = pre[p];
+        bool defer = (verdict >> p) & 1u, bad = (verdict >> (8 + p)) & 1u;
+        if (has_gen[p]) {
+          if ((d.y >> 28) == 1u) {
+            unsigned long long *sum = gsum + 6u * d.x;
+            const __int128 A = (__int128)(long long)sum[0] + ((__int128)(long long)sum[1] << 52);
+            const __int128 B = (__int128)(long long)sum[2] + ((__int128)(long long)sum[3] << 52);
+            const __int128 C = (__int128)(long long)sum[4] + ((__int128)(long long)sum[5] << 52);
+            defer = gflag[d.x] != 0u || (dbg & 32u) != 0u || !(A < lim && A > -lim && B < lim && B > -lim);
+            bad = !defer && A * B != C;                      // |A * B - C| < 2^127 < p: "= 0 mod p" is "= 0"
+#pragma unroll
+            for (int q = 0; q < 6; q++) sum[q] = 0ull;
+            gflag[d.x] = 0u;
+          }
+        }
+        if (bad) { nbad++; badmask |= 1u << p; }
+        const unsigned long long mask = (has_gen[p] || anomaly ? __ballot(defer) : 0ull) | dmask[p];
+        if (lane == 0) block[1 + (uint32_t)p * WAVES + wave] = mask;               // (word (row - first) / 64)
+      }
+      if (__ballot(nbad != 0) != 0ull) {                   // (rare: a body that violates something — the only global loads of the loop
+        // are in here: one anywhere else would make the compiler wait for every DMA in flight, unit after unit)
+#pragma unroll
+        for (int p = 0; p < RP; p++)
+          if ((badmask >> p) & 1u) low = min(low, S.row_id[td.x + (uint32_t)p * THREADS + tid]);
+#pragma unroll
+        for (int sh = 32; sh > 0; sh >>= 1) {
+          nbad += (uint32_t)__shfl_xor((int)nbad, sh);
+          low = min(low, (uint32_t)__shfl_xor((int)low, sh));
+        }
+        if (lane == 0) {
+          atomicAdd(&violations[b], nbad);
+          if (first) atomicMin(&first[b], low);
+        }
+      }
+    };
     for (uint32_t k = 0; k < (uint32_t)NBUF && k < m; k++) issue(b_lo + k, k);
-    for (uint32_t i = 0; i < m; i++) {
+    uint32_t pend_verdict = 0;                               // the unit whose words are in the sums but whose verdicts are not out yet
+    bool pend = false, pend_anomaly = false;
+    for (uint32_t i = 0; i <= m; i++) {                      // (iteration m only finishes unit m - 1: one copy of the verdict code)
       const uint32_t b = b_lo + i, buf = i % (uint32_t)NBUF;
-      const uint32_t ahead = m - 1u - i < (uint32_t)NBUF - 1u ? m - 1u - i : (uint32_t)NBUF - 1u;      // younger tiles in flight
+      const uint32_t ahead = i >= m ? 0u : m - 1u - i < (uint32_t)NBUF - 1u ? m - 1u - i : (uint32_t)NBUF - 1u;      // younger tiles in flight
       if (stamping) t_prev = __builtin_amdgcn_s_memtime();
-      vm_wait(per_tile * ahead);                                                   // this wave's pieces of tile i have landed
+      if (i < m) vm_wait(per_tile * ahead);                                        // this wave's pieces of tile i have landed
       B3W_STAMP(0);
       lds_barrier();                                                               // ... and everyone's; the rows of tile i - 1 are done with el
       B3W_STAMP(1);
+      if (pend) verdicts(b - 1u, pend_verdict, pend_anomaly);                       // (every word of unit i - 1 is in its row's sums)
+      B3W_STAMP(7);
+      if (i >= m) break;
       // ---- pack: 32-byte elements -> 8 bytes (bit 63 = "not below 2^63") + two bit words per 64 elements; anything the masks
       // take for a bit and that is none raises the anomaly flag, and so does wire 0 not being 1
       const unsigned char *raw = smem + (size_t)buf * raw_stride;
@@ -953,16 +1002,15 @@ __global__ __launch_bounds__(64 * WAVES, 4) void b3w_r1cs_stream_kernel(   // (s
           if (lane == 0) { packed[2 * (16u + xg)] = ones; packed[2 * (16u + xg) + 1] = bads; }
           flag = flag || (bads & xbit) != 0ull || (tile != 0 && xg == 0 && !(ones & 1ull));          // (outside wire 0 of every other tile)
         }
-        if (flag && lane == 0) *lanom = 1u;
+        if (flag && lane == 0) lanom[i & 1u] = 1u;
       }
       B3W_STAMP(2);
-      for (uint32_t k = tid; k < 6u * gd.z; k += THREADS) gsum[k] = 0ull;          // (the previous unit's owner lanes read theirs before barrier one)
-      for (uint32_t k = tid; k < gd.z; k += THREADS) gflag[k] = 0u;
-      lds_barrier();                                                               // raw image read out (lgkmcnt retired), el / packed in place
+      lds_barrier();                                                               // raw image read out (lgkmcnt retired), el / packed in place; the sums are zero
       if (i + (uint32_t)NBUF < m) issue(b + (uint32_t)NBUF, buf);                  // the freed buffer takes tile i + NBUF
       B3W_STAMP(3);
       if (dbg & 1u) continue;
-      const bool anomaly = __builtin_amdgcn_readfirstlane(*lanom) != 0u;
+      const bool anomaly = __builtin_amdgcn_readfirstlane(lanom[i & 1u]) != 0u;
+      if (tid == 0) lanom[(i + 1u) & 1u] = 0u;               // (read one unit ago by everyone; the next pack, behind a barrier, may set it)
       // ---- general rows, one WORD per lane: chunk c of 64 words goes to wave c mod WAVES; a lane adds coefficient * element (or
       // the value of a bit run) into its row's part sum.  A part sum is two 64-bit counters {low, high} worth low + high * 2^52: a
       // contribution below 2^54 goes to `low` whole, a larger one (the dyadic row scaling of the O2 systems makes 2^30 * word) is cut
@@ -1045,42 +1093,7 @@ __global__ __launch_bounds__(64 * WAVES, 4) void b3w_r1cs_stream_kernel(   // (s
         }
       }
       B3W_STAMP(5);
-      lds_barrier();                                                               // every word's contribution is in its row's sums
-      B3W_STAMP(6);
-      if (tid == 0) *lanom = 0u;                                                   // (everyone has read it; the next unit's pack comes after a barrier)
-      unsigned long long *block = scratch + ((size_t)b * S.ntiles + tile) * block_words;
-      uint32_t nbad = 0, low = 0xFFFFFFFFu;
-#pragma unroll
-      for (int p = 0; p < RP; p++) {
-        if (!has_rows[p]) continue;
-        const uint4 d = pre[p];
-        bool defer = (verdict >> p) & 1u, bad = (verdict >> (8 + p)) & 1u;
-        if (has_gen[p]) {
-          if ((d.y >> 28) == 1u) {
-            const unsigned long long *sum = gsum + 6u * d.x;
-            const __int128 A = (__int128)(long long)sum[0] + ((__int128)(long long)sum[1] << 52);
-            const __int128 B = (__int128)(long long)sum[2] + ((__int128)(long long)sum[3] << 52);
-            const __int128 C = (__int128)(long long)sum[4] + ((__int128)(long long)sum[5] << 52);
-            defer = gflag[d.x] != 0u || (dbg & 32u) != 0u || !(A < lim && A > -lim && B < lim && B > -lim);
-            bad = !defer && A * B != C;                      // |A * B - C| < 2^127 < p: "= 0 mod p" is "= 0"
-          }
-        }
-        if (bad) { nbad++; low = min(low, rid[p]); }
-        const unsigned long long mask = (has_gen[p] || anomaly ? __ballot(defer) : 0ull) | dmask[p];
-        if (lane == 0) block[1 + (uint32_t)p * WAVES + wave] = mask;               // (word (row - first) / 64)
-      }
-      if (__ballot(nbad != 0) != 0ull) {                   // (rare: a body that violates something)
-#pragma unroll
-        for (int sh = 32; sh > 0; sh >>= 1) {
-          nbad += (uint32_t)__shfl_xor((int)nbad, sh);
-          low = min(low, (uint32_t)__shfl_xor((int)low, sh));
-        }
-        if (lane == 0) {
-          atomicAdd(&violations[b], nbad);
-          if (first) atomicMin(&first[b], low);
-        }
-      }
-      B3W_STAMP(7);
+      pend = true; pend_verdict = verdict; pend_anomaly = anomaly;
     }
     u += m;
   }
@@ -1094,40 +1107,50 @@ __global__ __launch_bounds__(64 * WAVES, 4) void b3w_r1cs_stream_kernel(   // (s
 // workgroups fit a CU where four-wave ones fit four (354 -> 217 us per 4 096 nova bodies).  A lane takes a row; a LONG row (each
 // derived nova system has one of 66 ... 133 terms whose coefficients, 2^70 and more, are no small integers: always deferred, and
 // 200 us of dependent loads on one lane) is dealt to all 64 lanes instead.
+#define B3W_R1CS_DEFERRED_TILES 1u
 __global__ __launch_bounds__(64) void b3w_r1cs_deferred_kernel(const uint8_t *__restrict__ bodies, uint64_t pitch, uint32_t n, B3wR1csSystem S,
                                                                const unsigned long long *__restrict__ scratch, uint32_t block_words, B3wField F,
                                                                uint32_t *__restrict__ violations, uint32_t *__restrict__ first) {
-  const uint32_t per_group = 8u * S.ntiles;
+  // a wave looks at B3W_R1CS_DEFERRED_TILES consecutive tiles of one body (measured with 4: the same 22 us for a batch of
+  // blake3_compression as with 1 -- the launch is bound by the first load of each wave, not by the 98 304 dispatches)
+  const uint32_t tgroups = (S.ntiles + B3W_R1CS_DEFERRED_TILES - 1u) / B3W_R1CS_DEFERRED_TILES;
+  const uint32_t per_group = 8u * tgroups;
   const uint32_t b = (blockIdx.x / per_group) * 8u + (blockIdx.x & 7u);
-  const uint32_t tile = (blockIdx.x % per_group) >> 3;
+  const uint32_t tile0 = ((blockIdx.x % per_group) >> 3) * B3W_R1CS_DEFERRED_TILES;
   if (b >= n) return;
-  const unsigned long long *block = scratch + ((size_t)b * S.ntiles + tile) * block_words;
-  const uint4 td = reinterpret_cast<const uint4 *>(S.tiles)[tile];
-  const uint32_t words = (td.y + 63u) >> 6;              // word w of the first kernel = rows first + 64 * w + lane (at most 64 words: 4 096 rows)
-  // one load decides: lane w fetches mask word w; a (body, tile) none of whose rows was deferred leaves here
-  const unsigned long long mine_w = threadIdx.x < words ? block[1 + threadIdx.x] : 0ull;
-  if (__ballot(mine_w != 0ull) == 0ull) return;
   const uint8_t *body = bodies + (uint64_t)b * pitch;
   uint32_t nbad = 0, low = 0xFFFFFFFFu;
-  for (uint32_t wi = 0; wi < words; wi++) {
-    const unsigned long long mask = __shfl(mine_w, (int)wi);
-    if (mask == 0) continue;                             // (wave-uniform)
-    const bool mine = (mask >> threadIdx.x) & 1ull;
-    const uint32_t r = td.x + 64u * wi + threadIdx.x;    // (< td.x + td.y for a marked lane: only such lanes set a bit)
-    uint4 d = make_uint4(0, 0, 0, 0);
-    if (mine) d = reinterpret_cast<const uint4 *>(S.g_rows)[S.row_k[r]];
-    const bool is_long = mine && d.y + d.z + d.w > 24u;
-    if (mine && !is_long && gather_row(body, d, S.g_wires, S.g_cids, S.coefs, F)) { nbad++; low = min(low, S.row_id[r]); }
-    unsigned long long longs = __ballot(is_long);
-    while (longs) {                                      // (wave-uniform)
-      const int L = __ffsll((long long)longs) - 1;
-      longs &= longs - 1ull;
-      const uint4 dl = make_uint4((uint32_t)__shfl((int)d.x, L), (uint32_t)__shfl((int)d.y, L), (uint32_t)__shfl((int)d.z, L),
-                                  (uint32_t)__shfl((int)d.w, L));
-      const bool bad = gather_row_wave(body, dl, S.g_wires, S.g_cids, S.coefs, F);
-      if ((int)threadIdx.x == L && bad) { nbad++; low = min(low, S.row_id[r]); }
+  // all mask words of the tiles of this wave in one go: lane l fetches word l % 16 (+ 16, + 32 ...) of tile l / 16
+  unsigned long long any = 0ull;
+  for (uint32_t tile = tile0; tile < tile0 + B3W_R1CS_DEFERRED_TILES && tile < S.ntiles; tile++) {
+    const unsigned long long *block = scratch + ((size_t)b * S.ntiles + tile) * block_words;
+    const uint4 td = reinterpret_cast<const uint4 *>(S.tiles)[tile];
+    const uint32_t words = (td.y + 63u) >> 6;              // word w of the first kernel = rows first + 64 * w + lane (at most 64 words: 4 096 rows)
+    // one load decides: lane w fetches mask word w; a (body, tile) none of whose rows was deferred is done
+    const unsigned long long mine_w = threadIdx.x < words ? block[1 + threadIdx.x] : 0ull;
+    if (__ballot(mine_w != 0ull) == 0ull) continue;
+    any = 1ull;
+    for (uint32_t wi = 0; wi < words; wi++) {
+      const unsigned long long mask = __shfl(mine_w, (int)wi);
+      if (mask == 0) continue;                             // (wave-uniform)
+      const bool mine = (mask >> threadIdx.x) & 1ull;
+      const uint32_t r = td.x + 64u * wi + threadIdx.x;    // (< td.x + td.y for a marked lane: only such lanes set a bit)
+      uint4 d = make_uint4(0, 0, 0, 0);
+      if (mine) d = reinterpret_cast<const uint4 *>(S.g_rows)[S.row_k[r]];
+      const bool is_long = mine && d.y + d.z + d.w > 24u;
+      if (mine && !is_long && gather_row(body, d, S.g_wires, S.g_cids, S.coefs, F)) { nbad++; low = min(low, S.row_id[r]); }
+      unsigned long long longs = __ballot(is_long);
+      while (longs) {                                      // (wave-uniform)
+        const int L = __ffsll((long long)longs) - 1;
+        longs &= longs - 1ull;
+        const uint4 dl = make_uint4((uint32_t)__shfl((int)d.x, L), (uint32_t)__shfl((int)d.y, L), (uint32_t)__shfl((int)d.z, L),
+                                    (uint32_t)__shfl((int)d.w, L));
+        const bool bad = gather_row_wave(body, dl, S.g_wires, S.g_cids, S.coefs, F);
+        if ((int)threadIdx.x == L && bad) { nbad++; low = min(low, S.row_id[r]); }
+      }
     }
   }
+  if (any == 0ull) return;
 #pragma unroll
   for (int sh = 32; sh > 0; sh >>= 1) {
     nbad += (uint32_t)__shfl_xor((int)nbad, sh);
@@ -1279,7 +1302,8 @@ extern "C" int b3w_launch_r1cs_lean(const uint8_t *d_bodies, uint32_t n, uint64_
 #undef B3W_R1CS_LEAN_LAUNCH
     e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(b3w_r1cs_deferred_kernel, grid, dim3(64), 0, stream, d_bodies + (uint64_t)b0 * pitch, pitch, nb, *sys, d_scratch, bw,
+    const dim3 dgrid(((nb + 7) / 8) * 8 * ((sys->ntiles + B3W_R1CS_DEFERRED_TILES - 1u) / B3W_R1CS_DEFERRED_TILES));
+    hipLaunchKernelGGL(b3w_r1cs_deferred_kernel, dgrid, dim3(64), 0, stream, d_bodies + (uint64_t)b0 * pitch, pitch, nb, *sys, d_scratch, bw,
                        *field, d_violations + b0, d_first ? d_first + b0 : nullptr);
     e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
@@ -1293,7 +1317,7 @@ static inline size_t stream_smem(const B3wR1csSystem *sys, int nbuf) {
   const uint32_t groups = ((B3W_R1CS_TILE + ext_cap + 63u) >> 6) + 1u;
   return (size_t)nbuf * (B3W_R1CS_TILE + ext_cap) * 32u + (size_t)(B3W_R1CS_TILE + ext_cap) * 8u + (size_t)groups * 16u +
          (size_t)sys->max_g_rows * 48u + (size_t)((sys->max_g_rows + 1u) & ~1u) * 4u + 2u * (size_t)((sys->max_g_words + 4u) & ~3u) * 4u +
-         (size_t)sys->ncoef * 8u + 16u;
+         (size_t)sys->ncoef * 8u + 16u;       // (+ the two anomaly words)
 }
 
 // 0 = launched; -6 = this system does not fit the stream kernel (the caller takes the lean pair)
@@ -1379,7 +1403,7 @@ extern "C" int b3w_launch_r1cs_stream(const uint8_t *d_bodies, uint32_t n, uint6
       }
     }
     if (env_dbg) continue;                                 // (an experiment that skips phases leaves no valid masks behind)
-    const dim3 dgrid(((nb + 7) / 8) * 8 * sys->ntiles);
+    const dim3 dgrid(((nb + 7) / 8) * 8 * ((sys->ntiles + B3W_R1CS_DEFERRED_TILES - 1u) / B3W_R1CS_DEFERRED_TILES));
     hipLaunchKernelGGL(b3w_r1cs_deferred_kernel, dgrid, dim3(64), 0, stream, d_bodies + (uint64_t)b0 * pitch, pitch, nb, *sys, d_scratch, bw,
                        *field, d_violations + b0, d_first ? d_first + b0 : nullptr);
     e = hipGetLastError();
