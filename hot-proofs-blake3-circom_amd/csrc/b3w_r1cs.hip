@@ -771,6 +771,30 @@ __device__ __forceinline__ void glds16s(uint32_t lds_dst /* wave-uniform byte ad
                  : "=&s"(keep) : "v"(off), "s"(dst), "s"(base) : "memory");
 }
 
+// A value the compiler must take as new at this point: what is derived from a row descriptor (LDS addresses of its operands, of its
+// sums, the address of its id) is then computed where it is used, unit after unit, instead of once per tile into registers that
+// stay occupied through the whole pipeline — 74 VGPRs of such loop invariants against 49 the loop itself works in, and the
+// descriptors spilled to scratch to make room (every scratch reload waits for vmcnt(0): for every load in flight).
+__device__ __forceinline__ uint4 fresh(uint4 d) {
+  asm volatile("" : "+v"(d.x), "+v"(d.y), "+v"(d.z), "+v"(d.w));
+  return d;
+}
+// 16 bytes per lane into REGISTERS (the NBUF = 0 shapes): base + off, read once
+typedef uint32_t b3w_u32x4 __attribute__((ext_vector_type(4)));
+// a = {elements 0 ... 31: low halves | high halves}, b = {elements 32 ... 63 likewise}  ->  a = low halves of 0 ... 63, b = high halves
+__device__ __forceinline__ void halves_apart(uint32_t &a, uint32_t &b) {
+  const auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);           // lanes 32 ... 63 of a <-> lanes 0 ... 31 of b
+  a = r[0]; b = r[1];
+}
+template <bool NT>
+__device__ __forceinline__ uint4 ldg16(const uint8_t *base /* wave-uniform */, uint32_t off /* per lane */) {
+  const b3w_u32x4 *p = reinterpret_cast<const b3w_u32x4 *>(base + off);
+  b3w_u32x4 v;
+  if constexpr (NT) v = __builtin_nontemporal_load(p);
+  else v = *p;
+  return make_uint4(v.x, v.y, v.z, v.w);
+}
+
 // Everything a wave does here costs every other wave of its SIMD four cycles per instruction, and the waves of one workgroup move in
 // lockstep from barrier to barrier (profiles/r03 stamps: sixteen waves at 340 instructions per unit were 5 400 cycles), so
 //   * the steady state is written for instruction count: wave-uniform values live in SGPRs (the wave number comes through
@@ -816,13 +840,16 @@ __global__ __launch_bounds__(64 * WAVES, 4) void b3w_r1cs_stream_kernel(   // (s
   uint32_t *gwords = gflag + ((S.max_g_rows + 1u) & ~1u);
   uint32_t *gmeta = gwords + ((S.max_g_words + 4u) & ~3u);
   long long *lcoef = reinterpret_cast<long long *>(gmeta + ((S.max_g_words + 4u) & ~3u));
-  uint32_t *lanom = reinterpret_cast<uint32_t *>(lcoef + S.ncoef);                 // [unit parity] != 0: something the masks cannot vouch for in this (body, tile)
+  unsigned long long *lsum = reinterpret_cast<unsigned long long *>(lcoef + S.ncoef);      // [unit parity]: bit w = the unit's mask word w is not zero (and was stored)
+  uint32_t *lanom = reinterpret_cast<uint32_t *>(lsum + 2);                        // [unit parity] != 0: something the masks cannot vouch for in this (body, tile)
   const __int128 lim = (__int128)1 << 63;
   for (uint32_t k = tid; k < S.ncoef; k += THREADS) lcoef[k] = S.coef_small[k];
   if (tid < 2) packed[2 * (groups - 1) + tid] = 0ull;                              // the spare pair
   const uint32_t lds0 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)smem);
-  const uint32_t nxg = (ext_cap + 63u) >> 6;                                       // groups of outside wires (at most 8: the LAST waves pack them)
-  const uint32_t xg = (uint32_t)WAVES - 1u - wave;                                 // ... this wave's, if it has one
+  // who does what beside the equal shares (two element groups, every row pass): the general words go to the LAST waves (whose last
+  // row pass is the short one), the groups of outside wires (at most 8) to waves 2, 3, ... — not both to the same waves
+  const uint32_t nxg = (ext_cap + 63u) >> 6;
+  const uint32_t xg = (wave + (uint32_t)WAVES - 2u) % (uint32_t)WAVES;             // ... this wave's group of outside wires, if it has one
   const bool packs_ext = xg < nxg;
 
   // units, tile-major: u = tile * n + body; a workgroup takes a contiguous range of equal COST (S.scost: a tile with many general
@@ -862,6 +889,10 @@ __global__ __launch_bounds__(64 * WAVES, 4) void b3w_r1cs_stream_kernel(   // (s
       has_gen[p] = __ballot((pre[p].y >> 28) == 1u) != 0ull;
       dmask[p] = __ballot((pre[p].y >> 30) == 1u);
     }
+    bool any_gen = false;
+    unsigned long long any_dmask = 0ull;
+#pragma unroll
+    for (int p = 0; p < RP; p++) { any_gen = any_gen || has_gen[p]; any_dmask |= dmask[p]; }
     unsigned long long mbit[EG];                             // elements of this wave's groups the tile's rows take for bits
 #pragma unroll
     for (int q = 0; q < EG; q++) mbit[q] = S.smask[(size_t)tile * S.smask_groups + wave + (uint32_t)q * WAVES];
@@ -870,7 +901,7 @@ __global__ __launch_bounds__(64 * WAVES, 4) void b3w_r1cs_stream_kernel(   // (s
       gwords[k] = S.sgwords[gd.x + k];
       gmeta[k] = S.sgmeta[gd.x + k];
     }
-    if (tid < 2) lanom[tid] = 0u;
+    if (tid < 2) { lanom[tid] = 0u; lsum[tid] = 0ull; }
     for (uint32_t k = tid; k < 6u * gd.z; k += THREADS) gsum[k] = 0ull;            // (afterwards every general row's owner lane zeroes its own sums)
     for (uint32_t k = tid; k < gd.z; k += THREADS) gflag[k] = 0u;
     // DMA blocks of this wave: tile blocks wave + q * WAVES (a block = 32 elements = 1 KiB), outside-wire blocks likewise.
@@ -891,10 +922,53 @@ __global__ __launch_bounds__(64 * WAVES, 4) void b3w_r1cs_stream_kernel(   // (s
       offx[q] = (blk < nxblk ? S.ext[td.z + (e < td.w ? e : td.w - 1u)] : 0u) * 32u + half * 16u;
       per_tile += blk < nxblk ? 1u : 0u;
     }
+    // NBUF = 0: no raw image in LDS at all — the wave fetches the elements it packs (groups wave + q * WAVES, and its group of
+    // outside wires) into registers, one unit ahead: 16 + 8 VGPRs hold what 48 KB of LDS held, so a workgroup's next unit is in
+    // flight during everything but its own pack phase, whatever the LDS holds
+    uint4 rlo[EG], rhi[EG], xlo = make_uint4(0, 0, 0, 0), xhi = make_uint4(0, 0, 0, 0);
+    // A fetch of a group is two CONTIGUOUS 1 KiB loads (elements 64 g ... + 31 and + 32 ... + 63; a lane below 32 takes the low
+    // 16 bytes of its element, the lane 32 above it the high 16: 8 cache lines per instruction, every byte of them used), then
+    // v_permlane32_swap puts the low halves of all 64 elements into one register set and the high halves into the other.  (One
+    // element per lane — 32-byte stride, twice — is 16 half-used lines per instruction, and the texture path is what sixteen waves
+    // queue for here.)
+    uint32_t eoff[EG][2], xoff = 0;
+    bool xact = false;
+    if constexpr (NBUF == 0) {
+#pragma unroll
+      for (int q = 0; q < EG; q++)
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+          const uint32_t e = (wave + (uint32_t)q * WAVES) * 64u + (uint32_t)h * 32u + (lane & 31u);
+          eoff[q][h] = (t0 + (e < n_local ? e : n_local - 1u)) * 32u + (lane >> 5) * 16u;
+        }
+#pragma unroll
+      for (int q = 0; q < EG; q++) rlo[q] = rhi[q] = make_uint4(0, 0, 0, 0);
+      const uint32_t j = xg * 64u + lane;
+      xact = packs_ext && j < td.w;                          // outside wires: a lane per wire (a gather), lanes without one masked off
+      if (xact) xoff = S.ext[td.z + j] * 32u;
+      asm volatile("" :: "v"(xoff));
+    }
+    // (registers) the outside wires of a unit are fetched one phase EARLIER than its tile elements — a gather, 64 cache lines per
+    // instruction, is the slowest thing here to come back
+    auto issue_ext = [&](const uint32_t body_index) {
+      const uint8_t *body = bodies + (uint64_t)((dbg & 12u) ? b_lo : body_index) * pitch;
+      if (xact) {
+        xlo = ldg16<false>(body, xoff);
+        xhi = ldg16<false>(body, xoff + 16u);
+      }
+    };
     auto issue = [&](const uint32_t body_index, const uint32_t buf) {
-      const uint8_t *body = bodies + (uint64_t)body_index * pitch;                 // (scalar arithmetic)
+      const uint8_t *body = bodies + (uint64_t)(NBUF == 0 && (dbg & 12u) ? b_lo : body_index) * pitch;      // (scalar arithmetic; registers, 4 or 8: the tile's first body over and over — no HBM traffic, the same instructions)
       const uint32_t dst = lds0 + buf * raw_stride;
-      if ((dbg & 4u) || ((dbg & 8u) && body_index != b_lo)) return;       // (8: only the first body of the tile is ever staged)
+      if (NBUF != 0 && ((dbg & 4u) || ((dbg & 8u) && body_index != b_lo))) return;      // (8: only the first body of the tile is ever staged)
+      if constexpr (NBUF == 0) {
+#pragma unroll
+        for (int q = 0; q < EG; q++) {                       // (a group behind the last tile's end re-reads that tile's last element: no branch)
+          rlo[q] = ldg16<true>(body, eoff[q][0]);              // (until the pack: elements + 0 ... 31, both halves)
+          rhi[q] = ldg16<true>(body, eoff[q][1]);              // (... + 32 ... 63)
+        }
+        return;
+      }
 #pragma unroll
       for (int q = 0; q < MB; q++)
         if (wave + (uint32_t)q * WAVES < nblk) glds16s(dst + (wave + (uint32_t)q * WAVES) * 1024u, body, off[q], !(dbg & 64u));      // tile bytes are read once: non-temporal
@@ -917,15 +991,20 @@ __global__ __launch_bounds__(64 * WAVES, 4) void b3w_r1cs_stream_kernel(   // (s
     // ---- the verdicts of a unit: general rows from their finished sums (the owner lane zeroes them for the next unit), the mask
     // words of the deferred rows, the violation counts.  Runs one barrier AFTER the unit's words were added — behind barrier one
     // of the NEXT unit, beside that unit's pack phase — so a unit costs two barriers, not three.
+    // What goes to the deferred kernel, per (body, tile): word 0 of the block = which mask words are not zero; only those are
+    // stored.  A wave whose rows of this unit are all decided and hold (every wave of almost every unit) leaves at once: one
+    // compare.  (A mask word per wave and row pass, stored unit after unit, was 16 ... 32 stores a unit on the path sixteen waves
+    // queue for, and as many loads in the deferred kernel.)
     auto verdicts = [&](const uint32_t b, const uint32_t verdict, const bool anomaly) {
+      if (!any_gen && !anomaly && any_dmask == 0ull && __ballot(verdict != 0u) == 0ull) return;
       unsigned long long *block = scratch + ((size_t)b * S.ntiles + tile) * block_words;
       uint32_t nbad = 0, low = 0xFFFFFFFFu, badmask = 0;
 #pragma unroll
       for (int p = 0; p < RP; p++) {
         if (!has_rows[p]) continue;
-        const uint4 d = pre[p];
         bool defer = (verdict >> p) & 1u, bad = (verdict >> (8 + p)) & 1u;
         if (has_gen[p]) {
+          const uint4 d = fresh(pre[p]);
           if ((d.y >> 28) == 1u) {
             unsigned long long *sum = gsum + 6u * d.x;
             const __int128 A = (__int128)(long long)sum[0] + ((__int128)(long long)sum[1] << 52);
@@ -940,13 +1019,15 @@ __global__ __launch_bounds__(64 * WAVES, 4) void b3w_r1cs_stream_kernel(   // (s
         }
         if (bad) { nbad++; badmask |= 1u << p; }
         const unsigned long long mask = (has_gen[p] || anomaly ? __ballot(defer) : 0ull) | dmask[p];
-        if (lane == 0) block[1 + (uint32_t)p * WAVES + wave] = mask;               // (word (row - first) / 64)
+        if (mask != 0ull && lane == 0) {                     // (wave-uniform; word (row - first) / 64)
+          block[1 + (uint32_t)p * WAVES + wave] = mask;
+          atomicOr(&lsum[b & 1u], 1ull << ((uint32_t)p * WAVES + wave));
+        }
       }
-      if (__ballot(nbad != 0) != 0ull) {                   // (rare: a body that violates something — the only global loads of the loop
-        // are in here: one anywhere else would make the compiler wait for every DMA in flight, unit after unit)
+      if (__ballot(nbad != 0) != 0ull) {                   // (rare: a body that violates something)
 #pragma unroll
         for (int p = 0; p < RP; p++)
-          if ((badmask >> p) & 1u) low = min(low, S.row_id[td.x + (uint32_t)p * THREADS + tid]);
+          if ((badmask >> p) & 1u) low = min(low, S.row_id[td.x + (uint32_t)p * THREADS + fresh(make_uint4(tid, 0, 0, 0)).x]);
 #pragma unroll
         for (int sh = 32; sh > 0; sh >>= 1) {
           nbad += (uint32_t)__shfl_xor((int)nbad, sh);
@@ -958,143 +1039,178 @@ __global__ __launch_bounds__(64 * WAVES, 4) void b3w_r1cs_stream_kernel(   // (s
         }
       }
     };
-    for (uint32_t k = 0; k < (uint32_t)NBUF && k < m; k++) issue(b_lo + k, k);
-    uint32_t pend_verdict = 0;                               // the unit whose words are in the sums but whose verdicts are not out yet
-    bool pend = false, pend_anomaly = false;
-    for (uint32_t i = 0; i <= m; i++) {                      // (iteration m only finishes unit m - 1: one copy of the verdict code)
-      const uint32_t b = b_lo + i, buf = i % (uint32_t)NBUF;
-      const uint32_t ahead = i >= m ? 0u : m - 1u - i < (uint32_t)NBUF - 1u ? m - 1u - i : (uint32_t)NBUF - 1u;      // younger tiles in flight
-      if (stamping) t_prev = __builtin_amdgcn_s_memtime();
-      if (i < m) vm_wait(per_tile * ahead);                                        // this wave's pieces of tile i have landed
-      B3W_STAMP(0);
-      lds_barrier();                                                               // ... and everyone's; the rows of tile i - 1 are done with el
-      B3W_STAMP(1);
-      if (pend) verdicts(b - 1u, pend_verdict, pend_anomaly);                       // (every word of unit i - 1 is in its row's sums)
-      B3W_STAMP(7);
-      if (i >= m) break;
-      // ---- pack: 32-byte elements -> 8 bytes (bit 63 = "not below 2^63") + two bit words per 64 elements; anything the masks
-      // take for a bit and that is none raises the anomaly flag, and so does wire 0 not being 1
-      const unsigned char *raw = smem + (size_t)buf * raw_stride;
-      const bool do_pack = !(dbg & 2u) && !((dbg & 8u) && i > 0);                  // (8: ... and packed once; its rows are evaluated m times)
-      if (do_pack) {
-        bool flag = false;
-#pragma unroll
-        for (int q = 0; q < EG; q++) {
-          const uint32_t g = wave + (uint32_t)q * WAVES, e = g * 64u + lane;       // the wave holds elements 64 g ... 64 g + 63
-          const uint4 lo = *reinterpret_cast<const uint4 *>(raw + (e >> 5) * 1024u + (e & 31u) * 16u);
-          const uint4 hi = *reinterpret_cast<const uint4 *>(raw + (e >> 5) * 1024u + 512u + (e & 31u) * 16u);
-          const unsigned long long z = e < n_local ? lean_pack(lo, hi) : 0ull;
-          el[e] = z;
-          const unsigned long long ones = __ballot(z == 1ull), bads = __ballot(z > 1ull);
-          if (lane == 0) { packed[2 * g] = ones; packed[2 * g + 1] = bads; }
-          flag = flag || (bads & mbit[q]) != 0ull || (tile == 0 && g == 0 && !(ones & 1ull));        // (wire 0 is element 0 of tile 0)
-        }
-        if (packs_ext) {                                                           // (whole waves, for the ballots)
-          const uint32_t j = xg * 64u + lane;                                      // outside wire j of the tile
-          unsigned long long z = 0ull;
-          if (j < td.w) {
-            const uint4 lo = *reinterpret_cast<const uint4 *>(raw + B3W_R1CS_TILE * 32u + (j >> 5) * 1024u + (j & 31u) * 16u);
-            const uint4 hi = *reinterpret_cast<const uint4 *>(raw + B3W_R1CS_TILE * 32u + (j >> 5) * 1024u + 512u + (j & 31u) * 16u);
-            z = lean_pack(lo, hi);
-          }
-          if (j < ext_cap) el[B3W_R1CS_TILE + j] = z;
-          const unsigned long long ones = __ballot(z == 1ull), bads = __ballot(z > 1ull);
-          if (lane == 0) { packed[2 * (16u + xg)] = ones; packed[2 * (16u + xg) + 1] = bads; }
-          flag = flag || (bads & xbit) != 0ull || (tile != 0 && xg == 0 && !(ones & 1ull));          // (outside wire 0 of every other tile)
-        }
-        if (flag && lane == 0) lanom[i & 1u] = 1u;
+    // word 0 of a unit's block, by one lane, once every wave's verdicts of the unit are behind a barrier
+    auto summary = [&](const uint32_t b) {
+      if (wave == 1u % (uint32_t)WAVES && lane == 0) {
+        scratch[((size_t)b * S.ntiles + tile) * block_words] = lsum[b & 1u];
+        lsum[b & 1u] = 0ull;
       }
-      B3W_STAMP(2);
-      lds_barrier();                                                               // raw image read out (lgkmcnt retired), el / packed in place; the sums are zero
-      if (i + (uint32_t)NBUF < m) issue(b + (uint32_t)NBUF, buf);                  // the freed buffer takes tile i + NBUF
-      B3W_STAMP(3);
-      if (dbg & 1u) continue;
-      const bool anomaly = __builtin_amdgcn_readfirstlane(lanom[i & 1u]) != 0u;
-      if (tid == 0) lanom[(i + 1u) & 1u] = 0u;               // (read one unit ago by everyone; the next pack, behind a barrier, may set it)
-      // ---- general rows, one WORD per lane: chunk c of 64 words goes to wave c mod WAVES; a lane adds coefficient * element (or
-      // the value of a bit run) into its row's part sum.  A part sum is two 64-bit counters {low, high} worth low + high * 2^52: a
-      // contribution below 2^54 goes to `low` whole, a larger one (the dyadic row scaling of the O2 systems makes 2^30 * word) is cut
-      // at bit 52 — products stay below 2^103 (the lean kernel's bound) and a row has at most 256 words, so no counter overflows
-      // and the sum is exact.
-      if (!(dbg & 32u))
-        for (uint32_t c0 = wave * 64u; c0 < gd.y; c0 += THREADS) {
-          const uint32_t iw = c0 + lane;
-          const bool act = iw < gd.y;
-          const uint32_t w = gwords[act ? iw : 0u], w1 = gwords[act ? iw + 1u : 0u], mt = gmeta[act ? iw : 0u];
-          const bool second = (mt >> 2) & 1u;                // the second word of a run: nothing of its own
-          const bool is_run = act && !second && (w >> 16) == 0xFFFFu;
-          const bool is_term = act && !second && !is_run;
-          const unsigned long long z = el[is_term ? w & 0xFFFFu : 0u];
-          const long long c = lcoef[is_term ? w >> 16 : 0u];
-          const unsigned long long mag = c < 0 ? 0ull - (unsigned long long)c : (unsigned long long)c;
-          unsigned long long lo = mag * z, hi = __umul64hi(mag, z);
-          bool neg = c < 0;
-          bool ok = c != B3W_R1CS_NOT_SMALL && !(z >> 63) && hi < (1ull << 39);      // (bit 63 of an element = "not below 2^63")
-          if (__ballot(is_run) != 0ull) {
-            if (is_run) {
-              const uint32_t idx0 = w & 0xFFFFu, len = w1 & 0xFFu, sh = (w1 >> 8) & 0xFFu;
-              const uint32_t g = idx0 >> 6, r = idx0 & 63u;
-              const unsigned long long one_lo = packed[2 * g], bad_lo = packed[2 * g + 1], one_hi = packed[2 * g + 2], bad_hi = packed[2 * g + 3];
-              const unsigned long long mask = len == 64u ? ~0ull : (1ull << len) - 1ull;
-              const unsigned long long ones = ((one_lo >> r) | (r ? one_hi << (64u - r) : 0ull)) & mask;
-              const unsigned long long bads = ((bad_lo >> r) | (r ? bad_hi << (64u - r) : 0ull)) & mask;
-              ok = bads == 0ull;                             // (an element of the run that is no bit)
-              lo = ones << (sh & 63u); hi = 0ull;            // (below 2^62: the host checks sh + len)
-              neg = (w1 >> 16) & 1u;
-            }
-          }
-          if (is_term || is_run) {
-            const uint32_t g = mt >> 8;
-            unsigned long long *sum = gsum + 6u * g + 2u * (mt & 3u);
-            if (!ok) atomicOr(&gflag[g], 1u);
-            else if (hi == 0ull && lo < (1ull << 54)) atomicAdd(sum, neg ? 0ull - lo : lo);
-            else {                                           // cut at bit 52: value = low + high * 2^52, low in [0, 2^52)
-              __int128 v = (__int128)(((unsigned __int128)hi << 64) | lo);
-              if (neg) v = -v;
-              atomicAdd(sum, (unsigned long long)v & ((1ull << 52) - 1ull));
-              atomicAdd(sum + 1, (unsigned long long)(long long)(v >> 52));
-            }
-          }
-        }
-      B3W_STAMP(4);
-      // ---- this wave's own rows.  Usual road: the masks have vouched for every bit, so booleanity rows hold, and a truth-table row
-      // is its table indexed by the operands' low bits.  Anomaly road: row by row, with the bit-ness of every operand looked at.
-      uint32_t verdict = 0;                                  // bit p: row of pass p deferred, bit 8 + p: violated
-      auto table_row = [&](const uint4 d) {
-        const uint32_t k = (d.y >> 16) & 7u;
-        const uint32_t a = (el32[2u * (d.x & 0xFFFFu)] & 1u) | (el32[2u * (d.x >> 16)] & 1u) << 1 | (el32[2u * (d.z & 0xFFFFu)] & 1u) << 2 |
-                           (el32[2u * (d.z >> 16)] & 1u) << 3 | (el32[2u * (d.y & 0xFFFFu)] & 1u) << 4;      // (unused positions name element 0: masked)
-        return (d.y >> 29) == 1u && !((d.w >> (a & ((1u << k) - 1u))) & 1u);
-      };
-      auto careful_row = [&](const uint4 d, bool *defer, bool *bad) {
-        const bool w0_is_one = el[tile == 0 ? 0 : B3W_R1CS_TILE] == 1ull;
-        if (d.y >> 31) {                                     // booleanity  z * (1 - z) = 0: is the element 0 or 1
-          if (w0_is_one) *bad = el[d.w] > 1ull;              // (an element of 2^63 or more is no bit)
-          else *defer = true;                                // (wire 0 is not 1: nothing here means what it should — field arithmetic)
-        }
-        if ((d.y >> 29) == 1u) {
-          const uint32_t k = (d.y >> 16) & 7u;
-          const unsigned long long z0 = el[d.x & 0xFFFFu], z1 = el[d.x >> 16], z2 = el[d.z & 0xFFFFu], z3 = el[d.z >> 16], z4 = el[d.y & 0xFFFFu];
-          const unsigned long long nonbit = (z0 | (k > 1 ? z1 : 0ull) | (k > 2 ? z2 : 0ull) | (k > 3 ? z3 : 0ull) | (k > 4 ? z4 : 0ull)) >> 1;
-          const uint32_t a = ((uint32_t)z0 & 1u) | ((uint32_t)z1 & 1u) << 1 | ((uint32_t)z2 & 1u) << 2 | ((uint32_t)z3 & 1u) << 3 | ((uint32_t)z4 & 1u) << 4;
-          *defer = nonbit != 0ull || !w0_is_one;
-          *bad = !*defer && !((d.w >> (a & ((1u << k) - 1u))) & 1u);
-        }
-      };
+    };
+    constexpr uint32_t DEPTH = NBUF ? NBUF : 1;              // units in flight ahead of the one being packed
+    // ---- pack (unit i): 32-byte elements -> 8 bytes (bit 63 = "not below 2^63") + two bit words per 64 elements; anything the
+    // masks take for a bit and that is none raises the anomaly flag, and so does wire 0 not being 1
+    auto pack = [&](const uint32_t i) {
+      const unsigned char *raw = smem + (size_t)(i % DEPTH) * raw_stride;
+      const bool do_pack = !(dbg & 2u) && !((dbg & 8u) && i > 0);                  // (8: packed once; its rows are evaluated m times)
+      if constexpr (NBUF == 0) {
+        // every staged register is taken here, by every wave, whatever it goes on to use: the compiler waits for the fetch at this
+        // one point (and knows it has) — a fetch it could not prove consumed would cost a vmcnt(0) where the NEXT fetch is issued,
+        // right behind the verdict stores
 #pragma unroll
-      for (int p = 0; p < RP; p++) {
-        if (!has_rows[p]) continue;
-        if (!anomaly) {
-          if (has_tt[p] && table_row(pre[p])) verdict |= 0x100u << p;
+        for (int q = 0; q < EG; q++)
+          asm volatile("" :: "v"(rlo[q].x), "v"(rlo[q].y), "v"(rlo[q].z), "v"(rlo[q].w), "v"(rhi[q].x), "v"(rhi[q].y), "v"(rhi[q].z), "v"(rhi[q].w));
+        asm volatile("" :: "v"(xlo.x), "v"(xlo.y), "v"(xlo.z), "v"(xlo.w), "v"(xhi.x), "v"(xhi.y), "v"(xhi.z), "v"(xhi.w));
+      }
+      if (!do_pack) return;
+      bool flag = false;
+#pragma unroll
+      for (int q = 0; q < EG; q++) {
+        const uint32_t g = wave + (uint32_t)q * WAVES, e = g * 64u + lane;         // the wave holds elements 64 g ... 64 g + 63
+        uint4 lo, hi;
+        if constexpr (NBUF == 0) {
+          lo = rlo[q]; hi = rhi[q];
+          halves_apart(lo.x, hi.x); halves_apart(lo.y, hi.y); halves_apart(lo.z, hi.z); halves_apart(lo.w, hi.w);
         } else {
-          bool defer = false, bad = false;
-          careful_row(pre[p], &defer, &bad);                 // (a lane without a row holds an all-zero descriptor: no class)
-          verdict |= (defer ? 1u : 0u) << p | (bad ? 0x100u : 0u) << p;
+          lo = *reinterpret_cast<const uint4 *>(raw + (e >> 5) * 1024u + (e & 31u) * 16u);
+          hi = *reinterpret_cast<const uint4 *>(raw + (e >> 5) * 1024u + 512u + (e & 31u) * 16u);
         }
+        const unsigned long long z = e < n_local ? lean_pack(lo, hi) : 0ull;
+        el[e] = z;
+        const unsigned long long ones = __ballot(z == 1ull), bads = __ballot(z > 1ull);
+        if (lane == 0) { packed[2 * g] = ones; packed[2 * g + 1] = bads; }
+        flag = flag || (bads & mbit[q]) != 0ull || (tile == 0 && g == 0 && !(ones & 1ull));          // (wire 0 is element 0 of tile 0)
       }
+      if (packs_ext) {                                                             // (whole waves, for the ballots)
+        const uint32_t j = xg * 64u + lane;                                        // outside wire j of the tile
+        unsigned long long z = 0ull;
+        if constexpr (NBUF == 0) z = j < td.w ? lean_pack(xlo, xhi) : 0ull;
+        else if (j < td.w) {
+          const uint4 lo = *reinterpret_cast<const uint4 *>(raw + B3W_R1CS_TILE * 32u + (j >> 5) * 1024u + (j & 31u) * 16u);
+          const uint4 hi = *reinterpret_cast<const uint4 *>(raw + B3W_R1CS_TILE * 32u + (j >> 5) * 1024u + 512u + (j & 31u) * 16u);
+          z = lean_pack(lo, hi);
+        }
+        if (j < ext_cap) el[B3W_R1CS_TILE + j] = z;
+        const unsigned long long ones = __ballot(z == 1ull), bads = __ballot(z > 1ull);
+        if (lane == 0) { packed[2 * (16u + xg)] = ones; packed[2 * (16u + xg) + 1] = bads; }
+        flag = flag || (bads & xbit) != 0ull || (tile != 0 && xg == 0 && !(ones & 1ull));            // (outside wire 0 of every other tile)
+      }
+      if (flag && lane == 0) lanom[i & 1u] = 1u;
+    };
+    // ---- the pipeline.  Between two barriers B a workgroup holds unit i packed in LDS; one iteration is
+    //   fetch unit i + DEPTH | words and rows of unit i | barrier A | pack unit i + 1, verdicts of unit i | barrier B
+    // so the fetch of a unit and its pack sit in ONE iteration (registers: the compiler sees load and use together and waits exactly
+    // there; nothing is carried around the loop), a unit costs two barriers, and the verdict stores follow the pack's wait.
+    if (NBUF == 0) { issue_ext(b_lo); issue(b_lo, 0); }
+    else for (uint32_t k = 0; k < DEPTH && k < m; k++) issue(b_lo + k, k);
+    if (NBUF != 0) { vm_wait(per_tile * ((m < DEPTH ? m : DEPTH) - 1u)); lds_barrier(); }      // (DMA: a wave packs what other waves fetched)
+    pack(0);
+    if (NBUF == 0) issue_ext(1u < m ? b_lo + 1u : b_lo);
+    lds_barrier();                                                                 // barrier B of unit 0
+    for (uint32_t i = 0; i < m; i++) {
+      const uint32_t b = b_lo + i;
+      if (stamping) t_prev = __builtin_amdgcn_s_memtime();
+      if (i && !(dbg & 1u)) summary(b - 1u);
+      if (NBUF == 0) issue(i + 1u < m ? b + 1u : b, 0);                            // registers: unit i + 1, consumed at the end of this iteration (behind the tile's last unit: that unit again, packed and never looked at — no condition between fetch and use)
+      else if (i + DEPTH < m) issue(b + DEPTH, i % DEPTH);                         // DMA: the image of unit i, read out before barrier B, takes unit i + DEPTH
+      B3W_STAMP(0);
+      const bool anomaly = __builtin_amdgcn_readfirstlane(lanom[i & 1u]) != 0u;
+      if (tid == 0) lanom[(i + 1u) & 1u] = 0u;               // (read one unit ago by everyone; the next pack, behind barrier A, may set it)
+      uint32_t verdict = 0;                                  // bit p: row of pass p deferred, bit 8 + p: violated
+      if (!(dbg & 1u)) {
+        // ---- general rows, one WORD per lane: chunk c of 64 words goes to wave c mod WAVES; a lane adds coefficient * element (or
+        // the value of a bit run) into its row's part sum.  A part sum is two 64-bit counters {low, high} worth low + high * 2^52: a
+        // contribution below 2^54 goes to `low` whole, a larger one (the dyadic row scaling of the O2 systems makes 2^30 * word) is cut
+        // at bit 52 — products stay below 2^103 (the lean kernel's bound) and a row has at most 256 words, so no counter overflows
+        // and the sum is exact.
+        if (!(dbg & 32u))
+          for (uint32_t c0 = ((uint32_t)WAVES - 1u - wave) * 64u; c0 < gd.y; c0 += THREADS) {
+            const uint32_t iw = c0 + lane;
+            const bool act = iw < gd.y;
+            const uint32_t w = gwords[act ? iw : 0u], w1 = gwords[act ? iw + 1u : 0u], mt = gmeta[act ? iw : 0u];
+            const bool second = (mt >> 2) & 1u;                // the second word of a run: nothing of its own
+            const bool is_run = act && !second && (w >> 16) == 0xFFFFu;
+            const bool is_term = act && !second && !is_run;
+            const unsigned long long z = el[is_term ? w & 0xFFFFu : 0u];
+            const long long c = lcoef[is_term ? w >> 16 : 0u];
+            const unsigned long long mag = c < 0 ? 0ull - (unsigned long long)c : (unsigned long long)c;
+            unsigned long long lo = mag * z, hi = __umul64hi(mag, z);
+            bool neg = c < 0;
+            bool ok = c != B3W_R1CS_NOT_SMALL && !(z >> 63) && hi < (1ull << 39);      // (bit 63 of an element = "not below 2^63")
+            if (__ballot(is_run) != 0ull) {
+              if (is_run) {
+                const uint32_t idx0 = w & 0xFFFFu, len = w1 & 0xFFu, sh = (w1 >> 8) & 0xFFu;
+                const uint32_t g = idx0 >> 6, r = idx0 & 63u;
+                const unsigned long long one_lo = packed[2 * g], bad_lo = packed[2 * g + 1], one_hi = packed[2 * g + 2], bad_hi = packed[2 * g + 3];
+                const unsigned long long mask = len == 64u ? ~0ull : (1ull << len) - 1ull;
+                const unsigned long long ones = ((one_lo >> r) | (r ? one_hi << (64u - r) : 0ull)) & mask;
+                const unsigned long long bads = ((bad_lo >> r) | (r ? bad_hi << (64u - r) : 0ull)) & mask;
+                ok = bads == 0ull;                             // (an element of the run that is no bit)
+                lo = ones << (sh & 63u); hi = 0ull;            // (below 2^62: the host checks sh + len)
+                neg = (w1 >> 16) & 1u;
+              }
+            }
+            if (is_term || is_run) {
+              const uint32_t g = mt >> 8;
+              unsigned long long *sum = gsum + 6u * g + 2u * (mt & 3u);
+              if (!ok) atomicOr(&gflag[g], 1u);
+              else if (hi == 0ull && lo < (1ull << 54)) atomicAdd(sum, neg ? 0ull - lo : lo);
+              else {                                           // cut at bit 52: value = low + high * 2^52, low in [0, 2^52)
+                __int128 v = (__int128)(((unsigned __int128)hi << 64) | lo);
+                if (neg) v = -v;
+                atomicAdd(sum, (unsigned long long)v & ((1ull << 52) - 1ull));
+                atomicAdd(sum + 1, (unsigned long long)(long long)(v >> 52));
+              }
+            }
+          }
+        B3W_STAMP(1);
+        // ---- this wave's own rows.  Usual road: the masks have vouched for every bit, so booleanity rows hold, and a truth-table row
+        // is its table indexed by the operands' low bits.  Anomaly road: row by row, with the bit-ness of every operand looked at.
+        auto table_row = [&](const uint4 d) {
+          const uint32_t k = (d.y >> 16) & 7u;
+          const uint32_t a = (el32[2u * (d.x & 0xFFFFu)] & 1u) | (el32[2u * (d.x >> 16)] & 1u) << 1 | (el32[2u * (d.z & 0xFFFFu)] & 1u) << 2 |
+                             (el32[2u * (d.z >> 16)] & 1u) << 3 | (el32[2u * (d.y & 0xFFFFu)] & 1u) << 4;      // (unused positions name element 0: masked)
+          return (d.y >> 29) == 1u && !((d.w >> (a & ((1u << k) - 1u))) & 1u);
+        };
+        auto careful_row = [&](const uint4 d, bool *defer, bool *bad) {
+          const bool w0_is_one = el[tile == 0 ? 0 : B3W_R1CS_TILE] == 1ull;
+          if (d.y >> 31) {                                     // booleanity  z * (1 - z) = 0: is the element 0 or 1
+            if (w0_is_one) *bad = el[d.w] > 1ull;              // (an element of 2^63 or more is no bit)
+            else *defer = true;                                // (wire 0 is not 1: nothing here means what it should — field arithmetic)
+          }
+          if ((d.y >> 29) == 1u) {
+            const uint32_t k = (d.y >> 16) & 7u;
+            const unsigned long long z0 = el[d.x & 0xFFFFu], z1 = el[d.x >> 16], z2 = el[d.z & 0xFFFFu], z3 = el[d.z >> 16], z4 = el[d.y & 0xFFFFu];
+            const unsigned long long nonbit = (z0 | (k > 1 ? z1 : 0ull) | (k > 2 ? z2 : 0ull) | (k > 3 ? z3 : 0ull) | (k > 4 ? z4 : 0ull)) >> 1;
+            const uint32_t a = ((uint32_t)z0 & 1u) | ((uint32_t)z1 & 1u) << 1 | ((uint32_t)z2 & 1u) << 2 | ((uint32_t)z3 & 1u) << 3 | ((uint32_t)z4 & 1u) << 4;
+            *defer = nonbit != 0ull || !w0_is_one;
+            *bad = !*defer && !((d.w >> (a & ((1u << k) - 1u))) & 1u);
+          }
+        };
+#pragma unroll
+        for (int p = 0; p < RP; p++) {
+          if (!has_rows[p]) continue;
+          if (!anomaly) {
+            if (has_tt[p] && table_row(fresh(pre[p]))) verdict |= 0x100u << p;
+          } else {
+            bool defer = false, bad = false;
+            careful_row(fresh(pre[p]), &defer, &bad);          // (a lane without a row holds an all-zero descriptor: no class)
+            verdict |= (defer ? 1u : 0u) << p | (bad ? 0x100u : 0u) << p;
+          }
+        }
+        B3W_STAMP(2);
+      }
+      if (NBUF != 0 && i + 1u < m) vm_wait(per_tile * (m - 2u - i < DEPTH - 1u ? m - 2u - i : DEPTH - 1u));      // this wave's pieces of unit i + 1 have landed (younger units may fly on)
+      lds_barrier();                                                               // barrier A: every word of unit i is in its row's sums, nobody reads el any more
+      B3W_STAMP(3);
+      if (NBUF == 0 || i + 1u < m) pack(i + 1u);
+      if (NBUF == 0) issue_ext(i + 2u < m ? b + 2u : b);                           // (behind the tile's end: fetched, packed, never looked at)
+      B3W_STAMP(4);
+      if (!(dbg & 1u)) verdicts(b, verdict, anomaly);
       B3W_STAMP(5);
-      pend = true; pend_verdict = verdict; pend_anomaly = anomaly;
+      lds_barrier();                                                               // barrier B: unit i + 1 in place, the sums are zero again
+      B3W_STAMP(6);
     }
+    if (!(dbg & 1u)) summary(b_lo + m - 1u);
     u += m;
   }
   if (stamping && lane == 0)
@@ -1110,7 +1226,7 @@ __global__ __launch_bounds__(64 * WAVES, 4) void b3w_r1cs_stream_kernel(   // (s
 #define B3W_R1CS_DEFERRED_TILES 1u
 __global__ __launch_bounds__(64) void b3w_r1cs_deferred_kernel(const uint8_t *__restrict__ bodies, uint64_t pitch, uint32_t n, B3wR1csSystem S,
                                                                const unsigned long long *__restrict__ scratch, uint32_t block_words, B3wField F,
-                                                               uint32_t *__restrict__ violations, uint32_t *__restrict__ first) {
+                                                               uint32_t *__restrict__ violations, uint32_t *__restrict__ first, bool sparse) {
   // a wave looks at B3W_R1CS_DEFERRED_TILES consecutive tiles of one body (measured with 4: the same 22 us for a batch of
   // blake3_compression as with 1 -- the launch is bound by the first load of each wave, not by the 98 304 dispatches)
   const uint32_t tgroups = (S.ntiles + B3W_R1CS_DEFERRED_TILES - 1u) / B3W_R1CS_DEFERRED_TILES;
@@ -1126,8 +1242,11 @@ __global__ __launch_bounds__(64) void b3w_r1cs_deferred_kernel(const uint8_t *__
     const unsigned long long *block = scratch + ((size_t)b * S.ntiles + tile) * block_words;
     const uint4 td = reinterpret_cast<const uint4 *>(S.tiles)[tile];
     const uint32_t words = (td.y + 63u) >> 6;              // word w of the first kernel = rows first + 64 * w + lane (at most 64 words: 4 096 rows)
-    // one load decides: lane w fetches mask word w; a (body, tile) none of whose rows was deferred is done
-    const unsigned long long mine_w = threadIdx.x < words ? block[1 + threadIdx.x] : 0ull;
+    // one load decides: word 0 — 0 = none of this (body, tile)'s rows was deferred; sparse (the stream kernel's): bit w = mask
+    // word w was stored and is not zero; not sparse (the lean kernel's): every mask word was stored
+    const unsigned long long head = block[0];
+    if (head == 0ull) continue;                            // (wave-uniform: one address)
+    const unsigned long long mine_w = threadIdx.x < words && (!sparse || ((head >> threadIdx.x) & 1ull)) ? block[1 + threadIdx.x] : 0ull;
     if (__ballot(mine_w != 0ull) == 0ull) continue;
     any = 1ull;
     for (uint32_t wi = 0; wi < words; wi++) {
@@ -1304,7 +1423,7 @@ extern "C" int b3w_launch_r1cs_lean(const uint8_t *d_bodies, uint32_t n, uint64_
     if (e != hipSuccess) return (int)e;
     const dim3 dgrid(((nb + 7) / 8) * 8 * ((sys->ntiles + B3W_R1CS_DEFERRED_TILES - 1u) / B3W_R1CS_DEFERRED_TILES));
     hipLaunchKernelGGL(b3w_r1cs_deferred_kernel, dgrid, dim3(64), 0, stream, d_bodies + (uint64_t)b0 * pitch, pitch, nb, *sys, d_scratch, bw,
-                       *field, d_violations + b0, d_first ? d_first + b0 : nullptr);
+                       *field, d_violations + b0, d_first ? d_first + b0 : nullptr, false);
     e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
   }
@@ -1317,7 +1436,7 @@ static inline size_t stream_smem(const B3wR1csSystem *sys, int nbuf) {
   const uint32_t groups = ((B3W_R1CS_TILE + ext_cap + 63u) >> 6) + 1u;
   return (size_t)nbuf * (B3W_R1CS_TILE + ext_cap) * 32u + (size_t)(B3W_R1CS_TILE + ext_cap) * 8u + (size_t)groups * 16u +
          (size_t)sys->max_g_rows * 48u + (size_t)((sys->max_g_rows + 1u) & ~1u) * 4u + 2u * (size_t)((sys->max_g_words + 4u) & ~3u) * 4u +
-         (size_t)sys->ncoef * 8u + 16u;       // (+ the two anomaly words)
+         (size_t)sys->ncoef * 8u + 32u;       // (+ the two summary words and the two anomaly words)
 }
 
 // 0 = launched; -6 = this system does not fit the stream kernel (the caller takes the lean pair)
@@ -1337,6 +1456,7 @@ extern "C" int b3w_launch_r1cs_stream(const uint8_t *d_bodies, uint32_t n, uint6
   // the shapes: {raw buffers, waves per workgroup}; the default is the first that fits
   struct Shape { int nbuf, waves; const void *fn; };
   static const Shape shapes[] = {
+      {0, 8, reinterpret_cast<const void *>(&b3w_r1cs_stream_kernel<0, 8>)},   {0, 16, reinterpret_cast<const void *>(&b3w_r1cs_stream_kernel<0, 16>)},
       {1, 8, reinterpret_cast<const void *>(&b3w_r1cs_stream_kernel<1, 8>)},   {2, 8, reinterpret_cast<const void *>(&b3w_r1cs_stream_kernel<2, 8>)},
       {2, 16, reinterpret_cast<const void *>(&b3w_r1cs_stream_kernel<2, 16>)}, {3, 16, reinterpret_cast<const void *>(&b3w_r1cs_stream_kernel<3, 16>)}};
   struct PerDevice { int cus = 0, lds = 0; bool attr[8] = {false, false, false, false, false, false, false, false}; };
@@ -1352,7 +1472,7 @@ extern "C" int b3w_launch_r1cs_stream(const uint8_t *d_bodies, uint32_t n, uint6
       if (pd.lds < 160 * 1024) pd.lds = 64 * 1024;         // (gfx950: 160 KB per workgroup; anything else: be modest)
     }
     for (int k = 0; k < (int)(sizeof shapes / sizeof shapes[0]) && pick < 0; k++) {
-      if ((env_nbuf && shapes[k].nbuf != env_nbuf) || (env_waves && shapes[k].waves != env_waves)) continue;
+      if ((env_nbuf && shapes[k].nbuf != (env_nbuf < 0 ? 0 : env_nbuf)) || (env_waves && shapes[k].waves != env_waves)) continue;
       if (stream_smem(sys, shapes[k].nbuf) <= (size_t)pd.lds) pick = k;
     }
     if (pick < 0) return -6;
@@ -1392,7 +1512,7 @@ extern "C" int b3w_launch_r1cs_stream(const uint8_t *d_bodies, uint32_t n, uint6
       unsigned long long h[128];
       if (hipStreamSynchronize(stream) == hipSuccess && hipMemcpy(h, d_stamps, sizeof h, hipMemcpyDeviceToHost) == hipSuccess) {
         const double un = (double)(units / grid);
-        static const char *name[8] = {"dma-wait", "barrierA", "pack", "barrierB+issue", "words", "own-rows", "barrierC", "finish"};
+        static const char *name[8] = {"fetch-issue", "words", "own-rows", "wait+barrierA", "pack", "verdicts", "barrierB", "-"};
         fprintf(stderr, "b3w_r1cs_stream stamps (cycles per unit, workgroup 0 of %u, %d waves, %d buffers, %g units):\n", grid, shapes[pick].waves,
                 shapes[pick].nbuf, un);
         for (int k = 0; k < 8; k++) {
@@ -1405,7 +1525,7 @@ extern "C" int b3w_launch_r1cs_stream(const uint8_t *d_bodies, uint32_t n, uint6
     if (env_dbg) continue;                                 // (an experiment that skips phases leaves no valid masks behind)
     const dim3 dgrid(((nb + 7) / 8) * 8 * ((sys->ntiles + B3W_R1CS_DEFERRED_TILES - 1u) / B3W_R1CS_DEFERRED_TILES));
     hipLaunchKernelGGL(b3w_r1cs_deferred_kernel, dgrid, dim3(64), 0, stream, d_bodies + (uint64_t)b0 * pitch, pitch, nb, *sys, d_scratch, bw,
-                       *field, d_violations + b0, d_first ? d_first + b0 : nullptr);
+                       *field, d_violations + b0, d_first ? d_first + b0 : nullptr, true);
     e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
   }
