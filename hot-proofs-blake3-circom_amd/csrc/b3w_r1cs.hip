@@ -703,73 +703,35 @@ __global__ __launch_bounds__(256) void b3w_r1cs_lean_kernel(const uint8_t *__res
   }
 }
 
-// ---- the STREAM kernel (default): the lean kernel's arithmetic inside a persistent workgroup whose loads never stop --------
+// ---- the STREAM kernel (default): persistent workgroups, one barrier per (body, tile) unit ------------------------------------
 // The lean kernel is (body, tile) workgroups that load, pack, evaluate and leave: its HBM loads are in flight only part of a
-// workgroup's life, and with five workgroups per CU the sum of load time and evaluate time — not their maximum — is what a tile
-// costs (profiles/r02: 2.06 us per tile and CU = 1.37 us of loads at the achievable HBM rate + 0.7 us of evaluation; waves
-// parked 53-58 % of their cycles).  Here ONE 1 024-thread workgroup per CU walks a contiguous range of the tile-major unit
-// list (tile, body) and the next tiles' bytes travel HBM -> LDS by LDS-DMA (global_load_lds_dwordx4: no VGPRs, nothing for the
-// compiler to wait on) into a ring of NBUF raw 32-byte tile images while the current tile is packed and its rows evaluated:
-//     wait (counted vmcnt: the NBUF - 1 younger tiles stay in flight) | barrier | pack raw -> 8-byte elements + bit words |
-//     barrier | issue the DMA of tile i + NBUF into the buffer just freed | rows of tile i
-// Measured (profiles/r03/r1cs_stream_*): ONE buffer and two 8-wave workgroups per CU beat deeper rings in one 16-wave workgroup
-// (0.77 against 0.98 ms per 4 096 compression bodies) — with a single buffer the next tile still travels while this one's rows
-// are evaluated, and two workgroups whose phases drift apart fill each other's barrier waits; the tile loads are non-temporal
-// (read once: -4 % compression, -12 % nova, whose outside-wire gathers then keep their L2 lines).
-// Word list, coefficients, row descriptors and the DMA geometry are per TILE, so they are fetched once per tile switch (one or
-// two per workgroup) instead of once per (body, tile): the steady-state loop has no global load at all — only the DMAs, the
-// deferred-row mask stores and (rarely) the violation atomics.  The outside wires of a tile are gathered by the same DMAs
-// (per-lane source addresses).  Raw image of a 1 KiB DMA block = 32 elements: their 32 low halves, then their 32 high halves
-// (the swizzle is on the SOURCE address, the block still covers whole 128-byte lines), so the pack phase's ds_read_b128 are
-// conflict-free.  Same scratch format, same deferred kernel, same verdicts as the lean pair.
-// ROWS.  With one workgroup per CU nothing else runs while its rows are evaluated, so the lean kernel's "one row per lane walks its
-// words" (three dependent LDS round trips per term on the few waves that hold general rows: 2 us per tile) is replaced by the host's
-// STREAM PROGRAM (b3w_r1cs_host.cpp): booleanity rows as before; TRUTH-TABLE rows — a row over at most five wires that hold bits is
-// a function of five bits, tabulated by the host with exact field arithmetic and looked up from the elements' bits (every XOR gate
-// of these circuits: 87 % of the other rows); GENERAL rows one WORD per lane — every lane multiplies its coefficient and element
-// and adds the product into its row's sums in LDS (ds_add_u64), all sixteen waves sharing the tile's word list — then the row's
-// owner lane compares A * B with C.  A product that would not stay below 2^55, an element that is no bit in a truth-table row or
-// a coefficient that is no small integer defers the row to the deferred kernel's field arithmetic.
-__device__ __forceinline__ void glds16(uint32_t lds_dst /* wave-uniform byte address */, const void *gsrc /* per lane */) {
-  uint32_t keep;
-  const uint32_t dst = __builtin_amdgcn_readfirstlane(lds_dst);                    // (an SGPR operand needs a provably uniform value)
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep) : "v"(gsrc), "s"(dst) : "memory");
-}
-// wait until at most `outstanding` of this wave's vector-memory operations are in flight (DMAs retire in issue order; the mask
-// stores between them are not counted on, so the wait is exact or early-safe whichever way stores and loads are ordered)
-__device__ __forceinline__ void vm_wait(uint32_t outstanding) {
-  switch (outstanding) {                                   // (wave-uniform; s_waitcnt takes an immediate)
-    case 0: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
-    case 1: asm volatile("s_waitcnt vmcnt(1)" ::: "memory"); break;
-    case 2: asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); break;
-    case 3: asm volatile("s_waitcnt vmcnt(3)" ::: "memory"); break;
-    case 4: asm volatile("s_waitcnt vmcnt(4)" ::: "memory"); break;
-    case 5: asm volatile("s_waitcnt vmcnt(5)" ::: "memory"); break;
-    case 6: asm volatile("s_waitcnt vmcnt(6)" ::: "memory"); break;
-    case 7: asm volatile("s_waitcnt vmcnt(7)" ::: "memory"); break;
-    case 8: asm volatile("s_waitcnt vmcnt(8)" ::: "memory"); break;
-    case 9: asm volatile("s_waitcnt vmcnt(9)" ::: "memory"); break;
-    case 10: asm volatile("s_waitcnt vmcnt(10)" ::: "memory"); break;
-    case 11: asm volatile("s_waitcnt vmcnt(11)" ::: "memory"); break;
-    default: asm volatile("s_waitcnt vmcnt(12)" ::: "memory"); break;      // (six DMAs per tile and wave at most, two tiles ahead)
-  }
-}
-// workgroup barrier that leaves vector-memory operations (the DMAs) in flight: LDS traffic retired, then s_barrier
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
-
-// LDS-DMA with a scalar base: 16 bytes per lane from base + off (off < 4 GiB) into the wave's 1 KiB block at `lds_dst`
-__device__ __forceinline__ void glds16s(uint32_t lds_dst /* wave-uniform byte address */, const uint8_t *base /* wave-uniform */, uint32_t off /* per lane */,
-                                        bool nt = false /* wave-uniform: non-temporal (bytes read once) */) {
-  uint32_t keep;
-  const uint32_t dst = __builtin_amdgcn_readfirstlane(lds_dst);
-  if (nt)
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3 nt\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(off), "s"(dst), "s"(base) : "memory");
-  else
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %3\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "v"(off), "s"(dst), "s"(base) : "memory");
-}
+// workgroup's life, and the sum of load time and evaluate time — not their maximum — is what a tile costs (profiles/r02: waves
+// parked 53-58 % of their cycles).  Here a 512-thread workgroup (two to a CU) walks a contiguous, cost-weighted range of the
+// tile-major unit list (tile, body).  Per tile switch (one or two per workgroup) it fetches what is per TILE — row descriptors,
+// word list, masks, fetch offsets — so the steady-state loop has no global load but the elements themselves.
+// FETCH.  No raw image of the tile in LDS (rounds of r03 had one, filled by LDS-DMA: 48 KB a workgroup, one unit in flight per
+// workgroup and a barrier between fetch and pack).  A wave fetches the elements IT packs into registers, one unit ahead: a group
+// of 64 elements is two CONTIGUOUS 1 KiB loads (a lane below 32 takes the low 16 bytes of its element, the lane 32 above it the
+// high 16: 8 cache lines per instruction, every byte used), v_permlane32_swap then puts the low halves of the 64 elements into
+// one register set and the high halves into the other.  (One element per lane — 32-byte stride, twice — is 16 half-used lines
+// per instruction, and the texture path is what sixteen waves queue for: 0.75 -> 0.65 ms per 4 096 bodies.)  The outside wires
+// of a tile are a gather (a lane per wire), the slowest thing here to come back: fetched a whole unit earlier.
+// PIPELINE.  Elements, bit words and the general rows' sums exist twice in LDS (unit parity), so within one iteration
+//     fetch tile elements of unit i + 1 | words and rows of unit i | verdicts of unit i - 1 | pack unit i + 1 | barrier
+// nothing depends on anything else of the same iteration: ONE barrier per unit, and what a wave has more of than its neighbours
+// (general words, outside wires, general rows' verdicts — dealt to different waves) is not waited for phase by phase.
+// ROWS: the host's STREAM PROGRAM (b3w_r1cs_host.cpp).  Booleanity rows (64 % of all rows) and the bit-ness of every
+// truth-table operand: the host's per-tile masks of "elements taken for bits" ANDed with the pack's "neither 0 nor 1" ballots —
+// one scalar AND per 64 elements; only if that (or wire 0 not being 1) finds something does the unit take the row-by-row road
+// (`anomaly`).  TRUTH-TABLE rows — a row over at most five wires that hold bits is a function of five bits, tabulated by the host
+// with exact field arithmetic and looked up from the elements' bits (every XOR gate of these circuits: 87 % of the other rows).
+// GENERAL rows (first in every tile: waves 0, 1 own them) one WORD per lane — every lane multiplies its coefficient and element
+// and adds the product into its row's sums in LDS (ds_add_u64) — then the row's owner lane compares A * B with C.  A product that
+// would not stay below 2^103, an element that is no bit in a truth-table row or a coefficient that is no small integer defers
+// the row to the deferred kernel's field arithmetic; ALWAYS-DEFERRED rows have the same mask bits for every body of the tile.
+// Everything a wave does here costs every other wave of its SIMD four cycles per instruction, so the steady state is written for
+// instruction count: wave-uniform values live in SGPRs (the wave number comes through readfirstlane), whole classes of rows are
+// decided by masks, a wave runs only the code of the row classes it owns, and a wave whose rows all hold skips the verdicts.
 
 // A value the compiler must take as new at this point: what is derived from a row descriptor (LDS addresses of its operands, of its
 // sums, the address of its id) is then computed where it is used, unit after unit, instead of once per tile into registers that
@@ -779,7 +741,7 @@ __device__ __forceinline__ uint4 fresh(uint4 d) {
   asm volatile("" : "+v"(d.x), "+v"(d.y), "+v"(d.z), "+v"(d.w));
   return d;
 }
-// 16 bytes per lane into REGISTERS (the NBUF = 0 shapes): base + off, read once
+// 16 bytes per lane into registers: base + off, non-temporal (read once) or not
 typedef uint32_t b3w_u32x4 __attribute__((ext_vector_type(4)));
 // a = {elements 0 ... 31: low halves | high halves}, b = {elements 32 ... 63 likewise}  ->  a = low halves of 0 ... 63, b = high halves
 __device__ __forceinline__ void halves_apart(uint32_t &a, uint32_t &b) {
@@ -794,62 +756,52 @@ __device__ __forceinline__ uint4 ldg16(const uint8_t *base /* wave-uniform */, u
   else v = *p;
   return make_uint4(v.x, v.y, v.z, v.w);
 }
+// a part sum {low, high} = sext(low) + sext(high) * 2^52, as a 128-bit two's complement number in two halves
+__device__ __forceinline__ void part_sum(unsigned long long s_lo, unsigned long long s_hi, unsigned long long &lo, long long &hi) {
+  lo = s_lo + (s_hi << 52);
+  hi = ((long long)s_lo >> 63) + ((long long)s_hi >> 12) + (lo < s_lo ? 1ll : 0ll);
+}
+// workgroup barrier that leaves vector-memory operations (the fetches) in flight: LDS traffic retired, then s_barrier
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
-// Everything a wave does here costs every other wave of its SIMD four cycles per instruction, and the waves of one workgroup move in
-// lockstep from barrier to barrier (profiles/r03 stamps: sixteen waves at 340 instructions per unit were 5 400 cycles), so
-//   * the steady state is written for instruction count: wave-uniform values live in SGPRs (the wave number comes through
-//     readfirstlane), whole classes of rows are decided by masks instead of row by row, a wave runs only the code of the row classes
-//     it owns;
-//   * the workgroup size is a template parameter: WAVES = 8 (512 threads, two elements and up to four rows per lane) lets two or
-//     three workgroups share a CU (LDS permitting) — their phases drift apart, so one workgroup's barrier waits and LDS round trips are
-//     the other's issue slots, and each keeps its own DMAs in flight.
-// Row classes (host: b3w_r1cs_host.cpp, "the STREAM program"):
-//   * booleanity rows (64 % of all rows) and the bit-ness of every truth-table operand: the host's per-tile masks of "elements taken
-//     for bits" ANDed with the pack phase's "neither 0 nor 1" ballots — one scalar AND per 64 elements.  Only if that (or wire 0 not
-//     being 1) finds something does the tile take the row-by-row road (`anomaly`).
-//   * truth-table rows: the operands' low bits index the host's table.
-//   * general rows: one word per lane into the rows' sums (LDS atomics), verdict by the row's owner lane after a barrier.
-//   * always-deferred rows: their mask bits are the same for every body of the tile.
-template <int NBUF, int WAVES>
+template <int WAVES, bool STAMPS>
 __global__ __launch_bounds__(64 * WAVES, 4) void b3w_r1cs_stream_kernel(   // (second argument: waves per SIMD the register budget must allow — two 8-wave workgroups or one of 16)
-    const uint8_t *__restrict__ bodies, uint64_t pitch, uint32_t n, B3wR1csSystem S,
-                                                                     unsigned long long *__restrict__ scratch, uint32_t block_words,
-                                                                     uint32_t *__restrict__ violations, uint32_t *__restrict__ first, uint32_t dbg,
-                                                                     unsigned long long *__restrict__ stamps) {
+    const uint8_t *__restrict__ bodies, uint64_t pitch, uint32_t n, B3wR1csSystem S, unsigned long long *__restrict__ scratch, uint32_t block_words,
+    uint32_t *__restrict__ violations, uint32_t *__restrict__ first, uint32_t dbg_arg, unsigned long long *__restrict__ stamps) {
   constexpr uint32_t THREADS = 64u * WAVES;
+  const uint32_t dbg = STAMPS ? dbg_arg : 0u;               // (the experiments' switches exist in the diagnostic instantiation only)
   constexpr int EG = 16 / WAVES;                           // groups of 64 tile elements a wave packs (1 or 2)
   constexpr int RP = 32 / WAVES;                           // row passes at most (a tile has at most 2 048 rows)
-  constexpr int MB = 32 / WAVES;                           // tile DMA blocks (32 elements, 1 KiB) a wave issues
-  constexpr int XB = 16 / WAVES;                           // outside-wire DMA blocks a wave issues (at most 512 outside wires)
   extern __shared__ __align__(16) unsigned char smem[];
   const uint32_t tid = threadIdx.x, lane = tid & 63u;
   const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);                  // (an SGPR: what depends on it alone is scalar code)
-  // diagnostic build only (B3W_R1CS_STAMPS=1): cycles per phase, summed over the units of workgroup 0, per wave
+  // the diagnostic instantiation only (B3W_R1CS_STAMPS=1): cycles per phase, summed over the units of the middle workgroup, per wave
+  // (a kernel of its own: the sums and the clock are 20 SGPRs the measured one has better uses for)
   unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_prev = 0;
-  const bool stamping = stamps != nullptr && blockIdx.x == 0;
-#define B3W_STAMP(k) do { if (stamping) { const unsigned long long t_now = __builtin_amdgcn_s_memtime(); ph[k] += t_now - t_prev; t_prev = t_now; } } while (0)
-  const uint32_t ext_cap = (S.max_ext + 32u) & ~31u;                               // outside wires, in whole DMA blocks of 32 (+ at least one spare element)
-  const uint32_t raw_stride = (B3W_R1CS_TILE + ext_cap) * 32u;                     // one raw image: tile blocks, then outside-wire blocks
-  unsigned long long *el = reinterpret_cast<unsigned long long *>(smem + (size_t)NBUF * raw_stride);
-  const uint32_t *el32 = reinterpret_cast<const uint32_t *>(el);
-  unsigned long long *packed = el + B3W_R1CS_TILE + ext_cap;
-  const uint32_t groups = ((B3W_R1CS_TILE + ext_cap + 63u) >> 6) + 1u;            // (one spare pair: a run reads its group and the next)
-  // general rows of the tile: per-row sums {A, B, C} x {low, high} and flags, the word list with its meta words; the coefficients
-  unsigned long long *gsum = packed + 2 * groups;
-  uint32_t *gflag = reinterpret_cast<uint32_t *>(gsum + 6u * S.max_g_rows);
-  uint32_t *gwords = gflag + ((S.max_g_rows + 1u) & ~1u);
+  const bool stamping = STAMPS && stamps != nullptr && blockIdx.x == gridDim.x / 2u;
+#define B3W_STAMP(k) do { if (STAMPS && stamping) { const unsigned long long t_now = __builtin_amdgcn_s_memtime(); ph[k] += t_now - t_prev; t_prev = t_now; } } while (0)
+  // LDS: [parity] elements, [parity] bit words, [parity] general rows' sums {A, B, C} x {low, high} and flags; the tile's word list
+  // with its meta words; the coefficients; summary and anomaly words
+  const uint32_t ext_cap = (S.max_ext + 32u) & ~31u;                               // room for the outside wires (+ at least one spare element)
+  const uint32_t ne = B3W_R1CS_TILE + ext_cap;
+  const uint32_t groups = ((ne + 63u) >> 6) + 1u;                                  // (one spare pair: a run reads its group and the next)
+  const uint32_t gr2 = (S.max_g_rows + 1u) & ~1u;
+  unsigned long long *el0 = reinterpret_cast<unsigned long long *>(smem);
+  unsigned long long *packed0 = el0 + 2u * ne;
+  unsigned long long *gsum0 = packed0 + 4u * groups;
+  uint32_t *gflag0 = reinterpret_cast<uint32_t *>(gsum0 + 12u * S.max_g_rows);
+  uint32_t *gwords = gflag0 + 2u * gr2;
   uint32_t *gmeta = gwords + ((S.max_g_words + 4u) & ~3u);
   long long *lcoef = reinterpret_cast<long long *>(gmeta + ((S.max_g_words + 4u) & ~3u));
   unsigned long long *lsum = reinterpret_cast<unsigned long long *>(lcoef + S.ncoef);      // [unit parity]: bit w = the unit's mask word w is not zero (and was stored)
-  uint32_t *lanom = reinterpret_cast<uint32_t *>(lsum + 2);                        // [unit parity] != 0: something the masks cannot vouch for in this (body, tile)
-  const __int128 lim = (__int128)1 << 63;
+  uint32_t *lanom = reinterpret_cast<uint32_t *>(lsum + 2);                        // [unit mod 3] != 0: something the masks cannot vouch for in this (body, tile)
   for (uint32_t k = tid; k < S.ncoef; k += THREADS) lcoef[k] = S.coef_small[k];
-  if (tid < 2) packed[2 * (groups - 1) + tid] = 0ull;                              // the spare pair
-  const uint32_t lds0 = __builtin_amdgcn_readfirstlane((uint32_t)(uintptr_t)smem);
+  if (tid < 4) packed0[(tid >> 1) * 2u * groups + 2u * (groups - 1u) + (tid & 1u)] = 0ull;      // the spare pairs
   // who does what beside the equal shares (two element groups, every row pass): the general words go to the LAST waves (whose last
-  // row pass is the short one), the groups of outside wires (at most 8) to waves 2, 3, ... — not both to the same waves
+  // row pass is the short one), the groups of outside wires (at most 8) to waves 2, 3, ..., the general rows' verdicts are
+  // waves 0 and 1's (the host puts those rows first), the summary word is wave 1's
   const uint32_t nxg = (ext_cap + 63u) >> 6;
-  const uint32_t xg = (wave + (uint32_t)WAVES - 2u) % (uint32_t)WAVES;             // ... this wave's group of outside wires, if it has one
+  const uint32_t xg = (wave + (uint32_t)WAVES - 2u) % (uint32_t)WAVES;             // this wave's group of outside wires, if it has one
   const bool packs_ext = xg < nxg;
 
   // units, tile-major: u = tile * n + body; a workgroup takes a contiguous range of equal COST (S.scost: a tile with many general
@@ -869,30 +821,32 @@ __global__ __launch_bounds__(64 * WAVES, 4) void b3w_r1cs_stream_kernel(   // (s
   while (u < u_end) {
     const uint32_t tile = (uint32_t)(u / n), b_lo = (uint32_t)(u - (uint64_t)tile * n);
     const uint32_t m = (uint32_t)((u_end - u) < (uint64_t)(n - b_lo) ? (u_end - u) : (uint64_t)(n - b_lo));      // bodies of this tile
-    // ---- per tile: descriptors, the word list, the masks, the DMA geometry.  (No DMA is in flight here: the pipeline below drains.)
-    lds_barrier();                                                                 // the previous tile's rows are done with the word list
+    // ---- per tile: descriptors, the word list, the masks, the fetch offsets.  (Nothing is in flight here: the pipeline below drains.)
+    lds_barrier();                                                                 // the previous tile's last summary words are out, its word list is free
     const uint4 td = reinterpret_cast<const uint4 *>(S.tiles)[tile];               // {first row, rows, first outside wire, outside wires}
     const uint4 gd = reinterpret_cast<const uint4 *>(S.sgdesc)[tile];              // {first general word, general words, general rows, -}
     const uint32_t t0 = tile * B3W_R1CS_TILE;
     const uint32_t n_local = S.nwires - t0 < B3W_R1CS_TILE ? S.nwires - t0 : B3W_R1CS_TILE;
     const uint4 *srows = reinterpret_cast<const uint4 *>(S.srows);
     // this lane's rows (pass p: row p * THREADS + tid) and what the wave owns in each pass (wave-uniform: SGPRs)
+    // (ONE scalar of flag bits — p: the wave has truth-table rows in pass p, 8 + p: general rows, 16 + p: always-deferred rows — not
+    // a lane mask per flag and pass: the loop below has more wave-uniform state than there are SGPRs, and what does not fit is
+    // kept in the lanes of a VGPR, a v_readlane per use)
     uint4 pre[RP];
-    bool has_rows[RP], has_tt[RP], has_gen[RP];
-    unsigned long long dmask[RP];                            // always-deferred rows: the same mask bits for every body
+    uint32_t wflags = 0;
 #pragma unroll
     for (int p = 0; p < RP; p++) {
       const uint32_t r = (uint32_t)p * THREADS + tid;
       pre[p] = r < td.y ? srows[td.x + r] : make_uint4(0, 0, 0, 0);
-      has_rows[p] = (uint32_t)p * THREADS + wave * 64u < td.y && !(p > 0 && (dbg & 16u));
-      has_tt[p] = __ballot((pre[p].y >> 29) == 1u) != 0ull;
-      has_gen[p] = __ballot((pre[p].y >> 28) == 1u) != 0ull;
-      dmask[p] = __ballot((pre[p].y >> 30) == 1u);
+      wflags |= (__ballot((pre[p].y >> 29) == 1u) != 0ull ? 1u : 0u) << p | (__ballot((pre[p].y >> 28) == 1u) != 0ull ? 0x100u : 0u) << p |
+                (__ballot((pre[p].y >> 30) == 1u) != 0ull ? 0x10000u : 0u) << p;
     }
-    bool any_gen = false;
-    unsigned long long any_dmask = 0ull;
-#pragma unroll
-    for (int p = 0; p < RP; p++) { any_gen = any_gen || has_gen[p]; any_dmask |= dmask[p]; }
+    wflags = __builtin_amdgcn_readfirstlane(wflags);
+    const uint32_t my_rows = td.y > wave * 64u ? (td.y - wave * 64u + THREADS - 1u) / THREADS : 0u;      // row passes in which this wave has rows
+#define has_rows(p) ((uint32_t)(p) < my_rows)
+#define has_tt(p) ((wflags >> (p)) & 1u)
+#define has_gen(p) ((wflags >> (8 + (p))) & 1u)
+#define has_dmask(p) ((wflags >> (16 + (p))) & 1u)
     unsigned long long mbit[EG];                             // elements of this wave's groups the tile's rows take for bits
 #pragma unroll
     for (int q = 0; q < EG; q++) mbit[q] = S.smask[(size_t)tile * S.smask_groups + wave + (uint32_t)q * WAVES];
@@ -901,127 +855,213 @@ __global__ __launch_bounds__(64 * WAVES, 4) void b3w_r1cs_stream_kernel(   // (s
       gwords[k] = S.sgwords[gd.x + k];
       gmeta[k] = S.sgmeta[gd.x + k];
     }
-    if (tid < 2) { lanom[tid] = 0u; lsum[tid] = 0ull; }
-    for (uint32_t k = tid; k < 6u * gd.z; k += THREADS) gsum[k] = 0ull;            // (afterwards every general row's owner lane zeroes its own sums)
-    for (uint32_t k = tid; k < gd.z; k += THREADS) gflag[k] = 0u;
-    // DMA blocks of this wave: tile blocks wave + q * WAVES (a block = 32 elements = 1 KiB), outside-wire blocks likewise.
-    // Lane l of a block fetches the low (l < 32) or high half of element 32 * block + (l & 31).
-    const uint32_t half = lane >> 5, ein = lane & 31u;
-    const uint32_t nblk = (n_local + 31u) >> 5, nxblk = (td.w + 31u) >> 5;
-    uint32_t off[MB], offx[XB];
-    uint32_t per_tile = 0;                                   // this wave's DMAs per tile
-#pragma unroll
-    for (int q = 0; q < MB; q++) {
-      const uint32_t e = (wave + (uint32_t)q * WAVES) * 32u + ein;
-      off[q] = (t0 + (e < n_local ? e : n_local - 1u)) * 32u + half * 16u;
-      per_tile += wave + (uint32_t)q * WAVES < nblk ? 1u : 0u;
-    }
-#pragma unroll
-    for (int q = 0; q < XB; q++) {
-      const uint32_t blk = wave + (uint32_t)q * WAVES, e = blk * 32u + ein;
-      offx[q] = (blk < nxblk ? S.ext[td.z + (e < td.w ? e : td.w - 1u)] : 0u) * 32u + half * 16u;
-      per_tile += blk < nxblk ? 1u : 0u;
-    }
-    // NBUF = 0: no raw image in LDS at all — the wave fetches the elements it packs (groups wave + q * WAVES, and its group of
-    // outside wires) into registers, one unit ahead: 16 + 8 VGPRs hold what 48 KB of LDS held, so a workgroup's next unit is in
-    // flight during everything but its own pack phase, whatever the LDS holds
+    if (tid < 3) lanom[tid] = 0u;
+    if (tid < 2) lsum[tid] = 0ull;
+    for (uint32_t k = tid; k < 6u * gd.z; k += THREADS) { gsum0[k] = 0ull; gsum0[6u * S.max_g_rows + k] = 0ull; }      // (afterwards every general row's owner lane zeroes its own sums)
+    for (uint32_t k = tid; k < gd.z; k += THREADS) { gflag0[k] = 0u; gflag0[gr2 + k] = 0u; }
+    // fetch offsets: group g = elements 64 g ... 64 g + 63 as two blocks of 32; lane l of a block takes the low (l < 32) or high
+    // 16 bytes of element (l & 31) of the block.  (An element behind the last tile's end: that tile's last element again.)
     uint4 rlo[EG], rhi[EG], xlo = make_uint4(0, 0, 0, 0), xhi = make_uint4(0, 0, 0, 0);
-    // A fetch of a group is two CONTIGUOUS 1 KiB loads (elements 64 g ... + 31 and + 32 ... + 63; a lane below 32 takes the low
-    // 16 bytes of its element, the lane 32 above it the high 16: 8 cache lines per instruction, every byte of them used), then
-    // v_permlane32_swap puts the low halves of all 64 elements into one register set and the high halves into the other.  (One
-    // element per lane — 32-byte stride, twice — is 16 half-used lines per instruction, and the texture path is what sixteen waves
-    // queue for here.)
     uint32_t eoff[EG][2], xoff = 0;
-    bool xact = false;
-    if constexpr (NBUF == 0) {
 #pragma unroll
-      for (int q = 0; q < EG; q++)
+    for (int q = 0; q < EG; q++) {
 #pragma unroll
-        for (int h = 0; h < 2; h++) {
-          const uint32_t e = (wave + (uint32_t)q * WAVES) * 64u + (uint32_t)h * 32u + (lane & 31u);
-          eoff[q][h] = (t0 + (e < n_local ? e : n_local - 1u)) * 32u + (lane >> 5) * 16u;
-        }
-#pragma unroll
-      for (int q = 0; q < EG; q++) rlo[q] = rhi[q] = make_uint4(0, 0, 0, 0);
-      const uint32_t j = xg * 64u + lane;
-      xact = packs_ext && j < td.w;                          // outside wires: a lane per wire (a gather), lanes without one masked off
-      if (xact) xoff = S.ext[td.z + j] * 32u;
-      asm volatile("" :: "v"(xoff));
+      for (int h = 0; h < 2; h++) {
+        const uint32_t e = (wave + (uint32_t)q * WAVES) * 64u + (uint32_t)h * 32u + (lane & 31u);
+        eoff[q][h] = (t0 + (e < n_local ? e : n_local - 1u)) * 32u + (lane >> 5) * 16u;
+      }
+      rlo[q] = rhi[q] = make_uint4(0, 0, 0, 0);
     }
-    // (registers) the outside wires of a unit are fetched one phase EARLIER than its tile elements — a gather, 64 cache lines per
-    // instruction, is the slowest thing here to come back
-    auto issue_ext = [&](const uint32_t body_index) {
-      const uint8_t *body = bodies + (uint64_t)((dbg & 12u) ? b_lo : body_index) * pitch;
+    const uint32_t xj = xg * 64u + lane;                     // outside wires: a lane per wire, lanes without one masked off
+    const bool xact = packs_ext && xj < td.w;
+    if (xact) xoff = S.ext[td.z + xj] * 32u;
+    // every global load above has landed before the pipeline starts: inside it the compiler must find nothing of its own to wait for
+    // but the fetches
+#pragma unroll
+    for (int p = 0; p < RP; p++) asm volatile("" :: "v"(pre[p].x), "v"(pre[p].y), "v"(pre[p].z), "v"(pre[p].w));
+#pragma unroll
+    for (int q = 0; q < EG; q++) asm volatile("" :: "s"((uint32_t)mbit[q]), "s"((uint32_t)(mbit[q] >> 32)));
+    asm volatile("" :: "s"((uint32_t)xbit), "s"((uint32_t)(xbit >> 32)), "v"(xoff));
+    auto body_of = [&](const uint32_t k) -> const uint8_t * {      // body of unit k of this tile (behind the tile's end: the last one — fetched, packed, never looked at: no condition between a fetch and its use)
+      const uint32_t kk = (dbg & 12u) ? 0u : k < m ? k : m - 1u;   // (experiments 4, 8: the tile's first body over and over — no HBM traffic, the same instructions)
+      return bodies + (uint64_t)(b_lo + kk) * pitch;
+    };
+    auto fetch_ext = [&](const uint32_t k) {
+      const uint8_t *body = body_of(k);
       if (xact) {
         xlo = ldg16<false>(body, xoff);
         xhi = ldg16<false>(body, xoff + 16u);
       }
     };
-    auto issue = [&](const uint32_t body_index, const uint32_t buf) {
-      const uint8_t *body = bodies + (uint64_t)(NBUF == 0 && (dbg & 12u) ? b_lo : body_index) * pitch;      // (scalar arithmetic; registers, 4 or 8: the tile's first body over and over — no HBM traffic, the same instructions)
-      const uint32_t dst = lds0 + buf * raw_stride;
-      if (NBUF != 0 && ((dbg & 4u) || ((dbg & 8u) && body_index != b_lo))) return;      // (8: only the first body of the tile is ever staged)
-      if constexpr (NBUF == 0) {
+    auto fetch_tile = [&](const uint32_t k) {
+      const uint8_t *body = body_of(k);
 #pragma unroll
-        for (int q = 0; q < EG; q++) {                       // (a group behind the last tile's end re-reads that tile's last element: no branch)
-          rlo[q] = ldg16<true>(body, eoff[q][0]);              // (until the pack: elements + 0 ... 31, both halves)
-          rhi[q] = ldg16<true>(body, eoff[q][1]);              // (... + 32 ... 63)
-        }
-        return;
+      for (int q = 0; q < EG; q++) {
+        rlo[q] = ldg16<true>(body, eoff[q][0]);              // (until the pack: elements + 0 ... 31, both halves)
+        rhi[q] = ldg16<true>(body, eoff[q][1]);              // (... + 32 ... 63)
       }
-#pragma unroll
-      for (int q = 0; q < MB; q++)
-        if (wave + (uint32_t)q * WAVES < nblk) glds16s(dst + (wave + (uint32_t)q * WAVES) * 1024u, body, off[q], !(dbg & 64u));      // tile bytes are read once: non-temporal
-#pragma unroll
-      for (int q = 0; q < XB; q++)
-        if (wave + (uint32_t)q * WAVES < nxblk) glds16s(dst + B3W_R1CS_TILE * 32u + (wave + (uint32_t)q * WAVES) * 1024u, body, offx[q], (dbg & 128u) != 0u);
     };
-    // every global load above has landed before the first DMA is issued: inside the pipeline the compiler must find nothing of
-    // its own to wait for (a wait it placed at a first use in the loop would drain the DMAs on every iteration)
+    // ---- pack (unit k): 32-byte elements -> 8 bytes (bit 63 = "not below 2^63") + two bit words per 64 elements; anything the
+    // masks take for a bit and that is none raises the anomaly flag, and so does wire 0 not being 1
+    auto pack = [&](const uint32_t k, const uint32_t k3) {
+      // every staged register is taken here, by every wave, whatever it goes on to use: the compiler waits for the fetch at this
+      // one point (and knows it has) — a fetch it could not prove consumed would cost a vmcnt(0) where the NEXT fetch is issued
 #pragma unroll
-    for (int p = 0; p < RP; p++) asm volatile("" :: "v"(pre[p].x), "v"(pre[p].y), "v"(pre[p].z), "v"(pre[p].w));
+      for (int q = 0; q < EG; q++)
+        asm volatile("" :: "v"(rlo[q].x), "v"(rlo[q].y), "v"(rlo[q].z), "v"(rlo[q].w), "v"(rhi[q].x), "v"(rhi[q].y), "v"(rhi[q].z), "v"(rhi[q].w));
+      asm volatile("" :: "v"(xlo.x), "v"(xlo.y), "v"(xlo.z), "v"(xlo.w), "v"(xhi.x), "v"(xhi.y), "v"(xhi.z), "v"(xhi.w));
+      if (dbg & 2u) return;
+      unsigned long long *el = el0 + (k & 1u) * ne, *packed = packed0 + (k & 1u) * 2u * groups;
+      bool flag = false;
 #pragma unroll
-    for (int q = 0; q < MB; q++) asm volatile("" :: "v"(off[q]));
+      for (int q = 0; q < EG; q++) {
+        const uint32_t g = wave + (uint32_t)q * WAVES, e = g * 64u + lane;         // the wave holds elements 64 g ... 64 g + 63
+        uint4 lo = rlo[q], hi = rhi[q];
+        halves_apart(lo.x, hi.x); halves_apart(lo.y, hi.y); halves_apart(lo.z, hi.z); halves_apart(lo.w, hi.w);
+        const unsigned long long z = e < n_local ? lean_pack(lo, hi) : 0ull;
+        el[e] = z;
+        const unsigned long long ones = __ballot(z == 1ull), bads = __ballot(z > 1ull);
+        if (lane == 0) { packed[2 * g] = ones; packed[2 * g + 1] = bads; }
+        flag = flag || (bads & mbit[q]) != 0ull || (tile == 0 && g == 0 && !(ones & 1ull));          // (wire 0 is element 0 of tile 0)
+      }
+      if (packs_ext) {                                                             // (whole waves, for the ballots)
+        const unsigned long long z = xj < td.w ? lean_pack(xlo, xhi) : 0ull;
+        if (xj < ext_cap) el[B3W_R1CS_TILE + xj] = z;
+        const unsigned long long ones = __ballot(z == 1ull), bads = __ballot(z > 1ull);
+        if (lane == 0) { packed[2 * (16u + xg)] = ones; packed[2 * (16u + xg) + 1] = bads; }
+        flag = flag || (bads & xbit) != 0ull || (tile != 0 && xg == 0 && !(ones & 1ull));            // (outside wire 0 of every other tile)
+      }
+      if (flag && lane == 0) lanom[k3] = 1u;
+    };
+    // ---- general rows, one WORD per lane: chunk c of 64 words goes to wave WAVES - 1 - c mod WAVES; a lane adds coefficient *
+    // element (or the value of a bit run) into its row's part sum.  A part sum is two 64-bit counters {low, high} worth
+    // low + high * 2^52: a contribution below 2^54 goes to `low` whole, a larger one (the dyadic row scaling of the O2 systems makes
+    // 2^30 * word) is cut at bit 52 — products stay below 2^103 and a row has at most 256 words, so no counter overflows and the
+    // sum is exact.
+    auto words = [&](const uint32_t k) {
+      const unsigned long long *el = el0 + (k & 1u) * ne, *packed = packed0 + (k & 1u) * 2u * groups;
+      unsigned long long *gsum = gsum0 + (k & 1u) * 6u * S.max_g_rows;
+      uint32_t *gflag = gflag0 + (k & 1u) * gr2;
+      for (uint32_t c0 = ((uint32_t)WAVES - 1u - wave) * 64u; c0 < gd.y; c0 += THREADS) {
+        const uint32_t iw = c0 + lane;
+        const bool act = iw < gd.y;
+        const uint32_t w = gwords[act ? iw : 0u], w1 = gwords[act ? iw + 1u : 0u], mt = gmeta[act ? iw : 0u];
+        const bool second = (mt >> 2) & 1u;                  // the second word of a run: nothing of its own
+        const bool is_run = act && !second && (w >> 16) == 0xFFFFu;
+        const bool is_term = act && !second && !is_run;
+        const unsigned long long z = el[is_term ? w & 0xFFFFu : 0u];
+        const long long c = lcoef[is_term ? w >> 16 : 0u];
+        const unsigned long long mag = c < 0 ? 0ull - (unsigned long long)c : (unsigned long long)c;
+        unsigned long long lo = mag * z, hi = __umul64hi(mag, z);
+        bool neg = c < 0;
+        bool ok = c != B3W_R1CS_NOT_SMALL && !(z >> 63) && hi < (1ull << 39);        // (bit 63 of an element = "not below 2^63")
+        if (__ballot(is_run) != 0ull) {
+          if (is_run) {
+            const uint32_t idx0 = w & 0xFFFFu, len = w1 & 0xFFu, sh = (w1 >> 8) & 0xFFu;
+            const uint32_t g = idx0 >> 6, r = idx0 & 63u;
+            const unsigned long long one_lo = packed[2 * g], bad_lo = packed[2 * g + 1], one_hi = packed[2 * g + 2], bad_hi = packed[2 * g + 3];
+            const unsigned long long mask = len == 64u ? ~0ull : (1ull << len) - 1ull;
+            const unsigned long long ones = ((one_lo >> r) | (r ? one_hi << (64u - r) : 0ull)) & mask;
+            const unsigned long long bads = ((bad_lo >> r) | (r ? bad_hi << (64u - r) : 0ull)) & mask;
+            ok = bads == 0ull;                               // (an element of the run that is no bit)
+            lo = ones << (sh & 63u); hi = 0ull;              // (below 2^62: the host checks sh + len)
+            neg = (w1 >> 16) & 1u;
+          }
+        }
+        if (is_term || is_run) {
+          const uint32_t g = mt >> 8;
+          unsigned long long *sum = gsum + 6u * g + 2u * (mt & 3u);
+          if (!ok) atomicOr(&gflag[g], 1u);
+          else if (hi == 0ull && lo < (1ull << 54)) atomicAdd(sum, neg ? 0ull - lo : lo);
+          else {                                             // cut at bit 52: value = low + high * 2^52, low in [0, 2^52)
+            __int128 v = (__int128)(((unsigned __int128)hi << 64) | lo);
+            if (neg) v = -v;
+            atomicAdd(sum, (unsigned long long)v & ((1ull << 52) - 1ull));
+            atomicAdd(sum + 1, (unsigned long long)(long long)(v >> 52));
+          }
+        }
+      }
+    };
+    // ---- this wave's own rows (unit k).  Usual road: the masks have vouched for every bit, so booleanity rows hold, and a
+    // truth-table row is its table indexed by the operands' low bits.  Anomaly road: row by row, with the bit-ness of every operand
+    // looked at.  Returns bit p: row of pass p deferred, bit 8 + p: violated.
+    auto rows = [&](const uint32_t k, const bool anomaly) -> uint32_t {
+      const unsigned long long *el = el0 + (k & 1u) * ne;
+      const uint32_t *el32 = reinterpret_cast<const uint32_t *>(el);
+      uint32_t verdict = 0;
+      auto table_row = [&](const uint4 d) {
+        const uint32_t kk = (d.y >> 16) & 7u;
+        const uint32_t a = (el32[2u * (d.x & 0xFFFFu)] & 1u) | (el32[2u * (d.x >> 16)] & 1u) << 1 | (el32[2u * (d.z & 0xFFFFu)] & 1u) << 2 |
+                           (el32[2u * (d.z >> 16)] & 1u) << 3 | (el32[2u * (d.y & 0xFFFFu)] & 1u) << 4;      // (unused positions name element 0: masked)
+        return (d.y >> 29) == 1u && !((d.w >> (a & ((1u << kk) - 1u))) & 1u);
+      };
+      auto careful_row = [&](const uint4 d, bool *defer, bool *bad) {
+        const bool w0_is_one = el[tile == 0 ? 0 : B3W_R1CS_TILE] == 1ull;
+        if (d.y >> 31) {                                     // booleanity  z * (1 - z) = 0: is the element 0 or 1
+          if (w0_is_one) *bad = el[d.w] > 1ull;              // (an element of 2^63 or more is no bit)
+          else *defer = true;                                // (wire 0 is not 1: nothing here means what it should — field arithmetic)
+        }
+        if ((d.y >> 29) == 1u) {
+          const uint32_t kk = (d.y >> 16) & 7u;
+          const unsigned long long z0 = el[d.x & 0xFFFFu], z1 = el[d.x >> 16], z2 = el[d.z & 0xFFFFu], z3 = el[d.z >> 16], z4 = el[d.y & 0xFFFFu];
+          const unsigned long long nonbit = (z0 | (kk > 1 ? z1 : 0ull) | (kk > 2 ? z2 : 0ull) | (kk > 3 ? z3 : 0ull) | (kk > 4 ? z4 : 0ull)) >> 1;
+          const uint32_t a = ((uint32_t)z0 & 1u) | ((uint32_t)z1 & 1u) << 1 | ((uint32_t)z2 & 1u) << 2 | ((uint32_t)z3 & 1u) << 3 | ((uint32_t)z4 & 1u) << 4;
+          *defer = nonbit != 0ull || !w0_is_one;
+          *bad = !*defer && !((d.w >> (a & ((1u << kk) - 1u))) & 1u);
+        }
+      };
 #pragma unroll
-    for (int q = 0; q < XB; q++) asm volatile("" :: "v"(offx[q]));
-#pragma unroll
-    for (int q = 0; q < EG; q++) asm volatile("" :: "s"((uint32_t)mbit[q]), "s"((uint32_t)(mbit[q] >> 32)));
-    asm volatile("" :: "s"((uint32_t)xbit), "s"((uint32_t)(xbit >> 32)));
-    lds_barrier();                                                                 // the word list (and, the first time, the coefficients) in place
-    // ---- the verdicts of a unit: general rows from their finished sums (the owner lane zeroes them for the next unit), the mask
-    // words of the deferred rows, the violation counts.  Runs one barrier AFTER the unit's words were added — behind barrier one
-    // of the NEXT unit, beside that unit's pack phase — so a unit costs two barriers, not three.
-    // What goes to the deferred kernel, per (body, tile): word 0 of the block = which mask words are not zero; only those are
-    // stored.  A wave whose rows of this unit are all decided and hold (every wave of almost every unit) leaves at once: one
-    // compare.  (A mask word per wave and row pass, stored unit after unit, was 16 ... 32 stores a unit on the path sixteen waves
-    // queue for, and as many loads in the deferred kernel.)
-    auto verdicts = [&](const uint32_t b, const uint32_t verdict, const bool anomaly) {
-      if (!any_gen && !anomaly && any_dmask == 0ull && __ballot(verdict != 0u) == 0ull) return;
+      for (int p = 0; p < RP; p++) {
+        if (!has_rows(p)) continue;
+        if (!anomaly) {
+          if (has_tt(p) && table_row(pre[p])) verdict |= 0x100u << p;
+        } else {
+          bool defer = false, bad = false;
+          careful_row(pre[p], &defer, &bad);                 // (a lane without a row holds an all-zero descriptor: no class)
+          verdict |= (defer ? 1u : 0u) << p | (bad ? 0x100u : 0u) << p;
+        }
+      }
+      return verdict;
+    };
+    // ---- the verdicts of unit k (one iteration after its words were added): general rows from their finished sums (the owner
+    // lane zeroes them for unit k + 2), the mask words of the deferred rows, the violation counts.  What goes to the deferred kernel,
+    // per (body, tile): word 0 of the block = which mask words are not zero; only those are stored.  A wave whose rows of this unit
+    // are all decided and hold (every wave of almost every unit) leaves at once: one compare.
+    auto verdicts = [&](const uint32_t k, const uint32_t verdict, const bool anomaly) {
+      if (!(wflags & 0xFFFF00u) && !anomaly && __ballot(verdict != 0u) == 0ull) return;
+      const uint32_t b = b_lo + k;
       unsigned long long *block = scratch + ((size_t)b * S.ntiles + tile) * block_words;
+      unsigned long long *gsum = gsum0 + (k & 1u) * 6u * S.max_g_rows;
+      uint32_t *gflag = gflag0 + (k & 1u) * gr2;
       uint32_t nbad = 0, low = 0xFFFFFFFFu, badmask = 0;
 #pragma unroll
       for (int p = 0; p < RP; p++) {
-        if (!has_rows[p]) continue;
+        if (!has_rows(p)) continue;
         bool defer = (verdict >> p) & 1u, bad = (verdict >> (8 + p)) & 1u;
-        if (has_gen[p]) {
-          const uint4 d = fresh(pre[p]);
+        if (has_gen(p)) {
+          const uint4 d = pre[p];
           if ((d.y >> 28) == 1u) {
+            // (written out in 64-bit halves: the compiler's __int128 version of the same — range compares, a 128 x 128 product — was
+            // 120 vector instructions on the one wave every other wave of the workgroup then waits for)
             unsigned long long *sum = gsum + 6u * d.x;
-            const __int128 A = (__int128)(long long)sum[0] + ((__int128)(long long)sum[1] << 52);
-            const __int128 B = (__int128)(long long)sum[2] + ((__int128)(long long)sum[3] << 52);
-            const __int128 C = (__int128)(long long)sum[4] + ((__int128)(long long)sum[5] << 52);
-            defer = gflag[d.x] != 0u || (dbg & 32u) != 0u || !(A < lim && A > -lim && B < lim && B > -lim);
-            bad = !defer && A * B != C;                      // |A * B - C| < 2^127 < p: "= 0 mod p" is "= 0"
+            unsigned long long a_lo, b_lo, c_lo;
+            long long a_hi, b_hi, c_hi;
+            part_sum(sum[0], sum[1], a_lo, a_hi);
+            part_sum(sum[2], sum[3], b_lo, b_hi);
+            part_sum(sum[4], sum[5], c_lo, c_hi);
+            // A and B must fit 64 signed bits (then |A * B - C| < 2^127 < p: "= 0 mod p" is "= 0")
+            defer = gflag[d.x] != 0u || (dbg & 32u) != 0u || a_hi != ((long long)a_lo >> 63) || b_hi != ((long long)b_lo >> 63);
+            bad = !defer && (a_lo * b_lo != c_lo || __mul64hi((long long)a_lo, (long long)b_lo) != c_hi);
 #pragma unroll
             for (int q = 0; q < 6; q++) sum[q] = 0ull;
             gflag[d.x] = 0u;
           }
         }
         if (bad) { nbad++; badmask |= 1u << p; }
-        const unsigned long long mask = (has_gen[p] || anomaly ? __ballot(defer) : 0ull) | dmask[p];
+        const unsigned long long mask = (has_gen(p) || anomaly ? __ballot(defer) : 0ull) | (has_dmask(p) ? __ballot((pre[p].y >> 30) == 1u) : 0ull);      // (always-deferred rows: the same mask bits for every body)
         if (mask != 0ull && lane == 0) {                     // (wave-uniform; word (row - first) / 64)
           block[1 + (uint32_t)p * WAVES + wave] = mask;
-          atomicOr(&lsum[b & 1u], 1ull << ((uint32_t)p * WAVES + wave));
+          atomicOr(&lsum[k & 1u], 1ull << ((uint32_t)p * WAVES + wave));
         }
       }
       if (__ballot(nbad != 0) != 0ull) {                   // (rare: a body that violates something)
@@ -1039,183 +1079,64 @@ __global__ __launch_bounds__(64 * WAVES, 4) void b3w_r1cs_stream_kernel(   // (s
         }
       }
     };
-    // word 0 of a unit's block, by one lane, once every wave's verdicts of the unit are behind a barrier
-    auto summary = [&](const uint32_t b) {
+    // word 0 of unit k's block, by one lane, once every wave's verdicts of the unit are behind a barrier
+    auto summary = [&](const uint32_t k) {
       if (wave == 1u % (uint32_t)WAVES && lane == 0) {
-        scratch[((size_t)b * S.ntiles + tile) * block_words] = lsum[b & 1u];
-        lsum[b & 1u] = 0ull;
+        scratch[((size_t)(b_lo + k) * S.ntiles + tile) * block_words] = lsum[k & 1u];
+        lsum[k & 1u] = 0ull;
       }
     };
-    constexpr uint32_t DEPTH = NBUF ? NBUF : 1;              // units in flight ahead of the one being packed
-    // ---- pack (unit i): 32-byte elements -> 8 bytes (bit 63 = "not below 2^63") + two bit words per 64 elements; anything the
-    // masks take for a bit and that is none raises the anomaly flag, and so does wire 0 not being 1
-    auto pack = [&](const uint32_t i) {
-      const unsigned char *raw = smem + (size_t)(i % DEPTH) * raw_stride;
-      const bool do_pack = !(dbg & 2u) && !((dbg & 8u) && i > 0);                  // (8: packed once; its rows are evaluated m times)
-      if constexpr (NBUF == 0) {
-        // every staged register is taken here, by every wave, whatever it goes on to use: the compiler waits for the fetch at this
-        // one point (and knows it has) — a fetch it could not prove consumed would cost a vmcnt(0) where the NEXT fetch is issued,
-        // right behind the verdict stores
-#pragma unroll
-        for (int q = 0; q < EG; q++)
-          asm volatile("" :: "v"(rlo[q].x), "v"(rlo[q].y), "v"(rlo[q].z), "v"(rlo[q].w), "v"(rhi[q].x), "v"(rhi[q].y), "v"(rhi[q].z), "v"(rhi[q].w));
-        asm volatile("" :: "v"(xlo.x), "v"(xlo.y), "v"(xlo.z), "v"(xlo.w), "v"(xhi.x), "v"(xhi.y), "v"(xhi.z), "v"(xhi.w));
-      }
-      if (!do_pack) return;
-      bool flag = false;
-#pragma unroll
-      for (int q = 0; q < EG; q++) {
-        const uint32_t g = wave + (uint32_t)q * WAVES, e = g * 64u + lane;         // the wave holds elements 64 g ... 64 g + 63
-        uint4 lo, hi;
-        if constexpr (NBUF == 0) {
-          lo = rlo[q]; hi = rhi[q];
-          halves_apart(lo.x, hi.x); halves_apart(lo.y, hi.y); halves_apart(lo.z, hi.z); halves_apart(lo.w, hi.w);
-        } else {
-          lo = *reinterpret_cast<const uint4 *>(raw + (e >> 5) * 1024u + (e & 31u) * 16u);
-          hi = *reinterpret_cast<const uint4 *>(raw + (e >> 5) * 1024u + 512u + (e & 31u) * 16u);
-        }
-        const unsigned long long z = e < n_local ? lean_pack(lo, hi) : 0ull;
-        el[e] = z;
-        const unsigned long long ones = __ballot(z == 1ull), bads = __ballot(z > 1ull);
-        if (lane == 0) { packed[2 * g] = ones; packed[2 * g + 1] = bads; }
-        flag = flag || (bads & mbit[q]) != 0ull || (tile == 0 && g == 0 && !(ones & 1ull));          // (wire 0 is element 0 of tile 0)
-      }
-      if (packs_ext) {                                                             // (whole waves, for the ballots)
-        const uint32_t j = xg * 64u + lane;                                        // outside wire j of the tile
-        unsigned long long z = 0ull;
-        if constexpr (NBUF == 0) z = j < td.w ? lean_pack(xlo, xhi) : 0ull;
-        else if (j < td.w) {
-          const uint4 lo = *reinterpret_cast<const uint4 *>(raw + B3W_R1CS_TILE * 32u + (j >> 5) * 1024u + (j & 31u) * 16u);
-          const uint4 hi = *reinterpret_cast<const uint4 *>(raw + B3W_R1CS_TILE * 32u + (j >> 5) * 1024u + 512u + (j & 31u) * 16u);
-          z = lean_pack(lo, hi);
-        }
-        if (j < ext_cap) el[B3W_R1CS_TILE + j] = z;
-        const unsigned long long ones = __ballot(z == 1ull), bads = __ballot(z > 1ull);
-        if (lane == 0) { packed[2 * (16u + xg)] = ones; packed[2 * (16u + xg) + 1] = bads; }
-        flag = flag || (bads & xbit) != 0ull || (tile != 0 && xg == 0 && !(ones & 1ull));            // (outside wire 0 of every other tile)
-      }
-      if (flag && lane == 0) lanom[i & 1u] = 1u;
-    };
-    // ---- the pipeline.  Between two barriers B a workgroup holds unit i packed in LDS; one iteration is
-    //   fetch unit i + DEPTH | words and rows of unit i | barrier A | pack unit i + 1, verdicts of unit i | barrier B
-    // so the fetch of a unit and its pack sit in ONE iteration (registers: the compiler sees load and use together and waits exactly
-    // there; nothing is carried around the loop), a unit costs two barriers, and the verdict stores follow the pack's wait.
-    if (NBUF == 0) { issue_ext(b_lo); issue(b_lo, 0); }
-    else for (uint32_t k = 0; k < DEPTH && k < m; k++) issue(b_lo + k, k);
-    if (NBUF != 0) { vm_wait(per_tile * ((m < DEPTH ? m : DEPTH) - 1u)); lds_barrier(); }      // (DMA: a wave packs what other waves fetched)
-    pack(0);
-    if (NBUF == 0) issue_ext(1u < m ? b_lo + 1u : b_lo);
-    lds_barrier();                                                                 // barrier B of unit 0
+    // ---- the pipeline
+    fetch_ext(0);
+    fetch_tile(0);
+    lds_barrier();                                                                 // the word list (and, the first time, the coefficients) in place, sums and flags zero
+    pack(0, 0);
+    fetch_ext(1);
+    lds_barrier();
+    uint32_t pend_verdict = 0, i3 = 0;                       // (i3 = i mod 3)
+    bool pend_anomaly = false;
     for (uint32_t i = 0; i < m; i++) {
-      const uint32_t b = b_lo + i;
-      if (stamping) t_prev = __builtin_amdgcn_s_memtime();
-      if (i && !(dbg & 1u)) summary(b - 1u);
-      if (NBUF == 0) issue(i + 1u < m ? b + 1u : b, 0);                            // registers: unit i + 1, consumed at the end of this iteration (behind the tile's last unit: that unit again, packed and never looked at — no condition between fetch and use)
-      else if (i + DEPTH < m) issue(b + DEPTH, i % DEPTH);                         // DMA: the image of unit i, read out before barrier B, takes unit i + DEPTH
+      if (STAMPS && stamping) t_prev = __builtin_amdgcn_s_memtime();
+      if (i >= 2u && !(dbg & 1u)) summary(i - 2u);                                 // (its verdicts ran in the last iteration, behind the last barrier)
+      fetch_tile(i + 1u);                                                          // consumed by the pack at the end of this iteration
       B3W_STAMP(0);
-      const bool anomaly = __builtin_amdgcn_readfirstlane(lanom[i & 1u]) != 0u;
-      if (tid == 0) lanom[(i + 1u) & 1u] = 0u;               // (read one unit ago by everyone; the next pack, behind barrier A, may set it)
-      uint32_t verdict = 0;                                  // bit p: row of pass p deferred, bit 8 + p: violated
-      if (!(dbg & 1u)) {
-        // ---- general rows, one WORD per lane: chunk c of 64 words goes to wave c mod WAVES; a lane adds coefficient * element (or
-        // the value of a bit run) into its row's part sum.  A part sum is two 64-bit counters {low, high} worth low + high * 2^52: a
-        // contribution below 2^54 goes to `low` whole, a larger one (the dyadic row scaling of the O2 systems makes 2^30 * word) is cut
-        // at bit 52 — products stay below 2^103 (the lean kernel's bound) and a row has at most 256 words, so no counter overflows
-        // and the sum is exact.
-        if (!(dbg & 32u))
-          for (uint32_t c0 = ((uint32_t)WAVES - 1u - wave) * 64u; c0 < gd.y; c0 += THREADS) {
-            const uint32_t iw = c0 + lane;
-            const bool act = iw < gd.y;
-            const uint32_t w = gwords[act ? iw : 0u], w1 = gwords[act ? iw + 1u : 0u], mt = gmeta[act ? iw : 0u];
-            const bool second = (mt >> 2) & 1u;                // the second word of a run: nothing of its own
-            const bool is_run = act && !second && (w >> 16) == 0xFFFFu;
-            const bool is_term = act && !second && !is_run;
-            const unsigned long long z = el[is_term ? w & 0xFFFFu : 0u];
-            const long long c = lcoef[is_term ? w >> 16 : 0u];
-            const unsigned long long mag = c < 0 ? 0ull - (unsigned long long)c : (unsigned long long)c;
-            unsigned long long lo = mag * z, hi = __umul64hi(mag, z);
-            bool neg = c < 0;
-            bool ok = c != B3W_R1CS_NOT_SMALL && !(z >> 63) && hi < (1ull << 39);      // (bit 63 of an element = "not below 2^63")
-            if (__ballot(is_run) != 0ull) {
-              if (is_run) {
-                const uint32_t idx0 = w & 0xFFFFu, len = w1 & 0xFFu, sh = (w1 >> 8) & 0xFFu;
-                const uint32_t g = idx0 >> 6, r = idx0 & 63u;
-                const unsigned long long one_lo = packed[2 * g], bad_lo = packed[2 * g + 1], one_hi = packed[2 * g + 2], bad_hi = packed[2 * g + 3];
-                const unsigned long long mask = len == 64u ? ~0ull : (1ull << len) - 1ull;
-                const unsigned long long ones = ((one_lo >> r) | (r ? one_hi << (64u - r) : 0ull)) & mask;
-                const unsigned long long bads = ((bad_lo >> r) | (r ? bad_hi << (64u - r) : 0ull)) & mask;
-                ok = bads == 0ull;                             // (an element of the run that is no bit)
-                lo = ones << (sh & 63u); hi = 0ull;            // (below 2^62: the host checks sh + len)
-                neg = (w1 >> 16) & 1u;
-              }
-            }
-            if (is_term || is_run) {
-              const uint32_t g = mt >> 8;
-              unsigned long long *sum = gsum + 6u * g + 2u * (mt & 3u);
-              if (!ok) atomicOr(&gflag[g], 1u);
-              else if (hi == 0ull && lo < (1ull << 54)) atomicAdd(sum, neg ? 0ull - lo : lo);
-              else {                                           // cut at bit 52: value = low + high * 2^52, low in [0, 2^52)
-                __int128 v = (__int128)(((unsigned __int128)hi << 64) | lo);
-                if (neg) v = -v;
-                atomicAdd(sum, (unsigned long long)v & ((1ull << 52) - 1ull));
-                atomicAdd(sum + 1, (unsigned long long)(long long)(v >> 52));
-              }
-            }
-          }
-        B3W_STAMP(1);
-        // ---- this wave's own rows.  Usual road: the masks have vouched for every bit, so booleanity rows hold, and a truth-table row
-        // is its table indexed by the operands' low bits.  Anomaly road: row by row, with the bit-ness of every operand looked at.
-        auto table_row = [&](const uint4 d) {
-          const uint32_t k = (d.y >> 16) & 7u;
-          const uint32_t a = (el32[2u * (d.x & 0xFFFFu)] & 1u) | (el32[2u * (d.x >> 16)] & 1u) << 1 | (el32[2u * (d.z & 0xFFFFu)] & 1u) << 2 |
-                             (el32[2u * (d.z >> 16)] & 1u) << 3 | (el32[2u * (d.y & 0xFFFFu)] & 1u) << 4;      // (unused positions name element 0: masked)
-          return (d.y >> 29) == 1u && !((d.w >> (a & ((1u << k) - 1u))) & 1u);
-        };
-        auto careful_row = [&](const uint4 d, bool *defer, bool *bad) {
-          const bool w0_is_one = el[tile == 0 ? 0 : B3W_R1CS_TILE] == 1ull;
-          if (d.y >> 31) {                                     // booleanity  z * (1 - z) = 0: is the element 0 or 1
-            if (w0_is_one) *bad = el[d.w] > 1ull;              // (an element of 2^63 or more is no bit)
-            else *defer = true;                                // (wire 0 is not 1: nothing here means what it should — field arithmetic)
-          }
-          if ((d.y >> 29) == 1u) {
-            const uint32_t k = (d.y >> 16) & 7u;
-            const unsigned long long z0 = el[d.x & 0xFFFFu], z1 = el[d.x >> 16], z2 = el[d.z & 0xFFFFu], z3 = el[d.z >> 16], z4 = el[d.y & 0xFFFFu];
-            const unsigned long long nonbit = (z0 | (k > 1 ? z1 : 0ull) | (k > 2 ? z2 : 0ull) | (k > 3 ? z3 : 0ull) | (k > 4 ? z4 : 0ull)) >> 1;
-            const uint32_t a = ((uint32_t)z0 & 1u) | ((uint32_t)z1 & 1u) << 1 | ((uint32_t)z2 & 1u) << 2 | ((uint32_t)z3 & 1u) << 3 | ((uint32_t)z4 & 1u) << 4;
-            *defer = nonbit != 0ull || !w0_is_one;
-            *bad = !*defer && !((d.w >> (a & ((1u << k) - 1u))) & 1u);
-          }
-        };
+      // the row descriptors count as new in every iteration (see fresh(): nothing derived from them is to be kept around the loop)
 #pragma unroll
-        for (int p = 0; p < RP; p++) {
-          if (!has_rows[p]) continue;
-          if (!anomaly) {
-            if (has_tt[p] && table_row(fresh(pre[p]))) verdict |= 0x100u << p;
-          } else {
-            bool defer = false, bad = false;
-            careful_row(fresh(pre[p]), &defer, &bad);          // (a lane without a row holds an all-zero descriptor: no class)
-            verdict |= (defer ? 1u : 0u) << p | (bad ? 0x100u : 0u) << p;
-          }
-        }
+      for (int p = 0; p < RP; p++) asm volatile("" : "+v"(pre[p].x), "+v"(pre[p].y), "+v"(pre[p].z), "+v"(pre[p].w));
+      const uint32_t i3n = i3 == 2u ? 0u : i3 + 1u, i3nn = i3n == 2u ? 0u : i3n + 1u;
+      const bool anomaly = __builtin_amdgcn_readfirstlane(lanom[i3]) != 0u;
+      if (tid == 0) lanom[i3nn] = 0u;                        // (read one unit ago by everyone; the pack of the NEXT iteration may set it)
+      uint32_t verdict = 0;
+      if (!(dbg & 1u)) {
+        if (!(dbg & 32u)) words(i);
+        B3W_STAMP(1);
+        verdict = rows(i, anomaly);
         B3W_STAMP(2);
+        if (i) verdicts(i - 1u, pend_verdict, pend_anomaly);
+        B3W_STAMP(3);
       }
-      if (NBUF != 0 && i + 1u < m) vm_wait(per_tile * (m - 2u - i < DEPTH - 1u ? m - 2u - i : DEPTH - 1u));      // this wave's pieces of unit i + 1 have landed (younger units may fly on)
-      lds_barrier();                                                               // barrier A: every word of unit i is in its row's sums, nobody reads el any more
-      B3W_STAMP(3);
-      if (NBUF == 0 || i + 1u < m) pack(i + 1u);
-      if (NBUF == 0) issue_ext(i + 2u < m ? b + 2u : b);                           // (behind the tile's end: fetched, packed, never looked at)
+      pack(i + 1u, i3n);
+      fetch_ext(i + 2u);
       B3W_STAMP(4);
-      if (!(dbg & 1u)) verdicts(b, verdict, anomaly);
+      pend_verdict = verdict; pend_anomaly = anomaly; i3 = i3n;
+      lds_barrier();
       B3W_STAMP(5);
-      lds_barrier();                                                               // barrier B: unit i + 1 in place, the sums are zero again
-      B3W_STAMP(6);
     }
-    if (!(dbg & 1u)) summary(b_lo + m - 1u);
+    if (!(dbg & 1u)) {
+      verdicts(m - 1u, pend_verdict, pend_anomaly);
+      lds_barrier();
+      if (m >= 2u) summary(m - 2u);
+      summary(m - 1u);
+    }
     u += m;
   }
-  if (stamping && lane == 0)
+  if (STAMPS && stamping && lane == 0)
     for (int k = 0; k < 8; k++) stamps[wave * 8 + k] = ph[k];
 #undef B3W_STAMP
+#undef has_rows
+#undef has_tt
+#undef has_gen
+#undef has_dmask
 }
 
 // the rows the lean kernel left: one WAVE per (body, tile), almost all of which leave on their first load.  A wave, not the
@@ -1430,13 +1351,13 @@ extern "C" int b3w_launch_r1cs_lean(const uint8_t *d_bodies, uint32_t n, uint64_
   return 0;
 }
 
-// LDS of the stream kernel for a system: NBUF raw images + elements + bit words + term list + coefficients
-static inline size_t stream_smem(const B3wR1csSystem *sys, int nbuf) {
+// LDS of the stream kernel for a system: elements, bit words, general rows' sums and flags (each twice: unit parity) + word list +
+// coefficients + summary and anomaly words
+static inline size_t stream_smem(const B3wR1csSystem *sys) {
   const uint32_t ext_cap = (sys->max_ext + 32u) & ~31u;
   const uint32_t groups = ((B3W_R1CS_TILE + ext_cap + 63u) >> 6) + 1u;
-  return (size_t)nbuf * (B3W_R1CS_TILE + ext_cap) * 32u + (size_t)(B3W_R1CS_TILE + ext_cap) * 8u + (size_t)groups * 16u +
-         (size_t)sys->max_g_rows * 48u + (size_t)((sys->max_g_rows + 1u) & ~1u) * 4u + 2u * (size_t)((sys->max_g_words + 4u) & ~3u) * 4u +
-         (size_t)sys->ncoef * 8u + 32u;       // (+ the two summary words and the two anomaly words)
+  return 2u * (size_t)(B3W_R1CS_TILE + ext_cap) * 8u + 2u * (size_t)groups * 16u + 2u * (size_t)sys->max_g_rows * 48u +
+         2u * (size_t)((sys->max_g_rows + 1u) & ~1u) * 4u + 2u * (size_t)((sys->max_g_words + 4u) & ~3u) * 4u + (size_t)sys->ncoef * 8u + 32u;
 }
 
 // 0 = launched; -6 = this system does not fit the stream kernel (the caller takes the lean pair)
@@ -1444,24 +1365,24 @@ extern "C" int b3w_launch_r1cs_stream(const uint8_t *d_bodies, uint32_t n, uint6
                                       unsigned long long *d_scratch, uint32_t *d_violations, uint32_t *d_first, hipStream_t stream) {
   if (!n || !sys->ntiles) return 0;
   if (!d_scratch) return -5;
-  static const int env_nbuf = getenv("B3W_R1CS_NBUF") ? atoi(getenv("B3W_R1CS_NBUF")) : 0;
   static const int env_waves = getenv("B3W_R1CS_WAVES") ? atoi(getenv("B3W_R1CS_WAVES")) : 0;
   static const int env_wgs = getenv("B3W_R1CS_WGS") ? atoi(getenv("B3W_R1CS_WGS")) : 0;         // workgroups per CU
   static const int env_grid = getenv("B3W_R1CS_GRID") ? atoi(getenv("B3W_R1CS_GRID")) : 0;
-  static const uint32_t env_dbg = getenv("B3W_R1CS_DBG") ? (uint32_t)atoi(getenv("B3W_R1CS_DBG")) : 0u;     // experiments: 1 no rows, 2 no pack, 4 no DMA, 8 one body per tile staged and evaluated over and over, 16 first row pass only, 32 no general words, 64 tile loads without nt, 128 outside-wire loads nt
+  static const uint32_t env_dbg = getenv("B3W_R1CS_DBG") ? (uint32_t)atoi(getenv("B3W_R1CS_DBG")) : 0u;     // experiments (times only, verdicts meaningless): 1 no words / rows / verdicts, 2 no pack, 4 or 8 every unit fetches the tile's first body (no HBM traffic), 32 no general words
   if (sys->max_tile_rows > 2048u || sys->max_ext > 480u) return -6;
   int dev = 0;
   hipError_t e = hipGetDevice(&dev);
   if (e != hipSuccess) return (int)e;
-  // the shapes: {raw buffers, waves per workgroup}; the default is the first that fits
-  struct Shape { int nbuf, waves; const void *fn; };
-  static const Shape shapes[] = {
-      {0, 8, reinterpret_cast<const void *>(&b3w_r1cs_stream_kernel<0, 8>)},   {0, 16, reinterpret_cast<const void *>(&b3w_r1cs_stream_kernel<0, 16>)},
-      {1, 8, reinterpret_cast<const void *>(&b3w_r1cs_stream_kernel<1, 8>)},   {2, 8, reinterpret_cast<const void *>(&b3w_r1cs_stream_kernel<2, 8>)},
-      {2, 16, reinterpret_cast<const void *>(&b3w_r1cs_stream_kernel<2, 16>)}, {3, 16, reinterpret_cast<const void *>(&b3w_r1cs_stream_kernel<3, 16>)}};
-  struct PerDevice { int cus = 0, lds = 0; bool attr[8] = {false, false, false, false, false, false, false, false}; };
+  // the shapes: waves per workgroup; the default is the first
+  struct Shape { int waves; const void *fn; };
+  static const bool want_stamps = (getenv("B3W_R1CS_STAMPS") && atoi(getenv("B3W_R1CS_STAMPS"))) || env_dbg != 0u;      // (the diagnostic instantiation: phase stamps, experiment switches)
+  static const bool print_stamps = getenv("B3W_R1CS_STAMPS") && atoi(getenv("B3W_R1CS_STAMPS"));
+  static const Shape shapes[] = {{8, want_stamps ? reinterpret_cast<const void *>(&b3w_r1cs_stream_kernel<8, true>) : reinterpret_cast<const void *>(&b3w_r1cs_stream_kernel<8, false>)},
+                                 {16, reinterpret_cast<const void *>(&b3w_r1cs_stream_kernel<16, false>)}};
+  struct PerDevice { int cus = 0, lds = 0; bool attr[2] = {false, false}; };
   static PerDevice per[64];
   static std::mutex mu;
+  const size_t smem = stream_smem(sys);
   int pick = -1, cus = 0, lds = 0;
   {
     std::lock_guard<std::mutex> lock(mu);
@@ -1471,10 +1392,9 @@ extern "C" int b3w_launch_r1cs_stream(const uint8_t *d_bodies, uint32_t n, uint6
       if ((e = hipDeviceGetAttribute(&pd.lds, hipDeviceAttributeMaxSharedMemoryPerBlock, dev)) != hipSuccess) return (int)e;
       if (pd.lds < 160 * 1024) pd.lds = 64 * 1024;         // (gfx950: 160 KB per workgroup; anything else: be modest)
     }
-    for (int k = 0; k < (int)(sizeof shapes / sizeof shapes[0]) && pick < 0; k++) {
-      if ((env_nbuf && shapes[k].nbuf != (env_nbuf < 0 ? 0 : env_nbuf)) || (env_waves && shapes[k].waves != env_waves)) continue;
-      if (stream_smem(sys, shapes[k].nbuf) <= (size_t)pd.lds) pick = k;
-    }
+    if (smem > (size_t)pd.lds) return -6;
+    for (int k = 0; k < (int)(sizeof shapes / sizeof shapes[0]) && pick < 0; k++)
+      if (!env_waves || shapes[k].waves == env_waves) pick = k;
     if (pick < 0) return -6;
     if (!pd.attr[pick]) {
       if ((e = hipFuncSetAttribute(shapes[pick].fn, hipFuncAttributeMaxDynamicSharedMemorySize, pd.lds)) != hipSuccess) return (int)e;
@@ -1482,7 +1402,6 @@ extern "C" int b3w_launch_r1cs_stream(const uint8_t *d_bodies, uint32_t n, uint6
     }
     cus = pd.cus; lds = pd.lds;
   }
-  const size_t smem = stream_smem(sys, shapes[pick].nbuf);
   // workgroups per CU: what the LDS holds, and sixteen waves (the kernels are built for four waves per SIMD: 128 VGPRs)
   int wgs = (int)((size_t)lds / smem);
   if (wgs > 16 / shapes[pick].waves) wgs = 16 / shapes[pick].waves;
@@ -1491,9 +1410,8 @@ extern "C" int b3w_launch_r1cs_stream(const uint8_t *d_bodies, uint32_t n, uint6
   e = (hipError_t)r1cs_init_results(d_violations, d_first, n, stream);
   if (e != hipSuccess) return (int)e;
   // diagnostics (B3W_R1CS_STAMPS=1): per-phase cycle sums of workgroup 0, printed after every launch (synchronises: not for timing runs)
-  static const bool want_stamps = getenv("B3W_R1CS_STAMPS") && atoi(getenv("B3W_R1CS_STAMPS"));
   static unsigned long long *d_stamps = nullptr;
-  if (want_stamps && !d_stamps && hipMalloc((void **)&d_stamps, 16 * 8 * 8) != hipSuccess) d_stamps = nullptr;
+  if (print_stamps && !d_stamps && hipMalloc((void **)&d_stamps, 16 * 8 * 8) != hipSuccess) d_stamps = nullptr;
   const uint32_t bw = lean_block_words(sys);
   const uint32_t slab = lean_slab(sys);
   for (uint32_t b0 = 0; b0 < n; b0 += slab) {
@@ -1512,9 +1430,8 @@ extern "C" int b3w_launch_r1cs_stream(const uint8_t *d_bodies, uint32_t n, uint6
       unsigned long long h[128];
       if (hipStreamSynchronize(stream) == hipSuccess && hipMemcpy(h, d_stamps, sizeof h, hipMemcpyDeviceToHost) == hipSuccess) {
         const double un = (double)(units / grid);
-        static const char *name[8] = {"fetch-issue", "words", "own-rows", "wait+barrierA", "pack", "verdicts", "barrierB", "-"};
-        fprintf(stderr, "b3w_r1cs_stream stamps (cycles per unit, workgroup 0 of %u, %d waves, %d buffers, %g units):\n", grid, shapes[pick].waves,
-                shapes[pick].nbuf, un);
+        static const char *name[8] = {"fetch-issue", "words", "own-rows", "verdicts", "wait+pack", "barrier", "-", "-"};
+        fprintf(stderr, "b3w_r1cs_stream stamps (cycles per unit, workgroup %u of %u, %d waves, %g units):\n", grid / 2, grid, shapes[pick].waves, un);
         for (int k = 0; k < 8; k++) {
           fprintf(stderr, "  %-15s", name[k]);
           for (int w = 0; w < shapes[pick].waves; w++) fprintf(stderr, " %5.0f", (double)h[w * 8 + k] / un);

@@ -235,7 +235,9 @@ bool b3w_r1cs_host_build(const uint8_t *img, size_t len, const uint8_t prime_le[
     }
     return (uint32_t)(lterms.size() - before);
   };
-  if (tiled) {
+  auto build_tiles = [&]() {
+    text.clear(); trows.clear(); trow_id.clear(); trow_k.clear(); tterms.clear(); lrows.clear(); lterms.clear();
+    max_tile_terms = max_tile_rows = max_lean_terms = 0;
     for (uint32_t t = 0; t < ntiles; t++) {
       while (lterms.size() & 3) lterms.push_back(0);      // a tile's list starts on 16 bytes (the lean kernel stages it in uint4s)
       ltdesc[2 * t] = (uint32_t)lterms.size();
@@ -292,6 +294,49 @@ bool b3w_r1cs_host_build(const uint8_t *img, size_t len, const uint8_t prime_le[
     tterms.push_back(0);
     lterms.push_back(0); lterms.push_back(0);             // the lean kernel fetches up to two term words ahead,
     while (lterms.size() & 3) lterms.push_back(0);        // and stages whole uint4s
+  };
+  // A row's class in the stream program (below): 0 general, 1 truth table, 2 always deferred, 3 booleanity.  `nw` = its lean words.
+  auto boolean_wire = [&](const Row &r, uint32_t *w_out) {    // A = {w: 1},  B = {wire 0: 1, w: -1} or {w: 1, wire 0: -1},  C = {}
+    if (!(r.na == 1 && r.nb == 2 && r.nc == 0 && cids[r.off] == 0 && wires[r.off] != 0)) return false;
+    const uint32_t w = wires[r.off], w1 = wires[r.off + 1], w2 = wires[r.off + 2];
+    const uint16_t c1 = cids[r.off + 1], c2 = cids[r.off + 2];
+    const bool ok = (w1 == 0 && w2 == w && ((c1 == 0 && c2 == 1) || (c1 == 1 && c2 == 0))) ||
+                    (w2 == 0 && w1 == w && ((c2 == 0 && c1 == 1) || (c2 == 1 && c1 == 0)));
+    if (ok) *w_out = w;
+    return ok;
+  };
+  std::vector<uint8_t> is_bit;                             // wires expected to hold bits (set once the bit runs are known)
+  auto row_class = [&](const Row &r, uint32_t nw, std::vector<uint32_t> *W_out) -> int {
+    uint32_t bw = 0;
+    if (boolean_wire(r, &bw)) return 3;
+    const uint32_t nt = r.na + r.nb + r.nc;
+    std::vector<uint32_t> W;                               // truth table: at most five distinct wires, all of them bits by their own constraints
+    bool all_bits = true;
+    for (uint32_t x = 0; x < nt && all_bits && W.size() <= 5; x++) {
+      const uint32_t w = wires[r.off + x];
+      all_bits = is_bit[w] != 0;
+      if (std::find(W.begin(), W.end(), w) == W.end()) W.push_back(w);
+    }
+    if (all_bits && W.size() <= 5 && nt <= 64) { if (W_out) *W_out = W; return 1; }
+    bool not_small = false;
+    for (uint32_t x = 0; x < nt; x++) not_small = not_small || coef_small[cids[r.off + x]] == B3W_R1CS_NOT_SMALL;
+    return not_small || nw > 256 ? 2 : 0;
+  };
+  if (tiled) {
+    // Built TWICE.  The first pass finds the bit runs and every row's lean words, hence its class; then each tile's rows are put
+    // in the order  general | truth table | always deferred | booleanity  (stable within a class: the shape order) and the arrays are
+    // built again.  The stream kernel deals rows to waves by position: the general rows, whose verdicts are the expensive ones, are
+    // then always waves 0 and 1's, and the general words and the outside wires, which it deals to other waves, never meet them.
+    build_tiles();
+    is_bit = in_run;
+    is_bit[0] = 1;                                         // the constant wire: 1 in every witness (the kernels check it)
+    for (const Row &r : rows) { uint32_t w = 0; if (boolean_wire(r, &w)) is_bit[w] = 1; }
+    std::vector<uint8_t> cls(m, 3);
+    for (size_t r = 0; r < trow_k.size(); r++)
+      cls[trow_k[r]] = (uint8_t)row_class(rows[trow_k[r]], (lrows[4 * r + 1] & 0x3FFFFFFFu) + lrows[4 * r + 2] + (lrows[4 * r + 1] >> 31 ? 0u : lrows[4 * r + 3]), nullptr);
+    for (uint32_t t = 0; t < ntiles; t++)
+      std::stable_sort(tile_rows[t].begin(), tile_rows[t].end(), [&](uint32_t a, uint32_t b) { return cls[a] < cls[b]; });
+    build_tiles();
   }
   // ---- the STREAM program (b3w_r1cs_stream_kernel): the same tiles and the same row order, every row in one of four classes
   //   B  booleanity                 (descriptor only, as in the lean rows)
@@ -320,21 +365,9 @@ bool b3w_r1cs_host_build(const uint8_t *img, size_t len, const uint8_t prime_le[
     for (int i = 0; i < 5; i++) inv *= 2u - P[0] * inv;
     inv = 0u - inv;
     const uint32_t one[8] = {1, 0, 0, 0, 0, 0, 0, 0};
-    auto boolean_wire = [&](const Row &r, uint32_t *w_out) {    // A = {w: 1},  B = {wire 0: 1, w: -1} or {w: 1, wire 0: -1},  C = {}
-      if (!(r.na == 1 && r.nb == 2 && r.nc == 0 && cids[r.off] == 0 && wires[r.off] != 0)) return false;
-      const uint32_t w = wires[r.off], w1 = wires[r.off + 1], w2 = wires[r.off + 2];
-      const uint16_t c1 = cids[r.off + 1], c2 = cids[r.off + 2];
-      const bool ok = (w1 == 0 && w2 == w && ((c1 == 0 && c2 == 1) || (c1 == 1 && c2 == 0))) ||
-                      (w2 == 0 && w1 == w && ((c2 == 0 && c1 == 1) || (c2 == 1 && c1 == 0)));
-      if (ok) *w_out = w;
-      return ok;
-    };
-    // wires expected to hold bits: a booleanity row of their own, or a place in a bit run (circom's XOR gate constrains its
-    // output only through the gate itself; the outputs are then recomposed into words).  A wrong guess costs time, not
-    // correctness: an element that is no bit defers its truth-table rows to the field arithmetic.
-    std::vector<uint8_t> is_bit(in_run);
-    is_bit[0] = 1;                                         // the constant wire: 1 in every witness (the kernels check it)
-    for (const Row &r : rows) { uint32_t w = 0; if (boolean_wire(r, &w)) is_bit[w] = 1; }
+    // (is_bit — wires expected to hold bits: a booleanity row of their own, or a place in a bit run (circom's XOR gate constrains
+    // its output only through the gate itself; the outputs are then recomposed into words).  A wrong guess costs time, not
+    // correctness: an element that is no bit defers its truth-table rows to the field arithmetic.)
     std::map<std::vector<uint32_t>, uint32_t> table_of;    // (wires' positions, coefficient ids, part lengths) -> truth table
     for (uint32_t t = 0; t < ntiles; t++) {
       const uint32_t gw0 = (uint32_t)sgwords.size();
@@ -346,17 +379,13 @@ bool b3w_r1cs_host_build(const uint8_t *img, size_t len, const uint8_t prime_le[
         uint32_t bw = 0;
         auto must_be_bit = [&](uint32_t idx) { smask[(size_t)t * smask_groups + (idx >> 6)] |= 1ull << (idx & 63u); };
         if (boolean_wire(r, &bw)) { must_be_bit(lds_index(bw)); srows.insert(srows.end(), {0u, 0x80000000u | 1u, 2u, lds_index(bw)}); continue; }
-        bool not_small = false;
-        for (uint32_t x = 0; x < nt; x++) not_small = not_small || coef_small[cids[r.off + x]] == B3W_R1CS_NOT_SMALL;
-        // T: at most five distinct wires, all of them bits by their own constraints
+        // the row's lean words (what emit_part made of it: the lean rows are in the same order)
+        const size_t lr = srows.size();                     // (= 4 * this row's number in lrows)
+        const uint32_t off = lrows[lr], n3[3] = {lrows[lr + 1] & 0x3FFFFFFFu, lrows[lr + 2], lrows[lr + 3]};
+        const uint32_t nw = n3[0] + n3[1] + n3[2];
         std::vector<uint32_t> W;
-        bool all_bits = true;
-        for (uint32_t x = 0; x < nt && all_bits && W.size() <= 5; x++) {
-          const uint32_t w = wires[r.off + x];
-          all_bits = is_bit[w] != 0;
-          if (std::find(W.begin(), W.end(), w) == W.end()) W.push_back(w);
-        }
-        if (all_bits && W.size() <= 5 && nt <= 64) {
+        const int cls = row_class(r, nw, &W);
+        if (cls == 1) {
           std::vector<uint32_t> key = {r.na, r.nb, r.nc};
           for (uint32_t x = 0; x < nt; x++) {
             key.push_back((uint32_t)(std::find(W.begin(), W.end(), wires[r.off + x]) - W.begin()));
@@ -385,11 +414,7 @@ bool b3w_r1cs_host_build(const uint8_t *img, size_t len, const uint8_t prime_le[
           srows.insert(srows.end(), {idx[0] | idx[1] << 16, 0x20000000u | (uint32_t)W.size() << 16 | idx[4], idx[2] | idx[3] << 16, it->second});
           continue;
         }
-        // the row's lean words (what emit_part made of it: the lean rows are in the same order)
-        const size_t lr = srows.size();                     // (= 4 * this row's number in lrows)
-        const uint32_t off = lrows[lr], n3[3] = {lrows[lr + 1] & 0x3FFFFFFFu, lrows[lr + 2], lrows[lr + 3]};
-        const uint32_t nw = n3[0] + n3[1] + n3[2];
-        if (not_small || nw > 256 || ng >= 0xFFFFFFu) { srows.insert(srows.end(), {0u, 0x40000000u, 0u, 0u}); continue; }
+        if (cls == 2 || ng >= 0xFFFFFFu) { srows.insert(srows.end(), {0u, 0x40000000u, 0u, 0u}); continue; }
         uint32_t q = off;
         for (uint32_t part = 0; part < 3; part++)
           for (uint32_t x = 0; x < n3[part]; x++, q++) {

@@ -85,9 +85,13 @@ static bool indices_ok(const B3wR1csHost &H) {
     const uint32_t row0 = H.tdesc[4 * t], nrows = H.tdesc[4 * t + 1], next = H.tdesc[4 * t + 3];
     const uint32_t gw0 = H.sgdesc[4 * t], gwn = H.sgdesc[4 * t + 1], ng = H.sgdesc[4 * t + 2];
     CHECK((uint64_t)gw0 + gwn + 1 <= H.sgwords.size() && gwn <= H.max_g_words && ng <= H.max_g_rows);      // (a lane reads the word behind its own)
-    uint32_t seen_g = 0;
+    uint32_t seen_g = 0, last_class = 0;
     for (uint32_t r = row0; r < row0 + nrows; r++) {
       const uint32_t x = H.srows[4 * r], y = H.srows[4 * r + 1], z = H.srows[4 * r + 2], w = H.srows[4 * r + 3];
+      // the rows of a tile stand in the order general | truth table | always deferred | booleanity (the kernel's waves 0, 1 own the general rows)
+      const uint32_t cls = (y >> 28) == 1u ? 0u : (y >> 29) == 1u ? 1u : (y >> 31) ? 3u : 2u;
+      CHECK(cls >= last_class);
+      last_class = cls;
       auto masked = [&](uint32_t idx) { return (H.smask[(size_t)t * H.smask_groups + (idx >> 6)] >> (idx & 63u)) & 1ull; };
       if (y >> 31) { CHECK(w < T + next && (H.lrows[4 * r + 1] >> 31) && H.lrows[4 * r + 3] == w && masked(w)); continue; }
       CHECK(!(H.lrows[4 * r + 1] >> 31));

@@ -298,12 +298,12 @@ for circuit in ("compression", "nova_bn254_o1", "nova_vesta"):
 print(json.dumps(out))
 '''
     res = {}
-    for mode, extra in (("0", {}), ("1", {}), ("2", {}), ("3", {}), ("0/2buf", {"B3W_R1CS_NBUF": "2"}), ("0/grid7", {"B3W_R1CS_GRID": "7"})):
+    for mode, extra in (("0", {}), ("1", {}), ("2", {}), ("3", {}), ("0/16waves", {"B3W_R1CS_WAVES": "16"}), ("0/grid7", {"B3W_R1CS_GRID": "7"})):
         r = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, cwd=T.ROOT, timeout=600,
                            env=dict(os.environ, B3W_R1CS_GATHER=mode.split("/")[0], **extra))
         assert r.returncode == 0, r.stderr[-1500:]
         res[mode] = json.loads(r.stdout.strip().splitlines()[-1])
-    assert res["0"] == res["1"] == res["2"] == res["3"] == res["0/2buf"] == res["0/grid7"]
+    assert res["0"] == res["1"] == res["2"] == res["3"] == res["0/16waves"] == res["0/grid7"]
     for circuit in res["0"]:
         viol = res["0"][circuit][0]
         assert all(v == 0 for v in viol[1::2]) and all(v > 0 for v in viol[0::2]), circuit

@@ -1,6 +1,7 @@
 """r1cs_stream_dbg.py [circuit] [n] — where the stream formulation of the constraint check spends its time: the same check with
-phases switched off (B3W_R1CS_DBG: 1 no rows, 2 no pack, 4 no DMA, 16 no second row pass, 32 no general words), ring depths and grid sizes, each in a child process (the
-switches are read once per process).  Times only; verdicts are meaningless with a phase missing."""
+phases switched off (B3W_R1CS_DBG: 1 no words / rows / verdicts, 2 no pack, 4 or 8 no HBM traffic, 32 no general words) and other
+workgroup shapes, each in a child process (the switches are read once per process).  Times only; verdicts are meaningless with a
+phase missing."""
 import importlib, os, subprocess, sys
 if len(sys.argv) > 1 and sys.argv[1] == "--child":
     import numpy as np, torch
@@ -28,12 +29,11 @@ if len(sys.argv) > 1 and sys.argv[1] == "--child":
 circuit = sys.argv[1] if len(sys.argv) > 1 else "compression"
 n = sys.argv[2] if len(sys.argv) > 2 else "4096"
 E = lambda **kw: {"B3W_R1CS_" + k.upper(): str(v) for k, v in kw.items()}
-for label, env in (("lean pair (GATHER=3)", {"B3W_R1CS_GATHER": "3"}), ("stream, default shape", {}),
-                   ("stream 8 waves, 1 buffer, 2 WG/CU", E(waves=8, nbuf=1, wgs=2)), ("... tile loads without nt (64)", E(waves=8, nbuf=1, wgs=2, dbg=64)),
-                   ("... outside-wire loads nt too (128)", E(waves=8, nbuf=1, wgs=2, dbg=128)),
-                   ("stream 8 waves, 1 buffer, 1 WG/CU", E(waves=8, nbuf=1, wgs=1)), ("stream 8 waves, 2 buffers, 1 WG/CU", E(waves=8, nbuf=2, wgs=1)),
-                   ("stream 16 waves, 2 buffers", E(waves=16, nbuf=2)), ("stream 16 waves, 3 buffers", E(waves=16, nbuf=3)),
-                   ("default: no rows (1)", E(dbg=1)), ("default: DMA + barriers (3)", E(dbg=3)),
-                   ("default: rows on valid data, no DMA (8)", E(dbg=8)), ("default: loop + barriers (7)", E(dbg=7))):
+# (any B3W_R1CS_DBG value selects the diagnostic instantiation and skips the deferred kernel: compare those lines with "no switch (64)")
+for label, env in (("lean pair (GATHER=3)", {"B3W_R1CS_GATHER": "3"}), ("stream, default (8 waves, 2 WG/CU)", {}),
+                   ("stream 8 waves, 1 WG/CU", E(wgs=1)), ("stream 16 waves", E(waves=16)),
+                   ("diagnostic kernel, no switch (64)", E(dbg=64)), ("no general words (32)", E(dbg=32)),
+                   ("fetch + pack, no words / rows / verdicts (1)", E(dbg=1)), ("fetch + barrier (3)", E(dbg=3)),
+                   ("all phases, every unit the tile's first body: no HBM traffic (8)", E(dbg=8)), ("loop + barrier, no HBM traffic (11)", E(dbg=11))):
     r = subprocess.run([sys.executable, __file__, "--child", circuit, n], capture_output=True, text=True, env=dict(os.environ, **env), timeout=300)
-    print(f"{label:40s} {r.stdout.strip() if r.returncode == 0 else 'FAILED ' + r.stderr[-300:]}", flush=True)
+    print(f"{label:70s} {r.stdout.strip() if r.returncode == 0 else 'FAILED ' + r.stderr[-300:]}", flush=True)
