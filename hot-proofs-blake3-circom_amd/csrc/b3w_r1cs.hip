@@ -197,6 +197,71 @@ __device__ __forceinline__ Fe dot(const uint8_t *body, const uint32_t *wires, co
   return acc;
 }
 
+// a (< p) as a small signed number: a = k or a = p - k with k < 2^32?
+__device__ __forceinline__ bool small_signed(const Fe &a, const uint32_t p[8], uint32_t *k, bool *neg) {
+  uint32_t hi = 0;
+#pragma unroll
+  for (int i = 1; i < 8; i++) hi |= a.l[i];
+  if (!hi) { *k = a.l[0]; *neg = false; return true; }
+  uint32_t d0 = 0;
+  uint64_t br = 0;
+  hi = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    const uint64_t t = (uint64_t)p[i] - a.l[i] - br;
+    if (i == 0) d0 = (uint32_t)t; else hi |= (uint32_t)t;
+    br = (t >> 63) & 1;
+  }
+  *k = d0; *neg = true;
+  return hi == 0;
+}
+// (+-k) * w = c mod p, for w, c < p, without a field multiplication: k * w -+ c is an integer s in (-p, (k + 1) p), and s = 0 mod p
+// iff s = q p for the one q < 2^32 with q = s / p mod 2^32 (p is odd).  (The 134 rows of a nova step's 67 IsZero gadgets are
+// "in * inv = 1 - out" and "in * out = 0" with in = depth - i, a small signed number, and inv a full field element: all of them
+// deferred, and two Montgomery products each — 600 vector instructions — without this.)
+__device__ __forceinline__ bool small_product_is(uint32_t k, bool neg, const Fe &w, const Fe &c, const B3wField &F) {
+  uint32_t sgn[9];
+  uint64_t cy = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    const uint64_t t = (uint64_t)k * w.l[i] + cy;
+    sgn[i] = (uint32_t)t;
+    cy = t >> 32;
+  }
+  sgn[8] = (uint32_t)cy;
+  if (neg) {                                               // s = k w + c
+    cy = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      const uint64_t t = (uint64_t)sgn[i] + c.l[i] + cy;
+      sgn[i] = (uint32_t)t;
+      cy = t >> 32;
+    }
+    sgn[8] += (uint32_t)cy;                                // (k w + c < 2^32 p: nine limbs hold it)
+  } else {                                                 // s = k w - c
+    uint64_t br = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      const uint64_t t = (uint64_t)sgn[i] - c.l[i] - br;
+      sgn[i] = (uint32_t)t;
+      br = (t >> 63) & 1;
+    }
+    if (br > sgn[8]) return false;                         // s < 0 (and > -p): no multiple of p
+    sgn[8] -= (uint32_t)br;
+  }
+  const uint32_t q = sgn[0] * (0u - F.inv);                // F.inv = -1 / p mod 2^32
+  uint32_t diff = 0;
+  cy = 0;
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    const uint64_t t = (uint64_t)q * F.p[i] + cy;
+    diff |= (uint32_t)t ^ sgn[i];
+    cy = t >> 32;
+  }
+  diff |= (uint32_t)cy ^ sgn[8];
+  return diff == 0;
+}
+
 // A z * B z = C z for the three sums of a row?  (linear: the row has no A or no B terms: 0 * B - C = 0)
 __device__ __forceinline__ bool row_violated(const Fe &az, const Fe &bz, const Fe &cz, bool linear, const B3wField &F) {
   if (linear) return !fe_is_zero(cz);
@@ -208,6 +273,10 @@ __device__ __forceinline__ bool row_violated(const Fe &az, const Fe &bz, const F
   } else if (as == 1) ab = bz;                                                       // 1 * x
   else if (bs == 1) ab = az;
   else {
+    uint32_t k = 0;
+    bool neg = false;
+    if (small_signed(az, F.p, &k, &neg)) return !small_product_is(k, neg, bz, cz, F);
+    if (small_signed(bz, F.p, &k, &neg)) return !small_product_is(k, neg, az, cz, F);
     Fe r2;
 #pragma unroll
     for (int i = 0; i < 8; i++) r2.l[i] = F.r2[i];
