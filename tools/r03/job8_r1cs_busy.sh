@@ -19,6 +19,6 @@ for r in csv.DictReader(open(sys.argv[1])):
 for (k, cn), v in sorted(acc.items()):
     print(f"{sys.argv[2]:12s} {k:9s} {cn:24s} mean {sum(v)/len(v):.6g}  (n={len(v)})")
 PY
-    find $out/${c}_$tag -name "*.csv" -size +1M -delete
+    rm -rf $out/${c}_$tag
   done
 done
