@@ -118,8 +118,9 @@ struct B3wR1csSystem {
 extern "C" size_t b3w_r1cs_scratch_bytes(const B3wR1csSystem *sys);
 extern "C" int b3w_launch_r1cs_lean(const uint8_t *d_bodies, uint32_t n, uint64_t pitch, const B3wR1csSystem *sys, const B3wField *field,
                                     unsigned long long *d_scratch, uint32_t *d_violations, uint32_t *d_first, hipStream_t stream);
-// the STREAM kernel (default where the system fits): the lean kernel's arithmetic in one persistent 1 024-thread workgroup per CU
-// fed by LDS-DMA through a ring of raw tile images (b3w_r1cs.hip); same scratch, same deferred kernel, same verdicts.
+// the STREAM kernel (default where the system fits): persistent 512-thread workgroups, two to a CU, over the tile-major unit list;
+// elements fetched into registers one unit ahead, one barrier per unit (b3w_r1cs.hip); same scratch blocks (word 0 = which mask
+// words were stored), same deferred kernel, same verdicts.
 // Returns -6 when the system does not fit (more than 2 048 rows or 480 outside wires per tile, or no room in LDS).
 extern "C" int b3w_launch_r1cs_stream(const uint8_t *d_bodies, uint32_t n, uint64_t pitch, const B3wR1csSystem *sys, const B3wField *field,
                                       unsigned long long *d_scratch, uint32_t *d_violations, uint32_t *d_first, hipStream_t stream);

@@ -13,8 +13,11 @@
 // coefficients +1 / -1 (93 % of the terms of the compression system) are an addition / subtraction.  The tile formulations put
 // an exact integer fast path in front of that (small coefficients times small elements summed in 128 bits).
 //
-// THREE FORMULATIONS, same verdicts (tests/test_gpu_r1cs.py runs all three over clean, corrupted and random inputs):
-//  * the LEAN pair (default whenever the system allows tiles): circom constraints are local, so a workgroup takes (body, tile
+// FOUR FORMULATIONS, same verdicts (tests/test_gpu_r1cs.py runs all of them over clean, corrupted and random inputs):
+//  * the STREAM kernel (default whenever the system allows tiles; described where it stands, below): persistent workgroups over the
+//    tile-major list of (tile, body) units, elements fetched into registers one unit ahead, one barrier per unit, the host's
+//    stream program instead of row-by-row evaluation; what it cannot decide goes to the same deferred kernel as the lean pair's.
+//  * the LEAN pair (B3W_R1CS_GATHER=3; round 2's default): circom constraints are local, so a workgroup takes (body, tile
 //    of 1 024 consecutive wires), streams the tile from HBM once plus the few wires outside the tile its rows mention (<= 137
 //    per tile for the derived systems, listed per tile by the host: +6 % reads, L2 hits), keeps 8 bytes per element in LDS
 //    together with bit-packed copies, the tile's term list and the small coefficients, and decides the rows as exact integers;
