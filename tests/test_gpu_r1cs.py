@@ -265,6 +265,55 @@ def test_nova_o2_builds_on_the_device(circuit):
     r1cs.close(); ctx.close()
 
 
+@pytest.mark.parametrize("circuit", ["nova_vesta", "nova_bn254_o1"])
+def test_wide_elements_of_a_nova_step_tampered(circuit):
+    """The rows the stream kernel defers in a VALID nova step are those over full field elements: the 67 IsZero gadgets'
+    `in * inv = 1 - out` and `in * out = 0` (in = depth - i and the like, a small signed number; inv a 254-bit inverse).  The deferred
+    kernel decides (small signed) x (field element) = c without a field multiplication (small_product_is, csrc/b3w_r1cs.hip).  Every
+    wide slot of a step witness is changed in several ways — neighbours, 0, 1, -1, another gadget's inverse, the edges of "small"
+    (2^32 - 1, 2^32, p - 2^32 + 1, p - 2^32), random — and count and first violated row must equal the plain-integer evaluation."""
+    import torch
+    m = T.pkg()
+    dev = torch.device("cuda:0")
+    ctx = m.Context(circuit, 0)
+    r1cs = m.R1cs(ctx)
+    sys_ = R.parse(R.read_image(R.BUILTIN_NOVA_O2[circuit] if circuit in R.BUILTIN_NOVA_O2 else R.BUILTIN_NOVA_O1))
+    p = sys_["prime"]
+    by_wire = R.rows_of_wire(sys_)
+    recs = m.workloads.config3_nova(3, first=77)
+    d_recs = torch.from_numpy(recs.view(np.int32)).to(dev)
+    clean = torch.empty((3, ctx.body_bytes), dtype=torch.uint8, device=dev)
+    ctx.run_device(d_recs.data_ptr(), 3, clean.data_ptr(), 0, 0, 0, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    clean = clean.cpu().numpy()
+    rng = random.Random(11)
+    cases = []                                               # (body of origin, slot, new value)
+    for b in range(3):
+        z = R.body_to_ints(clean[b])
+        wide = [w for w, v in enumerate(z) if v >= 1 << 64]
+        assert len(wide) >= 60, len(wide)
+        for w in wide:
+            old = z[w]
+            other = z[rng.choice(wide)]
+            for new in {(old + 1) % p, (old - 1) % p, 0, 1, p - 1, other, (1 << 32) - 1, 1 << 32, p - (1 << 32) + 1, p - (1 << 32), rng.randrange(p)}:
+                if new != old and rng.random() < 0.4:
+                    cases.append((b, w, new))
+    host = np.stack([clean[b] for b, _, _ in cases])
+    for i, (_, w, new) in enumerate(cases):
+        host[i, 32 * w:32 * w + 32] = np.frombuffer(new.to_bytes(32, "little"), dtype=np.uint8)
+    d = torch.from_numpy(host).to(dev)
+    viol = torch.zeros(len(cases), dtype=torch.int32, device=dev)
+    first = torch.zeros(len(cases), dtype=torch.int32, device=dev)
+    r1cs.check_device(d.data_ptr(), len(cases), 0, viol.data_ptr(), first.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    viol, first = viol.cpu().numpy().view(np.uint32), first.cpu().numpy().view(np.uint32)
+    assert len(cases) > 500
+    for i, (b, w, new) in enumerate(cases):
+        want = R.violated(sys_, R.body_to_ints(host[i]), by_wire[w])
+        assert viol[i] == len(want) and first[i] == (min(want) if want else 0xFFFFFFFF), (i, b, w, hex(new), int(viol[i]), want[:4])
+    r1cs.close(); ctx.close()
+
+
 def test_gather_kernel_gives_the_same_verdicts(tmp_path):
     """csrc/b3w_r1cs.hip has four formulations with the same verdicts: the stream kernel (default: the lean arithmetic in persistent
     workgroups fed by LDS-DMA), the lean pair (B3W_R1CS_GATHER=3: 8-byte elements and integer sums in LDS, deferred rows by field
