@@ -896,7 +896,7 @@ __global__ __launch_bounds__(64 * WAVES, 4) void b3w_r1cs_stream_kernel(   // (s
     // ---- per tile: descriptors, the word list, the masks, the fetch offsets.  (Nothing is in flight here: the pipeline below drains.)
     lds_barrier();                                                                 // the previous tile's last summary words are out, its word list is free
     const uint4 td = reinterpret_cast<const uint4 *>(S.tiles)[tile];               // {first row, rows, first outside wire, outside wires}
-    const uint4 gd = reinterpret_cast<const uint4 *>(S.sgdesc)[tile];              // {first general word, general words, general rows, -}
+    const uint4 gd = reinterpret_cast<const uint4 *>(S.sgdesc)[tile];              // {first entry of the general rows, entries, general rows, entries that are bit runs (a multiple of 64; they stand first)}
     const uint32_t t0 = tile * B3W_R1CS_TILE;
     const uint32_t n_local = S.nwires - t0 < B3W_R1CS_TILE ? S.nwires - t0 : B3W_R1CS_TILE;
     const uint4 *srows = reinterpret_cast<const uint4 *>(S.srows);
@@ -1005,11 +1005,12 @@ __global__ __launch_bounds__(64 * WAVES, 4) void b3w_r1cs_stream_kernel(   // (s
       }
       if (flag && lane == 0) lanom[k3] = 1u;
     };
-    // ---- general rows, one WORD per lane: chunk c of 64 words goes to wave WAVES - 1 - c mod WAVES; a lane adds coefficient *
-    // element (or the value of a bit run) into its row's part sum.  A part sum is two 64-bit counters {low, high} worth
-    // low + high * 2^52: a contribution below 2^54 goes to `low` whole, a larger one (the dyadic row scaling of the O2 systems makes
-    // 2^30 * word) is cut at bit 52 — products stay below 2^103 and a row has at most 256 words, so no counter overflows and the
-    // sum is exact.
+    // ---- general rows, one ENTRY per lane: chunk c of 64 entries goes to wave WAVES - 1 - c mod WAVES; a lane adds coefficient *
+    // element (a term) or the value of a bit run into its row's part sum.  The host puts the tile's runs first (padded to whole
+    // chunks), so a chunk is of one kind and a wave runs one kind's code for it.  A part sum is two 64-bit counters {low, high}
+    // worth low + high * 2^52: a contribution below 2^54 goes to `low` whole, a larger one (the dyadic row scaling of the O2 systems
+    // makes 2^30 * word) is cut at bit 52 — products stay below 2^103 and a row has at most 256 entries, so no counter overflows
+    // and the sum is exact.
     auto words = [&](const uint32_t k) {
       const unsigned long long *el = el0 + (k & 1u) * ne, *packed = packed0 + (k & 1u) * 2u * groups;
       unsigned long long *gsum = gsum0 + (k & 1u) * 6u * S.max_g_rows;
@@ -1017,39 +1018,43 @@ __global__ __launch_bounds__(64 * WAVES, 4) void b3w_r1cs_stream_kernel(   // (s
       for (uint32_t c0 = ((uint32_t)WAVES - 1u - wave) * 64u; c0 < gd.y; c0 += THREADS) {
         const uint32_t iw = c0 + lane;
         const bool act = iw < gd.y;
-        const uint32_t w = gwords[act ? iw : 0u], w1 = gwords[act ? iw + 1u : 0u], mt = gmeta[act ? iw : 0u];
-        const bool second = (mt >> 2) & 1u;                  // the second word of a run: nothing of its own
-        const bool is_run = act && !second && (w >> 16) == 0xFFFFu;
-        const bool is_term = act && !second && !is_run;
-        const unsigned long long z = el[is_term ? w & 0xFFFFu : 0u];
-        const long long c = lcoef[is_term ? w >> 16 : 0u];
-        const unsigned long long mag = c < 0 ? 0ull - (unsigned long long)c : (unsigned long long)c;
-        unsigned long long lo = mag * z, hi = __umul64hi(mag, z);
-        bool neg = c < 0;
-        bool ok = c != B3W_R1CS_NOT_SMALL && !(z >> 63) && hi < (1ull << 39);        // (bit 63 of an element = "not below 2^63")
-        if (__ballot(is_run) != 0ull) {
-          if (is_run) {
-            const uint32_t idx0 = w & 0xFFFFu, len = w1 & 0xFFu, sh = (w1 >> 8) & 0xFFu;
-            const uint32_t g = idx0 >> 6, r = idx0 & 63u;
-            const unsigned long long one_lo = packed[2 * g], bad_lo = packed[2 * g + 1], one_hi = packed[2 * g + 2], bad_hi = packed[2 * g + 3];
-            const unsigned long long mask = len == 64u ? ~0ull : (1ull << len) - 1ull;
-            const unsigned long long ones = ((one_lo >> r) | (r ? one_hi << (64u - r) : 0ull)) & mask;
-            const unsigned long long bads = ((bad_lo >> r) | (r ? bad_hi << (64u - r) : 0ull)) & mask;
-            ok = bads == 0ull;                               // (an element of the run that is no bit)
-            lo = ones << (sh & 63u); hi = 0ull;              // (below 2^62: the host checks sh + len)
-            neg = (w1 >> 16) & 1u;
+        const uint32_t w = gwords[act ? iw : 0u], mt = gmeta[act ? iw : 0u];
+        const bool live = act && !(mt & 4u);                 // (4: a null entry of the padding)
+        unsigned long long *sum = gsum + 6u * (mt >> 8) + 2u * (mt & 3u);
+        if (c0 < gd.w) {                                     // a chunk of bit runs: first element | length << 16 | shift << 23 | negative << 29
+          const uint32_t idx0 = w & 0xFFFFu, len = (w >> 16) & 0x7Fu, sh = (w >> 23) & 0x3Fu;
+          const bool neg = (w >> 29) & 1u;
+          const uint32_t g = idx0 >> 6, r = idx0 & 63u;
+          const unsigned long long one_lo = packed[2 * g], bad_lo = packed[2 * g + 1], one_hi = packed[2 * g + 2], bad_hi = packed[2 * g + 3];
+          const unsigned long long mask = len == 64u ? ~0ull : (1ull << len) - 1ull;
+          const unsigned long long ones = ((one_lo >> r) | (r ? one_hi << (64u - r) : 0ull)) & mask;
+          const unsigned long long bads = ((bad_lo >> r) | (r ? bad_hi << (64u - r) : 0ull)) & mask;
+          const unsigned long long v = ones << sh;           // (below 2^62: the host checks shift + length)
+          if (live) {
+            if (bads) atomicOr(&gflag[mt >> 8], 1u);         // (an element of the run that is no bit)
+            else if (v < (1ull << 54)) atomicAdd(sum, neg ? 0ull - v : v);
+            else {
+              const unsigned long long v0 = v & ((1ull << 52) - 1ull), v1 = v >> 52;
+              atomicAdd(sum, neg ? 0ull - v0 : v0);
+              atomicAdd(sum + 1, neg ? 0ull - v1 : v1);
+            }
           }
-        }
-        if (is_term || is_run) {
-          const uint32_t g = mt >> 8;
-          unsigned long long *sum = gsum + 6u * g + 2u * (mt & 3u);
-          if (!ok) atomicOr(&gflag[g], 1u);
-          else if (hi == 0ull && lo < (1ull << 54)) atomicAdd(sum, neg ? 0ull - lo : lo);
-          else {                                             // cut at bit 52: value = low + high * 2^52, low in [0, 2^52)
-            __int128 v = (__int128)(((unsigned __int128)hi << 64) | lo);
-            if (neg) v = -v;
-            atomicAdd(sum, (unsigned long long)v & ((1ull << 52) - 1ull));
-            atomicAdd(sum + 1, (unsigned long long)(long long)(v >> 52));
+        } else {                                             // a chunk of terms: element | coefficient id << 16
+          const unsigned long long z = el[live ? w & 0xFFFFu : 0u];
+          const long long c = lcoef[live ? w >> 16 : 0u];
+          const unsigned long long mag = c < 0 ? 0ull - (unsigned long long)c : (unsigned long long)c;
+          const unsigned long long lo = mag * z, hi = __umul64hi(mag, z);
+          const bool neg = c < 0;
+          const bool ok = c != B3W_R1CS_NOT_SMALL && !(z >> 63) && hi < (1ull << 39);      // (bit 63 of an element = "not below 2^63")
+          if (live) {
+            if (!ok) atomicOr(&gflag[mt >> 8], 1u);
+            else if (hi == 0ull && lo < (1ull << 54)) atomicAdd(sum, neg ? 0ull - lo : lo);
+            else {                                           // cut at bit 52: value = low + high * 2^52, low in [0, 2^52)
+              __int128 v = (__int128)(((unsigned __int128)hi << 64) | lo);
+              if (neg) v = -v;
+              atomicAdd(sum, (unsigned long long)v & ((1ull << 52) - 1ull));
+              atomicAdd(sum + 1, (unsigned long long)(long long)(v >> 52));
+            }
           }
         }
       }
@@ -1163,6 +1168,7 @@ __global__ __launch_bounds__(64 * WAVES, 4) void b3w_r1cs_stream_kernel(   // (s
     fetch_tile(0);
     lds_barrier();                                                                 // the word list (and, the first time, the coefficients) in place, sums and flags zero
     pack(0, 0);
+    fetch_tile(1);
     fetch_ext(1);
     lds_barrier();
     uint32_t pend_verdict = 0, i3 = 0;                       // (i3 = i mod 3)
@@ -1170,7 +1176,6 @@ __global__ __launch_bounds__(64 * WAVES, 4) void b3w_r1cs_stream_kernel(   // (s
     for (uint32_t i = 0; i < m; i++) {
       if (STAMPS && stamping) t_prev = __builtin_amdgcn_s_memtime();
       if (i >= 2u && !(dbg & 1u)) summary(i - 2u);                                 // (its verdicts ran in the last iteration, behind the last barrier)
-      fetch_tile(i + 1u);                                                          // consumed by the pack at the end of this iteration
       B3W_STAMP(0);
       // the row descriptors count as new in every iteration (see fresh(): nothing derived from them is to be kept around the loop)
 #pragma unroll
@@ -1188,6 +1193,7 @@ __global__ __launch_bounds__(64 * WAVES, 4) void b3w_r1cs_stream_kernel(   // (s
         B3W_STAMP(3);
       }
       pack(i + 1u, i3n);
+      fetch_tile(i + 2u);                                                          // the registers just packed out of take the unit after: in flight through the barrier and all of the next iteration
       fetch_ext(i + 2u);
       B3W_STAMP(4);
       pend_verdict = verdict; pend_anomaly = anomaly; i3 = i3n;

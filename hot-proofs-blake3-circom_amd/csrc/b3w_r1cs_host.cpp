@@ -165,6 +165,12 @@ bool b3w_r1cs_host_build(const uint8_t *img, size_t len, const uint8_t prime_le[
       }
     }
   }
+  // a tile's outside wires in ADDRESS order (the map's order; the constant wire stays number 0): the kernels gather them a lane per
+  // wire, and neighbours in the list that are neighbours in the body — the bits of a word another tile owns — share cache lines
+  for (uint32_t t = 0; t < ntiles; t++) {
+    uint32_t id = 0;
+    for (auto &kv : tile_ext[t]) kv.second = id++;
+  }
   uint32_t max_ext = 0;
   for (uint32_t t = 0; t < ntiles; t++) max_ext = std::max<uint32_t>(max_ext, (uint32_t)tile_ext[t].size());
   uint32_t longest = 0;
@@ -345,8 +351,8 @@ bool b3w_r1cs_host_build(const uint8_t *img, size_t len, const uint8_t prime_le[
   //      coefficients — and looked up by the kernel from the elements' bits (87 % of the non-booleanity rows of blake3_compression:
   //      the XOR gates (2a)(b) = a + b - out).  An element that turns out to be no bit defers the row to the field arithmetic.
   //   D  always deferred            (a coefficient that is no small integer, or more than 256 words)
-  //   G  general: its lean words go to a flat list evaluated one WORD per lane (contributions added into per-row sums in LDS),
-  //      instead of one row per lane walking its words
+  //   G  general: its lean words go to a flat list of entries evaluated one ENTRY per lane (contributions added into per-row sums
+  //      in LDS), instead of one row per lane walking its words
   std::vector<uint32_t> srows, sgdesc(4 * (size_t)ntiles), sgwords, sgmeta;
   std::vector<unsigned long long> coef_zlim(coefs.size(), 0ull);      // an element times coefficient c stays below 2^55 while it is below zlim
   uint32_t max_g_words = 0, max_g_rows = 0;
@@ -369,6 +375,7 @@ bool b3w_r1cs_host_build(const uint8_t *img, size_t len, const uint8_t prime_le[
     // its output only through the gate itself; the outputs are then recomposed into words).  A wrong guess costs time, not
     // correctness: an element that is no bit defers its truth-table rows to the field arithmetic.)
     std::map<std::vector<uint32_t>, uint32_t> table_of;    // (wires' positions, coefficient ids, part lengths) -> truth table
+    std::vector<uint32_t> run_w, run_m, term_w, term_m;
     for (uint32_t t = 0; t < ntiles; t++) {
       const uint32_t gw0 = (uint32_t)sgwords.size();
       uint32_t ng = 0;
@@ -415,22 +422,36 @@ bool b3w_r1cs_host_build(const uint8_t *img, size_t len, const uint8_t prime_le[
           continue;
         }
         if (cls == 2 || ng >= 0xFFFFFFu) { srows.insert(srows.end(), {0u, 0x40000000u, 0u, 0u}); continue; }
+        // entries {word, meta}: a TERM is  element | coefficient id << 16,  meta = part | row << 8;  a BIT RUN (two lean words) is
+        // one entry  first element | length << 16 | shift << 23 | negative << 29,  meta = part | 8 | row << 8.  The tile's runs stand
+        // first, padded with null entries (meta = 4) to a multiple of 64, then its terms: every chunk of 64 entries a wave takes is
+        // of ONE kind (the kernel runs one kind's code per chunk, not both under lane masks).
         uint32_t q = off;
         for (uint32_t part = 0; part < 3; part++)
           for (uint32_t x = 0; x < n3[part]; x++, q++) {
             const uint32_t w = lterms[q];
-            sgwords.push_back(w);
-            sgmeta.push_back(part | ng << 8);
-            if ((w >> 16) == 0xFFFFu) { sgwords.push_back(lterms[++q]); sgmeta.push_back(part | 4u | ng << 8); x++; }      // the run's second word
+            if ((w >> 16) == 0xFFFFu) {
+              const uint32_t w1 = lterms[++q];               // length | shift << 8 | negative << 16
+              x++;
+              run_w.push_back((w & 0xFFFFu) | (w1 & 0xFFu) << 16 | ((w1 >> 8) & 0xFFu) << 23 | ((w1 >> 16) & 1u) << 29);
+              run_m.push_back(part | 8u | ng << 8);
+            } else {
+              term_w.push_back(w);
+              term_m.push_back(part | ng << 8);
+            }
           }
         srows.insert(srows.end(), {ng, 0x10000000u, 0u, 0u});
         ng++;
       }
-      sgdesc[4 * t] = gw0; sgdesc[4 * t + 1] = (uint32_t)sgwords.size() - gw0; sgdesc[4 * t + 2] = ng; sgdesc[4 * t + 3] = 0;
+      while (run_w.size() & 63u) { run_w.push_back(0u); run_m.push_back(4u); }
+      sgdesc[4 * t] = gw0; sgdesc[4 * t + 1] = (uint32_t)(run_w.size() + term_w.size()); sgdesc[4 * t + 2] = ng; sgdesc[4 * t + 3] = (uint32_t)run_w.size();
+      sgwords.insert(sgwords.end(), run_w.begin(), run_w.end()); sgwords.insert(sgwords.end(), term_w.begin(), term_w.end());
+      sgmeta.insert(sgmeta.end(), run_m.begin(), run_m.end()); sgmeta.insert(sgmeta.end(), term_m.begin(), term_m.end());
+      run_w.clear(); run_m.clear(); term_w.clear(); term_m.clear();
       max_g_words = std::max(max_g_words, sgdesc[4 * t + 1]);
       max_g_rows = std::max(max_g_rows, ng);
     }
-    sgwords.push_back(0); sgmeta.push_back(4u);            // (a lane reads the word behind its own)
+    sgwords.push_back(0); sgmeta.push_back(4u);            // (a spare null entry)
   }
   // what a (body, tile) unit costs the stream kernel, relative: a fixed part (barriers, descriptors), the tile's bytes, its
   // general words (a tile of blake3_compression with 170 words: 3.9 us; + 2 ns per word) — the kernel deals units

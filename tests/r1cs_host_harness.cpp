@@ -84,7 +84,8 @@ static bool indices_ok(const B3wR1csHost &H) {
   for (uint32_t t = 0; t < H.ntiles; t++) {
     const uint32_t row0 = H.tdesc[4 * t], nrows = H.tdesc[4 * t + 1], next = H.tdesc[4 * t + 3];
     const uint32_t gw0 = H.sgdesc[4 * t], gwn = H.sgdesc[4 * t + 1], ng = H.sgdesc[4 * t + 2];
-    CHECK((uint64_t)gw0 + gwn + 1 <= H.sgwords.size() && gwn <= H.max_g_words && ng <= H.max_g_rows);      // (a lane reads the word behind its own)
+    const uint32_t gruns = H.sgdesc[4 * t + 3];            // entries that are bit runs: they stand first, padded to whole chunks of 64
+    CHECK((uint64_t)gw0 + gwn + 1 <= H.sgwords.size() && gwn <= H.max_g_words && ng <= H.max_g_rows && gruns <= gwn && gruns % 64 == 0);
     uint32_t seen_g = 0, last_class = 0;
     for (uint32_t r = row0; r < row0 + nrows; r++) {
       const uint32_t x = H.srows[4 * r], y = H.srows[4 * r + 1], z = H.srows[4 * r + 2], w = H.srows[4 * r + 3];
@@ -108,12 +109,11 @@ static bool indices_ok(const B3wR1csHost &H) {
     CHECK(seen_g == ng);
     for (uint32_t i = 0; i < gwn; i++) {
       const uint32_t w = H.sgwords[gw0 + i], mt = H.sgmeta[gw0 + i];
-      CHECK((mt & 3u) < 3u && (mt >> 8) < ng);
-      if (mt & 4u) { CHECK(i > 0 && (H.sgwords[gw0 + i - 1] >> 16) == 0xFFFFu && !(H.sgmeta[gw0 + i - 1] & 4u)); continue; }
-      if ((w >> 16) == 0xFFFFu) {
-        CHECK(i + 1 < gwn && (H.sgmeta[gw0 + i + 1] & 4u) && (H.sgmeta[gw0 + i + 1] >> 8) == (mt >> 8));
-        const uint32_t w1 = H.sgwords[gw0 + i + 1], n = w1 & 0xFFu;
-        CHECK(n >= 4 && n <= 64 && (w & 0xFFFFu) + n <= T + next);
+      if (mt & 4u) { CHECK(i < gruns && mt == 4u); continue; }                      // a null entry: only in the runs' padding
+      CHECK((mt & 3u) < 3u && (mt >> 8) < ng && ((mt >> 3) & 1u) == (i < gruns ? 1u : 0u) && !(mt & 0xF0u));
+      if (i < gruns) {                                     // first element | length << 16 | shift << 23 | negative << 29
+        const uint32_t n = (w >> 16) & 0x7Fu, sh = (w >> 23) & 0x3Fu;
+        CHECK(n >= 4 && n <= 64 && (w & 0xFFFFu) + n <= T + next && sh + n <= 62 && !(w >> 30));
       } else CHECK((w & 0xFFFFu) < T + next && (w >> 16) < H.ncoef);
     }
   }
@@ -172,9 +172,9 @@ static bool same_sums(const B3wR1csHost &H, const uint8_t prime_le[32]) {
       const uint32_t w = H.sgwords[gw0 + i], mt = H.sgmeta[gw0 + i];
       if (mt & 4u) continue;
       uint64_t v = 0;
-      if ((w >> 16) == 0xFFFFu) {
-        const uint32_t w1 = H.sgwords[gw0 + i + 1], n = w1 & 0xFFu, sh = (w1 >> 8) & 0xFFu;
-        for (uint32_t q = 0; q < n; q++) v += ((w1 >> 16) & 1u ? p_lo - (1ull << (sh + q)) : 1ull << (sh + q)) * z[wire_of((w & 0xFFFFu) + q)];
+      if (mt & 8u) {
+        const uint32_t n = (w >> 16) & 0x7Fu, sh = (w >> 23) & 0x3Fu;
+        for (uint32_t q = 0; q < n; q++) v += ((w >> 29) & 1u ? p_lo - (1ull << (sh + q)) : 1ull << (sh + q)) * z[wire_of((w & 0xFFFFu) + q)];
       } else v = coef_lo(w >> 16) * z[wire_of(w & 0xFFFFu)];
       sums[3 * (size_t)(mt >> 8) + (mt & 3u)] += v;
     }
