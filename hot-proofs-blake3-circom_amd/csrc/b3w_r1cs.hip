@@ -865,8 +865,11 @@ __global__ __launch_bounds__(64 * WAVES, 4) void b3w_r1cs_stream_kernel(   // (s
   uint32_t *gwords = gflag0 + 2u * gr2;
   uint32_t *gmeta = gwords + ((S.max_g_words + 4u) & ~3u);
   long long *lcoef = reinterpret_cast<long long *>(gmeta + ((S.max_g_words + 4u) & ~3u));
-  unsigned long long *lsum = reinterpret_cast<unsigned long long *>(lcoef + S.ncoef);      // [unit parity]: bit w = the unit's mask word w is not zero (and was stored)
+  unsigned long long *lsum = reinterpret_cast<unsigned long long *>(lcoef + ((S.ncoef + 1u) & ~1u));      // [unit parity]: bit w = the unit's mask word w is not zero (and was stored)
   uint32_t *lanom = reinterpret_cast<uint32_t *>(lsum + 2);                        // [unit mod 3] != 0: something the masks cannot vouch for in this (body, tile)
+  // the row descriptors of the passes a lane does NOT keep in registers (rows PRE * THREADS and up of a tile: few tiles have any)
+  constexpr int PRE = RP < 2 ? RP : 2;
+  uint4 *lrow_hi = reinterpret_cast<uint4 *>(lanom + 4);
   for (uint32_t k = tid; k < S.ncoef; k += THREADS) lcoef[k] = S.coef_small[k];
   if (tid < 4) packed0[(tid >> 1) * 2u * groups + 2u * (groups - 1u) + (tid & 1u)] = 0ull;      // the spare pairs
   // who does what beside the equal shares (two element groups, every row pass): the general words go to the LAST waves (whose last
@@ -904,15 +907,21 @@ __global__ __launch_bounds__(64 * WAVES, 4) void b3w_r1cs_stream_kernel(   // (s
     // (ONE scalar of flag bits — p: the wave has truth-table rows in pass p, 8 + p: general rows, 16 + p: always-deferred rows — not
     // a lane mask per flag and pass: the loop below has more wave-uniform state than there are SGPRs, and what does not fit is
     // kept in the lanes of a VGPR, a v_readlane per use)
-    uint4 pre[RP];
+    uint4 pre[PRE];
     uint32_t wflags = 0;
 #pragma unroll
     for (int p = 0; p < RP; p++) {
       const uint32_t r = (uint32_t)p * THREADS + tid;
-      pre[p] = r < td.y ? srows[td.x + r] : make_uint4(0, 0, 0, 0);
-      wflags |= (__ballot((pre[p].y >> 29) == 1u) != 0ull ? 1u : 0u) << p | (__ballot((pre[p].y >> 28) == 1u) != 0ull ? 0x100u : 0u) << p |
-                (__ballot((pre[p].y >> 30) == 1u) != 0ull ? 0x10000u : 0u) << p;
+      const uint4 d = r < td.y ? srows[td.x + r] : make_uint4(0, 0, 0, 0);
+      if (p < PRE) pre[p < PRE ? p : 0] = d;
+      else if (r < ((S.max_tile_rows + 63u) & ~63u)) lrow_hi[r - (uint32_t)PRE * THREADS] = d;      // (whole waves: a lane behind the tile's rows reads an all-zero descriptor)
+      wflags |= (__ballot((d.y >> 29) == 1u) != 0ull ? 1u : 0u) << p | (__ballot((d.y >> 28) == 1u) != 0ull ? 0x100u : 0u) << p |
+                (__ballot((d.y >> 30) == 1u) != 0ull ? 0x10000u : 0u) << p;
     }
+    auto row_of = [&](const int p) -> uint4 {              // this lane's row of pass p (registers, or LDS for the passes behind)
+      if (p < PRE) return pre[p < PRE ? p : 0];
+      return lrow_hi[(uint32_t)(p - PRE) * THREADS + tid];
+    };
     wflags = __builtin_amdgcn_readfirstlane(wflags);
     const uint32_t my_rows = td.y > wave * 64u ? (td.y - wave * 64u + THREADS - 1u) / THREADS : 0u;      // row passes in which this wave has rows
 #define has_rows(p) ((uint32_t)(p) < my_rows)
@@ -950,7 +959,7 @@ __global__ __launch_bounds__(64 * WAVES, 4) void b3w_r1cs_stream_kernel(   // (s
     // every global load above has landed before the pipeline starts: inside it the compiler must find nothing of its own to wait for
     // but the fetches
 #pragma unroll
-    for (int p = 0; p < RP; p++) asm volatile("" :: "v"(pre[p].x), "v"(pre[p].y), "v"(pre[p].z), "v"(pre[p].w));
+    for (int p = 0; p < PRE; p++) asm volatile("" :: "v"(pre[p].x), "v"(pre[p].y), "v"(pre[p].z), "v"(pre[p].w));
 #pragma unroll
     for (int q = 0; q < EG; q++) asm volatile("" :: "s"((uint32_t)mbit[q]), "s"((uint32_t)(mbit[q] >> 32)));
     asm volatile("" :: "s"((uint32_t)xbit), "s"((uint32_t)(xbit >> 32)), "v"(xoff));
@@ -1091,10 +1100,10 @@ __global__ __launch_bounds__(64 * WAVES, 4) void b3w_r1cs_stream_kernel(   // (s
       for (int p = 0; p < RP; p++) {
         if (!has_rows(p)) continue;
         if (!anomaly) {
-          if (has_tt(p) && table_row(pre[p])) verdict |= 0x100u << p;
+          if (has_tt(p) && table_row(row_of(p))) verdict |= 0x100u << p;
         } else {
           bool defer = false, bad = false;
-          careful_row(pre[p], &defer, &bad);                 // (a lane without a row holds an all-zero descriptor: no class)
+          careful_row(row_of(p), &defer, &bad);              // (a lane without a row holds an all-zero descriptor: no class)
           verdict |= (defer ? 1u : 0u) << p | (bad ? 0x100u : 0u) << p;
         }
       }
@@ -1116,7 +1125,7 @@ __global__ __launch_bounds__(64 * WAVES, 4) void b3w_r1cs_stream_kernel(   // (s
         if (!has_rows(p)) continue;
         bool defer = (verdict >> p) & 1u, bad = (verdict >> (8 + p)) & 1u;
         if (has_gen(p)) {
-          const uint4 d = pre[p];
+          const uint4 d = row_of(p);
           if ((d.y >> 28) == 1u) {
             // (written out in 64-bit halves: the compiler's __int128 version of the same — range compares, a 128 x 128 product — was
             // 120 vector instructions on the one wave every other wave of the workgroup then waits for)
@@ -1135,7 +1144,7 @@ __global__ __launch_bounds__(64 * WAVES, 4) void b3w_r1cs_stream_kernel(   // (s
           }
         }
         if (bad) { nbad++; badmask |= 1u << p; }
-        const unsigned long long mask = (has_gen(p) || anomaly ? __ballot(defer) : 0ull) | (has_dmask(p) ? __ballot((pre[p].y >> 30) == 1u) : 0ull);      // (always-deferred rows: the same mask bits for every body)
+        const unsigned long long mask = (has_gen(p) || anomaly ? __ballot(defer) : 0ull) | (has_dmask(p) ? __ballot((row_of(p).y >> 30) == 1u) : 0ull);      // (always-deferred rows: the same mask bits for every body)
         if (mask != 0ull && lane == 0) {                     // (wave-uniform; word (row - first) / 64)
           block[1 + (uint32_t)p * WAVES + wave] = mask;
           atomicOr(&lsum[k & 1u], 1ull << ((uint32_t)p * WAVES + wave));
@@ -1179,7 +1188,7 @@ __global__ __launch_bounds__(64 * WAVES, 4) void b3w_r1cs_stream_kernel(   // (s
       B3W_STAMP(0);
       // the row descriptors count as new in every iteration (see fresh(): nothing derived from them is to be kept around the loop)
 #pragma unroll
-      for (int p = 0; p < RP; p++) asm volatile("" : "+v"(pre[p].x), "+v"(pre[p].y), "+v"(pre[p].z), "+v"(pre[p].w));
+      for (int p = 0; p < PRE; p++) asm volatile("" : "+v"(pre[p].x), "+v"(pre[p].y), "+v"(pre[p].z), "+v"(pre[p].w));
       const uint32_t i3n = i3 == 2u ? 0u : i3 + 1u, i3nn = i3n == 2u ? 0u : i3n + 1u;
       const bool anomaly = __builtin_amdgcn_readfirstlane(lanom[i3]) != 0u;
       if (tid == 0) lanom[i3nn] = 0u;                        // (read one unit ago by everyone; the pack of the NEXT iteration may set it)
@@ -1435,7 +1444,8 @@ static inline size_t stream_smem(const B3wR1csSystem *sys) {
   const uint32_t ext_cap = (sys->max_ext + 32u) & ~31u;
   const uint32_t groups = ((B3W_R1CS_TILE + ext_cap + 63u) >> 6) + 1u;
   return 2u * (size_t)(B3W_R1CS_TILE + ext_cap) * 8u + 2u * (size_t)groups * 16u + 2u * (size_t)sys->max_g_rows * 48u +
-         2u * (size_t)((sys->max_g_rows + 1u) & ~1u) * 4u + 2u * (size_t)((sys->max_g_words + 4u) & ~3u) * 4u + (size_t)sys->ncoef * 8u + 32u;
+         2u * (size_t)((sys->max_g_rows + 1u) & ~1u) * 4u + 2u * (size_t)((sys->max_g_words + 4u) & ~3u) * 4u + (size_t)((sys->ncoef + 1u) & ~1u) * 8u + 32u +
+         (sys->max_tile_rows > 1024u ? (size_t)(((sys->max_tile_rows + 63u) & ~63u) - 1024u) * 16u : 0u);      // (+ the row descriptors behind the first 1 024 of a tile)
 }
 
 // 0 = launched; -6 = this system does not fit the stream kernel (the caller takes the lean pair)
