@@ -412,6 +412,8 @@ def main():
 
     if args.variant is not None:
         os.environ["B3W_VARIANT"] = str(args.variant)
+    if args.placement == "plain":                            # (both workloads: the library's allocator reads it)
+        os.environ["B3W_PLACEMENT"] = "plain"
     m = importlib.import_module("hot-proofs-blake3-circom_amd")
     W = m.workloads
     # the bench owns its GPU: let the placement search walk as far as it may (the library's default is bounded to 16 x the
