@@ -1275,7 +1275,9 @@ struct b3w_commit_key {
   uint32_t *d_runs = nullptr; uint32_t nruns = 0;     // the same bit string as pieces of TRACE-image words (records mode)
   uint32_t *d_images = nullptr; uint32_t images_cap = 0;   // records mode: TRACE images of one chunk, word-major, grown on demand
   uint32_t *d_table = nullptr;                        // per window of `window` virtual slots: 2^window - 1 subset sums
-  uint32_t *d_invtab = nullptr; uint32_t inv_nk = 0;  // O2 nova circuits: per IsZero gadget the points of +-1/k for |k| <= inv_nk (records mode)
+  uint32_t *d_invtab = nullptr; uint32_t inv_nk = 0;  // O2 nova circuits: per IsZero gadget the points of +-1/k for |k| <= inv_nk
+  uint32_t *d_invmeta = nullptr;                      // ... and what bodies mode needs to use them: [0, 67) the committed slot of gadget j's inverse,
+                                                      // [67, 71) the witness slots of n_blocks, block_count, total_depth, depth, [71, 138) the slot's first virtual slot
   uint32_t *d_sums = nullptr;                         // Jacobian sums between the two kernels, grown on demand
   uint32_t sums_cap = 0;
 };
@@ -1390,6 +1392,33 @@ int32_t b3w_commit_key_create_folded(b3w_ctx *ctx, int32_t curve, uint32_t first
   auto one_bit_of_word = [&](uint32_t i) { return folded && (folded[i] & 0x80) != 0; };
   for (uint32_t i = 0; i < nslots; i++)                  // code 4: folded, skipped; 8 + b: bit b of a 32-bit word
     desc[i] = first_v[i] | (one_bit_of_word(i) ? 8u + (folded[i] & 31u) : nbits[i] == 0 ? 4u : nbits[i] == 1 ? 0u : nbits[i] == 32 ? 1u : nbits[i] == 64 ? 2u : 3u) << 24;
+  // O2 nova circuits: the 67 IsZero inverses of a step are 1/k of small signed k the step's inputs determine — one tabulated point
+  // each instead of sixteen windows (b3w_commit_invtab_kernel).  B3W_COMMIT_INVTAB=0 turns it off.  Records mode takes k from the
+  // record; bodies mode reads the four inputs from the body, COMPARES the body's inverse slot with +-1/k from the context's scalar
+  // table and takes the point only if they are equal (code 5: gadget number in the low bits; anything else goes through the
+  // windows like any 256-bit slot).
+  static const bool want_invtab = !(getenv("B3W_COMMIT_INVTAB") && !strcmp(getenv("B3W_COMMIT_INVTAB"), "0"));
+  const bool with_invtab = want_invtab && ctx->desc.kind == B3W_KIND_NOVA_O2 && ctx->d_aux;
+  std::vector<uint32_t> invmeta(2 * B3W_NOVA_ISZERO + 4, 0xFFFFFFFFu);
+  if (with_invtab) {
+    for (uint32_t i = 0; i < nslots; i++) {
+      const uint32_t src = table[first_slot + i] & 0xFFFu;           // (O2: the wide atoms are the inverses, wide index = gadget)
+      if (nbits[i] == 256 && src >= B3W_LDS_WIDE && (src - B3W_LDS_WIDE) % 8 == 0 && (src - B3W_LDS_WIDE) / 8 < B3W_NOVA_ISZERO)
+        invmeta[(src - B3W_LDS_WIDE) / 8] = i;
+    }
+    const uint32_t want_src[4] = {B3W_LDS_NV + NV_N_BLOCKS, B3W_LDS_NV + NV_BLOCK_COUNT, B3W_LDS_NV + NV_TOTAL_DEPTH, B3W_LDS_NV + NV_DEPTH};
+    bool inputs_found = true;
+    for (int q = 0; q < 4; q++) {
+      for (uint32_t sidx = 0; sidx < ctx->desc.nwit && invmeta[B3W_NOVA_ISZERO + q] == 0xFFFFFFFFu; sidx++)
+        if ((table[sidx] & 0xFFFu) == want_src[q] && ((table[sidx] >> 17) & 3u) == B3W_MODE_W32 && ((table[sidx] >> 12) & 31u) == 0) invmeta[B3W_NOVA_ISZERO + q] = sidx;
+      inputs_found = inputs_found && invmeta[B3W_NOVA_ISZERO + q] != 0xFFFFFFFFu;
+    }
+    for (uint32_t j = 0; j < B3W_NOVA_ISZERO; j++)
+      if (invmeta[j] != 0xFFFFFFFFu) {
+        invmeta[B3W_NOVA_ISZERO + 4 + j] = first_v[invmeta[j]];
+        if (inputs_found) desc[invmeta[j]] = j | 5u << 24;
+      }
+  }
   // records mode: slot s holds (image[src] >> sh) & mask (b3w_kernels.hip emit_group), so a run of bit slots reading
   // consecutive bits of one image word is one contiguous piece of the bit string
   std::vector<uint32_t> runs;
@@ -1435,27 +1464,16 @@ int32_t b3w_commit_key_create_folded(b3w_ctx *ctx, int32_t curve, uint32_t first
   for (uint32_t v = V0; v < nv && e == hipSuccess && rc == 0; v++)
     e = hipMemcpyAsync(d_points + (size_t)v * 16, d_points, 64, hipMemcpyDeviceToDevice, nullptr);
   if (e == hipSuccess && rc == 0) rc = b3w_launch_commit_windows(d_points, key->nwin, key->window, key->d_table, &key->curve, nullptr);
-  // O2 nova circuits: the 67 IsZero inverses of a step are 1/k of small signed k the record determines — one tabulated point
-  // each in records mode instead of sixteen windows (b3w_commit_invtab_kernel).  B3W_COMMIT_INVTAB=0 turns it off.
-  static const bool want_invtab = !(getenv("B3W_COMMIT_INVTAB") && !strcmp(getenv("B3W_COMMIT_INVTAB"), "0"));
-  uint32_t *d_inv_slot = nullptr;
-  if (e == hipSuccess && rc == 0 && want_invtab && ctx->desc.kind == B3W_KIND_NOVA_O2 && ctx->d_aux) {
-    std::vector<uint32_t> inv_slot(B3W_NOVA_ISZERO, 0xFFFFFFFFu);
-    for (uint32_t i = 0; i < nslots; i++) {
-      const uint32_t src = table[first_slot + i] & 0xFFFu;           // (O2: the wide atoms are the inverses, wide index = gadget)
-      if (nbits[i] == 256 && src >= B3W_LDS_WIDE && (src - B3W_LDS_WIDE) % 8 == 0 && (src - B3W_LDS_WIDE) / 8 < B3W_NOVA_ISZERO)
-        inv_slot[(src - B3W_LDS_WIDE) / 8] = i;
-    }
+  if (e == hipSuccess && rc == 0 && with_invtab) {       // (the tables themselves: see invmeta above)
     key->inv_nk = B3W_INV_TABLE_N - 1;
-    e = hipMalloc((void **)&d_inv_slot, inv_slot.size() * 4);
-    if (e == hipSuccess) e = hipMemcpy(d_inv_slot, inv_slot.data(), inv_slot.size() * 4, hipMemcpyHostToDevice);
+    e = hipMalloc((void **)&key->d_invmeta, invmeta.size() * 4);
+    if (e == hipSuccess) e = hipMemcpy(key->d_invmeta, invmeta.data(), invmeta.size() * 4, hipMemcpyHostToDevice);
     if (e == hipSuccess) e = hipMalloc((void **)&key->d_invtab, (size_t)B3W_NOVA_ISZERO * 2 * key->inv_nk * 64);
     if (e == hipSuccess)
-      rc = b3w_launch_commit_invtab(d_gens, d_inv_slot, static_cast<const uint32_t *>(ctx->d_aux) + 16, B3W_NOVA_ISZERO, key->inv_nk, key->d_invtab, &key->curve,
+      rc = b3w_launch_commit_invtab(d_gens, key->d_invmeta, static_cast<const uint32_t *>(ctx->d_aux) + 16, B3W_NOVA_ISZERO, key->inv_nk, key->d_invtab, &key->curve,
                                     nullptr);
   }
   if (e == hipSuccess && rc == 0) e = hipDeviceSynchronize();
-  if (d_inv_slot) (void)hipFree(d_inv_slot);
   if (d_gens) (void)hipFree(d_gens);
   if (d_first) (void)hipFree(d_first);
   if (d_nbits) (void)hipFree(d_nbits);
@@ -1472,6 +1490,7 @@ void b3w_commit_key_destroy(b3w_commit_key *key) {
   if (!key) return;
   DeviceGuard guard(key->ctx->device);
   if (key->d_slotdesc) (void)hipFree(key->d_slotdesc);
+  if (key->d_invmeta) (void)hipFree(key->d_invmeta);
   if (key->d_runs) (void)hipFree(key->d_runs);
   if (key->d_images) (void)hipFree(key->d_images);
   if (key->d_table) (void)hipFree(key->d_table);
@@ -1499,7 +1518,8 @@ int32_t b3w_batch_commit_device(b3w_ctx *ctx, const b3w_commit_key *key, const u
     k->sums_cap = n;
   }
   const int rc = b3w_launch_commit(d_bodies, n, pitch, key->first_slot, key->nslots, key->d_slotdesc, nullptr, 0, nullptr, 0, key->d_table,
-                                   key->nwin, key->window, k->d_sums, d_points, d_status, nullptr, 0, &key->curve, (hipStream_t)stream);
+                                   key->nwin, key->window, k->d_sums, d_points, d_status, key->d_invtab, key->inv_nk, key->d_invmeta,
+                                   static_cast<const uint32_t *>(ctx->d_aux), &key->curve, (hipStream_t)stream);
   return rc ? hip_fail(ctx, (hipError_t)rc, "commit launch") : B3W_OK;
 }
 
@@ -1539,7 +1559,7 @@ int32_t b3w_commit_records_device(b3w_ctx *ctx, const b3w_commit_key *key, const
     if (lrc == 0)
       lrc = b3w_launch_commit(nullptr, cn, 0, key->first_slot, key->nslots, key->d_slotdesc, k->d_images, cap, key->d_runs, key->nruns,
                               key->d_table, key->nwin, key->window, k->d_sums, d_points + (uint64_t)c0 * 64, nullptr, key->d_invtab, key->inv_nk,
-                              &key->curve, (hipStream_t)stream);
+                              nullptr, nullptr, &key->curve, (hipStream_t)stream);
     if (lrc) return hip_fail(ctx, (hipError_t)lrc, "commit-from-records launch");
   }
   return B3W_OK;

@@ -763,8 +763,9 @@ __global__ __launch_bounds__(T * WPB) __attribute__((amdgpu_waves_per_eu(3, 3)))
                                                          const uint32_t *__restrict__ table /* radix 2^261 */, uint32_t nwin,
                                                          uint32_t *__restrict__ sums /* n x B3W_COMMIT_SUM_WORDS: X Y ZZ ZZZ in 29-bit limbs */,
                                                          int32_t *__restrict__ status,
-                                                         const uint32_t *__restrict__ invtab /* or null: records mode of the O2 nova circuits, b3w_commit_invtab_kernel */,
-                                                         uint32_t inv_nk, CV C) {
+                                                         const uint32_t *__restrict__ invtab /* or null: the O2 nova circuits' inverse points, b3w_commit_invtab_kernel */,
+                                                         uint32_t inv_nk, const uint32_t *__restrict__ invmeta /* bodies mode: gadget slots, input slots, first virtual slots */,
+                                                         const uint32_t *__restrict__ aux /* bodies mode: the prime, then 1 / k as scalars */, CV C) {
   extern __shared__ uint32_t lds[];
   __shared__ uint32_t bad[WPB];
   // invtab: per IsZero gadget of the step 0 = nothing to add (k = 0: the inverse is 0; or a rejected step), +-mag = the tabulated
@@ -789,6 +790,48 @@ __global__ __launch_bounds__(T * WPB) __attribute__((amdgpu_waves_per_eu(3, 3)))
       else k = (int64_t)img[(uint64_t)(B3W_LDS_NV + NV_TOTAL_DEPTH) * img_row] - (int64_t)(j - 3) - 2 - depth;
       const uint64_t mag = k < 0 ? (uint64_t)(-k) : (uint64_t)k;
       kinv[sub][j] = !ok || mag == 0 ? 0 : mag > inv_nk ? INV_WINDOWS : k < 0 ? -(int32_t)mag : (int32_t)mag;
+    }
+  } else if (!images) {
+    // bodies mode: the same arguments from the body's four input slots — and the point is taken only if the body's inverse slot
+    // IS +-1 / k (the context's scalar table), whatever the rest of the body says; everything else goes through the windows
+    const uint4 *wbody = reinterpret_cast<const uint4 *>(bodies + (uint64_t)(live ? w : 0) * pitch);
+    uint32_t inw[4] = {0, 0, 0, 0};
+    bool words = live && invtab != nullptr;
+    if (words)
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const uint32_t sidx = invmeta[B3W_NOVA_ISZERO + q];
+        const uint4 a = wbody[(uint64_t)sidx * 2], b = wbody[(uint64_t)sidx * 2 + 1];
+        inw[q] = a.x;
+        words = words && !(a.y | a.z | a.w | b.x | b.y | b.z | b.w);
+      }
+    for (uint32_t j = t; j < B3W_NOVA_ISZERO; j += T) {
+      int32_t res = INV_WINDOWS;
+      const uint32_t sl = words ? invmeta[j] : 0xFFFFFFFFu;
+      const int64_t depth = inw[3];
+      const int64_t k = j == 0 ? -depth : j == 1 ? -(int64_t)inw[1] : j == 2 ? (int64_t)inw[0] - 1 - (int64_t)inw[1] : (int64_t)inw[2] - (int64_t)(j - 3) - 2 - depth;
+      const uint64_t mag = k < 0 ? (uint64_t)(-k) : (uint64_t)k;
+      if (sl != 0xFFFFFFFFu && mag <= inv_nk) {
+        const uint4 va = wbody[((uint64_t)first_slot + sl) * 2], vb = wbody[((uint64_t)first_slot + sl) * 2 + 1];
+        const uint32_t v[8] = {va.x, va.y, va.z, va.w, vb.x, vb.y, vb.z, vb.w};
+        uint32_t diff = 0;
+        if (mag == 0) {                                        // IsZero(0): the inverse slot holds 0 — nothing to add
+#pragma unroll
+          for (int i = 0; i < 8; i++) diff |= v[i];
+          if (!diff) res = 0;
+        } else {
+          const uint32_t *e = aux + 16 + 8 * mag;              // 1 / mag; a negative argument's inverse is p - 1 / mag
+          uint64_t br = 0;
+#pragma unroll
+          for (int i = 0; i < 8; i++) {
+            const uint64_t d = (uint64_t)aux[i] - e[i] - br;
+            br = (d >> 63) & 1;
+            diff |= v[i] ^ (k < 0 ? (uint32_t)d : e[i]);
+          }
+          if (!diff) res = k < 0 ? -(int32_t)mag : (int32_t)mag;
+        }
+      }
+      kinv[sub][j] = res;
     }
   }
   __syncthreads();
@@ -848,6 +891,13 @@ __global__ __launch_bounds__(T * WPB) __attribute__((amdgpu_waves_per_eu(3, 3)))
         else if (code == 2) { wrong |= (a[u].z | a[u].w | hi) != 0; put32(v0, a[u].x); put32(v0 + 32, a[u].y); }
         else if (code == 3) { put32(v0, a[u].x); put32(v0 + 32, a[u].y); put32(v0 + 64, a[u].z); put32(v0 + 96, a[u].w);
                               put32(v0 + 128, b[u].x); put32(v0 + 160, b[u].y); put32(v0 + 192, b[u].z); put32(v0 + 224, b[u].w); }
+        else if (code == 5) {                                  // a nova inverse slot (v0 = the gadget): tabulated, or eight words like any 256-bit slot
+          if (kinv[sub][v0] == INV_WINDOWS) {
+            const uint32_t vv = invmeta ? invmeta[B3W_NOVA_ISZERO + 4 + v0] : 0u;
+            put32(vv, a[u].x); put32(vv + 32, a[u].y); put32(vv + 64, a[u].z); put32(vv + 96, a[u].w);
+            put32(vv + 128, b[u].x); put32(vv + 160, b[u].y); put32(vv + 192, b[u].z); put32(vv + 224, b[u].w);
+          }
+        }
         else if (code >= 8 && code < 40) { wrong |= (a[u].y | a[u].z | a[u].w | hi) != 0; put32(v0, (a[u].x >> (code - 8)) & 1u); }   // folded key: one bit of a word
         // (code 4: a slot folded into others' generators — nothing to add)
       }
@@ -879,7 +929,7 @@ __global__ __launch_bounds__(T * WPB) __attribute__((amdgpu_waves_per_eu(3, 3)))
       win += T;
     }
   }
-  if (images && invtab && live)
+  if (invtab && live)
     for (uint32_t j = t; j < B3W_NOVA_ISZERO; j += T) {        // one tabulated point per IsZero gadget (y negated for a negative argument)
       const int32_t kc = kinv[sub][j];
       if (kc == 0 || kc == INV_WINDOWS) continue;
@@ -1019,8 +1069,10 @@ extern "C" int b3w_launch_commit(const uint8_t *d_bodies, uint32_t n, uint64_t p
                                  const uint32_t *d_slotdesc, const uint32_t *d_images /* or null */, uint32_t img_row, const uint32_t *d_runs,
                                  uint32_t nruns, const uint32_t *d_table, uint32_t nwin, uint32_t window,
                                  uint32_t *d_sums /* n * B3W_COMMIT_SUM_WORDS scratch */, uint8_t *d_out, int32_t *d_status,
-                                 const uint32_t *d_invtab, uint32_t inv_nk, const B3wCurve *curve, hipStream_t stream) {
+                                 const uint32_t *d_invtab, uint32_t inv_nk, const uint32_t *d_invmeta, const uint32_t *d_aux, const B3wCurve *curve,
+                                 hipStream_t stream) {
   if (!n) return 0;
+  if (!d_images && !(d_invtab && d_invmeta && d_aux)) { d_invtab = nullptr; d_invmeta = nullptr; }      // (bodies mode needs all three)
   if (window != B3W_COMMIT_WINDOW_SMALL && window != B3W_COMMIT_WINDOW_LARGE) return (int)hipErrorInvalidValue;
   const uint32_t bits_words = (nwin * window + 31) / 32 + 2;   // one packed witness in LDS (nova O1: 13.5 KB)
   if (bits_words * 4 > 32 * 1024) return (int)hipErrorInvalidValue;
@@ -1040,7 +1092,7 @@ extern "C" int b3w_launch_commit(const uint8_t *d_bodies, uint32_t n, uint64_t p
     if ((size_t)region * WPB * 4 > 64 * 1024) return (int)hipErrorInvalidValue;   /* LDS of one workgroup (nova O1: 54 KB) */ \
     hipLaunchKernelGGL((b3w_commit_kernel<T, WPB, W, CV>), dim3((n + WPB - 1) / WPB), dim3(T * WPB), region * WPB * 4, stream, d_bodies, n, \
                        pitch, first_slot, nslots, d_slotdesc, d_images, img_row, reinterpret_cast<const uint2 *>(d_runs), nruns, region, d_table, nwin, \
-                       d_sums, d_status, d_images ? d_invtab : nullptr, inv_nk, cv);                                      \
+                       d_sums, d_status, d_invtab, inv_nk, d_invmeta, d_aux, cv);                                         \
   }
   if (window == B3W_COMMIT_WINDOW_LARGE) {
     if (vesta) B3W_COMMIT_LAUNCH(64, 4, B3W_COMMIT_WINDOW_LARGE, B3wCurve9Vesta, c9v)

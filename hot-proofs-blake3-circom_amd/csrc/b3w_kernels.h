@@ -67,11 +67,15 @@ extern "C" int b3w_launch_commit_setup(const uint32_t *d_gens, const uint32_t *d
                                        uint32_t *d_points, const B3wCurve *curve, hipStream_t stream);
 extern "C" int b3w_launch_commit_windows(const uint32_t *d_points, uint32_t nwin, uint32_t window, uint32_t *d_table, const B3wCurve *curve, hipStream_t stream);
 extern "C" int b3w_launch_commit(const uint8_t *d_bodies, uint32_t n, uint64_t pitch, uint32_t first_slot, uint32_t nslots,
-                                 const uint32_t *d_slotdesc /* first virtual slot | width code (0 bit, 1 32, 2 64, 3 256) << 24 */,
+                                 const uint32_t *d_slotdesc /* first virtual slot | width code (0 bit, 1 32, 2 64, 3 256, 4 folded away, 8 + b bit b of a word) << 24;
+                                                               IsZero gadget | 5 << 24: a nova inverse slot with tabulated points */,
                                  const uint32_t *d_images /* null: read the bodies; else TRACE images (b3w_launch_trace), bodies unused */,
                                  uint32_t img_row, const uint32_t *d_runs /* pairs: v0 | (len - 1) << 24, image word | shift << 16 */, uint32_t nruns,
                                  const uint32_t *d_table, uint32_t nwin, uint32_t window, uint32_t *d_sums, uint8_t *d_out,
-                                 int32_t *d_status, const uint32_t *d_invtab /* or null: records mode of the O2 nova circuits */, uint32_t inv_nk,
+                                 int32_t *d_status, const uint32_t *d_invtab /* or null: the O2 nova circuits' inverse point tables */, uint32_t inv_nk,
+                                 const uint32_t *d_invmeta /* bodies mode with code-5 slots: [0, 67) committed slot of gadget j, [67, 71) witness slots of
+                                                              n_blocks, block_count, total_depth, depth, [71, 138) first virtual slot of gadget j's slot */,
+                                 const uint32_t *d_aux /* ... and the context's scalars: [0, 8) the prime, [16 + 8 k, + 8) 1 / k */,
                                  const B3wCurve *curve, hipStream_t stream);
 // O2 nova circuits, records mode: invtab[j * nk + mag - 1] = (1 / mag) * G of the slot holding IsZero gadget j's inverse
 // (d_inverses: 8 words per magnitude, standard form — the witness kernels' table; d_inv_slot[j] = committed slot index or ~0)

@@ -282,6 +282,8 @@ int32_t b3w_batch_commit(b3w_batch *batch, const b3w_commit_key *key, uint8_t *h
  * O2 nova circuits: the 67 IsZero inverses of a step (256 virtual bit slots each, 39 % of a folded key) are 1/k of small signed
  * k the record determines, so the key also holds, per gadget, the points (+-1/k) G for |k| <= 2 047 (18 MB, 10 ms of set-up)
  * and this path adds ONE point per gadget instead of sixteen windows; a larger |k| goes through the windows as before.
+ * b3w_batch_commit_device does the same with bodies: k from the body's input slots, the point taken only when the body's inverse
+ * slot holds exactly +-1/k — a body that says anything else is committed to as it stands.
  * Same points either way (tests/test_gpu_commit.py); B3W_COMMIT_INVTAB=0 builds keys without the tables. */
 int32_t b3w_commit_records_device(b3w_ctx *ctx, const b3w_commit_key *key, const uint32_t *d_records, uint32_t n, uint8_t *d_points,
                                   uint32_t *d_public, int32_t *d_status, void *stream);

@@ -302,6 +302,66 @@ def test_commitments_from_records_equal_commitments_of_the_bodies(circuit, curve
     key.close(); ctx.close()
 
 
+def test_bodies_mode_takes_a_tabulated_inverse_only_when_the_slot_holds_it():
+    """r03: bodies mode of the O2 nova builds adds ONE tabulated point (+-1/k) G per IsZero gadget too — k from the body's four
+    input slots, and only if the body's inverse slot IS that scalar; a body that says anything else (an inverse off by one, another
+    gadget's inverse, 0, inputs that do not fit the inverses, an input that is no word) must be committed to as it stands, through
+    the windows.  Plain-integer MSM of every tampered body."""
+    import torch
+    m = T.pkg()
+    W = T.workloads()
+    circuit, curve, first_slot = "nova_vesta", "vesta", 5
+    n = 7
+    recs = W.config3_nova(n, first=31)
+    bad, bodies = T.oracle_batch_u32(circuit, recs)
+    assert bad == 0
+    host = bodies.copy().reshape(n, -1, 32)
+    # the input slots, found by their values among the first 48 (the O2 build merges pass-through outputs with their inputs: total_depth
+    # and leaf_depth live among the outputs); leaf_depth = total_depth in this workload, so
+    # "total_depth" is every slot that holds it
+    def holds(col):
+        return [s_ for s_ in range(1, 48) if all(int.from_bytes(host[i, s_].tobytes(), "little") == int(recs[i, col]) for i in range(n))]
+    slot = {"n_blocks": holds(0), "block_count": holds(1), "total_depth": holds(13), "depth": holds(14)}
+    assert all(len(v) >= 1 for v in slot.values()) and len(slot["depth"]) == 1 and len(slot["block_count"]) == 1, slot
+    p = T.PRIME[circuit] if hasattr(T, "PRIME") else 0x40000000000000000000000000000000224698fc0994a8dd8c46eb2100000001
+    rng = np.random.default_rng(5)
+    def put(i, s_, v):
+        host[i, s_] = np.frombuffer(int(v % (1 << 256)).to_bytes(32, "little"), dtype=np.uint8)
+    def wide_slots(i):
+        return [s_ for s_ in range(first_slot, host.shape[1]) if int.from_bytes(host[i, s_, 8:].tobytes(), "little")]
+    for i in range(n):
+        ws = wide_slots(i)
+        assert len(ws) >= 60
+        a, b = (int(x) for x in rng.choice(ws, 2, replace=False))
+        va = int.from_bytes(host[i, a].tobytes(), "little")
+        if i == 0: put(i, a, (va + 1) % p)                                        # an inverse off by one
+        elif i == 1: put(i, a, int.from_bytes(host[i, b].tobytes(), "little"))   # another gadget's inverse
+        elif i == 2: put(i, a, 0)                                                 # 0 where 1 / k stands
+        elif i == 3: put(i, slot["depth"][0], int(recs[i, 14]) + 1)               # the inputs no longer fit the eqs[] inverses
+        elif i == 4:
+            for s_ in slot["total_depth"]: put(i, s_, (1 << 200) + 7)             # an input that is no word
+        elif i == 5: put(i, slot["block_count"][0], int(recs[i, 1]) + 3)          # ... nor gadgets 1 and 2
+        # i == 6: untouched
+    flat = host.reshape(n, -1)
+    vals = _slot_values(flat.copy())
+    ctx = m.Context(circuit, 0)
+    gens = E.random_points(curve, ctx.witness_size - first_slot, seed=b"bodies-invtab")
+    key = m.CommitKey(ctx, curve, E.points_to_bytes(gens), first_slot, 16)
+    dev = torch.device("cuda:0")
+    d = torch.from_numpy(flat.copy()).to(dev)
+    pts = torch.zeros((n, 64), dtype=torch.uint8, device=dev)
+    st = torch.zeros(n, dtype=torch.int32, device=dev)
+    key.commit_device(d.data_ptr(), n, 0, pts.data_ptr(), st.data_ptr(), torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    got, flags = pts.cpu().numpy(), st.cpu().numpy()
+    for i in range(n):
+        if i == 4:                                           # a 32-bit slot holding 2^200: outside the key's domain — flagged, as ever
+            assert flags[i] != 0
+            continue
+        assert flags[i] == 0 and E.point_from_bytes(got[i].tobytes()) == E.commit(vals[i][first_slot:], gens, curve), i
+    key.close(); ctx.close()
+
+
 def test_chained_pass_commit_only_matches_the_commit_consumer():
     """b3w_chain_commit_only: the same points as committing every batch of bodies in the ring, and still BLAKE3(preimage)."""
     import torch, blake3_ref
