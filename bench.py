@@ -180,6 +180,38 @@ def cpu_baseline(circuit, recs, budget_s):
     return out
 
 
+def native_comm(m, ctx, dist, world, rank, tag):
+    """--exchange-impl native: a b3w_comm over the ranks of the torch process group — RCCL (the id travels through the group)
+    under "nccl", the host shared-memory transport under "gloo" (several ranks on one GPU)."""
+    if dist.get_backend() == "nccl":
+        box = [m.Comm.unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        return m.Comm(ctx, box[0], rank, world)
+    return m.Comm.host(ctx, f"/b3w_bench_{os.environ.get('MASTER_PORT', '0')}_{tag}", rank, world)
+
+
+def valu_ceiling():
+    """Field multiplications per second of the chip in the commit kernel's arithmetic (nine 29-bit limbs), multiplications only:
+    tools/ubench/fpmul29_peak.hip, latest run under profiles/ (G/s for mul and sqr).  A mixed addition is 8 mul + 2 sqr."""
+    mul, sqr, src = 172.8, 199.1, "profiles/r01/commit/fpmul29_peak.log"
+    try:
+        doc = json.load(open(os.path.join(ROOT, "profiles", "valu_ceiling_latest.json")))
+        mul, sqr, src = float(doc["mul_g_per_s"]), float(doc["sqr_g_per_s"]), doc.get("source", src)
+    except Exception:
+        pass
+    return 10.0 / (8.0 / mul + 2.0 / sqr), src
+
+
+def placement_cost(ctx, before=None):
+    c = ctx.placement_cost()
+    if before:
+        for k in ("search_s", "search_gib_walked", "check_s", "search_timeouts"):
+            c[k] -= before[k]
+    return {"placement_search_s": round(c["search_s"], 3), "placement_search_gib_walked": round(c["search_gib_walked"], 2),
+            "placement_check_s": round(c["check_s"], 3), "placement_search_timeouts": int(c["search_timeouts"]),
+            "placement_search_limit_s": c["search_limit_s"]}
+
+
 def gather_strings(dist, world, s):
     if world == 1:
         return [s]
@@ -224,11 +256,17 @@ def bench_chain(args, m, torch, dist, dev, world, rank, local_rank):
         if args.consumer == "commit-only":
             consumer, commit_only = None, (key, d_pts)
     # the fold's exchange (N > 1) is part of every pass: chunk chaining values, then every step's h_out (BASELINE config 4)
+    comm = native_comm(m, ctx, dist, world, rank, "chain") if (world > 1 and args.exchange_impl == "native") else None
     run = lambda: m.chain.fold_witnesses(ctx, host, batch_steps=args.batch if args.batch != 4096 else 16384, ring=2, consumer=consumer,
-                                         commit_only=commit_only, gather_hout=args.exchange != "none")
-    for _ in range(max(3, args.warmup)):        # the first passes pay the allocator (24 GB ring, record buffers)
+                                         commit_only=commit_only, gather_hout=args.exchange != "none", comm=comm)
+    t_first = time.perf_counter()
+    for i in range(max(3, args.warmup)):        # the first passes pay the allocator (24 GB ring, record buffers)
         out = run()
+        if i == 0:
+            torch.cuda.synchronize()
+            first_pass_s = time.perf_counter() - t_first
     torch.cuda.synchronize()
+    place_cost = placement_cost(ctx)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -242,6 +280,7 @@ def bench_chain(args, m, torch, dist, dev, world, rank, local_rank):
     torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     assert int(out["status"].abs().sum().item()) == 0
+    ex_ms = m.chain.exchange_ms(out)                          # the last timed pass: (chunk CVs, h_out) on this rank's device
     local_steps = out["n_leaf_steps"] + out["n_parent_steps"]
     n_leaf_all = m.lib().b3w_chain_num_leaf_steps(nbytes)
     if args.exchange != "none" or world == 1:
@@ -288,9 +327,40 @@ def bench_chain(args, m, torch, dist, dev, world, rank, local_rank):
         total_steps = float(local_steps)
     placements = gather_strings(dist, world, out.get("placement"))
     pass_ms = [float(x) for x in gather_strings(dist, world, repr(local_elapsed / args.steps * 1e3))]
+    ex_all = [json.loads(x) for x in gather_strings(dist, world, json.dumps([round(ex_ms[0], 4), round(ex_ms[1], 4)]))]
+    # The roofline of the pass is its dominant kernel's.  No consumer: the witness kernel, HBM writes.  check: witness kernel +
+    # constraint check, both HBM-bound — every body is written once and read once.  commit / commit-only: the commit kernel, bound by
+    # the vector ALUs: mixed point additions of 8 field multiplications + 2 squarings, priced against the multiplication-only ceiling
+    # of tools/ubench/fpmul29_peak.hip; the additions are COUNTED by the kernel in one extra, untimed pass.
+    body_b = 32 * ctx.witness_size
+    rate = total_steps * args.steps / elapsed / world                         # steps per second and GPU
+    if key is None:
+        per = BYTES_PER_WITNESS[circuit] + (body_b if r1cs_t is not None else 0)
+        roof = {"bound": "hbm", "achieved": rate * per / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": rate * per / 1e9 / HBM_PEAK_GBS, "traffic": None,
+                "algorithmic_bytes_per_step": per,
+                "note": ("bytes per step = body written + record read" + (" + body read back by the constraint check" if r1cs_t is not None else "")
+                         + "; end-to-end per-GPU rate incl. planner, H2D and launch gaps")}
+    else:
+        key.count(True)
+        run()
+        torch.cuda.synchronize()
+        adds, wits = key.counts()
+        key.count(False)
+        adds_per_step = adds / max(wits, 1)
+        tree = 63 * 14 + 400                                                  # LDS tree (63 full additions of 12 M + 2 S) + normalisation (one Fermat inversion)
+        mults = 10.0 * adds_per_step + tree
+        peak, src = valu_ceiling()
+        roof = {"bound": "valu", "achieved": rate * mults / 1e9, "peak": peak, "unit": "G field mul/s", "frac": rate * mults / 1e9 / peak, "traffic": None,
+                "field_multiplications_per_step": mults, "point_additions_per_step": adds_per_step, "peak_source": src,
+                "note": "29-bit-limb field multiplications of the commit kernel (10 per mixed addition, counted by the kernel in an untimed pass; "
+                        "+ tree and normalisation) against the chip's multiplication-only rate; end-to-end per-GPU rate"
+                        + ("" if commit_only is not None else ", witness generation" + (" and constraint check" if r1cs_t is not None else "") + " included in the time")}
+    cpu = None
+    if rank == 0 and world == 1 and args.cpu_seconds > 0:
+        import numpy as np
+        cpu = cpu_baseline(circuit, out["records"][:16].cpu().numpy().view(np.uint32), args.cpu_seconds)
     if rank == 0:
-        per = BYTES_PER_WITNESS[circuit] if commit_only is None else 128      # commit-only reads the 128-byte step records
-        print(json.dumps({
+        line = {
             "metric": "BLAKE3-compression witnesses/sec", "value": total_steps * args.steps / elapsed, "unit": "witnesses/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "u32", "data": "synthetic",
@@ -305,15 +375,21 @@ def bench_chain(args, m, torch, dist, dev, world, rank, local_rank):
                                    f"all_gather of {out['n_chunks']} x 8 u32 chunk chaining values over {dist.get_world_size()} ranks "
                                    f"({dist.get_backend()}), inside every timed pass",
                        "exchange_mode": ("every" if args.exchange != "none" else "none") if world > 1 else "none",
-                       "pass_ms_per_rank": pass_ms,
+                       "exchange_impl": ("native b3w_comm (" + comm.transport + ")" if comm is not None else "torch.distributed") if world > 1 else "none",
+                       "exchange_ms_per_rank": {"chunk_cvs": [x[0] for x in ex_all], "h_out": [x[1] for x in ex_all],
+                                                "what": "HIP events on the compute stream around staging + collective + scatter, last timed pass"},
+                       "pass_ms_per_rank": pass_ms, "first_pass_s": round(first_pass_s, 3), **place_cost,
                        "consumer": " then ".join(
                            ([f"rank-1 constraint check of every step witness on the device ({r1cs_t.n_constraints} constraints)"] if r1cs_t is not None else []) +
                            ([f"Pedersen commitment of every step witness on the device ({key.window}-bit windows, {key.folded_slots} slots folded)"
                              + (", from the step records: no bodies written" if commit_only is not None else "")] if key is not None else [])) or "none"},
-            "roofline": {"bound": "hbm", "achieved": total_steps * args.steps * per / elapsed / 1e9 / world, "peak": HBM_PEAK_GBS,
-                         "unit": "GB/s", "frac": total_steps * args.steps * per / elapsed / 1e9 / world / HBM_PEAK_GBS,
-                         "traffic": None, "note": "end-to-end per-GPU rate incl. planner, H2D and launch gaps"},
-        }), flush=True)
+            "roofline": roof,
+        }
+        if cpu is not None:
+            line["cpu_baseline"] = cpu
+        print(json.dumps(line), flush=True)
+    if comm is not None:
+        comm.close()
     if world > 1:
         dist.destroy_process_group()
 
@@ -329,7 +405,7 @@ def main():
     ap.add_argument("--circuit", default="compression")
     ap.add_argument("--variant", type=int, default=None, help="kernel tuning variant (B3W_VARIANT)")
     ap.add_argument("--pitch", type=int, default=0, help="body pitch in bytes (0 = contiguous bodies)")
-    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="budget of the cpu_baseline leg (0 = skip)")
+    ap.add_argument("--cpu-seconds", type=float, default=5.0, help="budget of the cpu_baseline leg (0 = skip)")
     ap.add_argument("--placement", default="mixed", choices=["mixed", "plain"],
                     help="body buffer placement: mixed = b3w_bodies_alloc's two-class buffer (default), plain = hipMalloc")
     ap.add_argument("--workload", default="batch", choices=["batch", "chain"],
@@ -346,6 +422,13 @@ def main():
                          "after EVERY launch (default; pipelined with the next launch), after the LAST launch only, or not at all — "
                          "the three together split a scaling number into kernel and RCCL contention.  chain workload: every / last "
                          "= gather every step's h_out inside each pass, none = chunk chaining values only")
+    ap.add_argument("--exchange-impl", default="torch", choices=["torch", "native"],
+                    help="N > 1: who runs the exchange.  torch = torch.distributed collectives (nccl = RCCL; gloo staged through the host); "
+                         "native = the C-ABI's own b3w_comm (RCCL through librccl under nccl; the host shared-memory transport under "
+                         "B3W_DIST_BACKEND=gloo, several ranks on one GPU): b3w_chain_run_parents_sharded + b3w_chain_allgather_hout in the "
+                         "chain workload, b3w_comm_allgather of the public outputs in the batch workload")
+    ap.add_argument("--placement-search-s", type=float, default=30.0,
+                    help="time limit of the placement allocator's search for a second class of HBM (then the buffer is plain and says so)")
     ap.add_argument("--launch-timeout", type=float, default=120.0,
                     help="N > 1: seconds every rank has to pass rendezvous (process group + first barrier), counted from the moment "
                          "the first rank has imported torch; also the process group's own timeout.  0 = no watchdog")
@@ -419,6 +502,7 @@ def main():
     # the bench owns its GPU: let the placement search walk as far as it may (the library's default is bounded to 16 x the
     # buffer so that co-resident allocators are not starved; the first class border of a fresh device can lie 64 GiB in)
     m.lib().b3w_bodies_configure(160, -1)
+    m.lib().b3w_bodies_search_limit(args.placement_search_s)
     if args.workload == "chain":
         return bench_chain(args, m, torch, dist, dev, world, rank, local_rank)
     circuit, n = args.circuit, args.batch
@@ -435,6 +519,29 @@ def main():
     # the fold's exchange step (N > 1): all-gather of the per-step public outputs (h_out ...), pipelined — the gather
     # of launch i overlaps the kernel of launch i+1 on RCCL's own stream (sharding.PublicExchange)
     ex = sharding.PublicExchange(n, npub, dev)
+    comm = None
+    if world > 1 and args.exchange_impl == "native":
+        comm = native_comm(m, ctx, dist, world, rank, "batch")
+
+        class NativeExchange:
+            """the same hand-over as sharding.PublicExchange, through b3w_comm_allgather on the launch stream"""
+            def __init__(self):
+                self.bufs = [torch.zeros((n, npub), dtype=torch.int32, device=dev) for _ in range(2)]
+                self.outs = [torch.empty((world * n, npub), dtype=torch.int32, device=dev) for _ in range(2)]
+                self.i, self.last = 0, None
+
+            def next_buffer(self):
+                return self.bufs[self.i % 2]
+
+            def post(self):
+                k = self.i % 2
+                comm.allgather(self.bufs[k].data_ptr(), self.outs[k].data_ptr(), n * npub * 4, stream.cuda_stream)
+                self.last = k
+                self.i += 1
+
+            def finish(self):
+                return None if self.last is None else self.outs[self.last]
+        ex = NativeExchange()
 
     def launch(post=None):
         pub = ex.next_buffer()
@@ -464,6 +571,7 @@ def main():
                         raise
                     print(f"bench.py: {e2}; trying again in {2 + attempt} s", file=sys.stderr)
                     time.sleep(2 + attempt)
+    t_alloc = time.perf_counter()
     bodies = alloc()
     for attempt in range(4):                                # a box still releasing another process's memory: try again
         if bodies.placement == "mixed" or os.environ.get("B3W_PLACEMENT") == "plain":
@@ -475,6 +583,7 @@ def main():
         os.environ["B3W_PLACE_DEBUG"] = "1"                 # say on stderr what the search found
         bodies = alloc()
     d_bodies = bodies                                      # .data_ptr() like a tensor
+    place_cost = dict(placement_cost(ctx), placement_alloc_s=round(time.perf_counter() - t_alloc, 3))
     if args.variant is None:
         chosen, best_ms = ctx.autotune_device(d_recs.data_ptr(), n, bodies.ptr, pitch, d_pub.data_ptr(), d_status.data_ptr(),
                                               stream.cuda_stream)
@@ -541,6 +650,20 @@ def main():
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     kern_per_rank = [float(x) for x in gather_strings(dist, world, repr(kern_ms))]     # every rank's own HIP-event average
+    # the collective alone (N > 1): 20 all-gathers of the public outputs back to back, nothing else on the device, HIP events
+    ex_ms = 0.0
+    if world > 1:
+        torch.cuda.synchronize()
+        dist.barrier()
+        ev0.record(stream)
+        for _ in range(20):
+            ex.next_buffer()
+            ex.post()
+        ex.finish()
+        ev1.record(stream)
+        torch.cuda.synchronize()
+        ex_ms = ev0.elapsed_time(ev1) / 20
+    ex_per_rank = [float(x) for x in gather_strings(dist, world, repr(ex_ms))]
     elapsed, kern_ms = t[0].item(), t[1].item()
     placements = gather_strings(dist, world, bodies.placement)
 
@@ -590,7 +713,11 @@ def main():
                                        "last": f"all_gather of the {n} x {npub} u32 public outputs over {dist.get_world_size()} ranks "
                                                f"({dist.get_backend()}) after the last timed launch only",
                                        "none": f"no collective inside the timed region ({dist.get_world_size()} ranks, {dist.get_backend()}): kernels only"}[args.exchange],
-                       "exchange_mode": args.exchange if world > 1 else "none", "devices_per_rank": devices},
+                       "exchange_mode": args.exchange if world > 1 else "none",
+                       "exchange_impl": ("native b3w_comm (" + comm.transport + ")" if comm is not None else "torch.distributed") if world > 1 else "none",
+                       "exchange_ms_per_rank": {"public_outputs": ex_per_rank,
+                                                "what": "one all-gather of the batch's public outputs with nothing else on the device: HIP events around 20, after the timed region"},
+                       "devices_per_rank": devices, **place_cost},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
                          "kernel_ms": kern_ms, "kernel_ms_per_rank": kern_per_rank, "kernel_ms_min": min(kern_per_rank),
@@ -599,6 +726,8 @@ def main():
         if args.cpu_seconds > 0 and world == 1:
             out["cpu_baseline"] = cpu_baseline(circuit, recs, args.cpu_seconds)
         print(json.dumps(out), flush=True)
+    if comm is not None:
+        comm.close()
     if world > 1:
         dist.destroy_process_group()
 

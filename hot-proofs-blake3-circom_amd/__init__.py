@@ -102,6 +102,8 @@ def lib():
         "b3w_ctx_trim": (i32, [vp]),
         "b3w_bodies_configure": (None, [ctypes.c_int64, ctypes.c_int64]),
         "b3w_bodies_stats": (i32, [vp, vp]),
+        "b3w_bodies_search_stats": (i32, [vp, ctypes.POINTER(ctypes.c_double)]),
+        "b3w_bodies_search_limit": (None, [ctypes.c_double]),
         "b3w_batch_placement": (i32, [vp]),
         "b3w_chain_num_chunks": (u64, [u64]),
         "b3w_chain_num_leaf_steps": (u64, [u64]),
@@ -118,6 +120,8 @@ def lib():
         "b3w_slot_widths": (i32, [vp, vp]),
         "b3w_commit_key_window": (u32, [vp]),
         "b3w_commit_key_destroy": (None, [vp]),
+        "b3w_commit_key_count": (i32, [vp, i32]),
+        "b3w_commit_key_counts": (i32, [vp, ctypes.POINTER(u64)]),
         "b3w_commit_records_device": (i32, [vp, vp, vp, u32, vp, vp, vp, vp]),
         "b3w_commit_records": (i32, [vp, vp, vp, u32, vp, vp, vp]),
         "b3w_chain_commit_only": (i32, [vp, vp, vp]),
@@ -129,6 +133,10 @@ def lib():
         "b3w_commit_consumer": (None, [vp, vp, u64, u64, u32, vp]),
         "b3w_comm_unique_id": (i32, [vp]),
         "b3w_comm_create": (i32, [vp, vp, i32, i32, ctypes.POINTER(vp)]),
+        "b3w_comm_create_host": (i32, [vp, ctypes.c_char_p, i32, i32, ctypes.POINTER(vp)]),
+        "b3w_comm_create_external": (i32, [vp, i32, i32, vp, vp, ctypes.POINTER(vp)]),
+        "b3w_comm_rank": (i32, [vp]),
+        "b3w_comm_size": (i32, [vp]),
         "b3w_comm_destroy": (None, [vp]),
         "b3w_comm_allgather": (i32, [vp, vp, vp, u64, vp]),
         "b3w_batch_allgather_public": (i32, [vp, vp, vp]),
@@ -140,6 +148,7 @@ def lib():
         "b3w_chain_run_parents_sharded": (i32, [vp, vp, vp, vp, vp]),
         "b3w_chain_allgather_hout": (i32, [vp, vp, vp, vp, vp]),
         "b3w_chain_allgather_hout_host": (i32, [vp, vp, vp, vp, vp]),
+        "b3w_chain_exchange_ms": (i32, [vp, ctypes.POINTER(ctypes.c_float)]),
         "b3w_chain_info": (i32, [vp, ctypes.POINTER(u64), ctypes.POINTER(u64), ctypes.POINTER(u64), ctypes.POINTER(u32), ctypes.POINTER(i32)]),
         "b3w_chain_outputs": (i32, [vp, vp, vp, vp, vp]),
         "b3w_chain_records": (vp, [vp]),
@@ -160,12 +169,12 @@ EXPORTED_SYMBOLS = ("b3w_abi_version", "b3w_identify_wasm", "b3w_create", "b3w_d
                     "b3w_batch_run_device", "b3w_public_words", "b3w_batch_alloc", "b3w_batch_free",
                     "b3w_batch_run", "b3w_batch_outputs", "b3w_batch_fetch", "b3w_batch_device_ptr",
                     "b3w_batch_time_device", "b3w_batch_verify_device", "b3w_batch_verify",
-                    "b3w_r1cs_create", "b3w_r1cs_info", "b3w_r1cs_is_tiled", "b3w_r1cs_destroy", "b3w_r1cs_check_device", "b3w_batch_r1cs_check", "b3w_r1cs_consumer", "b3w_batch_write_wtns", "b3w_batch_autotune_device", "b3w_bodies_alloc", "b3w_bodies_free", "b3w_bodies_trim", "b3w_ctx_trim", "b3w_bodies_configure", "b3w_bodies_stats", "b3w_batch_placement", "b3w_chain_num_chunks", "b3w_chain_num_leaf_steps", "b3w_chain_path_len",
+                    "b3w_r1cs_create", "b3w_r1cs_info", "b3w_r1cs_is_tiled", "b3w_r1cs_destroy", "b3w_r1cs_check_device", "b3w_batch_r1cs_check", "b3w_r1cs_consumer", "b3w_batch_write_wtns", "b3w_batch_autotune_device", "b3w_bodies_alloc", "b3w_bodies_free", "b3w_bodies_trim", "b3w_ctx_trim", "b3w_bodies_configure", "b3w_bodies_stats", "b3w_bodies_search_stats", "b3w_bodies_search_limit", "b3w_batch_placement", "b3w_chain_num_chunks", "b3w_chain_num_leaf_steps", "b3w_chain_path_len",
                     "b3w_chain_num_parent_steps", "b3w_chain_parent_row", "b3w_chain_path_provable",
                     "b3w_chain_plan_leaves_device", "b3w_chain_tree_device", "b3w_chain_plan_parents_device",
-                    "b3w_commit_key_create", "b3w_commit_key_create_ex", "b3w_commit_key_create_folded", "b3w_slot_widths", "b3w_commit_key_window", "b3w_commit_key_destroy", "b3w_commit_records_device", "b3w_commit_records", "b3w_chain_commit_only", "b3w_chain_commitments", "b3w_chain_check_constraints", "b3w_chain_violations", "b3w_batch_commit_device", "b3w_batch_commit", "b3w_commit_consumer",
-                    "b3w_comm_unique_id", "b3w_comm_create", "b3w_comm_destroy", "b3w_comm_allgather", "b3w_batch_allgather_public",
-                    "b3w_chain_create", "b3w_chain_destroy", "b3w_chain_run_leaves", "b3w_chain_run_parents", "b3w_chain_shard", "b3w_chain_run_parents_sharded", "b3w_chain_allgather_hout", "b3w_chain_allgather_hout_host", "b3w_chain_info",
+                    "b3w_commit_key_create", "b3w_commit_key_create_ex", "b3w_commit_key_create_folded", "b3w_slot_widths", "b3w_commit_key_window", "b3w_commit_key_destroy", "b3w_commit_key_count", "b3w_commit_key_counts", "b3w_commit_records_device", "b3w_commit_records", "b3w_chain_commit_only", "b3w_chain_commitments", "b3w_chain_check_constraints", "b3w_chain_violations", "b3w_batch_commit_device", "b3w_batch_commit", "b3w_commit_consumer",
+                    "b3w_comm_unique_id", "b3w_comm_create", "b3w_comm_create_host", "b3w_comm_create_external", "b3w_comm_rank", "b3w_comm_size", "b3w_comm_destroy", "b3w_comm_allgather", "b3w_batch_allgather_public",
+                    "b3w_chain_create", "b3w_chain_destroy", "b3w_chain_run_leaves", "b3w_chain_run_parents", "b3w_chain_shard", "b3w_chain_run_parents_sharded", "b3w_chain_allgather_hout", "b3w_chain_allgather_hout_host", "b3w_chain_exchange_ms", "b3w_chain_info",
                     "b3w_chain_outputs", "b3w_chain_records", "b3w_chain_public", "b3w_chain_status", "b3w_chain_local_cvs", "b3w_chain_root")
 
 
@@ -293,6 +302,12 @@ class Context:
         self._lib.b3w_bodies_stats(self.handle, out)
         return dict(arena_bytes=out[0], arena_used=out[1], pooled_bytes=out[2], live_bytes=out[3], live_buffers=out[4], handles_created=out[5])
 
+    def placement_cost(self):
+        """What placement has cost on this context's device so far (b3w_bodies_search_stats)."""
+        out = (ctypes.c_double * 5)()
+        self._lib.b3w_bodies_search_stats(self.handle, out)
+        return dict(search_s=out[0], search_gib_walked=out[1], search_timeouts=int(out[2]), search_limit_s=out[3], check_s=out[4])
+
     def time_device(self, d_records, n, d_bodies, pitch, d_public, d_status, stream, iters):
         ms = ctypes.c_float()
         rc = self._lib.b3w_batch_time_device(self.handle, d_records, n, d_bodies, pitch, d_public or None,
@@ -339,10 +354,18 @@ class BodyBuffer:
             pass
 
 
+_ALLGATHER_FN = ctypes.CFUNCTYPE(ctypes.c_int32, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_void_p)
+
+
 class Comm:
-    """A native RCCL communicator of the C-ABI (b3w_comm_*: one process per GPU, librccl loaded at run time) — for hosts
-    without torch.distributed, and for chain.fold_witnesses(comm=...).  Rank 0 makes the id (Comm.unique_id()) and hands its
-    128 bytes to the other ranks."""
+    """A native communicator of the C-ABI (b3w_comm_*), for hosts without torch.distributed and for
+    chain.fold_witnesses(comm=...).  Three transports behind the same handle:
+      Comm(ctx, uid, rank, nranks)           RCCL over xGMI, one process per GPU (librccl loaded at run time); rank 0 makes the id
+                                             (Comm.unique_id()) and hands its 128 bytes to the other ranks
+      Comm.host(ctx, name, rank, nranks)     the processes of one host through POSIX shared memory (b3w_comm_create_host): several
+                                             ranks on ONE GPU, or no RCCL; `name` = "/unique-to-the-job", the same on every rank
+      Comm.external(ctx, rank, nranks, fn)   the caller's collective: fn(d_send, d_recv, bytes_per_rank, stream) with device
+                                             pointers as ints (sharding.torch_allgather builds one over torch.distributed)"""
 
     @staticmethod
     def unique_id():
@@ -352,18 +375,53 @@ class Comm:
             raise B3WError(rc, f"b3w_comm_unique_id: status {rc}")
         return bytes(uid)
 
-    def __init__(self, ctx, uid, rank, nranks):
+    def __init__(self, ctx, uid, rank, nranks, _handle=None):
         self.ctx, self.rank, self.nranks = ctx, int(rank), int(nranks)
+        self.transport, self._cb, self._cb_error = "rccl", None, None
+        if _handle is not None:
+            self.handle = _handle
+            return
         h = ctypes.c_void_p()
         rc = lib().b3w_comm_create(ctx.handle, (ctypes.c_uint8 * 128).from_buffer_copy(uid), self.rank, self.nranks, ctypes.byref(h))
         if rc != B3W_OK:
             raise B3WError(rc, f"b3w_comm_create: status {rc}: {ctx.last_error()}")
         self.handle = h
 
+    @classmethod
+    def host(cls, ctx, name, rank, nranks):
+        h = ctypes.c_void_p()
+        rc = lib().b3w_comm_create_host(ctx.handle, name.encode(), int(rank), int(nranks), ctypes.byref(h))
+        if rc != B3W_OK:
+            raise B3WError(rc, f"b3w_comm_create_host({name}): status {rc}: {ctx.last_error()}")
+        c = cls(ctx, None, rank, nranks, _handle=h)
+        c.transport = "host"
+        return c
+
+    @classmethod
+    def external(cls, ctx, rank, nranks, fn):
+        c = cls(ctx, None, rank, nranks, _handle=ctypes.c_void_p())
+        c.transport = "external"
+
+        def _cb(user, d_send, d_recv, nbytes, stream):
+            try:
+                fn(d_send or 0, d_recv or 0, nbytes, stream or 0)
+                return 0
+            except BaseException as e:          # never unwind through the C frames: report, fail the native call
+                c._cb_error = e
+                return -1
+        c._cb = _ALLGATHER_FN(_cb)                # (kept alive with the object)
+        h = ctypes.c_void_p()
+        rc = lib().b3w_comm_create_external(ctx.handle, int(rank), int(nranks), ctypes.cast(c._cb, ctypes.c_void_p), None, ctypes.byref(h))
+        if rc != B3W_OK:
+            raise B3WError(rc, f"b3w_comm_create_external: status {rc}: {ctx.last_error()}")
+        c.handle = h
+        return c
+
     def allgather(self, d_send, d_recv, bytes_per_rank, stream=0):
         rc = lib().b3w_comm_allgather(self.handle, d_send, d_recv, bytes_per_rank, stream or None)
         if rc != B3W_OK:
-            raise B3WError(rc, f"b3w_comm_allgather: status {rc}: {self.ctx.last_error()}")
+            err, self._cb_error = self._cb_error, None
+            raise B3WError(rc, f"b3w_comm_allgather: status {rc}: {self.ctx.last_error()}" + (f" ({err!r})" if err else ""))
 
     def close(self):
         if getattr(self, "handle", None):
@@ -492,6 +550,16 @@ class CommitKey:
         if rc != B3W_OK:
             raise B3WError(rc, f"b3w_commit_records: status {rc}: {self.ctx.last_error()}")
         return pts, pub, st
+
+    def count(self, on=True):
+        """start (and reset) / stop counting the point additions of this key's commit launches (b3w_commit_key_count)"""
+        lib().b3w_commit_key_count(self.handle, 1 if on else 0)
+
+    def counts(self):
+        """(mixed point additions, witnesses) since count() — 10 field multiplications per addition"""
+        out = (ctypes.c_uint64 * 2)()
+        lib().b3w_commit_key_counts(self.handle, out)
+        return int(out[0]), int(out[1])
 
     def close(self):
         if getattr(self, "handle", None):

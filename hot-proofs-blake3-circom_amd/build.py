@@ -35,12 +35,14 @@ def hipcc():
 def build_lib(force=False, extra_flags=()):
     """One object per source, compiled side by side (the commit kernels alone take 50 s), then one link."""
     from concurrent.futures import ThreadPoolExecutor
-    names = ("b3w_kernels.hip", "b3w_exact.hip", "b3w_plan.hip", "b3w_placement.hip", "b3w_commit.hip", "b3w_r1cs.hip", "b3w_r1cs_host.cpp", "b3w_capi.cpp")
+    names = ("b3w_kernels.hip", "b3w_exact.hip", "b3w_plan.hip", "b3w_placement.hip", "b3w_commit.hip", "b3w_r1cs.hip", "b3w_r1cs_host.cpp", "b3w_hostcomm.cpp", "b3w_capi.cpp")
     srcs = [os.path.join(CSRC, f) for f in names]
     hdrs = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".h", ".inc"))] + \
         [os.path.join(ROOT, "include", "b3wit.h")]
     objdir = os.path.join(PKG, "build")
     os.makedirs(objdir, exist_ok=True)
+    if os.environ.get("B3W_BUILD_DIAG") == "1":      # the constraint check's experiment switches (B3W_R1CS_DBG / _STAMPS): never in a product build
+        extra_flags = (*extra_flags, "-DB3W_R1CS_DIAG")
     flags = [f"--offload-arch={ARCH}", "-O3", "-std=c++17", "-fPIC", "-x", "hip", "-Wall", "-Wno-unused-function", *extra_flags]
     jobs = []
     for src in srcs:
@@ -52,7 +54,7 @@ def build_lib(force=False, extra_flags=()):
             list(ex.map(_run, jobs))
     objs = [os.path.join(objdir, os.path.basename(src) + ".o") for src in srcs]
     if jobs or _newer(LIB, objs):
-        _run([hipcc(), f"--offload-arch={ARCH}", "-fPIC", "-shared", "-o", LIB, *objs, "-ldl"])
+        _run([hipcc(), f"--offload-arch={ARCH}", "-fPIC", "-shared", "-o", LIB, *objs, "-ldl", "-lrt", "-lpthread"])
     return LIB
 
 

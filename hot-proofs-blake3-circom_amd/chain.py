@@ -144,8 +144,9 @@ def fold_witnesses(ctx, preimage, batch_steps=16384, ring=2, slice_chunks=1024, 
     rows = n_leaf + n_par
     public = _view(L.b3w_chain_public(h), (rows, 15), "<i4", dev)
     h_leaf, h_par = None, None
+    timer = None                                   # exchange_ms(out) reads it: how long the two exchanges took on this rank's device
     if comm is not None:
-        # ---- both exchanges natively (RCCL through the C-ABI)
+        # ---- both exchanges natively, through the b3w_comm (RCCL, host shared memory or the caller's collective)
         _chk(ctx, L.b3w_chain_run_parents_sharded(h, comm.handle, cb, None, compute.cuda_stream), "b3w_chain_run_parents_sharded")
         if gather_hout:
             sh = step_shards(ln, world, with_parents)
@@ -154,21 +155,51 @@ def fold_witnesses(ctx, preimage, batch_steps=16384, ring=2, slice_chunks=1024, 
             with torch.cuda.stream(compute):
                 _chk(ctx, L.b3w_chain_allgather_hout(h, comm.handle, h_leaf.data_ptr(), h_par.data_ptr() if h_par.numel() else None,
                                                      compute.cuda_stream), "b3w_chain_allgather_hout")
+        timer = ("native", h, bool(gather_hout))
     else:
         # ---- exchange 1: chunk chaining values of all ranks (32 B per chunk)
         all_cvs = None
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(4)] if world > 1 else None
         if world > 1:
+            ev[0].record(compute)
             cvs_local = _view(L.b3w_chain_local_cvs(h), (max(nl, 1), 8), "<i4", dev)
             all_cvs = gather_rows(cvs_local[:nl], [e - s for s, e in (shard_range(n, r, world) for r in range(world))]).contiguous()
+            ev[1].record(compute)
         _chk(ctx, L.b3w_chain_run_parents(h, all_cvs.data_ptr() if all_cvs is not None else None, cb, None, compute.cuda_stream),
              "b3w_chain_run_parents")
         # ---- exchange 2: h_out of every step (8 u32 per step), global step order on every rank
         if gather_hout or world == 1:
+            if world > 1:
+                ev[2].record(compute)
             h_leaf, h_par = gather_h_out(public, n_leaf, ln, with_parents)
+            if world > 1:
+                ev[3].record(compute)
+        if world > 1:
+            timer = ("torch", ev, bool(gather_hout))
 
     return dict(public=public, h_out_all=h_leaf, h_out_parents_all=h_par, chunk_cvs_local=_view(L.b3w_chain_local_cvs(h), (max(nl, 1), 8), "<i4", dev)[:nl],
                 status=_view(L.b3w_chain_status(h), (rows,), "<i4", dev),
                 records=_view(L.b3w_chain_records(h), (rows, 32), "<i4", dev), root=_view(L.b3w_chain_root(h), (8,), "<i4", dev),
                 n_leaf_steps=n_leaf, n_parent_steps=n_par, first_chunk=c0, n_chunks_local=nl, n_chunks=n, path_len=P.value,
                 batches=-(-n_leaf // batch_steps) + -(-n_par // batch_steps) if consumer is None else nbatch[0],
-                placement="mixed" if pl.value == 1 else "plain")
+                placement="mixed" if pl.value == 1 else "plain", exchange_timer=timer)
+
+
+def exchange_ms(out):
+    """(chunk-CV exchange ms, h_out exchange ms) of the pass fold_witnesses returned `out` for, on this rank's device (HIP events
+    on the compute stream around staging + collective + scatter); waits for the events.  (0, 0) on one rank."""
+    t = out.get("exchange_timer")
+    if t is None:
+        return 0.0, 0.0
+    if t[0] == "native":
+        ms = (ctypes.c_float * 2)()
+        lib().b3w_chain_exchange_ms(t[1], ms)
+        return float(ms[0]), float(ms[1]) if t[2] else 0.0
+    ev = t[1]
+    ev[1].synchronize()
+    a = ev[0].elapsed_time(ev[1])
+    b = 0.0
+    if t[2]:
+        ev[3].synchronize()
+        b = ev[2].elapsed_time(ev[3])
+    return a, b

@@ -8,6 +8,7 @@
 #include <string.h>
 #include <algorithm>
 #include <array>
+#include <chrono>
 #include <map>
 #include <mutex>
 #include <string>
@@ -740,6 +741,29 @@ float time_witness_fill(b3w_ctx *ctx, uint8_t *d_buf, uint64_t bytes) {
 
 extern "C" {
 
+namespace {
+std::mutex g_check_mtx;
+double g_check_seconds[64];                                   // per device: time spent in the real-kernel check of "mixed" buffers
+struct CheckClock {
+  int dev; std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+  explicit CheckClock(int d) : dev(d) {}
+  ~CheckClock() {
+    std::lock_guard<std::mutex> g(g_check_mtx);
+    if (dev >= 0 && dev < 64) g_check_seconds[dev] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+  }
+};
+}  // namespace
+
+int32_t b3w_bodies_search_stats(const b3w_ctx *ctx, double out[5]) {
+  if (!ctx || !out) return B3W_E_BAD_ARGUMENT;
+  b3w_place_search_stats(ctx->device, out);
+  std::lock_guard<std::mutex> g(g_check_mtx);
+  out[4] = ctx->device >= 0 && ctx->device < 64 ? g_check_seconds[ctx->device] : 0.0;
+  return B3W_OK;
+}
+
+void b3w_bodies_search_limit(double seconds) { b3w_place_search_limit(seconds); }
+
 int32_t b3w_bodies_alloc(b3w_ctx *ctx, uint64_t bytes, void **d_ptr, int32_t *placement) {
   if (!ctx || !d_ptr || !bytes) return B3W_E_BAD_ARGUMENT;
   *d_ptr = nullptr;
@@ -755,6 +779,7 @@ int32_t b3w_bodies_alloc(b3w_ctx *ctx, uint64_t bytes, void **d_ptr, int32_t *pl
       // (measured once per context) and take the label back when the gain is below 10 % — the buffer stays usable.
       static const bool check = !(getenv("B3W_PLACE_CHECK") && !strcmp(getenv("B3W_PLACE_CHECK"), "0"));
       if (mixed && check) {
+        CheckClock clock(ctx->device);
         if (ctx->plain_ms_per_gb == 0) {
           // the slowest of three distinct hipMalloc buffers: one plain buffer in eight or so straddles a class border
           // by luck and is as fast as a placed one (profiles/r02: a `--placement plain` bench run at 0.87) — that must
@@ -1280,6 +1305,9 @@ struct b3w_commit_key {
                                                       // [67, 71) the witness slots of n_blocks, block_count, total_depth, depth, [71, 138) the slot's first virtual slot
   uint32_t *d_sums = nullptr;                         // Jacobian sums between the two kernels, grown on demand
   uint32_t sums_cap = 0;
+  unsigned long long *d_counts = nullptr;             // b3w_commit_key_count: mixed additions of the launches made while counting
+  uint64_t host_witnesses = 0;                        // ... and the witnesses of those launches
+  bool counting = false;
 };
 
 namespace {
@@ -1398,7 +1426,11 @@ int32_t b3w_commit_key_create_folded(b3w_ctx *ctx, int32_t curve, uint32_t first
   // table and takes the point only if they are equal (code 5: gadget number in the low bits; anything else goes through the
   // windows like any 256-bit slot).
   static const bool want_invtab = !(getenv("B3W_COMMIT_INVTAB") && !strcmp(getenv("B3W_COMMIT_INVTAB"), "0"));
-  const bool with_invtab = want_invtab && ctx->desc.kind == B3W_KIND_NOVA_O2 && ctx->d_aux;
+  // ... and only for the curve whose group order IS the circuit's prime: the table holds (+-1/k) G with 1/k taken in the circuit's
+  // field, which is the scalar p - 1/k G's windows would add up to only when scalars live in that field (a caller of
+  // the C API who pairs nova_vesta with BN254 G1 gets the windows, like with B3W_COMMIT_INVTAB=0, and consistent points either way)
+  const bool order_is_prime = (ctx->desc.prime == P_BN254 && curve == B3W_CURVE_BN254_G1) || (ctx->desc.prime == P_VESTA && curve == B3W_CURVE_PALLAS);
+  const bool with_invtab = want_invtab && order_is_prime && ctx->desc.kind == B3W_KIND_NOVA_O2 && ctx->d_aux;
   std::vector<uint32_t> invmeta(2 * B3W_NOVA_ISZERO + 4, 0xFFFFFFFFu);
   if (with_invtab) {
     for (uint32_t i = 0; i < nslots; i++) {
@@ -1496,7 +1528,32 @@ void b3w_commit_key_destroy(b3w_commit_key *key) {
   if (key->d_table) (void)hipFree(key->d_table);
   if (key->d_invtab) (void)hipFree(key->d_invtab);
   if (key->d_sums) (void)hipFree(key->d_sums);
+  if (key->d_counts) (void)hipFree(key->d_counts);
   delete key;
+}
+
+int32_t b3w_commit_key_count(b3w_commit_key *key, int32_t on) {
+  if (!key) return B3W_E_BAD_ARGUMENT;
+  b3w_ctx *ctx = key->ctx;
+  ON_DEVICE(ctx);
+  HIP_TRY(ctx, hipDeviceSynchronize());
+  if (on && !key->d_counts) HIP_TRY(ctx, hipMalloc((void **)&key->d_counts, 8));
+  if (on) { HIP_TRY(ctx, hipMemset(key->d_counts, 0, 8)); key->host_witnesses = 0; }
+  key->counting = on != 0;
+  return B3W_OK;
+}
+
+int32_t b3w_commit_key_counts(const b3w_commit_key *key, uint64_t out[2]) {
+  if (!key || !out) return B3W_E_BAD_ARGUMENT;
+  b3w_ctx *ctx = key->ctx;
+  out[0] = 0; out[1] = key->host_witnesses;
+  if (!key->d_counts) return B3W_OK;
+  ON_DEVICE(ctx);
+  HIP_TRY(ctx, hipDeviceSynchronize());
+  unsigned long long v = 0;
+  HIP_TRY(ctx, hipMemcpy(&v, key->d_counts, 8, hipMemcpyDeviceToHost));
+  out[0] = v;
+  return B3W_OK;
 }
 
 int32_t b3w_batch_commit_device(b3w_ctx *ctx, const b3w_commit_key *key, const uint8_t *d_bodies, uint32_t n, uint64_t pitch,
@@ -1519,7 +1576,8 @@ int32_t b3w_batch_commit_device(b3w_ctx *ctx, const b3w_commit_key *key, const u
   }
   const int rc = b3w_launch_commit(d_bodies, n, pitch, key->first_slot, key->nslots, key->d_slotdesc, nullptr, 0, nullptr, 0, key->d_table,
                                    key->nwin, key->window, k->d_sums, d_points, d_status, key->d_invtab, key->inv_nk, key->d_invmeta,
-                                   static_cast<const uint32_t *>(ctx->d_aux), &key->curve, (hipStream_t)stream);
+                                   static_cast<const uint32_t *>(ctx->d_aux), key->counting ? key->d_counts : nullptr, &key->curve, (hipStream_t)stream);
+  if (rc == 0 && key->counting) k->host_witnesses += n;
   return rc ? hip_fail(ctx, (hipError_t)rc, "commit launch") : B3W_OK;
 }
 
@@ -1559,7 +1617,8 @@ int32_t b3w_commit_records_device(b3w_ctx *ctx, const b3w_commit_key *key, const
     if (lrc == 0)
       lrc = b3w_launch_commit(nullptr, cn, 0, key->first_slot, key->nslots, key->d_slotdesc, k->d_images, cap, key->d_runs, key->nruns,
                               key->d_table, key->nwin, key->window, k->d_sums, d_points + (uint64_t)c0 * 64, nullptr, key->d_invtab, key->inv_nk,
-                              nullptr, nullptr, &key->curve, (hipStream_t)stream);
+                              nullptr, nullptr, key->counting ? key->d_counts : nullptr, &key->curve, (hipStream_t)stream);
+    if (lrc == 0 && key->counting) k->host_witnesses += cn;
     if (lrc) return hip_fail(ctx, (hipError_t)lrc, "commit-from-records launch");
   }
   return B3W_OK;
@@ -1617,10 +1676,18 @@ int32_t b3w_batch_commit(b3w_batch *b, const b3w_commit_key *key, uint8_t *host_
 
 #include <dlfcn.h>
 
+#include "b3w_hostcomm.h"
+
 struct b3w_comm {
   b3w_ctx *ctx = nullptr;
-  void *comm = nullptr;          // ncclComm_t
   int32_t rank = 0, nranks = 1;
+  enum Kind { RCCL, HOST, EXTERNAL } kind = RCCL;
+  void *comm = nullptr;          // RCCL: ncclComm_t
+  B3wHostComm *host = nullptr;   // HOST: the shared-memory segment, and two pinned staging buffers that grow with the messages
+  uint8_t *h_send = nullptr, *h_recv = nullptr;
+  uint64_t h_cap = 0;
+  b3w_allgather_fn fn = nullptr; // EXTERNAL: the caller's collective
+  void *user = nullptr;
 };
 
 namespace {
@@ -1679,16 +1746,78 @@ int32_t b3w_comm_create(b3w_ctx *ctx, const uint8_t id[B3W_COMM_ID_BYTES], int32
   return B3W_OK;
 }
 
+int32_t b3w_comm_create_host(b3w_ctx *ctx, const char *name, int32_t rank, int32_t nranks, b3w_comm **out) {
+  if (!ctx || !name || !out || nranks < 1 || rank < 0 || rank >= nranks) return B3W_E_BAD_ARGUMENT;
+  *out = nullptr;
+  const char *t = getenv("B3W_HOSTCOMM_TIMEOUT_S");
+  char err[256] = "";
+  B3wHostComm *hc = nullptr;
+  // 4 MiB per rank at a time: config 4's exchanges (256 KiB of h_out per rank at two ranks) go through in one piece
+  if (b3w_hostcomm_open(name, rank, nranks, 4u << 20, t ? atof(t) : 120.0, &hc, err, sizeof err) != 0) {
+    ctx->last_error = err;
+    return B3W_E_RCCL;
+  }
+  b3w_comm *c = new b3w_comm;
+  c->ctx = ctx; c->rank = rank; c->nranks = nranks; c->kind = b3w_comm::HOST; c->host = hc;
+  *out = c;
+  return B3W_OK;
+}
+
+int32_t b3w_comm_create_external(b3w_ctx *ctx, int32_t rank, int32_t nranks, b3w_allgather_fn allgather, void *user, b3w_comm **out) {
+  if (!ctx || !allgather || !out || nranks < 1 || rank < 0 || rank >= nranks) return B3W_E_BAD_ARGUMENT;
+  b3w_comm *c = new b3w_comm;
+  c->ctx = ctx; c->rank = rank; c->nranks = nranks; c->kind = b3w_comm::EXTERNAL; c->fn = allgather; c->user = user;
+  *out = c;
+  return B3W_OK;
+}
+
+int32_t b3w_comm_rank(const b3w_comm *c) { return c ? c->rank : -1; }
+int32_t b3w_comm_size(const b3w_comm *c) { return c ? c->nranks : 0; }
+
 void b3w_comm_destroy(b3w_comm *c) {
   if (!c) return;
   DeviceGuard guard(c->ctx->device);
   if (c->comm && rccl.CommDestroy) (void)rccl.CommDestroy(c->comm);
+  if (c->h_send) (void)hipHostFree(c->h_send);
+  if (c->h_recv) (void)hipHostFree(c->h_recv);
+  b3w_hostcomm_close(c->host);
   delete c;
 }
+
+namespace {
+// HOST transport: device -> pinned host -> shared-memory all-gather -> device, ordered on `stream` by waiting for it (twice)
+int32_t host_allgather(b3w_comm *c, const void *d_send, void *d_recv, uint64_t bytes, hipStream_t st) {
+  b3w_ctx *ctx = c->ctx;
+  if (bytes > c->h_cap) {
+    if (c->h_send) (void)hipHostFree(c->h_send);
+    if (c->h_recv) (void)hipHostFree(c->h_recv);
+    c->h_send = c->h_recv = nullptr; c->h_cap = 0;
+    HIP_TRY(ctx, hipHostMalloc((void **)&c->h_send, bytes, hipHostMallocDefault));
+    HIP_TRY(ctx, hipHostMalloc((void **)&c->h_recv, bytes * (uint64_t)c->nranks, hipHostMallocDefault));
+    c->h_cap = bytes;
+  }
+  HIP_TRY(ctx, hipMemcpyAsync(c->h_send, d_send, bytes, hipMemcpyDeviceToHost, st));
+  HIP_TRY(ctx, hipStreamSynchronize(st));
+  char err[256] = "";
+  if (b3w_hostcomm_allgather(c->host, c->h_send, c->h_recv, bytes, err, sizeof err) != 0) { ctx->last_error = err; return B3W_E_RCCL; }
+  HIP_TRY(ctx, hipMemcpyAsync(d_recv, c->h_recv, bytes * (uint64_t)c->nranks, hipMemcpyHostToDevice, st));
+  HIP_TRY(ctx, hipStreamSynchronize(st));                     // the staging buffer is free for the next call, whatever its stream
+  return B3W_OK;
+}
+}  // namespace
 
 int32_t b3w_comm_allgather(b3w_comm *c, const void *d_send, void *d_recv, uint64_t bytes_per_rank, void *stream) {
   if (!c || !d_send || !d_recv || !bytes_per_rank) return B3W_E_BAD_ARGUMENT;
   ON_DEVICE(c->ctx);
+  if (c->kind == b3w_comm::HOST) return host_allgather(c, d_send, d_recv, bytes_per_rank, (hipStream_t)stream);
+  if (c->kind == b3w_comm::EXTERNAL) {
+    const int32_t rc = c->fn(c->user, d_send, d_recv, bytes_per_rank, stream);
+    if (rc != 0) {
+      c->ctx->last_error = "the caller's all-gather (b3w_comm_create_external) returned " + std::to_string(rc);
+      return B3W_E_RCCL;
+    }
+    return B3W_OK;
+  }
   const int rc = rccl.AllGather(d_send, d_recv, (size_t)bytes_per_rank, /* ncclInt8 */ 0, c->comm, (hipStream_t)stream);
   if (rc != 0) { c->ctx->last_error = std::string("ncclAllGather: ") + rccl.GetErrorString(rc); return B3W_E_RCCL; }
   return B3W_OK;
@@ -1736,6 +1865,8 @@ struct b3w_chain {
     uint32_t *d_cv_pad = nullptr, *d_cv_gath = nullptr, *d_cv_all = nullptr;
     uint32_t *d_h_send = nullptr, *d_h_recv = nullptr;
     uint64_t *d_tab = nullptr;                        // per rank {leaf dst row, leaf rows, parent dst row, parent rows}
+    hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};   // around the chunk-CV exchange and around the h_out exchange (b3w_chain_exchange_ms)
+    bool timed[2] = {false, false};
   } x;
 };
 
@@ -1918,6 +2049,7 @@ void b3w_chain_destroy(b3w_chain *c) {
   }
   for (void *q : {(void *)c->x.d_cv_pad, (void *)c->x.d_cv_gath, (void *)c->x.d_cv_all, (void *)c->x.d_h_send, (void *)c->x.d_h_recv, (void *)c->x.d_tab})
     if (q) (void)hipFree(q);
+  for (hipEvent_t e : c->x.ev) if (e) (void)hipEventDestroy(e);
   if (c->d_pre) (void)hipFree(c->d_pre);
   if (c->d_recs) (void)hipFree(c->d_recs);
   if (c->d_cvs) (void)hipFree(c->d_cvs);
@@ -2015,6 +2147,7 @@ int32_t chain_exchange(b3w_chain *c, int32_t nranks) {
   b3w_ctx *ctx = c->ctx;
   for (void *q : {(void *)x.d_cv_pad, (void *)x.d_cv_gath, (void *)x.d_cv_all, (void *)x.d_h_send, (void *)x.d_h_recv, (void *)x.d_tab})
     if (q) (void)hipFree(q);
+  for (hipEvent_t ev : x.ev) if (ev) (void)hipEventDestroy(ev);
   x = b3w_chain::Exchange();
   std::vector<uint64_t> tab(4 * (size_t)nranks);
   uint64_t mxc = 0, mxl = 0, mxp = 0;
@@ -2038,6 +2171,7 @@ int32_t chain_exchange(b3w_chain *c, int32_t nranks) {
   if (e == hipSuccess) e = hipMemset(x.d_cv_pad, 0, x.mx_chunks * 32);           // the padding goes over the wire: zeros, once
   if (e == hipSuccess) e = hipMemset(x.d_h_send, 0, hwords * 4);
   if (e == hipSuccess) e = hipMemcpy(x.d_tab, tab.data(), tab.size() * 8, hipMemcpyHostToDevice);
+  for (int i = 0; i < 4 && e == hipSuccess; i++) e = hipEventCreate(&x.ev[i]);
   if (e != hipSuccess) return e == hipErrorOutOfMemory ? B3W_E_NOT_ENOUGH_MEMORY : hip_fail(ctx, e, "exchange buffers of the sharded pass");
   x.nranks = nranks;
   return B3W_OK;
@@ -2060,8 +2194,8 @@ int32_t b3w_chain_run_parents_sharded(b3w_chain *c, b3w_comm *comm, b3w_batch_co
   if ((rc = chain_exchange(c, comm->nranks)) != B3W_OK) return rc;
   hipStream_t st = (hipStream_t)stream;
   b3w_chain::Exchange &x = c->x;
-  hipError_t e = hipSuccess;
-  if (c->nl) e = hipMemcpyAsync(x.d_cv_pad, c->d_cvs, (uint64_t)c->nl * 32, hipMemcpyDeviceToDevice, st);
+  hipError_t e = hipEventRecord(x.ev[0], st);
+  if (e == hipSuccess && c->nl) e = hipMemcpyAsync(x.d_cv_pad, c->d_cvs, (uint64_t)c->nl * 32, hipMemcpyDeviceToDevice, st);
   rc = e == hipSuccess ? b3w_comm_allgather(comm, x.d_cv_pad, x.d_cv_gath, x.mx_chunks * 32, stream) : hip_fail(ctx, e, "chunk CV staging");
   for (int32_t r = 0; r < comm->nranks && rc == B3W_OK; r++) {                 // drop the padding: global chunk order
     uint64_t f = 0; uint32_t k = 0;
@@ -2069,7 +2203,9 @@ int32_t b3w_chain_run_parents_sharded(b3w_chain *c, b3w_comm *comm, b3w_batch_co
     if (k && (e = hipMemcpyAsync(x.d_cv_all + f * 8, x.d_cv_gath + (uint64_t)r * x.mx_chunks * 8, (uint64_t)k * 32, hipMemcpyDeviceToDevice, st)) != hipSuccess)
       rc = hip_fail(ctx, e, "chunk CV compaction");
   }
+  if (rc == B3W_OK && (e = hipEventRecord(x.ev[1], st)) != hipSuccess) rc = hip_fail(ctx, e, "hipEventRecord");
   if (rc) return rc;
+  x.timed[0] = true;
   return b3w_chain_run_parents(c, x.d_cv_all, consumer, user, stream);
 }
 
@@ -2083,6 +2219,7 @@ int32_t b3w_chain_allgather_hout(b3w_chain *c, b3w_comm *comm, uint32_t *d_leaf_
   hipStream_t st = (hipStream_t)stream;
   b3w_chain::Exchange &x = c->x;
   // wire format per rank: [leaf h_out, mx_leaf rows | parent h_out, mx_par rows], 8 words a row
+  HIP_TRY(ctx, hipEventRecord(x.ev[2], st));
   int e = b3w_launch_pack_hout(c->d_pub, 0, c->n_leaf, x.d_h_send, st);
   if (e == 0) e = b3w_launch_pack_hout(c->d_pub, c->n_leaf, c->n_par, x.d_h_send + x.mx_leaf * 8, st);
   if (e) return hip_fail(ctx, (hipError_t)e, "h_out packing");
@@ -2091,6 +2228,21 @@ int32_t b3w_chain_allgather_hout(b3w_chain *c, b3w_comm *comm, uint32_t *d_leaf_
   e = b3w_launch_unpack_hout(x.d_h_recv, block_words, x.mx_leaf * 8, x.d_tab, (uint32_t)comm->nranks, x.mx_leaf + x.mx_par, d_leaf_hout,
                              x.mx_par ? d_parent_hout : nullptr, st);
   if (e) return hip_fail(ctx, (hipError_t)e, "h_out unpacking");
+  HIP_TRY(ctx, hipEventRecord(x.ev[3], st));
+  x.timed[1] = true;
+  return B3W_OK;
+}
+
+int32_t b3w_chain_exchange_ms(b3w_chain *c, float out_ms[2]) {
+  if (!c || !out_ms) return B3W_E_BAD_ARGUMENT;
+  b3w_ctx *ctx = c->ctx;
+  ON_DEVICE(ctx);
+  for (int k = 0; k < 2; k++) {
+    out_ms[k] = 0.0f;
+    if (!c->x.timed[k]) continue;
+    HIP_TRY(ctx, hipEventSynchronize(c->x.ev[2 * k + 1]));
+    HIP_TRY(ctx, hipEventElapsedTime(&out_ms[k], c->x.ev[2 * k], c->x.ev[2 * k + 1]));
+  }
   return B3W_OK;
 }
 

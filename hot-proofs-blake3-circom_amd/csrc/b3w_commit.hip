@@ -765,7 +765,8 @@ __global__ __launch_bounds__(T * WPB) __attribute__((amdgpu_waves_per_eu(3, 3)))
                                                          int32_t *__restrict__ status,
                                                          const uint32_t *__restrict__ invtab /* or null: the O2 nova circuits' inverse points, b3w_commit_invtab_kernel */,
                                                          uint32_t inv_nk, const uint32_t *__restrict__ invmeta /* bodies mode: gadget slots, input slots, first virtual slots */,
-                                                         const uint32_t *__restrict__ aux /* bodies mode: the prime, then 1 / k as scalars */, CV C) {
+                                                         const uint32_t *__restrict__ aux /* bodies mode: the prime, then 1 / k as scalars */,
+                                                         unsigned long long *__restrict__ adds /* or null: += mixed additions of phase 2 (b3w_commit_key_counts) */, CV C) {
   extern __shared__ uint32_t lds[];
   __shared__ uint32_t bad[WPB];
   // invtab: per IsZero gadget of the step 0 = nothing to add (k = 0: the inverse is 0; or a rejected step), +-mag = the tabulated
@@ -906,7 +907,7 @@ __global__ __launch_bounds__(T * WPB) __attribute__((amdgpu_waves_per_eu(3, 3)))
   }
   __syncthreads();
   J9 acc = j9_infinity();
-  uint32_t win = live ? t : nwin;
+  uint32_t win = live ? t : nwin, nadd = 0;
   while (true) {
     // skip ahead to this lane's next window with a set bit
     uint32_t m = 0;
@@ -924,8 +925,10 @@ __global__ __launch_bounds__(T * WPB) __attribute__((amdgpu_waves_per_eu(3, 3)))
     if (has) {
       const uint32_t *pt = table + ((uint64_t)win * B3W_COMMIT_ENTRIES(W) + m - 1) * 16;
       const Fp x2 = load_fp(pt), y2 = load_fp(pt + 8);
-      if (!(fp_is_zero(x2) && fp_is_zero(y2)))             // (0, 0) is not on these curves (b != 0): the table's infinity
+      if (!(fp_is_zero(x2) && fp_is_zero(y2))) {           // (0, 0) is not on these curves (b != 0): the table's infinity
         j9_madd(acc, to29(x2), to29(y2), C);
+        nadd++;
+      }
       win += T;
     }
   }
@@ -937,7 +940,12 @@ __global__ __launch_bounds__(T * WPB) __attribute__((amdgpu_waves_per_eu(3, 3)))
       const Fp x2 = load_fp(pt), y2 = load_fp(pt + 8);
       if (fp_is_zero(x2) && fp_is_zero(y2)) continue;          // (the gadget's slot is not committed)
       j9_madd(acc, to29(x2), to29(y2), C);
+      nadd++;
     }
+  if (adds) {                                                // (uniform: a statistics pass, b3w_commit_key_count)
+    for (int o = 32; o >= 1; o >>= 1) nadd += __shfl_xor(nadd, o);
+    if ((threadIdx.x & 63) == 0) atomicAdd(adds, (unsigned long long)nadd);
+  }
   __syncthreads();                                           // every lane is done with the bit string: the tree takes its place
   // LDS tree over each witness's T partial sums (infinity travels as ZZ = 0).  The additions of all WPB witnesses of a
   // level are dealt to the first threads of the workgroup, so whole waves drop out instead of running half empty
@@ -1069,8 +1077,8 @@ extern "C" int b3w_launch_commit(const uint8_t *d_bodies, uint32_t n, uint64_t p
                                  const uint32_t *d_slotdesc, const uint32_t *d_images /* or null */, uint32_t img_row, const uint32_t *d_runs,
                                  uint32_t nruns, const uint32_t *d_table, uint32_t nwin, uint32_t window,
                                  uint32_t *d_sums /* n * B3W_COMMIT_SUM_WORDS scratch */, uint8_t *d_out, int32_t *d_status,
-                                 const uint32_t *d_invtab, uint32_t inv_nk, const uint32_t *d_invmeta, const uint32_t *d_aux, const B3wCurve *curve,
-                                 hipStream_t stream) {
+                                 const uint32_t *d_invtab, uint32_t inv_nk, const uint32_t *d_invmeta, const uint32_t *d_aux,
+                                 unsigned long long *d_adds, const B3wCurve *curve, hipStream_t stream) {
   if (!n) return 0;
   if (!d_images && !(d_invtab && d_invmeta && d_aux)) { d_invtab = nullptr; d_invmeta = nullptr; }      // (bodies mode needs all three)
   if (window != B3W_COMMIT_WINDOW_SMALL && window != B3W_COMMIT_WINDOW_LARGE) return (int)hipErrorInvalidValue;
@@ -1092,7 +1100,7 @@ extern "C" int b3w_launch_commit(const uint8_t *d_bodies, uint32_t n, uint64_t p
     if ((size_t)region * WPB * 4 > 64 * 1024) return (int)hipErrorInvalidValue;   /* LDS of one workgroup (nova O1: 54 KB) */ \
     hipLaunchKernelGGL((b3w_commit_kernel<T, WPB, W, CV>), dim3((n + WPB - 1) / WPB), dim3(T * WPB), region * WPB * 4, stream, d_bodies, n, \
                        pitch, first_slot, nslots, d_slotdesc, d_images, img_row, reinterpret_cast<const uint2 *>(d_runs), nruns, region, d_table, nwin, \
-                       d_sums, d_status, d_invtab, inv_nk, d_invmeta, d_aux, cv);                                         \
+                       d_sums, d_status, d_invtab, inv_nk, d_invmeta, d_aux, d_adds, cv);                                         \
   }
   if (window == B3W_COMMIT_WINDOW_LARGE) {
     if (vesta) B3W_COMMIT_LAUNCH(64, 4, B3W_COMMIT_WINDOW_LARGE, B3wCurve9Vesta, c9v)

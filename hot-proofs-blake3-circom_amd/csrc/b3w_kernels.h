@@ -47,6 +47,8 @@ extern "C" int b3w_place_free(void *ptr);
 extern "C" void b3w_place_trim(void);
 extern "C" void b3w_place_configure(int64_t search_gib, int64_t pool_gib);      // < 0: leave as is
 extern "C" void b3w_place_stats(int device, uint64_t out[6]);
+extern "C" void b3w_place_search_limit(double seconds);                         // <= 0: none
+extern "C" void b3w_place_search_stats(int device, double out[4]);             // seconds, GiB walked, time-outs, the limit
 
 // b3w_commit.hip: Pedersen commitments of witness bodies (on-device consumer).
 // Window width W (virtual slots per window, 2^W - 1 tabulated subset sums each) is a property of the key:
@@ -76,6 +78,7 @@ extern "C" int b3w_launch_commit(const uint8_t *d_bodies, uint32_t n, uint64_t p
                                  const uint32_t *d_invmeta /* bodies mode with code-5 slots: [0, 67) committed slot of gadget j, [67, 71) witness slots of
                                                               n_blocks, block_count, total_depth, depth, [71, 138) first virtual slot of gadget j's slot */,
                                  const uint32_t *d_aux /* ... and the context's scalars: [0, 8) the prime, [16 + 8 k, + 8) 1 / k */,
+                                 unsigned long long *d_adds /* or null: += the mixed additions of this launch (statistics) */,
                                  const B3wCurve *curve, hipStream_t stream);
 // O2 nova circuits, records mode: invtab[j * nk + mag - 1] = (1 / mag) * G of the slot holding IsZero gadget j's inverse
 // (d_inverses: 8 words per magnitude, standard form — the witness kernels' table; d_inv_slot[j] = committed slot index or ~0)

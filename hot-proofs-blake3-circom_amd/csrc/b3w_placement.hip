@@ -41,6 +41,7 @@
 #include <math.h>
 #include <vector>
 #include <algorithm>
+#include <chrono>
 #include <mutex>
 
 #include "b3w_kernels.h"
@@ -92,6 +93,9 @@ struct Pool {
   hipEvent_t e0 = nullptr, e1 = nullptr;
   hipStream_t stream = nullptr;                     // the probes' own stream: other work of the process does not sit between the events
   uint64_t handles_created = 0;
+  uint64_t search_handles = 0;                      // ... of them by searches for a second class
+  double search_seconds = 0;                        // wall time inside b3w_place_alloc calls that wanted a mixed buffer
+  uint32_t search_timeouts = 0;                     // searches ended by the time limit
   hipMemAllocationProp prop{};
   hipMemAccessDesc acc{};
 };
@@ -101,9 +105,11 @@ struct Pool {
 struct Knobs {
   int64_t search_gib = -1;     // < 0: 16 x the buffer, at least 24 GiB, at most 160 GiB
   int64_t pool_gib = -1;       // < 0: POOL_CAP_DEFAULT per label
+  double search_s = 30.0;      // a search that has not found a second class after this many seconds ends: the buffer is plain
   Knobs() {
     if (const char *e = getenv("B3W_PLACE_SEARCH_GIB")) search_gib = atoll(e);
     if (const char *e = getenv("B3W_PLACE_POOL_GIB")) pool_gib = atoll(e);
+    if (const char *e = getenv("B3W_PLACE_SEARCH_S")) search_s = atof(e);
   }
 };
 Knobs &knobs() { static Knobs k; return k; }
@@ -112,6 +118,8 @@ uint64_t search_cap(uint64_t own) {
   if (knobs().search_gib >= 0) return std::min<uint64_t>((uint64_t)knobs().search_gib * GiB, SEARCH_CAP_MAX);
   return std::min<uint64_t>(std::max<uint64_t>(16 * own, 24 * GiB), SEARCH_CAP_MAX);
 }
+
+double wall_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 std::mutex &mtx() { static std::mutex m; return m; }
 std::vector<Pool *> &pools() { static std::vector<Pool *> p; return p; }
@@ -185,7 +193,7 @@ uint8_t label_slot(Pool *p, uint32_t slot) {
 // First use on a device: walk fresh handles until one is clearly fast with h0 and the next one agrees; fix the
 // references and the threshold.  Handles seen on the way are labelled and returned in `got`.  `budget` = handles
 // this search may still create.
-bool calibrate(Pool *p, uint32_t &budget, std::vector<Cand> &got) {
+bool calibrate(Pool *p, uint32_t &budget, std::vector<Cand> &got, double deadline, bool &timed_out) {
   Cand r{};
   if (!budget || !create_handle(p, &r.h)) return false;
   budget--;
@@ -195,6 +203,7 @@ bool calibrate(Pool *p, uint32_t &budget, std::vector<Cand> &got) {
   std::vector<double> r0;
   int cand = -1;
   while (budget) {
+    if (wall_s() > deadline) { timed_out = true; break; }
     Cand c{};
     if (!create_handle(p, &c.h)) break;
     budget--;
@@ -227,7 +236,7 @@ bool calibrate(Pool *p, uint32_t &budget, std::vector<Cand> &got) {
     r.label = LM;
     got.push_back(r);
     for (Cand &c : seen) { c.label = LM; got.push_back(c); }
-    p->hopeless = (uint64_t)seen.size() * HANDLE >= 64 * GiB;   // a short walk (little free memory right now) may be retried
+    p->hopeless = !timed_out && (uint64_t)seen.size() * HANDLE >= 64 * GiB;   // a short walk (little free memory right now, the time limit) may be retried
     return false;
   }
   p->h0 = r.h; p->slot_h0 = r.slot;
@@ -294,11 +303,19 @@ extern "C" int b3w_place_alloc(int device, uint64_t bytes, int want_mixed, void 
   int alone = -1;
   std::vector<Cand> got;
   got.swap(p->spare);                                          // labelled earlier, still mapped in their probe slots
+  const double t_begin = wall_s(), deadline = t_begin + (knobs().search_s > 0 ? knobs().search_s : 1e9);
+  const uint64_t created_before = p->handles_created;
+  bool timed_out = false;
+  struct Account {                                             // whatever way the call ends
+    Pool *p; double t0; uint64_t h0; bool on; bool *to;
+    ~Account() { if (on) { p->search_seconds += wall_s() - t0; p->search_handles += p->handles_created - h0; if (*to) p->search_timeouts++; } }
+  } account{p, t_begin, created_before, want_mixed != 0, &timed_out};
   if (want_mixed && !p->hopeless) {
-    if (!p->refs) (void)calibrate(p, budget, got);
+    if (!p->refs) (void)calibrate(p, budget, got, deadline, timed_out);
     for (const Cand &c : got) sort_in(c);
     got.clear();
     while (p->refs && (alone = split(alone1)) < 0 && budget) {
+      if (wall_s() > deadline) { timed_out = true; break; }
       Cand c{};
       if (!create_handle(p, &c.h)) break;
       budget--;
@@ -377,6 +394,8 @@ extern "C" int b3w_place_alloc(int device, uint64_t bytes, int want_mixed, void 
       order.push_back(c);
     }
   }
+  if (timed_out && getenv("B3W_PLACE_DEBUG"))
+    fprintf(stderr, "b3w_place_alloc: no second class of memory within %.0f s (B3W_PLACE_SEARCH_S): this buffer is plain\n", knobs().search_s);
   if (getenv("B3W_PLACE_DEBUG")) {
     fprintf(stderr, "b3w_place_alloc: %u pieces, found=%d, thr=%.0f (lo %.0f hi %.0f), slow seams left=%u, spare %zu, rejects %zu, slots used %u\n  ", nh,
             (int)found, p->thr, p->lo, p->hi, slow_seams, extra.size(), rejects.size(), p->next_slot);
@@ -439,6 +458,25 @@ extern "C" void b3w_place_configure(int64_t search_gib, int64_t pool_gib) {
   std::lock_guard<std::mutex> guard(mtx());
   if (search_gib >= 0) knobs().search_gib = search_gib;
   if (pool_gib >= 0) knobs().pool_gib = pool_gib;
+}
+
+extern "C" void b3w_place_search_limit(double seconds) {      // <= 0: no time limit
+  std::lock_guard<std::mutex> guard(mtx());
+  knobs().search_s = seconds;
+}
+
+// out: seconds inside searching b3w_place_alloc calls, GiB of new physical memory those calls created, searches ended by the
+// time limit, the time limit in seconds
+extern "C" void b3w_place_search_stats(int device, double out[4]) {
+  std::lock_guard<std::mutex> guard(mtx());
+  out[0] = out[1] = out[2] = 0;
+  out[3] = knobs().search_s;
+  for (Pool *p : pools()) {
+    if (p->device != device) continue;
+    out[0] = p->search_seconds;
+    out[1] = (double)p->search_handles * (double)HANDLE / (double)GiB;
+    out[2] = p->search_timeouts;
+  }
 }
 
 // out: arena bytes, arena bytes used up (never reused), pooled bytes, bytes of live placed buffers, live placed buffers,

@@ -1456,17 +1456,34 @@ extern "C" int b3w_launch_r1cs_stream(const uint8_t *d_bodies, uint32_t n, uint6
   static const int env_waves = getenv("B3W_R1CS_WAVES") ? atoi(getenv("B3W_R1CS_WAVES")) : 0;
   static const int env_wgs = getenv("B3W_R1CS_WGS") ? atoi(getenv("B3W_R1CS_WGS")) : 0;         // workgroups per CU
   static const int env_grid = getenv("B3W_R1CS_GRID") ? atoi(getenv("B3W_R1CS_GRID")) : 0;
-  static const uint32_t env_dbg = getenv("B3W_R1CS_DBG") ? (uint32_t)atoi(getenv("B3W_R1CS_DBG")) : 0u;     // experiments (times only, verdicts meaningless): 1 no words / rows / verdicts, 2 no pack, 4 or 8 every unit fetches the tile's first body (no HBM traffic), 32 no general words
+  // The experiment switches exist only in a diagnostic build (-DB3W_R1CS_DIAG: B3W_BUILD_DIAG=1 python -m ...build): B3W_R1CS_DBG
+  // switches phases of the kernel off (times only — such a launch marks EVERY body as violating, it cannot pass for a check) and
+  // B3W_R1CS_STAMPS prints per-phase cycle counts after each launch (synchronises; refused while the stream is capturing).
+#ifdef B3W_R1CS_DIAG
+  static const uint32_t env_dbg = getenv("B3W_R1CS_DBG") ? (uint32_t)atoi(getenv("B3W_R1CS_DBG")) : 0u;     // 1 no words / rows / verdicts, 2 no pack, 4 or 8 every unit fetches the tile's first body (no HBM traffic), 32 no general words
+#else
+  static const uint32_t env_dbg = 0u;
+#endif
   if (sys->max_tile_rows > 2048u || sys->max_ext > 480u) return -6;
   int dev = 0;
   hipError_t e = hipGetDevice(&dev);
   if (e != hipSuccess) return (int)e;
   // the shapes: waves per workgroup; the default is the first
   struct Shape { int waves; const void *fn; };
+#ifdef B3W_R1CS_DIAG
   static const bool want_stamps = (getenv("B3W_R1CS_STAMPS") && atoi(getenv("B3W_R1CS_STAMPS"))) || env_dbg != 0u;      // (the diagnostic instantiation: phase stamps, experiment switches)
   static const bool print_stamps = getenv("B3W_R1CS_STAMPS") && atoi(getenv("B3W_R1CS_STAMPS"));
   static const Shape shapes[] = {{8, want_stamps ? reinterpret_cast<const void *>(&b3w_r1cs_stream_kernel<8, true>) : reinterpret_cast<const void *>(&b3w_r1cs_stream_kernel<8, false>)},
                                  {16, reinterpret_cast<const void *>(&b3w_r1cs_stream_kernel<16, false>)}};
+  if (print_stamps) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return (int)hipErrorStreamCaptureUnsupported; }
+  }
+#else
+  static const bool print_stamps = false;
+  static const Shape shapes[] = {{8, reinterpret_cast<const void *>(&b3w_r1cs_stream_kernel<8, false>)},
+                                 {16, reinterpret_cast<const void *>(&b3w_r1cs_stream_kernel<16, false>)}};
+#endif
   struct PerDevice { int cus = 0, lds = 0; bool attr[2] = {false, false}; };
   static PerDevice per[64];
   static std::mutex mu;
@@ -1527,7 +1544,10 @@ extern "C" int b3w_launch_r1cs_stream(const uint8_t *d_bodies, uint32_t n, uint6
         }
       }
     }
-    if (env_dbg) continue;                                 // (an experiment that skips phases leaves no valid masks behind)
+    if (env_dbg) {                                         // an experiment that skips phases leaves no valid masks behind: no verdict
+      if ((e = hipMemsetAsync(d_violations + b0, 0xFF, (size_t)nb * 4, stream)) != hipSuccess) return (int)e;
+      continue;
+    }
     const dim3 dgrid(((nb + 7) / 8) * 8 * ((sys->ntiles + B3W_R1CS_DEFERRED_TILES - 1u) / B3W_R1CS_DEFERRED_TILES));
     hipLaunchKernelGGL(b3w_r1cs_deferred_kernel, dgrid, dim3(64), 0, stream, d_bodies + (uint64_t)b0 * pitch, pitch, nb, *sys, d_scratch, bw,
                        *field, d_violations + b0, d_first ? d_first + b0 : nullptr, true);

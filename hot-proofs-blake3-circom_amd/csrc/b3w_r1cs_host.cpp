@@ -354,19 +354,12 @@ bool b3w_r1cs_host_build(const uint8_t *img, size_t len, const uint8_t prime_le[
   //   G  general: its lean words go to a flat list of entries evaluated one ENTRY per lane (contributions added into per-row sums
   //      in LDS), instead of one row per lane walking its words
   std::vector<uint32_t> srows, sgdesc(4 * (size_t)ntiles), sgwords, sgmeta;
-  std::vector<unsigned long long> coef_zlim(coefs.size(), 0ull);      // an element times coefficient c stays below 2^55 while it is below zlim
   uint32_t max_g_words = 0, max_g_rows = 0;
   // per tile and group of 64 LDS elements: the elements a booleanity or truth-table row of the tile takes for bits.  While none of
   // them is anything else (and wire 0 is 1) the kernel decides those rows without looking at them one by one.
   const uint32_t smask_groups = (T + ((max_ext + 32u) & ~31u) + 63u) >> 6;
   std::vector<unsigned long long> smask((size_t)ntiles * smask_groups, 0ull);
   if (tiled) {
-    for (size_t i = 0; i < coefs.size(); i++) {
-      const long long c = coef_small[i];
-      if (c == B3W_R1CS_NOT_SMALL) continue;
-      const unsigned long long mag = c < 0 ? 0ull - (unsigned long long)c : (unsigned long long)c;
-      coef_zlim[i] = mag <= 1 ? 1ull << 55 : (1ull << 55) / mag;
-    }
     uint32_t inv = P[0];                                   // Newton: p^-1 mod 2^32
     for (int i = 0; i < 5; i++) inv *= 2u - P[0] * inv;
     inv = 0u - inv;
@@ -421,7 +414,16 @@ bool b3w_r1cs_host_build(const uint8_t *img, size_t len, const uint8_t prime_le[
           srows.insert(srows.end(), {idx[0] | idx[1] << 16, 0x20000000u | (uint32_t)W.size() << 16 | idx[4], idx[2] | idx[3] << 16, it->second});
           continue;
         }
-        if (cls == 2 || ng >= 0xFFFFFFu) { srows.insert(srows.end(), {0u, 0x40000000u, 0u, 0u}); continue; }
+        // a bit run is packed as length (7 bits) | shift (6 bits) and the kernel shifts a run's sum inside 64 bits: a run the
+        // fields or that arithmetic cannot hold (none in these systems: runs are cut at 64 bits and small coefficients stay below
+        // 2^62) sends its row to the field arithmetic instead of overflowing the encoding
+        bool runs_fit = true;
+        for (uint32_t qq = off; qq < off + nw && runs_fit; qq++)
+          if ((lterms[qq] >> 16) == 0xFFFFu && qq + 1 < off + nw) {
+            const uint32_t w1 = lterms[++qq], len = w1 & 0xFFu, sh = (w1 >> 8) & 0xFFu;
+            runs_fit = len >= 1 && len <= 64 && sh + len <= 62;
+          }
+        if (cls == 2 || !runs_fit || ng >= 0xFFFFFFu) { srows.insert(srows.end(), {0u, 0x40000000u, 0u, 0u}); continue; }
         // entries {word, meta}: a TERM is  element | coefficient id << 16,  meta = part | row << 8;  a BIT RUN (two lean words) is
         // one entry  first element | length << 16 | shift << 23 | negative << 29,  meta = part | 8 | row << 8.  The tile's runs stand
         // first, padded with null entries (meta = 4) to a multiple of 64, then its terms: every chunk of 64 entries a wave takes is
@@ -487,7 +489,7 @@ bool b3w_r1cs_host_build(const uint8_t *img, size_t len, const uint8_t prime_le[
   H->trow_id = std::move(trow_id); H->trow_k = std::move(trow_k); H->tterms = std::move(tterms);
   H->ltdesc = std::move(ltdesc); H->lrows = std::move(lrows); H->lterms = std::move(lterms);
   H->srows = std::move(srows); H->sgdesc = std::move(sgdesc); H->sgwords = std::move(sgwords); H->sgmeta = std::move(sgmeta);
-  H->coef_zlim = std::move(coef_zlim); H->max_g_words = max_g_words; H->max_g_rows = max_g_rows;
+  H->max_g_words = max_g_words; H->max_g_rows = max_g_rows;
   H->smask = std::move(smask); H->smask_groups = smask_groups; H->scost = std::move(scost);
   return true;
 }

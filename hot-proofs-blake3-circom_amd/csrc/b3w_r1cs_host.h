@@ -24,10 +24,10 @@ struct B3wR1csHost {
   std::vector<uint32_t> tdesc, ttdesc, text, trows, trow_id, trow_k, tterms;      // 32-byte tile kernel
   std::vector<uint32_t> ltdesc, lrows, lterms;                                    // lean kernel: its own rows and term stream (bit runs folded)
   // stream kernel: one descriptor per tile row (same order as lrows; classes booleanity / truth table / always deferred / general),
-  // per tile {first general word, general words, general rows, 0}, the general rows' lean words and per word part | run-second-word
-  // << 2 | general row << 8; per coefficient the bound an element must stay below for its product to stay below 2^55
+  // per tile {first general entry, entries, general rows, run entries (padded to whole chunks of 64)}; the general rows' ENTRIES,
+  // one lane each — sgwords: a term = element | coefficient id << 16, a bit run = first element | length << 16 | shift << 23 |
+  // negative << 29; sgmeta: part (0 A, 1 B, 2 C) | 4 = null padding entry | 8 = bit run | general row << 8
   std::vector<uint32_t> srows, sgdesc, sgwords, sgmeta;
-  std::vector<unsigned long long> coef_zlim;
   uint32_t max_g_words = 0, max_g_rows = 0;
   std::vector<unsigned long long> smask;          // per tile x smask_groups: LDS elements the tile's booleanity / truth-table rows take for bits
   uint32_t smask_groups = 0;

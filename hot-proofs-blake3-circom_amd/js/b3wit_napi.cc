@@ -60,6 +60,7 @@ struct Api {
   decltype(&b3w_chain_parent_row) chain_parent_row;
   decltype(&b3w_comm_unique_id) comm_unique_id;
   decltype(&b3w_comm_create) comm_create;
+  decltype(&b3w_comm_create_host) comm_create_host;
   decltype(&b3w_comm_destroy) comm_destroy;
   decltype(&b3w_batch_allgather_public) batch_allgather_public;
   decltype(&b3w_r1cs_create) r1cs_create;
@@ -91,7 +92,7 @@ bool load_api() {
   SYM(write_wtns_header) SYM(last_error) SYM(public_words) SYM(batch_alloc) SYM(batch_free) SYM(batch_run)
   SYM(batch_outputs) SYM(batch_fetch) SYM(batch_write_wtns) SYM(batch_verify) SYM(batch_placement) SYM(bodies_trim)
   SYM(chain_create) SYM(chain_destroy) SYM(chain_run_leaves) SYM(chain_run_parents) SYM(chain_info) SYM(chain_outputs)
-  SYM(commit_key_create_ex) SYM(commit_key_create_folded) SYM(commit_key_destroy) SYM(commit_records) SYM(chain_commit_only) SYM(chain_commitments) SYM(batch_commit) SYM(chain_shard) SYM(chain_run_parents_sharded) SYM(chain_allgather_hout_host) SYM(chain_num_leaf_steps) SYM(chain_parent_row) SYM(comm_unique_id) SYM(comm_create) SYM(comm_destroy) SYM(batch_allgather_public)
+  SYM(commit_key_create_ex) SYM(commit_key_create_folded) SYM(commit_key_destroy) SYM(commit_records) SYM(chain_commit_only) SYM(chain_commitments) SYM(batch_commit) SYM(chain_shard) SYM(chain_run_parents_sharded) SYM(chain_allgather_hout_host) SYM(chain_num_leaf_steps) SYM(chain_parent_row) SYM(comm_unique_id) SYM(comm_create) SYM(comm_create_host) SYM(comm_destroy) SYM(batch_allgather_public)
   SYM(r1cs_create) SYM(r1cs_info) SYM(r1cs_destroy) SYM(batch_r1cs_check) SYM(chain_check_constraints) SYM(chain_violations)
 #undef SYM
   api.so = so;
@@ -657,6 +658,28 @@ napi_value CommCreate(napi_env env, napi_callback_info info) {
   return u;
 }
 
+// commCreateHost(handle, name: "/unique-to-the-job", rank, nranks): the same communicator over the host's shared memory
+// (b3w_comm_create_host: several ranks on one GPU, or no RCCL)
+napi_value CommCreateHost(napi_env env, napi_callback_info info) {
+  size_t argc = 4; napi_value argv[4];
+  NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
+  Handle *h = get_handle(env, argv[0]);
+  if (!h) return nullptr;
+  char name[256]; size_t nlen = 0;
+  NAPI_OK(napi_get_value_string_utf8(env, argv[1], name, sizeof name, &nlen));
+  int32_t rank = 0, nranks = 1;
+  NAPI_OK(napi_get_value_int32(env, argv[2], &rank));
+  NAPI_OK(napi_get_value_int32(env, argv[3], &nranks));
+  if (h->comm) { api.comm_destroy(h->comm); h->comm = nullptr; }
+  const int32_t rc = api.comm_create_host(h->ctx, name, rank, nranks, &h->comm);
+  if (rc != B3W_OK) return throw_status(env, h, rc, "b3w_comm_create_host failed");
+  h->rank = rank;
+  h->nranks = nranks;
+  napi_value u;
+  napi_get_undefined(env, &u);
+  return u;
+}
+
 // batchAllgatherPublic(handle[, generation]) -> Uint32Array(nranks * n * publicWords): the last batchRun's public outputs of every rank
 napi_value BatchAllgatherPublic(napi_env env, napi_callback_info info) {
   size_t argc = 2; napi_value argv[2];
@@ -702,6 +725,7 @@ napi_value Init(napi_env env, napi_value exports) {
       {"commitRecords", nullptr, CommitRecords, nullptr, nullptr, nullptr, napi_default, nullptr},
       {"commUniqueId", nullptr, CommUniqueId, nullptr, nullptr, nullptr, napi_default, nullptr},
       {"commCreate", nullptr, CommCreate, nullptr, nullptr, nullptr, napi_default, nullptr},
+      {"commCreateHost", nullptr, CommCreateHost, nullptr, nullptr, nullptr, napi_default, nullptr},
       {"batchAllgatherPublic", nullptr, BatchAllgatherPublic, nullptr, nullptr, nullptr, napi_default, nullptr},
   };
   napi_define_properties(env, exports, sizeof props / sizeof props[0], props);

@@ -235,6 +235,14 @@ class WitnessCalculator {
     this.nranks = nranks;
   }
 
+  // ---- extension: the same over the host's shared memory instead of RCCL (b3w_comm_create_host): several Node processes on
+  // ONE GPU, or a host without librccl.  name = "/unique-to-the-job", the same string on every rank.
+  joinRanksHost(name, rank, nranks) {
+    native().commCreateHost(this.instance, name, rank, nranks);
+    this.rank = rank;
+    this.nranks = nranks;
+  }
+
   // ---- extension (nova circuits): chained mode.  preimage -> the step witnesses of every chunk path, what
   // rust_fold/src/main.rs:41-203 folds one step at a time.  Returns { nLeafSteps, nParentSteps, nChunks, pathLen,
   // placement, publicOutputs: Uint32Array (15 words per step: n_blocks_out block_count_out h_out[8] ...),

@@ -55,6 +55,30 @@ def gather_public(pub_local, n_total=None, group=None):
     return gather_rows(pub_local, [e - s for s, e in (shard_range(n_total, r, world) for r in range(world))], group)
 
 
+def torch_allgather(device, group=None):
+    """An all-gather for Comm.external(ctx, rank, nranks, fn) over torch.distributed: fn(d_send, d_recv, bytes_per_rank, stream)
+    on raw device pointers.  "nccl" (= RCCL): the collective is enqueued behind `stream`'s work; "gloo" (CPU rehearsal of several
+    ranks on one GPU): staged through the host, waits for `stream`."""
+    class _Dev:
+        def __init__(self, ptr, n):
+            self.__cuda_array_interface__ = {"shape": (n,), "typestr": "|u1", "data": (ptr, False), "version": 2, "strides": None}
+
+    def fn(d_send, d_recv, nbytes, stream):
+        world = dist.get_world_size(group)
+        st = torch.cuda.ExternalStream(stream, device=device) if stream else torch.cuda.default_stream(device)
+        with torch.cuda.stream(st):
+            send = torch.as_tensor(_Dev(d_send, nbytes), device=device)
+            recv = torch.as_tensor(_Dev(d_recv, nbytes * world), device=device)
+            if dist.get_backend(group) == "gloo":
+                host = torch.empty(nbytes * world, dtype=torch.uint8)
+                dist.all_gather_into_tensor(host, send.cpu(), group=group)
+                recv.copy_(host)
+                st.synchronize()
+            else:
+                dist.all_gather_into_tensor(recv, send, group=group)
+    return fn
+
+
 class PublicExchange:
     """Pipelined exchange of the per-step public outputs: the all-gather of step i runs on RCCL's stream while the
     witness kernel of step i+1 runs on the compute stream.  `depth` public-output buffers alternate; a buffer is

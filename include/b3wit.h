@@ -41,7 +41,8 @@ extern "C" {
 #define B3W_E_DOMAIN             103 /* batch status only: record outside the batch kernels' domain (DESIGN.md "Input domain");
                                         b3w_calc_witness evaluates such inputs with the exact kernel instead */
 #define B3W_E_NOT_ALL_INPUTS     104 /* WC:166-168 "Not all inputs have been set" */
-#define B3W_E_RCCL               105 /* librccl missing or a collective failed (b3w_last_error has the text) */
+#define B3W_E_RCCL               105 /* librccl missing or a collective failed — RCCL's, the host transport's or the caller's
+                                        (b3w_last_error has the text) */
 
 typedef struct b3w_ctx b3w_ctx;
 typedef struct b3w_batch b3w_batch;
@@ -153,6 +154,14 @@ int32_t b3w_ctx_trim(b3w_ctx *ctx);
  * Also B3W_PLACE_SEARCH_GIB / B3W_PLACE_POOL_GIB in the environment.  Other allocators in the process (torch, RCCL) cannot
  * see pooled memory: b3w_bodies_trim hands it back. */
 void b3w_bodies_configure(int64_t search_gib, int64_t pool_gib);
+/* What placement costs.  A search ends — and the buffer is plain — when it has not found a second class of memory after
+ * `seconds` (default 30; B3W_PLACE_SEARCH_S; <= 0 = no limit) as well as when it runs out of its GiB budget.
+ * b3w_bodies_search_stats: out[0] = seconds spent inside searching b3w_bodies_alloc calls on the ctx's device so far (probes,
+ * seam checks), out[1] = GiB of new physical memory those searches created (most of it released again), out[2] = searches that
+ * ended on the time limit, out[3] = the time limit, out[4] = seconds spent in the real-kernel check of "mixed" buffers (the three
+ * plain yardstick buffers are measured once per context). */
+void b3w_bodies_search_limit(double seconds);
+int32_t b3w_bodies_search_stats(const b3w_ctx *ctx, double out[5]);
 /* out[0] address-space arena of the ctx's device in bytes, out[1] of it used up (never reused), out[2] pooled bytes,
  * out[3] bytes of live placed buffers, out[4] their number, out[5] physical 256 MiB handles created so far. */
 int32_t b3w_bodies_stats(const b3w_ctx *ctx, uint64_t out[6]);
@@ -267,6 +276,12 @@ int32_t b3w_commit_key_create_folded(b3w_ctx *ctx, int32_t curve, uint32_t first
                                      b3w_commit_key **out);
 int32_t b3w_slot_widths(b3w_ctx *ctx, uint16_t *out_bits /* witness_size */);
 uint32_t b3w_commit_key_window(const b3w_commit_key *key);     /* 12 or 16 */
+/* Statistics for harnesses: while counting is on (on != 0 resets and starts, 0 stops; both wait for the device), every commit
+ * launch with this key adds its number of mixed point additions (one per non-zero window and per tabulated inverse: 8 field
+ * multiplications + 2 squarings each — the work the kernel's VALU roofline is priced in) to a device counter.
+ * b3w_commit_key_counts: out[0] = additions, out[1] = witnesses committed, since counting was switched on (waits for the device). */
+int32_t b3w_commit_key_count(b3w_commit_key *key, int32_t on);
+int32_t b3w_commit_key_counts(const b3w_commit_key *key, uint64_t out[2]);
 void b3w_commit_key_destroy(b3w_commit_key *key);
 /* d_bodies and d_points 16-byte aligned, pitch a multiple of 16 (0 = witness_size * 32). */
 int32_t b3w_batch_commit_device(b3w_ctx *ctx, const b3w_commit_key *key, const uint8_t *d_bodies, uint32_t n, uint64_t pitch,
@@ -381,6 +396,24 @@ typedef struct b3w_comm b3w_comm;
 #define B3W_COMM_ID_BYTES 128
 int32_t b3w_comm_unique_id(uint8_t id[B3W_COMM_ID_BYTES]);
 int32_t b3w_comm_create(b3w_ctx *ctx, const uint8_t id[B3W_COMM_ID_BYTES], int32_t rank, int32_t nranks, b3w_comm **out);
+/* Two more transports behind the same b3w_comm, so that everything below that takes one — b3w_batch_allgather_public,
+ * b3w_chain_run_parents_sharded, b3w_chain_allgather_hout[_host] — also runs where RCCL cannot: several ranks on ONE GPU
+ * (rehearsals of an N-GPU job, tests of the rank > 0 paths), hosts without librccl, or a caller that already has collectives.
+ *   b3w_comm_create_host      the processes of one host, through a POSIX shared-memory segment: every rank passes the same
+ *                             `name` ("/something-unique-to-the-job"; rank 0 creates the segment, the others wait for it, the
+ *                             name is removed again once all are attached).  An all-gather is D2H into pinned memory, the
+ *                             segment, H2D — it WAITS for `stream` (not for stream capture).  Every wait gives up after
+ *                             B3W_HOSTCOMM_TIMEOUT_S seconds (default 120) with B3W_E_RCCL on all ranks.
+ *   b3w_comm_create_external  the caller's collective: `allgather(user, d_send, d_recv, bytes_per_rank, stream)` must leave
+ *                             d_recv[r * bytes_per_rank ..) = rank r's d_send[0 .. bytes_per_rank) for every r, ordered on `stream`
+ *                             like a kernel launched there (it may also simply wait for the stream), and return 0; any other
+ *                             value fails the calling entry point with B3W_E_RCCL.  Device pointers; called on the thread
+ *                             that called into the library, with ctx's device current. */
+typedef int32_t (*b3w_allgather_fn)(void *user, const void *d_send, void *d_recv, uint64_t bytes_per_rank, void *stream);
+int32_t b3w_comm_create_host(b3w_ctx *ctx, const char *name, int32_t rank, int32_t nranks, b3w_comm **out);
+int32_t b3w_comm_create_external(b3w_ctx *ctx, int32_t rank, int32_t nranks, b3w_allgather_fn allgather, void *user, b3w_comm **out);
+int32_t b3w_comm_rank(const b3w_comm *comm);
+int32_t b3w_comm_size(const b3w_comm *comm);
 void b3w_comm_destroy(b3w_comm *comm);
 int32_t b3w_comm_allgather(b3w_comm *comm, const void *d_send, void *d_recv, uint64_t bytes_per_rank, void *stream);
 /* The public outputs of the last b3w_batch_run of every rank (all ranks ran the same number n of witnesses):
@@ -443,6 +476,10 @@ int32_t b3w_chain_run_parents_sharded(b3w_chain *chain, b3w_comm *comm, b3w_batc
 int32_t b3w_chain_allgather_hout(b3w_chain *chain, b3w_comm *comm, uint32_t *d_leaf_hout, uint32_t *d_parent_hout, void *stream);
 /* The same into host arrays (for bindings that hold no device memory: Node).  Waits for `stream`. */
 int32_t b3w_chain_allgather_hout_host(b3w_chain *chain, b3w_comm *comm, uint32_t *host_leaf_hout, uint32_t *host_parent_hout, void *stream);
+/* How long the two exchanges of the last sharded pass took on this rank's device, in milliseconds (HIP events on `stream`):
+ * out_ms[0] = chunk chaining values (staging + all-gather + compaction, b3w_chain_run_parents_sharded), out_ms[1] = h_out (pack +
+ * all-gather + scatter, b3w_chain_allgather_hout); 0 for an exchange that has not run.  Waits for those events. */
+int32_t b3w_chain_exchange_ms(b3w_chain *chain, float out_ms[2]);
 int32_t b3w_chain_info(const b3w_chain *chain, uint64_t *n_leaf_steps, uint64_t *n_parent_steps, uint64_t *n_chunks,
                        uint32_t *path_len, int32_t *placement);
 /* Waits for `stream`, then copies the results to the host: (n_leaf + n_parent) * 15 public-output words, as many

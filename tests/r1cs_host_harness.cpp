@@ -77,7 +77,6 @@ static bool indices_ok(const B3wR1csHost &H) {
   }
   // the stream kernel's program: every index it follows inside its array
   CHECK(H.srows.size() == H.lrows.size() && H.sgdesc.size() == 4 * (size_t)H.ntiles && H.sgwords.size() == H.sgmeta.size());
-  CHECK(H.coef_zlim.size() == H.ncoef);
   CHECK(H.smask_groups == (T + ((H.max_ext + 32u) & ~31u) + 63u) / 64u && H.smask.size() == (size_t)H.ntiles * H.smask_groups);
   CHECK(H.scost.size() == (size_t)H.ntiles + 1 && H.scost[0] == 0);
   for (uint32_t t = 0; t < H.ntiles; t++) CHECK(H.scost[t + 1] > H.scost[t] && H.scost[t + 1] - H.scost[t] < (1ull << 24));

@@ -362,6 +362,46 @@ def test_bodies_mode_takes_a_tabulated_inverse_only_when_the_slot_holds_it():
     key.close(); ctx.close()
 
 
+def test_inverse_tables_only_for_the_curve_whose_order_is_the_circuits_prime():
+    """the tabulated (+-1/k) G stand for a slot that holds 1/k in the CIRCUIT's field; that is the scalar the windows
+    add up to only on the curve whose group order is that prime.  A key that pairs the --prime vesta circuit with BN254 G1 (the C
+    API allows it) must therefore go through the windows: bodies mode, records mode and the plain-integer sum agree."""
+    import torch
+    m = T.pkg()
+    W = T.workloads()
+    circuit, curve, first_slot = "nova_vesta", "bn254_g1", 22950          # the control block: all 67 inverses, few other slots
+    n = 3
+    recs = W.config3_nova(n, first=77)
+    assert any(int(r[14]) > 0 for r in recs)                               # a negative argument (-depth) among them
+    bad, bodies = T.oracle_batch_u32(circuit, recs)
+    assert bad == 0
+    vals = _slot_values(bodies.copy())
+    ctx = m.Context(circuit, 0)
+    gens = E.random_points(curve, ctx.witness_size - first_slot, seed=b"mismatched-pair")
+    key = m.CommitKey(ctx, curve, E.points_to_bytes(gens), first_slot, 12)
+    b = m.Batch(ctx, n)
+    b.run(recs)
+    pts, st = b.commit(key)
+    rpts, _, rst = key.commit_records(recs)
+    assert (st == 0).all() and (rst == 0).all() and np.array_equal(pts, rpts)
+    for i in range(n):
+        assert E.point_from_bytes(pts[i].tobytes()) == E.commit(vals[i][first_slot:], gens, curve), i
+    # b3w_commit_key_count: the kernel counts its mixed additions = the witnesses' non-zero 12-bit windows (no tabulated inverses here)
+    key.count(True)
+    b.commit(key)
+    adds, wits = key.counts()
+    key.count(False)
+    want = 0
+    for i in range(n):
+        bits = []
+        for s_, w in zip(range(first_slot, ctx.witness_size), ctx.slot_widths()[first_slot:]):
+            bits += [(vals[i][s_] >> k) & 1 for k in range(int(w))]
+        bits += [0] * (-len(bits) % 12)
+        want += sum(1 for k in range(0, len(bits), 12) if any(bits[k:k + 12]))
+    assert (adds, wits) == (want, n)
+    key.close(); b.close(); ctx.close()
+
+
 def test_chained_pass_commit_only_matches_the_commit_consumer():
     """b3w_chain_commit_only: the same points as committing every batch of bodies in the ring, and still BLAKE3(preimage)."""
     import torch, blake3_ref

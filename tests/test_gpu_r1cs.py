@@ -4,6 +4,7 @@ system is the one tools/gen_r1cs.py derives from the circuit text (pinned on the
 the reference's own witness); the kernel's verdicts are compared with a plain-integer evaluation (tests/r1cs_ref.py).
 None of this runs the witness kernels' TRACE code on the bodies under test."""
 import ctypes
+import os
 import random
 
 import numpy as np
@@ -518,3 +519,37 @@ print(json.dumps([r.tiled] + [[int(x), int(y)] for x, y in zip(viol.cpu().numpy(
         assert got[0] == (shape == "local"), "the local system must take the tile kernels, the scattered one the gather kernel"
         got = got[1:]
         assert got == want, (shape, mode, [(i, g, w) for i, (g, w) in enumerate(zip(got, want)) if g != w][:5])
+
+
+def test_experiment_switches_cannot_neuter_a_product_build():
+    """B3W_R1CS_DBG / B3W_R1CS_STAMPS are compiled only into a diagnostic build (-DB3W_R1CS_DIAG).  With both set in the
+    environment of a fresh process the product library still finds a tampered witness (and, were it a diagnostic build, a launch
+    with phases switched off marks every body as violating instead of passing it)."""
+    import subprocess, sys
+    script = r"""
+import numpy as np, torch, sys
+sys.path.insert(0, %r)
+import b3w_testlib as T
+m = T.pkg()
+ctx = m.Context("compression", 0)
+n = 64
+recs = m.workloads.config2_compression(n, first=5)
+dev = torch.device("cuda", 0)
+d_recs = torch.from_numpy(recs.view(np.int32)).to(dev)
+bodies = torch.zeros((n, ctx.body_bytes), dtype=torch.uint8, device=dev)
+ctx.run_device(d_recs.data_ptr(), n, bodies.data_ptr(), 0, 0, 0, 0)
+bodies[7, 32 * 5000] ^= 1                      # one bit of one slot of body 7
+r = m.R1cs(ctx)
+viol = torch.full((n,), 12345, dtype=torch.int32, device=dev)
+r.check_device(bodies.data_ptr(), n, ctx.body_bytes, viol.data_ptr(), 0, 0)
+torch.cuda.synchronize()
+v = viol.cpu().numpy().view(np.uint32)
+print("VIOL", int(v[7]), int(np.count_nonzero(np.delete(v, 7))))
+""" % os.path.join(T.ROOT, "tests")
+    r = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, timeout=300, cwd=T.ROOT,
+                       env=dict(os.environ, B3W_R1CS_DBG="1", B3W_R1CS_STAMPS="1"))
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [x for x in r.stdout.splitlines() if x.startswith("VIOL")][0].split()
+    tampered, others = int(line[1]), int(line[2])
+    assert tampered > 0, "a tampered witness passed the constraint check with B3W_R1CS_DBG set"
+    assert others in (0, 63)                   # product build: only body 7; diagnostic build: every body is marked

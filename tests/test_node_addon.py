@@ -367,6 +367,58 @@ def test_js_rccl_exchange_single_rank():
 
 @needs_node
 @pytest.mark.gpu
+def test_js_two_node_processes_join_ranks_over_host_shared_memory(tmp_path):
+    """wc.joinRanksHost -> foldPreimage().hOutAll with TWO Node processes on the one GPU (b3w_comm_create_host): both get the
+    h_out of every step of BOTH ranks, equal to what one rank computes for the whole preimage; ragged shards (6 chunks, a
+    partial last one), then a one-chunk preimage (rank 1 has no chunk)."""
+    import uuid
+    import numpy as np, torch
+    m = T.pkg()
+    shapes = {"ragged": 5 * 1024 + 100, "tiny": 700}
+    for name, nbytes in shapes.items():
+        (tmp_path / (name + ".bin")).write_bytes(m.workloads.lcg_preimage(nbytes, seed=1).tobytes())
+    script = """
+      const builder = require('./hot-proofs-blake3-circom_amd/js/witness_calculator.js');
+      const fs = require('fs');
+      (async () => {
+        const [dir, name, rank] = [process.argv[1], process.argv[2], Number(process.argv[3])];
+        const wc = await builder('nova_vesta', {logDFlags: false});
+        wc.joinRanksHost(name, rank, 2);
+        const out = {};
+        for (const shape of ['ragged', 'tiny']) {
+          const r = await wc.foldPreimage(fs.readFileSync(dir + '/' + shape + '.bin'), {batchSteps: 64});
+          out[shape] = {first: r.firstChunk, local: r.nChunksLocal, hash: r.hash, bad: Array.from(r.status).filter(x => x !== 0).length,
+                        hOutAll: Array.from(r.hOutAll), hOutParentsAll: Array.from(r.hOutParentsAll)};
+        }
+        console.log(JSON.stringify(out));
+      })().catch(e => { console.error(e); process.exit(1); });
+    """
+    name = "/b3w_js_" + uuid.uuid4().hex[:16]
+    env = dict(os.environ, B3W_PLACEMENT="plain", B3W_HOSTCOMM_TIMEOUT_S="90")
+    procs = [subprocess.Popen([NODE, "-e", script, str(tmp_path), name, str(r)], stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                              cwd=T.ROOT, env=env) for r in range(2)]
+    outs = [p.communicate(timeout=300) for p in procs]
+    assert all(p.returncode == 0 for p in procs), [o[1][-1500:] for o in outs]
+    res = [json.loads(o[0].strip().splitlines()[-1]) for o in outs]
+    ctx = m.Context("nova_vesta", 0)
+    import blake3_ref
+    for shape, nbytes in shapes.items():
+        data = m.workloads.lcg_preimage(nbytes, seed=1)
+        one = m.chain.fold_witnesses(ctx, data, batch_steps=64)
+        torch.cuda.synchronize()
+        leaf = one["h_out_all"].cpu().numpy().view(np.uint32).reshape(-1).tolist()
+        par = one["h_out_parents_all"].cpu().numpy().view(np.uint32).reshape(-1).tolist()
+        for r in range(2):
+            got = res[r][shape]
+            assert got["hash"] == blake3_ref.blake3(data.tobytes()).hex() and got["bad"] == 0, (shape, r)
+            assert got["hOutAll"] == leaf and got["hOutParentsAll"] == par, (shape, r)
+    assert [(res[r]["ragged"]["first"], res[r]["ragged"]["local"]) for r in range(2)] == [(0, 3), (3, 3)]
+    assert [(res[r]["tiny"]["first"], res[r]["tiny"]["local"]) for r in range(2)] == [(0, 1), (1, 0)]
+    ctx.close()
+
+
+@needs_node
+@pytest.mark.gpu
 def test_js_batch_commit_matches_plain_integer_group_law(tmp_path):
     """wc.setCommitKey / batch.commit() from Node against tests/ec_ref.py."""
     import numpy as np, ec_ref as E
