@@ -95,6 +95,7 @@ def lib():
         "b3w_batch_r1cs_check": (i32, [vp, vp, vp, vp]),
         "b3w_r1cs_consumer": (None, [vp, vp, u64, u64, u32, vp]),
         "b3w_batch_write_wtns": (i32, [vp, u32, u32, ctypes.c_char_p, ctypes.c_char_p, ctypes.POINTER(u32)]),
+        "b3w_batch_write_wtns_ex": (i32, [vp, u32, u32, ctypes.c_char_p, ctypes.c_char_p, u32, ctypes.POINTER(u32)]),
         "b3w_batch_autotune_device": (i32, [vp, vp, u32, vp, u64, vp, vp, vp, ctypes.POINTER(i32), ctypes.POINTER(ctypes.c_float)]),
         "b3w_bodies_alloc": (i32, [vp, u64, ctypes.POINTER(vp), ctypes.POINTER(i32)]),
         "b3w_bodies_free": (i32, [vp, vp]),
@@ -169,7 +170,7 @@ EXPORTED_SYMBOLS = ("b3w_abi_version", "b3w_identify_wasm", "b3w_create", "b3w_d
                     "b3w_batch_run_device", "b3w_public_words", "b3w_batch_alloc", "b3w_batch_free",
                     "b3w_batch_run", "b3w_batch_outputs", "b3w_batch_fetch", "b3w_batch_device_ptr",
                     "b3w_batch_time_device", "b3w_batch_verify_device", "b3w_batch_verify",
-                    "b3w_r1cs_create", "b3w_r1cs_info", "b3w_r1cs_is_tiled", "b3w_r1cs_destroy", "b3w_r1cs_check_device", "b3w_batch_r1cs_check", "b3w_r1cs_consumer", "b3w_batch_write_wtns", "b3w_batch_autotune_device", "b3w_bodies_alloc", "b3w_bodies_free", "b3w_bodies_trim", "b3w_ctx_trim", "b3w_bodies_configure", "b3w_bodies_stats", "b3w_bodies_search_stats", "b3w_bodies_search_limit", "b3w_batch_placement", "b3w_chain_num_chunks", "b3w_chain_num_leaf_steps", "b3w_chain_path_len",
+                    "b3w_r1cs_create", "b3w_r1cs_info", "b3w_r1cs_is_tiled", "b3w_r1cs_destroy", "b3w_r1cs_check_device", "b3w_batch_r1cs_check", "b3w_r1cs_consumer", "b3w_batch_write_wtns", "b3w_batch_write_wtns_ex", "b3w_batch_autotune_device", "b3w_bodies_alloc", "b3w_bodies_free", "b3w_bodies_trim", "b3w_ctx_trim", "b3w_bodies_configure", "b3w_bodies_stats", "b3w_bodies_search_stats", "b3w_bodies_search_limit", "b3w_batch_placement", "b3w_chain_num_chunks", "b3w_chain_num_leaf_steps", "b3w_chain_path_len",
                     "b3w_chain_num_parent_steps", "b3w_chain_parent_row", "b3w_chain_path_provable",
                     "b3w_chain_plan_leaves_device", "b3w_chain_tree_device", "b3w_chain_plan_parents_device",
                     "b3w_commit_key_create", "b3w_commit_key_create_ex", "b3w_commit_key_create_folded", "b3w_slot_widths", "b3w_commit_key_window", "b3w_commit_key_destroy", "b3w_commit_key_count", "b3w_commit_key_counts", "b3w_commit_records_device", "b3w_commit_records", "b3w_chain_commit_only", "b3w_chain_commitments", "b3w_chain_check_constraints", "b3w_chain_violations", "b3w_batch_commit_device", "b3w_batch_commit", "b3w_commit_consumer",
@@ -687,11 +688,12 @@ class Batch:
             raise B3WError(rc, f"b3w_batch_r1cs_check: status {rc}: {self.ctx.last_error()}")
         return viol, first
 
-    def write_wtns(self, directory, prefix="witness_", first=0, count=None):
-        """Stream witnesses [first, first+count) to <directory>/<prefix><index>.wtns; returns files written."""
+    def write_wtns(self, directory, prefix="witness_", first=0, count=None, threads=0):
+        """Stream witnesses [first, first+count) to <directory>/<prefix><index>.wtns with `threads` writer threads (0 = the
+        library's choice); returns files written."""
         count = self.n - first if count is None else count
         wr = ctypes.c_uint32()
-        rc = lib().b3w_batch_write_wtns(self.handle, first, count, str(directory).encode(), prefix.encode(), ctypes.byref(wr))
+        rc = lib().b3w_batch_write_wtns_ex(self.handle, first, count, str(directory).encode(), prefix.encode(), threads, ctypes.byref(wr))
         if rc != B3W_OK:
             raise B3WError(rc, f"b3w_batch_write_wtns: status {rc}: {self.ctx.last_error()}")
         return wr.value

@@ -324,13 +324,16 @@ void b3w_commit_consumer(void *user, const uint8_t *d_bodies, uint64_t pitch, ui
 int32_t b3w_batch_verify(b3w_batch *batch, uint32_t *host_mismatch);
 
 /* Streaming .wtns writer (the hand-off the reference does one file at a time: generate_witness.js:15-18,
- * circomkit `witness` in test/witness_gen.test.ts:41): witnesses [first, first+count) of the last
- * b3w_batch_run are copied to the host through two pinned staging buffers (D2H of chunk k+1 overlaps the
- * file writes of chunk k) and written as <dir>/<prefix><index>.wtns, each byte-identical to
- * calculateWTNSBin's image (76-byte header + body).  Witnesses whose status is not 0 are skipped.
- * Returns the number of files written in *written.  PCIe-bound (about 70 k witnesses/s). */
+ * circomkit `witness` in test/witness_gen.test.ts:41, then `snarkjs groth16 prove` reads the file, :47-49): witnesses
+ * [first, first+count) of the last b3w_batch_run are copied to the host through two pinned staging buffers (D2H of chunk
+ * k+1 overlaps the file writes of chunk k) and written as <dir>/<prefix><index>.wtns, each byte-identical to
+ * calculateWTNSBin's image (76-byte header + body, one writev per file).  The files are written by `threads` writer threads
+ * (0 = B3W_WTNS_THREADS, else min(16, cores)).  Witnesses whose status is not 0 are skipped.  Returns the number of files
+ * written in *written.  Rates: profiles/r04/wtns_writer.log (PCIe D2H alone: about 56 GB/s = 72 k witnesses/s). */
 int32_t b3w_batch_write_wtns(b3w_batch *batch, uint32_t first, uint32_t count, const char *dir, const char *prefix,
                              uint32_t *written);
+int32_t b3w_batch_write_wtns_ex(b3w_batch *batch, uint32_t first, uint32_t count, const char *dir, const char *prefix,
+                                uint32_t threads, uint32_t *written);
 
 /* Choose the fastest bit-identical kernel variant for THIS output buffer (fused one-kernel path vs the
  * two-kernel sweep path, DESIGN.md "Roofline"): runs and times each candidate on the caller's device

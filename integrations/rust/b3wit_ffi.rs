@@ -20,6 +20,8 @@ extern "C" {
 
 pub const CIRCUIT_NOVA_BN254: i32 = 1; // build/blake3_nova_js/blake3_nova.wasm (rust_fold/src/main.rs:29)
 pub const CIRCUIT_NOVA_VESTA: i32 = 2; // build/blake3_nova_pasta_js/blake3_nova_pasta.wasm (main.rs:364)
+pub const CURVE_BN254_G1: i32 = 0;     // the group arecibo's Bn256Engine commits in (scalar field = the bn128 circuits' prime)
+pub const CURVE_PALLAS: i32 = 1;       // PallasEngine (rust_fold/src/main.rs:366): scalar field = circom's "--prime vesta"
 
 /// FNV-1a 64 of the signal name, as witness_calculator.js:325-337 / circom's WASM runtime key inputs.
 pub fn fnv1a64(name: &str) -> u64 {
@@ -67,10 +69,18 @@ impl Drop for Calculator {
     fn drop(&mut self) { unsafe { b3w_destroy(self.ctx) } }
 }
 
-// ---- declarations only (no wrappers: nothing here can be compiled or run in the build image, so the untested surface stays
-// at the one call the reference makes).  The chained pass a fold driver would stream (main.rs:41-203 as one pass) and the
-// witness commitment (main.rs:166-179 -> prove_step commits to W); parameter names, order and types are held against
-// include/b3wit.h by tests/test_rust_ffi_decls_cpu.py.
+// ---- the chained pass: what replaces the loop at rust_fold/src/main.rs:166-179 (prove_step per step, each calling
+// calculate_witness) with ONE pass that produces every step witness of a chunk range on the device and hands each batch to a
+// consumer while it sits in HBM.  Parameter names, order and types of every declaration below are held against include/b3wit.h
+// by tests/test_rust_ffi_decls_cpu.py; none of this file can be compiled in the build image (no Rust toolchain).
+
+/// b3w_batch_consumer: (user, d_bodies, pitch, first_step, count, stream).  `d_bodies` is a DEVICE pointer to `count` witness
+/// bodies `pitch` bytes apart (steps first_step .. first_step + count of this rank's pass); the callee must enqueue its work
+/// on `stream` (a hipStream_t) — the buffer is overwritten `ring` batches later.
+pub type BatchConsumer = extern "C" fn(user: *mut c_void, d_bodies: *const u8, pitch: u64, first_step: u64, count: u32, stream: *mut c_void);
+/// b3w_allgather_fn: the caller's own collective for b3w_comm_create_external (device pointers; 0 = done).
+pub type AllgatherFn = extern "C" fn(user: *mut c_void, d_send: *const c_void, d_recv: *mut c_void, bytes_per_rank: u64, stream: *mut c_void) -> i32;
+
 #[link(name = "b3wit")]
 extern "C" {
     pub fn b3w_chain_create(ctx: *mut c_void, preimage_len: u64, first_chunk: u64, n_chunks_local: u32, batch_steps: u32,
@@ -86,9 +96,80 @@ extern "C" {
                           placement: *mut i32) -> i32;
     pub fn b3w_chain_outputs(chain: *mut c_void, host_public: *mut u32, host_status: *mut i32, host_root: *mut u32,
                              stream: *mut c_void) -> i32;
+    // sharded over ranks (one process per GPU): this rank's chunk range, the two exchanges (chunk chaining values; every step's
+    // h_out = z_{i+1} of blake3_circuit.rs:111-123 in global step order on every rank), the communicator's three transports
+    pub fn b3w_chain_shard(n_chunks: u64, rank: i32, nranks: i32, first_chunk: *mut u64, n_chunks_local: *mut u32);
+    pub fn b3w_chain_num_chunks(preimage_len: u64) -> u64;
+    pub fn b3w_chain_num_leaf_steps(preimage_len: u64) -> u64;
+    pub fn b3w_chain_parent_row(chunk: u64, n_chunks: u64) -> u64;
+    pub fn b3w_chain_run_parents_sharded(chain: *mut c_void, comm: *mut c_void,
+                                         consumer: Option<extern "C" fn(*mut c_void, *const u8, u64, u64, u32, *mut c_void)>,
+                                         user: *mut c_void, stream: *mut c_void) -> i32;
+    pub fn b3w_chain_allgather_hout(chain: *mut c_void, comm: *mut c_void, d_leaf_hout: *mut u32, d_parent_hout: *mut u32,
+                                    stream: *mut c_void) -> i32;
+    pub fn b3w_chain_allgather_hout_host(chain: *mut c_void, comm: *mut c_void, host_leaf_hout: *mut u32, host_parent_hout: *mut u32,
+                                         stream: *mut c_void) -> i32;
+    pub fn b3w_comm_unique_id(id: *mut u8) -> i32;
+    pub fn b3w_comm_create(ctx: *mut c_void, id: *const u8, rank: i32, nranks: i32, out: *mut *mut c_void) -> i32;
+    pub fn b3w_comm_create_host(ctx: *mut c_void, name: *const c_char, rank: i32, nranks: i32, out: *mut *mut c_void) -> i32;
+    pub fn b3w_comm_create_external(ctx: *mut c_void, rank: i32, nranks: i32,
+                                    allgather: Option<extern "C" fn(*mut c_void, *const c_void, *mut c_void, u64, *mut c_void) -> i32>,
+                                    user: *mut c_void, out: *mut *mut c_void) -> i32;
+    pub fn b3w_comm_destroy(comm: *mut c_void);
+    // the witness commitment (main.rs:166-179 -> prove_step commits to W) and the constraint check (utils.rs:17-88) as consumers
     pub fn b3w_commit_key_create_ex(ctx: *mut c_void, curve: i32, first_slot: u32, host_generators: *const u8, window_bits: u32,
                                     out: *mut *mut c_void) -> i32;
     pub fn b3w_commit_key_destroy(key: *mut c_void);
     pub fn b3w_commit_records(ctx: *mut c_void, key: *const c_void, host_records: *const u32, n: u32, host_points: *mut u8,
                               host_public: *mut u32, host_status: *mut i32) -> i32;
+    pub fn b3w_chain_commit_only(chain: *mut c_void, key: *const c_void, d_points: *mut u8) -> i32;
+    pub fn b3w_chain_commitments(chain: *mut c_void, host_points: *mut u8, stream: *mut c_void) -> i32;
+}
+
+/// What one pass leaves on the host: 15 public-output words per step (leaf steps in (chunk, block) order, then the parent steps
+/// in (chunk, height) order: z_{i+1} of step i = words 0..15 of row i), a status per step, BLAKE3(preimage) as 8 words.
+pub struct FoldOutputs { pub public: Vec<u32>, pub status: Vec<i32>, pub root: [u32; 8], pub n_leaf_steps: u64, pub n_parent_steps: u64 }
+
+/// Safe wrapper of the chained pass for ONE rank: create -> run_leaves -> run_parents -> outputs.
+pub struct Fold { chain: *mut c_void }
+
+impl Fold {
+    /// `preimage_len` bytes, all chunks on this rank; bodies go through `ring` buffers of `batch_steps` step witnesses.
+    pub fn new(calc: &Calculator, preimage_len: u64, batch_steps: u32, ring: u32) -> Result<Self, i32> {
+        let mut chain = std::ptr::null_mut();
+        let n = unsafe { b3w_chain_num_chunks(preimage_len) };
+        let rc = unsafe { b3w_chain_create(calc.ctx, preimage_len, 0, n as u32, batch_steps, ring, 1, &mut chain) };
+        if rc != 0 { Err(rc) } else { Ok(Fold { chain }) }
+    }
+
+    /// One commitment per step instead of witness bodies (`key` from b3w_commit_key_create_ex on the same Calculator).
+    pub fn commit_only(&mut self, key: *const c_void) -> Result<(), i32> {
+        let rc = unsafe { b3w_chain_commit_only(self.chain, key, std::ptr::null_mut()) };
+        if rc != 0 { Err(rc) } else { Ok(()) }
+    }
+
+    /// The whole pass over `preimage`.  `consumer` (with its `user` pointer) sees every batch of step witnesses on the device.
+    pub fn run(&mut self, preimage: &[u8], consumer: Option<BatchConsumer>, user: *mut c_void) -> Result<FoldOutputs, i32> {
+        let (mut nl, mut np, mut nc, mut pl, mut place) = (0u64, 0u64, 0u64, 0u32, 0i32);
+        unsafe { b3w_chain_info(self.chain, &mut nl, &mut np, &mut nc, &mut pl, &mut place) };
+        let stream = std::ptr::null_mut();                       // the null stream; b3w_chain_outputs waits for it
+        let mut rc = unsafe { b3w_chain_run_leaves(self.chain, preimage.as_ptr(), consumer, user, stream) };
+        if rc == 0 { rc = unsafe { b3w_chain_run_parents(self.chain, std::ptr::null(), consumer, user, stream) }; }
+        if rc != 0 { return Err(rc); }
+        let rows = (nl + np) as usize;
+        let mut out = FoldOutputs { public: vec![0u32; rows * 15], status: vec![0i32; rows], root: [0u32; 8], n_leaf_steps: nl, n_parent_steps: np };
+        rc = unsafe { b3w_chain_outputs(self.chain, out.public.as_mut_ptr(), out.status.as_mut_ptr(), out.root.as_mut_ptr(), stream) };
+        if rc != 0 { Err(rc) } else { Ok(out) }
+    }
+
+    /// After `commit_only` + `run`: the points, 64 bytes (x, y little-endian) per step.
+    pub fn commitments(&mut self, n_steps: usize) -> Result<Vec<u8>, i32> {
+        let mut pts = vec![0u8; n_steps * 64];
+        let rc = unsafe { b3w_chain_commitments(self.chain, pts.as_mut_ptr(), std::ptr::null_mut()) };
+        if rc != 0 { Err(rc) } else { Ok(pts) }
+    }
+}
+
+impl Drop for Fold {
+    fn drop(&mut self) { unsafe { b3w_chain_destroy(self.chain) } }
 }

@@ -1,6 +1,7 @@
 """Parity of the HIP path against the oracle and the committed goldens, through the C-ABI.
 Bit-exact (integer work): every comparison is byte equality."""
 import ctypes, os
+
 import numpy as np
 import pytest
 import b3w_testlib as T
@@ -186,17 +187,26 @@ def test_streaming_wtns_writer(m, tmp_path):
     cases = [c for c in g["cases"] if "error" not in c and T.is_canonical_u32("compression", c["input"])][:40]
     W = T.workloads()
     recs = np.array([W.input_to_values(c["input"], W.COMPRESSION_KEYS) for c in cases], dtype=np.uint32)
-    recs = np.concatenate([recs, W.config2_compression(150, first=9000)])          # several staging chunks
+    recs = np.concatenate([recs, W.config2_compression(260, first=9000)])          # three staging chunks (128 + 128 + 44): a buffer is reused
     ctx = _ctx(m, "compression")
     b = m.Batch(ctx, recs.shape[0], 771072)                                        # padded pitch on the device, files stay packed
     b.run(recs)
-    assert b.write_wtns(tmp_path, "w") == recs.shape[0]
-    for i, c in enumerate(cases):
-        assert hashlib.sha256((tmp_path / f"w{i}.wtns").read_bytes()).hexdigest() == c["wtns_sha256"], c["name"]
     _, want = T.oracle_batch_u32("compression", recs[40:])
     hdr = T.oracle_header("compression")
-    for i in (40, 41, 103, 104, 167, 189):
-        assert (tmp_path / f"w{i}.wtns").read_bytes() == hdr + want[i - 40].tobytes()
+    for threads, prefix in ((0, "w"), (1, "one_"), (5, "five_")):                  # the library's choice, a single writer, a small pool
+        assert b.write_wtns(tmp_path, prefix, threads=threads) == recs.shape[0]
+        for i, c in enumerate(cases):
+            assert hashlib.sha256((tmp_path / f"{prefix}{i}.wtns").read_bytes()).hexdigest() == c["wtns_sha256"], c["name"]
+        for i in (40, 41, 127, 128, 167, 255, 256, 299):
+            assert (tmp_path / f"{prefix}{i}.wtns").read_bytes() == hdr + want[i - 40].tobytes(), (threads, i)
+        assert len([f for f in os.listdir(tmp_path) if f.startswith(prefix)]) == recs.shape[0]
+        for f in os.listdir(tmp_path):
+            os.unlink(tmp_path / f)
+    # a sub-range, and a directory that does not exist (every writer fails: one error, no hang)
+    assert b.write_wtns(tmp_path, "sub_", first=130, count=7, threads=3) == 7 and sorted(os.listdir(tmp_path)) == sorted(f"sub_{i}.wtns" for i in range(130, 137))
+    with pytest.raises(m.B3WError) as ei:
+        b.write_wtns(tmp_path / "missing", "x", threads=4)
+    assert "cannot write" in str(ei.value)
     b.close(); ctx.close()
     # nova: a rejected step produces no file
     nrecs = W.config3_nova(9, first=5).copy()
