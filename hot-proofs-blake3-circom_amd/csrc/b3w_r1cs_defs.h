@@ -9,3 +9,21 @@ struct B3wField {
 };
 #define B3W_R1CS_TILE 1024u
 #define B3W_R1CS_NOT_SMALL ((long long)0x8000000000000000ull)
+
+// the walk program's per-tile table (B3wR1csHost::wtile, 16 words per tile)
+#define B3W_WT_NLOCAL 0     // elements of the tile (1 024 but for the last)
+#define B3W_WT_EXP_OFF 1    // first entry of its export list
+#define B3W_WT_EXP_N 2      // exports
+#define B3W_WT_EXP_SLOT0 3  // first slot of the export area it writes (a multiple of 64)
+#define B3W_WT_RUN_OFF 4    // first truth-table run
+#define B3W_WT_RUN_N 5
+#define B3W_WT_ENT_OFF 6    // first entry of the general rows
+#define B3W_WT_ENT_N 7      // entries (bit runs first, padded to whole chunks of 64, then terms)
+#define B3W_WT_ENT_RUNS 8   // entries that are bit runs (a multiple of 64)
+#define B3W_WT_GEN_N 9      // general rows: the tile's first rows
+#define B3W_WT_ROW0 10      // first row of the tile in the walk row order
+#define B3W_WT_NROWS 11
+#define B3W_WT_WORDS 16
+#define B3W_WALK_MAX_EXP_SLOTS 4096u
+#define B3W_WALK_MAX_GEN 256u
+#define B3W_WALK_MAX_ENT 4096u

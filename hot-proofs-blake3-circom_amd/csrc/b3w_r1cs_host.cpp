@@ -466,6 +466,226 @@ bool b3w_r1cs_host_build(const uint8_t *img, size_t len, const uint8_t prime_le[
       // (calibrated on the three tilings, profiles/r03/r1cs_cost_calibration.log: fixed 1 500, bytes 400 per full tile, 1 per word)
       scost[t + 1] = scost[t] + 1500u + (400u * n_local) / T + sgdesc[4 * t + 1];
     }
+  // ---- the WALK program (b3w_r1cs_walk_kernel; b3w_r1cs_host.h).  Rows go to the tile of their highest wire; what they mention
+  // in earlier tiles is exported by those tiles.  Row order inside a tile: general | truth-table rows, grouped into RUNS |
+  // always deferred | booleanity.  A RUN = up to 32 truth-table rows with the same table whose operands each either stay put or
+  // advance by one element from row to row (the 32 XOR gates of a word: a_i, b_i, out_i) — one lane decides the whole run from
+  // the bit-packed elements.
+  if (tiled) {
+    uint32_t inv = P[0];
+    for (int i = 0; i < 5; i++) inv *= 2u - P[0] * inv;
+    inv = 0u - inv;
+    const uint32_t one[8] = {1, 0, 0, 0, 0, 0, 0, 0};
+    std::vector<uint32_t> home(m);
+    std::vector<std::vector<uint32_t>> wrows_of(ntiles);
+    std::vector<uint8_t> exported(nwires, 0);
+    for (uint32_t k = 0; k < m; k++) {
+      const Row &r = rows[k];
+      uint32_t hi = 0;
+      for (uint32_t x = 0; x < r.na + r.nb + r.nc; x++) hi = std::max(hi, wires[r.off + x]);
+      home[k] = hi / T;
+      wrows_of[home[k]].push_back(k);
+      for (uint32_t x = 0; x < r.na + r.nb + r.nc; x++) if (wires[r.off + x] / T != home[k]) exported[wires[r.off + x]] = 1;
+    }
+    std::vector<uint32_t> slot_of(nwires, 0), slot0(ntiles, 0);
+    std::vector<uint16_t> wexp;
+    std::vector<uint32_t> wtile((size_t)B3W_WT_WORDS * ntiles, 0u);
+    uint32_t slots = 0, wmax_exp = 0;
+    for (uint32_t t = 0; t < ntiles; t++) {
+      slot0[t] = slots;
+      wtile[(size_t)B3W_WT_WORDS * t + B3W_WT_NLOCAL] = std::min<uint32_t>(T, nwires - t * T);
+      wtile[(size_t)B3W_WT_WORDS * t + B3W_WT_EXP_OFF] = (uint32_t)wexp.size();
+      wtile[(size_t)B3W_WT_WORDS * t + B3W_WT_EXP_SLOT0] = slots;
+      uint32_t ne = 0;
+      for (uint32_t w = t * T; w < std::min(nwires, (t + 1) * T); w++)
+        if (exported[w]) { slot_of[w] = slots + ne; wexp.push_back((uint16_t)(w - t * T)); ne++; }
+      wtile[(size_t)B3W_WT_WORDS * t + B3W_WT_EXP_N] = ne;
+      wmax_exp = std::max(wmax_exp, ne);
+      slots += (ne + 63u) & ~63u;
+    }
+    bool walk = slots <= B3W_WALK_MAX_EXP_SLOTS;
+    auto widx = [&](uint32_t w, uint32_t t) { return w / T == t ? w - t * T : T + slot_of[w]; };
+    std::vector<uint8_t> mustbit(nwires, 0);
+    std::vector<uint32_t> wruns, wrun_row, went_w, went_m, wrow_k, wrow_id, wtiles4(4 * (size_t)ntiles, 0u);
+    uint32_t wmax_gen = 0, wmax_ent = 0, wmax_runs = 0, wmax_rows = 0;
+    std::map<std::vector<uint32_t>, uint32_t> wtable_of;    // (part lengths, per term: operand position, coefficient id) -> truth table
+    std::vector<std::vector<uint32_t>> static_rows(ntiles); // always-deferred rows, as positions in their tile
+    for (uint32_t t = 0; t < ntiles && walk; t++) {
+      // this tile's rows by class, with what each class needs
+      struct TRow { uint32_t k, table, nops; uint32_t idx[5]; uint32_t keyid; };
+      struct GRow { uint32_t k; std::vector<uint32_t> ew, em; };   // entries without the row number (filled in below)
+      std::vector<GRow> gen;
+      std::vector<TRow> tts;
+      std::vector<uint32_t> defs, bools;
+      std::map<std::vector<uint32_t>, uint32_t> keyids;
+      for (uint32_t k : wrows_of[t]) {
+        const Row &r = rows[k];
+        uint32_t bw = 0;
+        if (boolean_wire(r, &bw)) { bools.push_back(k); mustbit[bw] = 1; continue; }
+        // the row's entries (what the general road would take): per part, terms sorted by element, bit runs folded
+        GRow g{k, {}, {}};
+        const uint32_t plen[3] = {r.na, r.nb, r.nc};
+        uint32_t q = 0;
+        std::vector<std::vector<uint32_t>> run_wires;
+        for (uint32_t part = 0; part < 3; part++) {
+          std::vector<std::array<uint32_t, 3>> terms;          // element, coefficient id, wire
+          for (uint32_t x = 0; x < plen[part]; x++, q++) terms.push_back({widx(wires[r.off + q], t), cids[r.off + q], wires[r.off + q]});
+          std::stable_sort(terms.begin(), terms.end(), [](const std::array<uint32_t, 3> &a, const std::array<uint32_t, 3> &b) { return a[0] < b[0]; });
+          for (size_t i = 0; i < terms.size();) {
+            bool neg = false; uint32_t k0 = 0;
+            size_t j = i + 1;
+            if (pow2((uint16_t)terms[i][1], neg, k0)) {
+              while (j < terms.size() && j - i < 64 && terms[j][0] == terms[j - 1][0] + 1) {
+                bool ng = false; uint32_t kk = 0;
+                if (!pow2((uint16_t)terms[j][1], ng, kk) || ng != neg || kk != k0 + (uint32_t)(j - i)) break;
+                j++;
+              }
+            }
+            // (a run never crosses from the local elements into the export area: the two are different arrays in LDS)
+            while (j - i >= 4 && (terms[i][0] < T) != (terms[j - 1][0] < T)) j--;
+            if (j - i >= 4 && k0 + (uint32_t)(j - i) <= 62) {
+              g.ew.push_back(terms[i][0] | (uint32_t)(j - i) << 16 | k0 << 23 | (neg ? 1u << 29 : 0u));
+              g.em.push_back(part | 8u);
+              std::vector<uint32_t> ws;
+              for (size_t x = i; x < j; x++) ws.push_back(terms[x][2]);
+              run_wires.push_back(ws);
+              i = j;
+            } else {
+              g.ew.push_back(terms[i][0] | terms[i][1] << 16);
+              g.em.push_back(part);
+              i++;
+            }
+          }
+        }
+        std::vector<uint32_t> W;
+        const int cls = row_class(r, (uint32_t)g.ew.size(), &W);
+        if (cls == 1) {
+          const uint32_t nt = r.na + r.nb + r.nc;
+          std::vector<uint32_t> key = {r.na, r.nb, r.nc};
+          for (uint32_t x = 0; x < nt; x++) {
+            key.push_back((uint32_t)(std::find(W.begin(), W.end(), wires[r.off + x]) - W.begin()));
+            key.push_back(cids[r.off + x]);
+          }
+          auto it = wtable_of.find(key);
+          if (it == wtable_of.end()) {
+            uint32_t table = 0;
+            for (uint32_t a = 0; a < (1u << W.size()); a++) {
+              uint32_t sum[3][8];
+              memset(sum, 0, sizeof sum);
+              uint32_t qq = 0;
+              for (int part = 0; part < 3; part++)
+                for (uint32_t x = 0; x < plen[part]; x++, qq++)
+                  if ((a >> key[3 + 2 * qq]) & 1u) u256_add_mod(sum[part], coefs[cids[r.off + qq]].data(), P);
+              uint32_t ab[8], cr[8];
+              mont_mul_host(ab, sum[0], sum[1], P, inv);
+              mont_mul_host(cr, sum[2], one, P, inv);
+              if (!memcmp(ab, cr, 32)) table |= 1u << a;
+            }
+            it = wtable_of.emplace(key, table).first;
+          }
+          TRow tr{k, it->second, (uint32_t)W.size(), {0, 0, 0, 0, 0}, 0};
+          for (size_t j = 0; j < W.size(); j++) { tr.idx[j] = widx(W[j], t); mustbit[W[j]] = 1; }
+          auto kid = keyids.find(key);
+          if (kid == keyids.end()) kid = keyids.emplace(key, (uint32_t)keyids.size()).first;
+          tr.keyid = kid->second;
+          tts.push_back(tr);
+          continue;
+        }
+        if (cls == 2) { defs.push_back(k); continue; }
+        for (const auto &ws : run_wires) for (uint32_t w : ws) mustbit[w] = 1;
+        gen.push_back(std::move(g));
+      }
+      // truth-table rows into runs
+      std::stable_sort(tts.begin(), tts.end(), [](const TRow &a, const TRow &b) {
+        if (a.keyid != b.keyid) return a.keyid < b.keyid;
+        for (int j = 0; j < 5; j++) if (a.idx[j] != b.idx[j]) return a.idx[j] < b.idx[j];
+        return false;
+      });
+      const uint32_t row0 = (uint32_t)wrow_k.size();
+      wtile[(size_t)B3W_WT_WORDS * t + B3W_WT_ROW0] = row0;
+      wtile[(size_t)B3W_WT_WORDS * t + B3W_WT_GEN_N] = (uint32_t)gen.size();
+      wtile[(size_t)B3W_WT_WORDS * t + B3W_WT_ENT_OFF] = (uint32_t)went_w.size();
+      {
+        std::vector<uint32_t> rw, rm, tw, tm;
+        for (size_t gi = 0; gi < gen.size(); gi++) {
+          for (size_t e = 0; e < gen[gi].ew.size(); e++) {
+            const uint32_t mt = gen[gi].em[e] | (uint32_t)gi << 8;
+            if (gen[gi].em[e] & 8u) { rw.push_back(gen[gi].ew[e]); rm.push_back(mt); } else { tw.push_back(gen[gi].ew[e]); tm.push_back(mt); }
+          }
+          wrow_k.push_back(gen[gi].k); wrow_id.push_back(rows[gen[gi].k].id);
+        }
+        while (rw.size() & 63u) { rw.push_back(0u); rm.push_back(4u); }
+        wtile[(size_t)B3W_WT_WORDS * t + B3W_WT_ENT_RUNS] = (uint32_t)rw.size();
+        wtile[(size_t)B3W_WT_WORDS * t + B3W_WT_ENT_N] = (uint32_t)(rw.size() + tw.size());
+        went_w.insert(went_w.end(), rw.begin(), rw.end()); went_w.insert(went_w.end(), tw.begin(), tw.end());
+        went_m.insert(went_m.end(), rm.begin(), rm.end()); went_m.insert(went_m.end(), tm.begin(), tm.end());
+        wmax_ent = std::max<uint32_t>(wmax_ent, (uint32_t)(rw.size() + tw.size()));
+      }
+      wtile[(size_t)B3W_WT_WORDS * t + B3W_WT_RUN_OFF] = (uint32_t)(wruns.size() / 4);
+      for (size_t i = 0; i < tts.size();) {
+        uint32_t stride[5] = {0, 0, 0, 0, 0};
+        size_t j = i + 1;
+        if (j < tts.size() && tts[j].keyid == tts[i].keyid) {
+          bool ok = true;
+          for (uint32_t o = 0; o < tts[i].nops && ok; o++) {
+            const uint32_t d = tts[j].idx[o] - tts[i].idx[o];
+            ok = d <= 1;
+            stride[o] = d;
+          }
+          if (ok) {
+            j++;
+            while (j < tts.size() && j - i < 32 && tts[j].keyid == tts[i].keyid) {
+              bool same = true;
+              for (uint32_t o = 0; o < tts[i].nops && same; o++) same = tts[j].idx[o] == tts[i].idx[o] + stride[o] * (uint32_t)(j - i);
+              if (!same) break;
+              j++;
+            }
+          } else { for (uint32_t &x : stride) x = 0; }
+        }
+        // an advancing operand must stay inside its array (local elements or export area) and inside what one funnel read covers
+        for (uint32_t o = 0; o < tts[i].nops; o++)
+          if (stride[o]) while (j - i > 1 && ((tts[i].idx[o] < T) != (tts[i].idx[o] + (uint32_t)(j - i) - 1 < T))) j--;
+        if (j - i == 1) for (uint32_t &x : stride) x = 0;
+        const TRow &a = tts[i];
+        uint32_t sb = 0;
+        for (uint32_t o = 0; o < 5; o++) sb |= (stride[o] ? 1u : 0u) << o;
+        wruns.push_back(a.table);
+        wruns.push_back(a.idx[0] | a.idx[1] << 16);
+        wruns.push_back(a.idx[2] | a.idx[3] << 16);
+        wruns.push_back(a.idx[4] | (uint32_t)(j - i - 1) << 16 | a.nops << 21 | sb << 24);
+        wrun_row.push_back((uint32_t)wrow_k.size());
+        for (size_t x = i; x < j; x++) { wrow_k.push_back(tts[x].k); wrow_id.push_back(rows[tts[x].k].id); }
+        i = j;
+      }
+      wtile[(size_t)B3W_WT_WORDS * t + B3W_WT_RUN_N] = (uint32_t)(wruns.size() / 4) - wtile[(size_t)B3W_WT_WORDS * t + B3W_WT_RUN_OFF];
+      wmax_runs = std::max(wmax_runs, wtile[(size_t)B3W_WT_WORDS * t + B3W_WT_RUN_N]);
+      for (uint32_t k : defs) { static_rows[t].push_back((uint32_t)wrow_k.size() - row0); wrow_k.push_back(k); wrow_id.push_back(rows[k].id); }
+      for (uint32_t k : bools) { wrow_k.push_back(k); wrow_id.push_back(rows[k].id); }
+      const uint32_t nrows = (uint32_t)wrow_k.size() - row0;
+      wtile[(size_t)B3W_WT_WORDS * t + B3W_WT_NROWS] = nrows;
+      wtiles4[4 * (size_t)t] = row0; wtiles4[4 * (size_t)t + 1] = nrows;
+      wmax_gen = std::max<uint32_t>(wmax_gen, (uint32_t)gen.size());
+      wmax_rows = std::max(wmax_rows, nrows);
+      if (gen.size() > B3W_WALK_MAX_GEN || wmax_ent > B3W_WALK_MAX_ENT || nrows > 4096u) walk = false;
+    }
+    if (walk) {
+      const uint32_t sw = (wmax_rows + 63u) / 64u;
+      std::vector<unsigned long long> wstatic((size_t)ntiles * sw, 0ull), wmask((size_t)ntiles * 16u, 0ull);
+      for (uint32_t t = 0; t < ntiles; t++) {
+        for (uint32_t pos : static_rows[t]) wstatic[(size_t)t * sw + (pos >> 6)] |= 1ull << (pos & 63u);
+        for (uint32_t w = t * T; w < std::min(nwires, (t + 1) * T); w++)
+          if (mustbit[w]) wmask[(size_t)t * 16u + ((w - t * T) >> 6)] |= 1ull << ((w - t * T) & 63u);
+      }
+      wruns.insert(wruns.end(), {0u, 0u, 0u, 0u});           // (a lane may read one descriptor behind the last)
+      went_w.push_back(0u); went_m.push_back(4u);
+      wexp.push_back(0);
+      H->walk = true; H->wexp_slots = slots; H->wmax_gen = wmax_gen; H->wmax_ent = wmax_ent; H->wmax_exp = wmax_exp; H->wmax_runs = wmax_runs;
+      H->wmax_rows = wmax_rows; H->wstatic_words = sw;
+      H->wtile = std::move(wtile); H->wmask = std::move(wmask); H->wexp = std::move(wexp); H->wruns = std::move(wruns);
+      H->wrun_row = std::move(wrun_row); H->went_w = std::move(went_w); H->went_m = std::move(went_m); H->wrow_k = std::move(wrow_k);
+      H->wrow_id = std::move(wrow_id); H->wtiles4 = std::move(wtiles4); H->wstatic = std::move(wstatic);
+    }
+  }
   std::vector<uint32_t> coefR(16 * coefs.size());           // per coefficient: plain, then Montgomery form
   for (size_t i = 0; i < coefs.size(); i++) {
     memcpy(&coefR[16 * i], coefs[i].data(), 32);

@@ -32,6 +32,23 @@ struct B3wR1csHost {
   std::vector<unsigned long long> smask;          // per tile x smask_groups: LDS elements the tile's booleanity / truth-table rows take for bits
   uint32_t smask_groups = 0;
   std::vector<unsigned long long> scost;          // ntiles + 1 prefix sums of the tiles' relative unit costs (stream kernel's work split)
+  // ---- the WALK program (b3w_r1cs_walk_kernel, round 4): a workgroup walks whole bodies, tile after tile.  A row belongs to the
+  // tile of its HIGHEST wire, so everything else it mentions lies in the same or an EARLIER tile: such an earlier wire is
+  // "exported" by its home tile into a per-body export area in LDS when that tile is in LDS anyway — no outside wire is ever
+  // gathered from HBM.  Element index of a row: < TILE = local, TILE + slot = export slot (each tile's slots start at a multiple of
+  // 64 so that the same number indexes the bit-packed copy).
+  bool walk = false;                               // the system fits the walk kernel
+  uint32_t wexp_slots = 0;                         // export area, in slots (padded)
+  uint32_t wmax_gen = 0, wmax_ent = 0, wmax_exp = 0, wmax_runs = 0, wmax_rows = 0, wstatic_words = 0;
+  std::vector<uint32_t> wtile;                     // 16 per tile: see B3W_WT_* in b3w_r1cs_defs.h
+  std::vector<unsigned long long> wmask;           // 16 per tile: local elements some row takes for a bit
+  std::vector<uint16_t> wexp;                      // export lists: local element numbers, in slot order
+  std::vector<uint32_t> wruns;                     // truth-table RUNS, 4 words each: table | idx0, idx1 | idx2, idx3 | idx4, len - 1 << 16, k << 21, strides << 24
+  std::vector<uint32_t> wrun_row;                  // per run: its first row in the walk row order (rows of a run are consecutive)
+  std::vector<uint32_t> went_w, went_m;            // general rows' entries (term or bit run) and meta words, as sgwords / sgmeta
+  std::vector<uint32_t> wrow_k, wrow_id;           // walk row order -> gather row, -> constraint number in the file
+  std::vector<uint32_t> wtiles4;                   // per tile {first row, rows, 0, 0}: the deferred kernel's view of the walk order
+  std::vector<unsigned long long> wstatic;         // per tile wstatic_words words: rows that are ALWAYS deferred (bit = row - first)
 };
 
 // false: refused, H->error says why.  May throw std::bad_alloc / std::length_error on absurd sizes (the caller catches).
