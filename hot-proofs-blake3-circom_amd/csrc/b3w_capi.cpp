@@ -1162,6 +1162,14 @@ struct b3w_r1cs {
   uint32_t *d_srows = nullptr, *d_sgdesc = nullptr, *d_sgwords = nullptr, *d_sgmeta = nullptr;       // the stream kernel's program
   unsigned long long *d_smask = nullptr, *d_scost = nullptr;
   B3wR1csSystem sys{};
+  // the walk kernel's program, and the system as the deferred kernel sees it behind the walk kernel (walk row order)
+  bool has_walk = false;
+  uint32_t *d_wtile = nullptr, *d_wruns = nullptr, *d_wrun_row = nullptr, *d_went_w = nullptr, *d_went_m = nullptr, *d_wrow_k = nullptr, *d_wrow_id = nullptr,
+           *d_wtiles4 = nullptr;
+  uint16_t *d_wexp = nullptr;
+  unsigned long long *d_wmask = nullptr, *d_wstatic = nullptr;
+  B3wWalk walk{};
+  B3wR1csSystem sysw{};
   // ... at most R1CS_SCRATCH_STREAMS of them: the least recently used one goes when another stream comes (after the event that
   // follows its last check; a scratch a stream capture has seen stays, its graph may be replayed any time)
   struct Scratch { void *stream; unsigned long long *buf; hipEvent_t done; uint64_t tick; bool pinned; };
@@ -1232,6 +1240,24 @@ static int32_t r1cs_create_impl(b3w_ctx *ctx, const uint8_t *img, size_t len, b3
                            r->d_trow_id, r->d_trow_k, r->d_lterms, r->d_coefR, r->d_coef_small, r->d_rows, r->d_wires, r->d_cids,
                            H.max_g_words, H.max_g_rows, H.smask_groups, r->d_srows, r->d_sgdesc, r->d_sgwords, r->d_sgmeta, r->d_smask, r->d_scost};
   }
+  if (H.tiled && H.walk) {
+    up((void **)&r->d_wtile, H.wtile.data(), H.wtile.size() * 4);
+    up((void **)&r->d_wmask, H.wmask.data(), H.wmask.size() * 8);
+    up((void **)&r->d_wexp, H.wexp.data(), H.wexp.size() * 2);
+    up((void **)&r->d_wruns, H.wruns.data(), H.wruns.size() * 4);
+    up((void **)&r->d_wrun_row, H.wrun_row.data(), H.wrun_row.size() * 4);
+    up((void **)&r->d_went_w, H.went_w.data(), H.went_w.size() * 4);
+    up((void **)&r->d_went_m, H.went_m.data(), H.went_m.size() * 4);
+    up((void **)&r->d_wrow_k, H.wrow_k.data(), H.wrow_k.size() * 4);
+    up((void **)&r->d_wrow_id, H.wrow_id.data(), H.wrow_id.size() * 4);
+    up((void **)&r->d_wtiles4, H.wtiles4.data(), H.wtiles4.size() * 4);
+    up((void **)&r->d_wstatic, H.wstatic.data(), H.wstatic.size() * 8);
+    r->walk = B3wWalk{H.ntiles, H.wexp_slots, H.wmax_gen, H.wmax_ent, r->ncoef, H.wstatic_words, H.wmax_rows, 0u, r->d_wtile, r->d_wmask, r->d_wexp,
+                      reinterpret_cast<const uint4 *>(r->d_wruns), r->d_wrun_row, r->d_went_w, r->d_went_m, r->d_wrow_id, r->d_wstatic, r->d_coef_small};
+    r->sysw = r->sys;
+    r->sysw.tiles = r->d_wtiles4; r->sysw.row_k = r->d_wrow_k; r->sysw.row_id = r->d_wrow_id; r->sysw.max_tile_rows = H.wmax_rows;
+    r->has_walk = true;
+  }
   if (e != hipSuccess) { b3w_r1cs_destroy(r); return e == hipErrorOutOfMemory ? B3W_E_NOT_ENOUGH_MEMORY : hip_fail(ctx, e, "r1cs upload"); }
   *out = r;
   return B3W_OK;
@@ -1264,6 +1290,10 @@ void b3w_r1cs_destroy(b3w_r1cs *r) {
   for (uint32_t *q : {r->d_trow_k, r->d_lrows, r->d_lterms, r->d_ltile_terms, r->d_srows, r->d_sgdesc, r->d_sgwords, r->d_sgmeta}) if (q) (void)hipFree(q);
   if (r->d_smask) (void)hipFree(r->d_smask);
   if (r->d_scost) (void)hipFree(r->d_scost);
+  for (uint32_t *q : {r->d_wtile, r->d_wruns, r->d_wrun_row, r->d_went_w, r->d_went_m, r->d_wrow_k, r->d_wrow_id, r->d_wtiles4}) if (q) (void)hipFree(q);
+  if (r->d_wexp) (void)hipFree(r->d_wexp);
+  if (r->d_wmask) (void)hipFree(r->d_wmask);
+  if (r->d_wstatic) (void)hipFree(r->d_wstatic);
   for (auto &sc : r->scratch) {
     if (sc.done) { (void)hipEventSynchronize(sc.done); (void)hipEventDestroy(sc.done); }
     if (sc.buf) (void)hipFree(sc.buf);
@@ -1281,9 +1311,10 @@ int32_t b3w_r1cs_check_device(b3w_ctx *ctx, const b3w_r1cs *r, const uint8_t *d_
     return B3W_E_BAD_ARGUMENT;
   }
   ON_DEVICE(ctx);
-  // B3W_R1CS_GATHER=1: the gather kernel, =2: the 32-byte tile kernel, =3: the lean pair — the other formulations, for comparison
+  // the walk kernel where the system fits it, else the stream kernel, else the lean pair, else the gather kernel.
+  // B3W_R1CS_GATHER picks another formulation, for comparison: 1 the gather kernel, 3 the lean pair, 4 the stream kernel (round 3's default)
   static const int other = getenv("B3W_R1CS_GATHER") ? atoi(getenv("B3W_R1CS_GATHER")) : 0;
-  if (r->tiled && (other == 0 || other == 3)) {
+  if (r->tiled && (other == 0 || other == 3 || other == 4)) {
     unsigned long long *scratch = nullptr;
     hipEvent_t done = nullptr;
     {
@@ -1308,7 +1339,7 @@ int32_t b3w_r1cs_check_device(b3w_ctx *ctx, const b3w_r1cs *r, const uint8_t *d_
           r->scratch.erase(r->scratch.begin() + lru);
         }
         b3w_r1cs::Scratch sc{stream, nullptr, nullptr, 0, false};
-        HIP_TRY(ctx, hipMalloc((void **)&sc.buf, b3w_r1cs_scratch_bytes(&r->sys)));
+        HIP_TRY(ctx, hipMalloc((void **)&sc.buf, std::max(b3w_r1cs_scratch_bytes(&r->sys), r->has_walk ? b3w_r1cs_walk_scratch_bytes(&r->walk) : (size_t)0)));
         hipError_t ee = hipEventCreateWithFlags(&sc.done, hipEventDisableTiming);
         if (ee != hipSuccess) { (void)hipFree(sc.buf); return hip_fail(ctx, ee, "hipEventCreate(r1cs scratch)"); }
         r->scratch.push_back(sc);
@@ -1319,16 +1350,15 @@ int32_t b3w_r1cs_check_device(b3w_ctx *ctx, const b3w_r1cs *r, const uint8_t *d_
       scratch = hit->buf;
       done = capturing ? nullptr : hit->done;                                      // (a captured check stays made of kernel nodes only)
     }
-    int lrc = other == 3 ? -6 : b3w_launch_r1cs_stream(d_bodies, n, pitch, &r->sys, &r->field, scratch, d_violations, d_first, (hipStream_t)stream);
+    int lrc = -6;
+    if (other == 0 && r->has_walk) lrc = b3w_launch_r1cs_walk(d_bodies, n, pitch, &r->walk, &r->sysw, &r->field, scratch, d_violations, d_first, (hipStream_t)stream);
+    if (lrc == -6 && other != 3) lrc = b3w_launch_r1cs_stream(d_bodies, n, pitch, &r->sys, &r->field, scratch, d_violations, d_first, (hipStream_t)stream);
     if (lrc == -6) lrc = b3w_launch_r1cs_lean(d_bodies, n, pitch, &r->sys, &r->field, scratch, d_violations, d_first, (hipStream_t)stream);
     if (done) (void)hipEventRecord(done, (hipStream_t)stream);
     return lrc ? hip_fail(ctx, (hipError_t)lrc, "r1cs check launch") : B3W_OK;
   }
-  const int rc = r->tiled && other != 1
-                     ? b3w_launch_r1cs_tiled(d_bodies, n, pitch, r->nwires, r->ntiles, r->max_ext, r->max_tile_terms, r->d_tiles, r->d_tile_terms, r->d_ext, r->d_trows,
-                                             r->d_trow_id, r->d_terms, r->d_coefR, r->d_coef_small, r->ncoef, &r->field, d_violations, d_first, (hipStream_t)stream)
-                     : b3w_launch_r1cs(d_bodies, n, pitch, r->m, r->d_rows, r->d_row_id, r->d_wires, r->d_cids, r->d_coefR, &r->field,
-                                       d_violations, d_first, (hipStream_t)stream);
+  const int rc = b3w_launch_r1cs(d_bodies, n, pitch, r->m, r->d_rows, r->d_row_id, r->d_wires, r->d_cids, r->d_coefR, &r->field, d_violations, d_first,
+                                 (hipStream_t)stream);
   return rc ? hip_fail(ctx, (hipError_t)rc, "r1cs check launch") : B3W_OK;
 }
 

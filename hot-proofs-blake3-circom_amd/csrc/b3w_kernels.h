@@ -94,16 +94,8 @@ extern "C" int b3w_launch_commit_invtab(const uint32_t *d_gens, const uint32_t *
 extern "C" int b3w_launch_r1cs(const uint8_t *d_bodies, uint32_t n, uint64_t pitch, uint32_t m, const uint32_t *d_rows,
                                const uint32_t *d_row_id, const uint32_t *d_wires, const uint16_t *d_cids, const uint32_t *d_coefR,
                                const B3wField *field, uint32_t *d_violations, uint32_t *d_first, hipStream_t stream);
-// the tile formulation (preferred): tile t = wires [t * B3W_R1CS_TILE, +B3W_R1CS_TILE); tiles: ntiles x {first row, rows, first
-// outside wire, outside wires}; rows: {first term, terms in A, B, C}; term = LDS index (< TILE: wire - tile start; >= TILE: outside
-// wire number) | coefficient id << 16
-// rows: bit 31 of the A count marks a booleanity row (A = {w: 1}, B = {1, -w} or {w, -1}, C = {}): its C count field holds w's
-// LDS index instead (there are no C terms);
+// tiles: tile t = wires [t * B3W_R1CS_TILE, +B3W_R1CS_TILE); ntiles x {first row, rows, first outside wire, outside wires}
 // coef_small[cid] = the coefficient as a signed integer when |c| < 2^62 (c or c - p), else B3W_R1CS_NOT_SMALL
-extern "C" int b3w_launch_r1cs_tiled(const uint8_t *d_bodies, uint32_t n, uint64_t pitch, uint32_t nwires, uint32_t ntiles, uint32_t max_ext,
-                                     uint32_t max_tile_terms, const uint32_t *d_tiles, const uint32_t *d_tile_terms /* ntiles x {first term, terms} */, const uint32_t *d_ext, const uint32_t *d_rows, const uint32_t *d_row_id,
-                                     const uint32_t *d_terms, const uint32_t *d_coefs, const long long *d_coef_small, uint32_t ncoef,
-                                     const B3wField *field, uint32_t *d_violations, uint32_t *d_first, hipStream_t stream);
 // the LEAN pair (default): the same tiles with 8-byte elements in LDS and integer arithmetic only; the rows a workgroup cannot
 // decide that way (an element of 2^63 or more, a coefficient that is no small integer, |<A,z>| or |<B,z>| of 2^63 or more) are
 // marked in `scratch` and evaluated by a second launch with the gather kernel's field arithmetic.  Same verdicts as the other
@@ -121,6 +113,23 @@ struct B3wR1csSystem {
   const unsigned long long *smask;                 // per tile x smask_groups: elements the tile's rows take for bits
   const unsigned long long *scost;                 // ntiles + 1 prefix sums of the tiles' relative unit costs
 };
+// the WALK kernel's program (b3w_r1cs.hip "WALK kernel", b3w_r1cs_host.h): device pointers
+struct B3wWalk {
+  uint32_t ntiles, exp_slots, max_gen, max_ent, ncoef, static_words, max_rows, pad;
+  const uint32_t *tile;                  // B3W_WT_WORDS per tile
+  const unsigned long long *mask;        // 16 per tile
+  const uint16_t *exp;
+  const uint4 *runs;
+  const uint32_t *run_row, *ent_w, *ent_m, *row_id;
+  const unsigned long long *stat;        // static_words per tile
+  const long long *coef_small;
+};
+// The WALK kernel (default where the system fits): a workgroup walks whole bodies tile after tile, earlier tiles' wires come from an
+// export area in LDS — no outside wire is gathered from HBM.  `sysw` = the system with the WALK row order in tiles / row_k / row_id
+// (the deferred kernel's view).  Returns -6 when the program does not fit (LDS).
+extern "C" int b3w_launch_r1cs_walk(const uint8_t *d_bodies, uint32_t n, uint64_t pitch, const B3wWalk *walk, const B3wR1csSystem *sysw, const B3wField *field,
+                                    unsigned long long *d_scratch, uint32_t *d_violations, uint32_t *d_first, hipStream_t stream);
+extern "C" size_t b3w_r1cs_walk_scratch_bytes(const B3wWalk *walk);
 #define B3W_R1CS_SLAB 8192u                                  // bodies per launch pair at most: bounds the scratch (64 MB at most)
 extern "C" size_t b3w_r1cs_scratch_bytes(const B3wR1csSystem *sys);
 extern "C" int b3w_launch_r1cs_lean(const uint8_t *d_bodies, uint32_t n, uint64_t pitch, const B3wR1csSystem *sys, const B3wField *field,

@@ -14,7 +14,10 @@
 // an exact integer fast path in front of that (small coefficients times small elements summed in 128 bits).
 //
 // FOUR FORMULATIONS, same verdicts (tests/test_gpu_r1cs.py runs all of them over clean, corrupted and random inputs):
-//  * the STREAM kernel (default whenever the system allows tiles; described where it stands, below): persistent workgroups over the
+//  * the WALK kernel (round 4; default where the system fits: described where it stands, below): a persistent workgroup walks whole
+//    bodies tile after tile, the wires a tile's rows need from earlier tiles come out of an export area in LDS — HBM traffic = the
+//    bodies, nothing else; truth-table rows in runs of 32 decided by one lane each.
+//  * the STREAM kernel (B3W_R1CS_GATHER=4; round 3's default): persistent workgroups over the
 //    tile-major list of (tile, body) units, elements fetched into registers one unit ahead, one barrier per unit, the host's
 //    stream program instead of row-by-row evaluation; what it cannot decide goes to the same deferred kernel as the lean pair's.
 //  * the LEAN pair (B3W_R1CS_GATHER=3; round 2's default): circom constraints are local, so a workgroup takes (body, tile
@@ -23,8 +26,6 @@
 //    together with bit-packed copies, the tile's term list and the small coefficients, and decides the rows as exact integers;
 //    recomposition rows "word = sum 2^i bit_i" are folded into BIT RUNS.  What the integer case does not cover is marked and
 //    evaluated by a second launch (b3w_r1cs_deferred_kernel) with the field arithmetic.  A body is read from HBM once.
-//  * the 32-byte TILE kernel (B3W_R1CS_GATHER=2): the same tiles with whole elements in LDS and field arithmetic in every lane —
-//    the first tile kernel, kept as the reference formulation.
 //  * the GATHER kernel (B3W_R1CS_GATHER=1, and any system whose rows are not local enough: more than 1 024 outside wires for
 //    some tile).
 //
@@ -348,186 +349,6 @@ __global__ __launch_bounds__(256) void b3w_r1cs_kernel(const uint8_t *__restrict
       atomicAdd(&violations[b], (uint32_t)__popcll(mask));
       if (first) atomicMin(&first[b], mine);
     }
-  }
-}
-
-// ---- tile kernel ----------------------------------------------------------------------------------------------------
-// LDS image of a workgroup: element i < n_local = wire tile * TILE + i, element TILE + j = outside wire ext[j]; 32 bytes each,
-// reduced mod p at load time; bit 255 (never set in a reduced element of these fields: p < 2^255) marks an element that was
-// NOT canonical in the body.
-
-// <row, z> out of LDS, in two parts: `s` collects every term whose coefficient is a small signed integer (|c| < 2^40 with an
-// element below 2^64, or |c| < 2^62 with an element below 2^32: +-1, +-2^i, the IV words, the 2^(i+j) of the row-scaled O2
-// systems — all but a handful of the coefficients of these circuits), as an exact 128-bit integer (a row has < 2^20 terms:
-// no overflow); `big` (mod p) collects the rest — the general Montgomery
-// path, any field element.  A valid witness of these circuits never leaves the integer part.
-struct Dot {
-  __int128 s;
-  Fe big;
-  bool has_big;
-};
-
-// (terms: term k of the row is terms[off + k]; the caller has already rebased `off` for a term list staged in LDS —
-// no pointer is ever formed outside its array)
-__device__ __forceinline__ Dot dot_lds(const uint4 *lds, const uint32_t *terms /* lds index | cid << 16 */, const uint32_t *coefs,
-                                       const long long *coef_small, uint32_t off, uint32_t n, const B3wField &F, bool *wild) {
-  Dot d;
-  d.s = 0;
-  d.has_big = false;
-#pragma unroll
-  for (int i = 0; i < 8; i++) d.big.l[i] = 0;
-  for (uint32_t k = 0; k < n; k++) {
-    const uint32_t t = terms[off + k];
-    const uint32_t cid = t >> 16;
-    const uint32_t idx = t & 0xFFFFu;
-    const uint4 lo = lds[2 * idx], hi = lds[2 * idx + 1];
-    *wild = *wild || (hi.w >> 31);
-    const long long c = coef_small[cid];
-    const uint32_t wide = lo.z | lo.w | hi.x | hi.y | hi.z | (hi.w & 0x7FFFFFFFu);
-    // |c| < 2^62 with z < 2^32, or |c| < 2^40 with z < 2^64: the product stays below 2^104 and 2^20 of them below 2^127
-    bool narrow = wide == 0 && c != B3W_R1CS_NOT_SMALL;
-    if (narrow && lo.y != 0) narrow = (c < 0 ? -c : c) < (1ll << 40);               // (rare: elements of 33 bits and more)
-    if (narrow) {
-      const unsigned long long z64 = (unsigned long long)lo.x | (unsigned long long)lo.y << 32;
-      d.s += (__int128)c * (__int128)z64;
-    } else {
-      Fe z;
-      z.l[0] = lo.x; z.l[1] = lo.y; z.l[2] = lo.z; z.l[3] = lo.w;
-      z.l[4] = hi.x; z.l[5] = hi.y; z.l[6] = hi.z; z.l[7] = hi.w & 0x7FFFFFFFu;
-      d.has_big = true;
-      if (cid == 0) fe_add(d.big, z, F.p);
-      else if (cid == 1) fe_sub(d.big, z, F.p);
-      else {
-        const Fe cf = load_fe(coefs + (size_t)cid * 16 + 8);
-        const Fe tt = mont_mul(cf, z, F);
-        fe_add(d.big, tt, F.p);
-      }
-    }
-  }
-  return d;
-}
-
-// the whole dot product as a field element: big + s mod p (|s| < 2^127 < p)
-__device__ __forceinline__ Fe dot_value(const Dot &d, const B3wField &F) {
-  const bool negative = d.s < 0;
-  const unsigned __int128 mag = negative ? (unsigned __int128)(-d.s) : (unsigned __int128)d.s;
-  Fe m;
-  m.l[0] = (uint32_t)mag; m.l[1] = (uint32_t)(mag >> 32); m.l[2] = (uint32_t)(mag >> 64); m.l[3] = (uint32_t)(mag >> 96);
-  m.l[4] = m.l[5] = m.l[6] = m.l[7] = 0;
-  Fe r = d.big;
-  if (negative) fe_sub(r, m, F.p); else fe_add(r, m, F.p);
-  return r;
-}
-
-__device__ __forceinline__ void stage(uint4 *lds, uint32_t idx, const uint8_t *body, uint32_t wire, const B3wField &F) {
-  bool wild = false;
-  Fe z = load_z(body, wire, F, &wild);
-  lds[2 * idx] = make_uint4(z.l[0], z.l[1], z.l[2], z.l[3]);
-  lds[2 * idx + 1] = make_uint4(z.l[4], z.l[5], z.l[6], z.l[7] | (wild ? 0x80000000u : 0u));
-}
-
-template <bool STAGED, bool COEF_LDS>
-__global__ __launch_bounds__(256) void b3w_r1cs_tile_kernel(const uint8_t *__restrict__ bodies, uint64_t pitch, uint32_t n, uint32_t nwires,
-                                                            uint32_t ntiles, uint32_t max_ext, uint32_t max_tile_terms, uint32_t ncoef,
-                                                            const uint4 *__restrict__ tiles /* row_off, n_rows, ext_off, n_ext */,
-                                                            const uint2 *__restrict__ tile_terms /* term_off, n_terms */,
-                                                            const uint32_t *__restrict__ ext_wires, const uint4 *__restrict__ rows,
-                                                            const uint32_t *__restrict__ row_id, const uint32_t *__restrict__ terms,
-                                                            const uint32_t *__restrict__ coefs, const long long *__restrict__ coef_small, B3wField F,
-                                                            uint32_t *__restrict__ violations, uint32_t *__restrict__ first) {
-  extern __shared__ uint4 lds[];
-  // all tiles of a body on one XCD: its outside wires are then L2 hits of a neighbouring workgroup's tile
-  const uint32_t per_group = 8u * ntiles;
-  const uint32_t b = (blockIdx.x / per_group) * 8u + (blockIdx.x & 7u);
-  const uint32_t tile = (blockIdx.x % per_group) >> 3;
-  if (b >= n) return;
-  const uint8_t *body = bodies + (uint64_t)b * pitch;
-  const uint4 td = tiles[tile];
-  const uint32_t t0 = tile * B3W_R1CS_TILE;
-  const uint32_t n_local = nwires - t0 < B3W_R1CS_TILE ? nwires - t0 : B3W_R1CS_TILE;
-  // this lane's first row descriptors, fetched now so that their latency lies under the staging of the tile (profiles/r02:
-  // the kernel's waves are parked on memory 63 % of their cycles; a tile of these systems has 4-5 rows per lane)
-  constexpr uint32_t PRE = 6;
-  uint4 pre[PRE];
-#pragma unroll
-  for (uint32_t q = 0; q < PRE; q++) {
-    const uint32_t r = td.x + threadIdx.x + 256 * q;
-    pre[q] = r < td.x + td.y ? rows[r] : make_uint4(0, 0, 0, 0);
-  }
-  for (uint32_t i = threadIdx.x; i < n_local; i += 256) stage(lds, i, body, t0 + i, F);
-  for (uint32_t j = threadIdx.x; j < td.w; j += 256) stage(lds, B3W_R1CS_TILE + j, body, ext_wires[td.z + j], F);
-  // the tile's term list (5 100 words for these systems) behind the elements: read once, coalesced, instead of one
-  // dependent global load per term on every lane's critical path
-  // STAGED: the tile's term list (5 100 words for these systems) sits behind the elements — read once, coalesced, instead
-  // of one dependent global load per term on every lane's critical path
-  const uint2 tt = tile_terms[tile];                                               // first term of the tile, how many
-  uint32_t *lterms = reinterpret_cast<uint32_t *>(lds + 2 * (size_t)(B3W_R1CS_TILE + max_ext));
-  if (STAGED)
-    for (uint32_t k = threadIdx.x; k < tt.y; k += 256) lterms[k] = terms[tt.x + k];
-  const uint32_t *tsrc = STAGED ? lterms : terms;
-  const uint32_t tbase = STAGED ? tt.x : 0u;                                      // row offsets are global term numbers
-  // COEF_LDS: the table of small coefficients (80 entries for these systems) too — it is looked up once per term
-  long long *lcoef = reinterpret_cast<long long *>(lterms + (STAGED ? max_tile_terms : 0u) + ((STAGED ? max_tile_terms : 0u) & 1u));
-  if (COEF_LDS)
-    for (uint32_t k = threadIdx.x; k < ncoef; k += 256) lcoef[k] = coef_small[k];
-  const long long *csrc = COEF_LDS ? lcoef : coef_small;
-  __syncthreads();
-  uint32_t nbad = 0, low = 0xFFFFFFFFu;
-  // is the constant wire 1?  (wire 0 is element 0 of tile 0 and outside wire 0 of every other tile that mentions it)
-  const uint4 one_lo = lds[tile == 0 ? 0 : 2 * B3W_R1CS_TILE], one_hi = lds[(tile == 0 ? 0 : 2 * B3W_R1CS_TILE) + 1];
-  const bool w0_is_one = one_lo.x == 1 && (one_lo.y | one_lo.z | one_lo.w | one_hi.x | one_hi.y | one_hi.z | one_hi.w) == 0;
-  const __int128 lim = (__int128)1 << 63;
-  uint32_t it = 0;
-  for (uint32_t r = td.x + threadIdx.x; r < td.x + td.y; r += 256, it++) {
-    uint4 d;
-    switch (it) {                                        // (constant indices keep `pre` in registers)
-      case 0: d = pre[0]; break;
-      case 1: d = pre[1]; break;
-      case 2: d = pre[2]; break;
-      case 3: d = pre[3]; break;
-      case 4: d = pre[4]; break;
-      case 5: d = pre[5]; break;
-      default: d = rows[r];
-    }
-    bool wild = false, bad;
-    if ((d.y >> 31) && w0_is_one) {
-      // a booleanity row  z * (1 - z) = 0  (or z * (z - 1) = 0), recognised by the host: in a field that says z is 0 or 1.
-      // Its descriptor carries the element's LDS index (d.w; the row has no C terms): no term is fetched at all.
-      const uint32_t idx = d.w;
-      const uint4 lo = lds[2 * idx], hi = lds[2 * idx + 1];
-      wild = hi.w >> 31;
-      bad = ((lo.x >> 1) | lo.y | lo.z | lo.w | hi.x | hi.y | hi.z | (hi.w & 0x7FFFFFFFu)) != 0;
-    } else {
-      const uint32_t na = d.y & 0x7FFFFFFFu;
-      const uint32_t t0r = d.x - tbase;
-      const uint32_t nc = (d.y >> 31) ? 0u : d.w;        // (a booleanity row taking the general road: wire 0 is not 1)
-      const Dot C = dot_lds(lds, tsrc, coefs, csrc, t0r + na + d.z, nc, F, &wild);
-      const Dot A = dot_lds(lds, tsrc, coefs, csrc, t0r, na, F, &wild);
-      const Dot B = dot_lds(lds, tsrc, coefs, csrc, t0r + na, d.z, F, &wild);
-      if (!A.has_big && !B.has_big && !C.has_big && A.s < lim && A.s > -lim && B.s < lim && B.s > -lim) {
-        // integers all the way: |A * B - C| < 2^127 < p, so "= 0 mod p" is "= 0"  (an empty A or B is 0: linear rows too)
-        bad = A.s * B.s != C.s;
-      } else {
-        const Fe az = dot_value(A, F), bz = dot_value(B, F), cz = dot_value(C, F);
-        Fe r2;
-#pragma unroll
-        for (int i = 0; i < 8; i++) r2.l[i] = F.r2[i];
-        Fe diff = mont_mul(mont_mul(az, r2, F), bz, F);                              // (az * R) * bz / R = az * bz
-        fe_sub(diff, cz, F.p);
-        bad = !fe_is_zero(diff);
-      }
-    }
-    if (bad || wild) { nbad++; low = min(low, row_id[r]); }
-  }
-  // one atomic per wave
-#pragma unroll
-  for (int sh = 32; sh > 0; sh >>= 1) {
-    nbad += (uint32_t)__shfl_xor((int)nbad, sh);
-    low = min(low, (uint32_t)__shfl_xor((int)low, sh));
-  }
-  if ((threadIdx.x & 63) == 0 && nbad) {
-    atomicAdd(&violations[b], nbad);
-    if (first) atomicMin(&first[b], low);
   }
 }
 
@@ -1289,6 +1110,352 @@ __global__ __launch_bounds__(64) void b3w_r1cs_deferred_kernel(const uint8_t *__
   }
 }
 
+// ---- WALK kernel (round 4) -------------------------------------------------------------------------------------------------------
+// The stream kernel above walks the units tile-major: a workgroup keeps one tile's program and sees body after body.  Every row of
+// a tile that mentions a wire of another tile makes it GATHER that wire from HBM — 32 bytes wanted, a 128-byte line fetched, and
+// the line was read once already as part of its own tile by another workgroup at another time: 13 % (compression) to 18 % (nova)
+// more bytes from HBM than the bodies hold (profiles/r03/r1cs_check.json), on a kernel that sits on the HBM roofline.
+// Here a workgroup walks WHOLE BODIES, tile after tile (units body-major).  A row belongs to the tile of its HIGHEST wire (host:
+// b3w_r1cs_host.cpp, "WALK program"), so every other wire it mentions lies in the same tile or in one the workgroup has already
+// had in LDS for this body: each tile EXPORTS the elements later tiles mention (1 500 - 1 600 per body) into an export area in LDS,
+// 8 bytes each plus a bit-packed copy, and a row names an element as "local e" or "export slot s".  No outside wire is ever
+// fetched; HBM traffic = the bodies.  The tile's program now changes with every unit, so it is made small enough to be read from
+// L2 unit after unit, one unit ahead, straight into registers:
+//   * booleanity rows (64 % of the rows): still one AND of the tile's must-be-bit mask with the pack's ballots, no descriptor;
+//   * truth-table rows come in RUNS — the 32 XOR gates of a word have operands a_i, b_i, out_i that advance by one element from
+//     row to row — and ONE lane decides a run of up to 32 rows from three 32-bit cut-outs of the bit-packed elements with a
+//     bit-sliced evaluation of the table (16 + 15 v_bfi): 7 671 rows of blake3_compression are 480 descriptors of 16 bytes;
+//   * general rows as before: one ENTRY (term or bit run) per lane into per-row sums in LDS, verdict by the row's owner lane.
+// A (body, tile) in which something is no bit where the masks say bit (or wire 0 is not 1) goes to the deferred kernel with ALL its
+// rows, and so does every later tile of that body (they may import from it); a general row with an element of 2^63 or more (the
+// field inverses of a nova step) is deferred alone.  The deferred kernel and its scratch blocks are the stream kernel's.
+// One workgroup owns a body: its violation count is a plain store, there is no initialisation kernel.
+
+// 32 bits of a bit-packed array from bit `idx` on (the array has a spare word behind its last)
+__device__ __forceinline__ uint32_t cut32(const unsigned long long *words, uint32_t idx) {
+  const uint32_t g = idx >> 6, r = idx & 63u;
+  const unsigned long long lo = words[g], hi = words[g + 1];
+  return (uint32_t)(r ? (lo >> r) | (hi << (64u - r)) : lo);
+}
+// a 5-input truth table over 32 rows at once: bit j of the result = table[x0_j + 2 x1_j + 4 x2_j + 8 x3_j + 16 x4_j]
+__device__ __forceinline__ uint32_t table32(uint32_t table, uint32_t x0, uint32_t x1, uint32_t x2, uint32_t x3, uint32_t x4) {
+  uint32_t l[16];
+#pragma unroll
+  for (int j = 0; j < 16; j++) {
+    const uint32_t t0 = 0u - ((table >> (2 * j)) & 1u), t1 = 0u - ((table >> (2 * j + 1)) & 1u);
+    l[j] = (x0 & t1) | (~x0 & t0);
+  }
+#pragma unroll
+  for (int j = 0; j < 8; j++) l[j] = (x1 & l[2 * j + 1]) | (~x1 & l[2 * j]);
+#pragma unroll
+  for (int j = 0; j < 4; j++) l[j] = (x2 & l[2 * j + 1]) | (~x2 & l[2 * j]);
+#pragma unroll
+  for (int j = 0; j < 2; j++) l[j] = (x3 & l[2 * j + 1]) | (~x3 & l[2 * j]);
+  return (x4 & l[1]) | (~x4 & l[0]);
+}
+
+template <int NE>                                            // chunks of 64 general entries a wave takes at most (the tile with most: NE * 512)
+__global__ __launch_bounds__(512, 4) void b3w_r1cs_walk_kernel(const uint8_t *__restrict__ bodies, uint64_t pitch, uint32_t n, B3wWalk W,
+                                                               unsigned long long *__restrict__ scratch, uint32_t block_words,
+                                                               uint32_t *__restrict__ violations, uint32_t *__restrict__ first) {
+  constexpr uint32_t WAVES = 8, THREADS = 512, T = B3W_R1CS_TILE;
+  extern __shared__ __align__(16) unsigned char smem[];
+  const uint32_t tid = threadIdx.x, lane = tid & 63u;
+  const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // LDS: elements [parity][1 024]; export area; bit-packed "is 1" words of both (+ a spare word each); the general rows' sums
+  // {A, B, C} x {low, high} and flags [parity]; the deferred-row mask words of a unit [parity]; tile table; coefficients; counters
+  const uint32_t xw = (W.exp_slots >> 6) + 1u, gr2 = (W.max_gen + 1u) & ~1u;
+  unsigned long long *el0 = reinterpret_cast<unsigned long long *>(smem);
+  unsigned long long *xel = el0 + 2u * T;
+  unsigned long long *ones0 = xel + W.exp_slots;             // [parity][18]
+  unsigned long long *xones = ones0 + 36u;
+  unsigned long long *gsum0 = xones + xw;
+  unsigned long long *dmask0 = gsum0 + 12u * W.max_gen;      // [parity][8]
+  long long *lcoef = reinterpret_cast<long long *>(dmask0 + 16u);
+  unsigned long long *lmask = reinterpret_cast<unsigned long long *>(lcoef + ((W.ncoef + 1u) & ~1u));      // the tiles' must-be-bit masks
+  unsigned long long *lstat = lmask + 16u * W.ntiles;        // ... and always-deferred rows
+  uint32_t *gflag0 = reinterpret_cast<uint32_t *>(lstat + (size_t)W.static_words * W.ntiles);
+  uint32_t *ltile = gflag0 + 2u * gr2;
+  uint32_t *lanom = ltile + W.ntiles * B3W_WT_WORDS;         // [unit mod 3]
+  uint32_t *cnt = lanom + 4;                                 // [body mod 3]: violations, then lowest violated row
+  for (uint32_t k = tid; k < W.ncoef; k += THREADS) lcoef[k] = W.coef_small[k];
+  for (uint32_t k = tid; k < W.ntiles * B3W_WT_WORDS; k += THREADS) ltile[k] = W.tile[k];
+  for (uint32_t k = tid; k < 16u * W.ntiles; k += THREADS) lmask[k] = W.mask[k];
+  for (uint32_t k = tid; k < W.static_words * W.ntiles; k += THREADS) lstat[k] = W.stat[k];
+  for (uint32_t k = tid; k < 12u * W.max_gen; k += THREADS) gsum0[k] = 0ull;
+  for (uint32_t k = tid; k < 2u * gr2; k += THREADS) gflag0[k] = 0u;
+  for (uint32_t k = tid; k < xw; k += THREADS) xones[k] = 0ull;
+  for (uint32_t k = tid; k < W.exp_slots; k += THREADS) xel[k] = 0ull;
+  if (tid < 36) ones0[tid] = 0ull;
+  if (tid < 16) dmask0[tid] = 0ull;
+  if (tid < 4) lanom[tid] = 0u;
+  if (tid < 3) { cnt[tid] = 0u; cnt[3 + tid] = 0xFFFFFFFFu; }
+  // this workgroup's bodies: whole ones, contiguous, as even as whole bodies go
+  const uint32_t b0 = (uint32_t)((uint64_t)n * blockIdx.x / gridDim.x), b1 = (uint32_t)((uint64_t)n * (blockIdx.x + 1u) / gridDim.x);
+  const uint32_t m = (b1 - b0) * W.ntiles;                    // units
+  if (m == 0) return;
+  lds_barrier();
+  // unit k of this workgroup = body b0 + k / ntiles, tile k % ntiles: three cursors walk ahead of each other (fetch, pack, evaluate)
+  // (a cursor carries its tile's table row in the lanes of one VGPR — lane k holds word k — so that a field costs a v_readlane,
+  // not an LDS round trip: one ds_read per unit and cursor)
+  struct Cursor { uint32_t body, tile, rec; };
+  auto load_rec = [&](Cursor &c) { c.rec = ltile[c.tile * B3W_WT_WORDS + (lane & 15u)]; };
+  auto advance = [&](Cursor &c) { if (++c.tile == W.ntiles) { c.tile = 0; c.body++; } load_rec(c); };
+#define TW(c, field) ((uint32_t)__builtin_amdgcn_readlane((int)(c).rec, (field)))
+  // ---- fetch (unit k): this wave's two groups of 64 elements, each as two blocks of 32 — lanes 0-31 the low, 32-63 the high 16 bytes
+  uint4 rlo[2], rhi[2];
+  auto fetch = [&](const Cursor c) {                        // (a cursor behind the last unit points at the last unit again: fetched, packed, never looked at)
+    const uint32_t tile = c.tile, body_i = c.body;
+    const uint32_t n_local = TW(c, B3W_WT_NLOCAL);
+    const uint8_t *body = bodies + (uint64_t)body_i * pitch + (uint64_t)tile * (T * 32u);
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+      const uint32_t e0 = (wave + (uint32_t)q * WAVES) * 64u + (lane & 31u), e1 = e0 + 32u;
+      rlo[q] = ldg16<true>(body, (e0 < n_local ? e0 : n_local - 1u) * 32u + (lane >> 5) * 16u);
+      rhi[q] = ldg16<true>(body, (e1 < n_local ? e1 : n_local - 1u) * 32u + (lane >> 5) * 16u);
+    }
+  };
+  // ---- the program of a unit, read one unit ahead from L2 into registers: this wave's entry chunks, its run, its export
+  uint32_t pe_w[NE], pe_m[NE], px = 0;
+  uint4 prun = make_uint4(0, 0, 0, 0);
+  auto program = [&](const Cursor c) {
+    const uint32_t ent_off = TW(c, B3W_WT_ENT_OFF), ent_n = TW(c, B3W_WT_ENT_N);
+#pragma unroll
+    for (int q = 0; q < NE; q++) {
+      const uint32_t iw = (wave + (uint32_t)q * WAVES) * 64u + lane;
+      pe_w[q] = W.ent_w[ent_off + (iw < ent_n ? iw : ent_n)];                              // (behind the tile's entries: the next tile's first or the spare)
+      pe_m[q] = iw < ent_n ? W.ent_m[ent_off + iw] : 4u;
+    }
+    const uint32_t run_n = TW(c, B3W_WT_RUN_N);
+    prun = W.runs[TW(c, B3W_WT_RUN_OFF) + (tid < run_n ? tid : run_n)];
+    const uint32_t exp_n = TW(c, B3W_WT_EXP_N);
+    px = W.exp[TW(c, B3W_WT_EXP_OFF) + (tid < exp_n ? tid : exp_n)];
+  };
+  // ---- pack (unit k, into parity k & 1): 32-byte elements -> 8 bytes + the "is 1" word of each group of 64; something the tile's
+  // rows take for a bit that is none, or wire 0 not being 1, raises the unit's anomaly flag
+  auto pack = [&](const Cursor c, const bool real, const uint32_t par, const uint32_t k3) {      // (real: not a repeat of the last unit)
+#pragma unroll
+    for (int q = 0; q < 2; q++)
+      asm volatile("" :: "v"(rlo[q].x), "v"(rlo[q].y), "v"(rlo[q].z), "v"(rlo[q].w), "v"(rhi[q].x), "v"(rhi[q].y), "v"(rhi[q].z), "v"(rhi[q].w));
+    const uint32_t tile = c.tile;
+    const uint32_t n_local = TW(c, B3W_WT_NLOCAL);
+    unsigned long long *el = el0 + par * T, *ones = ones0 + par * 18u;
+    bool flag = false;
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+      const uint32_t g = wave + (uint32_t)q * WAVES, e = g * 64u + lane;
+      uint4 lo = rlo[q], hi = rhi[q];
+      halves_apart(lo.x, hi.x); halves_apart(lo.y, hi.y); halves_apart(lo.z, hi.z); halves_apart(lo.w, hi.w);
+      const unsigned long long z = e < n_local ? lean_pack(lo, hi) : 0ull;
+      el[e] = z;
+      const unsigned long long is1 = __ballot(z == 1ull), bads = __ballot(z > 1ull);
+      if (lane == 0) ones[g] = is1;
+      const unsigned long long mbit = lmask[tile * 16u + g];
+      flag = flag || (bads & mbit) != 0ull || (tile == 0 && g == 0 && !(is1 & 1ull));
+    }
+    if (flag && lane == 0 && real) lanom[k3] = 1u;
+  };
+  // ---- general entries of unit k (its program in pe_*): a lane adds coefficient * element (a term) or the value of a bit run
+  // into its row's part sum; a part sum is two counters {low, high} worth low + high * 2^52 (see the stream kernel)
+  auto entries = [&](const Cursor c, const uint32_t par) {
+    const unsigned long long *el = el0 + par * T, *ones = ones0 + par * 18u;
+    unsigned long long *gsum = gsum0 + par * 6u * W.max_gen;
+    uint32_t *gflag = gflag0 + par * gr2;
+    const uint32_t ent_n = TW(c, B3W_WT_ENT_N), ent_runs = TW(c, B3W_WT_ENT_RUNS);
+#pragma unroll
+    for (int q = 0; q < NE; q++) {
+      const uint32_t c0 = (wave + (uint32_t)q * WAVES) * 64u;
+      if (c0 >= ent_n) break;                                  // (wave-uniform)
+      const uint32_t w = pe_w[q], mt = pe_m[q];
+      const bool live = !(mt & 4u);
+      unsigned long long *sum = gsum + 6u * (mt >> 8) + 2u * (mt & 3u);
+      if (c0 < ent_runs) {                                     // a chunk of bit runs: first element | length << 16 | shift << 23 | negative << 29
+        const uint32_t idx0 = w & 0xFFFFu, len = (w >> 16) & 0x7Fu, sh = (w >> 23) & 0x3Fu;
+        const bool neg = (w >> 29) & 1u;
+        const unsigned long long *src = idx0 < T ? ones : xones;
+        const uint32_t i0 = idx0 < T ? idx0 : idx0 - T, g = i0 >> 6, r = i0 & 63u;
+        const unsigned long long lo = src[g], hi = src[g + 1];
+        const unsigned long long mask = len == 64u ? ~0ull : (1ull << len) - 1ull;
+        const unsigned long long v = (((lo >> r) | (r ? hi << (64u - r) : 0ull)) & mask) << sh;      // (below 2^62: the host checks shift + length; no-bit elements: the masks)
+        if (live) {
+          if (v < (1ull << 54)) atomicAdd(sum, neg ? 0ull - v : v);
+          else {
+            const unsigned long long v0 = v & ((1ull << 52) - 1ull), v1 = v >> 52;
+            atomicAdd(sum, neg ? 0ull - v0 : v0);
+            atomicAdd(sum + 1, neg ? 0ull - v1 : v1);
+          }
+        }
+      } else {                                                 // a chunk of terms: element | coefficient id << 16
+        const uint32_t idx = live ? w & 0xFFFFu : 0u;
+        const unsigned long long z = idx < T ? el[idx] : xel[idx - T];
+        const long long cf = lcoef[live ? w >> 16 : 0u];
+        const unsigned long long mag = cf < 0 ? 0ull - (unsigned long long)cf : (unsigned long long)cf;
+        const unsigned long long lo = mag * z, hi = __umul64hi(mag, z);
+        const bool neg = cf < 0;
+        const bool ok = cf != B3W_R1CS_NOT_SMALL && !(z >> 63) && hi < (1ull << 39);
+        if (live) {
+          if (!ok) atomicOr(&gflag[mt >> 8], 1u);
+          else if (hi == 0ull && lo < (1ull << 54)) atomicAdd(sum, neg ? 0ull - lo : lo);
+          else {
+            __int128 v = (__int128)(((unsigned __int128)hi << 64) | lo);
+            if (neg) v = -v;
+            atomicAdd(sum, (unsigned long long)v & ((1ull << 52) - 1ull));
+            atomicAdd(sum + 1, (unsigned long long)(long long)(v >> 52));
+          }
+        }
+      }
+    }
+  };
+  // ---- truth-table runs of unit k: lane j of the workgroup takes run j; returns violated rows (bit i = row i of the run)
+  auto run_bits = [&](const uint4 d, const uint32_t par, const bool mine) -> uint32_t {
+    const unsigned long long *ones = ones0 + par * 18u;
+    const uint32_t len = ((d.w >> 16) & 31u) + 1u, nops = (d.w >> 21) & 7u, strides = (d.w >> 24) & 31u;
+    const uint32_t idx[5] = {d.y & 0xFFFFu, d.y >> 16, d.z & 0xFFFFu, d.z >> 16, d.w & 0xFFFFu};
+    uint32_t x[5];
+#pragma unroll
+    for (int o = 0; o < 5; o++) {
+      const uint32_t i = idx[o];
+      const uint32_t v = cut32(i < T ? ones : xones, i < T ? i : i - T);
+      x[o] = (uint32_t)o < nops ? ((strides >> o) & 1u ? v : 0u - (v & 1u)) : 0u;
+    }
+    const uint32_t holds = table32(d.x, x[0], x[1], x[2], x[3], x[4]);
+    return mine ? ~holds & (len == 32u ? ~0u : (1u << len) - 1u) : 0u;
+  };
+  // ---- exports of unit k: lane j takes export j — element px of the tile to slot slot0 + j, and the bits of 64 of them as one word
+  auto exports = [&](const Cursor c, const uint32_t par) {
+    const uint32_t exp_n = TW(c, B3W_WT_EXP_N), slot0 = TW(c, B3W_WT_EXP_SLOT0);
+    if (wave * 64u >= exp_n) return;                           // (wave-uniform)
+    const unsigned long long z = tid < exp_n ? el0[par * T + px] : 0ull;
+    xel[slot0 + tid] = z;
+    const unsigned long long is1 = __ballot(z == 1ull);
+    if (lane == 0) xones[(slot0 >> 6) + wave] = is1;
+  };
+  // ---- verdicts of the general rows of unit k (one iteration after its entries were added): row g -> lane g of the workgroup
+  auto verdicts = [&](const Cursor c, const uint32_t par, const bool careful, uint32_t &nbad, uint32_t &low) {
+    const uint32_t gen_n = TW(c, B3W_WT_GEN_N);
+    if (wave * 64u >= gen_n) return;                           // (wave-uniform)
+    unsigned long long *sum = gsum0 + par * 6u * W.max_gen + 6u * tid;
+    uint32_t *gflag = gflag0 + par * gr2;
+    bool defer = false, bad = false;
+    if (tid < gen_n) {
+      unsigned long long a_lo, b_lo, c_lo;
+      long long a_hi, b_hi, c_hi;
+      part_sum(sum[0], sum[1], a_lo, a_hi);
+      part_sum(sum[2], sum[3], b_lo, b_hi);
+      part_sum(sum[4], sum[5], c_lo, c_hi);
+      defer = gflag[tid] != 0u || a_hi != ((long long)a_lo >> 63) || b_hi != ((long long)b_lo >> 63);
+      bad = !defer && (a_lo * b_lo != c_lo || __mul64hi((long long)a_lo, (long long)b_lo) != c_hi);
+#pragma unroll
+      for (int q = 0; q < 6; q++) sum[q] = 0ull;
+      gflag[tid] = 0u;
+    }
+    if (careful) return;                                       // (every row of this unit goes to the deferred kernel: nothing is counted here)
+    const unsigned long long dm = __ballot(defer);
+    if (dm != 0ull && lane == 0) dmask0[par * 8u + wave] = dm;
+    if (bad) { nbad++; low = min(low, W.row_id[TW(c, B3W_WT_ROW0) + tid]); }
+  };
+  // ---- the scratch block of unit k for the deferred kernel, by wave 1 once every wave's verdicts of the unit are behind a barrier:
+  // word 0 = which mask words follow (bit w = word w is stored and not zero); a careful unit: all its rows
+  auto summary = [&](const Cursor c, const uint32_t par, const bool careful) {
+    if (wave != 1u) return;
+    const uint32_t nrows = TW(c, B3W_WT_NROWS), words = (nrows + 63u) >> 6;
+    unsigned long long v = 0ull;
+    if (lane < words) {
+      v = lstat[c.tile * W.static_words + lane];
+      if (lane < 8u) { v |= dmask0[par * 8u + lane]; dmask0[par * 8u + lane] = 0ull; }
+      if (careful) v = lane + 1u < words || !(nrows & 63u) ? ~0ull : (1ull << (nrows & 63u)) - 1ull;
+    }
+    unsigned long long *block = scratch + ((size_t)c.body * W.ntiles + c.tile) * block_words;
+    const unsigned long long head = __ballot(v != 0ull);
+    if (v != 0ull) block[1u + lane] = v;
+    if (lane == 0) block[0] = head;
+  };
+  // ---- a body's result, once the verdicts of its last unit are behind a barrier: one lane stores what the workgroup counted
+  auto flush = [&](const uint32_t body) {
+    if (tid == 0) {
+      const uint32_t s = body % 3u;
+      violations[body] = cnt[s];
+      if (first) first[body] = cnt[3u + s];
+      cnt[s] = 0u; cnt[3u + s] = 0xFFFFFFFFu;
+    }
+  };
+  auto count = [&](uint32_t nbad, uint32_t low, const uint32_t body) {
+    if (__ballot(nbad != 0u) == 0ull) return;                  // (nearly always)
+#pragma unroll
+    for (int sh = 32; sh > 0; sh >>= 1) {
+      nbad += (uint32_t)__shfl_xor((int)nbad, sh);
+      low = min(low, (uint32_t)__shfl_xor((int)low, sh));
+    }
+    if (lane == 0) { atomicAdd(&cnt[body % 3u], nbad); atomicMin(&cnt[3u + body % 3u], low); }
+  };
+
+  // ---- the pipeline.  Iteration i: entries, runs, exports of unit i | verdicts of unit i - 1 | scratch block of unit i - 2 |
+  // pack unit i + 1 | program of unit i + 1, fetch of unit i + 2 | barrier.
+  Cursor cf{b0, 0, 0}, cp{b0, 0, 0}, ce{b0, 0, 0};            // fetch, pack, evaluate
+  load_rec(cf);
+  cp.rec = ce.rec = cf.rec;
+  const Cursor last{b1 - 1u, W.ntiles - 1u, 0};
+  auto step = [&](Cursor &c) { if (c.body != last.body || c.tile != last.tile) advance(c); };      // (stays on the last unit)
+  fetch(cf); step(cf);                                        // unit 0
+  program(cp);
+  pack(cp, true, 0u, 0u); step(cp);
+  fetch(cf); step(cf);                                        // unit 1
+  lds_barrier();
+  Cursor prev = ce, prev2 = ce;
+  bool sticky = false, prev_careful = false, prev2_careful = false;
+  uint32_t i3 = 0;
+  for (uint32_t i = 0; i < m; i++) {
+    const uint32_t par = i & 1u;
+    const uint32_t i3n = i3 == 2u ? 0u : i3 + 1u, i3nn = i3n == 2u ? 0u : i3n + 1u;
+    const bool anomaly = __builtin_amdgcn_readfirstlane(lanom[i3]) != 0u;
+    if (tid == 0) lanom[i3nn] = 0u;
+    sticky = ce.tile == 0u ? anomaly : (sticky || anomaly);   // (an anomalous tile taints the rest of its body: later tiles import from it)
+    if (i >= 2u) {
+      summary(prev2, par, prev2_careful);
+      if (prev2.tile == W.ntiles - 1u) flush(prev2.body);     // (its verdicts ran in the last iteration, behind the last barrier)
+    }
+    uint32_t nbad = 0, low = 0xFFFFFFFFu;
+    entries(ce, par);
+    {
+      const uint32_t run_n = TW(ce, B3W_WT_RUN_N);
+      if (wave * 64u < run_n) {
+        const uint32_t viol = run_bits(prun, par, tid < run_n);
+        if (viol && !sticky) {
+          nbad += (uint32_t)__popc(viol);
+          low = min(low, W.row_id[W.run_row[TW(ce, B3W_WT_RUN_OFF) + tid] + (uint32_t)__ffs((int)viol) - 1u]);
+        }
+      }
+    }
+    exports(ce, par);
+    count(nbad, low, ce.body);
+    if (i) {
+      uint32_t nb2 = 0, low2 = 0xFFFFFFFFu;
+      verdicts(prev, par ^ 1u, prev_careful, nb2, low2);
+      count(nb2, low2, prev.body);
+    }
+    pack(cp, i + 1u < m, par ^ 1u, i3n);
+    program(cp);
+    fetch(cf);
+    step(cp); step(cf);
+    prev2 = prev; prev2_careful = prev_careful;
+    prev = ce; prev_careful = sticky;
+    step(ce);
+    i3 = i3n;
+    lds_barrier();
+  }
+  {
+    uint32_t nb2 = 0, low2 = 0xFFFFFFFFu;
+    verdicts(prev, (m - 1u) & 1u, prev_careful, nb2, low2);
+    count(nb2, low2, prev.body);
+  }
+  lds_barrier();
+  if (m >= 2u) { summary(prev2, m & 1u, prev2_careful); if (prev2.tile == W.ntiles - 1u) flush(prev2.body); }
+  lds_barrier();
+  summary(prev, (m - 1u) & 1u, prev_careful);
+  flush(prev.body);
+}
+#undef TW
+
 // the result arrays start from "no violation": a kernel rather than hipMemsetAsync, so that the whole check is made of
 // kernel nodes when a caller captures it into a hipGraph (memset nodes of a captured graph were seen to leave garbage)
 __global__ void b3w_r1cs_init_kernel(uint32_t *__restrict__ violations, uint32_t *__restrict__ first, uint32_t n) {
@@ -1306,60 +1473,6 @@ static int r1cs_init_results(uint32_t *d_violations, uint32_t *d_first, uint32_t
   return (int)hipGetLastError();
 }
 
-extern "C" int b3w_launch_r1cs_tiled(const uint8_t *d_bodies, uint32_t n, uint64_t pitch, uint32_t nwires, uint32_t ntiles, uint32_t max_ext,
-                                     uint32_t max_tile_terms, const uint32_t *d_tiles, const uint32_t *d_tile_terms, const uint32_t *d_ext, const uint32_t *d_rows, const uint32_t *d_row_id,
-                                     const uint32_t *d_terms, const uint32_t *d_coefs, const long long *d_coef_small, uint32_t ncoef,
-                                     const B3wField *field, uint32_t *d_violations, uint32_t *d_first, hipStream_t stream) {
-  if (!n || !ntiles) return 0;
-  if (max_ext > B3W_R1CS_TILE) return -5;
-  hipError_t e = (hipError_t)r1cs_init_results(d_violations, d_first, n, stream);
-  if (e != hipSuccess) return (int)e;
-  size_t smem = (size_t)(B3W_R1CS_TILE + max_ext) * 32;
-  // the tile's term list rides along in LDS only while four workgroups still fit a CU (160 KB): measured on blake3_compression,
-  // staging the terms at the price of two workgroups per CU is 4.2 ms per 4 096 bodies against 2.5 ms with the terms read from
-  // global memory (L1/L2 hits) — occupancy hides the term loads better than LDS shortens them
-  uint32_t lds_terms = 0;
-  if (smem + (size_t)max_tile_terms * 4 <= 40 * 1024) { lds_terms = max_tile_terms; smem += (size_t)max_tile_terms * 4 + 4; }
-  const bool coef_lds = ncoef <= 512;                      // 4 KB at most
-  if (coef_lds) smem = ((smem + 7) & ~(size_t)7) + (size_t)ncoef * 8;
-  if (smem > 64 * 1024) {
-    // a system with many outside wires per tile (max_ext near 1 024: 64 KB of elements alone) needs more than the default
-    // dynamic-LDS limit: raise it for the instantiation this launch takes, once per device
-    static std::mutex mu;
-    static unsigned done[64][4];
-    int dev = 0;
-    if ((e = hipGetDevice(&dev)) != hipSuccess) return (int)e;
-    const int inst = (lds_terms ? 2 : 0) + (coef_lds ? 1 : 0);
-    std::lock_guard<std::mutex> lock(mu);
-    if (!done[dev & 63][inst]) {
-      const void *fn = inst == 3   ? reinterpret_cast<const void *>(&b3w_r1cs_tile_kernel<true, true>)
-                       : inst == 2 ? reinterpret_cast<const void *>(&b3w_r1cs_tile_kernel<true, false>)
-                       : inst == 1 ? reinterpret_cast<const void *>(&b3w_r1cs_tile_kernel<false, true>)
-                                   : reinterpret_cast<const void *>(&b3w_r1cs_tile_kernel<false, false>);
-      if ((e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)) != hipSuccess) return (int)e;
-      done[dev & 63][inst] = 1;
-    }
-  }
-  const uint32_t slab = (0x7FFFFFFFu / ntiles) & ~7u;
-  for (uint32_t b0 = 0; b0 < n; b0 += slab) {
-    const uint32_t nb = n - b0 < slab ? n - b0 : slab;
-    const uint32_t groups = (nb + 7) / 8;
-#define B3W_R1CS_TILE_LAUNCH(STAGED, CL)                                                                                               \
-    hipLaunchKernelGGL((b3w_r1cs_tile_kernel<STAGED, CL>), dim3(groups * 8 * ntiles), dim3(256), smem, stream,                             \
-                       d_bodies + (uint64_t)b0 * pitch, pitch, nb, nwires, ntiles, max_ext, lds_terms, ncoef,                              \
-                       reinterpret_cast<const uint4 *>(d_tiles), reinterpret_cast<const uint2 *>(d_tile_terms), d_ext,                    \
-                       reinterpret_cast<const uint4 *>(d_rows), d_row_id, d_terms, d_coefs, d_coef_small, *field, d_violations + b0,       \
-                       d_first ? d_first + b0 : nullptr)
-    if (lds_terms && coef_lds) B3W_R1CS_TILE_LAUNCH(true, true);
-    else if (lds_terms) B3W_R1CS_TILE_LAUNCH(true, false);
-    else if (coef_lds) B3W_R1CS_TILE_LAUNCH(false, true);
-    else B3W_R1CS_TILE_LAUNCH(false, false);
-#undef B3W_R1CS_TILE_LAUNCH
-    e = hipGetLastError();
-    if (e != hipSuccess) return (int)e;
-  }
-  return 0;
-}
 
 extern "C" int b3w_launch_r1cs(const uint8_t *d_bodies, uint32_t n, uint64_t pitch, uint32_t m, const uint32_t *d_rows,
                                const uint32_t *d_row_id, const uint32_t *d_wires, const uint16_t *d_cids, const uint32_t *d_coefR,
@@ -1551,6 +1664,69 @@ extern "C" int b3w_launch_r1cs_stream(const uint8_t *d_bodies, uint32_t n, uint6
     const dim3 dgrid(((nb + 7) / 8) * 8 * ((sys->ntiles + B3W_R1CS_DEFERRED_TILES - 1u) / B3W_R1CS_DEFERRED_TILES));
     hipLaunchKernelGGL(b3w_r1cs_deferred_kernel, dgrid, dim3(64), 0, stream, d_bodies + (uint64_t)b0 * pitch, pitch, nb, *sys, d_scratch, bw,
                        *field, d_violations + b0, d_first ? d_first + b0 : nullptr, true);
+    e = hipGetLastError();
+    if (e != hipSuccess) return (int)e;
+  }
+  return 0;
+}
+
+// ---- WALK launch
+static inline uint32_t walk_block_words(const B3wWalk *w) { return 2u + ((w->max_rows + 63u) >> 6); }
+static inline size_t walk_smem(const B3wWalk *w) {
+  const size_t xw = (w->exp_slots >> 6) + 1u, gr2 = (w->max_gen + 1u) & ~1u;
+  return 8u * (2u * (size_t)B3W_R1CS_TILE + w->exp_slots + 36u + xw + 12u * (size_t)w->max_gen + 16u + ((w->ncoef + 1u) & ~1u) + 16u * (size_t)w->ntiles +
+               (size_t)w->static_words * w->ntiles) +
+         4u * (2u * gr2 + (size_t)w->ntiles * B3W_WT_WORDS + 4u + 6u) + 32u;
+}
+extern "C" size_t b3w_r1cs_walk_scratch_bytes(const B3wWalk *w) { return (size_t)B3W_R1CS_SLAB * w->ntiles * walk_block_words(w) * 8; }
+
+extern "C" int b3w_launch_r1cs_walk(const uint8_t *d_bodies, uint32_t n, uint64_t pitch, const B3wWalk *walk, const B3wR1csSystem *sysw, const B3wField *field,
+                                    unsigned long long *d_scratch, uint32_t *d_violations, uint32_t *d_first, hipStream_t stream) {
+  if (!n || !walk->ntiles) return 0;
+  if (!d_scratch) return -5;
+  static const int env_grid = getenv("B3W_R1CS_GRID") ? atoi(getenv("B3W_R1CS_GRID")) : 0;
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return (int)e;
+  const uint32_t ne = (walk->max_ent + 511u) / 512u;         // entry chunks per wave
+  if (ne > 4u) return -6;
+  const void *fn = ne <= 1u ? reinterpret_cast<const void *>(&b3w_r1cs_walk_kernel<1>) : ne == 2u ? reinterpret_cast<const void *>(&b3w_r1cs_walk_kernel<2>)
+                   : ne == 3u ? reinterpret_cast<const void *>(&b3w_r1cs_walk_kernel<3>) : reinterpret_cast<const void *>(&b3w_r1cs_walk_kernel<4>);
+  struct PerDevice { int cus = 0, lds = 0; bool attr[4] = {false, false, false, false}; };
+  static PerDevice per[64];
+  static std::mutex mu;
+  const size_t smem = walk_smem(walk);
+  int cus = 0, lds = 0;
+  {
+    std::lock_guard<std::mutex> lock(mu);
+    PerDevice &pd = per[dev & 63];
+    if (!pd.cus) {
+      if ((e = hipDeviceGetAttribute(&pd.cus, hipDeviceAttributeMultiprocessorCount, dev)) != hipSuccess) return (int)e;
+      if ((e = hipDeviceGetAttribute(&pd.lds, hipDeviceAttributeMaxSharedMemoryPerBlock, dev)) != hipSuccess) return (int)e;
+      if (pd.lds < 160 * 1024) pd.lds = 64 * 1024;
+    }
+    if (smem > (size_t)pd.lds) return -6;
+    if (!pd.attr[ne ? ne - 1u : 0u]) {
+      if ((e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, pd.lds)) != hipSuccess) return (int)e;
+      pd.attr[ne ? ne - 1u : 0u] = true;
+    }
+    cus = pd.cus; lds = pd.lds;
+  }
+  int wgs = (int)((size_t)lds / smem);
+  if (wgs > 2) wgs = 2;
+  if (wgs < 1) wgs = 1;
+  const uint32_t bw = walk_block_words(walk);
+  for (uint32_t b0 = 0; b0 < n; b0 += B3W_R1CS_SLAB) {
+    const uint32_t nb = n - b0 < B3W_R1CS_SLAB ? n - b0 : B3W_R1CS_SLAB;
+    uint32_t grid = env_grid > 0 ? (uint32_t)env_grid : (uint32_t)(cus * wgs);
+    if (grid > nb) grid = nb;                                // (whole bodies per workgroup)
+    const uint8_t *bodies0 = d_bodies + (uint64_t)b0 * pitch;
+    uint32_t *viol0 = d_violations + b0, *first0 = d_first ? d_first + b0 : nullptr;
+    void *args[] = {(void *)&bodies0, (void *)&pitch, (void *)&nb, (void *)walk, (void *)&d_scratch, (void *)&bw, (void *)&viol0, (void *)&first0};
+    e = hipLaunchKernel(fn, dim3(grid), dim3(512), args, smem, stream);
+    if (e != hipSuccess) return (int)e;
+    const dim3 dgrid(((nb + 7) / 8) * 8 * ((sysw->ntiles + B3W_R1CS_DEFERRED_TILES - 1u) / B3W_R1CS_DEFERRED_TILES));
+    hipLaunchKernelGGL(b3w_r1cs_deferred_kernel, dgrid, dim3(64), 0, stream, bodies0, pitch, nb, *sysw, d_scratch, bw, *field, viol0, first0, true);
     e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
   }

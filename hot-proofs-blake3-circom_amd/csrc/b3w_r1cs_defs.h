@@ -25,5 +25,5 @@ struct B3wField {
 #define B3W_WT_NROWS 11
 #define B3W_WT_WORDS 16
 #define B3W_WALK_MAX_EXP_SLOTS 4096u
-#define B3W_WALK_MAX_GEN 256u
+#define B3W_WALK_MAX_GEN 512u
 #define B3W_WALK_MAX_ENT 4096u

@@ -666,7 +666,7 @@ bool b3w_r1cs_host_build(const uint8_t *img, size_t len, const uint8_t prime_le[
       wtiles4[4 * (size_t)t] = row0; wtiles4[4 * (size_t)t + 1] = nrows;
       wmax_gen = std::max<uint32_t>(wmax_gen, (uint32_t)gen.size());
       wmax_rows = std::max(wmax_rows, nrows);
-      if (gen.size() > B3W_WALK_MAX_GEN || wmax_ent > B3W_WALK_MAX_ENT || nrows > 4096u) walk = false;
+      if (gen.size() > B3W_WALK_MAX_GEN || wmax_ent > B3W_WALK_MAX_ENT || nrows > 4096u) { if (getenv("B3W_WALK_DEBUG")) fprintf(stderr, "walk: tile %u gen %zu ent %u rows %u\n", t, gen.size(), wmax_ent, nrows); walk = false; }
     }
     if (walk) {
       const uint32_t sw = (wmax_rows + 63u) / 64u;

@@ -10,6 +10,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <new>
 #include <stdexcept>
 #include <vector>
@@ -119,6 +120,64 @@ static bool indices_ok(const B3wR1csHost &H) {
   return true;
 }
 
+// the walk kernel's program: every index it follows inside its array, every import from an EARLIER tile
+static bool walk_ok(const B3wR1csHost &H) {
+  if (!H.walk) return true;
+  const uint32_t T = B3W_R1CS_TILE, nt = H.ntiles;
+  CHECK(H.wtile.size() == (size_t)B3W_WT_WORDS * nt && H.wmask.size() == 16 * (size_t)nt && H.wtiles4.size() == 4 * (size_t)nt);
+  CHECK(H.wexp_slots % 64 == 0 && H.wexp_slots <= B3W_WALK_MAX_EXP_SLOTS && H.wstatic.size() == (size_t)nt * H.wstatic_words);
+  CHECK(H.wrow_k.size() == H.m && H.wrow_id.size() == H.m && H.wruns.size() % 4 == 0 && H.wrun_row.size() + 1 == H.wruns.size() / 4);
+  CHECK(H.went_w.size() == H.went_m.size() && H.wmax_gen <= B3W_WALK_MAX_GEN && H.wmax_ent <= B3W_WALK_MAX_ENT);
+  std::vector<uint8_t> seen(H.m, 0);
+  uint32_t rows_so_far = 0, slots_so_far = 0;
+  for (uint32_t t = 0; t < nt; t++) {
+    const uint32_t *w = &H.wtile[(size_t)B3W_WT_WORDS * t];
+    const uint32_t n_local = w[B3W_WT_NLOCAL], exp_n = w[B3W_WT_EXP_N], slot0 = w[B3W_WT_EXP_SLOT0];
+    CHECK(n_local == std::min<uint32_t>(T, H.nwires - t * T) && slot0 == slots_so_far && slot0 % 64 == 0);
+    CHECK((uint64_t)w[B3W_WT_EXP_OFF] + exp_n + 1 <= H.wexp.size() && exp_n <= H.wmax_exp);
+    for (uint32_t j = 0; j < exp_n; j++) CHECK(H.wexp[w[B3W_WT_EXP_OFF] + j] < n_local && (j == 0 || H.wexp[w[B3W_WT_EXP_OFF] + j] > H.wexp[w[B3W_WT_EXP_OFF] + j - 1]));
+    slots_so_far += (exp_n + 63u) & ~63u;
+    // an element index of this tile: local, or a slot an EARLIER tile has filled
+    auto idx_ok = [&](uint32_t idx, uint32_t len) { return idx < T ? idx + len <= n_local : idx - T + len <= slot0; };
+    CHECK(w[B3W_WT_ROW0] == rows_so_far && H.wtiles4[4 * t] == rows_so_far && H.wtiles4[4 * t + 1] == w[B3W_WT_NROWS]);
+    const uint32_t row0 = w[B3W_WT_ROW0], nrows = w[B3W_WT_NROWS], gen_n = w[B3W_WT_GEN_N];
+    CHECK(nrows <= H.wmax_rows && (nrows + 63) / 64 <= H.wstatic_words && gen_n <= nrows && gen_n <= H.wmax_gen);
+    for (uint32_t r = row0; r < row0 + nrows; r++) { CHECK(H.wrow_k[r] < H.m && !seen[H.wrow_k[r]]); seen[H.wrow_k[r]] = 1; }
+    rows_so_far += nrows;
+    const uint32_t run_off = w[B3W_WT_RUN_OFF], run_n = w[B3W_WT_RUN_N];
+    CHECK((uint64_t)run_off + run_n + 1 <= H.wruns.size() / 4 && run_n <= H.wmax_runs);
+    uint32_t next_row = row0 + gen_n;
+    for (uint32_t r = run_off; r < run_off + run_n; r++) {
+      const uint32_t *d = &H.wruns[4 * (size_t)r];
+      const uint32_t len = ((d[3] >> 16) & 31u) + 1u, nops = (d[3] >> 21) & 7u, strides = (d[3] >> 24) & 31u;
+      const uint32_t idx[5] = {d[1] & 0xFFFFu, d[1] >> 16, d[2] & 0xFFFFu, d[2] >> 16, d[3] & 0xFFFFu};
+      CHECK(nops >= 1 && nops <= 5 && !(d[3] >> 29) && (len > 1 || strides == 0));
+      for (uint32_t o = 0; o < 5; o++) CHECK(o < nops ? idx_ok(idx[o], (strides >> o) & 1u ? len : 1u) : (idx[o] == 0 && !((strides >> o) & 1u)));
+      CHECK(H.wrun_row[r] == next_row);                     // the rows of the runs follow the general rows, run after run
+      next_row += len;
+    }
+    CHECK(next_row <= row0 + nrows);
+    const uint32_t ent_off = w[B3W_WT_ENT_OFF], ent_n = w[B3W_WT_ENT_N], ent_runs = w[B3W_WT_ENT_RUNS];
+    CHECK((uint64_t)ent_off + ent_n + 1 <= H.went_w.size() && ent_n <= H.wmax_ent && ent_runs <= ent_n && ent_runs % 64 == 0);
+    for (uint32_t i = 0; i < ent_n; i++) {
+      const uint32_t e = H.went_w[ent_off + i], mt = H.went_m[ent_off + i];
+      if (mt & 4u) { CHECK(i < ent_runs && mt == 4u); continue; }
+      CHECK((mt & 3u) < 3u && (mt >> 8) < gen_n && ((mt >> 3) & 1u) == (i < ent_runs ? 1u : 0u) && !(mt & 0xF0u));
+      if (i < ent_runs) {
+        const uint32_t n = (e >> 16) & 0x7Fu, sh = (e >> 23) & 0x3Fu;
+        CHECK(n >= 4 && n <= 64 && sh + n <= 62 && !(e >> 30) && idx_ok(e & 0xFFFFu, n));
+      } else CHECK(idx_ok(e & 0xFFFFu, 1) && (e >> 16) < H.ncoef);
+    }
+    // always-deferred rows lie behind the general rows and the runs, inside the tile
+    for (uint32_t k = 0; k < H.wstatic_words; k++) {
+      const unsigned long long sm = H.wstatic[(size_t)t * H.wstatic_words + k];
+      for (uint32_t bit = 0; bit < 64; bit++) if ((sm >> bit) & 1ull) CHECK(64 * k + bit >= next_row - row0 && 64 * k + bit < nrows);
+    }
+  }
+  CHECK(rows_so_far == H.m && slots_so_far == H.wexp_slots);
+  return true;
+}
+
 // the lean stream against the gather arrays
 static bool same_sums(const B3wR1csHost &H, const uint8_t prime_le[32]) {
   if (!H.tiled) return true;
@@ -191,6 +250,103 @@ static bool same_sums(const B3wR1csHost &H, const uint8_t prime_le[32]) {
   return true;
 }
 
+// the walk program's data path on a random assignment: exports, general rows' sums (mod 2^64, against the gather arrays), every row
+// of every truth-table run against the row evaluated in plain integers, booleanity rows' wires in the must-be-bit masks
+static bool walk_same(const B3wR1csHost &H, const uint8_t prime_le[32]) {
+  if (!H.walk) return true;
+  const uint32_t T = B3W_R1CS_TILE, nt = H.ntiles;
+  uint64_t p_lo;
+  memcpy(&p_lo, prime_le, 8);
+  auto coef_lo = [&](uint32_t cid) { uint64_t c; memcpy(&c, &H.coefR[16 * (size_t)cid], 8); return c; };
+  std::vector<uint64_t> z(H.nwires);
+  for (uint32_t w = 0; w < H.nwires; w++) {
+    const uint64_t x = rnd();
+    const bool mustbit = (H.wmask[(size_t)(w / T) * 16 + ((w % T) >> 6)] >> (w & 63u)) & 1ull;
+    z[w] = mustbit || (x & 3) ? (x >> 2) & 1 : (x >> 8) & 0xFFFFFFFFu;
+  }
+  z[0] = 1;
+  std::vector<uint64_t> xel(H.wexp_slots, 0);
+  std::vector<uint32_t> slot_wire(H.wexp_slots, 0xFFFFFFFFu);
+  size_t tt_rows = 0;
+  for (uint32_t t = 0; t < nt; t++) {
+    const uint32_t *w = &H.wtile[(size_t)B3W_WT_WORDS * t];
+    auto value = [&](uint32_t idx) { return idx < T ? z[t * T + idx] : xel[idx - T]; };
+    auto wire_of = [&](uint32_t idx) { return idx < T ? t * T + idx : slot_wire[idx - T]; };
+    const uint32_t row0 = w[B3W_WT_ROW0], nrows = w[B3W_WT_NROWS], gen_n = w[B3W_WT_GEN_N];
+    // general rows
+    std::vector<uint64_t> sums(3 * (size_t)gen_n, 0);
+    for (uint32_t i = 0; i < w[B3W_WT_ENT_N]; i++) {
+      const uint32_t e = H.went_w[w[B3W_WT_ENT_OFF] + i], mt = H.went_m[w[B3W_WT_ENT_OFF] + i];
+      if (mt & 4u) continue;
+      uint64_t v = 0;
+      if (mt & 8u) {
+        const uint32_t n = (e >> 16) & 0x7Fu, sh = (e >> 23) & 0x3Fu;
+        for (uint32_t q = 0; q < n; q++) {
+          CHECK(value((e & 0xFFFFu) + q) <= 1);             // a run's elements are must-be-bit wires
+          v += ((e >> 29) & 1u ? p_lo - (1ull << (sh + q)) : 1ull << (sh + q)) * value((e & 0xFFFFu) + q);
+        }
+      } else v = coef_lo(e >> 16) * value(e & 0xFFFFu);
+      sums[3 * (size_t)(mt >> 8) + (mt & 3u)] += v;
+    }
+    for (uint32_t g = 0; g < gen_n; g++) {
+      const uint32_t k = H.wrow_k[row0 + g];
+      uint32_t gq = H.rowdesc[4 * k];
+      for (int part = 0; part < 3; part++) {
+        uint64_t want = 0;
+        for (uint32_t x = 0; x < H.rowdesc[4 * k + 1 + part]; x++, gq++) { want += coef_lo(H.cids[gq]) * z[H.wires[gq]]; CHECK(H.wires[gq] / T <= t); }
+        CHECK(want == sums[3 * (size_t)g + part]);
+      }
+    }
+    // truth-table runs
+    uint32_t next_row = row0 + gen_n;
+    for (uint32_t r = w[B3W_WT_RUN_OFF]; r < w[B3W_WT_RUN_OFF] + w[B3W_WT_RUN_N]; r++) {
+      const uint32_t *d = &H.wruns[4 * (size_t)r];
+      const uint32_t len = ((d[3] >> 16) & 31u) + 1u, nops = (d[3] >> 21) & 7u, strides = (d[3] >> 24) & 31u;
+      const uint32_t idx[5] = {d[1] & 0xFFFFu, d[1] >> 16, d[2] & 0xFFFFu, d[2] >> 16, d[3] & 0xFFFFu};
+      for (uint32_t j = 0; j < len; j++, next_row++) {
+        uint32_t a = 0;
+        std::vector<uint32_t> ops;
+        for (uint32_t o = 0; o < nops; o++) {
+          const uint32_t ix = idx[o] + ((strides >> o) & 1u ? j : 0u);
+          CHECK(value(ix) <= 1);
+          a |= (uint32_t)value(ix) << o;
+          ops.push_back(wire_of(ix));
+        }
+        const bool holds = (d[0] >> a) & 1u;
+        const uint32_t k = H.wrow_k[next_row];
+        uint32_t gq = H.rowdesc[4 * k];
+        __int128 part[3] = {0, 0, 0};
+        bool small = true;
+        for (int pt = 0; pt < 3; pt++)
+          for (uint32_t x = 0; x < H.rowdesc[4 * k + 1 + pt]; x++, gq++) {
+            const long long cs = H.coef_small[H.cids[gq]];
+            small = small && cs != B3W_R1CS_NOT_SMALL;
+            part[pt] += (__int128)cs * (__int128)z[H.wires[gq]];
+            CHECK(std::find(ops.begin(), ops.end(), H.wires[gq]) != ops.end());      // the run's operands are this row's wires
+          }
+        if (small) CHECK(holds == (part[0] * part[1] == part[2]));
+        tt_rows++;
+      }
+    }
+    // behind them: always-deferred rows (a coefficient that is no small integer, or very long), then booleanity rows
+    for (uint32_t r = next_row; r < row0 + nrows; r++) {
+      const uint32_t k = H.wrow_k[r], pos = r - row0;
+      const bool stat = (H.wstatic[(size_t)t * H.wstatic_words + (pos >> 6)] >> (pos & 63u)) & 1ull;
+      if (stat) continue;
+      CHECK(H.rowdesc[4 * k + 1] == 1 && H.rowdesc[4 * k + 2] == 2 && H.rowdesc[4 * k + 3] == 0);
+      const uint32_t bw = H.wires[H.rowdesc[4 * k]];
+      CHECK(bw / T == t && ((H.wmask[(size_t)t * 16 + ((bw % T) >> 6)] >> (bw & 63u)) & 1ull));
+    }
+    // this tile's exports, for the tiles behind it
+    for (uint32_t j = 0; j < w[B3W_WT_EXP_N]; j++) {
+      xel[w[B3W_WT_EXP_SLOT0] + j] = z[t * T + H.wexp[w[B3W_WT_EXP_OFF] + j]];
+      slot_wire[w[B3W_WT_EXP_SLOT0] + j] = t * T + H.wexp[w[B3W_WT_EXP_OFF] + j];
+    }
+  }
+  printf("walk program: %zu truth-table rows in runs agree with plain integers\n", tt_rows);
+  return true;
+}
+
 int main(int argc, char **argv) {
   if (argc < 5) { fprintf(stderr, "usage: harness <image> <nwit> <mutations> <seed>\n"); return 2; }
   FILE *f = fopen(argv[1], "rb");
@@ -209,7 +365,8 @@ int main(int argc, char **argv) {
   {
     B3wR1csHost H;
     if (!b3w_r1cs_host_build(img.data(), img.size(), prime, nwit, &H)) { fprintf(stderr, "pristine image refused: %s\n", H.error.c_str()); return 1; }
-    if (!indices_ok(H) || !same_sums(H, prime)) return 1;
+    if (!indices_ok(H) || !walk_ok(H) || !same_sums(H, prime) || !walk_same(H, prime)) return 1;
+    printf("walk %d: %u export slots, %zu runs, %zu entries\n", (int)H.walk, H.wexp_slots, H.wruns.size() / 4, H.went_w.size());
     uint64_t runs = 0;
     for (size_t i = 0; i + 1 < H.lterms.size(); i++) runs += (H.lterms[i] >> 16) == 0xFFFFu;
     printf("pristine: %u constraints, %llu terms, tiled %d, %u tiles, max_ext %u, lean words %zu (%llu runs)\n", H.m,
@@ -228,7 +385,7 @@ int main(int argc, char **argv) {
     try {
       B3wR1csHost H;
       if (b3w_r1cs_host_build(bad.data(), bad.size(), prime, nwit, &H)) {
-        if (!indices_ok(H)) { fprintf(stderr, "mutation %d loaded with bad indices\n", k); return 1; }
+        if (!indices_ok(H) || !walk_ok(H)) { fprintf(stderr, "mutation %d loaded with bad indices\n", k); return 1; }
         loaded++;
       } else {
         if (H.error.empty()) { fprintf(stderr, "mutation %d refused without a text\n", k); return 1; }

@@ -35,5 +35,7 @@ def test_host_builder_under_sanitizers(harness, tmp_path, name, nwit, mutations)
                        env=dict(os.environ, ASAN_OPTIONS="detect_leaks=1:allocator_may_return_null=1", UBSAN_OPTIONS="print_stacktrace=1"))
     assert r.returncode == 0, (r.stdout[-1500:], r.stderr[-3000:])
     assert "pristine:" in r.stdout and "tiled 1" in r.stdout and f"mutations: " in r.stdout
+    # the walk program (round 4) exists for all three and its data path agrees with the gather arrays and with plain integers
+    assert "walk 1:" in r.stdout and "truth-table rows in runs agree with plain integers" in r.stdout
     runs = int(r.stdout.split("(")[1].split(" runs")[0])
     assert runs >= (900 if name != "blake3_nova_vesta" else 2000)             # the recomposition rows were folded
