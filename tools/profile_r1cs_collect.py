@@ -6,7 +6,7 @@ reports half of a wide coalesced read stream — /opt/skills/guides/MI355X_MICRO
 import csv, glob, json, os, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-rnd = sys.argv[1] if len(sys.argv) > 1 else "r03"
+rnd = sys.argv[1] if len(sys.argv) > 1 else "r04"
 src = os.path.join(ROOT, "gpurun_out", "prof_r1cs")
 dst = os.path.join(ROOT, "profiles", rnd)
 os.makedirs(dst, exist_ok=True)
@@ -25,7 +25,7 @@ for c in ("compression", "nova_vesta"):
     with open(os.path.join(dst, f"r1cs_check_{c}_kernel_stats.csv"), "w") as f:
         w = csv.DictWriter(f, fieldnames=rows[0].keys(), quoting=csv.QUOTE_NONNUMERIC)
         w.writeheader(); w.writerows(rows)
-    kind = lambda name: "stream" if "stream" in name else "lean" if "lean" in name else "deferred" if "deferred" in name else "init"
+    kind = lambda name: "walk" if "walk" in name else "stream" if "stream" in name else "lean" if "lean" in name else "deferred" if "deferred" in name else "init"
     avg = {kind(r["Name"]): float(r["AverageNs"]) for r in rows}
     pm = [r for r in csv.DictReader(open(find(f"fetch_{c}", "*counter_collection.csv")))
           if r["Counter_Name"] == "FETCH_SIZE" and "b3w_r1cs" in r["Kernel_Name"]]
