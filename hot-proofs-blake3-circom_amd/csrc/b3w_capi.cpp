@@ -1168,7 +1168,6 @@ struct b3w_r1cs {
            *d_wtiles4 = nullptr;
   uint16_t *d_wexp = nullptr;
   unsigned long long *d_wmask = nullptr, *d_wstatic = nullptr;
-  B3wField *d_field = nullptr;
   B3wWalk walk{};
   B3wR1csSystem sysw{};
   // ... at most R1CS_SCRATCH_STREAMS of them: the least recently used one goes when another stream comes (after the event that
@@ -1253,7 +1252,6 @@ static int32_t r1cs_create_impl(b3w_ctx *ctx, const uint8_t *img, size_t len, b3
     up((void **)&r->d_wrow_id, H.wrow_id.data(), H.wrow_id.size() * 4);
     up((void **)&r->d_wtiles4, H.wtiles4.data(), H.wtiles4.size() * 4);
     up((void **)&r->d_wstatic, H.wstatic.data(), H.wstatic.size() * 8);
-    up((void **)&r->d_field, &r->field, sizeof r->field);
     r->walk = B3wWalk{H.ntiles, H.wexp_slots, H.wmax_gen, H.wmax_ent, r->ncoef, H.wstatic_words, H.wmax_rows, 0u, r->d_wtile, r->d_wmask, r->d_wexp,
                       reinterpret_cast<const uint4 *>(r->d_wruns), r->d_wrun_row, r->d_went_w, r->d_went_m, r->d_wrow_id, r->d_wstatic, r->d_coef_small};
     r->sysw = r->sys;
@@ -1296,7 +1294,6 @@ void b3w_r1cs_destroy(b3w_r1cs *r) {
   if (r->d_wexp) (void)hipFree(r->d_wexp);
   if (r->d_wmask) (void)hipFree(r->d_wmask);
   if (r->d_wstatic) (void)hipFree(r->d_wstatic);
-  if (r->d_field) (void)hipFree(r->d_field);
   for (auto &sc : r->scratch) {
     if (sc.done) { (void)hipEventSynchronize(sc.done); (void)hipEventDestroy(sc.done); }
     if (sc.buf) (void)hipFree(sc.buf);
@@ -1354,7 +1351,7 @@ int32_t b3w_r1cs_check_device(b3w_ctx *ctx, const b3w_r1cs *r, const uint8_t *d_
       done = capturing ? nullptr : hit->done;                                      // (a captured check stays made of kernel nodes only)
     }
     int lrc = -6;
-    if (other == 0 && r->has_walk) lrc = b3w_launch_r1cs_walk(d_bodies, n, pitch, &r->walk, &r->sysw, &r->field, r->d_field, scratch, d_violations, d_first, (hipStream_t)stream);
+    if (other == 0 && r->has_walk) lrc = b3w_launch_r1cs_walk(d_bodies, n, pitch, &r->walk, &r->sysw, &r->field, scratch, d_violations, d_first, (hipStream_t)stream);
     if (lrc == -6 && other != 3) lrc = b3w_launch_r1cs_stream(d_bodies, n, pitch, &r->sys, &r->field, scratch, d_violations, d_first, (hipStream_t)stream);
     if (lrc == -6) lrc = b3w_launch_r1cs_lean(d_bodies, n, pitch, &r->sys, &r->field, scratch, d_violations, d_first, (hipStream_t)stream);
     if (done) (void)hipEventRecord(done, (hipStream_t)stream);

@@ -128,7 +128,7 @@ struct B3wWalk {
 // export area in LDS — no outside wire is gathered from HBM.  `sysw` = the system with the WALK row order in tiles / row_k / row_id
 // (the deferred kernel's view).  Returns -6 when the program does not fit (LDS).
 extern "C" int b3w_launch_r1cs_walk(const uint8_t *d_bodies, uint32_t n, uint64_t pitch, const B3wWalk *walk, const B3wR1csSystem *sysw, const B3wField *field,
-                                    const B3wField *d_field /* the same in device memory */, unsigned long long *d_scratch, uint32_t *d_violations, uint32_t *d_first, hipStream_t stream);
+                                    unsigned long long *d_scratch, uint32_t *d_violations, uint32_t *d_first, hipStream_t stream);
 extern "C" size_t b3w_r1cs_walk_scratch_bytes(const B3wWalk *walk);
 #define B3W_R1CS_SLAB 8192u                                  // bodies per launch pair at most: bounds the scratch (64 MB at most)
 extern "C" size_t b3w_r1cs_scratch_bytes(const B3wR1csSystem *sys);

@@ -1057,19 +1057,20 @@ __global__ __launch_bounds__(64 * WAVES, 4) void b3w_r1cs_stream_kernel(   // (s
 // kernels' blocks: bit w = mask word w was stored and is not zero; not sparse — the lean kernel's: every mask word was stored)
 __device__ __forceinline__ bool deferred_tile(const uint8_t *body, const uint32_t b, const uint32_t tile, const B3wR1csSystem &S,
                                               const unsigned long long *__restrict__ scratch, const uint32_t block_words, const B3wField &F, const bool sparse,
-                                              uint32_t &nbad, uint32_t &low) {
+                                              uint32_t &nbad, uint32_t &low, const uint32_t wave = 0u, const uint32_t nwaves = 1u) {      // (wave w of nwaves takes mask words w, w + nwaves, ...)
+  const uint32_t lane = threadIdx.x & 63u;
   const unsigned long long *block = scratch + ((size_t)b * S.ntiles + tile) * block_words;
   const uint4 td = reinterpret_cast<const uint4 *>(S.tiles)[tile];
   const uint32_t words = (td.y + 63u) >> 6;              // word w of the first kernel = rows first + 64 * w + lane (at most 64 words: 4 096 rows)
   const unsigned long long head = block[0];
   if (head == 0ull) return false;                        // (wave-uniform: one address)
-  const unsigned long long mine_w = threadIdx.x < words && (!sparse || ((head >> threadIdx.x) & 1ull)) ? block[1 + threadIdx.x] : 0ull;
+  const unsigned long long mine_w = lane < words && (!sparse || ((head >> lane) & 1ull)) ? block[1 + lane] : 0ull;
   if (__ballot(mine_w != 0ull) == 0ull) return false;
-  for (uint32_t wi = 0; wi < words; wi++) {
+  for (uint32_t wi = wave; wi < words; wi += nwaves) {
     const unsigned long long mask = __shfl(mine_w, (int)wi);
     if (mask == 0) continue;                             // (wave-uniform)
-    const bool mine = (mask >> threadIdx.x) & 1ull;
-    const uint32_t r = td.x + 64u * wi + threadIdx.x;    // (< td.x + td.y for a marked lane: only such lanes set a bit)
+    const bool mine = (mask >> lane) & 1ull;
+    const uint32_t r = td.x + 64u * wi + lane;    // (< td.x + td.y for a marked lane: only such lanes set a bit)
     uint4 d = make_uint4(0, 0, 0, 0);
     if (mine) d = reinterpret_cast<const uint4 *>(S.g_rows)[S.row_k[r]];
     const bool is_long = mine && d.y + d.z + d.w > 24u;
@@ -1081,7 +1082,7 @@ __device__ __forceinline__ bool deferred_tile(const uint8_t *body, const uint32_
       const uint4 dl = make_uint4((uint32_t)__shfl((int)d.x, L), (uint32_t)__shfl((int)d.y, L), (uint32_t)__shfl((int)d.z, L),
                                   (uint32_t)__shfl((int)d.w, L));
       const bool bad = gather_row_wave(body, dl, S.g_wires, S.g_cids, S.coefs, F);
-      if ((int)threadIdx.x == L && bad) { nbad++; low = min(low, S.row_id[r]); }
+      if ((int)lane == L && bad) { nbad++; low = min(low, S.row_id[r]); }
     }
   }
   return true;
@@ -1092,7 +1093,7 @@ __device__ __forceinline__ void deferred_report(uint32_t nbad, uint32_t low, con
     nbad += (uint32_t)__shfl_xor((int)nbad, sh);
     low = min(low, (uint32_t)__shfl_xor((int)low, sh));
   }
-  if (threadIdx.x == 0 && nbad) {
+  if ((threadIdx.x & 63u) == 0 && nbad) {
     atomicAdd(&violations[b], nbad);
     if (first) atomicMin(&first[b], low);
   }
@@ -1115,9 +1116,10 @@ __global__ __launch_bounds__(64) void b3w_r1cs_deferred_kernel(const uint8_t *__
   if (!any) return;
   deferred_report(nbad, low, b, violations, first);
 }
-// behind the walk kernel: one wave per BODY, told by one word which of the body's tiles have deferred rows at all (bit t = tile t) —
-// a batch of valid blake3_compression witnesses is 4 096 waves that load a zero and leave
-__global__ __launch_bounds__(64) void b3w_r1cs_walk_deferred_kernel(const uint8_t *__restrict__ bodies, uint64_t pitch, uint32_t n, B3wR1csSystem S,
+// behind the walk kernel: one workgroup of four waves per BODY, told by one word which of the body's tiles have deferred rows at all
+// (bit t = tile t) — a batch of valid blake3_compression witnesses is 4 096 workgroups that load a zero and leave.  The waves share a
+// flagged tile's mask words: a deferred row is a chain of dependent loads, and a nova step's 66 inverse rows lie in five words.
+__global__ __launch_bounds__(256) void b3w_r1cs_walk_deferred_kernel(const uint8_t *__restrict__ bodies, uint64_t pitch, uint32_t n, B3wR1csSystem S,
                                                                     const unsigned long long *__restrict__ scratch, uint32_t block_words,
                                                                     const unsigned long long *__restrict__ body_flags, B3wField F,
                                                                     uint32_t *__restrict__ violations, uint32_t *__restrict__ first) {
@@ -1129,7 +1131,7 @@ __global__ __launch_bounds__(64) void b3w_r1cs_walk_deferred_kernel(const uint8_
   while (flags) {
     const uint32_t tile = (uint32_t)__ffsll((long long)flags) - 1u;
     flags &= flags - 1ull;
-    (void)deferred_tile(body, b, tile, S, scratch, block_words, F, true, nbad, low);
+    (void)deferred_tile(body, b, tile, S, scratch, block_words, F, true, nbad, low, threadIdx.x >> 6, 4u);
   }
   deferred_report(nbad, low, b, violations, first);
 }
@@ -1178,48 +1180,10 @@ __device__ __forceinline__ uint32_t table32(uint32_t table, uint32_t x0, uint32_
   return (x4 & l[1]) | (~x4 & l[0]);
 }
 
-// a general row with ONE wide term s * W (s = +-1, W the element as it lies in the body): with the other terms' sums a, b, c — small
-// integers — the row says  (a + sW) b = c,  a (b + sW) = c  or  a b = c + sW,  i.e.  k W = d  with k = s b, s a or s and
-// d = c - a b or a b - c: decided by small_product_is (no field multiplication: |k| < 2^32).  An element that is no canonical
-// representative (>= p) violates the row, as everywhere.  Returns 0 holds, 1 violated, 2 not decidable here (the field arithmetic's).
-// (Not inlined: it runs for the 66 inverse rows of a nova step, once per body, and its scalars would otherwise crowd the walk
-// kernel's loop out of its SGPRs.)
-__device__ __attribute__((noinline)) uint32_t b3w_walk_wide_row(const uint32_t gw, const uint8_t *elem, const long long a, const long long b,
-                                                                const unsigned long long c_lo, const long long c_hi, const B3wField *Fg) {
-  const uint32_t part = (gw >> 16) & 3u;
-  const bool sneg = (gw >> 18) & 1u;
-  B3wField F;
-  for (int q = 0; q < 8; q++) { F.p[q] = Fg->p[q]; F.r2[q] = 0u; }
-  F.inv = Fg->inv;
-  const uint4 lo4 = *reinterpret_cast<const uint4 *>(elem), hi4 = *reinterpret_cast<const uint4 *>(elem + 16);
-  Fe Wv;
-  Wv.l[0] = lo4.x; Wv.l[1] = lo4.y; Wv.l[2] = lo4.z; Wv.l[3] = lo4.w; Wv.l[4] = hi4.x; Wv.l[5] = hi4.y; Wv.l[6] = hi4.z; Wv.l[7] = hi4.w;
-  if (fe_geq(Wv, F.p)) return 1u;
-  const __int128 ab = (__int128)a * (__int128)b, cc = (__int128)(((unsigned __int128)(unsigned long long)c_hi << 64) | c_lo);
-  const __int128 d = part == 2u ? ab - cc : cc - ab;
-  long long k = part == 0u ? b : part == 1u ? a : 1ll;
-  if (sneg) k = -k;
-  const unsigned long long kmag = k < 0 ? 0ull - (unsigned long long)k : (unsigned long long)k;
-  if (kmag >> 32) return 2u;
-  const unsigned __int128 dmag = d < 0 ? (unsigned __int128)(-d) : (unsigned __int128)d;
-  if (kmag == 0ull) return dmag != 0 ? 1u : 0u;
-  Fe dv;                                                     // d mod p  (|d| < 2^127 < p)
-  dv.l[0] = (uint32_t)dmag; dv.l[1] = (uint32_t)(dmag >> 32); dv.l[2] = (uint32_t)(dmag >> 64); dv.l[3] = (uint32_t)(dmag >> 96);
-  dv.l[4] = dv.l[5] = dv.l[6] = dv.l[7] = 0u;
-  if (d < 0) {
-    Fe pm;
-    for (int q = 0; q < 8; q++) pm.l[q] = F.p[q];
-    fe_sub(pm, dv, F.p);
-    dv = pm;
-  }
-  return small_product_is((uint32_t)kmag, k < 0, Wv, dv, F) ? 0u : 1u;
-}
-
 template <int NE>                                            // chunks of 64 general entries a wave takes at most (the tile with most: NE * 512)
 __global__ __launch_bounds__(512, 4) void b3w_r1cs_walk_kernel(const uint8_t *__restrict__ bodies, uint64_t pitch, uint32_t n, B3wWalk W,
                                                                unsigned long long *__restrict__ scratch, uint32_t block_words,
                                                                unsigned long long *__restrict__ body_flags /* per body: bit t = tile t has deferred rows */,
-                                                               const B3wField *__restrict__ Fg /* in device memory: read on the rare exact road only */,
                                                                uint32_t *__restrict__ violations, uint32_t *__restrict__ first) {
   constexpr uint32_t WAVES = 8, THREADS = 512, T = B3W_R1CS_TILE;
   extern __shared__ __align__(16) unsigned char smem[];
@@ -1238,8 +1202,7 @@ __global__ __launch_bounds__(512, 4) void b3w_r1cs_walk_kernel(const uint8_t *__
   unsigned long long *lmask = reinterpret_cast<unsigned long long *>(lcoef + ((W.ncoef + 1u) & ~1u));      // the tiles' must-be-bit masks
   unsigned long long *lstat = lmask + 16u * W.ntiles;        // ... and always-deferred rows
   uint32_t *gflag0 = reinterpret_cast<uint32_t *>(lstat + (size_t)W.static_words * W.ntiles);
-  uint32_t *gwide0 = gflag0 + 2u * gr2;                      // [parity][general row]: the row's ONE term on an element of 2^63 or more (below)
-  uint32_t *ltile = gwide0 + 2u * gr2;
+  uint32_t *ltile = gflag0 + 2u * gr2;
   uint32_t *lanom = ltile + W.ntiles * B3W_WT_WORDS;         // [unit mod 3]
   uint32_t *cnt = lanom + 4;                                 // [body mod 3]: violations, then lowest violated row
   unsigned long long *bflag = dmask0 + 16u;                  // [body mod 3]: tiles with deferred rows
@@ -1248,7 +1211,7 @@ __global__ __launch_bounds__(512, 4) void b3w_r1cs_walk_kernel(const uint8_t *__
   for (uint32_t k = tid; k < 16u * W.ntiles; k += THREADS) lmask[k] = W.mask[k];
   for (uint32_t k = tid; k < W.static_words * W.ntiles; k += THREADS) lstat[k] = W.stat[k];
   for (uint32_t k = tid; k < 12u * W.max_gen; k += THREADS) gsum0[k] = 0ull;
-  for (uint32_t k = tid; k < 4u * gr2; k += THREADS) gflag0[k] = 0u;      // (flags and wide-term words)
+  for (uint32_t k = tid; k < 2u * gr2; k += THREADS) gflag0[k] = 0u;
   for (uint32_t k = tid; k < xw; k += THREADS) xones[k] = 0ull;
   for (uint32_t k = tid; k < W.exp_slots; k += THREADS) xel[k] = 0ull;
   if (tid < 36) ones0[tid] = 0ull;
@@ -1325,7 +1288,7 @@ __global__ __launch_bounds__(512, 4) void b3w_r1cs_walk_kernel(const uint8_t *__
   auto entries = [&](const Cursor c, const uint32_t par) {
     const unsigned long long *el = el0 + par * T, *ones = ones0 + par * 18u;
     unsigned long long *gsum = gsum0 + par * 6u * W.max_gen;
-    uint32_t *gflag = gflag0 + par * gr2, *gwide = gwide0 + par * gr2;
+    uint32_t *gflag = gflag0 + par * gr2;
     const uint32_t ent_n = TW(c, B3W_WT_ENT_N), ent_runs = TW(c, B3W_WT_ENT_RUNS);
 #pragma unroll
     for (int q = 0; q < NE; q++) {
@@ -1358,12 +1321,8 @@ __global__ __launch_bounds__(512, 4) void b3w_r1cs_walk_kernel(const uint8_t *__
         const unsigned long long lo = mag * z, hi = __umul64hi(mag, z);
         const bool neg = cf < 0;
         const bool ok = cf != B3W_R1CS_NOT_SMALL && !(z >> 63) && hi < (1ull << 39);
-        // ONE term +-1 * (a local element of 2^63 or more) — the field inverse of an IsZero gadget, "in * inv = 1 - out" — does not
-        // defer its row: the term stays out of the sum, the row remembers it, and the verdict lane settles the row exactly (below)
-        const bool wide1 = (z >> 63) && mag == 1ull && idx < T;
         if (live) {
-          if (wide1) { if (atomicCAS(&gwide[mt >> 8], 0u, 0x80000000u | (mt & 3u) << 16 | (neg ? 1u << 18 : 0u) | idx) != 0u) atomicOr(&gflag[mt >> 8], 1u); }
-          else if (!ok) atomicOr(&gflag[mt >> 8], 1u);
+          if (!ok) atomicOr(&gflag[mt >> 8], 1u);
           else if (hi == 0ull && lo < (1ull << 54)) atomicAdd(sum, neg ? 0ull - lo : lo);
           else {
             __int128 v = (__int128)(((unsigned __int128)hi << 64) | lo);
@@ -1404,30 +1363,19 @@ __global__ __launch_bounds__(512, 4) void b3w_r1cs_walk_kernel(const uint8_t *__
     const uint32_t gen_n = TW(c, B3W_WT_GEN_N);
     if (wave * 64u >= gen_n) return;                           // (wave-uniform)
     unsigned long long *sum = gsum0 + par * 6u * W.max_gen + 6u * tid;
-    uint32_t *gflag = gflag0 + par * gr2, *gwide = gwide0 + par * gr2;
+    uint32_t *gflag = gflag0 + par * gr2;
     bool defer = false, bad = false;
-    uint32_t gw = 0;
-    unsigned long long a_lo = 0, b_lo = 0, c_lo = 0;
-    long long a_hi = 0, b_hi = 0, c_hi = 0;
     if (tid < gen_n) {
+      unsigned long long a_lo, b_lo, c_lo;
+      long long a_hi, b_hi, c_hi;
       part_sum(sum[0], sum[1], a_lo, a_hi);
       part_sum(sum[2], sum[3], b_lo, b_hi);
       part_sum(sum[4], sum[5], c_lo, c_hi);
-      gw = gwide[tid];
       defer = gflag[tid] != 0u || a_hi != ((long long)a_lo >> 63) || b_hi != ((long long)b_lo >> 63);
-      bad = !defer && !gw && (a_lo * b_lo != c_lo || __mul64hi((long long)a_lo, (long long)b_lo) != c_hi);
+      bad = !defer && (a_lo * b_lo != c_lo || __mul64hi((long long)a_lo, (long long)b_lo) != c_hi);
 #pragma unroll
       for (int q = 0; q < 6; q++) sum[q] = 0ull;
       gflag[tid] = 0u;
-      gwide[tid] = 0u;
-    }
-    if (__ballot(gw != 0u && !defer) != 0ull && !careful) {     // (a wave with such rows: the last tile of a nova step, once per body)
-      if (gw != 0u && !defer) {
-        const uint32_t v = b3w_walk_wide_row(gw, bodies + (uint64_t)c.body * pitch + ((uint64_t)c.tile * T + (gw & 0xFFFFu)) * 32u, (long long)a_lo, (long long)b_lo,
-                                             c_lo, c_hi, Fg);
-        bad = v == 1u;
-        defer = v == 2u;
-      }
     }
     if (careful) return;                                       // (every row of this unit goes to the deferred kernel: nothing is counted here)
     const unsigned long long dm = __ballot(defer);
@@ -1757,12 +1705,12 @@ static inline size_t walk_smem(const B3wWalk *w) {
   const size_t xw = (w->exp_slots >> 6) + 1u, gr2 = (w->max_gen + 1u) & ~1u;
   return 8u * (2u * (size_t)B3W_R1CS_TILE + w->exp_slots + 36u + xw + 12u * (size_t)w->max_gen + 20u + ((w->ncoef + 1u) & ~1u) + 16u * (size_t)w->ntiles +
                (size_t)w->static_words * w->ntiles) +
-         4u * (4u * gr2 + (size_t)w->ntiles * B3W_WT_WORDS + 4u + 6u) + 32u;
+         4u * (2u * gr2 + (size_t)w->ntiles * B3W_WT_WORDS + 4u + 6u) + 32u;
 }
 extern "C" size_t b3w_r1cs_walk_scratch_bytes(const B3wWalk *w) { return ((size_t)B3W_R1CS_SLAB * w->ntiles * walk_block_words(w) + B3W_R1CS_SLAB) * 8; }
 
 extern "C" int b3w_launch_r1cs_walk(const uint8_t *d_bodies, uint32_t n, uint64_t pitch, const B3wWalk *walk, const B3wR1csSystem *sysw, const B3wField *field,
-                                    const B3wField *d_field, unsigned long long *d_scratch, uint32_t *d_violations, uint32_t *d_first, hipStream_t stream) {
+                                    unsigned long long *d_scratch, uint32_t *d_violations, uint32_t *d_first, hipStream_t stream) {
   if (!n || !walk->ntiles) return 0;
   if (!d_scratch) return -5;
   static const int env_grid = getenv("B3W_R1CS_GRID") ? atoi(getenv("B3W_R1CS_GRID")) : 0;
@@ -1804,10 +1752,10 @@ extern "C" int b3w_launch_r1cs_walk(const uint8_t *d_bodies, uint32_t n, uint64_
     const uint8_t *bodies0 = d_bodies + (uint64_t)b0 * pitch;
     uint32_t *viol0 = d_violations + b0, *first0 = d_first ? d_first + b0 : nullptr;
     unsigned long long *flags = d_scratch + (size_t)B3W_R1CS_SLAB * walk->ntiles * bw;
-    void *args[] = {(void *)&bodies0, (void *)&pitch, (void *)&nb, (void *)walk, (void *)&d_scratch, (void *)&bw, (void *)&flags, (void *)&d_field, (void *)&viol0, (void *)&first0};
+    void *args[] = {(void *)&bodies0, (void *)&pitch, (void *)&nb, (void *)walk, (void *)&d_scratch, (void *)&bw, (void *)&flags, (void *)&viol0, (void *)&first0};
     e = hipLaunchKernel(fn, dim3(grid), dim3(512), args, smem, stream);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(b3w_r1cs_walk_deferred_kernel, dim3(nb), dim3(64), 0, stream, bodies0, pitch, nb, *sysw, d_scratch, bw, flags, *field, viol0, first0);
+    hipLaunchKernelGGL(b3w_r1cs_walk_deferred_kernel, dim3(nb), dim3(256), 0, stream, bodies0, pitch, nb, *sysw, d_scratch, bw, flags, *field, viol0, first0);
     e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
   }

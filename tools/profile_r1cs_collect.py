@@ -25,7 +25,7 @@ for c in ("compression", "nova_vesta"):
     with open(os.path.join(dst, f"r1cs_check_{c}_kernel_stats.csv"), "w") as f:
         w = csv.DictWriter(f, fieldnames=rows[0].keys(), quoting=csv.QUOTE_NONNUMERIC)
         w.writeheader(); w.writerows(rows)
-    kind = lambda name: "walk" if "walk" in name else "stream" if "stream" in name else "lean" if "lean" in name else "deferred" if "deferred" in name else "init"
+    kind = lambda name: "deferred" if "deferred" in name else "walk" if "walk" in name else "stream" if "stream" in name else "lean" if "lean" in name else "init"
     avg = {kind(r["Name"]): float(r["AverageNs"]) for r in rows}
     pm = [r for r in csv.DictReader(open(find(f"fetch_{c}", "*counter_collection.csv")))
           if r["Counter_Name"] == "FETCH_SIZE" and "b3w_r1cs" in r["Kernel_Name"]]
