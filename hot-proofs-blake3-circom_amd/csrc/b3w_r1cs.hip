@@ -1121,13 +1121,55 @@ __global__ __launch_bounds__(64) void b3w_r1cs_deferred_kernel(const uint8_t *__
 // flagged tile's mask words: a deferred row is a chain of dependent loads, and a nova step's 66 inverse rows lie in five words.
 __global__ __launch_bounds__(256) void b3w_r1cs_walk_deferred_kernel(const uint8_t *__restrict__ bodies, uint64_t pitch, uint32_t n, B3wR1csSystem S,
                                                                     const unsigned long long *__restrict__ scratch, uint32_t block_words,
-                                                                    const unsigned long long *__restrict__ body_flags, B3wField F,
+                                                                    const unsigned long long *__restrict__ body_flags,
+                                                                    const unsigned long long *__restrict__ wide_recs, B3wField F,
                                                                     uint32_t *__restrict__ violations, uint32_t *__restrict__ first) {
   const uint32_t b = blockIdx.x;
   unsigned long long flags = body_flags[b];
   if (flags == 0ull) return;
   const uint8_t *body = bodies + (uint64_t)b * pitch;
   uint32_t nbad = 0, low = 0xFFFFFFFFu;
+  // WIDE RECORDS: rows with ONE term s * W (s = +-1, W an element of 2^63 or more, as it lies in the body): with the other terms'
+  // sums a, b, c — small integers, from the walk kernel — the row says (a + sW) b = c, a (b + sW) = c or a b = c + sW, i.e. k W = d
+  // with k = s b, s a or s and d = c - a b or a b - c: decided by small_product_is (|k| < 2^32; else the general road).  An element
+  // that is no canonical representative (>= p) violates the row, as everywhere.
+  const uint32_t nwide = (uint32_t)(flags >> 56);
+  flags &= (1ull << 56) - 1ull;
+  if (threadIdx.x < nwide) {
+    const unsigned long long *rec = wide_recs + ((size_t)b * B3W_WALK_WIDE_CAP + threadIdx.x) * 5u;
+    const long long ra = (long long)rec[0], rb = (long long)rec[1];
+    const unsigned long long c_lo = rec[2];
+    const long long c_hi = (long long)rec[3];
+    const unsigned long long gw = rec[4];
+    const uint32_t part = (uint32_t)(gw >> 16) & 3u, tile = (uint32_t)(gw >> 32) & 0xFFu, row = (uint32_t)(gw >> 40);
+    const bool sneg = (gw >> 18) & 1ull;
+    bool wild = false;
+    const Fe Wv = load_z(body, tile * B3W_R1CS_TILE + (uint32_t)(gw & 0xFFFFull), F, &wild);
+    const __int128 ab = (__int128)ra * (__int128)rb, cc = (__int128)(((unsigned __int128)(unsigned long long)c_hi << 64) | c_lo);
+    const __int128 d = part == 2u ? ab - cc : cc - ab;
+    long long k = part == 0u ? rb : part == 1u ? ra : 1ll;
+    if (sneg) k = -k;
+    const unsigned long long kmag = k < 0 ? 0ull - (unsigned long long)k : (unsigned long long)k;
+    const unsigned __int128 dmag = d < 0 ? (unsigned __int128)(-d) : (unsigned __int128)d;
+    bool bad;
+    if (wild) bad = true;
+    else if (kmag >> 32) bad = gather_row(body, reinterpret_cast<const uint4 *>(S.g_rows)[S.row_k[row]], S.g_wires, S.g_cids, S.coefs, F);
+    else if (kmag == 0ull) bad = dmag != 0;
+    else {
+      Fe dv;                                                   // d mod p  (|d| < 2^127 < p)
+      dv.l[0] = (uint32_t)dmag; dv.l[1] = (uint32_t)(dmag >> 32); dv.l[2] = (uint32_t)(dmag >> 64); dv.l[3] = (uint32_t)(dmag >> 96);
+      dv.l[4] = dv.l[5] = dv.l[6] = dv.l[7] = 0u;
+      if (d < 0) {
+        Fe pm;
+#pragma unroll
+        for (int q = 0; q < 8; q++) pm.l[q] = F.p[q];
+        fe_sub(pm, dv, F.p);
+        dv = pm;
+      }
+      bad = !small_product_is((uint32_t)kmag, k < 0, Wv, dv, F);
+    }
+    if (bad) { nbad++; low = min(low, S.row_id[row]); }
+  }
   while (flags) {
     const uint32_t tile = (uint32_t)__ffsll((long long)flags) - 1u;
     flags &= flags - 1ull;
@@ -1183,7 +1225,8 @@ __device__ __forceinline__ uint32_t table32(uint32_t table, uint32_t x0, uint32_
 template <int NE>                                            // chunks of 64 general entries a wave takes at most (the tile with most: NE * 512)
 __global__ __launch_bounds__(512, 4) void b3w_r1cs_walk_kernel(const uint8_t *__restrict__ bodies, uint64_t pitch, uint32_t n, B3wWalk W,
                                                                unsigned long long *__restrict__ scratch, uint32_t block_words,
-                                                               unsigned long long *__restrict__ body_flags /* per body: bit t = tile t has deferred rows */,
+                                                               unsigned long long *__restrict__ body_flags /* per body: bit t = tile t has deferred rows; bits 56 up: wide records */,
+                                                               unsigned long long *__restrict__ wide_recs /* per body B3W_WALK_WIDE_CAP x 5 words */,
                                                                uint32_t *__restrict__ violations, uint32_t *__restrict__ first) {
   constexpr uint32_t WAVES = 8, THREADS = 512, T = B3W_R1CS_TILE;
   extern __shared__ __align__(16) unsigned char smem[];
@@ -1202,7 +1245,8 @@ __global__ __launch_bounds__(512, 4) void b3w_r1cs_walk_kernel(const uint8_t *__
   unsigned long long *lmask = reinterpret_cast<unsigned long long *>(lcoef + ((W.ncoef + 1u) & ~1u));      // the tiles' must-be-bit masks
   unsigned long long *lstat = lmask + 16u * W.ntiles;        // ... and always-deferred rows
   uint32_t *gflag0 = reinterpret_cast<uint32_t *>(lstat + (size_t)W.static_words * W.ntiles);
-  uint32_t *ltile = gflag0 + 2u * gr2;
+  uint32_t *gwide0 = gflag0 + 2u * gr2;                      // [parity][general row]: the row's ONE term +-1 * (element of 2^63 or more), see entries
+  uint32_t *ltile = gwide0 + 2u * gr2;
   uint32_t *lanom = ltile + W.ntiles * B3W_WT_WORDS;         // [unit mod 3]
   uint32_t *cnt = lanom + 4;                                 // [body mod 3]: violations, then lowest violated row
   unsigned long long *bflag = dmask0 + 16u;                  // [body mod 3]: tiles with deferred rows
@@ -1211,13 +1255,13 @@ __global__ __launch_bounds__(512, 4) void b3w_r1cs_walk_kernel(const uint8_t *__
   for (uint32_t k = tid; k < 16u * W.ntiles; k += THREADS) lmask[k] = W.mask[k];
   for (uint32_t k = tid; k < W.static_words * W.ntiles; k += THREADS) lstat[k] = W.stat[k];
   for (uint32_t k = tid; k < 12u * W.max_gen; k += THREADS) gsum0[k] = 0ull;
-  for (uint32_t k = tid; k < 2u * gr2; k += THREADS) gflag0[k] = 0u;
+  for (uint32_t k = tid; k < 4u * gr2; k += THREADS) gflag0[k] = 0u;      // (flags and wide-term words)
   for (uint32_t k = tid; k < xw; k += THREADS) xones[k] = 0ull;
   for (uint32_t k = tid; k < W.exp_slots; k += THREADS) xel[k] = 0ull;
   if (tid < 36) ones0[tid] = 0ull;
   if (tid < 19) dmask0[tid] = 0ull;                          // (and the body flags)
   if (tid < 4) lanom[tid] = 0u;
-  if (tid < 3) { cnt[tid] = 0u; cnt[3 + tid] = 0xFFFFFFFFu; }
+  if (tid < 3) { cnt[tid] = 0u; cnt[3 + tid] = 0xFFFFFFFFu; cnt[6 + tid] = 0u; }      // (violations, lowest violated row, wide records)
   // this workgroup's bodies: whole ones, contiguous, as even as whole bodies go
   const uint32_t b0 = (uint32_t)((uint64_t)n * blockIdx.x / gridDim.x), b1 = (uint32_t)((uint64_t)n * (blockIdx.x + 1u) / gridDim.x);
   const uint32_t m = (b1 - b0) * W.ntiles;                    // units
@@ -1288,7 +1332,7 @@ __global__ __launch_bounds__(512, 4) void b3w_r1cs_walk_kernel(const uint8_t *__
   auto entries = [&](const Cursor c, const uint32_t par) {
     const unsigned long long *el = el0 + par * T, *ones = ones0 + par * 18u;
     unsigned long long *gsum = gsum0 + par * 6u * W.max_gen;
-    uint32_t *gflag = gflag0 + par * gr2;
+    uint32_t *gflag = gflag0 + par * gr2, *gwide = gwide0 + par * gr2;
     const uint32_t ent_n = TW(c, B3W_WT_ENT_N), ent_runs = TW(c, B3W_WT_ENT_RUNS);
 #pragma unroll
     for (int q = 0; q < NE; q++) {
@@ -1321,8 +1365,13 @@ __global__ __launch_bounds__(512, 4) void b3w_r1cs_walk_kernel(const uint8_t *__
         const unsigned long long lo = mag * z, hi = __umul64hi(mag, z);
         const bool neg = cf < 0;
         const bool ok = cf != B3W_R1CS_NOT_SMALL && !(z >> 63) && hi < (1ull << 39);
+        // ONE term +-1 * (a local element of 2^63 or more) — the field inverse of an IsZero gadget, "in * inv = 1 - out" — stays out of
+        // the sums and is remembered with its row: the verdict lane then hands the deferred kernel the row's small sums and the
+        // element's place (a WIDE RECORD) instead of the row — one load there, not a walk through the row's terms
+        const bool wide1 = (z >> 63) && mag == 1ull && idx < T;
         if (live) {
-          if (!ok) atomicOr(&gflag[mt >> 8], 1u);
+          if (wide1) { if (atomicCAS(&gwide[mt >> 8], 0u, 0x80000000u | (mt & 3u) << 16 | (neg ? 1u << 18 : 0u) | idx) != 0u) atomicOr(&gflag[mt >> 8], 1u); }
+          else if (!ok) atomicOr(&gflag[mt >> 8], 1u);
           else if (hi == 0ull && lo < (1ull << 54)) atomicAdd(sum, neg ? 0ull - lo : lo);
           else {
             __int128 v = (__int128)(((unsigned __int128)hi << 64) | lo);
@@ -1363,7 +1412,7 @@ __global__ __launch_bounds__(512, 4) void b3w_r1cs_walk_kernel(const uint8_t *__
     const uint32_t gen_n = TW(c, B3W_WT_GEN_N);
     if (wave * 64u >= gen_n) return;                           // (wave-uniform)
     unsigned long long *sum = gsum0 + par * 6u * W.max_gen + 6u * tid;
-    uint32_t *gflag = gflag0 + par * gr2;
+    uint32_t *gflag = gflag0 + par * gr2, *gwide = gwide0 + par * gr2;
     bool defer = false, bad = false;
     if (tid < gen_n) {
       unsigned long long a_lo, b_lo, c_lo;
@@ -1371,11 +1420,23 @@ __global__ __launch_bounds__(512, 4) void b3w_r1cs_walk_kernel(const uint8_t *__
       part_sum(sum[0], sum[1], a_lo, a_hi);
       part_sum(sum[2], sum[3], b_lo, b_hi);
       part_sum(sum[4], sum[5], c_lo, c_hi);
+      const uint32_t gw = gwide[tid];
       defer = gflag[tid] != 0u || a_hi != ((long long)a_lo >> 63) || b_hi != ((long long)b_lo >> 63);
-      bad = !defer && (a_lo * b_lo != c_lo || __mul64hi((long long)a_lo, (long long)b_lo) != c_hi);
+      bad = !defer && !gw && (a_lo * b_lo != c_lo || __mul64hi((long long)a_lo, (long long)b_lo) != c_hi);
 #pragma unroll
       for (int q = 0; q < 6; q++) sum[q] = 0ull;
       gflag[tid] = 0u;
+      if (gw) {
+        gwide[tid] = 0u;
+        if (!defer && !careful) {                              // a wide record, while the body's list has room; else the row itself
+          const uint32_t slot = atomicAdd(&cnt[6u + c.body % 3u], 1u);
+          if (slot < B3W_WALK_WIDE_CAP) {
+            unsigned long long *rec = wide_recs + ((size_t)c.body * B3W_WALK_WIDE_CAP + slot) * 5u;
+            rec[0] = a_lo; rec[1] = b_lo; rec[2] = c_lo; rec[3] = (unsigned long long)c_hi;
+            rec[4] = (unsigned long long)(gw & 0x7FFFFFFFu) | (unsigned long long)c.tile << 32 | (unsigned long long)(TW(c, B3W_WT_ROW0) + tid) << 40;
+          } else defer = true;
+        }
+      }
     }
     if (careful) return;                                       // (every row of this unit goes to the deferred kernel: nothing is counted here)
     const unsigned long long dm = __ballot(defer);
@@ -1404,8 +1465,9 @@ __global__ __launch_bounds__(512, 4) void b3w_r1cs_walk_kernel(const uint8_t *__
       const uint32_t s = body % 3u;
       violations[body] = cnt[s];
       if (first) first[body] = cnt[3u + s];
-      body_flags[body] = bflag[s];
-      cnt[s] = 0u; cnt[3u + s] = 0xFFFFFFFFu; bflag[s] = 0ull;
+      const uint32_t nwide = cnt[6u + s] < B3W_WALK_WIDE_CAP ? cnt[6u + s] : B3W_WALK_WIDE_CAP;
+      body_flags[body] = bflag[s] | (unsigned long long)nwide << 56;
+      cnt[s] = 0u; cnt[3u + s] = 0xFFFFFFFFu; cnt[6u + s] = 0u; bflag[s] = 0ull;
     }
   };
   auto count = [&](uint32_t nbad, uint32_t low, const uint32_t body) {
@@ -1705,9 +1767,11 @@ static inline size_t walk_smem(const B3wWalk *w) {
   const size_t xw = (w->exp_slots >> 6) + 1u, gr2 = (w->max_gen + 1u) & ~1u;
   return 8u * (2u * (size_t)B3W_R1CS_TILE + w->exp_slots + 36u + xw + 12u * (size_t)w->max_gen + 20u + ((w->ncoef + 1u) & ~1u) + 16u * (size_t)w->ntiles +
                (size_t)w->static_words * w->ntiles) +
-         4u * (2u * gr2 + (size_t)w->ntiles * B3W_WT_WORDS + 4u + 6u) + 32u;
+         4u * (4u * gr2 + (size_t)w->ntiles * B3W_WT_WORDS + 4u + 9u) + 32u;
 }
-extern "C" size_t b3w_r1cs_walk_scratch_bytes(const B3wWalk *w) { return ((size_t)B3W_R1CS_SLAB * w->ntiles * walk_block_words(w) + B3W_R1CS_SLAB) * 8; }
+extern "C" size_t b3w_r1cs_walk_scratch_bytes(const B3wWalk *w) {      // blocks | body flags | wide records
+  return ((size_t)B3W_R1CS_SLAB * w->ntiles * walk_block_words(w) + B3W_R1CS_SLAB + (size_t)B3W_R1CS_SLAB * B3W_WALK_WIDE_CAP * 5u) * 8;
+}
 
 extern "C" int b3w_launch_r1cs_walk(const uint8_t *d_bodies, uint32_t n, uint64_t pitch, const B3wWalk *walk, const B3wR1csSystem *sysw, const B3wField *field,
                                     unsigned long long *d_scratch, uint32_t *d_violations, uint32_t *d_first, hipStream_t stream) {
@@ -1718,7 +1782,7 @@ extern "C" int b3w_launch_r1cs_walk(const uint8_t *d_bodies, uint32_t n, uint64_
   hipError_t e = hipGetDevice(&dev);
   if (e != hipSuccess) return (int)e;
   const uint32_t ne = (walk->max_ent + 511u) / 512u;         // entry chunks per wave
-  if (ne > 4u || walk->ntiles > 64u) return -6;
+  if (ne > 4u || walk->ntiles > 56u) return -6;
   const void *fn = ne <= 1u ? reinterpret_cast<const void *>(&b3w_r1cs_walk_kernel<1>) : ne == 2u ? reinterpret_cast<const void *>(&b3w_r1cs_walk_kernel<2>)
                    : ne == 3u ? reinterpret_cast<const void *>(&b3w_r1cs_walk_kernel<3>) : reinterpret_cast<const void *>(&b3w_r1cs_walk_kernel<4>);
   struct PerDevice { int cus = 0, lds = 0; bool attr[4] = {false, false, false, false}; };
@@ -1751,11 +1815,11 @@ extern "C" int b3w_launch_r1cs_walk(const uint8_t *d_bodies, uint32_t n, uint64_
     if (grid > nb) grid = nb;                                // (whole bodies per workgroup)
     const uint8_t *bodies0 = d_bodies + (uint64_t)b0 * pitch;
     uint32_t *viol0 = d_violations + b0, *first0 = d_first ? d_first + b0 : nullptr;
-    unsigned long long *flags = d_scratch + (size_t)B3W_R1CS_SLAB * walk->ntiles * bw;
-    void *args[] = {(void *)&bodies0, (void *)&pitch, (void *)&nb, (void *)walk, (void *)&d_scratch, (void *)&bw, (void *)&flags, (void *)&viol0, (void *)&first0};
+    unsigned long long *flags = d_scratch + (size_t)B3W_R1CS_SLAB * walk->ntiles * bw, *wide = flags + B3W_R1CS_SLAB;
+    void *args[] = {(void *)&bodies0, (void *)&pitch, (void *)&nb, (void *)walk, (void *)&d_scratch, (void *)&bw, (void *)&flags, (void *)&wide, (void *)&viol0, (void *)&first0};
     e = hipLaunchKernel(fn, dim3(grid), dim3(512), args, smem, stream);
     if (e != hipSuccess) return (int)e;
-    hipLaunchKernelGGL(b3w_r1cs_walk_deferred_kernel, dim3(nb), dim3(256), 0, stream, bodies0, pitch, nb, *sysw, d_scratch, bw, flags, *field, viol0, first0);
+    hipLaunchKernelGGL(b3w_r1cs_walk_deferred_kernel, dim3(nb), dim3(256), 0, stream, bodies0, pitch, nb, *sysw, d_scratch, bw, flags, wide, *field, viol0, first0);
     e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
   }

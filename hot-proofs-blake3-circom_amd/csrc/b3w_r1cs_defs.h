@@ -27,3 +27,4 @@ struct B3wField {
 #define B3W_WALK_MAX_EXP_SLOTS 4096u
 #define B3W_WALK_MAX_GEN 512u
 #define B3W_WALK_MAX_ENT 4096u
+#define B3W_WALK_WIDE_CAP 128u     // wide records per body (a nova step has 66)
