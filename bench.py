@@ -228,7 +228,7 @@ def bench_chain(args, m, torch, dist, dev, world, rank, local_rank):
     ctx = m.Context(circuit, local_rank)
     nbytes = int(args.preimage_mib * (1 << 20))
     host = torch.from_numpy(m.workloads.lcg_preimage(nbytes, seed=1).copy()).pin_memory()
-    consumer, key, commit_only, r1cs_t, d_viol_t = None, None, None, None, None
+    consumer, key, commit_only, commit_records, r1cs_t, d_viol_t = None, None, None, None, None, None
     n_max = m.lib().b3w_chain_num_chunks(nbytes) * 64 + 64
     if "check" in args.consumer:                     # SURVEY.md 8(f) row 2, first half: Az * Bz = Cz for every step witness, timed
         if circuit not in m.BUILTIN_R1CS:
@@ -255,10 +255,12 @@ def bench_chain(args, m, torch, dist, dev, world, rank, local_rank):
                               torch.cuda.current_stream().cuda_stream)
         if args.consumer == "commit-only":
             consumer, commit_only = None, (key, d_pts)
+        elif "bodies" not in args.consumer:                 # commit / check+commit: the commitments come from the step records, the check reads the bodies
+            consumer, commit_records = check_first, (key, d_pts)
     # the fold's exchange (N > 1) is part of every pass: chunk chaining values, then every step's h_out (BASELINE config 4)
     comm = native_comm(m, ctx, dist, world, rank, "chain") if (world > 1 and args.exchange_impl == "native") else None
     run = lambda: m.chain.fold_witnesses(ctx, host, batch_steps=args.batch if args.batch != 4096 else 16384, ring=2, consumer=consumer,
-                                         commit_only=commit_only, gather_hout=args.exchange != "none", comm=comm)
+                                         commit_only=commit_only, commit_records=commit_records, gather_hout=args.exchange != "none", comm=comm)
     t_first = time.perf_counter()
     for i in range(max(3, args.warmup)):        # the first passes pay the allocator (24 GB ring, record buffers)
         out = run()
@@ -281,6 +283,7 @@ def bench_chain(args, m, torch, dist, dev, world, rank, local_rank):
     elapsed = time.perf_counter() - t0
     assert int(out["status"].abs().sum().item()) == 0
     ex_ms = m.chain.exchange_ms(out)                          # the last timed pass: (chunk CVs, h_out) on this rank's device
+    recs16 = out["records"][:16].cpu().numpy().copy()         # (the views die with the chain object: the verification pass below may replace it)
     local_steps = out["n_leaf_steps"] + out["n_parent_steps"]
     n_leaf_all = m.lib().b3w_chain_num_leaf_steps(nbytes)
     if args.exchange != "none" or world == 1:
@@ -354,11 +357,12 @@ def bench_chain(args, m, torch, dist, dev, world, rank, local_rank):
                 "field_multiplications_per_step": mults, "point_additions_per_step": adds_per_step, "peak_source": src,
                 "note": "29-bit-limb field multiplications of the commit kernel (10 per mixed addition, counted by the kernel in an untimed pass; "
                         "+ tree and normalisation) against the chip's multiplication-only rate; end-to-end per-GPU rate"
-                        + ("" if commit_only is not None else ", witness generation" + (" and constraint check" if r1cs_t is not None else "") + " included in the time")}
+                        + ("" if commit_only is not None else ", witness generation" + (" and constraint check" if r1cs_t is not None else "") + " included in the time"
+                           + ("" if commit_records is not None else "; this consumer also reads every body back"))}
     cpu = None
     if rank == 0 and world == 1 and args.cpu_seconds > 0:
         import numpy as np
-        cpu = cpu_baseline(circuit, out["records"][:16].cpu().numpy().view(np.uint32), args.cpu_seconds)
+        cpu = cpu_baseline(circuit, recs16.view(np.uint32), args.cpu_seconds)
     if rank == 0:
         line = {
             "metric": "BLAKE3-compression witnesses/sec", "value": total_steps * args.steps / elapsed, "unit": "witnesses/s",
@@ -382,7 +386,8 @@ def bench_chain(args, m, torch, dist, dev, world, rank, local_rank):
                        "consumer": " then ".join(
                            ([f"rank-1 constraint check of every step witness on the device ({r1cs_t.n_constraints} constraints)"] if r1cs_t is not None else []) +
                            ([f"Pedersen commitment of every step witness on the device ({key.window}-bit windows, {key.folded_slots} slots folded)"
-                             + (", from the step records: no bodies written" if commit_only is not None else "")] if key is not None else [])) or "none"},
+                             + (", from the step records: no bodies written" if commit_only is not None else
+                                ", from the step records, beside the bodies" if commit_records is not None else ", read from the bodies")] if key is not None else [])) or "none"},
             "roofline": roof,
         }
         if cpu is not None:
@@ -412,11 +417,12 @@ def main():
                     help="batch = BASELINE config 2/3 (default, the headline metric); chain = configs 4/5: "
                          "preimage -> planner -> nova step witnesses, streamed through a ring of buffers")
     ap.add_argument("--preimage-mib", type=float, default=1.0, help="chain workload: preimage size (1 = config 4, 1024 = config 5)")
-    ap.add_argument("--consumer", default="none", choices=["none", "commit", "commit-only", "check", "check+commit"],
-                    help="chain workload: what reads each batch of step witnesses while it sits in the ring "
-                         "(commit = Pedersen commitments on the circuit's curve, synthetic generators; commit-only = the same "
-                         "commitments straight from the step records, no bodies written; check = the step circuit's rank-1 "
-                         "constraints over every step witness; check+commit = both, in that order)")
+    ap.add_argument("--consumer", default="none", choices=["none", "commit", "commit-only", "check", "check+commit", "commit-bodies", "check+commit-bodies"],
+                    help="chain workload: what is done with each batch of step witnesses while it sits in the ring.  check = the step "
+                         "circuit's rank-1 constraints over every step witness; commit = Pedersen commitments on the circuit's curve "
+                         "(synthetic generators) computed from the step records beside the bodies (b3w_chain_commit_from_records: the "
+                         "fold-shaped pass); commit-only = the same commitments, no bodies written; check+commit = both; "
+                         "commit-bodies / check+commit-bodies = the commitment kernel that READS the bodies (for bodies the library did not make)")
     ap.add_argument("--exchange", default="every", choices=["every", "last", "none"],
                     help="N > 1: the fold's exchange inside the timed region.  batch workload: all-gather of the public outputs "
                          "after EVERY launch (default; pipelined with the next launch), after the LAST launch only, or not at all — "

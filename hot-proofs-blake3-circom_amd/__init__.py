@@ -126,6 +126,7 @@ def lib():
         "b3w_commit_records_device": (i32, [vp, vp, vp, u32, vp, vp, vp, vp]),
         "b3w_commit_records": (i32, [vp, vp, vp, u32, vp, vp, vp]),
         "b3w_chain_commit_only": (i32, [vp, vp, vp]),
+        "b3w_chain_commit_from_records": (i32, [vp, vp, vp]),
         "b3w_chain_commitments": (i32, [vp, vp, vp]),
         "b3w_chain_check_constraints": (i32, [vp, vp]),
         "b3w_chain_violations": (i32, [vp, vp, vp]),
@@ -173,7 +174,7 @@ EXPORTED_SYMBOLS = ("b3w_abi_version", "b3w_identify_wasm", "b3w_create", "b3w_d
                     "b3w_r1cs_create", "b3w_r1cs_info", "b3w_r1cs_is_tiled", "b3w_r1cs_destroy", "b3w_r1cs_check_device", "b3w_batch_r1cs_check", "b3w_r1cs_consumer", "b3w_batch_write_wtns", "b3w_batch_write_wtns_ex", "b3w_batch_autotune_device", "b3w_bodies_alloc", "b3w_bodies_free", "b3w_bodies_trim", "b3w_ctx_trim", "b3w_bodies_configure", "b3w_bodies_stats", "b3w_bodies_search_stats", "b3w_bodies_search_limit", "b3w_batch_placement", "b3w_chain_num_chunks", "b3w_chain_num_leaf_steps", "b3w_chain_path_len",
                     "b3w_chain_num_parent_steps", "b3w_chain_parent_row", "b3w_chain_path_provable",
                     "b3w_chain_plan_leaves_device", "b3w_chain_tree_device", "b3w_chain_plan_parents_device",
-                    "b3w_commit_key_create", "b3w_commit_key_create_ex", "b3w_commit_key_create_folded", "b3w_slot_widths", "b3w_commit_key_window", "b3w_commit_key_destroy", "b3w_commit_key_count", "b3w_commit_key_counts", "b3w_commit_records_device", "b3w_commit_records", "b3w_chain_commit_only", "b3w_chain_commitments", "b3w_chain_check_constraints", "b3w_chain_violations", "b3w_batch_commit_device", "b3w_batch_commit", "b3w_commit_consumer",
+                    "b3w_commit_key_create", "b3w_commit_key_create_ex", "b3w_commit_key_create_folded", "b3w_slot_widths", "b3w_commit_key_window", "b3w_commit_key_destroy", "b3w_commit_key_count", "b3w_commit_key_counts", "b3w_commit_records_device", "b3w_commit_records", "b3w_chain_commit_only", "b3w_chain_commit_from_records", "b3w_chain_commitments", "b3w_chain_check_constraints", "b3w_chain_violations", "b3w_batch_commit_device", "b3w_batch_commit", "b3w_commit_consumer",
                     "b3w_comm_unique_id", "b3w_comm_create", "b3w_comm_create_host", "b3w_comm_create_external", "b3w_comm_rank", "b3w_comm_size", "b3w_comm_destroy", "b3w_comm_allgather", "b3w_batch_allgather_public",
                     "b3w_chain_create", "b3w_chain_destroy", "b3w_chain_run_leaves", "b3w_chain_run_parents", "b3w_chain_shard", "b3w_chain_run_parents_sharded", "b3w_chain_allgather_hout", "b3w_chain_allgather_hout_host", "b3w_chain_exchange_ms", "b3w_chain_info",
                     "b3w_chain_outputs", "b3w_chain_records", "b3w_chain_public", "b3w_chain_status", "b3w_chain_local_cvs", "b3w_chain_root")

@@ -83,12 +83,14 @@ def gather_h_out(public_local, n_leaf_local, preimage_len, with_parents=True, gr
 
 
 def fold_witnesses(ctx, preimage, batch_steps=16384, ring=2, slice_chunks=1024, with_parents=True, consumer=None,
-                   device=None, commit_only=None, gather_hout=True, comm=None):
+                   device=None, commit_only=None, gather_hout=True, comm=None, commit_records=None):
     """preimage: 1-D uint8 numpy array / torch CPU tensor (the whole preimage; every rank passes the same).
     consumer(bodies_view [k, body_bytes] uint8 CUDA, first_local_step, k): called after each batch is enqueued;
     it must enqueue its work on the current stream (the view is overwritten `ring` batches later).
     commit_only=(CommitKey, d_points): no bodies at all — one commitment per step, computed from the step records
     (b3w_chain_commit_only), into the caller's [n_steps, 64] uint8 CUDA tensor.
+    commit_records=(CommitKey, d_points): the same commitments from the records WHILE the bodies are written and handed to the
+    consumer as usual (b3w_chain_commit_from_records): the fold-shaped pass, without reading the bodies back for the commitment.
     gather_hout: all-gather every step's h_out across the ranks inside the pass (the fold's exchange, module docstring);
     comm: a native b3w_comm handle (b3w_comm_create) — the two exchanges then go through the library's own RCCL calls
     (b3w_chain_run_parents_sharded, b3w_chain_allgather_hout) instead of torch.distributed.
@@ -129,6 +131,8 @@ def fold_witnesses(ctx, preimage, batch_steps=16384, ring=2, slice_chunks=1024, 
     n_leaf, n_par = nleaf.value, npar.value
     if commit_only is not None:
         _chk(ctx, L.b3w_chain_commit_only(h, commit_only[0].handle, commit_only[1].data_ptr()), "b3w_chain_commit_only")
+    elif commit_records is not None:
+        _chk(ctx, L.b3w_chain_commit_from_records(h, commit_records[0].handle, commit_records[1].data_ptr()), "b3w_chain_commit_from_records")
     else:
         _chk(ctx, L.b3w_chain_commit_only(h, None, None), "b3w_chain_commit_only")
     compute = torch.cuda.current_stream(dev)

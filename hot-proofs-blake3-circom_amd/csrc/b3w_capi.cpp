@@ -1950,7 +1950,8 @@ struct b3w_chain {
   hipStream_t copy = nullptr, side = nullptr;        // H2D slices; tree + parent planning beside the leaf witness kernels
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   hipEvent_t ev_cvs = nullptr, ev_par = nullptr;     // chunk CVs complete (main stream); parent records ready (side stream)
-  const b3w_commit_key *co_key = nullptr;            // commitments only: no bodies, one point per step into co_points
+  const b3w_commit_key *co_key = nullptr;            // commitments from the step records, one point per step into co_points ...
+  bool co_bodies = false;                            // ... instead of the bodies (false), or beside them (true: b3w_chain_commit_from_records)
   uint8_t *co_points = nullptr, *co_own = nullptr;   // (co_own: the chain's own buffer when the caller passed none)
   const b3w_r1cs *r1cs = nullptr;                    // constraint check of every batch while it sits in the ring
   uint32_t *d_viol = nullptr;                        // ... violated constraints per step
@@ -2009,9 +2010,11 @@ int32_t chain_run_steps(b3w_chain *c, uint64_t first_row, uint64_t count, b3w_ba
       const int32_t rc = b3w_commit_records_device(c->ctx, c->co_key, c->d_recs + r0 * 32, k, c->co_points + r0 * 64, c->d_pub + r0 * 15,
                                                    c->d_status + r0, stream);
       if (rc) return rc;
-      c->nbatch++;
-      done += k;
-      continue;
+      if (!c->co_bodies) {
+        c->nbatch++;
+        done += k;
+        continue;
+      }
     }
     int32_t rc;
     { Range r("b3w:witness batch"); rc = b3w_batch_run_device(c->ctx, c->d_recs + r0 * 32, k, slot, body, c->d_pub + r0 * 15, c->d_status + r0, stream); }
@@ -2031,8 +2034,15 @@ int32_t chain_run_steps(b3w_chain *c, uint64_t first_row, uint64_t count, b3w_ba
 
 extern "C" {
 
+int32_t b3w_chain_commit_from_records(b3w_chain *c, const b3w_commit_key *key, uint8_t *d_points) {
+  const int32_t rc = b3w_chain_commit_only(c, key, d_points);
+  if (rc == B3W_OK) c->co_bodies = key != nullptr;
+  return rc;
+}
+
 int32_t b3w_chain_commit_only(b3w_chain *c, const b3w_commit_key *key, uint8_t *d_points) {
   if (!c || (key && key->ctx != c->ctx)) return B3W_E_BAD_ARGUMENT;
+  c->co_bodies = false;
   if (key && !d_points) {                              // the chain's own buffer: fetch it with b3w_chain_commitments
     if (!c->co_own) {
       ON_DEVICE(c->ctx);

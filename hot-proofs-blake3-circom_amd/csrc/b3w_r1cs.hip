@@ -1408,6 +1408,8 @@ __global__ __launch_bounds__(512, 4) void b3w_r1cs_walk_kernel(const uint8_t *__
     if (lane == 0) xones[(slot0 >> 6) + wave] = is1;
   };
   // ---- verdicts of the general rows of unit k (one iteration after its entries were added): row g -> lane g of the workgroup
+  unsigned long long wrec[5] = {0, 0, 0, 0, 0};
+  size_t wrec_at = 0;                                        // (1 + the record's place: 0 = this lane has none pending)
   auto verdicts = [&](const Cursor c, const uint32_t par, const bool careful, uint32_t &nbad, uint32_t &low) {
     const uint32_t gen_n = TW(c, B3W_WT_GEN_N);
     if (wave * 64u >= gen_n) return;                           // (wave-uniform)
@@ -1430,10 +1432,10 @@ __global__ __launch_bounds__(512, 4) void b3w_r1cs_walk_kernel(const uint8_t *__
         gwide[tid] = 0u;
         if (!defer && !careful) {                              // a wide record, while the body's list has room; else the row itself
           const uint32_t slot = atomicAdd(&cnt[6u + c.body % 3u], 1u);
-          if (slot < B3W_WALK_WIDE_CAP) {
-            unsigned long long *rec = wide_recs + ((size_t)c.body * B3W_WALK_WIDE_CAP + slot) * 5u;
-            rec[0] = a_lo; rec[1] = b_lo; rec[2] = c_lo; rec[3] = (unsigned long long)c_hi;
-            rec[4] = (unsigned long long)(gw & 0x7FFFFFFFu) | (unsigned long long)c.tile << 32 | (unsigned long long)(TW(c, B3W_WT_ROW0) + tid) << 40;
+          if (slot < B3W_WALK_WIDE_CAP) {                      // (kept in registers: the stores go out behind the pack — see the pipeline)
+            wrec_at = ((size_t)c.body * B3W_WALK_WIDE_CAP + slot) * 5u + 1u;
+            wrec[0] = a_lo; wrec[1] = b_lo; wrec[2] = c_lo; wrec[3] = (unsigned long long)c_hi;
+            wrec[4] = (unsigned long long)(gw & 0x7FFFFFFFu) | (unsigned long long)c.tile << 32 | (unsigned long long)(TW(c, B3W_WT_ROW0) + tid) << 40;
           } else defer = true;
         }
       }
@@ -1525,6 +1527,16 @@ __global__ __launch_bounds__(512, 4) void b3w_r1cs_walk_kernel(const uint8_t *__
       count(nb2, low2, prev.body);
     }
     pack(cp, i + 1u < m, par ^ 1u, i3n);
+    // (a wide record's stores go out HERE: behind the wait for the fetch the pack consumes, in front of the next loads — the compiler
+    // cannot count conditional stores, so a wait that follows them is a wait for all of them)
+    if (__ballot(wrec_at != 0) != 0ull) {
+      if (wrec_at) {
+        unsigned long long *rec = wide_recs + (wrec_at - 1u);
+#pragma unroll
+        for (int q = 0; q < 5; q++) rec[q] = wrec[q];
+      }
+      wrec_at = 0;
+    }
     program(cp);
     fetch(cf);
     step(cp); step(cf);
@@ -1538,6 +1550,11 @@ __global__ __launch_bounds__(512, 4) void b3w_r1cs_walk_kernel(const uint8_t *__
     uint32_t nb2 = 0, low2 = 0xFFFFFFFFu;
     verdicts(prev, (m - 1u) & 1u, prev_careful, nb2, low2);
     count(nb2, low2, prev.body);
+    if (wrec_at) {
+      unsigned long long *rec = wide_recs + (wrec_at - 1u);
+#pragma unroll
+      for (int q = 0; q < 5; q++) rec[q] = wrec[q];
+    }
   }
   lds_barrier();
   if (m >= 2u) { summary(prev2, m & 1u, prev2_careful); if (prev2.tile == W.ntiles - 1u) flush(prev2.body); }

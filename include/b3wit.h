@@ -447,6 +447,11 @@ void b3w_chain_destroy(b3w_chain *chain);
  * (b3w_commit_records_device) into d_points (n_leaf + n_parent points of 64 bytes, step order) and writes no witness
  * bodies; the consumer arguments of the run calls are ignored.  key = NULL switches back to bodies. */
 int32_t b3w_chain_commit_only(b3w_chain *chain, const b3w_commit_key *key, uint8_t *d_points);
+/* The same commitments (from the step records, at the speed of the point additions) WHILE the bodies are written as usual —
+ * constraint check and consumers see every batch: the fold-shaped pass "witness -> check -> commit" where the commitment does not
+ * read the 745 KB body back (b3w_batch_commit_device / b3w_commit_consumer do: they are for bodies the library did not make).
+ * A step's commitment from its record equals the commitment of the body the witness kernel writes for it (tests/test_gpu_commit.py). */
+int32_t b3w_chain_commit_from_records(b3w_chain *chain, const b3w_commit_key *key, uint8_t *d_points);
 /* d_points = NULL above: the chain keeps the points itself; this copies them (n_leaf + n_parent times 64 bytes) to the host. */
 int32_t b3w_chain_commitments(b3w_chain *chain, uint8_t *host_points, void *stream);
 /* Constraint check inside the chained pass: after this call (r1cs = a system of the chain's context; NULL turns it off) every

@@ -131,6 +131,7 @@ def test_chain_workload_with_each_consumer(consumer):
     assert d["cpu_baseline"]["kind"] == "port" and d["cpu_baseline"]["value"] > 0 and "first_pass_s" in d["config"]
     assert d["scaling"] == "strong" and d["value"] > 0 and d["config"]["n_chunks"] == 256 and d["config"]["path_len"] == 8
     assert ("no bodies" in d["config"]["consumer"]) == (consumer == "commit-only")
+    assert ("beside the bodies" in d["config"]["consumer"]) == (consumer == "check+commit")
     assert ("constraint check" in d["config"]["consumer"]) == ("check" in consumer)
     if "check" in consumer:
         assert "inside the timed pass: 0 of 23744 constraints violated by any of 6144 step witnesses" in d["config"]["verification"]

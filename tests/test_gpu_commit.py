@@ -423,6 +423,14 @@ def test_chained_pass_commit_only_matches_the_commit_consumer():
     torch.cuda.synchronize()
     assert out2["root"].cpu().numpy().view(np.uint32).tobytes() == root == blake3_ref.blake3(data.tobytes())
     assert int(out2["status"].abs().sum().item()) == 0 and torch.equal(a, b) and int(b.max(dim=1).values.min().item()) > 0
+    # b3w_chain_commit_from_records: the same points from the records WHILE the bodies are written and the consumer sees every batch
+    # (here it commits to the bodies once more, into another array: three ways to the same 152 points)
+    c = torch.zeros((152, 64), dtype=torch.uint8, device=dev)
+    a.zero_()
+    seen = []
+    out3 = m.chain.fold_witnesses(ctx, data, batch_steps=48, ring=2, consumer=lambda v, f, k: (seen.append(k), consumer(v, f, k)), commit_records=(key, c))
+    torch.cuda.synchronize()
+    assert sum(seen) == 152 and torch.equal(c, b) and torch.equal(a, b) and out3["root"].cpu().numpy().view(np.uint32).tobytes() == root
     key.close(); ctx.close()
 
 

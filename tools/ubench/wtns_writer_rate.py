@@ -32,6 +32,28 @@ for rep in range(3):
     dt = time.perf_counter() - t0
 print(f"D2H alone (one hipMemcpy of {k} bodies into pinned memory): {k * body / dt / 1e9:.1f} GB/s = {k / dt / 1e3:.1f} k witnesses/s", flush=True)
 
+# the filesystem alone: the same files written from a buffer that is already in host memory (no GPU, no copy) by T Python threads
+# (os.writev releases the GIL); what the writer can reach at most on this target
+import threading
+blob = bytes(body)
+hdr = ctx.wtns_header()
+for threads in (1, 4, 16, 32):
+    d = tempfile.mkdtemp(prefix="b3w_raw_", dir=base)
+    try:
+        def work(t):
+            for i in range(t, n, threads):
+                fd = os.open(os.path.join(d, f"r{i}.wtns"), os.O_WRONLY | os.O_CREAT | os.O_TRUNC, 0o644)
+                os.writev(fd, [hdr, blob])
+                os.close(fd)
+        t0 = time.perf_counter()
+        th = [threading.Thread(target=work, args=(t,)) for t in range(threads)]
+        for x in th: x.start()
+        for x in th: x.join()
+        dt = time.perf_counter() - t0
+        print(f"filesystem alone, {threads:2d} threads: {n / dt / 1e3:7.2f} k files/s = {n * (len(blob) + 76) / dt / 1e9:5.1f} GB/s", flush=True)
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+
 for threads in (1, 2, 4, 8, 16, 32):
     d = tempfile.mkdtemp(prefix="b3w_wtns_", dir=base)
     try:
