@@ -2,6 +2,7 @@
 // Host code only; every witness is computed by the HIP kernels in b3w_kernels.hip.  There is no
 // CPU evaluation path in this library: without a HIP device b3w_create fails with B3W_E_NO_DEVICE.
 #include <hip/hip_runtime_api.h>
+#include <hip/hip_ext.h>
 #include <errno.h>
 #include <fcntl.h>
 #include <stdint.h>
@@ -1952,6 +1953,9 @@ struct b3w_chain {
   hipEvent_t ev_cvs = nullptr, ev_par = nullptr;     // chunk CVs complete (main stream); parent records ready (side stream)
   const b3w_commit_key *co_key = nullptr;            // commitments from the step records, one point per step into co_points ...
   bool co_bodies = false;                            // ... instead of the bodies (false), or beside them (true: b3w_chain_commit_from_records)
+  hipStream_t co_stream = nullptr;                   // beside them = on a stream of its own: the commit kernels are bound by the vector ALUs, the
+  hipEvent_t ev_co_in = nullptr, ev_co_out = nullptr;//   witness kernels by HBM writes — they run side by side
+  int32_t *d_co_status = nullptr;
   uint8_t *co_points = nullptr, *co_own = nullptr;   // (co_own: the chain's own buffer when the caller passed none)
   const b3w_r1cs *r1cs = nullptr;                    // constraint check of every batch while it sits in the ring
   uint32_t *d_viol = nullptr;                        // ... violated constraints per step
@@ -2005,7 +2009,15 @@ int32_t chain_run_steps(b3w_chain *c, uint64_t first_row, uint64_t count, b3w_ba
     const uint32_t k = (uint32_t)std::min<uint64_t>(c->batch_steps, count - done);
     uint8_t *slot = static_cast<uint8_t *>(c->bodies[c->nbatch % c->ring]);
     const uint64_t r0 = first_row + done;
-    if (c->co_key) {
+    if (c->co_key && c->co_bodies && c->co_stream) {
+      // beside the bodies: on the commit stream, behind everything `stream` holds so far (the records of this batch are planned)
+      Range r("b3w:commit from records (side stream)");
+      hipError_t e = hipEventRecord(c->ev_co_in, (hipStream_t)stream);
+      if (e == hipSuccess) e = hipStreamWaitEvent(c->co_stream, c->ev_co_in, 0);
+      if (e != hipSuccess) return hip_fail(c->ctx, e, "commit stream");
+      const int32_t rc = b3w_commit_records_device(c->ctx, c->co_key, c->d_recs + r0 * 32, k, c->co_points + r0 * 64, nullptr, c->d_co_status + r0, c->co_stream);
+      if (rc) return rc;
+    } else if (c->co_key) {
       Range r("b3w:commit from records");
       const int32_t rc = b3w_commit_records_device(c->ctx, c->co_key, c->d_recs + r0 * 32, k, c->co_points + r0 * 64, c->d_pub + r0 * 15,
                                                    c->d_status + r0, stream);
@@ -2028,6 +2040,11 @@ int32_t chain_run_steps(b3w_chain *c, uint64_t first_row, uint64_t count, b3w_ba
     c->nbatch++;
     done += k;
   }
+  if (c->co_key && c->co_bodies && c->co_stream) {           // `stream` has drained = the commitments are there too
+    hipError_t e = hipEventRecord(c->ev_co_out, c->co_stream);
+    if (e == hipSuccess) e = hipStreamWaitEvent((hipStream_t)stream, c->ev_co_out, 0);
+    if (e != hipSuccess) return hip_fail(c->ctx, e, "commit stream");
+  }
   return B3W_OK;
 }
 }  // namespace
@@ -2036,8 +2053,31 @@ extern "C" {
 
 int32_t b3w_chain_commit_from_records(b3w_chain *c, const b3w_commit_key *key, uint8_t *d_points) {
   const int32_t rc = b3w_chain_commit_only(c, key, d_points);
-  if (rc == B3W_OK) c->co_bodies = key != nullptr;
-  return rc;
+  if (rc != B3W_OK) return rc;
+  c->co_bodies = key != nullptr;
+  // The commit stream (B3W_CHAIN_COMMIT_ASYNC=0: none, the commitments go on the caller's stream between the witness launches).
+  // B3W_COMMIT_CU_PCT=<p>: the stream may use only p % of the CUs (hipExtStreamCreateWithCUMask), the rest stay free for the
+  // witness kernels and the consumers.
+  static const bool async = !(getenv("B3W_CHAIN_COMMIT_ASYNC") && !strcmp(getenv("B3W_CHAIN_COMMIT_ASYNC"), "0"));
+  if (key && async && !c->co_stream) {
+    b3w_ctx *ctx = c->ctx;
+    ON_DEVICE(ctx);
+    static const int pct = getenv("B3W_COMMIT_CU_PCT") ? atoi(getenv("B3W_COMMIT_CU_PCT")) : 0;
+    hipError_t e = hipSuccess;
+    if (pct > 0 && pct < 100) {
+      int cus = 0;
+      e = hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device);
+      std::vector<uint32_t> mask((size_t)(cus + 31) / 32, 0u);
+      // every (100 / (100 - pct))-th CU stays out of the mask: spread over the XCDs (CU ids are dealt to them round-robin)
+      for (int cu = 0; cu < cus; cu++) if ((int64_t)cu * (100 - pct) / 100 == (int64_t)(cu + 1) * (100 - pct) / 100) mask[cu / 32] |= 1u << (cu % 32);
+      if (e == hipSuccess) e = hipExtStreamCreateWithCUMask(&c->co_stream, (uint32_t)mask.size(), mask.data());
+    } else e = hipStreamCreateWithFlags(&c->co_stream, hipStreamNonBlocking);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_co_in, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_co_out, hipEventDisableTiming);
+    if (e == hipSuccess) e = hipMalloc((void **)&c->d_co_status, (size_t)(c->n_leaf + c->n_par + 1) * 4);
+    if (e != hipSuccess) return hip_fail(ctx, e, "commit stream");
+  }
+  return B3W_OK;
 }
 
 int32_t b3w_chain_commit_only(b3w_chain *c, const b3w_commit_key *key, uint8_t *d_points) {
@@ -2165,6 +2205,10 @@ void b3w_chain_destroy(b3w_chain *c) {
   if (c->d_levels) (void)hipFree(c->d_levels);
   if (c->d_root) (void)hipFree(c->d_root);
   if (c->co_own) (void)hipFree(c->co_own);
+  if (c->d_co_status) (void)hipFree(c->d_co_status);
+  if (c->co_stream) (void)hipStreamDestroy(c->co_stream);
+  if (c->ev_co_in) (void)hipEventDestroy(c->ev_co_in);
+  if (c->ev_co_out) (void)hipEventDestroy(c->ev_co_out);
   if (c->d_viol) (void)hipFree(c->d_viol);
   if (c->copy) (void)hipStreamDestroy(c->copy);
   if (c->side) (void)hipStreamDestroy(c->side);

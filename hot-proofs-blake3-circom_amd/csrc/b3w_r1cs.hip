@@ -1370,7 +1370,7 @@ __global__ __launch_bounds__(512, 4) void b3w_r1cs_walk_kernel(const uint8_t *__
         // element's place (a WIDE RECORD) instead of the row — one load there, not a walk through the row's terms
         const bool wide1 = (z >> 63) && mag == 1ull && idx < T;
         if (live) {
-          if (wide1) { if (atomicCAS(&gwide[mt >> 8], 0u, 0x80000000u | (mt & 3u) << 16 | (neg ? 1u << 18 : 0u) | idx) != 0u) atomicOr(&gflag[mt >> 8], 1u); }
+          if (wide1) atomicAdd(&gwide[mt >> 8], 1u << 24 | (mt & 3u) << 16 | (neg ? 1u << 18 : 0u) | idx);      // (bits 24 up count such terms: the verdict lane takes exactly one)
           else if (!ok) atomicOr(&gflag[mt >> 8], 1u);
           else if (hi == 0ull && lo < (1ull << 54)) atomicAdd(sum, neg ? 0ull - lo : lo);
           else {
@@ -1423,7 +1423,7 @@ __global__ __launch_bounds__(512, 4) void b3w_r1cs_walk_kernel(const uint8_t *__
       part_sum(sum[2], sum[3], b_lo, b_hi);
       part_sum(sum[4], sum[5], c_lo, c_hi);
       const uint32_t gw = gwide[tid];
-      defer = gflag[tid] != 0u || a_hi != ((long long)a_lo >> 63) || b_hi != ((long long)b_lo >> 63);
+      defer = gflag[tid] != 0u || (gw >> 24) > 1u || a_hi != ((long long)a_lo >> 63) || b_hi != ((long long)b_lo >> 63);
       bad = !defer && !gw && (a_lo * b_lo != c_lo || __mul64hi((long long)a_lo, (long long)b_lo) != c_hi);
 #pragma unroll
       for (int q = 0; q < 6; q++) sum[q] = 0ull;
@@ -1435,7 +1435,7 @@ __global__ __launch_bounds__(512, 4) void b3w_r1cs_walk_kernel(const uint8_t *__
           if (slot < B3W_WALK_WIDE_CAP) {                      // (kept in registers: the stores go out behind the pack — see the pipeline)
             wrec_at = ((size_t)c.body * B3W_WALK_WIDE_CAP + slot) * 5u + 1u;
             wrec[0] = a_lo; wrec[1] = b_lo; wrec[2] = c_lo; wrec[3] = (unsigned long long)c_hi;
-            wrec[4] = (unsigned long long)(gw & 0x7FFFFFFFu) | (unsigned long long)c.tile << 32 | (unsigned long long)(TW(c, B3W_WT_ROW0) + tid) << 40;
+            wrec[4] = (unsigned long long)(gw & 0xFFFFFFu) | (unsigned long long)c.tile << 32 | (unsigned long long)(TW(c, B3W_WT_ROW0) + tid) << 40;
           } else defer = true;
         }
       }

@@ -43,7 +43,7 @@ def test_default_line_has_the_contract_fields():
 
 
 def test_nova_line_is_labelled_config3():
-    d = _bench("--circuit", "nova_vesta", "--batch", "512", "--steps", "2", "--warmup", "1", "--inner", "2", "--cpu-seconds", "0")
+    d = _bench("--circuit", "nova_vesta", "--batch", "512", "--steps", "2", "--warmup", "1", "--inner", "2", "--cpu-seconds", "0", "--placement", "plain")
     assert d["config"]["workload"].startswith("config3") and "Vesta" in d["config"]["workload"] and d["config"]["launches_per_step"] == 2
 
 
@@ -77,11 +77,11 @@ def test_gpus_2_exchange_modes(mode, impl):
 
 def test_a_rank_hung_before_the_rendezvous_fails_the_run_quickly():
     """one rank never reaches init_process_group (GPU initialised, then stuck): the launcher's watchdog ends the run with status
-    124 well inside the driver's time limit instead of waiting for it"""
+    124 well inside the driver's time limit instead of waiting for it (--launch-timeout 8: seconds from the first rank's torch import)"""
     import time
     t0 = time.monotonic()
     r = subprocess.run([sys.executable, os.path.join(T.ROOT, "bench.py"), "--gpus", "2", "--batch", "256", "--steps", "1", "--warmup", "0",
-                        "--launch-timeout", "12", "--placement", "plain"], capture_output=True, text=True, timeout=400, cwd=T.ROOT,
+                        "--launch-timeout", "8", "--placement", "plain"], capture_output=True, text=True, timeout=400, cwd=T.ROOT,
                        env=dict(os.environ, B3W_DIST_BACKEND="gloo", B3W_BENCH_TEST_HANG_RANK="1", B3W_BENCH_TEST_HANG_AT="rendezvous"))
     assert r.returncode == 124, (r.returncode, r.stderr[-1500:])
     assert "ranks [0, 1] have not passed rendezvous" in r.stderr or "ranks [1] have not passed rendezvous" in r.stderr
