@@ -257,6 +257,9 @@ def bench_chain(args, m, torch, dist, dev, world, rank, local_rank):
             consumer, commit_only = None, (key, d_pts)
         elif "bodies" not in args.consumer:                 # commit / check+commit: the commitments come from the step records, the check reads the bodies
             consumer, commit_records = check_first, (key, d_pts)
+            # (the commitments get a stream of their own beside the witness kernels — not beside the constraint check, which this
+            # harness runs from its consumer callback where the library cannot see it: include/b3wit.h, b3w_chain_commit_from_records)
+            os.environ.setdefault("B3W_CHAIN_COMMIT_ASYNC", "0" if check_first is not None else "1")
     # the fold's exchange (N > 1) is part of every pass: chunk chaining values, then every step's h_out (BASELINE config 4)
     comm = native_comm(m, ctx, dist, world, rank, "chain") if (world > 1 and args.exchange_impl == "native") else None
     run = lambda: m.chain.fold_witnesses(ctx, host, batch_steps=args.batch if args.batch != 4096 else 16384, ring=2, consumer=consumer,

@@ -2058,7 +2058,18 @@ int32_t b3w_chain_commit_from_records(b3w_chain *c, const b3w_commit_key *key, u
   // The commit stream (B3W_CHAIN_COMMIT_ASYNC=0: none, the commitments go on the caller's stream between the witness launches).
   // B3W_COMMIT_CU_PCT=<p>: the stream may use only p % of the CUs (hipExtStreamCreateWithCUMask), the rest stay free for the
   // witness kernels and the consumers.
-  static const bool async = !(getenv("B3W_CHAIN_COMMIT_ASYNC") && !strcmp(getenv("B3W_CHAIN_COMMIT_ASYNC"), "0"));
+  // Measured (profiles/r04/bench_chain_64mib_commit_*): beside the witness kernels alone the stream gains 11 % (3.86 -> 4.27 M steps/s);
+  // beside the constraint check it LOSES (2.50 -> 2.36: the check's persistent workgroups want every CU's LDS) and so does any CU mask —
+  // so the default is: a stream of its own unless the chain also checks constraints; B3W_CHAIN_COMMIT_ASYNC=0 / 1 says otherwise (a caller
+  // whose consumer callback runs the check itself sets 0).
+  const char *env_async = getenv("B3W_CHAIN_COMMIT_ASYNC");
+  const bool async = env_async ? strcmp(env_async, "0") != 0 : c->r1cs == nullptr;
+  if (key && !async && c->co_stream) {                       // (switched off for a chain that had it)
+    ON_DEVICE(c->ctx);
+    (void)hipStreamSynchronize(c->co_stream);
+    (void)hipStreamDestroy(c->co_stream);
+    c->co_stream = nullptr;
+  }
   if (key && async && !c->co_stream) {
     b3w_ctx *ctx = c->ctx;
     ON_DEVICE(ctx);
@@ -2072,9 +2083,9 @@ int32_t b3w_chain_commit_from_records(b3w_chain *c, const b3w_commit_key *key, u
       for (int cu = 0; cu < cus; cu++) if ((int64_t)cu * (100 - pct) / 100 == (int64_t)(cu + 1) * (100 - pct) / 100) mask[cu / 32] |= 1u << (cu % 32);
       if (e == hipSuccess) e = hipExtStreamCreateWithCUMask(&c->co_stream, (uint32_t)mask.size(), mask.data());
     } else e = hipStreamCreateWithFlags(&c->co_stream, hipStreamNonBlocking);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_co_in, hipEventDisableTiming);
-    if (e == hipSuccess) e = hipEventCreateWithFlags(&c->ev_co_out, hipEventDisableTiming);
-    if (e == hipSuccess) e = hipMalloc((void **)&c->d_co_status, (size_t)(c->n_leaf + c->n_par + 1) * 4);
+    if (e == hipSuccess && !c->ev_co_in) e = hipEventCreateWithFlags(&c->ev_co_in, hipEventDisableTiming);
+    if (e == hipSuccess && !c->ev_co_out) e = hipEventCreateWithFlags(&c->ev_co_out, hipEventDisableTiming);
+    if (e == hipSuccess && !c->d_co_status) e = hipMalloc((void **)&c->d_co_status, (size_t)(c->n_leaf + c->n_par + 1) * 4);
     if (e != hipSuccess) return hip_fail(ctx, e, "commit stream");
   }
   return B3W_OK;

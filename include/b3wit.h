@@ -450,7 +450,11 @@ int32_t b3w_chain_commit_only(b3w_chain *chain, const b3w_commit_key *key, uint8
 /* The same commitments (from the step records, at the speed of the point additions) WHILE the bodies are written as usual —
  * constraint check and consumers see every batch: the fold-shaped pass "witness -> check -> commit" where the commitment does not
  * read the 745 KB body back (b3w_batch_commit_device / b3w_commit_consumer do: they are for bodies the library did not make).
- * A step's commitment from its record equals the commitment of the body the witness kernel writes for it (tests/test_gpu_commit.py). */
+ * A step's commitment from its record equals the commitment of the body the witness kernel writes for it (tests/test_gpu_commit.py).
+ * The commit kernels are bound by the vector ALUs, the witness kernels by HBM writes: unless the chain also checks constraints
+ * (b3w_chain_check_constraints) the commitments run on a stream of the chain's own, side by side with the witness kernels, and
+ * `stream` is made to wait for them at the end of each run call (+11 %: 4.27 M steps/s for 64 MiB).  B3W_CHAIN_COMMIT_ASYNC=0 / 1
+ * overrides that choice; B3W_COMMIT_CU_PCT=<p> confines that stream to p % of the CUs (measured: slower at 75 and 88). */
 int32_t b3w_chain_commit_from_records(b3w_chain *chain, const b3w_commit_key *key, uint8_t *d_points);
 /* d_points = NULL above: the chain keeps the points itself; this copies them (n_leaf + n_parent times 64 bytes) to the host. */
 int32_t b3w_chain_commitments(b3w_chain *chain, uint8_t *host_points, void *stream);
