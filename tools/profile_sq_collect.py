@@ -5,12 +5,14 @@ anything: memory, barrier, dependencies) and issuing = SQ_ACTIVE_INST_ANY / SQ_W
 import csv, glob, json, os, re, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-rnd = sys.argv[1] if len(sys.argv) > 1 else "r03"
+rnd = sys.argv[1] if len(sys.argv) > 1 else "r04"
 src = os.path.join(ROOT, "gpurun_out", "prof_sq")
 doc = {"source": "rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_INST_LDS SQ_INSTS_VALU SQ_INSTS_LDS "
                  "SQ_ACTIVE_INST_LDS (tools/profile_sq.sh), averaged per launch", "kernels": {}}
-WANT = {"comp": ("b3w_compression_kernel",), "nova": ("b3w_nova_kernel",), "r1cs": ("b3w_r1cs_stream_kernel", "b3w_r1cs_lean_kernel", "b3w_r1cs_deferred_kernel"),
-        "r1cs_nova": ("b3w_r1cs_stream_kernel", "b3w_r1cs_lean_kernel", "b3w_r1cs_deferred_kernel"),
+WANT = {"comp": ("b3w_compression_kernel",), "nova": ("b3w_nova_kernel",),
+        "r1cs": ("b3w_r1cs_walk_kernel", "b3w_r1cs_walk_deferred_kernel", "b3w_r1cs_stream_kernel", "b3w_r1cs_lean_kernel", "b3w_r1cs_deferred_kernel"),
+        "r1cs_nova": ("b3w_r1cs_walk_kernel", "b3w_r1cs_walk_deferred_kernel", "b3w_r1cs_stream_kernel", "b3w_r1cs_lean_kernel", "b3w_r1cs_deferred_kernel"),
+        "r1cs_stream": ("b3w_r1cs_stream_kernel", "b3w_r1cs_deferred_kernel"),
         "r1cs_lean": ("b3w_r1cs_lean_kernel", "b3w_r1cs_deferred_kernel")}
 for sub, names in WANT.items():
     hits = glob.glob(os.path.join(src, sub, "**", "*counter_collection.csv"), recursive=True)
@@ -27,7 +29,7 @@ for sub, names in WANT.items():
         per.setdefault(short, {}).setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
     for short, ctr in per.items():
         launches = max(len(v) for v in ctr.values())
-        if launches < 2 and "lean" not in short and "deferred" not in short and "stream" not in short:
+        if launches < 2 and "lean" not in short and "deferred" not in short and "stream" not in short and "walk" not in short:
             continue
         avg = {k: sum(v) / len(v) for k, v in ctr.items()}
         if avg.get("SQ_WAVE_CYCLES"):
