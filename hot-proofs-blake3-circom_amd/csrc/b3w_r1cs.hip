@@ -1276,17 +1276,27 @@ __global__ __launch_bounds__(512, 4) void b3w_r1cs_walk_kernel(const uint8_t *__
 #define TW(c, field) ((uint32_t)__builtin_amdgcn_readlane((int)(c).rec, (field)))
   // ---- fetch (unit k): this wave's two groups of 64 elements, each as two blocks of 32 — lanes 0-31 the low, 32-63 the high 16 bytes
   uint4 rlo[2], rhi[2];
+  uint32_t foff[2][2];                                       // this lane's four places in a tile (bytes): constant, but for the end of the last tile
+#pragma unroll
+  for (int q = 0; q < 2; q++)
+#pragma unroll
+    for (int h = 0; h < 2; h++) foff[q][h] = ((wave + (uint32_t)q * WAVES) * 64u + (uint32_t)h * 32u + (lane & 31u)) * 32u + (lane >> 5) * 16u;
   auto fetch = [&](const Cursor c) {                        // (a cursor behind the last unit points at the last unit again: fetched, packed, never looked at)
-    const uint32_t tile = c.tile, body_i = c.body;
-    const uint32_t n_local = TW(c, B3W_WT_NLOCAL);
-    const uint8_t *body = bodies + (uint64_t)body_i * pitch + (uint64_t)tile * (T * 32u);
+    const uint8_t *body = bodies + (uint64_t)c.body * pitch + (uint64_t)c.tile * (T * 32u);
+    const uint32_t lim = (TW(c, B3W_WT_NLOCAL) - 1u) * 32u + (lane >> 5) * 16u;      // (an element behind the tile's end: its last element again)
 #pragma unroll
     for (int q = 0; q < 2; q++) {
-      const uint32_t e0 = (wave + (uint32_t)q * WAVES) * 64u + (lane & 31u), e1 = e0 + 32u;
-      rlo[q] = ldg16<true>(body, (e0 < n_local ? e0 : n_local - 1u) * 32u + (lane >> 5) * 16u);
-      rhi[q] = ldg16<true>(body, (e1 < n_local ? e1 : n_local - 1u) * 32u + (lane >> 5) * 16u);
+      rlo[q] = ldg16<true>(body, min(foff[q][0], lim));
+      rhi[q] = ldg16<true>(body, min(foff[q][1], lim));
     }
   };
+  // ---- who does what beside the equal shares (fetch and pack): every wave's instruction stream is a chain of LDS round trips that
+  // ends at the unit's barrier, so the extra kinds of work go to DIFFERENT waves — the general rows' verdicts to waves 0 ... (the
+  // rows' lanes), the scratch block and the body's results to wave 1, the truth-table runs to waves 3 ..., the exports to waves 4 ...,
+  // the general entries to the last waves (chunk c to wave 7 - c mod 8)
+  const uint32_t ewave = (WAVES - 1u) - wave;                 // this wave's first chunk of entries
+  const uint32_t rtid = (tid + THREADS - 3u * 64u) % THREADS, rwave = (wave + WAVES - 3u) % WAVES;      // this lane's run, were there that many
+  const uint32_t xtid = (tid + THREADS - 4u * 64u) % THREADS, xwave = (wave + WAVES - 4u) % WAVES;      // ... and its export
   // ---- the program of a unit, read one unit ahead from L2 into registers: this wave's entry chunks, its run, its export
   uint32_t pe_w[NE], pe_m[NE], px = 0;
   uint4 prun = make_uint4(0, 0, 0, 0);
@@ -1294,14 +1304,14 @@ __global__ __launch_bounds__(512, 4) void b3w_r1cs_walk_kernel(const uint8_t *__
     const uint32_t ent_off = TW(c, B3W_WT_ENT_OFF), ent_n = TW(c, B3W_WT_ENT_N);
 #pragma unroll
     for (int q = 0; q < NE; q++) {
-      const uint32_t iw = (wave + (uint32_t)q * WAVES) * 64u + lane;
+      const uint32_t iw = (ewave + (uint32_t)q * WAVES) * 64u + lane;
       pe_w[q] = W.ent_w[ent_off + (iw < ent_n ? iw : ent_n)];                              // (behind the tile's entries: the next tile's first or the spare)
       pe_m[q] = iw < ent_n ? W.ent_m[ent_off + iw] : 4u;
     }
     const uint32_t run_n = TW(c, B3W_WT_RUN_N);
-    prun = W.runs[TW(c, B3W_WT_RUN_OFF) + (tid < run_n ? tid : run_n)];
+    prun = W.runs[TW(c, B3W_WT_RUN_OFF) + (rtid < run_n ? rtid : run_n)];
     const uint32_t exp_n = TW(c, B3W_WT_EXP_N);
-    px = W.exp[TW(c, B3W_WT_EXP_OFF) + (tid < exp_n ? tid : exp_n)];
+    px = W.exp[TW(c, B3W_WT_EXP_OFF) + (xtid < exp_n ? xtid : exp_n)];
   };
   // ---- pack (unit k, into parity k & 1): 32-byte elements -> 8 bytes + the "is 1" word of each group of 64; something the tile's
   // rows take for a bit that is none, or wire 0 not being 1, raises the unit's anomaly flag
@@ -1336,7 +1346,7 @@ __global__ __launch_bounds__(512, 4) void b3w_r1cs_walk_kernel(const uint8_t *__
     const uint32_t ent_n = TW(c, B3W_WT_ENT_N), ent_runs = TW(c, B3W_WT_ENT_RUNS);
 #pragma unroll
     for (int q = 0; q < NE; q++) {
-      const uint32_t c0 = (wave + (uint32_t)q * WAVES) * 64u;
+      const uint32_t c0 = (ewave + (uint32_t)q * WAVES) * 64u;
       if (c0 >= ent_n) break;                                  // (wave-uniform)
       const uint32_t w = pe_w[q], mt = pe_m[q];
       const bool live = !(mt & 4u);
@@ -1401,11 +1411,11 @@ __global__ __launch_bounds__(512, 4) void b3w_r1cs_walk_kernel(const uint8_t *__
   // ---- exports of unit k: lane j takes export j — element px of the tile to slot slot0 + j, and the bits of 64 of them as one word
   auto exports = [&](const Cursor c, const uint32_t par) {
     const uint32_t exp_n = TW(c, B3W_WT_EXP_N), slot0 = TW(c, B3W_WT_EXP_SLOT0);
-    if (wave * 64u >= exp_n) return;                           // (wave-uniform)
-    const unsigned long long z = tid < exp_n ? el0[par * T + px] : 0ull;
-    xel[slot0 + tid] = z;
+    if (xwave * 64u >= exp_n) return;                          // (wave-uniform)
+    const unsigned long long z = xtid < exp_n ? el0[par * T + px] : 0ull;
+    xel[slot0 + xtid] = z;
     const unsigned long long is1 = __ballot(z == 1ull);
-    if (lane == 0) xones[(slot0 >> 6) + wave] = is1;
+    if (lane == 0) xones[(slot0 >> 6) + xwave] = is1;
   };
   // ---- verdicts of the general rows of unit k (one iteration after its entries were added): row g -> lane g of the workgroup
   unsigned long long wrec[5] = {0, 0, 0, 0, 0};
@@ -1511,11 +1521,11 @@ __global__ __launch_bounds__(512, 4) void b3w_r1cs_walk_kernel(const uint8_t *__
     entries(ce, par);
     {
       const uint32_t run_n = TW(ce, B3W_WT_RUN_N);
-      if (wave * 64u < run_n) {
-        const uint32_t viol = run_bits(prun, par, tid < run_n);
+      if (rwave * 64u < run_n) {
+        const uint32_t viol = run_bits(prun, par, rtid < run_n);
         if (viol && !sticky) {
           nbad += (uint32_t)__popc(viol);
-          low = min(low, W.row_id[W.run_row[TW(ce, B3W_WT_RUN_OFF) + tid] + (uint32_t)__ffs((int)viol) - 1u]);
+          low = min(low, W.row_id[W.run_row[TW(ce, B3W_WT_RUN_OFF) + rtid] + (uint32_t)__ffs((int)viol) - 1u]);
         }
       }
     }

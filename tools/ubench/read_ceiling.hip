@@ -67,6 +67,7 @@ int main(int argc, char **argv) {
   hipDeviceSynchronize();
   printf("reading %llu GiB in 32 KiB units, 512-thread persistent workgroups\n", (unsigned long long)(bytes >> 30));
   for (int grid : {256, 512, 768, 1024}) {
+    run<1, true, true>("1 unit ahead, nt loads, barrier per unit", d, bytes, sink, grid);
     run<2, true, true>("2 units ahead, nt loads, barrier per unit", d, bytes, sink, grid);
     run<2, false, true>("2 units ahead, plain loads, barrier per unit", d, bytes, sink, grid);
     run<2, true, false>("2 units ahead, nt loads, no barrier", d, bytes, sink, grid);
