@@ -1222,13 +1222,17 @@ __device__ __forceinline__ uint32_t table32(uint32_t table, uint32_t x0, uint32_
   return (x4 & l[1]) | (~x4 & l[0]);
 }
 
-template <int NE>                                            // chunks of 64 general entries a wave takes at most (the tile with most: NE * 512)
+template <int NE, bool STAMPS = false>                       // chunks of 64 general entries a wave takes at most (the tile with most: NE * 512); STAMPS: the diagnostic build's
 __global__ __launch_bounds__(512, 4) void b3w_r1cs_walk_kernel(const uint8_t *__restrict__ bodies, uint64_t pitch, uint32_t n, B3wWalk W,
                                                                unsigned long long *__restrict__ scratch, uint32_t block_words,
                                                                unsigned long long *__restrict__ body_flags /* per body: bit t = tile t has deferred rows; bits 56 up: wide records */,
                                                                unsigned long long *__restrict__ wide_recs /* per body B3W_WALK_WIDE_CAP x 5 words */,
-                                                               uint32_t *__restrict__ violations, uint32_t *__restrict__ first) {
+                                                               uint32_t *__restrict__ violations, uint32_t *__restrict__ first,
+                                                               unsigned long long *__restrict__ stamps /* STAMPS: per wave 8 cycle sums of the middle workgroup */) {
   constexpr uint32_t WAVES = 8, THREADS = 512, T = B3W_R1CS_TILE;
+  unsigned long long ph[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t_prev = 0;
+  const bool stamping = STAMPS && stamps != nullptr && blockIdx.x == gridDim.x / 2u;
+#define B3W_WSTAMP(k) do { if (STAMPS && stamping) { const unsigned long long t_now = __builtin_amdgcn_s_memtime(); ph[k] += t_now - t_prev; t_prev = t_now; } } while (0)
   extern __shared__ __align__(16) unsigned char smem[];
   const uint32_t tid = threadIdx.x, lane = tid & 63u;
   const uint32_t wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -1508,6 +1512,7 @@ __global__ __launch_bounds__(512, 4) void b3w_r1cs_walk_kernel(const uint8_t *__
   bool sticky = false, prev_careful = false, prev2_careful = false;
   uint32_t i3 = 0;
   for (uint32_t i = 0; i < m; i++) {
+    if (STAMPS && stamping) t_prev = __builtin_amdgcn_s_memtime();
     const uint32_t par = i & 1u;
     const uint32_t i3n = i3 == 2u ? 0u : i3 + 1u, i3nn = i3n == 2u ? 0u : i3n + 1u;
     const bool anomaly = __builtin_amdgcn_readfirstlane(lanom[i3]) != 0u;
@@ -1517,8 +1522,10 @@ __global__ __launch_bounds__(512, 4) void b3w_r1cs_walk_kernel(const uint8_t *__
       summary(prev2, par, prev2_careful);
       if (prev2.tile == W.ntiles - 1u) flush(prev2.body);     // (its verdicts ran in the last iteration, behind the last barrier)
     }
+    B3W_WSTAMP(0);
     uint32_t nbad = 0, low = 0xFFFFFFFFu;
     entries(ce, par);
+    B3W_WSTAMP(1);
     {
       const uint32_t run_n = TW(ce, B3W_WT_RUN_N);
       if (rwave * 64u < run_n) {
@@ -1529,14 +1536,18 @@ __global__ __launch_bounds__(512, 4) void b3w_r1cs_walk_kernel(const uint8_t *__
         }
       }
     }
+    B3W_WSTAMP(2);
     exports(ce, par);
     count(nbad, low, ce.body);
+    B3W_WSTAMP(3);
     if (i) {
       uint32_t nb2 = 0, low2 = 0xFFFFFFFFu;
       verdicts(prev, par ^ 1u, prev_careful, nb2, low2);
       count(nb2, low2, prev.body);
     }
+    B3W_WSTAMP(4);
     pack(cp, i + 1u < m, par ^ 1u, i3n);
+    B3W_WSTAMP(5);
     // (a wide record's stores go out HERE: behind the wait for the fetch the pack consumes, in front of the next loads — the compiler
     // cannot count conditional stores, so a wait that follows them is a wait for all of them)
     if (__ballot(wrec_at != 0) != 0ull) {
@@ -1554,8 +1565,12 @@ __global__ __launch_bounds__(512, 4) void b3w_r1cs_walk_kernel(const uint8_t *__
     prev = ce; prev_careful = sticky;
     step(ce);
     i3 = i3n;
+    B3W_WSTAMP(6);
     lds_barrier();
+    B3W_WSTAMP(7);
   }
+  if (STAMPS && stamping && lane == 0)
+    for (int k = 0; k < 8; k++) stamps[wave * 8 + k] = ph[k];
   {
     uint32_t nb2 = 0, low2 = 0xFFFFFFFFu;
     verdicts(prev, (m - 1u) & 1u, prev_careful, nb2, low2);
@@ -1571,6 +1586,7 @@ __global__ __launch_bounds__(512, 4) void b3w_r1cs_walk_kernel(const uint8_t *__
   lds_barrier();
   summary(prev, (m - 1u) & 1u, prev_careful);
   flush(prev.body);
+#undef B3W_WSTAMP
 }
 #undef TW
 
@@ -1812,6 +1828,20 @@ extern "C" int b3w_launch_r1cs_walk(const uint8_t *d_bodies, uint32_t n, uint64_
   if (ne > 4u || walk->ntiles > 56u) return -6;
   const void *fn = ne <= 1u ? reinterpret_cast<const void *>(&b3w_r1cs_walk_kernel<1>) : ne == 2u ? reinterpret_cast<const void *>(&b3w_r1cs_walk_kernel<2>)
                    : ne == 3u ? reinterpret_cast<const void *>(&b3w_r1cs_walk_kernel<3>) : reinterpret_cast<const void *>(&b3w_r1cs_walk_kernel<4>);
+  unsigned long long *d_stamps = nullptr;
+#ifdef B3W_R1CS_DIAG
+  // diagnostic build only: B3W_R1CS_STAMPS=1 prints per-phase cycle sums of the middle workgroup after every launch (synchronises)
+  static const bool print_stamps = getenv("B3W_R1CS_STAMPS") && atoi(getenv("B3W_R1CS_STAMPS"));
+  static unsigned long long *d_stamps_buf = nullptr;
+  if (print_stamps) {
+    hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return (int)hipErrorStreamCaptureUnsupported; }
+    if (!d_stamps_buf && hipMalloc((void **)&d_stamps_buf, 8 * 8 * 8) != hipSuccess) d_stamps_buf = nullptr;
+    d_stamps = d_stamps_buf;
+    fn = ne <= 1u ? reinterpret_cast<const void *>(&b3w_r1cs_walk_kernel<1, true>) : reinterpret_cast<const void *>(&b3w_r1cs_walk_kernel<3, true>);
+    if (ne == 2u || ne > 3u) return -6;
+  }
+#endif
   struct PerDevice { int cus = 0, lds = 0; bool attr[4] = {false, false, false, false}; };
   static PerDevice per[64];
   static std::mutex mu;
@@ -1843,9 +1873,22 @@ extern "C" int b3w_launch_r1cs_walk(const uint8_t *d_bodies, uint32_t n, uint64_
     const uint8_t *bodies0 = d_bodies + (uint64_t)b0 * pitch;
     uint32_t *viol0 = d_violations + b0, *first0 = d_first ? d_first + b0 : nullptr;
     unsigned long long *flags = d_scratch + (size_t)B3W_R1CS_SLAB * walk->ntiles * bw, *wide = flags + B3W_R1CS_SLAB;
-    void *args[] = {(void *)&bodies0, (void *)&pitch, (void *)&nb, (void *)walk, (void *)&d_scratch, (void *)&bw, (void *)&flags, (void *)&wide, (void *)&viol0, (void *)&first0};
+    void *args[] = {(void *)&bodies0, (void *)&pitch, (void *)&nb, (void *)walk, (void *)&d_scratch, (void *)&bw, (void *)&flags, (void *)&wide, (void *)&viol0, (void *)&first0, (void *)&d_stamps};
     e = hipLaunchKernel(fn, dim3(grid), dim3(512), args, smem, stream);
     if (e != hipSuccess) return (int)e;
+    if (d_stamps) {
+      unsigned long long h[64];
+      if (hipStreamSynchronize(stream) == hipSuccess && hipMemcpy(h, d_stamps, sizeof h, hipMemcpyDeviceToHost) == hipSuccess) {
+        const double un = (double)nb / grid * walk->ntiles;
+        static const char *name[8] = {"top+summary", "entries", "runs", "exports", "verdicts", "wait+pack", "program+fetch", "barrier"};
+        fprintf(stderr, "b3w_r1cs_walk stamps (cycles per unit, workgroup %u of %u, %g units):\n", grid / 2, grid, un);
+        for (int k = 0; k < 8; k++) {
+          fprintf(stderr, "  %-15s", name[k]);
+          for (int w = 0; w < 8; w++) fprintf(stderr, " %5.0f", (double)h[w * 8 + k] / un);
+          fprintf(stderr, "\n");
+        }
+      }
+    }
     hipLaunchKernelGGL(b3w_r1cs_walk_deferred_kernel, dim3(nb), dim3(256), 0, stream, bodies0, pitch, nb, *sysw, d_scratch, bw, flags, wide, *field, viol0, first0);
     e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
