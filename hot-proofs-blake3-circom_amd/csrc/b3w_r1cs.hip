@@ -1307,15 +1307,18 @@ __global__ __launch_bounds__(512, 4) void b3w_r1cs_walk_kernel(const uint8_t *__
   auto program = [&](const Cursor c) {
     const uint32_t ent_off = TW(c, B3W_WT_ENT_OFF), ent_n = TW(c, B3W_WT_ENT_N);
 #pragma unroll
+    // (only what this wave will use — the loads stand in FRONT of the next fetch, where a wait for them never waits for a fetch)
     for (int q = 0; q < NE; q++) {
       const uint32_t iw = (ewave + (uint32_t)q * WAVES) * 64u + lane;
-      pe_w[q] = W.ent_w[ent_off + (iw < ent_n ? iw : ent_n)];                              // (behind the tile's entries: the next tile's first or the spare)
-      pe_m[q] = iw < ent_n ? W.ent_m[ent_off + iw] : 4u;
+      if ((ewave + (uint32_t)q * WAVES) * 64u < ent_n) {                                   // (wave-uniform)
+        pe_w[q] = W.ent_w[ent_off + iw];                                                   // (behind the tile's entries: the next tile's or the spare)
+        pe_m[q] = iw < ent_n ? W.ent_m[ent_off + iw] : 4u;
+      }
     }
     const uint32_t run_n = TW(c, B3W_WT_RUN_N);
-    prun = W.runs[TW(c, B3W_WT_RUN_OFF) + (rtid < run_n ? rtid : run_n)];
+    if (rwave * 64u < run_n) prun = W.runs[TW(c, B3W_WT_RUN_OFF) + rtid];
     const uint32_t exp_n = TW(c, B3W_WT_EXP_N);
-    px = W.exp[TW(c, B3W_WT_EXP_OFF) + (xtid < exp_n ? xtid : exp_n)];
+    if (xwave * 64u < exp_n) px = W.exp[TW(c, B3W_WT_EXP_OFF) + xtid];
   };
   // ---- pack (unit k, into parity k & 1): 32-byte elements -> 8 bytes + the "is 1" word of each group of 64; something the tile's
   // rows take for a bit that is none, or wire 0 not being 1, raises the unit's anomaly flag
@@ -1560,10 +1563,10 @@ __global__ __launch_bounds__(512, 4) void b3w_r1cs_walk_kernel(const uint8_t *__
     }
     program(cp);
     fetch(cf);
-    step(cp); step(cf);
     prev2 = prev; prev2_careful = prev_careful;
     prev = ce; prev_careful = sticky;
-    step(ce);
+    ce = cp; cp = cf;                                         // (the cursors follow one another: one table row read per unit)
+    step(cf);
     i3 = i3n;
     B3W_WSTAMP(6);
     lds_barrier();

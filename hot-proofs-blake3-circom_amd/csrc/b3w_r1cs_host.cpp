@@ -676,9 +676,8 @@ bool b3w_r1cs_host_build(const uint8_t *img, size_t len, const uint8_t prime_le[
         for (uint32_t w = t * T; w < std::min(nwires, (t + 1) * T); w++)
           if (mustbit[w]) wmask[(size_t)t * 16u + ((w - t * T) >> 6)] |= 1ull << ((w - t * T) & 63u);
       }
-      wruns.insert(wruns.end(), {0u, 0u, 0u, 0u});           // (a lane may read one descriptor behind the last)
-      went_w.push_back(0u); went_m.push_back(4u);
-      wexp.push_back(0);
+      // (a wave reads whole chunks of 64: a lane may read up to 63 entries, descriptors or exports behind its tile's last)
+      for (int pad = 0; pad < 64; pad++) { wruns.insert(wruns.end(), {0u, 0u, 0u, 0u}); went_w.push_back(0u); went_m.push_back(4u); wexp.push_back(0); }
       H->walk = true; H->wexp_slots = slots; H->wmax_gen = wmax_gen; H->wmax_ent = wmax_ent; H->wmax_exp = wmax_exp; H->wmax_runs = wmax_runs;
       H->wmax_rows = wmax_rows; H->wstatic_words = sw;
       H->wtile = std::move(wtile); H->wmask = std::move(wmask); H->wexp = std::move(wexp); H->wruns = std::move(wruns);

@@ -126,7 +126,7 @@ static bool walk_ok(const B3wR1csHost &H) {
   const uint32_t T = B3W_R1CS_TILE, nt = H.ntiles;
   CHECK(H.wtile.size() == (size_t)B3W_WT_WORDS * nt && H.wmask.size() == 16 * (size_t)nt && H.wtiles4.size() == 4 * (size_t)nt);
   CHECK(H.wexp_slots % 64 == 0 && H.wexp_slots <= B3W_WALK_MAX_EXP_SLOTS && H.wstatic.size() == (size_t)nt * H.wstatic_words);
-  CHECK(H.wrow_k.size() == H.m && H.wrow_id.size() == H.m && H.wruns.size() % 4 == 0 && H.wrun_row.size() + 1 == H.wruns.size() / 4);
+  CHECK(H.wrow_k.size() == H.m && H.wrow_id.size() == H.m && H.wruns.size() % 4 == 0 && H.wrun_row.size() + 64 == H.wruns.size() / 4);
   CHECK(H.went_w.size() == H.went_m.size() && H.wmax_gen <= B3W_WALK_MAX_GEN && H.wmax_ent <= B3W_WALK_MAX_ENT);
   std::vector<uint8_t> seen(H.m, 0);
   uint32_t rows_so_far = 0, slots_so_far = 0;
@@ -134,7 +134,7 @@ static bool walk_ok(const B3wR1csHost &H) {
     const uint32_t *w = &H.wtile[(size_t)B3W_WT_WORDS * t];
     const uint32_t n_local = w[B3W_WT_NLOCAL], exp_n = w[B3W_WT_EXP_N], slot0 = w[B3W_WT_EXP_SLOT0];
     CHECK(n_local == std::min<uint32_t>(T, H.nwires - t * T) && slot0 == slots_so_far && slot0 % 64 == 0);
-    CHECK((uint64_t)w[B3W_WT_EXP_OFF] + exp_n + 1 <= H.wexp.size() && exp_n <= H.wmax_exp);
+    CHECK((uint64_t)w[B3W_WT_EXP_OFF] + exp_n + 64 <= H.wexp.size() && exp_n <= H.wmax_exp);
     for (uint32_t j = 0; j < exp_n; j++) CHECK(H.wexp[w[B3W_WT_EXP_OFF] + j] < n_local && (j == 0 || H.wexp[w[B3W_WT_EXP_OFF] + j] > H.wexp[w[B3W_WT_EXP_OFF] + j - 1]));
     slots_so_far += (exp_n + 63u) & ~63u;
     // an element index of this tile: local, or a slot an EARLIER tile has filled
@@ -145,7 +145,7 @@ static bool walk_ok(const B3wR1csHost &H) {
     for (uint32_t r = row0; r < row0 + nrows; r++) { CHECK(H.wrow_k[r] < H.m && !seen[H.wrow_k[r]]); seen[H.wrow_k[r]] = 1; }
     rows_so_far += nrows;
     const uint32_t run_off = w[B3W_WT_RUN_OFF], run_n = w[B3W_WT_RUN_N];
-    CHECK((uint64_t)run_off + run_n + 1 <= H.wruns.size() / 4 && run_n <= H.wmax_runs);
+    CHECK((uint64_t)run_off + run_n + 64 <= H.wruns.size() / 4 && run_n <= H.wmax_runs);
     uint32_t next_row = row0 + gen_n;
     for (uint32_t r = run_off; r < run_off + run_n; r++) {
       const uint32_t *d = &H.wruns[4 * (size_t)r];
@@ -158,7 +158,7 @@ static bool walk_ok(const B3wR1csHost &H) {
     }
     CHECK(next_row <= row0 + nrows);
     const uint32_t ent_off = w[B3W_WT_ENT_OFF], ent_n = w[B3W_WT_ENT_N], ent_runs = w[B3W_WT_ENT_RUNS];
-    CHECK((uint64_t)ent_off + ent_n + 1 <= H.went_w.size() && ent_n <= H.wmax_ent && ent_runs <= ent_n && ent_runs % 64 == 0);
+    CHECK((uint64_t)ent_off + ent_n + 64 <= H.went_w.size() && ent_n <= H.wmax_ent && ent_runs <= ent_n && ent_runs % 64 == 0);
     for (uint32_t i = 0; i < ent_n; i++) {
       const uint32_t e = H.went_w[ent_off + i], mt = H.went_m[ent_off + i];
       if (mt & 4u) { CHECK(i < ent_runs && mt == 4u); continue; }
