@@ -1166,7 +1166,7 @@ struct b3w_r1cs {
   // the walk kernel's program, and the system as the deferred kernel sees it behind the walk kernel (walk row order)
   bool has_walk = false;
   uint32_t *d_wtile = nullptr, *d_wruns = nullptr, *d_wrun_row = nullptr, *d_went_w = nullptr, *d_went_m = nullptr, *d_wrow_k = nullptr, *d_wrow_id = nullptr,
-           *d_wtiles4 = nullptr;
+           *d_wtiles4 = nullptr, *d_wstatic_k = nullptr, *d_wstatic_id = nullptr;
   uint16_t *d_wexp = nullptr;
   unsigned long long *d_wmask = nullptr, *d_wstatic = nullptr;
   B3wWalk walk{};
@@ -1253,8 +1253,18 @@ static int32_t r1cs_create_impl(b3w_ctx *ctx, const uint8_t *img, size_t len, b3
     up((void **)&r->d_wrow_id, H.wrow_id.data(), H.wrow_id.size() * 4);
     up((void **)&r->d_wtiles4, H.wtiles4.data(), H.wtiles4.size() * 4);
     up((void **)&r->d_wstatic, H.wstatic.data(), H.wstatic.size() * 8);
+    std::vector<uint32_t> sk, sid;                           // the always-deferred rows as a list (the deferred kernel walks it for every body)
+    for (uint32_t t = 0; t < H.ntiles; t++)
+      for (uint32_t pos = 0; pos < H.wtiles4[4 * (size_t)t + 1]; pos++)
+        if ((H.wstatic[(size_t)t * H.wstatic_words + (pos >> 6)] >> (pos & 63u)) & 1ull) {
+          sk.push_back(H.wrow_k[H.wtiles4[4 * (size_t)t] + pos]);
+          sid.push_back(H.wrow_id[H.wtiles4[4 * (size_t)t] + pos]);
+        }
+    up((void **)&r->d_wstatic_k, sk.data(), sk.size() * 4);
+    up((void **)&r->d_wstatic_id, sid.data(), sid.size() * 4);
     r->walk = B3wWalk{H.ntiles, H.wexp_slots, H.wmax_gen, H.wmax_ent, r->ncoef, H.wstatic_words, H.wmax_rows, 0u, r->d_wtile, r->d_wmask, r->d_wexp,
-                      reinterpret_cast<const uint4 *>(r->d_wruns), r->d_wrun_row, r->d_went_w, r->d_went_m, r->d_wrow_id, r->d_wstatic, r->d_coef_small};
+                      reinterpret_cast<const uint4 *>(r->d_wruns), r->d_wrun_row, r->d_went_w, r->d_went_m, r->d_wrow_id, r->d_wstatic, r->d_coef_small,
+                      r->d_wstatic_k, r->d_wstatic_id, (uint32_t)sk.size(), 0u};
     r->sysw = r->sys;
     r->sysw.tiles = r->d_wtiles4; r->sysw.row_k = r->d_wrow_k; r->sysw.row_id = r->d_wrow_id; r->sysw.max_tile_rows = H.wmax_rows;
     r->has_walk = true;
@@ -1291,7 +1301,7 @@ void b3w_r1cs_destroy(b3w_r1cs *r) {
   for (uint32_t *q : {r->d_trow_k, r->d_lrows, r->d_lterms, r->d_ltile_terms, r->d_srows, r->d_sgdesc, r->d_sgwords, r->d_sgmeta}) if (q) (void)hipFree(q);
   if (r->d_smask) (void)hipFree(r->d_smask);
   if (r->d_scost) (void)hipFree(r->d_scost);
-  for (uint32_t *q : {r->d_wtile, r->d_wruns, r->d_wrun_row, r->d_went_w, r->d_went_m, r->d_wrow_k, r->d_wrow_id, r->d_wtiles4}) if (q) (void)hipFree(q);
+  for (uint32_t *q : {r->d_wtile, r->d_wruns, r->d_wrun_row, r->d_went_w, r->d_went_m, r->d_wrow_k, r->d_wrow_id, r->d_wtiles4, r->d_wstatic_k, r->d_wstatic_id}) if (q) (void)hipFree(q);
   if (r->d_wexp) (void)hipFree(r->d_wexp);
   if (r->d_wmask) (void)hipFree(r->d_wmask);
   if (r->d_wstatic) (void)hipFree(r->d_wstatic);

@@ -123,6 +123,8 @@ struct B3wWalk {
   const uint32_t *run_row, *ent_w, *ent_m, *row_id;
   const unsigned long long *stat;        // static_words per tile
   const long long *coef_small;
+  const uint32_t *static_k, *static_id;  // the always-deferred rows as a list: gather row, constraint number
+  uint32_t nstatic, pad2;
 };
 // The WALK kernel (default where the system fits): a workgroup walks whole bodies tile after tile, earlier tiles' wires come from an
 // export area in LDS — no outside wire is gathered from HBM.  `sysw` = the system with the WALK row order in tiles / row_k / row_id

@@ -1122,13 +1122,26 @@ __global__ __launch_bounds__(64) void b3w_r1cs_deferred_kernel(const uint8_t *__
 __global__ __launch_bounds__(256) void b3w_r1cs_walk_deferred_kernel(const uint8_t *__restrict__ bodies, uint64_t pitch, uint32_t n, B3wR1csSystem S,
                                                                     const unsigned long long *__restrict__ scratch, uint32_t block_words,
                                                                     const unsigned long long *__restrict__ body_flags,
-                                                                    const unsigned long long *__restrict__ wide_recs, B3wField F,
-                                                                    uint32_t *__restrict__ violations, uint32_t *__restrict__ first) {
+                                                                    const unsigned long long *__restrict__ wide_recs,
+                                                                    const uint32_t *__restrict__ static_k, const uint32_t *__restrict__ static_id, uint32_t nstatic,
+                                                                    B3wField F, uint32_t *__restrict__ violations, uint32_t *__restrict__ first) {
   const uint32_t b = blockIdx.x;
-  unsigned long long flags = body_flags[b];
-  if (flags == 0ull) return;
   const uint8_t *body = bodies + (uint64_t)b * pitch;
   uint32_t nbad = 0, low = 0xFFFFFFFFu;
+  // the system's ALWAYS-deferred rows (a coefficient that is no small integer: one row of 133 terms in each O2 nova system), for every
+  // body, by the last wave, straight from the kernel's own list — no flag, no block, no mask word stands between the launch and the
+  // row's terms
+  if ((threadIdx.x >> 6) == 3u)
+    for (uint32_t sr = 0; sr < nstatic; sr++) {
+      const uint4 d = reinterpret_cast<const uint4 *>(S.g_rows)[static_k[sr]];
+      const bool bad = gather_row_wave(body, d, S.g_wires, S.g_cids, S.coefs, F);
+      if ((threadIdx.x & 63u) == 0 && bad) { nbad++; low = min(low, static_id[sr]); }
+    }
+  unsigned long long flags = body_flags[b];
+  if (flags == 0ull) {                                       // (wave-uniform)
+    if (nstatic) deferred_report(nbad, low, b, violations, first);
+    return;
+  }
   // WIDE RECORDS: rows with ONE term s * W (s = +-1, W an element of 2^63 or more, as it lies in the body): with the other terms'
   // sums a, b, c — small integers, from the walk kernel — the row says (a + sW) b = c, a (b + sW) = c or a b = c + sW, i.e. k W = d
   // with k = s b, s a or s and d = c - a b or a b - c: decided by small_product_is (|k| < 2^32; else the general road).  An element
@@ -1469,9 +1482,9 @@ __global__ __launch_bounds__(512, 4) void b3w_r1cs_walk_kernel(const uint8_t *__
     const uint32_t nrows = TW(c, B3W_WT_NROWS), words = (nrows + 63u) >> 6;
     unsigned long long v = 0ull;
     if (lane < words) {
-      v = lstat[c.tile * W.static_words + lane];
-      if (lane < 8u) { v |= dmask0[par * 8u + lane]; dmask0[par * 8u + lane] = 0ull; }
-      if (careful) v = lane + 1u < words || !(nrows & 63u) ? ~0ull : (1ull << (nrows & 63u)) - 1ull;
+      if (lane < 8u) { v = dmask0[par * 8u + lane]; dmask0[par * 8u + lane] = 0ull; }
+      // (the ALWAYS-deferred rows are not in the blocks: the deferred kernel takes them for every body from its own list)
+      if (careful) v = (lane + 1u < words || !(nrows & 63u) ? ~0ull : (1ull << (nrows & 63u)) - 1ull) & ~lstat[c.tile * W.static_words + lane];
     }
     unsigned long long *block = scratch + ((size_t)c.body * W.ntiles + c.tile) * block_words;
     const unsigned long long head = __ballot(v != 0ull);
@@ -1892,7 +1905,8 @@ extern "C" int b3w_launch_r1cs_walk(const uint8_t *d_bodies, uint32_t n, uint64_
         }
       }
     }
-    hipLaunchKernelGGL(b3w_r1cs_walk_deferred_kernel, dim3(nb), dim3(256), 0, stream, bodies0, pitch, nb, *sysw, d_scratch, bw, flags, wide, *field, viol0, first0);
+    hipLaunchKernelGGL(b3w_r1cs_walk_deferred_kernel, dim3(nb), dim3(256), 0, stream, bodies0, pitch, nb, *sysw, d_scratch, bw, flags, wide, walk->static_k, walk->static_id, walk->nstatic, *field,
+                       viol0, first0);
     e = hipGetLastError();
     if (e != hipSuccess) return (int)e;
   }

@@ -347,6 +347,8 @@ for circuit in ("compression", "nova_bn254_o1", "nova_vesta", "nova_bn254"):
             s = 23100 + 2 * j
             v = int.from_bytes(host[i, 32 * s:32 * s + 32].tobytes(), "little")
             host[i, 32 * s:32 * s + 32] = np.frombuffer([v + 1, 5, (1 << 255) + 3][j % 3].to_bytes(32, "little"), dtype=np.uint8)
+        for j, i in enumerate(range(90, 130, 2)):  # ... and one bit of Num2Bits(65)(chunk_idx) flipped: the always-deferred row of 133 terms (the deferred kernel's own list)
+            host[i, 32 * (23230 + 3 * j)] ^= 1
     d = torch.from_numpy(host).cuda()
     viol = torch.zeros(n, dtype=torch.int32, device="cuda"); first = torch.zeros(n, dtype=torch.int32, device="cuda")
     r1cs.check_device(d.data_ptr(), n, 0, viol.data_ptr(), first.data_ptr(), torch.cuda.current_stream().cuda_stream)
