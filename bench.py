@@ -583,8 +583,11 @@ def main():
     t_alloc = time.perf_counter()
     bodies = alloc()
     for attempt in range(4):                                # a box still releasing another process's memory: try again
-        if bodies.placement == "mixed" or os.environ.get("B3W_PLACEMENT") == "plain":
+        if bodies.placement in ("mixed", "interleaved") or os.environ.get("B3W_PLACEMENT") == "plain":   # interleaved: placed, this box's plain buffers were as fast
             break
+        cost = ctx.placement_cost()
+        if cost["search_timeouts"] or cost["search_gib_walked"] > 1.5 * n * pitch / 2**30:
+            break                                           # the search ran out its time or walked far beyond the buffer and found one class: it IS plain here
         bodies.free()
         ctx.trim()                                          # (ring buffers a context keeps from destroyed chains: none here, but say so)
         m.lib().b3w_bodies_trim()                           # hand the pooled pieces back: the next search starts afresh

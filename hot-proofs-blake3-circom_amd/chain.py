@@ -25,7 +25,7 @@ import numpy as np
 import torch
 import torch.distributed as dist
 
-from . import B3W_OK, B3WError, lib
+from . import B3W_OK, PLACEMENT_NAMES, B3WError, lib
 from .sharding import gather_rows, shard_range
 
 
@@ -186,7 +186,7 @@ def fold_witnesses(ctx, preimage, batch_steps=16384, ring=2, slice_chunks=1024, 
                 records=_view(L.b3w_chain_records(h), (rows, 32), "<i4", dev), root=_view(L.b3w_chain_root(h), (8,), "<i4", dev),
                 n_leaf_steps=n_leaf, n_parent_steps=n_par, first_chunk=c0, n_chunks_local=nl, n_chunks=n, path_len=P.value,
                 batches=-(-n_leaf // batch_steps) + -(-n_par // batch_steps) if consumer is None else nbatch[0],
-                placement="mixed" if pl.value == 1 else "plain", exchange_timer=timer)
+                placement=PLACEMENT_NAMES.get(pl.value, "plain"), exchange_timer=timer)
 
 
 def exchange_ms(out):

@@ -806,9 +806,9 @@ int32_t b3w_bodies_alloc(b3w_ctx *ctx, uint64_t bytes, void **d_ptr, int32_t *pl
         if (ctx->plain_ms_per_gb > 0) {
           const float placed = time_witness_fill(ctx, static_cast<uint8_t *>(*d_ptr), std::min<uint64_t>(bytes, 8ull << 30));
           if (placed > 0 && placed > ctx->plain_ms_per_gb / 1.10f) {
-            mixed = 0;
+            mixed = B3W_PLACEMENT_INTERLEAVED;
             if (getenv("B3W_PLACE_DEBUG"))
-              fprintf(stderr, "b3w_bodies_alloc: placed buffer %.4f ms/GB against plain %.4f ms/GB: below +10 %%, reported as plain\n", placed,
+              fprintf(stderr, "b3w_bodies_alloc: placed buffer %.4f ms/GB against plain %.4f ms/GB: below +10 %%, reported as interleaved (no speed claim)\n", placed,
                       ctx->plain_ms_per_gb);
           } else if (getenv("B3W_PLACE_DEBUG")) {
             fprintf(stderr, "b3w_bodies_alloc: placed buffer %.4f ms/GB, plain %.4f ms/GB (%+.0f %%)\n", placed, ctx->plain_ms_per_gb,
@@ -816,7 +816,7 @@ int32_t b3w_bodies_alloc(b3w_ctx *ctx, uint64_t bytes, void **d_ptr, int32_t *pl
           }
         }
       }
-      if (placement) *placement = mixed ? B3W_PLACEMENT_MIXED : B3W_PLACEMENT_PLAIN;
+      if (placement) *placement = mixed;                              // 0 plain, 1 mixed, 2 interleaved without the speed claim
       return B3W_OK;
     }
     (void)hipGetLastError();   // the virtual-memory path is an optimisation: fall through to a plain allocation
@@ -2192,7 +2192,8 @@ int32_t b3w_chain_create(b3w_ctx *ctx, uint64_t preimage_len, uint64_t first_chu
     const int32_t rc = p ? B3W_OK : b3w_bodies_alloc(ctx, want, &p, &pl);
     if (rc) { b3w_chain_destroy(c); return rc; }
     c->bodies.push_back(p);
-    if (pl != B3W_PLACEMENT_MIXED) c->placement = B3W_PLACEMENT_PLAIN;
+    if (pl == B3W_PLACEMENT_PLAIN) c->placement = B3W_PLACEMENT_PLAIN;                    // the weakest of the ring's buffers names the ring
+    else if (pl == B3W_PLACEMENT_INTERLEAVED && c->placement == B3W_PLACEMENT_MIXED) c->placement = B3W_PLACEMENT_INTERLEAVED;
   }
   *out = c;
   return B3W_OK;

@@ -313,13 +313,56 @@ __device__ __forceinline__ Fe wave_sum(Fe v, const uint32_t p[8]) {
   }
   return v;
 }
+// The row's three sums in ONE pass over its terms (A | B | C lie one behind the other in the term list): a lane takes every 64th
+// term, whichever part it falls into.  Element and coefficient are loaded side by side (dot() asks for the coefficient only once it
+// has seen the element: one more dependent load), and the next term's loads are in flight while this one is multiplied — a nova
+// step's always-deferred row (66 + 67 terms with field-sized coefficients) is three rounds of two load levels, not four of three.
 __device__ __forceinline__ bool gather_row_wave(const uint8_t *body, const uint4 d, const uint32_t *wires, const uint16_t *cids,
                                                 const uint32_t *coefR, const B3wField &F) {
   bool wild = false;
-  const uint32_t lane = threadIdx.x & 63u;
-  const Fe cz = wave_sum(dot(body, wires, cids, coefR, d.x + d.y + d.z, d.w, F, &wild, lane, 64), F.p);
-  const Fe az = wave_sum(dot(body, wires, cids, coefR, d.x, d.y, F, &wild, lane, 64), F.p);
-  const Fe bz = wave_sum(dot(body, wires, cids, coefR, d.x + d.y, d.z, F, &wild, lane, 64), F.p);
+  const uint32_t lane = threadIdx.x & 63u, n = d.y + d.z + d.w;
+  Fe az, bz, cz;
+#pragma unroll
+  for (int i = 0; i < 8; i++) az.l[i] = bz.l[i] = cz.l[i] = 0;
+  uint32_t cid = 0;
+  uint4 zlo = make_uint4(0, 0, 0, 0), zhi = zlo;
+  Fe cf;
+  auto issue = [&](uint32_t k) {                            // (k < n)
+    const uint32_t w = wires[d.x + k];
+    cid = cids[d.x + k];
+    const uint4 *q = reinterpret_cast<const uint4 *>(body + (size_t)w * 32);
+    zlo = q[0]; zhi = q[1];
+    cf = load_fe(coefR + (size_t)cid * 16 + 8);             // (coef * R; entries 0 and 1 — plus and minus one — are not used through it)
+  };
+  if (lane < n) issue(lane);
+  for (uint32_t k = lane; k < n; k += 64u) {
+    Fe z;
+    z.l[0] = zlo.x; z.l[1] = zlo.y; z.l[2] = zlo.z; z.l[3] = zlo.w;
+    z.l[4] = zhi.x; z.l[5] = zhi.y; z.l[6] = zhi.z; z.l[7] = zhi.w;
+    const uint32_t c = cid;
+    const Fe cfk = cf;
+    if (k + 64u < n) issue(k + 64u);
+    if (fe_geq(z, F.p)) {
+      wild = true;
+      do fe_sub_p(z, F.p); while (fe_geq(z, F.p));
+    }
+    if (fe_is_zero(z)) continue;
+    Fe t = z;
+    if (c >= 2u) t = mont_mul(cfk, z, F);                   // (coef * R) * z / R
+    if (c == 1u) {                                          // - z  =  + (p - z)   (z != 0)
+      Fe pm;
+#pragma unroll
+      for (int i = 0; i < 8; i++) pm.l[i] = F.p[i];
+      fe_sub(pm, t, F.p);
+      t = pm;
+    }
+    if (k < d.y) fe_add(az, t, F.p);
+    else if (k < d.y + d.z) fe_add(bz, t, F.p);
+    else fe_add(cz, t, F.p);
+  }
+  az = wave_sum(az, F.p);
+  bz = wave_sum(bz, F.p);
+  if (d.w) cz = wave_sum(cz, F.p);                          // (wave-uniform)
   return row_violated(az, bz, cz, d.y == 0 || d.z == 0, F) || __ballot(wild) != 0;
 }
 
@@ -1116,10 +1159,14 @@ __global__ __launch_bounds__(64) void b3w_r1cs_deferred_kernel(const uint8_t *__
   if (!any) return;
   deferred_report(nbad, low, b, violations, first);
 }
-// behind the walk kernel: one workgroup of four waves per BODY, told by one word which of the body's tiles have deferred rows at all
+// behind the walk kernel: one workgroup of TWO waves per BODY, told by one word which of the body's tiles have deferred rows at all
 // (bit t = tile t) — a batch of valid blake3_compression witnesses is 4 096 workgroups that load a zero and leave.  The waves share a
-// flagged tile's mask words: a deferred row is a chain of dependent loads, and a nova step's 66 inverse rows lie in five words.
-__global__ __launch_bounds__(256) void b3w_r1cs_walk_deferred_kernel(const uint8_t *__restrict__ bodies, uint64_t pitch, uint32_t n, B3wR1csSystem S,
+// flagged tile's mask words.  Everything here is a chain of three dependent loads and a field multiplication, 145 VGPRs allow twelve
+// waves on a CU, so what counts is that no resident wave idles: a nova step's 134 wide records are three rounds of wave 0, its
+// always-deferred row of 133 terms three rounds of wave 1 (four waves per body, three of them waiting for the fourth: 50 us per
+// 4 096 nova bodies; two: B3W_WALK_DEFERRED_US).
+#define B3W_WALK_DEFERRED_WAVES 2u
+__global__ __launch_bounds__(64 * B3W_WALK_DEFERRED_WAVES) void b3w_r1cs_walk_deferred_kernel(const uint8_t *__restrict__ bodies, uint64_t pitch, uint32_t n, B3wR1csSystem S,
                                                                     const unsigned long long *__restrict__ scratch, uint32_t block_words,
                                                                     const unsigned long long *__restrict__ body_flags,
                                                                     const unsigned long long *__restrict__ wide_recs,
@@ -1131,7 +1178,8 @@ __global__ __launch_bounds__(256) void b3w_r1cs_walk_deferred_kernel(const uint8
   // the system's ALWAYS-deferred rows (a coefficient that is no small integer: one row of 133 terms in each O2 nova system), for every
   // body, by the last wave, straight from the kernel's own list — no flag, no block, no mask word stands between the launch and the
   // row's terms
-  if ((threadIdx.x >> 6) == 3u)
+  const uint32_t wave = threadIdx.x >> 6;
+  if (wave == B3W_WALK_DEFERRED_WAVES - 1u)
     for (uint32_t sr = 0; sr < nstatic; sr++) {
       const uint4 d = reinterpret_cast<const uint4 *>(S.g_rows)[static_k[sr]];
       const bool bad = gather_row_wave(body, d, S.g_wires, S.g_cids, S.coefs, F);
@@ -1148,8 +1196,10 @@ __global__ __launch_bounds__(256) void b3w_r1cs_walk_deferred_kernel(const uint8
   // that is no canonical representative (>= p) violates the row, as everywhere.
   const uint32_t nwide = (uint32_t)(flags >> 56);
   flags &= (1ull << 56) - 1ull;
-  if (threadIdx.x < nwide) {
-    const unsigned long long *rec = wide_recs + ((size_t)b * B3W_WALK_WIDE_CAP + threadIdx.x) * 5u;
+  // (with always-deferred rows the last wave has had its share: the records are the other waves')
+  const uint32_t rec_waves = nstatic ? B3W_WALK_DEFERRED_WAVES - 1u : B3W_WALK_DEFERRED_WAVES;
+  for (uint32_t wr = threadIdx.x; wr < nwide && wave < rec_waves; wr += 64u * rec_waves) {
+    const unsigned long long *rec = wide_recs + ((size_t)b * B3W_WALK_WIDE_CAP + wr) * 5u;
     const long long ra = (long long)rec[0], rb = (long long)rec[1];
     const unsigned long long c_lo = rec[2];
     const long long c_hi = (long long)rec[3];
@@ -1186,7 +1236,7 @@ __global__ __launch_bounds__(256) void b3w_r1cs_walk_deferred_kernel(const uint8
   while (flags) {
     const uint32_t tile = (uint32_t)__ffsll((long long)flags) - 1u;
     flags &= flags - 1ull;
-    (void)deferred_tile(body, b, tile, S, scratch, block_words, F, true, nbad, low, threadIdx.x >> 6, 4u);
+    (void)deferred_tile(body, b, tile, S, scratch, block_words, F, true, nbad, low, wave, B3W_WALK_DEFERRED_WAVES);
   }
   deferred_report(nbad, low, b, violations, first);
 }
@@ -1905,7 +1955,7 @@ extern "C" int b3w_launch_r1cs_walk(const uint8_t *d_bodies, uint32_t n, uint64_
         }
       }
     }
-    hipLaunchKernelGGL(b3w_r1cs_walk_deferred_kernel, dim3(nb), dim3(256), 0, stream, bodies0, pitch, nb, *sysw, d_scratch, bw, flags, wide, walk->static_k, walk->static_id, walk->nstatic, *field,
+    hipLaunchKernelGGL(b3w_r1cs_walk_deferred_kernel, dim3(nb), dim3(64 * B3W_WALK_DEFERRED_WAVES), 0, stream, bodies0, pitch, nb, *sysw, d_scratch, bw, flags, wide, walk->static_k, walk->static_id, walk->nstatic, *field,
                        viol0, first0);
     e = hipGetLastError();
     if (e != hipSuccess) return (int)e;

@@ -388,14 +388,16 @@ napi_value BatchVerify(napi_env env, napi_callback_info info) {
   return out;
 }
 
-// batchPlacement(handle) -> "mixed" | "plain": where the body buffer of the last batchRun lives (b3w_bodies_alloc)
+static const char *placement_name(int32_t p) { return p == B3W_PLACEMENT_MIXED ? "mixed" : p == B3W_PLACEMENT_INTERLEAVED ? "interleaved" : "plain"; }
+
+// batchPlacement(handle) -> "mixed" | "interleaved" | "plain": where the body buffer of the last batchRun lives (b3w_bodies_alloc)
 napi_value BatchPlacement(napi_env env, napi_callback_info info) {
   size_t argc = 1; napi_value argv[1];
   NAPI_OK(napi_get_cb_info(env, info, &argc, argv, nullptr, nullptr));
   Handle *h = get_handle(env, argv[0]);
   if (!h) return nullptr;
   napi_value out;
-  NAPI_OK(napi_create_string_utf8(env, h->batch && api.batch_placement(h->batch) == B3W_PLACEMENT_MIXED ? "mixed" : "plain", NAPI_AUTO_LENGTH, &out));
+  NAPI_OK(napi_create_string_utf8(env, placement_name(h->batch ? api.batch_placement(h->batch) : B3W_PLACEMENT_PLAIN), NAPI_AUTO_LENGTH, &out));
   return out;
 }
 
@@ -484,7 +486,7 @@ napi_value ChainFold(napi_env env, napi_callback_info info) {
   napi_create_double(env, (double)first, &v); napi_set_named_property(env, o, "firstChunk", v);
   napi_create_uint32(env, count, &v); napi_set_named_property(env, o, "nChunksLocal", v);
   napi_create_uint32(env, plen, &v); napi_set_named_property(env, o, "pathLen", v);
-  napi_create_string_utf8(env, placement == B3W_PLACEMENT_MIXED ? "mixed" : "plain", NAPI_AUTO_LENGTH, &v); napi_set_named_property(env, o, "placement", v);
+  napi_create_string_utf8(env, placement_name(placement), NAPI_AUTO_LENGTH, &v); napi_set_named_property(env, o, "placement", v);
   napi_create_typedarray(env, napi_uint32_array, rows * 15, abp, 0, &v); napi_set_named_property(env, o, "publicOutputs", v);
   napi_create_typedarray(env, napi_int32_array, rows, abs_, 0, &v); napi_set_named_property(env, o, "status", v);
   napi_create_typedarray(env, napi_uint32_array, 8, abr, 0, &v); napi_set_named_property(env, o, "root", v);

@@ -131,12 +131,14 @@ void *b3w_batch_device_ptr(b3w_batch *batch, uint64_t *pitch);
  * virtual-memory API);
  * *placement reports what was achieved — and "mixed" is only reported when ONE REAL witness launch of this context's
  * circuit into the buffer is at least 10 % faster than into a plain hipMalloc buffer (measured once per context; a buffer
- * that fails the check stays usable and is reported as plain; B3W_PLACE_CHECK=0 skips the check).  Use the pointer like
+ * that fails the check stays usable and is reported as INTERLEAVED: its pieces do alternate, but on this box, today,
+ * plain buffers were as fast — no speed claim; B3W_PLACE_CHECK=0 skips the check).  Use the pointer like
  * any device pointer (kernels, hipMemcpy); release it
  * with b3w_bodies_free.  B3W_PLACEMENT=plain in the environment turns the search off.
  * b3w_batch_alloc places its body buffer this way. */
 #define B3W_PLACEMENT_PLAIN 0 /* one class (no search, search failed, or a buffer below 512 MiB) */
-#define B3W_PLACEMENT_MIXED 1 /* alternating classes */
+#define B3W_PLACEMENT_MIXED 1 /* alternating classes, and measured >= 10 % faster than plain buffers */
+#define B3W_PLACEMENT_INTERLEAVED 2 /* alternating classes, measured gain below 10 % (this box's plain buffers were fast themselves) */
 int32_t b3w_bodies_alloc(b3w_ctx *ctx, uint64_t bytes, void **d_ptr, int32_t *placement);
 int32_t b3w_bodies_free(b3w_ctx *ctx, void *d_ptr);
 /* The allocator keeps up to 3 x 12 GiB of classified-but-unused physical memory per device for the next buffer (and two

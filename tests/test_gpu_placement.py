@@ -29,7 +29,7 @@ def test_batch_on_placed_buffer_matches_oracle():
     ctx = m.Context("compression", 0)
     recs = m.workloads.config2_compression(n)
     b = m.Batch(ctx, n)
-    assert b.placement in ("mixed", "plain")
+    assert b.placement in ("mixed", "interleaved", "plain")
     b.run(recs)
     pub, st = b.outputs()
     assert (st == 0).all()
@@ -287,7 +287,7 @@ def test_two_processes_search_the_same_gpu_at_once():
     mp.spawn(_concurrent_searcher, args=(ret,), nprocs=2, join=True)
     for r in (0, 1):
         got = ret[r]
-        assert got["ok"] and got["placement"] in ("mixed", "plain"), got
+        assert got["ok"] and got["placement"] in ("mixed", "interleaved", "plain"), got
         c = got["cost"]
         assert c["search_limit_s"] == 20.0 and 0 <= c["search_s"] <= got["alloc_s"] + 0.5
         assert got["alloc_s"] < 20.0 + 40.0, got            # the limit, plus seam checks and the real-kernel check of a "mixed" claim

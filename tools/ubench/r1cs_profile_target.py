@@ -1,5 +1,6 @@
 """r1cs_profile_target.py <circuit> [n] — what tools/profile_r1cs.sh runs under rocprofv3: one batch of valid witnesses, then
-10 constraint checks of it (lean kernel pair)."""
+3 + 10 constraint checks of it (the first three are warm-up: the first launch of a process runs 15 % longer — cold instruction
+cache and program tables — and tools/profile_r1cs_collect.py averages the LAST ten launches of each kernel)."""
 import importlib, os, sys, numpy as np, torch
 sys.path.insert(0, os.getcwd())
 m = importlib.import_module("hot-proofs-blake3-circom_amd")
@@ -13,7 +14,7 @@ d_recs = torch.from_numpy(recs.view(np.int32)).cuda()
 bodies = torch.empty((n, ctx.body_bytes), dtype=torch.uint8, device="cuda")
 ctx.run_device(d_recs.data_ptr(), n, bodies.data_ptr(), 0, 0, 0, s)
 viol = torch.zeros(n, dtype=torch.int32, device="cuda")
-for _ in range(10):
+for _ in range(13):
     r.check_device(bodies.data_ptr(), n, 0, viol.data_ptr(), 0, s)
 torch.cuda.synchronize()
 assert int(viol.abs().sum().item()) == 0
