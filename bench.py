@@ -15,7 +15,9 @@ Prints ONE JSON line on rank 0 (see the driver contract) with `roofline` (HBM-wr
 bytes / HIP-event kernel time) and, at N = 1, `cpu_baseline` (the C oracle timed on all host cores on a bounded
 sample of the same workload, with the reference WASM's rate quoted beside it).
 """
-import argparse, importlib, json, math, os, sys, time
+import argparse
+import contextlib
+import importlib, json, math, os, sys, time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -200,6 +202,21 @@ def valu_ceiling():
     except Exception:
         pass
     return 10.0 / (8.0 / mul + 2.0 / sqr), src
+
+
+@contextlib.contextmanager
+def native_stdout_to_stderr():
+    """stdout is ONE JSON line: what a native library writes to fd 1 meanwhile (gloo's "[Gloo] Rank 0 is connected to ..." at
+    rendezvous) goes to stderr."""
+    sys.stdout.flush()
+    saved = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        yield
+    finally:
+        sys.stdout.flush()
+        os.dup2(saved, 1)
+        os.close(saved)
 
 
 def placement_cost(ctx, before=None):
@@ -489,10 +506,11 @@ def main():
         # (the process group's own limit is the backstop under a foreign launcher; 30 s later than the watchdog so that it is the
         # watchdog that reports which ranks were missing)
         pg_timeout = datetime.timedelta(seconds=args.launch_timeout + 30 if args.launch_timeout > 0 else 1800)
-        if backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=pg_timeout)
-        else:
-            dist.init_process_group(backend, rank=rank, world_size=world, timeout=pg_timeout)
+        with native_stdout_to_stderr():
+            if backend == "nccl":
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev, timeout=pg_timeout)
+            else:
+                dist.init_process_group(backend, rank=rank, world_size=world, timeout=pg_timeout)
         # one rank per GPU: every rank's card must be a different one (uuid where torch reports it, else the PCI address)
         pr = torch.cuda.get_device_properties(dev)
         ident = f"{getattr(pr, 'uuid', '')}@pci{getattr(pr, 'pci_domain_id', 0):04x}:{getattr(pr, 'pci_bus_id', 0):02x}:{getattr(pr, 'pci_device_id', 0):02x}"

@@ -123,8 +123,9 @@ struct B3wWalk {
   const uint32_t *run_row, *ent_w, *ent_m, *row_id;
   const unsigned long long *stat;        // static_words per tile
   const long long *coef_small;
-  const uint32_t *static_k, *static_id;  // the always-deferred rows as a list: gather row, constraint number
+  const uint32_t *static_k, *static_id;  // the always-deferred rows as a list: gather descriptor (4 words), constraint number
   uint32_t nstatic, pad2;
+  uint32_t static_d0[4];                 // the first one's descriptor (a kernel argument of the deferred kernel)
 };
 // The WALK kernel (default where the system fits): a workgroup walks whole bodies tile after tile, earlier tiles' wires come from an
 // export area in LDS — no outside wire is gathered from HBM.  `sysw` = the system with the WALK row order in tiles / row_k / row_id

@@ -1164,28 +1164,42 @@ __global__ __launch_bounds__(64) void b3w_r1cs_deferred_kernel(const uint8_t *__
 // flagged tile's mask words.  Everything here is a chain of three dependent loads and a field multiplication, 145 VGPRs allow twelve
 // waves on a CU, so what counts is that no resident wave idles: a nova step's 134 wide records are three rounds of wave 0, its
 // always-deferred row of 133 terms three rounds of wave 1 (four waves per body, three of them waiting for the fourth: 50 us per
-// 4 096 nova bodies; two: B3W_WALK_DEFERRED_US).
+// 4 096 nova bodies; two: 37 us).  What is left is arithmetic, not waiting: 1.5e7 wave instructions per launch, a third of them
+// quarter-rate multiplications (133 Montgomery products per body), keep the chip's 1 024 SIMDs busy for most of those 37 us — issuing
+// the loads of a level side by side (below, and in gather_row_wave) and a build squeezed to 128 VGPRs (4 waves per SIMD, 104 bytes
+// of scratch) each moved it by 1 us.
 #define B3W_WALK_DEFERRED_WAVES 2u
 __global__ __launch_bounds__(64 * B3W_WALK_DEFERRED_WAVES) void b3w_r1cs_walk_deferred_kernel(const uint8_t *__restrict__ bodies, uint64_t pitch, uint32_t n, B3wR1csSystem S,
                                                                     const unsigned long long *__restrict__ scratch, uint32_t block_words,
                                                                     const unsigned long long *__restrict__ body_flags,
                                                                     const unsigned long long *__restrict__ wide_recs,
-                                                                    const uint32_t *__restrict__ static_k, const uint32_t *__restrict__ static_id, uint32_t nstatic,
-                                                                    B3wField F, uint32_t *__restrict__ violations, uint32_t *__restrict__ first) {
-  const uint32_t b = blockIdx.x;
+                                                                    const uint32_t *__restrict__ static_d /* 4 words per row: its gather descriptor */, uint4 static_d0,
+                                                                    const uint32_t *__restrict__ static_id, uint32_t nstatic, B3wField F, uint32_t *__restrict__ violations, uint32_t *__restrict__ first) {
+  const uint32_t b = blockIdx.x, wave = threadIdx.x >> 6;
   const uint8_t *body = bodies + (uint64_t)b * pitch;
   uint32_t nbad = 0, low = 0xFFFFFFFFu;
+  // Everything below is latency: what can be asked for at once, is.  The body's word and — on speculation, the place is valid memory
+  // whatever it holds — this lane's first wide record go out side by side; the element a record points to is loaded only once the
+  // word has said that the record exists.
+  // (with always-deferred rows the last wave has its share in them: the records are the other waves')
+  const uint32_t rec_waves = nstatic ? B3W_WALK_DEFERRED_WAVES - 1u : B3W_WALK_DEFERRED_WAVES;
+  const bool rec_lane = wave < rec_waves && threadIdx.x < B3W_WALK_WIDE_CAP;
+  unsigned long long flags = body_flags[b];
+  unsigned long long rec[5] = {0ull, 0ull, 0ull, 0ull, 0ull};
+  if (rec_lane) {
+    const unsigned long long *at = wide_recs + ((size_t)b * B3W_WALK_WIDE_CAP + threadIdx.x) * 5u;
+#pragma unroll
+    for (int q = 0; q < 5; q++) rec[q] = at[q];
+  }
   // the system's ALWAYS-deferred rows (a coefficient that is no small integer: one row of 133 terms in each O2 nova system), for every
   // body, by the last wave, straight from the kernel's own list — no flag, no block, no mask word stands between the launch and the
-  // row's terms
-  const uint32_t wave = threadIdx.x >> 6;
+  // row's terms; the first one's descriptor is a kernel argument
   if (wave == B3W_WALK_DEFERRED_WAVES - 1u)
     for (uint32_t sr = 0; sr < nstatic; sr++) {
-      const uint4 d = reinterpret_cast<const uint4 *>(S.g_rows)[static_k[sr]];
+      const uint4 d = sr ? reinterpret_cast<const uint4 *>(static_d)[sr] : static_d0;
       const bool bad = gather_row_wave(body, d, S.g_wires, S.g_cids, S.coefs, F);
       if ((threadIdx.x & 63u) == 0 && bad) { nbad++; low = min(low, static_id[sr]); }
     }
-  unsigned long long flags = body_flags[b];
   if (flags == 0ull) {                                       // (wave-uniform)
     if (nstatic) deferred_report(nbad, low, b, violations, first);
     return;
@@ -1196,10 +1210,12 @@ __global__ __launch_bounds__(64 * B3W_WALK_DEFERRED_WAVES) void b3w_r1cs_walk_de
   // that is no canonical representative (>= p) violates the row, as everywhere.
   const uint32_t nwide = (uint32_t)(flags >> 56);
   flags &= (1ull << 56) - 1ull;
-  // (with always-deferred rows the last wave has had its share: the records are the other waves')
-  const uint32_t rec_waves = nstatic ? B3W_WALK_DEFERRED_WAVES - 1u : B3W_WALK_DEFERRED_WAVES;
   for (uint32_t wr = threadIdx.x; wr < nwide && wave < rec_waves; wr += 64u * rec_waves) {
-    const unsigned long long *rec = wide_recs + ((size_t)b * B3W_WALK_WIDE_CAP + wr) * 5u;
+    if (wr != threadIdx.x) {
+      const unsigned long long *at = wide_recs + ((size_t)b * B3W_WALK_WIDE_CAP + wr) * 5u;
+#pragma unroll
+      for (int q = 0; q < 5; q++) rec[q] = at[q];
+    }
     const long long ra = (long long)rec[0], rb = (long long)rec[1];
     const unsigned long long c_lo = rec[2];
     const long long c_hi = (long long)rec[3];
@@ -1955,7 +1971,10 @@ extern "C" int b3w_launch_r1cs_walk(const uint8_t *d_bodies, uint32_t n, uint64_
         }
       }
     }
-    hipLaunchKernelGGL(b3w_r1cs_walk_deferred_kernel, dim3(nb), dim3(64 * B3W_WALK_DEFERRED_WAVES), 0, stream, bodies0, pitch, nb, *sysw, d_scratch, bw, flags, wide, walk->static_k, walk->static_id, walk->nstatic, *field,
+    // (on a second stream beside the next slab's walk kernel — two halves of the scratch in turn — the deferred kernel made a check of
+    // 65 536 nova bodies SLOWER, 8.4 -> 9.2 ms: HISTORY.md, round 4)
+    hipLaunchKernelGGL(b3w_r1cs_walk_deferred_kernel, dim3(nb), dim3(64 * B3W_WALK_DEFERRED_WAVES), 0, stream, bodies0, pitch, nb, *sysw, d_scratch, bw, flags, wide, walk->static_k,
+                       make_uint4(walk->static_d0[0], walk->static_d0[1], walk->static_d0[2], walk->static_d0[3]), walk->static_id, walk->nstatic, *field,
                        viol0, first0);
     e = hipGetLastError();
     if (e != hipSuccess) return (int)e;

@@ -440,6 +440,55 @@ def test_slabs_and_streams(env):
     assert np.array_equal(vb.cpu().numpy().view(np.uint32), viol[8000:8400])
 
 
+def test_three_slabs_of_nova_steps():
+    """A check of more than 8 192 bodies goes slab by slab through one scratch (blocks, body words, wide records).  3 x 8 192 + 100
+    nova steps — every one with 67 wide records and the always-deferred row — with tampered inverses, tampered bits and random
+    elements on both sides of every slab border: verdicts and first rows equal those of the same bodies checked alone, twice in a row."""
+    import torch
+    m = T.pkg()
+    dev = torch.device("cuda:0")
+    ctx = m.Context("nova_vesta", 0)
+    r1cs = m.R1cs(ctx)
+    n = 3 * 8192 + 100
+    recs = m.workloads.config3_nova(n, first=5)
+    d_recs = torch.from_numpy(recs.view(np.int32)).to(dev)
+    bodies = torch.empty((n, ctx.body_bytes), dtype=torch.uint8, device=dev)
+    s = torch.cuda.current_stream().cuda_stream
+    ctx.run_device(d_recs.data_ptr(), n, bodies.data_ptr(), 0, 0, 0, s)
+    torch.cuda.synchronize()
+    z0 = R.body_to_ints(bodies[0].cpu().numpy())
+    wide = [w for w, v in enumerate(z0) if v >= 1 << 64]
+    rng = random.Random(21)
+    hit = sorted(set([0, 8191, 8192, 16383, 16384, 24575, 24576, n - 1] + rng.sample(range(n), 150)))
+    elems = bodies.view(n, ctx.witness_size, 32)
+    for k, i in enumerate(hit):
+        if k % 3 == 0:                                       # an inverse of its own step, off by one: a wide record says no
+            w = rng.choice(wide)
+            old = int.from_bytes(bytes(elems[i, w].cpu().numpy()), "little")
+            val = old + 1 if old else 5
+        elif k % 3 == 1:                                     # a 2 where a bit belongs (or a general row's operand)
+            w, val = rng.randrange(1, ctx.witness_size), 2
+        else:                                                # a random 250-bit element
+            w, val = rng.randrange(1, ctx.witness_size), rng.randrange(1 << 250)
+        elems[i, w] = torch.from_numpy(np.frombuffer(val.to_bytes(32, "little"), dtype=np.uint8).copy()).to(dev)
+
+    def check(b):
+        k = b.shape[0]
+        viol = torch.full((k,), 77, dtype=torch.int32, device=dev)
+        first = torch.zeros((k,), dtype=torch.int32, device=dev)
+        r1cs.check_device(b.data_ptr(), k, b.stride(0), viol.data_ptr(), first.data_ptr(), s)
+        torch.cuda.synchronize()
+        return viol.cpu().numpy().view(np.uint32), first.cpu().numpy().view(np.uint32)
+    alone_v, alone_f = check(bodies[hit].contiguous())
+    assert np.count_nonzero(alone_v) >= len(hit) - 3, np.count_nonzero(alone_v)       # (a random slot may be one no constraint reads)
+    for _ in range(2):
+        viol, first = check(bodies)
+        bad = set(np.nonzero(viol)[0].tolist())
+        assert bad <= set(hit), sorted(bad - set(hit))[:10]
+        assert np.array_equal(viol[hit], alone_v) and np.array_equal(first[hit], alone_f)
+    r1cs.close(); ctx.close()
+
+
 @pytest.mark.parametrize("shape", ["local", "scattered"])
 def test_random_systems_against_plain_integers(shape, tmp_path):
     """b3w_r1cs_create takes ANY iden3 .r1cs over the context's field.  Synthetic systems over the 24 093 wires — random

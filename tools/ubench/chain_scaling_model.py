@@ -3,7 +3,7 @@ one GPU can measure: rank 0's share of the pass at every rank count through the 
 + b3w_chain_allgather_hout over a b3w_comm whose all-gather is a stand-in: it copies this rank's block into every rank's place
 on the device, so packing, scatter and the bytes are real and the wire is not), plus RCCL's own ncclAllGather of the two messages
 measured on a one-rank communicator (a lower bound of its latency: no peer is waited for).  Not a measurement of scaling."""
-import importlib, json, os, sys, time
+import ctypes, importlib, json, os, sys, time
 sys.path.insert(0, os.getcwd())
 import numpy as np, torch
 m = importlib.import_module("hot-proofs-blake3-circom_amd")
@@ -16,18 +16,18 @@ n_chunks = m.lib().b3w_chain_num_chunks(nbytes)
 total_steps = m.lib().b3w_chain_num_leaf_steps(nbytes) + m.lib().b3w_chain_parent_row(n_chunks, n_chunks)
 
 
-class _Dev:
-    def __init__(self, ptr, n):
-        self.__cuda_array_interface__ = {"shape": (n,), "typestr": "|u1", "data": (ptr, False), "version": 2, "strides": None}
+_hip = ctypes.CDLL("libamdhip64.so")
+_hip.hipMemcpyAsync.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]
+_hip.hipMemcpyAsync.restype = ctypes.c_int
 
 
 def standin(world):
+    """this rank's block into every rank's place, device to device on the exchange's stream: the bytes and the stream order of an
+    all-gather, no wire and no peer (a few microseconds of host time per copy: no torch op stands in the callback)"""
     def fn(d_send, d_recv, nbytes_per_rank, stream):
-        st = torch.cuda.ExternalStream(stream, device=dev) if stream else torch.cuda.default_stream(dev)
-        with torch.cuda.stream(st):
-            send = torch.as_tensor(_Dev(d_send, nbytes_per_rank), device=dev)
-            recv = torch.as_tensor(_Dev(d_recv, nbytes_per_rank * world), device=dev)
-            recv.view(world, nbytes_per_rank).copy_(send.unsqueeze(0).expand(world, nbytes_per_rank))
+        for r in range(world):
+            if _hip.hipMemcpyAsync(d_recv + r * nbytes_per_rank, d_send, nbytes_per_rank, 3, stream) != 0:
+                raise RuntimeError("hipMemcpyAsync")
     return fn
 
 
@@ -35,18 +35,24 @@ rows = []
 for world in (1, 2, 4, 8):
     comm = m.Comm.external(ctx, 0, world, standin(world)) if world > 1 else None
     run = lambda: m.chain.fold_witnesses(ctx, host, batch_steps=16384, ring=2, comm=comm)
-    for _ in range(3):
-        out = run()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    reps = 20
-    for _ in range(reps):
-        out = run()
-    torch.cuda.synchronize()
-    pass_ms = (time.perf_counter() - t0) / reps * 1e3
+    def timed(fn, reps=20):
+        for _ in range(3):
+            o = fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(reps):
+            o = fn()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / reps * 1e3, o
+    pass_ms, out = timed(run)
     ex = m.chain.exchange_ms(out)
     steps = out["n_leaf_steps"] + out["n_parent_steps"]
-    rows.append(dict(ranks=world, rank0_steps=steps, rank0_pass_ms=round(pass_ms, 3), standin_exchange_ms=[round(ex[0], 3), round(ex[1], 3)]))
+    # beside it: an ordinary one-rank pass over a preimage of the shard's size (what the sharded path costs beyond its share of the steps)
+    small = host[: nbytes // world]
+    small_ms, small_out = timed(lambda: m.chain.fold_witnesses(ctx, small, batch_steps=16384, ring=2))
+    rows.append(dict(ranks=world, rank0_steps=steps, rank0_pass_ms=round(pass_ms, 3), standin_exchange_ms=[round(ex[0], 3), round(ex[1], 3)],
+                     one_rank_pass_of_a_preimage_of_the_shards_size_ms=round(small_ms, 3),
+                     its_steps=small_out["n_leaf_steps"] + small_out["n_parent_steps"]))
     if comm is not None:
         comm.close()
     ctx.trim()
