@@ -2276,10 +2276,10 @@ int32_t b3w_chain_run_leaves(b3w_chain *c, const uint8_t *host_preimage, b3w_bat
   return B3W_OK;
 }
 
-int32_t b3w_chain_run_parents(b3w_chain *c, const uint32_t *d_all_chunk_cvs, b3w_batch_consumer consumer, void *user, void *stream) {
-  if (!c) return B3W_E_BAD_ARGUMENT;
+namespace {
+// cvs_on_side: d_all_chunk_cvs was written by work already queued on the chain's side stream (the sharded pass's own exchange)
+int32_t chain_run_parents(b3w_chain *c, const uint32_t *d_all_chunk_cvs, bool cvs_on_side, b3w_batch_consumer consumer, void *user, void *stream) {
   b3w_ctx *ctx = c->ctx;
-  ON_DEVICE(ctx);
   hipStream_t st = (hipStream_t)stream;
   // The tree and the parent-step records only need the chunk CVs, not the leaf witnesses: they run on a side stream
   // beside the leaf witness kernels still queued on `stream` (250 us of small dependent launches for a 1 MiB preimage).
@@ -2287,7 +2287,7 @@ int32_t b3w_chain_run_parents(b3w_chain *c, const uint32_t *d_all_chunk_cvs, b3w
     if (c->nl != c->n_chunks) { ctx->last_error = "a chunk sub-range needs the chunk CVs of all ranks"; return B3W_E_BAD_ARGUMENT; }
     d_all_chunk_cvs = c->d_cvs;
     HIP_TRY(ctx, hipStreamWaitEvent(c->side, c->ev_cvs, 0));
-  } else {                                             // gathered by the caller on `stream`: order after that
+  } else if (!cvs_on_side) {                           // gathered by the caller on `stream`: order after that
     HIP_TRY(ctx, hipEventRecord(c->ev_cvs, st));
     HIP_TRY(ctx, hipStreamWaitEvent(c->side, c->ev_cvs, 0));
   }
@@ -2304,6 +2304,13 @@ int32_t b3w_chain_run_parents(b3w_chain *c, const uint32_t *d_all_chunk_cvs, b3w
   if (rc) return rc;
   if (!c->n_par) return B3W_OK;
   return chain_run_steps(c, c->n_leaf, c->n_par, consumer, user, stream);
+}
+}  // namespace
+
+int32_t b3w_chain_run_parents(b3w_chain *c, const uint32_t *d_all_chunk_cvs, b3w_batch_consumer consumer, void *user, void *stream) {
+  if (!c) return B3W_E_BAD_ARGUMENT;
+  ON_DEVICE(c->ctx);
+  return chain_run_parents(c, d_all_chunk_cvs, false, consumer, user, stream);
 }
 
 void b3w_chain_shard(uint64_t n_chunks, int32_t rank, int32_t nranks, uint64_t *first_chunk, uint32_t *n_chunks_local) {
@@ -2366,21 +2373,34 @@ int32_t b3w_chain_run_parents_sharded(b3w_chain *c, b3w_comm *comm, b3w_batch_co
   if (rc) return rc;
   ON_DEVICE(ctx);
   if ((rc = chain_exchange(c, comm->nranks)) != B3W_OK) return rc;
-  hipStream_t st = (hipStream_t)stream;
+  // The chunk CVs exist as soon as the last leaf PLAN has run (ev_cvs, b3w_chain_run_leaves) — long before the leaf witness kernels
+  // queued behind it on `stream` have finished.  Their exchange therefore runs on the chain's side stream, beside those kernels, and
+  // the tree and the parent plan follow it there: `stream` only joins for the parent witnesses.  (On `stream` itself the exchange and
+  // 250 us of small dependent launches stood behind the last leaf witness: a rank's share of a 1 MiB pass took 1.1 ms at 8 ranks
+  // against 0.47 ms for an ordinary pass over a preimage of the shard's size, profiles/r04/chain_scaling_model_1mib.json.)
+  hipStream_t side = c->side;
   b3w_chain::Exchange &x = c->x;
-  hipError_t e = hipEventRecord(x.ev[0], st);
-  if (e == hipSuccess && c->nl) e = hipMemcpyAsync(x.d_cv_pad, c->d_cvs, (uint64_t)c->nl * 32, hipMemcpyDeviceToDevice, st);
-  rc = e == hipSuccess ? b3w_comm_allgather(comm, x.d_cv_pad, x.d_cv_gath, x.mx_chunks * 32, stream) : hip_fail(ctx, e, "chunk CV staging");
-  for (int32_t r = 0; r < comm->nranks && rc == B3W_OK; r++) {                 // drop the padding: global chunk order
+  // equal shards (config 4: 1 024 chunks over 8 ranks): no padding, so the collective takes the chunk CVs where they lie and leaves
+  // them in global chunk order — no staging copy, no compaction (each a hipMemcpyAsync of its own: 17 of them cost 0.2 ms at 8 ranks)
+  const bool even = c->n_chunks % (uint64_t)comm->nranks == 0;
+  const uint32_t *d_all = even ? x.d_cv_gath : x.d_cv_all;
+  hipError_t e = hipStreamWaitEvent(side, c->ev_cvs, 0);
+  if (e == hipSuccess) e = hipEventRecord(x.ev[0], side);
+  if (e == hipSuccess && c->nl && !even) e = hipMemcpyAsync(x.d_cv_pad, c->d_cvs, (uint64_t)c->nl * 32, hipMemcpyDeviceToDevice, side);
+  rc = e == hipSuccess ? b3w_comm_allgather(comm, even ? c->d_cvs : x.d_cv_pad, x.d_cv_gath, x.mx_chunks * 32, side) : hip_fail(ctx, e, "chunk CV staging");
+  for (int32_t r = 0; r < comm->nranks && rc == B3W_OK && !even; r++) {        // drop the padding: global chunk order
     uint64_t f = 0; uint32_t k = 0;
     b3w_chain_shard(c->n_chunks, r, comm->nranks, &f, &k);
-    if (k && (e = hipMemcpyAsync(x.d_cv_all + f * 8, x.d_cv_gath + (uint64_t)r * x.mx_chunks * 8, (uint64_t)k * 32, hipMemcpyDeviceToDevice, st)) != hipSuccess)
+    if (k && (e = hipMemcpyAsync(x.d_cv_all + f * 8, x.d_cv_gath + (uint64_t)r * x.mx_chunks * 8, (uint64_t)k * 32, hipMemcpyDeviceToDevice, side)) != hipSuccess)
       rc = hip_fail(ctx, e, "chunk CV compaction");
   }
-  if (rc == B3W_OK && (e = hipEventRecord(x.ev[1], st)) != hipSuccess) rc = hip_fail(ctx, e, "hipEventRecord");
-  if (rc) return rc;
+  if (rc == B3W_OK && (e = hipEventRecord(x.ev[1], side)) != hipSuccess) rc = hip_fail(ctx, e, "hipEventRecord");
+  if (rc) {                                                  // `stream` must not run ahead of what the side stream still holds
+    if (hipEventRecord(c->ev_par, side) == hipSuccess) (void)hipStreamWaitEvent((hipStream_t)stream, c->ev_par, 0);
+    return rc;
+  }
   x.timed[0] = true;
-  return b3w_chain_run_parents(c, x.d_cv_all, consumer, user, stream);
+  return chain_run_parents(c, d_all, true, consumer, user, stream);
 }
 
 int32_t b3w_chain_allgather_hout(b3w_chain *c, b3w_comm *comm, uint32_t *d_leaf_hout, uint32_t *d_parent_hout, void *stream) {

@@ -36,6 +36,7 @@ for world in (1, 2, 4, 8):
     comm = m.Comm.external(ctx, 0, world, standin(world)) if world > 1 else None
     run = lambda: m.chain.fold_witnesses(ctx, host, batch_steps=16384, ring=2, comm=comm)
     def timed(fn, reps=20):
+        """-> (ms per pass with `reps` passes queued back to back, median ms of one pass waited for, the last pass's result)"""
         for _ in range(3):
             o = fn()
         torch.cuda.synchronize()
@@ -43,15 +44,23 @@ for world in (1, 2, 4, 8):
         for _ in range(reps):
             o = fn()
         torch.cuda.synchronize()
-        return (time.perf_counter() - t0) / reps * 1e3, o
-    pass_ms, out = timed(run)
+        queued = (time.perf_counter() - t0) / reps * 1e3
+        one = []
+        for _ in range(reps):
+            t0 = time.perf_counter()
+            o = fn()
+            torch.cuda.synchronize()
+            one.append((time.perf_counter() - t0) * 1e3)
+        return queued, sorted(one)[len(one) // 2], o
+    pass_ms, pass_one_ms, out = timed(run)
     ex = m.chain.exchange_ms(out)
     steps = out["n_leaf_steps"] + out["n_parent_steps"]
     # beside it: an ordinary one-rank pass over a preimage of the shard's size (what the sharded path costs beyond its share of the steps)
     small = host[: nbytes // world]
-    small_ms, small_out = timed(lambda: m.chain.fold_witnesses(ctx, small, batch_steps=16384, ring=2))
-    rows.append(dict(ranks=world, rank0_steps=steps, rank0_pass_ms=round(pass_ms, 3), standin_exchange_ms=[round(ex[0], 3), round(ex[1], 3)],
-                     one_rank_pass_of_a_preimage_of_the_shards_size_ms=round(small_ms, 3),
+    small_ms, small_one_ms, small_out = timed(lambda: m.chain.fold_witnesses(ctx, small, batch_steps=16384, ring=2))
+    rows.append(dict(ranks=world, rank0_steps=steps, rank0_pass_ms=round(pass_ms, 3), rank0_single_pass_median_ms=round(pass_one_ms, 3),
+                     standin_exchange_ms=[round(ex[0], 3), round(ex[1], 3)],
+                     one_rank_pass_of_a_preimage_of_the_shards_size_ms=round(small_ms, 3), its_single_pass_median_ms=round(small_one_ms, 3),
                      its_steps=small_out["n_leaf_steps"] + small_out["n_parent_steps"]))
     if comm is not None:
         comm.close()
@@ -76,7 +85,7 @@ except Exception as e:                                       # (no librccl on th
 lat = sum(v["one_rank_ncclAllGather_us"] for v in rccl.values()) * 1e-3 if "error" not in rccl else 0.0
 for r in rows:
     for label, extra in (("with_one_rank_rccl_latency", lat), ("with_50us_per_collective", 0.1)):
-        t = r["rank0_pass_ms"] + (extra if r["ranks"] > 1 else 0.0)
+        t = r["rank0_single_pass_median_ms"] + (extra if r["ranks"] > 1 else 0.0)   # (a config-4 fold IS one pass: its latency counts)
         r["predicted_M_steps_per_s_" + label] = round(total_steps / t / 1e3, 3)
 print(json.dumps({"what": "PREDICTED, not measured: rank 0's share through the native sharded path with a stand-in all-gather on one GPU",
                   "preimage_mib": mib, "total_steps": int(total_steps), "rccl_one_rank": rccl, "rows": rows}, indent=1))
