@@ -473,9 +473,12 @@ int32_t b3w_chain_run_parents(b3w_chain *chain, const uint32_t *d_all_chunk_cvs 
 /* Contiguous, balanced chunk ranges (the first n_chunks % nranks ranks take one extra chunk): what rank `rank` passes
  * to b3w_chain_create as first_chunk / n_chunks_local. */
 void b3w_chain_shard(uint64_t n_chunks, int32_t rank, int32_t nranks, uint64_t *first_chunk, uint32_t *n_chunks_local);
-/* b3w_chain_run_parents for a sharded pass: all-gathers the chunk chaining values over `comm` (RCCL, 32 B per chunk,
- * shards padded to the largest) and continues with the tree and this rank's parent steps.  The chain must have been
- * created with this rank's b3w_chain_shard range. */
+/* b3w_chain_run_parents for a sharded pass: all-gathers the chunk chaining values over `comm` (32 B per chunk; shards
+ * padded to the largest — equal shards are gathered where they lie, without a copy) and continues with the tree and this
+ * rank's parent steps.  The chain must have been created with this rank's b3w_chain_shard range, and b3w_chain_run_leaves
+ * of the same pass must have been called.  The exchange, the tree and the parent plan run on a stream of the CHAIN's —
+ * beside the leaf witness kernels still queued on `stream`, which only joins for the parent witnesses — so an external
+ * transport's callback (b3w_comm_create_external) is handed that stream, not the caller's. */
 int32_t b3w_chain_run_parents_sharded(b3w_chain *chain, b3w_comm *comm, b3w_batch_consumer consumer, void *user, void *stream);
 /* The fold's exchange in chained mode (BASELINE config 4: "RCCL gather of h_out"): the folding driver consumes z_{i+1} = the
  * public outputs of step i (Blake3CompressPubIO::to_vec, rust_fold/src/blake3_circuit.rs:111-123, fed back at
@@ -490,7 +493,7 @@ int32_t b3w_chain_run_parents_sharded(b3w_chain *chain, b3w_comm *comm, b3w_batc
 int32_t b3w_chain_allgather_hout(b3w_chain *chain, b3w_comm *comm, uint32_t *d_leaf_hout, uint32_t *d_parent_hout, void *stream);
 /* The same into host arrays (for bindings that hold no device memory: Node).  Waits for `stream`. */
 int32_t b3w_chain_allgather_hout_host(b3w_chain *chain, b3w_comm *comm, uint32_t *host_leaf_hout, uint32_t *host_parent_hout, void *stream);
-/* How long the two exchanges of the last sharded pass took on this rank's device, in milliseconds (HIP events on `stream`):
+/* How long the two exchanges of the last sharded pass took on this rank's device, in milliseconds (HIP events on the stream each ran on):
  * out_ms[0] = chunk chaining values (staging + all-gather + compaction, b3w_chain_run_parents_sharded), out_ms[1] = h_out (pack +
  * all-gather + scatter, b3w_chain_allgather_hout); 0 for an exchange that has not run.  Waits for those events. */
 int32_t b3w_chain_exchange_ms(b3w_chain *chain, float out_ms[2]);

@@ -1,0 +1,7 @@
+#!/bin/bash
+# r04 job 23 (GPU box): the whole -m gpu suite with per-test durations
+set -o pipefail
+export TMPDIR=/tmp
+out=gpurun_out/r04_job23
+mkdir -p $out
+timeout -k 10 1100 python3 -m pytest tests -m gpu -x -q --durations=25 > $out/gpu_suite.log 2>&1; rc=$?; echo "suite rc=$rc"; tail -45 $out/gpu_suite.log
