@@ -1254,7 +1254,7 @@ static int32_t r1cs_create_impl(b3w_ctx *ctx, const uint8_t *img, size_t len, b3
     up((void **)&r->d_wtiles4, H.wtiles4.data(), H.wtiles4.size() * 4);
     up((void **)&r->d_wstatic, H.wstatic.data(), H.wstatic.size() * 8);
     std::vector<uint32_t> sk, sid;                           // the always-deferred rows as a list (the deferred kernel walks it for every body)
-    for (uint32_t t = 0; t < H.ntiles; t++)
+    for (uint32_t t = 0; t < H.wunits; t++)
       for (uint32_t pos = 0; pos < H.wtiles4[4 * (size_t)t + 1]; pos++)
         if ((H.wstatic[(size_t)t * H.wstatic_words + (pos >> 6)] >> (pos & 63u)) & 1ull) {
           const size_t k = H.wrow_k[H.wtiles4[4 * (size_t)t] + pos];            // its gather descriptor {first term, terms in A, B, C}, copied: one load less per body
@@ -1263,11 +1263,12 @@ static int32_t r1cs_create_impl(b3w_ctx *ctx, const uint8_t *img, size_t len, b3
         }
     up((void **)&r->d_wstatic_k, sk.data(), sk.size() * 4);
     up((void **)&r->d_wstatic_id, sid.data(), sid.size() * 4);
-    r->walk = B3wWalk{H.ntiles, H.wexp_slots, H.wmax_gen, H.wmax_ent, r->ncoef, H.wstatic_words, H.wmax_rows, 0u, r->d_wtile, r->d_wmask, r->d_wexp,
+    r->walk = B3wWalk{H.wunits, H.wexp_slots, H.wmax_gen, H.wmax_ent, r->ncoef, H.wstatic_words, H.wmax_rows, 0u, r->d_wtile, r->d_wmask, r->d_wexp,
                       reinterpret_cast<const uint4 *>(r->d_wruns), r->d_wrun_row, r->d_went_w, r->d_went_m, r->d_wrow_id, r->d_wstatic, r->d_coef_small,
                       r->d_wstatic_k, r->d_wstatic_id, (uint32_t)sid.size(), 0u, {sk.empty() ? 0u : sk[0], sk.empty() ? 0u : sk[1], sk.empty() ? 0u : sk[2], sk.empty() ? 0u : sk[3]}};
     r->sysw = r->sys;
     r->sysw.tiles = r->d_wtiles4; r->sysw.row_k = r->d_wrow_k; r->sysw.row_id = r->d_wrow_id; r->sysw.max_tile_rows = H.wmax_rows;
+    r->sysw.ntiles = H.wunits;                               // (the deferred kernel's blocks are per unit)
     r->has_walk = true;
   }
   if (e != hipSuccess) { b3w_r1cs_destroy(r); return e == hipErrorOutOfMemory ? B3W_E_NOT_ENOUGH_MEMORY : hip_fail(ctx, e, "r1cs upload"); }

@@ -1365,7 +1365,7 @@ __global__ __launch_bounds__(512, 4) void b3w_r1cs_walk_kernel(const uint8_t *__
 #pragma unroll
     for (int h = 0; h < 2; h++) foff[q][h] = ((wave + (uint32_t)q * WAVES) * 64u + (uint32_t)h * 32u + (lane & 31u)) * 32u + (lane >> 5) * 16u;
   auto fetch = [&](const Cursor c) {                        // (a cursor behind the last unit points at the last unit again: fetched, packed, never looked at)
-    const uint8_t *body = bodies + (uint64_t)c.body * pitch + (uint64_t)c.tile * (T * 32u);
+    const uint8_t *body = bodies + (uint64_t)c.body * pitch + (uint64_t)TW(c, B3W_WT_SRC) * (T * 32u);      // (a unit = a tile, or one of several over the same tile)
     const uint32_t lim = (TW(c, B3W_WT_NLOCAL) - 1u) * 32u + (lane >> 5) * 16u;      // (an element behind the tile's end: its last element again)
 #pragma unroll
     for (int q = 0; q < 2; q++) {
@@ -1531,7 +1531,7 @@ __global__ __launch_bounds__(512, 4) void b3w_r1cs_walk_kernel(const uint8_t *__
           if (slot < B3W_WALK_WIDE_CAP) {                      // (kept in registers: the stores go out behind the pack — see the pipeline)
             wrec_at = ((size_t)c.body * B3W_WALK_WIDE_CAP + slot) * 5u + 1u;
             wrec[0] = a_lo; wrec[1] = b_lo; wrec[2] = c_lo; wrec[3] = (unsigned long long)c_hi;
-            wrec[4] = (unsigned long long)(gw & 0xFFFFFFu) | (unsigned long long)c.tile << 32 | (unsigned long long)(TW(c, B3W_WT_ROW0) + tid) << 40;
+            wrec[4] = (unsigned long long)(gw & 0xFFFFFFu) | (unsigned long long)TW(c, B3W_WT_SRC) << 32 | (unsigned long long)(TW(c, B3W_WT_ROW0) + tid) << 40;
           } else defer = true;
         }
       }

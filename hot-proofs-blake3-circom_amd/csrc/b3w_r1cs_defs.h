@@ -23,8 +23,11 @@ struct B3wField {
 #define B3W_WT_GEN_N 9      // general rows: the tile's first rows
 #define B3W_WT_ROW0 10      // first row of the tile in the walk row order
 #define B3W_WT_NROWS 11
+#define B3W_WT_SRC 12        // the tile whose elements the unit reads (a tile with many general rows is several units)
 #define B3W_WT_WORDS 16
 #define B3W_WALK_MAX_EXP_SLOTS 4096u
+#define B3W_WALK_SPLIT_GEN 320u   // general rows per unit at most: a tile with more becomes several units (b3w_r1cs_host.cpp)
+#define B3W_WALK_MAX_UNITS 56u    // units per body at most (the body word of the deferred kernel: one bit a unit, 8 bits for the wide records)
 #define B3W_WALK_MAX_GEN 512u
 #define B3W_WALK_MAX_ENT 4096u
 #define B3W_WALK_WIDE_CAP 128u     // wide records per body (a nova step has 66)

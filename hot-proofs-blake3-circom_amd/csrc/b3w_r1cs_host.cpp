@@ -487,29 +487,31 @@ bool b3w_r1cs_host_build(const uint8_t *img, size_t len, const uint8_t prime_le[
       wrows_of[home[k]].push_back(k);
       for (uint32_t x = 0; x < r.na + r.nb + r.nc; x++) if (wires[r.off + x] / T != home[k]) exported[wires[r.off + x]] = 1;
     }
-    std::vector<uint32_t> slot_of(nwires, 0), slot0(ntiles, 0);
+    std::vector<uint32_t> slot_of(nwires, 0), slot0(ntiles, 0), exp_off(ntiles, 0), exp_n(ntiles, 0);
     std::vector<uint16_t> wexp;
-    std::vector<uint32_t> wtile((size_t)B3W_WT_WORDS * ntiles, 0u);
+    // The kernel's UNITS per body: a tile, or — where a tile has more general rows than B3W_WALK_SPLIT_GEN — the tile several times
+    // over, each unit with a share of those rows (the first one also with the tile's exports, runs and masks' rows).  The row sums
+    // in LDS are sized by the largest unit (96 bytes per general row, twice): one tile of 425 such rows (the circomkit nova build:
+    // its last full tile) would otherwise push a workgroup past half a CU's LDS and the whole system off the walk kernel.
+    std::vector<uint32_t> wtile;                            // B3W_WT_WORDS per unit
     uint32_t slots = 0, wmax_exp = 0;
     for (uint32_t t = 0; t < ntiles; t++) {
       slot0[t] = slots;
-      wtile[(size_t)B3W_WT_WORDS * t + B3W_WT_NLOCAL] = std::min<uint32_t>(T, nwires - t * T);
-      wtile[(size_t)B3W_WT_WORDS * t + B3W_WT_EXP_OFF] = (uint32_t)wexp.size();
-      wtile[(size_t)B3W_WT_WORDS * t + B3W_WT_EXP_SLOT0] = slots;
+      exp_off[t] = (uint32_t)wexp.size();
       uint32_t ne = 0;
       for (uint32_t w = t * T; w < std::min(nwires, (t + 1) * T); w++)
         if (exported[w]) { slot_of[w] = slots + ne; wexp.push_back((uint16_t)(w - t * T)); ne++; }
-      wtile[(size_t)B3W_WT_WORDS * t + B3W_WT_EXP_N] = ne;
+      exp_n[t] = ne;
       wmax_exp = std::max(wmax_exp, ne);
       slots += (ne + 63u) & ~63u;
     }
     bool walk = slots <= B3W_WALK_MAX_EXP_SLOTS;
     auto widx = [&](uint32_t w, uint32_t t) { return w / T == t ? w - t * T : T + slot_of[w]; };
     std::vector<uint8_t> mustbit(nwires, 0);
-    std::vector<uint32_t> wruns, wrun_row, went_w, went_m, wrow_k, wrow_id, wtiles4(4 * (size_t)ntiles, 0u);
+    std::vector<uint32_t> wruns, wrun_row, went_w, went_m, wrow_k, wrow_id, wtiles4, unit_tile;
     uint32_t wmax_gen = 0, wmax_ent = 0, wmax_runs = 0, wmax_rows = 0;
     std::map<std::vector<uint32_t>, uint32_t> wtable_of;    // (part lengths, per term: operand position, coefficient id) -> truth table
-    std::vector<std::vector<uint32_t>> static_rows(ntiles); // always-deferred rows, as positions in their tile
+    std::vector<std::vector<uint32_t>> static_rows;         // per unit: always-deferred rows, as positions in the unit
     for (uint32_t t = 0; t < ntiles && walk; t++) {
       // this tile's rows by class, with what each class needs
       struct TRow { uint32_t k, table, nops; uint32_t idx[5]; uint32_t keyid; };
@@ -601,28 +603,43 @@ bool b3w_r1cs_host_build(const uint8_t *img, size_t len, const uint8_t prime_le[
         for (int j = 0; j < 5; j++) if (a.idx[j] != b.idx[j]) return a.idx[j] < b.idx[j];
         return false;
       });
+      // (B3W_WALK_SPLIT_GEN in the environment: another threshold, for measurements — at most the compiled one, which sizes nothing)
+      static const uint32_t split_gen = getenv("B3W_WALK_SPLIT_GEN") ? std::min<uint32_t>(B3W_WALK_SPLIT_GEN, std::max(16, atoi(getenv("B3W_WALK_SPLIT_GEN")))) : B3W_WALK_SPLIT_GEN;
+      const uint32_t nparts = std::max<uint32_t>(1u, ((uint32_t)gen.size() + split_gen - 1u) / split_gen);
+      for (uint32_t part = 0; part < nparts && walk; part++) {
+      const size_t g_lo = gen.size() * part / nparts, g_hi = gen.size() * (part + 1u) / nparts;
+      const size_t u = unit_tile.size();                    // this unit
+      unit_tile.push_back(t);
+      wtile.resize((u + 1) * (size_t)B3W_WT_WORDS, 0u);
+      wtiles4.resize(4 * (u + 1), 0u);
+      static_rows.emplace_back();
+      wtile[(size_t)B3W_WT_WORDS * u + B3W_WT_NLOCAL] = std::min<uint32_t>(T, nwires - t * T);
+      wtile[(size_t)B3W_WT_WORDS * u + B3W_WT_SRC] = t;
+      wtile[(size_t)B3W_WT_WORDS * u + B3W_WT_EXP_OFF] = exp_off[t];
+      wtile[(size_t)B3W_WT_WORDS * u + B3W_WT_EXP_N] = part ? 0u : exp_n[t];
+      wtile[(size_t)B3W_WT_WORDS * u + B3W_WT_EXP_SLOT0] = slot0[t];
       const uint32_t row0 = (uint32_t)wrow_k.size();
-      wtile[(size_t)B3W_WT_WORDS * t + B3W_WT_ROW0] = row0;
-      wtile[(size_t)B3W_WT_WORDS * t + B3W_WT_GEN_N] = (uint32_t)gen.size();
-      wtile[(size_t)B3W_WT_WORDS * t + B3W_WT_ENT_OFF] = (uint32_t)went_w.size();
+      wtile[(size_t)B3W_WT_WORDS * u + B3W_WT_ROW0] = row0;
+      wtile[(size_t)B3W_WT_WORDS * u + B3W_WT_GEN_N] = (uint32_t)(g_hi - g_lo);
+      wtile[(size_t)B3W_WT_WORDS * u + B3W_WT_ENT_OFF] = (uint32_t)went_w.size();
       {
         std::vector<uint32_t> rw, rm, tw, tm;
-        for (size_t gi = 0; gi < gen.size(); gi++) {
+        for (size_t gi = g_lo; gi < g_hi; gi++) {
           for (size_t e = 0; e < gen[gi].ew.size(); e++) {
-            const uint32_t mt = gen[gi].em[e] | (uint32_t)gi << 8;
+            const uint32_t mt = gen[gi].em[e] | (uint32_t)(gi - g_lo) << 8;
             if (gen[gi].em[e] & 8u) { rw.push_back(gen[gi].ew[e]); rm.push_back(mt); } else { tw.push_back(gen[gi].ew[e]); tm.push_back(mt); }
           }
           wrow_k.push_back(gen[gi].k); wrow_id.push_back(rows[gen[gi].k].id);
         }
         while (rw.size() & 63u) { rw.push_back(0u); rm.push_back(4u); }
-        wtile[(size_t)B3W_WT_WORDS * t + B3W_WT_ENT_RUNS] = (uint32_t)rw.size();
-        wtile[(size_t)B3W_WT_WORDS * t + B3W_WT_ENT_N] = (uint32_t)(rw.size() + tw.size());
+        wtile[(size_t)B3W_WT_WORDS * u + B3W_WT_ENT_RUNS] = (uint32_t)rw.size();
+        wtile[(size_t)B3W_WT_WORDS * u + B3W_WT_ENT_N] = (uint32_t)(rw.size() + tw.size());
         went_w.insert(went_w.end(), rw.begin(), rw.end()); went_w.insert(went_w.end(), tw.begin(), tw.end());
         went_m.insert(went_m.end(), rm.begin(), rm.end()); went_m.insert(went_m.end(), tm.begin(), tm.end());
         wmax_ent = std::max<uint32_t>(wmax_ent, (uint32_t)(rw.size() + tw.size()));
       }
-      wtile[(size_t)B3W_WT_WORDS * t + B3W_WT_RUN_OFF] = (uint32_t)(wruns.size() / 4);
-      for (size_t i = 0; i < tts.size();) {
+      wtile[(size_t)B3W_WT_WORDS * u + B3W_WT_RUN_OFF] = (uint32_t)(wruns.size() / 4);
+      for (size_t i = 0; i < tts.size() && part == 0u;) {
         uint32_t stride[5] = {0, 0, 0, 0, 0};
         size_t j = i + 1;
         if (j < tts.size() && tts[j].keyid == tts[i].keyid) {
@@ -657,28 +674,32 @@ bool b3w_r1cs_host_build(const uint8_t *img, size_t len, const uint8_t prime_le[
         for (size_t x = i; x < j; x++) { wrow_k.push_back(tts[x].k); wrow_id.push_back(rows[tts[x].k].id); }
         i = j;
       }
-      wtile[(size_t)B3W_WT_WORDS * t + B3W_WT_RUN_N] = (uint32_t)(wruns.size() / 4) - wtile[(size_t)B3W_WT_WORDS * t + B3W_WT_RUN_OFF];
-      wmax_runs = std::max(wmax_runs, wtile[(size_t)B3W_WT_WORDS * t + B3W_WT_RUN_N]);
-      for (uint32_t k : defs) { static_rows[t].push_back((uint32_t)wrow_k.size() - row0); wrow_k.push_back(k); wrow_id.push_back(rows[k].id); }
-      for (uint32_t k : bools) { wrow_k.push_back(k); wrow_id.push_back(rows[k].id); }
+      wtile[(size_t)B3W_WT_WORDS * u + B3W_WT_RUN_N] = (uint32_t)(wruns.size() / 4) - wtile[(size_t)B3W_WT_WORDS * u + B3W_WT_RUN_OFF];
+      wmax_runs = std::max(wmax_runs, wtile[(size_t)B3W_WT_WORDS * u + B3W_WT_RUN_N]);
+      if (part == 0u) {
+        for (uint32_t k : defs) { static_rows[u].push_back((uint32_t)wrow_k.size() - row0); wrow_k.push_back(k); wrow_id.push_back(rows[k].id); }
+        for (uint32_t k : bools) { wrow_k.push_back(k); wrow_id.push_back(rows[k].id); }
+      }
       const uint32_t nrows = (uint32_t)wrow_k.size() - row0;
-      wtile[(size_t)B3W_WT_WORDS * t + B3W_WT_NROWS] = nrows;
-      wtiles4[4 * (size_t)t] = row0; wtiles4[4 * (size_t)t + 1] = nrows;
-      wmax_gen = std::max<uint32_t>(wmax_gen, (uint32_t)gen.size());
+      wtile[(size_t)B3W_WT_WORDS * u + B3W_WT_NROWS] = nrows;
+      wtiles4[4 * u] = row0; wtiles4[4 * u + 1] = nrows;
+      wmax_gen = std::max<uint32_t>(wmax_gen, (uint32_t)(g_hi - g_lo));
       wmax_rows = std::max(wmax_rows, nrows);
-      if (gen.size() > B3W_WALK_MAX_GEN || wmax_ent > B3W_WALK_MAX_ENT || nrows > 4096u) { if (getenv("B3W_WALK_DEBUG")) fprintf(stderr, "walk: tile %u gen %zu ent %u rows %u\n", t, gen.size(), wmax_ent, nrows); walk = false; }
+      if (g_hi - g_lo > B3W_WALK_MAX_GEN || wmax_ent > B3W_WALK_MAX_ENT || nrows > 4096u || unit_tile.size() > B3W_WALK_MAX_UNITS) { if (getenv("B3W_WALK_DEBUG")) fprintf(stderr, "walk: tile %u gen %zu ent %u rows %u\n", t, g_hi - g_lo, wmax_ent, nrows); walk = false; }
+      }
     }
     if (walk) {
-      const uint32_t sw = (wmax_rows + 63u) / 64u;
-      std::vector<unsigned long long> wstatic((size_t)ntiles * sw, 0ull), wmask((size_t)ntiles * 16u, 0ull);
-      for (uint32_t t = 0; t < ntiles; t++) {
-        for (uint32_t pos : static_rows[t]) wstatic[(size_t)t * sw + (pos >> 6)] |= 1ull << (pos & 63u);
+      const uint32_t sw = (wmax_rows + 63u) / 64u, nunits = (uint32_t)unit_tile.size();
+      std::vector<unsigned long long> wstatic((size_t)nunits * sw, 0ull), wmask((size_t)nunits * 16u, 0ull);
+      for (uint32_t u = 0; u < nunits; u++) {               // (every unit of a tile carries the tile's must-be-bit mask: the same anomaly, seen again)
+        const uint32_t t = unit_tile[u];
+        for (uint32_t pos : static_rows[u]) wstatic[(size_t)u * sw + (pos >> 6)] |= 1ull << (pos & 63u);
         for (uint32_t w = t * T; w < std::min(nwires, (t + 1) * T); w++)
-          if (mustbit[w]) wmask[(size_t)t * 16u + ((w - t * T) >> 6)] |= 1ull << ((w - t * T) & 63u);
+          if (mustbit[w]) wmask[(size_t)u * 16u + ((w - t * T) >> 6)] |= 1ull << ((w - t * T) & 63u);
       }
       // (a wave reads whole chunks of 64: a lane may read up to 63 entries, descriptors or exports behind its tile's last)
       for (int pad = 0; pad < 64; pad++) { wruns.insert(wruns.end(), {0u, 0u, 0u, 0u}); went_w.push_back(0u); went_m.push_back(4u); wexp.push_back(0); }
-      H->walk = true; H->wexp_slots = slots; H->wmax_gen = wmax_gen; H->wmax_ent = wmax_ent; H->wmax_exp = wmax_exp; H->wmax_runs = wmax_runs;
+      H->walk = true; H->wunits = nunits; H->wexp_slots = slots; H->wmax_gen = wmax_gen; H->wmax_ent = wmax_ent; H->wmax_exp = wmax_exp; H->wmax_runs = wmax_runs;
       H->wmax_rows = wmax_rows; H->wstatic_words = sw;
       H->wtile = std::move(wtile); H->wmask = std::move(wmask); H->wexp = std::move(wexp); H->wruns = std::move(wruns);
       H->wrun_row = std::move(wrun_row); H->went_w = std::move(went_w); H->went_m = std::move(went_m); H->wrow_k = std::move(wrow_k);

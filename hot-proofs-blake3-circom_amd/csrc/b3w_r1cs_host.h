@@ -38,6 +38,8 @@ struct B3wR1csHost {
   // gathered from HBM.  Element index of a row: < TILE = local, TILE + slot = export slot (each tile's slots start at a multiple of
   // 64 so that the same number indexes the bit-packed copy).
   bool walk = false;                               // the system fits the walk kernel
+  uint32_t wunits = 0;                             // UNITS per body: a tile each, but a tile with more than B3W_WALK_SPLIT_GEN general rows is several
+                                                   // (B3W_WT_SRC = the tile a unit reads); every "per tile" below is per unit
   uint32_t wexp_slots = 0;                         // export area, in slots (padded)
   uint32_t wmax_gen = 0, wmax_ent = 0, wmax_exp = 0, wmax_runs = 0, wmax_rows = 0, wstatic_words = 0;
   std::vector<uint32_t> wtile;                     // 16 per tile: see B3W_WT_* in b3w_r1cs_defs.h

@@ -123,22 +123,31 @@ static bool indices_ok(const B3wR1csHost &H) {
 // the walk kernel's program: every index it follows inside its array, every import from an EARLIER tile
 static bool walk_ok(const B3wR1csHost &H) {
   if (!H.walk) return true;
-  const uint32_t T = B3W_R1CS_TILE, nt = H.ntiles;
+  const uint32_t T = B3W_R1CS_TILE, nt = H.wunits;          // units: a tile each, a tile with many general rows several
+  CHECK(nt >= H.ntiles && nt <= B3W_WALK_MAX_UNITS);
   CHECK(H.wtile.size() == (size_t)B3W_WT_WORDS * nt && H.wmask.size() == 16 * (size_t)nt && H.wtiles4.size() == 4 * (size_t)nt);
   CHECK(H.wexp_slots % 64 == 0 && H.wexp_slots <= B3W_WALK_MAX_EXP_SLOTS && H.wstatic.size() == (size_t)nt * H.wstatic_words);
   CHECK(H.wrow_k.size() == H.m && H.wrow_id.size() == H.m && H.wruns.size() % 4 == 0 && H.wrun_row.size() + 64 == H.wruns.size() / 4);
   CHECK(H.went_w.size() == H.went_m.size() && H.wmax_gen <= B3W_WALK_MAX_GEN && H.wmax_ent <= B3W_WALK_MAX_ENT);
   std::vector<uint8_t> seen(H.m, 0);
-  uint32_t rows_so_far = 0, slots_so_far = 0;
+  uint32_t rows_so_far = 0, slots_so_far = 0, prev_src = 0xFFFFFFFFu;
   for (uint32_t t = 0; t < nt; t++) {
     const uint32_t *w = &H.wtile[(size_t)B3W_WT_WORDS * t];
-    const uint32_t n_local = w[B3W_WT_NLOCAL], exp_n = w[B3W_WT_EXP_N], slot0 = w[B3W_WT_EXP_SLOT0];
-    CHECK(n_local == std::min<uint32_t>(T, H.nwires - t * T) && slot0 == slots_so_far && slot0 % 64 == 0);
+    const uint32_t n_local = w[B3W_WT_NLOCAL], exp_n = w[B3W_WT_EXP_N], slot0 = w[B3W_WT_EXP_SLOT0], src = w[B3W_WT_SRC];
+    const bool first = src != prev_src;                     // the tile's first unit: exports, runs, booleanity rows
+    CHECK(src < H.ntiles && (first ? src == prev_src + 1u : true) && (t != 0 || src == 0));
+    prev_src = src;
+    CHECK(n_local == std::min<uint32_t>(T, H.nwires - src * T) && slot0 % 64 == 0 && (first ? slot0 == slots_so_far : (exp_n == 0 && w[B3W_WT_RUN_N] == 0)));
+    if (!first) {                                           // the same mask as the tile's first unit, and nothing but general rows
+      for (int q = 0; q < 16; q++) CHECK(H.wmask[16 * (size_t)t + q] == H.wmask[16 * (size_t)(t - 1) + q]);
+      CHECK(w[B3W_WT_GEN_N] == w[B3W_WT_NROWS]);
+    }
+    CHECK(w[B3W_WT_GEN_N] <= B3W_WALK_SPLIT_GEN);
     CHECK((uint64_t)w[B3W_WT_EXP_OFF] + exp_n + 64 <= H.wexp.size() && exp_n <= H.wmax_exp);
     for (uint32_t j = 0; j < exp_n; j++) CHECK(H.wexp[w[B3W_WT_EXP_OFF] + j] < n_local && (j == 0 || H.wexp[w[B3W_WT_EXP_OFF] + j] > H.wexp[w[B3W_WT_EXP_OFF] + j - 1]));
     slots_so_far += (exp_n + 63u) & ~63u;
     // an element index of this tile: local, or a slot an EARLIER tile has filled
-    auto idx_ok = [&](uint32_t idx, uint32_t len) { return idx < T ? idx + len <= n_local : idx - T + len <= slot0; };
+    auto idx_ok = [&](uint32_t idx, uint32_t len) { return idx < T ? idx + len <= n_local : idx - T + len <= slot0; };      // (slot0: the TILE's first slot)
     CHECK(w[B3W_WT_ROW0] == rows_so_far && H.wtiles4[4 * t] == rows_so_far && H.wtiles4[4 * t + 1] == w[B3W_WT_NROWS]);
     const uint32_t row0 = w[B3W_WT_ROW0], nrows = w[B3W_WT_NROWS], gen_n = w[B3W_WT_GEN_N];
     CHECK(nrows <= H.wmax_rows && (nrows + 63) / 64 <= H.wstatic_words && gen_n <= nrows && gen_n <= H.wmax_gen);
@@ -174,7 +183,7 @@ static bool walk_ok(const B3wR1csHost &H) {
       for (uint32_t bit = 0; bit < 64; bit++) if ((sm >> bit) & 1ull) CHECK(64 * k + bit >= next_row - row0 && 64 * k + bit < nrows);
     }
   }
-  CHECK(rows_so_far == H.m && slots_so_far == H.wexp_slots);
+  CHECK(rows_so_far == H.m && slots_so_far == H.wexp_slots && prev_src + 1u == H.ntiles);
   return true;
 }
 
@@ -254,22 +263,25 @@ static bool same_sums(const B3wR1csHost &H, const uint8_t prime_le[32]) {
 // of every truth-table run against the row evaluated in plain integers, booleanity rows' wires in the must-be-bit masks
 static bool walk_same(const B3wR1csHost &H, const uint8_t prime_le[32]) {
   if (!H.walk) return true;
-  const uint32_t T = B3W_R1CS_TILE, nt = H.ntiles;
+  const uint32_t T = B3W_R1CS_TILE, nt = H.wunits;
   uint64_t p_lo;
   memcpy(&p_lo, prime_le, 8);
   auto coef_lo = [&](uint32_t cid) { uint64_t c; memcpy(&c, &H.coefR[16 * (size_t)cid], 8); return c; };
+  std::vector<uint32_t> unit_of(H.ntiles, 0);               // a tile's first unit
+  for (uint32_t u = nt; u-- > 0;) unit_of[H.wtile[(size_t)B3W_WT_WORDS * u + B3W_WT_SRC]] = u;
   std::vector<uint64_t> z(H.nwires);
   for (uint32_t w = 0; w < H.nwires; w++) {
     const uint64_t x = rnd();
-    const bool mustbit = (H.wmask[(size_t)(w / T) * 16 + ((w % T) >> 6)] >> (w & 63u)) & 1ull;
+    const bool mustbit = (H.wmask[(size_t)unit_of[w / T] * 16 + ((w % T) >> 6)] >> (w & 63u)) & 1ull;
     z[w] = mustbit || (x & 3) ? (x >> 2) & 1 : (x >> 8) & 0xFFFFFFFFu;
   }
   z[0] = 1;
   std::vector<uint64_t> xel(H.wexp_slots, 0);
   std::vector<uint32_t> slot_wire(H.wexp_slots, 0xFFFFFFFFu);
   size_t tt_rows = 0;
-  for (uint32_t t = 0; t < nt; t++) {
-    const uint32_t *w = &H.wtile[(size_t)B3W_WT_WORDS * t];
+  for (uint32_t u = 0; u < nt; u++) {
+    const uint32_t *w = &H.wtile[(size_t)B3W_WT_WORDS * u];
+    const uint32_t t = w[B3W_WT_SRC];                       // (the tile; u indexes what is per unit)
     auto value = [&](uint32_t idx) { return idx < T ? z[t * T + idx] : xel[idx - T]; };
     auto wire_of = [&](uint32_t idx) { return idx < T ? t * T + idx : slot_wire[idx - T]; };
     const uint32_t row0 = w[B3W_WT_ROW0], nrows = w[B3W_WT_NROWS], gen_n = w[B3W_WT_GEN_N];
@@ -331,11 +343,11 @@ static bool walk_same(const B3wR1csHost &H, const uint8_t prime_le[32]) {
     // behind them: always-deferred rows (a coefficient that is no small integer, or very long), then booleanity rows
     for (uint32_t r = next_row; r < row0 + nrows; r++) {
       const uint32_t k = H.wrow_k[r], pos = r - row0;
-      const bool stat = (H.wstatic[(size_t)t * H.wstatic_words + (pos >> 6)] >> (pos & 63u)) & 1ull;
+      const bool stat = (H.wstatic[(size_t)u * H.wstatic_words + (pos >> 6)] >> (pos & 63u)) & 1ull;
       if (stat) continue;
       CHECK(H.rowdesc[4 * k + 1] == 1 && H.rowdesc[4 * k + 2] == 2 && H.rowdesc[4 * k + 3] == 0);
       const uint32_t bw = H.wires[H.rowdesc[4 * k]];
-      CHECK(bw / T == t && ((H.wmask[(size_t)t * 16 + ((bw % T) >> 6)] >> (bw & 63u)) & 1ull));
+      CHECK(bw / T == t && ((H.wmask[(size_t)u * 16 + ((bw % T) >> 6)] >> (bw & 63u)) & 1ull));
     }
     // this tile's exports, for the tiles behind it
     for (uint32_t j = 0; j < w[B3W_WT_EXP_N]; j++) {
@@ -366,7 +378,7 @@ int main(int argc, char **argv) {
     B3wR1csHost H;
     if (!b3w_r1cs_host_build(img.data(), img.size(), prime, nwit, &H)) { fprintf(stderr, "pristine image refused: %s\n", H.error.c_str()); return 1; }
     if (!indices_ok(H) || !walk_ok(H) || !same_sums(H, prime) || !walk_same(H, prime)) return 1;
-    printf("walk %d: %u export slots, %zu runs, %zu entries\n", (int)H.walk, H.wexp_slots, H.wruns.size() / 4, H.went_w.size());
+    printf("walk %d: %u units over %u tiles, %u export slots, %zu runs, %zu entries, %u general rows a unit at most\n", (int)H.walk, H.wunits, H.ntiles, H.wexp_slots, H.wruns.size() / 4, H.went_w.size(), H.wmax_gen);
     uint64_t runs = 0;
     for (size_t i = 0; i + 1 < H.lterms.size(); i++) runs += (H.lterms[i] >> 16) == 0xFFFFu;
     printf("pristine: %u constraints, %llu terms, tiled %d, %u tiles, max_ext %u, lean words %zu (%llu runs)\n", H.m,
