@@ -123,7 +123,8 @@ struct B3wWalk {
   const uint32_t *run_row, *ent_w, *ent_m, *row_id;
   const unsigned long long *stat;        // static_words per tile
   const long long *coef_small;
-  const uint32_t *static_k, *static_id;  // the always-deferred rows as a list: gather descriptor (4 words), constraint number
+  const uint32_t *static_k, *static_id;  // the always-deferred rows as a list: {first pair, pairs, linear, has C} per row, then their unique terms
+                                         // as pairs {wire, coefficient id | parts << 16} (b3w_capi.cpp); constraint numbers
   uint32_t nstatic, pad2;
   uint32_t static_d0[4];                 // the first one's descriptor (a kernel argument of the deferred kernel)
 };

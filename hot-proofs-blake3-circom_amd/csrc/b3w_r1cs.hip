@@ -1159,6 +1159,76 @@ __global__ __launch_bounds__(64) void b3w_r1cs_deferred_kernel(const uint8_t *__
   if (!any) return;
   deferred_report(nbad, low, b, violations, first);
 }
+// two sums over the wave at the price of one: the lower half of the wave reduces a, the upper half b
+__device__ __forceinline__ void wave_sum2(Fe &a, Fe &b, const uint32_t p[8]) {
+  const bool upper = (threadIdx.x & 32u) != 0u;
+  Fe keep = upper ? b : a, give = upper ? a : b;
+#pragma unroll
+  for (int i = 0; i < 8; i++) give.l[i] = (uint32_t)__shfl_xor((int)give.l[i], 32);
+  fe_add(keep, give, p);
+#pragma unroll
+  for (int sh = 16; sh > 0; sh >>= 1) {
+    Fe o;
+#pragma unroll
+    for (int i = 0; i < 8; i++) o.l[i] = (uint32_t)__shfl_xor((int)keep.l[i], sh);
+    fe_add(keep, o, p);
+  }
+#pragma unroll
+  for (int i = 0; i < 8; i++) {
+    a.l[i] = (uint32_t)__builtin_amdgcn_readlane((int)keep.l[i], 0);
+    b.l[i] = (uint32_t)__builtin_amdgcn_readlane((int)keep.l[i], 32);
+  }
+}
+// An always-deferred row of the walk kernel's list, by one wave: d = {first pair, pairs, linear, has C terms}, pairs = the row's
+// UNIQUE terms {wire, coefficient id | parts << 16} (b3w_capi.cpp) — a term that stands in A and in B (X (X - 1) = 0) is multiplied
+// once and added twice; element and coefficient are loaded side by side, the next pair's while this one is multiplied.
+__device__ __forceinline__ bool static_row_wave(const uint8_t *body, const uint4 d, const uint2 *pairs, const uint32_t *coefR, const B3wField &F) {
+  bool wild = false;
+  const uint32_t lane = threadIdx.x & 63u, n = d.y;
+  Fe az, bz, cz;
+#pragma unroll
+  for (int i = 0; i < 8; i++) az.l[i] = bz.l[i] = cz.l[i] = 0;
+  uint32_t meta = 0;
+  uint4 zlo = make_uint4(0, 0, 0, 0), zhi = zlo;
+  Fe cf;
+  auto issue = [&](uint32_t k) {                            // (k < n)
+    const uint2 pr = pairs[d.x + k];
+    meta = pr.y;
+    const uint4 *q = reinterpret_cast<const uint4 *>(body + (size_t)pr.x * 32);
+    zlo = q[0]; zhi = q[1];
+    cf = load_fe(coefR + (size_t)(pr.y & 0xFFFFu) * 16 + 8);
+  };
+  if (lane < n) issue(lane);
+  for (uint32_t k = lane; k < n; k += 64u) {
+    Fe z;
+    z.l[0] = zlo.x; z.l[1] = zlo.y; z.l[2] = zlo.z; z.l[3] = zlo.w;
+    z.l[4] = zhi.x; z.l[5] = zhi.y; z.l[6] = zhi.z; z.l[7] = zhi.w;
+    const uint32_t c = meta & 0xFFFFu, parts = meta >> 16;
+    const Fe cfk = cf;
+    if (k + 64u < n) issue(k + 64u);
+    if (fe_geq(z, F.p)) {
+      wild = true;
+      do fe_sub_p(z, F.p); while (fe_geq(z, F.p));
+    }
+    if (fe_is_zero(z)) continue;
+    Fe t = z;
+    if (c >= 2u) t = mont_mul(cfk, z, F);                   // (coef * R) * z / R
+    if (c == 1u) {                                          // - z  =  + (p - z)   (z != 0)
+      Fe pm;
+#pragma unroll
+      for (int i = 0; i < 8; i++) pm.l[i] = F.p[i];
+      fe_sub(pm, t, F.p);
+      t = pm;
+    }
+    if (parts & 1u) fe_add(az, t, F.p);
+    if (parts & 2u) fe_add(bz, t, F.p);
+    if (parts & 4u) fe_add(cz, t, F.p);
+  }
+  wave_sum2(az, bz, F.p);
+  if (d.w) cz = wave_sum(cz, F.p);                          // (wave-uniform)
+  return row_violated(az, bz, cz, d.z != 0u, F) || __ballot(wild) != 0;
+}
+
 // behind the walk kernel: one workgroup of TWO waves per BODY, told by one word which of the body's tiles have deferred rows at all
 // (bit t = tile t) — a batch of valid blake3_compression witnesses is 4 096 workgroups that load a zero and leave.  The waves share a
 // flagged tile's mask words.  Everything here is a chain of three dependent loads and a field multiplication, 145 VGPRs allow twelve
@@ -1173,7 +1243,7 @@ __global__ __launch_bounds__(64 * B3W_WALK_DEFERRED_WAVES) void b3w_r1cs_walk_de
                                                                     const unsigned long long *__restrict__ scratch, uint32_t block_words,
                                                                     const unsigned long long *__restrict__ body_flags,
                                                                     const unsigned long long *__restrict__ wide_recs,
-                                                                    const uint32_t *__restrict__ static_d /* 4 words per row: its gather descriptor */, uint4 static_d0,
+                                                                    const uint32_t *__restrict__ static_d /* 4 words per row, then the rows' unique terms as pairs: static_row_wave */, uint4 static_d0,
                                                                     const uint32_t *__restrict__ static_id, uint32_t nstatic, B3wField F, uint32_t *__restrict__ violations, uint32_t *__restrict__ first) {
   const uint32_t b = blockIdx.x, wave = threadIdx.x >> 6;
   const uint8_t *body = bodies + (uint64_t)b * pitch;
@@ -1197,7 +1267,7 @@ __global__ __launch_bounds__(64 * B3W_WALK_DEFERRED_WAVES) void b3w_r1cs_walk_de
   if (wave == B3W_WALK_DEFERRED_WAVES - 1u)
     for (uint32_t sr = 0; sr < nstatic; sr++) {
       const uint4 d = sr ? reinterpret_cast<const uint4 *>(static_d)[sr] : static_d0;
-      const bool bad = gather_row_wave(body, d, S.g_wires, S.g_cids, S.coefs, F);
+      const bool bad = static_row_wave(body, d, reinterpret_cast<const uint2 *>(static_d), S.coefs, F);
       if ((threadIdx.x & 63u) == 0 && bad) { nbad++; low = min(low, static_id[sr]); }
     }
   if (flags == 0ull) {                                       // (wave-uniform)
