@@ -1523,14 +1523,28 @@ __global__ __launch_bounds__(512, 4) void b3w_r1cs_walk_kernel(const uint8_t *__
             atomicAdd(sum + 1, neg ? 0ull - v1 : v1);
           }
         }
-      } else {                                                 // a chunk of terms: element | coefficient id << 16
+      } else {                                                 // a chunk of terms: element | coefficient id << 16, or element | k << 16 | negative << 22 | 1 << 31 for +-2^k
         const uint32_t idx = live ? w & 0xFFFFu : 0u;
         const unsigned long long z = idx < T ? el[idx] : xel[idx - T];
-        const long long cf = lcoef[live ? w >> 16 : 0u];
-        const unsigned long long mag = cf < 0 ? 0ull - (unsigned long long)cf : (unsigned long long)cf;
-        const unsigned long long lo = mag * z, hi = __umul64hi(mag, z);
-        const bool neg = cf < 0;
-        const bool ok = cf != B3W_R1CS_NOT_SMALL && !(z >> 63) && hi < (1ull << 39);
+        unsigned long long mag, lo, hi;
+        bool neg, small;
+        if (__ballot(live && !(w >> 31)) == 0ull) {            // every term of the chunk shifts (98 % of all terms do; the host puts the others last): no
+          const uint32_t k = (w >> 16) & 63u;                  // coefficient from the table, no 64 x 64 multiplication
+          neg = (w >> 22) & 1u;
+          lo = z << k;
+          hi = k ? z >> (64u - k) : 0ull;
+          mag = 1ull << k;
+          small = true;
+        } else {
+          long long cf;
+          if (w >> 31) { const long long one_k = 1ll << ((w >> 16) & 63u); cf = (w >> 22) & 1u ? -one_k : one_k; }
+          else cf = lcoef[live ? w >> 16 : 0u];
+          mag = cf < 0 ? 0ull - (unsigned long long)cf : (unsigned long long)cf;
+          lo = mag * z; hi = __umul64hi(mag, z);
+          neg = cf < 0;
+          small = cf != B3W_R1CS_NOT_SMALL;
+        }
+        const bool ok = small && !(z >> 63) && hi < (1ull << 39);
         // ONE term +-1 * (a local element of 2^63 or more) — the field inverse of an IsZero gadget, "in * inv = 1 - out" — stays out of
         // the sums and is remembered with its row: the verdict lane then hands the deferred kernel the row's small sums and the
         // element's place (a WIDE RECORD) instead of the row — one load there, not a walk through the row's terms

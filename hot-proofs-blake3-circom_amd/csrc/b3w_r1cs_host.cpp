@@ -553,7 +553,12 @@ bool b3w_r1cs_host_build(const uint8_t *img, size_t len, const uint8_t prime_le[
               run_wires.push_back(ws);
               i = j;
             } else {
-              g.ew.push_back(terms[i][0] | terms[i][1] << 16);
+              // a term: element | coefficient id << 16 — or, for a coefficient +-2^k (98 % of them), element | k << 16 | negative << 22
+              // | 1 << 31: the kernel shifts instead of multiplying and needs no coefficient from its table
+              bool ng = false; uint32_t kk = 0;
+              static const bool shift_terms = !(getenv("B3W_WALK_SHIFT_TERMS") && !strcmp(getenv("B3W_WALK_SHIFT_TERMS"), "0"));      // (0: measurements)
+              if (shift_terms && pow2((uint16_t)terms[i][1], ng, kk)) g.ew.push_back(terms[i][0] | kk << 16 | (ng ? 1u << 22 : 0u) | 1u << 31);
+              else g.ew.push_back(terms[i][0] | terms[i][1] << 16);
               g.em.push_back(part);
               i++;
             }
@@ -623,14 +628,18 @@ bool b3w_r1cs_host_build(const uint8_t *img, size_t len, const uint8_t prime_le[
       wtile[(size_t)B3W_WT_WORDS * u + B3W_WT_GEN_N] = (uint32_t)(g_hi - g_lo);
       wtile[(size_t)B3W_WT_WORDS * u + B3W_WT_ENT_OFF] = (uint32_t)went_w.size();
       {
-        std::vector<uint32_t> rw, rm, tw, tm;
+        std::vector<uint32_t> rw, rm, tw, tm, ow, om;        // bit runs | terms with a power-of-two coefficient | other terms
         for (size_t gi = g_lo; gi < g_hi; gi++) {
           for (size_t e = 0; e < gen[gi].ew.size(); e++) {
             const uint32_t mt = gen[gi].em[e] | (uint32_t)(gi - g_lo) << 8;
-            if (gen[gi].em[e] & 8u) { rw.push_back(gen[gi].ew[e]); rm.push_back(mt); } else { tw.push_back(gen[gi].ew[e]); tm.push_back(mt); }
+            if (gen[gi].em[e] & 8u) { rw.push_back(gen[gi].ew[e]); rm.push_back(mt); }
+            else if (gen[gi].ew[e] >> 31) { tw.push_back(gen[gi].ew[e]); tm.push_back(mt); }
+            else { ow.push_back(gen[gi].ew[e]); om.push_back(mt); }
           }
           wrow_k.push_back(gen[gi].k); wrow_id.push_back(rows[gen[gi].k].id);
         }
+        // (the other terms last: a chunk of 64 whose terms all shift takes the kernel's short road — one mixed chunk a unit at most)
+        tw.insert(tw.end(), ow.begin(), ow.end()); tm.insert(tm.end(), om.begin(), om.end());
         while (rw.size() & 63u) { rw.push_back(0u); rm.push_back(4u); }
         wtile[(size_t)B3W_WT_WORDS * u + B3W_WT_ENT_RUNS] = (uint32_t)rw.size();
         wtile[(size_t)B3W_WT_WORDS * u + B3W_WT_ENT_N] = (uint32_t)(rw.size() + tw.size());

@@ -175,6 +175,8 @@ static bool walk_ok(const B3wR1csHost &H) {
       if (i < ent_runs) {
         const uint32_t n = (e >> 16) & 0x7Fu, sh = (e >> 23) & 0x3Fu;
         CHECK(n >= 4 && n <= 64 && sh + n <= 62 && !(e >> 30) && idx_ok(e & 0xFFFFu, n));
+      } else if (e >> 31) {                                // a term with a coefficient +-2^k: element | k << 16 | negative << 22 | 1 << 31
+        CHECK(idx_ok(e & 0xFFFFu, 1) && ((e >> 16) & 63u) <= 62u && !((e >> 23) & 0xFFu));
       } else CHECK(idx_ok(e & 0xFFFFu, 1) && (e >> 16) < H.ncoef);
     }
     // always-deferred rows lie behind the general rows and the runs, inside the tile
@@ -297,7 +299,8 @@ static bool walk_same(const B3wR1csHost &H, const uint8_t prime_le[32]) {
           CHECK(value((e & 0xFFFFu) + q) <= 1);             // a run's elements are must-be-bit wires
           v += ((e >> 29) & 1u ? p_lo - (1ull << (sh + q)) : 1ull << (sh + q)) * value((e & 0xFFFFu) + q);
         }
-      } else v = coef_lo(e >> 16) * value(e & 0xFFFFu);
+      } else if (e >> 31) v = ((e >> 22) & 1u ? p_lo - (1ull << ((e >> 16) & 63u)) : 1ull << ((e >> 16) & 63u)) * value(e & 0xFFFFu);
+      else v = coef_lo(e >> 16) * value(e & 0xFFFFu);
       sums[3 * (size_t)(mt >> 8) + (mt & 3u)] += v;
     }
     for (uint32_t g = 0; g < gen_n; g++) {
