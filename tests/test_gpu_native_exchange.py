@@ -21,6 +21,8 @@ import blake3_ref as B
 pytestmark = pytest.mark.gpu
 
 SHAPES = [("config4_1mib", 1 << 20), ("6chunks_partial_last", 5 * 1024 + 100), ("one_chunk", 700)]
+if os.environ.get("B3W_TEST_EXTRA_PREIMAGE_BYTES"):           # a one-off soak shape (tools/r04/job31_soak.sh: 8 MiB + 77: several slices a rank, ragged)
+    SHAPES.append(("extra", int(os.environ["B3W_TEST_EXTRA_PREIMAGE_BYTES"])))
 
 
 def _worker(rank, world, transport, name, port, ret):
