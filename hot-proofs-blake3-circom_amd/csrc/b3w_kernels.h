@@ -127,6 +127,7 @@ struct B3wWalk {
                                          // as pairs {wire, coefficient id | parts << 16} (b3w_capi.cpp); constraint numbers
   uint32_t nstatic, pad2;
   uint32_t static_d0[4];                 // the first one's descriptor (a kernel argument of the deferred kernel)
+  uint32_t p[8];                         // the field's prime: the walk kernel takes an element p - k (k < 2^62) for the small number -k
 };
 // The WALK kernel (default where the system fits): a workgroup walks whole bodies tile after tile, earlier tiles' wires come from an
 // export area in LDS — no outside wire is gathered from HBM.  `sysw` = the system with the WALK row order in tiles / row_k / row_id

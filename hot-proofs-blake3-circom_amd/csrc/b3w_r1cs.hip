@@ -1348,6 +1348,29 @@ __global__ __launch_bounds__(64 * B3W_WALK_DEFERRED_WAVES) void b3w_r1cs_walk_de
 // field inverses of a nova step) is deferred alone.  The deferred kernel and its scratch blocks are the stream kernel's.
 // One workgroup owns a body: its violation count is a plain store, there is no initialisation kernel.
 
+// An element as the walk kernel keeps it, 8 bytes: a SIGNED small number — v < 2^63 as it stands, and p - k (0 < k <= 2^62) as -k:
+// unsimplified systems hold their small negative numbers that way (the circomkit nova build: 121 rows a step over such wires, which the
+// unsigned form sent to the deferred kernel row by row) — or B3W_WALK_WIDE for everything else (a field inverse).  The test for
+// "near p" is one compare of the top limb; the subtraction behind it runs only in a wave that has such an element.
+#define B3W_WALK_WIDE 0x8000000000000000ull
+__device__ __forceinline__ unsigned long long walk_pack(const uint4 lo, const uint4 hi, const uint32_t p[8]) {
+  const uint32_t wide = lo.z | lo.w | hi.x | hi.y | hi.z | hi.w | (lo.y & 0x80000000u);
+  if (!wide) return (unsigned long long)lo.x | (unsigned long long)lo.y << 32;
+  unsigned long long z = B3W_WALK_WIDE;
+  if (hi.w == p[7]) {                                        // (a lane here is rare in an optimised system's bodies)
+    const uint32_t e[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
+    uint32_t d[8], borrow = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      const uint64_t t = (uint64_t)p[i] - e[i] - borrow;
+      d[i] = (uint32_t)t;
+      borrow = (uint32_t)(t >> 63);
+    }
+    const unsigned long long k = (unsigned long long)d[0] | (unsigned long long)d[1] << 32;
+    if (!borrow && !(d[2] | d[3] | d[4] | d[5] | d[6] | d[7]) && k != 0ull && k <= (1ull << 62)) z = 0ull - k;      // (k = 0: the element is p itself, no witness value)
+  }
+  return z;
+}
 // 32 bits of a bit-packed array from bit `idx` on (the array has a spare word behind its last)
 __device__ __forceinline__ uint32_t cut32(const unsigned long long *words, uint32_t idx) {
   const uint32_t g = idx >> 6, r = idx & 63u;
@@ -1484,7 +1507,7 @@ __global__ __launch_bounds__(512, 4) void b3w_r1cs_walk_kernel(const uint8_t *__
       const uint32_t g = wave + (uint32_t)q * WAVES, e = g * 64u + lane;
       uint4 lo = rlo[q], hi = rhi[q];
       halves_apart(lo.x, hi.x); halves_apart(lo.y, hi.y); halves_apart(lo.z, hi.z); halves_apart(lo.w, hi.w);
-      const unsigned long long z = e < n_local ? lean_pack(lo, hi) : 0ull;
+      const unsigned long long z = e < n_local ? walk_pack(lo, hi, W.p) : 0ull;
       el[e] = z;
       const unsigned long long is1 = __ballot(z == 1ull), bads = __ballot(z > 1ull);
       if (lane == 0) ones[g] = is1;
@@ -1525,7 +1548,9 @@ __global__ __launch_bounds__(512, 4) void b3w_r1cs_walk_kernel(const uint8_t *__
         }
       } else {                                                 // a chunk of terms: element | coefficient id << 16, or element | k << 16 | negative << 22 | 1 << 31 for +-2^k
         const uint32_t idx = live ? w & 0xFFFFu : 0u;
-        const unsigned long long z = idx < T ? el[idx] : xel[idx - T];
+        const unsigned long long zs = idx < T ? el[idx] : xel[idx - T];      // (signed small, or B3W_WALK_WIDE: walk_pack)
+        const bool zwide = zs == B3W_WALK_WIDE, zneg = !zwide && (long long)zs < 0ll;
+        const unsigned long long z = zneg ? 0ull - zs : zs;     // (its magnitude: at most 2^63 - 1)
         unsigned long long mag, lo, hi;
         bool neg, small;
         if (__ballot(live && !(w >> 31)) == 0ull) {            // every term of the chunk shifts (98 % of all terms do; the host puts the others last): no
@@ -1544,11 +1569,12 @@ __global__ __launch_bounds__(512, 4) void b3w_r1cs_walk_kernel(const uint8_t *__
           neg = cf < 0;
           small = cf != B3W_R1CS_NOT_SMALL;
         }
-        const bool ok = small && !(z >> 63) && hi < (1ull << 39);
+        neg = neg != zneg;
+        const bool ok = small && !zwide && hi < (1ull << 39);
         // ONE term +-1 * (a local element of 2^63 or more) — the field inverse of an IsZero gadget, "in * inv = 1 - out" — stays out of
         // the sums and is remembered with its row: the verdict lane then hands the deferred kernel the row's small sums and the
         // element's place (a WIDE RECORD) instead of the row — one load there, not a walk through the row's terms
-        const bool wide1 = (z >> 63) && mag == 1ull && idx < T;
+        const bool wide1 = zwide && mag == 1ull && idx < T;
         if (live) {
           if (wide1) atomicAdd(&gwide[mt >> 8], 1u << 24 | (mt & 3u) << 16 | (neg ? 1u << 18 : 0u) | idx);      // (bits 24 up count such terms: the verdict lane takes exactly one)
           else if (!ok) atomicOr(&gflag[mt >> 8], 1u);

@@ -30,4 +30,4 @@ struct B3wField {
 #define B3W_WALK_MAX_UNITS 56u    // units per body at most (the body word of the deferred kernel: one bit a unit, 8 bits for the wide records)
 #define B3W_WALK_MAX_GEN 512u
 #define B3W_WALK_MAX_ENT 4096u
-#define B3W_WALK_WIDE_CAP 128u     // wide records per body (a nova step has 66)
+#define B3W_WALK_WIDE_CAP 224u     // wide records per body (an O2 nova step has 66, the circomkit build 197; the body word counts them in 8 bits)
