@@ -1284,7 +1284,12 @@ static int32_t r1cs_create_impl(b3w_ctx *ctx, const uint8_t *img, size_t len, b3
     }
     up((void **)&r->d_wstatic_k, sk.data(), sk.size() * 4);
     up((void **)&r->d_wstatic_id, sid.data(), sid.size() * 4);
-    r->walk = B3wWalk{H.wunits, H.wexp_slots, H.wmax_gen, H.wmax_ent, r->ncoef, H.wstatic_words, H.wmax_rows, 0u, r->d_wtile, r->d_wmask, r->d_wexp,
+    // SIGNED elements (b3w_r1cs.hip, walk_pack): where the system keeps linear rows — no optimiser has been over it, its bodies hold
+    // small negative numbers as p - k (the circomkit nova build: 121 rows a step over such wires).  2 % slower on bodies that have none,
+    // so an optimised system gets the other instantiation.  B3W_R1CS_SIGNED=0/1 overrides.
+    const char *sg_env = getenv("B3W_R1CS_SIGNED");
+    const uint32_t signed_elems = sg_env ? (atoi(sg_env) ? 1u : 0u) : (H.wlinear_rows >= 64u ? 1u : 0u);
+    r->walk = B3wWalk{H.wunits, H.wexp_slots, H.wmax_gen, H.wmax_ent, r->ncoef, H.wstatic_words, H.wmax_rows, signed_elems, r->d_wtile, r->d_wmask, r->d_wexp,
                       reinterpret_cast<const uint4 *>(r->d_wruns), r->d_wrun_row, r->d_went_w, r->d_went_m, r->d_wrow_id, r->d_wstatic, r->d_coef_small,
                       r->d_wstatic_k, r->d_wstatic_id, (uint32_t)sid.size(), 0u, {sk.empty() ? 0u : sk[0], sk.empty() ? 0u : sk[1], sk.empty() ? 0u : sk[2], sk.empty() ? 0u : sk[3]}, {}};
     memcpy(r->walk.p, H.field.p, 32);

@@ -115,7 +115,7 @@ struct B3wR1csSystem {
 };
 // the WALK kernel's program (b3w_r1cs.hip "WALK kernel", b3w_r1cs_host.h): device pointers
 struct B3wWalk {
-  uint32_t ntiles, exp_slots, max_gen, max_ent, ncoef, static_words, max_rows, pad;
+  uint32_t ntiles, exp_slots, max_gen, max_ent, ncoef, static_words, max_rows, signed_elems;   // signed_elems: the kernel instantiation that takes p - k for -k
   const uint32_t *tile;                  // B3W_WT_WORDS per tile
   const unsigned long long *mask;        // 16 per tile
   const uint16_t *exp;

@@ -1353,11 +1353,12 @@ __global__ __launch_bounds__(64 * B3W_WALK_DEFERRED_WAVES) void b3w_r1cs_walk_de
 // unsigned form sent to the deferred kernel row by row) — or B3W_WALK_WIDE for everything else (a field inverse).  The test for
 // "near p" is one compare of the top limb; the subtraction behind it runs only in a wave that has such an element.
 #define B3W_WALK_WIDE 0x8000000000000000ull
-__device__ __forceinline__ unsigned long long walk_pack(const uint4 lo, const uint4 hi, const uint32_t p[8]) {
+// (p7 = the prime's top limb, a scalar; the whole prime lies in LDS for the rare road: eight more scalars held across the kernel's
+// loop were 30 more scalar spills, 2 % of a nova check)
+__device__ __forceinline__ unsigned long long walk_pack(const uint4 lo, const uint4 hi, const uint32_t p7, const uint32_t *p /* LDS */) {
   const uint32_t wide = lo.z | lo.w | hi.x | hi.y | hi.z | hi.w | (lo.y & 0x80000000u);
-  if (!wide) return (unsigned long long)lo.x | (unsigned long long)lo.y << 32;
-  unsigned long long z = B3W_WALK_WIDE;
-  if (hi.w == p[7]) {                                        // (a lane here is rare in an optimised system's bodies)
+  unsigned long long z = wide ? B3W_WALK_WIDE : (unsigned long long)lo.x | (unsigned long long)lo.y << 32;
+  if (hi.w == p7) {                                          // (ONE branch, and rare in an optimised system's bodies: p - k has the prime's top limb)
     const uint32_t e[8] = {lo.x, lo.y, lo.z, lo.w, hi.x, hi.y, hi.z, hi.w};
     uint32_t d[8], borrow = 0;
 #pragma unroll
@@ -1367,7 +1368,8 @@ __device__ __forceinline__ unsigned long long walk_pack(const uint4 lo, const ui
       borrow = (uint32_t)(t >> 63);
     }
     const unsigned long long k = (unsigned long long)d[0] | (unsigned long long)d[1] << 32;
-    if (!borrow && !(d[2] | d[3] | d[4] | d[5] | d[6] | d[7]) && k != 0ull && k <= (1ull << 62)) z = 0ull - k;      // (k = 0: the element is p itself, no witness value)
+    const bool fits = !borrow && !(d[2] | d[3] | d[4] | d[5] | d[6] | d[7]) && k != 0ull && k <= (1ull << 62);      // (k = 0: the element is p itself, no witness value)
+    z = fits ? 0ull - k : z;
   }
   return z;
 }
@@ -1394,7 +1396,7 @@ __device__ __forceinline__ uint32_t table32(uint32_t table, uint32_t x0, uint32_
   return (x4 & l[1]) | (~x4 & l[0]);
 }
 
-template <int NE, bool STAMPS = false>                       // chunks of 64 general entries a wave takes at most (the tile with most: NE * 512); STAMPS: the diagnostic build's
+template <int NE, bool SIGNED, bool STAMPS = false>          // SIGNED: elements p - k count as -k (walk_pack); chunks of 64 general entries a wave takes at most (the tile with most: NE * 512); STAMPS: the diagnostic build's
 __global__ __launch_bounds__(512, 4) void b3w_r1cs_walk_kernel(const uint8_t *__restrict__ bodies, uint64_t pitch, uint32_t n, B3wWalk W,
                                                                unsigned long long *__restrict__ scratch, uint32_t block_words,
                                                                unsigned long long *__restrict__ body_flags /* per body: bit t = tile t has deferred rows; bits 56 up: wide records */,
@@ -1425,6 +1427,8 @@ __global__ __launch_bounds__(512, 4) void b3w_r1cs_walk_kernel(const uint8_t *__
   uint32_t *ltile = gwide0 + 2u * gr2;
   uint32_t *lanom = ltile + W.ntiles * B3W_WT_WORDS;         // [unit mod 3]
   uint32_t *cnt = lanom + 4;                                 // [body mod 3]: violations, then lowest violated row
+  uint32_t *lprime = cnt + 9;                                // the field's prime (walk_pack)
+  const uint32_t p7 = W.p[7];
   unsigned long long *bflag = dmask0 + 16u;                  // [body mod 3]: tiles with deferred rows
   for (uint32_t k = tid; k < W.ncoef; k += THREADS) lcoef[k] = W.coef_small[k];
   for (uint32_t k = tid; k < W.ntiles * B3W_WT_WORDS; k += THREADS) ltile[k] = W.tile[k];
@@ -1438,6 +1442,7 @@ __global__ __launch_bounds__(512, 4) void b3w_r1cs_walk_kernel(const uint8_t *__
   if (tid < 19) dmask0[tid] = 0ull;                          // (and the body flags)
   if (tid < 4) lanom[tid] = 0u;
   if (tid < 3) { cnt[tid] = 0u; cnt[3 + tid] = 0xFFFFFFFFu; cnt[6 + tid] = 0u; }      // (violations, lowest violated row, wide records)
+  if (tid < 8) lprime[tid] = W.p[tid];
   // this workgroup's bodies: whole ones, contiguous, as even as whole bodies go
   const uint32_t b0 = (uint32_t)((uint64_t)n * blockIdx.x / gridDim.x), b1 = (uint32_t)((uint64_t)n * (blockIdx.x + 1u) / gridDim.x);
   const uint32_t m = (b1 - b0) * W.ntiles;                    // units
@@ -1507,7 +1512,7 @@ __global__ __launch_bounds__(512, 4) void b3w_r1cs_walk_kernel(const uint8_t *__
       const uint32_t g = wave + (uint32_t)q * WAVES, e = g * 64u + lane;
       uint4 lo = rlo[q], hi = rhi[q];
       halves_apart(lo.x, hi.x); halves_apart(lo.y, hi.y); halves_apart(lo.z, hi.z); halves_apart(lo.w, hi.w);
-      const unsigned long long z = e < n_local ? walk_pack(lo, hi, W.p) : 0ull;
+      const unsigned long long z = e < n_local ? (SIGNED ? walk_pack(lo, hi, p7, lprime) : lean_pack(lo, hi)) : 0ull;
       el[e] = z;
       const unsigned long long is1 = __ballot(z == 1ull), bads = __ballot(z > 1ull);
       if (lane == 0) ones[g] = is1;
@@ -1548,9 +1553,7 @@ __global__ __launch_bounds__(512, 4) void b3w_r1cs_walk_kernel(const uint8_t *__
         }
       } else {                                                 // a chunk of terms: element | coefficient id << 16, or element | k << 16 | negative << 22 | 1 << 31 for +-2^k
         const uint32_t idx = live ? w & 0xFFFFu : 0u;
-        const unsigned long long zs = idx < T ? el[idx] : xel[idx - T];      // (signed small, or B3W_WALK_WIDE: walk_pack)
-        const bool zwide = zs == B3W_WALK_WIDE, zneg = !zwide && (long long)zs < 0ll;
-        const unsigned long long z = zneg ? 0ull - zs : zs;     // (its magnitude: at most 2^63 - 1)
+        const unsigned long long z = idx < T ? el[idx] : xel[idx - T];      // (walk_pack: below 2^63 as it stands; bit 63: -k, or B3W_WALK_WIDE)
         unsigned long long mag, lo, hi;
         bool neg, small;
         if (__ballot(live && !(w >> 31)) == 0ull) {            // every term of the chunk shifts (98 % of all terms do; the host puts the others last): no
@@ -1569,16 +1572,28 @@ __global__ __launch_bounds__(512, 4) void b3w_r1cs_walk_kernel(const uint8_t *__
           neg = cf < 0;
           small = cf != B3W_R1CS_NOT_SMALL;
         }
-        neg = neg != zneg;
-        const bool ok = small && !zwide && hi < (1ull << 39);
-        // ONE term +-1 * (a local element of 2^63 or more) — the field inverse of an IsZero gadget, "in * inv = 1 - out" — stays out of
-        // the sums and is remembered with its row: the verdict lane then hands the deferred kernel the row's small sums and the
+        const bool ok = small && !(z >> 63) && hi < (1ull << 39);      // (the road every term of an optimised system's valid body takes)
+        // ONE term +-1 * (a local element that is no small number) — the field inverse of an IsZero gadget, "in * inv = 1 - out" — stays
+        // out of the sums and is remembered with its row: the verdict lane then hands the deferred kernel the row's small sums and the
         // element's place (a WIDE RECORD) instead of the row — one load there, not a walk through the row's terms
-        const bool wide1 = zwide && mag == 1ull && idx < T;
+        const bool wide1 = (SIGNED ? z == B3W_WALK_WIDE : (z >> 63) != 0ull) && mag == 1ull && idx < T;
         if (live) {
           if (wide1) atomicAdd(&gwide[mt >> 8], 1u << 24 | (mt & 3u) << 16 | (neg ? 1u << 18 : 0u) | idx);      // (bits 24 up count such terms: the verdict lane takes exactly one)
-          else if (!ok) atomicOr(&gflag[mt >> 8], 1u);
-          else if (hi == 0ull && lo < (1ull << 54)) atomicAdd(sum, neg ? 0ull - lo : lo);
+          else if (!ok) {
+            // off the road.  With SIGNED elements a NEGATIVE small one (walk_pack: p - k as -k; an unsimplified system's bodies are full
+            // of them) is multiplied again by its magnitude and added with the other sign; everything else marks its row for the
+            // deferred kernel
+            bool negel = false;
+            if constexpr (SIGNED) {
+              const unsigned long long za = 0ull - z;
+              const unsigned long long n_lo = mag * za, n_hi = __umul64hi(mag, za);
+              negel = small && (z >> 63) && z != B3W_WALK_WIDE && n_hi < (1ull << 39);
+              __int128 v = (__int128)(((unsigned __int128)n_hi << 64) | n_lo);
+              if (!neg) v = -v;
+              if (negel) { atomicAdd(sum, (unsigned long long)v & ((1ull << 52) - 1ull)); atomicAdd(sum + 1, (unsigned long long)(long long)(v >> 52)); }
+            }
+            if (!negel) atomicOr(&gflag[mt >> 8], 1u);
+          } else if (hi == 0ull && lo < (1ull << 54)) atomicAdd(sum, neg ? 0ull - lo : lo);
           else {
             __int128 v = (__int128)(((unsigned __int128)hi << 64) | lo);
             if (neg) v = -v;
@@ -2002,7 +2017,7 @@ static inline size_t walk_smem(const B3wWalk *w) {
   const size_t xw = (w->exp_slots >> 6) + 1u, gr2 = (w->max_gen + 1u) & ~1u;
   return 8u * (2u * (size_t)B3W_R1CS_TILE + w->exp_slots + 36u + xw + 12u * (size_t)w->max_gen + 20u + ((w->ncoef + 1u) & ~1u) + 16u * (size_t)w->ntiles +
                (size_t)w->static_words * w->ntiles) +
-         4u * (4u * gr2 + (size_t)w->ntiles * B3W_WT_WORDS + 4u + 9u) + 32u;
+         4u * (4u * gr2 + (size_t)w->ntiles * B3W_WT_WORDS + 4u + 9u + 8u) + 32u;
 }
 extern "C" size_t b3w_r1cs_walk_scratch_bytes(const B3wWalk *w) {      // blocks | body flags | wide records
   return ((size_t)B3W_R1CS_SLAB * w->ntiles * walk_block_words(w) + B3W_R1CS_SLAB + (size_t)B3W_R1CS_SLAB * B3W_WALK_WIDE_CAP * 5u) * 8;
@@ -2018,8 +2033,11 @@ extern "C" int b3w_launch_r1cs_walk(const uint8_t *d_bodies, uint32_t n, uint64_
   if (e != hipSuccess) return (int)e;
   const uint32_t ne = (walk->max_ent + 511u) / 512u;         // entry chunks per wave
   if (ne > 4u || walk->ntiles > 56u) return -6;
-  const void *fn = ne <= 1u ? reinterpret_cast<const void *>(&b3w_r1cs_walk_kernel<1>) : ne == 2u ? reinterpret_cast<const void *>(&b3w_r1cs_walk_kernel<2>)
-                   : ne == 3u ? reinterpret_cast<const void *>(&b3w_r1cs_walk_kernel<3>) : reinterpret_cast<const void *>(&b3w_r1cs_walk_kernel<4>);
+  const bool sg = walk->signed_elems != 0u;
+  const void *fn = sg ? (ne <= 1u ? reinterpret_cast<const void *>(&b3w_r1cs_walk_kernel<1, true>) : ne == 2u ? reinterpret_cast<const void *>(&b3w_r1cs_walk_kernel<2, true>)
+                         : ne == 3u ? reinterpret_cast<const void *>(&b3w_r1cs_walk_kernel<3, true>) : reinterpret_cast<const void *>(&b3w_r1cs_walk_kernel<4, true>))
+                      : (ne <= 1u ? reinterpret_cast<const void *>(&b3w_r1cs_walk_kernel<1, false>) : ne == 2u ? reinterpret_cast<const void *>(&b3w_r1cs_walk_kernel<2, false>)
+                         : ne == 3u ? reinterpret_cast<const void *>(&b3w_r1cs_walk_kernel<3, false>) : reinterpret_cast<const void *>(&b3w_r1cs_walk_kernel<4, false>));
   unsigned long long *d_stamps = nullptr;
 #ifdef B3W_R1CS_DIAG
   // diagnostic build only: B3W_R1CS_STAMPS=1 prints per-phase cycle sums of the middle workgroup after every launch (synchronises)
@@ -2030,14 +2048,15 @@ extern "C" int b3w_launch_r1cs_walk(const uint8_t *d_bodies, uint32_t n, uint64_
     if (hipStreamIsCapturing(stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return (int)hipErrorStreamCaptureUnsupported; }
     if (!d_stamps_buf && hipMalloc((void **)&d_stamps_buf, 8 * 8 * 8) != hipSuccess) d_stamps_buf = nullptr;
     d_stamps = d_stamps_buf;
-    fn = ne <= 1u ? reinterpret_cast<const void *>(&b3w_r1cs_walk_kernel<1, true>) : reinterpret_cast<const void *>(&b3w_r1cs_walk_kernel<3, true>);
+    fn = ne <= 1u ? reinterpret_cast<const void *>(&b3w_r1cs_walk_kernel<1, false, true>) : reinterpret_cast<const void *>(&b3w_r1cs_walk_kernel<3, false, true>);
     if (ne == 2u || ne > 3u) return -6;
   }
 #endif
-  struct PerDevice { int cus = 0, lds = 0; bool attr[4] = {false, false, false, false}; };
+  struct PerDevice { int cus = 0, lds = 0; bool attr[8] = {false, false, false, false, false, false, false, false}; };      // (per instantiation: NE x SIGNED)
   static PerDevice per[64];
   static std::mutex mu;
   const size_t smem = walk_smem(walk);
+  const uint32_t inst = (ne ? ne - 1u : 0u) + (sg ? 4u : 0u);
   int cus = 0, lds = 0;
   {
     std::lock_guard<std::mutex> lock(mu);
@@ -2048,9 +2067,9 @@ extern "C" int b3w_launch_r1cs_walk(const uint8_t *d_bodies, uint32_t n, uint64_
       if (pd.lds < 160 * 1024) pd.lds = 64 * 1024;
     }
     if (smem > (size_t)pd.lds) return -6;
-    if (!pd.attr[ne ? ne - 1u : 0u]) {
+    if (!pd.attr[inst]) {
       if ((e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, pd.lds)) != hipSuccess) return (int)e;
-      pd.attr[ne ? ne - 1u : 0u] = true;
+      pd.attr[inst] = true;
     }
     cus = pd.cus; lds = pd.lds;
   }

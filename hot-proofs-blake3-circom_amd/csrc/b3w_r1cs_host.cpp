@@ -708,6 +708,9 @@ bool b3w_r1cs_host_build(const uint8_t *img, size_t len, const uint8_t prime_le[
       }
       // (a wave reads whole chunks of 64: a lane may read up to 63 entries, descriptors or exports behind its tile's last)
       for (int pad = 0; pad < 64; pad++) { wruns.insert(wruns.end(), {0u, 0u, 0u, 0u}); went_w.push_back(0u); went_m.push_back(4u); wexp.push_back(0); }
+      uint32_t nlin = 0;
+      for (uint32_t k = 0; k < m; k++) if (rows[k].na == 0 || rows[k].nb == 0) nlin++;
+      H->wlinear_rows = nlin;
       H->walk = true; H->wunits = nunits; H->wexp_slots = slots; H->wmax_gen = wmax_gen; H->wmax_ent = wmax_ent; H->wmax_exp = wmax_exp; H->wmax_runs = wmax_runs;
       H->wmax_rows = wmax_rows; H->wstatic_words = sw;
       H->wtile = std::move(wtile); H->wmask = std::move(wmask); H->wexp = std::move(wexp); H->wruns = std::move(wruns);

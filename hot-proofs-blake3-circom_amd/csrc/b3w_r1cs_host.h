@@ -40,6 +40,8 @@ struct B3wR1csHost {
   bool walk = false;                               // the system fits the walk kernel
   uint32_t wunits = 0;                             // UNITS per body: a tile each, but a tile with more than B3W_WALK_SPLIT_GEN general rows is several
                                                    // (B3W_WT_SRC = the tile a unit reads); every "per tile" below is per unit
+  uint32_t wlinear_rows = 0;                       // rows without A or B terms: an optimiser leaves none; an unsimplified system keeps its differences as wires, and
+                                                   // small NEGATIVE values (p - k) with them: the walk kernel then runs its SIGNED instantiation
   uint32_t wexp_slots = 0;                         // export area, in slots (padded)
   uint32_t wmax_gen = 0, wmax_ent = 0, wmax_exp = 0, wmax_runs = 0, wmax_rows = 0, wstatic_words = 0;
   std::vector<uint32_t> wtile;                     // 16 per tile: see B3W_WT_* in b3w_r1cs_defs.h
