@@ -2012,7 +2012,11 @@ struct b3w_chain {
 };
 
 namespace {
-constexpr uint32_t CHAIN_SLICE_CHUNKS = 1024;       // 1 MiB of preimage per H2D slice = 16 384 leaf steps
+// Preimage per H2D slice = leaf steps per plan + witness (+ consumer) round: 1 MiB (16 384 steps) for small preimages, so that the
+// copy of slice i + 1 hides under slice i; an eighth of the local preimage, up to 8 MiB, for large ones — fewer, larger launches and
+// longer stretches in which the commit stream runs beside the witness kernels (64 MiB, profiles/r04/chain_slice_chunks.log: none 9.32
+// -> 9.41, check 4.19 -> 4.22, commit 4.22 -> 4.44 M steps/s).  B3W_CHAIN_SLICE_CHUNKS overrides.
+constexpr uint32_t CHAIN_SLICE_CHUNKS = 1024, CHAIN_SLICE_CHUNKS_MAX = 8192;
 constexpr uint64_t RING_SPARE_CAP = 26ull << 30;    // ring buffers a context keeps between chains: two 16 384-step nova buffers
 
 // roctx ranges around the stages of the chained pass (H2D slice, leaf planning, witness batches, consumer, tree + parent
@@ -2278,7 +2282,8 @@ int32_t b3w_chain_run_leaves(b3w_chain *c, const uint8_t *host_preimage, b3w_bat
   HIP_TRY(ctx, hipEventRecord(c->ev[3], st));
   HIP_TRY(ctx, hipStreamWaitEvent(c->copy, c->ev[3], 0));
   uint32_t slice = 0;
-  static const uint32_t SLICE = getenv("B3W_CHAIN_SLICE_CHUNKS") ? (uint32_t)atoi(getenv("B3W_CHAIN_SLICE_CHUNKS")) : CHAIN_SLICE_CHUNKS;
+  static const uint32_t slice_env = getenv("B3W_CHAIN_SLICE_CHUNKS") ? (uint32_t)std::max(1, atoi(getenv("B3W_CHAIN_SLICE_CHUNKS"))) : 0u;
+  const uint32_t SLICE = slice_env ? slice_env : std::min<uint32_t>(CHAIN_SLICE_CHUNKS_MAX, std::max<uint32_t>(CHAIN_SLICE_CHUNKS, (uint32_t)(c->nl / 8)));
   for (uint32_t s0 = 0; s0 < c->nl; s0 += SLICE, slice++) {
     const uint32_t sc = std::min<uint32_t>(SLICE, c->nl - s0);
     const uint64_t b0 = (c->first_chunk + s0) * 1024, b1 = std::min<uint64_t>(b0 + (uint64_t)sc * 1024, c->len);
