@@ -1253,35 +1253,7 @@ static int32_t r1cs_create_impl(b3w_ctx *ctx, const uint8_t *img, size_t len, b3
     up((void **)&r->d_wrow_id, H.wrow_id.data(), H.wrow_id.size() * 4);
     up((void **)&r->d_wtiles4, H.wtiles4.data(), H.wtiles4.size() * 4);
     up((void **)&r->d_wstatic, H.wstatic.data(), H.wstatic.size() * 8);
-    // The always-deferred rows as a list the deferred kernel walks for every body: per row four words {first pair, pairs, linear, has
-    // C terms}, behind them the rows' UNIQUE terms as pairs {wire, coefficient id | parts << 16} (bit 16 A, 17 B, 18 C).  A term
-    // that stands in several parts with the same coefficient — the always-deferred row of a nova step is X (X - 1) = 0 with an X of
-    // 66 field-sized terms — is multiplied once.
-    std::vector<uint32_t> sk, sid, srows;
-    for (uint32_t t = 0; t < H.wunits; t++)
-      for (uint32_t pos = 0; pos < H.wtiles4[4 * (size_t)t + 1]; pos++)
-        if ((H.wstatic[(size_t)t * H.wstatic_words + (pos >> 6)] >> (pos & 63u)) & 1ull) {
-          srows.push_back(H.wrow_k[H.wtiles4[4 * (size_t)t] + pos]);
-          sid.push_back(H.wrow_id[H.wtiles4[4 * (size_t)t] + pos]);
-        }
-    sk.assign(4 * srows.size(), 0u);
-    for (size_t i = 0; i < srows.size(); i++) {
-      const uint32_t *d = &H.rowdesc[4 * (size_t)srows[i]];
-      const size_t first = sk.size() / 2;
-      std::map<uint64_t, size_t> seen;                       // (wire, coefficient) -> its pair, while no part has it twice
-      uint32_t q = d[0];
-      for (uint32_t part = 0; part < 3; part++)
-        for (uint32_t x = 0; x < d[1 + part]; x++, q++) {
-          const uint64_t key = (uint64_t)H.wires[q] << 16 | H.cids[q];
-          auto it = seen.find(key);
-          if (it != seen.end() && !((sk[it->second + 1] >> (16 + part)) & 1u)) { sk[it->second + 1] |= 1u << (16 + part); continue; }
-          seen[key] = sk.size();
-          sk.push_back(H.wires[q]);
-          sk.push_back((uint32_t)H.cids[q] | 1u << (16 + part));
-        }
-      sk[4 * i] = (uint32_t)first; sk[4 * i + 1] = (uint32_t)(sk.size() / 2 - first);
-      sk[4 * i + 2] = d[1] == 0 || d[2] == 0 ? 1u : 0u; sk[4 * i + 3] = d[3] ? 1u : 0u;
-    }
+    const std::vector<uint32_t> &sk = H.wstatic_list, &sid = H.wstatic_ids;      // (b3w_r1cs_host.h: the always-deferred rows as the deferred kernel walks them)
     up((void **)&r->d_wstatic_k, sk.data(), sk.size() * 4);
     up((void **)&r->d_wstatic_id, sid.data(), sid.size() * 4);
     // SIGNED elements (b3w_r1cs.hip, walk_pack): where the system keeps linear rows — no optimiser has been over it, its bodies hold

@@ -716,6 +716,35 @@ bool b3w_r1cs_host_build(const uint8_t *img, size_t len, const uint8_t prime_le[
       H->wtile = std::move(wtile); H->wmask = std::move(wmask); H->wexp = std::move(wexp); H->wruns = std::move(wruns);
       H->wrun_row = std::move(wrun_row); H->went_w = std::move(went_w); H->went_m = std::move(went_m); H->wrow_k = std::move(wrow_k);
       H->wrow_id = std::move(wrow_id); H->wtiles4 = std::move(wtiles4); H->wstatic = std::move(wstatic);
+      {
+        std::vector<uint32_t> &sk = H->wstatic_list, &sid = H->wstatic_ids, srows;
+        sk.clear(); sid.clear();
+        for (uint32_t u = 0; u < nunits; u++)
+          for (uint32_t pos = 0; pos < H->wtiles4[4 * (size_t)u + 1]; pos++)
+            if ((H->wstatic[(size_t)u * sw + (pos >> 6)] >> (pos & 63u)) & 1ull) {
+              srows.push_back(H->wrow_k[H->wtiles4[4 * (size_t)u] + pos]);
+              sid.push_back(H->wrow_id[H->wtiles4[4 * (size_t)u] + pos]);
+            }
+        sk.assign(4 * srows.size(), 0u);
+        for (size_t i = 0; i < srows.size(); i++) {
+          const Row &r = rows[srows[i]];
+          const uint32_t plen[3] = {r.na, r.nb, r.nc};
+          const size_t first = sk.size() / 2;
+          std::map<uint64_t, size_t> seen;                   // (wire, coefficient) -> its pair, while no part has it twice
+          uint32_t q = r.off;
+          for (uint32_t part = 0; part < 3; part++)
+            for (uint32_t x = 0; x < plen[part]; x++, q++) {
+              const uint64_t key = (uint64_t)wires[q] << 16 | cids[q];
+              auto it = seen.find(key);
+              if (it != seen.end() && !((sk[it->second + 1] >> (16 + part)) & 1u)) { sk[it->second + 1] |= 1u << (16 + part); continue; }
+              seen[key] = sk.size();
+              sk.push_back(wires[q]);
+              sk.push_back((uint32_t)cids[q] | 1u << (16 + part));
+            }
+          sk[4 * i] = (uint32_t)first; sk[4 * i + 1] = (uint32_t)(sk.size() / 2 - first);
+          sk[4 * i + 2] = r.na == 0 || r.nb == 0 ? 1u : 0u; sk[4 * i + 3] = r.nc ? 1u : 0u;
+        }
+      }
     }
   }
   std::vector<uint32_t> coefR(16 * coefs.size());           // per coefficient: plain, then Montgomery form

@@ -53,6 +53,11 @@ struct B3wR1csHost {
   std::vector<uint32_t> wrow_k, wrow_id;           // walk row order -> gather row, -> constraint number in the file
   std::vector<uint32_t> wtiles4;                   // per tile {first row, rows, 0, 0}: the deferred kernel's view of the walk order
   std::vector<unsigned long long> wstatic;         // per tile wstatic_words words: rows that are ALWAYS deferred (bit = row - first)
+  // the same rows as a list the deferred kernel walks for every body: per row four words {first pair, pairs, linear, has C terms},
+  // behind them the rows' UNIQUE terms as pairs {wire, coefficient id | parts << 16} (bit 16 A, 17 B, 18 C) — a term that stands in
+  // several parts with the same coefficient (the always-deferred row of a nova step is X (X - 1) = 0 with an X of 66 field-sized
+  // terms) is multiplied once; and the rows' constraint numbers
+  std::vector<uint32_t> wstatic_list, wstatic_ids;
 };
 
 // false: refused, H->error says why.  May throw std::bad_alloc / std::length_error on absurd sizes (the caller catches).

@@ -186,6 +186,38 @@ static bool walk_ok(const B3wR1csHost &H) {
     }
   }
   CHECK(rows_so_far == H.m && slots_so_far == H.wexp_slots && prev_src + 1u == H.ntiles);
+  // the always-deferred rows as the deferred kernel's list: every row's unique pairs, expanded by their part flags, are the row's terms
+  {
+    std::vector<uint32_t> srows;
+    for (uint32_t u = 0; u < nt; u++)
+      for (uint32_t pos = 0; pos < H.wtiles4[4 * u + 1]; pos++)
+        if ((H.wstatic[(size_t)u * H.wstatic_words + (pos >> 6)] >> (pos & 63u)) & 1ull) srows.push_back(H.wtiles4[4 * u] + pos);
+    const std::vector<uint32_t> &L = H.wstatic_list;
+    CHECK(H.wstatic_ids.size() == srows.size() && L.size() >= 4 * srows.size() && L.size() % 2 == 0);
+    size_t next_pair = 2 * srows.size();
+    for (size_t i = 0; i < srows.size(); i++) {
+      const uint32_t k = H.wrow_k[srows[i]];
+      CHECK(H.wstatic_ids[i] == H.wrow_id[srows[i]]);
+      const uint32_t first = L[4 * i], n = L[4 * i + 1];
+      CHECK(first == next_pair && (size_t)first + n <= L.size() / 2);
+      next_pair += n;
+      const uint32_t *d = &H.rowdesc[4 * (size_t)k];
+      CHECK(L[4 * i + 2] == (d[1] == 0 || d[2] == 0 ? 1u : 0u) && L[4 * i + 3] == (d[3] ? 1u : 0u) && n <= d[1] + d[2] + d[3]);
+      uint32_t q = d[0];
+      for (uint32_t part = 0; part < 3; part++) {
+        std::vector<uint64_t> want, got;
+        for (uint32_t x = 0; x < d[1 + part]; x++, q++) want.push_back((uint64_t)H.wires[q] << 16 | H.cids[q]);
+        for (uint32_t j = first; j < first + n; j++) {
+          const uint32_t w = L[2 * (size_t)j], mt = L[2 * (size_t)j + 1];
+          CHECK(w < H.nwires && (mt & 0xFFFFu) < H.ncoef && !(mt >> 19) && (mt >> 16) != 0);
+          if ((mt >> (16 + part)) & 1u) got.push_back((uint64_t)w << 16 | (mt & 0xFFFFu));
+        }
+        std::sort(want.begin(), want.end()); std::sort(got.begin(), got.end());
+        CHECK(want == got);
+      }
+    }
+    CHECK(next_pair == L.size() / 2);
+  }
   return true;
 }
 
