@@ -1256,11 +1256,14 @@ static int32_t r1cs_create_impl(b3w_ctx *ctx, const uint8_t *img, size_t len, b3
     const std::vector<uint32_t> &sk = H.wstatic_list, &sid = H.wstatic_ids;      // (b3w_r1cs_host.h: the always-deferred rows as the deferred kernel walks them)
     up((void **)&r->d_wstatic_k, sk.data(), sk.size() * 4);
     up((void **)&r->d_wstatic_id, sid.data(), sid.size() * 4);
-    // SIGNED elements (b3w_r1cs.hip, walk_pack): where the system keeps linear rows — no optimiser has been over it, its bodies hold
-    // small negative numbers as p - k (the circomkit nova build: 121 rows a step over such wires).  2 % slower on bodies that have none,
-    // so an optimised system gets the other instantiation.  B3W_R1CS_SIGNED=0/1 overrides.
+    // SIGNED elements (b3w_r1cs_walk.hip, walk_pack): the instantiation that takes an element p - k for the small number -k.  Which
+    // bodies hold such elements is a property of the circuit BUILD the context stands for (a system over this context has its witness
+    // size, so it is checked against this build's bodies, whoever derived it): the circomkit nova build keeps its differences as wires
+    // (121 rows a step over such values); the O2 builds and blake3_compression hold none, and for them the signed instantiation is 1 - 2 %
+    // slower (profiles/r04/walk_ab_signed_elements.log, ab_signed_compression_rocprof.log).  B3W_R1CS_SIGNED=0/1 overrides;
+    // H.wlinear_rows (linear rows: no optimiser has been over the system) is the static hint a foreign build would be judged by.
     const char *sg_env = getenv("B3W_R1CS_SIGNED");
-    const uint32_t signed_elems = sg_env ? (atoi(sg_env) ? 1u : 0u) : (H.wlinear_rows >= 64u ? 1u : 0u);
+    const uint32_t signed_elems = sg_env ? (atoi(sg_env) ? 1u : 0u) : (ctx->desc.kind == B3W_KIND_NOVA_O1 ? 1u : 0u);
     r->walk = B3wWalk{H.wunits, H.wexp_slots, H.wmax_gen, H.wmax_ent, r->ncoef, H.wstatic_words, H.wmax_rows, signed_elems, r->d_wtile, r->d_wmask, r->d_wexp,
                       reinterpret_cast<const uint4 *>(r->d_wruns), r->d_wrun_row, r->d_went_w, r->d_went_m, r->d_wrow_id, r->d_wstatic, r->d_coef_small,
                       r->d_wstatic_k, r->d_wstatic_id, (uint32_t)sid.size(), 0u, {sk.empty() ? 0u : sk[0], sk.empty() ? 0u : sk[1], sk.empty() ? 0u : sk[2], sk.empty() ? 0u : sk[3]}, {}};

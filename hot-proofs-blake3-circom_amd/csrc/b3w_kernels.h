@@ -113,7 +113,7 @@ struct B3wR1csSystem {
   const unsigned long long *smask;                 // per tile x smask_groups: elements the tile's rows take for bits
   const unsigned long long *scost;                 // ntiles + 1 prefix sums of the tiles' relative unit costs
 };
-// the WALK kernel's program (b3w_r1cs.hip "WALK kernel", b3w_r1cs_host.h): device pointers
+// the WALK kernel's program (b3w_r1cs_walk.hip, b3w_r1cs_host.h): device pointers
 struct B3wWalk {
   uint32_t ntiles, exp_slots, max_gen, max_ent, ncoef, static_words, max_rows, signed_elems;   // signed_elems: the kernel instantiation that takes p - k for -k
   const uint32_t *tile;                  // B3W_WT_WORDS per tile

@@ -270,7 +270,7 @@ def test_nova_o2_builds_on_the_device(circuit):
 def test_wide_elements_of_a_nova_step_tampered(circuit):
     """The rows the stream kernel defers in a VALID nova step are those over full field elements: the 67 IsZero gadgets'
     `in * inv = 1 - out` and `in * out = 0` (in = depth - i and the like, a small signed number; inv a 254-bit inverse).  The deferred
-    kernel decides (small signed) x (field element) = c without a field multiplication (small_product_is, csrc/b3w_r1cs.hip).  Every
+    kernel decides (small signed) x (field element) = c without a field multiplication (small_product_is, csrc/b3w_r1cs_device.h).  Every
     wide slot of a step witness is changed in several ways — neighbours, 0, 1, -1, another gadget's inverse, the edges of "small"
     (2^32 - 1, 2^32, p - 2^32 + 1, p - 2^32), random — and count and first violated row must equal the plain-integer evaluation."""
     import torch
@@ -316,7 +316,7 @@ def test_wide_elements_of_a_nova_step_tampered(circuit):
 
 
 def test_gather_kernel_gives_the_same_verdicts(tmp_path):
-    """csrc/b3w_r1cs.hip has four formulations with the same verdicts: the walk kernel (default since round 4: a workgroup walks whole
+    """csrc/b3w_r1cs_walk.hip and b3w_r1cs.hip hold four formulations with the same verdicts: the walk kernel (default since round 4: a workgroup walks whole
     bodies, earlier tiles' wires come from an export area in LDS, truth-table rows in runs), the stream kernel (B3W_R1CS_GATHER=4:
     tile-major units, outside wires gathered), the lean pair (B3W_R1CS_GATHER=3: 8-byte elements and integer sums in LDS, deferred rows
     by field arithmetic) and the gather kernel (any system; B3W_R1CS_GATHER=1).  Child processes run each over the same clean and
@@ -358,7 +358,10 @@ print(json.dumps(out))
 '''
     res = {}
     for mode, extra in (("0", {}), ("1", {}), ("3", {}), ("4", {}), ("4/16waves", {"B3W_R1CS_WAVES": "16"}), ("4/grid7", {"B3W_R1CS_GRID": "7"}),
-                        ("0/grid7", {"B3W_R1CS_GRID": "7"}), ("0/grid1", {"B3W_R1CS_GRID": "1"})):
+                        ("0/grid7", {"B3W_R1CS_GRID": "7"}), ("0/grid1", {"B3W_R1CS_GRID": "1"}),
+                        # the walk kernel's two instantiations, each for every circuit (by default the circomkit build takes the signed one — small
+                        # negative numbers p - k count as -k — and the others the unsigned one)
+                        ("0/signed", {"B3W_R1CS_SIGNED": "1"}), ("0/unsigned", {"B3W_R1CS_SIGNED": "0"})):
         r = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, cwd=T.ROOT, timeout=600,
                            env=dict(os.environ, B3W_R1CS_GATHER=mode.split("/")[0], **extra))
         assert r.returncode == 0, r.stderr[-1500:]
