@@ -659,6 +659,20 @@ def main():
     if world > 1 and args.exchange != "none":               # the gathered buffer of the last launch: every rank's outputs
         assert allpub.shape == (world * n, npub) and int((allpub[:, :npub].abs().sum(dim=1) == 0).sum().item()) == 0
         assert torch.equal(allpub[rank * n:(rank + 1) * n], ex.bufs[ex.last]), "this rank's share of the gathered outputs differs from what it sent"
+        # ... and the OTHER ranks' shares against what this rank computes itself for their first records (the inputs are a function of the
+        # global index): the first run on a real node is the first time a block crosses xGMI — it is checked, not assumed
+        k = min(64, n)
+        d_k_bodies = torch.empty(k * ctx.body_bytes, dtype=torch.uint8, device=dev)
+        d_k_pub = torch.zeros((k, npub), dtype=torch.int32, device=dev)
+        d_k_status = torch.zeros(k, dtype=torch.int32, device=dev)
+        for q in range(world):
+            if q == rank:
+                continue
+            rq = W.config2_compression(k, first=q * n) if circuit == "compression" else W.config3_nova(k, first=q * n)
+            d_rq = torch.from_numpy(rq.view(np.int32)).to(dev)
+            ctx.run_device(d_rq.data_ptr(), k, d_k_bodies.data_ptr(), 0, d_k_pub.data_ptr(), d_k_status.data_ptr(), stream.cuda_stream)
+            torch.cuda.synchronize()
+            assert torch.equal(allpub[q * n:q * n + k, :npub].to(torch.int32), d_k_pub), f"rank {q}'s share of the gathered outputs is not what its inputs give"
     # untimed: every body of the last launch is checked on the device: the rank-1 constraint check
     # Az*Bz = Cz with the constraint system derived from the circuit text where there is one (blake3_compression), and the
     # recompute-and-compare tamper check
