@@ -317,6 +317,13 @@ def bench_chain(args, m, torch, dist, dev, world, rank, local_rank):
             assert torch.equal(h_all[c0 * 16 + 15:(c0 + full) * 16:16], out["chunk_cvs_local"][:full]), "gathered h_out of step 16c+15 is not chunk c's chaining value"
         if world > 1:
             assert int((h_all.abs().sum(dim=1) == 0).sum().item()) == 0, "rows of another rank are missing from the gathered h_out"
+            # every rank has checked its OWN rows against its planner; the same array (and the same root, built from the gathered chunk
+            # CVs) on every rank then means every rank holds every other rank's rows as that rank computed them
+            w64 = h_all.to(torch.int64) & 0xFFFFFFFF
+            pos = (torch.arange(h_all.shape[0], device=dev, dtype=torch.int64) % 65521 + 1).unsqueeze(1)
+            sig = f"{int(w64.sum().item())}:{int((w64 * pos).sum().item())}:{out['root'].cpu().tolist()}"
+            sigs = gather_strings(dist, world, sig)
+            assert len(set(sigs)) == 1, f"the ranks disagree about the gathered h_out or the root: {sigs}"
     # untimed: one more pass over the first MiB (at most) of the preimage whose consumer checks EVERY step witness against the
     # step circuit's rank-1 constraints while it sits in the ring
     verification = "none"
