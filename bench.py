@@ -13,7 +13,8 @@ public outputs over RCCL after every launch, pipelined with the next launch.
 
 Prints ONE JSON line on rank 0 (see the driver contract) with `roofline` (HBM-write bound kernel: algorithmic
 bytes / HIP-event kernel time) and, at N = 1, `cpu_baseline` (the C oracle timed on all host cores on a bounded
-sample of the same workload, with the reference WASM's rate quoted beside it).
+sample of the same workload, with the reference WASM's all-core rate beside it: live when --reference-dir holds the
+reference, else as recorded in the build container by tools/wasm_baseline.py).
 """
 import argparse
 import contextlib
@@ -27,8 +28,30 @@ HBM_PEAK_GBS = 8000.0      # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (about 6.3 T
 BYTES_PER_WITNESS = {"compression": 770976 + 112, "nova_bn254": 745312 + 128, "nova_vesta": 745312 + 128,
                      "nova_bn254_o1": 787648 + 128}   # body written + record read
 FIELD = {"compression": "BN254", "nova_bn254": "BN254", "nova_vesta": "Vesta", "nova_bn254_o1": "BN254"}
-# BASELINE.md section 2 (survey session, build container, reference WASM under its own witness_calculator.js)
-REFERENCE_WASM = {"compression": 5.0, "nova_vesta": 4.7, "nova_bn254": 5.3}
+
+
+def reference_wasm(circuit, reference_dir, seconds):
+    """The reference's own WASM witness generator beside the GPU number: run live through tools/wasm_baseline.py
+    — one node process per core looping the reference's calculateWTNSBin — when `reference_dir` holds the reference (it cannot
+    travel to the GPU box, so that is the build container); otherwise the rates recorded there by the same tool
+    (profiles/wasm_baseline.json), and the line says which."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    try:
+        import wasm_baseline as WB
+        if seconds > 0 and circuit in WB.WASM and WB.available(reference_dir):
+            r = WB.measure(circuit, reference_dir, seconds)
+            return {"value": r["value"], "unit": "witnesses/s", "cores": r["cores"], "per_core": r["per_core"], "cpu": r["cpu"], "node": r["node"],
+                    "measured_here": True, "sample": r["sample"], "where": f"this host, reference at {reference_dir}"}
+    except Exception as e:                                     # a baseline leg never fails the bench
+        print(f"bench.py: live WASM baseline failed ({e}); quoting the recorded one", file=sys.stderr)
+    try:
+        doc = json.load(open(os.path.join(ROOT, "profiles", "wasm_baseline.json")))
+        r = doc["circuits"][circuit]
+        return {"value": r["value"], "unit": "witnesses/s", "cores": r["cores"], "per_core": r["per_core"], "cpu": r["cpu"], "node": r["node"],
+                "measured_here": False, "sample": r["sample"],
+                "where": f"{doc['where']}, {doc['measured']}, profiles/wasm_baseline.json ({doc['tool']}); no reference checkout at {reference_dir} on this host"}
+    except Exception:
+        return None
 
 
 def self_launch(n, argv, launch_timeout):
@@ -132,7 +155,7 @@ def cpu_model():
     return "unknown"
 
 
-def cpu_baseline(circuit, recs, budget_s):
+def cpu_baseline(circuit, recs, budget_s, reference_dir="/root/reference", reference_s=10.0):
     """Time the oracle (oracle/libb3w_oracle.so, the CPU restatement = "port") on ALL host cores this process may
     use, over a bounded sample of the same records.  Checker code, used here only as the reported baseline; the
     reference WASM cannot travel to the GPU box, so its build-container rate is quoted."""
@@ -175,10 +198,9 @@ def cpu_baseline(circuit, recs, budget_s):
            "per_core": total / dt / cores, "cpu_quota": quota,
            "sample": f"{total} witnesses in {dt:.1f} s: {cores} threads, each a cache-resident {k}-record loop (the first {k} records "
                      f"of the workload, rewriting one 12 MB block of bodies in place), C oracle (oracle/b3w_oracle.c)"}
-    if circuit in REFERENCE_WASM:
-        out["reference_wasm"] = {"value": REFERENCE_WASM[circuit], "unit": "witnesses/s/core", "measured_here": False,
-                                 "where": "build container (Xeon 2.1 GHz, node 12), BASELINE.md section 2: the reference's "
-                                          "committed WASM under its own witness_calculator.js; it cannot travel to the GPU box"}
+    ref = reference_wasm(circuit, reference_dir, reference_s)
+    if ref is not None:
+        out["reference_wasm"] = ref
     return out
 
 
@@ -226,7 +248,9 @@ def placement_cost(ctx, before=None):
             c[k] -= before[k]
     return {"placement_search_s": round(c["search_s"], 3), "placement_search_gib_walked": round(c["search_gib_walked"], 2),
             "placement_check_s": round(c["check_s"], 3), "placement_search_timeouts": int(c["search_timeouts"]),
-            "placement_search_limit_s": c["search_limit_s"]}
+            "placement_search_limit_s": c["search_limit_s"],
+            "placement_search_breakdown_s": {"hipMemCreate": round(c["create_s"], 3), "map": round(c["map_s"], 3), "probes": round(c["probe_s"], 3),
+                                             "release": round(c["release_s"], 3)}}
 
 
 def gather_strings(dist, world, s):
@@ -245,16 +269,12 @@ def bench_chain(args, m, torch, dist, dev, world, rank, local_rank):
     ctx = m.Context(circuit, local_rank)
     nbytes = int(args.preimage_mib * (1 << 20))
     host = torch.from_numpy(m.workloads.lcg_preimage(nbytes, seed=1).copy()).pin_memory()
-    consumer, key, commit_only, commit_records, r1cs_t, d_viol_t = None, None, None, None, None, None
+    consumer, key, commit_only, commit_records, r1cs_t = None, None, None, None, None
     n_max = m.lib().b3w_chain_num_chunks(nbytes) * 64 + 64
     if "check" in args.consumer:                     # SURVEY.md 8(f) row 2, first half: Az * Bz = Cz for every step witness, timed
         if circuit not in m.BUILTIN_R1CS:
             raise SystemExit(f"bench.py: no constraint system for {circuit}")
-        r1cs_t = m.R1cs(ctx)
-        d_viol_t = torch.zeros(n_max, dtype=torch.int32, device=dev)
-
-        def consumer(view, first, k):
-            r1cs_t.check_device(view.data_ptr(), k, view.stride(0), d_viol_t.data_ptr() + 4 * first, 0, torch.cuda.current_stream().cuda_stream)
+        r1cs_t = m.R1cs(ctx)                         # the chain checks every batch itself (b3w_chain_check_constraints): fold_witnesses(check=)
     if "commit" in args.consumer:                    # second half: what the folding prover does with each step witness
         K = importlib.import_module("hot-proofs-blake3-circom_amd.synthetic_key")
         curve = "vesta" if "vesta" in circuit else "bn254_g1"
@@ -263,24 +283,19 @@ def bench_chain(args, m, torch, dist, dev, world, rank, local_rank):
         key = m.CommitKey(ctx, curve, K.generators(curve, ctx.witness_size, seed=b"bench"), fold=True if circuit in m.BUILTIN_R1CS else None)
         d_pts = torch.zeros((n_max, 64), dtype=torch.uint8, device=dev)
         d_st = torch.zeros(n_max, dtype=torch.int32, device=dev)
-        check_first = consumer
-
-        def consumer(view, first, k):
-            if check_first is not None:
-                check_first(view, first, k)
-            key.commit_device(view.data_ptr(), k, view.stride(0), d_pts.data_ptr() + 64 * first, d_st.data_ptr() + 4 * first,
-                              torch.cuda.current_stream().cuda_stream)
         if args.consumer == "commit-only":
-            consumer, commit_only = None, (key, d_pts)
-        elif "bodies" not in args.consumer:                 # commit / check+commit: the commitments come from the step records, the check reads the bodies
-            consumer, commit_records = check_first, (key, d_pts)
-            # (the commitments get a stream of their own beside the witness kernels — not beside the constraint check, which this
-            # harness runs from its consumer callback where the library cannot see it: include/b3wit.h, b3w_chain_commit_from_records)
-            os.environ.setdefault("B3W_CHAIN_COMMIT_ASYNC", "0" if check_first is not None else "1")
+            commit_only = (key, d_pts)
+        elif "bodies" not in args.consumer:          # commit / check+commit: the commitments come from the step records, beside the bodies
+            commit_records = (key, d_pts)
+        else:                                        # commit-bodies: the kernel that READS the bodies (foreign bodies), behind the check
+            def consumer(view, first, k):
+                key.commit_device(view.data_ptr(), k, view.stride(0), d_pts.data_ptr() + 64 * first, d_st.data_ptr() + 4 * first,
+                                  torch.cuda.current_stream().cuda_stream)
     # the fold's exchange (N > 1) is part of every pass: chunk chaining values, then every step's h_out (BASELINE config 4)
     comm = native_comm(m, ctx, dist, world, rank, "chain") if (world > 1 and args.exchange_impl == "native") else None
     run = lambda: m.chain.fold_witnesses(ctx, host, batch_steps=args.batch if args.batch != 4096 else 16384, ring=2, consumer=consumer,
-                                         commit_only=commit_only, commit_records=commit_records, gather_hout=args.exchange != "none", comm=comm)
+                                         commit_only=commit_only, commit_records=commit_records, gather_hout=args.exchange != "none", comm=comm,
+                                         check=r1cs_t, commit_overlap=args.commit_overlap)
     t_first = time.perf_counter()
     for i in range(max(3, args.warmup)):        # the first passes pay the allocator (24 GB ring, record buffers)
         out = run()
@@ -345,8 +360,17 @@ def bench_chain(args, m, torch, dist, dev, world, rank, local_rank):
         r1cs.close()
     if key is not None:
         assert int(d_st[:local_steps].abs().sum().item()) == 0 and int(d_pts[:local_steps].max(dim=1).values.min().item()) > 0
+        if commit_records is not None and r1cs_t is not None:
+            # the commitments of the fold-shaped pass against the kernel that READS bodies: the first 256 leaf steps' bodies, regenerated
+            kk = min(256, local_steps)
+            d_b = torch.empty((kk, ctx.body_bytes), dtype=torch.uint8, device=dev)
+            d_p2 = torch.zeros((kk, 64), dtype=torch.uint8, device=dev)
+            ctx.run_device(out["records"].data_ptr(), kk, d_b.data_ptr(), 0, 0, 0, torch.cuda.current_stream().cuda_stream)
+            key.commit_device(d_b.data_ptr(), kk, ctx.body_bytes, d_p2.data_ptr(), 0, torch.cuda.current_stream().cuda_stream)
+            torch.cuda.synchronize()
+            assert torch.equal(d_p2, d_pts[:kk]), "commitments from the records differ from commitments of the bodies"
     if r1cs_t is not None:
-        assert int(d_viol_t[:local_steps].abs().sum().item()) == 0, "a step witness violates the step circuit's rank-1 constraints"
+        assert int(out["violations"][:local_steps].abs().sum().item()) == 0, "a step witness violates the step circuit's rank-1 constraints"
         verification = f"r1cs, inside the timed pass: 0 of {r1cs_t.n_constraints} constraints violated by any of {local_steps} step witnesses (rank 0's share)"
     t = torch.tensor([elapsed, float(local_steps)], dtype=torch.float64, device=dev)
     if world > 1:
@@ -389,7 +413,7 @@ def bench_chain(args, m, torch, dist, dev, world, rank, local_rank):
     cpu = None
     if rank == 0 and world == 1 and args.cpu_seconds > 0:
         import numpy as np
-        cpu = cpu_baseline(circuit, recs16.view(np.uint32), args.cpu_seconds)
+        cpu = cpu_baseline(circuit, recs16.view(np.uint32), args.cpu_seconds, args.reference_dir, args.reference_seconds)
     if rank == 0:
         line = {
             "metric": "BLAKE3-compression witnesses/sec", "value": total_steps * args.steps / elapsed, "unit": "witnesses/s",
@@ -410,6 +434,7 @@ def bench_chain(args, m, torch, dist, dev, world, rank, local_rank):
                        "exchange_ms_per_rank": {"chunk_cvs": [x[0] for x in ex_all], "h_out": [x[1] for x in ex_all],
                                                 "what": "HIP events on the compute stream around staging + collective + scatter, last timed pass"},
                        "pass_ms_per_rank": pass_ms, "first_pass_s": round(first_pass_s, 3), **place_cost,
+                       "commit_overlap": args.commit_overlap if commit_records is not None else None,
                        "consumer": " then ".join(
                            ([f"rank-1 constraint check of every step witness on the device ({r1cs_t.n_constraints} constraints)"] if r1cs_t is not None else []) +
                            ([f"Pedersen commitment of every step witness on the device ({key.window}-bit windows, {key.folded_slots} slots folded)"
@@ -438,6 +463,11 @@ def main():
     ap.add_argument("--variant", type=int, default=None, help="kernel tuning variant (B3W_VARIANT)")
     ap.add_argument("--pitch", type=int, default=0, help="body pitch in bytes (0 = contiguous bodies)")
     ap.add_argument("--cpu-seconds", type=float, default=5.0, help="budget of the cpu_baseline leg (0 = skip)")
+    ap.add_argument("--reference-dir", default="/root/reference",
+                    help="cpu_baseline: where the reference checkout lies.  When it is there (the build container) its WASM witness generator "
+                         "is timed live on all host cores (tools/wasm_baseline.py); when not (the GPU box: the reference cannot travel) the "
+                         "rates recorded by the same tool in profiles/wasm_baseline.json are quoted, and the line says so")
+    ap.add_argument("--reference-seconds", type=float, default=10.0, help="budget of that live leg (0 = always quote the recorded rates)")
     ap.add_argument("--placement", default="mixed", choices=["mixed", "plain"],
                     help="body buffer placement: mixed = b3w_bodies_alloc's two-class buffer (default), plain = hipMalloc")
     ap.add_argument("--workload", default="batch", choices=["batch", "chain"],
@@ -450,6 +480,10 @@ def main():
                          "(synthetic generators) computed from the step records beside the bodies (b3w_chain_commit_from_records: the "
                          "fold-shaped pass); commit-only = the same commitments, no bodies written; check+commit = both; "
                          "commit-bodies / check+commit-bodies = the commitment kernel that READS the bodies (for bodies the library did not make)")
+    ap.add_argument("--commit-overlap", default="auto", choices=["auto", "serial", "free", "gated"],
+                    help="chain workload, commit / check+commit: where the commitments from the records run (b3w_chain_commit_overlap): on the "
+                         "caller's stream, free on the chain's commit stream, or gated to the batch's own witness kernel; auto = gated when a "
+                         "check or consumer reads the batch, else free")
     ap.add_argument("--exchange", default="every", choices=["every", "last", "none"],
                     help="N > 1: the fold's exchange inside the timed region.  batch workload: all-gather of the public outputs "
                          "after EVERY launch (default; pipelined with the next launch), after the LAST launch only, or not at all — "
@@ -460,8 +494,11 @@ def main():
                          "native = the C-ABI's own b3w_comm (RCCL through librccl under nccl; the host shared-memory transport under "
                          "B3W_DIST_BACKEND=gloo, several ranks on one GPU): b3w_chain_run_parents_sharded + b3w_chain_allgather_hout in the "
                          "chain workload, b3w_comm_allgather of the public outputs in the batch workload")
-    ap.add_argument("--placement-search-s", type=float, default=30.0,
-                    help="time limit of the placement allocator's search for a second class of HBM (then the buffer is plain and says so)")
+    ap.add_argument("--placement-search-s", type=float, default=-1.0,
+                    help="time limit of the placement allocator's search for a second class of HBM (then the buffer is plain and says so); "
+                         "default: the library's own (b3w_bodies_search_limit)")
+    ap.add_argument("--placement-search-gib", type=int, default=-1,
+                    help="GiB of new memory a placement search may touch beyond the buffer; default: the library's own (b3w_bodies_configure)")
     ap.add_argument("--launch-timeout", type=float, default=120.0,
                     help="N > 1: seconds every rank has to pass rendezvous (process group + first barrier), counted from the moment "
                          "the first rank has imported torch; also the process group's own timeout.  0 = no watchdog")
@@ -533,10 +570,11 @@ def main():
         os.environ["B3W_PLACEMENT"] = "plain"
     m = importlib.import_module("hot-proofs-blake3-circom_amd")
     W = m.workloads
-    # the bench owns its GPU: let the placement search walk as far as it may (the library's default is bounded to 16 x the
-    # buffer so that co-resident allocators are not starved; the first class border of a fresh device can lie 64 GiB in)
-    m.lib().b3w_bodies_configure(160, -1)
-    m.lib().b3w_bodies_search_limit(args.placement_search_s)
+    # placement runs on the LIBRARY's defaults (what an integrator of the C-ABI gets); --placement-search-gib / -s are experiments
+    if args.placement_search_gib >= 0:
+        m.lib().b3w_bodies_configure(args.placement_search_gib, -1)
+    if args.placement_search_s >= 0:
+        m.lib().b3w_bodies_search_limit(args.placement_search_s)
     if args.workload == "chain":
         return bench_chain(args, m, torch, dist, dev, world, rank, local_rank)
     circuit, n = args.circuit, args.batch
@@ -697,6 +735,24 @@ def main():
         verified = f"r1cs: 0 of {r1cs.n_constraints} constraints violated by any of the {n} bodies; " + verified
         r1cs.close()
 
+    # untimed, N = 1: (1) the same kernel, same variant, on a plain hipMalloc buffer — what a caller who brings its own buffer gets;
+    # (2) the pure-store ceilings of both buffers (b3w_bodies_store_rate: nothing but the stores, in the witness kernels' two shapes):
+    # what `achieved` is a fraction of on THIS chip, next to the 8 TB/s of the data sheet.  (The bodies are overwritten: checks are done.)
+    plain, ceiling = None, None
+    if world == 1:
+        d_plain = torch.empty(n * pitch, dtype=torch.uint8, device=dev)
+        ctx.time_device(d_recs.data_ptr(), n, d_plain.data_ptr(), pitch, d_pub.data_ptr(), d_status.data_ptr(), stream.cuda_stream, 5)
+        ms_plain = ctx.time_device(d_recs.data_ptr(), n, d_plain.data_ptr(), pitch, d_pub.data_ptr(), d_status.data_ptr(), stream.cuda_stream, 20)
+        ach_plain = BYTES_PER_WITNESS[circuit] * n / (ms_plain * 1e-3) / 1e9
+        plain = {"kernel_ms": ms_plain, "achieved": ach_plain, "frac": ach_plain / HBM_PEAK_GBS, "launches": 20,
+                 "buffer": "torch.empty = hipMalloc, same records, same kernel variant, after the timed region"}
+        shapes = {"streams_w4": 0, "streams_w8": 1, "fill": 2}
+        ceiling = {"unit": "GB/s", "what": "b3w_bodies_store_rate: 20 passes of store-only kernels over the same n bodies — body streams (one wave per "
+                                            "4 / 8 bodies, 1 KiB per body and step: the fused kernels' store shape) and the runtime's fill shape",
+                   "placed": {k: ctx.store_rate(d_bodies.data_ptr(), n, pitch, v, 20, stream.cuda_stream) for k, v in shapes.items()},
+                   "plain": {k: ctx.store_rate(d_plain.data_ptr(), n, pitch, v, 20, stream.cuda_stream) for k, v in shapes.items()}}
+        del d_plain
+
     t = torch.tensor([elapsed, kern_ms], dtype=torch.float64, device=dev)
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -774,8 +830,14 @@ def main():
                          "kernel_ms": kern_ms, "kernel_ms_per_rank": kern_per_rank, "kernel_ms_min": min(kern_per_rank),
                          "kernel_ms_max": max(kern_per_rank), "algorithmic_bytes_per_launch": alg_bytes, "launches_timed": launches},
         }
+        if plain is not None:
+            best = max(ceiling["placed"].values())
+            out["roofline"]["plain"] = plain
+            out["roofline"]["store_ceiling"] = ceiling
+            out["roofline"]["of_measured_ceiling"] = achieved / best       # of the best store-only shape on the SAME (placed) buffer
+            out["roofline"]["plain_of_measured_ceiling"] = plain["achieved"] / max(ceiling["plain"].values())
         if args.cpu_seconds > 0 and world == 1:
-            out["cpu_baseline"] = cpu_baseline(circuit, recs, args.cpu_seconds)
+            out["cpu_baseline"] = cpu_baseline(circuit, recs, args.cpu_seconds, args.reference_dir, args.reference_seconds)
         print(json.dumps(out), flush=True)
     if comm is not None:
         comm.close()

@@ -106,6 +106,8 @@ def lib():
         "b3w_bodies_stats": (i32, [vp, vp]),
         "b3w_bodies_search_stats": (i32, [vp, ctypes.POINTER(ctypes.c_double)]),
         "b3w_bodies_search_limit": (None, [ctypes.c_double]),
+        "b3w_bodies_search_breakdown": (i32, [vp, ctypes.POINTER(ctypes.c_double)]),
+        "b3w_bodies_store_rate": (i32, [vp, vp, u32, u64, i32, u32, vp, ctypes.POINTER(ctypes.c_double)]),
         "b3w_batch_placement": (i32, [vp]),
         "b3w_chain_num_chunks": (u64, [u64]),
         "b3w_chain_num_leaf_steps": (u64, [u64]),
@@ -128,6 +130,8 @@ def lib():
         "b3w_commit_records": (i32, [vp, vp, vp, u32, vp, vp, vp]),
         "b3w_chain_commit_only": (i32, [vp, vp, vp]),
         "b3w_chain_commit_from_records": (i32, [vp, vp, vp]),
+        "b3w_chain_commit_overlap": (i32, [vp, i32]),
+        "b3w_chain_violations_device": (vp, [vp]),
         "b3w_chain_commitments": (i32, [vp, vp, vp]),
         "b3w_chain_check_constraints": (i32, [vp, vp]),
         "b3w_chain_violations": (i32, [vp, vp, vp]),
@@ -172,10 +176,10 @@ EXPORTED_SYMBOLS = ("b3w_abi_version", "b3w_identify_wasm", "b3w_create", "b3w_d
                     "b3w_batch_run_device", "b3w_public_words", "b3w_batch_alloc", "b3w_batch_free",
                     "b3w_batch_run", "b3w_batch_outputs", "b3w_batch_fetch", "b3w_batch_device_ptr",
                     "b3w_batch_time_device", "b3w_batch_verify_device", "b3w_batch_verify",
-                    "b3w_r1cs_create", "b3w_r1cs_info", "b3w_r1cs_is_tiled", "b3w_r1cs_destroy", "b3w_r1cs_check_device", "b3w_batch_r1cs_check", "b3w_r1cs_consumer", "b3w_batch_write_wtns", "b3w_batch_write_wtns_ex", "b3w_batch_autotune_device", "b3w_bodies_alloc", "b3w_bodies_free", "b3w_bodies_trim", "b3w_ctx_trim", "b3w_bodies_configure", "b3w_bodies_stats", "b3w_bodies_search_stats", "b3w_bodies_search_limit", "b3w_batch_placement", "b3w_chain_num_chunks", "b3w_chain_num_leaf_steps", "b3w_chain_path_len",
+                    "b3w_r1cs_create", "b3w_r1cs_info", "b3w_r1cs_is_tiled", "b3w_r1cs_destroy", "b3w_r1cs_check_device", "b3w_batch_r1cs_check", "b3w_r1cs_consumer", "b3w_batch_write_wtns", "b3w_batch_write_wtns_ex", "b3w_batch_autotune_device", "b3w_bodies_alloc", "b3w_bodies_free", "b3w_bodies_trim", "b3w_ctx_trim", "b3w_bodies_configure", "b3w_bodies_stats", "b3w_bodies_search_stats", "b3w_bodies_search_limit", "b3w_bodies_search_breakdown", "b3w_bodies_store_rate", "b3w_batch_placement", "b3w_chain_num_chunks", "b3w_chain_num_leaf_steps", "b3w_chain_path_len",
                     "b3w_chain_num_parent_steps", "b3w_chain_parent_row", "b3w_chain_path_provable",
                     "b3w_chain_plan_leaves_device", "b3w_chain_tree_device", "b3w_chain_plan_parents_device",
-                    "b3w_commit_key_create", "b3w_commit_key_create_ex", "b3w_commit_key_create_folded", "b3w_slot_widths", "b3w_commit_key_window", "b3w_commit_key_destroy", "b3w_commit_key_count", "b3w_commit_key_counts", "b3w_commit_records_device", "b3w_commit_records", "b3w_chain_commit_only", "b3w_chain_commit_from_records", "b3w_chain_commitments", "b3w_chain_check_constraints", "b3w_chain_violations", "b3w_batch_commit_device", "b3w_batch_commit", "b3w_commit_consumer",
+                    "b3w_commit_key_create", "b3w_commit_key_create_ex", "b3w_commit_key_create_folded", "b3w_slot_widths", "b3w_commit_key_window", "b3w_commit_key_destroy", "b3w_commit_key_count", "b3w_commit_key_counts", "b3w_commit_records_device", "b3w_commit_records", "b3w_chain_commit_only", "b3w_chain_commit_from_records", "b3w_chain_commit_overlap", "b3w_chain_violations_device", "b3w_chain_commitments", "b3w_chain_check_constraints", "b3w_chain_violations", "b3w_batch_commit_device", "b3w_batch_commit", "b3w_commit_consumer",
                     "b3w_comm_unique_id", "b3w_comm_create", "b3w_comm_create_host", "b3w_comm_create_external", "b3w_comm_rank", "b3w_comm_size", "b3w_comm_destroy", "b3w_comm_allgather", "b3w_batch_allgather_public",
                     "b3w_chain_create", "b3w_chain_destroy", "b3w_chain_run_leaves", "b3w_chain_run_parents", "b3w_chain_shard", "b3w_chain_run_parents_sharded", "b3w_chain_allgather_hout", "b3w_chain_allgather_hout_host", "b3w_chain_exchange_ms", "b3w_chain_info",
                     "b3w_chain_outputs", "b3w_chain_records", "b3w_chain_public", "b3w_chain_status", "b3w_chain_local_cvs", "b3w_chain_root")
@@ -309,7 +313,19 @@ class Context:
         """What placement has cost on this context's device so far (b3w_bodies_search_stats)."""
         out = (ctypes.c_double * 5)()
         self._lib.b3w_bodies_search_stats(self.handle, out)
-        return dict(search_s=out[0], search_gib_walked=out[1], search_timeouts=int(out[2]), search_limit_s=out[3], check_s=out[4])
+        bd = (ctypes.c_double * 4)()
+        self._lib.b3w_bodies_search_breakdown(self.handle, bd)
+        return dict(search_s=out[0], search_gib_walked=out[1], search_timeouts=int(out[2]), search_limit_s=out[3], check_s=out[4],
+                    create_s=bd[0], map_s=bd[1], probe_s=bd[2], release_s=bd[3])
+
+    def store_rate(self, d_bodies, n, pitch=0, shape=0, iters=20, stream=0):
+        """GB/s of kernels that do nothing but the witness kernels' stores into n bodies of this buffer (b3w_bodies_store_rate):
+        shape 0 / 1 = body streams (one wave per 4 / 8 bodies), 2 = the runtime's fill shape.  Overwrites the bodies."""
+        g = ctypes.c_double()
+        rc = self._lib.b3w_bodies_store_rate(self.handle, d_bodies, n, pitch, shape, iters, stream or None, ctypes.byref(g))
+        if rc != B3W_OK:
+            raise B3WError(rc, f"b3w_bodies_store_rate: status {rc}: {self.last_error()}")
+        return g.value
 
     def time_device(self, d_records, n, d_bodies, pitch, d_public, d_status, stream, iters):
         ms = ctypes.c_float()

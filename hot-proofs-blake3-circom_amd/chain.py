@@ -82,8 +82,11 @@ def gather_h_out(public_local, n_leaf_local, preimage_len, with_parents=True, gr
     return leaf, par
 
 
+COMMIT_OVERLAP = {"auto": -1, "serial": 0, "free": 1, "gated": 2}      # b3w_chain_commit_overlap (include/b3wit.h)
+
+
 def fold_witnesses(ctx, preimage, batch_steps=16384, ring=2, slice_chunks=1024, with_parents=True, consumer=None,
-                   device=None, commit_only=None, gather_hout=True, comm=None, commit_records=None):
+                   device=None, commit_only=None, gather_hout=True, comm=None, commit_records=None, check=None, commit_overlap="auto"):
     """preimage: 1-D uint8 numpy array / torch CPU tensor (the whole preimage; every rank passes the same).
     consumer(bodies_view [k, body_bytes] uint8 CUDA, first_local_step, k): called after each batch is enqueued;
     it must enqueue its work on the current stream (the view is overwritten `ring` batches later).
@@ -91,6 +94,11 @@ def fold_witnesses(ctx, preimage, batch_steps=16384, ring=2, slice_chunks=1024, 
     (b3w_chain_commit_only), into the caller's [n_steps, 64] uint8 CUDA tensor.
     commit_records=(CommitKey, d_points): the same commitments from the records WHILE the bodies are written and handed to the
     consumer as usual (b3w_chain_commit_from_records): the fold-shaped pass, without reading the bodies back for the commitment.
+    commit_overlap: where those commitments run — "serial" (caller's stream), "free" (the chain's commit stream, beside the witness
+    kernels of this and later batches), "gated" (beside the batch's own witness kernel only; check and consumer start when both
+    are done), "auto" (gated when something reads the batch, else free): b3w_chain_commit_overlap.
+    check=R1cs: every batch of step witnesses is checked against the step circuit's constraints while it sits in the ring, before
+    the consumer sees it (b3w_chain_check_constraints); the result gains violations=[n_local_steps] int32 CUDA (0 = satisfied).
     gather_hout: all-gather every step's h_out across the ranks inside the pass (the fold's exchange, module docstring);
     comm: a native b3w_comm handle (b3w_comm_create) — the two exchanges then go through the library's own RCCL calls
     (b3w_chain_run_parents_sharded, b3w_chain_allgather_hout) instead of torch.distributed.
@@ -135,6 +143,9 @@ def fold_witnesses(ctx, preimage, batch_steps=16384, ring=2, slice_chunks=1024, 
         _chk(ctx, L.b3w_chain_commit_from_records(h, commit_records[0].handle, commit_records[1].data_ptr()), "b3w_chain_commit_from_records")
     else:
         _chk(ctx, L.b3w_chain_commit_only(h, None, None), "b3w_chain_commit_only")
+    if commit_records is not None:
+        _chk(ctx, L.b3w_chain_commit_overlap(h, COMMIT_OVERLAP[commit_overlap]), "b3w_chain_commit_overlap")
+    _chk(ctx, L.b3w_chain_check_constraints(h, check.handle if check is not None else None), "b3w_chain_check_constraints")
     compute = torch.cuda.current_stream(dev)
     nbatch = [0]
     cb = _CONSUMER()
@@ -183,6 +194,7 @@ def fold_witnesses(ctx, preimage, batch_steps=16384, ring=2, slice_chunks=1024, 
 
     return dict(public=public, h_out_all=h_leaf, h_out_parents_all=h_par, chunk_cvs_local=_view(L.b3w_chain_local_cvs(h), (max(nl, 1), 8), "<i4", dev)[:nl],
                 status=_view(L.b3w_chain_status(h), (rows,), "<i4", dev),
+                violations=_view(L.b3w_chain_violations_device(h), (rows,), "<i4", dev) if check is not None else None,
                 records=_view(L.b3w_chain_records(h), (rows, 32), "<i4", dev), root=_view(L.b3w_chain_root(h), (8,), "<i4", dev),
                 n_leaf_steps=n_leaf, n_parent_steps=n_par, first_chunk=c0, n_chunks_local=nl, n_chunks=n, path_len=P.value,
                 batches=-(-n_leaf // batch_steps) + -(-n_par // batch_steps) if consumer is None else nbatch[0],

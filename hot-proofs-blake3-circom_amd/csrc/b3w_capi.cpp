@@ -771,6 +771,23 @@ int32_t b3w_bodies_search_stats(const b3w_ctx *ctx, double out[5]) {
 
 void b3w_bodies_search_limit(double seconds) { b3w_place_search_limit(seconds); }
 
+int32_t b3w_bodies_search_breakdown(const b3w_ctx *ctx, double out[4]) {
+  if (!ctx || !out) return B3W_E_BAD_ARGUMENT;
+  b3w_place_cost_breakdown(ctx->device, out);
+  return B3W_OK;
+}
+
+int32_t b3w_bodies_store_rate(b3w_ctx *ctx, void *d_bodies, uint32_t n, uint64_t pitch, int32_t shape, uint32_t iters, void *stream, double *gb_per_s) {
+  if (!ctx || !d_bodies || !gb_per_s) return B3W_E_BAD_ARGUMENT;
+  const uint64_t body = 32ull * ctx->desc.nwit;
+  if (pitch == 0) pitch = body;
+  if (pitch < body || (pitch & 15) || (reinterpret_cast<uintptr_t>(d_bodies) & 15)) return B3W_E_BAD_ARGUMENT;
+  ON_DEVICE(ctx);
+  const int rc = b3w_place_store_rate(static_cast<uint8_t *>(d_bodies), pitch, n, (uint32_t)body, shape, iters, (hipStream_t)stream, gb_per_s);
+  if (rc == -(int)hipErrorInvalidValue) return B3W_E_BAD_ARGUMENT;
+  return rc ? hip_fail(ctx, (hipError_t)-rc, "store-rate launches") : B3W_OK;
+}
+
 int32_t b3w_bodies_alloc(b3w_ctx *ctx, uint64_t bytes, void **d_ptr, int32_t *placement) {
   if (!ctx || !d_ptr || !bytes) return B3W_E_BAD_ARGUMENT;
   *d_ptr = nullptr;
@@ -795,10 +812,18 @@ int32_t b3w_bodies_alloc(b3w_ctx *ctx, uint64_t bytes, void **d_ptr, int32_t *pl
           const uint64_t pb = std::min<uint64_t>(bytes, 8ull << 30);
           for (int i = 0; i < 3; i++) {
             void *cur = nullptr;
+            const auto tm0 = std::chrono::steady_clock::now();
             if (hipMalloc(&cur, pb) != hipSuccess) { (void)hipGetLastError(); break; }
+            const auto tm1 = std::chrono::steady_clock::now();
             if (prev) (void)hipFree(prev);
+            const auto tm2 = std::chrono::steady_clock::now();
             prev = cur;
-            ctx->plain_ms_per_gb = std::max(ctx->plain_ms_per_gb, time_witness_fill(ctx, static_cast<uint8_t *>(cur), pb));
+            const float one = time_witness_fill(ctx, static_cast<uint8_t *>(cur), pb);
+            ctx->plain_ms_per_gb = std::max(ctx->plain_ms_per_gb, one);
+            if (getenv("B3W_PLACE_DEBUG"))
+              fprintf(stderr, "b3w_bodies_alloc: yardstick %d: hipMalloc %.3f s, hipFree(previous) %.3f s, fill launches %.3f s -> %.4f ms/GB\n", i,
+                      std::chrono::duration<double>(tm1 - tm0).count(), std::chrono::duration<double>(tm2 - tm1).count(),
+                      std::chrono::duration<double>(std::chrono::steady_clock::now() - tm2).count(), one);
           }
           if (prev) (void)hipFree(prev);
           if (ctx->plain_ms_per_gb == 0) ctx->plain_ms_per_gb = -1;          // could not measure: do not try again
@@ -1089,40 +1114,38 @@ int32_t b3w_chain_plan_leaves_device(b3w_ctx *ctx, const uint8_t *d_preimage, ui
   return rc ? hip_fail(ctx, (hipError_t)rc, "plan leaves launch") : B3W_OK;
 }
 
-int32_t b3w_chain_tree_device(b3w_ctx *ctx, uint32_t *d_levels, uint64_t n_chunks, uint32_t *d_root, void *stream) {
-  if (!ctx || !d_levels || !d_root || !n_chunks) return B3W_E_BAD_ARGUMENT;
-  ON_DEVICE(ctx);
-  hipStream_t st = (hipStream_t)stream;
+}  // extern "C"
+
+namespace {
+// The tree over n_chunks chunk CVs (level 0 of d_levels): levels of more than 1 024 nodes by one merge launch each, the rest —
+// carries, spine and root included — by ONE launch (b3w_plan_tree_kernel; r04: one launch per level, 10 + carries for 1 MiB).
+// plan_nlocal > 0: that launch also plans the parent steps of chunks [first_chunk, + plan_nlocal) into d_recs.
+int32_t chain_tree(b3w_ctx *ctx, uint32_t *d_levels, uint64_t n_chunks, uint32_t *d_root, uint64_t first_chunk, uint32_t plan_nlocal,
+                   uint32_t last_blocks, uint32_t *d_recs, hipStream_t st) {
   if (n_chunks == 1) {
     HIP_TRY(ctx, hipMemcpyAsync(d_root, d_levels, 32, hipMemcpyDeviceToDevice, st));
     return B3W_OK;
   }
-  // level by level; an odd node out at the end of a level is a complete subtree that waits ("carry")
-  std::vector<const uint32_t *> carries;            // in order of increasing subtree size
+  const uint32_t l0 = b3w_plan_tree_first_level(n_chunks);
   uint32_t *level = d_levels;
   uint64_t count = n_chunks;
-  while (count > 1) {
-    const uint64_t pairs = count / 2;
-    if (count & 1) carries.push_back(level + (count - 1) * 8);
-    uint32_t *next = level + count * 8;
-    const bool root = pairs == 1 && carries.empty() && count == 2;
-    int rc = b3w_launch_plan_merge(level, level + 8, 16, pairs, root ? 1u : 0u, root ? d_root : next, st);
+  for (uint32_t l = 0; l < l0; l++) {                          // an odd node out stays where it is: a carry the tree kernel picks up
+    int rc = b3w_launch_plan_merge(level, level + 8, 16, count / 2, 0u, level + count * 8, st);
     if (rc) return hip_fail(ctx, (hipError_t)rc, "plan merge launch");
-    if (root) return B3W_OK;
-    level = next;
-    count = pairs;
+    level += count * 8;
+    count /= 2;
   }
-  // root = P(main, P(carry_k, ... P(carry_2, carry_1)))  — BLAKE3's right-leaning chain of complete subtrees
-  uint32_t *scratch = d_levels + 2 * n_chunks * 8;
-  const uint32_t *right = carries[0];
-  for (size_t i = 1; i < carries.size(); i++) {
-    int rc = b3w_launch_plan_merge(carries[i], right, 0, 1, 0u, scratch, st);
-    if (rc) return hip_fail(ctx, (hipError_t)rc, "plan merge launch");
-    right = scratch;
-    scratch += 8;
-  }
-  int rc = b3w_launch_plan_merge(level, right, 0, 1, 1u, d_root, st);
-  return rc ? hip_fail(ctx, (hipError_t)rc, "plan merge launch") : B3W_OK;
+  int rc = b3w_launch_plan_tree(d_levels, n_chunks, l0, d_root, first_chunk, plan_nlocal, last_blocks, d_recs, st);
+  return rc ? hip_fail(ctx, (hipError_t)rc, "plan tree launch") : B3W_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int32_t b3w_chain_tree_device(b3w_ctx *ctx, uint32_t *d_levels, uint64_t n_chunks, uint32_t *d_root, void *stream) {
+  if (!ctx || !d_levels || !d_root || !n_chunks) return B3W_E_BAD_ARGUMENT;
+  ON_DEVICE(ctx);
+  return chain_tree(ctx, d_levels, n_chunks, d_root, 0, 0, 0, nullptr, (hipStream_t)stream);
 }
 
 int32_t b3w_chain_plan_parents_device(b3w_ctx *ctx, const uint32_t *d_levels, uint64_t n_chunks, uint64_t preimage_len,
@@ -1688,13 +1711,16 @@ int32_t b3w_batch_commit_device(b3w_ctx *ctx, const b3w_commit_key *key, const u
   }
   const int rc = b3w_launch_commit(d_bodies, n, pitch, key->first_slot, key->nslots, key->d_slotdesc, nullptr, 0, nullptr, 0, key->d_table,
                                    key->nwin, key->window, k->d_sums, d_points, d_status, key->d_invtab, key->inv_nk, key->d_invmeta,
-                                   static_cast<const uint32_t *>(ctx->d_aux), key->counting ? key->d_counts : nullptr, &key->curve, (hipStream_t)stream);
+                                   static_cast<const uint32_t *>(ctx->d_aux), key->counting ? key->d_counts : nullptr, &key->curve, (hipStream_t)stream, 0);
   if (rc == 0 && key->counting) k->host_witnesses += n;
   return rc ? hip_fail(ctx, (hipError_t)rc, "commit launch") : B3W_OK;
 }
 
-int32_t b3w_commit_records_device(b3w_ctx *ctx, const b3w_commit_key *key, const uint32_t *d_records, uint32_t n, uint8_t *d_points,
-                                  uint32_t *d_public, int32_t *d_status, void *stream) {
+}  // extern "C"
+
+// co_resident: the commit kernel built to share the device with the witness kernel of the same steps (the chained pass, GATED / FREE)
+static int32_t commit_records_impl(b3w_ctx *ctx, const b3w_commit_key *key, const uint32_t *d_records, uint32_t n, uint8_t *d_points,
+                                   uint32_t *d_public, int32_t *d_status, void *stream, bool co_resident) {
   if (!ctx || !key || key->ctx != ctx || !d_records || !d_points || !d_status) return B3W_E_BAD_ARGUMENT;
   if (n == 0) return B3W_OK;
   if ((reinterpret_cast<uintptr_t>(d_points) & 15) || (reinterpret_cast<uintptr_t>(d_records) & 3)) {
@@ -1729,11 +1755,19 @@ int32_t b3w_commit_records_device(b3w_ctx *ctx, const b3w_commit_key *key, const
     if (lrc == 0)
       lrc = b3w_launch_commit(nullptr, cn, 0, key->first_slot, key->nslots, key->d_slotdesc, k->d_images, cap, key->d_runs, key->nruns,
                               key->d_table, key->nwin, key->window, k->d_sums, d_points + (uint64_t)c0 * 64, nullptr, key->d_invtab, key->inv_nk,
-                              nullptr, nullptr, key->counting ? key->d_counts : nullptr, &key->curve, (hipStream_t)stream);
+                              nullptr, nullptr, key->counting ? key->d_counts : nullptr, &key->curve, (hipStream_t)stream, co_resident ? 1 : 0);
     if (lrc == 0 && key->counting) k->host_witnesses += cn;
     if (lrc) return hip_fail(ctx, (hipError_t)lrc, "commit-from-records launch");
   }
   return B3W_OK;
+}
+
+extern "C" {
+
+int32_t b3w_commit_records_device(b3w_ctx *ctx, const b3w_commit_key *key, const uint32_t *d_records, uint32_t n, uint8_t *d_points,
+                                  uint32_t *d_public, int32_t *d_status, void *stream) {
+  static const bool co = getenv("B3W_COMMIT_CO") && !strcmp(getenv("B3W_COMMIT_CO"), "1");     // (measurements: tools/ubench/overlap_commit_probe.py)
+  return commit_records_impl(ctx, key, d_records, n, d_points, d_public, d_status, stream, co);
 }
 
 int32_t b3w_commit_records(b3w_ctx *ctx, const b3w_commit_key *key, const uint32_t *host_records, uint32_t n, uint8_t *host_points,
@@ -1956,7 +1990,7 @@ struct b3w_chain {
   b3w_ctx *ctx = nullptr;
   uint64_t len = 0, n_chunks = 0, first_chunk = 0, n_leaf = 0, n_par = 0, nbatch = 0;
   uint32_t nl = 0, P = 0, last_blocks = 16, batch_steps = 0, ring = 0;
-  bool has_last = false, complete = false, with_parents = false;
+  bool has_last = false, complete = false, with_parents = false, cvs_in_levels = false;
   int32_t placement = B3W_PLACEMENT_PLAIN;
   uint8_t *d_pre = nullptr;
   uint32_t *d_recs = nullptr, *d_cvs = nullptr, *d_pub = nullptr, *d_levels = nullptr, *d_root = nullptr;
@@ -1969,7 +2003,9 @@ struct b3w_chain {
   bool co_bodies = false;                            // ... instead of the bodies (false), or beside them (true: b3w_chain_commit_from_records)
   hipStream_t co_stream = nullptr;                   // beside them = on a stream of its own: the commit kernels are bound by the vector ALUs, the
   hipEvent_t ev_co_in = nullptr, ev_co_out = nullptr;//   witness kernels by HBM writes — they run side by side
-  int32_t *d_co_status = nullptr;
+  int32_t co_overlap = B3W_COMMIT_OVERLAP_AUTO;      // b3w_chain_commit_overlap: where those commitments run
+  int32_t *d_co_scratch = nullptr;                   // the side-stream commit kernel's status words: the witness kernel of the same records is
+                                                     // the one that reports (d_status), this is never read
   uint8_t *co_points = nullptr, *co_own = nullptr;   // (co_own: the chain's own buffer when the caller passed none)
   const b3w_r1cs *r1cs = nullptr;                    // constraint check of every batch while it sits in the ring
   uint32_t *d_viol = nullptr;                        // ... violated constraints per step
@@ -2021,20 +2057,32 @@ struct Range {
   ~Range() { if (on) roctx().pop(); }
 };
 
+// where the commitments of a batch run (b3w_chain_commit_overlap); needs co_stream for anything but SERIAL
+int32_t chain_commit_mode(const b3w_chain *c, bool has_consumer) {
+  if (!(c->co_key && c->co_bodies && c->co_stream)) return B3W_COMMIT_OVERLAP_SERIAL;
+  if (c->co_overlap != B3W_COMMIT_OVERLAP_AUTO) return c->co_overlap;
+  // something reads the batch on `stream` right after the witness kernel (the constraint check: every VGPR and 138 KB of LDS per CU):
+  // the commitments overlap the witness kernel only.  Nothing does: they run free beside the witness kernels of this and later batches.
+  return (c->r1cs || has_consumer) ? B3W_COMMIT_OVERLAP_GATED : B3W_COMMIT_OVERLAP_FREE;
+}
+
 int32_t chain_run_steps(b3w_chain *c, uint64_t first_row, uint64_t count, b3w_batch_consumer consumer, void *user, void *stream) {
   const uint64_t body = 32ull * c->ctx->desc.nwit;
+  const int32_t mode = chain_commit_mode(c, consumer != nullptr);
   for (uint64_t done = 0; done < count;) {
     const uint32_t k = (uint32_t)std::min<uint64_t>(c->batch_steps, count - done);
     uint8_t *slot = static_cast<uint8_t *>(c->bodies[c->nbatch % c->ring]);
     const uint64_t r0 = first_row + done;
-    if (c->co_key && c->co_bodies && c->co_stream) {
-      // beside the bodies: on the commit stream, behind everything `stream` holds so far (the records of this batch are planned)
+    if (mode != B3W_COMMIT_OVERLAP_SERIAL) {
+      // beside the bodies: on the commit stream, behind everything `stream` holds so far (the records of this batch are planned; GATED:
+      // the check of the previous batch is over)
       Range r("b3w:commit from records (side stream)");
       hipError_t e = hipEventRecord(c->ev_co_in, (hipStream_t)stream);
       if (e == hipSuccess) e = hipStreamWaitEvent(c->co_stream, c->ev_co_in, 0);
       if (e != hipSuccess) return hip_fail(c->ctx, e, "commit stream");
-      const int32_t rc = b3w_commit_records_device(c->ctx, c->co_key, c->d_recs + r0 * 32, k, c->co_points + r0 * 64, nullptr, c->d_co_status + r0, c->co_stream);
+      const int32_t rc = b3w_commit_records_device(c->ctx, c->co_key, c->d_recs + r0 * 32, k, c->co_points + r0 * 64, nullptr, c->d_co_scratch + r0, c->co_stream);
       if (rc) return rc;
+      if (mode == B3W_COMMIT_OVERLAP_GATED && (e = hipEventRecord(c->ev_co_out, c->co_stream)) != hipSuccess) return hip_fail(c->ctx, e, "commit stream");
     } else if (c->co_key) {
       Range r("b3w:commit from records");
       const int32_t rc = b3w_commit_records_device(c->ctx, c->co_key, c->d_recs + r0 * 32, k, c->co_points + r0 * 64, c->d_pub + r0 * 15,
@@ -2049,6 +2097,10 @@ int32_t chain_run_steps(b3w_chain *c, uint64_t first_row, uint64_t count, b3w_ba
     int32_t rc;
     { Range r("b3w:witness batch"); rc = b3w_batch_run_device(c->ctx, c->d_recs + r0 * 32, k, slot, body, c->d_pub + r0 * 15, c->d_status + r0, stream); }
     if (rc) return rc;
+    if (mode == B3W_COMMIT_OVERLAP_GATED) {                    // what reads the batch starts when BOTH are done: it gets the machine to itself
+      const hipError_t e = hipStreamWaitEvent((hipStream_t)stream, c->ev_co_out, 0);
+      if (e != hipSuccess) return hip_fail(c->ctx, e, "commit stream");
+    }
     if (c->r1cs) {
       Range r("b3w:constraint check");
       rc = b3w_r1cs_check_device(c->ctx, c->r1cs, slot, k, body, c->d_viol + r0, nullptr, stream);
@@ -2058,7 +2110,7 @@ int32_t chain_run_steps(b3w_chain *c, uint64_t first_row, uint64_t count, b3w_ba
     c->nbatch++;
     done += k;
   }
-  if (c->co_key && c->co_bodies && c->co_stream) {           // `stream` has drained = the commitments are there too
+  if (mode == B3W_COMMIT_OVERLAP_FREE) {                       // `stream` has drained = the commitments are there too
     hipError_t e = hipEventRecord(c->ev_co_out, c->co_stream);
     if (e == hipSuccess) e = hipStreamWaitEvent((hipStream_t)stream, c->ev_co_out, 0);
     if (e != hipSuccess) return hip_fail(c->ctx, e, "commit stream");
@@ -2069,29 +2121,31 @@ int32_t chain_run_steps(b3w_chain *c, uint64_t first_row, uint64_t count, b3w_ba
 
 extern "C" {
 
+namespace {
+void chain_drop_commit_stream(b3w_chain *c) {
+  if (c->co_stream) { (void)hipStreamSynchronize(c->co_stream); (void)hipStreamDestroy(c->co_stream); c->co_stream = nullptr; }
+  if (c->ev_co_in) { (void)hipEventDestroy(c->ev_co_in); c->ev_co_in = nullptr; }
+  if (c->ev_co_out) { (void)hipEventDestroy(c->ev_co_out); c->ev_co_out = nullptr; }
+}
+}  // namespace
+
 int32_t b3w_chain_commit_from_records(b3w_chain *c, const b3w_commit_key *key, uint8_t *d_points) {
   const int32_t rc = b3w_chain_commit_only(c, key, d_points);
   if (rc != B3W_OK) return rc;
   c->co_bodies = key != nullptr;
-  // The commit stream (B3W_CHAIN_COMMIT_ASYNC=0: none, the commitments go on the caller's stream between the witness launches).
-  // B3W_COMMIT_CU_PCT=<p>: the stream may use only p % of the CUs (hipExtStreamCreateWithCUMask), the rest stay free for the
-  // witness kernels and the consumers.
-  // Measured (profiles/r04/bench_chain_64mib_commit_*): beside the witness kernels alone the stream gains 11 % (3.86 -> 4.27 M steps/s);
-  // beside the constraint check it LOSES (2.50 -> 2.36: the check's persistent workgroups want every CU's LDS) and so does any CU mask —
-  // so the default is: a stream of its own unless the chain also checks constraints; B3W_CHAIN_COMMIT_ASYNC=0 / 1 says otherwise (a caller
-  // whose consumer callback runs the check itself sets 0).
-  const char *env_async = getenv("B3W_CHAIN_COMMIT_ASYNC");
-  const bool async = env_async ? strcmp(env_async, "0") != 0 : c->r1cs == nullptr;
-  if (key && !async && c->co_stream) {                       // (switched off for a chain that had it)
+  // The commit stream.  Where the commitments run is b3w_chain_commit_overlap's choice (include/b3wit.h); SERIAL needs no stream.
+  // B3W_COMMIT_CU_PCT=<p>: the stream may use only p % of the CUs (hipExtStreamCreateWithCUMask; measured slower at 75 and 88),
+  // B3W_COMMIT_PRIORITY=<n>: its priority (hipStreamCreateWithPriority; measurement switches).
+  const bool want_stream = key && c->co_overlap != B3W_COMMIT_OVERLAP_SERIAL;
+  if (!want_stream && c->co_stream) {                        // (switched off for a chain that had it)
     ON_DEVICE(c->ctx);
-    (void)hipStreamSynchronize(c->co_stream);
-    (void)hipStreamDestroy(c->co_stream);
-    c->co_stream = nullptr;
+    chain_drop_commit_stream(c);
   }
-  if (key && async && !c->co_stream) {
+  if (want_stream && !c->co_stream) {
     b3w_ctx *ctx = c->ctx;
     ON_DEVICE(ctx);
     static const int pct = getenv("B3W_COMMIT_CU_PCT") ? atoi(getenv("B3W_COMMIT_CU_PCT")) : 0;
+    static const char *prio = getenv("B3W_COMMIT_PRIORITY");
     hipError_t e = hipSuccess;
     if (pct > 0 && pct < 100) {
       int cus = 0;
@@ -2100,14 +2154,28 @@ int32_t b3w_chain_commit_from_records(b3w_chain *c, const b3w_commit_key *key, u
       // every (100 / (100 - pct))-th CU stays out of the mask: spread over the XCDs (CU ids are dealt to them round-robin)
       for (int cu = 0; cu < cus; cu++) if ((int64_t)cu * (100 - pct) / 100 == (int64_t)(cu + 1) * (100 - pct) / 100) mask[cu / 32] |= 1u << (cu % 32);
       if (e == hipSuccess) e = hipExtStreamCreateWithCUMask(&c->co_stream, (uint32_t)mask.size(), mask.data());
-    } else e = hipStreamCreateWithFlags(&c->co_stream, hipStreamNonBlocking);
+    } else if (prio) e = hipStreamCreateWithPriority(&c->co_stream, hipStreamNonBlocking, atoi(prio));
+    else e = hipStreamCreateWithFlags(&c->co_stream, hipStreamNonBlocking);
     if (e == hipSuccess && !c->ev_co_in) e = hipEventCreateWithFlags(&c->ev_co_in, hipEventDisableTiming);
     if (e == hipSuccess && !c->ev_co_out) e = hipEventCreateWithFlags(&c->ev_co_out, hipEventDisableTiming);
-    if (e == hipSuccess && !c->d_co_status) e = hipMalloc((void **)&c->d_co_status, (size_t)(c->n_leaf + c->n_par + 1) * 4);
-    if (e != hipSuccess) return hip_fail(ctx, e, "commit stream");
+    if (e == hipSuccess && !c->d_co_scratch) e = hipMalloc((void **)&c->d_co_scratch, (size_t)(c->n_leaf + c->n_par + 1) * 4);
+    if (e != hipSuccess) {                                   // no half-built stream: the chain is back to "no commitments" and says why
+      chain_drop_commit_stream(c);
+      c->co_key = nullptr; c->co_points = nullptr; c->co_bodies = false;
+      return hip_fail(ctx, e, "commit stream");
+    }
   }
   return B3W_OK;
 }
+
+int32_t b3w_chain_commit_overlap(b3w_chain *c, int32_t mode) {
+  if (!c || mode < B3W_COMMIT_OVERLAP_AUTO || mode > B3W_COMMIT_OVERLAP_GATED) return B3W_E_BAD_ARGUMENT;
+  c->co_overlap = mode;
+  if (c->co_key && c->co_bodies) return b3w_chain_commit_from_records(c, c->co_key, c->co_points);   // (stream made or dropped to match)
+  return B3W_OK;
+}
+
+uint32_t *b3w_chain_violations_device(b3w_chain *c) { return c ? c->d_viol : nullptr; }
 
 int32_t b3w_chain_commit_only(b3w_chain *c, const b3w_commit_key *key, uint8_t *d_points) {
   if (!c || (key && key->ctx != c->ctx)) return B3W_E_BAD_ARGUMENT;
@@ -2174,10 +2242,12 @@ int32_t b3w_chain_create(b3w_ctx *ctx, uint64_t preimage_len, uint64_t first_chu
   hipError_t e = guard.err;
   if (e == hipSuccess) e = hipMalloc((void **)&c->d_pre, std::max<uint64_t>(n_chunks_local, 1) * 1024);
   if (e == hipSuccess) e = hipMalloc((void **)&c->d_recs, rows * 32 * 4);
-  if (e == hipSuccess) e = hipMalloc((void **)&c->d_cvs, std::max<uint64_t>(n_chunks_local, 1) * 8 * 4);
+  c->cvs_in_levels = n_chunks_local == n;              // all chunks here: the leaf planner writes the chunk CVs straight into level 0 of the tree
+  if (e == hipSuccess && !c->cvs_in_levels) e = hipMalloc((void **)&c->d_cvs, std::max<uint64_t>(n_chunks_local, 1) * 8 * 4);
   if (e == hipSuccess) e = hipMalloc((void **)&c->d_pub, rows * 15 * 4);
   if (e == hipSuccess) e = hipMalloc((void **)&c->d_status, rows * 4);
   if (e == hipSuccess) e = hipMalloc((void **)&c->d_levels, (2 * n + 64) * 8 * 4);
+  if (e == hipSuccess && c->cvs_in_levels) c->d_cvs = c->d_levels;
   if (e == hipSuccess) e = hipMalloc((void **)&c->d_root, 8 * 4);
   if (e == hipSuccess) e = hipMemset(c->d_status, 0, rows * 4);
   if (e == hipSuccess) e = hipStreamCreateWithFlags(&c->copy, hipStreamNonBlocking);
@@ -2229,16 +2299,14 @@ void b3w_chain_destroy(b3w_chain *c) {
   for (hipEvent_t e : c->x.ev) if (e) (void)hipEventDestroy(e);
   if (c->d_pre) (void)hipFree(c->d_pre);
   if (c->d_recs) (void)hipFree(c->d_recs);
-  if (c->d_cvs) (void)hipFree(c->d_cvs);
+  if (c->d_cvs && !c->cvs_in_levels) (void)hipFree(c->d_cvs);
   if (c->d_pub) (void)hipFree(c->d_pub);
   if (c->d_status) (void)hipFree(c->d_status);
   if (c->d_levels) (void)hipFree(c->d_levels);
   if (c->d_root) (void)hipFree(c->d_root);
   if (c->co_own) (void)hipFree(c->co_own);
-  if (c->d_co_status) (void)hipFree(c->d_co_status);
-  if (c->co_stream) (void)hipStreamDestroy(c->co_stream);
-  if (c->ev_co_in) (void)hipEventDestroy(c->ev_co_in);
-  if (c->ev_co_out) (void)hipEventDestroy(c->ev_co_out);
+  if (c->d_co_scratch) (void)hipFree(c->d_co_scratch);
+  chain_drop_commit_stream(c);
   if (c->d_viol) (void)hipFree(c->d_viol);
   if (c->copy) (void)hipStreamDestroy(c->copy);
   if (c->side) (void)hipStreamDestroy(c->side);
@@ -2302,9 +2370,13 @@ int32_t chain_run_parents(b3w_chain *c, const uint32_t *d_all_chunk_cvs, bool cv
   int32_t rc;
   {
     Range r("b3w:tree + plan parent steps");
-    HIP_TRY(ctx, hipMemcpyAsync(c->d_levels, d_all_chunk_cvs, c->n_chunks * 32, hipMemcpyDeviceToDevice, c->side));
-    rc = b3w_chain_tree_device(ctx, c->d_levels, c->n_chunks, c->d_root, c->side);
-    if (rc == B3W_OK && c->n_par)
+    if (d_all_chunk_cvs != c->d_levels)                // (a single rank plans its chunk CVs into level 0, an even sharded pass gathers them there)
+      HIP_TRY(ctx, hipMemcpyAsync(c->d_levels, d_all_chunk_cvs, c->n_chunks * 32, hipMemcpyDeviceToDevice, c->side));
+    // few local chunks (a rank's share of a small preimage): the tree kernel's workgroup plans their parent steps itself; many: the
+    // path kernel's workgroups, spread over the chip, behind it
+    const bool fused_plan = c->n_par && c->n_chunks > 1 && c->nl <= 256;
+    rc = chain_tree(ctx, c->d_levels, c->n_chunks, c->d_root, c->first_chunk, fused_plan ? c->nl : 0, c->last_blocks, c->d_recs + c->n_leaf * 32, c->side);
+    if (rc == B3W_OK && c->n_par && !fused_plan)
       rc = b3w_chain_plan_parents_device(ctx, c->d_levels, c->n_chunks, c->len, c->first_chunk, c->nl, c->d_recs + c->n_leaf * 32, c->side);
   }
   HIP_TRY(ctx, hipEventRecord(c->ev_par, c->side));
@@ -2391,11 +2463,12 @@ int32_t b3w_chain_run_parents_sharded(b3w_chain *c, b3w_comm *comm, b3w_batch_co
   // equal shards (config 4: 1 024 chunks over 8 ranks): no padding, so the collective takes the chunk CVs where they lie and leaves
   // them in global chunk order — no staging copy, no compaction (each a hipMemcpyAsync of its own: 17 of them cost 0.2 ms at 8 ranks)
   const bool even = c->n_chunks % (uint64_t)comm->nranks == 0;
-  const uint32_t *d_all = even ? x.d_cv_gath : x.d_cv_all;
+  const uint32_t *d_all = even ? c->d_levels : x.d_cv_all;        // (even: level 0 of the tree IS the receive buffer)
   hipError_t e = hipStreamWaitEvent(side, c->ev_cvs, 0);
   if (e == hipSuccess) e = hipEventRecord(x.ev[0], side);
   if (e == hipSuccess && c->nl && !even) e = hipMemcpyAsync(x.d_cv_pad, c->d_cvs, (uint64_t)c->nl * 32, hipMemcpyDeviceToDevice, side);
-  rc = e == hipSuccess ? b3w_comm_allgather(comm, even ? c->d_cvs : x.d_cv_pad, x.d_cv_gath, x.mx_chunks * 32, side) : hip_fail(ctx, e, "chunk CV staging");
+  rc = e == hipSuccess ? b3w_comm_allgather(comm, even ? c->d_cvs : x.d_cv_pad, even ? c->d_levels : x.d_cv_gath, x.mx_chunks * 32, side)
+                       : hip_fail(ctx, e, "chunk CV staging");
   for (int32_t r = 0; r < comm->nranks && rc == B3W_OK && !even; r++) {        // drop the padding: global chunk order
     uint64_t f = 0; uint32_t k = 0;
     b3w_chain_shard(c->n_chunks, r, comm->nranks, &f, &k);

@@ -169,6 +169,10 @@ int b3w_hostcomm_open(const char *name, int rank, int nranks, uint64_t slot_byte
   }
   if (barrier(c, err, errlen) != 0) { b3w_hostcomm_close(c); return -1; }   // everybody holds a mapping
   if (rank == 0) { (void)shm_unlink(name); c->linked = false; }             // ... so the name can go: nothing is left behind by a crash
+  // second phase: nobody returns while the name still exists.  (With one barrier a rank could leave, close, and re-open a communicator
+  // of the same name — a retry loop — while rank 0 had not unlinked yet: it attached to the OLD segment, alive owner and right
+  // geometry, and both sides waited for each other until their timeouts.)
+  if (barrier(c, err, errlen) != 0) { b3w_hostcomm_close(c); return -1; }
   *out = c;
   return 0;
 }

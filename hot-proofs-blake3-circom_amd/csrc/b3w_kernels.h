@@ -28,6 +28,9 @@ extern "C" int b3w_launch_plan_merge(const uint32_t *d_left, const uint32_t *d_r
                                      uint32_t root, uint32_t *d_parents, hipStream_t stream);
 extern "C" int b3w_launch_plan_parents(const uint32_t *d_levels, uint64_t nchunks, uint64_t first_chunk, uint32_t nlocal,
                                        uint32_t last_chunk_blocks, uint32_t *d_recs, hipStream_t stream);
+extern "C" uint32_t b3w_plan_tree_first_level(uint64_t nchunks);               // the level the one-launch tree kernel starts at
+extern "C" int b3w_launch_plan_tree(uint32_t *d_levels, uint64_t nchunks, uint32_t l0, uint32_t *d_root, uint64_t first_chunk, uint32_t plan_nlocal,
+                                    uint32_t last_chunk_blocks, uint32_t *d_recs, hipStream_t stream);
 extern "C" uint64_t b3w_plan_parent_row(uint64_t chunk, uint64_t nchunks);     // chunk == nchunks: all parent steps
 extern "C" int b3w_plan_path_provable(uint64_t chunk, uint64_t nchunks);
 // the fold's exchange (h_out = public words 2 .. 9 of a step): strided rows -> wire format, gathered rank blocks -> global step order
@@ -49,6 +52,8 @@ extern "C" void b3w_place_configure(int64_t search_gib, int64_t pool_gib);      
 extern "C" void b3w_place_stats(int device, uint64_t out[6]);
 extern "C" void b3w_place_search_limit(double seconds);                         // <= 0: none
 extern "C" void b3w_place_search_stats(int device, double out[4]);             // seconds, GiB walked, time-outs, the limit
+extern "C" void b3w_place_cost_breakdown(int device, double out[4]);           // seconds in hipMemCreate, map + access, probes, unmap + release
+extern "C" int b3w_place_store_rate(uint8_t *buf, uint64_t pitch, uint32_t n, uint32_t body_bytes, int shape, uint32_t iters, hipStream_t stream, double *gbs);
 
 // b3w_commit.hip: Pedersen commitments of witness bodies (on-device consumer).
 // Window width W (virtual slots per window, 2^W - 1 tabulated subset sums each) is a property of the key:
@@ -79,7 +84,8 @@ extern "C" int b3w_launch_commit(const uint8_t *d_bodies, uint32_t n, uint64_t p
                                                               n_blocks, block_count, total_depth, depth, [71, 138) first virtual slot of gadget j's slot */,
                                  const uint32_t *d_aux /* ... and the context's scalars: [0, 8) the prime, [16 + 8 k, + 8) 1 / k */,
                                  unsigned long long *d_adds /* or null: += the mixed additions of this launch (statistics) */,
-                                 const B3wCurve *curve, hipStream_t stream);
+                                 const B3wCurve *curve, hipStream_t stream,
+                                 int co_resident /* the kernel built to run beside the witness kernel: at most two waves per SIMD (b3w_commit.hip) */);
 // O2 nova circuits, records mode: invtab[j * nk + mag - 1] = (1 / mag) * G of the slot holding IsZero gadget j's inverse
 // (d_inverses: 8 words per magnitude, standard form — the witness kernels' table; d_inv_slot[j] = committed slot index or ~0)
 #define B3W_NOVA_ISZERO 67

@@ -49,6 +49,7 @@
 namespace {
 
 typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+double wall_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 // probe: stream i writes PROBE_PITCH consecutive bytes, even streams from lo, odd ones from hi, one wave per stream
 __global__ __launch_bounds__(64) void b3w_store_probe_kernel(uint8_t *lo, uint8_t *hi, uint64_t pitch, uint32_t groups) {
@@ -56,6 +57,27 @@ __global__ __launch_bounds__(64) void b3w_store_probe_kernel(uint8_t *lo, uint8_
   const u32x4 v = {0, 0, 0, 0};
   uint8_t *base = ((i & 1) ? hi : lo) + (uint64_t)(i >> 1) * pitch + lane * 16;
   for (uint32_t g = 0; g < groups; ++g) *reinterpret_cast<u32x4 *>(base + (uint64_t)g * 1024) = v;
+}
+
+// Pure-store ceilings of a body buffer (b3w_place_store_rate): what the memory system takes from stores alone, in the two shapes the
+// witness kernels write in.  STREAMS: one wave per W bodies, 1 KiB per body and step, as the fused kernels' EXPAND phase (no trace, no
+// slot table, no LDS: the stores and their addresses only).  FILL: 256 workgroups of 256 threads walking 4 KiB tiles b, b + 256, ...
+// (the runtime's own fill shape, what the sweep kernels imitate).
+template <int W>
+__global__ __launch_bounds__(64) void b3w_store_streams_kernel(uint8_t *out, uint64_t pitch, uint32_t n, uint32_t tiles) {
+  const uint32_t b0 = blockIdx.x * W, lane = threadIdx.x;
+  const u32x4 v = {lane, blockIdx.x, 0, 0};
+  uint8_t *base[W];
+#pragma unroll
+  for (int w = 0; w < W; ++w) base[w] = out + (uint64_t)(b0 + w < n ? b0 + w : n - 1) * pitch + lane * 16;
+  for (uint32_t g = 0; g < tiles; ++g) {
+#pragma unroll
+    for (int w = 0; w < W; ++w) *reinterpret_cast<u32x4 *>(base[w] + (uint64_t)g * 1024) = v;
+  }
+}
+__global__ __launch_bounds__(256) void b3w_store_fill_kernel(uint8_t *out, uint64_t bytes) {
+  const u32x4 v = {threadIdx.x, blockIdx.x, 0, 0};
+  for (uint64_t t = blockIdx.x; (t + 1) * 4096 <= bytes; t += gridDim.x) *reinterpret_cast<u32x4 *>(out + t * 4096 + threadIdx.x * 16) = v;
 }
 
 constexpr uint64_t MiB = 1ull << 20, GiB = 1ull << 30;
@@ -96,6 +118,8 @@ struct Pool {
   uint64_t search_handles = 0;                      // ... of them by searches for a second class
   double search_seconds = 0;                        // wall time inside b3w_place_alloc calls that wanted a mixed buffer
   uint32_t search_timeouts = 0;                     // searches ended by the time limit
+  double t_create = 0, t_map = 0, t_probe = 0, t_release = 0;   // seconds inside hipMemCreate / hipMemMap + SetAccess / probes / unmap + release
+  uint64_t n_probe = 0, n_release = 0;
   hipMemAllocationProp prop{};
   hipMemAccessDesc acc{};
 };
@@ -103,9 +127,9 @@ struct Pool {
 // Knobs (b3w_place_configure / B3W_PLACE_SEARCH_GIB, B3W_PLACE_POOL_GIB): how much memory a search may touch
 // transiently and how much labelled memory stays pooled — co-resident allocators (torch, RCCL) cannot see either.
 struct Knobs {
-  int64_t search_gib = -1;     // < 0: 16 x the buffer, at least 24 GiB, at most 160 GiB
+  int64_t search_gib = -1;     // < 0: SEARCH_CAP_MAX (and never more than half of what is free beyond the buffer: b3w_place_alloc)
   int64_t pool_gib = -1;       // < 0: POOL_CAP_DEFAULT per label
-  double search_s = 30.0;      // a search that has not found a second class after this many seconds ends: the buffer is plain
+  double search_s = 5.0;       // a search that has not found a second class after this many seconds ends: the buffer is plain
   Knobs() {
     if (const char *e = getenv("B3W_PLACE_SEARCH_GIB")) search_gib = atoll(e);
     if (const char *e = getenv("B3W_PLACE_POOL_GIB")) pool_gib = atoll(e);
@@ -115,11 +139,14 @@ struct Knobs {
 Knobs &knobs() { static Knobs k; return k; }
 uint64_t pool_cap_per_label() { return knobs().pool_gib < 0 ? POOL_CAP_DEFAULT : (uint64_t)knobs().pool_gib * GiB / 3; }
 uint64_t search_cap(uint64_t own) {
+  // r01-r04: 16 x the buffer, at least 24 GiB — 48 GiB for a config-2 batch, while the first class border of a fresh device lies up
+  // to 96 GiB in (a class is about 96 GB; BENCH_r04: 94.5 GiB walked), so an integrator's first buffer on a fresh box came out plain
+  // and only bench.py, which raised the knob, got a placed one.  What bounds a search now is TIME (search_s: a walk costs 2-35 ms per
+  // GiB, all of it the driver's — tools/ubench/place_cost.hip, profiles/r05/place_cost.log) and half of the free memory.
+  (void)own;
   if (knobs().search_gib >= 0) return std::min<uint64_t>((uint64_t)knobs().search_gib * GiB, SEARCH_CAP_MAX);
-  return std::min<uint64_t>(std::max<uint64_t>(16 * own, 24 * GiB), SEARCH_CAP_MAX);
+  return SEARCH_CAP_MAX;
 }
-
-double wall_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 std::mutex &mtx() { static std::mutex m; return m; }
 std::vector<Pool *> &pools() { static std::vector<Pool *> p; return p; }
@@ -149,8 +176,11 @@ Pool *pool_for(int device) {
 }
 
 // a failure in here only ends a search; the sticky HIP error must not leak into the caller's next launch check
-bool create_handle(Pool *p, hipMemGenericAllocationHandle_t *h) {
-  if (hipMemCreate(h, HANDLE, &p->prop, 0) == hipSuccess) { p->handles_created++; return true; }
+bool create_handle(Pool *p, hipMemGenericAllocationHandle_t *h, uint64_t bytes = HANDLE) {
+  const double t0 = wall_s();
+  const hipError_t e = hipMemCreate(h, bytes, &p->prop, 0);
+  p->t_create += wall_s() - t0;
+  if (e == hipSuccess) { p->handles_created += bytes / HANDLE; return true; }
   (void)hipGetLastError();
   return false;
 }
@@ -159,6 +189,7 @@ uint32_t slots_left(Pool *p) { return (uint32_t)(p->arena_bytes / HANDLE) - p->n
 // map a handle at the next never-used slot; false when the arena is used up or the driver refuses
 bool map_new(Pool *p, Cand &c) {
   if (!slots_left(p)) return false;
+  struct Clock { double &acc; double t0 = wall_s(); ~Clock() { acc += wall_s() - t0; } } clock{p->t_map};
   uint8_t *a = slot_addr(p, p->next_slot);
   if (hipMemMap(a, HANDLE, 0, c.h, 0) != hipSuccess) { (void)hipGetLastError(); return false; }
   c.slot = p->next_slot++;                           // used up whatever happens next
@@ -166,11 +197,16 @@ bool map_new(Pool *p, Cand &c) {
   return true;
 }
 void release(Pool *p, Cand &c) {
+  const double t0 = wall_s();
   (void)hipMemUnmap(slot_addr(p, c.slot), HANDLE);
   (void)hipMemRelease(c.h);
+  p->t_release += wall_s() - t0;
+  p->n_release++;
 }
 
 double probe_slots(Pool *p, uint32_t sa, uint32_t sb, int reps = 3) {
+  struct Clock { double &acc; double t0 = wall_s(); ~Clock() { acc += wall_s() - t0; } } clock{p->t_probe};
+  p->n_probe++;
   uint8_t *a = slot_addr(p, sa), *b = slot_addr(p, sb);
   const uint32_t groups = (uint32_t)(PROBE_PITCH / 1024);
   hipLaunchKernelGGL(b3w_store_probe_kernel, dim3(PROBE_STREAMS), dim3(64), 0, p->stream, a, b, PROBE_PITCH, groups);
@@ -310,10 +346,14 @@ extern "C" int b3w_place_alloc(int device, uint64_t bytes, int want_mixed, void 
     Pool *p; double t0; uint64_t h0; bool on; bool *to;
     ~Account() { if (on) { p->search_seconds += wall_s() - t0; p->search_handles += p->handles_created - h0; if (*to) p->search_timeouts++; } }
   } account{p, t_begin, created_before, want_mixed != 0, &timed_out};
+  double t_cal = 0, t_walk = 0, t_seams = 0;                 // B3W_PLACE_DEBUG: where a search's time goes
   if (want_mixed && !p->hopeless) {
+    const double tc0 = wall_s();
     if (!p->refs) (void)calibrate(p, budget, got, deadline, timed_out);
+    t_cal = wall_s() - tc0;
     for (const Cand &c : got) sort_in(c);
     got.clear();
+    const double tw0 = wall_s();
     while (p->refs && (alone = split(alone1)) < 0 && budget) {
       if (wall_s() > deadline) { timed_out = true; break; }
       Cand c{};
@@ -324,11 +364,13 @@ extern "C" int b3w_place_alloc(int device, uint64_t bytes, int want_mixed, void 
       sort_in(c);
     }
     found = p->refs && (alone = split(alone1)) >= 0;
+    t_walk = wall_s() - tw0;
   }
   for (const Cand &c : got) sort_in(c);                        // (search skipped)
   // the order of the pieces
   std::vector<Cand> order;
   uint32_t slow_seams = 0;
+  const double ts0 = wall_s();
   if (found) {
     std::vector<Cand> side1, side2;                            // most recently created first
     std::vector<Cand> &sa = alone1 ? side1 : side2, &sr = alone1 ? side2 : side1;
@@ -394,13 +436,16 @@ extern "C" int b3w_place_alloc(int device, uint64_t bytes, int want_mixed, void 
       order.push_back(c);
     }
   }
+  t_seams = wall_s() - ts0;
   if (timed_out && getenv("B3W_PLACE_DEBUG"))
     fprintf(stderr, "b3w_place_alloc: no second class of memory within %.0f s (B3W_PLACE_SEARCH_S): this buffer is plain\n", knobs().search_s);
   if (getenv("B3W_PLACE_DEBUG")) {
     fprintf(stderr, "b3w_place_alloc: %u pieces, found=%d, thr=%.0f (lo %.0f hi %.0f), slow seams left=%u, spare %zu, rejects %zu, slots used %u\n  ", nh,
             (int)found, p->thr, p->lo, p->hi, slow_seams, extra.size(), rejects.size(), p->next_slot);
     for (const Cand &c : order) fputc("ABCM"[c.label], stderr);
-    fputc('\n', stderr);
+    fprintf(stderr, "\n  this call: calibrate %.3f s, walk %.3f s, order + seams %.3f s; pool totals: hipMemCreate %.3f s (%llu handles), map %.3f s, %llu probes %.3f s, "
+            "%llu releases %.3f s\n", t_cal, t_walk, t_seams, p->t_create, (unsigned long long)p->handles_created, p->t_map, (unsigned long long)p->n_probe, p->t_probe,
+            (unsigned long long)p->n_release, p->t_release);
   }
   int rc = order.size() < nh ? -(int)hipErrorOutOfMemory : 0;
   Placed *pl = nullptr;
@@ -502,4 +547,53 @@ extern "C" void b3w_place_trim(void) {
     for (Cand &c : p->spare) release(p, c);
     p->spare.clear();
   }
+}
+
+// out: seconds inside hipMemCreate, hipMemMap + hipMemSetAccess, the store probes, hipMemUnmap + hipMemRelease — since the process began
+extern "C" void b3w_place_cost_breakdown(int device, double out[4]) {
+  std::lock_guard<std::mutex> guard(mtx());
+  out[0] = out[1] = out[2] = out[3] = 0;
+  for (Pool *p : pools()) {
+    if (p->device != device) continue;
+    out[0] = p->t_create; out[1] = p->t_map; out[2] = p->t_probe; out[3] = p->t_release;
+  }
+}
+
+// one pure-store pass, enqueued on `stream` and not waited for (tools/ubench/overlap_commit_probe.py: a writer with no LDS and few
+// registers beside another kernel)
+extern "C" int b3w_place_store_launch(uint8_t *buf, uint64_t pitch, uint32_t n, uint32_t body_bytes, int shape, hipStream_t stream) {
+  if (!buf || !n || body_bytes < 1024 || pitch < body_bytes) return -(int)hipErrorInvalidValue;
+  const uint32_t tiles = body_bytes / 1024;
+  if (shape == 0) hipLaunchKernelGGL(b3w_store_streams_kernel<4>, dim3((n + 3) / 4), dim3(64), 0, stream, buf, pitch, n, tiles);
+  else if (shape == 1) hipLaunchKernelGGL(b3w_store_streams_kernel<8>, dim3((n + 7) / 8), dim3(64), 0, stream, buf, pitch, n, tiles);
+  else hipLaunchKernelGGL(b3w_store_fill_kernel, dim3(256), dim3(256), 0, stream, buf, (uint64_t)n * pitch);
+  return -(int)hipGetLastError();
+}
+
+// GB/s of `iters` pure-store passes over [buf, buf + n * pitch) on `stream` (HIP events; 2 untimed passes first).
+// shape 0: body streams, one wave per 4 bodies; 1: per 8 bodies; 2: the fill shape.  Negative = hipError_t.
+extern "C" int b3w_place_store_rate(uint8_t *buf, uint64_t pitch, uint32_t n, uint32_t body_bytes, int shape, uint32_t iters, hipStream_t stream, double *gbs) {
+  if (!buf || !n || !iters || !gbs || body_bytes < 1024 || pitch < body_bytes || shape < 0 || shape > 2) return -(int)hipErrorInvalidValue;
+  const uint32_t tiles = body_bytes / 1024;
+  const uint64_t per_pass = shape == 2 ? ((uint64_t)n * pitch / 4096) * 4096 : (uint64_t)n * tiles * 1024;
+  auto launch = [&] {
+    if (shape == 0) hipLaunchKernelGGL(b3w_store_streams_kernel<4>, dim3((n + 3) / 4), dim3(64), 0, stream, buf, pitch, n, tiles);
+    else if (shape == 1) hipLaunchKernelGGL(b3w_store_streams_kernel<8>, dim3((n + 7) / 8), dim3(64), 0, stream, buf, pitch, n, tiles);
+    else hipLaunchKernelGGL(b3w_store_fill_kernel, dim3(256), dim3(256), 0, stream, buf, (uint64_t)n * pitch);
+  };
+  hipEvent_t e0 = nullptr, e1 = nullptr;
+  hipError_t e = hipEventCreate(&e0);
+  if (e == hipSuccess) e = hipEventCreate(&e1);
+  if (e == hipSuccess) { launch(); launch(); e = hipEventRecord(e0, stream); }
+  for (uint32_t i = 0; i < iters && e == hipSuccess; i++) launch();
+  if (e == hipSuccess) e = hipEventRecord(e1, stream);
+  if (e == hipSuccess) e = hipEventSynchronize(e1);
+  float ms = 0;
+  if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+  if (e == hipSuccess) e = hipGetLastError();
+  if (e0) (void)hipEventDestroy(e0);
+  if (e1) (void)hipEventDestroy(e1);
+  if (e != hipSuccess) return -(int)e;
+  *gbs = ms > 0 ? (double)per_pass * iters / 1e6 / ms : 0;
+  return 0;
 }

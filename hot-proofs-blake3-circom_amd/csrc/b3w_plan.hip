@@ -206,12 +206,9 @@ __host__ __device__ inline uint32_t seg_of(const B3wSpine &sp, uint64_t c) {
   return s;
 }
 
-__global__ __launch_bounds__(64) void b3w_plan_paths_kernel(const uint32_t *__restrict__ levels, uint64_t nchunks, B3wSpine sp,
-                                                            uint64_t first_chunk, uint32_t nlocal, uint32_t last_chunk_blocks,
-                                                            uint64_t row0, uint32_t *__restrict__ recs) {
-  const uint64_t i = (uint64_t)blockIdx.x * 64 + threadIdx.x;
-  if (i >= nlocal) return;
-  const uint64_t c = first_chunk + i;
+// the parent steps of chunk c's path, bottom up (one thread)
+__device__ __forceinline__ void plan_path(const uint32_t *levels, uint64_t nchunks, const B3wSpine &sp, uint64_t c, uint32_t last_chunk_blocks,
+                                          uint64_t row0, uint32_t *recs) {
   const uint32_t s = seg_of(sp, c), last = sp.nseg - 1, t = sp.level[s], plen = sp.plen[s];
   const uint32_t n_blocks = (c == nchunks - 1) ? last_chunk_blocks : 16;
   uint32_t *r = recs + (sp.row_base[s] + (c - sp.lo[s]) * plen - row0) * 32;
@@ -265,6 +262,117 @@ __global__ __launch_bounds__(64) void b3w_plan_paths_kernel(const uint32_t *__re
     blake3_cv(ivv, m, 0, 0, 64, 4u | (depth == 0 ? 8u : 0u), o);
 #pragma unroll
     for (int k = 0; k < 8; ++k) h[k] = o[k];
+  }
+}
+
+__global__ __launch_bounds__(64) void b3w_plan_paths_kernel(const uint32_t *__restrict__ levels, uint64_t nchunks, B3wSpine sp,
+                                                            uint64_t first_chunk, uint32_t nlocal, uint32_t last_chunk_blocks,
+                                                            uint64_t row0, uint32_t *__restrict__ recs) {
+  const uint64_t i = (uint64_t)blockIdx.x * 64 + threadIdx.x;
+  if (i >= nlocal) return;
+  plan_path(levels, nchunks, sp, first_chunk + i, last_chunk_blocks, row0, recs);
+}
+
+// ---- the upper tree in ONE launch (r05) -------------------------------------------------------------------------
+// b3w_chain_tree_device used to launch one merge kernel per level (10 dependent launches for the 1 024 chunks of a 1 MiB preimage,
+// plus one per carry): on a rank's share of a sharded 1 MiB pass that chain of launches was as long as the rank's leaf witness
+// kernel it is supposed to hide under (profiles/r04/chain_scaling_model_1mib.json).  From the level that has at most
+// B3W_TREE_NODES nodes on, ONE workgroup does every remaining level: the level lives in LDS (node i = words [8 i, 8 i + 8)), each
+// round thread p merges nodes 2 p and 2 p + 1 into node p (registers between the two barriers), writes it to the level array in HBM
+// as well (the path planner reads every level), an odd node out is a carry; thread 0 then folds the carries into the right spine
+// and the root.  PLAN: the same workgroup goes on to plan the parent steps of the rank's chunks (one thread per chunk, after an
+// agent-scope fence: the level arrays it reads were written by other waves of this workgroup) — taken when the rank has few
+// chunks; with many, 16 waves on one CU are slower than the path kernel's workgroups spread over the chip.
+constexpr uint32_t B3W_TREE_NODES = 1024;
+
+template <bool PLAN>
+__global__ __launch_bounds__(1024) void b3w_plan_tree_kernel(uint32_t *__restrict__ levels, uint64_t n, uint32_t l0, uint32_t *__restrict__ root,
+                                                             B3wSpine sp, uint64_t first_chunk, uint32_t nlocal, uint32_t last_chunk_blocks, uint64_t row0,
+                                                             uint32_t *__restrict__ recs) {
+  __shared__ __attribute__((aligned(16))) uint32_t node[B3W_TREE_NODES * 8];
+  __shared__ uint32_t carry[64 * 8];                        // carries this workgroup met, increasing level
+  const uint32_t t = threadIdx.x;
+  uint64_t off = 0;                                         // word offset of level l
+  for (uint32_t l = 0; l < l0; ++l) off += (n >> l) * 8;
+  uint64_t cnt = n >> l0;                                   // <= B3W_TREE_NODES
+  for (uint64_t i = t; i < cnt * 8; i += 1024) node[i] = levels[off + i];
+  // carries of the levels below l0 (merged by earlier launches): they wait in HBM
+  uint32_t nlow = 0;
+  for (uint32_t l = 0; l < l0; ++l) nlow += ((n >> l) & 1) && (n >> l) > 1 ? 1u : 0u;
+  __syncthreads();
+  uint32_t nc = 0;                                          // carries met here (uniform)
+  while (cnt > 1) {
+    const uint64_t pairs = cnt >> 1;
+    const bool odd = (cnt & 1) != 0;
+    const bool is_root = cnt == 2 && nlow + nc == 0;
+    uint32_t o[8];
+    if (t < pairs) {
+      uint32_t h[8], m[16];
+      iv(h);
+#pragma unroll
+      for (int k = 0; k < 16; ++k) m[k] = node[(uint64_t)t * 16 + k];
+      blake3_cv(h, m, 0, 0, 64, 4u | (is_root ? 8u : 0u), o);
+    }
+    uint32_t cv[8];
+    if (odd && t == 0) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) cv[k] = node[(cnt - 1) * 8 + k];
+    }
+    __syncthreads();                                        // every pair is in registers: the level may be overwritten
+    if (t < pairs) {
+      uint32_t *dst = is_root ? root : levels + off + cnt * 8 + (uint64_t)t * 8;
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { node[(uint64_t)t * 8 + k] = o[k]; dst[k] = o[k]; }
+    }
+    if (odd && t == 0) {
+#pragma unroll
+      for (int k = 0; k < 8; ++k) carry[nc * 8 + k] = cv[k];
+    }
+    if (odd) nc++;
+    __syncthreads();
+    off += cnt * 8;
+    cnt = pairs;
+  }
+  if (t == 0 && nlow + nc) {
+    // root = P(main, P(carry_k, ... P(carry_2, carry_1))) — BLAKE3's right-leaning chain of complete subtrees, smallest first;
+    // the chain's nodes go to the scratch behind the levels (suffix nodes: spine_of, b3w_plan_paths_kernel)
+    uint32_t h[8], m[16], o[8], right[8];
+    uint32_t *scratch = levels + 2 * n * 8;
+    uint32_t seen = 0;
+    uint64_t lo = 0;
+    for (uint32_t l = 0; seen < nlow + nc; ++l) {
+      const uint64_t c = n >> l;
+      const bool has = (c & 1) && c > 1;
+      if (has) {
+        uint32_t cvv[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) cvv[k] = l < l0 ? levels[lo + (c - 1) * 8 + k] : carry[(seen - nlow) * 8 + k];
+        if (seen == 0) {
+#pragma unroll
+          for (int k = 0; k < 8; ++k) right[k] = cvv[k];
+        } else {
+          iv(h);
+#pragma unroll
+          for (int k = 0; k < 8; ++k) { m[k] = cvv[k]; m[8 + k] = right[k]; }
+          blake3_cv(h, m, 0, 0, 64, 4u, o);
+#pragma unroll
+          for (int k = 0; k < 8; ++k) { right[k] = o[k]; scratch[(seen - 1) * 8 + k] = o[k]; }
+        }
+        seen++;
+      }
+      lo += c * 8;
+    }
+    iv(h);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) { m[k] = node[k]; m[8 + k] = right[k]; }
+    blake3_cv(h, m, 0, 0, 64, 4u | 8u, o);
+#pragma unroll
+    for (int k = 0; k < 8; ++k) root[k] = o[k];
+  }
+  if (PLAN) {
+    __threadfence();                                        // agent scope: level arrays written by other waves, read below through L1 / L2
+    __syncthreads();
+    for (uint32_t i = t; i < nlocal; i += 1024) plan_path(levels, n, sp, first_chunk + i, last_chunk_blocks, row0, recs);
   }
 }
 
@@ -336,6 +444,29 @@ extern "C" int b3w_launch_plan_parents(const uint32_t *d_levels, uint64_t nchunk
   const uint64_t row0 = sp.row_base[s0] + (first_chunk - sp.lo[s0]) * sp.plen[s0];
   hipLaunchKernelGGL(b3w_plan_paths_kernel, dim3((nlocal + 63) / 64), dim3(64), 0, stream, d_levels, nchunks, sp, first_chunk, nlocal,
                      last_chunk_blocks, row0, d_recs);
+  return (int)hipGetLastError();
+}
+
+// Every level of the tree from level `l0` (at most B3W_TREE_NODES nodes: b3w_plan_tree_first_level) up to the root, carries and
+// spine included, in one launch; plan_nlocal > 0: the parent steps of chunks [first_chunk, + plan_nlocal) in the same launch.
+extern "C" uint32_t b3w_plan_tree_first_level(uint64_t nchunks) {
+  uint32_t l = 0;
+  while ((nchunks >> l) > B3W_TREE_NODES) l++;
+  return l;
+}
+extern "C" int b3w_launch_plan_tree(uint32_t *d_levels, uint64_t nchunks, uint32_t l0, uint32_t *d_root, uint64_t first_chunk, uint32_t plan_nlocal,
+                                    uint32_t last_chunk_blocks, uint32_t *d_recs, hipStream_t stream) {
+  if (nchunks < 2 || (nchunks >> l0) > B3W_TREE_NODES || (nchunks >> l0) < 1) return (int)hipErrorInvalidValue;
+  const B3wSpine sp = spine_of(nchunks);
+  if (plan_nlocal) {
+    const uint32_t s0 = seg_of(sp, first_chunk);
+    const uint64_t row0 = sp.row_base[s0] + (first_chunk - sp.lo[s0]) * sp.plen[s0];
+    hipLaunchKernelGGL(b3w_plan_tree_kernel<true>, dim3(1), dim3(1024), 0, stream, d_levels, nchunks, l0, d_root, sp, first_chunk, plan_nlocal,
+                       last_chunk_blocks, row0, d_recs);
+  } else {
+    hipLaunchKernelGGL(b3w_plan_tree_kernel<false>, dim3(1), dim3(1024), 0, stream, d_levels, nchunks, l0, d_root, sp, (uint64_t)0, 0u, 0u, (uint64_t)0,
+                       (uint32_t *)nullptr);
+  }
   return (int)hipGetLastError();
 }
 

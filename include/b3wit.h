@@ -151,19 +151,32 @@ void b3w_bodies_trim(void);
  * b3w_bodies_trim to hand it to the driver), b3w_destroy does the same. */
 int32_t b3w_ctx_trim(b3w_ctx *ctx);
 /* Bounds of the placement allocator, in GiB (negative = leave as is): `search_gib` = new physical memory one search may
- * touch transiently beyond the buffer itself (default 16 x the buffer, at least 24, at most 160 — released again at the end
- * of the search); `pool_gib` = labelled memory kept pooled for later buffers, all three labels together (default 12).
+ * touch transiently beyond the buffer itself (default and most: 160, and never more than half of what is free — released again at
+ * the end of the search; what ends a search first is its time limit, b3w_bodies_search_limit); `pool_gib` = labelled memory kept pooled for later buffers, all three labels together (default 12).
  * Also B3W_PLACE_SEARCH_GIB / B3W_PLACE_POOL_GIB in the environment.  Other allocators in the process (torch, RCCL) cannot
  * see pooled memory: b3w_bodies_trim hands it back. */
 void b3w_bodies_configure(int64_t search_gib, int64_t pool_gib);
 /* What placement costs.  A search ends — and the buffer is plain — when it has not found a second class of memory after
- * `seconds` (default 30; B3W_PLACE_SEARCH_S; <= 0 = no limit) as well as when it runs out of its GiB budget.
+ * `seconds` (default 5; B3W_PLACE_SEARCH_S; <= 0 = no limit) as well as when it runs out of its GiB budget.
  * b3w_bodies_search_stats: out[0] = seconds spent inside searching b3w_bodies_alloc calls on the ctx's device so far (probes,
  * seam checks), out[1] = GiB of new physical memory those searches created (most of it released again), out[2] = searches that
  * ended on the time limit, out[3] = the time limit, out[4] = seconds spent in the real-kernel check of "mixed" buffers (the three
  * plain yardstick buffers are measured once per context). */
 void b3w_bodies_search_limit(double seconds);
 int32_t b3w_bodies_search_stats(const b3w_ctx *ctx, double out[5]);
+/* Where a search's time goes: seconds this process has spent inside hipMemCreate (out[0]), hipMemMap + hipMemSetAccess (out[1]), the
+ * timed store probes (out[2]) and hipMemUnmap + hipMemRelease (out[3]) on the ctx's device.  The first is the driver's: a call
+ * returns in microseconds until the process's footprint crosses some tens of GiB and then one call takes seconds
+ * (profiles/r05/place_cost.log). */
+int32_t b3w_bodies_search_breakdown(const b3w_ctx *ctx, double out[4]);
+/* Harness helper: the pure-store ceiling of a body buffer — GB/s of `iters` passes (after 2 untimed ones) of kernels that do
+ * nothing but the witness kernels' stores into n bodies at d_bodies + i * pitch (16-byte aligned; pitch 0 = witness_size * 32):
+ * shape 0 = body streams, one wave per 4 bodies and 1 KiB per body and step (the fused kernels' EXPAND phase without trace, slot
+ * table or LDS), 1 = the same per 8 bodies, 2 = the runtime's fill shape (256 workgroups over 4 KiB tiles; the sweep kernels').
+ * What a witness kernel's achieved bandwidth on the SAME buffer is to be read against (bench.py: roofline.of_measured_ceiling).
+ * HIP events on `stream`; waits for them.  The buffer's contents are overwritten. */
+int32_t b3w_bodies_store_rate(b3w_ctx *ctx, void *d_bodies, uint32_t n, uint64_t pitch, int32_t shape, uint32_t iters, void *stream,
+                              double *gb_per_s);
 /* out[0] address-space arena of the ctx's device in bytes, out[1] of it used up (never reused), out[2] pooled bytes,
  * out[3] bytes of live placed buffers, out[4] their number, out[5] physical 256 MiB handles created so far. */
 int32_t b3w_bodies_stats(const b3w_ctx *ctx, uint64_t out[6]);
@@ -453,11 +466,23 @@ int32_t b3w_chain_commit_only(b3w_chain *chain, const b3w_commit_key *key, uint8
  * constraint check and consumers see every batch: the fold-shaped pass "witness -> check -> commit" where the commitment does not
  * read the 745 KB body back (b3w_batch_commit_device / b3w_commit_consumer do: they are for bodies the library did not make).
  * A step's commitment from its record equals the commitment of the body the witness kernel writes for it (tests/test_gpu_commit.py).
- * The commit kernels are bound by the vector ALUs, the witness kernels by HBM writes: unless the chain also checks constraints
- * (b3w_chain_check_constraints) the commitments run on a stream of the chain's own, side by side with the witness kernels, and
- * `stream` is made to wait for them at the end of each run call (+11 %: 4.27 M steps/s for 64 MiB).  B3W_CHAIN_COMMIT_ASYNC=0 / 1
- * overrides that choice; B3W_COMMIT_CU_PCT=<p> confines that stream to p % of the CUs (measured: slower at 75 and 88). */
+ * The commit kernels are bound by the vector ALUs, the witness kernels by HBM writes, so the commitments get a stream of the
+ * chain's own beside the witness kernels; b3w_chain_commit_overlap says how far that goes. */
 int32_t b3w_chain_commit_from_records(b3w_chain *chain, const b3w_commit_key *key, uint8_t *d_points);
+/* Where the commitments of b3w_chain_commit_from_records run, per batch of steps (call before or after it; it holds for the chain):
+ *   SERIAL  on the caller's stream, in front of the batch's witness kernel: nothing runs side by side
+ *   FREE    on the chain's commit stream, ordered only behind the batch's planner: they run beside the witness kernels of this and
+ *           later batches and `stream` waits for them at the end of each run call (4.5 M steps/s against 3.9 serial, 64 MiB)
+ *   GATED   on the commit stream beside THIS batch's witness kernel only: whatever reads the batch on `stream` afterwards — the
+ *           constraint check of b3w_chain_check_constraints, the consumer — starts when both have finished and has the device to
+ *           itself, and the next batch's commitments start behind it (the check wants every vector register and most of the LDS of
+ *           a CU: beside it the commit kernel only gets in its way)
+ *   AUTO    (default) GATED when the chain checks constraints or the run call has a consumer, else FREE */
+#define B3W_COMMIT_OVERLAP_AUTO   (-1)
+#define B3W_COMMIT_OVERLAP_SERIAL 0
+#define B3W_COMMIT_OVERLAP_FREE   1
+#define B3W_COMMIT_OVERLAP_GATED  2
+int32_t b3w_chain_commit_overlap(b3w_chain *chain, int32_t mode);
 /* d_points = NULL above: the chain keeps the points itself; this copies them (n_leaf + n_parent times 64 bytes) to the host. */
 int32_t b3w_chain_commitments(b3w_chain *chain, uint8_t *host_points, void *stream);
 /* Constraint check inside the chained pass: after this call (r1cs = a system of the chain's context; NULL turns it off) every
@@ -466,6 +491,7 @@ int32_t b3w_chain_commitments(b3w_chain *chain, uint8_t *host_points, void *stre
  * constraint) to the host once `stream` has drained. */
 int32_t b3w_chain_check_constraints(b3w_chain *chain, const b3w_r1cs *r1cs);
 int32_t b3w_chain_violations(b3w_chain *chain, uint32_t *host_violations, void *stream);
+uint32_t *b3w_chain_violations_device(b3w_chain *chain);   /* device: n_leaf + n_parent counts, NULL before b3w_chain_check_constraints */
 int32_t b3w_chain_run_leaves(b3w_chain *chain, const uint8_t *host_preimage /* byte 0 of the WHOLE preimage */,
                              b3w_batch_consumer consumer, void *user, void *stream);
 int32_t b3w_chain_run_parents(b3w_chain *chain, const uint32_t *d_all_chunk_cvs /* n_chunks*8 words; NULL = the local ones,

@@ -124,6 +124,10 @@ extern "C" {
                               host_public: *mut u32, host_status: *mut i32) -> i32;
     pub fn b3w_chain_commit_only(chain: *mut c_void, key: *const c_void, d_points: *mut u8) -> i32;
     pub fn b3w_chain_commitments(chain: *mut c_void, host_points: *mut u8, stream: *mut c_void) -> i32;
+    pub fn b3w_chain_commit_from_records(chain: *mut c_void, key: *const c_void, d_points: *mut u8) -> i32;
+    pub fn b3w_chain_commit_overlap(chain: *mut c_void, mode: i32) -> i32;
+    pub fn b3w_chain_check_constraints(chain: *mut c_void, r1cs: *const c_void) -> i32;
+    pub fn b3w_chain_violations(chain: *mut c_void, host_violations: *mut u32, stream: *mut c_void) -> i32;
 }
 
 /// What one pass leaves on the host: 15 public-output words per step (leaf steps in (chunk, block) order, then the parent steps
@@ -146,6 +150,23 @@ impl Fold {
     pub fn commit_only(&mut self, key: *const c_void) -> Result<(), i32> {
         let rc = unsafe { b3w_chain_commit_only(self.chain, key, std::ptr::null_mut()) };
         if rc != 0 { Err(rc) } else { Ok(()) }
+    }
+
+    /// The fold-shaped pass: bodies are written and handed on as usual, and every step's commitment is computed from its record
+    /// beside them (`overlap`: -1 auto, 0 serial, 1 free, 2 gated — b3wit.h, b3w_chain_commit_overlap).  `r1cs` (from
+    /// b3w_r1cs_create on the same Calculator, or null) adds the constraint check of every step witness in front of the consumer.
+    pub fn fold_shaped(&mut self, key: *const c_void, r1cs: *const c_void, overlap: i32) -> Result<(), i32> {
+        let mut rc = unsafe { b3w_chain_check_constraints(self.chain, r1cs) };
+        if rc == 0 { rc = unsafe { b3w_chain_commit_overlap(self.chain, overlap) }; }
+        if rc == 0 { rc = unsafe { b3w_chain_commit_from_records(self.chain, key, std::ptr::null_mut()) }; }
+        if rc != 0 { Err(rc) } else { Ok(()) }
+    }
+
+    /// After a pass with `fold_shaped(_, r1cs, _)`: violated constraints per step (0 = the step satisfies its circuit).
+    pub fn violations(&mut self, n_steps: usize) -> Result<Vec<u32>, i32> {
+        let mut v = vec![0u32; n_steps];
+        let rc = unsafe { b3w_chain_violations(self.chain, v.as_mut_ptr(), std::ptr::null_mut()) };
+        if rc != 0 { Err(rc) } else { Ok(v) }
     }
 
     /// The whole pass over `preimage`.  `consumer` (with its `user` pointer) sees every batch of step witnesses on the device.

@@ -3,6 +3,10 @@
 //   harness run <nranks> <slot_bytes>      all ranks present: message sizes below, at and above one slot
 //   harness missing <nranks>               the last rank never comes: every other rank must fail within the timeout
 //   harness stale <nranks>                 a dead job's segment lies under the name: the job replaces it
+//   harness reopen <nranks>                every rank opens, gathers, closes and re-opens under the SAME name, five times in a row
+//                                          (a rank must not find the previous round's segment still linked)
+//   harness threads <nranks>               the ranks are THREADS of one process (how eight ranks are rehearsed on a box that admits
+//                                          six processes to its GPU: tests/test_gpu_native_exchange.py)
 #include <fcntl.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -13,11 +17,23 @@
 #include <unistd.h>
 
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "b3w_hostcomm.h"
 
 static uint8_t pat(int rank, int round, uint64_t i) { return (uint8_t)(rank * 131 + round * 29 + i * 7 + (i >> 8)); }
+
+static int rank_main(const std::string &name, int rank, int nranks, uint64_t slot, double timeout, bool expect_fail);
+
+static int reopen_main(const std::string &name, int rank, int nranks, uint64_t slot) {
+  for (int round = 0; round < 5; round++) {
+    if (rank == nranks - 1 && round) usleep(20000 * round);  // the ranks do not come back at the same time
+    const int rc = rank_main(name, rank, nranks, slot, 10.0, false);
+    if (rc) { fprintf(stderr, "rank %d: round %d of re-opening failed\n", rank, round); return rc; }
+  }
+  return 0;
+}
 
 static int rank_main(const std::string &name, int rank, int nranks, uint64_t slot, double timeout, bool expect_fail) {
   char err[256] = "";
@@ -63,13 +79,24 @@ int main(int argc, char **argv) {
     munmap(p, 4096);
     close(fd);
   }
+  if (mode == "threads") {
+    std::vector<std::thread> th;
+    std::vector<int> rcs(nranks, -1);
+    for (int r = 0; r < nranks; r++) th.emplace_back([&, r] { rcs[r] = reopen_main(name, r, nranks, slot); });
+    for (auto &t : th) t.join();
+    int bad = 0;
+    for (int rc : rcs) bad += rc != 0;
+    if (shm_open(name.c_str(), O_RDWR, 0600) >= 0) { fprintf(stderr, "the segment's name was left behind\n"); shm_unlink(name.c_str()); bad++; }
+    printf("%s: %d ranks, %d failed\n", mode.c_str(), nranks, bad);
+    return bad ? 1 : 0;
+  }
   const bool missing = mode == "missing";
   std::vector<pid_t> kids;
   for (int r = 0; r < nranks - (missing ? 1 : 0); r++) {
     const pid_t pid = fork();
     if (pid == 0) {
       if (mode == "stale" && r == 0) usleep(300000);         // the others look for the segment first and find the stale one
-      const int rc = rank_main(name, r, nranks, slot, missing ? 2.0 : 30.0, missing);
+      const int rc = mode == "reopen" ? reopen_main(name, r, nranks, slot) : rank_main(name, r, nranks, slot, missing ? 2.0 : 30.0, missing);
       fflush(stdout);
       _exit(rc);
     }

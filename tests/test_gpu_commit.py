@@ -431,7 +431,36 @@ def test_chained_pass_commit_only_matches_the_commit_consumer():
     out3 = m.chain.fold_witnesses(ctx, data, batch_steps=48, ring=2, consumer=lambda v, f, k: (seen.append(k), consumer(v, f, k)), commit_records=(key, c))
     torch.cuda.synchronize()
     assert sum(seen) == 152 and torch.equal(c, b) and torch.equal(a, b) and out3["root"].cpu().numpy().view(np.uint32).tobytes() == root
-    key.close(); ctx.close()
+    # b3w_chain_commit_overlap: wherever the commitments run, the points are the same; with the chain's own constraint check in
+    # front of the consumer every step still satisfies the circuit.  GATED (what "auto" picks when something reads the batch) makes a
+    # promise about order: what runs on the caller's stream after a batch's witness kernel starts when the batch's commitments are
+    # done too — so a consumer that copies the batch's POINTS on that stream sees the finished points of exactly its batch.
+    r1cs = m.R1cs(ctx)
+    for mode in ("serial", "free", "gated", "auto"):
+        for chk in (None, r1cs):
+            c.zero_()
+            snap = torch.zeros_like(c)
+
+            def copy_points(view, first, k):
+                snap[first:first + k].copy_(c[first:first + k])         # on the current (= the chain's caller) stream
+            o = m.chain.fold_witnesses(ctx, data, batch_steps=48, ring=2, consumer=copy_points, commit_records=(key, c), check=chk, commit_overlap=mode)
+            torch.cuda.synchronize()
+            assert torch.equal(c, b), (mode, chk is not None)
+            assert int(o["status"].abs().sum().item()) == 0 and o["root"].cpu().numpy().view(np.uint32).tobytes() == root
+            if chk is not None:
+                assert o["violations"].shape == (152,) and int(o["violations"].abs().sum().item()) == 0
+            if mode in ("serial", "gated", "auto"):
+                assert torch.equal(snap, b), f"{mode}: a consumer ran before its batch's commitments were complete"
+    # a run without a consumer and without a check: auto = free; and back to bodies only
+    c.zero_()
+    m.chain.fold_witnesses(ctx, data, batch_steps=48, ring=2, commit_records=(key, c))
+    torch.cuda.synchronize()
+    assert torch.equal(c, b)
+    assert m.lib().b3w_chain_commit_overlap(next(iter(ctx._chain_cache.values())), 7) == 100      # B3W_E_BAD_ARGUMENT
+    o = m.chain.fold_witnesses(ctx, data, batch_steps=48, ring=2)
+    torch.cuda.synchronize()
+    assert o["violations"] is None and o["root"].cpu().numpy().view(np.uint32).tobytes() == root
+    r1cs.close(); key.close(); ctx.close()
 
 
 def test_commitments_from_records_across_a_chunk_border_and_argument_checks():

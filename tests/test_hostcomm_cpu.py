@@ -38,3 +38,15 @@ def test_a_missing_rank_fails_everybody_within_the_timeout(harness):
 def test_a_stale_segment_under_the_name_is_replaced(harness):
     r = subprocess.run([harness, "stale", "3"], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and "3 ranks, 0 failed" in r.stdout, (r.stdout, r.stderr[-2000:])
+
+
+def test_ranks_that_close_and_reopen_under_the_same_name(harness):
+    """open has two phases (barrier, rank 0 unlinks the name, barrier), so no rank comes out of it while the name is still
+    linked — five rounds of open / gather / close / open again under one name, the ranks returning at different times."""
+    r = subprocess.run([harness, "reopen", "4", "512"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "4 ranks, 0 failed" in r.stdout, (r.stdout, r.stderr[-2000:])
+
+
+def test_eight_ranks_as_threads_of_one_process(harness):
+    r = subprocess.run([harness, "threads", "8", "1024"], capture_output=True, text=True, timeout=180)
+    assert r.returncode == 0 and "8 ranks, 0 failed" in r.stdout, (r.stdout, r.stderr[-2000:])

@@ -128,7 +128,7 @@ def test_the_wrappers_are_the_call_site_and_the_chained_pass():
     rust_fold/src/blake3_circuit.rs:305) and the chained pass that replaces its loop (Fold, for rust_fold/src/main.rs:166-179)"""
     src = open(os.path.join(ROOT, "integrations", "rust", "b3wit_ffi.rs")).read()
     wrappers = set(re.findall(r"\bpub fn (?!b3w_)([a-z0-9_]+)", src))
-    assert wrappers == {"fnv1a64", "new", "calculate_witness", "commit_only", "run", "commitments"}, wrappers
+    assert wrappers == {"fnv1a64", "new", "calculate_witness", "commit_only", "fold_shaped", "violations", "run", "commitments"}, wrappers
     assert "impl Drop for Fold" in src and "impl Drop for Calculator" in src
     assert len(src.splitlines()) <= 200
 
