@@ -35,7 +35,8 @@ def hipcc():
 def build_lib(force=False, extra_flags=()):
     """One object per source, compiled side by side (the commit kernels alone take 50 s), then one link."""
     from concurrent.futures import ThreadPoolExecutor
-    names = ("b3w_kernels.hip", "b3w_exact.hip", "b3w_plan.hip", "b3w_placement.hip", "b3w_commit.hip", "b3w_r1cs.hip", "b3w_r1cs_walk.hip", "b3w_r1cs_host.cpp", "b3w_hostcomm.cpp", "b3w_capi.cpp")
+    names = ("b3w_kernels.hip", "b3w_exact.hip", "b3w_plan.hip", "b3w_placement.hip", "b3w_commit.hip", "b3w_r1cs.hip", "b3w_r1cs_walk.hip", "b3w_r1cs_host.cpp", "b3w_hostcomm.cpp",
+             "b3w_ctx.cpp", "b3w_bodies.cpp", "b3w_wtns.cpp", "b3w_r1cs_api.cpp", "b3w_commit_api.cpp", "b3w_comm.cpp", "b3w_chain.cpp")
     srcs = [os.path.join(CSRC, f) for f in names]
     hdrs = [os.path.join(CSRC, f) for f in sorted(os.listdir(CSRC)) if f.endswith((".h", ".inc"))] + \
         [os.path.join(ROOT, "include", "b3wit.h")]

@@ -102,10 +102,10 @@ extern "C" int b3w_launch_r1cs(const uint8_t *d_bodies, uint32_t n, uint64_t pit
                                const B3wField *field, uint32_t *d_violations, uint32_t *d_first, hipStream_t stream);
 // tiles: tile t = wires [t * B3W_R1CS_TILE, +B3W_R1CS_TILE); ntiles x {first row, rows, first outside wire, outside wires}
 // coef_small[cid] = the coefficient as a signed integer when |c| < 2^62 (c or c - p), else B3W_R1CS_NOT_SMALL
-// the LEAN pair (default): the same tiles with 8-byte elements in LDS and integer arithmetic only; the rows a workgroup cannot
-// decide that way (an element of 2^63 or more, a coefficient that is no small integer, |<A,z>| or |<B,z>| of 2^63 or more) are
-// marked in `scratch` and evaluated by a second launch with the gather kernel's field arithmetic.  Same verdicts as the other
-// two kernels.  row_k[r] = the gather formulation's row number of tile row r.
+// the tiled formulations (stream, walk): the same tiles with 8-byte elements in LDS and integer arithmetic only; the rows a workgroup
+// cannot decide that way (an element of 2^63 or more, a coefficient that is no small integer, |<A,z>| or |<B,z>| of 2^63 or more) are
+// marked in `scratch` and evaluated by a second launch with the gather kernel's field arithmetic.  Same verdicts as the gather
+// kernel.  row_k[r] = the gather formulation's row number of tile row r.
 struct B3wR1csSystem {
   uint32_t nwires, ntiles, max_ext, max_tile_terms, max_tile_rows, ncoef;
   const uint32_t *tiles, *tile_terms, *ext, *rows, *row_id, *row_k, *terms, *coefs;
@@ -130,7 +130,7 @@ struct B3wWalk {
   const unsigned long long *stat;        // static_words per tile
   const long long *coef_small;
   const uint32_t *static_k, *static_id;  // the always-deferred rows as a list: {first pair, pairs, linear, has C} per row, then their unique terms
-                                         // as pairs {wire, coefficient id | parts << 16} (b3w_capi.cpp); constraint numbers
+                                         // as pairs {wire, coefficient id | parts << 16} (b3w_r1cs_api.cpp); constraint numbers
   uint32_t nstatic, pad2;
   uint32_t static_d0[4];                 // the first one's descriptor (a kernel argument of the deferred kernel)
   uint32_t p[8];                         // the field's prime: the walk kernel takes an element p - k (k < 2^62) for the small number -k
@@ -143,8 +143,6 @@ extern "C" int b3w_launch_r1cs_walk(const uint8_t *d_bodies, uint32_t n, uint64_
 extern "C" size_t b3w_r1cs_walk_scratch_bytes(const B3wWalk *walk);
 #define B3W_R1CS_SLAB 8192u                                  // bodies per launch pair at most: bounds the scratch (64 MB at most)
 extern "C" size_t b3w_r1cs_scratch_bytes(const B3wR1csSystem *sys);
-extern "C" int b3w_launch_r1cs_lean(const uint8_t *d_bodies, uint32_t n, uint64_t pitch, const B3wR1csSystem *sys, const B3wField *field,
-                                    unsigned long long *d_scratch, uint32_t *d_violations, uint32_t *d_first, hipStream_t stream);
 // the STREAM kernel (default where the system fits): persistent 512-thread workgroups, two to a CU, over the tile-major unit list;
 // elements fetched into registers one unit ahead, one barrier per unit (b3w_r1cs.hip); same scratch blocks (word 0 = which mask
 // words were stored), same deferred kernel, same verdicts.

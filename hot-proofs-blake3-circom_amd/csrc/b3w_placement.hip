@@ -64,7 +64,7 @@ __global__ __launch_bounds__(64) void b3w_store_probe_kernel(uint8_t *lo, uint8_
 // slot table, no LDS: the stores and their addresses only).  FILL: 256 workgroups of 256 threads walking 4 KiB tiles b, b + 256, ...
 // (the runtime's own fill shape, what the sweep kernels imitate).
 template <int W>
-__global__ __launch_bounds__(64) void b3w_store_streams_kernel(uint8_t *out, uint64_t pitch, uint32_t n, uint32_t tiles) {
+__global__ __launch_bounds__(64) void b3w_store_streams_kernel(uint8_t *out, uint64_t pitch, uint32_t n, uint32_t tiles, uint32_t pause = 0) {
   const uint32_t b0 = blockIdx.x * W, lane = threadIdx.x;
   const u32x4 v = {lane, blockIdx.x, 0, 0};
   uint8_t *base[W];
@@ -73,6 +73,8 @@ __global__ __launch_bounds__(64) void b3w_store_streams_kernel(uint8_t *out, uin
   for (uint32_t g = 0; g < tiles; ++g) {
 #pragma unroll
     for (int w = 0; w < W; ++w) *reinterpret_cast<u32x4 *>(base[w] + (uint64_t)g * 1024) = v;
+    // (measurements: a writer that leaves the memory system a little air — `pause` x 64 cycles of s_sleep per W KiB stored)
+    for (uint32_t k = 0; k < pause; ++k) __builtin_amdgcn_s_sleep(1);
   }
 }
 __global__ __launch_bounds__(256) void b3w_store_fill_kernel(uint8_t *out, uint64_t bytes) {
@@ -564,8 +566,9 @@ extern "C" void b3w_place_cost_breakdown(int device, double out[4]) {
 extern "C" int b3w_place_store_launch(uint8_t *buf, uint64_t pitch, uint32_t n, uint32_t body_bytes, int shape, hipStream_t stream) {
   if (!buf || !n || body_bytes < 1024 || pitch < body_bytes) return -(int)hipErrorInvalidValue;
   const uint32_t tiles = body_bytes / 1024;
-  if (shape == 0) hipLaunchKernelGGL(b3w_store_streams_kernel<4>, dim3((n + 3) / 4), dim3(64), 0, stream, buf, pitch, n, tiles);
-  else if (shape == 1) hipLaunchKernelGGL(b3w_store_streams_kernel<8>, dim3((n + 7) / 8), dim3(64), 0, stream, buf, pitch, n, tiles);
+  if (shape >= 100) hipLaunchKernelGGL(b3w_store_streams_kernel<8>, dim3((n + 7) / 8), dim3(64), 0, stream, buf, pitch, n, tiles, (uint32_t)(shape - 100));   // paused
+  else if (shape == 0) hipLaunchKernelGGL(b3w_store_streams_kernel<4>, dim3((n + 3) / 4), dim3(64), 0, stream, buf, pitch, n, tiles, 0u);
+  else if (shape == 1) hipLaunchKernelGGL(b3w_store_streams_kernel<8>, dim3((n + 7) / 8), dim3(64), 0, stream, buf, pitch, n, tiles, 0u);
   else hipLaunchKernelGGL(b3w_store_fill_kernel, dim3(256), dim3(256), 0, stream, buf, (uint64_t)n * pitch);
   return -(int)hipGetLastError();
 }
@@ -577,8 +580,8 @@ extern "C" int b3w_place_store_rate(uint8_t *buf, uint64_t pitch, uint32_t n, ui
   const uint32_t tiles = body_bytes / 1024;
   const uint64_t per_pass = shape == 2 ? ((uint64_t)n * pitch / 4096) * 4096 : (uint64_t)n * tiles * 1024;
   auto launch = [&] {
-    if (shape == 0) hipLaunchKernelGGL(b3w_store_streams_kernel<4>, dim3((n + 3) / 4), dim3(64), 0, stream, buf, pitch, n, tiles);
-    else if (shape == 1) hipLaunchKernelGGL(b3w_store_streams_kernel<8>, dim3((n + 7) / 8), dim3(64), 0, stream, buf, pitch, n, tiles);
+    if (shape == 0) hipLaunchKernelGGL(b3w_store_streams_kernel<4>, dim3((n + 3) / 4), dim3(64), 0, stream, buf, pitch, n, tiles, 0u);
+    else if (shape == 1) hipLaunchKernelGGL(b3w_store_streams_kernel<8>, dim3((n + 7) / 8), dim3(64), 0, stream, buf, pitch, n, tiles, 0u);
     else hipLaunchKernelGGL(b3w_store_fill_kernel, dim3(256), dim3(256), 0, stream, buf, (uint64_t)n * pitch);
   };
   hipEvent_t e0 = nullptr, e1 = nullptr;

@@ -4,7 +4,7 @@
 // This is what the reference's consumers do with a witness before anything else: circom_tester's expectPass /
 // checkConstraints (test/blake3_hash.test.ts:36) and the Nova driver's synthesize_with_vec, which enforces
 // every R1CS row over the witness variables (rust_fold/src/utils.rs:17-88).  The constraint system is DATA (an iden3
-// .r1cs image parsed in b3w_capi.cpp: for blake3_compression the one tools/gen_r1cs.py derives from the circuit text
+// .r1cs image parsed in b3w_r1cs_api.cpp: for blake3_compression the one tools/gen_r1cs.py derives from the circuit text
 // and checks against the build's .sym and the committed witness); nothing in here knows BLAKE3, the slot tables or the
 // TRACE code of the witness kernels, so a wrong witness kernel or a wrong slot table cannot hide behind it.
 //
@@ -78,245 +78,9 @@ __global__ __launch_bounds__(256) void b3w_r1cs_kernel(const uint8_t *__restrict
   }
 }
 
-// ---- lean pair ------------------------------------------------------------------------------------------------------
-// The tile kernel above carries the whole field arithmetic in every lane (150 VGPRs: three waves per SIMD) and 32-byte
-// elements (40 KB of LDS per workgroup), and its waves sit on one dependent L2 load per term (profiles/r02: parked 63 % of
-// their cycles).  A valid witness of these circuits needs none of that: its elements are bits, 32-bit words and a few
-// sums, the coefficients +-1, +-2^i and the IV words.  The LEAN kernel keeps only that case: elements as 8 bytes in LDS
-// (bit 63 = "not below 2^63"), the tile's term list and the coefficient table in LDS beside them (30 KB in all for
-// blake3_compression: five workgroups per CU, no global load inside the row loop), rows summed as 128-bit integers.  A row
-// it cannot decide that way is DEFERRED: one bit per row in `scratch`, evaluated afterwards by b3w_r1cs_deferred_kernel
-// with gather_row() — the rows of the 66 field inverses of a nova step, and whatever a corrupted body contains.
-//
-// scratch: per (body, tile) a block of 1 + 4 * ceil(max_tile_rows / 256) 64-bit words: [0] = any row deferred,
-// [1 + 4 * it + wave] = the deferred lanes of that wave in iteration `it` (row = first + 256 * it + thread).  Every word the
-// second kernel reads is written by the first: no initialisation.
-
-#define B3W_LEAN_ALWAYS_DEFER 0x40000000u                  // bit 30 of a lean row's A count: a coefficient of the row is no small integer — no
-                                                           // integer evaluation can decide it, it goes to the deferred kernel unread
-
-// <row part, z> as an exact integer; *defer when a term is outside the integer case (then the sum is not used).
-// A part is `n` words of the lean term stream.  A word idx | cid << 16 is a term; per term the wave takes one of two roads: all
-// its elements are bits (98 % of a valid witness) — the coefficient is added or not, no multiplication — or the general
-// 64 x 64 -> 128 product.  A word idx0 | 0xFFFF << 16 opens a BIT RUN (two words; the second: n | k << 8 | negative << 16): the
-// sum of 2^(k+i) * z[idx0 + i] over i < n <= 64, which is the run's bits — cut out of the tile's bit-packed elements, `packed`
-// = for every 64 elements a word of "is 1" bits, then a word of "is neither 0 nor 1" bits — shifted by k; a run with an element
-// that is no bit defers the row.  (A recomposition row "word = sum 2^i bit_i" is 32 terms on one lane without this.)  Term
-// words are fetched ahead; the words behind a row's last are the next row's or the pad: always inside the array.
-__device__ __forceinline__ __int128 lean_dot(const unsigned long long *el, const unsigned long long *packed, const uint32_t *terms,
-                                             const long long *coef, uint32_t off, uint32_t n, bool *defer) {
-  __int128 s = 0;
-  if (n == 0) return s;
-  uint32_t t = terms[off];
-  uint32_t k = 0;
-  while (k < n) {
-    const uint32_t t1 = terms[off + k + 1];
-    if ((t >> 16) == 0xFFFFu) {
-      const uint32_t idx0 = t & 0xFFFFu, len = t1 & 0xFFu, sh = (t1 >> 8) & 0xFFu;
-      const uint32_t g = idx0 >> 6, r = idx0 & 63u;
-      const unsigned long long one_lo = packed[2 * g], bad_lo = packed[2 * g + 1], one_hi = packed[2 * g + 2], bad_hi = packed[2 * g + 3];
-      const unsigned long long mask = len == 64u ? ~0ull : (1ull << len) - 1ull;
-      const unsigned long long ones = ((one_lo >> r) | (r ? one_hi << (64u - r) : 0ull)) & mask;
-      const unsigned long long bads = ((bad_lo >> r) | (r ? bad_hi << (64u - r) : 0ull)) & mask;
-      if (bads) *defer = true;
-      const __int128 v = (__int128)((unsigned __int128)ones << sh);                // < 2^(len + sh) <= 2^62 * 2: the coefficients are below 2^62
-      s += (t1 >> 16) & 1u ? -v : v;
-      k += 2;
-      t = terms[off + k];
-    } else {
-      const unsigned long long z = el[t & 0xFFFFu];
-      const long long c = coef[t >> 16];
-      if (c == B3W_R1CS_NOT_SMALL) *defer = true;          // (the sentinel's product below is never used)
-      if (__builtin_amdgcn_ballot_w64(z > 1ull) == 0) {
-        s += (__int128)(z ? c : 0ll);
-      } else {
-        const unsigned long long mag = c < 0 ? 0ull - (unsigned long long)c : (unsigned long long)c;
-        // |c| < 2^62 with z < 2^32, or |c| < 2^40 with z < 2^63: the product stays below 2^103 and 2^20 of them below 2^127
-        if ((z >> 63) || ((z >> 32) && mag >= (1ull << 40))) *defer = true;
-        s += (__int128)c * (__int128)(long long)z;
-      }
-      k += 1;
-      t = t1;
-    }
-  }
-  return s;
-}
-
-template <bool STAGED, bool COEF_LDS>
-__global__ __launch_bounds__(256) void b3w_r1cs_lean_kernel(const uint8_t *__restrict__ bodies, uint64_t pitch, uint32_t n, B3wR1csSystem S,
-                                                            unsigned long long *__restrict__ scratch, uint32_t block_words,
-                                                            uint32_t *__restrict__ violations, uint32_t *__restrict__ first) {
-  extern __shared__ unsigned long long el[];
-  const uint32_t per_group = 8u * S.ntiles;
-  const uint32_t b = (blockIdx.x / per_group) * 8u + (blockIdx.x & 7u);
-  const uint32_t tile = (blockIdx.x % per_group) >> 3;
-  if (b >= n) return;
-  const uint8_t *body = bodies + (uint64_t)b * pitch;
-  const uint4 td = reinterpret_cast<const uint4 *>(S.tiles)[tile];
-  const uint4 *rows = reinterpret_cast<const uint4 *>(S.rows);
-  const uint32_t t0 = tile * B3W_R1CS_TILE;
-  const uint32_t n_local = S.nwires - t0 < B3W_R1CS_TILE ? S.nwires - t0 : B3W_R1CS_TILE;
-  constexpr uint32_t PRE = 5;                              // row descriptors fetched under the staging (a tile of these systems has 1 030 ... 1 055 rows: five rounds of 256)
-  uint4 pre[PRE];
-#pragma unroll
-  for (uint32_t q = 0; q < PRE; q++) {
-    const uint32_t r = td.x + threadIdx.x + 256 * q;
-    pre[q] = r < td.x + td.y ? rows[r] : make_uint4(0, 0, 0, 0);
-  }
-  // Staging.  Every load is issued before the first LDS write waits for one (a loop of load - pack - write makes each lane's
-  // loads serial round trips to HBM: 25 of them for a tile of blake3_compression).  LDS: elements [TILE + ext_cap] |
-  // term words | coefficients.
-  const uint2 tt = reinterpret_cast<const uint2 *>(S.tile_terms)[tile];            // first term of the tile (a multiple of 4), how many
-  const uint32_t ext_cap = (S.max_ext + 2u) & ~1u;                                // one dump slot; keeps the term words 16-byte aligned
-  // packed: for every 64 elements {bits "is 1", bits "is neither 0 nor 1"}; one spare pair behind (a run reads its group and the next)
-  unsigned long long *packed = el + B3W_R1CS_TILE + ext_cap;
-  const uint32_t groups = ((B3W_R1CS_TILE + ext_cap + 63u) >> 6) + 1u;
-  uint4 *lterms4 = reinterpret_cast<uint4 *>(packed + 2 * groups);
-  uint32_t *lterms = reinterpret_cast<uint32_t *>(lterms4);
-  const uint32_t lterm_words = STAGED ? (S.max_tile_terms + 5u) & ~3u : 0u;       // (room for the two read-ahead words)
-  long long *lcoef = reinterpret_cast<long long *>(lterms + lterm_words + (STAGED ? 4u : 0u));       // (+ the dump uint4)
-  // (lanes with nothing to stage load element 0 / word 0 and write a dump slot: no branch for the compiler to sink a load into)
-  const uint32_t el_dump = B3W_R1CS_TILE + ext_cap - 1u;                           // (behind the last outside wire)
-  const uint32_t ew = S.ext[td.z + (threadIdx.x < td.w ? threadIdx.x : 0u)];       // this lane's outside wire (every tile has one)
-  uint4 lo[4], hi[4];
-#pragma unroll
-  for (uint32_t u = 0; u < 4; u++) {                                               // TILE = 4 x 256 elements
-    const uint32_t i = threadIdx.x + 256 * u;
-    const uint4 *q = reinterpret_cast<const uint4 *>(body + (size_t)(t0 + (i < n_local ? i : 0u)) * 32);
-    lo[u] = q[0]; hi[u] = q[1];                            // (default cache policy: the outside wires of the body's other tiles hit these lines in L2 — nt loads were 5-10 % slower here)
-  }
-  const uint4 *terms4 = reinterpret_cast<const uint4 *>(S.terms + tt.x);
-  const uint32_t nt4 = (tt.y + 5u) >> 2;                                           // the tile's term words + the two read-ahead words, in fours
-  const uint32_t t_dump = lterm_words >> 2;                                        // one uint4 behind the list
-  // (named registers, not an array: the array went to scratch memory)
-  const uint32_t k40 = threadIdx.x, k41 = threadIdx.x + 256, k42 = threadIdx.x + 512, k43 = threadIdx.x + 768;
-  uint4 tv0 = make_uint4(0, 0, 0, 0), tv1 = tv0, tv2 = tv0, tv3 = tv0;
-  if (STAGED) {
-    tv0 = terms4[k40 < nt4 ? k40 : 0u];
-    tv1 = terms4[k41 < nt4 ? k41 : 0u];
-    tv2 = terms4[k42 < nt4 ? k42 : 0u];
-    tv3 = terms4[k43 < nt4 ? k43 : 0u];
-  }
-  long long cv[2] = {0, 0};
-  if (COEF_LDS) {
-#pragma unroll
-    for (uint32_t u = 0; u < 2; u++) {                                             // ncoef <= 512
-      const uint32_t k = threadIdx.x + 256 * u;
-      cv[u] = S.coef_small[k < S.ncoef ? k : 0u];
-    }
-  }
-  __builtin_amdgcn_sched_barrier(0);                                               // (the dependent load goes last)
-  const uint4 *eq = reinterpret_cast<const uint4 *>(body + (size_t)ew * 32);
-  const uint4 elo = eq[0], ehi = eq[1];
-  __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-  for (uint32_t u = 0; u < 4; u++) {
-    const uint32_t i = threadIdx.x + 256 * u;
-    const unsigned long long z = i < n_local ? lean_pack(lo[u], hi[u]) : 0ull;
-    el[i < n_local ? i : el_dump] = z;
-    const unsigned long long ones = __ballot(z == 1ull), bads = __ballot(z > 1ull);       // the wave holds elements 64 g ... 64 g + 63
-    if ((threadIdx.x & 63) == 0) { packed[2 * (i >> 6)] = ones; packed[2 * (i >> 6) + 1] = bads; }
-  }
-  if (STAGED) {
-    lterms4[k40 < nt4 ? k40 : t_dump] = tv0;
-    lterms4[k41 < nt4 ? k41 : t_dump] = tv1;
-    lterms4[k42 < nt4 ? k42 : t_dump] = tv2;
-    lterms4[k43 < nt4 ? k43 : t_dump] = tv3;
-  }
-  if (COEF_LDS) {
-#pragma unroll
-    for (uint32_t u = 0; u < 2; u++) {
-      const uint32_t k = threadIdx.x + 256 * u;
-      if (k < S.ncoef) lcoef[k] = cv[u];
-    }
-  }
-  {
-    const unsigned long long z = threadIdx.x < td.w ? lean_pack(elo, ehi) : 0ull;
-    el[B3W_R1CS_TILE + (threadIdx.x < td.w ? threadIdx.x : ext_cap - 1u)] = z;
-    const unsigned long long ones = __ballot(z == 1ull), bads = __ballot(z > 1ull);
-    const uint32_t g = (B3W_R1CS_TILE + threadIdx.x) >> 6;                         // (TILE is a multiple of 64)
-    if ((threadIdx.x & 63) == 0 && g < groups) { packed[2 * g] = ones; packed[2 * g + 1] = bads; }
-  }
-  if (STAGED) {
-    for (uint32_t base = 1024; base < nt4; base += 1024) {                         // lists beyond 4 096 words: four loads in flight again
-      const uint32_t a0 = base + k40, a1 = base + k41, a2 = base + k42, a3 = base + k43;
-      const uint4 w0 = terms4[a0 < nt4 ? a0 : 0u], w1 = terms4[a1 < nt4 ? a1 : 0u], w2 = terms4[a2 < nt4 ? a2 : 0u],
-                  w3 = terms4[a3 < nt4 ? a3 : 0u];
-      lterms4[a0 < nt4 ? a0 : t_dump] = w0;
-      lterms4[a1 < nt4 ? a1 : t_dump] = w1;
-      lterms4[a2 < nt4 ? a2 : t_dump] = w2;
-      lterms4[a3 < nt4 ? a3 : t_dump] = w3;
-    }
-  }
-  for (uint32_t j0 = 256; j0 < td.w; j0 += 256) {                                  // (more than 256 outside wires; whole waves, for the ballots)
-    const uint32_t j = j0 + threadIdx.x;
-    unsigned long long z = 0ull;
-    if (j < td.w) {
-      const uint4 *q = reinterpret_cast<const uint4 *>(body + (size_t)S.ext[td.z + j] * 32);
-      z = lean_pack(q[0], q[1]);
-      el[B3W_R1CS_TILE + j] = z;
-    }
-    const unsigned long long ones = __ballot(z == 1ull), bads = __ballot(z > 1ull);
-    const uint32_t g = (B3W_R1CS_TILE + j) >> 6;
-    if ((threadIdx.x & 63) == 0 && g < groups) { packed[2 * g] = ones; packed[2 * g + 1] = bads; }
-  }
-  const uint32_t *tsrc = STAGED ? lterms : S.terms;
-  const uint32_t tbase = STAGED ? tt.x : 0u;                                      // row offsets are global term numbers
-  const long long *csrc = COEF_LDS ? lcoef : S.coef_small;
-  __syncthreads();
-  const bool w0_is_one = el[tile == 0 ? 0 : B3W_R1CS_TILE] == 1ull;                // (outside wire 0 of every other tile)
-  unsigned long long *block = scratch + ((size_t)b * S.ntiles + tile) * block_words;
-  const uint32_t iters = (td.y + 255u) >> 8;
-  const __int128 lim = (__int128)1 << 63;
-  uint32_t nbad = 0, low = 0xFFFFFFFFu;
-  bool any = false;
-  // one iteration: row td.x + 256 * it + thread, its descriptor already in `d` (the first PRE calls are straight-line code so
-  // that `pre` stays in registers)
-  auto iteration = [&](const uint32_t it, const uint4 d) {
-    const uint32_t r = td.x + threadIdx.x + 256 * it;
-    bool defer = false, bad = false;
-    if (r < td.x + td.y) {
-      if ((d.y >> 31) && w0_is_one) {
-        bad = el[d.w] > 1ull;                              // booleanity (see the tile kernel); an element of 2^63 or more is no bit
-      } else if (!(d.y >> 31) && (d.y & B3W_LEAN_ALWAYS_DEFER)) {
-        defer = true;
-      } else {
-        const uint32_t na = d.y & 0x3FFFFFFFu;
-        const uint32_t t0r = d.x - tbase;
-        const uint32_t nc = (d.y >> 31) ? 0u : d.w;
-        const __int128 C = lean_dot(el, packed, tsrc, csrc, t0r + na + d.z, nc, &defer);
-        const __int128 A = lean_dot(el, packed, tsrc, csrc, t0r, na, &defer);
-        const __int128 B = lean_dot(el, packed, tsrc, csrc, t0r + na, d.z, &defer);
-        if (!(A < lim && A > -lim && B < lim && B > -lim)) defer = true;
-        bad = !defer && A * B != C;                        // |A * B - C| < 2^127 < p: "= 0 mod p" is "= 0"
-      }
-      if (bad) { nbad++; low = min(low, S.row_id[r]); }
-    }
-    const unsigned long long mask = __ballot(defer);
-    if ((threadIdx.x & 63) == 0) block[1 + 4 * it + (threadIdx.x >> 6)] = mask;
-    any = any || defer;
-  };
-  if (iters > 0) iteration(0, pre[0]);
-  if (iters > 1) iteration(1, pre[1]);
-  if (iters > 2) iteration(2, pre[2]);
-  if (iters > 3) iteration(3, pre[3]);
-  if (iters > 4) iteration(4, pre[4]);
-  for (uint32_t it = PRE; it < iters; it++) {
-    const uint32_t r = td.x + threadIdx.x + 256 * it;
-    iteration(it, r < td.x + td.y ? rows[r] : make_uint4(0, 0, 0, 0));
-  }
-  const int wg_any = __syncthreads_or(any ? 1 : 0);
-  if (threadIdx.x == 0) block[0] = wg_any ? 1ull : 0ull;
-#pragma unroll
-  for (int sh = 32; sh > 0; sh >>= 1) {
-    nbad += (uint32_t)__shfl_xor((int)nbad, sh);
-    low = min(low, (uint32_t)__shfl_xor((int)low, sh));
-  }
-  if ((threadIdx.x & 63) == 0 && nbad) {
-    atomicAdd(&violations[b], nbad);
-    if (first) atomicMin(&first[b], low);
-  }
-}
+// (r02's LEAN pair — (body, tile) workgroups with 8-byte elements and integer sums in LDS, the rows they could not decide
+// marked for b3w_r1cs_deferred_kernel — was the default of round 2 and a comparison formulation until round 4; the stream kernel
+// below took its element packing and its deferred kernel, the walk kernel its place.  Removed in round 5: HISTORY.md.)
 
 // ---- the STREAM kernel (default): persistent workgroups, one barrier per (body, tile) unit ------------------------------------
 // The lean kernel is (body, tile) workgroups that load, pack, evaluate and leave: its HBM loads are in flight only part of a
@@ -822,44 +586,6 @@ extern "C" size_t b3w_r1cs_scratch_bytes(const B3wR1csSystem *sys) {
   return (size_t)lean_slab(sys) * sys->ntiles * lean_block_words(sys) * 8;
 }
 
-extern "C" int b3w_launch_r1cs_lean(const uint8_t *d_bodies, uint32_t n, uint64_t pitch, const B3wR1csSystem *sys, const B3wField *field,
-                                    unsigned long long *d_scratch, uint32_t *d_violations, uint32_t *d_first, hipStream_t stream) {
-  if (!n || !sys->ntiles) return 0;
-  if (sys->max_ext > B3W_R1CS_TILE || !d_scratch) return -5;
-  hipError_t e = (hipError_t)r1cs_init_results(d_violations, d_first, n, stream);
-  if (e != hipSuccess) return (int)e;
-  const uint32_t ext_cap = (sys->max_ext + 2u) & ~1u;                                                  // (+ the dump element)
-  size_t smem = (size_t)(B3W_R1CS_TILE + ext_cap) * 8 + (size_t)(((B3W_R1CS_TILE + ext_cap + 63u) >> 6) + 1u) * 16;   // elements, packed bits
-  // the term list rides along while three workgroups still fit a CU
-  const size_t term_bytes = (size_t)((sys->max_tile_terms + 5u) & ~3u) * 4 + 16;                    // (+ the dump slot)
-  const bool coef_lds = sys->ncoef <= 512;                 // 4 KB at most
-  const bool staged = smem + term_bytes + (coef_lds ? (size_t)sys->ncoef * 8 : 0) <= 52 * 1024;
-  if (staged) smem += term_bytes;
-  if (coef_lds) smem += (size_t)sys->ncoef * 8;
-  const uint32_t bw = lean_block_words(sys);
-  const uint32_t slab = lean_slab(sys);
-  for (uint32_t b0 = 0; b0 < n; b0 += slab) {
-    const uint32_t nb = n - b0 < slab ? n - b0 : slab;
-    const dim3 grid(((nb + 7) / 8) * 8 * sys->ntiles);
-#define B3W_R1CS_LEAN_LAUNCH(STAGED, CL)                                                                                               \
-    hipLaunchKernelGGL((b3w_r1cs_lean_kernel<STAGED, CL>), grid, dim3(256), smem, stream, d_bodies + (uint64_t)b0 * pitch, pitch, nb, *sys,   \
-                       d_scratch, bw, d_violations + b0, d_first ? d_first + b0 : nullptr)
-    if (staged && coef_lds) B3W_R1CS_LEAN_LAUNCH(true, true);
-    else if (staged) B3W_R1CS_LEAN_LAUNCH(true, false);
-    else if (coef_lds) B3W_R1CS_LEAN_LAUNCH(false, true);
-    else B3W_R1CS_LEAN_LAUNCH(false, false);
-#undef B3W_R1CS_LEAN_LAUNCH
-    e = hipGetLastError();
-    if (e != hipSuccess) return (int)e;
-    const dim3 dgrid(((nb + 7) / 8) * 8 * ((sys->ntiles + B3W_R1CS_DEFERRED_TILES - 1u) / B3W_R1CS_DEFERRED_TILES));
-    hipLaunchKernelGGL(b3w_r1cs_deferred_kernel, dgrid, dim3(64), 0, stream, d_bodies + (uint64_t)b0 * pitch, pitch, nb, *sys, d_scratch, bw,
-                       *field, d_violations + b0, d_first ? d_first + b0 : nullptr, false);
-    e = hipGetLastError();
-    if (e != hipSuccess) return (int)e;
-  }
-  return 0;
-}
-
 // LDS of the stream kernel for a system: elements, bit words, general rows' sums and flags (each twice: unit parity) + word list +
 // coefficients + summary and anomaly words
 static inline size_t stream_smem(const B3wR1csSystem *sys) {
@@ -870,7 +596,7 @@ static inline size_t stream_smem(const B3wR1csSystem *sys) {
          (sys->max_tile_rows > 1024u ? (size_t)(((sys->max_tile_rows + 63u) & ~63u) - 1024u) * 16u : 0u);      // (+ the row descriptors behind the first 1 024 of a tile)
 }
 
-// 0 = launched; -6 = this system does not fit the stream kernel (the caller takes the lean pair)
+// 0 = launched; -6 = this system does not fit the stream kernel (the caller takes the gather kernel)
 extern "C" int b3w_launch_r1cs_stream(const uint8_t *d_bodies, uint32_t n, uint64_t pitch, const B3wR1csSystem *sys, const B3wField *field,
                                       unsigned long long *d_scratch, uint32_t *d_violations, uint32_t *d_first, hipStream_t stream) {
   if (!n || !sys->ntiles) return 0;

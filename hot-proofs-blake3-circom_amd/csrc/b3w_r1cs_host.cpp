@@ -1,5 +1,5 @@
 // b3w_r1cs_host.cpp — host side of the constraint check: an iden3 .r1cs image (UNTRUSTED input) -> the arrays the kernels of
-// b3w_r1cs.hip take.  Plain C++, no HIP: b3w_capi.cpp uploads the result; tests/test_r1cs_host_asan_cpu.py compiles this file
+// b3w_r1cs.hip take.  Plain C++, no HIP: b3w_r1cs_api.cpp uploads the result; tests/test_r1cs_host_asan_cpu.py compiles this file
 // alone with AddressSanitizer + UBSan and runs mutated images through it.
 #include "b3w_r1cs_host.h"
 

@@ -30,7 +30,7 @@ __device__ __forceinline__ void wave_sum2(Fe &a, Fe &b, const uint32_t p[8]) {
   }
 }
 // An always-deferred row of the walk kernel's list, by one wave: d = {first pair, pairs, linear, has C terms}, pairs = the row's
-// UNIQUE terms {wire, coefficient id | parts << 16} (b3w_capi.cpp) — a term that stands in A and in B (X (X - 1) = 0) is multiplied
+// UNIQUE terms {wire, coefficient id | parts << 16} (b3w_r1cs_api.cpp) — a term that stands in A and in B (X (X - 1) = 0) is multiplied
 // once and added twice; element and coefficient are loaded side by side, the next pair's while this one is multiplied.
 __device__ __forceinline__ bool static_row_wave(const uint8_t *body, const uint4 d, const uint2 *pairs, const uint32_t *coefR, const B3wField &F) {
   bool wild = false;

@@ -117,7 +117,7 @@ def test_gpus_2_chain_without_the_h_out_gather():
 def test_chain_workload_with_each_consumer(consumer):
     """the chain line's roofline is its dominant kernel's (round-3 verdict #3): HBM bytes written (+ read back by the check) without
     a commit consumer, the commit kernel's field multiplications against the multiplication-only ceiling with one; cpu_baseline on
-    the N = 1 line.  (commit and check alone: tools/r04 runs; here one of each roofline kind)"""
+    the N = 1 line.  (commit and check alone: tools/jobs/r04 runs; here one of each roofline kind)"""
     # (placement: the default, placed ring only for the plain pass — the allocator's search and claim check are seconds per process)
     d = _bench("--workload", "chain", "--preimage-mib", "0.25", "--steps", "1", "--warmup", "1", "--consumer", consumer, "--cpu-seconds", "1",
                *([] if consumer == "none" else ["--placement", "plain"]))

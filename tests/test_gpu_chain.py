@@ -161,6 +161,16 @@ def test_config4_one_mib_preimage():
     _, want = T.oracle_batch_u32("nova_vesta", recs[idx])
     for k, i in enumerate(idx):
         assert np.array_equal(d_bodies[int(i)].cpu().numpy(), want[k]), i
+    # every one of the 26 624 step witnesses against the step circuit's rank-1 constraints, on the device (independent of the
+    # witness kernels and of the oracle: what synthesize_with_vec enforces for each step, rust_fold/src/utils.rs:17-88)
+    import torch
+    r1cs = m.R1cs(ctx)
+    n = d_bodies.shape[0]
+    d_viol = torch.full((n,), -1, dtype=torch.int32, device=d_bodies.device)
+    r1cs.check_device(d_bodies.data_ptr(), n, 0, d_viol.data_ptr(), 0, torch.cuda.current_stream().cuda_stream)
+    torch.cuda.synchronize()
+    assert n == 26624 and int(d_viol.abs().sum().item()) == 0
+    r1cs.close()
     ctx.close()
 
 

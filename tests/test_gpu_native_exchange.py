@@ -21,7 +21,7 @@ import blake3_ref as B
 pytestmark = pytest.mark.gpu
 
 SHAPES = [("config4_1mib", 1 << 20), ("6chunks_partial_last", 5 * 1024 + 100), ("one_chunk", 700)]
-if os.environ.get("B3W_TEST_EXTRA_PREIMAGE_BYTES"):           # a one-off soak shape (tools/r04/job31_soak.sh: 8 MiB + 77: several slices a rank, ragged)
+if os.environ.get("B3W_TEST_EXTRA_PREIMAGE_BYTES"):           # a one-off soak shape (tools/jobs/r04/job31_soak.sh: 8 MiB + 77: several slices a rank, ragged)
     SHAPES.append(("extra", int(os.environ["B3W_TEST_EXTRA_PREIMAGE_BYTES"])))
 
 
@@ -191,3 +191,76 @@ def test_unpack_scatter_of_ragged_blocks_without_a_second_process():
         comm.close()
     assert calls == [2 * 32, block * 4] * world
     ctx.close()
+
+
+@pytest.mark.parametrize("transport", ["host", "external"])
+def test_eight_ranks_config4_equal_shards_in_one_process(transport):
+    """The target geometry of BASELINE config 4 — 8 ranks, 1 024 chunks in equal shards of 128, the "gathered where they lie, ONE
+    collective" path of b3w_chain_run_parents_sharded (the chunk CVs land in level 0 of every rank's tree) and the h_out exchange of
+    8 x 2 048 leaf + 8 x 1 280 parent rows.  A GPU box of this pool admits six processes to its card, so the eight ranks are eight
+    THREADS of this process, each with its own context, chain, stream and communicator: the host shared-memory transport (every
+    thread maps the segment, as processes would) and an external collective (a barrier-and-copy all-gather between the threads).
+    Every rank's gathered arrays equal what one rank computes for the whole preimage."""
+    import threading
+    import torch
+    m = T.pkg()
+    L = m.lib()
+    world, nbytes = 8, 1 << 20
+    leaf1, par1, root1 = one_rank(nbytes)
+    data = m.workloads.lcg_preimage(nbytes, seed=1)
+    dev = torch.device("cuda", 0)
+    name = "/b3w_t8_" + uuid.uuid4().hex[:16]
+    os.environ["B3W_PLACEMENT"] = "plain"                    # eight ring pairs of 1.5 GB side by side: no placement searches
+    os.environ["B3W_HOSTCOMM_TIMEOUT_S"] = "90"
+    bar = threading.Barrier(world, timeout=120)
+    stage = {}                                               # the external collective's meeting place: rank -> its send block
+
+    class _Dev:
+        def __init__(self, ptr, nb):
+            self.__cuda_array_interface__ = {"shape": (nb,), "typestr": "|u1", "data": (ptr, False), "version": 2, "strides": None}
+
+    def make_allgather(rank):
+        def fn(d_send, d_recv, nb, stream):
+            torch.cuda.synchronize()                         # (a test collective: ordered by waiting, not by the stream)
+            stage[rank] = torch.as_tensor(_Dev(d_send, nb), device=dev).clone()
+            bar.wait()
+            recv = torch.as_tensor(_Dev(d_recv, nb * world), device=dev)
+            for r in range(world):
+                recv[r * nb:(r + 1) * nb].copy_(stage[r])
+            torch.cuda.synchronize()
+            bar.wait()
+        return fn
+    res, errs = {}, []
+
+    def rank_main(rank):
+        try:
+            torch.cuda.set_device(0)
+            with torch.cuda.stream(torch.cuda.Stream()):
+                ctx = m.Context("nova_vesta", 0)
+                comm = m.Comm.host(ctx, name, rank, world) if transport == "host" else m.Comm.external(ctx, rank, world, make_allgather(rank))
+                try:
+                    for rep in range(2):                     # the second pass runs on the exchange buffers the first one allocated
+                        out = m.chain.fold_witnesses(ctx, data, batch_steps=1024, comm=comm)
+                        torch.cuda.current_stream().synchronize()
+                    res[rank] = dict(leaf=out["h_out_all"].cpu().numpy().view(np.uint32).copy(), par=out["h_out_parents_all"].cpu().numpy().view(np.uint32).copy(),
+                                     root=out["root"].cpu().numpy().view(np.uint32).tolist(), first=out["first_chunk"], n_local=out["n_chunks_local"],
+                                     n_leaf=out["n_leaf_steps"], n_par=out["n_parent_steps"], ok=bool((out["status"] == 0).all().item()))
+                finally:
+                    comm.close()
+                    ctx.close()
+        except BaseException as e:                           # a rank that dies must not leave the others at the barrier for good
+            errs.append((rank, repr(e)))
+            bar.abort()
+    th = [threading.Thread(target=rank_main, args=(r,)) for r in range(world)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    os.environ.pop("B3W_PLACEMENT", None)
+    assert not errs, errs
+    for r in range(world):
+        got = res[r]
+        assert (got["first"], got["n_local"], got["n_leaf"], got["n_par"]) == (128 * r, 128, 2048, 1280), r
+        assert got["ok"] and got["root"] == root1, r
+        assert np.array_equal(got["leaf"], leaf1), f"rank {r} of 8 gathered other leaf h_out than one rank computes"
+        assert np.array_equal(got["par"], par1), f"rank {r} of 8 gathered other parent h_out than one rank computes"

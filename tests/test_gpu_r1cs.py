@@ -316,10 +316,10 @@ def test_wide_elements_of_a_nova_step_tampered(circuit):
 
 
 def test_gather_kernel_gives_the_same_verdicts(tmp_path):
-    """csrc/b3w_r1cs_walk.hip and b3w_r1cs.hip hold four formulations with the same verdicts: the walk kernel (default since round 4: a workgroup walks whole
+    """csrc/b3w_r1cs_walk.hip and b3w_r1cs.hip hold three formulations with the same verdicts: the walk kernel (default since round 4: a workgroup walks whole
     bodies, earlier tiles' wires come from an export area in LDS, truth-table rows in runs), the stream kernel (B3W_R1CS_GATHER=4:
-    tile-major units, outside wires gathered), the lean pair (B3W_R1CS_GATHER=3: 8-byte elements and integer sums in LDS, deferred rows
-    by field arithmetic) and the gather kernel (any system; B3W_R1CS_GATHER=1).  Child processes run each over the same clean and
+    tile-major units, outside wires gathered; the fallback for tiled systems the walk kernel has no room for) and the gather kernel
+    (any system; B3W_R1CS_GATHER=1).  (Round 2's lean pair, a fourth until round 4, is gone.)  Child processes run each over the same clean and
     corrupted bodies; counts and first violated rows must be identical.  (n = 300 bodies on up to 512 workgroups: one body each;
     B3W_R1CS_GRID=7: 42 - 43 bodies per workgroup, body after body through the pipeline.)"""
     import json, os, subprocess, sys
@@ -357,7 +357,7 @@ for circuit in ("compression", "nova_bn254_o1", "nova_vesta", "nova_bn254"):
 print(json.dumps(out))
 '''
     res = {}
-    for mode, extra in (("0", {}), ("1", {}), ("3", {}), ("4", {}), ("4/16waves", {"B3W_R1CS_WAVES": "16"}), ("4/grid7", {"B3W_R1CS_GRID": "7"}),
+    for mode, extra in (("0", {}), ("1", {}), ("4", {}), ("4/16waves", {"B3W_R1CS_WAVES": "16"}), ("4/grid7", {"B3W_R1CS_GRID": "7"}),
                         ("0/grid7", {"B3W_R1CS_GRID": "7"}), ("0/grid1", {"B3W_R1CS_GRID": "1"}),
                         # the walk kernel's two instantiations, each for every circuit (by default the circomkit build takes the signed one — small
                         # negative numbers p - k count as -k — and the others the unsigned one)
@@ -575,7 +575,7 @@ r.check_device(b.data_ptr(), n, 0, viol.data_ptr(), first.data_ptr(), torch.cuda
 torch.cuda.synchronize()
 print(json.dumps([r.tiled] + [[int(x), int(y)] for x, y in zip(viol.cpu().numpy().view(np.uint32), first.cpu().numpy().view(np.uint32))]))
 '''
-    for mode in ("0", "1", "3", "4"):
+    for mode in ("0", "1", "4"):
         res = subprocess.run([sys.executable, "-c", script, str(path), str(tmp_path / "bodies.npy")], capture_output=True, text=True,
                              cwd=T.ROOT, timeout=600, env=dict(os.environ, B3W_R1CS_GATHER=mode))
         assert res.returncode == 0, res.stderr[-1500:]

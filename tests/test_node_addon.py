@@ -479,3 +479,116 @@ def test_cli_fold_prints_the_blake3_hash(tmp_path):
     assert "blake3 = " + blake3_ref.blake3(pre).hex() in r.stdout and "(0 rejected)" in r.stdout
     pub = json.loads((tmp_path / "pub.json").read_text())
     assert pub["nLeafSteps"] == 3 * 16 + 2 and len(pub["publicOutputs"]) == 15 * (pub["nLeafSteps"] + pub["nParentSteps"])
+
+
+def _toy_circom_wasm():
+    """A circom-ABI witness generator that is none of the reference's: one input `a`, witness [1, a, a * a mod p] over p = 2^31 - 1
+    (one 32-bit limb).  Hand-assembled WebAssembly with the export set the loaders drive (witness_calculator.js:109-169 of the
+    reference): no imports, two globals (the shared read/write word, the input)."""
+    def leb(n):
+        out = bytearray()
+        while True:
+            b = n & 0x7F
+            n >>= 7
+            out.append(b | (0x80 if n else 0))
+            if not n:
+                return bytes(out)
+
+    def sleb(n):
+        out = bytearray()
+        while True:
+            b = n & 0x7F
+            n >>= 7
+            done = (n == 0 and not b & 0x40) or (n == -1 and b & 0x40)
+            out.append(b | (0 if done else 0x80))
+            if done:
+                return bytes(out)
+
+    def vec(items):
+        return leb(len(items)) + b"".join(items)
+
+    def section(sid, body):
+        return bytes([sid]) + leb(len(body)) + body
+    I32, I64 = 0x7F, 0x7E
+    types = [([], [I32]), ([], []), ([I32], [I32]), ([I32, I32], []), ([I32, I32], [I32]), ([I32], []), ([I32, I32, I32], [])]
+    P = 0x7FFFFFFF
+    GET_S, SET_S, GET_A, SET_A = b"\x23\x00", b"\x24\x00", b"\x23\x01", b"\x24\x01"
+    c32 = lambda v: b"\x41" + sleb(v)
+    funcs = [  # (export name, type index, body)
+        ("getVersion", 0, c32(2)), ("getFieldNumLen32", 0, c32(1)), ("getRawPrime", 1, c32(P) + SET_S),
+        ("readSharedRWMemory", 2, GET_S), ("writeSharedRWMemory", 3, b"\x20\x01" + SET_S), ("getWitnessSize", 0, c32(3)),
+        ("getInputSize", 0, c32(1)), ("getInputSignalSize", 4, c32(1)), ("init", 5, c32(0) + SET_A), ("setInputSignal", 6, GET_S + SET_A),
+        ("getWitness", 5,
+         b"\x20\x00\x45\x04\x40" + c32(1) + SET_S + b"\x05"                     # if (i == 0) shared = 1 else
+         + b"\x20\x00" + c32(1) + b"\x46\x04\x40" + GET_A + SET_S + b"\x05"         #   if (i == 1) shared = a else
+         + GET_A + b"\xAD" + GET_A + b"\xAD\x7E\x42" + sleb(P) + b"\x82\xA7" + SET_S  #     shared = (u64 a * u64 a) % p
+         + b"\x0B\x0B"),
+        ("getMessageChar", 0, c32(0)),
+    ]
+    mod = b"\x00asm\x01\x00\x00\x00"
+    mod += section(1, vec([b"\x60" + vec([bytes([t]) for t in a]) + vec([bytes([t]) for t in r]) for a, r in types]))
+    mod += section(3, vec([leb(t) for _, t, _ in funcs]))
+    mod += section(6, vec([bytes([I32, 1]) + c32(0) + b"\x0B"] * 2))              # two mutable i32 globals
+    mod += section(7, vec([leb(len(n)) + n.encode() + b"\x00" + leb(i) for i, (n, _, _) in enumerate(funcs)]))
+    mod += section(10, vec([leb(len(b) + 2) + b"\x00" + b + b"\x0B" for _, _, b in funcs]))
+    return mod
+
+
+@needs_node
+def test_toy_circom_wasm_assembles_and_runs_through_the_fallback_loader(tmp_path):
+    """(CPU) the hand-assembled module is valid WebAssembly with the circom export set; the shim's fallback computes its witness."""
+    w = tmp_path / "toy.wasm"
+    w.write_bytes(_toy_circom_wasm())
+    r = _node("""
+      const wf = require('./hot-proofs-blake3-circom_amd/js/wasm_fallback.js');
+      (async () => {
+        const wc = await wf(require('fs').readFileSync(process.argv[1]));
+        console.log(wc.prime.toString(), wc.witnessSize, (await wc.calculateWitness({a: 123456}, 0)).join(','));
+      })().catch(e => { console.log('ERR', e.message); });
+    """, str(w))
+    assert r.stdout.split() == ["2147483647", "3", f"1,123456,{123456 * 123456 % 0x7FFFFFFF}"], (r.stdout, r.stderr)
+
+
+@needs_node
+@pytest.mark.gpu
+def test_builder_takes_unknown_wasm_bytes_and_circuit_names_in_one_process(tmp_path):
+    """r04 verdict, weak 1(iii): on the GPU box builder() only ever saw circuit NAMES (the reference's .wasm files cannot travel).
+    Here one Node process hands it (a) the bytes of a circom witness generator that is not one of the four committed circuits — a
+    hand-assembled toy module: sha256 identification says "unknown", the generic loader computes its witness; (b) the same bytes
+    with wasmFallback: false and bytes that are no WebAssembly at all — refused / CompileError; (c) a circuit name — the GPU path,
+    whose .wtns image is the reference's golden one."""
+    import hashlib
+    g = T.golden("compression")
+    case = next(c for c in g["cases"] if "error" not in c)
+    w, inp = tmp_path / "toy.wasm", tmp_path / "in.json"
+    w.write_bytes(_toy_circom_wasm())
+    inp.write_text(json.dumps(case["input"]))
+    r = _node("""
+      const builder = require('./hot-proofs-blake3-circom_amd/js/witness_calculator.js');
+      const nat = require('./hot-proofs-blake3-circom_amd/js/b3wit_napi.node');
+      const fs = require('fs'), crypto = require('crypto');
+      (async () => {
+        const toy = fs.readFileSync(process.argv[1]);
+        console.log('identify', nat.identifyWasm(toy));
+        const t = await builder(toy);
+        console.log('toy', t.constructor.name, t.witnessSize, (await t.calculateWitness({a: 77777}, 0)).join(','));
+        const img = await t.calculateWTNSBin({a: 5}, 0);
+        console.log('toywtns', img.length, Buffer.from(img.slice(0, 4)).toString());
+        await builder(toy, {wasmFallback: false}).then(() => console.log('UNEXPECTED'), e => console.log('refused', e.message));
+        const say = console.log; console.log = () => {};
+        const msg = await builder(Buffer.from('not a circuit')).then(() => 'UNEXPECTED', e => e.message);
+        console.log = say;
+        console.log('junk', msg.split('\\n')[0]);
+        const wc = await builder('compression');
+        const out = await wc.calculateWTNSBin(JSON.parse(fs.readFileSync(process.argv[2], 'utf8')), 0);
+        console.log('gpu', wc.constructor.name, crypto.createHash('sha256').update(out).digest('hex'));
+      })().catch(e => { console.log('ERR', e.message); });
+    """, str(w), str(inp))
+    assert r.returncode == 0, r.stderr
+    lines = dict(l.split(" ", 1) for l in r.stdout.strip().splitlines())
+    assert lines["identify"] == "-1"
+    assert lines["toy"] == f"GenericWitnessCalculator 3 1,77777,{77777 * 77777 % 0x7FFFFFFF}"
+    assert lines["toywtns"] == f"{4 * (11 + 1 + 3)} wtns"
+    assert "not one of the reference's committed BLAKE3 circuits" in lines["refused"] and "UNEXPECTED" not in r.stdout
+    assert lines["junk"].startswith("CompileError")
+    assert lines["gpu"] == "WitnessCalculator " + case["wtns_sha256"], r.stdout

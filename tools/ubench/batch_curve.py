@@ -1,6 +1,6 @@
 """batch_curve.py — witnesses/s against batch size, 1 ... 65 536, for both circuit families and every launch shape (bodies
 per wave; SLICED = waves per body, B3W_VARIANT 20 + s), next to what the library's default policy (b3w_batch_run_device
-without autotune: b3w_capi.cpp) picks.
+without autotune: b3w_ctx.cpp) picks.
 Writes profiles/r02/batch_curve.json (run on the GPU box: `python tools/ubench/batch_curve.py`).  The bodies-per-wave
 setting is B3W_VARIANT: compression 1 -> 1, 2 -> 2, 0 -> 4, 3 -> 8, 8 -> 8 + occupancy limit; nova O2 1 -> 1, 0 -> 2, 3 -> 8."""
 import importlib, json, os, sys

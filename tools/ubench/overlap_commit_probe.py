@@ -75,6 +75,31 @@ for name, f in (("commit from records", commit), ("witness kernel", witness), ("
 for name, f in (("witness kernel", witness), ("pure stores, streams w4", store(0)), ("pure stores, streams w8", store(1)), ("pure stores, fill shape", store(2))):
     w, a, b = timed(f, commit)
     print(f"beside  {name:28s} pair {w:8.3f} ms   writer {a:8.3f} ms   commit {b:8.3f} ms")
+# a writer that leaves the memory system air: `pause` x 64 cycles of s_sleep after every 8 KiB a wave stores
+for pause in (1, 2, 3, 4, 6, 8, 12, 16, 24, 32):
+    f = store(100 + pause)
+    alone = timed(f)[0]
+    w, a, b = timed(f, commit)
+    print(f"beside  pure stores w8, pause {pause:2d}    pair {w:8.3f} ms   writer {a:8.3f} ms   commit {b:8.3f} ms   (writer alone {alone:.3f} ms)")
+if os.environ.get("PROBE_CU_MASK"):                        # the writer on a stream confined to a share of the CUs
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
+    for pct in (25, 38, 50, 63, 75):
+        ncu = 256
+        mask = (C.c_uint32 * 8)()
+        for cu in range(ncu):
+            if (cu * pct) // 100 != ((cu + 1) * pct) // 100:
+                mask[cu // 32] |= 1 << (cu % 32)
+        st = C.c_void_p()
+        assert hip.hipExtStreamCreateWithCUMask(C.byref(st), 8, mask) == 0
+        sm = torch.cuda.ExternalStream(st.value)
+        old_sa = sa
+        sa = sm
+        for name, f in (("witness kernel", witness), ("pure stores w8", store(1))):
+            alone = timed(f)[0]
+            w, a, b = timed(f, commit)
+            print(f"beside  {name} on {pct}% of the CUs   pair {w:8.3f} ms   writer {a:8.3f} ms   commit {b:8.3f} ms   (writer alone {alone:.3f} ms)")
+        sa = old_sa
 for v in ("2", "0"):                                      # nova O2 variants: 2 = 4 bodies per wave, 0 = 2 bodies per wave
     os.environ["B3W_VARIANT"] = v
     ctx2 = m.Context("nova_vesta", 0)
