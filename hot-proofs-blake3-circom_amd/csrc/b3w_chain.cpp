@@ -97,7 +97,6 @@ struct b3w_chain {
   hipStream_t co_stream = nullptr;                   // beside them = on a stream of its own: the commit kernels are bound by the vector ALUs, the
   hipEvent_t ev_co_in = nullptr, ev_co_out = nullptr;//   witness kernels by HBM writes — they run side by side
   int32_t co_overlap = B3W_COMMIT_OVERLAP_AUTO;      // b3w_chain_commit_overlap: where those commitments run
-  bool co_resident = false;                          // ... with the commit kernel that is built to share a CU with the witness kernel
   int32_t *d_co_scratch = nullptr;                   // the side-stream commit kernel's status words: the witness kernel of the same records is
                                                      // the one that reports (d_status), this is never read
   uint8_t *co_points = nullptr, *co_own = nullptr;   // (co_own: the chain's own buffer when the caller passed none)
@@ -173,7 +172,7 @@ int32_t chain_run_steps(b3w_chain *c, uint64_t first_row, uint64_t count, b3w_ba
       hipError_t e = hipEventRecord(c->ev_co_in, (hipStream_t)stream);
       if (e == hipSuccess) e = hipStreamWaitEvent(c->co_stream, c->ev_co_in, 0);
       if (e != hipSuccess) return hip_fail(c->ctx, e, "commit stream");
-      const int32_t rc = b3w_int_commit_records(c->ctx, c->co_key, c->d_recs + r0 * 32, k, c->co_points + r0 * 64, nullptr, c->d_co_scratch + r0, c->co_stream, c->co_resident);
+      const int32_t rc = b3w_commit_records_device(c->ctx, c->co_key, c->d_recs + r0 * 32, k, c->co_points + r0 * 64, nullptr, c->d_co_scratch + r0, c->co_stream);
       if (rc) return rc;
       if (mode == B3W_COMMIT_OVERLAP_GATED && (e = hipEventRecord(c->ev_co_out, c->co_stream)) != hipSuccess) return hip_fail(c->ctx, e, "commit stream");
     } else if (c->co_key) {

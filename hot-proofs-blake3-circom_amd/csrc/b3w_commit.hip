@@ -753,12 +753,8 @@ __global__ __launch_bounds__(64) void b3w_commit_window_kernel(const uint32_t *_
 //            as a separate streaming kernel in front, 30 %.)
 //   phase 2  lane t adds the tabulated points of the witness's non-zero windows t, t + T, ...
 //   phase 3  LDS tree over the T partial sums (in the bit string's place).
-//
-// PF (the CO-RESIDENT instantiation, b3w_commit_kernel_co below): the point of a lane's NEXT non-zero window is loaded before the
-// current one is added, so that a wave's table reads (a 14 GB table: every one an HBM access) run under its own additions instead of
-// under other waves' — that kernel is built for two waves per SIMD, not three, and has the registers for it.
-template <int T, int WPB, int W, class CV, bool PF>        // threads per witness, witnesses per workgroup (T * WPB threads), window width, field
-__device__ __forceinline__ void commit_body(const uint8_t *__restrict__ bodies, uint32_t n, uint64_t pitch,
+template <int T, int WPB, int W, class CV>        // threads per witness, witnesses per workgroup (T * WPB threads), window width, field
+__global__ __launch_bounds__(T * WPB) __attribute__((amdgpu_waves_per_eu(3, 3))) void b3w_commit_kernel(const uint8_t *__restrict__ bodies, uint32_t n, uint64_t pitch,
                                                          uint32_t first_slot, uint32_t nslots,
                                                          const uint32_t *__restrict__ slotdesc /* per committed slot: first virtual slot | width code << 24 */,
                                                          const uint32_t *__restrict__ images /* or null: TRACE images, word j of witness w at [j * img_row + w] */,
@@ -912,8 +908,8 @@ __device__ __forceinline__ void commit_body(const uint8_t *__restrict__ bodies, 
   __syncthreads();
   J9 acc = j9_infinity();
   uint32_t win = live ? t : nwin, nadd = 0;
-  // this lane's next window with a set bit, from `win` on: its table entry, or null when the lane has run out of windows
-  auto next_entry = [&]() -> const uint32_t * {
+  while (true) {
+    // skip ahead to this lane's next window with a set bit
     uint32_t m = 0;
     while (win < nwin) {
       if (W == 16) m = (packed[win >> 1] >> ((win & 1) * 16)) & 0xFFFFu;
@@ -924,36 +920,16 @@ __device__ __forceinline__ void commit_body(const uint8_t *__restrict__ bodies, 
       if (m) break;
       win += T;
     }
-    if (win >= nwin) return nullptr;
-    const uint32_t *pt = table + ((uint64_t)win * B3W_COMMIT_ENTRIES(W) + m - 1) * 16;
-    win += T;
-    return pt;
-  };
-  if (PF) {
-    const uint32_t *pt = next_entry();
-    Fp x2 = fp_zero(), y2 = fp_zero();
-    if (pt) { x2 = load_fp(pt); y2 = load_fp(pt + 8); }
-    while (__any(pt != nullptr)) {
-      const uint32_t *pn = next_entry();                     // the next point is on its way while this one is added
-      Fp xn = fp_zero(), yn = fp_zero();
-      if (pn) { xn = load_fp(pn); yn = load_fp(pn + 8); }
-      if (pt && !(fp_is_zero(x2) && fp_is_zero(y2))) {
+    const bool has = win < nwin;
+    if (!__any(has)) break;
+    if (has) {
+      const uint32_t *pt = table + ((uint64_t)win * B3W_COMMIT_ENTRIES(W) + m - 1) * 16;
+      const Fp x2 = load_fp(pt), y2 = load_fp(pt + 8);
+      if (!(fp_is_zero(x2) && fp_is_zero(y2))) {           // (0, 0) is not on these curves (b != 0): the table's infinity
         j9_madd(acc, to29(x2), to29(y2), C);
         nadd++;
       }
-      pt = pn; x2 = xn; y2 = yn;
-    }
-  } else {
-    while (true) {
-      const uint32_t *pt = next_entry();
-      if (!__any(pt != nullptr)) break;
-      if (pt) {
-        const Fp x2 = load_fp(pt), y2 = load_fp(pt + 8);
-        if (!(fp_is_zero(x2) && fp_is_zero(y2))) {           // (0, 0) is not on these curves (b != 0): the table's infinity
-          j9_madd(acc, to29(x2), to29(y2), C);
-          nadd++;
-        }
-      }
+      win += T;
     }
   }
   if (invtab && live)
@@ -999,31 +975,6 @@ __device__ __forceinline__ void commit_body(const uint8_t *__restrict__ bodies, 
   }
   if (live) for (uint32_t i = t; i < 36; i += T) sums[(uint64_t)w * B3W_COMMIT_SUM_WORDS + i] = packed[i];   // normalised by the next kernel
   if (live && t == 0 && status) status[w] = bad[sub] ? 103 : 0;
-}
-
-#define B3W_COMMIT_PARAMS                                                                                                                   \
-  const uint8_t *__restrict__ bodies, uint32_t n, uint64_t pitch, uint32_t first_slot, uint32_t nslots, const uint32_t *__restrict__ slotdesc,  \
-      const uint32_t *__restrict__ images, uint32_t img_row, const uint2 *__restrict__ runs, uint32_t nruns, uint32_t region_words,            \
-      const uint32_t *__restrict__ table, uint32_t nwin, uint32_t *__restrict__ sums, int32_t *__restrict__ status,                             \
-      const uint32_t *__restrict__ invtab, uint32_t inv_nk, const uint32_t *__restrict__ invmeta, const uint32_t *__restrict__ aux,             \
-      unsigned long long *__restrict__ adds, CV C
-#define B3W_COMMIT_ARGS                                                                                                                         \
-  bodies, n, pitch, first_slot, nslots, slotdesc, images, img_row, runs, nruns, region_words, table, nwin, sums, status, invtab, inv_nk, invmeta, aux, adds, C
-
-// three waves per SIMD (166 registers): the kernel when it has the device to itself
-template <int T, int WPB, int W, class CV>
-__global__ __launch_bounds__(T * WPB) __attribute__((amdgpu_waves_per_eu(3, 3))) void b3w_commit_kernel(B3W_COMMIT_PARAMS) {
-  commit_body<T, WPB, W, CV, false>(B3W_COMMIT_ARGS);
-}
-// CO-RESIDENT (r05): built to run BESIDE the witness kernel of the same steps (the fold-shaped pass, b3w_chain_commit_overlap).  Three
-// of the kernel above fill every SIMD's register file (3 x 168 of 512) and take 111 KB of a CU's LDS: where they sit no witness wave
-// fits, so the two kernels shared the device by turns, not side by side (14.7 ms per 65 536 steps against 7.0 + 9.2 one after the
-// other).  This one is capped at 192 registers — at most TWO waves per SIMD whatever the dispatcher would like — which leaves 128
-// registers per SIMD and 86 KB of LDS per CU for the witness kernel's single-wave workgroups of four bodies (112 registers, 27.5 KB),
-// and hides its table reads under its own additions (PF) instead of under a third wave.
-template <int W, class CV>
-__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2), amdgpu_num_vgpr(192))) void b3w_commit_kernel_co(B3W_COMMIT_PARAMS) {
-  commit_body<64, 4, W, CV, true>(B3W_COMMIT_ARGS);
 }
 
 // ---- normalise: one THREAD per witness (a Fermat inversion is 380 dependent multiplications: on thread 0 of the commit
@@ -1127,7 +1078,7 @@ extern "C" int b3w_launch_commit(const uint8_t *d_bodies, uint32_t n, uint64_t p
                                  uint32_t nruns, const uint32_t *d_table, uint32_t nwin, uint32_t window,
                                  uint32_t *d_sums /* n * B3W_COMMIT_SUM_WORDS scratch */, uint8_t *d_out, int32_t *d_status,
                                  const uint32_t *d_invtab, uint32_t inv_nk, const uint32_t *d_invmeta, const uint32_t *d_aux,
-                                 unsigned long long *d_adds, const B3wCurve *curve, hipStream_t stream, int co_resident) {
+                                 unsigned long long *d_adds, const B3wCurve *curve, hipStream_t stream) {
   if (!n) return 0;
   if (!d_images && !(d_invtab && d_invmeta && d_aux)) { d_invtab = nullptr; d_invmeta = nullptr; }      // (bodies mode needs all three)
   if (window != B3W_COMMIT_WINDOW_SMALL && window != B3W_COMMIT_WINDOW_LARGE) return (int)hipErrorInvalidValue;
@@ -1151,19 +1102,6 @@ extern "C" int b3w_launch_commit(const uint8_t *d_bodies, uint32_t n, uint64_t p
                        pitch, first_slot, nslots, d_slotdesc, d_images, img_row, reinterpret_cast<const uint2 *>(d_runs), nruns, region, d_table, nwin, \
                        d_sums, d_status, d_invtab, inv_nk, d_invmeta, d_aux, d_adds, cv);                                         \
   }
-  // the co-resident kernel (two waves per SIMD at most, prefetched table reads): 64 lanes per witness only
-#define B3W_COMMIT_LAUNCH_CO(W, CV, cv)                                                                                   \
-  {                                                                                                                       \
-    const uint32_t region = bits_words > 36u * 64 ? bits_words : 36u * 64;                                                \
-    if ((size_t)region * 4 * 4 > 64 * 1024) return (int)hipErrorInvalidValue;                                             \
-    hipLaunchKernelGGL((b3w_commit_kernel_co<W, CV>), dim3((n + 3) / 4), dim3(256), region * 4 * 4, stream, d_bodies, n, pitch, first_slot, nslots, \
-                       d_slotdesc, d_images, img_row, reinterpret_cast<const uint2 *>(d_runs), nruns, region, d_table, nwin, d_sums, d_status, d_invtab, \
-                       inv_nk, d_invmeta, d_aux, d_adds, cv);                                                             \
-  }
-  if (co_resident && tpw == 64) {
-    if (window == B3W_COMMIT_WINDOW_LARGE) { if (vesta) B3W_COMMIT_LAUNCH_CO(B3W_COMMIT_WINDOW_LARGE, B3wCurve9Vesta, c9v) else B3W_COMMIT_LAUNCH_CO(B3W_COMMIT_WINDOW_LARGE, B3wCurve9, c9) }
-    else { if (vesta) B3W_COMMIT_LAUNCH_CO(B3W_COMMIT_WINDOW_SMALL, B3wCurve9Vesta, c9v) else B3W_COMMIT_LAUNCH_CO(B3W_COMMIT_WINDOW_SMALL, B3wCurve9, c9) }
-  } else
   if (window == B3W_COMMIT_WINDOW_LARGE) {
     if (vesta) B3W_COMMIT_LAUNCH(64, 4, B3W_COMMIT_WINDOW_LARGE, B3wCurve9Vesta, c9v)
     else if (tpw == 64) B3W_COMMIT_LAUNCH(64, 4, B3W_COMMIT_WINDOW_LARGE, B3wCurve9, c9)
@@ -1174,7 +1112,6 @@ extern "C" int b3w_launch_commit(const uint8_t *d_bodies, uint32_t n, uint64_t p
     else B3W_COMMIT_LAUNCH(32, 2, B3W_COMMIT_WINDOW_SMALL, B3wCurve9, c9)
   }
 #undef B3W_COMMIT_LAUNCH
-#undef B3W_COMMIT_LAUNCH_CO
   if (vesta) hipLaunchKernelGGL(b3w_commit_normalize_kernel<B3wCurve9Vesta>, dim3((n + 63) / 64), dim3(64), 0, stream, d_sums, n, d_out, *curve, c9v);
   else hipLaunchKernelGGL(b3w_commit_normalize_kernel<B3wCurve9>, dim3((n + 63) / 64), dim3(64), 0, stream, d_sums, n, d_out, *curve, c9);
   return (int)hipGetLastError();

@@ -287,16 +287,13 @@ int32_t b3w_batch_commit_device(b3w_ctx *ctx, const b3w_commit_key *key, const u
   }
   const int rc = b3w_launch_commit(d_bodies, n, pitch, key->first_slot, key->nslots, key->d_slotdesc, nullptr, 0, nullptr, 0, key->d_table,
                                    key->nwin, key->window, k->d_sums, d_points, d_status, key->d_invtab, key->inv_nk, key->d_invmeta,
-                                   static_cast<const uint32_t *>(ctx->d_aux), key->counting ? key->d_counts : nullptr, &key->curve, (hipStream_t)stream, 0);
+                                   static_cast<const uint32_t *>(ctx->d_aux), key->counting ? key->d_counts : nullptr, &key->curve, (hipStream_t)stream);
   if (rc == 0 && key->counting) k->host_witnesses += n;
   return rc ? hip_fail(ctx, (hipError_t)rc, "commit launch") : B3W_OK;
 }
 
-}  // extern "C"
-
-// co_resident: the commit kernel built to share the device with the witness kernel of the same steps (the chained pass, GATED / FREE)
-int32_t b3w_int_commit_records(b3w_ctx *ctx, const b3w_commit_key *key, const uint32_t *d_records, uint32_t n, uint8_t *d_points,
-                                   uint32_t *d_public, int32_t *d_status, void *stream, bool co_resident) {
+int32_t b3w_commit_records_device(b3w_ctx *ctx, const b3w_commit_key *key, const uint32_t *d_records, uint32_t n, uint8_t *d_points,
+                                  uint32_t *d_public, int32_t *d_status, void *stream) {
   if (!ctx || !key || key->ctx != ctx || !d_records || !d_points || !d_status) return B3W_E_BAD_ARGUMENT;
   if (n == 0) return B3W_OK;
   if ((reinterpret_cast<uintptr_t>(d_points) & 15) || (reinterpret_cast<uintptr_t>(d_records) & 3)) {
@@ -331,19 +328,11 @@ int32_t b3w_int_commit_records(b3w_ctx *ctx, const b3w_commit_key *key, const ui
     if (lrc == 0)
       lrc = b3w_launch_commit(nullptr, cn, 0, key->first_slot, key->nslots, key->d_slotdesc, k->d_images, cap, key->d_runs, key->nruns,
                               key->d_table, key->nwin, key->window, k->d_sums, d_points + (uint64_t)c0 * 64, nullptr, key->d_invtab, key->inv_nk,
-                              nullptr, nullptr, key->counting ? key->d_counts : nullptr, &key->curve, (hipStream_t)stream, co_resident ? 1 : 0);
+                              nullptr, nullptr, key->counting ? key->d_counts : nullptr, &key->curve, (hipStream_t)stream);
     if (lrc == 0 && key->counting) k->host_witnesses += cn;
     if (lrc) return hip_fail(ctx, (hipError_t)lrc, "commit-from-records launch");
   }
   return B3W_OK;
-}
-
-extern "C" {
-
-int32_t b3w_commit_records_device(b3w_ctx *ctx, const b3w_commit_key *key, const uint32_t *d_records, uint32_t n, uint8_t *d_points,
-                                  uint32_t *d_public, int32_t *d_status, void *stream) {
-  static const bool co = getenv("B3W_COMMIT_CO") && !strcmp(getenv("B3W_COMMIT_CO"), "1");     // (measurements: tools/ubench/overlap_commit_probe.py)
-  return b3w_int_commit_records(ctx, key, d_records, n, d_points, d_public, d_status, stream, co);
 }
 
 int32_t b3w_commit_records(b3w_ctx *ctx, const b3w_commit_key *key, const uint32_t *host_records, uint32_t n, uint8_t *host_points,

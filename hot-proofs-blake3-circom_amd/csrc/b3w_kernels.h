@@ -84,8 +84,7 @@ extern "C" int b3w_launch_commit(const uint8_t *d_bodies, uint32_t n, uint64_t p
                                                               n_blocks, block_count, total_depth, depth, [71, 138) first virtual slot of gadget j's slot */,
                                  const uint32_t *d_aux /* ... and the context's scalars: [0, 8) the prime, [16 + 8 k, + 8) 1 / k */,
                                  unsigned long long *d_adds /* or null: += the mixed additions of this launch (statistics) */,
-                                 const B3wCurve *curve, hipStream_t stream,
-                                 int co_resident /* the kernel built to run beside the witness kernel: at most two waves per SIMD (b3w_commit.hip) */);
+                                 const B3wCurve *curve, hipStream_t stream);
 // O2 nova circuits, records mode: invtab[j * nk + mag - 1] = (1 / mag) * G of the slot holding IsZero gadget j's inverse
 // (d_inverses: 8 words per magnitude, standard form — the witness kernels' table; d_inv_slot[j] = committed slot index or ~0)
 #define B3W_NOVA_ISZERO 67

@@ -77,6 +77,20 @@ __global__ __launch_bounds__(64) void b3w_store_streams_kernel(uint8_t *out, uin
     for (uint32_t k = 0; k < pause; ++k) __builtin_amdgcn_s_sleep(1);
   }
 }
+// a writer with a FIXED small footprint: `gridDim.x` single-wave workgroups (a few per CU) that take groups of 8 bodies in turn
+__global__ __launch_bounds__(64) void b3w_store_persistent_kernel(uint8_t *out, uint64_t pitch, uint32_t n, uint32_t tiles) {
+  const uint32_t lane = threadIdx.x;
+  const u32x4 v = {lane, blockIdx.x, 0, 0};
+  for (uint32_t b0 = blockIdx.x * 8; b0 < n; b0 += gridDim.x * 8) {
+    uint8_t *base[8];
+#pragma unroll
+    for (int w = 0; w < 8; ++w) base[w] = out + (uint64_t)(b0 + w < n ? b0 + w : n - 1) * pitch + lane * 16;
+    for (uint32_t g = 0; g < tiles; ++g) {
+#pragma unroll
+      for (int w = 0; w < 8; ++w) *reinterpret_cast<u32x4 *>(base[w] + (uint64_t)g * 1024) = v;
+    }
+  }
+}
 __global__ __launch_bounds__(256) void b3w_store_fill_kernel(uint8_t *out, uint64_t bytes) {
   const u32x4 v = {threadIdx.x, blockIdx.x, 0, 0};
   for (uint64_t t = blockIdx.x; (t + 1) * 4096 <= bytes; t += gridDim.x) *reinterpret_cast<u32x4 *>(out + t * 4096 + threadIdx.x * 16) = v;
@@ -164,6 +178,12 @@ Pool *pool_for(int device) {
   p->acc.location = p->prop.location;
   p->acc.flags = hipMemAccessFlagsProtReadWrite;
   void *va = nullptr;
+  // B3W_PLACE_ARENA_GIB: a smaller address range (tests of what happens when it is used up: buffers come from hipMalloc, labelled plain)
+  const uint64_t want = getenv("B3W_PLACE_ARENA_GIB") ? std::max<uint64_t>(2, (uint64_t)atoll(getenv("B3W_PLACE_ARENA_GIB"))) * GiB : ARENA;
+  if (want < ARENA) {
+    if (hipMemAddressReserve(&va, want, 2 * MiB, nullptr, 0) == hipSuccess) p->arena_bytes = want;
+    else { (void)hipGetLastError(); va = nullptr; }
+  }
   for (uint64_t sz = ARENA; sz >= (1ull << 40) && !va; sz >>= 1) {
     if (hipMemAddressReserve(&va, sz, 2 * MiB, nullptr, 0) == hipSuccess) p->arena_bytes = sz;
     else { (void)hipGetLastError(); va = nullptr; }
@@ -566,7 +586,8 @@ extern "C" void b3w_place_cost_breakdown(int device, double out[4]) {
 extern "C" int b3w_place_store_launch(uint8_t *buf, uint64_t pitch, uint32_t n, uint32_t body_bytes, int shape, hipStream_t stream) {
   if (!buf || !n || body_bytes < 1024 || pitch < body_bytes) return -(int)hipErrorInvalidValue;
   const uint32_t tiles = body_bytes / 1024;
-  if (shape >= 100) hipLaunchKernelGGL(b3w_store_streams_kernel<8>, dim3((n + 7) / 8), dim3(64), 0, stream, buf, pitch, n, tiles, (uint32_t)(shape - 100));   // paused
+  if (shape >= 200) hipLaunchKernelGGL(b3w_store_persistent_kernel, dim3(256u * (uint32_t)(shape - 200)), dim3(64), 0, stream, buf, pitch, n, tiles);   // (shape - 200) waves per CU
+  else if (shape >= 100) hipLaunchKernelGGL(b3w_store_streams_kernel<8>, dim3((n + 7) / 8), dim3(64), 0, stream, buf, pitch, n, tiles, (uint32_t)(shape - 100));   // paused
   else if (shape == 0) hipLaunchKernelGGL(b3w_store_streams_kernel<4>, dim3((n + 3) / 4), dim3(64), 0, stream, buf, pitch, n, tiles, 0u);
   else if (shape == 1) hipLaunchKernelGGL(b3w_store_streams_kernel<8>, dim3((n + 7) / 8), dim3(64), 0, stream, buf, pitch, n, tiles, 0u);
   else hipLaunchKernelGGL(b3w_store_fill_kernel, dim3(256), dim3(256), 0, stream, buf, (uint64_t)n * pitch);

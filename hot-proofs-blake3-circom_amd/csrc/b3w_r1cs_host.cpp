@@ -505,7 +505,9 @@ bool b3w_r1cs_host_build(const uint8_t *img, size_t len, const uint8_t prime_le[
       wmax_exp = std::max(wmax_exp, ne);
       slots += (ne + 63u) & ~63u;
     }
-    bool walk = slots <= B3W_WALK_MAX_EXP_SLOTS;
+    // (a term word is element | coefficient id << 16 with bit 31 = "shift term": ids from 0x8000 on would read as shifts.  Such a
+    // system would not fit the kernel's LDS either — its coefficient table alone is 256 KB — but that is a budget, not a guarantee)
+    bool walk = slots <= B3W_WALK_MAX_EXP_SLOTS && coefs.size() < 0x8000;
     auto widx = [&](uint32_t w, uint32_t t) { return w / T == t ? w - t * T : T + slot_of[w]; };
     std::vector<uint8_t> mustbit(nwires, 0);
     std::vector<uint32_t> wruns, wrun_row, went_w, went_m, wrow_k, wrow_id, wtiles4, unit_tile;

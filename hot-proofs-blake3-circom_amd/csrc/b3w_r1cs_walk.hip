@@ -508,6 +508,9 @@ __global__ __launch_bounds__(512, 4) void b3w_r1cs_walk_kernel(const uint8_t *__
       gflag[tid] = 0u;
       if (gw) {
         gwide[tid] = 0u;
+        // (the deferred kernel forms c - a b in 128 bits: |a b| < 2^126 because a and b passed for 64-bit numbers above, and c must
+        // leave room too — nothing else bounds a foreign system's C part; a row whose c does not stays a deferred ROW)
+        if (!defer && !careful && (c_hi < -(1ll << 61) || c_hi >= (1ll << 61))) defer = true;
         if (!defer && !careful) {                              // a wide record, while the body's list has room; else the row itself
           const uint32_t slot = atomicAdd(&cnt[6u + c.body % 3u], 1u);
           if (slot < B3W_WALK_WIDE_CAP) {                      // (kept in registers: the stores go out behind the pack — see the pipeline)
@@ -576,7 +579,9 @@ __global__ __launch_bounds__(512, 4) void b3w_r1cs_walk_kernel(const uint8_t *__
   bool sticky = false, prev_careful = false, prev2_careful = false;
   uint32_t i3 = 0;
   for (uint32_t i = 0; i < m; i++) {
-    if (STAMPS && stamping) t_prev = __builtin_amdgcn_s_memtime();
+    unsigned long long t_unit = 0;
+    if (STAMPS && stamping) { t_prev = __builtin_amdgcn_s_memtime(); t_unit = t_prev; }
+    const uint32_t unit_tile = ce.tile;
     const uint32_t par = i & 1u;
     const uint32_t i3n = i3 == 2u ? 0u : i3 + 1u, i3nn = i3n == 2u ? 0u : i3n + 1u;
     const bool anomaly = __builtin_amdgcn_readfirstlane(lanom[i3]) != 0u;
@@ -632,6 +637,8 @@ __global__ __launch_bounds__(512, 4) void b3w_r1cs_walk_kernel(const uint8_t *__
     B3W_WSTAMP(6);
     lds_barrier();
     B3W_WSTAMP(7);
+    // (per tile: cycles of the iterations that evaluated it, barrier to barrier, by wave 0 — stamps[64 + tile]; [128 + tile]: how many)
+    if (STAMPS && stamping && tid == 0) { stamps[64u + unit_tile] += __builtin_amdgcn_s_memtime() - t_unit; stamps[128u + unit_tile] += 1ull; }
   }
   if (STAMPS && stamping && lane == 0)
     for (int k = 0; k < 8; k++) stamps[wave * 8 + k] = ph[k];
@@ -691,8 +698,9 @@ extern "C" int b3w_launch_r1cs_walk(const uint8_t *d_bodies, uint32_t n, uint64_
   if (print_stamps) {
     hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
     if (hipStreamIsCapturing(stream, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone) { (void)hipGetLastError(); return (int)hipErrorStreamCaptureUnsupported; }
-    if (!d_stamps_buf && hipMalloc((void **)&d_stamps_buf, 8 * 8 * 8) != hipSuccess) d_stamps_buf = nullptr;
+    if (!d_stamps_buf && hipMalloc((void **)&d_stamps_buf, 192 * 8) != hipSuccess) d_stamps_buf = nullptr;
     d_stamps = d_stamps_buf;
+    if (d_stamps && hipMemsetAsync(d_stamps, 0, 192 * 8, stream) != hipSuccess) return (int)hipGetLastError();
     fn = ne <= 1u ? reinterpret_cast<const void *>(&b3w_r1cs_walk_kernel<1, false, true>) : reinterpret_cast<const void *>(&b3w_r1cs_walk_kernel<3, false, true>);
     if (ne == 2u || ne > 3u) return -6;
   }
@@ -734,7 +742,7 @@ extern "C" int b3w_launch_r1cs_walk(const uint8_t *d_bodies, uint32_t n, uint64_
     e = hipLaunchKernel(fn, dim3(grid), dim3(512), args, smem, stream);
     if (e != hipSuccess) return (int)e;
     if (d_stamps) {
-      unsigned long long h[64];
+      unsigned long long h[192];
       if (hipStreamSynchronize(stream) == hipSuccess && hipMemcpy(h, d_stamps, sizeof h, hipMemcpyDeviceToHost) == hipSuccess) {
         const double un = (double)nb / grid * walk->ntiles;
         static const char *name[8] = {"top+summary", "entries", "runs", "exports", "verdicts", "wait+pack", "program+fetch", "barrier"};
@@ -744,6 +752,9 @@ extern "C" int b3w_launch_r1cs_walk(const uint8_t *d_bodies, uint32_t n, uint64_
           for (int w = 0; w < 8; w++) fprintf(stderr, " %5.0f", (double)h[w * 8 + k] / un);
           fprintf(stderr, "\n");
         }
+        fprintf(stderr, "  cycles per iteration by the tile it evaluated:");
+        for (uint32_t t = 0; t < walk->ntiles && t < 64u; t++) fprintf(stderr, " %u:%.0f", t, h[128 + t] ? (double)h[64 + t] / (double)h[128 + t] : 0.0);
+        fprintf(stderr, "\n");
       }
     }
     // (on a second stream beside the next slab's walk kernel — two halves of the scratch in turn — the deferred kernel made a check of

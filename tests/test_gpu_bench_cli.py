@@ -35,7 +35,18 @@ def test_default_line_has_the_contract_fields():
     # value, ms_per_step and the launch count hang together
     c = d["config"]
     # what placement cost this process (round-3 verdict #6): seconds and GiB walked by the search, the real-kernel check, the limit
-    assert c["placement_search_limit_s"] == 30.0 and c["placement_search_s"] >= 0 and c["placement_alloc_s"] >= c["placement_search_s"]
+    # (r05: bench.py sets none of the allocator's knobs — the library's own defaults: 5 s)
+    assert c["placement_search_limit_s"] == 5.0 and c["placement_search_s"] >= 0 and c["placement_alloc_s"] >= c["placement_search_s"]
+    assert set(c["placement_search_breakdown_s"]) == {"hipMemCreate", "map", "probes", "release"}
+    # r05: the same kernel on a plain hipMalloc buffer and the pure-store ceilings of both buffers, measured in the same run
+    r = d["roofline"]
+    assert r["plain"]["kernel_ms"] > 0 and abs(r["plain"]["frac"] - r["plain"]["achieved"] / r["peak"]) < 1e-9
+    assert set(r["store_ceiling"]["placed"]) == set(r["store_ceiling"]["plain"]) == {"streams_w4", "streams_w8", "fill"}
+    assert min(list(r["store_ceiling"]["placed"].values()) + list(r["store_ceiling"]["plain"].values())) > 100
+    assert abs(r["of_measured_ceiling"] - r["achieved"] / max(r["store_ceiling"]["placed"].values())) < 1e-9
+    # the reference WASM's all-core rate: recorded in the build container (the reference cannot travel to this box), and the line says so
+    w = d["cpu_baseline"]["reference_wasm"]
+    assert w["cores"] >= 1 and w["value"] > 1 and w["unit"] == "witnesses/s" and "wasm_baseline.json" in w["where"] and "calculateWTNSBin" in w["sample"]
     assert c["placement_search_gib_walked"] >= 0 and c["placement_search_timeouts"] in (0, 1) and c["exchange_impl"] == "none"
     assert c["witnesses_per_step"] == 512 * c["launches_per_step"]
     assert abs(d["value"] - c["witnesses_per_step"] / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
@@ -135,3 +146,4 @@ def test_chain_workload_with_each_consumer(consumer):
     assert ("constraint check" in d["config"]["consumer"]) == ("check" in consumer)
     if "check" in consumer:
         assert "inside the timed pass: 0 of 23744 constraints violated by any of 6144 step witnesses" in d["config"]["verification"]
+    assert d["config"]["commit_overlap"] == ("auto" if consumer == "check+commit" else None)

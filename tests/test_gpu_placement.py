@@ -173,8 +173,14 @@ def test_mixed_is_a_measured_claim():
     n = 4096
     d_recs = torch.from_numpy(m.workloads.config2_compression(n).view(np.int32)).cuda()
     d_st = torch.zeros(n, dtype=torch.int32, device="cuda")
-    plain = torch.empty(n * ctx.body_bytes, dtype=torch.uint8, device="cuda")
-    r_plain = _fill_rate(ctx, plain.data_ptr(), n, d_recs, d_st, torch)
+    # (the yardstick the allocator itself uses: the slowest of three distinct plain buffers — one hipMalloc buffer in eight or so
+    # straddles a class border by luck and is as fast as a placed one; r05: this test met one, 6 910 GB/s)
+    keep, r_plain = [], None
+    for _ in range(3):
+        plain = torch.empty(n * ctx.body_bytes, dtype=torch.uint8, device="cuda")
+        r = _fill_rate(ctx, plain.data_ptr(), n, d_recs, d_st, torch)
+        r_plain = r if r_plain is None else min(r_plain, r)
+        keep.append(plain)
     buf = ctx.alloc_bodies(n * ctx.body_bytes)
     r_buf = _fill_rate(ctx, buf.ptr, n, d_recs, d_st, torch)
     print(f"plain {r_plain:.0f} GB/s, b3w_bodies_alloc ({buf.placement}) {r_buf:.0f} GB/s")
@@ -183,45 +189,103 @@ def test_mixed_is_a_measured_claim():
     st = ctx.bodies_stats()
     assert st["live_buffers"] >= 1 and st["live_bytes"] >= n * ctx.body_bytes and st["arena_used"] <= st["arena_bytes"]
     buf.free()
-    del plain
+    del plain, keep
     ctx.close()
 
 
-def test_soak_200_buffers_keep_their_rate_and_the_pool_stays_bounded():
-    """200 allocate / fill / free cycles of a 3.2 GB body buffer: the 200th buffer is as fast as the first (within 3 %),
-    every one holds what the kernel wrote, the pool never exceeds its cap, and the address space used up is what
-    DESIGN.md says (one buffer's size per cycle, never reused) — far from the 32 TiB arena."""
+def test_service_2000_buffers_of_mixed_sizes_keep_their_rate_and_the_allocator_stays_bounded():
+    """A long-lived process (r04 verdict #8): 2 000 allocate / fill / free cycles of body buffers of mixed sizes — 0.6 to 6.3 GB, now and
+    then two alive at once — on one context.  The last buffers are as fast as the first (within 3 %), every buffer checked holds
+    what the kernel wrote, and b3w_bodies_stats stays bounded all the way: pooled memory under its cap, no live buffer left behind,
+    physical handles created in the hundreds (the pool is reused, not re-walked), address space used up = the sum of the buffers'
+    sizes (never reused: about a fifth of the 32 TiB arena after 2 000 buffers)."""
     import torch
     ctx = m.Context("compression", 0)
     n = 4096
-    recs = m.workloads.config2_compression(n)
+    recs = m.workloads.config2_compression(2 * n)
     d_recs = torch.from_numpy(recs.view(np.int32)).cuda()
-    d_st = torch.zeros(n, dtype=torch.int32, device="cuda")
-    d_mm = torch.zeros(n, dtype=torch.int32, device="cuda")
-    rates, labels = [], []
-    used0 = ctx.bodies_stats()["arena_used"]
-    for k in range(200):
-        buf = ctx.alloc_bodies(n * ctx.body_bytes)
+    d_st = torch.zeros(2 * n, dtype=torch.int32, device="cuda")
+    d_mm = torch.zeros(2 * n, dtype=torch.int32, device="cuda")
+    rng = np.random.default_rng(8)
+    sizes = rng.choice([768, 1024, 2048, 3000, 4096, 6000, 8192], size=2000)     # bodies per buffer
+    sizes[:3] = n
+    sizes[-3:] = n
+    rates, labels, total = [], [], 0
+    st0 = ctx.bodies_stats()
+    held = None
+    for k, nb in enumerate(int(x) for x in sizes):
+        buf = ctx.alloc_bodies(nb * ctx.body_bytes)
+        total += -(-nb * ctx.body_bytes // HANDLE) * HANDLE
         labels.append(buf.placement)
-        if k in (0, 1, 2, 197, 198, 199):
-            rates.append(_fill_rate(ctx, buf.ptr, n, d_recs, d_st, torch))
-        else:
-            ctx.run_device(d_recs.data_ptr(), n, buf.ptr, 0, 0, d_st.data_ptr(), torch.cuda.current_stream().cuda_stream)
-        if k % 20 == 0 or k == 199:
-            ctx.verify_device(buf.ptr, n, 0, d_mm.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        if k < 3 or k >= 1997:
+            rates.append(_fill_rate(ctx, buf.ptr, nb, d_recs, d_st, torch))
+        elif k % 10 == 0:
+            ctx.run_device(d_recs.data_ptr(), nb, buf.ptr, 0, 0, d_st.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        if k % 100 == 0 or k == 1999:
+            ctx.run_device(d_recs.data_ptr(), nb, buf.ptr, 0, 0, d_st.data_ptr(), torch.cuda.current_stream().cuda_stream)
+            ctx.verify_device(buf.ptr, nb, 0, d_mm.data_ptr(), torch.cuda.current_stream().cuda_stream)
             torch.cuda.synchronize()
-            assert int(d_mm.abs().sum().item()) == 0 and int(d_st.abs().sum().item()) == 0, k
+            assert int(d_mm[:nb].abs().sum().item()) == 0 and int(d_st[:nb].abs().sum().item()) == 0, k
         st = ctx.bodies_stats()
-        assert st["pooled_bytes"] <= 13 << 30 and st["live_buffers"] == 1
-        buf.free()
+        assert st["pooled_bytes"] <= 13 << 30, (k, st)
+        assert st["live_buffers"] == (2 if held is not None else 1), (k, st)
+        if held is not None:
+            held.free()
+            held = None
+        if k % 7 == 3 and k < 1990:
+            held = buf                                      # stays alive over the next allocation
+        else:
+            buf.free()
     st = ctx.bodies_stats()
-    print(f"rates GB/s first {rates[:3]} last {rates[3:]}; labels {sorted(set(labels))}; arena used {(st['arena_used'] - used0) / 2**30:.0f} GiB "
-          f"of {st['arena_bytes'] / 2**40:.0f} TiB; handles created {st['handles_created']}")
-    assert len(set(labels)) == 1, "the placement changed along the way"
+    print(f"rates GB/s first {[round(r) for r in rates[:3]]} last {[round(r) for r in rates[3:]]}; labels {sorted(set(labels))}; arena used "
+          f"{(st['arena_used'] - st0['arena_used']) / 2**40:.2f} TiB of {st['arena_bytes'] / 2**40:.0f}; handles created {st['handles_created']}; pooled {st['pooled_bytes'] >> 30} GiB")
+    assert st["live_buffers"] == 0 and st["live_bytes"] == 0
+    # placed all the way, or plain all the way (a box without a second class): never a placed buffer early and plain ones later.
+    # ("interleaved" = placed, but that size's real-kernel check found this box's plain buffer within 10 %: the small buffers')
+    assert set(labels) <= {"mixed", "interleaved"} or set(labels) == {"plain"}, f"the placement changed along the way: {sorted(set(labels))}"
     first, last = max(rates[:3]), max(rates[3:])
     assert abs(last - first) <= 0.03 * first, (first, last)
-    assert st["arena_used"] - used0 <= 200 * (13 * HANDLE) + (64 << 30) and st["live_buffers"] == 0
+    assert st["arena_used"] - st0["arena_used"] <= total + (256 << 30)         # the buffers themselves + the probe mappings of the handles ever created
+    assert st["handles_created"] - st0["handles_created"] <= 8192               # new physical memory per cycle stays a fraction of a buffer: the pool serves the rest
     ctx.close()
+
+
+def test_address_space_used_up_means_plain_buffers_not_failures():
+    """The placement arena only grows (virtual addresses are never reused on this ROCm stack).  When it is used up — here a 24 GiB
+    arena instead of 32 TiB — b3w_bodies_alloc keeps answering: the buffer comes from hipMalloc, is labelled plain, and holds
+    what the kernel writes; a batch never fails for it."""
+    import subprocess, sys
+    script = r"""
+import importlib, sys
+import numpy as np, torch
+sys.path.insert(0, %r)
+m = importlib.import_module("hot-proofs-blake3-circom_amd")
+ctx = m.Context("compression", 0)
+n = 2048
+d_recs = torch.from_numpy(m.workloads.config2_compression(n).view(np.int32)).cuda()
+d_st = torch.zeros(n, dtype=torch.int32, device="cuda"); d_mm = torch.zeros(n, dtype=torch.int32, device="cuda")
+labels = []
+for k in range(12):
+    buf = ctx.alloc_bodies(n * ctx.body_bytes)
+    labels.append(buf.placement)
+    ctx.run_device(d_recs.data_ptr(), n, buf.ptr, 0, 0, d_st.data_ptr(), 0)
+    ctx.verify_device(buf.ptr, n, 0, d_mm.data_ptr(), 0)
+    torch.cuda.synchronize()
+    assert int(d_mm.abs().sum().item()) == 0 and int(d_st.abs().sum().item()) == 0, k
+    buf.free()
+b = m.Batch(ctx, 1024)                                   # a batch object's own buffer, after the arena has run out
+b.run(m.workloads.config2_compression(1024))
+st = ctx.bodies_stats()
+print("RESULT", ",".join(labels), b.placement(), st["arena_bytes"] >> 30, st["arena_used"] >> 30)
+""" % T.ROOT
+    r = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, timeout=600, cwd=T.ROOT,
+                       env=dict(os.environ, B3W_PLACE_ARENA_GIB="24"))
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [x for x in r.stdout.splitlines() if x.startswith("RESULT")][0].split()
+    labels = line[1].split(",")
+    assert int(line[3]) == 24 and int(line[4]) <= 24
+    assert labels[0] in ("mixed", "interleaved", "plain") and labels[-1] == "plain" and "plain" in labels[3:], labels
+    assert line[2] in ("0", "plain"), line                 # (Batch.placement(): the plain label)
 
 
 def test_chain_rings_are_reused_across_chain_objects():

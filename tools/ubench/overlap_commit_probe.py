@@ -6,7 +6,11 @@ Times, for one slice of n nova/Vesta steps: the commitments from the records alo
 the same bytes alone (no LDS, a dozen registers: b3w_store_streams_kernel) — and each writer BESIDE the commitments on a second
 stream, with every kernel's own duration from HIP events on its stream.  If the pure-store writer overlaps well and the witness
 kernel does not, what stands in the way is residency (LDS / registers), not the memory system.
-  [B3W_COMMIT_CO=1] [PROBE_COMMIT_PRIO=-1] python tools/ubench/overlap_commit_probe.py [n]"""
+  [PROBE_COMMIT_PRIO=-1] python tools/ubench/overlap_commit_probe.py [n]
+What r05 found (profiles/r05/overlap/): a store-only writer of ONE wave per CU — no LDS, a dozen registers, 6.96 ms alone — next to
+the commitments: 10.0 ms for the writer, 14.1 ms for the pair; two waves per CU: the writer keeps its 7.6 ms and the commitments make
+no progress while it runs (pair 17.0 = 7.6 + 9.1 + 0.3).  Residency is not what stands in the way: a saturated HBM write stream
+starves the commit kernel's 110 M random 64-byte table reads per slice."""
 import ctypes, importlib, os, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -49,16 +53,18 @@ def store(shape):
 
 
 def timed(fa, fb=None, reps=5):
-    """ms of fa alone (fb None), or (wall of the pair, fa's own, fb's own) side by side"""
+    """ms of fa alone (fb None), or (wall of the pair, fa's own, fb's own) side by side — fb is enqueued FIRST (the chain enqueues
+    the commitments of a batch before its witness kernel), each on its own stream"""
     out = []
     for _ in range(reps + 2):
         torch.cuda.synchronize()
         e = [torch.cuda.Event(enable_timing=True) for _ in range(6)]
         e[0].record(sa)
         sb.wait_event(e[0])
-        e[1].record(sa); fa(sa); e[2].record(sa)
         if fb is not None:
             e[3].record(sb); fb(sb); e[4].record(sb)
+        e[1].record(sa); fa(sa); e[2].record(sa)
+        if fb is not None:
             sa.wait_event(e[4])
         e[5].record(sa)
         torch.cuda.synchronize()
@@ -67,44 +73,15 @@ def timed(fa, fb=None, reps=5):
     return tuple(sorted(x[i] for x in out)[len(out) // 2] for i in range(3))
 
 
-print(f"n = {n} nova_vesta steps, bodies {bodies.placement}, key window {key.window}, commit stream priority {prio}, "
-      f"B3W_COMMIT_CO={os.environ.get('B3W_COMMIT_CO', '0')} (1 = the co-resident commit kernel: two waves per SIMD at most)")
-for name, f in (("commit from records", commit), ("witness kernel", witness), ("pure stores, streams w4", store(0)), ("pure stores, streams w8", store(1)),
-                ("pure stores, fill shape", store(2))):
-    print(f"alone   {name:28s} {timed(f)[0]:8.3f} ms")
-for name, f in (("witness kernel", witness), ("pure stores, streams w4", store(0)), ("pure stores, streams w8", store(1)), ("pure stores, fill shape", store(2))):
-    w, a, b = timed(f, commit)
-    print(f"beside  {name:28s} pair {w:8.3f} ms   writer {a:8.3f} ms   commit {b:8.3f} ms")
-# a writer that leaves the memory system air: `pause` x 64 cycles of s_sleep after every 8 KiB a wave stores
-for pause in (1, 2, 3, 4, 6, 8, 12, 16, 24, 32):
-    f = store(100 + pause)
-    alone = timed(f)[0]
-    w, a, b = timed(f, commit)
-    print(f"beside  pure stores w8, pause {pause:2d}    pair {w:8.3f} ms   writer {a:8.3f} ms   commit {b:8.3f} ms   (writer alone {alone:.3f} ms)")
-if os.environ.get("PROBE_CU_MASK"):                        # the writer on a stream confined to a share of the CUs
-    import ctypes as C
-    hip = C.CDLL("libamdhip64.so")
-    for pct in (25, 38, 50, 63, 75):
-        ncu = 256
-        mask = (C.c_uint32 * 8)()
-        for cu in range(ncu):
-            if (cu * pct) // 100 != ((cu + 1) * pct) // 100:
-                mask[cu // 32] |= 1 << (cu % 32)
-        st = C.c_void_p()
-        assert hip.hipExtStreamCreateWithCUMask(C.byref(st), 8, mask) == 0
-        sm = torch.cuda.ExternalStream(st.value)
-        old_sa = sa
-        sa = sm
-        for name, f in (("witness kernel", witness), ("pure stores w8", store(1))):
-            alone = timed(f)[0]
-            w, a, b = timed(f, commit)
-            print(f"beside  {name} on {pct}% of the CUs   pair {w:8.3f} ms   writer {a:8.3f} ms   commit {b:8.3f} ms   (writer alone {alone:.3f} ms)")
-        sa = old_sa
-for v in ("2", "0"):                                      # nova O2 variants: 2 = 4 bodies per wave, 0 = 2 bodies per wave
+print(f"n = {n} nova_vesta steps, bodies {bodies.placement}, key window {key.window}, commit stream priority {prio}; the commitments are enqueued first")
+print(f"alone   {'commit from records':34s} {timed(commit)[0]:8.3f} ms")
+writers = [("witness kernel (8 bodies a wave)", witness), ("pure stores, streams w8 (fills every wave slot)", store(1))]
+writers += [(f"pure stores, {k} persistent wave(s) per CU", store(200 + k)) for k in (1, 2, 3, 4, 8)]
+for v, what in (("2", "4 bodies a wave"), ("0", "2 bodies a wave")):
     os.environ["B3W_VARIANT"] = v
     ctx2 = m.Context("nova_vesta", 0)
-
-    def witness_v(s, c=ctx2):
-        c.run_device(d_recs.data_ptr(), n, bodies.ptr, 0, d_pub.data_ptr(), d_st.data_ptr(), s.cuda_stream)
-    w, a, b = timed(witness_v, commit)
-    print(f"beside  witness kernel B3W_VARIANT={v}  pair {w:8.3f} ms   writer {a:8.3f} ms   commit {b:8.3f} ms   (alone {timed(witness_v)[0]:.3f} ms)")
+    writers.append((f"witness kernel ({what})", (lambda c: lambda s: c.run_device(d_recs.data_ptr(), n, bodies.ptr, 0, d_pub.data_ptr(), d_st.data_ptr(), s.cuda_stream))(ctx2)))
+for name, f in writers:
+    alone = timed(f)[0]
+    w, a, b = timed(f, commit)
+    print(f"beside  {name:48s} pair {w:8.3f} ms   writer {a:8.3f} ms   commit {b:8.3f} ms   (writer alone {alone:.3f} ms)")
