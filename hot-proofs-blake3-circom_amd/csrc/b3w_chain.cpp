@@ -413,21 +413,28 @@ int32_t b3w_chain_run_leaves(b3w_chain *c, const uint8_t *host_preimage, b3w_bat
   b3w_ctx *ctx = c->ctx;
   ON_DEVICE(ctx);
   hipStream_t st = (hipStream_t)stream;
-  // the copy stream must not run ahead of work still reading d_pre from an earlier pass on `stream`
-  HIP_TRY(ctx, hipEventRecord(c->ev[3], st));
-  HIP_TRY(ctx, hipStreamWaitEvent(c->copy, c->ev[3], 0));
   uint32_t slice = 0;
   static const uint32_t slice_env = getenv("B3W_CHAIN_SLICE_CHUNKS") ? (uint32_t)std::max(1, atoi(getenv("B3W_CHAIN_SLICE_CHUNKS"))) : 0u;
   const uint32_t SLICE = slice_env ? slice_env : std::min<uint32_t>(CHAIN_SLICE_CHUNKS_MAX, std::max<uint32_t>(CHAIN_SLICE_CHUNKS, (uint32_t)(c->nl / 8)));
+  // ONE slice (a preimage of up to 1 MiB, a rank's share of config 4): nothing to overlap the copy with, so it goes on `stream` itself —
+  // an event from the copy stream to `stream` is 20-30 us of latency in front of the first kernel (profiles/r05/timeline_*.txt)
+  const bool one_slice = c->nl <= SLICE;
+  if (!one_slice) {
+    // the copy stream must not run ahead of work still reading d_pre from an earlier pass on `stream`
+    HIP_TRY(ctx, hipEventRecord(c->ev[3], st));
+    HIP_TRY(ctx, hipStreamWaitEvent(c->copy, c->ev[3], 0));
+  }
   for (uint32_t s0 = 0; s0 < c->nl; s0 += SLICE, slice++) {
     const uint32_t sc = std::min<uint32_t>(SLICE, c->nl - s0);
     const uint64_t b0 = (c->first_chunk + s0) * 1024, b1 = std::min<uint64_t>(b0 + (uint64_t)sc * 1024, c->len);
     hipEvent_t ev = c->ev[slice % 3];
     {
       Range r("b3w:h2d preimage slice");
-      if (b1 > b0) HIP_TRY(ctx, hipMemcpyAsync(c->d_pre + (uint64_t)s0 * 1024, host_preimage + b0, b1 - b0, hipMemcpyHostToDevice, c->copy));
-      HIP_TRY(ctx, hipEventRecord(ev, c->copy));
-      HIP_TRY(ctx, hipStreamWaitEvent(st, ev, 0));
+      if (b1 > b0) HIP_TRY(ctx, hipMemcpyAsync(c->d_pre + (uint64_t)s0 * 1024, host_preimage + b0, b1 - b0, hipMemcpyHostToDevice, one_slice ? st : c->copy));
+      if (!one_slice) {
+        HIP_TRY(ctx, hipEventRecord(ev, c->copy));
+        HIP_TRY(ctx, hipStreamWaitEvent(st, ev, 0));
+      }
     }
     int32_t rc;
     {

@@ -18,6 +18,8 @@
 // Record layout = the batch input format of the nova kernels (b3wit.h).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
+#include <atomic>
 #include "b3w_kernels.h"
 
 namespace {
@@ -69,6 +71,107 @@ __host__ __device__ inline uint32_t path_len(uint64_t c, uint64_t n) {
     p++;
   }
   return p;
+}
+
+// ---- the leaf planner, four lanes per chunk (r05) ------------------------------------------------------------------
+// A chunk's 16 blocks chain through the chaining value: 16 compressions one after the other, 33 us with one thread per chunk — in
+// front of the first witness kernel of every pass (7 % of a rank's share of a 1 MiB pass at 8 ranks).  Four lanes share a
+// compression the way the witness kernels' TRACE phase does: lane `col` of a quad holds column col of the state, the diagonal
+// step is the column step after a quad rotate (DPP), the block's 16 message words lie in LDS and every lane picks the two a G needs
+// by the round's schedule.  Same records, a third of the latency.
+template <int P0, int P1, int P2, int P3>
+__device__ __forceinline__ uint32_t plan_quad_perm(uint32_t x) {
+  return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)x, P0 | (P1 << 2) | (P2 << 4) | (P3 << 6), 0xF, 0xF, false);
+}
+__device__ __forceinline__ void plan_g(uint32_t &a, uint32_t &b, uint32_t &c, uint32_t &d, uint32_t x, uint32_t y) {
+  a = a + b + x; d = rotr(d ^ a, 16);
+  c = c + d;     b = rotr(b ^ c, 12);
+  a = a + b + y; d = rotr(d ^ a, 8);
+  c = c + d;     b = rotr(b ^ c, 7);
+}
+// message schedule of round r, 4 bits per entry: round r uses m[PERM_r[j]] in place of m[j]
+__host__ __device__ constexpr uint64_t plan_sched(int r) {
+  const int sigma[16] = {2, 6, 3, 10, 7, 0, 4, 13, 1, 11, 12, 5, 9, 14, 15, 8};
+  int p[16] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15};
+  for (int i = 0; i < r; i++) {
+    int q[16] = {};
+    for (int j = 0; j < 16; j++) q[j] = p[sigma[j]];
+    for (int j = 0; j < 16; j++) p[j] = q[j];
+  }
+  uint64_t v = 0;
+  for (int j = 0; j < 16; j++) v |= (uint64_t)p[j] << (4 * j);
+  return v;
+}
+template <int R>
+__device__ __forceinline__ void plan_quad_round(uint32_t &a, uint32_t &b, uint32_t &c, uint32_t &d, const uint32_t *M, int col) {
+  constexpr uint64_t P = plan_sched(R);
+  plan_g(a, b, c, d, M[(P >> (8 * col)) & 15], M[(P >> (8 * col + 4)) & 15]);
+  b = plan_quad_perm<1, 2, 3, 0>(b); c = plan_quad_perm<2, 3, 0, 1>(c); d = plan_quad_perm<3, 0, 1, 2>(d);
+  plan_g(a, b, c, d, M[(P >> (32 + 8 * col)) & 15], M[(P >> (36 + 8 * col)) & 15]);
+  b = plan_quad_perm<3, 0, 1, 2>(b); c = plan_quad_perm<2, 3, 0, 1>(c); d = plan_quad_perm<1, 2, 3, 0>(d);
+}
+// lane col: in h_lo = h[col], h_hi = h[4 + col]; out the same words of the compression's first eight output words
+__device__ __forceinline__ void plan_quad_cv(uint32_t &h_lo, uint32_t &h_hi, const uint32_t *M, int col, uint32_t t0, uint32_t t1, uint32_t b, uint32_t dflag) {
+  const uint32_t IVc = col == 0 ? 0x6A09E667u : col == 1 ? 0xBB67AE85u : col == 2 ? 0x3C6EF372u : 0xA54FF53Au;
+  uint32_t a = h_lo, bb = h_hi, c = IVc, d = col == 0 ? t0 : col == 1 ? t1 : col == 2 ? b : dflag;
+  plan_quad_round<0>(a, bb, c, d, M, col); plan_quad_round<1>(a, bb, c, d, M, col); plan_quad_round<2>(a, bb, c, d, M, col);
+  plan_quad_round<3>(a, bb, c, d, M, col); plan_quad_round<4>(a, bb, c, d, M, col); plan_quad_round<5>(a, bb, c, d, M, col);
+  plan_quad_round<6>(a, bb, c, d, M, col);
+  h_lo = a ^ c;
+  h_hi = bb ^ d;
+}
+
+__global__ __launch_bounds__(64) void b3w_plan_leaf_quad_kernel(const uint8_t *__restrict__ pre /* at chunk first_chunk */, uint64_t total_len, uint64_t first_chunk,
+                                                                uint32_t nlocal, uint64_t nchunks, uint32_t *__restrict__ recs, uint32_t *__restrict__ chunk_cv) {
+  __shared__ uint32_t Ms[16][16];                             // the current block's message words, per chunk of the workgroup
+  const uint32_t q = threadIdx.x >> 2, col = threadIdx.x & 3u;
+  const uint32_t i = blockIdx.x * 16u + q;
+  const bool live = i < nlocal;                               // (a dead quad walks chunk 0 of the workgroup's range with stores masked: the DPP moves want whole quads)
+  const uint32_t ii = live ? i : blockIdx.x * 16u;
+  const uint64_t c = first_chunk + ii;
+  const uint64_t off = c * 1024;
+  const uint32_t bytes = (uint32_t)(total_len - off < 1024 ? total_len - off : 1024);
+  const uint32_t n_blocks = bytes ? (bytes + 63) / 64 : 1;
+  const uint32_t P = path_len(c, nchunks);
+  const uint8_t *src = pre + (uint64_t)ii * 1024;
+  uint32_t *rec = recs + (uint64_t)ii * 16 * 32;
+  uint32_t *M = Ms[q];
+  uint32_t h_lo = col == 0 ? 0x6A09E667u : col == 1 ? 0xBB67AE85u : col == 2 ? 0x3C6EF372u : 0xA54FF53Au;
+  uint32_t h_hi = col == 0 ? 0x510E527Fu : col == 1 ? 0x9B05688Cu : col == 2 ? 0x1F83D9ABu : 0x5BE0CD19u;
+  for (uint32_t j = 0; j < n_blocks; ++j) {                   // (uniform over the quad; quads of a wave with fewer blocks idle)
+    const uint32_t bb = bytes - j * 64 < 64 ? bytes - j * 64 : 64;
+    uint32_t m4[4];
+    if (bb == 64 && ((uintptr_t)src & 15) == 0) {
+      const uint4 v = *reinterpret_cast<const uint4 *>(src + j * 64 + col * 16);
+      m4[0] = v.x; m4[1] = v.y; m4[2] = v.z; m4[3] = v.w;
+    } else {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        uint32_t w = 0;
+        for (int x = 0; x < 4; ++x) { const uint32_t p = (col * 4 + k) * 4 + x; if (p < bb) w |= (uint32_t)src[j * 64 + p] << (8 * x); }
+        m4[k] = w;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) M[col * 4 + k] = m4[k];
+    __builtin_amdgcn_wave_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");       // (one wave: the quad's words are in LDS)
+    if (live) {
+      uint32_t *r = rec + j * 32;
+      if (col == 0) { r[0] = n_blocks; r[1] = j; r[10] = (uint32_t)c; r[11] = (uint32_t)(c >> 32); }
+      if (col == 1) { r[12] = P + 1; r[13] = P + 1; r[14] = P; r[31] = bb; }      // leaf_depth, total_depth, depth (blake3_circuit.rs:83-110)
+      r[2 + col] = h_lo;
+      r[6 + col] = h_hi;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) r[15 + col * 4 + k] = m4[k];
+    }
+    // flags as Blake3GetFlag assigns them (circuits/blake3_nova.circom:122-167)
+    const uint32_t last = j == n_blocks - 1;
+    const uint32_t d = (j == 0 ? 1u : 0u) | (last ? 2u : 0u) | ((last && P == 0) ? 8u : 0u);
+    plan_quad_cv(h_lo, h_hi, M, (int)col, (uint32_t)c, (uint32_t)(c >> 32), bb, d);
+    __builtin_amdgcn_wave_barrier();                          // (every lane has read this block's words before the next block's overwrite them)
+  }
+  if (live) { chunk_cv[(uint64_t)i * 8 + col] = h_lo; chunk_cv[(uint64_t)i * 8 + 4 + col] = h_hi; }
 }
 
 __global__ __launch_bounds__(64) void b3w_plan_leaf_kernel(const uint8_t *__restrict__ pre /* at chunk first_chunk */,
@@ -423,8 +526,15 @@ extern "C" uint32_t b3w_plan_path_len(uint64_t chunk, uint64_t nchunks) { return
 extern "C" int b3w_launch_plan_leaves(const uint8_t *d_pre, uint64_t total_len, uint64_t first_chunk, uint32_t nlocal,
                                       uint64_t nchunks, uint32_t *d_recs, uint32_t *d_chunk_cv, hipStream_t stream) {
   if (!nlocal) return 0;
-  hipLaunchKernelGGL(b3w_plan_leaf_kernel, dim3((nlocal + 63) / 64), dim3(64), 0, stream, d_pre, total_len, first_chunk, nlocal,
-                     nchunks, d_recs, d_chunk_cv);
+  // four lanes per chunk while that leaves the chip room (a third of the latency); one thread per chunk for preimages of 64 MiB and more,
+  // where the planner is a throughput kernel (B3W_PLAN_QUAD=0 / 1: measurements)
+  static const int env_quad = getenv("B3W_PLAN_QUAD") ? atoi(getenv("B3W_PLAN_QUAD")) : -1;
+  const bool quad = env_quad >= 0 ? env_quad != 0 : nlocal <= 65536u;
+  if (quad)
+    hipLaunchKernelGGL(b3w_plan_leaf_quad_kernel, dim3((nlocal + 15) / 16), dim3(64), 0, stream, d_pre, total_len, first_chunk, nlocal, nchunks, d_recs, d_chunk_cv);
+  else
+    hipLaunchKernelGGL(b3w_plan_leaf_kernel, dim3((nlocal + 63) / 64), dim3(64), 0, stream, d_pre, total_len, first_chunk, nlocal,
+                       nchunks, d_recs, d_chunk_cv);
   return (int)hipGetLastError();
 }
 

@@ -112,3 +112,60 @@ def test_scratch_of_short_lived_streams_is_bounded():
     # after the eighth stream the footprint stops growing (24 unbounded scratches would be 650 MB)
     assert free[8] - free[-1] < (64 << 20), [f >> 20 for f in free]
     r1cs.close(); ctx.close()
+
+
+@pytest.mark.parametrize("world", [1, 8])
+def test_a_whole_chained_pass_replays_from_a_graph(world):
+    """r04 verdict 4b: the chained pass — copy of the preimage, leaf plan, witness batches through the ring, tree + parent plan on the
+    chain's side stream, parent witnesses, and (world = 8: rank 0's share through the native sharded path) both exchanges through a
+    communicator whose collective only enqueues device work — captured once per geometry into a hipGraph and replayed on NEW preimage
+    bytes (the pinned host buffer the capture read from is overwritten in place): public outputs, root and the gathered h_out of every
+    replay equal the eager pass over the same bytes.  The library allocates nothing and waits for nothing inside a pass that has run once;
+    the forks to its side stream are joined before the run calls return, so the capture closes."""
+    import ctypes
+    import torch
+    import blake3_ref as B
+    m = T.pkg()
+    dev = torch.device("cuda:0")
+    ctx = m.Context("nova_vesta", 0)
+    nbytes = 64 * 1024                                         # 64 chunks: 1 024 leaf + 384 parent steps (world 8: 128 + 48 here)
+    host = torch.zeros(nbytes, dtype=torch.uint8).pin_memory()
+    hip = ctypes.CDLL("libamdhip64.so")
+    hip.hipMemcpyAsync.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]
+
+    def standin(d_send, d_recv, nb, stream):                   # this rank's block into place 0 of the gathered buffer: device work on `stream` only
+        assert hip.hipMemcpyAsync(d_recv, d_send, nb, 3, stream) == 0
+    comm = m.Comm.external(ctx, 0, world, standin) if world > 1 else None
+
+    def fold():
+        return m.chain.fold_witnesses(ctx, host, batch_steps=512, ring=2, comm=comm)
+
+    def snapshot(out):
+        return (out["public"].clone(), out["root"].clone(), out["h_out_all"].clone(), out["status"].clone())
+    side = torch.cuda.Stream()
+    data = [((np.arange(nbytes, dtype=np.uint64) * (7919 + 2 * k) + k) % 251).astype(np.uint8) for k in range(3)]
+    want = []
+    with torch.cuda.stream(side):
+        for k in range(3):                                     # eager passes: what every replay must reproduce (and the warm-up of the capture)
+            host.copy_(torch.from_numpy(data[k]))
+            out = fold()
+            side.synchronize()
+            want.append(snapshot(out))
+            if world == 1:
+                assert out["root"].cpu().numpy().view(np.uint32).tolist() == B.hash_words(data[k].tobytes())
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side):
+        out = fold()
+    for k in (1, 2, 0):
+        host.copy_(torch.from_numpy(data[k]))
+        for t in (out["public"], out["status"]):
+            t.fill_(-1)
+        g.replay()
+        torch.cuda.synchronize()
+        got = snapshot(out)
+        own = slice(0, out["n_leaf_steps"])                    # (world 8: the gathered array's other places hold rank 0's block or nothing: only the own rows are compared)
+        assert torch.equal(got[0], want[k][0]) and torch.equal(got[1], want[k][1]) and int(got[3].abs().sum().item()) == 0, k
+        assert torch.equal(got[2][own], want[k][2][own]), k
+    if comm is not None:
+        comm.close()
+    ctx.close()

@@ -251,8 +251,8 @@ def test_service_2000_buffers_of_mixed_sizes_keep_their_rate_and_the_allocator_s
 
 
 def test_address_space_used_up_means_plain_buffers_not_failures():
-    """The placement arena only grows (virtual addresses are never reused on this ROCm stack).  When it is used up — here a 24 GiB
-    arena instead of 32 TiB — b3w_bodies_alloc keeps answering: the buffer comes from hipMalloc, is labelled plain, and holds
+    """The placement arena only grows (virtual addresses are never reused on this ROCm stack).  When it is used up — here a 12 GiB
+    arena instead of 32 TiB: 48 slots of 256 MiB, a 1.6 GB buffer takes seven and a search some more — b3w_bodies_alloc keeps answering: the buffer comes from hipMalloc, is labelled plain, and holds
     what the kernel writes; a batch never fails for it."""
     import subprocess, sys
     script = r"""
@@ -276,14 +276,14 @@ for k in range(12):
 b = m.Batch(ctx, 1024)                                   # a batch object's own buffer, after the arena has run out
 b.run(m.workloads.config2_compression(1024))
 st = ctx.bodies_stats()
-print("RESULT", ",".join(labels), b.placement(), st["arena_bytes"] >> 30, st["arena_used"] >> 30)
+print("RESULT", ",".join(labels), b.placement, st["arena_bytes"] >> 30, st["arena_used"] >> 30)
 """ % T.ROOT
     r = subprocess.run([sys.executable, "-c", script], capture_output=True, text=True, timeout=600, cwd=T.ROOT,
-                       env=dict(os.environ, B3W_PLACE_ARENA_GIB="24"))
+                       env=dict(os.environ, B3W_PLACE_ARENA_GIB="12"))
     assert r.returncode == 0, r.stderr[-2000:]
     line = [x for x in r.stdout.splitlines() if x.startswith("RESULT")][0].split()
     labels = line[1].split(",")
-    assert int(line[3]) == 24 and int(line[4]) <= 24
+    assert int(line[3]) == 12 and int(line[4]) <= 12
     assert labels[0] in ("mixed", "interleaved", "plain") and labels[-1] == "plain" and "plain" in labels[3:], labels
     assert line[2] in ("0", "plain"), line                 # (Batch.placement(): the plain label)
 
