@@ -581,6 +581,35 @@ extern "C" void b3w_place_cost_breakdown(int device, double out[4]) {
   }
 }
 
+// (measurements, tools/ubench/gather_beside_writer.py) the commit kernels' memory behaviour without their arithmetic's details: every lane
+// reads a random 64-byte entry of a table of `entries` entries and then runs `valu` dependent 32-bit multiply-adds on it, `iters` times;
+// 768 threads a CU as the commit kernel.  Does an L2-sized table keep such a kernel fed beside a writer that saturates HBM?
+__global__ __launch_bounds__(256) void b3w_gather_valu_kernel(const uint4 *__restrict__ table, uint32_t entries, uint32_t iters, uint32_t valu, uint32_t *__restrict__ sink) {
+  uint32_t x = (blockIdx.x * 256u + threadIdx.x) * 2654435761u + 12345u, acc = 0;
+  // (the shader clock this kernel runs at: cycles / (100 MHz ticks) around the loop, by one lane of a workgroup in the middle of the grid)
+  const bool stamp = blockIdx.x == gridDim.x / 2u && threadIdx.x == 0;
+  const unsigned long long c0 = stamp ? __builtin_amdgcn_s_memtime() : 0ull, r0 = stamp ? __builtin_amdgcn_s_memrealtime() : 0ull;
+  for (uint32_t i = 0; i < iters; ++i) {
+    x = x * 1664525u + 1013904223u;
+    const uint4 *e = table + (size_t)((x >> 4) % entries) * 4;
+    const uint4 a = e[0], b = e[1], c = e[2], d = e[3];
+    uint32_t v = a.x ^ b.y ^ c.z ^ d.w ^ x;
+    for (uint32_t k = 0; k < valu; ++k) v = v * 2246822519u + (v >> 15) + k;
+    acc += v;
+  }
+  if (stamp) {
+    const unsigned long long c1 = __builtin_amdgcn_s_memtime(), r1 = __builtin_amdgcn_s_memrealtime();
+    reinterpret_cast<unsigned long long *>(sink)[1] = c1 - c0;
+    reinterpret_cast<unsigned long long *>(sink)[2] = r1 - r0;
+  }
+  if (acc == 0x9E3779B9u) sink[0] = acc;                      // (keeps the loop)
+}
+extern "C" int b3w_place_gather_launch(const void *table, uint64_t table_bytes, uint32_t iters, uint32_t valu, uint32_t grid, uint32_t *sink, hipStream_t stream) {
+  if (!table || table_bytes < 64 || !grid) return -(int)hipErrorInvalidValue;
+  hipLaunchKernelGGL(b3w_gather_valu_kernel, dim3(grid), dim3(256), 0, stream, static_cast<const uint4 *>(table), (uint32_t)(table_bytes / 64), iters, valu, sink);
+  return -(int)hipGetLastError();
+}
+
 // one pure-store pass, enqueued on `stream` and not waited for (tools/ubench/overlap_commit_probe.py: a writer with no LDS and few
 // registers beside another kernel)
 extern "C" int b3w_place_store_launch(uint8_t *buf, uint64_t pitch, uint32_t n, uint32_t body_bytes, int shape, hipStream_t stream) {

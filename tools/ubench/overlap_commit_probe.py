@@ -9,8 +9,9 @@ kernel does not, what stands in the way is residency (LDS / registers), not the 
   [PROBE_COMMIT_PRIO=-1] python tools/ubench/overlap_commit_probe.py [n]
 What r05 found (profiles/r05/overlap/): a store-only writer of ONE wave per CU — no LDS, a dozen registers, 6.96 ms alone — next to
 the commitments: 10.0 ms for the writer, 14.1 ms for the pair; two waves per CU: the writer keeps its 7.6 ms and the commitments make
-no progress while it runs (pair 17.0 = 7.6 + 9.1 + 0.3).  Residency is not what stands in the way: a saturated HBM write stream
-starves the commit kernel's 110 M random 64-byte table reads per slice."""
+no progress while it runs (pair 17.0 = 7.6 + 9.1 + 0.3).  Residency is not what stands in the way; nor are the commit kernel's table
+reads (gather_beside_writer.py: an L2-resident table changes nothing): every pairing gives back 0.9 x the sum of the two times.
+"""
 import ctypes, importlib, os, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
