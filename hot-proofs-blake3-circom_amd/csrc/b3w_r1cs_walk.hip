@@ -253,6 +253,9 @@ __device__ __forceinline__ uint32_t table32(uint32_t table, uint32_t x0, uint32_
   return (x4 & l[1]) | (~x4 & l[0]);
 }
 
+#ifndef B3W_WALK_ABLATE
+#define B3W_WALK_ABLATE 0      // measurements only (tools/ubench/walk_ablate.py builds the variants; never set in a product build). Leaves OUT: 1 the
+#endif                         // truth-table runs, 2 the verdicts, 4 the entries, 8 the exports, 32 the scratch blocks, 2048 the wide records, 4096 their stores
 template <int NE, bool SIGNED, bool STAMPS = false>          // SIGNED: elements p - k count as -k (walk_pack); chunks of 64 general entries a wave takes at most (the tile with most: NE * 512); STAMPS: the diagnostic build's
 __global__ __launch_bounds__(512, 4) void b3w_r1cs_walk_kernel(const uint8_t *__restrict__ bodies, uint64_t pitch, uint32_t n, B3wWalk W,
                                                                unsigned long long *__restrict__ scratch, uint32_t block_words,
@@ -500,7 +503,7 @@ __global__ __launch_bounds__(512, 4) void b3w_r1cs_walk_kernel(const uint8_t *__
       part_sum(sum[0], sum[1], a_lo, a_hi);
       part_sum(sum[2], sum[3], b_lo, b_hi);
       part_sum(sum[4], sum[5], c_lo, c_hi);
-      const uint32_t gw = gwide[tid];
+      const uint32_t gw = (B3W_WALK_ABLATE & 2048) ? 0u : gwide[tid];
       defer = gflag[tid] != 0u || (gw >> 24) > 1u || a_hi != ((long long)a_lo >> 63) || b_hi != ((long long)b_lo >> 63);
       bad = !defer && !gw && (a_lo * b_lo != c_lo || __mul64hi((long long)a_lo, (long long)b_lo) != c_hi);
 #pragma unroll
@@ -588,14 +591,14 @@ __global__ __launch_bounds__(512, 4) void b3w_r1cs_walk_kernel(const uint8_t *__
     if (tid == 0) lanom[i3nn] = 0u;
     sticky = ce.tile == 0u ? anomaly : (sticky || anomaly);   // (an anomalous tile taints the rest of its body: later tiles import from it)
     if (i >= 2u) {
-      summary(prev2, par, prev2_careful);
+      if (!(B3W_WALK_ABLATE & 32)) summary(prev2, par, prev2_careful);
       if (prev2.tile == W.ntiles - 1u) flush(prev2.body);     // (its verdicts ran in the last iteration, behind the last barrier)
     }
     B3W_WSTAMP(0);
     uint32_t nbad = 0, low = 0xFFFFFFFFu;
-    entries(ce, par);
+    if (!(B3W_WALK_ABLATE & 4)) entries(ce, par);
     B3W_WSTAMP(1);
-    {
+    if (!(B3W_WALK_ABLATE & 1)) {
       const uint32_t run_n = TW(ce, B3W_WT_RUN_N);
       if (rwave * 64u < run_n) {
         const uint32_t viol = run_bits(prun, par, rtid < run_n);
@@ -606,10 +609,10 @@ __global__ __launch_bounds__(512, 4) void b3w_r1cs_walk_kernel(const uint8_t *__
       }
     }
     B3W_WSTAMP(2);
-    exports(ce, par);
+    if (!(B3W_WALK_ABLATE & 8)) exports(ce, par);
     count(nbad, low, ce.body);
     B3W_WSTAMP(3);
-    if (i) {
+    if (i && !(B3W_WALK_ABLATE & 2)) {
       uint32_t nb2 = 0, low2 = 0xFFFFFFFFu;
       verdicts(prev, par ^ 1u, prev_careful, nb2, low2);
       count(nb2, low2, prev.body);
@@ -620,11 +623,12 @@ __global__ __launch_bounds__(512, 4) void b3w_r1cs_walk_kernel(const uint8_t *__
     // (a wide record's stores go out HERE: behind the wait for the fetch the pack consumes, in front of the next loads — the compiler
     // cannot count conditional stores, so a wait that follows them is a wait for all of them)
     if (__ballot(wrec_at != 0) != 0ull) {
-      if (wrec_at) {
+      if (wrec_at && !(B3W_WALK_ABLATE & 4096)) {
         unsigned long long *rec = wide_recs + (wrec_at - 1u);
 #pragma unroll
         for (int q = 0; q < 5; q++) rec[q] = wrec[q];
       }
+      if (B3W_WALK_ABLATE & 4096) asm volatile("" :: "v"(wrec[0]), "v"(wrec[1]), "v"(wrec[2]), "v"(wrec[3]), "v"(wrec[4]));
       wrec_at = 0;
     }
     program(cp);
