@@ -106,12 +106,68 @@ def nova_cases():
     return cases
 
 
+def splitter_candidates(kind):
+    """More inputs of the same families, for pin_slots below: the config-2 / config-3 streams behind the cases above, and seeded probes."""
+    import random
+    rng = random.Random(78)
+    if kind == "compression":
+        c2 = W.config2_compression(32 + 300)
+        cand = [(f"config2_{i}", W.record_to_input(c2[i], W.COMPRESSION_KEYS)) for i in range(32, 332)]
+        cand += [(f"probe_{i}", RL.compression_probe(rng)) for i in range(100)]
+    else:
+        c3 = W.config3_nova(40 + 300)
+        cand = [(f"config3_{i}", W.record_to_input(c3[i], W.NOVA_KEYS)) for i in range(40, 340)]
+        cand += [(f"probe_{i + 8}", RL.nova_probe(rng)) for i in range(200)]
+        cand += [(f"directed_i{i}_b{bit}", RL.nova_probe(rng, directed=(i, bit))) for i in range(64) for bit in (0, 1)]      # (every eqs[i])
+        cand += [(f"probe_{i + 208}", RL.nova_probe(rng)) for i in range(300)]
+    return cand
+
+
+def pin_slots(cfg, cases, bodies, errors):
+    """Two witness slots that hold equal values in EVERY case above are not told apart by the fixtures: a layout that swapped them
+    would pass.  Most such pairs are the same signal twice (a gadget's output bits and the next gadget's input bits) and stay
+    equal whatever the input; the others are split here, by the reference's own witnesses of more inputs: a candidate is added as a
+    case when it separates two slots no earlier case separates.  (tests/test_golden_pinning_cpu.py then checks that a few hundred
+    further inputs of the CPU restatement separate nothing more.)"""
+    ok = [i for i in range(len(cases)) if i not in errors]
+    nwit = cfg["nwit"]
+
+    def slot_keys(body):                                       # one 64-bit key per slot value
+        w = np.frombuffer(body.tobytes(), dtype="<u8").reshape(nwit, 4)
+        return w[:, 0] * np.uint64(0x9E3779B97F4A7C15) ^ w[:, 1] * np.uint64(0xC2B2AE3D27D4EB4F) ^ w[:, 2] * np.uint64(0x165667B19E3779F9) ^ w[:, 3] * np.uint64(0x27D4EB2F165667C5)
+
+    def refine(gid, body):
+        pair = np.stack([gid.astype(np.uint64), slot_keys(body)], axis=1)
+        _, new = np.unique(pair, axis=0, return_inverse=True)
+        return new.reshape(-1)
+
+    gid = np.zeros(nwit, dtype=np.int64)
+    for i in ok:
+        gid = refine(gid, bodies[i])
+    cand = splitter_candidates(cfg["kind"])
+    cb, ce = RL.run_oracle(cfg["wasm"], [c[1] for c in cand])
+    added = []
+    for j, (name, inp) in enumerate(cand):
+        if j in ce:
+            continue
+        new = refine(gid, cb[j])
+        if new.max() > gid.max():
+            added.append(("pin_" + name, inp, cb[j]))
+            gid = new
+    return added, int(gid.max()) + 1
+
+
 def main():
     os.makedirs(GOLD, exist_ok=True)
     for circuit, cfg in RL.CIRCUITS.items():
         cases = compression_cases() if cfg["kind"] == "compression" else nova_cases()
         inputs = [c[1] for c in cases]
         bodies, errors = RL.run_oracle(cfg["wasm"], inputs)
+        added, ngroups = pin_slots(cfg, cases, bodies, errors)
+        print(f"{circuit}: {len(added)} pinning cases added; {ngroups} distinguishable slot groups of {cfg['nwit']} slots")
+        if added:
+            cases += [(a[0], a[1]) for a in added]
+            bodies = np.concatenate([bodies, np.stack([a[2] for a in added])])
         hdr = wtns_header(cfg["prime"], cfg["nwit"])
         out = dict(circuit=circuit, prime=str(cfg["prime"]), nwit=cfg["nwit"],
                    generated_by="tools/gen_golden.py from the reference's committed " + cfg["wasm"],
@@ -124,7 +180,8 @@ def main():
                 body = bodies[i].tobytes()
                 e["body_sha256"] = hashlib.sha256(body).hexdigest()
                 e["wtns_sha256"] = hashlib.sha256(hdr + body).hexdigest()
-                e["first16"] = [str(int.from_bytes(body[32 * s:32 * s + 32], "little")) for s in range(16)]
+                if not name.startswith("pin_"):
+                    e["first16"] = [str(int.from_bytes(body[32 * s:32 * s + 32], "little")) for s in range(16)]
             out["cases"].append(e)
         with open(os.path.join(GOLD, f"{circuit}.json"), "w") as f:
             json.dump(out, f, indent=1)
