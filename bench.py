@@ -54,6 +54,49 @@ def reference_wasm(circuit, reference_dir, seconds):
         return None
 
 
+WITNESS_KERNELS = ("b3w_compression_kernel", "b3w_nova_kernel", "b3w_sweep_kernel")
+
+
+def live_traffic(args):
+    """HBM bytes per launch of the witness kernel(s), measured for THIS invocation: two child runs of this script under
+    `rocprofv3 --pmc WRITE_SIZE` and `--pmc FETCH_SIZE` (separate passes, as MI355X_MICROARCH.md's HBM section prescribes; values are
+    KiB; on gfx950 FETCH_SIZE reports half of a wide read stream: doubled), each 8 launches of the same batch (`--traffic-child`),
+    BEFORE this process touches the GPU.  -> (dict, None) or (None, why not)."""
+    import csv, glob, shutil, subprocess, tempfile
+    roc = shutil.which("rocprofv3")
+    if not roc:
+        return None, "no rocprofv3 on PATH"
+    if any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
+        return None, "this run is itself under a profiler"
+    tmp = tempfile.mkdtemp(prefix="b3w_traffic_", dir="/tmp")
+    per, t0 = {}, time.perf_counter()
+    try:
+        for counter in ("WRITE_SIZE", "FETCH_SIZE"):
+            # (a plain buffer: the bytes a kernel moves do not depend on where its buffer lies, and the child needs no placement search)
+            cmd = [roc, "--pmc", counter, "--output-format", "csv", "-d", os.path.join(tmp, counter), "--", sys.executable, os.path.abspath(__file__),
+                   "--traffic-child", "1", "--circuit", args.circuit, "--batch", str(args.batch), "--pitch", str(args.pitch), "--placement", "plain",
+                   "--cpu-seconds", "0"] + (["--variant", str(args.variant)] if args.variant is not None else [])
+            r = subprocess.run(cmd, cwd=tmp, env=dict(os.environ, TMPDIR="/tmp", B3W_PLACE_CHECK="0"), capture_output=True, text=True, timeout=300)
+            if r.returncode != 0:
+                return None, f"the {counter} pass failed (rc {r.returncode}): " + (r.stderr or r.stdout)[-200:].replace("\n", " | ")
+            child = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+            files = glob.glob(os.path.join(tmp, counter, "**", "*counter_collection.csv"), recursive=True)
+            if not files:
+                return None, f"the {counter} pass left no counter_collection.csv"
+            rows = [x for x in csv.DictReader(open(files[0])) if x["Counter_Name"] == counter and any(k in x["Kernel_Name"] for k in WITNESS_KERNELS)]
+            rows.sort(key=lambda x: int(x["Dispatch_Id"]))
+            k = child["launches"] * child["kernels_per_launch"]      # the child's last launches: behind its autotune
+            if len(rows) < k:
+                return None, f"the {counter} pass shows {len(rows)} witness-kernel dispatches, {k} expected"
+            per[counter] = sum(float(x["Counter_Value"]) for x in rows[-k:]) * 1024.0 / child["launches"]
+    except Exception as e:                                  # (a time-out, an unreadable csv: the line then quotes the recorded passes)
+        return None, f"{type(e).__name__}: {e}"
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+    return {"hbm_bytes_per_launch": per["WRITE_SIZE"] + 2.0 * per["FETCH_SIZE"], "write_bytes": per["WRITE_SIZE"], "fetch_bytes_x2": 2.0 * per["FETCH_SIZE"],
+            "seconds": round(time.perf_counter() - t0, 1)}, None
+
+
 def self_launch(n, argv, launch_timeout):
     """`python bench.py --gpus N` without a launcher: N fresh child processes, one rank per GPU, started BEFORE this
     process has touched HIP (it never does: the parent only waits).  Rank 0's child prints the JSON line; the parent
@@ -505,10 +548,18 @@ def main():
     ap.add_argument("--timed-ms", type=float, default=5000.0,
                     help="batch workload with --inner 0: how long the K timed steps should last together (the driver's busy "
                          "sampler needs seconds, not a 9 ms burst)")
+    ap.add_argument("--traffic", default="auto", choices=["auto", "quoted"],
+                    help="roofline.traffic of the batch line at N = 1: auto = measured by this invocation (two rocprofv3 --pmc child passes of 8 "
+                         "launches, before anything else; about half a minute) where rocprofv3 is there and this run is not itself profiled, "
+                         "else — and with `quoted` — the figure of the recorded passes (profiles/traffic_latest.json), said so in traffic_source")
+    ap.add_argument("--traffic-child", default=None, help=argparse.SUPPRESS)      # (internal: what --traffic auto runs under rocprofv3)
     args = ap.parse_args()
 
     if "WORLD_SIZE" not in os.environ and args.gpus > 1:
         sys.exit(self_launch(args.gpus, sys.argv[1:], args.launch_timeout))      # nothing above has loaded torch or HIP
+    measured_traffic, traffic_why_not = None, "--traffic quoted"
+    if args.traffic == "auto" and args.traffic_child is None and args.workload == "batch" and "WORLD_SIZE" not in os.environ:
+        measured_traffic, traffic_why_not = live_traffic(args)      # (children of a process that has not touched the GPU yet)
 
     rank = int(os.environ.get("RANK", "0"))
     hang = os.environ.get("B3W_BENCH_TEST_HANG_RANK")       # tests only: this rank never reaches the rendezvous
@@ -664,6 +715,12 @@ def main():
                                               stream.cuda_stream)
     else:                                                   # (autotune leaves the winner selected in ctx)
         chosen = args.variant
+    if args.traffic_child is not None:                      # under rocprofv3 --pmc (live_traffic): the last 8 launches are what is counted
+        for _ in range(2 + 8):
+            launch(post=False)
+        torch.cuda.synchronize()
+        print(json.dumps({"traffic_child": True, "variant": chosen, "launches": 8, "kernels_per_launch": 2 if chosen >= 100 else 1}))
+        return
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     for _ in range(2):
         launch(post=args.exchange != "none")                # (the communicator's first collective — connection set-up — stays untimed)
@@ -778,16 +835,21 @@ def main():
         total = world * n * launches
         alg_bytes = BYTES_PER_WITNESS[circuit] * n                   # per launch
         achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
-        traffic, traffic_source = None, None
+        traffic, traffic_source, traffic_parts = None, None, None
         tf = os.path.join(ROOT, "profiles", "traffic_latest.json")   # PMC passes (WRITE_SIZE/FETCH_SIZE), see profiles/README.md
-        if os.path.exists(tf):
+        if measured_traffic is not None:
+            traffic = measured_traffic["hbm_bytes_per_launch"]
+            traffic_parts = measured_traffic
+            traffic_source = ("measured by this invocation: rocprofv3 --pmc WRITE_SIZE and --pmc FETCH_SIZE (separate child passes of 8 launches of this "
+                              "batch on a plain buffer, before the timed region), KiB x 1024, FETCH_SIZE x 2 (MI355X_MICROARCH.md, HBM)")
+        elif os.path.exists(tf):
             try:
                 path = "sweep" if chosen >= 100 else "fused"
                 doc = json.load(open(tf))
                 for ent in doc.get("entries", []):
                     if ent.get("circuit") == circuit and ent.get("batch") == n and ent.get("path") == path:
                         traffic = ent.get("hbm_bytes_per_launch")
-                        traffic_source = (f"NOT measured by this run: profiles/r{int(doc.get('round', 0)):02d}/{ent.get('tag', circuit)}"
+                        traffic_source = (f"NOT measured by this run ({traffic_why_not}): profiles/r{int(doc.get('round', 0)):02d}/{ent.get('tag', circuit)}"
                                           "_pmc_{WRITE,FETCH}_SIZE.csv (separate rocprofv3 --pmc passes of this command)")
             except Exception:
                 traffic = None
@@ -826,7 +888,7 @@ def main():
                                                 "what": "one all-gather of the batch's public outputs with nothing else on the device: HIP events around 20, after the timed region"},
                        "devices_per_rank": devices, **place_cost},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_source": traffic_source, "traffic_measured": traffic_parts,
                          "kernel_ms": kern_ms, "kernel_ms_per_rank": kern_per_rank, "kernel_ms_min": min(kern_per_rank),
                          "kernel_ms_max": max(kern_per_rank), "algorithmic_bytes_per_launch": alg_bytes, "launches_timed": launches},
         }

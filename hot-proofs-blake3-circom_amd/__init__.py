@@ -185,6 +185,40 @@ EXPORTED_SYMBOLS = ("b3w_abi_version", "b3w_identify_wasm", "b3w_create", "b3w_d
                     "b3w_chain_outputs", "b3w_chain_records", "b3w_chain_public", "b3w_chain_status", "b3w_chain_local_cvs", "b3w_chain_root")
 
 
+class graph_capture:
+    """`with graph_capture(g, stream=side): <library launches>` — torch.cuda.graph(g, stream=side) for launches of this library.
+    What every entry point that takes a stream enqueues is capturable (tests/test_gpu_graph_capture.py: batches, constraint
+    checks, a whole chained pass); what is NOT is a finaliser: a Context, Chain, R1cs or CommitKey that Python's cyclic collector
+    frees while the capture is open releases device memory and streams — calls the capture's global mode forbids, and the
+    process aborts.  So: garbage is collected before the capture opens and the collector stays off until it has closed (objects
+    you drop by hand inside the block are your own affair: keep them alive until the block ends)."""
+
+    def __init__(self, graph, stream=None, **kw):
+        import torch
+        self._inner = torch.cuda.graph(graph, stream=stream, **kw)
+        self._gc_was_on = False
+
+    def __enter__(self):
+        import gc
+        gc.collect()
+        self._gc_was_on = gc.isenabled()
+        gc.disable()
+        try:
+            return self._inner.__enter__()
+        except BaseException:
+            if self._gc_was_on:
+                gc.enable()
+            raise
+
+    def __exit__(self, *exc):
+        import gc
+        try:
+            return self._inner.__exit__(*exc)
+        finally:
+            if self._gc_was_on:
+                gc.enable()
+
+
 def fnv_hash(name):
     """witness_calculator.js:325-337 fnvHash (FNV-1a 64) as an int."""
     h = 0xCBF29CE484222325

@@ -51,10 +51,16 @@ def test_default_line_has_the_contract_fields():
     assert c["witnesses_per_step"] == 512 * c["launches_per_step"]
     assert abs(d["value"] - c["witnesses_per_step"] / (d["ms_per_step"] * 1e-3)) < 1e-6 * d["value"]
     assert d["roofline"]["launches_timed"] == 3 * c["launches_per_step"] and d["roofline"]["kernel_ms"] * c["launches_per_step"] <= d["ms_per_step"] * 1.001
+    # r05: the HBM traffic of a launch is measured by the invocation itself (two rocprofv3 --pmc child passes before it touches the GPU)
+    tm = r["traffic_measured"]
+    assert tm is not None and "measured by this invocation" in r["traffic_source"], r["traffic_source"]
+    assert abs(r["traffic"] - (tm["write_bytes"] + tm["fetch_bytes_x2"])) < 1.0 and tm["write_bytes"] > 100 * tm["fetch_bytes_x2"] >= 0
+    assert 0.995 < r["traffic"] / r["algorithmic_bytes_per_launch"] < 1.03, (r["traffic"], r["algorithmic_bytes_per_launch"])
 
 
 def test_nova_line_is_labelled_config3():
-    d = _bench("--circuit", "nova_vesta", "--batch", "512", "--steps", "2", "--warmup", "1", "--inner", "2", "--cpu-seconds", "0", "--placement", "plain")
+    d = _bench("--circuit", "nova_vesta", "--batch", "512", "--steps", "2", "--warmup", "1", "--inner", "2", "--cpu-seconds", "0", "--placement", "plain", "--traffic", "quoted")
+    assert d["roofline"]["traffic_measured"] is None and "--traffic quoted" in (d["roofline"]["traffic_source"] or "--traffic quoted")
     assert d["config"]["workload"].startswith("config3") and "Vesta" in d["config"]["workload"] and d["config"]["launches_per_step"] == 2
 
 

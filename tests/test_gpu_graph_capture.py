@@ -38,7 +38,7 @@ def test_witness_and_checks_replay_from_a_graph():
         enqueue(side.cuda_stream)                              # warm-up outside the capture (module load, first-use set-up)
     side.synchronize()
     g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g, stream=side):
+    with T.pkg().graph_capture(g, stream=side):
         enqueue(torch.cuda.current_stream().cuda_stream)
     for round_, start in enumerate((5000, 9000)):              # replay on new inputs: only the record buffer changes
         new = W.config2_compression(k * n, first=start).reshape(k, n, 28)
@@ -73,7 +73,7 @@ def test_first_check_on_a_capturing_stream_is_refused_not_allocated():
         ctx.run_device(recs.data_ptr(), n, bodies.data_ptr(), 0, 0, 0, side.cuda_stream)          # (the witness kernel may be captured cold)
     side.synchronize()
     g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g, stream=side):
+    with T.pkg().graph_capture(g, stream=side):
         s = torch.cuda.current_stream().cuda_stream
         ctx.run_device(recs.data_ptr(), n, bodies.data_ptr(), 0, 0, 0, s)
         with pytest.raises(m.B3WError) as e:
@@ -154,7 +154,7 @@ def test_a_whole_chained_pass_replays_from_a_graph(world):
             if world == 1:
                 assert out["root"].cpu().numpy().view(np.uint32).tolist() == B.hash_words(data[k].tobytes())
     g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g, stream=side):
+    with T.pkg().graph_capture(g, stream=side):
         out = fold()
     for k in (1, 2, 0):
         host.copy_(torch.from_numpy(data[k]))

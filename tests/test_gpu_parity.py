@@ -240,7 +240,7 @@ def test_batch_launch_inside_a_hip_graph(m):
     torch.cuda.current_stream().wait_stream(side)
     torch.cuda.synchronize()
     g = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(g, stream=side):
+    with T.pkg().graph_capture(g, stream=side):
         ctx.run_device(d_recs.data_ptr(), n, d_bodies.data_ptr(), 0, d_pub.data_ptr(), d_st.data_ptr(), torch.cuda.current_stream().cuda_stream)
     d_recs.copy_(torch.from_numpy(recs_b.view(np.int32)))                 # new inputs, same buffers
     d_bodies.zero_()

@@ -35,7 +35,7 @@ with torch.cuda.stream(side):
     side.synchronize()
     eager = (time.perf_counter() - t0) / reps * 1e3
 g = torch.cuda.CUDAGraph()
-with torch.cuda.graph(g, stream=side):
+with m.graph_capture(g, stream=side):
     fold()
 g.replay(); torch.cuda.synchronize()
 t0 = time.perf_counter()
