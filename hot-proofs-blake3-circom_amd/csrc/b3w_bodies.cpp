@@ -153,6 +153,7 @@ int32_t b3w_bodies_alloc(b3w_ctx *ctx, uint64_t bytes, void **d_ptr, int32_t *pl
 
 int32_t b3w_bodies_free(b3w_ctx *ctx, void *d_ptr) {
   if (!d_ptr) return B3W_OK;
+  B3wCaptureRelaxed relaxed;                                 // (b3w_capture.h)
   int cur = 0;
   (void)hipGetDevice(&cur);
   DeviceGuard guard(ctx ? ctx->device : cur);
@@ -161,10 +162,11 @@ int32_t b3w_bodies_free(b3w_ctx *ctx, void *d_ptr) {
   return e == hipSuccess ? B3W_OK : hip_fail(ctx, e, "hipFree(bodies)");
 }
 
-void b3w_bodies_trim(void) { b3w_place_trim(); }
+void b3w_bodies_trim(void) { B3wCaptureRelaxed relaxed; b3w_place_trim(); }
 
 int32_t b3w_ctx_trim(b3w_ctx *ctx) {
   if (!ctx) return B3W_E_BAD_ARGUMENT;
+  B3wCaptureRelaxed relaxed;                                 // (b3w_capture.h)
   DeviceGuard guard(ctx->device);
   for (const b3w_ctx::Spare &sp : ctx->ring_spares) (void)b3w_bodies_free(ctx, sp.ptr);
   ctx->ring_spares.clear();
@@ -205,6 +207,7 @@ int32_t b3w_batch_alloc(b3w_ctx *ctx, uint32_t capacity, uint64_t pitch, b3w_bat
 
 void b3w_batch_free(b3w_batch *b) {
   if (!b) return;
+  B3wCaptureRelaxed relaxed;                                 // (b3w_capture.h)
   DeviceGuard guard(b->ctx->device);
   if (b->d_recs) (void)hipFree(b->d_recs);
   if (b->d_bodies) (void)b3w_bodies_free(b->ctx, b->d_bodies);

@@ -371,8 +371,9 @@ int32_t b3w_chain_create(b3w_ctx *ctx, uint64_t preimage_len, uint64_t first_chu
 
 void b3w_chain_destroy(b3w_chain *c) {
   if (!c) return;
+  B3wCaptureRelaxed relaxed;                                 // (b3w_capture.h)
   DeviceGuard guard(c->ctx->device);
-  (void)hipDeviceSynchronize();
+  b3w_device_wait();                                         // the ring buffers outlive the chain (spares): nothing may still write them
   // ring buffers go back to the context (placed buffers use up address space for good: DESIGN.md "Placement") for the next
   // chain of the same ring geometry.  Spares of another size are released first (one size at a time) and the spares never
   // hold more than B3W_RING_SPARE_CAP bytes; b3w_ctx_trim releases them.

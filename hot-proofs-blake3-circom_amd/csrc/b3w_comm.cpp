@@ -105,6 +105,7 @@ int32_t b3w_comm_size(const b3w_comm *c) { return c ? c->nranks : 0; }
 
 void b3w_comm_destroy(b3w_comm *c) {
   if (!c) return;
+  B3wCaptureRelaxed relaxed;                                 // (b3w_capture.h)
   DeviceGuard guard(c->ctx->device);
   if (c->comm && rccl.CommDestroy) (void)rccl.CommDestroy(c->comm);
   if (c->h_send) (void)hipHostFree(c->h_send);

@@ -231,6 +231,7 @@ int32_t b3w_commit_key_create_folded(b3w_ctx *ctx, int32_t curve, uint32_t first
 
 void b3w_commit_key_destroy(b3w_commit_key *key) {
   if (!key) return;
+  B3wCaptureRelaxed relaxed;                                 // (b3w_capture.h)
   DeviceGuard guard(key->ctx->device);
   if (key->d_slotdesc) (void)hipFree(key->d_slotdesc);
   if (key->d_invmeta) (void)hipFree(key->d_invmeta);

@@ -347,6 +347,7 @@ int32_t b3w_create(int32_t circuit, int32_t device, b3w_ctx **out) {
 
 void b3w_destroy(b3w_ctx *ctx) {
   if (!ctx) return;
+  B3wCaptureRelaxed relaxed;                                 // (b3w_capture.h: a release may run while somebody's capture is open)
   DeviceGuard guard(ctx->device);
   (void)b3w_ctx_trim(ctx);
   if (ctx->d_table_base) (void)hipFree(ctx->d_table_base);

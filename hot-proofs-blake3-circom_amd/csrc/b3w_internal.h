@@ -23,6 +23,7 @@
 
 #include "../../include/b3wit.h"
 #include "b3w_atoms.h"
+#include "b3w_capture.h"
 #include "b3w_kernels.h"
 #include "b3w_r1cs_host.h"
 

@@ -35,6 +35,7 @@
 // in a buffer is fine).  A buffer of B bytes therefore uses up B bytes of address space for good: thousands of
 // 12 GB buffers per process; when the range is used up allocations fall back to plain hipMalloc.
 #include <hip/hip_runtime.h>
+#include "b3w_capture.h"
 #include <stdint.h>
 #include <stdlib.h>
 #include <stdio.h>
@@ -513,7 +514,10 @@ extern "C" int b3w_place_free(void *ptr) {
     if (r[i]->va == ptr) { pl = r[i]; r.erase(r.begin() + i); }
   if (!pl) return 1;
   (void)hipSetDevice(pl->device);
-  (void)hipDeviceSynchronize();
+  {
+    B3wCaptureRelaxed relaxed;                               // (b3w_capture.h: hipDeviceSynchronize is refused while ANY stream captures)
+    b3w_device_wait();                                       // nothing may still write what is unmapped next
+  }
   for (size_t s = 0; s < pl->pieces.size(); s++) (void)hipMemUnmap(static_cast<uint8_t *>(pl->va) + s * HANDLE, HANDLE);   // the range is not used again
   Pool *p = pool_for(pl->device);
   if (p) give_back(p, pl->pieces);                       // labelled pieces: kept for the next buffer while there is room

@@ -155,6 +155,7 @@ int32_t b3w_r1cs_is_tiled(const b3w_r1cs *r) { return r && r->tiled ? 1 : 0; }
 
 void b3w_r1cs_destroy(b3w_r1cs *r) {
   if (!r) return;
+  B3wCaptureRelaxed relaxed;                                 // (b3w_capture.h)
   DeviceGuard guard(r->ctx->device);
   if (r->d_rows) (void)hipFree(r->d_rows);
   if (r->d_row_id) (void)hipFree(r->d_row_id);

@@ -169,3 +169,62 @@ def test_a_whole_chained_pass_replays_from_a_graph(world):
     if comm is not None:
         comm.close()
     ctx.close()
+
+
+def test_releasing_other_objects_while_a_capture_is_open_leaves_the_capture_valid():
+    """r05: a finaliser may run at any time — Python's cyclic collector released a Context inside somebody's capture and the suite
+    aborted (profiles/r05/gpu_suite_abort_in_capture.log).  The release paths now put their thread into the relaxed capture mode and wait
+    for the device without hipDeviceSynchronize (csrc/b3w_capture.h).  Here: contexts, a batch, placed and plain body buffers, a constraint
+    system with a used scratch, a commit key, a chain with ring buffers, a communicator are all released INSIDE a bare torch.cuda.graph
+    capture of another context's launch; the capture closes, replays on new records, and the bodies are those records' witnesses."""
+    import gc
+    import torch
+    m = T.pkg()
+    dev = torch.device("cuda:0")
+    n = 64
+    ctx = m.Context("compression", 0)
+    recs_a = T.workloads().config2_compression(n, first=3)
+    recs_b = T.workloads().config2_compression(n, first=7000)
+    d_recs = torch.from_numpy(recs_a.view(np.int32)).to(dev)
+    d_bodies = torch.zeros((n, ctx.body_bytes), dtype=torch.uint8, device=dev)
+    d_pub = torch.zeros((n, 16), dtype=torch.int32, device=dev)
+    d_st = torch.full((n,), -1, dtype=torch.int32, device=dev)
+    # the objects that will be released inside the capture, all of them used before
+    victim = m.Context("nova_vesta", 0)
+    v_r1cs = m.R1cs(victim)
+    v_n = 32
+    v_recs = torch.from_numpy(T.workloads().config3_nova(v_n).view(np.int32)).to(dev)
+    v_placed = victim.alloc_bodies(v_n * victim.body_bytes)
+    victim.run_device(v_recs.data_ptr(), v_n, v_placed.ptr, 0, 0, 0, 0)
+    v_viol = torch.full((v_n,), -1, dtype=torch.int32, device=dev)
+    v_r1cs.check_device(v_placed.ptr, v_n, 0, v_viol.data_ptr(), 0, 0)
+    import ec_ref as E
+    gens = E.points_to_bytes(E.random_points("pallas", 40, seed=b"capture"))
+    v_key = m.CommitKey(victim, "pallas", gens, first_slot=victim.witness_size - 40, window=12)
+    v_out = m.chain.fold_witnesses(victim, torch.zeros(8 * 1024, dtype=torch.uint8).pin_memory(), batch_steps=64, ring=2)
+    v_batch = m.Batch(victim, 16)
+    v_comm = m.Comm.external(victim, 0, 2, lambda a, b, c, d: None)
+    torch.cuda.synchronize()
+    assert int(v_viol.abs().sum().item()) == 0
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        ctx.run_device(d_recs.data_ptr(), n, d_bodies.data_ptr(), 0, d_pub.data_ptr(), d_st.data_ptr(), side.cuda_stream)
+    torch.cuda.synchronize()
+    gc.collect()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side):                     # (bare: the global capture mode, no collector games)
+        ctx.run_device(d_recs.data_ptr(), n, d_bodies.data_ptr(), 0, d_pub.data_ptr(), d_st.data_ptr(), torch.cuda.current_stream().cuda_stream)
+        del v_out
+        v_comm.close(); v_batch.close()
+        v_key.close(); v_r1cs.close(); v_placed.free()
+        victim.close()                                         # (its cached chain and ring spares go with it)
+        m.lib().b3w_bodies_trim()
+    d_recs.copy_(torch.from_numpy(recs_b.view(np.int32)))
+    d_bodies.zero_(); d_st.fill_(-1)
+    g.replay()
+    torch.cuda.synchronize()
+    assert int(d_st.abs().sum().item()) == 0
+    bad, want = T.oracle_batch_u32("compression", recs_b)
+    assert bad == 0 and np.array_equal(d_bodies.cpu().numpy(), want)
+    ctx.close()
