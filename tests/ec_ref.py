@@ -72,11 +72,15 @@ def neg(P, p):
     return None if P is None else (P[0], (-P[1]) % p)
 
 
+_POINTS = {}                                                   # (curve, seed) -> the points made so far: point i depends on (seed, i) only
+
+
 def random_points(curve, n, seed=b"b3wit-test-generators"):
-    """n points by try-and-increment on a hash of (seed, i, counter)."""
+    """n points by try-and-increment on a hash of (seed, i, counter).  (Kept per (curve, seed) for the process: a witness's worth of
+    points is 5-10 s of square roots in Python, and the GPU suite asks for the same ones again and again.)"""
     p, b = CURVES[curve]
-    out = []
-    for i in range(n):
+    out = _POINTS.setdefault((curve, bytes(seed)), [])
+    for i in range(len(out), n):
         ctr = 0
         while True:
             h = hashlib.sha256(seed + i.to_bytes(4, "little") + ctr.to_bytes(4, "little")).digest()
@@ -86,7 +90,7 @@ def random_points(curve, n, seed=b"b3wit-test-generators"):
                 out.append((x, y if h[0] & 1 else p - y))
                 break
             ctr += 1
-    return out
+    return list(out[:n])
 
 
 def on_curve(P, curve):

@@ -53,7 +53,7 @@ def test_commitments_match_plain_integer_group_law(circuit, curve, first_slot, n
     assert bad == 0
     vals = _slot_values(bodies.copy())
     nwit = T.NWIT[circuit]
-    gens = E.random_points(curve, nwit - first_slot, seed=circuit.encode())
+    gens = E.random_points(curve, nwit - first_slot)
     assert all(E.on_curve(G, curve) for G in gens[:50])
     ctx = m.Context(circuit, 0)
     b = m.Batch(ctx, n)
@@ -108,7 +108,7 @@ def test_commit_flags_bodies_outside_its_domain_and_reports_rate():
     n = 512
     ctx = m.Context("compression", 0)
     recs = T.workloads().config2_compression(n)
-    gens = E.random_points("bn254_g1", T.NWIT["compression"], seed=b"rate")
+    gens = E.random_points("bn254_g1", T.NWIT["compression"])
     key = _key(m, ctx, "bn254_g1", 0, gens)
     dev = torch.device("cuda:0")
     d_recs = torch.from_numpy(recs.view(np.int32)).to(dev)
@@ -155,7 +155,7 @@ def test_chained_pass_with_the_commit_consumer():
     circuit, curve = "nova_vesta", "vesta"
     ctx = m.Context(circuit, 0)
     data = ((np.arange(8 * 1024, dtype=np.uint64) * 40503 + 11) % 253).astype(np.uint8)        # 8 chunks: 128 leaf + 24 parent steps
-    gens = E.random_points(curve, T.NWIT[circuit], seed=b"chain")
+    gens = E.random_points(curve, T.NWIT[circuit])
     key = _key(m, ctx, curve, 0, gens)
     h = ctypes.c_void_p()
     assert L.b3w_chain_create(ctx.handle, data.size, 0, 8, 48, 2, 1, ctypes.byref(h)) == 0      # batches of 48 steps: several ring turns
@@ -210,7 +210,7 @@ def test_chained_pass_check_then_commit():
     ctx = m.Context(circuit, 0)
     r1cs = m.R1cs(ctx)
     data = ((np.arange(5 * 1024 + 300, dtype=np.uint64) * 9973 + 5) % 251).astype(np.uint8)   # 6 chunks, incomplete tree: 85 leaf + 16 parent steps
-    key = m.CommitKey(ctx, curve, E.points_to_bytes(E.random_points(curve, T.NWIT[circuit], seed=b"cc")), window=12)
+    key = m.CommitKey(ctx, curve, E.points_to_bytes(E.random_points(curve, T.NWIT[circuit])), window=12)
     dev = torch.device("cuda:0")
 
     def run(with_check):
@@ -267,7 +267,7 @@ def test_commitments_from_records_equal_commitments_of_the_bodies(circuit, curve
         recs[13, 0] = 5000; recs[13, 1] = 3                   # n_blocks - 1 - block_count = 4 996
     ctx = m.Context(circuit, 0)
     first_slot = 3
-    gens = E.random_points(curve, ctx.witness_size - first_slot, seed=b"records" + circuit.encode())
+    gens = E.random_points(curve, ctx.witness_size - first_slot)
     key = m.CommitKey(ctx, curve, E.points_to_bytes(gens), first_slot, window)
     dev = torch.device("cuda:0")
     s = torch.cuda.current_stream().cuda_stream
@@ -345,7 +345,7 @@ def test_bodies_mode_takes_a_tabulated_inverse_only_when_the_slot_holds_it():
     flat = host.reshape(n, -1)
     vals = _slot_values(flat.copy())
     ctx = m.Context(circuit, 0)
-    gens = E.random_points(curve, ctx.witness_size - first_slot, seed=b"bodies-invtab")
+    gens = E.random_points(curve, ctx.witness_size - first_slot)
     key = m.CommitKey(ctx, curve, E.points_to_bytes(gens), first_slot, 16)
     dev = torch.device("cuda:0")
     d = torch.from_numpy(flat.copy()).to(dev)
@@ -377,7 +377,7 @@ def test_inverse_tables_only_for_the_curve_whose_order_is_the_circuits_prime():
     assert bad == 0
     vals = _slot_values(bodies.copy())
     ctx = m.Context(circuit, 0)
-    gens = E.random_points(curve, ctx.witness_size - first_slot, seed=b"mismatched-pair")
+    gens = E.random_points(curve, ctx.witness_size - first_slot)
     key = m.CommitKey(ctx, curve, E.points_to_bytes(gens), first_slot, 12)
     b = m.Batch(ctx, n)
     b.run(recs)
@@ -409,7 +409,7 @@ def test_chained_pass_commit_only_matches_the_commit_consumer():
     circuit, curve = "nova_vesta", "vesta"
     ctx = m.Context(circuit, 0)
     data = ((np.arange(8 * 1024, dtype=np.uint64) * 40503 + 11) % 253).astype(np.uint8)        # 8 chunks: 128 leaf + 24 parent steps
-    key = m.CommitKey(ctx, curve, E.points_to_bytes(E.random_points(curve, T.NWIT[circuit], seed=b"chain")))
+    key = m.CommitKey(ctx, curve, E.points_to_bytes(E.random_points(curve, T.NWIT[circuit])))
     dev = torch.device("cuda:0")
     a = torch.zeros((152, 64), dtype=torch.uint8, device=dev)
     b = torch.zeros((152, 64), dtype=torch.uint8, device=dev)
@@ -471,7 +471,7 @@ def test_commitments_from_records_across_a_chunk_border_and_argument_checks():
     n = 32768 + 900
     ctx = m.Context("compression", 0)
     recs = T.workloads().config2_compression(n, first=1)
-    key = m.CommitKey(ctx, "bn254_g1", E.points_to_bytes(E.random_points("bn254_g1", ctx.witness_size, seed=b"border")), 0, 12)
+    key = m.CommitKey(ctx, "bn254_g1", E.points_to_bytes(E.random_points("bn254_g1", ctx.witness_size)), 0, 12)
     dev = torch.device("cuda:0")
     s = torch.cuda.current_stream().cuda_stream
     d_recs = torch.from_numpy(recs.view(np.int32)).to(dev)
@@ -569,7 +569,7 @@ def test_folded_keys_commit_to_the_same_points(circuit, curve, first_slot, windo
         recs = recs.copy()
         recs[5, 14] = recs[5, 12]                             # a rejected step
     ctx = m.Context(circuit, 0)
-    gens = E.points_to_bytes(E.random_points(curve, ctx.witness_size - first_slot, seed=b"fold" + circuit.encode()))
+    gens = E.points_to_bytes(E.random_points(curve, ctx.witness_size - first_slot))
     plain = m.CommitKey(ctx, curve, gens, first_slot, window)
     folded = m.CommitKey(ctx, curve, gens, first_slot, window, fold=True)
     st = folded.fold_stats

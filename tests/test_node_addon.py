@@ -269,7 +269,7 @@ def test_js_fold_preimage_matches_blake3_and_python_driver(tmp_path):
         data = ((np.arange(nbytes, dtype=np.uint64) * 2654435761 + 7) % 251).astype(np.uint8)
         (tmp_path / (name + ".bin")).write_bytes(data.tobytes())
     import ec_ref as E
-    gens_bytes = E.points_to_bytes(E.random_points("vesta", T.NWIT["nova_vesta"], seed=b"jsfold"))
+    gens_bytes = E.points_to_bytes(E.random_points("vesta", T.NWIT["nova_vesta"]))
     (tmp_path / "gens.bin").write_bytes(gens_bytes)
     r = _node("""
       const builder = require('./hot-proofs-blake3-circom_amd/js/witness_calculator.js');
@@ -424,7 +424,7 @@ def test_js_batch_commit_matches_plain_integer_group_law(tmp_path):
     import numpy as np, ec_ref as E
     g = T.golden("compression")
     cases = [c for c in g["cases"] if "error" not in c and T.is_canonical_u32("compression", c["input"])][:2]
-    gens = E.random_points("bn254_g1", T.NWIT["compression"] - 17, seed=b"js")
+    gens = E.random_points("bn254_g1", T.NWIT["compression"] - 17)
     (tmp_path / "gens.bin").write_bytes(E.points_to_bytes(gens))
     import subprocess, sys
     fk = subprocess.run([sys.executable, os.path.join(T.ROOT, "tools", "fold_key.py"), "compression", "bn254_g1", str(tmp_path / "gens.bin"),
