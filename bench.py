@@ -323,7 +323,7 @@ def bench_chain(args, m, torch, dist, dev, world, rank, local_rank):
         curve = "vesta" if "vesta" in circuit else "bn254_g1"
         # (folded key: slots the circuit's linear constraints express through others drop out of the tables — the circomkit /
         # compression builds lose half their virtual slots, the O2 builds have no linear constraints left: DESIGN.md 8d)
-        key = m.CommitKey(ctx, curve, K.generators(curve, ctx.witness_size, seed=b"bench"), fold=True if circuit in m.BUILTIN_R1CS else None)
+        key = m.CommitKey(ctx, curve, K.generators(curve, ctx.witness_size, seed=b"bench"), window=args.commit_window, fold=True if circuit in m.BUILTIN_R1CS else None)
         d_pts = torch.zeros((n_max, 64), dtype=torch.uint8, device=dev)
         d_st = torch.zeros(n_max, dtype=torch.int32, device=dev)
         if args.consumer == "commit-only":
@@ -523,6 +523,8 @@ def main():
                          "(synthetic generators) computed from the step records beside the bodies (b3w_chain_commit_from_records: the "
                          "fold-shaped pass); commit-only = the same commitments, no bodies written; check+commit = both; "
                          "commit-bodies / check+commit-bodies = the commitment kernel that READS the bodies (for bodies the library did not make)")
+    ap.add_argument("--commit-window", type=int, default=0, choices=[0, 12, 16, 18],
+                    help="chain workload with a commit consumer: bits per table window of the commitment key (0 = the library's choice)")
     ap.add_argument("--commit-overlap", default="auto", choices=["auto", "serial", "free", "gated"],
                     help="chain workload, commit / check+commit: where the commitments from the records run (b3w_chain_commit_overlap): on the "
                          "caller's stream, free on the chain's commit stream, or gated to the batch's own witness kernel; auto = gated when a "

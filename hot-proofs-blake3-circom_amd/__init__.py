@@ -555,7 +555,7 @@ class R1cs:
 class CommitKey:
     """Commitment key on the device (b3w_commit_key_create): `generators` = bytes, one affine point (x, y: 32-byte
     little-endian each, standard form) per committed slot, i.e. witness_size - first_slot of them; curve "bn254_g1"
-    or "pallas" (the group whose scalar field is the --prime vesta circuit's field; "vesta" is accepted as its older name); window = 12 | 16 bits per table window (0: automatic, see include/b3wit.h)."""
+    or "pallas" (the group whose scalar field is the --prime vesta circuit's field; "vesta" is accepted as its older name); window = 12 | 16 | 18 bits per table window (0: automatic, see include/b3wit.h)."""
     CURVES = {"bn254_g1": 0, "pallas": 1, "vesta": 1}     # "vesta" = older name of the Pallas curve id (after the circuit's prime)
 
     def __init__(self, ctx, curve, generators, first_slot=0, window=0, fold=None):

@@ -1062,11 +1062,13 @@ extern "C" int b3w_launch_commit_setup(const uint32_t *d_gens, const uint32_t *d
 
 extern "C" int b3w_launch_commit_windows(const uint32_t *d_points, uint32_t nwin, uint32_t window, uint32_t *d_table, const B3wCurve *curve, hipStream_t stream) {
   if (!nwin) return 0;
-  if (window != B3W_COMMIT_WINDOW_SMALL && window != B3W_COMMIT_WINDOW_LARGE) return (int)hipErrorInvalidValue;
+  if (!B3W_COMMIT_WINDOW_OK(window)) return (int)hipErrorInvalidValue;
   const uint64_t total = (uint64_t)nwin * ((1u << window) / B3W_WINDOW_K);      // threads: B3W_WINDOW_K entries each
   const dim3 grid((uint32_t)((total + 63) / 64));
   const B3wCurve9 c9 = make_curve9(*curve);
-  if (window == B3W_COMMIT_WINDOW_LARGE)
+  if (window == B3W_COMMIT_WINDOW_XL)
+    hipLaunchKernelGGL(b3w_commit_window_kernel<B3W_COMMIT_WINDOW_XL>, grid, dim3(64), 0, stream, d_points, nwin, d_table, *curve, c9);
+  else if (window == B3W_COMMIT_WINDOW_LARGE)
     hipLaunchKernelGGL(b3w_commit_window_kernel<B3W_COMMIT_WINDOW_LARGE>, grid, dim3(64), 0, stream, d_points, nwin, d_table, *curve, c9);
   else
     hipLaunchKernelGGL(b3w_commit_window_kernel<B3W_COMMIT_WINDOW_SMALL>, grid, dim3(64), 0, stream, d_points, nwin, d_table, *curve, c9);
@@ -1081,14 +1083,14 @@ extern "C" int b3w_launch_commit(const uint8_t *d_bodies, uint32_t n, uint64_t p
                                  unsigned long long *d_adds, const B3wCurve *curve, hipStream_t stream) {
   if (!n) return 0;
   if (!d_images && !(d_invtab && d_invmeta && d_aux)) { d_invtab = nullptr; d_invmeta = nullptr; }      // (bodies mode needs all three)
-  if (window != B3W_COMMIT_WINDOW_SMALL && window != B3W_COMMIT_WINDOW_LARGE) return (int)hipErrorInvalidValue;
+  if (!B3W_COMMIT_WINDOW_OK(window)) return (int)hipErrorInvalidValue;
   const uint32_t bits_words = (nwin * window + 31) / 32 + 2;   // one packed witness in LDS (nova O1: 13.5 KB)
   if (bits_words * 4 > 32 * 1024) return (int)hipErrorInvalidValue;
   const B3wCurve9 c9 = make_curve9(*curve);
   // lanes per witness: 32 (two witnesses per wave) for small batches of the compression circuit, 64 for large ones and for
   // the longer nova witnesses (measured at both window widths).  Virtual slots: 53 k compression, 58 k nova O2, 108 k nova O1.
   static const int env_tpw = getenv("B3W_COMMIT_THREADS") ? atoi(getenv("B3W_COMMIT_THREADS")) : 0;
-  const int tpw = env_tpw ? env_tpw : ((uint64_t)nwin * window > 55200 || n >= 8192) ? 64 : 32;
+  const int tpw = window > B3W_COMMIT_WINDOW_LARGE ? 64 : env_tpw ? env_tpw : ((uint64_t)nwin * window > 55200 || n >= 8192) ? 64 : 32;
   bool vesta = true;                                           // the modulus with compile-time limbs?
   for (int i = 0; i < 9; ++i) vesta = vesta && c9.p[i] == B3wCurve9Vesta::P(i);
   vesta = vesta && c9.inv == B3wCurve9Vesta::INV() && tpw == 64;
@@ -1102,7 +1104,10 @@ extern "C" int b3w_launch_commit(const uint8_t *d_bodies, uint32_t n, uint64_t p
                        pitch, first_slot, nslots, d_slotdesc, d_images, img_row, reinterpret_cast<const uint2 *>(d_runs), nruns, region, d_table, nwin, \
                        d_sums, d_status, d_invtab, inv_nk, d_invmeta, d_aux, d_adds, cv);                                         \
   }
-  if (window == B3W_COMMIT_WINDOW_LARGE) {
+  if (window == B3W_COMMIT_WINDOW_XL) {                        // (the wide table: 64 lanes a witness only)
+    if (vesta) B3W_COMMIT_LAUNCH(64, 4, B3W_COMMIT_WINDOW_XL, B3wCurve9Vesta, c9v)
+    else B3W_COMMIT_LAUNCH(64, 4, B3W_COMMIT_WINDOW_XL, B3wCurve9, c9)
+  } else if (window == B3W_COMMIT_WINDOW_LARGE) {
     if (vesta) B3W_COMMIT_LAUNCH(64, 4, B3W_COMMIT_WINDOW_LARGE, B3wCurve9Vesta, c9v)
     else if (tpw == 64) B3W_COMMIT_LAUNCH(64, 4, B3W_COMMIT_WINDOW_LARGE, B3wCurve9, c9)
     else B3W_COMMIT_LAUNCH(32, 2, B3W_COMMIT_WINDOW_LARGE, B3wCurve9, c9)

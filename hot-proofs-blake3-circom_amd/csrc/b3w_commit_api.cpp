@@ -80,8 +80,8 @@ int32_t b3w_slot_widths(b3w_ctx *ctx, uint16_t *out_bits) {
 int32_t b3w_commit_key_create_folded(b3w_ctx *ctx, int32_t curve, uint32_t first_slot, const uint8_t *host_generators,
                                      const uint8_t *folded /* per committed slot, or null */, uint32_t window_bits, b3w_commit_key **out) {
   if (!ctx || !out || !host_generators || (curve != B3W_CURVE_BN254_G1 && curve != B3W_CURVE_VESTA) || first_slot >= ctx->desc.nwit ||
-      (window_bits != 0 && window_bits != B3W_COMMIT_WINDOW_SMALL && window_bits != B3W_COMMIT_WINDOW_LARGE)) {
-    if (ctx) ctx->last_error = "commit key: curve 0/1, first_slot < witness_size, window_bits 0 (auto), 12 or 16";
+      (window_bits != 0 && !B3W_COMMIT_WINDOW_OK(window_bits))) {
+    if (ctx) ctx->last_error = "commit key: curve 0/1, first_slot < witness_size, window_bits 0 (auto), 12, 16 or 18";
     return B3W_E_BAD_ARGUMENT;
   }
   *out = nullptr;
@@ -102,19 +102,21 @@ int32_t b3w_commit_key_create_folded(b3w_ctx *ctx, int32_t curve, uint32_t first
     first_v[i] = (uint32_t)nv;
     nv += nbits[i];
   }
-  // window width: the caller's, else B3W_COMMIT_WINDOW, else 16 when its table takes at most a quarter of the free HBM
+  // window width: the caller's, else B3W_COMMIT_WINDOW, else the widest of 18, 16, 12 whose table takes at most a quarter of the free HBM
   DeviceGuard guard(ctx->device);
   hipError_t e = guard.err;
   uint32_t window = window_bits;
   if (!window && getenv("B3W_COMMIT_WINDOW")) {
     window = (uint32_t)atoi(getenv("B3W_COMMIT_WINDOW"));
-    if (window != B3W_COMMIT_WINDOW_SMALL && window != B3W_COMMIT_WINDOW_LARGE) window = 0;
+    if (!B3W_COMMIT_WINDOW_OK(window)) window = 0;
   }
   if (!window) {
     size_t free_b = 0, total_b = 0;
-    const uint64_t large = (nv / B3W_COMMIT_WINDOW_LARGE + 1) * B3W_COMMIT_ENTRIES(B3W_COMMIT_WINDOW_LARGE) * 64;
-    window = e == hipSuccess && hipMemGetInfo(&free_b, &total_b) == hipSuccess && large <= free_b / 4 ? B3W_COMMIT_WINDOW_LARGE
-                                                                                                      : B3W_COMMIT_WINDOW_SMALL;
+    const bool known = e == hipSuccess && hipMemGetInfo(&free_b, &total_b) == hipSuccess;
+    auto table_bytes = [&](uint32_t w) { return (nv / w + 1) * (uint64_t)B3W_COMMIT_ENTRIES(w) * 64; };
+    window = known && table_bytes(B3W_COMMIT_WINDOW_XL) <= free_b / 4      ? B3W_COMMIT_WINDOW_XL
+             : known && table_bytes(B3W_COMMIT_WINDOW_LARGE) <= free_b / 4 ? B3W_COMMIT_WINDOW_LARGE
+                                                                           : B3W_COMMIT_WINDOW_SMALL;
   }
   // windows of `window` virtual slots; the pad bits of the last window are never set
   const uint32_t V0 = (uint32_t)nv;

@@ -57,9 +57,13 @@ extern "C" int b3w_place_store_rate(uint8_t *buf, uint64_t pitch, uint32_t n, ui
 
 // b3w_commit.hip: Pedersen commitments of witness bodies (on-device consumer).
 // Window width W (virtual slots per window, 2^W - 1 tabulated subset sums each) is a property of the key:
-//   12: 1.2 GB table, 0.03 s set-up;   16: 14 GB table, 0.3 s set-up, a quarter fewer additions per witness (+15-18 %)
+//   12: 1.2 GB table, 0.03 s set-up;   16: 14 GB table, 0.3 s set-up, a quarter fewer additions per witness (+15-18 %);   18: 51 GB, 1 s, +7.6 % more
 #define B3W_COMMIT_WINDOW_SMALL 12
 #define B3W_COMMIT_WINDOW_LARGE 16
+#define B3W_COMMIT_WINDOW_XL 18          // (r05) 4 x the table of 16 (a folded nova key: 25 GB, an unfolded one 51) for a ninth fewer additions: +7.6 % —
+                                         // HBM for VALU work, the card has 288 GB.  (20 bits, 16 x the table: SLOWER than 16, 7.01 against 7.17 M steps/s —
+                                         // the gathers over 90-180 GB become the limit; not built.  profiles/r05/commit_windows_rates.log)
+#define B3W_COMMIT_WINDOW_OK(w) ((w) == B3W_COMMIT_WINDOW_SMALL || (w) == B3W_COMMIT_WINDOW_LARGE || (w) == B3W_COMMIT_WINDOW_XL)
 #define B3W_COMMIT_ENTRIES(W) ((1u << (W)) - 1u)
 #define B3W_COMMIT_SUM_WORDS 36        // per witness between the commit and the normalise kernel: X, Y, ZZ, ZZZ in nine 29-bit limbs each
 // Field of the curve's coordinates:

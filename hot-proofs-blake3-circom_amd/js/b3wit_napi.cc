@@ -496,7 +496,7 @@ napi_value ChainFold(napi_env env, napi_callback_info info) {
 }
 
 // commitKey(handle, curve: 0 = BN254 G1 | 1 = Vesta, firstSlot, generators: Uint8Array((witnessSize - firstSlot) * 64)
-//           [, windowBits: 0 (automatic) | 12 | 16[, folded: Uint8Array(witnessSize - firstSlot)]])
+//           [, windowBits: 0 (automatic) | 12 | 16 | 18[, folded: Uint8Array(witnessSize - firstSlot)]])
 // installs the commitment key of this handle (tables on the device).  folded: include/b3wit.h "FOLDED keys" — the generators are
 // then the folded ones and folded[k] says what became of slot k (0 kept, 1 folded away, 0x80 | i only bit i of the word);
 // tools/fold_key.py writes both files for a circuit and a key.

@@ -212,7 +212,7 @@ class WitnessCalculator {
 
   // ---- extension: commitment key for batch.commit().  curve: "bn254_g1" | "pallas" (the group over the --prime vesta circuit's scalar field); generators: Uint8Array with one
   // affine point per committed slot (x then y, 32-byte little-endian each), slots firstSlot .. witnessSize - 1;
-  // windowBits: 12 | 16 (table size against speed, see include/b3wit.h), default automatic.
+  // windowBits: 12 | 16 | 18 (table size against speed, see include/b3wit.h), default automatic.
   // folded (optional Uint8Array, one byte per committed slot): `generators` are FOLDED ones (include/b3wit.h "FOLDED keys": slots
   // the circuit's constraints express through others are folded into those slots' generators — same points, fewer additions);
   // tools/fold_key.py derives both arrays from a circuit and a key.

@@ -271,8 +271,10 @@ typedef struct b3w_commit_key b3w_commit_key;
 int32_t b3w_commit_key_create(b3w_ctx *ctx, int32_t curve, uint32_t first_slot, const uint8_t *host_generators, b3w_commit_key **out);
 /* The same with the table's window width chosen by the caller: every `window_bits` consecutive bits of the witness share one
  * table of 2^window_bits - 1 precomputed subset sums.  12: 1.2-1.3 GB of HBM, 0.03 s set-up;  16: 14-15 GB, 0.3 s, a
- * quarter fewer point additions per witness (+15-18 % throughput).  0 = automatic (b3w_commit_key_create): the
- * environment's B3W_COMMIT_WINDOW, else 16 when that table takes at most a quarter of the free device memory. */
+ * quarter fewer point additions per witness (+15-18 % throughput);  18 (r05): 51 GB for an unfolded nova key, 25 for a folded
+ * one, 1 s, another ninth fewer additions (+7.6 %) — HBM spent for VALU work on a 288 GB card.  0 = automatic
+ * (b3w_commit_key_create): the environment's B3W_COMMIT_WINDOW, else the widest of 18, 16, 12 whose table takes at most a
+ * quarter of the free device memory. */
 int32_t b3w_commit_key_create_ex(b3w_ctx *ctx, int32_t curve, uint32_t first_slot, const uint8_t *host_generators, uint32_t window_bits,
                                  b3w_commit_key **out);
 /* FOLDED keys.  A witness satisfies its circuit's LINEAR constraints, so a slot that is a linear combination of others — every
@@ -290,7 +292,7 @@ int32_t b3w_commit_key_create_folded(b3w_ctx *ctx, int32_t curve, uint32_t first
                                      const uint8_t *folded /* witness_size - first_slot flags, or NULL */, uint32_t window_bits,
                                      b3w_commit_key **out);
 int32_t b3w_slot_widths(b3w_ctx *ctx, uint16_t *out_bits /* witness_size */);
-uint32_t b3w_commit_key_window(const b3w_commit_key *key);     /* 12 or 16 */
+uint32_t b3w_commit_key_window(const b3w_commit_key *key);     /* 12, 16 or 18 */
 /* Statistics for harnesses: while counting is on (on != 0 resets and starts, 0 stops; both wait for the device), every commit
  * launch with this key adds its number of mixed point additions (one per non-zero window and per tabulated inverse: 8 field
  * multiplications + 2 squarings each — the work the kernel's VALU roofline is priced in) to a device counter.

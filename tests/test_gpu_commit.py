@@ -21,7 +21,7 @@ def _slot_values(bodies):
 
 
 def _key(m, ctx, curve, first_slot, gens, window=0):
-    """window: 12 or 16 bits per table window; 0 = the library's choice (b3w_commit_key_create)"""
+    """window: 12, 16 or 18 bits per table window; 0 = the library's choice (b3w_commit_key_create)"""
     key = ctypes.c_void_p()
     buf = E.points_to_bytes(gens)
     if window:
@@ -30,7 +30,7 @@ def _key(m, ctx, curve, first_slot, gens, window=0):
         rc = m.lib().b3w_commit_key_create(ctx.handle, E.CURVE_ID[curve], first_slot, buf, ctypes.byref(key))
     assert rc == 0, ctx.last_error()
     assert m.lib().b3w_commit_key_window(key) == (window or m.lib().b3w_commit_key_window(key)) and \
-        m.lib().b3w_commit_key_window(key) in (12, 16)
+        m.lib().b3w_commit_key_window(key) in (12, 16, 18)
     return key
 
 
@@ -44,7 +44,7 @@ def _commit(m, batch, key, n):
 
 @pytest.mark.parametrize("circuit,curve,first_slot,n,window", [
     ("compression", "bn254_g1", 0, 4, 12), ("compression", "bn254_g1", 17, 2, 16), ("nova_vesta", "vesta", 16, 3, 12),
-    ("nova_vesta", "vesta", 0, 2, 16), ("nova_bn254", "bn254_g1", 0, 2, 0)])
+    ("nova_vesta", "vesta", 0, 2, 16), ("nova_bn254", "bn254_g1", 0, 2, 0), ("nova_vesta", "vesta", 0, 2, 18), ("compression", "bn254_g1", 5, 2, 18)])
 def test_commitments_match_plain_integer_group_law(circuit, curve, first_slot, n, window):
     m = T.pkg()
     W = T.workloads()
@@ -82,7 +82,7 @@ def test_related_generators_hit_the_exceptional_cases():
     ctx = m.Context(circuit, 0)
     b = m.Batch(ctx, n)
     b.run(recs)
-    for window in (12, 16):
+    for window in (12, 16, 18):
         # (a) one point everywhere: C = (sum of all slot values) * G
         key = _key(m, ctx, curve, 0, [base[0]] * nwit, window)
         got, st = _commit(m, b, key, n)
