@@ -100,6 +100,7 @@ struct b3w_chain {
   int32_t *d_co_scratch = nullptr;                   // the side-stream commit kernel's status words: the witness kernel of the same records is
                                                      // the one that reports (d_status), this is never read
   uint8_t *co_points = nullptr, *co_own = nullptr;   // (co_own: the chain's own buffer when the caller passed none)
+  uint32_t *d_co_sums = nullptr;                     // the steps' projective sums where the points are made once per run call, not per batch (chain_run_steps)
   const b3w_r1cs *r1cs = nullptr;                    // constraint check of every batch while it sits in the ring
   uint32_t *d_viol = nullptr;                        // ... violated constraints per step
   // sharded passes: exchange buffers, allocated on the first exchange for that communicator's rank count and kept
@@ -161,6 +162,14 @@ int32_t chain_commit_mode(const b3w_chain *c, bool has_consumer) {
 int32_t chain_run_steps(b3w_chain *c, uint64_t first_row, uint64_t count, b3w_batch_consumer consumer, void *user, void *stream) {
   const uint64_t body = 32ull * c->ctx->desc.nwit;
   const int32_t mode = chain_commit_mode(c, consumer != nullptr);
+  // Commitments ONLY (no bodies, no consumer call: nobody is promised a batch's points before the run call returns): the batches leave
+  // their projective sums and ONE launch behind the last batch makes the points.  A batch's own normalisation is a chain of 380
+  // dependent multiplications on one wave per CU — 130 us with nothing else running, 6 % of such a pass: 7.63 -> 8.04 M steps/s
+  // (profiles/r05/commit_defer_normalize.log).  Beside bodies the per-batch launch hides behind the witness kernels and putting it
+  // off gains nothing (FREE: 4.69 -> 4.62), and under SERIAL / GATED the batch's consumer may read its points: those keep theirs.
+  static const bool defer_env = !(getenv("B3W_COMMIT_DEFER_NORMALIZE") && !strcmp(getenv("B3W_COMMIT_DEFER_NORMALIZE"), "0"));
+  const bool defer = defer_env && c->co_key && c->d_co_sums && mode == B3W_COMMIT_OVERLAP_SERIAL && !c->co_bodies;
+  uint32_t *sums = defer ? c->d_co_sums : nullptr;
   for (uint64_t done = 0; done < count;) {
     const uint32_t k = (uint32_t)std::min<uint64_t>(c->batch_steps, count - done);
     uint8_t *slot = static_cast<uint8_t *>(c->bodies[c->nbatch % c->ring]);
@@ -172,13 +181,13 @@ int32_t chain_run_steps(b3w_chain *c, uint64_t first_row, uint64_t count, b3w_ba
       hipError_t e = hipEventRecord(c->ev_co_in, (hipStream_t)stream);
       if (e == hipSuccess) e = hipStreamWaitEvent(c->co_stream, c->ev_co_in, 0);
       if (e != hipSuccess) return hip_fail(c->ctx, e, "commit stream");
-      const int32_t rc = b3w_commit_records_device(c->ctx, c->co_key, c->d_recs + r0 * 32, k, c->co_points + r0 * 64, nullptr, c->d_co_scratch + r0, c->co_stream);
+      const int32_t rc = b3w_int_commit_records(c->ctx, c->co_key, c->d_recs + r0 * 32, k, c->co_points + r0 * 64, nullptr, c->d_co_scratch + r0, c->co_stream, nullptr);
       if (rc) return rc;
       if (mode == B3W_COMMIT_OVERLAP_GATED && (e = hipEventRecord(c->ev_co_out, c->co_stream)) != hipSuccess) return hip_fail(c->ctx, e, "commit stream");
     } else if (c->co_key) {
       Range r("b3w:commit from records");
-      const int32_t rc = b3w_commit_records_device(c->ctx, c->co_key, c->d_recs + r0 * 32, k, c->co_points + r0 * 64, c->d_pub + r0 * 15,
-                                                   c->d_status + r0, stream);
+      const int32_t rc = b3w_int_commit_records(c->ctx, c->co_key, c->d_recs + r0 * 32, k, c->co_points + r0 * 64, c->d_pub + r0 * 15,
+                                                c->d_status + r0, stream, sums ? sums + r0 * B3W_COMMIT_SUM_WORDS : nullptr);
       if (rc) return rc;
       if (!c->co_bodies) {
         c->nbatch++;
@@ -201,6 +210,11 @@ int32_t chain_run_steps(b3w_chain *c, uint64_t first_row, uint64_t count, b3w_ba
     if (consumer) { Range r("b3w:consumer"); consumer(user, slot, body, r0, k, stream); }
     c->nbatch++;
     done += k;
+  }
+  if (defer && count) {                                        // the points of this call's steps, behind the last batch's sums on the stream that made them
+    Range r("b3w:commit normalise");
+    const int32_t rc = b3w_int_commit_normalize(c->ctx, c->co_key, sums + first_row * B3W_COMMIT_SUM_WORDS, count, c->co_points + first_row * 64, stream);
+    if (rc) return rc;
   }
   if (mode == B3W_COMMIT_OVERLAP_FREE) {                       // `stream` has drained = the commitments are there too
     hipError_t e = hipEventRecord(c->ev_co_out, c->co_stream);
@@ -278,6 +292,10 @@ int32_t b3w_chain_commit_only(b3w_chain *c, const b3w_commit_key *key, uint8_t *
       HIP_TRY(c->ctx, hipMalloc((void **)&c->co_own, (size_t)(c->n_leaf + c->n_par + 1) * 64));
     }
     d_points = c->co_own;
+  }
+  if (key && !c->d_co_sums) {                          // (144 bytes a step: the sums of chain_run_steps' deferred normalisation; without it the batches normalise their own)
+    ON_DEVICE(c->ctx);
+    if (hipMalloc((void **)&c->d_co_sums, (size_t)(c->n_leaf + c->n_par + 1) * B3W_COMMIT_SUM_WORDS * 4) != hipSuccess) { (void)hipGetLastError(); c->d_co_sums = nullptr; }
   }
   c->co_key = key;
   c->co_points = key ? d_points : nullptr;
@@ -398,6 +416,7 @@ void b3w_chain_destroy(b3w_chain *c) {
   if (c->d_levels) (void)hipFree(c->d_levels);
   if (c->d_root) (void)hipFree(c->d_root);
   if (c->co_own) (void)hipFree(c->co_own);
+  if (c->d_co_sums) (void)hipFree(c->d_co_sums);
   if (c->d_co_scratch) (void)hipFree(c->d_co_scratch);
   chain_drop_commit_stream(c);
   if (c->d_viol) (void)hipFree(c->d_viol);

@@ -1009,6 +1009,64 @@ __global__ __launch_bounds__(64) void b3w_commit_normalize_kernel(const uint32_t
   store_fp(o + 8, y);
 }
 
+// ---- normalise MANY: a thread takes B3W_NORMALIZE_K consecutive witnesses and inverts the product of their ZZ * ZZZ once
+// (Montgomery's trick, as the window kernel above): 95 + 14 multiplications a witness instead of 390, and — the point — launched once
+// for all the witnesses of a pass it fills the machine, where the per-batch launch was a chain of dependent multiplications on one
+// wave per CU.  The sums are read twice (144 bytes a witness).
+#define B3W_NORMALIZE_K 4
+template <class CV>
+__global__ __launch_bounds__(64) void b3w_commit_normalize_many_kernel(const uint32_t *__restrict__ sums, uint64_t n, uint8_t *__restrict__ out,
+                                                                       B3wCurve C, CV C9) {
+  constexpr int K = B3W_NORMALIZE_K;
+  const uint64_t w0 = ((uint64_t)blockIdx.x * 64 + threadIdx.x) * K;
+  if (w0 >= n) return;
+  auto coord = [&](uint64_t w, int c) {
+    F9 v;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) v.l[i] = sums[w * B3W_COMMIT_SUM_WORDS + c * 9 + i];
+    return v;
+  };
+  auto is_zero = [](const F9 &v) { uint32_t z = 0;
+#pragma unroll
+    for (int i = 0; i < 9; ++i) z |= v.l[i];
+    return z == 0; };
+  F9 pre[K];                                                 // prefix products of the finite witnesses' ZZ * ZZZ (infinity: the product so far)
+#pragma unroll
+  for (int e = 0; e < K; ++e) {
+    const uint64_t w = w0 + e;
+    F9 a = one29(C9);
+    if (w < n) {
+      const F9 zz = coord(w, 2);
+      if (!is_zero(zz)) a = mul29(zz, coord(w, 3), C9);
+    }
+    pre[e] = e == 0 ? a : mul29(pre[e - 1], a, C9);
+  }
+  F9 inv = inv29(pre[K - 1], C.pm2, C9);                      // 1 / (A_0 ... A_{K-1})
+  F9 unit;
+#pragma unroll
+  for (int i = 0; i < 9; ++i) unit.l[i] = i == 0 ? 1u : 0u;
+#pragma unroll
+  for (int e = K - 1; e >= 0; --e) {
+    const uint64_t w = w0 + e;
+    if (w >= n) continue;                                      // (its A was one: nothing to take out of `inv`)
+    const F9 zz = coord(w, 2);
+    Fp x = fp_zero(), y = fp_zero();                           // infinity -> (0, 0)
+    if (!is_zero(zz)) {
+      const F9 zzz = coord(w, 3);
+      const F9 ia = e > 0 ? mul29(inv, pre[e - 1], C9) : inv;  // 1 / A_e
+      inv = mul29(inv, mul29(zz, zzz, C9), C9);
+      const F9 xs = mul29(mul29(coord(w, 0), mul29(ia, zzz, C9), C9), unit, C9);    // 1 / ZZ = ZZZ / A; out of Montgomery form: < 2p
+      const F9 ys = mul29(mul29(coord(w, 1), mul29(ia, zz, C9), C9), unit, C9);     // 1 / ZZZ = ZZ / A
+      uint32_t hi;
+      x = from29(xs, hi); x = fp_reduce_once(x, hi, C);
+      y = from29(ys, hi); y = fp_reduce_once(y, hi, C);
+    }
+    uint32_t *o = reinterpret_cast<uint32_t *>(out + w * 64);
+    store_fp(o, x);
+    store_fp(o + 8, y);
+  }
+}
+
 // host: the 29-bit constants of a curve
 void u288_split29(const uint32_t w[9], uint32_t out[9]) {
   for (int k = 0; k < 9; ++k) {
@@ -1117,8 +1175,17 @@ extern "C" int b3w_launch_commit(const uint8_t *d_bodies, uint32_t n, uint64_t p
     else B3W_COMMIT_LAUNCH(32, 2, B3W_COMMIT_WINDOW_SMALL, B3wCurve9, c9)
   }
 #undef B3W_COMMIT_LAUNCH
+  if (!d_out) return (int)hipGetLastError();                  // (the sums are normalised later: b3w_launch_commit_normalize)
   if (vesta) hipLaunchKernelGGL(b3w_commit_normalize_kernel<B3wCurve9Vesta>, dim3((n + 63) / 64), dim3(64), 0, stream, d_sums, n, d_out, *curve, c9v);
   else hipLaunchKernelGGL(b3w_commit_normalize_kernel<B3wCurve9>, dim3((n + 63) / 64), dim3(64), 0, stream, d_sums, n, d_out, *curve, c9);
+  return (int)hipGetLastError();
+}
+
+extern "C" int b3w_launch_commit_normalize(const uint32_t *d_sums, uint64_t n, uint8_t *d_out, const B3wCurve *curve, hipStream_t stream) {
+  if (!n) return 0;
+  const B3wCurve9 c9 = make_curve9(*curve);
+  const uint64_t threads = (n + B3W_NORMALIZE_K - 1) / B3W_NORMALIZE_K;
+  hipLaunchKernelGGL(b3w_commit_normalize_many_kernel<B3wCurve9>, dim3((uint32_t)((threads + 63) / 64)), dim3(64), 0, stream, d_sums, n, d_out, *curve, c9);
   return (int)hipGetLastError();
 }
 

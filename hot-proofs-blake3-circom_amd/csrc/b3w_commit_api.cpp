@@ -297,6 +297,20 @@ int32_t b3w_batch_commit_device(b3w_ctx *ctx, const b3w_commit_key *key, const u
 
 int32_t b3w_commit_records_device(b3w_ctx *ctx, const b3w_commit_key *key, const uint32_t *d_records, uint32_t n, uint8_t *d_points,
                                   uint32_t *d_public, int32_t *d_status, void *stream) {
+  return b3w_int_commit_records(ctx, key, d_records, n, d_points, d_public, d_status, stream, nullptr);
+}
+
+}  // extern "C"
+
+int32_t b3w_int_commit_normalize(b3w_ctx *ctx, const b3w_commit_key *key, const uint32_t *d_sums, uint64_t n, uint8_t *d_points, void *stream) {
+  if (!ctx || !key || key->ctx != ctx || !d_sums || !d_points) return B3W_E_BAD_ARGUMENT;
+  ON_DEVICE(ctx);
+  const int rc = b3w_launch_commit_normalize(d_sums, n, d_points, &key->curve, (hipStream_t)stream);
+  return rc ? hip_fail(ctx, (hipError_t)rc, "commit normalise launch") : B3W_OK;
+}
+
+int32_t b3w_int_commit_records(b3w_ctx *ctx, const b3w_commit_key *key, const uint32_t *d_records, uint32_t n, uint8_t *d_points, uint32_t *d_public,
+                               int32_t *d_status, void *stream, uint32_t *d_sums_out) {
   if (!ctx || !key || key->ctx != ctx || !d_records || !d_points || !d_status) return B3W_E_BAD_ARGUMENT;
   if (n == 0) return B3W_OK;
   if ((reinterpret_cast<uintptr_t>(d_points) & 15) || (reinterpret_cast<uintptr_t>(d_records) & 3)) {
@@ -330,13 +344,16 @@ int32_t b3w_commit_records_device(b3w_ctx *ctx, const b3w_commit_key *key, const
                                d_public ? d_public + (uint64_t)c0 * pw : nullptr, d_status + c0, ctx->d_aux, (hipStream_t)stream);
     if (lrc == 0)
       lrc = b3w_launch_commit(nullptr, cn, 0, key->first_slot, key->nslots, key->d_slotdesc, k->d_images, cap, key->d_runs, key->nruns,
-                              key->d_table, key->nwin, key->window, k->d_sums, d_points + (uint64_t)c0 * 64, nullptr, key->d_invtab, key->inv_nk,
+                              key->d_table, key->nwin, key->window, d_sums_out ? d_sums_out + (uint64_t)c0 * B3W_COMMIT_SUM_WORDS : k->d_sums,
+                              d_sums_out ? nullptr : d_points + (uint64_t)c0 * 64, nullptr, key->d_invtab, key->inv_nk,
                               nullptr, nullptr, key->counting ? key->d_counts : nullptr, &key->curve, (hipStream_t)stream);
     if (lrc == 0 && key->counting) k->host_witnesses += cn;
     if (lrc) return hip_fail(ctx, (hipError_t)lrc, "commit-from-records launch");
   }
   return B3W_OK;
 }
+
+extern "C" {
 
 int32_t b3w_commit_records(b3w_ctx *ctx, const b3w_commit_key *key, const uint32_t *host_records, uint32_t n, uint8_t *host_points,
                            uint32_t *host_public, int32_t *host_status) {

@@ -89,6 +89,11 @@ extern "C" int b3w_launch_commit(const uint8_t *d_bodies, uint32_t n, uint64_t p
                                  const uint32_t *d_aux /* ... and the context's scalars: [0, 8) the prime, [16 + 8 k, + 8) 1 / k */,
                                  unsigned long long *d_adds /* or null: += the mixed additions of this launch (statistics) */,
                                  const B3wCurve *curve, hipStream_t stream);
+// (d_out = null: the sums stay sums — X, Y, ZZ, ZZZ in d_sums, B3W_COMMIT_SUM_WORDS per witness — and are made points later, many at
+// once: a normalisation is one field inversion, 380 DEPENDENT multiplications, and the launch that does a batch's worth of them right
+// behind its commit kernel is one wave per CU busy for 130 us with the machine idle around it — 6 % of a commit-only pass.
+// b3w_launch_commit_normalize: four witnesses a thread share one inversion (Montgomery's trick), any number of witnesses at once.)
+extern "C" int b3w_launch_commit_normalize(const uint32_t *d_sums, uint64_t n, uint8_t *d_out, const B3wCurve *curve, hipStream_t stream);
 // O2 nova circuits, records mode: invtab[j * nk + mag - 1] = (1 / mag) * G of the slot holding IsZero gadget j's inverse
 // (d_inverses: 8 words per magnitude, standard form — the witness kernels' table; d_inv_slot[j] = committed slot index or ~0)
 #define B3W_NOVA_ISZERO 67
