@@ -602,3 +602,37 @@ def test_folded_keys_commit_to_the_same_points(circuit, curve, first_slot, windo
     assert (out["folded"][2][ok] == 0).all() and np.array_equal(out["folded"][3], out["plain"][3])
     assert int(out["folded"][1][~ok].astype(np.int64).sum()) == 0               # rejected: the point at infinity
     plain.close(); folded.close(); ctx.close()
+
+
+def test_commit_only_pass_makes_its_points_at_the_end_of_a_run_call():
+    """r05: a commit-only chained pass leaves its batches' projective sums and makes the points by ONE launch per run call (four
+    witnesses share an inversion: b3w_commit_normalize_many_kernel).  Step counts that are no multiples of four, batches that are no
+    multiples of anything, and a key that commits nothing (every sum is the point at infinity -> (0, 0)): the points equal those of
+    b3w_commit_records on the pass's own records, which normalises witness by witness."""
+    import torch
+    m = T.pkg()
+    circuit, curve = "nova_vesta", "vesta"
+    ctx = m.Context(circuit, 0)
+    dev = torch.device("cuda:0")
+    data = ((np.arange(2 * 1024 + 100, dtype=np.uint64) * 2654435761 + 5) % 251).astype(np.uint8)      # 16 + 16 + 2 leaf steps
+    gens = E.points_to_bytes(E.random_points(curve, T.NWIT[circuit]))
+    for key_bytes, what in ((gens, "real"), (bytes(len(gens)), "nothing committed")):
+        key = m.CommitKey(ctx, curve, key_bytes, window=12)
+        probe = m.chain.fold_witnesses(ctx, data, batch_steps=7, ring=2)
+        rows = probe["n_leaf_steps"] + probe["n_parent_steps"]
+        assert probe["n_leaf_steps"] == 34 and (probe["n_leaf_steps"] % 4 != 0 or probe["n_parent_steps"] % 4 != 0)
+        pts = torch.full((rows, 64), 0xAB, dtype=torch.uint8, device=dev)
+        out = m.chain.fold_witnesses(ctx, data, batch_steps=7, ring=2, commit_only=(key, pts))
+        torch.cuda.synchronize()
+        assert int(out["status"].abs().sum().item()) == 0
+        recs = out["records"].cpu().numpy().astype(np.uint32)
+        want, _, st = key.commit_records(recs)
+        assert int(np.abs(st).sum()) == 0
+        got = pts.cpu().numpy()
+        assert want.shape == got.shape and np.array_equal(got, want), what
+        if what != "real":
+            assert int(got.max()) == 0
+        else:
+            assert int(got.max(axis=1).min()) > 0
+        key.close()
+    ctx.close()
