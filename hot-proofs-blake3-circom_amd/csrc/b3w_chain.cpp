@@ -178,10 +178,21 @@ int32_t chain_run_steps(b3w_chain *c, uint64_t first_row, uint64_t count, b3w_ba
       // beside the bodies: on the commit stream, behind everything `stream` holds so far (the records of this batch are planned; GATED:
       // the check of the previous batch is over)
       Range r("b3w:commit from records (side stream)");
-      hipError_t e = hipEventRecord(c->ev_co_in, (hipStream_t)stream);
-      if (e == hipSuccess) e = hipStreamWaitEvent(c->co_stream, c->ev_co_in, 0);
-      if (e != hipSuccess) return hip_fail(c->ctx, e, "commit stream");
-      const int32_t rc = b3w_int_commit_records(c->ctx, c->co_key, c->d_recs + r0 * 32, k, c->co_points + r0 * 64, nullptr, c->d_co_scratch + r0, c->co_stream, nullptr);
+      // GATED: the TRACE images (115 MB of stores for 16 384 nova steps) are written on `stream`, IN FRONT of the witness kernel — 40 us
+      // there, 640 us beside it, and the commit stream is the longer of the two (timeline_ranks1_8mib_check_commit.txt) —; the commit
+      // kernel waits for them on its own stream (the event stands for ev_co_in: behind everything `stream` held, the last batch's
+      // check included, which is also why the key's one image buffer is free again).  FREE keeps both on the commit stream: its
+      // witness kernels run ahead of the commitments, and the image buffer of the batch before would still be read.
+      static const bool split_env = !(getenv("B3W_COMMIT_SPLIT_TRACE") && !strcmp(getenv("B3W_COMMIT_SPLIT_TRACE"), "0"));
+      const bool split = split_env && mode == B3W_COMMIT_OVERLAP_GATED && k <= 32768u;
+      hipError_t e = hipSuccess;
+      if (!split) {
+        e = hipEventRecord(c->ev_co_in, (hipStream_t)stream);
+        if (e == hipSuccess) e = hipStreamWaitEvent(c->co_stream, c->ev_co_in, 0);
+        if (e != hipSuccess) return hip_fail(c->ctx, e, "commit stream");
+      }
+      const int32_t rc = b3w_int_commit_records(c->ctx, c->co_key, c->d_recs + r0 * 32, k, c->co_points + r0 * 64, nullptr, c->d_co_scratch + r0, c->co_stream, nullptr,
+                                                split ? stream : nullptr, split ? c->ev_co_in : nullptr);
       if (rc) return rc;
       if (mode == B3W_COMMIT_OVERLAP_GATED && (e = hipEventRecord(c->ev_co_out, c->co_stream)) != hipSuccess) return hip_fail(c->ctx, e, "commit stream");
     } else if (c->co_key) {

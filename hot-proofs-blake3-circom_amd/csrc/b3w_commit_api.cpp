@@ -297,7 +297,7 @@ int32_t b3w_batch_commit_device(b3w_ctx *ctx, const b3w_commit_key *key, const u
 
 int32_t b3w_commit_records_device(b3w_ctx *ctx, const b3w_commit_key *key, const uint32_t *d_records, uint32_t n, uint8_t *d_points,
                                   uint32_t *d_public, int32_t *d_status, void *stream) {
-  return b3w_int_commit_records(ctx, key, d_records, n, d_points, d_public, d_status, stream, nullptr);
+  return b3w_int_commit_records(ctx, key, d_records, n, d_points, d_public, d_status, stream, nullptr, nullptr, nullptr);
 }
 
 }  // extern "C"
@@ -310,8 +310,10 @@ int32_t b3w_int_commit_normalize(b3w_ctx *ctx, const b3w_commit_key *key, const 
 }
 
 int32_t b3w_int_commit_records(b3w_ctx *ctx, const b3w_commit_key *key, const uint32_t *d_records, uint32_t n, uint8_t *d_points, uint32_t *d_public,
-                               int32_t *d_status, void *stream, uint32_t *d_sums_out) {
+                               int32_t *d_status, void *stream, uint32_t *d_sums_out, void *trace_stream, hipEvent_t trace_done) {
   if (!ctx || !key || key->ctx != ctx || !d_records || !d_points || !d_status) return B3W_E_BAD_ARGUMENT;
+  const bool split = trace_stream && trace_done && trace_stream != stream;
+  if (split && n > 32768u) return B3W_E_BAD_ARGUMENT;                         // (one chunk: the next chunk's TRACE would have to wait for this one's commit kernel)
   if (n == 0) return B3W_OK;
   if ((reinterpret_cast<uintptr_t>(d_points) & 15) || (reinterpret_cast<uintptr_t>(d_records) & 3)) {
     ctx->last_error = "records 4-byte and points 16-byte aligned";
@@ -323,6 +325,7 @@ int32_t b3w_int_commit_records(b3w_ctx *ctx, const b3w_commit_key *key, const ui
   const uint32_t want = std::min(n, CHUNK);
   if (k->images_cap < want || k->sums_cap < want) {
     HIP_TRY(ctx, hipStreamSynchronize((hipStream_t)stream));
+    if (split) HIP_TRY(ctx, hipStreamSynchronize((hipStream_t)trace_stream));
     if (k->sums_cap < want) {
       if (k->d_sums) (void)hipFree(k->d_sums);
       k->d_sums = nullptr; k->sums_cap = 0;
@@ -341,7 +344,12 @@ int32_t b3w_int_commit_records(b3w_ctx *ctx, const b3w_commit_key *key, const ui
   for (uint32_t c0 = 0; c0 < n; c0 += cap) {                                 // the TRACE images of one chunk at a time
     const uint32_t cn = std::min(cap, n - c0);
     int lrc = b3w_launch_trace(ctx->desc.kind, d_records + (uint64_t)c0 * rw, cn, k->d_images, cap, ctx->d_table, ctx->desc.nwit,
-                               d_public ? d_public + (uint64_t)c0 * pw : nullptr, d_status + c0, ctx->d_aux, (hipStream_t)stream);
+                               d_public ? d_public + (uint64_t)c0 * pw : nullptr, d_status + c0, ctx->d_aux, (hipStream_t)(split ? trace_stream : stream));
+    if (lrc == 0 && split) {
+      hipError_t e = hipEventRecord(trace_done, (hipStream_t)trace_stream);
+      if (e == hipSuccess) e = hipStreamWaitEvent((hipStream_t)stream, trace_done, 0);
+      if (e != hipSuccess) return hip_fail(ctx, e, "TRACE event");
+    }
     if (lrc == 0)
       lrc = b3w_launch_commit(nullptr, cn, 0, key->first_slot, key->nslots, key->d_slotdesc, k->d_images, cap, key->d_runs, key->nruns,
                               key->d_table, key->nwin, key->window, d_sums_out ? d_sums_out + (uint64_t)c0 * B3W_COMMIT_SUM_WORDS : k->d_sums,
