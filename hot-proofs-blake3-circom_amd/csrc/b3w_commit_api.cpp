@@ -312,7 +312,7 @@ int32_t b3w_int_commit_normalize(b3w_ctx *ctx, const b3w_commit_key *key, const 
 int32_t b3w_int_commit_records(b3w_ctx *ctx, const b3w_commit_key *key, const uint32_t *d_records, uint32_t n, uint8_t *d_points, uint32_t *d_public,
                                int32_t *d_status, void *stream, uint32_t *d_sums_out, void *trace_stream, hipEvent_t trace_done) {
   if (!ctx || !key || key->ctx != ctx || !d_records || !d_points || !d_status) return B3W_E_BAD_ARGUMENT;
-  const bool split = trace_stream && trace_done && trace_stream != stream;
+  const bool split = trace_done != nullptr && trace_stream != stream;         // (trace_stream may be the null stream: a stream like any other)
   if (split && n > 32768u) return B3W_E_BAD_ARGUMENT;                         // (one chunk: the next chunk's TRACE would have to wait for this one's commit kernel)
   if (n == 0) return B3W_OK;
   if ((reinterpret_cast<uintptr_t>(d_points) & 15) || (reinterpret_cast<uintptr_t>(d_records) & 3)) {

@@ -123,8 +123,8 @@ b3w_ctx *b3w_int_key_ctx(const b3w_commit_key *key);
 // b3w_commit_api.cpp: b3w_commit_records_device with the normalisation put off — d_sums_out (B3W_COMMIT_SUM_WORDS words per record) takes
 // the projective sums and d_points is not written; b3w_int_commit_normalize makes points of any number of them at once (the chained pass:
 // once per run call instead of once per batch, b3w_kernels.h at b3w_launch_commit_normalize)
-// trace_stream / trace_done: the TRACE launch on ANOTHER stream than the commit kernel's (n at most one chunk of 32 768; `stream` waits for
-// trace_done, an event the caller owns; null: both on `stream`) — chain_run_steps: the images are 115 MB of stores that crawl beside a
+// trace_done (an event the caller owns; null: both launches on `stream`): the TRACE launch goes to trace_stream — ANOTHER stream than the commit
+// kernel's, and the null stream is a stream — and `stream` waits for the event (n at most one chunk of 32 768) — chain_run_steps: the images are 115 MB of stores that crawl beside a
 // witness kernel but take 40 us in front of it
 int32_t b3w_int_commit_records(b3w_ctx *ctx, const b3w_commit_key *key, const uint32_t *d_records, uint32_t n, uint8_t *d_points, uint32_t *d_public,
                                int32_t *d_status, void *stream, uint32_t *d_sums_out, void *trace_stream = nullptr, hipEvent_t trace_done = nullptr);

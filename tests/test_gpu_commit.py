@@ -636,3 +636,36 @@ def test_commit_only_pass_makes_its_points_at_the_end_of_a_run_call():
             assert int(got.max(axis=1).min()) > 0
         key.close()
     ctx.close()
+
+
+@pytest.mark.parametrize("use_null_stream", [True, False])
+def test_gated_commitments_of_a_many_slice_pass_equal_the_commit_only_points(use_null_stream):
+    """r05: under GATED the TRACE images of a batch are written on the CALLER's stream in front of its witness kernel and the commit kernel
+    waits for them on the commit stream — ordered by an event, also when the caller's stream is the null stream (a first version took
+    "null" for "no stream", lost the ordering and read records the planner had not written yet: only a pass of several slices shows it).
+    2 MiB = 32 768 leaf steps in batches of 4 096, planned slice by slice: the points of check + commit-from-records equal those of the
+    commit-only pass, every step satisfies the circuit, the fold ends in BLAKE3(preimage)."""
+    import torch, blake3_ref
+    m = T.pkg()
+    ctx = m.Context("nova_vesta", 0)
+    dev = torch.device("cuda:0")
+    data = m.workloads.lcg_preimage(2 << 20, seed=9)
+    key = m.CommitKey(ctx, "pallas", E.points_to_bytes(E.random_points("pallas", T.NWIT["nova_vesta"])), window=12)
+    r1cs = m.R1cs(ctx)
+    probe = m.chain.fold_witnesses(ctx, data, batch_steps=4096, ring=2)
+    rows = probe["n_leaf_steps"] + probe["n_parent_steps"]
+    want = torch.zeros((rows, 64), dtype=torch.uint8, device=dev)
+    m.chain.fold_witnesses(ctx, data, batch_steps=4096, ring=2, commit_only=(key, want))
+    torch.cuda.synchronize()
+    got = torch.zeros((rows, 64), dtype=torch.uint8, device=dev)
+    st = torch.cuda.current_stream() if use_null_stream else torch.cuda.Stream()
+    assert (st.cuda_stream == 0) == use_null_stream
+    with torch.cuda.stream(st):
+        for _ in range(2):                                     # (twice: the second pass finds every buffer in place and runs ahead of the host)
+            got.zero_()
+            out = m.chain.fold_witnesses(ctx, data, batch_steps=4096, ring=2, commit_records=(key, got), check=r1cs, commit_overlap="gated")
+        st.synchronize()
+    assert torch.equal(got, want) and int(got.max(dim=1).values.min().item()) > 0
+    assert int(out["status"].abs().sum().item()) == 0 and int(out["violations"].abs().sum().item()) == 0
+    assert out["root"].cpu().numpy().view(np.uint32).tobytes() == blake3_ref.blake3(data.tobytes())
+    r1cs.close(); key.close(); ctx.close()

@@ -13,4 +13,4 @@ import json; d=json.load(open('$O/b.json')); print('split $d', 'check+commit', r
   done
 done
 export TMPDIR=/tmp
-rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d gpurun_out/prof_split -- python3 tools/ubench/chain_one_pass.py 8 check+commit > $O/split_timeline.log 2>&1 && python3 tools/pass_timeline.py gpurun_out/prof_split > $O/timeline_ranks1_8mib_check_commit_split_trace.txt 2>&1; head -40 $O/timeline_ranks1_8mib_check_commit_split_trace.txt
+rocprofv3 --kernel-trace --memory-copy-trace --output-format csv -d gpurun_out/prof_split -- python3 tools/ubench/chain_one_pass.py 1 8 check+commit > $O/split_timeline.log 2>&1 && python3 tools/pass_timeline.py gpurun_out/prof_split > $O/timeline_ranks1_8mib_check_commit_split_trace.txt 2>&1; head -40 $O/timeline_ranks1_8mib_check_commit_split_trace.txt
