@@ -491,7 +491,15 @@ __global__ __launch_bounds__(512, 4) void b3w_r1cs_walk_kernel(const uint8_t *__
   // ---- verdicts of the general rows of unit k (one iteration after its entries were added): row g -> lane g of the workgroup
   unsigned long long wrec[5] = {0, 0, 0, 0, 0};
   size_t wrec_at = 0;                                        // (1 + the record's place: 0 = this lane has none pending)
-  auto verdicts = [&](const Cursor c, const uint32_t par, const bool careful, uint32_t &nbad, uint32_t &low) {
+  // A violated row goes straight into its body's counters (LDS) INSIDE the branch that found it: a lane's "lowest violated row" is a
+  // load (the row's constraint number), and a load whose result is still under way where the branches meet makes the compiler wait
+  // there for everything in flight (s_waitcnt vmcnt(0)) — the NEXT unit's fetch too, in the verdict phase of every wave and every
+  // iteration (the ISA had it until r05; inside the branch the wait is the violating wave's alone).
+  auto report = [&](const uint32_t body, const uint32_t nrows, const uint32_t row_at) {
+    atomicAdd(&cnt[body % 3u], nrows);
+    atomicMin(&cnt[3u + body % 3u], W.row_id[row_at]);
+  };
+  auto verdicts = [&](const Cursor c, const uint32_t par, const bool careful) {
     const uint32_t gen_n = TW(c, B3W_WT_GEN_N);
     if (wave * 64u >= gen_n) return;                           // (wave-uniform)
     unsigned long long *sum = gsum0 + par * 6u * W.max_gen + 6u * tid;
@@ -527,7 +535,7 @@ __global__ __launch_bounds__(512, 4) void b3w_r1cs_walk_kernel(const uint8_t *__
     if (careful) return;                                       // (every row of this unit goes to the deferred kernel: nothing is counted here)
     const unsigned long long dm = __ballot(defer);
     if (dm != 0ull && lane == 0) dmask0[par * 8u + wave] = dm;
-    if (bad) { nbad++; low = min(low, W.row_id[TW(c, B3W_WT_ROW0) + tid]); }
+    if (bad) report(c.body, 1u, TW(c, B3W_WT_ROW0) + tid);
   };
   // ---- the scratch block of unit k for the deferred kernel, by wave 1 once every wave's verdicts of the unit are behind a barrier:
   // word 0 = which mask words follow (bit w = word w is stored and not zero); a careful unit: all its rows
@@ -556,16 +564,6 @@ __global__ __launch_bounds__(512, 4) void b3w_r1cs_walk_kernel(const uint8_t *__
       cnt[s] = 0u; cnt[3u + s] = 0xFFFFFFFFu; cnt[6u + s] = 0u; bflag[s] = 0ull;
     }
   };
-  auto count = [&](uint32_t nbad, uint32_t low, const uint32_t body) {
-    if (__ballot(nbad != 0u) == 0ull) return;                  // (nearly always)
-#pragma unroll
-    for (int sh = 32; sh > 0; sh >>= 1) {
-      nbad += (uint32_t)__shfl_xor((int)nbad, sh);
-      low = min(low, (uint32_t)__shfl_xor((int)low, sh));
-    }
-    if (lane == 0) { atomicAdd(&cnt[body % 3u], nbad); atomicMin(&cnt[3u + body % 3u], low); }
-  };
-
   // ---- the pipeline.  Iteration i: entries, runs, exports of unit i | verdicts of unit i - 1 | scratch block of unit i - 2 |
   // pack unit i + 1 | program of unit i + 1, fetch of unit i + 2 | barrier.
   Cursor cf{b0, 0, 0}, cp{b0, 0, 0}, ce{b0, 0, 0};            // fetch, pack, evaluate
@@ -595,28 +593,19 @@ __global__ __launch_bounds__(512, 4) void b3w_r1cs_walk_kernel(const uint8_t *__
       if (prev2.tile == W.ntiles - 1u) flush(prev2.body);     // (its verdicts ran in the last iteration, behind the last barrier)
     }
     B3W_WSTAMP(0);
-    uint32_t nbad = 0, low = 0xFFFFFFFFu;
     if (!(B3W_WALK_ABLATE & 4)) entries(ce, par);
     B3W_WSTAMP(1);
     if (!(B3W_WALK_ABLATE & 1)) {
       const uint32_t run_n = TW(ce, B3W_WT_RUN_N);
       if (rwave * 64u < run_n) {
         const uint32_t viol = run_bits(prun, par, rtid < run_n);
-        if (viol && !sticky) {
-          nbad += (uint32_t)__popc(viol);
-          low = min(low, W.row_id[W.run_row[TW(ce, B3W_WT_RUN_OFF) + rtid] + (uint32_t)__ffs((int)viol) - 1u]);
-        }
+        if (viol && !sticky) report(ce.body, (uint32_t)__popc(viol), W.run_row[TW(ce, B3W_WT_RUN_OFF) + rtid] + (uint32_t)__ffs((int)viol) - 1u);
       }
     }
     B3W_WSTAMP(2);
     if (!(B3W_WALK_ABLATE & 8)) exports(ce, par);
-    count(nbad, low, ce.body);
     B3W_WSTAMP(3);
-    if (i && !(B3W_WALK_ABLATE & 2)) {
-      uint32_t nb2 = 0, low2 = 0xFFFFFFFFu;
-      verdicts(prev, par ^ 1u, prev_careful, nb2, low2);
-      count(nb2, low2, prev.body);
-    }
+    if (i && !(B3W_WALK_ABLATE & 2)) verdicts(prev, par ^ 1u, prev_careful);
     B3W_WSTAMP(4);
     pack(cp, i + 1u < m, par ^ 1u, i3n);
     B3W_WSTAMP(5);
@@ -647,9 +636,7 @@ __global__ __launch_bounds__(512, 4) void b3w_r1cs_walk_kernel(const uint8_t *__
   if (STAMPS && stamping && lane == 0)
     for (int k = 0; k < 8; k++) stamps[wave * 8 + k] = ph[k];
   {
-    uint32_t nb2 = 0, low2 = 0xFFFFFFFFu;
-    verdicts(prev, (m - 1u) & 1u, prev_careful, nb2, low2);
-    count(nb2, low2, prev.body);
+    verdicts(prev, (m - 1u) & 1u, prev_careful);
     if (wrec_at) {
       unsigned long long *rec = wide_recs + (wrec_at - 1u);
 #pragma unroll
