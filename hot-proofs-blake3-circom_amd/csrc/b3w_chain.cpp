@@ -168,7 +168,13 @@ int32_t chain_run_steps(b3w_chain *c, uint64_t first_row, uint64_t count, b3w_ba
   // (profiles/r05/commit_defer_normalize.log).  Beside bodies the per-batch launch hides behind the witness kernels and putting it
   // off gains nothing (FREE: 4.69 -> 4.62), and under SERIAL / GATED the batch's consumer may read its points: those keep theirs.
   static const bool defer_env = !(getenv("B3W_COMMIT_DEFER_NORMALIZE") && !strcmp(getenv("B3W_COMMIT_DEFER_NORMALIZE"), "0"));
-  const bool defer = defer_env && c->co_key && c->d_co_sums && mode == B3W_COMMIT_OVERLAP_SERIAL && !c->co_bodies;
+  bool defer = defer_env && c->co_key && mode == B3W_COMMIT_OVERLAP_SERIAL && !c->co_bodies;
+  if (defer && !c->d_co_sums &&                              // (144 bytes a step, the first commit-only pass of the chain; none to be had: the batches normalise their own)
+      hipMalloc((void **)&c->d_co_sums, (size_t)(c->n_leaf + c->n_par + 1) * B3W_COMMIT_SUM_WORDS * 4) != hipSuccess) {
+    (void)hipGetLastError();
+    c->d_co_sums = nullptr;
+    defer = false;
+  }
   uint32_t *sums = defer ? c->d_co_sums : nullptr;
   for (uint64_t done = 0; done < count;) {
     const uint32_t k = (uint32_t)std::min<uint64_t>(c->batch_steps, count - done);
@@ -303,10 +309,6 @@ int32_t b3w_chain_commit_only(b3w_chain *c, const b3w_commit_key *key, uint8_t *
       HIP_TRY(c->ctx, hipMalloc((void **)&c->co_own, (size_t)(c->n_leaf + c->n_par + 1) * 64));
     }
     d_points = c->co_own;
-  }
-  if (key && !c->d_co_sums) {                          // (144 bytes a step: the sums of chain_run_steps' deferred normalisation; without it the batches normalise their own)
-    ON_DEVICE(c->ctx);
-    if (hipMalloc((void **)&c->d_co_sums, (size_t)(c->n_leaf + c->n_par + 1) * B3W_COMMIT_SUM_WORDS * 4) != hipSuccess) { (void)hipGetLastError(); c->d_co_sums = nullptr; }
   }
   c->co_key = key;
   c->co_points = key ? d_points : nullptr;
