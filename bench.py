@@ -336,7 +336,11 @@ def bench_chain(args, m, torch, dist, dev, world, rank, local_rank):
                                   torch.cuda.current_stream().cuda_stream)
     # the fold's exchange (N > 1) is part of every pass: chunk chaining values, then every step's h_out (BASELINE config 4)
     comm = native_comm(m, ctx, dist, world, rank, "chain") if (world > 1 and args.exchange_impl == "native") else None
-    run = lambda: m.chain.fold_witnesses(ctx, host, batch_steps=args.batch if args.batch != 4096 else 16384, ring=2, consumer=consumer,
+    # steps per ring buffer (`--batch`, 4096 = not given): 32 768 where a constraint check is in the pass — its per-batch costs (planner, TRACE,
+    # normalisation, the launches' gaps) are paid half as often: +2.5 % `check`, +3.6 % `check+commit` — else 16 384: the commitments that run FREE
+    # beside the witness kernels pipeline better over more, smaller batches (4.76 against 4.57 M steps/s); the ring is 2 x 24 or 2 x 12 GB
+    batch_steps = args.batch if args.batch != 4096 else 32768 if "check" in args.consumer else 16384
+    run = lambda: m.chain.fold_witnesses(ctx, host, batch_steps=batch_steps, ring=2, consumer=consumer,
                                          commit_only=commit_only, commit_records=commit_records, gather_hout=args.exchange != "none", comm=comm,
                                          check=r1cs_t, commit_overlap=args.commit_overlap)
     t_first = time.perf_counter()
@@ -465,7 +469,7 @@ def bench_chain(args, m, torch, dist, dev, world, rank, local_rank):
             "config": {"workload": f"config{5 if args.preimage_mib >= 1024 else 4}-style chain: {args.preimage_mib:g} MiB preimage "
                                    f"(LE stream of LCG(1)) -> {int(total_steps)} nova steps ({circuit}), "
                                    "planner + witness kernels, bodies through a 2-deep ring, H2D overlapped",
-                       "circuit": circuit, "n_chunks": out["n_chunks"], "path_len": out["path_len"],
+                       "circuit": circuit, "n_chunks": out["n_chunks"], "path_len": out["path_len"], "batch_steps": batch_steps, "ring": 2,
                        "placement": placements[0], "placement_per_rank": placements, "verification": verification,
                        "exchange": "none" if world == 1 else
                                    (f"all_gather of {n_leaf_all} x 8 u32 h_out (+ {int(total_steps) - n_leaf_all} x 8 of the parent steps) + "
