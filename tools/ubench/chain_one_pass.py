@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""chain_one_pass.py [ranks] [preimage MiB] [consumer] — a few warm-up passes of the chained pass, a pause, then ONE pass: the subject of
+"""chain_one_pass.py [ranks] [preimage MiB] [consumer] [steps per ring buffer: 16384] — a few warm-up passes of the chained pass, a pause, then ONE pass: the subject of
 a rocprofv3 timeline (tools/pass_timeline.py prints the kernels and copies behind the last pause with their start offsets).
 ranks > 1: rank 0's share through the native sharded path with the one-call stand-in all-gather of chain_scaling_model.py.
 consumer: none | check | commit | check+commit (the library's own check and the commitments from the records, b3w_chain_commit_overlap auto)."""
@@ -35,7 +35,8 @@ if "commit" in consumer:
     key = m.CommitKey(ctx, "vesta", K.generators("vesta", ctx.witness_size, seed=b"bench"), fold=True)
     n_max = m.lib().b3w_chain_num_chunks(nbytes) * 64 + 64
     kw["commit_records"] = (key, torch.zeros((n_max, 64), dtype=torch.uint8, device=dev))
-run = lambda: m.chain.fold_witnesses(ctx, host, batch_steps=16384, ring=2, comm=comm, **kw)
+batch_steps = int(sys.argv[4]) if len(sys.argv) > 4 else 16384
+run = lambda: m.chain.fold_witnesses(ctx, host, batch_steps=batch_steps, ring=2, comm=comm, **kw)
 for _ in range(4):
     run()
 torch.cuda.synchronize()
