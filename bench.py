@@ -556,7 +556,7 @@ def main():
                          "sampler needs seconds, not a 9 ms burst)")
     ap.add_argument("--traffic", default="auto", choices=["auto", "quoted"],
                     help="roofline.traffic of the batch line at N = 1: auto = measured by this invocation (two rocprofv3 --pmc child passes of 8 "
-                         "launches, before anything else; about half a minute) where rocprofv3 is there and this run is not itself profiled, "
+                         "launches, before anything else; a few seconds) where rocprofv3 is there and this run is not itself profiled, "
                          "else — and with `quoted` — the figure of the recorded passes (profiles/traffic_latest.json), said so in traffic_source")
     ap.add_argument("--traffic-child", default=None, help=argparse.SUPPRESS)      # (internal: what --traffic auto runs under rocprofv3)
     args = ap.parse_args()
