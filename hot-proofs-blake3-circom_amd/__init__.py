@@ -13,6 +13,7 @@ entry point raises.
 """
 import ctypes
 import os
+import re
 
 import numpy as np
 
@@ -784,8 +785,17 @@ class Batch:
 class WitnessCalculator:
     """Mirror of `class WitnessCalculator` (witness_calculator.js:108-274) over the C-ABI.
 
-    Same fields (version, n32, prime, witnessSize), same methods, same error text.  The
-    reference methods are `async` but resolve synchronously; these are plain calls."""
+    Same fields (version, n32, prime, witnessSize), same methods, same error text, same EVALUATION ORDER (below).  The
+    reference methods are `async` but resolve synchronously; these are plain calls.
+
+    `sanity_check` is the reference's `options` object (witness_calculator.js:66-75); a dict may carry this mirror's own
+    switches, named as in the Node shim: `logDFlags` (False: the nova circuits' "D_FLAGS:  0" line is not printed), `log`
+    (a callable that receives the line instead of `print` — what console.log is to the reference), `strictErrorParity`
+    (the loader's never-cleared errStr, witness_calculator.js:16,41: an assert's text carries the traces of every earlier
+    assert on this calculator)."""
+
+    _CHECKDEPTH_FIRST = re.compile(r"^Error in template (Num2Bits_\d+ line: \d+\nError in template (LessThan|GreaterEqThan)_\d+ "
+                                   r"line: \d+\nError in template )?Blake3NovaTreePath_CheckDepth_")
 
     def __init__(self, ctx, sanity_check=True):
         self.instance = ctx
@@ -794,14 +804,27 @@ class WitnessCalculator:
         self.prime = ctx.prime
         self.witnessSize = ctx.witness_size
         self.sanityCheck = sanity_check
+        opts = sanity_check if isinstance(sanity_check, dict) else {}
+        # circuits/blake3_nova.circom:166 logs once per witness through writeBufferMessage (witness_calculator.js:44-58) — also
+        # when a LATER assert rejects the input, not when the first component (CheckDepth, blake3_nova.circom:201) already does
+        self._log_dflags = ctx.circuit != "compression" and opts.get("logDFlags", True) is not False
+        self._log = opts.get("log", print)
+        self._strict_err = bool(opts.get("strictErrorParity"))
+        self._err_str = ""
 
     def circom_version(self):
         return self.version
 
     def _do_calculate_witness(self, inp):
-        """_doCalculateWitness (witness_calculator.js:131-169): returns the body (uint8 array)."""
+        """_doCalculateWitness (witness_calculator.js:131-169): returns the body (uint8 array).
+
+        In the reference's order: keys as the mapping yields them; per key the size check (:142-151), then its values are set
+        one by one (:152-163) and the circuit runs INSIDE the call that sets the last missing input — so its assert, or its log
+        line, comes before anything is known about the keys behind the completing one, and a fault of an earlier key before the
+        circuit has run (tests/golden/order.json, made by the reference loader)."""
         ctx = self.instance
         hashes, counts, vals = [], [], []
+        body = None
         for k in inp.keys():
             farr = flat_array(inp[k])
             size = ctx.input_signal_size(k)
@@ -812,8 +835,14 @@ class WitnessCalculator:
             hashes.append(fnv_hash(k))
             counts.append(len(farr))
             vals += [(_to_int(v) % self.prime) for v in farr]          # normalize(), :319-323
+            if body is None and farr and len(vals) == ctx.input_size:
+                body = self._run(hashes, counts, vals)                 # the last missing input has just been set
         if len(vals) < ctx.input_size:
             raise B3WError(104, f"Not all inputs have been set. Only {len(vals)} out of {ctx.input_size}")
+        return body
+
+    def _run(self, hashes, counts, vals):
+        ctx = self.instance
         h = np.array(hashes, dtype=np.uint64)
         c = np.array(counts, dtype=np.uint32)
         v = np.frombuffer(b"".join(x.to_bytes(32, "little") for x in vals), dtype=np.uint8)
@@ -822,8 +851,18 @@ class WitnessCalculator:
         if rc != B3W_OK:
             if rc in _CIRCOM_ERR:
                 tail = ctx.last_error()            # "Assert Failed.\n" + the circom trace lines
-                raise B3WError(rc, "Error: " + (tail if tail.startswith(_CIRCOM_ERR[rc]) else _CIRCOM_ERR[rc] + tail))
+                head = _CIRCOM_ERR[rc]
+                trace = tail[len(head):] if tail.startswith(head) else tail
+                if rc == B3W_E_ASSERT_FAILED:
+                    if self._log_dflags and not self._CHECKDEPTH_FIRST.match(trace):
+                        self._log("D_FLAGS:  0")
+                    prior = self._err_str if self._strict_err else ""
+                    self._err_str += trace
+                    raise B3WError(rc, "Error: " + head + prior + trace)
+                raise B3WError(rc, "Error: " + head + trace)
             raise B3WError(rc, ctx.last_error())
+        if self._log_dflags:
+            self._log("D_FLAGS:  0")
         return body
 
     def calculateWitness(self, inp, sanity_check=0):

@@ -527,38 +527,11 @@ int32_t b3w_batch_time_device(b3w_ctx *ctx, const uint32_t *d_records, uint32_t 
   return B3W_OK;
 }
 
-int32_t b3w_calc_witness(b3w_ctx *ctx, const uint64_t *name_hashes, const uint32_t *counts, const uint8_t *values_le32,
-                         uint32_t nkeys, uint8_t *out_body) {
-  if (!ctx || !name_hashes || !counts || !values_le32 || !out_body) return B3W_E_BAD_ARGUMENT;
+// The circuit runs for a complete set of inputs: the batch kernel with n = 1 for a canonical record, else the exact kernel.
+static int32_t calc_witness_run(b3w_ctx *ctx, const std::vector<uint32_t> &rec, const std::vector<uint8_t> &fe, bool canonical,
+                                uint8_t *out_body) {
   const CircuitDesc &d = ctx->desc;
-  std::vector<uint32_t> rec(d.nin, 0);
-  std::vector<uint8_t> fe((size_t)d.nin * 32, 0);       // inputs as field elements, record order
-  std::vector<uint8_t> set(d.nin, 0);
-  uint32_t nset = 0;
-  bool canonical = true;
-  const uint8_t *v = values_le32;
   char msg[200];
-  for (uint32_t k = 0; k < nkeys; k++) {
-    const InputSignal *sig = nullptr;
-    for (const InputSignal &s : ctx->inputs) if (s.hash == name_hashes[k]) sig = &s;
-    const uint32_t size = sig ? sig->count : 0;
-    if (counts[k] < size) { ctx->last_error = std::string("Not enough values for input signal ") + (sig ? sig->name : "?") + "\n"; return B3W_E_ARRAY_ACCESS; }
-    if (counts[k] > size) { ctx->last_error = std::string("Too many values for input signal ") + (sig ? sig->name : "?") + "\n"; return B3W_E_TOO_MANY_SIGNALS; }
-    for (uint32_t i = 0; i < size; i++, v += 32) {
-      const uint32_t idx = sig->rec_off + i;
-      if (set[idx]) { ctx->last_error = "Signal already set.\n"; return B3W_E_SIGNAL_ALREADY_SET; }
-      memcpy(&fe[(size_t)idx * 32], v, 32);
-      memcpy(&rec[idx], v, 4);
-      for (int b = 4; b < 32; b++) canonical &= (v[b] == 0);
-      set[idx] = 1;
-      nset++;
-    }
-  }
-  if (nset < d.nin) {
-    snprintf(msg, sizeof msg, "Not all inputs have been set. Only %u out of %u", nset, d.nin);
-    ctx->last_error = msg;
-    return B3W_E_NOT_ALL_INPUTS;
-  }
   ON_DEVICE(ctx);
   if (canonical) {
     // canonical u32 record: the batch kernel with n = 1
@@ -586,6 +559,49 @@ int32_t b3w_calc_witness(b3w_ctx *ctx, const uint64_t *name_hashes, const uint32
     return B3W_E_ASSERT_FAILED;
   }
   HIP_TRY(ctx, hipMemcpy(out_body, ctx->d_body1, (size_t)d.nwit * 32, hipMemcpyDeviceToHost));
+  return B3W_OK;
+}
+
+// Keys are taken in the caller's order, as the reference's loader walks Object.keys (blake3_nova_js/witness_calculator.js:136-160):
+// per key the size check, then its values; the circuit runs when the last missing input has been set — BEFORE the keys behind the
+// completing one are looked at.  An assert therefore wins over a fault of a later key, a fault of an earlier key over the assert.
+int32_t b3w_calc_witness(b3w_ctx *ctx, const uint64_t *name_hashes, const uint32_t *counts, const uint8_t *values_le32,
+                         uint32_t nkeys, uint8_t *out_body) {
+  if (!ctx || !name_hashes || !counts || !values_le32 || !out_body) return B3W_E_BAD_ARGUMENT;
+  const CircuitDesc &d = ctx->desc;
+  std::vector<uint32_t> rec(d.nin, 0);
+  std::vector<uint8_t> fe((size_t)d.nin * 32, 0);       // inputs as field elements, record order
+  std::vector<uint8_t> set(d.nin, 0);
+  uint32_t nset = 0;
+  bool canonical = true, ran = false;
+  const uint8_t *v = values_le32;
+  char msg[200];
+  for (uint32_t k = 0; k < nkeys; k++) {
+    const InputSignal *sig = nullptr;
+    for (const InputSignal &s : ctx->inputs) if (s.hash == name_hashes[k]) sig = &s;
+    const uint32_t size = sig ? sig->count : 0;
+    if (counts[k] < size) { ctx->last_error = std::string("Not enough values for input signal ") + (sig ? sig->name : "?") + "\n"; return B3W_E_ARRAY_ACCESS; }
+    if (counts[k] > size) { ctx->last_error = std::string("Too many values for input signal ") + (sig ? sig->name : "?") + "\n"; return B3W_E_TOO_MANY_SIGNALS; }
+    for (uint32_t i = 0; i < size; i++, v += 32) {
+      const uint32_t idx = sig->rec_off + i;
+      if (set[idx]) { ctx->last_error = "Signal already set.\n"; return B3W_E_SIGNAL_ALREADY_SET; }
+      memcpy(&fe[(size_t)idx * 32], v, 32);
+      memcpy(&rec[idx], v, 4);
+      for (int b = 4; b < 32; b++) canonical &= (v[b] == 0);
+      set[idx] = 1;
+      nset++;
+    }
+    if (!ran && size > 0 && nset == d.nin) {
+      const int32_t rc = calc_witness_run(ctx, rec, fe, canonical, out_body);
+      if (rc) return rc;
+      ran = true;
+    }
+  }
+  if (nset < d.nin) {
+    snprintf(msg, sizeof msg, "Not all inputs have been set. Only %u out of %u", nset, d.nin);
+    ctx->last_error = msg;
+    return B3W_E_NOT_ALL_INPUTS;
+  }
   return B3W_OK;
 }
 

@@ -82,12 +82,19 @@ class WitnessCalculator {
     return this.version;
   }
 
-  // witness_calculator.js:131-169: hash the names, check sizes, normalise mod p, hand over
+  // witness_calculator.js:131-169, in the reference's EVALUATION ORDER: the keys are walked as Object.keys gives them; per key the
+  // name is hashed (:138-140) and its size checked (:142-151), then its values are normalised and set one by one (:152-163) —
+  // and the circuit runs INSIDE the setInputSignal call that sets the last missing input.  So an assert (or the D_FLAGS log line)
+  // comes before anything is known about the keys behind the completing one, and a fault of an earlier key comes before the
+  // circuit has run at all: { ...valid, m[0] = 2^34, zz: 1 } is "Assert Failed" in Bits34, { zz: 1, ...the same } is
+  // "Too many values for input signal zz", and a valid nova step followed by an unknown key logs its line and THEN throws
+  // (tests/golden/order.json, made by the reference loader).
   async _doCalculateWitness(input, sanityCheck, asWtns) {   // (asWtns: extension — the .wtns image instead of the bare body)
     const nat = native();
     const keys = Object.keys(input);
     const hashes = [], counts = [], values = [];
     let inputCounter = 0;
+    let body = null;
     keys.forEach((k) => {
       const h = fnvHash(k);
       const hMSB = parseInt(h.slice(0, 8), 16);
@@ -109,10 +116,20 @@ class WitnessCalculator {
         values.push(normalize(fArr[i], this.prime));
         inputCounter++;
       }
+      // the last missing input has just been set: the reference's circuit runs here, before the next key is looked at
+      if (body === null && fArr.length > 0 && inputCounter === this.inputSize) {
+        body = this._run(hashes, counts, values, asWtns);
+      }
     });
     if (inputCounter < this.inputSize) {
       throw new Error(`Not all inputs have been set. Only ${inputCounter} out of ${this.inputSize}`);
     }
+    return body;
+  }
+
+  // the device call for a complete set of inputs: throws the circuit's assert with the reference's text, logs what the circuit logs
+  _run(hashes, counts, values, asWtns) {
+    const nat = native();
     const vals = new Uint8Array(32 * values.length);
     const mask = BigInt(0xffffffff), s32 = BigInt(32);
     const dv = new DataView(vals.buffer);

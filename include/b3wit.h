@@ -79,7 +79,13 @@ int32_t b3w_input_signal_size(const b3w_ctx *ctx, uint64_t fnv1a64_of_name);
  * through the exact (256-bit field arithmetic) device kernel — both on the GPU.
  * Size errors mirror WC:142-150 (B3W_E_TOO_MANY_SIGNALS / B3W_E_ARRAY_ACCESS /
  * B3W_E_NOT_ALL_INPUTS); a failed circuit assert returns B3W_E_ASSERT_FAILED and b3w_last_error gives
- * the reference WASM's own trace text ("Assert Failed.\nError in template Bits34_1 line: 201\n..."). */
+ * the reference WASM's own trace text ("Assert Failed.\nError in template Bits34_1 line: 201\n...").
+ * ORDER (WC:136-160): keys are taken as given; per key the size check, then its values; the circuit runs when the
+ * last missing input has been set, before the keys BEHIND the completing one are looked at.  So a failed assert
+ * wins over the fault of a later key, the fault of an earlier key over the assert; when a later key is refused
+ * (an unknown name with values: B3W_E_TOO_MANY_SIGNALS) the circuit HAS run and out_body holds the witness — the
+ * JS shim and the Python mirror call with the keys up to the completing one, log what the circuit logs, and look
+ * at the rest themselves (tests/golden/order.json, tests/test_order_parity.py). */
 int32_t b3w_calc_witness(b3w_ctx *ctx, const uint64_t *name_hashes, const uint32_t *counts,
                          const uint8_t *values_le32, uint32_t nkeys, uint8_t *out_body);
 
