@@ -55,6 +55,10 @@ def reference_wasm(circuit, reference_dir, seconds):
 
 
 WITNESS_KERNELS = ("b3w_compression_kernel", "b3w_nova_kernel", "b3w_sweep_kernel")
+# store-only shapes of b3w_bodies_store_rate the batch line reads `achieved` against (roofline.store_ceiling)
+STORE_SHAPES = {"streams_w4": 0, "streams_w8": 1, "fill": 2}
+STORE_SHAPES_WHAT = ("b3w_bodies_store_rate: 20 passes of store-only kernels over the same n bodies — body streams (one wave per 4 / 8 bodies, 1 KiB per body "
+                     "and step: the fused kernels' store shape) and the runtime's fill shape")
 
 
 def live_traffic(args):
@@ -69,7 +73,7 @@ def live_traffic(args):
     if any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
         return None, "this run is itself under a profiler"
     tmp = tempfile.mkdtemp(prefix="b3w_traffic_", dir="/tmp")
-    per, t0 = {}, time.perf_counter()
+    per, variants, t0 = {}, {}, time.perf_counter()
     try:
         for counter in ("WRITE_SIZE", "FETCH_SIZE"):
             # (a plain buffer: the bytes a kernel moves do not depend on where its buffer lies, and the child needs no placement search)
@@ -89,12 +93,13 @@ def live_traffic(args):
             if len(rows) < k:
                 return None, f"the {counter} pass shows {len(rows)} witness-kernel dispatches, {k} expected"
             per[counter] = sum(float(x["Counter_Value"]) for x in rows[-k:]) * 1024.0 / child["launches"]
+            variants[counter] = child["variant"]                      # what the child's own autotune picked (a plain buffer: it may differ from the parent's)
     except Exception as e:                                  # (a time-out, an unreadable csv: the line then quotes the recorded passes)
         return None, f"{type(e).__name__}: {e}"
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
     return {"hbm_bytes_per_launch": per["WRITE_SIZE"] + 2.0 * per["FETCH_SIZE"], "write_bytes": per["WRITE_SIZE"], "fetch_bytes_x2": 2.0 * per["FETCH_SIZE"],
-            "seconds": round(time.perf_counter() - t0, 1)}, None
+            "seconds": round(time.perf_counter() - t0, 1), "variant": variants.get("WRITE_SIZE"), "variants_by_pass": variants}, None
 
 
 def self_launch(n, argv, launch_timeout):
@@ -803,18 +808,41 @@ def main():
     # what `achieved` is a fraction of on THIS chip, next to the 8 TB/s of the data sheet.  (The bodies are overwritten: checks are done.)
     plain, ceiling = None, None
     if world == 1:
-        d_plain = torch.empty(n * pitch, dtype=torch.uint8, device=dev)
-        ctx.time_device(d_recs.data_ptr(), n, d_plain.data_ptr(), pitch, d_pub.data_ptr(), d_status.data_ptr(), stream.cuda_stream, 5)
-        ms_plain = ctx.time_device(d_recs.data_ptr(), n, d_plain.data_ptr(), pitch, d_pub.data_ptr(), d_status.data_ptr(), stream.cuda_stream, 20)
-        ach_plain = BYTES_PER_WITNESS[circuit] * n / (ms_plain * 1e-3) / 1e9
-        plain = {"kernel_ms": ms_plain, "achieved": ach_plain, "frac": ach_plain / HBM_PEAK_GBS, "launches": 20,
-                 "buffer": "torch.empty = hipMalloc, same records, same kernel variant, after the timed region"}
-        shapes = {"streams_w4": 0, "streams_w8": 1, "fill": 2}
-        ceiling = {"unit": "GB/s", "what": "b3w_bodies_store_rate: 20 passes of store-only kernels over the same n bodies — body streams (one wave per "
-                                            "4 / 8 bodies, 1 KiB per body and step: the fused kernels' store shape) and the runtime's fill shape",
-                   "placed": {k: ctx.store_rate(d_bodies.data_ptr(), n, pitch, v, 20, stream.cuda_stream) for k, v in shapes.items()},
-                   "plain": {k: ctx.store_rate(d_plain.data_ptr(), n, pitch, v, 20, stream.cuda_stream) for k, v in shapes.items()}}
-        del d_plain
+        # (a baseline leg never fails the bench: the measurement is done; an out-of-memory here — the second buffer is 49 GB for config 3 —
+        # or a B3WError must not cost the driver its JSON line)
+        d_plain = ctx_plain = None
+        try:
+            d_plain = torch.empty(n * pitch, dtype=torch.uint8, device=dev)
+            # its OWN context and its own autotune ON THIS BUFFER: the launch shape that suits a placed buffer is not the one that suits a plain
+            # one, and an integrator who brings a buffer calls b3w_batch_autotune_device on that buffer
+            ctx_plain = m.Context(circuit, torch.cuda.current_device())
+            if args.variant is None:
+                v_plain, _ = ctx_plain.autotune_device(d_recs.data_ptr(), n, d_plain.data_ptr(), pitch, d_pub.data_ptr(), d_status.data_ptr(), stream.cuda_stream)
+            else:
+                v_plain = args.variant
+            ctx_plain.time_device(d_recs.data_ptr(), n, d_plain.data_ptr(), pitch, d_pub.data_ptr(), d_status.data_ptr(), stream.cuda_stream, 5)
+            ms_plain = ctx_plain.time_device(d_recs.data_ptr(), n, d_plain.data_ptr(), pitch, d_pub.data_ptr(), d_status.data_ptr(), stream.cuda_stream, 20)
+            ach_plain = BYTES_PER_WITNESS[circuit] * n / (ms_plain * 1e-3) / 1e9
+            plain = {"kernel_ms": ms_plain, "achieved": ach_plain, "frac": ach_plain / HBM_PEAK_GBS, "launches": 20, "kernel_variant": v_plain,
+                     "buffer": "torch.empty = hipMalloc, same records; the launch shape autotuned ON THIS BUFFER (b3w_batch_autotune_device, as an integrator "
+                               "with its own allocator would), after the timed region"}
+            shapes = STORE_SHAPES
+            ceiling = {"unit": "GB/s", "what": STORE_SHAPES_WHAT,
+                       "placed": {k: ctx.store_rate(d_bodies.data_ptr(), n, pitch, v, 20, stream.cuda_stream) for k, v in shapes.items()},
+                       "plain": {k: ctx.store_rate(d_plain.data_ptr(), n, pitch, v, 20, stream.cuda_stream) for k, v in shapes.items()}}
+        except Exception as e:
+            why = f"{type(e).__name__}: {e}"[:300]
+            print(f"bench.py: the untimed plain-buffer / store-ceiling legs failed ({why}); the line goes out without them", file=sys.stderr)
+            plain = plain if plain is not None else {"why": why}
+            ceiling = {"why": why}
+            try:
+                torch.cuda.synchronize()
+            except Exception:
+                pass
+        finally:
+            if ctx_plain is not None:
+                ctx_plain.close()
+            del d_plain
 
     t = torch.tensor([elapsed, kern_ms], dtype=torch.float64, device=dev)
     if world > 1:
@@ -843,6 +871,13 @@ def main():
         achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
         traffic, traffic_source, traffic_parts = None, None, None
         tf = os.path.join(ROOT, "profiles", "traffic_latest.json")   # PMC passes (WRITE_SIZE/FETCH_SIZE), see profiles/README.md
+        path_of = lambda v: "sweep" if v is not None and v >= 100 else "fused"
+        if measured_traffic is not None and any(path_of(v) != path_of(chosen) for v in measured_traffic.get("variants_by_pass", {}).values()):
+            # the children autotuned on THEIR (plain) buffers and took another kernel path than the timed one (fused against TRACE + SWEEP: another
+            # number of kernels per launch, and the TRACE images' traffic): their bytes are not this run's — quote the recorded passes of the timed path
+            traffic_why_not = (f"the counter passes' autotune picked variant(s) {sorted(set(measured_traffic['variants_by_pass'].values()))} "
+                               f"({'/'.join(sorted({path_of(v) for v in measured_traffic['variants_by_pass'].values()}))}), the timed run {chosen} ({path_of(chosen)})")
+            measured_traffic = None
         if measured_traffic is not None:
             traffic = measured_traffic["hbm_bytes_per_launch"]
             traffic_parts = measured_traffic
@@ -899,11 +934,15 @@ def main():
                          "kernel_ms_max": max(kern_per_rank), "algorithmic_bytes_per_launch": alg_bytes, "launches_timed": launches},
         }
         if plain is not None:
-            best = max(ceiling["placed"].values())
-            out["roofline"]["plain"] = plain
-            out["roofline"]["store_ceiling"] = ceiling
-            out["roofline"]["of_measured_ceiling"] = achieved / best       # of the best store-only shape on the SAME (placed) buffer
-            out["roofline"]["plain_of_measured_ceiling"] = plain["achieved"] / max(ceiling["plain"].values())
+            out["roofline"]["plain"] = plain if "achieved" in plain else None
+            out["roofline"]["store_ceiling"] = ceiling if "placed" in ceiling else None
+            if "why" in plain or "why" in ceiling:
+                out["roofline"]["untimed_legs_failed"] = plain.get("why") or ceiling.get("why")
+            if "placed" in ceiling:
+                best = max(ceiling["placed"].values())
+                out["roofline"]["of_measured_ceiling"] = achieved / best       # of the best store-only shape on the SAME (placed) buffer
+                if "achieved" in plain:
+                    out["roofline"]["plain_of_measured_ceiling"] = plain["achieved"] / max(ceiling["plain"].values())
         if args.cpu_seconds > 0 and world == 1:
             out["cpu_baseline"] = cpu_baseline(circuit, recs, args.cpu_seconds, args.reference_dir, args.reference_seconds)
         print(json.dumps(out), flush=True)

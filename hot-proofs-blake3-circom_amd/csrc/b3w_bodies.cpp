@@ -97,7 +97,9 @@ int32_t b3w_bodies_alloc(b3w_ctx *ctx, uint64_t bytes, void **d_ptr, int32_t *pl
   const bool want_mixed = !(env && !strcmp(env, "plain")) && bytes >= (512ull << 20);
   if (want_mixed) {
     int mixed = 0;
-    const int rc = b3w_place_alloc(ctx->device, bytes, 1, d_ptr, &mixed, nullptr);
+    // B3W_PLACEMENT=single (harness): every piece from ONE class of memory — a worst-case plain buffer made on purpose, labelled plain
+    const bool single = env && !strcmp(env, "single");
+    const int rc = b3w_place_alloc(ctx->device, bytes, single ? 2 : 1, d_ptr, &mixed, nullptr);
     if (rc == 0) {
       // "mixed" is a claim about speed: check it with the real witness kernel against a plain hipMalloc buffer
       // (measured once per context) and take the label back when the gain is below 10 % — the buffer stays usable.

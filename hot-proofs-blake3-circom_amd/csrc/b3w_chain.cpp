@@ -90,6 +90,7 @@ struct b3w_chain {
   int32_t *d_status = nullptr;
   std::vector<void *> bodies;
   hipStream_t copy = nullptr, side = nullptr;        // H2D slices; tree + parent planning beside the leaf witness kernels
+  hipStream_t last_caller = nullptr;                 // the stream of the last run call (b3w_chain_destroy waits for it when it has to wait stream by stream)
   hipEvent_t ev[4] = {nullptr, nullptr, nullptr, nullptr};
   hipEvent_t ev_cvs = nullptr, ev_par = nullptr;     // chunk CVs complete (main stream); parent records ready (side stream)
   const b3w_commit_key *co_key = nullptr;            // commitments from the step records, one point per step into co_points ...
@@ -404,7 +405,10 @@ void b3w_chain_destroy(b3w_chain *c) {
   if (!c) return;
   B3wCaptureRelaxed relaxed;                                 // (b3w_capture.h)
   DeviceGuard guard(c->ctx->device);
-  b3w_device_wait();                                         // the ring buffers outlive the chain (spares): nothing may still write them
+  {                                                          // the ring buffers outlive the chain (spares): nothing may still write them
+    const hipStream_t mine[4] = {c->last_caller, c->copy, c->side, c->co_stream};
+    (void)b3w_device_wait(mine, 4);                          // (says so on stderr when it could not wait: b3w_capture.h)
+  }
   // ring buffers go back to the context (placed buffers use up address space for good: DESIGN.md "Placement") for the next
   // chain of the same ring geometry.  Spares of another size are released first (one size at a time) and the spares never
   // hold more than B3W_RING_SPARE_CAP bytes; b3w_ctx_trim releases them.
@@ -442,6 +446,7 @@ void b3w_chain_destroy(b3w_chain *c) {
 }
 
 int32_t b3w_chain_run_leaves(b3w_chain *c, const uint8_t *host_preimage, b3w_batch_consumer consumer, void *user, void *stream) {
+  if (c) c->last_caller = (hipStream_t)stream;
   if (!c || !host_preimage) return B3W_E_BAD_ARGUMENT;
   b3w_ctx *ctx = c->ctx;
   ON_DEVICE(ctx);
@@ -520,6 +525,7 @@ int32_t chain_run_parents(b3w_chain *c, const uint32_t *d_all_chunk_cvs, bool cv
 }  // namespace
 
 int32_t b3w_chain_run_parents(b3w_chain *c, const uint32_t *d_all_chunk_cvs, b3w_batch_consumer consumer, void *user, void *stream) {
+  if (c) c->last_caller = (hipStream_t)stream;
   if (!c) return B3W_E_BAD_ARGUMENT;
   ON_DEVICE(c->ctx);
   return chain_run_parents(c, d_all_chunk_cvs, false, consumer, user, stream);
@@ -579,6 +585,7 @@ int32_t chain_check_shard(b3w_chain *c, const b3w_comm *comm) {
 }  // namespace
 
 int32_t b3w_chain_run_parents_sharded(b3w_chain *c, b3w_comm *comm, b3w_batch_consumer consumer, void *user, void *stream) {
+  if (c) c->last_caller = (hipStream_t)stream;
   if (!c || !comm) return B3W_E_BAD_ARGUMENT;
   b3w_ctx *ctx = c->ctx;
   int32_t rc = chain_check_shard(c, comm);

@@ -77,8 +77,32 @@ int32_t b3w_slot_widths(b3w_ctx *ctx, uint16_t *out_bits) {
   return B3W_OK;
 }
 
+// One attempt with the window given, or chosen (window_bits 0: *auto_window tells which, *herr what the runtime said when it failed).
+static int32_t commit_key_create_once(b3w_ctx *ctx, int32_t curve, uint32_t first_slot, const uint8_t *host_generators,
+                                      const uint8_t *folded, uint32_t window_bits, b3w_commit_key **out, uint32_t *auto_window, hipError_t *herr);
+
+// An automatic window is a guess from hipMemGetInfo's free figure at one moment: other ranks or processes sizing their keys on the
+// same GPU, torch or the placement pool taking memory between the query and the allocation, or fragmentation can make the 25-51 GB
+// table of 18 bits fail where 16 (a quarter of it) or 12 fit.  Then — and only for a window nobody asked for — the next narrower
+// one is tried instead of returning B3W_E_HIP.
 int32_t b3w_commit_key_create_folded(b3w_ctx *ctx, int32_t curve, uint32_t first_slot, const uint8_t *host_generators,
                                      const uint8_t *folded /* per committed slot, or null */, uint32_t window_bits, b3w_commit_key **out) {
+  uint32_t chosen = 0;
+  hipError_t herr = hipSuccess;
+  int32_t rc = commit_key_create_once(ctx, curve, first_slot, host_generators, folded, window_bits, out, &chosen, &herr);
+  while (rc == B3W_E_HIP && herr == hipErrorOutOfMemory && chosen > B3W_COMMIT_WINDOW_SMALL) {
+    (void)hipGetLastError();                               // the failed allocation's sticky error
+    const uint32_t narrower = chosen == B3W_COMMIT_WINDOW_XL ? B3W_COMMIT_WINDOW_LARGE : B3W_COMMIT_WINDOW_SMALL;
+    uint32_t ignored = 0;
+    herr = hipSuccess;
+    rc = commit_key_create_once(ctx, curve, first_slot, host_generators, folded, narrower, out, &ignored, &herr);
+    chosen = narrower;
+  }
+  return rc;
+}
+
+static int32_t commit_key_create_once(b3w_ctx *ctx, int32_t curve, uint32_t first_slot, const uint8_t *host_generators,
+                                      const uint8_t *folded, uint32_t window_bits, b3w_commit_key **out, uint32_t *auto_window, hipError_t *herr) {
   if (!ctx || !out || !host_generators || (curve != B3W_CURVE_BN254_G1 && curve != B3W_CURVE_VESTA) || first_slot >= ctx->desc.nwit ||
       (window_bits != 0 && !B3W_COMMIT_WINDOW_OK(window_bits))) {
     if (ctx) ctx->last_error = "commit key: curve 0/1, first_slot < witness_size, window_bits 0 (auto), 12, 16 or 18";
@@ -112,11 +136,14 @@ int32_t b3w_commit_key_create_folded(b3w_ctx *ctx, int32_t curve, uint32_t first
   }
   if (!window) {
     size_t free_b = 0, total_b = 0;
-    const bool known = e == hipSuccess && hipMemGetInfo(&free_b, &total_b) == hipSuccess;
+    bool known = e == hipSuccess && hipMemGetInfo(&free_b, &total_b) == hipSuccess;
+    // (tests of the fallback below: the figure the choice BELIEVES — as if the memory had been free at the query and gone at the allocation)
+    if (known && getenv("B3W_COMMIT_ASSUME_FREE_GIB")) free_b = (size_t)atoll(getenv("B3W_COMMIT_ASSUME_FREE_GIB")) << 30;
     auto table_bytes = [&](uint32_t w) { return (nv / w + 1) * (uint64_t)B3W_COMMIT_ENTRIES(w) * 64; };
     window = known && table_bytes(B3W_COMMIT_WINDOW_XL) <= free_b / 4      ? B3W_COMMIT_WINDOW_XL
              : known && table_bytes(B3W_COMMIT_WINDOW_LARGE) <= free_b / 4 ? B3W_COMMIT_WINDOW_LARGE
                                                                            : B3W_COMMIT_WINDOW_SMALL;
+    *auto_window = window;                               // nobody asked for this width: a failed allocation may fall back
   }
   // windows of `window` virtual slots; the pad bits of the last window are never set
   const uint32_t V0 = (uint32_t)nv;
@@ -225,6 +252,8 @@ int32_t b3w_commit_key_create_folded(b3w_ctx *ctx, int32_t curve, uint32_t first
   if (d_points) (void)hipFree(d_points);
   if (e != hipSuccess || rc != 0) {
     b3w_commit_key_destroy(key);
+    *herr = e != hipSuccess ? e : (hipError_t)rc;
+    (void)hipGetLastError();                               // not left behind for the next launch's hipGetLastError() to find
     return hip_fail(ctx, e != hipSuccess ? e : (hipError_t)rc, "commitment key set-up");
   }
   *out = key;

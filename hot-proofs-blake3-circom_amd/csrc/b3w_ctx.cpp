@@ -307,6 +307,12 @@ int32_t b3w_create(int32_t circuit, int32_t device, b3w_ctx **out) {
   set_inputs(ctx);
   std::vector<uint32_t> table;
   if (!build_slot_table(ctx->desc, table, ctx->last_error)) { delete ctx; return B3W_E_BAD_ARGUMENT; }
+  // the fill-ordered variants (caller-owned buffers) keep the table in LDS in 16 bits: image words below 1024, no shifted word slots, no 256-bit slots
+  ctx->fill_ok = ctx->desc.kind == B3W_KIND_COMP;
+  for (uint32_t e : table) {
+    const uint32_t src = e & 0xFFFu, sh = (e >> 12) & 31u, mode = (e >> 17) & 3u;
+    if (src >= 1023 || mode == B3W_MODE_W256 || (mode != B3W_MODE_BIT && sh != 0)) ctx->fill_ok = false;
+  }
   DeviceGuard guard(device);              // the caller's current device (torch's, say) is put back on return
   if (guard.err != hipSuccess) { delete ctx; return B3W_E_NO_DEVICE; }
   const CircuitDesc &d = ctx->desc;
@@ -340,7 +346,7 @@ int32_t b3w_create(int32_t circuit, int32_t device, b3w_ctx **out) {
   if (e != hipSuccess) { b3w_destroy(ctx); return B3W_E_HIP; }
   const char *v = getenv("B3W_VARIANT");
   if (v) { ctx->variant = atoi(v); ctx->variant_auto = false; }
-  if (ctx->variant >= B3W_VARIANT_SWEEP && ensure_scratch(ctx) != B3W_OK) { b3w_destroy(ctx); return B3W_E_HIP; }
+  if (ctx->variant >= B3W_VARIANT_SWEEP && ctx->variant < B3W_VARIANT_REGIONFILL && ensure_scratch(ctx) != B3W_OK) { b3w_destroy(ctx); return B3W_E_HIP; }
   *out = ctx;
   return B3W_OK;
 }
@@ -426,10 +432,11 @@ int32_t b3w_batch_run_device(b3w_ctx *ctx, const uint32_t *d_records, uint32_t n
     else if (ctx->desc.kind == B3W_KIND_NOVA_O2) variant = n <= 3072 ? 0 : 3;
     else variant = 0;
   }
+  if (variant >= B3W_VARIANT_REGIONFILL && !ctx->fill_ok) { ctx->last_error = "the fill-ordered variant (200) exists for the compression circuit only"; return B3W_E_BAD_ARGUMENT; }
   int rc = b3w_launch_batch(ctx->desc.kind, variant, d_records, n, d_bodies, pitch, ctx->d_table, ctx->desc.nwit,
                             d_public, d_status, ctx->d_aux, ctx->d_scratch, ctx->scratch_cap, (hipStream_t)stream);
   if (rc == 0) return B3W_OK;
-  if (rc == -5) { ctx->last_error = "the sweep path needs 32-byte aligned bodies and pitch < 2^30"; return B3W_E_BAD_ARGUMENT; }
+  if (rc == -5) { ctx->last_error = "the sweep and fill-ordered paths need 32-byte aligned bodies and pitch < 2^30"; return B3W_E_BAD_ARGUMENT; }
   if (rc < 0) { ctx->last_error = "no kernel for this circuit kind / variant"; return B3W_E_BAD_ARGUMENT; }
   return hip_fail(ctx, (hipError_t)rc, "kernel launch");
 }
@@ -476,16 +483,18 @@ int32_t b3w_batch_autotune_device(b3w_ctx *ctx, const uint32_t *d_records, uint3
   rc = ensure_scratch(ctx);
   if (rc) return rc;
   // fused with 4 (compression) / 2 (nova) bodies per wave, also with 8 (compression: for large batches occupancy-limited,
-  // variant 8; nova O2: variant 3), and the two-kernel sweep
-  const int candidates[3] = {0, ctx->desc.kind == B3W_KIND_COMP ? (n > 6144 ? 8 : 3) : ctx->desc.kind == B3W_KIND_NOVA_O2 ? 3 : 0, B3W_VARIANT_SWEEP};
+  // variant 8; nova O2: variant 3), the two-kernel sweep, and — compression — the fill-ordered fused kernel: on a placed buffer the body
+  // streams win (7.2 against 6.7 TB/s), on a caller's plain buffer the fill order does (6.4 against 5.5; profiles/r06/variant_scan_*.log)
+  const int candidates[4] = {0, ctx->desc.kind == B3W_KIND_COMP ? (n > 6144 ? 8 : 3) : ctx->desc.kind == B3W_KIND_NOVA_O2 ? 3 : 0, B3W_VARIANT_SWEEP,
+                             ctx->fill_ok ? B3W_VARIANT_REGIONFILL : 0};
   int best = ctx->variant;
   float best_ms = 1e30f;
   const int saved = ctx->variant;
   const bool saved_auto = ctx->variant_auto;
   ctx->variant_auto = false;
-  for (int ci = 0; ci < 3; ci++) {
+  for (int ci = 0; ci < 4; ci++) {
     const int c = candidates[ci];
-    if (ci == 1 && c == candidates[0]) continue;
+    if (ci > 0 && c == candidates[0]) continue;
     ctx->variant = c;
     float ms = 0;
     rc = B3W_OK;

@@ -50,6 +50,7 @@ struct b3w_ctx {
   int device = -1;
   int variant = 0;
   bool variant_auto = true;           // no B3W_VARIANT and no autotune yet: launch shape chosen by batch size
+  bool fill_ok = false;               // the slot table can be said in 16 bits a slot (b3w_kernels.hip fill_entry16): the REGIONFILL variant applies
   bool variant_tuned = false;         // `variant` comes from b3w_batch_autotune_device: it holds for large batches only
   std::vector<InputSignal> inputs;
   uint32_t *d_table = nullptr;        // slot table; 32 pad entries in front of it (expand() indexes from slot - 3)

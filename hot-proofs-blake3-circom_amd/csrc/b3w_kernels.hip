@@ -841,6 +841,201 @@ __global__ __launch_bounds__(64) void b3w_nova_kernel(const uint32_t *__restrict
   else expand<W, WORDS, true, NT>(lds, table, nwit, out, pitch, wb, n, okf, all_ok);
 }
 
+
+// ------------------------------------------------------------------ fill-ordered fused kernel ("REGIONFILL") — caller-owned buffers
+// Where the fused kernels above leave thousands of body streams in flight, a plain hipMalloc buffer — all of it in ONE class of HBM
+// (b3w_placement.hip) — takes 5.4-5.5 TB/s from them; the runtime's fill shape (256 workgroups of four waves, one per CU, workgroup b
+// writing the 4 KiB blocks b, b + 256, ...) gets 6.4-6.5 out of the same memory, and the store-only sweep of round 6
+// (tools/ubench/store_sweep.hip, profiles/r06/store_sweep*.log) says what of that shape matters: four-wave workgroups that store whole
+// 4 KiB blocks, ONE workgroup per CU (twice as many: 5.3), every XCD writing the blocks of its own residue class (block index mod 8 =
+// workgroup index mod 8: the dispatcher deals workgroups to the XCDs round-robin; without that: 5.5), and one compact window chip-wide.
+// The fill order itself would need a trace per block (a workgroup's consecutive blocks lie 1 MiB = 1.4 bodies apart); a workgroup that
+// stays in a 128 KiB region for four steps needs one per four, and that order ("A256x4" in the sweep) was the best of all: 6.56 TB/s.
+//   * waves 0..3 of a workgroup store a block (1 KiB each; lane pair = one slot, as in EXPAND) from the images in LDS through the slot
+//     table in LDS: their only vector-memory instructions are stores, and they never wait for one (a table word loaded from L2 by the
+//     same wave would be waited for IN ORDER behind the wave's own stores — what holds the two-kernel sweep at 5.5 TB/s);
+//   * wave 4 is the TRACER: while the others store the units of one half of the image buffer it computes the images of the next NH
+//     units into the other half (four lanes per body, the same trace_compression), records prefetched a half ahead — one barrier per
+//     NH units.
+// Bit-identical to the other variants (tests/test_gpu_parity.py); b3w_batch_autotune_device times it on the buffer it is given.
+// (Also built and measured in round 6, and taken out: the same workgroup dealt BODY-major — groups of 8 m workgroups per body, a workgroup
+// the body's blocks = u (mod 8 m): 5.8-6.0 TB/s on one-class memory for m = 1 .. 8, profiles/r06/variant_scan_bf*.log.)
+// The slot table in LDS, 16 bits a slot (so that 2 x 14 images fit beside it): src (10 bits: an image word below 1024), then 5 bits that are
+// the shift of a BIT slot or, under the word flag (bit 15), "two words" in their lowest bit.  The host checks that the circuit's table can
+// be said that way (b3w_fill_table_ok: word slots never shift) before it offers these variants.
+__device__ __forceinline__ uint16_t fill_entry16(uint32_t e) {
+  const uint32_t src = e & 0xFFFu, sh = (e >> 12) & 31u, mode = (e >> 17) & 3u;
+  return (uint16_t)(mode == B3W_MODE_BIT ? (src | sh << 10) : (src | (mode == B3W_MODE_W64 ? 1u : 0u) << 10 | 0x8000u));
+}
+__device__ __forceinline__ void fill_store(uint32_t e16, uint32_t w0, uint32_t w1, uint32_t par, bool in, uint8_t *p) {
+  const uint32_t f = (e16 >> 10) & 31u;
+  const bool word = (e16 & 0x8000u) != 0;
+  uint4 v;
+  v.x = par ? 0u : (word ? w0 : (w0 >> f) & 1u);
+  v.y = (!par && word && (f & 1u)) ? w1 : 0u;
+  v.z = 0; v.w = 0;
+  if (in) store16<false>(p, v);
+}
+
+// A body's public outputs and status go out through a STORING wave (from the image: O[16] is part of it), not through the tracer:
+// the tracer's vector-memory counter then holds loads only — behind a saturated write stream a store is acknowledged microseconds
+// later, and the tracer would wait for its own output stores in order before it may use the next half's records.
+__device__ __forceinline__ void fill_report(const uint32_t *img, uint32_t w, uint32_t lane, uint32_t *__restrict__ pub, int32_t *__restrict__ status) {
+  if (pub && lane < 16) pub[(uint64_t)w * 16 + lane] = img[B3W_A_O + lane];
+  if (status && lane == 16) status[w] = 0;                                  // canonical u32 inputs cannot fail an assert
+}
+
+// the tracer's half: records of `cnt` bodies (w_of(k)) from registers into the images, the traces, the outputs of the bodies this
+// workgroup reports (rep_of(k)); while it traces, the NEXT half's records are already on their way (a dependent global load costs
+// as much as the whole trace)
+template <int NH>
+struct TracerRecs { uint32_t r[(NH * 28 + 63) / 64]; };
+template <int NH, typename WOf>
+__device__ __forceinline__ void tracer_load(TracerRecs<NH> &t, const uint32_t *__restrict__ recs, uint32_t cnt, uint32_t lane, WOf w_of) {
+#pragma unroll
+  for (int c = 0; c < (NH * 28 + 63) / 64; ++c) {
+    const uint32_t i = lane + 64u * c, k = i / 28, j = i - k * 28;
+    t.r[c] = k < cnt ? recs[(uint64_t)w_of(k) * 28 + j] : 0u;
+  }
+}
+template <int NH>
+__device__ __forceinline__ void tracer_put(const TracerRecs<NH> &t, uint32_t *half, uint32_t cnt, uint32_t lane) {
+#pragma unroll
+  for (int c = 0; c < (NH * 28 + 63) / 64; ++c) {
+    const uint32_t i = lane + 64u * c, k = i / 28, j = i - k * 28;
+    if (k < cnt) half[k * B3W_LDS_WORDS_COMP + B3W_A_H + j] = t.r[c];
+  }
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+  __builtin_amdgcn_wave_barrier();
+}
+
+// The deal: the buffer is cut into absolute 128 KiB REGIONS of 32 blocks; the eight workgroups of a group (one per XCD) share a region,
+// workgroup x storing its blocks = x (mod 8) — four steps —, and the 32 groups take 32 consecutive regions: chip-wide ONE contiguous
+// 4 MiB window that moves on every four steps.  A region lies in one body or across the border of two: the UNIT of work is
+// (region, body), NH units per half of the image buffer.
+// The units a workgroup's group visits are listed by the TRACER, 64 region visits at a time (a lane per visit: which body reaches into
+// the region — one integer division —, does a second one start in it; a ballot numbers the units), into a ring of descriptors in LDS
+// that the storing waves read: a wave walking the regions by itself spends more scalar branches per unit than the unit has stores.
+// All positions in SLOT units (32 bytes) from the start of the region that holds the buffer's first byte: 32-bit arithmetic (the
+// launch checks n * pitch < 2^37 bytes).
+#define B3W_RF_RING 256
+struct RegionList {
+  uint32_t n, body32, pitch32, off0, end;   // slots per body, from body to body, of the first body's start, one past the last body's last slot
+  uint32_t grp, v_next, produced;           // this workgroup's group; next visit to list; units listed so far
+  bool done;
+};
+__device__ __forceinline__ void region_list_batch(RegionList &s, uint2 *ring, uint32_t lane) {
+  const uint32_t v = s.v_next + lane, j = s.grp + 32u * v;
+  const bool valid = (uint64_t)j << 12 < s.end;
+  const uint32_t rs = j << 12, re = rs + 4096u;
+  const uint32_t w_lo = (valid && rs >= s.off0 + s.body32) ? (rs - s.off0 - s.body32) / s.pitch32 + 1u : 0u;   // bodies that end before the region
+  const uint32_t bs = s.off0 + w_lo * s.pitch32;
+  const bool e1 = valid && w_lo < s.n && bs < re;                       // (bs >= re: the region lies in a gap between two bodies, pitch > body)
+  const bool e2 = e1 && w_lo + 1 < s.n && bs + s.pitch32 < re;          // a second body starts in the region
+  const uint64_t b1 = __builtin_amdgcn_ballot_w64(e1), b2 = __builtin_amdgcn_ballot_w64(e2), lt = (1ull << lane) - 1;
+  const uint32_t pos = s.produced + __builtin_popcountll(b1 & lt) + __builtin_popcountll(b2 & lt);
+  // descriptor: x = body | starts-here << 31, y = bytes from the body's start to the region's (negative: the body starts inside it)
+  if (e1) ring[pos % B3W_RF_RING] = make_uint2(w_lo | (bs >= rs ? 0x80000000u : 0u), (uint32_t)((int32_t)(rs - bs) << 5));
+  if (e2) ring[(pos + 1) % B3W_RF_RING] = make_uint2((w_lo + 1) | 0x80000000u, (uint32_t)((int32_t)(rs - bs - s.pitch32) << 5));
+  s.produced = uni(s.produced + (uint32_t)__builtin_popcountll(b1) + (uint32_t)__builtin_popcountll(b2));
+  s.v_next += 64;
+  s.done = s.done || __builtin_amdgcn_ballot_w64(!valid) != 0;
+}
+
+template <int NH>
+__global__ __launch_bounds__(320, 1) void b3w_compression_regionfill_kernel(const uint32_t *__restrict__ recs, uint32_t n,
+                                                                            uint8_t *__restrict__ out, uint64_t pitch,
+                                                                            const uint32_t *__restrict__ table, uint32_t nwit,
+                                                                            uint32_t *__restrict__ pub, int32_t *__restrict__ status) {
+  constexpr int WORDS = B3W_LDS_WORDS_COMP, R = 4;
+  extern __shared__ __attribute__((aligned(16))) uint32_t bf_lds[];
+  __shared__ uint2 ring[B3W_RF_RING];                                       // unit descriptors, unit k at k % ring
+  __shared__ uint32_t cnt_ring[4];                                          // units of half h at h % 4
+  uint16_t *tab = reinterpret_cast<uint16_t *>(bf_lds);
+  uint32_t *lds = bf_lds + ((nwit + 7u) & ~7u) / 2;
+  const uint32_t wave = uni(threadIdx.x >> 6), lane = threadIdx.x & 63u;
+  const uint32_t x = blockIdx.x & 7u, grp = blockIdx.x >> 3;              // XCD residue; group (32 of them: gridDim.x = 256)
+  const uint32_t body = 32u * nwit;
+  for (uint32_t i = threadIdx.x; i < nwit; i += 320) tab[i] = fill_entry16(table[i]);
+  __syncthreads();
+  if (wave == 4) {
+    // ---- TRACER: lists the units two halves ahead, loads the records one half ahead, traces half h into image half h & 1; one barrier
+    // per half, the last one for a half that is not full (possibly empty)
+    const uint32_t q = lane >> 2, col = lane & 3;
+    RegionList rl;
+    rl.n = n; rl.body32 = nwit; rl.pitch32 = (uint32_t)(pitch >> 5);
+    rl.off0 = (uint32_t)((reinterpret_cast<uint64_t>(out) & ((1ull << 17) - 1)) >> 5);
+    rl.end = rl.off0 + (n - 1) * rl.pitch32 + rl.body32;
+    rl.grp = grp; rl.v_next = 0; rl.produced = 0; rl.done = false;
+    auto list_until = [&](uint32_t target) {
+      while (!rl.done && rl.produced < target) region_list_batch(rl, ring, lane);
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+    };
+    auto cnt_of = [&](uint32_t h) { return rl.produced <= h * NH ? 0u : (rl.produced - h * NH < (uint32_t)NH ? rl.produced - h * NH : (uint32_t)NH); };
+    TracerRecs<NH> tr;
+    list_until(2 * NH);
+    tracer_load<NH>(tr, recs, cnt_of(0), lane, [&](uint32_t k) { return ring[k % B3W_RF_RING].x & 0x7FFFFFFFu; });
+    for (uint32_t h = 0;; ++h) {
+      uint32_t *half = lds + (h & 1) * NH * WORDS;
+      list_until((h + 3) * NH);                                             // (ring: at most 3 NH + 127 units between the oldest in use and the newest)
+      const uint32_t cnt = cnt_of(h);
+      if (lane == 0) cnt_ring[h & 3] = cnt;
+      tracer_put<NH>(tr, half, cnt, lane);
+      tracer_load<NH>(tr, recs, cnt_of(h + 1), lane, [&](uint32_t k) { return ring[((h + 1) * NH + k) % B3W_RF_RING].x & 0x7FFFFFFFu; });
+      if (q < cnt) trace_compression(half + q * WORDS, col, nullptr);       // (outputs: the storers', see fill_report)
+      __syncthreads();
+      if (cnt < (uint32_t)NH) break;
+    }
+    return;
+  }
+  // ---- STORERS: per half, after its barrier: the units' descriptors from the ring; table words one unit ahead
+  const uint32_t par = lane & 1u;
+  const uint32_t lane_off = (x << 12) + (wave << 10) + (lane << 4);         // this lane's byte offset into a region in step 0; step r: + r * 32 KiB
+  auto read_unit = [&](uint32_t k, uint32_t &wq, int32_t &rel0, uint32_t (&e)[R]) {
+    const uint2 d = ring[k % B3W_RF_RING];
+    wq = uni(d.x);
+    rel0 = (int32_t)uni(d.y) + (int32_t)lane_off;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const uint32_t rel = (uint32_t)(rel0 + (int32_t)(r << 15));
+      e[r] = tab[rel < body ? rel >> 5 : 0u];
+    }
+  };
+  auto store_unit = [&](uint32_t wq, int32_t rel0, const uint32_t (&e)[R], const uint32_t *img) {
+    uint32_t w0[R], w1[R];
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const uint32_t *L = img + (e[r] & 0x3FFu);
+      w0[r] = L[0]; w1[r] = L[1];
+    }
+    const uint32_t w = wq & 0x7FFFFFFFu;
+    if ((wq >> 31) && x == 0 && wave == 0) fill_report(img, w, lane, pub, status);   // the unit in which the body starts reports for it
+    uint8_t *dst = out + (uint64_t)w * pitch;
+#pragma unroll
+    for (int r = 0; r < R; ++r) {
+      const uint32_t rel = (uint32_t)(rel0 + (int32_t)(r << 15));
+      fill_store(e[r], w0[r], w1[r], par, rel < body, dst + rel);
+    }
+  };
+  for (uint32_t h = 0;; ++h) {
+    __syncthreads();                                                         // image half h & 1, descriptors and count of half h are there
+    const uint32_t cnt = uni(cnt_ring[h & 3]);
+    const uint32_t *half = lds + (h & 1) * NH * WORDS;
+    uint32_t wa = 0, wb = 0, ea[R], eb[R];
+    int32_t ra = 0, rb = 0;
+    if (cnt) read_unit(h * NH, wa, ra, ea);
+    for (uint32_t i = 0; i < cnt; i += 2) {
+      if (i + 1 < cnt) read_unit(h * NH + i + 1, wb, rb, eb);
+      store_unit(wa, ra, ea, half + i * WORDS);
+      if (i + 1 >= cnt) break;
+      if (i + 2 < cnt) read_unit(h * NH + i + 2, wa, ra, ea);
+      store_unit(wb, rb, eb, half + (i + 1) * WORDS);
+    }
+    if (cnt < (uint32_t)NH) break;
+  }
+}
+
 }  // namespace
 
 // ------------------------------------------------------------------ launch
@@ -930,7 +1125,7 @@ extern "C" int b3w_launch_batch(int kind, int variant, const uint32_t *d_recs, u
                                 int32_t *d_status, const void *d_aux, uint32_t *d_scratch, uint32_t scratch_cap,
                                 hipStream_t stream) {
   if (n == 0) return 0;
-  if (variant >= B3W_VARIANT_SWEEP) {
+  if (variant >= B3W_VARIANT_SWEEP && variant < B3W_VARIANT_REGIONFILL) {
     // TRACE kernel -> scratch, SWEEP kernel -> bodies, in chunks of scratch_cap witnesses
     if (!d_scratch || scratch_cap != (1u << B3W_SWEEP_LOGC)) return -4;
     if (kind != B3W_KIND_COMP && !d_aux) return -3;
@@ -949,6 +1144,31 @@ extern "C" int b3w_launch_batch(int kind, int variant, const uint32_t *d_recs, u
     }
     return (int)hipGetLastError();
   }
+#define B3W_FILL_NH 14
+#define B3W_FILL_SMEM(nwit) ((size_t)(((nwit) + 7u) & ~7u) * 2 + (size_t)(2 * B3W_FILL_NH * B3W_LDS_WORDS_COMP + 4) * 4)
+  if (variant == B3W_VARIANT_REGIONFILL) {
+    // 256 workgroups (one per CU; workgroup i on XCD i % 8); 32-byte aligned bodies (a lane pair is one slot); the compression circuit
+    if (kind != B3W_KIND_COMP) return -1;
+    if ((reinterpret_cast<uintptr_t>(d_out) & 31) || (pitch & 31) || pitch >= (1ull << 30)) return -5;
+    if (32ull * nwit < (1ull << 17) || (uint64_t)n * pitch + (1ull << 20) >= (1ull << 37)) return -5;      // a region meets two bodies at most; 32-bit slot positions
+    const size_t smem = B3W_FILL_SMEM(nwit);                     // slot table (16 bits a slot) + 2 x NH images
+    constexpr size_t B3W_FILL_MAX_SMEM = 160 * 1024 - 4096;      // (+ the kernel's static descriptor ring)
+    if (smem > B3W_FILL_MAX_SMEM) return -5;
+    static std::atomic<uint64_t> attr_done{0};                   // per device: one bit per ordinal, as for the sweep kernels
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const uint64_t bit = 1ull << (dev & 63);
+    if (!(attr_done.load(std::memory_order_acquire) & bit)) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&b3w_compression_regionfill_kernel<B3W_FILL_NH>),
+                                         hipFuncAttributeMaxDynamicSharedMemorySize, (int)B3W_FILL_MAX_SMEM);
+      if (e != hipSuccess) return (int)e;
+      attr_done.fetch_or(bit, std::memory_order_release);
+    }
+    hipLaunchKernelGGL((b3w_compression_regionfill_kernel<B3W_FILL_NH>), dim3(B3W_REGIONFILL_GRID), dim3(320), smem, stream, d_recs, n, d_out, pitch,
+                       d_table, nwit, d_pub, d_status);
+    return (int)hipGetLastError();
+  }
+  if (variant > B3W_VARIANT_REGIONFILL) return -1;
   // bodies that start at the same offset into a 128-byte line are `stride` apart (WaveBodies); a wave takes W of them
   const uint32_t pm = (uint32_t)(pitch >> 5) & 3u, stride = (pitch & 31) ? 1u : pm == 0 ? 1u : pm == 2 ? 2u : 4u;
 #define B3W_GRID(WV) dim3((n + stride * WV - 1) / (stride * WV) * stride)

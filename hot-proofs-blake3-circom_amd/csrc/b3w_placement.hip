@@ -358,7 +358,7 @@ extern "C" int b3w_place_alloc(int device, uint64_t bytes, int want_mixed, void 
     }
     return -1;
   };
-  bool found = false, alone1 = true;
+  bool found = false, alone1 = true, single_class = false;
   int alone = -1;
   std::vector<Cand> got;
   got.swap(p->spare);                                          // labelled earlier, still mapped in their probe slots
@@ -387,6 +387,28 @@ extern "C" int b3w_place_alloc(int device, uint64_t bytes, int want_mixed, void 
       sort_in(c);
     }
     found = p->refs && (alone = split(alone1)) >= 0;
+    // want_mixed == 2 (harness, B3W_PLACEMENT=single): every piece from ONE class — the buffer a plain hipMalloc is on an unlucky day,
+    // made on purpose, so that the store shapes meant for caller-owned buffers can be developed and measured on any box
+    if (want_mixed == 2 && p->refs) {
+      auto biggest = [&] { int b = 0; for (int x = 1; x < 3; x++) if (cls[x].size() > cls[b].size()) b = x; return b; };
+      while (cls[biggest()].size() < nh && budget && wall_s() <= deadline) {
+        Cand c{};
+        if (!create_handle(p, &c.h)) break;
+        budget--;
+        if (!map_new(p, c)) { (void)hipMemRelease(c.h); break; }
+        c.label = label_slot(p, c.slot);
+        sort_in(c);
+      }
+      const int b = biggest();
+      if (cls[b].size() >= nh) {
+        std::vector<Cand> keep(cls[b].end() - nh, cls[b].end());
+        cls[b].resize(cls[b].size() - nh);
+        for (auto *v : {&cls[0], &cls[1], &cls[2]}) { extra.insert(extra.end(), v->begin(), v->end()); v->clear(); }
+        cls[b] = keep;                                         // the plain branch below takes these nh pieces first
+        single_class = true;
+      }
+      found = false;
+    }
     t_walk = wall_s() - tw0;
   }
   for (const Cand &c : got) sort_in(c);                        // (search skipped)
@@ -491,7 +513,7 @@ extern "C" int b3w_place_alloc(int device, uint64_t bytes, int want_mixed, void 
       pl->va_bytes = (size_t)nh * HANDLE;
       pl->pieces = order;
       pl->device = device;
-      pl->mixed = found ? 1 : 0;
+      pl->mixed = found ? 1 : single_class ? -1 : 0;           // (-1: one class on purpose; reported as plain)
     }
   }
   if (rc != 0) give_back(p, order);
@@ -500,7 +522,7 @@ extern "C" int b3w_place_alloc(int device, uint64_t bytes, int want_mixed, void 
   if (rc != 0) return rc;
   registry().push_back(pl);
   *out = pl->va;
-  if (mixed) *mixed = pl->mixed;
+  if (mixed) *mixed = pl->mixed > 0 ? pl->mixed : 0;
   if (rates) { rates[0] = (float)p->lo; rates[1] = (float)p->hi; }
   return 0;
 }
@@ -516,7 +538,9 @@ extern "C" int b3w_place_free(void *ptr) {
   (void)hipSetDevice(pl->device);
   {
     B3wCaptureRelaxed relaxed;                               // (b3w_capture.h: hipDeviceSynchronize is refused while ANY stream captures)
-    b3w_device_wait();                                       // nothing may still write what is unmapped next
+    Pool *pw = pool_for(pl->device);                         // nothing may still write what is unmapped next
+    const hipStream_t mine[1] = {pw ? pw->stream : nullptr};
+    (void)b3w_device_wait(mine, pw && pw->stream ? 1 : 0);   // (without a spare and without streams: hipDeviceSynchronize; b3w_capture.h)
   }
   for (size_t s = 0; s < pl->pieces.size(); s++) (void)hipMemUnmap(static_cast<uint8_t *>(pl->va) + s * HANDLE, HANDLE);   // the range is not used again
   Pool *p = pool_for(pl->device);

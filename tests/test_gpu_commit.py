@@ -669,3 +669,43 @@ def test_gated_commitments_of_a_many_slice_pass_equal_the_commit_only_points(use
     assert int(out["status"].abs().sum().item()) == 0 and int(out["violations"].abs().sum().item()) == 0
     assert out["root"].cpu().numpy().view(np.uint32).tobytes() == blake3_ref.blake3(data.tobytes())
     r1cs.close(); key.close(); ctx.close()
+
+
+def test_automatic_window_falls_back_when_its_table_does_not_fit(monkeypatch):
+    """the automatic window is a guess from ONE reading of the free memory; when the 18-bit table then fails to allocate
+    (other ranks sizing their keys on the same GPU, torch or the placement pool in between, fragmentation) the key must come out with 16
+    or 12 bits instead of B3W_E_HIP.  Here: the choice is told to believe in memory that a torch tensor already holds."""
+    import torch
+    m = T.pkg()
+    ctx = m.Context("nova_vesta", 0)
+    gens = E.points_to_bytes(E.random_points("vesta", ctx.witness_size))
+    torch.cuda.empty_cache()
+    m.lib().b3w_bodies_trim()
+    free, total = torch.cuda.mem_get_info(0)
+    # an unfolded nova key: 51 GB at 18 bits, 13 GB at 16.  Leave 30 GB: too little for the first, enough for the second.
+    hog = torch.empty(max(free - (30 << 30), 1 << 20), dtype=torch.uint8, device="cuda:0")
+    monkeypatch.setenv("B3W_COMMIT_ASSUME_FREE_GIB", "1000")
+    key = m.CommitKey(ctx, "vesta", gens, 0, 0)
+    assert key.window == 16, key.window
+    # an explicit window that does not fit is the caller's decision: an error, no fallback
+    with pytest.raises(m.B3WError):
+        m.CommitKey(ctx, "vesta", gens, 0, 18)
+    torch.cuda.synchronize()
+    # the key that came out works: same points as an explicit 16-bit key
+    n = 8
+    recs = T.workloads().config3_nova(n)
+    d_recs = torch.from_numpy(recs.view(np.int32)).to("cuda:0")
+    s = torch.cuda.current_stream().cuda_stream
+    monkeypatch.delenv("B3W_COMMIT_ASSUME_FREE_GIB")
+    del hog
+    torch.cuda.empty_cache()
+    ref = m.CommitKey(ctx, "vesta", gens, 0, 16)
+    out = []
+    for k in (key, ref):
+        p = torch.zeros((n, 64), dtype=torch.uint8, device="cuda:0")
+        st = torch.zeros(n, dtype=torch.int32, device="cuda:0")
+        k.commit_records_device(d_recs.data_ptr(), n, p.data_ptr(), st.data_ptr(), 0, s)
+        torch.cuda.synchronize()
+        out.append(p.cpu().numpy())
+    assert np.array_equal(out[0], out[1]) and int(out[0].max(axis=1).min()) > 0
+    key.close(); ref.close(); ctx.close()

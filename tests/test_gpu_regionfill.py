@@ -1,0 +1,139 @@
+"""The fill-ordered fused kernel for caller-owned buffers (B3W_VARIANT=200, csrc/b3w_kernels.hip "REGIONFILL") against the oracle: same
+bit-exact bar as the other launch shapes, plus the cases its deal has of its own — bodies that start and end anywhere inside a 128 KiB
+region, regions shared by two bodies, gaps between bodies (padded pitch), buffers that start anywhere in a region, fewer bodies than
+workgroup groups, many halves of the image buffer per workgroup, and the bytes around the bodies left alone."""
+import os
+import numpy as np
+import pytest
+import b3w_testlib as T
+
+pytestmark = pytest.mark.gpu
+FILL = 0x3C
+
+
+@pytest.fixture(scope="module")
+def m():
+    return T.pkg()
+
+
+def _fill_ctx(m, circuit="compression"):
+    os.environ["B3W_VARIANT"] = "200"
+    try:
+        return m.Context(circuit, 0)
+    finally:
+        del os.environ["B3W_VARIANT"]
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 31, 33, 97, 300])
+def test_regionfill_matches_oracle_with_outputs(m, n):
+    recs = T.workloads().config2_compression(n, first=123)
+    bad, want = T.oracle_batch_u32("compression", recs)
+    assert bad == 0
+    want = want.copy()
+    ctx = _fill_ctx(m)
+    for pitch in (0, 771072, 770976 + 32, 770976 + 4096 + 64):
+        b = m.Batch(ctx, n, pitch)
+        b.run(recs)
+        pub, st = b.outputs()
+        assert (st == 0).all()
+        assert np.array_equal(pub, want.reshape(n, -1, 32)[:, 1:17, :4].copy().view(np.uint32).reshape(n, 16)), (n, pitch)
+        for i in range(n):
+            got = b.fetch(i)
+            assert np.array_equal(got, want[i]), (n, pitch, i, np.nonzero(got != want[i])[0][:8] // 32)
+        b.close()
+    ctx.close()
+
+
+def test_regionfill_every_start_in_a_region_and_untouched_bytes(m):
+    """The buffer starts at 32-byte steps through a 4 KiB block and at block steps through a region; pitches that put body borders
+    everywhere; every byte of every body equals the oracle's, every byte outside — before the first body, in the gaps, after the last —
+    stays as it was."""
+    import torch
+    n = 19
+    recs = T.workloads().config2_compression(n, first=5)
+    _, want = T.oracle_batch_u32("compression", recs)
+    want = want.copy()
+    ctx = _fill_ctx(m)
+    body = ctx.body_bytes
+    dev = torch.device("cuda:0")
+    d_recs = torch.from_numpy(recs.view(np.int32)).to(dev)
+    s = torch.cuda.current_stream().cuda_stream
+    margin = 1 << 17
+    for pad in (0, 32, 992, 4096, 131072 + 160):
+        pitch = body + pad
+        for skew in (0, 32, 4064, 4096, 65536 + 96, 131072 - 32):
+            buf = torch.full((2 * margin + n * pitch + 4096,), FILL, dtype=torch.uint8, device=dev)
+            lo = margin - (buf.data_ptr() % margin) + skew              # the first body `skew` bytes into a region
+            d_st = torch.full((n,), -1, dtype=torch.int32, device=dev)
+            d_pub = torch.zeros((n, 16), dtype=torch.int32, device=dev)
+            ctx.run_device(d_recs.data_ptr(), n, buf.data_ptr() + lo, pitch, d_pub.data_ptr(), d_st.data_ptr(), s)
+            torch.cuda.synchronize()
+            assert int(d_st.abs().sum().item()) == 0
+            host = buf.cpu().numpy()
+            assert (host[:lo] == FILL).all(), (pad, skew, "bytes before the first body were written")
+            for i in range(n):
+                got = host[lo + i * pitch: lo + i * pitch + body]
+                assert np.array_equal(got, want[i]), (pad, skew, i, np.nonzero(got != want[i])[0][:8])
+                gap = host[lo + i * pitch + body: lo + (i + 1) * pitch] if i + 1 < n else host[lo + i * pitch + body:]
+                assert (gap == FILL).all(), (pad, skew, i, "bytes after the body were written")
+            assert np.array_equal(d_pub.cpu().numpy().view(np.uint32), want.reshape(n, -1, 32)[:, 1:17, :4].copy().view(np.uint32).reshape(n, 16))
+    ctx.close()
+
+
+def test_regionfill_refuses_what_it_cannot_take(m):
+    """16-byte aligned bodies (a lane pair is one 32-byte slot) and the nova circuits: B3W_E_BAD_ARGUMENT, nothing written."""
+    import torch
+    dev = torch.device("cuda:0")
+    s = torch.cuda.current_stream().cuda_stream
+    ctx = _fill_ctx(m)
+    recs = T.workloads().config2_compression(4)
+    d_recs = torch.from_numpy(recs.view(np.int32)).to(dev)
+    buf = torch.full((4 * ctx.body_bytes + 64,), FILL, dtype=torch.uint8, device=dev)
+    with pytest.raises(m.B3WError):
+        ctx.run_device(d_recs.data_ptr(), 4, buf.data_ptr() + 16, 0, 0, 0, s)
+    torch.cuda.synchronize()
+    assert bool((buf == FILL).all().item())
+    ctx.close()
+    nova = _fill_ctx(m, "nova_vesta")
+    nrec = torch.from_numpy(T.workloads().config3_nova(4).view(np.int32)).to(dev)
+    nb = torch.empty(4 * nova.body_bytes, dtype=torch.uint8, device=dev)
+    with pytest.raises(m.B3WError):
+        nova.run_device(nrec.data_ptr(), 4, nb.data_ptr(), 0, 0, 0, s)
+    nova.close()
+
+
+def test_regionfill_full_config2_batch_on_a_plain_buffer_and_the_autotuner(m):
+    """BASELINE config 2 (4 096 witnesses) into a caller-owned torch buffer: all public outputs against a plain BLAKE3 compression, 600
+    bodies byte for byte against the oracle (the first and last of the buffer, a run across the middle), the whole buffer equal to the
+    default variant's; and b3w_batch_autotune_device offers the variant on such a buffer (0, 3, 100 or 200) and stays bit-exact."""
+    import torch
+    from test_gpu_parity import _blake3_compress_np
+    dev = torch.device("cuda:0")
+    s = torch.cuda.current_stream().cuda_stream
+    n = 4096
+    recs = T.workloads().config2_compression(n)
+    d_recs = torch.from_numpy(recs.view(np.int32)).to(dev)
+    ctx = _fill_ctx(m)
+    d_bodies = torch.full((n, ctx.body_bytes), 9, dtype=torch.uint8, device=dev)
+    d_pub = torch.zeros((n, 16), dtype=torch.int32, device=dev)
+    d_st = torch.full((n,), -1, dtype=torch.int32, device=dev)
+    ctx.run_device(d_recs.data_ptr(), n, d_bodies.data_ptr(), 0, d_pub.data_ptr(), d_st.data_ptr(), s)
+    torch.cuda.synchronize()
+    assert (d_st == 0).all().item()
+    want_pub = _blake3_compress_np(recs[:, 0:8], recs[:, 8:24], recs[:, 24], recs[:, 25], recs[:, 26], recs[:, 27])
+    assert np.array_equal(d_pub.cpu().numpy().view(np.uint32), want_pub)
+    idx = np.array(list(range(200)) + list(range(1900, 2100)) + list(range(n - 200, n)))
+    _, want = T.oracle_batch_u32("compression", recs[idx])
+    assert np.array_equal(d_bodies[torch.from_numpy(idx).to(dev)].cpu().numpy(), want)
+    ref = m.Context("compression", 0)
+    d_ref = torch.empty((n, ctx.body_bytes), dtype=torch.uint8, device=dev)
+    ref.run_device(d_recs.data_ptr(), n, d_ref.data_ptr(), 0, 0, 0, s)
+    torch.cuda.synchronize()
+    assert torch.equal(d_ref, d_bodies)
+    v, ms = ref.autotune_device(d_recs.data_ptr(), n, d_ref.data_ptr(), 0, 0, d_st.data_ptr(), s)
+    assert v in (0, 3, 100, 200) and ms > 0
+    d_ref.fill_(1)
+    ref.run_device(d_recs.data_ptr(), n, d_ref.data_ptr(), 0, 0, 0, s)
+    torch.cuda.synchronize()
+    assert torch.equal(d_ref, d_bodies)
+    ref.close(); ctx.close()
