@@ -54,11 +54,22 @@ def reference_wasm(circuit, reference_dir, seconds):
         return None
 
 
-WITNESS_KERNELS = ("b3w_compression_kernel", "b3w_nova_kernel", "b3w_sweep_kernel")
+WITNESS_KERNELS = ("b3w_compression_kernel", "b3w_nova_kernel", "b3w_sweep_kernel", "b3w_compression_regionfill_kernel")
+
+
+def kernel_path(v):
+    """the kernel PATH a variant number stands for: the traffic per launch is a property of the path, not of the body-stream shape"""
+    return "fused" if v is None or v < 100 else "sweep" if v < 200 else "fill"
+
+
+def variant_name(v):
+    return {"fused": f"fused ({v})", "sweep": "sweep (TRACE + SWEEP kernels)", "fill": "fill-ordered fused (REGIONFILL, 200)"}[kernel_path(v)]
 # store-only shapes of b3w_bodies_store_rate the batch line reads `achieved` against (roofline.store_ceiling)
-STORE_SHAPES = {"streams_w4": 0, "streams_w8": 1, "fill": 2}
+STORE_SHAPES = {"streams_w4": 0, "streams_w8": 1, "fill": 2, "paced_persistent_w4x512": 3, "paced_persistent_w8x512": 4, "paced_streams_w8": 5}
 STORE_SHAPES_WHAT = ("b3w_bodies_store_rate: 20 passes of store-only kernels over the same n bodies — body streams (one wave per 4 / 8 bodies, 1 KiB per body "
-                     "and step: the fused kernels' store shape) and the runtime's fill shape")
+                     "and step: the fused kernels' store shape), the runtime's fill shape, and the PACED shapes (four vector-ALU instructions in front of every "
+                     "store; 512 persistent waves taking groups of 4 / 8 bodies, or one wave per 8 bodies) that the round-6 sweep of 100 shapes found fastest "
+                     "(tools/ubench/store_sweep.hip, profiles/r06/store_sweep*.log): an unpaced store-only kernel fills HBM slower than the witness kernel")
 
 
 def live_traffic(args):
@@ -483,6 +494,7 @@ def bench_chain(args, m, torch, dist, dev, world, rank, local_rank):
                                    f"({dist.get_backend()}), inside every timed pass",
                        "exchange_mode": ("every" if args.exchange != "none" else "none") if world > 1 else "none",
                        "exchange_impl": ("native b3w_comm (" + comm.transport + ")" if comm is not None else "torch.distributed") if world > 1 else "none",
+                       "comm_size": (int(m.lib().b3w_comm_size(comm.handle)) if comm is not None else dist.get_world_size()) if world > 1 else 1,
                        "exchange_ms_per_rank": {"chunk_cvs": [x[0] for x in ex_all], "h_out": [x[1] for x in ex_all],
                                                 "what": "HIP events on the compute stream around staging + collective + scatter, last timed pass"},
                        "pass_ms_per_rank": pass_ms, "first_pass_s": round(first_pass_s, 3), **place_cost,
@@ -721,7 +733,11 @@ def main():
         bodies = alloc()
     d_bodies = bodies                                      # .data_ptr() like a tensor
     place_cost = dict(placement_cost(ctx), placement_alloc_s=round(time.perf_counter() - t_alloc, 3))
-    if args.variant is None:
+    if args.traffic_child is not None and args.variant is None:
+        # (the counter passes run on a plain buffer, where an autotune would pick the fill-ordered kernel: they count the library's DEFAULT
+        # launch shape instead — a fused body-stream variant, the path a placed buffer's autotune ends on; the parent checks that it did)
+        chosen = 0
+    elif args.variant is None:
         chosen, best_ms = ctx.autotune_device(d_recs.data_ptr(), n, bodies.ptr, pitch, d_pub.data_ptr(), d_status.data_ptr(),
                                               stream.cuda_stream)
     else:                                                   # (autotune leaves the winner selected in ctx)
@@ -730,7 +746,7 @@ def main():
         for _ in range(2 + 8):
             launch(post=False)
         torch.cuda.synchronize()
-        print(json.dumps({"traffic_child": True, "variant": chosen, "launches": 8, "kernels_per_launch": 2 if chosen >= 100 else 1}))
+        print(json.dumps({"traffic_child": True, "variant": chosen, "launches": 8, "kernels_per_launch": 2 if kernel_path(chosen) == "sweep" else 1}))
         return
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     for _ in range(2):
@@ -823,7 +839,7 @@ def main():
             ctx_plain.time_device(d_recs.data_ptr(), n, d_plain.data_ptr(), pitch, d_pub.data_ptr(), d_status.data_ptr(), stream.cuda_stream, 5)
             ms_plain = ctx_plain.time_device(d_recs.data_ptr(), n, d_plain.data_ptr(), pitch, d_pub.data_ptr(), d_status.data_ptr(), stream.cuda_stream, 20)
             ach_plain = BYTES_PER_WITNESS[circuit] * n / (ms_plain * 1e-3) / 1e9
-            plain = {"kernel_ms": ms_plain, "achieved": ach_plain, "frac": ach_plain / HBM_PEAK_GBS, "launches": 20, "kernel_variant": v_plain,
+            plain = {"kernel_ms": ms_plain, "achieved": ach_plain, "frac": ach_plain / HBM_PEAK_GBS, "launches": 20, "kernel_variant": variant_name(v_plain),
                      "buffer": "torch.empty = hipMalloc, same records; the launch shape autotuned ON THIS BUFFER (b3w_batch_autotune_device, as an integrator "
                                "with its own allocator would), after the timed region"}
             shapes = STORE_SHAPES
@@ -871,7 +887,7 @@ def main():
         achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
         traffic, traffic_source, traffic_parts = None, None, None
         tf = os.path.join(ROOT, "profiles", "traffic_latest.json")   # PMC passes (WRITE_SIZE/FETCH_SIZE), see profiles/README.md
-        path_of = lambda v: "sweep" if v is not None and v >= 100 else "fused"
+        path_of = kernel_path
         if measured_traffic is not None and any(path_of(v) != path_of(chosen) for v in measured_traffic.get("variants_by_pass", {}).values()):
             # the children autotuned on THEIR (plain) buffers and took another kernel path than the timed one (fused against TRACE + SWEEP: another
             # number of kernels per launch, and the TRACE images' traffic): their bytes are not this run's — quote the recorded passes of the timed path
@@ -885,7 +901,7 @@ def main():
                               "batch on a plain buffer, before the timed region), KiB x 1024, FETCH_SIZE x 2 (MI355X_MICROARCH.md, HBM)")
         elif os.path.exists(tf):
             try:
-                path = "sweep" if chosen >= 100 else "fused"
+                path = kernel_path(chosen)
                 doc = json.load(open(tf))
                 for ent in doc.get("entries", []):
                     if ent.get("circuit") == circuit and ent.get("batch") == n and ent.get("path") == path:
@@ -913,7 +929,7 @@ def main():
                                    f"one step = {inner} launches over the batch",
                        "circuit": circuit, "batch_per_gpu": n, "launches_per_step": inner, "witnesses_per_step": world * n * inner,
                        "timed_region_s": elapsed, "witness_bytes": ctx.body_bytes, "pitch": pitch,
-                       "kernel_variant": "sweep (TRACE + SWEEP kernels)" if chosen >= 100 else f"fused ({chosen})",
+                       "kernel_variant": variant_name(chosen),
                        "verified_on_device": True, "verification": verified,
                        "placement": placements[0], "placement_per_rank": placements,
                        "exchange": "none" if world == 1 else
@@ -925,6 +941,7 @@ def main():
                                        "none": f"no collective inside the timed region ({dist.get_world_size()} ranks, {dist.get_backend()}): kernels only"}[args.exchange],
                        "exchange_mode": args.exchange if world > 1 else "none",
                        "exchange_impl": ("native b3w_comm (" + comm.transport + ")" if comm is not None else "torch.distributed") if world > 1 else "none",
+                       "comm_size": (int(m.lib().b3w_comm_size(comm.handle)) if comm is not None else dist.get_world_size()) if world > 1 else 1,
                        "exchange_ms_per_rank": {"public_outputs": ex_per_rank,
                                                 "what": "one all-gather of the batch's public outputs with nothing else on the device: HIP events around 20, after the timed region"},
                        "devices_per_rank": devices, **place_cost},

@@ -429,7 +429,7 @@ int32_t b3w_batch_run_device(b3w_ctx *ctx, const uint32_t *d_records, uint32_t n
     const bool comp = ctx->desc.kind == B3W_KIND_COMP;
     if (n <= 2560) variant = B3W_VARIANT_SLICED + (n <= (comp ? 32u : 8u) ? 64 : n <= 96 ? 32 : n <= 192 ? 16 : n <= 768 ? 8 : 4);
     else if (comp) variant = n <= 6144 ? 0 : 8;
-    else if (ctx->desc.kind == B3W_KIND_NOVA_O2) variant = n <= 3072 ? 0 : 3;
+    else if (ctx->desc.kind == B3W_KIND_NOVA_O2) variant = n <= 3072 ? 0 : n < 32768 ? 3 : 4;      // (4: 8 bodies a wave on a persistent grid)
     else variant = 0;
   }
   if (variant >= B3W_VARIANT_REGIONFILL && !ctx->fill_ok) { ctx->last_error = "the fill-ordered variant (200) exists for the compression circuit only"; return B3W_E_BAD_ARGUMENT; }
@@ -486,7 +486,7 @@ int32_t b3w_batch_autotune_device(b3w_ctx *ctx, const uint32_t *d_records, uint3
   // variant 8; nova O2: variant 3), the two-kernel sweep, and — compression — the fill-ordered fused kernel: on a placed buffer the body
   // streams win (7.2 against 6.7 TB/s), on a caller's plain buffer the fill order does (6.4 against 5.5; profiles/r06/variant_scan_*.log)
   const int candidates[4] = {0, ctx->desc.kind == B3W_KIND_COMP ? (n > 6144 ? 8 : 3) : ctx->desc.kind == B3W_KIND_NOVA_O2 ? 3 : 0, B3W_VARIANT_SWEEP,
-                             ctx->fill_ok ? B3W_VARIANT_REGIONFILL : 0};
+                             ctx->fill_ok ? B3W_VARIANT_REGIONFILL : ctx->desc.kind == B3W_KIND_NOVA_O2 && n >= 16384 ? 4 : 0};
   int best = ctx->variant;
   float best_ms = 1e30f;
   const int saved = ctx->variant;

@@ -509,7 +509,9 @@ __global__ __launch_bounds__(128 * PAIRS, 1) void b3w_sweep_kernel(const uint32_
 // SL (MODE 0 only): SLICED launch for small batches — `slices` consecutive workgroups take the same W bodies, each recomputes
 // their (cheap) traces and stores 1/slices of the tiles.  A lone body streams at 13 GB/s per wave, so a batch of a few hundred
 // bodies is latency-bound with one wave per body; sliced, it has slices x as many store streams in flight.
-template <int W, bool NT, int MODE, bool SL = false>
+// PERSIST (MODE 0): a FIXED grid (gridDim.x a multiple of the stride) whose waves take the groups of W bodies in turn — however large the
+// batch, the same number of body streams is in flight (used by the nova O2 kernel for very large batches, see b3w_launch_batch).
+template <int W, bool NT, int MODE, bool SL = false, bool PERSIST = false>
 __global__ __launch_bounds__(64) void b3w_compression_kernel(const uint32_t *__restrict__ recs, uint32_t n,
                                                              uint8_t *__restrict__ out, uint64_t pitch,
                                                              const uint32_t *__restrict__ table, uint32_t nwit,
@@ -520,8 +522,9 @@ __global__ __launch_bounds__(64) void b3w_compression_kernel(const uint32_t *__r
   const int lane = threadIdx.x;
   const uint32_t slice = SL ? blockIdx.x % slices : 0u;
   if (SL && slice != 0) { pub = nullptr; status = nullptr; }             // slice 0 reports for the body
-  const WaveBodies wb = wave_bodies<W>(SL ? blockIdx.x / slices : blockIdx.x, stride);
-  if (wb.first >= n) return;                           // the grid is rounded up to whole stride groups: nothing for this wave
+ for (uint32_t bid = blockIdx.x;; bid += gridDim.x) {
+  const WaveBodies wb = wave_bodies<W>(SL ? bid / slices : bid, stride);
+  if (wb.first >= n) return;                           // the grid is rounded up to whole stride groups: nothing (more) for this wave
   const uint32_t wit0 = wb.first;                      // MODE 1 runs with stride 1
   // stage the 28-word records of this wave's witnesses into atoms H M T B D (image words 1..28)
   __shared__ uint32_t ncf[W];      // VERIFY: an input slot of the body is not a plain 32-bit value
@@ -557,6 +560,9 @@ __global__ __launch_bounds__(64) void b3w_compression_kernel(const uint32_t *__r
     publish_counts<W>(cnt, pub, wb, n, ncf);
   } else if (SL) expand<W, WORDS, false, NT>(lds, table, nwit, out, pitch, wb, n, nullptr, true, slice, slices);
   else expand<W, WORDS, false, NT>(lds, table, nwit, out, pitch, wb, n, nullptr, true);
+  if (!PERSIST) return;
+  __syncthreads();                                     // the images are overwritten by the next group's
+ }
 }
 
 
@@ -660,7 +666,7 @@ __device__ __forceinline__ void lds_put256(uint32_t *L, const U256 &v) {
   *reinterpret_cast<uint4 *>(L + 4) = make_uint4(v.l[4], v.l[5], v.l[6], v.l[7]);
 }
 
-template <int KIND, int W, bool NT, int MODE, bool SL = false>
+template <int KIND, int W, bool NT, int MODE, bool SL = false, bool PERSIST = false>
 __global__ __launch_bounds__(64) void b3w_nova_kernel(const uint32_t *__restrict__ recs, uint32_t n,
                                                       uint8_t *__restrict__ out, uint64_t pitch,
                                                       const uint32_t *__restrict__ table, uint32_t nwit,
@@ -674,10 +680,14 @@ __global__ __launch_bounds__(64) void b3w_nova_kernel(const uint32_t *__restrict
   const int lane = threadIdx.x;
   const uint32_t slice = SL ? blockIdx.x % slices : 0u;                  // SLICED launch: see b3w_compression_kernel
   if (SL && slice != 0) { pub = nullptr; status = nullptr; }
-  const WaveBodies wb = wave_bodies<W>(SL ? blockIdx.x / slices : blockIdx.x, stride);
-  if (wb.first >= n) return;                           // the grid is rounded up to whole stride groups: nothing for this wave
-  const uint32_t wit0 = wb.first;                      // MODE 1 runs with stride 1
   __shared__ uint32_t ncf[W];      // VERIFY: an input slot of the body is not a plain 32-bit value
+  U256 P;
+#pragma unroll
+  for (int i = 0; i < 8; ++i) P.l[i] = aux[i];
+ for (uint32_t bid = blockIdx.x;; bid += gridDim.x) {                    // PERSIST: see b3w_compression_kernel
+  const WaveBodies wb = wave_bodies<W>(SL ? bid / slices : bid, stride);
+  if (wb.first >= n) return;                           // the grid is rounded up to whole stride groups: nothing (more) for this wave
+  const uint32_t wit0 = wb.first;                      // MODE 1 runs with stride 1
   if (lane < W) { okf[lane] = 0; domf[lane] = 0; ncf[lane] = 0; }
   if (MODE == 2) __syncthreads();
   for (int i = lane; i < W * 32; i += 64) {
@@ -695,10 +705,6 @@ __global__ __launch_bounds__(64) void b3w_nova_kernel(const uint32_t *__restrict
     }
   }
   __syncthreads();
-
-  U256 P;
-#pragma unroll
-  for (int i = 0; i < 8; ++i) P.l[i] = aux[i];
 
   // ---- A: the 67 IsZero gadgets of each step, one per lane-job
   for (int t = lane; t < 67 * W; t += 64) {
@@ -839,6 +845,9 @@ __global__ __launch_bounds__(64) void b3w_nova_kernel(const uint32_t *__restrict
     publish_counts<W>(cnt, pub, wb, n, ncf);
   } else if (SL) expand<W, WORDS, true, NT>(lds, table, nwit, out, pitch, wb, n, okf, all_ok, slice, slices);
   else expand<W, WORDS, true, NT>(lds, table, nwit, out, pitch, wb, n, okf, all_ok);
+  if (!PERSIST) return;
+  __syncthreads();                                     // images and flags are overwritten by the next group's
+ }
 }
 
 
@@ -1208,6 +1217,9 @@ extern "C" int b3w_launch_batch(int kind, int variant, const uint32_t *d_recs, u
 #define B3W_LAUNCH_NOVA(KV, WV)                                                                           \
   hipLaunchKernelGGL((b3w_nova_kernel<KV, WV, false, 0>), B3W_GRID(WV), dim3(64), lds_pad, stream,          \
                      d_recs, n, d_out, pitch, d_table, nwit, d_pub, d_status, (const uint32_t *)d_aux, stride)
+#define B3W_LAUNCH_NOVA_P(KV, WV, G)                                                                            \
+  hipLaunchKernelGGL((b3w_nova_kernel<KV, WV, false, 0, false, true>), dim3(B3W_GRID(WV).x < (G) ? B3W_GRID(WV).x : (G)), dim3(64), lds_pad, stream, \
+                     d_recs, n, d_out, pitch, d_table, nwit, d_pub, d_status, (const uint32_t *)d_aux, stride)
     if (variant >= B3W_VARIANT_SLICED && variant < B3W_VARIANT_SWEEP) {
       const uint32_t slices = (uint32_t)(variant - B3W_VARIANT_SLICED);
       if (slices < 2 || slices > 64) return -1;
@@ -1225,6 +1237,10 @@ extern "C" int b3w_launch_batch(int kind, int variant, const uint32_t *d_recs, u
         case 1: B3W_LAUNCH_NOVA(B3W_KIND_NOVA_O2, 1); break;
         case 2: B3W_LAUNCH_NOVA(B3W_KIND_NOVA_O2, 4); break;
         case 3: B3W_LAUNCH_NOVA(B3W_KIND_NOVA_O2, 8); break;
+        // 4: W = 8 on a PERSISTENT grid of 512 waves (two per CU) that take the groups of 8 bodies in turn: for batches of tens of
+        // thousands of steps (65 536: 7.13 against 7.04 TB/s; 16 384: 6.91 against 6.99 — profiles/r06/variant_scan_persistent.log, where the
+        // same grid with 4 or 2 bodies a wave, the store-only sweep's best shape, is issue-bound at 5.7 with the kernel's real work)
+        case 4: B3W_LAUNCH_NOVA_P(B3W_KIND_NOVA_O2, 8, 512u); break;
         default: return -1;
       }
     } else {
@@ -1235,6 +1251,7 @@ extern "C" int b3w_launch_batch(int kind, int variant, const uint32_t *d_recs, u
       }
     }
 #undef B3W_LAUNCH_NOVA
+#undef B3W_LAUNCH_NOVA_P
     return (int)hipGetLastError();
   }
   return -2;

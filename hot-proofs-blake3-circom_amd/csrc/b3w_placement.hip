@@ -78,17 +78,27 @@ __global__ __launch_bounds__(64) void b3w_store_streams_kernel(uint8_t *out, uin
     for (uint32_t k = 0; k < pause; ++k) __builtin_amdgcn_s_sleep(1);
   }
 }
-// a writer with a FIXED small footprint: `gridDim.x` single-wave workgroups (a few per CU) that take groups of 8 bodies in turn
-__global__ __launch_bounds__(64) void b3w_store_persistent_kernel(uint8_t *out, uint64_t pitch, uint32_t n, uint32_t tiles) {
+// a writer with a FIXED small footprint: `gridDim.x` single-wave workgroups (a few per CU) that take groups of W bodies in turn.
+// `pace` = dependent vector-ALU instructions in front of every 16-byte store: a store-only kernel without any issues its stores faster than
+// the memory system drains them, and that is NOT the fastest way to fill HBM (round 6, tools/ubench/store_sweep.hip: 512 waves x 4 bodies
+// at pace 4 store 7.29 TB/s into a placed buffer, the same without pacing 6.96 — and the witness kernel, which has ~6 instructions and an
+// LDS read per store by itself, 7.18: the r05 probes were SLOWER than the kernel they were meant to bound)
+__device__ __forceinline__ void store_pace(u32x4 &v, uint32_t k) {
+  uint32_t x = v.z;
+  for (uint32_t i = 0; i < k; ++i) asm volatile("v_add_u32 %0, %0, 1" : "+v"(x));
+  v.z = x;
+}
+template <int W>
+__global__ __launch_bounds__(64) void b3w_store_persistent_kernel(uint8_t *out, uint64_t pitch, uint32_t n, uint32_t tiles, uint32_t pace = 0) {
   const uint32_t lane = threadIdx.x;
-  const u32x4 v = {lane, blockIdx.x, 0, 0};
-  for (uint32_t b0 = blockIdx.x * 8; b0 < n; b0 += gridDim.x * 8) {
-    uint8_t *base[8];
+  u32x4 v = {lane, blockIdx.x, 0, 0};
+  for (uint32_t b0 = blockIdx.x * W; b0 < n; b0 += gridDim.x * W) {
+    uint8_t *base[W];
 #pragma unroll
-    for (int w = 0; w < 8; ++w) base[w] = out + (uint64_t)(b0 + w < n ? b0 + w : n - 1) * pitch + lane * 16;
+    for (int w = 0; w < W; ++w) base[w] = out + (uint64_t)(b0 + w < n ? b0 + w : n - 1) * pitch + lane * 16;
     for (uint32_t g = 0; g < tiles; ++g) {
 #pragma unroll
-      for (int w = 0; w < 8; ++w) *reinterpret_cast<u32x4 *>(base[w] + (uint64_t)g * 1024) = v;
+      for (int w = 0; w < W; ++w) { store_pace(v, pace); *reinterpret_cast<u32x4 *>(base[w] + (uint64_t)g * 1024) = v; }
     }
   }
 }
@@ -643,7 +653,7 @@ extern "C" int b3w_place_gather_launch(const void *table, uint64_t table_bytes, 
 extern "C" int b3w_place_store_launch(uint8_t *buf, uint64_t pitch, uint32_t n, uint32_t body_bytes, int shape, hipStream_t stream) {
   if (!buf || !n || body_bytes < 1024 || pitch < body_bytes) return -(int)hipErrorInvalidValue;
   const uint32_t tiles = body_bytes / 1024;
-  if (shape >= 200) hipLaunchKernelGGL(b3w_store_persistent_kernel, dim3(256u * (uint32_t)(shape - 200)), dim3(64), 0, stream, buf, pitch, n, tiles);   // (shape - 200) waves per CU
+  if (shape >= 200) hipLaunchKernelGGL(b3w_store_persistent_kernel<8>, dim3(256u * (uint32_t)(shape - 200)), dim3(64), 0, stream, buf, pitch, n, tiles, 0u);   // (shape - 200) waves per CU
   else if (shape >= 100) hipLaunchKernelGGL(b3w_store_streams_kernel<8>, dim3((n + 7) / 8), dim3(64), 0, stream, buf, pitch, n, tiles, (uint32_t)(shape - 100));   // paused
   else if (shape == 0) hipLaunchKernelGGL(b3w_store_streams_kernel<4>, dim3((n + 3) / 4), dim3(64), 0, stream, buf, pitch, n, tiles, 0u);
   else if (shape == 1) hipLaunchKernelGGL(b3w_store_streams_kernel<8>, dim3((n + 7) / 8), dim3(64), 0, stream, buf, pitch, n, tiles, 0u);
@@ -652,14 +662,19 @@ extern "C" int b3w_place_store_launch(uint8_t *buf, uint64_t pitch, uint32_t n, 
 }
 
 // GB/s of `iters` pure-store passes over [buf, buf + n * pitch) on `stream` (HIP events; 2 untimed passes first).
-// shape 0: body streams, one wave per 4 bodies; 1: per 8 bodies; 2: the fill shape.  Negative = hipError_t.
+// shape 0: body streams, one wave per 4 bodies; 1: per 8 bodies; 2: the fill shape; 3 / 4: PACED persistent body streams — 512 single-wave
+// workgroups (two per CU) taking groups of 4 / 8 bodies in turn, 4 vector-ALU instructions in front of every store (the best store-only
+// shapes of round 6's sweep on a placed buffer); 5: 8 bodies per wave, paced, one wave per group.  Negative = hipError_t.
 extern "C" int b3w_place_store_rate(uint8_t *buf, uint64_t pitch, uint32_t n, uint32_t body_bytes, int shape, uint32_t iters, hipStream_t stream, double *gbs) {
-  if (!buf || !n || !iters || !gbs || body_bytes < 1024 || pitch < body_bytes || shape < 0 || shape > 2) return -(int)hipErrorInvalidValue;
+  if (!buf || !n || !iters || !gbs || body_bytes < 1024 || pitch < body_bytes || shape < 0 || shape > 5) return -(int)hipErrorInvalidValue;
   const uint32_t tiles = body_bytes / 1024;
   const uint64_t per_pass = shape == 2 ? ((uint64_t)n * pitch / 4096) * 4096 : (uint64_t)n * tiles * 1024;
   auto launch = [&] {
     if (shape == 0) hipLaunchKernelGGL(b3w_store_streams_kernel<4>, dim3((n + 3) / 4), dim3(64), 0, stream, buf, pitch, n, tiles, 0u);
     else if (shape == 1) hipLaunchKernelGGL(b3w_store_streams_kernel<8>, dim3((n + 7) / 8), dim3(64), 0, stream, buf, pitch, n, tiles, 0u);
+    else if (shape == 3) hipLaunchKernelGGL(b3w_store_persistent_kernel<4>, dim3(512), dim3(64), 0, stream, buf, pitch, n, tiles, 4u);
+    else if (shape == 4) hipLaunchKernelGGL(b3w_store_persistent_kernel<8>, dim3(512), dim3(64), 0, stream, buf, pitch, n, tiles, 4u);
+    else if (shape == 5) hipLaunchKernelGGL(b3w_store_persistent_kernel<8>, dim3((n + 7) / 8), dim3(64), 0, stream, buf, pitch, n, tiles, 4u);
     else hipLaunchKernelGGL(b3w_store_fill_kernel, dim3(256), dim3(256), 0, stream, buf, (uint64_t)n * pitch);
   };
   hipEvent_t e0 = nullptr, e1 = nullptr;

@@ -178,7 +178,10 @@ int32_t b3w_bodies_search_breakdown(const b3w_ctx *ctx, double out[4]);
 /* Harness helper: the pure-store ceiling of a body buffer — GB/s of `iters` passes (after 2 untimed ones) of kernels that do
  * nothing but the witness kernels' stores into n bodies at d_bodies + i * pitch (16-byte aligned; pitch 0 = witness_size * 32):
  * shape 0 = body streams, one wave per 4 bodies and 1 KiB per body and step (the fused kernels' EXPAND phase without trace, slot
- * table or LDS), 1 = the same per 8 bodies, 2 = the runtime's fill shape (256 workgroups over 4 KiB tiles; the sweep kernels').
+ * table or LDS), 1 = the same per 8 bodies, 2 = the runtime's fill shape (256 workgroups over 4 KiB tiles; the sweep kernels'),
+ * 3 / 4 = PACED persistent body streams (512 single-wave workgroups taking groups of 4 / 8 bodies in turn, four vector-ALU instructions
+ * in front of every store: a store-only kernel without any issues faster than HBM drains and fills it SLOWER — the best store-only
+ * shapes of tools/ubench/store_sweep.hip on a placed buffer), 5 = 8 bodies per wave, paced, one wave per group.
  * What a witness kernel's achieved bandwidth on the SAME buffer is to be read against (bench.py: roofline.of_measured_ceiling).
  * HIP events on `stream`; waits for them.  The buffer's contents are overwritten. */
 int32_t b3w_bodies_store_rate(b3w_ctx *ctx, void *d_bodies, uint32_t n, uint64_t pitch, int32_t shape, uint32_t iters, void *stream,
@@ -358,8 +361,10 @@ int32_t b3w_batch_write_wtns(b3w_batch *batch, uint32_t first, uint32_t count, c
 int32_t b3w_batch_write_wtns_ex(b3w_batch *batch, uint32_t first, uint32_t count, const char *dir, const char *prefix,
                                 uint32_t threads, uint32_t *written);
 
-/* Choose the fastest bit-identical kernel variant for THIS output buffer (fused one-kernel path vs the
- * two-kernel sweep path, DESIGN.md "Roofline"): runs and times each candidate on the caller's device
+/* Choose the fastest bit-identical kernel variant for THIS output buffer: the body-stream kernels (variants 0 / 3 / 8: fastest
+ * on a buffer from b3w_bodies_alloc), the fill-ordered fused kernel (200, compression circuit: fastest on a caller's own plain
+ * hipMalloc / torch buffer — 6.4-6.6 against 5.5 TB/s on one-class memory) and the two-kernel sweep path (100), DESIGN.md
+ * "Witness kernels".  An integrator that brings its own buffers calls this once per (context, buffer).  Runs and times each candidate on the caller's device
  * buffers, which end up holding the correct witnesses, and keeps the winner in the ctx for later
  * b3w_batch_run_device calls of more than 2 560 witnesses.  Batches up to 2 560 witnesses are always launched SLICED —
  * several waves per body, DESIGN.md "Batch size" — unless B3W_VARIANT says otherwise; for such an n the call only times that

@@ -24,7 +24,7 @@ def test_nova_batch_matches_oracle(m, circuit):
     bad, want = T.oracle_batch_u32(circuit, recs)
     assert bad == 0
     want = want.copy()
-    for variant in (0, 1, 22, 27, 36, 84) + ((2,) if circuit != "nova_bn254_o1" else ()):        # 20 + s: SLICED (any s in 2..64)
+    for variant in (0, 1, 22, 27, 36, 84) + ((2, 3, 4) if circuit != "nova_bn254_o1" else ()):   # 20 + s: SLICED (any s in 2..64); 4: persistent grid
         os.environ["B3W_VARIANT"] = str(variant)
         try:
             ctx = m.Context(circuit, 0)
@@ -186,3 +186,45 @@ def test_nova_full_config3_batch(m):
         assert np.array_equal(got, want), c0
     del d_bodies
     ctx.close()
+
+
+def test_nova_persistent_grid_takes_several_groups_per_wave_with_rejected_steps(m):
+    """Variant 4 of the O2 kernels (8 bodies a wave on a persistent grid of 512 waves — the default for batches of 32 768 steps and more):
+    9 000 steps are more than two rounds of the grid, the last one ragged; rejected steps in the first, a middle and the last group must
+    leave their bodies alone and must not leak their flags into the wave's next group.  Status and public outputs of every step and the
+    bodies around every rejected step equal variant 3's; 300 bodies byte for byte against the oracle."""
+    import torch
+    n = 9000
+    recs = T.workloads().config3_nova(n, first=3).copy()
+    bad_idx = [0, 5, 4095, 4096, 4100, 8191, 8192, 8999]
+    for i in bad_idx:
+        recs[i, 14] = recs[i, 12]                             # depth >= leaf_depth: CheckDepth rejects the step
+    dev = torch.device("cuda:0")
+    s = torch.cuda.current_stream().cuda_stream
+    d_recs = torch.from_numpy(recs.view(np.int32)).to(dev)
+    out = {}
+    for variant in (3, 4):
+        os.environ["B3W_VARIANT"] = str(variant)
+        try:
+            ctx = m.Context("nova_vesta", 0)
+        finally:
+            del os.environ["B3W_VARIANT"]
+        d_bodies = torch.full((n, ctx.body_bytes), 0x6B, dtype=torch.uint8, device=dev)
+        d_pub = torch.zeros((n, 15), dtype=torch.int32, device=dev)
+        d_st = torch.full((n,), -1, dtype=torch.int32, device=dev)
+        ctx.run_device(d_recs.data_ptr(), n, d_bodies.data_ptr(), 0, d_pub.data_ptr(), d_st.data_ptr(), s)
+        torch.cuda.synchronize()
+        out[variant] = (d_bodies, d_pub.cpu().numpy(), d_st.cpu().numpy())
+        ctx.close()
+    st = out[4][2]
+    assert [i for i in range(n) if st[i] != 0] == bad_idx and np.array_equal(st, out[3][2])
+    ok = st == 0
+    assert np.array_equal(out[4][1][ok], out[3][1][ok])
+    for i in bad_idx:
+        assert bool((out[4][0][i] == 0x6B).all().item()), i                                  # a rejected step's body is left alone
+    near = sorted({j for i in bad_idx for j in range(max(0, i - 9), min(n, i + 10))} - set(bad_idx))
+    sel = torch.tensor(near, device=dev)
+    assert torch.equal(out[4][0][sel], out[3][0][sel])
+    idx = np.sort(np.random.default_rng(11).choice(np.flatnonzero(ok), 300, replace=False))
+    _, want = T.oracle_batch_u32("nova_vesta", recs[idx])
+    assert np.array_equal(out[4][0][torch.from_numpy(idx).to(dev)].cpu().numpy(), want)

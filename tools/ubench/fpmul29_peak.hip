@@ -1,6 +1,8 @@
 // fpmul_peak.hip — how many 256-bit Montgomery multiplications per second does the chip do with this code?
 // (the ALU ceiling of csrc/b3w_commit.hip)   build: hipcc --offload-arch=gfx950 -O3 -I../../hot-proofs-blake3-circom_amd/csrc -o fpmul_peak fpmul_peak.hip
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
+#include <time.h>
 #include <stdio.h>
 #include <stdint.h>
 #include <string.h>
@@ -211,7 +213,7 @@ __global__ void kcheck(uint32_t *out, B3wCurve C, Curve9 C9) {
   for (int i = 0; i < 9; ++i) ok &= s9.l[i] == m9.l[i];
   out[threadIdx.x] = ok;
 }
-int main() {
+int main(int argc, char **argv) {
   B3wCurve C{};
   const uint64_t q[4] = {0x3c208c16d87cfd47ull, 0x97816a916871ca8dull, 0xb85045b68181585dull, 0x30644e72e131a029ull};
   memcpy(C.p, q, 32); C.inv = 0xe4866389u;   // -q^-1 mod 2^32 of BN254 q
@@ -230,6 +232,29 @@ int main() {
     printf("%-36s %8.2f ms  %7.1f G field mul/s\n", name, ms, muls / ms / 1e6);
   };
   const uint32_t iters = 2000, grid = 4096;
+  if (argc > 2 && !strcmp(argv[1], "loop")) {
+    // ./fpmul29_peak loop <seconds> [chains = 2]: the multiplication loop alone for that long, its rate second by second — the workload
+    // of a power measurement (tools/ubench/power_cases.py: is the "VALU ceiling" the commit kernel is priced against the chip's
+    // arithmetic or its power limit?)
+    const double secs = atof(argv[2]);
+    const int chains = argc > 3 ? atoi(argv[3]) : 2;
+    timespec t0; clock_gettime(CLOCK_MONOTONIC, &t0);
+    for (;;) {
+      timespec ta, tb; clock_gettime(CLOCK_MONOTONIC, &ta);
+      int n = 0;
+      do {
+        if (chains == 1) hipLaunchKernelGGL((k29<1, false>), dim3(grid), dim3(256), 0, 0, out, iters, C9);
+        else hipLaunchKernelGGL((k29<2, false>), dim3(grid), dim3(256), 0, 0, out, iters, C9);
+        hipDeviceSynchronize(); n++;
+        clock_gettime(CLOCK_MONOTONIC, &tb);
+      } while ((tb.tv_sec - ta.tv_sec) + (tb.tv_nsec - ta.tv_nsec) * 1e-9 < 1.0);
+      const double dt = (tb.tv_sec - ta.tv_sec) + (tb.tv_nsec - ta.tv_nsec) * 1e-9;
+      printf("%d chain(s): %.1f G field mul/s\n", chains, (double)grid * 256 * iters * chains * n / dt / 1e9);
+      fflush(stdout);
+      if ((tb.tv_sec - t0.tv_sec) + (tb.tv_nsec - t0.tv_nsec) * 1e-9 >= secs) break;
+    }
+    return 0;
+  }
   run("8 x 32-bit CIOS, 2 chains", [&] { hipLaunchKernelGGL(k32<2>, dim3(grid), dim3(256), 0, 0, out, iters, C); }, (double)grid * 256 * iters * 2);
   run("9 x 29-bit mul, 1 chain", [&] { hipLaunchKernelGGL((k29<1, false>), dim3(grid), dim3(256), 0, 0, out, iters, C9); }, (double)grid * 256 * iters);
   run("9 x 29-bit mul, 2 chains", [&] { hipLaunchKernelGGL((k29<2, false>), dim3(grid), dim3(256), 0, 0, out, iters, C9); }, (double)grid * 256 * iters * 2);

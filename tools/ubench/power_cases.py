@@ -12,6 +12,8 @@ cut the sampler's CSV by case.  The sampler is started by tools/ubench/power_run
   walk            constraint check (walk + deferred kernel) over the bodies the witness kernel left (HBM-read / issue bound)
   compression     the headline kernel: 4 096 compression witnesses per launch
   stores          the store-only body-stream kernel over the same buffer (no ALU work at all)
+  fpmul_1chain / fpmul_2chains   tools/ubench/fpmul29_peak loop: nothing but the commit kernel's 9 x 29-bit Montgomery multiplication, one / two
+                  independent chains per lane — the "VALU ceiling" the commit lines are priced against
 
   python tools/ubench/power_cases.py out.json [seconds=4] [n=65536]
 """
@@ -119,6 +121,16 @@ def run_case(name, fn, steps_per_iter):
                 m_steps_per_s=steps_per_iter / ms / 1e3)
 
 
+def run_binary(name, argv):
+    """another process's kernels for `seconds` (the field-multiplication loop of tools/ubench/fpmul29_peak.hip): the window it ran in"""
+    import subprocess
+    t0 = time.monotonic()
+    r = subprocess.run(argv, capture_output=True, text=True, timeout=seconds + 60)
+    t1 = time.monotonic()
+    rates = [float(ln.split(":")[1].split()[0]) for ln in r.stdout.splitlines() if "G field mul/s" in ln]
+    return dict(name=name, t0=t0 + 0.5, t1=t1, iters=len(rates), g_field_mul_per_s=(sorted(rates)[len(rates) // 2] if rates else None), rc=r.returncode)
+
+
 witness(sa); torch.cuda.synchronize()                         # the walk case reads valid bodies
 cases = []
 plan = [("idle", None, 0), ("witness", witness, n), ("commit", commit, n), ("both", both, n), ("walk", walk, n),
@@ -127,5 +139,11 @@ for name, fn, steps in plan:
     cases.append(run_case(name, fn, steps))
     print(name, {k: (round(v, 3) if isinstance(v, float) else v) for k, v in cases[-1].items() if k != "name"}, flush=True)
     time.sleep(1.0)                                           # a visible gap between the cases in the power trace
+fp = os.path.join(ROOT, "tools", "ubench", "fpmul29_peak")
+if os.path.exists(fp):                                        # the commit kernel's VALU ceiling: is it arithmetic or power?
+    for name, chains in (("fpmul_1chain", "1"), ("fpmul_2chains", "2")):
+        cases.append(run_binary(name, [fp, "loop", str(seconds), chains]))
+        print(name, {k: v for k, v in cases[-1].items() if k != "name"}, flush=True)
+        time.sleep(1.0)
 json.dump(dict(device=props.name, bdf=bdf, n=n, seconds=seconds, t_import=t_import, t_gpu_first_touch=t_gpu_first_touch,
                placement=bodies.placement, key_window=key.window, cases=cases), open(out_path, "w"), indent=1)

@@ -52,7 +52,7 @@ for c in cases["cases"]:
              uclk_mhz_mean=round(float(uclk[sel].mean()), 1), hotspot_c_max=float(hot[sel].max()), hbm_c_max=float(mem[sel].max()),
              ppt_limited_fraction=frac(ppt), thermal_limited_fraction=frac(thm), hbm_thermal_limited_fraction=frac(hbm), prochot_fraction=frac(pro),
              throttle_status_seen=sorted({int(float(r["throttle_status"])) for r, s in zip(R, sel) if s})[:8])
-    for k in ("ms_per_iter", "m_steps_per_s", "iters"):
+    for k in ("ms_per_iter", "m_steps_per_s", "iters", "g_field_mul_per_s"):
         if k in c:
             e[k] = round(c[k], 4) if isinstance(c[k], float) else c[k]
     out["cases"].append(e)
@@ -62,4 +62,4 @@ print(f"{'case':12s} {'W mean':>7s} {'p5':>6s} {'p95':>6s} {'W(energy)':>9s} {'s
 for e in out["cases"]:
     print(f"{e['case']:12s} {e['socket_w_mean']:7.1f} {e['socket_w_p5']:6.0f} {e['socket_w_p95']:6.0f} {str(e['socket_w_from_energy']):>9s} {e['gfxclk_mhz_mean']:7.1f} "
           f"{e['gfxclk_mhz_min']:6.0f} {e['gfxclk_mhz_max']:6.0f} {e['uclk_mhz_mean']:6.0f} {str(e['ppt_limited_fraction']):>6s} {str(e['thermal_limited_fraction']):>6s} "
-          f"{e['hotspot_c_max']:6.0f}  {e.get('m_steps_per_s', '')}")
+          f"{e['hotspot_c_max']:6.0f}  {e.get('m_steps_per_s', e.get('g_field_mul_per_s', ''))}")
