@@ -320,7 +320,7 @@ def gather_strings(dist, world, s):
     return out
 
 
-def bench_chain(args, m, torch, dist, dev, world, rank, local_rank):
+def bench_chain(args, m, torch, dist, dev, world, rank, local_rank, devices=None):
     """Configs 4/5: a step = one pass over the whole preimage (plan + all leaf and parent step witnesses of this
     rank's chunk range, bodies streamed through a ring of batch buffers).  Strong scaling: the preimage is fixed.
     Preimage = little-endian byte stream of LCG(1)."""
@@ -497,7 +497,7 @@ def bench_chain(args, m, torch, dist, dev, world, rank, local_rank):
                        "comm_size": (int(m.lib().b3w_comm_size(comm.handle)) if comm is not None else dist.get_world_size()) if world > 1 else 1,
                        "exchange_ms_per_rank": {"chunk_cvs": [x[0] for x in ex_all], "h_out": [x[1] for x in ex_all],
                                                 "what": "HIP events on the compute stream around staging + collective + scatter, last timed pass"},
-                       "pass_ms_per_rank": pass_ms, "first_pass_s": round(first_pass_s, 3), **place_cost,
+                       "pass_ms_per_rank": pass_ms, "first_pass_s": round(first_pass_s, 3), "devices_per_rank": devices or [], **place_cost,
                        "commit_overlap": args.commit_overlap if commit_records is not None else None,
                        "consumer": " then ".join(
                            ([f"rank-1 constraint check of every step witness on the device ({r1cs_t.n_constraints} constraints)"] if r1cs_t is not None else []) +
@@ -650,7 +650,7 @@ def main():
     if args.placement_search_s >= 0:
         m.lib().b3w_bodies_search_limit(args.placement_search_s)
     if args.workload == "chain":
-        return bench_chain(args, m, torch, dist, dev, world, rank, local_rank)
+        return bench_chain(args, m, torch, dist, dev, world, rank, local_rank, devices)
     circuit, n = args.circuit, args.batch
     ctx = m.Context(circuit, local_rank)
     recs = W.config2_compression(n, first=rank * n) if circuit == "compression" else W.config3_nova(n, first=rank * n)

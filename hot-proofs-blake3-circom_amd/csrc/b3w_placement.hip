@@ -102,6 +102,21 @@ __global__ __launch_bounds__(64) void b3w_store_persistent_kernel(uint8_t *out, 
     }
   }
 }
+// A writer that takes as little of a SIMD's register file as a wave can: one body stream per wave, 6 VGPRs used (the allocation granule is 8),
+// on a persistent grid.  CLOB > 0 makes the SAME code ALLOCATE CLOB + 1 registers (an empty asm that names v<CLOB> as clobbered): what a
+// neighbour's registers cost the kernel beside it (round 6: does a commit kernel of 3 x 168 registers a SIMD lose a whole wave to a writer
+// that needs 16?  tools/ubench/overlap_commit_probe.py)
+template <int CLOB>
+__global__ __launch_bounds__(64) void b3w_store_tiny_kernel(uint8_t *out, uint64_t pitch, uint32_t n, uint32_t tiles) {
+  if (CLOB == 15) asm volatile("" ::: "v15");
+  if (CLOB == 31) asm volatile("" ::: "v31");
+  if (CLOB == 63) asm volatile("" ::: "v63");
+  const u32x4 v = {0, 0, 0, 0};
+  for (uint32_t b = blockIdx.x; b < n; b += gridDim.x) {
+    uint8_t *p = out + (uint64_t)b * pitch + threadIdx.x * 16;
+    for (uint32_t g = 0; g < tiles; ++g, p += 1024) *reinterpret_cast<u32x4 *>(p) = v;
+  }
+}
 __global__ __launch_bounds__(256) void b3w_store_fill_kernel(uint8_t *out, uint64_t bytes) {
   const u32x4 v = {threadIdx.x, blockIdx.x, 0, 0};
   for (uint64_t t = blockIdx.x; (t + 1) * 4096 <= bytes; t += gridDim.x) *reinterpret_cast<u32x4 *>(out + t * 4096 + threadIdx.x * 16) = v;
@@ -653,7 +668,12 @@ extern "C" int b3w_place_gather_launch(const void *table, uint64_t table_bytes, 
 extern "C" int b3w_place_store_launch(uint8_t *buf, uint64_t pitch, uint32_t n, uint32_t body_bytes, int shape, hipStream_t stream) {
   if (!buf || !n || body_bytes < 1024 || pitch < body_bytes) return -(int)hipErrorInvalidValue;
   const uint32_t tiles = body_bytes / 1024;
-  if (shape >= 200) hipLaunchKernelGGL(b3w_store_persistent_kernel<8>, dim3(256u * (uint32_t)(shape - 200)), dim3(64), 0, stream, buf, pitch, n, tiles, 0u);   // (shape - 200) waves per CU
+  // 300 + k / 400 + k / 500 + k / 600 + k: the minimal-register writer, k waves per CU, allocating 8 / 16 / 32 / 64 VGPRs
+  if (shape >= 600) hipLaunchKernelGGL(b3w_store_tiny_kernel<63>, dim3(256u * (uint32_t)(shape - 600)), dim3(64), 0, stream, buf, pitch, n, tiles);
+  else if (shape >= 500) hipLaunchKernelGGL(b3w_store_tiny_kernel<31>, dim3(256u * (uint32_t)(shape - 500)), dim3(64), 0, stream, buf, pitch, n, tiles);
+  else if (shape >= 400) hipLaunchKernelGGL(b3w_store_tiny_kernel<15>, dim3(256u * (uint32_t)(shape - 400)), dim3(64), 0, stream, buf, pitch, n, tiles);
+  else if (shape >= 300) hipLaunchKernelGGL(b3w_store_tiny_kernel<0>, dim3(256u * (uint32_t)(shape - 300)), dim3(64), 0, stream, buf, pitch, n, tiles);
+  else if (shape >= 200) hipLaunchKernelGGL(b3w_store_persistent_kernel<8>, dim3(256u * (uint32_t)(shape - 200)), dim3(64), 0, stream, buf, pitch, n, tiles, 0u);   // (shape - 200) waves per CU
   else if (shape >= 100) hipLaunchKernelGGL(b3w_store_streams_kernel<8>, dim3((n + 7) / 8), dim3(64), 0, stream, buf, pitch, n, tiles, (uint32_t)(shape - 100));   // paused
   else if (shape == 0) hipLaunchKernelGGL(b3w_store_streams_kernel<4>, dim3((n + 3) / 4), dim3(64), 0, stream, buf, pitch, n, tiles, 0u);
   else if (shape == 1) hipLaunchKernelGGL(b3w_store_streams_kernel<8>, dim3((n + 7) / 8), dim3(64), 0, stream, buf, pitch, n, tiles, 0u);

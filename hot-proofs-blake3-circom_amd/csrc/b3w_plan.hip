@@ -391,7 +391,7 @@ constexpr uint32_t B3W_TREE_NODES = 1024;
 template <bool PLAN>
 __global__ __launch_bounds__(1024) void b3w_plan_tree_kernel(uint32_t *__restrict__ levels, uint64_t n, uint32_t l0, uint32_t *__restrict__ root,
                                                              B3wSpine sp, uint64_t first_chunk, uint32_t nlocal, uint32_t last_chunk_blocks, uint64_t row0,
-                                                             uint32_t *__restrict__ recs, uint32_t wg_fence) {
+                                                             uint32_t *__restrict__ recs) {
   __shared__ __attribute__((aligned(16))) uint32_t node[B3W_TREE_NODES * 8];
   __shared__ uint32_t carry[64 * 8];                        // carries this workgroup met, increasing level
   const uint32_t t = threadIdx.x;
@@ -473,8 +473,8 @@ __global__ __launch_bounds__(1024) void b3w_plan_tree_kernel(uint32_t *__restric
     for (int k = 0; k < 8; ++k) root[k] = o[k];
   }
   if (PLAN) {
-    if (wg_fence) __threadfence_block(); else __threadfence();    // (A/B, round 6)
-    __syncthreads();
+    __threadfence();                                        // agent scope: level arrays written by other waves, read below through L1 / L2
+    __syncthreads();                                        // (r06: a workgroup-scope fence here changes nothing — 0.498 against 0.501 ms for rank 0's pass at 8 ranks)
     for (uint32_t i = t; i < nlocal; i += 1024) plan_path(levels, n, sp, first_chunk + i, last_chunk_blocks, row0, recs);
   }
 }
@@ -572,10 +572,10 @@ extern "C" int b3w_launch_plan_tree(uint32_t *d_levels, uint64_t nchunks, uint32
     const uint32_t s0 = seg_of(sp, first_chunk);
     const uint64_t row0 = sp.row_base[s0] + (first_chunk - sp.lo[s0]) * sp.plen[s0];
     hipLaunchKernelGGL(b3w_plan_tree_kernel<true>, dim3(1), dim3(1024), 0, stream, d_levels, nchunks, l0, d_root, sp, first_chunk, plan_nlocal,
-                       last_chunk_blocks, row0, d_recs, (uint32_t)(getenv("B3W_TREE_WG_FENCE") ? atoi(getenv("B3W_TREE_WG_FENCE")) : 0));
+                       last_chunk_blocks, row0, d_recs);
   } else {
     hipLaunchKernelGGL(b3w_plan_tree_kernel<false>, dim3(1), dim3(1024), 0, stream, d_levels, nchunks, l0, d_root, sp, (uint64_t)0, 0u, 0u, (uint64_t)0,
-                       (uint32_t *)nullptr, 0u);
+                       (uint32_t *)nullptr);
   }
   return (int)hipGetLastError();
 }

@@ -162,30 +162,37 @@ impl Fold {
         if rc != 0 { Err(rc) } else { Ok(()) }
     }
 
-    /// After a pass with `fold_shaped(_, r1cs, _)`: violated constraints per step (0 = the step satisfies its circuit).
-    pub fn violations(&mut self, n_steps: usize) -> Result<Vec<u32>, i32> {
-        let mut v = vec![0u32; n_steps];
+    /// After a pass with `fold_shaped(_, r1cs, _)`: violated constraints per step (0 = the step satisfies its circuit), leaf steps then
+    /// parent steps: n_leaf + n_parent words, sized HERE from b3w_chain_info (a caller's smaller count would be a heap overflow).
+    pub fn violations(&mut self) -> Result<Vec<u32>, i32> {
+        let mut v = vec![0u32; self.steps()?];
         let rc = unsafe { b3w_chain_violations(self.chain, v.as_mut_ptr(), std::ptr::null_mut()) };
         if rc != 0 { Err(rc) } else { Ok(v) }
     }
 
+    fn steps(&self) -> Result<usize, i32> {                      // n_leaf + n_parent: what the per-step outputs of the chain are sized by
+        let (mut nl, mut np, mut nc, mut pl, mut place) = (0u64, 0u64, 0u64, 0u32, 0i32);
+        let rc = unsafe { b3w_chain_info(self.chain, &mut nl, &mut np, &mut nc, &mut pl, &mut place) };
+        if rc != 0 { Err(rc) } else { Ok((nl + np) as usize) }
+    }
+
     /// The whole pass over `preimage`.  `consumer` (with its `user` pointer) sees every batch of step witnesses on the device.
     pub fn run(&mut self, preimage: &[u8], consumer: Option<BatchConsumer>, user: *mut c_void) -> Result<FoldOutputs, i32> {
-        let (mut nl, mut np, mut nc, mut pl, mut place) = (0u64, 0u64, 0u64, 0u32, 0i32);
-        unsafe { b3w_chain_info(self.chain, &mut nl, &mut np, &mut nc, &mut pl, &mut place) };
         let stream = std::ptr::null_mut();                       // the null stream; b3w_chain_outputs waits for it
         let mut rc = unsafe { b3w_chain_run_leaves(self.chain, preimage.as_ptr(), consumer, user, stream) };
         if rc == 0 { rc = unsafe { b3w_chain_run_parents(self.chain, std::ptr::null(), consumer, user, stream) }; }
         if rc != 0 { return Err(rc); }
+        let (mut nl, mut np, mut nc, mut pl, mut place) = (0u64, 0u64, 0u64, 0u32, 0i32);
+        unsafe { b3w_chain_info(self.chain, &mut nl, &mut np, &mut nc, &mut pl, &mut place) };
         let rows = (nl + np) as usize;
         let mut out = FoldOutputs { public: vec![0u32; rows * 15], status: vec![0i32; rows], root: [0u32; 8], n_leaf_steps: nl, n_parent_steps: np };
         rc = unsafe { b3w_chain_outputs(self.chain, out.public.as_mut_ptr(), out.status.as_mut_ptr(), out.root.as_mut_ptr(), stream) };
         if rc != 0 { Err(rc) } else { Ok(out) }
     }
 
-    /// After `commit_only` + `run`: the points, 64 bytes (x, y little-endian) per step.
-    pub fn commitments(&mut self, n_steps: usize) -> Result<Vec<u8>, i32> {
-        let mut pts = vec![0u8; n_steps * 64];
+    /// After `commit_only` + `run`: the points, 64 bytes (x, y little-endian) per step (n_leaf + n_parent of them, from b3w_chain_info).
+    pub fn commitments(&mut self) -> Result<Vec<u8>, i32> {
+        let mut pts = vec![0u8; self.steps()? * 64];
         let rc = unsafe { b3w_chain_commitments(self.chain, pts.as_mut_ptr(), std::ptr::null_mut()) };
         if rc != 0 { Err(rc) } else { Ok(pts) }
     }

@@ -47,7 +47,11 @@ def check(line, n, what, rehearsal):
     if len(places) != n:
         problems.append(f"placement_per_rank has {len(places)} entries")
     if any(p not in ("mixed", "interleaved") for p in places):
-        problems.append(f"a rank's body buffer is plain: {places} (placement_search_s / _timeouts in the line say why)")
+        note = f"a rank's body buffer is plain: {places} (placement_search_s / _timeouts in the line say why)"
+        if rehearsal:                                          # (several ranks searching ONE card's memory at once: expected, not a fault)
+            sys.stderr.write(f"scale_day1: note, {what} at {n}: {note}\n")
+        else:
+            problems.append(note)
     km = roof.get("kernel_ms_per_rank") or cfg.get("pass_ms_per_rank") or []          # (chain lines: the pass of every rank)
     if isinstance(km, dict):
         km = km.get("all") or [km.get("min"), km.get("max")]

@@ -78,7 +78,13 @@ print(f"n = {n} nova_vesta steps, bodies {bodies.placement}, key window {key.win
 print(f"alone   {'commit from records':34s} {timed(commit)[0]:8.3f} ms")
 writers = [("witness kernel (8 bodies a wave)", witness), ("pure stores, streams w8 (fills every wave slot)", store(1))]
 writers += [(f"pure stores, {k} persistent wave(s) per CU", store(200 + k)) for k in (1, 2, 3, 4, 8)]
-for v, what in (("2", "4 bodies a wave"), ("0", "2 bodies a wave")):
+# r06: the same stores from a wave that ALLOCATES 8 / 16 / 32 / 64 VGPRs (b3w_store_tiny_kernel): the commit kernel holds 3 x 168 of a SIMD's 512
+writers += [(f"tiny writer, {k} wave(s) per CU, {regs} VGPRs allocated", store(base + k)) for k in (1, 2, 4) for base, regs in ((300, 8), (400, 16), (500, 32), (600, 64))]
+if os.environ.get("PROBE_ONLY_TINY"):
+    writers = [w for w in writers if w[0].startswith(("tiny writer, 1", "witness kernel (8"))]
+# (r06 also tried the witness kernel on ONE persistent wave per CU, 8 / 4 / 2 bodies a wave — the shape of the tiny writer, which overlaps best:
+# 11.3 / 13.1 / 15.6 ms alone, pairs of 15.8-16.2 ms; profiles/r06/overlap/overlap_one_wave_per_cu.log; those variants are gone again)
+for v, what in (("2", "4 bodies a wave"), ("0", "2 bodies a wave"), ("4", "8 bodies a wave, 512 persistent waves")):
     os.environ["B3W_VARIANT"] = v
     ctx2 = m.Context("nova_vesta", 0)
     writers.append((f"witness kernel ({what})", (lambda c: lambda s: c.run_device(d_recs.data_ptr(), n, bodies.ptr, 0, d_pub.data_ptr(), d_st.data_ptr(), s.cuda_stream))(ctx2)))
