@@ -137,3 +137,27 @@ def test_regionfill_full_config2_batch_on_a_plain_buffer_and_the_autotuner(m):
     torch.cuda.synchronize()
     assert torch.equal(d_ref, d_bodies)
     ref.close(); ctx.close()
+
+
+def test_a_batch_whose_own_buffer_came_out_plain_takes_the_fill_order_and_stays_exact(m, monkeypatch):
+    """b3w_batch_run under the default policy: the batch's body buffer is plain (here: B3W_PLACEMENT=plain; on a box where the placement
+    search finds one class only: by itself) -> the library launches the fill-ordered kernel for more than 2 560 witnesses.  Bodies and
+    outputs as ever; small batches on the same batch object keep the sliced launch."""
+    monkeypatch.setenv("B3W_PLACEMENT", "plain")
+    n = 3000
+    recs = T.workloads().config2_compression(n, first=9)
+    ctx = m.Context("compression", 0)
+    b = m.Batch(ctx, n)
+    assert b.placement == "plain"
+    b.run(recs)
+    pub, st = b.outputs()
+    assert (st == 0).all()
+    idx = list(range(40)) + list(range(1480, 1520)) + list(range(n - 40, n))
+    _, want = T.oracle_batch_u32("compression", recs[idx])
+    for k, i in enumerate(idx):
+        assert np.array_equal(b.fetch(i), want[k]), i
+    assert np.array_equal(pub[idx], want.reshape(len(idx), -1, 32)[:, 1:17, :4].copy().view(np.uint32).reshape(len(idx), 16))
+    b.run(recs[:100])
+    for i in (0, 57, 99):
+        assert np.array_equal(b.fetch(i), want[i] if i < 40 else T.oracle_batch_u32("compression", recs[i:i + 1])[1][0])
+    b.close(); ctx.close()

@@ -12,9 +12,10 @@ rnd = sys.argv[2] if len(sys.argv) > 2 else "r01"
 src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
 dst = os.path.join(ROOT, "profiles", rnd)
 os.makedirs(dst, exist_ok=True)
-WITNESS_KERNELS = ("b3w_compression_kernel", "b3w_nova_kernel", "b3w_sweep_kernel")
-# the MODE template argument of the witness kernels: <W, NT, MODE, SL> / <KIND, W, NT, MODE, SL> (0 fused, 1 TRACE, 2 VERIFY)
-MODE = re.compile(r"(?:true|false), (\d), (?:true|false)>\(")
+WITNESS_KERNELS = ("b3w_compression_kernel", "b3w_nova_kernel", "b3w_sweep_kernel", "b3w_compression_regionfill_kernel")
+# the MODE template argument of the witness kernels: <W, NT, MODE, SL, PERSIST> / <KIND, W, NT, MODE, SL, PERSIST> (0 fused, 1 TRACE, 2 VERIFY;
+# PERSIST since r06)
+MODE = re.compile(r"(?:true|false), (\d), (?:true|false)(?:, (?:true|false))?>\(")
 
 
 def find(sub, pattern):
@@ -37,6 +38,7 @@ for name in ("WRITE_SIZE", "FETCH_SIZE"):
     # the kernel(s) of the timed step only: the fused kernel, or TRACE (MODE 1) + SWEEP for the two-kernel path —
     # the set-up's autotune launches and the untimed VERIFY pass (MODE 2, reads every body) are other instantiations
     sweep = "sweep" in bench["config"]["kernel_variant"]
+    fill = "fill-ordered" in bench["config"]["kernel_variant"]
     allrows = [r for r in csv.DictReader(open(f)) if r["Counter_Name"] == name]
     # fused path: the MODE-0 instantiation this pass launched most often (its autotune may settle on another W than
     # the stats pass did — the candidates are bit-identical and write the same bytes)
@@ -47,6 +49,8 @@ for name in ("WRITE_SIZE", "FETCH_SIZE"):
             fused[kn] = fused.get(kn, 0) + 1
     chosen = max(fused, key=fused.get) if fused else None
     def timed(kn):
+        if fill:
+            return "b3w_compression_regionfill_kernel" in kn
         if sweep:
             return "b3w_sweep_kernel" in kn or bool(MODE.search(kn) and MODE.search(kn).group(1) == "1")
         return kn == chosen
@@ -63,7 +67,7 @@ for name in ("WRITE_SIZE", "FETCH_SIZE"):
 traffic = per_launch["WRITE_SIZE"] + 2.0 * per_launch["FETCH_SIZE"]
 cfg = bench["config"]
 entry = {"tag": tag, "circuit": cfg["circuit"], "batch": cfg["batch_per_gpu"],
-         "path": "sweep" if "sweep" in cfg["kernel_variant"] else "fused", "placement": cfg.get("placement"),
+         "path": "sweep" if "sweep" in cfg["kernel_variant"] else "fill" if "fill-ordered" in cfg["kernel_variant"] else "fused", "placement": cfg.get("placement"),
          "hbm_bytes_per_launch": traffic, "write_bytes": per_launch["WRITE_SIZE"], "fetch_bytes_x2": 2.0 * per_launch["FETCH_SIZE"],
          "algorithmic_bytes_per_launch": bench["roofline"]["algorithmic_bytes_per_launch"],
          "kernel_avg_ns_rocprof": float(main["AverageNs"]), "kernel_ms_bench": bench["roofline"]["kernel_ms"]}

@@ -21,4 +21,4 @@ python3 bench.py "$@" --cpu-seconds 0 > $out/bench.json 2> $out/bench.err || { e
 B3W_PLACE_CHECK=0 rocprofv3 --kernel-trace --stats --output-format csv -d $out/stats -- python3 bench.py "$@" --cpu-seconds 0 --traffic quoted > $out/stats.log 2>&1 || { echo "kernel-trace pass failed"; tail -5 $out/stats.log; exit 1; }
 B3W_PLACE_CHECK=0 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/write -- python3 bench.py "$@" --cpu-seconds 0 --traffic quoted --timed-ms 400 --placement-search-s 8 > $out/write.log 2>&1 || { echo "WRITE_SIZE pass failed"; tail -5 $out/write.log; exit 1; }
 B3W_PLACE_CHECK=0 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/fetch -- python3 bench.py "$@" --cpu-seconds 0 --traffic quoted --timed-ms 400 --placement-search-s 8 > $out/fetch.log 2>&1 || { echo "FETCH_SIZE pass failed"; tail -5 $out/fetch.log; exit 1; }
-python3 tools/profile_collect.py $tag ${B3W_PROFILE_ROUND:-r04}
+python3 tools/profile_collect.py $tag ${B3W_PROFILE_ROUND:-r06}
