@@ -307,12 +307,23 @@ int32_t b3w_create(int32_t circuit, int32_t device, b3w_ctx **out) {
   set_inputs(ctx);
   std::vector<uint32_t> table;
   if (!build_slot_table(ctx->desc, table, ctx->last_error)) { delete ctx; return B3W_E_BAD_ARGUMENT; }
-  // the fill-ordered variants (caller-owned buffers) keep the table in LDS in 16 bits: image words below 1024, no shifted word slots, no 256-bit slots
-  ctx->fill_ok = ctx->desc.kind == B3W_KIND_COMP;
-  for (uint32_t e : table) {
-    const uint32_t src = e & 0xFFFu, sh = (e >> 12) & 31u, mode = (e >> 17) & 3u;
-    if (src >= 1023 || mode == B3W_MODE_W256 || (mode != B3W_MODE_BIT && sh != 0)) ctx->fill_ok = false;
+  // the fill-ordered variant (caller-owned buffers) keeps the table in LDS in 16 bits a slot (b3w_kernels.hip fill_entry16[_nova]): compression —
+  // image words below 1024, no shifted word slots, no 256-bit slots; nova O2 — everything but the 67 IsZero inverses in the NARROW part of the
+  // image (below B3W_LDS_WIDE), no shifted word slots, and the 256-bit slots exactly those 67 (their numbers go behind the inverse table in d_aux)
+  std::vector<uint32_t> wide_slots(B3W_NOVA_ISZERO, 0xFFFFFFFFu);
+  ctx->fill_ok = ctx->desc.kind == B3W_KIND_COMP || ctx->desc.kind == B3W_KIND_NOVA_O2;
+  for (uint32_t i = 0; i < table.size(); i++) {
+    const uint32_t e = table[i], src = e & 0xFFFu, sh = (e >> 12) & 31u, mode = (e >> 17) & 3u;
+    if (mode != B3W_MODE_BIT && sh != 0) ctx->fill_ok = false;
+    if (ctx->desc.kind == B3W_KIND_COMP) {
+      if (src >= 1023 || mode == B3W_MODE_W256) ctx->fill_ok = false;
+    } else if (mode == B3W_MODE_W256) {
+      const uint32_t j = src >= B3W_LDS_WIDE && (src - B3W_LDS_WIDE) % 8 == 0 ? (src - B3W_LDS_WIDE) / 8 : 0xFFFFFFFFu;
+      if (j >= B3W_NOVA_ISZERO || wide_slots[j] != 0xFFFFFFFFu) ctx->fill_ok = false; else wide_slots[j] = i;
+    } else if (src + (mode == B3W_MODE_W64 ? 1u : 0u) >= B3W_LDS_WIDE) ctx->fill_ok = false;      // (the word behind src is read for every slot, used by two-word slots only)
   }
+  if (ctx->desc.kind == B3W_KIND_NOVA_O2)
+    for (uint32_t v : wide_slots) if (v == 0xFFFFFFFFu) ctx->fill_ok = false;
   DeviceGuard guard(device);              // the caller's current device (torch's, say) is put back on return
   if (guard.err != hipSuccess) { delete ctx; return B3W_E_NO_DEVICE; }
   const CircuitDesc &d = ctx->desc;
@@ -321,7 +332,9 @@ int32_t b3w_create(int32_t circuit, int32_t device, b3w_ctx **out) {
   if (e == hipSuccess) ctx->d_table = ctx->d_table_base + 32;
   if (e == hipSuccess) e = hipMemcpy(ctx->d_table, table.data(), table.size() * 4, hipMemcpyHostToDevice);
   if (e == hipSuccess && d.kind != B3W_KIND_COMP) {
-    const std::vector<uint32_t> aux = build_nova_aux(d.prime);
+    std::vector<uint32_t> aux = build_nova_aux(d.prime);
+    static_assert(B3W_AUX_WIDE_SLOTS == 16 + 8 * B3W_INV_TABLE_N, "b3w_kernels.h and b3w_internal.h disagree about the inverse table");
+    aux.insert(aux.end(), wide_slots.begin(), wide_slots.end());          // (O2: where the fill-ordered path's second launch writes the inverses)
     e = hipMalloc(&ctx->d_aux, aux.size() * 4);
     if (e == hipSuccess) e = hipMemcpy(ctx->d_aux, aux.data(), aux.size() * 4, hipMemcpyHostToDevice);
   }
@@ -432,7 +445,7 @@ int32_t b3w_batch_run_device(b3w_ctx *ctx, const uint32_t *d_records, uint32_t n
     else if (ctx->desc.kind == B3W_KIND_NOVA_O2) variant = n <= 3072 ? 0 : n < 32768 ? 3 : 4;      // (4: 8 bodies a wave on a persistent grid)
     else variant = 0;
   }
-  if (variant >= B3W_VARIANT_REGIONFILL && !ctx->fill_ok) { ctx->last_error = "the fill-ordered variant (200) exists for the compression circuit only"; return B3W_E_BAD_ARGUMENT; }
+  if (variant >= B3W_VARIANT_REGIONFILL && !ctx->fill_ok) { ctx->last_error = "the fill-ordered variant (200) exists for the compression circuit and the nova O2 builds"; return B3W_E_BAD_ARGUMENT; }
   int rc = b3w_launch_batch(ctx->desc.kind, variant, d_records, n, d_bodies, pitch, ctx->d_table, ctx->desc.nwit,
                             d_public, d_status, ctx->d_aux, ctx->d_scratch, ctx->scratch_cap, (hipStream_t)stream);
   if (rc == 0) return B3W_OK;
@@ -485,14 +498,16 @@ int32_t b3w_batch_autotune_device(b3w_ctx *ctx, const uint32_t *d_records, uint3
   // fused with 4 (compression) / 2 (nova) bodies per wave, also with 8 (compression: for large batches occupancy-limited,
   // variant 8; nova O2: variant 3), the two-kernel sweep, and — compression — the fill-ordered fused kernel: on a placed buffer the body
   // streams win (7.2 against 6.7 TB/s), on a caller's plain buffer the fill order does (6.4 against 5.5; profiles/r06/variant_scan_*.log)
-  const int candidates[4] = {0, ctx->desc.kind == B3W_KIND_COMP ? (n > 6144 ? 8 : 3) : ctx->desc.kind == B3W_KIND_NOVA_O2 ? 3 : 0, B3W_VARIANT_SWEEP,
-                             ctx->fill_ok ? B3W_VARIANT_REGIONFILL : ctx->desc.kind == B3W_KIND_NOVA_O2 && n >= 16384 ? 4 : 0};
+  // (nova O2: the fill-ordered path gains 4-6 % on a plain buffer — its tracer shares a SIMD with a storing wave and the nova storers do more
+  // per slot —, and large batches have the persistent grid, variant 4)
+  const int candidates[5] = {0, ctx->desc.kind == B3W_KIND_COMP ? (n > 6144 ? 8 : 3) : ctx->desc.kind == B3W_KIND_NOVA_O2 ? 3 : 0, B3W_VARIANT_SWEEP,
+                             ctx->fill_ok ? B3W_VARIANT_REGIONFILL : 0, ctx->desc.kind == B3W_KIND_NOVA_O2 && n >= 16384 ? 4 : 0};
   int best = ctx->variant;
   float best_ms = 1e30f;
   const int saved = ctx->variant;
   const bool saved_auto = ctx->variant_auto;
   ctx->variant_auto = false;
-  for (int ci = 0; ci < 4; ci++) {
+  for (int ci = 0; ci < 5; ci++) {
     const int c = candidates[ci];
     if (ci > 0 && c == candidates[0]) continue;
     ctx->variant = c;

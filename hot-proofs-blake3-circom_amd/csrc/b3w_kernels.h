@@ -8,9 +8,11 @@
 // variants B3W_VARIANT_SLICED + s (s = 2 .. 64): one body per wave and s waves per body, each storing 1/s of its tiles (small batches)
 #define B3W_VARIANT_SLICED 20
 // variant B3W_VARIANT_REGIONFILL: the fill-ordered fused kernel for caller-owned (plain) buffers — 256 workgroups of four storing waves and
-// a tracer wave over absolute 128 KiB regions, one contiguous 4 MiB window chip-wide (b3w_kernels.hip "REGIONFILL"); compression circuit
+// a tracer wave over absolute 128 KiB regions, one contiguous 4 MiB window chip-wide (b3w_kernels.hip "REGIONFILL"); compression and nova O2 circuits
 #define B3W_VARIANT_REGIONFILL 200
 #define B3W_REGIONFILL_GRID 256  // one workgroup per CU, workgroup i on XCD i % 8
+// d_aux of the nova circuits: [0,8) prime, [8] TABLE_N, [16 + 8k, +8) k^-1 mod p for k < 2048, then (O2) the slot numbers of the 67 IsZero inverses
+#define B3W_AUX_WIDE_SLOTS (16 + 8 * 2048)
 #define B3W_SWEEP_GRID 256       // one 256-thread workgroup per CU, tile = 4 KiB: the runtime fill kernel's shape
 #define B3W_SWEEP_LOGC 13
 #define B3W_SWEEP_CHUNK (1u << B3W_SWEEP_LOGC)   // witnesses per TRACE+SWEEP pair = row length of the scratch

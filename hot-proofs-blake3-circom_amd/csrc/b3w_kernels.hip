@@ -666,6 +666,145 @@ __device__ __forceinline__ void lds_put256(uint32_t *L, const U256 &v) {
   *reinterpret_cast<uint4 *>(L + 4) = make_uint4(v.l[4], v.l[5], v.l[6], v.l[7]);
 }
 
+// One IsZero gadget of a step (job j of 67) on the image L whose record is staged at B3W_LDS_NV: the gadget's flag, and — INV — its
+// inverse (and, for the unsimplified build, the differences themselves) as field elements into the image's wide part.  INV = false is the
+// fill-ordered kernel's tracer: its images carry no wide part (the 67 256-bit slots are written by another launch).
+// -> false: |k| outside the supported range.
+template <bool O1, bool INV>
+__device__ __forceinline__ bool nova_iszero_job(uint32_t *L, int j, const U256 &P, const uint32_t *__restrict__ aux) {
+  const uint32_t *in = L + B3W_LDS_NV;
+  const int64_t depth = in[NV_DEPTH];
+  int64_t k, in1 = 0;
+  uint32_t flag_atom, isz_wide = 0, in1_wide = 0;
+  if (j == 0) { k = -depth; flag_atom = NV_IS_ROOT; isz_wide = NV_ROOT_ISZ_IN; }                     // check_root (:19-23)
+  else if (j == 1) { k = -(int64_t)in[NV_BLOCK_COUNT]; flag_atom = NV_E0; isz_wide = NV_E0_ISZ_IN; }  // check_block_counts[0] (:136-141)
+  else if (j == 2) { in1 = (int64_t)in[NV_N_BLOCKS] - 1; k = in1 - (int64_t)in[NV_BLOCK_COUNT];       // check_block_counts[1] (:142-144)
+                     flag_atom = NV_E1; isz_wide = NV_E1_ISZ_IN; in1_wide = NV_E1_IN1; }
+  else { const int i = j - 3; in1 = (int64_t)in[NV_TOTAL_DEPTH] - i - 2; k = in1 - depth;              // eqs[i] (:65-72)
+         flag_atom = NV_EQ_OUT + i; isz_wide = NV_EQ_ISZ_IN + i; in1_wide = NV_EQ_IN1 + i; }
+  L[B3W_LDS_NV + flag_atom] = (k == 0) ? 1u : 0u;
+  if (!INV) return ((uint64_t)(k < 0 ? -k : k) >> 32) == 0;
+  U256 inv;
+  const bool ok = inv_signed(k, P, aux, inv);
+  if (!O1) {
+    lds_put256(L + B3W_LDS_WIDE + 8 * j, inv);                 // O2 keeps only the inverses: wide index = job index
+  } else {
+    const uint32_t inv_wide = j < 3 ? (uint32_t)j : (uint32_t)(NV_EQ_INV - NV_NARROW_COUNT + (j - 3));
+    lds_put256(L + B3W_LDS_WIDE + 8 * inv_wide, inv);
+    lds_put256(L + B3W_LDS_WIDE + 8 * (isz_wide - NV_NARROW_COUNT), u256_signed(k, P));
+    if (in1_wide) lds_put256(L + B3W_LDS_WIDE + 8 * (in1_wide - NV_NARROW_COUNT), u256_signed(in1, P));
+  }
+  return ok;
+}
+
+// The FLAGS of the 67 IsZero gadgets in closed form, by the four lanes of the step's quad (the fill-ordered kernel's tracer: no inverses,
+// and 67 lane-jobs with four LDS reads each cost it more than the compression trace).  Same values as nova_iszero_job<*, false> for every
+// j (tests: every body of the fill-ordered path is compared with the body-stream kernels', which run the jobs).
+// -> true: an IsZero argument is out of the supported range (|k| >= 2^32).
+__device__ __forceinline__ bool nova_iszero_flags_quad(uint32_t *L, int col) {
+  uint32_t *nv = L + B3W_LDS_NV;
+  const int64_t depth = nv[NV_DEPTH], block_count = nv[NV_BLOCK_COUNT], n_blocks = nv[NV_N_BLOCKS], total_depth = nv[NV_TOTAL_DEPTH];
+  if (col == 0) {
+    nv[NV_IS_ROOT] = depth == 0 ? 1u : 0u;                               // k = -depth
+    nv[NV_E0] = block_count == 0 ? 1u : 0u;                              // k = -block_count
+    nv[NV_E1] = n_blocks - 1 - block_count == 0 ? 1u : 0u;               // k = n_blocks - 1 - block_count
+  }
+  const int64_t istar = total_depth - 2 - depth;                         // eqs[i]: k = total_depth - i - 2 - depth = istar - i
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const int i = col * 16 + q;
+    nv[NV_EQ_OUT + i] = istar == i ? 1u : 0u;
+  }
+  const int64_t k2 = n_blocks - 1 - block_count;
+  const int64_t mag2 = k2 < 0 ? -k2 : k2, magl = istar < 0 ? -istar : istar, magh = istar - 63 < 0 ? 63 - istar : istar - 63;
+  return (mag2 >> 32) != 0 || (magl >> 32) != 0 || (magh >> 32) != 0;    // (|istar - i| is largest at i = 0 or i = 63)
+}
+
+// Flags, message / chaining-value selection of a step: the four lanes of a quad (col) on the step's image L, after its IsZero jobs.
+// -> the step's status (0, 4 = the circuit's assert, 103 = outside the kernels' domain); the inputs of the compression are in place.
+__device__ __forceinline__ int32_t nova_select(uint32_t *L, int col, bool dom_a /* an IsZero argument was out of range */) {
+  uint32_t *nv = L + B3W_LDS_NV;
+  const uint32_t n_blocks = nv[NV_N_BLOCKS], block_count = nv[NV_BLOCK_COUNT], cil = nv[NV_CIL], cih = nv[NV_CIH];
+  const uint32_t leaf_depth = nv[NV_LEAF_DEPTH], total_depth = nv[NV_TOTAL_DEPTH], depth = nv[NV_DEPTH];
+  // Blake3NovaTreePath_CheckDepth (:13-45): LessThan(8) / GreaterEqThan(8) through Num2Bits(9)
+  const int64_t cp = (int64_t)depth + 257 - (int64_t)leaf_depth;       // check_parent.n2b.in
+  const int64_t ed = (int64_t)leaf_depth + 255 - (int64_t)depth;       // exceed_depth.lt.n2b.in
+  const bool assert_fail = cp < 0 || cp >= 512 || ed < 0 || ed >= 512 || ((ed >> 8) & 1) == 0;
+  const uint32_t parent = 1u - (uint32_t)((cp >> 8) & 1);
+  const uint32_t is_root = depth == 0 ? 1u : 0u;
+  const uint32_t e0 = block_count == 0 ? 1u : 0u;
+  const uint32_t e1 = ((int64_t)n_blocks - 1 == (int64_t)block_count) ? 1u : 0u;
+  const bool dom = dom_a || depth == 0xFFFFFFFFu || (block_count == 0xFFFFFFFFu && !parent);
+  const int32_t st = assert_fail ? 4 : dom ? 103 : 0;
+  // Blake3GetFlag (:122-167)
+  const uint32_t last = e1 & (1u - parent), first = e0 & (1u - parent);
+  const uint32_t ur_tmp = parent | e1, ur_flag = ur_tmp & is_root;
+  const uint32_t dflag = first + 2u * last + 8u * ur_flag + 4u * parent;
+  // Blake3GetDownLeftPath (:47-84): eqs[i].out = [i == istar]; bit_at_depth is a running sum
+  const int64_t istar = (int64_t)total_depth - 2 - (int64_t)depth;
+  const uint64_t chunk_idx = (uint64_t)cil | ((uint64_t)cih << 32);
+  const bool has_star = istar >= 0 && istar < 64;
+  const uint32_t nb_star = has_star ? 1u - (uint32_t)((chunk_idx >> (istar & 63)) & 1) : 0u;
+  const uint32_t dl = parent ? nb_star : 1u;                            // (1-parent) + parent*bit_at_depth[63]
+  const uint32_t cdd = last | parent, decr = cdd & (1u - is_root);
+  if (col == 0) {
+    nv[NV_BLOCK_COUNT_OUT] = block_count + (1u - parent);               // :251
+    nv[NV_DEPTH_OUT] = depth - decr;                                    // :262
+    nv[NV_IS_PARENT] = parent;
+    nv[NV_CP_IN1] = leaf_depth - 1u;
+    nv[NV_CP_N2B_IN] = (uint32_t)cp;
+    nv[NV_ED_IN1] = depth + 1u;
+    nv[NV_ED_N2B_IN] = (uint32_t)ed;
+    nv[NV_ED_OUT] = 0u;
+    nv[NV_NOT_ROOT] = 1u - is_root;
+    nv[NV_NOT_PARENT] = 1u - parent;
+    nv[NV_IS_LAST_BLOCK] = last;
+    nv[NV_FIRST] = first;
+    nv[NV_UR_TMP] = ur_tmp;
+    nv[NV_UR_FLAG] = ur_flag;
+    nv[NV_DL] = dl;
+    nv[NV_CDD_OUT] = cdd;
+    nv[NV_DECR_DEPTH] = decr;
+    L[B3W_LDS_CHUNK_IDX] = cil;
+    L[B3W_LDS_CHUNK_IDX + 1] = cih;
+    L[B3W_A_T] = parent ? 0u : cil;                                     // :244-245
+    L[B3W_A_T + 1] = parent ? 0u : cih;
+    L[B3W_A_B] = nv[NV_B];
+    L[B3W_A_D] = dflag;
+  }
+  // Blake3GetFinal_m (:86-120) and h_compression (:229-233): products of a word and a bit
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int i = col + 4 * q;
+    const uint32_t hsel = nv[NV_H + (i & 7)], msel = nv[NV_M + (i & 7)], mi = nv[NV_M + i];
+    const uint32_t take_h = i < 8 ? dl : 1u - dl;                        // tmp_down = h * (dl | 1-dl)
+    const uint32_t td = take_h ? hsel : 0u;
+    const uint32_t mp = (take_h ? 0u : msel) + td;                       // m_is_parent
+    const uint32_t tp = parent ? mp : 0u;
+    nv[NV_TMP_DOWN + i] = td;
+    nv[NV_M_IS_PARENT + i] = mp;
+    nv[NV_TMP_IS_PAR + i] = tp;
+    L[B3W_A_M + i] = (parent ? 0u : mi) + tp;                            // out_m
+  }
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    const int i = col + 4 * q;
+    const uint32_t iv = i == 0 ? 0x6A09E667u : i == 1 ? 0xBB67AE85u : i == 2 ? 0x3C6EF372u : i == 3 ? 0xA54FF53Au
+                      : i == 4 ? 0x510E527Fu : i == 5 ? 0x9B05688Cu : i == 6 ? 0x1F83D9ABu : 0x5BE0CD19u;
+    const uint32_t tiv = parent ? iv : 0u;
+    nv[NV_TMPIV + i] = tiv;
+    L[B3W_A_H + i] = (parent ? 0u : nv[NV_H + i]) + tiv;                 // h_compression
+  }
+#pragma unroll
+  for (int q = 0; q < 16; ++q) {
+    const int i = col * 16 + q;
+    nv[NV_BIT_AT_DEPTH + i] = (has_star && (int64_t)i >= istar) ? nb_star : 0u;
+  }
+  return st;
+}
+
+// MODE 3 (O2): the 67 256-bit slots of every body only — the field inverses of the IsZero gadgets, `table` = their 67 slot numbers —
+// behind a launch of the fill-ordered kernel, whose images carry no wide part; rejected steps are left alone as everywhere.
 template <int KIND, int W, bool NT, int MODE, bool SL = false, bool PERSIST = false>
 __global__ __launch_bounds__(64) void b3w_nova_kernel(const uint32_t *__restrict__ recs, uint32_t n,
                                                       uint8_t *__restrict__ out, uint64_t pitch,
@@ -710,28 +849,7 @@ __global__ __launch_bounds__(64) void b3w_nova_kernel(const uint32_t *__restrict
   for (int t = lane; t < 67 * W; t += 64) {
     const int w = t / 67, j = t - w * 67;
     if (wb(w) >= n) continue;
-    uint32_t *L = lds + w * WORDS;
-    const uint32_t *in = L + B3W_LDS_NV;
-    const int64_t depth = in[NV_DEPTH];
-    int64_t k, in1 = 0;
-    uint32_t flag_atom, isz_wide = 0, in1_wide = 0;
-    if (j == 0) { k = -depth; flag_atom = NV_IS_ROOT; isz_wide = NV_ROOT_ISZ_IN; }                     // check_root (:19-23)
-    else if (j == 1) { k = -(int64_t)in[NV_BLOCK_COUNT]; flag_atom = NV_E0; isz_wide = NV_E0_ISZ_IN; }  // check_block_counts[0] (:136-141)
-    else if (j == 2) { in1 = (int64_t)in[NV_N_BLOCKS] - 1; k = in1 - (int64_t)in[NV_BLOCK_COUNT];       // check_block_counts[1] (:142-144)
-                       flag_atom = NV_E1; isz_wide = NV_E1_ISZ_IN; in1_wide = NV_E1_IN1; }
-    else { const int i = j - 3; in1 = (int64_t)in[NV_TOTAL_DEPTH] - i - 2; k = in1 - depth;              // eqs[i] (:65-72)
-           flag_atom = NV_EQ_OUT + i; isz_wide = NV_EQ_ISZ_IN + i; in1_wide = NV_EQ_IN1 + i; }
-    U256 inv;
-    if (!inv_signed(k, P, aux, inv)) domf[w] = 1;
-    L[B3W_LDS_NV + flag_atom] = (k == 0) ? 1u : 0u;
-    if (!O1) {
-      lds_put256(L + B3W_LDS_WIDE + 8 * j, inv);                 // O2 keeps only the inverses: wide index = job index
-    } else {
-      const uint32_t inv_wide = j < 3 ? (uint32_t)j : (uint32_t)(NV_EQ_INV - NV_NARROW_COUNT + (j - 3));
-      lds_put256(L + B3W_LDS_WIDE + 8 * inv_wide, inv);
-      lds_put256(L + B3W_LDS_WIDE + 8 * (isz_wide - NV_NARROW_COUNT), u256_signed(k, P));
-      if (in1_wide) lds_put256(L + B3W_LDS_WIDE + 8 * (in1_wide - NV_NARROW_COUNT), u256_signed(in1, P));
-    }
+    if (!nova_iszero_job<O1, true>(lds + w * WORDS, j, P, aux)) domf[w] = 1;
   }
   __syncthreads();
 
@@ -740,87 +858,26 @@ __global__ __launch_bounds__(64) void b3w_nova_kernel(const uint32_t *__restrict
   const bool active = w < W && wb(w) < n;
   uint32_t *L = lds + (active ? w : 0) * WORDS;
   if (active) {
-    uint32_t *nv = L + B3W_LDS_NV;
-    const uint32_t n_blocks = nv[NV_N_BLOCKS], block_count = nv[NV_BLOCK_COUNT], cil = nv[NV_CIL], cih = nv[NV_CIH];
-    const uint32_t leaf_depth = nv[NV_LEAF_DEPTH], total_depth = nv[NV_TOTAL_DEPTH], depth = nv[NV_DEPTH];
-    // Blake3NovaTreePath_CheckDepth (:13-45): LessThan(8) / GreaterEqThan(8) through Num2Bits(9)
-    const int64_t cp = (int64_t)depth + 257 - (int64_t)leaf_depth;       // check_parent.n2b.in
-    const int64_t ed = (int64_t)leaf_depth + 255 - (int64_t)depth;       // exceed_depth.lt.n2b.in
-    const bool assert_fail = cp < 0 || cp >= 512 || ed < 0 || ed >= 512 || ((ed >> 8) & 1) == 0;
-    const uint32_t parent = 1u - (uint32_t)((cp >> 8) & 1);
-    const uint32_t is_root = depth == 0 ? 1u : 0u;
-    const uint32_t e0 = block_count == 0 ? 1u : 0u;
-    const uint32_t e1 = ((int64_t)n_blocks - 1 == (int64_t)block_count) ? 1u : 0u;
-    const bool dom = domf[w] != 0 || depth == 0xFFFFFFFFu || (block_count == 0xFFFFFFFFu && !parent);
-    const int32_t st = assert_fail ? 4 : dom ? 103 : 0;
-    // Blake3GetFlag (:122-167)
-    const uint32_t last = e1 & (1u - parent), first = e0 & (1u - parent);
-    const uint32_t ur_tmp = parent | e1, ur_flag = ur_tmp & is_root;
-    const uint32_t dflag = first + 2u * last + 8u * ur_flag + 4u * parent;
-    // Blake3GetDownLeftPath (:47-84): eqs[i].out = [i == istar]; bit_at_depth is a running sum
-    const int64_t istar = (int64_t)total_depth - 2 - (int64_t)depth;
-    const uint64_t chunk_idx = (uint64_t)cil | ((uint64_t)cih << 32);
-    const bool has_star = istar >= 0 && istar < 64;
-    const uint32_t nb_star = has_star ? 1u - (uint32_t)((chunk_idx >> (istar & 63)) & 1) : 0u;
-    const uint32_t dl = parent ? nb_star : 1u;                            // (1-parent) + parent*bit_at_depth[63]
-    const uint32_t cdd = last | parent, decr = cdd & (1u - is_root);
+    const int32_t st = nova_select(L, col, domf[w] != 0);
     if (col == 0) {
       okf[w] = st == 0 ? 1u : 0u;
       if (MODE != 2 && status) status[wb(w)] = st;
-      nv[NV_BLOCK_COUNT_OUT] = block_count + (1u - parent);               // :251
-      nv[NV_DEPTH_OUT] = depth - decr;                                    // :262
-      nv[NV_IS_PARENT] = parent;
-      nv[NV_CP_IN1] = leaf_depth - 1u;
-      nv[NV_CP_N2B_IN] = (uint32_t)cp;
-      nv[NV_ED_IN1] = depth + 1u;
-      nv[NV_ED_N2B_IN] = (uint32_t)ed;
-      nv[NV_ED_OUT] = 0u;
-      nv[NV_NOT_ROOT] = 1u - is_root;
-      nv[NV_NOT_PARENT] = 1u - parent;
-      nv[NV_IS_LAST_BLOCK] = last;
-      nv[NV_FIRST] = first;
-      nv[NV_UR_TMP] = ur_tmp;
-      nv[NV_UR_FLAG] = ur_flag;
-      nv[NV_DL] = dl;
-      nv[NV_CDD_OUT] = cdd;
-      nv[NV_DECR_DEPTH] = decr;
-      L[B3W_LDS_CHUNK_IDX] = cil;
-      L[B3W_LDS_CHUNK_IDX + 1] = cih;
-      L[B3W_A_T] = parent ? 0u : cil;                                     // :244-245
-      L[B3W_A_T + 1] = parent ? 0u : cih;
-      L[B3W_A_B] = nv[NV_B];
-      L[B3W_A_D] = dflag;
-    }
-    // Blake3GetFinal_m (:86-120) and h_compression (:229-233): products of a word and a bit
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int i = col + 4 * q;
-      const uint32_t hsel = nv[NV_H + (i & 7)], msel = nv[NV_M + (i & 7)], mi = nv[NV_M + i];
-      const uint32_t take_h = i < 8 ? dl : 1u - dl;                        // tmp_down = h * (dl | 1-dl)
-      const uint32_t td = take_h ? hsel : 0u;
-      const uint32_t mp = (take_h ? 0u : msel) + td;                       // m_is_parent
-      const uint32_t tp = parent ? mp : 0u;
-      nv[NV_TMP_DOWN + i] = td;
-      nv[NV_M_IS_PARENT + i] = mp;
-      nv[NV_TMP_IS_PAR + i] = tp;
-      L[B3W_A_M + i] = (parent ? 0u : mi) + tp;                            // out_m
-    }
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      const int i = col + 4 * q;
-      const uint32_t iv = i == 0 ? 0x6A09E667u : i == 1 ? 0xBB67AE85u : i == 2 ? 0x3C6EF372u : i == 3 ? 0xA54FF53Au
-                        : i == 4 ? 0x510E527Fu : i == 5 ? 0x9B05688Cu : i == 6 ? 0x1F83D9ABu : 0x5BE0CD19u;
-      const uint32_t tiv = parent ? iv : 0u;
-      nv[NV_TMPIV + i] = tiv;
-      L[B3W_A_H + i] = (parent ? 0u : nv[NV_H + i]) + tiv;                 // h_compression
-    }
-#pragma unroll
-    for (int q = 0; q < 16; ++q) {
-      const int i = col * 16 + q;
-      nv[NV_BIT_AT_DEPTH + i] = (has_star && (int64_t)i >= istar) ? nb_star : 0u;
     }
   }
   __syncthreads();
+  if (MODE == 3) {
+    // the wide slots alone: lane pair = one of the body's 67 slots (table[j] = its number), each lane a 16-byte half
+    for (int t = lane; t < 134 * W; t += 64) {
+      const int ww = t / 134, r = t - ww * 134, j = r >> 1, half = r & 1;
+      if (wb(ww) < n && okf[ww]) {
+        const uint32_t *src = lds + ww * WORDS + B3W_LDS_WIDE + 8 * j + 4 * half;
+        store16<false>(out + (uint64_t)wb(ww) * pitch + (uint64_t)table[j] * 32 + 16 * half, make_uint4(src[0], src[1], src[2], src[3]));
+      }
+    }
+    if (!PERSIST) return;
+    __syncthreads();
+    continue;
+  }
   if (active && okf[w]) trace_compression(L, col, nullptr);
   __syncthreads();
   bool all_ok = true;
@@ -869,50 +926,88 @@ __global__ __launch_bounds__(64) void b3w_nova_kernel(const uint32_t *__restrict
 // Bit-identical to the other variants (tests/test_gpu_parity.py); b3w_batch_autotune_device times it on the buffer it is given.
 // (Also built and measured in round 6, and taken out: the same workgroup dealt BODY-major — groups of 8 m workgroups per body, a workgroup
 // the body's blocks = u (mod 8 m): 5.8-6.0 TB/s on one-class memory for m = 1 .. 8, profiles/r06/variant_scan_bf*.log.)
-// The slot table in LDS, 16 bits a slot (so that 2 x 14 images fit beside it): src (10 bits: an image word below 1024), then 5 bits that are
-// the shift of a BIT slot or, under the word flag (bit 15), "two words" in their lowest bit.  The host checks that the circuit's table can
-// be said that way (b3w_fill_table_ok: word slots never shift) before it offers these variants.
+// The slot table in LDS, 16 bits a slot (so that the images fit beside it).
+//   compression: src (10 bits: an image word below 1024), then 5 bits that are the shift of a BIT slot or, under the word flag (bit 15),
+//                "two words" in their lowest bit;
+//   nova O2:     src (11 bits: the NARROW part of the image, below 2048), then 5 bits that are the shift of a BIT slot or the kind of a word
+//                slot (0 one word, 1 two words, 2 a 256-bit slot: SKIPPED here, written by the wide-slot launch), and the word flag in a
+//                bitmap of its own, one bit a slot (18 bits would not fit 16).
+// The host checks that the circuit's table can be said that way (b3w_ctx.cpp: fill_ok) before it offers the variant.
 __device__ __forceinline__ uint16_t fill_entry16(uint32_t e) {
   const uint32_t src = e & 0xFFFu, sh = (e >> 12) & 31u, mode = (e >> 17) & 3u;
   return (uint16_t)(mode == B3W_MODE_BIT ? (src | sh << 10) : (src | (mode == B3W_MODE_W64 ? 1u : 0u) << 10 | 0x8000u));
 }
-__device__ __forceinline__ void fill_store(uint32_t e16, uint32_t w0, uint32_t w1, uint32_t par, bool in, uint8_t *p) {
-  const uint32_t f = (e16 >> 10) & 31u;
-  const bool word = (e16 & 0x8000u) != 0;
+__device__ __forceinline__ uint16_t fill_entry16_nova(uint32_t e) {
+  const uint32_t src = e & 0xFFFu, sh = (e >> 12) & 31u, mode = (e >> 17) & 3u;
+  return (uint16_t)(mode == B3W_MODE_BIT ? (src | sh << 11) : ((mode == B3W_MODE_W256 ? 0u : src) | (mode - 1u) << 11));
+}
+// e: the 16-bit entry, and for nova bit 16 = the word flag
+template <bool NOVA>
+__device__ __forceinline__ void fill_store(uint32_t e, uint32_t w0, uint32_t w1, uint32_t par, bool in, uint8_t *p) {
+  const uint32_t f = NOVA ? (e >> 11) & 31u : (e >> 10) & 31u;
+  const bool word = NOVA ? (e >> 16) != 0 : (e & 0x8000u) != 0;
   uint4 v;
   v.x = par ? 0u : (word ? w0 : (w0 >> f) & 1u);
   v.y = (!par && word && (f & 1u)) ? w1 : 0u;
   v.z = 0; v.w = 0;
-  if (in) store16<false>(p, v);
+  if (in && !(NOVA && word && f == 2u)) store16<false>(p, v);              // (a 256-bit slot: not this launch's)
+}
+// The same store through a BUFFER resource over the body (base, body bytes): a lane whose offset lies outside — in front of the body
+// (negative, i.e. huge), behind it, or made so on purpose (a 256-bit slot, a rejected step) — is dropped by the hardware's range check:
+// no branch and no exec-mask juggling per store (the nova storers were bound by their own instruction stream: 25 branches a unit).
+__device__ __forceinline__ void fill_store_nova(uint32_t e, uint32_t w0, uint32_t w1, uint32_t par, bool ok, __amdgpu_buffer_rsrc_t rsrc, uint32_t rel) {
+  const uint32_t f = (e >> 11) & 31u;
+  const bool word = (e >> 16) != 0;
+  u32x4 v;
+  v.x = par ? 0u : (word ? w0 : (w0 >> f) & 1u);
+  v.y = (!par && word && (f & 1u)) ? w1 : 0u;
+  v.z = 0; v.w = 0;
+  const uint32_t off = (ok && !(word && f == 2u)) ? rel : 0xFFFFFFF0u;
+  __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, (int)off, 0, 0);
 }
 
-// A body's public outputs and status go out through a STORING wave (from the image: O[16] is part of it), not through the tracer:
+// A body's public outputs and status go out through a STORING wave (from the image: they are part of it), not through the tracer:
 // the tracer's vector-memory counter then holds loads only — behind a saturated write stream a store is acknowledged microseconds
 // later, and the tracer would wait for its own output stores in order before it may use the next half's records.
+#define B3W_LDS_STWORD 46   // unused pad word of the image: the step's status (nova, fill-ordered kernel)
+template <bool NOVA>
 __device__ __forceinline__ void fill_report(const uint32_t *img, uint32_t w, uint32_t lane, uint32_t *__restrict__ pub, int32_t *__restrict__ status) {
-  if (pub && lane < 16) pub[(uint64_t)w * 16 + lane] = img[B3W_A_O + lane];
-  if (status && lane == 16) status[w] = 0;                                  // canonical u32 inputs cannot fail an assert
+  if (!NOVA) {
+    if (pub && lane < 16) pub[(uint64_t)w * 16 + lane] = img[B3W_A_O + lane];
+    if (status && lane == 16) status[w] = 0;                                // canonical u32 inputs cannot fail an assert
+    return;
+  }
+  // w[1..15]: n_blocks_out block_count_out h_out[8] total_depth_out depth_out chunk_idx_low_out chunk_idx_high_out leaf_depth_out
+  if (pub && lane < 15 && img[B3W_LDS_OKWORD]) {
+    const uint32_t *nv = img + B3W_LDS_NV;
+    const uint32_t src = lane == 0 ? B3W_LDS_NV + NV_N_BLOCKS : lane == 1 ? B3W_LDS_NV + NV_BLOCK_COUNT_OUT : lane < 10 ? B3W_A_O + (lane - 2)
+                       : lane == 10 ? B3W_LDS_NV + NV_TOTAL_DEPTH : lane == 11 ? B3W_LDS_NV + NV_DEPTH_OUT : lane == 12 ? B3W_LDS_NV + NV_CIL
+                       : lane == 13 ? B3W_LDS_NV + NV_CIH : B3W_LDS_NV + NV_LEAF_DEPTH;
+    (void)nv;
+    pub[(uint64_t)w * 15 + lane] = img[src];
+  }
+  if (status && lane == 16) status[w] = (int32_t)img[B3W_LDS_STWORD];
 }
 
-// the tracer's half: records of `cnt` bodies (w_of(k)) from registers into the images, the traces, the outputs of the bodies this
-// workgroup reports (rep_of(k)); while it traces, the NEXT half's records are already on their way (a dependent global load costs
-// as much as the whole trace)
-template <int NH>
-struct TracerRecs { uint32_t r[(NH * 28 + 63) / 64]; };
-template <int NH, typename WOf>
-__device__ __forceinline__ void tracer_load(TracerRecs<NH> &t, const uint32_t *__restrict__ recs, uint32_t cnt, uint32_t lane, WOf w_of) {
+// the tracer's half: records of `cnt` bodies (w_of(k)) from registers into the images; while it traces, the NEXT half's records are
+// already on their way (a dependent global load costs as much as the whole trace).  NREC words a record, to image word DST of a
+// WORDS-word image.
+template <int NH, int NREC>
+struct TracerRecs { uint32_t r[(NH * NREC + 63) / 64]; };
+template <int NH, int NREC, typename WOf>
+__device__ __forceinline__ void tracer_load(TracerRecs<NH, NREC> &t, const uint32_t *__restrict__ recs, uint32_t cnt, uint32_t lane, WOf w_of) {
 #pragma unroll
-  for (int c = 0; c < (NH * 28 + 63) / 64; ++c) {
-    const uint32_t i = lane + 64u * c, k = i / 28, j = i - k * 28;
-    t.r[c] = k < cnt ? recs[(uint64_t)w_of(k) * 28 + j] : 0u;
+  for (int c = 0; c < (NH * NREC + 63) / 64; ++c) {
+    const uint32_t i = lane + 64u * c, k = i / NREC, j = i - k * NREC;
+    t.r[c] = k < cnt ? recs[(uint64_t)w_of(k) * NREC + j] : 0u;
   }
 }
-template <int NH>
-__device__ __forceinline__ void tracer_put(const TracerRecs<NH> &t, uint32_t *half, uint32_t cnt, uint32_t lane) {
+template <int NH, int NREC, int WORDS, int DST>
+__device__ __forceinline__ void tracer_put(const TracerRecs<NH, NREC> &t, uint32_t *half, uint32_t cnt, uint32_t lane) {
 #pragma unroll
-  for (int c = 0; c < (NH * 28 + 63) / 64; ++c) {
-    const uint32_t i = lane + 64u * c, k = i / 28, j = i - k * 28;
-    if (k < cnt) half[k * B3W_LDS_WORDS_COMP + B3W_A_H + j] = t.r[c];
+  for (int c = 0; c < (NH * NREC + 63) / 64; ++c) {
+    const uint32_t i = lane + 64u * c, k = i / NREC, j = i - k * NREC;
+    if (k < cnt) half[k * WORDS + DST + j] = t.r[c];
   }
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
   __builtin_amdgcn_wave_barrier();
@@ -951,23 +1046,41 @@ __device__ __forceinline__ void region_list_batch(RegionList &s, uint2 *ring, ui
   s.done = s.done || __builtin_amdgcn_ballot_w64(!valid) != 0;
 }
 
-template <int NH>
-__global__ __launch_bounds__(320, 1) void b3w_compression_regionfill_kernel(const uint32_t *__restrict__ recs, uint32_t n,
-                                                                            uint8_t *__restrict__ out, uint64_t pitch,
-                                                                            const uint32_t *__restrict__ table, uint32_t nwit,
-                                                                            uint32_t *__restrict__ pub, int32_t *__restrict__ status) {
-  constexpr int WORDS = B3W_LDS_WORDS_COMP, R = 4;
+// KIND: the compression circuit, or the nova O2 builds — whose images here are the NARROW part only (4.7 instead of 6.9 KB: the tracer
+// computes the IsZero gadgets' flags, not their inverses; the 67 256-bit slots of a body are skipped and written by a second small
+// launch, b3w_nova_kernel MODE 3).
+// NSTG: groups of four storing waves; group g takes the units g, g + NSTG, ... of a half (the nova storers do more per slot — the word-flag
+// bitmap, the 256-bit skip — and a unit's three dependent LDS round trips cost a lone wave as much as its four stores take: two groups
+// hide them behind each other).
+template <int KIND, int NH, int NSTG>
+__global__ __launch_bounds__(64 * (4 * NSTG + 1), 1) void b3w_regionfill_kernel(const uint32_t *__restrict__ recs, uint32_t n,
+                                                                uint8_t *__restrict__ out, uint64_t pitch,
+                                                                const uint32_t *__restrict__ table, uint32_t nwit,
+                                                                uint32_t *__restrict__ pub, int32_t *__restrict__ status) {
+  constexpr bool NOVA = KIND != B3W_KIND_COMP;
+  constexpr int WORDS = NOVA ? B3W_LDS_WIDE : B3W_LDS_WORDS_COMP, NREC = NOVA ? 32 : 28, RDST = NOVA ? B3W_LDS_NV : B3W_A_H, R = 4;
   extern __shared__ __attribute__((aligned(16))) uint32_t bf_lds[];
   __shared__ uint2 ring[B3W_RF_RING];                                       // unit descriptors, unit k at k % ring
   __shared__ uint32_t cnt_ring[4];                                          // units of half h at h % 4
   uint16_t *tab = reinterpret_cast<uint16_t *>(bf_lds);
-  uint32_t *lds = bf_lds + ((nwit + 7u) & ~7u) / 2;
+  const uint32_t tabw = ((nwit + 7u) & ~7u) / 2, bmw = NOVA ? ((nwit + 127u) & ~127u) / 32 : 0u;
+  uint32_t *bitmap = bf_lds + tabw, *lds = bf_lds + tabw + bmw;
   const uint32_t wave = uni(threadIdx.x >> 6), lane = threadIdx.x & 63u;
   const uint32_t x = blockIdx.x & 7u, grp = blockIdx.x >> 3;              // XCD residue; group (32 of them: gridDim.x = 256)
   const uint32_t body = 32u * nwit;
-  for (uint32_t i = threadIdx.x; i < nwit; i += 320) tab[i] = fill_entry16(table[i]);
+  constexpr uint32_t NTHR = 64 * (4 * NSTG + 1);
+  for (uint32_t i = threadIdx.x; i < nwit; i += NTHR) tab[i] = NOVA ? fill_entry16_nova(table[i]) : fill_entry16(table[i]);
+  if (NOVA)
+    for (uint32_t wd = threadIdx.x; wd < bmw; wd += NTHR) {
+      uint32_t bits = 0;
+      for (uint32_t bb = 0; bb < 32; ++bb) {
+        const uint32_t sl = wd * 32 + bb;
+        if (sl < nwit && ((table[sl] >> 17) & 3u) != B3W_MODE_BIT) bits |= 1u << bb;
+      }
+      bitmap[wd] = bits;
+    }
   __syncthreads();
-  if (wave == 4) {
+  if (wave == 4 * NSTG) {
     // ---- TRACER: lists the units two halves ahead, loads the records one half ahead, traces half h into image half h & 1; one barrier
     // per half, the last one for a half that is not full (possibly empty)
     const uint32_t q = lane >> 2, col = lane & 3;
@@ -982,17 +1095,27 @@ __global__ __launch_bounds__(320, 1) void b3w_compression_regionfill_kernel(cons
       __builtin_amdgcn_wave_barrier();
     };
     auto cnt_of = [&](uint32_t h) { return rl.produced <= h * NH ? 0u : (rl.produced - h * NH < (uint32_t)NH ? rl.produced - h * NH : (uint32_t)NH); };
-    TracerRecs<NH> tr;
+    TracerRecs<NH, NREC> tr;
     list_until(2 * NH);
-    tracer_load<NH>(tr, recs, cnt_of(0), lane, [&](uint32_t k) { return ring[k % B3W_RF_RING].x & 0x7FFFFFFFu; });
+    tracer_load<NH, NREC>(tr, recs, cnt_of(0), lane, [&](uint32_t k) { return ring[k % B3W_RF_RING].x & 0x7FFFFFFFu; });
     for (uint32_t h = 0;; ++h) {
       uint32_t *half = lds + (h & 1) * NH * WORDS;
       list_until((h + 3) * NH);                                             // (ring: at most 3 NH + 127 units between the oldest in use and the newest)
       const uint32_t cnt = cnt_of(h);
       if (lane == 0) cnt_ring[h & 3] = cnt;
-      tracer_put<NH>(tr, half, cnt, lane);
-      tracer_load<NH>(tr, recs, cnt_of(h + 1), lane, [&](uint32_t k) { return ring[((h + 1) * NH + k) % B3W_RF_RING].x & 0x7FFFFFFFu; });
-      if (q < cnt) trace_compression(half + q * WORDS, col, nullptr);       // (outputs: the storers', see fill_report)
+      tracer_put<NH, NREC, WORDS, RDST>(tr, half, cnt, lane);
+      tracer_load<NH, NREC>(tr, recs, cnt_of(h + 1), lane, [&](uint32_t k) { return ring[((h + 1) * NH + k) % B3W_RF_RING].x & 0x7FFFFFFFu; });
+      if (!NOVA) {
+        if (q < cnt) trace_compression(half + q * WORDS, col, nullptr);     // (outputs: the storers', see fill_report)
+      } else {
+        if (q < cnt) {
+          uint32_t *L = half + q * WORDS;
+          const bool dom_a = nova_iszero_flags_quad(L, (int)col);           // (flags only: no field arithmetic, no table of inverses)
+          const int32_t st = nova_select(L, (int)col, dom_a);
+          if (col == 0) { L[B3W_LDS_OKWORD] = st == 0 ? 1u : 0u; L[B3W_LDS_STWORD] = (uint32_t)st; }
+          if (st == 0) trace_compression(L, col, nullptr);
+        }
+      }
       __syncthreads();
       if (cnt < (uint32_t)NH) break;
     }
@@ -1000,46 +1123,72 @@ __global__ __launch_bounds__(320, 1) void b3w_compression_regionfill_kernel(cons
   }
   // ---- STORERS: per half, after its barrier: the units' descriptors from the ring; table words one unit ahead
   const uint32_t par = lane & 1u;
-  const uint32_t lane_off = (x << 12) + (wave << 10) + (lane << 4);         // this lane's byte offset into a region in step 0; step r: + r * 32 KiB
-  auto read_unit = [&](uint32_t k, uint32_t &wq, int32_t &rel0, uint32_t (&e)[R]) {
+  const uint32_t sub = wave & 3u, sg = wave >> 2;                           // which KiB of a block; which group of storing waves
+  const uint32_t lane_off = (x << 12) + (sub << 10) + (lane << 4);          // this lane's byte offset into a region in step 0; step r: + r * 32 KiB
+  // A unit goes through three stages, each an LDS round trip behind the one before: S1 descriptor -> table words; S2 image words (and the
+  // image's ok word); S3 shape and store.  Three register sets rotate so that S1 of unit i + 2 and S2 of unit i + 1 are in flight while
+  // unit i is stored (a lone wave per SIMD has nobody else to hide the round trips behind: exposed, they were a quarter of a unit's time).
+  struct Ent { uint32_t wq; int32_t rel0; uint32_t e[R]; };
+  struct Wd { uint32_t w0[R], w1[R], ok; };
+  auto s1 = [&](uint32_t k, Ent &en) {                                       // (the descriptor read a further stage ahead was measured: slower)
     const uint2 d = ring[k % B3W_RF_RING];
-    wq = uni(d.x);
-    rel0 = (int32_t)uni(d.y) + (int32_t)lane_off;
+    en.wq = uni(d.x);
+    en.rel0 = (int32_t)uni(d.y) + (int32_t)lane_off;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-      const uint32_t rel = (uint32_t)(rel0 + (int32_t)(r << 15));
-      e[r] = tab[rel < body ? rel >> 5 : 0u];
+      const uint32_t rel = (uint32_t)(en.rel0 + (int32_t)(r << 15));
+      const uint32_t slot = rel < body ? rel >> 5 : 0u;
+      en.e[r] = tab[slot];
+      if (NOVA) en.e[r] |= ((bitmap[slot >> 5] >> (slot & 31u)) & 1u) << 16;
     }
   };
-  auto store_unit = [&](uint32_t wq, int32_t rel0, const uint32_t (&e)[R], const uint32_t *img) {
-    uint32_t w0[R], w1[R];
+  auto s2 = [&](const Ent &en, Wd &wd, const uint32_t *img) {
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-      const uint32_t *L = img + (e[r] & 0x3FFu);
-      w0[r] = L[0]; w1[r] = L[1];
+      const uint32_t *L = img + (en.e[r] & (NOVA ? 0x7FFu : 0x3FFu));
+      wd.w0[r] = L[0]; wd.w1[r] = L[1];
     }
-    const uint32_t w = wq & 0x7FFFFFFFu;
-    if ((wq >> 31) && x == 0 && wave == 0) fill_report(img, w, lane, pub, status);   // the unit in which the body starts reports for it
+    wd.ok = NOVA ? img[B3W_LDS_OKWORD] : 1u;                                 // a rejected step's body is left alone
+  };
+  auto s3 = [&](const Ent &en, const Wd &wd, const uint32_t *img) {
+    const uint32_t w = en.wq & 0x7FFFFFFFu;
+    if ((en.wq >> 31) && x == 0 && sub == 0) fill_report<NOVA>(img, w, lane, pub, status);    // the unit in which the body starts reports for it
     uint8_t *dst = out + (uint64_t)w * pitch;
+    if (NOVA) {
+      const bool ok = uni(wd.ok) != 0;
+      const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(dst, 0, (int)body, 0x00020000);
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-      const uint32_t rel = (uint32_t)(rel0 + (int32_t)(r << 15));
-      fill_store(e[r], w0[r], w1[r], par, rel < body, dst + rel);
+      for (int r = 0; r < R; ++r) fill_store_nova(en.e[r], wd.w0[r], wd.w1[r], par, ok, rsrc, (uint32_t)(en.rel0 + (int32_t)(r << 15)));
+    } else {
+#pragma unroll
+      for (int r = 0; r < R; ++r) {
+        const uint32_t rel = (uint32_t)(en.rel0 + (int32_t)(r << 15));
+        fill_store<NOVA>(en.e[r], wd.w0[r], wd.w1[r], par, rel < body, dst + rel);
+      }
     }
   };
   for (uint32_t h = 0;; ++h) {
     __syncthreads();                                                         // image half h & 1, descriptors and count of half h are there
     const uint32_t cnt = uni(cnt_ring[h & 3]);
     const uint32_t *half = lds + (h & 1) * NH * WORDS;
-    uint32_t wa = 0, wb = 0, ea[R], eb[R];
-    int32_t ra = 0, rb = 0;
-    if (cnt) read_unit(h * NH, wa, ra, ea);
-    for (uint32_t i = 0; i < cnt; i += 2) {
-      if (i + 1 < cnt) read_unit(h * NH + i + 1, wb, rb, eb);
-      store_unit(wa, ra, ea, half + i * WORDS);
+    const uint32_t k0 = h * NH;
+    Ent e0, e1, e2;
+    Wd d0, d1, d2;
+    if (0 < cnt) s1(k0, e0);
+    if (1 < cnt) s1(k0 + 1, e1);
+    if (0 < cnt) s2(e0, d0, half);
+    for (uint32_t i = 0; i < cnt; i += 3) {
+      if (i + 2 < cnt) s1(k0 + i + 2, e2);
+      if (i + 1 < cnt) s2(e1, d1, half + (i + 1) * WORDS);
+      s3(e0, d0, half + i * WORDS);
       if (i + 1 >= cnt) break;
-      if (i + 2 < cnt) read_unit(h * NH + i + 2, wa, ra, ea);
-      store_unit(wb, rb, eb, half + (i + 1) * WORDS);
+      if (i + 3 < cnt) s1(k0 + i + 3, e0);
+      if (i + 2 < cnt) s2(e2, d2, half + (i + 2) * WORDS);
+      s3(e1, d1, half + (i + 1) * WORDS);
+      if (i + 2 >= cnt) break;
+      if (i + 4 < cnt) s1(k0 + i + 4, e1);
+      if (i + 3 < cnt) s2(e0, d0, half + (i + 3) * WORDS);
+      s3(e2, d2, half + (i + 2) * WORDS);
     }
     if (cnt < (uint32_t)NH) break;
   }
@@ -1153,14 +1302,17 @@ extern "C" int b3w_launch_batch(int kind, int variant, const uint32_t *d_recs, u
     }
     return (int)hipGetLastError();
   }
-#define B3W_FILL_NH 14
-#define B3W_FILL_SMEM(nwit) ((size_t)(((nwit) + 7u) & ~7u) * 2 + (size_t)(2 * B3W_FILL_NH * B3W_LDS_WORDS_COMP + 4) * 4)
   if (variant == B3W_VARIANT_REGIONFILL) {
-    // 256 workgroups (one per CU; workgroup i on XCD i % 8); 32-byte aligned bodies (a lane pair is one slot); the compression circuit
-    if (kind != B3W_KIND_COMP) return -1;
+    // 256 workgroups (one per CU; workgroup i on XCD i % 8); 32-byte aligned bodies (a lane pair is one slot); compression and nova O2
+    if (kind != B3W_KIND_COMP && kind != B3W_KIND_NOVA_O2) return -1;
+    if (kind == B3W_KIND_NOVA_O2 && !d_aux) return -3;
     if ((reinterpret_cast<uintptr_t>(d_out) & 31) || (pitch & 31) || pitch >= (1ull << 30)) return -5;
     if (32ull * nwit < (1ull << 17) || (uint64_t)n * pitch + (1ull << 20) >= (1ull << 37)) return -5;      // a region meets two bodies at most; 32-bit slot positions
-    const size_t smem = B3W_FILL_SMEM(nwit);                     // slot table (16 bits a slot) + 2 x NH images
+    // slot table (16 bits a slot) [+ one bit a slot] + 2 x NH images: 14 of 3.7 KB (compression), 11 of the 4.7 KB narrow nova image
+    constexpr int NH_C = 14, NH_N = 11;
+    const bool nova = kind != B3W_KIND_COMP;
+    const size_t smem = (size_t)((nwit + 7u) & ~7u) * 2 + (nova ? (size_t)((nwit + 127u) & ~127u) / 8 : 0) +
+                        (size_t)(2 * (nova ? NH_N * B3W_LDS_WIDE : NH_C * B3W_LDS_WORDS_COMP) + 4) * 4;
     constexpr size_t B3W_FILL_MAX_SMEM = 160 * 1024 - 4096;      // (+ the kernel's static descriptor ring)
     if (smem > B3W_FILL_MAX_SMEM) return -5;
     static std::atomic<uint64_t> attr_done{0};                   // per device: one bit per ordinal, as for the sweep kernels
@@ -1168,13 +1320,25 @@ extern "C" int b3w_launch_batch(int kind, int variant, const uint32_t *d_recs, u
     (void)hipGetDevice(&dev);
     const uint64_t bit = 1ull << (dev & 63);
     if (!(attr_done.load(std::memory_order_acquire) & bit)) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&b3w_compression_regionfill_kernel<B3W_FILL_NH>),
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&b3w_regionfill_kernel<B3W_KIND_COMP, NH_C, 1>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)B3W_FILL_MAX_SMEM);
+      if (e == hipSuccess)
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&b3w_regionfill_kernel<B3W_KIND_NOVA_O2, NH_N, 1>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)B3W_FILL_MAX_SMEM);
       if (e != hipSuccess) return (int)e;
       attr_done.fetch_or(bit, std::memory_order_release);
     }
-    hipLaunchKernelGGL((b3w_compression_regionfill_kernel<B3W_FILL_NH>), dim3(B3W_REGIONFILL_GRID), dim3(320), smem, stream, d_recs, n, d_out, pitch,
-                       d_table, nwit, d_pub, d_status);
+    if (!nova) {
+      hipLaunchKernelGGL((b3w_regionfill_kernel<B3W_KIND_COMP, NH_C, 1>), dim3(B3W_REGIONFILL_GRID), dim3(320), smem, stream, d_recs, n, d_out, pitch,
+                         d_table, nwit, d_pub, d_status);
+    } else {
+      hipLaunchKernelGGL((b3w_regionfill_kernel<B3W_KIND_NOVA_O2, NH_N, 1>), dim3(B3W_REGIONFILL_GRID), dim3(320), smem, stream, d_recs, n, d_out, pitch,
+                         d_table, nwit, d_pub, d_status);
+      // ... and the 67 field inverses of every body (0.3 % of its bytes): the body-stream kernel's gadget phase, its stores alone
+      const uint32_t *d_wide = static_cast<const uint32_t *>(d_aux) + B3W_AUX_WIDE_SLOTS;
+      hipLaunchKernelGGL((b3w_nova_kernel<B3W_KIND_NOVA_O2, 2, false, 3>), dim3((n + 1) / 2), dim3(64), 0, stream, d_recs, n, d_out, pitch, d_wide, nwit,
+                         (uint32_t *)nullptr, (int32_t *)nullptr, (const uint32_t *)d_aux, 1u);
+    }
     return (int)hipGetLastError();
   }
   if (variant > B3W_VARIANT_REGIONFILL) return -1;

@@ -81,7 +81,7 @@ def test_regionfill_every_start_in_a_region_and_untouched_bytes(m):
 
 
 def test_regionfill_refuses_what_it_cannot_take(m):
-    """16-byte aligned bodies (a lane pair is one 32-byte slot) and the nova circuits: B3W_E_BAD_ARGUMENT, nothing written."""
+    """16-byte aligned bodies (a lane pair is one 32-byte slot) and the unsimplified nova build: B3W_E_BAD_ARGUMENT, nothing written."""
     import torch
     dev = torch.device("cuda:0")
     s = torch.cuda.current_stream().cuda_stream
@@ -94,7 +94,7 @@ def test_regionfill_refuses_what_it_cannot_take(m):
     torch.cuda.synchronize()
     assert bool((buf == FILL).all().item())
     ctx.close()
-    nova = _fill_ctx(m, "nova_vesta")
+    nova = _fill_ctx(m, "nova_bn254_o1")                     # the unsimplified build: 11 KB images, no fill-ordered kernel
     nrec = torch.from_numpy(T.workloads().config3_nova(4).view(np.int32)).to(dev)
     nb = torch.empty(4 * nova.body_bytes, dtype=torch.uint8, device=dev)
     with pytest.raises(m.B3WError):
@@ -161,3 +161,94 @@ def test_a_batch_whose_own_buffer_came_out_plain_takes_the_fill_order_and_stays_
     for i in (0, 57, 99):
         assert np.array_equal(b.fetch(i), want[i] if i < 40 else T.oracle_batch_u32("compression", recs[i:i + 1])[1][0])
     b.close(); ctx.close()
+
+
+@pytest.mark.parametrize("circuit", ["nova_vesta", "nova_bn254"])
+def test_regionfill_nova_matches_oracle_with_rejected_steps_everywhere(m, circuit):
+    """The nova O2 builds through the fill-ordered path: narrow images in the fill kernel + the 67 field inverses of every body from a
+    second launch.  Rejected steps (first, middle, last; neighbours in one region) leave their bodies alone and report their status; every
+    other body, the public outputs and the bytes around the bodies as ever — for several pitches and starts of the buffer in a region."""
+    import torch
+    n = 41
+    recs = T.workloads().config3_nova(n, first=17).copy()
+    bad_idx = [0, 7, 8, 23, 40]
+    for i in bad_idx:
+        recs[i, 14] = recs[i, 12] + (i % 2)                    # depth >= leaf_depth
+    recs[11, 14] = 0xFFFFFFFF                                  # outside the kernels' domain: status 103
+    nbad, want = T.oracle_batch_u32(circuit, recs)
+    want = want.copy()
+    ctx = _fill_ctx(m, circuit)
+    body = ctx.body_bytes
+    dev = torch.device("cuda:0")
+    d_recs = torch.from_numpy(recs.view(np.int32)).to(dev)
+    s = torch.cuda.current_stream().cuda_stream
+    ref = m.Context(circuit, 0)
+    d_ref_st = torch.full((n,), -1, dtype=torch.int32, device=dev)
+    d_ref_pub = torch.zeros((n, 15), dtype=torch.int32, device=dev)
+    d_ref = torch.full((n, body), FILL, dtype=torch.uint8, device=dev)
+    ref.run_device(d_recs.data_ptr(), n, d_ref.data_ptr(), 0, d_ref_pub.data_ptr(), d_ref_st.data_ptr(), s)
+    torch.cuda.synchronize()
+    ref_st = d_ref_st.cpu().numpy()
+    assert [i for i in range(n) if ref_st[i] != 0] == sorted(bad_idx + [11])
+    margin = 1 << 17
+    for pad in (0, 32, 4096 + 96):
+        pitch = body + pad
+        for skew in (0, 4064, 65536 + 32):
+            buf = torch.full((2 * margin + n * pitch + 4096,), FILL, dtype=torch.uint8, device=dev)
+            lo = margin - (buf.data_ptr() % margin) + skew
+            d_st = torch.full((n,), -1, dtype=torch.int32, device=dev)
+            d_pub = torch.zeros((n, 15), dtype=torch.int32, device=dev)
+            ctx.run_device(d_recs.data_ptr(), n, buf.data_ptr() + lo, pitch, d_pub.data_ptr(), d_st.data_ptr(), s)
+            torch.cuda.synchronize()
+            st = d_st.cpu().numpy()
+            assert np.array_equal(st, ref_st), (pad, skew, st)
+            ok = st == 0
+            assert np.array_equal(d_pub.cpu().numpy()[ok], d_ref_pub.cpu().numpy()[ok])
+            host = buf.cpu().numpy()
+            assert (host[:lo] == FILL).all()
+            for i in range(n):
+                got = host[lo + i * pitch: lo + i * pitch + body]
+                if ok[i]:
+                    assert np.array_equal(got, want[i]), (circuit, pad, skew, i, np.nonzero(got != want[i])[0][:8] // 32)
+                else:
+                    assert (got == FILL).all(), (pad, skew, i, "a rejected step's body was written")
+                gap = host[lo + i * pitch + body: lo + (i + 1) * pitch] if i + 1 < n else host[lo + i * pitch + body:]
+                assert (gap == FILL).all(), (pad, skew, i)
+    ref.close(); ctx.close()
+
+
+def test_regionfill_nova_large_batch_and_large_iszero_arguments(m):
+    """9 000 Vesta steps through the fill-ordered path against the body-stream kernel (whole buffer, outputs, status), among them steps whose
+    IsZero arguments leave the table of small inverses (the second launch's general inverse) and steps outside the domain."""
+    import torch
+    n = 9000
+    recs = T.workloads().config3_nova(n, first=1).copy()
+    recs[5, 12] = 250; recs[5, 13] = 4000000000; recs[5, 14] = 249          # total_depth far from depth: |k| beyond the table
+    recs[77, 1] = 3000000000; recs[77, 0] = 3000000001                      # block_count near n_blocks, both huge
+    recs[4000, 14] = recs[4000, 12]                                         # rejected
+    dev = torch.device("cuda:0")
+    s = torch.cuda.current_stream().cuda_stream
+    d_recs = torch.from_numpy(recs.view(np.int32)).to(dev)
+    out = {}
+    for variant in (3, 200):
+        os.environ["B3W_VARIANT"] = str(variant)
+        try:
+            ctx = m.Context("nova_vesta", 0)
+        finally:
+            del os.environ["B3W_VARIANT"]
+        d_bodies = torch.full((n, ctx.body_bytes), FILL, dtype=torch.uint8, device=dev)
+        d_pub = torch.zeros((n, 15), dtype=torch.int32, device=dev)
+        d_st = torch.full((n,), -1, dtype=torch.int32, device=dev)
+        ctx.run_device(d_recs.data_ptr(), n, d_bodies.data_ptr(), 0, d_pub.data_ptr(), d_st.data_ptr(), s)
+        torch.cuda.synchronize()
+        out[variant] = (d_bodies, d_pub, d_st)
+        ctx.close()
+    assert torch.equal(out[3][2], out[200][2]) and int(out[200][2][4000].item()) == 4
+    ok = out[3][2] == 0
+    assert torch.equal(out[3][1][ok], out[200][1][ok])
+    assert torch.equal(out[3][0], out[200][0])
+    idx = np.array([0, 5, 77, 3999, 4001, n - 1])
+    okh = ok.cpu().numpy()
+    idx = idx[okh[idx]]
+    _, want = T.oracle_batch_u32("nova_vesta", recs[idx])
+    assert np.array_equal(out[200][0][torch.from_numpy(idx).to(dev)].cpu().numpy(), want)
