@@ -54,7 +54,7 @@ def reference_wasm(circuit, reference_dir, seconds):
         return None
 
 
-WITNESS_KERNELS = ("b3w_compression_kernel", "b3w_nova_kernel", "b3w_sweep_kernel", "b3w_compression_regionfill_kernel")
+WITNESS_KERNELS = ("b3w_compression_kernel", "b3w_nova_kernel", "b3w_sweep_kernel", "b3w_regionfill_kernel")
 
 
 def kernel_path(v):

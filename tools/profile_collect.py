@@ -12,7 +12,7 @@ rnd = sys.argv[2] if len(sys.argv) > 2 else "r01"
 src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
 dst = os.path.join(ROOT, "profiles", rnd)
 os.makedirs(dst, exist_ok=True)
-WITNESS_KERNELS = ("b3w_compression_kernel", "b3w_nova_kernel", "b3w_sweep_kernel", "b3w_compression_regionfill_kernel")
+WITNESS_KERNELS = ("b3w_compression_kernel", "b3w_nova_kernel", "b3w_sweep_kernel", "b3w_regionfill_kernel")
 # the MODE template argument of the witness kernels: <W, NT, MODE, SL, PERSIST> / <KIND, W, NT, MODE, SL, PERSIST> (0 fused, 1 TRACE, 2 VERIFY;
 # PERSIST since r06)
 MODE = re.compile(r"(?:true|false), (\d), (?:true|false)(?:, (?:true|false))?>\(")
@@ -50,7 +50,7 @@ for name in ("WRITE_SIZE", "FETCH_SIZE"):
     chosen = max(fused, key=fused.get) if fused else None
     def timed(kn):
         if fill:
-            return "b3w_compression_regionfill_kernel" in kn
+            return "b3w_regionfill_kernel" in kn
         if sweep:
             return "b3w_sweep_kernel" in kn or bool(MODE.search(kn) and MODE.search(kn).group(1) == "1")
         return kn == chosen
