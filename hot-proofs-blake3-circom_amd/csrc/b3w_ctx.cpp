@@ -442,7 +442,7 @@ int32_t b3w_batch_run_device(b3w_ctx *ctx, const uint32_t *d_records, uint32_t n
     const bool comp = ctx->desc.kind == B3W_KIND_COMP;
     if (n <= 2560) variant = B3W_VARIANT_SLICED + (n <= (comp ? 32u : 8u) ? 64 : n <= 96 ? 32 : n <= 192 ? 16 : n <= 768 ? 8 : 4);
     else if (comp) variant = n <= 6144 ? 0 : 8;
-    else if (ctx->desc.kind == B3W_KIND_NOVA_O2) variant = n <= 3072 ? 0 : n < 32768 ? 3 : 4;      // (4: 8 bodies a wave on a persistent grid)
+    else if (ctx->desc.kind == B3W_KIND_NOVA_O2) variant = n <= 3072 ? 0 : n <= 32768 ? 3 : 4;     // (4: 8 bodies a wave on a persistent grid — 16 384 steps: -1 %, 32 768: equal, 65 536: +1.3 %)
     else variant = 0;
   }
   if (variant >= B3W_VARIANT_REGIONFILL && !ctx->fill_ok) { ctx->last_error = "the fill-ordered variant (200) exists for the compression circuit and the nova O2 builds"; return B3W_E_BAD_ARGUMENT; }

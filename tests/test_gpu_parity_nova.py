@@ -189,7 +189,7 @@ def test_nova_full_config3_batch(m):
 
 
 def test_nova_persistent_grid_takes_several_groups_per_wave_with_rejected_steps(m):
-    """Variant 4 of the O2 kernels (8 bodies a wave on a persistent grid of 512 waves — the default for batches of 32 768 steps and more):
+    """Variant 4 of the O2 kernels (8 bodies a wave on a persistent grid of 512 waves — the default for batches of more than 32 768 steps):
     9 000 steps are more than two rounds of the grid, the last one ragged; rejected steps in the first, a middle and the last group must
     leave their bodies alone and must not leak their flags into the wave's next group.  Status and public outputs of every step and the
     bodies around every rejected step equal variant 3's; 300 bodies byte for byte against the oracle."""
