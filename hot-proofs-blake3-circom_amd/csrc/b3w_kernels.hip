@@ -1049,11 +1049,10 @@ __device__ __forceinline__ void region_list_batch(RegionList &s, uint2 *ring, ui
 // KIND: the compression circuit, or the nova O2 builds — whose images here are the NARROW part only (4.7 instead of 6.9 KB: the tracer
 // computes the IsZero gadgets' flags, not their inverses; the 67 256-bit slots of a body are skipped and written by a second small
 // launch, b3w_nova_kernel MODE 3).
-// NSTG: groups of four storing waves; group g takes the units g, g + NSTG, ... of a half (the nova storers do more per slot — the word-flag
-// bitmap, the 256-bit skip — and a unit's three dependent LDS round trips cost a lone wave as much as its four stores take: two groups
-// hide them behind each other).
-template <int KIND, int NH, int NSTG>
-__global__ __launch_bounds__(64 * (4 * NSTG + 1), 1) void b3w_regionfill_kernel(const uint32_t *__restrict__ recs, uint32_t n,
+// (Two groups of four storing waves were measured for the nova storers, which do more per slot: the storers' own time halves, the store
+// rate FALLS — 5.2 against 5.9 TB/s —, eight storing waves a CU being no fill shape any more.)
+template <int KIND, int NH>
+__global__ __launch_bounds__(320, 1) void b3w_regionfill_kernel(const uint32_t *__restrict__ recs, uint32_t n,
                                                                 uint8_t *__restrict__ out, uint64_t pitch,
                                                                 const uint32_t *__restrict__ table, uint32_t nwit,
                                                                 uint32_t *__restrict__ pub, int32_t *__restrict__ status) {
@@ -1068,7 +1067,7 @@ __global__ __launch_bounds__(64 * (4 * NSTG + 1), 1) void b3w_regionfill_kernel(
   const uint32_t wave = uni(threadIdx.x >> 6), lane = threadIdx.x & 63u;
   const uint32_t x = blockIdx.x & 7u, grp = blockIdx.x >> 3;              // XCD residue; group (32 of them: gridDim.x = 256)
   const uint32_t body = 32u * nwit;
-  constexpr uint32_t NTHR = 64 * (4 * NSTG + 1);
+  constexpr uint32_t NTHR = 320;
   for (uint32_t i = threadIdx.x; i < nwit; i += NTHR) tab[i] = NOVA ? fill_entry16_nova(table[i]) : fill_entry16(table[i]);
   if (NOVA)
     for (uint32_t wd = threadIdx.x; wd < bmw; wd += NTHR) {
@@ -1080,7 +1079,7 @@ __global__ __launch_bounds__(64 * (4 * NSTG + 1), 1) void b3w_regionfill_kernel(
       bitmap[wd] = bits;
     }
   __syncthreads();
-  if (wave == 4 * NSTG) {
+  if (wave == 4) {
     // ---- TRACER: lists the units two halves ahead, loads the records one half ahead, traces half h into image half h & 1; one barrier
     // per half, the last one for a half that is not full (possibly empty)
     const uint32_t q = lane >> 2, col = lane & 3;
@@ -1123,7 +1122,7 @@ __global__ __launch_bounds__(64 * (4 * NSTG + 1), 1) void b3w_regionfill_kernel(
   }
   // ---- STORERS: per half, after its barrier: the units' descriptors from the ring; table words one unit ahead
   const uint32_t par = lane & 1u;
-  const uint32_t sub = wave & 3u, sg = wave >> 2;                           // which KiB of a block; which group of storing waves
+  const uint32_t sub = wave;                                                // which KiB of a block this storing wave takes
   const uint32_t lane_off = (x << 12) + (sub << 10) + (lane << 4);          // this lane's byte offset into a region in step 0; step r: + r * 32 KiB
   // A unit goes through three stages, each an LDS round trip behind the one before: S1 descriptor -> table words; S2 image words (and the
   // image's ok word); S3 shape and store.  Three register sets rotate so that S1 of unit i + 2 and S2 of unit i + 1 are in flight while
@@ -1320,19 +1319,19 @@ extern "C" int b3w_launch_batch(int kind, int variant, const uint32_t *d_recs, u
     (void)hipGetDevice(&dev);
     const uint64_t bit = 1ull << (dev & 63);
     if (!(attr_done.load(std::memory_order_acquire) & bit)) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&b3w_regionfill_kernel<B3W_KIND_COMP, NH_C, 1>),
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(&b3w_regionfill_kernel<B3W_KIND_COMP, NH_C>),
                                          hipFuncAttributeMaxDynamicSharedMemorySize, (int)B3W_FILL_MAX_SMEM);
       if (e == hipSuccess)
-        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&b3w_regionfill_kernel<B3W_KIND_NOVA_O2, NH_N, 1>), hipFuncAttributeMaxDynamicSharedMemorySize,
+        e = hipFuncSetAttribute(reinterpret_cast<const void *>(&b3w_regionfill_kernel<B3W_KIND_NOVA_O2, NH_N>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)B3W_FILL_MAX_SMEM);
       if (e != hipSuccess) return (int)e;
       attr_done.fetch_or(bit, std::memory_order_release);
     }
     if (!nova) {
-      hipLaunchKernelGGL((b3w_regionfill_kernel<B3W_KIND_COMP, NH_C, 1>), dim3(B3W_REGIONFILL_GRID), dim3(320), smem, stream, d_recs, n, d_out, pitch,
+      hipLaunchKernelGGL((b3w_regionfill_kernel<B3W_KIND_COMP, NH_C>), dim3(B3W_REGIONFILL_GRID), dim3(320), smem, stream, d_recs, n, d_out, pitch,
                          d_table, nwit, d_pub, d_status);
     } else {
-      hipLaunchKernelGGL((b3w_regionfill_kernel<B3W_KIND_NOVA_O2, NH_N, 1>), dim3(B3W_REGIONFILL_GRID), dim3(320), smem, stream, d_recs, n, d_out, pitch,
+      hipLaunchKernelGGL((b3w_regionfill_kernel<B3W_KIND_NOVA_O2, NH_N>), dim3(B3W_REGIONFILL_GRID), dim3(320), smem, stream, d_recs, n, d_out, pitch,
                          d_table, nwit, d_pub, d_status);
       // ... and the 67 field inverses of every body (0.3 % of its bytes): the body-stream kernel's gadget phase, its stores alone
       const uint32_t *d_wide = static_cast<const uint32_t *>(d_aux) + B3W_AUX_WIDE_SLOTS;
