@@ -91,7 +91,7 @@ def live_traffic(args):
             cmd = [roc, "--pmc", counter, "--output-format", "csv", "-d", os.path.join(tmp, counter), "--", sys.executable, os.path.abspath(__file__),
                    "--traffic-child", "1", "--circuit", args.circuit, "--batch", str(args.batch), "--pitch", str(args.pitch), "--placement", "plain",
                    "--cpu-seconds", "0"] + (["--variant", str(args.variant)] if args.variant is not None else [])
-            r = subprocess.run(cmd, cwd=tmp, env=dict(os.environ, TMPDIR="/tmp", B3W_PLACE_CHECK="0"), capture_output=True, text=True, timeout=60)      # (two such passes at most: 2 s each when the profiler is healthy)
+            r = subprocess.run(cmd, cwd=tmp, env=dict(os.environ, TMPDIR="/tmp", B3W_PLACE_CHECK="0"), capture_output=True, text=True, timeout=120)     # (2 s a pass when warm; the first child of a fresh box also pays the cold `import torch`)
             if r.returncode != 0:
                 return None, f"the {counter} pass failed (rc {r.returncode}): " + (r.stderr or r.stdout)[-200:].replace("\n", " | ")
             child = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
