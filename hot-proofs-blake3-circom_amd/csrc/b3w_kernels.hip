@@ -1055,7 +1055,7 @@ template <int KIND, int NH>
 __global__ __launch_bounds__(320, 1) void b3w_regionfill_kernel(const uint32_t *__restrict__ recs, uint32_t n,
                                                                 uint8_t *__restrict__ out, uint64_t pitch,
                                                                 const uint32_t *__restrict__ table, uint32_t nwit,
-                                                                uint32_t *__restrict__ pub, int32_t *__restrict__ status) {
+                                                                uint32_t *__restrict__ pub, int32_t *__restrict__ status, uint32_t pace) {
   constexpr bool NOVA = KIND != B3W_KIND_COMP;
   constexpr int WORDS = NOVA ? B3W_LDS_WIDE : B3W_LDS_WORDS_COMP, NREC = NOVA ? 32 : 28, RDST = NOVA ? B3W_LDS_NV : B3W_A_H, R = 4;
   extern __shared__ __attribute__((aligned(16))) uint32_t bf_lds[];
@@ -1133,12 +1133,16 @@ __global__ __launch_bounds__(320, 1) void b3w_regionfill_kernel(const uint32_t *
     const uint2 d = ring[k % B3W_RF_RING];
     en.wq = uni(d.x);
     en.rel0 = (int32_t)uni(d.y) + (int32_t)lane_off;
+    // the four steps' slots are 1 024 apart (a step is 32 KiB further on): ONE address and immediate offsets for the table words, one for
+    // the word-flag bitmap (32 words apart, the SAME bit in each).  No clamping: a lane in front of or behind the body reads whatever
+    // lies there — or zeros outside the LDS allocation — and its store is suppressed (range check / predicate) anyway.
+    const int32_t s0 = en.rel0 >> 5;
+    const uint16_t *tp = tab + s0;
+    const uint32_t *bp = bitmap + (s0 >> 5);
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-      const uint32_t rel = (uint32_t)(en.rel0 + (int32_t)(r << 15));
-      const uint32_t slot = rel < body ? rel >> 5 : 0u;
-      en.e[r] = tab[slot];
-      if (NOVA) en.e[r] |= ((bitmap[slot >> 5] >> (slot & 31u)) & 1u) << 16;
+      en.e[r] = tp[1024 * r];
+      if (NOVA) en.e[r] |= ((bp[32 * r] >> (s0 & 31)) & 1u) << 16;
     }
   };
   auto s2 = [&](const Ent &en, Wd &wd, const uint32_t *img) {
@@ -1150,6 +1154,7 @@ __global__ __launch_bounds__(320, 1) void b3w_regionfill_kernel(const uint32_t *
     wd.ok = NOVA ? img[B3W_LDS_OKWORD] : 1u;                                 // a rejected step's body is left alone
   };
   auto s3 = [&](const Ent &en, const Wd &wd, const uint32_t *img) {
+    for (uint32_t z = 0; z < pace; ++z) __builtin_amdgcn_s_sleep(1);         // PACE, see the launch
     const uint32_t w = en.wq & 0x7FFFFFFFu;
     if ((en.wq >> 31) && x == 0 && sub == 0) fill_report<NOVA>(img, w, lane, pub, status);    // the unit in which the body starts reports for it
     uint8_t *dst = out + (uint64_t)w * pitch;
@@ -1327,12 +1332,20 @@ extern "C" int b3w_launch_batch(int kind, int variant, const uint32_t *d_recs, u
       if (e != hipSuccess) return (int)e;
       attr_done.fetch_or(bit, std::memory_order_release);
     }
+    // PACE: every storing wave sleeps `pace` x s_sleep 1 (64 clocks each, on the chip's 64-clock grid) per unit.  The storers are built to
+    // issue as little as they can, and then they are too fast: unpaced, the workgroups run at whatever the memory system lets each of
+    // them have, drift apart, and the one compact window the fill order lives on frays — 6.2 (compression) / 5.6 (nova) TB/s on one-class
+    // memory; paced to just under the memory's rate they stay in step: 6.65 at 2, 6.1 at 3 (tools/ubench/pace_scan.py,
+    // profiles/r06/fill_pace_scan.log: a clean optimum, -5 % one step to either side).  B3W_FILL_PACE overrides (measurements).
+    const char *pace_s = getenv("B3W_FILL_PACE");                      // (read per launch: pace_scan.py changes it inside one process)
+    const int pace_env = pace_s ? atoi(pace_s) : -1;
+    const uint32_t pace = pace_env >= 0 ? (uint32_t)pace_env : nova ? 3u : 2u;
     if (!nova) {
       hipLaunchKernelGGL((b3w_regionfill_kernel<B3W_KIND_COMP, NH_C>), dim3(B3W_REGIONFILL_GRID), dim3(320), smem, stream, d_recs, n, d_out, pitch,
-                         d_table, nwit, d_pub, d_status);
+                         d_table, nwit, d_pub, d_status, pace);
     } else {
       hipLaunchKernelGGL((b3w_regionfill_kernel<B3W_KIND_NOVA_O2, NH_N>), dim3(B3W_REGIONFILL_GRID), dim3(320), smem, stream, d_recs, n, d_out, pitch,
-                         d_table, nwit, d_pub, d_status);
+                         d_table, nwit, d_pub, d_status, pace);
       // ... and the 67 field inverses of every body (0.3 % of its bytes): the body-stream kernel's gadget phase, its stores alone
       const uint32_t *d_wide = static_cast<const uint32_t *>(d_aux) + B3W_AUX_WIDE_SLOTS;
       hipLaunchKernelGGL((b3w_nova_kernel<B3W_KIND_NOVA_O2, 2, false, 3>), dim3((n + 1) / 2), dim3(64), 0, stream, d_recs, n, d_out, pitch, d_wide, nwit,
