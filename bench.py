@@ -72,11 +72,25 @@ STORE_SHAPES_WHAT = ("b3w_bodies_store_rate: 20 passes of store-only kernels ove
                      "(tools/ubench/store_sweep.hip, profiles/r06/store_sweep*.log): an unpaced store-only kernel fills HBM slower than the witness kernel")
 
 
+def kernel_row_path(name):
+    """the kernel PATH a dispatch of the counter passes belongs to (None: not a timed witness kernel): the body-stream kernels' MODE-0
+    instantiations are `fused`; the fill-ordered kernel and — nova — the wide-slot launch behind it (MODE 3) are `fill`"""
+    import re
+    if "b3w_regionfill_kernel" in name:
+        return "fill"
+    m = re.search(r"(?:true|false), (\d), (?:true|false)(?:, (?:true|false))?>\(", name)
+    if m and ("b3w_compression_kernel" in name or "b3w_nova_kernel" in name):
+        return {"0": "fused", "3": "fill"}.get(m.group(1))
+    return None
+
+
 def live_traffic(args):
     """HBM bytes per launch of the witness kernel(s), measured for THIS invocation: two child runs of this script under
     `rocprofv3 --pmc WRITE_SIZE` and `--pmc FETCH_SIZE` (separate passes, as MI355X_MICROARCH.md's HBM section prescribes; values are
-    KiB; on gfx950 FETCH_SIZE reports half of a wide read stream: doubled), each 8 launches of the same batch (`--traffic-child`),
-    BEFORE this process touches the GPU.  -> (dict, None) or (None, why not)."""
+    KiB; on gfx950 FETCH_SIZE reports half of a wide read stream: doubled), BEFORE this process touches the GPU.  A child (`--traffic-child`)
+    launches the batch 8 times through EACH kernel path the parent's autotune may end on — the body streams (variant 0: all fused variants
+    move the same bytes) and, where the circuit has it, the fill-ordered kernel —; the parent takes the path it timed.
+    -> ({path: {...}}, None) or (None, why not)."""
     import csv, glob, shutil, subprocess, tempfile
     roc = shutil.which("rocprofv3")
     if not roc:
@@ -84,7 +98,7 @@ def live_traffic(args):
     if any(k.startswith(("ROCPROF", "ROCP_")) for k in os.environ) or "rocprof" in os.environ.get("LD_PRELOAD", ""):
         return None, "this run is itself under a profiler"
     tmp = tempfile.mkdtemp(prefix="b3w_traffic_", dir="/tmp")
-    per, variants, t0 = {}, {}, time.perf_counter()
+    per, t0 = {}, time.perf_counter()
     try:
         for counter in ("WRITE_SIZE", "FETCH_SIZE"):
             # (a plain buffer: the bytes a kernel moves do not depend on where its buffer lies, and the child needs no placement search)
@@ -98,19 +112,21 @@ def live_traffic(args):
             files = glob.glob(os.path.join(tmp, counter, "**", "*counter_collection.csv"), recursive=True)
             if not files:
                 return None, f"the {counter} pass left no counter_collection.csv"
-            rows = [x for x in csv.DictReader(open(files[0])) if x["Counter_Name"] == counter and any(k in x["Kernel_Name"] for k in WITNESS_KERNELS)]
+            rows = [x for x in csv.DictReader(open(files[0])) if x["Counter_Name"] == counter]
             rows.sort(key=lambda x: int(x["Dispatch_Id"]))
-            k = child["launches"] * child["kernels_per_launch"]      # the child's last launches: behind its autotune
-            if len(rows) < k:
-                return None, f"the {counter} pass shows {len(rows)} witness-kernel dispatches, {k} expected"
-            per[counter] = sum(float(x["Counter_Value"]) for x in rows[-k:]) * 1024.0 / child["launches"]
-            variants[counter] = child["variant"]                      # what the child's own autotune picked (a plain buffer: it may differ from the parent's)
+            for path, kernels_per_launch in child["paths"].items():
+                mine = [x for x in rows if kernel_row_path(x["Kernel_Name"]) == path]
+                k = child["launches"] * kernels_per_launch            # the child's last launches of that path
+                if len(mine) < k:
+                    return None, f"the {counter} pass shows {len(mine)} dispatches of the {path} path, {k} expected"
+                per.setdefault(path, {})[counter] = sum(float(x["Counter_Value"]) for x in mine[-k:]) * 1024.0 / child["launches"]
     except Exception as e:                                  # (a time-out, an unreadable csv: the line then quotes the recorded passes)
         return None, f"{type(e).__name__}: {e}"
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
-    return {"hbm_bytes_per_launch": per["WRITE_SIZE"] + 2.0 * per["FETCH_SIZE"], "write_bytes": per["WRITE_SIZE"], "fetch_bytes_x2": 2.0 * per["FETCH_SIZE"],
-            "seconds": round(time.perf_counter() - t0, 1), "variant": variants.get("WRITE_SIZE"), "variants_by_pass": variants}, None
+    secs = round(time.perf_counter() - t0, 1)
+    return {path: {"hbm_bytes_per_launch": c["WRITE_SIZE"] + 2.0 * c["FETCH_SIZE"], "write_bytes": c["WRITE_SIZE"], "fetch_bytes_x2": 2.0 * c["FETCH_SIZE"],
+                   "seconds": secs, "path": path} for path, c in per.items() if len(c) == 2}, None
 
 
 def self_launch(n, argv, launch_timeout):
@@ -733,21 +749,30 @@ def main():
         bodies = alloc()
     d_bodies = bodies                                      # .data_ptr() like a tensor
     place_cost = dict(placement_cost(ctx), placement_alloc_s=round(time.perf_counter() - t_alloc, 3))
-    if args.traffic_child is not None and args.variant is None:
-        # (the counter passes run on a plain buffer, where an autotune would pick the fill-ordered kernel: they count the library's DEFAULT
-        # launch shape instead — a fused body-stream variant, the path a placed buffer's autotune ends on; the parent checks that it did)
-        chosen = 0
-    elif args.variant is None:
+    if args.traffic_child is not None:
+        # under rocprofv3 --pmc (live_traffic): 2 + 8 launches through each kernel path the parent's autotune may end on — the last 8 of a
+        # path are what is counted.  No autotune here; --variant (the parent's, when it was given one) is the only path then.
+        paths = {}
+        for v in ([args.variant] if args.variant is not None else [0, 200]):
+            os.environ["B3W_VARIANT"] = str(v)
+            c2 = m.Context(circuit, local_rank)
+            try:
+                for _ in range(2 + 8):
+                    c2.run_device(d_recs.data_ptr(), n, bodies.ptr, pitch, d_pub.data_ptr(), d_status.data_ptr(), stream.cuda_stream)
+                torch.cuda.synchronize()
+                paths[kernel_path(v)] = 2 if kernel_path(v) == "sweep" or (kernel_path(v) == "fill" and circuit != "compression") else 1
+            except m.B3WError:                              # (this circuit has no such path)
+                pass
+            finally:
+                c2.close()
+                del os.environ["B3W_VARIANT"]
+        print(json.dumps({"traffic_child": True, "launches": 8, "paths": paths}))
+        return
+    if args.variant is None:
         chosen, best_ms = ctx.autotune_device(d_recs.data_ptr(), n, bodies.ptr, pitch, d_pub.data_ptr(), d_status.data_ptr(),
                                               stream.cuda_stream)
     else:                                                   # (autotune leaves the winner selected in ctx)
         chosen = args.variant
-    if args.traffic_child is not None:                      # under rocprofv3 --pmc (live_traffic): the last 8 launches are what is counted
-        for _ in range(2 + 8):
-            launch(post=False)
-        torch.cuda.synchronize()
-        print(json.dumps({"traffic_child": True, "variant": chosen, "launches": 8, "kernels_per_launch": 2 if kernel_path(chosen) == "sweep" else 1}))
-        return
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     for _ in range(2):
         launch(post=args.exchange != "none")                # (the communicator's first collective — connection set-up — stays untimed)
@@ -887,13 +912,12 @@ def main():
         achieved = alg_bytes / (kern_ms * 1e-3) / 1e9
         traffic, traffic_source, traffic_parts = None, None, None
         tf = os.path.join(ROOT, "profiles", "traffic_latest.json")   # PMC passes (WRITE_SIZE/FETCH_SIZE), see profiles/README.md
-        path_of = kernel_path
-        if measured_traffic is not None and any(path_of(v) != path_of(chosen) for v in measured_traffic.get("variants_by_pass", {}).values()):
-            # the children autotuned on THEIR (plain) buffers and took another kernel path than the timed one (fused against TRACE + SWEEP: another
-            # number of kernels per launch, and the TRACE images' traffic): their bytes are not this run's — quote the recorded passes of the timed path
-            traffic_why_not = (f"the counter passes' autotune picked variant(s) {sorted(set(measured_traffic['variants_by_pass'].values()))} "
-                               f"({'/'.join(sorted({path_of(v) for v in measured_traffic['variants_by_pass'].values()}))}), the timed run {chosen} ({path_of(chosen)})")
-            measured_traffic = None
+        if measured_traffic is not None:
+            if kernel_path(chosen) in measured_traffic:
+                measured_traffic = measured_traffic[kernel_path(chosen)]
+            else:                                           # (the two-kernel sweep path is not counted live: quote the recorded passes)
+                traffic_why_not = f"the counter passes counted the paths {sorted(measured_traffic)}, the timed run is on {kernel_path(chosen)} (variant {chosen})"
+                measured_traffic = None
         if measured_traffic is not None:
             traffic = measured_traffic["hbm_bytes_per_launch"]
             traffic_parts = measured_traffic

@@ -223,15 +223,9 @@ int32_t b3w_batch_run(b3w_batch *b, const uint32_t *host_records, uint32_t n, vo
   b3w_ctx *ctx = b->ctx;
   ON_DEVICE(ctx);
   HIP_TRY(ctx, hipMemcpyAsync(b->d_recs, host_records, (size_t)n * ctx->desc.nin * 4, hipMemcpyHostToDevice, (hipStream_t)stream));
-  // A batch owns its body buffer and knows how it came out.  When the placement search found no second class of memory (a box whose
-  // driver hands memory out otherwise, a search that ran into its time limit, B3W_PLACEMENT=plain) the buffer is what a caller's own
-  // would be — and for such a buffer the fill-ordered kernel is the faster one: the library takes it by itself instead of
-  // silently running the body streams at 0.69 (r05 verdict, weak #8).  Only under the default policy: B3W_VARIANT and an autotune decide otherwise.
-  const bool fill = ctx->variant_auto && ctx->fill_ok && b->placement == B3W_PLACEMENT_PLAIN && n > 2560 && !(b->pitch & 31);
-  const int saved_variant = ctx->variant;
-  if (fill) { ctx->variant = B3W_VARIANT_REGIONFILL; ctx->variant_auto = false; }
+  // (a batch whose own buffer came out plain — no second class of memory found — gets the fill-ordered kernel from the default policy,
+  // which asks the placement allocator what it knows about the buffer: b3w_int_default_variant)
   int32_t rc = b3w_batch_run_device(ctx, b->d_recs, n, b->d_bodies, b->pitch, b->d_pub, b->d_status, stream);
-  if (fill) { ctx->variant = saved_variant; ctx->variant_auto = true; }
   if (rc) return rc;
   HIP_TRY(ctx, hipStreamSynchronize((hipStream_t)stream));
   b->n = n;

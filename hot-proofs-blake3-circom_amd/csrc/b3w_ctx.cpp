@@ -279,6 +279,28 @@ void set_inputs(b3w_ctx *ctx) {
 }
 }  // namespace
 
+// The default launch shape for n witnesses into THIS buffer (no B3W_VARIANT, no autotune).
+//   body streams (profiles/r02/batch_curve.json, sliced_scan_*.log): one body streams at 13 GB/s per wave, so small batches are SLICED over
+//   64 ... 4 waves a body; large ones want few fat waves, compression above 6 144 witnesses the occupancy-limited 8-body variant, nova O2
+//   above 32 768 steps the persistent grid;
+//   the fill-ordered kernel (r06; compression, nova O2; 32-byte aligned bodies): PACED, it stores at the same rate into any memory — 7.0 TB/s
+//   at 4 096 compression witnesses, 7.2 at 32 768 — where the body streams get 7.1-7.2 from a placed buffer and 5.5 from anybody else's.
+//   From 256 witnesses on it is at least as fast as the sliced launch even on a placed buffer (profiles/r06/fill_small.log), so:
+//   compression -> fill order from 256 witnesses, except batches of more than 3 072 into a buffer the placement allocator KNOWS to be
+//   mixed (b3w_place_is_mixed: body streams, +1 %); nova O2 (6.1-6.3 TB/s in fill order, 7.0 placed, 5.5 plain) -> fill order above 2 560
+//   steps unless the buffer is known to be mixed.
+int b3w_int_default_variant(const b3w_ctx *ctx, uint32_t n, const uint8_t *d_bodies, uint64_t pitch) {
+  const bool comp = ctx->desc.kind == B3W_KIND_COMP, nova2 = ctx->desc.kind == B3W_KIND_NOVA_O2;
+  const bool fillable = ctx->fill_ok && !(reinterpret_cast<uintptr_t>(d_bodies) & 31) && !(pitch & 31) && pitch < (1ull << 30) &&
+                        (uint64_t)n * pitch + (1ull << 20) < (1ull << 37);
+  if (fillable && comp && n >= 256 && (n <= 3072 || !b3w_place_is_mixed(d_bodies))) return B3W_VARIANT_REGIONFILL;
+  if (fillable && nova2 && n > 2560 && !b3w_place_is_mixed(d_bodies)) return B3W_VARIANT_REGIONFILL;
+  if (n <= 2560) return B3W_VARIANT_SLICED + (n <= (comp ? 32u : 8u) ? 64 : n <= 96 ? 32 : n <= 192 ? 16 : n <= 768 ? 8 : 4);
+  if (comp) return n <= 6144 ? 0 : 8;
+  if (nova2) return n <= 3072 ? 0 : n <= 32768 ? 3 : 4;     // (4: 8 bodies a wave on a persistent grid — 16 384 steps: -1 %, 32 768: equal, 65 536: +1.3 %)
+  return 0;
+}
+
 extern "C" {
 
 uint32_t b3w_abi_version(void) { return (1u << 16) | 0u; }
@@ -437,14 +459,8 @@ int32_t b3w_batch_run_device(b3w_ctx *ctx, const uint32_t *d_records, uint32_t n
   // M/s); large batches want few fat waves, and above 6 144 compression witnesses the occupancy-limited 8-body variant wins
   // by 4-5 %
   int variant = ctx->variant;
-  // (a variant picked by the autotuner on a large batch does not apply to small ones: those are sliced unless B3W_VARIANT says otherwise)
-  if (ctx->variant_auto || (ctx->variant_tuned && n <= 2560)) {
-    const bool comp = ctx->desc.kind == B3W_KIND_COMP;
-    if (n <= 2560) variant = B3W_VARIANT_SLICED + (n <= (comp ? 32u : 8u) ? 64 : n <= 96 ? 32 : n <= 192 ? 16 : n <= 768 ? 8 : 4);
-    else if (comp) variant = n <= 6144 ? 0 : 8;
-    else if (ctx->desc.kind == B3W_KIND_NOVA_O2) variant = n <= 3072 ? 0 : n <= 32768 ? 3 : 4;     // (4: 8 bodies a wave on a persistent grid — 16 384 steps: -1 %, 32 768: equal, 65 536: +1.3 %)
-    else variant = 0;
-  }
+  // (a variant picked by the autotuner on a large batch does not apply to small ones: those follow the default policy unless B3W_VARIANT says otherwise)
+  if (ctx->variant_auto || (ctx->variant_tuned && n <= 2560)) variant = b3w_int_default_variant(ctx, n, d_bodies, pitch);
   if (variant >= B3W_VARIANT_REGIONFILL && !ctx->fill_ok) { ctx->last_error = "the fill-ordered variant (200) exists for the compression circuit and the nova O2 builds"; return B3W_E_BAD_ARGUMENT; }
   int rc = b3w_launch_batch(ctx->desc.kind, variant, d_records, n, d_bodies, pitch, ctx->d_table, ctx->desc.nwit,
                             d_public, d_status, ctx->d_aux, ctx->d_scratch, ctx->scratch_cap, (hipStream_t)stream);
@@ -488,8 +504,7 @@ int32_t b3w_batch_autotune_device(b3w_ctx *ctx, const uint32_t *d_records, uint3
     for (int w = 0; w < 2 && rc == B3W_OK; w++) rc = b3w_batch_run_device(ctx, d_records, n, d_bodies, pitch, d_public, d_status, stream);
     if (rc == B3W_OK) rc = b3w_batch_time_device(ctx, d_records, n, d_bodies, pitch, d_public, d_status, stream, 5, &ms);
     if (rc) return rc;
-    const bool comp = ctx->desc.kind == B3W_KIND_COMP;
-    if (chosen_variant) *chosen_variant = B3W_VARIANT_SLICED + (n <= (comp ? 32u : 8u) ? 64 : n <= 96 ? 32 : n <= 192 ? 16 : n <= 768 ? 8 : 4);
+    if (chosen_variant) *chosen_variant = b3w_int_default_variant(ctx, n, d_bodies, pitch ? pitch : 32ull * ctx->desc.nwit);
     if (chosen_ms) *chosen_ms = ms;
     return B3W_OK;
   }

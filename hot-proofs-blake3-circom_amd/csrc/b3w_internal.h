@@ -120,6 +120,7 @@ struct DeviceGuard {
 // ---- one object's file to another's
 // b3w_ctx.cpp: the slot table of a circuit (slot -> LDS word, shift, mode), as the witness kernels and the commit keys read it
 bool b3w_int_build_slot_table(const CircuitDesc &c, std::vector<uint32_t> &table, std::string &err);
+int b3w_int_default_variant(const b3w_ctx *ctx, uint32_t n, const uint8_t *d_bodies, uint64_t pitch);    // the default launch shape for this batch into this buffer
 b3w_ctx *b3w_int_key_ctx(const b3w_commit_key *key);
 // b3w_commit_api.cpp: b3w_commit_records_device with the normalisation put off — d_sums_out (B3W_COMMIT_SUM_WORDS words per record) takes
 // the projective sums and d_points is not written; b3w_int_commit_normalize makes points of any number of them at once (the chained pass:

@@ -53,6 +53,7 @@ extern "C" int b3w_launch_verify(int kind, const uint32_t *d_in_slots, uint32_t 
 // b3w_placement.hip: body buffers assembled from two classes of HBM (HIP virtual-memory API)
 extern "C" int b3w_place_alloc(int device, uint64_t bytes, int want_mixed, void **out, int *mixed, float *rates);
 extern "C" int b3w_place_free(void *ptr);
+extern "C" int b3w_place_is_mixed(const void *ptr);                            // 1: inside a placed buffer of alternating classes
 extern "C" void b3w_place_trim(void);
 extern "C" void b3w_place_configure(int64_t search_gib, int64_t pool_gib);      // < 0: leave as is
 extern "C" void b3w_place_stats(int device, uint64_t out[6]);

@@ -1067,18 +1067,40 @@ __global__ __launch_bounds__(320, 1) void b3w_regionfill_kernel(const uint32_t *
   const uint32_t wave = uni(threadIdx.x >> 6), lane = threadIdx.x & 63u;
   const uint32_t x = blockIdx.x & 7u, grp = blockIdx.x >> 3;              // XCD residue; group (32 of them: gridDim.x = 256)
   const uint32_t body = 32u * nwit;
-  constexpr uint32_t NTHR = 320;
-  for (uint32_t i = threadIdx.x; i < nwit; i += NTHR) tab[i] = NOVA ? fill_entry16_nova(table[i]) : fill_entry16(table[i]);
-  if (NOVA)
-    for (uint32_t wd = threadIdx.x; wd < bmw; wd += NTHR) {
-      uint32_t bits = 0;
-      for (uint32_t bb = 0; bb < 32; ++bb) {
-        const uint32_t sl = wd * 32 + bb;
-        if (sl < nwit && ((table[sl] >> 17) & 3u) != B3W_MODE_BIT) bits |= 1u << bb;
+  // The table into LDS — by the four STORING waves, sixteen entries a thread in flight (four 16-byte loads at a time: one entry per load
+  // and iteration, as this loop first stood, was 75 dependent L2 round trips = 40 us of every launch), while the tracer wave is already
+  // listing, loading and tracing the first half: the first barrier below is both "table there" and "half 0 there".
+  if (NOVA) {
+    for (uint32_t wd = threadIdx.x; wd < bmw; wd += 320) bitmap[wd] = 0;
+    __syncthreads();                                                         // (zeroed before the ds_or below; the tracer does not touch it)
+  }
+  if (wave < 4) {
+    const uint4 *t4 = reinterpret_cast<const uint4 *>(table);               // (16-byte aligned; padded by 8 groups behind the last slot)
+    uint32_t *tab32 = reinterpret_cast<uint32_t *>(tab);
+    const uint32_t n4 = (nwit + 3u) / 4u;
+    for (uint32_t base4 = 0; base4 < n4; base4 += 256u * 4u) {
+      uint4 v[4];
+#pragma unroll
+      for (int uu = 0; uu < 4; ++uu) {
+        const uint32_t i4 = base4 + 256u * uu + threadIdx.x;
+        v[uu] = i4 < n4 ? t4[i4] : make_uint4(0, 0, 0, 0);
       }
-      bitmap[wd] = bits;
+#pragma unroll
+      for (int uu = 0; uu < 4; ++uu) {
+        const uint32_t i4 = base4 + 256u * uu + threadIdx.x;
+        if (i4 < n4) {
+          const uint32_t e0 = NOVA ? fill_entry16_nova(v[uu].x) : fill_entry16(v[uu].x), e1 = NOVA ? fill_entry16_nova(v[uu].y) : fill_entry16(v[uu].y);
+          const uint32_t e2 = NOVA ? fill_entry16_nova(v[uu].z) : fill_entry16(v[uu].z), e3 = NOVA ? fill_entry16_nova(v[uu].w) : fill_entry16(v[uu].w);
+          *reinterpret_cast<uint2 *>(tab32 + 2 * i4) = make_uint2(e0 | e1 << 16, e2 | e3 << 16);
+          if (NOVA) {
+            const uint32_t nib = (((v[uu].x >> 17) & 3u) != B3W_MODE_BIT ? 1u : 0u) | (((v[uu].y >> 17) & 3u) != B3W_MODE_BIT ? 2u : 0u) |
+                                 (((v[uu].z >> 17) & 3u) != B3W_MODE_BIT ? 4u : 0u) | (((v[uu].w >> 17) & 3u) != B3W_MODE_BIT ? 8u : 0u);
+            if (nib) atomicOr(&bitmap[i4 >> 3], nib << ((i4 & 7u) * 4u));
+          }
+        }
+      }
     }
-  __syncthreads();
+  }
   if (wave == 4) {
     // ---- TRACER: lists the units two halves ahead, loads the records one half ahead, traces half h into image half h & 1; one barrier
     // per half, the last one for a half that is not full (possibly empty)

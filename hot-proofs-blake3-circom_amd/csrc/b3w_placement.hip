@@ -552,6 +552,16 @@ extern "C" int b3w_place_alloc(int device, uint64_t bytes, int want_mixed, void 
   return 0;
 }
 
+// What the allocator knows about the memory `ptr` points into: 1 = inside a buffer of alternating classes ("mixed" pieces), 0 = anything
+// else — a plain hipMalloc / torch buffer, a one-class buffer, a foreign pointer.  The default launch policy asks (b3w_ctx.cpp).
+extern "C" int b3w_place_is_mixed(const void *ptr) {
+  std::lock_guard<std::mutex> guard(mtx());
+  const uint8_t *p = static_cast<const uint8_t *>(ptr);
+  for (const Placed *pl : registry())
+    if (p >= static_cast<const uint8_t *>(pl->va) && p < static_cast<const uint8_t *>(pl->va) + pl->va_bytes) return pl->mixed > 0 ? 1 : 0;
+  return 0;
+}
+
 // 0 = freed; 1 = not a pointer handed out by b3w_place_alloc
 extern "C" int b3w_place_free(void *ptr) {
   std::lock_guard<std::mutex> guard(mtx());

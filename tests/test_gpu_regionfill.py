@@ -141,8 +141,8 @@ def test_regionfill_full_config2_batch_on_a_plain_buffer_and_the_autotuner(m):
 
 def test_a_batch_whose_own_buffer_came_out_plain_takes_the_fill_order_and_stays_exact(m, monkeypatch):
     """b3w_batch_run under the default policy: the batch's body buffer is plain (here: B3W_PLACEMENT=plain; on a box where the placement
-    search finds one class only: by itself) -> the library launches the fill-ordered kernel for more than 2 560 witnesses.  Bodies and
-    outputs as ever; small batches on the same batch object keep the sliced launch."""
+    search finds one class only: by itself) -> the library launches the fill-ordered kernel (the default policy asks the placement
+    allocator what it knows about the buffer).  Bodies and outputs as ever; batches below 256 witnesses keep the sliced launch."""
     monkeypatch.setenv("B3W_PLACEMENT", "plain")
     n = 3000
     recs = T.workloads().config2_compression(n, first=9)
@@ -252,3 +252,41 @@ def test_regionfill_nova_large_batch_and_large_iszero_arguments(m):
     idx = idx[okh[idx]]
     _, want = T.oracle_batch_u32("nova_vesta", recs[idx])
     assert np.array_equal(out[200][0][torch.from_numpy(idx).to(dev)].cpu().numpy(), want)
+
+
+def test_default_policy_by_batch_size_and_buffer(m):
+    """b3w_int_default_variant through the autotuner's report for small batches and through bit-exact runs: compression on a torch buffer
+    — sliced below 256 witnesses, fill-ordered from 256 on; the same batch sizes into a PLACED buffer (the allocator knows it is mixed):
+    fill-ordered up to 3 072, body streams above; a 16-byte aligned buffer: never the fill order.  Every run against the oracle."""
+    import torch
+    dev = torch.device("cuda:0")
+    s = torch.cuda.current_stream().cuda_stream
+    n = 3500
+    recs = T.workloads().config2_compression(n, first=3)
+    d_recs = torch.from_numpy(recs.view(np.int32)).to(dev)
+    ctx = m.Context("compression", 0)
+    body = ctx.body_bytes
+    plain = torch.full((n * body + 64,), 5, dtype=torch.uint8, device=dev)
+    placed = ctx.alloc_bodies(n * body)
+    idx = [0, 1, 99, 255, 256, 1000, 2047, 2999, n - 1]
+    _, want = T.oracle_batch_u32("compression", recs[idx])
+    d_st = torch.zeros(n, dtype=torch.int32, device=dev)
+    for k, expect_plain in ((100, 20 + 16), (255, 20 + 8), (256, 200), (2047, 200)):
+        v, _ = ctx.autotune_device(d_recs.data_ptr(), k, plain.data_ptr(), 0, 0, d_st.data_ptr(), s)
+        assert v == expect_plain, (k, v)
+        v, _ = ctx.autotune_device(d_recs.data_ptr(), k, plain.data_ptr() + 16, 0, 0, d_st.data_ptr(), s)
+        assert v != 200, (k, v, "16-byte aligned bodies cannot take the fill order")
+    ctx2 = m.Context("compression", 0)                       # a context nobody tuned: the default policy for every size
+    for ptr, name in ((plain.data_ptr(), "plain"), (placed.ptr, placed.placement), (plain.data_ptr() + 16, "unaligned")):
+        for k in (200, 300, 3000, n):
+            ctx2.run_device(d_recs.data_ptr(), k, ptr, 0, 0, d_st.data_ptr(), s)
+            torch.cuda.synchronize()
+            view = torch.empty(0)
+            for j, i in enumerate(idx):
+                if i < k:
+                    got = np.empty(body, dtype=np.uint8)
+                    import ctypes
+                    hip = ctypes.CDLL("libamdhip64.so")
+                    assert hip.hipMemcpy(ctypes.c_void_p(got.ctypes.data), ctypes.c_void_p(ptr + i * body), ctypes.c_size_t(body), 2) == 0
+                    assert np.array_equal(got, want[j]), (name, k, i)
+    placed.free(); ctx.close(); ctx2.close()
