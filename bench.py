@@ -65,11 +65,13 @@ def kernel_path(v):
 def variant_name(v):
     return {"fused": f"fused ({v})", "sweep": "sweep (TRACE + SWEEP kernels)", "fill": "fill-ordered fused (REGIONFILL, 200)"}[kernel_path(v)]
 # store-only shapes of b3w_bodies_store_rate the batch line reads `achieved` against (roofline.store_ceiling)
-STORE_SHAPES = {"streams_w4": 0, "streams_w8": 1, "fill": 2, "paced_persistent_w4x512": 3, "paced_persistent_w8x512": 4, "paced_streams_w8": 5}
+STORE_SHAPES = {"streams_w4": 0, "streams_w8": 1, "fill": 2, "paced_persistent_w4x512": 3, "paced_persistent_w8x512": 4, "paced_streams_w8": 5,
+                "paced_region_fill_sleep": 6, "paced_region_fill_valu": 7}
 STORE_SHAPES_WHAT = ("b3w_bodies_store_rate: 20 passes of store-only kernels over the same n bodies — body streams (one wave per 4 / 8 bodies, 1 KiB per body "
                      "and step: the fused kernels' store shape), the runtime's fill shape, and the PACED shapes (four vector-ALU instructions in front of every "
                      "store; 512 persistent waves taking groups of 4 / 8 bodies, or one wave per 8 bodies) that the round-6 sweep of 100 shapes found fastest "
-                     "(tools/ubench/store_sweep.hip, profiles/r06/store_sweep*.log): an unpaced store-only kernel fills HBM slower than the witness kernel")
+                     "(tools/ubench/store_sweep.hip, profiles/r06/store_sweep*.log), and the fill-ordered kernel's store order paced by s_sleep / by vector-ALU "
+                     "instructions (tools/ubench/store_region_scan.py): an unpaced store-only kernel fills HBM slower than the witness kernel")
 
 
 def kernel_row_path(name):

@@ -122,6 +122,49 @@ __global__ __launch_bounds__(256) void b3w_store_fill_kernel(uint8_t *out, uint6
   for (uint64_t t = blockIdx.x; (t + 1) * 4096 <= bytes; t += gridDim.x) *reinterpret_cast<u32x4 *>(out + t * 4096 + threadIdx.x * 16) = v;
 }
 
+// The fill-ordered witness kernel's store order with nothing else (b3w_regionfill_kernel): absolute 128 KiB regions of 32 blocks, 32 groups
+// of eight 4-wave workgroups (one per XCD) on 32 consecutive regions, workgroup x storing the blocks x, x + 8, x + 16, x + 24 of its region —
+// one contiguous 4 MiB window chip-wide — and every wave waiting behind every store (that kernel's storing waves have ~300 clocks of table
+// and image reads per store).  The rate is a cliff in the pace: a wave that stores faster than its share of the memory drains is held up at
+// random, the 256 workgroups drift and the window frays (6.0-6.5 TB/s); paced just below that it runs at 6.95-7.27 TB/s on ANY buffer, placed
+// or not (tools/ubench/store_region_scan.py, profiles/r06/store_region_scan*.log).
+// PACE is compiled in (straight-line code: a run-time pacing loop or switch costs more than the steps it is to provide):
+// PACE / 16 x `s_sleep 1` (64 clocks each) and one `s_nop` of PACE % 16 wait states behind every store.
+template <int PACE>
+__global__ __launch_bounds__(256) void b3w_store_regionfill_kernel(uint8_t *out, uint64_t bytes) {
+  const uint32_t grp = blockIdx.x >> 3, x = blockIdx.x & 7;
+  u32x4 v = {threadIdx.x, blockIdx.x, 0, 0};
+  uint8_t *first = reinterpret_cast<uint8_t *>((reinterpret_cast<uintptr_t>(out) + 0x1ffff) & ~(uintptr_t)0x1ffff);   // (whole regions only)
+  const uint64_t regions = (uint64_t)(out + bytes - first) >> 17;
+  for (uint64_t r = grp; r < regions; r += 32) {
+    uint8_t *p = first + (r << 17) + x * 4096 + threadIdx.x * 16;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      *reinterpret_cast<u32x4 *>(p + k * 32768) = v;
+      if (PACE < 1000) {
+#pragma unroll
+        for (int i = 0; i < PACE / 16; ++i) __builtin_amdgcn_s_sleep(1);
+        if (PACE % 16) asm volatile("s_nop %0" :: "n"(PACE % 16 ? PACE % 16 - 1 : 0));
+      } else {                                              // PACE - 1000 dependent vector-ALU instructions instead (no 64-clock grid)
+#pragma unroll
+        for (int i = 0; i < PACE - 1000; ++i) asm volatile("v_add_u32 %0, %0, 1" : "+v"(v.z));
+      }
+    }
+  }
+}
+constexpr int REGION_PACES[] = {0, 64, 80, 84, 88, 92, 96, 1032, 1036, 1038, 1039, 1040, 1041, 1042, 1044, 1048};
+static bool region_pace_known(int pace) {
+  for (int p : REGION_PACES) if (p == pace) return true;
+  return false;
+}
+template <int I = 0>
+static void launch_region_store(int pace, uint8_t *buf, uint64_t bytes, hipStream_t stream) {
+  if constexpr (I < (int)(sizeof(REGION_PACES) / sizeof(int))) {
+    if (pace == REGION_PACES[I]) hipLaunchKernelGGL(b3w_store_regionfill_kernel<REGION_PACES[I]>, dim3(256), dim3(256), 0, stream, buf, bytes);
+    else launch_region_store<I + 1>(pace, buf, bytes, stream);
+  }
+}
+
 constexpr uint64_t MiB = 1ull << 20, GiB = 1ull << 30;
 constexpr uint64_t HANDLE = 256 * MiB;             // physical granule of a placed buffer
 constexpr uint32_t PROBE_STREAMS = 512;            // 256 per side
@@ -694,17 +737,25 @@ extern "C" int b3w_place_store_launch(uint8_t *buf, uint64_t pitch, uint32_t n, 
 // GB/s of `iters` pure-store passes over [buf, buf + n * pitch) on `stream` (HIP events; 2 untimed passes first).
 // shape 0: body streams, one wave per 4 bodies; 1: per 8 bodies; 2: the fill shape; 3 / 4: PACED persistent body streams — 512 single-wave
 // workgroups (two per CU) taking groups of 4 / 8 bodies in turn, 4 vector-ALU instructions in front of every store (the best store-only
-// shapes of round 6's sweep on a placed buffer); 5: 8 bodies per wave, paced, one wave per group.  Negative = hipError_t.
+// shapes of round 6's sweep on a placed buffer); 5: 8 bodies per wave, paced, one wave per group; 6 / 7: the fill-ordered kernel's store order
+// over the whole 128 KiB regions of the buffer, paced by s_sleep (5 x 64 clocks + s_nop 7 per store) / by 40 dependent vector-ALU instructions
+// per store (700 + p: the same at another pace of REGION_PACES, for the scan).  Negative = hipError_t.
+constexpr int REGIONFILL_STORE_PACE_SLEEP = 88, REGIONFILL_STORE_PACE_VALU = 1040;
 extern "C" int b3w_place_store_rate(uint8_t *buf, uint64_t pitch, uint32_t n, uint32_t body_bytes, int shape, uint32_t iters, hipStream_t stream, double *gbs) {
-  if (!buf || !n || !iters || !gbs || body_bytes < 1024 || pitch < body_bytes || shape < 0 || shape > 5) return -(int)hipErrorInvalidValue;
+  if (!buf || !n || !iters || !gbs || body_bytes < 1024 || pitch < body_bytes || shape < 0 || (shape > 7 && (shape < 700 || shape > 1899))) return -(int)hipErrorInvalidValue;
   const uint32_t tiles = body_bytes / 1024;
-  const uint64_t per_pass = shape == 2 ? ((uint64_t)n * pitch / 4096) * 4096 : (uint64_t)n * tiles * 1024;
+  const bool region = shape == 6 || shape == 7 || shape >= 700;
+  const uint64_t whole = (uint64_t)n * pitch, lead = (0x20000 - (reinterpret_cast<uintptr_t>(buf) & 0x1ffff)) & 0x1ffff;
+  if (region && whole < lead + 0x20000) return -(int)hipErrorInvalidValue;
+  if (shape >= 700 && !region_pace_known(shape - 700)) return -(int)hipErrorInvalidValue;
+  const uint64_t per_pass = region ? ((whole - lead) >> 17) << 17 : shape == 2 ? ((uint64_t)n * pitch / 4096) * 4096 : (uint64_t)n * tiles * 1024;
   auto launch = [&] {
     if (shape == 0) hipLaunchKernelGGL(b3w_store_streams_kernel<4>, dim3((n + 3) / 4), dim3(64), 0, stream, buf, pitch, n, tiles, 0u);
     else if (shape == 1) hipLaunchKernelGGL(b3w_store_streams_kernel<8>, dim3((n + 7) / 8), dim3(64), 0, stream, buf, pitch, n, tiles, 0u);
     else if (shape == 3) hipLaunchKernelGGL(b3w_store_persistent_kernel<4>, dim3(512), dim3(64), 0, stream, buf, pitch, n, tiles, 4u);
     else if (shape == 4) hipLaunchKernelGGL(b3w_store_persistent_kernel<8>, dim3(512), dim3(64), 0, stream, buf, pitch, n, tiles, 4u);
     else if (shape == 5) hipLaunchKernelGGL(b3w_store_persistent_kernel<8>, dim3((n + 7) / 8), dim3(64), 0, stream, buf, pitch, n, tiles, 4u);
+    else if (region) launch_region_store(shape == 6 ? REGIONFILL_STORE_PACE_SLEEP : shape == 7 ? REGIONFILL_STORE_PACE_VALU : shape - 700, buf, whole, stream);
     else hipLaunchKernelGGL(b3w_store_fill_kernel, dim3(256), dim3(256), 0, stream, buf, (uint64_t)n * pitch);
   };
   hipEvent_t e0 = nullptr, e1 = nullptr;

@@ -44,7 +44,8 @@ def test_default_line_has_the_contract_fields():
     # r06: the plain buffer's launch shape is autotuned ON the plain buffer and named; the ceilings include the paced shapes of the sweep
     assert isinstance(r["plain"]["kernel_variant"], str) and r["plain"]["kernel_variant"].split()[0] in ("fused", "sweep", "fill-ordered")
     assert set(r["store_ceiling"]["placed"]) == set(r["store_ceiling"]["plain"]) == {"streams_w4", "streams_w8", "fill", "paced_persistent_w4x512",
-                                                                                      "paced_persistent_w8x512", "paced_streams_w8"}
+                                                                                      "paced_persistent_w8x512", "paced_streams_w8",
+                                                                                      "paced_region_fill_sleep", "paced_region_fill_valu"}
     assert min(list(r["store_ceiling"]["placed"].values()) + list(r["store_ceiling"]["plain"].values())) > 100
     assert abs(r["of_measured_ceiling"] - r["achieved"] / max(r["store_ceiling"]["placed"].values())) < 1e-9
     # the reference WASM's all-core rate: recorded in the build container (the reference cannot travel to this box), and the line says so

@@ -290,3 +290,33 @@ def test_default_policy_by_batch_size_and_buffer(m):
                     assert hip.hipMemcpy(ctypes.c_void_p(got.ctypes.data), ctypes.c_void_p(ptr + i * body), ctypes.c_size_t(body), 2) == 0
                     assert np.array_equal(got, want[j]), (name, k, i)
     placed.free(); ctx.close(); ctx2.close()
+
+
+def test_store_only_region_shapes_stay_inside_the_buffer(m):
+    """b3w_bodies_store_rate shapes 6 / 7 (the fill order with nothing but its stores, paced by sleeps / by vector-ALU instructions — what
+    bench.py reads the fill-ordered kernel against on a plain buffer) write whole 128 KiB regions INSIDE [buf, buf + n * pitch) only,
+    wherever the buffer starts, and refuse a buffer that holds no whole region."""
+    import torch
+    ctx = m.Context("compression", 0)
+    dev = torch.device("cuda:0")
+    s = torch.cuda.current_stream().cuda_stream
+    n, margin = 24, 1 << 17
+    span = n * ctx.body_bytes
+    for shape in (6, 7, 700, 1739):
+        for skew in (0, 16, 4096 + 48, margin - 16):
+            buf = torch.full((3 * margin + span,), FILL, dtype=torch.uint8, device=dev)
+            lo = margin - (buf.data_ptr() % margin) + skew
+            rate = ctx.store_rate(buf.data_ptr() + lo, n, 0, shape, 2, s)
+            torch.cuda.synchronize()
+            host = buf.cpu().numpy()
+            assert rate > 10 and (host[:lo] == FILL).all() and (host[lo + span:] == FILL).all(), (shape, skew)
+            first = lo + (-(buf.data_ptr() + lo)) % margin
+            whole = (lo + span - first) // margin * margin
+            assert (host[first:first + whole] != FILL).any(axis=None) and (host[lo:first] == FILL).all() and (host[first + whole:] == FILL).all(), (shape, skew)
+            # every 16-byte store of the region walk landed: no run of 16 fill bytes left inside
+            inner = host[first:first + whole].reshape(-1, 16)
+            assert not (inner == FILL).all(axis=1).any(), (shape, skew)
+    small = torch.zeros(4 * margin, dtype=torch.uint8, device=dev)
+    with pytest.raises(m.B3WError):                                 # a pace the library was not compiled with: refused, not a launch of nothing
+        ctx.store_rate(small.data_ptr(), 1, 0, 701, 1, s)
+    ctx.close()
