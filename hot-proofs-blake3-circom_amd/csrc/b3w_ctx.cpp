@@ -344,8 +344,21 @@ int32_t b3w_create(int32_t circuit, int32_t device, b3w_ctx **out) {
       if (j >= B3W_NOVA_ISZERO || wide_slots[j] != 0xFFFFFFFFu) ctx->fill_ok = false; else wide_slots[j] = i;
     } else if (src + (mode == B3W_MODE_W64 ? 1u : 0u) >= B3W_LDS_WIDE) ctx->fill_ok = false;      // (the word behind src is read for every slot, used by two-word slots only)
   }
-  if (ctx->desc.kind == B3W_KIND_NOVA_O2)
+  if (ctx->desc.kind == B3W_KIND_NOVA_O2) {
     for (uint32_t v : wide_slots) if (v == 0xFFFFFFFFu) ctx->fill_ok = false;
+    // the second launch writes the inverses' whole 128-byte LINES, wherever a body starts in a line: the three slots to either side of an
+    // inverse must be things it has without the compression trace (step inputs and what nova_select makes of them), and the inverses' slot
+    // numbers ascend (it tells a line it has written already by the slot before)
+    for (uint32_t j = 0; ctx->fill_ok && j < B3W_NOVA_ISZERO; j++) {
+      if (j > 0 && wide_slots[j] <= wide_slots[j - 1]) ctx->fill_ok = false;
+      for (int d = -3; ctx->fill_ok && d <= 3; d++) {
+        const int64_t k = (int64_t)wide_slots[j] + d;
+        if (k < 0 || k >= (int64_t)ctx->desc.nwit) continue;
+        const uint32_t e = table[k], src = e & 0xFFFu, mode = (e >> 17) & 3u;
+        if (mode != B3W_MODE_W256 && !((src >= B3W_A_H && src < B3W_A_O) || src >= B3W_LDS_NV)) ctx->fill_ok = false;
+      }
+    }
+  }
   DeviceGuard guard(device);              // the caller's current device (torch's, say) is put back on return
   if (guard.err != hipSuccess) { delete ctx; return B3W_E_NO_DEVICE; }
   const CircuitDesc &d = ctx->desc;

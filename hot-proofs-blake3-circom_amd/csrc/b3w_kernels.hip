@@ -803,8 +803,9 @@ __device__ __forceinline__ int32_t nova_select(uint32_t *L, int col, bool dom_a 
   return st;
 }
 
-// MODE 3 (O2): the 67 256-bit slots of every body only — the field inverses of the IsZero gadgets, `table` = their 67 slot numbers —
-// behind a launch of the fill-ordered kernel, whose images carry no wide part; rejected steps are left alone as everywhere.
+// MODE 3 (O2): the lines of every body that hold its 67 256-bit slots only — the field inverses of the IsZero gadgets, their slot numbers
+// behind the inverse table in `aux` — beside a launch of the fill-ordered kernel, whose images carry no wide part and which leaves exactly
+// those lines alone; rejected steps are left alone as everywhere.
 template <int KIND, int W, bool NT, int MODE, bool SL = false, bool PERSIST = false>
 __global__ __launch_bounds__(64) void b3w_nova_kernel(const uint32_t *__restrict__ recs, uint32_t n,
                                                       uint8_t *__restrict__ out, uint64_t pitch,
@@ -866,12 +867,26 @@ __global__ __launch_bounds__(64) void b3w_nova_kernel(const uint32_t *__restrict
   }
   __syncthreads();
   if (MODE == 3) {
-    // the wide slots alone: lane pair = one of the body's 67 slots (table[j] = its number), each lane a 16-byte half
-    for (int t = lane; t < 134 * W; t += 64) {
-      const int ww = t / 134, r = t - ww * 134, j = r >> 1, half = r & 1;
+    // the 128-byte lines (absolute addresses) that hold one of the body's 67 256-bit slots, whole — as far as they lie in the body —: eight
+    // lane-jobs a slot, lane pair = one slot of its line, each lane a 16-byte half.  What stands beside the inverses are select flags and
+    // step inputs (b3w_ctx.cpp checks it: nothing of the compression trace, which this launch does not run).
+    const uint32_t *ws = aux + B3W_AUX_WIDE_SLOTS;
+    for (int t = lane; t < 536 * W; t += 64) {
+      const int ww = t / 536, r = t - ww * 536, j = r >> 3, i = (r >> 1) & 3, half = r & 1;
       if (wb(ww) < n && okf[ww]) {
-        const uint32_t *src = lds + ww * WORDS + B3W_LDS_WIDE + 8 * j + 4 * half;
-        store16<false>(out + (uint64_t)wb(ww) * pitch + (uint64_t)table[j] * 32 + 16 * half, make_uint4(src[0], src[1], src[2], src[3]));
+        uint8_t *base = out + (uint64_t)wb(ww) * pitch;
+        const uint32_t ph = (uint32_t)(reinterpret_cast<uint64_t>(base) >> 5) & 3u;
+        const uint32_t line = (ph + ws[j]) >> 2;
+        const uint32_t k = line * 4u + (uint32_t)i - ph;                  // (wraps for the slots of the line in front of the body)
+        const bool again = j > 0 && ((ph + ws[j - 1]) >> 2) == line;       // the line was the slot before's already (slots ascend)
+        if (k < nwit && !again) {
+          const uint32_t e = table[k], src = e & 0xFFFu, sh = (e >> 12) & 31u, mode = (e >> 17) & 3u;
+          const uint32_t *L = lds + ww * WORDS + src + (mode == B3W_MODE_W256 ? 4u * half : 0u);
+          uint4 v = make_uint4(0, 0, 0, 0);
+          if (mode == B3W_MODE_W256) v = make_uint4(L[0], L[1], L[2], L[3]);
+          else if (!half) { v.x = mode == B3W_MODE_BIT ? (L[0] >> sh) & 1u : L[0]; v.y = mode == B3W_MODE_W64 ? L[1] : 0u; }
+          store16<false>(base + (uint64_t)k * 32 + 16 * half, v);
+        }
       }
     }
     if (!PERSIST) return;
@@ -953,16 +968,29 @@ __device__ __forceinline__ void fill_store(uint32_t e, uint32_t w0, uint32_t w1,
   if (in && !(NOVA && word && f == 2u)) store16<false>(p, v);              // (a 256-bit slot: not this launch's)
 }
 // The same store through a BUFFER resource over the body (base, body bytes): a lane whose offset lies outside — in front of the body
-// (negative, i.e. huge), behind it, or made so on purpose (a 256-bit slot, a rejected step) — is dropped by the hardware's range check:
-// no branch and no exec-mask juggling per store (the nova storers were bound by their own instruction stream: 25 branches a unit).
-__device__ __forceinline__ void fill_store_nova(uint32_t e, uint32_t w0, uint32_t w1, uint32_t par, bool ok, __amdgpu_buffer_rsrc_t rsrc, uint32_t rel) {
+// (negative, i.e. huge), behind it, or made so on purpose (a rejected step; a line that holds a 256-bit slot) — is dropped by the hardware's
+// range check: no branch and no exec-mask juggling per store (the nova storers were bound by their own instruction stream: 25 branches a unit).
+// A 256-bit slot is not this launch's, and NEITHER ARE THE OTHER SLOTS OF ITS 128-BYTE LINE (eight lanes: the wave's KiB is aligned in
+// absolute addresses): a line written in part costs the memory system far more than its bytes — the 67 slots of a nova body lie in 35 lines,
+// 0.6 % of the body, and leaving 32-byte holes in them held the whole kernel at 6.4 instead of 6.9 TB/s.  The wide-slot launch writes those
+// lines whole (b3w_nova_kernel MODE 3); of a line that straddles two bodies each body's unit decides for its own slots.
+// ZONE: the wave's KiB may hold such a line (decided per store from scalars: the 67 slots lie within 256 slots of each other, nine of a
+// body's 728 KiB); outside the zone a store costs neither the ballot nor the test for a 256-bit slot.
+template <bool ZONE>
+__device__ __forceinline__ void fill_store_nova(uint32_t e, uint32_t w0, uint32_t w1, uint32_t par, bool ok, __amdgpu_buffer_rsrc_t rsrc, uint32_t rel,
+                                                uint32_t body, uint32_t lane) {
   const uint32_t f = (e >> 11) & 31u;
   const bool word = (e >> 16) != 0;
   u32x4 v;
   v.x = par ? 0u : (word ? w0 : (w0 >> f) & 1u);
   v.y = (!par && word && (f & 1u)) ? w1 : 0u;
   v.z = 0; v.w = 0;
-  const uint32_t off = (ok && !(word && f == 2u)) ? rel : 0xFFFFFFF0u;
+  bool skip = false;
+  if (ZONE) {
+    const uint64_t wide = __builtin_amdgcn_ballot_w64(word && f == 2u && rel < body);    // (a lane outside the body read garbage for e)
+    skip = ((uint32_t)(wide >> (lane & 56u)) & 0xFFu) != 0;
+  }
+  const uint32_t off = (ok && !skip) ? rel : 0xFFFFFFF0u;
   __builtin_amdgcn_raw_buffer_store_b128(v, rsrc, (int)off, 0, 0);
 }
 
@@ -1061,6 +1089,7 @@ __global__ __launch_bounds__(320, 1) void b3w_regionfill_kernel(const uint32_t *
   extern __shared__ __attribute__((aligned(16))) uint32_t bf_lds[];
   __shared__ uint2 ring[B3W_RF_RING];                                       // unit descriptors, unit k at k % ring
   __shared__ uint32_t cnt_ring[4];                                          // units of half h at h % 4
+  __shared__ uint32_t zone[2];                                              // nova: the lowest and the highest 256-bit slot of a body
   uint16_t *tab = reinterpret_cast<uint16_t *>(bf_lds);
   const uint32_t tabw = ((nwit + 7u) & ~7u) / 2, bmw = NOVA ? ((nwit + 127u) & ~127u) / 32 : 0u;
   uint32_t *bitmap = bf_lds + tabw, *lds = bf_lds + tabw + bmw;
@@ -1072,6 +1101,7 @@ __global__ __launch_bounds__(320, 1) void b3w_regionfill_kernel(const uint32_t *
   // listing, loading and tracing the first half: the first barrier below is both "table there" and "half 0 there".
   if (NOVA) {
     for (uint32_t wd = threadIdx.x; wd < bmw; wd += 320) bitmap[wd] = 0;
+    if (threadIdx.x == 0) { zone[0] = 0xFFFFFFFFu; zone[1] = 0u; }
     __syncthreads();                                                         // (zeroed before the ds_or below; the tracer does not touch it)
   }
   if (wave < 4) {
@@ -1096,6 +1126,11 @@ __global__ __launch_bounds__(320, 1) void b3w_regionfill_kernel(const uint32_t *
             const uint32_t nib = (((v[uu].x >> 17) & 3u) != B3W_MODE_BIT ? 1u : 0u) | (((v[uu].y >> 17) & 3u) != B3W_MODE_BIT ? 2u : 0u) |
                                  (((v[uu].z >> 17) & 3u) != B3W_MODE_BIT ? 4u : 0u) | (((v[uu].w >> 17) & 3u) != B3W_MODE_BIT ? 8u : 0u);
             if (nib) atomicOr(&bitmap[i4 >> 3], nib << ((i4 & 7u) * 4u));
+#pragma unroll
+            for (int c = 0; c < 4; ++c) {
+              const uint32_t ec = c == 0 ? v[uu].x : c == 1 ? v[uu].y : c == 2 ? v[uu].z : v[uu].w;
+              if (((ec >> 17) & 3u) == B3W_MODE_W256 && 4u * i4 + c < nwit) { atomicMin(&zone[0], 4u * i4 + c); atomicMax(&zone[1], 4u * i4 + c); }
+            }
           }
         }
       }
@@ -1143,18 +1178,21 @@ __global__ __launch_bounds__(320, 1) void b3w_regionfill_kernel(const uint32_t *
     return;
   }
   // ---- STORERS: per half, after its barrier: the units' descriptors from the ring; table words one unit ahead
+  __builtin_amdgcn_s_setprio(3);                                             // (wave 0 shares its SIMD with the tracer: the stores go first)
   const uint32_t par = lane & 1u;
   const uint32_t sub = wave;                                                // which KiB of a block this storing wave takes
   const uint32_t lane_off = (x << 12) + (sub << 10) + (lane << 4);          // this lane's byte offset into a region in step 0; step r: + r * 32 KiB
   // A unit goes through three stages, each an LDS round trip behind the one before: S1 descriptor -> table words; S2 image words (and the
   // image's ok word); S3 shape and store.  Three register sets rotate so that S1 of unit i + 2 and S2 of unit i + 1 are in flight while
   // unit i is stored (a lone wave per SIMD has nobody else to hide the round trips behind: exposed, they were a quarter of a unit's time).
-  struct Ent { uint32_t wq; int32_t rel0; uint32_t e[R]; };
+  int32_t zlo = 0, zhi = 0;                                                  // nova: zone[] once the table is there
+  struct Ent { uint32_t wq; int32_t rel0, relw; uint32_t e[R]; };             // relw: rel0 of the wave's lane 0 (a scalar)
   struct Wd { uint32_t w0[R], w1[R], ok; };
   auto s1 = [&](uint32_t k, Ent &en) {                                       // (the descriptor read a further stage ahead was measured: slower)
     const uint2 d = ring[k % B3W_RF_RING];
     en.wq = uni(d.x);
-    en.rel0 = (int32_t)uni(d.y) + (int32_t)lane_off;
+    en.relw = (int32_t)uni(d.y) + (int32_t)((x << 12) + (sub << 10));
+    en.rel0 = en.relw + (int32_t)(lane << 4);
     // the four steps' slots are 1 024 apart (a step is 32 KiB further on): ONE address and immediate offsets for the table words, one for
     // the word-flag bitmap (32 words apart, the SAME bit in each).  No clamping: a lane in front of or behind the body reads whatever
     // lies there — or zeros outside the LDS allocation — and its store is suppressed (range check / predicate) anyway.
@@ -1183,8 +1221,15 @@ __global__ __launch_bounds__(320, 1) void b3w_regionfill_kernel(const uint32_t *
     if (NOVA) {
       const bool ok = uni(wd.ok) != 0;
       const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(dst, 0, (int)body, 0x00020000);
+      // the wave's four KiB of this unit: slots [t0 + 1024 r, + 32) of the body — near the 256-bit slots? (a scalar: one branch a unit)
+      const int32_t t0 = en.relw >> 5;
+      if (uni((uint32_t)(t0 + 3072 + 35 > zlo && t0 < zhi + 4))) {
 #pragma unroll
-      for (int r = 0; r < R; ++r) fill_store_nova(en.e[r], wd.w0[r], wd.w1[r], par, ok, rsrc, (uint32_t)(en.rel0 + (int32_t)(r << 15)));
+        for (int r = 0; r < R; ++r) fill_store_nova<true>(en.e[r], wd.w0[r], wd.w1[r], par, ok, rsrc, (uint32_t)(en.rel0 + (int32_t)(r << 15)), body, lane);
+      } else {
+#pragma unroll
+        for (int r = 0; r < R; ++r) fill_store_nova<false>(en.e[r], wd.w0[r], wd.w1[r], par, ok, rsrc, (uint32_t)(en.rel0 + (int32_t)(r << 15)), body, lane);
+      }
     } else {
 #pragma unroll
       for (int r = 0; r < R; ++r) {
@@ -1195,6 +1240,7 @@ __global__ __launch_bounds__(320, 1) void b3w_regionfill_kernel(const uint32_t *
   };
   for (uint32_t h = 0;; ++h) {
     __syncthreads();                                                         // image half h & 1, descriptors and count of half h are there
+    if (NOVA && h == 0) { zlo = (int32_t)uni(zone[0]); zhi = (int32_t)uni(zone[1]); }
     const uint32_t cnt = uni(cnt_ring[h & 3]);
     const uint32_t *half = lds + (h & 1) * NH * WORDS;
     const uint32_t k0 = h * NH;
@@ -1361,16 +1407,16 @@ extern "C" int b3w_launch_batch(int kind, int variant, const uint32_t *d_recs, u
     // profiles/r06/fill_pace_scan.log: a clean optimum, -5 % one step to either side).  B3W_FILL_PACE overrides (measurements).
     const char *pace_s = getenv("B3W_FILL_PACE");                      // (read per launch: pace_scan.py changes it inside one process)
     const int pace_env = pace_s ? atoi(pace_s) : -1;
-    const uint32_t pace = pace_env >= 0 ? (uint32_t)pace_env : nova ? 3u : 2u;
+    const uint32_t pace = pace_env >= 0 ? (uint32_t)pace_env : nova ? 0u : 2u;
     if (!nova) {
       hipLaunchKernelGGL((b3w_regionfill_kernel<B3W_KIND_COMP, NH_C>), dim3(B3W_REGIONFILL_GRID), dim3(320), smem, stream, d_recs, n, d_out, pitch,
                          d_table, nwit, d_pub, d_status, pace);
     } else {
       hipLaunchKernelGGL((b3w_regionfill_kernel<B3W_KIND_NOVA_O2, NH_N>), dim3(B3W_REGIONFILL_GRID), dim3(320), smem, stream, d_recs, n, d_out, pitch,
                          d_table, nwit, d_pub, d_status, pace);
-      // ... and the 67 field inverses of every body (0.3 % of its bytes): the body-stream kernel's gadget phase, its stores alone
-      const uint32_t *d_wide = static_cast<const uint32_t *>(d_aux) + B3W_AUX_WIDE_SLOTS;
-      hipLaunchKernelGGL((b3w_nova_kernel<B3W_KIND_NOVA_O2, 2, false, 3>), dim3((n + 1) / 2), dim3(64), 0, stream, d_recs, n, d_out, pitch, d_wide, nwit,
+      // ... and the lines that hold the 67 field inverses of every body (35 lines, 0.6 % of its bytes): the body-stream kernel's gadget and
+      // select phases, and those lines' stores alone
+      hipLaunchKernelGGL((b3w_nova_kernel<B3W_KIND_NOVA_O2, 2, false, 3>), dim3((n + 1) / 2), dim3(64), 0, stream, d_recs, n, d_out, pitch, d_table, nwit,
                          (uint32_t *)nullptr, (int32_t *)nullptr, (const uint32_t *)d_aux, 1u);
     }
     return (int)hipGetLastError();
