@@ -287,14 +287,14 @@ void set_inputs(b3w_ctx *ctx) {
 //   at 4 096 compression witnesses, 7.2 at 32 768 — where the body streams get 7.1-7.2 from a placed buffer and 5.5 from anybody else's.
 //   From 256 witnesses on it is at least as fast as the sliced launch even on a placed buffer (profiles/r06/fill_small.log), so:
 //   compression -> fill order from 256 witnesses, except batches of more than 3 072 into a buffer the placement allocator KNOWS to be
-//   mixed (b3w_place_is_mixed: body streams, +1 %); nova O2 (6.1-6.3 TB/s in fill order, 7.0 placed, 5.5 plain) -> fill order above 2 560
-//   steps unless the buffer is known to be mixed.
+//   mixed (b3w_place_is_mixed: body streams, +1 %); nova O2 (6.5-6.85 TB/s in fill order, 7.0 placed, 5.2-5.5 plain) -> fill order from 768
+//   steps on unless the buffer is known to be mixed (profiles/r06/fill_small_nova.log).
 int b3w_int_default_variant(const b3w_ctx *ctx, uint32_t n, const uint8_t *d_bodies, uint64_t pitch) {
   const bool comp = ctx->desc.kind == B3W_KIND_COMP, nova2 = ctx->desc.kind == B3W_KIND_NOVA_O2;
   const bool fillable = ctx->fill_ok && !(reinterpret_cast<uintptr_t>(d_bodies) & 31) && !(pitch & 31) && pitch < (1ull << 30) &&
                         (uint64_t)n * pitch + (1ull << 20) < (1ull << 37);
   if (fillable && comp && n >= 256 && (n <= 3072 || !b3w_place_is_mixed(d_bodies))) return B3W_VARIANT_REGIONFILL;
-  if (fillable && nova2 && n > 2560 && !b3w_place_is_mixed(d_bodies)) return B3W_VARIANT_REGIONFILL;
+  if (fillable && nova2 && n >= 768 && !b3w_place_is_mixed(d_bodies)) return B3W_VARIANT_REGIONFILL;
   if (n <= 2560) return B3W_VARIANT_SLICED + (n <= (comp ? 32u : 8u) ? 64 : n <= 96 ? 32 : n <= 192 ? 16 : n <= 768 ? 8 : 4);
   if (comp) return n <= 6144 ? 0 : 8;
   if (nova2) return n <= 3072 ? 0 : n <= 32768 ? 3 : 4;     // (4: 8 bodies a wave on a persistent grid — 16 384 steps: -1 %, 32 768: equal, 65 536: +1.3 %)
@@ -370,6 +370,27 @@ int32_t b3w_create(int32_t circuit, int32_t device, b3w_ctx **out) {
     std::vector<uint32_t> aux = build_nova_aux(d.prime);
     static_assert(B3W_AUX_WIDE_SLOTS == 16 + 8 * B3W_INV_TABLE_N, "b3w_kernels.h and b3w_internal.h disagree about the inverse table");
     aux.insert(aux.end(), wide_slots.begin(), wide_slots.end());          // (O2: where the fill-ordered path's second launch writes the inverses)
+    if (ctx->fill_ok && d.kind == B3W_KIND_NOVA_O2) {
+      // ... and what that launch stores: per offset of a body in a 128-byte line (ph slots), the body's slots in lines that hold an inverse
+      aux.resize(B3W_AUX_LINE_LISTS + 2 * 4 * B3W_LINE_LIST_MAX, 0xFFFFFFFFu);
+      for (uint32_t ph = 0; ph < 4; ph++) {
+        uint32_t cnt = 0, last_line = 0xFFFFFFFFu;
+        for (uint32_t j = 0; j < B3W_NOVA_ISZERO; j++) {
+          const uint32_t line = (ph + wide_slots[j]) >> 2;
+          if (line == last_line) continue;                                   // (the slot numbers ascend: checked above)
+          last_line = line;
+          for (uint32_t i = 0; i < 4; i++) {
+            const uint32_t k = line * 4 + i - ph;                            // wraps in front of the body
+            if (k >= d.nwit) continue;
+            if (cnt == B3W_LINE_LIST_MAX) { ctx->fill_ok = false; break; }
+            aux[B3W_AUX_LINE_LISTS + 2 * (ph * B3W_LINE_LIST_MAX + cnt)] = k;
+            aux[B3W_AUX_LINE_LISTS + 2 * (ph * B3W_LINE_LIST_MAX + cnt) + 1] = table[k];
+            cnt++;
+          }
+        }
+        aux[B3W_AUX_LINE_COUNTS + ph] = cnt;
+      }
+    }
     e = hipMalloc(&ctx->d_aux, aux.size() * 4);
     if (e == hipSuccess) e = hipMemcpy(ctx->d_aux, aux.data(), aux.size() * 4, hipMemcpyHostToDevice);
   }

@@ -11,8 +11,12 @@
 // a tracer wave over absolute 128 KiB regions, one contiguous 4 MiB window chip-wide (b3w_kernels.hip "REGIONFILL"); compression and nova O2 circuits
 #define B3W_VARIANT_REGIONFILL 200
 #define B3W_REGIONFILL_GRID 256  // one workgroup per CU, workgroup i on XCD i % 8
-// d_aux of the nova circuits: [0,8) prime, [8] TABLE_N, [16 + 8k, +8) k^-1 mod p for k < 2048, then (O2) the slot numbers of the 67 IsZero inverses
+// d_aux of the nova circuits: [0,8) prime, [8] TABLE_N, [16 + 8k, +8) k^-1 mod p for k < 2048, then (O2) the slot numbers of the 67 IsZero inverses,
+// then — for the four offsets a body may have in a 128-byte line — how many slots lie in lines that hold an inverse, and those slots as (slot, table entry)
 #define B3W_AUX_WIDE_SLOTS (16 + 8 * 2048)
+#define B3W_AUX_LINE_COUNTS (B3W_AUX_WIDE_SLOTS + 68)
+#define B3W_AUX_LINE_LISTS (B3W_AUX_LINE_COUNTS + 4)      // uint2[4][B3W_LINE_LIST_MAX]
+#define B3W_LINE_LIST_MAX 160
 #define B3W_SWEEP_GRID 256       // one 256-thread workgroup per CU, tile = 4 KiB: the runtime fill kernel's shape
 #define B3W_SWEEP_LOGC 13
 #define B3W_SWEEP_CHUNK (1u << B3W_SWEEP_LOGC)   // witnesses per TRACE+SWEEP pair = row length of the scratch

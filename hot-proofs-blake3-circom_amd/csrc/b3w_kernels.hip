@@ -867,25 +867,36 @@ __global__ __launch_bounds__(64) void b3w_nova_kernel(const uint32_t *__restrict
   }
   __syncthreads();
   if (MODE == 3) {
-    // the 128-byte lines (absolute addresses) that hold one of the body's 67 256-bit slots, whole — as far as they lie in the body —: eight
-    // lane-jobs a slot, lane pair = one slot of its line, each lane a 16-byte half.  What stands beside the inverses are select flags and
+    // the 128-byte lines (absolute addresses) that hold one of the body's 67 256-bit slots, whole — as far as they lie in the body —:
+    // lane pair = one slot of such a line, each lane a 16-byte half.  What stands beside the inverses are select flags and
     // step inputs (b3w_ctx.cpp checks it: nothing of the compression trace, which this launch does not run).
-    const uint32_t *ws = aux + B3W_AUX_WIDE_SLOTS;
-    for (int t = lane; t < 536 * W; t += 64) {
-      const int ww = t / 536, r = t - ww * 536, j = r >> 3, i = (r >> 1) & 3, half = r & 1;
+    // The host lists them per offset of a body in a line (aux: B3W_AUX_LINE_LISTS): all of a body's list entries are loaded before its
+    // first store — a load behind a store comes back behind it.
+    const uint2 *lists = reinterpret_cast<const uint2 *>(aux + B3W_AUX_LINE_LISTS);
+    const uint32_t half = (uint32_t)lane & 1u;
+#pragma unroll
+    for (int ww = 0; ww < W; ++ww) {
       if (wb(ww) < n && okf[ww]) {
         uint8_t *base = out + (uint64_t)wb(ww) * pitch;
         const uint32_t ph = (uint32_t)(reinterpret_cast<uint64_t>(base) >> 5) & 3u;
-        const uint32_t line = (ph + ws[j]) >> 2;
-        const uint32_t k = line * 4u + (uint32_t)i - ph;                  // (wraps for the slots of the line in front of the body)
-        const bool again = j > 0 && ((ph + ws[j - 1]) >> 2) == line;       // the line was the slot before's already (slots ascend)
-        if (k < nwit && !again) {
-          const uint32_t e = table[k], src = e & 0xFFFu, sh = (e >> 12) & 31u, mode = (e >> 17) & 3u;
-          const uint32_t *L = lds + ww * WORDS + src + (mode == B3W_MODE_W256 ? 4u * half : 0u);
-          uint4 v = make_uint4(0, 0, 0, 0);
-          if (mode == B3W_MODE_W256) v = make_uint4(L[0], L[1], L[2], L[3]);
-          else if (!half) { v.x = mode == B3W_MODE_BIT ? (L[0] >> sh) & 1u : L[0]; v.y = mode == B3W_MODE_W64 ? L[1] : 0u; }
-          store16<false>(base + (uint64_t)k * 32 + 16 * half, v);
+        const uint32_t cnt = aux[B3W_AUX_LINE_COUNTS + ph];
+        constexpr int IT = B3W_LINE_LIST_MAX / 32;
+        uint2 it[IT];
+#pragma unroll
+        for (int u = 0; u < IT; ++u) {
+          const uint32_t idx = ((uint32_t)lane >> 1) + 32u * u;
+          it[u] = idx < cnt ? lists[ph * B3W_LINE_LIST_MAX + idx] : make_uint2(0xFFFFFFFFu, 0u);
+        }
+#pragma unroll
+        for (int u = 0; u < IT; ++u) {
+          if (it[u].x < nwit) {
+            const uint32_t e = it[u].y, src = e & 0xFFFu, sh = (e >> 12) & 31u, mode = (e >> 17) & 3u;
+            const uint32_t *L = lds + ww * WORDS + src + (mode == B3W_MODE_W256 ? 4u * half : 0u);
+            uint4 v = make_uint4(0, 0, 0, 0);
+            if (mode == B3W_MODE_W256) v = make_uint4(L[0], L[1], L[2], L[3]);
+            else if (!half) { v.x = mode == B3W_MODE_BIT ? (L[0] >> sh) & 1u : L[0]; v.y = mode == B3W_MODE_W64 ? L[1] : 0u; }
+            store16<false>(base + (uint64_t)it[u].x * 32 + 16 * half, v);
+          }
         }
       }
     }
@@ -1091,7 +1102,7 @@ __global__ __launch_bounds__(320, 1) void b3w_regionfill_kernel(const uint32_t *
   __shared__ uint32_t cnt_ring[4];                                          // units of half h at h % 4
   __shared__ uint32_t zone[2];                                              // nova: the lowest and the highest 256-bit slot of a body
   uint16_t *tab = reinterpret_cast<uint16_t *>(bf_lds);
-  const uint32_t tabw = ((nwit + 7u) & ~7u) / 2, bmw = NOVA ? ((nwit + 127u) & ~127u) / 32 : 0u;
+  const uint32_t tabw = ((nwit + 7u) & ~7u) / 2, bmw = NOVA ? 1024u : 0u;   // nova: the word flags, TRANSPOSED — word i holds the flags of the slots i, i + 1024, i + 2048, ... (nwit < 32 K)
   uint32_t *bitmap = bf_lds + tabw, *lds = bf_lds + tabw + bmw;
   const uint32_t wave = uni(threadIdx.x >> 6), lane = threadIdx.x & 63u;
   const uint32_t x = blockIdx.x & 7u, grp = blockIdx.x >> 3;              // XCD residue; group (32 of them: gridDim.x = 256)
@@ -1125,7 +1136,8 @@ __global__ __launch_bounds__(320, 1) void b3w_regionfill_kernel(const uint32_t *
           if (NOVA) {
             const uint32_t nib = (((v[uu].x >> 17) & 3u) != B3W_MODE_BIT ? 1u : 0u) | (((v[uu].y >> 17) & 3u) != B3W_MODE_BIT ? 2u : 0u) |
                                  (((v[uu].z >> 17) & 3u) != B3W_MODE_BIT ? 4u : 0u) | (((v[uu].w >> 17) & 3u) != B3W_MODE_BIT ? 8u : 0u);
-            if (nib) atomicOr(&bitmap[i4 >> 3], nib << ((i4 & 7u) * 4u));
+#pragma unroll
+            for (int c = 0; c < 4; ++c) if (nib >> c & 1u) atomicOr(&bitmap[(4u * i4 + c) & 1023u], 1u << ((4u * i4 + c) >> 10));
 #pragma unroll
             for (int c = 0; c < 4; ++c) {
               const uint32_t ec = c == 0 ? v[uu].x : c == 1 ? v[uu].y : c == 2 ? v[uu].z : v[uu].w;
@@ -1193,16 +1205,17 @@ __global__ __launch_bounds__(320, 1) void b3w_regionfill_kernel(const uint32_t *
     en.wq = uni(d.x);
     en.relw = (int32_t)uni(d.y) + (int32_t)((x << 12) + (sub << 10));
     en.rel0 = en.relw + (int32_t)(lane << 4);
-    // the four steps' slots are 1 024 apart (a step is 32 KiB further on): ONE address and immediate offsets for the table words, one for
-    // the word-flag bitmap (32 words apart, the SAME bit in each).  No clamping: a lane in front of or behind the body reads whatever
+    // the four steps' slots are 1 024 apart (a step is 32 KiB further on): ONE address and immediate offsets for the table words.  No clamping: a lane in front of or behind the body reads whatever
     // lies there — or zeros outside the LDS allocation — and its store is suppressed (range check / predicate) anyway.
     const int32_t s0 = en.rel0 >> 5;
     const uint16_t *tp = tab + s0;
-    const uint32_t *bp = bitmap + (s0 >> 5);
+    // (the four steps' flags: ONE word of the transposed bitmap, four neighbouring bits from bit s0 >> 10 on — which is -4 .. -1 where the
+    // body starts inside the region: the first steps' lanes lie in front of it)
+    const uint32_t bw = NOVA ? (uint32_t)(((uint64_t)bitmap[s0 & 1023] << 4) >> ((s0 >> 10) + 4)) : 0u;
 #pragma unroll
     for (int r = 0; r < R; ++r) {
       en.e[r] = tp[1024 * r];
-      if (NOVA) en.e[r] |= ((bp[32 * r] >> (s0 & 31)) & 1u) << 16;
+      if (NOVA) en.e[r] |= ((bw >> r) & 1u) << 16;
     }
   };
   auto s2 = [&](const Ent &en, Wd &wd, const uint32_t *img) {
@@ -1383,7 +1396,8 @@ extern "C" int b3w_launch_batch(int kind, int variant, const uint32_t *d_recs, u
     // slot table (16 bits a slot) [+ one bit a slot] + 2 x NH images: 14 of 3.7 KB (compression), 11 of the 4.7 KB narrow nova image
     constexpr int NH_C = 14, NH_N = 11;
     const bool nova = kind != B3W_KIND_COMP;
-    const size_t smem = (size_t)((nwit + 7u) & ~7u) * 2 + (nova ? (size_t)((nwit + 127u) & ~127u) / 8 : 0) +
+    if (nova && nwit > 32u * 1024u) return -5;                   // (the transposed word-flag bitmap: 32 slots a word, 1 024 apart)
+    const size_t smem = (size_t)((nwit + 7u) & ~7u) * 2 + (nova ? 4096u : 0u) +
                         (size_t)(2 * (nova ? NH_N * B3W_LDS_WIDE : NH_C * B3W_LDS_WORDS_COMP) + 4) * 4;
     constexpr size_t B3W_FILL_MAX_SMEM = 160 * 1024 - 4096;      // (+ the kernel's static descriptor ring)
     if (smem > B3W_FILL_MAX_SMEM) return -5;

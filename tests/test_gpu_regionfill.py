@@ -290,6 +290,18 @@ def test_default_policy_by_batch_size_and_buffer(m):
                     assert hip.hipMemcpy(ctypes.c_void_p(got.ctypes.data), ctypes.c_void_p(ptr + i * body), ctypes.c_size_t(body), 2) == 0
                     assert np.array_equal(got, want[j]), (name, k, i)
     placed.free(); ctx.close(); ctx2.close()
+    # the nova O2 builds: the fill order from 768 steps on, for a buffer the allocator does not know to be mixed (profiles/r06/fill_small_nova.log)
+    nv = m.Context("nova_vesta", 0)
+    nrecs = torch.from_numpy(T.workloads().config3_nova(800).view(np.int32)).to(dev)
+    nplain = torch.empty(800 * nv.body_bytes, dtype=torch.uint8, device=dev)
+    nplaced = nv.alloc_bodies(800 * nv.body_bytes)
+    for k, ptr, expect in ((767, nplain.data_ptr(), 20 + 8), (768, nplain.data_ptr(), 200), (800, nplain.data_ptr() + 16, 20 + 4)):
+        v, _ = nv.autotune_device(nrecs.data_ptr(), k, ptr, 0, 0, d_st.data_ptr(), s)
+        assert v == expect, (k, v)
+    if nplaced.placement in ("mixed", "interleaved"):             # (both: classes alternate in it, the allocator knows)
+        v, _ = nv.autotune_device(nrecs.data_ptr(), 800, nplaced.ptr, 0, 0, d_st.data_ptr(), s)
+        assert v == 20 + 4, v
+    nplaced.free(); nv.close()
 
 
 def test_store_only_region_shapes_stay_inside_the_buffer(m):
