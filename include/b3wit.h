@@ -182,8 +182,8 @@ int32_t b3w_bodies_search_breakdown(const b3w_ctx *ctx, double out[4]);
  * 3 / 4 = PACED persistent body streams (512 single-wave workgroups taking groups of 4 / 8 bodies in turn, four vector-ALU instructions
  * in front of every store: a store-only kernel without any issues faster than HBM drains and fills it SLOWER — the best store-only
  * shapes of tools/ubench/store_sweep.hip on a placed buffer), 5 = 8 bodies per wave, paced, one wave per group, 6 / 7 = the fill-ordered
- * witness kernel's store order (variant 200: one contiguous 4 MiB window chip-wide) paced by s_sleep / by vector-ALU instructions — the
- * only store-only shapes that fill a caller's plain buffer as fast as a placed one (7.0 TB/s).
+ * witness kernel's store order (variant 200: one contiguous 4 MiB window chip-wide) paced by s_sleep / by vector-ALU instructions (the best of five / six
+ * paces each: the rate is a cliff in the pace) — the only store-only shapes that fill a caller's plain buffer as fast as a placed one (7.0 TB/s).
  * What a witness kernel's achieved bandwidth on the SAME buffer is to be read against (bench.py: roofline.of_measured_ceiling).
  * HIP events on `stream`; waits for them.  The buffer's contents are overwritten. */
 int32_t b3w_bodies_store_rate(b3w_ctx *ctx, void *d_bodies, uint32_t n, uint64_t pitch, int32_t shape, uint32_t iters, void *stream,
