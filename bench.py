@@ -63,7 +63,7 @@ def kernel_path(v):
 
 
 def variant_name(v):
-    return {"fused": f"fused ({v})", "sweep": "sweep (TRACE + SWEEP kernels)", "fill": "fill-ordered fused (REGIONFILL, 200)"}[kernel_path(v)]
+    return {"fused": f"fused ({v})", "sweep": "sweep (TRACE + SWEEP kernels)", "fill": f"fill-ordered fused (REGIONFILL, {v})"}[kernel_path(v)]
 # store-only shapes of b3w_bodies_store_rate the batch line reads `achieved` against (roofline.store_ceiling)
 STORE_SHAPES = {"streams_w4": 0, "streams_w8": 1, "fill": 2, "paced_persistent_w4x512": 3, "paced_persistent_w8x512": 4, "paced_streams_w8": 5,
                 "paced_region_fill_sleep": 6, "paced_region_fill_valu": 7}

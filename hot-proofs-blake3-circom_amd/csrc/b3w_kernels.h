@@ -10,6 +10,10 @@
 // variant B3W_VARIANT_REGIONFILL: the fill-ordered fused kernel for caller-owned (plain) buffers — 256 workgroups of four storing waves and
 // a tracer wave over absolute 128 KiB regions, one contiguous 4 MiB window chip-wide (b3w_kernels.hip "REGIONFILL"); compression and nova O2 circuits
 #define B3W_VARIANT_REGIONFILL 200
+// the same kernel paced one step lighter (compression): the fastest on every buffer measured (7.15 TB/s at 4 096 witnesses, 7.3 from 16 384 on) —
+// and one step from the cliff below which the chip-wide store window frays (6.7): a choice for the autotuner, which times it on the buffer
+// at hand, not for the default
+#define B3W_VARIANT_REGIONFILL_LIGHT 201
 #define B3W_REGIONFILL_GRID 256  // one workgroup per CU, workgroup i on XCD i % 8
 // d_aux of the nova circuits: [0,8) prime, [8] TABLE_N, [16 + 8k, +8) k^-1 mod p for k < 2048, then (O2) the slot numbers of the 67 IsZero inverses,
 // then — for the four offsets a body may have in a 128-byte line — how many slots lie in lines that hold an inverse, and those slots as (slot, table entry)

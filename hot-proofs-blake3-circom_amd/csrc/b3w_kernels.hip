@@ -1227,7 +1227,8 @@ __global__ __launch_bounds__(320, 1) void b3w_regionfill_kernel(const uint32_t *
     wd.ok = NOVA ? img[B3W_LDS_OKWORD] : 1u;                                 // a rejected step's body is left alone
   };
   auto s3 = [&](const Ent &en, const Wd &wd, const uint32_t *img) {
-    for (uint32_t z = 0; z < pace; ++z) __builtin_amdgcn_s_sleep(1);         // PACE, see the launch
+    for (uint32_t z = 0; z < (pace & 15u); ++z) __builtin_amdgcn_s_sleep(1);  // PACE, see the launch: sleeps (64 clocks) ...
+    { uint32_t pv = lane; for (uint32_t z = 0; z < (pace >> 4); ++z) asm volatile("v_add_u32 %0, %0, 1" : "+v"(pv)); }   // ... and finer steps
     const uint32_t w = en.wq & 0x7FFFFFFFu;
     if ((en.wq >> 31) && x == 0 && sub == 0) fill_report<NOVA>(img, w, lane, pub, status);    // the unit in which the body starts reports for it
     uint8_t *dst = out + (uint64_t)w * pitch;
@@ -1387,9 +1388,10 @@ extern "C" int b3w_launch_batch(int kind, int variant, const uint32_t *d_recs, u
     }
     return (int)hipGetLastError();
   }
-  if (variant == B3W_VARIANT_REGIONFILL) {
+  if (variant == B3W_VARIANT_REGIONFILL || variant == B3W_VARIANT_REGIONFILL_LIGHT) {
     // 256 workgroups (one per CU; workgroup i on XCD i % 8); 32-byte aligned bodies (a lane pair is one slot); compression and nova O2
     if (kind != B3W_KIND_COMP && kind != B3W_KIND_NOVA_O2) return -1;
+    if (variant == B3W_VARIANT_REGIONFILL_LIGHT && kind != B3W_KIND_COMP) return -1;       // (the nova storing waves have no slack to pace)
     if (kind == B3W_KIND_NOVA_O2 && !d_aux) return -3;
     if ((reinterpret_cast<uintptr_t>(d_out) & 31) || (pitch & 31) || pitch >= (1ull << 30)) return -5;
     if (32ull * nwit < (1ull << 17) || (uint64_t)n * pitch + (1ull << 20) >= (1ull << 37)) return -5;      // a region meets two bodies at most; 32-bit slot positions
@@ -1414,14 +1416,17 @@ extern "C" int b3w_launch_batch(int kind, int variant, const uint32_t *d_recs, u
       if (e != hipSuccess) return (int)e;
       attr_done.fetch_or(bit, std::memory_order_release);
     }
-    // PACE: every storing wave sleeps `pace` x s_sleep 1 (64 clocks each, on the chip's 64-clock grid) per unit.  The storers are built to
-    // issue as little as they can, and then they are too fast: unpaced, the workgroups run at whatever the memory system lets each of
-    // them have, drift apart, and the one compact window the fill order lives on frays — 6.2 (compression) / 5.6 (nova) TB/s on one-class
-    // memory; paced to just under the memory's rate they stay in step: 6.65 at 2, 6.1 at 3 (tools/ubench/pace_scan.py,
-    // profiles/r06/fill_pace_scan.log: a clean optimum, -5 % one step to either side).  B3W_FILL_PACE overrides (measurements).
+    // PACE: every storing wave waits per unit — pace % 16 x s_sleep 1 (64 clocks each) and pace / 16 single vector-ALU steps (~ 25 clocks
+    // each with their loop).  The storers are built to issue as little as they can, and then they are too fast: unpaced, the workgroups run
+    // at whatever the memory system lets each of them have, drift apart, and the one compact window the fill order lives on frays — 6.6
+    // (compression) TB/s on one-class memory.  Paced to just under the memory's rate they stay in step, and the rate is a CLIFF in the
+    // pace: compression 6.7 at one step, 7.15 (4 096 witnesses) / 7.3 (16 384 and more) at two, -1 % for every further step, on placed,
+    // one-class and hipMalloc buffers alike (tools/ubench/pace_robust.py, pace_scan.py; profiles/r06/pace_robust.log).  The default stands
+    // one step behind the edge (48: three steps; sleeps alone — 2, the first default — are four), variant 201 on it.  The nova storing waves
+    // do more per slot and have no slack: 0.  B3W_FILL_PACE overrides (measurements).
     const char *pace_s = getenv("B3W_FILL_PACE");                      // (read per launch: pace_scan.py changes it inside one process)
     const int pace_env = pace_s ? atoi(pace_s) : -1;
-    const uint32_t pace = pace_env >= 0 ? (uint32_t)pace_env : nova ? 0u : 2u;
+    const uint32_t pace = pace_env >= 0 ? (uint32_t)pace_env : nova ? 0u : variant == B3W_VARIANT_REGIONFILL_LIGHT ? 32u : 48u;
     if (!nova) {
       hipLaunchKernelGGL((b3w_regionfill_kernel<B3W_KIND_COMP, NH_C>), dim3(B3W_REGIONFILL_GRID), dim3(320), smem, stream, d_recs, n, d_out, pitch,
                          d_table, nwit, d_pub, d_status, pace);
@@ -1435,7 +1440,7 @@ extern "C" int b3w_launch_batch(int kind, int variant, const uint32_t *d_recs, u
     }
     return (int)hipGetLastError();
   }
-  if (variant > B3W_VARIANT_REGIONFILL) return -1;
+  if (variant > B3W_VARIANT_REGIONFILL_LIGHT) return -1;
   // bodies that start at the same offset into a 128-byte line are `stride` apart (WaveBodies); a wave takes W of them
   const uint32_t pm = (uint32_t)(pitch >> 5) & 3u, stride = (pitch & 31) ? 1u : pm == 0 ? 1u : pm == 2 ? 2u : 4u;
 #define B3W_GRID(WV) dim3((n + stride * WV - 1) / (stride * WV) * stride)

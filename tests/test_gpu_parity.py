@@ -51,7 +51,7 @@ def test_compression_batch_matches_oracle_every_variant(m):
     bad, want = T.oracle_batch_u32("compression", recs)
     assert bad == 0
     want = want.copy()
-    for variant in list(range(9)) + [22, 24, 28, 36, 52, 84, 200]:                           # 20 + s: SLICED, s waves per body; 200: fill-ordered
+    for variant in list(range(9)) + [22, 24, 28, 36, 52, 84, 200, 201]:                      # 20 + s: SLICED, s waves per body; 200 / 201: fill-ordered
         os.environ["B3W_VARIANT"] = str(variant)
         try:
             ctx = _ctx(m, "compression")

@@ -100,12 +100,23 @@ def test_regionfill_refuses_what_it_cannot_take(m):
     with pytest.raises(m.B3WError):
         nova.run_device(nrec.data_ptr(), 4, nb.data_ptr(), 0, 0, 0, s)
     nova.close()
+    os.environ["B3W_VARIANT"] = "201"                        # the lighter pace is the compression circuit's alone
+    try:
+        light = m.Context("nova_vesta", 0)
+    finally:
+        del os.environ["B3W_VARIANT"]
+    nb2 = torch.full((4 * light.body_bytes,), FILL, dtype=torch.uint8, device=dev)
+    with pytest.raises(m.B3WError):
+        light.run_device(nrec.data_ptr(), 4, nb2.data_ptr(), 0, 0, 0, s)
+    torch.cuda.synchronize()
+    assert bool((nb2 == FILL).all().item())
+    light.close()
 
 
 def test_regionfill_full_config2_batch_on_a_plain_buffer_and_the_autotuner(m):
     """BASELINE config 2 (4 096 witnesses) into a caller-owned torch buffer: all public outputs against a plain BLAKE3 compression, 600
     bodies byte for byte against the oracle (the first and last of the buffer, a run across the middle), the whole buffer equal to the
-    default variant's; and b3w_batch_autotune_device offers the variant on such a buffer (0, 3, 100 or 200) and stays bit-exact."""
+    default variant's; and b3w_batch_autotune_device offers the variants on such a buffer (0, 3, 100, 200 or 201) and stays bit-exact."""
     import torch
     from test_gpu_parity import _blake3_compress_np
     dev = torch.device("cuda:0")
@@ -131,7 +142,7 @@ def test_regionfill_full_config2_batch_on_a_plain_buffer_and_the_autotuner(m):
     torch.cuda.synchronize()
     assert torch.equal(d_ref, d_bodies)
     v, ms = ref.autotune_device(d_recs.data_ptr(), n, d_ref.data_ptr(), 0, 0, d_st.data_ptr(), s)
-    assert v in (0, 3, 100, 200) and ms > 0
+    assert v in (0, 3, 100, 200, 201) and ms > 0
     d_ref.fill_(1)
     ref.run_device(d_recs.data_ptr(), n, d_ref.data_ptr(), 0, 0, 0, s)
     torch.cuda.synchronize()

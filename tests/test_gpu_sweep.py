@@ -132,7 +132,7 @@ def test_autotune_picks_a_variant_and_stays_bit_exact(m):
     d_bodies = torch.empty((n, ctx.body_bytes), dtype=torch.uint8, device=dev)
     d_st = torch.zeros(n, dtype=torch.int32, device=dev)
     v, ms = ctx.autotune_device(d_recs.data_ptr(), n, d_bodies.data_ptr(), 0, 0, d_st.data_ptr(), s)
-    assert v in (0, 3, 100, 200) and ms > 0
+    assert v in (0, 3, 100, 200, 201) and ms > 0
     _, want = T.oracle_batch_u32("compression", recs[:64])
     for k in (n, 512, 5):                                    # the tuned variant, then small batches on the same context
         d_bodies.fill_(7)

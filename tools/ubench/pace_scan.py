@@ -14,7 +14,7 @@ for circuit, n in (("compression", 4096), ("nova_vesta", 8192)):
     os.environ.pop("B3W_PLACEMENT")
     algo = n * (ctx.body_bytes + (112 if circuit == "compression" else 128))
     row = []
-    for pace in (0, 1, 2, 3, 4, 5, 6, 8):
+    for pace in [int(a) for a in sys.argv[1:]] or (0, 1, 2, 3, 4, 5, 6, 8):
         os.environ["B3W_FILL_PACE"] = str(pace)
         for _ in range(2):
             ctx.run_device(d_recs.data_ptr(), n, buf.ptr, 0, 0, 0, st)
