@@ -1065,8 +1065,14 @@ __device__ __forceinline__ void tracer_put(const TracerRecs<NH, NREC> &t, uint32
 struct RegionList {
   uint32_t n, body32, pitch32, off0, end;   // slots per body, from body to body, of the first body's start, one past the last body's last slot
   uint32_t grp, v_next, produced;           // this workgroup's group; next visit to list; units listed so far
+  int32_t zlo, zhi, xoff;                   // nova: a body's lowest / highest 256-bit slot; this workgroup's block in a region, in slots (zlo > zhi: none)
   bool done;
 };
+// descriptor flags beside the body number (below 2^29: n * pitch < 2^37 bytes, a body at least a region)
+#define B3W_RF_STARTS 0x80000000u    // the body starts in this region: the unit reports its outputs and status
+#define B3W_RF_NEAR 0x40000000u      // nova: one of the workgroup's four KiB of this unit may hold a line with a 256-bit slot (fill_store_nova<true>)
+#define B3W_RF_REJECT 0x20000000u    // nova: the step was rejected (set by the tracer once the unit is traced): nothing of it is stored
+#define B3W_RF_BODY 0x1FFFFFFFu
 __device__ __forceinline__ void region_list_batch(RegionList &s, uint2 *ring, uint32_t lane) {
   const uint32_t v = s.v_next + lane, j = s.grp + 32u * v;
   const bool valid = (uint64_t)j << 12 < s.end;
@@ -1077,9 +1083,11 @@ __device__ __forceinline__ void region_list_batch(RegionList &s, uint2 *ring, ui
   const bool e2 = e1 && w_lo + 1 < s.n && bs + s.pitch32 < re;          // a second body starts in the region
   const uint64_t b1 = __builtin_amdgcn_ballot_w64(e1), b2 = __builtin_amdgcn_ballot_w64(e2), lt = (1ull << lane) - 1;
   const uint32_t pos = s.produced + __builtin_popcountll(b1 & lt) + __builtin_popcountll(b2 & lt);
-  // descriptor: x = body | starts-here << 31, y = bytes from the body's start to the region's (negative: the body starts inside it)
-  if (e1) ring[pos % B3W_RF_RING] = make_uint2(w_lo | (bs >= rs ? 0x80000000u : 0u), (uint32_t)((int32_t)(rs - bs) << 5));
-  if (e2) ring[(pos + 1) % B3W_RF_RING] = make_uint2((w_lo + 1) | 0x80000000u, (uint32_t)((int32_t)(rs - bs - s.pitch32) << 5));
+  // descriptor: x = body | flags, y = bytes from the body's start to the region's (negative: the body starts inside it)
+  // (near: the workgroup's waves store the body's slots [t, t + 32) + 1 024 r, t = rel + xoff + 32 sub, sub and r = 0 .. 3)
+  auto near = [&](int32_t rel) { const int32_t t = rel + s.xoff; return (t + 96 + 3072 + 35 > s.zlo && t < s.zhi + 4) ? B3W_RF_NEAR : 0u; };
+  if (e1) ring[pos % B3W_RF_RING] = make_uint2(w_lo | (bs >= rs ? B3W_RF_STARTS : 0u) | near((int32_t)(rs - bs)), (uint32_t)((int32_t)(rs - bs) << 5));
+  if (e2) ring[(pos + 1) % B3W_RF_RING] = make_uint2((w_lo + 1) | B3W_RF_STARTS | near((int32_t)(rs - bs - s.pitch32)), (uint32_t)((int32_t)(rs - bs - s.pitch32) << 5));
   s.produced = uni(s.produced + (uint32_t)__builtin_popcountll(b1) + (uint32_t)__builtin_popcountll(b2));
   s.v_next += 64;
   s.done = s.done || __builtin_amdgcn_ballot_w64(!valid) != 0;
@@ -1094,13 +1102,13 @@ template <int KIND, int NH>
 __global__ __launch_bounds__(320, 1) void b3w_regionfill_kernel(const uint32_t *__restrict__ recs, uint32_t n,
                                                                 uint8_t *__restrict__ out, uint64_t pitch,
                                                                 const uint32_t *__restrict__ table, uint32_t nwit,
-                                                                uint32_t *__restrict__ pub, int32_t *__restrict__ status, uint32_t pace) {
+                                                                uint32_t *__restrict__ pub, int32_t *__restrict__ status, uint32_t pace,
+                                                                const uint32_t *__restrict__ aux) {
   constexpr bool NOVA = KIND != B3W_KIND_COMP;
   constexpr int WORDS = NOVA ? B3W_LDS_WIDE : B3W_LDS_WORDS_COMP, NREC = NOVA ? 32 : 28, RDST = NOVA ? B3W_LDS_NV : B3W_A_H, R = 4;
   extern __shared__ __attribute__((aligned(16))) uint32_t bf_lds[];
   __shared__ uint2 ring[B3W_RF_RING];                                       // unit descriptors, unit k at k % ring
   __shared__ uint32_t cnt_ring[4];                                          // units of half h at h % 4
-  __shared__ uint32_t zone[2];                                              // nova: the lowest and the highest 256-bit slot of a body
   uint16_t *tab = reinterpret_cast<uint16_t *>(bf_lds);
   const uint32_t tabw = ((nwit + 7u) & ~7u) / 2, bmw = NOVA ? 1024u : 0u;   // nova: the word flags, TRANSPOSED — word i holds the flags of the slots i, i + 1024, i + 2048, ... (nwit < 32 K)
   uint32_t *bitmap = bf_lds + tabw, *lds = bf_lds + tabw + bmw;
@@ -1112,7 +1120,6 @@ __global__ __launch_bounds__(320, 1) void b3w_regionfill_kernel(const uint32_t *
   // listing, loading and tracing the first half: the first barrier below is both "table there" and "half 0 there".
   if (NOVA) {
     for (uint32_t wd = threadIdx.x; wd < bmw; wd += 320) bitmap[wd] = 0;
-    if (threadIdx.x == 0) { zone[0] = 0xFFFFFFFFu; zone[1] = 0u; }
     __syncthreads();                                                         // (zeroed before the ds_or below; the tracer does not touch it)
   }
   if (wave < 4) {
@@ -1138,11 +1145,6 @@ __global__ __launch_bounds__(320, 1) void b3w_regionfill_kernel(const uint32_t *
                                  (((v[uu].z >> 17) & 3u) != B3W_MODE_BIT ? 4u : 0u) | (((v[uu].w >> 17) & 3u) != B3W_MODE_BIT ? 8u : 0u);
 #pragma unroll
             for (int c = 0; c < 4; ++c) if (nib >> c & 1u) atomicOr(&bitmap[(4u * i4 + c) & 1023u], 1u << ((4u * i4 + c) >> 10));
-#pragma unroll
-            for (int c = 0; c < 4; ++c) {
-              const uint32_t ec = c == 0 ? v[uu].x : c == 1 ? v[uu].y : c == 2 ? v[uu].z : v[uu].w;
-              if (((ec >> 17) & 3u) == B3W_MODE_W256 && 4u * i4 + c < nwit) { atomicMin(&zone[0], 4u * i4 + c); atomicMax(&zone[1], 4u * i4 + c); }
-            }
           }
         }
       }
@@ -1157,6 +1159,9 @@ __global__ __launch_bounds__(320, 1) void b3w_regionfill_kernel(const uint32_t *
     rl.off0 = (uint32_t)((reinterpret_cast<uint64_t>(out) & ((1ull << 17) - 1)) >> 5);
     rl.end = rl.off0 + (n - 1) * rl.pitch32 + rl.body32;
     rl.grp = grp; rl.v_next = 0; rl.produced = 0; rl.done = false;
+    rl.xoff = (int32_t)(x << 7);
+    rl.zlo = NOVA ? (int32_t)aux[B3W_AUX_WIDE_SLOTS] : 0x7FFFFFFF;          // (the slot numbers ascend: b3w_create checks it)
+    rl.zhi = NOVA ? (int32_t)aux[B3W_AUX_WIDE_SLOTS + B3W_NOVA_ISZERO - 1] : -1;
     auto list_until = [&](uint32_t target) {
       while (!rl.done && rl.produced < target) region_list_batch(rl, ring, lane);
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
@@ -1165,14 +1170,14 @@ __global__ __launch_bounds__(320, 1) void b3w_regionfill_kernel(const uint32_t *
     auto cnt_of = [&](uint32_t h) { return rl.produced <= h * NH ? 0u : (rl.produced - h * NH < (uint32_t)NH ? rl.produced - h * NH : (uint32_t)NH); };
     TracerRecs<NH, NREC> tr;
     list_until(2 * NH);
-    tracer_load<NH, NREC>(tr, recs, cnt_of(0), lane, [&](uint32_t k) { return ring[k % B3W_RF_RING].x & 0x7FFFFFFFu; });
+    tracer_load<NH, NREC>(tr, recs, cnt_of(0), lane, [&](uint32_t k) { return ring[k % B3W_RF_RING].x & B3W_RF_BODY; });
     for (uint32_t h = 0;; ++h) {
       uint32_t *half = lds + (h & 1) * NH * WORDS;
       list_until((h + 3) * NH);                                             // (ring: at most 3 NH + 127 units between the oldest in use and the newest)
       const uint32_t cnt = cnt_of(h);
       if (lane == 0) cnt_ring[h & 3] = cnt;
       tracer_put<NH, NREC, WORDS, RDST>(tr, half, cnt, lane);
-      tracer_load<NH, NREC>(tr, recs, cnt_of(h + 1), lane, [&](uint32_t k) { return ring[((h + 1) * NH + k) % B3W_RF_RING].x & 0x7FFFFFFFu; });
+      tracer_load<NH, NREC>(tr, recs, cnt_of(h + 1), lane, [&](uint32_t k) { return ring[((h + 1) * NH + k) % B3W_RF_RING].x & B3W_RF_BODY; });
       if (!NOVA) {
         if (q < cnt) trace_compression(half + q * WORDS, col, nullptr);     // (outputs: the storers', see fill_report)
       } else {
@@ -1180,7 +1185,10 @@ __global__ __launch_bounds__(320, 1) void b3w_regionfill_kernel(const uint32_t *
           uint32_t *L = half + q * WORDS;
           const bool dom_a = nova_iszero_flags_quad(L, (int)col);           // (flags only: no field arithmetic, no table of inverses)
           const int32_t st = nova_select(L, (int)col, dom_a);
-          if (col == 0) { L[B3W_LDS_OKWORD] = st == 0 ? 1u : 0u; L[B3W_LDS_STWORD] = (uint32_t)st; }
+          if (col == 0) {
+            L[B3W_LDS_OKWORD] = st == 0 ? 1u : 0u; L[B3W_LDS_STWORD] = (uint32_t)st;
+            if (st != 0) ring[(h * NH + q) % B3W_RF_RING].x |= B3W_RF_REJECT;   // (this unit's descriptor: nobody else's to write, and read behind the barrier)
+          }
           if (st == 0) trace_compression(L, col, nullptr);
         }
       }
@@ -1193,13 +1201,12 @@ __global__ __launch_bounds__(320, 1) void b3w_regionfill_kernel(const uint32_t *
   __builtin_amdgcn_s_setprio(3);                                             // (wave 0 shares its SIMD with the tracer: the stores go first)
   const uint32_t par = lane & 1u;
   const uint32_t sub = wave;                                                // which KiB of a block this storing wave takes
-  const uint32_t lane_off = (x << 12) + (sub << 10) + (lane << 4);          // this lane's byte offset into a region in step 0; step r: + r * 32 KiB
+  // (a lane's byte offset into a region in step 0: (x << 12) + (sub << 10) + (lane << 4); step r: + r * 32 KiB)
   // A unit goes through three stages, each an LDS round trip behind the one before: S1 descriptor -> table words; S2 image words (and the
   // image's ok word); S3 shape and store.  Three register sets rotate so that S1 of unit i + 2 and S2 of unit i + 1 are in flight while
   // unit i is stored (a lone wave per SIMD has nobody else to hide the round trips behind: exposed, they were a quarter of a unit's time).
-  int32_t zlo = 0, zhi = 0;                                                  // nova: zone[] once the table is there
   struct Ent { uint32_t wq; int32_t rel0, relw; uint32_t e[R]; };             // relw: rel0 of the wave's lane 0 (a scalar)
-  struct Wd { uint32_t w0[R], w1[R], ok; };
+  struct Wd { uint32_t w0[R], w1[R]; };
   auto s1 = [&](uint32_t k, Ent &en) {                                       // (the descriptor read a further stage ahead was measured: slower)
     const uint2 d = ring[k % B3W_RF_RING];
     en.wq = uni(d.x);
@@ -1224,20 +1231,18 @@ __global__ __launch_bounds__(320, 1) void b3w_regionfill_kernel(const uint32_t *
       const uint32_t *L = img + (en.e[r] & (NOVA ? 0x7FFu : 0x3FFu));
       wd.w0[r] = L[0]; wd.w1[r] = L[1];
     }
-    wd.ok = NOVA ? img[B3W_LDS_OKWORD] : 1u;                                 // a rejected step's body is left alone
   };
   auto s3 = [&](const Ent &en, const Wd &wd, const uint32_t *img) {
     for (uint32_t z = 0; z < (pace & 15u); ++z) __builtin_amdgcn_s_sleep(1);  // PACE, see the launch: sleeps (64 clocks) ...
     { uint32_t pv = lane; for (uint32_t z = 0; z < (pace >> 4); ++z) asm volatile("v_add_u32 %0, %0, 1" : "+v"(pv)); }   // ... and finer steps
-    const uint32_t w = en.wq & 0x7FFFFFFFu;
+    const uint32_t w = en.wq & B3W_RF_BODY;
     if ((en.wq >> 31) && x == 0 && sub == 0) fill_report<NOVA>(img, w, lane, pub, status);    // the unit in which the body starts reports for it
     uint8_t *dst = out + (uint64_t)w * pitch;
     if (NOVA) {
-      const bool ok = uni(wd.ok) != 0;
+      const bool ok = !(en.wq & B3W_RF_REJECT);                               // a rejected step's body is left alone
       const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(dst, 0, (int)body, 0x00020000);
-      // the wave's four KiB of this unit: slots [t0 + 1024 r, + 32) of the body — near the 256-bit slots? (a scalar: one branch a unit)
-      const int32_t t0 = en.relw >> 5;
-      if (uni((uint32_t)(t0 + 3072 + 35 > zlo && t0 < zhi + 4))) {
+      // near the 256-bit slots?  (the tracer's word in the descriptor, a scalar: one branch a unit)
+      if (en.wq & B3W_RF_NEAR) {
 #pragma unroll
         for (int r = 0; r < R; ++r) fill_store_nova<true>(en.e[r], wd.w0[r], wd.w1[r], par, ok, rsrc, (uint32_t)(en.rel0 + (int32_t)(r << 15)), body, lane);
       } else {
@@ -1254,7 +1259,6 @@ __global__ __launch_bounds__(320, 1) void b3w_regionfill_kernel(const uint32_t *
   };
   for (uint32_t h = 0;; ++h) {
     __syncthreads();                                                         // image half h & 1, descriptors and count of half h are there
-    if (NOVA && h == 0) { zlo = (int32_t)uni(zone[0]); zhi = (int32_t)uni(zone[1]); }
     const uint32_t cnt = uni(cnt_ring[h & 3]);
     const uint32_t *half = lds + (h & 1) * NH * WORDS;
     const uint32_t k0 = h * NH;
@@ -1416,23 +1420,24 @@ extern "C" int b3w_launch_batch(int kind, int variant, const uint32_t *d_recs, u
       if (e != hipSuccess) return (int)e;
       attr_done.fetch_or(bit, std::memory_order_release);
     }
-    // PACE: every storing wave waits per unit — pace % 16 x s_sleep 1 (64 clocks each) and pace / 16 single vector-ALU steps (~ 25 clocks
-    // each with their loop).  The storers are built to issue as little as they can, and then they are too fast: unpaced, the workgroups run
-    // at whatever the memory system lets each of them have, drift apart, and the one compact window the fill order lives on frays — 6.6
-    // (compression) TB/s on one-class memory.  Paced to just under the memory's rate they stay in step, and the rate is a CLIFF in the
-    // pace: compression 6.7 at one step, 7.15 (4 096 witnesses) / 7.3 (16 384 and more) at two, -1 % for every further step, on placed,
-    // one-class and hipMalloc buffers alike (tools/ubench/pace_robust.py, pace_scan.py; profiles/r06/pace_robust.log).  The default stands
-    // one step behind the edge (48: three steps; sleeps alone — 2, the first default — are four), variant 201 on it.  The nova storing waves
-    // do more per slot and have no slack: 0.  B3W_FILL_PACE overrides (measurements).
+    // PACE: every storing wave waits per unit — pace % 16 x s_sleep 1 (to the chip's next 64-clock grid point each) and pace / 16 single
+    // vector-ALU steps (~ 25 clocks each with their loop).  The storers are built to issue as little as they can, and then they are too fast:
+    // unpaced, the workgroups run at whatever the memory system lets each of them have, drift apart, and the one compact window the fill order
+    // lives on frays — 6.6 (compression) TB/s on one-class memory.  Paced to just under the memory's rate they stay in step, and the rate is a
+    // CLIFF in the pace: compression 6.6 at one step, 7.15-7.19 (4 096 witnesses) / 7.3-7.38 (16 384 and more) at two steps or one sleep, -1 %
+    // for every further step, on placed, one-class and hipMalloc buffers alike — but on the edge a launch now and then falls off (6.7-7.2).
+    // One sleep AND one step (17) held in every one of 36 cases on three boxes at 7.10-7.16 / 7.28-7.35: the default; three steps (48) 7.05-7.09 /
+    // 7.2-7.27; two sleeps (2, the first default) 6.98-7.02 / 7.15-7.19 (tools/ubench/pace_robust.py, profiles/r06/pace_robust*.log).
+    // Variant 201 stands on the edge (32).  The nova storing waves do more per slot and have no slack: 0.  B3W_FILL_PACE overrides (measurements).
     const char *pace_s = getenv("B3W_FILL_PACE");                      // (read per launch: pace_scan.py changes it inside one process)
     const int pace_env = pace_s ? atoi(pace_s) : -1;
-    const uint32_t pace = pace_env >= 0 ? (uint32_t)pace_env : nova ? 0u : variant == B3W_VARIANT_REGIONFILL_LIGHT ? 32u : 48u;
+    const uint32_t pace = pace_env >= 0 ? (uint32_t)pace_env : nova ? 0u : variant == B3W_VARIANT_REGIONFILL_LIGHT ? 32u : 17u;
     if (!nova) {
       hipLaunchKernelGGL((b3w_regionfill_kernel<B3W_KIND_COMP, NH_C>), dim3(B3W_REGIONFILL_GRID), dim3(320), smem, stream, d_recs, n, d_out, pitch,
-                         d_table, nwit, d_pub, d_status, pace);
+                         d_table, nwit, d_pub, d_status, pace, (const uint32_t *)nullptr);
     } else {
       hipLaunchKernelGGL((b3w_regionfill_kernel<B3W_KIND_NOVA_O2, NH_N>), dim3(B3W_REGIONFILL_GRID), dim3(320), smem, stream, d_recs, n, d_out, pitch,
-                         d_table, nwit, d_pub, d_status, pace);
+                         d_table, nwit, d_pub, d_status, pace, (const uint32_t *)d_aux);
       // ... and the lines that hold the 67 field inverses of every body (35 lines, 0.6 % of its bytes): the body-stream kernel's gadget and
       // select phases, and those lines' stores alone
       hipLaunchKernelGGL((b3w_nova_kernel<B3W_KIND_NOVA_O2, 2, false, 3>), dim3((n + 1) / 2), dim3(64), 0, stream, d_recs, n, d_out, pitch, d_table, nwit,
