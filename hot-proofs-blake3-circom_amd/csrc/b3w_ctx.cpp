@@ -359,13 +359,55 @@ int32_t b3w_create(int32_t circuit, int32_t device, b3w_ctx **out) {
       }
     }
   }
+  // The fill-ordered kernel's own table, 16 bits a slot, made here: image word (10 bits) | shift of a BIT slot or kind of a word slot (5 bits:
+  // 0 one word, 1 two, 2 a 256-bit slot) | word flag.  A nova image has 1 184 words — 11 bits — but its slots mention only some 820 of them:
+  // the words from 1 024 on get an ALIAS in a word below 1 024 that no slot mentions (the tracer copies them there once a unit is traced;
+  // what the trace kept in such a word is scratch by then), and the table names the alias.
+  std::vector<uint16_t> ftab(table.size(), 0);
+  std::vector<uint32_t> alias;                                              // from | to << 16
+  if (ctx->fill_ok) {
+    const bool nova = ctx->desc.kind != B3W_KIND_COMP;
+    std::vector<uint8_t> used(2048, 0);
+    for (uint32_t i = 0; i < ctx->desc.nwit; i++) {
+      const uint32_t e = table[i], src = e & 0xFFFu, mode = (e >> 17) & 3u;
+      if (mode == B3W_MODE_W256) continue;
+      used[src] = 1;
+      if (mode == B3W_MODE_W64) used[src + 1] = 1;
+    }
+    // not to be written over: the ok / status words and what the storing waves report from (outputs; the nova outputs' words)
+    used[B3W_LDS_OKWORD] = used[B3W_LDS_OKWORD + 1] = 1;
+    for (uint32_t k = 0; k < 16; k++) used[B3W_A_O + k] = 1;
+    if (nova) for (uint32_t k : {NV_N_BLOCKS, NV_BLOCK_COUNT_OUT, NV_TOTAL_DEPTH, NV_DEPTH_OUT, NV_CIL, NV_CIH, NV_LEAF_DEPTH}) used[B3W_LDS_NV + k] = 1;
+    std::vector<uint16_t> to(2048, 0xFFFFu);
+    uint32_t hole = B3W_LDS_HG;                                             // (holes among the G-function words first: the high halves of its sums)
+    for (uint32_t w = 1024; w < 2048 && ctx->fill_ok; w++) {
+      if (!used[w]) continue;
+      while (hole < 1024 && used[hole]) hole++;
+      if (hole >= 1024 || alias.size() >= B3W_ALIAS_MAX) { ctx->fill_ok = false; break; }
+      used[hole] = 1; to[w] = (uint16_t)hole;
+      alias.push_back(w | hole << 16);
+    }
+    for (uint32_t i = 0; i < table.size() && ctx->fill_ok; i++) {
+      const uint32_t e = table[i], sh = (e >> 12) & 31u, mode = (e >> 17) & 3u;
+      uint32_t src = e & 0xFFFu;
+      if (mode == B3W_MODE_W256) { ftab[i] = (uint16_t)(0x8000u | 2u << 10); continue; }
+      if (src >= 1024) {
+        if (mode == B3W_MODE_W64 || to[src] == 0xFFFFu) { if (i < ctx->desc.nwit) ctx->fill_ok = false; continue; }   // (padding entries name word 0)
+        src = to[src];
+      }
+      if (mode == B3W_MODE_W64 && src + 1 >= 1024) { ctx->fill_ok = false; continue; }
+      ftab[i] = (uint16_t)(mode == B3W_MODE_BIT ? (src | sh << 10) : (src | (mode == B3W_MODE_W64 ? 1u : 0u) << 10 | 0x8000u));
+    }
+  }
   DeviceGuard guard(device);              // the caller's current device (torch's, say) is put back on return
   if (guard.err != hipSuccess) { delete ctx; return B3W_E_NO_DEVICE; }
   const CircuitDesc &d = ctx->desc;
-  hipError_t e = hipMalloc((void **)&ctx->d_table_base, (table.size() + 32) * 4);
+  // (the 16-bit table of the fill-ordered kernel lies behind the 32-bit one: table.size() is a multiple of 32 words)
+  hipError_t e = hipMalloc((void **)&ctx->d_table_base, (table.size() + 32) * 4 + ftab.size() * 2);
   if (e == hipSuccess) e = hipMemset(ctx->d_table_base, 0, 32 * 4);
   if (e == hipSuccess) ctx->d_table = ctx->d_table_base + 32;
   if (e == hipSuccess) e = hipMemcpy(ctx->d_table, table.data(), table.size() * 4, hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMemcpy(ctx->d_table + table.size(), ftab.data(), ftab.size() * 2, hipMemcpyHostToDevice);
   if (e == hipSuccess && d.kind != B3W_KIND_COMP) {
     std::vector<uint32_t> aux = build_nova_aux(d.prime);
     static_assert(B3W_AUX_WIDE_SLOTS == 16 + 8 * B3W_INV_TABLE_N, "b3w_kernels.h and b3w_internal.h disagree about the inverse table");
@@ -390,6 +432,9 @@ int32_t b3w_create(int32_t circuit, int32_t device, b3w_ctx **out) {
         }
         aux[B3W_AUX_LINE_COUNTS + ph] = cnt;
       }
+      aux.resize(B3W_AUX_ALIAS_LIST + B3W_ALIAS_MAX, 0u);                    // ... and the aliases its tracer makes
+      aux[B3W_AUX_ALIAS_COUNT] = (uint32_t)alias.size();
+      for (size_t k = 0; k < alias.size(); k++) aux[B3W_AUX_ALIAS_LIST + k] = alias[k];
     }
     e = hipMalloc(&ctx->d_aux, aux.size() * 4);
     if (e == hipSuccess) e = hipMemcpy(ctx->d_aux, aux.data(), aux.size() * 4, hipMemcpyHostToDevice);

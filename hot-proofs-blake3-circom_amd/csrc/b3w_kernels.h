@@ -21,6 +21,10 @@
 #define B3W_AUX_LINE_COUNTS (B3W_AUX_WIDE_SLOTS + 68)
 #define B3W_AUX_LINE_LISTS (B3W_AUX_LINE_COUNTS + 4)      // uint2[4][B3W_LINE_LIST_MAX]
 #define B3W_LINE_LIST_MAX 160
+// then the aliases of the nova image words from 1 024 on (from | to << 16): see b3w_create, the fill-ordered kernel's 16-bit table
+#define B3W_AUX_ALIAS_COUNT (B3W_AUX_LINE_LISTS + 2 * 4 * B3W_LINE_LIST_MAX)
+#define B3W_AUX_ALIAS_LIST (B3W_AUX_ALIAS_COUNT + 1)
+#define B3W_ALIAS_MAX 192
 #define B3W_SWEEP_GRID 256       // one 256-thread workgroup per CU, tile = 4 KiB: the runtime fill kernel's shape
 #define B3W_SWEEP_LOGC 13
 #define B3W_SWEEP_CHUNK (1u << B3W_SWEEP_LOGC)   // witnesses per TRACE+SWEEP pair = row length of the scratch

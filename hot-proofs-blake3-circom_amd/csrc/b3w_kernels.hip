@@ -952,31 +952,23 @@ __global__ __launch_bounds__(64) void b3w_nova_kernel(const uint32_t *__restrict
 // Bit-identical to the other variants (tests/test_gpu_parity.py); b3w_batch_autotune_device times it on the buffer it is given.
 // (Also built and measured in round 6, and taken out: the same workgroup dealt BODY-major — groups of 8 m workgroups per body, a workgroup
 // the body's blocks = u (mod 8 m): 5.8-6.0 TB/s on one-class memory for m = 1 .. 8, profiles/r06/variant_scan_bf*.log.)
-// The slot table in LDS, 16 bits a slot (so that the images fit beside it).
-//   compression: src (10 bits: an image word below 1024), then 5 bits that are the shift of a BIT slot or, under the word flag (bit 15),
-//                "two words" in their lowest bit;
-//   nova O2:     src (11 bits: the NARROW part of the image, below 2048), then 5 bits that are the shift of a BIT slot or the kind of a word
-//                slot (0 one word, 1 two words, 2 a 256-bit slot: SKIPPED here, written by the wide-slot launch), and the word flag in a
-//                bitmap of its own, one bit a slot (18 bits would not fit 16).
-// The host checks that the circuit's table can be said that way (b3w_ctx.cpp: fill_ok) before it offers the variant.
-__device__ __forceinline__ uint16_t fill_entry16(uint32_t e) {
-  const uint32_t src = e & 0xFFFu, sh = (e >> 12) & 31u, mode = (e >> 17) & 3u;
-  return (uint16_t)(mode == B3W_MODE_BIT ? (src | sh << 10) : (src | (mode == B3W_MODE_W64 ? 1u : 0u) << 10 | 0x8000u));
-}
-__device__ __forceinline__ uint16_t fill_entry16_nova(uint32_t e) {
-  const uint32_t src = e & 0xFFFu, sh = (e >> 12) & 31u, mode = (e >> 17) & 3u;
-  return (uint16_t)(mode == B3W_MODE_BIT ? (src | sh << 11) : ((mode == B3W_MODE_W256 ? 0u : src) | (mode - 1u) << 11));
-}
-// e: the 16-bit entry, and for nova bit 16 = the word flag
+// The slot table in LDS, 16 bits a slot (so that the images fit beside it), made by the host (b3w_create):
+//   image word (10 bits: below 1 024), then 5 bits that are the shift of a BIT slot or — under the word flag, bit 15 — the kind of a word slot:
+//   0 one word, 1 two words, 2 (nova O2) a 256-bit slot, left to the wide-slot launch with the rest of its line.
+// A nova image has 1 184 narrow words, but its slots mention only some 820 of them: the mentioned words from 1 024 on have an ALIAS below
+// 1 024 in a word no slot mentions (b3w_create picks them; the tracer copies, alias_copy below), and the table names the alias — the same
+// 16 bits as the compression circuit's, where a flag bit more (first kept in a bitmap beside the table) cost the nova storing waves eleven
+// instructions a unit of the ~ 200 they are bound by.
+// The host checks that the circuit's table can be said that way (fill_ok) before it offers the variant.
 template <bool NOVA>
 __device__ __forceinline__ void fill_store(uint32_t e, uint32_t w0, uint32_t w1, uint32_t par, bool in, uint8_t *p) {
-  const uint32_t f = NOVA ? (e >> 11) & 31u : (e >> 10) & 31u;
-  const bool word = NOVA ? (e >> 16) != 0 : (e & 0x8000u) != 0;
+  const uint32_t f = (e >> 10) & 31u;
+  const bool word = (e & 0x8000u) != 0;
   uint4 v;
   v.x = par ? 0u : (word ? w0 : (w0 >> f) & 1u);
   v.y = (!par && word && (f & 1u)) ? w1 : 0u;
   v.z = 0; v.w = 0;
-  if (in && !(NOVA && word && f == 2u)) store16<false>(p, v);              // (a 256-bit slot: not this launch's)
+  if (in) store16<false>(p, v);
 }
 // The same store through a BUFFER resource over the body (base, body bytes): a lane whose offset lies outside — in front of the body
 // (negative, i.e. huge), behind it, or made so on purpose (a rejected step; a line that holds a 256-bit slot) — is dropped by the hardware's
@@ -990,8 +982,8 @@ __device__ __forceinline__ void fill_store(uint32_t e, uint32_t w0, uint32_t w1,
 template <bool ZONE>
 __device__ __forceinline__ void fill_store_nova(uint32_t e, uint32_t w0, uint32_t w1, uint32_t par, bool ok, __amdgpu_buffer_rsrc_t rsrc, uint32_t rel,
                                                 uint32_t body, uint32_t lane) {
-  const uint32_t f = (e >> 11) & 31u;
-  const bool word = (e >> 16) != 0;
+  const uint32_t f = (e >> 10) & 31u;
+  const bool word = (e & 0x8000u) != 0;
   u32x4 v;
   v.x = par ? 0u : (word ? w0 : (w0 >> f) & 1u);
   v.y = (!par && word && (f & 1u)) ? w1 : 0u;
@@ -1110,43 +1102,31 @@ __global__ __launch_bounds__(320, 1) void b3w_regionfill_kernel(const uint32_t *
   __shared__ uint2 ring[B3W_RF_RING];                                       // unit descriptors, unit k at k % ring
   __shared__ uint32_t cnt_ring[4];                                          // units of half h at h % 4
   uint16_t *tab = reinterpret_cast<uint16_t *>(bf_lds);
-  const uint32_t tabw = ((nwit + 7u) & ~7u) / 2, bmw = NOVA ? 1024u : 0u;   // nova: the word flags, TRANSPOSED — word i holds the flags of the slots i, i + 1024, i + 2048, ... (nwit < 32 K)
-  uint32_t *bitmap = bf_lds + tabw, *lds = bf_lds + tabw + bmw;
+  const uint32_t tabw = ((nwit + 7u) & ~7u) / 2;
+  uint32_t *lds = bf_lds + tabw;
   const uint32_t wave = uni(threadIdx.x >> 6), lane = threadIdx.x & 63u;
   const uint32_t x = blockIdx.x & 7u, grp = blockIdx.x >> 3;              // XCD residue; group (32 of them: gridDim.x = 256)
   const uint32_t body = 32u * nwit;
-  // The table into LDS — by the four STORING waves, sixteen entries a thread in flight (four 16-byte loads at a time: one entry per load
-  // and iteration, as this loop first stood, was 75 dependent L2 round trips = 40 us of every launch), while the tracer wave is already
-  // listing, loading and tracing the first half: the first barrier below is both "table there" and "half 0 there".
-  if (NOVA) {
-    for (uint32_t wd = threadIdx.x; wd < bmw; wd += 320) bitmap[wd] = 0;
-    __syncthreads();                                                         // (zeroed before the ds_or below; the tracer does not touch it)
-  }
+  // The 16-bit table (made by the host, behind the 32-bit one: b3w_create) into LDS — by the four STORING waves, 32 entries a thread in
+  // flight (four 16-byte loads at a time: one entry per load and iteration, as this loop first stood, was 75 dependent L2 round trips = 40 us
+  // of every launch), while the tracer wave is already listing, loading and tracing the first half: the first barrier below is both "table
+  // there" and "half 0 there".
   if (wave < 4) {
-    const uint4 *t4 = reinterpret_cast<const uint4 *>(table);               // (16-byte aligned; padded by 8 groups behind the last slot)
-    uint32_t *tab32 = reinterpret_cast<uint32_t *>(tab);
-    const uint32_t n4 = (nwit + 3u) / 4u;
-    for (uint32_t base4 = 0; base4 < n4; base4 += 256u * 4u) {
+    const uint32_t padded = ((nwit + 31u) / 32u + 8u) * 32u;                // entries of the 32-bit table (build_slot_table)
+    const uint4 *t8 = reinterpret_cast<const uint4 *>(table + padded);      // (16-byte aligned: padded is a multiple of 32 words)
+    uint4 *tab8 = reinterpret_cast<uint4 *>(tab);
+    const uint32_t n8 = (nwit + 7u) / 8u;
+    for (uint32_t base8 = 0; base8 < n8; base8 += 256u * 4u) {
       uint4 v[4];
 #pragma unroll
       for (int uu = 0; uu < 4; ++uu) {
-        const uint32_t i4 = base4 + 256u * uu + threadIdx.x;
-        v[uu] = i4 < n4 ? t4[i4] : make_uint4(0, 0, 0, 0);
+        const uint32_t i8 = base8 + 256u * uu + threadIdx.x;
+        v[uu] = i8 < n8 ? t8[i8] : make_uint4(0, 0, 0, 0);
       }
 #pragma unroll
       for (int uu = 0; uu < 4; ++uu) {
-        const uint32_t i4 = base4 + 256u * uu + threadIdx.x;
-        if (i4 < n4) {
-          const uint32_t e0 = NOVA ? fill_entry16_nova(v[uu].x) : fill_entry16(v[uu].x), e1 = NOVA ? fill_entry16_nova(v[uu].y) : fill_entry16(v[uu].y);
-          const uint32_t e2 = NOVA ? fill_entry16_nova(v[uu].z) : fill_entry16(v[uu].z), e3 = NOVA ? fill_entry16_nova(v[uu].w) : fill_entry16(v[uu].w);
-          *reinterpret_cast<uint2 *>(tab32 + 2 * i4) = make_uint2(e0 | e1 << 16, e2 | e3 << 16);
-          if (NOVA) {
-            const uint32_t nib = (((v[uu].x >> 17) & 3u) != B3W_MODE_BIT ? 1u : 0u) | (((v[uu].y >> 17) & 3u) != B3W_MODE_BIT ? 2u : 0u) |
-                                 (((v[uu].z >> 17) & 3u) != B3W_MODE_BIT ? 4u : 0u) | (((v[uu].w >> 17) & 3u) != B3W_MODE_BIT ? 8u : 0u);
-#pragma unroll
-            for (int c = 0; c < 4; ++c) if (nib >> c & 1u) atomicOr(&bitmap[(4u * i4 + c) & 1023u], 1u << ((4u * i4 + c) >> 10));
-          }
-        }
+        const uint32_t i8 = base8 + 256u * uu + threadIdx.x;
+        if (i8 < n8) tab8[i8] = v[uu];
       }
     }
   }
@@ -1168,6 +1148,13 @@ __global__ __launch_bounds__(320, 1) void b3w_regionfill_kernel(const uint32_t *
       __builtin_amdgcn_wave_barrier();
     };
     auto cnt_of = [&](uint32_t h) { return rl.produced <= h * NH ? 0u : (rl.produced - h * NH < (uint32_t)NH ? rl.produced - h * NH : (uint32_t)NH); };
+    // nova: the aliases of the image words from 1 024 on (aux: from | to << 16), three a lane; copied once a half is traced
+    uint32_t al[3] = {0, 0, 0};
+    if (NOVA) {
+      const uint32_t na = aux[B3W_AUX_ALIAS_COUNT];
+#pragma unroll
+      for (int u = 0; u < 3; ++u) al[u] = lane + 64u * u < na ? aux[B3W_AUX_ALIAS_LIST + lane + 64u * u] : 0u;
+    }
     TracerRecs<NH, NREC> tr;
     list_until(2 * NH);
     tracer_load<NH, NREC>(tr, recs, cnt_of(0), lane, [&](uint32_t k) { return ring[k % B3W_RF_RING].x & B3W_RF_BODY; });
@@ -1190,6 +1177,19 @@ __global__ __launch_bounds__(320, 1) void b3w_regionfill_kernel(const uint32_t *
             if (st != 0) ring[(h * NH + q) % B3W_RF_RING].x |= B3W_RF_REJECT;   // (this unit's descriptor: nobody else's to write, and read behind the barrier)
           }
           if (st == 0) trace_compression(L, col, nullptr);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");               // (the whole wave copies what its quads have written)
+        __builtin_amdgcn_wave_barrier();
+        {
+        uint32_t av[NH * 3];                                                  // (all reads, then all writes: one LDS round trip, not 33)
+#pragma unroll
+        for (int qq = 0; qq < NH; ++qq)
+#pragma unroll
+          for (int u = 0; u < 3; ++u) av[qq * 3 + u] = ((uint32_t)qq < cnt && al[u]) ? half[qq * WORDS + (al[u] & 0xFFFFu)] : 0u;
+#pragma unroll
+        for (int qq = 0; qq < NH; ++qq)
+#pragma unroll
+          for (int u = 0; u < 3; ++u) if ((uint32_t)qq < cnt && al[u]) half[qq * WORDS + (al[u] >> 16)] = av[qq * 3 + u];
         }
       }
       __syncthreads();
@@ -1216,19 +1216,13 @@ __global__ __launch_bounds__(320, 1) void b3w_regionfill_kernel(const uint32_t *
     // lies there — or zeros outside the LDS allocation — and its store is suppressed (range check / predicate) anyway.
     const int32_t s0 = en.rel0 >> 5;
     const uint16_t *tp = tab + s0;
-    // (the four steps' flags: ONE word of the transposed bitmap, four neighbouring bits from bit s0 >> 10 on — which is -4 .. -1 where the
-    // body starts inside the region: the first steps' lanes lie in front of it)
-    const uint32_t bw = NOVA ? (uint32_t)(((uint64_t)bitmap[s0 & 1023] << 4) >> ((s0 >> 10) + 4)) : 0u;
 #pragma unroll
-    for (int r = 0; r < R; ++r) {
-      en.e[r] = tp[1024 * r];
-      if (NOVA) en.e[r] |= ((bw >> r) & 1u) << 16;
-    }
+    for (int r = 0; r < R; ++r) en.e[r] = tp[1024 * r];
   };
   auto s2 = [&](const Ent &en, Wd &wd, const uint32_t *img) {
 #pragma unroll
     for (int r = 0; r < R; ++r) {
-      const uint32_t *L = img + (en.e[r] & (NOVA ? 0x7FFu : 0x3FFu));
+      const uint32_t *L = img + (en.e[r] & 0x3FFu);
       wd.w0[r] = L[0]; wd.w1[r] = L[1];
     }
   };
@@ -1402,8 +1396,7 @@ extern "C" int b3w_launch_batch(int kind, int variant, const uint32_t *d_recs, u
     // slot table (16 bits a slot) [+ one bit a slot] + 2 x NH images: 14 of 3.7 KB (compression), 11 of the 4.7 KB narrow nova image
     constexpr int NH_C = 14, NH_N = 11;
     const bool nova = kind != B3W_KIND_COMP;
-    if (nova && nwit > 32u * 1024u) return -5;                   // (the transposed word-flag bitmap: 32 slots a word, 1 024 apart)
-    const size_t smem = (size_t)((nwit + 7u) & ~7u) * 2 + (nova ? 4096u : 0u) +
+    const size_t smem = (size_t)((nwit + 7u) & ~7u) * 2 +
                         (size_t)(2 * (nova ? NH_N * B3W_LDS_WIDE : NH_C * B3W_LDS_WORDS_COMP) + 4) * 4;
     constexpr size_t B3W_FILL_MAX_SMEM = 160 * 1024 - 4096;      // (+ the kernel's static descriptor ring)
     if (smem > B3W_FILL_MAX_SMEM) return -5;
@@ -1428,10 +1421,12 @@ extern "C" int b3w_launch_batch(int kind, int variant, const uint32_t *d_recs, u
     // for every further step, on placed, one-class and hipMalloc buffers alike — but on the edge a launch now and then falls off (6.7-7.2).
     // One sleep AND one step (17) held in every one of 36 cases on three boxes at 7.10-7.16 / 7.28-7.35: the default; three steps (48) 7.05-7.09 /
     // 7.2-7.27; two sleeps (2, the first default) 6.98-7.02 / 7.15-7.19 (tools/ubench/pace_robust.py, profiles/r06/pace_robust*.log).
-    // Variant 201 stands on the edge (32).  The nova storing waves do more per slot and have no slack: 0.  B3W_FILL_PACE overrides (measurements).
+    // Variant 201 stands on the edge (32).  The nova storing waves (same table format, flags from the tracer's descriptors: as lean as the
+    // compression circuit's since r06) have their edge at 33 — 7.0-7.07 TB/s, or 6.5-6.7 —; 18 held in all twelve cases at 6.74-6.97
+    // (profiles/r06/pace_robust_nova*.log).  B3W_FILL_PACE overrides (measurements).
     const char *pace_s = getenv("B3W_FILL_PACE");                      // (read per launch: pace_scan.py changes it inside one process)
     const int pace_env = pace_s ? atoi(pace_s) : -1;
-    const uint32_t pace = pace_env >= 0 ? (uint32_t)pace_env : nova ? 0u : variant == B3W_VARIANT_REGIONFILL_LIGHT ? 32u : 17u;
+    const uint32_t pace = pace_env >= 0 ? (uint32_t)pace_env : nova ? 18u : variant == B3W_VARIANT_REGIONFILL_LIGHT ? 32u : 17u;
     if (!nova) {
       hipLaunchKernelGGL((b3w_regionfill_kernel<B3W_KIND_COMP, NH_C>), dim3(B3W_REGIONFILL_GRID), dim3(320), smem, stream, d_recs, n, d_out, pitch,
                          d_table, nwit, d_pub, d_status, pace, (const uint32_t *)nullptr);
