@@ -285,16 +285,16 @@ void set_inputs(b3w_ctx *ctx) {
 //   above 32 768 steps the persistent grid;
 //   the fill-ordered kernel (r06; compression, nova O2; 32-byte aligned bodies): PACED, it stores at the same rate into any memory — 7.0 TB/s
 //   at 4 096 compression witnesses, 7.2 at 32 768 — where the body streams get 7.1-7.2 from a placed buffer and 5.5 from anybody else's.
-//   From 256 witnesses on it is at least as fast as the sliced launch even on a placed buffer (profiles/r06/fill_small.log), so:
-//   compression -> fill order from 256 witnesses, except batches of more than 3 072 into a buffer the placement allocator KNOWS to be
-//   mixed (b3w_place_is_mixed: body streams, +1 %); nova O2 (6.5-6.85 TB/s in fill order, 7.0 placed, 5.2-5.5 plain) -> fill order from 768
-//   steps on unless the buffer is known to be mixed (profiles/r06/fill_small_nova.log).
+//   From 128 witnesses on it is at least as fast as the sliced launch even on a placed buffer (profiles/r06/fill_small*.log), so:
+//   compression -> fill order from 128 witnesses, except batches of more than 3 072 into a buffer the placement allocator KNOWS to be
+//   mixed (b3w_place_is_mixed: body streams, +1 %); nova O2 (6.75-6.97 TB/s in fill order on any buffer; body streams 7.0 placed, 5.2-5.5
+//   plain) -> fill order from 512 steps on, in a buffer known to be mixed from 768 to 2 560 (body streams beyond: +2 %).
 int b3w_int_default_variant(const b3w_ctx *ctx, uint32_t n, const uint8_t *d_bodies, uint64_t pitch) {
   const bool comp = ctx->desc.kind == B3W_KIND_COMP, nova2 = ctx->desc.kind == B3W_KIND_NOVA_O2;
   const bool fillable = ctx->fill_ok && !(reinterpret_cast<uintptr_t>(d_bodies) & 31) && !(pitch & 31) && pitch < (1ull << 30) &&
                         (uint64_t)n * pitch + (1ull << 20) < (1ull << 37);
-  if (fillable && comp && n >= 256 && (n <= 3072 || !b3w_place_is_mixed(d_bodies))) return B3W_VARIANT_REGIONFILL;
-  if (fillable && nova2 && n >= 768 && !b3w_place_is_mixed(d_bodies)) return B3W_VARIANT_REGIONFILL;
+  if (fillable && comp && n >= 128 && (n <= 3072 || !b3w_place_is_mixed(d_bodies))) return B3W_VARIANT_REGIONFILL;
+  if (fillable && nova2 && (b3w_place_is_mixed(d_bodies) ? n >= 768 && n <= 2560 : n >= 512)) return B3W_VARIANT_REGIONFILL;
   if (n <= 2560) return B3W_VARIANT_SLICED + (n <= (comp ? 32u : 8u) ? 64 : n <= 96 ? 32 : n <= 192 ? 16 : n <= 768 ? 8 : 4);
   if (comp) return n <= 6144 ? 0 : 8;
   if (nova2) return n <= 3072 ? 0 : n <= 32768 ? 3 : 4;     // (4: 8 bodies a wave on a persistent grid — 16 384 steps: -1 %, 32 768: equal, 65 536: +1.3 %)

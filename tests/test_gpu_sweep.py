@@ -120,7 +120,7 @@ def test_sweep_several_scratch_chunks(m):
 def test_autotune_picks_a_variant_and_stays_bit_exact(m):
     """Large batches: the autotuner times the bit-identical candidates on the caller's buffers and keeps the fastest.  Small
     batches (up to 2 560 witnesses) follow the DEFAULT policy whatever a tuning run on a large batch chose, and the tuner then reports
-    that policy's shape: the fill-ordered kernel from 256 compression witnesses on (r06: at least as fast as the sliced launch on any
+    that policy's shape: the fill-ordered kernel from 128 compression witnesses on (r06: at least as fast as the sliced launch on any
     buffer), the sliced launch below (20 + waves per body)."""
     import torch
     dev = torch.device("cuda:0")
@@ -143,8 +143,8 @@ def test_autotune_picks_a_variant_and_stays_bit_exact(m):
             assert int((d_bodies[k:k + 2] != 7).sum().item()) == 0, "a small batch wrote past its bodies"
     v512, ms512 = ctx.autotune_device(d_recs.data_ptr(), 512, d_bodies.data_ptr(), 0, 0, d_st.data_ptr(), s)
     assert v512 == 200 and 0 < ms512 < 0.5                     # (fill-ordered: 0.07 ms for 512 witnesses; one body per wave took 0.14)
-    v128, _ = ctx.autotune_device(d_recs.data_ptr(), 128, d_bodies.data_ptr(), 0, 0, d_st.data_ptr(), s)
-    assert v128 == 20 + 16
+    v100, _ = ctx.autotune_device(d_recs.data_ptr(), 100, d_bodies.data_ptr(), 0, 0, d_st.data_ptr(), s)
+    assert v100 == 20 + 16
     v1, _ = ctx.autotune_device(d_recs.data_ptr(), 1, d_bodies.data_ptr(), 0, 0, d_st.data_ptr(), s)
     assert v1 == 20 + 64
     ctx.close()
