@@ -370,7 +370,7 @@ int32_t b3w_batch_write_wtns_ex(b3w_batch *batch, uint32_t first, uint32_t count
  * the buffer says) and the two-kernel sweep path (100), DESIGN.md "Witness kernels".  An integrator that brings its own buffers calls this once per (context, buffer).  Runs and times each candidate on the caller's device
  * buffers, which end up holding the correct witnesses, and keeps the winner in the ctx for later
  * b3w_batch_run_device calls of more than 2 560 witnesses.  Batches up to 2 560 witnesses follow the default policy — SLICED
- * (several waves per body, DESIGN.md "Batch size") or, from 256 witnesses / 768 nova steps on, the fill order — unless B3W_VARIANT says otherwise; for such an n the call only times that
+ * (several waves per body, DESIGN.md "Batch size") or, from 128 witnesses / 512 nova steps on, the fill order — unless B3W_VARIANT says otherwise; for such an n the call only times that
  * shape and reports it (*chosen_variant = 20 + waves per body).  Allocates the sweep scratch on first use; not for stream
  * capture. */
 int32_t b3w_batch_autotune_device(b3w_ctx *ctx, const uint32_t *d_records, uint32_t n, uint8_t *d_bodies,
