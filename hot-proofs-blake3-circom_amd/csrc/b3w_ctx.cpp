@@ -612,7 +612,9 @@ int32_t b3w_batch_autotune_device(b3w_ctx *ctx, const uint32_t *d_records, uint3
     rc = B3W_OK;
     for (int w = 0; w < 2 && rc == B3W_OK; w++)
       rc = b3w_batch_run_device(ctx, d_records, n, d_bodies, pitch, d_public, d_status, stream);
-    if (rc == B3W_OK) rc = b3w_batch_time_device(ctx, d_records, n, d_bodies, pitch, d_public, d_status, stream, 5, &ms);
+    // (the candidates lie within a per cent or two of each other, and the edge-paced fill order falls off its cliff in a launch now and then:
+    // twenty launches each where a launch is short)
+    if (rc == B3W_OK) rc = b3w_batch_time_device(ctx, d_records, n, d_bodies, pitch, d_public, d_status, stream, n <= 8192 ? 20 : 5, &ms);
     if (rc == B3W_E_BAD_ARGUMENT) continue;          // this path cannot take these buffers (alignment): not a candidate
     if (rc) { ctx->variant = saved; ctx->variant_auto = saved_auto; return rc; }
     if (ms < best_ms) { best_ms = ms; best = c; }
