@@ -49,8 +49,8 @@ for name in ("WRITE_SIZE", "FETCH_SIZE"):
             fused[kn] = fused.get(kn, 0) + 1
     chosen = max(fused, key=fused.get) if fused else None
     def timed(kn):
-        if fill:
-            return "b3w_regionfill_kernel" in kn
+        if fill:                                            # (nova: the wide-slot launch behind the fill kernel, MODE 3, is part of the step)
+            return "b3w_regionfill_kernel" in kn or bool("b3w_nova_kernel" in kn and MODE.search(kn) and MODE.search(kn).group(1) == "3")
         if sweep:
             return "b3w_sweep_kernel" in kn or bool(MODE.search(kn) and MODE.search(kn).group(1) == "1")
         return kn == chosen
