@@ -540,7 +540,7 @@ int32_t b3w_batch_run_device(b3w_ctx *ctx, const uint32_t *d_records, uint32_t n
   int variant = ctx->variant;
   // (a variant picked by the autotuner on a large batch does not apply to small ones: those follow the default policy unless B3W_VARIANT says otherwise)
   if (ctx->variant_auto || (ctx->variant_tuned && n <= 2560)) variant = b3w_int_default_variant(ctx, n, d_bodies, pitch);
-  if (variant >= B3W_VARIANT_REGIONFILL && !ctx->fill_ok) { ctx->last_error = "the fill-ordered variants (200, 201) exist for the compression circuit and (200) the nova O2 builds"; return B3W_E_BAD_ARGUMENT; }
+  if (variant >= B3W_VARIANT_REGIONFILL && !ctx->fill_ok) { ctx->last_error = "the fill-ordered variants (200, 201) exist for the compression circuit and the nova O2 builds"; return B3W_E_BAD_ARGUMENT; }
   int rc = b3w_launch_batch(ctx->desc.kind, variant, d_records, n, d_bodies, pitch, ctx->d_table, ctx->desc.nwit,
                             d_public, d_status, ctx->d_aux, ctx->d_scratch, ctx->scratch_cap, (hipStream_t)stream);
   if (rc == 0) return B3W_OK;
@@ -598,7 +598,7 @@ int32_t b3w_batch_autotune_device(b3w_ctx *ctx, const uint32_t *d_records, uint3
   // this buffer and batch, it is taken only where it holds)
   const int candidates[6] = {0, ctx->desc.kind == B3W_KIND_COMP ? (n > 6144 ? 8 : 3) : ctx->desc.kind == B3W_KIND_NOVA_O2 ? 3 : 0, B3W_VARIANT_SWEEP,
                              ctx->fill_ok ? B3W_VARIANT_REGIONFILL : 0, ctx->desc.kind == B3W_KIND_NOVA_O2 && n >= 16384 ? 4 : 0,
-                             ctx->fill_ok && ctx->desc.kind == B3W_KIND_COMP ? B3W_VARIANT_REGIONFILL_LIGHT : 0};
+                             ctx->fill_ok ? B3W_VARIANT_REGIONFILL_LIGHT : 0};
   int best = ctx->variant;
   float best_ms = 1e30f;
   const int saved = ctx->variant;

@@ -10,7 +10,7 @@
 // variant B3W_VARIANT_REGIONFILL: the fill-ordered fused kernel for caller-owned (plain) buffers — 256 workgroups of four storing waves and
 // a tracer wave over absolute 128 KiB regions, one contiguous 4 MiB window chip-wide (b3w_kernels.hip "REGIONFILL"); compression and nova O2 circuits
 #define B3W_VARIANT_REGIONFILL 200
-// the same kernel paced lighter (compression): on the edge of the cliff below which the chip-wide store window frays — the fastest where it
+// the same kernel paced lighter: on the edge of the cliff below which the chip-wide store window frays — the fastest where it
 // holds (7.17-7.19 TB/s at 4 096 witnesses, up to 7.38 from 16 384 on), 6.7-7.2 where it does not: a choice for the autotuner, which times it on the buffer
 // at hand, not for the default
 #define B3W_VARIANT_REGIONFILL_LIGHT 201

@@ -1389,7 +1389,6 @@ extern "C" int b3w_launch_batch(int kind, int variant, const uint32_t *d_recs, u
   if (variant == B3W_VARIANT_REGIONFILL || variant == B3W_VARIANT_REGIONFILL_LIGHT) {
     // 256 workgroups (one per CU; workgroup i on XCD i % 8); 32-byte aligned bodies (a lane pair is one slot); compression and nova O2
     if (kind != B3W_KIND_COMP && kind != B3W_KIND_NOVA_O2) return -1;
-    if (variant == B3W_VARIANT_REGIONFILL_LIGHT && kind != B3W_KIND_COMP) return -1;       // (the nova storing waves have no slack to pace)
     if (kind == B3W_KIND_NOVA_O2 && !d_aux) return -3;
     if ((reinterpret_cast<uintptr_t>(d_out) & 31) || (pitch & 31) || pitch >= (1ull << 30)) return -5;
     if (32ull * nwit < (1ull << 17) || (uint64_t)n * pitch + (1ull << 20) >= (1ull << 37)) return -5;      // a region meets two bodies at most; 32-bit slot positions
@@ -1421,12 +1420,12 @@ extern "C" int b3w_launch_batch(int kind, int variant, const uint32_t *d_recs, u
     // for every further step, on placed, one-class and hipMalloc buffers alike — but on the edge a launch now and then falls off (6.7-7.2).
     // One sleep AND one step (17) held in every one of 36 cases on three boxes at 7.10-7.16 / 7.28-7.35: the default; three steps (48) 7.05-7.09 /
     // 7.2-7.27; two sleeps (2, the first default) 6.98-7.02 / 7.15-7.19 (tools/ubench/pace_robust.py, profiles/r06/pace_robust*.log).
-    // Variant 201 stands on the edge (32).  The nova storing waves (same table format, flags from the tracer's descriptors: as lean as the
+    // Variant 201 stands on the edge (32; nova 33).  The nova storing waves (same table format, flags from the tracer's descriptors: as lean as the
     // compression circuit's since r06) have their edge at 33 — 7.0-7.07 TB/s, or 6.5-6.7 —; 18 held in all twelve cases at 6.74-6.97
     // (profiles/r06/pace_robust_nova*.log).  B3W_FILL_PACE overrides (measurements).
     const char *pace_s = getenv("B3W_FILL_PACE");                      // (read per launch: pace_scan.py changes it inside one process)
     const int pace_env = pace_s ? atoi(pace_s) : -1;
-    const uint32_t pace = pace_env >= 0 ? (uint32_t)pace_env : nova ? 18u : variant == B3W_VARIANT_REGIONFILL_LIGHT ? 32u : 17u;
+    const uint32_t pace = pace_env >= 0 ? (uint32_t)pace_env : variant == B3W_VARIANT_REGIONFILL_LIGHT ? (nova ? 33u : 32u) : nova ? 18u : 17u;
     if (!nova) {
       hipLaunchKernelGGL((b3w_regionfill_kernel<B3W_KIND_COMP, NH_C>), dim3(B3W_REGIONFILL_GRID), dim3(320), smem, stream, d_recs, n, d_out, pitch,
                          d_table, nwit, d_pub, d_status, pace, (const uint32_t *)nullptr);

@@ -366,7 +366,7 @@ int32_t b3w_batch_write_wtns_ex(b3w_batch *batch, uint32_t first, uint32_t count
 /* Choose the fastest bit-identical kernel variant for THIS output buffer: the body-stream kernels (variants 0 / 3 / 8: fastest
  * on a buffer from b3w_bodies_alloc), the fill-ordered fused kernel (200; compression circuit and nova O2 builds: fastest on a
  * caller's own plain hipMalloc / torch buffer — 7.0-7.2 against 5.5 TB/s on one-class memory — and the default there even without
- * this call), the same paced one step lighter (201, compression: fastest of all where its pace holds, which only a measurement on
+ * this call), the same paced lighter (201: fastest of all where its pace holds, which only a measurement on
  * the buffer says) and the two-kernel sweep path (100), DESIGN.md "Witness kernels".  An integrator that brings its own buffers calls this once per (context, buffer).  Runs and times each candidate on the caller's device
  * buffers, which end up holding the correct witnesses, and keeps the winner in the ctx for later
  * b3w_batch_run_device calls of more than 2 560 witnesses.  Batches up to 2 560 witnesses follow the default policy — SLICED

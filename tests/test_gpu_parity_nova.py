@@ -24,7 +24,7 @@ def test_nova_batch_matches_oracle(m, circuit):
     bad, want = T.oracle_batch_u32(circuit, recs)
     assert bad == 0
     want = want.copy()
-    for variant in (0, 1, 22, 27, 36, 84) + ((2, 3, 4) if circuit != "nova_bn254_o1" else ()):   # 20 + s: SLICED (any s in 2..64); 4: persistent grid
+    for variant in (0, 1, 22, 27, 36, 84) + ((2, 3, 4, 200, 201) if circuit != "nova_bn254_o1" else ()):   # 20 + s: SLICED (any s in 2..64); 4: persistent grid; 200 / 201: fill-ordered
         os.environ["B3W_VARIANT"] = str(variant)
         try:
             ctx = m.Context(circuit, 0)
