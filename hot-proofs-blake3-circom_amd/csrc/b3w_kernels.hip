@@ -470,7 +470,7 @@ __global__ __launch_bounds__(128 * PAIRS, 1) void b3w_sweep_kernel(const uint32_
       uint4 lo, hi;
       lo.x = (rg.a[k][0] >> sh) & m0;
       lo.y = rg.a[k][1] & m1;
-      if (WIDE) {
+      if constexpr (WIDE) {
         const uint32_t m2 = mode == B3W_MODE_W256 ? 0xFFFFFFFFu : 0u;
         lo.z = rg.a[k][2] & m2; lo.w = rg.a[k][3] & m2;
         hi = make_uint4(rg.a[k][4] & m2, rg.a[k][5] & m2, rg.a[k][6] & m2, rg.a[k][7] & m2);
