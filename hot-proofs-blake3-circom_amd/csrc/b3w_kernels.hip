@@ -1227,8 +1227,16 @@ __global__ __launch_bounds__(320, 1) void b3w_regionfill_kernel(const uint32_t *
     }
   };
   auto s3 = [&](const Ent &en, const Wd &wd, const uint32_t *img) {
-    for (uint32_t z = 0; z < (pace & 15u); ++z) __builtin_amdgcn_s_sleep(1);  // PACE, see the launch: sleeps (64 clocks) ...
-    { uint32_t pv = lane; for (uint32_t z = 0; z < (pace >> 4); ++z) asm volatile("v_add_u32 %0, %0, 1" : "+v"(pv)); }   // ... and finer steps
+    // PACE, see the launch: sleeps (to the next 64-clock grid point each) and finer single steps.  Compression: once per REGION visit, not per
+    // unit — where a body starts inside the region the visit is two units (the end of one body, the head of the next) that store one region's
+    // bytes together: paced twice, the groups that meet more borders fell behind the others (r06: per visit, the same pace holds on every box
+    // measured where per unit one of three lost the window at 32 768 witnesses).  (The nova instantiation keeps the pace per unit: its code
+    // is sensitive to every branch in this loop — the same test there cost 9 %.)
+    if (NOVA || !(en.wq & B3W_RF_STARTS)) {
+      for (uint32_t z = 0; z < (pace & 15u); ++z) __builtin_amdgcn_s_sleep(1);
+      uint32_t pv = lane;
+      for (uint32_t z = 0; z < (pace >> 4); ++z) asm volatile("v_add_u32 %0, %0, 1" : "+v"(pv));
+    }
     const uint32_t w = en.wq & B3W_RF_BODY;
     if ((en.wq >> 31) && x == 0 && sub == 0) fill_report<NOVA>(img, w, lane, pub, status);    // the unit in which the body starts reports for it
     uint8_t *dst = out + (uint64_t)w * pitch;
@@ -1412,20 +1420,20 @@ extern "C" int b3w_launch_batch(int kind, int variant, const uint32_t *d_recs, u
       if (e != hipSuccess) return (int)e;
       attr_done.fetch_or(bit, std::memory_order_release);
     }
-    // PACE: every storing wave waits per unit — pace % 16 x s_sleep 1 (to the chip's next 64-clock grid point each) and pace / 16 single
-    // vector-ALU steps (~ 25 clocks each with their loop).  The storers are built to issue as little as they can, and then they are too fast:
-    // unpaced, the workgroups run at whatever the memory system lets each of them have, drift apart, and the one compact window the fill order
-    // lives on frays — 6.6 (compression) TB/s on one-class memory.  Paced to just under the memory's rate they stay in step, and the rate is a
-    // CLIFF in the pace: compression 6.6 at one step, 7.15-7.19 (4 096 witnesses) / 7.3-7.38 (16 384 and more) at two steps or one sleep, -1 %
-    // for every further step, on placed, one-class and hipMalloc buffers alike — but on the edge a launch now and then falls off (6.7-7.2).
-    // One sleep AND one step (17) held in every one of 36 cases on three boxes at 7.10-7.16 / 7.28-7.35: the default; three steps (48) 7.05-7.09 /
-    // 7.2-7.27; two sleeps (2, the first default) 6.98-7.02 / 7.15-7.19 (tools/ubench/pace_robust.py, profiles/r06/pace_robust*.log).
-    // Variant 201 stands on the edge (32; nova 33).  The nova storing waves (same table format, flags from the tracer's descriptors: as lean as the
-    // compression circuit's since r06) have their edge at 33 — 7.0-7.07 TB/s, or 6.5-6.7 —; 18 held in all twelve cases at 6.74-6.97
-    // (profiles/r06/pace_robust_nova*.log).  B3W_FILL_PACE overrides (measurements).
+    // PACE: every storing wave waits per region visit (compression) / per unit (nova) — pace % 16 x s_sleep 1 (to the chip's next 64-clock
+    // grid point each) and pace / 16 single vector-ALU steps (~ 25 clocks each with their loop).  The storers are built to issue as little as
+    // they can, and then they are too fast: unpaced, the workgroups run at whatever the memory system lets each of them have, drift apart, and
+    // the one compact window the fill order lives on frays — 6.6 (compression) TB/s on one-class memory.  Paced to just under the memory's
+    // rate they stay in step, and the rate is a CLIFF in the pace: 6.6 below it, 7.15-7.2 (4 096 witnesses) / 7.3-7.35 (16 384 and more) on its
+    // edge, -1 % for every further step, on placed, one-class and hipMalloc buffers alike — but on the edge a launch now and then falls off
+    // (6.7-7.2), and the edge moves by a step from box to box.  Compression: one sleep and two steps per visit (33) held in all 72 cases —
+    // three boxes x {256 ... 32 768 witnesses} x {placed, one-class, torch.empty} — at 7.11-7.19 / 7.26-7.30; three steps (48) are the edge
+    // (7.15-7.21 / 7.3-7.35; fell to 7.06 once): variant 201 (tools/ubench/pace_robust.py, profiles/r06/pace_robust*.log, pace_visit*.log).
+    // Nova (per unit): edge at 33 — 7.0-7.07 TB/s, or 6.5-6.7 —; 18 held in all twelve cases at 6.74-6.97 (pace_robust_nova*.log).
+    // B3W_FILL_PACE overrides (measurements).
     const char *pace_s = getenv("B3W_FILL_PACE");                      // (read per launch: pace_scan.py changes it inside one process)
     const int pace_env = pace_s ? atoi(pace_s) : -1;
-    const uint32_t pace = pace_env >= 0 ? (uint32_t)pace_env : variant == B3W_VARIANT_REGIONFILL_LIGHT ? (nova ? 33u : 32u) : nova ? 18u : 17u;
+    const uint32_t pace = pace_env >= 0 ? (uint32_t)pace_env : variant == B3W_VARIANT_REGIONFILL_LIGHT ? (nova ? 33u : 48u) : nova ? 18u : 33u;
     if (!nova) {
       hipLaunchKernelGGL((b3w_regionfill_kernel<B3W_KIND_COMP, NH_C>), dim3(B3W_REGIONFILL_GRID), dim3(320), smem, stream, d_recs, n, d_out, pitch,
                          d_table, nwit, d_pub, d_status, pace, (const uint32_t *)nullptr);

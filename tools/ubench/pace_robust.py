@@ -20,7 +20,7 @@ os.environ.pop("B3W_PLACEMENT")
 plain = torch.empty(nmax * ctx.body_bytes, dtype=torch.uint8, device="cuda")
 ptrs = {"placed (" + bufs["placed"].placement + ")": bufs["placed"].ptr, "one-class": bufs["one-class"].ptr, "torch.empty": plain.data_ptr()}
 print(circuit, "TB/s by pace", paces)
-for n in (1024, 4096, 16384, 32768):
+for n in [int(a) for a in os.environ.get("SIZES", "1024,4096,16384,32768").split(",")]:
     for name, ptr in ptrs.items():
         row = []
         for pace in paces:
