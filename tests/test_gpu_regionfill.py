@@ -334,3 +334,40 @@ def test_store_only_region_shapes_stay_inside_the_buffer(m):
     with pytest.raises(m.B3WError):                                 # a pace the library was not compiled with: refused, not a launch of nothing
         ctx.store_rate(small.data_ptr(), 1, 0, 701, 1, s)
     ctx.close()
+
+
+def test_regionfill_does_not_depend_on_all_workgroups_being_resident(m):
+    """The kernel's 256 workgroups share nothing but the buffer: on a stream confined to 40 of the 256 CUs (hipExtStreamCreateWithCUMask) they
+    run in seven rounds, no compact window, and the bodies are the same — compression and nova_vesta, against the body-stream kernel."""
+    import ctypes
+    import torch
+    dev = torch.device("cuda:0")
+    hip = ctypes.CDLL("libamdhip64.so")
+    hip.hipExtStreamCreateWithCUMask.argtypes = [ctypes.POINTER(ctypes.c_void_p), ctypes.c_uint32, ctypes.POINTER(ctypes.c_uint32)]
+    ncu = torch.cuda.get_device_properties(0).multi_processor_count
+    words = (ncu + 31) // 32
+    mask = (ctypes.c_uint32 * words)()
+    for cu in range(40):
+        mask[cu // 32] |= 1 << (cu % 32)
+    hs = ctypes.c_void_p()
+    assert hip.hipExtStreamCreateWithCUMask(ctypes.byref(hs), words, mask) == 0
+    masked = torch.cuda.ExternalStream(hs.value)
+    for circuit, n in (("compression", 700), ("nova_vesta", 700)):
+        recs = T.workloads().config2_compression(n, first=9) if circuit == "compression" else T.workloads().config3_nova(n, first=9)
+        d_recs = torch.from_numpy(recs.view(np.int32)).to(dev)
+        ctx = _fill_ctx(m, circuit)
+        a = torch.full((n, ctx.body_bytes), 1, dtype=torch.uint8, device=dev)
+        b = torch.full((n, ctx.body_bytes), 2, dtype=torch.uint8, device=dev)
+        torch.cuda.synchronize()
+        ctx.run_device(d_recs.data_ptr(), n, a.data_ptr(), 0, 0, 0, masked.cuda_stream)
+        os.environ["B3W_VARIANT"] = "0"
+        try:
+            ref0 = m.Context(circuit, 0)
+        finally:
+            del os.environ["B3W_VARIANT"]
+        ref0.run_device(d_recs.data_ptr(), n, b.data_ptr(), 0, 0, 0, torch.cuda.current_stream().cuda_stream)
+        masked.synchronize()
+        torch.cuda.synchronize()
+        assert torch.equal(a, b), circuit
+        ctx.close(); ref0.close()
+    assert hip.hipStreamDestroy(hs) == 0
