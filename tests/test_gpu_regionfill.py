@@ -217,23 +217,25 @@ def test_regionfill_nova_matches_oracle_with_rejected_steps_everywhere(m, circui
     ref.close(); ctx.close()
 
 
-def test_regionfill_nova_large_batch_and_large_iszero_arguments(m):
-    """9 000 Vesta steps through the fill-ordered path against the body-stream kernel (whole buffer, outputs, status), among them steps whose
-    IsZero arguments leave the table of small inverses (the second launch's general inverse) and steps outside the domain."""
+@pytest.mark.parametrize("circuit,n,fill_variant", [("nova_vesta", 9000, 200), ("nova_bn254", 3000, 200), ("nova_vesta", 3000, 201)])
+def test_regionfill_nova_large_batch_and_large_iszero_arguments(m, circuit, n, fill_variant):
+    """9 000 Vesta (3 000 BN254; 3 000 at the lighter pace) steps through the fill-ordered path against the body-stream kernel (whole buffer,
+    outputs, status), among them steps whose IsZero arguments leave the table of small inverses (the second launch's general inverse) and
+    steps outside the domain."""
     import torch
-    n = 9000
     recs = T.workloads().config3_nova(n, first=1).copy()
     recs[5, 12] = 250; recs[5, 13] = 4000000000; recs[5, 14] = 249          # total_depth far from depth: |k| beyond the table
     recs[77, 1] = 3000000000; recs[77, 0] = 3000000001                      # block_count near n_blocks, both huge
-    recs[4000, 14] = recs[4000, 12]                                         # rejected
+    rej = n // 2 + 500
+    recs[rej, 14] = recs[rej, 12]                                           # rejected
     dev = torch.device("cuda:0")
     s = torch.cuda.current_stream().cuda_stream
     d_recs = torch.from_numpy(recs.view(np.int32)).to(dev)
     out = {}
-    for variant in (3, 200):
+    for variant in (3, fill_variant):
         os.environ["B3W_VARIANT"] = str(variant)
         try:
-            ctx = m.Context("nova_vesta", 0)
+            ctx = m.Context(circuit, 0)
         finally:
             del os.environ["B3W_VARIANT"]
         d_bodies = torch.full((n, ctx.body_bytes), FILL, dtype=torch.uint8, device=dev)
@@ -243,15 +245,16 @@ def test_regionfill_nova_large_batch_and_large_iszero_arguments(m):
         torch.cuda.synchronize()
         out[variant] = (d_bodies, d_pub, d_st)
         ctx.close()
-    assert torch.equal(out[3][2], out[200][2]) and int(out[200][2][4000].item()) == 4
+    f = out[fill_variant]
+    assert torch.equal(out[3][2], f[2]) and int(f[2][rej].item()) == 4
     ok = out[3][2] == 0
-    assert torch.equal(out[3][1][ok], out[200][1][ok])
-    assert torch.equal(out[3][0], out[200][0])
-    idx = np.array([0, 5, 77, 3999, 4001, n - 1])
+    assert torch.equal(out[3][1][ok], f[1][ok])
+    assert torch.equal(out[3][0], f[0])
+    idx = np.array([0, 5, 77, rej - 1, rej + 1, n - 1])
     okh = ok.cpu().numpy()
     idx = idx[okh[idx]]
-    _, want = T.oracle_batch_u32("nova_vesta", recs[idx])
-    assert np.array_equal(out[200][0][torch.from_numpy(idx).to(dev)].cpu().numpy(), want)
+    _, want = T.oracle_batch_u32(circuit, recs[idx])
+    assert np.array_equal(f[0][torch.from_numpy(idx).to(dev)].cpu().numpy(), want)
 
 
 def test_default_policy_by_batch_size_and_buffer(m):
