@@ -367,7 +367,7 @@ int32_t b3w_create(int32_t circuit, int32_t device, b3w_ctx **out) {
   std::vector<uint32_t> alias;                                              // from | to << 16
   if (ctx->fill_ok) {
     const bool nova = ctx->desc.kind != B3W_KIND_COMP;
-    std::vector<uint8_t> used(2048, 0);
+    std::vector<uint8_t> used(4097, 0);                                       // (an entry's word: 12 bits)
     for (uint32_t i = 0; i < ctx->desc.nwit; i++) {
       const uint32_t e = table[i], src = e & 0xFFFu, mode = (e >> 17) & 3u;
       if (mode == B3W_MODE_W256) continue;
@@ -378,6 +378,7 @@ int32_t b3w_create(int32_t circuit, int32_t device, b3w_ctx **out) {
     used[B3W_LDS_OKWORD] = used[B3W_LDS_OKWORD + 1] = 1;
     for (uint32_t k = 0; k < 16; k++) used[B3W_A_O + k] = 1;
     if (nova) for (uint32_t k : {NV_N_BLOCKS, NV_BLOCK_COUNT_OUT, NV_TOTAL_DEPTH, NV_DEPTH_OUT, NV_CIL, NV_CIH, NV_LEAF_DEPTH}) used[B3W_LDS_NV + k] = 1;
+    for (uint32_t w = 2048; w < 4097; w++) if (used[w]) ctx->fill_ok = false;     // (no alias for those: 11 bits of from)
     std::vector<uint16_t> to(2048, 0xFFFFu);
     uint32_t hole = B3W_LDS_HG;                                             // (holes among the G-function words first: the high halves of its sums)
     for (uint32_t w = 1024; w < 2048 && ctx->fill_ok; w++) {
@@ -392,7 +393,7 @@ int32_t b3w_create(int32_t circuit, int32_t device, b3w_ctx **out) {
       uint32_t src = e & 0xFFFu;
       if (mode == B3W_MODE_W256) { ftab[i] = (uint16_t)(0x8000u | 2u << 10); continue; }
       if (src >= 1024) {
-        if (mode == B3W_MODE_W64 || to[src] == 0xFFFFu) { if (i < ctx->desc.nwit) ctx->fill_ok = false; continue; }   // (padding entries name word 0)
+        if (mode == B3W_MODE_W64 || src >= 2048 || to[src] == 0xFFFFu) { if (i < ctx->desc.nwit) ctx->fill_ok = false; continue; }   // (padding entries name word 0)
         src = to[src];
       }
       if (mode == B3W_MODE_W64 && src + 1 >= 1024) { ctx->fill_ok = false; continue; }
