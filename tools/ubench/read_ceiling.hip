@@ -17,7 +17,7 @@ template <bool NT> __device__ __forceinline__ u32x4 ld(const uint8_t *p) {
 }
 
 template <int AHEAD, bool NT, bool BARRIER>
-__global__ __launch_bounds__(512) void read_kernel(const uint8_t *__restrict__ buf, uint64_t units, uint32_t *__restrict__ sink) {
+__global__ __launch_bounds__(512) void read_kernel(const uint8_t *__restrict__ buf, uint64_t units, uint32_t *__restrict__ sink, uint32_t pace = 0) {
   const uint32_t tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
   const uint64_t u0 = units * blockIdx.x / gridDim.x, u1 = units * (blockIdx.x + 1) / gridDim.x;
   u32x4 r[AHEAD][4];
@@ -36,6 +36,7 @@ __global__ __launch_bounds__(512) void read_kernel(const uint8_t *__restrict__ b
       for (int q = 0; q < 4; q++) acc ^= r[a][q];
       const uint64_t nxt = u + a + AHEAD;
       fetch(nxt < u1 ? nxt : u1 - 1, a);
+      for (uint32_t z = 0; z < pace; ++z) __builtin_amdgcn_s_sleep(1);      // PACED (round 6: the write side has a cliff in its pace; the read side?)
       if (BARRIER) __syncthreads();
     }
   }
@@ -43,18 +44,18 @@ __global__ __launch_bounds__(512) void read_kernel(const uint8_t *__restrict__ b
 }
 
 template <int AHEAD, bool NT, bool BARRIER>
-static void run(const char *name, const uint8_t *d, uint64_t bytes, uint32_t *sink, int grid) {
+static void run(const char *name, const uint8_t *d, uint64_t bytes, uint32_t *sink, int grid, uint32_t pace = 0) {
   const uint64_t units = bytes / 32768;
   hipEvent_t e0, e1;
   hipEventCreate(&e0); hipEventCreate(&e1);
-  hipLaunchKernelGGL((read_kernel<AHEAD, NT, BARRIER>), dim3(grid), dim3(512), 0, 0, d, units, sink);
+  hipLaunchKernelGGL((read_kernel<AHEAD, NT, BARRIER>), dim3(grid), dim3(512), 0, 0, d, units, sink, pace);
   hipEventRecord(e0);
-  for (int i = 0; i < 5; i++) hipLaunchKernelGGL((read_kernel<AHEAD, NT, BARRIER>), dim3(grid), dim3(512), 0, 0, d, units, sink);
+  for (int i = 0; i < 5; i++) hipLaunchKernelGGL((read_kernel<AHEAD, NT, BARRIER>), dim3(grid), dim3(512), 0, 0, d, units, sink, pace);
   hipEventRecord(e1);
   hipEventSynchronize(e1);
   float ms = 0;
   hipEventElapsedTime(&ms, e0, e1);
-  printf("%-44s grid %4d: %7.3f ms per pass = %6.2f TB/s\n", name, grid, ms / 5, (double)units * 32768 / (ms / 5 * 1e-3) / 1e12);
+  printf("%-44s grid %4d pace %2u: %7.3f ms per pass = %6.2f TB/s\n", name, grid, pace, ms / 5, (double)units * 32768 / (ms / 5 * 1e-3) / 1e12);
   fflush(stdout);
 }
 
@@ -74,5 +75,9 @@ int main(int argc, char **argv) {
     run<3, true, true>("3 units ahead, nt loads, barrier per unit", d, bytes, sink, grid);
     run<4, true, false>("4 units ahead, nt loads, no barrier", d, bytes, sink, grid);
   }
+  // round 6: the same readers PACED (s_sleep 1 per unit and wave): does a read stream have the cliff the fill-ordered stores have?
+  if (argc > 2)
+    for (int grid : {512, 768})
+      for (uint32_t pace : {0u, 1u, 2u, 3u, 4u, 6u, 8u, 12u}) run<3, true, true>("3 units ahead, nt loads, barrier, PACED", d, bytes, sink, grid, pace);
   return 0;
 }
